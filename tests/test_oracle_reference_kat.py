@@ -1,0 +1,254 @@
+"""Pins the CPU oracle (oracle/dropest_oracle.cpp) on the reference's own known-answer tests.
+
+Every test below replays one Boost.Test case of the reference that touches the hot path and asserts
+the same values (reference file:line in each docstring; files under /root/reference/Tests).  The inputs
+(reads, whitelists) are the reference fixtures' data, re-typed here as data; no reference source is
+executed.  CPU only.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import Oracle
+from oracle import binding as ob
+
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dropest_amd", "data", "barcodes")
+TEST_EST = os.path.join(DATA, "test_est")
+
+
+def fixture_container():
+    """Tests/TestEstimation.cpp:33-80 (struct Fixture): RealBarcodesMergeStrategy(parser, 0, 0, 7, 0),
+    MergeUMIsStrategySimple(1), default marks; 17 reads over 7 CBs; read_info() uses umi as quality (:27-31)."""
+    o = Oracle(merge_kind=1, barcodes_kind=0, barcodes_file=TEST_EST, min_genes_before=0, min_genes_after=0,
+               max_cb_merge_ed=7, min_merge_fraction=0.0, umi_merge_kind=0, max_umi_merge_ed=1)
+    reads = [
+        ("AAATTAGGTCCA", "AAACCT", "Gene1"), ("AAATTAGGTCCA", "CCCCCT", "Gene2"),
+        ("AAATTAGGTCCA", "ACCCCT", "Gene3"), ("AAATTAGGTCCA", "ACCCCT", "Gene4"),
+        ("AAATTAGGTCCC", "CAACCT", "Gene1"), ("AAATTAGGTCCC", "CAACCT", "Gene10"),
+        ("AAATTAGGTCCC", "CAACCT", "Gene20"),
+        ("AAATTAGGTCCG", "CAACCT", "Gene1"),
+        ("AAATTAGGTCGG", "AAACCT", "Gene1"), ("AAATTAGGTCGG", "CCCCCT", "Gene2"),
+        ("CCCTTAGGTCCA", "CCATTC", "Gene3"), ("CCCTTAGGTCCA", "CCCCCT", "Gene2"),
+        ("CCCTTAGGTCCA", "ACCCCT", "Gene3"),
+        ("CAATTAGGTCCG", "CAACCT", "Gene1"), ("CAATTAGGTCCG", "AAACCT", "Gene1"),
+        ("CAATTAGGTCCG", "CCCCCT", "Gene2"),
+        ("AAAAAAAAAAAA", "CCCCCT", "Gene2"),
+    ]
+    for cb, umi, gene in reads:
+        o.add_record(cb, umi, gene, "", 2, umi_qual=umi)
+    o.set_initialized()
+    return o
+
+
+def test_barcodes_file():
+    """TestEstimation.cpp:98-121 testBarcodesFile: reverse-complemented whitelist parts + missing file throws."""
+    o = fixture_container()
+    assert o.wl_part(0) == ["AAT", "GAA", "AAA"]
+    assert o.wl_part(1) == ["TTAGGTCCA", "TTAGGGGCC", "TTAGGTCCC"]
+    with pytest.raises(RuntimeError):
+        Oracle().wl_load(0, "/barcodes.wrong")
+
+
+def test_umigs_intersection():
+    """TestEstimation.cpp:160-178 testUmigsIntersection = 2, 1, 0."""
+    o = fixture_container()
+    cid = o.cell_id_by_cb
+    assert o.umig_intersection(cid("AAATTAGGTCCA"), cid("CCCTTAGGTCCA")) == 2
+    assert o.umig_intersection(cid("AAATTAGGTCCC"), cid("AAATTAGGTCCG")) == 1
+    assert o.umig_intersection(cid("AAATTAGGTCCA"), cid("AAATTAGGTCCC")) == 0
+
+
+def test_fill_distances():
+    """TestEstimation.cpp:180-206 testFillDistances: parts {AAT,AAA,CCT}x2, barcode ACTACT."""
+    o = Oracle()
+    o.wl_set(0, ["AAT", "AAA", "CCT"], ["AAT", "AAA", "CCT"])
+    for part in (0, 1):
+        vals, idx = o.wl_distances("ACTACT", part)
+        assert len(vals) == 3
+        assert list(vals) == [1, 1, 2]
+        assert idx[2] == 1
+
+
+def test_real_neighbours_cbs():
+    """TestEstimation.cpp:208-225 testRealNeighboursCbs."""
+    o = fixture_container()
+    ids = o.real_neighbours(o.cell_id_by_cb("CAATTAGGTCCG"))
+    assert [o.cell_barcode(int(i)) for i in ids] == ["AAATTAGGTCCA", "AAATTAGGTCCC"]
+    ids = o.real_neighbours(o.cell_id_by_cb("AAATTAGGTCCC"))
+    assert len(ids) == 1 and o.cell_barcode(int(ids[0])) == "AAATTAGGTCCC"
+
+
+def test_real_neighbours_targets():
+    """TestEstimation.cpp:227-235 testRealNeighbours: targets of cells 0..5 = 0,1,1,0,0,0."""
+    o = fixture_container()
+    assert [o.merge_target(i) for i in range(6)] == [0, 1, 1, 0, 0, 0]
+
+
+def test_merge_by_real_barcodes():
+    """TestEstimation.cpp:237-280 testMergeByRealBarcodes (+ SURVEY probe: merge_targets 0 1 1 0 0 0 6)."""
+    o = fixture_container()
+    o.merge_and_filter()
+    assert o.n_cells == 7
+    f = o.filtered_cells()
+    assert len(f) == 2
+    rows = o.cell_rows()
+    assert rows[int(f[0]), 3] == 3 and rows[int(f[1]), 3] == 4          # cell sizes (#genes)
+    mol = o.molecule_dict()
+    c0, c1 = o.cell_barcode(int(f[0])), o.cell_barcode(int(f[1]))
+    assert len(mol[(c0, "Gene1")]) == 1 and mol[(c0, "Gene1")]["CAACCT"][0] == 2
+    assert len(mol[(c1, "Gene1")]) == 2 and mol[(c1, "Gene1")]["AAACCT"][0] == 3
+    assert len(mol[(c1, "Gene2")]) == 1 and mol[(c1, "Gene2")]["CCCCCT"][0] == 4
+    assert len(mol[(c1, "Gene3")]) == 2
+    assert mol[(c1, "Gene3")]["ACCCCT"][0] == 2 and mol[(c1, "Gene3")]["CCATTC"][0] == 1
+    assert list(rows[:, 0]) == [0, 0, 1, 1, 1, 1, 0]                    # is_merged
+    assert int(rows[:, 1].sum()) == 1                                    # exactly one excluded
+    assert list(o.merge_targets()) == [0, 1, 1, 0, 0, 0, 6]
+
+
+def test_split_barcode_and_const_length_parser():
+    """TestEstimation.cpp:282-320 testSplitBarcode + testConstLengthBarcodeParser."""
+    o = Oracle()
+    o.wl_load(1, os.path.join(DATA, "indrop_v3"))
+    assert o.wl_split("TAATGAGCACTAATGA") == ["TAATGAGC", "ACTAATGA"]
+    assert o.wl_parts() == 2
+    p0, p1 = o.wl_part(0), o.wl_part(1)
+    assert len(p0) == 384 and len(p1) == 384 and len(p0[0]) == 8 and len(p1[0]) == 8
+    t = Oracle()
+    t.wl_load(1, os.path.join(DATA, "10x_aug_2016_split"))
+    q0, q1 = t.wl_part(0), t.wl_part(1)
+    assert t.wl_parts() == 2 and len(q0) == 480 and len(q1) == 1536 and len(q0[0]) == 7 and len(q1[0]) == 9
+    v0, _ = t.wl_distances("GGTGCGTAGCTAAACA", 0)
+    v1, _ = t.wl_distances("GGTGCGTAGCTAAACA", 1)
+    assert v0[0] == 0 and v1[0] == 0
+
+
+def test_umi_exclusion():
+    """TestEstimation.cpp:369-397 testUmiExclusion: marks OR per UMI; query 'e' uses mark equality."""
+    o = Oracle(merge_kind=1, barcodes_file=TEST_EST, min_genes_before=0, min_genes_after=0,
+               min_merge_fraction=0.0, match_levels="e")
+    cb = "AAATTAGGTCCA"
+    for umi, gene in [("AAACCT", "Gene1"), ("CCCCCT", "Gene2"), ("ACCCCT", "Gene3"), ("ACCCCT", "Gene4")]:
+        o.add_record(cb, umi, gene, "", 2, umi_qual=umi)
+    assert o.molecule_dict()[(cb, "Gene4")]["ACCCCT"][0] == 1
+    o.add_record(cb, "TTTTTT", "Gene3", "chr1", 1, umi_qual="TTTTTT")
+    o.add_record(cb, "ACCCCT", "Gene4", "chr1", 1, umi_qual="ACCCCT")
+    mol = o.molecule_dict()
+    assert mol[(cb, "Gene3")]["TTTTTT"][1] & 1 and mol[(cb, "Gene4")]["ACCCCT"][1] & 1
+    o.set_initialized()
+    o.merge_and_filter()
+    mol = o.molecule_dict()
+    # requested (mark == EXON exactly): Gene3 keeps only ACCCCT, Gene4 has nothing requested
+    req3 = {u: r for u, (r, m) in mol[(cb, "Gene3")].items() if m == 2}
+    req4 = {u: r for u, (r, m) in mol[(cb, "Gene4")].items() if m == 2}
+    assert req3 == {"ACCCCT": 1} and req4 == {}
+    assert mol[(cb, "Gene4")]["ACCCCT"][0] == 2
+    g, c, v = o.count_matrix(filtered=True)
+    names = {o.gene_name(int(x)) for x in g}
+    assert "Gene4" not in names and "Gene3" in names
+
+
+def test_gene_match_level_exclusion():
+    """TestEstimation.cpp:399-466 (core-container part): same UMI seen with EXON then EXON|NOT_ANNOTATED."""
+    cb, g = "TGAGTTCTGTTACTGCATC", "FAM138A"
+    o = Oracle(merge_kind=1, barcodes_file=TEST_EST, min_genes_before=0, min_genes_after=0,
+               min_merge_fraction=0.0, match_levels="e")
+    o.add_record(cb, "ATGGGC", g, "chrX", 2)
+    assert o.molecule_dict()[(cb, g)]["ATGGGC"][0] == 1
+    o.add_record(cb, "ATGGGC", g, "chrX", 3)
+    o.add_record(cb, "ATGGGC", g, "chrX", 2)
+    o.add_record(cb, "ATTTTC", g, "chrX", 3)
+    mol = o.molecule_dict()
+    assert mol[(cb, g)]["ATGGGC"][1] & 1 and mol[(cb, g)]["ATTTTC"][1] & 1
+    o.set_initialized(); o.merge_and_filter()
+    gi, _, _ = o.count_matrix(filtered=True)
+    assert len(gi) == 0                       # nothing requested under "e"
+    o2 = Oracle(merge_kind=1, barcodes_file=TEST_EST, min_genes_before=0, min_genes_after=0,
+                min_merge_fraction=0.0, match_levels="eE")
+    o2.add_record(cb, "ATGGGC", g, "chrX", 2); o2.add_record(cb, "ATGGGC", g, "chrX", 3)
+    o2.add_record(cb, "ATTTTC", g, "chrX", 2)
+    assert o2.molecule_dict()[(cb, g)]["ATTTTC"][1] == 2
+    o2.add_record(cb, "ATTTTC", g, "chrX", 3)
+    o2.set_initialized(); o2.merge_and_filter()
+    assert len(o2.molecule_dict()[(cb, g)]) == 2
+
+
+def test_umi_merge_explicit():
+    """TestEstimation.cpp:468-488 testUMIMerge."""
+    o = Oracle(merge_kind=1, barcodes_file=TEST_EST, min_genes_before=0, min_genes_after=0, min_merge_fraction=0.0)
+    cb = "AAATTAGGTCCA"
+    for umi in ["AAACCT", "CCCCCT", "AAATTN", "ACCCCT"]:
+        o.add_record(cb, umi, "Gene1", "", 2, umi_qual=umi)
+    o.merge_umis_explicit(0, "Gene1", {"AAACCT": "CCCCCT", "AAATTN": "GGGGGG", "ACCCCT": "ACCCCT"})
+    m = o.molecule_dict()[(cb, "Gene1")]
+    assert len(m) == 3 and m["CCCCCT"][0] == 2 and m["GGGGGG"][0] == 1 and m["ACCCCT"][0] == 1
+
+
+def test_fill_wrong_umis():
+    """TestEstimation.cpp:490-503 testFillWrongUmis."""
+    for umi in ["AAANTTT", "AAANCTT", "NNNNNNN"]:
+        t = ob.fill_wrong_umi(umi)
+        assert t != umi and ob.hamming_distance(umi, t) == 0 and "N" not in t
+
+
+def test_umi_merge_strategy_simple():
+    """TestEstimation.cpp:505-540 testUMIMergeStrategySimple."""
+    o = Oracle(merge_kind=1, barcodes_file=TEST_EST, min_genes_before=0, min_genes_after=0, min_merge_fraction=0.0)
+    cb = "AAATTAGGTCCA"
+    for umi in ["AAACCT", "AAACCT", "AAACCG", "AAACCN", "CCCCCT", "ACCCCT"]:
+        o.add_record(cb, umi, "Gene1", "", 2, umi_qual=umi)
+    for umi in ["TTTTTT", "TTTNNG", "TTGNNG", "ACCCCT", "NNNNNN"]:
+        o.add_record(cb, umi, "Gene2", "", 2, umi_qual=umi)
+    o.set_initialized()
+    o.merge_umis_only()
+    mol = o.molecule_dict()
+    g1, g2 = mol[(cb, "Gene1")], mol[(cb, "Gene2")]
+    assert len(g1) == 4 and len(g2) == 3
+    assert g1["AAACCT"][0] == 3 and g1["AAACCG"][0] == 1 and g1["CCCCCT"][0] == 1 and g1["ACCCCT"][0] == 1
+    assert "TTTTTT" in g2 and "ACCCCT" in g2
+    assert all("N" not in u for u in g2)
+
+
+def test_umi_merge_strategy_directional():
+    """TestEstimation.cpp:588-608 testUMIMergeStrategyDirectional."""
+    o = Oracle(umi_merge_kind=1, max_umi_merge_ed=1, umi_mult=2.0)
+    t = o.directional_targets([("AAA", 2), ("AAC", 5), ("AAT", 6), ("AGT", 20), ("CCC", 10), ("TCC", 20)])
+    assert t == {"AAA": "AGT", "AAT": "AGT", "CCC": "TCC"}
+
+
+def test_edit_distance():
+    """Tests/TestTools.cpp:47-54 testEditDistance."""
+    assert ob.edit_distance("ATTTTC", "ATTTGC") == 1
+    assert ob.edit_distance("ATTTTCC", "ATTTGNC") == 1
+    assert ob.edit_distance("ATTTTCC", "ATTTGNC", False) == 2
+    assert ob.edit_distance("ATTTTCC", "ATTTGTC") == 2
+    assert ob.edit_distance("ATTTTCC", "ATTTTCC") == 0
+
+
+def test_read_params():
+    """Tests/TestTools.cpp:56-87 testReadParams (id!CB#UMI encoding)."""
+    assert ob.parse_encoded_id("@111!ATTTGC#ATATC") == ("ATTTGC", "ATATC")
+    assert ob.parse_encoded_id("111!ATTTG#ATAT") == ("ATTTG", "ATAT")
+    assert ob.parse_encoded_id("!ATTTGC#ATATC") == ("ATTTGC", "ATATC")
+    assert ob.parse_encoded_id("trash!ATTTG#ATAT") == ("ATTTG", "ATAT")
+    assert ob.parse_encoded_id("1111!AAATTTTATA#TTGG") == ("AAATTTTATA", "TTGG")
+    with pytest.raises(RuntimeError):
+        ob.parse_encoded_id("ATTTG#ATAT")
+
+
+def test_survey_probes():
+    """SURVEY.md §7 'hard parts' observations made with the compiled reference while surveying:
+    (i) Stats::merge adds TOTAL_UMIS even for coinciding UMIs; (ii) random fill after srand(42) draws
+    G,A,C,C and decrements TOTAL_UMIS for the re-keyed UMI."""
+    o = fixture_container()
+    o.merge_and_filter()
+    rows = o.cell_rows()
+    # cell 1 (AAATTAGGTCCC: 3 UMIs) absorbed cell 2 (1 UMI, same UMI-gene CAACCT/Gene1) -> stat 4, 3 distinct
+    assert rows[1, 7] == 4
+    assert sum(len(v) for (cb, _), v in o.molecule_dict().items() if cb == "AAATTAGGTCCC") == 3
+    p = Oracle(min_genes_before=0, min_genes_after=0)
+    p.add_record("AAAA", "ACGTCC", "G"); p.add_record("AAAA", "NNNNAA", "G")
+    p.set_initialized(); p.merge_and_filter()
+    # all-N prefix has wildcard distance 2 to ACGTCC (> 1) -> random fill GACC + AA
+    assert set(p.molecule_dict()[("AAAA", "G")]) == {"ACGTCC", "GACCAA"}
+    assert p.cell_rows()[0, 7] == 1
