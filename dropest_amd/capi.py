@@ -1,0 +1,351 @@
+"""ctypes binding of the C-ABI in include/dropest_amd.h (the product path; fails loudly without the
+HIP library or without a GPU -- there is no CPU implementation behind it)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB, build
+
+ESCAPE = 1 << 63
+NO_GENE = 0xFFFFFFFF
+
+MERGE_NONE, MERGE_REAL_BARCODES = 0, 1
+BARCODES_INDROP, BARCODES_CONST = 0, 1
+
+_STATUS = {1: "INVALID", 2: "RANGE", 3: "DEVICE", 4: "UNSUPPORTED", 5: "IO"}
+
+
+class DropestError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("dropest_amd [%s]: %s" % (_STATUS.get(status, status), msg))
+        self.status = status
+
+
+class Cfg(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("merge_kind", C.c_int32), ("barcodes_kind", C.c_int32),
+        ("barcodes_file", C.c_char_p), ("min_genes_before_merge", C.c_int32), ("min_genes_after_merge", C.c_int32),
+        ("min_merge_fraction", C.c_double), ("max_cb_merge_edit_distance", C.c_int32),
+        ("umi_merge_kind", C.c_int32), ("max_umi_merge_edit_distance", C.c_int32),
+        ("gene_match_levels", C.c_char_p), ("max_cells", C.c_int32), ("cb_table_capacity", C.c_uint64),
+    ]
+
+
+class CellRow(C.Structure):
+    _fields_ = [
+        ("barcode", C.c_uint64), ("first_read", C.c_uint32), ("n_genes", C.c_uint32),
+        ("requested_genes", C.c_uint32), ("requested_umis", C.c_uint32), ("total_reads", C.c_int32),
+        ("total_umis", C.c_int32), ("is_merged", C.c_uint8), ("is_excluded", C.c_uint8), ("is_real", C.c_uint8),
+        ("pad", C.c_uint8),
+    ]
+
+
+CELL_ROW_DTYPE = np.dtype([
+    ("barcode", "<u8"), ("first_read", "<u4"), ("n_genes", "<u4"), ("requested_genes", "<u4"),
+    ("requested_umis", "<u4"), ("total_reads", "<i4"), ("total_umis", "<i4"), ("is_merged", "u1"),
+    ("is_excluded", "u1"), ("is_real", "u1"), ("pad", "u1")], align=True)
+assert CELL_ROW_DTYPE.itemsize == C.sizeof(CellRow)
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_uint32), ("ms", C.c_double), ("bytes", C.c_double)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64), ("stream_id", C.c_uint32), ("n_cells", C.c_uint32), ("cell_cb", C.c_void_p),
+        ("cell_cdf", C.c_void_p), ("n_genes", C.c_uint32), ("gene_cdf", C.c_void_p), ("cb_len", C.c_uint32),
+        ("umi_len", C.c_uint32), ("n_chr", C.c_uint32), ("permille_neighbour", C.c_uint32),
+        ("permille_ambient", C.c_uint32), ("permille_intergenic", C.c_uint32), ("permille_intron", C.c_uint32),
+        ("permille_exon_na", C.c_uint32), ("n_effective", C.c_uint64), ("reads_per_molecule", C.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Loads (building first if the sources are newer) dropest_amd/lib/libdropest_amd.so."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        build()
+    L = C.CDLL(LIB)
+    vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+    P = C.POINTER
+    sig = {
+        "dropest_last_error": (C.c_char_p, []),
+        "dropest_cfg_defaults": (None, [P(Cfg)]),
+        "dropest_ctx_create": (C.c_int, [P(Cfg), P(vp)]),
+        "dropest_ctx_destroy": (None, [vp]),
+        "dropest_set_side_strings": (C.c_int, [vp, P(C.c_char_p), C.c_uint64]),
+        "dropest_push_reads": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64]),
+        "dropest_push_reads_device": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, C.c_int]),
+        "dropest_set_initialized": (C.c_int, [vp]),
+        "dropest_merge_and_filter": (C.c_int, [vp]),
+        "dropest_reset_results": (C.c_int, [vp]),
+        "dropest_total_cells": (C.c_int, [vp, u64p]),
+        "dropest_real_cells": (C.c_int, [vp, u64p]),
+        "dropest_cell_rows": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp]),
+        "dropest_cell_id_by_cb": (C.c_int, [vp, C.c_uint64, P(C.c_int64)]),
+        "dropest_filtered_cells": (C.c_int, [vp, u64p, vp]),
+        "dropest_merge_targets": (C.c_int, [vp, u64p, vp, vp]),
+        "dropest_global_counters": (C.c_int, [vp, vp]),
+        "dropest_cell_molecules": (C.c_int, [vp, C.c_uint64, u64p, vp, vp, vp, vp]),
+        "dropest_molecules": (C.c_int, [vp, u64p, vp, vp, vp, vp, vp]),
+        "dropest_count_matrix": (C.c_int, [vp, C.c_int, C.c_int, u64p, vp, vp, vp]),
+        "dropest_chr_stats": (C.c_int, [vp, u64p, vp, vp, vp, vp]),
+        "dropest_merge_target": (C.c_int, [vp, C.c_uint64, P(C.c_int64)]),
+        "dropest_kernel_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
+        "dropest_set_profiling": (C.c_int, [vp, C.c_int]),
+        "dropest_stream": (vp, [vp]),
+        "dropest_synth_generate_host": (C.c_int, [P(SynthParams), C.c_uint64, C.c_uint64, vp, vp, vp, vp]),
+        "dropest_synth_generate_device": (C.c_int, [P(SynthParams), C.c_int, C.c_uint64, C.c_uint64, vp, vp, vp, vp]),
+        "dropest_dev_alloc": (C.c_int, [C.c_int, C.c_uint64, P(vp)]),
+        "dropest_dev_free": (C.c_int, [C.c_int, vp]),
+        "dropest_dev_copy_to_host": (C.c_int, [C.c_int, vp, vp, C.c_uint64]),
+        "dropest_dev_copy_from_host": (C.c_int, [C.c_int, vp, vp, C.c_uint64]),
+        "dropest_dev_count": (C.c_int, []),
+        "dropest_dev_sync": (C.c_int, [C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "dropest_last_error", "dropest_cfg_defaults", "dropest_ctx_create", "dropest_ctx_destroy",
+    "dropest_set_side_strings", "dropest_push_reads", "dropest_push_reads_device", "dropest_set_initialized",
+    "dropest_merge_and_filter", "dropest_reset_results", "dropest_total_cells", "dropest_real_cells",
+    "dropest_cell_rows", "dropest_cell_id_by_cb", "dropest_filtered_cells", "dropest_merge_targets",
+    "dropest_global_counters", "dropest_cell_molecules", "dropest_molecules", "dropest_count_matrix",
+    "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_stream",
+    "dropest_synth_generate_host", "dropest_synth_generate_device", "dropest_dev_alloc", "dropest_dev_free",
+    "dropest_dev_copy_to_host", "dropest_dev_copy_from_host", "dropest_dev_count", "dropest_dev_sync",
+]
+
+
+# ---- 2-bit codes (include/dropest_amd.h) ----
+_B2C = {"A": 0, "C": 1, "G": 2, "T": 3}
+
+
+def pack_seq(s):
+    """Returns the packed code of `s`, or None when it needs an escape (N, other letters, > 31 bases)."""
+    if not s or len(s) > 31:
+        return None
+    c = 1
+    for ch in s:
+        b = _B2C.get(ch)
+        if b is None:
+            return None
+        c = (c << 2) | b
+    return c
+
+
+def unpack_code(code, side=()):
+    code = int(code)
+    if code & ESCAPE:
+        return side[code & (ESCAPE - 1)]
+    n = (code.bit_length() - 1) // 2
+    return "".join("ACGT"[(code >> (2 * (n - 1 - i))) & 3] for i in range(n))
+
+
+class Context:
+    """One container on one GPU.  Method names follow Estimation::CellsDataContainer."""
+
+    def __init__(self, device=0, merge_kind=MERGE_NONE, barcodes_kind=BARCODES_INDROP, barcodes_file=None,
+                 min_genes_before_merge=10, min_genes_after_merge=10, min_merge_fraction=0.2,
+                 max_cb_merge_edit_distance=2, max_umi_merge_edit_distance=1, gene_match_levels="eEBA",
+                 max_cells=-1, cb_table_capacity=0):
+        self.L = lib()
+        self.device = device
+        cfg = Cfg()
+        self.L.dropest_cfg_defaults(C.byref(cfg))
+        cfg.device = device; cfg.merge_kind = merge_kind; cfg.barcodes_kind = barcodes_kind
+        self._bf = barcodes_file.encode() if barcodes_file else None
+        self._ml = gene_match_levels.encode()
+        cfg.barcodes_file = self._bf; cfg.gene_match_levels = self._ml
+        cfg.min_genes_before_merge = min_genes_before_merge; cfg.min_genes_after_merge = min_genes_after_merge
+        cfg.min_merge_fraction = min_merge_fraction; cfg.max_cb_merge_edit_distance = max_cb_merge_edit_distance
+        cfg.max_umi_merge_edit_distance = max_umi_merge_edit_distance; cfg.max_cells = max_cells
+        cfg.cb_table_capacity = cb_table_capacity
+        h = C.c_void_p()
+        self.h = None
+        self._chk(self.L.dropest_ctx_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.side = []
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.L.dropest_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DropestError(rc, self.L.dropest_last_error().decode())
+
+    # ---- ingest ----
+    def set_side_strings(self, strings):
+        self.side = list(strings)
+        arr = (C.c_char_p * max(1, len(self.side)))(*[s.encode() for s in self.side])
+        self._chk(self.L.dropest_set_side_strings(self.h, arr, len(self.side)))
+
+    def push_reads(self, cb, umi, gene, aux):
+        cb = np.ascontiguousarray(cb, np.uint64); umi = np.ascontiguousarray(umi, np.uint64)
+        gene = np.ascontiguousarray(gene, np.uint32); aux = np.ascontiguousarray(aux, np.uint32)
+        assert len(cb) == len(umi) == len(gene) == len(aux)
+        self._chk(self.L.dropest_push_reads(self.h, cb.ctypes.data, umi.ctypes.data, gene.ctypes.data,
+                                            aux.ctypes.data, len(cb)))
+
+    def push_reads_device(self, d_cb, d_umi, d_gene, d_aux, n, adopt=True):
+        self._chk(self.L.dropest_push_reads_device(self.h, d_cb, d_umi, d_gene, d_aux, n, int(adopt)))
+
+    def set_initialized(self):
+        self._chk(self.L.dropest_set_initialized(self.h))
+
+    def merge_and_filter(self):
+        self._chk(self.L.dropest_merge_and_filter(self.h))
+
+    def reset_results(self):
+        self._chk(self.L.dropest_reset_results(self.h))
+
+    # ---- accessors ----
+    def total_cells_number(self):
+        n = C.c_uint64()
+        self._chk(self.L.dropest_total_cells(self.h, C.byref(n)))
+        return n.value
+
+    def real_cells_number(self):
+        n = C.c_uint64()
+        self._chk(self.L.dropest_real_cells(self.h, C.byref(n)))
+        return n.value
+
+    def cell_rows(self, first=0, count=None):
+        if count is None:
+            count = self.total_cells_number() - first
+        out = np.zeros(count, CELL_ROW_DTYPE)
+        self._chk(self.L.dropest_cell_rows(self.h, first, count, out.ctypes.data))
+        return out
+
+    def cell_id_by_cb(self, barcode_code):
+        i = C.c_int64()
+        self._chk(self.L.dropest_cell_id_by_cb(self.h, barcode_code, C.byref(i)))
+        return i.value
+
+    def filtered_cells(self):
+        n = C.c_uint64()
+        self._chk(self.L.dropest_filtered_cells(self.h, C.byref(n), None))
+        out = np.zeros(n.value, np.uint64)
+        if n.value:
+            self._chk(self.L.dropest_filtered_cells(self.h, C.byref(n), out.ctypes.data))
+        return out
+
+    def merge_targets(self):
+        """Full merge_targets() vector of the reference (identity where nothing was merged)."""
+        n = C.c_uint64()
+        self._chk(self.L.dropest_merge_targets(self.h, C.byref(n), None, None))
+        src = np.zeros(n.value, np.uint64); tgt = np.zeros(n.value, np.uint64)
+        if n.value:
+            self._chk(self.L.dropest_merge_targets(self.h, C.byref(n), src.ctypes.data, tgt.ctypes.data))
+        full = np.arange(self.total_cells_number(), dtype=np.uint64)
+        full[src.astype(np.int64)] = tgt
+        return full
+
+    def global_counters(self):
+        out = np.zeros(4, np.uint64)
+        self._chk(self.L.dropest_global_counters(self.h, out.ctypes.data))
+        return out
+
+    def molecules(self):
+        n = C.c_uint64()
+        self._chk(self.L.dropest_molecules(self.h, C.byref(n), None, None, None, None, None))
+        cell = np.zeros(n.value, np.uint32); gene = np.zeros(n.value, np.uint32); umi = np.zeros(n.value, np.uint64)
+        reads = np.zeros(n.value, np.uint32); mark = np.zeros(n.value, np.uint8)
+        if n.value:
+            self._chk(self.L.dropest_molecules(self.h, C.byref(n), cell.ctypes.data, gene.ctypes.data, umi.ctypes.data,
+                                               reads.ctypes.data, mark.ctypes.data))
+        return cell, gene, umi, reads, mark
+
+    def cell_molecules(self, cell):
+        n = C.c_uint64()
+        self._chk(self.L.dropest_cell_molecules(self.h, cell, C.byref(n), None, None, None, None))
+        gene = np.zeros(n.value, np.uint32); umi = np.zeros(n.value, np.uint64)
+        reads = np.zeros(n.value, np.uint32); mark = np.zeros(n.value, np.uint8)
+        if n.value:
+            self._chk(self.L.dropest_cell_molecules(self.h, cell, C.byref(n), gene.ctypes.data, umi.ctypes.data,
+                                                    reads.ctypes.data, mark.ctypes.data))
+        return gene, umi, reads, mark
+
+    def count_matrix(self, filtered=True, reads_output=False):
+        n = C.c_uint64()
+        self._chk(self.L.dropest_count_matrix(self.h, int(filtered), int(reads_output), C.byref(n), None, None, None))
+        g = np.zeros(n.value, np.uint32); c = np.zeros(n.value, np.uint32); v = np.zeros(n.value, np.uint32)
+        if n.value:
+            self._chk(self.L.dropest_count_matrix(self.h, int(filtered), int(reads_output), C.byref(n), g.ctypes.data,
+                                                  c.ctypes.data, v.ctypes.data))
+        return g, c, v
+
+    def chr_stats(self):
+        n = C.c_uint64()
+        self._chk(self.L.dropest_chr_stats(self.h, C.byref(n), None, None, None, None))
+        cell = np.zeros(n.value, np.uint32); kind = np.zeros(n.value, np.uint32); chr_ = np.zeros(n.value, np.uint32)
+        cnt = np.zeros(n.value, np.int32)
+        if n.value:
+            self._chk(self.L.dropest_chr_stats(self.h, C.byref(n), cell.ctypes.data, kind.ctypes.data, chr_.ctypes.data,
+                                               cnt.ctypes.data))
+        return cell, kind, chr_, cnt
+
+    def merge_target(self, cell):
+        t = C.c_int64()
+        self._chk(self.L.dropest_merge_target(self.h, cell, C.byref(t)))
+        return t.value
+
+    def set_profiling(self, on=True):
+        self._chk(self.L.dropest_set_profiling(self.h, int(on)))
+
+    def kernel_stats(self):
+        n = C.c_uint32()
+        self._chk(self.L.dropest_kernel_stats(self.h, C.byref(n), None))
+        arr = (KernelStat * max(1, n.value))()
+        self._chk(self.L.dropest_kernel_stats(self.h, C.byref(n), arr))
+        return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, bytes=arr[i].bytes)
+                for i in range(n.value)}
+
+
+class DeviceArrays:
+    """Four device arrays (cb, umi, gene, aux) of n reads, allocated through the library."""
+
+    def __init__(self, device, n):
+        self.L = lib()
+        self.device, self.n = device, n
+        self.ptrs = []
+        for width in (8, 8, 4, 4):
+            p = C.c_void_p()
+            if self.L.dropest_dev_alloc(device, n * width, C.byref(p)) != 0:
+                self.free()
+                raise DropestError(3, "device allocation of %d bytes failed" % (n * width))
+            self.ptrs.append(p)
+
+    def free(self):
+        for p in self.ptrs:
+            self.L.dropest_dev_free(self.device, p)
+        self.ptrs = []
+
+    def to_host(self):
+        out = [np.zeros(self.n, np.uint64), np.zeros(self.n, np.uint64), np.zeros(self.n, np.uint32),
+               np.zeros(self.n, np.uint32)]
+        for a, p, w in zip(out, self.ptrs, (8, 8, 4, 4)):
+            if self.L.dropest_dev_copy_to_host(self.device, a.ctypes.data, p, self.n * w) != 0:
+                raise DropestError(3, "device-to-host copy failed")
+        return out

@@ -1,0 +1,155 @@
+// context.h -- the device pipeline behind dropest_ctx (host orchestration of the HIP kernels).
+#pragma once
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/dropest_amd.h"
+#include "k_cbhash.h"
+#include "k_misc.h"
+#include "k_radix.h"
+#include "k_segreduce.h"
+#include "util.h"
+
+namespace dropest {
+
+typedef unsigned long long u64;
+typedef uint32_t u32;
+
+struct ReadChunk {
+	DevBuf<u64> cb, umi;
+	DevBuf<u32> gene, aux;
+	const u64 *p_cb = nullptr, *p_umi = nullptr;
+	const u32 *p_gene = nullptr, *p_aux = nullptr;
+	uint64_t n = 0;
+};
+
+struct KernelStat { u32 launches = 0; double ms = 0, bytes = 0; };
+
+// decode a packed 2-bit code (include/dropest_amd.h) to text
+inline std::string decode_code(u64 code, const std::vector<std::string> &side) {
+	if (code & ESCAPE_BIT) {
+		u64 k = code & ~ESCAPE_BIT;
+		if (k >= side.size()) throw RangeError("escaped code refers to an unregistered side string");
+		return side[k];
+	}
+	if (code == 0) return std::string();
+	int len = (bit_length(code) - 1) / 2;
+	std::string s(size_t(len), 'A');
+	for (int i = 0; i < len; ++i) s[size_t(i)] = "ACGT"[(code >> (2 * (len - 1 - i))) & 3];
+	return s;
+}
+inline bool encode_code(const std::string &s, u64 &code) {   // false: needs an escape
+	if (s.empty() || s.size() > 31) return false;
+	u64 c = 1;
+	for (char ch : s) {
+		u64 b;
+		switch (ch) { case 'A': b = 0; break; case 'C': b = 1; break; case 'G': b = 2; break; case 'T': b = 3; break; default: return false; }
+		c = (c << 2) | b;
+	}
+	code = c;
+	return true;
+}
+
+struct HostCell {   // host mirror of one REAL-candidate cell (n_genes >= min_genes_before_merge at init)
+	u32 id;
+	CellRowPod row;         // sizes as of the last device update + stat adjustments
+	std::string barcode;
+	bool merged = false, excluded = false;
+};
+
+}  // namespace dropest
+
+struct dropest_ctx {
+	using u64 = dropest::u64;
+	using u32 = dropest::u32;
+
+	dropest_cfg cfg;
+	std::string barcodes_file, match_levels;
+	u32 query_mask = 0;
+	u32 min_before = 0, min_after = 0;
+	hipStream_t stream = nullptr;
+
+	std::vector<dropest::ReadChunk> chunks;
+	uint64_t n_reads = 0;
+	dropest::DevBuf<u64> cat_cb, cat_umi;
+	dropest::DevBuf<u32> cat_gene, cat_aux;
+	const u64 *d_cb = nullptr, *d_umi = nullptr;
+	const u32 *d_gene = nullptr, *d_aux = nullptr;
+	std::vector<std::string> side;
+
+	bool initialized = false, merged = false;
+
+	// ---- device results ----
+	dropest::DevBuf<u64> t_keys;
+	dropest::DevBuf<u32> t_first, t_cell, slot;
+	dropest::CbTable table{};
+	u32 n_cells = 0;
+	dropest::DevBuf<u64> cell_cb;
+	dropest::DevBuf<u32> cell_first;
+	dropest::KeyLayout layout{};
+	int umi_clean_bits = 0;          // bits of a clean UMI code inside the key
+	bool umi_sentinel_stripped = false;
+	dropest::IngestStats ingest{};
+	dropest::GlobalCounters counters{};
+
+	dropest::DevBuf<u64> keys_a, keys_b;     // sort ping-pong (released after the reduces)
+	dropest::DevBuf<u32> vals_a, vals_b;
+
+	u32 n_mol = 0;
+	dropest::DevBuf<u64> mol_key;
+	dropest::DevBuf<u32> mol_reads, mol_mark;
+	u32 n_cg = 0;
+	dropest::DevBuf<u64> cg_key;
+	dropest::DevBuf<u32> cg_mol_begin, cg_n_all, cg_n_req, cg_reads_all, cg_reads_req;
+	dropest::DevBuf<u32> cell_cg_begin, cell_n_genes, cell_req_genes, cell_req_umis, cell_total_umis, cell_total_reads;
+	u32 n_chr_rows = 0;
+	dropest::DevBuf<u64> chr_row_key;
+	dropest::DevBuf<u32> chr_exon, chr_intron, chr_inter;
+
+	// scratch
+	dropest::DevBuf<u32> tile_counts, tile_prefix, scalars, rs_hist, rs_row_total, rs_digit_base;
+	dropest::DevBuf<dropest::IngestStats> d_ingest;
+	dropest::DevBuf<dropest::GlobalCounters> d_counters;
+
+	// ---- host state over real-candidate cells ----
+	std::vector<dropest::HostCell> real;                 // ascending cell id
+	std::unordered_map<u32, u32> real_index_of;          // cell id -> index in `real`
+	std::vector<uint64_t> filtered;                      // cell ids, ascending compare_cells order
+	std::vector<std::pair<uint64_t, uint64_t>> merge_pairs;   // (source, target), target != source
+	uint64_t n_real_now = 0;
+
+	// ---- instrumentation ----
+	bool profiling = false;
+	std::map<std::string, dropest::KernelStat> stats;
+	struct Pending { std::string name; hipEvent_t a, b; double bytes; };
+	std::vector<Pending> pending;
+	std::vector<hipEvent_t> event_pool;
+
+	~dropest_ctx();
+	void init_from_cfg(const dropest_cfg &c);
+
+	template <class F> void timed(const char *name, double bytes, F &&launch);
+	void collect_timings();
+
+	void concat_chunks();
+	void free_results();
+	void run_set_initialized();
+	void run_merge_and_filter();
+
+	void build_cb_table();
+	void assign_cell_ids();
+	void plan_key_layout();
+	void build_keys();
+	void radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask);
+	void reduce_all();
+	void fetch_real_cells();
+	void sort_filtered(u32 genes_threshold, int max_cells);
+	void emit_matrix(bool filtered_m, bool reads_output, std::vector<u32> &g, std::vector<u32> &c, std::vector<u32> &v);
+	u64 unmap_umi(u64 ucode) const;
+};

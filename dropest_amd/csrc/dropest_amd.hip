@@ -1,0 +1,873 @@
+// dropest_amd.hip -- MI355X-native Estimation hot path of dropEst: device pipeline + C-ABI (include/dropest_amd.h).
+//
+// Pipeline of dropest_set_initialized (all launches on the context's stream):
+//   cb_insert        barcode hash build + first-seen ordinals            (CellsDataContainer.cpp:64-69)
+//   cb_first_count / scan_small / cb_assign_ids   first-seen cell ids
+//   build_keys       (cell | gene | UMI) sort keys + global read counters (CellsDataContainer.cpp:73-78, :309-327)
+//   rs_hist / rs_scan / rs_scatter  x passes      LSD radix sort
+//   seg_count / scan_small / seg_reduce  x 4      reads->molecules, reads->(cell,chr), molecules->(cell,gene), ->cells
+//   flag_real / gather_cell_rows                  real cells to the host, which orders them (compare_cells)
+// This file contains no CPU implementation of the path: without a GPU every entry point fails loudly.
+
+#include "context.h"
+
+#include <functional>
+
+using namespace dropest;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+template <class F>
+static dropest_status guarded(F &&f) {
+	try {
+		f();
+		return DROPEST_OK;
+	} catch (const InvalidError &e) { g_last_error = e.what(); return DROPEST_ERR_INVALID;
+	} catch (const RangeError &e) { g_last_error = e.what(); return DROPEST_ERR_RANGE;
+	} catch (const UnsupportedError &e) { g_last_error = e.what(); return DROPEST_ERR_UNSUPPORTED;
+	} catch (const IoError &e) { g_last_error = e.what(); return DROPEST_ERR_IO;
+	} catch (const DeviceError &e) { g_last_error = e.what(); return DROPEST_ERR_DEVICE;
+	} catch (const std::bad_alloc &) { g_last_error = "host allocation failed"; return DROPEST_ERR_DEVICE;
+	} catch (const std::exception &e) { g_last_error = e.what(); return DROPEST_ERR_INVALID; }
+}
+
+static inline u32 div_up(uint64_t a, uint64_t b) { return u32((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------------
+// context basics
+// ------------------------------------------------------------------------------------------------
+static u32 query_mask_from_code(const std::string &code) {   // UMI::Mark::get_by_code, UMI.cpp:112-154
+	u32 m = 0;
+	for (char c : code) {
+		switch (c) {
+			case 'e': m |= 1u << 2; break;
+			case 'i': m |= 1u << 4; break;
+			case 'E': m |= 1u << 3; break;
+			case 'I': m |= 1u << 5; break;
+			case 'B': m |= 1u << 6; break;
+			case 'A': m |= 1u << 7; break;
+			default: throw InvalidError(std::string("Unexpected gene match levels: ") + c);
+		}
+	}
+	return m;
+}
+
+void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
+	cfg = c;
+	barcodes_file = c.barcodes_file ? c.barcodes_file : "";
+	match_levels = c.gene_match_levels ? c.gene_match_levels : "eEBA";
+	cfg.barcodes_file = barcodes_file.c_str();
+	cfg.gene_match_levels = match_levels.c_str();
+	query_mask = query_mask_from_code(match_levels);
+	if (c.min_genes_before_merge < 0 || c.min_genes_after_merge < 0) throw InvalidError("negative gene threshold");
+	min_before = u32(c.min_genes_before_merge);
+	min_after = std::max(u32(c.min_genes_after_merge), min_before);   // MergeStrategyAbstract.cpp:8-11
+	if (c.merge_kind != DROPEST_MERGE_NONE && c.merge_kind != DROPEST_MERGE_REAL_BARCODES)
+		throw InvalidError("unknown merge_kind");
+	if (c.umi_merge_kind != DROPEST_UMI_MERGE_SIMPLE) throw UnsupportedError("only the simple UMI merge is built");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+		throw DeviceError("no HIP device visible: the dropEst hot path has no CPU implementation");
+	if (c.device < 0 || c.device >= ndev) throw InvalidError("device ordinal out of range");
+	HIP_CHECK(hipSetDevice(c.device));
+	HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+}
+
+dropest_ctx::~dropest_ctx() {
+	for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+	for (auto e : event_pool) (void)hipEventDestroy(e);
+	if (stream) (void)hipStreamDestroy(stream);
+}
+
+template <class F>
+void dropest_ctx::timed(const char *name, double bytes, F &&launch) {
+	if (!profiling) { launch(); HIP_CHECK(hipGetLastError()); return; }
+	auto get = [&]() {
+		if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+		hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
+	};
+	hipEvent_t a = get(), b = get();
+	HIP_CHECK(hipEventRecord(a, stream));
+	launch();
+	HIP_CHECK(hipGetLastError());
+	HIP_CHECK(hipEventRecord(b, stream));
+	pending.push_back(Pending{name, a, b, bytes});
+}
+
+void dropest_ctx::collect_timings() {
+	if (pending.empty()) return;
+	HIP_CHECK(hipStreamSynchronize(stream));
+	for (auto &p : pending) {
+		float ms = 0;
+		HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+		auto &s = stats[p.name];
+		s.launches++; s.ms += ms; s.bytes += p.bytes;
+		event_pool.push_back(p.a); event_pool.push_back(p.b);
+	}
+	pending.clear();
+}
+
+void dropest_ctx::concat_chunks() {
+	if (d_cb) return;
+	if (n_reads == 0) return;
+	if (n_reads >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads in one context (shard across GPUs)");
+	if (chunks.size() == 1) {
+		d_cb = chunks[0].p_cb; d_umi = chunks[0].p_umi; d_gene = chunks[0].p_gene; d_aux = chunks[0].p_aux;
+		return;
+	}
+	cat_cb.alloc(n_reads); cat_umi.alloc(n_reads); cat_gene.alloc(n_reads); cat_aux.alloc(n_reads);
+	uint64_t off = 0;
+	for (auto &c : chunks) {
+		HIP_CHECK(hipMemcpyAsync(cat_cb.p + off, c.p_cb, c.n * 8, hipMemcpyDeviceToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(cat_umi.p + off, c.p_umi, c.n * 8, hipMemcpyDeviceToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(cat_gene.p + off, c.p_gene, c.n * 4, hipMemcpyDeviceToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(cat_aux.p + off, c.p_aux, c.n * 4, hipMemcpyDeviceToDevice, stream));
+		off += c.n;
+	}
+	HIP_CHECK(hipStreamSynchronize(stream));
+	chunks.clear();
+	chunks.emplace_back();
+	chunks[0].p_cb = cat_cb.p; chunks[0].p_umi = cat_umi.p; chunks[0].p_gene = cat_gene.p; chunks[0].p_aux = cat_aux.p;
+	chunks[0].n = n_reads;
+	d_cb = cat_cb.p; d_umi = cat_umi.p; d_gene = cat_gene.p; d_aux = cat_aux.p;
+}
+
+void dropest_ctx::free_results() {
+	initialized = merged = false;
+	n_cells = n_mol = n_cg = n_chr_rows = 0;
+	real.clear(); real_index_of.clear(); filtered.clear(); merge_pairs.clear(); n_real_now = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: barcode table + cell ids
+// ------------------------------------------------------------------------------------------------
+void dropest_ctx::build_cb_table() {
+	const u32 n = u32(n_reads);
+	uint64_t cap = cfg.cb_table_capacity;
+	if (cap == 0) { cap = 1024; while (cap < n_reads / 2) cap <<= 1; }
+	if (cap & (cap - 1)) throw InvalidError("cb_table_capacity must be a power of two");
+	slot.ensure(n);
+	d_ingest.ensure(1);
+	for (int attempt = 0;; ++attempt) {
+		if (cap > (1ull << 32)) throw UnsupportedError("barcode table would exceed 2^32 slots");
+		t_keys.ensure(cap); t_first.ensure(cap); t_cell.ensure(cap);
+		table.keys = t_keys.p; table.first = t_first.p; table.cell_id = t_cell.p; table.mask = cap - 1;
+		HIP_CHECK(hipMemsetAsync(t_keys.p, 0, cap * 8, stream));
+		HIP_CHECK(hipMemsetAsync(t_first.p, 0xFF, cap * 4, stream));
+		IngestStats init{};
+		init.umi_clean_min = ~0ull;
+		HIP_CHECK(hipMemcpyAsync(d_ingest.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
+		const u32 blocks = std::min<u32>(div_up(n, 256), 256u * 16u);
+		timed("cb_insert", double(n) * (8 + 8 + 4 + 4), [&] {
+			hipLaunchKernelGGL(cb_insert_kernel<256>, dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, n, table,
+			                   slot.p, d_ingest.p);
+		});
+		HIP_CHECK(hipMemcpyAsync(&ingest, d_ingest.p, sizeof(ingest), hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		if (!ingest.overflow) break;
+		if (attempt >= 6) throw DeviceError("barcode table overflow after repeated growth");
+		cap <<= 2;
+	}
+}
+
+void dropest_ctx::assign_cell_ids() {
+	const u32 n = u32(n_reads);
+	const u32 tiles = div_up(n, CID_TILE);
+	tile_counts.ensure(tiles); tile_prefix.ensure(tiles); scalars.ensure(16);
+	timed("cb_first_count", double(n) * 8, [&] {
+		hipLaunchKernelGGL(cb_first_count_kernel, dim3(tiles), dim3(CID_THREADS), 0, stream, slot.p, n, table, tile_counts.p);
+	});
+	timed("scan_small", double(tiles) * 8, [&] {
+		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, tile_counts.p, tile_prefix.p, tiles, scalars.p);
+	});
+	u32 total = 0;
+	HIP_CHECK(hipMemcpyAsync(&total, scalars.p, 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	n_cells = total;
+	if (uint64_t(n_cells) * 10 > (table.mask + 1) * 7)   // load factor > 0.7: rebuild larger for short probe chains
+	{
+		cfg.cb_table_capacity = (table.mask + 1) << 2;
+		build_cb_table();
+		return assign_cell_ids();
+	}
+	cell_cb.ensure(n_cells); cell_first.ensure(n_cells);
+	timed("cb_assign_ids", double(n) * 8 + double(n_cells) * 16, [&] {
+		hipLaunchKernelGGL(cb_assign_ids_kernel, dim3(tiles), dim3(CID_THREADS), 0, stream, d_cb, slot.p, n, table,
+		                   tile_prefix.p, cell_cb.p, cell_first.p);
+	});
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: key layout + keys
+// ------------------------------------------------------------------------------------------------
+void dropest_ctx::plan_key_layout() {
+	KeyLayout L{};
+	// UMI field
+	const bool any_clean = ingest.umi_clean_max != 0;
+	int clean_bits = 0;
+	umi_sentinel_stripped = false;
+	if (any_clean) {
+		const int bl_min = bit_length(ingest.umi_clean_min), bl_max = bit_length(ingest.umi_clean_max);
+		if (bl_min == bl_max) {   // one UMI length: drop the sentinel bit
+			umi_sentinel_stripped = true;
+			clean_bits = bl_max - 1;
+			L.umi_strip_mask = clean_bits ? ((1ull << clean_bits) - 1ull) : 0ull;
+		} else {
+			clean_bits = bl_max;
+			L.umi_strip_mask = ~0ull;
+		}
+	}
+	umi_clean_bits = clean_bits;
+	L.umi_escape_base = 1ull << clean_bits;
+	L.umi_bits = clean_bits;
+	if (ingest.umi_escape_max_plus1) L.umi_bits = bit_length(L.umi_escape_base + ingest.umi_escape_max_plus1 - 1);
+	// gene field: ids 0..gene_max, plus the "no gene" code = all ones
+	L.gene_bits = bit_length(uint64_t(ingest.gene_max_plus1));
+	if ((1ull << L.gene_bits) - 1 < ingest.gene_max_plus1) L.gene_bits++;
+	if (L.gene_bits == 0) L.gene_bits = 1;
+	L.gene_none = (1ull << L.gene_bits) - 1ull;
+	L.cell_bits = std::max(1, bit_length(uint64_t(n_cells ? n_cells - 1 : 0)));
+	if (L.umi_bits + L.gene_bits + L.cell_bits > 64)
+		throw UnsupportedError("sort key needs " + std::to_string(L.umi_bits + L.gene_bits + L.cell_bits) +
+		                       " bits (cell " + std::to_string(L.cell_bits) + " + gene " + std::to_string(L.gene_bits) +
+		                       " + UMI " + std::to_string(L.umi_bits) + "); this build sorts 64-bit keys");
+	if (L.gene_bits + L.umi_bits >= 64) throw UnsupportedError("gene + UMI field too wide");
+	layout = L;
+}
+
+dropest_ctx::u64 dropest_ctx::unmap_umi(u64 ucode) const {
+	if (ucode >= layout.umi_escape_base && ingest.umi_escape_max_plus1) return ESCAPE_BIT | (ucode - layout.umi_escape_base);
+	if (umi_sentinel_stripped) return (1ull << umi_clean_bits) | ucode;
+	return ucode;
+}
+
+void dropest_ctx::build_keys() {
+	const u32 n = u32(n_reads);
+	keys_a.ensure(n); keys_b.ensure(n); vals_a.ensure(n); vals_b.ensure(n);
+	d_counters.ensure(1);
+	GlobalCounters init{};
+	init.key_and = ~0ull;
+	HIP_CHECK(hipMemcpyAsync(d_counters.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
+	const u32 blocks = std::min<u32>(div_up(n, 256), 256u * 16u);
+	timed("build_keys", double(n) * (8 + 4 + 4 + 4 + 4 + 8 + 4), [&] {
+		hipLaunchKernelGGL(build_keys_kernel<256>, dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n,
+		                   table, layout, keys_a.p, vals_a.p, d_counters.p);
+	});
+	HIP_CHECK(hipMemcpyAsync(&counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: radix sort
+// ------------------------------------------------------------------------------------------------
+void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask) {
+	if (n == 0) return;
+	const u32 n_tiles = div_up(n, RS_TILE);
+	u32 nblocks = std::min<u32>(n_tiles, 1024);
+	const u32 tpb = div_up(n_tiles, nblocks);
+	nblocks = div_up(n_tiles, tpb);
+	rs_hist.ensure(size_t(RS_RADIX) * nblocks); rs_row_total.ensure(RS_RADIX); rs_digit_base.ensure(RS_RADIX);
+	for (int shift = 0; shift < 64; shift += 8) {
+		if (((varying_mask >> shift) & 0xFFull) == 0) continue;   // digit constant over all keys: pass is the identity
+		timed("rs_hist", double(n) * 8, [&] {
+			hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, keys, n, shift, tpb, rs_hist.p);
+		});
+		timed("rs_scan", double(RS_RADIX) * nblocks * 8, [&] {
+			hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, stream, rs_hist.p, nblocks, rs_row_total.p);
+			hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(256), 0, stream, rs_row_total.p, rs_digit_base.p);
+		});
+		timed("rs_scatter", double(n) * 24, [&] {
+			hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, keys, vals, keys_alt, vals_alt,
+			                   n, shift, tpb, rs_hist.p, rs_digit_base.p);
+		});
+		std::swap(keys, keys_alt);
+		std::swap(vals, vals_alt);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: segmented reduces
+// ------------------------------------------------------------------------------------------------
+// Runs count -> scan -> reduce for one policy.  `prepare(total)` allocates + zeroes the outputs and wires the
+// policy's pointers once the number of runs is known.  Returns the number of runs.
+template <class P, class Prep>
+static u32 run_segmented_reduce(dropest_ctx &c, const char *tag, P &policy, u32 n, double bytes_per_row, Prep &&prepare) {
+	if (n == 0) { prepare(0); return 0; }
+	const u32 tiles = div_up(n, SR_TILE);
+	c.tile_counts.ensure(tiles); c.tile_prefix.ensure(tiles); c.scalars.ensure(16);
+	const std::string n_count = std::string("seg_count:") + tag, n_reduce = std::string("seg_reduce:") + tag;
+	c.timed(n_count.c_str(), double(n) * 8, [&] {
+		hipLaunchKernelGGL(seg_count_kernel<P>, dim3(tiles), dim3(SR_THREADS), 0, c.stream, policy, n, c.tile_counts.p);
+	});
+	c.timed("scan_small", double(tiles) * 8, [&] {
+		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, c.stream, c.tile_counts.p, c.tile_prefix.p, tiles,
+		                   c.scalars.p);
+	});
+	u32 total = 0;
+	HIP_CHECK(hipMemcpyAsync(&total, c.scalars.p, 4, hipMemcpyDeviceToHost, c.stream));
+	HIP_CHECK(hipStreamSynchronize(c.stream));
+	prepare(total);
+	c.timed(n_reduce.c_str(), double(n) * bytes_per_row, [&] {
+		hipLaunchKernelGGL(seg_reduce_kernel<P>, dim3(tiles), dim3(SR_THREADS), 0, c.stream, policy, n, c.tile_prefix.p);
+	});
+	return total;
+}
+
+static void zero_async(dropest_ctx &c, void *p, size_t bytes) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, c.stream)); }
+
+void dropest_ctx::reduce_all() {
+	const u32 n = u32(n_reads);
+	u64 *keys = keys_a.p, *keys_alt = keys_b.p;
+	u32 *vals = vals_a.p, *vals_alt = vals_b.p;
+	radix_sort(keys, vals, keys_alt, vals_alt, n, counters.key_or ^ counters.key_and);
+
+	// reads -> molecules
+	{
+		ReadsToMolecules p{};
+		p.keys = keys; p.vals = vals;
+		n_mol = run_segmented_reduce(*this, "molecules", p, n, 12 + 4, [&](u32 total) {
+			mol_key.ensure(total + 1); mol_reads.ensure(total + 1); mol_mark.ensure(total + 1);
+			zero_async(*this, mol_reads.p, size_t(total + 1) * 4); zero_async(*this, mol_mark.p, size_t(total + 1) * 4);
+			p.mol_key = mol_key.p; p.out[0] = mol_reads.p; p.out[1] = mol_mark.p;
+		});
+	}
+	// reads -> (cell, chr) partial rows
+	{
+		ReadsToChrRows p{};
+		p.keys = keys; p.vals = vals;
+		p.cell_shift = layout.gene_bits + layout.umi_bits; p.umi_bits = layout.umi_bits; p.gene_mask = layout.gene_none;
+		n_chr_rows = run_segmented_reduce(*this, "chr_rows", p, n, 12 + 2, [&](u32 total) {
+			chr_row_key.ensure(total + 1); chr_exon.ensure(total + 1); chr_intron.ensure(total + 1); chr_inter.ensure(total + 1);
+			zero_async(*this, chr_exon.p, size_t(total + 1) * 4); zero_async(*this, chr_intron.p, size_t(total + 1) * 4);
+			zero_async(*this, chr_inter.p, size_t(total + 1) * 4);
+			p.row_key = chr_row_key.p; p.out[0] = chr_exon.p; p.out[1] = chr_intron.p; p.out[2] = chr_inter.p;
+		});
+	}
+	// molecules -> (cell, gene)
+	{
+		MoleculesToCellGene p{};
+		p.mol_key = mol_key.p; p.mol_reads = mol_reads.p; p.mol_mark = mol_mark.p;
+		p.umi_bits = layout.umi_bits; p.query_mask = query_mask;
+		n_cg = run_segmented_reduce(*this, "cell_gene", p, n_mol, 16 + 8, [&](u32 total) {
+			cg_key.ensure(total + 1); cg_mol_begin.ensure(total + 1); cg_n_all.ensure(total + 1); cg_n_req.ensure(total + 1);
+			cg_reads_all.ensure(total + 1); cg_reads_req.ensure(total + 1);
+			zero_async(*this, cg_n_all.p, size_t(total + 1) * 4); zero_async(*this, cg_n_req.p, size_t(total + 1) * 4);
+			zero_async(*this, cg_reads_all.p, size_t(total + 1) * 4); zero_async(*this, cg_reads_req.p, size_t(total + 1) * 4);
+			p.cg_key = cg_key.p; p.cg_mol_begin = cg_mol_begin.p;
+			p.out[0] = cg_n_all.p; p.out[1] = cg_n_req.p; p.out[2] = cg_reads_all.p; p.out[3] = cg_reads_req.p;
+		});
+		// sentinel so that row i owns molecules [cg_mol_begin[i], cg_mol_begin[i+1])
+		HIP_CHECK(hipMemcpyAsync(cg_mol_begin.p + n_cg, &n_mol, 4, hipMemcpyHostToDevice, stream));
+	}
+	// (cell, gene) -> cells
+	{
+		CellGeneToCells p{};
+		p.cg_key = cg_key.p; p.n_all = cg_n_all.p; p.n_req = cg_n_req.p; p.reads_all = cg_reads_all.p;
+		p.gene_bits = layout.gene_bits; p.gene_mask = layout.gene_none;
+		u32 runs = run_segmented_reduce(*this, "cells", p, n_cg, 24 + 4, [&](u32 total) {
+			if (total != n_cells) throw DeviceError("internal: cell runs (" + std::to_string(total) + ") != cells (" +
+			                                        std::to_string(n_cells) + ")");
+			cell_cg_begin.ensure(total + 1); cell_n_genes.ensure(total + 1); cell_req_genes.ensure(total + 1);
+			cell_req_umis.ensure(total + 1); cell_total_umis.ensure(total + 1); cell_total_reads.ensure(total + 1);
+			for (DevBuf<u32> *b : {&cell_n_genes, &cell_req_genes, &cell_req_umis, &cell_total_umis, &cell_total_reads})
+				zero_async(*this, b->p, size_t(total + 1) * 4);
+			p.cell_cg_begin = cell_cg_begin.p;
+			p.out[0] = cell_n_genes.p; p.out[1] = cell_req_genes.p; p.out[2] = cell_req_umis.p;
+			p.out[3] = cell_total_umis.p; p.out[4] = cell_total_reads.p;
+		});
+		(void)runs;
+		HIP_CHECK(hipMemcpyAsync(cell_cg_begin.p + n_cells, &n_cg, 4, hipMemcpyHostToDevice, stream));
+	}
+	HIP_CHECK(hipStreamSynchronize(stream));
+	keys_a.release(); keys_b.release(); vals_a.release(); vals_b.release();
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage: real cells to the host; ordering (CellsDataContainer::update_filtered_gene_counts)
+// ------------------------------------------------------------------------------------------------
+void dropest_ctx::fetch_real_cells() {
+	real.clear(); real_index_of.clear();
+	if (n_cells == 0) return;
+	DevBuf<u32> list; list.alloc(n_cells);
+	scalars.ensure(16);
+	zero_async(*this, scalars.p, 4);
+	timed("flag_real", double(n_cells) * 4, [&] {
+		hipLaunchKernelGGL(flag_real_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, stream, cell_n_genes.p, n_cells,
+		                   min_before, list.p, scalars.p);
+	});
+	u32 count = 0;
+	HIP_CHECK(hipMemcpyAsync(&count, scalars.p, 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	if (count == 0) return;
+	DevBuf<CellRowPod> rows; rows.alloc(count);
+	CellArrays a{cell_cb.p, cell_first.p, cell_n_genes.p, cell_req_genes.p, cell_req_umis.p, cell_total_umis.p, cell_total_reads.p};
+	timed("gather_cell_rows", double(count) * 72, [&] {
+		hipLaunchKernelGGL(gather_cell_rows_kernel, dim3(div_up(count, 256)), dim3(256), 0, stream, a, list.p, 0u, count, rows.p);
+	});
+	std::vector<u32> ids(count);
+	std::vector<CellRowPod> host_rows(count);
+	HIP_CHECK(hipMemcpyAsync(ids.data(), list.p, size_t(count) * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(host_rows.data(), rows.p, size_t(count) * sizeof(CellRowPod), hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	std::vector<u32> order(count);
+	for (u32 i = 0; i < count; ++i) order[i] = i;
+	std::sort(order.begin(), order.end(), [&](u32 x, u32 y) { return ids[x] < ids[y]; });
+	real.resize(count);
+	for (u32 i = 0; i < count; ++i) {
+		HostCell &h = real[i];
+		h.id = ids[order[i]];
+		h.row = host_rows[order[i]];
+		h.barcode = decode_code(h.row.barcode, side);
+		real_index_of.emplace(h.id, i);
+	}
+}
+
+void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
+	// CellsDataContainer.cpp:250-276 with compare_cells :329-344
+	filtered.clear();
+	n_real_now = 0;
+	std::vector<u32> idx;
+	for (u32 i = 0; i < real.size(); ++i) {
+		const HostCell &h = real[i];
+		const bool is_real = !h.merged && !h.excluded && h.row.n_genes >= min_before;
+		if (!is_real) continue;
+		++n_real_now;
+		if (h.row.requested_genes >= genes_threshold) idx.push_back(i);
+	}
+	std::sort(idx.begin(), idx.end(), [&](u32 x, u32 y) {
+		const HostCell &a = real[x], &b = real[y];
+		if (a.row.requested_genes != b.row.requested_genes) return a.row.requested_genes < b.row.requested_genes;
+		if (a.row.requested_umis != b.row.requested_umis) return a.row.requested_umis < b.row.requested_umis;
+		const size_t ua = size_t(a.row.total_umis), ub = size_t(b.row.total_umis);   // Cell::umis_number casts the int stat
+		if (ua != ub) return ua < ub;
+		return a.barcode < b.barcode;
+	});
+	size_t start = 0;
+	if (max_cells > 0 && size_t(max_cells) < idx.size()) start = idx.size() - size_t(max_cells);
+	for (size_t i = start; i < idx.size(); ++i) filtered.push_back(real[idx[i]].id);
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-level stages
+// ------------------------------------------------------------------------------------------------
+void dropest_ctx::run_set_initialized() {
+	if (initialized) throw InvalidError("Container is already initialized");
+	concat_chunks();
+	if (n_reads > 0) {
+		build_cb_table();
+		assign_cell_ids();
+		plan_key_layout();
+		build_keys();
+		reduce_all();
+		fetch_real_cells();
+	}
+	sort_filtered(0, -1);   // update_cell_sizes(query, 0, -1), CellsDataContainer.cpp:168
+	initialized = true;
+	collect_timings();
+}
+
+void dropest_ctx::run_merge_and_filter() {
+	if (!initialized) throw InvalidError("You must initialize container");
+	if (merged) throw InvalidError("merge_and_filter was already run");
+	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES)
+		throw UnsupportedError("RealBarcodes merge is not built yet in this revision");
+	if (ingest.umi_escape_max_plus1 != 0)
+		throw UnsupportedError("UMIs with N (escaped codes) are not handled yet in this revision");
+	sort_filtered(min_after, cfg.max_cells);   // CellsDataContainer.cpp:47-49
+	merged = true;
+	collect_timings();
+}
+
+// ------------------------------------------------------------------------------------------------
+// count matrices
+// ------------------------------------------------------------------------------------------------
+void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, std::vector<u32> &g, std::vector<u32> &c, std::vector<u32> &v) {
+	std::vector<u32> col_cell, col_start;
+	uint64_t nnz = 0;
+	if (filtered_m) {
+		for (uint64_t id : filtered) {
+			const HostCell &h = real[real_index_of.at(u32(id))];
+			col_cell.push_back(h.id); col_start.push_back(u32(nnz)); nnz += h.row.requested_genes;
+		}
+	} else {
+		for (const HostCell &h : real) {
+			if (h.merged || h.excluded || h.row.n_genes < min_before) continue;
+			col_cell.push_back(h.id); col_start.push_back(u32(nnz)); nnz += h.row.n_genes;
+		}
+	}
+	if (nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
+	g.assign(nnz, 0); c.assign(nnz, 0); v.assign(nnz, 0);
+	if (nnz == 0) return;
+	const u32 ncols = u32(col_cell.size());
+	DevBuf<u32> d_cc, d_cs, tg, tc, tv;
+	d_cc.alloc(ncols); d_cs.alloc(ncols); tg.alloc(nnz); tc.alloc(nnz); tv.alloc(nnz);
+	HIP_CHECK(hipMemcpyAsync(d_cc.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemcpyAsync(d_cs.p, col_start.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
+	MatrixArgs a{};
+	a.col_cell = d_cc.p; a.col_start = d_cs.p; a.cell_cg_begin = cell_cg_begin.p; a.cg_key = cg_key.p;
+	a.value = filtered_m ? (reads_output ? cg_reads_req.p : cg_n_req.p) : (reads_output ? cg_reads_all.p : cg_n_all.p);
+	a.gene_mask = layout.gene_none; a.skip_zero = filtered_m ? 1 : 0;
+	a.t_gene = tg.p; a.t_col = tc.p; a.t_val = tv.p;
+	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * 24, [&] {
+		hipLaunchKernelGGL(emit_matrix_kernel, dim3(ncols), dim3(256), 0, stream, a);
+	});
+	HIP_CHECK(hipMemcpyAsync(g.data(), tg.p, nnz * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(c.data(), tc.p, nnz * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(v.data(), tv.p, nnz * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	collect_timings();
+}
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+extern "C" {
+
+const char *dropest_last_error(void) { return g_last_error.c_str(); }
+
+void dropest_cfg_defaults(dropest_cfg *cfg) {
+	std::memset(cfg, 0, sizeof(*cfg));
+	cfg->device = 0;
+	cfg->merge_kind = DROPEST_MERGE_NONE;
+	cfg->barcodes_kind = DROPEST_BARCODES_INDROP;   // MergeStrategyFactory.cpp:32 default "indrop"
+	cfg->barcodes_file = nullptr;
+	cfg->min_genes_before_merge = 10;
+	cfg->min_genes_after_merge = 10;
+	cfg->min_merge_fraction = 0.2;
+	cfg->max_cb_merge_edit_distance = 2;
+	cfg->umi_merge_kind = DROPEST_UMI_MERGE_SIMPLE;
+	cfg->max_umi_merge_edit_distance = 1;
+	cfg->gene_match_levels = "eEBA";
+	cfg->max_cells = -1;
+	cfg->cb_table_capacity = 0;
+}
+
+dropest_status dropest_ctx_create(const dropest_cfg *cfg, dropest_ctx **out) {
+	if (!cfg || !out) { g_last_error = "null argument"; return DROPEST_ERR_INVALID; }
+	*out = nullptr;
+	return guarded([&] {
+		std::unique_ptr<dropest_ctx> c(new dropest_ctx());
+		c->init_from_cfg(*cfg);
+		*out = c.release();
+	});
+}
+
+void dropest_ctx_destroy(dropest_ctx *ctx) {
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->cfg.device);
+	delete ctx;
+}
+
+dropest_status dropest_set_side_strings(dropest_ctx *ctx, const char *const *strings, uint64_t n) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		if (n < ctx->side.size()) throw InvalidError("the side-string table may only grow");
+		for (uint64_t i = ctx->side.size(); i < n; ++i) ctx->side.emplace_back(strings[i]);
+	});
+}
+
+static void push_common(dropest_ctx *ctx, uint64_t n) {
+	if (!ctx) throw InvalidError("null context");
+	if (ctx->initialized) throw InvalidError("Container is already initialized");   // CellsDataContainer.cpp:61-62
+	if (ctx->d_cb) throw InvalidError("reads were already frozen by a previous set_initialized");
+	if (ctx->n_reads + n >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads in one context (shard across GPUs)");
+	HIP_CHECK(hipSetDevice(ctx->cfg.device));
+}
+
+dropest_status dropest_push_reads(dropest_ctx *ctx, const uint64_t *cb, const uint64_t *umi, const uint32_t *gene,
+                                  const uint32_t *aux, uint64_t n) {
+	return guarded([&] {
+		push_common(ctx, n);
+		if (n == 0) return;
+		if (!cb || !umi || !gene || !aux) throw InvalidError("null read array");
+		ReadChunk c;
+		c.cb.alloc(n); c.umi.alloc(n); c.gene.alloc(n); c.aux.alloc(n);
+		HIP_CHECK(hipMemcpyAsync(c.cb.p, cb, n * 8, hipMemcpyHostToDevice, ctx->stream));
+		HIP_CHECK(hipMemcpyAsync(c.umi.p, umi, n * 8, hipMemcpyHostToDevice, ctx->stream));
+		HIP_CHECK(hipMemcpyAsync(c.gene.p, gene, n * 4, hipMemcpyHostToDevice, ctx->stream));
+		HIP_CHECK(hipMemcpyAsync(c.aux.p, aux, n * 4, hipMemcpyHostToDevice, ctx->stream));
+		HIP_CHECK(hipStreamSynchronize(ctx->stream));   // caller keeps ownership of the host arrays
+		c.p_cb = c.cb.p; c.p_umi = c.umi.p; c.p_gene = c.gene.p; c.p_aux = c.aux.p; c.n = n;
+		ctx->chunks.push_back(std::move(c));
+		ctx->n_reads += n;
+	});
+}
+
+dropest_status dropest_push_reads_device(dropest_ctx *ctx, const uint64_t *d_cb, const uint64_t *d_umi,
+                                         const uint32_t *d_gene, const uint32_t *d_aux, uint64_t n, int adopt) {
+	return guarded([&] {
+		push_common(ctx, n);
+		if (n == 0) return;
+		if (!d_cb || !d_umi || !d_gene || !d_aux) throw InvalidError("null read array");
+		ReadChunk c;
+		c.n = n;
+		if (adopt) {
+			c.p_cb = reinterpret_cast<const u64 *>(d_cb); c.p_umi = reinterpret_cast<const u64 *>(d_umi);
+			c.p_gene = d_gene; c.p_aux = d_aux;
+		} else {
+			c.cb.alloc(n); c.umi.alloc(n); c.gene.alloc(n); c.aux.alloc(n);
+			HIP_CHECK(hipMemcpyAsync(c.cb.p, d_cb, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+			HIP_CHECK(hipMemcpyAsync(c.umi.p, d_umi, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+			HIP_CHECK(hipMemcpyAsync(c.gene.p, d_gene, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+			HIP_CHECK(hipMemcpyAsync(c.aux.p, d_aux, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+			HIP_CHECK(hipStreamSynchronize(ctx->stream));
+			c.p_cb = c.cb.p; c.p_umi = c.umi.p; c.p_gene = c.gene.p; c.p_aux = c.aux.p;
+		}
+		ctx->chunks.push_back(std::move(c));
+		ctx->n_reads += n;
+	});
+}
+
+dropest_status dropest_set_initialized(dropest_ctx *ctx) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		ctx->run_set_initialized();
+	});
+}
+
+dropest_status dropest_merge_and_filter(dropest_ctx *ctx) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		ctx->run_merge_and_filter();
+	});
+}
+
+dropest_status dropest_reset_results(dropest_ctx *ctx) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		ctx->free_results();
+	});
+}
+
+static void need_init(dropest_ctx *ctx) {
+	if (!ctx) throw InvalidError("null context");
+	if (!ctx->initialized) throw InvalidError("You must initialize container");
+	HIP_CHECK(hipSetDevice(ctx->cfg.device));
+}
+
+dropest_status dropest_total_cells(dropest_ctx *ctx, uint64_t *n) {
+	return guarded([&] { need_init(ctx); *n = ctx->n_cells; });
+}
+dropest_status dropest_real_cells(dropest_ctx *ctx, uint64_t *n) {
+	return guarded([&] { need_init(ctx); *n = ctx->n_real_now; });
+}
+
+dropest_status dropest_cell_rows(dropest_ctx *ctx, uint64_t first, uint64_t count, dropest_cell_row *out) {
+	static_assert(sizeof(dropest_cell_row) == sizeof(CellRowPod), "row layout");
+	return guarded([&] {
+		need_init(ctx);
+		if (first + count > ctx->n_cells) throw RangeError("cell index out of range");
+		if (count == 0) return;
+		DevBuf<CellRowPod> rows; rows.alloc(count);
+		CellArrays a{ctx->cell_cb.p, ctx->cell_first.p, ctx->cell_n_genes.p, ctx->cell_req_genes.p, ctx->cell_req_umis.p,
+		             ctx->cell_total_umis.p, ctx->cell_total_reads.p};
+		hipLaunchKernelGGL(gather_cell_rows_kernel, dim3(div_up(count, 256)), dim3(256), 0, ctx->stream, a,
+		                   static_cast<const u32 *>(nullptr), u32(first), u32(count), rows.p);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipMemcpyAsync(out, rows.p, count * sizeof(CellRowPod), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		for (uint64_t j = 0; j < count; ++j) {   // overlay the host-tracked state of real-candidate cells
+			auto it = ctx->real_index_of.find(u32(first + j));
+			if (it == ctx->real_index_of.end()) continue;
+			const HostCell &h = ctx->real[it->second];
+			dropest_cell_row &r = out[j];
+			r.n_genes = h.row.n_genes; r.requested_genes = h.row.requested_genes; r.requested_umis = h.row.requested_umis;
+			r.total_reads = h.row.total_reads; r.total_umis = h.row.total_umis;
+			r.is_merged = h.merged; r.is_excluded = h.excluded;
+			r.is_real = !h.merged && !h.excluded && h.row.n_genes >= ctx->min_before;
+		}
+	});
+}
+
+dropest_status dropest_cell_id_by_cb(dropest_ctx *ctx, uint64_t barcode, int64_t *id) {
+	return guarded([&] {
+		need_init(ctx);
+		*id = -1;
+		if (ctx->n_cells == 0) return;
+		// host-side probe of the device table (a handful of 8-byte reads)
+		uint64_t h = mix64(barcode) & ctx->table.mask;
+		for (u32 probe = 0; probe < CB_MAX_PROBE; ++probe) {
+			u64 k = 0;
+			HIP_CHECK(hipMemcpy(&k, ctx->table.keys + h, 8, hipMemcpyDeviceToHost));
+			if (k == barcode) { u32 c = 0; HIP_CHECK(hipMemcpy(&c, ctx->table.cell_id + h, 4, hipMemcpyDeviceToHost)); *id = c; return; }
+			if (k == 0) return;
+			h = (h + 1) & ctx->table.mask;
+		}
+	});
+}
+
+dropest_status dropest_filtered_cells(dropest_ctx *ctx, uint64_t *n, uint64_t *ids) {
+	return guarded([&] {
+		need_init(ctx);
+		*n = ctx->filtered.size();
+		if (ids) std::copy(ctx->filtered.begin(), ctx->filtered.end(), ids);
+	});
+}
+
+dropest_status dropest_merge_targets(dropest_ctx *ctx, uint64_t *n, uint64_t *src, uint64_t *tgt) {
+	return guarded([&] {
+		need_init(ctx);
+		if (!ctx->merged) throw InvalidError("merge_and_filter has not run");
+		*n = ctx->merge_pairs.size();
+		if (src && tgt)
+			for (size_t i = 0; i < ctx->merge_pairs.size(); ++i) { src[i] = ctx->merge_pairs[i].first; tgt[i] = ctx->merge_pairs[i].second; }
+	});
+}
+
+dropest_status dropest_global_counters(dropest_ctx *ctx, uint64_t out[4]) {
+	return guarded([&] {
+		need_init(ctx);
+		out[0] = ctx->counters.intergenic; out[1] = ctx->counters.exon; out[2] = ctx->counters.intron;
+		out[3] = ctx->counters.not_annotated;
+	});
+}
+
+static void fetch_molecule_range(dropest_ctx *ctx, u32 mb, u32 me, std::vector<u64> &k, std::vector<u32> &r, std::vector<u32> &m) {
+	const u32 cnt = me - mb;
+	k.resize(cnt); r.resize(cnt); m.resize(cnt);
+	if (!cnt) return;
+	HIP_CHECK(hipMemcpyAsync(k.data(), ctx->mol_key.p + mb, size_t(cnt) * 8, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_CHECK(hipMemcpyAsync(r.data(), ctx->mol_reads.p + mb, size_t(cnt) * 4, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_CHECK(hipMemcpyAsync(m.data(), ctx->mol_mark.p + mb, size_t(cnt) * 4, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+}
+
+dropest_status dropest_molecules(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, uint32_t *gene, uint64_t *umi,
+                                 uint32_t *reads, uint8_t *mark) {
+	return guarded([&] {
+		need_init(ctx);
+		std::vector<u64> k; std::vector<u32> r, m;
+		fetch_molecule_range(ctx, 0, ctx->n_mol, k, r, m);
+		const KeyLayout &L = ctx->layout;
+		const u64 umask = L.umi_bits ? ((1ull << L.umi_bits) - 1ull) : 0ull;
+		uint64_t cnt = 0;
+		for (size_t i = 0; i < k.size(); ++i) {
+			const u64 g = (k[i] >> L.umi_bits) & L.gene_none;
+			if (g == L.gene_none) continue;   // reads without a gene never form molecules
+			if (cell) {
+				cell[cnt] = u32(k[i] >> (L.umi_bits + L.gene_bits)); gene[cnt] = u32(g);
+				umi[cnt] = ctx->unmap_umi(k[i] & umask); reads[cnt] = r[i]; mark[cnt] = uint8_t(m[i]);
+			}
+			++cnt;
+		}
+		*n = cnt;
+	});
+}
+
+dropest_status dropest_cell_molecules(dropest_ctx *ctx, uint64_t cell_id, uint64_t *n, uint32_t *gene, uint64_t *umi,
+                                      uint32_t *reads, uint8_t *mark) {
+	return guarded([&] {
+		need_init(ctx);
+		if (cell_id >= ctx->n_cells) throw RangeError("cell index out of range");
+		u32 cgb[2], mb = 0, me = 0;
+		HIP_CHECK(hipMemcpy(cgb, ctx->cell_cg_begin.p + cell_id, 8, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(&mb, ctx->cg_mol_begin.p + cgb[0], 4, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(&me, ctx->cg_mol_begin.p + cgb[1], 4, hipMemcpyDeviceToHost));
+		std::vector<u64> k; std::vector<u32> r, m;
+		fetch_molecule_range(ctx, mb, me, k, r, m);
+		const KeyLayout &L = ctx->layout;
+		const u64 umask = L.umi_bits ? ((1ull << L.umi_bits) - 1ull) : 0ull;
+		uint64_t cnt = 0;
+		for (size_t i = 0; i < k.size(); ++i) {
+			const u64 g = (k[i] >> L.umi_bits) & L.gene_none;
+			if (g == L.gene_none) continue;
+			if (gene) { gene[cnt] = u32(g); umi[cnt] = ctx->unmap_umi(k[i] & umask); reads[cnt] = r[i]; mark[cnt] = uint8_t(m[i]); }
+			++cnt;
+		}
+		*n = cnt;
+	});
+}
+
+dropest_status dropest_count_matrix(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *nnz, uint32_t *gene,
+                                    uint32_t *col, uint32_t *val) {
+	return guarded([&] {
+		need_init(ctx);
+		std::vector<u32> g, c, v;
+		ctx->emit_matrix(filtered != 0, reads_output != 0, g, c, v);
+		*nnz = g.size();
+		if (gene && col && val) {
+			std::copy(g.begin(), g.end(), gene); std::copy(c.begin(), c.end(), col); std::copy(v.begin(), v.end(), val);
+		}
+	});
+}
+
+dropest_status dropest_chr_stats(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, uint32_t *kind, uint32_t *chr, int32_t *count) {
+	return guarded([&] {
+		need_init(ctx);
+		*n = 0;
+		// real cells now, and the cell -> real index map (merged sources fold into their targets)
+		std::vector<u32> real_ids;
+		std::vector<u32> map(ctx->n_cells, 0xFFFFFFFFu);
+		for (const HostCell &h : ctx->real)
+			if (!h.merged && !h.excluded && h.row.n_genes >= ctx->min_before) { map[h.id] = u32(real_ids.size()); real_ids.push_back(h.id); }
+		for (auto &p : ctx->merge_pairs) map[p.first] = map[p.second];
+		if (real_ids.empty() || ctx->n_chr_rows == 0) return;
+		// number of chromosomes = 1 + max chr id seen in the partial rows
+		std::vector<u64> keys(ctx->n_chr_rows);
+		HIP_CHECK(hipMemcpy(keys.data(), ctx->chr_row_key.p, size_t(ctx->n_chr_rows) * 8, hipMemcpyDeviceToHost));
+		u32 n_chr = 0;
+		for (u64 k : keys) n_chr = std::max(n_chr, u32(k & 0xFFFF) + 1);
+		const size_t cells_n = real_ids.size(), tab = cells_n * 3 * n_chr;
+		if (tab > (size_t(1) << 30)) throw UnsupportedError("per-chromosome table too large for the dense path");
+		DevBuf<u32> d_map, d_tab;
+		d_map.alloc(ctx->n_cells); d_tab.alloc(tab);
+		HIP_CHECK(hipMemcpyAsync(d_map.p, map.data(), size_t(ctx->n_cells) * 4, hipMemcpyHostToDevice, ctx->stream));
+		HIP_CHECK(hipMemsetAsync(d_tab.p, 0, tab * 4, ctx->stream));
+		hipLaunchKernelGGL(chr_accumulate_kernel, dim3(div_up(ctx->n_chr_rows, 256)), dim3(256), 0, ctx->stream,
+		                   ctx->chr_row_key.p, ctx->chr_exon.p, ctx->chr_intron.p, ctx->chr_inter.p, ctx->n_chr_rows, d_map.p,
+		                   n_chr, d_tab.p);
+		HIP_CHECK(hipGetLastError());
+		std::vector<u32> t(tab);
+		HIP_CHECK(hipMemcpyAsync(t.data(), d_tab.p, tab * 4, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		uint64_t cnt = 0;
+		for (size_t ci = 0; ci < cells_n; ++ci)
+			for (u32 k = 0; k < 3; ++k)
+				for (u32 ch = 0; ch < n_chr; ++ch) {
+					u32 v = t[(ci * 3 + k) * n_chr + ch];
+					if (!v) continue;
+					if (cell) { cell[cnt] = real_ids[ci]; kind[cnt] = k; chr[cnt] = ch; count[cnt] = int32_t(v); }
+					++cnt;
+				}
+		*n = cnt;
+	});
+}
+
+dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *target) {
+	return guarded([&] {
+		need_init(ctx);
+		(void)cell; (void)target;
+		throw UnsupportedError("RealBarcodes merge is not built yet in this revision");
+	});
+}
+
+dropest_status dropest_kernel_stats(dropest_ctx *ctx, uint32_t *n, dropest_kernel_stat *out) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		ctx->collect_timings();
+		u32 i = 0;
+		for (auto &kv : ctx->stats) {
+			if (out) { out[i].name = kv.first.c_str(); out[i].launches = kv.second.launches; out[i].ms = kv.second.ms; out[i].bytes = kv.second.bytes; }
+			++i;
+		}
+		*n = i;
+	});
+}
+
+dropest_status dropest_set_profiling(dropest_ctx *ctx, int enabled) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		ctx->collect_timings();
+		ctx->profiling = enabled != 0;
+		if (enabled) ctx->stats.clear();
+	});
+}
+
+void *dropest_stream(dropest_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
+
+}  // extern "C"

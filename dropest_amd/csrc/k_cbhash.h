@@ -1,0 +1,149 @@
+// k_cbhash.h -- cell-barcode table: open-addressed hash build, first-seen ordinals, first-seen cell ids.
+//
+// Replaces the per-read `_cell_ids_by_cb.emplace(cb, size)` of CellsDataContainer::add_record
+// (Estimation/CellsDataContainer.cpp:64-69): cell id = rank of the barcode's first occurrence in stream
+// order, including reads without a gene.  On the device that is
+//   (1) insert every barcode into an open-addressed table and atomicMin the read ordinal per slot,
+//   (2) flag the reads that ARE their barcode's first occurrence and prefix-sum the flags: the exclusive
+//       prefix at a first occurrence is exactly the first-seen rank.
+// Integer/HBM-latency work, no MFMA.  Table keys: 0 = empty (packed codes always carry a sentinel bit).
+#pragma once
+
+#include "util.h"
+
+namespace dropest {
+
+struct CbTable {
+	unsigned long long *keys;   // [capacity] packed barcode, 0 = empty
+	uint32_t *first;            // [capacity] min read ordinal, 0xFFFFFFFF = unset
+	uint32_t *cell_id;          // [capacity] first-seen rank (filled by assign_cell_ids)
+	uint64_t mask;              // capacity - 1
+};
+
+// Statistics gathered while streaming the reads once (sizes the sort key; see pipeline).
+struct IngestStats {
+	unsigned long long umi_clean_min, umi_clean_max;   // over non-escaped UMI codes
+	unsigned long long umi_escape_max_plus1;           // 1 + max escape id among UMIs, 0 if none
+	unsigned long long cb_escape_count;                // number of reads with an escaped barcode
+	unsigned int gene_max_plus1;                       // 1 + max gene id, 0 if no read has a gene
+	unsigned int overflow;                             // probe chain exceeded the limit -> grow & retry
+};
+
+constexpr uint32_t CB_MAX_PROBE = 8192;
+constexpr uint64_t ESCAPE_BIT = 0x8000000000000000ull;
+constexpr uint32_t NO_GENE = 0xFFFFFFFFu;
+
+__device__ inline uint32_t cb_find_or_insert(const CbTable &t, unsigned long long k, bool &ok) {
+	uint64_t h = mix64(k) & t.mask;
+	for (uint32_t probe = 0; probe < CB_MAX_PROBE; ++probe) {
+		// Plain load as a hint: a slot only ever goes 0 -> key, so a stale 0 merely sends us to the CAS,
+		// whose return value is authoritative.
+		unsigned long long cur = t.keys[h];
+		if (cur == k) return uint32_t(h);
+		if (cur == 0ull) {
+			unsigned long long prev = atomicCAS(&t.keys[h], 0ull, k);
+			if (prev == 0ull || prev == k) return uint32_t(h);
+		}
+		h = (h + 1) & t.mask;
+	}
+	ok = false;
+	return 0;
+}
+
+__device__ inline uint32_t cb_find(const CbTable &t, unsigned long long k) {   // 0xFFFFFFFF if absent
+	uint64_t h = mix64(k) & t.mask;
+	for (uint32_t probe = 0; probe < CB_MAX_PROBE; ++probe) {
+		unsigned long long cur = t.keys[h];
+		if (cur == k) return uint32_t(h);
+		if (cur == 0ull) return 0xFFFFFFFFu;
+		h = (h + 1) & t.mask;
+	}
+	return 0xFFFFFFFFu;
+}
+
+// One pass over (cb, umi, gene): table insert + first ordinal + ingest statistics.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long long *__restrict__ cb,
+                                                            const unsigned long long *__restrict__ umi,
+                                                            const uint32_t *__restrict__ gene, uint32_t n, CbTable t,
+                                                            uint32_t *__restrict__ slot_out, IngestStats *stats) {
+	unsigned long long umin = ~0ull, umax = 0ull, uesc = 0ull, cbesc = 0ull;
+	uint32_t gmax = 0;
+	bool ok = true;
+	const uint32_t stride = gridDim.x * THREADS;
+	for (uint32_t r = blockIdx.x * THREADS + threadIdx.x; r < n; r += stride) {
+		const unsigned long long k = cb[r];
+		const uint32_t s = cb_find_or_insert(t, k, ok);
+		slot_out[r] = s;
+		// stale (too large) values of first[] only cost an extra atomic; values never grow
+		if (r < t.first[s]) atomicMin(&t.first[s], r);
+		const unsigned long long u = umi[r];
+		if (u & ESCAPE_BIT) { unsigned long long id1 = (u & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
+		else { umin = u < umin ? u : umin; umax = u > umax ? u : umax; }
+		if (k & ESCAPE_BIT) ++cbesc;
+		const uint32_t g = gene[r];
+		if (g != NO_GENE && g + 1 > gmax) gmax = g + 1;
+	}
+	umin = wave_reduce_min_u64(umin); umax = wave_reduce_max_u64(umax); uesc = wave_reduce_max_u64(uesc);
+	cbesc = wave_reduce_add_u64(cbesc);
+	unsigned long long g64 = wave_reduce_max_u64(gmax);
+	unsigned long long bad = wave_reduce_max_u64(ok ? 0ull : 1ull);
+	if (lane_id() == 0) {
+		if (umin != ~0ull) atomicMin(&stats->umi_clean_min, umin);
+		if (umax != 0ull) atomicMax(&stats->umi_clean_max, umax);
+		if (uesc) atomicMax(&stats->umi_escape_max_plus1, uesc);
+		if (cbesc) atomicAdd(&stats->cb_escape_count, cbesc);
+		if (g64) atomicMax(&stats->gene_max_plus1, uint32_t(g64));
+		if (bad) atomicMax(&stats->overflow, 1u);
+	}
+}
+
+// first-occurrence flags -> per-tile counts
+constexpr int CID_THREADS = 256, CID_ITEMS = 8, CID_TILE = CID_THREADS * CID_ITEMS;
+
+__global__ __launch_bounds__(CID_THREADS) void cb_first_count_kernel(const uint32_t *__restrict__ slot, uint32_t n,
+                                                                     CbTable t, uint32_t *__restrict__ tile_counts) {
+	__shared__ uint32_t scratch[CID_THREADS / 64 + 1];
+	const uint32_t base = blockIdx.x * CID_TILE;
+	uint32_t c = 0;
+#pragma unroll
+	for (int j = 0; j < CID_ITEMS; ++j) {
+		uint32_t r = base + j * CID_THREADS + threadIdx.x;
+		if (r < n) c += (t.first[slot[r]] == r);
+	}
+	uint32_t total;
+	block_excl_scan_u32<CID_THREADS>(c, scratch, total);
+	if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+
+// assigns cell ids (= exclusive prefix over first-occurrence flags) and fills the per-cell header arrays
+__global__ __launch_bounds__(CID_THREADS) void cb_assign_ids_kernel(const unsigned long long *__restrict__ cb,
+                                                                    const uint32_t *__restrict__ slot, uint32_t n,
+                                                                    CbTable t, const uint32_t *__restrict__ tile_prefix,
+                                                                    unsigned long long *__restrict__ cell_cb,
+                                                                    uint32_t *__restrict__ cell_first) {
+	__shared__ uint32_t scratch[CID_THREADS / 64 + 1];
+	const uint32_t base = blockIdx.x * CID_TILE;
+	// blocked arrangement so that ranks follow read order
+	uint32_t flags = 0, c = 0;
+	const uint32_t r0 = base + threadIdx.x * CID_ITEMS;
+#pragma unroll
+	for (int j = 0; j < CID_ITEMS; ++j) {
+		uint32_t r = r0 + j;
+		if (r < n && t.first[slot[r]] == r) { flags |= 1u << j; ++c; }
+	}
+	uint32_t total;
+	uint32_t id = tile_prefix[blockIdx.x] + block_excl_scan_u32<CID_THREADS>(c, scratch, total);
+#pragma unroll
+	for (int j = 0; j < CID_ITEMS; ++j) {
+		if (flags & (1u << j)) {
+			uint32_t r = r0 + j;
+			t.cell_id[slot[r]] = id;
+			cell_cb[id] = cb[r];
+			cell_first[id] = r;
+			++id;
+		}
+	}
+}
+
+}  // namespace dropest

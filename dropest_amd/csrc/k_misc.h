@@ -1,0 +1,188 @@
+// k_misc.h -- key construction, single-block scan, count-matrix emission, per-chromosome accumulation.
+#pragma once
+
+#include "k_cbhash.h"
+#include "util.h"
+
+namespace dropest {
+
+// ---- exclusive scan of a short u32 array by ONE block (tile counts: N/2048 entries) ----
+__global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                          uint32_t n, uint32_t *__restrict__ total_out) {
+	__shared__ uint32_t scratch[1024 / 64 + 1];
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < n; base += 1024) {
+		uint32_t i = base + threadIdx.x;
+		uint32_t v = i < n ? in[i] : 0;
+		uint32_t total;
+		uint32_t ex = block_excl_scan_u32<1024>(v, scratch, total);
+		if (i < n) out[i] = carry + ex;
+		carry += total;
+	}
+	if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+// ---- sort-key construction -------------------------------------------------------------------------
+// key = cell_id << (gene_bits + umi_bits) | gene_code << umi_bits | umi_code, value = chr | mark << 16.
+// gene_code of a read without a gene = all ones in gene_bits (sorts last inside its cell); such reads
+// carry umi_code 0 (they never enter a Gene, CellsDataContainer.cpp:73-78).
+struct KeyLayout {
+	int umi_bits, gene_bits, cell_bits;
+	unsigned long long umi_strip_mask;   // applied to clean UMI codes (drops the sentinel when all lengths agree)
+	unsigned long long umi_escape_base;  // escaped UMI k -> umi_escape_base + k
+	unsigned long long gene_none;        // (1 << gene_bits) - 1
+};
+
+struct GlobalCounters {   // CellsDataContainer.cpp:73-78, :309-327
+	unsigned long long intergenic, exon, intron, not_annotated;
+	unsigned long long key_or, key_and;
+};
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long long *__restrict__ umi,
+                                                             const uint32_t *__restrict__ gene,
+                                                             const uint32_t *__restrict__ aux,
+                                                             const uint32_t *__restrict__ slot, uint32_t n, CbTable t,
+                                                             KeyLayout L, unsigned long long *__restrict__ keys,
+                                                             uint32_t *__restrict__ vals, GlobalCounters *gc) {
+	unsigned long long c_inter = 0, c_exon = 0, c_intron = 0, c_na = 0, k_or = 0, k_and = ~0ull;
+	const uint32_t stride = gridDim.x * THREADS;
+	for (uint32_t r = blockIdx.x * THREADS + threadIdx.x; r < n; r += stride) {
+		const unsigned long long cell = t.cell_id[slot[r]];
+		const uint32_t g = gene[r];
+		const uint32_t a = aux[r];
+		const uint32_t mark = (a >> 16) & 0xFFu;
+		unsigned long long gcode, ucode;
+		if (g == NO_GENE) {
+			gcode = L.gene_none; ucode = 0; ++c_inter;
+		} else {
+			gcode = g;
+			const unsigned long long u = umi[r];
+			ucode = (u & ESCAPE_BIT) ? (L.umi_escape_base + (u & ~ESCAPE_BIT)) : (u & L.umi_strip_mask);
+			c_exon += (mark >> 1) & 1u; c_intron += (mark >> 2) & 1u; c_na += mark & 1u;
+		}
+		const unsigned long long k = (cell << (L.gene_bits + L.umi_bits)) | (gcode << L.umi_bits) | ucode;
+		keys[r] = k;
+		vals[r] = a & 0x00FFFFFFu;
+		k_or |= k; k_and &= k;
+	}
+	c_inter = wave_reduce_add_u64(c_inter); c_exon = wave_reduce_add_u64(c_exon);
+	c_intron = wave_reduce_add_u64(c_intron); c_na = wave_reduce_add_u64(c_na);
+	k_or = wave_reduce_or_u64(k_or); k_and = wave_reduce_and_u64(k_and);
+	if (lane_id() == 0) {
+		if (c_inter) atomicAdd(&gc->intergenic, c_inter);
+		if (c_exon) atomicAdd(&gc->exon, c_exon);
+		if (c_intron) atomicAdd(&gc->intron, c_intron);
+		if (c_na) atomicAdd(&gc->not_annotated, c_na);
+		atomicOr(&gc->key_or, k_or);
+		atomicAnd(&gc->key_and, k_and);
+	}
+}
+
+// ---- real cells: Cell::is_real before any merge (Cell.cpp:125-128) -> compacted id list --------------
+__global__ __launch_bounds__(256) void flag_real_kernel(const uint32_t *__restrict__ n_genes, uint32_t n_cells,
+                                                        uint32_t min_genes, uint32_t *__restrict__ real_list,
+                                                        uint32_t *__restrict__ real_count) {
+	// order of the list is irrelevant (the host sorts); one atomic per wave
+	uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	bool real = i < n_cells && n_genes[i] >= min_genes;
+	unsigned long long m = __ballot(real);
+	uint32_t base = 0;
+	if (lane_id() == 0 && m) base = atomicAdd(real_count, uint32_t(__popcll(m)));
+	base = __shfl(base, 0, 64);
+	if (real) real_list[base + __popcll(m & ((1ull << lane_id()) - 1ull))] = i;
+}
+
+// gathers the per-cell header + size rows of a list of cells (device -> staging for one D2H copy)
+struct CellArrays {
+	const unsigned long long *cb;
+	const uint32_t *first, *n_genes, *req_genes, *req_umis, *total_umis, *total_reads;
+};
+struct CellRowPod {   // == dropest_cell_row (include/dropest_amd.h)
+	unsigned long long barcode;
+	uint32_t first_read, n_genes, requested_genes, requested_umis;
+	int32_t total_reads, total_umis;
+	uint8_t is_merged, is_excluded, is_real, pad;
+};
+__global__ __launch_bounds__(256) void gather_cell_rows_kernel(CellArrays a, const uint32_t *__restrict__ ids,
+                                                               uint32_t first_id, uint32_t count,
+                                                               CellRowPod *__restrict__ out) {
+	uint32_t j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= count) return;
+	uint32_t i = ids ? ids[j] : first_id + j;
+	CellRowPod r;
+	r.barcode = a.cb[i]; r.first_read = a.first[i]; r.n_genes = a.n_genes[i]; r.requested_genes = a.req_genes[i];
+	r.requested_umis = a.req_umis[i]; r.total_reads = int32_t(a.total_reads[i]); r.total_umis = int32_t(a.total_umis[i]);
+	r.is_merged = r.is_excluded = r.is_real = r.pad = 0;
+	out[j] = r;
+}
+
+// ---- count matrix (ResultsPrinter::get_count_matrix_filtered / _raw, ResultsPrinter.cpp:334-396) -------
+// One block per matrix column.  The column's cell owns the contiguous (cell, gene) rows
+// [cg_begin[cell], cg_begin[cell+1]); rows are already gene-ascending.  `col_start` is the exclusive
+// prefix of the per-column non-zero counts (requested_genes resp. n_genes), computed by the caller.
+struct MatrixArgs {
+	const uint32_t *col_cell;       // [ncols] cell id of each column
+	const uint32_t *col_start;      // [ncols] first triplet of the column
+	const uint32_t *cell_cg_begin;  // [n_cells + 1]
+	const unsigned long long *cg_key;
+	const uint32_t *value;          // per (cell, gene) row: n_req | reads_req | n_all | reads_all
+	unsigned long long gene_mask;
+	int skip_zero;                  // filtered matrix omits zero entries (Cell.cpp:59-62)
+	uint32_t *t_gene, *t_col, *t_val;
+};
+__global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
+	__shared__ uint32_t scratch[256 / 64 + 1];
+	const uint32_t col = blockIdx.x;
+	const uint32_t cell = a.col_cell[col];
+	const uint32_t b = a.cell_cg_begin[cell], e = a.cell_cg_begin[cell + 1];
+	uint32_t out = a.col_start[col];
+	for (uint32_t base = b; base < e; base += 256) {
+		const uint32_t i = base + threadIdx.x;
+		bool keep = false;
+		uint32_t g = 0, v = 0;
+		if (i < e) {
+			g = uint32_t(a.cg_key[i] & a.gene_mask);
+			v = a.value[i];
+			keep = (a.cg_key[i] & a.gene_mask) != a.gene_mask && !(a.skip_zero && v == 0);
+		}
+		uint32_t total;
+		const uint32_t ex = block_excl_scan_u32<256>(keep ? 1u : 0u, scratch, total);
+		if (keep) { a.t_gene[out + ex] = g; a.t_col[out + ex] = col; a.t_val[out + ex] = v; }
+		out += total;
+	}
+}
+
+// ---- per-chromosome counters of real cells -------------------------------------------------------------
+// partial rows (cell << 16 | chr ; exon, intron, intergenic) are folded into a dense
+// [n_real][3][n_chr] table through the cell -> (merged) real-cell index map; rows are pre-aggregated per
+// run of equal (cell, chr), so the atomics are few and mostly to distinct addresses.
+__global__ __launch_bounds__(256) void chr_accumulate_kernel(const unsigned long long *__restrict__ row_key,
+                                                             const uint32_t *__restrict__ exon,
+                                                             const uint32_t *__restrict__ intron,
+                                                             const uint32_t *__restrict__ intergenic, uint32_t n_rows,
+                                                             const uint32_t *__restrict__ real_index /* [n_cells] */,
+                                                             uint32_t n_chr, uint32_t *__restrict__ table) {
+	uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_rows) return;
+	const unsigned long long k = row_key[i];
+	const uint32_t ri = real_index[uint32_t(k >> 16)];
+	if (ri == 0xFFFFFFFFu) return;
+	const uint32_t chr = uint32_t(k & 0xFFFFu);
+	uint32_t *base = table + size_t(ri) * 3 * n_chr;
+	if (exon[i]) atomicAdd(base + chr, exon[i]);
+	if (intron[i]) atomicAdd(base + n_chr + chr, intron[i]);
+	if (intergenic[i]) atomicAdd(base + 2 * n_chr + chr, intergenic[i]);
+}
+
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *p, uint32_t v, size_t n) {
+	size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+	if (i < n) p[i] = v;
+}
+__global__ __launch_bounds__(256) void scatter_index_kernel(const uint32_t *__restrict__ ids, uint32_t n,
+                                                            uint32_t *__restrict__ map) {
+	uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) map[ids[i]] = i;
+}
+
+}  // namespace dropest

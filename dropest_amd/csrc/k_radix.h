@@ -1,0 +1,172 @@
+// k_radix.h -- LSD radix sort of (u64 key, u32 value) records, 8-bit digits, hand-written for gfx950.
+//
+// This is the "radix partition" of the UMI de-duplication: records keyed (cell id | gene | UMI) are brought
+// into key order so that molecules, (cell, gene) groups and cells become contiguous runs (k_segreduce.h
+// then reduces the runs).  It replaces the per-read red-black-tree descents of the reference
+// (Cell::genes().emplace / Gene::_umis.emplace, Estimation/CellsDataContainer.cpp:356-364, Gene.cpp:17-24).
+//
+// Per pass, three launches on one stream:
+//   rs_hist     one histogram PER BLOCK (each block owns a contiguous range of tiles), 8 B/record read
+//   rs_scan     row-wise exclusive scan of the [256][blocks] histogram + scan of the 256 digit totals
+//   rs_scatter  each block walks its tiles carrying 256 running output cursors in LDS:
+//               wave-level multisplit by ballot (8 ballots per key, 64-lane waves), ranks combined over
+//               waves through LDS, keys re-ordered by digit in an LDS tile so that the global writes of
+//               one digit are contiguous, then written out; 12 B read + 12 B written per record
+// HBM-bound integer work; no MFMA.  The sort is stable (required between LSD passes).
+#pragma once
+
+#include "util.h"
+
+namespace dropest {
+
+constexpr int RS_THREADS = 512;
+constexpr int RS_ITEMS = 8;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;   // 4096 records per tile
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_RADIX = 256;
+
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const unsigned long long *__restrict__ keys, uint32_t n,
+                                                             int shift, uint32_t tiles_per_block,
+                                                             uint32_t *__restrict__ hist /* [256][gridDim.x] */) {
+	__shared__ uint32_t h[RS_WAVES][RS_RADIX];
+	for (int j = threadIdx.x; j < RS_WAVES * RS_RADIX; j += RS_THREADS) (&h[0][0])[j] = 0;
+	__syncthreads();
+	const uint64_t begin = uint64_t(blockIdx.x) * tiles_per_block * RS_TILE;
+	uint64_t end = begin + uint64_t(tiles_per_block) * RS_TILE;
+	if (end > n) end = n;
+	const uint32_t w = wave_id();
+	for (uint64_t i = begin + threadIdx.x; i < end; i += RS_THREADS) {
+		uint32_t d = uint32_t(keys[i] >> shift) & 0xFFu;
+		atomicAdd(&h[w][d], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < RS_RADIX) {
+		uint32_t s = 0;
+#pragma unroll
+		for (int k = 0; k < RS_WAVES; ++k) s += h[k][threadIdx.x];
+		hist[threadIdx.x * gridDim.x + blockIdx.x] = s;
+	}
+}
+
+// block d scans row d of hist in place (exclusive) and stores the row total
+__global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t *__restrict__ hist, uint32_t nblocks,
+                                                           uint32_t *__restrict__ row_total) {
+	__shared__ uint32_t scratch[256 / 64 + 1];
+	uint32_t *row = hist + size_t(blockIdx.x) * nblocks;
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < nblocks; base += 256) {
+		uint32_t i = base + threadIdx.x;
+		uint32_t v = i < nblocks ? row[i] : 0;
+		uint32_t total;
+		uint32_t ex = block_excl_scan_u32<256>(v, scratch, total);
+		if (i < nblocks) row[i] = carry + ex;
+		carry += total;
+	}
+	if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void rs_scan_totals_kernel(const uint32_t *__restrict__ row_total,
+                                                             uint32_t *__restrict__ digit_base) {
+	__shared__ uint32_t scratch[256 / 64 + 1];
+	uint32_t total;
+	digit_base[threadIdx.x] = block_excl_scan_u32<256>(row_total[threadIdx.x], scratch, total);
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const unsigned long long *__restrict__ keys,
+                                                                const uint32_t *__restrict__ vals,
+                                                                unsigned long long *__restrict__ okeys,
+                                                                uint32_t *__restrict__ ovals, uint32_t n, int shift,
+                                                                uint32_t tiles_per_block,
+                                                                const uint32_t *__restrict__ hist,
+                                                                const uint32_t *__restrict__ digit_base) {
+	__shared__ uint32_t wcnt[RS_WAVES][RS_RADIX];   // per-wave digit counts -> per-wave digit offsets
+	__shared__ uint32_t tcnt[RS_RADIX];             // digit counts of the tile
+	__shared__ uint32_t tstart[RS_RADIX];           // digit start inside the re-ordered tile
+	__shared__ uint32_t goff[RS_RADIX];             // running global cursor per digit (this block)
+	__shared__ uint32_t scratch[RS_THREADS / 64 + 1];
+	__shared__ unsigned long long sk[RS_TILE];
+	__shared__ uint32_t sv[RS_TILE];
+
+	const uint32_t tid = threadIdx.x, w = wave_id(), lane = lane_id();
+	const unsigned long long lt_mask = (1ull << lane) - 1ull;
+	if (tid < RS_RADIX) goff[tid] = digit_base[tid] + hist[tid * gridDim.x + blockIdx.x];
+
+	const uint64_t first_tile = uint64_t(blockIdx.x) * tiles_per_block;
+	for (uint32_t tt = 0; tt < tiles_per_block; ++tt) {
+		const uint64_t tile_base = (first_tile + tt) * RS_TILE;
+		if (tile_base >= n) break;
+		const uint64_t wave_base = tile_base + uint64_t(w) * (64 * RS_ITEMS);
+
+		unsigned long long key[RS_ITEMS];
+		uint32_t val[RS_ITEMS], lrank[RS_ITEMS];
+#pragma unroll
+		for (int i = 0; i < RS_ITEMS; ++i) {
+			uint64_t idx = wave_base + uint64_t(i) * 64 + lane;
+			bool valid = idx < n;
+			key[i] = valid ? keys[idx] : ~0ull;
+			val[i] = valid ? vals[idx] : 0u;
+		}
+		for (int j = tid; j < RS_WAVES * RS_RADIX; j += RS_THREADS) (&wcnt[0][0])[j] = 0;
+		__syncthreads();
+
+		// wave-level multisplit: rank of each key among the keys of its wave with the same digit
+#pragma unroll
+		for (int i = 0; i < RS_ITEMS; ++i) {
+			const bool valid = (wave_base + uint64_t(i) * 64 + lane) < n;
+			const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
+			unsigned long long m = __ballot(valid);
+#pragma unroll
+			for (int b = 0; b < 8; ++b) {
+				const bool bit = (d >> b) & 1u;
+				const unsigned long long bal = __ballot(bit);
+				m &= bit ? bal : ~bal;
+			}
+			const uint32_t before = __popcll(m & lt_mask);
+			const uint32_t old = wcnt[w][d];
+			__builtin_amdgcn_wave_barrier();
+			if (valid && before == 0) wcnt[w][d] = old + __popcll(m);
+			__builtin_amdgcn_wave_barrier();
+			lrank[i] = old + before;
+		}
+		__syncthreads();
+
+		// combine waves: per digit exclusive offsets over waves, then exclusive scan over digits
+		uint32_t run = 0;
+		if (tid < RS_RADIX) {
+#pragma unroll
+			for (int k = 0; k < RS_WAVES; ++k) { uint32_t c = wcnt[k][tid]; wcnt[k][tid] = run; run += c; }
+			tcnt[tid] = run;
+		}
+		uint32_t total;
+		uint32_t ex = block_excl_scan_u32<RS_THREADS>(tid < RS_RADIX ? run : 0u, scratch, total);
+		if (tid < RS_RADIX) tstart[tid] = ex;
+		__syncthreads();
+
+		// re-order the tile by digit in LDS
+#pragma unroll
+		for (int i = 0; i < RS_ITEMS; ++i) {
+			const bool valid = (wave_base + uint64_t(i) * 64 + lane) < n;
+			if (valid) {
+				const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
+				const uint32_t p = tstart[d] + wcnt[w][d] + lrank[i];
+				sk[p] = key[i];
+				sv[p] = val[i];
+			}
+		}
+		__syncthreads();
+
+		// coalesced write-out: consecutive threads write consecutive addresses inside a digit run
+		for (uint32_t p = tid; p < total; p += RS_THREADS) {
+			const unsigned long long k = sk[p];
+			const uint32_t d = uint32_t(k >> shift) & 0xFFu;
+			const uint32_t g = goff[d] + (p - tstart[d]);
+			okeys[g] = k;
+			ovals[g] = sv[p];
+		}
+		__syncthreads();
+		if (tid < RS_RADIX) goff[tid] += tcnt[tid];
+		__syncthreads();
+	}
+}
+
+}  // namespace dropest

@@ -1,0 +1,219 @@
+// k_segreduce.h -- segmented reduce over key-sorted rows ("runs of equal segment key -> one output row").
+//
+// Three instantiations build the reference's nested containers bottom-up from the sorted read records:
+//   reads      -> molecules      (Gene::add_umi / UMI::add_read: read_count++, mark |= ; Gene.cpp:17-24, UMI.cpp:21-34)
+//   molecules  -> (cell, gene)   (Gene::number_of_requested_umis / number_of_umis; Gene.cpp:60-93)
+//   (cell,gene)-> cells          (Cell::update_requested_size, Cell::size, Stats TOTAL_*; Cell.cpp:130-143)
+// plus reads -> (cell, chromosome) partial rows for Stats' per-chromosome counters
+// (CellsDataContainer::update_cell_stats, CellsDataContainer.cpp:309-327, :73-78).
+//
+// Scheme per instantiation (no inter-workgroup communication inside a launch):
+//   seg_count   heads per tile (a head = row whose segment key differs from its predecessor's)
+//   scan        exclusive scan of the tile counts (single block, tiles are few)
+//   seg_reduce  each thread folds its 8 consecutive rows per run, run aggregates of the tile are combined
+//               with LDS atomics indexed by the run's rank inside the tile, then written coalesced;
+//               only the first/last run of a tile may straddle a tile border: those two use global atomics
+//               on the zero-initialised outputs, every interior run is a plain store.
+// Works for any run length (one molecule with 10^6 reads, a cell with one chromosome, ...).
+#pragma once
+
+#include "util.h"
+
+namespace dropest {
+
+constexpr int SR_THREADS = 256, SR_ITEMS = 8, SR_TILE = SR_THREADS * SR_ITEMS;
+
+template <class P>
+__global__ __launch_bounds__(SR_THREADS) void seg_count_kernel(P p, uint32_t n, uint32_t *__restrict__ tile_heads) {
+	__shared__ uint32_t scratch[SR_THREADS / 64 + 1];
+	const uint32_t i0 = blockIdx.x * SR_TILE + threadIdx.x * SR_ITEMS;
+	uint32_t c = 0;
+	if (i0 < n) {
+		unsigned long long prev = i0 ? p.seg_key(i0 - 1) : ~p.seg_key(0);
+#pragma unroll
+		for (int j = 0; j < SR_ITEMS; ++j) {
+			if (i0 + j < n) {
+				unsigned long long k = p.seg_key(i0 + j);
+				c += (k != prev);
+				prev = k;
+			}
+		}
+	}
+	uint32_t total;
+	block_excl_scan_u32<SR_THREADS>(c, scratch, total);
+	if (threadIdx.x == 0) tile_heads[blockIdx.x] = total;
+}
+
+// P must provide:
+//   static constexpr int NV;                         number of u32 channels
+//   static constexpr unsigned OR_MASK;               bit c set: channel c combines with OR, else with +
+//   __device__ unsigned long long seg_key(uint32_t i) const;
+//   __device__ void load(uint32_t i, uint32_t (&v)[NV]) const;      per-row contribution
+//   __device__ void write_head(uint32_t out, uint32_t i, unsigned long long key) const;
+//   uint32_t *out[NV];                               zero-initialised output channels
+template <class P>
+__global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
+                                                                const uint32_t *__restrict__ tile_prefix) {
+	constexpr int NV = P::NV;
+	__shared__ uint32_t scratch[SR_THREADS / 64 + 1];
+	__shared__ uint32_t agg[NV][SR_TILE + 1];   // slot 0 = run continuing from the previous tile
+	for (int j = threadIdx.x; j < NV * (SR_TILE + 1); j += SR_THREADS) (&agg[0][0])[j] = 0;
+
+	const uint32_t i0 = blockIdx.x * SR_TILE + threadIdx.x * SR_ITEMS;
+	unsigned long long key[SR_ITEMS];
+	uint32_t heads = 0, c = 0;
+	if (i0 < n) {
+		unsigned long long prev = i0 ? p.seg_key(i0 - 1) : ~p.seg_key(0);
+#pragma unroll
+		for (int j = 0; j < SR_ITEMS; ++j) {
+			if (i0 + j < n) {
+				key[j] = p.seg_key(i0 + j);
+				if (key[j] != prev) { heads |= 1u << j; ++c; }
+				prev = key[j];
+			}
+		}
+	}
+	uint32_t total;
+	const uint32_t ex = block_excl_scan_u32<SR_THREADS>(c, scratch, total);   // also orders the agg zeroing
+	const uint32_t tp = tile_prefix[blockIdx.x];
+
+	uint32_t slot = ex;   // rows before this thread's first head belong to the last head seen so far
+	uint32_t acc[NV];
+#pragma unroll
+	for (int c2 = 0; c2 < NV; ++c2) acc[c2] = 0;
+	bool dirty = false;
+	auto flush = [&]() {
+		if (!dirty) return;
+#pragma unroll
+		for (int c2 = 0; c2 < NV; ++c2) {
+			if (acc[c2]) {
+				if (P::OR_MASK & (1u << c2)) atomicOr(&agg[c2][slot], acc[c2]);
+				else atomicAdd(&agg[c2][slot], acc[c2]);
+			}
+			acc[c2] = 0;
+		}
+		dirty = false;
+	};
+	if (i0 < n) {
+#pragma unroll
+		for (int j = 0; j < SR_ITEMS; ++j) {
+			if (i0 + j < n) {
+				if (heads & (1u << j)) {
+					flush();
+					++slot;
+					p.write_head(tp + slot - 1, i0 + j, key[j]);
+				}
+				uint32_t v[NV];
+				p.load(i0 + j, v);
+#pragma unroll
+				for (int c2 = 0; c2 < NV; ++c2) {
+					if (P::OR_MASK & (1u << c2)) acc[c2] |= v[c2]; else acc[c2] += v[c2];
+				}
+				dirty = true;
+			}
+		}
+		flush();
+	}
+	__syncthreads();
+
+	for (uint32_t s = threadIdx.x; s <= total; s += SR_THREADS) {
+		if (s == 0 && tp == 0) continue;   // row 0 is always a head: no carry-in run for the first tile
+		const uint32_t g = tp + s - 1;
+		const bool border = (s == 0) || (s == total);
+#pragma unroll
+		for (int c2 = 0; c2 < NV; ++c2) {
+			const uint32_t v = agg[c2][s];
+			if (border) {
+				if (v) { if (P::OR_MASK & (1u << c2)) atomicOr(&p.out[c2][g], v); else atomicAdd(&p.out[c2][g], v); }
+			} else {
+				p.out[c2][g] = v;
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Policies
+// ---------------------------------------------------------------------------------------------------
+
+// sorted read records (key = cell|gene|umi, val = chr | mark<<16)  ->  molecules
+struct ReadsToMolecules {
+	static constexpr int NV = 2;
+	static constexpr unsigned OR_MASK = 0x2;   // ch0 read_count (+), ch1 mark (|)
+	const unsigned long long *keys;
+	const uint32_t *vals;
+	unsigned long long *mol_key;
+	uint32_t *out[NV];
+	__device__ unsigned long long seg_key(uint32_t i) const { return keys[i]; }
+	__device__ void load(uint32_t i, uint32_t (&v)[NV]) const { v[0] = 1; v[1] = (vals[i] >> 16) & 0xFFu; }
+	__device__ void write_head(uint32_t o, uint32_t, unsigned long long k) const { mol_key[o] = k; }
+};
+
+// sorted read records -> (cell, chromosome) partial rows with exon / intron / intergenic read counts
+struct ReadsToChrRows {
+	static constexpr int NV = 3;
+	static constexpr unsigned OR_MASK = 0;
+	const unsigned long long *keys;
+	const uint32_t *vals;
+	int cell_shift;                  // gene_bits + umi_bits
+	int umi_bits;
+	unsigned long long gene_mask;    // (1 << gene_bits) - 1  == code of "no gene"
+	unsigned long long *row_key;     // cell << 16 | chr
+	uint32_t *out[NV];
+	__device__ unsigned long long seg_key(uint32_t i) const {
+		return ((keys[i] >> cell_shift) << 16) | (vals[i] & 0xFFFFu);
+	}
+	__device__ void load(uint32_t i, uint32_t (&v)[NV]) const {
+		const bool nogene = ((keys[i] >> umi_bits) & gene_mask) == gene_mask;
+		const uint32_t mark = (vals[i] >> 16) & 0xFFu;
+		v[0] = (!nogene && (mark & 2u)) ? 1u : 0u;
+		v[1] = (!nogene && (mark & 4u)) ? 1u : 0u;
+		v[2] = nogene ? 1u : 0u;
+	}
+	__device__ void write_head(uint32_t o, uint32_t, unsigned long long k) const { row_key[o] = k; }
+};
+
+// molecules -> (cell, gene) rows
+struct MoleculesToCellGene {
+	static constexpr int NV = 4;   // n_all, n_req, reads_all, reads_req
+	static constexpr unsigned OR_MASK = 0;
+	const unsigned long long *mol_key;
+	const uint32_t *mol_reads, *mol_mark;
+	int umi_bits;
+	uint32_t query_mask;             // bit m set: mark value m is requested (UMI::Mark::match, UMI.cpp:76-85)
+	unsigned long long *cg_key;      // cell << gene_bits | gene
+	uint32_t *cg_mol_begin;
+	uint32_t *out[NV];
+	__device__ unsigned long long seg_key(uint32_t i) const { return mol_key[i] >> umi_bits; }
+	__device__ void load(uint32_t i, uint32_t (&v)[NV]) const {
+		const uint32_t r = mol_reads[i];
+		const uint32_t req = (query_mask >> (mol_mark[i] & 7u)) & 1u;
+		v[0] = 1; v[1] = req; v[2] = r; v[3] = req ? r : 0u;
+	}
+	__device__ void write_head(uint32_t o, uint32_t i, unsigned long long k) const { cg_key[o] = k; cg_mol_begin[o] = i; }
+};
+
+// (cell, gene) rows -> cells.  Output index == cell id (every cell owns at least one row).
+struct CellGeneToCells {
+	static constexpr int NV = 5;   // n_genes, req_genes, req_umis, total_umis, total_reads
+	static constexpr unsigned OR_MASK = 0;
+	const unsigned long long *cg_key;
+	const uint32_t *n_all, *n_req, *reads_all;
+	int gene_bits;
+	unsigned long long gene_mask;
+	uint32_t *cell_cg_begin;
+	uint32_t *out[NV];
+	__device__ unsigned long long seg_key(uint32_t i) const { return cg_key[i] >> gene_bits; }
+	__device__ void load(uint32_t i, uint32_t (&v)[NV]) const {
+		const bool nogene = (cg_key[i] & gene_mask) == gene_mask;
+		const uint32_t rq = n_req[i];
+		v[0] = nogene ? 0u : 1u;
+		v[1] = (!nogene && rq) ? 1u : 0u;
+		v[2] = nogene ? 0u : rq;
+		v[3] = nogene ? 0u : n_all[i];
+		v[4] = nogene ? 0u : reads_all[i];
+	}
+	__device__ void write_head(uint32_t o, uint32_t i, unsigned long long) const { cell_cg_begin[o] = i; }
+};
+
+}  // namespace dropest

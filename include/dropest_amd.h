@@ -1,0 +1,176 @@
+/* dropest_amd.h -- C-ABI of the MI355X-native dropEst Estimation hot path.
+ *
+ * The reference (kharchenkolab/dropEst v0.8.6) has no plugin/FFI seam; the seam of this path is the
+ * C++ class Estimation::CellsDataContainer (Estimation/CellsDataContainer.h:33-123).  Every entry point
+ * below names the reference interface it replaces (file:line under the reference tree).  The C++ facade
+ * `dropest_amd::CellsDataContainer` (dropest_amd/csrc/host/CellsDataContainer.h) re-creates the reference
+ * class on top of exactly these calls; INTEGRATION.md shows the binding a dropEst maintainer would add.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no exceptions cross the boundary: every call returns a
+ *     dropest_status and dropest_last_error() holds the message of the last failure on this thread
+ *     (the reference throws std::runtime_error / std::out_of_range, dropest.cpp:322-336).
+ *   - result getters follow "ask the size, then pass a caller-owned buffer of that size".
+ *   - one context = one container = one GPU (the reference container is single-threaded; Stats keeps
+ *     process-global statics, Estimation/Stats.cpp:5-7).  Contexts are not thread-safe.
+ *
+ * Packed read record (replaces Estimation::ReadInfo, Estimation/ReadInfo.h:9-24 and
+ * Tools::ReadParameters, Tools/ReadParameters.h:9-50), structure-of-arrays, one entry per read in
+ * stream (= BAM record) order:
+ *   cb[i], umi[i] : uint64 "2-bit code": bases A=0 C=1 G=2 T=3, first base most significant, with a
+ *                   sentinel 1 bit above the top base: code = (1 << 2*len) | bases, len <= 31.
+ *                   Strings that do not fit (an 'N', other letters, len > 31) are ESCAPED:
+ *                   code = DROPEST_ESCAPE | k, k = index into the side-string table registered with
+ *                   dropest_set_side_strings() (first-seen order, one table for barcodes and UMIs).
+ *   gene[i]       : dense id of the gene NAME in first-seen order over gene-bearing reads
+ *                   (= StringIndexer ids, Estimation/StringIndexer.cpp:10-18), DROPEST_NO_GENE when the
+ *                   read has no gene (ReadInfo::gene empty, CellsDataContainer.cpp:73-78).
+ *   aux[i]        : chromosome id (first-seen dense id of the chromosome name, Stats.cpp:81-90) in bits
+ *                   0..15, UMI::Mark bits (UMI.h:16-22: 1 not-annotated, 2 exon, 4 intron) in bits 16..23.
+ */
+#ifndef DROPEST_AMD_H
+#define DROPEST_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DROPEST_ESCAPE   0x8000000000000000ull
+#define DROPEST_NO_GENE  0xFFFFFFFFu
+
+typedef enum {
+	DROPEST_OK = 0,
+	DROPEST_ERR_INVALID = 1,        /* bad argument / call order (reference: std::runtime_error) */
+	DROPEST_ERR_RANGE = 2,          /* index out of range (reference: std::out_of_range) */
+	DROPEST_ERR_DEVICE = 3,         /* HIP runtime failure, no GPU, allocation failure */
+	DROPEST_ERR_UNSUPPORTED = 4,    /* input shape outside this build's limits */
+	DROPEST_ERR_IO = 5              /* whitelist file unreadable / malformed */
+} dropest_status;
+
+/* Which CB-merge strategy (MergeStrategyFactory::get_cb_strat, Estimation/Merge/MergeStrategyFactory.cpp:61-103) */
+enum { DROPEST_MERGE_NONE = 0,          /* DummyMergeStrategy.h:12-17 (no -m) */
+       DROPEST_MERGE_REAL_BARCODES = 1  /* RealBarcodesMergeStrategy.cpp (-m + barcodes_file) */ };
+/* Whitelist file flavour (MergeStrategyFactory.cpp:23-59 barcodes_type) */
+enum { DROPEST_BARCODES_INDROP = 0,     /* InDropBarcodesParser.cpp:15-48 */
+       DROPEST_BARCODES_CONST = 1       /* ConstLengthBarcodesParser.cpp:23-68 */ };
+/* UMI-merge strategy (MergeStrategyFactory::get_umi, :105-111) */
+enum { DROPEST_UMI_MERGE_SIMPLE = 0     /* MergeUMIsStrategySimple.cpp:21-102 (fix UMIs with N) */ };
+
+/* Replaces the constructor arguments of CellsDataContainer (CellsDataContainer.h:82-85) together with
+ * the Estimation.Merge.* keys read by MergeStrategyFactory (MergeStrategyFactory.cpp:26-58). */
+typedef struct {
+	int32_t device;                       /* HIP device ordinal */
+	int32_t merge_kind;                   /* DROPEST_MERGE_* */
+	int32_t barcodes_kind;                /* DROPEST_BARCODES_* */
+	const char *barcodes_file;            /* whitelist path (Estimation.Merge.barcodes_file), may be NULL */
+	int32_t min_genes_before_merge;       /* default 10 in the reference */
+	int32_t min_genes_after_merge;        /* default 10; effective value = max(after, before) (MergeStrategyAbstract.cpp:8-11) */
+	double  min_merge_fraction;           /* default 0.2 */
+	int32_t max_cb_merge_edit_distance;   /* kept for API parity; RealBarcodes ignores it (RealBarcodesMergeStrategy.cpp:111-114) */
+	int32_t umi_merge_kind;               /* DROPEST_UMI_MERGE_* */
+	int32_t max_umi_merge_edit_distance;  /* default 1 */
+	const char *gene_match_levels;        /* -L code, default "eEBA" (UMI.cpp:112-154) */
+	int32_t max_cells;                    /* -C, <= 0: unlimited (CellsDataContainer.cpp:269-273) */
+	uint64_t cb_table_capacity;           /* 0 = auto; power of two >= 2 x distinct barcodes otherwise */
+} dropest_cfg;
+
+typedef struct dropest_ctx dropest_ctx;
+
+/* Fills *cfg with the reference defaults (MergeStrategyFactory.cpp:26-58; dropest.cpp:239-254). */
+void dropest_cfg_defaults(dropest_cfg *cfg);
+
+const char *dropest_last_error(void);
+
+/* CellsDataContainer::CellsDataContainer (CellsDataContainer.cpp:20-37) + strategy construction
+ * (MergeStrategyFactory.cpp:23-59, RealBarcodesMergeStrategy.cpp:12-20 loads the whitelist). */
+dropest_status dropest_ctx_create(const dropest_cfg *cfg, dropest_ctx **out);
+void dropest_ctx_destroy(dropest_ctx *ctx);
+
+/* Side strings for escaped codes (barcodes / UMIs containing 'N' etc.); the table may only grow. */
+dropest_status dropest_set_side_strings(dropest_ctx *ctx, const char *const *strings, uint64_t n);
+
+/* CellsDataContainer::add_record (CellsDataContainer.cpp:59-88), batched.  Host pointers; the batch is
+ * copied to the device, the caller keeps ownership.  Fails with DROPEST_ERR_INVALID after
+ * dropest_set_initialized ("Container is already initialized", :61-62). */
+dropest_status dropest_push_reads(dropest_ctx *ctx, const uint64_t *cb, const uint64_t *umi,
+                                  const uint32_t *gene, const uint32_t *aux, uint64_t n);
+/* Same, for arrays already resident in this GPU's HBM (device pointers).  With adopt != 0 the context
+ * uses the caller's buffers in place (no copy); they must stay alive and unmodified until destroy. */
+dropest_status dropest_push_reads_device(dropest_ctx *ctx, const uint64_t *d_cb, const uint64_t *d_umi,
+                                         const uint32_t *d_gene, const uint32_t *d_aux, uint64_t n, int adopt);
+
+/* CellsDataContainer::set_initialized (CellsDataContainer.cpp:163-175): cell ids, UMI de-duplication,
+ * per-cell sizes, real/filtered cells.  Runs the device pipeline. */
+dropest_status dropest_set_initialized(dropest_ctx *ctx);
+/* CellsDataContainer::merge_and_filter (CellsDataContainer.cpp:39-57): CB merge, UMI merge, final filter. */
+dropest_status dropest_merge_and_filter(dropest_ctx *ctx);
+/* Drops everything computed by set_initialized/merge_and_filter but keeps the pushed reads, so the same
+ * resident stream can be processed again (bench steps).  No reference counterpart. */
+dropest_status dropest_reset_results(dropest_ctx *ctx);
+
+/* ---- accessors (CellsDataContainer.h:99-122) ---- */
+typedef struct {                 /* one row per cell id (first-seen order, CellsDataContainer.cpp:64-69) */
+	uint64_t barcode;            /* packed code of the barcode (Cell::barcode, Cell.cpp:100-103) */
+	uint32_t first_read;         /* ordinal of the first read of this barcode */
+	uint32_t n_genes;            /* Cell::size (Cell.cpp:120-123) */
+	uint32_t requested_genes;    /* Cell::requested_genes_num (Cell.cpp:130-143) */
+	uint32_t requested_umis;     /* Cell::requested_umis_num */
+	int32_t  total_reads;        /* Stats::TOTAL_READS_PER_CB */
+	int32_t  total_umis;         /* Stats::TOTAL_UMIS_PER_CB = Cell::umis_number (quirks of Stats.cpp:29-43, Cell.cpp:31-42 kept) */
+	uint8_t  is_merged, is_excluded, is_real, pad;
+} dropest_cell_row;
+
+dropest_status dropest_total_cells(dropest_ctx *ctx, uint64_t *n);                 /* total_cells_number() */
+dropest_status dropest_real_cells(dropest_ctx *ctx, uint64_t *n);                  /* real_cells_number() */
+dropest_status dropest_cell_rows(dropest_ctx *ctx, uint64_t first, uint64_t count, dropest_cell_row *out); /* cell(i) */
+dropest_status dropest_cell_id_by_cb(dropest_ctx *ctx, uint64_t barcode, int64_t *id); /* cell_id_by_cb(); -1 if absent */
+dropest_status dropest_filtered_cells(dropest_ctx *ctx, uint64_t *n, uint64_t *ids);   /* filtered_cells(); ids may be NULL */
+/* merge_targets(): only entries with target != self are returned (pairs source -> target, ascending
+ * source id); every other cell is its own target (MergeStrategyBase.cpp:13-15). */
+dropest_status dropest_merge_targets(dropest_ctx *ctx, uint64_t *n, uint64_t *src, uint64_t *tgt);
+/* [0] intergenic_reads_num [1] has_exon_reads_num [2] has_intron_reads_num [3] has_not_annotated_reads_num */
+dropest_status dropest_global_counters(dropest_ctx *ctx, uint64_t out[4]);
+
+/* Molecule table of one cell: rows (gene id, umi code, read count, mark), ascending (gene, umi code).
+ * Replaces Cell::genes() / Gene::umis() walks (Cell.h:19, Gene.h:19). */
+dropest_status dropest_cell_molecules(dropest_ctx *ctx, uint64_t cell, uint64_t *n, uint32_t *gene,
+                                      uint64_t *umi, uint32_t *reads, uint8_t *mark);
+/* Whole molecule table, ascending (cell id, gene id, umi code). */
+dropest_status dropest_molecules(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, uint32_t *gene, uint64_t *umi,
+                                 uint32_t *reads, uint8_t *mark);
+
+/* Count matrices as triplets; replaces ResultsPrinter::get_count_matrix_filtered
+ * (Estimation/ResultsPrinter.cpp:334-361; columns = filtered cells ascending, values = requested UMIs,
+ * or reads with reads_output) and ::get_count_matrix_raw (:363-396; columns = real cells in cell-id
+ * order, values = all UMIs).  Rows are gene ids.  Triplets come column-major, genes ascending in a column. */
+dropest_status dropest_count_matrix(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *nnz,
+                                    uint32_t *gene, uint32_t *col, uint32_t *val);
+/* Per-chromosome read counts of real cells (CellsDataContainer::get_stat_by_real_cells,
+ * CellsDataContainer.cpp:291-307): rows (cell id, kind 0 exon / 1 intron / 2 intergenic, chr id, count),
+ * non-zero entries only, ascending (cell, kind, chr). */
+dropest_status dropest_chr_stats(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, uint32_t *kind, uint32_t *chr,
+                                 int32_t *count);
+
+/* RealBarcodesMergeStrategy::get_merge_target (RealBarcodesMergeStrategy.cpp:22-29) for one cell,
+ * evaluated on the un-merged state; valid between set_initialized and merge_and_filter. */
+dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *target);
+
+/* ---- instrumentation (no reference counterpart; Tools::trace_time stage stamps, Tools/Logs.cpp:63-71) ---- */
+typedef struct {
+	const char *name;      /* kernel family */
+	uint32_t launches;
+	double   ms;           /* sum of HIP-event durations on the context's stream */
+	double   bytes;        /* algorithmic bytes moved by those launches */
+} dropest_kernel_stat;
+dropest_status dropest_kernel_stats(dropest_ctx *ctx, uint32_t *n, dropest_kernel_stat *out);
+dropest_status dropest_set_profiling(dropest_ctx *ctx, int enabled);   /* HIP events per launch; off by default */
+/* The HIP stream all kernels of this context are launched on (hipStream_t). */
+void *dropest_stream(dropest_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DROPEST_AMD_H */

@@ -1,0 +1,87 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every symbol the headers declare,
+fails loudly without a GPU, and the product package never touches the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from dropest_amd import capi
+from dropest_amd.synth import SynthStream, load_whitelist, reverse_complement
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dropest_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    names = _declared("dropest_amd.h") + _declared("dropest_synth.h")
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), "missing export: " + n
+    assert sorted(names) == sorted(capi.EXPORTED_SYMBOLS)
+
+
+def test_cfg_defaults_match_reference_defaults():
+    """MergeStrategyFactory.cpp:26-58 defaults."""
+    cfg = capi.Cfg()
+    capi.lib().dropest_cfg_defaults(C.byref(cfg))
+    assert cfg.min_genes_before_merge == 10 and cfg.min_genes_after_merge == 10
+    assert cfg.min_merge_fraction == 0.2 and cfg.max_umi_merge_edit_distance == 1
+    assert cfg.gene_match_levels == b"eEBA" and cfg.max_cells == -1
+
+
+@pytest.mark.skipif(capi.lib().dropest_dev_count() > 0, reason="a GPU is present")
+def test_fails_loudly_without_gpu():
+    with pytest.raises(capi.DropestError) as e:
+        capi.Context()
+    assert e.value.status == 3 and "no CPU implementation" in str(e.value)
+
+
+def test_product_package_never_references_the_oracle():
+    pkg = os.path.join(ROOT, "dropest_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                text = open(os.path.join(base, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), "%s mentions the oracle" % os.path.join(base, f)
+
+
+def test_pack_roundtrip_and_order():
+    for s in ["A", "ACGT", "TTTTTTTTTTTTTTTT", "GATTACAGATTACAGATTACAGATTACAGAT"]:
+        assert capi.unpack_code(capi.pack_seq(s)) == s
+    assert capi.pack_seq("ACGN") is None and capi.pack_seq("") is None and capi.pack_seq("A" * 32) is None
+    seqs = sorted(["ACGT", "AAAA", "TTTT", "CAGT", "ACGA"])
+    assert sorted(seqs, key=capi.pack_seq) == seqs      # equal-length codes sort like the strings
+
+
+def test_host_generator_is_deterministic_and_shaped():
+    s = SynthStream(n_reads=200_000, n_cells=50, n_genes=2000)
+    a = s.generate_host(0, 50_000)
+    b = s.generate_host(0, 50_000)
+    c = s.generate_host(10_000, 1000)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    for x, y in zip(a, c):
+        assert np.array_equal(x[10_000:11_000], y)       # read i depends on i only
+    cb, umi, gene, aux = a
+    frac_ig = float((gene == capi.NO_GENE).mean())
+    assert 0.05 < frac_ig < 0.09
+    assert set(np.unique(aux >> 16)) <= {2, 3, 4}
+    real = np.isin(cb, s.cell_cb)
+    assert 0.90 < real.mean() < 0.94
+    assert all(len(capi.unpack_code(x)) == 16 for x in cb[:100])
+    assert all(len(capi.unpack_code(x)) == 10 for x in umi[:100])
+
+
+def test_whitelist_loader_matches_reference_fixture():
+    """Tests/TestEstimation.cpp:98-121: reverse-complemented parts of data/barcodes/test_est."""
+    parts = load_whitelist(os.path.join(ROOT, "dropest_amd", "data", "barcodes", "test_est"))
+    assert parts[0] == ["AAT", "GAA", "AAA"] and parts[1] == ["TTAGGTCCA", "TTAGGGGCC", "TTAGGTCCC"]
+    assert reverse_complement("AACG") == "CGTT"

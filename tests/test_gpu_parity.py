@@ -1,0 +1,127 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded streams.
+Integer / index work: the bar is bit-exact equality of every observable."""
+import numpy as np
+import pytest
+
+from dropest_amd import capi
+from dropest_amd.synth import SynthStream
+from oracle import Oracle
+
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(stream_kw, n_reads, min_before, min_after, chunks=1, max_cells=-1, levels="eEBA", reads_output=False):
+    s = SynthStream(n_reads=n_reads, **stream_kw)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    o = parity.oracle_run(Oracle, dict(merge_kind=0, min_genes_before=min_before, min_genes_after=min_after,
+                                       match_levels=levels, max_cells=max_cells), cb, umi, gene, aux)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_NONE, min_genes_before_merge=min_before,
+                            min_genes_after_merge=min_after, gene_match_levels=levels, max_cells=max_cells),
+                       cb, umi, gene, aux, chunks=chunks)
+    parity.compare(o, c, reads_output=reads_output)
+    return o, c
+
+
+def test_tiny_stream():
+    _both(dict(n_cells=8, n_genes=50, umi_len=6), 2000, 3, 5)
+
+
+def test_c2_shape_100k():
+    """10x v2 shape (CB 16 + UMI 10), no CB merge -- the C2 configuration scaled down."""
+    o, c = _both(dict(n_cells=40, n_genes=3000), 100_000, 20, 100)
+    assert len(c.filtered_cells()) > 10
+
+
+def test_c2_shape_1m_chunked():
+    _both(dict(n_cells=200, n_genes=8000), 1_000_000, 20, 100, chunks=7)
+
+
+def test_query_levels_and_reads_output():
+    _both(dict(n_cells=30, n_genes=1500), 60_000, 10, 10, levels="e", reads_output=True)
+    _both(dict(n_cells=30, n_genes=1500), 60_000, 10, 10, levels="iI")
+
+
+def test_max_cells_cut():
+    o, c = _both(dict(n_cells=40, n_genes=3000), 80_000, 10, 10, max_cells=7)
+    assert len(c.filtered_cells()) == 7
+
+
+def test_v3_shape_umi12():
+    _both(dict(n_cells=60, n_genes=4000, umi_len=12), 150_000, 20, 50)
+
+
+def test_single_read_and_empty():
+    cb = np.array([capi.pack_seq("ACGTACGTACGTACGT")], np.uint64)
+    umi = np.array([capi.pack_seq("ACGTACGTAC")], np.uint64)
+    gene = np.array([0], np.uint32); aux = np.array([0 | (2 << 16)], np.uint32)
+    o = parity.oracle_run(Oracle, dict(min_genes_before=0, min_genes_after=0), cb, umi, gene, aux)
+    c = parity.gpu_run(dict(min_genes_before_merge=0, min_genes_after_merge=0), cb, umi, gene, aux)
+    parity.compare(o, c)
+    e = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
+    e.set_initialized(); e.merge_and_filter()
+    assert e.total_cells_number() == 0 and len(e.filtered_cells()) == 0
+    assert len(e.count_matrix()[0]) == 0
+
+
+def test_intergenic_only_cell_and_ragged():
+    """A barcode with only gene-less reads still becomes a cell (CellsDataContainer.cpp:64-69)."""
+    P = capi.pack_seq
+    recs = [("AAAACCCCGGGGTTTT", "AAAAAAAAAA", None, 1, 2), ("AAAACCCCGGGGTTTT", "AAAAAAAAAC", None, 2, 2),
+            ("CCCCAAAAGGGGTTTT", "AAAAAAAAAA", 0, 0, 2), ("CCCCAAAAGGGGTTTT", "AAAAAAAAAA", 0, 0, 4),
+            ("CCCCAAAAGGGGTTTT", "AAAAAAAAAA", 1, 1, 1), ("GGGGAAAACCCCTTTT", "TTTTTTTTTT", 1, 1, 3)]
+    cb = np.array([P(r[0]) for r in recs], np.uint64); umi = np.array([P(r[1]) for r in recs], np.uint64)
+    gene = np.array([capi.NO_GENE if r[2] is None else r[2] for r in recs], np.uint32)
+    aux = np.array([r[3] | (r[4] << 16) for r in recs], np.uint32)
+    cb, umi, gene, aux = parity.canonical_stream(cb, umi, gene, aux)
+    o = parity.oracle_run(Oracle, dict(min_genes_before=0, min_genes_after=0), cb, umi, gene, aux)
+    c = parity.gpu_run(dict(min_genes_before_merge=0, min_genes_after_merge=0), cb, umi, gene, aux)
+    parity.compare(o, c)
+    assert c.total_cells_number() == 3
+
+
+def test_state_machine_errors():
+    """add_record after set_initialized / merge before init are errors (CellsDataContainer.cpp:41-42, :61-62, :165-166)."""
+    c = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
+    with pytest.raises(capi.DropestError):
+        c.merge_and_filter()
+    cb = np.array([capi.pack_seq("ACGT")], np.uint64)
+    c.push_reads(cb, cb, np.array([0], np.uint32), np.array([2 << 16], np.uint32))
+    c.set_initialized()
+    with pytest.raises(capi.DropestError):
+        c.set_initialized()
+    with pytest.raises(capi.DropestError):
+        c.push_reads(cb, cb, np.array([0], np.uint32), np.array([2 << 16], np.uint32))
+
+
+def test_device_generator_matches_host():
+    s = SynthStream(n_reads=300_000, n_cells=100, n_genes=5000)
+    host = s.generate_host(first=1000, n=50_000)
+    dev = s.generate_device(0, first=1000, n=50_000)
+    got = dev.to_host()
+    dev.free()
+    for a, b in zip(host, got):
+        assert np.array_equal(a, b)
+
+
+def test_sortedness_and_checksum_at_scale():
+    """Size-independent properties on a stream too long for the oracle: conservation of reads and
+    sortedness of the molecule table."""
+    s = SynthStream(n_reads=20_000_000, n_cells=2000, n_genes=30000)
+    dev = s.generate_device(0)
+    c = capi.Context(min_genes_before_merge=20, min_genes_after_merge=100)
+    c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
+    c.set_initialized(); c.merge_and_filter()
+    cell, gene, umi, reads, mark = c.molecules()
+    counters = c.global_counters()
+    assert int(reads.sum()) + int(counters[0]) == dev.n                      # every read counted exactly once
+    key = (cell.astype(np.uint64) << np.uint64(40)) | (gene.astype(np.uint64) << np.uint64(22)) | (umi & np.uint64((1 << 20) - 1))
+    assert np.all(key[1:] > key[:-1])                                        # strictly ascending, no duplicate molecule
+    rows = c.cell_rows()
+    assert int(rows["total_reads"].astype(np.int64).sum()) == int(reads.sum())
+    assert int(rows["total_umis"].astype(np.int64).sum()) == len(reads)
+    g, col, v = c.count_matrix(filtered=False)
+    real = rows["is_real"].astype(bool)
+    assert int(v.astype(np.int64).sum()) == int(rows["total_umis"][real].astype(np.int64).sum())
+    dev.free()
