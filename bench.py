@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- Mreads/s of the dropEst Estimation hot path (packed reads resident in HBM -> final count
+matrix on the host) on N x MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): synthetic 10x v2 stream, 1e8 reads per GPU, 5 000 real cells per
+GPU-share drawn from the 10x 737K whitelist, 16 bp CB + 10 bp UMI, 30 000 genes, no CB merge
+(DummyMergeStrategy), default N-UMI merge, -L eEBA.  A "step" is one full pass: barcode table, first-seen
+cell ids, UMI de-duplication (radix sort + segmented reduces), per-cell sizes, real/filtered cells, and
+both count matrices copied to the host.  Inputs are resident in HBM before the timed region.
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+DOMINANT = "rs_scatter"        # the radix scatter pass (dropest_amd/csrc/k_radix.h)
+DOMINANT_BYTES_PER_RECORD = 24  # 8 B key + 4 B value read, 8 B + 4 B written: the pass's algorithmic minimum
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=float, default=float(os.environ.get("DROPEST_BENCH_READS", 1e8)),
+                    help="reads per GPU (C2: 1e8)")
+    ap.add_argument("--cells", type=int, default=5000, help="real cells per GPU-share")
+    ap.add_argument("--cpu-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_CPU_SAMPLE", 4e6)),
+                    help="reads of the same stream timed on the CPU oracle (rank 0, N=1 only; 0 disables)")
+    return ap.parse_args()
+
+
+def one_step(ctx):
+    """One pass of the hot path over the resident stream; returns what lands on the host."""
+    ctx.reset_results()
+    ctx.set_initialized()
+    ctx.merge_and_filter()
+    cm = ctx.count_matrix_csc(filtered=True)
+    cm_raw = ctx.count_matrix_csc(filtered=False)
+    return cm, cm_raw, ctx.filtered_cells()
+
+
+def cpu_baseline(stream, n_sample, cfg):
+    """The CPU oracle (oracle/dropest_oracle.cpp, a single-threaded restatement of the reference) timed on the
+    first n_sample reads of the same stream: ingest + set_initialized + merge_and_filter + both matrices."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity
+    from oracle import Oracle
+    cb, umi, gene, aux = parity.canonical_stream(*stream.generate_host(0, n_sample))
+    o = Oracle(merge_kind=0, min_genes_before=cfg["min_before"], min_genes_after=cfg["min_after"])
+    t0 = time.perf_counter()
+    o.add_packed(cb, umi, gene, aux)
+    t1 = time.perf_counter()
+    o.set_initialized(); o.merge_and_filter()
+    o.count_matrix(filtered=True); o.count_matrix(filtered=False)
+    t2 = time.perf_counter()
+    return {"value": round(n_sample / (t2 - t0) / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the same synthetic C2 stream; oracle/dropest_oracle.cpp single thread; "
+                      "ingest %.2f s + finalize/matrices %.2f s; host has %d cores"
+                      % (n_sample, t1 - t0, t2 - t1, os.cpu_count() or 0)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    from dropest_amd import capi
+    from dropest_amd.synth import SynthStream
+
+    if not torch.cuda.is_available() or capi.lib().dropest_dev_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the dropEst hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    reads_per_gpu = int(args.reads)
+    total_reads = reads_per_gpu * world
+    cfg = {"min_before": 20, "min_after": 100}    # configs/10x.xml:26-27
+    stream = SynthStream(n_reads=total_reads, n_cells=args.cells * world, n_genes=30000, cb_len=16, umi_len=10)
+
+    if world == 1:
+        from dropest_amd.capi import Context
+        dev = stream.generate_device(local_rank, first=0, n=reads_per_gpu)
+        ctx = Context(device=local_rank, merge_kind=capi.MERGE_NONE, min_genes_before_merge=cfg["min_before"],
+                      min_genes_after_merge=cfg["min_after"])
+        ctx.push_reads_device(*dev.ptrs, dev.n, adopt=True)
+        step = lambda: one_step(ctx)   # noqa: E731
+        get_stats = ctx.kernel_stats
+        set_prof = ctx.set_profiling
+    else:
+        from dropest_amd.multi import ShardedRun
+        run = ShardedRun(stream, rank, world, local_rank, reads_per_gpu, cfg, dist)
+        step = run.step
+        get_stats = run.kernel_stats
+        set_prof = run.set_profiling
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    set_prof(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    stats = get_stats()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / max(1, args.steps) * 1e3
+        value = total_reads / (elapsed / max(1, args.steps)) / 1e6
+        dom = stats.get(DOMINANT, {"launches": 0, "ms": 0.0, "bytes": 0.0})
+        roof = None
+        if dom["launches"]:
+            avg_ms = dom["ms"] / dom["launches"]
+            achieved = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_rs_scatter.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
+                    "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"]}
+        kernels = {k: {"ms_per_step": round(v["ms"] / max(1, args.steps), 4), "launches_per_step": v["launches"] / max(1, args.steps)}
+                   for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}
+        cpu = None
+        if world == 1 and args.cpu_sample > 0:
+            cpu = cpu_baseline(stream, int(min(args.cpu_sample, total_reads)), cfg)
+        cm = out[0]
+        line = {
+            "metric": "Mreads/s processed to final count matrix", "value": round(value, 2), "unit": "Mreads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "C2: synthetic 10x v2, %d reads/GPU, %d cells/GPU, 16bp CB + 10bp UMI, 30000 genes, "
+                                   "no CB merge, -L eEBA" % (reads_per_gpu, args.cells),
+                       "reads_total": total_reads, "parallelism": "cb-hash-shard x%d" % world,
+                       "cm_nnz": int(len(cm[1])), "filtered_cells": int(len(out[2]))},
+            "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kernels,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,7 @@ def lib():
         "dropest_cell_molecules": (C.c_int, [vp, C.c_uint64, u64p, vp, vp, vp, vp]),
         "dropest_molecules": (C.c_int, [vp, u64p, vp, vp, vp, vp, vp]),
         "dropest_count_matrix": (C.c_int, [vp, C.c_int, C.c_int, u64p, vp, vp, vp]),
+        "dropest_count_matrix_csc": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
         "dropest_chr_stats": (C.c_int, [vp, u64p, vp, vp, vp, vp]),
         "dropest_merge_target": (C.c_int, [vp, C.c_uint64, P(C.c_int64)]),
         "dropest_kernel_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
@@ -123,6 +124,7 @@ EXPORTED_SYMBOLS = [
     "dropest_merge_and_filter", "dropest_reset_results", "dropest_total_cells", "dropest_real_cells",
     "dropest_cell_rows", "dropest_cell_id_by_cb", "dropest_filtered_cells", "dropest_merge_targets",
     "dropest_global_counters", "dropest_cell_molecules", "dropest_molecules", "dropest_count_matrix",
+    "dropest_count_matrix_csc",
     "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_stream",
     "dropest_synth_generate_host", "dropest_synth_generate_device", "dropest_dev_alloc", "dropest_dev_free",
     "dropest_dev_copy_to_host", "dropest_dev_copy_from_host", "dropest_dev_count", "dropest_dev_sync",
@@ -295,6 +297,19 @@ class Context:
             self._chk(self.L.dropest_count_matrix(self.h, int(filtered), int(reads_output), C.byref(n), g.ctypes.data,
                                                   c.ctypes.data, v.ctypes.data))
         return g, c, v
+
+    def count_matrix_csc(self, filtered=True, reads_output=False):
+        """(colptr, rowidx, values) as zero-copy numpy views of context-owned pinned memory (valid until the
+        next call for the same matrix)."""
+        ncols, nnz = C.c_uint64(), C.c_uint64()
+        pc, pr, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.L.dropest_count_matrix_csc(self.h, int(filtered), int(reads_output), C.byref(ncols), C.byref(nnz),
+                                                  C.byref(pc), C.byref(pr), C.byref(pv)))
+        def view(ptr, n):
+            if n == 0 or not ptr.value:
+                return np.zeros(0, np.uint32)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n,))
+        return view(pc, ncols.value + 1), view(pr, nnz.value), view(pv, nnz.value)
 
     def chr_stats(self):
         n = C.c_uint64()

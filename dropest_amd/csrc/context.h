@@ -114,6 +114,15 @@ struct dropest_ctx {
 
 	// scratch
 	dropest::DevBuf<u32> tile_counts, tile_prefix, scalars, rs_hist, rs_row_total, rs_digit_base;
+	dropest::DevBuf<u32> real_list, m_col_cell, m_col_start;
+	dropest::DevBuf<dropest::CellRowPod> real_rows_dev;
+	// count matrices in CSC form: [0] filtered (cm), [1] raw (cm_raw); device staging + pinned host result
+	struct MatrixResult {
+		dropest::DevBuf<u32> d_row, d_val;
+		dropest::PinnedBuf<u32> h_row, h_val;
+		std::vector<u32> colptr;
+		uint64_t nnz = 0, ncols = 0;
+	} mat[2];
 	dropest::DevBuf<dropest::IngestStats> d_ingest;
 	dropest::DevBuf<dropest::GlobalCounters> d_counters;
 
@@ -150,6 +159,6 @@ struct dropest_ctx {
 	void reduce_all();
 	void fetch_real_cells();
 	void sort_filtered(u32 genes_threshold, int max_cells);
-	void emit_matrix(bool filtered_m, bool reads_output, std::vector<u32> &g, std::vector<u32> &c, std::vector<u32> &v);
+	void emit_matrix(bool filtered_m, bool reads_output);
 	u64 unmap_umi(u64 ucode) const;
 };

@@ -382,7 +382,7 @@ void dropest_ctx::reduce_all() {
 		HIP_CHECK(hipMemcpyAsync(cell_cg_begin.p + n_cells, &n_cg, 4, hipMemcpyHostToDevice, stream));
 	}
 	HIP_CHECK(hipStreamSynchronize(stream));
-	keys_a.release(); keys_b.release(); vals_a.release(); vals_b.release();
+	// the sort ping-pong buffers stay allocated: the next run_set_initialized on this context reuses them
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,7 +391,7 @@ void dropest_ctx::reduce_all() {
 void dropest_ctx::fetch_real_cells() {
 	real.clear(); real_index_of.clear();
 	if (n_cells == 0) return;
-	DevBuf<u32> list; list.alloc(n_cells);
+	DevBuf<u32> &list = real_list; list.ensure(n_cells);
 	scalars.ensure(16);
 	zero_async(*this, scalars.p, 4);
 	timed("flag_real", double(n_cells) * 4, [&] {
@@ -402,7 +402,7 @@ void dropest_ctx::fetch_real_cells() {
 	HIP_CHECK(hipMemcpyAsync(&count, scalars.p, 4, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
 	if (count == 0) return;
-	DevBuf<CellRowPod> rows; rows.alloc(count);
+	DevBuf<CellRowPod> &rows = real_rows_dev; rows.ensure(count);
 	CellArrays a{cell_cb.p, cell_first.p, cell_n_genes.p, cell_req_genes.p, cell_req_umis.p, cell_total_umis.p, cell_total_reads.p};
 	timed("gather_cell_rows", double(count) * 72, [&] {
 		hipLaunchKernelGGL(gather_cell_rows_kernel, dim3(div_up(count, 256)), dim3(256), 0, stream, a, list.p, 0u, count, rows.p);
@@ -484,40 +484,42 @@ void dropest_ctx::run_merge_and_filter() {
 // ------------------------------------------------------------------------------------------------
 // count matrices
 // ------------------------------------------------------------------------------------------------
-void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, std::vector<u32> &g, std::vector<u32> &c, std::vector<u32> &v) {
-	std::vector<u32> col_cell, col_start;
+void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output) {
+	MatrixResult &M = mat[filtered_m ? 0 : 1];
+	std::vector<u32> col_cell;
+	M.colptr.clear();
 	uint64_t nnz = 0;
 	if (filtered_m) {
 		for (uint64_t id : filtered) {
 			const HostCell &h = real[real_index_of.at(u32(id))];
-			col_cell.push_back(h.id); col_start.push_back(u32(nnz)); nnz += h.row.requested_genes;
+			col_cell.push_back(h.id); M.colptr.push_back(u32(nnz)); nnz += h.row.requested_genes;
 		}
 	} else {
 		for (const HostCell &h : real) {
 			if (h.merged || h.excluded || h.row.n_genes < min_before) continue;
-			col_cell.push_back(h.id); col_start.push_back(u32(nnz)); nnz += h.row.n_genes;
+			col_cell.push_back(h.id); M.colptr.push_back(u32(nnz)); nnz += h.row.n_genes;
 		}
 	}
 	if (nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
-	g.assign(nnz, 0); c.assign(nnz, 0); v.assign(nnz, 0);
+	M.colptr.push_back(u32(nnz));
+	M.nnz = nnz; M.ncols = col_cell.size();
 	if (nnz == 0) return;
 	const u32 ncols = u32(col_cell.size());
-	DevBuf<u32> d_cc, d_cs, tg, tc, tv;
-	d_cc.alloc(ncols); d_cs.alloc(ncols); tg.alloc(nnz); tc.alloc(nnz); tv.alloc(nnz);
-	HIP_CHECK(hipMemcpyAsync(d_cc.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
-	HIP_CHECK(hipMemcpyAsync(d_cs.p, col_start.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
+	m_col_cell.ensure(ncols); m_col_start.ensure(ncols);
+	M.d_row.ensure(nnz); M.d_val.ensure(nnz); M.h_row.ensure(nnz); M.h_val.ensure(nnz);
+	HIP_CHECK(hipMemcpyAsync(m_col_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemcpyAsync(m_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	MatrixArgs a{};
-	a.col_cell = d_cc.p; a.col_start = d_cs.p; a.cell_cg_begin = cell_cg_begin.p; a.cg_key = cg_key.p;
+	a.col_cell = m_col_cell.p; a.col_start = m_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cg_key = cg_key.p;
 	a.value = filtered_m ? (reads_output ? cg_reads_req.p : cg_n_req.p) : (reads_output ? cg_reads_all.p : cg_n_all.p);
 	a.gene_mask = layout.gene_none; a.skip_zero = filtered_m ? 1 : 0;
-	a.t_gene = tg.p; a.t_col = tc.p; a.t_val = tv.p;
-	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * 24, [&] {
+	a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
+	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * 20, [&] {
 		hipLaunchKernelGGL(emit_matrix_kernel, dim3(ncols), dim3(256), 0, stream, a);
 	});
-	HIP_CHECK(hipMemcpyAsync(g.data(), tg.p, nnz * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipMemcpyAsync(c.data(), tc.p, nnz * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipMemcpyAsync(v.data(), tv.p, nnz * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(hipMemcpyAsync(M.h_row.p, M.d_row.p, nnz * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(M.h_val.p, M.d_val.p, nnz * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));   // col_cell (host vector) must outlive the H2D copy
 	collect_timings();
 }
 
@@ -783,15 +785,27 @@ dropest_status dropest_cell_molecules(dropest_ctx *ctx, uint64_t cell_id, uint64
 	});
 }
 
+dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *ncols, uint64_t *nnz,
+                                        const uint32_t **colptr, const uint32_t **rowidx, const uint32_t **values) {
+	return guarded([&] {
+		need_init(ctx);
+		ctx->emit_matrix(filtered != 0, reads_output != 0);
+		const dropest_ctx::MatrixResult &M = ctx->mat[filtered ? 0 : 1];
+		*ncols = M.ncols; *nnz = M.nnz;
+		*colptr = M.colptr.data(); *rowidx = M.h_row.p; *values = M.h_val.p;
+	});
+}
+
 dropest_status dropest_count_matrix(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *nnz, uint32_t *gene,
                                     uint32_t *col, uint32_t *val) {
 	return guarded([&] {
 		need_init(ctx);
-		std::vector<u32> g, c, v;
-		ctx->emit_matrix(filtered != 0, reads_output != 0, g, c, v);
-		*nnz = g.size();
+		ctx->emit_matrix(filtered != 0, reads_output != 0);
+		const dropest_ctx::MatrixResult &M = ctx->mat[filtered ? 0 : 1];
+		*nnz = M.nnz;
 		if (gene && col && val) {
-			std::copy(g.begin(), g.end(), gene); std::copy(c.begin(), c.end(), col); std::copy(v.begin(), v.end(), val);
+			for (uint64_t c = 0; c < M.ncols; ++c)
+				for (u32 k = M.colptr[c]; k < M.colptr[c + 1]; ++k) { gene[k] = M.h_row.p[k]; col[k] = u32(c); val[k] = M.h_val.p[k]; }
 		}
 	});
 }

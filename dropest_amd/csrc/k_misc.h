@@ -129,7 +129,7 @@ struct MatrixArgs {
 	const uint32_t *value;          // per (cell, gene) row: n_req | reads_req | n_all | reads_all
 	unsigned long long gene_mask;
 	int skip_zero;                  // filtered matrix omits zero entries (Cell.cpp:59-62)
-	uint32_t *t_gene, *t_col, *t_val;
+	uint32_t *t_gene, *t_val;
 };
 __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
 	__shared__ uint32_t scratch[256 / 64 + 1];
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
 		}
 		uint32_t total;
 		const uint32_t ex = block_excl_scan_u32<256>(keep ? 1u : 0u, scratch, total);
-		if (keep) { a.t_gene[out + ex] = g; a.t_col[out + ex] = col; a.t_val[out + ex] = v; }
+		if (keep) { a.t_gene[out + ex] = g; a.t_val[out + ex] = v; }
 		out += total;
 	}
 }

@@ -59,6 +59,25 @@ struct DevBuf {
 	size_t bytes() const { return n * sizeof(T); }
 };
 
+// RAII pinned host buffer (results land here so that D2H runs at PCIe rate and callers get zero-copy views)
+template <typename T>
+struct PinnedBuf {
+	T *p = nullptr;
+	size_t n = 0;
+	PinnedBuf() = default;
+	PinnedBuf(const PinnedBuf &) = delete;
+	PinnedBuf &operator=(const PinnedBuf &) = delete;
+	~PinnedBuf() { release(); }
+	void release() { if (p) { (void)hipHostFree(p); p = nullptr; n = 0; } }
+	void ensure(size_t count) {
+		if (count <= n) return;
+		release();
+		size_t cap = count + count / 8 + 16;
+		HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), cap * sizeof(T), hipHostMallocDefault));
+		n = cap;
+	}
+};
+
 // ---- wave / block primitives (256- or 512-thread blocks, 64-lane waves) ----
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }

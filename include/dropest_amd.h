@@ -148,6 +148,13 @@ dropest_status dropest_molecules(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, 
  * order, values = all UMIs).  Rows are gene ids.  Triplets come column-major, genes ascending in a column. */
 dropest_status dropest_count_matrix(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *nnz,
                                     uint32_t *gene, uint32_t *col, uint32_t *val);
+/* The same matrices in compressed-sparse-column form -- what ResultsPrinter::create_matrix finally builds
+ * (Eigen triplets -> dgCMatrix, ResultsPrinter.cpp:433-442): colptr[ncols + 1], rowidx[nnz] (gene ids,
+ * ascending inside a column), values[nnz].  Zero-copy: the three pointers refer to context-owned (pinned)
+ * host memory that stays valid until the next call for the same `filtered` or until destroy. */
+dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *ncols,
+                                        uint64_t *nnz, const uint32_t **colptr, const uint32_t **rowidx,
+                                        const uint32_t **values);
 /* Per-chromosome read counts of real cells (CellsDataContainer::get_stat_by_real_cells,
  * CellsDataContainer.cpp:291-307): rows (cell id, kind 0 exon / 1 intron / 2 intergenic, chr id, count),
  * non-zero entries only, ascending (cell, kind, chr). */
