@@ -7,10 +7,13 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/dropest_amd.h"
 #include "k_cbhash.h"
+#include "k_merge.h"
+#include "whitelist.h"
 #include "k_misc.h"
 #include "k_radix.h"
 #include "k_segreduce.h"
@@ -107,10 +110,18 @@ struct dropest_ctx {
 	u32 n_cg = 0;
 	dropest::DevBuf<u64> cg_key;
 	dropest::DevBuf<u32> cg_mol_begin, cg_n_all, cg_n_req, cg_reads_all, cg_reads_req;
+	dropest::DevBuf<u32> cell_cg_count;
 	dropest::DevBuf<u32> cell_cg_begin, cell_n_genes, cell_req_genes, cell_req_umis, cell_total_umis, cell_total_reads;
 	u32 n_chr_rows = 0;
 	dropest::DevBuf<u64> chr_row_key;
 	dropest::DevBuf<u32> chr_exon, chr_intron, chr_inter;
+
+	// CB merge
+	dropest::Whitelist wl;
+	dropest::DevBuf<dropest::WlEntry> d_wl[2];
+	dropest::DevBuf<u64> mol_key2;           // re-keyed molecule table (swapped in after a merge)
+	dropest::DevBuf<u32> mol_reads2, mol_mark2, remap;
+	std::unordered_map<u32, u32> reassign;   // merged cell -> final target (MergeStrategyBase cb_reassign_targets, sparse)
 
 	// scratch
 	dropest::DevBuf<u32> tile_counts, tile_prefix, scalars, rs_hist, rs_row_total, rs_digit_base;
@@ -157,6 +168,13 @@ struct dropest_ctx {
 	void build_keys();
 	void radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask);
 	void reduce_all();
+	void reduce_molecules_to_cell_gene();
+	void reduce_cell_gene_to_cells();
+	void refresh_real_rows();
+	void upload_whitelist();
+	std::vector<long> compute_merge_targets(const std::vector<u32> &cells);
+	void run_cb_merge_real();
+	void reaggregate_after_merge();
 	void fetch_real_cells();
 	void sort_filtered(u32 genes_threshold, int max_cells);
 	void emit_matrix(bool filtered_m, bool reads_output);

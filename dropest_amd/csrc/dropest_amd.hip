@@ -138,7 +138,7 @@ void dropest_ctx::concat_chunks() {
 void dropest_ctx::free_results() {
 	initialized = merged = false;
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
-	real.clear(); real_index_of.clear(); filtered.clear(); merge_pairs.clear(); n_real_now = 0;
+	real.clear(); real_index_of.clear(); filtered.clear(); merge_pairs.clear(); reassign.clear(); n_real_now = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -346,43 +346,48 @@ void dropest_ctx::reduce_all() {
 			p.row_key = chr_row_key.p; p.out[0] = chr_exon.p; p.out[1] = chr_intron.p; p.out[2] = chr_inter.p;
 		});
 	}
-	// molecules -> (cell, gene)
-	{
-		MoleculesToCellGene p{};
-		p.mol_key = mol_key.p; p.mol_reads = mol_reads.p; p.mol_mark = mol_mark.p;
-		p.umi_bits = layout.umi_bits; p.query_mask = query_mask;
-		n_cg = run_segmented_reduce(*this, "cell_gene", p, n_mol, 16 + 8, [&](u32 total) {
-			cg_key.ensure(total + 1); cg_mol_begin.ensure(total + 1); cg_n_all.ensure(total + 1); cg_n_req.ensure(total + 1);
-			cg_reads_all.ensure(total + 1); cg_reads_req.ensure(total + 1);
-			zero_async(*this, cg_n_all.p, size_t(total + 1) * 4); zero_async(*this, cg_n_req.p, size_t(total + 1) * 4);
-			zero_async(*this, cg_reads_all.p, size_t(total + 1) * 4); zero_async(*this, cg_reads_req.p, size_t(total + 1) * 4);
-			p.cg_key = cg_key.p; p.cg_mol_begin = cg_mol_begin.p;
-			p.out[0] = cg_n_all.p; p.out[1] = cg_n_req.p; p.out[2] = cg_reads_all.p; p.out[3] = cg_reads_req.p;
-		});
-		// sentinel so that row i owns molecules [cg_mol_begin[i], cg_mol_begin[i+1])
-		HIP_CHECK(hipMemcpyAsync(cg_mol_begin.p + n_cg, &n_mol, 4, hipMemcpyHostToDevice, stream));
-	}
-	// (cell, gene) -> cells
-	{
-		CellGeneToCells p{};
-		p.cg_key = cg_key.p; p.n_all = cg_n_all.p; p.n_req = cg_n_req.p; p.reads_all = cg_reads_all.p;
-		p.gene_bits = layout.gene_bits; p.gene_mask = layout.gene_none;
-		u32 runs = run_segmented_reduce(*this, "cells", p, n_cg, 24 + 4, [&](u32 total) {
-			if (total != n_cells) throw DeviceError("internal: cell runs (" + std::to_string(total) + ") != cells (" +
-			                                        std::to_string(n_cells) + ")");
-			cell_cg_begin.ensure(total + 1); cell_n_genes.ensure(total + 1); cell_req_genes.ensure(total + 1);
-			cell_req_umis.ensure(total + 1); cell_total_umis.ensure(total + 1); cell_total_reads.ensure(total + 1);
-			for (DevBuf<u32> *b : {&cell_n_genes, &cell_req_genes, &cell_req_umis, &cell_total_umis, &cell_total_reads})
-				zero_async(*this, b->p, size_t(total + 1) * 4);
-			p.cell_cg_begin = cell_cg_begin.p;
-			p.out[0] = cell_n_genes.p; p.out[1] = cell_req_genes.p; p.out[2] = cell_req_umis.p;
-			p.out[3] = cell_total_umis.p; p.out[4] = cell_total_reads.p;
-		});
-		(void)runs;
-		HIP_CHECK(hipMemcpyAsync(cell_cg_begin.p + n_cells, &n_cg, 4, hipMemcpyHostToDevice, stream));
-	}
+	reduce_molecules_to_cell_gene();
+	reduce_cell_gene_to_cells();
 	HIP_CHECK(hipStreamSynchronize(stream));
 	// the sort ping-pong buffers stay allocated: the next run_set_initialized on this context reuses them
+}
+
+void dropest_ctx::reduce_molecules_to_cell_gene() {
+	MoleculesToCellGene p{};
+	p.mol_key = mol_key.p; p.mol_reads = mol_reads.p; p.mol_mark = mol_mark.p;
+	p.umi_bits = layout.umi_bits; p.query_mask = query_mask;
+	n_cg = run_segmented_reduce(*this, "cell_gene", p, n_mol, 16 + 8, [&](u32 total) {
+		cg_key.ensure(total + 1); cg_mol_begin.ensure(total + 1); cg_n_all.ensure(total + 1); cg_n_req.ensure(total + 1);
+		cg_reads_all.ensure(total + 1); cg_reads_req.ensure(total + 1);
+		zero_async(*this, cg_n_all.p, size_t(total + 1) * 4); zero_async(*this, cg_n_req.p, size_t(total + 1) * 4);
+		zero_async(*this, cg_reads_all.p, size_t(total + 1) * 4); zero_async(*this, cg_reads_req.p, size_t(total + 1) * 4);
+		p.cg_key = cg_key.p; p.cg_mol_begin = cg_mol_begin.p;
+		p.out[0] = cg_n_all.p; p.out[1] = cg_n_req.p; p.out[2] = cg_reads_all.p; p.out[3] = cg_reads_req.p;
+	});
+	// sentinel so that row i owns molecules [cg_mol_begin[i], cg_mol_begin[i+1])
+	HIP_CHECK(hipMemcpyAsync(cg_mol_begin.p + n_cg, &n_mol, 4, hipMemcpyHostToDevice, stream));
+}
+
+void dropest_ctx::reduce_cell_gene_to_cells() {
+	// DIRECT segmented reduce: output row = cell id, no count/scan pass; cells without rows stay zero
+	CellGeneToCells p{};
+	p.cg_key = cg_key.p; p.n_all = cg_n_all.p; p.n_req = cg_n_req.p; p.reads_all = cg_reads_all.p;
+	p.gene_bits = layout.gene_bits; p.gene_mask = layout.gene_none;
+	const size_t nc = size_t(n_cells) + 1;
+	cell_cg_begin.ensure(nc); cell_cg_count.ensure(nc); cell_n_genes.ensure(nc); cell_req_genes.ensure(nc);
+	cell_req_umis.ensure(nc); cell_total_umis.ensure(nc); cell_total_reads.ensure(nc);
+	for (DevBuf<u32> *b : {&cell_cg_begin, &cell_cg_count, &cell_n_genes, &cell_req_genes, &cell_req_umis, &cell_total_umis,
+	                       &cell_total_reads})
+		zero_async(*this, b->p, nc * 4);
+	p.cell_cg_begin = cell_cg_begin.p;
+	p.out[0] = cell_n_genes.p; p.out[1] = cell_req_genes.p; p.out[2] = cell_req_umis.p;
+	p.out[3] = cell_total_umis.p; p.out[4] = cell_total_reads.p; p.out[5] = cell_cg_count.p;
+	if (n_cg == 0) return;
+	const u32 tiles = div_up(n_cg, SR_TILE);
+	timed("seg_reduce:cells", double(n_cg) * (24 + 4), [&] {
+		hipLaunchKernelGGL(seg_reduce_kernel<CellGeneToCells>, dim3(tiles), dim3(SR_THREADS), 0, stream, p, n_cg,
+		                   static_cast<const u32 *>(nullptr));
+	});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -450,6 +455,8 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 	for (size_t i = start; i < idx.size(); ++i) filtered.push_back(real[idx[i]].id);
 }
 
+#include "merge_host.h"
+
 // ------------------------------------------------------------------------------------------------
 // top-level stages
 // ------------------------------------------------------------------------------------------------
@@ -472,10 +479,9 @@ void dropest_ctx::run_set_initialized() {
 void dropest_ctx::run_merge_and_filter() {
 	if (!initialized) throw InvalidError("You must initialize container");
 	if (merged) throw InvalidError("merge_and_filter was already run");
-	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES)
-		throw UnsupportedError("RealBarcodes merge is not built yet in this revision");
 	if (ingest.umi_escape_max_plus1 != 0)
 		throw UnsupportedError("UMIs with N (escaped codes) are not handled yet in this revision");
+	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells) run_cb_merge_real();
 	sort_filtered(min_after, cfg.max_cells);   // CellsDataContainer.cpp:47-49
 	merged = true;
 	collect_timings();
@@ -510,7 +516,7 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output) {
 	HIP_CHECK(hipMemcpyAsync(m_col_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(m_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	MatrixArgs a{};
-	a.col_cell = m_col_cell.p; a.col_start = m_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cg_key = cg_key.p;
+	a.col_cell = m_col_cell.p; a.col_start = m_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
 	a.value = filtered_m ? (reads_output ? cg_reads_req.p : cg_n_req.p) : (reads_output ? cg_reads_all.p : cg_n_all.p);
 	a.gene_mask = layout.gene_none; a.skip_zero = filtered_m ? 1 : 0;
 	a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
@@ -766,10 +772,13 @@ dropest_status dropest_cell_molecules(dropest_ctx *ctx, uint64_t cell_id, uint64
 	return guarded([&] {
 		need_init(ctx);
 		if (cell_id >= ctx->n_cells) throw RangeError("cell index out of range");
-		u32 cgb[2], mb = 0, me = 0;
-		HIP_CHECK(hipMemcpy(cgb, ctx->cell_cg_begin.p + cell_id, 8, hipMemcpyDeviceToHost));
-		HIP_CHECK(hipMemcpy(&mb, ctx->cg_mol_begin.p + cgb[0], 4, hipMemcpyDeviceToHost));
-		HIP_CHECK(hipMemcpy(&me, ctx->cg_mol_begin.p + cgb[1], 4, hipMemcpyDeviceToHost));
+		u32 cgb = 0, cgc = 0, mb = 0, me = 0;
+		HIP_CHECK(hipMemcpy(&cgb, ctx->cell_cg_begin.p + cell_id, 4, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(&cgc, ctx->cell_cg_count.p + cell_id, 4, hipMemcpyDeviceToHost));
+		if (cgc) {
+			HIP_CHECK(hipMemcpy(&mb, ctx->cg_mol_begin.p + cgb, 4, hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(&me, ctx->cg_mol_begin.p + cgb + cgc, 4, hipMemcpyDeviceToHost));
+		}
 		std::vector<u64> k; std::vector<u32> r, m;
 		fetch_molecule_range(ctx, mb, me, k, r, m);
 		const KeyLayout &L = ctx->layout;
@@ -855,8 +864,10 @@ dropest_status dropest_chr_stats(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, 
 dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *target) {
 	return guarded([&] {
 		need_init(ctx);
-		(void)cell; (void)target;
-		throw UnsupportedError("RealBarcodes merge is not built yet in this revision");
+		if (ctx->merged) throw InvalidError("merge targets are defined on the un-merged state (call before merge_and_filter)");
+		if (ctx->cfg.merge_kind != DROPEST_MERGE_REAL_BARCODES) { *target = int64_t(cell); return; }   // DummyMergeStrategy
+		if (cell >= ctx->n_cells) throw RangeError("cell index out of range");
+		*target = ctx->compute_merge_targets(std::vector<u32>{u32(cell)})[0];
 	});
 }
 

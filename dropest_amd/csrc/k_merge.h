@@ -1,0 +1,224 @@
+// k_merge.h -- device side of the cell-barcode merge against a whitelist ("real barcodes").
+//
+// Replaces the read-only LOOP B of MergeStrategyBase::merge_inited (Estimation/Merge/MergeStrategyBase.cpp:20-27)
+// for RealBarcodesMergeStrategy (RealBarcodesMergeStrategy.cpp:22-109):
+//   wl_neighbours   per filtered cell: edit distance of each barcode part to EVERY whitelist part
+//                   (BarcodesParser::get_distances_to_barcode, BarcodesParser.cpp:21-39), enumeration of the part
+//                   combinations by increasing total distance <= 5 (push_remaining_dists, :52-74), barcode-table
+//                   lookup of each combination, and the candidate test of RealBarcodesMergeStrategy.cpp:93-103.
+//                   The scan stops after the first distance level that yields a candidate (:82-106).
+//   umig_intersect  |UMI-genes(base) n UMI-genes(candidate)| (MergeStrategyBase::get_umigs_intersect_size, :100-147)
+//                   as a binary-search join of the two cells' sorted molecule ranges.
+//   rekey_molecules molecules of merged cells take their target's cell id (Gene::merge, Gene.cpp:26-36, applied by
+//                   re-sorting + re-reducing the molecule table).
+// The merge decision itself (double arithmetic, strict arg-max, sequential smallest-first application with
+// re-targeting, MergeStrategyBase.cpp:30-51,:64-82) runs on the host over the few filtered cells.
+// Integer work; no MFMA.
+#pragma once
+
+#include "k_cbhash.h"
+#include "util.h"
+
+namespace dropest {
+
+constexpr int WL_MAX_LEN = 31;          // bases per barcode part
+constexpr int WL_MAX_DIST = 5;          // BarcodesParser::MAX_REAL_MERGE_EDIT_DISTANCE (BarcodesParser.h:57)
+constexpr int WL_CAND_CAP = 128;        // candidates kept per cell (exceeding it is reported, never truncated silently)
+constexpr int WL_THREADS = 256;
+
+struct WlEntry {            // one whitelist part entry
+	char seq[32];           // ASCII, NUL padded
+};
+
+struct WlBase {             // one filtered cell's barcode, split on the host (BarcodesParser::split_barcode)
+	char part[2][32];
+	uint8_t len[2];
+	uint8_t pad[2];
+	uint32_t cell;          // cell id of the base
+};
+
+// Levenshtein distance with 'N' as a wildcard on either side == Tools::edit_distance(a, b) with its default
+// arguments (Tools/UtilFunctions.cpp:32-65; the band is inactive for max_ed = 10000).  Bit-parallel
+// (Myers / Hyyro) over the pattern `pat` (length m <= 31) against text `txt` (NUL terminated).
+__device__ inline uint32_t wl_peq(const uint32_t peq[5], char c) {
+	switch (c) {
+		case 'A': return peq[0];
+		case 'C': return peq[1];
+		case 'G': return peq[2];
+		case 'T': return peq[3];
+		case 'N': return peq[4];
+		default: return peq[4] & 0u;   // foreign letter: matches only pattern wildcards (set below)
+	}
+}
+__device__ inline void wl_build_peq(const char *pat, int m, uint32_t peq[5], uint32_t &wild) {
+	peq[0] = peq[1] = peq[2] = peq[3] = 0; wild = 0;
+	for (int i = 0; i < m; ++i) {
+		const char c = pat[i];
+		const uint32_t bit = 1u << i;
+		if (c == 'A') peq[0] |= bit; else if (c == 'C') peq[1] |= bit; else if (c == 'G') peq[2] |= bit;
+		else if (c == 'T') peq[3] |= bit; else if (c == 'N') wild |= bit;
+	}
+	peq[0] |= wild; peq[1] |= wild; peq[2] |= wild; peq[3] |= wild;
+	peq[4] = m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u);   // a text 'N' matches every pattern position
+}
+__device__ inline uint32_t wl_edit_distance(const uint32_t peq[5], uint32_t wild, int m, const char *txt) {
+	if (m == 0) { int n = 0; while (n < 32 && txt[n]) ++n; return uint32_t(n); }
+	uint32_t pv = m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u), mv = 0, score = uint32_t(m);
+	const uint32_t last = 1u << (m - 1);
+	for (int j = 0; j < 32 && txt[j]; ++j) {
+		const char c = txt[j];
+		uint32_t eq;
+		if (c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') eq = wl_peq(peq, c); else eq = wild;
+		const uint32_t xv = eq | mv;
+		const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+		uint32_t ph = mv | ~(xh | pv);
+		uint32_t mh = pv & xh;
+		if (ph & last) ++score; else if (mh & last) --score;
+		ph = (ph << 1) | 1u;
+		mh <<= 1;
+		pv = mh | ~(xv | ph);
+		mv = ph & xv;
+	}
+	return score;
+}
+
+// appends the 2-bit payload of a NUL-terminated ACGT string to `c` (clean strings only)
+__device__ inline unsigned long long wl_append(unsigned long long c, const char *s) {
+	for (int i = 0; i < 32 && s[i]; ++i) {
+		const char ch = s[i];
+		c = (c << 2) | (ch == 'C' ? 1ull : ch == 'G' ? 2ull : ch == 'T' ? 3ull : 0ull);
+	}
+	return c;
+}
+
+struct WlArgs {
+	const WlBase *bases; uint32_t n_bases;
+	const WlEntry *part[2]; uint32_t part_size[2];                         // whitelist (two parts)
+	CbTable table;
+	const uint32_t *cell_n_genes, *cell_total_umis;
+	uint32_t min_genes;
+	uint32_t *cand_count;    // [n_bases] qualifying candidates found (may exceed WL_CAND_CAP: overflow)
+	uint32_t *cand_level;    // [n_bases] total distance of the level that produced them
+	uint32_t *cand_cell;     // [n_bases][WL_CAND_CAP]
+	uint8_t *dist_dump;      // optional [n_bases][part_size[0] + part_size[1]] per-part distances (tie replay), or null
+};
+
+// one block per filtered cell; dynamic LDS: dist bytes [n0 + n1] + index lists u16 [n0 + n1]
+__global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const uint32_t n0 = a.part_size[0], n1 = a.part_size[1], ntot = n0 + n1;
+	uint8_t *dist = smem;                                             // [ntot]
+	uint16_t *lists = reinterpret_cast<uint16_t *>(smem + ((ntot + 15u) & ~15u));   // [ntot], grouped by (part, distance)
+	__shared__ uint32_t cnt[2][WL_MAX_DIST + 2];      // entries per distance 0..5, [6] = farther
+	__shared__ uint32_t start[2][WL_MAX_DIST + 2];
+	__shared__ uint32_t fill[2][WL_MAX_DIST + 2];
+	__shared__ uint32_t n_found;
+
+	const WlBase &b = a.bases[blockIdx.x];
+	const uint32_t tid = threadIdx.x;
+	if (tid < 2 * (WL_MAX_DIST + 2)) { (&cnt[0][0])[tid] = 0; (&fill[0][0])[tid] = 0; }
+	if (tid == 0) n_found = 0;
+	__syncthreads();
+
+	// 1. distances of both parts to every whitelist entry
+	for (int p = 0; p < 2; ++p) {
+		uint32_t peq[5], wild;
+		wl_build_peq(b.part[p], b.len[p], peq, wild);
+		const uint32_t np = a.part_size[p], off = p ? n0 : 0;
+		for (uint32_t i = tid; i < np; i += WL_THREADS) {
+			const uint32_t d = wl_edit_distance(peq, wild, b.len[p], a.part[p][i].seq);
+			dist[off + i] = uint8_t(d > 255 ? 255 : d);
+			atomicAdd(&cnt[p][d > WL_MAX_DIST ? WL_MAX_DIST + 1 : d], 1u);
+		}
+	}
+	__syncthreads();
+	if (a.dist_dump) for (uint32_t i = tid; i < ntot; i += WL_THREADS) a.dist_dump[size_t(blockIdx.x) * ntot + i] = dist[i];
+	if (tid < 2) {
+		uint32_t run = tid ? n0 : 0;
+		for (int k = 0; k <= WL_MAX_DIST + 1; ++k) { start[tid][k] = run; run += cnt[tid][k]; }
+	}
+	__syncthreads();
+	// 2. index lists grouped by distance (order inside a group is irrelevant: candidates form a set)
+	for (int p = 0; p < 2; ++p) {
+		const uint32_t np = a.part_size[p], off = p ? n0 : 0;
+		for (uint32_t i = tid; i < np; i += WL_THREADS) {
+			const uint32_t d = dist[off + i];
+			if (d <= WL_MAX_DIST) lists[start[p][d] + atomicAdd(&fill[p][d], 1u)] = uint16_t(i);
+		}
+	}
+	__syncthreads();
+
+	// 3. levels of increasing total distance; stop after the first level with a candidate
+	const uint32_t base_umis = a.cell_total_umis[b.cell];
+	uint32_t level = 0;
+	for (; level <= WL_MAX_DIST; ++level) {
+		for (uint32_t d0 = 0; d0 <= level; ++d0) {
+			const uint32_t d1 = level - d0;
+			const uint32_t na = cnt[0][d0], nb = cnt[1][d1];
+			const uint64_t pairs = uint64_t(na) * nb;
+			for (uint64_t q = tid; q < pairs; q += WL_THREADS) {
+				const uint32_t i = lists[start[0][d0] + uint32_t(q / nb)];
+				const uint32_t j = lists[start[1][d1] + uint32_t(q % nb)];
+				// packed code of the concatenation (sentinel bit first; entries of a part may differ in length)
+				const unsigned long long code = wl_append(wl_append(1ull, a.part[0][i].seq), a.part[1][j].seq);
+				const uint32_t s = cb_find(a.table, code);
+				if (s == 0xFFFFFFFFu) continue;
+				const uint32_t c = a.table.cell_id[s];
+				if (a.cell_n_genes[c] >= a.min_genes && a.cell_total_umis[c] >= base_umis) {
+					const uint32_t k = atomicAdd(&n_found, 1u);
+					if (k < WL_CAND_CAP) a.cand_cell[size_t(blockIdx.x) * WL_CAND_CAP + k] = c;
+				}
+			}
+		}
+		__syncthreads();
+		if (n_found) break;
+		__syncthreads();
+	}
+	if (tid == 0) { a.cand_count[blockIdx.x] = n_found; a.cand_level[blockIdx.x] = level; }
+}
+
+// ---- UMI-gene intersection sizes ---------------------------------------------------------------------
+struct PairRange { uint32_t base_begin, base_end, cand_begin, cand_end; };
+
+__global__ __launch_bounds__(256) void umig_intersect_kernel(const PairRange *__restrict__ pairs, uint32_t n_pairs,
+                                                             const unsigned long long *__restrict__ mol_key,
+                                                             unsigned long long low_mask, int umi_bits,
+                                                             unsigned long long gene_none, uint32_t *__restrict__ out) {
+	__shared__ uint32_t scratch[256 / 64 + 1];
+	const PairRange r = pairs[blockIdx.x];
+	uint32_t c = 0;
+	for (uint32_t i = r.base_begin + threadIdx.x; i < r.base_end; i += 256) {
+		const unsigned long long k = mol_key[i] & low_mask;
+		if ((k >> umi_bits) == gene_none) continue;          // reads without a gene are not UMI-genes
+		uint32_t lo = r.cand_begin, hi = r.cand_end;
+		while (lo < hi) {
+			const uint32_t mid = lo + ((hi - lo) >> 1);
+			if ((mol_key[mid] & low_mask) < k) lo = mid + 1; else hi = mid;
+		}
+		if (lo < r.cand_end && (mol_key[lo] & low_mask) == k) ++c;
+	}
+	uint32_t total;
+	block_excl_scan_u32<256>(c, scratch, total);
+	if (threadIdx.x == 0) out[blockIdx.x] = total;
+}
+
+// ---- re-keying after the merge decisions --------------------------------------------------------------
+// remap[cell] = final target of a merged cell, identity otherwise
+__global__ __launch_bounds__(256) void rekey_molecules_kernel(const unsigned long long *__restrict__ mol_key, uint32_t n,
+                                                              int cell_shift, const uint32_t *__restrict__ remap,
+                                                              unsigned long long *__restrict__ keys,
+                                                              uint32_t *__restrict__ vals, unsigned long long *key_or_and) {
+	unsigned long long k_or = 0, k_and = ~0ull;
+	const uint32_t stride = gridDim.x * 256;
+	const unsigned long long low = (1ull << cell_shift) - 1ull;
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+		const unsigned long long k = mol_key[i];
+		const unsigned long long nk = ((unsigned long long)remap[uint32_t(k >> cell_shift)] << cell_shift) | (k & low);
+		keys[i] = nk; vals[i] = i;
+		k_or |= nk; k_and &= nk;
+	}
+	k_or = wave_reduce_or_u64(k_or); k_and = wave_reduce_and_u64(k_and);
+	if (lane_id() == 0) { atomicOr(&key_or_and[0], k_or); atomicAnd(&key_or_and[1], k_and); }
+}
+
+}  // namespace dropest

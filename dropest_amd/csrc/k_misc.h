@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void gather_cell_rows_kernel(CellArrays a, con
 struct MatrixArgs {
 	const uint32_t *col_cell;       // [ncols] cell id of each column
 	const uint32_t *col_start;      // [ncols] first triplet of the column
-	const uint32_t *cell_cg_begin;  // [n_cells + 1]
+	const uint32_t *cell_cg_begin;  // [n_cells] first (cell, gene) row of the cell
+	const uint32_t *cell_cg_count;  // [n_cells] number of rows
 	const unsigned long long *cg_key;
 	const uint32_t *value;          // per (cell, gene) row: n_req | reads_req | n_all | reads_all
 	unsigned long long gene_mask;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
 	__shared__ uint32_t scratch[256 / 64 + 1];
 	const uint32_t col = blockIdx.x;
 	const uint32_t cell = a.col_cell[col];
-	const uint32_t b = a.cell_cg_begin[cell], e = a.cell_cg_begin[cell + 1];
+	const uint32_t b = a.cell_cg_begin[cell], e = b + a.cell_cg_count[cell];
 	uint32_t out = a.col_start[col];
 	for (uint32_t base = b; base < e; base += 256) {
 		const uint32_t i = base + threadIdx.x;

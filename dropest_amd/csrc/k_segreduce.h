@@ -51,13 +51,21 @@ __global__ __launch_bounds__(SR_THREADS) void seg_count_kernel(P p, uint32_t n, 
 //   __device__ void load(uint32_t i, uint32_t (&v)[NV]) const;      per-row contribution
 //   __device__ void write_head(uint32_t out, uint32_t i, unsigned long long key) const;
 //   uint32_t *out[NV];                               zero-initialised output channels
+//   static constexpr bool DIRECT;                    false: output row = rank of the run (needs seg_count + scan);
+//                                                    true: output row = direct_index(segment key), no count pass
+//   __device__ uint32_t direct_index(unsigned long long key) const;   (DIRECT only)
 template <class P>
 __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
                                                                 const uint32_t *__restrict__ tile_prefix) {
 	constexpr int NV = P::NV;
 	__shared__ uint32_t scratch[SR_THREADS / 64 + 1];
 	__shared__ uint32_t agg[NV][SR_TILE + 1];   // slot 0 = run continuing from the previous tile
+	__shared__ uint32_t slot_row[P::DIRECT ? SR_TILE + 1 : 1];   // DIRECT: output row of each slot
 	for (int j = threadIdx.x; j < NV * (SR_TILE + 1); j += SR_THREADS) (&agg[0][0])[j] = 0;
+	if (P::DIRECT && threadIdx.x == 0) {
+		const uint32_t t0 = blockIdx.x * SR_TILE;
+		slot_row[0] = (t0 && t0 < n) ? p.direct_index(p.seg_key(t0 - 1)) : 0u;
+	}
 
 	const uint32_t i0 = blockIdx.x * SR_TILE + threadIdx.x * SR_ITEMS;
 	unsigned long long key[SR_ITEMS];
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 	}
 	uint32_t total;
 	const uint32_t ex = block_excl_scan_u32<SR_THREADS>(c, scratch, total);   // also orders the agg zeroing
-	const uint32_t tp = tile_prefix[blockIdx.x];
+	const uint32_t tp = P::DIRECT ? 1u : tile_prefix[blockIdx.x];   // DIRECT: only "tp != 0" matters below
 
 	uint32_t slot = ex;   // rows before this thread's first head belong to the last head seen so far
 	uint32_t acc[NV];
@@ -101,7 +109,13 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 				if (heads & (1u << j)) {
 					flush();
 					++slot;
-					p.write_head(tp + slot - 1, i0 + j, key[j]);
+					if (P::DIRECT) {
+						const uint32_t row = p.direct_index(key[j]);
+						slot_row[slot] = row;
+						p.write_head(row, i0 + j, key[j]);
+					} else {
+						p.write_head(tp + slot - 1, i0 + j, key[j]);
+					}
 				}
 				uint32_t v[NV];
 				p.load(i0 + j, v);
@@ -117,8 +131,8 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 	__syncthreads();
 
 	for (uint32_t s = threadIdx.x; s <= total; s += SR_THREADS) {
-		if (s == 0 && tp == 0) continue;   // row 0 is always a head: no carry-in run for the first tile
-		const uint32_t g = tp + s - 1;
+		if (s == 0 && (P::DIRECT ? blockIdx.x == 0 : tp == 0)) continue;   // row 0 is always a head: no carry-in run for the first tile
+		const uint32_t g = P::DIRECT ? slot_row[s] : tp + s - 1;
 		const bool border = (s == 0) || (s == total);
 #pragma unroll
 		for (int c2 = 0; c2 < NV; ++c2) {
@@ -138,6 +152,8 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 
 // sorted read records (key = cell|gene|umi, val = chr | mark<<16)  ->  molecules
 struct ReadsToMolecules {
+	static constexpr bool DIRECT = false;
+	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 2;
 	static constexpr unsigned OR_MASK = 0x2;   // ch0 read_count (+), ch1 mark (|)
 	const unsigned long long *keys;
@@ -151,6 +167,8 @@ struct ReadsToMolecules {
 
 // sorted read records -> (cell, chromosome) partial rows with exon / intron / intergenic read counts
 struct ReadsToChrRows {
+	static constexpr bool DIRECT = false;
+	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 3;
 	static constexpr unsigned OR_MASK = 0;
 	const unsigned long long *keys;
@@ -175,6 +193,8 @@ struct ReadsToChrRows {
 
 // molecules -> (cell, gene) rows
 struct MoleculesToCellGene {
+	static constexpr bool DIRECT = false;
+	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 4;   // n_all, n_req, reads_all, reads_req
 	static constexpr unsigned OR_MASK = 0;
 	const unsigned long long *mol_key;
@@ -193,9 +213,11 @@ struct MoleculesToCellGene {
 	__device__ void write_head(uint32_t o, uint32_t i, unsigned long long k) const { cg_key[o] = k; cg_mol_begin[o] = i; }
 };
 
-// (cell, gene) rows -> cells.  Output index == cell id (every cell owns at least one row).
+// (cell, gene) rows -> cells.  DIRECT: the output row is the cell id itself, so cells that lost all their rows
+// to a merge simply stay zero.
 struct CellGeneToCells {
-	static constexpr int NV = 5;   // n_genes, req_genes, req_umis, total_umis, total_reads
+	static constexpr bool DIRECT = true;
+	static constexpr int NV = 6;   // n_genes, req_genes, req_umis, total_umis, total_reads, n_rows
 	static constexpr unsigned OR_MASK = 0;
 	const unsigned long long *cg_key;
 	const uint32_t *n_all, *n_req, *reads_all;
@@ -203,6 +225,7 @@ struct CellGeneToCells {
 	unsigned long long gene_mask;
 	uint32_t *cell_cg_begin;
 	uint32_t *out[NV];
+	__device__ uint32_t direct_index(unsigned long long key) const { return uint32_t(key); }
 	__device__ unsigned long long seg_key(uint32_t i) const { return cg_key[i] >> gene_bits; }
 	__device__ void load(uint32_t i, uint32_t (&v)[NV]) const {
 		const bool nogene = (cg_key[i] & gene_mask) == gene_mask;
@@ -212,8 +235,25 @@ struct CellGeneToCells {
 		v[2] = nogene ? 0u : rq;
 		v[3] = nogene ? 0u : n_all[i];
 		v[4] = nogene ? 0u : reads_all[i];
+		v[5] = 1u;
 	}
 	__device__ void write_head(uint32_t o, uint32_t i, unsigned long long) const { cell_cg_begin[o] = i; }
+};
+
+// re-keyed molecules (sorted by their new key; value = index of the molecule in the old table) -> molecules
+struct RekeyedToMolecules {
+	static constexpr bool DIRECT = false;
+	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
+	static constexpr int NV = 2;
+	static constexpr unsigned OR_MASK = 0x2;
+	const unsigned long long *keys;
+	const uint32_t *idx;
+	const uint32_t *old_reads, *old_mark;
+	unsigned long long *mol_key;
+	uint32_t *out[NV];
+	__device__ unsigned long long seg_key(uint32_t i) const { return keys[i]; }
+	__device__ void load(uint32_t i, uint32_t (&v)[NV]) const { const uint32_t j = idx[i]; v[0] = old_reads[j]; v[1] = old_mark[j]; }
+	__device__ void write_head(uint32_t o, uint32_t, unsigned long long k) const { mol_key[o] = k; }
 };
 
 }  // namespace dropest

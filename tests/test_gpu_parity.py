@@ -125,3 +125,103 @@ def test_sortedness_and_checksum_at_scale():
     real = rows["is_real"].astype(bool)
     assert int(v.astype(np.int64).sum()) == int(rows["total_umis"][real].astype(np.int64).sum())
     dev.free()
+
+
+# ---------------------------------------------------------------------------------------------------
+# CB merge against a whitelist (RealBarcodesMergeStrategy)
+# ---------------------------------------------------------------------------------------------------
+import os
+
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dropest_amd", "data", "barcodes")
+
+FIXTURE_READS = [   # Tests/TestEstimation.cpp:49-74 (struct Fixture)
+    ("AAATTAGGTCCA", "AAACCT", "Gene1"), ("AAATTAGGTCCA", "CCCCCT", "Gene2"), ("AAATTAGGTCCA", "ACCCCT", "Gene3"),
+    ("AAATTAGGTCCA", "ACCCCT", "Gene4"), ("AAATTAGGTCCC", "CAACCT", "Gene1"), ("AAATTAGGTCCC", "CAACCT", "Gene10"),
+    ("AAATTAGGTCCC", "CAACCT", "Gene20"), ("AAATTAGGTCCG", "CAACCT", "Gene1"), ("AAATTAGGTCGG", "AAACCT", "Gene1"),
+    ("AAATTAGGTCGG", "CCCCCT", "Gene2"), ("CCCTTAGGTCCA", "CCATTC", "Gene3"), ("CCCTTAGGTCCA", "CCCCCT", "Gene2"),
+    ("CCCTTAGGTCCA", "ACCCCT", "Gene3"), ("CAATTAGGTCCG", "CAACCT", "Gene1"), ("CAATTAGGTCCG", "AAACCT", "Gene1"),
+    ("CAATTAGGTCCG", "CCCCCT", "Gene2"), ("AAAAAAAAAAAA", "CCCCCT", "Gene2"),
+]
+
+
+def _pack_reads(reads):
+    genes = {}
+    cb = np.array([capi.pack_seq(r[0]) for r in reads], np.uint64)
+    umi = np.array([capi.pack_seq(r[1]) for r in reads], np.uint64)
+    gene = np.array([genes.setdefault(r[2], len(genes)) for r in reads], np.uint32)
+    aux = np.full(len(reads), 2 << 16, np.uint32)
+    return cb, umi, gene, aux, list(genes)
+
+
+def test_reference_fixture_merge_by_real_barcodes():
+    """Tests/TestEstimation.cpp:227-280 (testRealNeighbours, testMergeByRealBarcodes) through the C-ABI on the GPU."""
+    cb, umi, gene, aux, names = _pack_reads(FIXTURE_READS)
+    kw = dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_INDROP,
+              barcodes_file=os.path.join(DATA, "test_est"), min_genes_before_merge=0, min_genes_after_merge=0,
+              max_cb_merge_edit_distance=7, min_merge_fraction=0.0)
+    c = capi.Context(**kw)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_initialized()
+    assert [c.merge_target(i) for i in range(6)] == [0, 1, 1, 0, 0, 0]          # :227-235
+    assert c.merge_target(6) == -1
+    c.merge_and_filter()
+    assert c.total_cells_number() == 7
+    f = c.filtered_cells()
+    assert len(f) == 2
+    rows = c.cell_rows()
+    assert rows["n_genes"][int(f[0])] == 3 and rows["n_genes"][int(f[1])] == 4
+    assert list(rows["is_merged"]) == [0, 0, 1, 1, 1, 1, 0]
+    assert int(rows["is_excluded"].sum()) == 1
+    assert list(c.merge_targets()) == [0, 1, 1, 0, 0, 0, 6]
+
+    def mol(cell):
+        g, u, r, m = c.cell_molecules(cell)
+        out = {}
+        for gi, ui, ri in zip(g, u, r):
+            out.setdefault(names[int(gi)], {})[capi.unpack_code(ui)] = int(ri)
+        return out
+    m0, m1 = mol(int(f[0])), mol(int(f[1]))
+    assert m0["Gene1"] == {"CAACCT": 2}
+    assert m1["Gene1"] == {"AAACCT": 3, "CAACCT": 1} and m1["Gene2"] == {"CCCCCT": 4}
+    assert m1["Gene3"] == {"ACCCCT": 2, "CCATTC": 1}
+    # and everything else against the oracle
+    o = parity.oracle_run(Oracle, dict(merge_kind=1, barcodes_kind=0, barcodes_file=os.path.join(DATA, "test_est"),
+                                       min_genes_before=0, min_genes_after=0, max_cb_merge_ed=7, min_merge_fraction=0.0),
+                          cb, umi, gene, aux)
+    parity.compare(o, c)
+
+
+def _both_merge(stream_kw, n_reads, min_before, min_after, whitelist, kind, frac=0.2):
+    s = SynthStream(n_reads=n_reads, whitelist=whitelist, **stream_kw)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    path = os.path.join(DATA, whitelist)
+    o = parity.oracle_run(Oracle, dict(merge_kind=1, barcodes_kind=kind, barcodes_file=path, min_genes_before=min_before,
+                                       min_genes_after=min_after, min_merge_fraction=frac), cb, umi, gene, aux)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=kind, barcodes_file=path,
+                            min_genes_before_merge=min_before, min_genes_after_merge=min_after,
+                            min_merge_fraction=frac), cb, umi, gene, aux)
+    parity.compare(o, c)
+    return o, c
+
+
+def test_c3_shape_merge_10x_whitelist():
+    """10x v3 shape with Hamming-1 neighbour barcodes and -m + whitelist (C3 scaled down)."""
+    o, c = _both_merge(dict(n_cells=30, n_genes=2000, umi_len=12, permille_neighbour=150), 200_000, 3, 20,
+                       "10x_aug_2016_split", capi.BARCODES_CONST)
+    mt = c.merge_targets()
+    assert int((mt != np.arange(len(mt))).sum()) > 50          # neighbours really merged
+    assert int(c.cell_rows()["is_excluded"].sum()) > 0         # and unrelated barcodes excluded
+
+
+def test_c4_shape_merge_indrop_v3_whitelist():
+    """inDrop v3 shape: split 8+8 barcode, UMI 8, const-length parser (C4 scaled down)."""
+    o, c = _both_merge(dict(n_cells=25, n_genes=1500, umi_len=8, permille_neighbour=120), 120_000, 3, 10,
+                       "indrop_v3", capi.BARCODES_CONST)
+    mt = c.merge_targets()
+    assert int((mt != np.arange(len(mt))).sum()) > 20
+
+
+def test_merge_zero_fraction_threshold_order_dependence():
+    """min_merge_fraction = 0: candidates with an empty intersection still win (first in the reference's order)."""
+    _both_merge(dict(n_cells=20, n_genes=800, umi_len=10, permille_neighbour=200), 60_000, 2, 5,
+                "10x_aug_2016_split", capi.BARCODES_CONST, frac=0.0)
