@@ -59,6 +59,8 @@ inline bool encode_code(const std::string &s, u64 &code) {   // false: needs an 
 	return true;
 }
 
+struct UmiOverride { u64 umi; u32 reads; uint8_t mark; };   // molecule of a group re-keyed by the N-UMI merge
+
 struct HostCell {   // host mirror of one REAL-candidate cell (n_genes >= min_genes_before_merge at init)
 	u32 id;
 	CellRowPod row;         // sizes as of the last device update + stat adjustments
@@ -122,6 +124,8 @@ struct dropest_ctx {
 	dropest::DevBuf<u64> mol_key2;           // re-keyed molecule table (swapped in after a merge)
 	dropest::DevBuf<u32> mol_reads2, mol_mark2, remap;
 	std::unordered_map<u32, u32> reassign;   // merged cell -> final target (MergeStrategyBase cb_reassign_targets, sparse)
+	// (cell, gene) groups rewritten by the N-UMI merge: key = molecule key >> umi_bits, value = the group's molecules
+	std::unordered_map<u64, std::vector<dropest::UmiOverride>> umi_overrides;
 
 	// scratch
 	dropest::DevBuf<u32> tile_counts, tile_prefix, scalars, rs_hist, rs_row_total, rs_digit_base;
@@ -175,6 +179,7 @@ struct dropest_ctx {
 	std::vector<long> compute_merge_targets(const std::vector<u32> &cells);
 	void run_cb_merge_real();
 	void reaggregate_after_merge();
+	void run_umi_merge_simple();
 	void fetch_real_cells();
 	void sort_filtered(u32 genes_threshold, int max_cells);
 	void emit_matrix(bool filtered_m, bool reads_output);

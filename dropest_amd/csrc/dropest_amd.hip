@@ -74,6 +74,7 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 	if (c.device < 0 || c.device >= ndev) throw InvalidError("device ordinal out of range");
 	HIP_CHECK(hipSetDevice(c.device));
 	HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+	srand(42);   // MergeUMIsStrategySimple's constructor (MergeUMIsStrategySimple.cpp:15-19): random fills use glibc rand()
 }
 
 dropest_ctx::~dropest_ctx() {
@@ -138,7 +139,7 @@ void dropest_ctx::concat_chunks() {
 void dropest_ctx::free_results() {
 	initialized = merged = false;
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
-	real.clear(); real_index_of.clear(); filtered.clear(); merge_pairs.clear(); reassign.clear(); n_real_now = 0;
+	real.clear(); real_index_of.clear(); filtered.clear(); merge_pairs.clear(); reassign.clear(); umi_overrides.clear(); n_real_now = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -456,6 +457,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 }
 
 #include "merge_host.h"
+#include "umi_merge_host.h"
 
 // ------------------------------------------------------------------------------------------------
 // top-level stages
@@ -479,9 +481,8 @@ void dropest_ctx::run_set_initialized() {
 void dropest_ctx::run_merge_and_filter() {
 	if (!initialized) throw InvalidError("You must initialize container");
 	if (merged) throw InvalidError("merge_and_filter was already run");
-	if (ingest.umi_escape_max_plus1 != 0)
-		throw UnsupportedError("UMIs with N (escaped codes) are not handled yet in this revision");
 	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells) run_cb_merge_real();
+	run_umi_merge_simple();   // MergeUMIsStrategySimple::merge, after the CB merge (CellsDataContainer.cpp:45)
 	sort_filtered(min_after, cfg.max_cells);   // CellsDataContainer.cpp:47-49
 	merged = true;
 	collect_timings();
@@ -527,6 +528,29 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output) {
 	HIP_CHECK(hipMemcpyAsync(M.h_val.p, M.d_val.p, nnz * 4, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));   // col_cell (host vector) must outlive the H2D copy
 	collect_timings();
+}
+
+// Walks a fetched slice of the molecule table in order, skipping the pseudo rows of gene-less reads and replacing
+// the groups that the N-UMI merge rewrote by their host-side contents.
+template <class F>
+static void for_each_molecule(dropest_ctx *ctx, const std::vector<u64> &k, const std::vector<u32> &r, const std::vector<u32> &m, F &&emit) {
+	const KeyLayout &L = ctx->layout;
+	const u64 umask = L.umi_bits ? ((1ull << L.umi_bits) - 1ull) : 0ull;
+	u64 done_group = ~0ull;
+	for (size_t i = 0; i < k.size(); ++i) {
+		const u64 cg = k[i] >> L.umi_bits;
+		const u64 g = cg & L.gene_none;
+		if (g == L.gene_none) continue;   // reads without a gene never form molecules
+		const u32 c = u32(cg >> L.gene_bits);
+		if (!ctx->umi_overrides.empty()) {
+			auto it = ctx->umi_overrides.find(cg);
+			if (it != ctx->umi_overrides.end()) {
+				if (done_group != cg) { for (const UmiOverride &o : it->second) emit(c, u32(g), o.umi, o.reads, o.mark); done_group = cg; }
+				continue;
+			}
+		}
+		emit(c, u32(g), ctx->unmap_umi(k[i] & umask), r[i], uint8_t(m[i]));
+	}
 }
 
 // ================================================================================================
@@ -754,15 +778,11 @@ dropest_status dropest_molecules(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, 
 		const KeyLayout &L = ctx->layout;
 		const u64 umask = L.umi_bits ? ((1ull << L.umi_bits) - 1ull) : 0ull;
 		uint64_t cnt = 0;
-		for (size_t i = 0; i < k.size(); ++i) {
-			const u64 g = (k[i] >> L.umi_bits) & L.gene_none;
-			if (g == L.gene_none) continue;   // reads without a gene never form molecules
-			if (cell) {
-				cell[cnt] = u32(k[i] >> (L.umi_bits + L.gene_bits)); gene[cnt] = u32(g);
-				umi[cnt] = ctx->unmap_umi(k[i] & umask); reads[cnt] = r[i]; mark[cnt] = uint8_t(m[i]);
-			}
+		for_each_molecule(ctx, k, r, m, [&](u32 c, u32 g, u64 u, u32 rd, uint8_t mk) {
+			if (cell) { cell[cnt] = c; gene[cnt] = g; umi[cnt] = u; reads[cnt] = rd; mark[cnt] = mk; }
 			++cnt;
-		}
+		});
+		(void)umask; (void)L;
 		*n = cnt;
 	});
 }
@@ -784,12 +804,11 @@ dropest_status dropest_cell_molecules(dropest_ctx *ctx, uint64_t cell_id, uint64
 		const KeyLayout &L = ctx->layout;
 		const u64 umask = L.umi_bits ? ((1ull << L.umi_bits) - 1ull) : 0ull;
 		uint64_t cnt = 0;
-		for (size_t i = 0; i < k.size(); ++i) {
-			const u64 g = (k[i] >> L.umi_bits) & L.gene_none;
-			if (g == L.gene_none) continue;
-			if (gene) { gene[cnt] = u32(g); umi[cnt] = ctx->unmap_umi(k[i] & umask); reads[cnt] = r[i]; mark[cnt] = uint8_t(m[i]); }
+		for_each_molecule(ctx, k, r, m, [&](u32, u32 g, u64 u, u32 rd, uint8_t mk) {
+			if (gene) { gene[cnt] = g; umi[cnt] = u; reads[cnt] = rd; mark[cnt] = mk; }
 			++cnt;
-		}
+		});
+		(void)umask; (void)L;
 		*n = cnt;
 	});
 }

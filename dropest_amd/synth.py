@@ -102,11 +102,13 @@ class SynthStream:
         return arrs
 
 
-def inject_n(umi, rate, seed, umi_len):
-    """Replaces one base of a fraction `rate` of the UMIs by N: returns (codes with escapes, side strings)."""
+def inject_n(umi, gene, rate, seed, umi_len):
+    """Replaces one base of a fraction `rate` of the UMIs of gene-bearing reads by N: returns (codes with
+    escapes, side strings).  Side strings are registered in first-seen order over gene-bearing reads, which is
+    what the C-ABI requires (the UMI of a read without a gene is ignored and must not be registered)."""
     rng = np.random.default_rng(seed)
     umi = umi.copy()
-    hit = np.nonzero(rng.random(len(umi)) < rate)[0]
+    hit = np.nonzero((rng.random(len(umi)) < rate) & (gene != capi.NO_GENE))[0]
     side, index = [], {}
     for i in hit:
         s = list(capi.unpack_code(umi[i]))

@@ -21,7 +21,12 @@
  *                   sentinel 1 bit above the top base: code = (1 << 2*len) | bases, len <= 31.
  *                   Strings that do not fit (an 'N', other letters, len > 31) are ESCAPED:
  *                   code = DROPEST_ESCAPE | k, k = index into the side-string table registered with
- *                   dropest_set_side_strings() (first-seen order, one table for barcodes and UMIs).
+ *                   dropest_set_side_strings().  The table is shared by barcodes and UMIs; entries used as
+ *                   UMIs MUST be registered in the order in which those UMI strings first occur on
+ *                   gene-bearing reads (= their StringIndexer order, Gene.cpp:19): the N-UMI merge inserts
+ *                   them into a std::unordered_set in that order (MergeUMIsStrategySimple.cpp:31-41) and
+ *                   the random fills depend on it.  The umi[] entry of a read WITHOUT a gene is ignored
+ *                   (such reads never reach Gene::add_umi) and must not register a side string.
  *   gene[i]       : dense id of the gene NAME in first-seen order over gene-bearing reads
  *                   (= StringIndexer ids, Estimation/StringIndexer.cpp:10-18), DROPEST_NO_GENE when the
  *                   read has no gene (ReadInfo::gene empty, CellsDataContainer.cpp:73-78).

@@ -225,3 +225,84 @@ def test_merge_zero_fraction_threshold_order_dependence():
     """min_merge_fraction = 0: candidates with an empty intersection still win (first in the reference's order)."""
     _both_merge(dict(n_cells=20, n_genes=800, umi_len=10, permille_neighbour=200), 60_000, 2, 5,
                 "10x_aug_2016_split", capi.BARCODES_CONST, frac=0.0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# UMIs containing N (MergeUMIsStrategySimple)
+# ---------------------------------------------------------------------------------------------------
+from dropest_amd.synth import inject_n
+
+
+def _pack_with_escapes(reads):
+    genes, side, index = {}, [], {}
+    def code(s):
+        c = capi.pack_seq(s)
+        if c is not None:
+            return c
+        k = index.get(s)
+        if k is None:
+            k = index[s] = len(side)
+            side.append(s)
+        return capi.ESCAPE | k
+    cb = np.array([code(r[0]) for r in reads], np.uint64)
+    umi = np.array([code(r[1]) for r in reads], np.uint64)
+    gene = np.array([genes.setdefault(r[2], len(genes)) for r in reads], np.uint32)
+    aux = np.full(len(reads), 2 << 16, np.uint32)
+    return cb, umi, gene, aux, list(genes), side
+
+
+def test_reference_fixture_umi_merge_strategy_simple():
+    """Tests/TestEstimation.cpp:505-540 testUMIMergeStrategySimple through the C-ABI."""
+    cbs = "AAATTAGGTCCA"
+    reads = [(cbs, u, "Gene1") for u in ["AAACCT", "AAACCT", "AAACCG", "AAACCN", "CCCCCT", "ACCCCT"]]
+    reads += [(cbs, u, "Gene2") for u in ["TTTTTT", "TTTNNG", "TTGNNG", "ACCCCT", "NNNNNN"]]
+    cb, umi, gene, aux, names, side = _pack_with_escapes(reads)
+    c = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
+    c.set_side_strings(side)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_initialized(); c.merge_and_filter()
+    g, u, r, m = c.cell_molecules(0)
+    mol = {}
+    for gi, ui, ri in zip(g, u, r):
+        mol.setdefault(names[int(gi)], {})[capi.unpack_code(ui, side)] = int(ri)
+    assert len(mol["Gene1"]) == 4 and len(mol["Gene2"]) == 3
+    assert mol["Gene1"] == {"AAACCT": 3, "AAACCG": 1, "CCCCCT": 1, "ACCCCT": 1}
+    assert "TTTTTT" in mol["Gene2"] and "ACCCCT" in mol["Gene2"]
+    assert all("N" not in x for x in mol["Gene2"])
+    o = parity.oracle_run(Oracle, dict(min_genes_before=0, min_genes_after=0), cb, umi, gene, aux, side)
+    parity.compare(o, c, side)          # includes the glibc rand() fills and the TOTAL_UMIS decrements
+
+
+def test_survey_probe_random_fill():
+    """SURVEY.md §7 probe: gene {ACGTCC, NNNNAA} ends as {ACGTCC, GACCAA}, umis_number() == 1."""
+    reads = [("AAAA", "ACGTCC", "G"), ("AAAA", "NNNNAA", "G")]
+    cb, umi, gene, aux, names, side = _pack_with_escapes(reads)
+    c = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
+    c.set_side_strings(side); c.push_reads(cb, umi, gene, aux)
+    c.set_initialized(); c.merge_and_filter()
+    g, u, r, m = c.cell_molecules(0)
+    assert sorted(capi.unpack_code(x, side) for x in u) == ["ACGTCC", "GACCAA"]
+    assert c.cell_rows()["total_umis"][0] == 1
+
+
+@pytest.mark.parametrize("rate,n_reads", [(1e-2, 120_000), (1e-3, 600_000)])
+def test_n_umis_synthetic(rate, n_reads):
+    s = SynthStream(n_reads=n_reads, n_cells=40, n_genes=1500, umi_len=8)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    umi, side = inject_n(umi, gene, rate, 7, 8)
+    assert len(side) > 20
+    o = parity.oracle_run(Oracle, dict(min_genes_before=10, min_genes_after=20), cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(min_genes_before_merge=10, min_genes_after_merge=20), cb, umi, gene, aux, side)
+    parity.compare(o, c, side)
+
+
+def test_n_umis_with_cb_merge():
+    s = SynthStream(n_reads=150_000, n_cells=25, n_genes=1200, umi_len=8, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    umi, side = inject_n(umi, gene, 5e-3, 11, 8)
+    path = os.path.join(DATA, "10x_aug_2016_split")
+    o = parity.oracle_run(Oracle, dict(merge_kind=1, barcodes_kind=1, barcodes_file=path, min_genes_before=3,
+                                       min_genes_after=10), cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST, barcodes_file=path,
+                            min_genes_before_merge=3, min_genes_after_merge=10), cb, umi, gene, aux, side)
+    parity.compare(o, c, side)
