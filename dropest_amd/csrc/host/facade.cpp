@@ -1,0 +1,355 @@
+// facade.cpp -- see facade.h.  Host-side packing and result relaying only; no counting happens here.
+#include "facade.h"
+
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+
+namespace Tools {
+ReadParameters ReadParameters::parse_encoded_id(const std::string &encoded_id) {   // Tools/ReadParameters.cpp:42-56
+	const size_t umi_pos = encoded_id.rfind('#');
+	if (umi_pos == std::string::npos) throw std::runtime_error("ERROR: unable to parse out UMI in: " + encoded_id);
+	const size_t cb_pos = encoded_id.rfind('!', umi_pos);
+	if (cb_pos == std::string::npos) throw std::runtime_error("ERROR: unable to parse out cell barcode in: " + encoded_id);
+	return ReadParameters(encoded_id.substr(cb_pos + 1, umi_pos - cb_pos - 1), encoded_id.substr(umi_pos + 1));
+}
+}  // namespace Tools
+
+namespace Estimation {
+
+const std::string UMI::Mark::DEFAULT_CODE = "eEBA";
+
+UMI::Mark UMI::Mark::get_by_code(char code) {   // UMI.cpp:123-154
+	Mark m;
+	switch (code) {
+		case 'e': m.add(HAS_EXONS); break;
+		case 'i': m.add(HAS_INTRONS); break;
+		case 'E': m.add(HAS_EXONS); m.add(HAS_NOT_ANNOTATED); break;
+		case 'I': m.add(HAS_INTRONS); m.add(HAS_NOT_ANNOTATED); break;
+		case 'B': m.add(HAS_EXONS); m.add(HAS_INTRONS); break;
+		case 'A': m.add(HAS_EXONS); m.add(HAS_INTRONS); m.add(HAS_NOT_ANNOTATED); break;
+		default: throw std::runtime_error(std::string("Unexpected gene match levels: ") + code);
+	}
+	return m;
+}
+UMI::Mark::query_t UMI::Mark::get_by_code(const std::string &code) {
+	query_t q;
+	for (char c : code) q.push_back(get_by_code(c));
+	return q;
+}
+std::string UMI::Mark::to_code(const query_t &levels) {
+	std::string s;
+	for (auto const &l : levels) {
+		switch (l.bits()) {
+			case 2: s += 'e'; break; case 4: s += 'i'; break; case 3: s += 'E'; break; case 5: s += 'I'; break;
+			case 6: s += 'B'; break; case 7: s += 'A'; break;
+			default: throw std::runtime_error("Unexpected gene match level");
+		}
+	}
+	return s;
+}
+
+// ---- 2-bit codes ----
+static bool pack2(const std::string &s, uint64_t &code) {
+	if (s.empty() || s.size() > 31) return false;
+	uint64_t c = 1;
+	for (char ch : s) {
+		uint64_t b;
+		switch (ch) { case 'A': b = 0; break; case 'C': b = 1; break; case 'G': b = 2; break; case 'T': b = 3; break; default: return false; }
+		c = (c << 2) | b;
+	}
+	code = c;
+	return true;
+}
+std::string CellsDataContainer::decode(uint64_t code) const {
+	if (code & DROPEST_ESCAPE) return _side.at(size_t(code & ~DROPEST_ESCAPE));
+	if (!code) return std::string();
+	const int len = (63 - __builtin_clzll(code)) / 2;
+	std::string s(size_t(len), 'A');
+	for (int i = 0; i < len; ++i) s[size_t(i)] = "ACGT"[(code >> (2 * (len - 1 - i))) & 3];
+	return s;
+}
+uint64_t CellsDataContainer::encode(const std::string &s, std::unordered_map<std::string, uint64_t> &escapes) {
+	uint64_t code;
+	if (pack2(s, code)) return code;
+	auto it = escapes.find(s);
+	if (it != escapes.end()) return it->second;
+	code = DROPEST_ESCAPE | uint64_t(_side.size());
+	_side.push_back(s);
+	escapes.emplace(s, code);
+	return code;
+}
+
+void CellsDataContainer::fail(dropest_status st) const {
+	const std::string msg = dropest_last_error();
+	if (st == DROPEST_ERR_RANGE) throw std::out_of_range(msg);
+	throw std::runtime_error(msg);
+}
+
+CellsDataContainer::CellsDataContainer(const std::shared_ptr<Merge::MergeStrategyAbstract> &merge_strategy,
+                                       const std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> &umi_merge_strategy,
+                                       const std::vector<UMI::Mark> &gene_match_levels, bool /*save_umi_merge_targets*/,
+                                       int max_cells_num, int device)
+	: _merge_strategy(merge_strategy), _umi_merge_strategy(umi_merge_strategy), _query_marks(gene_match_levels) {
+	dropest_cfg cfg;
+	dropest_cfg_defaults(&cfg);
+	cfg.device = device;
+	merge_strategy->fill(cfg);
+	umi_merge_strategy->fill(cfg);
+	cfg.min_genes_before_merge = int(merge_strategy->min_genes_before_merge());
+	cfg.min_genes_after_merge = int(merge_strategy->min_genes_after_merge());
+	const std::string levels = UMI::Mark::to_code(gene_match_levels);
+	cfg.gene_match_levels = levels.c_str();
+	cfg.max_cells = max_cells_num;
+	check(dropest_ctx_create(&cfg, &_ctx));
+}
+
+CellsDataContainer::~CellsDataContainer() { dropest_ctx_destroy(_ctx); }
+
+void CellsDataContainer::add_record(const ReadInfo &r) {   // CellsDataContainer.cpp:59-88
+	if (_is_initialized) throw std::runtime_error("Container is already initialized");
+	const uint8_t mark = uint8_t(r.umi_mark.bits());
+	const bool has_gene = !r.gene.empty();
+	_cb.push_back(encode(r.params.cell_barcode(), _side_cb));
+	uint32_t chr = 0;
+	if (has_gene) {
+		// UMI::add_read checks the quality length per molecule (UMI.cpp:26-28); here: one length per container
+		const size_t ql = r.params.umi_quality().size();
+		if (_umi_quality_length == size_t(-1)) _umi_quality_length = ql;
+		else if (ql != _umi_quality_length)
+			throw std::runtime_error("Wrong quality length: " + std::to_string(ql) + ", expected: " + std::to_string(_umi_quality_length));
+		_umi.push_back(encode(r.params.umi(), _side_umi));   // UMI side strings: first seen on gene-bearing reads only
+		_gene.push_back(uint32_t(_gene_indexer.add(r.gene)));
+		// Stats::inc(chr) is reached only for exon / intron reads (CellsDataContainer.cpp:312-321)
+		if (mark & (UMI::Mark::HAS_EXONS | UMI::Mark::HAS_INTRONS)) chr = uint32_t(_chr_indexer.add(r.chromosome_name));
+	} else {
+		_umi.push_back(1);   // ignored by the device for gene-less reads
+		_gene.push_back(DROPEST_NO_GENE);
+		chr = uint32_t(_chr_indexer.add(r.chromosome_name));   // :75
+	}
+	if (chr > 0xFFFF) throw std::runtime_error("more than 65536 chromosome names");
+	_aux.push_back(chr | (uint32_t(mark) << 16));
+	if (_cb.size() >= BATCH) flush();
+}
+
+void CellsDataContainer::flush() {
+	if (_cb.empty()) return;
+	std::vector<const char *> ptrs(_side.size());
+	for (size_t i = 0; i < _side.size(); ++i) ptrs[i] = _side[i].c_str();
+	check(dropest_set_side_strings(_ctx, ptrs.data(), ptrs.size()));
+	check(dropest_push_reads(_ctx, _cb.data(), _umi.data(), _gene.data(), _aux.data(), _cb.size()));
+	_cb.clear(); _umi.clear(); _gene.clear(); _aux.clear();
+}
+
+void CellsDataContainer::set_initialized() {   // CellsDataContainer.cpp:163-175
+	if (_is_initialized) throw std::runtime_error("Container is already initialized");
+	flush();
+	check(dropest_set_initialized(_ctx));
+	_is_initialized = true;
+}
+
+void CellsDataContainer::merge_and_filter() {   // CellsDataContainer.cpp:39-57
+	if (!_is_initialized) throw std::runtime_error("You must initialize container");
+	check(dropest_merge_and_filter(_ctx));
+}
+
+size_t CellsDataContainer::total_cells_number() const { uint64_t n = 0; check(dropest_total_cells(_ctx, &n)); return size_t(n); }
+size_t CellsDataContainer::real_cells_number() const { uint64_t n = 0; check(dropest_real_cells(_ctx, &n)); return size_t(n); }
+
+size_t CellsDataContainer::cell_id_by_cb(const std::string &barcode) const {
+	uint64_t code;
+	if (!pack2(barcode, code)) {
+		auto it = _side_cb.find(barcode);
+		if (it == _side_cb.end()) throw std::out_of_range("unknown barcode: " + barcode);
+		code = it->second;
+	}
+	int64_t id = -1;
+	check(dropest_cell_id_by_cb(_ctx, code, &id));
+	if (id < 0) throw std::out_of_range("unknown barcode: " + barcode);
+	return size_t(id);
+}
+
+const CellsDataContainer::ids_t &CellsDataContainer::filtered_cells() const {
+	uint64_t n = 0;
+	check(dropest_filtered_cells(_ctx, &n, nullptr));
+	std::vector<uint64_t> ids(n);
+	if (n) check(dropest_filtered_cells(_ctx, &n, ids.data()));
+	_filtered_cache.assign(ids.begin(), ids.end());
+	return _filtered_cache;
+}
+
+const CellsDataContainer::ids_t &CellsDataContainer::merge_targets() const {
+	uint64_t n = 0;
+	check(dropest_merge_targets(_ctx, &n, nullptr, nullptr));
+	std::vector<uint64_t> src(n), tgt(n);
+	if (n) check(dropest_merge_targets(_ctx, &n, src.data(), tgt.data()));
+	_merge_targets_cache.resize(total_cells_number());
+	for (size_t i = 0; i < _merge_targets_cache.size(); ++i) _merge_targets_cache[i] = i;
+	for (size_t i = 0; i < n; ++i) _merge_targets_cache[size_t(src[i])] = size_t(tgt[i]);
+	return _merge_targets_cache;
+}
+
+long CellsDataContainer::get_merge_target(size_t base_cell_ind) const {
+	int64_t t = 0;
+	check(dropest_merge_target(_ctx, base_cell_ind, &t));
+	return long(t);
+}
+
+Cell CellsDataContainer::cell(size_t index) const {
+	Cell c;
+	c._owner = this; c._id = index;
+	check(dropest_cell_rows(_ctx, index, 1, &c._row));   // DROPEST_ERR_RANGE -> std::out_of_range (vector::at in the reference)
+	c._barcode = decode(c._row.barcode);
+	return c;
+}
+
+CellsDataContainer::s_i_hash_t CellsDataContainer::get_stat_by_real_cells(Stats::CellStatType type) const {   // :278-289
+	s_i_hash_t res;
+	const size_t n = total_cells_number();
+	std::vector<dropest_cell_row> rows(n);
+	if (n) check(dropest_cell_rows(_ctx, 0, n, rows.data()));
+	for (auto const &r : rows)
+		if (r.is_real) res[decode(r.barcode)] = type == Stats::TOTAL_READS_PER_CB ? r.total_reads : r.total_umis;
+	return res;
+}
+
+void CellsDataContainer::get_stat_by_real_cells(Stats::CellChrStatType stat, names_t &cell_barcodes, names_t &chromosome_names,
+                                                counts_t &counts) const {   // :291-307, chromosomes in first-seen order
+	uint64_t n = 0;
+	check(dropest_chr_stats(_ctx, &n, nullptr, nullptr, nullptr, nullptr));
+	std::vector<uint32_t> cell(n), kind(n), chr(n);
+	std::vector<int32_t> cnt(n);
+	if (n) check(dropest_chr_stats(_ctx, &n, cell.data(), kind.data(), chr.data(), cnt.data()));
+	std::vector<char> present(_chr_indexer.values().size(), 0);
+	for (size_t i = 0; i < n; ++i) if (kind[i] == uint32_t(stat)) present[chr[i]] = 1;
+	std::vector<int> column(present.size(), -1);
+	for (size_t c = 0; c < present.size(); ++c) if (present[c]) { column[c] = int(chromosome_names.size()); chromosome_names.push_back(_chr_indexer.get_value(c)); }
+	const size_t width = chromosome_names.size();
+	size_t i = 0;
+	while (i < n) {
+		const uint32_t cur = cell[i];
+		std::vector<int> row(width, 0);
+		bool any = false;
+		for (; i < n && cell[i] == cur; ++i)
+			if (kind[i] == uint32_t(stat)) { row[size_t(column[chr[i]])] = cnt[i]; any = true; }
+		if (!any) continue;   // Stats::get returns false for a cell without entries of this kind (Stats.cpp:50-63)
+		this->cell(cur);      // (validates the id)
+		cell_barcodes.push_back(decode(this->cell(cur)._row.barcode));
+		counts.insert(counts.end(), row.begin(), row.end());
+	}
+}
+
+static uint64_t counter(dropest_ctx *ctx, int i) { uint64_t c[4] = {0, 0, 0, 0}; if (dropest_global_counters(ctx, c) != DROPEST_OK) throw std::runtime_error(dropest_last_error()); return c[i]; }
+size_t CellsDataContainer::intergenic_reads_num() const { return size_t(counter(_ctx, 0)); }
+size_t CellsDataContainer::has_exon_reads_num() const { return size_t(counter(_ctx, 1)); }
+size_t CellsDataContainer::has_intron_reads_num() const { return size_t(counter(_ctx, 2)); }
+size_t CellsDataContainer::has_not_annotated_reads_num() const { return size_t(counter(_ctx, 3)); }
+
+std::vector<Cell::MoleculeRow> Cell::molecules() const {
+	uint64_t n = 0;
+	dropest_ctx *h = _owner->handle();
+	if (dropest_cell_molecules(h, _id, &n, nullptr, nullptr, nullptr, nullptr) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+	std::vector<uint32_t> gene(n), reads(n);
+	std::vector<uint64_t> umi(n);
+	std::vector<uint8_t> mark(n);
+	if (n && dropest_cell_molecules(h, _id, &n, gene.data(), umi.data(), reads.data(), mark.data()) != DROPEST_OK)
+		throw std::runtime_error(dropest_last_error());
+	std::vector<MoleculeRow> out;
+	for (size_t i = 0; i < n; ++i) {
+		UMI::Mark m;
+		if (mark[i] & 1) m.add(UMI::Mark::HAS_NOT_ANNOTATED);
+		if (mark[i] & 2) m.add(UMI::Mark::HAS_EXONS);
+		if (mark[i] & 4) m.add(UMI::Mark::HAS_INTRONS);
+		out.push_back(MoleculeRow{_owner->gene_indexer().get_value(gene[i]), _owner->decode(umi[i]), reads[i], m});
+	}
+	return out;
+}
+
+std::unordered_map<std::string, size_t> Cell::requested_umis_per_gene(const UMI::Mark::query_t &query, bool return_reads) const {
+	std::unordered_map<std::string, size_t> res;   // Cell.cpp:54-68: inserted in gene-index order
+	std::string cur; size_t acc = 0; bool open = false;
+	auto close = [&]() { if (open && acc) res.emplace(cur, acc); };
+	for (auto const &m : molecules()) {
+		if (!open || m.gene != cur) { close(); cur = m.gene; acc = 0; open = true; }
+		if (m.mark.match(query)) acc += return_reads ? m.read_count : 1;
+	}
+	close();
+	return res;
+}
+
+// ---- ResultsPrinter ---------------------------------------------------------------------------------
+ResultsPrinter::SparseMatrix ResultsPrinter::get_count_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order) const {
+	SparseMatrix M;
+	uint64_t ncols = 0, nnz = 0;
+	const uint32_t *colptr = nullptr, *rowidx = nullptr, *values = nullptr;
+	if (dropest_count_matrix_csc(c.handle(), filtered ? 1 : 0, reads_output ? 1 : 0, &ncols, &nnz, &colptr, &rowidx, &values) != DROPEST_OK)
+		throw std::runtime_error(dropest_last_error());
+	// column names: filtered cells in their order / real cells in cell-id order
+	if (filtered) { for (size_t id : c.filtered_cells()) M.col_names.push_back(c.cell(id).barcode()); }
+	else {
+		const size_t n = c.total_cells_number();
+		std::vector<dropest_cell_row> rows(n);
+		if (n && dropest_cell_rows(c.handle(), 0, n, rows.data()) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+		for (auto const &r : rows) if (r.is_real) M.col_names.push_back(c.decode(r.barcode));
+	}
+	M.colptr.assign(colptr, colptr + ncols + 1);
+	M.values.assign(values, values + nnz);
+	M.rowidx.resize(nnz);
+	const auto &genes = c.gene_indexer().values();
+	std::vector<uint32_t> row_of_gene(genes.size(), 0xFFFFFFFFu);
+	auto row_id = [&](uint32_t g) {
+		if (row_of_gene[g] == 0xFFFFFFFFu) { row_of_gene[g] = uint32_t(M.row_names.size()); M.row_names.push_back(genes[g]); }
+		return row_of_gene[g];
+	};
+	if (!reference_row_order) {
+		// rows = genes that occur, in gene-index order
+		std::vector<char> seen(genes.size(), 0);
+		for (uint64_t k = 0; k < nnz; ++k) seen[rowidx[k]] = 1;
+		for (uint32_t g = 0; g < genes.size(); ++g) if (seen[g]) row_id(g);
+		for (uint64_t k = 0; k < nnz; ++k) M.rowidx[k] = row_of_gene[rowidx[k]];
+		return M;
+	}
+	// the reference numbers rows on first encounter while walking, per cell, an unordered_map<string,size_t> that was
+	// filled in gene-index order (filtered: Cell.cpp:54-68) -- replayed here with the same container type; the raw
+	// matrix walks the std::map directly (gene-index order, ResultsPrinter.cpp:376-387).  Inside a column the entries
+	// are then sorted by row id (Eigen::setFromTriplets builds a CSC with ascending inner indices).
+	for (uint64_t col = 0; col < ncols; ++col) {
+		std::vector<std::pair<uint32_t, uint32_t>> entries;   // (row, value)
+		if (filtered) {
+			std::unordered_map<std::string, size_t> per_gene;
+			std::unordered_map<std::string, uint32_t> gene_of;
+			for (uint32_t k = colptr[col]; k < colptr[col + 1]; ++k) { per_gene.emplace(genes[rowidx[k]], values[k]); gene_of.emplace(genes[rowidx[k]], rowidx[k]); }
+			for (auto const &kv : per_gene) entries.emplace_back(row_id(gene_of.at(kv.first)), uint32_t(kv.second));
+		} else {
+			for (uint32_t k = colptr[col]; k < colptr[col + 1]; ++k) entries.emplace_back(row_id(rowidx[k]), values[k]);
+		}
+		std::sort(entries.begin(), entries.end());
+		for (uint32_t k = colptr[col], j = 0; k < colptr[col + 1]; ++k, ++j) { M.rowidx[k] = entries[j].first; M.values[k] = entries[j].second; }
+	}
+	return M;
+}
+
+void ResultsPrinter::save_mtx(const CellsDataContainer &c, const std::string &base) const {   // ResultsPrinter.cpp:81-91
+	const SparseMatrix M = get_count_matrix(c, true, true);
+	std::ofstream mtx(base + ".mtx");
+	if (!mtx) throw std::runtime_error("Can't open file: " + base + ".mtx");
+	// Matrix::writeMM of a dgCMatrix: coordinate / real / general, 1-based, column-major
+	mtx << "%%MatrixMarket matrix coordinate real general\n";
+	mtx << M.row_names.size() << ' ' << M.col_names.size() << ' ' << M.values.size() << '\n';
+	for (size_t col = 0; col + 1 < M.colptr.size(); ++col)
+		for (uint32_t k = M.colptr[col]; k < M.colptr[col + 1]; ++k) mtx << (M.rowidx[k] + 1) << ' ' << (col + 1) << ' ' << M.values[k] << '\n';
+	std::ofstream cells(base + ".cells.tsv"), genes(base + ".genes.tsv");
+	for (auto const &s : M.col_names) cells << s << '\n';
+	for (auto const &s : M.row_names) genes << s << '\n';
+}
+
+void ResultsPrinter::save_results(const CellsDataContainer &c, const std::string &filename) const {   // ResultsPrinter.cpp:23-79
+	std::string base = filename;
+	const size_t dot = filename.find_last_of('.');
+	if (dot != std::string::npos && filename.substr(dot + 1) == "rds") base = filename.substr(0, dot);
+	// The .rds container (R serialisation of list(cm, cm_raw, ...)) is not written yet; the matrix
+	// triple is what -w produces in the reference.
+	if (write_matrix) save_mtx(c, base);
+}
+
+}  // namespace Estimation

@@ -1,0 +1,256 @@
+// facade.h -- the reference's C++ surface for this path, re-created on top of the C-ABI (include/dropest_amd.h).
+//
+// A dropEst maintainer swaps Estimation/CellsDataContainer.h + Estimation/ResultsPrinter.h for this header:
+// same namespaces, class names, member names, argument meaning and exceptions (std::runtime_error for
+// call-order errors, std::out_of_range for bad indices), so dropest.cpp:239-254 / BamProcessor.cpp:18-21 compile
+// against it unchanged in spirit.  Everything below is plain host C++ that only PACKS
+// records (2-bit codes, first-seen dictionaries for gene / chromosome names) and RELAYS results; all counting,
+// de-duplication and merging happens on the GPU behind the C-ABI.
+//
+// Reference declarations mirrored here:
+//   Tools::ReadParameters           Tools/ReadParameters.h:9-50
+//   Estimation::UMI::Mark           Estimation/UMI.h:13-44
+//   Estimation::ReadInfo            Estimation/ReadInfo.h:9-24
+//   Estimation::Stats (enums)       Estimation/Stats.h:18-32
+//   Estimation::Merge::*Strategy    Estimation/Merge/{MergeStrategyAbstract.h,DummyMergeStrategy.h,RealBarcodesMergeStrategy.h}
+//   Estimation::CellsDataContainer  Estimation/CellsDataContainer.h:33-123
+//   Estimation::ResultsPrinter      Estimation/ResultsPrinter.h:59-62 (count matrices + MatrixMarket; .rds is "next")
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/dropest_amd.h"
+
+namespace Tools {
+class ReadParameters {
+	std::string _cb, _umi, _cb_quality, _umi_quality;
+public:
+	ReadParameters(const std::string &cell_barcode, const std::string &umi, const std::string &cell_barcode_quality = "",
+	               const std::string &umi_quality = "")
+		: _cb(cell_barcode), _umi(umi), _cb_quality(cell_barcode_quality), _umi_quality(umi_quality) {
+		if (cell_barcode.empty() || umi.empty())
+			throw std::runtime_error("Wrong read parameters: '" + cell_barcode + "' '" + umi + "'");
+	}
+	static ReadParameters parse_encoded_id(const std::string &encoded_id);   // "<id>!<CB>#<UMI>"
+	const std::string &cell_barcode() const { return _cb; }
+	const std::string &umi() const { return _umi; }
+	const std::string &cell_barcode_quality() const { return _cb_quality; }
+	const std::string &umi_quality() const { return _umi_quality; }
+};
+}  // namespace Tools
+
+namespace Estimation {
+
+class UMI {
+public:
+	class Mark {
+		char _mark;
+	public:
+		enum MarkType { NONE = 0, HAS_NOT_ANNOTATED = 1, HAS_EXONS = 2, HAS_INTRONS = 4 };
+		using query_t = std::vector<Mark>;
+		static const std::string DEFAULT_CODE;   // "eEBA"
+		explicit Mark(MarkType type = NONE) : _mark(char(type)) {}
+		void add(MarkType type) { _mark = char(_mark | type); }
+		void add(const Mark &m) { _mark = char(_mark | m._mark); }
+		bool check(MarkType type) const { return (_mark & type) != 0; }
+		bool match(const query_t &levels) const { for (auto const &l : levels) if (l._mark == _mark) return true; return false; }
+		bool operator==(const MarkType &o) const { return _mark == o; }
+		bool operator==(const Mark &o) const { return _mark == o._mark; }
+		char bits() const { return _mark; }
+		static Mark get_by_code(char code);
+		static query_t get_by_code(const std::string &code);
+		static std::string to_code(const query_t &levels);
+	};
+};
+
+class ReadInfo {
+public:
+	const Tools::ReadParameters params;
+	const std::string gene, chromosome_name;
+	const UMI::Mark umi_mark;
+	ReadInfo(const Tools::ReadParameters &p, const std::string &g, const std::string &chr, const UMI::Mark &m)
+		: params(p), gene(g), chromosome_name(chr), umi_mark(m) {}
+};
+
+struct Stats {
+	enum CellStatType { TOTAL_READS_PER_CB, TOTAL_UMIS_PER_CB, CELL_STAT_SIZE };
+	enum CellChrStatType { EXON_READS_PER_CHR_PER_CELL = 0, INTRON_READS_PER_CHR_PER_CELL, INTERGENIC_READS_PER_CHR_PER_CELL, CHROMOSOME_STAT_SIZE };
+};
+
+class StringIndexer {   // read-only view of a first-seen dictionary
+	std::vector<std::string> _values;
+	std::unordered_map<std::string, size_t> _index;
+public:
+	using index_t = size_t;
+	index_t add(const std::string &v) { auto it = _index.emplace(v, _index.size()); if (it.second) _values.push_back(v); return it.first->second; }
+	const std::string &get_value(index_t i) const { return _values.at(i); }
+	index_t get_index(const std::string &v) const { return _index.at(v); }
+	const std::vector<std::string> &values() const { return _values; }
+};
+
+namespace Merge {
+// Parameter carriers: the strategy objects of the reference own the merge algorithm; here the algorithm lives on the
+// device and these classes only say WHICH strategy with WHICH thresholds (MergeStrategyFactory.cpp:61-111).
+class MergeStrategyAbstract {
+	size_t _min_before, _min_after;
+public:
+	MergeStrategyAbstract(size_t min_genes_before_merge, size_t min_genes_after_merge)
+		: _min_before(min_genes_before_merge), _min_after(std::max(min_genes_after_merge, min_genes_before_merge)) {}
+	virtual ~MergeStrategyAbstract() = default;
+	virtual std::string merge_type() const = 0;
+	virtual void fill(dropest_cfg &cfg) const = 0;
+	size_t min_genes_before_merge() const { return _min_before; }
+	size_t min_genes_after_merge() const { return _min_after; }
+};
+class DummyMergeStrategy : public MergeStrategyAbstract {
+public:
+	using MergeStrategyAbstract::MergeStrategyAbstract;
+	std::string merge_type() const override { return "No"; }
+	void fill(dropest_cfg &cfg) const override { cfg.merge_kind = DROPEST_MERGE_NONE; }
+};
+class RealBarcodesMergeStrategy : public MergeStrategyAbstract {
+	std::string _file; int _kind; unsigned _max_ed; double _min_fraction;
+public:
+	enum BarcodesType { INDROP = DROPEST_BARCODES_INDROP, CONST_LENGTH = DROPEST_BARCODES_CONST };
+	RealBarcodesMergeStrategy(BarcodesType type, const std::string &barcodes_filename, size_t min_genes_before_merge,
+	                          size_t min_genes_after_merge, unsigned max_merge_edit_distance, double min_merge_fraction)
+		: MergeStrategyAbstract(min_genes_before_merge, min_genes_after_merge), _file(barcodes_filename), _kind(type),
+		  _max_ed(max_merge_edit_distance), _min_fraction(min_merge_fraction) {}
+	std::string merge_type() const override { return "Real CBs"; }
+	void fill(dropest_cfg &cfg) const override {
+		cfg.merge_kind = DROPEST_MERGE_REAL_BARCODES; cfg.barcodes_kind = _kind; cfg.barcodes_file = _file.c_str();
+		cfg.max_cb_merge_edit_distance = int(_max_ed); cfg.min_merge_fraction = _min_fraction;
+	}
+};
+namespace UMIs {
+class MergeUMIsStrategyAbstract {
+public:
+	virtual ~MergeUMIsStrategyAbstract() = default;
+	virtual void fill(dropest_cfg &cfg) const = 0;
+};
+class MergeUMIsStrategySimple : public MergeUMIsStrategyAbstract {
+	unsigned _max_merge_distance;
+public:
+	explicit MergeUMIsStrategySimple(unsigned max_merge_distance) : _max_merge_distance(max_merge_distance) {}
+	void fill(dropest_cfg &cfg) const override { cfg.umi_merge_kind = DROPEST_UMI_MERGE_SIMPLE; cfg.max_umi_merge_edit_distance = int(_max_merge_distance); }
+};
+}  // namespace UMIs
+}  // namespace Merge
+
+class CellsDataContainer;
+
+// What Cell / Gene / UMI expose to ResultsPrinter and the tests, as a value snapshot of one cell.
+class Cell {
+	friend class CellsDataContainer;
+	const CellsDataContainer *_owner = nullptr;
+	size_t _id = 0;
+	dropest_cell_row _row{};
+	std::string _barcode;
+public:
+	struct MoleculeRow { std::string gene, umi; size_t read_count; UMI::Mark mark; };
+	bool is_merged() const { return _row.is_merged; }
+	bool is_excluded() const { return _row.is_excluded; }
+	bool is_real() const { return _row.is_real; }
+	std::string barcode() const { return _barcode; }
+	size_t umis_number() const { return size_t(_row.total_umis); }
+	size_t requested_genes_num() const { return _row.requested_genes; }
+	size_t requested_umis_num() const { return _row.requested_umis; }
+	size_t size() const { return _row.n_genes; }
+	int stat(Stats::CellStatType t) const { return t == Stats::TOTAL_READS_PER_CB ? _row.total_reads : _row.total_umis; }
+	std::vector<MoleculeRow> molecules() const;                                  // walk of genes() x umis()
+	std::unordered_map<std::string, size_t> requested_umis_per_gene(const UMI::Mark::query_t &query, bool return_reads) const;
+};
+
+class CellsDataContainer {
+public:
+	using s_ul_hash_t = std::unordered_map<std::string, size_t>;
+	using s_i_hash_t = std::unordered_map<std::string, int>;
+	using ids_t = std::vector<size_t>;
+	using counts_t = std::vector<int>;
+	using names_t = std::vector<std::string>;
+
+private:
+	std::shared_ptr<Merge::MergeStrategyAbstract> _merge_strategy;
+	std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> _umi_merge_strategy;
+	UMI::Mark::query_t _query_marks;
+	dropest_ctx *_ctx = nullptr;
+	bool _is_initialized = false;
+	// host-side dictionaries (strings never reach the device)
+	StringIndexer _gene_indexer, _chr_indexer;
+	std::vector<std::string> _side;
+	std::unordered_map<std::string, uint64_t> _side_cb, _side_umi;
+	// pending batch
+	std::vector<uint64_t> _cb, _umi;
+	std::vector<uint32_t> _gene, _aux;
+	size_t _umi_quality_length = size_t(-1);
+	mutable ids_t _filtered_cache, _merge_targets_cache;
+
+	uint64_t encode(const std::string &s, std::unordered_map<std::string, uint64_t> &escapes);
+	void flush();
+	[[noreturn]] void fail(dropest_status st) const;
+	void check(dropest_status st) const { if (st != DROPEST_OK) fail(st); }
+
+public:
+	static const size_t BATCH = size_t(1) << 20;
+
+	CellsDataContainer(const std::shared_ptr<Merge::MergeStrategyAbstract> &merge_strategy,
+	                   const std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> &umi_merge_strategy,
+	                   const std::vector<UMI::Mark> &gene_match_levels, bool save_umi_merge_targets = false,
+	                   int max_cells_num = -1, int device = 0);
+	~CellsDataContainer();
+	CellsDataContainer(const CellsDataContainer &) = delete;              // pointer-stable, like the reference needs to be
+	CellsDataContainer &operator=(const CellsDataContainer &) = delete;
+
+	void add_record(const ReadInfo &read_info);
+	void set_initialized();
+	void merge_and_filter();
+
+	size_t total_cells_number() const;
+	size_t cell_id_by_cb(const std::string &barcode) const;             // throws std::out_of_range
+	const ids_t &filtered_cells() const;
+	const ids_t &merge_targets() const;
+	const UMI::Mark::query_t &gene_match_level() const { return _query_marks; }
+	long get_merge_target(size_t base_cell_ind) const;                  // RealBarcodesMergeStrategy::get_merge_target
+
+	s_i_hash_t get_stat_by_real_cells(Stats::CellStatType type) const;
+	void get_stat_by_real_cells(Stats::CellChrStatType stat, names_t &cell_barcodes, names_t &chromosome_names,
+	                            counts_t &counts) const;
+	Cell cell(size_t index) const;                                      // throws std::out_of_range
+
+	size_t intergenic_reads_num() const;
+	size_t has_exon_reads_num() const;
+	size_t has_intron_reads_num() const;
+	size_t has_not_annotated_reads_num() const;
+	size_t real_cells_number() const;
+	std::string merge_type() const { return _merge_strategy->merge_type(); }
+	const StringIndexer &gene_indexer() const { return _gene_indexer; }
+	const std::vector<std::string> &side_strings() const { return _side; }
+	dropest_ctx *handle() const { return _ctx; }
+	std::string decode(uint64_t code) const;
+};
+
+// Count-matrix assembly and the MatrixMarket writer of ResultsPrinter (Estimation/ResultsPrinter.cpp:334-396, :81-91).
+class ResultsPrinter {
+	const bool write_matrix, reads_output;
+public:
+	struct SparseMatrix {            // dgCMatrix layout (CSC), rows = genes, columns = cells
+		std::vector<std::string> row_names, col_names;
+		std::vector<uint32_t> colptr, rowidx, values;
+	};
+	ResultsPrinter(bool write_matrix_, bool reads_output_, bool /*validation_stats*/ = false, bool /*umi_correction_info*/ = false)
+		: write_matrix(write_matrix_), reads_output(reads_output_) {}
+	// reference_row_order = true reproduces the row order of the reference's dgCMatrix (rows numbered on first
+	// encounter while iterating an unordered_map per cell, Cell.cpp:54-68 + ResultsPrinter.cpp:345-355); false keeps
+	// rows in gene-index order.
+	SparseMatrix get_count_matrix(const CellsDataContainer &container, bool filtered, bool reference_row_order = true) const;
+	// <base>.mtx + <base>.cells.tsv + <base>.genes.tsv (what save_mtx writes through R's Matrix::writeMM)
+	void save_mtx(const CellsDataContainer &container, const std::string &filename_base) const;
+	void save_results(const CellsDataContainer &container, const std::string &filename) const;
+};
+
+}  // namespace Estimation

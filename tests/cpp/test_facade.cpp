@@ -1,0 +1,189 @@
+// test_facade.cpp -- the reference's Boost.Test cases for the container (Tests/TestEstimation.cpp) replayed against the
+// C++ facade (dropest_amd/csrc/host/facade.h), i.e. written the way the reference's own tests are written: build a
+// container with strategies, add_record(...) hand-written reads, set_initialized(), merge_and_filter(), assert.
+// Needs a GPU (run by tests/test_gpu_facade.py).  Exit code 0 = all checks passed.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+
+#include "../../dropest_amd/csrc/host/facade.h"
+
+using namespace Estimation;
+using Mark = UMI::Mark;
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+#define CHECK_EQ(a, b) do { auto va = (a); auto vb = (b); if (!(va == vb)) { std::cout << "FAILED " << __FILE__ << ":" << __LINE__ << ": " #a " == " #b " (" << va << " vs " << vb << ")\n"; ++failures; } } while (0)
+#define CHECK_THROWS(expr, Ex) do { bool ok = false; try { expr; } catch (const Ex &) { ok = true; } catch (...) {} if (!ok) { std::printf("FAILED %s:%d: %s should throw %s\n", __FILE__, __LINE__, #expr, #Ex); ++failures; } } while (0)
+
+static std::string g_data;
+
+static ReadInfo read_info(const std::string &cb, const std::string &umi, const std::string &gene, const std::string &chr = "",
+                          const Mark &mark = Mark(Mark::HAS_EXONS)) {
+	return ReadInfo(Tools::ReadParameters(cb, umi, "", umi), gene, chr, mark);   // Tests/TestEstimation.cpp:27-31
+}
+
+struct Fixture {   // Tests/TestEstimation.cpp:33-80
+	std::shared_ptr<Merge::RealBarcodesMergeStrategy> real_cb_strat;
+	std::shared_ptr<Merge::UMIs::MergeUMIsStrategySimple> umi_merge_strat;
+	std::vector<Mark> any_mark;
+	std::shared_ptr<CellsDataContainer> container_full;
+	Fixture() {
+		real_cb_strat = std::make_shared<Merge::RealBarcodesMergeStrategy>(Merge::RealBarcodesMergeStrategy::INDROP, g_data + "/test_est", 0, 0, 7, 0);
+		umi_merge_strat = std::make_shared<Merge::UMIs::MergeUMIsStrategySimple>(1);
+		any_mark = Mark::get_by_code(Mark::DEFAULT_CODE);
+		container_full = std::make_shared<CellsDataContainer>(real_cb_strat, umi_merge_strat, any_mark);
+		auto &c = *container_full;
+		c.add_record(read_info("AAATTAGGTCCA", "AAACCT", "Gene1")); c.add_record(read_info("AAATTAGGTCCA", "CCCCCT", "Gene2"));
+		c.add_record(read_info("AAATTAGGTCCA", "ACCCCT", "Gene3")); c.add_record(read_info("AAATTAGGTCCA", "ACCCCT", "Gene4"));
+		c.add_record(read_info("AAATTAGGTCCC", "CAACCT", "Gene1")); c.add_record(read_info("AAATTAGGTCCC", "CAACCT", "Gene10"));
+		c.add_record(read_info("AAATTAGGTCCC", "CAACCT", "Gene20"));
+		c.add_record(read_info("AAATTAGGTCCG", "CAACCT", "Gene1"));
+		c.add_record(read_info("AAATTAGGTCGG", "AAACCT", "Gene1")); c.add_record(read_info("AAATTAGGTCGG", "CCCCCT", "Gene2"));
+		c.add_record(read_info("CCCTTAGGTCCA", "CCATTC", "Gene3")); c.add_record(read_info("CCCTTAGGTCCA", "CCCCCT", "Gene2"));
+		c.add_record(read_info("CCCTTAGGTCCA", "ACCCCT", "Gene3"));
+		c.add_record(read_info("CAATTAGGTCCG", "CAACCT", "Gene1")); c.add_record(read_info("CAATTAGGTCCG", "AAACCT", "Gene1"));
+		c.add_record(read_info("CAATTAGGTCCG", "CCCCCT", "Gene2"));
+		c.add_record(read_info("AAAAAAAAAAAA", "CCCCCT", "Gene2"));
+		c.set_initialized();
+	}
+};
+
+static std::map<std::string, std::map<std::string, size_t>> by_gene(const Cell &c) {
+	std::map<std::string, std::map<std::string, size_t>> out;
+	for (auto const &m : c.molecules()) out[m.gene][m.umi] = m.read_count;
+	return out;
+}
+
+static void testRealNeighbours() {   // :227-235
+	Fixture f;
+	long expect[6] = {0, 1, 1, 0, 0, 0};
+	for (size_t i = 0; i < 6; ++i) CHECK_EQ(f.container_full->get_merge_target(i), expect[i]);
+}
+
+static void testMergeByRealBarcodes() {   // :237-280
+	Fixture f;
+	auto &c = *f.container_full;
+	c.merge_and_filter();
+	CHECK_EQ(c.total_cells_number(), size_t(7));
+	CHECK_EQ(c.filtered_cells().size(), size_t(2));
+	if (c.filtered_cells().size() < 2) return;
+	const Cell cell0 = c.cell(c.filtered_cells()[0]), cell1 = c.cell(c.filtered_cells()[1]);
+	CHECK_EQ(cell0.size(), size_t(3)); CHECK_EQ(cell1.size(), size_t(4));
+	auto g0 = by_gene(cell0), g1 = by_gene(cell1);
+	CHECK_EQ(g0["Gene1"].size(), size_t(1)); CHECK_EQ(g0["Gene1"]["CAACCT"], size_t(2));
+	CHECK_EQ(g1["Gene1"].size(), size_t(2)); CHECK_EQ(g1["Gene1"]["AAACCT"], size_t(3));
+	CHECK_EQ(g1["Gene2"].size(), size_t(1)); CHECK_EQ(g1["Gene2"]["CCCCCT"], size_t(4));
+	CHECK_EQ(g1["Gene3"].size(), size_t(2)); CHECK_EQ(g1["Gene3"]["ACCCCT"], size_t(2)); CHECK_EQ(g1["Gene3"]["CCATTC"], size_t(1));
+	bool merged[7] = {false, false, true, true, true, true, false};
+	size_t excluded = 0;
+	for (size_t i = 0; i < 7; ++i) { CHECK_EQ(c.cell(i).is_merged(), merged[i]); excluded += c.cell(i).is_excluded(); }
+	CHECK_EQ(excluded, size_t(1));
+	size_t expect_targets[7] = {0, 1, 1, 0, 0, 0, 6};
+	for (size_t i = 0; i < 7; ++i) CHECK_EQ(c.merge_targets()[i], expect_targets[i]);
+	CHECK_EQ(c.cell_id_by_cb("CCCTTAGGTCCA"), size_t(4));
+	CHECK_THROWS(c.cell_id_by_cb("TTTTTTTTTTTT"), std::out_of_range);
+	CHECK_THROWS(c.cell(7), std::out_of_range);
+}
+
+static void testUmiExclusion() {   // :369-397
+	Fixture f;
+	CellsDataContainer c(f.real_cb_strat, f.umi_merge_strat, Mark::get_by_code("e"));
+	c.add_record(read_info("AAATTAGGTCCA", "AAACCT", "Gene1")); c.add_record(read_info("AAATTAGGTCCA", "CCCCCT", "Gene2"));
+	c.add_record(read_info("AAATTAGGTCCA", "ACCCCT", "Gene3")); c.add_record(read_info("AAATTAGGTCCA", "ACCCCT", "Gene4"));
+	c.add_record(read_info("AAATTAGGTCCA", "TTTTTT", "Gene3", "chr1", Mark(Mark::HAS_NOT_ANNOTATED)));
+	c.add_record(read_info("AAATTAGGTCCA", "ACCCCT", "Gene4", "chr1", Mark(Mark::HAS_NOT_ANNOTATED)));
+	c.set_initialized();
+	c.merge_and_filter();
+	const Cell cell = c.cell(0);
+	bool na3 = false, na4 = false;
+	for (auto const &m : cell.molecules()) {
+		if (m.gene == "Gene3" && m.umi == "TTTTTT") na3 = m.mark.check(Mark::HAS_NOT_ANNOTATED);
+		if (m.gene == "Gene4" && m.umi == "ACCCCT") { na4 = m.mark.check(Mark::HAS_NOT_ANNOTATED); CHECK_EQ(m.read_count, size_t(2)); }
+	}
+	CHECK(na3); CHECK(na4);
+	auto req = cell.requested_umis_per_gene(c.gene_match_level(), true);
+	CHECK_EQ(req.count("Gene3"), size_t(1)); CHECK_EQ(req["Gene3"], size_t(1));
+	CHECK_EQ(req.count("Gene4"), size_t(0));
+}
+
+static void testUMIMergeStrategySimple() {   // :505-540
+	Fixture f;
+	auto dummy = std::make_shared<Merge::DummyMergeStrategy>(0, 0);
+	CellsDataContainer c(dummy, f.umi_merge_strat, f.any_mark);
+	for (const char *u : {"AAACCT", "AAACCT", "AAACCG", "AAACCN", "CCCCCT", "ACCCCT"}) c.add_record(read_info("AAATTAGGTCCA", u, "Gene1"));
+	for (const char *u : {"TTTTTT", "TTTNNG", "TTGNNG", "ACCCCT", "NNNNNN"}) c.add_record(read_info("AAATTAGGTCCA", u, "Gene2"));
+	c.set_initialized();
+	c.merge_and_filter();
+	auto g = by_gene(c.cell(0));
+	CHECK_EQ(g["Gene1"].size(), size_t(4)); CHECK_EQ(g["Gene2"].size(), size_t(3));
+	CHECK_EQ(g["Gene1"]["AAACCT"], size_t(3)); CHECK_EQ(g["Gene1"]["AAACCG"], size_t(1));
+	CHECK_EQ(g["Gene1"]["CCCCCT"], size_t(1)); CHECK_EQ(g["Gene1"]["ACCCCT"], size_t(1));
+	CHECK(g["Gene2"].count("TTTTTT") == 1); CHECK(g["Gene2"].count("ACCCCT") == 1);
+	for (auto const &kv : g["Gene2"]) CHECK(kv.first.find('N') == std::string::npos);
+}
+
+static void testStateMachineAndParams() {   // CellsDataContainer.cpp:41-42,:61-62,:165-166; Tests/TestTools.cpp:56-87
+	Fixture f;
+	CHECK_THROWS(f.container_full->add_record(read_info("AAAA", "CCCC", "G")), std::runtime_error);
+	CHECK_THROWS(f.container_full->set_initialized(), std::runtime_error);
+	auto dummy = std::make_shared<Merge::DummyMergeStrategy>(0, 0);
+	CellsDataContainer c(dummy, f.umi_merge_strat, f.any_mark);
+	CHECK_THROWS(c.merge_and_filter(), std::runtime_error);
+	auto rp = Tools::ReadParameters::parse_encoded_id("@111!ATTTGC#ATATC");
+	CHECK_EQ(rp.cell_barcode(), std::string("ATTTGC")); CHECK_EQ(rp.umi(), std::string("ATATC"));
+	rp = Tools::ReadParameters::parse_encoded_id("trash!ATTTG#ATAT");
+	CHECK_EQ(rp.cell_barcode(), std::string("ATTTG")); CHECK_EQ(rp.umi(), std::string("ATAT"));
+	CHECK_THROWS(Tools::ReadParameters::parse_encoded_id("ATTTG#ATAT"), std::runtime_error);
+	CHECK_THROWS(Mark::get_by_code('x'), std::runtime_error);
+}
+
+static void testResultsPrinterMtx(const std::string &tmp) {   // ResultsPrinter.cpp:81-91, :334-361 (not pinned by the reference)
+	Fixture f;
+	auto &c = *f.container_full;
+	c.merge_and_filter();
+	ResultsPrinter printer(true, false);
+	auto cm = printer.get_count_matrix(c, true, true);
+	CHECK_EQ(cm.col_names.size(), size_t(2));
+	CHECK_EQ(cm.col_names[0], std::string("AAATTAGGTCCC")); CHECK_EQ(cm.col_names[1], std::string("AAATTAGGTCCA"));
+	CHECK_EQ(cm.values.size(), size_t(7));     // 3 genes + 4 genes
+	std::map<std::string, std::map<std::string, uint32_t>> dense;
+	for (size_t col = 0; col + 1 < cm.colptr.size(); ++col)
+		for (uint32_t k = cm.colptr[col]; k < cm.colptr[col + 1]; ++k) dense[cm.col_names[col]][cm.row_names[cm.rowidx[k]]] = cm.values[k];
+	CHECK_EQ(dense["AAATTAGGTCCA"]["Gene1"], 2u); CHECK_EQ(dense["AAATTAGGTCCA"]["Gene3"], 2u);
+	CHECK_EQ(dense["AAATTAGGTCCC"]["Gene10"], 1u);
+	printer.save_results(c, tmp + "/cell.counts.rds");
+	std::ifstream mtx(tmp + "/cell.counts.mtx");
+	std::string header; std::getline(mtx, header);
+	CHECK_EQ(header, std::string("%%MatrixMarket matrix coordinate real general"));
+	size_t r, cc, nnz; mtx >> r >> cc >> nnz;
+	CHECK_EQ(cc, size_t(2)); CHECK_EQ(nnz, size_t(7)); CHECK_EQ(r, cm.row_names.size());
+	auto raw = printer.get_count_matrix(c, false, false);
+	CHECK_EQ(raw.col_names.size(), size_t(2));
+	CHECK_EQ(raw.col_names[0], std::string("AAATTAGGTCCA"));   // real cells in cell-id order
+	CHECK_EQ(c.get_stat_by_real_cells(Stats::TOTAL_UMIS_PER_CB).at("AAATTAGGTCCC"), 4);   // Stats::merge quirk
+	CHECK_EQ(c.real_cells_number(), size_t(2));
+	CHECK_EQ(c.has_exon_reads_num(), size_t(17)); CHECK_EQ(c.intergenic_reads_num(), size_t(0));
+}
+
+int main(int argc, char **argv) {
+	g_data = argc > 1 ? argv[1] : "dropest_amd/data/barcodes";
+	const std::string tmp = argc > 2 ? argv[2] : "/tmp";
+	try {
+		testRealNeighbours();
+		testMergeByRealBarcodes();
+		testUmiExclusion();
+		testUMIMergeStrategySimple();
+		testStateMachineAndParams();
+		testResultsPrinterMtx(tmp);
+	} catch (const std::exception &e) {
+		std::printf("UNEXPECTED EXCEPTION: %s\n", e.what());
+		return 2;
+	}
+	if (failures) { std::printf("%d check(s) failed\n", failures); return 1; }
+	std::printf("facade: all reference test cases passed\n");
+	return 0;
+}
