@@ -90,7 +90,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the dropEst hot path has no CPU implementation")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("DROPEST_BENCH_FORCE_SHARDED") == "1" and "RANK" in os.environ
+    if world > 1 or force_sharded:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -99,7 +100,7 @@ def main():
     cfg = {"min_before": 20, "min_after": 100}    # configs/10x.xml:26-27
     stream = SynthStream(n_reads=total_reads, n_cells=args.cells * world, n_genes=30000, cb_len=16, umi_len=10)
 
-    if world == 1:
+    if world == 1 and not force_sharded:
         from dropest_amd.capi import Context
         dev = stream.generate_device(local_rank, first=0, n=reads_per_gpu)
         ctx = Context(device=local_rank, merge_kind=capi.MERGE_NONE, min_genes_before_merge=cfg["min_before"],

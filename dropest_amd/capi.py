@@ -99,6 +99,14 @@ def lib():
         "dropest_count_matrix_csc": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
         "dropest_chr_stats": (C.c_int, [vp, u64p, vp, vp, vp, vp]),
         "dropest_merge_target": (C.c_int, [vp, C.c_uint64, P(C.c_int64)]),
+        "dropest_owner_of": (C.c_uint32, [C.c_uint64, C.c_uint32]),
+        "dropest_partition_by_owner": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp, vp]),
+        "dropest_clear_reads": (C.c_int, [vp]),
+        "dropest_count_matrix_device": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
+        "dropest_cell_first_reads_device": (C.c_int, [vp, u64p, P(vp)]),
+        "dropest_assemble_columns": (C.c_int, [C.c_int, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]),
+        "dropest_real_candidate_rows": (C.c_int, [vp, u64p, vp, vp]),
+        "dropest_dev_copy_device": (C.c_int, [C.c_int, vp, vp, C.c_uint64]),
         "dropest_kernel_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
         "dropest_set_profiling": (C.c_int, [vp, C.c_int]),
         "dropest_stream": (vp, [vp]),
@@ -124,7 +132,9 @@ EXPORTED_SYMBOLS = [
     "dropest_merge_and_filter", "dropest_reset_results", "dropest_total_cells", "dropest_real_cells",
     "dropest_cell_rows", "dropest_cell_id_by_cb", "dropest_filtered_cells", "dropest_merge_targets",
     "dropest_global_counters", "dropest_cell_molecules", "dropest_molecules", "dropest_count_matrix",
-    "dropest_count_matrix_csc",
+    "dropest_count_matrix_csc", "dropest_owner_of", "dropest_partition_by_owner", "dropest_clear_reads",
+    "dropest_count_matrix_device", "dropest_cell_first_reads_device", "dropest_assemble_columns",
+    "dropest_real_candidate_rows", "dropest_dev_copy_device",
     "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_stream",
     "dropest_synth_generate_host", "dropest_synth_generate_device", "dropest_dev_alloc", "dropest_dev_free",
     "dropest_dev_copy_to_host", "dropest_dev_copy_from_host", "dropest_dev_count", "dropest_dev_sync",
@@ -310,6 +320,31 @@ class Context:
                 return np.zeros(0, np.uint32)
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n,))
         return view(pc, ncols.value + 1), view(pr, nnz.value), view(pv, nnz.value)
+
+    def count_matrix_device(self, filtered=True, reads_output=False):
+        """(colptr numpy copy, d_rowidx, d_values, nnz): row indices / values stay in HBM (raw device pointers)."""
+        ncols, nnz = C.c_uint64(), C.c_uint64()
+        pc, pr, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.L.dropest_count_matrix_device(self.h, int(filtered), int(reads_output), C.byref(ncols), C.byref(nnz),
+                                                     C.byref(pc), C.byref(pr), C.byref(pv)))
+        colptr = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_uint32)), shape=(ncols.value + 1,)).copy()
+        return colptr, pr.value, pv.value, nnz.value
+
+    def cell_first_reads_device(self):
+        n, p = C.c_uint64(), C.c_void_p()
+        self._chk(self.L.dropest_cell_first_reads_device(self.h, C.byref(n), C.byref(p)))
+        return n.value, p.value
+
+    def real_candidate_rows(self):
+        n = C.c_uint64()
+        self._chk(self.L.dropest_real_candidate_rows(self.h, C.byref(n), None, None))
+        ids = np.zeros(n.value, np.uint64); rows = np.zeros(n.value, CELL_ROW_DTYPE)
+        if n.value:
+            self._chk(self.L.dropest_real_candidate_rows(self.h, C.byref(n), ids.ctypes.data, rows.ctypes.data))
+        return ids, rows
+
+    def clear_reads(self):
+        self._chk(self.L.dropest_clear_reads(self.h))
 
     def chr_stats(self):
         n = C.c_uint64()

@@ -182,6 +182,6 @@ struct dropest_ctx {
 	void run_umi_merge_simple();
 	void fetch_real_cells();
 	void sort_filtered(u32 genes_threshold, int max_cells);
-	void emit_matrix(bool filtered_m, bool reads_output);
+	void emit_matrix(bool filtered_m, bool reads_output, bool to_host = true);
 	u64 unmap_umi(u64 ucode) const;
 };

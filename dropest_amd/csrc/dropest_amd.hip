@@ -491,7 +491,7 @@ void dropest_ctx::run_merge_and_filter() {
 // ------------------------------------------------------------------------------------------------
 // count matrices
 // ------------------------------------------------------------------------------------------------
-void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output) {
+void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host) {
 	MatrixResult &M = mat[filtered_m ? 0 : 1];
 	std::vector<u32> col_cell;
 	M.colptr.clear();
@@ -513,7 +513,7 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output) {
 	if (nnz == 0) return;
 	const u32 ncols = u32(col_cell.size());
 	m_col_cell.ensure(ncols); m_col_start.ensure(ncols);
-	M.d_row.ensure(nnz); M.d_val.ensure(nnz); M.h_row.ensure(nnz); M.h_val.ensure(nnz);
+	M.d_row.ensure(nnz); M.d_val.ensure(nnz);
 	HIP_CHECK(hipMemcpyAsync(m_col_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(m_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	MatrixArgs a{};
@@ -524,8 +524,11 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output) {
 	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * 20, [&] {
 		hipLaunchKernelGGL(emit_matrix_kernel, dim3(ncols), dim3(256), 0, stream, a);
 	});
-	HIP_CHECK(hipMemcpyAsync(M.h_row.p, M.d_row.p, nnz * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipMemcpyAsync(M.h_val.p, M.d_val.p, nnz * 4, hipMemcpyDeviceToHost, stream));
+	if (to_host) {
+		M.h_row.ensure(nnz); M.h_val.ensure(nnz);
+		HIP_CHECK(hipMemcpyAsync(M.h_row.p, M.d_row.p, nnz * 4, hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipMemcpyAsync(M.h_val.p, M.d_val.p, nnz * 4, hipMemcpyDeviceToHost, stream));
+	}
 	HIP_CHECK(hipStreamSynchronize(stream));   // col_cell (host vector) must outlive the H2D copy
 	collect_timings();
 }
@@ -887,6 +890,111 @@ dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *ta
 		if (ctx->cfg.merge_kind != DROPEST_MERGE_REAL_BARCODES) { *target = int64_t(cell); return; }   // DummyMergeStrategy
 		if (cell >= ctx->n_cells) throw RangeError("cell index out of range");
 		*target = ctx->compute_merge_targets(std::vector<u32>{u32(cell)})[0];
+	});
+}
+
+// ---- multi-GPU building blocks ---------------------------------------------------------------------------------
+uint32_t dropest_owner_of(uint64_t barcode, uint32_t n_parts) { return n_parts ? uint32_t(mix64(barcode) % n_parts) : 0u; }
+
+dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene,
+                                          const uint32_t *d_aux, uint64_t n64, uint32_t n_parts, uint64_t *d_out_cb,
+                                          uint64_t *d_out_umi, uint32_t *d_out_gene, uint32_t *d_out_aux, uint32_t *d_out_idx,
+                                          uint64_t *counts) {
+	return guarded([&] {
+		if (n_parts == 0 || n_parts > 256) throw InvalidError("n_parts must be in 1..256");
+		if (n64 >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads per GPU");
+		HIP_CHECK(hipSetDevice(device));
+		const u32 n = u32(n64);
+		for (u32 p = 0; p < n_parts; ++p) counts[p] = 0;
+		if (n == 0) return;
+		// one stable radix pass on the owner digit over (owner, position) records, then a gather of the four arrays
+		DevBuf<u64> k0, k1; DevBuf<u32> v0, v1, hist, row_total, digit_base;
+		k0.alloc(n); k1.alloc(n); v0.alloc(n); v1.alloc(n);
+		const u32 n_tiles = div_up(n, RS_TILE);
+		u32 nblocks = std::min<u32>(n_tiles, 1024);
+		const u32 tpb = div_up(n_tiles, nblocks);
+		nblocks = div_up(n_tiles, tpb);
+		hist.alloc(size_t(RS_RADIX) * nblocks); row_total.alloc(RS_RADIX); digit_base.alloc(RS_RADIX);
+		hipStream_t st = nullptr;
+		hipLaunchKernelGGL(owner_keys_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st,
+		                   reinterpret_cast<const u64 *>(d_cb), n, n_parts, k0.p, v0.p);
+		hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, st, k0.p, n, 0, tpb, hist.p);
+		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, st, hist.p, nblocks, row_total.p);
+		hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(256), 0, st, row_total.p, digit_base.p);
+		hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, st, k0.p, v0.p, k1.p, v1.p, n, 0, tpb, hist.p,
+		                   digit_base.p);
+		hipLaunchKernelGGL(gather_reads_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st, v1.p, n,
+		                   reinterpret_cast<const u64 *>(d_cb), reinterpret_cast<const u64 *>(d_umi), d_gene, d_aux,
+		                   reinterpret_cast<u64 *>(d_out_cb), reinterpret_cast<u64 *>(d_out_umi), d_out_gene, d_out_aux, d_out_idx);
+		HIP_CHECK(hipGetLastError());
+		std::vector<u32> totals(RS_RADIX);
+		HIP_CHECK(hipMemcpy(totals.data(), row_total.p, RS_RADIX * 4, hipMemcpyDeviceToHost));
+		for (u32 p = 0; p < n_parts; ++p) counts[p] = totals[p];
+	});
+}
+
+dropest_status dropest_real_candidate_rows(dropest_ctx *ctx, uint64_t *n, uint64_t *ids, dropest_cell_row *rows) {
+	return guarded([&] {
+		need_init(ctx);
+		*n = ctx->real.size();
+		if (!ids || !rows) return;
+		for (size_t i = 0; i < ctx->real.size(); ++i) {
+			const HostCell &h = ctx->real[i];
+			ids[i] = h.id;
+			dropest_cell_row &r = rows[i];
+			std::memcpy(&r, &h.row, sizeof(r));
+			r.is_merged = h.merged; r.is_excluded = h.excluded;
+			r.is_real = !h.merged && !h.excluded && h.row.n_genes >= ctx->min_before;
+		}
+	});
+}
+
+dropest_status dropest_dev_copy_device(int device, void *d_dst, const void *d_src, uint64_t bytes) {
+	return guarded([&] {
+		HIP_CHECK(hipSetDevice(device));
+		if (bytes) HIP_CHECK(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+	});
+}
+
+dropest_status dropest_clear_reads(dropest_ctx *ctx) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		ctx->free_results();
+		ctx->chunks.clear();
+		ctx->n_reads = 0;
+		ctx->d_cb = ctx->d_umi = nullptr; ctx->d_gene = ctx->d_aux = nullptr;
+	});
+}
+
+dropest_status dropest_count_matrix_device(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *ncols, uint64_t *nnz,
+                                           const uint32_t **colptr, const uint32_t **d_rowidx, const uint32_t **d_values) {
+	return guarded([&] {
+		need_init(ctx);
+		ctx->emit_matrix(filtered != 0, reads_output != 0, /*to_host=*/false);
+		const dropest_ctx::MatrixResult &M = ctx->mat[filtered ? 0 : 1];
+		*ncols = M.ncols; *nnz = M.nnz;
+		*colptr = M.colptr.data(); *d_rowidx = M.d_row.p; *d_values = M.d_val.p;
+	});
+}
+
+dropest_status dropest_cell_first_reads_device(dropest_ctx *ctx, uint64_t *n_cells, const uint32_t **d_first) {
+	return guarded([&] { need_init(ctx); *n_cells = ctx->n_cells; *d_first = ctx->cell_first.p; });
+}
+
+dropest_status dropest_assemble_columns(int device, uint64_t n_cols, const uint64_t *src_start, const uint64_t *dst_start,
+                                        const uint64_t *len, const uint32_t *d_src_rows, const uint32_t *d_src_vals,
+                                        uint32_t *d_dst_rows, uint32_t *d_dst_vals) {
+	return guarded([&] {
+		HIP_CHECK(hipSetDevice(device));
+		if (n_cols == 0) return;
+		DevBuf<u64> d_desc; d_desc.alloc(n_cols * 3);
+		std::vector<u64> desc(n_cols * 3);
+		for (uint64_t c = 0; c < n_cols; ++c) { desc[3 * c] = src_start[c]; desc[3 * c + 1] = dst_start[c]; desc[3 * c + 2] = len[c]; }
+		HIP_CHECK(hipMemcpy(d_desc.p, desc.data(), desc.size() * 8, hipMemcpyHostToDevice));
+		hipLaunchKernelGGL(assemble_columns_kernel, dim3(u32(n_cols)), dim3(256), 0, nullptr, d_desc.p, d_src_rows, d_src_vals,
+		                   d_dst_rows, d_dst_vals);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipDeviceSynchronize());
 	});
 }
 

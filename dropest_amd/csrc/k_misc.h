@@ -176,6 +176,32 @@ __global__ __launch_bounds__(256) void chr_accumulate_kernel(const unsigned long
 	if (intergenic[i]) atomicAdd(base + 2 * n_chr + chr, intergenic[i]);
 }
 
+// ---- multi-GPU: owner keys, stable gather after the owner partition, column assembly ---------------------
+__global__ __launch_bounds__(256) void owner_keys_kernel(const unsigned long long *__restrict__ cb, uint32_t n, uint32_t n_parts,
+                                                         unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
+	const uint32_t stride = gridDim.x * 256;
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) { keys[i] = mix64(cb[i]) % n_parts; vals[i] = i; }
+}
+__global__ __launch_bounds__(256) void gather_reads_kernel(const uint32_t *__restrict__ idx, uint32_t n,
+                                                           const unsigned long long *__restrict__ cb, const unsigned long long *__restrict__ umi,
+                                                           const uint32_t *__restrict__ gene, const uint32_t *__restrict__ aux,
+                                                           unsigned long long *__restrict__ o_cb, unsigned long long *__restrict__ o_umi,
+                                                           uint32_t *__restrict__ o_gene, uint32_t *__restrict__ o_aux,
+                                                           uint32_t *__restrict__ o_idx) {
+	const uint32_t stride = gridDim.x * 256;
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+		const uint32_t j = idx[i];
+		o_cb[i] = cb[j]; o_umi[i] = umi[j]; o_gene[i] = gene[j]; o_aux[i] = aux[j]; o_idx[i] = j;
+	}
+}
+// desc[3c .. 3c+2] = (src_start, dst_start, len) of column c
+__global__ __launch_bounds__(256) void assemble_columns_kernel(const unsigned long long *__restrict__ desc,
+                                                               const uint32_t *__restrict__ src_rows, const uint32_t *__restrict__ src_vals,
+                                                               uint32_t *__restrict__ dst_rows, uint32_t *__restrict__ dst_vals) {
+	const unsigned long long s = desc[3ull * blockIdx.x], d = desc[3ull * blockIdx.x + 1], len = desc[3ull * blockIdx.x + 2];
+	for (unsigned long long t = threadIdx.x; t < len; t += 256) { dst_rows[d + t] = src_rows[s + t]; dst_vals[d + t] = src_vals[s + t]; }
+}
+
 __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *p, uint32_t v, size_t n) {
 	size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
 	if (i < n) p[i] = v;

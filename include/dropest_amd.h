@@ -170,6 +170,37 @@ dropest_status dropest_chr_stats(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, 
  * evaluated on the un-merged state; valid between set_initialized and merge_and_filter. */
 dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *target);
 
+/* ---- multi-GPU building blocks (the reference has no distributed runtime) ----------------------
+ * Reads are sharded by barcode: owner(cb) = dropest_owner_of(cb, n_parts).  All pointers are DEVICE pointers on
+ * `device`.  dropest_partition_by_owner groups n reads by owner, STABLY (reads of one owner keep their stream
+ * order, which keeps first-seen order meaningful after the exchange); out_idx[i] is the position the i-th output
+ * read had in the input; counts[p] (host) is the number of reads of owner p.  One all-to-all(v) of the five
+ * output arrays (RCCL) is the only data-path collective. */
+uint32_t dropest_owner_of(uint64_t barcode, uint32_t n_parts);
+dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene,
+                                          const uint32_t *d_aux, uint64_t n, uint32_t n_parts, uint64_t *d_out_cb,
+                                          uint64_t *d_out_umi, uint32_t *d_out_gene, uint32_t *d_out_aux,
+                                          uint32_t *d_out_idx, uint64_t *counts);
+/* Rows of the real-candidate cells (n_genes >= min_genes_before_merge at set_initialized) with the host-tracked
+ * merge state: ids[k] = cell id, rows[k] as dropest_cell_rows would return it.  Ascending cell id. */
+dropest_status dropest_real_candidate_rows(dropest_ctx *ctx, uint64_t *n, uint64_t *ids, dropest_cell_row *rows);
+/* Plain device-to-device copy on `device` (lets a caller stage results into buffers it owns, e.g. torch tensors). */
+dropest_status dropest_dev_copy_device(int device, void *d_dst, const void *d_src, uint64_t bytes);
+/* Forgets the pushed reads (and all results) so that a new batch can be pushed into the same context. */
+dropest_status dropest_clear_reads(dropest_ctx *ctx);
+/* As dropest_count_matrix_csc, but rowidx / values stay in HBM (device pointers) for a gather over RCCL;
+ * colptr is a host pointer. */
+dropest_status dropest_count_matrix_device(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *ncols,
+                                           uint64_t *nnz, const uint32_t **colptr, const uint32_t **d_rowidx,
+                                           const uint32_t **d_values);
+/* Device pointer to first_read of every cell (ascending: cell ids are first-seen ranks). */
+dropest_status dropest_cell_first_reads_device(dropest_ctx *ctx, uint64_t *n_cells, const uint32_t **d_first);
+/* Copies n_cols column segments (src_start, dst_start, len: host arrays) of (rows, vals) into their places in
+ * the destination matrix: the final column permutation of the gathered per-shard matrices. */
+dropest_status dropest_assemble_columns(int device, uint64_t n_cols, const uint64_t *src_start, const uint64_t *dst_start,
+                                        const uint64_t *len, const uint32_t *d_src_rows, const uint32_t *d_src_vals,
+                                        uint32_t *d_dst_rows, uint32_t *d_dst_vals);
+
 /* ---- instrumentation (no reference counterpart; Tools::trace_time stage stamps, Tools/Logs.cpp:63-71) ---- */
 typedef struct {
 	const char *name;      /* kernel family */

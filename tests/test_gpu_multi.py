@@ -1,0 +1,56 @@
+"""Two ranks of the sharded run with the REAL engine (HIP path) on one GPU: the collectives hop through host memory
+over gloo (two ranks cannot share a device under RCCL), everything else is the production code path.  The assembled
+matrices must equal a single-context run over the whole stream."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dropest_amd import capi
+from dropest_amd.multi import ShardedRun
+from dropest_amd.synth import SynthStream
+
+pytestmark = pytest.mark.gpu
+
+CFG = {"min_before": 10, "min_after": 30}
+STREAM = dict(n_reads=400_000, n_cells=60, n_genes=3000)
+
+
+def _worker(rank, world, port, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        stream = SynthStream(**STREAM)
+        run = ShardedRun(stream, rank, world, 0, STREAM["n_reads"] // world, CFG, dist, staging="cpu")
+        for _ in range(2):                      # a second step exercises clear_reads / buffer reuse
+            cm, cm_raw, cols = run.step()
+        if rank == 0:
+            np.savez(path, cm_p=cm[0], cm_i=cm[1], cm_x=cm[2], cm_cols=cm[3], raw_p=cm_raw[0], raw_i=cm_raw[1],
+                     raw_x=cm_raw[2], raw_cols=cm_raw[3])
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_single_context(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    path = str(tmp_path / "res.npz")
+    mp.spawn(_worker, args=(2, port, path), nprocs=2, join=True)
+    got = np.load(path)
+    stream = SynthStream(**STREAM)
+    dev = stream.generate_device(0)
+    c = capi.Context(min_genes_before_merge=CFG["min_before"], min_genes_after_merge=CFG["min_after"])
+    c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
+    c.set_initialized(); c.merge_and_filter()
+    rows = c.cell_rows()
+    for filt, pre in ((True, "cm"), (False, "raw")):
+        p, i, x = c.count_matrix_csc(filtered=filt)
+        assert np.array_equal(got[pre + "_p"].astype(np.uint32), p)
+        assert np.array_equal(got[pre + "_i"], i) and np.array_equal(got[pre + "_x"], x)
+    assert [int(b) for b in got["cm_cols"]] == [int(rows["barcode"][int(k)]) for k in c.filtered_cells()]
+    assert [int(b) for b in got["raw_cols"]] == [int(b) for b in rows["barcode"][rows["is_real"].astype(bool)]]
+    assert len(got["cm_cols"]) > 20
+    dev.free()
