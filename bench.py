@@ -156,7 +156,8 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"]}
         kernels = {k: {"ms_per_step": round(v["ms"] / max(1, args.steps), 4), "launches_per_step": v["launches"] / max(1, args.steps)}
-                   for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])}
+                   for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"]) if not k.startswith("host:")}
+        host_stages = {k[5:]: round(v["ms"] / max(1, args.steps), 3) for k, v in stats.items() if k.startswith("host:")}
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             cpu = cpu_baseline(stream, int(min(args.cpu_sample, total_reads)), cfg)
@@ -170,6 +171,7 @@ def main():
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d" % world,
                        "cm_nnz": int(len(cm[1])), "filtered_cells": int(len(out[2]))},
             "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kernels,
+            "host_stage_wall_ms_per_step": host_stages,
         }
         print(json.dumps(line))
     if dist is not None:

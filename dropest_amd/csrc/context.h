@@ -2,6 +2,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -63,8 +64,7 @@ struct UmiOverride { u64 umi; u32 reads; uint8_t mark; };   // molecule of a gro
 
 struct HostCell {   // host mirror of one REAL-candidate cell (n_genes >= min_genes_before_merge at init)
 	u32 id;
-	CellRowPod row;         // sizes as of the last device update + stat adjustments
-	std::string barcode;
+	CellRowPod row;         // sizes as of the last device update + stat adjustments (row.barcode = packed code)
 	bool merged = false, excluded = false;
 };
 
@@ -143,8 +143,22 @@ struct dropest_ctx {
 
 	// ---- host state over real-candidate cells ----
 	std::vector<dropest::HostCell> real;                 // ascending cell id
-	std::unordered_map<u32, u32> real_index_of;          // cell id -> index in `real`
-	std::vector<uint64_t> filtered;                      // cell ids, ascending compare_cells order
+	std::vector<uint64_t> filtered;                      // cell ids, ascending compare_cells order (built lazily)
+	bool filtered_valid = false;
+	u32 filtered_threshold = 0;
+	int filtered_max_cells = -1;
+	long real_find(u32 cell_id) const {                  // index in `real` (binary search, ids ascending) or -1
+		size_t lo = 0, hi = real.size();
+		while (lo < hi) { size_t mid = (lo + hi) / 2; if (real[mid].id < cell_id) lo = mid + 1; else hi = mid; }
+		return (lo < real.size() && real[lo].id == cell_id) ? long(lo) : -1;
+	}
+	u32 real_at(u32 cell_id) const {
+		long i = real_find(cell_id);
+		if (i < 0) throw dropest::RangeError("cell is not a real-candidate cell");
+		return u32(i);
+	}
+	std::string barcode_of(const dropest::HostCell &h) const { return dropest::decode_code(h.row.barcode, side); }
+	const std::vector<uint64_t> &filtered_cells();       // sorts on first use
 	std::vector<std::pair<uint64_t, uint64_t>> merge_pairs;   // (source, target), target != source
 	uint64_t n_real_now = 0;
 
@@ -154,6 +168,18 @@ struct dropest_ctx {
 	struct Pending { std::string name; hipEvent_t a, b; double bytes; };
 	std::vector<Pending> pending;
 	std::vector<hipEvent_t> event_pool;
+
+	// wall-clock time of a host stage (only while profiling); reported as "host:<name>" in the kernel stats
+	struct HostStage {
+		dropest_ctx *c; const char *name; std::chrono::steady_clock::time_point t0;
+		HostStage(dropest_ctx *ctx, const char *n) : c(ctx), name(n), t0(std::chrono::steady_clock::now()) {}
+		~HostStage() {
+			if (!c->profiling) return;
+			auto &s = c->stats[std::string("host:") + name];
+			s.launches++;
+			s.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		}
+	};
 
 	~dropest_ctx();
 	void init_from_cfg(const dropest_cfg &c);
@@ -181,6 +207,7 @@ struct dropest_ctx {
 	void reaggregate_after_merge();
 	void run_umi_merge_simple();
 	void fetch_real_cells();
+	void request_filtered(u32 genes_threshold, int max_cells);   // CellsDataContainer::update_filtered_gene_counts, lazily
 	void sort_filtered(u32 genes_threshold, int max_cells);
 	void emit_matrix(bool filtered_m, bool reads_output, bool to_host = true);
 	u64 unmap_umi(u64 ucode) const;

@@ -139,7 +139,7 @@ void dropest_ctx::concat_chunks() {
 void dropest_ctx::free_results() {
 	initialized = merged = false;
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
-	real.clear(); real_index_of.clear(); filtered.clear(); merge_pairs.clear(); reassign.clear(); umi_overrides.clear(); n_real_now = 0;
+	real.clear(); filtered.clear(); filtered_valid = false; merge_pairs.clear(); reassign.clear(); umi_overrides.clear(); n_real_now = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -395,7 +395,7 @@ void dropest_ctx::reduce_cell_gene_to_cells() {
 // stage: real cells to the host; ordering (CellsDataContainer::update_filtered_gene_counts)
 // ------------------------------------------------------------------------------------------------
 void dropest_ctx::fetch_real_cells() {
-	real.clear(); real_index_of.clear();
+	real.clear();
 	if (n_cells == 0) return;
 	DevBuf<u32> &list = real_list; list.ensure(n_cells);
 	scalars.ensure(16);
@@ -426,34 +426,46 @@ void dropest_ctx::fetch_real_cells() {
 		HostCell &h = real[i];
 		h.id = ids[order[i]];
 		h.row = host_rows[order[i]];
-		h.barcode = decode_code(h.row.barcode, side);
-		real_index_of.emplace(h.id, i);
 	}
 }
 
-void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
-	// CellsDataContainer.cpp:250-276 with compare_cells :329-344
-	filtered.clear();
+void dropest_ctx::request_filtered(u32 genes_threshold, int max_cells) {
+	// the real-cell count is cheap and always current; the ordering is produced when somebody reads it
+	filtered_threshold = genes_threshold; filtered_max_cells = max_cells; filtered_valid = false;
 	n_real_now = 0;
-	std::vector<u32> idx;
+	for (const HostCell &h : real) n_real_now += (!h.merged && !h.excluded && h.row.n_genes >= min_before);
+}
+
+const std::vector<uint64_t> &dropest_ctx::filtered_cells() {
+	if (!filtered_valid) { HostStage hs(this, "sort_filtered"); sort_filtered(filtered_threshold, filtered_max_cells); }
+	return filtered;
+}
+
+void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
+	// CellsDataContainer.cpp:250-276 with compare_cells :329-344, on compact keys
+	struct Key { u64 sizes; u64 umis; u64 code; u32 idx; };
+	std::vector<Key> keys;
 	for (u32 i = 0; i < real.size(); ++i) {
 		const HostCell &h = real[i];
-		const bool is_real = !h.merged && !h.excluded && h.row.n_genes >= min_before;
-		if (!is_real) continue;
-		++n_real_now;
-		if (h.row.requested_genes >= genes_threshold) idx.push_back(i);
+		if (h.merged || h.excluded || h.row.n_genes < min_before) continue;
+		if (h.row.requested_genes < genes_threshold) continue;
+		keys.push_back(Key{(u64(h.row.requested_genes) << 32) | h.row.requested_umis,
+		                   u64(size_t(h.row.total_umis)),   // Cell::umis_number casts the int stat to size_t
+		                   h.row.barcode, i});
 	}
-	std::sort(idx.begin(), idx.end(), [&](u32 x, u32 y) {
-		const HostCell &a = real[x], &b = real[y];
-		if (a.row.requested_genes != b.row.requested_genes) return a.row.requested_genes < b.row.requested_genes;
-		if (a.row.requested_umis != b.row.requested_umis) return a.row.requested_umis < b.row.requested_umis;
-		const size_t ua = size_t(a.row.total_umis), ub = size_t(b.row.total_umis);   // Cell::umis_number casts the int stat
-		if (ua != ub) return ua < ub;
-		return a.barcode < b.barcode;
+	std::sort(keys.begin(), keys.end(), [&](const Key &a, const Key &b) {
+		if (a.sizes != b.sizes) return a.sizes < b.sizes;
+		if (a.umis != b.umis) return a.umis < b.umis;
+		// barcode strings: clean codes of equal length order like their strings; anything else is decoded
+		const bool plain = !((a.code | b.code) & ESCAPE_BIT) && bit_length(a.code) == bit_length(b.code);
+		if (plain) return a.code < b.code;
+		return barcode_of(real[a.idx]) < barcode_of(real[b.idx]);
 	});
+	filtered.clear();
 	size_t start = 0;
-	if (max_cells > 0 && size_t(max_cells) < idx.size()) start = idx.size() - size_t(max_cells);
-	for (size_t i = start; i < idx.size(); ++i) filtered.push_back(real[idx[i]].id);
+	if (max_cells > 0 && size_t(max_cells) < keys.size()) start = keys.size() - size_t(max_cells);
+	for (size_t i = start; i < keys.size(); ++i) filtered.push_back(real[keys[i].idx].id);
+	filtered_valid = true;
 }
 
 #include "merge_host.h"
@@ -464,16 +476,16 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 // ------------------------------------------------------------------------------------------------
 void dropest_ctx::run_set_initialized() {
 	if (initialized) throw InvalidError("Container is already initialized");
+	HostStage hs_all(this, "set_initialized");
 	concat_chunks();
 	if (n_reads > 0) {
-		build_cb_table();
-		assign_cell_ids();
-		plan_key_layout();
-		build_keys();
-		reduce_all();
-		fetch_real_cells();
+		{ HostStage hs(this, "cb_table"); build_cb_table(); }
+		{ HostStage hs(this, "cell_ids"); assign_cell_ids(); }
+		{ HostStage hs(this, "keys"); plan_key_layout(); build_keys(); }
+		{ HostStage hs(this, "sort+reduce"); reduce_all(); }
+		{ HostStage hs(this, "real_cells"); fetch_real_cells(); }
 	}
-	sort_filtered(0, -1);   // update_cell_sizes(query, 0, -1), CellsDataContainer.cpp:168
+	request_filtered(0, -1);   // update_cell_sizes(query, 0, -1), CellsDataContainer.cpp:168
 	initialized = true;
 	collect_timings();
 }
@@ -481,9 +493,10 @@ void dropest_ctx::run_set_initialized() {
 void dropest_ctx::run_merge_and_filter() {
 	if (!initialized) throw InvalidError("You must initialize container");
 	if (merged) throw InvalidError("merge_and_filter was already run");
+	HostStage hs(this, "merge_and_filter");
 	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells) run_cb_merge_real();
 	run_umi_merge_simple();   // MergeUMIsStrategySimple::merge, after the CB merge (CellsDataContainer.cpp:45)
-	sort_filtered(min_after, cfg.max_cells);   // CellsDataContainer.cpp:47-49
+	request_filtered(min_after, cfg.max_cells);   // CellsDataContainer.cpp:47-49
 	merged = true;
 	collect_timings();
 }
@@ -492,13 +505,14 @@ void dropest_ctx::run_merge_and_filter() {
 // count matrices
 // ------------------------------------------------------------------------------------------------
 void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host) {
+	HostStage hs(this, filtered_m ? "matrix:cm" : "matrix:cm_raw");
 	MatrixResult &M = mat[filtered_m ? 0 : 1];
 	std::vector<u32> col_cell;
 	M.colptr.clear();
 	uint64_t nnz = 0;
 	if (filtered_m) {
-		for (uint64_t id : filtered) {
-			const HostCell &h = real[real_index_of.at(u32(id))];
+		for (uint64_t id : filtered_cells()) {
+			const HostCell &h = real[real_at(u32(id))];
 			col_cell.push_back(h.id); M.colptr.push_back(u32(nnz)); nnz += h.row.requested_genes;
 		}
 	} else {
@@ -707,9 +721,9 @@ dropest_status dropest_cell_rows(dropest_ctx *ctx, uint64_t first, uint64_t coun
 		HIP_CHECK(hipMemcpyAsync(out, rows.p, count * sizeof(CellRowPod), hipMemcpyDeviceToHost, ctx->stream));
 		HIP_CHECK(hipStreamSynchronize(ctx->stream));
 		for (uint64_t j = 0; j < count; ++j) {   // overlay the host-tracked state of real-candidate cells
-			auto it = ctx->real_index_of.find(u32(first + j));
-			if (it == ctx->real_index_of.end()) continue;
-			const HostCell &h = ctx->real[it->second];
+			const long ri = ctx->real_find(u32(first + j));
+			if (ri < 0) continue;
+			const HostCell &h = ctx->real[size_t(ri)];
 			dropest_cell_row &r = out[j];
 			r.n_genes = h.row.n_genes; r.requested_genes = h.row.requested_genes; r.requested_umis = h.row.requested_umis;
 			r.total_reads = h.row.total_reads; r.total_umis = h.row.total_umis;
@@ -739,8 +753,9 @@ dropest_status dropest_cell_id_by_cb(dropest_ctx *ctx, uint64_t barcode, int64_t
 dropest_status dropest_filtered_cells(dropest_ctx *ctx, uint64_t *n, uint64_t *ids) {
 	return guarded([&] {
 		need_init(ctx);
-		*n = ctx->filtered.size();
-		if (ids) std::copy(ctx->filtered.begin(), ctx->filtered.end(), ids);
+		const std::vector<uint64_t> &f = ctx->filtered_cells();
+		*n = f.size();
+		if (ids) std::copy(f.begin(), f.end(), ids);
 	});
 }
 

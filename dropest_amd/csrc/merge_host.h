@@ -90,10 +90,10 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 
 	std::vector<WlBase> bases(F);
 	for (u32 f = 0; f < F; ++f) {
-		auto it = real_index_of.find(cells[f]);
-		if (it == real_index_of.end()) throw InvalidError("merge target requested for a cell below min_genes_before_merge");
+		const long ri = real_find(cells[f]);
+		if (ri < 0) throw InvalidError("merge target requested for a cell below min_genes_before_merge");
 		std::string a, b;
-		wl.split(real[it->second].barcode, a, b);
+		wl.split(barcode_of(real[size_t(ri)]), a, b);
 		WlBase &wb = bases[f];
 		std::memset(&wb, 0, sizeof(wb));
 		std::memcpy(wb.part[0], a.data(), a.size()); std::memcpy(wb.part[1], b.data(), b.size());
@@ -153,7 +153,7 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 
 	// decisions (RealBarcodesMergeStrategy::get_best_merge_target, :31-61)
 	std::vector<u32> need_order;   // cells whose result depends on the reference's candidate order
-	auto umis_of = [&](u32 cell) { return size_t(real[real_index_of.at(cell)].row.total_umis); };
+	auto umis_of = [&](u32 cell) { return size_t(real[real_at(cell)].row.total_umis); };
 	auto frac_of = [&](u32 base, u32 other, u32 n) { return 0.5 * n * (1. / umis_of(base) + 1. / umis_of(other)); };
 	for (u32 f = 0; f < F; ++f) {
 		if (cnt[f] == 0) { targets[f] = -1; continue; }
@@ -189,7 +189,7 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 			std::unordered_map<u64, u32> by_code;
 			std::unordered_map<u32, u32> inter_of;
 			for (u32 p = pair_first[f]; p < pair_first[f + 1]; ++p) {
-				by_code[real[real_index_of.at(pair_cand[p])].row.barcode] = pair_cand[p];
+				by_code[real[real_at(pair_cand[p])].row.barcode] = pair_cand[p];
 				inter_of[pair_cand[p]] = inter[p];
 			}
 			const std::vector<u32> order = reference_candidate_order(wl, dump.data() + size_t(r) * ntot, by_code);
@@ -206,7 +206,8 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 }
 
 void dropest_ctx::run_cb_merge_real() {
-	std::vector<u32> cells(filtered.begin(), filtered.end());
+	const std::vector<uint64_t> &order = filtered_cells();
+	std::vector<u32> cells(order.begin(), order.end());
 	const std::vector<long> targets = compute_merge_targets(cells);
 
 	// MergeStrategyBase::merge_inited second loop (:30-51) + reassign (:64-82)
@@ -216,12 +217,12 @@ void dropest_ctx::run_cb_merge_real() {
 	bool any_merge = false;
 	for (size_t i = 0; i < cells.size(); ++i) {
 		const u32 base = cells[i];
-		HostCell &hb = real[real_index_of.at(base)];
+		HostCell &hb = real[real_at(base)];
 		long t = targets[i];
 		if (t < 0) { hb.excluded = true; continue; }
 		u32 tgt = current(u32(t));
 		if (tgt == base) continue;
-		HostCell &ht = real[real_index_of.at(tgt)];
+		HostCell &ht = real[real_at(tgt)];
 		// CellsDataContainer::merge_cells (:90-104): Stats::merge adds every counter, TOTAL_UMIS included
 		ht.row.total_reads += hb.row.total_reads;
 		ht.row.total_umis += hb.row.total_umis;

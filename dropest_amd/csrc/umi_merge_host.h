@@ -268,5 +268,5 @@ void dropest_ctx::run_umi_merge_simple() {
 	reduce_cell_gene_to_cells();
 	HIP_CHECK(hipStreamSynchronize(stream));
 	refresh_real_rows();
-	for (auto &kv : umis_removed) real[real_index_of.at(kv.first)].row.total_umis -= kv.second;
+	for (auto &kv : umis_removed) real[real_at(kv.first)].row.total_umis -= kv.second;
 }
