@@ -36,7 +36,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=float, default=float(os.environ.get("DROPEST_BENCH_READS", 1e8)),
                     help="reads per GPU (C2: 1e8)")
-    ap.add_argument("--cells", type=int, default=5000, help="real cells per GPU-share")
+    ap.add_argument("--cells", type=int, default=0, help="real cells per GPU-share (default: 5000 for c2, 50000 for c3)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3"],
+                    help="c2 (default, the metric's configuration): 10x v2, UMI 10, no CB merge; "
+                         "c3: 10x v3, UMI 12, -m + whitelist merge (use --reads 1e9 for BASELINE's size)")
     ap.add_argument("--cpu-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_CPU_SAMPLE", 4e6)),
                     help="reads of the same stream timed on the CPU oracle (rank 0, N=1 only; 0 disables)")
     return ap.parse_args()
@@ -98,13 +101,25 @@ def main():
     reads_per_gpu = int(args.reads)
     total_reads = reads_per_gpu * world
     cfg = {"min_before": 20, "min_after": 100}    # configs/10x.xml:26-27
-    stream = SynthStream(n_reads=total_reads, n_cells=args.cells * world, n_genes=30000, cb_len=16, umi_len=10)
+    c3 = args.config == "c3"
+    if not args.cells:
+        args.cells = 50000 if c3 else 5000
+    if c3 and world > 1:
+        raise SystemExit("c3 (CB merge) is single-GPU in this revision")
+    stream = SynthStream(n_reads=total_reads, n_cells=args.cells * world, n_genes=30000, cb_len=16,
+                         umi_len=12 if c3 else 10, stream_id=3 if c3 else 2)
 
     if world == 1 and not force_sharded:
         from dropest_amd.capi import Context
         dev = stream.generate_device(local_rank, first=0, n=reads_per_gpu)
-        ctx = Context(device=local_rank, merge_kind=capi.MERGE_NONE, min_genes_before_merge=cfg["min_before"],
-                      min_genes_after_merge=cfg["min_after"])
+        if c3:
+            wl = os.path.join(ROOT, "dropest_amd", "data", "barcodes", "10x_aug_2016_split")
+            ctx = Context(device=local_rank, merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST,
+                          barcodes_file=wl, min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"],
+                          min_merge_fraction=0.2)
+        else:
+            ctx = Context(device=local_rank, merge_kind=capi.MERGE_NONE, min_genes_before_merge=cfg["min_before"],
+                          min_genes_after_merge=cfg["min_after"])
         ctx.push_reads_device(*dev.ptrs, dev.n, adopt=True)
         step = lambda: one_step(ctx)   # noqa: E731
         get_stats = ctx.kernel_stats
@@ -166,8 +181,10 @@ def main():
             "metric": "Mreads/s processed to final count matrix", "value": round(value, 2), "unit": "Mreads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2: synthetic 10x v2, %d reads/GPU, %d cells/GPU, 16bp CB + 10bp UMI, 30000 genes, "
-                                   "no CB merge, -L eEBA" % (reads_per_gpu, args.cells),
+            "config": {"workload": ("C3: synthetic 10x v3, %d reads/GPU, %d cells/GPU, 16bp CB + 12bp UMI, 30000 genes, "
+                                    "-m + 10x whitelist (RealBarcodes merge), -L eEBA" if c3 else
+                                    "C2: synthetic 10x v2, %d reads/GPU, %d cells/GPU, 16bp CB + 10bp UMI, 30000 genes, "
+                                    "no CB merge, -L eEBA") % (reads_per_gpu, args.cells),
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d" % world,
                        "cm_nnz": int(len(cm[1])), "filtered_cells": int(len(out[2]))},
             "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kernels,

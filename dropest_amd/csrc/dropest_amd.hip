@@ -264,9 +264,36 @@ void dropest_ctx::build_keys() {
 // ------------------------------------------------------------------------------------------------
 // stage: radix sort
 // ------------------------------------------------------------------------------------------------
+// Variant of the scatter kernel (threads x items per tile, register prefetch); DROPEST_RS_VARIANT overrides the
+// default for A/B measurements.
+struct RsVariant { int tile; void (*launch)(dim3, hipStream_t, const u64 *, const u32 *, u64 *, u32 *, u32, int, u32, const u32 *, const u32 *); };
+template <int T, int I, bool P>
+static void rs_launch(dim3 grid, hipStream_t st, const u64 *k, const u32 *v, u64 *ok, u32 *ov, u32 n, int shift, u32 tpb, const u32 *hist, const u32 *base) {
+	hipLaunchKernelGGL((rs_scatter_kernel_t<T, I, P>), grid, dim3(T), 0, st, k, v, ok, ov, n, shift, tpb, hist, base);
+}
+static RsVariant rs_variant() {
+	static const RsVariant table[] = {
+		{512 * 8, rs_launch<512, 8, false>},    // 0: round-1 baseline
+		{512 * 8, rs_launch<512, 8, true>},     // 1
+		{256 * 16, rs_launch<256, 16, false>},  // 2
+		{256 * 16, rs_launch<256, 16, true>},   // 3
+		{1024 * 4, rs_launch<1024, 4, true>},   // 4
+		{256 * 8, rs_launch<256, 8, true>},     // 5
+		{512 * 4, rs_launch<512, 4, true>},     // 6
+		{1024 * 8, rs_launch<1024, 8, true>},   // 7: 8192-record tile (96 KB of LDS, one block per CU)
+		{1024 * 8, rs_launch<1024, 8, false>},  // 8
+		{512 * 16, rs_launch<512, 16, true>},   // 9
+	};
+	int v = 1;
+	if (const char *e = getenv("DROPEST_RS_VARIANT")) v = atoi(e);
+	if (v < 0 || v >= int(sizeof(table) / sizeof(table[0]))) v = 1;
+	return table[v];
+}
+
 void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask) {
 	if (n == 0) return;
-	const u32 n_tiles = div_up(n, RS_TILE);
+	const RsVariant var = rs_variant();
+	const u32 n_tiles = div_up(n, var.tile);
 	u32 nblocks = std::min<u32>(n_tiles, 1024);
 	const u32 tpb = div_up(n_tiles, nblocks);
 	nblocks = div_up(n_tiles, tpb);
@@ -274,15 +301,14 @@ void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_
 	for (int shift = 0; shift < 64; shift += 8) {
 		if (((varying_mask >> shift) & 0xFFull) == 0) continue;   // digit constant over all keys: pass is the identity
 		timed("rs_hist", double(n) * 8, [&] {
-			hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, keys, n, shift, tpb, rs_hist.p);
+			hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, keys, n, shift, tpb, u32(var.tile), rs_hist.p);
 		});
 		timed("rs_scan", double(RS_RADIX) * nblocks * 8, [&] {
 			hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, stream, rs_hist.p, nblocks, rs_row_total.p);
 			hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(256), 0, stream, rs_row_total.p, rs_digit_base.p);
 		});
 		timed("rs_scatter", double(n) * 24, [&] {
-			hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, keys, vals, keys_alt, vals_alt,
-			                   n, shift, tpb, rs_hist.p, rs_digit_base.p);
+			var.launch(dim3(nblocks), stream, keys, vals, keys_alt, vals_alt, n, shift, tpb, rs_hist.p, rs_digit_base.p);
 		});
 		std::swap(keys, keys_alt);
 		std::swap(vals, vals_alt);
@@ -925,7 +951,8 @@ dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, cons
 		// one stable radix pass on the owner digit over (owner, position) records, then a gather of the four arrays
 		DevBuf<u64> k0, k1; DevBuf<u32> v0, v1, hist, row_total, digit_base;
 		k0.alloc(n); k1.alloc(n); v0.alloc(n); v1.alloc(n);
-		const u32 n_tiles = div_up(n, RS_TILE);
+		const RsVariant var = rs_variant();
+		const u32 n_tiles = div_up(n, var.tile);
 		u32 nblocks = std::min<u32>(n_tiles, 1024);
 		const u32 tpb = div_up(n_tiles, nblocks);
 		nblocks = div_up(n_tiles, tpb);
@@ -933,11 +960,10 @@ dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, cons
 		hipStream_t st = nullptr;
 		hipLaunchKernelGGL(owner_keys_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st,
 		                   reinterpret_cast<const u64 *>(d_cb), n, n_parts, k0.p, v0.p);
-		hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, st, k0.p, n, 0, tpb, hist.p);
+		hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, st, k0.p, n, 0, tpb, u32(var.tile), hist.p);
 		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, st, hist.p, nblocks, row_total.p);
 		hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(256), 0, st, row_total.p, digit_base.p);
-		hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(RS_THREADS), 0, st, k0.p, v0.p, k1.p, v1.p, n, 0, tpb, hist.p,
-		                   digit_base.p);
+		var.launch(dim3(nblocks), st, k0.p, v0.p, k1.p, v1.p, n, 0, tpb, hist.p, digit_base.p);
 		hipLaunchKernelGGL(gather_reads_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st, v1.p, n,
 		                   reinterpret_cast<const u64 *>(d_cb), reinterpret_cast<const u64 *>(d_umi), d_gene, d_aux,
 		                   reinterpret_cast<u64 *>(d_out_cb), reinterpret_cast<u64 *>(d_out_umi), d_out_gene, d_out_aux, d_out_idx);

@@ -26,13 +26,13 @@ constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_RADIX = 256;
 
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const unsigned long long *__restrict__ keys, uint32_t n,
-                                                             int shift, uint32_t tiles_per_block,
+                                                             int shift, uint32_t tiles_per_block, uint32_t tile,
                                                              uint32_t *__restrict__ hist /* [256][gridDim.x] */) {
 	__shared__ uint32_t h[RS_WAVES][RS_RADIX];
 	for (int j = threadIdx.x; j < RS_WAVES * RS_RADIX; j += RS_THREADS) (&h[0][0])[j] = 0;
 	__syncthreads();
-	const uint64_t begin = uint64_t(blockIdx.x) * tiles_per_block * RS_TILE;
-	uint64_t end = begin + uint64_t(tiles_per_block) * RS_TILE;
+	const uint64_t begin = uint64_t(blockIdx.x) * tiles_per_block * tile;
+	uint64_t end = begin + uint64_t(tiles_per_block) * tile;
 	if (end > n) end = n;
 	const uint32_t w = wave_id();
 	for (uint64_t i = begin + threadIdx.x; i < end; i += RS_THREADS) {
@@ -72,46 +72,62 @@ __global__ __launch_bounds__(256) void rs_scan_totals_kernel(const uint32_t *__r
 	digit_base[threadIdx.x] = block_excl_scan_u32<256>(row_total[threadIdx.x], scratch, total);
 }
 
-__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const unsigned long long *__restrict__ keys,
-                                                                const uint32_t *__restrict__ vals,
-                                                                unsigned long long *__restrict__ okeys,
-                                                                uint32_t *__restrict__ ovals, uint32_t n, int shift,
-                                                                uint32_t tiles_per_block,
-                                                                const uint32_t *__restrict__ hist,
-                                                                const uint32_t *__restrict__ digit_base) {
-	__shared__ uint32_t wcnt[RS_WAVES][RS_RADIX];   // per-wave digit counts -> per-wave digit offsets
+// THREADS x ITEMS records per tile.  PREFETCH: the next tile's records are loaded into registers before the
+// current tile is ranked, so the HBM latency of tile t+1 hides behind the LDS / ballot work of tile t.
+template <int THREADS, int ITEMS, bool PREFETCH>
+__global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned long long *__restrict__ keys,
+                                                               const uint32_t *__restrict__ vals,
+                                                               unsigned long long *__restrict__ okeys,
+                                                               uint32_t *__restrict__ ovals, uint32_t n, int shift,
+                                                               uint32_t tiles_per_block,
+                                                               const uint32_t *__restrict__ hist,
+                                                               const uint32_t *__restrict__ digit_base) {
+	constexpr int TILE = THREADS * ITEMS, WAVES = THREADS / 64;
+	static_assert(THREADS >= RS_RADIX, "one thread per digit is needed for the digit scan");
+	__shared__ uint32_t wcnt[WAVES][RS_RADIX];      // per-wave digit counts -> per-wave digit offsets
 	__shared__ uint32_t tcnt[RS_RADIX];             // digit counts of the tile
 	__shared__ uint32_t tstart[RS_RADIX];           // digit start inside the re-ordered tile
 	__shared__ uint32_t goff[RS_RADIX];             // running global cursor per digit (this block)
-	__shared__ uint32_t scratch[RS_THREADS / 64 + 1];
-	__shared__ unsigned long long sk[RS_TILE];
-	__shared__ uint32_t sv[RS_TILE];
+	__shared__ uint32_t scratch[THREADS / 64 + 1];
+	__shared__ unsigned long long sk[TILE];
+	__shared__ uint32_t sv[TILE];
 
 	const uint32_t tid = threadIdx.x, w = wave_id(), lane = lane_id();
 	const unsigned long long lt_mask = (1ull << lane) - 1ull;
 	if (tid < RS_RADIX) goff[tid] = digit_base[tid] + hist[tid * gridDim.x + blockIdx.x];
 
 	const uint64_t first_tile = uint64_t(blockIdx.x) * tiles_per_block;
-	for (uint32_t tt = 0; tt < tiles_per_block; ++tt) {
-		const uint64_t tile_base = (first_tile + tt) * RS_TILE;
-		if (tile_base >= n) break;
-		const uint64_t wave_base = tile_base + uint64_t(w) * (64 * RS_ITEMS);
-
-		unsigned long long key[RS_ITEMS];
-		uint32_t val[RS_ITEMS], lrank[RS_ITEMS];
+	unsigned long long key[ITEMS], nkey[ITEMS];
+	uint32_t val[ITEMS], nval[ITEMS], lrank[ITEMS];
+	auto load_tile = [&](uint64_t tile_base, unsigned long long (&k)[ITEMS], uint32_t (&v)[ITEMS]) {
+		const uint64_t wave_base = tile_base + uint64_t(w) * (64 * ITEMS);
 #pragma unroll
-		for (int i = 0; i < RS_ITEMS; ++i) {
-			uint64_t idx = wave_base + uint64_t(i) * 64 + lane;
-			bool valid = idx < n;
-			key[i] = valid ? keys[idx] : ~0ull;
-			val[i] = valid ? vals[idx] : 0u;
+		for (int i = 0; i < ITEMS; ++i) {
+			const uint64_t idx = wave_base + uint64_t(i) * 64 + lane;
+			const bool valid = idx < n;
+			k[i] = valid ? keys[idx] : ~0ull;
+			v[i] = valid ? vals[idx] : 0u;
 		}
-		for (int j = tid; j < RS_WAVES * RS_RADIX; j += RS_THREADS) (&wcnt[0][0])[j] = 0;
+	};
+	if (PREFETCH && first_tile * TILE < n) load_tile(first_tile * TILE, nkey, nval);
+
+	for (uint32_t tt = 0; tt < tiles_per_block; ++tt) {
+		const uint64_t tile_base = (first_tile + tt) * TILE;
+		if (tile_base >= n) break;
+		const uint64_t wave_base = tile_base + uint64_t(w) * (64 * ITEMS);
+		if (PREFETCH) {
+#pragma unroll
+			for (int i = 0; i < ITEMS; ++i) { key[i] = nkey[i]; val[i] = nval[i]; }
+			if (tt + 1 < tiles_per_block && tile_base + TILE < n) load_tile(tile_base + TILE, nkey, nval);
+		} else {
+			load_tile(tile_base, key, val);
+		}
+		for (int j = tid; j < WAVES * RS_RADIX; j += THREADS) (&wcnt[0][0])[j] = 0;
 		__syncthreads();
 
 		// wave-level multisplit: rank of each key among the keys of its wave with the same digit
 #pragma unroll
-		for (int i = 0; i < RS_ITEMS; ++i) {
+		for (int i = 0; i < ITEMS; ++i) {
 			const bool valid = (wave_base + uint64_t(i) * 64 + lane) < n;
 			const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
 			unsigned long long m = __ballot(valid);
@@ -134,17 +150,17 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const unsigned l
 		uint32_t run = 0;
 		if (tid < RS_RADIX) {
 #pragma unroll
-			for (int k = 0; k < RS_WAVES; ++k) { uint32_t c = wcnt[k][tid]; wcnt[k][tid] = run; run += c; }
+			for (int k = 0; k < WAVES; ++k) { uint32_t c = wcnt[k][tid]; wcnt[k][tid] = run; run += c; }
 			tcnt[tid] = run;
 		}
 		uint32_t total;
-		uint32_t ex = block_excl_scan_u32<RS_THREADS>(tid < RS_RADIX ? run : 0u, scratch, total);
+		uint32_t ex = block_excl_scan_u32<THREADS>(tid < RS_RADIX ? run : 0u, scratch, total);
 		if (tid < RS_RADIX) tstart[tid] = ex;
 		__syncthreads();
 
 		// re-order the tile by digit in LDS
 #pragma unroll
-		for (int i = 0; i < RS_ITEMS; ++i) {
+		for (int i = 0; i < ITEMS; ++i) {
 			const bool valid = (wave_base + uint64_t(i) * 64 + lane) < n;
 			if (valid) {
 				const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const unsigned l
 		__syncthreads();
 
 		// coalesced write-out: consecutive threads write consecutive addresses inside a digit run
-		for (uint32_t p = tid; p < total; p += RS_THREADS) {
+		for (uint32_t p = tid; p < total; p += THREADS) {
 			const unsigned long long k = sk[p];
 			const uint32_t d = uint32_t(k >> shift) & 0xFFu;
 			const uint32_t g = goff[d] + (p - tstart[d]);
