@@ -91,8 +91,8 @@ struct dropest_ctx {
 	bool initialized = false, merged = false;
 
 	// ---- device results ----
-	dropest::DevBuf<u64> t_keys;
-	dropest::DevBuf<u32> t_first, t_cell, slot;
+	dropest::DevBuf<dropest::CbSlot> t_slots;
+	dropest::DevBuf<u32> slot;
 	dropest::CbTable table{};
 	u32 n_cells = 0;
 	dropest::DevBuf<u64> cell_cb;
@@ -126,6 +126,10 @@ struct dropest_ctx {
 	std::unordered_map<u32, u32> reassign;   // merged cell -> final target (MergeStrategyBase cb_reassign_targets, sparse)
 	// (cell, gene) groups rewritten by the N-UMI merge: key = molecule key >> umi_bits, value = the group's molecules
 	std::unordered_map<u64, std::vector<dropest::UmiOverride>> umi_overrides;
+
+	// pinned staging for the small device->host read-backs of the hot path (pageable copies cost ~0.5 ms each)
+	dropest::PinnedBuf<unsigned char> h_stage;
+	void fetch(void *dst, const void *d_src, size_t bytes);   // D2H through h_stage + stream sync
 
 	// scratch
 	dropest::DevBuf<u32> tile_counts, tile_prefix, scalars, rs_hist, rs_row_total, rs_digit_base;

@@ -98,6 +98,14 @@ void dropest_ctx::timed(const char *name, double bytes, F &&launch) {
 	pending.push_back(Pending{name, a, b, bytes});
 }
 
+void dropest_ctx::fetch(void *dst, const void *d_src, size_t bytes) {
+	if (!bytes) return;
+	h_stage.ensure(std::max<size_t>(bytes, 4096));
+	HIP_CHECK(hipMemcpyAsync(h_stage.p, d_src, bytes, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	std::memcpy(dst, h_stage.p, bytes);
+}
+
 void dropest_ctx::collect_timings() {
 	if (pending.empty()) return;
 	HIP_CHECK(hipStreamSynchronize(stream));
@@ -154,10 +162,9 @@ void dropest_ctx::build_cb_table() {
 	d_ingest.ensure(1);
 	for (int attempt = 0;; ++attempt) {
 		if (cap > (1ull << 32)) throw UnsupportedError("barcode table would exceed 2^32 slots");
-		t_keys.ensure(cap); t_first.ensure(cap); t_cell.ensure(cap);
-		table.keys = t_keys.p; table.first = t_first.p; table.cell_id = t_cell.p; table.mask = cap - 1;
-		HIP_CHECK(hipMemsetAsync(t_keys.p, 0, cap * 8, stream));
-		HIP_CHECK(hipMemsetAsync(t_first.p, 0xFF, cap * 4, stream));
+		t_slots.ensure(cap);
+		table.slots = t_slots.p; table.mask = cap - 1;
+		HIP_CHECK(hipMemsetAsync(t_slots.p, 0, cap * sizeof(CbSlot), stream));
 		IngestStats init{};
 		init.umi_clean_min = ~0ull;
 		HIP_CHECK(hipMemcpyAsync(d_ingest.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
@@ -166,8 +173,7 @@ void dropest_ctx::build_cb_table() {
 			hipLaunchKernelGGL(cb_insert_kernel<256>, dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, n, table,
 			                   slot.p, d_ingest.p);
 		});
-		HIP_CHECK(hipMemcpyAsync(&ingest, d_ingest.p, sizeof(ingest), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
+		fetch(&ingest, d_ingest.p, sizeof(ingest));
 		if (!ingest.overflow) break;
 		if (attempt >= 6) throw DeviceError("barcode table overflow after repeated growth");
 		cap <<= 2;
@@ -185,8 +191,7 @@ void dropest_ctx::assign_cell_ids() {
 		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, tile_counts.p, tile_prefix.p, tiles, scalars.p);
 	});
 	u32 total = 0;
-	HIP_CHECK(hipMemcpyAsync(&total, scalars.p, 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	fetch(&total, scalars.p, 4);
 	n_cells = total;
 	if (uint64_t(n_cells) * 10 > (table.mask + 1) * 7)   // load factor > 0.7: rebuild larger for short probe chains
 	{
@@ -257,8 +262,7 @@ void dropest_ctx::build_keys() {
 		hipLaunchKernelGGL(build_keys_kernel<256>, dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n,
 		                   table, layout, keys_a.p, vals_a.p, d_counters.p);
 	});
-	HIP_CHECK(hipMemcpyAsync(&counters, d_counters.p, sizeof(counters), hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	fetch(&counters, d_counters.p, sizeof(counters));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -323,7 +327,7 @@ void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_
 template <class P, class Prep>
 static u32 run_segmented_reduce(dropest_ctx &c, const char *tag, P &policy, u32 n, double bytes_per_row, Prep &&prepare) {
 	if (n == 0) { prepare(0); return 0; }
-	const u32 tiles = div_up(n, SR_TILE);
+	const u32 tiles = div_up(n, SR_THREADS * P::ITEMS);
 	c.tile_counts.ensure(tiles); c.tile_prefix.ensure(tiles); c.scalars.ensure(16);
 	const std::string n_count = std::string("seg_count:") + tag, n_reduce = std::string("seg_reduce:") + tag;
 	c.timed(n_count.c_str(), double(n) * 8, [&] {
@@ -334,8 +338,7 @@ static u32 run_segmented_reduce(dropest_ctx &c, const char *tag, P &policy, u32 
 		                   c.scalars.p);
 	});
 	u32 total = 0;
-	HIP_CHECK(hipMemcpyAsync(&total, c.scalars.p, 4, hipMemcpyDeviceToHost, c.stream));
-	HIP_CHECK(hipStreamSynchronize(c.stream));
+	c.fetch(&total, c.scalars.p, 4);
 	prepare(total);
 	c.timed(n_reduce.c_str(), double(n) * bytes_per_row, [&] {
 		hipLaunchKernelGGL(seg_reduce_kernel<P>, dim3(tiles), dim3(SR_THREADS), 0, c.stream, policy, n, c.tile_prefix.p);
@@ -410,7 +413,7 @@ void dropest_ctx::reduce_cell_gene_to_cells() {
 	p.out[0] = cell_n_genes.p; p.out[1] = cell_req_genes.p; p.out[2] = cell_req_umis.p;
 	p.out[3] = cell_total_umis.p; p.out[4] = cell_total_reads.p; p.out[5] = cell_cg_count.p;
 	if (n_cg == 0) return;
-	const u32 tiles = div_up(n_cg, SR_TILE);
+	const u32 tiles = div_up(n_cg, SR_THREADS * CellGeneToCells::ITEMS);
 	timed("seg_reduce:cells", double(n_cg) * (24 + 4), [&] {
 		hipLaunchKernelGGL(seg_reduce_kernel<CellGeneToCells>, dim3(tiles), dim3(SR_THREADS), 0, stream, p, n_cg,
 		                   static_cast<const u32 *>(nullptr));
@@ -425,14 +428,16 @@ void dropest_ctx::fetch_real_cells() {
 	if (n_cells == 0) return;
 	DevBuf<u32> &list = real_list; list.ensure(n_cells);
 	scalars.ensure(16);
-	zero_async(*this, scalars.p, 4);
-	timed("flag_real", double(n_cells) * 4, [&] {
-		hipLaunchKernelGGL(flag_real_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, stream, cell_n_genes.p, n_cells,
-		                   min_before, list.p, scalars.p);
+	const u32 tiles = div_up(n_cells, RC_TILE);
+	tile_counts.ensure(tiles); tile_prefix.ensure(tiles);
+	timed("flag_real", double(n_cells) * 8, [&] {
+		hipLaunchKernelGGL(count_real_kernel, dim3(tiles), dim3(RC_THREADS), 0, stream, cell_n_genes.p, n_cells, min_before, tile_counts.p);
+		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, tile_counts.p, tile_prefix.p, tiles, scalars.p);
+		hipLaunchKernelGGL(write_real_kernel, dim3(tiles), dim3(RC_THREADS), 0, stream, cell_n_genes.p, n_cells, min_before,
+		                   tile_prefix.p, list.p);
 	});
 	u32 count = 0;
-	HIP_CHECK(hipMemcpyAsync(&count, scalars.p, 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	fetch(&count, scalars.p, 4);
 	if (count == 0) return;
 	DevBuf<CellRowPod> &rows = real_rows_dev; rows.ensure(count);
 	CellArrays a{cell_cb.p, cell_first.p, cell_n_genes.p, cell_req_genes.p, cell_req_umis.p, cell_total_umis.p, cell_total_reads.p};
@@ -441,17 +446,14 @@ void dropest_ctx::fetch_real_cells() {
 	});
 	std::vector<u32> ids(count);
 	std::vector<CellRowPod> host_rows(count);
-	HIP_CHECK(hipMemcpyAsync(ids.data(), list.p, size_t(count) * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipMemcpyAsync(host_rows.data(), rows.p, size_t(count) * sizeof(CellRowPod), hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
-	std::vector<u32> order(count);
-	for (u32 i = 0; i < count; ++i) order[i] = i;
-	std::sort(order.begin(), order.end(), [&](u32 x, u32 y) { return ids[x] < ids[y]; });
-	real.resize(count);
+	fetch(ids.data(), list.p, size_t(count) * 4);
+	fetch(host_rows.data(), rows.p, size_t(count) * sizeof(CellRowPod));
+	real.resize(count);   // ids arrive ascending (ordered compaction)
 	for (u32 i = 0; i < count; ++i) {
 		HostCell &h = real[i];
-		h.id = ids[order[i]];
-		h.row = host_rows[order[i]];
+		h.id = ids[i];
+		h.row = host_rows[i];
+		h.merged = h.excluded = false;
 	}
 }
 
@@ -767,10 +769,10 @@ dropest_status dropest_cell_id_by_cb(dropest_ctx *ctx, uint64_t barcode, int64_t
 		// host-side probe of the device table (a handful of 8-byte reads)
 		uint64_t h = mix64(barcode) & ctx->table.mask;
 		for (u32 probe = 0; probe < CB_MAX_PROBE; ++probe) {
-			u64 k = 0;
-			HIP_CHECK(hipMemcpy(&k, ctx->table.keys + h, 8, hipMemcpyDeviceToHost));
-			if (k == barcode) { u32 c = 0; HIP_CHECK(hipMemcpy(&c, ctx->table.cell_id + h, 4, hipMemcpyDeviceToHost)); *id = c; return; }
-			if (k == 0) return;
+			CbSlot sl;
+			HIP_CHECK(hipMemcpy(&sl, ctx->table.slots + h, sizeof(sl), hipMemcpyDeviceToHost));
+			if (sl.key == barcode) { *id = sl.cell_id; return; }
+			if (sl.key == 0) return;
 			h = (h + 1) & ctx->table.mask;
 		}
 	});

@@ -13,11 +13,20 @@
 
 namespace dropest {
 
+// One 16-byte slot per barcode: the key, its first-seen ordinal and its cell id share a cache line, so a probe
+// that hits costs ONE random access.  `nfirst` stores ~ordinal: the all-zero pattern of a fresh table then means
+// "empty key, no ordinal yet" and atomicMax(nfirst, ~r) is atomicMin(first, r).
+struct CbSlot {
+	unsigned long long key;   // packed barcode, 0 = empty
+	uint32_t nfirst;          // ~(min read ordinal), 0 = unset
+	uint32_t cell_id;         // first-seen rank (filled by cb_assign_ids)
+};
+static_assert(sizeof(CbSlot) == 16, "slot layout");
+
 struct CbTable {
-	unsigned long long *keys;   // [capacity] packed barcode, 0 = empty
-	uint32_t *first;            // [capacity] min read ordinal, 0xFFFFFFFF = unset
-	uint32_t *cell_id;          // [capacity] first-seen rank (filled by assign_cell_ids)
-	uint64_t mask;              // capacity - 1
+	CbSlot *slots;
+	uint64_t mask;   // capacity - 1
+	__device__ uint32_t first(uint32_t s) const { return ~slots[s].nfirst; }
 };
 
 // Statistics gathered while streaming the reads once (sizes the sort key; see pipeline).
@@ -33,15 +42,14 @@ constexpr uint32_t CB_MAX_PROBE = 8192;
 constexpr uint64_t ESCAPE_BIT = 0x8000000000000000ull;
 constexpr uint32_t NO_GENE = 0xFFFFFFFFu;
 
-__device__ inline uint32_t cb_find_or_insert(const CbTable &t, unsigned long long k, bool &ok) {
-	uint64_t h = mix64(k) & t.mask;
+__device__ inline uint32_t cb_find_or_insert(const CbTable &t, unsigned long long k, uint64_t h, bool &ok) {
 	for (uint32_t probe = 0; probe < CB_MAX_PROBE; ++probe) {
 		// Plain load as a hint: a slot only ever goes 0 -> key, so a stale 0 merely sends us to the CAS,
 		// whose return value is authoritative.
-		unsigned long long cur = t.keys[h];
+		unsigned long long cur = t.slots[h].key;
 		if (cur == k) return uint32_t(h);
 		if (cur == 0ull) {
-			unsigned long long prev = atomicCAS(&t.keys[h], 0ull, k);
+			unsigned long long prev = atomicCAS(&t.slots[h].key, 0ull, k);
 			if (prev == 0ull || prev == k) return uint32_t(h);
 		}
 		h = (h + 1) & t.mask;
@@ -53,7 +61,7 @@ __device__ inline uint32_t cb_find_or_insert(const CbTable &t, unsigned long lon
 __device__ inline uint32_t cb_find(const CbTable &t, unsigned long long k) {   // 0xFFFFFFFF if absent
 	uint64_t h = mix64(k) & t.mask;
 	for (uint32_t probe = 0; probe < CB_MAX_PROBE; ++probe) {
-		unsigned long long cur = t.keys[h];
+		unsigned long long cur = t.slots[h].key;
 		if (cur == k) return uint32_t(h);
 		if (cur == 0ull) return 0xFFFFFFFFu;
 		h = (h + 1) & t.mask;
@@ -61,28 +69,56 @@ __device__ inline uint32_t cb_find(const CbTable &t, unsigned long long k) {   /
 	return 0xFFFFFFFFu;
 }
 
-// One pass over (cb, umi, gene): table insert + first ordinal + ingest statistics.
+// One pass over (cb, umi, gene): table insert + first ordinal + ingest statistics.  Four reads per thread and
+// iteration: their first probes are independent 16-byte loads in flight together (the kernel is latency-bound).
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long long *__restrict__ cb,
                                                             const unsigned long long *__restrict__ umi,
                                                             const uint32_t *__restrict__ gene, uint32_t n, CbTable t,
                                                             uint32_t *__restrict__ slot_out, IngestStats *stats) {
+	constexpr int ILP = 4;
 	unsigned long long umin = ~0ull, umax = 0ull, uesc = 0ull, cbesc = 0ull;
 	uint32_t gmax = 0;
 	bool ok = true;
-	const uint32_t stride = gridDim.x * THREADS;
-	for (uint32_t r = blockIdx.x * THREADS + threadIdx.x; r < n; r += stride) {
-		const unsigned long long k = cb[r];
-		const uint32_t s = cb_find_or_insert(t, k, ok);
-		slot_out[r] = s;
-		// stale (too large) values of first[] only cost an extra atomic; values never grow
-		if (r < t.first[s]) atomicMin(&t.first[s], r);
-		const unsigned long long u = umi[r];
-		if (u & ESCAPE_BIT) { unsigned long long id1 = (u & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
-		else { umin = u < umin ? u : umin; umax = u > umax ? u : umax; }
-		if (k & ESCAPE_BIT) ++cbesc;
-		const uint32_t g = gene[r];
-		if (g != NO_GENE && g + 1 > gmax) gmax = g + 1;
+	const uint64_t stride = uint64_t(gridDim.x) * THREADS;
+	for (uint64_t r0 = uint64_t(blockIdx.x) * THREADS + threadIdx.x; r0 < n; r0 += stride * ILP) {
+		unsigned long long k[ILP], u[ILP];
+		uint64_t h[ILP];
+		uint4 v[ILP];
+		uint32_t g[ILP];
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) {
+			const uint64_t r = r0 + uint64_t(j) * stride;
+			k[j] = r < n ? cb[r] : 0ull;
+		}
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) {
+			h[j] = mix64(k[j]) & t.mask;
+			v[j] = *reinterpret_cast<const uint4 *>(&t.slots[h[j]]);   // key + ~first in one access
+		}
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) {
+			const uint64_t r = r0 + uint64_t(j) * stride;
+			u[j] = r < n ? umi[r] : 0ull;
+			g[j] = r < n ? gene[r] : NO_GENE;
+		}
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) {
+			const uint64_t r = r0 + uint64_t(j) * stride;
+			if (r >= n) continue;
+			const unsigned long long cur = (unsigned long long)v[j].x | ((unsigned long long)v[j].y << 32);
+			uint32_t s;
+			uint32_t first_hint = 0xFFFFFFFFu;
+			if (cur == k[j]) { s = uint32_t(h[j]); first_hint = ~v[j].z; }
+			else s = cb_find_or_insert(t, k[j], h[j], ok);
+			slot_out[r] = s;
+			// stale (too large) hints only cost an extra atomic; ordinals only ever decrease
+			if (uint32_t(r) < first_hint) atomicMax(&t.slots[s].nfirst, ~uint32_t(r));
+			if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
+			else { umin = u[j] < umin ? u[j] : umin; umax = u[j] > umax ? u[j] : umax; }
+			if (k[j] & ESCAPE_BIT) ++cbesc;
+			if (g[j] != NO_GENE && g[j] + 1 > gmax) gmax = g[j] + 1;
+		}
 	}
 	umin = wave_reduce_min_u64(umin); umax = wave_reduce_max_u64(umax); uesc = wave_reduce_max_u64(uesc);
 	cbesc = wave_reduce_add_u64(cbesc);
@@ -109,7 +145,7 @@ __global__ __launch_bounds__(CID_THREADS) void cb_first_count_kernel(const uint3
 #pragma unroll
 	for (int j = 0; j < CID_ITEMS; ++j) {
 		uint32_t r = base + j * CID_THREADS + threadIdx.x;
-		if (r < n) c += (t.first[slot[r]] == r);
+		if (r < n) c += (t.first(slot[r]) == r);
 	}
 	uint32_t total;
 	block_excl_scan_u32<CID_THREADS>(c, scratch, total);
@@ -130,7 +166,7 @@ __global__ __launch_bounds__(CID_THREADS) void cb_assign_ids_kernel(const unsign
 #pragma unroll
 	for (int j = 0; j < CID_ITEMS; ++j) {
 		uint32_t r = r0 + j;
-		if (r < n && t.first[slot[r]] == r) { flags |= 1u << j; ++c; }
+		if (r < n && t.first(slot[r]) == r) { flags |= 1u << j; ++c; }
 	}
 	uint32_t total;
 	uint32_t id = tile_prefix[blockIdx.x] + block_excl_scan_u32<CID_THREADS>(c, scratch, total);
@@ -138,7 +174,7 @@ __global__ __launch_bounds__(CID_THREADS) void cb_assign_ids_kernel(const unsign
 	for (int j = 0; j < CID_ITEMS; ++j) {
 		if (flags & (1u << j)) {
 			uint32_t r = r0 + j;
-			t.cell_id[slot[r]] = id;
+			t.slots[slot[r]].cell_id = id;
 			cell_cb[id] = cb[r];
 			cell_first[id] = r;
 			++id;

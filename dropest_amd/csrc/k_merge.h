@@ -163,7 +163,7 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 				const unsigned long long code = wl_append(wl_append(1ull, a.part[0][i].seq), a.part[1][j].seq);
 				const uint32_t s = cb_find(a.table, code);
 				if (s == 0xFFFFFFFFu) continue;
-				const uint32_t c = a.table.cell_id[s];
+				const uint32_t c = a.table.slots[s].cell_id;
 				if (a.cell_n_genes[c] >= a.min_genes && a.cell_total_umis[c] >= base_umis) {
 					const uint32_t k = atomicAdd(&n_found, 1u);
 					if (k < WL_CAND_CAP) a.cand_cell[size_t(blockIdx.x) * WL_CAND_CAP + k] = c;

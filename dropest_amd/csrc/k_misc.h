@@ -48,7 +48,7 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 	unsigned long long c_inter = 0, c_exon = 0, c_intron = 0, c_na = 0, k_or = 0, k_and = ~0ull;
 	const uint32_t stride = gridDim.x * THREADS;
 	for (uint32_t r = blockIdx.x * THREADS + threadIdx.x; r < n; r += stride) {
-		const unsigned long long cell = t.cell_id[slot[r]];
+		const unsigned long long cell = t.slots[slot[r]].cell_id;
 		const uint32_t g = gene[r];
 		const uint32_t a = aux[r];
 		const uint32_t mark = (a >> 16) & 0xFFu;
@@ -79,18 +79,34 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 	}
 }
 
-// ---- real cells: Cell::is_real before any merge (Cell.cpp:125-128) -> compacted id list --------------
-__global__ __launch_bounds__(256) void flag_real_kernel(const uint32_t *__restrict__ n_genes, uint32_t n_cells,
-                                                        uint32_t min_genes, uint32_t *__restrict__ real_list,
-                                                        uint32_t *__restrict__ real_count) {
-	// order of the list is irrelevant (the host sorts); one atomic per wave
-	uint32_t i = blockIdx.x * 256 + threadIdx.x;
-	bool real = i < n_cells && n_genes[i] >= min_genes;
-	unsigned long long m = __ballot(real);
-	uint32_t base = 0;
-	if (lane_id() == 0 && m) base = atomicAdd(real_count, uint32_t(__popcll(m)));
-	base = __shfl(base, 0, 64);
-	if (real) real_list[base + __popcll(m & ((1ull << lane_id()) - 1ull))] = i;
+// ---- real cells: Cell::is_real before any merge (Cell.cpp:125-128) -> id list in ascending order ---------
+// ordered stream compaction: per-tile counts, scan_small, ordered write (the host needs the ids ascending)
+constexpr int RC_THREADS = 256, RC_ITEMS = 8, RC_TILE = RC_THREADS * RC_ITEMS;
+__global__ __launch_bounds__(RC_THREADS) void count_real_kernel(const uint32_t *__restrict__ n_genes, uint32_t n_cells,
+                                                                uint32_t min_genes, uint32_t *__restrict__ tile_counts) {
+	__shared__ uint32_t scratch[RC_THREADS / 64 + 1];
+	const uint32_t i0 = blockIdx.x * RC_TILE + threadIdx.x * RC_ITEMS;
+	uint32_t c = 0;
+#pragma unroll
+	for (int j = 0; j < RC_ITEMS; ++j) c += (i0 + j < n_cells && n_genes[i0 + j] >= min_genes);
+	uint32_t total;
+	block_excl_scan_u32<RC_THREADS>(c, scratch, total);
+	if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(RC_THREADS) void write_real_kernel(const uint32_t *__restrict__ n_genes, uint32_t n_cells,
+                                                                uint32_t min_genes, const uint32_t *__restrict__ tile_prefix,
+                                                                uint32_t *__restrict__ real_list) {
+	__shared__ uint32_t scratch[RC_THREADS / 64 + 1];
+	const uint32_t i0 = blockIdx.x * RC_TILE + threadIdx.x * RC_ITEMS;
+	uint32_t flags = 0, c = 0;
+#pragma unroll
+	for (int j = 0; j < RC_ITEMS; ++j)
+		if (i0 + j < n_cells && n_genes[i0 + j] >= min_genes) { flags |= 1u << j; ++c; }
+	uint32_t total;
+	uint32_t o = tile_prefix[blockIdx.x] + block_excl_scan_u32<RC_THREADS>(c, scratch, total);
+#pragma unroll
+	for (int j = 0; j < RC_ITEMS; ++j)
+		if (flags & (1u << j)) real_list[o++] = i0 + j;
 }
 
 // gathers the per-cell header + size rows of a list of cells (device -> staging for one D2H copy)

@@ -21,23 +21,23 @@
 
 namespace dropest {
 
-constexpr int SR_THREADS = 256, SR_ITEMS = 8, SR_TILE = SR_THREADS * SR_ITEMS;
+constexpr int SR_THREADS = 256;   // rows per thread = P::ITEMS, tile = SR_THREADS * P::ITEMS
+
+// padded LDS index: 8 logical entries occupy 9 physical ones, so that a thread reading its consecutive rows
+// (stride ITEMS entries across lanes) hits distinct banks
+__device__ inline uint32_t sr_pad(uint32_t i) { return i + (i >> 3); }
 
 template <class P>
 __global__ __launch_bounds__(SR_THREADS) void seg_count_kernel(P p, uint32_t n, uint32_t *__restrict__ tile_heads) {
+	constexpr int SR_ITEMS = P::ITEMS, SR_TILE = SR_THREADS * SR_ITEMS;
 	__shared__ uint32_t scratch[SR_THREADS / 64 + 1];
-	const uint32_t i0 = blockIdx.x * SR_TILE + threadIdx.x * SR_ITEMS;
+	// striped (coalesced) accesses: a head is a row whose segment key differs from its predecessor's
+	const uint32_t t0 = blockIdx.x * SR_TILE;
 	uint32_t c = 0;
-	if (i0 < n) {
-		unsigned long long prev = i0 ? p.seg_key(i0 - 1) : ~p.seg_key(0);
 #pragma unroll
-		for (int j = 0; j < SR_ITEMS; ++j) {
-			if (i0 + j < n) {
-				unsigned long long k = p.seg_key(i0 + j);
-				c += (k != prev);
-				prev = k;
-			}
-		}
+	for (int j = 0; j < SR_ITEMS; ++j) {
+		const uint32_t i = t0 + j * SR_THREADS + threadIdx.x;
+		if (i < n) c += (i == 0) || (p.seg_key(i) != p.seg_key(i - 1));
 	}
 	uint32_t total;
 	block_excl_scan_u32<SR_THREADS>(c, scratch, total);
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(SR_THREADS) void seg_count_kernel(P p, uint32_t n, 
 }
 
 // P must provide:
+//   static constexpr int ITEMS;                      rows per thread (tile = 256 * ITEMS)
 //   static constexpr int NV;                         number of u32 channels
 //   static constexpr unsigned OR_MASK;               bit c set: channel c combines with OR, else with +
 //   __device__ unsigned long long seg_key(uint32_t i) const;
@@ -58,31 +59,52 @@ template <class P>
 __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
                                                                 const uint32_t *__restrict__ tile_prefix) {
 	constexpr int NV = P::NV;
+	constexpr int SR_ITEMS = P::ITEMS, SR_TILE = SR_THREADS * SR_ITEMS;
+	constexpr int PADDED = SR_TILE + SR_TILE / 8 + 2;
 	__shared__ uint32_t scratch[SR_THREADS / 64 + 1];
-	__shared__ uint32_t agg[NV][SR_TILE + 1];   // slot 0 = run continuing from the previous tile
+	__shared__ unsigned long long skey[PADDED];   // logical index 0 = predecessor of the tile, 1.. = rows
+	__shared__ uint32_t sval[NV][PADDED];         // per-row contributions
+	__shared__ uint32_t agg[NV][SR_TILE + 1];     // slot 0 = run continuing from the previous tile
 	__shared__ uint32_t slot_row[P::DIRECT ? SR_TILE + 1 : 1];   // DIRECT: output row of each slot
 	for (int j = threadIdx.x; j < NV * (SR_TILE + 1); j += SR_THREADS) (&agg[0][0])[j] = 0;
-	if (P::DIRECT && threadIdx.x == 0) {
-		const uint32_t t0 = blockIdx.x * SR_TILE;
-		slot_row[0] = (t0 && t0 < n) ? p.direct_index(p.seg_key(t0 - 1)) : 0u;
-	}
 
-	const uint32_t i0 = blockIdx.x * SR_TILE + threadIdx.x * SR_ITEMS;
+	// phase 1: coalesced (striped) loads of keys and contributions into LDS
+	const uint32_t t0 = blockIdx.x * SR_TILE;
+#pragma unroll
+	for (int j = 0; j < SR_ITEMS; ++j) {
+		const uint32_t r = j * SR_THREADS + threadIdx.x, i = t0 + r;
+		if (i < n) {
+			skey[sr_pad(r + 1)] = p.seg_key(i);
+			uint32_t v[NV];
+			p.load(i, v);
+#pragma unroll
+			for (int c2 = 0; c2 < NV; ++c2) sval[c2][sr_pad(r)] = v[c2];
+		}
+	}
+	if (threadIdx.x == 0) {
+		const unsigned long long pred = t0 ? p.seg_key(t0 - 1) : ~p.seg_key(0);
+		skey[sr_pad(0)] = pred;
+		if (P::DIRECT) slot_row[0] = t0 ? p.direct_index(pred) : 0u;
+	}
+	__syncthreads();
+
+	// phase 2: each thread owns SR_ITEMS consecutive rows
+	const uint32_t r0 = threadIdx.x * SR_ITEMS, i0 = t0 + r0;
 	unsigned long long key[SR_ITEMS];
 	uint32_t heads = 0, c = 0;
 	if (i0 < n) {
-		unsigned long long prev = i0 ? p.seg_key(i0 - 1) : ~p.seg_key(0);
+		unsigned long long prev = skey[sr_pad(r0)];
 #pragma unroll
 		for (int j = 0; j < SR_ITEMS; ++j) {
 			if (i0 + j < n) {
-				key[j] = p.seg_key(i0 + j);
+				key[j] = skey[sr_pad(r0 + j + 1)];
 				if (key[j] != prev) { heads |= 1u << j; ++c; }
 				prev = key[j];
 			}
 		}
 	}
 	uint32_t total;
-	const uint32_t ex = block_excl_scan_u32<SR_THREADS>(c, scratch, total);   // also orders the agg zeroing
+	const uint32_t ex = block_excl_scan_u32<SR_THREADS>(c, scratch, total);
 	const uint32_t tp = P::DIRECT ? 1u : tile_prefix[blockIdx.x];   // DIRECT: only "tp != 0" matters below
 
 	uint32_t slot = ex;   // rows before this thread's first head belong to the last head seen so far
@@ -117,11 +139,10 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 						p.write_head(tp + slot - 1, i0 + j, key[j]);
 					}
 				}
-				uint32_t v[NV];
-				p.load(i0 + j, v);
 #pragma unroll
 				for (int c2 = 0; c2 < NV; ++c2) {
-					if (P::OR_MASK & (1u << c2)) acc[c2] |= v[c2]; else acc[c2] += v[c2];
+					const uint32_t v = sval[c2][sr_pad(r0 + j)];
+					if (P::OR_MASK & (1u << c2)) acc[c2] |= v; else acc[c2] += v;
 				}
 				dirty = true;
 			}
@@ -152,6 +173,7 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 
 // sorted read records (key = cell|gene|umi, val = chr | mark<<16)  ->  molecules
 struct ReadsToMolecules {
+	static constexpr int ITEMS = 8;
 	static constexpr bool DIRECT = false;
 	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 2;
@@ -167,6 +189,7 @@ struct ReadsToMolecules {
 
 // sorted read records -> (cell, chromosome) partial rows with exon / intron / intergenic read counts
 struct ReadsToChrRows {
+	static constexpr int ITEMS = 8;
 	static constexpr bool DIRECT = false;
 	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 3;
@@ -193,6 +216,7 @@ struct ReadsToChrRows {
 
 // molecules -> (cell, gene) rows
 struct MoleculesToCellGene {
+	static constexpr int ITEMS = 4;
 	static constexpr bool DIRECT = false;
 	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 4;   // n_all, n_req, reads_all, reads_req
@@ -216,6 +240,7 @@ struct MoleculesToCellGene {
 // (cell, gene) rows -> cells.  DIRECT: the output row is the cell id itself, so cells that lost all their rows
 // to a merge simply stay zero.
 struct CellGeneToCells {
+	static constexpr int ITEMS = 4;
 	static constexpr bool DIRECT = true;
 	static constexpr int NV = 6;   // n_genes, req_genes, req_umis, total_umis, total_reads, n_rows
 	static constexpr unsigned OR_MASK = 0;
@@ -242,6 +267,7 @@ struct CellGeneToCells {
 
 // re-keyed molecules (sorted by their new key; value = index of the molecule in the old table) -> molecules
 struct RekeyedToMolecules {
+	static constexpr int ITEMS = 8;
 	static constexpr bool DIRECT = false;
 	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 2;
