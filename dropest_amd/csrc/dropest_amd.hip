@@ -288,9 +288,9 @@ static RsVariant rs_variant() {
 		{1024 * 8, rs_launch<1024, 8, false>},  // 8
 		{512 * 16, rs_launch<512, 16, true>},   // 9
 	};
-	int v = 1;
+	int v = 9;   // 512 threads x 16 records: 8192-record tiles give the longest digit runs that fit two blocks per CU
 	if (const char *e = getenv("DROPEST_RS_VARIANT")) v = atoi(e);
-	if (v < 0 || v >= int(sizeof(table) / sizeof(table[0]))) v = 1;
+	if (v < 0 || v >= int(sizeof(table) / sizeof(table[0]))) v = 9;
 	return table[v];
 }
 

@@ -35,10 +35,16 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const unsigned long
 	uint64_t end = begin + uint64_t(tiles_per_block) * tile;
 	if (end > n) end = n;
 	const uint32_t w = wave_id();
-	for (uint64_t i = begin + threadIdx.x; i < end; i += RS_THREADS) {
-		uint32_t d = uint32_t(keys[i] >> shift) & 0xFFu;
-		atomicAdd(&h[w][d], 1u);
+	// four independent coalesced loads in flight per thread
+	uint64_t i = begin + threadIdx.x;
+	for (; i + 3ull * RS_THREADS < end; i += 4ull * RS_THREADS) {
+		const unsigned long long k0 = keys[i], k1 = keys[i + RS_THREADS], k2 = keys[i + 2ull * RS_THREADS], k3 = keys[i + 3ull * RS_THREADS];
+		atomicAdd(&h[w][uint32_t(k0 >> shift) & 0xFFu], 1u);
+		atomicAdd(&h[w][uint32_t(k1 >> shift) & 0xFFu], 1u);
+		atomicAdd(&h[w][uint32_t(k2 >> shift) & 0xFFu], 1u);
+		atomicAdd(&h[w][uint32_t(k3 >> shift) & 0xFFu], 1u);
 	}
+	for (; i < end; i += RS_THREADS) atomicAdd(&h[w][uint32_t(keys[i] >> shift) & 0xFFu], 1u);
 	__syncthreads();
 	if (threadIdx.x < RS_RADIX) {
 		uint32_t s = 0;
@@ -74,6 +80,7 @@ __global__ __launch_bounds__(256) void rs_scan_totals_kernel(const uint32_t *__r
 
 // THREADS x ITEMS records per tile.  PREFETCH: the next tile's records are loaded into registers before the
 // current tile is ranked, so the HBM latency of tile t+1 hides behind the LDS / ballot work of tile t.
+// Full tiles (all but possibly the last one of the array) run without per-record bounds checks.
 template <int THREADS, int ITEMS, bool PREFETCH>
 __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned long long *__restrict__ keys,
                                                                const uint32_t *__restrict__ vals,
@@ -82,12 +89,13 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
                                                                uint32_t tiles_per_block,
                                                                const uint32_t *__restrict__ hist,
                                                                const uint32_t *__restrict__ digit_base) {
-	constexpr int TILE = THREADS * ITEMS, WAVES = THREADS / 64;
+	constexpr uint32_t TILE = THREADS * ITEMS, WAVES = THREADS / 64;
 	static_assert(THREADS >= RS_RADIX, "one thread per digit is needed for the digit scan");
 	__shared__ uint32_t wcnt[WAVES][RS_RADIX];      // per-wave digit counts -> per-wave digit offsets
 	__shared__ uint32_t tcnt[RS_RADIX];             // digit counts of the tile
 	__shared__ uint32_t tstart[RS_RADIX];           // digit start inside the re-ordered tile
 	__shared__ uint32_t goff[RS_RADIX];             // running global cursor per digit (this block)
+	__shared__ uint32_t gdelta[RS_RADIX];           // goff - tstart: global position = gdelta[digit] + position in tile
 	__shared__ uint32_t scratch[THREADS / 64 + 1];
 	__shared__ unsigned long long sk[TILE];
 	__shared__ uint32_t sv[TILE];
@@ -96,41 +104,49 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 	const unsigned long long lt_mask = (1ull << lane) - 1ull;
 	if (tid < RS_RADIX) goff[tid] = digit_base[tid] + hist[tid * gridDim.x + blockIdx.x];
 
-	const uint64_t first_tile = uint64_t(blockIdx.x) * tiles_per_block;
+	const uint32_t n_tiles = (n + TILE - 1) / TILE;
+	const uint32_t first_tile = blockIdx.x * tiles_per_block;
+	const uint32_t lane_off = w * (64 * ITEMS) + lane;     // position of item 0 of this lane inside a tile
 	unsigned long long key[ITEMS], nkey[ITEMS];
 	uint32_t val[ITEMS], nval[ITEMS], lrank[ITEMS];
-	auto load_tile = [&](uint64_t tile_base, unsigned long long (&k)[ITEMS], uint32_t (&v)[ITEMS]) {
-		const uint64_t wave_base = tile_base + uint64_t(w) * (64 * ITEMS);
+	auto load_tile = [&](uint32_t tile, unsigned long long (&k)[ITEMS], uint32_t (&v)[ITEMS]) {
+		const uint32_t base = tile * TILE + lane_off;      // n < 2^32: 32-bit indices throughout
+		if (tile + 1 < n_tiles || n % TILE == 0) {
 #pragma unroll
-		for (int i = 0; i < ITEMS; ++i) {
-			const uint64_t idx = wave_base + uint64_t(i) * 64 + lane;
-			const bool valid = idx < n;
-			k[i] = valid ? keys[idx] : ~0ull;
-			v[i] = valid ? vals[idx] : 0u;
+			for (int i = 0; i < ITEMS; ++i) { k[i] = keys[base + i * 64]; v[i] = vals[base + i * 64]; }
+		} else {
+#pragma unroll
+			for (int i = 0; i < ITEMS; ++i) {
+				const uint32_t idx = base + i * 64;
+				const bool valid = idx < n;
+				k[i] = valid ? keys[idx] : ~0ull;
+				v[i] = valid ? vals[idx] : 0u;
+			}
 		}
 	};
-	if (PREFETCH && first_tile * TILE < n) load_tile(first_tile * TILE, nkey, nval);
+	if (PREFETCH && first_tile < n_tiles) load_tile(first_tile, nkey, nval);
 
 	for (uint32_t tt = 0; tt < tiles_per_block; ++tt) {
-		const uint64_t tile_base = (first_tile + tt) * TILE;
-		if (tile_base >= n) break;
-		const uint64_t wave_base = tile_base + uint64_t(w) * (64 * ITEMS);
+		const uint32_t tile = first_tile + tt;
+		if (tile >= n_tiles) break;
+		const bool full = tile + 1 < n_tiles || n % TILE == 0;
+		const uint32_t in_tile = full ? TILE : n - tile * TILE;
 		if (PREFETCH) {
 #pragma unroll
 			for (int i = 0; i < ITEMS; ++i) { key[i] = nkey[i]; val[i] = nval[i]; }
-			if (tt + 1 < tiles_per_block && tile_base + TILE < n) load_tile(tile_base + TILE, nkey, nval);
+			if (tt + 1 < tiles_per_block && tile + 1 < n_tiles) load_tile(tile + 1, nkey, nval);
 		} else {
-			load_tile(tile_base, key, val);
+			load_tile(tile, key, val);
 		}
-		for (int j = tid; j < WAVES * RS_RADIX; j += THREADS) (&wcnt[0][0])[j] = 0;
+		for (uint32_t j = tid; j < WAVES * RS_RADIX; j += THREADS) (&wcnt[0][0])[j] = 0;
 		__syncthreads();
 
 		// wave-level multisplit: rank of each key among the keys of its wave with the same digit
 #pragma unroll
 		for (int i = 0; i < ITEMS; ++i) {
-			const bool valid = (wave_base + uint64_t(i) * 64 + lane) < n;
+			const bool valid = full || (lane_off + i * 64) < in_tile;
 			const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
-			unsigned long long m = __ballot(valid);
+			unsigned long long m = full ? ~0ull : __ballot(valid);
 #pragma unroll
 			for (int b = 0; b < 8; ++b) {
 				const bool bit = (d >> b) & 1u;
@@ -150,18 +166,18 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 		uint32_t run = 0;
 		if (tid < RS_RADIX) {
 #pragma unroll
-			for (int k = 0; k < WAVES; ++k) { uint32_t c = wcnt[k][tid]; wcnt[k][tid] = run; run += c; }
+			for (uint32_t k = 0; k < WAVES; ++k) { uint32_t c = wcnt[k][tid]; wcnt[k][tid] = run; run += c; }
 			tcnt[tid] = run;
 		}
 		uint32_t total;
 		uint32_t ex = block_excl_scan_u32<THREADS>(tid < RS_RADIX ? run : 0u, scratch, total);
-		if (tid < RS_RADIX) tstart[tid] = ex;
+		if (tid < RS_RADIX) { tstart[tid] = ex; gdelta[tid] = goff[tid] - ex; }
 		__syncthreads();
 
 		// re-order the tile by digit in LDS
 #pragma unroll
 		for (int i = 0; i < ITEMS; ++i) {
-			const bool valid = (wave_base + uint64_t(i) * 64 + lane) < n;
+			const bool valid = full || (lane_off + i * 64) < in_tile;
 			if (valid) {
 				const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
 				const uint32_t p = tstart[d] + wcnt[w][d] + lrank[i];
@@ -172,16 +188,24 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 		__syncthreads();
 
 		// coalesced write-out: consecutive threads write consecutive addresses inside a digit run
-		for (uint32_t p = tid; p < total; p += THREADS) {
-			const unsigned long long k = sk[p];
-			const uint32_t d = uint32_t(k >> shift) & 0xFFu;
-			const uint32_t g = goff[d] + (p - tstart[d]);
-			okeys[g] = k;
-			ovals[g] = sv[p];
+		if (full) {
+			for (uint32_t p = tid; p < TILE; p += THREADS) {
+				const unsigned long long k = sk[p];
+				const uint32_t g = gdelta[uint32_t(k >> shift) & 0xFFu] + p;
+				okeys[g] = k;
+				ovals[g] = sv[p];
+			}
+		} else {
+			for (uint32_t p = tid; p < total; p += THREADS) {
+				const unsigned long long k = sk[p];
+				const uint32_t g = gdelta[uint32_t(k >> shift) & 0xFFu] + p;
+				okeys[g] = k;
+				ovals[g] = sv[p];
+			}
 		}
 		__syncthreads();
 		if (tid < RS_RADIX) goff[tid] += tcnt[tid];
-		__syncthreads();
+		// (the next iteration's barriers order this update before gdelta is recomputed)
 	}
 }
 
