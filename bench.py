@@ -129,7 +129,9 @@ def main():
         run = ShardedRun(stream, rank, world, local_rank, reads_per_gpu, cfg, dist)
         step = run.step
         get_stats = run.kernel_stats
-        set_prof = run.set_profiling
+        def set_prof(on):
+            run.set_profiling(on)
+            run.trace = {} if on else None
 
     def fence():
         if dist is not None:
@@ -173,6 +175,8 @@ def main():
         kernels = {k: {"ms_per_step": round(v["ms"] / max(1, args.steps), 4), "launches_per_step": v["launches"] / max(1, args.steps)}
                    for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"]) if not k.startswith("host:")}
         host_stages = {k[5:]: round(v["ms"] / max(1, args.steps), 3) for k, v in stats.items() if k.startswith("host:")}
+        if world > 1 or force_sharded:
+            host_stages.update({"shard:" + k: round(v / max(1, args.steps), 3) for k, v in (run.trace or {}).items()})
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             cpu = cpu_baseline(stream, int(min(args.cpu_sample, total_reads)), cfg)

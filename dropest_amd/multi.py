@@ -99,8 +99,20 @@ class GpuEngine:
             raise capi.DropestError(rc, self.L.dropest_last_error().decode())
         return dst_rows, dst_vals
 
-    def to_numpy_u32(self, tensor):
-        return tensor.cpu().numpy().view(np.uint32)
+    def to_numpy_u32(self, tensor, slot=0):
+        """Device tensor -> numpy view of a persistent PINNED host buffer (valid until the next call with the same slot):
+        a pageable .cpu() copy runs at a fraction of the PCIe rate and page-faults fresh memory every step."""
+        t = self.torch
+        n = tensor.numel()
+        if not hasattr(self, "_pinned"):
+            self._pinned = {}
+        buf = self._pinned.get(slot)
+        if buf is None or buf.numel() < n:
+            buf = t.empty(max(int(n * 1.25), 1024), dtype=t.int32, pin_memory=True)
+            self._pinned[slot] = buf
+        buf[:n].copy_(tensor, non_blocking=True)
+        t.cuda.synchronize(self.dev)
+        return buf[:n].numpy().view(np.uint32)
 
     def take(self, tensor, positions):
         t = self.torch
@@ -191,6 +203,7 @@ class ShardedRun:
         self.engine = engine or GpuEngine(local_rank, cfg)
         self.coll = Collectives(dist, rank, world, staging)
         self.resident = self.engine.generate(stream, rank * self.R, self.R)   # this rank's ordinal range, in HBM
+        self.trace = None           # set to {} to accumulate per-phase wall times (ms)
 
     def set_profiling(self, on):
         self.engine.set_profiling(on)
@@ -198,14 +211,27 @@ class ShardedRun:
     def kernel_stats(self):
         return self.engine.kernel_stats()
 
+    def _tick(self, name, t0):
+        import time
+        if self.trace is not None:
+            if hasattr(self.engine, "torch"):
+                self.engine.torch.cuda.synchronize()
+            self.trace[name] = self.trace.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        return time.perf_counter()
+
     def step(self):
+        import time
         e, c, n = self.engine, self.coll, self.world
+        t = time.perf_counter()
         # 1-2. partition by owner, all-to-all
         parts, send_counts = e.partition(self.resident, n)
+        t = self._tick("partition", t)
         recv_counts = c.all_to_all_counts(send_counts)
         recv = [c.all_to_all_v(x, send_counts, recv_counts) for x in parts]
+        t = self._tick("all_to_all", t)
         # 3. local pipeline on the owned reads
         ids, rows = e.pipeline(recv)
+        t = self._tick("pipeline", t)
         # 4. global view of the real cells
         offs = np.concatenate([[0], np.cumsum(recv_counts)])
         first_pos = rows["first_read"].astype(np.int64)
@@ -218,12 +244,15 @@ class ShardedRun:
         if np.any(rows["barcode"][is_real] >> np.uint64(63)):
             raise capi.DropestError(4, "escaped barcodes are not supported in sharded runs yet")
         everyone = c.all_gather_rows(table)
+        t = self._tick("cells_allgather", t)
         # 5. local matrices, gathered on rank 0
         out = {}
         for name, filtered in (("cm", True), ("cm_raw", False)):
             colptr, rows_t, vals_t = e.matrix(filtered)
+            t = self._tick("emit:" + name, t)
             local_cols = e.filtered_ids().astype(np.int64) if filtered else table[:, 5]
             out[name] = self._gather_matrix(everyone, filtered, colptr, rows_t, vals_t, local_cols)
+            t = self._tick("matrix:" + name, t)
         return out["cm"], out["cm_raw"], out["cm"][3] if self.rank == 0 else None
 
     def _gather_matrix(self, everyone, filtered, colptr, rows_t, vals_t, local_cols):
@@ -232,12 +261,16 @@ class ShardedRun:
         lens = np.diff(colptr.astype(np.int64)) if len(colptr) > 1 else np.zeros(0, np.int64)
         # tell rank 0 which cell each local column is and how long it is
         meta = np.stack([local_cols, lens], axis=1) if len(lens) else np.zeros((0, 2), np.int64)
+        import time
+        tt = time.perf_counter()
         metas = c.all_gather_rows(meta)
+        tt = self._tick("gm:meta_allgather", tt)
         nnz_all = [int(m[:, 1].sum()) for m in metas]
         send = [nnz_local if p == 0 else 0 for p in range(n)]
         recv = nnz_all if self.rank == 0 else [0] * n
         g_rows = c.all_to_all_v(rows_t, send, recv)
         g_vals = c.all_to_all_v(vals_t, send, recv)
+        tt = self._tick("gm:gather", tt)
         if self.rank != 0:
             return None
         # global column order on rank 0
@@ -269,6 +302,12 @@ class ShardedRun:
         ln = np.asarray(ln, np.int64)
         dst = np.concatenate([[0], np.cumsum(ln)[:-1]]) if len(ln) else np.zeros(0, np.int64)
         total = int(ln.sum())
+        tt = self._tick("gm:order", tt)
         a_rows, a_vals = e.assemble(np.asarray(src, np.int64), dst, ln, g_rows, g_vals, total)
+        tt = self._tick("gm:assemble", tt)
         colptr_g = np.concatenate([[0], np.cumsum(ln)]).astype(np.uint64)
-        return colptr_g, e.to_numpy_u32(a_rows), e.to_numpy_u32(a_vals), keep[:, 4].astype(np.uint64)
+        slot = 0 if filtered else 2
+        res = (colptr_g, e.to_numpy_u32(a_rows, slot), e.to_numpy_u32(a_vals, slot + 1), keep[:, 4].astype(np.uint64))
+        self._tick("gm:d2h", tt)
+        return res
+        return colptr_g, e.to_numpy_u32(a_rows, slot), e.to_numpy_u32(a_vals, slot + 1), keep[:, 4].astype(np.uint64)

@@ -91,7 +91,7 @@ class CpuEngine:
             r[d:d + l] = rows[s:s + l]; v[d:d + l] = vals[s:s + l]
         return r, v
 
-    def to_numpy_u32(self, t):
+    def to_numpy_u32(self, t, slot=0):
         return t.numpy().view(np.uint32)
 
     def take(self, tensor, positions):
