@@ -106,9 +106,9 @@ def test_device_generator_matches_host():
 
 
 def test_sortedness_and_checksum_at_scale():
-    """Size-independent properties on a stream too long for the oracle: conservation of reads and
-    sortedness of the molecule table."""
-    s = SynthStream(n_reads=20_000_000, n_cells=2000, n_genes=30000)
+    """BASELINE configs[1] at FULL size (1e8 reads, 5000 cells): size-independent properties on a stream far too
+    long for the oracle -- conservation of reads, strict sortedness (no duplicate molecule), per-cell sums."""
+    s = SynthStream(n_reads=100_000_000, n_cells=5000, n_genes=30000)
     dev = s.generate_device(0)
     c = capi.Context(min_genes_before_merge=20, min_genes_after_merge=100)
     c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
@@ -121,9 +121,51 @@ def test_sortedness_and_checksum_at_scale():
     rows = c.cell_rows()
     assert int(rows["total_reads"].astype(np.int64).sum()) == int(reads.sum())
     assert int(rows["total_umis"].astype(np.int64).sum()) == len(reads)
-    g, col, v = c.count_matrix(filtered=False)
+    p, i, v = c.count_matrix_csc(filtered=False)
     real = rows["is_real"].astype(bool)
     assert int(v.astype(np.int64).sum()) == int(rows["total_umis"][real].astype(np.int64).sum())
+    assert len(p) - 1 == int(real.sum()) and np.all(np.diff(p.astype(np.int64)) == rows["n_genes"][real])
+    # the filtered matrix: columns ascending in the compare_cells key, every column has >= min_genes_after_merge genes
+    p, i, v = c.count_matrix_csc(filtered=True)
+    f = c.filtered_cells().astype(np.int64)
+    key = list(zip(rows["requested_genes"][f].tolist(), rows["requested_umis"][f].tolist(), rows["total_umis"][f].tolist()))
+    assert key == sorted(key) and min(k[0] for k in key) >= 100
+    assert np.all(np.diff(p.astype(np.int64)) == rows["requested_genes"][f])
+    # idempotence: a second pass over the same resident stream reproduces every byte
+    i1, v1 = i.copy(), v.copy()
+    c.reset_results(); c.set_initialized(); c.merge_and_filter()
+    p2, i2, v2 = c.count_matrix_csc(filtered=True)
+    assert np.array_equal(p, p2) and np.array_equal(i1, i2) and np.array_equal(v1, v2)
+    dev.free()
+
+
+def test_merge_properties_at_scale():
+    """C3 shape (UMI 12, Hamming-1 neighbour barcodes, -m + whitelist) at 1e8 reads: properties of the merge."""
+    s = SynthStream(n_reads=100_000_000, n_cells=20000, n_genes=30000, umi_len=12, stream_id=3)
+    dev = s.generate_device(0)
+    c = capi.Context(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST,
+                     barcodes_file=os.path.join(DATA, "10x_aug_2016_split"), min_genes_before_merge=20,
+                     min_genes_after_merge=100)
+    c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
+    c.set_initialized()
+    n_real_before = c.real_cells_number()
+    c.merge_and_filter()
+    rows = c.cell_rows()
+    mt = c.merge_targets().astype(np.int64)
+    src = np.nonzero(mt != np.arange(len(mt)))[0]
+    assert len(src) > 1000                                                  # neighbours were merged
+    assert np.all(rows["is_merged"][src] == 1) and np.all(rows["is_merged"][mt[src]] == 0)   # targets are final
+    assert np.all(mt[mt[src]] == mt[src])                                   # no chains left (reassign, :64-82)
+    whitelist_cells = set(int(x) for x in s.cell_cb)
+    assert all(int(b) in whitelist_cells for b in rows["barcode"][mt[src]])   # every target is a whitelist barcode
+    assert c.real_cells_number() < n_real_before
+    cell, gene, umi, reads, mark = c.molecules()
+    assert int(reads.sum()) + int(c.global_counters()[0]) == dev.n          # reads conserved through the unions
+    assert not np.any(np.isin(cell, src))                                   # merged sources own no molecule any more
+    # Stats::merge quirk: TOTAL_UMIS of a target = sum over its sources, >= its distinct molecule count
+    real = rows["is_real"].astype(bool)
+    per_cell = np.bincount(cell, minlength=len(rows))
+    assert np.all(rows["total_umis"][real] >= per_cell[real])
     dev.free()
 
 
