@@ -30,8 +30,11 @@
  *   gene[i]       : dense id of the gene NAME in first-seen order over gene-bearing reads
  *                   (= StringIndexer ids, Estimation/StringIndexer.cpp:10-18), DROPEST_NO_GENE when the
  *                   read has no gene (ReadInfo::gene empty, CellsDataContainer.cpp:73-78).
- *   aux[i]        : chromosome id (first-seen dense id of the chromosome name, Stats.cpp:81-90) in bits
- *                   0..15, UMI::Mark bits (UMI.h:16-22: 1 not-annotated, 2 exon, 4 intron) in bits 16..23.
+ *   aux[i]        : chromosome id in bits 0..15, UMI::Mark bits (UMI.h:16-22: 1 not-annotated, 2 exon, 4 intron)
+ *                   in bits 16..23.  Chromosome ids are first-seen dense ids of the chromosome NAME over the
+ *                   reads that reach Stats::inc(chr) (Stats.cpp:22-27,:81-90): reads without a gene and reads
+ *                   whose mark has the exon or intron bit (CellsDataContainer.cpp:73-78,:312-321).  The
+ *                   chromosome field of any other read is ignored.
  */
 #ifndef DROPEST_AMD_H
 #define DROPEST_AMD_H

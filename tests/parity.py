@@ -21,7 +21,15 @@ def first_seen_ids(values, skip=None):
 def canonical_stream(cb, umi, gene, aux):
     """Re-labels gene and chromosome ids to first-seen order, as the C-ABI requires."""
     gene = first_seen_ids(gene, skip=capi.NO_GENE)
-    chr_ids = first_seen_ids(aux & 0xFFFF)
+    # chromosome ids: first-seen over the reads that reach Stats::inc(chr), i.e. gene-less reads and reads whose
+    # mark has the exon or intron bit (CellsDataContainer.cpp:73-78, :312-321); other reads never touch the
+    # chromosome dictionary and carry chr 0 (ignored by the path)
+    raw_chr = aux & 0xFFFF
+    mark = (aux >> 16) & 0xFF
+    touches = (gene == capi.NO_GENE) | ((mark & 6) != 0)
+    sentinel = np.uint32(0xFFFFFFFF)
+    chr_ids = first_seen_ids(np.where(touches, raw_chr, sentinel).astype(np.uint32), skip=sentinel)
+    chr_ids = np.where(touches, chr_ids, 0).astype(np.uint32)
     aux = (aux & np.uint32(0xFFFF0000)) | chr_ids
     return cb, umi, gene, aux.astype(np.uint32)
 

@@ -1,0 +1,169 @@
+"""Randomised parity sweep: many small, adversarially shaped streams (heavy duplication, one giant run, all-distinct
+barcodes, tile-boundary sizes, variable lengths, Ns, sparse gene ids) through the HIP path and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from dropest_amd import capi
+from oracle import Oracle
+
+import parity
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dropest_amd", "data", "barcodes")
+
+
+def random_stream(rng, n, n_cb, n_gene, n_umi, cb_len=(12, 12), umi_len=(6, 6), n_rate=0.0, p_nogene=0.1, n_chr=5,
+                  cb_n_rate=0.0):
+    def seqs(count, lo, hi):
+        out = []
+        for _ in range(count):
+            L = int(rng.integers(lo, hi + 1))
+            out.append("".join(rng.choice(list("ACGT"), L)))
+        return out
+    cbs, umis = seqs(n_cb, *cb_len), seqs(n_umi, *umi_len)
+    side, index = [], {}
+
+    def code(s):
+        c = capi.pack_seq(s)
+        if c is not None:
+            return c
+        k = index.get(s)
+        if k is None:
+            k = index[s] = len(side)
+            side.append(s)
+        return capi.ESCAPE | k
+
+    def with_n(s, rate):
+        if rate and rng.random() < rate:
+            i = int(rng.integers(0, len(s)))
+            return s[:i] + "N" + s[i + 1:]
+        return s
+    cb = np.zeros(n, np.uint64); umi = np.zeros(n, np.uint64); gene = np.zeros(n, np.uint32); aux = np.zeros(n, np.uint32)
+    # zipf-ish choice so that some barcodes / UMIs are very hot
+    w_cb = 1.0 / np.arange(1, n_cb + 1) ** rng.uniform(0.0, 1.5); w_cb /= w_cb.sum()
+    w_umi = 1.0 / np.arange(1, n_umi + 1) ** rng.uniform(0.0, 1.0); w_umi /= w_umi.sum()
+    ci = rng.choice(n_cb, n, p=w_cb); ui = rng.choice(n_umi, n, p=w_umi)
+    gi = rng.integers(0, n_gene, n)
+    for r in range(n):
+        has_gene = rng.random() >= p_nogene
+        cb[r] = code(with_n(cbs[ci[r]], cb_n_rate))
+        # the UMI of a gene-less read is ignored by the path and must not register a side string
+        umi[r] = code(with_n(umis[ui[r]], n_rate)) if has_gene else capi.pack_seq(umis[ui[r]])
+        gene[r] = gi[r] if has_gene else capi.NO_GENE
+        aux[r] = int(rng.integers(0, n_chr)) | (int(rng.choice([1, 2, 3, 4, 5, 6, 7])) << 16)
+    return parity.canonical_stream(cb, umi, gene, aux) + (side,)
+
+
+def run_case(rng, **kw):
+    min_before = int(kw.pop("min_before", rng.integers(0, 4)))
+    min_after = int(kw.pop("min_after", rng.integers(0, 6)))
+    levels = kw.pop("levels", str(rng.choice(["eEBA", "e", "eE", "iIBA", "A"])))
+    cb, umi, gene, aux, side = random_stream(rng, **kw)
+    o = parity.oracle_run(Oracle, dict(min_genes_before=min_before, min_genes_after=min_after, match_levels=levels),
+                          cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(min_genes_before_merge=min_before, min_genes_after_merge=min_after, gene_match_levels=levels),
+                       cb, umi, gene, aux, side, chunks=int(rng.integers(1, 4)))
+    parity.compare(o, c, side)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_small_streams(seed):
+    rng = np.random.default_rng(1000 + seed)
+    run_case(rng, n=int(rng.integers(1, 6000)), n_cb=int(rng.integers(1, 60)), n_gene=int(rng.integers(1, 40)),
+             n_umi=int(rng.integers(1, 80)))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193, 16385])
+def test_tile_boundary_sizes(n):
+    run_case(np.random.default_rng(n), n=n, n_cb=7, n_gene=5, n_umi=9, min_before=0, min_after=0)
+
+
+def test_one_giant_molecule_and_all_distinct_barcodes():
+    rng = np.random.default_rng(5)
+    run_case(rng, n=20_000, n_cb=1, n_gene=1, n_umi=1, p_nogene=0.0, min_before=0, min_after=0)     # a single run of 20k reads
+    run_case(rng, n=20_000, n_cb=1, n_gene=1, n_umi=1, p_nogene=1.0, min_before=0, min_after=0)     # only gene-less reads
+    run_case(rng, n=12_000, n_cb=12_000, n_gene=3, n_umi=4, cb_len=(16, 16), min_before=0, min_after=0)   # table growth path
+
+
+def test_variable_lengths_and_ns():
+    rng = np.random.default_rng(9)
+    run_case(rng, n=5000, n_cb=30, n_gene=12, n_umi=40, cb_len=(8, 19), umi_len=(6, 6), n_rate=0.05, min_before=0)
+    run_case(rng, n=5000, n_cb=30, n_gene=12, n_umi=25, cb_len=(10, 10), umi_len=(4, 9), min_before=1)       # mixed UMI lengths keep the sentinel
+    run_case(rng, n=4000, n_cb=25, n_gene=6, n_umi=12, umi_len=(5, 5), n_rate=0.3, cb_n_rate=0.1, min_before=0)   # many Ns, also in barcodes
+
+
+def test_key_wider_than_64_bits_is_refused_loudly():
+    P = capi.pack_seq
+    n = 5
+    cb = np.array([P("ACGT" * 7 + "AC" + "ACGT"[i % 4]) for i in range(n)], np.uint64)          # 31 bases
+    umi = np.array([P("TTGCA" * 6)] * n, np.uint64)                                              # 30 bases -> 60 bits
+    gene = np.array([1_000_000] * n, np.uint32)                                                  # 20 bits
+    c = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
+    c.push_reads(cb, umi, gene, np.full(n, 2 << 16, np.uint32))
+    with pytest.raises(capi.DropestError) as e:
+        c.set_initialized()
+    assert e.value.status == 4 and "bits" in str(e.value)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_whitelist_merges(seed, tmp_path):
+    """Random small whitelists (inDrop-style two lines, variable first-part length allowed) and barcodes that are exact,
+    mutated (substitution / insertion / deletion -> different length) or carry an N: stresses the neighbour search,
+    the tie replay (min_merge_fraction 0 half of the time) and the sequential merge application."""
+    rng = np.random.default_rng(7000 + seed)
+    rc = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    def rnd(L):
+        return "".join(rng.choice(list("ACGT"), L))
+    const_kind = bool(rng.integers(0, 2))
+    l1 = int(rng.integers(3, 7)); l2 = int(rng.integers(5, 9))
+    p1 = sorted({rnd(l1 if const_kind else int(rng.integers(l1, l1 + 2))) for _ in range(int(rng.integers(3, 9)))})
+    p2 = sorted({rnd(l2) for _ in range(int(rng.integers(3, 10)))})
+    wl = tmp_path / "wl"
+    # the file stores reverse complements (the loader reverses them back, BarcodesParser.cpp:140)
+    wl.write_text(" ".join("".join(rc[c] for c in reversed(s)) for s in p1) + "\n" +
+                  " ".join("".join(rc[c] for c in reversed(s)) for s in p2) + "\n")
+    real = [a + b for a in p1 for b in p2]
+    rng.shuffle(real)
+    real = real[:max(2, len(real) // 2)]
+
+    def mutate(s):
+        k = rng.integers(0, 5)
+        i = int(rng.integers(0, len(s)))
+        if k == 0:
+            return s[:i] + str(rng.choice(list("ACGT"))) + s[i + 1:]
+        if k == 1 and not const_kind:
+            return s[:i] + str(rng.choice(list("ACGT"))) + s[i:]
+        if k == 2 and not const_kind and len(s) > l2 + 2:
+            return s[:i] + s[i + 1:]
+        if k == 3:
+            return s[:i] + "N" + s[i + 1:]
+        return s
+    pool = list(real) + [mutate(str(rng.choice(real))) for _ in range(40)] + [mutate(mutate(str(rng.choice(real)))) for _ in range(15)]
+    genes = ["g%d" % i for i in range(int(rng.integers(2, 12)))]
+    umis = [rnd(5) for _ in range(int(rng.integers(3, 25)))]
+    n = int(rng.integers(200, 3000))
+    w = np.concatenate([np.full(len(real), 8.0), np.ones(len(pool) - len(real))]); w /= w.sum()
+    side, index, gids = [], {}, {}
+
+    def code(s):
+        c = capi.pack_seq(s)
+        if c is not None:
+            return c
+        if s not in index:
+            index[s] = len(side); side.append(s)
+        return capi.ESCAPE | index[s]
+    cb = np.array([code(pool[i]) for i in rng.choice(len(pool), n, p=w)], np.uint64)
+    umi = np.array([code(str(u)) for u in rng.choice(umis, n)], np.uint64)
+    gene = np.array([gids.setdefault(str(g), len(gids)) for g in rng.choice(genes, n)], np.uint32)
+    aux = np.full(n, 2 << 16, np.uint32)
+    frac = 0.0 if rng.integers(0, 2) else 0.2
+    min_before = int(rng.integers(0, 3))
+    kind = capi.BARCODES_CONST if const_kind else capi.BARCODES_INDROP
+    o = parity.oracle_run(Oracle, dict(merge_kind=1, barcodes_kind=kind, barcodes_file=str(wl), min_genes_before=min_before,
+                                       min_genes_after=min_before, min_merge_fraction=frac), cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=kind, barcodes_file=str(wl),
+                            min_genes_before_merge=min_before, min_genes_after_merge=min_before, min_merge_fraction=frac),
+                       cb, umi, gene, aux, side)
+    parity.compare(o, c, side)
