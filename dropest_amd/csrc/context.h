@@ -148,6 +148,7 @@ struct dropest_ctx {
 	// ---- host state over real-candidate cells ----
 	std::vector<dropest::HostCell> real;                 // ascending cell id
 	std::vector<uint64_t> filtered;                      // cell ids, ascending compare_cells order (built lazily)
+	std::vector<u32> filtered_ridx;                      // index in `real` of each filtered cell
 	bool filtered_valid = false;
 	u32 filtered_threshold = 0;
 	int filtered_max_cells = -1;
@@ -206,7 +207,9 @@ struct dropest_ctx {
 	void reduce_cell_gene_to_cells();
 	void refresh_real_rows();
 	void upload_whitelist();
-	std::vector<long> compute_merge_targets(const std::vector<u32> &cells);
+	std::vector<long> compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx,
+	                                        std::vector<u32> *target_ridx = nullptr);
+	dropest::DevBuf<u32> cell_real_index;   // [n_cells] cell id -> index in `real` (0xFFFFFFFF otherwise)
 	void run_cb_merge_real();
 	void reaggregate_after_merge();
 	void run_umi_merge_simple();

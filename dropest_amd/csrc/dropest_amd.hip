@@ -481,18 +481,61 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 		                   u64(size_t(h.row.total_umis)),   // Cell::umis_number casts the int stat to size_t
 		                   h.row.barcode, i});
 	}
-	std::sort(keys.begin(), keys.end(), [&](const Key &a, const Key &b) {
+	auto less = [&](const Key &a, const Key &b) {
 		if (a.sizes != b.sizes) return a.sizes < b.sizes;
 		if (a.umis != b.umis) return a.umis < b.umis;
 		// barcode strings: clean codes of equal length order like their strings; anything else is decoded
 		const bool plain = !((a.code | b.code) & ESCAPE_BIT) && bit_length(a.code) == bit_length(b.code);
 		if (plain) return a.code < b.code;
 		return barcode_of(real[a.idx]) < barcode_of(real[b.idx]);
-	});
-	filtered.clear();
+	};
+	// Large lists (10^5..10^6 cells at BASELINE sizes) are ordered on the device: three stable LSD radix sorts
+	// (barcode, then TOTAL_UMIS, then the packed sizes) when every barcode is a clean code of one length, so that
+	// the numeric order of the codes IS the string order.  The key is total, so any correct sort gives the same list.
+	size_t device_min = 50000;
+	if (const char *e = getenv("DROPEST_DEVICE_SORT_MIN")) device_min = size_t(std::max(1, atoi(e)));   // tests force the device path
+	bool device_sort = !keys.empty() && keys.size() >= device_min;
+	if (device_sort) {
+		u64 any = 0; int bl = bit_length(keys[0].code);
+		for (const Key &k : keys) { any |= k.code; if (bit_length(k.code) != bl) { device_sort = false; break; } }
+		if (any & ESCAPE_BIT) device_sort = false;
+	}
+	if (device_sort) {
+		const u32 m = u32(keys.size());
+		std::vector<u64> col(m);
+		std::vector<u32> perm(m);
+		DevBuf<u64> d_code, d_umis, d_sizes;
+		d_code.alloc(m); d_umis.alloc(m); d_sizes.alloc(m);
+		keys_a.ensure(m); keys_b.ensure(m); vals_a.ensure(m); vals_b.ensure(m);
+		auto upload = [&](DevBuf<u64> &dst, u64 Key::*field) {   // returns the mask of bits that vary (constant digits are skipped)
+			u64 o = 0, a = ~0ull;
+			for (u32 i = 0; i < m; ++i) { col[i] = keys[i].*field; o |= col[i]; a &= col[i]; }
+			HIP_CHECK(hipMemcpy(dst.p, col.data(), size_t(m) * 8, hipMemcpyHostToDevice));
+			return o ^ a;
+		};
+		const u64 mask_code = upload(d_code, &Key::code), mask_umis = upload(d_umis, &Key::umis), mask_sizes = upload(d_sizes, &Key::sizes);
+		u64 *k = keys_a.p, *k_alt = keys_b.p;
+		u32 *v = vals_a.p, *v_alt = vals_b.p;
+		hipLaunchKernelGGL(iota_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, v, m);
+		HIP_CHECK(hipMemcpyAsync(k, d_code.p, size_t(m) * 8, hipMemcpyDeviceToDevice, stream));
+		radix_sort(k, v, k_alt, v_alt, m, mask_code);
+		const std::pair<DevBuf<u64> *, u64> more[2] = {{&d_umis, mask_umis}, {&d_sizes, mask_sizes}};
+		for (auto const &nx : more) {
+			hipLaunchKernelGGL(gather_u64_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, nx.first->p, v, m, k);
+			HIP_CHECK(hipGetLastError());
+			radix_sort(k, v, k_alt, v_alt, m, nx.second);
+		}
+		fetch(perm.data(), v, size_t(m) * 4);
+		std::vector<Key> sorted(m);
+		for (u32 i = 0; i < m; ++i) sorted[i] = keys[perm[i]];
+		keys.swap(sorted);
+	} else {
+		std::sort(keys.begin(), keys.end(), less);
+	}
+	filtered.clear(); filtered_ridx.clear();
 	size_t start = 0;
 	if (max_cells > 0 && size_t(max_cells) < keys.size()) start = keys.size() - size_t(max_cells);
-	for (size_t i = start; i < keys.size(); ++i) filtered.push_back(real[keys[i].idx].id);
+	for (size_t i = start; i < keys.size(); ++i) { filtered.push_back(real[keys[i].idx].id); filtered_ridx.push_back(keys[i].idx); }
 	filtered_valid = true;
 }
 
@@ -539,8 +582,9 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host) 
 	M.colptr.clear();
 	uint64_t nnz = 0;
 	if (filtered_m) {
-		for (uint64_t id : filtered_cells()) {
-			const HostCell &h = real[real_at(u32(id))];
+		filtered_cells();
+		for (u32 ri : filtered_ridx) {
+			const HostCell &h = real[ri];
 			col_cell.push_back(h.id); M.colptr.push_back(u32(nnz)); nnz += h.row.requested_genes;
 		}
 	} else {
@@ -932,7 +976,7 @@ dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *ta
 		if (ctx->merged) throw InvalidError("merge targets are defined on the un-merged state (call before merge_and_filter)");
 		if (ctx->cfg.merge_kind != DROPEST_MERGE_REAL_BARCODES) { *target = int64_t(cell); return; }   // DummyMergeStrategy
 		if (cell >= ctx->n_cells) throw RangeError("cell index out of range");
-		*target = ctx->compute_merge_targets(std::vector<u32>{u32(cell)})[0];
+		*target = ctx->compute_merge_targets(std::vector<u32>{u32(cell)}, std::vector<u32>{ctx->real_at(u32(cell))})[0];
 	});
 }
 

@@ -99,7 +99,13 @@ struct WlArgs {
 	uint32_t min_genes;
 	uint32_t *cand_count;    // [n_bases] qualifying candidates found (may exceed WL_CAND_CAP: overflow)
 	uint32_t *cand_level;    // [n_bases] total distance of the level that produced them
-	uint32_t *cand_cell;     // [n_bases][WL_CAND_CAP]
+	uint32_t *cand_off;      // [n_bases] first entry of the cell's candidates in the flat lists
+	uint32_t *flat_cell;     // [flat_cap] candidate cell ids, all cells back to back (order of cells arbitrary)
+	uint32_t *flat_umis;     // [flat_cap] TOTAL_UMIS of each candidate (un-merged state)
+	uint32_t *flat_ridx;     // [flat_cap] index of each candidate in the host's real-candidate list
+	const uint32_t *cell_real_index;   // [n_cells] cell id -> that index (0xFFFFFFFF for the others)
+	uint32_t *flat_total;    // running size of the flat lists (atomic)
+	uint32_t flat_cap;
 	uint8_t *dist_dump;      // optional [n_bases][part_size[0] + part_size[1]] per-part distances (tie replay), or null
 };
 
@@ -113,6 +119,8 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 	__shared__ uint32_t start[2][WL_MAX_DIST + 2];
 	__shared__ uint32_t fill[2][WL_MAX_DIST + 2];
 	__shared__ uint32_t n_found;
+	__shared__ uint32_t found[WL_CAND_CAP];
+	__shared__ uint32_t flat_base;
 
 	const WlBase &b = a.bases[blockIdx.x];
 	const uint32_t tid = threadIdx.x;
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 				const uint32_t c = a.table.slots[s].cell_id;
 				if (a.cell_n_genes[c] >= a.min_genes && a.cell_total_umis[c] >= base_umis) {
 					const uint32_t k = atomicAdd(&n_found, 1u);
-					if (k < WL_CAND_CAP) a.cand_cell[size_t(blockIdx.x) * WL_CAND_CAP + k] = c;
+					if (k < WL_CAND_CAP) found[k] = c;
 				}
 			}
 		}
@@ -174,7 +182,57 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 		if (n_found) break;
 		__syncthreads();
 	}
-	if (tid == 0) { a.cand_count[blockIdx.x] = n_found; a.cand_level[blockIdx.x] = level; }
+	// append this cell's candidates to the flat lists
+	const uint32_t keep = n_found < uint32_t(WL_CAND_CAP) ? n_found : uint32_t(WL_CAND_CAP);
+	if (tid == 0) {
+		a.cand_count[blockIdx.x] = n_found; a.cand_level[blockIdx.x] = level;
+		flat_base = keep ? atomicAdd(a.flat_total, keep) : 0u;
+		a.cand_off[blockIdx.x] = flat_base;
+	}
+	__syncthreads();
+	for (uint32_t k = tid; k < keep; k += WL_THREADS) {
+		const uint32_t o = flat_base + k;
+		if (o < a.flat_cap) {
+			a.flat_cell[o] = found[k]; a.flat_umis[o] = a.cell_total_umis[found[k]]; a.flat_ridx[o] = a.cell_real_index[found[k]];
+		}
+	}
+}
+
+// Splits the barcodes of a list of cells into the two whitelist parts on the device
+// (BarcodesParser::split_barcode: InDropBarcodesParser.cpp:32-39 / ConstLengthBarcodesParser.cpp:33-48).
+// Escaped barcodes (with N) are left for the host (len[0] = 0xFF); a barcode whose length does not fit sets *bad.
+__global__ __launch_bounds__(256) void make_bases_kernel(const uint32_t *__restrict__ cells, uint32_t n,
+                                                         const unsigned long long *__restrict__ cell_cb, int const_kind,
+                                                         uint32_t len1, uint32_t len2, WlBase *__restrict__ out,
+                                                         uint32_t *__restrict__ bad) {
+	const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+	if (f >= n) return;
+	WlBase b;
+	for (int p = 0; p < 2; ++p) for (int i = 0; i < 32; ++i) b.part[p][i] = 0;
+	b.pad[0] = b.pad[1] = 0;
+	b.cell = cells[f];
+	const unsigned long long code = cell_cb[b.cell];
+	if (code & ESCAPE_BIT) { b.len[0] = 0xFF; b.len[1] = 0; out[f] = b; return; }
+	const uint32_t len = uint32_t(bit_length(code) - 1) / 2;
+	uint32_t la, lb;
+	if (const_kind) { la = len1; lb = len2; if (len != len1 + len2) { atomicMax(bad, 1u); la = lb = 0; } }
+	else { lb = len2; if (len < len2) { atomicMax(bad, 1u); la = lb = 0; } else la = len - len2; }
+	if (la > uint32_t(WL_MAX_LEN) || lb > uint32_t(WL_MAX_LEN)) { atomicMax(bad, 2u); la = lb = 0; }
+	for (uint32_t i = 0; i < la; ++i) b.part[0][i] = "ACGT"[(code >> (2 * (len - 1 - i))) & 3];
+	for (uint32_t i = 0; i < lb; ++i) b.part[1][i] = "ACGT"[(code >> (2 * (lb - 1 - i))) & 3];
+	b.len[0] = uint8_t(la); b.len[1] = uint8_t(lb);
+	out[f] = b;
+}
+
+// remap[cell] = cell, then the (source -> target) pairs of the merge are scattered over it
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t *p, uint32_t n) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) p[i] = i;
+}
+__global__ __launch_bounds__(256) void scatter_pairs_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ tgt,
+                                                            uint32_t n, uint32_t *__restrict__ remap) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) remap[src[i]] = tgt[i];
 }
 
 // ---- UMI-gene intersection sizes ---------------------------------------------------------------------

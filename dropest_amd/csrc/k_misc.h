@@ -218,6 +218,13 @@ __global__ __launch_bounds__(256) void assemble_columns_kernel(const unsigned lo
 	for (unsigned long long t = threadIdx.x; t < len; t += 256) { dst_rows[d + t] = src_rows[s + t]; dst_vals[d + t] = src_vals[s + t]; }
 }
 
+// keys_out[i] = table[idx[i]]: re-keys an index permutation for the next stable sort pass of a multi-key sort
+__global__ __launch_bounds__(256) void gather_u64_kernel(const unsigned long long *__restrict__ table, const uint32_t *__restrict__ idx,
+                                                         uint32_t n, unsigned long long *__restrict__ keys_out) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) keys_out[i] = table[idx[i]];
+}
+
 __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *p, uint32_t v, size_t n) {
 	size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
 	if (i < n) p[i] = v;

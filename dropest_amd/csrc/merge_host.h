@@ -82,54 +82,108 @@ void dropest_ctx::upload_whitelist() {
 }
 
 // RealBarcodesMergeStrategy::get_merge_target for a list of cells, on the current (unmerged) device state.
-std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cells) {
+// `ridx[f]` = index of cells[f] in `real`.  Everything per-cell that scales with the number of filtered cells
+// (10^5..10^6 at BASELINE sizes) is done on the device; the host only walks flat arrays.
+std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx,
+                                                     std::vector<u32> *target_ridx) {
 	std::vector<long> targets(cells.size(), -1);
+	if (target_ridx) target_ridx->assign(cells.size(), 0xFFFFFFFFu);
 	if (cells.empty()) return targets;
 	upload_whitelist();
 	const u32 F = u32(cells.size());
 
-	std::vector<WlBase> bases(F);
-	for (u32 f = 0; f < F; ++f) {
-		const long ri = real_find(cells[f]);
-		if (ri < 0) throw InvalidError("merge target requested for a cell below min_genes_before_merge");
-		std::string a, b;
-		wl.split(barcode_of(real[size_t(ri)]), a, b);
-		WlBase &wb = bases[f];
-		std::memset(&wb, 0, sizeof(wb));
-		std::memcpy(wb.part[0], a.data(), a.size()); std::memcpy(wb.part[1], b.data(), b.size());
-		wb.len[0] = uint8_t(a.size()); wb.len[1] = uint8_t(b.size());
-		wb.cell = cells[f];
-	}
+	// 1. barcodes split into the two parts (device; escaped barcodes patched by the host)
+	DevBuf<u32> d_cells; d_cells.alloc(F);
 	DevBuf<WlBase> d_bases; d_bases.alloc(F);
-	DevBuf<u32> d_cnt, d_lvl, d_cand;
-	d_cnt.alloc(F); d_lvl.alloc(F); d_cand.alloc(size_t(F) * WL_CAND_CAP);
-	HIP_CHECK(hipMemcpyAsync(d_bases.p, bases.data(), size_t(F) * sizeof(WlBase), hipMemcpyHostToDevice, stream));
-	WlArgs a{};
-	a.bases = d_bases.p; a.n_bases = F;
-	a.part[0] = d_wl[0].p; a.part[1] = d_wl[1].p;
-	a.part_size[0] = u32(wl.parts[0].size()); a.part_size[1] = u32(wl.parts[1].size());
-	a.table = table; a.cell_n_genes = cell_n_genes.p; a.cell_total_umis = cell_total_umis.p; a.min_genes = min_before;
-	a.cand_count = d_cnt.p; a.cand_level = d_lvl.p; a.cand_cell = d_cand.p; a.dist_dump = nullptr;
-	const u32 ntot = a.part_size[0] + a.part_size[1];
-	const size_t lds = ((ntot + 15u) & ~15u) + size_t(ntot) * 2;
-	timed("wl_neighbours", double(F) * ntot * 32, [&] {
-		hipLaunchKernelGGL(wl_neighbours_kernel, dim3(F), dim3(WL_THREADS), lds, stream, a);
-	});
-	std::vector<u32> cnt(F), cand(size_t(F) * WL_CAND_CAP);
-	HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt.p, size_t(F) * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipMemcpyAsync(cand.data(), d_cand.p, cand.size() * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	scalars.ensure(16);
+	HIP_CHECK(hipMemcpyAsync(d_cells.p, cells.data(), size_t(F) * 4, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
+	hipLaunchKernelGGL(make_bases_kernel, dim3(div_up(F, 256)), dim3(256), 0, stream, d_cells.p, F, cell_cb.p,
+	                   cfg.barcodes_kind == DROPEST_BARCODES_CONST ? 1 : 0, u32(wl.part_lengths[0]), u32(wl.part_lengths[1]),
+	                   d_bases.p, scalars.p);
+	HIP_CHECK(hipGetLastError());
+	u32 bad = 0;
+	fetch(&bad, scalars.p, 4);
+	if (bad == 2) throw UnsupportedError("barcode part longer than 31 bases");
+	if (bad) {   // reproduce the reference's message for the first offending barcode
+		for (u32 f = 0; f < F; ++f) { std::string a, b; wl.split(barcode_of(real[ridx[f]]), a, b); }
+		throw InvalidError("barcode length does not fit the whitelist");
+	}
+	if (ingest.cb_escape_count) {
+		for (u32 f = 0; f < F; ++f) {
+			if (!(real[ridx[f]].row.barcode & ESCAPE_BIT)) continue;
+			std::string a, b;
+			wl.split(barcode_of(real[ridx[f]]), a, b);
+			WlBase wb;
+			std::memset(&wb, 0, sizeof(wb));
+			std::memcpy(wb.part[0], a.data(), a.size()); std::memcpy(wb.part[1], b.data(), b.size());
+			wb.len[0] = uint8_t(a.size()); wb.len[1] = uint8_t(b.size()); wb.cell = cells[f];
+			HIP_CHECK(hipMemcpy(d_bases.p + f, &wb, sizeof(wb), hipMemcpyHostToDevice));
+		}
+	}
 
-	// pairs (base, candidate) whose UMI-gene intersection is needed
-	std::vector<u32> pair_base, pair_cand, pair_first(F + 1, 0);
+	// cell id -> index in `real` (the ids of `real` are still on the device from fetch_real_cells / refresh)
+	{
+		const u32 nr = u32(real.size());
+		std::vector<u32> ids(nr);
+		for (u32 i = 0; i < nr; ++i) ids[i] = real[i].id;
+		real_list.ensure(nr); cell_real_index.ensure(n_cells);
+		HIP_CHECK(hipMemcpyAsync(real_list.p, ids.data(), size_t(nr) * 4, hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemsetAsync(cell_real_index.p, 0xFF, size_t(n_cells) * 4, stream));
+		hipLaunchKernelGGL(scatter_index_kernel, dim3(div_up(nr, 256)), dim3(256), 0, stream, real_list.p, nr, cell_real_index.p);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipStreamSynchronize(stream));
+	}
+
+	// 2. neighbour search; candidates land in flat lists
+	DevBuf<u32> d_cnt, d_lvl, d_off, d_fcell, d_fumis, d_fridx;
+	u32 flat_cap = std::max<u32>(F * 2u, 1024u);
+	std::vector<u32> cnt(F), off(F), fcell, fumis, fridx;
+	WlArgs a{};
+	const u32 ntot = u32(wl.parts[0].size() + wl.parts[1].size());
+	const size_t lds = ((ntot + 15u) & ~15u) + size_t(ntot) * 2;
+	for (;;) {
+		d_cnt.alloc(F); d_lvl.alloc(F); d_off.alloc(F); d_fcell.alloc(flat_cap); d_fumis.alloc(flat_cap); d_fridx.alloc(flat_cap);
+		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
+		a = WlArgs{};
+		a.bases = d_bases.p; a.n_bases = F;
+		a.part[0] = d_wl[0].p; a.part[1] = d_wl[1].p;
+		a.part_size[0] = u32(wl.parts[0].size()); a.part_size[1] = u32(wl.parts[1].size());
+		a.table = table; a.cell_n_genes = cell_n_genes.p; a.cell_total_umis = cell_total_umis.p; a.min_genes = min_before;
+		a.cand_count = d_cnt.p; a.cand_level = d_lvl.p; a.cand_off = d_off.p; a.flat_cell = d_fcell.p; a.flat_umis = d_fumis.p;
+		a.flat_ridx = d_fridx.p; a.cell_real_index = cell_real_index.p;
+		a.flat_total = scalars.p; a.flat_cap = flat_cap; a.dist_dump = nullptr;
+		timed("wl_neighbours", double(F) * ntot * 32, [&] {
+			hipLaunchKernelGGL(wl_neighbours_kernel, dim3(F), dim3(WL_THREADS), lds, stream, a);
+		});
+		u32 total = 0;
+		fetch(&total, scalars.p, 4);
+		if (total <= flat_cap) {
+			fetch(cnt.data(), d_cnt.p, size_t(F) * 4);
+			fetch(off.data(), d_off.p, size_t(F) * 4);
+			fcell.resize(total); fumis.resize(total); fridx.resize(total);
+			fetch(fcell.data(), d_fcell.p, size_t(total) * 4);
+			fetch(fumis.data(), d_fumis.p, size_t(total) * 4);
+			fetch(fridx.data(), d_fridx.p, size_t(total) * 4);
+			break;
+		}
+		flat_cap = total + 1024;   // rare: more candidates than twice the number of cells; run again with room
+	}
+
+	// 3. pairs (base, candidate) whose UMI-gene intersection is needed
+	std::vector<u32> pair_base, pair_cand, pair_umis, pair_ridx, pair_first(size_t(F) + 1, 0);
+	pair_base.reserve(F); pair_cand.reserve(F); pair_umis.reserve(F); pair_ridx.reserve(F);
 	for (u32 f = 0; f < F; ++f) {
 		pair_first[f] = u32(pair_base.size());
 		if (cnt[f] > u32(WL_CAND_CAP))
 			throw UnsupportedError("more than " + std::to_string(WL_CAND_CAP) + " merge candidates for one barcode");
 		bool self = false;
-		for (u32 k = 0; k < cnt[f]; ++k) self |= cand[size_t(f) * WL_CAND_CAP + k] == cells[f];
+		for (u32 k = 0; k < cnt[f]; ++k) self |= fcell[off[f] + k] == cells[f];
 		if (self) continue;   // the base is itself a whitelist barcode: neighbour_cells[0] == base (RealBarcodesMergeStrategy.cpp:34-35)
-		for (u32 k = 0; k < cnt[f]; ++k) { pair_base.push_back(cells[f]); pair_cand.push_back(cand[size_t(f) * WL_CAND_CAP + k]); }
+		for (u32 k = 0; k < cnt[f]; ++k) {
+			pair_base.push_back(cells[f]); pair_cand.push_back(fcell[off[f] + k]); pair_umis.push_back(fumis[off[f] + k]);
+			pair_ridx.push_back(fridx[off[f] + k]);
+		}
 	}
 	pair_first[F] = u32(pair_base.size());
 	const u32 NP = u32(pair_base.size());
@@ -147,108 +201,127 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 			hipLaunchKernelGGL(umig_intersect_kernel, dim3(NP), dim3(256), 0, stream, d_pr.p, NP, mol_key.p, (1ull << low_bits) - 1ull,
 			                   layout.umi_bits, layout.gene_none, d_inter.p);
 		});
-		HIP_CHECK(hipMemcpyAsync(inter.data(), d_inter.p, size_t(NP) * 4, hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
+		fetch(inter.data(), d_inter.p, size_t(NP) * 4);
 	}
 
-	// decisions (RealBarcodesMergeStrategy::get_best_merge_target, :31-61)
+	// 4. decisions (RealBarcodesMergeStrategy::get_best_merge_target, :31-61); all inputs are integers, the
+	//    fraction is evaluated exactly as the reference writes it (double, no contraction on the host)
 	std::vector<u32> need_order;   // cells whose result depends on the reference's candidate order
-	auto umis_of = [&](u32 cell) { return size_t(real[real_at(cell)].row.total_umis); };
-	auto frac_of = [&](u32 base, u32 other, u32 n) { return 0.5 * n * (1. / umis_of(base) + 1. / umis_of(other)); };
+	auto frac_of = [&](u32 f, u32 p) {
+		return 0.5 * inter[p] * (1. / size_t(real[ridx[f]].row.total_umis) + 1. / size_t(int32_t(pair_umis[p])));
+	};
 	for (u32 f = 0; f < F; ++f) {
 		if (cnt[f] == 0) { targets[f] = -1; continue; }
 		const u32 p0 = pair_first[f], p1 = pair_first[f + 1];
-		if (p0 == p1) { targets[f] = long(cells[f]); continue; }   // self
-		double best = 0; u32 n_best = 0, best_cell = 0;
+		if (p0 == p1) { targets[f] = long(cells[f]); if (target_ridx) (*target_ridx)[f] = ridx[f]; continue; }   // self
+		double best = 0; u32 n_best = 0, best_p = 0;
 		for (u32 p = p0; p < p1; ++p) {
-			const double fr = frac_of(cells[f], pair_cand[p], inter[p]);
-			if (fr > best) { best = fr; n_best = 1; best_cell = pair_cand[p]; }
+			const double fr = frac_of(f, p);
+			if (fr > best) { best = fr; n_best = 1; best_p = p; }
 			else if (fr == best) ++n_best;
 		}
 		if (best < cfg.min_merge_fraction) { targets[f] = -1; continue; }   // holds for any order
-		if (best > 0 && n_best == 1) { targets[f] = long(best_cell); continue; }
+		if (best > 0 && n_best == 1) { targets[f] = long(pair_cand[best_p]); if (target_ridx) (*target_ridx)[f] = pair_ridx[best_p]; continue; }
 		need_order.push_back(f);   // tie at the maximum (or all fractions zero with a non-positive threshold)
 	}
 	if (!need_order.empty()) {
 		const u32 R = u32(need_order.size());
 		std::vector<WlBase> rb(R);
-		for (u32 r = 0; r < R; ++r) rb[r] = bases[need_order[r]];
+		for (u32 r = 0; r < R; ++r) HIP_CHECK(hipMemcpy(&rb[r], d_bases.p + need_order[r], sizeof(WlBase), hipMemcpyDeviceToHost));
 		DevBuf<WlBase> d_rb; d_rb.alloc(R);
 		DevBuf<uint8_t> d_dump; d_dump.alloc(size_t(R) * ntot);
-		DevBuf<u32> d_c2, d_l2, d_k2; d_c2.alloc(R); d_l2.alloc(R); d_k2.alloc(size_t(R) * WL_CAND_CAP);
+		DevBuf<u32> d_c2, d_l2, d_o2, d_f2, d_u2;
+		d_c2.alloc(R); d_l2.alloc(R); d_o2.alloc(R); d_f2.alloc(size_t(R) * WL_CAND_CAP); d_u2.alloc(size_t(R) * WL_CAND_CAP);
 		HIP_CHECK(hipMemcpyAsync(d_rb.p, rb.data(), size_t(R) * sizeof(WlBase), hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
 		WlArgs a2 = a;
-		a2.bases = d_rb.p; a2.n_bases = R; a2.cand_count = d_c2.p; a2.cand_level = d_l2.p; a2.cand_cell = d_k2.p; a2.dist_dump = d_dump.p;
+		a2.bases = d_rb.p; a2.n_bases = R; a2.cand_count = d_c2.p; a2.cand_level = d_l2.p; a2.cand_off = d_o2.p;
+		a2.flat_cell = d_f2.p; a2.flat_umis = d_u2.p; a2.flat_cap = R * u32(WL_CAND_CAP); a2.dist_dump = d_dump.p;
 		hipLaunchKernelGGL(wl_neighbours_kernel, dim3(R), dim3(WL_THREADS), lds, stream, a2);
 		HIP_CHECK(hipGetLastError());
 		std::vector<uint8_t> dump(size_t(R) * ntot);
-		HIP_CHECK(hipMemcpyAsync(dump.data(), d_dump.p, dump.size(), hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
+		fetch(dump.data(), d_dump.p, dump.size());
+		// barcodes of the candidates (whitelist cells, hence real-candidate cells) for the replay
 		for (u32 r = 0; r < R; ++r) {
 			const u32 f = need_order[r];
 			std::unordered_map<u64, u32> by_code;
-			std::unordered_map<u32, u32> inter_of;
+			std::unordered_map<u32, u32> pair_of;
 			for (u32 p = pair_first[f]; p < pair_first[f + 1]; ++p) {
 				by_code[real[real_at(pair_cand[p])].row.barcode] = pair_cand[p];
-				inter_of[pair_cand[p]] = inter[p];
+				pair_of[pair_cand[p]] = p;
 			}
 			const std::vector<u32> order = reference_candidate_order(wl, dump.data() + size_t(r) * ntot, by_code);
 			if (order.empty()) throw DeviceError("internal: candidate replay found no candidate");
 			double best = 0; u32 best_cell = order[0];
 			for (u32 c : order) {
-				const double fr = frac_of(cells[f], c, inter_of.at(c));
+				const double fr = frac_of(f, pair_of.at(c));
 				if (best < fr) { best = fr; best_cell = c; }
 			}
 			targets[f] = best < cfg.min_merge_fraction ? -1 : long(best_cell);
+			if (target_ridx && targets[f] >= 0) (*target_ridx)[f] = pair_ridx[pair_of.at(best_cell)];
 		}
 	}
 	return targets;
 }
 
 void dropest_ctx::run_cb_merge_real() {
+	HostStage hs(this, "cb_merge");
 	const std::vector<uint64_t> &order = filtered_cells();
 	std::vector<u32> cells(order.begin(), order.end());
-	const std::vector<long> targets = compute_merge_targets(cells);
+	const std::vector<u32> ridx = filtered_ridx;
+	std::vector<long> targets;
+	std::vector<u32> target_ridx;
+	{ HostStage hs2(this, "cb_merge:targets"); targets = compute_merge_targets(cells, ridx, &target_ridx); }
 
-	// MergeStrategyBase::merge_inited second loop (:30-51) + reassign (:64-82)
-	std::unordered_map<u32, std::unordered_set<u32>> reassigned_to;
-	reassign.clear();
-	auto current = [&](u32 c) { auto it = reassign.find(c); return it == reassign.end() ? c : it->second; };
+	// MergeStrategyBase::merge_inited second loop (:30-51) + reassign (:64-82), on flat arrays indexed by the
+	// position in `real`: cur[x] = final target of x; the cells merged into a target form an intrusive list.
+	HostStage hs3(this, "cb_merge:apply");
+	const u32 NIL = 0xFFFFFFFFu, nR = u32(real.size());
+	std::vector<u32> cur(nR), head(nR, NIL), tail(nR, NIL), next(nR, NIL);
+	for (u32 i = 0; i < nR; ++i) cur[i] = i;
+	auto append = [&](u32 tgt, u32 x) { if (head[tgt] == NIL) head[tgt] = x; else next[tail[tgt]] = x; tail[tgt] = x; next[x] = NIL; };
 	bool any_merge = false;
 	for (size_t i = 0; i < cells.size(); ++i) {
-		const u32 base = cells[i];
-		HostCell &hb = real[real_at(base)];
-		long t = targets[i];
-		if (t < 0) { hb.excluded = true; continue; }
-		u32 tgt = current(u32(t));
-		if (tgt == base) continue;
-		HostCell &ht = real[real_at(tgt)];
+		const u32 b = ridx[i];
+		HostCell &hb = real[b];
+		if (targets[i] < 0) { hb.excluded = true; continue; }
+		const u32 tr = cur[target_ridx[i]];        // "real barcodes could be merged too" (:43-46)
+		if (tr == b) continue;
+		HostCell &ht = real[tr];
 		// CellsDataContainer::merge_cells (:90-104): Stats::merge adds every counter, TOTAL_UMIS included
 		ht.row.total_reads += hb.row.total_reads;
 		ht.row.total_umis += hb.row.total_umis;
 		hb.merged = true;
 		any_merge = true;
-		reassign[base] = tgt;
-		reassigned_to[tgt].insert(base);
-		auto it = reassigned_to.find(base);
-		if (it != reassigned_to.end()) {
-			for (u32 moved : it->second) { reassign[moved] = tgt; reassigned_to[tgt].insert(moved); }
-			reassigned_to.find(base)->second.clear();
-		}
+		cur[b] = tr;
+		u32 moved = head[b];                         // cells previously merged into b follow it (reassign, :64-82)
+		head[b] = tail[b] = NIL;
+		append(tr, b);
+		while (moved != NIL) { const u32 nx = next[moved]; cur[moved] = tr; append(tr, moved); moved = nx; }
 	}
+	reassign.clear();
 	merge_pairs.clear();
-	for (auto &kv : reassign) merge_pairs.emplace_back(kv.first, kv.second);
-	std::sort(merge_pairs.begin(), merge_pairs.end());
+	for (u32 i = 0; i < nR; ++i) if (cur[i] != i) merge_pairs.emplace_back(real[i].id, real[cur[i]].id);   // ascending source id
 	if (any_merge) reaggregate_after_merge();
 }
 
 // Unions of the merged cells' molecule sets: re-key, re-sort, re-reduce (Gene::merge, Gene.cpp:26-36).
 void dropest_ctx::reaggregate_after_merge() {
-	std::vector<u32> h_remap(n_cells);
-	for (u32 i = 0; i < n_cells; ++i) h_remap[i] = i;
-	for (auto &kv : reassign) h_remap[kv.first] = kv.second;
+	HostStage hs(this, "cb_merge:reaggregate");
 	remap.ensure(n_cells);
-	HIP_CHECK(hipMemcpyAsync(remap.p, h_remap.data(), size_t(n_cells) * 4, hipMemcpyHostToDevice, stream));
+	{
+		std::vector<u32> src, tgt;
+		src.reserve(merge_pairs.size()); tgt.reserve(merge_pairs.size());
+		for (auto &kv : merge_pairs) { src.push_back(u32(kv.first)); tgt.push_back(u32(kv.second)); }
+		DevBuf<u32> d_src, d_tgt; d_src.alloc(src.size()); d_tgt.alloc(tgt.size());
+		HIP_CHECK(hipMemcpyAsync(d_src.p, src.data(), src.size() * 4, hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(d_tgt.p, tgt.data(), tgt.size() * 4, hipMemcpyHostToDevice, stream));
+		hipLaunchKernelGGL(iota_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, stream, remap.p, n_cells);
+		hipLaunchKernelGGL(scatter_pairs_kernel, dim3(div_up(u32(src.size()), 256)), dim3(256), 0, stream, d_src.p, d_tgt.p,
+		                   u32(src.size()), remap.p);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipStreamSynchronize(stream));   // src / tgt are host vectors
+	}
 	keys_a.ensure(n_mol); keys_b.ensure(n_mol); vals_a.ensure(n_mol); vals_b.ensure(n_mol);
 	scalars.ensure(16);
 	u64 init[2] = {0ull, ~0ull};

@@ -348,3 +348,12 @@ def test_n_umis_with_cb_merge():
     c = parity.gpu_run(dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST, barcodes_file=path,
                             min_genes_before_merge=3, min_genes_after_merge=10), cb, umi, gene, aux, side)
     parity.compare(o, c, side)
+
+
+def test_device_ordering_of_filtered_cells(monkeypatch):
+    """Large filtered lists are ordered by three stable radix sorts on the device; force that path on a stream
+    small enough for the oracle (DROPEST_DEVICE_SORT_MIN) -- with and without the whitelist merge."""
+    monkeypatch.setenv("DROPEST_DEVICE_SORT_MIN", "1")
+    _both(dict(n_cells=60, n_genes=3000), 150_000, 2, 5)
+    _both_merge(dict(n_cells=30, n_genes=2000, umi_len=12, permille_neighbour=150), 200_000, 3, 20,
+                "10x_aug_2016_split", capi.BARCODES_CONST)
