@@ -99,6 +99,8 @@ def lib():
         "dropest_count_matrix_csc": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
         "dropest_chr_stats": (C.c_int, [vp, u64p, vp, vp, vp, vp]),
         "dropest_merge_target": (C.c_int, [vp, C.c_uint64, P(C.c_int64)]),
+        "dropest_umi_distribution": (C.c_int, [vp, u64p, vp, vp]),
+        "dropest_collisions_adjusted_sizes": (C.c_int, [C.c_int, vp, C.c_uint64, C.c_uint64, vp]),
         "dropest_owner_of": (C.c_uint32, [C.c_uint64, C.c_uint32]),
         "dropest_partition_by_owner": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp, vp]),
         "dropest_clear_reads": (C.c_int, [vp]),
@@ -134,7 +136,8 @@ EXPORTED_SYMBOLS = [
     "dropest_global_counters", "dropest_cell_molecules", "dropest_molecules", "dropest_count_matrix",
     "dropest_count_matrix_csc", "dropest_owner_of", "dropest_partition_by_owner", "dropest_clear_reads",
     "dropest_count_matrix_device", "dropest_cell_first_reads_device", "dropest_assemble_columns",
-    "dropest_real_candidate_rows", "dropest_dev_copy_device",
+    "dropest_real_candidate_rows", "dropest_dev_copy_device", "dropest_umi_distribution",
+    "dropest_collisions_adjusted_sizes",
     "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_stream",
     "dropest_synth_generate_host", "dropest_synth_generate_device", "dropest_dev_alloc", "dropest_dev_free",
     "dropest_dev_copy_to_host", "dropest_dev_copy_from_host", "dropest_dev_count", "dropest_dev_sync",
@@ -356,6 +359,14 @@ class Context:
                                                cnt.ctypes.data))
         return cell, kind, chr_, cnt
 
+    def umi_distribution(self):
+        n = C.c_uint64()
+        self._chk(self.L.dropest_umi_distribution(self.h, C.byref(n), None, None))
+        umi = np.zeros(n.value, np.uint64); cnt = np.zeros(n.value, np.uint64)
+        if n.value:
+            self._chk(self.L.dropest_umi_distribution(self.h, C.byref(n), umi.ctypes.data, cnt.ctypes.data))
+        return umi, cnt
+
     def merge_target(self, cell):
         t = C.c_int64()
         self._chk(self.L.dropest_merge_target(self.h, cell, C.byref(t)))
@@ -371,6 +382,16 @@ class Context:
         self._chk(self.L.dropest_kernel_stats(self.h, C.byref(n), arr))
         return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, bytes=arr[i].bytes)
                 for i in range(n.value)}
+
+
+def collisions_adjusted_sizes(probs, max_expression, device=0):
+    """Tools::CollisionsAdjuster table on the device."""
+    p = np.ascontiguousarray(probs, np.float64)
+    out = np.zeros(max_expression, np.uint64)
+    rc = lib().dropest_collisions_adjusted_sizes(device, p.ctypes.data, len(p), max_expression, out.ctypes.data)
+    if rc != 0:
+        raise DropestError(rc, lib().dropest_last_error().decode())
+    return out
 
 
 class DeviceArrays:

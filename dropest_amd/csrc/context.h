@@ -13,6 +13,7 @@
 
 #include "../../include/dropest_amd.h"
 #include "k_cbhash.h"
+#include "k_collisions.h"
 #include "k_merge.h"
 #include "whitelist.h"
 #include "k_misc.h"

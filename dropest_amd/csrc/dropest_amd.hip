@@ -970,6 +970,94 @@ dropest_status dropest_chr_stats(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, 
 	});
 }
 
+dropest_status dropest_umi_distribution(dropest_ctx *ctx, uint64_t *n, uint64_t *umi, uint64_t *count) {
+	return guarded([&] {
+		need_init(ctx);
+		*n = 0;
+		if (ctx->n_mol == 0) return;
+		// flags of the filtered cells
+		std::vector<u32> flags(ctx->n_cells, 0);
+		for (uint64_t id : ctx->filtered_cells()) flags[id] = 1;
+		ctx->remap.ensure(ctx->n_cells);
+		HIP_CHECK(hipMemcpyAsync(ctx->remap.p, flags.data(), size_t(ctx->n_cells) * 4, hipMemcpyHostToDevice, ctx->stream));
+		const u32 nm = ctx->n_mol;
+		ctx->keys_a.ensure(nm); ctx->keys_b.ensure(nm); ctx->vals_a.ensure(nm); ctx->vals_b.ensure(nm);
+		ctx->scalars.ensure(16);
+		HIP_CHECK(hipMemsetAsync(ctx->scalars.p, 0, 4, ctx->stream));
+		const KeyLayout &L = ctx->layout;
+		hipLaunchKernelGGL(emit_filtered_umis_kernel, dim3(div_up(nm, 256)), dim3(256), 0, ctx->stream, ctx->mol_key.p, nm, L.umi_bits,
+		                   L.gene_bits, L.gene_none, ctx->remap.p, ctx->keys_a.p, ctx->scalars.p);
+		HIP_CHECK(hipGetLastError());
+		u32 kept = 0;
+		ctx->fetch(&kept, ctx->scalars.p, 4);
+		std::map<u64, uint64_t> dist;   // API code -> molecules
+		if (kept) {
+			u64 *k = ctx->keys_a.p, *k_alt = ctx->keys_b.p;
+			u32 *v = ctx->vals_a.p, *v_alt = ctx->vals_b.p;
+			ctx->radix_sort(k, v, k_alt, v_alt, kept, L.umi_bits >= 64 ? ~0ull : ((1ull << L.umi_bits) - 1ull));
+			UmiRuns p{};
+			p.keys = k;
+			DevBuf<u64> run_key; DevBuf<u32> run_cnt;
+			const u32 runs = run_segmented_reduce(*ctx, "umi_runs", p, kept, 8, [&](u32 total) {
+				run_key.alloc(total + 1); run_cnt.alloc(total + 1);
+				zero_async(*ctx, run_cnt.p, size_t(total + 1) * 4);
+				p.run_key = run_key.p; p.out[0] = run_cnt.p;
+			});
+			std::vector<u64> hk(runs); std::vector<u32> hc(runs);
+			ctx->fetch(hk.data(), run_key.p, size_t(runs) * 8);
+			ctx->fetch(hc.data(), run_cnt.p, size_t(runs) * 4);
+			for (u32 i = 0; i < runs; ++i) dist[ctx->unmap_umi(hk[i])] += hc[i];
+		}
+		// groups rewritten by the N-UMI merge: replace their device molecules by the host-side contents
+		if (!ctx->umi_overrides.empty()) {
+			const u64 umask = L.umi_bits ? ((1ull << L.umi_bits) - 1ull) : 0ull;
+			for (auto const &kv : ctx->umi_overrides) {
+				const u32 cell = u32(kv.first >> L.gene_bits);
+				if (!flags[cell]) continue;
+				// device molecules of the group
+				u32 cgb = 0, cgc = 0;
+				HIP_CHECK(hipMemcpy(&cgb, ctx->cell_cg_begin.p + cell, 4, hipMemcpyDeviceToHost));
+				HIP_CHECK(hipMemcpy(&cgc, ctx->cell_cg_count.p + cell, 4, hipMemcpyDeviceToHost));
+				std::vector<u64> cgk(cgc); std::vector<u32> mb(cgc + 1);
+				HIP_CHECK(hipMemcpy(cgk.data(), ctx->cg_key.p + cgb, size_t(cgc) * 8, hipMemcpyDeviceToHost));
+				HIP_CHECK(hipMemcpy(mb.data(), ctx->cg_mol_begin.p + cgb, size_t(cgc + 1) * 4, hipMemcpyDeviceToHost));
+				for (u32 j = 0; j < cgc; ++j) {
+					if (cgk[j] != kv.first) continue;
+					std::vector<u64> mk(mb[j + 1] - mb[j]);
+					HIP_CHECK(hipMemcpy(mk.data(), ctx->mol_key.p + mb[j], mk.size() * 8, hipMemcpyDeviceToHost));
+					for (u64 k2 : mk) { auto it = dist.find(ctx->unmap_umi(k2 & umask)); if (it != dist.end() && --it->second == 0) dist.erase(it); }
+				}
+				for (const UmiOverride &o : kv.second) dist[o.umi]++;
+			}
+		}
+		*n = dist.size();
+		if (umi && count) { size_t i = 0; for (auto const &kv : dist) { umi[i] = kv.first; count[i] = kv.second; ++i; } }
+	});
+}
+
+dropest_status dropest_collisions_adjusted_sizes(int device, const double *umi_probabilities, uint64_t n, uint64_t max_expression,
+                                                 uint64_t *adjusted_sizes) {
+	return guarded([&] {
+		if (!umi_probabilities || !adjusted_sizes) throw InvalidError("null argument");
+		HIP_CHECK(hipSetDevice(device));
+		if (max_expression == 0) return;
+		DevBuf<double> d_p, d_np, d_partial; DevBuf<CollisionState> d_st; DevBuf<u64> d_adj;
+		d_p.alloc(n); d_np.alloc(n); d_partial.alloc(CA_BLOCKS); d_st.alloc(1); d_adj.alloc(max_expression);
+		std::vector<double> ones(n, 1.0);
+		HIP_CHECK(hipMemcpy(d_p.p, umi_probabilities, n * 8, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy(d_np.p, ones.data(), n * 8, hipMemcpyHostToDevice));
+		CollisionState st{0.0, 0ull, 0ull};
+		HIP_CHECK(hipMemcpy(d_st.p, &st, sizeof(st), hipMemcpyHostToDevice));
+		hipLaunchKernelGGL(collisions_finish_kernel, dim3(1), dim3(1), 0, nullptr, d_partial.p, d_st.p, 0ull, d_adj.p);   // exponent of s = 1
+		for (uint64_t s = 1; s <= max_expression; ++s) {
+			hipLaunchKernelGGL(collisions_step_kernel, dim3(CA_BLOCKS), dim3(CA_THREADS), 0, nullptr, d_p.p, d_np.p, n, d_st.p, d_partial.p);
+			hipLaunchKernelGGL(collisions_finish_kernel, dim3(1), dim3(1), 0, nullptr, d_partial.p, d_st.p, s, d_adj.p);
+		}
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipMemcpy(adjusted_sizes, d_adj.p, max_expression * 8, hipMemcpyDeviceToHost));
+	});
+}
+
 dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *target) {
 	return guarded([&] {
 		need_init(ctx);

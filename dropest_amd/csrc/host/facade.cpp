@@ -13,6 +13,23 @@ ReadParameters ReadParameters::parse_encoded_id(const std::string &encoded_id) {
 	if (cb_pos == std::string::npos) throw std::runtime_error("ERROR: unable to parse out cell barcode in: " + encoded_id);
 	return ReadParameters(encoded_id.substr(cb_pos + 1, umi_pos - cb_pos - 1), encoded_id.substr(umi_pos + 1));
 }
+void CollisionsAdjuster::init(const probs_vec_t &umi_probabilities, size_t max_gene_expression) {   // CollisionsAdjuster.cpp:12-19
+	_umi_probabilities = umi_probabilities;
+	_adjusted_sizes.clear();
+	update_adjusted_sizes(max_gene_expression);
+}
+void CollisionsAdjuster::update_adjusted_sizes(size_t max_gene_expression) {
+	if (max_gene_expression <= _adjusted_sizes.size()) return;
+	// the recurrence restarts from s = 1 on the device (deterministic: same prefix every time)
+	std::vector<uint64_t> t(max_gene_expression);
+	if (dropest_collisions_adjusted_sizes(_device, _umi_probabilities.data(), _umi_probabilities.size(), max_gene_expression, t.data()) != DROPEST_OK)
+		throw std::runtime_error(dropest_last_error());
+	_adjusted_sizes.assign(t.begin(), t.end());
+}
+size_t CollisionsAdjuster::estimate_adjusted_gene_expression(size_t expression) {   // :41-49
+	if (expression > _adjusted_sizes.size()) update_adjusted_sizes(expression);
+	return _adjusted_sizes.at(expression - 1);
+}
 }  // namespace Tools
 
 namespace Estimation {
@@ -237,6 +254,16 @@ void CellsDataContainer::get_stat_by_real_cells(Stats::CellChrStatType stat, nam
 		cell_barcodes.push_back(decode(this->cell(cur)._row.barcode));
 		counts.insert(counts.end(), row.begin(), row.end());
 	}
+}
+
+CellsDataContainer::s_ul_hash_t CellsDataContainer::umi_distribution() const {
+	uint64_t n = 0;
+	check(dropest_umi_distribution(_ctx, &n, nullptr, nullptr));
+	std::vector<uint64_t> umi(n), cnt(n);
+	if (n) check(dropest_umi_distribution(_ctx, &n, umi.data(), cnt.data()));
+	s_ul_hash_t res;
+	for (size_t i = 0; i < n; ++i) res[decode(umi[i])] = size_t(cnt[i]);
+	return res;
 }
 
 static uint64_t counter(dropest_ctx *ctx, int i) { uint64_t c[4] = {0, 0, 0, 0}; if (dropest_global_counters(ctx, c) != DROPEST_OK) throw std::runtime_error(dropest_last_error()); return c[i]; }

@@ -42,6 +42,19 @@ public:
 	const std::string &cell_barcode_quality() const { return _cb_quality; }
 	const std::string &umi_quality() const { return _umi_quality; }
 };
+// Tools::CollisionsAdjuster (Tools/CollisionsAdjuster.h:8-33); the table is computed on the GPU
+// (dropest_collisions_adjusted_sizes) and extended on demand like the reference does.
+class CollisionsAdjuster {
+	std::vector<size_t> _adjusted_sizes;
+	std::vector<double> _umi_probabilities;
+	int _device;
+	void update_adjusted_sizes(size_t max_gene_expression);
+public:
+	using probs_vec_t = std::vector<double>;
+	explicit CollisionsAdjuster(int device = 0) : _device(device) {}
+	void init(const probs_vec_t &umi_probabilities, size_t max_gene_expression = 0);
+	size_t estimate_adjusted_gene_expression(size_t expression);
+};
 }  // namespace Tools
 
 namespace Estimation {
@@ -229,6 +242,7 @@ public:
 	size_t real_cells_number() const;
 	std::string merge_type() const { return _merge_strategy->merge_type(); }
 	const StringIndexer &gene_indexer() const { return _gene_indexer; }
+	s_ul_hash_t umi_distribution() const;                               // CellsDataContainer.cpp:182-197
 	const std::vector<std::string> &side_strings() const { return _side; }
 	dropest_ctx *handle() const { return _ctx; }
 	std::string decode(uint64_t code) const;

@@ -169,6 +169,17 @@ dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int read
 dropest_status dropest_chr_stats(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, uint32_t *kind, uint32_t *chr,
                                  int32_t *count);
 
+/* CellsDataContainer::umi_distribution (CellsDataContainer.cpp:182-197): number of molecules per UMI over the
+ * FILTERED cells, ascending UMI code (the reference returns an unordered_map; this is its content, ordered). */
+dropest_status dropest_umi_distribution(dropest_ctx *ctx, uint64_t *n, uint64_t *umi, uint64_t *count);
+/* Tools::CollisionsAdjuster (Tools/CollisionsAdjuster.cpp:12-49): adjusted_size[s-1] for s = 1..max_expression, from
+ * the UMI probability vector (PoissonTargetEstimator::init, PoissonTargetEstimator.cpp:46-60).  Evaluated on the
+ * device in double precision, one launch pair per s (the recurrence over s is sequential); the inner sum over the
+ * UMIs is a FIXED-ORDER parallel reduction, so results are reproducible run to run but may differ from the
+ * reference's left-to-right sum in the last bits of `new_umi_prob` (the table itself is integer, after lround).
+ * The reference pins this component only to 1e-2 (Tests/TestEstimationMergeProbs.cpp:113-140). */
+dropest_status dropest_collisions_adjusted_sizes(int device, const double *umi_probabilities, uint64_t n,
+                                                 uint64_t max_expression, uint64_t *adjusted_sizes);
 /* RealBarcodesMergeStrategy::get_merge_target (RealBarcodesMergeStrategy.cpp:22-29) for one cell,
  * evaluated on the un-merged state; valid between set_initialized and merge_and_filter. */
 dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *target);

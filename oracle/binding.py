@@ -57,6 +57,7 @@ def oracle_lib():
         "orc_molecules": (u64, [vp, vp, vp, vp, C.c_int, vp, vp]),
         "orc_count_matrix": (u64, [vp, C.c_int, C.c_int, vp, vp, vp]),
         "orc_chr_stats": (u64, [vp, vp, vp, vp, vp]),
+        "orc_umi_distribution": (u64, [vp, C.c_char_p, C.c_int, vp]),
         "orc_edit_distance": (C.c_uint, [C.c_char_p, C.c_char_p, C.c_int, C.c_uint]),
         "orc_hamming_distance": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "orc_parse_encoded_id": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]),
@@ -204,6 +205,12 @@ class Oracle:
         cnt = np.zeros(n, np.int64)
         self.L.orc_chr_stats(self.h, cell.ctypes.data, kind.ctypes.data, chr_.ctypes.data, cnt.ctypes.data)
         return cell, kind, chr_, cnt
+
+    def umi_distribution(self, stride=40):
+        n = int(self.L.orc_umi_distribution(self.h, None, stride, None))
+        buf = C.create_string_buffer(max(1, n * stride)); counts = np.zeros(n, np.uint64)
+        self.L.orc_umi_distribution(self.h, buf, stride, counts.ctypes.data)
+        return _strs(buf.raw, n, stride), counts
 
     # ---- fine-grained (pinning) ----
     def merge_target(self, cell):

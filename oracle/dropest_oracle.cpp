@@ -852,6 +852,22 @@ uint64_t orc_chr_stats(void *h, uint64_t *cell, int32_t *kind, uint64_t *chr, in
 	return n;
 }
 
+// CellsDataContainer::umi_distribution (CellsDataContainer.cpp:182-197): molecules per UMI over the filtered
+// cells; returned sorted by UMI string (the reference returns an unordered_map).  out == NULL counts.
+uint64_t orc_umi_distribution(void *h, char *umi_buf, int stride, uint64_t *counts) {
+	auto *c = static_cast<orc::Container *>(h);
+	std::map<std::string, size_t> dist;
+	for (size_t id : c->filtered)
+		for (auto const &g : c->cells[id].genes)
+			for (auto const &u : g.second) dist[c->umi_ix.values.at(u.first)]++;
+	uint64_t n = 0;
+	for (auto const &kv : dist) {
+		if (umi_buf) { std::strncpy(umi_buf + size_t(stride) * n, kv.first.c_str(), size_t(stride)); counts[n] = kv.second; }
+		++n;
+	}
+	return n;
+}
+
 // ---- fine-grained entry points used to pin the oracle on the reference's unit tests ----
 unsigned orc_edit_distance(const char *a, const char *b, int skip_n, unsigned max_ed) { return orc::edit_distance(a, b, skip_n != 0, max_ed); }
 int orc_hamming_distance(const char *a, const char *b, int skip_n) {

@@ -169,6 +169,24 @@ static void testResultsPrinterMtx(const std::string &tmp) {   // ResultsPrinter.
 	CHECK_EQ(c.has_exon_reads_num(), size_t(17)); CHECK_EQ(c.intergenic_reads_num(), size_t(0));
 }
 
+static void testUmiDistributionAndCollisions() {   // CellsDataContainer.cpp:182-197; Tools/CollisionsAdjuster.cpp
+	Fixture f;
+	auto &c = *f.container_full;
+	c.merge_and_filter();
+	auto dist = c.umi_distribution();   // over the 2 filtered cells: 3 + 6 molecules
+	size_t total = 0;
+	for (auto const &kv : dist) total += kv.second;
+	CHECK_EQ(total, size_t(9));
+	CHECK_EQ(dist.at("CAACCT"), size_t(4)); CHECK_EQ(dist.at("CCCCCT"), size_t(1)); CHECK_EQ(dist.at("ACCCCT"), size_t(2));
+	std::vector<double> probs;
+	for (auto const &kv : dist) probs.push_back(double(kv.second) / double(total));
+	Tools::CollisionsAdjuster adj;
+	adj.init(std::vector<double>(4096, 1.0 / 4096));
+	CHECK_EQ(adj.estimate_adjusted_gene_expression(1), size_t(1));
+	CHECK(adj.estimate_adjusted_gene_expression(1000) > size_t(1000));          // collisions inflate large expressions
+	CHECK(adj.estimate_adjusted_gene_expression(1000) < size_t(1300));
+}
+
 int main(int argc, char **argv) {
 	g_data = argc > 1 ? argv[1] : "dropest_amd/data/barcodes";
 	const std::string tmp = argc > 2 ? argv[2] : "/tmp";
@@ -179,6 +197,7 @@ int main(int argc, char **argv) {
 		testUMIMergeStrategySimple();
 		testStateMachineAndParams();
 		testResultsPrinterMtx(tmp);
+		testUmiDistributionAndCollisions();
 	} catch (const std::exception &e) {
 		std::printf("UNEXPECTED EXCEPTION: %s\n", e.what());
 		return 2;

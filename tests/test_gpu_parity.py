@@ -357,3 +357,46 @@ def test_device_ordering_of_filtered_cells(monkeypatch):
     _both(dict(n_cells=60, n_genes=3000), 150_000, 2, 5)
     _both_merge(dict(n_cells=30, n_genes=2000, umi_len=12, permille_neighbour=150), 200_000, 3, 20,
                 "10x_aug_2016_split", capi.BARCODES_CONST)
+
+
+# ---------------------------------------------------------------------------------------------------
+# UMI distribution + Tools::CollisionsAdjuster
+# ---------------------------------------------------------------------------------------------------
+from oracle import binding as ob
+
+
+def test_umi_distribution_matches_oracle():
+    """CellsDataContainer::umi_distribution (CellsDataContainer.cpp:182-197), also after the N-UMI merge."""
+    s = SynthStream(n_reads=150_000, n_cells=40, n_genes=1500, umi_len=6)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    umi, side = inject_n(umi, gene, 5e-3, 3, 6)
+    o = parity.oracle_run(Oracle, dict(min_genes_before=10, min_genes_after=20), cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(min_genes_before_merge=10, min_genes_after_merge=20), cb, umi, gene, aux, side)
+    codes, counts = c.umi_distribution()
+    names, ocounts = o.umi_distribution()
+    got = {capi.unpack_code(u, side): int(n) for u, n in zip(codes, counts)}
+    assert got == dict(zip(names, [int(x) for x in ocounts]))
+    assert len(got) > 1000 and all("N" not in k for k in got)
+    assert np.all(np.diff(codes.astype(np.float64)) > 0)            # ascending UMI code
+
+
+def test_collisions_adjuster_table():
+    """Tools::CollisionsAdjuster (Tools/CollisionsAdjuster.cpp:12-49).  The recurrence is evaluated in double on the
+    device with a fixed-order parallel sum; the oracle sums left to right like the reference.  Bar (stated in
+    include/dropest_amd.h): the integer table is identical; the reference itself pins this component to 1e-2 only."""
+    rng = np.random.default_rng(12)
+    # (a) the UMI distribution of a synthetic run, normalised as PoissonTargetEstimator::init does (:46-60)
+    s = SynthStream(n_reads=200_000, n_cells=40, n_genes=1500, umi_len=6)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    c = parity.gpu_run(dict(min_genes_before_merge=10, min_genes_after_merge=20), cb, umi, gene, aux)
+    _, counts = c.umi_distribution()
+    p = counts.astype(np.float64) / float(counts.sum())
+    smax = len(p) // 3          # the recurrence diverges once the expression approaches the size of the UMI space
+    assert np.array_equal(capi.collisions_adjusted_sizes(p, smax), ob.collisions_table(p, smax))
+    # (b) uniform and skewed toy distributions (expression well below the UMI-space size, as in real use)
+    for n, skew, smax in ((16, 0.0, 8), (64, 1.0, 20), (4096, 0.5, 1500), (4096, 0.0, 3000)):
+        w = 1.0 / np.arange(1, n + 1) ** skew
+        w = rng.permutation(w / w.sum())
+        got, want = capi.collisions_adjusted_sizes(w, smax), ob.collisions_table(w, smax)
+        assert np.array_equal(got, want), (n, skew)
+        assert np.all(np.diff(got.astype(np.int64)) >= 1)                   # adjusted sizes grow with s
