@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 DOMINANT = "rs_scatter"        # the radix scatter pass (dropest_amd/csrc/k_radix.h)
-DOMINANT_BYTES_PER_RECORD = 24  # 8 B key + 4 B value read, 8 B + 4 B written: the pass's algorithmic minimum
+# algorithmic bytes of one pass = 2 x (8 B key + value bytes) per record, value bytes = 0 / 1 / 4
 
 
 def parse():
@@ -124,11 +124,13 @@ def main():
         step = lambda: one_step(ctx)   # noqa: E731
         get_stats = ctx.kernel_stats
         set_prof = ctx.set_profiling
+        get_layout = ctx.sort_layout
     else:
         from dropest_amd.multi import ShardedRun
         run = ShardedRun(stream, rank, world, local_rank, reads_per_gpu, cfg, dist)
         step = run.step
         get_stats = run.kernel_stats
+        get_layout = run.engine.ctx.sort_layout
         def set_prof(on):
             run.set_profiling(on)
             run.trace = {} if on else None
@@ -156,7 +158,10 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / max(1, args.steps) * 1e3
         value = total_reads / (elapsed / max(1, args.steps)) / 1e6
-        dom = stats.get(DOMINANT, {"launches": 0, "ms": 0.0, "bytes": 0.0})
+        # the scatter pass exists in three record widths (keys only / key + 1 B / key + 4 B); the widest share of time wins
+        cands = {k: v for k, v in stats.items() if k.startswith(DOMINANT)}
+        dom_name = max(cands, key=lambda k: cands[k]["ms"]) if cands else DOMINANT
+        dom = stats.get(dom_name, {"launches": 0, "ms": 0.0, "bytes": 0.0})
         roof = None
         if dom["launches"]:
             avg_ms = dom["ms"] / dom["launches"]
@@ -165,10 +170,13 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_rs_scatter.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                    rec = json.load(open(pmc))
+                    # the PMC passes were taken on one kernel variant at one size: only quote them for that case
+                    if rec.get("kernel_stat_name") == dom_name and rec.get("records_per_launch") == reads_per_gpu:
+                        traffic = rec.get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roof = {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"]}
@@ -190,7 +198,7 @@ def main():
                                     "C2: synthetic 10x v2, %d reads/GPU, %d cells/GPU, 16bp CB + 10bp UMI, 30000 genes, "
                                     "no CB merge, -L eEBA") % (reads_per_gpu, args.cells),
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d" % world,
-                       "cm_nnz": int(len(cm[1])), "filtered_cells": int(len(out[2]))},
+                       "cm_nnz": int(len(cm[1])), "filtered_cells": int(len(out[2])), "sort_layout": get_layout()},
             "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kernels,
             "host_stage_wall_ms_per_step": host_stages,
         }

@@ -111,6 +111,7 @@ def lib():
         "dropest_dev_copy_device": (C.c_int, [C.c_int, vp, vp, C.c_uint64]),
         "dropest_kernel_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
         "dropest_set_profiling": (C.c_int, [vp, C.c_int]),
+        "dropest_sort_layout": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "dropest_stream": (vp, [vp]),
         "dropest_synth_generate_host": (C.c_int, [P(SynthParams), C.c_uint64, C.c_uint64, vp, vp, vp, vp]),
         "dropest_synth_generate_device": (C.c_int, [P(SynthParams), C.c_int, C.c_uint64, C.c_uint64, vp, vp, vp, vp]),
@@ -139,6 +140,7 @@ EXPORTED_SYMBOLS = [
     "dropest_real_candidate_rows", "dropest_dev_copy_device", "dropest_umi_distribution",
     "dropest_collisions_adjusted_sizes",
     "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_stream",
+    "dropest_sort_layout",
     "dropest_synth_generate_host", "dropest_synth_generate_device", "dropest_dev_alloc", "dropest_dev_free",
     "dropest_dev_copy_to_host", "dropest_dev_copy_from_host", "dropest_dev_count", "dropest_dev_sync",
 ]
@@ -371,6 +373,11 @@ class Context:
         t = C.c_int64()
         self._chk(self.L.dropest_merge_target(self.h, cell, C.byref(t)))
         return t.value
+
+    def sort_layout(self):
+        out = (C.c_uint32 * 6)()
+        self._chk(self.L.dropest_sort_layout(self.h, out))
+        return dict(zip(("cell_bits", "gene_bits", "umi_bits", "mark_bits_in_key", "value_bytes", "passes"), map(int, out)))
 
     def set_profiling(self, on=True):
         self._chk(self.L.dropest_set_profiling(self.h, int(on)))

@@ -104,8 +104,11 @@ struct dropest_ctx {
 	dropest::IngestStats ingest{};
 	dropest::GlobalCounters counters{};
 
-	dropest::DevBuf<u64> keys_a, keys_b;     // sort ping-pong (released after the reduces)
-	dropest::DevBuf<u32> vals_a, vals_b;
+	dropest::DevBuf<u64> keys_a, keys_b;     // sort ping-pong
+	dropest::DevBuf<u32> vals_a, vals_b;     // values: u32, or bytes in the same storage (layout.val_bytes)
+	bool chr_from_gene = false;              // chromosome is a function of the gene: sort layouts VB 0 / 1
+	dropest::DevBuf<u32> gene_chr;           // [GENE_CHR_CAP] gene id -> chromosome id (GENE_CHR_UNSET if never counted)
+	dropest::DevBuf<u32> mol_exon, mol_intron, mol_exon2, mol_intron2, cg_exon, cg_intron;
 
 	u32 n_mol = 0;
 	dropest::DevBuf<u64> mol_key;
@@ -202,7 +205,8 @@ struct dropest_ctx {
 	void assign_cell_ids();
 	void plan_key_layout();
 	void build_keys();
-	void radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask);
+	u32 main_sort_passes = 0;
+	void radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes = 4);
 	void reduce_all();
 	void reduce_molecules_to_cell_gene();
 	void reduce_cell_gene_to_cells();

@@ -153,6 +153,8 @@ void dropest_ctx::free_results() {
 // ------------------------------------------------------------------------------------------------
 // stage: barcode table + cell ids
 // ------------------------------------------------------------------------------------------------
+static constexpr u32 GENE_CHR_CAP = 1u << 20;   // genes beyond this id fall back to the general sort layout
+
 void dropest_ctx::build_cb_table() {
 	const u32 n = u32(n_reads);
 	uint64_t cap = cfg.cb_table_capacity;
@@ -168,10 +170,12 @@ void dropest_ctx::build_cb_table() {
 		IngestStats init{};
 		init.umi_clean_min = ~0ull;
 		HIP_CHECK(hipMemcpyAsync(d_ingest.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
+		gene_chr.ensure(GENE_CHR_CAP);
+		HIP_CHECK(hipMemsetAsync(gene_chr.p, 0xFF, size_t(GENE_CHR_CAP) * 4, stream));
 		const u32 blocks = std::min<u32>(div_up(n, 256), 256u * 16u);
-		timed("cb_insert", double(n) * (8 + 8 + 4 + 4), [&] {
-			hipLaunchKernelGGL(cb_insert_kernel<256>, dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, n, table,
-			                   slot.p, d_ingest.p);
+		timed("cb_insert", double(n) * (8 + 8 + 4 + 4 + 4), [&] {
+			hipLaunchKernelGGL(cb_insert_kernel<256>, dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table,
+			                   slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
 		});
 		fetch(&ingest, d_ingest.p, sizeof(ingest));
 		if (!ingest.overflow) break;
@@ -241,6 +245,17 @@ void dropest_ctx::plan_key_layout() {
 		                       " bits (cell " + std::to_string(L.cell_bits) + " + gene " + std::to_string(L.gene_bits) +
 		                       " + UMI " + std::to_string(L.umi_bits) + "); this build sorts 64-bit keys");
 	if (L.gene_bits + L.umi_bits >= 64) throw UnsupportedError("gene + UMI field too wide");
+	// sort-record layout (k_misc.h): derive the chromosome from the gene when that is a function and the chromosome
+	// of a gene-less read fits the UMI field; then the mark rides in the key if 3 bits are free, else as one byte
+	chr_from_gene = !ingest.gene_chr_conflict && (L.umi_bits >= 16 || (u64(ingest.chr_max_plus1) <= (1ull << L.umi_bits)));
+	if (getenv("DROPEST_FORCE_GENERAL_LAYOUT")) chr_from_gene = false;   // tests exercise the general path on any data
+	if (chr_from_gene) {
+		const bool fits = L.umi_bits + L.gene_bits + L.cell_bits + 3 <= 64 && !getenv("DROPEST_FORCE_BYTE_VALUES");
+		L.mark_shift = fits ? 3 : 0;
+		L.val_bytes = fits ? 0 : 1;
+	} else {
+		L.mark_shift = 0; L.val_bytes = 4;
+	}
 	layout = L;
 }
 
@@ -258,9 +273,14 @@ void dropest_ctx::build_keys() {
 	init.key_and = ~0ull;
 	HIP_CHECK(hipMemcpyAsync(d_counters.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
 	const u32 blocks = std::min<u32>(div_up(n, 256), 256u * 16u);
-	timed("build_keys", double(n) * (8 + 4 + 4 + 4 + 4 + 8 + 4), [&] {
-		hipLaunchKernelGGL(build_keys_kernel<256>, dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n,
-		                   table, layout, keys_a.p, vals_a.p, d_counters.p);
+	timed("build_keys", double(n) * (8 + 4 + 4 + 4 + 4 + 8 + layout.val_bytes), [&] {
+		void *v = vals_a.p;
+		if (layout.val_bytes == 0)
+			hipLaunchKernelGGL((build_keys_kernel<256, 0>), dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p);
+		else if (layout.val_bytes == 1)
+			hipLaunchKernelGGL((build_keys_kernel<256, 1>), dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p);
+		else
+			hipLaunchKernelGGL((build_keys_kernel<256, 4>), dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p);
 	});
 	fetch(&counters, d_counters.p, sizeof(counters));
 }
@@ -268,51 +288,38 @@ void dropest_ctx::build_keys() {
 // ------------------------------------------------------------------------------------------------
 // stage: radix sort
 // ------------------------------------------------------------------------------------------------
-// Variant of the scatter kernel (threads x items per tile, register prefetch); DROPEST_RS_VARIANT overrides the
-// default for A/B measurements.
-struct RsVariant { int tile; void (*launch)(dim3, hipStream_t, const u64 *, const u32 *, u64 *, u32 *, u32, int, u32, const u32 *, const u32 *); };
-template <int T, int I, bool P>
-static void rs_launch(dim3 grid, hipStream_t st, const u64 *k, const u32 *v, u64 *ok, u32 *ov, u32 n, int shift, u32 tpb, const u32 *hist, const u32 *base) {
-	hipLaunchKernelGGL((rs_scatter_kernel_t<T, I, P>), grid, dim3(T), 0, st, k, v, ok, ov, n, shift, tpb, hist, base);
-}
-static RsVariant rs_variant() {
-	static const RsVariant table[] = {
-		{512 * 8, rs_launch<512, 8, false>},    // 0: round-1 baseline
-		{512 * 8, rs_launch<512, 8, true>},     // 1
-		{256 * 16, rs_launch<256, 16, false>},  // 2
-		{256 * 16, rs_launch<256, 16, true>},   // 3
-		{1024 * 4, rs_launch<1024, 4, true>},   // 4
-		{256 * 8, rs_launch<256, 8, true>},     // 5
-		{512 * 4, rs_launch<512, 4, true>},     // 6
-		{1024 * 8, rs_launch<1024, 8, true>},   // 7: 8192-record tile (96 KB of LDS, one block per CU)
-		{1024 * 8, rs_launch<1024, 8, false>},  // 8
-		{512 * 16, rs_launch<512, 16, true>},   // 9
-	};
-	int v = 9;   // 512 threads x 16 records: 8192-record tiles give the longest digit runs that fit two blocks per CU
-	if (const char *e = getenv("DROPEST_RS_VARIANT")) v = atoi(e);
-	if (v < 0 || v >= int(sizeof(table) / sizeof(table[0]))) v = 9;
-	return table[v];
+// 512 threads x 16 records per tile with register prefetch (measured best of seven shapes);
+// one instantiation per value width.
+static constexpr int RS_T = 512, RS_I = 16, RS_TILE_REC = RS_T * RS_I;
+static void rs_launch(int val_bytes, dim3 grid, hipStream_t st, const u64 *k, const void *v, u64 *ok, void *ov, u32 n, int shift, u32 tpb,
+                      const u32 *hist, const u32 *base) {
+	if (val_bytes == 0) hipLaunchKernelGGL((rs_scatter_kernel_t<RS_T, RS_I, true, 0>), grid, dim3(RS_T), 0, st, k, v, ok, ov, n, shift, tpb, hist, base);
+	else if (val_bytes == 1) hipLaunchKernelGGL((rs_scatter_kernel_t<RS_T, RS_I, true, 1>), grid, dim3(RS_T), 0, st, k, v, ok, ov, n, shift, tpb, hist, base);
+	else hipLaunchKernelGGL((rs_scatter_kernel_t<RS_T, RS_I, true, 4>), grid, dim3(RS_T), 0, st, k, v, ok, ov, n, shift, tpb, hist, base);
 }
 
-void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask) {
+void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes) {
 	if (n == 0) return;
-	const RsVariant var = rs_variant();
-	const u32 n_tiles = div_up(n, var.tile);
+	const u32 n_tiles = div_up(n, RS_TILE_REC);
 	u32 nblocks = std::min<u32>(n_tiles, 1024);   // measured flat between 256 and 2048 blocks
 	const u32 tpb = div_up(n_tiles, nblocks);
 	nblocks = div_up(n_tiles, tpb);
 	rs_hist.ensure(size_t(RS_RADIX) * nblocks); rs_row_total.ensure(RS_RADIX); rs_digit_base.ensure(RS_RADIX);
-	for (int shift = 0; shift < 64; shift += 8) {
+	const char *scatter_name = val_bytes == 4 ? "rs_scatter" : (val_bytes == 1 ? "rs_scatter:key+1B" : "rs_scatter:keys");
+	// Digit windows start at the lowest bit that differs between two keys (the caller masks out bits that need no
+	// ordering, e.g. a mark folded under the key), so ceil(varying width / 8) passes suffice.
+	if (varying_mask == 0) return;
+	for (int shift = __builtin_ctzll(varying_mask); shift < 64; shift += 8) {
 		if (((varying_mask >> shift) & 0xFFull) == 0) continue;   // digit constant over all keys: pass is the identity
 		timed("rs_hist", double(n) * 8, [&] {
-			hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, keys, n, shift, tpb, u32(var.tile), rs_hist.p);
+			hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, keys, n, shift, tpb, u32(RS_TILE_REC), rs_hist.p);
 		});
 		timed("rs_scan", double(RS_RADIX) * nblocks * 8, [&] {
 			hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, stream, rs_hist.p, nblocks, rs_row_total.p);
 			hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(256), 0, stream, rs_row_total.p, rs_digit_base.p);
 		});
-		timed("rs_scatter", double(n) * 24, [&] {
-			var.launch(dim3(nblocks), stream, keys, vals, keys_alt, vals_alt, n, shift, tpb, rs_hist.p, rs_digit_base.p);
+		timed(scatter_name, double(n) * 2 * (8 + val_bytes), [&] {
+			rs_launch(val_bytes, dim3(nblocks), stream, keys, vals, keys_alt, vals_alt, n, shift, tpb, rs_hist.p, rs_digit_base.p);
 		});
 		std::swap(keys, keys_alt);
 		std::swap(vals, vals_alt);
@@ -352,29 +359,48 @@ void dropest_ctx::reduce_all() {
 	const u32 n = u32(n_reads);
 	u64 *keys = keys_a.p, *keys_alt = keys_b.p;
 	u32 *vals = vals_a.p, *vals_alt = vals_b.p;
-	radix_sort(keys, vals, keys_alt, vals_alt, n, counters.key_or ^ counters.key_and);
+	// a mark folded under the key needs no ordering: its bits are masked out of the sort
+	const u64 order_mask = ~((1ull << layout.mark_shift) - 1ull);
+	const u64 varying = (counters.key_or ^ counters.key_and) & order_mask;
+	main_sort_passes = 0;
+	if (varying) for (int shift = __builtin_ctzll(varying); shift < 64; shift += 8) main_sort_passes += ((varying >> shift) & 0xFFull) != 0;
+	radix_sort(keys, vals, keys_alt, vals_alt, n, varying, layout.val_bytes);
 
-	// reads -> molecules
-	{
-		ReadsToMolecules p{};
-		p.keys = keys; p.vals = vals;
-		n_mol = run_segmented_reduce(*this, "molecules", p, n, 12 + 4, [&](u32 total) {
-			mol_key.ensure(total + 1); mol_reads.ensure(total + 1); mol_mark.ensure(total + 1);
-			zero_async(*this, mol_reads.p, size_t(total + 1) * 4); zero_async(*this, mol_mark.p, size_t(total + 1) * 4);
-			p.mol_key = mol_key.p; p.out[0] = mol_reads.p; p.out[1] = mol_mark.p;
-		});
-	}
-	// reads -> (cell, chr) partial rows
-	{
-		ReadsToChrRows p{};
-		p.keys = keys; p.vals = vals;
-		p.cell_shift = layout.gene_bits + layout.umi_bits; p.umi_bits = layout.umi_bits; p.gene_mask = layout.gene_none;
-		n_chr_rows = run_segmented_reduce(*this, "chr_rows", p, n, 12 + 2, [&](u32 total) {
-			chr_row_key.ensure(total + 1); chr_exon.ensure(total + 1); chr_intron.ensure(total + 1); chr_inter.ensure(total + 1);
-			zero_async(*this, chr_exon.p, size_t(total + 1) * 4); zero_async(*this, chr_intron.p, size_t(total + 1) * 4);
-			zero_async(*this, chr_inter.p, size_t(total + 1) * 4);
-			p.row_key = chr_row_key.p; p.out[0] = chr_exon.p; p.out[1] = chr_intron.p; p.out[2] = chr_inter.p;
-		});
+	if (chr_from_gene) {
+		// reads -> molecules with exon / intron read counts; no second pass over the reads for the chromosomes
+		auto run = [&](auto &p) {
+			p.keys = keys;
+			n_mol = run_segmented_reduce(*this, "molecules", p, n, 8 + layout.val_bytes + 6, [&](u32 total) {
+				mol_key.ensure(total + 1);
+				for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) { b->ensure(total + 1); zero_async(*this, b->p, size_t(total + 1) * 4); }
+				p.mol_key = mol_key.p; p.out[0] = mol_reads.p; p.out[1] = mol_mark.p; p.out[2] = mol_exon.p; p.out[3] = mol_intron.p;
+			});
+		};
+		if (layout.val_bytes == 0) { ReadsToMoleculesX<0> p{}; run(p); }
+		else { ReadsToMoleculesX<1> p{}; p.marks = reinterpret_cast<const uint8_t *>(vals); run(p); }
+		n_chr_rows = 0;
+	} else {
+		// general layout: a gene may sit on several chromosomes, the chromosome travels with every read
+		{
+			ReadsToMolecules p{};
+			p.keys = keys; p.vals = vals;
+			n_mol = run_segmented_reduce(*this, "molecules", p, n, 12 + 4, [&](u32 total) {
+				mol_key.ensure(total + 1); mol_reads.ensure(total + 1); mol_mark.ensure(total + 1);
+				zero_async(*this, mol_reads.p, size_t(total + 1) * 4); zero_async(*this, mol_mark.p, size_t(total + 1) * 4);
+				p.mol_key = mol_key.p; p.out[0] = mol_reads.p; p.out[1] = mol_mark.p;
+			});
+		}
+		{
+			ReadsToChrRows p{};
+			p.keys = keys; p.vals = vals;
+			p.cell_shift = layout.gene_bits + layout.umi_bits; p.umi_bits = layout.umi_bits; p.gene_mask = layout.gene_none;
+			n_chr_rows = run_segmented_reduce(*this, "chr_rows", p, n, 12 + 2, [&](u32 total) {
+				chr_row_key.ensure(total + 1); chr_exon.ensure(total + 1); chr_intron.ensure(total + 1); chr_inter.ensure(total + 1);
+				zero_async(*this, chr_exon.p, size_t(total + 1) * 4); zero_async(*this, chr_intron.p, size_t(total + 1) * 4);
+				zero_async(*this, chr_inter.p, size_t(total + 1) * 4);
+				p.row_key = chr_row_key.p; p.out[0] = chr_exon.p; p.out[1] = chr_intron.p; p.out[2] = chr_inter.p;
+			});
+		}
 	}
 	reduce_molecules_to_cell_gene();
 	reduce_cell_gene_to_cells();
@@ -383,17 +409,31 @@ void dropest_ctx::reduce_all() {
 }
 
 void dropest_ctx::reduce_molecules_to_cell_gene() {
-	MoleculesToCellGene p{};
-	p.mol_key = mol_key.p; p.mol_reads = mol_reads.p; p.mol_mark = mol_mark.p;
-	p.umi_bits = layout.umi_bits; p.query_mask = query_mask;
-	n_cg = run_segmented_reduce(*this, "cell_gene", p, n_mol, 16 + 8, [&](u32 total) {
-		cg_key.ensure(total + 1); cg_mol_begin.ensure(total + 1); cg_n_all.ensure(total + 1); cg_n_req.ensure(total + 1);
-		cg_reads_all.ensure(total + 1); cg_reads_req.ensure(total + 1);
-		zero_async(*this, cg_n_all.p, size_t(total + 1) * 4); zero_async(*this, cg_n_req.p, size_t(total + 1) * 4);
-		zero_async(*this, cg_reads_all.p, size_t(total + 1) * 4); zero_async(*this, cg_reads_req.p, size_t(total + 1) * 4);
-		p.cg_key = cg_key.p; p.cg_mol_begin = cg_mol_begin.p;
-		p.out[0] = cg_n_all.p; p.out[1] = cg_n_req.p; p.out[2] = cg_reads_all.p; p.out[3] = cg_reads_req.p;
-	});
+	auto prepare_common = [&](u32 total) {
+		cg_key.ensure(total + 1); cg_mol_begin.ensure(total + 1);
+		for (DevBuf<u32> *b : {&cg_n_all, &cg_n_req, &cg_reads_all, &cg_reads_req}) { b->ensure(total + 1); zero_async(*this, b->p, size_t(total + 1) * 4); }
+	};
+	if (chr_from_gene) {
+		MoleculesToCellGeneX p{};
+		p.mol_key = mol_key.p; p.mol_reads = mol_reads.p; p.mol_mark = mol_mark.p; p.mol_exon = mol_exon.p; p.mol_intron = mol_intron.p;
+		p.umi_bits = layout.umi_bits; p.query_mask = query_mask;
+		n_cg = run_segmented_reduce(*this, "cell_gene", p, n_mol, 24 + 8, [&](u32 total) {
+			prepare_common(total);
+			for (DevBuf<u32> *b : {&cg_exon, &cg_intron}) { b->ensure(total + 1); zero_async(*this, b->p, size_t(total + 1) * 4); }
+			p.cg_key = cg_key.p; p.cg_mol_begin = cg_mol_begin.p;
+			p.out[0] = cg_n_all.p; p.out[1] = cg_n_req.p; p.out[2] = cg_reads_all.p; p.out[3] = cg_reads_req.p;
+			p.out[4] = cg_exon.p; p.out[5] = cg_intron.p;
+		});
+	} else {
+		MoleculesToCellGene p{};
+		p.mol_key = mol_key.p; p.mol_reads = mol_reads.p; p.mol_mark = mol_mark.p;
+		p.umi_bits = layout.umi_bits; p.query_mask = query_mask;
+		n_cg = run_segmented_reduce(*this, "cell_gene", p, n_mol, 16 + 8, [&](u32 total) {
+			prepare_common(total);
+			p.cg_key = cg_key.p; p.cg_mol_begin = cg_mol_begin.p;
+			p.out[0] = cg_n_all.p; p.out[1] = cg_n_req.p; p.out[2] = cg_reads_all.p; p.out[3] = cg_reads_req.p;
+		});
+	}
 	// sentinel so that row i owns molecules [cg_mol_begin[i], cg_mol_begin[i+1])
 	HIP_CHECK(hipMemcpyAsync(cg_mol_begin.p + n_cg, &n_mol, 4, hipMemcpyHostToDevice, stream));
 }
@@ -841,6 +881,15 @@ dropest_status dropest_merge_targets(dropest_ctx *ctx, uint64_t *n, uint64_t *sr
 	});
 }
 
+dropest_status dropest_sort_layout(dropest_ctx *ctx, uint32_t out[6]) {
+	return guarded([&] {
+		need_init(ctx);
+		const KeyLayout &L = ctx->layout;
+		out[0] = L.cell_bits; out[1] = L.gene_bits; out[2] = L.umi_bits; out[3] = L.mark_shift; out[4] = L.val_bytes;
+		out[5] = ctx->main_sort_passes;
+	});
+}
+
 dropest_status dropest_global_counters(dropest_ctx *ctx, uint64_t out[4]) {
 	return guarded([&] {
 		need_init(ctx);
@@ -938,21 +987,35 @@ dropest_status dropest_chr_stats(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, 
 		for (const HostCell &h : ctx->real)
 			if (!h.merged && !h.excluded && h.row.n_genes >= ctx->min_before) { map[h.id] = u32(real_ids.size()); real_ids.push_back(h.id); }
 		for (auto &p : ctx->merge_pairs) map[p.first] = map[p.second];
-		if (real_ids.empty() || ctx->n_chr_rows == 0) return;
-		// number of chromosomes = 1 + max chr id seen in the partial rows
-		std::vector<u64> keys(ctx->n_chr_rows);
-		HIP_CHECK(hipMemcpy(keys.data(), ctx->chr_row_key.p, size_t(ctx->n_chr_rows) * 8, hipMemcpyDeviceToHost));
+		if (real_ids.empty()) return;
+		if (!ctx->chr_from_gene && ctx->n_chr_rows == 0) return;
 		u32 n_chr = 0;
-		for (u64 k : keys) n_chr = std::max(n_chr, u32(k & 0xFFFF) + 1);
+		if (ctx->chr_from_gene) {
+			n_chr = ctx->ingest.chr_max_plus1;
+		} else {   // number of chromosomes = 1 + max chr id seen in the partial rows
+			std::vector<u64> keys(ctx->n_chr_rows);
+			HIP_CHECK(hipMemcpy(keys.data(), ctx->chr_row_key.p, size_t(ctx->n_chr_rows) * 8, hipMemcpyDeviceToHost));
+			for (u64 k : keys) n_chr = std::max(n_chr, u32(k & 0xFFFF) + 1);
+		}
+		if (n_chr == 0) return;
 		const size_t cells_n = real_ids.size(), tab = cells_n * 3 * n_chr;
 		if (tab > (size_t(1) << 30)) throw UnsupportedError("per-chromosome table too large for the dense path");
 		DevBuf<u32> d_map, d_tab;
 		d_map.alloc(ctx->n_cells); d_tab.alloc(tab);
 		HIP_CHECK(hipMemcpyAsync(d_map.p, map.data(), size_t(ctx->n_cells) * 4, hipMemcpyHostToDevice, ctx->stream));
 		HIP_CHECK(hipMemsetAsync(d_tab.p, 0, tab * 4, ctx->stream));
-		hipLaunchKernelGGL(chr_accumulate_kernel, dim3(div_up(ctx->n_chr_rows, 256)), dim3(256), 0, ctx->stream,
-		                   ctx->chr_row_key.p, ctx->chr_exon.p, ctx->chr_intron.p, ctx->chr_inter.p, ctx->n_chr_rows, d_map.p,
-		                   n_chr, d_tab.p);
+		if (ctx->chr_from_gene) {
+			ChrFromGeneArgs a{};
+			a.cg_key = ctx->cg_key.p; a.cg_exon = ctx->cg_exon.p; a.cg_intron = ctx->cg_intron.p; a.cg_mol_begin = ctx->cg_mol_begin.p;
+			a.n_cg = ctx->n_cg; a.mol_key = ctx->mol_key.p; a.mol_reads = ctx->mol_reads.p;
+			a.gene_bits = ctx->layout.gene_bits; a.umi_bits = ctx->layout.umi_bits; a.gene_none = ctx->layout.gene_none;
+			a.gene_chr = ctx->gene_chr.p; a.real_index = d_map.p; a.n_chr = n_chr; a.table = d_tab.p;
+			hipLaunchKernelGGL(chr_from_gene_kernel, dim3(div_up(ctx->n_cg, 256)), dim3(256), 0, ctx->stream, a);
+		} else {
+			hipLaunchKernelGGL(chr_accumulate_kernel, dim3(div_up(ctx->n_chr_rows, 256)), dim3(256), 0, ctx->stream,
+			                   ctx->chr_row_key.p, ctx->chr_exon.p, ctx->chr_intron.p, ctx->chr_inter.p, ctx->n_chr_rows, d_map.p,
+			                   n_chr, d_tab.p);
+		}
 		HIP_CHECK(hipGetLastError());
 		std::vector<u32> t(tab);
 		HIP_CHECK(hipMemcpyAsync(t.data(), d_tab.p, tab * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1085,8 +1148,7 @@ dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, cons
 		// one stable radix pass on the owner digit over (owner, position) records, then a gather of the four arrays
 		DevBuf<u64> k0, k1; DevBuf<u32> v0, v1, hist, row_total, digit_base;
 		k0.alloc(n); k1.alloc(n); v0.alloc(n); v1.alloc(n);
-		const RsVariant var = rs_variant();
-		const u32 n_tiles = div_up(n, var.tile);
+		const u32 n_tiles = div_up(n, RS_TILE_REC);
 		u32 nblocks = std::min<u32>(n_tiles, 1024);
 		const u32 tpb = div_up(n_tiles, nblocks);
 		nblocks = div_up(n_tiles, tpb);
@@ -1094,10 +1156,10 @@ dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, cons
 		hipStream_t st = nullptr;
 		hipLaunchKernelGGL(owner_keys_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st,
 		                   reinterpret_cast<const u64 *>(d_cb), n, n_parts, k0.p, v0.p);
-		hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, st, k0.p, n, 0, tpb, u32(var.tile), hist.p);
+		hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, st, k0.p, n, 0, tpb, u32(RS_TILE_REC), hist.p);
 		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, st, hist.p, nblocks, row_total.p);
 		hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(256), 0, st, row_total.p, digit_base.p);
-		var.launch(dim3(nblocks), st, k0.p, v0.p, k1.p, v1.p, n, 0, tpb, hist.p, digit_base.p);
+		rs_launch(4, dim3(nblocks), st, k0.p, v0.p, k1.p, v1.p, n, 0, tpb, hist.p, digit_base.p);
 		hipLaunchKernelGGL(gather_reads_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st, v1.p, n,
 		                   reinterpret_cast<const u64 *>(d_cb), reinterpret_cast<const u64 *>(d_umi), d_gene, d_aux,
 		                   reinterpret_cast<u64 *>(d_out_cb), reinterpret_cast<u64 *>(d_out_umi), d_out_gene, d_out_aux, d_out_idx);

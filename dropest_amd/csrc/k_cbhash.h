@@ -36,7 +36,11 @@ struct IngestStats {
 	unsigned long long cb_escape_count;                // number of reads with an escaped barcode
 	unsigned int gene_max_plus1;                       // 1 + max gene id, 0 if no read has a gene
 	unsigned int overflow;                             // probe chain exceeded the limit -> grow & retry
+	unsigned int chr_max_plus1;                        // 1 + max chromosome id over the reads that count per chromosome
+	unsigned int gene_chr_conflict;                    // some gene was seen on two chromosomes (or its id exceeds the table)
 };
+
+constexpr uint32_t GENE_CHR_UNSET = 0xFFFFFFFFu;
 
 constexpr uint32_t CB_MAX_PROBE = 8192;
 constexpr uint64_t ESCAPE_BIT = 0x8000000000000000ull;
@@ -74,18 +78,20 @@ __device__ inline uint32_t cb_find(const CbTable &t, unsigned long long k) {   /
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long long *__restrict__ cb,
                                                             const unsigned long long *__restrict__ umi,
-                                                            const uint32_t *__restrict__ gene, uint32_t n, CbTable t,
-                                                            uint32_t *__restrict__ slot_out, IngestStats *stats) {
+                                                            const uint32_t *__restrict__ gene,
+                                                            const uint32_t *__restrict__ aux, uint32_t n, CbTable t,
+                                                            uint32_t *__restrict__ slot_out, uint32_t *__restrict__ gene_chr,
+                                                            uint32_t gene_chr_cap, IngestStats *stats) {
 	constexpr int ILP = 4;
 	unsigned long long umin = ~0ull, umax = 0ull, uesc = 0ull, cbesc = 0ull;
-	uint32_t gmax = 0;
-	bool ok = true;
+	uint32_t gmax = 0, cmax = 0;
+	bool ok = true, chr_conflict = false;
 	const uint64_t stride = uint64_t(gridDim.x) * THREADS;
 	for (uint64_t r0 = uint64_t(blockIdx.x) * THREADS + threadIdx.x; r0 < n; r0 += stride * ILP) {
 		unsigned long long k[ILP], u[ILP];
 		uint64_t h[ILP];
 		uint4 v[ILP];
-		uint32_t g[ILP];
+		uint32_t g[ILP], a[ILP];
 #pragma unroll
 		for (int j = 0; j < ILP; ++j) {
 			const uint64_t r = r0 + uint64_t(j) * stride;
@@ -101,6 +107,7 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 			const uint64_t r = r0 + uint64_t(j) * stride;
 			u[j] = r < n ? umi[r] : 0ull;
 			g[j] = r < n ? gene[r] : NO_GENE;
+			a[j] = r < n ? aux[r] : 0u;
 		}
 #pragma unroll
 		for (int j = 0; j < ILP; ++j) {
@@ -118,11 +125,26 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 			else { umin = u[j] < umin ? u[j] : umin; umax = u[j] > umax ? u[j] : umax; }
 			if (k[j] & ESCAPE_BIT) ++cbesc;
 			if (g[j] != NO_GENE && g[j] + 1 > gmax) gmax = g[j] + 1;
+			// Is the chromosome a function of the gene?  (Only reads that are counted per chromosome matter:
+			// gene-less reads and reads with an exon / intron mark, CellsDataContainer.cpp:73-78, :312-321.)
+			const uint32_t chr = a[j] & 0xFFFFu, mark = (a[j] >> 16) & 0xFFu;
+			if (g[j] == NO_GENE) { if (chr + 1 > cmax) cmax = chr + 1; }
+			else if (mark & 6u) {
+				if (chr + 1 > cmax) cmax = chr + 1;
+				if (g[j] >= gene_chr_cap) chr_conflict = true;
+				else {
+					uint32_t cur = gene_chr[g[j]];            // L1/L2-hot table; the CAS runs once per gene
+					if (cur == GENE_CHR_UNSET) cur = atomicCAS(&gene_chr[g[j]], GENE_CHR_UNSET, chr), cur = cur == GENE_CHR_UNSET ? chr : cur;
+					if (cur != chr) chr_conflict = true;
+				}
+			}
 		}
 	}
 	umin = wave_reduce_min_u64(umin); umax = wave_reduce_max_u64(umax); uesc = wave_reduce_max_u64(uesc);
 	cbesc = wave_reduce_add_u64(cbesc);
 	unsigned long long g64 = wave_reduce_max_u64(gmax);
+	unsigned long long c64 = wave_reduce_max_u64(cmax);
+	unsigned long long conf = wave_reduce_max_u64(chr_conflict ? 1ull : 0ull);
 	unsigned long long bad = wave_reduce_max_u64(ok ? 0ull : 1ull);
 	if (lane_id() == 0) {
 		if (umin != ~0ull) atomicMin(&stats->umi_clean_min, umin);
@@ -131,6 +153,8 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 		if (cbesc) atomicAdd(&stats->cb_escape_count, cbesc);
 		if (g64) atomicMax(&stats->gene_max_plus1, uint32_t(g64));
 		if (bad) atomicMax(&stats->overflow, 1u);
+		if (c64) atomicMax(&stats->chr_max_plus1, uint32_t(c64));
+		if (conf) atomicMax(&stats->gene_chr_conflict, 1u);
 	}
 }
 

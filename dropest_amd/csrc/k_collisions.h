@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void emit_filtered_umis_kernel(const unsigned 
 // sorted UMI codes -> (code, count) runs
 struct UmiRuns {
 	static constexpr int ITEMS = 8;
+	static constexpr bool PACKED = false;
 	static constexpr bool DIRECT = false;
 	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 1;

@@ -23,11 +23,20 @@ __global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t *__rest
 }
 
 // ---- sort-key construction -------------------------------------------------------------------------
-// key = cell_id << (gene_bits + umi_bits) | gene_code << umi_bits | umi_code, value = chr | mark << 16.
-// gene_code of a read without a gene = all ones in gene_bits (sorts last inside its cell); such reads
-// carry umi_code 0 (they never enter a Gene, CellsDataContainer.cpp:73-78).
+// molecule key = cell_id << (gene_bits + umi_bits) | gene_code << umi_bits | umi_code.
+// gene_code of a read without a gene = all ones in gene_bits (sorts last inside its cell).
+//
+// Three sort-record layouts, chosen from the data (dropest_ctx::plan_key_layout):
+//   VB = 0  key = molecule key << 3 | mark            keys only; needs 3 spare bits; chromosome derived from the gene
+//   VB = 1  key = molecule key, value = mark (1 byte)  chromosome derived from the gene
+//   VB = 4  key = molecule key, value = chr | mark<<16 general case (a gene seen on several chromosomes)
+// With the chromosome derived from the gene (VB 0 / 1), a gene-less read stores its chromosome in the UMI field (it
+// never enters a Gene, CellsDataContainer.cpp:73-78), so the per-(cell, chromosome) intergenic counts fall out of
+// the molecule reduce; with VB = 4 gene-less reads carry umi_code 0.
 struct KeyLayout {
 	int umi_bits, gene_bits, cell_bits;
+	int mark_shift;                      // 3 when the mark lives in the low key bits (VB = 0), else 0
+	int val_bytes;                       // 0, 1 or 4
 	unsigned long long umi_strip_mask;   // applied to clean UMI codes (drops the sentinel when all lengths agree)
 	unsigned long long umi_escape_base;  // escaped UMI k -> umi_escape_base + k
 	unsigned long long gene_none;        // (1 << gene_bits) - 1
@@ -38,32 +47,36 @@ struct GlobalCounters {   // CellsDataContainer.cpp:73-78, :309-327
 	unsigned long long key_or, key_and;
 };
 
-template <int THREADS>
+template <int THREADS, int VB>
 __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long long *__restrict__ umi,
                                                              const uint32_t *__restrict__ gene,
                                                              const uint32_t *__restrict__ aux,
                                                              const uint32_t *__restrict__ slot, uint32_t n, CbTable t,
                                                              KeyLayout L, unsigned long long *__restrict__ keys,
-                                                             uint32_t *__restrict__ vals, GlobalCounters *gc) {
+                                                             void *__restrict__ vals_, GlobalCounters *gc) {
 	unsigned long long c_inter = 0, c_exon = 0, c_intron = 0, c_na = 0, k_or = 0, k_and = ~0ull;
 	const uint32_t stride = gridDim.x * THREADS;
 	for (uint32_t r = blockIdx.x * THREADS + threadIdx.x; r < n; r += stride) {
 		const unsigned long long cell = t.slots[slot[r]].cell_id;
 		const uint32_t g = gene[r];
 		const uint32_t a = aux[r];
-		const uint32_t mark = (a >> 16) & 0xFFu;
+		uint32_t mark = (a >> 16) & 0xFFu;
 		unsigned long long gcode, ucode;
 		if (g == NO_GENE) {
-			gcode = L.gene_none; ucode = 0; ++c_inter;
+			gcode = L.gene_none; ++c_inter;
+			ucode = VB == 4 ? 0ull : (unsigned long long)(a & 0xFFFFu);   // chromosome of the gene-less read
+			if (VB != 4) mark = 0;
 		} else {
 			gcode = g;
 			const unsigned long long u = umi[r];
 			ucode = (u & ESCAPE_BIT) ? (L.umi_escape_base + (u & ~ESCAPE_BIT)) : (u & L.umi_strip_mask);
 			c_exon += (mark >> 1) & 1u; c_intron += (mark >> 2) & 1u; c_na += mark & 1u;
 		}
-		const unsigned long long k = (cell << (L.gene_bits + L.umi_bits)) | (gcode << L.umi_bits) | ucode;
+		unsigned long long k = (cell << (L.gene_bits + L.umi_bits)) | (gcode << L.umi_bits) | ucode;
+		if (VB == 0) k = (k << 3) | (mark & 7u);
 		keys[r] = k;
-		vals[r] = a & 0x00FFFFFFu;
+		if (VB == 1) static_cast<uint8_t *>(vals_)[r] = uint8_t(mark);
+		if (VB == 4) static_cast<uint32_t *>(vals_)[r] = a & 0x00FFFFFFu;
 		k_or |= k; k_and &= k;
 	}
 	c_inter = wave_reduce_add_u64(c_inter); c_exon = wave_reduce_add_u64(c_exon);
@@ -223,6 +236,35 @@ __global__ __launch_bounds__(256) void gather_u64_kernel(const unsigned long lon
                                                          uint32_t n, unsigned long long *__restrict__ keys_out) {
 	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
 	if (i < n) keys_out[i] = table[idx[i]];
+}
+
+// Same table, chromosome derived from the gene: exon / intron read counts come from the (cell, gene) rows, the
+// gene-less reads of a cell from its pseudo-molecules (cell, NONE, chromosome) whose read count is the answer.
+struct ChrFromGeneArgs {
+	const unsigned long long *cg_key; const uint32_t *cg_exon, *cg_intron, *cg_mol_begin; uint32_t n_cg;
+	const unsigned long long *mol_key; const uint32_t *mol_reads;
+	int gene_bits, umi_bits; unsigned long long gene_none;
+	const uint32_t *gene_chr, *real_index; uint32_t n_chr; uint32_t *table;
+};
+__global__ __launch_bounds__(256) void chr_from_gene_kernel(ChrFromGeneArgs a) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= a.n_cg) return;
+	const unsigned long long k = a.cg_key[i];
+	const uint32_t ri = a.real_index[uint32_t(k >> a.gene_bits)];
+	if (ri == 0xFFFFFFFFu) return;
+	uint32_t *base = a.table + size_t(ri) * 3 * a.n_chr;
+	const unsigned long long g = k & a.gene_none;
+	if (g == a.gene_none) {
+		const unsigned long long umask = (1ull << a.umi_bits) - 1ull;
+		for (uint32_t m = a.cg_mol_begin[i]; m < a.cg_mol_begin[i + 1]; ++m)
+			atomicAdd(base + 2 * a.n_chr + uint32_t(a.mol_key[m] & umask), a.mol_reads[m]);
+		return;
+	}
+	const uint32_t e = a.cg_exon[i], n = a.cg_intron[i];
+	if (!(e | n)) return;
+	const uint32_t chr = a.gene_chr[uint32_t(g)];
+	if (e) atomicAdd(base + chr, e);
+	if (n) atomicAdd(base + a.n_chr + chr, n);
 }
 
 __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *p, uint32_t v, size_t n) {

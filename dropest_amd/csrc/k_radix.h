@@ -11,7 +11,8 @@
 //   rs_scatter  each block walks its tiles carrying 256 running output cursors in LDS:
 //               wave-level multisplit by ballot (8 ballots per key, 64-lane waves), ranks combined over
 //               waves through LDS, keys re-ordered by digit in an LDS tile so that the global writes of
-//               one digit are contiguous, then written out; 12 B read + 12 B written per record
+//               one digit are contiguous, then written out; (8 + VB) B read + (8 + VB) B written per record,
+//               VB = bytes of the value that travels with the key (0, 1 or 4)
 // HBM-bound integer work; no MFMA.  The sort is stable (required between LSD passes).
 #pragma once
 
@@ -78,17 +79,26 @@ __global__ __launch_bounds__(256) void rs_scan_totals_kernel(const uint32_t *__r
 	digit_base[threadIdx.x] = block_excl_scan_u32<256>(row_total[threadIdx.x], scratch, total);
 }
 
+template <int VB> struct RsVal;
+template <> struct RsVal<0> { typedef uint8_t T; };    // (unused)
+template <> struct RsVal<1> { typedef uint8_t T; };
+template <> struct RsVal<4> { typedef uint32_t T; };
+
 // THREADS x ITEMS records per tile.  PREFETCH: the next tile's records are loaded into registers before the
 // current tile is ranked, so the HBM latency of tile t+1 hides behind the LDS / ballot work of tile t.
 // Full tiles (all but possibly the last one of the array) run without per-record bounds checks.
-template <int THREADS, int ITEMS, bool PREFETCH>
+// VB: bytes of the value carried with each key (0 = keys only).
+template <int THREADS, int ITEMS, bool PREFETCH, int VB>
 __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned long long *__restrict__ keys,
-                                                               const uint32_t *__restrict__ vals,
+                                                               const void *__restrict__ vals_,
                                                                unsigned long long *__restrict__ okeys,
-                                                               uint32_t *__restrict__ ovals, uint32_t n, int shift,
+                                                               void *__restrict__ ovals_, uint32_t n, int shift,
                                                                uint32_t tiles_per_block,
                                                                const uint32_t *__restrict__ hist,
                                                                const uint32_t *__restrict__ digit_base) {
+	typedef typename RsVal<VB>::T val_t;
+	const val_t *__restrict__ vals = static_cast<const val_t *>(vals_);
+	val_t *__restrict__ ovals = static_cast<val_t *>(ovals_);
 	constexpr uint32_t TILE = THREADS * ITEMS, WAVES = THREADS / 64;
 	static_assert(THREADS >= RS_RADIX, "one thread per digit is needed for the digit scan");
 	__shared__ uint32_t wcnt[WAVES][RS_RADIX];      // per-wave digit counts -> per-wave digit offsets
@@ -98,7 +108,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 	__shared__ uint32_t gdelta[RS_RADIX];           // goff - tstart: global position = gdelta[digit] + position in tile
 	__shared__ uint32_t scratch[THREADS / 64 + 1];
 	__shared__ unsigned long long sk[TILE];
-	__shared__ uint32_t sv[TILE];
+	__shared__ val_t sv[VB ? TILE : 1];
 
 	const uint32_t tid = threadIdx.x, w = wave_id(), lane = lane_id();
 	const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -108,19 +118,20 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 	const uint32_t first_tile = blockIdx.x * tiles_per_block;
 	const uint32_t lane_off = w * (64 * ITEMS) + lane;     // position of item 0 of this lane inside a tile
 	unsigned long long key[ITEMS], nkey[ITEMS];
-	uint32_t val[ITEMS], nval[ITEMS], lrank[ITEMS];
-	auto load_tile = [&](uint32_t tile, unsigned long long (&k)[ITEMS], uint32_t (&v)[ITEMS]) {
+	val_t val[VB ? ITEMS : 1], nval[VB ? ITEMS : 1];
+	uint32_t lrank[ITEMS];
+	auto load_tile = [&](uint32_t tile, unsigned long long (&k)[ITEMS], val_t (&v)[VB ? ITEMS : 1]) {
 		const uint32_t base = tile * TILE + lane_off;      // n < 2^32: 32-bit indices throughout
 		if (tile + 1 < n_tiles || n % TILE == 0) {
 #pragma unroll
-			for (int i = 0; i < ITEMS; ++i) { k[i] = keys[base + i * 64]; v[i] = vals[base + i * 64]; }
+			for (int i = 0; i < ITEMS; ++i) { k[i] = keys[base + i * 64]; if (VB) v[i] = vals[base + i * 64]; }
 		} else {
 #pragma unroll
 			for (int i = 0; i < ITEMS; ++i) {
 				const uint32_t idx = base + i * 64;
 				const bool valid = idx < n;
 				k[i] = valid ? keys[idx] : ~0ull;
-				v[i] = valid ? vals[idx] : 0u;
+				if (VB) v[i] = valid ? vals[idx] : val_t(0);
 			}
 		}
 	};
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 		const uint32_t in_tile = full ? TILE : n - tile * TILE;
 		if (PREFETCH) {
 #pragma unroll
-			for (int i = 0; i < ITEMS; ++i) { key[i] = nkey[i]; val[i] = nval[i]; }
+			for (int i = 0; i < ITEMS; ++i) { key[i] = nkey[i]; if (VB) val[i] = nval[i]; }
 			if (tt + 1 < tiles_per_block && tile + 1 < n_tiles) load_tile(tile + 1, nkey, nval);
 		} else {
 			load_tile(tile, key, val);
@@ -182,26 +193,18 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 				const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
 				const uint32_t p = tstart[d] + wcnt[w][d] + lrank[i];
 				sk[p] = key[i];
-				sv[p] = val[i];
+				if (VB) sv[p] = val[i];
 			}
 		}
 		__syncthreads();
 
 		// coalesced write-out: consecutive threads write consecutive addresses inside a digit run
-		if (full) {
-			for (uint32_t p = tid; p < TILE; p += THREADS) {
-				const unsigned long long k = sk[p];
-				const uint32_t g = gdelta[uint32_t(k >> shift) & 0xFFu] + p;
-				okeys[g] = k;
-				ovals[g] = sv[p];
-			}
-		} else {
-			for (uint32_t p = tid; p < total; p += THREADS) {
-				const unsigned long long k = sk[p];
-				const uint32_t g = gdelta[uint32_t(k >> shift) & 0xFFu] + p;
-				okeys[g] = k;
-				ovals[g] = sv[p];
-			}
+		const uint32_t count = full ? TILE : total;
+		for (uint32_t p = tid; p < count; p += THREADS) {
+			const unsigned long long k = sk[p];
+			const uint32_t g = gdelta[uint32_t(k >> shift) & 0xFFu] + p;
+			okeys[g] = k;
+			if (VB) ovals[g] = sv[p];
 		}
 		__syncthreads();
 		if (tid < RS_RADIX) goff[tid] += tcnt[tid];

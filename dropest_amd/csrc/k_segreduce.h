@@ -52,6 +52,8 @@ __global__ __launch_bounds__(SR_THREADS) void seg_count_kernel(P p, uint32_t n, 
 //   __device__ void load(uint32_t i, uint32_t (&v)[NV]) const;      per-row contribution
 //   __device__ void write_head(uint32_t out, uint32_t i, unsigned long long key) const;
 //   uint32_t *out[NV];                               zero-initialised output channels
+//   static constexpr bool PACKED;                    true: the row's contribution is staged as ONE word (pack / unpack)
+//                                                    instead of NV words (load) -- less LDS for wide reductions
 //   static constexpr bool DIRECT;                    false: output row = rank of the run (needs seg_count + scan);
 //                                                    true: output row = direct_index(segment key), no count pass
 //   __device__ uint32_t direct_index(unsigned long long key) const;   (DIRECT only)
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 	constexpr int PADDED = SR_TILE + SR_TILE / 8 + 2;
 	__shared__ uint32_t scratch[SR_THREADS / 64 + 1];
 	__shared__ unsigned long long skey[PADDED];   // logical index 0 = predecessor of the tile, 1.. = rows
-	__shared__ uint32_t sval[NV][PADDED];         // per-row contributions
+	__shared__ uint32_t sval[P::PACKED ? 1 : NV][PADDED];   // per-row contributions (one packed word, or NV words)
 	__shared__ uint32_t agg[NV][SR_TILE + 1];     // slot 0 = run continuing from the previous tile
 	__shared__ uint32_t slot_row[P::DIRECT ? SR_TILE + 1 : 1];   // DIRECT: output row of each slot
 	for (int j = threadIdx.x; j < NV * (SR_TILE + 1); j += SR_THREADS) (&agg[0][0])[j] = 0;
@@ -75,10 +77,14 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 		const uint32_t r = j * SR_THREADS + threadIdx.x, i = t0 + r;
 		if (i < n) {
 			skey[sr_pad(r + 1)] = p.seg_key(i);
-			uint32_t v[NV];
-			p.load(i, v);
+			if constexpr (P::PACKED) {
+				sval[0][sr_pad(r)] = p.pack(i);
+			} else {
+				uint32_t v[NV];
+				p.load(i, v);
 #pragma unroll
-			for (int c2 = 0; c2 < NV; ++c2) sval[c2][sr_pad(r)] = v[c2];
+				for (int c2 = 0; c2 < NV; ++c2) sval[c2][sr_pad(r)] = v[c2];
+			}
 		}
 	}
 	if (threadIdx.x == 0) {
@@ -139,10 +145,17 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 						p.write_head(tp + slot - 1, i0 + j, key[j]);
 					}
 				}
+				if constexpr (P::PACKED) {
+					uint32_t v[NV];
+					p.unpack(sval[0][sr_pad(r0 + j)], v);
 #pragma unroll
-				for (int c2 = 0; c2 < NV; ++c2) {
-					const uint32_t v = sval[c2][sr_pad(r0 + j)];
-					if (P::OR_MASK & (1u << c2)) acc[c2] |= v; else acc[c2] += v;
+					for (int c2 = 0; c2 < NV; ++c2) { if (P::OR_MASK & (1u << c2)) acc[c2] |= v[c2]; else acc[c2] += v[c2]; }
+				} else {
+#pragma unroll
+					for (int c2 = 0; c2 < NV; ++c2) {
+						const uint32_t v = sval[c2][sr_pad(r0 + j)];
+						if (P::OR_MASK & (1u << c2)) acc[c2] |= v; else acc[c2] += v;
+					}
 				}
 				dirty = true;
 			}
@@ -174,6 +187,7 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 // sorted read records (key = cell|gene|umi, val = chr | mark<<16)  ->  molecules
 struct ReadsToMolecules {
 	static constexpr int ITEMS = 8;
+	static constexpr bool PACKED = false;
 	static constexpr bool DIRECT = false;
 	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 2;
@@ -190,6 +204,7 @@ struct ReadsToMolecules {
 // sorted read records -> (cell, chromosome) partial rows with exon / intron / intergenic read counts
 struct ReadsToChrRows {
 	static constexpr int ITEMS = 8;
+	static constexpr bool PACKED = false;
 	static constexpr bool DIRECT = false;
 	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 3;
@@ -217,6 +232,7 @@ struct ReadsToChrRows {
 // molecules -> (cell, gene) rows
 struct MoleculesToCellGene {
 	static constexpr int ITEMS = 4;
+	static constexpr bool PACKED = false;
 	static constexpr bool DIRECT = false;
 	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 4;   // n_all, n_req, reads_all, reads_req
@@ -241,6 +257,7 @@ struct MoleculesToCellGene {
 // to a merge simply stay zero.
 struct CellGeneToCells {
 	static constexpr int ITEMS = 4;
+	static constexpr bool PACKED = false;
 	static constexpr bool DIRECT = true;
 	static constexpr int NV = 6;   // n_genes, req_genes, req_umis, total_umis, total_reads, n_rows
 	static constexpr unsigned OR_MASK = 0;
@@ -268,6 +285,7 @@ struct CellGeneToCells {
 // re-keyed molecules (sorted by their new key; value = index of the molecule in the old table) -> molecules
 struct RekeyedToMolecules {
 	static constexpr int ITEMS = 8;
+	static constexpr bool PACKED = false;
 	static constexpr bool DIRECT = false;
 	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
 	static constexpr int NV = 2;
@@ -279,6 +297,73 @@ struct RekeyedToMolecules {
 	uint32_t *out[NV];
 	__device__ unsigned long long seg_key(uint32_t i) const { return keys[i]; }
 	__device__ void load(uint32_t i, uint32_t (&v)[NV]) const { const uint32_t j = idx[i]; v[0] = old_reads[j]; v[1] = old_mark[j]; }
+	__device__ void write_head(uint32_t o, uint32_t, unsigned long long k) const { mol_key[o] = k; }
+};
+
+// sorted read records -> molecules, chromosome derived from the gene (sort layouts VB = 0 / 1): besides read count and
+// mark the molecule keeps how many of its reads carry the exon / intron bit (UMI::Mark::HAS_EXONS / HAS_INTRONS), which
+// is what Stats counts per chromosome (CellsDataContainer.cpp:312-321).  Only the mark byte is staged.
+template <int VB>
+struct ReadsToMoleculesX {
+	static constexpr int ITEMS = 8;
+	static constexpr bool PACKED = true;
+	static constexpr bool DIRECT = false;
+	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
+	static constexpr int NV = 4;               // read_count (+), mark (|), exon reads (+), intron reads (+)
+	static constexpr unsigned OR_MASK = 0x2;
+	const unsigned long long *keys;
+	const uint8_t *marks;                      // VB == 1
+	unsigned long long *mol_key;
+	uint32_t *out[NV];
+	__device__ unsigned long long seg_key(uint32_t i) const { return VB == 0 ? keys[i] >> 3 : keys[i]; }
+	__device__ uint32_t pack(uint32_t i) const { return VB == 0 ? uint32_t(keys[i] & 7u) : uint32_t(marks[i]); }
+	__device__ void unpack(uint32_t m, uint32_t (&v)[NV]) const { v[0] = 1; v[1] = m; v[2] = (m >> 1) & 1u; v[3] = (m >> 2) & 1u; }
+	__device__ void load(uint32_t, uint32_t (&)[NV]) const {}
+	__device__ void write_head(uint32_t o, uint32_t, unsigned long long k) const { mol_key[o] = k; }
+};
+
+// molecules -> (cell, gene) rows, with the exon / intron read counts
+struct MoleculesToCellGeneX {
+	static constexpr int ITEMS = 4;
+	static constexpr bool PACKED = false;
+	static constexpr bool DIRECT = false;
+	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
+	static constexpr int NV = 6;   // n_all, n_req, reads_all, reads_req, exon reads, intron reads
+	static constexpr unsigned OR_MASK = 0;
+	const unsigned long long *mol_key;
+	const uint32_t *mol_reads, *mol_mark, *mol_exon, *mol_intron;
+	int umi_bits;
+	uint32_t query_mask;
+	unsigned long long *cg_key;
+	uint32_t *cg_mol_begin;
+	uint32_t *out[NV];
+	__device__ unsigned long long seg_key(uint32_t i) const { return mol_key[i] >> umi_bits; }
+	__device__ void load(uint32_t i, uint32_t (&v)[NV]) const {
+		const uint32_t r = mol_reads[i];
+		const uint32_t req = (query_mask >> (mol_mark[i] & 7u)) & 1u;
+		v[0] = 1; v[1] = req; v[2] = r; v[3] = req ? r : 0u; v[4] = mol_exon[i]; v[5] = mol_intron[i];
+	}
+	__device__ void write_head(uint32_t o, uint32_t i, unsigned long long k) const { cg_key[o] = k; cg_mol_begin[o] = i; }
+};
+
+// re-keyed molecules -> molecules, carrying the exon / intron read counts through a CB merge
+struct RekeyedToMoleculesX {
+	static constexpr int ITEMS = 4;
+	static constexpr bool PACKED = false;
+	static constexpr bool DIRECT = false;
+	__device__ uint32_t direct_index(unsigned long long) const { return 0; }
+	static constexpr int NV = 4;
+	static constexpr unsigned OR_MASK = 0x2;
+	const unsigned long long *keys;
+	const uint32_t *idx;
+	const uint32_t *old_reads, *old_mark, *old_exon, *old_intron;
+	unsigned long long *mol_key;
+	uint32_t *out[NV];
+	__device__ unsigned long long seg_key(uint32_t i) const { return keys[i]; }
+	__device__ void load(uint32_t i, uint32_t (&v)[NV]) const {
+		const uint32_t j = idx[i];
+		v[0] = old_reads[j]; v[1] = old_mark[j]; v[2] = old_exon[j]; v[3] = old_intron[j];
+	}
 	__device__ void write_head(uint32_t o, uint32_t, unsigned long long k) const { mol_key[o] = k; }
 };
 

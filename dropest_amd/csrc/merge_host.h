@@ -338,14 +338,27 @@ void dropest_ctx::reaggregate_after_merge() {
 	u64 *keys = keys_a.p, *keys_alt = keys_b.p;
 	u32 *vals = vals_a.p, *vals_alt = vals_b.p;
 	radix_sort(keys, vals, keys_alt, vals_alt, n_mol, or_and[0] ^ or_and[1]);
-	RekeyedToMolecules p{};
-	p.keys = keys; p.idx = vals; p.old_reads = mol_reads.p; p.old_mark = mol_mark.p;
-	const u32 new_n = run_segmented_reduce(*this, "molecules_rekeyed", p, n_mol, 12 + 8, [&](u32 total) {
-		mol_key2.ensure(total + 1); mol_reads2.ensure(total + 1); mol_mark2.ensure(total + 1);
-		zero_async(*this, mol_reads2.p, size_t(total + 1) * 4); zero_async(*this, mol_mark2.p, size_t(total + 1) * 4);
-		p.mol_key = mol_key2.p; p.out[0] = mol_reads2.p; p.out[1] = mol_mark2.p;
-	});
-	HIP_CHECK(hipStreamSynchronize(stream));
+	u32 new_n = 0;
+	if (chr_from_gene) {
+		RekeyedToMoleculesX p{};
+		p.keys = keys; p.idx = vals; p.old_reads = mol_reads.p; p.old_mark = mol_mark.p; p.old_exon = mol_exon.p; p.old_intron = mol_intron.p;
+		new_n = run_segmented_reduce(*this, "molecules_rekeyed", p, n_mol, 12 + 16, [&](u32 total) {
+			mol_key2.ensure(total + 1);
+			for (DevBuf<u32> *b : {&mol_reads2, &mol_mark2, &mol_exon2, &mol_intron2}) { b->ensure(total + 1); zero_async(*this, b->p, size_t(total + 1) * 4); }
+			p.mol_key = mol_key2.p; p.out[0] = mol_reads2.p; p.out[1] = mol_mark2.p; p.out[2] = mol_exon2.p; p.out[3] = mol_intron2.p;
+		});
+		HIP_CHECK(hipStreamSynchronize(stream));
+		std::swap(mol_exon, mol_exon2); std::swap(mol_intron, mol_intron2);
+	} else {
+		RekeyedToMolecules p{};
+		p.keys = keys; p.idx = vals; p.old_reads = mol_reads.p; p.old_mark = mol_mark.p;
+		new_n = run_segmented_reduce(*this, "molecules_rekeyed", p, n_mol, 12 + 8, [&](u32 total) {
+			mol_key2.ensure(total + 1); mol_reads2.ensure(total + 1); mol_mark2.ensure(total + 1);
+			zero_async(*this, mol_reads2.p, size_t(total + 1) * 4); zero_async(*this, mol_mark2.p, size_t(total + 1) * 4);
+			p.mol_key = mol_key2.p; p.out[0] = mol_reads2.p; p.out[1] = mol_mark2.p;
+		});
+		HIP_CHECK(hipStreamSynchronize(stream));
+	}
 	std::swap(mol_key, mol_key2); std::swap(mol_reads, mol_reads2); std::swap(mol_mark, mol_mark2);
 	n_mol = new_n;
 	reduce_molecules_to_cell_gene();

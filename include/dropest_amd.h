@@ -223,6 +223,9 @@ typedef struct {
 	double   bytes;        /* algorithmic bytes moved by those launches */
 } dropest_kernel_stat;
 dropest_status dropest_kernel_stats(dropest_ctx *ctx, uint32_t *n, dropest_kernel_stat *out);
+/* Sort-record layout chosen for the pushed reads: [0] cell bits [1] gene bits [2] UMI bits
+ * [3] mark bits folded under the key [4] value bytes per record (0, 1 or 4) [5] radix passes of the main sort. */
+dropest_status dropest_sort_layout(dropest_ctx *ctx, uint32_t out[6]);
 dropest_status dropest_set_profiling(dropest_ctx *ctx, int enabled);   /* HIP events per launch; off by default */
 /* The HIP stream all kernels of this context are launched on (hipStream_t). */
 void *dropest_stream(dropest_ctx *ctx);

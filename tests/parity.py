@@ -42,8 +42,10 @@ def oracle_run(oracle_cls, cfg_kw, cb, umi, gene, aux, side=()):
     return o
 
 
-def gpu_run(ctx_kw, cb, umi, gene, aux, side=(), chunks=1):
+def gpu_run(ctx_kw, cb, umi, gene, aux, side=(), chunks=1, profile=False):
     c = capi.Context(**ctx_kw)
+    if profile:
+        c.set_profiling(True)
     if side:
         c.set_side_strings(side)
     n = len(cb)

@@ -360,6 +360,57 @@ def test_device_ordering_of_filtered_cells(monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------------------
+# sort-record layouts: keys only / key + 1-byte mark / key + (chromosome | mark)
+# ---------------------------------------------------------------------------------------------------
+LAYOUTS = {"keys": (None, "rs_scatter:keys"), "byte": ("DROPEST_FORCE_BYTE_VALUES", "rs_scatter:key+1B"),
+           "general": ("DROPEST_FORCE_GENERAL_LAYOUT", "rs_scatter")}
+
+
+@pytest.mark.parametrize("layout", sorted(LAYOUTS))
+@pytest.mark.parametrize("case", ["plain", "n_umis", "cb_merge"])
+def test_sort_layouts_agree_with_oracle(monkeypatch, layout, case):
+    """The three record layouts must give identical results on a stream whose genes each sit on one chromosome
+    (the synthetic generator's); which one ran is read back from the kernel statistics."""
+    env, kernel = LAYOUTS[layout]
+    if env:
+        monkeypatch.setenv(env, "1")
+    okw = dict(min_genes_before=3, min_genes_after=10)
+    gkw = dict(min_genes_before_merge=3, min_genes_after_merge=10)
+    side = ()
+    if case == "cb_merge":
+        s = SynthStream(n_reads=150_000, n_cells=25, n_genes=1200, umi_len=8, permille_neighbour=150,
+                        whitelist="10x_aug_2016_split")
+        path = os.path.join(DATA, "10x_aug_2016_split")
+        okw.update(merge_kind=1, barcodes_kind=1, barcodes_file=path)
+        gkw.update(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST, barcodes_file=path)
+    else:
+        s = SynthStream(n_reads=120_000, n_cells=40, n_genes=1500, umi_len=8, permille_intergenic=120)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    if case != "plain":
+        umi, side = inject_n(umi, gene, 5e-3, 5, 8)
+    o = parity.oracle_run(Oracle, okw, cb, umi, gene, aux, side)
+    c = parity.gpu_run(gkw, cb, umi, gene, aux, side, chunks=2, profile=True)
+    parity.compare(o, c, side)
+    names = set(c.kernel_stats())
+    assert kernel in names and not (names & {k for _, k in LAYOUTS.values()} - {kernel, "rs_scatter"}), names
+    assert ("seg_reduce:chr_rows" in names) == (layout == "general")
+
+
+def test_gene_on_two_chromosomes_falls_back_to_general_layout():
+    """One gene reported on two chromosomes: chromosome counters can no longer be derived from (cell, gene) rows."""
+    s = SynthStream(n_reads=60_000, n_cells=20, n_genes=500, umi_len=8)
+    cb, umi, gene, aux = s.generate_host()
+    hit = np.flatnonzero((gene != capi.NO_GENE) & (((aux >> 16) & 6) != 0))
+    i = int(hit[-1]); old = int(aux[i]) & 0xFFFF
+    aux = aux.copy(); aux[i] = (int(aux[i]) & 0xFFFF0000) | ((old + 1) % 3)          # always != old
+    cb, umi, gene, aux = parity.canonical_stream(cb, umi, gene, aux)
+    o = parity.oracle_run(Oracle, dict(min_genes_before=3, min_genes_after=10), cb, umi, gene, aux)
+    c = parity.gpu_run(dict(min_genes_before_merge=3, min_genes_after_merge=10), cb, umi, gene, aux, profile=True)
+    parity.compare(o, c)
+    assert "seg_reduce:chr_rows" in c.kernel_stats()
+
+
+# ---------------------------------------------------------------------------------------------------
 # UMI distribution + Tools::CollisionsAdjuster
 # ---------------------------------------------------------------------------------------------------
 from oracle import binding as ob
