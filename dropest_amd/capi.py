@@ -52,6 +52,12 @@ class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char_p), ("launches", C.c_uint32), ("ms", C.c_double), ("bytes", C.c_double)]
 
 
+class IngestSummary(C.Structure):
+    _fields_ = [("umi_clean_min", C.c_uint64), ("umi_clean_max", C.c_uint64), ("umi_escape_max_plus1", C.c_uint64),
+                ("gene_max_plus1", C.c_uint32), ("chr_max_plus1", C.c_uint32), ("gene_chr_conflict", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [
         ("seed", C.c_uint64), ("stream_id", C.c_uint32), ("n_cells", C.c_uint32), ("cell_cb", C.c_void_p),
@@ -113,6 +119,17 @@ def lib():
         "dropest_set_profiling": (C.c_int, [vp, C.c_int]),
         "dropest_sort_layout": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "dropest_stream": (vp, [vp]),
+        "dropest_ingest": (C.c_int, [vp]),
+        "dropest_ingest_summary_get": (C.c_int, [vp, P(IngestSummary)]),
+        "dropest_ingest_summary_set": (C.c_int, [vp, P(IngestSummary)]),
+        "dropest_gene_chr_table": (C.c_int, [vp, P(vp), u64p]),
+        "dropest_shard_merge_search": (C.c_int, [vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, u64p]),
+        "dropest_shard_merge_pairs": (C.c_int, [vp, vp, vp]),
+        "dropest_shard_merge_export": (C.c_int, [vp, u64p, vp, vp, P(vp), vp]),
+        "dropest_shard_merge_intersect": (C.c_int, [vp, C.c_uint64, vp, vp, vp, vp, vp]),
+        "dropest_shard_merge_decide": (C.c_int, [vp, vp, vp]),
+        "dropest_merge_apply": (C.c_int, [C.c_uint64, C.c_uint64, vp, vp, vp, vp, vp, vp]),
+        "dropest_shard_merge_finish": (C.c_int, [vp, C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp]),
         "dropest_synth_generate_host": (C.c_int, [P(SynthParams), C.c_uint64, C.c_uint64, vp, vp, vp, vp]),
         "dropest_synth_generate_device": (C.c_int, [P(SynthParams), C.c_int, C.c_uint64, C.c_uint64, vp, vp, vp, vp]),
         "dropest_dev_alloc": (C.c_int, [C.c_int, C.c_uint64, P(vp)]),
@@ -140,7 +157,9 @@ EXPORTED_SYMBOLS = [
     "dropest_real_candidate_rows", "dropest_dev_copy_device", "dropest_umi_distribution",
     "dropest_collisions_adjusted_sizes",
     "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_stream",
-    "dropest_sort_layout",
+    "dropest_sort_layout", "dropest_ingest", "dropest_ingest_summary_get", "dropest_ingest_summary_set",
+    "dropest_gene_chr_table", "dropest_shard_merge_search", "dropest_shard_merge_pairs", "dropest_shard_merge_export",
+    "dropest_shard_merge_intersect", "dropest_shard_merge_decide", "dropest_merge_apply", "dropest_shard_merge_finish",
     "dropest_synth_generate_host", "dropest_synth_generate_device", "dropest_dev_alloc", "dropest_dev_free",
     "dropest_dev_copy_to_host", "dropest_dev_copy_from_host", "dropest_dev_count", "dropest_dev_sync",
 ]
@@ -348,6 +367,69 @@ class Context:
             self._chk(self.L.dropest_real_candidate_rows(self.h, C.byref(n), ids.ctypes.data, rows.ctypes.data))
         return ids, rows
 
+    # ---- sharded runs: phases with the caller's collectives between them (include/dropest_amd.h) ----
+    def ingest(self):
+        self._chk(self.L.dropest_ingest(self.h))
+
+    def ingest_summary(self):
+        s = IngestSummary()
+        self._chk(self.L.dropest_ingest_summary_get(self.h, C.byref(s)))
+        return s
+
+    def set_ingest_summary(self, s):
+        self._chk(self.L.dropest_ingest_summary_set(self.h, C.byref(s)))
+
+    def gene_chr_table(self):
+        p = C.c_void_p(); n = C.c_uint64()
+        self._chk(self.L.dropest_gene_chr_table(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def shard_merge_search(self, g_barcode, g_n_genes, g_total_umis, base_global, base_local):
+        gb = np.ascontiguousarray(g_barcode, np.uint64); gg = np.ascontiguousarray(g_n_genes, np.uint32)
+        gu = np.ascontiguousarray(g_total_umis, np.int32)
+        bg = np.ascontiguousarray(base_global, np.uint32); bl = np.ascontiguousarray(base_local, np.uint32)
+        n = C.c_uint64()
+        self._chk(self.L.dropest_shard_merge_search(self.h, len(gb), gb.ctypes.data, gg.ctypes.data, gu.ctypes.data, len(bg),
+                                                    bg.ctypes.data, bl.ctypes.data, C.byref(n)))
+        pb = np.zeros(n.value, np.uint32); pc = np.zeros(n.value, np.uint32)
+        if n.value:
+            self._chk(self.L.dropest_shard_merge_pairs(self.h, pb.ctypes.data, pc.ctypes.data))
+        return pb, pc
+
+    def shard_merge_export(self):
+        """-> listed_global, row_offset, device pointer of the key fields, 4 device pointers {reads, mark, exon, intron}"""
+        n = C.c_uint64()
+        self._chk(self.L.dropest_shard_merge_export(self.h, C.byref(n), None, None, None, None))
+        listed = np.zeros(n.value, np.uint32); off = np.zeros(n.value + 1, np.uint64)
+        low = C.c_void_p(); cols = (C.c_void_p * 4)()
+        self._chk(self.L.dropest_shard_merge_export(self.h, C.byref(n), listed.ctypes.data, off.ctypes.data, C.byref(low), cols))
+        return listed, off, low.value, [cols[k] for k in range(4)]
+
+    def shard_merge_intersect(self, cand_local, base_begin, base_end, d_base_low):
+        c = np.ascontiguousarray(cand_local, np.uint32); b = np.ascontiguousarray(base_begin, np.uint64)
+        e = np.ascontiguousarray(base_end, np.uint64)
+        out = np.zeros(len(c), np.uint32)
+        self._chk(self.L.dropest_shard_merge_intersect(self.h, len(c), c.ctypes.data, b.ctypes.data, e.ctypes.data, d_base_low,
+                                                       out.ctypes.data))
+        return out
+
+    def shard_merge_decide(self, inter, n_bases):
+        i = np.ascontiguousarray(inter, np.uint32)
+        out = np.full(n_bases, -1, np.int64)
+        self._chk(self.L.dropest_shard_merge_decide(self.h, i.ctypes.data, out.ctypes.data))
+        return out
+
+    def shard_merge_finish(self, local_id, excluded, merged_away, total_reads, total_umis, move_src, move_tgt, n_import,
+                           d_cell, d_low, d_cols):
+        li = np.ascontiguousarray(local_id, np.uint32); ex = np.ascontiguousarray(excluded, np.uint8)
+        mg = np.ascontiguousarray(merged_away, np.uint8); tr = np.ascontiguousarray(total_reads, np.int32)
+        tu = np.ascontiguousarray(total_umis, np.int32)
+        ms = np.ascontiguousarray(move_src, np.uint32); mt = np.ascontiguousarray(move_tgt, np.uint32)
+        cols = (C.c_void_p * 4)(*[C.c_void_p(x) for x in d_cols])
+        self._chk(self.L.dropest_shard_merge_finish(self.h, len(li), li.ctypes.data, ex.ctypes.data, mg.ctypes.data, tr.ctypes.data,
+                                                    tu.ctypes.data, len(ms), ms.ctypes.data, mt.ctypes.data, int(n_import),
+                                                    d_cell, d_low, cols))
+
     def clear_reads(self):
         self._chk(self.L.dropest_clear_reads(self.h))
 
@@ -389,6 +471,21 @@ class Context:
         self._chk(self.L.dropest_kernel_stats(self.h, C.byref(n), arr))
         return {arr[i].name.decode(): dict(launches=arr[i].launches, ms=arr[i].ms, bytes=arr[i].bytes)
                 for i in range(n.value)}
+
+
+def merge_apply(order, target, total_reads, total_umis):
+    """MergeStrategyBase::merge_inited second loop over flat arrays (no context): returns (final_target, excluded,
+    total_reads, total_umis) after applying step i = (order[i] -> target[i] or -1)."""
+    o = np.ascontiguousarray(order, np.uint32); t = np.ascontiguousarray(target, np.int64)
+    r = np.array(total_reads, np.int32); u = np.array(total_umis, np.int32)
+    n = len(r)
+    final = np.zeros(n, np.uint32); excl = np.zeros(n, np.uint8)
+    L = lib()
+    rc = L.dropest_merge_apply(n, len(o), o.ctypes.data, t.ctypes.data, r.ctypes.data, u.ctypes.data, final.ctypes.data,
+                               excl.ctypes.data)
+    if rc != 0:
+        raise DropestError(rc, L.dropest_last_error().decode())
+    return final, excl, r, u
 
 
 def collisions_adjusted_sizes(probs, max_expression, device=0):

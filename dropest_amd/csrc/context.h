@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -62,6 +63,27 @@ inline bool encode_code(const std::string &s, u64 &code) {   // false: needs an 
 }
 
 struct UmiOverride { u64 umi; u32 reads; uint8_t mark; };   // molecule of a group re-keyed by the N-UMI merge
+
+// The cells a whitelist merge search runs over: the context's own cells, or (sharded runs) the real cells of every
+// shard.  Device arrays are indexed by the universe's cell index; the callbacks serve the few host-side look-ups.
+struct MergeUniverse {
+	CbTable table{};                                   // barcode -> universe index
+	const u64 *cell_cb = nullptr;                      // packed barcodes
+	const u32 *n_genes = nullptr, *total_umis = nullptr;
+	const u32 *real_index = nullptr;                   // universe index -> index in the caller's cell list
+	bool any_escaped = false;
+	std::function<int32_t(u32)> base_total_umis;       // TOTAL_UMIS stat of base f (position in the searched list)
+	std::function<u64(u32)> barcode_code;              // packed barcode of a universe cell
+	std::function<std::string(u32)> base_barcode_text; // text of base f's barcode
+};
+struct MergeSearch {                                   // neighbour search result (merge_host.h)
+	u32 F = 0, ntot = 0;
+	size_t lds = 0;
+	std::vector<u32> cells, cnt, off, fcell, fumis, fridx, self_ridx;
+	std::vector<u32> pair_base /* position f */, pair_cand, pair_umis, pair_ridx, pair_first;
+	DevBuf<WlBase> d_bases;
+	WlArgs args{};
+};
 
 struct HostCell {   // host mirror of one REAL-candidate cell (n_genes >= min_genes_before_merge at init)
 	u32 id;
@@ -212,10 +234,27 @@ struct dropest_ctx {
 	void reduce_cell_gene_to_cells();
 	void refresh_real_rows();
 	void upload_whitelist();
+	void search_merge_candidates(const std::vector<u32> &cells, const dropest::MergeUniverse &U, dropest::MergeSearch &S);
+	void decide_merge_targets(const dropest::MergeUniverse &U, dropest::MergeSearch &S, const std::vector<u32> &inter,
+	                          std::vector<long> &targets, std::vector<u32> &target_ridx);
 	std::vector<long> compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx,
 	                                        std::vector<u32> *target_ridx = nullptr);
 	dropest::DevBuf<u32> cell_real_index;   // [n_cells] cell id -> index in `real` (0xFFFFFFFF otherwise)
 	void run_cb_merge_real();
+	// sharded runs (merge_shard.h): ingest / merge phases with collectives between them
+	struct ShardMerge;
+	std::shared_ptr<ShardMerge> shard;
+	bool ingested = false, external_merge_done = false;
+	void run_ingest();
+	void shard_merge_search(uint64_t n_global, const uint64_t *g_barcode, const uint32_t *g_n_genes, const int32_t *g_total_umis,
+	                        uint64_t n_bases, const uint32_t *base_g, const uint32_t *base_local, uint64_t *n_pairs);
+	void shard_merge_intersect(uint64_t n_pairs, const uint32_t *cand_local, const uint64_t *base_begin, const uint64_t *base_end,
+	                           const uint64_t *d_base_low, uint32_t *inter);
+	void shard_merge_decide(const uint32_t *inter, int64_t *target_g);
+	void shard_merge_finish(uint64_t n_local, const uint32_t *local_id, const uint8_t *excluded, const uint8_t *merged_away,
+	                        const int32_t *total_reads, const int32_t *total_umis, uint64_t n_moves, const uint32_t *move_src,
+	                        const uint32_t *move_tgt, uint64_t n_import, const uint32_t *d_cell, const uint64_t *d_low,
+	                        const uint32_t *const d_cols[4]);
 	void reaggregate_after_merge();
 	void run_umi_merge_simple();
 	void fetch_real_cells();

@@ -145,7 +145,8 @@ void dropest_ctx::concat_chunks() {
 }
 
 void dropest_ctx::free_results() {
-	initialized = merged = false;
+	initialized = merged = ingested = external_merge_done = false;
+	shard.reset();
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
 	real.clear(); filtered.clear(); filtered_valid = false; merge_pairs.clear(); reassign.clear(); umi_overrides.clear(); n_real_now = 0;
 }
@@ -580,18 +581,33 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 }
 
 #include "merge_host.h"
+#include "merge_shard.h"
 #include "umi_merge_host.h"
 
 // ------------------------------------------------------------------------------------------------
 // top-level stages
 // ------------------------------------------------------------------------------------------------
-void dropest_ctx::run_set_initialized() {
+// First half of set_initialized: barcode table, cell ids and the statistics that size the sort key.  A sharded run
+// stops here, all-reduces the statistics (dropest_ingest_summary_get / _set) and goes on with set_initialized.
+void dropest_ctx::run_ingest() {
 	if (initialized) throw InvalidError("Container is already initialized");
-	HostStage hs_all(this, "set_initialized");
+	if (ingested) return;
+	HostStage hs_all(this, "ingest");
 	concat_chunks();
+	ingest = IngestStats{};
+	ingest.umi_clean_min = ~0ull;
 	if (n_reads > 0) {
 		{ HostStage hs(this, "cb_table"); build_cb_table(); }
 		{ HostStage hs(this, "cell_ids"); assign_cell_ids(); }
+	}
+	ingested = true;
+}
+
+void dropest_ctx::run_set_initialized() {
+	if (initialized) throw InvalidError("Container is already initialized");
+	run_ingest();
+	HostStage hs_all(this, "set_initialized");
+	if (n_reads > 0) {
 		{ HostStage hs(this, "keys"); plan_key_layout(); build_keys(); }
 		{ HostStage hs(this, "sort+reduce"); reduce_all(); }
 		{ HostStage hs(this, "real_cells"); fetch_real_cells(); }
@@ -605,7 +621,7 @@ void dropest_ctx::run_merge_and_filter() {
 	if (!initialized) throw InvalidError("You must initialize container");
 	if (merged) throw InvalidError("merge_and_filter was already run");
 	HostStage hs(this, "merge_and_filter");
-	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells) run_cb_merge_real();
+	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells && !external_merge_done) run_cb_merge_real();
 	run_umi_merge_simple();   // MergeUMIsStrategySimple::merge, after the CB merge (CellsDataContainer.cpp:45)
 	request_filtered(min_after, cfg.max_cells);   // CellsDataContainer.cpp:47-49
 	merged = true;
@@ -787,6 +803,125 @@ dropest_status dropest_set_initialized(dropest_ctx *ctx) {
 		if (!ctx) throw InvalidError("null context");
 		HIP_CHECK(hipSetDevice(ctx->cfg.device));
 		ctx->run_set_initialized();
+	});
+}
+
+dropest_status dropest_ingest(dropest_ctx *ctx) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		ctx->run_ingest();
+		ctx->collect_timings();
+	});
+}
+
+dropest_status dropest_ingest_summary_get(dropest_ctx *ctx, dropest_ingest_summary *out) {
+	return guarded([&] {
+		if (!ctx || !out) throw InvalidError("null argument");
+		if (!ctx->ingested) throw InvalidError("dropest_ingest was not run");
+		const IngestStats &g = ctx->ingest;
+		out->umi_clean_min = g.umi_clean_min; out->umi_clean_max = g.umi_clean_max;
+		out->umi_escape_max_plus1 = g.umi_escape_max_plus1; out->gene_max_plus1 = g.gene_max_plus1;
+		out->chr_max_plus1 = g.chr_max_plus1; out->gene_chr_conflict = g.gene_chr_conflict; out->reserved = 0;
+	});
+}
+
+dropest_status dropest_ingest_summary_set(dropest_ctx *ctx, const dropest_ingest_summary *in) {
+	return guarded([&] {
+		if (!ctx || !in) throw InvalidError("null argument");
+		if (!ctx->ingested || ctx->initialized) throw InvalidError("the ingest summary is set between dropest_ingest and dropest_set_initialized");
+		IngestStats &g = ctx->ingest;
+		// widening only: every local value must stay representable
+		if (in->umi_clean_min > g.umi_clean_min || in->umi_clean_max < g.umi_clean_max || in->umi_escape_max_plus1 < g.umi_escape_max_plus1 ||
+		    in->gene_max_plus1 < g.gene_max_plus1 || in->chr_max_plus1 < g.chr_max_plus1 || (g.gene_chr_conflict && !in->gene_chr_conflict))
+			throw InvalidError("the global ingest summary does not cover this shard's values");
+		g.umi_clean_min = in->umi_clean_min; g.umi_clean_max = in->umi_clean_max; g.umi_escape_max_plus1 = in->umi_escape_max_plus1;
+		g.gene_max_plus1 = in->gene_max_plus1; g.chr_max_plus1 = in->chr_max_plus1; g.gene_chr_conflict = in->gene_chr_conflict;
+	});
+}
+
+dropest_status dropest_gene_chr_table(dropest_ctx *ctx, uint32_t **d_table, uint64_t *n) {
+	return guarded([&] {
+		if (!ctx || !d_table || !n) throw InvalidError("null argument");
+		if (!ctx->ingested) throw InvalidError("dropest_ingest was not run");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		if (!ctx->gene_chr.p) {   // a shard without reads: an all-unset table
+			ctx->gene_chr.ensure(GENE_CHR_CAP);
+			HIP_CHECK(hipMemsetAsync(ctx->gene_chr.p, 0xFF, size_t(GENE_CHR_CAP) * 4, ctx->stream));
+			HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		}
+		*d_table = ctx->gene_chr.p; *n = GENE_CHR_CAP;
+	});
+}
+
+dropest_status dropest_shard_merge_search(dropest_ctx *ctx, uint64_t n_global, const uint64_t *g_barcode, const uint32_t *g_n_genes,
+                                          const int32_t *g_total_umis, uint64_t n_bases, const uint32_t *base_global,
+                                          const uint32_t *base_local, uint64_t *n_pairs) {
+	return guarded([&] {
+		if (!ctx || !n_pairs) throw InvalidError("null argument");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		ctx->shard_merge_search(n_global, g_barcode, g_n_genes, g_total_umis, n_bases, base_global, base_local, n_pairs);
+	});
+}
+
+dropest_status dropest_shard_merge_pairs(dropest_ctx *ctx, uint32_t *pair_base_global, uint32_t *pair_cand_global) {
+	return guarded([&] {
+		if (!ctx || !ctx->shard) throw InvalidError("dropest_shard_merge_search was not run");
+		const MergeSearch &S = ctx->shard->S;
+		for (size_t p = 0; p < S.pair_base.size(); ++p) {
+			pair_base_global[p] = ctx->shard->base_g[S.pair_base[p]];
+			pair_cand_global[p] = S.pair_cand[p];
+		}
+	});
+}
+
+dropest_status dropest_shard_merge_export(dropest_ctx *ctx, uint64_t *n_listed, uint32_t *listed_global, uint64_t *row_offset,
+                                          const uint64_t **d_low, const uint32_t *d_cols[4]) {
+	return guarded([&] {
+		if (!ctx || !ctx->shard || !n_listed) throw InvalidError("dropest_shard_merge_search was not run");
+		dropest_ctx::ShardMerge &M = *ctx->shard;
+		*n_listed = M.listed_f.size();
+		if (listed_global) for (size_t i = 0; i < M.listed_f.size(); ++i) listed_global[i] = M.base_g[M.listed_f[i]];
+		if (row_offset) for (size_t i = 0; i < M.row_offset.size(); ++i) row_offset[i] = M.row_offset[i];
+		if (d_low) *d_low = reinterpret_cast<const uint64_t *>(M.x_low.p);
+		if (d_cols) for (int k = 0; k < 4; ++k) d_cols[k] = M.x_col[k].p;
+	});
+}
+
+dropest_status dropest_shard_merge_intersect(dropest_ctx *ctx, uint64_t n_pairs, const uint32_t *cand_local, const uint64_t *base_begin,
+                                             const uint64_t *base_end, const uint64_t *d_base_low, uint32_t *inter) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		ctx->shard_merge_intersect(n_pairs, cand_local, base_begin, base_end, d_base_low, inter);
+	});
+}
+
+dropest_status dropest_shard_merge_decide(dropest_ctx *ctx, const uint32_t *inter, int64_t *target_global) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		ctx->shard_merge_decide(inter, target_global);
+	});
+}
+
+dropest_status dropest_merge_apply(uint64_t n_cells, uint64_t n_order, const uint32_t *order, const int64_t *target, int32_t *total_reads,
+                                   int32_t *total_umis, uint32_t *final_target, uint8_t *excluded) {
+	return guarded([&] {
+		if (n_cells >= 0xFFFFFFF0ull) throw UnsupportedError("too many cells");
+		apply_merge_order(u32(n_cells), size_t(n_order), order, target, total_reads, total_umis, final_target, excluded);
+	});
+}
+
+dropest_status dropest_shard_merge_finish(dropest_ctx *ctx, uint64_t n_local, const uint32_t *local_id, const uint8_t *excluded,
+                                          const uint8_t *merged_away, const int32_t *total_reads, const int32_t *total_umis,
+                                          uint64_t n_moves, const uint32_t *move_src, const uint32_t *move_tgt, uint64_t n_import,
+                                          const uint32_t *d_cell, const uint64_t *d_low, const uint32_t *const d_cols[4]) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		ctx->shard_merge_finish(n_local, local_id, excluded, merged_away, total_reads, total_umis, n_moves, move_src, move_tgt, n_import,
+		                        d_cell, d_low, d_cols);
 	});
 }
 

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256) void scatter_pairs_kernel(const uint32_t *__re
 struct PairRange { uint32_t base_begin, base_end, cand_begin, cand_end; };
 
 __global__ __launch_bounds__(256) void umig_intersect_kernel(const PairRange *__restrict__ pairs, uint32_t n_pairs,
+                                                             const unsigned long long *__restrict__ base_key,
                                                              const unsigned long long *__restrict__ mol_key,
                                                              unsigned long long low_mask, int umi_bits,
                                                              unsigned long long gene_none, uint32_t *__restrict__ out) {
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void umig_intersect_kernel(const PairRange *__
 	const PairRange r = pairs[blockIdx.x];
 	uint32_t c = 0;
 	for (uint32_t i = r.base_begin + threadIdx.x; i < r.base_end; i += 256) {
-		const unsigned long long k = mol_key[i] & low_mask;
+		const unsigned long long k = base_key[i] & low_mask;   // the base's rows may live in another table (sharded runs)
 		if ((k >> umi_bits) == gene_none) continue;          // reads without a gene are not UMI-genes
 		uint32_t lo = r.cand_begin, hi = r.cand_end;
 		while (lo < hi) {

@@ -81,48 +81,175 @@ void dropest_ctx::upload_whitelist() {
 	}
 }
 
-// RealBarcodesMergeStrategy::get_merge_target for a list of cells, on the current (unmerged) device state.
-// `ridx[f]` = index of cells[f] in `real`.  Everything per-cell that scales with the number of filtered cells
-// (10^5..10^6 at BASELINE sizes) is done on the device; the host only walks flat arrays.
-std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx,
-                                                     std::vector<u32> *target_ridx) {
-	std::vector<long> targets(cells.size(), -1);
-	if (target_ridx) target_ridx->assign(cells.size(), 0xFFFFFFFFu);
-	if (cells.empty()) return targets;
+// Neighbour search of RealBarcodesMergeStrategy::get_merge_target for a list of base cells, over a universe of
+// cells (the context's own, or in sharded runs the real cells of every shard).  Everything per-cell that scales
+// with the number of filtered cells (10^5..10^6 at BASELINE sizes) is done on the device; the host only walks flat
+// arrays.  Fills the candidate lists and the (base, candidate) pairs whose UMI-gene intersection is needed.
+void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const MergeUniverse &U, MergeSearch &S) {
 	upload_whitelist();
 	const u32 F = u32(cells.size());
+	S.F = F;
+	S.cells = cells;
 
 	// 1. barcodes split into the two parts (device; escaped barcodes patched by the host)
 	DevBuf<u32> d_cells; d_cells.alloc(F);
-	DevBuf<WlBase> d_bases; d_bases.alloc(F);
+	S.d_bases.alloc(F);
 	scalars.ensure(16);
 	HIP_CHECK(hipMemcpyAsync(d_cells.p, cells.data(), size_t(F) * 4, hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
-	hipLaunchKernelGGL(make_bases_kernel, dim3(div_up(F, 256)), dim3(256), 0, stream, d_cells.p, F, cell_cb.p,
+	hipLaunchKernelGGL(make_bases_kernel, dim3(div_up(F, 256)), dim3(256), 0, stream, d_cells.p, F, U.cell_cb,
 	                   cfg.barcodes_kind == DROPEST_BARCODES_CONST ? 1 : 0, u32(wl.part_lengths[0]), u32(wl.part_lengths[1]),
-	                   d_bases.p, scalars.p);
+	                   S.d_bases.p, scalars.p);
 	HIP_CHECK(hipGetLastError());
 	u32 bad = 0;
 	fetch(&bad, scalars.p, 4);
 	if (bad == 2) throw UnsupportedError("barcode part longer than 31 bases");
 	if (bad) {   // reproduce the reference's message for the first offending barcode
-		for (u32 f = 0; f < F; ++f) { std::string a, b; wl.split(barcode_of(real[ridx[f]]), a, b); }
+		for (u32 f = 0; f < F; ++f) { std::string a, b; wl.split(U.base_barcode_text(f), a, b); }
 		throw InvalidError("barcode length does not fit the whitelist");
 	}
-	if (ingest.cb_escape_count) {
+	if (U.any_escaped) {
 		for (u32 f = 0; f < F; ++f) {
-			if (!(real[ridx[f]].row.barcode & ESCAPE_BIT)) continue;
+			if (!(U.barcode_code(cells[f]) & ESCAPE_BIT)) continue;
 			std::string a, b;
-			wl.split(barcode_of(real[ridx[f]]), a, b);
+			wl.split(U.base_barcode_text(f), a, b);
 			WlBase wb;
 			std::memset(&wb, 0, sizeof(wb));
 			std::memcpy(wb.part[0], a.data(), a.size()); std::memcpy(wb.part[1], b.data(), b.size());
 			wb.len[0] = uint8_t(a.size()); wb.len[1] = uint8_t(b.size()); wb.cell = cells[f];
-			HIP_CHECK(hipMemcpy(d_bases.p + f, &wb, sizeof(wb), hipMemcpyHostToDevice));
+			HIP_CHECK(hipMemcpy(S.d_bases.p + f, &wb, sizeof(wb), hipMemcpyHostToDevice));
 		}
 	}
 
-	// cell id -> index in `real` (the ids of `real` are still on the device from fetch_real_cells / refresh)
+	// 2. neighbour search; candidates land in flat lists
+	DevBuf<u32> d_cnt, d_lvl, d_off, d_fcell, d_fumis, d_fridx;
+	u32 flat_cap = std::max<u32>(F * 2u, 1024u);
+	S.cnt.resize(F); S.off.resize(F);
+	WlArgs &a = S.args;
+	S.ntot = u32(wl.parts[0].size() + wl.parts[1].size());
+	S.lds = ((S.ntot + 15u) & ~15u) + size_t(S.ntot) * 2;
+	for (;;) {
+		d_cnt.alloc(F); d_lvl.alloc(F); d_off.alloc(F); d_fcell.alloc(flat_cap); d_fumis.alloc(flat_cap); d_fridx.alloc(flat_cap);
+		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
+		a = WlArgs{};
+		a.bases = S.d_bases.p; a.n_bases = F;
+		a.part[0] = d_wl[0].p; a.part[1] = d_wl[1].p;
+		a.part_size[0] = u32(wl.parts[0].size()); a.part_size[1] = u32(wl.parts[1].size());
+		a.table = U.table; a.cell_n_genes = U.n_genes; a.cell_total_umis = U.total_umis; a.min_genes = min_before;
+		a.cand_count = d_cnt.p; a.cand_level = d_lvl.p; a.cand_off = d_off.p; a.flat_cell = d_fcell.p; a.flat_umis = d_fumis.p;
+		a.flat_ridx = d_fridx.p; a.cell_real_index = U.real_index;
+		a.flat_total = scalars.p; a.flat_cap = flat_cap; a.dist_dump = nullptr;
+		timed("wl_neighbours", double(F) * S.ntot * 32, [&] {
+			hipLaunchKernelGGL(wl_neighbours_kernel, dim3(F), dim3(WL_THREADS), S.lds, stream, a);
+		});
+		u32 total = 0;
+		fetch(&total, scalars.p, 4);
+		if (total <= flat_cap) {
+			fetch(S.cnt.data(), d_cnt.p, size_t(F) * 4);
+			fetch(S.off.data(), d_off.p, size_t(F) * 4);
+			S.fcell.resize(total); S.fumis.resize(total); S.fridx.resize(total);
+			fetch(S.fcell.data(), d_fcell.p, size_t(total) * 4);
+			fetch(S.fumis.data(), d_fumis.p, size_t(total) * 4);
+			fetch(S.fridx.data(), d_fridx.p, size_t(total) * 4);
+			break;
+		}
+		flat_cap = total + 1024;   // rare: more candidates than twice the number of cells; run again with room
+	}
+
+	// 3. pairs (base, candidate) whose UMI-gene intersection is needed
+	S.pair_base.clear(); S.pair_cand.clear(); S.pair_umis.clear(); S.pair_ridx.clear();
+	S.pair_first.assign(size_t(F) + 1, 0); S.self_ridx.assign(F, 0xFFFFFFFFu);
+	S.pair_base.reserve(F); S.pair_cand.reserve(F); S.pair_umis.reserve(F); S.pair_ridx.reserve(F);
+	for (u32 f = 0; f < F; ++f) {
+		S.pair_first[f] = u32(S.pair_base.size());
+		if (S.cnt[f] > u32(WL_CAND_CAP))
+			throw UnsupportedError("more than " + std::to_string(WL_CAND_CAP) + " merge candidates for one barcode");
+		bool self = false;
+		for (u32 k = 0; k < S.cnt[f]; ++k)
+			if (S.fcell[S.off[f] + k] == cells[f]) { self = true; S.self_ridx[f] = S.fridx[S.off[f] + k]; }
+		if (self) continue;   // the base is itself a whitelist barcode: neighbour_cells[0] == base (RealBarcodesMergeStrategy.cpp:34-35)
+		for (u32 k = 0; k < S.cnt[f]; ++k) {
+			S.pair_base.push_back(f); S.pair_cand.push_back(S.fcell[S.off[f] + k]); S.pair_umis.push_back(S.fumis[S.off[f] + k]);
+			S.pair_ridx.push_back(S.fridx[S.off[f] + k]);
+		}
+	}
+	S.pair_first[F] = u32(S.pair_base.size());
+}
+
+// Decisions (RealBarcodesMergeStrategy::get_best_merge_target, :31-61) from the intersection sizes of S's pairs;
+// all inputs are integers, the fraction is evaluated exactly as the reference writes it (double, no contraction on
+// the host).  targets[f] = candidate cell (universe index) or -1; target_ridx[f] = its real_index.
+void dropest_ctx::decide_merge_targets(const MergeUniverse &U, MergeSearch &S, const std::vector<u32> &inter,
+                                       std::vector<long> &targets, std::vector<u32> &target_ridx) {
+	const u32 F = S.F;
+	targets.assign(F, -1);
+	target_ridx.assign(F, 0xFFFFFFFFu);
+	std::vector<u32> need_order;   // cells whose result depends on the reference's candidate order
+	auto frac_of = [&](u32 f, u32 p) {
+		return 0.5 * inter[p] * (1. / size_t(U.base_total_umis(f)) + 1. / size_t(int32_t(S.pair_umis[p])));
+	};
+	for (u32 f = 0; f < F; ++f) {
+		if (S.cnt[f] == 0) { targets[f] = -1; continue; }
+		const u32 p0 = S.pair_first[f], p1 = S.pair_first[f + 1];
+		if (p0 == p1) { targets[f] = long(S.cells[f]); target_ridx[f] = S.self_ridx[f]; continue; }   // self
+		double best = 0; u32 n_best = 0, best_p = 0;
+		for (u32 p = p0; p < p1; ++p) {
+			const double fr = frac_of(f, p);
+			if (fr > best) { best = fr; n_best = 1; best_p = p; }
+			else if (fr == best) ++n_best;
+		}
+		if (best < cfg.min_merge_fraction) { targets[f] = -1; continue; }   // holds for any order
+		if (best > 0 && n_best == 1) { targets[f] = long(S.pair_cand[best_p]); target_ridx[f] = S.pair_ridx[best_p]; continue; }
+		need_order.push_back(f);   // tie at the maximum (or all fractions zero with a non-positive threshold)
+	}
+	if (need_order.empty()) return;
+	const u32 R = u32(need_order.size()), ntot = S.ntot;
+	std::vector<WlBase> rb(R);
+	for (u32 r = 0; r < R; ++r) HIP_CHECK(hipMemcpy(&rb[r], S.d_bases.p + need_order[r], sizeof(WlBase), hipMemcpyDeviceToHost));
+	DevBuf<WlBase> d_rb; d_rb.alloc(R);
+	DevBuf<uint8_t> d_dump; d_dump.alloc(size_t(R) * ntot);
+	DevBuf<u32> d_c2, d_l2, d_o2, d_f2, d_u2, d_r2;
+	d_c2.alloc(R); d_l2.alloc(R); d_o2.alloc(R); d_f2.alloc(size_t(R) * WL_CAND_CAP); d_u2.alloc(size_t(R) * WL_CAND_CAP);
+	d_r2.alloc(size_t(R) * WL_CAND_CAP);
+	HIP_CHECK(hipMemcpyAsync(d_rb.p, rb.data(), size_t(R) * sizeof(WlBase), hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
+	WlArgs a2 = S.args;
+	a2.bases = d_rb.p; a2.n_bases = R; a2.cand_count = d_c2.p; a2.cand_level = d_l2.p; a2.cand_off = d_o2.p;
+	a2.flat_cell = d_f2.p; a2.flat_umis = d_u2.p; a2.flat_ridx = d_r2.p; a2.flat_cap = R * u32(WL_CAND_CAP); a2.dist_dump = d_dump.p;
+	hipLaunchKernelGGL(wl_neighbours_kernel, dim3(R), dim3(WL_THREADS), S.lds, stream, a2);
+	HIP_CHECK(hipGetLastError());
+	std::vector<uint8_t> dump(size_t(R) * ntot);
+	fetch(dump.data(), d_dump.p, dump.size());
+	// barcodes of the candidates (whitelist cells, hence real-candidate cells) for the replay
+	for (u32 r = 0; r < R; ++r) {
+		const u32 f = need_order[r];
+		std::unordered_map<u64, u32> by_code;
+		std::unordered_map<u32, u32> pair_of;
+		for (u32 p = S.pair_first[f]; p < S.pair_first[f + 1]; ++p) {
+			by_code[U.barcode_code(S.pair_cand[p])] = S.pair_cand[p];
+			pair_of[S.pair_cand[p]] = p;
+		}
+		const std::vector<u32> order = reference_candidate_order(wl, dump.data() + size_t(r) * ntot, by_code);
+		if (order.empty()) throw DeviceError("internal: candidate replay found no candidate");
+		double best = 0; u32 best_cell = order[0];
+		for (u32 c : order) {
+			const double fr = frac_of(f, pair_of.at(c));
+			if (best < fr) { best = fr; best_cell = c; }
+		}
+		targets[f] = best < cfg.min_merge_fraction ? -1 : long(best_cell);
+		if (targets[f] >= 0) target_ridx[f] = S.pair_ridx[pair_of.at(best_cell)];
+	}
+}
+
+// RealBarcodesMergeStrategy::get_merge_target for a list of this context's cells, on the current (unmerged) device
+// state.  `ridx[f]` = index of cells[f] in `real`.
+std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx,
+                                                     std::vector<u32> *target_ridx) {
+	std::vector<long> targets(cells.size(), -1);
+	if (target_ridx) target_ridx->assign(cells.size(), 0xFFFFFFFFu);
+	if (cells.empty()) return targets;
+
+	// cell id -> index in `real`
 	{
 		const u32 nr = u32(real.size());
 		std::vector<u32> ids(nr);
@@ -134,134 +261,71 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipStreamSynchronize(stream));
 	}
+	MergeUniverse U;
+	U.table = table; U.cell_cb = cell_cb.p; U.n_genes = cell_n_genes.p; U.total_umis = cell_total_umis.p;
+	U.real_index = cell_real_index.p; U.any_escaped = ingest.cb_escape_count != 0;
+	U.base_total_umis = [&](u32 f) { return real[ridx[f]].row.total_umis; };
+	U.barcode_code = [&](u32 cell) { return u64(real[real_at(cell)].row.barcode); };
+	U.base_barcode_text = [&](u32 f) { return barcode_of(real[ridx[f]]); };
+	MergeSearch S;
+	search_merge_candidates(cells, U, S);
 
-	// 2. neighbour search; candidates land in flat lists
-	DevBuf<u32> d_cnt, d_lvl, d_off, d_fcell, d_fumis, d_fridx;
-	u32 flat_cap = std::max<u32>(F * 2u, 1024u);
-	std::vector<u32> cnt(F), off(F), fcell, fumis, fridx;
-	WlArgs a{};
-	const u32 ntot = u32(wl.parts[0].size() + wl.parts[1].size());
-	const size_t lds = ((ntot + 15u) & ~15u) + size_t(ntot) * 2;
-	for (;;) {
-		d_cnt.alloc(F); d_lvl.alloc(F); d_off.alloc(F); d_fcell.alloc(flat_cap); d_fumis.alloc(flat_cap); d_fridx.alloc(flat_cap);
-		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
-		a = WlArgs{};
-		a.bases = d_bases.p; a.n_bases = F;
-		a.part[0] = d_wl[0].p; a.part[1] = d_wl[1].p;
-		a.part_size[0] = u32(wl.parts[0].size()); a.part_size[1] = u32(wl.parts[1].size());
-		a.table = table; a.cell_n_genes = cell_n_genes.p; a.cell_total_umis = cell_total_umis.p; a.min_genes = min_before;
-		a.cand_count = d_cnt.p; a.cand_level = d_lvl.p; a.cand_off = d_off.p; a.flat_cell = d_fcell.p; a.flat_umis = d_fumis.p;
-		a.flat_ridx = d_fridx.p; a.cell_real_index = cell_real_index.p;
-		a.flat_total = scalars.p; a.flat_cap = flat_cap; a.dist_dump = nullptr;
-		timed("wl_neighbours", double(F) * ntot * 32, [&] {
-			hipLaunchKernelGGL(wl_neighbours_kernel, dim3(F), dim3(WL_THREADS), lds, stream, a);
-		});
-		u32 total = 0;
-		fetch(&total, scalars.p, 4);
-		if (total <= flat_cap) {
-			fetch(cnt.data(), d_cnt.p, size_t(F) * 4);
-			fetch(off.data(), d_off.p, size_t(F) * 4);
-			fcell.resize(total); fumis.resize(total); fridx.resize(total);
-			fetch(fcell.data(), d_fcell.p, size_t(total) * 4);
-			fetch(fumis.data(), d_fumis.p, size_t(total) * 4);
-			fetch(fridx.data(), d_fridx.p, size_t(total) * 4);
-			break;
-		}
-		flat_cap = total + 1024;   // rare: more candidates than twice the number of cells; run again with room
-	}
-
-	// 3. pairs (base, candidate) whose UMI-gene intersection is needed
-	std::vector<u32> pair_base, pair_cand, pair_umis, pair_ridx, pair_first(size_t(F) + 1, 0);
-	pair_base.reserve(F); pair_cand.reserve(F); pair_umis.reserve(F); pair_ridx.reserve(F);
-	for (u32 f = 0; f < F; ++f) {
-		pair_first[f] = u32(pair_base.size());
-		if (cnt[f] > u32(WL_CAND_CAP))
-			throw UnsupportedError("more than " + std::to_string(WL_CAND_CAP) + " merge candidates for one barcode");
-		bool self = false;
-		for (u32 k = 0; k < cnt[f]; ++k) self |= fcell[off[f] + k] == cells[f];
-		if (self) continue;   // the base is itself a whitelist barcode: neighbour_cells[0] == base (RealBarcodesMergeStrategy.cpp:34-35)
-		for (u32 k = 0; k < cnt[f]; ++k) {
-			pair_base.push_back(cells[f]); pair_cand.push_back(fcell[off[f] + k]); pair_umis.push_back(fumis[off[f] + k]);
-			pair_ridx.push_back(fridx[off[f] + k]);
-		}
-	}
-	pair_first[F] = u32(pair_base.size());
-	const u32 NP = u32(pair_base.size());
+	const u32 NP = u32(S.pair_base.size());
 	std::vector<u32> inter(NP);
 	if (NP) {
+		std::vector<u32> pb(NP);
+		for (u32 p = 0; p < NP; ++p) pb[p] = cells[S.pair_base[p]];
 		DevBuf<u32> d_pb, d_pc, d_inter; DevBuf<PairRange> d_pr;
 		d_pb.alloc(NP); d_pc.alloc(NP); d_inter.alloc(NP); d_pr.alloc(NP);
-		HIP_CHECK(hipMemcpyAsync(d_pb.p, pair_base.data(), size_t(NP) * 4, hipMemcpyHostToDevice, stream));
-		HIP_CHECK(hipMemcpyAsync(d_pc.p, pair_cand.data(), size_t(NP) * 4, hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(d_pb.p, pb.data(), size_t(NP) * 4, hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(d_pc.p, S.pair_cand.data(), size_t(NP) * 4, hipMemcpyHostToDevice, stream));
 		hipLaunchKernelGGL(pair_ranges_kernel, dim3(div_up(NP, 256)), dim3(256), 0, stream, d_pb.p, d_pc.p, NP, cell_cg_begin.p,
 		                   cell_cg_count.p, cg_mol_begin.p, d_pr.p);
 		HIP_CHECK(hipGetLastError());
 		const int low_bits = layout.gene_bits + layout.umi_bits;
 		timed("umig_intersect", double(NP) * 64, [&] {
-			hipLaunchKernelGGL(umig_intersect_kernel, dim3(NP), dim3(256), 0, stream, d_pr.p, NP, mol_key.p, (1ull << low_bits) - 1ull,
-			                   layout.umi_bits, layout.gene_none, d_inter.p);
+			hipLaunchKernelGGL(umig_intersect_kernel, dim3(NP), dim3(256), 0, stream, d_pr.p, NP, mol_key.p, mol_key.p,
+			                   (1ull << low_bits) - 1ull, layout.umi_bits, layout.gene_none, d_inter.p);
 		});
 		fetch(inter.data(), d_inter.p, size_t(NP) * 4);
 	}
-
-	// 4. decisions (RealBarcodesMergeStrategy::get_best_merge_target, :31-61); all inputs are integers, the
-	//    fraction is evaluated exactly as the reference writes it (double, no contraction on the host)
-	std::vector<u32> need_order;   // cells whose result depends on the reference's candidate order
-	auto frac_of = [&](u32 f, u32 p) {
-		return 0.5 * inter[p] * (1. / size_t(real[ridx[f]].row.total_umis) + 1. / size_t(int32_t(pair_umis[p])));
-	};
-	for (u32 f = 0; f < F; ++f) {
-		if (cnt[f] == 0) { targets[f] = -1; continue; }
-		const u32 p0 = pair_first[f], p1 = pair_first[f + 1];
-		if (p0 == p1) { targets[f] = long(cells[f]); if (target_ridx) (*target_ridx)[f] = ridx[f]; continue; }   // self
-		double best = 0; u32 n_best = 0, best_p = 0;
-		for (u32 p = p0; p < p1; ++p) {
-			const double fr = frac_of(f, p);
-			if (fr > best) { best = fr; n_best = 1; best_p = p; }
-			else if (fr == best) ++n_best;
-		}
-		if (best < cfg.min_merge_fraction) { targets[f] = -1; continue; }   // holds for any order
-		if (best > 0 && n_best == 1) { targets[f] = long(pair_cand[best_p]); if (target_ridx) (*target_ridx)[f] = pair_ridx[best_p]; continue; }
-		need_order.push_back(f);   // tie at the maximum (or all fractions zero with a non-positive threshold)
-	}
-	if (!need_order.empty()) {
-		const u32 R = u32(need_order.size());
-		std::vector<WlBase> rb(R);
-		for (u32 r = 0; r < R; ++r) HIP_CHECK(hipMemcpy(&rb[r], d_bases.p + need_order[r], sizeof(WlBase), hipMemcpyDeviceToHost));
-		DevBuf<WlBase> d_rb; d_rb.alloc(R);
-		DevBuf<uint8_t> d_dump; d_dump.alloc(size_t(R) * ntot);
-		DevBuf<u32> d_c2, d_l2, d_o2, d_f2, d_u2;
-		d_c2.alloc(R); d_l2.alloc(R); d_o2.alloc(R); d_f2.alloc(size_t(R) * WL_CAND_CAP); d_u2.alloc(size_t(R) * WL_CAND_CAP);
-		HIP_CHECK(hipMemcpyAsync(d_rb.p, rb.data(), size_t(R) * sizeof(WlBase), hipMemcpyHostToDevice, stream));
-		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
-		WlArgs a2 = a;
-		a2.bases = d_rb.p; a2.n_bases = R; a2.cand_count = d_c2.p; a2.cand_level = d_l2.p; a2.cand_off = d_o2.p;
-		a2.flat_cell = d_f2.p; a2.flat_umis = d_u2.p; a2.flat_cap = R * u32(WL_CAND_CAP); a2.dist_dump = d_dump.p;
-		hipLaunchKernelGGL(wl_neighbours_kernel, dim3(R), dim3(WL_THREADS), lds, stream, a2);
-		HIP_CHECK(hipGetLastError());
-		std::vector<uint8_t> dump(size_t(R) * ntot);
-		fetch(dump.data(), d_dump.p, dump.size());
-		// barcodes of the candidates (whitelist cells, hence real-candidate cells) for the replay
-		for (u32 r = 0; r < R; ++r) {
-			const u32 f = need_order[r];
-			std::unordered_map<u64, u32> by_code;
-			std::unordered_map<u32, u32> pair_of;
-			for (u32 p = pair_first[f]; p < pair_first[f + 1]; ++p) {
-				by_code[real[real_at(pair_cand[p])].row.barcode] = pair_cand[p];
-				pair_of[pair_cand[p]] = p;
-			}
-			const std::vector<u32> order = reference_candidate_order(wl, dump.data() + size_t(r) * ntot, by_code);
-			if (order.empty()) throw DeviceError("internal: candidate replay found no candidate");
-			double best = 0; u32 best_cell = order[0];
-			for (u32 c : order) {
-				const double fr = frac_of(f, pair_of.at(c));
-				if (best < fr) { best = fr; best_cell = c; }
-			}
-			targets[f] = best < cfg.min_merge_fraction ? -1 : long(best_cell);
-			if (target_ridx && targets[f] >= 0) (*target_ridx)[f] = pair_ridx[pair_of.at(best_cell)];
-		}
-	}
+	std::vector<u32> tr;
+	decide_merge_targets(U, S, inter, targets, tr);
+	if (target_ridx) *target_ridx = tr;
 	return targets;
+}
+
+// MergeStrategyBase::merge_inited second loop (:30-51) + reassign (:64-82), on flat arrays indexed by the position
+// in the caller's cell list: order[i] = base of step i (ascending compare_cells order), target[i] = its target
+// position or -1.  final_target[x] = where x's molecules end up (x itself if never merged); the cells merged into
+// a target form an intrusive list so that a later merge of that target moves them along.  Stats::merge adds
+// every int counter, TOTAL_UMIS included (Stats.cpp:29-43).  Returns whether anything was merged.
+static bool apply_merge_order(u32 n_cells, size_t n_order, const u32 *order, const int64_t *target, int32_t *total_reads,
+                              int32_t *total_umis, u32 *final_target, uint8_t *excluded) {
+	const u32 NIL = 0xFFFFFFFFu;
+	std::vector<u32> head(n_cells, NIL), tail(n_cells, NIL), next(n_cells, NIL);
+	u32 *cur = final_target;
+	for (u32 i = 0; i < n_cells; ++i) { cur[i] = i; excluded[i] = 0; }
+	auto append = [&](u32 tgt, u32 x) { if (head[tgt] == NIL) head[tgt] = x; else next[tail[tgt]] = x; tail[tgt] = x; next[x] = NIL; };
+	bool any_merge = false;
+	for (size_t i = 0; i < n_order; ++i) {
+		const u32 b = order[i];
+		if (b >= n_cells) throw RangeError("merge order refers to a cell outside the list");
+		if (target[i] < 0) { excluded[b] = 1; continue; }
+		if (u64(target[i]) >= n_cells) throw RangeError("merge target outside the list");
+		const u32 tr = cur[u32(target[i])];        // "real barcodes could be merged too" (:43-46)
+		if (tr == b) continue;
+		// CellsDataContainer::merge_cells (:90-104)
+		total_reads[tr] += total_reads[b];
+		total_umis[tr] += total_umis[b];
+		any_merge = true;
+		cur[b] = tr;
+		u32 moved = head[b];                         // cells previously merged into b follow it (reassign, :64-82)
+		head[b] = tail[b] = NIL;
+		append(tr, b);
+		while (moved != NIL) { const u32 nx = next[moved]; cur[moved] = tr; append(tr, moved); moved = nx; }
+	}
+	return any_merge;
 }
 
 void dropest_ctx::run_cb_merge_real() {
@@ -273,35 +337,22 @@ void dropest_ctx::run_cb_merge_real() {
 	std::vector<u32> target_ridx;
 	{ HostStage hs2(this, "cb_merge:targets"); targets = compute_merge_targets(cells, ridx, &target_ridx); }
 
-	// MergeStrategyBase::merge_inited second loop (:30-51) + reassign (:64-82), on flat arrays indexed by the
-	// position in `real`: cur[x] = final target of x; the cells merged into a target form an intrusive list.
 	HostStage hs3(this, "cb_merge:apply");
-	const u32 NIL = 0xFFFFFFFFu, nR = u32(real.size());
-	std::vector<u32> cur(nR), head(nR, NIL), tail(nR, NIL), next(nR, NIL);
-	for (u32 i = 0; i < nR; ++i) cur[i] = i;
-	auto append = [&](u32 tgt, u32 x) { if (head[tgt] == NIL) head[tgt] = x; else next[tail[tgt]] = x; tail[tgt] = x; next[x] = NIL; };
-	bool any_merge = false;
-	for (size_t i = 0; i < cells.size(); ++i) {
-		const u32 b = ridx[i];
-		HostCell &hb = real[b];
-		if (targets[i] < 0) { hb.excluded = true; continue; }
-		const u32 tr = cur[target_ridx[i]];        // "real barcodes could be merged too" (:43-46)
-		if (tr == b) continue;
-		HostCell &ht = real[tr];
-		// CellsDataContainer::merge_cells (:90-104): Stats::merge adds every counter, TOTAL_UMIS included
-		ht.row.total_reads += hb.row.total_reads;
-		ht.row.total_umis += hb.row.total_umis;
-		hb.merged = true;
-		any_merge = true;
-		cur[b] = tr;
-		u32 moved = head[b];                         // cells previously merged into b follow it (reassign, :64-82)
-		head[b] = tail[b] = NIL;
-		append(tr, b);
-		while (moved != NIL) { const u32 nx = next[moved]; cur[moved] = tr; append(tr, moved); moved = nx; }
-	}
+	const u32 nR = u32(real.size());
+	std::vector<int64_t> tgt(cells.size());
+	for (size_t i = 0; i < cells.size(); ++i) tgt[i] = targets[i] < 0 ? -1 : int64_t(target_ridx[i]);
+	std::vector<int32_t> reads(nR), umis(nR);
+	for (u32 i = 0; i < nR; ++i) { reads[i] = real[i].row.total_reads; umis[i] = real[i].row.total_umis; }
+	std::vector<u32> cur(nR);
+	std::vector<uint8_t> excl(nR);
+	const bool any_merge = apply_merge_order(nR, cells.size(), ridx.data(), tgt.data(), reads.data(), umis.data(), cur.data(), excl.data());
 	reassign.clear();
 	merge_pairs.clear();
-	for (u32 i = 0; i < nR; ++i) if (cur[i] != i) merge_pairs.emplace_back(real[i].id, real[cur[i]].id);   // ascending source id
+	for (u32 i = 0; i < nR; ++i) {
+		real[i].row.total_reads = reads[i]; real[i].row.total_umis = umis[i];
+		if (excl[i]) real[i].excluded = true;
+		if (cur[i] != i) { real[i].merged = true; merge_pairs.emplace_back(real[i].id, real[cur[i]].id); }   // ascending source id
+	}
 	if (any_merge) reaggregate_after_merge();
 }
 

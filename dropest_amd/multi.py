@@ -15,7 +15,13 @@ independent per barcode, so reads are sharded by owner(cb) = mix64(cb) mod n:
 
 `torch.distributed` (backend "nccl" = RCCL) is the transport; the compute is the C-ABI library.  The engine that
 does the local compute is injected, so the orchestration can be exercised on CPU tensors over gloo (tests only).
-CB merge across shards (a barcode's merge target can live on another GPU) is not built yet: merge_kind must be NONE.
+
+With cfg["merge"] (the reference's -m with a barcode whitelist) a barcode's merge target can live on another shard.
+The key fields are first made identical on every shard (all-reduced ingest summary), then the merge runs in phases
+(search / export / intersect / decide / apply / finish, see include/dropest_amd.h and csrc/merge_shard.h) with small
+all-gathers between them: the real cells' rows, the (base, candidate) pairs, the molecule rows of the non-whitelist
+bases (a few % of all molecules), the intersection sizes and the targets.  Not supported in sharded runs: barcodes or
+UMIs with N (the reference's random UMI fill draws from one global rand() sequence).
 """
 import ctypes as C
 
@@ -32,8 +38,11 @@ class GpuEngine:
         self.torch = torch
         self.device = device
         self.L = capi.lib()
-        self.ctx = capi.Context(device=device, merge_kind=capi.MERGE_NONE, min_genes_before_merge=cfg["min_before"],
-                                min_genes_after_merge=cfg["min_after"], gene_match_levels=cfg.get("levels", "eEBA"))
+        m = cfg.get("merge")
+        kw = dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=m["barcodes_kind"], barcodes_file=m["barcodes_file"],
+                  min_merge_fraction=m.get("min_merge_fraction", 0.2)) if m else dict(merge_kind=capi.MERGE_NONE)
+        self.ctx = capi.Context(device=device, min_genes_before_merge=cfg["min_before"],
+                                min_genes_after_merge=cfg["min_after"], gene_match_levels=cfg.get("levels", "eEBA"), **kw)
         self.dev = torch.device("cuda", device)
 
     def empty(self, n, dtype):
@@ -59,18 +68,82 @@ class GpuEngine:
             raise capi.DropestError(rc, self.L.dropest_last_error().decode())
         return out, [int(c) for c in counts]
 
-    def pipeline(self, reads):
-        """Runs the single-GPU path on the owned reads; returns the real-candidate cells."""
+    # ---- the single-GPU path on the owned reads, in the three pieces a sharded run needs ----
+    def ingest(self, reads):
+        """Barcode table + cell ids; returns the key statistics [umi_clean_min, umi_clean_max, umi_escape_max_plus1,
+        gene_max_plus1, chr_max_plus1, gene_chr_conflict] (uint64)."""
         self.torch.cuda.synchronize(self.dev)
         self.ctx.clear_reads()
         self._held = reads            # adopted in place: keep the tensors alive until the next clear
         n = reads[0].numel()
         if n:
             self.ctx.push_reads_device(*[x.data_ptr() for x in reads[:4]], n, adopt=True)
+        self.ctx.ingest()
+        s = self.ctx.ingest_summary()
+        return np.array([s.umi_clean_min, s.umi_clean_max, s.umi_escape_max_plus1, s.gene_max_plus1, s.chr_max_plus1,
+                         s.gene_chr_conflict], np.uint64)
+
+    def set_ingest_summary(self, a):
+        s = capi.IngestSummary(int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), 0)
+        self.ctx.set_ingest_summary(s)
+
+    def gene_chr(self, n):
+        """Copy of the first n entries of the gene -> chromosome table (int32, -1 = unset)."""
+        p, cap = self.ctx.gene_chr_table()
+        out = self.empty(min(n, cap), self.torch.int32)
+        self._copy(out.data_ptr(), p, out.numel() * 4)
+        return out
+
+    def set_gene_chr(self, tensor):
+        p, cap = self.ctx.gene_chr_table()
+        self.torch.cuda.synchronize(self.dev)
+        self._copy(p, tensor.data_ptr(), tensor.numel() * 4)
+
+    def _copy(self, dst, src, nbytes):
+        if nbytes:
+            rc = self.L.dropest_dev_copy_device(self.device, dst, src, nbytes)
+            if rc != 0:
+                raise capi.DropestError(rc, self.L.dropest_last_error().decode())
+
+    def initialize(self):
         self.ctx.set_initialized()
+        return self.ctx.real_candidate_rows()
+
+    def finalize(self):
         self.ctx.merge_and_filter()
-        ids, rows = self.ctx.real_candidate_rows()
-        return ids, rows
+        return self.ctx.real_candidate_rows()
+
+    # ---- whitelist CB merge across shards: local phases (csrc/merge_shard.h) ----
+    def merge_search(self, g_barcode, g_n_genes, g_total_umis, base_global, base_local):
+        return self.ctx.shard_merge_search(g_barcode, g_n_genes, g_total_umis, base_global, base_local)
+
+    def merge_export(self):
+        t = self.torch
+        listed, off, p_low, p_cols = self.ctx.shard_merge_export()
+        n = int(off[-1])
+        low = self.empty(n, t.int64); cols = [self.empty(n, t.int32) for _ in range(4)]
+        self._copy(low.data_ptr(), p_low, n * 8)
+        for c, p in zip(cols, p_cols):
+            self._copy(c.data_ptr(), p, n * 4)
+        return listed, off, low, cols
+
+    def merge_intersect(self, cand_local, base_begin, base_end, low_all):
+        self.torch.cuda.synchronize(self.dev)
+        return self.ctx.shard_merge_intersect(cand_local, base_begin, base_end, low_all.data_ptr())
+
+    def merge_decide(self, inter, n_bases):
+        return self.ctx.shard_merge_decide(inter, n_bases)
+
+    def merge_finish(self, local_id, excluded, merged_away, total_reads, total_umis, move_src, move_tgt, import_rows,
+                     import_cell, low_all, cols_all):
+        t = self.torch
+        idx = t.as_tensor(np.asarray(import_rows, np.int64), device=self.dev)
+        cell = t.as_tensor(np.asarray(import_cell, np.int64), device=self.dev).to(t.int32)
+        low = low_all[idx] if len(import_rows) else self.empty(0, t.int64)
+        cols = [c[idx] if len(import_rows) else self.empty(0, t.int32) for c in cols_all]
+        t.cuda.synchronize(self.dev)
+        self.ctx.shard_merge_finish(local_id, excluded, merged_away, total_reads, total_umis, move_src, move_tgt, len(import_rows),
+                                    cell.data_ptr(), low.data_ptr(), [c.data_ptr() for c in cols])
 
     def matrix(self, filtered, col_ids_expected=None):
         """Local CSC pieces as tensors (rowidx, values) + colptr (numpy)."""
@@ -171,6 +244,26 @@ class Collectives:
             self.dist.all_to_all_single(out, src, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
         return out.to(tensor.device) if out.device != tensor.device else out
 
+    def all_gather_v(self, tensor, counts):
+        """Concatenation of every rank's 1-D tensor (counts[r] elements from rank r), on every rank."""
+        t = self.torch
+        src = self._stage(tensor)
+        kmax = max(list(counts) + [1])
+        pad = t.zeros(kmax, dtype=src.dtype, device=src.device)
+        pad[:src.numel()] = src
+        bufs = [t.empty_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(bufs, pad)
+        out = t.cat([b[:k] for b, k in zip(bufs, counts)])
+        return out.to(tensor.device) if out.device != tensor.device else out
+
+    def all_reduce(self, tensor, op):
+        """In-place all-reduce of a device tensor ("min" / "max")."""
+        src = self._stage(tensor)
+        self.dist.all_reduce(src, op=self.dist.ReduceOp.MIN if op == "min" else self.dist.ReduceOp.MAX)
+        if src is not tensor:
+            tensor.copy_(src)
+        return tensor
+
     def all_gather_rows(self, array):
         """numpy (k, w) int64 per rank -> list of arrays (every rank gets all)."""
         t = self.torch
@@ -229,9 +322,19 @@ class ShardedRun:
         recv_counts = c.all_to_all_counts(send_counts)
         recv = [c.all_to_all_v(x, send_counts, recv_counts) for x in parts]
         t = self._tick("all_to_all", t)
-        # 3. local pipeline on the owned reads
-        ids, rows = e.pipeline(recv)
+        # 3. local pipeline on the owned reads; the shards agree on the key fields before the keys are built
+        summary = e.ingest(recv)
+        if n > 1:
+            self._agree_on_key_fields(summary)
+        t = self._tick("ingest", t)
+        ids, rows = e.initialize()
         t = self._tick("pipeline", t)
+        merge_pairs = None
+        if self.cfg.get("merge"):
+            merge_pairs = self._cb_merge(ids, rows)
+            t = self._tick("cb_merge", t)
+        ids, rows = e.finalize()
+        t = self._tick("finalize", t)
         # 4. global view of the real cells
         offs = np.concatenate([[0], np.cumsum(recv_counts)])
         first_pos = rows["first_read"].astype(np.int64)
@@ -253,7 +356,85 @@ class ShardedRun:
             local_cols = e.filtered_ids().astype(np.int64) if filtered else table[:, 5]
             out[name] = self._gather_matrix(everyone, filtered, colptr, rows_t, vals_t, local_cols)
             t = self._tick("matrix:" + name, t)
+        self.merge_pairs = merge_pairs     # (source barcode, target barcode) of every merged cell, ascending source
         return out["cm"], out["cm_raw"], out["cm"][3] if self.rank == 0 else None
+
+    def _agree_on_key_fields(self, summary):
+        """All shards must lay out the gene / UMI fields of the sort key identically (molecule rows move between
+        shards in a merge) and agree on whether a gene determines its chromosome."""
+        e, c = self.engine, self.coll
+        rows = np.concatenate(c.all_gather_rows(summary.view(np.int64).reshape(1, 6))).view(np.uint64)
+        g = np.array([rows[:, 0].min(), rows[:, 1].max(), rows[:, 2].max(), rows[:, 3].max(), rows[:, 4].max(),
+                      rows[:, 5].max()], np.uint64)
+        n_genes = int(g[3])
+        if n_genes and not g[5]:
+            tmax = e.gene_chr(n_genes)
+            tmin = tmax.clone()
+            tmin[tmin < 0] = 0x7FFFFFFF
+            c.all_reduce(tmax, "max"); c.all_reduce(tmin, "min")
+            if bool(((tmax >= 0) & (tmin != tmax)).any()):
+                g[5] = 1                               # one gene on two chromosomes, seen by different shards
+            else:
+                e.set_gene_chr(tmax)
+        e.set_ingest_summary(g)
+
+    def _cb_merge(self, ids, rows):
+        """RealBarcodes CB merge over all shards (MergeStrategyBase::merge_inited, MergeStrategyBase.cpp:11-57)."""
+        e, c, rank = self.engine, self.coll, self.rank
+        is_real = rows["is_real"].astype(bool)
+        r = rows[is_real]
+        if np.any(r["barcode"] >> np.uint64(63)):
+            raise capi.DropestError(4, "escaped barcodes are not supported in sharded runs yet")
+        # columns: 0 barcode 1 n_genes 2 total_umis 3 total_reads 4 requested_genes 5 requested_umis 6 local id
+        local = np.stack([r["barcode"].astype(np.int64), r["n_genes"].astype(np.int64), r["total_umis"].astype(np.int64),
+                          r["total_reads"].astype(np.int64), r["requested_genes"].astype(np.int64),
+                          r["requested_umis"].astype(np.int64), ids[is_real].astype(np.int64)], axis=1)
+        per_rank = c.all_gather_rows(local)
+        goff = np.concatenate([[0], np.cumsum([len(x) for x in per_rank])]).astype(np.int64)
+        G = np.concatenate(per_rank)
+        nG, lo, hi = len(G), int(goff[rank]), int(goff[rank + 1])
+        # search: my real cells against everybody's
+        pb, pc = e.merge_search(G[:, 0].astype(np.uint64), G[:, 1], G[:, 2], np.arange(lo, hi), G[lo:hi, 6])
+        listed, off, low_t, cols_t = e.merge_export()
+        pairs = c.all_gather_rows(np.stack([pb, pc], axis=1).astype(np.int64))
+        lists = c.all_gather_rows(np.stack([listed, off[:-1], off[1:]], axis=1).astype(np.int64))
+        row_counts = [int(x[:, 2].max()) if len(x) else 0 for x in lists]
+        row_base = np.concatenate([[0], np.cumsum(row_counts)]).astype(np.int64)
+        low_all = c.all_gather_v(low_t, row_counts)
+        cols_all = [c.all_gather_v(x, row_counts) for x in cols_t]
+        beg = np.full(nG, -1, np.int64); end = np.full(nG, -1, np.int64)
+        for q, x in enumerate(lists):
+            if len(x):
+                beg[x[:, 0]] = x[:, 1] + row_base[q]; end[x[:, 0]] = x[:, 2] + row_base[q]
+        # intersect: the pairs whose candidate is mine
+        allp = np.concatenate(pairs) if nG else np.zeros((0, 2), np.int64)
+        poff = np.concatenate([[0], np.cumsum([len(x) for x in pairs])]).astype(np.int64)
+        mine = np.flatnonzero((allp[:, 1] >= lo) & (allp[:, 1] < hi))
+        inter = e.merge_intersect(G[allp[mine, 1], 6], beg[allp[mine, 0]], end[allp[mine, 0]], low_all)
+        answers = c.all_gather_rows(np.stack([mine, inter.astype(np.int64)], axis=1))
+        inter_all = np.zeros(len(allp), np.int64)
+        for x in answers:
+            if len(x):
+                inter_all[x[:, 0]] = x[:, 1]
+        # decide: targets of my bases; then the same sequential application everywhere
+        tgt = e.merge_decide(inter_all[poff[rank]:poff[rank + 1]], hi - lo)
+        target = np.concatenate(c.all_gather_rows(tgt.reshape(-1, 1)))[:, 0] if nG else np.zeros(0, np.int64)
+        order = order_cells(G[:, [4, 5, 2, 0]])               # all real cells are "filtered" before the merge (threshold 0)
+        final, excl, reads, umis = capi.merge_apply(order, target[order], G[:, 3], G[:, 2])
+        final = final.astype(np.int64)
+        me = np.arange(lo, hi)
+        moved = np.flatnonzero(final != np.arange(nG))
+        local_moves = moved[(moved >= lo) & (moved < hi) & (final[moved] >= lo) & (final[moved] < hi)]
+        incoming = moved[((moved < lo) | (moved >= hi)) & (final[moved] >= lo) & (final[moved] < hi)]
+        if np.any(beg[incoming] < 0):
+            raise capi.DropestError(5, "internal: a merged cell's molecule rows were not exported")
+        lens = end[incoming] - beg[incoming]
+        import_rows = (np.concatenate([np.arange(b, b2) for b, b2 in zip(beg[incoming], end[incoming])])
+                       if len(incoming) else np.zeros(0, np.int64))
+        import_cell = np.repeat(G[final[incoming], 6], lens) if len(incoming) else np.zeros(0, np.int64)
+        e.merge_finish(G[me, 6], excl[me], (final[me] != me).astype(np.uint8), reads[me], umis[me], G[local_moves, 6],
+                       G[final[local_moves], 6], import_rows, import_cell, low_all, cols_all)
+        return G[moved, 0].astype(np.uint64), G[final[moved], 0].astype(np.uint64)
 
     def _gather_matrix(self, everyone, filtered, colptr, rows_t, vals_t, local_cols):
         e, c, n = self.engine, self.coll, self.world

@@ -215,6 +215,61 @@ dropest_status dropest_assemble_columns(int device, uint64_t n_cols, const uint6
                                         const uint64_t *len, const uint32_t *d_src_rows, const uint32_t *d_src_vals,
                                         uint32_t *d_dst_rows, uint32_t *d_dst_vals);
 
+/* ---- sharded runs, continued: the two places where shards must agree --------------------------------------
+ * (1) The sort key's gene / UMI fields must have one layout on every shard so that molecule rows can move between
+ *     shards: dropest_ingest runs the first half of set_initialized (barcode table, cell ids, key statistics);
+ *     the caller all-reduces the summary (min of umi_clean_min, max of the rest; the gene -> chromosome tables by
+ *     element-wise min / max, a difference = conflict) and hands it back before dropest_set_initialized.
+ * (2) The whitelist CB merge (RealBarcodesMergeStrategy.cpp:22-114 driven by MergeStrategyBase.cpp:11-57): a
+ *     barcode's target can live on another shard.  Phases, with the caller's collectives between them:
+ *       search    this shard's real cells (bases) against the all-gathered real cells of every shard
+ *       export    molecule rows of the bases that need an intersection size (device arrays owned by the context)
+ *       intersect pairs whose candidate lives here, against all-gathered base rows
+ *       decide    targets of this shard's bases from the intersection sizes of its pairs
+ *       dropest_merge_apply   (no context) the sequential application over the global compare_cells order
+ *       finish    flags / stats of the local cells, local re-keying, import of the rows merged into local cells
+ *     dropest_merge_and_filter then skips its own CB merge and continues with the UMI merge and the filtering. */
+typedef struct {
+	uint64_t umi_clean_min, umi_clean_max;   /* over clean UMI codes (sentinel included); min = ~0 if none */
+	uint64_t umi_escape_max_plus1;           /* 1 + largest escaped UMI index, 0 if none */
+	uint32_t gene_max_plus1, chr_max_plus1;
+	uint32_t gene_chr_conflict, reserved;    /* a gene was counted on two chromosomes */
+} dropest_ingest_summary;
+dropest_status dropest_ingest(dropest_ctx *ctx);
+dropest_status dropest_ingest_summary_get(dropest_ctx *ctx, dropest_ingest_summary *out);
+dropest_status dropest_ingest_summary_set(dropest_ctx *ctx, const dropest_ingest_summary *global);
+/* device table gene id -> chromosome id (0xFFFFFFFF = gene never counted on a chromosome), owned by the context */
+dropest_status dropest_gene_chr_table(dropest_ctx *ctx, uint32_t **d_table, uint64_t *n);
+
+/* g_*[n_global]: packed barcode, gene count and TOTAL_UMIS stat of the real cells of all shards (identical arrays on
+ * every shard); base_global / base_local[n_bases]: this shard's real cells as indices into g_* and as local ids. */
+dropest_status dropest_shard_merge_search(dropest_ctx *ctx, uint64_t n_global, const uint64_t *g_barcode, const uint32_t *g_n_genes,
+                                          const int32_t *g_total_umis, uint64_t n_bases, const uint32_t *base_global,
+                                          const uint32_t *base_local, uint64_t *n_pairs);
+/* the (base, candidate) pairs of the search, as indices into g_*; pairs of one base are adjacent, bases ascending */
+dropest_status dropest_shard_merge_pairs(dropest_ctx *ctx, uint32_t *pair_base_global, uint32_t *pair_cand_global);
+/* rows of the bases that have pairs: listed_global[n_listed], row_offset[n_listed + 1] (arrays may be NULL to query
+ * n_listed); *d_low = gene|UMI key fields, d_cols = {reads, mark, exon reads, intron reads}, row_offset[n_listed] rows */
+dropest_status dropest_shard_merge_export(dropest_ctx *ctx, uint64_t *n_listed, uint32_t *listed_global, uint64_t *row_offset,
+                                          const uint64_t **d_low, const uint32_t *d_cols[4]);
+/* inter[p] = |UMI-genes(base p) n UMI-genes(candidate p)| (MergeStrategyBase.cpp:100-147); the base's rows are
+ * [base_begin[p], base_end[p]) of the device array d_base_low, the candidate is this shard's cell cand_local[p] */
+dropest_status dropest_shard_merge_intersect(dropest_ctx *ctx, uint64_t n_pairs, const uint32_t *cand_local, const uint64_t *base_begin,
+                                             const uint64_t *base_end, const uint64_t *d_base_low, uint32_t *inter);
+/* inter[n_pairs] in the order of dropest_shard_merge_pairs; target_global[n_bases] = index into g_* or -1 (exclude) */
+dropest_status dropest_shard_merge_decide(dropest_ctx *ctx, const uint32_t *inter, int64_t *target_global);
+/* MergeStrategyBase::merge_inited second loop (:30-51) with reassign (:64-82) over n_cells cells: step i merges cell
+ * order[i] into target[i] (or excludes it when -1); total_reads / total_umis are updated as Stats::merge does;
+ * final_target[c] = the cell holding c's molecules afterwards. */
+dropest_status dropest_merge_apply(uint64_t n_cells, uint64_t n_order, const uint32_t *order, const int64_t *target, int32_t *total_reads,
+                                   int32_t *total_umis, uint32_t *final_target, uint8_t *excluded);
+/* local_id[n_local] with their new flags and stats; (move_src -> move_tgt)[n_moves]: merges between two local cells;
+ * n_import device rows (target local cell, gene|UMI fields, {reads, mark, exon, intron}) merged in from other shards */
+dropest_status dropest_shard_merge_finish(dropest_ctx *ctx, uint64_t n_local, const uint32_t *local_id, const uint8_t *excluded,
+                                          const uint8_t *merged_away, const int32_t *total_reads, const int32_t *total_umis,
+                                          uint64_t n_moves, const uint32_t *move_src, const uint32_t *move_tgt, uint64_t n_import,
+                                          const uint32_t *d_cell, const uint64_t *d_low, const uint32_t *const d_cols[4]);
+
 /* ---- instrumentation (no reference counterpart; Tools::trace_time stage stamps, Tools/Logs.cpp:63-71) ---- */
 typedef struct {
 	const char *name;      /* kernel family */

@@ -64,7 +64,21 @@ class CpuEngine:
         out = [r[torch.from_numpy(order)] for r in reads] + [torch.from_numpy(order.astype(np.int32))]
         return out, [int(x) for x in np.bincount(owner, minlength=n_parts)]
 
-    def pipeline(self, reads):
+    def ingest(self, reads):
+        self.reads = reads
+        return np.array([2 ** 63, 0, 0, 0, 0, 0], np.uint64)      # neutral: the oracle container has no key layout
+
+    def set_ingest_summary(self, summary):
+        pass
+
+    def initialize(self):
+        return self._rows()
+
+    def finalize(self):
+        return self._rows()
+
+    def _rows(self):
+        reads = self.reads
         cb = reads[0].numpy().view(np.uint64); umi = reads[1].numpy().view(np.uint64)
         gene = reads[2].numpy().view(np.uint32); aux = reads[3].numpy().view(np.uint32)
         self.o, self.mats = oracle_tables(cb, umi, gene, aux)
