@@ -37,9 +37,10 @@ def parse():
     ap.add_argument("--reads", type=float, default=float(os.environ.get("DROPEST_BENCH_READS", 1e8)),
                     help="reads per GPU (C2: 1e8)")
     ap.add_argument("--cells", type=int, default=0, help="real cells per GPU-share (default: 5000 for c2, 50000 for c3)")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
                     help="c2 (default, the metric's configuration): 10x v2, UMI 10, no CB merge; "
-                         "c3: 10x v3, UMI 12, -m + whitelist merge (use --reads 1e9 for BASELINE's size)")
+                         "c3: 10x v3, UMI 12, -m + whitelist merge (use --reads 1e9 for BASELINE's size); "
+                         "c4: inDrop v3, split 8+8 barcode, UMI 8, -m + whitelist merge (BASELINE: 4 GPUs x 1.25e8 reads)")
     ap.add_argument("--cpu-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_CPU_SAMPLE", 4e6)),
                     help="reads of the same stream timed on the CPU oracle (rank 0, N=1 only; 0 disables)")
     return ap.parse_args()
@@ -94,26 +95,34 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     force_sharded = os.environ.get("DROPEST_BENCH_FORCE_SHARDED") == "1" and "RANK" in os.environ
+    saved_stdout = None
     if world > 1 or force_sharded:
+        # RCCL prints a version banner on stdout when the first communicator comes up; stdout carries exactly one
+        # JSON line, so everything before it goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     reads_per_gpu = int(args.reads)
     total_reads = reads_per_gpu * world
     cfg = {"min_before": 20, "min_after": 100}    # configs/10x.xml:26-27
-    c3 = args.config == "c3"
+    c3, c4 = args.config == "c3", args.config == "c4"
+    merge = c3 or c4
     if not args.cells:
         args.cells = 50000 if c3 else 5000
-    if c3 and world > 1:
-        raise SystemExit("c3 (CB merge) is single-GPU in this revision")
-    stream = SynthStream(n_reads=total_reads, n_cells=args.cells * world, n_genes=30000, cb_len=16,
-                         umi_len=12 if c3 else 10, stream_id=3 if c3 else 2)
+    wl_name = "indrop_v3" if c4 else "10x_aug_2016_split"
+    wl = os.path.join(ROOT, "dropest_amd", "data", "barcodes", wl_name)
+    if merge:
+        cfg["merge"] = {"barcodes_kind": capi.BARCODES_CONST, "barcodes_file": wl, "min_merge_fraction": 0.2}
+    stream = SynthStream(n_reads=total_reads, n_cells=args.cells * world, n_genes=30000, cb_len=16, whitelist=wl_name,
+                         umi_len=12 if c3 else (8 if c4 else 10), stream_id={"c2": 2, "c3": 3, "c4": 4}[args.config])
 
     if world == 1 and not force_sharded:
         from dropest_amd.capi import Context
         dev = stream.generate_device(local_rank, first=0, n=reads_per_gpu)
-        if c3:
-            wl = os.path.join(ROOT, "dropest_amd", "data", "barcodes", "10x_aug_2016_split")
+        if merge:
             ctx = Context(device=local_rank, merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST,
                           barcodes_file=wl, min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"],
                           min_merge_fraction=0.2)
@@ -195,6 +204,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": ("C3: synthetic 10x v3, %d reads/GPU, %d cells/GPU, 16bp CB + 12bp UMI, 30000 genes, "
                                     "-m + 10x whitelist (RealBarcodes merge), -L eEBA" if c3 else
+                                    "C4: synthetic inDrop v3, %d reads/GPU, %d cells/GPU, 8+8bp split CB + 8bp UMI, 30000 genes, "
+                                    "-m + inDrop v3 whitelist (RealBarcodes merge), -L eEBA" if c4 else
                                     "C2: synthetic 10x v2, %d reads/GPU, %d cells/GPU, 16bp CB + 10bp UMI, 30000 genes, "
                                     "no CB merge, -L eEBA") % (reads_per_gpu, args.cells),
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d" % world,
@@ -202,7 +213,10 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kernels,
             "host_stage_wall_ms_per_step": host_stages,
         }
-        print(json.dumps(line))
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -108,7 +108,9 @@ def lib():
         "dropest_umi_distribution": (C.c_int, [vp, u64p, vp, vp]),
         "dropest_collisions_adjusted_sizes": (C.c_int, [C.c_int, vp, C.c_uint64, C.c_uint64, vp]),
         "dropest_owner_of": (C.c_uint32, [C.c_uint64, C.c_uint32]),
-        "dropest_partition_by_owner": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp, vp]),
+        "dropest_partition_by_owner": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_uint64, C.c_uint32, vp, vp, vp, vp, vp, vp, vp,
+                                                 C.c_uint64]),
+        "dropest_partition_scratch_bytes": (C.c_int, [C.c_uint64, u64p]),
         "dropest_clear_reads": (C.c_int, [vp]),
         "dropest_count_matrix_device": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
         "dropest_cell_first_reads_device": (C.c_int, [vp, u64p, P(vp)]),
@@ -119,6 +121,8 @@ def lib():
         "dropest_set_profiling": (C.c_int, [vp, C.c_int]),
         "dropest_sort_layout": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "dropest_stream": (vp, [vp]),
+        "dropest_host_register": (C.c_int, [C.c_int, vp, C.c_uint64, P(vp)]),
+        "dropest_host_unregister": (C.c_int, [C.c_int, vp]),
         "dropest_ingest": (C.c_int, [vp]),
         "dropest_ingest_summary_get": (C.c_int, [vp, P(IngestSummary)]),
         "dropest_ingest_summary_set": (C.c_int, [vp, P(IngestSummary)]),
@@ -152,12 +156,12 @@ EXPORTED_SYMBOLS = [
     "dropest_merge_and_filter", "dropest_reset_results", "dropest_total_cells", "dropest_real_cells",
     "dropest_cell_rows", "dropest_cell_id_by_cb", "dropest_filtered_cells", "dropest_merge_targets",
     "dropest_global_counters", "dropest_cell_molecules", "dropest_molecules", "dropest_count_matrix",
-    "dropest_count_matrix_csc", "dropest_owner_of", "dropest_partition_by_owner", "dropest_clear_reads",
+    "dropest_count_matrix_csc", "dropest_owner_of", "dropest_partition_by_owner", "dropest_partition_scratch_bytes", "dropest_clear_reads",
     "dropest_count_matrix_device", "dropest_cell_first_reads_device", "dropest_assemble_columns",
     "dropest_real_candidate_rows", "dropest_dev_copy_device", "dropest_umi_distribution",
     "dropest_collisions_adjusted_sizes",
     "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_stream",
-    "dropest_sort_layout", "dropest_ingest", "dropest_ingest_summary_get", "dropest_ingest_summary_set",
+    "dropest_sort_layout", "dropest_host_register", "dropest_host_unregister", "dropest_ingest", "dropest_ingest_summary_get", "dropest_ingest_summary_set",
     "dropest_gene_chr_table", "dropest_shard_merge_search", "dropest_shard_merge_pairs", "dropest_shard_merge_export",
     "dropest_shard_merge_intersect", "dropest_shard_merge_decide", "dropest_merge_apply", "dropest_shard_merge_finish",
     "dropest_synth_generate_host", "dropest_synth_generate_device", "dropest_dev_alloc", "dropest_dev_free",

@@ -1269,10 +1269,32 @@ dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *ta
 // ---- multi-GPU building blocks ---------------------------------------------------------------------------------
 uint32_t dropest_owner_of(uint64_t barcode, uint32_t n_parts) { return n_parts ? uint32_t(mix64(barcode) % n_parts) : 0u; }
 
+static void partition_plan(u32 n, u32 &nblocks, u32 &tpb, size_t &off_k1, size_t &off_hist, size_t &off_row, size_t &off_base, size_t &total) {
+	const u32 n_tiles = div_up(n, RS_TILE_REC);
+	nblocks = std::min<u32>(std::max<u32>(n_tiles, 1u), 1024);
+	tpb = div_up(std::max<u32>(n_tiles, 1u), nblocks);
+	nblocks = div_up(std::max<u32>(n_tiles, 1u), tpb);
+	auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
+	off_k1 = up(size_t(n) * 8);
+	off_hist = off_k1 + up(size_t(n) * 8);
+	off_row = off_hist + up(size_t(RS_RADIX) * nblocks * 4);
+	off_base = off_row + up(size_t(RS_RADIX) * 4);
+	total = off_base + up(size_t(RS_RADIX) * 4);
+}
+
+dropest_status dropest_partition_scratch_bytes(uint64_t n, uint64_t *bytes) {
+	return guarded([&] {
+		if (n >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads per GPU");
+		u32 nb, tpb; size_t a, b, c, d, total;
+		partition_plan(u32(n), nb, tpb, a, b, c, d, total);
+		*bytes = total;
+	});
+}
+
 dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene,
                                           const uint32_t *d_aux, uint64_t n64, uint32_t n_parts, uint64_t *d_out_cb,
                                           uint64_t *d_out_umi, uint32_t *d_out_gene, uint32_t *d_out_aux, uint32_t *d_out_idx,
-                                          uint64_t *counts) {
+                                          uint64_t *counts, void *d_scratch, uint64_t scratch_bytes) {
 	return guarded([&] {
 		if (n_parts == 0 || n_parts > 256) throw InvalidError("n_parts must be in 1..256");
 		if (n64 >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads per GPU");
@@ -1280,27 +1302,27 @@ dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, cons
 		const u32 n = u32(n64);
 		for (u32 p = 0; p < n_parts; ++p) counts[p] = 0;
 		if (n == 0) return;
-		// one stable radix pass on the owner digit over (owner, position) records, then a gather of the four arrays
-		DevBuf<u64> k0, k1; DevBuf<u32> v0, v1, hist, row_total, digit_base;
-		k0.alloc(n); k1.alloc(n); v0.alloc(n); v1.alloc(n);
-		const u32 n_tiles = div_up(n, RS_TILE_REC);
-		u32 nblocks = std::min<u32>(n_tiles, 1024);
-		const u32 tpb = div_up(n_tiles, nblocks);
-		nblocks = div_up(n_tiles, tpb);
-		hist.alloc(size_t(RS_RADIX) * nblocks); row_total.alloc(RS_RADIX); digit_base.alloc(RS_RADIX);
+		// one stable keys-only radix pass on the owner digit over (position, owner) records, then a gather of the four arrays
+		u32 nblocks, tpb; size_t off_k1, off_hist, off_row, off_base, total;
+		partition_plan(n, nblocks, tpb, off_k1, off_hist, off_row, off_base, total);
+		if (!d_scratch || scratch_bytes < total) throw InvalidError("partition scratch too small (dropest_partition_scratch_bytes)");
+		char *base = static_cast<char *>(d_scratch);
+		u64 *k0 = reinterpret_cast<u64 *>(base), *k1 = reinterpret_cast<u64 *>(base + off_k1);
+		u32 *hist = reinterpret_cast<u32 *>(base + off_hist), *row_total = reinterpret_cast<u32 *>(base + off_row);
+		u32 *digit_base = reinterpret_cast<u32 *>(base + off_base);
 		hipStream_t st = nullptr;
 		hipLaunchKernelGGL(owner_keys_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st,
-		                   reinterpret_cast<const u64 *>(d_cb), n, n_parts, k0.p, v0.p);
-		hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, st, k0.p, n, 0, tpb, u32(RS_TILE_REC), hist.p);
-		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, st, hist.p, nblocks, row_total.p);
-		hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(256), 0, st, row_total.p, digit_base.p);
-		rs_launch(4, dim3(nblocks), st, k0.p, v0.p, k1.p, v1.p, n, 0, tpb, hist.p, digit_base.p);
-		hipLaunchKernelGGL(gather_reads_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st, v1.p, n,
+		                   reinterpret_cast<const u64 *>(d_cb), n, n_parts, k0);
+		hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, st, k0, n, 0, tpb, u32(RS_TILE_REC), hist);
+		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, st, hist, nblocks, row_total);
+		hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(256), 0, st, row_total, digit_base);
+		rs_launch(0, dim3(nblocks), st, k0, nullptr, k1, nullptr, n, 0, tpb, hist, digit_base);
+		hipLaunchKernelGGL(gather_reads_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st, k1, n,
 		                   reinterpret_cast<const u64 *>(d_cb), reinterpret_cast<const u64 *>(d_umi), d_gene, d_aux,
 		                   reinterpret_cast<u64 *>(d_out_cb), reinterpret_cast<u64 *>(d_out_umi), d_out_gene, d_out_aux, d_out_idx);
 		HIP_CHECK(hipGetLastError());
 		std::vector<u32> totals(RS_RADIX);
-		HIP_CHECK(hipMemcpy(totals.data(), row_total.p, RS_RADIX * 4, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(totals.data(), row_total, RS_RADIX * 4, hipMemcpyDeviceToHost));
 		for (u32 p = 0; p < n_parts; ++p) counts[p] = totals[p];
 	});
 }
@@ -1359,14 +1381,35 @@ dropest_status dropest_assemble_columns(int device, uint64_t n_cols, const uint6
 	return guarded([&] {
 		HIP_CHECK(hipSetDevice(device));
 		if (n_cols == 0) return;
-		DevBuf<u64> d_desc; d_desc.alloc(n_cols * 3);
-		std::vector<u64> desc(n_cols * 3);
-		for (uint64_t c = 0; c < n_cols; ++c) { desc[3 * c] = src_start[c]; desc[3 * c + 1] = dst_start[c]; desc[3 * c + 2] = len[c]; }
-		HIP_CHECK(hipMemcpy(d_desc.p, desc.data(), desc.size() * 8, hipMemcpyHostToDevice));
+		// descriptor scratch: one buffer per device, kept for the life of the library (this runs once per matrix and step)
+		static DevBuf<u64> desc_cache[64];
+		static PinnedBuf<u64> desc_host[64];
+		if (device < 0 || device >= 64) throw InvalidError("device index out of range");
+		DevBuf<u64> &d_desc = desc_cache[device];
+		PinnedBuf<u64> &desc = desc_host[device];
+		d_desc.ensure(n_cols * 3 + n_cols / 2); desc.ensure(n_cols * 3);
+		for (uint64_t c = 0; c < n_cols; ++c) { desc.p[3 * c] = src_start[c]; desc.p[3 * c + 1] = dst_start[c]; desc.p[3 * c + 2] = len[c]; }
+		HIP_CHECK(hipMemcpyAsync(d_desc.p, desc.p, n_cols * 3 * 8, hipMemcpyHostToDevice, nullptr));
 		hipLaunchKernelGGL(assemble_columns_kernel, dim3(u32(n_cols)), dim3(256), 0, nullptr, d_desc.p, d_src_rows, d_src_vals,
 		                   d_dst_rows, d_dst_vals);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipDeviceSynchronize());
+	});
+}
+
+dropest_status dropest_host_register(int device, void *host, uint64_t bytes, void **d_ptr) {
+	return guarded([&] {
+		if (!host || !d_ptr) throw InvalidError("null argument");
+		HIP_CHECK(hipSetDevice(device));
+		HIP_CHECK(hipHostRegister(host, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+		HIP_CHECK(hipHostGetDevicePointer(d_ptr, host, 0));
+	});
+}
+
+dropest_status dropest_host_unregister(int device, void *host) {
+	return guarded([&] {
+		HIP_CHECK(hipSetDevice(device));
+		HIP_CHECK(hipHostUnregister(host));
 	});
 }
 

@@ -206,12 +206,13 @@ __global__ __launch_bounds__(256) void chr_accumulate_kernel(const unsigned long
 }
 
 // ---- multi-GPU: owner keys, stable gather after the owner partition, column assembly ---------------------
+// record = (position << 8) | owner: ONE keys-only radix pass on the low digit groups the reads by owner, stably
 __global__ __launch_bounds__(256) void owner_keys_kernel(const unsigned long long *__restrict__ cb, uint32_t n, uint32_t n_parts,
-                                                         unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                         unsigned long long *__restrict__ keys) {
 	const uint32_t stride = gridDim.x * 256;
-	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) { keys[i] = mix64(cb[i]) % n_parts; vals[i] = i; }
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) keys[i] = ((unsigned long long)i << 8) | (mix64(cb[i]) % n_parts);
 }
-__global__ __launch_bounds__(256) void gather_reads_kernel(const uint32_t *__restrict__ idx, uint32_t n,
+__global__ __launch_bounds__(256) void gather_reads_kernel(const unsigned long long *__restrict__ rec, uint32_t n,
                                                            const unsigned long long *__restrict__ cb, const unsigned long long *__restrict__ umi,
                                                            const uint32_t *__restrict__ gene, const uint32_t *__restrict__ aux,
                                                            unsigned long long *__restrict__ o_cb, unsigned long long *__restrict__ o_umi,
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void gather_reads_kernel(const uint32_t *__res
                                                            uint32_t *__restrict__ o_idx) {
 	const uint32_t stride = gridDim.x * 256;
 	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-		const uint32_t j = idx[i];
+		const uint32_t j = uint32_t(rec[i] >> 8);
 		o_cb[i] = cb[j]; o_umi[i] = umi[j]; o_gene[i] = gene[j]; o_aux[i] = aux[j]; o_idx[i] = j;
 	}
 }

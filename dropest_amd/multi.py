@@ -24,6 +24,7 @@ bases (a few % of all molecules), the intersection sizes and the targets.  Not s
 UMIs with N (the reference's random UMI fill draws from one global rand() sequence).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -61,9 +62,13 @@ class GpuEngine:
         n = reads[0].numel()
         out = [self.empty(n, t.int64), self.empty(n, t.int64), self.empty(n, t.int32), self.empty(n, t.int32), self.empty(n, t.int32)]
         counts = np.zeros(n_parts, np.uint64)
+        need = C.c_uint64()
+        self.L.dropest_partition_scratch_bytes(n, C.byref(need))
+        scratch = self.empty(need.value, t.uint8)           # torch's caching allocator: no hipMalloc per step
         t.cuda.synchronize(self.dev)
         rc = self.L.dropest_partition_by_owner(self.device, *[x.data_ptr() for x in reads], n, n_parts,
-                                               *[x.data_ptr() for x in out], counts.ctypes.data)
+                                               *[x.data_ptr() for x in out], counts.ctypes.data, scratch.data_ptr(),
+                                               need.value)
         if rc != 0:
             raise capi.DropestError(rc, self.L.dropest_last_error().decode())
         return out, [int(c) for c in counts]
@@ -145,10 +150,13 @@ class GpuEngine:
         self.ctx.shard_merge_finish(local_id, excluded, merged_away, total_reads, total_umis, move_src, move_tgt, len(import_rows),
                                     cell.data_ptr(), low.data_ptr(), [c.data_ptr() for c in cols])
 
-    def matrix(self, filtered, col_ids_expected=None):
-        """Local CSC pieces as tensors (rowidx, values) + colptr (numpy)."""
+    def matrix(self, filtered, as_tensors=True):
+        """Local CSC pieces: colptr (numpy) + (rowidx, values) as tensors, or as the context's own device pointers
+        (valid until the next matrix of the same kind)."""
         t = self.torch
         colptr, d_rows, d_vals, nnz = self.ctx.count_matrix_device(filtered=filtered)
+        if not as_tensors:
+            return colptr, d_rows, d_vals
         rows = self.empty(nnz, t.int32); vals = self.empty(nnz, t.int32)
         if nnz:
             for dst, src in ((rows, d_rows), (vals, d_vals)):
@@ -171,6 +179,28 @@ class GpuEngine:
         if rc != 0:
             raise capi.DropestError(rc, self.L.dropest_last_error().decode())
         return dst_rows, dst_vals
+
+    def register_shared(self, buf):
+        addr = buf["host"].ctypes.data
+        d = C.c_void_p()
+        rc = self.L.dropest_host_register(self.device, addr, buf["cap"] * 8, C.byref(d))
+        if rc != 0:
+            raise capi.DropestError(rc, self.L.dropest_last_error().decode())
+        buf["addr"], buf["dptr"] = addr, d.value
+
+    def unregister_shared(self, buf):
+        self.L.dropest_host_unregister(self.device, buf["addr"])
+
+    def write_columns(self, src_start, dst_start, length, src_rows, src_vals, buf):
+        """This rank's columns -> their places in the shared host buffer (a kernel writing mapped host memory)."""
+        self.torch.cuda.synchronize(self.dev)
+        s = np.ascontiguousarray(src_start, np.uint64); d = np.ascontiguousarray(dst_start, np.uint64)
+        ln = np.ascontiguousarray(length, np.uint64)
+        ptr = lambda x: x if isinstance(x, int) or x is None else x.data_ptr()      # noqa: E731
+        rc = self.L.dropest_assemble_columns(self.device, len(s), s.ctypes.data, d.ctypes.data, ln.ctypes.data,
+                                             ptr(src_rows), ptr(src_vals), buf["dptr"], buf["dptr"] + buf["cap"] * 4)
+        if rc != 0:
+            raise capi.DropestError(rc, self.L.dropest_last_error().decode())
 
     def to_numpy_u32(self, tensor, slot=0):
         """Device tensor -> numpy view of a persistent PINNED host buffer (valid until the next call with the same slot):
@@ -244,6 +274,9 @@ class Collectives:
             self.dist.all_to_all_single(out, src, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
         return out.to(tensor.device) if out.device != tensor.device else out
 
+    def barrier(self):
+        self.dist.barrier()
+
     def all_gather_v(self, tensor, counts):
         """Concatenation of every rank's 1-D tensor (counts[r] elements from rank r), on every rank."""
         t = self.torch
@@ -297,6 +330,15 @@ class ShardedRun:
         self.coll = Collectives(dist, rank, world, staging)
         self.resident = self.engine.generate(stream, rank * self.R, self.R)   # this rank's ordinal range, in HBM
         self.trace = None           # set to {} to accumulate per-phase wall times (ms)
+        self.merge_pairs = None
+        # where the final matrices are assembled: "shm" = every rank writes its columns into host memory shared by
+        # the node's ranks; "gather" = RCCL gather onto rank 0's GPU, then one D2H
+        self.output = cfg.get("output") or os.environ.get("DROPEST_SHARD_OUTPUT", "shm")
+        if self.output not in ("shm", "gather"):
+            raise ValueError("output must be 'shm' or 'gather'")
+        self._shm, self._shm_gen = {}, 0
+        tok = self.coll.all_gather_rows(np.array([[os.getpid()]], np.int64))
+        self._token = int(tok[0][0, 0])
 
     def set_profiling(self, on):
         self.engine.set_profiling(on)
@@ -351,7 +393,7 @@ class ShardedRun:
         # 5. local matrices, gathered on rank 0
         out = {}
         for name, filtered in (("cm", True), ("cm_raw", False)):
-            colptr, rows_t, vals_t = e.matrix(filtered)
+            colptr, rows_t, vals_t = e.matrix(filtered, as_tensors=self.output != "shm")
             t = self._tick("emit:" + name, t)
             local_cols = e.filtered_ids().astype(np.int64) if filtered else table[:, 5]
             out[name] = self._gather_matrix(everyone, filtered, colptr, rows_t, vals_t, local_cols)
@@ -436,25 +478,9 @@ class ShardedRun:
                        G[final[local_moves], 6], import_rows, import_cell, low_all, cols_all)
         return G[moved, 0].astype(np.uint64), G[final[moved], 0].astype(np.uint64)
 
-    def _gather_matrix(self, everyone, filtered, colptr, rows_t, vals_t, local_cols):
-        e, c, n = self.engine, self.coll, self.world
-        nnz_local = int(colptr[-1]) if len(colptr) else 0
-        lens = np.diff(colptr.astype(np.int64)) if len(colptr) > 1 else np.zeros(0, np.int64)
-        # tell rank 0 which cell each local column is and how long it is
-        meta = np.stack([local_cols, lens], axis=1) if len(lens) else np.zeros((0, 2), np.int64)
-        import time
-        tt = time.perf_counter()
-        metas = c.all_gather_rows(meta)
-        tt = self._tick("gm:meta_allgather", tt)
-        nnz_all = [int(m[:, 1].sum()) for m in metas]
-        send = [nnz_local if p == 0 else 0 for p in range(n)]
-        recv = nnz_all if self.rank == 0 else [0] * n
-        g_rows = c.all_to_all_v(rows_t, send, recv)
-        g_vals = c.all_to_all_v(vals_t, send, recv)
-        tt = self._tick("gm:gather", tt)
-        if self.rank != 0:
-            return None
-        # global column order on rank 0
+    def _global_columns(self, everyone, metas, filtered):
+        """Global column order of a matrix (identical on every rank): returns the kept cells' rows, and per column its
+        owner rank, its start inside that rank's local arrays and its length."""
         cells = np.concatenate([np.concatenate([np.full((len(t), 1), r, np.int64), t], axis=1) for r, t in enumerate(everyone)])
         # columns: [rank, req_genes, req_umis, total_umis, barcode, first_global, local_id, n_genes]
         if filtered:
@@ -464,31 +490,105 @@ class ShardedRun:
             keep = cells
             order = np.argsort(keep[:, 5], kind="stable")       # cell-id order == first-seen order
         keep = keep[order]
-        # locate every kept column inside the gathered buffer: key = (rank, local cell id)
         keys, starts, lens_all = [], [], []
-        base = 0
         for r, m in enumerate(metas):
             if len(m):
                 keys.append((np.int64(r) << 40) | m[:, 0])
-                starts.append(base + np.concatenate([[0], np.cumsum(m[:, 1])[:-1]]))
+                starts.append(np.concatenate([[0], np.cumsum(m[:, 1])[:-1]]))
                 lens_all.append(m[:, 1])
-            base += nnz_all[r]
-        if keys:
+        if keys and len(keep):
             keys = np.concatenate(keys); starts = np.concatenate(starts); lens_all = np.concatenate(lens_all)
             o = np.argsort(keys, kind="stable")
             pos = np.searchsorted(keys[o], (keep[:, 0] << 40) | keep[:, 6])
             src, ln = starts[o][pos], lens_all[o][pos]
         else:
             src, ln = np.zeros(0, np.int64), np.zeros(0, np.int64)
-        ln = np.asarray(ln, np.int64)
-        dst = np.concatenate([[0], np.cumsum(ln)[:-1]]) if len(ln) else np.zeros(0, np.int64)
+        return keep, keep[:, 0], np.asarray(src, np.int64), np.asarray(ln, np.int64)
+
+    def _shared(self, slot, total):
+        """Host buffer of one matrix, shared by the ranks of the node: a /dev/shm file mapped (and registered with the
+        GPU) by every rank, grown collectively; [rows | vals] uint32 halves of `cap` entries."""
+        import mmap
+        cur = self._shm.get(slot)
+        if cur is not None and cur["cap"] >= total:
+            return cur
+        c, e = self.coll, self.engine
+        if cur is not None:
+            e.unregister_shared(cur)
+            cur["mm"] = None
+        cap = int(total * 1.25) + 4096
+        self._shm_gen += 1
+        path = "/dev/shm/dropest_%d_%d_%d" % (self._token, slot, self._shm_gen)
+        if self.rank == 0:
+            with open(path, "w+b") as f:
+                f.truncate(cap * 8)
+        c.barrier()
+        with open(path, "r+b") as f:
+            mm = mmap.mmap(f.fileno(), cap * 8)
+        c.barrier()
+        if self.rank == 0:
+            os.unlink(path)                     # the mappings keep it alive; nothing is left behind on a crash
+        buf = {"mm": mm, "cap": cap, "host": np.frombuffer(mm, np.uint32)}
+        try:
+            e.register_shared(buf)
+            ok = 1
+        except capi.DropestError as err:          # e.g. a driver that cannot pin tmpfs pages
+            ok, self._shm_error = 0, str(err)
+        if not all(int(x[0, 0]) for x in c.all_gather_rows(np.array([[ok]], np.int64))):
+            if ok:
+                e.unregister_shared(buf)
+            return None
+        self._shm[slot] = buf
+        return buf
+
+    def _gather_matrix(self, everyone, filtered, colptr, rows_t, vals_t, local_cols):
+        e, c, n = self.engine, self.coll, self.world
+        nnz_local = int(colptr[-1]) if len(colptr) else 0
+        lens = np.diff(colptr.astype(np.int64)) if len(colptr) > 1 else np.zeros(0, np.int64)
+        # tell everybody which cell each local column is and how long it is
+        meta = np.stack([local_cols, lens], axis=1) if len(lens) else np.zeros((0, 2), np.int64)
+        import time
+        tt = time.perf_counter()
+        metas = c.all_gather_rows(meta)
+        tt = self._tick("gm:meta_allgather", tt)
+        keep, col_rank, src, ln = self._global_columns(everyone, metas, filtered)
+        dst = np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.int64) if len(ln) else np.zeros(0, np.int64)
         total = int(ln.sum())
-        tt = self._tick("gm:order", tt)
-        a_rows, a_vals = e.assemble(np.asarray(src, np.int64), dst, ln, g_rows, g_vals, total)
-        tt = self._tick("gm:assemble", tt)
         colptr_g = np.concatenate([[0], np.cumsum(ln)]).astype(np.uint64)
-        slot = 0 if filtered else 2
-        res = (colptr_g, e.to_numpy_u32(a_rows, slot), e.to_numpy_u32(a_vals, slot + 1), keep[:, 4].astype(np.uint64))
+        tt = self._tick("gm:order", tt)
+        slot = 0 if filtered else 1
+        if self.output == "shm" and total > 0:
+            # every rank writes ITS columns of the global matrix into the node's shared host buffer: all PCIe links
+            # work at once and no GPU has to hold (or copy out) the whole matrix
+            buf = self._shared(slot, total)
+            if buf is None:
+                if self.rank == 0:
+                    import sys
+                    print("dropest_amd: shared host buffer unavailable (%s); gathering over RCCL instead"
+                          % getattr(self, "_shm_error", "another rank failed"), file=sys.stderr)
+                self.output = "gather"
+                _, rows_t, vals_t = e.matrix(filtered)       # the gather needs tensors, not the context's own arrays
+            else:
+                mine = col_rank == self.rank
+                e.write_columns(src[mine], dst[mine], ln[mine], rows_t, vals_t, buf)
+                c.barrier()
+                tt = self._tick("gm:write_shared", tt)
+                if self.rank != 0:
+                    return None
+                return (colptr_g, buf["host"][:total], buf["host"][buf["cap"]:buf["cap"] + total], keep[:, 4].astype(np.uint64))
+        # "gather": all columns to rank 0's GPU over RCCL (all-to-all(v) with a single receiver), one copy kernel
+        # puts them in the global order, one D2H
+        nnz_all = [int(m[:, 1].sum()) for m in metas]
+        send = [nnz_local if p == 0 else 0 for p in range(n)]
+        recv = nnz_all if self.rank == 0 else [0] * n
+        g_rows = c.all_to_all_v(rows_t, send, recv)
+        g_vals = c.all_to_all_v(vals_t, send, recv)
+        tt = self._tick("gm:gather", tt)
+        if self.rank != 0:
+            return None
+        base = np.concatenate([[0], np.cumsum(nnz_all)]).astype(np.int64)
+        a_rows, a_vals = e.assemble(src + base[col_rank], dst, ln, g_rows, g_vals, total)
+        tt = self._tick("gm:assemble", tt)
+        res = (colptr_g, e.to_numpy_u32(a_rows, 2 * slot), e.to_numpy_u32(a_vals, 2 * slot + 1), keep[:, 4].astype(np.uint64))
         self._tick("gm:d2h", tt)
         return res
-        return colptr_g, e.to_numpy_u32(a_rows, slot), e.to_numpy_u32(a_vals, slot + 1), keep[:, 4].astype(np.uint64)

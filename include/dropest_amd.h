@@ -189,12 +189,14 @@ dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *ta
  * `device`.  dropest_partition_by_owner groups n reads by owner, STABLY (reads of one owner keep their stream
  * order, which keeps first-seen order meaningful after the exchange); out_idx[i] is the position the i-th output
  * read had in the input; counts[p] (host) is the number of reads of owner p.  One all-to-all(v) of the five
- * output arrays (RCCL) is the only data-path collective. */
+ * output arrays (RCCL) is the only data-path collective.  d_scratch: caller-owned device memory of at least
+ * dropest_partition_scratch_bytes(n) bytes (the call allocates nothing). */
 uint32_t dropest_owner_of(uint64_t barcode, uint32_t n_parts);
+dropest_status dropest_partition_scratch_bytes(uint64_t n, uint64_t *bytes);
 dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene,
                                           const uint32_t *d_aux, uint64_t n, uint32_t n_parts, uint64_t *d_out_cb,
-                                          uint64_t *d_out_umi, uint32_t *d_out_gene, uint32_t *d_out_aux,
-                                          uint32_t *d_out_idx, uint64_t *counts);
+                                          uint64_t *d_out_umi, uint32_t *d_out_gene, uint32_t *d_out_aux, uint32_t *d_out_idx,
+                                          uint64_t *counts, void *d_scratch, uint64_t scratch_bytes);
 /* Rows of the real-candidate cells (n_genes >= min_genes_before_merge at set_initialized) with the host-tracked
  * merge state: ids[k] = cell id, rows[k] as dropest_cell_rows would return it.  Ascending cell id. */
 dropest_status dropest_real_candidate_rows(dropest_ctx *ctx, uint64_t *n, uint64_t *ids, dropest_cell_row *rows);
@@ -214,6 +216,12 @@ dropest_status dropest_cell_first_reads_device(dropest_ctx *ctx, uint64_t *n_cel
 dropest_status dropest_assemble_columns(int device, uint64_t n_cols, const uint64_t *src_start, const uint64_t *dst_start,
                                         const uint64_t *len, const uint32_t *d_src_rows, const uint32_t *d_src_vals,
                                         uint32_t *d_dst_rows, uint32_t *d_dst_vals);
+
+/* Host memory shared by the ranks of one node (e.g. a /dev/shm mapping): registered once, then each rank's
+ * dropest_assemble_columns writes ITS columns of the global matrix straight into it through *d_ptr, so the final
+ * matrix reaches the host over all PCIe links at once instead of through one GPU. */
+dropest_status dropest_host_register(int device, void *host, uint64_t bytes, void **d_ptr);
+dropest_status dropest_host_unregister(int device, void *host);
 
 /* ---- sharded runs, continued: the two places where shards must agree --------------------------------------
  * (1) The sort key's gene / UMI fields must have one layout on every shard so that molecule rows can move between

@@ -29,8 +29,9 @@ MERGE_CASES = {
 }
 
 
-def _worker(rank, world, port, path, case=None):
+def _worker(rank, world, port, path, case=None, output="shm"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["DROPEST_SHARD_OUTPUT"] = output
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         if case is None:
@@ -53,10 +54,13 @@ def _worker(rank, world, port, path, case=None):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_context(tmp_path):
+@pytest.mark.parametrize("output", ["shm", "gather"])
+def test_two_ranks_on_one_gpu_match_single_context(output, tmp_path):
+    """output = "shm": every rank writes its columns into host memory shared by the ranks (registered /dev/shm
+    mapping); "gather": the columns are gathered on rank 0's GPU first."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     path = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(2, port, path), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, path, None, output), nprocs=2, join=True)
     got = np.load(path)
     stream = SynthStream(**STREAM)
     dev = stream.generate_device(0)

@@ -92,7 +92,7 @@ class CpuEngine:
         keep = orows[:, 3] >= CFG["min_before"]
         return np.nonzero(keep)[0].astype(np.uint64), rows[keep]
 
-    def matrix(self, filtered):
+    def matrix(self, filtered, as_tensors=True):
         colptr, g, v = self.mats[filtered]
         return colptr.astype(np.uint32), torch.from_numpy(g.astype(np.int32)), torch.from_numpy(v.astype(np.int32))
 
@@ -104,6 +104,18 @@ class CpuEngine:
         for s, d, l in zip(src, dst, ln):
             r[d:d + l] = rows[s:s + l]; v[d:d + l] = vals[s:s + l]
         return r, v
+
+    def register_shared(self, buf):
+        pass
+
+    def unregister_shared(self, buf):
+        pass
+
+    def write_columns(self, src, dst, ln, rows, vals, buf):
+        host, cap = buf["host"], buf["cap"]
+        r = rows.numpy().view(np.uint32); v = vals.numpy().view(np.uint32)
+        for s, d, l in zip(src, dst, ln):
+            host[d:d + l] = r[s:s + l]; host[cap + d:cap + d + l] = v[s:s + l]
 
     def to_numpy_u32(self, t, slot=0):
         return t.numpy().view(np.uint32)
@@ -118,13 +130,13 @@ class CpuEngine:
         return {}
 
 
-def _worker(rank, world, port, result_path):
+def _worker(rank, world, port, result_path, output="shm"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         stream = SynthStream(**STREAM)
         per = STREAM["n_reads"] // world
-        run = ShardedRun(stream, rank, world, 0, per, CFG, dist, engine=CpuEngine())
+        run = ShardedRun(stream, rank, world, 0, per, dict(CFG, output=output), dist, engine=CpuEngine())
         cm, cm_raw, cols = run.step()
         if rank == 0:
             np.savez(result_path, cm_p=cm[0], cm_i=cm[1], cm_x=cm[2], cm_cols=cm[3],
@@ -139,10 +151,10 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_run_matches_single_container(world, tmp_path):
+@pytest.mark.parametrize("world,output", [(2, "shm"), (3, "shm"), (2, "gather")])
+def test_sharded_run_matches_single_container(world, output, tmp_path):
     path = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(world, _free_port(), path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), path, output), nprocs=world, join=True)
     got = np.load(path)
     # reference: ONE oracle container over the whole stream
     stream = SynthStream(**STREAM)
