@@ -154,8 +154,11 @@ def main():
     set_prof(True)
     fence()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         out = step()
+        step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))     # host clock; a step ends with its results on the host
     fence()
     elapsed = time.perf_counter() - t0
     stats = get_stats()
@@ -210,7 +213,7 @@ def main():
                                     "no CB merge, -L eEBA") % (reads_per_gpu, args.cells),
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d" % world,
                        "cm_nnz": int(len(cm[1])), "filtered_cells": int(len(out[2])), "sort_layout": get_layout()},
-            "roofline": roof, "cpu_baseline": cpu, "kernels_ms_per_step": kernels,
+            "roofline": roof, "cpu_baseline": cpu, "step_ms": step_ms, "kernels_ms_per_step": kernels,
             "host_stage_wall_ms_per_step": host_stages,
         }
         if saved_stdout is not None:

@@ -519,10 +519,19 @@ class ShardedRun:
         cap = int(total * 1.25) + 4096
         self._shm_gen += 1
         path = "/dev/shm/dropest_%d_%d_%d" % (self._token, slot, self._shm_gen)
+        made = 1
         if self.rank == 0:
-            with open(path, "w+b") as f:
-                f.truncate(cap * 8)
-        c.barrier()
+            try:
+                with open(path, "w+b") as f:
+                    os.posix_fallocate(f.fileno(), 0, cap * 8)     # reserve the pages now: a full tmpfs must fail here,
+            except OSError as err:                                  # not with SIGBUS in the middle of a write
+                made, self._shm_error = 0, "cannot reserve %d bytes in /dev/shm: %s" % (cap * 8, err)
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+        if not int(c.all_gather_rows(np.array([[made]], np.int64))[0][0, 0]):
+            return None
         with open(path, "r+b") as f:
             mm = mmap.mmap(f.fileno(), cap * 8)
         c.barrier()

@@ -1,0 +1,89 @@
+"""Turns two rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE, collected separately as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes) into profiles/<round>_pmc_summary.csv and the per-launch HBM
+traffic record of the dominant kernel that bench.py quotes (profiles/pmc_rs_scatter.json).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc/fetch -o r -- python bench.py --steps 1 --warmup 0 --cpu-sample 0
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc/write -o r -- python bench.py --steps 1 --warmup 0 --cpu-sample 0
+    python scripts/pmc_summary.py gpurun_out/pmc/fetch gpurun_out/pmc/write profiles r01b 100000000
+
+Corrections (gfx950, calibrated in THIS repo on kernels with exactly known traffic): FETCH_SIZE is in KB and
+under-reports coalesced 8 B/lane loads by 2x (rs_hist_kernel reads exactly 8 B x N); WRITE_SIZE (KB) is exact
+(synth_kernel writes exactly 24 B x N).  The summary keeps the raw and corrected columns side by side.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("dropest::", "")
+    m = re.match(r"([A-Za-z_0-9:]+(<[^(]*>)?)\(", name)
+    name = m.group(1) if m else name.split("(")[0]
+    return name.replace("(anonymous namespace)::", "")
+
+
+def load(directory, counter):
+    files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit("no counter_collection.csv under " + directory)
+    acc = defaultdict(lambda: [0, 0.0])
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            a = acc[short(row["Kernel_Name"])]
+            a[0] += 1
+            a[1] += float(row["Counter_Value"])
+    return acc
+
+
+def main():
+    fetch_dir, write_dir, out_dir, tag, n_records = sys.argv[1:6]
+    n_records = int(float(n_records))
+    fetch, write = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    rows = []
+    for k in sorted(set(fetch) | set(write)):
+        nf, f = fetch.get(k, [0, 0.0]); nw, w = write.get(k, [0, 0.0])
+        n = max(nf, nw)
+        fr = f / nf if nf else 0.0
+        wr = w / nw if nw else 0.0
+        rows.append((k, n, fr, 2.0 * fr, wr, (2.0 * fr + wr) * 1024.0))
+    path = os.path.join(out_dir, tag + "_pmc_summary.csv")
+    with open(path, "w") as out:
+        out.write("# rocprofv3 PMC summary (%s): FETCH_SIZE and WRITE_SIZE in separate passes over one bench.py step of %d reads.\n" % (tag, n_records))
+        out.write("# Units: KB (1024 B) per launch, averaged over the launches of the kernel.  FETCH_KB_corrected = 2 x raw (gfx950;\n")
+        out.write("# calibrated on rs_hist_kernel = 8 B x N reads), WRITE_KB is exact (calibrated on synth_kernel = 24 B x N writes).\n")
+        out.write("kernel,launches,FETCH_KB_raw,FETCH_KB_corrected,WRITE_KB,hbm_bytes_per_launch\n")
+        for r in rows:
+            out.write("%s,%d,%.1f,%.1f,%.1f,%.4g\n" % r)
+    print("wrote", path)
+    # calibration check + dominant kernel record
+    by = {r[0]: r for r in rows}
+    hist = next((r for k, r in by.items() if k.startswith("rs_hist_kernel")), None)
+    if hist:
+        print("calibration: rs_hist FETCH raw %.1f KB vs exact %.1f KB -> x%.3f" % (hist[2], 8.0 * n_records / 1024, 8.0 * n_records / 1024 / hist[2]))
+    variants = {"rs_scatter:keys": (", 0>", 16), "rs_scatter:key+1B": (", 1>", 18), "rs_scatter": (", 4>", 24)}
+    best = None
+    for stat_name, (suffix, bytes_per_rec) in variants.items():
+        for k, r in by.items():
+            if k.startswith("rs_scatter_kernel_t") and k.endswith(suffix) and (best is None or r[1] > best[1][1]):
+                best = (stat_name, r, bytes_per_rec, k)
+    if best:
+        stat_name, r, bpr, k = best
+        rec = {"kernel": k, "kernel_stat_name": stat_name, "records_per_launch": n_records, "workload": tag,
+               "fetch_kb_raw": r[2], "fetch_correction": 2.0, "write_kb": r[4], "hbm_bytes_per_launch": r[5],
+               "algorithmic_bytes_per_launch": float(bpr) * n_records, "amplification": r[5] / (float(bpr) * n_records),
+               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950), calibrated on "
+                         "rs_hist (8 B x N reads) and synth_kernel (24 B x N writes); see profiles/%s_pmc_summary.csv" % tag}
+        with open(os.path.join(out_dir, "pmc_rs_scatter.json"), "w") as out:
+            json.dump(rec, out, indent=1)
+        print("dominant:", json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()
