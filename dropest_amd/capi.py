@@ -12,6 +12,7 @@ NO_GENE = 0xFFFFFFFF
 
 MERGE_NONE, MERGE_REAL_BARCODES = 0, 1
 BARCODES_INDROP, BARCODES_CONST = 0, 1
+UMI_MERGE_SIMPLE, UMI_MERGE_DIRECTIONAL = 0, 1
 
 _STATUS = {1: "INVALID", 2: "RANGE", 3: "DEVICE", 4: "UNSUPPORTED", 5: "IO"}
 
@@ -29,6 +30,7 @@ class Cfg(C.Structure):
         ("min_merge_fraction", C.c_double), ("max_cb_merge_edit_distance", C.c_int32),
         ("umi_merge_kind", C.c_int32), ("max_umi_merge_edit_distance", C.c_int32),
         ("gene_match_levels", C.c_char_p), ("max_cells", C.c_int32), ("cb_table_capacity", C.c_uint64),
+        ("umi_merge_multiplier", C.c_double),
     ]
 
 
@@ -200,7 +202,7 @@ class Context:
     def __init__(self, device=0, merge_kind=MERGE_NONE, barcodes_kind=BARCODES_INDROP, barcodes_file=None,
                  min_genes_before_merge=10, min_genes_after_merge=10, min_merge_fraction=0.2,
                  max_cb_merge_edit_distance=2, max_umi_merge_edit_distance=1, gene_match_levels="eEBA",
-                 max_cells=-1, cb_table_capacity=0):
+                 max_cells=-1, cb_table_capacity=0, umi_merge_kind=UMI_MERGE_SIMPLE, umi_merge_multiplier=2.0):
         self.L = lib()
         self.device = device
         cfg = Cfg()
@@ -213,6 +215,7 @@ class Context:
         cfg.min_merge_fraction = min_merge_fraction; cfg.max_cb_merge_edit_distance = max_cb_merge_edit_distance
         cfg.max_umi_merge_edit_distance = max_umi_merge_edit_distance; cfg.max_cells = max_cells
         cfg.cb_table_capacity = cb_table_capacity
+        cfg.umi_merge_kind = umi_merge_kind; cfg.umi_merge_multiplier = umi_merge_multiplier
         h = C.c_void_p()
         self.h = None
         self._chk(self.L.dropest_ctx_create(C.byref(cfg), C.byref(h)))

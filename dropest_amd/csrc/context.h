@@ -16,6 +16,7 @@
 #include "k_cbhash.h"
 #include "k_collisions.h"
 #include "k_merge.h"
+#include "k_umi_directional.h"
 #include "whitelist.h"
 #include "k_misc.h"
 #include "k_radix.h"
@@ -257,6 +258,13 @@ struct dropest_ctx {
 	                        const uint32_t *const d_cols[4]);
 	void reaggregate_after_merge();
 	void run_umi_merge_simple();
+	struct GatheredGroups { std::vector<u32> size, off, hr, hm, hfirst; std::vector<u64> hk; };
+	void umi_gather_groups(const std::vector<u32> &groups, GatheredGroups &G, const u32 *d_first_table);
+	void umi_patch_groups(const std::vector<u32> &p_idx, const std::vector<u32> &p_all, const std::vector<u32> &p_req,
+	                      const std::vector<u32> &p_rreq, const std::unordered_map<u32, int> &umis_removed);
+	void run_umi_merge_directional();            // -u (umi_directional_host.h)
+	void reaggregate_from_keys(u64 varying_mask); // keys_a / vals_a hold the re-keyed molecule table
+	dropest::DevBuf<u32> umi_first;
 	void fetch_real_cells();
 	void request_filtered(u32 genes_threshold, int max_cells);   // CellsDataContainer::update_filtered_gene_counts, lazily
 	void sort_filtered(u32 genes_threshold, int max_cells);

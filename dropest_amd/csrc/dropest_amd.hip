@@ -67,14 +67,18 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 	min_after = std::max(u32(c.min_genes_after_merge), min_before);   // MergeStrategyAbstract.cpp:8-11
 	if (c.merge_kind != DROPEST_MERGE_NONE && c.merge_kind != DROPEST_MERGE_REAL_BARCODES)
 		throw InvalidError("unknown merge_kind");
-	if (c.umi_merge_kind != DROPEST_UMI_MERGE_SIMPLE) throw UnsupportedError("only the simple UMI merge is built");
+	if (c.umi_merge_kind != DROPEST_UMI_MERGE_SIMPLE && c.umi_merge_kind != DROPEST_UMI_MERGE_DIRECTIONAL)
+		throw InvalidError("unknown umi_merge_kind");
+	if (c.max_umi_merge_edit_distance < 0) throw InvalidError("negative max_umi_merge_edit_distance");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
 		throw DeviceError("no HIP device visible: the dropEst hot path has no CPU implementation");
 	if (c.device < 0 || c.device >= ndev) throw InvalidError("device ordinal out of range");
 	HIP_CHECK(hipSetDevice(c.device));
 	HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-	srand(42);   // MergeUMIsStrategySimple's constructor (MergeUMIsStrategySimple.cpp:15-19): random fills use glibc rand()
+	// MergeUMIsStrategySimple's constructor (MergeUMIsStrategySimple.cpp:15-19): random fills use glibc rand();
+	// MergeUMIsStrategyDirectional does not seed
+	if (c.umi_merge_kind == DROPEST_UMI_MERGE_SIMPLE) srand(42);
 }
 
 dropest_ctx::~dropest_ctx() {
@@ -583,6 +587,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 #include "merge_host.h"
 #include "merge_shard.h"
 #include "umi_merge_host.h"
+#include "umi_directional_host.h"
 
 // ------------------------------------------------------------------------------------------------
 // top-level stages
@@ -622,7 +627,8 @@ void dropest_ctx::run_merge_and_filter() {
 	if (merged) throw InvalidError("merge_and_filter was already run");
 	HostStage hs(this, "merge_and_filter");
 	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells && !external_merge_done) run_cb_merge_real();
-	run_umi_merge_simple();   // MergeUMIsStrategySimple::merge, after the CB merge (CellsDataContainer.cpp:45)
+	// MergeUMIsStrategy*::merge, after the CB merge (CellsDataContainer.cpp:45)
+	if (cfg.umi_merge_kind == DROPEST_UMI_MERGE_DIRECTIONAL) run_umi_merge_directional(); else run_umi_merge_simple();
 	request_filtered(min_after, cfg.max_cells);   // CellsDataContainer.cpp:47-49
 	merged = true;
 	collect_timings();
@@ -716,6 +722,7 @@ void dropest_cfg_defaults(dropest_cfg *cfg) {
 	cfg->min_merge_fraction = 0.2;
 	cfg->max_cb_merge_edit_distance = 2;
 	cfg->umi_merge_kind = DROPEST_UMI_MERGE_SIMPLE;
+	cfg->umi_merge_multiplier = 2.0;
 	cfg->max_umi_merge_edit_distance = 1;
 	cfg->gene_match_levels = "eEBA";
 	cfg->max_cells = -1;

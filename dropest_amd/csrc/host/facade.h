@@ -152,6 +152,17 @@ public:
 	explicit MergeUMIsStrategySimple(unsigned max_merge_distance) : _max_merge_distance(max_merge_distance) {}
 	void fill(dropest_cfg &cfg) const override { cfg.umi_merge_kind = DROPEST_UMI_MERGE_SIMPLE; cfg.max_umi_merge_edit_distance = int(_max_merge_distance); }
 };
+
+// Estimation/Merge/UMIs/MergeUMIsStrategyDirectional.h:44 (-u)
+class MergeUMIsStrategyDirectional : public MergeUMIsStrategyAbstract {
+	double _mult; unsigned _max_edit_distance;
+public:
+	explicit MergeUMIsStrategyDirectional(double mult = 2, unsigned max_edit_distance = 1) : _mult(mult), _max_edit_distance(max_edit_distance) {}
+	void fill(dropest_cfg &cfg) const override {
+		cfg.umi_merge_kind = DROPEST_UMI_MERGE_DIRECTIONAL; cfg.umi_merge_multiplier = _mult;
+		cfg.max_umi_merge_edit_distance = int(_max_edit_distance);
+	}
+};
 }  // namespace UMIs
 }  // namespace Merge
 

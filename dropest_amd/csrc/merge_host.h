@@ -386,9 +386,15 @@ void dropest_ctx::reaggregate_after_merge() {
 	u64 or_and[2];
 	HIP_CHECK(hipMemcpyAsync(or_and, d_or_and, 16, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
+	reaggregate_from_keys(or_and[0] ^ or_and[1]);
+}
+
+// keys_a holds the re-keyed molecule keys, vals_a the row each one came from: sort, fold equal keys (read counts
+// add, marks OR: Gene::merge / UMI::merge, Gene.cpp:26-58, UMI.cpp:15-19), rebuild the (cell, gene) and cell levels.
+void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 	u64 *keys = keys_a.p, *keys_alt = keys_b.p;
 	u32 *vals = vals_a.p, *vals_alt = vals_b.p;
-	radix_sort(keys, vals, keys_alt, vals_alt, n_mol, or_and[0] ^ or_and[1]);
+	radix_sort(keys, vals, keys_alt, vals_alt, n_mol, varying_mask);
 	u32 new_n = 0;
 	if (chr_from_gene) {
 		RekeyedToMoleculesX p{};

@@ -72,6 +72,13 @@ __global__ __launch_bounds__(256) void umi_first_seen_kernel(const unsigned long
 	}
 }
 
+__global__ __launch_bounds__(256) void first_of_keys_kernel(const unsigned long long *__restrict__ keys, uint32_t n,
+                                                           unsigned long long umi_mask, const uint32_t *__restrict__ table,
+                                                           uint32_t *__restrict__ out) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) out[i] = table[keys[i] & umi_mask];
+}
+
 __global__ __launch_bounds__(256) void patch_cg_kernel(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ n_all,
                                                        const uint32_t *__restrict__ n_req, const uint32_t *__restrict__ reads_req,
                                                        uint32_t n, uint32_t *cg_n_all, uint32_t *cg_n_req, uint32_t *cg_reads_req) {
@@ -98,6 +105,68 @@ std::string fix_n_with_random(const std::string &umi) {
 }
 
 }  // namespace
+
+// Molecules of a sorted list of (cell, gene) groups, copied to the host (+ optionally the first read ordinal of
+// each molecule's UMI from a umi_first table).
+void dropest_ctx::umi_gather_groups(const std::vector<u32> &groups, GatheredGroups &G, const u32 *d_first_table) {
+	const u32 n_groups = u32(groups.size());
+	G.size.assign(n_groups, 0); G.off.assign(n_groups, 0);
+	if (!n_groups) return;
+	DevBuf<u32> d_idx, d_begin, d_size, d_off;
+	d_idx.alloc(n_groups); d_begin.alloc(n_groups); d_size.alloc(n_groups); d_off.alloc(n_groups);
+	HIP_CHECK(hipMemcpyAsync(d_idx.p, groups.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
+	hipLaunchKernelGGL(group_extents_kernel, dim3(div_up(n_groups, 256)), dim3(256), 0, stream, d_idx.p, n_groups, cg_mol_begin.p,
+	                   d_begin.p, d_size.p);
+	HIP_CHECK(hipGetLastError());
+	HIP_CHECK(hipMemcpyAsync(G.size.data(), d_size.p, size_t(n_groups) * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	uint64_t total = 0;
+	for (u32 g = 0; g < n_groups; ++g) { G.off[g] = u32(total); total += G.size[g]; }
+	if (total > 0xFFFFFFF0ull) throw UnsupportedError("too many molecules in the groups handled on the host");
+	DevBuf<u64> s_key; DevBuf<u32> s_reads, s_mark, s_first;
+	s_key.alloc(total); s_reads.alloc(total); s_mark.alloc(total);
+	HIP_CHECK(hipMemcpyAsync(d_off.p, G.off.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
+	hipLaunchKernelGGL(gather_groups_kernel, dim3(n_groups), dim3(64), 0, stream, d_begin.p, d_size.p, d_off.p, mol_key.p,
+	                   mol_reads.p, mol_mark.p, s_key.p, s_reads.p, s_mark.p);
+	HIP_CHECK(hipGetLastError());
+	G.hk.resize(total); G.hr.resize(total); G.hm.resize(total);
+	HIP_CHECK(hipMemcpyAsync(G.hk.data(), s_key.p, total * 8, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(G.hr.data(), s_reads.p, total * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(G.hm.data(), s_mark.p, total * 4, hipMemcpyDeviceToHost, stream));
+	if (d_first_table) {
+		s_first.alloc(total);
+		const u64 umask = layout.umi_bits ? ((1ull << layout.umi_bits) - 1ull) : 0ull;
+		hipLaunchKernelGGL(first_of_keys_kernel, dim3(div_up(u32(total), 256)), dim3(256), 0, stream, s_key.p, u32(total), umask,
+		                   d_first_table, s_first.p);
+		HIP_CHECK(hipGetLastError());
+		G.hfirst.resize(total);
+		HIP_CHECK(hipMemcpyAsync(G.hfirst.data(), s_first.p, total * 4, hipMemcpyDeviceToHost, stream));
+	}
+	HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+// Writes the host-decided contents of re-keyed groups back: patched (cell, gene) rows, recomputed cell sizes, and the
+// TOTAL_UMIS decrements of Cell::merge_umis (Cell.cpp:31-42).
+void dropest_ctx::umi_patch_groups(const std::vector<u32> &p_idx, const std::vector<u32> &p_all, const std::vector<u32> &p_req,
+                                   const std::vector<u32> &p_rreq, const std::unordered_map<u32, int> &umis_removed) {
+	const u32 n_groups = u32(p_idx.size());
+	if (n_groups) {
+		DevBuf<u32> d_idx, d_pa, d_pr, d_prr;
+		d_idx.alloc(n_groups); d_pa.alloc(n_groups); d_pr.alloc(n_groups); d_prr.alloc(n_groups);
+		HIP_CHECK(hipMemcpyAsync(d_idx.p, p_idx.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(d_pa.p, p_all.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(d_pr.p, p_req.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(d_prr.p, p_rreq.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
+		hipLaunchKernelGGL(patch_cg_kernel, dim3(div_up(n_groups, 256)), dim3(256), 0, stream, d_idx.p, d_pa.p, d_pr.p, d_prr.p, n_groups,
+		                   cg_n_all.p, cg_n_req.p, cg_reads_req.p);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipStreamSynchronize(stream));   // the host vectors must outlive the copies
+	}
+	reduce_cell_gene_to_cells();
+	HIP_CHECK(hipStreamSynchronize(stream));
+	refresh_real_rows();
+	for (auto &kv : umis_removed) real[real_at(kv.first)].row.total_umis -= kv.second;
+}
 
 void dropest_ctx::run_umi_merge_simple() {
 	umi_overrides.clear();
@@ -126,29 +195,11 @@ void dropest_ctx::run_umi_merge_simple() {
 	std::sort(groups.begin(), groups.end());   // (cell id, gene id) ascending == the reference's iteration order
 
 	// 2. their molecules
-	DevBuf<u32> d_idx, d_begin, d_size, d_off;
-	d_idx.alloc(n_groups); d_begin.alloc(n_groups); d_size.alloc(n_groups); d_off.alloc(n_groups);
-	HIP_CHECK(hipMemcpyAsync(d_idx.p, groups.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
-	hipLaunchKernelGGL(group_extents_kernel, dim3(div_up(n_groups, 256)), dim3(256), 0, stream, d_idx.p, n_groups, cg_mol_begin.p,
-	                   d_begin.p, d_size.p);
-	HIP_CHECK(hipGetLastError());
-	std::vector<u32> size(n_groups), off(n_groups);
-	HIP_CHECK(hipMemcpyAsync(size.data(), d_size.p, size_t(n_groups) * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
-	uint64_t total = 0;
-	for (u32 g = 0; g < n_groups; ++g) { off[g] = u32(total); total += size[g]; }
-	if (total > 0xFFFFFFF0ull) throw UnsupportedError("too many molecules in groups with N-UMIs");
-	DevBuf<u64> s_key; DevBuf<u32> s_reads, s_mark;
-	s_key.alloc(total); s_reads.alloc(total); s_mark.alloc(total);
-	HIP_CHECK(hipMemcpyAsync(d_off.p, off.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
-	hipLaunchKernelGGL(gather_groups_kernel, dim3(n_groups), dim3(64), 0, stream, d_begin.p, d_size.p, d_off.p, mol_key.p,
-	                   mol_reads.p, mol_mark.p, s_key.p, s_reads.p, s_mark.p);
-	HIP_CHECK(hipGetLastError());
-	std::vector<u64> hk(total); std::vector<u32> hr(total), hm(total);
-	HIP_CHECK(hipMemcpyAsync(hk.data(), s_key.p, total * 8, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipMemcpyAsync(hr.data(), s_reads.p, total * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipMemcpyAsync(hm.data(), s_mark.p, total * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	GatheredGroups GG;
+	umi_gather_groups(groups, GG, nullptr);
+	const std::vector<u32> &size = GG.size, &off = GG.off;
+	const std::vector<u64> &hk = GG.hk;
+	const std::vector<u32> &hr = GG.hr, &hm = GG.hm;
 
 	struct Mol { u64 code; std::string seq; u32 reads, mark; bool bad; };
 	std::vector<std::vector<Mol>> G(n_groups);
@@ -256,17 +307,5 @@ void dropest_ctx::run_umi_merge_simple() {
 	}
 
 	// 5. patch the (cell, gene) rows, recompute the cell sizes, apply the TOTAL_UMIS decrements
-	DevBuf<u32> d_pa, d_pr, d_prr;
-	d_pa.alloc(n_groups); d_pr.alloc(n_groups); d_prr.alloc(n_groups);
-	HIP_CHECK(hipMemcpyAsync(d_idx.p, p_idx.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
-	HIP_CHECK(hipMemcpyAsync(d_pa.p, p_all.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
-	HIP_CHECK(hipMemcpyAsync(d_pr.p, p_req.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
-	HIP_CHECK(hipMemcpyAsync(d_prr.p, p_rreq.data(), size_t(n_groups) * 4, hipMemcpyHostToDevice, stream));
-	hipLaunchKernelGGL(patch_cg_kernel, dim3(div_up(n_groups, 256)), dim3(256), 0, stream, d_idx.p, d_pa.p, d_pr.p, d_prr.p, n_groups,
-	                   cg_n_all.p, cg_n_req.p, cg_reads_req.p);
-	HIP_CHECK(hipGetLastError());
-	reduce_cell_gene_to_cells();
-	HIP_CHECK(hipStreamSynchronize(stream));
-	refresh_real_rows();
-	for (auto &kv : umis_removed) real[real_at(kv.first)].row.total_umis -= kv.second;
+	umi_patch_groups(p_idx, p_all, p_req, p_rreq, umis_removed);
 }

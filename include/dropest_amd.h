@@ -65,7 +65,9 @@ enum { DROPEST_MERGE_NONE = 0,          /* DummyMergeStrategy.h:12-17 (no -m) */
 enum { DROPEST_BARCODES_INDROP = 0,     /* InDropBarcodesParser.cpp:15-48 */
        DROPEST_BARCODES_CONST = 1       /* ConstLengthBarcodesParser.cpp:23-68 */ };
 /* UMI-merge strategy (MergeStrategyFactory::get_umi, :105-111) */
-enum { DROPEST_UMI_MERGE_SIMPLE = 0     /* MergeUMIsStrategySimple.cpp:21-102 (fix UMIs with N) */ };
+enum { DROPEST_UMI_MERGE_SIMPLE = 0,      /* MergeUMIsStrategySimple.cpp:21-102 (fix UMIs with N); seeds glibc rand() with 42 */
+       DROPEST_UMI_MERGE_DIRECTIONAL = 1  /* -u: MergeUMIsStrategyDirectional.cpp:18-116; random fills of N-UMIs draw from
+                                             the process's rand() state as found (the reference never seeds it here) */ };
 
 /* Replaces the constructor arguments of CellsDataContainer (CellsDataContainer.h:82-85) together with
  * the Estimation.Merge.* keys read by MergeStrategyFactory (MergeStrategyFactory.cpp:26-58). */
@@ -83,6 +85,7 @@ typedef struct {
 	const char *gene_match_levels;        /* -L code, default "eEBA" (UMI.cpp:112-154) */
 	int32_t max_cells;                    /* -C, <= 0: unlimited (CellsDataContainer.cpp:269-273) */
 	uint64_t cb_table_capacity;           /* 0 = auto; power of two >= 2 x distinct barcodes otherwise */
+	double  umi_merge_multiplier;         /* Estimation.Merge.umi_merge_multiplier, default 2 (MergeStrategyFactory.cpp:58) */
 } dropest_cfg;
 
 typedef struct dropest_ctx dropest_ctx;

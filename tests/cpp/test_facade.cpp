@@ -126,6 +126,21 @@ static void testUMIMergeStrategySimple() {   // :505-540
 	for (auto const &kv : g["Gene2"]) CHECK(kv.first.find('N') == std::string::npos);
 }
 
+static void testUMIMergeStrategyDirectional() {   // :588-608, driven through the container instead of find_targets
+	Fixture f;
+	auto dummy = std::make_shared<Merge::DummyMergeStrategy>(0, 0);
+	auto strat = std::make_shared<Merge::UMIs::MergeUMIsStrategyDirectional>();
+	CellsDataContainer c(dummy, strat, f.any_mark);
+	const std::pair<const char *, int> umis[] = {{"AAA", 2}, {"AAC", 5}, {"AAT", 6}, {"AGT", 20}, {"CCC", 10}, {"TCC", 20}};
+	for (auto const &u : umis) c.add_record(read_info("AAATTAGGTCCA", u.first, "Gene1"));            // UMI-index order as listed
+	for (auto const &u : umis) for (int k = 1; k < u.second; ++k) c.add_record(read_info("AAATTAGGTCCA", u.first, "Gene1"));
+	c.set_initialized();
+	c.merge_and_filter();
+	auto g = by_gene(c.cell(0));
+	CHECK_EQ(g["Gene1"].size(), size_t(3));
+	CHECK_EQ(g["Gene1"]["AGT"], size_t(28)); CHECK_EQ(g["Gene1"]["AAC"], size_t(5)); CHECK_EQ(g["Gene1"]["TCC"], size_t(30));
+}
+
 static void testStateMachineAndParams() {   // CellsDataContainer.cpp:41-42,:61-62,:165-166; Tests/TestTools.cpp:56-87
 	Fixture f;
 	CHECK_THROWS(f.container_full->add_record(read_info("AAAA", "CCCC", "G")), std::runtime_error);
@@ -195,6 +210,7 @@ int main(int argc, char **argv) {
 		testMergeByRealBarcodes();
 		testUmiExclusion();
 		testUMIMergeStrategySimple();
+		testUMIMergeStrategyDirectional();
 		testStateMachineAndParams();
 		testResultsPrinterMtx(tmp);
 		testUmiDistributionAndCollisions();

@@ -451,3 +451,86 @@ def test_collisions_adjuster_table():
         got, want = capi.collisions_adjusted_sizes(w, smax), ob.collisions_table(w, smax)
         assert np.array_equal(got, want), (n, skew)
         assert np.all(np.diff(got.astype(np.int64)) >= 1)                   # adjusted sizes grow with s
+
+
+# ---------------------------------------------------------------------------------------------------
+# -u: MergeUMIsStrategyDirectional (Estimation/Merge/UMIs/MergeUMIsStrategyDirectional.cpp:18-116)
+# ---------------------------------------------------------------------------------------------------
+import ctypes as _C
+
+_libc = _C.CDLL("libc.so.6")
+
+
+def _both_directional(cb, umi, gene, aux, side=(), mult=2.0, max_ed=1, extra_o=None, extra_g=None, min_genes=1):
+    """The directional strategy never seeds rand(): both runs start from the same explicit state (a fresh reference
+    process starts from srand(1))."""
+    okw = dict(umi_merge_kind=1, max_umi_merge_ed=max_ed, umi_mult=mult, min_genes_before=min_genes, min_genes_after=min_genes)
+    gkw = dict(umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL, max_umi_merge_edit_distance=max_ed, umi_merge_multiplier=mult,
+               min_genes_before_merge=min_genes, min_genes_after_merge=min_genes)
+    okw.update(extra_o or {}); gkw.update(extra_g or {})
+    _libc.srand(1)
+    o = parity.oracle_run(Oracle, okw, cb, umi, gene, aux, side)
+    _libc.srand(1)
+    c = parity.gpu_run(gkw, cb, umi, gene, aux, side, profile=True)
+    parity.compare(o, c, side)
+    return o, c
+
+
+def test_directional_reference_fixture_on_gpu():
+    """The UMI list of testUMIMergeStrategyDirectional (Tests/TestEstimation.cpp:588-608) as reads of one (cell, gene):
+    AAA and AAT collapse into AGT, CCC into TCC."""
+    umis = [("AAA", 2), ("AAC", 5), ("AAT", 6), ("AGT", 20), ("CCC", 10), ("TCC", 20)]
+    seqs = [u for u, n in umis for _ in range(n)]
+    # first occurrences in the listed order, the remaining reads shuffled
+    rng = np.random.default_rng(3)
+    rest = [u for u, n in umis for _ in range(n - 1)]
+    rng.shuffle(rest)
+    seqs = [u for u, _ in umis] + rest
+    n = len(seqs)
+    cb = np.full(n, capi.pack_seq("ACGTACGTACGT"), np.uint64)
+    umi = np.array([capi.pack_seq(s) for s in seqs], np.uint64)
+    gene = np.zeros(n, np.uint32); aux = np.full(n, 2 << 16, np.uint32)
+    o, c = _both_directional(cb, umi, gene, aux)
+    _, g, u, r, m = c.molecules()
+    got = {capi.unpack_code(x): int(y) for x, y in zip(u, r)}
+    assert got == {"AGT": 28, "AAC": 5, "TCC": 30}
+    assert int(c.cell_rows()["total_umis"][0]) == 6 - 3                 # one decrement per re-keyed UMI
+
+
+@pytest.mark.parametrize("umi_len,n_genes,max_ed,mult", [(5, 300, 1, 2.0), (6, 150, 2, 1.5), (4, 60, 1, 1.0), (8, 400, 3, 2.0)])
+def test_directional_synthetic(umi_len, n_genes, max_ed, mult):
+    """Short UMIs on few genes: many Hamming-1 neighbours inside a (cell, gene) group, groups of 2..16 UMIs decided on
+    the device and larger ones on the host."""
+    s = SynthStream(n_reads=150_000, n_cells=30, n_genes=n_genes, umi_len=umi_len)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    o, c = _both_directional(cb, umi, gene, aux, mult=mult, max_ed=max_ed, min_genes=5)
+    st = c.kernel_stats()
+    assert "umi_directional" in st and "seg_reduce:molecules_rekeyed" in st      # the device path re-keyed molecules
+    has_gene = gene != capi.NO_GENE
+    distinct = np.unique(np.stack([cb[has_gene], gene[has_gene].astype(np.uint64), umi[has_gene]]), axis=1).shape[1]
+    assert int(c.molecules()[0].shape[0]) < distinct * 0.98                       # UMIs really collapsed
+
+
+def test_directional_with_n_umis_and_cb_merge():
+    """N-UMIs (random fills from rand()) and the whitelist CB merge before the UMI correction."""
+    s = SynthStream(n_reads=150_000, n_cells=25, n_genes=400, umi_len=6, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    umi, side = inject_n(umi, gene, 1e-2, 5, 6)
+    path = os.path.join(DATA, "10x_aug_2016_split")
+    o, c = _both_directional(cb, umi, gene, aux, side, min_genes=3,
+                             extra_o=dict(merge_kind=1, barcodes_kind=1, barcodes_file=path),
+                             extra_g=dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST, barcodes_file=path))
+    assert int((c.merge_targets() != np.arange(c.total_cells_number())).sum()) > 20
+    codes, counts = c.umi_distribution()
+    assert all("N" not in capi.unpack_code(u, side) for u in codes)
+
+
+def test_directional_all_layouts(monkeypatch):
+    for env in (None, "DROPEST_FORCE_BYTE_VALUES", "DROPEST_FORCE_GENERAL_LAYOUT"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        s = SynthStream(n_reads=80_000, n_cells=20, n_genes=200, umi_len=5, permille_intergenic=100)
+        cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+        _both_directional(cb, umi, gene, aux, min_genes=5)
+        if env:
+            monkeypatch.delenv(env)

@@ -167,3 +167,24 @@ def test_random_whitelist_merges(seed, tmp_path):
                             min_genes_before_merge=min_before, min_genes_after_merge=min_before, min_merge_fraction=frac),
                        cb, umi, gene, aux, side)
     parity.compare(o, c, side)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_directional_umi_merge(seed):
+    """-u on adversarial streams: very short UMIs (everything is a neighbour of everything), several UMI lengths in
+    one run (host replay of the banded edit distance), Ns (random fills), hot genes with more than 16 UMIs."""
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    rng = np.random.default_rng(7000 + seed)
+    var_len = seed % 3 == 0
+    cb, umi, gene, aux, side = random_stream(
+        rng, n=int(rng.integers(200, 9000)), n_cb=int(rng.integers(1, 12)), n_gene=int(rng.integers(1, 12)),
+        n_umi=int(rng.integers(2, 120)), umi_len=(3, 5) if var_len else (4, 4), n_rate=0.05 if seed % 2 else 0.0)
+    max_ed, mult = int(rng.integers(1, 4)), float(rng.choice([1.0, 1.5, 2.0, 3.0]))
+    libc.srand(1)
+    o = parity.oracle_run(Oracle, dict(min_genes_before=0, min_genes_after=0, umi_merge_kind=1, max_umi_merge_ed=max_ed,
+                                       umi_mult=mult), cb, umi, gene, aux, side)
+    libc.srand(1)
+    c = parity.gpu_run(dict(min_genes_before_merge=0, min_genes_after_merge=0, umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL,
+                            max_umi_merge_edit_distance=max_ed, umi_merge_multiplier=mult), cb, umi, gene, aux, side)
+    parity.compare(o, c, side)
