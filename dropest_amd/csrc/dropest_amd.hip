@@ -293,14 +293,42 @@ void dropest_ctx::build_keys() {
 // ------------------------------------------------------------------------------------------------
 // stage: radix sort
 // ------------------------------------------------------------------------------------------------
-// 512 threads x 16 records per tile with register prefetch (measured best of seven shapes);
-// one instantiation per value width.
+// Tile shape per value width, by measurement: the narrow records (keys only, key + 1 byte) run best as
+// 512 threads x 8 records without register prefetch (96-112 VGPRs, 45 KB LDS: 3 blocks per CU hide the latency instead);
+// the 12-byte record keeps 512 x 16 with the next tile prefetched into registers (1 block per CU).
 static constexpr int RS_T = 512, RS_I = 16, RS_TILE_REC = RS_T * RS_I;
+// Tile shapes of the keys-only pass (THREADS x ITEMS must equal RS_TILE_REC or divide it: the histogram pass counts per
+// block range, not per tile).  Chosen by measurement; DROPEST_RS_SHAPE=<n> selects another for tuning.
+template <int T, int I, bool PF, int VB>
+static void rs_launch_shape(dim3 grid, hipStream_t st, const u64 *k, const void *v, u64 *ok, void *ov, u32 n, int shift, u32 tpb,
+                            const u32 *hist, const u32 *base) {
+	static_assert(RS_TILE_REC % (T * I) == 0, "shape must tile the histogram ranges");
+	hipLaunchKernelGGL((rs_scatter_kernel_t<T, I, PF, VB>), grid, dim3(T), 0, st, k, v, ok, ov, n, shift, tpb * u32(RS_TILE_REC / (T * I)), hist, base);
+}
+static int rs_shape_override() {
+	static const int shape = [] { const char *e = getenv("DROPEST_RS_SHAPE"); return e ? atoi(e) : -1; }();
+	return shape;
+}
+template <int VB>
+static void rs_launch_vb(int shape, dim3 grid, hipStream_t st, const u64 *k, const void *v, u64 *ok, void *ov, u32 n, int shift, u32 tpb,
+                         const u32 *hist, const u32 *base) {
+	switch (shape) {
+		case 1: return rs_launch_shape<512, 8, true, VB>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+		case 2: return rs_launch_shape<512, 8, false, VB>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+		case 3: return rs_launch_shape<256, 8, false, VB>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+		case 4: return rs_launch_shape<512, 4, false, VB>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+		case 5: return rs_launch_shape<1024, 4, false, VB>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+		case 6: return rs_launch_shape<256, 16, false, VB>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+		case 7: return rs_launch_shape<1024, 8, false, VB>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+		default: return rs_launch_shape<512, 16, true, VB>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+	}
+}
 static void rs_launch(int val_bytes, dim3 grid, hipStream_t st, const u64 *k, const void *v, u64 *ok, void *ov, u32 n, int shift, u32 tpb,
                       const u32 *hist, const u32 *base) {
-	if (val_bytes == 0) hipLaunchKernelGGL((rs_scatter_kernel_t<RS_T, RS_I, true, 0>), grid, dim3(RS_T), 0, st, k, v, ok, ov, n, shift, tpb, hist, base);
-	else if (val_bytes == 1) hipLaunchKernelGGL((rs_scatter_kernel_t<RS_T, RS_I, true, 1>), grid, dim3(RS_T), 0, st, k, v, ok, ov, n, shift, tpb, hist, base);
-	else hipLaunchKernelGGL((rs_scatter_kernel_t<RS_T, RS_I, true, 4>), grid, dim3(RS_T), 0, st, k, v, ok, ov, n, shift, tpb, hist, base);
+	const int o = rs_shape_override();
+	if (val_bytes == 0) rs_launch_vb<0>(o >= 0 ? o : 2, grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+	else if (val_bytes == 1) rs_launch_vb<1>(o >= 0 ? o : 2, grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+	else rs_launch_vb<4>(o >= 0 ? o : 0, grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
 }
 
 void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes) {
