@@ -48,14 +48,15 @@ def build_facade(force=False, verbose=False):
     """g++: the C++ facade (host/facade.cpp, plain host code over the C-ABI) and the reference-style test driver."""
     build(force=False)
     src = os.path.join(CSRC, "host", "facade.cpp")
+    rds = os.path.join(CSRC, "host", "rds_writer.cpp")
     hdr = os.path.join(CSRC, "host", "facade.h")
     test_src = os.path.join(HERE, "..", "tests", "cpp", "test_facade.cpp")
-    newest = max(os.path.getmtime(x) for x in (src, hdr, test_src, LIB))
+    newest = max(os.path.getmtime(x) for x in (src, rds, os.path.join(CSRC, "host", "rds_writer.h"), hdr, test_src, LIB))
     if not force and os.path.exists(FACADE_LIB) and os.path.exists(FACADE_TEST) and \
             min(os.path.getmtime(FACADE_LIB), os.path.getmtime(FACADE_TEST)) > newest:
         return FACADE_LIB, FACADE_TEST
     cmds = [
-        ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, "-o", FACADE_LIB, "-L" + LIB_DIR, "-ldropest_amd",
+        ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, rds, "-o", FACADE_LIB, "-L" + LIB_DIR, "-ldropest_amd", "-lz",
          "-Wl,-rpath,$ORIGIN"],
         ["g++", "-O2", "-std=c++17", "-Wall", test_src, "-o", FACADE_TEST, "-L" + LIB_DIR, "-ldropest_facade", "-ldropest_amd",
          "-Wl,-rpath,$ORIGIN/../../dropest_amd/lib"],

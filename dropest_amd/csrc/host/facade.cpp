@@ -1,5 +1,6 @@
 // facade.cpp -- see facade.h.  Host-side packing and result relaying only; no counting happens here.
 #include "facade.h"
+#include "rds_writer.h"
 
 #include <algorithm>
 #include <cstring>
@@ -370,12 +371,124 @@ void ResultsPrinter::save_mtx(const CellsDataContainer &c, const std::string &ba
 	for (auto const &s : M.row_names) genes << s << '\n';
 }
 
+// The R list `d` of ResultsPrinter::save_results (ResultsPrinter.cpp:23-79), written natively (rds_writer.h) instead
+// of through RInside::saveRDS.  Element names and R types follow the reference; the ORDER of entries inside vectors
+// that the reference fills from unordered_map iteration (merge_targets, aligned_*_per_cell, saturation_info,
+// reads_per_umi_per_cell) is not pinned by anything and is deterministic here: cell-id order, then gene index, then UMI.
+Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
+	using namespace Rds;
+	const size_t n_cells = c.total_cells_number();
+	std::vector<dropest_cell_row> rows(n_cells);
+	if (n_cells && dropest_cell_rows(c.handle(), 0, n_cells, rows.data()) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+	std::vector<size_t> real_ids;
+	std::vector<std::string> real_names;
+	for (size_t i = 0; i < n_cells; ++i) if (rows[i].is_real) { real_ids.push_back(i); real_names.push_back(c.decode(rows[i].barcode)); }
+
+	auto matrix = [&](bool filtered) {
+		const SparseMatrix M = get_count_matrix(c, filtered, true);
+		return dgCMatrix(M.colptr, M.rowidx, M.values, M.row_names, M.col_names);
+	};
+	// reads_per_chr_per_cells: as.data.frame of the cells x chromosomes IntegerMatrix (:144-172, :117-126)
+	auto chr_frame = [&](Stats::CellChrStatType stat) {
+		CellsDataContainer::names_t cells, chrs;
+		CellsDataContainer::counts_t counts;
+		c.get_stat_by_real_cells(stat, cells, chrs, counts);
+		std::vector<std::vector<int32_t>> cols(chrs.size(), std::vector<int32_t>(cells.size()));
+		for (size_t ci = 0; ci < cells.size(); ++ci)
+			for (size_t k = 0; k < chrs.size(); ++k) cols[k][ci] = counts[ci * chrs.size() + k];
+		return data_frame(chrs, cells, std::move(cols));
+	};
+
+	// one walk over the molecules of the real cells feeds mean_reads_per_umi, saturation_info, requested reads and
+	// (for the filtered cells) reads_per_umi_per_cell
+	std::vector<double> mean_rpu(real_ids.size());
+	std::vector<int32_t> sat_reads, req_umis(real_ids.size()), req_reads(real_ids.size());
+	std::vector<std::string> sat_cbs, sat_umis;
+	std::unordered_map<size_t, std::vector<Cell::MoleculeRow>> filtered_mols;
+	std::vector<char> is_filtered(n_cells, 0);
+	for (size_t id : c.filtered_cells()) is_filtered[id] = 1;
+	for (size_t k = 0; k < real_ids.size(); ++k) {
+		const Cell cell = c.cell(real_ids[k]);
+		auto mols = cell.molecules();
+		double reads = 0;
+		size_t rr = 0;
+		for (auto const &m : mols) {
+			reads += double(m.read_count);
+			if (m.mark.match(c.gene_match_level())) {
+				sat_reads.push_back(int32_t(m.read_count)); sat_cbs.push_back(real_names[k]); sat_umis.push_back(m.umi);
+				rr += m.read_count;
+			}
+		}
+		mean_rpu[k] = reads / double(mols.size());                      // :225-249 (0/0 = NaN for a cell without UMIs, as in R)
+		req_umis[k] = int32_t(cell.requested_umis_num());               // :398-431
+		req_reads[k] = int32_t(rr);
+		if (umi_correction_info && is_filtered[real_ids[k]]) filtered_mols.emplace(real_ids[k], std::move(mols));
+	}
+
+	std::vector<std::pair<std::string, ValuePtr>> merged;               // :313-332: list(source barcode = target barcode)
+	{
+		const auto &mt = c.merge_targets();
+		for (size_t i = 0; i < mt.size(); ++i)
+			if (mt[i] != i) merged.emplace_back(c.decode(rows[i].barcode), strings({c.decode(rows[mt[i]].barcode)}));
+	}
+	std::vector<int32_t> aligned_reads(real_ids.size()), aligned_umis(real_ids.size());
+	for (size_t k = 0; k < real_ids.size(); ++k) { aligned_reads[k] = rows[real_ids[k]].total_reads; aligned_umis[k] = rows[real_ids[k]].total_umis; }
+
+	std::vector<std::pair<std::string, ValuePtr>> d = {
+		{"cm", matrix(true)},
+		{"cm_raw", matrix(false)},
+		{"reads_per_chr_per_cells", named_list({{"Exon", chr_frame(Stats::EXON_READS_PER_CHR_PER_CELL)},
+		                                        {"Intron", chr_frame(Stats::INTRON_READS_PER_CHR_PER_CELL)},
+		                                        {"Intergenic", chr_frame(Stats::INTERGENIC_READS_PER_CHR_PER_CELL)}})},
+		{"mean_reads_per_umi", with_names(reals(std::move(mean_rpu)), real_names)},
+		{"saturation_info", named_list({{"reads", integers(std::move(sat_reads))}, {"cbs", strings(std::move(sat_cbs))},
+		                                {"umis", strings(std::move(sat_umis))}})},
+		{"merge_targets", named_list(std::move(merged))},
+		{"aligned_reads_per_cell", with_names(integers(std::move(aligned_reads)), real_names)},
+		{"aligned_umis_per_cell", with_names(integers(std::move(aligned_umis)), real_names)},
+		{"requested_umis_per_cb", with_names(integers(std::move(req_umis)), real_names)},
+		{"requested_reads_per_cb", with_names(integers(std::move(req_reads)), real_names)},
+	};
+	if (umi_correction_info) {
+		// get_reads_per_umi_per_cell (:251-311): filtered cells, requested UMIs; per UMI list(reads, mean quality).  UMI
+		// qualities are not accumulated by this build: the mean quality is numeric(0), what the
+		// reference writes when the BAM carries no UMI quality tag.
+		StringIndexer cell_ix, gene_ix;
+		std::vector<int32_t> cell_indexes, gene_indexes;
+		std::vector<ValuePtr> per_gene;
+		for (size_t id : c.filtered_cells()) {
+			auto it = filtered_mols.find(id);
+			if (it == filtered_mols.end()) continue;
+			const int32_t ci = int32_t(cell_ix.add(c.decode(rows[id].barcode)));
+			std::vector<ValuePtr> umis; std::vector<std::string> umi_names;
+			std::string cur;
+			auto close = [&]() {
+				if (umis.empty()) return;
+				per_gene.push_back(with_names(list(std::move(umis)), std::move(umi_names)));
+				cell_indexes.push_back(ci); gene_indexes.push_back(int32_t(gene_ix.add(cur)));
+				umis.clear(); umi_names.clear();
+			};
+			for (auto const &m : it->second) {
+				if (m.gene != cur) { close(); cur = m.gene; }
+				if (!m.mark.match(c.gene_match_level())) continue;
+				umis.push_back(list({integers({int32_t(m.read_count)}), reals({})}));
+				umi_names.push_back(m.umi);
+			}
+			close();
+		}
+		d.emplace_back("reads_per_umi_per_cell", named_list({{"cells", strings(cell_ix.values())}, {"genes", strings(gene_ix.values())},
+		                                                     {"cell_indexes", integers(std::move(cell_indexes))},
+		                                                     {"gene_indexes", integers(std::move(gene_indexes))},
+		                                                     {"reads_per_umi", list(std::move(per_gene))}}));
+	}
+	return named_list(std::move(d));
+}
+
 void ResultsPrinter::save_results(const CellsDataContainer &c, const std::string &filename) const {   // ResultsPrinter.cpp:23-79
 	std::string base = filename;
 	const size_t dot = filename.find_last_of('.');
 	if (dot != std::string::npos && filename.substr(dot + 1) == "rds") base = filename.substr(0, dot);
-	// The .rds container (R serialisation of list(cm, cm_raw, ...)) is not written yet; the matrix
-	// triple is what -w produces in the reference.
+	Rds::save(results_list(c), base + ".rds");                          // save_rds (:442-452)
 	if (write_matrix) save_mtx(c, base);
 }
 

@@ -26,6 +26,8 @@
 
 #include "../../../include/dropest_amd.h"
 
+namespace Rds { struct Value; }   // rds_writer.h
+
 namespace Tools {
 class ReadParameters {
 	std::string _cb, _umi, _cb_quality, _umi_quality;
@@ -261,21 +263,25 @@ public:
 
 // Count-matrix assembly and the MatrixMarket writer of ResultsPrinter (Estimation/ResultsPrinter.cpp:334-396, :81-91).
 class ResultsPrinter {
-	const bool write_matrix, reads_output;
+	const bool write_matrix, reads_output, umi_correction_info;
 public:
 	struct SparseMatrix {            // dgCMatrix layout (CSC), rows = genes, columns = cells
 		std::vector<std::string> row_names, col_names;
 		std::vector<uint32_t> colptr, rowidx, values;
 	};
-	ResultsPrinter(bool write_matrix_, bool reads_output_, bool /*validation_stats*/ = false, bool /*umi_correction_info*/ = false)
-		: write_matrix(write_matrix_), reads_output(reads_output_) {}
+	ResultsPrinter(bool write_matrix_, bool reads_output_, bool /*validation_stats*/ = false, bool umi_correction_info_ = false)
+		: write_matrix(write_matrix_), reads_output(reads_output_), umi_correction_info(umi_correction_info_) {}
 	// reference_row_order = true reproduces the row order of the reference's dgCMatrix (rows numbered on first
 	// encounter while iterating an unordered_map per cell, Cell.cpp:54-68 + ResultsPrinter.cpp:345-355); false keeps
 	// rows in gene-index order.
 	SparseMatrix get_count_matrix(const CellsDataContainer &container, bool filtered, bool reference_row_order = true) const;
 	// <base>.mtx + <base>.cells.tsv + <base>.genes.tsv (what save_mtx writes through R's Matrix::writeMM)
 	void save_mtx(const CellsDataContainer &container, const std::string &filename_base) const;
+	// <base>.rds: the R list d = list(cm, cm_raw, reads_per_chr_per_cells, mean_reads_per_umi, saturation_info, merge_targets,
+	// aligned_reads_per_cell, aligned_umis_per_cell, requested_umis_per_cb, requested_reads_per_cb[, reads_per_umi_per_cell]),
+	// written natively in R's serialisation format (rds_writer.h); + the matrix triple with write_matrix
 	void save_results(const CellsDataContainer &container, const std::string &filename) const;
+	std::shared_ptr<Rds::Value> results_list(const CellsDataContainer &container) const;
 };
 
 }  // namespace Estimation

@@ -171,6 +171,7 @@ static void testResultsPrinterMtx(const std::string &tmp) {   // ResultsPrinter.
 	CHECK_EQ(dense["AAATTAGGTCCA"]["Gene1"], 2u); CHECK_EQ(dense["AAATTAGGTCCA"]["Gene3"], 2u);
 	CHECK_EQ(dense["AAATTAGGTCCC"]["Gene10"], 1u);
 	printer.save_results(c, tmp + "/cell.counts.rds");
+	ResultsPrinter(false, false, false, true).save_results(c, tmp + "/cell.counts.full.rds");   // + reads_per_umi_per_cell
 	std::ifstream mtx(tmp + "/cell.counts.mtx");
 	std::string header; std::getline(mtx, header);
 	CHECK_EQ(header, std::string("%%MatrixMarket matrix coordinate real general"));
