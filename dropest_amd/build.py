@@ -42,6 +42,7 @@ def build(force=False, verbose=False):
 
 FACADE_LIB = os.path.join(LIB_DIR, "libdropest_facade.so")
 FACADE_TEST = os.path.join(HERE, "..", "tests", "cpp", "test_facade")
+BAM_TOOL = os.path.join(HERE, "..", "tests", "cpp", "bam_to_counts")
 
 
 def build_facade(force=False, verbose=False):
@@ -49,16 +50,21 @@ def build_facade(force=False, verbose=False):
     build(force=False)
     src = os.path.join(CSRC, "host", "facade.cpp")
     rds = os.path.join(CSRC, "host", "rds_writer.cpp")
+    bam = os.path.join(CSRC, "host", "bam_ingest.cpp")
     hdr = os.path.join(CSRC, "host", "facade.h")
     test_src = os.path.join(HERE, "..", "tests", "cpp", "test_facade.cpp")
-    newest = max(os.path.getmtime(x) for x in (src, rds, os.path.join(CSRC, "host", "rds_writer.h"), hdr, test_src, LIB))
-    if not force and os.path.exists(FACADE_LIB) and os.path.exists(FACADE_TEST) and \
-            min(os.path.getmtime(FACADE_LIB), os.path.getmtime(FACADE_TEST)) > newest:
+    bam_tool_src = os.path.join(HERE, "..", "tests", "cpp", "bam_to_counts.cpp")
+    newest = max(os.path.getmtime(x) for x in (src, rds, bam, os.path.join(CSRC, "host", "rds_writer.h"), os.path.join(CSRC, "host", "bam_ingest.h"),
+                                               hdr, test_src, bam_tool_src, LIB))
+    if not force and os.path.exists(FACADE_LIB) and os.path.exists(FACADE_TEST) and os.path.exists(BAM_TOOL) and \
+            min(os.path.getmtime(FACADE_LIB), os.path.getmtime(FACADE_TEST), os.path.getmtime(BAM_TOOL)) > newest:
         return FACADE_LIB, FACADE_TEST
     cmds = [
-        ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, rds, "-o", FACADE_LIB, "-L" + LIB_DIR, "-ldropest_amd", "-lz",
-         "-Wl,-rpath,$ORIGIN"],
+        ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, rds, bam, "-o", FACADE_LIB, "-L" + LIB_DIR, "-ldropest_amd", "-lz",
+         "-lpthread", "-Wl,-rpath,$ORIGIN"],
         ["g++", "-O2", "-std=c++17", "-Wall", test_src, "-o", FACADE_TEST, "-L" + LIB_DIR, "-ldropest_facade", "-ldropest_amd",
+         "-Wl,-rpath,$ORIGIN/../../dropest_amd/lib"],
+        ["g++", "-O2", "-std=c++17", "-Wall", bam_tool_src, "-o", BAM_TOOL, "-L" + LIB_DIR, "-ldropest_facade", "-ldropest_amd",
          "-Wl,-rpath,$ORIGIN/../../dropest_amd/lib"],
     ]
     for cmd in cmds:

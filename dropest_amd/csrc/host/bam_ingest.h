@@ -1,0 +1,76 @@
+// bam_ingest.h -- BAM records -> CellsDataContainer::add_record, without BamTools.
+//
+// Mirrors the part of Estimation::BamProcessing that feeds the container:
+//   BamController::parse_bam_file / process_alignment  (Estimation/BamProcessing/BamController.cpp:70-172)
+//   FilledBamParamsParser::get_read_params (-f: CB / UB tags, FilledBamParamsParser.cpp:12-40)
+//   ReadParamsParser::get_read_params (read name "id!CB#UMI", ReadParamsParser.cpp:20-33)
+//   ReadParamsParser::get_gene / parse_read_type (gene tag + optional read-type tag, :36-90)
+//   BamTags defaults (BamTags.cpp:7-24), Tools::ReadParameters quality check (Tools/ReadParameters.cpp:118-136)
+// Not built: gene annotation from a GTF (-g), the read-parameters file of droptag (-r), filtered BAM output (-F, -b).
+//
+// The container format: BGZF (gzip members with a 'BC' extra field, SAMv1 §4.1) holding the BAM stream (§4.2).
+// Blocks are inflated by a pool of host threads, records are parsed in stream order by the caller's thread (the
+// order of add_record calls defines cell, gene and UMI ids).  Host-only code; zlib.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "facade.h"
+
+namespace Estimation {
+namespace BamProcessing {
+
+struct BamTags {   // BamTags.cpp:7-24 (defaults of the XML config)
+	std::string cell_barcode = "CB", cell_barcode_raw = "CR", umi = "UB", umi_raw = "UR", gene = "GX";
+	std::string cell_barcode_quality = "CQ", umi_quality = "UQ";
+	std::string read_type, intronic_read_value, intergenic_read_value, exonic_read_value;
+};
+
+// One decoded alignment (the fields the path looks at)
+struct BamRecord {
+	int32_t ref_id = -1;
+	uint16_t flag = 0;
+	std::string name;
+	const uint8_t *tags = nullptr;   // aux data, valid until the next record is read
+	size_t tags_size = 0;
+	bool is_mapped() const { return !(flag & 0x4); }
+	bool is_primary() const { return !(flag & 0x100); }
+	// Z / A / H tags as text (BamAlignment::GetTag(tag, std::string&)); false if absent or numeric
+	bool get_string_tag(const std::string &tag, std::string &value, char *type = nullptr) const;
+};
+
+class BamReader {
+	struct Impl;
+	Impl *impl;
+public:
+	explicit BamReader(const std::string &path, unsigned threads = 0);   // throws std::runtime_error("Can't open BAM file: ...")
+	~BamReader();
+	BamReader(const BamReader &) = delete;
+	BamReader &operator=(const BamReader &) = delete;
+	const std::vector<std::string> &reference_names() const;
+	const std::string &header_text() const;
+	bool next(BamRecord &rec);                                           // false at end of file
+};
+
+class BamController {
+public:
+	struct Counters { size_t total_reads = 0, cant_parse = 0, low_quality = 0, saved = 0; };
+private:
+	BamTags _tags;
+	bool _filled_bam, _gene_in_chromosome_name;
+	int _min_barcode_phred;
+	unsigned _threads;
+	Counters _counters;
+public:
+	// gtf_path / read_param_filenames must be empty (not built)
+	BamController(const BamTags &tags, bool filled_bam, const std::string &read_param_filenames, const std::string &gtf_path,
+	              bool gene_in_chromosome_name, int min_barcode_phred, unsigned threads = 0);
+	// BamController::parse_bam_files with a BamProcessor: every accepted read reaches container.add_record in file order
+	void parse_bam_files(const std::vector<std::string> &bam_files, CellsDataContainer &container);
+	const Counters &counters() const { return _counters; }
+};
+
+}  // namespace BamProcessing
+}  // namespace Estimation

@@ -1,0 +1,43 @@
+"""Developer tool: throughput of the native BAM ingest (BGZF inflate on a thread pool + record / tag parsing +
+CellsDataContainer::add_record) on a synthetic 10x-style BAM, next to the estimation and output stages."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np                                   # noqa: E402
+import bam_writer as bw                              # noqa: E402
+from dropest_amd import capi                         # noqa: E402
+from dropest_amd.build import build_facade           # noqa: E402
+from dropest_amd.synth import SynthStream            # noqa: E402
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
+build_facade()
+s = SynthStream(n_reads=n, n_cells=500, n_genes=5000, umi_len=10)
+cb, umi, gene, aux = s.generate_host()
+t0 = time.time()
+refs = [("chr%d" % i, 10_000_000) for i in range(25)]
+cbs = [capi.unpack_code(c) for c in np.unique(cb)]
+cb_of = dict(zip(np.unique(cb).tolist(), cbs))
+recs = []
+for i in range(n):
+    tags = [("CB", "Z", cb_of[int(cb[i])]), ("UB", "Z", capi.unpack_code(umi[i]))]
+    if gene[i] != capi.NO_GENE:
+        tags.append(("GX", "Z", "ENSG%011d" % gene[i]))
+    recs.append(bw.record(int(aux[i]) & 0xFFFF, i, "A00000:1:HXXXX:1:1101:%d:%d" % (i, i), seq="ACGT" * 24 + "AC", tags=tags))
+tmp = tempfile.mkdtemp()
+bam = os.path.join(tmp, "synth.bam")
+bw.write_bam(bam, refs, recs)
+print("wrote %s: %d reads, %.1f MB, %.1f s" % (bam, n, os.path.getsize(bam) / 1e6, time.time() - t0), file=sys.stderr)
+for threads in (1, 4, 16):
+    res = subprocess.run([os.path.join(ROOT, "tests", "cpp", "bam_to_counts"), os.path.join(tmp, "out"), "filled", "20", "100", "-",
+                          str(threads), bam], capture_output=True, text=True)
+    if res.returncode:
+        raise SystemExit(res.stderr)
+    st = json.loads(res.stdout.strip().splitlines()[-1])
+    st.update(threads=threads, ingest_mreads_per_s=round(n / st["ingest_ms"] / 1e3, 3), bam_mb=round(os.path.getsize(bam) / 1e6, 1))
+    print(json.dumps(st))

@@ -1,0 +1,126 @@
+"""BAM ingest without BamTools (dropest_amd/csrc/host/bam_ingest.cpp): BAM -> BamController -> CellsDataContainer ->
+ResultsPrinter, compared with the CPU oracle fed with the same reads through add_record (strings)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from dropest_amd import capi
+from dropest_amd.build import build_facade
+from dropest_amd.synth import SynthStream
+from oracle import Oracle
+
+import bam_writer as bw
+import rds_reader as rr
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tests", "cpp", "bam_to_counts")
+
+
+def _reads(n_reads, seed_cells=20):
+    s = SynthStream(n_reads=n_reads, n_cells=seed_cells, n_genes=300, umi_len=8, permille_intergenic=80, permille_intron=100)
+    cb, umi, gene, aux = s.generate_host()
+    out = []
+    for i in range(n_reads):
+        g = None if gene[i] == capi.NO_GENE else "ENSG%05d" % gene[i]
+        mark = int(aux[i] >> 16) & 7
+        out.append((capi.unpack_code(cb[i]), capi.unpack_code(umi[i]), g, "chr%d" % (int(aux[i]) & 0xFFFF), mark))
+    return out
+
+
+def _oracle(reads, min_before, min_after, wl=None):
+    kw = dict(merge_kind=1, barcodes_kind=1, barcodes_file=wl) if wl else {}
+    o = Oracle(min_genes_before=min_before, min_genes_after=min_after, **kw)
+    for cb, umi, g, chr_, mark in reads:
+        o.add_record(cb, umi, g or "", chr_, mark)
+    o.set_initialized(); o.merge_and_filter()
+    gi, ci, v = o.count_matrix(filtered=True)
+    cols = [o.cell_barcode(int(k)) for k in o.filtered_cells()]
+    return {(o.gene_name(int(g)), cols[int(c)]): int(x) for g, c, x in zip(gi, ci, v)}, cols
+
+
+def _run(tmp_path, mode, bams, min_before, min_after, wl="-", threads=3):
+    build_facade()
+    out = str(tmp_path / "res")
+    res = subprocess.run([TOOL, out, mode, str(min_before), str(min_after), wl, str(threads)] + bams, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    stats = json.loads(res.stdout.strip().splitlines()[-1])
+    d = rr.read_rds(out + ".rds")
+    cm, genes, cells = rr.dgcmatrix_to_dense(d["cm"])
+    got = {(genes[r], cells[c]): int(cm[r, c]) for r, c in zip(*np.nonzero(cm))}
+    return got, cells, stats, d
+
+
+def test_filled_bam_tags(tmp_path):
+    """-f: CB / UB / GX tags + a read-type tag, with every kind of record the controller must skip or count."""
+    reads = _reads(40_000)
+    refs = [("chr%d" % i, 1_000_000) for i in range(25)]
+    recs, kept = [], []
+    rng = np.random.default_rng(1)
+    for i, (cb, umi, g, chr_, mark) in enumerate(reads):
+        rid = int(chr_[3:])
+        # the read-type tag decides the mark when a gene tag is present (ReadParamsParser.cpp:67-90)
+        if g is None:
+            tags, m = [("CB", "Z", cb), ("UB", "Z", umi)], 1                      # no gene tag: gene "", NOT_ANNOTATED
+        else:
+            code, m = (("N", 4) if mark & 4 else ("I", 1) if mark == 1 else ("E", 2))
+            tags = [("xf", "i", 25), ("CB", "Z", cb), ("fx", "B", [1, -2, 3]), ("UB", "Z", umi), ("GX", "Z", g), ("RE", "A", code)]
+        kind = rng.integers(0, 40)
+        if kind == 0:
+            recs.append(bw.record(rid, i, "r%d" % i, flag=4, tags=tags)); continue          # unmapped
+        if kind == 1:
+            recs.append(bw.record(rid, i, "r%d" % i, flag=0x100, tags=tags)); continue      # secondary
+        if kind == 2:
+            recs.append(bw.record(rid, i, "r%d" % i, tags=[t for t in tags if t[0] != "CB"])); continue   # can't parse
+        if kind == 3:
+            recs.append(bw.record(-1, i, "r%d" % i, tags=tags)); continue                   # unknown chromosome id
+        recs.append(bw.record(rid, i, "r%d" % i, flag=16 if i % 2 else 0, tags=tags))
+        kept.append((cb, umi, g, chr_, m))
+    half = len(recs) // 2
+    b1, b2 = str(tmp_path / "a.bam"), str(tmp_path / "b.bam")
+    bw.write_bam(b1, refs, recs[:half], block=40_000)          # records straddle block boundaries
+    bw.write_bam(b2, refs, recs[half:], block=0xFF00)
+    got, cells, stats, d = _run(tmp_path, "filled", [b1, b2], 5, 10)
+    want, cols = _oracle(kept, 5, 10)
+    assert cells == cols and got == want and len(want) > 500
+    assert stats["saved"] == len(kept) and stats["low_quality"] == 0
+    n_skipped = sum(1 for r in recs) - len(kept)
+    assert 0 < stats["cant_parse"] < n_skipped                 # missing CB tag + unknown chromosome; unmapped / secondary are not counted
+    chr_frames = d["reads_per_chr_per_cells"]
+    assert len(chr_frames["Intron"].value) > 0 and len(chr_frames["Intergenic"].value) > 0
+
+
+def test_read_name_encoding_and_whitelist_merge(tmp_path):
+    """Without -f the barcodes come from the read name "id!CB#UMI" (ReadParamsParser.cpp:20-33); with -m + whitelist."""
+    s = SynthStream(n_reads=40_000, n_cells=20, n_genes=300, umi_len=8, permille_neighbour=150)
+    cb, umi, gene, aux = s.generate_host()
+    refs = [("chr%d" % i, 1_000_000) for i in range(25)]
+    recs, kept = [], []
+    for i in range(len(cb)):
+        c, u = capi.unpack_code(cb[i]), capi.unpack_code(umi[i])
+        g = None if gene[i] == capi.NO_GENE else "G%d" % gene[i]
+        chr_ = "chr%d" % (int(aux[i]) & 0xFFFF)
+        tags = [("GX", "Z", g)] if g else []
+        recs.append(bw.record(int(aux[i]) & 0xFFFF, i, "@read%d!%s#%s" % (i, c, u), tags=tags))
+        kept.append((c, u, g, chr_, 2 if g else 1))
+    recs.insert(100, bw.record(0, 0, "no_separator_here", tags=[("GX", "Z", "G1")]))
+    bam = str(tmp_path / "n.bam")
+    bw.write_bam(bam, refs, recs)
+    wl = os.path.join(ROOT, "dropest_amd", "data", "barcodes", "10x_aug_2016_split")
+    got, cells, stats, d = _run(tmp_path, "name", [bam], 3, 10, wl=wl, threads=1)
+    want, cols = _oracle(kept, 3, 10, wl=wl)
+    assert cells == cols and got == want
+    assert stats["cant_parse"] == 1 and stats["saved"] == len(kept)
+    assert len(d["merge_targets"].value) > 10
+
+
+def test_bad_files(tmp_path):
+    build_facade()
+    p = str(tmp_path / "x.bam")
+    open(p, "wb").write(b"not a bam")
+    for bam in (p, str(tmp_path / "missing.bam")):
+        res = subprocess.run([TOOL, str(tmp_path / "o"), "filled", "1", "1", "-", "1", bam], capture_output=True, text=True)
+        assert res.returncode == 1 and "BAM" in res.stderr
