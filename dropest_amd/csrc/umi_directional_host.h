@@ -2,10 +2,9 @@
 // Device part: k_umi_directional.h.  What stays here is the part of
 // MergeUMIsStrategyDirectional (Estimation/Merge/UMIs/MergeUMIsStrategyDirectional.cpp:18-116) whose result depends
 // on library behaviour: groups holding an N-UMI (glibc rand() fills drawn in cell order; the std::unordered_map
-// iteration order of Cell::merge_umis matters once a fill collides with another source), groups of more than 16 UMIs
-// (std::sort's introsort leaves the order of equal read counts implementation-defined) and UMIs of several lengths
-// (the reference's banded edit distance is not a plain Levenshtein there).  Those groups are replayed literally with
-// the same libstdc++ containers and calls.
+// iteration order of Cell::merge_umis matters once a fill collides with another source) and UMIs of several lengths
+// (the reference's banded edit distance is not a plain Levenshtein there).  Those groups are replayed literally with the same libstdc++
+// containers and calls.
 #pragma once
 
 namespace {
@@ -103,8 +102,8 @@ void dropest_ctx::run_umi_merge_directional() {
 	// 2. device decision for the groups it can decide; re-keyed keys land in keys_a
 	keys_a.ensure(n_mol); keys_b.ensure(n_mol); vals_a.ensure(n_mol); vals_b.ensure(n_mol);
 	HIP_CHECK(hipMemcpyAsync(keys_a.p, mol_key.p, size_t(n_mol) * 8, hipMemcpyDeviceToDevice, stream));
-	DevBuf<u32> d_removed, d_list;
-	d_removed.alloc(n_cells); d_list.alloc(n_cg);
+	DevBuf<u32> d_removed, d_list, d_big, d_huge;
+	d_removed.alloc(n_cells); d_list.alloc(n_cg); d_big.alloc(n_cg); d_huge.alloc(n_cg);
 	HIP_CHECK(hipMemsetAsync(d_removed.p, 0, size_t(n_cells) * 4, stream));
 	scalars.ensure(16);
 	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
@@ -115,12 +114,52 @@ void dropest_ctx::run_umi_merge_directional() {
 	a.gene_none = layout.gene_none; a.escape_base = ingest.umi_escape_max_plus1 ? layout.umi_escape_base : ~0ull;
 	a.umi_first = umi_first.p; a.mult = cfg.umi_merge_multiplier; a.max_ed = u32(cfg.max_umi_merge_edit_distance);
 	a.new_key = keys_a.p; a.cell_removed = d_removed.p; a.host_list = d_list.p; a.host_count = scalars.p; a.n_changed = scalars.p + 1;
+	a.big_list = d_big.p; a.big_count = scalars.p + 2; a.huge_list = d_huge.p; a.huge_count = scalars.p + 3;
 	timed("umi_directional", double(n_mol) * 24, [&] {
 		hipLaunchKernelGGL(directional_kernel, dim3(div_up(n_cg, 256)), dim3(256), 0, stream, a);
 	});
-	u32 counts[2] = {0, 0};
-	fetch(counts, scalars.p, 8);
+	u32 counts[4] = {0, 0, 0, 0};
+	fetch(counts, scalars.p, 16);
+	const u32 n_big = counts[2], n_huge = counts[3];
+	DirBigArgs bg{};
+	bg.cg_mol_begin = cg_mol_begin.p; bg.cg_key = cg_key.p; bg.mol_key = mol_key.p; bg.mol_reads = mol_reads.p;
+	bg.gene_bits = layout.gene_bits; bg.umi_bits = layout.umi_bits; bg.umi_len = a.umi_len; bg.umi_first = umi_first.p;
+	bg.mult = a.mult; bg.max_ed = a.max_ed; bg.new_key = keys_a.p; bg.cell_removed = d_removed.p; bg.n_changed = scalars.p + 1;
+	if (n_big) {   // groups of 17 .. 4096 UMIs: one wave each, work arrays in LDS
+		bg.groups = d_big.p; bg.n_groups = n_big;
+		timed("umi_directional:big", double(n_big) * 64 * 14, [&] {
+			hipLaunchKernelGGL(directional_big_kernel, dim3(n_big), dim3(64), 0, stream, bg);
+		});
+	}
+	DevBuf<u32> h_off, h_scratch[4]; DevBuf<int32_t> h_tgt;
+	if (n_huge) {  // beyond that: 256 threads each, work arrays in global scratch
+		std::vector<u32> hg(n_huge), ext_b(n_huge), ext_s(n_huge), off(n_huge);
+		fetch(hg.data(), d_huge.p, size_t(n_huge) * 4);
+		DevBuf<u32> d_b, d_s;
+		d_b.alloc(n_huge); d_s.alloc(n_huge); h_off.alloc(n_huge);
+		hipLaunchKernelGGL(group_extents_kernel, dim3(div_up(n_huge, 256)), dim3(256), 0, stream, d_huge.p, n_huge, cg_mol_begin.p, d_b.p, d_s.p);
+		HIP_CHECK(hipGetLastError());
+		fetch(ext_s.data(), d_s.p, size_t(n_huge) * 4);
+		uint64_t total = 0;
+		for (u32 i = 0; i < n_huge; ++i) { off[i] = u32(total); total += ext_s[i]; }
+		if (total > 0x7FFFFFF0ull) throw UnsupportedError("too many UMIs in very large (cell, gene) groups");
+		for (auto &b : h_scratch) b.alloc(total);
+		h_tgt.alloc(total);
+		HIP_CHECK(hipMemcpyAsync(h_off.p, off.data(), size_t(n_huge) * 4, hipMemcpyHostToDevice, stream));
+		bg.groups = d_huge.p; bg.n_groups = n_huge; bg.scratch_off = h_off.p;
+		bg.s_code = h_scratch[0].p; bg.s_reads = h_scratch[1].p; bg.s_first = h_scratch[2].p; bg.s_ord = h_scratch[3].p; bg.s_tgt = h_tgt.p;
+		timed("umi_directional:huge", double(total) * 20, [&] {
+			hipLaunchKernelGGL(directional_huge_kernel, dim3(n_huge), dim3(256), 0, stream, bg);
+		});
+		HIP_CHECK(hipStreamSynchronize(stream));   // off (host vector) and the scratch buffers outlive the launch
+	}
+	if (n_big || n_huge) fetch(counts, scalars.p, 16);
 	const u32 n_host = counts[0], n_changed = counts[1];
+	if (profiling) {   // group counts by path, reported next to the kernel timings
+		stats["count:umi_groups_host"].launches += n_host; stats["count:umi_groups_wave"].launches += n_big;
+		stats["count:umi_groups_huge"].launches += n_huge;
+		stats["count:umi_rekeyed"].launches += n_changed;
+	}
 	std::vector<u32> groups(n_host);
 	if (n_host) fetch(groups.data(), d_list.p, size_t(n_host) * 4);
 	std::sort(groups.begin(), groups.end());   // (cell id, gene id) ascending == the reference's iteration order

@@ -534,3 +534,26 @@ def test_directional_all_layouts(monkeypatch):
         _both_directional(cb, umi, gene, aux, min_genes=5)
         if env:
             monkeypatch.delenv(env)
+
+
+def test_directional_very_large_groups():
+    """(cell, gene) groups beyond the LDS kernel's 4096 UMIs (one hot gene in one cell) run in the global-scratch kernel:
+    introsort on 5 000+ elements with heavy ties in the read counts, against the oracle's real std::sort."""
+    rng = np.random.default_rng(5)
+    n_umis = [6000, 4097, 4096, 900]                                   # per (cell, gene) group
+    cb, umi, gene = [], [], []
+    for g, k in enumerate(n_umis):
+        codes = rng.choice(4 ** 7, size=k, replace=False).astype(np.uint64) | np.uint64(1 << 14)
+        reps = rng.choice([1, 1, 1, 2, 2, 3, 5, 9], size=k)
+        u = np.repeat(codes, reps)
+        rng.shuffle(u)
+        umi.append(u); gene.append(np.full(len(u), g % 2, np.uint32)); cb.append(np.full(len(u), capi.pack_seq("ACGTACGTAC" + "AC"[g // 2] * 2), np.uint64))
+    cb, umi, gene = np.concatenate(cb), np.concatenate(umi), np.concatenate(gene)
+    perm = rng.permutation(len(cb))
+    cb, umi, gene = cb[perm], umi[perm], gene[perm]
+    aux = np.full(len(cb), 2 << 16, np.uint32)
+    cb, umi, gene, aux = parity.canonical_stream(cb, umi, gene, aux)
+    o, c = _both_directional(cb, umi, gene, aux, min_genes=1)
+    st = c.kernel_stats()
+    assert st["count:umi_groups_huge"]["launches"] == 2 and st["count:umi_groups_wave"]["launches"] == 2
+    assert st["count:umi_groups_host"]["launches"] == 0 and st["count:umi_rekeyed"]["launches"] > 1000
