@@ -128,6 +128,17 @@ public:
 	std::string merge_type() const override { return "No"; }
 	void fill(dropest_cfg &cfg) const override { cfg.merge_kind = DROPEST_MERGE_NONE; }
 };
+// Estimation/Merge/SimpleMergeStrategy.h (-m without a barcodes file)
+class SimpleMergeStrategy : public MergeStrategyAbstract {
+	unsigned _max_ed; double _min_fraction;
+public:
+	SimpleMergeStrategy(size_t min_genes_before_merge, size_t min_genes_after_merge, unsigned max_merge_edit_distance, double min_merge_fraction)
+		: MergeStrategyAbstract(min_genes_before_merge, min_genes_after_merge), _max_ed(max_merge_edit_distance), _min_fraction(min_merge_fraction) {}
+	std::string merge_type() const override { return "Simple"; }
+	void fill(dropest_cfg &cfg) const override {
+		cfg.merge_kind = DROPEST_MERGE_SIMPLE; cfg.max_cb_merge_edit_distance = int(_max_ed); cfg.min_merge_fraction = _min_fraction;
+	}
+};
 class RealBarcodesMergeStrategy : public MergeStrategyAbstract {
 	std::string _file; int _kind; unsigned _max_ed; double _min_fraction;
 public:

@@ -60,7 +60,8 @@ typedef enum {
 
 /* Which CB-merge strategy (MergeStrategyFactory::get_cb_strat, Estimation/Merge/MergeStrategyFactory.cpp:61-103) */
 enum { DROPEST_MERGE_NONE = 0,          /* DummyMergeStrategy.h:12-17 (no -m) */
-       DROPEST_MERGE_REAL_BARCODES = 1  /* RealBarcodesMergeStrategy.cpp (-m + barcodes_file) */ };
+       DROPEST_MERGE_REAL_BARCODES = 1, /* RealBarcodesMergeStrategy.cpp (-m + barcodes_file) */
+       DROPEST_MERGE_SIMPLE = 2         /* SimpleMergeStrategy.cpp (-m without a barcodes file); uses max_cb_merge_edit_distance */ };
 /* Whitelist file flavour (MergeStrategyFactory.cpp:23-59 barcodes_type) */
 enum { DROPEST_BARCODES_INDROP = 0,     /* InDropBarcodesParser.cpp:15-48 */
        DROPEST_BARCODES_CONST = 1       /* ConstLengthBarcodesParser.cpp:23-68 */ };
@@ -79,7 +80,8 @@ typedef struct {
 	int32_t min_genes_before_merge;       /* default 10 in the reference */
 	int32_t min_genes_after_merge;        /* default 10; effective value = max(after, before) (MergeStrategyAbstract.cpp:8-11) */
 	double  min_merge_fraction;           /* default 0.2 */
-	int32_t max_cb_merge_edit_distance;   /* kept for API parity; RealBarcodes ignores it (RealBarcodesMergeStrategy.cpp:111-114) */
+	int32_t max_cb_merge_edit_distance;   /* SimpleMergeStrategy: candidates need edit distance < this (SimpleMergeStrategy.cpp:68-69);
+	                                         RealBarcodes ignores it (RealBarcodesMergeStrategy.cpp:111-114) */
 	int32_t umi_merge_kind;               /* DROPEST_UMI_MERGE_* */
 	int32_t max_umi_merge_edit_distance;  /* default 1 */
 	const char *gene_match_levels;        /* -L code, default "eEBA" (UMI.cpp:112-154) */

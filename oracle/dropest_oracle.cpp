@@ -324,12 +324,12 @@ struct Whitelist {
 // ----------------------------------------------------------------------------------------------
 
 struct Config {
-	int merge_kind = 0;          // 0 = none (DummyMergeStrategy), 1 = RealBarcodes
+	int merge_kind = 0;          // 0 = none (DummyMergeStrategy), 1 = RealBarcodes, 2 = Simple (-m without a whitelist)
 	int barcodes_kind = 0;       // Whitelist::Kind
 	std::string barcodes_file;
 	size_t min_genes_before = 10, min_genes_after = 10;   // MergeStrategyFactory.cpp:26-58 defaults
 	double min_merge_fraction = 0.2;
-	int max_cb_merge_ed = 0;     // ignored by RealBarcodes (RealBarcodesMergeStrategy.cpp:111-114)
+	int max_cb_merge_ed = 0;     // ignored by RealBarcodes (RealBarcodesMergeStrategy.cpp:111-114); used by Simple
 	int umi_merge_kind = 0;      // 0 = MergeUMIsStrategySimple (N fix), 1 = Directional
 	unsigned max_umi_merge_ed = 1;
 	double umi_mult = 2.0;       // MergeUMIsStrategyDirectional default multiplier
@@ -515,6 +515,42 @@ struct Container {
 		return long(best);
 	}
 
+	// SimpleMergeStrategy (Estimation/Merge/SimpleMergeStrategy.cpp).  The reference keys its inverted index with
+	// Tools::PairHash, whose seed is an uninitialised local (UtilFunctions.h:36-41); the index is only ever probed with
+	// emplace / at, never iterated, so any consistent hash gives the same results -- std::map is used here.  What DOES
+	// shape the result is the iteration order of the two unordered containers keyed by cell id (identity hash), kept.
+	std::map<std::pair<size_t, size_t>, std::unordered_set<size_t>> cell_ids_by_umig;
+	void simple_init() {                                       // SimpleMergeStrategy::init (:88-102)
+		cell_ids_by_umig.clear();
+		for (size_t cell_id : filtered)
+			for (auto const &g : cells[cell_id].genes)
+				for (auto const &u : g.second)
+					cell_ids_by_umig[std::make_pair(u.first, g.first)].emplace(cell_id);
+	}
+	long simple_merge_target(size_t base) const {              // get_cells_with_common_umigs + get_merge_target (:16-86)
+		const double EPS = 0.00001;
+		std::unordered_map<size_t, size_t> common;
+		for (auto const &g : cells[base].genes)
+			for (auto const &u : g.second)
+				for (size_t other : cell_ids_by_umig.at(std::make_pair(u.first, g.first))) {
+					if (other == base) continue;
+					if (cells[other].genes.size() >= cells[base].genes.size()) common[other]++;
+				}
+		long top = -1, top_genes = -1;
+		double top_frac = -1;
+		for (auto const &c : common) {
+			const size_t ind = c.first;
+			const double frac = 0.5 * c.second * (1. / umis_number(cells[base]) + 1. / umis_number(cells[ind]));
+			if (frac - top_frac > EPS || (std::abs(frac - top_frac) < EPS && long(cells[ind].genes.size()) > top_genes)) {
+				const int ed = int(edit_distance(cells[base].barcode.c_str(), cells[ind].barcode.c_str()));
+				if (ed >= cfg.max_cb_merge_ed) continue;
+				top = long(ind); top_frac = frac; top_genes = long(cells[ind].genes.size());
+			}
+		}
+		if (top_frac < cfg.min_merge_fraction) return long(base);
+		return top;
+	}
+
 	// MergeStrategyBase.cpp:11-57, :64-82 ; DummyMergeStrategy.h:12-17
 	std::vector<size_t> run_cb_merge() {
 		std::vector<size_t> reassign(cells.size());
@@ -523,7 +559,10 @@ struct Container {
 
 		std::unordered_map<size_t, std::unordered_set<size_t>> reassigned_to;
 		std::vector<long> targets(filtered.size());
-		for (size_t i = 0; i < filtered.size(); ++i) targets[i] = real_merge_target(filtered[i]);
+		if (cfg.merge_kind == 2) simple_init();
+		for (size_t i = 0; i < filtered.size(); ++i)
+			targets[i] = cfg.merge_kind == 2 ? simple_merge_target(filtered[i]) : real_merge_target(filtered[i]);
+		cell_ids_by_umig.clear();
 
 		for (size_t i = 0; i < filtered.size(); ++i) {
 			const size_t base = filtered[i];

@@ -557,3 +557,49 @@ def test_directional_very_large_groups():
     st = c.kernel_stats()
     assert st["count:umi_groups_huge"]["launches"] == 2 and st["count:umi_groups_wave"]["launches"] == 2
     assert st["count:umi_groups_host"]["launches"] == 0 and st["count:umi_rekeyed"]["launches"] > 1000
+
+
+# ---------------------------------------------------------------------------------------------------
+# -m without a whitelist: SimpleMergeStrategy (Estimation/Merge/SimpleMergeStrategy.cpp)
+# ---------------------------------------------------------------------------------------------------
+def _both_simple(cb, umi, gene, aux, side=(), max_ed=2, frac=0.2, min_before=3, min_after=10):
+    o = parity.oracle_run(Oracle, dict(merge_kind=2, max_cb_merge_ed=max_ed, min_merge_fraction=frac, min_genes_before=min_before,
+                                       min_genes_after=min_after), cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=max_ed, min_merge_fraction=frac,
+                            min_genes_before_merge=min_before, min_genes_after_merge=min_after), cb, umi, gene, aux, side, profile=True)
+    parity.compare(o, c, side)
+    return o, c
+
+
+@pytest.mark.parametrize("max_ed,frac,umi_len", [(2, 0.2, 8), (3, 0.05, 8), (7, 0.0, 6), (2, 0.2, 5)])
+def test_simple_merge_synthetic(max_ed, frac, umi_len):
+    """Hamming-1 error barcodes share their cell's molecules: they merge into it when no whitelist is given.  Short
+    UMIs add chance collisions between unrelated cells (near-tie replays); frac = 0 keeps every candidate alive."""
+    s = SynthStream(n_reads=150_000, n_cells=25, n_genes=1200, umi_len=umi_len, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    o, c = _both_simple(cb, umi, gene, aux, max_ed=max_ed, frac=frac)
+    mt = c.merge_targets()
+    assert int((mt != np.arange(len(mt))).sum()) > 300
+    assert int(c.cell_rows()["is_excluded"].sum()) == 0                    # this strategy never excludes
+
+
+def test_simple_merge_ties_are_replayed():
+    """Few distinct UMIs and genes: many candidates with exactly equal fractions and sizes, so the reference's answer
+    hangs on the iteration order of its unordered containers -- the replay path must reproduce it."""
+    s = SynthStream(n_reads=60_000, n_cells=12, n_genes=40, umi_len=3, permille_neighbour=250)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    o, c = _both_simple(cb, umi, gene, aux, max_ed=17, frac=0.0, min_before=1, min_after=1)
+    assert "host:cb_merge:replay" in c.kernel_stats()
+
+
+def test_simple_merge_with_n_and_directional():
+    s = SynthStream(n_reads=100_000, n_cells=20, n_genes=600, umi_len=6, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    umi, side = inject_n(umi, gene, 5e-3, 9, 6)
+    _libc.srand(1)
+    o = parity.oracle_run(Oracle, dict(merge_kind=2, max_cb_merge_ed=2, umi_merge_kind=1, min_genes_before=3, min_genes_after=10),
+                          cb, umi, gene, aux, side)
+    _libc.srand(1)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=2, umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL,
+                            min_genes_before_merge=3, min_genes_after_merge=10), cb, umi, gene, aux, side)
+    parity.compare(o, c, side)

@@ -188,3 +188,20 @@ def test_random_directional_umi_merge(seed):
     c = parity.gpu_run(dict(min_genes_before_merge=0, min_genes_after_merge=0, umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL,
                             max_umi_merge_edit_distance=max_ed, umi_merge_multiplier=mult), cb, umi, gene, aux, side)
     parity.compare(o, c, side)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_simple_merge(seed):
+    """-m without a whitelist on adversarial streams (few UMIs and genes: many exact ties, barcodes with N, variable
+    barcode lengths, every edit-distance threshold)."""
+    rng = np.random.default_rng(9000 + seed)
+    cb, umi, gene, aux, side = random_stream(
+        rng, n=int(rng.integers(300, 8000)), n_cb=int(rng.integers(2, 40)), n_gene=int(rng.integers(1, 15)),
+        n_umi=int(rng.integers(2, 60)), cb_len=(6, 8) if seed % 3 == 0 else (8, 8), cb_n_rate=0.02 if seed % 2 else 0.0)
+    max_ed, frac = int(rng.integers(0, 10)), float(rng.choice([0.0, 0.05, 0.2, 0.5]))
+    mb = int(rng.integers(0, 3))
+    o = parity.oracle_run(Oracle, dict(merge_kind=2, max_cb_merge_ed=max_ed, min_merge_fraction=frac, min_genes_before=mb,
+                                       min_genes_after=mb), cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=max_ed, min_merge_fraction=frac,
+                            min_genes_before_merge=mb, min_genes_after_merge=mb), cb, umi, gene, aux, side)
+    parity.compare(o, c, side)
