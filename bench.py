@@ -41,6 +41,7 @@ def parse():
                     help="c2 (default, the metric's configuration): 10x v2, UMI 10, no CB merge; "
                          "c3: 10x v3, UMI 12, -m + whitelist merge (use --reads 1e9 for BASELINE's size); "
                          "c4: inDrop v3, split 8+8 barcode, UMI 8, -m + whitelist merge (BASELINE: 4 GPUs x 1.25e8 reads)")
+    ap.add_argument("--no-whitelist", action="store_true", help="c3 / c4: -m WITHOUT the barcode whitelist (SimpleMergeStrategy, single GPU)")
     ap.add_argument("--merge-umi", action="store_true", help="-u: directional UMI correction (single-GPU configs only)")
     ap.add_argument("--cpu-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_CPU_SAMPLE", 4e6)),
                     help="reads of the same stream timed on the CPU oracle (rank 0, N=1 only; 0 disables)")
@@ -124,7 +125,10 @@ def main():
         from dropest_amd.capi import Context
         dev = stream.generate_device(local_rank, first=0, n=reads_per_gpu)
         ukw = dict(umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL) if args.merge_umi else {}
-        if merge:
+        if merge and args.no_whitelist:
+            ctx = Context(device=local_rank, merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=2, min_merge_fraction=0.2,
+                          min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"], **ukw)
+        elif merge:
             ctx = Context(device=local_rank, merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST,
                           barcodes_file=wl, min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"],
                           min_merge_fraction=0.2, **ukw)
@@ -214,7 +218,8 @@ def main():
                                     "C4: synthetic inDrop v3, %d reads/GPU, %d cells/GPU, 8+8bp split CB + 8bp UMI, 30000 genes, "
                                     "-m + inDrop v3 whitelist (RealBarcodes merge), -L eEBA" if c4 else
                                     "C2: synthetic 10x v2, %d reads/GPU, %d cells/GPU, 16bp CB + 10bp UMI, 30000 genes, "
-                                    "no CB merge, -L eEBA") % (reads_per_gpu, args.cells) + (", -u" if args.merge_umi else ""),
+                                    "no CB merge, -L eEBA") % (reads_per_gpu, args.cells) + (", -u" if args.merge_umi else "")
+                                   + (", no whitelist (SimpleMergeStrategy)" if args.no_whitelist else ""),
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d" % world,
                        "cm_nnz": int(len(cm[1])), "filtered_cells": int(len(out[2])), "sort_layout": get_layout()},
             "roofline": roof, "cpu_baseline": cpu, "step_ms": step_ms, "kernels_ms_per_step": kernels,
