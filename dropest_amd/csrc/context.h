@@ -229,7 +229,8 @@ struct dropest_ctx {
 	void plan_key_layout();
 	void build_keys();
 	u32 main_sort_passes = 0;
-	void radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes = 4);
+	void radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes = 4,
+	                const char *stat_prefix = nullptr);
 	void reduce_all();
 	void reduce_molecules_to_cell_gene();
 	void reduce_cell_gene_to_cells();

@@ -191,27 +191,31 @@ void dropest_ctx::build_cb_table() {
 
 void dropest_ctx::assign_cell_ids() {
 	const u32 n = u32(n_reads);
-	const u32 tiles = div_up(n, CID_TILE);
-	tile_counts.ensure(tiles); tile_prefix.ensure(tiles); scalars.ensure(16);
-	timed("cb_first_count", double(n) * 8, [&] {
-		hipLaunchKernelGGL(cb_first_count_kernel, dim3(tiles), dim3(CID_THREADS), 0, stream, slot.p, n, table, tile_counts.p);
-	});
-	timed("scan_small", double(tiles) * 8, [&] {
-		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, tile_counts.p, tile_prefix.p, tiles, scalars.p);
+	// occupied slots -> (first ordinal, slot) records, sorted by first ordinal: position = first-seen cell id
+	const uint64_t cap = table.mask + 1;
+	keys_a.ensure(n); keys_b.ensure(n); vals_a.ensure(n); vals_b.ensure(n);   // (the sort buffers of the main sort: n >= number of barcodes)
+	scalars.ensure(16);
+	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4, stream));
+	timed("cb_compact_slots", double(cap) * 16, [&] {
+		hipLaunchKernelGGL(cb_compact_slots_kernel, dim3(u32(std::min<uint64_t>((cap + 4095) / 4096, 4096))), dim3(256), 0, stream, table,
+		                   keys_a.p, scalars.p);
 	});
 	u32 total = 0;
 	fetch(&total, scalars.p, 4);
 	n_cells = total;
-	if (uint64_t(n_cells) * 10 > (table.mask + 1) * 7)   // load factor > 0.7: rebuild larger for short probe chains
+	if (uint64_t(n_cells) * 10 > cap * 7)   // load factor > 0.7: rebuild larger for short probe chains
 	{
-		cfg.cb_table_capacity = (table.mask + 1) << 2;
+		cfg.cb_table_capacity = cap << 2;
 		build_cb_table();
 		return assign_cell_ids();
 	}
+	u64 *k = keys_a.p, *k_alt = keys_b.p;
+	u32 *v = vals_a.p, *v_alt = vals_b.p;
+	const int ord_bits = std::max(1, bit_length(uint64_t(n ? n - 1 : 0)));
+	radix_sort(k, v, k_alt, v_alt, n_cells, ((1ull << ord_bits) - 1ull) << 32, 0, "cell_ids:");
 	cell_cb.ensure(n_cells); cell_first.ensure(n_cells);
-	timed("cb_assign_ids", double(n) * 8 + double(n_cells) * 16, [&] {
-		hipLaunchKernelGGL(cb_assign_ids_kernel, dim3(tiles), dim3(CID_THREADS), 0, stream, d_cb, slot.p, n, table,
-		                   tile_prefix.p, cell_cb.p, cell_first.p);
+	timed("cb_assign_ids", double(n_cells) * 40, [&] {
+		hipLaunchKernelGGL(cb_assign_sorted_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, stream, k, n_cells, table, cell_cb.p, cell_first.p);
 	});
 }
 
@@ -331,23 +335,27 @@ static void rs_launch(int val_bytes, dim3 grid, hipStream_t st, const u64 *k, co
 	else rs_launch_vb<4>(o >= 0 ? o : 0, grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
 }
 
-void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes) {
+void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes,
+                             const char *stat_prefix) {
 	if (n == 0) return;
 	const u32 n_tiles = div_up(n, RS_TILE_REC);
 	u32 nblocks = std::min<u32>(n_tiles, 1024);   // measured flat between 256 and 2048 blocks
 	const u32 tpb = div_up(n_tiles, nblocks);
 	nblocks = div_up(n_tiles, tpb);
 	rs_hist.ensure(size_t(RS_RADIX) * nblocks); rs_row_total.ensure(RS_RADIX); rs_digit_base.ensure(RS_RADIX);
-	const char *scatter_name = val_bytes == 4 ? "rs_scatter" : (val_bytes == 1 ? "rs_scatter:key+1B" : "rs_scatter:keys");
+	const std::string scatter_s = std::string(stat_prefix ? stat_prefix : "") +
+	                              (val_bytes == 4 ? "rs_scatter" : (val_bytes == 1 ? "rs_scatter:key+1B" : "rs_scatter:keys"));
+	const std::string hist_s = std::string(stat_prefix ? stat_prefix : "") + "rs_hist", scan_s = std::string(stat_prefix ? stat_prefix : "") + "rs_scan";
+	const char *scatter_name = scatter_s.c_str();
 	// Digit windows start at the lowest bit that differs between two keys (the caller masks out bits that need no
 	// ordering, e.g. a mark folded under the key), so ceil(varying width / 8) passes suffice.
 	if (varying_mask == 0) return;
 	for (int shift = __builtin_ctzll(varying_mask); shift < 64; shift += 8) {
 		if (((varying_mask >> shift) & 0xFFull) == 0) continue;   // digit constant over all keys: pass is the identity
-		timed("rs_hist", double(n) * 8, [&] {
+		timed(hist_s.c_str(), double(n) * 8, [&] {
 			hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, keys, n, shift, tpb, u32(RS_TILE_REC), rs_hist.p);
 		});
-		timed("rs_scan", double(RS_RADIX) * nblocks * 8, [&] {
+		timed(scan_s.c_str(), double(RS_RADIX) * nblocks * 8, [&] {
 			hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, stream, rs_hist.p, nblocks, rs_row_total.p);
 			hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(256), 0, stream, rs_row_total.p, rs_digit_base.p);
 		});

@@ -158,52 +158,44 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 	}
 }
 
-// first-occurrence flags -> per-tile counts
-constexpr int CID_THREADS = 256, CID_ITEMS = 8, CID_TILE = CID_THREADS * CID_ITEMS;
-
-__global__ __launch_bounds__(CID_THREADS) void cb_first_count_kernel(const uint32_t *__restrict__ slot, uint32_t n,
-                                                                     CbTable t, uint32_t *__restrict__ tile_counts) {
-	__shared__ uint32_t scratch[CID_THREADS / 64 + 1];
-	const uint32_t base = blockIdx.x * CID_TILE;
-	uint32_t c = 0;
+// ---- cell ids from the table alone ---------------------------------------------------------------------------
+// The first-seen rank of a barcode is the rank of its first read ordinal among the first ordinals of all barcodes:
+// compact the occupied slots into (first ordinal << 32 | slot) records, radix-sort them (a few million records instead
+// of two more passes over all reads), and the position in the sorted list IS the cell id.
+constexpr int CS_ITEMS = 16;   // slots per thread and iteration: one atomic per 4096 slots
+__global__ __launch_bounds__(256) void cb_compact_slots_kernel(CbTable t, unsigned long long *__restrict__ out, uint32_t *__restrict__ count) {
+	__shared__ uint32_t scratch[256 / 64 + 1];
+	__shared__ uint32_t block_base;
+	const uint64_t cap = t.mask + 1, chunk = uint64_t(256) * CS_ITEMS;
+	for (uint64_t c0 = uint64_t(blockIdx.x) * chunk; c0 < cap; c0 += uint64_t(gridDim.x) * chunk) {
+		uint32_t hits = 0, mine = 0;
 #pragma unroll
-	for (int j = 0; j < CID_ITEMS; ++j) {
-		uint32_t r = base + j * CID_THREADS + threadIdx.x;
-		if (r < n) c += (t.first(slot[r]) == r);
-	}
-	uint32_t total;
-	block_excl_scan_u32<CID_THREADS>(c, scratch, total);
-	if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
-}
-
-// assigns cell ids (= exclusive prefix over first-occurrence flags) and fills the per-cell header arrays
-__global__ __launch_bounds__(CID_THREADS) void cb_assign_ids_kernel(const unsigned long long *__restrict__ cb,
-                                                                    const uint32_t *__restrict__ slot, uint32_t n,
-                                                                    CbTable t, const uint32_t *__restrict__ tile_prefix,
-                                                                    unsigned long long *__restrict__ cell_cb,
-                                                                    uint32_t *__restrict__ cell_first) {
-	__shared__ uint32_t scratch[CID_THREADS / 64 + 1];
-	const uint32_t base = blockIdx.x * CID_TILE;
-	// blocked arrangement so that ranks follow read order
-	uint32_t flags = 0, c = 0;
-	const uint32_t r0 = base + threadIdx.x * CID_ITEMS;
-#pragma unroll
-	for (int j = 0; j < CID_ITEMS; ++j) {
-		uint32_t r = r0 + j;
-		if (r < n && t.first(slot[r]) == r) { flags |= 1u << j; ++c; }
-	}
-	uint32_t total;
-	uint32_t id = tile_prefix[blockIdx.x] + block_excl_scan_u32<CID_THREADS>(c, scratch, total);
-#pragma unroll
-	for (int j = 0; j < CID_ITEMS; ++j) {
-		if (flags & (1u << j)) {
-			uint32_t r = r0 + j;
-			t.slots[slot[r]].cell_id = id;
-			cell_cb[id] = cb[r];
-			cell_first[id] = r;
-			++id;
+		for (int j = 0; j < CS_ITEMS; ++j) {
+			const uint64_t s = c0 + uint64_t(j) * 256 + threadIdx.x;
+			if (s < cap && t.slots[s].key != 0ull) { hits |= 1u << j; ++mine; }
 		}
+		uint32_t total;
+		const uint32_t ex = block_excl_scan_u32<256>(mine, scratch, total);
+		if (threadIdx.x == 0) block_base = total ? atomicAdd(count, total) : 0u;
+		__syncthreads();
+		uint32_t o = block_base + ex;
+#pragma unroll
+		for (int j = 0; j < CS_ITEMS; ++j)
+			if (hits & (1u << j)) {
+				const uint32_t s = uint32_t(c0 + uint64_t(j) * 256 + threadIdx.x);
+				out[o++] = ((unsigned long long)t.first(s) << 32) | s;
+			}
+		__syncthreads();
 	}
+}
+__global__ __launch_bounds__(256) void cb_assign_sorted_kernel(const unsigned long long *__restrict__ sorted, uint32_t n_cells, CbTable t,
+                                                               unsigned long long *__restrict__ cell_cb, uint32_t *__restrict__ cell_first) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_cells) return;
+	const uint32_t s = uint32_t(sorted[i]);
+	t.slots[s].cell_id = i;
+	cell_cb[i] = t.slots[s].key;
+	cell_first[i] = uint32_t(sorted[i] >> 32);
 }
 
 }  // namespace dropest
