@@ -150,7 +150,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 			load_tile(tile, key, val);
 		}
 		for (uint32_t j = tid; j < WAVES * RS_RADIX; j += THREADS) (&wcnt[0][0])[j] = 0;
-		__syncthreads();
+		lds_barrier();
 
 		// wave-level multisplit: rank of each key among the keys of its wave with the same digit
 #pragma unroll
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 			__builtin_amdgcn_wave_barrier();
 			lrank[i] = old + before;
 		}
-		__syncthreads();
+		lds_barrier();
 
 		// combine waves: per digit exclusive offsets over waves, then exclusive scan over digits
 		uint32_t run = 0;
@@ -181,9 +181,9 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 			tcnt[tid] = run;
 		}
 		uint32_t total;
-		uint32_t ex = block_excl_scan_u32<THREADS>(tid < RS_RADIX ? run : 0u, scratch, total);
+		uint32_t ex = block_excl_scan_u32<THREADS, true>(tid < RS_RADIX ? run : 0u, scratch, total);
 		if (tid < RS_RADIX) { tstart[tid] = ex; gdelta[tid] = goff[tid] - ex; }
-		__syncthreads();
+		lds_barrier();
 
 		// re-order the tile by digit in LDS
 #pragma unroll
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 				if (VB) sv[p] = val[i];
 			}
 		}
-		__syncthreads();
+		lds_barrier();
 
 		// coalesced write-out: consecutive threads write consecutive addresses inside a digit run
 		const uint32_t count = full ? TILE : total;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 			okeys[g] = k;
 			if (VB) ovals[g] = sv[p];
 		}
-		__syncthreads();
+		lds_barrier();
 		if (tid < RS_RADIX) goff[tid] += tcnt[tid];
 		// (the next iteration's barriers order this update before gdelta is recomputed)
 	}

@@ -92,23 +92,34 @@ __device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {
 	return v;
 }
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS / scalar-memory operations (lgkmcnt) but
+// not for its outstanding global loads and stores (vmcnt), then s_barrier.  For kernels whose threads communicate
+// through LDS alone, global stores of one tile then stay in flight under the work on the next one.
+// s_waitcnt immediate (gfx9 encoding): vmcnt = 63 (bits 3:0 and 15:14), expcnt = 7 (6:4), lgkmcnt = 0 (11:8).
+__device__ inline void lds_barrier() {
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_waitcnt(0xC07F);
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // exclusive scan over the block; `scratch` needs blockDim.x/64 + 1 entries; returns prefix, sets total
-template <int THREADS>
+template <int THREADS, bool LDS_ONLY = false>
 __device__ inline uint32_t block_excl_scan_u32(uint32_t v, uint32_t *scratch, uint32_t &total) {
 	constexpr int NW = THREADS / 64;
 	uint32_t incl = wave_incl_scan_u32(v);
 	if (lane_id() == 63) scratch[wave_id()] = incl;
-	__syncthreads();
+	if (LDS_ONLY) lds_barrier(); else __syncthreads();
 	if (threadIdx.x == 0) {
 		uint32_t run = 0;
 #pragma unroll
 		for (int w = 0; w < NW; ++w) { uint32_t t = scratch[w]; scratch[w] = run; run += t; }
 		scratch[NW] = run;
 	}
-	__syncthreads();
+	if (LDS_ONLY) lds_barrier(); else __syncthreads();
 	uint32_t res = scratch[wave_id()] + incl - v;
 	total = scratch[NW];
-	__syncthreads();   // scratch may be reused right after
+	if (LDS_ONLY) lds_barrier(); else __syncthreads();   // scratch may be reused right after
 	return res;
 }
 
