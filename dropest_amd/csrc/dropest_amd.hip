@@ -193,7 +193,8 @@ void dropest_ctx::assign_cell_ids() {
 	const u32 n = u32(n_reads);
 	// occupied slots -> (first ordinal, slot) records, sorted by first ordinal: position = first-seen cell id
 	const uint64_t cap = table.mask + 1;
-	keys_a.ensure(n); keys_b.ensure(n); vals_a.ensure(n); vals_b.ensure(n);   // (the sort buffers of the main sort: n >= number of barcodes)
+	keys_a.ensure(n); keys_b.ensure(n);   // (the key buffers of the main sort: n >= number of barcodes; keys-only sort below)
+	vals_a.ensure(1); vals_b.ensure(1);
 	scalars.ensure(16);
 	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4, stream));
 	timed("cb_compact_slots", double(cap) * 16, [&] {
@@ -276,7 +277,9 @@ dropest_ctx::u64 dropest_ctx::unmap_umi(u64 ucode) const {
 
 void dropest_ctx::build_keys() {
 	const u32 n = u32(n_reads);
-	keys_a.ensure(n); keys_b.ensure(n); vals_a.ensure(n); vals_b.ensure(n);
+	// value buffers hold val_bytes per record (0, 1 or 4): nothing at all for the keys-only layout
+	const size_t val_words = (size_t(n) * size_t(layout.val_bytes) + 3) / 4 + 1;
+	keys_a.ensure(n); keys_b.ensure(n); vals_a.ensure(val_words); vals_b.ensure(val_words);
 	d_counters.ensure(1);
 	GlobalCounters init{};
 	init.key_and = ~0ull;
