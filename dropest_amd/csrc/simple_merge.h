@@ -14,7 +14,7 @@
 // of the others; otherwise the reference's answer depends on the iteration order of two std::unordered containers
 // keyed by cell id, and those bases are replayed with the same containers filled in the same order (the members of
 // each UMI-gene come from the sorted table, the base's UMIs in (gene index, UMI first occurrence) order).
-// No reference test pins this strategy: the oracle restates it with the same containers.
+// No reference test pins this strategy; DESIGN.md §2b says how it is checked.
 #pragma once
 
 namespace {
