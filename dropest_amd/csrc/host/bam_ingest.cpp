@@ -4,9 +4,11 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <future>
+#include <memory>
 #include <stdexcept>
 #include <thread>
 #include <unordered_set>
@@ -66,14 +68,21 @@ struct BamReader::Impl {
 	FILE *f = nullptr;
 	unsigned threads = 1;
 	static constexpr size_t BATCH_BLOCKS = 512;        // <= 32 MB of BAM per batch
-	std::vector<uint8_t> data;                         // decompressed window
+	static constexpr size_t HEADROOM = 1 << 20;
+	// Decompressed windows live in a few recycled buffers (a fresh 32 MB allocation per batch would spend more time in
+	// page faults than the inflate takes).  A batch leaves HEADROOM bytes free in front: the unconsumed tail of the
+	// previous window (a partial record) is copied there, so a new batch is adopted without moving it.
+	struct Buf { std::unique_ptr<uint8_t[]> p; size_t cap = 0, size = 0; void need(size_t n) { if (n > cap) { p.reset(new uint8_t[n]); cap = n; } } };
+	Buf cur;                                           // window being parsed: bytes [pos, cur.size)
+	std::vector<Buf> spare;                            // touched by the caller's thread only
 	size_t pos = 0;
 	bool file_done = false;
-	std::future<std::vector<uint8_t>> ahead;           // next batch, being inflated while the caller parses this one
+	std::future<Buf> ahead;                            // next batch, being inflated while the caller parses this one
 	std::vector<std::string> refs;
 	std::string text;
+	const uint8_t *bytes() const { return cur.p.get(); }
 
-	std::vector<uint8_t> load_batch() {
+	Buf load_batch(Buf out) {
 		std::vector<RawBlock> blocks;
 		blocks.reserve(BATCH_BLOCKS);
 		while (blocks.size() < BATCH_BLOCKS) {
@@ -81,31 +90,54 @@ struct BamReader::Impl {
 			if (!read_block(f, b, path)) { file_done = true; break; }
 			blocks.push_back(std::move(b));
 		}
-		std::vector<size_t> off(blocks.size() + 1, 0);
+		std::vector<size_t> off(blocks.size() + 1, HEADROOM);
 		for (size_t i = 0; i < blocks.size(); ++i) off[i + 1] = off[i] + blocks[i].isize;
-		std::vector<uint8_t> out(off.back());
+		out.need(off.back());
+		out.size = off.back();
 		const unsigned nt = unsigned(std::min<size_t>(threads, std::max<size_t>(1, blocks.size() / 8)));
 		std::vector<std::thread> pool;
 		std::vector<std::string> errors(nt);
+		uint8_t *base = out.p.get();
 		for (unsigned t = 0; t < nt; ++t)
 			pool.emplace_back([&, t] {
-				try { for (size_t i = t; i < blocks.size(); i += nt) inflate_block(blocks[i], out.data() + off[i]); }
+				try { for (size_t i = t; i < blocks.size(); i += nt) inflate_block(blocks[i], base + off[i]); }
 				catch (const std::exception &e) { errors[t] = e.what(); }
 			});
 		for (auto &th : pool) th.join();
 		for (auto const &e : errors) if (!e.empty()) throw std::runtime_error(e + ": " + path);
 		return out;
 	}
-	// makes at least `need` bytes available at data[pos..]; false if the stream ends first
+	Buf take_spare() {
+		if (spare.empty()) return Buf();
+		Buf b = std::move(spare.back());
+		spare.pop_back();
+		return b;
+	}
+	// makes at least `need` bytes available at bytes()[pos..]; false if the stream ends first
 	bool ensure(size_t need) {
-		while (data.size() - pos < need) {
-			std::vector<uint8_t> next;
+		while (cur.size - pos < need) {
+			Buf next;
 			if (ahead.valid()) next = ahead.get();
-			else if (!file_done) next = load_batch();
-			if (next.empty() && file_done && !ahead.valid()) return false;
-			if (!file_done) ahead = std::async(std::launch::async, [this] { return load_batch(); });
-			if (pos) { data.erase(data.begin(), data.begin() + long(pos)); pos = 0; }
-			data.insert(data.end(), next.begin(), next.end());
+			else if (!file_done) next = load_batch(take_spare());
+			if (next.size <= HEADROOM && file_done && !ahead.valid()) return false;
+			if (!file_done) ahead = std::async(std::launch::async, [this](Buf b) { return load_batch(std::move(b)); }, take_spare());
+			const size_t tail = cur.size - pos;
+			if (tail <= HEADROOM && next.size >= HEADROOM) {
+				if (tail) std::memcpy(next.p.get() + HEADROOM - tail, cur.p.get() + pos, tail);
+				std::swap(cur, next);
+				pos = HEADROOM - tail;
+			} else {   // a tail longer than the headroom (one enormous record): concatenate into a larger buffer
+				Buf big;
+				const size_t payload = next.size > HEADROOM ? next.size - HEADROOM : 0;
+				big.need(tail + payload);
+				if (tail) std::memcpy(big.p.get(), cur.p.get() + pos, tail);
+				if (payload) std::memcpy(big.p.get() + tail, next.p.get() + HEADROOM, payload);
+				big.size = tail + payload;
+				std::swap(cur, big);
+				pos = 0;
+				if (big.cap) spare.push_back(std::move(big));
+			}
+			if (next.cap && spare.size() < 3) spare.push_back(std::move(next));   // the old window, recycled
 		}
 		return true;
 	}
@@ -118,17 +150,17 @@ BamReader::BamReader(const std::string &path, unsigned threads) : impl(new Impl(
 	if (!impl->f) { delete impl; throw std::runtime_error("Can't open BAM file: " + path); }
 	try {
 		Impl &m = *impl;
-		if (!m.ensure(12) || std::memcmp(m.data.data() + m.pos, "BAM\1", 4) != 0) throw std::runtime_error("Can't open BAM file: " + path);
-		const uint32_t l_text = le32(m.data.data() + m.pos + 4);
+		if (!m.ensure(12) || std::memcmp(m.bytes() + m.pos, "BAM\1", 4) != 0) throw std::runtime_error("Can't open BAM file: " + path);
+		const uint32_t l_text = le32(m.bytes() + m.pos + 4);
 		if (!m.ensure(12 + size_t(l_text))) throw std::runtime_error("Truncated BAM header: " + path);
-		m.text.assign(reinterpret_cast<const char *>(m.data.data() + m.pos + 8), l_text);
-		const uint32_t n_ref = le32(m.data.data() + m.pos + 8 + l_text);
+		m.text.assign(reinterpret_cast<const char *>(m.bytes() + m.pos + 8), l_text);
+		const uint32_t n_ref = le32(m.bytes() + m.pos + 8 + l_text);
 		m.pos += 12 + size_t(l_text);
 		for (uint32_t r = 0; r < n_ref; ++r) {
 			if (!m.ensure(4)) throw std::runtime_error("Truncated BAM header: " + path);
-			const uint32_t l_name = le32(m.data.data() + m.pos);
+			const uint32_t l_name = le32(m.bytes() + m.pos);
 			if (!m.ensure(8 + size_t(l_name))) throw std::runtime_error("Truncated BAM header: " + path);
-			m.refs.emplace_back(reinterpret_cast<const char *>(m.data.data() + m.pos + 4), l_name ? l_name - 1 : 0);
+			m.refs.emplace_back(reinterpret_cast<const char *>(m.bytes() + m.pos + 4), l_name ? l_name - 1 : 0);
 			m.pos += 8 + size_t(l_name);
 		}
 	} catch (...) {
@@ -146,13 +178,9 @@ BamReader::~BamReader() {
 const std::vector<std::string> &BamReader::reference_names() const { return impl->refs; }
 const std::string &BamReader::header_text() const { return impl->text; }
 
-bool BamReader::next(BamRecord &rec) {
-	Impl &m = *impl;
-	if (!m.ensure(4)) return false;
-	const uint32_t block_size = le32(m.data.data() + m.pos);
-	if (block_size < 32) throw std::runtime_error("Corrupt BAM record: " + m.path);
-	if (!m.ensure(4 + size_t(block_size))) throw std::runtime_error("Truncated BAM record: " + m.path);
-	const uint8_t *p = m.data.data() + m.pos + 4;
+void BamReader::parse_record(const uint8_t *at, BamRecord &rec) {
+	const uint32_t block_size = le32(at);
+	const uint8_t *p = at + 4;
 	rec.ref_id = int32_t(le32(p));
 	const uint32_t l_read_name = p[8];
 	const uint32_t n_cigar = le16(p + 12);
@@ -160,14 +188,45 @@ bool BamReader::next(BamRecord &rec) {
 	const uint32_t l_seq = le32(p + 16);
 	const size_t fixed = 32, name_end = fixed + l_read_name;
 	const size_t aux = name_end + size_t(n_cigar) * 4 + (size_t(l_seq) + 1) / 2 + l_seq;
-	if (aux > block_size) throw std::runtime_error("Corrupt BAM record: " + m.path);
-	rec.name.assign(reinterpret_cast<const char *>(p + fixed), l_read_name ? l_read_name - 1 : 0);
+	if (block_size < 32 || aux > block_size) throw std::runtime_error("Corrupt BAM record");
+	rec.name_view = std::string_view(reinterpret_cast<const char *>(p + fixed), l_read_name ? l_read_name - 1 : 0);
 	rec.tags = p + aux; rec.tags_size = block_size - aux;
+}
+
+bool BamReader::next(BamRecord &rec) {
+	Impl &m = *impl;
+	if (!m.ensure(4)) return false;
+	const uint32_t block_size = le32(m.bytes() + m.pos);
+	if (block_size < 32) throw std::runtime_error("Corrupt BAM record: " + m.path);
+	if (!m.ensure(4 + size_t(block_size))) throw std::runtime_error("Truncated BAM record: " + m.path);
+	parse_record(m.bytes() + m.pos, rec);
+	rec.name.assign(rec.name_view);
 	m.pos += 4 + size_t(block_size);
 	return true;
 }
 
-bool BamRecord::get_string_tag(const std::string &tag, std::string &value, char *type_out) const {
+bool BamReader::next_window(const uint8_t *&data, std::vector<uint32_t> &offsets) {
+	Impl &m = *impl;
+	offsets.clear();
+	if (!m.ensure(4)) return false;
+	const uint32_t first_size = le32(m.bytes() + m.pos);
+	if (first_size < 32) throw std::runtime_error("Corrupt BAM record: " + m.path);
+	if (!m.ensure(4 + size_t(first_size))) throw std::runtime_error("Truncated BAM record: " + m.path);
+	data = m.bytes() + m.pos;
+	const size_t avail = m.cur.size - m.pos;
+	size_t o = 0;
+	while (o + 4 <= avail) {
+		const uint32_t bs = le32(data + o);
+		if (bs < 32) throw std::runtime_error("Corrupt BAM record: " + m.path);
+		if (o + 4 + size_t(bs) > avail || o > 0xFFFFFFF0ull) break;
+		offsets.push_back(uint32_t(o));
+		o += 4 + size_t(bs);
+	}
+	m.pos += o;
+	return true;
+}
+
+bool BamRecord::get_string_tag(const std::string &tag, std::string_view &value, char *type_out) const {
 	if (tag.size() != 2) return false;
 	size_t o = 0;
 	while (o + 3 <= tags_size) {
@@ -193,13 +252,20 @@ bool BamRecord::get_string_tag(const std::string &tag, std::string &value, char 
 		if (o + len > tags_size) return false;
 		if (t0 == tag[0] && t1 == tag[1]) {
 			if (type_out) *type_out = type;
-			if (text) { value.assign(reinterpret_cast<const char *>(tags + o), len - 1); return true; }
-			if (type == 'A') { value.assign(1, char(tags[o])); return true; }
+			if (text) { value = std::string_view(reinterpret_cast<const char *>(tags + o), len - 1); return true; }
+			if (type == 'A') { value = std::string_view(reinterpret_cast<const char *>(tags + o), 1); return true; }
 			return false;    // numeric tag: not a string (BamTools would read past it; no caller relies on that)
 		}
 		o += len;
 	}
 	return false;
+}
+
+bool BamRecord::get_string_tag(const std::string &tag, std::string &value, char *type_out) const {
+	std::string_view v;
+	if (!get_string_tag(tag, v, type_out)) return false;
+	value.assign(v);
+	return true;
 }
 
 BamController::BamController(const BamTags &tags, bool filled_bam, const std::string &read_param_filenames, const std::string &gtf_path,
@@ -214,55 +280,102 @@ BamController::BamController(const BamTags &tags, bool filled_bam, const std::st
 
 void BamController::parse_bam_files(const std::vector<std::string> &bam_files, CellsDataContainer &container) {
 	const int quality_offset = 33;                                       // Tools::ReadParameters::quality_offset
+	enum : uint8_t { OK = 0, SKIP, CANT_PARSE_NO_COUNT, CANT_PARSE, LOW_QUALITY };
+	struct Parsed { CellsDataContainer::ParsedRead r; uint8_t status; };
+	const unsigned nthreads = _threads ? _threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 	for (auto const &bam_name : bam_files) {
 		BamReader reader(bam_name, _threads);
 		const auto &refs = reader.reference_names();
-		BamRecord al;
-		std::string cb, umi, cbq, umiq, gene, read_type;
-		while (reader.next(al)) {
-			if (!al.is_mapped() || !al.is_primary()) continue;            // BamController.cpp:87-88
-			if (al.ref_id < 0 || size_t(al.ref_id) >= refs.size()) { ++_counters.cant_parse; continue; }   // :90-104
+		container.set_reference_names(refs);
+		const uint8_t *data = nullptr;
+		std::vector<uint32_t> offsets;
+		std::vector<Parsed> parsed;
+		// one record -> Parsed; runs on the worker threads (reads `data`, writes only its own slot)
+		auto parse_one = [&](const uint8_t *at, Parsed &out) {
+			BamRecord al;
+			BamReader::parse_record(at, al);
+			CellsDataContainer::ParsedRead &r = out.r;
+			r = CellsDataContainer::ParsedRead();
+			if (!al.is_mapped() || !al.is_primary()) { out.status = SKIP; return; }            // BamController.cpp:87-88
+			if (al.ref_id < 0 || size_t(al.ref_id) >= refs.size()) { out.status = CANT_PARSE_NO_COUNT; return; }   // :90-104
+			r.ref_id = al.ref_id;
 			const std::string &chr_name = refs[size_t(al.ref_id)];
-			++_counters.total_reads;
-			// get_read_params
-			cbq.clear(); umiq.clear();
 			bool pass_quality = true;
 			if (_filled_bam) {                                            // FilledBamParamsParser.cpp:12-40
-				if (!al.get_string_tag(_tags.cell_barcode, cb) || !al.get_string_tag(_tags.umi, umi)) { ++_counters.cant_parse; continue; }
+				std::string_view cbq, umiq;
+				if (!al.get_string_tag(_tags.cell_barcode, r.cb) || !al.get_string_tag(_tags.umi, r.umi)) { out.status = CANT_PARSE; return; }
 				al.get_string_tag(_tags.cell_barcode_quality, cbq);
 				al.get_string_tag(_tags.umi_quality, umiq);
-				if (cb.empty() || umi.empty()) { ++_counters.cant_parse; continue; }   // ReadParameters ctor throws -> false
+				if (r.cb.empty() || r.umi.empty()) { out.status = CANT_PARSE; return; }       // ReadParameters ctor throws -> false
 				if (_min_barcode_phred > quality_offset) {                 // ReadParameters::check_quality (:118-136)
 					for (char q : cbq) pass_quality &= q >= char(_min_barcode_phred);
 					for (char q : umiq) pass_quality &= q >= char(_min_barcode_phred);
 				}
+				r.umi_quality_length = uint32_t(umiq.size());
 			} else {                                                      // ReadParamsParser.cpp:20-33: "id!CB#UMI"
-				const size_t up = al.name.rfind('#');
-				const size_t cp = up == std::string::npos ? std::string::npos : al.name.rfind('!', up);
-				if (up == std::string::npos || cp == std::string::npos) { ++_counters.cant_parse; continue; }
-				cb = al.name.substr(cp + 1, up - cp - 1); umi = al.name.substr(up + 1);
-				if (cb.empty() || umi.empty()) { ++_counters.cant_parse; continue; }
+				const std::string_view name = al.name_view;
+				const size_t up = name.rfind('#');
+				const size_t cp = up == std::string_view::npos ? std::string_view::npos : name.rfind('!', up);
+				if (up == std::string_view::npos || cp == std::string_view::npos) { out.status = CANT_PARSE; return; }
+				r.cb = name.substr(cp + 1, up - cp - 1); r.umi = name.substr(up + 1);
+				if (r.cb.empty() || r.umi.empty()) { out.status = CANT_PARSE; return; }
 				// parse_encoded_id builds ReadParameters(cb, umi, "", "") = min_phred_score 0: always passes (ReadParameters.cpp:42-56)
 			}
-			if (!pass_quality) { ++_counters.low_quality; continue; }
+			if (!pass_quality) { out.status = LOW_QUALITY; return; }
 			// get_gene (ReadParamsParser.cpp:36-65) + parse_read_type (:67-90)
 			UMI::Mark mark;
-			gene.clear();
 			if (_gene_in_chromosome_name) {
-				gene = chr_name;
+				r.gene = chr_name;
 				if (!chr_name.empty()) mark.add(UMI::Mark::HAS_EXONS);
-			} else if (!al.get_string_tag(_tags.gene, gene)) {
-				gene.clear();
+			} else if (!al.get_string_tag(_tags.gene, r.gene)) {
+				r.gene = std::string_view();
 				mark.add(UMI::Mark::HAS_NOT_ANNOTATED);
 			} else {
-				char type = 0;
-				if (_tags.read_type.empty() || !al.get_string_tag(_tags.read_type, read_type, &type)) mark.add(UMI::Mark::HAS_EXONS);
+				std::string_view read_type;
+				if (_tags.read_type.empty() || !al.get_string_tag(_tags.read_type, read_type)) mark.add(UMI::Mark::HAS_EXONS);
 				else if (read_type == _tags.intronic_read_value) mark.add(UMI::Mark::HAS_INTRONS);
 				else if (!_tags.intergenic_read_value.empty() && read_type == _tags.intergenic_read_value) mark.add(UMI::Mark::HAS_NOT_ANNOTATED);
 				else mark.add(UMI::Mark::HAS_EXONS);
 			}
-			container.add_record(ReadInfo(Tools::ReadParameters(cb, umi, cbq, umiq), gene, chr_name, mark));
-			++_counters.saved;
+			r.mark = uint8_t(mark.bits());
+			if (!CellsDataContainer::pack_code(r.cb, r.cb_code)) r.cb_code = 0;
+			if (!CellsDataContainer::pack_code(r.umi, r.umi_code)) r.umi_code = 0;
+			r.gene_hash = CellsDataContainer::hash_name(r.gene);
+			if (!r.gene.empty()) r.gene_id = container.lookup_gene(r.gene_hash, r.gene);   // dictionary is read-only while the workers run
+			out.status = OK;
+		};
+		using clk = std::chrono::steady_clock;
+		auto since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+		for (;;) {
+			auto t_wait = clk::now();
+			if (!reader.next_window(data, offsets)) break;
+			_counters.wait_ms += since(t_wait);
+			auto t_parse = clk::now();
+			const size_t n = offsets.size();
+			parsed.resize(n);
+			const unsigned nt = unsigned(std::min<size_t>(nthreads, std::max<size_t>(1, n / 2048)));
+			std::vector<std::thread> pool;
+			std::vector<std::string> errors(nt);
+			for (unsigned t = 0; t < nt; ++t)
+				pool.emplace_back([&, t] {
+					try { for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) parse_one(data + offsets[i], parsed[i]); }
+					catch (const std::exception &e) { errors[t] = e.what(); }
+				});
+			for (auto &th : pool) th.join();
+			for (auto const &e : errors) if (!e.empty()) throw std::runtime_error(e + ": " + bam_name);
+			_counters.parse_ms += since(t_parse);
+			auto t_add = clk::now();
+			// in file order: the counters and the container (first-seen ids are defined by this order)
+			for (size_t i = 0; i < n; ++i) {
+				switch (parsed[i].status) {
+					case SKIP: break;
+					case CANT_PARSE_NO_COUNT: ++_counters.cant_parse; break;             // reads with unknown chromosome are not counted (:107)
+					case CANT_PARSE: ++_counters.total_reads; ++_counters.cant_parse; break;
+					case LOW_QUALITY: ++_counters.total_reads; ++_counters.low_quality; break;
+					default: ++_counters.total_reads; container.add_record(parsed[i].r); ++_counters.saved;
+				}
+			}
+			_counters.add_ms += since(t_add);
 		}
 	}
 }

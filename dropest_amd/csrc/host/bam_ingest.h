@@ -15,6 +15,7 @@
 
 #include <cstdint>
 #include <string>
+#include <string_view>
 #include <vector>
 
 #include "facade.h"
@@ -33,12 +34,14 @@ struct BamRecord {
 	int32_t ref_id = -1;
 	uint16_t flag = 0;
 	std::string name;
+	std::string_view name_view;      // set by parse_record (points into the window)
 	const uint8_t *tags = nullptr;   // aux data, valid until the next record is read
 	size_t tags_size = 0;
 	bool is_mapped() const { return !(flag & 0x4); }
 	bool is_primary() const { return !(flag & 0x100); }
 	// Z / A / H tags as text (BamAlignment::GetTag(tag, std::string&)); false if absent or numeric
 	bool get_string_tag(const std::string &tag, std::string &value, char *type = nullptr) const;
+	bool get_string_tag(const std::string &tag, std::string_view &value, char *type = nullptr) const;   // view into `tags`
 };
 
 class BamReader {
@@ -52,11 +55,18 @@ public:
 	const std::vector<std::string> &reference_names() const;
 	const std::string &header_text() const;
 	bool next(BamRecord &rec);                                           // false at end of file
+	// A run of whole records (as many as the decompressed window holds), valid until the next call of next / next_window;
+	// offsets[i] = start of record i (its block_size field) relative to data
+	bool next_window(const uint8_t *&data, std::vector<uint32_t> &offsets);
+	static void parse_record(const uint8_t *at, BamRecord &rec);         // name is NOT copied: see name_view
 };
 
 class BamController {
 public:
-	struct Counters { size_t total_reads = 0, cant_parse = 0, low_quality = 0, saved = 0; };
+	struct Counters {
+		size_t total_reads = 0, cant_parse = 0, low_quality = 0, saved = 0;
+		double wait_ms = 0, parse_ms = 0, add_ms = 0;   // waiting for decompressed data / parallel record parsing / add_record (serial)
+	};
 private:
 	BamTags _tags;
 	bool _filled_bam, _gene_in_chromosome_name;

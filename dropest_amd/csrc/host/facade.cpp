@@ -150,6 +150,72 @@ void CellsDataContainer::add_record(const ReadInfo &r) {   // CellsDataContainer
 	if (_cb.size() >= BATCH) flush();
 }
 
+bool CellsDataContainer::pack_code(std::string_view s, uint64_t &code) {
+	if (s.empty() || s.size() > 31) return false;
+	uint64_t c = 1;
+	for (char ch : s) {
+		uint64_t b;
+		switch (ch) { case 'A': b = 0; break; case 'C': b = 1; break; case 'G': b = 2; break; case 'T': b = 3; break; default: return false; }
+		c = (c << 2) | b;
+	}
+	code = c;
+	return true;
+}
+
+uint64_t CellsDataContainer::hash_name(std::string_view s) {   // FNV-1a
+	uint64_t h = 1469598103934665603ull;
+	for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+	return h;
+}
+
+int64_t CellsDataContainer::lookup_gene(uint64_t gene_hash, std::string_view name) const {
+	auto it = _gene_by_hash.find(gene_hash);
+	if (it != _gene_by_hash.end() && _gene_indexer.get_value(it->second) == name) return int64_t(it->second);
+	return -1;
+}
+
+void CellsDataContainer::set_reference_names(const std::vector<std::string> &names) {
+	_ref_names = names;
+	_ref_chr.assign(names.size(), -1);
+}
+
+void CellsDataContainer::add_record(const ParsedRead &r) {   // same statements as add_record(const ReadInfo&), on parsed fields
+	if (_is_initialized) throw std::runtime_error("Container is already initialized");
+	if (r.ref_id < 0 || size_t(r.ref_id) >= _ref_names.size()) throw std::out_of_range("reference id outside set_reference_names");
+	const bool has_gene = !r.gene.empty();
+	_cb.push_back(r.cb_code ? r.cb_code : encode(std::string(r.cb), _side_cb));
+	auto chr_index = [&]() {
+		int32_t &slot = _ref_chr[size_t(r.ref_id)];
+		if (slot < 0) slot = int32_t(_chr_indexer.add(_ref_names[size_t(r.ref_id)]));
+		return uint32_t(slot);
+	};
+	uint32_t chr = 0;
+	if (has_gene) {
+		const size_t ql = r.umi_quality_length;
+		if (_umi_quality_length == size_t(-1)) _umi_quality_length = ql;
+		else if (ql != _umi_quality_length)
+			throw std::runtime_error("Wrong quality length: " + std::to_string(ql) + ", expected: " + std::to_string(_umi_quality_length));
+		_umi.push_back(r.umi_code ? r.umi_code : encode(std::string(r.umi), _side_umi));
+		uint32_t gid;
+		auto it = r.gene_id >= 0 ? _gene_by_hash.end() : _gene_by_hash.find(r.gene_hash);
+		if (r.gene_id >= 0) gid = uint32_t(r.gene_id);
+		else if (it != _gene_by_hash.end() && _gene_indexer.get_value(it->second) == r.gene) gid = it->second;
+		else {
+			gid = uint32_t(_gene_indexer.add(std::string(r.gene)));
+			if (it == _gene_by_hash.end()) _gene_by_hash.emplace(r.gene_hash, gid);   // (a colliding name keeps taking the slow path)
+		}
+		_gene.push_back(gid);
+		if (r.mark & (UMI::Mark::HAS_EXONS | UMI::Mark::HAS_INTRONS)) chr = chr_index();
+	} else {
+		_umi.push_back(1);
+		_gene.push_back(DROPEST_NO_GENE);
+		chr = chr_index();
+	}
+	if (chr > 0xFFFF) throw std::runtime_error("more than 65536 chromosome names");
+	_aux.push_back(chr | (uint32_t(r.mark) << 16));
+	if (_cb.size() >= BATCH) flush();
+}
+
 void CellsDataContainer::flush() {
 	if (_cb.empty()) return;
 	std::vector<const char *> ptrs(_side.size());

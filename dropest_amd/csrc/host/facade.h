@@ -21,6 +21,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <vector>
 
@@ -225,6 +226,9 @@ private:
 	std::vector<uint64_t> _cb, _umi;
 	std::vector<uint32_t> _gene, _aux;
 	size_t _umi_quality_length = size_t(-1);
+	std::vector<std::string> _ref_names;                      // ParsedRead::ref_id -> chromosome name
+	std::vector<int32_t> _ref_chr;                            // ... -> index in _chr_indexer, -1 = not met yet
+	std::unordered_map<uint64_t, uint32_t> _gene_by_hash;     // name hash -> gene index (verified against the name)
 	mutable ids_t _filtered_cache, _merge_targets_cache;
 
 	uint64_t encode(const std::string &s, std::unordered_map<std::string, uint64_t> &escapes);
@@ -244,6 +248,25 @@ public:
 	CellsDataContainer &operator=(const CellsDataContainer &) = delete;
 
 	void add_record(const ReadInfo &read_info);
+	// add_record for callers that parsed the read themselves (the BAM reader's worker threads): barcode / UMI arrive as
+	// 2-bit codes when they are packable (0 = use the text), the gene name with its hash, the chromosome as a slot of
+	// the caller's reference table.  Same effect as add_record(ReadInfo(...)) read by read.
+	struct ParsedRead {
+		uint64_t cb_code = 0, umi_code = 0;
+		std::string_view cb, umi, gene;
+		uint64_t gene_hash = 0;
+		int64_t gene_id = -1;                 // from lookup_gene (a parser thread may resolve known genes ahead), -1 = unknown
+		int32_t ref_id = 0;                   // index into the chromosome names given to set_reference_names
+		uint8_t mark = 0;
+		uint32_t umi_quality_length = 0;
+	};
+	void set_reference_names(const std::vector<std::string> &names);
+	void add_record(const ParsedRead &read);
+	// index of a gene that is ALREADY in the dictionary, -1 otherwise; safe to call from several threads as long as no
+	// add_record runs at the same time
+	int64_t lookup_gene(uint64_t gene_hash, std::string_view name) const;
+	static bool pack_code(std::string_view s, uint64_t &code);
+	static uint64_t hash_name(std::string_view s);
 	void set_initialized();
 	void merge_and_filter();
 

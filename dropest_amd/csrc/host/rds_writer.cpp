@@ -23,7 +23,7 @@ class Out {
 	std::vector<unsigned char> buf;
 	std::unordered_map<std::string, int> symbols;   // name -> 1-based reference index
 public:
-	explicit Out(const std::string &path) : f(gzopen(path.c_str(), "wb6")) {
+	explicit Out(const std::string &path) : f(gzopen(path.c_str(), "wb4")) {
 		if (!f) throw std::runtime_error("Can't open file: " + path);
 		buf.reserve(1 << 20);
 	}

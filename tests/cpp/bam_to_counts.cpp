@@ -34,8 +34,8 @@ int main(int argc, char **argv) {
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 		const auto &k = ctl.counters();
 		std::printf("{\"total_reads\": %zu, \"cant_parse\": %zu, \"low_quality\": %zu, \"saved\": %zu, \"cells\": %zu, \"real_cells\": %zu, "
-		            "\"ingest_ms\": %.3f, \"estimate_ms\": %.3f, \"write_ms\": %.3f}\n",
-		            k.total_reads, k.cant_parse, k.low_quality, k.saved, c.total_cells_number(), c.real_cells_number(), ms(t0, t1), ms(t1, t2), ms(t2, t3));
+		            "\"ingest_ms\": %.3f, \"ingest_wait_ms\": %.3f, \"ingest_parse_ms\": %.3f, \"ingest_add_ms\": %.3f, \"estimate_ms\": %.3f, \"write_ms\": %.3f}\n",
+		            k.total_reads, k.cant_parse, k.low_quality, k.saved, c.total_cells_number(), c.real_cells_number(), ms(t0, t1), k.wait_ms, k.parse_ms, k.add_ms, ms(t1, t2), ms(t2, t3));
 	} catch (const std::exception &e) {
 		std::fprintf(stderr, "ERROR: %s\n", e.what());
 		return 1;
