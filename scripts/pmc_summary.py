@@ -31,14 +31,23 @@ def load(directory, counter):
     files = glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True)
     if not files:
         raise SystemExit("no counter_collection.csv under " + directory)
-    acc = defaultdict(lambda: [0, 0.0])
+    # a kernel launched with several grid sizes (the radix passes also sort the few million barcode records) is split
+    # by grid size: averaging a 1e8-record launch with a 4e6-record one says nothing about either
+    by_grid = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
     for f in files:
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != counter:
                 continue
-            a = acc[short(row["Kernel_Name"])]
+            a = by_grid[short(row["Kernel_Name"])][int(row["Grid_Size"])]
             a[0] += 1
             a[1] += float(row["Counter_Value"])
+    acc = {}
+    for k, grids in by_grid.items():
+        if len(grids) == 1:
+            acc[k] = list(grids.values())[0]
+        else:
+            for g, a in grids.items():
+                acc["%s [grid %d]" % (k, g)] = a
     return acc
 
 
@@ -60,19 +69,20 @@ def main():
         out.write("# calibrated on rs_hist_kernel = 8 B x N reads), WRITE_KB is exact (calibrated on synth_kernel = 24 B x N writes).\n")
         out.write("kernel,launches,FETCH_KB_raw,FETCH_KB_corrected,WRITE_KB,hbm_bytes_per_launch\n")
         for r in rows:
-            out.write("%s,%d,%.1f,%.1f,%.1f,%.4g\n" % r)
+            out.write('"%s",%d,%.1f,%.1f,%.1f,%.4g\n' % r)
     print("wrote", path)
     # calibration check + dominant kernel record
     by = {r[0]: r for r in rows}
-    hist = next((r for k, r in by.items() if k.startswith("rs_hist_kernel")), None)
+    hist = max((r for k, r in by.items() if k.startswith("rs_hist_kernel")), key=lambda r: r[2], default=None)
     if hist:
         print("calibration: rs_hist FETCH raw %.1f KB vs exact %.1f KB -> x%.3f" % (hist[2], 8.0 * n_records / 1024, 8.0 * n_records / 1024 / hist[2]))
     variants = {"rs_scatter:keys": (", 0>", 16), "rs_scatter:key+1B": (", 1>", 18), "rs_scatter": (", 4>", 24)}
     best = None
     for stat_name, (suffix, bytes_per_rec) in variants.items():
         for k, r in by.items():
-            if k.startswith("rs_scatter_kernel_t") and k.endswith(suffix) and (best is None or r[1] > best[1][1]):
-                best = (stat_name, r, bytes_per_rec, k)
+            base = k.split(" [grid")[0]
+            if base.startswith("rs_scatter_kernel_t") and base.endswith(suffix) and (best is None or r[5] > best[1][5]):
+                best = (stat_name, r, bytes_per_rec, k)   # the launches with the most traffic = the main sort's
     if best:
         stat_name, r, bpr, k = best
         rec = {"kernel": k, "kernel_stat_name": stat_name, "records_per_launch": n_records, "workload": tag,
