@@ -68,7 +68,6 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 	__shared__ uint32_t sval[P::PACKED ? 1 : NV][PADDED];   // per-row contributions (one packed word, or NV words)
 	__shared__ uint32_t agg[NV][SR_TILE + 1];     // slot 0 = run continuing from the previous tile
 	__shared__ uint32_t slot_row[P::DIRECT ? SR_TILE + 1 : 1];   // DIRECT: output row of each slot
-	for (int j = threadIdx.x; j < NV * (SR_TILE + 1); j += SR_THREADS) (&agg[0][0])[j] = 0;
 
 	// phase 1: coalesced (striped) loads of keys and contributions into LDS
 	const uint32_t t0 = blockIdx.x * SR_TILE;
@@ -92,7 +91,7 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 		skey[sr_pad(0)] = pred;
 		if (P::DIRECT) slot_row[0] = t0 ? p.direct_index(pred) : 0u;
 	}
-	__syncthreads();
+	lds_barrier();
 
 	// phase 2: each thread owns SR_ITEMS consecutive rows
 	const uint32_t r0 = threadIdx.x * SR_ITEMS, i0 = t0 + r0;
@@ -110,8 +109,14 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 		}
 	}
 	uint32_t total;
-	const uint32_t ex = block_excl_scan_u32<SR_THREADS>(c, scratch, total);
+	const uint32_t ex = block_excl_scan_u32<SR_THREADS, true>(c, scratch, total);
 	const uint32_t tp = P::DIRECT ? 1u : tile_prefix[blockIdx.x];   // DIRECT: only "tp != 0" matters below
+	// only the slots this tile uses (0 = carry-in run, 1..total = its heads) are cleared and, later, read back
+	for (uint32_t s = threadIdx.x; s <= total; s += SR_THREADS) {
+#pragma unroll
+		for (int c2 = 0; c2 < NV; ++c2) agg[c2][s] = 0;
+	}
+	lds_barrier();
 
 	uint32_t slot = ex;   // rows before this thread's first head belong to the last head seen so far
 	uint32_t acc[NV];
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 		}
 		flush();
 	}
-	__syncthreads();
+	lds_barrier();
 
 	for (uint32_t s = threadIdx.x; s <= total; s += SR_THREADS) {
 		if (s == 0 && (P::DIRECT ? blockIdx.x == 0 : tp == 0)) continue;   // row 0 is always a head: no carry-in run for the first tile
