@@ -27,6 +27,7 @@ class _Cfg(C.Structure):
         ("min_genes_before", C.c_int), ("min_genes_after", C.c_int), ("min_merge_fraction", C.c_double),
         ("max_cb_merge_ed", C.c_int), ("umi_merge_kind", C.c_int), ("max_umi_merge_ed", C.c_int),
         ("umi_mult", C.c_double), ("match_levels", C.c_char_p), ("max_cells", C.c_int),
+        ("max_merge_prob", C.c_double), ("max_real_merge_prob", C.c_double),
     ]
 
 
@@ -75,6 +76,11 @@ def oracle_lib():
         "orc_fill_wrong_umi": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "orc_directional_targets": (C.c_int, [vp, P(C.c_char_p), vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int]),
         "orc_collisions_table": (C.c_int, [vp, u64, u64, vp]),
+        "orc_poisson_init": (C.c_int, [vp]), "orc_poisson_distribution_size": (u64, [vp]),
+        "orc_poisson_gene_intersection": (C.c_double, [vp, u64, u64]),
+        "orc_poisson_intersection_prob": (C.c_double, [vp, u64, u64]),
+        "orc_poisson_merge_target": (C.c_long, [vp, u64]),
+        "orc_poisson_upper_tail": (C.c_double, [C.c_long, C.c_double]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -86,7 +92,7 @@ def oracle_lib():
 class OracleConfig:
     def __init__(self, merge_kind=0, barcodes_kind=0, barcodes_file="", min_genes_before=10, min_genes_after=10,
                  min_merge_fraction=0.2, max_cb_merge_ed=0, umi_merge_kind=0, max_umi_merge_ed=1, umi_mult=2.0,
-                 match_levels="eEBA", max_cells=-1):
+                 match_levels="eEBA", max_cells=-1, max_merge_prob=1e-4, max_real_merge_prob=1e-7):
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -104,7 +110,8 @@ class Oracle:
         self.L = oracle_lib()
         c = _Cfg(cfg.merge_kind, cfg.barcodes_kind, cfg.barcodes_file.encode(), cfg.min_genes_before,
                  cfg.min_genes_after, cfg.min_merge_fraction, cfg.max_cb_merge_ed, cfg.umi_merge_kind,
-                 cfg.max_umi_merge_ed, cfg.umi_mult, cfg.match_levels.encode(), cfg.max_cells)
+                 cfg.max_umi_merge_ed, cfg.umi_mult, cfg.match_levels.encode(), cfg.max_cells, cfg.max_merge_prob,
+                 cfg.max_real_merge_prob)
         self.h = self.L.orc_create(C.byref(c))
         if not self.h:
             raise RuntimeError(self.L.orc_last_error().decode())
@@ -219,6 +226,23 @@ class Oracle:
             raise RuntimeError(self.L.orc_last_error().decode())
         return r
 
+    # PoissonTargetEstimator pieces (Tests/TestEstimationMergeProbs.cpp)
+    def poisson_init(self):
+        self._chk(self.L.orc_poisson_init(self.h))
+        return int(self.L.orc_poisson_distribution_size(self.h))
+
+    def poisson_gene_intersection(self, g1, g2):
+        return float(self.L.orc_poisson_gene_intersection(self.h, g1, g2))
+
+    def poisson_intersection_prob(self, c1, c2):
+        return float(self.L.orc_poisson_intersection_prob(self.h, c1, c2))
+
+    def poisson_merge_target(self, cell):
+        r = int(self.L.orc_poisson_merge_target(self.h, cell))
+        if r == -2:
+            raise RuntimeError(self.L.orc_last_error().decode())
+        return r
+
     def real_neighbours(self, cell):
         out = np.zeros(4096, np.uint64)
         n = int(self.L.orc_real_neighbours(self.h, cell, out.ctypes.data, 4096))
@@ -302,6 +326,11 @@ def fill_wrong_umi(umi):
     out = C.create_string_buffer(len(umi) + 1)
     oracle_lib().orc_fill_wrong_umi(umi.encode(), out, len(umi) + 1)
     return out.value.decode()
+
+
+def poisson_upper_tail(k, lam):
+    """P(X >= k), X ~ Poisson(lam) = Rcpp::ppois(k - 1, lam, lower = false)"""
+    return float(oracle_lib().orc_poisson_upper_tail(k, lam))
 
 
 def collisions_table(probs, max_expr):

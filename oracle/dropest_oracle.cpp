@@ -79,6 +79,7 @@ static unsigned hamming_distance(const std::string &a, const std::string &b, boo
 
 // Tools/UtilFunctions.cpp:13-30
 static double fpow(double base, long exp) {
+	if (exp < 0) throw std::runtime_error("fpow: negative exponent (the reference does not terminate here: the collisions adjustment diverged)");
 	if (exp == 1) return base;
 	double r = 1;
 	while (exp) {
@@ -324,7 +325,9 @@ struct Whitelist {
 // ----------------------------------------------------------------------------------------------
 
 struct Config {
-	int merge_kind = 0;          // 0 = none (DummyMergeStrategy), 1 = RealBarcodes, 2 = Simple (-m without a whitelist)
+	int merge_kind = 0;          // 0 = none (DummyMergeStrategy), 1 = RealBarcodes, 2 = Simple (-m without a whitelist),
+	                             // 3 = PoissonRealBarcodes (-M with a whitelist)
+	double max_merge_prob = 1e-4, max_real_merge_prob = 1e-7;   // PreciseMerge.* (MergeStrategyFactory.cpp:52-55)
 	int barcodes_kind = 0;       // Whitelist::Kind
 	std::string barcodes_file;
 	size_t min_genes_before = 10, min_genes_after = 10;   // MergeStrategyFactory.cpp:26-58 defaults
@@ -354,7 +357,7 @@ struct Container {
 	explicit Container(const Config &c) : cfg(c), query(marks_by_code(c.match_levels)) {
 		// MergeStrategyAbstract.cpp:8-11 : after >= before
 		cfg.min_genes_after = std::max(cfg.min_genes_after, cfg.min_genes_before);
-		if (cfg.merge_kind == 1) wl.load(Whitelist::Kind(cfg.barcodes_kind), cfg.barcodes_file);
+		if (cfg.merge_kind == 1 || cfg.merge_kind == 3) wl.load(Whitelist::Kind(cfg.barcodes_kind), cfg.barcodes_file);
 		if (cfg.umi_merge_kind == 0) srand(42);   // MergeUMIsStrategySimple.cpp:15-19
 	}
 
@@ -486,6 +489,7 @@ struct Container {
 		if (dists.empty()) return out;
 		std::sort(dists.begin(), dists.end(), [](const ComboDist &x, const ComboDist &y) { return x.ed < y.ed; });
 		unsigned max_dist = dists.front().ed;   // get_max_merge_dist(min) == min (:111-114)
+		if (cfg.merge_kind == 3) max_dist = max_dist == 0 ? 2 : max_dist + 1;   // PoissonRealBarcodesMergeStrategy.cpp:21-24
 		for (const ComboDist &cd : dists) {
 			if (cd.ed > max_dist && !out.empty()) break;
 			auto it = cell_by_cb.find(wl.barcode_of(cd.part_inds));
@@ -551,6 +555,88 @@ struct Container {
 		return top;
 	}
 
+	// ---- PoissonTargetEstimator (Estimation/Merge/PoissonTargetEstimator.cpp) --------------------------------------
+	// Rcpp::ppois(k - 1, lambda, lower = false) = P(X >= k), X ~ Poisson(lambda): summed here term by term from the
+	// mode outwards in log space (R uses its own pgamma; pinned against scipy.stats.poisson.sf in the tests)
+	static double poisson_upper_tail(long k, double lambda) {
+		if (k <= 0) return 1.0;
+		if (!(lambda > 0)) return 0.0;
+		// P(X >= k) = 1 - sum_{j<k} pmf(j) when k is below the mean (stable: the sum is not close to 1 ... unless k >> lambda),
+		// else the direct sum of the upper terms
+		auto logpmf = [&](long j) { return -lambda + double(j) * std::log(lambda) - std::lgamma(double(j) + 1.0); };
+		if (double(k) > lambda) {
+			double sum = 0;
+			for (long j = k;; ++j) {
+				const double t = std::exp(logpmf(j));
+				sum += t;
+				if (t < sum * 1e-18 || t == 0) break;
+			}
+			return sum > 1 ? 1.0 : sum;
+		}
+		double sum = 0;
+		for (long j = k - 1; j >= 0; --j) sum += std::exp(logpmf(j));
+		return sum >= 1 ? 0.0 : 1.0 - sum;
+	}
+	std::vector<double> umi_probs;
+	CollisionsAdjuster adjuster;
+	std::map<std::pair<size_t, size_t>, double> est_cache;
+	void poisson_init() {                                         // PoissonTargetEstimator::init (:46-60)
+		std::unordered_map<std::string, size_t> dist;              // CellsDataContainer::umi_distribution (:182-197)
+		for (size_t id : filtered)
+			for (auto const &g : cells[id].genes)
+				for (auto const &u : g.second) dist[umi_ix.values.at(u.first)]++;
+		double sum = 0;
+		for (auto const &it : dist) sum += double(it.second);
+		umi_probs.clear();
+		for (auto const &it : dist) umi_probs.push_back(double(it.second) / sum);
+		adjuster = CollisionsAdjuster();
+		adjuster.init(umi_probs, 0);
+		est_cache.clear();
+	}
+	double estimate_genes_intersection_size(size_t g1, size_t g2) {   // (:96-127)
+		if (g1 > g2) std::swap(g1, g2);
+		g1 = adjuster.estimate(g1); g2 = adjuster.estimate(g2);
+		auto it = est_cache.find(std::make_pair(g1, g2));
+		if (it != est_cache.end()) return it->second;
+		const size_t d = g2 - g1;
+		double est = 0;
+		for (size_t i = 0; i < umi_probs.size(); ++i) {
+			const double mn = fpow(1 - umi_probs[i], long(g1));
+			const double mx = mn * fpow(1 - umi_probs[i], long(d));
+			est += (1 - mn) * (1 - mx);
+		}
+		est_cache.emplace(std::make_pair(g1, g2), est);
+		return est;
+	}
+	double intersection_prob(size_t c1, size_t c2, double *expected_out = nullptr) {   // estimate_intersection_prob (:67-94)
+		const size_t inter = umig_intersection(cells[c1], cells[c2]);
+		if (expected_out) *expected_out = -1;
+		if (inter == 0) return 1.0;
+		double expected = 0;
+		for (auto const &g1 : cells[c1].genes) {
+			auto g2 = cells[c2].genes.find(g1.first);
+			if (g2 == cells[c2].genes.end()) continue;
+			expected += estimate_genes_intersection_size(g1.second.size(), g2->second.size());
+		}
+		if (expected_out) *expected_out = expected;
+		return poisson_upper_tail(long(inter), expected);
+	}
+	long poisson_merge_target(size_t base) {                      // get_merge_target (:22-29) + get_best_merge_target (:14-44)
+		std::vector<size_t> nb = real_neighbour_cells(base);
+		if (nb.empty()) return -1;
+		const bool base_real = nb.at(0) == base;
+		double max_prob = (base_real ? cfg.max_merge_prob : cfg.max_real_merge_prob) / double(nb.size());
+		long best = -1;
+		double min_prob = 2;
+		for (size_t n : nb) {
+			if (n == base) continue;
+			const double prob = intersection_prob(base, n);
+			if (prob < min_prob) { min_prob = prob; best = long(n); }
+		}
+		if (min_prob > max_prob) return base_real ? long(base) : -1;
+		return best;
+	}
+
 	// MergeStrategyBase.cpp:11-57, :64-82 ; DummyMergeStrategy.h:12-17
 	std::vector<size_t> run_cb_merge() {
 		std::vector<size_t> reassign(cells.size());
@@ -560,8 +646,10 @@ struct Container {
 		std::unordered_map<size_t, std::unordered_set<size_t>> reassigned_to;
 		std::vector<long> targets(filtered.size());
 		if (cfg.merge_kind == 2) simple_init();
+		if (cfg.merge_kind == 3) poisson_init();
 		for (size_t i = 0; i < filtered.size(); ++i)
-			targets[i] = cfg.merge_kind == 2 ? simple_merge_target(filtered[i]) : real_merge_target(filtered[i]);
+			targets[i] = cfg.merge_kind == 2 ? simple_merge_target(filtered[i])
+			           : cfg.merge_kind == 3 ? poisson_merge_target(filtered[i]) : real_merge_target(filtered[i]);
 		cell_ids_by_umig.clear();
 
 		for (size_t i = 0; i < filtered.size(); ++i) {
@@ -733,6 +821,7 @@ struct orc_config {
 	double umi_mult;
 	const char *match_levels;
 	int max_cells;
+	double max_merge_prob, max_real_merge_prob;
 };
 
 const char *orc_last_error() { return g_err.c_str(); }
@@ -747,6 +836,7 @@ void *orc_create(const orc_config *c) {
 		k.umi_merge_kind = c->umi_merge_kind; k.max_umi_merge_ed = unsigned(c->max_umi_merge_ed);
 		k.umi_mult = c->umi_mult; k.match_levels = c->match_levels ? c->match_levels : "eEBA";
 		k.max_cells = c->max_cells;
+		k.max_merge_prob = c->max_merge_prob; k.max_real_merge_prob = c->max_real_merge_prob;
 		return new orc::Container(k);
 	} catch (const std::exception &e) { g_err = e.what(); return nullptr; }
 }
@@ -908,6 +998,20 @@ uint64_t orc_umi_distribution(void *h, char *umi_buf, int stride, uint64_t *coun
 }
 
 // ---- fine-grained entry points used to pin the oracle on the reference's unit tests ----
+// PoissonTargetEstimator (Tests/TestEstimationMergeProbs.cpp:93-140)
+int orc_poisson_init(void *h) { ORC_TRY static_cast<orc::Container *>(h)->poisson_init(); ORC_CATCH }
+uint64_t orc_poisson_distribution_size(void *h) { return static_cast<orc::Container *>(h)->umi_probs.size(); }
+double orc_poisson_gene_intersection(void *h, uint64_t g1, uint64_t g2) {
+	try { return static_cast<orc::Container *>(h)->estimate_genes_intersection_size(g1, g2); } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+double orc_poisson_intersection_prob(void *h, uint64_t c1, uint64_t c2) {
+	try { return static_cast<orc::Container *>(h)->intersection_prob(c1, c2); } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+long orc_poisson_merge_target(void *h, uint64_t cell) {
+	try { return static_cast<orc::Container *>(h)->poisson_merge_target(cell); } catch (const std::exception &e) { g_err = e.what(); return -2; }
+}
+double orc_poisson_upper_tail(long k, double lambda) { return orc::Container::poisson_upper_tail(k, lambda); }
+
 unsigned orc_edit_distance(const char *a, const char *b, int skip_n, unsigned max_ed) { return orc::edit_distance(a, b, skip_n != 0, max_ed); }
 int orc_hamming_distance(const char *a, const char *b, int skip_n) {
 	try { return int(orc::hamming_distance(a, b, skip_n != 0)); } catch (...) { return -1; }
