@@ -51,16 +51,18 @@ def build_facade(force=False, verbose=False):
     src = os.path.join(CSRC, "host", "facade.cpp")
     rds = os.path.join(CSRC, "host", "rds_writer.cpp")
     bam = os.path.join(CSRC, "host", "bam_ingest.cpp")
+    ga = os.path.join(CSRC, "host", "gene_annotation.cpp")
     hdr = os.path.join(CSRC, "host", "facade.h")
     test_src = os.path.join(HERE, "..", "tests", "cpp", "test_facade.cpp")
     bam_tool_src = os.path.join(HERE, "..", "tests", "cpp", "bam_to_counts.cpp")
-    newest = max(os.path.getmtime(x) for x in (src, rds, bam, os.path.join(CSRC, "host", "rds_writer.h"), os.path.join(CSRC, "host", "bam_ingest.h"),
+    newest = max(os.path.getmtime(x) for x in (src, rds, bam, ga, os.path.join(CSRC, "host", "rds_writer.h"), os.path.join(CSRC, "host", "bam_ingest.h"),
+                                               os.path.join(CSRC, "host", "gene_annotation.h"),
                                                hdr, test_src, bam_tool_src, LIB))
     if not force and os.path.exists(FACADE_LIB) and os.path.exists(FACADE_TEST) and os.path.exists(BAM_TOOL) and \
             min(os.path.getmtime(FACADE_LIB), os.path.getmtime(FACADE_TEST), os.path.getmtime(BAM_TOOL)) > newest:
         return FACADE_LIB, FACADE_TEST
     cmds = [
-        ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, rds, bam, "-o", FACADE_LIB, "-L" + LIB_DIR, "-ldropest_amd", "-lz",
+        ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, rds, bam, ga, "-o", FACADE_LIB, "-L" + LIB_DIR, "-ldropest_amd", "-lz",
          "-lpthread", "-Wl,-rpath,$ORIGIN"],
         ["g++", "-O2", "-std=c++17", "-Wall", test_src, "-o", FACADE_TEST, "-L" + LIB_DIR, "-ldropest_facade", "-ldropest_amd",
          "-Wl,-rpath,$ORIGIN/../../dropest_amd/lib"],

@@ -182,6 +182,7 @@ void BamReader::parse_record(const uint8_t *at, BamRecord &rec) {
 	const uint32_t block_size = le32(at);
 	const uint8_t *p = at + 4;
 	rec.ref_id = int32_t(le32(p));
+	rec.position = int32_t(le32(p + 4));
 	const uint32_t l_read_name = p[8];
 	const uint32_t n_cigar = le16(p + 12);
 	rec.flag = le16(p + 14);
@@ -189,6 +190,13 @@ void BamReader::parse_record(const uint8_t *at, BamRecord &rec) {
 	const size_t fixed = 32, name_end = fixed + l_read_name;
 	const size_t aux = name_end + size_t(n_cigar) * 4 + (size_t(l_seq) + 1) / 2 + l_seq;
 	if (block_size < 32 || aux > block_size) throw std::runtime_error("Corrupt BAM record");
+	int64_t ref_len = 0;                                                 // CIGAR ops: MIDNSHP=X -> 0..8 (SAMv1 §4.2)
+	for (uint32_t k = 0; k < n_cigar; ++k) {
+		const uint32_t op = le32(p + name_end + size_t(k) * 4);
+		const uint32_t kind = op & 0xF;
+		if (kind == 0 || kind == 2 || kind == 3 || kind == 7 || kind == 8) ref_len += op >> 4;
+	}
+	rec.end_position = int32_t(int64_t(rec.position) + ref_len);
 	rec.name_view = std::string_view(reinterpret_cast<const char *>(p + fixed), l_read_name ? l_read_name - 1 : 0);
 	rec.tags = p + aux; rec.tags_size = block_size - aux;
 }
@@ -272,7 +280,7 @@ BamController::BamController(const BamTags &tags, bool filled_bam, const std::st
                              bool gene_in_chromosome_name, int min_barcode_phred, unsigned threads)
 	: _tags(tags), _filled_bam(filled_bam), _gene_in_chromosome_name(gene_in_chromosome_name), _min_barcode_phred(min_barcode_phred),
 	  _threads(threads) {
-	if (!gtf_path.empty()) throw std::runtime_error("gene annotation from a GTF (-g) is not built: the BAM must carry gene tags");
+	if (!gtf_path.empty()) _genes = Tools::GeneAnnotation::RefGenesContainer(gtf_path);
 	if (!read_param_filenames.empty()) throw std::runtime_error("read-parameter files (-r) are not built");
 	if (!_tags.read_type.empty() && _tags.intronic_read_value.empty())
 		throw std::runtime_error("You have to specify tag values to be able to parse info about read types (see conf_desc.xml \"Estimation/BamTags/Type/\")");
@@ -281,7 +289,7 @@ BamController::BamController(const BamTags &tags, bool filled_bam, const std::st
 void BamController::parse_bam_files(const std::vector<std::string> &bam_files, CellsDataContainer &container) {
 	const int quality_offset = 33;                                       // Tools::ReadParameters::quality_offset
 	enum : uint8_t { OK = 0, SKIP, CANT_PARSE_NO_COUNT, CANT_PARSE, LOW_QUALITY };
-	struct Parsed { CellsDataContainer::ParsedRead r; uint8_t status; };
+	struct Parsed { CellsDataContainer::ParsedRead r; uint8_t status; std::string gene; /* -g: the annotation's answer (owned) */ };
 	const unsigned nthreads = _threads ? _threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 	for (auto const &bam_name : bam_files) {
 		BamReader reader(bam_name, _threads);
@@ -327,6 +335,14 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			if (_gene_in_chromosome_name) {
 				r.gene = chr_name;
 				if (!chr_name.empty()) mark.add(UMI::Mark::HAS_EXONS);
+			} else if (!_genes.is_empty()) {                              // get_gene_from_reference (:92-151)
+				int bits;
+				try { bits = _genes.gene_of_alignment(chr_name, size_t(al.position), size_t(al.end_position), out.gene); }
+				catch (const Tools::GeneAnnotation::RefGenesContainer::ChrNotFoundException &) { out.status = CANT_PARSE; return; }   // BamController.cpp:153-161
+				if (bits & 1) mark.add(UMI::Mark::HAS_NOT_ANNOTATED);
+				if (bits & 2) mark.add(UMI::Mark::HAS_EXONS);
+				if (bits & 4) mark.add(UMI::Mark::HAS_INTRONS);
+				r.gene = out.gene;
 			} else if (!al.get_string_tag(_tags.gene, r.gene)) {
 				r.gene = std::string_view();
 				mark.add(UMI::Mark::HAS_NOT_ANNOTATED);

@@ -6,7 +6,8 @@
 //   ReadParamsParser::get_read_params (read name "id!CB#UMI", ReadParamsParser.cpp:20-33)
 //   ReadParamsParser::get_gene / parse_read_type (gene tag + optional read-type tag, :36-90)
 //   BamTags defaults (BamTags.cpp:7-24), Tools::ReadParameters quality check (Tools/ReadParameters.cpp:118-136)
-// Not built: gene annotation from a GTF (-g), the read-parameters file of droptag (-r), filtered BAM output (-F, -b).
+//   ReadParamsParser::get_gene_from_reference (-g: gene annotation from a GTF / BED file, gene_annotation.h)
+// Not built: the read-parameters file of droptag (-r), filtered BAM output (-F, -b).
 //
 // The container format: BGZF (gzip members with a 'BC' extra field, SAMv1 §4.1) holding the BAM stream (§4.2).
 // Blocks are inflated by a pool of host threads, records are parsed in stream order by the caller's thread (the
@@ -19,6 +20,7 @@
 #include <vector>
 
 #include "facade.h"
+#include "gene_annotation.h"
 
 namespace Estimation {
 namespace BamProcessing {
@@ -32,6 +34,8 @@ struct BamTags {   // BamTags.cpp:7-24 (defaults of the XML config)
 // One decoded alignment (the fields the path looks at)
 struct BamRecord {
 	int32_t ref_id = -1;
+	int32_t position = -1;           // 0-based leftmost coordinate
+	int32_t end_position = -1;       // BamAlignment::GetEndPosition(): position + reference bases consumed by the CIGAR (M, D, N, =, X)
 	uint16_t flag = 0;
 	std::string name;
 	std::string_view name_view;      // set by parse_record (points into the window)
@@ -73,8 +77,9 @@ private:
 	int _min_barcode_phred;
 	unsigned _threads;
 	Counters _counters;
+	Tools::GeneAnnotation::RefGenesContainer _genes;   // -g: empty unless a GTF / BED file was given
 public:
-	// gtf_path / read_param_filenames must be empty (not built)
+	// gtf_path: GTF / BED annotation (-g), "" = genes come from the BAM's gene tag; read_param_filenames must be empty (not built)
 	BamController(const BamTags &tags, bool filled_bam, const std::string &read_param_filenames, const std::string &gtf_path,
 	              bool gene_in_chromosome_name, int min_barcode_phred, unsigned threads = 0);
 	// BamController::parse_bam_files with a BamProcessor: every accepted read reaches container.add_record in file order

@@ -15,8 +15,8 @@ _lib = None
 
 def build_oracle(force=False):
     """Compile liboracle.so with g++ (a few seconds).  Building the checker is not using it."""
-    src = os.path.join(_HERE, "dropest_oracle.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("dropest_oracle.cpp", "gene_annotation_oracle.cpp", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(x) for x in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
     return _LIB_PATH
 
@@ -339,3 +339,105 @@ def collisions_table(probs, max_expr):
     if oracle_lib().orc_collisions_table(p.ctypes.data, len(p), max_expr, out.ctypes.data) != 0:
         raise RuntimeError(oracle_lib().orc_last_error().decode())
     return out
+
+
+# ---- gene annotation (-g): Tools/GeneAnnotation/*, ReadParamsParser::get_gene_from_reference -----------------
+class GeneAnnotationOracle:
+    """RefGenesContainer restated (oracle/gene_annotation_oracle.cpp)."""
+    TYPE = {0: "NONE", 1: "INTRON", 2: "EXON"}
+
+    def __init__(self, path):
+        self.L = oracle_lib()
+        L = self.L
+        L.orc_ga_load.restype = C.c_void_p; L.orc_ga_load.argtypes = [C.c_char_p]
+        L.orc_ga_last_error.restype = C.c_char_p
+        L.orc_ga_free.argtypes = [C.c_void_p]
+        L.orc_ga_n_chromosomes.restype = C.c_uint64; L.orc_ga_n_chromosomes.argtypes = [C.c_void_p]
+        L.orc_ga_n_homogeneous.restype = C.c_long; L.orc_ga_n_homogeneous.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_ga_homogeneous_labels.restype = C.c_long; L.orc_ga_homogeneous_labels.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+        L.orc_ga_parse_gtf.restype = C.c_int
+        L.orc_ga_parse_gtf.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_ga_query.restype = C.c_long
+        L.orc_ga_query.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.orc_ga_gene_for_read.restype = C.c_int
+        L.orc_ga_gene_for_read.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int]
+        self.h = L.orc_ga_load(path.encode())
+        if not self.h:
+            raise RuntimeError(L.orc_ga_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_ga_free(self.h)
+            self.h = None
+
+    def n_chromosomes(self):
+        return int(self.L.orc_ga_n_chromosomes(self.h))
+
+    def n_homogeneous(self, chr_):
+        return int(self.L.orc_ga_n_homogeneous(self.h, chr_.encode()))
+
+    def homogeneous_labels(self, chr_, i):
+        return int(self.L.orc_ga_homogeneous_labels(self.h, chr_.encode(), i))
+
+    def parse_gtf(self, line):
+        chr_ = C.create_string_buffer(64); gid = C.create_string_buffer(64)
+        s = C.c_uint64(); e = C.c_uint64()
+        rc = self.L.orc_ga_parse_gtf(self.h, line.encode(), chr_, gid, 64, C.byref(s), C.byref(e))
+        if rc < 0:
+            raise RuntimeError(self.L.orc_ga_last_error().decode())
+        return None if rc == 0 else (chr_.value.decode(), gid.value.decode(), int(s.value), int(e.value))
+
+    def query(self, chr_, start, end):
+        """get_gene_info -> [(gene name, type name)] in std::set order; None for an unknown chromosome"""
+        names = C.create_string_buffer(64 * 64); types = (C.c_int * 64)()
+        n = int(self.L.orc_ga_query(self.h, chr_.encode(), start, end, names, 64, types, 64))
+        if n < 0:
+            return None
+        return [(names.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode(), self.TYPE[types[i]]) for i in range(n)]
+
+    def gene_for_read(self, chr_, position, end_position):
+        """get_gene_from_reference -> (gene, mark bits); None for an unknown chromosome"""
+        gene = C.create_string_buffer(128)
+        m = int(self.L.orc_ga_gene_for_read(self.h, chr_.encode(), position, end_position, gene, 128))
+        return None if m < 0 else (gene.value.decode(), m)
+
+
+class IntervalsOracle:
+    """IntervalsContainer<std::string> restated."""
+
+    def __init__(self):
+        self.L = oracle_lib()
+        L = self.L
+        L.orc_iv_new.restype = C.c_void_p
+        L.orc_iv_free.argtypes = [C.c_void_p]
+        L.orc_iv_add.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int]
+        L.orc_iv_set_initialized.argtypes = [C.c_void_p, C.c_int]
+        L.orc_iv_n_homogeneous.restype = C.c_uint64; L.orc_iv_n_homogeneous.argtypes = [C.c_void_p]
+        L.orc_iv_homogeneous.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_iv_query.restype = C.c_long; L.orc_iv_query.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_int, C.c_int]
+        self.h = L.orc_iv_new()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_iv_free(self.h)
+            self.h = None
+
+    def add(self, s, e, label, force=False):
+        if self.L.orc_iv_add(self.h, s, e, label.encode(), int(force)) != 0:
+            raise RuntimeError(self.L.orc_ga_last_error().decode())
+
+    def set_initialized(self, clear=True):
+        self.L.orc_iv_set_initialized(self.h, int(clear))
+
+    def homogeneous(self):
+        out = []
+        for i in range(int(self.L.orc_iv_n_homogeneous(self.h))):
+            s = C.c_uint64(); e = C.c_uint64()
+            self.L.orc_iv_homogeneous(self.h, i, C.byref(s), C.byref(e))
+            out.append((int(s.value), int(e.value)))
+        return out
+
+    def query(self, s, e):
+        buf = C.create_string_buffer(64 * 32)
+        n = int(self.L.orc_iv_query(self.h, s, e, buf, 64, 32))
+        return [buf.raw[i * 64:(i + 1) * 64].split(b"\0", 1)[0].decode() for i in range(n)]

@@ -31,13 +31,18 @@ def _tag(tag, typ, value):
     raise ValueError(typ)
 
 
-def record(ref_id, pos, name, flag=0, mapq=255, seq="ACGT" * 10, tags=()):
+_CIGAR = {c: i for i, c in enumerate("MIDNSHP=X")}
+
+
+def record(ref_id, pos, name, flag=0, mapq=255, seq="ACGT" * 10, tags=(), cigar=None):
+    """cigar: list of (length, op) -- default one M over the whole read"""
     n = len(seq)
-    cigar = struct.pack("<I", (n << 4) | 0)
+    ops = cigar or [(n, "M")]
+    cigar = b"".join(struct.pack("<I", (ln << 4) | _CIGAR[op]) for ln, op in ops)
     packed = bytearray((n + 1) // 2)
     for i, c in enumerate(seq):
         packed[i // 2] |= _SEQ[c] << (4 if i % 2 == 0 else 0)
-    body = struct.pack("<iiBBHHHIiii", ref_id, pos, len(name) + 1, mapq, 4680, 1, flag, n, -1, -1, 0)
+    body = struct.pack("<iiBBHHHIiii", ref_id, pos, len(name) + 1, mapq, 4680, len(ops), flag, n, -1, -1, 0)
     body += name.encode() + b"\x00" + cigar + bytes(packed) + b"\xff" * n + b"".join(_tag(*t) for t in tags)
     return struct.pack("<I", len(body)) + body
 

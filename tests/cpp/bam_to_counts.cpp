@@ -1,6 +1,7 @@
 // BAM file(s) -> count matrices through the facade: BamController (native BGZF/BAM reader) -> CellsDataContainer ->
 // ResultsPrinter::save_results.  Used by tests/test_gpu_bam.py and as the timing harness of the ingest path.
 //   bam_to_counts <out_base> <filled|name> <min_genes_before> <min_genes_after> <whitelist|-> <threads> <bam> [<bam> ...]
+//   environment: DROPEST_GTF = annotation file for -g (genes from the alignment positions instead of the gene tag)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -22,7 +23,8 @@ int main(int argc, char **argv) {
 		CellsDataContainer c(merge, umi, UMI::Mark::get_by_code(UMI::Mark::DEFAULT_CODE));
 		BamProcessing::BamTags tags;
 		tags.read_type = "RE"; tags.intronic_read_value = "N"; tags.intergenic_read_value = "I"; tags.exonic_read_value = "E";   // configs/10x.xml style
-		BamProcessing::BamController ctl(tags, mode == "filled", "", "", false, 0, threads);
+		const char *gtf = std::getenv("DROPEST_GTF");
+		BamProcessing::BamController ctl(tags, mode == "filled", "", gtf ? gtf : "", false, 0, threads);
 		const auto t0 = std::chrono::steady_clock::now();
 		ctl.parse_bam_files(bams, c);
 		const auto t1 = std::chrono::steady_clock::now();

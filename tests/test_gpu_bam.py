@@ -124,3 +124,53 @@ def test_bad_files(tmp_path):
     for bam in (p, str(tmp_path / "missing.bam")):
         res = subprocess.run([TOOL, str(tmp_path / "o"), "filled", "1", "1", "-", "1", bam], capture_output=True, text=True)
         assert res.returncode == 1 and "BAM" in res.stderr
+
+
+def test_genes_from_a_gtf_annotation(tmp_path):
+    """-g: no gene tags in the BAM, genes and marks come from the alignment's two end points in a GTF
+    (ReadParamsParser::get_gene_from_reference); spliced alignments (N in the CIGAR) reach the next exon, soft clips
+    and insertions do not move the end.  The oracle gets the reads annotated by its own restatement of the reference."""
+    import gzip
+    from oracle import binding as ob
+    rng = np.random.default_rng(6)
+    lines = []
+    for chr_ in ("chr1", "chr2"):
+        pos = 1000
+        for g in range(60):
+            for x in range(int(rng.integers(1, 5))):
+                ln = int(rng.integers(60, 400))
+                lines.append('%s\tsrc\texon\t%d\t%d\t.\t+\t.\tgene_id "G%s_%d"; transcript_id "T%s_%d";' % (chr_, pos + 1, pos + ln, chr_, g, chr_, g))
+                pos += ln + int(rng.integers(50, 600))
+            pos += int(rng.integers(0, 2000))
+    gtf = str(tmp_path / "ann.gtf.gz")
+    with gzip.open(gtf, "wt") as f:
+        f.write("\n".join(lines) + "\n")
+    ann = ob.GeneAnnotationOracle(gtf)
+    s = SynthStream(n_reads=30_000, n_cells=15, n_genes=10, umi_len=8)
+    cb, umi, _, _ = s.generate_host()
+    refs = [("chr1", 1_000_000), ("chr2", 1_000_000), ("chrUn", 1000)]
+    recs, kept, n_unknown = [], [], 0
+    for i in range(len(cb)):
+        c, u = capi.unpack_code(cb[i]), capi.unpack_code(umi[i])
+        rid = int(rng.integers(0, 3)) if i % 50 == 0 else int(rng.integers(0, 2))
+        p = int(rng.integers(0, 120_000))
+        cigar = [[(40, "M")], [(5, "S"), (35, "M")], [(15, "M"), (int(rng.integers(50, 900)), "N"), (25, "M")],
+                 [(20, "M"), (3, "I"), (10, "M"), (2, "D"), (7, "M")]][int(rng.integers(0, 4))]
+        end = p + sum(ln for ln, op in cigar if op in "MDN=X")
+        recs.append(bw.record(rid, p, "r%d" % i, tags=[("CB", "Z", c), ("UB", "Z", u)], cigar=cigar))
+        got = ann.gene_for_read(refs[rid][0], p, end)
+        if got is None:
+            n_unknown += 1
+            continue
+        kept.append((c, u, got[0] or None, refs[rid][0], got[1]))
+    bam = str(tmp_path / "g.bam")
+    bw.write_bam(bam, refs, recs, block=30_000)
+    os.environ["DROPEST_GTF"] = gtf
+    try:
+        got, cells, stats, d = _run(tmp_path, "filled", [bam], 2, 3)
+    finally:
+        del os.environ["DROPEST_GTF"]
+    want, cols = _oracle(kept, 2, 3)
+    assert cells == cols and got == want and len(want) > 100
+    assert stats["cant_parse"] == n_unknown > 0 and stats["saved"] == len(kept)
+    assert sum(1 for k in kept if k[4] & 1) > 100 and sum(1 for k in kept if k[2] is None) > 1000    # half-annotated and intergenic reads

@@ -317,3 +317,55 @@ def test_poisson_upper_tail_against_scipy():
         k = int(rng.integers(0, 60)) if rng.random() < 0.5 else int(max(0, rng.normal(lam, 3 * np.sqrt(lam) + 2)))
         got, want = ob.poisson_upper_tail(k, lam), float(poisson.sf(k - 1, lam))
         assert abs(got - want) <= 1e-12 * max(want, 1e-300) + 1e-15 or abs(got - want) / max(want, 1e-300) < 1e-9, (k, lam, got, want)
+
+
+# ---------------------------------------------------------------------------------------------------
+# -g: Tools/GeneAnnotation (Tests/TestTools.cpp)
+# ---------------------------------------------------------------------------------------------------
+GTF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gtf_test.gtf.gz")   # the reference's data/gtf/gtf_test.gtf.gz
+
+
+def test_gtf_record_parsing():
+    """testGtf (Tests/TestTools.cpp:31-44)."""
+    g = ob.GeneAnnotationOracle(GTF)
+    line = ('chr1\tunknown\texon\t878633  878757  .       +       2       gene_id "SAMD11"; gene_name "SAMD11"; p_id "P11277"; '
+            'transcript_id "NM_152486"; tss_id "TSS28354";')
+    assert g.parse_gtf(line) == ("chr1", "SAMD11", 878632, 878757)
+
+
+def test_intervals_container_merging():
+    """testGeneMerge (:89-126)."""
+    iv = ob.IntervalsOracle()
+    for s, e in ((0, 100), (200, 300), (400, 500)):
+        iv.add(s, e, "")
+    iv.set_initialized(False)
+    h = iv.homogeneous()
+    assert len(h) == 3 and h[-1] == (400, 500)
+    iv.add(90, 110, "", True); iv.set_initialized(False)
+    assert iv.homogeneous()[0][1] == 110
+    iv.add(150, 190, "", True); iv.set_initialized(False)
+    assert len(iv.homogeneous()) == 4
+    iv.add(110, 151, "", True); iv.set_initialized(False)
+    h = iv.homogeneous()
+    assert len(h) == 3 and h[0][1] == 190
+    iv.add(190, 401, "", True); iv.set_initialized(False)
+    assert iv.homogeneous() == [(0, 500)]
+
+
+def test_intervals_container_queries():
+    """testInterval (:244-264)."""
+    iv = ob.IntervalsOracle()
+    iv.add(10, 20, "i1"); iv.add(10, 20, "i1"); iv.add(15, 30, "i1"); iv.add(15, 20, "i2")
+    iv.set_initialized()
+    assert iv.query(0, 11) == ["i1"] and iv.query(0, 5) == [] and iv.query(25, 30) == ["i1"] and iv.query(17, 20) == ["i1", "i2"]
+
+
+def test_gtf_container_init_and_intron_queries():
+    """testInitGtf (:128-140) and testGenesWithIntrons (:266-287)."""
+    g = ob.GeneAnnotationOracle(GTF)
+    assert g.n_chromosomes() == 3
+    assert g.n_homogeneous("chr1") == 8 and g.homogeneous_labels("chr1", 7) == 1 and g.n_homogeneous("chr2") == 5
+    assert g.query("chr1", 20000, 20010) == [("WASH7P", "INTRON")]
+    assert g.query("chr1", 24750, 24760) == [("WASH7P", "EXON")]
+    assert g.query("chr1", 10, 20) == []
+    assert g.query("chrNope", 10, 20) is None
