@@ -10,7 +10,7 @@ from .build import LIB, build
 ESCAPE = 1 << 63
 NO_GENE = 0xFFFFFFFF
 
-MERGE_NONE, MERGE_REAL_BARCODES, MERGE_SIMPLE = 0, 1, 2
+MERGE_NONE, MERGE_REAL_BARCODES, MERGE_SIMPLE, MERGE_POISSON_REAL = 0, 1, 2, 3
 BARCODES_INDROP, BARCODES_CONST = 0, 1
 UMI_MERGE_SIMPLE, UMI_MERGE_DIRECTIONAL = 0, 1
 
@@ -30,7 +30,7 @@ class Cfg(C.Structure):
         ("min_merge_fraction", C.c_double), ("max_cb_merge_edit_distance", C.c_int32),
         ("umi_merge_kind", C.c_int32), ("max_umi_merge_edit_distance", C.c_int32),
         ("gene_match_levels", C.c_char_p), ("max_cells", C.c_int32), ("cb_table_capacity", C.c_uint64),
-        ("umi_merge_multiplier", C.c_double),
+        ("umi_merge_multiplier", C.c_double), ("max_merge_prob", C.c_double), ("max_real_merge_prob", C.c_double),
     ]
 
 
@@ -107,6 +107,7 @@ def lib():
         "dropest_count_matrix_csc": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
         "dropest_chr_stats": (C.c_int, [vp, u64p, vp, vp, vp, vp]),
         "dropest_merge_target": (C.c_int, [vp, C.c_uint64, P(C.c_int64)]),
+        "dropest_poisson_intersection_prob": (C.c_int, [vp, C.c_uint64, C.c_uint64, u64p, P(C.c_double), P(C.c_double)]),
         "dropest_umi_distribution": (C.c_int, [vp, u64p, vp, vp]),
         "dropest_collisions_adjusted_sizes": (C.c_int, [C.c_int, vp, C.c_uint64, C.c_uint64, vp]),
         "dropest_owner_of": (C.c_uint32, [C.c_uint64, C.c_uint32]),
@@ -161,7 +162,7 @@ EXPORTED_SYMBOLS = [
     "dropest_count_matrix_csc", "dropest_owner_of", "dropest_partition_by_owner", "dropest_partition_scratch_bytes", "dropest_clear_reads",
     "dropest_count_matrix_device", "dropest_cell_first_reads_device", "dropest_assemble_columns",
     "dropest_real_candidate_rows", "dropest_dev_copy_device", "dropest_umi_distribution",
-    "dropest_collisions_adjusted_sizes",
+    "dropest_collisions_adjusted_sizes", "dropest_poisson_intersection_prob",
     "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_stream",
     "dropest_sort_layout", "dropest_host_register", "dropest_host_unregister", "dropest_ingest", "dropest_ingest_summary_get", "dropest_ingest_summary_set",
     "dropest_gene_chr_table", "dropest_shard_merge_search", "dropest_shard_merge_pairs", "dropest_shard_merge_export",
@@ -202,7 +203,8 @@ class Context:
     def __init__(self, device=0, merge_kind=MERGE_NONE, barcodes_kind=BARCODES_INDROP, barcodes_file=None,
                  min_genes_before_merge=10, min_genes_after_merge=10, min_merge_fraction=0.2,
                  max_cb_merge_edit_distance=2, max_umi_merge_edit_distance=1, gene_match_levels="eEBA",
-                 max_cells=-1, cb_table_capacity=0, umi_merge_kind=UMI_MERGE_SIMPLE, umi_merge_multiplier=2.0):
+                 max_cells=-1, cb_table_capacity=0, umi_merge_kind=UMI_MERGE_SIMPLE, umi_merge_multiplier=2.0,
+                 max_merge_prob=1e-4, max_real_merge_prob=1e-7):
         self.L = lib()
         self.device = device
         cfg = Cfg()
@@ -216,6 +218,7 @@ class Context:
         cfg.max_umi_merge_edit_distance = max_umi_merge_edit_distance; cfg.max_cells = max_cells
         cfg.cb_table_capacity = cb_table_capacity
         cfg.umi_merge_kind = umi_merge_kind; cfg.umi_merge_multiplier = umi_merge_multiplier
+        cfg.max_merge_prob = max_merge_prob; cfg.max_real_merge_prob = max_real_merge_prob
         h = C.c_void_p()
         self.h = None
         self._chk(self.L.dropest_ctx_create(C.byref(cfg), C.byref(h)))
@@ -462,6 +465,12 @@ class Context:
         t = C.c_int64()
         self._chk(self.L.dropest_merge_target(self.h, cell, C.byref(t)))
         return t.value
+
+    def poisson_intersection_prob(self, cell1, cell2):
+        """(intersection size, expected intersection size, merge probability) -- PoissonTargetEstimator::estimate_intersection_prob."""
+        n, e, p = C.c_uint64(), C.c_double(), C.c_double()
+        self._chk(self.L.dropest_poisson_intersection_prob(self.h, cell1, cell2, C.byref(n), C.byref(e), C.byref(p)))
+        return n.value, e.value, p.value
 
     def sort_layout(self):
         out = (C.c_uint32 * 6)()

@@ -239,6 +239,13 @@ struct dropest_ctx {
 	void search_merge_candidates(const std::vector<u32> &cells, const dropest::MergeUniverse &U, dropest::MergeSearch &S);
 	void decide_merge_targets(const dropest::MergeUniverse &U, dropest::MergeSearch &S, const std::vector<u32> &inter,
 	                          std::vector<long> &targets, std::vector<u32> &target_ridx);
+	std::vector<std::vector<u32>> replay_candidate_orders(const dropest::MergeUniverse &U, dropest::MergeSearch &S,
+	                                                      const std::vector<u32> &need_order);
+	std::vector<u32> pair_intersections(const std::vector<u32> &pair_base_cell, const std::vector<u32> &pair_cand_cell);
+	// PoissonRealBarcodesMergeStrategy (poisson_merge.h)
+	std::vector<double> poisson_expected_intersections(const std::vector<u32> &pair_base_cell, const std::vector<u32> &pair_cand_cell);
+	void decide_poisson_targets(const dropest::MergeUniverse &U, dropest::MergeSearch &S, const std::vector<u32> &inter,
+	                            const std::vector<double> &expected, std::vector<long> &targets, std::vector<u32> &target_ridx);
 	std::vector<long> compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx,
 	                                        std::vector<u32> *target_ridx = nullptr);
 	dropest::DevBuf<u32> cell_real_index;   // [n_cells] cell id -> index in `real` (0xFFFFFFFF otherwise)

@@ -65,7 +65,8 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 	if (c.min_genes_before_merge < 0 || c.min_genes_after_merge < 0) throw InvalidError("negative gene threshold");
 	min_before = u32(c.min_genes_before_merge);
 	min_after = std::max(u32(c.min_genes_after_merge), min_before);   // MergeStrategyAbstract.cpp:8-11
-	if (c.merge_kind != DROPEST_MERGE_NONE && c.merge_kind != DROPEST_MERGE_REAL_BARCODES && c.merge_kind != DROPEST_MERGE_SIMPLE)
+	if (c.merge_kind != DROPEST_MERGE_NONE && c.merge_kind != DROPEST_MERGE_REAL_BARCODES && c.merge_kind != DROPEST_MERGE_SIMPLE &&
+	    c.merge_kind != DROPEST_MERGE_POISSON_REAL)
 		throw InvalidError("unknown merge_kind");
 	if (c.umi_merge_kind != DROPEST_UMI_MERGE_SIMPLE && c.umi_merge_kind != DROPEST_UMI_MERGE_DIRECTIONAL)
 		throw InvalidError("unknown umi_merge_kind");
@@ -628,6 +629,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 #include "umi_merge_host.h"
 #include "umi_directional_host.h"
 #include "simple_merge.h"
+#include "poisson_merge.h"
 
 // ------------------------------------------------------------------------------------------------
 // top-level stages
@@ -667,6 +669,7 @@ void dropest_ctx::run_merge_and_filter() {
 	if (merged) throw InvalidError("merge_and_filter was already run");
 	HostStage hs(this, "merge_and_filter");
 	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells && !external_merge_done) run_cb_merge_real();
+	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL && n_cells) run_cb_merge_real();   // same loop, Poisson decisions
 	if (cfg.merge_kind == DROPEST_MERGE_SIMPLE && n_cells) run_cb_merge_simple();
 	// MergeUMIsStrategy*::merge, after the CB merge (CellsDataContainer.cpp:45)
 	if (cfg.umi_merge_kind == DROPEST_UMI_MERGE_DIRECTIONAL) run_umi_merge_directional(); else run_umi_merge_simple();
@@ -764,6 +767,8 @@ void dropest_cfg_defaults(dropest_cfg *cfg) {
 	cfg->max_cb_merge_edit_distance = 2;
 	cfg->umi_merge_kind = DROPEST_UMI_MERGE_SIMPLE;
 	cfg->umi_merge_multiplier = 2.0;
+	cfg->max_merge_prob = 1e-4;
+	cfg->max_real_merge_prob = 1e-7;
 	cfg->max_umi_merge_edit_distance = 1;
 	cfg->gene_match_levels = "eEBA";
 	cfg->max_cells = -1;
@@ -1304,11 +1309,33 @@ dropest_status dropest_collisions_adjusted_sizes(int device, const double *umi_p
 	});
 }
 
+dropest_status dropest_poisson_intersection_prob(dropest_ctx *ctx, uint64_t cell1, uint64_t cell2, uint64_t *intersection_size,
+                                                 double *expected_intersection_size, double *merge_probability) {
+	return guarded([&] {
+		need_init(ctx);
+		if (ctx->merged) throw InvalidError("the estimator is defined on the un-merged state (call before merge_and_filter)");
+		if (cell1 >= ctx->n_cells || cell2 >= ctx->n_cells) throw RangeError("cell index out of range");
+		const std::vector<u32> b{u32(cell1)}, c{u32(cell2)};
+		const u32 inter = ctx->pair_intersections(b, c)[0];
+		double expected = -1, prob = 1;
+		if (inter) {
+			expected = ctx->poisson_expected_intersections(b, c)[0];
+			prob = poisson_upper_tail(long(inter), expected);
+		}
+		if (intersection_size) *intersection_size = inter;
+		if (expected_intersection_size) *expected_intersection_size = expected;
+		if (merge_probability) *merge_probability = prob;
+	});
+}
+
 dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *target) {
 	return guarded([&] {
 		need_init(ctx);
 		if (ctx->merged) throw InvalidError("merge targets are defined on the un-merged state (call before merge_and_filter)");
-		if (ctx->cfg.merge_kind != DROPEST_MERGE_REAL_BARCODES) { *target = int64_t(cell); return; }   // DummyMergeStrategy
+		if (ctx->cfg.merge_kind != DROPEST_MERGE_REAL_BARCODES && ctx->cfg.merge_kind != DROPEST_MERGE_POISSON_REAL) {
+			*target = int64_t(cell);   // DummyMergeStrategy
+			return;
+		}
 		if (cell >= ctx->n_cells) throw RangeError("cell index out of range");
 		*target = ctx->compute_merge_targets(std::vector<u32>{u32(cell)}, std::vector<u32>{ctx->real_at(u32(cell))})[0];
 	});

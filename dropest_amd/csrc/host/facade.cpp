@@ -279,6 +279,19 @@ long CellsDataContainer::get_merge_target(size_t base_cell_ind) const {
 	return long(t);
 }
 
+Merge::PoissonTargetEstimator::EstimationResult
+Merge::PoissonTargetEstimator::estimate_intersection_prob(const CellsDataContainer &container, size_t cell1_ind, size_t cell2_ind) const {
+	size_t n = 0; double expected = -1, prob = 1;
+	container.poisson_intersection(cell1_ind, cell2_ind, n, expected, prob);
+	return EstimationResult{n, expected, prob};
+}
+
+void CellsDataContainer::poisson_intersection(size_t cell1_ind, size_t cell2_ind, size_t &intersection, double &expected, double &probability) const {
+	uint64_t n = 0;
+	check(dropest_poisson_intersection_prob(_ctx, cell1_ind, cell2_ind, &n, &expected, &probability));
+	intersection = size_t(n);
+}
+
 Cell CellsDataContainer::cell(size_t index) const {
 	Cell c;
 	c._owner = this; c._id = index;

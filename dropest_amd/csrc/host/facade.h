@@ -109,6 +109,8 @@ public:
 	const std::vector<std::string> &values() const { return _values; }
 };
 
+class CellsDataContainer;
+
 namespace Merge {
 // Parameter carriers: the strategy objects of the reference own the merge algorithm; here the algorithm lives on the
 // device and these classes only say WHICH strategy with WHICH thresholds (MergeStrategyFactory.cpp:61-111).
@@ -152,6 +154,32 @@ public:
 	void fill(dropest_cfg &cfg) const override {
 		cfg.merge_kind = DROPEST_MERGE_REAL_BARCODES; cfg.barcodes_kind = _kind; cfg.barcodes_file = _file.c_str();
 		cfg.max_cb_merge_edit_distance = int(_max_ed); cfg.min_merge_fraction = _min_fraction;
+	}
+};
+// Estimation/Merge/PoissonTargetEstimator.h:57 + PoissonRealBarcodesMergeStrategy.h (-M with a barcodes file)
+struct PoissonTargetEstimator {
+	struct EstimationResult {                                  // PoissonTargetEstimator.h:21-33
+		size_t intersection_size; double expected_intersection_size, merge_probability;
+	};
+	double max_merge_prob, max_real_cb_merge_prob;
+	PoissonTargetEstimator(double max_merge_prob_, double max_real_cb_merge_prob_)
+		: max_merge_prob(max_merge_prob_), max_real_cb_merge_prob(max_real_cb_merge_prob_) {}
+	// PoissonTargetEstimator.cpp:67-94; the UMI distribution is taken from the container's filtered cells (init, :46-60)
+	EstimationResult estimate_intersection_prob(const CellsDataContainer &container, size_t cell1_ind, size_t cell2_ind) const;
+};
+class PoissonRealBarcodesMergeStrategy : public MergeStrategyAbstract {
+	PoissonTargetEstimator _estimator; std::string _file; int _kind; unsigned _max_ed;
+public:
+	PoissonRealBarcodesMergeStrategy(const PoissonTargetEstimator &target_estimator, RealBarcodesMergeStrategy::BarcodesType type,
+	                                 const std::string &barcodes_filename, size_t min_genes_before_merge, size_t min_genes_after_merge,
+	                                 unsigned max_merge_edit_distance)
+		: MergeStrategyAbstract(min_genes_before_merge, min_genes_after_merge), _estimator(target_estimator), _file(barcodes_filename),
+		  _kind(type), _max_ed(max_merge_edit_distance) {}
+	std::string merge_type() const override { return "Poisson Real CBs"; }
+	void fill(dropest_cfg &cfg) const override {
+		cfg.merge_kind = DROPEST_MERGE_POISSON_REAL; cfg.barcodes_kind = _kind; cfg.barcodes_file = _file.c_str();
+		cfg.max_cb_merge_edit_distance = int(_max_ed); cfg.min_merge_fraction = 0;   // PoissonRealBarcodesMergeStrategy.cpp:15-16
+		cfg.max_merge_prob = _estimator.max_merge_prob; cfg.max_real_merge_prob = _estimator.max_real_cb_merge_prob;
 	}
 };
 namespace UMIs {
@@ -275,6 +303,8 @@ public:
 	const ids_t &filtered_cells() const;
 	const ids_t &merge_targets() const;
 	const UMI::Mark::query_t &gene_match_level() const { return _query_marks; }
+	// PoissonTargetEstimator::estimate_intersection_prob's numbers for two cells (PoissonTargetEstimator.cpp:67-94)
+	void poisson_intersection(size_t cell1_ind, size_t cell2_ind, size_t &intersection, double &expected, double &probability) const;
 	long get_merge_target(size_t base_cell_ind) const;                  // RealBarcodesMergeStrategy::get_merge_target
 
 	s_i_hash_t get_stat_by_real_cells(Stats::CellStatType type) const;

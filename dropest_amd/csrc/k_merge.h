@@ -107,6 +107,7 @@ struct WlArgs {
 	uint32_t *flat_total;    // running size of the flat lists (atomic)
 	uint32_t flat_cap;
 	uint8_t *dist_dump;      // optional [n_bases][part_size[0] + part_size[1]] per-part distances (tie replay), or null
+	int poisson;             // PoissonRealBarcodesMergeStrategy::get_max_merge_dist: all levels up to (min == 0 ? 2 : min + 1)
 };
 
 // one block per filtered cell; dynamic LDS: dist bytes [n0 + n1] + index lists u16 [n0 + n1]
@@ -156,10 +157,18 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 	}
 	__syncthreads();
 
-	// 3. levels of increasing total distance; stop after the first level with a candidate
+	// 3. levels of increasing total distance (RealBarcodesMergeStrategy::get_real_neighbour_cbs, :63-109): every level
+	//    up to max_dist = get_max_merge_dist(smallest distance of ANY whitelist combination), then further levels one
+	//    at a time while no candidate has been found; a level is taken whole
 	const uint32_t base_umis = a.cell_total_umis[b.cell];
-	uint32_t level = 0;
-	for (; level <= WL_MAX_DIST; ++level) {
+	uint32_t level = 0, min_level = WL_MAX_DIST + 1;
+	for (uint32_t l = 0; l <= WL_MAX_DIST && min_level > WL_MAX_DIST; ++l)
+		for (uint32_t d0 = 0; d0 <= l; ++d0)
+			if (cnt[0][d0] && cnt[1][l - d0]) { min_level = l; break; }
+	uint32_t max_dist = a.poisson ? (min_level == 0 ? 2u : min_level + 1u) : min_level;
+	uint32_t last_level = min_level;
+	for (level = min_level; level <= WL_MAX_DIST; ++level) {
+		last_level = level;
 		for (uint32_t d0 = 0; d0 <= level; ++d0) {
 			const uint32_t d1 = level - d0;
 			const uint32_t na = cnt[0][d0], nb = cnt[1][d1];
@@ -178,10 +187,13 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 				}
 			}
 		}
-		__syncthreads();
-		if (n_found) break;
-		__syncthreads();
+		__syncthreads();                  // n_found of this level is final for everybody
+		const uint32_t found_so_far = n_found;
+		__syncthreads();                  // ... and read by everybody before the next level adds to it
+		if (level > max_dist) max_dist = level;
+		if (level + 1 > max_dist && found_so_far) break;
 	}
+	level = last_level;
 	// append this cell's candidates to the flat lists
 	const uint32_t keep = n_found < uint32_t(WL_CAND_CAP) ? n_found : uint32_t(WL_CAND_CAP);
 	if (tid == 0) {

@@ -16,7 +16,7 @@ struct ComboH { size_t i0, i1; unsigned ed; };
 // the same std::sort calls on the same sequences (BarcodesParser.cpp:21-74, RealBarcodesMergeStrategy.cpp:63-109).
 // Only needed when the arg-max of the merge fraction is tied (the reference's result then depends on this order).
 std::vector<u32> reference_candidate_order(const dropest::Whitelist &wl, const uint8_t *dist,
-                                           const std::unordered_map<u64, u32> &qualifying_by_code) {
+                                           const std::unordered_map<u64, u32> &qualifying_by_code, bool poisson) {
 	std::vector<std::vector<PartDistH>> d(2);
 	size_t off = 0;
 	for (int p = 0; p < 2; ++p) {
@@ -37,6 +37,7 @@ std::vector<u32> reference_candidate_order(const dropest::Whitelist &wl, const u
 	if (combos.empty()) return out;
 	std::sort(combos.begin(), combos.end(), [](const ComboH &x, const ComboH &y) { return x.ed < y.ed; });
 	unsigned max_dist = combos.front().ed;
+	if (poisson) max_dist = max_dist == 0 ? 2 : max_dist + 1;   // PoissonRealBarcodesMergeStrategy::get_max_merge_dist (:20-23)
 	for (const ComboH &c : combos) {
 		if (c.ed > max_dist && !out.empty()) break;
 		u64 code = 0;
@@ -139,6 +140,7 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 		a.cand_count = d_cnt.p; a.cand_level = d_lvl.p; a.cand_off = d_off.p; a.flat_cell = d_fcell.p; a.flat_umis = d_fumis.p;
 		a.flat_ridx = d_fridx.p; a.cell_real_index = U.real_index;
 		a.flat_total = scalars.p; a.flat_cap = flat_cap; a.dist_dump = nullptr;
+		a.poisson = cfg.merge_kind == DROPEST_MERGE_POISSON_REAL ? 1 : 0;
 		timed("wl_neighbours", double(F) * S.ntot * 32, [&] {
 			hipLaunchKernelGGL(wl_neighbours_kernel, dim3(F), dim3(WL_THREADS), S.lds, stream, a);
 		});
@@ -167,13 +169,47 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 		bool self = false;
 		for (u32 k = 0; k < S.cnt[f]; ++k)
 			if (S.fcell[S.off[f] + k] == cells[f]) { self = true; S.self_ridx[f] = S.fridx[S.off[f] + k]; }
-		if (self) continue;   // the base is itself a whitelist barcode: neighbour_cells[0] == base (RealBarcodesMergeStrategy.cpp:34-35)
+		// the base is itself a whitelist barcode: neighbour_cells[0] == base (RealBarcodesMergeStrategy.cpp:34-35) ends the
+		// decision there; the Poisson estimator goes on to its other neighbours (PoissonTargetEstimator.cpp:26-29)
+		if (self && cfg.merge_kind != DROPEST_MERGE_POISSON_REAL) continue;
 		for (u32 k = 0; k < S.cnt[f]; ++k) {
+			if (S.fcell[S.off[f] + k] == cells[f]) continue;
 			S.pair_base.push_back(f); S.pair_cand.push_back(S.fcell[S.off[f] + k]); S.pair_umis.push_back(S.fumis[S.off[f] + k]);
 			S.pair_ridx.push_back(S.fridx[S.off[f] + k]);
 		}
 	}
 	S.pair_first[F] = u32(S.pair_base.size());
+}
+
+// The reference's candidate order (a replay of its two unstable std::sorts) for the bases in `need_order`: the
+// kernel runs again for those bases only and dumps the per-part distances.  Only candidates that are part of S's
+// pairs appear (the base itself is skipped like PoissonTargetEstimator.cpp:28-29 does).
+std::vector<std::vector<u32>> dropest_ctx::replay_candidate_orders(const MergeUniverse &U, MergeSearch &S, const std::vector<u32> &need_order) {
+	const u32 R = u32(need_order.size()), ntot = S.ntot;
+	std::vector<WlBase> rb(R);
+	for (u32 r = 0; r < R; ++r) HIP_CHECK(hipMemcpy(&rb[r], S.d_bases.p + need_order[r], sizeof(WlBase), hipMemcpyDeviceToHost));
+	DevBuf<WlBase> d_rb; d_rb.alloc(R);
+	DevBuf<uint8_t> d_dump; d_dump.alloc(size_t(R) * ntot);
+	DevBuf<u32> d_c2, d_l2, d_o2, d_f2, d_u2, d_r2;
+	d_c2.alloc(R); d_l2.alloc(R); d_o2.alloc(R); d_f2.alloc(size_t(R) * WL_CAND_CAP); d_u2.alloc(size_t(R) * WL_CAND_CAP);
+	d_r2.alloc(size_t(R) * WL_CAND_CAP);
+	HIP_CHECK(hipMemcpyAsync(d_rb.p, rb.data(), size_t(R) * sizeof(WlBase), hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
+	WlArgs a2 = S.args;
+	a2.bases = d_rb.p; a2.n_bases = R; a2.cand_count = d_c2.p; a2.cand_level = d_l2.p; a2.cand_off = d_o2.p;
+	a2.flat_cell = d_f2.p; a2.flat_umis = d_u2.p; a2.flat_ridx = d_r2.p; a2.flat_cap = R * u32(WL_CAND_CAP); a2.dist_dump = d_dump.p;
+	hipLaunchKernelGGL(wl_neighbours_kernel, dim3(R), dim3(WL_THREADS), S.lds, stream, a2);
+	HIP_CHECK(hipGetLastError());
+	std::vector<uint8_t> dump(size_t(R) * ntot);
+	fetch(dump.data(), d_dump.p, dump.size());
+	std::vector<std::vector<u32>> orders(R);
+	for (u32 r = 0; r < R; ++r) {
+		const u32 f = need_order[r];
+		std::unordered_map<u64, u32> by_code;
+		for (u32 p = S.pair_first[f]; p < S.pair_first[f + 1]; ++p) by_code[U.barcode_code(S.pair_cand[p])] = S.pair_cand[p];
+		orders[r] = reference_candidate_order(wl, dump.data() + size_t(r) * ntot, by_code, S.args.poisson != 0);
+	}
+	return orders;
 }
 
 // Decisions (RealBarcodesMergeStrategy::get_best_merge_target, :31-61) from the intersection sizes of S's pairs;
@@ -203,33 +239,12 @@ void dropest_ctx::decide_merge_targets(const MergeUniverse &U, MergeSearch &S, c
 		need_order.push_back(f);   // tie at the maximum (or all fractions zero with a non-positive threshold)
 	}
 	if (need_order.empty()) return;
-	const u32 R = u32(need_order.size()), ntot = S.ntot;
-	std::vector<WlBase> rb(R);
-	for (u32 r = 0; r < R; ++r) HIP_CHECK(hipMemcpy(&rb[r], S.d_bases.p + need_order[r], sizeof(WlBase), hipMemcpyDeviceToHost));
-	DevBuf<WlBase> d_rb; d_rb.alloc(R);
-	DevBuf<uint8_t> d_dump; d_dump.alloc(size_t(R) * ntot);
-	DevBuf<u32> d_c2, d_l2, d_o2, d_f2, d_u2, d_r2;
-	d_c2.alloc(R); d_l2.alloc(R); d_o2.alloc(R); d_f2.alloc(size_t(R) * WL_CAND_CAP); d_u2.alloc(size_t(R) * WL_CAND_CAP);
-	d_r2.alloc(size_t(R) * WL_CAND_CAP);
-	HIP_CHECK(hipMemcpyAsync(d_rb.p, rb.data(), size_t(R) * sizeof(WlBase), hipMemcpyHostToDevice, stream));
-	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
-	WlArgs a2 = S.args;
-	a2.bases = d_rb.p; a2.n_bases = R; a2.cand_count = d_c2.p; a2.cand_level = d_l2.p; a2.cand_off = d_o2.p;
-	a2.flat_cell = d_f2.p; a2.flat_umis = d_u2.p; a2.flat_ridx = d_r2.p; a2.flat_cap = R * u32(WL_CAND_CAP); a2.dist_dump = d_dump.p;
-	hipLaunchKernelGGL(wl_neighbours_kernel, dim3(R), dim3(WL_THREADS), S.lds, stream, a2);
-	HIP_CHECK(hipGetLastError());
-	std::vector<uint8_t> dump(size_t(R) * ntot);
-	fetch(dump.data(), d_dump.p, dump.size());
-	// barcodes of the candidates (whitelist cells, hence real-candidate cells) for the replay
-	for (u32 r = 0; r < R; ++r) {
+	const std::vector<std::vector<u32>> orders = replay_candidate_orders(U, S, need_order);
+	for (u32 r = 0; r < u32(need_order.size()); ++r) {
 		const u32 f = need_order[r];
-		std::unordered_map<u64, u32> by_code;
 		std::unordered_map<u32, u32> pair_of;
-		for (u32 p = S.pair_first[f]; p < S.pair_first[f + 1]; ++p) {
-			by_code[U.barcode_code(S.pair_cand[p])] = S.pair_cand[p];
-			pair_of[S.pair_cand[p]] = p;
-		}
-		const std::vector<u32> order = reference_candidate_order(wl, dump.data() + size_t(r) * ntot, by_code);
+		for (u32 p = S.pair_first[f]; p < S.pair_first[f + 1]; ++p) pair_of[S.pair_cand[p]] = p;
+		const std::vector<u32> &order = orders[r];
 		if (order.empty()) throw DeviceError("internal: candidate replay found no candidate");
 		double best = 0; u32 best_cell = order[0];
 		for (u32 c : order) {
@@ -239,6 +254,27 @@ void dropest_ctx::decide_merge_targets(const MergeUniverse &U, MergeSearch &S, c
 		targets[f] = best < cfg.min_merge_fraction ? -1 : long(best_cell);
 		if (targets[f] >= 0) target_ridx[f] = S.pair_ridx[pair_of.at(best_cell)];
 	}
+}
+
+// CellsDataContainer.cpp:320-350 (get_umigs_intersect_size) for a list of cell pairs of this context
+std::vector<u32> dropest_ctx::pair_intersections(const std::vector<u32> &pb, const std::vector<u32> &pc) {
+	const u32 NP = u32(pb.size());
+	std::vector<u32> inter(NP);
+	if (!NP) return inter;
+	DevBuf<u32> d_pb, d_pc, d_inter; DevBuf<PairRange> d_pr;
+	d_pb.alloc(NP); d_pc.alloc(NP); d_inter.alloc(NP); d_pr.alloc(NP);
+	HIP_CHECK(hipMemcpyAsync(d_pb.p, pb.data(), size_t(NP) * 4, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemcpyAsync(d_pc.p, pc.data(), size_t(NP) * 4, hipMemcpyHostToDevice, stream));
+	hipLaunchKernelGGL(pair_ranges_kernel, dim3(div_up(NP, 256)), dim3(256), 0, stream, d_pb.p, d_pc.p, NP, cell_cg_begin.p,
+	                   cell_cg_count.p, cg_mol_begin.p, d_pr.p);
+	HIP_CHECK(hipGetLastError());
+	const int low_bits = layout.gene_bits + layout.umi_bits;
+	timed("umig_intersect", double(NP) * 64, [&] {
+		hipLaunchKernelGGL(umig_intersect_kernel, dim3(NP), dim3(256), 0, stream, d_pr.p, NP, mol_key.p, mol_key.p,
+		                   (1ull << low_bits) - 1ull, layout.umi_bits, layout.gene_none, d_inter.p);
+	});
+	fetch(inter.data(), d_inter.p, size_t(NP) * 4);
+	return inter;
 }
 
 // RealBarcodesMergeStrategy::get_merge_target for a list of this context's cells, on the current (unmerged) device
@@ -271,26 +307,15 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 	search_merge_candidates(cells, U, S);
 
 	const u32 NP = u32(S.pair_base.size());
-	std::vector<u32> inter(NP);
-	if (NP) {
-		std::vector<u32> pb(NP);
-		for (u32 p = 0; p < NP; ++p) pb[p] = cells[S.pair_base[p]];
-		DevBuf<u32> d_pb, d_pc, d_inter; DevBuf<PairRange> d_pr;
-		d_pb.alloc(NP); d_pc.alloc(NP); d_inter.alloc(NP); d_pr.alloc(NP);
-		HIP_CHECK(hipMemcpyAsync(d_pb.p, pb.data(), size_t(NP) * 4, hipMemcpyHostToDevice, stream));
-		HIP_CHECK(hipMemcpyAsync(d_pc.p, S.pair_cand.data(), size_t(NP) * 4, hipMemcpyHostToDevice, stream));
-		hipLaunchKernelGGL(pair_ranges_kernel, dim3(div_up(NP, 256)), dim3(256), 0, stream, d_pb.p, d_pc.p, NP, cell_cg_begin.p,
-		                   cell_cg_count.p, cg_mol_begin.p, d_pr.p);
-		HIP_CHECK(hipGetLastError());
-		const int low_bits = layout.gene_bits + layout.umi_bits;
-		timed("umig_intersect", double(NP) * 64, [&] {
-			hipLaunchKernelGGL(umig_intersect_kernel, dim3(NP), dim3(256), 0, stream, d_pr.p, NP, mol_key.p, mol_key.p,
-			                   (1ull << low_bits) - 1ull, layout.umi_bits, layout.gene_none, d_inter.p);
-		});
-		fetch(inter.data(), d_inter.p, size_t(NP) * 4);
-	}
+	std::vector<u32> pb(NP);
+	for (u32 p = 0; p < NP; ++p) pb[p] = cells[S.pair_base[p]];
+	const std::vector<u32> inter = pair_intersections(pb, S.pair_cand);
 	std::vector<u32> tr;
-	decide_merge_targets(U, S, inter, targets, tr);
+	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL) {
+		const std::vector<double> expected = poisson_expected_intersections(pb, S.pair_cand);
+		decide_poisson_targets(U, S, inter, expected, targets, tr);
+	} else
+		decide_merge_targets(U, S, inter, targets, tr);
 	if (target_ridx) *target_ridx = tr;
 	return targets;
 }

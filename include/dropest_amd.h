@@ -61,7 +61,9 @@ typedef enum {
 /* Which CB-merge strategy (MergeStrategyFactory::get_cb_strat, Estimation/Merge/MergeStrategyFactory.cpp:61-103) */
 enum { DROPEST_MERGE_NONE = 0,          /* DummyMergeStrategy.h:12-17 (no -m) */
        DROPEST_MERGE_REAL_BARCODES = 1, /* RealBarcodesMergeStrategy.cpp (-m + barcodes_file) */
-       DROPEST_MERGE_SIMPLE = 2         /* SimpleMergeStrategy.cpp (-m without a barcodes file); uses max_cb_merge_edit_distance */ };
+       DROPEST_MERGE_SIMPLE = 2,        /* SimpleMergeStrategy.cpp (-m without a barcodes file); uses max_cb_merge_edit_distance */
+       DROPEST_MERGE_POISSON_REAL = 3   /* PoissonRealBarcodesMergeStrategy.cpp + PoissonTargetEstimator.cpp (-M + barcodes_file):
+                                           floating-point decisions, see DESIGN.md for the agreement bar */ };
 /* Whitelist file flavour (MergeStrategyFactory.cpp:23-59 barcodes_type) */
 enum { DROPEST_BARCODES_INDROP = 0,     /* InDropBarcodesParser.cpp:15-48 */
        DROPEST_BARCODES_CONST = 1       /* ConstLengthBarcodesParser.cpp:23-68 */ };
@@ -88,6 +90,8 @@ typedef struct {
 	int32_t max_cells;                    /* -C, <= 0: unlimited (CellsDataContainer.cpp:269-273) */
 	uint64_t cb_table_capacity;           /* 0 = auto; power of two >= 2 x distinct barcodes otherwise */
 	double  umi_merge_multiplier;         /* Estimation.Merge.umi_merge_multiplier, default 2 (MergeStrategyFactory.cpp:58) */
+	double  max_merge_prob;               /* Estimation.PreciseMerge.max_merge_prob, default 1e-4 (MergeStrategyFactory.cpp:54) */
+	double  max_real_merge_prob;          /* Estimation.PreciseMerge.max_real_merge_prob, default 1e-7 (:55) */
 } dropest_cfg;
 
 typedef struct dropest_ctx dropest_ctx;
@@ -185,6 +189,13 @@ dropest_status dropest_umi_distribution(dropest_ctx *ctx, uint64_t *n, uint64_t 
  * The reference pins this component only to 1e-2 (Tests/TestEstimationMergeProbs.cpp:113-140). */
 dropest_status dropest_collisions_adjusted_sizes(int device, const double *umi_probabilities, uint64_t n,
                                                  uint64_t max_expression, uint64_t *adjusted_sizes);
+
+/* PoissonTargetEstimator::estimate_intersection_prob (PoissonTargetEstimator.cpp:67-94; the reference's tests call
+ * it directly, Tests/TestEstimationMergeProbs.cpp:93-111) for two cells of the un-merged container: the UMI-gene
+ * intersection size, its expected size under independent sampling from the filtered cells' UMI distribution, and
+ * P(Poisson(expected) >= intersection).  expected = -1 and probability = 1 when the intersection is empty (:72-75). */
+dropest_status dropest_poisson_intersection_prob(dropest_ctx *ctx, uint64_t cell1, uint64_t cell2, uint64_t *intersection_size,
+                                                 double *expected_intersection_size, double *merge_probability);
 /* RealBarcodesMergeStrategy::get_merge_target (RealBarcodesMergeStrategy.cpp:22-29) for one cell,
  * evaluated on the un-merged state; valid between set_initialized and merge_and_filter. */
 dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *target);

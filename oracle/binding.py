@@ -79,6 +79,7 @@ def oracle_lib():
         "orc_poisson_init": (C.c_int, [vp]), "orc_poisson_distribution_size": (u64, [vp]),
         "orc_poisson_gene_intersection": (C.c_double, [vp, u64, u64]),
         "orc_poisson_intersection_prob": (C.c_double, [vp, u64, u64]),
+        "orc_poisson_expected_intersection": (C.c_double, [vp, u64, u64]),
         "orc_poisson_merge_target": (C.c_long, [vp, u64]),
         "orc_poisson_upper_tail": (C.c_double, [C.c_long, C.c_double]),
     }
@@ -236,6 +237,9 @@ class Oracle:
 
     def poisson_intersection_prob(self, c1, c2):
         return float(self.L.orc_poisson_intersection_prob(self.h, c1, c2))
+
+    def poisson_expected_intersection(self, c1, c2):
+        return float(self.L.orc_poisson_expected_intersection(self.h, c1, c2))
 
     def poisson_merge_target(self, cell):
         r = int(self.L.orc_poisson_merge_target(self.h, cell))

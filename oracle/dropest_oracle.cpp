@@ -1007,6 +1007,9 @@ double orc_poisson_gene_intersection(void *h, uint64_t g1, uint64_t g2) {
 double orc_poisson_intersection_prob(void *h, uint64_t c1, uint64_t c2) {
 	try { return static_cast<orc::Container *>(h)->intersection_prob(c1, c2); } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+double orc_poisson_expected_intersection(void *h, uint64_t c1, uint64_t c2) {   // -1: empty intersection (:72-75)
+	try { double e = -1; static_cast<orc::Container *>(h)->intersection_prob(c1, c2, &e); return e; } catch (const std::exception &e) { g_err = e.what(); return -2; }
+}
 long orc_poisson_merge_target(void *h, uint64_t cell) {
 	try { return static_cast<orc::Container *>(h)->poisson_merge_target(cell); } catch (const std::exception &e) { g_err = e.what(); return -2; }
 }

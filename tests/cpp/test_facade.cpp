@@ -2,6 +2,7 @@
 // C++ facade (dropest_amd/csrc/host/facade.h), i.e. written the way the reference's own tests are written: build a
 // container with strategies, add_record(...) hand-written reads, set_initialized(), merge_and_filter(), assert.
 // Needs a GPU (run by tests/test_gpu_facade.py).  Exit code 0 = all checks passed.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -203,6 +204,30 @@ static void testUmiDistributionAndCollisions() {   // CellsDataContainer.cpp:182
 	CHECK(adj.estimate_adjusted_gene_expression(1000) < size_t(1300));
 }
 
+static void testPoissonMerge() {   // Tests/TestEstimationMergeProbs.cpp:30-91 (fixture), :127-140
+	Merge::PoissonTargetEstimator estimator(1.0e-4, 1.0e-7);
+	auto strat = std::make_shared<Merge::PoissonRealBarcodesMergeStrategy>(estimator, Merge::RealBarcodesMergeStrategy::INDROP,
+	                                                                       g_data + "/test_est", 0, 0, 7);
+	CellsDataContainer c(strat, std::make_shared<Merge::UMIs::MergeUMIsStrategySimple>(1), Mark::get_by_code(Mark::DEFAULT_CODE));
+	const char *reads[][3] = {
+		{"AAATTAGGTCCA", "AAACCT", "Gene1"}, {"AAATTAGGTCCA", "CCCCCT", "Gene2"}, {"AAATTAGGTCCA", "ACCCCT", "Gene3"},
+		{"AAATTAGGTCCC", "CAACCT", "Gene1"}, {"AAATTAGGTCCG", "CAACCT", "Gene1"},
+		{"AAATTAGGTCGG", "AAACCT", "Gene1"}, {"AAATTAGGTCGG", "CCCCCT", "Gene2"},
+		{"CCCTTAGGTCCA", "CCATTC", "Gene3"}, {"CCCTTAGGTCCA", "CCCCCT", "Gene2"}, {"CCCTTAGGTCCA", "ACCCCT", "Gene3"},
+		{"CAATTAGGTCCG", "CAACCT", "Gene1"}, {"CAATTAGGTCCG", "AAACCT", "Gene1"}, {"CAATTAGGTCCG", "CCCCCT", "Gene2"},
+		{"CAATTAGGTCCG", "TTTTTT", "Gene2"}, {"CAATTAGGTCCG", "TTCTTT", "Gene2"},
+		{"CCCCCCCCCCCC", "CAACCT", "Gene1"}, {"CCCCCCCCCCCC", "AAACCT", "Gene1"}, {"CCCCCCCCCCCC", "CCCCCT", "Gene2"},
+		{"CCCCCCCCCCCC", "TTTTTT", "Gene2"}, {"CCCCCCCCCCCC", "TTCTTT", "Gene2"}, {"TAATTAGGTCCA", "AAAAAA", "Gene4"}};
+	for (auto const &r : reads) c.add_record(read_info(r[0], r[1], r[2]));
+	c.set_initialized();
+	CHECK_EQ(strat->merge_type(), std::string("Poisson Real CBs"));
+	CHECK_EQ(estimator.estimate_intersection_prob(c, 0, 1).merge_probability, 1.0);                     // :129
+	CHECK(std::fabs(estimator.estimate_intersection_prob(c, 1, 2).merge_probability - 0.16) <= 0.05);   // :130
+	CHECK(std::fabs(estimator.estimate_intersection_prob(c, 3, 4).merge_probability - 0.15) <= 0.05);   // :131
+	CHECK_EQ(estimator.estimate_intersection_prob(c, 5, 6).intersection_size, size_t(5));
+	CHECK_EQ(c.get_merge_target(7), long(-1));                                                          // :136-140
+}
+
 int main(int argc, char **argv) {
 	g_data = argc > 1 ? argv[1] : "dropest_amd/data/barcodes";
 	const std::string tmp = argc > 2 ? argv[2] : "/tmp";
@@ -215,6 +240,7 @@ int main(int argc, char **argv) {
 		testStateMachineAndParams();
 		testResultsPrinterMtx(tmp);
 		testUmiDistributionAndCollisions();
+		testPoissonMerge();
 	} catch (const std::exception &e) {
 		std::printf("UNEXPECTED EXCEPTION: %s\n", e.what());
 		return 2;

@@ -603,3 +603,112 @@ def test_simple_merge_with_n_and_directional():
     c = parity.gpu_run(dict(merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=2, umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL,
                             min_genes_before_merge=3, min_genes_after_merge=10), cb, umi, gene, aux, side)
     parity.compare(o, c, side)
+
+
+# ---------------------------------------------------------------------------------------------------
+# -M with a whitelist: PoissonRealBarcodesMergeStrategy + PoissonTargetEstimator
+# ---------------------------------------------------------------------------------------------------
+POISSON_FIXTURE = [("AAATTAGGTCCA", "AAACCT", "Gene1"), ("AAATTAGGTCCA", "CCCCCT", "Gene2"), ("AAATTAGGTCCA", "ACCCCT", "Gene3"),
+                   ("AAATTAGGTCCC", "CAACCT", "Gene1"), ("AAATTAGGTCCG", "CAACCT", "Gene1"),
+                   ("AAATTAGGTCGG", "AAACCT", "Gene1"), ("AAATTAGGTCGG", "CCCCCT", "Gene2"),
+                   ("CCCTTAGGTCCA", "CCATTC", "Gene3"), ("CCCTTAGGTCCA", "CCCCCT", "Gene2"), ("CCCTTAGGTCCA", "ACCCCT", "Gene3"),
+                   ("CAATTAGGTCCG", "CAACCT", "Gene1"), ("CAATTAGGTCCG", "AAACCT", "Gene1"), ("CAATTAGGTCCG", "CCCCCT", "Gene2"),
+                   ("CAATTAGGTCCG", "TTTTTT", "Gene2"), ("CAATTAGGTCCG", "TTCTTT", "Gene2"),
+                   ("CCCCCCCCCCCC", "CAACCT", "Gene1"), ("CCCCCCCCCCCC", "AAACCT", "Gene1"), ("CCCCCCCCCCCC", "CCCCCT", "Gene2"),
+                   ("CCCCCCCCCCCC", "TTTTTT", "Gene2"), ("CCCCCCCCCCCC", "TTCTTT", "Gene2"), ("TAATTAGGTCCA", "AAAAAA", "Gene4")]
+
+
+def _poisson_kw(path, kind, min_before, min_after, p_merge=1e-4, p_real=1e-7):
+    okw = dict(merge_kind=3, barcodes_kind=kind, barcodes_file=path, min_genes_before=min_before, min_genes_after=min_after,
+               max_merge_prob=p_merge, max_real_merge_prob=p_real)
+    gkw = dict(merge_kind=capi.MERGE_POISSON_REAL, barcodes_kind=kind, barcodes_file=path, min_genes_before_merge=min_before,
+               min_genes_after_merge=min_after, max_merge_prob=p_merge, max_real_merge_prob=p_real)
+    return okw, gkw
+
+
+def test_poisson_reference_fixture_on_gpu():
+    """Tests/TestEstimationMergeProbs.cpp:30-140 through the C-ABI: testPoissonMergeProbs' tolerances (three of the four
+    values; see tests/test_oracle_reference_kat.py for the fourth), testPoissonMergeRejections, and the estimator's
+    numbers against the oracle's for every cell pair."""
+    cb, umi, gene, aux, names = _pack_reads(POISSON_FIXTURE)
+    okw, gkw = _poisson_kw(os.path.join(DATA, "test_est"), 0, 0, 0)
+    c = capi.Context(**gkw)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_initialized()
+    o = Oracle(**okw)
+    o.add_packed(cb, umi, gene, aux, ())
+    o.set_initialized()
+    o.poisson_init()
+    assert c.poisson_intersection_prob(0, 1)[2] == 1                                   # :129
+    assert abs(c.poisson_intersection_prob(1, 2)[2] - 0.16) <= 0.05                    # :130
+    assert abs(c.poisson_intersection_prob(3, 4)[2] - 0.15) <= 0.05                    # :131
+    n = c.total_cells_number()
+    for i in range(n):
+        for j in range(n):
+            if i == j:
+                continue
+            inter, expected, prob = c.poisson_intersection_prob(i, j)
+            want_e, want_p = o.poisson_expected_intersection(i, j), o.poisson_intersection_prob(i, j)
+            if inter == 0:
+                assert expected == -1 and prob == 1 and want_p == 1
+            else:
+                assert abs(expected - want_e) <= 1e-12 * max(1.0, want_e), (i, j, expected, want_e)
+                assert abs(prob - want_p) <= 1e-10 * want_p + 1e-300, (i, j, prob, want_p)
+    assert c.merge_target(7) == -1 == o.poisson_merge_target(7)                        # :136-140
+    assert [c.merge_target(i) for i in range(n)] == [o.poisson_merge_target(i) for i in range(n)]
+    c.merge_and_filter()
+    o.merge_and_filter()
+    parity.compare(o, c)
+
+
+def _both_poisson(stream_kw, n_reads, min_before, min_after, whitelist, kind, **probs):
+    s = SynthStream(n_reads=n_reads, whitelist=whitelist, **stream_kw)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    okw, gkw = _poisson_kw(os.path.join(DATA, whitelist), kind, min_before, min_after, **probs)
+    o = parity.oracle_run(Oracle, okw, cb, umi, gene, aux)
+    c = parity.gpu_run(gkw, cb, umi, gene, aux)
+    parity.compare(o, c)
+    return o, c
+
+
+def test_poisson_merge_10x_whitelist():
+    o, c = _both_poisson(dict(n_cells=30, n_genes=2000, umi_len=12, permille_neighbour=150), 200_000, 3, 20,
+                         "10x_aug_2016_split", capi.BARCODES_CONST)
+    mt = c.merge_targets()
+    assert int((mt != np.arange(len(mt))).sum()) > 50
+    assert int(c.cell_rows()["is_excluded"].sum()) > 0
+
+
+def test_poisson_merge_indrop_v3_whitelist_and_loose_thresholds():
+    """Short UMIs (8 bases: collisions are frequent, the adjuster matters) and thresholds loose enough that real
+    barcodes merge into each other (PoissonTargetEstimator.cpp:17-20 uses max_merge_prob for REAL bases)."""
+    _both_poisson(dict(n_cells=25, n_genes=1500, umi_len=8, permille_neighbour=120), 120_000, 3, 10, "indrop_v3", capi.BARCODES_CONST)
+    _both_poisson(dict(n_cells=25, n_genes=300, umi_len=8, permille_neighbour=120), 120_000, 3, 10, "indrop_v3", capi.BARCODES_CONST,
+                  p_merge=0.5, p_real=0.5)
+
+
+def test_poisson_probabilities_against_oracle_on_synthetic_pairs():
+    s = SynthStream(n_reads=80_000, whitelist="10x_aug_2016_split", n_cells=20, n_genes=60, umi_len=6, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    okw, gkw = _poisson_kw(os.path.join(DATA, "10x_aug_2016_split"), capi.BARCODES_CONST, 3, 10)
+    c = capi.Context(**gkw)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_initialized()
+    o = Oracle(**okw)
+    o.add_packed(cb, umi, gene, aux, ())
+    o.set_initialized()
+    o.poisson_init()
+    f = np.array([int(x) for x in c.filtered_cells()])
+    big = f[np.argsort(-c.cell_rows()["total_umis"][f].astype(np.int64), kind="stable")[:9]]   # the cells that do intersect
+    checked = 0
+    for i, j in ((int(a), int(b)) for a in big for b in big if a != b):
+        inter, expected, prob = c.poisson_intersection_prob(i, j)
+        want_p = o.poisson_intersection_prob(i, j)
+        if inter == 0:
+            assert prob == 1 == want_p
+            continue
+        want_e = o.poisson_expected_intersection(i, j)
+        assert abs(expected - want_e) <= 1e-11 * want_e, (i, j, expected, want_e)
+        assert abs(prob - want_p) <= 1e-9 * want_p + 1e-300, (i, j, prob, want_p)
+        checked += 1
+    assert checked > 10

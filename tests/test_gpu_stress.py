@@ -107,8 +107,9 @@ def test_key_wider_than_64_bits_is_refused_loudly():
     assert e.value.status == 4 and "bits" in str(e.value)
 
 
+@pytest.mark.parametrize("poisson", [False, True])
 @pytest.mark.parametrize("seed", range(10))
-def test_random_whitelist_merges(seed, tmp_path):
+def test_random_whitelist_merges(seed, poisson, tmp_path):
     """Random small whitelists (inDrop-style two lines, variable first-part length allowed) and barcodes that are exact,
     mutated (substitution / insertion / deletion -> different length) or carry an N: stresses the neighbour search,
     the tie replay (min_merge_fraction 0 half of the time) and the sequential merge application."""
@@ -142,7 +143,8 @@ def test_random_whitelist_merges(seed, tmp_path):
         return s
     pool = list(real) + [mutate(str(rng.choice(real))) for _ in range(40)] + [mutate(mutate(str(rng.choice(real)))) for _ in range(15)]
     genes = ["g%d" % i for i in range(int(rng.integers(2, 12)))]
-    umis = [rnd(5) for _ in range(int(rng.integers(3, 25)))]
+    # -M: enough distinct UMIs that no gene's size comes near their number (the collisions adjustment diverges there)
+    umis = [rnd(6) for _ in range(int(rng.integers(300, 1000)))] if poisson else [rnd(5) for _ in range(int(rng.integers(3, 25)))]
     n = int(rng.integers(200, 3000))
     w = np.concatenate([np.full(len(real), 8.0), np.ones(len(pool) - len(real))]); w /= w.sum()
     side, index, gids = [], {}, {}
@@ -161,6 +163,16 @@ def test_random_whitelist_merges(seed, tmp_path):
     frac = 0.0 if rng.integers(0, 2) else 0.2
     min_before = int(rng.integers(0, 3))
     kind = capi.BARCODES_CONST if const_kind else capi.BARCODES_INDROP
+    if poisson:   # PoissonRealBarcodesMergeStrategy: wider neighbour levels, real bases can merge, probability thresholds
+        p_merge, p_real = float(rng.choice([1e-4, 0.05, 0.9])), float(rng.choice([1e-7, 0.05, 0.9]))
+        o = parity.oracle_run(Oracle, dict(merge_kind=3, barcodes_kind=kind, barcodes_file=str(wl), min_genes_before=min_before,
+                                           min_genes_after=min_before, max_merge_prob=p_merge, max_real_merge_prob=p_real),
+                              cb, umi, gene, aux, side)
+        c = parity.gpu_run(dict(merge_kind=capi.MERGE_POISSON_REAL, barcodes_kind=kind, barcodes_file=str(wl),
+                                min_genes_before_merge=min_before, min_genes_after_merge=min_before, max_merge_prob=p_merge,
+                                max_real_merge_prob=p_real), cb, umi, gene, aux, side)
+        parity.compare(o, c, side)
+        return
     o = parity.oracle_run(Oracle, dict(merge_kind=1, barcodes_kind=kind, barcodes_file=str(wl), min_genes_before=min_before,
                                        min_genes_after=min_before, min_merge_fraction=frac), cb, umi, gene, aux, side)
     c = parity.gpu_run(dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=kind, barcodes_file=str(wl),
