@@ -41,6 +41,7 @@ def parse():
                     help="c2 (default, the metric's configuration): 10x v2, UMI 10, no CB merge; "
                          "c3: 10x v3, UMI 12, -m + whitelist merge (use --reads 1e9 for BASELINE's size); "
                          "c4: inDrop v3, split 8+8 barcode, UMI 8, -m + whitelist merge (BASELINE: 4 GPUs x 1.25e8 reads)")
+    ap.add_argument("--poisson", action="store_true", help="c3 / c4: -M (PoissonRealBarcodesMergeStrategy) instead of -m, single GPU")
     ap.add_argument("--no-whitelist", action="store_true", help="c3 / c4: -m WITHOUT the barcode whitelist (SimpleMergeStrategy, single GPU)")
     ap.add_argument("--merge-umi", action="store_true", help="-u: directional UMI correction (single-GPU configs only)")
     ap.add_argument("--cpu-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_CPU_SAMPLE", 4e6)),
@@ -129,7 +130,8 @@ def main():
             ctx = Context(device=local_rank, merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=2, min_merge_fraction=0.2,
                           min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"], **ukw)
         elif merge:
-            ctx = Context(device=local_rank, merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST,
+            ctx = Context(device=local_rank, merge_kind=capi.MERGE_POISSON_REAL if args.poisson else capi.MERGE_REAL_BARCODES,
+                          barcodes_kind=capi.BARCODES_CONST,
                           barcodes_file=wl, min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"],
                           min_merge_fraction=0.2, **ukw)
         else:
@@ -219,7 +221,8 @@ def main():
                                     "-m + inDrop v3 whitelist (RealBarcodes merge), -L eEBA" if c4 else
                                     "C2: synthetic 10x v2, %d reads/GPU, %d cells/GPU, 16bp CB + 10bp UMI, 30000 genes, "
                                     "no CB merge, -L eEBA") % (reads_per_gpu, args.cells) + (", -u" if args.merge_umi else "")
-                                   + (", no whitelist (SimpleMergeStrategy)" if args.no_whitelist else ""),
+                                   + (", no whitelist (SimpleMergeStrategy)" if args.no_whitelist else "")
+                                   + (", -M (Poisson decisions)" if args.poisson else ""),
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d" % world,
                        "cm_nnz": int(len(cm[1])), "filtered_cells": int(len(out[2])), "sort_layout": get_layout()},
             "roofline": roof, "cpu_baseline": cpu, "step_ms": step_ms, "kernels_ms_per_step": kernels,

@@ -8,12 +8,13 @@
 //   prob         = ppois(intersection - 1, expected, lower = false) = P(Poisson(expected) >= intersection)
 // and the target is the neighbour of smallest prob if that is <= max_(real_)merge_prob / |neighbours|.
 //
-// Device: the UMI distribution (sort + run lengths), the adjuster table (k_collisions.h), the genes in common of every
+// Device: the UMI distribution (sort + run lengths, then classes of equally frequent UMIs), the adjuster table, the genes in common of every
 // (base, neighbour) pair, one est() per DISTINCT pair of adjusted sizes (the reference caches the same way,
 // :104-108), and the per-pair sums.  Host: the Poisson tail and the few comparisons per cell.
 // Floating point: est() and the adjuster's sums are reductions over the UMI distribution; the reference adds them
-// in the iteration order of an unordered_map of strings, the kernels in a fixed tree order, so `expected` agrees to
-// rounding (~1e-15 relative) and the decisions agree unless a probability lies that close to its threshold.
+// in the iteration order of an unordered_map of strings, the kernels per class of equally frequent UMIs (count x term)
+// in a fixed tree order, so `expected` agrees to rounding (measured <= 1e-12 relative) and the decisions agree unless
+// a probability lies that close to its threshold.
 #pragma once
 
 #include "context.h"
@@ -68,16 +69,67 @@ __global__ __launch_bounds__(256) void max_gene_size_kernel(const unsigned long 
 	if (lane_id() == 0 && v) atomicMax(out, v);
 }
 
-__global__ __launch_bounds__(256) void counts_to_probs_kernel(const uint32_t *__restrict__ count, uint32_t n, double total,
-                                                              double *__restrict__ p, double *__restrict__ ones) {
+__global__ __launch_bounds__(256) void widen_counts_kernel(const uint32_t *__restrict__ count, uint32_t n, unsigned long long *__restrict__ out,
+                                                           uint32_t *__restrict__ max_out) {
 	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-	if (i < n) { p[i] = double(count[i]) / total; ones[i] = 1.0; }
+	uint32_t v = i < n ? count[i] : 0u;
+	if (i < n) out[i] = v;
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) v = max(v, uint32_t(__shfl_down(v, d, 64)));
+	if (lane_id() == 0 && v) atomicMax(max_out, v);
+}
+
+// UMIs that were seen equally often have the same probability and go through every formula below together: the
+// distribution is kept as (probability, number of UMIs with it) classes -- a few dozen to a few thousand entries
+// where the reference walks millions of UMIs
+__global__ __launch_bounds__(256) void classes_to_probs_kernel(const unsigned long long *__restrict__ count_value,
+                                                               const uint32_t *__restrict__ multiplicity, uint32_t n, double total,
+                                                               double *__restrict__ p, double *__restrict__ mult, double *__restrict__ ones) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { p[i] = double(count_value[i]) / total; mult[i] = double(multiplicity[i]); ones[i] = 1.0; }
+}
+
+// Tools::CollisionsAdjuster table (CollisionsAdjuster.cpp:12-49) over the probability classes, one block: the
+// recurrence over s is sequential, the work per s a reduction over the classes (fixed order: strided per thread,
+// wave shuffle tree, waves in index order)
+__global__ __launch_bounds__(PM_THREADS) void collisions_table_kernel(const double *__restrict__ p, const double *__restrict__ mult,
+                                                                      double *__restrict__ neg_prod, uint32_t n_classes, uint32_t max_size,
+                                                                      unsigned long long *__restrict__ adjusted) {
+	__shared__ double wave_sum[PM_THREADS / 64];
+	__shared__ unsigned long long delta_s;
+	double sum_collisions = 0;                 // meaningful in thread 0
+	unsigned long long last_total = 0;
+	for (uint32_t s = 1; s <= max_size; ++s) {
+		if (threadIdx.x == 0) {
+			const unsigned long long total = s + (unsigned long long)sum_collisions;
+			delta_s = total - last_total;
+			last_total = total;
+		}
+		__syncthreads();
+		const unsigned long long delta = delta_s;
+		double acc = 0;
+		for (uint32_t i = threadIdx.x; i < n_classes; i += PM_THREADS) {
+			const double np = neg_prod[i] * dev_fpow(1 - p[i], delta);
+			neg_prod[i] = np;
+			acc += mult[i] * (p[i] * (1 - np));
+		}
+#pragma unroll
+		for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d, 64);
+		if (lane_id() == 0) wave_sum[wave_id()] = acc;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			double new_prob = 0;
+			for (int w = 0; w < PM_THREADS / 64; ++w) new_prob += wave_sum[w];
+			sum_collisions += 1.0 / (1.0 - new_prob) - 1.0;
+			adjusted[s - 1] = isfinite(sum_collisions) && sum_collisions < 4e9 ? (unsigned long long)lround(double(s) + sum_collisions) : ~0ull;
+		}
+	}
 }
 
 // est(a1, a2) of one distinct size pair per block (PoissonTargetEstimator::estimate_genes_intersection_size, :110-123)
 __global__ __launch_bounds__(PM_THREADS) void genes_intersection_kernel(const unsigned long long *__restrict__ size_pair, uint32_t n_keys,
-                                                                        const double *__restrict__ p, uint32_t n_umis,
-                                                                        double *__restrict__ est) {
+                                                                        const double *__restrict__ p, const double *__restrict__ mult,
+                                                                        uint32_t n_umis, double *__restrict__ est) {
 	__shared__ double wave_sum[PM_THREADS / 64];
 	const unsigned long long key = size_pair[blockIdx.x];
 	const unsigned long long a1 = key >> 32, d = (key & 0xFFFFFFFFull) - a1;
@@ -86,7 +138,7 @@ __global__ __launch_bounds__(PM_THREADS) void genes_intersection_kernel(const un
 		const double q = 1 - p[i];
 		const double mn = dev_fpow(q, a1);
 		const double mx = mn * dev_fpow(q, d);
-		acc += (1 - mn) * (1 - mx);
+		acc += mult[i] * ((1 - mn) * (1 - mx));
 	}
 #pragma unroll
 	for (int s = 32; s > 0; s >>= 1) acc += __shfl_down(acc, s, 64);
@@ -191,21 +243,38 @@ std::vector<double> dropest_ctx::poisson_expected_intersections(const std::vecto
 		zero_async(*this, run_cnt.p, size_t(total + 1) * 4);
 		runs_policy.run_key = run_key.p; runs_policy.out[0] = run_cnt.p;
 	});
-	DevBuf<double> d_p, d_np, d_partial;
-	d_p.alloc(n_umis); d_np.alloc(n_umis); d_partial.alloc(CA_BLOCKS);
-	hipLaunchKernelGGL(counts_to_probs_kernel, dim3(div_up(n_umis, 256)), dim3(256), 0, stream, run_cnt.p, n_umis, double(kept), d_p.p, d_np.p);
+	// classes of equally frequent UMIs
+	DevBuf<u64> class_count; DevBuf<u32> class_mult;
+	u32 n_classes = 0;
+	{
+		keys_a.ensure(n_umis); keys_b.ensure(n_umis); vals_a.ensure(n_umis); vals_b.ensure(n_umis);
+		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4, stream));
+		hipLaunchKernelGGL(widen_counts_kernel, dim3(div_up(n_umis, 256)), dim3(256), 0, stream, run_cnt.p, n_umis, keys_a.p, scalars.p);
+		HIP_CHECK(hipGetLastError());
+		u32 max_count = 0;
+		fetch(&max_count, scalars.p, 4);
+		u64 mask = 1;
+		while (mask <= max_count) mask <<= 1;
+		k = keys_a.p; k_alt = keys_b.p; v = vals_a.p; v_alt = vals_b.p;
+		radix_sort(k, v, k_alt, v_alt, n_umis, mask - 1);
+		UmiRuns class_policy{};
+		class_policy.keys = k;
+		n_classes = run_segmented_reduce(*this, "umi_classes", class_policy, n_umis, 8, [&](u32 total) {
+			class_count.alloc(total + 1); class_mult.alloc(total + 1);
+			zero_async(*this, class_mult.p, size_t(total + 1) * 4);
+			class_policy.run_key = class_count.p; class_policy.out[0] = class_mult.p;
+		});
+	}
+	DevBuf<double> d_p, d_mult, d_np;
+	d_p.alloc(n_classes); d_mult.alloc(n_classes); d_np.alloc(n_classes);
+	hipLaunchKernelGGL(classes_to_probs_kernel, dim3(div_up(n_classes, 256)), dim3(256), 0, stream, class_count.p, class_mult.p, n_classes,
+	                   double(kept), d_p.p, d_mult.p, d_np.p);
 
 	// 2. adjusted sizes 1..max_size (Tools::CollisionsAdjuster)
-	DevBuf<CollisionState> d_st; DevBuf<u64> d_adj;
-	d_st.alloc(1); d_adj.alloc(max_size);
-	CollisionState st{0.0, 0ull, 0ull};
-	HIP_CHECK(hipMemcpyAsync(d_st.p, &st, sizeof(st), hipMemcpyHostToDevice, stream));
-	timed("collisions_adjust", double(max_size) * n_umis * 24, [&] {
-		hipLaunchKernelGGL(collisions_finish_kernel, dim3(1), dim3(1), 0, stream, d_partial.p, d_st.p, 0ull, d_adj.p);
-		for (u64 s = 1; s <= max_size; ++s) {
-			hipLaunchKernelGGL(collisions_step_kernel, dim3(CA_BLOCKS), dim3(CA_THREADS), 0, stream, d_p.p, d_np.p, u64(n_umis), d_st.p, d_partial.p);
-			hipLaunchKernelGGL(collisions_finish_kernel, dim3(1), dim3(1), 0, stream, d_partial.p, d_st.p, s, d_adj.p);
-		}
+	DevBuf<u64> d_adj;
+	d_adj.alloc(max_size);
+	timed("collisions_table", double(max_size) * n_classes * 24, [&] {
+		hipLaunchKernelGGL(collisions_table_kernel, dim3(1), dim3(PM_THREADS), 0, stream, d_p.p, d_mult.p, d_np.p, n_classes, max_size, d_adj.p);
 	});
 	{
 		u64 top = 0;
@@ -252,8 +321,9 @@ std::vector<double> dropest_ctx::poisson_expected_intersections(const std::vecto
 	});
 	DevBuf<double> d_est, d_expected;
 	d_est.alloc(n_uniq); d_expected.alloc(NP);
-	timed("genes_intersection", double(n_uniq) * n_umis * 8, [&] {
-		hipLaunchKernelGGL(genes_intersection_kernel, dim3(n_uniq), dim3(PM_THREADS), 0, stream, uniq.p, n_uniq, d_p.p, n_umis, d_est.p);
+	timed("genes_intersection", double(n_uniq) * n_classes * 16, [&] {
+		hipLaunchKernelGGL(genes_intersection_kernel, dim3(n_uniq), dim3(PM_THREADS), 0, stream, uniq.p, n_uniq, d_p.p, d_mult.p, n_classes,
+		                   d_est.p);
 	});
 	hipLaunchKernelGGL(expected_intersection_kernel, dim3(div_up(NP, 256)), dim3(256), 0, stream, d_off.p, NP, d_keys.p, uniq.p, n_uniq,
 	                   d_est.p, d_expected.p);
