@@ -107,6 +107,9 @@ def lib():
         "dropest_count_matrix_csc": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
         "dropest_chr_stats": (C.c_int, [vp, u64p, vp, vp, vp, vp]),
         "dropest_merge_target": (C.c_int, [vp, C.c_uint64, P(C.c_int64)]),
+        "dropest_set_umi_qualities": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64]),
+        "dropest_umi_quality_length": (C.c_int, [vp, P(C.c_uint32)]),
+        "dropest_cell_molecule_qualities": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp]),
         "dropest_poisson_intersection_prob": (C.c_int, [vp, C.c_uint64, C.c_uint64, u64p, P(C.c_double), P(C.c_double)]),
         "dropest_umi_distribution": (C.c_int, [vp, u64p, vp, vp]),
         "dropest_collisions_adjusted_sizes": (C.c_int, [C.c_int, vp, C.c_uint64, C.c_uint64, vp]),
@@ -163,6 +166,7 @@ EXPORTED_SYMBOLS = [
     "dropest_count_matrix_device", "dropest_cell_first_reads_device", "dropest_assemble_columns",
     "dropest_real_candidate_rows", "dropest_dev_copy_device", "dropest_umi_distribution",
     "dropest_collisions_adjusted_sizes", "dropest_poisson_intersection_prob",
+    "dropest_set_umi_qualities", "dropest_umi_quality_length", "dropest_cell_molecule_qualities",
     "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_stream",
     "dropest_sort_layout", "dropest_host_register", "dropest_host_unregister", "dropest_ingest", "dropest_ingest_summary_get", "dropest_ingest_summary_set",
     "dropest_gene_chr_table", "dropest_shard_merge_search", "dropest_shard_merge_pairs", "dropest_shard_merge_export",
@@ -465,6 +469,23 @@ class Context:
         t = C.c_int64()
         self._chk(self.L.dropest_merge_target(self.h, cell, C.byref(t)))
         return t.value
+
+    def set_umi_qualities(self, qual):
+        """qual: uint8 array [n_reads, quality_length] (phred+33 characters), read order."""
+        qual = np.ascontiguousarray(qual, np.uint8)
+        assert qual.ndim == 2
+        self._chk(self.L.dropest_set_umi_qualities(self.h, qual.ctypes.data, qual.shape[1], qual.shape[0]))
+
+    def umi_quality_length(self):
+        q = C.c_uint32()
+        self._chk(self.L.dropest_umi_quality_length(self.h, C.byref(q)))
+        return q.value
+
+    def cell_molecule_qualities(self, cell, n):
+        """Quality sums [n, quality_length] of the cell's molecules, in the order of cell_molecules()."""
+        out = np.zeros((n, self.umi_quality_length()), np.uint32)
+        self._chk(self.L.dropest_cell_molecule_qualities(self.h, cell, n, out.ctypes.data))
+        return out
 
     def poisson_intersection_prob(self, cell1, cell2):
         """(intersection size, expected intersection size, merge probability) -- PoissonTargetEstimator::estimate_intersection_prob."""

@@ -63,7 +63,7 @@ inline bool encode_code(const std::string &s, u64 &code) {   // false: needs an 
 	return true;
 }
 
-struct UmiOverride { u64 umi; u32 reads; uint8_t mark; };   // molecule of a group re-keyed by the N-UMI merge
+struct UmiOverride { u64 umi; u32 reads; uint8_t mark; u32 src_row; };   // src_row: molecule row whose quality sums it shows   // molecule of a group re-keyed by the N-UMI merge
 
 // The cells a whitelist merge search runs over: the context's own cells, or (sharded runs) the real cells of every
 // shard.  Device arrays are indexed by the universe's cell index; the callbacks serve the few host-side look-ups.
@@ -267,12 +267,25 @@ struct dropest_ctx {
 	                        const uint32_t *const d_cols[4]);
 	void reaggregate_after_merge();
 	void run_umi_merge_simple();
-	struct GatheredGroups { std::vector<u32> size, off, hr, hm, hfirst; std::vector<u64> hk; };
+	struct GatheredGroups { std::vector<u32> size, off, begin, hr, hm, hfirst; std::vector<u64> hk; };   // begin: first molecule row of the group
 	void umi_gather_groups(const std::vector<u32> &groups, GatheredGroups &G, const u32 *d_first_table);
 	void umi_patch_groups(const std::vector<u32> &p_idx, const std::vector<u32> &p_all, const std::vector<u32> &p_req,
 	                      const std::vector<u32> &p_rreq, const std::unordered_map<u32, int> &umis_removed);
 	void run_umi_merge_directional();            // -u (umi_directional_host.h)
 	void reaggregate_from_keys(u64 varying_mask); // keys_a / vals_a hold the re-keyed molecule table
+	// UMI quality sums (quality.h)
+	dropest::DevBuf<uint8_t> umi_qual;          // [qual_reads][qual_len], read order
+	u32 qual_len = 0;
+	uint64_t qual_reads = 0;
+	bool have_qual = false;
+	u32 n_mol_at_init = 0;
+	dropest::DevBuf<u32> mol_qsum, mol_qrow, mol_qrow2;   // sums per ORIGINAL molecule row; current row -> original row
+	const u32 *reagg_prio = nullptr;            // per old molecule row, for the next reaggregate_from_keys (device)
+	dropest::DevBuf<u32> reagg_prio_buf;
+	std::vector<u32> merge_rank;                // per cell id: position in its target's merge order (0 = not merged away)
+	void accumulate_umi_qualities();
+	void requality_after_fold(const u64 *sorted_key, const u32 *old_row, u32 n_old, const u64 *new_key, u32 n_new);
+	void fetch_quality_rows(const std::vector<u32> &rows, uint32_t *out);
 	dropest::DevBuf<u32> umi_first;
 	void fetch_real_cells();
 	void request_filtered(u32 genes_threshold, int max_cells);   // CellsDataContainer::update_filtered_gene_counts, lazily

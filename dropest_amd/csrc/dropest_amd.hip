@@ -154,6 +154,7 @@ void dropest_ctx::free_results() {
 	shard.reset();
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
 	real.clear(); filtered.clear(); filtered_valid = false; merge_pairs.clear(); reassign.clear(); umi_overrides.clear(); n_real_now = 0;
+	merge_rank.clear(); reagg_prio = nullptr;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -624,6 +625,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 	filtered_valid = true;
 }
 
+#include "quality.h"
 #include "merge_host.h"
 #include "merge_shard.h"
 #include "umi_merge_host.h"
@@ -657,6 +659,7 @@ void dropest_ctx::run_set_initialized() {
 	if (n_reads > 0) {
 		{ HostStage hs(this, "keys"); plan_key_layout(); build_keys(); }
 		{ HostStage hs(this, "sort+reduce"); reduce_all(); }
+		accumulate_umi_qualities();
 		{ HostStage hs(this, "real_cells"); fetch_real_cells(); }
 	}
 	request_filtered(0, -1);   // update_cell_sizes(query, 0, -1), CellsDataContainer.cpp:168
@@ -727,8 +730,10 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host) 
 
 // Walks a fetched slice of the molecule table in order, skipping the pseudo rows of gene-less reads and replacing
 // the groups that the N-UMI merge rewrote by their host-side contents.
+// `emit` also receives the molecule row whose quality sums the molecule shows (first_row = row of k[0]).
 template <class F>
-static void for_each_molecule(dropest_ctx *ctx, const std::vector<u64> &k, const std::vector<u32> &r, const std::vector<u32> &m, F &&emit) {
+static void for_each_molecule(dropest_ctx *ctx, const std::vector<u64> &k, const std::vector<u32> &r, const std::vector<u32> &m, F &&emit,
+                              u32 first_row = 0) {
 	const KeyLayout &L = ctx->layout;
 	const u64 umask = L.umi_bits ? ((1ull << L.umi_bits) - 1ull) : 0ull;
 	u64 done_group = ~0ull;
@@ -740,11 +745,11 @@ static void for_each_molecule(dropest_ctx *ctx, const std::vector<u64> &k, const
 		if (!ctx->umi_overrides.empty()) {
 			auto it = ctx->umi_overrides.find(cg);
 			if (it != ctx->umi_overrides.end()) {
-				if (done_group != cg) { for (const UmiOverride &o : it->second) emit(c, u32(g), o.umi, o.reads, o.mark); done_group = cg; }
+				if (done_group != cg) { for (const UmiOverride &o : it->second) emit(c, u32(g), o.umi, o.reads, o.mark, o.src_row); done_group = cg; }
 				continue;
 			}
 		}
-		emit(c, u32(g), ctx->unmap_umi(k[i] & umask), r[i], uint8_t(m[i]));
+		emit(c, u32(g), ctx->unmap_umi(k[i] & umask), r[i], uint8_t(m[i]), first_row + u32(i));
 	}
 }
 
@@ -1105,7 +1110,7 @@ dropest_status dropest_molecules(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, 
 		const KeyLayout &L = ctx->layout;
 		const u64 umask = L.umi_bits ? ((1ull << L.umi_bits) - 1ull) : 0ull;
 		uint64_t cnt = 0;
-		for_each_molecule(ctx, k, r, m, [&](u32 c, u32 g, u64 u, u32 rd, uint8_t mk) {
+		for_each_molecule(ctx, k, r, m, [&](u32 c, u32 g, u64 u, u32 rd, uint8_t mk, u32) {
 			if (cell) { cell[cnt] = c; gene[cnt] = g; umi[cnt] = u; reads[cnt] = rd; mark[cnt] = mk; }
 			++cnt;
 		});
@@ -1131,12 +1136,58 @@ dropest_status dropest_cell_molecules(dropest_ctx *ctx, uint64_t cell_id, uint64
 		const KeyLayout &L = ctx->layout;
 		const u64 umask = L.umi_bits ? ((1ull << L.umi_bits) - 1ull) : 0ull;
 		uint64_t cnt = 0;
-		for_each_molecule(ctx, k, r, m, [&](u32, u32 g, u64 u, u32 rd, uint8_t mk) {
+		for_each_molecule(ctx, k, r, m, [&](u32, u32 g, u64 u, u32 rd, uint8_t mk, u32) {
 			if (gene) { gene[cnt] = g; umi[cnt] = u; reads[cnt] = rd; mark[cnt] = mk; }
 			++cnt;
 		});
 		(void)umask; (void)L;
 		*n = cnt;
+	});
+}
+
+dropest_status dropest_set_umi_qualities(dropest_ctx *ctx, const uint8_t *qualities, uint32_t quality_length, uint64_t n_reads) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		if (ctx->initialized || ctx->ingested) throw InvalidError("UMI qualities must be set before set_initialized");
+		if (n_reads != ctx->n_reads) throw InvalidError("UMI qualities must cover every pushed read (" + std::to_string(ctx->n_reads) + ")");
+		if (quality_length > 255) throw UnsupportedError("UMI quality strings longer than 255");
+		if (n_reads && quality_length && !qualities) throw InvalidError("null quality array");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		ctx->qual_len = quality_length; ctx->qual_reads = n_reads; ctx->have_qual = true;
+		const size_t bytes = size_t(n_reads) * quality_length;
+		if (bytes) {
+			ctx->umi_qual.alloc(bytes);
+			HIP_CHECK(hipMemcpyAsync(ctx->umi_qual.p, qualities, bytes, hipMemcpyHostToDevice, ctx->stream));
+			HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		}
+	});
+}
+
+dropest_status dropest_umi_quality_length(dropest_ctx *ctx, uint32_t *quality_length) {
+	return guarded([&] {
+		if (!ctx || !quality_length) throw InvalidError("null argument");
+		*quality_length = ctx->have_qual ? ctx->qual_len : 0u;
+	});
+}
+
+dropest_status dropest_cell_molecule_qualities(dropest_ctx *ctx, uint64_t cell_id, uint64_t n, uint32_t *quality_sums) {
+	return guarded([&] {
+		need_init(ctx);
+		if (cell_id >= ctx->n_cells) throw RangeError("cell index out of range");
+		if (!ctx->have_qual || ctx->qual_len == 0) { if (n) { /* nothing to write: quality length 0 */ } return; }
+		u32 cgb = 0, cgc = 0, mb = 0, me = 0;
+		HIP_CHECK(hipMemcpy(&cgb, ctx->cell_cg_begin.p + cell_id, 4, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(&cgc, ctx->cell_cg_count.p + cell_id, 4, hipMemcpyDeviceToHost));
+		if (cgc) {
+			HIP_CHECK(hipMemcpy(&mb, ctx->cg_mol_begin.p + cgb, 4, hipMemcpyDeviceToHost));
+			HIP_CHECK(hipMemcpy(&me, ctx->cg_mol_begin.p + cgb + cgc, 4, hipMemcpyDeviceToHost));
+		}
+		std::vector<u64> k; std::vector<u32> r, m, rows;
+		fetch_molecule_range(ctx, mb, me, k, r, m);
+		for_each_molecule(ctx, k, r, m, [&](u32, u32, u64, u32, uint8_t, u32 row) { rows.push_back(row); }, mb);
+		if (rows.size() != n) throw InvalidError("the cell has " + std::to_string(rows.size()) + " molecules, not " + std::to_string(n));
+		if (!quality_sums) throw InvalidError("null output array");
+		ctx->fetch_quality_rows(rows, quality_sums);
 	});
 }
 

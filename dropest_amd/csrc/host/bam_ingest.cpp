@@ -320,6 +320,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					for (char q : umiq) pass_quality &= q >= char(_min_barcode_phred);
 				}
 				r.umi_quality_length = uint32_t(umiq.size());
+				r.umi_quality = umiq;
 			} else {                                                      // ReadParamsParser.cpp:20-33: "id!CB#UMI"
 				const std::string_view name = al.name_view;
 				const size_t up = name.rfind('#');

@@ -136,11 +136,13 @@ void CellsDataContainer::add_record(const ReadInfo &r) {   // CellsDataContainer
 		if (_umi_quality_length == size_t(-1)) _umi_quality_length = ql;
 		else if (ql != _umi_quality_length)
 			throw std::runtime_error("Wrong quality length: " + std::to_string(ql) + ", expected: " + std::to_string(_umi_quality_length));
+		append_quality(r.params.umi_quality().data(), ql, true);
 		_umi.push_back(encode(r.params.umi(), _side_umi));   // UMI side strings: first seen on gene-bearing reads only
 		_gene.push_back(uint32_t(_gene_indexer.add(r.gene)));
 		// Stats::inc(chr) is reached only for exon / intron reads (CellsDataContainer.cpp:312-321)
 		if (mark & (UMI::Mark::HAS_EXONS | UMI::Mark::HAS_INTRONS)) chr = uint32_t(_chr_indexer.add(r.chromosome_name));
 	} else {
+		append_quality(nullptr, 0, false);
 		_umi.push_back(1);   // ignored by the device for gene-less reads
 		_gene.push_back(DROPEST_NO_GENE);
 		chr = uint32_t(_chr_indexer.add(r.chromosome_name));   // :75
@@ -195,6 +197,7 @@ void CellsDataContainer::add_record(const ParsedRead &r) {   // same statements 
 		if (_umi_quality_length == size_t(-1)) _umi_quality_length = ql;
 		else if (ql != _umi_quality_length)
 			throw std::runtime_error("Wrong quality length: " + std::to_string(ql) + ", expected: " + std::to_string(_umi_quality_length));
+		append_quality(r.umi_quality.data(), ql, true);
 		_umi.push_back(r.umi_code ? r.umi_code : encode(std::string(r.umi), _side_umi));
 		uint32_t gid;
 		auto it = r.gene_id >= 0 ? _gene_by_hash.end() : _gene_by_hash.find(r.gene_hash);
@@ -207,6 +210,7 @@ void CellsDataContainer::add_record(const ParsedRead &r) {   // same statements 
 		_gene.push_back(gid);
 		if (r.mark & (UMI::Mark::HAS_EXONS | UMI::Mark::HAS_INTRONS)) chr = chr_index();
 	} else {
+		append_quality(nullptr, 0, false);
 		_umi.push_back(1);
 		_gene.push_back(DROPEST_NO_GENE);
 		chr = chr_index();
@@ -214,6 +218,18 @@ void CellsDataContainer::add_record(const ParsedRead &r) {   // same statements 
 	if (chr > 0xFFFF) throw std::runtime_error("more than 65536 chromosome names");
 	_aux.push_back(chr | (uint32_t(r.mark) << 16));
 	if (_cb.size() >= BATCH) flush();
+}
+
+// One fixed-length quality row per read for dropest_set_umi_qualities: the bytes of gene-bearing reads, zeros for reads
+// without a gene (never read: they do not reach Gene::add_umi).
+void CellsDataContainer::append_quality(const char *q, size_t len, bool has_gene) {
+	if (!has_gene) {
+		if (_umi_quality_length == size_t(-1)) ++_qual_pending;
+		else _qual.insert(_qual.end(), _umi_quality_length, uint8_t(0));
+		return;
+	}
+	if (_qual_pending) { _qual.insert(_qual.end(), _qual_pending * _umi_quality_length, uint8_t(0)); _qual_pending = 0; }
+	_qual.insert(_qual.end(), reinterpret_cast<const uint8_t *>(q), reinterpret_cast<const uint8_t *>(q) + len);
 }
 
 void CellsDataContainer::flush() {
@@ -228,6 +244,10 @@ void CellsDataContainer::flush() {
 void CellsDataContainer::set_initialized() {   // CellsDataContainer.cpp:163-175
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
 	flush();
+	if (_umi_quality_length != size_t(-1) && _umi_quality_length > 0) {
+		check(dropest_set_umi_qualities(_ctx, _qual.data(), uint32_t(_umi_quality_length), _qual.size() / _umi_quality_length));
+		std::vector<uint8_t>().swap(_qual);
+	}
 	check(dropest_set_initialized(_ctx));
 	_is_initialized = true;
 }
@@ -361,13 +381,18 @@ std::vector<Cell::MoleculeRow> Cell::molecules() const {
 	std::vector<uint8_t> mark(n);
 	if (n && dropest_cell_molecules(h, _id, &n, gene.data(), umi.data(), reads.data(), mark.data()) != DROPEST_OK)
 		throw std::runtime_error(dropest_last_error());
+	uint32_t ql = 0;
+	if (dropest_umi_quality_length(h, &ql) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+	std::vector<uint32_t> qsum(size_t(n) * ql);
+	if (n && ql && dropest_cell_molecule_qualities(h, _id, n, qsum.data()) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
 	std::vector<MoleculeRow> out;
 	for (size_t i = 0; i < n; ++i) {
 		UMI::Mark m;
 		if (mark[i] & 1) m.add(UMI::Mark::HAS_NOT_ANNOTATED);
 		if (mark[i] & 2) m.add(UMI::Mark::HAS_EXONS);
 		if (mark[i] & 4) m.add(UMI::Mark::HAS_INTRONS);
-		out.push_back(MoleculeRow{_owner->gene_indexer().get_value(gene[i]), _owner->decode(umi[i]), reads[i], m});
+		out.push_back(MoleculeRow{_owner->gene_indexer().get_value(gene[i]), _owner->decode(umi[i]), reads[i], m,
+		                          std::vector<unsigned>(qsum.begin() + long(i * ql), qsum.begin() + long((i + 1) * ql))});
 	}
 	return out;
 }
@@ -529,9 +554,8 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 		{"requested_reads_per_cb", with_names(integers(std::move(req_reads)), real_names)},
 	};
 	if (umi_correction_info) {
-		// get_reads_per_umi_per_cell (:251-311): filtered cells, requested UMIs; per UMI list(reads, mean quality).  UMI
-		// qualities are not accumulated by this build: the mean quality is numeric(0), what the
-		// reference writes when the BAM carries no UMI quality tag.
+		// get_reads_per_umi_per_cell (:251-311): filtered cells, requested UMIs; per UMI list(reads, mean quality); the
+		// mean quality is numeric(0) when the reads carried no UMI quality (as in the reference).
 		StringIndexer cell_ix, gene_ix;
 		std::vector<int32_t> cell_indexes, gene_indexes;
 		std::vector<ValuePtr> per_gene;
@@ -550,7 +574,7 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 			for (auto const &m : it->second) {
 				if (m.gene != cur) { close(); cur = m.gene; }
 				if (!m.mark.match(c.gene_match_level())) continue;
-				umis.push_back(list({integers({int32_t(m.read_count)}), reals({})}));
+				umis.push_back(list({integers({int32_t(m.read_count)}), reals(m.mean_quality())}));
 				umi_names.push_back(m.umi);
 			}
 			close();

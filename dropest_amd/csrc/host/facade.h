@@ -39,6 +39,7 @@ public:
 		if (cell_barcode.empty() || umi.empty())
 			throw std::runtime_error("Wrong read parameters: '" + cell_barcode + "' '" + umi + "'");
 	}
+	static const char quality_offset = 33;                                     // ReadParameters.h:21
 	static ReadParameters parse_encoded_id(const std::string &encoded_id);   // "<id>!<CB>#<UMI>"
 	const std::string &cell_barcode() const { return _cb; }
 	const std::string &umi() const { return _umi; }
@@ -218,7 +219,15 @@ class Cell {
 	dropest_cell_row _row{};
 	std::string _barcode;
 public:
-	struct MoleculeRow { std::string gene, umi; size_t read_count; UMI::Mark mark; };
+	struct MoleculeRow {
+		std::string gene, umi; size_t read_count; UMI::Mark mark;
+		std::vector<unsigned> sum_quality;                                 // UMI::_sum_quality (UMI.h:51); empty without qualities
+		std::vector<double> mean_quality() const {                         // UMI.cpp:46-55: unsigned integer arithmetic, as written
+			std::vector<double> res(sum_quality.size());
+			for (size_t i = 0; i < res.size(); ++i) res[i] = double((sum_quality[i] - unsigned(Tools::ReadParameters::quality_offset)) / read_count);
+			return res;
+		}
+	};
 	bool is_merged() const { return _row.is_merged; }
 	bool is_excluded() const { return _row.is_excluded; }
 	bool is_real() const { return _row.is_real; }
@@ -254,6 +263,9 @@ private:
 	std::vector<uint64_t> _cb, _umi;
 	std::vector<uint32_t> _gene, _aux;
 	size_t _umi_quality_length = size_t(-1);
+	std::vector<uint8_t> _qual;               // qualities of every read so far, _umi_quality_length bytes each
+	size_t _qual_pending = 0;                 // gene-less reads seen before the length was known
+	void append_quality(const char *q, size_t len, bool has_gene);
 	std::vector<std::string> _ref_names;                      // ParsedRead::ref_id -> chromosome name
 	std::vector<int32_t> _ref_chr;                            // ... -> index in _chr_indexer, -1 = not met yet
 	std::unordered_map<uint64_t, uint32_t> _gene_by_hash;     // name hash -> gene index (verified against the name)
@@ -287,6 +299,7 @@ public:
 		int32_t ref_id = 0;                   // index into the chromosome names given to set_reference_names
 		uint8_t mark = 0;
 		uint32_t umi_quality_length = 0;
+		std::string_view umi_quality;         // umi_quality_length characters (phred+33)
 	};
 	void set_reference_names(const std::vector<std::string> &names);
 	void add_record(const ParsedRead &read);

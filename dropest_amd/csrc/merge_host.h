@@ -326,7 +326,7 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 // a target form an intrusive list so that a later merge of that target moves them along.  Stats::merge adds
 // every int counter, TOTAL_UMIS included (Stats.cpp:29-43).  Returns whether anything was merged.
 static bool apply_merge_order(u32 n_cells, size_t n_order, const u32 *order, const int64_t *target, int32_t *total_reads,
-                              int32_t *total_umis, u32 *final_target, uint8_t *excluded) {
+                              int32_t *total_umis, u32 *final_target, uint8_t *excluded, u32 *rank = nullptr) {
 	const u32 NIL = 0xFFFFFFFFu;
 	std::vector<u32> head(n_cells, NIL), tail(n_cells, NIL), next(n_cells, NIL);
 	u32 *cur = final_target;
@@ -350,6 +350,13 @@ static bool apply_merge_order(u32 n_cells, size_t n_order, const u32 *order, con
 		append(tr, b);
 		while (moved != NIL) { const u32 nx = next[moved]; cur[moved] = tr; append(tr, moved); moved = nx; }
 	}
+	if (rank) {   // order in which Gene::merge offered the cells' molecules to the final target (it keeps the first it saw)
+		for (u32 i = 0; i < n_cells; ++i) rank[i] = 0;
+		for (u32 t = 0; t < n_cells; ++t) {
+			u32 r = 0;
+			for (u32 x = head[t]; x != NIL; x = next[x]) rank[x] = ++r;
+		}
+	}
 	return any_merge;
 }
 
@@ -370,7 +377,10 @@ void dropest_ctx::run_cb_merge_real() {
 	for (u32 i = 0; i < nR; ++i) { reads[i] = real[i].row.total_reads; umis[i] = real[i].row.total_umis; }
 	std::vector<u32> cur(nR);
 	std::vector<uint8_t> excl(nR);
-	const bool any_merge = apply_merge_order(nR, cells.size(), ridx.data(), tgt.data(), reads.data(), umis.data(), cur.data(), excl.data());
+	std::vector<u32> rank(nR);
+	const bool any_merge = apply_merge_order(nR, cells.size(), ridx.data(), tgt.data(), reads.data(), umis.data(), cur.data(), excl.data(), rank.data());
+	merge_rank.assign(n_cells, 0);
+	for (u32 i = 0; i < nR; ++i) merge_rank[real[i].id] = rank[i];
 	reassign.clear();
 	merge_pairs.clear();
 	for (u32 i = 0; i < nR; ++i) {
@@ -397,6 +407,17 @@ void dropest_ctx::reaggregate_after_merge() {
 		                   u32(src.size()), remap.p);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipStreamSynchronize(stream));   // src / tgt are host vectors
+	}
+	if (have_qual && qual_len && n_mol) {   // which member's quality sums a folded molecule keeps (quality.h)
+		if (merge_rank.size() != n_cells) merge_rank.assign(n_cells, 0);
+		DevBuf<u32> d_rank; d_rank.alloc(n_cells);
+		HIP_CHECK(hipMemcpyAsync(d_rank.p, merge_rank.data(), size_t(n_cells) * 4, hipMemcpyHostToDevice, stream));
+		reagg_prio_buf.ensure(n_mol);
+		hipLaunchKernelGGL(prio_from_cell_kernel, dim3(div_up(n_mol, 256)), dim3(256), 0, stream, mol_key.p, n_mol,
+		                   layout.gene_bits + layout.umi_bits, d_rank.p, reagg_prio_buf.p);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipStreamSynchronize(stream));
+		reagg_prio = reagg_prio_buf.p;
 	}
 	keys_a.ensure(n_mol); keys_b.ensure(n_mol); vals_a.ensure(n_mol); vals_b.ensure(n_mol);
 	scalars.ensure(16);
@@ -441,6 +462,7 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 		});
 		HIP_CHECK(hipStreamSynchronize(stream));
 	}
+	requality_after_fold(keys, vals, n_mol, mol_key2.p, new_n);
 	std::swap(mol_key, mol_key2); std::swap(mol_reads, mol_reads2); std::swap(mol_mark, mol_mark2);
 	n_mol = new_n;
 	reduce_molecules_to_cell_gene();

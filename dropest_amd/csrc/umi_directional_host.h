@@ -182,6 +182,11 @@ void dropest_ctx::run_umi_merge_directional() {
 		HIP_CHECK(hipMemcpyAsync(d_or_and, init, 16, hipMemcpyHostToDevice, stream));
 		hipLaunchKernelGGL(iota_or_and_kernel, dim3(std::min<u32>(div_up(n_mol, 256), 4096u)), dim3(256), 0, stream, keys_a.p, n_mol,
 		                   vals_a.p, d_or_and);
+		if (have_qual && qual_len) {   // a molecule that receives others keeps its own quality sums (Gene.cpp:50-54)
+			reagg_prio_buf.ensure(n_mol);
+			hipLaunchKernelGGL(prio_from_rekey_kernel, dim3(div_up(n_mol, 256)), dim3(256), 0, stream, mol_key.p, keys_a.p, n_mol, reagg_prio_buf.p);
+			reagg_prio = reagg_prio_buf.p;
+		}
 		HIP_CHECK(hipGetLastError());
 		u64 or_and[2];
 		fetch(or_and, d_or_and, 16);
@@ -195,10 +200,11 @@ void dropest_ctx::run_umi_merge_directional() {
 	umi_gather_groups(groups, GG, umi_first.p);
 	std::vector<u32> p_idx, p_all, p_req, p_rreq;
 	for (u32 g = 0; g < n_host; ++g) {
-		struct Mol { u64 code; std::string seq; u32 reads, mark, first; };
+		struct Mol { u64 code; std::string seq; u32 reads, mark, first, row; };
 		std::vector<Mol> mols(GG.size[g]);
 		for (u32 t = 0; t < GG.size[g]; ++t) {
 			Mol &m = mols[t];
+			m.row = GG.begin[g] + t;
 			m.code = unmap_umi(GG.hk[GG.off[g] + t] & umask);
 			m.seq = decode_code(m.code, side);
 			m.reads = GG.hr[GG.off[g] + t]; m.mark = GG.hm[GG.off[g] + t]; m.first = GG.hfirst[GG.off[g] + t];
@@ -211,18 +217,19 @@ void dropest_ctx::run_umi_merge_directional() {
 		const auto targets = directional_find_targets(v, cfg.umi_merge_multiplier, unsigned(cfg.max_umi_merge_edit_distance));
 		if (targets.empty()) continue;
 		// Cell::merge_umis + Gene::merge(src, tgt) (Cell.cpp:31-42, Gene.cpp:38-58), in the map's own iteration order
-		std::map<std::string, std::pair<u32, u32>> merged;    // sequence -> (reads, mark)
+		struct Folded { u32 reads, mark, row; };               // row: the molecule whose quality sums this one shows
+		std::map<std::string, Folded> merged;                  // sequence -> molecule
 		std::unordered_map<std::string, u64> code_of;
-		for (const Mol &m : mols) { merged[m.seq] = {m.reads, m.mark}; code_of[m.seq] = m.code; }
+		for (const Mol &m : mols) { merged[m.seq] = Folded{m.reads, m.mark, m.row}; code_of[m.seq] = m.code; }
 		const u32 cell = u32(GG.hk[GG.off[g]] >> (layout.umi_bits + layout.gene_bits));
 		for (auto const &t : targets) {
 			if (t.second == t.first) continue;
 			auto s = merged.find(t.first);
 			if (s == merged.end()) throw InvalidError("Source UMI doesn't belong to the gene: " + t.first);
-			const std::pair<u32, u32> moved = s->second;
+			const Folded moved = s->second;
 			auto it = merged.find(t.second);
-			if (it == merged.end()) merged[t.second] = moved;
-			else { it->second.first += moved.first; it->second.second |= moved.second; }
+			if (it == merged.end()) merged[t.second] = moved;   // a copy of the source, quality sums included (Gene.cpp:49)
+			else { it->second.reads += moved.reads; it->second.mark |= moved.mark; }
 			merged.erase(t.first);
 			umis_removed[cell] += 1;
 		}
@@ -234,7 +241,7 @@ void dropest_ctx::run_umi_merge_directional() {
 			auto known = code_of.find(kv.first);
 			if (known != code_of.end()) code = known->second;
 			else if (!encode_code(kv.first, code)) throw UnsupportedError("re-keyed UMI does not fit a 2-bit code: " + kv.first);
-			o.umi = code; o.reads = kv.second.first; o.mark = uint8_t(kv.second.second);
+			o.umi = code; o.reads = kv.second.reads; o.mark = uint8_t(kv.second.mark); o.src_row = kv.second.row;
 			ov.push_back(o);
 			if ((query_mask >> (o.mark & 7u)) & 1u) { ++n_req; reads_req += o.reads; }
 		}

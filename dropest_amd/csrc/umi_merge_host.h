@@ -118,7 +118,9 @@ void dropest_ctx::umi_gather_groups(const std::vector<u32> &groups, GatheredGrou
 	hipLaunchKernelGGL(group_extents_kernel, dim3(div_up(n_groups, 256)), dim3(256), 0, stream, d_idx.p, n_groups, cg_mol_begin.p,
 	                   d_begin.p, d_size.p);
 	HIP_CHECK(hipGetLastError());
+	G.begin.assign(n_groups, 0);
 	HIP_CHECK(hipMemcpyAsync(G.size.data(), d_size.p, size_t(n_groups) * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(G.begin.data(), d_begin.p, size_t(n_groups) * 4, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
 	uint64_t total = 0;
 	for (u32 g = 0; g < n_groups; ++g) { G.off[g] = u32(total); total += G.size[g]; }
@@ -201,11 +203,12 @@ void dropest_ctx::run_umi_merge_simple() {
 	const std::vector<u64> &hk = GG.hk;
 	const std::vector<u32> &hr = GG.hr, &hm = GG.hm;
 
-	struct Mol { u64 code; std::string seq; u32 reads, mark; bool bad; };
+	struct Mol { u64 code; std::string seq; u32 reads, mark, row; bool bad; };
 	std::vector<std::vector<Mol>> G(n_groups);
 	for (u32 g = 0; g < n_groups; ++g) {
 		for (u32 t = 0; t < size[g]; ++t) {
 			Mol m;
+			m.row = GG.begin[g] + t;
 			m.code = unmap_umi(hk[off[g] + t] & umask);
 			m.seq = decode_code(m.code, side);
 			m.reads = hr[off[g] + t]; m.mark = hm[off[g] + t];
@@ -277,16 +280,17 @@ void dropest_ctx::run_umi_merge_simple() {
 			targets[b] = mols[pick].seq;
 		}
 		// Cell::merge_umis + Gene::merge(src, tgt) (Gene.cpp:38-58): counts add, marks OR
-		std::map<std::string, std::pair<u32, u32>> merged;   // clean sequence -> (reads, mark)
+		struct Folded { u32 reads, mark, row; };              // row: the molecule whose quality sums this one shows
+		std::map<std::string, Folded> merged;                 // clean sequence -> molecule
 		std::unordered_map<std::string, u64> code_of;         // codes of the molecules that already exist
-		for (const Mol &m : mols) if (!m.bad) { merged[m.seq] = {m.reads, m.mark}; code_of[m.seq] = m.code; }
+		for (const Mol &m : mols) if (!m.bad) { merged[m.seq] = Folded{m.reads, m.mark, m.row}; code_of[m.seq] = m.code; }
 		const u32 cell = u32(hk[off[g]] >> (layout.umi_bits + layout.gene_bits));
 		for (auto const &t : targets) {
 			if (t.second == t.first) continue;
 			const Mol &src = mols[mol_of.at(t.first)];
 			auto it = merged.find(t.second);
-			if (it == merged.end()) merged[t.second] = {src.reads, src.mark};
-			else { it->second.first += src.reads; it->second.second |= src.mark; }
+			if (it == merged.end()) merged[t.second] = Folded{src.reads, src.mark, src.row};   // copy of the source (Gene.cpp:49)
+			else { it->second.reads += src.reads; it->second.mark |= src.mark; }
 			umis_removed[cell] += 1;
 		}
 		std::vector<UmiOverride> ov;
@@ -297,7 +301,7 @@ void dropest_ctx::run_umi_merge_simple() {
 			auto known = code_of.find(kv.first);
 			if (known != code_of.end()) code = known->second;
 			else if (!encode_code(kv.first, code)) throw UnsupportedError("re-keyed UMI does not fit a 2-bit code: " + kv.first);
-			o.umi = code; o.reads = kv.second.first; o.mark = uint8_t(kv.second.second);
+			o.umi = code; o.reads = kv.second.reads; o.mark = uint8_t(kv.second.mark); o.src_row = kv.second.row;
 			ov.push_back(o);
 			if ((query_mask >> (o.mark & 7u)) & 1u) { ++n_req; reads_req += o.reads; }
 		}

@@ -155,6 +155,20 @@ dropest_status dropest_global_counters(dropest_ctx *ctx, uint64_t out[4]);
  * Replaces Cell::genes() / Gene::umis() walks (Cell.h:19, Gene.h:19). */
 dropest_status dropest_cell_molecules(dropest_ctx *ctx, uint64_t cell, uint64_t *n, uint32_t *gene,
                                       uint64_t *umi, uint32_t *reads, uint8_t *mark);
+
+/* UMI base qualities (ReadParameters::umi_quality, Tools/ReadParameters.h:9-50): one fixed-length string per pushed
+ * read, in push order, quality_length bytes each (host memory; raw phred+33 characters as in the BAM tag).  Call after
+ * the last push and before set_initialized.  The container then accumulates the per-position sums of every molecule
+ * (UMI::add_read, UMI.cpp:21-34) and carries them through the merges the way the reference does: UMI::merge does
+ * NOT add qualities (UMI.cpp:15-19), a molecule copied into another cell / re-keyed to a new UMI takes its sums along
+ * (Gene.cpp:26-58).  The reference allows a different length per molecule and throws on a mismatch inside one
+ * (UMI.cpp:26-28); one length per container covers what its BAM readers produce. */
+dropest_status dropest_set_umi_qualities(dropest_ctx *ctx, const uint8_t *qualities, uint32_t quality_length, uint64_t n_reads);
+dropest_status dropest_umi_quality_length(dropest_ctx *ctx, uint32_t *quality_length);   /* 0 when none were given */
+/* UMI::_sum_quality of the molecules of one cell, in the order of dropest_cell_molecules: n x quality_length sums
+ * (UMI::mean_quality, UMI.cpp:46-55, is (sum - 33) / read_count in unsigned integer arithmetic).  n must equal the
+ * cell's molecule count. */
+dropest_status dropest_cell_molecule_qualities(dropest_ctx *ctx, uint64_t cell_id, uint64_t n, uint32_t *quality_sums);
 /* Whole molecule table, ascending (cell id, gene id, umi code). */
 dropest_status dropest_molecules(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, uint32_t *gene, uint64_t *umi,
                                  uint32_t *reads, uint8_t *mark);

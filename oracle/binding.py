@@ -76,6 +76,8 @@ def oracle_lib():
         "orc_fill_wrong_umi": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "orc_directional_targets": (C.c_int, [vp, P(C.c_char_p), vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int]),
         "orc_collisions_table": (C.c_int, [vp, u64, u64, vp]),
+        "orc_add_packed_q": (C.c_int, [vp, vp, vp, vp, vp, u64, C.POINTER(C.c_char_p), vp, C.c_uint32]),
+        "orc_molecule_qualities": (C.c_int, [vp, C.c_uint32, vp]),
         "orc_poisson_init": (C.c_int, [vp]), "orc_poisson_distribution_size": (u64, [vp]),
         "orc_poisson_gene_intersection": (C.c_double, [vp, u64, u64]),
         "orc_poisson_intersection_prob": (C.c_double, [vp, u64, u64]),
@@ -137,6 +139,22 @@ class Oracle:
         arr = (C.c_char_p * max(1, len(side)))(*[s.encode() for s in side])
         self._chk(self.L.orc_add_packed(self.h, cb.ctypes.data, umi.ctypes.data, gene.ctypes.data,
                                         aux.ctypes.data, len(cb), arr))
+
+    def add_packed_q(self, cb, umi, gene, aux, qual, side=()):
+        """Like add_packed, with UMI qualities: uint8 [n, quality_length]."""
+        cb = np.ascontiguousarray(cb, np.uint64); umi = np.ascontiguousarray(umi, np.uint64)
+        gene = np.ascontiguousarray(gene, np.uint32); aux = np.ascontiguousarray(aux, np.uint32)
+        qual = np.ascontiguousarray(qual, np.uint8)
+        arr = (C.c_char_p * max(1, len(side)))(*[s.encode() for s in side])
+        self._chk(self.L.orc_add_packed_q(self.h, cb.ctypes.data, umi.ctypes.data, gene.ctypes.data, aux.ctypes.data, len(cb), arr,
+                                          qual.ctypes.data, qual.shape[1]))
+
+    def molecule_qualities(self, n_molecules, qlen):
+        """UMI::_sum_quality of every molecule, in the order of molecules()."""
+        out = np.zeros((n_molecules, qlen), np.uint32)
+        if self.L.orc_molecule_qualities(self.h, qlen, out.ctypes.data) != 0:
+            raise RuntimeError("a molecule has another quality length")
+        return out
 
     def set_initialized(self):
         self._chk(self.L.orc_set_initialized(self.h))

@@ -870,6 +870,34 @@ int orc_add_packed(void *h, const uint64_t *cb, const uint64_t *umi, const uint3
 	ORC_CATCH
 }
 
+// same with UMI qualities: qual = n x qlen bytes (phred+33 characters)
+int orc_add_packed_q(void *h, const uint64_t *cb, const uint64_t *umi, const uint32_t *gene, const uint32_t *aux,
+                     uint64_t n, const char *const *side, const uint8_t *qual, uint32_t qlen) {
+	ORC_TRY
+	auto *c = static_cast<orc::Container *>(h);
+	for (uint64_t i = 0; i < n; ++i) {
+		std::string g = gene[i] == 0xFFFFFFFFu ? std::string() : "G" + std::to_string(gene[i]);
+		c->add_record(unpack2(cb[i], side), unpack2(umi[i], side), std::string(reinterpret_cast<const char *>(qual) + size_t(i) * qlen, qlen), g,
+		              "chr" + std::to_string(aux[i] & 0xFFFFu), uint8_t((aux[i] >> 16) & 0xFF));
+	}
+	ORC_CATCH
+}
+
+// UMI::_sum_quality of every molecule, in the order of orc_molecules; qlen values each (molecules with another
+// length -- impossible through orc_add_packed_q -- report -1)
+int orc_molecule_qualities(void *h, uint32_t qlen, uint32_t *out) {
+	auto *c = static_cast<orc::Container *>(h);
+	uint64_t n = 0;
+	for (size_t i = 0; i < c->cells.size(); ++i)
+		for (auto const &g : c->cells[i].genes)
+			for (auto const &u : g.second) {
+				if (u.second.qual_sum.size() != qlen) return -1;
+				for (uint32_t p = 0; p < qlen; ++p) out[n * qlen + p] = u.second.qual_sum[p];
+				++n;
+			}
+	return 0;
+}
+
 int orc_set_initialized(void *h) { ORC_TRY static_cast<orc::Container *>(h)->set_initialized(); ORC_CATCH }
 int orc_merge_and_filter(void *h) { ORC_TRY static_cast<orc::Container *>(h)->merge_and_filter(); ORC_CATCH }
 int orc_merge_umis_only(void *h) {   // Tests/TestEstimation.cpp:525 calls the UMI strategy alone

@@ -31,7 +31,7 @@ int main(int argc, char **argv) {
 		c.set_initialized();
 		c.merge_and_filter();
 		const auto t2 = std::chrono::steady_clock::now();
-		ResultsPrinter(true, false).save_results(c, out + ".rds");
+		ResultsPrinter(true, false, false, std::getenv("DROPEST_RPUPC") != nullptr).save_results(c, out + ".rds");   // + reads_per_umi_per_cell
 		const auto t3 = std::chrono::steady_clock::now();
 		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 		const auto &k = ctl.counters();

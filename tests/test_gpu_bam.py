@@ -42,10 +42,11 @@ def _oracle(reads, min_before, min_after, wl=None):
     return {(o.gene_name(int(g)), cols[int(c)]): int(x) for g, c, x in zip(gi, ci, v)}, cols
 
 
-def _run(tmp_path, mode, bams, min_before, min_after, wl="-", threads=3):
+def _run(tmp_path, mode, bams, min_before, min_after, wl="-", threads=3, env=None):
     build_facade()
     out = str(tmp_path / "res")
-    res = subprocess.run([TOOL, out, mode, str(min_before), str(min_after), wl, str(threads)] + bams, capture_output=True, text=True, timeout=300)
+    res = subprocess.run([TOOL, out, mode, str(min_before), str(min_after), wl, str(threads)] + bams, capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, **(env or {})))
     assert res.returncode == 0, res.stdout + res.stderr
     stats = json.loads(res.stdout.strip().splitlines()[-1])
     d = rr.read_rds(out + ".rds")
@@ -174,3 +175,39 @@ def test_genes_from_a_gtf_annotation(tmp_path):
     assert cells == cols and got == want and len(want) > 100
     assert stats["cant_parse"] == n_unknown > 0 and stats["saved"] == len(kept)
     assert sum(1 for k in kept if k[4] & 1) > 100 and sum(1 for k in kept if k[2] is None) > 1000    # half-annotated and intergenic reads
+
+
+def test_umi_quality_tags_reach_reads_per_umi_per_cell(tmp_path):
+    """UQ tags -> UMI::add_read sums -> UMI::mean_quality in reads_per_umi_per_cell (ResultsPrinter.cpp:261-314), against the oracle."""
+    reads = _reads(30_000, seed_cells=12)
+    refs = [("chr%d" % i, 1_000_000) for i in range(25)]
+    rng = np.random.default_rng(9)
+    recs, o = [], Oracle(min_genes_before=5, min_genes_after=10)
+    for i, (cb, umi, g, chr_, mark) in enumerate(reads):
+        q = "".join(chr(int(x)) for x in rng.integers(35, 74, 8))
+        if g is None:
+            tags, m = [("CB", "Z", cb), ("UB", "Z", umi), ("UQ", "Z", q)], 1
+        else:
+            code, m = (("N", 4) if mark & 4 else ("I", 1) if mark == 1 else ("E", 2))
+            tags = [("CB", "Z", cb), ("UB", "Z", umi), ("UQ", "Z", q), ("GX", "Z", g), ("RE", "A", code)]
+        recs.append(bw.record(int(chr_[3:]), i, "r%d" % i, tags=tags))
+        o.add_record(cb, umi, g or "", chr_, m, umi_qual=q)
+    o.set_initialized(); o.merge_and_filter()
+    b = str(tmp_path / "q.bam")
+    bw.write_bam(b, refs, recs)
+    got, cells, stats, d = _run(tmp_path, "filled", [b], 5, 10, env={"DROPEST_RPUPC": "1"})
+    assert stats["saved"] == len(reads)
+    oc, og, ou, orr, om = o.molecules()
+    oq = o.molecule_qualities(len(oc), 8)
+    want = {}
+    filtered = {int(x) for x in o.filtered_cells()}
+    for i in range(len(oc)):
+        if int(oc[i]) in filtered and om[i] in (2, 3, 6, 7):                      # requested UMIs (default -L eEBA: marks with an exon bit)
+            want[(o.cell_barcode(int(oc[i])), o.gene_name(int(og[i])), ou[i])] = (int(orr[i]), [float((int(s) - 33) // int(orr[i])) for s in oq[i]])
+    rp = d["reads_per_umi_per_cell"]
+    cells_l, genes_l = rp["cells"].value, rp["genes"].value
+    seen = {}
+    for ci, gi, per_gene in zip(rp["cell_indexes"].value, rp["gene_indexes"].value, rp["reads_per_umi"].value):
+        for name, entry in zip(per_gene.names, per_gene.value):
+            seen[(cells_l[int(ci)], genes_l[int(gi)], name)] = (int(entry.value[0].value[0]), [float(x) for x in entry.value[1].value])
+    assert len(seen) > 1000 and seen == want

@@ -61,4 +61,15 @@ def test_results_rds_written_by_the_facade(tmp_path):
     assert rp.names == ["cells", "genes", "cell_indexes", "gene_indexes", "reads_per_umi"]
     assert rp["cells"].value == cells and len(rp["reads_per_umi"].value) == len(rp["cell_indexes"].value) == 7
     first = rp["reads_per_umi"].value[0]
-    assert first.kind == "list" and first.names and first.value[0].value[0].kind == "integer" and len(first.value[0].value[1].value) == 0
+    assert first.kind == "list" and first.names and first.value[0].value[0].kind == "integer"
+    # the reference's fixture passes the UMI itself as its quality string (Tests/TestEstimation.cpp:27-31): every molecule's
+    # sums are k x the UMI's characters, k = reads added by add_read to the molecule whose sums survived the merges
+    # (UMI::merge adds no qualities), and UMI::mean_quality is (sum - 33) / read_count in unsigned integer arithmetic
+    n_checked = 0
+    for per_gene in rp["reads_per_umi"].value:
+        for umi, entry in zip(per_gene.names, per_gene.value):
+            reads, mean = int(entry.value[0].value[0]), [int(x) for x in entry.value[1].value]
+            assert len(mean) == len(umi)
+            assert any(mean == [(k * ord(ch) - 33) // reads for ch in umi] for k in range(1, reads + 1)), (umi, reads, mean)
+            n_checked += 1
+    assert n_checked >= 7

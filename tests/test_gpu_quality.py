@@ -1,0 +1,186 @@
+"""UMI quality sums (UMI::add_read / UMI::mean_quality, Estimation/UMI.cpp:21-55): the HIP path against the oracle,
+through every step that moves molecules around (CB merges, N-UMI merge, directional UMI merge)."""
+import os
+
+import numpy as np
+import pytest
+
+from dropest_amd import capi
+from dropest_amd.synth import SynthStream, inject_n
+from oracle import Oracle
+
+import parity
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dropest_amd", "data", "barcodes")
+
+
+def _qualities(n, qlen, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(33, 75, size=(n, qlen), dtype=np.uint8)     # phred+33 characters '!' .. 'J'
+
+
+def _both_q(okw, gkw, cb, umi, gene, aux, qual, side=()):
+    o = Oracle(**okw)
+    o.add_packed_q(cb, umi, gene, aux, qual, side)
+    o.set_initialized()
+    o.merge_and_filter()
+    c = capi.Context(**gkw)
+    if side:
+        c.set_side_strings(side)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_umi_qualities(qual)
+    c.set_initialized()
+    c.merge_and_filter()
+    parity.compare(o, c, side)
+    return o, c
+
+
+def _compare_qualities(o, c, qlen, side=()):
+    oc, og, ou, orr, om = o.molecules()
+    oq = o.molecule_qualities(len(oc), qlen)
+    merged = o.cell_rows()[:, 0] != 0
+    want = {}
+    for i in range(len(oc)):
+        if not merged[int(oc[i])]:          # the stale maps of merged-away cells are never read again
+            want[(int(oc[i]), int(og[i]), ou[i])] = (int(orr[i]), tuple(int(x) for x in oq[i]))
+    got = {}
+    assert c.umi_quality_length() == qlen
+    for cell in sorted({k[0] for k in want}):
+        g, u, r, m = c.cell_molecules(cell)
+        q = c.cell_molecule_qualities(cell, len(g))
+        for j in range(len(g)):
+            got[(cell, int(g[j]), capi.unpack_code(u[j], side))] = (int(r[j]), tuple(int(x) for x in q[j]))
+    assert len(got) == len(want)
+    bad = [k for k in want if got.get(k) != want[k]]
+    assert not bad, "quality sums differ for %d molecules, e.g. %s: got %s want %s" % (len(bad), bad[0], got.get(bad[0]), want[bad[0]])
+    # UMI::mean_quality (UMI.cpp:46-55): unsigned integer arithmetic
+    k0 = next(iter(want))
+    reads, sums = want[k0]
+    assert all(((s - 33) // reads) >= 0 for s in sums)
+
+
+def test_quality_sums_without_merge():
+    s = SynthStream(n_reads=60_000, n_cells=20, n_genes=300, umi_len=8)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    qual = _qualities(len(cb), 8, 1)
+    okw = dict(merge_kind=0, min_genes_before=3, min_genes_after=5)
+    gkw = dict(merge_kind=capi.MERGE_NONE, min_genes_before_merge=3, min_genes_after_merge=5)
+    o, c = _both_q(okw, gkw, cb, umi, gene, aux, qual)
+    _compare_qualities(o, c, 8)
+
+
+@pytest.mark.parametrize("kind", ["real", "poisson", "simple"])
+def test_quality_sums_follow_the_cb_merge(kind):
+    """A molecule present in the target keeps the target's sums; one that only a merged cell had brings its own; with
+    several merged cells the first in merge order wins (Gene::merge, Gene.cpp:26-36)."""
+    s = SynthStream(n_reads=150_000, whitelist="10x_aug_2016_split", n_cells=25, n_genes=60, umi_len=6, permille_neighbour=200)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    qual = _qualities(len(cb), 6, 2)
+    path = os.path.join(DATA, "10x_aug_2016_split")
+    if kind == "simple":
+        okw = dict(merge_kind=2, max_cb_merge_ed=2, min_merge_fraction=0.1, min_genes_before=3, min_genes_after=10)
+        gkw = dict(merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=2, min_merge_fraction=0.1, min_genes_before_merge=3,
+                   min_genes_after_merge=10)
+    else:
+        okw = dict(merge_kind=1 if kind == "real" else 3, barcodes_kind=1, barcodes_file=path, min_genes_before=3, min_genes_after=10)
+        gkw = dict(merge_kind=capi.MERGE_REAL_BARCODES if kind == "real" else capi.MERGE_POISSON_REAL, barcodes_kind=capi.BARCODES_CONST,
+                   barcodes_file=path, min_genes_before_merge=3, min_genes_after_merge=10)
+    o, c = _both_q(okw, gkw, cb, umi, gene, aux, qual)
+    mt = c.merge_targets()
+    assert int((mt != np.arange(len(mt))).sum()) > 20
+    _compare_qualities(o, c, 6)
+
+
+def test_quality_sums_follow_the_n_umi_merge():
+    s = SynthStream(n_reads=40_000, n_cells=15, n_genes=40, umi_len=6)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    umi, side = inject_n(umi, gene, 0.03, 3, 6)
+    qual = _qualities(len(cb), 6, 3)
+    okw = dict(merge_kind=0, min_genes_before=3, min_genes_after=5)
+    gkw = dict(merge_kind=capi.MERGE_NONE, min_genes_before_merge=3, min_genes_after_merge=5)
+    o, c = _both_q(okw, gkw, cb, umi, gene, aux, qual, side)
+    _compare_qualities(o, c, 6, side)
+
+
+@pytest.mark.parametrize("with_n", [False, True])
+def test_quality_sums_follow_the_directional_umi_merge(with_n):
+    import ctypes
+    s = SynthStream(n_reads=50_000, n_cells=15, n_genes=30, umi_len=6)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    side = ()
+    if with_n:
+        umi, side = inject_n(umi, gene, 0.02, 4, 6)
+    qual = _qualities(len(cb), 6, 4)
+    okw = dict(merge_kind=0, umi_merge_kind=1, min_genes_before=3, min_genes_after=5)
+    gkw = dict(merge_kind=capi.MERGE_NONE, umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL, min_genes_before_merge=3, min_genes_after_merge=5)
+    libc = ctypes.CDLL("libc.so.6")
+    o = Oracle(**okw)
+    o.add_packed_q(cb, umi, gene, aux, qual, side)
+    o.set_initialized()
+    libc.srand(1)
+    o.merge_and_filter()
+    c = capi.Context(**gkw)
+    if side:
+        c.set_side_strings(side)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_umi_qualities(qual)
+    c.set_initialized()
+    libc.srand(1)
+    c.merge_and_filter()
+    parity.compare(o, c, side)
+    _compare_qualities(o, c, 6, side)
+
+
+def test_quality_errors_are_explicit():
+    c = capi.Context()
+    cb = np.array([capi.pack_seq("ACGTACGTACGT")] * 3, np.uint64); umi = np.array([capi.pack_seq("ACGTAC")] * 3, np.uint64)
+    c.push_reads(cb, umi, np.zeros(3, np.uint32), np.full(3, 2 << 16, np.uint32))
+    with pytest.raises(capi.DropestError):
+        c.set_umi_qualities(np.zeros((2, 6), np.uint8))          # must cover every read
+    c.set_umi_qualities(np.full((3, 6), 40, np.uint8))
+    c.set_initialized()
+    g, u, r, m = c.cell_molecules(0)
+    assert list(r) == [3] and c.cell_molecule_qualities(0, 1).tolist() == [[120] * 6]
+    with pytest.raises(capi.DropestError):
+        c.cell_molecule_qualities(0, 2)
+    with pytest.raises(capi.DropestError):
+        c.set_umi_qualities(np.full((3, 6), 40, np.uint8))      # after set_initialized
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_streams_with_qualities(seed):
+    """Adversarial small streams (few UMIs and genes: many molecules shared between merged cells, chains of merges,
+    UMIs with N, directional merges with ties) -- the quality sums must follow the molecules exactly."""
+    import ctypes
+    from test_gpu_stress import random_stream
+    rng = np.random.default_rng(12000 + seed)
+    umi_len = 6
+    cb, umi, gene, aux, side = random_stream(
+        rng, n=int(rng.integers(300, 6000)), n_cb=int(rng.integers(2, 40)), n_gene=int(rng.integers(1, 12)),
+        n_umi=int(rng.integers(2, 60)), cb_len=(8, 8), umi_len=(umi_len, umi_len), n_rate=0.05 if seed % 2 else 0.0)
+    qual = _qualities(len(cb), umi_len, 100 + seed)
+    directional = seed % 3 == 0
+    okw = dict(merge_kind=2, max_cb_merge_ed=int(rng.integers(1, 6)), min_merge_fraction=float(rng.choice([0.0, 0.1, 0.3])),
+               min_genes_before=int(rng.integers(0, 3)), min_genes_after=0, umi_merge_kind=1 if directional else 0)
+    gkw = dict(merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=okw["max_cb_merge_ed"], min_merge_fraction=okw["min_merge_fraction"],
+               min_genes_before_merge=okw["min_genes_before"], min_genes_after_merge=0,
+               umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL if directional else capi.UMI_MERGE_SIMPLE)
+    libc = ctypes.CDLL("libc.so.6")
+    o = Oracle(**okw)
+    o.add_packed_q(cb, umi, gene, aux, qual, side)
+    o.set_initialized()
+    if directional:
+        libc.srand(1)
+    o.merge_and_filter()
+    c = capi.Context(**gkw)
+    if side:
+        c.set_side_strings(side)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_umi_qualities(qual)
+    c.set_initialized()
+    if directional:
+        libc.srand(1)
+    c.merge_and_filter()
+    parity.compare(o, c, side)
+    _compare_qualities(o, c, umi_len, side)
