@@ -183,6 +183,19 @@ public:
 		cfg.max_merge_prob = _estimator.max_merge_prob; cfg.max_real_merge_prob = _estimator.max_real_cb_merge_prob;
 	}
 };
+// Estimation/Merge/PoissonSimpleMergeStrategy.h (-M without a barcodes file)
+class PoissonSimpleMergeStrategy : public MergeStrategyAbstract {
+	PoissonTargetEstimator _estimator; unsigned _max_ed;
+public:
+	PoissonSimpleMergeStrategy(const PoissonTargetEstimator &target_estimator, unsigned min_genes_before_merge, unsigned min_genes_after_merge,
+	                           unsigned max_merge_edit_distance)
+		: MergeStrategyAbstract(min_genes_before_merge, min_genes_after_merge), _estimator(target_estimator), _max_ed(max_merge_edit_distance) {}
+	std::string merge_type() const override { return "Poisson Simple"; }
+	void fill(dropest_cfg &cfg) const override {
+		cfg.merge_kind = DROPEST_MERGE_POISSON_SIMPLE; cfg.max_cb_merge_edit_distance = int(_max_ed); cfg.min_merge_fraction = 0;
+		cfg.max_merge_prob = _estimator.max_merge_prob; cfg.max_real_merge_prob = _estimator.max_real_cb_merge_prob;
+	}
+};
 namespace UMIs {
 class MergeUMIsStrategyAbstract {
 public:

@@ -167,6 +167,11 @@ void dropest_ctx::run_cb_merge_simple() {
 	const int key_bits = low_bits + layout.cell_bits;
 	radix_sort(k, v, k_alt, v_alt, n_mol, key_bits >= 64 ? ~0ull : ((1ull << key_bits) - 1ull) | (1ull << 63), 0);   // sentinels (all ones) sort last
 	const u64 *sorted = k;
+	DevBuf<u64> sorted_keep;   // -M: the estimator below reuses the sort buffers; the tie replay still needs this table
+	if (cfg.merge_kind == DROPEST_MERGE_POISSON_SIMPLE && n_valid) {
+		sorted_keep.alloc(n_valid);
+		HIP_CHECK(hipMemcpyAsync(sorted_keep.p, k, size_t(n_valid) * 8, hipMemcpyDeviceToDevice, stream));
+	}
 
 	// 2. shared UMI-genes: ordered pairs per run, sorted, run-length encoded
 	std::vector<u64> pair_key; std::vector<u32> pair_cnt, pair_ed;
@@ -223,7 +228,44 @@ void dropest_ctx::run_cb_merge_simple() {
 		if (pair_ed[p] != 0xFFFFFFFFu) return int(pair_ed[p]);
 		return int(plain_edit_distance(barcode_of(real[real_at(base)]), barcode_of(real[real_at(other)])));
 	};
-	for (size_t p = 0; p < pair_key.size();) {
+	// PoissonSimpleMergeStrategy::get_merge_target (PoissonSimpleMergeStrategy.cpp:15-43): the neighbours are the cells
+	// with common UMI-genes within the edit distance (<=, not < as above); the shared count IS the intersection size
+	const bool poisson = cfg.merge_kind == DROPEST_MERGE_POISSON_SIMPLE;
+	std::vector<double> pair_prob;                                           // per pair; 2 = not a neighbour
+	std::vector<u32> nb_count(F, 0);
+	if (poisson) {
+		std::vector<u32> pb, pc; std::vector<size_t> at;
+		for (size_t p = 0; p < pair_key.size(); ++p) {
+			const u32 base = u32(pair_key[p] >> 32), other = u32(pair_key[p]);
+			if (ed_of(p, base, other) > max_ed) continue;
+			pb.push_back(base); pc.push_back(other); at.push_back(p);
+			++nb_count[rank_of[base]];
+		}
+		const std::vector<double> expected = poisson_expected_intersections(pb, pc);
+		if (sorted_keep.p) sorted = sorted_keep.p;
+		pair_prob.assign(pair_key.size(), 2.0);
+		for (size_t i = 0; i < at.size(); ++i) pair_prob[at[i]] = poisson_upper_tail(long(pair_cnt[at[i]]), expected[i]);
+	}
+	for (size_t p = 0; poisson && p < pair_key.size();) {
+		const u32 base = u32(pair_key[p] >> 32);
+		size_t e = p;
+		while (e < pair_key.size() && u32(pair_key[e] >> 32) == base) ++e;
+		const u32 f = rank_of[base];
+		if (nb_count[f]) {
+			// the base is never its own neighbour: PoissonTargetEstimator.cpp:17-22 takes max_real_cb_merge_prob / |neighbours|
+			const double limit = cfg.max_real_merge_prob / double(nb_count[f]);
+			double min_prob = 2; size_t n_min = 0, min_p = p;
+			for (size_t q = p; q < e; ++q) {
+				if (pair_prob[q] < min_prob) { min_prob = pair_prob[q]; n_min = 1; min_p = q; }
+				else if (pair_prob[q] == min_prob && min_prob < 2) ++n_min;
+			}
+			if (min_prob > limit) { /* -1 -> the base itself (:39-42) */ }
+			else if (n_min == 1) target[f] = int64_t(real_at(u32(pair_key[min_p])));
+			else replay.push_back(f);                                        // first of the minima in the map's iteration order
+		}
+		p = e;
+	}
+	for (size_t p = 0; !poisson && p < pair_key.size();) {
 		const u32 base = u32(pair_key[p] >> 32);
 		size_t e = p;
 		while (e < pair_key.size() && u32(pair_key[e] >> 32) == base) ++e;
@@ -326,6 +368,19 @@ void dropest_ctx::run_cb_merge_simple() {
 					if (other == base) continue;
 					if (size_t(real[real_at(u32(other))].row.n_genes) >= base_size) common[other]++;
 				}
+			}
+			if (poisson) {   // neighbours in the map's order; probabilities from the pair table (sorted by (base, other))
+				double min_prob = 2; long best = -1;
+				for (auto const &c : common) {
+					const u64 key = (u64(base) << 32) | u64(c.first);
+					const size_t q = size_t(std::lower_bound(pair_key.begin(), pair_key.end(), key) - pair_key.begin());
+					if (q >= pair_key.size() || pair_key[q] != key) throw DeviceError("internal: replayed neighbour without a pair record");
+					if (pair_prob[q] >= 2) continue;                             // beyond the edit distance
+					if (pair_prob[q] < min_prob) { min_prob = pair_prob[q]; best = long(c.first); }
+				}
+				const double limit = cfg.max_real_merge_prob / double(nb_count[f]);
+				target[f] = (best < 0 || min_prob > limit) ? int64_t(ridx[f]) : int64_t(real_at(u32(best)));
+				continue;
 			}
 			long top = -1, top_genes = -1;
 			double top_frac = -1;

@@ -326,7 +326,7 @@ struct Whitelist {
 
 struct Config {
 	int merge_kind = 0;          // 0 = none (DummyMergeStrategy), 1 = RealBarcodes, 2 = Simple (-m without a whitelist),
-	                             // 3 = PoissonRealBarcodes (-M with a whitelist)
+	                             // 3 = PoissonRealBarcodes (-M with a whitelist), 4 = PoissonSimple (-M without)
 	double max_merge_prob = 1e-4, max_real_merge_prob = 1e-7;   // PreciseMerge.* (MergeStrategyFactory.cpp:52-55)
 	int barcodes_kind = 0;       // Whitelist::Kind
 	std::string barcodes_file;
@@ -531,8 +531,7 @@ struct Container {
 				for (auto const &u : g.second)
 					cell_ids_by_umig[std::make_pair(u.first, g.first)].emplace(cell_id);
 	}
-	long simple_merge_target(size_t base) const {              // get_cells_with_common_umigs + get_merge_target (:16-86)
-		const double EPS = 0.00001;
+	std::unordered_map<size_t, size_t> cells_with_common_umigs(size_t base) const {   // SimpleMergeStrategy.cpp:16-40
 		std::unordered_map<size_t, size_t> common;
 		for (auto const &g : cells[base].genes)
 			for (auto const &u : g.second)
@@ -540,6 +539,11 @@ struct Container {
 					if (other == base) continue;
 					if (cells[other].genes.size() >= cells[base].genes.size()) common[other]++;
 				}
+		return common;
+	}
+	long simple_merge_target(size_t base) const {              // get_merge_target (:47-86)
+		const double EPS = 0.00001;
+		const std::unordered_map<size_t, size_t> common = cells_with_common_umigs(base);
 		long top = -1, top_genes = -1;
 		double top_frac = -1;
 		for (auto const &c : common) {
@@ -621,9 +625,23 @@ struct Container {
 		if (expected_out) *expected_out = expected;
 		return poisson_upper_tail(long(inter), expected);
 	}
+	long poisson_simple_merge_target(size_t base) {               // PoissonSimpleMergeStrategy::get_merge_target (:15-43)
+		std::vector<size_t> nb;
+		for (auto const &c : cells_with_common_umigs(base)) {
+			const unsigned ed = edit_distance(cells[base].barcode.c_str(), cells[c.first].barcode.c_str());
+			if (ed > unsigned(cfg.max_cb_merge_ed)) continue;      // (:27; the plain Simple strategy uses >=)
+			nb.push_back(c.first);
+		}
+		if (nb.empty()) return long(base);
+		const long t = poisson_best_target(base, nb);
+		return t != -1 ? t : long(base);
+	}
 	long poisson_merge_target(size_t base) {                      // get_merge_target (:22-29) + get_best_merge_target (:14-44)
 		std::vector<size_t> nb = real_neighbour_cells(base);
 		if (nb.empty()) return -1;
+		return poisson_best_target(base, nb);
+	}
+	long poisson_best_target(size_t base, const std::vector<size_t> &nb) {   // PoissonTargetEstimator::get_best_merge_target (:14-44)
 		const bool base_real = nb.at(0) == base;
 		double max_prob = (base_real ? cfg.max_merge_prob : cfg.max_real_merge_prob) / double(nb.size());
 		long best = -1;
@@ -645,10 +663,11 @@ struct Container {
 
 		std::unordered_map<size_t, std::unordered_set<size_t>> reassigned_to;
 		std::vector<long> targets(filtered.size());
-		if (cfg.merge_kind == 2) simple_init();
-		if (cfg.merge_kind == 3) poisson_init();
+		if (cfg.merge_kind == 2 || cfg.merge_kind == 4) simple_init();
+		if (cfg.merge_kind == 3 || cfg.merge_kind == 4) poisson_init();
 		for (size_t i = 0; i < filtered.size(); ++i)
-			targets[i] = cfg.merge_kind == 2 ? simple_merge_target(filtered[i])
+			targets[i] = cfg.merge_kind == 4 ? poisson_simple_merge_target(filtered[i])
+			           : cfg.merge_kind == 2 ? simple_merge_target(filtered[i])
 			           : cfg.merge_kind == 3 ? poisson_merge_target(filtered[i]) : real_merge_target(filtered[i]);
 		cell_ids_by_umig.clear();
 

@@ -712,3 +712,24 @@ def test_poisson_probabilities_against_oracle_on_synthetic_pairs():
         assert abs(prob - want_p) <= 1e-9 * want_p + 1e-300, (i, j, prob, want_p)
         checked += 1
     assert checked > 10
+
+
+# ---------------------------------------------------------------------------------------------------
+# -M without a whitelist: PoissonSimpleMergeStrategy
+# ---------------------------------------------------------------------------------------------------
+def _both_poisson_simple(cb, umi, gene, aux, side=(), max_ed=2, p_real=1e-7, min_before=3, min_after=10):
+    o = parity.oracle_run(Oracle, dict(merge_kind=4, max_cb_merge_ed=max_ed, max_real_merge_prob=p_real, min_genes_before=min_before,
+                                       min_genes_after=min_after), cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_POISSON_SIMPLE, max_cb_merge_edit_distance=max_ed, max_real_merge_prob=p_real,
+                            min_genes_before_merge=min_before, min_genes_after_merge=min_after), cb, umi, gene, aux, side)
+    parity.compare(o, c, side)
+    return o, c
+
+
+@pytest.mark.parametrize("max_ed,p_real,umi_len", [(2, 1e-7, 10), (1, 1e-3, 8), (3, 0.5, 8)])
+def test_poisson_simple_merge_synthetic(max_ed, p_real, umi_len):
+    s = SynthStream(n_reads=150_000, whitelist="10x_aug_2016_split", n_cells=30, n_genes=1500, umi_len=umi_len, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    o, c = _both_poisson_simple(cb, umi, gene, aux, max_ed=max_ed, p_real=p_real)
+    mt = c.merge_targets()
+    assert int((mt != np.arange(len(mt))).sum()) > 20

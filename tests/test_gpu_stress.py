@@ -203,6 +203,23 @@ def test_random_directional_umi_merge(seed):
 
 
 @pytest.mark.parametrize("seed", range(10))
+def test_random_poisson_simple_merge(seed):
+    """-M without a whitelist: few genes / many exact probability ties (resolved by the unordered_map order replay),
+    barcodes with N, every edit-distance threshold and loose to strict probability thresholds."""
+    rng = np.random.default_rng(9500 + seed)
+    cb, umi, gene, aux, side = random_stream(
+        rng, n=int(rng.integers(300, 8000)), n_cb=int(rng.integers(2, 40)), n_gene=int(rng.integers(1, 15)),
+        n_umi=int(rng.integers(300, 900)), cb_len=(6, 8) if seed % 3 == 0 else (8, 8), cb_n_rate=0.02 if seed % 2 else 0.0)
+    max_ed, p_real = int(rng.integers(0, 8)), float(rng.choice([1e-7, 1e-3, 0.3, 0.9]))
+    mb = int(rng.integers(0, 3))
+    o = parity.oracle_run(Oracle, dict(merge_kind=4, max_cb_merge_ed=max_ed, max_real_merge_prob=p_real, min_genes_before=mb,
+                                       min_genes_after=mb), cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_POISSON_SIMPLE, max_cb_merge_edit_distance=max_ed, max_real_merge_prob=p_real,
+                            min_genes_before_merge=mb, min_genes_after_merge=mb), cb, umi, gene, aux, side)
+    parity.compare(o, c, side)
+
+
+@pytest.mark.parametrize("seed", range(10))
 def test_random_simple_merge(seed):
     """-m without a whitelist on adversarial streams (few UMIs and genes: many exact ties, barcodes with N, variable
     barcode lengths, every edit-distance threshold)."""
