@@ -10,7 +10,7 @@ from .build import LIB, build
 ESCAPE = 1 << 63
 NO_GENE = 0xFFFFFFFF
 
-MERGE_NONE, MERGE_REAL_BARCODES, MERGE_SIMPLE, MERGE_POISSON_REAL, MERGE_POISSON_SIMPLE = 0, 1, 2, 3, 4
+MERGE_NONE, MERGE_REAL_BARCODES, MERGE_SIMPLE, MERGE_POISSON_REAL, MERGE_POISSON_SIMPLE, MERGE_ALL = 0, 1, 2, 3, 4, 5
 BARCODES_INDROP, BARCODES_CONST = 0, 1
 UMI_MERGE_SIMPLE, UMI_MERGE_DIRECTIONAL = 0, 1
 

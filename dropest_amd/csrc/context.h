@@ -251,6 +251,7 @@ struct dropest_ctx {
 	dropest::DevBuf<u32> cell_real_index;   // [n_cells] cell id -> index in `real` (0xFFFFFFFF otherwise)
 	void run_cb_merge_real();
 	void run_cb_merge_simple();                  // SimpleMergeStrategy (simple_merge.h)
+	void run_cb_merge_all();                     // MergeAllMergeStrategy (merge_all.h)
 	// sharded runs (merge_shard.h): ingest / merge phases with collectives between them
 	struct ShardMerge;
 	std::shared_ptr<ShardMerge> shard;

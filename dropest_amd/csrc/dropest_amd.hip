@@ -66,7 +66,7 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 	min_before = u32(c.min_genes_before_merge);
 	min_after = std::max(u32(c.min_genes_after_merge), min_before);   // MergeStrategyAbstract.cpp:8-11
 	if (c.merge_kind != DROPEST_MERGE_NONE && c.merge_kind != DROPEST_MERGE_REAL_BARCODES && c.merge_kind != DROPEST_MERGE_SIMPLE &&
-	    c.merge_kind != DROPEST_MERGE_POISSON_REAL && c.merge_kind != DROPEST_MERGE_POISSON_SIMPLE)
+	    c.merge_kind != DROPEST_MERGE_POISSON_REAL && c.merge_kind != DROPEST_MERGE_POISSON_SIMPLE && c.merge_kind != DROPEST_MERGE_ALL)
 		throw InvalidError("unknown merge_kind");
 	if (c.umi_merge_kind != DROPEST_UMI_MERGE_SIMPLE && c.umi_merge_kind != DROPEST_UMI_MERGE_DIRECTIONAL)
 		throw InvalidError("unknown umi_merge_kind");
@@ -632,6 +632,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 #include "umi_directional_host.h"
 #include "poisson_merge.h"
 #include "simple_merge.h"
+#include "merge_all.h"
 
 // ------------------------------------------------------------------------------------------------
 // top-level stages
@@ -674,6 +675,7 @@ void dropest_ctx::run_merge_and_filter() {
 	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells && !external_merge_done) run_cb_merge_real();
 	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL && n_cells) run_cb_merge_real();   // same loop, Poisson decisions
 	if ((cfg.merge_kind == DROPEST_MERGE_SIMPLE || cfg.merge_kind == DROPEST_MERGE_POISSON_SIMPLE) && n_cells) run_cb_merge_simple();
+	if (cfg.merge_kind == DROPEST_MERGE_ALL && n_cells) run_cb_merge_all();
 	// MergeUMIsStrategy*::merge, after the CB merge (CellsDataContainer.cpp:45)
 	if (cfg.umi_merge_kind == DROPEST_UMI_MERGE_DIRECTIONAL) run_umi_merge_directional(); else run_umi_merge_simple();
 	request_filtered(min_after, cfg.max_cells);   // CellsDataContainer.cpp:47-49

@@ -143,6 +143,15 @@ public:
 		cfg.merge_kind = DROPEST_MERGE_SIMPLE; cfg.max_cb_merge_edit_distance = int(_max_ed); cfg.min_merge_fraction = _min_fraction;
 	}
 };
+// Estimation/Merge/MergeAllMergeStrategy.h (merge_type = "all")
+class MergeAllMergeStrategy : public MergeStrategyAbstract {
+	unsigned _max_ed;
+public:
+	MergeAllMergeStrategy(size_t min_genes_before_merge, size_t min_genes_after_merge, unsigned max_merge_edit_distance)
+		: MergeStrategyAbstract(min_genes_before_merge, min_genes_after_merge), _max_ed(max_merge_edit_distance) {}
+	std::string merge_type() const override { return "Merge all"; }
+	void fill(dropest_cfg &cfg) const override { cfg.merge_kind = DROPEST_MERGE_ALL; cfg.max_cb_merge_edit_distance = int(_max_ed); cfg.min_merge_fraction = 0; }
+};
 class RealBarcodesMergeStrategy : public MergeStrategyAbstract {
 	std::string _file; int _kind; unsigned _max_ed; double _min_fraction;
 public:

@@ -64,7 +64,8 @@ enum { DROPEST_MERGE_NONE = 0,          /* DummyMergeStrategy.h:12-17 (no -m) */
        DROPEST_MERGE_SIMPLE = 2,        /* SimpleMergeStrategy.cpp (-m without a barcodes file); uses max_cb_merge_edit_distance */
        DROPEST_MERGE_POISSON_REAL = 3,  /* PoissonRealBarcodesMergeStrategy.cpp + PoissonTargetEstimator.cpp (-M + barcodes_file):
                                            floating-point decisions, see DESIGN.md for the agreement bar */
-       DROPEST_MERGE_POISSON_SIMPLE = 4 /* PoissonSimpleMergeStrategy.cpp (-M without a barcodes file) */ };
+       DROPEST_MERGE_POISSON_SIMPLE = 4,/* PoissonSimpleMergeStrategy.cpp (-M without a barcodes file) */
+       DROPEST_MERGE_ALL = 5            /* MergeAllMergeStrategy.h:16-50 (Estimation.Merge.merge_type = "all") */ };
 /* Whitelist file flavour (MergeStrategyFactory.cpp:23-59 barcodes_type) */
 enum { DROPEST_BARCODES_INDROP = 0,     /* InDropBarcodesParser.cpp:15-48 */
        DROPEST_BARCODES_CONST = 1       /* ConstLengthBarcodesParser.cpp:23-68 */ };

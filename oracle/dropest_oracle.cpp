@@ -326,7 +326,7 @@ struct Whitelist {
 
 struct Config {
 	int merge_kind = 0;          // 0 = none (DummyMergeStrategy), 1 = RealBarcodes, 2 = Simple (-m without a whitelist),
-	                             // 3 = PoissonRealBarcodes (-M with a whitelist), 4 = PoissonSimple (-M without)
+	                             // 3 = PoissonRealBarcodes (-M with a whitelist), 4 = PoissonSimple (-M without), 5 = MergeAll (merge_type all)
 	double max_merge_prob = 1e-4, max_real_merge_prob = 1e-7;   // PreciseMerge.* (MergeStrategyFactory.cpp:52-55)
 	int barcodes_kind = 0;       // Whitelist::Kind
 	std::string barcodes_file;
@@ -625,6 +625,19 @@ struct Container {
 		if (expected_out) *expected_out = expected;
 		return poisson_upper_tail(long(inter), expected);
 	}
+	long merge_all_target(size_t base) const {                    // MergeAllMergeStrategy.h:16-50
+		int min_ed = std::numeric_limits<int>::max(), max_umi_num = 0;
+		size_t target = std::numeric_limits<size_t>::max();
+		for (size_t ind : filtered) {
+			const int n_umis = umis_number(cells[ind]);
+			if (n_umis <= umis_number(cells[base])) continue;
+			const int ed = int(edit_distance(cells[base].barcode.c_str(), cells[ind].barcode.c_str(), false, unsigned(cfg.max_cb_merge_ed)));
+			if (ed > cfg.max_cb_merge_ed) continue;
+			if (min_ed > ed) { min_ed = ed; max_umi_num = n_umis; target = ind; }
+			else if ((min_ed == ed) & (max_umi_num < n_umis)) { max_umi_num = n_umis; target = ind; }
+		}
+		return target != std::numeric_limits<size_t>::max() ? long(target) : long(base);
+	}
 	long poisson_simple_merge_target(size_t base) {               // PoissonSimpleMergeStrategy::get_merge_target (:15-43)
 		std::vector<size_t> nb;
 		for (auto const &c : cells_with_common_umigs(base)) {
@@ -666,7 +679,8 @@ struct Container {
 		if (cfg.merge_kind == 2 || cfg.merge_kind == 4) simple_init();
 		if (cfg.merge_kind == 3 || cfg.merge_kind == 4) poisson_init();
 		for (size_t i = 0; i < filtered.size(); ++i)
-			targets[i] = cfg.merge_kind == 4 ? poisson_simple_merge_target(filtered[i])
+			targets[i] = cfg.merge_kind == 5 ? merge_all_target(filtered[i])
+			           : cfg.merge_kind == 4 ? poisson_simple_merge_target(filtered[i])
 			           : cfg.merge_kind == 2 ? simple_merge_target(filtered[i])
 			           : cfg.merge_kind == 3 ? poisson_merge_target(filtered[i]) : real_merge_target(filtered[i]);
 		cell_ids_by_umig.clear();

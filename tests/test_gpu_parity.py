@@ -733,3 +733,18 @@ def test_poisson_simple_merge_synthetic(max_ed, p_real, umi_len):
     o, c = _both_poisson_simple(cb, umi, gene, aux, max_ed=max_ed, p_real=p_real)
     mt = c.merge_targets()
     assert int((mt != np.arange(len(mt))).sum()) > 20
+
+
+# ---------------------------------------------------------------------------------------------------
+# merge_type = "all": MergeAllMergeStrategy
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("max_ed", [1, 2, 4])
+def test_merge_all_synthetic(max_ed):
+    s = SynthStream(n_reads=150_000, whitelist="10x_aug_2016_split", n_cells=30, n_genes=1500, umi_len=10, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    o = parity.oracle_run(Oracle, dict(merge_kind=5, max_cb_merge_ed=max_ed, min_genes_before=3, min_genes_after=10), cb, umi, gene, aux)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_ALL, max_cb_merge_edit_distance=max_ed, min_genes_before_merge=3, min_genes_after_merge=10),
+                       cb, umi, gene, aux)
+    parity.compare(o, c)
+    mt = c.merge_targets()
+    assert int((mt != np.arange(len(mt))).sum()) > 20

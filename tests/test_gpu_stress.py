@@ -203,6 +203,21 @@ def test_random_directional_umi_merge(seed):
 
 
 @pytest.mark.parametrize("seed", range(10))
+def test_random_merge_all(seed):
+    """merge_type = all: chains of merges towards ever larger cells; barcodes of one length go through the device
+    kernel, mixed lengths and barcodes with N through the host's banded edit distance."""
+    rng = np.random.default_rng(9700 + seed)
+    cb, umi, gene, aux, side = random_stream(
+        rng, n=int(rng.integers(300, 8000)), n_cb=int(rng.integers(2, 60)), n_gene=int(rng.integers(1, 15)),
+        n_umi=int(rng.integers(2, 60)), cb_len=(6, 8) if seed % 3 == 0 else (8, 8), cb_n_rate=0.02 if seed % 4 == 1 else 0.0)
+    max_ed, mb = int(rng.integers(0, 9)), int(rng.integers(0, 3))
+    o = parity.oracle_run(Oracle, dict(merge_kind=5, max_cb_merge_ed=max_ed, min_genes_before=mb, min_genes_after=mb), cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_ALL, max_cb_merge_edit_distance=max_ed, min_genes_before_merge=mb, min_genes_after_merge=mb),
+                       cb, umi, gene, aux, side)
+    parity.compare(o, c, side)
+
+
+@pytest.mark.parametrize("seed", range(10))
 def test_random_poisson_simple_merge(seed):
     """-M without a whitelist: few genes / many exact probability ties (resolved by the unordered_map order replay),
     barcodes with N, every edit-distance threshold and loose to strict probability thresholds."""
