@@ -121,6 +121,7 @@ def lib():
         "dropest_count_matrix_device": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
         "dropest_cell_first_reads_device": (C.c_int, [vp, u64p, P(vp)]),
         "dropest_assemble_columns": (C.c_int, [C.c_int, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]),
+        "dropest_assemble_columns_async": (C.c_int, [C.c_int, C.c_int, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]),
         "dropest_real_candidate_rows": (C.c_int, [vp, u64p, vp, vp]),
         "dropest_dev_copy_device": (C.c_int, [C.c_int, vp, vp, C.c_uint64]),
         "dropest_kernel_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
@@ -163,7 +164,7 @@ EXPORTED_SYMBOLS = [
     "dropest_cell_rows", "dropest_cell_id_by_cb", "dropest_filtered_cells", "dropest_merge_targets",
     "dropest_global_counters", "dropest_cell_molecules", "dropest_molecules", "dropest_count_matrix",
     "dropest_count_matrix_csc", "dropest_owner_of", "dropest_partition_by_owner", "dropest_partition_scratch_bytes", "dropest_clear_reads",
-    "dropest_count_matrix_device", "dropest_cell_first_reads_device", "dropest_assemble_columns",
+    "dropest_count_matrix_device", "dropest_cell_first_reads_device", "dropest_assemble_columns", "dropest_assemble_columns_async",
     "dropest_real_candidate_rows", "dropest_dev_copy_device", "dropest_umi_distribution",
     "dropest_collisions_adjusted_sizes", "dropest_poisson_intersection_prob",
     "dropest_set_umi_qualities", "dropest_umi_quality_length", "dropest_cell_molecule_qualities",

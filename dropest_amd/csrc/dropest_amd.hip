@@ -1503,25 +1503,41 @@ dropest_status dropest_cell_first_reads_device(dropest_ctx *ctx, uint64_t *n_cel
 	return guarded([&] { need_init(ctx); *n_cells = ctx->n_cells; *d_first = ctx->cell_first.p; });
 }
 
+static void assemble_columns_launch(int device, int slot, uint64_t n_cols, const uint64_t *src_start, const uint64_t *dst_start,
+                                    const uint64_t *len, const uint32_t *d_src_rows, const uint32_t *d_src_vals,
+                                    uint32_t *d_dst_rows, uint32_t *d_dst_vals) {
+	HIP_CHECK(hipSetDevice(device));
+	if (n_cols == 0) return;
+	// descriptor scratch: two slots per device, kept for the life of the library (this runs once per matrix and step;
+	// a slot must not be reused before the launch that reads it has been waited for)
+	static DevBuf<u64> desc_cache[64][2];
+	static PinnedBuf<u64> desc_host[64][2];
+	if (device < 0 || device >= 64) throw InvalidError("device index out of range");
+	if (slot < 0 || slot > 1) throw InvalidError("descriptor slot must be 0 or 1");
+	DevBuf<u64> &d_desc = desc_cache[device][slot];
+	PinnedBuf<u64> &desc = desc_host[device][slot];
+	d_desc.ensure(n_cols * 3 + n_cols / 2); desc.ensure(n_cols * 3);
+	for (uint64_t c = 0; c < n_cols; ++c) { desc.p[3 * c] = src_start[c]; desc.p[3 * c + 1] = dst_start[c]; desc.p[3 * c + 2] = len[c]; }
+	HIP_CHECK(hipMemcpyAsync(d_desc.p, desc.p, n_cols * 3 * 8, hipMemcpyHostToDevice, nullptr));
+	hipLaunchKernelGGL(assemble_columns_kernel, dim3(u32(n_cols)), dim3(256), 0, nullptr, d_desc.p, d_src_rows, d_src_vals,
+	                   d_dst_rows, d_dst_vals);
+	HIP_CHECK(hipGetLastError());
+}
+
 dropest_status dropest_assemble_columns(int device, uint64_t n_cols, const uint64_t *src_start, const uint64_t *dst_start,
                                         const uint64_t *len, const uint32_t *d_src_rows, const uint32_t *d_src_vals,
                                         uint32_t *d_dst_rows, uint32_t *d_dst_vals) {
 	return guarded([&] {
-		HIP_CHECK(hipSetDevice(device));
-		if (n_cols == 0) return;
-		// descriptor scratch: one buffer per device, kept for the life of the library (this runs once per matrix and step)
-		static DevBuf<u64> desc_cache[64];
-		static PinnedBuf<u64> desc_host[64];
-		if (device < 0 || device >= 64) throw InvalidError("device index out of range");
-		DevBuf<u64> &d_desc = desc_cache[device];
-		PinnedBuf<u64> &desc = desc_host[device];
-		d_desc.ensure(n_cols * 3 + n_cols / 2); desc.ensure(n_cols * 3);
-		for (uint64_t c = 0; c < n_cols; ++c) { desc.p[3 * c] = src_start[c]; desc.p[3 * c + 1] = dst_start[c]; desc.p[3 * c + 2] = len[c]; }
-		HIP_CHECK(hipMemcpyAsync(d_desc.p, desc.p, n_cols * 3 * 8, hipMemcpyHostToDevice, nullptr));
-		hipLaunchKernelGGL(assemble_columns_kernel, dim3(u32(n_cols)), dim3(256), 0, nullptr, d_desc.p, d_src_rows, d_src_vals,
-		                   d_dst_rows, d_dst_vals);
-		HIP_CHECK(hipGetLastError());
+		assemble_columns_launch(device, 0, n_cols, src_start, dst_start, len, d_src_rows, d_src_vals, d_dst_rows, d_dst_vals);
 		HIP_CHECK(hipDeviceSynchronize());
+	});
+}
+
+dropest_status dropest_assemble_columns_async(int device, int slot, uint64_t n_cols, const uint64_t *src_start, const uint64_t *dst_start,
+                                              const uint64_t *len, const uint32_t *d_src_rows, const uint32_t *d_src_vals,
+                                              uint32_t *d_dst_rows, uint32_t *d_dst_vals) {
+	return guarded([&] {
+		assemble_columns_launch(device, slot, n_cols, src_start, dst_start, len, d_src_rows, d_src_vals, d_dst_rows, d_dst_vals);
 	});
 }
 

@@ -191,14 +191,25 @@ class GpuEngine:
     def unregister_shared(self, buf):
         self.L.dropest_host_unregister(self.device, buf["addr"])
 
-    def write_columns(self, src_start, dst_start, length, src_rows, src_vals, buf):
-        """This rank's columns -> their places in the shared host buffer (a kernel writing mapped host memory)."""
-        self.torch.cuda.synchronize(self.dev)
+    deferred_writes = True      # write_columns only queues the copy; wait_writes() completes it
+
+    def write_columns(self, src_start, dst_start, length, src_rows, src_vals, buf, slot=0):
+        """This rank's columns -> their places in the shared host buffer (a kernel writing mapped host memory).  Queued
+        behind the emission kernels on the device; the host goes on preparing the next matrix meanwhile."""
         s = np.ascontiguousarray(src_start, np.uint64); d = np.ascontiguousarray(dst_start, np.uint64)
         ln = np.ascontiguousarray(length, np.uint64)
         ptr = lambda x: x if isinstance(x, int) or x is None else x.data_ptr()      # noqa: E731
-        rc = self.L.dropest_assemble_columns(self.device, len(s), s.ctypes.data, d.ctypes.data, ln.ctypes.data,
-                                             ptr(src_rows), ptr(src_vals), buf["dptr"], buf["dptr"] + buf["cap"] * 4)
+        # the context's kernels run on its own (non-blocking) stream, the copy on the default stream: order them.  This
+        # also waits for the previous matrix's copy -- after the host work it was meant to hide.
+        rc = self.L.dropest_dev_sync(self.device)
+        if rc == 0:
+            rc = self.L.dropest_assemble_columns_async(self.device, slot, len(s), s.ctypes.data, d.ctypes.data, ln.ctypes.data,
+                                                       ptr(src_rows), ptr(src_vals), buf["dptr"], buf["dptr"] + buf["cap"] * 4)
+        if rc != 0:
+            raise capi.DropestError(rc, self.L.dropest_last_error().decode())
+
+    def wait_writes(self):
+        rc = self.L.dropest_dev_sync(self.device)
         if rc != 0:
             raise capi.DropestError(rc, self.L.dropest_last_error().decode())
 
@@ -392,12 +403,17 @@ class ShardedRun:
         t = self._tick("cells_allgather", t)
         # 5. local matrices, gathered on rank 0
         out = {}
+        self._pending_writes = False
         for name, filtered in (("cm", True), ("cm_raw", False)):
             colptr, rows_t, vals_t = e.matrix(filtered, as_tensors=self.output != "shm")
             t = self._tick("emit:" + name, t)
             local_cols = e.filtered_ids().astype(np.int64) if filtered else table[:, 5]
             out[name] = self._gather_matrix(everyone, filtered, colptr, rows_t, vals_t, local_cols)
             t = self._tick("matrix:" + name, t)
+        if self._pending_writes:           # both matrices are on their way to the shared host buffer: wait once, for everybody
+            e.wait_writes()
+            c.barrier()
+            t = self._tick("matrix:wait", t)
         self.merge_pairs = merge_pairs     # (source barcode, target barcode) of every merged cell, ascending source
         return out["cm"], out["cm_raw"], out["cm"][3] if self.rank == 0 else None
 
@@ -579,8 +595,12 @@ class ShardedRun:
                 _, rows_t, vals_t = e.matrix(filtered)       # the gather needs tensors, not the context's own arrays
             else:
                 mine = col_rank == self.rank
-                e.write_columns(src[mine], dst[mine], ln[mine], rows_t, vals_t, buf)
-                c.barrier()
+                if getattr(e, "deferred_writes", False):
+                    e.write_columns(src[mine], dst[mine], ln[mine], rows_t, vals_t, buf, slot)
+                    self._pending_writes = True
+                else:
+                    e.write_columns(src[mine], dst[mine], ln[mine], rows_t, vals_t, buf)
+                    c.barrier()
                 tt = self._tick("gm:write_shared", tt)
                 if self.rank != 0:
                     return None

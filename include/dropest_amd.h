@@ -248,6 +248,12 @@ dropest_status dropest_cell_first_reads_device(dropest_ctx *ctx, uint64_t *n_cel
 dropest_status dropest_assemble_columns(int device, uint64_t n_cols, const uint64_t *src_start, const uint64_t *dst_start,
                                         const uint64_t *len, const uint32_t *d_src_rows, const uint32_t *d_src_vals,
                                         uint32_t *d_dst_rows, uint32_t *d_dst_vals);
+/* Same without waiting: the copy kernel is queued on the device's default stream and the call returns; `slot` (0 or 1)
+ * names the descriptor buffer to use -- a slot may be reused only after dropest_dev_sync.  Lets the host prepare the next
+ * matrix while this one crosses PCIe. */
+dropest_status dropest_assemble_columns_async(int device, int slot, uint64_t n_cols, const uint64_t *src_start,
+                                              const uint64_t *dst_start, const uint64_t *len, const uint32_t *d_src_rows,
+                                              const uint32_t *d_src_vals, uint32_t *d_dst_rows, uint32_t *d_dst_vals);
 
 /* Host memory shared by the ranks of one node (e.g. a /dev/shm mapping): registered once, then each rank's
  * dropest_assemble_columns writes ITS columns of the global matrix straight into it through *d_ptr, so the final
