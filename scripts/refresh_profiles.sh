@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects the round's profile artefacts on the GPU box into gpurun_out/prof (copy what is to be judged into profiles/):
+#   kernel-trace stats of a 5-step bench run, FETCH_SIZE / WRITE_SIZE counters in separate passes (never together with
+#   any other trace domain), the PMC summary + the per-kernel roofline table, and the default bench line.
+# usage (from the repo root on the GPU box): bash scripts/refresh_profiles.sh r01e
+set -u
+TAG=${1:-r01e}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+export PYTHONPATH=$R
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o r -- python $R/bench.py --steps 5 --warmup 2 --cpu-sample 0 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/kt.err
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o r -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2> $OUT/fetch.err
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o r -- python $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2> $OUT/write.err
+cd $R
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
+python scripts/pmc_summary.py $OUT/fetch $OUT/write $OUT $TAG 100000000 > $OUT/pmc_summary.log 2>&1
+cp $OUT/pmc_rs_scatter.json profiles/pmc_rs_scatter.json 2>/dev/null    # so that the bench line below quotes the fresh traffic
+python scripts/roofline_table.py $OUT/${TAG}_pmc_summary.csv > $OUT/${TAG}_roofline_by_kernel.md 2> $OUT/roofline.err
+timeout 600 python bench.py > $OUT/${TAG}_bench_c2.json 2> $OUT/bench.err
+rm -rf $OUT/kt $OUT/fetch $OUT/write
+ls -la $OUT; tail -3 $OUT/pmc_summary.log; tail -c 600 $OUT/${TAG}_bench_c2.json
