@@ -55,29 +55,42 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
                                                              KeyLayout L, unsigned long long *__restrict__ keys,
                                                              void *__restrict__ vals_, GlobalCounters *gc) {
 	unsigned long long c_inter = 0, c_exon = 0, c_intron = 0, c_na = 0, k_or = 0, k_and = ~0ull;
-	const uint32_t stride = gridDim.x * THREADS;
-	for (uint32_t r = blockIdx.x * THREADS + threadIdx.x; r < n; r += stride) {
-		const unsigned long long cell = t.slots[slot[r]].cell_id;
-		const uint32_t g = gene[r];
-		const uint32_t a = aux[r];
-		uint32_t mark = (a >> 16) & 0xFFu;
-		unsigned long long gcode, ucode;
-		if (g == NO_GENE) {
-			gcode = L.gene_none; ++c_inter;
-			ucode = VB == 4 ? 0ull : (unsigned long long)(a & 0xFFFFu);   // chromosome of the gene-less read
-			if (VB != 4) mark = 0;
-		} else {
-			gcode = g;
-			const unsigned long long u = umi[r];
-			ucode = (u & ESCAPE_BIT) ? (L.umi_escape_base + (u & ~ESCAPE_BIT)) : (u & L.umi_strip_mask);
-			c_exon += (mark >> 1) & 1u; c_intron += (mark >> 2) & 1u; c_na += mark & 1u;
+	// four records per thread and iteration: their 16 streaming loads are issued together, then the four dependent
+	// gathers of the cell ids -- the kernel is bound by the latency of that chain, not by bytes
+	constexpr int U = 4;
+	const uint32_t stride = gridDim.x * THREADS * U;
+	for (uint32_t base = blockIdx.x * THREADS * U + threadIdx.x; base < n; base += stride) {
+		uint32_t sl[U], g[U], a[U];
+		unsigned long long u[U], cell[U];
+#pragma unroll
+		for (int q = 0; q < U; ++q) {
+			const uint32_t r = base + q * THREADS;
+			if (r < n) { sl[q] = slot[r]; g[q] = gene[r]; a[q] = aux[r]; u[q] = umi[r]; }
 		}
-		unsigned long long k = (cell << (L.gene_bits + L.umi_bits)) | (gcode << L.umi_bits) | ucode;
-		if (VB == 0) k = (k << 3) | (mark & 7u);
-		keys[r] = k;
-		if (VB == 1) static_cast<uint8_t *>(vals_)[r] = uint8_t(mark);
-		if (VB == 4) static_cast<uint32_t *>(vals_)[r] = a & 0x00FFFFFFu;
-		k_or |= k; k_and &= k;
+#pragma unroll
+		for (int q = 0; q < U; ++q) if (base + q * THREADS < n) cell[q] = t.slots[sl[q]].cell_id;
+#pragma unroll
+		for (int q = 0; q < U; ++q) {
+			const uint32_t r = base + q * THREADS;
+			if (r >= n) continue;
+			uint32_t mark = (a[q] >> 16) & 0xFFu;
+			unsigned long long gcode, ucode;
+			if (g[q] == NO_GENE) {
+				gcode = L.gene_none; ++c_inter;
+				ucode = VB == 4 ? 0ull : (unsigned long long)(a[q] & 0xFFFFu);   // chromosome of the gene-less read
+				if (VB != 4) mark = 0;
+			} else {
+				gcode = g[q];
+				ucode = (u[q] & ESCAPE_BIT) ? (L.umi_escape_base + (u[q] & ~ESCAPE_BIT)) : (u[q] & L.umi_strip_mask);
+				c_exon += (mark >> 1) & 1u; c_intron += (mark >> 2) & 1u; c_na += mark & 1u;
+			}
+			unsigned long long k = (cell[q] << (L.gene_bits + L.umi_bits)) | (gcode << L.umi_bits) | ucode;
+			if (VB == 0) k = (k << 3) | (mark & 7u);
+			keys[r] = k;
+			if (VB == 1) static_cast<uint8_t *>(vals_)[r] = uint8_t(mark);
+			if (VB == 4) static_cast<uint32_t *>(vals_)[r] = a[q] & 0x00FFFFFFu;
+			k_or |= k; k_and &= k;
+		}
 	}
 	c_inter = wave_reduce_add_u64(c_inter); c_exon = wave_reduce_add_u64(c_exon);
 	c_intron = wave_reduce_add_u64(c_intron); c_na = wave_reduce_add_u64(c_na);

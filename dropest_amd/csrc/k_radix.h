@@ -36,16 +36,22 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const unsigned long
 	uint64_t end = begin + uint64_t(tiles_per_block) * tile;
 	if (end > n) end = n;
 	const uint32_t w = wave_id();
-	// four independent coalesced loads in flight per thread
-	uint64_t i = begin + threadIdx.x;
-	for (; i + 3ull * RS_THREADS < end; i += 4ull * RS_THREADS) {
-		const unsigned long long k0 = keys[i], k1 = keys[i + RS_THREADS], k2 = keys[i + 2ull * RS_THREADS], k3 = keys[i + 3ull * RS_THREADS];
-		atomicAdd(&h[w][uint32_t(k0 >> shift) & 0xFFu], 1u);
-		atomicAdd(&h[w][uint32_t(k1 >> shift) & 0xFFu], 1u);
-		atomicAdd(&h[w][uint32_t(k2 >> shift) & 0xFFu], 1u);
-		atomicAdd(&h[w][uint32_t(k3 >> shift) & 0xFFu], 1u);
+	// 16-byte loads (two keys each), four of them in flight per thread; `begin` is a multiple of the tile size, so the
+	// pairs are aligned
+	uint64_t i = begin + 2ull * threadIdx.x;
+	const ulonglong2 *k2 = reinterpret_cast<const ulonglong2 *>(keys);
+	for (; i + 6ull * RS_THREADS + 1 < end; i += 8ull * RS_THREADS) {
+		const ulonglong2 a = k2[i >> 1], b = k2[(i >> 1) + RS_THREADS], c = k2[(i >> 1) + 2ull * RS_THREADS], d = k2[(i >> 1) + 3ull * RS_THREADS];
+		atomicAdd(&h[w][uint32_t(a.x >> shift) & 0xFFu], 1u); atomicAdd(&h[w][uint32_t(a.y >> shift) & 0xFFu], 1u);
+		atomicAdd(&h[w][uint32_t(b.x >> shift) & 0xFFu], 1u); atomicAdd(&h[w][uint32_t(b.y >> shift) & 0xFFu], 1u);
+		atomicAdd(&h[w][uint32_t(c.x >> shift) & 0xFFu], 1u); atomicAdd(&h[w][uint32_t(c.y >> shift) & 0xFFu], 1u);
+		atomicAdd(&h[w][uint32_t(d.x >> shift) & 0xFFu], 1u); atomicAdd(&h[w][uint32_t(d.y >> shift) & 0xFFu], 1u);
 	}
-	for (; i < end; i += RS_THREADS) atomicAdd(&h[w][uint32_t(keys[i] >> shift) & 0xFFu], 1u);
+	for (; i + 1 < end; i += 2ull * RS_THREADS) {
+		const ulonglong2 a = k2[i >> 1];
+		atomicAdd(&h[w][uint32_t(a.x >> shift) & 0xFFu], 1u); atomicAdd(&h[w][uint32_t(a.y >> shift) & 0xFFu], 1u);
+	}
+	if (i < end) atomicAdd(&h[w][uint32_t(keys[i] >> shift) & 0xFFu], 1u);   // odd tail (end == n)
 	__syncthreads();
 	if (threadIdx.x < RS_RADIX) {
 		uint32_t s = 0;
