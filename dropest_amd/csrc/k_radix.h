@@ -36,17 +36,27 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const unsigned long
 	uint64_t end = begin + uint64_t(tiles_per_block) * tile;
 	if (end > n) end = n;
 	const uint32_t w = wave_id();
+	// Digits are often heavily skewed (the high bits of the cell id: most reads belong to a few thousand cells): 64 lanes
+	// adding to ONE LDS address serialise.  The lanes that share the first lane's digit are counted with a ballot and
+	// added once; the others add individually.  (Measured: 1.85 -> 1.46 ms per C2 step; peeling a second digit
+	// changes nothing, matching all groups with 8 ballots per key as the scatter does is slower, 1.8 ms.)
+	const unsigned long long lt_mask = (1ull << lane_id()) - 1ull;
+	auto add = [&](unsigned long long k) {
+		const uint32_t d = uint32_t(k >> shift) & 0xFFu;
+		const uint32_t lead = __builtin_amdgcn_readfirstlane(d);
+		const unsigned long long same = __ballot(d == lead);
+		if (d != lead) atomicAdd(&h[w][d], 1u);
+		else if ((same & lt_mask) == 0) atomicAdd(&h[w][lead], uint32_t(__popcll(same)));
+	};
 	// 16-byte loads (two keys each), four of them in flight per thread; `begin` is a multiple of the tile size, so the
 	// pairs are aligned
 	uint64_t i = begin + 2ull * threadIdx.x;
 	const ulonglong2 *k2 = reinterpret_cast<const ulonglong2 *>(keys);
 	for (; i + 6ull * RS_THREADS + 1 < end; i += 8ull * RS_THREADS) {
 		const ulonglong2 a = k2[i >> 1], b = k2[(i >> 1) + RS_THREADS], c = k2[(i >> 1) + 2ull * RS_THREADS], d = k2[(i >> 1) + 3ull * RS_THREADS];
-		atomicAdd(&h[w][uint32_t(a.x >> shift) & 0xFFu], 1u); atomicAdd(&h[w][uint32_t(a.y >> shift) & 0xFFu], 1u);
-		atomicAdd(&h[w][uint32_t(b.x >> shift) & 0xFFu], 1u); atomicAdd(&h[w][uint32_t(b.y >> shift) & 0xFFu], 1u);
-		atomicAdd(&h[w][uint32_t(c.x >> shift) & 0xFFu], 1u); atomicAdd(&h[w][uint32_t(c.y >> shift) & 0xFFu], 1u);
-		atomicAdd(&h[w][uint32_t(d.x >> shift) & 0xFFu], 1u); atomicAdd(&h[w][uint32_t(d.y >> shift) & 0xFFu], 1u);
+		add(a.x); add(a.y); add(b.x); add(b.y); add(c.x); add(c.y); add(d.x); add(d.y);
 	}
+	// (the tails are wave-divergent: plain atomics)
 	for (; i + 1 < end; i += 2ull * RS_THREADS) {
 		const ulonglong2 a = k2[i >> 1];
 		atomicAdd(&h[w][uint32_t(a.x >> shift) & 0xFFu], 1u); atomicAdd(&h[w][uint32_t(a.y >> shift) & 0xFFu], 1u);
