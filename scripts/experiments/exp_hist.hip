@@ -1,3 +1,5 @@
+// Experiment behind the rs_hist notes in DESIGN.md: the histogram pass with block ranges vs interleaved tiles, with and
+// without LDS atomics, over uniform random keys.  hipcc --offload-arch=gfx950 -O3 exp_hist.hip -o exp_hist
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
