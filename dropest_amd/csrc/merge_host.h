@@ -446,8 +446,11 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 		RekeyedToMoleculesX p{};
 		p.keys = keys; p.idx = vals; p.old_reads = mol_reads.p; p.old_mark = mol_mark.p; p.old_exon = mol_exon.p; p.old_intron = mol_intron.p;
 		new_n = run_segmented_reduce(*this, "molecules_rekeyed", p, n_mol, 12 + 16, [&](u32 total) {
-			mol_key2.ensure(total + 1);
-			for (DevBuf<u32> *b : {&mol_reads2, &mol_mark2, &mol_exon2, &mol_intron2}) { b->ensure(total + 1); zero_async(*this, b->p, size_t(total + 1) * 4); }
+			// the tables are swapped with their twins below: give the twins the same capacity, or the next pass's first
+			// reduce finds a smaller buffer and pays a hipFree + hipMalloc of gigabytes (measured: +300 ms at 1e9 reads)
+			const size_t cap = std::max<size_t>(size_t(total) + 1, mol_key.n);
+			mol_key2.ensure(cap);
+			for (DevBuf<u32> *b : {&mol_reads2, &mol_mark2, &mol_exon2, &mol_intron2}) { b->ensure(cap); zero_async(*this, b->p, size_t(total + 1) * 4); }
 			p.mol_key = mol_key2.p; p.out[0] = mol_reads2.p; p.out[1] = mol_mark2.p; p.out[2] = mol_exon2.p; p.out[3] = mol_intron2.p;
 		});
 		HIP_CHECK(hipStreamSynchronize(stream));
@@ -456,7 +459,8 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 		RekeyedToMolecules p{};
 		p.keys = keys; p.idx = vals; p.old_reads = mol_reads.p; p.old_mark = mol_mark.p;
 		new_n = run_segmented_reduce(*this, "molecules_rekeyed", p, n_mol, 12 + 8, [&](u32 total) {
-			mol_key2.ensure(total + 1); mol_reads2.ensure(total + 1); mol_mark2.ensure(total + 1);
+			const size_t cap = std::max<size_t>(size_t(total) + 1, mol_key.n);
+			mol_key2.ensure(cap); mol_reads2.ensure(cap); mol_mark2.ensure(cap);
 			zero_async(*this, mol_reads2.p, size_t(total + 1) * 4); zero_async(*this, mol_mark2.p, size_t(total + 1) * 4);
 			p.mol_key = mol_key2.p; p.out[0] = mol_reads2.p; p.out[1] = mol_mark2.p;
 		});

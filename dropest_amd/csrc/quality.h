@@ -118,7 +118,7 @@ void dropest_ctx::requality_after_fold(const u64 *sorted_key, const u32 *old_row
 	if (!have_qual || !qual_len || !n_new) return;
 	DevBuf<u64> best; best.alloc(n_new);
 	HIP_CHECK(hipMemsetAsync(best.p, 0xFF, size_t(n_new) * 8, stream));
-	mol_qrow2.ensure(n_new);
+	mol_qrow2.ensure(std::max<size_t>(n_new, mol_qrow.n));
 	hipLaunchKernelGGL(member_best_kernel, dim3(div_up(n_old, 256)), dim3(256), 0, stream, sorted_key, old_row, n_old, new_key, n_new,
 	                   reagg_prio, best.p);
 	hipLaunchKernelGGL(take_best_qrow_kernel, dim3(div_up(n_new, 256)), dim3(256), 0, stream, best.p, n_new, mol_qrow.p, mol_qrow2.p);
