@@ -9,7 +9,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libdropest_amd.so")
 SOURCES = ["dropest_amd.hip", "synth_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-pthread"]
 
 
 def _hipcc():

@@ -176,6 +176,8 @@ struct dropest_ctx {
 	std::vector<dropest::HostCell> real;                 // ascending cell id
 	std::vector<uint64_t> filtered;                      // cell ids, ascending compare_cells order (built lazily)
 	std::vector<u32> filtered_ridx;                      // index in `real` of each filtered cell
+	dropest::PinnedBuf<u64> sort_stage;                  // staging of sort_filtered's key columns / permutation
+	dropest::DevBuf<u64> sort_cols;
 	bool filtered_valid = false;
 	u32 filtered_threshold = 0;
 	int filtered_max_cells = -1;

@@ -559,6 +559,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 	// CellsDataContainer.cpp:250-276 with compare_cells :329-344, on compact keys
 	struct Key { u64 sizes; u64 umis; u64 code; u32 idx; };
 	std::vector<Key> keys;
+	keys.reserve(real.size());
 	for (u32 i = 0; i < real.size(); ++i) {
 		const HostCell &h = real[i];
 		if (h.merged || h.excluded || h.row.n_genes < min_before) continue;
@@ -588,33 +589,40 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 	}
 	if (device_sort) {
 		const u32 m = u32(keys.size());
-		std::vector<u64> col(m);
-		std::vector<u32> perm(m);
-		DevBuf<u64> d_code, d_umis, d_sizes;
-		d_code.alloc(m); d_umis.alloc(m); d_sizes.alloc(m);
+		// the three key columns go up through one pinned staging buffer (a pageable hipMemcpy runs at a tenth of the PCIe rate)
+		sort_stage.ensure(size_t(m) * 3);
+		sort_cols.ensure(size_t(m) * 3);
 		keys_a.ensure(m); keys_b.ensure(m); vals_a.ensure(m); vals_b.ensure(m);
-		auto upload = [&](DevBuf<u64> &dst, u64 Key::*field) {   // returns the mask of bits that vary (constant digits are skipped)
-			u64 o = 0, a = ~0ull;
-			for (u32 i = 0; i < m; ++i) { col[i] = keys[i].*field; o |= col[i]; a &= col[i]; }
-			HIP_CHECK(hipMemcpy(dst.p, col.data(), size_t(m) * 8, hipMemcpyHostToDevice));
-			return o ^ a;
-		};
-		const u64 mask_code = upload(d_code, &Key::code), mask_umis = upload(d_umis, &Key::umis), mask_sizes = upload(d_sizes, &Key::sizes);
+		u64 *h_code = sort_stage.p, *h_umis = sort_stage.p + m, *h_sizes = sort_stage.p + 2 * size_t(m);
+		u64 o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull};
+		for (u32 i = 0; i < m; ++i) {
+			const Key &k = keys[i];
+			h_code[i] = k.code; h_umis[i] = k.umis; h_sizes[i] = k.sizes;
+			o[0] |= k.code; a[0] &= k.code; o[1] |= k.umis; a[1] &= k.umis; o[2] |= k.sizes; a[2] &= k.sizes;
+		}
+		HIP_CHECK(hipMemcpyAsync(sort_cols.p, sort_stage.p, size_t(m) * 3 * 8, hipMemcpyHostToDevice, stream));
+		const u64 *d_code = sort_cols.p, *d_umis = sort_cols.p + m, *d_sizes = sort_cols.p + 2 * size_t(m);
 		u64 *k = keys_a.p, *k_alt = keys_b.p;
 		u32 *v = vals_a.p, *v_alt = vals_b.p;
 		hipLaunchKernelGGL(iota_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, v, m);
-		HIP_CHECK(hipMemcpyAsync(k, d_code.p, size_t(m) * 8, hipMemcpyDeviceToDevice, stream));
-		radix_sort(k, v, k_alt, v_alt, m, mask_code);
-		const std::pair<DevBuf<u64> *, u64> more[2] = {{&d_umis, mask_umis}, {&d_sizes, mask_sizes}};
+		HIP_CHECK(hipMemcpyAsync(k, d_code, size_t(m) * 8, hipMemcpyDeviceToDevice, stream));
+		radix_sort(k, v, k_alt, v_alt, m, o[0] ^ a[0]);                 // bits that vary: constant digits are skipped
+		const std::pair<const u64 *, u64> more[2] = {{d_umis, o[1] ^ a[1]}, {d_sizes, o[2] ^ a[2]}};
 		for (auto const &nx : more) {
-			hipLaunchKernelGGL(gather_u64_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, nx.first->p, v, m, k);
+			hipLaunchKernelGGL(gather_u64_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, nx.first, v, m, k);
 			HIP_CHECK(hipGetLastError());
 			radix_sort(k, v, k_alt, v_alt, m, nx.second);
 		}
-		fetch(perm.data(), v, size_t(m) * 4);
-		std::vector<Key> sorted(m);
-		for (u32 i = 0; i < m; ++i) sorted[i] = keys[perm[i]];
-		keys.swap(sorted);
+		u32 *perm = reinterpret_cast<u32 *>(sort_stage.p);              // the staging buffer is free again (stream order)
+		HIP_CHECK(hipMemcpyAsync(perm, v, size_t(m) * 4, hipMemcpyDeviceToHost, stream));
+		HIP_CHECK(hipStreamSynchronize(stream));
+		filtered.clear(); filtered_ridx.clear();
+		size_t start = 0;
+		if (max_cells > 0 && size_t(max_cells) < size_t(m)) start = size_t(m) - size_t(max_cells);
+		filtered.reserve(m - start); filtered_ridx.reserve(m - start);
+		for (size_t i = start; i < m; ++i) { const u32 idx = keys[perm[i]].idx; filtered.push_back(real[idx].id); filtered_ridx.push_back(idx); }
+		filtered_valid = true;
+		return;
 	} else {
 		std::sort(keys.begin(), keys.end(), less);
 	}

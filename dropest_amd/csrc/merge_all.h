@@ -125,8 +125,10 @@ void dropest_ctx::run_cb_merge_all() {
 	std::vector<u32> cur(nR), rank(nR);
 	std::vector<uint8_t> excl(nR);
 	const bool any_merge = apply_merge_order(nR, F, ridx.data(), target.data(), reads.data(), tu.data(), cur.data(), excl.data(), rank.data());
-	merge_rank.assign(n_cells, 0);
-	for (u32 i = 0; i < nR; ++i) merge_rank[real[i].id] = rank[i];
+	if (have_qual) {   // only the quality sums need the merge order (quality.h)
+		merge_rank.assign(n_cells, 0);
+		for (u32 i = 0; i < nR; ++i) merge_rank[real[i].id] = rank[i];
+	}
 	for (u32 i = 0; i < nR; ++i) {
 		real[i].row.total_reads = reads[i]; real[i].row.total_umis = tu[i];
 		if (cur[i] != i) { real[i].merged = true; merge_pairs.emplace_back(real[i].id, real[cur[i]].id); }

@@ -6,6 +6,7 @@
 //          (reassign, :64-82), Stats::merge bookkeeping (Stats.cpp:29-43)
 //   then the molecule table is re-keyed and re-reduced on the device (= the unions done by Gene::merge).
 #pragma once
+#include <thread>
 
 namespace {
 
@@ -93,6 +94,7 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 	S.cells = cells;
 
 	// 1. barcodes split into the two parts (device; escaped barcodes patched by the host)
+	auto st_bases = std::make_unique<HostStage>(this, "cb_merge:targets:bases");
 	DevBuf<u32> d_cells; d_cells.alloc(F);
 	S.d_bases.alloc(F);
 	scalars.ensure(16);
@@ -123,6 +125,8 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 	}
 
 	// 2. neighbour search; candidates land in flat lists
+	st_bases.reset();
+	auto st_search = std::make_unique<HostStage>(this, "cb_merge:targets:search");
 	DevBuf<u32> d_cnt, d_lvl, d_off, d_fcell, d_fumis, d_fridx;
 	u32 flat_cap = std::max<u32>(F * 2u, 1024u);
 	S.cnt.resize(F); S.off.resize(F);
@@ -159,6 +163,8 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 	}
 
 	// 3. pairs (base, candidate) whose UMI-gene intersection is needed
+	st_search.reset();
+	HostStage st_pairs(this, "cb_merge:targets:pairs");
 	S.pair_base.clear(); S.pair_cand.clear(); S.pair_umis.clear(); S.pair_ridx.clear();
 	S.pair_first.assign(size_t(F) + 1, 0); S.self_ridx.assign(F, 0xFFFFFFFFu);
 	S.pair_base.reserve(F); S.pair_cand.reserve(F); S.pair_umis.reserve(F); S.pair_ridx.reserve(F);
@@ -224,21 +230,37 @@ void dropest_ctx::decide_merge_targets(const MergeUniverse &U, MergeSearch &S, c
 	auto frac_of = [&](u32 f, u32 p) {
 		return 0.5 * inter[p] * (1. / size_t(U.base_total_umis(f)) + 1. / size_t(int32_t(S.pair_umis[p])));
 	};
-	for (u32 f = 0; f < F; ++f) {
-		if (S.cnt[f] == 0) { targets[f] = -1; continue; }
-		const u32 p0 = S.pair_first[f], p1 = S.pair_first[f + 1];
-		if (p0 == p1) { targets[f] = long(S.cells[f]); target_ridx[f] = S.self_ridx[f]; continue; }   // self
-		double best = 0; u32 n_best = 0, best_p = 0;
-		for (u32 p = p0; p < p1; ++p) {
-			const double fr = frac_of(f, p);
-			if (fr > best) { best = fr; n_best = 1; best_p = p; }
-			else if (fr == best) ++n_best;
+	// independent per base: a few worker threads over contiguous ranges (2.5 M bases at C3 size, each a cache-missing
+	// look-up of its row); the bases that need the replay are collected per range and concatenated in order
+	auto decide_range = [&](u32 f0, u32 f1, std::vector<u32> &ties) {
+		for (u32 f = f0; f < f1; ++f) {
+			if (S.cnt[f] == 0) { targets[f] = -1; continue; }
+			const u32 p0 = S.pair_first[f], p1 = S.pair_first[f + 1];
+			if (p0 == p1) { targets[f] = long(S.cells[f]); target_ridx[f] = S.self_ridx[f]; continue; }   // self
+			double best = 0; u32 n_best = 0, best_p = 0;
+			for (u32 p = p0; p < p1; ++p) {
+				const double fr = frac_of(f, p);
+				if (fr > best) { best = fr; n_best = 1; best_p = p; }
+				else if (fr == best) ++n_best;
+			}
+			if (best < cfg.min_merge_fraction) { targets[f] = -1; continue; }   // holds for any order
+			if (best > 0 && n_best == 1) { targets[f] = long(S.pair_cand[best_p]); target_ridx[f] = S.pair_ridx[best_p]; continue; }
+			ties.push_back(f);   // tie at the maximum (or all fractions zero with a non-positive threshold)
 		}
-		if (best < cfg.min_merge_fraction) { targets[f] = -1; continue; }   // holds for any order
-		if (best > 0 && n_best == 1) { targets[f] = long(S.pair_cand[best_p]); target_ridx[f] = S.pair_ridx[best_p]; continue; }
-		need_order.push_back(f);   // tie at the maximum (or all fractions zero with a non-positive threshold)
+	};
+	const unsigned n_workers = F >= 200000 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+	if (n_workers == 1) decide_range(0, F, need_order);
+	else {
+		std::vector<std::vector<u32>> ties(n_workers);
+		std::vector<std::thread> pool;
+		for (unsigned w = 0; w < n_workers; ++w)
+			pool.emplace_back(decide_range, u32(uint64_t(F) * w / n_workers), u32(uint64_t(F) * (w + 1) / n_workers), std::ref(ties[w]));
+		for (auto &t : pool) t.join();
+		for (auto &t : ties) need_order.insert(need_order.end(), t.begin(), t.end());
 	}
 	if (need_order.empty()) return;
+	HostStage st_replay(this, "cb_merge:targets:replay");
+	if (profiling) stats["count:merge_ties_replayed"].launches += need_order.size();
 	const std::vector<std::vector<u32>> orders = replay_candidate_orders(U, S, need_order);
 	for (u32 r = 0; r < u32(need_order.size()); ++r) {
 		const u32 f = need_order[r];
@@ -297,6 +319,7 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipStreamSynchronize(stream));
 	}
+	HostStage st_universe(this, "cb_merge:targets:universe");
 	MergeUniverse U;
 	U.table = table; U.cell_cb = cell_cb.p; U.n_genes = cell_n_genes.p; U.total_umis = cell_total_umis.p;
 	U.real_index = cell_real_index.p; U.any_escaped = ingest.cb_escape_count != 0;
@@ -309,7 +332,9 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 	const u32 NP = u32(S.pair_base.size());
 	std::vector<u32> pb(NP);
 	for (u32 p = 0; p < NP; ++p) pb[p] = cells[S.pair_base[p]];
-	const std::vector<u32> inter = pair_intersections(pb, S.pair_cand);
+	std::vector<u32> inter;
+	{ HostStage st(this, "cb_merge:targets:intersect"); inter = pair_intersections(pb, S.pair_cand); }
+	HostStage st_decide(this, "cb_merge:targets:decide");
 	std::vector<u32> tr;
 	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL) {
 		const std::vector<double> expected = poisson_expected_intersections(pb, S.pair_cand);
@@ -379,8 +404,10 @@ void dropest_ctx::run_cb_merge_real() {
 	std::vector<uint8_t> excl(nR);
 	std::vector<u32> rank(nR);
 	const bool any_merge = apply_merge_order(nR, cells.size(), ridx.data(), tgt.data(), reads.data(), umis.data(), cur.data(), excl.data(), rank.data());
-	merge_rank.assign(n_cells, 0);
-	for (u32 i = 0; i < nR; ++i) merge_rank[real[i].id] = rank[i];
+	if (have_qual) {   // only the quality sums need the merge order (quality.h)
+		merge_rank.assign(n_cells, 0);
+		for (u32 i = 0; i < nR; ++i) merge_rank[real[i].id] = rank[i];
+	}
 	reassign.clear();
 	merge_pairs.clear();
 	for (u32 i = 0; i < nR; ++i) {
