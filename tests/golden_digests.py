@@ -34,7 +34,21 @@ CASES = {
                    dict(merge="simple", max_ed=2, min_before=3, min_after=10)),
     "directional_1e5": (dict(n_reads=100_000, n_cells=30, n_genes=300, umi_len=5, stream_id=6), 0.0,
                         dict(merge="none", umi="directional", min_before=5, min_after=5)),
+    # -M (PoissonTargetEstimator): with the 10x whitelist and without; merge_type = all; UMI quality sums through a merge
+    "poisson_real_2e5": (dict(n_reads=200_000, n_cells=30, n_genes=2000, umi_len=12, permille_neighbour=150, stream_id=7), 0.0,
+                         dict(merge="poisson_real", whitelist="10x_aug_2016_split", min_before=3, min_after=20)),
+    "poisson_simple_1e5": (dict(n_reads=100_000, n_cells=25, n_genes=1000, umi_len=8, permille_neighbour=150, stream_id=8), 0.0,
+                           dict(merge="poisson_simple", max_ed=2, min_before=3, min_after=10)),
+    "merge_all_1e5": (dict(n_reads=100_000, n_cells=25, n_genes=1000, umi_len=8, permille_neighbour=150, stream_id=9), 0.0,
+                      dict(merge="all", max_ed=2, min_before=3, min_after=10)),
+    "quality_1e5_merge": (dict(n_reads=100_000, n_cells=25, n_genes=60, umi_len=6, permille_neighbour=200, stream_id=10), 1e-3,
+                          dict(merge="real", whitelist="10x_aug_2016_split", min_before=3, min_after=10, quality=6)),
 }
+
+
+def qualities(n, qlen):
+    """The (seeded) UMI qualities of the cases that carry them: uint8 [n, qlen], phred+33 characters."""
+    return np.random.default_rng(4242).integers(33, 75, size=(n, qlen), dtype=np.uint8)
 
 
 def stream(case):
@@ -63,13 +77,16 @@ def digests(view):
     return out
 
 
-def canonical(barcodes, rows8, filtered, merge_targets, counters, cm, cm_raw, chr_rows, molecules):
+def canonical(barcodes, rows8, filtered, merge_targets, counters, cm, cm_raw, chr_rows, molecules, quality=None):
     """Everything as fixed-width numpy data.  rows8 = [merged, excluded, real, n_genes, req_genes, req_umis, total_reads,
     total_umis] per cell (sizes of merged source cells zeroed: the reference keeps stale values nobody reads)."""
     rows8 = np.array(rows8, np.int64)
     rows8[rows8[:, 0] != 0, 3:6] = 0
     mol = sorted(molecules)
-    return {
+    extra = {}
+    if quality is not None:   # {(cell, gene, umi): sums} -> rows in the molecule table's order
+        extra["quality"] = np.array([quality[(m[0], m[1], m[2])] for m in mol], np.int64)
+    return {**extra,
         "cells": np.array([b.encode() for b in barcodes], "S40"), "rows": rows8,
         "filtered": np.array(filtered, np.int64), "merge_targets": np.array(merge_targets, np.int64),
         "counters": np.array(counters, np.int64),
@@ -90,16 +107,32 @@ def oracle_view(case):
         kw.update(merge_kind=1, barcodes_kind=1, barcodes_file=os.path.join(DATA, cfg["whitelist"]))
     elif cfg["merge"] == "simple":
         kw.update(merge_kind=2, max_cb_merge_ed=cfg["max_ed"])
+    elif cfg["merge"] == "poisson_real":
+        kw.update(merge_kind=3, barcodes_kind=1, barcodes_file=os.path.join(DATA, cfg["whitelist"]))
+    elif cfg["merge"] == "poisson_simple":
+        kw.update(merge_kind=4, max_cb_merge_ed=cfg["max_ed"])
+    elif cfg["merge"] == "all":
+        kw.update(merge_kind=5, max_cb_merge_ed=cfg["max_ed"])
     if cfg.get("umi") == "directional":
         kw.update(umi_merge_kind=1)
         ctypes.CDLL("libc.so.6").srand(1)
-    o = parity.oracle_run(Oracle, kw, cb, umi, gene, aux, side)
+    qlen = cfg.get("quality")
+    if qlen:
+        o = Oracle(**kw)
+        o.add_packed_q(cb, umi, gene, aux, qualities(len(cb), qlen), side)
+        o.set_initialized(); o.merge_and_filter()
+    else:
+        o = parity.oracle_run(Oracle, kw, cb, umi, gene, aux, side)
     rows = o.cell_rows()
     oc, og, ou, orr, om = o.molecules()
     keep = rows[oc.astype(np.int64), 0] == 0
     mols = [(int(c), int(g), u, int(r), int(m)) for c, g, u, r, m, k in zip(oc, og, ou, orr, om, keep) if k]
+    quality = None
+    if qlen:
+        oq = o.molecule_qualities(len(oc), qlen)
+        quality = {(int(c), int(g), u): [int(x) for x in q] for c, g, u, q, k in zip(oc, og, ou, oq, keep) if k}
     return canonical([o.cell_barcode(i) for i in range(o.n_cells)], rows, o.filtered_cells(), o.merge_targets(), o.global_counters(),
-                     o.count_matrix(filtered=True), o.count_matrix(filtered=False), o.chr_stats(), mols)
+                     o.count_matrix(filtered=True), o.count_matrix(filtered=False), o.chr_stats(), mols, quality)
 
 
 if __name__ == "__main__":

@@ -26,17 +26,40 @@ def hip_view(case):
         kw.update(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST, barcodes_file=os.path.join(gd.DATA, cfg["whitelist"]))
     elif cfg["merge"] == "simple":
         kw.update(merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=cfg["max_ed"])
+    elif cfg["merge"] == "poisson_real":
+        kw.update(merge_kind=capi.MERGE_POISSON_REAL, barcodes_kind=capi.BARCODES_CONST, barcodes_file=os.path.join(gd.DATA, cfg["whitelist"]))
+    elif cfg["merge"] == "poisson_simple":
+        kw.update(merge_kind=capi.MERGE_POISSON_SIMPLE, max_cb_merge_edit_distance=cfg["max_ed"])
+    elif cfg["merge"] == "all":
+        kw.update(merge_kind=capi.MERGE_ALL, max_cb_merge_edit_distance=cfg["max_ed"])
     if cfg.get("umi") == "directional":
         kw.update(umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL)
         ctypes.CDLL("libc.so.6").srand(1)
-    c = parity.gpu_run(kw, cb, umi, gene, aux, side, chunks=2)
+    qlen = cfg.get("quality")
+    if qlen:
+        c = capi.Context(**kw)
+        if side:
+            c.set_side_strings(side)
+        c.push_reads(cb, umi, gene, aux)
+        c.set_umi_qualities(gd.qualities(len(cb), qlen))
+        c.set_initialized(); c.merge_and_filter()
+    else:
+        c = parity.gpu_run(kw, cb, umi, gene, aux, side, chunks=2)
     rows = c.cell_rows()
     rows8 = np.stack([rows[k].astype(np.int64) for k in ("is_merged", "is_excluded", "is_real", "n_genes", "requested_genes",
                                                          "requested_umis", "total_reads", "total_umis")], axis=1)
     mc, mg, mu, mr, mm = c.molecules()
     mols = [(int(a), int(b), capi.unpack_code(u, side), int(r), int(m)) for a, b, u, r, m in zip(mc, mg, mu, mr, mm)]
+    quality = None
+    if qlen:
+        quality = {}
+        for cell in sorted({m[0] for m in mols}):
+            g, u, r, m = c.cell_molecules(cell)
+            q = c.cell_molecule_qualities(cell, len(g))
+            for j in range(len(g)):
+                quality[(cell, int(g[j]), capi.unpack_code(u[j], side))] = [int(x) for x in q[j]]
     return gd.canonical([capi.unpack_code(x, side) for x in rows["barcode"]], rows8, c.filtered_cells(), c.merge_targets(),
-                        c.global_counters(), c.count_matrix(filtered=True), c.count_matrix(filtered=False), c.chr_stats(), mols)
+                        c.global_counters(), c.count_matrix(filtered=True), c.count_matrix(filtered=False), c.chr_stats(), mols, quality)
 
 
 @pytest.mark.gpu
