@@ -497,8 +497,9 @@ class ShardedRun:
     def _global_columns(self, everyone, metas, filtered):
         """Global column order of a matrix (identical on every rank): returns the kept cells' rows, and per column its
         owner rank, its start inside that rank's local arrays and its length."""
-        cells = np.concatenate([np.concatenate([np.full((len(t), 1), r, np.int64), t], axis=1) for r, t in enumerate(everyone)])
-        # columns: [rank, req_genes, req_umis, total_umis, barcode, first_global, local_id, n_genes]
+        # columns: [rank, req_genes, req_umis, total_umis, barcode, first_global, local_id, n_genes, row within the rank's table]
+        cells = np.concatenate([np.concatenate([np.full((len(t), 1), r, np.int64), t, np.arange(len(t), dtype=np.int64)[:, None]], axis=1)
+                                for r, t in enumerate(everyone)])
         if filtered:
             keep = cells[cells[:, 1] >= self.cfg["min_after"]]
             order = order_cells(keep[:, 1:5])
@@ -506,19 +507,19 @@ class ShardedRun:
             keep = cells
             order = np.argsort(keep[:, 5], kind="stable")       # cell-id order == first-seen order
         keep = keep[order]
-        keys, starts, lens_all = [], [], []
-        for r, m in enumerate(metas):
-            if len(m):
-                keys.append((np.int64(r) << 40) | m[:, 0])
-                starts.append(np.concatenate([[0], np.cumsum(m[:, 1])[:-1]]))
-                lens_all.append(m[:, 1])
-        if keys and len(keep):
-            keys = np.concatenate(keys); starts = np.concatenate(starts); lens_all = np.concatenate(lens_all)
-            o = np.argsort(keys, kind="stable")
-            pos = np.searchsorted(keys[o], (keep[:, 0] << 40) | keep[:, 6])
-            src, ln = starts[o][pos], lens_all[o][pos]
+        if not len(keep) or not any(len(m) for m in metas):
+            return keep, keep[:, 0], np.zeros(0, np.int64), np.zeros(0, np.int64)
+        starts = [np.concatenate([[0], np.cumsum(m[:, 1])[:-1]]) if len(m) else np.zeros(0, np.int64) for m in metas]
+        base = np.concatenate([[0], np.cumsum([len(m) for m in metas])]).astype(np.int64)
+        starts_all = np.concatenate(starts); lens_all = np.concatenate([m[:, 1] for m in metas if len(m)] or [np.zeros(0, np.int64)])
+        if not filtered and all(len(m) == len(t) and (not len(m) or np.array_equal(m[:, 0], t[:, 5])) for m, t in zip(metas, everyone)):
+            # cm_raw: a rank's columns ARE its real cells in table order -- no search
+            pos = base[keep[:, 0]] + keep[:, 8]
         else:
-            src, ln = np.zeros(0, np.int64), np.zeros(0, np.int64)
+            keys = np.concatenate([(np.int64(r) << 40) | m[:, 0] for r, m in enumerate(metas) if len(m)])
+            o = np.argsort(keys, kind="stable")
+            pos = o[np.searchsorted(keys[o], (keep[:, 0] << 40) | keep[:, 6])]
+        src, ln = starts_all[pos], lens_all[pos]
         return keep, keep[:, 0], np.asarray(src, np.int64), np.asarray(ln, np.int64)
 
     def _shared(self, slot, total):
