@@ -31,9 +31,13 @@ __global__ __launch_bounds__(256) void quality_sums_kernel(const unsigned long l
 		uint32_t lo = 0, hi = n_mol;
 		while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (mol_key[mid] < k) lo = mid + 1; else hi = mid; }
 		if (lo >= n_mol || mol_key[lo] != k) { atomicAdd(missing, 1u); continue; }
+		// two positions per 64-bit atomic (rows are padded to an even number of sums; a sum stays below 2^32, so the low
+		// half never carries into the high one): the kernel is bound by the number of L2 atomics
 		const uint8_t *q = qual + size_t(r) * qlen;
-		uint32_t *s = qsum + size_t(lo) * qlen;
-		for (uint32_t i = 0; i < qlen; ++i) atomicAdd(s + i, uint32_t(q[i]));
+		const uint32_t qstride = (qlen + 1u) & ~1u;
+		unsigned long long *s = reinterpret_cast<unsigned long long *>(qsum + size_t(lo) * qstride);
+		for (uint32_t i = 0; i < qlen; i += 2)
+			atomicAdd(s + (i >> 1), (unsigned long long)q[i] | (i + 1 < qlen ? (unsigned long long)q[i + 1] << 32 : 0ull));
 	}
 }
 
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void gather_quality_rows_kernel(const uint32_t
 	const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
 	if (i >= size_t(n) * qlen) return;
 	const uint32_t m = uint32_t(i / qlen), p = uint32_t(i % qlen);
-	out[i] = qsum[size_t(qrow[rows[m]]) * qlen + p];
+	out[i] = qsum[size_t(qrow[rows[m]]) * ((qlen + 1u) & ~1u) + p];
 }
 
 }  // namespace
@@ -95,8 +99,9 @@ void dropest_ctx::accumulate_umi_qualities() {
 	n_mol_at_init = n_mol;
 	if (!n_mol || !qual_len) return;
 	HostStage hs(this, "umi_qualities");
-	mol_qsum.ensure(size_t(n_mol) * qual_len);
-	HIP_CHECK(hipMemsetAsync(mol_qsum.p, 0, size_t(n_mol) * qual_len * 4, stream));
+	const size_t qstride = (size_t(qual_len) + 1) & ~size_t(1);   // padded to whole 64-bit pairs
+	mol_qsum.ensure(size_t(n_mol) * qstride);
+	HIP_CHECK(hipMemsetAsync(mol_qsum.p, 0, size_t(n_mol) * qstride * 4, stream));
 	mol_qrow.ensure(n_mol);
 	scalars.ensure(16);
 	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4, stream));
