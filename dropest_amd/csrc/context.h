@@ -8,6 +8,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -85,6 +86,19 @@ struct MergeSearch {                                   // neighbour search resul
 	DevBuf<WlBase> d_bases;
 	WlArgs args{};
 };
+
+// Host loops over millions of cells (C3 size: 2.5 M real-candidate cells): contiguous ranges on a few worker threads.
+// fn(begin, end, worker); ranges are in worker order, so per-worker results can be concatenated in input order.
+template <class F>
+inline unsigned parallel_ranges(size_t n, F &&fn, size_t min_per_worker = 100000, unsigned max_workers = 8) {
+	unsigned workers = unsigned(std::min<size_t>(std::min<size_t>(max_workers, std::max(1u, std::thread::hardware_concurrency())),
+	                                             std::max<size_t>(1, n / std::max<size_t>(1, min_per_worker))));
+	if (workers <= 1) { fn(size_t(0), n, 0u); return 1; }
+	std::vector<std::thread> pool;
+	for (unsigned w = 0; w < workers; ++w) pool.emplace_back([&, w] { fn(n * w / workers, n * (w + 1) / workers, w); });
+	for (auto &t : pool) t.join();
+	return workers;
+}
 
 struct HostCell {   // host mirror of one REAL-candidate cell (n_genes >= min_genes_before_merge at init)
 	u32 id;
@@ -178,6 +192,7 @@ struct dropest_ctx {
 	std::vector<u32> filtered_ridx;                      // index in `real` of each filtered cell
 	dropest::PinnedBuf<u64> sort_stage;                  // staging of sort_filtered's key columns / permutation
 	dropest::DevBuf<u64> sort_cols;
+	std::vector<u32> sort_idx;
 	bool filtered_valid = false;
 	u32 filtered_threshold = 0;
 	int filtered_max_cells = -1;

@@ -557,13 +557,98 @@ const std::vector<uint64_t> &dropest_ctx::filtered_cells() {
 
 void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 	// CellsDataContainer.cpp:250-276 with compare_cells :329-344, on compact keys
+	auto passes = [&](const HostCell &h) {
+		return !(h.merged || h.excluded || h.row.n_genes < min_before) && h.row.requested_genes >= genes_threshold;
+	};
+	size_t device_min = 50000;
+	if (const char *e = getenv("DROPEST_DEVICE_SORT_MIN")) device_min = size_t(std::max(1, atoi(e)));   // tests force the device path
+
+	// Large lists (10^5..10^6 cells at BASELINE sizes) are ordered on the device: three stable LSD radix sorts
+	// (barcode, then TOTAL_UMIS, then the packed sizes) when every barcode is a clean code of one length, so that
+	// the numeric order of the codes IS the string order.  The key is total, so any correct sort gives the same list.
+	// The host side of it (two passes over `real`, one over the result) runs on a few worker threads.
+	const size_t R = real.size();
+	if (R >= device_min) {
+		constexpr unsigned W = 8;
+		size_t count[W] = {0};
+		u64 any[W] = {0}; int bl[W]; bool uniform[W];
+		for (unsigned w = 0; w < W; ++w) { bl[w] = -1; uniform[w] = true; }
+		const unsigned workers = parallel_ranges(R, [&](size_t b, size_t e, unsigned w) {
+			for (size_t i = b; i < e; ++i) {
+				const HostCell &h = real[i];
+				if (!passes(h)) continue;
+				++count[w];
+				any[w] |= h.row.barcode;
+				const int l = bit_length(h.row.barcode);
+				if (bl[w] < 0) bl[w] = l; else if (l != bl[w]) uniform[w] = false;
+			}
+		}, 100000, W);
+		size_t m64 = 0; u64 any_all = 0; int bl_all = -1; bool device_sort = true;
+		size_t offset[W + 1];
+		for (unsigned w = 0; w < workers; ++w) {
+			offset[w] = m64; m64 += count[w]; any_all |= any[w];
+			if (count[w]) { if (bl_all < 0) bl_all = bl[w]; device_sort &= uniform[w] && bl[w] == bl_all; }
+		}
+		if (m64 >= device_min && m64 < 0xFFFFFFF0ull && device_sort && !(any_all & ESCAPE_BIT)) {
+			const u32 m = u32(m64);
+			sort_stage.ensure(size_t(m) * 3);
+			sort_cols.ensure(size_t(m) * 3);
+			sort_idx.resize(m);
+			keys_a.ensure(m); keys_b.ensure(m); vals_a.ensure(m); vals_b.ensure(m);
+			u64 *h_code = sort_stage.p, *h_umis = sort_stage.p + m, *h_sizes = sort_stage.p + 2 * size_t(m);
+			u64 o[W][3], a[W][3];
+			parallel_ranges(R, [&](size_t b, size_t e, unsigned w) {
+				u64 lo[3] = {0, 0, 0}, la[3] = {~0ull, ~0ull, ~0ull};
+				size_t at = offset[w];
+				for (size_t i = b; i < e; ++i) {
+					const HostCell &h = real[i];
+					if (!passes(h)) continue;
+					const u64 sizes = (u64(h.row.requested_genes) << 32) | h.row.requested_umis;
+					const u64 umis = u64(size_t(h.row.total_umis));   // Cell::umis_number casts the int stat to size_t
+					h_code[at] = h.row.barcode; h_umis[at] = umis; h_sizes[at] = sizes; sort_idx[at] = u32(i);
+					lo[0] |= h.row.barcode; la[0] &= h.row.barcode; lo[1] |= umis; la[1] &= umis; lo[2] |= sizes; la[2] &= sizes;
+					++at;
+				}
+				for (int c = 0; c < 3; ++c) { o[w][c] = lo[c]; a[w][c] = la[c]; }
+			}, 100000, W);   // same n and limits as above: the same ranges
+			u64 vary[3];
+			for (int c = 0; c < 3; ++c) {
+				u64 oo = 0, aa = ~0ull;
+				for (unsigned w = 0; w < workers; ++w) if (count[w]) { oo |= o[w][c]; aa &= a[w][c]; }
+				vary[c] = oo ^ aa;                                      // bits that vary: constant digits are skipped
+			}
+			HIP_CHECK(hipMemcpyAsync(sort_cols.p, sort_stage.p, size_t(m) * 3 * 8, hipMemcpyHostToDevice, stream));
+			const u64 *d_code = sort_cols.p, *d_umis = sort_cols.p + m, *d_sizes = sort_cols.p + 2 * size_t(m);
+			u64 *k = keys_a.p, *k_alt = keys_b.p;
+			u32 *v = vals_a.p, *v_alt = vals_b.p;
+			hipLaunchKernelGGL(iota_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, v, m);
+			HIP_CHECK(hipMemcpyAsync(k, d_code, size_t(m) * 8, hipMemcpyDeviceToDevice, stream));
+			radix_sort(k, v, k_alt, v_alt, m, vary[0]);
+			const std::pair<const u64 *, u64> more[2] = {{d_umis, vary[1]}, {d_sizes, vary[2]}};
+			for (auto const &nx : more) {
+				hipLaunchKernelGGL(gather_u64_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, nx.first, v, m, k);
+				HIP_CHECK(hipGetLastError());
+				radix_sort(k, v, k_alt, v_alt, m, nx.second);
+			}
+			u32 *perm = reinterpret_cast<u32 *>(sort_stage.p);              // the staging buffer is free again (stream order)
+			HIP_CHECK(hipMemcpyAsync(perm, v, size_t(m) * 4, hipMemcpyDeviceToHost, stream));
+			HIP_CHECK(hipStreamSynchronize(stream));
+			size_t start = 0;
+			if (max_cells > 0 && size_t(max_cells) < size_t(m)) start = size_t(m) - size_t(max_cells);
+			filtered.resize(m - start); filtered_ridx.resize(m - start);
+			parallel_ranges(m - start, [&](size_t b, size_t e, unsigned) {
+				for (size_t i = b; i < e; ++i) { const u32 idx = sort_idx[perm[start + i]]; filtered[i] = real[idx].id; filtered_ridx[i] = idx; }
+			});
+			filtered_valid = true;
+			return;
+		}
+	}
+
 	struct Key { u64 sizes; u64 umis; u64 code; u32 idx; };
 	std::vector<Key> keys;
-	keys.reserve(real.size());
 	for (u32 i = 0; i < real.size(); ++i) {
 		const HostCell &h = real[i];
-		if (h.merged || h.excluded || h.row.n_genes < min_before) continue;
-		if (h.row.requested_genes < genes_threshold) continue;
+		if (!passes(h)) continue;
 		keys.push_back(Key{(u64(h.row.requested_genes) << 32) | h.row.requested_umis,
 		                   u64(size_t(h.row.total_umis)),   // Cell::umis_number casts the int stat to size_t
 		                   h.row.barcode, i});
@@ -576,56 +661,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 		if (plain) return a.code < b.code;
 		return barcode_of(real[a.idx]) < barcode_of(real[b.idx]);
 	};
-	// Large lists (10^5..10^6 cells at BASELINE sizes) are ordered on the device: three stable LSD radix sorts
-	// (barcode, then TOTAL_UMIS, then the packed sizes) when every barcode is a clean code of one length, so that
-	// the numeric order of the codes IS the string order.  The key is total, so any correct sort gives the same list.
-	size_t device_min = 50000;
-	if (const char *e = getenv("DROPEST_DEVICE_SORT_MIN")) device_min = size_t(std::max(1, atoi(e)));   // tests force the device path
-	bool device_sort = !keys.empty() && keys.size() >= device_min;
-	if (device_sort) {
-		u64 any = 0; int bl = bit_length(keys[0].code);
-		for (const Key &k : keys) { any |= k.code; if (bit_length(k.code) != bl) { device_sort = false; break; } }
-		if (any & ESCAPE_BIT) device_sort = false;
-	}
-	if (device_sort) {
-		const u32 m = u32(keys.size());
-		// the three key columns go up through one pinned staging buffer (a pageable hipMemcpy runs at a tenth of the PCIe rate)
-		sort_stage.ensure(size_t(m) * 3);
-		sort_cols.ensure(size_t(m) * 3);
-		keys_a.ensure(m); keys_b.ensure(m); vals_a.ensure(m); vals_b.ensure(m);
-		u64 *h_code = sort_stage.p, *h_umis = sort_stage.p + m, *h_sizes = sort_stage.p + 2 * size_t(m);
-		u64 o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull};
-		for (u32 i = 0; i < m; ++i) {
-			const Key &k = keys[i];
-			h_code[i] = k.code; h_umis[i] = k.umis; h_sizes[i] = k.sizes;
-			o[0] |= k.code; a[0] &= k.code; o[1] |= k.umis; a[1] &= k.umis; o[2] |= k.sizes; a[2] &= k.sizes;
-		}
-		HIP_CHECK(hipMemcpyAsync(sort_cols.p, sort_stage.p, size_t(m) * 3 * 8, hipMemcpyHostToDevice, stream));
-		const u64 *d_code = sort_cols.p, *d_umis = sort_cols.p + m, *d_sizes = sort_cols.p + 2 * size_t(m);
-		u64 *k = keys_a.p, *k_alt = keys_b.p;
-		u32 *v = vals_a.p, *v_alt = vals_b.p;
-		hipLaunchKernelGGL(iota_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, v, m);
-		HIP_CHECK(hipMemcpyAsync(k, d_code, size_t(m) * 8, hipMemcpyDeviceToDevice, stream));
-		radix_sort(k, v, k_alt, v_alt, m, o[0] ^ a[0]);                 // bits that vary: constant digits are skipped
-		const std::pair<const u64 *, u64> more[2] = {{d_umis, o[1] ^ a[1]}, {d_sizes, o[2] ^ a[2]}};
-		for (auto const &nx : more) {
-			hipLaunchKernelGGL(gather_u64_kernel, dim3(div_up(m, 256)), dim3(256), 0, stream, nx.first, v, m, k);
-			HIP_CHECK(hipGetLastError());
-			radix_sort(k, v, k_alt, v_alt, m, nx.second);
-		}
-		u32 *perm = reinterpret_cast<u32 *>(sort_stage.p);              // the staging buffer is free again (stream order)
-		HIP_CHECK(hipMemcpyAsync(perm, v, size_t(m) * 4, hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
-		filtered.clear(); filtered_ridx.clear();
-		size_t start = 0;
-		if (max_cells > 0 && size_t(max_cells) < size_t(m)) start = size_t(m) - size_t(max_cells);
-		filtered.reserve(m - start); filtered_ridx.reserve(m - start);
-		for (size_t i = start; i < m; ++i) { const u32 idx = keys[perm[i]].idx; filtered.push_back(real[idx].id); filtered_ridx.push_back(idx); }
-		filtered_valid = true;
-		return;
-	} else {
-		std::sort(keys.begin(), keys.end(), less);
-	}
+	std::sort(keys.begin(), keys.end(), less);
 	filtered.clear(); filtered_ridx.clear();
 	size_t start = 0;
 	if (max_cells > 0 && size_t(max_cells) < keys.size()) start = keys.size() - size_t(max_cells);

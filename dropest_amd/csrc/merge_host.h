@@ -397,24 +397,36 @@ void dropest_ctx::run_cb_merge_real() {
 	HostStage hs3(this, "cb_merge:apply");
 	const u32 nR = u32(real.size());
 	std::vector<int64_t> tgt(cells.size());
-	for (size_t i = 0; i < cells.size(); ++i) tgt[i] = targets[i] < 0 ? -1 : int64_t(target_ridx[i]);
+	parallel_ranges(cells.size(), [&](size_t b, size_t e, unsigned) {
+		for (size_t i = b; i < e; ++i) tgt[i] = targets[i] < 0 ? -1 : int64_t(target_ridx[i]);
+	});
 	std::vector<int32_t> reads(nR), umis(nR);
-	for (u32 i = 0; i < nR; ++i) { reads[i] = real[i].row.total_reads; umis[i] = real[i].row.total_umis; }
+	parallel_ranges(nR, [&](size_t b, size_t e, unsigned) {
+		for (size_t i = b; i < e; ++i) { reads[i] = real[i].row.total_reads; umis[i] = real[i].row.total_umis; }
+	});
 	std::vector<u32> cur(nR);
 	std::vector<uint8_t> excl(nR);
-	std::vector<u32> rank(nR);
-	const bool any_merge = apply_merge_order(nR, cells.size(), ridx.data(), tgt.data(), reads.data(), umis.data(), cur.data(), excl.data(), rank.data());
-	if (have_qual) {   // only the quality sums need the merge order (quality.h)
+	std::vector<u32> rank(have_qual ? nR : 0u);   // only the quality sums need the merge order (quality.h)
+	const bool any_merge = apply_merge_order(nR, cells.size(), ridx.data(), tgt.data(), reads.data(), umis.data(), cur.data(), excl.data(),
+	                                         have_qual ? rank.data() : nullptr);
+	if (have_qual) {
 		merge_rank.assign(n_cells, 0);
 		for (u32 i = 0; i < nR; ++i) merge_rank[real[i].id] = rank[i];
 	}
 	reassign.clear();
 	merge_pairs.clear();
-	for (u32 i = 0; i < nR; ++i) {
-		real[i].row.total_reads = reads[i]; real[i].row.total_umis = umis[i];
-		if (excl[i]) real[i].excluded = true;
-		if (cur[i] != i) { real[i].merged = true; merge_pairs.emplace_back(real[i].id, real[cur[i]].id); }   // ascending source id
-	}
+	std::vector<std::vector<std::pair<uint64_t, uint64_t>>> moved(8);
+	const unsigned workers = parallel_ranges(nR, [&](size_t b, size_t e, unsigned w) {
+		for (size_t i = b; i < e; ++i) {
+			real[i].row.total_reads = reads[i]; real[i].row.total_umis = umis[i];
+			if (excl[i]) real[i].excluded = true;
+			if (cur[i] != i) { real[i].merged = true; moved[w].emplace_back(real[i].id, real[cur[i]].id); }
+		}
+	});
+	size_t n_moved = 0;
+	for (unsigned w = 0; w < workers; ++w) n_moved += moved[w].size();
+	merge_pairs.reserve(n_moved);
+	for (unsigned w = 0; w < workers; ++w) merge_pairs.insert(merge_pairs.end(), moved[w].begin(), moved[w].end());   // ascending source id
 	if (any_merge) reaggregate_after_merge();
 }
 
