@@ -22,6 +22,7 @@
 #include "k_misc.h"
 #include "k_radix.h"
 #include "k_segreduce.h"
+#include "k_mergepath.h"
 #include "util.h"
 
 namespace dropest {
@@ -291,6 +292,10 @@ struct dropest_ctx {
 	                      const std::vector<u32> &p_rreq, const std::unordered_map<u32, int> &umis_removed);
 	void run_umi_merge_directional();            // -u (umi_directional_host.h)
 	void reaggregate_from_keys(u64 varying_mask); // keys_a / vals_a hold the re-keyed molecule table
+	bool resort_changed_rows(u64 varying_mask);   // split + sort the changed rows + merge (k_mergepath.h)
+	u32 mol_sorted_rows = 0xFFFFFFFFu;            // rows of the molecule table below this index are sorted (a sharded merge appends behind)
+	dropest::DevBuf<u64> mp_bk, mp_bk2;
+	dropest::DevBuf<u32> mp_bv, mp_bv2, mp_astart;
 	// UMI quality sums (quality.h)
 	dropest::DevBuf<uint8_t> umi_qual;          // [qual_reads][qual_len], read order
 	u32 qual_len = 0;

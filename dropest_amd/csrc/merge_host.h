@@ -476,10 +476,44 @@ void dropest_ctx::reaggregate_after_merge() {
 
 // keys_a holds the re-keyed molecule keys, vals_a the row each one came from: sort, fold equal keys (read counts
 // add, marks OR: Gene::merge / UMI::merge, Gene.cpp:26-58, UMI.cpp:15-19), rebuild the (cell, gene) and cell levels.
+// keys_a holds the new key of every molecule row: when only a small part of them differs from the current (sorted) keys,
+// split / sort the changed part / merge (k_mergepath.h) instead of radix-sorting everything.  Returns false when the
+// radix sort should run (many changes); else leaves the sorted (key, old row) pairs in keys_a / vals_a.
+bool dropest_ctx::resort_changed_rows(u64 varying_mask) {
+	if (n_mol < 4 * u32(MP_TILE)) return false;
+	const u32 tiles = div_up(n_mol, u32(MP_TILE));
+	tile_counts.ensure(tiles); tile_prefix.ensure(tiles); scalars.ensure(16);
+	timed("mp_split_count", double(n_mol) * 16, [&] {
+		hipLaunchKernelGGL(mp_split_count_kernel, dim3(tiles), dim3(MP_THREADS), 0, stream, mol_key.p, keys_a.p, n_mol, mol_sorted_rows, tile_counts.p);
+		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, tile_counts.p, tile_prefix.p, tiles, scalars.p);
+	});
+	u32 nb = 0;
+	fetch(&nb, scalars.p, 4);
+	if (nb == 0 || nb > n_mol / 4) return false;
+	const u32 na = n_mol - nb;
+	mp_bk.ensure(nb); mp_bk2.ensure(nb); mp_bv.ensure(nb); mp_bv2.ensure(nb);
+	timed("mp_split_write", double(n_mol) * 28, [&] {
+		hipLaunchKernelGGL(mp_split_write_kernel, dim3(tiles), dim3(MP_THREADS), 0, stream, mol_key.p, keys_a.p, n_mol, mol_sorted_rows, tile_prefix.p,
+		                   keys_b.p, vals_b.p, mp_bk.p, mp_bv.p);
+	});
+	u64 *bk = mp_bk.p, *bk_alt = mp_bk2.p;
+	u32 *bv = mp_bv.p, *bv_alt = mp_bv2.p;
+	radix_sort(bk, bv, bk_alt, bv_alt, nb, varying_mask, 4, "changed:");
+	const u32 out_tiles = div_up(n_mol, u32(MP_TILE));
+	mp_astart.ensure(size_t(out_tiles) + 1);
+	timed("mp_merge", double(n_mol) * 24, [&] {
+		hipLaunchKernelGGL(mp_partition_kernel, dim3(div_up(out_tiles + 1, 256u)), dim3(256), 0, stream, keys_b.p, na, bk, nb, out_tiles, mp_astart.p);
+		hipLaunchKernelGGL(mp_merge_kernel, dim3(out_tiles), dim3(MP_THREADS), 0, stream, keys_b.p, vals_b.p, na, bk, bv, nb, mp_astart.p,
+		                   keys_a.p, vals_a.p);
+	});
+	HIP_CHECK(hipGetLastError());
+	return true;
+}
+
 void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 	u64 *keys = keys_a.p, *keys_alt = keys_b.p;
 	u32 *vals = vals_a.p, *vals_alt = vals_b.p;
-	radix_sort(keys, vals, keys_alt, vals_alt, n_mol, varying_mask);
+	if (!resort_changed_rows(varying_mask)) radix_sort(keys, vals, keys_alt, vals_alt, n_mol, varying_mask);
 	u32 new_n = 0;
 	if (chr_from_gene) {
 		RekeyedToMoleculesX p{};
@@ -505,6 +539,7 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 		});
 		HIP_CHECK(hipStreamSynchronize(stream));
 	}
+	mol_sorted_rows = 0xFFFFFFFFu;   // the folded table is sorted throughout
 	requality_after_fold(keys, vals, n_mol, mol_key2.p, new_n);
 	std::swap(mol_key, mol_key2); std::swap(mol_reads, mol_reads2); std::swap(mol_mark, mol_mark2);
 	n_mol = new_n;

@@ -282,6 +282,7 @@ void dropest_ctx::shard_merge_finish(uint64_t n_local, const uint32_t *local_id,
 			HIP_CHECK(hipMemcpyAsync(mol_intron.p + n_mol, d_cols[3], size_t(ni) * 4, hipMemcpyDeviceToDevice, stream));
 		}
 		HIP_CHECK(hipStreamSynchronize(stream));
+		mol_sorted_rows = n_mol;   // the imported rows sit behind the sorted table
 		n_mol = total;
 	}
 	if (n_import || !merge_pairs.empty()) reaggregate_after_merge();
