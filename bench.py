@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--poisson", action="store_true", help="c3 / c4: -M (PoissonRealBarcodesMergeStrategy) instead of -m, single GPU")
     ap.add_argument("--no-whitelist", action="store_true", help="c3 / c4: -m WITHOUT the barcode whitelist (SimpleMergeStrategy, single GPU)")
     ap.add_argument("--merge-umi", action="store_true", help="-u: directional UMI correction (single-GPU configs only)")
-    ap.add_argument("--cpu-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_CPU_SAMPLE", 4e6)),
+    ap.add_argument("--cpu-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_CPU_SAMPLE", 6e6)),
                     help="reads of the same stream timed on the CPU oracle (rank 0, N=1 only; 0 disables)")
     return ap.parse_args()
 
