@@ -82,6 +82,26 @@ __device__ inline uint32_t wl_edit_distance(const uint32_t peq[5], uint32_t wild
 	return score;
 }
 
+// the same against a text given as a 2-bit code of `n` bases (most significant base first): no per-character branches
+__device__ inline uint32_t wl_edit_distance_code(const uint32_t peq[5], int m, unsigned long long code, int n) {
+	if (m == 0) return uint32_t(n);
+	uint32_t pv = m >= 32 ? 0xFFFFFFFFu : ((1u << m) - 1u), mv = 0, score = uint32_t(m);
+	const uint32_t last = 1u << (m - 1);
+	for (int j = n - 1; j >= 0; --j) {
+		const uint32_t eq = peq[uint32_t(code >> (2 * j)) & 3u];
+		const uint32_t xv = eq | mv;
+		const uint32_t xh = (((eq & pv) + pv) ^ pv) | eq;
+		uint32_t ph = mv | ~(xh | pv);
+		uint32_t mh = pv & xh;
+		if (ph & last) ++score; else if (mh & last) --score;
+		ph = (ph << 1) | 1u;
+		mh <<= 1;
+		pv = mh | ~(xv | ph);
+		mv = ph & xv;
+	}
+	return score;
+}
+
 // appends the 2-bit payload of a NUL-terminated ACGT string to `c` (clean strings only)
 __device__ inline unsigned long long wl_append(unsigned long long c, const char *s) {
 	for (int i = 0; i < 32 && s[i]; ++i) {
@@ -94,6 +114,7 @@ __device__ inline unsigned long long wl_append(unsigned long long c, const char 
 struct WlArgs {
 	const WlBase *bases; uint32_t n_bases;
 	const WlEntry *part[2]; uint32_t part_size[2];                         // whitelist (two parts)
+	const unsigned long long *part_code[2];                                // per entry: length << 58 | 2-bit code, ~0 = not a clean ACGT string
 	CbTable table;
 	const uint32_t *cell_n_genes, *cell_total_umis;
 	uint32_t min_genes;
@@ -135,7 +156,9 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 		wl_build_peq(b.part[p], b.len[p], peq, wild);
 		const uint32_t np = a.part_size[p], off = p ? n0 : 0;
 		for (uint32_t i = tid; i < np; i += WL_THREADS) {
-			const uint32_t d = wl_edit_distance(peq, wild, b.len[p], a.part[p][i].seq);
+			const unsigned long long pc = a.part_code[p][i];
+			const uint32_t d = pc != ~0ull ? wl_edit_distance_code(peq, b.len[p], pc & ((1ull << 58) - 1ull), int(pc >> 58))
+			                               : wl_edit_distance(peq, wild, b.len[p], a.part[p][i].seq);
 			dist[off + i] = uint8_t(d > 255 ? 255 : d);
 			atomicAdd(&cnt[p][d > WL_MAX_DIST ? WL_MAX_DIST + 1 : d], 1u);
 		}

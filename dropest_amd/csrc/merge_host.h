@@ -80,6 +80,20 @@ void dropest_ctx::upload_whitelist() {
 		}
 		d_wl[p].alloc(h.size());
 		HIP_CHECK(hipMemcpy(d_wl[p].p, h.data(), h.size() * sizeof(WlEntry), hipMemcpyHostToDevice));
+		// packed copies for the branch-free distance loop (entries of up to 29 clean bases; the others keep the string path)
+		std::vector<u64> codes(h.size(), ~0ull);
+		for (size_t i = 0; i < h.size(); ++i) {
+			const std::string &e = wl.parts[size_t(p)][i];
+			if (e.size() > 29) continue;
+			u64 c = 0; bool clean = true;
+			for (char ch : e) {
+				if (ch == 'A') c = (c << 2); else if (ch == 'C') c = (c << 2) | 1; else if (ch == 'G') c = (c << 2) | 2; else if (ch == 'T') c = (c << 2) | 3;
+				else { clean = false; break; }
+			}
+			if (clean) codes[i] = (u64(e.size()) << 58) | c;
+		}
+		d_wl_code[p].alloc(codes.size());
+		HIP_CHECK(hipMemcpy(d_wl_code[p].p, codes.data(), codes.size() * 8, hipMemcpyHostToDevice));
 	}
 }
 
@@ -139,6 +153,7 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 		a = WlArgs{};
 		a.bases = S.d_bases.p; a.n_bases = F;
 		a.part[0] = d_wl[0].p; a.part[1] = d_wl[1].p;
+		a.part_code[0] = d_wl_code[0].p; a.part_code[1] = d_wl_code[1].p;
 		a.part_size[0] = u32(wl.parts[0].size()); a.part_size[1] = u32(wl.parts[1].size());
 		a.table = U.table; a.cell_n_genes = U.n_genes; a.cell_total_umis = U.total_umis; a.min_genes = min_before;
 		a.cand_count = d_cnt.p; a.cand_level = d_lvl.p; a.cand_off = d_off.p; a.flat_cell = d_fcell.p; a.flat_umis = d_fumis.p;
