@@ -570,18 +570,21 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 	const size_t R = real.size();
 	if (R >= device_min) {
 		constexpr unsigned W = 8;
+		auto st1 = std::make_unique<HostStage>(this, "sort_filtered:scan");
 		size_t count[W] = {0};
 		u64 any[W] = {0}; int bl[W]; bool uniform[W];
 		for (unsigned w = 0; w < W; ++w) { bl[w] = -1; uniform[w] = true; }
 		const unsigned workers = parallel_ranges(R, [&](size_t b, size_t e, unsigned w) {
+			size_t c = 0; u64 a = 0; int l0 = -1; bool uni = true;   // locals: the per-worker slots share cache lines
 			for (size_t i = b; i < e; ++i) {
 				const HostCell &h = real[i];
 				if (!passes(h)) continue;
-				++count[w];
-				any[w] |= h.row.barcode;
+				++c;
+				a |= h.row.barcode;
 				const int l = bit_length(h.row.barcode);
-				if (bl[w] < 0) bl[w] = l; else if (l != bl[w]) uniform[w] = false;
+				if (l0 < 0) l0 = l; else if (l != l0) uni = false;
 			}
+			count[w] = c; any[w] = a; bl[w] = l0; uniform[w] = uni;
 		}, 100000, W);
 		size_t m64 = 0; u64 any_all = 0; int bl_all = -1; bool device_sort = true;
 		size_t offset[W + 1];
@@ -591,6 +594,8 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 		}
 		if (m64 >= device_min && m64 < 0xFFFFFFF0ull && device_sort && !(any_all & ESCAPE_BIT)) {
 			const u32 m = u32(m64);
+			st1.reset();
+			auto st2 = std::make_unique<HostStage>(this, "sort_filtered:fill");
 			sort_stage.ensure(size_t(m) * 3);
 			sort_cols.ensure(size_t(m) * 3);
 			sort_idx.resize(m);
@@ -617,6 +622,8 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 				for (unsigned w = 0; w < workers; ++w) if (count[w]) { oo |= o[w][c]; aa &= a[w][c]; }
 				vary[c] = oo ^ aa;                                      // bits that vary: constant digits are skipped
 			}
+			st2.reset();
+			auto st3 = std::make_unique<HostStage>(this, "sort_filtered:device");
 			HIP_CHECK(hipMemcpyAsync(sort_cols.p, sort_stage.p, size_t(m) * 3 * 8, hipMemcpyHostToDevice, stream));
 			const u64 *d_code = sort_cols.p, *d_umis = sort_cols.p + m, *d_sizes = sort_cols.p + 2 * size_t(m);
 			u64 *k = keys_a.p, *k_alt = keys_b.p;
@@ -633,6 +640,8 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 			u32 *perm = reinterpret_cast<u32 *>(sort_stage.p);              // the staging buffer is free again (stream order)
 			HIP_CHECK(hipMemcpyAsync(perm, v, size_t(m) * 4, hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipStreamSynchronize(stream));
+			st3.reset();
+			HostStage st4(this, "sort_filtered:gather");
 			size_t start = 0;
 			if (max_cells > 0 && size_t(max_cells) < size_t(m)) start = size_t(m) - size_t(max_cells);
 			filtered.resize(m - start); filtered_ridx.resize(m - start);

@@ -269,7 +269,11 @@ void dropest_ctx::decide_merge_targets(const MergeUniverse &U, MergeSearch &S, c
 		std::vector<std::vector<u32>> ties(n_workers);
 		std::vector<std::thread> pool;
 		for (unsigned w = 0; w < n_workers; ++w)
-			pool.emplace_back(decide_range, u32(uint64_t(F) * w / n_workers), u32(uint64_t(F) * (w + 1) / n_workers), std::ref(ties[w]));
+			pool.emplace_back([&, w] {
+				std::vector<u32> mine;   // local: the slots' vector headers share cache lines
+				decide_range(u32(uint64_t(F) * w / n_workers), u32(uint64_t(F) * (w + 1) / n_workers), mine);
+				ties[w] = std::move(mine);
+			});
 		for (auto &t : pool) t.join();
 		for (auto &t : ties) need_order.insert(need_order.end(), t.begin(), t.end());
 	}
@@ -432,11 +436,13 @@ void dropest_ctx::run_cb_merge_real() {
 	merge_pairs.clear();
 	std::vector<std::vector<std::pair<uint64_t, uint64_t>>> moved(8);
 	const unsigned workers = parallel_ranges(nR, [&](size_t b, size_t e, unsigned w) {
+		std::vector<std::pair<uint64_t, uint64_t>> mine;   // local: the slots' vector headers share cache lines
 		for (size_t i = b; i < e; ++i) {
 			real[i].row.total_reads = reads[i]; real[i].row.total_umis = umis[i];
 			if (excl[i]) real[i].excluded = true;
-			if (cur[i] != i) { real[i].merged = true; moved[w].emplace_back(real[i].id, real[cur[i]].id); }
+			if (cur[i] != i) { real[i].merged = true; mine.emplace_back(real[i].id, real[cur[i]].id); }
 		}
+		moved[w] = std::move(mine);
 	});
 	size_t n_moved = 0;
 	for (unsigned w = 0; w < workers; ++w) n_moved += moved[w].size();

@@ -21,3 +21,11 @@ python scripts/roofline_table.py $OUT/${TAG}_pmc_summary.csv > $OUT/${TAG}_roofl
 timeout 600 python bench.py > $OUT/${TAG}_bench_c2.json 2> $OUT/bench.err
 rm -rf $OUT/kt $OUT/fetch $OUT/write
 ls -la $OUT; tail -3 $OUT/pmc_summary.log; tail -c 600 $OUT/${TAG}_bench_c2.json
+# the other BASELINE shapes on one GPU (bench lines only)
+timeout 900 python bench.py --config c3 --reads 1e9 --steps 3 --warmup 1 --cpu-sample 0 2> /dev/null | tail -1 > $OUT/${TAG}_bench_c3_1e9.json
+timeout 600 python bench.py --config c4 --reads 1.25e8 --steps 5 --warmup 2 --cpu-sample 0 2> /dev/null | tail -1 > $OUT/${TAG}_bench_c4_1gpu.json
+python - <<PY
+import json
+for n in ("c3_1e9", "c4_1gpu"):
+    d = json.load(open("$OUT/${TAG}_bench_%s.json" % n)); print(n, d["value"], d["ms_per_step"])
+PY
