@@ -162,8 +162,8 @@ struct dropest_ctx {
 
 	// CB merge
 	dropest::Whitelist wl;
-	dropest::DevBuf<dropest::WlEntry> d_wl[2];
-	dropest::DevBuf<u64> d_wl_code[2];            // packed copies of the whitelist parts (k_merge.h: wl_edit_distance_code)
+	dropest::DevBuf<dropest::WlEntry> d_wl[dropest::WL_MAX_PARTS];
+	dropest::DevBuf<u64> d_wl_code[dropest::WL_MAX_PARTS];            // packed copies of the whitelist parts (k_merge.h: wl_edit_distance_code)
 	dropest::DevBuf<u64> mol_key2;           // re-keyed molecule table (swapped in after a merge)
 	dropest::DevBuf<u32> mol_reads2, mol_mark2, remap;
 	std::unordered_map<u32, u32> reassign;   // merged cell -> final target (MergeStrategyBase cb_reassign_targets, sparse)

@@ -25,15 +25,15 @@ constexpr int WL_MAX_LEN = 31;          // bases per barcode part
 constexpr int WL_MAX_DIST = 5;          // BarcodesParser::MAX_REAL_MERGE_EDIT_DISTANCE (BarcodesParser.h:57)
 constexpr int WL_CAND_CAP = 128;        // candidates kept per cell (exceeding it is reported, never truncated silently)
 constexpr int WL_THREADS = 256;
+constexpr int WL_MAX_PARTS = 4;         // whitelist parts (lines of a const-length file; the reference ships files of 2 and 3)
 
 struct WlEntry {            // one whitelist part entry
 	char seq[32];           // ASCII, NUL padded
 };
 
-struct WlBase {             // one filtered cell's barcode, split on the host (BarcodesParser::split_barcode)
-	char part[2][32];
-	uint8_t len[2];
-	uint8_t pad[2];
+struct WlBase {             // one filtered cell's barcode, split into the whitelist's parts (BarcodesParser::split_barcode)
+	char part[WL_MAX_PARTS][32];
+	uint8_t len[WL_MAX_PARTS];
 	uint32_t cell;          // cell id of the base
 };
 
@@ -113,8 +113,9 @@ __device__ inline unsigned long long wl_append(unsigned long long c, const char 
 
 struct WlArgs {
 	const WlBase *bases; uint32_t n_bases;
-	const WlEntry *part[2]; uint32_t part_size[2];                         // whitelist (two parts)
-	const unsigned long long *part_code[2];                                // per entry: length << 58 | 2-bit code, ~0 = not a clean ACGT string
+	const WlEntry *part[WL_MAX_PARTS]; uint32_t part_size[WL_MAX_PARTS];   // whitelist parts
+	uint32_t n_parts;
+	const unsigned long long *part_code[WL_MAX_PARTS];                     // per entry: length << 58 | 2-bit code, ~0 = not a clean ACGT string
 	CbTable table;
 	const uint32_t *cell_n_genes, *cell_total_umis;
 	uint32_t min_genes;
@@ -131,30 +132,34 @@ struct WlArgs {
 	int poisson;             // PoissonRealBarcodesMergeStrategy::get_max_merge_dist: all levels up to (min == 0 ? 2 : min + 1)
 };
 
-// one block per filtered cell; dynamic LDS: dist bytes [n0 + n1] + index lists u16 [n0 + n1]
+// one block per filtered cell; dynamic LDS: dist bytes [ntot] + index lists u16 [ntot], ntot = entries of all parts
 __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const uint32_t n0 = a.part_size[0], n1 = a.part_size[1], ntot = n0 + n1;
+	const uint32_t P = a.n_parts;
+	uint32_t poff[WL_MAX_PARTS + 1];                  // first entry of each part in dist / lists
+	poff[0] = 0;
+	for (uint32_t p = 0; p < P; ++p) poff[p + 1] = poff[p] + a.part_size[p];
+	const uint32_t ntot = poff[P];
 	uint8_t *dist = smem;                                             // [ntot]
 	uint16_t *lists = reinterpret_cast<uint16_t *>(smem + ((ntot + 15u) & ~15u));   // [ntot], grouped by (part, distance)
-	__shared__ uint32_t cnt[2][WL_MAX_DIST + 2];      // entries per distance 0..5, [6] = farther
-	__shared__ uint32_t start[2][WL_MAX_DIST + 2];
-	__shared__ uint32_t fill[2][WL_MAX_DIST + 2];
+	__shared__ uint32_t cnt[WL_MAX_PARTS][WL_MAX_DIST + 2];      // entries per distance 0..5, [6] = farther
+	__shared__ uint32_t start[WL_MAX_PARTS][WL_MAX_DIST + 2];
+	__shared__ uint32_t fill[WL_MAX_PARTS][WL_MAX_DIST + 2];
 	__shared__ uint32_t n_found;
 	__shared__ uint32_t found[WL_CAND_CAP];
 	__shared__ uint32_t flat_base;
 
 	const WlBase &b = a.bases[blockIdx.x];
 	const uint32_t tid = threadIdx.x;
-	if (tid < 2 * (WL_MAX_DIST + 2)) { (&cnt[0][0])[tid] = 0; (&fill[0][0])[tid] = 0; }
+	if (tid < WL_MAX_PARTS * (WL_MAX_DIST + 2)) { (&cnt[0][0])[tid] = 0; (&fill[0][0])[tid] = 0; }
 	if (tid == 0) n_found = 0;
 	__syncthreads();
 
-	// 1. distances of both parts to every whitelist entry
-	for (int p = 0; p < 2; ++p) {
+	// 1. distances of every part to every whitelist entry of that part
+	for (uint32_t p = 0; p < P; ++p) {
 		uint32_t peq[5], wild;
 		wl_build_peq(b.part[p], b.len[p], peq, wild);
-		const uint32_t np = a.part_size[p], off = p ? n0 : 0;
+		const uint32_t np = a.part_size[p], off = poff[p];
 		for (uint32_t i = tid; i < np; i += WL_THREADS) {
 			const unsigned long long pc = a.part_code[p][i];
 			const uint32_t d = pc != ~0ull ? wl_edit_distance_code(peq, b.len[p], pc & ((1ull << 58) - 1ull), int(pc >> 58))
@@ -165,14 +170,14 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 	}
 	__syncthreads();
 	if (a.dist_dump) for (uint32_t i = tid; i < ntot; i += WL_THREADS) a.dist_dump[size_t(blockIdx.x) * ntot + i] = dist[i];
-	if (tid < 2) {
-		uint32_t run = tid ? n0 : 0;
+	if (tid < P) {
+		uint32_t run = poff[tid];
 		for (int k = 0; k <= WL_MAX_DIST + 1; ++k) { start[tid][k] = run; run += cnt[tid][k]; }
 	}
 	__syncthreads();
 	// 2. index lists grouped by distance (order inside a group is irrelevant: candidates form a set)
-	for (int p = 0; p < 2; ++p) {
-		const uint32_t np = a.part_size[p], off = p ? n0 : 0;
+	for (uint32_t p = 0; p < P; ++p) {
+		const uint32_t np = a.part_size[p], off = poff[p];
 		for (uint32_t i = tid; i < np; i += WL_THREADS) {
 			const uint32_t d = dist[off + i];
 			if (d <= WL_MAX_DIST) lists[start[p][d] + atomicAdd(&fill[p][d], 1u)] = uint16_t(i);
@@ -182,25 +187,34 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 
 	// 3. levels of increasing total distance (RealBarcodesMergeStrategy::get_real_neighbour_cbs, :63-109): every level
 	//    up to max_dist = get_max_merge_dist(smallest distance of ANY whitelist combination), then further levels one
-	//    at a time while no candidate has been found; a level is taken whole
+	//    at a time while no candidate has been found; a level is taken whole.  A level = every tuple of per-part
+	//    distances with that sum; a tuple contributes the product of its parts' lists.
 	const uint32_t base_umis = a.cell_total_umis[b.cell];
-	uint32_t level = 0, min_level = WL_MAX_DIST + 1;
-	for (uint32_t l = 0; l <= WL_MAX_DIST && min_level > WL_MAX_DIST; ++l)
-		for (uint32_t d0 = 0; d0 <= l; ++d0)
-			if (cnt[0][d0] && cnt[1][l - d0]) { min_level = l; break; }
+	uint32_t min_level = 0;
+	for (uint32_t p = 0; p < P; ++p) {
+		uint32_t m = WL_MAX_DIST + 1;
+		for (uint32_t d = 0; d <= WL_MAX_DIST; ++d) if (cnt[p][d]) { m = d; break; }
+		min_level += m;                                   // (> WL_MAX_DIST when a part has no entry that close)
+	}
+	uint32_t n_tuples = 1;
+	for (uint32_t p = 0; p < P; ++p) n_tuples *= WL_MAX_DIST + 1;
 	uint32_t max_dist = a.poisson ? (min_level == 0 ? 2u : min_level + 1u) : min_level;
-	uint32_t last_level = min_level;
-	for (level = min_level; level <= WL_MAX_DIST; ++level) {
+	uint32_t level = min_level, last_level = min_level;
+	for (; level <= WL_MAX_DIST; ++level) {
 		last_level = level;
-		for (uint32_t d0 = 0; d0 <= level; ++d0) {
-			const uint32_t d1 = level - d0;
-			const uint32_t na = cnt[0][d0], nb = cnt[1][d1];
-			const uint64_t pairs = uint64_t(na) * nb;
-			for (uint64_t q = tid; q < pairs; q += WL_THREADS) {
-				const uint32_t i = lists[start[0][d0] + uint32_t(q / nb)];
-				const uint32_t j = lists[start[1][d1] + uint32_t(q % nb)];
+		for (uint32_t t = 0; t < n_tuples; ++t) {
+			uint32_t dd[WL_MAX_PARTS], cc[WL_MAX_PARTS], sum = 0, x = t;
+			unsigned long long combos = 1;
+			for (uint32_t p = 0; p < P; ++p) { dd[p] = x % (WL_MAX_DIST + 1); x /= WL_MAX_DIST + 1; sum += dd[p]; cc[p] = cnt[p][dd[p]]; combos *= cc[p]; }
+			if (sum != level || combos == 0) continue;
+			for (unsigned long long q = tid; q < combos; q += WL_THREADS) {
 				// packed code of the concatenation (sentinel bit first; entries of a part may differ in length)
-				const unsigned long long code = wl_append(wl_append(1ull, a.part[0][i].seq), a.part[1][j].seq);
+				unsigned long long code = 1ull, r = q;
+				for (uint32_t p = 0; p < P; ++p) {
+					const uint32_t i = lists[start[p][dd[p]] + uint32_t(r % cc[p])];
+					r /= cc[p];
+					code = wl_append(code, a.part[p][i].seq);
+				}
 				const uint32_t s = cb_find(a.table, code);
 				if (s == 0xFFFFFFFFu) continue;
 				const uint32_t c = a.table.slots[s].cell_id;
@@ -233,29 +247,41 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 	}
 }
 
-// Splits the barcodes of a list of cells into the two whitelist parts on the device
-// (BarcodesParser::split_barcode: InDropBarcodesParser.cpp:32-39 / ConstLengthBarcodesParser.cpp:33-48).
+// Splits the barcodes of a list of cells into the whitelist's parts on the device
+// (BarcodesParser::split_barcode: InDropBarcodesParser.cpp:32-39 -- two parts, the second of fixed length --
+// / ConstLengthBarcodesParser.cpp:33-48 -- any number of parts of fixed lengths).
 // Escaped barcodes (with N) are left for the host (len[0] = 0xFF); a barcode whose length does not fit sets *bad.
+struct WlSplit { uint32_t n_parts; uint32_t len[WL_MAX_PARTS]; int const_kind; };
 __global__ __launch_bounds__(256) void make_bases_kernel(const uint32_t *__restrict__ cells, uint32_t n,
-                                                         const unsigned long long *__restrict__ cell_cb, int const_kind,
-                                                         uint32_t len1, uint32_t len2, WlBase *__restrict__ out,
-                                                         uint32_t *__restrict__ bad) {
+                                                         const unsigned long long *__restrict__ cell_cb, WlSplit sp,
+                                                         WlBase *__restrict__ out, uint32_t *__restrict__ bad) {
 	const uint32_t f = blockIdx.x * 256 + threadIdx.x;
 	if (f >= n) return;
 	WlBase b;
-	for (int p = 0; p < 2; ++p) for (int i = 0; i < 32; ++i) b.part[p][i] = 0;
-	b.pad[0] = b.pad[1] = 0;
+	for (int p = 0; p < WL_MAX_PARTS; ++p) { for (int i = 0; i < 32; ++i) b.part[p][i] = 0; b.len[p] = 0; }
 	b.cell = cells[f];
 	const unsigned long long code = cell_cb[b.cell];
-	if (code & ESCAPE_BIT) { b.len[0] = 0xFF; b.len[1] = 0; out[f] = b; return; }
+	if (code & ESCAPE_BIT) { b.len[0] = 0xFF; out[f] = b; return; }
 	const uint32_t len = uint32_t(bit_length(code) - 1) / 2;
-	uint32_t la, lb;
-	if (const_kind) { la = len1; lb = len2; if (len != len1 + len2) { atomicMax(bad, 1u); la = lb = 0; } }
-	else { lb = len2; if (len < len2) { atomicMax(bad, 1u); la = lb = 0; } else la = len - len2; }
-	if (la > uint32_t(WL_MAX_LEN) || lb > uint32_t(WL_MAX_LEN)) { atomicMax(bad, 2u); la = lb = 0; }
-	for (uint32_t i = 0; i < la; ++i) b.part[0][i] = "ACGT"[(code >> (2 * (len - 1 - i))) & 3];
-	for (uint32_t i = 0; i < lb; ++i) b.part[1][i] = "ACGT"[(code >> (2 * (lb - 1 - i))) & 3];
-	b.len[0] = uint8_t(la); b.len[1] = uint8_t(lb);
+	uint32_t lens[WL_MAX_PARTS];
+	bool ok = true;
+	if (sp.const_kind) {
+		uint32_t total = 0;
+		for (uint32_t p = 0; p < sp.n_parts; ++p) { lens[p] = sp.len[p]; total += lens[p]; }
+		if (len != total) { atomicMax(bad, 1u); ok = false; }
+	} else {
+		lens[1] = sp.len[1];
+		if (len < lens[1]) { atomicMax(bad, 1u); ok = false; } else lens[0] = len - lens[1];
+	}
+	if (ok) for (uint32_t p = 0; p < sp.n_parts; ++p) if (lens[p] > uint32_t(WL_MAX_LEN)) { atomicMax(bad, 2u); ok = false; }
+	if (ok) {
+		uint32_t at = 0;                                   // bases consumed so far, from the first base of the barcode
+		for (uint32_t p = 0; p < sp.n_parts; ++p) {
+			for (uint32_t i = 0; i < lens[p]; ++i) b.part[p][i] = "ACGT"[(code >> (2 * (len - 1 - (at + i)))) & 3];
+			b.len[p] = uint8_t(lens[p]);
+			at += lens[p];
+		}
+	}
 	out[f] = b;
 }
 

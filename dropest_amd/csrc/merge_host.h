@@ -11,29 +11,36 @@
 namespace {
 
 struct PartDistH { size_t index; long value; };            // Tools/IndexedValue.h
-struct ComboH { size_t i0, i1; unsigned ed; };
+struct ComboH { size_t idx[dropest::WL_MAX_PARTS]; unsigned ed; };   // BarcodesParser::BarcodesDistance
+
+// BarcodesParser::push_remaining_dists (BarcodesParser.cpp:52-74): nested walk of the per-part lists in part order;
+// the first entry that takes the running distance beyond the limit ends the walk of that list (the lists are sorted)
+void push_remaining_dists(const std::vector<std::vector<PartDistH>> &d, size_t part, unsigned ed, ComboH &cur, std::vector<ComboH> &res) {
+	if (part == d.size()) { cur.ed = ed; res.push_back(cur); return; }
+	for (const PartDistH &x : d[part]) {
+		const unsigned cur_ed = ed + unsigned(x.value);
+		if (cur_ed > unsigned(dropest::WL_MAX_DIST)) return;
+		cur.idx[part] = x.index;
+		push_remaining_dists(d, part + 1, cur_ed, cur, res);
+	}
+}
 
 // Reference ORDER of the candidate list for one cell, rebuilt from the device-computed per-part distances with
 // the same std::sort calls on the same sequences (BarcodesParser.cpp:21-74, RealBarcodesMergeStrategy.cpp:63-109).
 // Only needed when the arg-max of the merge fraction is tied (the reference's result then depends on this order).
 std::vector<u32> reference_candidate_order(const dropest::Whitelist &wl, const uint8_t *dist,
                                            const std::unordered_map<u64, u32> &qualifying_by_code, bool poisson) {
-	std::vector<std::vector<PartDistH>> d(2);
+	const size_t P = wl.parts.size();
+	std::vector<std::vector<PartDistH>> d(P);
 	size_t off = 0;
-	for (int p = 0; p < 2; ++p) {
-		for (size_t i = 0; i < wl.parts[size_t(p)].size(); ++i) d[size_t(p)].push_back(PartDistH{i, long(dist[off + i])});
-		std::sort(d[size_t(p)].begin(), d[size_t(p)].end(), [](const PartDistH &x, const PartDistH &y) { return x.value < y.value; });
-		off += wl.parts[size_t(p)].size();
+	for (size_t p = 0; p < P; ++p) {
+		for (size_t i = 0; i < wl.parts[p].size(); ++i) d[p].push_back(PartDistH{i, long(dist[off + i])});
+		std::sort(d[p].begin(), d[p].end(), [](const PartDistH &x, const PartDistH &y) { return x.value < y.value; });
+		off += wl.parts[p].size();
 	}
 	std::vector<ComboH> combos;
-	for (const PartDistH &a : d[0]) {
-		if (unsigned(a.value) > unsigned(dropest::WL_MAX_DIST)) break;
-		for (const PartDistH &b : d[1]) {
-			const unsigned ed = unsigned(a.value) + unsigned(b.value);
-			if (ed > unsigned(dropest::WL_MAX_DIST)) break;
-			combos.push_back(ComboH{a.index, b.index, ed});
-		}
-	}
+	ComboH cur{};
+	push_remaining_dists(d, 0, 0, cur, combos);
 	std::vector<u32> out;
 	if (combos.empty()) return out;
 	std::sort(combos.begin(), combos.end(), [](const ComboH &x, const ComboH &y) { return x.ed < y.ed; });
@@ -41,8 +48,10 @@ std::vector<u32> reference_candidate_order(const dropest::Whitelist &wl, const u
 	if (poisson) max_dist = max_dist == 0 ? 2 : max_dist + 1;   // PoissonRealBarcodesMergeStrategy::get_max_merge_dist (:20-23)
 	for (const ComboH &c : combos) {
 		if (c.ed > max_dist && !out.empty()) break;
+		std::string text;
+		for (size_t p = 0; p < P; ++p) text += wl.parts[p][c.idx[p]];
 		u64 code = 0;
-		if (dropest::encode_code(wl.parts[0][c.i0] + wl.parts[1][c.i1], code)) {
+		if (dropest::encode_code(text, code)) {
 			auto it = qualifying_by_code.find(code);
 			if (it != qualifying_by_code.end()) out.push_back(it->second);
 		}
@@ -71,7 +80,7 @@ void dropest_ctx::upload_whitelist() {
 		if (barcodes_file.empty()) throw InvalidError("merge_kind = REAL_BARCODES needs barcodes_file");
 		wl.load(cfg.barcodes_kind, barcodes_file);
 	}
-	for (int p = 0; p < 2; ++p) {
+	for (size_t p = 0; p < wl.parts.size(); ++p) {
 		if (d_wl[p].p) continue;
 		std::vector<WlEntry> h(wl.parts[size_t(p)].size());
 		for (size_t i = 0; i < h.size(); ++i) {
@@ -114,26 +123,27 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 	scalars.ensure(16);
 	HIP_CHECK(hipMemcpyAsync(d_cells.p, cells.data(), size_t(F) * 4, hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
-	hipLaunchKernelGGL(make_bases_kernel, dim3(div_up(F, 256)), dim3(256), 0, stream, d_cells.p, F, U.cell_cb,
-	                   cfg.barcodes_kind == DROPEST_BARCODES_CONST ? 1 : 0, u32(wl.part_lengths[0]), u32(wl.part_lengths[1]),
-	                   S.d_bases.p, scalars.p);
+	const u32 P = u32(wl.parts.size());
+	WlSplit sp{};
+	sp.n_parts = P; sp.const_kind = cfg.barcodes_kind == DROPEST_BARCODES_CONST ? 1 : 0;
+	for (u32 p = 0; p < P; ++p) sp.len[p] = u32(wl.part_lengths[p]);
+	hipLaunchKernelGGL(make_bases_kernel, dim3(div_up(F, 256)), dim3(256), 0, stream, d_cells.p, F, U.cell_cb, sp, S.d_bases.p, scalars.p);
 	HIP_CHECK(hipGetLastError());
 	u32 bad = 0;
 	fetch(&bad, scalars.p, 4);
 	if (bad == 2) throw UnsupportedError("barcode part longer than 31 bases");
 	if (bad) {   // reproduce the reference's message for the first offending barcode
-		for (u32 f = 0; f < F; ++f) { std::string a, b; wl.split(U.base_barcode_text(f), a, b); }
+		for (u32 f = 0; f < F; ++f) wl.split(U.base_barcode_text(f));
 		throw InvalidError("barcode length does not fit the whitelist");
 	}
 	if (U.any_escaped) {
 		for (u32 f = 0; f < F; ++f) {
 			if (!(U.barcode_code(cells[f]) & ESCAPE_BIT)) continue;
-			std::string a, b;
-			wl.split(U.base_barcode_text(f), a, b);
+			const std::vector<std::string> pieces = wl.split(U.base_barcode_text(f));
 			WlBase wb;
 			std::memset(&wb, 0, sizeof(wb));
-			std::memcpy(wb.part[0], a.data(), a.size()); std::memcpy(wb.part[1], b.data(), b.size());
-			wb.len[0] = uint8_t(a.size()); wb.len[1] = uint8_t(b.size()); wb.cell = cells[f];
+			for (size_t p = 0; p < pieces.size(); ++p) { std::memcpy(wb.part[p], pieces[p].data(), pieces[p].size()); wb.len[p] = uint8_t(pieces[p].size()); }
+			wb.cell = cells[f];
 			HIP_CHECK(hipMemcpy(S.d_bases.p + f, &wb, sizeof(wb), hipMemcpyHostToDevice));
 		}
 	}
@@ -145,16 +155,16 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 	u32 flat_cap = std::max<u32>(F * 2u, 1024u);
 	S.cnt.resize(F); S.off.resize(F);
 	WlArgs &a = S.args;
-	S.ntot = u32(wl.parts[0].size() + wl.parts[1].size());
+	S.ntot = 0;
+	for (auto const &part : wl.parts) S.ntot += u32(part.size());
 	S.lds = ((S.ntot + 15u) & ~15u) + size_t(S.ntot) * 2;
 	for (;;) {
 		d_cnt.alloc(F); d_lvl.alloc(F); d_off.alloc(F); d_fcell.alloc(flat_cap); d_fumis.alloc(flat_cap); d_fridx.alloc(flat_cap);
 		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
 		a = WlArgs{};
 		a.bases = S.d_bases.p; a.n_bases = F;
-		a.part[0] = d_wl[0].p; a.part[1] = d_wl[1].p;
-		a.part_code[0] = d_wl_code[0].p; a.part_code[1] = d_wl_code[1].p;
-		a.part_size[0] = u32(wl.parts[0].size()); a.part_size[1] = u32(wl.parts[1].size());
+		a.n_parts = P;
+		for (u32 p = 0; p < P; ++p) { a.part[p] = d_wl[p].p; a.part_code[p] = d_wl_code[p].p; a.part_size[p] = u32(wl.parts[p].size()); }
 		a.table = U.table; a.cell_n_genes = U.n_genes; a.cell_total_umis = U.total_umis; a.min_genes = min_before;
 		a.cand_count = d_cnt.p; a.cand_level = d_lvl.p; a.cand_off = d_off.p; a.flat_cell = d_fcell.p; a.flat_umis = d_fumis.p;
 		a.flat_ridx = d_fridx.p; a.cell_real_index = U.real_index;

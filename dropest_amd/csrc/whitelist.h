@@ -75,23 +75,27 @@ struct Whitelist {
 				if (s.find('N') != std::string::npos) throw UnsupportedError("whitelist entries containing N are not supported");
 			}
 		}
-		if (parts.size() != 2) throw UnsupportedError("this build handles whitelists with exactly two parts (got " +
-		                                              std::to_string(parts.size()) + ")");
-		if (parts[0].size() > 65535 || parts[1].size() > 65535) throw UnsupportedError("whitelist part with more than 65535 entries");
+		if (parts.size() > size_t(WL_MAX_PARTS))
+			throw UnsupportedError("this build handles whitelists of up to " + std::to_string(WL_MAX_PARTS) + " parts (got " +
+			                       std::to_string(parts.size()) + ")");
+		for (auto &p : parts) if (p.size() > 65535) throw UnsupportedError("whitelist part with more than 65535 entries");
 		loaded = true;
 	}
 	// BarcodesParser::split_barcode: InDropBarcodesParser.cpp:32-39 / ConstLengthBarcodesParser.cpp:33-48
-	void split(const std::string &cb, std::string &a, std::string &b) const {
+	std::vector<std::string> split(const std::string &cb) const {
+		std::vector<std::string> out;
 		if (kind == 0) {
 			const size_t l2 = part_lengths[1];
 			if (cb.size() < l2) throw InvalidError("Barcode '" + cb + "' is shorter than the second whitelist part");
-			a = cb.substr(0, cb.size() - l2); b = cb.substr(cb.size() - l2);
+			out.push_back(cb.substr(0, cb.size() - l2)); out.push_back(cb.substr(cb.size() - l2));
 		} else {
 			if (cb.size() != total_length)
 				throw InvalidError("Barcode '" + cb + "' has wrong length (" + std::to_string(total_length) + " expected)");
-			a = cb.substr(0, part_lengths[0]); b = cb.substr(part_lengths[0], part_lengths[1]);
+			size_t at = 0;
+			for (size_t l : part_lengths) { out.push_back(cb.substr(at, l)); at += l; }
 		}
-		if (a.size() > size_t(WL_MAX_LEN) || b.size() > size_t(WL_MAX_LEN)) throw UnsupportedError("barcode part longer than 31 bases");
+		for (auto &x : out) if (x.size() > size_t(WL_MAX_LEN)) throw UnsupportedError("barcode part longer than 31 bases");
+		return out;
 	}
 };
 

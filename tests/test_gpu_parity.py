@@ -748,3 +748,24 @@ def test_merge_all_synthetic(max_ed):
     parity.compare(o, c)
     mt = c.merge_targets()
     assert int((mt != np.arange(len(mt))).sum()) > 20
+
+
+# ---------------------------------------------------------------------------------------------------
+# whitelists of three parts (the reference's data/barcodes/split_seq and 10x_v2_0_split, configs/split_seq.xml)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("whitelist,poisson", [("split_seq", False), ("10x_v2_0_split", False), ("split_seq", True)])
+def test_three_part_whitelist_merge(whitelist, poisson):
+    s = SynthStream(n_reads=150_000, whitelist=whitelist, cb_len=24, n_cells=30, n_genes=1500, umi_len=10, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    path = os.path.join(DATA, whitelist)
+    if poisson:
+        okw, gkw = _poisson_kw(path, capi.BARCODES_CONST, 3, 10)
+    else:
+        okw = dict(merge_kind=1, barcodes_kind=1, barcodes_file=path, min_genes_before=3, min_genes_after=10, min_merge_fraction=0.0)
+        gkw = dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST, barcodes_file=path, min_genes_before_merge=3,
+                   min_genes_after_merge=10, min_merge_fraction=0.0)
+    o = parity.oracle_run(Oracle, okw, cb, umi, gene, aux)
+    c = parity.gpu_run(gkw, cb, umi, gene, aux)
+    parity.compare(o, c)
+    mt = c.merge_targets()
+    assert int((mt != np.arange(len(mt))).sum()) > 20

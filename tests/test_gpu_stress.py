@@ -121,11 +121,19 @@ def test_random_whitelist_merges(seed, poisson, tmp_path):
     l1 = int(rng.integers(3, 7)); l2 = int(rng.integers(5, 9))
     p1 = sorted({rnd(l1 if const_kind else int(rng.integers(l1, l1 + 2))) for _ in range(int(rng.integers(3, 9)))})
     p2 = sorted({rnd(l2) for _ in range(int(rng.integers(3, 10)))})
+    lines = [p1, p2]
+    if const_kind and seed % 3 != 1:   # const-length files may have any number of lines: one, three or four parts too
+        n_parts = int(rng.choice([1, 3, 4]))
+        lines = ([p1] if n_parts == 1 else
+                 [p1, p2] + [sorted({rnd(int(rng.integers(2, 5)) if k == 0 else 3) for _ in range(int(rng.integers(2, 6)))}) for k in range(n_parts - 2)])
+        for k in range(2, len(lines)):     # one length per line
+            L = len(lines[k][0]); lines[k] = sorted({x[:L].ljust(L, "A") for x in lines[k]})
     wl = tmp_path / "wl"
     # the file stores reverse complements (the loader reverses them back, BarcodesParser.cpp:140)
-    wl.write_text(" ".join("".join(rc[c] for c in reversed(s)) for s in p1) + "\n" +
-                  " ".join("".join(rc[c] for c in reversed(s)) for s in p2) + "\n")
-    real = [a + b for a in p1 for b in p2]
+    wl.write_text("".join(" ".join("".join(rc[c] for c in reversed(s)) for s in part) + "\n" for part in lines))
+    real = [""]
+    for part in lines:
+        real = [a + b for a in real for b in part]
     rng.shuffle(real)
     real = real[:max(2, len(real) // 2)]
 

@@ -369,3 +369,23 @@ def test_gtf_container_init_and_intron_queries():
     assert g.query("chr1", 24750, 24760) == [("WASH7P", "EXON")]
     assert g.query("chr1", 10, 20) == []
     assert g.query("chrNope", 10, 20) is None
+
+
+def test_const_length_whitelists_of_three_parts():
+    """ConstLengthBarcodesParser reads one part per line, any number of lines (ConstLengthBarcodesParser.cpp:50-68); the
+    reference ships two three-part files (data/barcodes/split_seq for configs/split_seq.xml, 10x_v2_0_split).  The parts
+    are reverse-complemented one by one and split_barcode cuts the barcode in file order (:33-48)."""
+    o = Oracle()
+    o.wl_load(1, os.path.join(DATA, "split_seq"))
+    assert o.wl_parts() == 3 and [len(o.wl_part(p)) for p in range(3)] == [96, 96, 96]
+    raw = open(os.path.join(DATA, "split_seq")).read().split("\n")[1].split()[0]
+    assert o.wl_part(1)[0] == "".join({"A": "T", "C": "G", "G": "C", "T": "A"}[c] for c in reversed(raw))
+    cb = o.wl_part(0)[5] + o.wl_part(1)[7] + o.wl_part(2)[11]
+    assert o.wl_split(cb) == [o.wl_part(0)[5], o.wl_part(1)[7], o.wl_part(2)[11]]
+    for p, i in ((0, 5), (1, 7), (2, 11)):
+        vals, idx = o.wl_distances(cb, p)
+        assert vals[0] == 0 and idx[0] == i and np.all(np.diff(vals) >= 0)      # sorted by distance, the exact entry first
+    with pytest.raises(RuntimeError):
+        o.wl_split(cb[:-1])                                                         # wrong total length
+    o.wl_load(1, os.path.join(DATA, "10x_v2_0_split"))
+    assert [len(o.wl_part(p)) for p in range(3)] == [384, 1248, 3840]
