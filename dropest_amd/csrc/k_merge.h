@@ -133,11 +133,13 @@ struct WlArgs {
 };
 
 // one block per filtered cell; dynamic LDS: dist bytes [ntot] + index lists u16 [ntot], ntot = entries of all parts
+// (the number of parts is a template parameter: the per-part arrays then live in registers, not in scratch)
+template <uint32_t P>
 __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const uint32_t P = a.n_parts;
 	uint32_t poff[WL_MAX_PARTS + 1];                  // first entry of each part in dist / lists
 	poff[0] = 0;
+#pragma unroll
 	for (uint32_t p = 0; p < P; ++p) poff[p + 1] = poff[p] + a.part_size[p];
 	const uint32_t ntot = poff[P];
 	uint8_t *dist = smem;                                             // [ntot]
@@ -156,6 +158,7 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 	__syncthreads();
 
 	// 1. distances of every part to every whitelist entry of that part
+#pragma unroll
 	for (uint32_t p = 0; p < P; ++p) {
 		uint32_t peq[5], wild;
 		wl_build_peq(b.part[p], b.len[p], peq, wild);
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 	}
 	__syncthreads();
 	// 2. index lists grouped by distance (order inside a group is irrelevant: candidates form a set)
+#pragma unroll
 	for (uint32_t p = 0; p < P; ++p) {
 		const uint32_t np = a.part_size[p], off = poff[p];
 		for (uint32_t i = tid; i < np; i += WL_THREADS) {
@@ -191,12 +195,14 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 	//    distances with that sum; a tuple contributes the product of its parts' lists.
 	const uint32_t base_umis = a.cell_total_umis[b.cell];
 	uint32_t min_level = 0;
+#pragma unroll
 	for (uint32_t p = 0; p < P; ++p) {
 		uint32_t m = WL_MAX_DIST + 1;
 		for (uint32_t d = 0; d <= WL_MAX_DIST; ++d) if (cnt[p][d]) { m = d; break; }
 		min_level += m;                                   // (> WL_MAX_DIST when a part has no entry that close)
 	}
 	uint32_t n_tuples = 1;
+#pragma unroll
 	for (uint32_t p = 0; p < P; ++p) n_tuples *= WL_MAX_DIST + 1;
 	uint32_t max_dist = a.poisson ? (min_level == 0 ? 2u : min_level + 1u) : min_level;
 	uint32_t level = min_level, last_level = min_level;
@@ -205,22 +211,43 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 		for (uint32_t t = 0; t < n_tuples; ++t) {
 			uint32_t dd[WL_MAX_PARTS], cc[WL_MAX_PARTS], sum = 0, x = t;
 			unsigned long long combos = 1;
+#pragma unroll
 			for (uint32_t p = 0; p < P; ++p) { dd[p] = x % (WL_MAX_DIST + 1); x /= WL_MAX_DIST + 1; sum += dd[p]; cc[p] = cnt[p][dd[p]]; combos *= cc[p]; }
 			if (sum != level || combos == 0) continue;
-			for (unsigned long long q = tid; q < combos; q += WL_THREADS) {
-				// packed code of the concatenation (sentinel bit first; entries of a part may differ in length)
-				unsigned long long code = 1ull, r = q;
-				for (uint32_t p = 0; p < P; ++p) {
-					const uint32_t i = lists[start[p][dd[p]] + uint32_t(r % cc[p])];
-					r /= cc[p];
-					code = wl_append(code, a.part[p][i].seq);
-				}
+			auto probe = [&](unsigned long long code) {
 				const uint32_t s = cb_find(a.table, code);
-				if (s == 0xFFFFFFFFu) continue;
+				if (s == 0xFFFFFFFFu) return;
 				const uint32_t c = a.table.slots[s].cell_id;
 				if (a.cell_n_genes[c] >= a.min_genes && a.cell_total_umis[c] >= base_umis) {
 					const uint32_t k = atomicAdd(&n_found, 1u);
 					if (k < WL_CAND_CAP) found[k] = c;
+				}
+			};
+			// packed code of the concatenation (sentinel bit first; entries of a part may differ in length); mixed-radix
+			// decoding of the combination number in 32-bit arithmetic whenever it fits (64-bit divisions are slow)
+			if (combos <= 0xFFFFFFFFull) {
+				const uint32_t n32 = uint32_t(combos);
+				for (uint32_t q = tid; q < n32; q += WL_THREADS) {
+					unsigned long long code = 1ull;
+					uint32_t r = q;
+#pragma unroll
+					for (uint32_t p = 0; p + 1 < P; ++p) {
+						const uint32_t quot = r / cc[p];
+						code = wl_append(code, a.part[p][lists[start[p][dd[p]] + (r - quot * cc[p])]].seq);
+						r = quot;
+					}
+					code = wl_append(code, a.part[P - 1][lists[start[P - 1][dd[P - 1]] + r]].seq);
+					probe(code);
+				}
+			} else {
+				for (unsigned long long q = tid; q < combos; q += WL_THREADS) {
+					unsigned long long code = 1ull, r = q;
+#pragma unroll
+					for (uint32_t p = 0; p < P; ++p) {
+						code = wl_append(code, a.part[p][lists[start[p][dd[p]] + uint32_t(r % cc[p])]].seq);
+						r /= cc[p];
+					}
+					probe(code);
 				}
 			}
 		}
@@ -244,6 +271,15 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 		if (o < a.flat_cap) {
 			a.flat_cell[o] = found[k]; a.flat_umis[o] = a.cell_total_umis[found[k]]; a.flat_ridx[o] = a.cell_real_index[found[k]];
 		}
+	}
+}
+
+inline void wl_neighbours_launch(const WlArgs &a, uint32_t n_blocks, size_t lds, hipStream_t stream) {
+	switch (a.n_parts) {
+		case 1: hipLaunchKernelGGL(wl_neighbours_kernel<1>, dim3(n_blocks), dim3(WL_THREADS), lds, stream, a); break;
+		case 2: hipLaunchKernelGGL(wl_neighbours_kernel<2>, dim3(n_blocks), dim3(WL_THREADS), lds, stream, a); break;
+		case 3: hipLaunchKernelGGL(wl_neighbours_kernel<3>, dim3(n_blocks), dim3(WL_THREADS), lds, stream, a); break;
+		default: hipLaunchKernelGGL(wl_neighbours_kernel<4>, dim3(n_blocks), dim3(WL_THREADS), lds, stream, a); break;
 	}
 }
 

@@ -171,7 +171,7 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 		a.flat_total = scalars.p; a.flat_cap = flat_cap; a.dist_dump = nullptr;
 		a.poisson = cfg.merge_kind == DROPEST_MERGE_POISSON_REAL ? 1 : 0;
 		timed("wl_neighbours", double(F) * S.ntot * 32, [&] {
-			hipLaunchKernelGGL(wl_neighbours_kernel, dim3(F), dim3(WL_THREADS), S.lds, stream, a);
+			wl_neighbours_launch(a, F, S.lds, stream);
 		});
 		u32 total = 0;
 		fetch(&total, scalars.p, 4);
@@ -229,7 +229,7 @@ std::vector<std::vector<u32>> dropest_ctx::replay_candidate_orders(const MergeUn
 	WlArgs a2 = S.args;
 	a2.bases = d_rb.p; a2.n_bases = R; a2.cand_count = d_c2.p; a2.cand_level = d_l2.p; a2.cand_off = d_o2.p;
 	a2.flat_cell = d_f2.p; a2.flat_umis = d_u2.p; a2.flat_ridx = d_r2.p; a2.flat_cap = R * u32(WL_CAND_CAP); a2.dist_dump = d_dump.p;
-	hipLaunchKernelGGL(wl_neighbours_kernel, dim3(R), dim3(WL_THREADS), S.lds, stream, a2);
+	wl_neighbours_launch(a2, R, S.lds, stream);
 	HIP_CHECK(hipGetLastError());
 	std::vector<uint8_t> dump(size_t(R) * ntot);
 	fetch(dump.data(), d_dump.p, dump.size());
