@@ -106,6 +106,7 @@ def lib():
         "dropest_count_matrix": (C.c_int, [vp, C.c_int, C.c_int, u64p, vp, vp, vp]),
         "dropest_count_matrix_csc": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
         "dropest_chr_stats": (C.c_int, [vp, u64p, vp, vp, vp, vp]),
+        "dropest_count_matrix_csc_levels": (C.c_int, [vp, C.c_char_p, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
         "dropest_merge_target": (C.c_int, [vp, C.c_uint64, P(C.c_int64)]),
         "dropest_set_umi_qualities": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64]),
         "dropest_umi_quality_length": (C.c_int, [vp, P(C.c_uint32)]),
@@ -163,7 +164,7 @@ EXPORTED_SYMBOLS = [
     "dropest_merge_and_filter", "dropest_reset_results", "dropest_total_cells", "dropest_real_cells",
     "dropest_cell_rows", "dropest_cell_id_by_cb", "dropest_filtered_cells", "dropest_merge_targets",
     "dropest_global_counters", "dropest_cell_molecules", "dropest_molecules", "dropest_count_matrix",
-    "dropest_count_matrix_csc", "dropest_owner_of", "dropest_partition_by_owner", "dropest_partition_scratch_bytes", "dropest_clear_reads",
+    "dropest_count_matrix_csc", "dropest_count_matrix_csc_levels", "dropest_owner_of", "dropest_partition_by_owner", "dropest_partition_scratch_bytes", "dropest_clear_reads",
     "dropest_count_matrix_device", "dropest_cell_first_reads_device", "dropest_assemble_columns", "dropest_assemble_columns_async",
     "dropest_real_candidate_rows", "dropest_dev_copy_device", "dropest_umi_distribution",
     "dropest_collisions_adjusted_sizes", "dropest_poisson_intersection_prob",
@@ -359,6 +360,22 @@ class Context:
                 return np.zeros(0, np.uint32)
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n,))
         return view(pc, ncols.value + 1), view(pr, nnz.value), view(pv, nnz.value)
+
+    def count_matrix_levels(self, levels, reads_output=False):
+        """Filtered count matrix under another mark query, as triplets (gene, column, value) in column-major order."""
+        ncols, nnz = C.c_uint64(), C.c_uint64()
+        pc, pr, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.L.dropest_count_matrix_csc_levels(self.h, levels.encode(), int(reads_output), C.byref(ncols), C.byref(nnz),
+                                                         C.byref(pc), C.byref(pr), C.byref(pv)))
+        n = nnz.value
+        if n == 0:
+            z = np.zeros(0, np.uint32)
+            return z, z, z
+        colptr = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_uint32)), shape=(ncols.value + 1,))
+        rows = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_uint32)), shape=(n,)).copy()
+        vals = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_uint32)), shape=(n,)).copy()
+        cols = np.repeat(np.arange(ncols.value, dtype=np.uint32), np.diff(colptr.astype(np.int64)))
+        return rows, cols, vals
 
     def count_matrix_device(self, filtered=True, reads_output=False):
         """(colptr numpy copy, d_rowidx, d_values, nnz): row indices / values stay in HBM (raw device pointers)."""

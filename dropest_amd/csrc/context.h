@@ -184,7 +184,7 @@ struct dropest_ctx {
 		dropest::PinnedBuf<u32> h_row, h_val;
 		std::vector<u32> colptr;
 		uint64_t nnz = 0, ncols = 0;
-	} mat[2];
+	} mat[3];   // cm, cm_raw, and the filtered matrix under another mark query (emit_matrix_levels)
 	dropest::DevBuf<dropest::IngestStats> d_ingest;
 	dropest::DevBuf<dropest::GlobalCounters> d_counters;
 
@@ -271,6 +271,7 @@ struct dropest_ctx {
 	void run_cb_merge_real();
 	void run_cb_merge_simple();                  // SimpleMergeStrategy (simple_merge.h)
 	void run_cb_merge_all();                     // MergeAllMergeStrategy (merge_all.h)
+	void emit_matrix_levels(u32 query_mask, bool reads_output);   // get_count_matrix_filtered(container, query)
 	// sharded runs (merge_shard.h): ingest / merge phases with collectives between them
 	struct ShardMerge;
 	std::shared_ptr<ShardMerge> shard;

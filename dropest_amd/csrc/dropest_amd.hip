@@ -783,6 +783,66 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host) 
 	collect_timings();
 }
 
+// ResultsPrinter::get_count_matrix_filtered(container, query_marks) (ResultsPrinter.cpp:333-361) for a query other than
+// the container's own: columns = the filtered cells, values = UMIs (reads) of each gene whose mark matches, zero
+// entries dropped (Cell::requested_umis_per_gene, Cell.cpp:54-68).
+void dropest_ctx::emit_matrix_levels(u32 mask, bool reads_output) {
+	HostStage hs(this, "matrix:levels");
+	MatrixResult &M = mat[2];
+	M.colptr.assign(1, 0); M.nnz = 0; M.ncols = 0;
+	filtered_cells();
+	std::vector<u32> col_cell;
+	for (u32 ri : filtered_ridx) col_cell.push_back(real[ri].id);
+	const u32 ncols = u32(col_cell.size());
+	M.ncols = ncols;
+	M.colptr.assign(size_t(ncols) + 1, 0);
+	if (!ncols || !n_cg) return;
+	DevBuf<u32> d_value, d_count;
+	d_value.alloc(n_cg); d_count.alloc(ncols);
+	hipLaunchKernelGGL(cg_requested_by_mask_kernel, dim3(div_up(n_cg, 256)), dim3(256), 0, stream, cg_mol_begin.p, n_cg, mol_mark.p, mol_reads.p,
+	                   mask, reads_output ? 1 : 0, d_value.p);
+	HIP_CHECK(hipGetLastError());
+	// groups rewritten by a UMI merge on the host: their molecules live in the override map
+	for (auto const &kv : umi_overrides) {
+		const u32 cell = u32(kv.first >> layout.gene_bits);
+		u32 cgb = 0, cgc = 0;
+		HIP_CHECK(hipMemcpy(&cgb, cell_cg_begin.p + cell, 4, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpy(&cgc, cell_cg_count.p + cell, 4, hipMemcpyDeviceToHost));
+		std::vector<u64> keys(cgc);
+		HIP_CHECK(hipMemcpy(keys.data(), cg_key.p + cgb, size_t(cgc) * 8, hipMemcpyDeviceToHost));
+		for (u32 j = 0; j < cgc; ++j) {
+			if (keys[j] != kv.first) continue;
+			u32 v = 0;
+			for (const UmiOverride &o : kv.second) if ((mask >> (o.mark & 7u)) & 1u) v += reads_output ? o.reads : 1u;
+			HIP_CHECK(hipMemcpy(d_value.p + cgb + j, &v, 4, hipMemcpyHostToDevice));
+		}
+	}
+	m_col_cell.ensure(ncols); m_col_start.ensure(ncols);
+	HIP_CHECK(hipMemcpyAsync(m_col_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
+	hipLaunchKernelGGL(count_nonzero_rows_kernel, dim3(div_up(ncols, 256)), dim3(256), 0, stream, m_col_cell.p, ncols, cell_cg_begin.p,
+	                   cell_cg_count.p, cg_key.p, layout.gene_none, d_value.p, d_count.p);
+	HIP_CHECK(hipGetLastError());
+	std::vector<u32> cnt(ncols);
+	fetch(cnt.data(), d_count.p, size_t(ncols) * 4);
+	uint64_t nnz = 0;
+	for (u32 c = 0; c < ncols; ++c) { M.colptr[c] = u32(nnz); nnz += cnt[c]; }
+	if (nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
+	M.colptr[ncols] = u32(nnz);
+	M.nnz = nnz;
+	if (!nnz) return;
+	M.d_row.ensure(nnz); M.d_val.ensure(nnz); M.h_row.ensure(nnz); M.h_val.ensure(nnz);
+	HIP_CHECK(hipMemcpyAsync(m_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
+	MatrixArgs a{};
+	a.col_cell = m_col_cell.p; a.col_start = m_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
+	a.value = d_value.p; a.gene_mask = layout.gene_none; a.skip_zero = 1;
+	a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
+	hipLaunchKernelGGL(emit_matrix_kernel, dim3(ncols), dim3(256), 0, stream, a);
+	HIP_CHECK(hipGetLastError());
+	HIP_CHECK(hipMemcpyAsync(M.h_row.p, M.d_row.p, nnz * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipMemcpyAsync(M.h_val.p, M.d_val.p, nnz * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+}
+
 // Walks a fetched slice of the molecule table in order, skipping the pseudo rows of gene-less reads and replacing
 // the groups that the N-UMI merge rewrote by their host-side contents.
 // `emit` also receives the molecule row whose quality sums the molecule shows (first_row = row of k[0]).
@@ -1252,6 +1312,18 @@ dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int read
 		need_init(ctx);
 		ctx->emit_matrix(filtered != 0, reads_output != 0);
 		const dropest_ctx::MatrixResult &M = ctx->mat[filtered ? 0 : 1];
+		*ncols = M.ncols; *nnz = M.nnz;
+		*colptr = M.colptr.data(); *rowidx = M.h_row.p; *values = M.h_val.p;
+	});
+}
+
+dropest_status dropest_count_matrix_csc_levels(dropest_ctx *ctx, const char *gene_match_levels, int reads_output, uint64_t *ncols,
+                                               uint64_t *nnz, const uint32_t **colptr, const uint32_t **rowidx, const uint32_t **values) {
+	return guarded([&] {
+		need_init(ctx);
+		if (!gene_match_levels) throw InvalidError("null gene_match_levels");
+		ctx->emit_matrix_levels(query_mask_from_code(gene_match_levels), reads_output != 0);
+		const dropest_ctx::MatrixResult &M = ctx->mat[2];
 		*ncols = M.ncols; *nnz = M.nnz;
 		*colptr = M.colptr.data(); *rowidx = M.h_row.p; *values = M.h_val.p;
 	});

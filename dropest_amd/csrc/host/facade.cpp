@@ -411,11 +411,36 @@ std::unordered_map<std::string, size_t> Cell::requested_umis_per_gene(const UMI:
 
 // ---- ResultsPrinter ---------------------------------------------------------------------------------
 ResultsPrinter::SparseMatrix ResultsPrinter::get_count_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order) const {
-	SparseMatrix M;
 	uint64_t ncols = 0, nnz = 0;
 	const uint32_t *colptr = nullptr, *rowidx = nullptr, *values = nullptr;
 	if (dropest_count_matrix_csc(c.handle(), filtered ? 1 : 0, reads_output ? 1 : 0, &ncols, &nnz, &colptr, &rowidx, &values) != DROPEST_OK)
 		throw std::runtime_error(dropest_last_error());
+	return named_matrix(c, filtered, reference_row_order, ncols, nnz, colptr, rowidx, values);
+}
+
+static std::string levels_code(const UMI::Mark::query_t &query) {   // inverse of UMI::Mark::get_by_code (UMI.cpp:112-154)
+	std::string code;
+	for (const UMI::Mark &m : query) {
+		const bool e = m.check(UMI::Mark::HAS_EXONS), i = m.check(UMI::Mark::HAS_INTRONS), n = m.check(UMI::Mark::HAS_NOT_ANNOTATED);
+		if (e && !i && !n) code += 'e'; else if (!e && i && !n) code += 'i'; else if (e && !i && n) code += 'E';
+		else if (!e && i && n) code += 'I'; else if (e && i && !n) code += 'B'; else if (e && i && n) code += 'A';
+		else throw std::runtime_error("Unexpected gene match level");
+	}
+	return code;
+}
+
+ResultsPrinter::SparseMatrix ResultsPrinter::get_count_matrix_filtered(const CellsDataContainer &c, const UMI::Mark::query_t &query,
+                                                                       bool reference_row_order) const {
+	uint64_t ncols = 0, nnz = 0;
+	const uint32_t *colptr = nullptr, *rowidx = nullptr, *values = nullptr;
+	if (dropest_count_matrix_csc_levels(c.handle(), levels_code(query).c_str(), reads_output ? 1 : 0, &ncols, &nnz, &colptr, &rowidx, &values) != DROPEST_OK)
+		throw std::runtime_error(dropest_last_error());
+	return named_matrix(c, true, reference_row_order, ncols, nnz, colptr, rowidx, values);
+}
+
+ResultsPrinter::SparseMatrix ResultsPrinter::named_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order, uint64_t ncols,
+                                                          uint64_t nnz, const uint32_t *colptr, const uint32_t *rowidx, const uint32_t *values) const {
+	SparseMatrix M;
 	// column names: filtered cells in their order / real cells in cell-id order
 	if (filtered) { for (size_t id : c.filtered_cells()) M.col_names.push_back(c.cell(id).barcode()); }
 	else {
@@ -585,6 +610,18 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 		                                                     {"reads_per_umi", list(std::move(per_gene))}}));
 	}
 	return named_list(std::move(d));
+}
+
+void ResultsPrinter::save_intron_exon_matrices(const CellsDataContainer &c, const std::string &filename) const {   // ResultsPrinter.cpp:455-474
+	using namespace Rds;
+	auto m = [&](const char *code) {
+		const SparseMatrix M = get_count_matrix_filtered(c, UMI::Mark::get_by_code(code), true);
+		return dgCMatrix(M.colptr, M.rowidx, M.values, M.row_names, M.col_names);
+	};
+	std::string base = filename;
+	const size_t dot = filename.find_last_of('.');
+	if (dot != std::string::npos && filename.substr(dot + 1) == "rds") base = filename.substr(0, dot);
+	Rds::save(named_list({{"exon", m("e")}, {"intron", m("i")}, {"spanning", m("BA")}}), base + ".matrices.rds");
 }
 
 void ResultsPrinter::save_results(const CellsDataContainer &c, const std::string &filename) const {   // ResultsPrinter.cpp:23-79

@@ -374,6 +374,15 @@ public:
 	// encounter while iterating an unordered_map per cell, Cell.cpp:54-68 + ResultsPrinter.cpp:345-355); false keeps
 	// rows in gene-index order.
 	SparseMatrix get_count_matrix(const CellsDataContainer &container, bool filtered, bool reference_row_order = true) const;
+	// get_count_matrix_filtered(container, query_marks) for an explicit query (ResultsPrinter.cpp:333-361)
+	SparseMatrix get_count_matrix_filtered(const CellsDataContainer &container, const UMI::Mark::query_t &query_marks,
+	                                       bool reference_row_order = true) const;
+	// <base>.matrices.rds: list(exon, intron, spanning) of dgCMatrix (-V, ResultsPrinter.cpp:455-474)
+	void save_intron_exon_matrices(const CellsDataContainer &container, const std::string &filename) const;
+private:
+	SparseMatrix named_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order, uint64_t ncols, uint64_t nnz,
+	                          const uint32_t *colptr, const uint32_t *rowidx, const uint32_t *values) const;
+public:
 	// <base>.mtx + <base>.cells.tsv + <base>.genes.tsv (what save_mtx writes through R's Matrix::writeMM)
 	void save_mtx(const CellsDataContainer &container, const std::string &filename_base) const;
 	// <base>.rds: the R list d = list(cm, cm_raw, reads_per_chr_per_cells, mean_reads_per_umi, saturation_info, merge_targets,

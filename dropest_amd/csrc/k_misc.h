@@ -196,6 +196,34 @@ __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
 	}
 }
 
+// requested UMIs / reads of every (cell, gene) row under ANOTHER mark query than the container's own
+// (ResultsPrinter::save_intron_exon_matrices asks for "e", "i" and "BA", ResultsPrinter.cpp:455-474)
+__global__ __launch_bounds__(256) void cg_requested_by_mask_kernel(const uint32_t *__restrict__ cg_mol_begin, uint32_t n_cg,
+                                                                   const uint32_t *__restrict__ mol_mark, const uint32_t *__restrict__ mol_reads,
+                                                                   uint32_t query_mask, int reads_output, uint32_t *__restrict__ out) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_cg) return;
+	uint32_t v = 0;
+	for (uint32_t m = cg_mol_begin[i]; m < cg_mol_begin[i + 1]; ++m)
+		if ((query_mask >> (mol_mark[m] & 7u)) & 1u) v += reads_output ? mol_reads[m] : 1u;
+	out[i] = v;
+}
+
+// non-zero gene rows of each column's cell
+__global__ __launch_bounds__(256) void count_nonzero_rows_kernel(const uint32_t *__restrict__ col_cell, uint32_t ncols,
+                                                                 const uint32_t *__restrict__ cell_cg_begin,
+                                                                 const uint32_t *__restrict__ cell_cg_count,
+                                                                 const unsigned long long *__restrict__ cg_key, unsigned long long gene_mask,
+                                                                 const uint32_t *__restrict__ value, uint32_t *__restrict__ count) {
+	const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+	if (c >= ncols) return;
+	const uint32_t cell = col_cell[c];
+	uint32_t n = 0;
+	for (uint32_t i = cell_cg_begin[cell], e = i + cell_cg_count[cell]; i < e; ++i)
+		n += (cg_key[i] & gene_mask) != gene_mask && value[i] != 0;
+	count[c] = n;
+}
+
 // ---- per-chromosome counters of real cells -------------------------------------------------------------
 // partial rows (cell << 16 | chr ; exon, intron, intergenic) are folded into a dense
 // [n_real][3][n_chr] table through the cell -> (merged) real-cell index map; rows are pre-aggregated per

@@ -188,6 +188,14 @@ dropest_status dropest_count_matrix(dropest_ctx *ctx, int filtered, int reads_ou
 dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *ncols,
                                         uint64_t *nnz, const uint32_t **colptr, const uint32_t **rowidx,
                                         const uint32_t **values);
+
+/* ResultsPrinter::get_count_matrix_filtered(container, query_marks) (ResultsPrinter.cpp:333-361) for a mark query other
+ * than the container's own -- what ResultsPrinter::save_intron_exon_matrices asks for (-V: "e", "i", "BA",
+ * ResultsPrinter.cpp:455-474).  Columns = the filtered cells in their order, zero entries dropped; same CSC
+ * conventions and lifetime as dropest_count_matrix_csc (valid until the next call of this function). */
+dropest_status dropest_count_matrix_csc_levels(dropest_ctx *ctx, const char *gene_match_levels, int reads_output,
+                                               uint64_t *ncols, uint64_t *nnz, const uint32_t **colptr,
+                                               const uint32_t **rowidx, const uint32_t **values);
 /* Per-chromosome read counts of real cells (CellsDataContainer::get_stat_by_real_cells,
  * CellsDataContainer.cpp:291-307): rows (cell id, kind 0 exon / 1 intron / 2 intergenic, chr id, count),
  * non-zero entries only, ascending (cell, kind, chr). */

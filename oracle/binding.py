@@ -76,6 +76,7 @@ def oracle_lib():
         "orc_fill_wrong_umi": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "orc_directional_targets": (C.c_int, [vp, P(C.c_char_p), vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int]),
         "orc_collisions_table": (C.c_int, [vp, u64, u64, vp]),
+        "orc_count_matrix_levels": (u64, [vp, C.c_char_p, C.c_int, vp, vp, vp]),
         "orc_add_packed_q": (C.c_int, [vp, vp, vp, vp, vp, u64, C.POINTER(C.c_char_p), vp, C.c_uint32]),
         "orc_molecule_qualities": (C.c_int, [vp, C.c_uint32, vp]),
         "orc_poisson_init": (C.c_int, [vp]), "orc_poisson_distribution_size": (u64, [vp]),
@@ -223,6 +224,13 @@ class Oracle:
         n = int(self.L.orc_count_matrix(self.h, int(filtered), int(reads_output), None, None, None))
         g = np.zeros(n, np.uint64); c = np.zeros(n, np.uint64); v = np.zeros(n, np.uint64)
         self.L.orc_count_matrix(self.h, int(filtered), int(reads_output), g.ctypes.data, c.ctypes.data, v.ctypes.data)
+        return g, c, v
+
+    def count_matrix_levels(self, levels, reads_output=False):
+        """get_count_matrix_filtered(container, query) for an explicit -L style code ("e", "i", "BA", ...)."""
+        n = int(self.L.orc_count_matrix_levels(self.h, levels.encode(), int(reads_output), None, None, None))
+        g = np.zeros(n, np.uint64); c = np.zeros(n, np.uint64); v = np.zeros(n, np.uint64)
+        self.L.orc_count_matrix_levels(self.h, levels.encode(), int(reads_output), g.ctypes.data, c.ctypes.data, v.ctypes.data)
         return g, c, v
 
     def chr_stats(self):

@@ -1024,6 +1024,24 @@ uint64_t orc_count_matrix(void *h, int filtered, int reads_output, uint64_t *gen
 	return n;
 }
 
+// ResultsPrinter::get_count_matrix_filtered(container, query_marks) for an explicit mark query
+// (save_intron_exon_matrices, ResultsPrinter.cpp:455-474): filtered cells, zero entries dropped
+uint64_t orc_count_matrix_levels(void *h, const char *levels, int reads_output, uint64_t *gene, uint64_t *col, uint64_t *val) {
+	auto *c = static_cast<orc::Container *>(h);
+	const std::vector<uint8_t> query = orc::marks_by_code(levels);
+	uint64_t n = 0, column = 0;
+	for (size_t id : c->filtered) {
+		for (auto const &g : c->cells[id].genes) {
+			const size_t v = orc::Container::requested_in_gene(g.second, query, reads_output != 0);
+			if (v == 0) continue;
+			if (gene) { gene[n] = g.first; col[n] = column; val[n] = v; }
+			++n;
+		}
+		++column;
+	}
+	return n;
+}
+
 // Per-chromosome stats of real cells (CellsDataContainer.cpp:291-307 content, order-free form):
 // rows (cell id, kind, chr id, count) for every non-zero entry of every real cell.
 uint64_t orc_chr_stats(void *h, uint64_t *cell, int32_t *kind, uint64_t *chr, int64_t *count) {

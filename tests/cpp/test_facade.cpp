@@ -173,6 +173,10 @@ static void testResultsPrinterMtx(const std::string &tmp) {   // ResultsPrinter.
 	CHECK_EQ(dense["AAATTAGGTCCC"]["Gene10"], 1u);
 	printer.save_results(c, tmp + "/cell.counts.rds");
 	ResultsPrinter(false, false, false, true).save_results(c, tmp + "/cell.counts.full.rds");   // + reads_per_umi_per_cell
+	printer.save_intron_exon_matrices(c, tmp + "/cell.counts.rds");                             // -V: cell.counts.matrices.rds
+	auto exon = printer.get_count_matrix_filtered(c, Mark::get_by_code("e"));
+	CHECK_EQ(exon.values.size(), cm.values.size());             // every read of the fixture is exonic: "e" == the default query here
+	CHECK_EQ(printer.get_count_matrix_filtered(c, Mark::get_by_code("i")).values.size(), size_t(0));
 	std::ifstream mtx(tmp + "/cell.counts.mtx");
 	std::string header; std::getline(mtx, header);
 	CHECK_EQ(header, std::string("%%MatrixMarket matrix coordinate real general"));

@@ -56,6 +56,11 @@ def test_results_rds_written_by_the_facade(tmp_path):
     assert list(chr_frames["Exon"].attributes["class"].value) == ["data.frame"]
     assert int(sum(col.value.sum() for col in chr_frames["Exon"].value)) == 16          # 17 exon reads, one of them in the excluded cell AAAAAAAAAAAA
     assert d["mean_reads_per_umi"].names == rcells and np.all(d["mean_reads_per_umi"].value >= 1.0)
+    vel = rr.read_rds(str(tmp_path / "cell.counts.matrices.rds"))                     # save_intron_exon_matrices (-V)
+    assert vel.names == ["exon", "intron", "spanning"]
+    ex, exg, exc = rr.dgcmatrix_to_dense(vel["exon"])
+    assert exc == cells and np.array_equal(ex, cm) and exg == genes                     # all reads of the fixture are exonic
+    assert rr.dgcmatrix_to_dense(vel["intron"])[0].sum() == 0 and rr.dgcmatrix_to_dense(vel["spanning"])[0].sum() == 0
     full = rr.read_rds(str(tmp_path / "cell.counts.full.rds"))
     rp = full["reads_per_umi_per_cell"]
     assert rp.names == ["cells", "genes", "cell_indexes", "gene_indexes", "reads_per_umi"]

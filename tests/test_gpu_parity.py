@@ -800,3 +800,29 @@ def test_indrop_v1_2_whitelist_with_barcodes_of_several_lengths():
     parity.compare(o, c)
     mt = c.merge_targets()
     assert int((mt != np.arange(len(mt))).sum()) >= 12
+
+
+@pytest.mark.parametrize("with_n", [False, True])
+def test_count_matrices_under_other_mark_queries(with_n):
+    """ResultsPrinter::save_intron_exon_matrices (-V): the filtered matrix for the queries "e", "i", "BA" (and a few
+    more) next to the container's own -L, with UMI counts and with read counts, also over groups rewritten by the
+    N-UMI merge."""
+    s = SynthStream(n_reads=120_000, n_cells=25, n_genes=400, umi_len=8, permille_intron=250, permille_exon_na=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    side = ()
+    if with_n:
+        umi, side = inject_n(umi, gene, 0.01, 13, 8)
+    o = parity.oracle_run(Oracle, dict(min_genes_before=3, min_genes_after=10), cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(min_genes_before_merge=3, min_genes_after_merge=10), cb, umi, gene, aux, side)
+    parity.compare(o, c, side)
+    total = 0
+    for levels in ("e", "i", "BA", "eEBA", "iI", "A"):
+        for reads_output in (False, True):
+            g, col, v = c.count_matrix_levels(levels, reads_output)
+            og, ocol, ov = o.count_matrix_levels(levels, reads_output)
+            assert np.array_equal(g.astype(np.uint64), og) and np.array_equal(col.astype(np.uint64), ocol) and np.array_equal(v.astype(np.uint64), ov), levels
+            total += len(g)
+    g0, c0, v0 = c.count_matrix(filtered=True)
+    g1, c1, v1 = c.count_matrix_levels("eEBA")
+    assert np.array_equal(g0, g1) and np.array_equal(v0, v1)            # the default query again
+    assert total > 10_000
