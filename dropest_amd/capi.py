@@ -108,6 +108,8 @@ def lib():
         "dropest_chr_stats": (C.c_int, [vp, u64p, vp, vp, vp, vp]),
         "dropest_count_matrix_csc_levels": (C.c_int, [vp, C.c_char_p, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
         "dropest_merge_target": (C.c_int, [vp, C.c_uint64, P(C.c_int64)]),
+        "dropest_exclude_cell": (C.c_int, [vp, C.c_uint64]), "dropest_merge_cells": (C.c_int, [vp, C.c_uint64, C.c_uint64]),
+        "dropest_merge_umis": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp]),
         "dropest_set_umi_qualities": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64]),
         "dropest_umi_quality_length": (C.c_int, [vp, P(C.c_uint32)]),
         "dropest_cell_molecule_qualities": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp]),
@@ -169,6 +171,7 @@ EXPORTED_SYMBOLS = [
     "dropest_real_candidate_rows", "dropest_dev_copy_device", "dropest_umi_distribution",
     "dropest_collisions_adjusted_sizes", "dropest_poisson_intersection_prob",
     "dropest_set_umi_qualities", "dropest_umi_quality_length", "dropest_cell_molecule_qualities",
+    "dropest_exclude_cell", "dropest_merge_cells", "dropest_merge_umis",
     "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_stream",
     "dropest_sort_layout", "dropest_host_register", "dropest_host_unregister", "dropest_ingest", "dropest_ingest_summary_get", "dropest_ingest_summary_set",
     "dropest_gene_chr_table", "dropest_shard_merge_search", "dropest_shard_merge_pairs", "dropest_shard_merge_export",
@@ -487,6 +490,17 @@ class Context:
         t = C.c_int64()
         self._chk(self.L.dropest_merge_target(self.h, cell, C.byref(t)))
         return t.value
+
+    def exclude_cell(self, cell):
+        self._chk(self.L.dropest_exclude_cell(self.h, cell))
+
+    def merge_cells(self, src, tgt):
+        self._chk(self.L.dropest_merge_cells(self.h, src, tgt))
+
+    def merge_umis(self, cell, gene, pairs):
+        """pairs: [(source code, target code)] applied in order (Cell::merge_umis walks the caller's map)."""
+        s = np.array([p[0] for p in pairs], np.uint64); t = np.array([p[1] for p in pairs], np.uint64)
+        self._chk(self.L.dropest_merge_umis(self.h, cell, gene, len(pairs), s.ctypes.data, t.ctypes.data))
 
     def set_umi_qualities(self, qual):
         """qual: uint8 array [n_reads, quality_length] (phred+33 characters), read order."""

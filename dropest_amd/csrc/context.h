@@ -271,6 +271,18 @@ struct dropest_ctx {
 	void run_cb_merge_real();
 	void run_cb_merge_simple();                  // SimpleMergeStrategy (simple_merge.h)
 	void run_cb_merge_all();                     // MergeAllMergeStrategy (merge_all.h)
+	// public mutators of the container (mutate_host.h)
+	std::unordered_set<u32> extra_excluded;      // excluded cells outside the host mirror of real-candidate cells
+	std::unordered_set<u32> explicit_sources;    // sources of dropest_merge_cells (not part of the strategy's merge targets)
+	void clear_strategy_pairs() {                // a strategy starts over; pairs merged by hand stay (their molecules have moved)
+		if (explicit_sources.empty()) { merge_pairs.clear(); return; }
+		std::vector<std::pair<uint64_t, uint64_t>> keep;
+		for (auto const &pr : merge_pairs) if (explicit_sources.count(u32(pr.first))) keep.push_back(pr);
+		merge_pairs.swap(keep);
+	}
+	void mutate_exclude_cell(u32 cell);
+	void mutate_merge_cells(u32 src, u32 tgt);
+	void mutate_merge_umis(u32 cell, u32 gene, uint64_t n, const uint64_t *src, const uint64_t *tgt);
 	void emit_matrix_levels(u32 query_mask, bool reads_output);   // get_count_matrix_filtered(container, query)
 	// sharded runs (merge_shard.h): ingest / merge phases with collectives between them
 	struct ShardMerge;

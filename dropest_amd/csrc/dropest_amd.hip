@@ -154,7 +154,7 @@ void dropest_ctx::free_results() {
 	shard.reset();
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
 	real.clear(); filtered.clear(); filtered_valid = false; merge_pairs.clear(); reassign.clear(); umi_overrides.clear(); n_real_now = 0;
-	merge_rank.clear(); reagg_prio = nullptr;
+	merge_rank.clear(); reagg_prio = nullptr; extra_excluded.clear(); explicit_sources.clear();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,6 +686,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 #include "poisson_merge.h"
 #include "simple_merge.h"
 #include "merge_all.h"
+#include "mutate_host.h"
 
 // ------------------------------------------------------------------------------------------------
 // top-level stages
@@ -1150,6 +1151,7 @@ dropest_status dropest_cell_rows(dropest_ctx *ctx, uint64_t first, uint64_t coun
 			r.is_merged = h.merged; r.is_excluded = h.excluded;
 			r.is_real = !h.merged && !h.excluded && h.row.n_genes >= ctx->min_before;
 		}
+		for (u32 c : ctx->extra_excluded) if (c >= first && c < first + count) out[c - first].is_excluded = 1;
 	});
 }
 
@@ -1183,9 +1185,15 @@ dropest_status dropest_merge_targets(dropest_ctx *ctx, uint64_t *n, uint64_t *sr
 	return guarded([&] {
 		need_init(ctx);
 		if (!ctx->merged) throw InvalidError("merge_and_filter has not run");
-		*n = ctx->merge_pairs.size();
-		if (src && tgt)
-			for (size_t i = 0; i < ctx->merge_pairs.size(); ++i) { src[i] = ctx->merge_pairs[i].first; tgt[i] = ctx->merge_pairs[i].second; }
+		// (pairs merged through dropest_merge_cells are not the strategy's: CellsDataContainer::_merge_targets is what
+		// MergeStrategyAbstract::merge returned, CellsDataContainer.cpp:44)
+		size_t k = 0;
+		for (auto const &pr : ctx->merge_pairs) {
+			if (ctx->explicit_sources.count(u32(pr.first))) continue;
+			if (src && tgt) { src[k] = pr.first; tgt[k] = pr.second; }
+			++k;
+		}
+		*n = k;
 	});
 }
 
@@ -1257,6 +1265,32 @@ dropest_status dropest_cell_molecules(dropest_ctx *ctx, uint64_t cell_id, uint64
 		});
 		(void)umask; (void)L;
 		*n = cnt;
+	});
+}
+
+dropest_status dropest_exclude_cell(dropest_ctx *ctx, uint64_t cell) {
+	return guarded([&] {
+		need_init(ctx);
+		if (cell >= ctx->n_cells) throw RangeError("cell index out of range");
+		ctx->mutate_exclude_cell(u32(cell));
+	});
+}
+
+dropest_status dropest_merge_cells(dropest_ctx *ctx, uint64_t source_cell, uint64_t target_cell) {
+	return guarded([&] {
+		need_init(ctx);
+		if (source_cell >= ctx->n_cells || target_cell >= ctx->n_cells) throw RangeError("cell index out of range");
+		ctx->mutate_merge_cells(u32(source_cell), u32(target_cell));
+	});
+}
+
+dropest_status dropest_merge_umis(dropest_ctx *ctx, uint64_t cell, uint32_t gene, uint64_t n, const uint64_t *source_umis,
+                                  const uint64_t *target_umis) {
+	return guarded([&] {
+		need_init(ctx);
+		if (cell >= ctx->n_cells) throw RangeError("cell index out of range");
+		if (n && (!source_umis || !target_umis)) throw InvalidError("null UMI array");
+		ctx->mutate_merge_umis(u32(cell), gene, n, source_umis, target_umis);
 	});
 }
 

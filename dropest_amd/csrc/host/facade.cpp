@@ -293,6 +293,29 @@ const CellsDataContainer::ids_t &CellsDataContainer::merge_targets() const {
 	return _merge_targets_cache;
 }
 
+void CellsDataContainer::exclude_cell(size_t index) {   // CellsDataContainer.cpp:106-109
+	if (!_is_initialized) throw std::runtime_error("You must initialize container");
+	check(dropest_exclude_cell(_ctx, index));
+}
+
+void CellsDataContainer::merge_cells(size_t source_cell_ind, size_t target_cell_ind) {   // :90-104
+	if (!_is_initialized) throw std::runtime_error("You must initialize container");
+	check(dropest_merge_cells(_ctx, source_cell_ind, target_cell_ind));
+}
+
+void CellsDataContainer::merge_umis(size_t cell_id, size_t gene, const s_s_hash_t &merge_targets) {   // :209-213, Cell.cpp:31-42
+	if (!_is_initialized) throw std::runtime_error("You must initialize container");
+	std::vector<uint64_t> src, tgt;
+	for (auto const &t : merge_targets) {   // the map's own iteration order, like Cell::merge_umis
+		src.push_back(encode(t.first, _side_umi));
+		tgt.push_back(encode(t.second, _side_umi));
+	}
+	std::vector<const char *> ptrs(_side.size());          // a target with N registers a new side string
+	for (size_t i = 0; i < _side.size(); ++i) ptrs[i] = _side[i].c_str();
+	check(dropest_set_side_strings(_ctx, ptrs.data(), ptrs.size()));
+	check(dropest_merge_umis(_ctx, cell_id, uint32_t(gene), src.size(), src.data(), tgt.data()));
+}
+
 long CellsDataContainer::get_merge_target(size_t base_cell_ind) const {
 	int64_t t = 0;
 	check(dropest_merge_target(_ctx, base_cell_ind, &t));

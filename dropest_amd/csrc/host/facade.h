@@ -340,7 +340,12 @@ public:
 	const UMI::Mark::query_t &gene_match_level() const { return _query_marks; }
 	// PoissonTargetEstimator::estimate_intersection_prob's numbers for two cells (PoissonTargetEstimator.cpp:67-94)
 	void poisson_intersection(size_t cell1_ind, size_t cell2_ind, size_t &intersection, double &expected, double &probability) const;
-	long get_merge_target(size_t base_cell_ind) const;                  // RealBarcodesMergeStrategy::get_merge_target
+	long get_merge_target(size_t base_cell_ind) const;
+	// the public mutators (CellsDataContainer.h:88-95); here they act on the initialised container
+	using s_s_hash_t = std::unordered_map<std::string, std::string>;
+	void exclude_cell(size_t index);
+	void merge_cells(size_t source_cell_ind, size_t target_cell_ind);
+	void merge_umis(size_t cell_id, size_t gene, const s_s_hash_t &merge_targets);                  // RealBarcodesMergeStrategy::get_merge_target
 
 	s_i_hash_t get_stat_by_real_cells(Stats::CellStatType type) const;
 	void get_stat_by_real_cells(Stats::CellChrStatType stat, names_t &cell_barcodes, names_t &chromosome_names,

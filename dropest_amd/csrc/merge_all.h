@@ -69,7 +69,7 @@ void dropest_ctx::run_cb_merge_all() {
 	std::vector<u32> cells(order.begin(), order.end());
 	const std::vector<u32> ridx = filtered_ridx;
 	const u32 F = u32(cells.size()), nR = u32(real.size());
-	merge_pairs.clear();
+	clear_strategy_pairs();
 	if (F == 0) return;
 	if (F >= (1u << 25)) throw UnsupportedError("merge_type = all over more than 2^25 filtered cells");
 	const u32 max_ed = u32(std::max(cfg.max_cb_merge_edit_distance, 0));

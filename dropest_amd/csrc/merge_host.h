@@ -443,7 +443,7 @@ void dropest_ctx::run_cb_merge_real() {
 		for (u32 i = 0; i < nR; ++i) merge_rank[real[i].id] = rank[i];
 	}
 	reassign.clear();
-	merge_pairs.clear();
+	clear_strategy_pairs();
 	std::vector<std::vector<std::pair<uint64_t, uint64_t>>> moved(8);
 	const unsigned workers = parallel_ranges(nR, [&](size_t b, size_t e, unsigned w) {
 		std::vector<std::pair<uint64_t, uint64_t>> mine;   // local: the slots' vector headers share cache lines

@@ -258,7 +258,7 @@ void dropest_ctx::shard_merge_finish(uint64_t n_local, const uint32_t *local_id,
 		h.excluded = excluded[i] != 0; h.merged = merged_away[i] != 0;
 		h.row.total_reads = total_reads[i]; h.row.total_umis = total_umis[i];
 	}
-	merge_pairs.clear();
+	clear_strategy_pairs();
 	for (uint64_t i = 0; i < n_moves; ++i) {
 		if (move_src[i] >= n_cells || move_tgt[i] >= n_cells) throw RangeError("merge move outside this shard");
 		merge_pairs.emplace_back(move_src[i], move_tgt[i]);

@@ -144,7 +144,7 @@ void dropest_ctx::run_cb_merge_simple() {
 	std::vector<u32> cells(order.begin(), order.end());
 	const std::vector<u32> ridx = filtered_ridx;
 	const u32 F = u32(cells.size()), nR = u32(real.size());
-	merge_pairs.clear();
+	clear_strategy_pairs();
 	if (F == 0 || n_mol == 0) return;
 	const int low_bits = layout.umi_bits + layout.gene_bits;
 

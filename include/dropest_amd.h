@@ -158,6 +158,20 @@ dropest_status dropest_global_counters(dropest_ctx *ctx, uint64_t out[4]);
 dropest_status dropest_cell_molecules(dropest_ctx *ctx, uint64_t cell, uint64_t *n, uint32_t *gene,
                                       uint64_t *umi, uint32_t *reads, uint8_t *mark);
 
+/* The container's public mutators (the reference's strategies and tests call them directly); they act on the
+ * initialised state.
+ *   exclude_cell   CellsDataContainer::exclude_cell (CellsDataContainer.cpp:106-109)
+ *   merge_cells    CellsDataContainer::merge_cells (:90-104): union of the molecules (counts add, marks OR), Stats::merge,
+ *                  the source becomes merged.  Supported between real-candidate cells (what strategies merge).
+ *   merge_umis     CellsDataContainer::merge_umis (:209-213) -> Cell::merge_umis (Cell.cpp:31-42): the (source, target)
+ *                  pairs are applied in the given order (the reference walks the caller's unordered_map); a pair with
+ *                  source == target is skipped, a missing source is DROPEST_ERR_INVALID ("Source UMI doesn't belong to
+ *                  the gene"); UMIs in the packed / escaped form of dropest_push_reads (side strings already set). */
+dropest_status dropest_exclude_cell(dropest_ctx *ctx, uint64_t cell);
+dropest_status dropest_merge_cells(dropest_ctx *ctx, uint64_t source_cell, uint64_t target_cell);
+dropest_status dropest_merge_umis(dropest_ctx *ctx, uint64_t cell, uint32_t gene, uint64_t n, const uint64_t *source_umis,
+                                  const uint64_t *target_umis);
+
 /* UMI base qualities (ReadParameters::umi_quality, Tools/ReadParameters.h:9-50): one fixed-length string per pushed
  * read, in push order, quality_length bytes each (host memory; raw phred+33 characters as in the BAM tag).  Call after
  * the last push and before set_initialized.  The container then accumulates the per-position sums of every molecule

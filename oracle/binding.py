@@ -76,6 +76,7 @@ def oracle_lib():
         "orc_fill_wrong_umi": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
         "orc_directional_targets": (C.c_int, [vp, P(C.c_char_p), vp, C.c_int, C.c_char_p, C.c_char_p, C.c_int]),
         "orc_collisions_table": (C.c_int, [vp, u64, u64, vp]),
+        "orc_merge_cells_explicit": (C.c_int, [vp, u64, u64]), "orc_exclude_cell_explicit": (C.c_int, [vp, u64]),
         "orc_count_matrix_levels": (u64, [vp, C.c_char_p, C.c_int, vp, vp, vp]),
         "orc_add_packed_q": (C.c_int, [vp, vp, vp, vp, vp, u64, C.POINTER(C.c_char_p), vp, C.c_uint32]),
         "orc_molecule_qualities": (C.c_int, [vp, C.c_uint32, vp]),
@@ -225,6 +226,12 @@ class Oracle:
         g = np.zeros(n, np.uint64); c = np.zeros(n, np.uint64); v = np.zeros(n, np.uint64)
         self.L.orc_count_matrix(self.h, int(filtered), int(reads_output), g.ctypes.data, c.ctypes.data, v.ctypes.data)
         return g, c, v
+
+    def merge_cells(self, src, tgt):
+        self._chk(self.L.orc_merge_cells_explicit(self.h, src, tgt))
+
+    def exclude_cell(self, cell):
+        self._chk(self.L.orc_exclude_cell_explicit(self.h, cell))
 
     def count_matrix_levels(self, levels, reads_output=False):
         """get_count_matrix_filtered(container, query) for an explicit -L style code ("e", "i", "BA", ...)."""

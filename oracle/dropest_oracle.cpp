@@ -1162,6 +1162,19 @@ int orc_merge_umis_explicit(void *h, uint64_t cell, const char *gene, const char
 	c->merge_umis(cell, c->gene_ix.get(gene), m);
 	ORC_CATCH
 }
+// CellsDataContainer::merge_cells / exclude_cell called directly (CellsDataContainer.cpp:90-109); the filtered list is
+// refreshed like merge_and_filter does (update_cell_sizes keeps the last threshold)
+int orc_merge_cells_explicit(void *h, uint64_t src, uint64_t tgt) {
+	ORC_TRY
+	auto *c = static_cast<orc::Container *>(h);
+	c->merge_cells(src, tgt);
+	ORC_CATCH
+}
+int orc_exclude_cell_explicit(void *h, uint64_t cell) {
+	ORC_TRY
+	static_cast<orc::Container *>(h)->cells.at(cell).excluded = true;
+	ORC_CATCH
+}
 // MergeUMIsStrategySimple::fill_wrong_umis (MergeUMIsStrategySimple.cpp:104-112)
 int orc_fill_wrong_umi(const char *umi, char *out, int cap) {
 	std::strncpy(out, orc::Container::fix_n_with_random(umi).c_str(), size_t(cap));

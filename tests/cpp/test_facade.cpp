@@ -208,6 +208,38 @@ static void testUmiDistributionAndCollisions() {   // CellsDataContainer.cpp:182
 	CHECK(adj.estimate_adjusted_gene_expression(1000) < size_t(1300));
 }
 
+static void testUMIMerge() {   // Tests/TestEstimation.cpp:468-488 (here the container is initialised first: the mutators act on the built state)
+	Fixture f;
+	CellsDataContainer container(f.real_cb_strat, f.umi_merge_strat, f.any_mark);
+	container.add_record(read_info("AAATTAGGTCCA", "AAACCT", "Gene1"));
+	container.add_record(read_info("AAATTAGGTCCA", "CCCCCT", "Gene1"));
+	container.add_record(read_info("AAATTAGGTCCA", "AAATTN", "Gene1"));
+	container.add_record(read_info("AAATTAGGTCCA", "ACCCCT", "Gene1"));
+	container.set_initialized();
+	CellsDataContainer::s_s_hash_t merge_targets;
+	merge_targets["AAACCT"] = "CCCCCT";
+	merge_targets["AAATTN"] = "GGGGGG";
+	merge_targets["ACCCCT"] = "ACCCCT";
+	container.merge_umis(0, container.gene_indexer().get_index("Gene1"), merge_targets);
+	auto g = by_gene(container.cell(0));
+	CHECK_EQ(g.at("Gene1").size(), size_t(3));
+	CHECK_EQ(g.at("Gene1").at("CCCCCT"), size_t(2));
+	CHECK_EQ(g.at("Gene1").at("GGGGGG"), size_t(1));
+	CHECK_EQ(g.at("Gene1").at("ACCCCT"), size_t(1));
+	CHECK_THROWS(container.merge_umis(0, container.gene_indexer().get_index("Gene1"), merge_targets), std::runtime_error);   // sources are gone
+}
+
+static void testMergeAndExcludeCells() {   // CellsDataContainer::merge_cells / exclude_cell (:90-109), as the strategies call them
+	Fixture f;
+	auto &c = *f.container_full;
+	c.merge_cells(2, 1);                   // AAATTAGGTCCG -> AAATTAGGTCCC (what the strategy decides for this fixture)
+	c.exclude_cell(6);
+	CHECK(c.cell(2).is_merged()); CHECK(c.cell(6).is_excluded()); CHECK(!c.cell(1).is_merged());
+	auto g = by_gene(c.cell(1));
+	CHECK_EQ(g.at("Gene1").at("CAACCT"), size_t(2));          // one read each in the two cells
+	CHECK_EQ(c.cell(1).stat(Stats::TOTAL_READS_PER_CB), 4);
+}
+
 static void testPoissonMerge() {   // Tests/TestEstimationMergeProbs.cpp:30-91 (fixture), :127-140
 	Merge::PoissonTargetEstimator estimator(1.0e-4, 1.0e-7);
 	auto strat = std::make_shared<Merge::PoissonRealBarcodesMergeStrategy>(estimator, Merge::RealBarcodesMergeStrategy::INDROP,
@@ -245,6 +277,8 @@ int main(int argc, char **argv) {
 		testResultsPrinterMtx(tmp);
 		testUmiDistributionAndCollisions();
 		testPoissonMerge();
+		testUMIMerge();
+		testMergeAndExcludeCells();
 	} catch (const std::exception &e) {
 		std::printf("UNEXPECTED EXCEPTION: %s\n", e.what());
 		return 2;

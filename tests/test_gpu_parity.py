@@ -826,3 +826,58 @@ def test_count_matrices_under_other_mark_queries(with_n):
     g1, c1, v1 = c.count_matrix_levels("eEBA")
     assert np.array_equal(g0, g1) and np.array_equal(v0, v1)            # the default query again
     assert total > 10_000
+
+
+def test_public_mutators_exclude_merge_cells_merge_umis():
+    """CellsDataContainer::exclude_cell / merge_cells / merge_umis called directly (CellsDataContainer.cpp:90-109, :209-213),
+    between set_initialized and merge_and_filter, against the same calls on the oracle; then the reference's testUMIMerge
+    (Tests/TestEstimation.cpp:468-488)."""
+    s = SynthStream(n_reads=60_000, n_cells=20, n_genes=120, umi_len=6, permille_neighbour=0)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    okw = dict(min_genes_before=3, min_genes_after=5)
+    gkw = dict(min_genes_before_merge=3, min_genes_after_merge=5)
+    o = Oracle(**okw); o.add_packed(cb, umi, gene, aux, ()); o.set_initialized()
+    c = capi.Context(**gkw); c.push_reads(cb, umi, gene, aux); c.set_initialized()
+    real = [int(i) for i in np.nonzero(c.cell_rows()["is_real"])[0]]
+    assert len(real) >= 8
+    a, b, d, e, f = real[0], real[3], real[5], real[6], real[7]
+    # merges (also a chain: d -> b after b received a), an exclusion
+    for src, tgt in ((a, b), (d, b)):
+        o.merge_cells(src, tgt); c.merge_cells(src, tgt)
+    o.exclude_cell(e); c.exclude_cell(e)
+    # explicit UMI merge inside one (cell, gene) group: a -> existing target, a -> new UMI, identity pair skipped
+    g, u, r, m = c.cell_molecules(f)
+    g0 = int(g[0]); mine = [int(x) for x, gg in zip(u, g) if int(gg) == g0]
+    assert len(mine) >= 3
+    new_code = capi.pack_seq("TTTTTT") if capi.pack_seq("TTTTTT") not in mine else capi.pack_seq("GGGGGG")
+    pairs = [(mine[0], mine[1]), (mine[2], new_code), (mine[1], mine[1])]
+    c.merge_umis(f, g0, pairs)
+    o.merge_umis_explicit(f, "G%d" % g0, {capi.unpack_code(x): capi.unpack_code(y) for x, y in pairs})
+    with pytest.raises(capi.DropestError):
+        c.merge_umis(f, g0, [(mine[0], mine[1])])            # "Source UMI doesn't belong to the gene"
+    o.merge_and_filter(); c.merge_and_filter()
+    parity.compare(o, c)
+    rows = c.cell_rows()
+    assert rows["is_merged"][a] == 1 and rows["is_merged"][d] == 1 and rows["is_excluded"][e] == 1
+    assert list(c.merge_targets()) == list(range(c.total_cells_number()))   # the strategy's targets: identity (no -m)
+
+    # testUMIMerge
+    reads = [("AAATTAGGTCCA", "AAACCT", "Gene1"), ("AAATTAGGTCCA", "CCCCCT", "Gene1"), ("AAATTAGGTCCA", "AAATTN", "Gene1"),
+             ("AAATTAGGTCCA", "ACCCCT", "Gene1")]
+    side, index = [], {}
+
+    def code(sq):
+        p = capi.pack_seq(sq)
+        if p is not None:
+            return p
+        index.setdefault(sq, len(side)); side.append(sq) if len(side) == index[sq] else None
+        return capi.ESCAPE | index[sq]
+    cb2 = np.array([code(x[0]) for x in reads], np.uint64); umi2 = np.array([code(x[1]) for x in reads], np.uint64)
+    t = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
+    t.set_side_strings(side)
+    t.push_reads(cb2, umi2, np.zeros(4, np.uint32), np.full(4, 2 << 16, np.uint32))
+    t.set_initialized()
+    t.merge_umis(0, 0, [(code("AAACCT"), code("CCCCCT")), (code("AAATTN"), code("GGGGGG")), (code("ACCCCT"), code("ACCCCT"))])
+    g, u, r, m = t.cell_molecules(0)
+    got = {capi.unpack_code(x, side): int(y) for x, y in zip(u, r)}
+    assert got == {"CCCCCT": 2, "GGGGGG": 1, "ACCCCT": 1}                                       # :484-487
