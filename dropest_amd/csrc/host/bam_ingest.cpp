@@ -9,6 +9,7 @@
 #include <cstring>
 #include <future>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <thread>
 #include <unordered_set>
@@ -281,15 +282,62 @@ BamController::BamController(const BamTags &tags, bool filled_bam, const std::st
 	: _tags(tags), _filled_bam(filled_bam), _gene_in_chromosome_name(gene_in_chromosome_name), _min_barcode_phred(min_barcode_phred),
 	  _threads(threads) {
 	if (!gtf_path.empty()) _genes = Tools::GeneAnnotation::RefGenesContainer(gtf_path);
-	if (!read_param_filenames.empty()) throw std::runtime_error("read-parameter files (-r) are not built");
+	if (!filled_bam && !read_param_filenames.empty()) load_read_params(read_param_filenames);   // BamController::get_parser (:117-130)
 	if (!_tags.read_type.empty() && _tags.intronic_read_value.empty())
 		throw std::runtime_error("You have to specify tag values to be able to parse info about read types (see conf_desc.xml \"Estimation/BamTags/Type/\")");
+}
+
+// ReadMapParamsParser::init (ReadMapParamsParser.cpp:50-108): gzip text files, one "name cb umi cb_quality umi_quality" row per
+// read (ReadParameters::parse_from_string, ReadParameters.cpp:58-78); malformed rows and repeated names are reported and skipped
+void BamController::load_read_params(const std::string &filenames) {
+	_params_from_files = true;
+	std::istringstream names(filenames);
+	std::string name;
+	const int quality_offset = 33;
+	while (names >> name) {
+		gzFile f = gzopen(name.c_str(), "rb");
+		if (!f) throw std::runtime_error("Can't open file with read parameters'" + name + "'");
+		std::string row;
+		char buf[1 << 16];
+		auto handle_row = [&]() {
+			if (row.empty()) return;
+			std::string parts[5];
+			size_t start = 0;
+			bool ok = true;
+			for (int i = 0; i < 4 && ok; ++i) {
+				const size_t end = row.find(' ', start);
+				if (end == std::string::npos) { ok = false; break; }
+				parts[i] = row.substr(start, end - start);
+				start = end + 1;
+			}
+			if (!ok) return;                                            // "can't parse read parameters from string": skipped
+			parts[4] = row.substr(start);
+			if (!parts[0].empty() && parts[0][0] == '@') parts[0] = parts[0].substr(1);
+			if (parts[1].empty() || parts[2].empty()) return;           // the ReadParameters constructor throws: skipped
+			bool pass = true;                                           // ReadParameters::check_quality (:118-136)
+			if (_min_barcode_phred > quality_offset) {
+				for (char q : parts[3]) pass &= q >= char(_min_barcode_phred);
+				for (char q : parts[4]) pass &= q >= char(_min_barcode_phred);
+			}
+			_read_params.emplace(parts[0], ReadParams{parts[1], parts[2], parts[4], pass});   // a repeated name keeps the first row
+		};
+		while (gzgets(f, buf, int(sizeof(buf)))) {
+			row += buf;
+			if (!row.empty() && row.back() == '\n') { row.pop_back(); if (!row.empty() && row.back() == '\r') row.pop_back(); handle_row(); row.clear(); }
+		}
+		handle_row();
+		gzclose(f);
+	}
 }
 
 void BamController::parse_bam_files(const std::vector<std::string> &bam_files, CellsDataContainer &container) {
 	const int quality_offset = 33;                                       // Tools::ReadParameters::quality_offset
 	enum : uint8_t { OK = 0, SKIP, CANT_PARSE_NO_COUNT, CANT_PARSE, LOW_QUALITY };
-	struct Parsed { CellsDataContainer::ParsedRead r; uint8_t status; std::string gene; /* -g: the annotation's answer (owned) */ };
+	struct Parsed {
+		CellsDataContainer::ParsedRead r; uint8_t status; std::string gene; /* -g: the annotation's answer (owned) */
+		std::string_view name;                  // -r: the read name, looked up in file order by the caller's thread
+		std::string p_cb, p_umi, p_quality;     // -r: the served parameters (owned: the map entry is erased)
+	};
 	const unsigned nthreads = _threads ? _threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 	for (auto const &bam_name : bam_files) {
 		BamReader reader(bam_name, _threads);
@@ -321,6 +369,8 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				}
 				r.umi_quality_length = uint32_t(umiq.size());
 				r.umi_quality = umiq;
+			} else if (_params_from_files) {                              // ReadMapParamsParser: resolved below, in file order
+				out.name = al.name_view;
 			} else {                                                      // ReadParamsParser.cpp:20-33: "id!CB#UMI"
 				const std::string_view name = al.name_view;
 				const size_t up = name.rfind('#');
@@ -355,8 +405,11 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				else mark.add(UMI::Mark::HAS_EXONS);
 			}
 			r.mark = uint8_t(mark.bits());
-			if (!CellsDataContainer::pack_code(r.cb, r.cb_code)) r.cb_code = 0;
-			if (!CellsDataContainer::pack_code(r.umi, r.umi_code)) r.umi_code = 0;
+			if (_params_from_files) r.cb_code = r.umi_code = 0;
+			else {
+				if (!CellsDataContainer::pack_code(r.cb, r.cb_code)) r.cb_code = 0;
+				if (!CellsDataContainer::pack_code(r.umi, r.umi_code)) r.umi_code = 0;
+			}
 			r.gene_hash = CellsDataContainer::hash_name(r.gene);
 			if (!r.gene.empty()) r.gene_id = container.lookup_gene(r.gene_hash, r.gene);   // dictionary is read-only while the workers run
 			out.status = OK;
@@ -384,6 +437,26 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			auto t_add = clk::now();
 			// in file order: the counters and the container (first-seen ids are defined by this order)
 			for (size_t i = 0; i < n; ++i) {
+				if (_params_from_files && parsed[i].status != SKIP && parsed[i].status != CANT_PARSE_NO_COUNT) {
+					// ReadMapParamsParser::get_read_params (:22-48) comes BEFORE the gene look-up (BamController.cpp:140-152):
+					// an unknown name is "can't parse", a served name is erased, its quality verdict precedes the gene's
+					Parsed &pr = parsed[i];
+					std::string_view nm = pr.name;
+					if (!nm.empty() && nm[0] == '@') nm.remove_prefix(1);
+					auto it = _read_params.find(std::string(nm));
+					if (it == _read_params.end()) pr.status = CANT_PARSE;
+					else {
+						const bool pass = it->second.pass_quality;
+						pr.p_cb = std::move(it->second.cb); pr.p_umi = std::move(it->second.umi); pr.p_quality = std::move(it->second.umi_quality);
+						_read_params.erase(it);
+						if (!pass) pr.status = LOW_QUALITY;
+						else if (pr.status == OK) {
+							pr.r.cb = pr.p_cb; pr.r.umi = pr.p_umi; pr.r.umi_quality = pr.p_quality; pr.r.umi_quality_length = uint32_t(pr.p_quality.size());
+							if (!CellsDataContainer::pack_code(pr.r.cb, pr.r.cb_code)) pr.r.cb_code = 0;
+							if (!CellsDataContainer::pack_code(pr.r.umi, pr.r.umi_code)) pr.r.umi_code = 0;
+						}
+					}
+				}
 				switch (parsed[i].status) {
 					case SKIP: break;
 					case CANT_PARSE_NO_COUNT: ++_counters.cant_parse; break;             // reads with unknown chromosome are not counted (:107)

@@ -7,7 +7,9 @@
 //   ReadParamsParser::get_gene / parse_read_type (gene tag + optional read-type tag, :36-90)
 //   BamTags defaults (BamTags.cpp:7-24), Tools::ReadParameters quality check (Tools/ReadParameters.cpp:118-136)
 //   ReadParamsParser::get_gene_from_reference (-g: gene annotation from a GTF / BED file, gene_annotation.h)
-// Not built: the read-parameters file of droptag (-r), filtered BAM output (-F, -b).
+//   ReadMapParamsParser::get_read_params (-r: droptag's read-parameter files "name cb umi cb_quality umi_quality", gzip;
+//     ReadMapParamsParser.cpp:22-48, :50-108; every name serves once)
+// Not built: filtered BAM output (-F, -b).
 //
 // The container format: BGZF (gzip members with a 'BC' extra field, SAMv1 §4.1) holding the BAM stream (§4.2).
 // Blocks are inflated by a pool of host threads, records are parsed in stream order by the caller's thread (the
@@ -16,6 +18,7 @@
 
 #include <cstdint>
 #include <string>
+#include <unordered_map>
 #include <string_view>
 #include <vector>
 
@@ -73,6 +76,10 @@ public:
 	};
 private:
 	BamTags _tags;
+	struct ReadParams { std::string cb, umi, umi_quality; bool pass_quality; };
+	std::unordered_map<std::string, ReadParams> _read_params;     // -r: read name -> parameters (erased when served)
+	bool _params_from_files = false;
+	void load_read_params(const std::string &filenames);
 	bool _filled_bam, _gene_in_chromosome_name;
 	int _min_barcode_phred;
 	unsigned _threads;

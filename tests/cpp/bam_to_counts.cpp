@@ -24,7 +24,10 @@ int main(int argc, char **argv) {
 		BamProcessing::BamTags tags;
 		tags.read_type = "RE"; tags.intronic_read_value = "N"; tags.intergenic_read_value = "I"; tags.exonic_read_value = "E";   // configs/10x.xml style
 		const char *gtf = std::getenv("DROPEST_GTF");
-		BamProcessing::BamController ctl(tags, mode == "filled", "", gtf ? gtf : "", false, 0, threads);
+		// mode: filled | name | params:<read-parameter files of droptag, space separated> ; DROPEST_MIN_PHRED = min_barcode_quality
+		const std::string param_files = mode.rfind("params:", 0) == 0 ? mode.substr(7) : "";
+		const char *phred = std::getenv("DROPEST_MIN_PHRED");
+		BamProcessing::BamController ctl(tags, mode == "filled", param_files, gtf ? gtf : "", false, phred ? std::atoi(phred) + 33 : 0, threads);
 		const auto t0 = std::chrono::steady_clock::now();
 		ctl.parse_bam_files(bams, c);
 		const auto t1 = std::chrono::steady_clock::now();

@@ -211,3 +211,61 @@ def test_umi_quality_tags_reach_reads_per_umi_per_cell(tmp_path):
         for name, entry in zip(per_gene.names, per_gene.value):
             seen[(cells_l[int(ci)], genes_l[int(gi)], name)] = (int(entry.value[0].value[0]), [float(x) for x in entry.value[1].value])
     assert len(seen) > 1000 and seen == want
+
+
+def test_read_parameter_files(tmp_path):
+    """-r: droptag's read-parameter files (ReadMapParamsParser.cpp): barcodes, UMIs and qualities come from gzip text
+    rows keyed by the read name; every name serves once (a second primary alignment of the same name cannot be parsed),
+    unknown names cannot be parsed, rows below min_barcode_quality are low-quality reads, malformed rows are skipped."""
+    import gzip
+    reads = _reads(30_000, seed_cells=12)
+    refs = [("chr%d" % i, 1_000_000) for i in range(25)]
+    rng = np.random.default_rng(17)
+    recs, rows, kept = [], [], []
+    n_missing = n_low = n_dup = 0
+    for i, (cb, umi, g, chr_, mark) in enumerate(reads):
+        if g is None:
+            tags, m = [], 1
+        else:
+            code, m = (("N", 4) if mark & 4 else ("I", 1) if mark == 1 else ("E", 2))
+            tags = [("GX", "Z", g), ("RE", "A", code)]
+        name = "read%d" % i
+        recs.append(bw.record(int(chr_[3:]), i, name, tags=tags))
+        kind = int(rng.integers(0, 30))
+        if kind == 0:
+            n_missing += 1; continue                                              # no row for this read
+        low = kind == 1
+        qcb = "".join(chr(int(x)) for x in rng.integers(53, 74, len(cb)))
+        qumi = "".join(chr(int(x)) for x in rng.integers(53, 74, len(umi)))
+        if low:
+            qumi = qumi[:2] + chr(33 + 5) + qumi[3:]; n_low += 1
+        rows.append("%s%s %s %s %s %s" % ("@" if i % 2 else "", name, cb, umi, qcb, qumi))
+        if kind == 2:                                                             # the same name aligned twice as primary
+            recs.append(bw.record(int(chr_[3:]), i, name, tags=tags)); n_dup += 1
+        if kind == 3:
+            rows.append("%s %s %s %s %s" % (name, "AAAA", "CCCC", "IIII", "IIII"))  # a repeated name: the first row stays
+        if not low:
+            kept.append((cb, umi, g, chr_, m, qumi))
+    rows.insert(5, "broken row without enough fields")
+    rows.insert(9, "emptycb  ACGT II II")                                          # empty barcode: ReadParameters throws, row skipped
+    half = len(rows) // 2
+    f1, f2 = str(tmp_path / "p1.gz"), str(tmp_path / "p2.gz")
+    for path, part in ((f1, rows[:half]), (f2, rows[half:])):
+        with gzip.open(path, "wt") as f:
+            f.write("\n".join(part) + "\n")
+    b = str(tmp_path / "r.bam")
+    bw.write_bam(b, refs, recs)
+    got, cells, stats, d = _run(tmp_path, "params:%s %s" % (f1, f2), [b], 5, 10, env={"DROPEST_MIN_PHRED": "10", "DROPEST_RPUPC": "1"})
+    o = Oracle(min_genes_before=5, min_genes_after=10)
+    for cb, umi, g, chr_, m, q in kept:
+        o.add_record(cb, umi, g or "", chr_, m, umi_qual=q)
+    o.set_initialized(); o.merge_and_filter()
+    gi, ci, v = o.count_matrix(filtered=True)
+    cols = [o.cell_barcode(int(k)) for k in o.filtered_cells()]
+    want = {(o.gene_name(int(g)), cols[int(c)]): int(x) for g, c, x in zip(gi, ci, v)}
+    assert cells == cols and got == want and len(want) > 300
+    assert stats["saved"] == len(kept) and stats["low_quality"] == n_low and stats["cant_parse"] == n_missing + n_dup
+    assert stats["total_reads"] == len(recs)
+    # the qualities of the rows reached the molecules
+    rp = d["reads_per_umi_per_cell"]
+    assert len(rp["reads_per_umi"].value[0].value[0].value[1].value) == 8
