@@ -154,7 +154,7 @@ void dropest_ctx::free_results() {
 	shard.reset();
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
 	real.clear(); filtered.clear(); filtered_valid = false; merge_pairs.clear(); reassign.clear(); umi_overrides.clear(); n_real_now = 0;
-	merge_rank.clear(); reagg_prio = nullptr; extra_excluded.clear(); explicit_sources.clear();
+	merge_rank.clear(); reagg_prio = nullptr; extra_excluded.clear(); explicit_sources.clear(); mol_sorted_rows = 0xFFFFFFFFu;
 }
 
 // ------------------------------------------------------------------------------------------------
