@@ -152,7 +152,9 @@ def main():
         get_layout = run.engine.ctx.sort_layout
         def set_prof(on):
             run.set_profiling(on)
-            run.trace = {} if on else None
+            # the per-stage trace synchronises the device at every stage boundary: a diagnostic of the one-GPU sharded run
+            # only, never part of a multi-GPU timing
+            run.trace = {} if (on and world == 1) else None
 
     def fence():
         if dist is not None:
