@@ -127,7 +127,6 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 	__shared__ val_t sv[VB ? TILE : 1];
 
 	const uint32_t tid = threadIdx.x, w = wave_id(), lane = lane_id();
-	const unsigned long long lt_mask = (1ull << lane) - 1ull;
 	if (tid < RS_RADIX) goff[tid] = digit_base[tid] + hist[tid * gridDim.x + blockIdx.x];
 
 	const uint32_t n_tiles = (n + TILE - 1) / TILE;
@@ -173,14 +172,20 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 		for (int i = 0; i < ITEMS; ++i) {
 			const bool valid = full || (lane_off + i * 64) < in_tile;
 			const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
-			unsigned long long m = full ? ~0ull : __ballot(valid);
+			// lanes of the wave with the same digit: a lane differs from me in bit b iff (ballot of bit b) ^ (my bit b,
+			// broadcast to 0 / ~0) has its bit set; the eight "differs" masks are OR-ed and inverted.  Written on the two
+			// 32-bit halves so that it compiles to bfe + cmp + 2 xor + or3 per bit (the 64-bit select form took 9).
+			uint32_t diff_lo = 0, diff_hi = 0;
 #pragma unroll
 			for (int b = 0; b < 8; ++b) {
-				const bool bit = (d >> b) & 1u;
-				const unsigned long long bal = __ballot(bit);
-				m &= bit ? bal : ~bal;
+				const int32_t mine = int32_t(d << (31 - b)) >> 31;          // 0 or ~0
+				const unsigned long long bal = __ballot(mine != 0);
+				diff_lo |= uint32_t(bal) ^ uint32_t(mine);
+				diff_hi |= uint32_t(bal >> 32) ^ uint32_t(mine);
 			}
-			const uint32_t before = __popcll(m & lt_mask);
+			unsigned long long m = ~(((unsigned long long)diff_hi << 32) | diff_lo);
+			if (!full) m &= __ballot(valid);
+			const uint32_t before = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));   // same-digit lanes below me
 			const uint32_t old = wcnt[w][d];
 			__builtin_amdgcn_wave_barrier();
 			if (valid && before == 0) wcnt[w][d] = old + __popcll(m);
