@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libdropest_amd.so")
-SOURCES = ["dropest_amd.hip", "synth_api.hip"]
+SOURCES = ["dropest_amd.hip", "synth_api.hip", "annotation_api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-pthread"]
 

@@ -283,6 +283,32 @@ int RefGenesContainer::gene_of_alignment(const std::string &chr_name, pos_t posi
 	return mark;
 }
 
+RefGenesContainer::Flat RefGenesContainer::flatten() const {
+	Flat f;
+	f.gene_names = _genes;
+	f.use_introns_from_gtf = _use_introns_from_gtf;
+	auto u32 = [](pos_t v) { if (v > 0xFFFFFFFFull) throw std::runtime_error("annotation position beyond 32 bits"); return uint32_t(v); };
+	f.chr_seg_begin.push_back(0); f.seg_tr_begin.push_back(0); f.tr_exon_begin.push_back(0); f.tr_intron_begin.push_back(0);
+	for (auto const &kv : _chromosomes) {
+		f.chr_names.push_back(kv.first);
+		const Chromosome &c = kv.second;
+		const uint32_t tr0 = uint32_t(f.tr_gene.size());
+		for (const Transcript &t : c.transcripts) {
+			f.tr_gene.push_back(t.gene);
+			for (const Span &sp : t.exons) { f.exon_start.push_back(u32(sp.start)); f.exon_end.push_back(u32(sp.end)); }
+			for (const Span &sp : t.introns) { f.intron_start.push_back(u32(sp.start)); f.intron_end.push_back(u32(sp.end)); }
+			f.tr_exon_begin.push_back(uint32_t(f.exon_start.size())); f.tr_intron_begin.push_back(uint32_t(f.intron_start.size()));
+		}
+		for (size_t sgm = 0; sgm < c.seg_start.size(); ++sgm) {
+			f.seg_start.push_back(u32(c.seg_start[sgm])); f.seg_end.push_back(u32(c.seg_end[sgm]));
+			for (uint32_t k = c.seg_begin[sgm]; k < c.seg_begin[sgm + 1]; ++k) f.seg_tr.push_back(tr0 + c.seg_transcripts[k]);
+			f.seg_tr_begin.push_back(uint32_t(f.seg_tr.size()));
+		}
+		f.chr_seg_begin.push_back(uint32_t(f.seg_start.size()));
+	}
+	return f;
+}
+
 }  // namespace GeneAnnotation
 }  // namespace Tools
 
@@ -308,6 +334,28 @@ long dropest_gene_annotation_query(void *h, const char *chr, uint64_t start, uin
 		return n;
 	} catch (const RefGenesContainer::ChrNotFoundException &) { return -1; }
 }
+namespace {
+struct FlatCache { void *owner = nullptr; RefGenesContainer::Flat flat; };
+thread_local FlatCache g_flat;
+const RefGenesContainer::Flat &flat_of(void *h) {
+	if (g_flat.owner != h) { g_flat.flat = static_cast<RefGenesContainer *>(h)->flatten(); g_flat.owner = h; }
+	return g_flat.flat;
+}
+}  // namespace
+void dropest_gene_annotation_flat_sizes(void *h, uint32_t sizes[8]) {
+	const auto &f = flat_of(h);
+	sizes[0] = uint32_t(f.chr_names.size()); sizes[1] = uint32_t(f.seg_start.size()); sizes[2] = uint32_t(f.tr_gene.size());
+	sizes[3] = uint32_t(f.gene_names.size()); sizes[4] = uint32_t(f.seg_tr.size()); sizes[5] = uint32_t(f.exon_start.size());
+	sizes[6] = uint32_t(f.intron_start.size()); sizes[7] = f.use_introns_from_gtf ? 1u : 0u;
+}
+void dropest_gene_annotation_flat_fill(void *h, uint32_t *const arrays[12]) {
+	const auto &f = flat_of(h);
+	const std::vector<uint32_t> *src[12] = {&f.chr_seg_begin, &f.seg_start, &f.seg_end, &f.seg_tr_begin, &f.seg_tr, &f.tr_gene, &f.tr_exon_begin,
+	                                        &f.tr_intron_begin, &f.exon_start, &f.exon_end, &f.intron_start, &f.intron_end};
+	for (int i = 0; i < 12; ++i) std::copy(src[i]->begin(), src[i]->end(), arrays[i]);
+}
+const char *dropest_gene_annotation_chr_name(void *h, uint32_t i) { return flat_of(h).chr_names.at(i).c_str(); }
+const char *dropest_gene_annotation_gene_name(void *h, uint32_t i) { return flat_of(h).gene_names.at(i).c_str(); }
 int dropest_gene_annotation_read(void *h, const char *chr, uint64_t position, uint64_t end_position, char *gene, int cap) {
 	try {
 		std::string g;

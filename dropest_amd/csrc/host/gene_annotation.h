@@ -53,6 +53,16 @@ public:
 	int gene_of_alignment(const std::string &chr_name, pos_t position, pos_t end_position, std::string &gene) const;
 	size_t chromosomes_number() const { return _chromosomes.size(); }
 
+	// Flat tables for the device kernel (include/dropest_annotation.h); chromosomes in the order of chr_names, genes in the
+	// order of gene_names.  Positions must fit 32 bits.
+	struct Flat {
+		std::vector<std::string> chr_names, gene_names;
+		bool use_introns_from_gtf = false;
+		std::vector<uint32_t> chr_seg_begin, seg_start, seg_end, seg_tr_begin, seg_tr, tr_gene, tr_exon_begin, tr_intron_begin,
+		                      exon_start, exon_end, intron_start, intron_end;
+	};
+	Flat flatten() const;
+
 private:
 	struct Span { pos_t start, end; };
 	struct Transcript {
@@ -86,4 +96,10 @@ const char *dropest_gene_annotation_error(void);
 long dropest_gene_annotation_query(void *handle, const char *chr, uint64_t start, uint64_t end, char *names, int stride, int *types, int cap);
 // mark bits >= 0, -1 = unknown chromosome
 int dropest_gene_annotation_read(void *handle, const char *chr, uint64_t position, uint64_t end_position, char *gene, int cap);
+// flat tables (RefGenesContainer::Flat): sizes = {n_chr, n_seg, n_tr, n_genes, covering transcripts, exon spans, intron
+// spans, use_introns_from_gtf}; `arrays` = the 12 tables in the order of dropest_flat_annotation's pointers
+void dropest_gene_annotation_flat_sizes(void *handle, uint32_t sizes[8]);
+void dropest_gene_annotation_flat_fill(void *handle, uint32_t *const arrays[12]);
+const char *dropest_gene_annotation_chr_name(void *handle, uint32_t index);
+const char *dropest_gene_annotation_gene_name(void *handle, uint32_t index);
 }
