@@ -308,8 +308,9 @@ class Collectives:
             tensor.copy_(src)
         return tensor
 
-    def all_gather_rows(self, array):
-        """numpy (k, w) int64 per rank -> list of arrays (every rank gets all)."""
+    def all_gather_rows(self, array, as_tensors=False):
+        """numpy (k, w) int64 per rank -> list of arrays (every rank gets all); as_tensors: torch tensors left on the
+        collective's device (the global cell table has 10^5..10^6 rows: it is ordered there, not in numpy)."""
         t = self.torch
         backend_cpu = self.staging == "cpu" or self.dist.get_backend() == "gloo"
         dev = "cpu" if backend_cpu else "cuda"
@@ -324,6 +325,8 @@ class Collectives:
         mine = t.from_numpy(pad).to(dev)
         bufs = [t.empty_like(mine) for _ in range(self.world)]
         self.dist.all_gather(bufs, mine)
+        if as_tensors:
+            return [b[:n] for b, n in zip(bufs, ks)]
         return [b.cpu().numpy()[:n] for b, n in zip(bufs, ks)]
 
 
@@ -399,7 +402,7 @@ class ShardedRun:
                           ids.astype(np.int64), rows["n_genes"].astype(np.int64)], axis=1)[is_real]
         if np.any(rows["barcode"][is_real] >> np.uint64(63)):
             raise capi.DropestError(4, "escaped barcodes are not supported in sharded runs yet")
-        everyone = c.all_gather_rows(table)
+        everyone = c.all_gather_rows(table, as_tensors=True)
         t = self._tick("cells_allgather", t)
         # 5. local matrices, gathered on rank 0
         out = {}
@@ -495,32 +498,42 @@ class ShardedRun:
         return G[moved, 0].astype(np.uint64), G[final[moved], 0].astype(np.uint64)
 
     def _global_columns(self, everyone, metas, filtered):
-        """Global column order of a matrix (identical on every rank): returns the kept cells' rows, and per column its
-        owner rank, its start inside that rank's local arrays and its length."""
-        # columns: [rank, req_genes, req_umis, total_umis, barcode, first_global, local_id, n_genes, row within the rank's table]
-        cells = np.concatenate([np.concatenate([np.full((len(t), 1), r, np.int64), t, np.arange(len(t), dtype=np.int64)[:, None]], axis=1)
-                                for r, t in enumerate(everyone)])
+        """Global column order of a matrix (identical on every rank): the kept cells' barcodes, and per column its owner
+        rank, its start inside that rank's local arrays and its length -- torch tensors on the collectives' device.  The
+        table has 10^5..10^6 rows at BASELINE sizes and every rank orders it every pass: a few device sorts, where
+        numpy took 50-100 ms at 8 ranks."""
+        import torch as t
+        # table columns: [req_genes, req_umis, total_umis, barcode, first_global, local_id, n_genes]; metas: [local_id, length]
+        dev = everyone[0].device
+        sizes = [int(x.shape[0]) for x in everyone]
+        empty = t.zeros(0, dtype=t.int64, device=dev)
+        if not sum(sizes) or not any(int(m.shape[0]) for m in metas):
+            return empty, empty, empty, empty
+        table = t.cat(everyone)
+        rank_col = t.repeat_interleave(t.arange(len(everyone), dtype=t.int64, device=dev), t.tensor(sizes, dtype=t.int64, device=dev))
+        row_col = t.cat([t.arange(k, dtype=t.int64, device=dev) for k in sizes])
         if filtered:
-            keep = cells[cells[:, 1] >= self.cfg["min_after"]]
-            order = order_cells(keep[:, 1:5])
+            sel = t.nonzero(table[:, 0] >= self.cfg["min_after"]).flatten()
+            # CellsDataContainer::compare_cells: lexicographic (requested_genes, requested_umis, total_umis, barcode) = stable
+            # sorts from the least significant key up
+            for j in (3, 2, 1, 0):
+                sel = sel[t.argsort(table[sel, j], stable=True)]
         else:
-            keep = cells
-            order = np.argsort(keep[:, 5], kind="stable")       # cell-id order == first-seen order
-        keep = keep[order]
-        if not len(keep) or not any(len(m) for m in metas):
-            return keep, keep[:, 0], np.zeros(0, np.int64), np.zeros(0, np.int64)
-        starts = [np.concatenate([[0], np.cumsum(m[:, 1])[:-1]]) if len(m) else np.zeros(0, np.int64) for m in metas]
-        base = np.concatenate([[0], np.cumsum([len(m) for m in metas])]).astype(np.int64)
-        starts_all = np.concatenate(starts); lens_all = np.concatenate([m[:, 1] for m in metas if len(m)] or [np.zeros(0, np.int64)])
-        if not filtered and all(len(m) == len(t) and (not len(m) or np.array_equal(m[:, 0], t[:, 5])) for m, t in zip(metas, everyone)):
-            # cm_raw: a rank's columns ARE its real cells in table order -- no search
-            pos = base[keep[:, 0]] + keep[:, 8]
+            sel = t.argsort(table[:, 4], stable=True)                    # cell-id order == first-seen order
+        ranks, rows = rank_col[sel], row_col[sel]
+        barcodes = table[sel, 3]
+        m_sizes = [int(m.shape[0]) for m in metas]
+        base = t.tensor(np.concatenate([[0], np.cumsum(m_sizes)]).astype(np.int64), device=dev)
+        lens_all = t.cat([m[:, 1] for m in metas])
+        starts_all = t.cat([t.cumsum(m[:, 1], 0) - m[:, 1] for m in metas])
+        direct = (not filtered) and m_sizes == sizes and all(k == 0 or bool(t.equal(m[:, 0], x[:, 5])) for m, x, k in zip(metas, everyone, sizes))
+        if direct:
+            pos = base[ranks] + rows                                     # cm_raw: a rank's columns ARE its real cells in table order
         else:
-            keys = np.concatenate([(np.int64(r) << 40) | m[:, 0] for r, m in enumerate(metas) if len(m)])
-            o = np.argsort(keys, kind="stable")
-            pos = o[np.searchsorted(keys[o], (keep[:, 0] << 40) | keep[:, 6])]
-        src, ln = starts_all[pos], lens_all[pos]
-        return keep, keep[:, 0], np.asarray(src, np.int64), np.asarray(ln, np.int64)
+            keys = t.cat([(r << 40) | m[:, 0] for r, m in enumerate(metas)])
+            o = t.argsort(keys, stable=True)
+            pos = o[t.searchsorted(keys[o], (ranks << 40) | table[sel, 5])]
+        return barcodes, ranks, starts_all[pos], lens_all[pos]
 
     def _shared(self, slot, total):
         """Host buffer of one matrix, shared by the ranks of the node: a /dev/shm file mapped (and registered with the
@@ -568,21 +581,27 @@ class ShardedRun:
         return buf
 
     def _gather_matrix(self, everyone, filtered, colptr, rows_t, vals_t, local_cols):
+        import time
+        import torch as t
         e, c, n = self.engine, self.coll, self.world
         nnz_local = int(colptr[-1]) if len(colptr) else 0
         lens = np.diff(colptr.astype(np.int64)) if len(colptr) > 1 else np.zeros(0, np.int64)
         # tell everybody which cell each local column is and how long it is
         meta = np.stack([local_cols, lens], axis=1) if len(lens) else np.zeros((0, 2), np.int64)
-        import time
         tt = time.perf_counter()
-        metas = c.all_gather_rows(meta)
+        metas = c.all_gather_rows(meta, as_tensors=True)
         tt = self._tick("gm:meta_allgather", tt)
-        keep, col_rank, src, ln = self._global_columns(everyone, metas, filtered)
-        dst = np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.int64) if len(ln) else np.zeros(0, np.int64)
-        total = int(ln.sum())
-        colptr_g = np.concatenate([[0], np.cumsum(ln)]).astype(np.uint64)
+        barcodes, col_rank, src, ln = self._global_columns(everyone, metas, filtered)
+        csum = t.cumsum(ln, 0)
+        dst = csum - ln
+        total = int(csum[-1]) if len(ln) else 0
+        host = lambda x: x.cpu().numpy()      # noqa: E731
         tt = self._tick("gm:order", tt)
         slot = 0 if filtered else 1
+
+        def result(rows_h, vals_h):           # rank 0 only: the global CSC pieces on the host
+            colptr_g = np.concatenate([[0], host(csum)]).astype(np.uint64)
+            return (colptr_g, rows_h, vals_h, host(barcodes).astype(np.uint64))
         if self.output == "shm" and total > 0:
             # every rank writes ITS columns of the global matrix into the node's shared host buffer: all PCIe links
             # work at once and no GPU has to hold (or copy out) the whole matrix
@@ -596,16 +615,17 @@ class ShardedRun:
                 _, rows_t, vals_t = e.matrix(filtered)       # the gather needs tensors, not the context's own arrays
             else:
                 mine = col_rank == self.rank
+                args = (host(src[mine]), host(dst[mine]), host(ln[mine]), rows_t, vals_t, buf)
                 if getattr(e, "deferred_writes", False):
-                    e.write_columns(src[mine], dst[mine], ln[mine], rows_t, vals_t, buf, slot)
+                    e.write_columns(*args, slot)
                     self._pending_writes = True
                 else:
-                    e.write_columns(src[mine], dst[mine], ln[mine], rows_t, vals_t, buf)
+                    e.write_columns(*args)
                     c.barrier()
                 tt = self._tick("gm:write_shared", tt)
                 if self.rank != 0:
                     return None
-                return (colptr_g, buf["host"][:total], buf["host"][buf["cap"]:buf["cap"] + total], keep[:, 4].astype(np.uint64))
+                return result(buf["host"][:total], buf["host"][buf["cap"]:buf["cap"] + total])
         # "gather": all columns to rank 0's GPU over RCCL (all-to-all(v) with a single receiver), one copy kernel
         # puts them in the global order, one D2H
         nnz_all = [int(m[:, 1].sum()) for m in metas]
@@ -617,8 +637,8 @@ class ShardedRun:
         if self.rank != 0:
             return None
         base = np.concatenate([[0], np.cumsum(nnz_all)]).astype(np.int64)
-        a_rows, a_vals = e.assemble(src + base[col_rank], dst, ln, g_rows, g_vals, total)
+        a_rows, a_vals = e.assemble(host(src) + base[host(col_rank)], host(dst), host(ln), g_rows, g_vals, total)
         tt = self._tick("gm:assemble", tt)
-        res = (colptr_g, e.to_numpy_u32(a_rows, 2 * slot), e.to_numpy_u32(a_vals, 2 * slot + 1), keep[:, 4].astype(np.uint64))
+        res = result(e.to_numpy_u32(a_rows, 2 * slot), e.to_numpy_u32(a_vals, 2 * slot + 1))
         self._tick("gm:d2h", tt)
         return res
