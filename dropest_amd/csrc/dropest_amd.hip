@@ -308,11 +308,11 @@ void dropest_ctx::build_keys() {
 static constexpr int RS_T = 512, RS_I = 16, RS_TILE_REC = RS_T * RS_I;
 // Tile shapes of the keys-only pass (THREADS x ITEMS must equal RS_TILE_REC or divide it: the histogram pass counts per
 // block range, not per tile).  Chosen by measurement; DROPEST_RS_SHAPE=<n> selects another for tuning.
-template <int T, int I, bool PF, int VB>
+template <int T, int I, bool PF, int VB, int RB = 8>
 static void rs_launch_shape(dim3 grid, hipStream_t st, const u64 *k, const void *v, u64 *ok, void *ov, u32 n, int shift, u32 tpb,
                             const u32 *hist, const u32 *base) {
 	static_assert(RS_TILE_REC % (T * I) == 0, "shape must tile the histogram ranges");
-	hipLaunchKernelGGL((rs_scatter_kernel_t<T, I, PF, VB>), grid, dim3(T), 0, st, k, v, ok, ov, n, shift, tpb * u32(RS_TILE_REC / (T * I)), hist, base);
+	hipLaunchKernelGGL((rs_scatter_kernel_t<T, I, PF, VB, RB>), grid, dim3(T), 0, st, k, v, ok, ov, n, shift, tpb * u32(RS_TILE_REC / (T * I)), hist, base);
 }
 static int rs_shape_override() {
 	static const int shape = [] { const char *e = getenv("DROPEST_RS_SHAPE"); return e ? atoi(e) : -1; }();
@@ -332,12 +332,42 @@ static void rs_launch_vb(int shape, dim3 grid, hipStream_t st, const u64 *k, con
 		default: return rs_launch_shape<512, 16, true, VB>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
 	}
 }
-static void rs_launch(int val_bytes, dim3 grid, hipStream_t st, const u64 *k, const void *v, u64 *ok, void *ov, u32 n, int shift, u32 tpb,
+static void rs_launch(int val_bytes, int bits, dim3 grid, hipStream_t st, const u64 *k, const void *v, u64 *ok, void *ov, u32 n, int shift, u32 tpb,
                       const u32 *hist, const u32 *base) {
+	if (bits == 9) {   // the widened pass: the default shapes only (512 threads = one per digit)
+		if (val_bytes == 0) return rs_launch_shape<512, 8, false, 0, 9>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+		if (val_bytes == 1) return rs_launch_shape<512, 8, false, 1, 9>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+		return rs_launch_shape<512, 16, true, 4, 9>(grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+	}
 	const int o = rs_shape_override();
 	if (val_bytes == 0) rs_launch_vb<0>(o >= 0 ? o : 2, grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
 	else if (val_bytes == 1) rs_launch_vb<1>(o >= 0 ? o : 2, grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
 	else rs_launch_vb<4>(o >= 0 ? o : 0, grid, st, k, v, ok, ov, n, shift, tpb, hist, base);
+}
+
+// Digit windows of an LSD sort over the bits set in `varying_mask` (the caller masks out bits that need no ordering,
+// e.g. a mark folded under the key; bits equal in all keys are not set either).  8-bit windows from the lowest varying
+// bit, windows without a varying bit skipped: ceil(width / 8) passes.  When ceil(width / 9) is smaller (C2: 22 + 15 +
+// 20 = 57 bits -> 7 passes instead of 8; C4: 53 bits -> 6 instead of 7) the TOP windows take 9 bits, as many as needed,
+// and a whole pass (one histogram + one scatter over all records) disappears.  A 9-bit scatter launch costs ~10 % more
+// than an 8-bit one (runs per tile half as long; measured 0.59 vs 0.55 ms on the C4 shape, 0.53 vs 0.47 ms for the one
+// widened pass of C2, whose digit -- the high bits of the cell id -- is so skewed that most of the 512 buckets are
+// empty), a pass less saves 0.65-0.75 ms: C2 20.05 -> 19.40 ms, C4 shape 33.8 -> 31.8 ms, C3 at 1e8 reads 36.7 -> 36.2.
+struct RadixPass { int shift, bits; };
+static constexpr u32 RS_RADIX_MAX = 512;
+static std::vector<RadixPass> plan_radix_passes(u64 varying_mask) {
+	std::vector<RadixPass> plain, wide;
+	if (!varying_mask) return plain;
+	const int lo = __builtin_ctzll(varying_mask), hi = 64 - __builtin_clzll(varying_mask), width = hi - lo;
+	for (int shift = lo; shift < 64; shift += 8)
+		if ((varying_mask >> shift) & 0xFFull) plain.push_back({shift, 8});
+	static const bool allow_wide = getenv("DROPEST_RS_NO_WIDE") == nullptr;
+	const int passes = (width + 8) / 9, n9 = width - 8 * passes;   // passes = ceil(width / 9)
+	static const int max_wide = [] { const char *e = getenv("DROPEST_RS_WIDE_MAX"); return e ? atoi(e) : 64; }();
+	if (!allow_wide || n9 < 1 || n9 > max_wide || size_t(passes) >= plain.size()) return plain;
+	int shift = lo;
+	for (int i = 0; i < passes; ++i) { const int bits = i >= passes - n9 ? 9 : 8; wide.push_back({shift, bits}); shift += bits; }
+	return wide;
 }
 
 void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes,
@@ -347,25 +377,25 @@ void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_
 	u32 nblocks = std::min<u32>(n_tiles, 1024);   // measured flat between 256 and 2048 blocks
 	const u32 tpb = div_up(n_tiles, nblocks);
 	nblocks = div_up(n_tiles, tpb);
-	rs_hist.ensure(size_t(RS_RADIX) * nblocks); rs_row_total.ensure(RS_RADIX); rs_digit_base.ensure(RS_RADIX);
+	rs_hist.ensure(size_t(RS_RADIX_MAX) * nblocks); rs_row_total.ensure(RS_RADIX_MAX); rs_digit_base.ensure(RS_RADIX_MAX);
 	const std::string scatter_s = std::string(stat_prefix ? stat_prefix : "") +
 	                              (val_bytes == 4 ? "rs_scatter" : (val_bytes == 1 ? "rs_scatter:key+1B" : "rs_scatter:keys"));
 	const std::string hist_s = std::string(stat_prefix ? stat_prefix : "") + "rs_hist", scan_s = std::string(stat_prefix ? stat_prefix : "") + "rs_scan";
 	const char *scatter_name = scatter_s.c_str();
-	// Digit windows start at the lowest bit that differs between two keys (the caller masks out bits that need no
-	// ordering, e.g. a mark folded under the key), so ceil(varying width / 8) passes suffice.
-	if (varying_mask == 0) return;
-	for (int shift = __builtin_ctzll(varying_mask); shift < 64; shift += 8) {
-		if (((varying_mask >> shift) & 0xFFull) == 0) continue;   // digit constant over all keys: pass is the identity
+	for (const RadixPass &ps : plan_radix_passes(varying_mask)) {
+		const int shift = ps.shift;
+		const u32 radix = 1u << ps.bits;
 		timed(hist_s.c_str(), double(n) * 8, [&] {
-			hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, stream, keys, n, shift, tpb, u32(RS_TILE_REC), rs_hist.p);
+			if (ps.bits == 9) hipLaunchKernelGGL(rs_hist_kernel<9>, dim3(nblocks), dim3(RS_THREADS), 0, stream, keys, n, shift, tpb, u32(RS_TILE_REC), rs_hist.p);
+			else hipLaunchKernelGGL(rs_hist_kernel<8>, dim3(nblocks), dim3(RS_THREADS), 0, stream, keys, n, shift, tpb, u32(RS_TILE_REC), rs_hist.p);
 		});
-		timed(scan_s.c_str(), double(RS_RADIX) * nblocks * 8, [&] {
-			hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, stream, rs_hist.p, nblocks, rs_row_total.p);
-			hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(256), 0, stream, rs_row_total.p, rs_digit_base.p);
+		timed(scan_s.c_str(), double(radix) * nblocks * 8, [&] {
+			hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(radix), dim3(256), 0, stream, rs_hist.p, nblocks, rs_row_total.p);
+			if (ps.bits == 9) hipLaunchKernelGGL(rs_scan_totals_kernel<512>, dim3(1), dim3(512), 0, stream, rs_row_total.p, rs_digit_base.p);
+			else hipLaunchKernelGGL(rs_scan_totals_kernel<256>, dim3(1), dim3(256), 0, stream, rs_row_total.p, rs_digit_base.p);
 		});
 		timed(scatter_name, double(n) * 2 * (8 + val_bytes), [&] {
-			rs_launch(val_bytes, dim3(nblocks), stream, keys, vals, keys_alt, vals_alt, n, shift, tpb, rs_hist.p, rs_digit_base.p);
+			rs_launch(val_bytes, ps.bits, dim3(nblocks), stream, keys, vals, keys_alt, vals_alt, n, shift, tpb, rs_hist.p, rs_digit_base.p);
 		});
 		std::swap(keys, keys_alt);
 		std::swap(vals, vals_alt);
@@ -408,8 +438,7 @@ void dropest_ctx::reduce_all() {
 	// a mark folded under the key needs no ordering: its bits are masked out of the sort
 	const u64 order_mask = ~((1ull << layout.mark_shift) - 1ull);
 	const u64 varying = (counters.key_or ^ counters.key_and) & order_mask;
-	main_sort_passes = 0;
-	if (varying) for (int shift = __builtin_ctzll(varying); shift < 64; shift += 8) main_sort_passes += ((varying >> shift) & 0xFFull) != 0;
+	main_sort_passes = u32(plan_radix_passes(varying).size());
 	radix_sort(keys, vals, keys_alt, vals_alt, n, varying, layout.val_bytes);
 
 	if (chr_from_gene) {
@@ -1600,10 +1629,10 @@ dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, cons
 		hipStream_t st = nullptr;
 		hipLaunchKernelGGL(owner_keys_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st,
 		                   reinterpret_cast<const u64 *>(d_cb), n, n_parts, k0);
-		hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(RS_THREADS), 0, st, k0, n, 0, tpb, u32(RS_TILE_REC), hist);
+		hipLaunchKernelGGL(rs_hist_kernel<8>, dim3(nblocks), dim3(RS_THREADS), 0, st, k0, n, 0, tpb, u32(RS_TILE_REC), hist);
 		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, st, hist, nblocks, row_total);
-		hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(256), 0, st, row_total, digit_base);
-		rs_launch(0, dim3(nblocks), st, k0, nullptr, k1, nullptr, n, 0, tpb, hist, digit_base);
+		hipLaunchKernelGGL(rs_scan_totals_kernel<256>, dim3(1), dim3(256), 0, st, row_total, digit_base);
+		rs_launch(0, 8, dim3(nblocks), st, k0, nullptr, k1, nullptr, n, 0, tpb, hist, digit_base);
 		hipLaunchKernelGGL(gather_reads_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st, k1, n,
 		                   reinterpret_cast<const u64 *>(d_cb), reinterpret_cast<const u64 *>(d_umi), d_gene, d_aux,
 		                   reinterpret_cast<u64 *>(d_out_cb), reinterpret_cast<u64 *>(d_out_umi), d_out_gene, d_out_aux, d_out_idx);

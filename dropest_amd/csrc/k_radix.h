@@ -26,11 +26,15 @@ constexpr int RS_TILE = RS_THREADS * RS_ITEMS;   // 4096 records per tile
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_RADIX = 256;
 
+// RB = bits of the digit (8, or 9 for the passes radix_sort widens to save a whole pass): RADIX = 2^RB counters
+template <int RB>
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const unsigned long long *__restrict__ keys, uint32_t n,
                                                              int shift, uint32_t tiles_per_block, uint32_t tile,
-                                                             uint32_t *__restrict__ hist /* [256][gridDim.x] */) {
-	__shared__ uint32_t h[RS_WAVES][RS_RADIX];
-	for (int j = threadIdx.x; j < RS_WAVES * RS_RADIX; j += RS_THREADS) (&h[0][0])[j] = 0;
+                                                             uint32_t *__restrict__ hist /* [RADIX][gridDim.x] */) {
+	constexpr uint32_t RADIX = 1u << RB, DMASK = RADIX - 1u;
+	static_assert(RADIX <= RS_THREADS, "one thread per digit writes the block's histogram");
+	__shared__ uint32_t h[RS_WAVES][RADIX];
+	for (int j = threadIdx.x; j < RS_WAVES * int(RADIX); j += RS_THREADS) (&h[0][0])[j] = 0;
 	__syncthreads();
 	const uint64_t begin = uint64_t(blockIdx.x) * tiles_per_block * tile;
 	uint64_t end = begin + uint64_t(tiles_per_block) * tile;
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const unsigned long
 	// changes nothing, matching all groups with 8 ballots per key as the scatter does is slower, 1.8 ms.)
 	const unsigned long long lt_mask = (1ull << lane_id()) - 1ull;
 	auto add = [&](unsigned long long k) {
-		const uint32_t d = uint32_t(k >> shift) & 0xFFu;
+		const uint32_t d = uint32_t(k >> shift) & DMASK;
 		const uint32_t lead = __builtin_amdgcn_readfirstlane(d);
 		const unsigned long long same = __ballot(d == lead);
 		if (d != lead) atomicAdd(&h[w][d], 1u);
@@ -59,11 +63,11 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const unsigned long
 	// (the tails are wave-divergent: plain atomics)
 	for (; i + 1 < end; i += 2ull * RS_THREADS) {
 		const ulonglong2 a = k2[i >> 1];
-		atomicAdd(&h[w][uint32_t(a.x >> shift) & 0xFFu], 1u); atomicAdd(&h[w][uint32_t(a.y >> shift) & 0xFFu], 1u);
+		atomicAdd(&h[w][uint32_t(a.x >> shift) & DMASK], 1u); atomicAdd(&h[w][uint32_t(a.y >> shift) & DMASK], 1u);
 	}
-	if (i < end) atomicAdd(&h[w][uint32_t(keys[i] >> shift) & 0xFFu], 1u);   // odd tail (end == n)
+	if (i < end) atomicAdd(&h[w][uint32_t(keys[i] >> shift) & DMASK], 1u);   // odd tail (end == n)
 	__syncthreads();
-	if (threadIdx.x < RS_RADIX) {
+	if (threadIdx.x < RADIX) {
 		uint32_t s = 0;
 #pragma unroll
 		for (int k = 0; k < RS_WAVES; ++k) s += h[k][threadIdx.x];
@@ -88,11 +92,12 @@ __global__ __launch_bounds__(256) void rs_scan_rows_kernel(uint32_t *__restrict_
 	if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
 }
 
-__global__ __launch_bounds__(256) void rs_scan_totals_kernel(const uint32_t *__restrict__ row_total,
-                                                             uint32_t *__restrict__ digit_base) {
-	__shared__ uint32_t scratch[256 / 64 + 1];
+template <int RADIX>
+__global__ __launch_bounds__(RADIX) void rs_scan_totals_kernel(const uint32_t *__restrict__ row_total,
+                                                               uint32_t *__restrict__ digit_base) {
+	__shared__ uint32_t scratch[RADIX / 64 + 1];
 	uint32_t total;
-	digit_base[threadIdx.x] = block_excl_scan_u32<256>(row_total[threadIdx.x], scratch, total);
+	digit_base[threadIdx.x] = block_excl_scan_u32<RADIX>(row_total[threadIdx.x], scratch, total);
 }
 
 template <int VB> struct RsVal;
@@ -104,7 +109,7 @@ template <> struct RsVal<4> { typedef uint32_t T; };
 // current tile is ranked, so the HBM latency of tile t+1 hides behind the LDS / ballot work of tile t.
 // Full tiles (all but possibly the last one of the array) run without per-record bounds checks.
 // VB: bytes of the value carried with each key (0 = keys only).
-template <int THREADS, int ITEMS, bool PREFETCH, int VB>
+template <int THREADS, int ITEMS, bool PREFETCH, int VB, int RB = 8>
 __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned long long *__restrict__ keys,
                                                                const void *__restrict__ vals_,
                                                                unsigned long long *__restrict__ okeys,
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 	const val_t *__restrict__ vals = static_cast<const val_t *>(vals_);
 	val_t *__restrict__ ovals = static_cast<val_t *>(ovals_);
 	constexpr uint32_t TILE = THREADS * ITEMS, WAVES = THREADS / 64;
+	constexpr uint32_t RS_RADIX = 1u << RB, DMASK = RS_RADIX - 1u;   // (shadows the 8-bit constant of the namespace)
 	static_assert(THREADS >= RS_RADIX, "one thread per digit is needed for the digit scan");
 	__shared__ uint32_t wcnt[WAVES][RS_RADIX];      // per-wave digit counts -> per-wave digit offsets
 	__shared__ uint32_t tcnt[RS_RADIX];             // digit counts of the tile
@@ -171,13 +177,13 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 #pragma unroll
 		for (int i = 0; i < ITEMS; ++i) {
 			const bool valid = full || (lane_off + i * 64) < in_tile;
-			const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
+			const uint32_t d = uint32_t(key[i] >> shift) & DMASK;
 			// lanes of the wave with the same digit: a lane differs from me in bit b iff (ballot of bit b) ^ (my bit b,
 			// broadcast to 0 / ~0) has its bit set; the eight "differs" masks are OR-ed and inverted.  Written on the two
 			// 32-bit halves so that it compiles to bfe + cmp + 2 xor + or3 per bit (the 64-bit select form took 9).
 			uint32_t diff_lo = 0, diff_hi = 0;
 #pragma unroll
-			for (int b = 0; b < 8; ++b) {
+			for (int b = 0; b < RB; ++b) {
 				const int32_t mine = int32_t(d << (31 - b)) >> 31;          // 0 or ~0
 				const unsigned long long bal = __ballot(mine != 0);
 				diff_lo |= uint32_t(bal) ^ uint32_t(mine);
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 		for (int i = 0; i < ITEMS; ++i) {
 			const bool valid = full || (lane_off + i * 64) < in_tile;
 			if (valid) {
-				const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
+				const uint32_t d = uint32_t(key[i] >> shift) & DMASK;
 				const uint32_t p = tstart[d] + wcnt[w][d] + lrank[i];
 				sk[p] = key[i];
 				if (VB) sv[p] = val[i];
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(THREADS) void rs_scatter_kernel_t(const unsigned lo
 		const uint32_t count = full ? TILE : total;
 		for (uint32_t p = tid; p < count; p += THREADS) {
 			const unsigned long long k = sk[p];
-			const uint32_t g = gdelta[uint32_t(k >> shift) & 0xFFu] + p;
+			const uint32_t g = gdelta[uint32_t(k >> shift) & DMASK] + p;
 			okeys[g] = k;
 			if (VB) ovals[g] = sv[p];
 		}

@@ -113,6 +113,9 @@ def test_sortedness_and_checksum_at_scale():
     c = capi.Context(min_genes_before_merge=20, min_genes_after_merge=100)
     c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
     c.set_initialized(); c.merge_and_filter()
+    L = c.sort_layout()
+    width = L["cell_bits"] + L["gene_bits"] + L["umi_bits"]
+    assert width == 57 and L["passes"] == 7                                  # 6 x 8 bits + one 9-bit digit on top
     cell, gene, umi, reads, mark = c.molecules()
     counters = c.global_counters()
     assert int(reads.sum()) + int(counters[0]) == dev.n                      # every read counted exactly once
