@@ -129,6 +129,7 @@ def lib():
         "dropest_dev_copy_device": (C.c_int, [C.c_int, vp, vp, C.c_uint64]),
         "dropest_kernel_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
         "dropest_set_profiling": (C.c_int, [vp, C.c_int]),
+        "dropest_set_profiling_filter": (C.c_int, [vp, C.c_char_p]),
         "dropest_sort_layout": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "dropest_stream": (vp, [vp]),
         "dropest_host_register": (C.c_int, [C.c_int, vp, C.c_uint64, P(vp)]),
@@ -172,7 +173,7 @@ EXPORTED_SYMBOLS = [
     "dropest_collisions_adjusted_sizes", "dropest_poisson_intersection_prob",
     "dropest_set_umi_qualities", "dropest_umi_quality_length", "dropest_cell_molecule_qualities",
     "dropest_exclude_cell", "dropest_merge_cells", "dropest_merge_umis",
-    "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_stream",
+    "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_set_profiling_filter", "dropest_stream",
     "dropest_sort_layout", "dropest_host_register", "dropest_host_unregister", "dropest_ingest", "dropest_ingest_summary_get", "dropest_ingest_summary_set",
     "dropest_gene_chr_table", "dropest_shard_merge_search", "dropest_shard_merge_pairs", "dropest_shard_merge_export",
     "dropest_shard_merge_intersect", "dropest_shard_merge_decide", "dropest_merge_apply", "dropest_shard_merge_finish",
@@ -530,7 +531,9 @@ class Context:
         self._chk(self.L.dropest_sort_layout(self.h, out))
         return dict(zip(("cell_bits", "gene_bits", "umi_bits", "mark_bits_in_key", "value_bytes", "passes"), map(int, out)))
 
-    def set_profiling(self, on=True):
+    def set_profiling(self, on=True, only=None):
+        """HIP events around the launches; only="rs_scatter": just the launches whose stat name starts with that."""
+        self._chk(self.L.dropest_set_profiling_filter(self.h, (only or "").encode()))
         self._chk(self.L.dropest_set_profiling(self.h, int(on)))
 
     def kernel_stats(self):

@@ -215,6 +215,7 @@ struct dropest_ctx {
 
 	// ---- instrumentation ----
 	bool profiling = false;
+	std::string profile_only;      // non-empty: only launches whose stat name starts with this are timed, host stages are not
 	std::map<std::string, dropest::KernelStat> stats;
 	struct Pending { std::string name; hipEvent_t a, b; double bytes; };
 	std::vector<Pending> pending;
@@ -225,7 +226,7 @@ struct dropest_ctx {
 		dropest_ctx *c; const char *name; std::chrono::steady_clock::time_point t0;
 		HostStage(dropest_ctx *ctx, const char *n) : c(ctx), name(n), t0(std::chrono::steady_clock::now()) {}
 		~HostStage() {
-			if (!c->profiling) return;
+			if (!c->profiling || !c->profile_only.empty()) return;
 			auto &s = c->stats[std::string("host:") + name];
 			s.launches++;
 			s.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -90,7 +90,9 @@ dropest_ctx::~dropest_ctx() {
 
 template <class F>
 void dropest_ctx::timed(const char *name, double bytes, F &&launch) {
-	if (!profiling) { launch(); HIP_CHECK(hipGetLastError()); return; }
+	if (!profiling || (!profile_only.empty() && std::strncmp(name, profile_only.c_str(), profile_only.size()) != 0)) {
+		launch(); HIP_CHECK(hipGetLastError()); return;
+	}
 	auto get = [&]() {
 		if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
 		hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
@@ -1764,6 +1766,14 @@ dropest_status dropest_set_profiling(dropest_ctx *ctx, int enabled) {
 		ctx->collect_timings();
 		ctx->profiling = enabled != 0;
 		if (enabled) ctx->stats.clear();
+	});
+}
+
+dropest_status dropest_set_profiling_filter(dropest_ctx *ctx, const char *name_prefix) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		ctx->collect_timings();
+		ctx->profile_only = name_prefix ? name_prefix : "";
 	});
 }
 

@@ -238,8 +238,8 @@ class GpuEngine:
     def kernel_stats(self):
         return self.ctx.kernel_stats()
 
-    def set_profiling(self, on):
-        self.ctx.set_profiling(on)
+    def set_profiling(self, on, only=None):
+        self.ctx.set_profiling(on, only=only)
 
 
 class Collectives:
@@ -354,8 +354,8 @@ class ShardedRun:
         tok = self.coll.all_gather_rows(np.array([[os.getpid()]], np.int64))
         self._token = int(tok[0][0, 0])
 
-    def set_profiling(self, on):
-        self.engine.set_profiling(on)
+    def set_profiling(self, on, only=None):
+        self.engine.set_profiling(on, only=only)
 
     def kernel_stats(self):
         return self.engine.kernel_stats()

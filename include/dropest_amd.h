@@ -350,6 +350,10 @@ dropest_status dropest_kernel_stats(dropest_ctx *ctx, uint32_t *n, dropest_kerne
  * [3] mark bits folded under the key [4] value bytes per record (0, 1 or 4) [5] radix passes of the main sort. */
 dropest_status dropest_sort_layout(dropest_ctx *ctx, uint32_t out[6]);
 dropest_status dropest_set_profiling(dropest_ctx *ctx, int enabled);   /* HIP events per launch; off by default */
+/* Restrict the events to the launches whose stat name starts with `name_prefix` (NULL / "" = all launches and the
+ * host stages).  Two events per launch cost ~0.5 ms per C2 pass when every kernel is timed; bench.py times only the
+ * dominant kernel inside its timed region and collects the full table in a separate pass. */
+dropest_status dropest_set_profiling_filter(dropest_ctx *ctx, const char *name_prefix);
 /* The HIP stream all kernels of this context are launched on (hipStream_t). */
 void *dropest_stream(dropest_ctx *ctx);
 

@@ -123,7 +123,7 @@ class CpuEngine:
     def take(self, tensor, positions):
         return tensor.numpy()[np.asarray(positions, np.int64)].astype(np.int64)
 
-    def set_profiling(self, on):
+    def set_profiling(self, on, only=None):
         pass
 
     def kernel_stats(self):
