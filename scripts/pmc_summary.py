@@ -76,7 +76,8 @@ def main():
     hist = max((r for k, r in by.items() if k.startswith("rs_hist_kernel")), key=lambda r: r[2], default=None)
     if hist:
         print("calibration: rs_hist FETCH raw %.1f KB vs exact %.1f KB -> x%.3f" % (hist[2], 8.0 * n_records / 1024, 8.0 * n_records / 1024 / hist[2]))
-    variants = {"rs_scatter:keys": (", 0>", 16), "rs_scatter:key+1B": (", 1>", 18), "rs_scatter": (", 4>", 24)}
+    # template arguments: <THREADS, ITEMS, PREFETCH, VB, RB>; the 8-bit-digit launches are the bulk of a sort
+    variants = {"rs_scatter:keys": (", 0, 8>", 16), "rs_scatter:key+1B": (", 1, 8>", 18), "rs_scatter": (", 4, 8>", 24)}
     best = None
     for stat_name, (suffix, bytes_per_rec) in variants.items():
         for k, r in by.items():

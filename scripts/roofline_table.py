@@ -38,7 +38,7 @@ if len(sys.argv) > 1 and os.path.exists(sys.argv[1]):
     for row in csv.DictReader(l for l in open(sys.argv[1]) if not l.startswith("#")):
         pmc[row["kernel"]] = float(row["hbm_bytes_per_launch"])
 # kernel-stat name -> substring of the rocprof kernel name
-alias = {"rs_scatter:keys": "rs_scatter_kernel_t<512, 8, false, 0>", "rs_hist": "rs_hist_kernel", "cb_insert": "cb_insert_kernel",
+alias = {"rs_scatter:keys": "rs_scatter_kernel_t<512, 8, false, 0, 8>", "rs_hist": "rs_hist_kernel", "cb_insert": "cb_insert_kernel",
          "build_keys": "build_keys_kernel", "seg_reduce:molecules": "seg_reduce_kernel<ReadsToMoleculesX<0>",
          "seg_reduce:cell_gene": "seg_reduce_kernel<MoleculesToCellGeneX>", "seg_reduce:cells": "seg_reduce_kernel<CellGeneToCells>",
          "seg_count:molecules": "seg_count_kernel<ReadsToMoleculesX<0>", "seg_count:cell_gene": "seg_count_kernel<MoleculesToCellGeneX>",
