@@ -409,9 +409,27 @@ void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_
 // ------------------------------------------------------------------------------------------------
 // Runs count -> scan -> reduce for one policy.  `prepare(total)` allocates + zeroes the outputs and wires the
 // policy's pointers once the number of runs is known.  Returns the number of runs.
+// Grid of the persistent seg_reduce kernel: as many workgroups as are resident at once (occupancy x CUs), at most one
+// per tile.
+template <class P>
+static u32 seg_reduce_grid(u32 tiles) {
+	static const u32 resident = [] {
+		int dev = 0, cus = 0, per_cu = 0;
+		HIP_CHECK(hipGetDevice(&dev));
+		HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+		HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, seg_reduce_kernel<P>, SR_THREADS, 0));
+		return u32(std::max(1, cus) * std::max(1, per_cu));
+	}();
+	return std::max<u32>(1u, std::min(tiles, resident));
+}
+
 template <class P, class Prep>
 static u32 run_segmented_reduce(dropest_ctx &c, const char *tag, P &policy, u32 n, double bytes_per_row, Prep &&prepare) {
-	if (n == 0) { prepare(0); return 0; }
+	if (n == 0) {
+		prepare(0);
+		if constexpr (!P::DIRECT) for (int ch = 0; ch < P::NV; ++ch) if (policy.out[ch]) HIP_CHECK(hipMemsetAsync(policy.out[ch], 0, 4, c.stream));
+		return 0;
+	}
 	const u32 tiles = div_up(n, SR_THREADS * P::ITEMS);
 	c.tile_counts.ensure(tiles); c.tile_prefix.ensure(tiles); c.scalars.ensure(16);
 	const std::string n_count = std::string("seg_count:") + tag, n_reduce = std::string("seg_reduce:") + tag;
@@ -425,8 +443,11 @@ static u32 run_segmented_reduce(dropest_ctx &c, const char *tag, P &policy, u32 
 	u32 total = 0;
 	c.fetch(&total, c.scalars.p, 4);
 	prepare(total);
+	if constexpr (!P::DIRECT) {   // the rows the reduce adds into with atomics (tile-border runs) + the sentinel row; see k_segreduce.h
+		hipLaunchKernelGGL(seg_zero_borders_kernel<P>, dim3(div_up(tiles, 256)), dim3(256), 0, c.stream, policy, c.tile_prefix.p, tiles, total);
+	}
 	c.timed(n_reduce.c_str(), double(n) * bytes_per_row, [&] {
-		hipLaunchKernelGGL(seg_reduce_kernel<P>, dim3(tiles), dim3(SR_THREADS), 0, c.stream, policy, n, c.tile_prefix.p);
+		hipLaunchKernelGGL(seg_reduce_kernel<P>, dim3(seg_reduce_grid<P>(tiles)), dim3(SR_THREADS), 0, c.stream, policy, n, c.tile_prefix.p);
 	});
 	return total;
 }
@@ -449,7 +470,7 @@ void dropest_ctx::reduce_all() {
 			p.keys = keys;
 			n_mol = run_segmented_reduce(*this, "molecules", p, n, 8 + layout.val_bytes + 6, [&](u32 total) {
 				mol_key.ensure(total + 1);
-				for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) { b->ensure(total + 1); zero_async(*this, b->p, size_t(total + 1) * 4); }
+				for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) b->ensure(total + 1);
 				p.mol_key = mol_key.p; p.out[0] = mol_reads.p; p.out[1] = mol_mark.p; p.out[2] = mol_exon.p; p.out[3] = mol_intron.p;
 			});
 		};
@@ -463,7 +484,6 @@ void dropest_ctx::reduce_all() {
 			p.keys = keys; p.vals = vals;
 			n_mol = run_segmented_reduce(*this, "molecules", p, n, 12 + 4, [&](u32 total) {
 				mol_key.ensure(total + 1); mol_reads.ensure(total + 1); mol_mark.ensure(total + 1);
-				zero_async(*this, mol_reads.p, size_t(total + 1) * 4); zero_async(*this, mol_mark.p, size_t(total + 1) * 4);
 				p.mol_key = mol_key.p; p.out[0] = mol_reads.p; p.out[1] = mol_mark.p;
 			});
 		}
@@ -473,8 +493,6 @@ void dropest_ctx::reduce_all() {
 			p.cell_shift = layout.gene_bits + layout.umi_bits; p.umi_bits = layout.umi_bits; p.gene_mask = layout.gene_none;
 			n_chr_rows = run_segmented_reduce(*this, "chr_rows", p, n, 12 + 2, [&](u32 total) {
 				chr_row_key.ensure(total + 1); chr_exon.ensure(total + 1); chr_intron.ensure(total + 1); chr_inter.ensure(total + 1);
-				zero_async(*this, chr_exon.p, size_t(total + 1) * 4); zero_async(*this, chr_intron.p, size_t(total + 1) * 4);
-				zero_async(*this, chr_inter.p, size_t(total + 1) * 4);
 				p.row_key = chr_row_key.p; p.out[0] = chr_exon.p; p.out[1] = chr_intron.p; p.out[2] = chr_inter.p;
 			});
 		}
@@ -488,7 +506,7 @@ void dropest_ctx::reduce_all() {
 void dropest_ctx::reduce_molecules_to_cell_gene() {
 	auto prepare_common = [&](u32 total) {
 		cg_key.ensure(total + 1); cg_mol_begin.ensure(total + 1);
-		for (DevBuf<u32> *b : {&cg_n_all, &cg_n_req, &cg_reads_all, &cg_reads_req}) { b->ensure(total + 1); zero_async(*this, b->p, size_t(total + 1) * 4); }
+		for (DevBuf<u32> *b : {&cg_n_all, &cg_n_req, &cg_reads_all, &cg_reads_req}) b->ensure(total + 1);
 	};
 	if (chr_from_gene) {
 		MoleculesToCellGeneX p{};
@@ -496,7 +514,7 @@ void dropest_ctx::reduce_molecules_to_cell_gene() {
 		p.umi_bits = layout.umi_bits; p.query_mask = query_mask;
 		n_cg = run_segmented_reduce(*this, "cell_gene", p, n_mol, 24 + 8, [&](u32 total) {
 			prepare_common(total);
-			for (DevBuf<u32> *b : {&cg_exon, &cg_intron}) { b->ensure(total + 1); zero_async(*this, b->p, size_t(total + 1) * 4); }
+			for (DevBuf<u32> *b : {&cg_exon, &cg_intron}) b->ensure(total + 1);
 			p.cg_key = cg_key.p; p.cg_mol_begin = cg_mol_begin.p;
 			p.out[0] = cg_n_all.p; p.out[1] = cg_n_req.p; p.out[2] = cg_reads_all.p; p.out[3] = cg_reads_req.p;
 			p.out[4] = cg_exon.p; p.out[5] = cg_intron.p;
@@ -532,7 +550,7 @@ void dropest_ctx::reduce_cell_gene_to_cells() {
 	if (n_cg == 0) return;
 	const u32 tiles = div_up(n_cg, SR_THREADS * CellGeneToCells::ITEMS);
 	timed("seg_reduce:cells", double(n_cg) * (24 + 4), [&] {
-		hipLaunchKernelGGL(seg_reduce_kernel<CellGeneToCells>, dim3(tiles), dim3(SR_THREADS), 0, stream, p, n_cg,
+		hipLaunchKernelGGL(seg_reduce_kernel<CellGeneToCells>, dim3(seg_reduce_grid<CellGeneToCells>(tiles)), dim3(SR_THREADS), 0, stream, p, n_cg,
 		                   static_cast<const u32 *>(nullptr));
 	});
 }

@@ -44,6 +44,23 @@ __global__ __launch_bounds__(SR_THREADS) void seg_count_kernel(P p, uint32_t n, 
 	if (threadIdx.x == 0) tile_heads[blockIdx.x] = total;
 }
 
+// The only output rows seg_reduce accumulates into with atomics are the runs that touch a tile border: the last run of
+// every tile (row tile_prefix[t + 1] - 1; it may continue as the carry-in run of the following tiles).  Every other row
+// is written with one plain store.  So instead of a memset of all output channels (0.7 GB for the molecules of C2)
+// only those rows are cleared, plus the sentinel row `total` behind the table.
+template <class P>
+__global__ __launch_bounds__(256) void seg_zero_borders_kernel(P p, const uint32_t *__restrict__ tile_prefix, uint32_t tiles, uint32_t total) {
+	const uint32_t t = blockIdx.x * 256 + threadIdx.x + 1;   // 1 .. tiles
+	if (t > tiles) return;
+	const uint32_t row = t < tiles ? tile_prefix[t] - 1 : total - 1;
+#pragma unroll
+	for (int c = 0; c < P::NV; ++c) p.out[c][row] = 0;
+	if (t == tiles) {
+#pragma unroll
+		for (int c = 0; c < P::NV; ++c) p.out[c][total] = 0;
+	}
+}
+
 // P must provide:
 //   static constexpr int ITEMS;                      rows per thread (tile = 256 * ITEMS)
 //   static constexpr int NV;                         number of u32 channels
@@ -51,7 +68,8 @@ __global__ __launch_bounds__(SR_THREADS) void seg_count_kernel(P p, uint32_t n, 
 //   __device__ unsigned long long seg_key(uint32_t i) const;
 //   __device__ void load(uint32_t i, uint32_t (&v)[NV]) const;      per-row contribution
 //   __device__ void write_head(uint32_t out, uint32_t i, unsigned long long key) const;
-//   uint32_t *out[NV];                               zero-initialised output channels
+//   uint32_t *out[NV];                               output channels, total + 1 rows each (DIRECT: zero-initialised by the
+//                                                    caller; otherwise run_segmented_reduce clears what needs clearing)
 //   static constexpr bool PACKED;                    true: the row's contribution is staged as ONE word (pack / unpack)
 //                                                    instead of NV words (load) -- less LDS for wide reductions
 //   static constexpr bool DIRECT;                    false: output row = rank of the run (needs seg_count + scan);
@@ -63,125 +81,154 @@ __global__ __launch_bounds__(SR_THREADS) void seg_reduce_kernel(P p, uint32_t n,
 	constexpr int NV = P::NV;
 	constexpr int SR_ITEMS = P::ITEMS, SR_TILE = SR_THREADS * SR_ITEMS;
 	constexpr int PADDED = SR_TILE + SR_TILE / 8 + 2;
+	constexpr int NSV = P::PACKED ? 1 : NV;               // staged words per row
+	// One LDS buffer, used twice: first as the staging area of the coalesced loads (keys + per-row contributions), then --
+	// once every thread holds its rows in registers -- as the per-run aggregates.  max() instead of the sum keeps the
+	// kernel at 4 workgroups per CU instead of 2 (33-37 KB instead of 60 KB), i.e. twice the bytes in flight during the
+	// load and the write-out phases, which is what bounds this kernel (measured: the load phase alone took 0.43 ms of the
+	// 1.0 ms for 0.8 GB at two workgroups per CU).
+	constexpr int KEY_WORDS = 2 * PADDED, VAL_WORDS = NSV * PADDED, AGG_STRIDE = SR_TILE + 1, AGG_WORDS = NV * AGG_STRIDE;
+	constexpr int RAW_WORDS = (KEY_WORDS + VAL_WORDS) > AGG_WORDS ? (KEY_WORDS + VAL_WORDS) : AGG_WORDS;
 	__shared__ uint32_t scratch[SR_THREADS / 64 + 1];
-	__shared__ unsigned long long skey[PADDED];   // logical index 0 = predecessor of the tile, 1.. = rows
-	__shared__ uint32_t sval[P::PACKED ? 1 : NV][PADDED];   // per-row contributions (one packed word, or NV words)
-	__shared__ uint32_t agg[NV][SR_TILE + 1];     // slot 0 = run continuing from the previous tile
+	__shared__ unsigned long long raw[(RAW_WORDS + 1) / 2];
 	__shared__ uint32_t slot_row[P::DIRECT ? SR_TILE + 1 : 1];   // DIRECT: output row of each slot
+	unsigned long long *skey = raw;                              // logical index 0 = predecessor of the tile, 1.. = rows
+	uint32_t *sval = reinterpret_cast<uint32_t *>(raw) + KEY_WORDS;   // [NSV][PADDED]: per-row contributions
+	uint32_t *agg = reinterpret_cast<uint32_t *>(raw);                // [NV][AGG_STRIDE]: slot 0 = run continuing from the previous tile
 
-	// phase 1: coalesced (striped) loads of keys and contributions into LDS
-	const uint32_t t0 = blockIdx.x * SR_TILE;
-#pragma unroll
-	for (int j = 0; j < SR_ITEMS; ++j) {
-		const uint32_t r = j * SR_THREADS + threadIdx.x, i = t0 + r;
-		if (i < n) {
-			skey[sr_pad(r + 1)] = p.seg_key(i);
-			if constexpr (P::PACKED) {
-				sval[0][sr_pad(r)] = p.pack(i);
-			} else {
-				uint32_t v[NV];
-				p.load(i, v);
-#pragma unroll
-				for (int c2 = 0; c2 < NV; ++c2) sval[c2][sr_pad(r)] = v[c2];
-			}
-		}
-	}
-	if (threadIdx.x == 0) {
-		const unsigned long long pred = t0 ? p.seg_key(t0 - 1) : ~p.seg_key(0);
-		skey[sr_pad(0)] = pred;
-		if (P::DIRECT) slot_row[0] = t0 ? p.direct_index(pred) : 0u;
-	}
-	lds_barrier();
-
-	// phase 2: each thread owns SR_ITEMS consecutive rows
-	const uint32_t r0 = threadIdx.x * SR_ITEMS, i0 = t0 + r0;
-	unsigned long long key[SR_ITEMS];
-	uint32_t heads = 0, c = 0;
-	if (i0 < n) {
-		unsigned long long prev = skey[sr_pad(r0)];
+	// Persistent workgroups: each walks tiles blockIdx.x, + gridDim.x, ...; the NEXT tile's rows are fetched into registers
+	// (striped, coalesced) before the current tile is processed, so the HBM latency hides behind the LDS phases.
+	const uint32_t n_tiles = (n + SR_TILE - 1) / SR_TILE;
+	unsigned long long pk[SR_ITEMS], ppred = 0;
+	uint32_t pv[SR_ITEMS][NSV];
+	auto fetch = [&](uint32_t tile) {
+		const uint32_t t0 = tile * SR_TILE;
 #pragma unroll
 		for (int j = 0; j < SR_ITEMS; ++j) {
-			if (i0 + j < n) {
-				key[j] = skey[sr_pad(r0 + j + 1)];
-				if (key[j] != prev) { heads |= 1u << j; ++c; }
-				prev = key[j];
+			const uint32_t i = t0 + j * SR_THREADS + threadIdx.x;
+			if (i < n) {
+				pk[j] = p.seg_key(i);
+				if constexpr (P::PACKED) pv[j][0] = p.pack(i); else p.load(i, pv[j]);
 			}
 		}
-	}
-	uint32_t total;
-	const uint32_t ex = block_excl_scan_u32<SR_THREADS, true>(c, scratch, total);
-	const uint32_t tp = P::DIRECT ? 1u : tile_prefix[blockIdx.x];   // DIRECT: only "tp != 0" matters below
-	// only the slots this tile uses (0 = carry-in run, 1..total = its heads) are cleared and, later, read back
-	for (uint32_t s = threadIdx.x; s <= total; s += SR_THREADS) {
-#pragma unroll
-		for (int c2 = 0; c2 < NV; ++c2) agg[c2][s] = 0;
-	}
-	lds_barrier();
-
-	uint32_t slot = ex;   // rows before this thread's first head belong to the last head seen so far
-	uint32_t acc[NV];
-#pragma unroll
-	for (int c2 = 0; c2 < NV; ++c2) acc[c2] = 0;
-	bool dirty = false;
-	auto flush = [&]() {
-		if (!dirty) return;
-#pragma unroll
-		for (int c2 = 0; c2 < NV; ++c2) {
-			if (acc[c2]) {
-				if (P::OR_MASK & (1u << c2)) atomicOr(&agg[c2][slot], acc[c2]);
-				else atomicAdd(&agg[c2][slot], acc[c2]);
-			}
-			acc[c2] = 0;
-		}
-		dirty = false;
+		if (threadIdx.x == 0) ppred = t0 ? p.seg_key(t0 - 1) : ~p.seg_key(0);
 	};
-	if (i0 < n) {
+	if (blockIdx.x < n_tiles) fetch(blockIdx.x);
+
+	for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		// phase 1: the fetched rows go to LDS
+		const uint32_t t0 = tile * SR_TILE;
 #pragma unroll
 		for (int j = 0; j < SR_ITEMS; ++j) {
-			if (i0 + j < n) {
-				if (heads & (1u << j)) {
-					flush();
-					++slot;
-					if (P::DIRECT) {
-						const uint32_t row = p.direct_index(key[j]);
-						slot_row[slot] = row;
-						p.write_head(row, i0 + j, key[j]);
-					} else {
-						p.write_head(tp + slot - 1, i0 + j, key[j]);
-					}
-				}
-				if constexpr (P::PACKED) {
-					uint32_t v[NV];
-					p.unpack(sval[0][sr_pad(r0 + j)], v);
+			const uint32_t r = j * SR_THREADS + threadIdx.x, i = t0 + r;
+			if (i < n) {
+				skey[sr_pad(r + 1)] = pk[j];
 #pragma unroll
-					for (int c2 = 0; c2 < NV; ++c2) { if (P::OR_MASK & (1u << c2)) acc[c2] |= v[c2]; else acc[c2] += v[c2]; }
-				} else {
-#pragma unroll
-					for (int c2 = 0; c2 < NV; ++c2) {
-						const uint32_t v = sval[c2][sr_pad(r0 + j)];
-						if (P::OR_MASK & (1u << c2)) acc[c2] |= v; else acc[c2] += v;
-					}
-				}
-				dirty = true;
+				for (int c2 = 0; c2 < NSV; ++c2) sval[c2 * PADDED + sr_pad(r)] = pv[j][c2];
 			}
 		}
-		flush();
-	}
-	lds_barrier();
+		if (threadIdx.x == 0) {
+			skey[sr_pad(0)] = ppred;
+			if (P::DIRECT) slot_row[0] = t0 ? p.direct_index(ppred) : 0u;
+		}
+		if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+		lds_barrier();
 
-	for (uint32_t s = threadIdx.x; s <= total; s += SR_THREADS) {
-		if (s == 0 && (P::DIRECT ? blockIdx.x == 0 : tp == 0)) continue;   // row 0 is always a head: no carry-in run for the first tile
-		const uint32_t g = P::DIRECT ? slot_row[s] : tp + s - 1;
-		const bool border = (s == 0) || (s == total);
+		// phase 2: each thread owns SR_ITEMS consecutive rows and takes them (keys and contributions) into registers
+		const uint32_t r0 = threadIdx.x * SR_ITEMS, i0 = t0 + r0;
+		unsigned long long key[SR_ITEMS];
+		uint32_t rv[SR_ITEMS][NSV];
+		uint32_t heads = 0, c = 0;
+		if (i0 < n) {
+			unsigned long long prev = skey[sr_pad(r0)];
 #pragma unroll
-		for (int c2 = 0; c2 < NV; ++c2) {
-			const uint32_t v = agg[c2][s];
-			if (border) {
-				if (v) { if (P::OR_MASK & (1u << c2)) atomicOr(&p.out[c2][g], v); else atomicAdd(&p.out[c2][g], v); }
-			} else {
-				p.out[c2][g] = v;
+			for (int j = 0; j < SR_ITEMS; ++j) {
+				if (i0 + j < n) {
+					key[j] = skey[sr_pad(r0 + j + 1)];
+					if (key[j] != prev) { heads |= 1u << j; ++c; }
+					prev = key[j];
+#pragma unroll
+					for (int c2 = 0; c2 < NSV; ++c2) rv[j][c2] = sval[c2 * PADDED + sr_pad(r0 + j)];
+				}
 			}
 		}
+		lds_barrier();   // every thread has its rows: the staging area is dead, the aggregates may overwrite it
+		uint32_t total;
+		const uint32_t ex = block_excl_scan_u32<SR_THREADS, true>(c, scratch, total);
+		const uint32_t tp = P::DIRECT ? 1u : tile_prefix[tile];   // DIRECT: only "tp != 0" matters below
+		// only the slots this tile uses (0 = carry-in run, 1..total = its heads) are cleared and, later, read back
+		for (uint32_t s = threadIdx.x; s <= total; s += SR_THREADS) {
+#pragma unroll
+			for (int c2 = 0; c2 < NV; ++c2) agg[c2 * AGG_STRIDE + s] = 0;
+		}
+		lds_barrier();
+
+		uint32_t slot = ex;   // rows before this thread's first head belong to the last head seen so far
+		uint32_t acc[NV];
+#pragma unroll
+		for (int c2 = 0; c2 < NV; ++c2) acc[c2] = 0;
+		bool dirty = false;
+		auto flush = [&]() {
+			if (!dirty) return;
+#pragma unroll
+			for (int c2 = 0; c2 < NV; ++c2) {
+				if (acc[c2]) {
+					if (P::OR_MASK & (1u << c2)) atomicOr(&agg[c2 * AGG_STRIDE + slot], acc[c2]);
+					else atomicAdd(&agg[c2 * AGG_STRIDE + slot], acc[c2]);
+				}
+				acc[c2] = 0;
+			}
+			dirty = false;
+		};
+		if (i0 < n) {
+#pragma unroll
+			for (int j = 0; j < SR_ITEMS; ++j) {
+				if (i0 + j < n) {
+					if (heads & (1u << j)) {
+						flush();
+						++slot;
+						if (P::DIRECT) {
+							const uint32_t row = p.direct_index(key[j]);
+							slot_row[slot] = row;
+							p.write_head(row, i0 + j, key[j]);
+						} else {
+							p.write_head(tp + slot - 1, i0 + j, key[j]);
+						}
+					}
+					if constexpr (P::PACKED) {
+						uint32_t v[NV];
+						p.unpack(rv[j][0], v);
+#pragma unroll
+						for (int c2 = 0; c2 < NV; ++c2) { if (P::OR_MASK & (1u << c2)) acc[c2] |= v[c2]; else acc[c2] += v[c2]; }
+					} else {
+#pragma unroll
+						for (int c2 = 0; c2 < NV; ++c2) {
+							const uint32_t v = rv[j][c2];
+							if (P::OR_MASK & (1u << c2)) acc[c2] |= v; else acc[c2] += v;
+						}
+					}
+					dirty = true;
+				}
+			}
+			flush();
+		}
+		lds_barrier();
+
+		for (uint32_t s = threadIdx.x; s <= total; s += SR_THREADS) {
+			if (s == 0 && (P::DIRECT ? tile == 0 : tp == 0)) continue;   // row 0 is always a head: no carry-in run for the first tile
+			const uint32_t g = P::DIRECT ? slot_row[s] : tp + s - 1;
+			const bool border = (s == 0) || (s == total);
+#pragma unroll
+			for (int c2 = 0; c2 < NV; ++c2) {
+				const uint32_t v = agg[c2 * AGG_STRIDE + s];
+				if (border) {
+					if (v) { if (P::OR_MASK & (1u << c2)) atomicOr(&p.out[c2][g], v); else atomicAdd(&p.out[c2][g], v); }
+				} else {
+					p.out[c2][g] = v;
+				}
+			}
+		}
+		lds_barrier();   // the aggregates (and slot_row) are read: the next tile may stage over them
 	}
 }
 

@@ -554,7 +554,7 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 			// reduce finds a smaller buffer and pays a hipFree + hipMalloc of gigabytes (measured: +300 ms at 1e9 reads)
 			const size_t cap = std::max<size_t>(size_t(total) + 1, mol_key.n);
 			mol_key2.ensure(cap);
-			for (DevBuf<u32> *b : {&mol_reads2, &mol_mark2, &mol_exon2, &mol_intron2}) { b->ensure(cap); zero_async(*this, b->p, size_t(total + 1) * 4); }
+			for (DevBuf<u32> *b : {&mol_reads2, &mol_mark2, &mol_exon2, &mol_intron2}) b->ensure(cap);
 			p.mol_key = mol_key2.p; p.out[0] = mol_reads2.p; p.out[1] = mol_mark2.p; p.out[2] = mol_exon2.p; p.out[3] = mol_intron2.p;
 		});
 		HIP_CHECK(hipStreamSynchronize(stream));
@@ -565,7 +565,6 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 		new_n = run_segmented_reduce(*this, "molecules_rekeyed", p, n_mol, 12 + 8, [&](u32 total) {
 			const size_t cap = std::max<size_t>(size_t(total) + 1, mol_key.n);
 			mol_key2.ensure(cap); mol_reads2.ensure(cap); mol_mark2.ensure(cap);
-			zero_async(*this, mol_reads2.p, size_t(total + 1) * 4); zero_async(*this, mol_mark2.p, size_t(total + 1) * 4);
 			p.mol_key = mol_key2.p; p.out[0] = mol_reads2.p; p.out[1] = mol_mark2.p;
 		});
 		HIP_CHECK(hipStreamSynchronize(stream));
