@@ -424,7 +424,8 @@ static u32 seg_reduce_grid(u32 tiles) {
 }
 
 template <class P, class Prep>
-static u32 run_segmented_reduce(dropest_ctx &c, const char *tag, P &policy, u32 n, double bytes_per_row, Prep &&prepare) {
+static u32 run_segmented_reduce(dropest_ctx &c, const char *tag, P &policy, u32 n, double bytes_per_row, Prep &&prepare,
+                                double out_bytes_per_run = 0) {
 	if (n == 0) {
 		prepare(0);
 		if constexpr (!P::DIRECT) for (int ch = 0; ch < P::NV; ++ch) if (policy.out[ch]) HIP_CHECK(hipMemsetAsync(policy.out[ch], 0, 4, c.stream));
@@ -446,7 +447,7 @@ static u32 run_segmented_reduce(dropest_ctx &c, const char *tag, P &policy, u32 
 	if constexpr (!P::DIRECT) {   // the rows the reduce adds into with atomics (tile-border runs) + the sentinel row; see k_segreduce.h
 		hipLaunchKernelGGL(seg_zero_borders_kernel<P>, dim3(div_up(tiles, 256)), dim3(256), 0, c.stream, policy, c.tile_prefix.p, tiles, total);
 	}
-	c.timed(n_reduce.c_str(), double(n) * bytes_per_row, [&] {
+	c.timed(n_reduce.c_str(), double(n) * bytes_per_row + double(total) * out_bytes_per_run, [&] {
 		hipLaunchKernelGGL(seg_reduce_kernel<P>, dim3(seg_reduce_grid<P>(tiles)), dim3(SR_THREADS), 0, c.stream, policy, n, c.tile_prefix.p);
 	});
 	return total;
@@ -468,11 +469,11 @@ void dropest_ctx::reduce_all() {
 		// reads -> molecules with exon / intron read counts; no second pass over the reads for the chromosomes
 		auto run = [&](auto &p) {
 			p.keys = keys;
-			n_mol = run_segmented_reduce(*this, "molecules", p, n, 8 + layout.val_bytes + 6, [&](u32 total) {
+			n_mol = run_segmented_reduce(*this, "molecules", p, n, 8 + layout.val_bytes, [&](u32 total) {
 				mol_key.ensure(total + 1);
 				for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) b->ensure(total + 1);
 				p.mol_key = mol_key.p; p.out[0] = mol_reads.p; p.out[1] = mol_mark.p; p.out[2] = mol_exon.p; p.out[3] = mol_intron.p;
-			});
+			}, 24);
 		};
 		if (layout.val_bytes == 0) { ReadsToMoleculesX<0> p{}; run(p); }
 		else { ReadsToMoleculesX<1> p{}; p.marks = reinterpret_cast<const uint8_t *>(vals); run(p); }
@@ -482,10 +483,10 @@ void dropest_ctx::reduce_all() {
 		{
 			ReadsToMolecules p{};
 			p.keys = keys; p.vals = vals;
-			n_mol = run_segmented_reduce(*this, "molecules", p, n, 12 + 4, [&](u32 total) {
+			n_mol = run_segmented_reduce(*this, "molecules", p, n, 12, [&](u32 total) {
 				mol_key.ensure(total + 1); mol_reads.ensure(total + 1); mol_mark.ensure(total + 1);
 				p.mol_key = mol_key.p; p.out[0] = mol_reads.p; p.out[1] = mol_mark.p;
-			});
+			}, 16);
 		}
 		{
 			ReadsToChrRows p{};
@@ -512,22 +513,22 @@ void dropest_ctx::reduce_molecules_to_cell_gene() {
 		MoleculesToCellGeneX p{};
 		p.mol_key = mol_key.p; p.mol_reads = mol_reads.p; p.mol_mark = mol_mark.p; p.mol_exon = mol_exon.p; p.mol_intron = mol_intron.p;
 		p.umi_bits = layout.umi_bits; p.query_mask = query_mask;
-		n_cg = run_segmented_reduce(*this, "cell_gene", p, n_mol, 24 + 8, [&](u32 total) {
+		n_cg = run_segmented_reduce(*this, "cell_gene", p, n_mol, 24, [&](u32 total) {
 			prepare_common(total);
 			for (DevBuf<u32> *b : {&cg_exon, &cg_intron}) b->ensure(total + 1);
 			p.cg_key = cg_key.p; p.cg_mol_begin = cg_mol_begin.p;
 			p.out[0] = cg_n_all.p; p.out[1] = cg_n_req.p; p.out[2] = cg_reads_all.p; p.out[3] = cg_reads_req.p;
 			p.out[4] = cg_exon.p; p.out[5] = cg_intron.p;
-		});
+		}, 36);
 	} else {
 		MoleculesToCellGene p{};
 		p.mol_key = mol_key.p; p.mol_reads = mol_reads.p; p.mol_mark = mol_mark.p;
 		p.umi_bits = layout.umi_bits; p.query_mask = query_mask;
-		n_cg = run_segmented_reduce(*this, "cell_gene", p, n_mol, 16 + 8, [&](u32 total) {
+		n_cg = run_segmented_reduce(*this, "cell_gene", p, n_mol, 16, [&](u32 total) {
 			prepare_common(total);
 			p.cg_key = cg_key.p; p.cg_mol_begin = cg_mol_begin.p;
 			p.out[0] = cg_n_all.p; p.out[1] = cg_n_req.p; p.out[2] = cg_reads_all.p; p.out[3] = cg_reads_req.p;
-		});
+		}, 28);
 	}
 	// sentinel so that row i owns molecules [cg_mol_begin[i], cg_mol_begin[i+1])
 	HIP_CHECK(hipMemcpyAsync(cg_mol_begin.p + n_cg, &n_mol, 4, hipMemcpyHostToDevice, stream));
