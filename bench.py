@@ -54,6 +54,7 @@ def one_step(ctx):
     ctx.reset_results()
     ctx.set_initialized()
     ctx.merge_and_filter()
+    ctx.prefetch_raw_matrix()                     # cm_raw's copy to the host runs under the preparation of cm
     cm = ctx.count_matrix_csc(filtered=True)
     cm_raw = ctx.count_matrix_csc(filtered=False)
     return cm, cm_raw, ctx.filtered_cells()

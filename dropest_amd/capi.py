@@ -130,6 +130,7 @@ def lib():
         "dropest_kernel_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
         "dropest_set_profiling": (C.c_int, [vp, C.c_int]),
         "dropest_set_profiling_filter": (C.c_int, [vp, C.c_char_p]),
+        "dropest_prefetch_raw_matrix": (C.c_int, [vp, C.c_int]),
         "dropest_sort_layout": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "dropest_stream": (vp, [vp]),
         "dropest_host_register": (C.c_int, [C.c_int, vp, C.c_uint64, P(vp)]),
@@ -173,7 +174,7 @@ EXPORTED_SYMBOLS = [
     "dropest_collisions_adjusted_sizes", "dropest_poisson_intersection_prob",
     "dropest_set_umi_qualities", "dropest_umi_quality_length", "dropest_cell_molecule_qualities",
     "dropest_exclude_cell", "dropest_merge_cells", "dropest_merge_umis",
-    "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_set_profiling_filter", "dropest_stream",
+    "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_set_profiling_filter", "dropest_prefetch_raw_matrix", "dropest_stream",
     "dropest_sort_layout", "dropest_host_register", "dropest_host_unregister", "dropest_ingest", "dropest_ingest_summary_get", "dropest_ingest_summary_set",
     "dropest_gene_chr_table", "dropest_shard_merge_search", "dropest_shard_merge_pairs", "dropest_shard_merge_export",
     "dropest_shard_merge_intersect", "dropest_shard_merge_decide", "dropest_merge_apply", "dropest_shard_merge_finish",
@@ -364,6 +365,10 @@ class Context:
                 return np.zeros(0, np.uint32)
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n,))
         return view(pc, ncols.value + 1), view(pr, nnz.value), view(pv, nnz.value)
+
+    def prefetch_raw_matrix(self, reads_output=False):
+        """Start cm_raw (emit + copy to the host) on a second stream; count_matrix_csc(filtered=False) then only waits."""
+        self._chk(self.L.dropest_prefetch_raw_matrix(self.h, int(reads_output)))
 
     def count_matrix_levels(self, levels, reads_output=False):
         """Filtered count matrix under another mark query, as triplets (gene, column, value) in column-major order."""

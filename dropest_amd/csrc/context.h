@@ -329,5 +329,14 @@ struct dropest_ctx {
 	void request_filtered(u32 genes_threshold, int max_cells);   // CellsDataContainer::update_filtered_gene_counts, lazily
 	void sort_filtered(u32 genes_threshold, int max_cells);
 	void emit_matrix(bool filtered_m, bool reads_output, bool to_host = true);
+	// columns of a count matrix from the host rows: cell id of every column, start of every column, number of entries
+	void matrix_columns(bool filtered_m, std::vector<u32> &col_cell, std::vector<u32> &colptr, uint64_t &nnz);
+	// cm_raw produced and copied to the host on a second stream while the caller goes on (dropest_prefetch_raw_matrix)
+	struct RawPrefetch { bool valid = false, reads_output = false, in_flight = false; std::vector<u32> col_cell; } raw_pf;
+	hipStream_t stream2 = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_raw = nullptr;
+	dropest::DevBuf<u32> m2_col_cell, m2_col_start;
+	void prefetch_raw_matrix(bool reads_output);
+	void invalidate_prefetch();
 	u64 unmap_umi(u64 ucode) const;
 };

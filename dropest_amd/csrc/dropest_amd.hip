@@ -85,6 +85,9 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 dropest_ctx::~dropest_ctx() {
 	for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for (auto e : event_pool) (void)hipEventDestroy(e);
+	if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+	if (ev_fork) (void)hipEventDestroy(ev_fork);
+	if (ev_raw) (void)hipEventDestroy(ev_raw);
 	if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -152,6 +155,7 @@ void dropest_ctx::concat_chunks() {
 }
 
 void dropest_ctx::free_results() {
+	invalidate_prefetch();
 	initialized = merged = ingested = external_merge_done = false;
 	shard.reset();
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
@@ -560,6 +564,7 @@ void dropest_ctx::reduce_cell_gene_to_cells() {
 // stage: real cells to the host; ordering (CellsDataContainer::update_filtered_gene_counts)
 // ------------------------------------------------------------------------------------------------
 void dropest_ctx::fetch_real_cells() {
+	invalidate_prefetch();
 	real.clear();
 	if (n_cells == 0) return;
 	DevBuf<u32> &list = real_list; list.ensure(n_cells);
@@ -775,6 +780,7 @@ void dropest_ctx::run_set_initialized() {
 void dropest_ctx::run_merge_and_filter() {
 	if (!initialized) throw InvalidError("You must initialize container");
 	if (merged) throw InvalidError("merge_and_filter was already run");
+	invalidate_prefetch();
 	HostStage hs(this, "merge_and_filter");
 	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells && !external_merge_done) run_cb_merge_real();
 	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL && n_cells) run_cb_merge_real();   // same loop, Poisson decisions
@@ -790,26 +796,83 @@ void dropest_ctx::run_merge_and_filter() {
 // ------------------------------------------------------------------------------------------------
 // count matrices
 // ------------------------------------------------------------------------------------------------
-void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host) {
-	HostStage hs(this, filtered_m ? "matrix:cm" : "matrix:cm_raw");
-	MatrixResult &M = mat[filtered_m ? 0 : 1];
-	std::vector<u32> col_cell;
-	M.colptr.clear();
-	uint64_t nnz = 0;
+void dropest_ctx::matrix_columns(bool filtered_m, std::vector<u32> &col_cell, std::vector<u32> &colptr, uint64_t &nnz) {
+	col_cell.clear(); colptr.clear();
+	nnz = 0;
 	if (filtered_m) {
 		filtered_cells();
 		for (u32 ri : filtered_ridx) {
 			const HostCell &h = real[ri];
-			col_cell.push_back(h.id); M.colptr.push_back(u32(nnz)); nnz += h.row.requested_genes;
+			col_cell.push_back(h.id); colptr.push_back(u32(nnz)); nnz += h.row.requested_genes;
 		}
 	} else {
 		for (const HostCell &h : real) {
 			if (h.merged || h.excluded || h.row.n_genes < min_before) continue;
-			col_cell.push_back(h.id); M.colptr.push_back(u32(nnz)); nnz += h.row.n_genes;
+			col_cell.push_back(h.id); colptr.push_back(u32(nnz)); nnz += h.row.n_genes;
 		}
 	}
 	if (nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
-	M.colptr.push_back(u32(nnz));
+	colptr.push_back(u32(nnz));
+}
+
+void dropest_ctx::invalidate_prefetch() {
+	if (raw_pf.in_flight && stream2) HIP_CHECK(hipStreamSynchronize(stream2));   // its buffers are about to be reused
+	raw_pf.valid = raw_pf.in_flight = false;
+}
+
+// cm_raw on a second stream: emit + device-to-host copy start now and run under whatever the caller does next (ordering
+// the filtered cells, emitting cm); dropest_count_matrix_csc(filtered = 0) later only waits for the copy.
+void dropest_ctx::prefetch_raw_matrix(bool reads_output) {
+	invalidate_prefetch();
+	MatrixResult &M = mat[1];
+	uint64_t nnz = 0;
+	matrix_columns(false, raw_pf.col_cell, M.colptr, nnz);
+	M.nnz = nnz; M.ncols = raw_pf.col_cell.size();
+	raw_pf.valid = true; raw_pf.reads_output = reads_output;
+	if (nnz == 0) return;
+	if (!stream2) {
+		HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+		HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+		HIP_CHECK(hipEventCreateWithFlags(&ev_raw, hipEventDisableTiming));
+	}
+	const u32 ncols = u32(raw_pf.col_cell.size());
+	m2_col_cell.ensure(ncols); m2_col_start.ensure(ncols);
+	M.d_row.ensure(nnz); M.d_val.ensure(nnz); M.h_row.ensure(nnz); M.h_val.ensure(nnz);
+	HIP_CHECK(hipEventRecord(ev_fork, stream));                // everything enqueued so far (the tables) comes first
+	HIP_CHECK(hipStreamWaitEvent(stream2, ev_fork, 0));
+	HIP_CHECK(hipMemcpyAsync(m2_col_cell.p, raw_pf.col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream2));
+	HIP_CHECK(hipMemcpyAsync(m2_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream2));
+	MatrixArgs a{};
+	a.col_cell = m2_col_cell.p; a.col_start = m2_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
+	a.value = reads_output ? cg_reads_all.p : cg_n_all.p;
+	a.gene_mask = layout.gene_none; a.skip_zero = 0;
+	a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
+	hipLaunchKernelGGL(emit_matrix_kernel, dim3(ncols), dim3(256), 0, stream2, a);
+	HIP_CHECK(hipGetLastError());
+	HIP_CHECK(hipMemcpyAsync(M.h_row.p, M.d_row.p, nnz * 4, hipMemcpyDeviceToHost, stream2));
+	HIP_CHECK(hipMemcpyAsync(M.h_val.p, M.d_val.p, nnz * 4, hipMemcpyDeviceToHost, stream2));
+	HIP_CHECK(hipEventRecord(ev_raw, stream2));
+	raw_pf.in_flight = true;
+}
+
+void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host) {
+	HostStage hs(this, filtered_m ? "matrix:cm" : "matrix:cm_raw");
+	MatrixResult &M = mat[filtered_m ? 0 : 1];
+	std::vector<u32> col_cell;
+	uint64_t nnz = 0;
+	if (!filtered_m && raw_pf.valid) {
+		// a prefetched cm_raw is used if it is what this call would produce: same columns, same sizes, same value kind
+		std::vector<u32> colptr;
+		matrix_columns(false, col_cell, colptr, nnz);
+		if (to_host && raw_pf.reads_output == reads_output && col_cell == raw_pf.col_cell && colptr == M.colptr) {
+			if (raw_pf.in_flight) { HIP_CHECK(hipEventSynchronize(ev_raw)); raw_pf.in_flight = false; }
+			return;
+		}
+		invalidate_prefetch();
+		M.colptr = colptr;
+	} else {
+		matrix_columns(filtered_m, col_cell, M.colptr, nnz);
+	}
 	M.nnz = nnz; M.ncols = col_cell.size();
 	if (nnz == 0) return;
 	const u32 ncols = u32(col_cell.size());
@@ -1398,6 +1461,13 @@ dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int read
 		const dropest_ctx::MatrixResult &M = ctx->mat[filtered ? 0 : 1];
 		*ncols = M.ncols; *nnz = M.nnz;
 		*colptr = M.colptr.data(); *rowidx = M.h_row.p; *values = M.h_val.p;
+	});
+}
+
+dropest_status dropest_prefetch_raw_matrix(dropest_ctx *ctx, int reads_output) {
+	return guarded([&] {
+		need_init(ctx);
+		ctx->prefetch_raw_matrix(reads_output != 0);
 	});
 }
 

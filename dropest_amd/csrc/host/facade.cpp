@@ -529,6 +529,9 @@ void ResultsPrinter::save_mtx(const CellsDataContainer &c, const std::string &ba
 // reads_per_umi_per_cell) is not pinned by anything and is deterministic here: cell-id order, then gene index, then UMI.
 Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 	using namespace Rds;
+	// both matrices are part of the list: cm_raw's emit + copy to the host start now, on the device's second stream, and
+	// run under the cell rows and cm
+	if (dropest_prefetch_raw_matrix(c.handle(), reads_output ? 1 : 0) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
 	const size_t n_cells = c.total_cells_number();
 	std::vector<dropest_cell_row> rows(n_cells);
 	if (n_cells && dropest_cell_rows(c.handle(), 0, n_cells, rows.data()) != DROPEST_OK) throw std::runtime_error(dropest_last_error());

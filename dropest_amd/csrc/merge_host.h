@@ -582,6 +582,7 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 // Re-reads the device sizes of the real-candidate cells; the int stats (TOTAL_READS / TOTAL_UMIS) and the flags
 // are host-tracked through the merges (Stats::merge sums, it does not recount) and are kept.
 void dropest_ctx::refresh_real_rows() {
+	invalidate_prefetch();
 	const u32 count = u32(real.size());
 	if (!count) return;
 	std::vector<u32> ids(count);

@@ -6,6 +6,7 @@
 #pragma once
 
 void dropest_ctx::mutate_exclude_cell(u32 cell) {
+	invalidate_prefetch();
 	const long ri = real_find(cell);
 	if (ri < 0) { extra_excluded.insert(cell); return; }   // not a real-candidate cell: only the flag is observable
 	real[size_t(ri)].excluded = true;

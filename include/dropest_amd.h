@@ -203,6 +203,12 @@ dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int read
                                         uint64_t *nnz, const uint32_t **colptr, const uint32_t **rowidx,
                                         const uint32_t **values);
 
+/* ResultsPrinter::save_results (ResultsPrinter.cpp:23-79) always builds both matrices.  This call starts cm_raw on a
+ * second stream -- emit kernel and the device-to-host copy -- and returns at once; what the caller does next (the
+ * ordering of the filtered cells, cm) runs under that copy.  A following dropest_count_matrix_csc(filtered = 0, same
+ * reads_output) only waits for it; any call that changes the container in between discards the prefetch. */
+dropest_status dropest_prefetch_raw_matrix(dropest_ctx *ctx, int reads_output);
+
 /* ResultsPrinter::get_count_matrix_filtered(container, query_marks) (ResultsPrinter.cpp:333-361) for a mark query other
  * than the container's own -- what ResultsPrinter::save_intron_exon_matrices asks for (-V: "e", "i", "BA",
  * ResultsPrinter.cpp:455-474).  Columns = the filtered cells in their order, zero entries dropped; same CSC

@@ -884,3 +884,38 @@ def test_public_mutators_exclude_merge_cells_merge_umis():
     g, u, r, m = t.cell_molecules(0)
     got = {capi.unpack_code(x, side): int(y) for x, y in zip(u, r)}
     assert got == {"CCCCCT": 2, "GGGGGG": 1, "ACCCCT": 1}                                       # :484-487
+
+
+def test_prefetched_raw_matrix_is_the_same_matrix():
+    """dropest_prefetch_raw_matrix: cm_raw produced on the second stream equals the one produced on demand; a change of
+    the container or another value kind discards the prefetch."""
+    s = SynthStream(n_reads=300_000, n_cells=80, n_genes=4000)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    def fresh():
+        c = capi.Context(min_genes_before_merge=10, min_genes_after_merge=20)
+        c.push_reads(cb, umi, gene, aux); c.set_initialized(); c.merge_and_filter()
+        return c
+    ref = fresh()
+    want = [a.copy() for a in ref.count_matrix_csc(filtered=False)]
+    want_reads = [a.copy() for a in ref.count_matrix_csc(filtered=False, reads_output=True)]
+    c = fresh()
+    c.prefetch_raw_matrix()
+    cm = [a.copy() for a in c.count_matrix_csc(filtered=True)]            # work on the main stream in between
+    got = [a.copy() for a in c.count_matrix_csc(filtered=False)]
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
+    assert all(np.array_equal(a, b) for a, b in zip(cm, ref.count_matrix_csc(filtered=True)))
+    # another value kind than the prefetched one: produced on demand
+    c.prefetch_raw_matrix()
+    got = [a.copy() for a in c.count_matrix_csc(filtered=False, reads_output=True)]
+    assert all(np.array_equal(a, b) for a, b in zip(want_reads, got))
+    # the container changes after the prefetch: the stale matrix must not be returned
+    c.prefetch_raw_matrix()
+    victim = int(c.filtered_cells()[0])
+    c.exclude_cell(victim); ref.exclude_cell(victim)
+    got = [a.copy() for a in c.count_matrix_csc(filtered=False)]
+    want2 = ref.count_matrix_csc(filtered=False)
+    assert all(np.array_equal(a, b) for a, b in zip(want2, got)) and len(got[0]) == len(want[0]) - 1
+    # idempotent over passes
+    c.reset_results(); c.set_initialized(); c.merge_and_filter(); c.prefetch_raw_matrix()
+    got = [a.copy() for a in c.count_matrix_csc(filtered=False)]
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
