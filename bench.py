@@ -21,6 +21,11 @@ import time
 
 import numpy as np
 
+# Completion signals are polled, not interrupt-driven: a step has ~15 host waits, and on the shared hosts of the GPU
+# boxes a blocked thread occasionally takes 5-10 ms to be scheduled again after the interrupt (3 of 30 steps in an A/B,
+# none with polling).  Must be in the environment before the ROCm runtime initialises, i.e. before torch touches the GPU.
+os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -54,7 +59,8 @@ def one_step(ctx):
     ctx.reset_results()
     ctx.set_initialized()
     ctx.merge_and_filter()
-    ctx.prefetch_raw_matrix()                     # cm_raw's copy to the host runs under the preparation of cm
+    if not os.environ.get("DROPEST_BENCH_NO_PREFETCH"):
+        ctx.prefetch_raw_matrix()                 # cm_raw's copy to the host runs under the preparation of cm
     cm = ctx.count_matrix_csc(filtered=True)
     cm_raw = ctx.count_matrix_csc(filtered=False)
     return cm, cm_raw, ctx.filtered_cells()

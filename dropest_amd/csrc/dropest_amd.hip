@@ -1012,6 +1012,10 @@ void dropest_cfg_defaults(dropest_cfg *cfg) {
 dropest_status dropest_ctx_create(const dropest_cfg *cfg, dropest_ctx **out) {
 	if (!cfg || !out) { g_last_error = "null argument"; return DROPEST_ERR_INVALID; }
 	*out = nullptr;
+	// Polled completion signals (no effect if the process initialised the ROCm runtime before, or set the variable
+	// itself): a pass has ~15 host waits; a thread blocked on the interrupt occasionally takes 5-10 ms to run again on a
+	// busy host, a third of a C2 pass.
+	setenv("HSA_ENABLE_INTERRUPT", "0", /*overwrite=*/0);
 	return guarded([&] {
 		std::unique_ptr<dropest_ctx> c(new dropest_ctx());
 		c->init_from_cfg(*cfg);

@@ -106,6 +106,8 @@ const char *dropest_last_error(void);
 /* CellsDataContainer::CellsDataContainer (CellsDataContainer.cpp:20-37) + strategy construction
  * (MergeStrategyFactory.cpp:23-59, RealBarcodesMergeStrategy.cpp:12-20 loads the whitelist). */
 dropest_status dropest_ctx_create(const dropest_cfg *cfg, dropest_ctx **out);
+/* (The first dropest_ctx_create of a process puts HSA_ENABLE_INTERRUPT=0 into the environment unless the variable is
+ * already set: host waits poll the completion signals instead of sleeping on an interrupt -- see DESIGN.md §5.) */
 void dropest_ctx_destroy(dropest_ctx *ctx);
 
 /* Side strings for escaped codes (barcodes / UMIs containing 'N' etc.); the table may only grow. */

@@ -2,9 +2,9 @@
 # Collects the round's profile artefacts on the GPU box into gpurun_out/prof (copy what is to be judged into profiles/):
 #   kernel-trace stats of a 5-step bench run, FETCH_SIZE / WRITE_SIZE counters in separate passes (never together with
 #   any other trace domain), the PMC summary + the per-kernel roofline table, and the default bench line.
-# usage (from the repo root on the GPU box): bash scripts/refresh_profiles.sh r01h
+# usage (from the repo root on the GPU box): bash scripts/refresh_profiles.sh r01i
 set -u
-TAG=${1:-r01h}
+TAG=${1:-r01i}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
