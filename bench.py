@@ -24,7 +24,9 @@ import numpy as np
 # Completion signals are polled, not interrupt-driven: a step has ~15 host waits, and on the shared hosts of the GPU
 # boxes a blocked thread occasionally takes 5-10 ms to be scheduled again after the interrupt (3 of 30 steps in an A/B,
 # none with polling).  Must be in the environment before the ROCm runtime initialises, i.e. before torch touches the GPU.
-os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+# (Single-process runs only: the multi-rank RCCL runs keep the ROCm defaults they were validated with.)
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
