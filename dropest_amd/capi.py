@@ -131,6 +131,7 @@ def lib():
         "dropest_set_profiling": (C.c_int, [vp, C.c_int]),
         "dropest_set_profiling_filter": (C.c_int, [vp, C.c_char_p]),
         "dropest_prefetch_raw_matrix": (C.c_int, [vp, C.c_int]),
+        "dropest_radix_plan": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "dropest_sort_layout": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "dropest_stream": (vp, [vp]),
         "dropest_host_register": (C.c_int, [C.c_int, vp, C.c_uint64, P(vp)]),
@@ -174,7 +175,7 @@ EXPORTED_SYMBOLS = [
     "dropest_collisions_adjusted_sizes", "dropest_poisson_intersection_prob",
     "dropest_set_umi_qualities", "dropest_umi_quality_length", "dropest_cell_molecule_qualities",
     "dropest_exclude_cell", "dropest_merge_cells", "dropest_merge_umis",
-    "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_set_profiling_filter", "dropest_prefetch_raw_matrix", "dropest_stream",
+    "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_set_profiling_filter", "dropest_prefetch_raw_matrix", "dropest_radix_plan", "dropest_stream",
     "dropest_sort_layout", "dropest_host_register", "dropest_host_unregister", "dropest_ingest", "dropest_ingest_summary_get", "dropest_ingest_summary_set",
     "dropest_gene_chr_table", "dropest_shard_merge_search", "dropest_shard_merge_pairs", "dropest_shard_merge_export",
     "dropest_shard_merge_intersect", "dropest_shard_merge_decide", "dropest_merge_apply", "dropest_shard_merge_finish",
@@ -563,6 +564,16 @@ def merge_apply(order, target, total_reads, total_umis):
     if rc != 0:
         raise DropestError(rc, L.dropest_last_error().decode())
     return final, excl, r, u
+
+
+def radix_plan(varying_mask):
+    """[(shift, bits), ...] of the radix sort for keys whose varying bits are `varying_mask` (host logic, no GPU)."""
+    n = C.c_uint32()
+    sh = (C.c_int32 * 8)(); bt = (C.c_int32 * 8)()
+    rc = lib().dropest_radix_plan(C.c_uint64(varying_mask), C.byref(n), sh, bt)
+    if rc != 0:
+        raise DropestError(rc, lib().dropest_last_error().decode())
+    return [(int(sh[i]), int(bt[i])) for i in range(n.value)]
 
 
 def collisions_adjusted_sizes(probs, max_expression, device=0):

@@ -1862,6 +1862,15 @@ dropest_status dropest_set_profiling(dropest_ctx *ctx, int enabled) {
 	});
 }
 
+dropest_status dropest_radix_plan(uint64_t varying_mask, uint32_t *n_passes, int32_t *shifts, int32_t *bits) {
+	return guarded([&] {
+		if (!n_passes) throw InvalidError("null argument");
+		const std::vector<RadixPass> plan = plan_radix_passes(varying_mask);
+		*n_passes = u32(plan.size());
+		for (size_t i = 0; i < plan.size(); ++i) { if (shifts) shifts[i] = plan[i].shift; if (bits) bits[i] = plan[i].bits; }
+	});
+}
+
 dropest_status dropest_set_profiling_filter(dropest_ctx *ctx, const char *name_prefix) {
 	return guarded([&] {
 		if (!ctx) throw InvalidError("null context");

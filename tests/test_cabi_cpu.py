@@ -87,3 +87,41 @@ def test_whitelist_loader_matches_reference_fixture():
     parts = load_whitelist(os.path.join(ROOT, "dropest_amd", "data", "barcodes", "test_est"))
     assert parts[0] == ["AAT", "GAA", "AAA"] and parts[1] == ["TTAGGTCCA", "TTAGGGGCC", "TTAGGTCCC"]
     assert reverse_complement("AACG") == "CGTT"
+
+
+def test_radix_plan_covers_the_varying_bits_with_the_fewest_passes():
+    """plan_radix_passes (dropest_amd.hip): windows ascend without overlap, every varying bit is inside one, digits are 8
+    bits wide except the top ones, which widen to 9 when that saves a whole pass (C2: 57 bits -> 7, C4: 53 -> 6)."""
+    import random
+    from dropest_amd import capi
+    def check(mask):
+        plan = capi.radix_plan(mask)
+        covered = 0
+        at = -1
+        for shift, bits in plan:
+            assert bits in (8, 9) and at < shift < 64
+            assert shift + bits <= 64 or bits == 8          # a plain top window may hang over bit 63 (it reads zeros there)
+            at = shift + bits - 1
+            covered |= ((1 << bits) - 1) << shift
+        assert (mask & ~covered & ((1 << 64) - 1)) == 0
+        if mask:
+            lo = (mask & -mask).bit_length() - 1
+            width = mask.bit_length() - lo
+            plain = sum(1 for s in range(lo, 64, 8) if (mask >> s) & 0xFF)
+            assert len(plan) == min(plain, -(-width // 9)) or len(plan) == plain
+            assert len(plan) <= plain
+        return plan
+    assert check(0) == []
+    assert [b for _, b in check(((1 << 57) - 1) << 3)] == [8] * 6 + [9]                 # C2 key under 3 mark bits
+    assert [b for _, b in check(((1 << 53) - 1) << 3)] == [8] + [9] * 5                 # C4
+    assert [b for _, b in check((1 << 64) - 1)] == [8] * 8                              # C3 at 1e9 reads
+    assert check(0xFF << 32) == [(32, 8)]
+    assert len(check((0xFF << 48) | 0xFF)) == 2                                         # constant windows are skipped
+    rng = random.Random(7)
+    for _ in range(2000):
+        lo, width = rng.randrange(0, 60), rng.randrange(1, 65)
+        width = min(width, 64 - lo)
+        m = ((1 << width) - 1) << lo
+        if rng.random() < 0.5:
+            m &= rng.getrandbits(64) | (1 << lo) | (1 << (lo + width - 1))
+        check(m)
