@@ -11,6 +11,10 @@ from oracle import Oracle
 import parity
 
 pytestmark = pytest.mark.gpu
+
+# soak runs: DROPEST_STRESS_SEED_OFFSET=<n> shifts every random stream of this file (default 0 = the committed cases)
+import os as _os
+SEED_OFFSET = int(_os.environ.get("DROPEST_STRESS_SEED_OFFSET", "0"))
 DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dropest_amd", "data", "barcodes")
 
 
@@ -70,7 +74,7 @@ def run_case(rng, **kw):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_random_small_streams(seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + SEED_OFFSET)
     run_case(rng, n=int(rng.integers(1, 6000)), n_cb=int(rng.integers(1, 60)), n_gene=int(rng.integers(1, 40)),
              n_umi=int(rng.integers(1, 80)))
 
@@ -113,7 +117,7 @@ def test_random_whitelist_merges(seed, poisson, tmp_path):
     """Random small whitelists (inDrop-style two lines, variable first-part length allowed) and barcodes that are exact,
     mutated (substitution / insertion / deletion -> different length) or carry an N: stresses the neighbour search,
     the tie replay (min_merge_fraction 0 half of the time) and the sequential merge application."""
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(7000 + seed + SEED_OFFSET)
     rc = {"A": "T", "C": "G", "G": "C", "T": "A"}
     def rnd(L):
         return "".join(rng.choice(list("ACGT"), L))
@@ -195,7 +199,7 @@ def test_random_directional_umi_merge(seed):
     one run (host replay of the banded edit distance), Ns (random fills), hot genes with more than 16 UMIs."""
     import ctypes
     libc = ctypes.CDLL("libc.so.6")
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(7000 + seed + SEED_OFFSET)
     var_len = seed % 3 == 0
     cb, umi, gene, aux, side = random_stream(
         rng, n=int(rng.integers(200, 9000)), n_cb=int(rng.integers(1, 12)), n_gene=int(rng.integers(1, 12)),
@@ -214,7 +218,7 @@ def test_random_directional_umi_merge(seed):
 def test_random_merge_all(seed):
     """merge_type = all: chains of merges towards ever larger cells; barcodes of one length go through the device
     kernel, mixed lengths and barcodes with N through the host's banded edit distance."""
-    rng = np.random.default_rng(9700 + seed)
+    rng = np.random.default_rng(9700 + seed + SEED_OFFSET)
     cb, umi, gene, aux, side = random_stream(
         rng, n=int(rng.integers(300, 8000)), n_cb=int(rng.integers(2, 60)), n_gene=int(rng.integers(1, 15)),
         n_umi=int(rng.integers(2, 60)), cb_len=(6, 8) if seed % 3 == 0 else (8, 8), cb_n_rate=0.02 if seed % 4 == 1 else 0.0)
@@ -229,7 +233,7 @@ def test_random_merge_all(seed):
 def test_random_poisson_simple_merge(seed):
     """-M without a whitelist: few genes / many exact probability ties (resolved by the unordered_map order replay),
     barcodes with N, every edit-distance threshold and loose to strict probability thresholds."""
-    rng = np.random.default_rng(9500 + seed)
+    rng = np.random.default_rng(9500 + seed + SEED_OFFSET)
     cb, umi, gene, aux, side = random_stream(
         rng, n=int(rng.integers(300, 8000)), n_cb=int(rng.integers(2, 40)), n_gene=int(rng.integers(1, 15)),
         n_umi=int(rng.integers(300, 900)), cb_len=(6, 8) if seed % 3 == 0 else (8, 8), cb_n_rate=0.02 if seed % 2 else 0.0)
@@ -246,7 +250,7 @@ def test_random_poisson_simple_merge(seed):
 def test_random_simple_merge(seed):
     """-m without a whitelist on adversarial streams (few UMIs and genes: many exact ties, barcodes with N, variable
     barcode lengths, every edit-distance threshold)."""
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(9000 + seed + SEED_OFFSET)
     cb, umi, gene, aux, side = random_stream(
         rng, n=int(rng.integers(300, 8000)), n_cb=int(rng.integers(2, 40)), n_gene=int(rng.integers(1, 15)),
         n_umi=int(rng.integers(2, 60)), cb_len=(6, 8) if seed % 3 == 0 else (8, 8), cb_n_rate=0.02 if seed % 2 else 0.0)
