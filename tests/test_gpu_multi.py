@@ -15,16 +15,18 @@ from dropest_amd.synth import SynthStream
 
 pytestmark = pytest.mark.gpu
 
+# soak runs: DROPEST_MULTI_SCALE=<k> multiplies reads and cells of every case of this file (default 1 = the committed cases)
+SCALE = int(os.environ.get("DROPEST_MULTI_SCALE", "1"))
 CFG = {"min_before": 10, "min_after": 30}
-STREAM = dict(n_reads=400_000, n_cells=60, n_genes=3000)
+STREAM = dict(n_reads=400_000 * SCALE, n_cells=60 * SCALE, n_genes=3000)
 
 
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropest_amd", "data", "barcodes")
 MERGE_CASES = {
     # name: (stream parameters, whitelist file, barcodes kind, thresholds)
-    "10x": (dict(n_reads=300_000, n_cells=40, n_genes=2000, umi_len=12, permille_neighbour=150), "10x_aug_2016_split",
+    "10x": (dict(n_reads=300_000 * SCALE, n_cells=40 * SCALE, n_genes=2000, umi_len=12, permille_neighbour=150), "10x_aug_2016_split",
             capi.BARCODES_CONST, {"min_before": 3, "min_after": 20}),
-    "indrop": (dict(n_reads=300_000, n_cells=40, n_genes=2000, umi_len=8, permille_neighbour=150, whitelist="indrop_v3"),
+    "indrop": (dict(n_reads=300_000 * SCALE, n_cells=40 * SCALE, n_genes=2000, umi_len=8, permille_neighbour=150, whitelist="indrop_v3"),
                "indrop_v3", capi.BARCODES_CONST, {"min_before": 3, "min_after": 20}),
 }
 
