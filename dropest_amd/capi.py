@@ -155,6 +155,7 @@ def lib():
         "dropest_dev_copy_from_host": (C.c_int, [C.c_int, vp, vp, C.c_uint64]),
         "dropest_dev_count": (C.c_int, []),
         "dropest_dev_sync": (C.c_int, [C.c_int]),
+        "dropest_rand_sequence": (C.c_int, [C.c_uint32, C.c_uint64, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -181,6 +182,7 @@ EXPORTED_SYMBOLS = [
     "dropest_shard_merge_intersect", "dropest_shard_merge_decide", "dropest_merge_apply", "dropest_shard_merge_finish",
     "dropest_synth_generate_host", "dropest_synth_generate_device", "dropest_dev_alloc", "dropest_dev_free",
     "dropest_dev_copy_to_host", "dropest_dev_copy_from_host", "dropest_dev_count", "dropest_dev_sync",
+    "dropest_rand_sequence",
 ]
 
 

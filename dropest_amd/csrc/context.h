@@ -101,6 +101,40 @@ inline unsigned parallel_ranges(size_t n, F &&fn, size_t min_per_worker = 100000
 	return workers;
 }
 
+// glibc's rand() (random_r, TYPE_3: r[i] = r[i-31] + r[i-3], 310 outputs discarded, result >> 1), restated so that every
+// container owns its sequence: MergeUMIsStrategySimple seeds the PROCESS generator with 42 in its constructor
+// (MergeUMIsStrategySimple.cpp:15-19) and fix_n_umi_with_random draws rand() % 4 per 'N' (MergeUMIsStrategyAbstract.cpp:11-23);
+// a library must not touch the host application's generator, and a second container (or a second pass over the same
+// reads) must reproduce the first.  Checked against libc's srand / rand by tests/test_cabi_cpu.py.
+struct GlibcRand {
+	uint32_t ring[34];
+	int pos = 0;              // index of the oldest entry (= r[i-34])
+	uint64_t drawn = 0;
+	explicit GlibcRand(unsigned seed = 1) { this->seed(seed); }
+	void seed(unsigned s) {
+		int32_t r[34];
+		r[0] = int32_t(s ? s : 1u);
+		for (int i = 1; i < 31; ++i) {
+			const int64_t hi = r[i - 1] / 127773, lo = r[i - 1] % 127773;
+			int64_t w = 16807 * lo - 2836 * hi;
+			if (w < 0) w += 2147483647;
+			r[i] = int32_t(w);
+		}
+		for (int i = 0; i < 31; ++i) ring[i] = uint32_t(r[i]);
+		for (int i = 31; i < 34; ++i) ring[i] = ring[i - 31];
+		pos = 0; drawn = 0;
+		for (int i = 0; i < 310; ++i) step();
+	}
+	uint32_t step() {            // a[i] = a[i-31] + a[i-3] over a window of the last 34 values
+		const uint32_t v = ring[(pos + 3) % 34] + ring[(pos + 31) % 34];
+		ring[pos] = v;
+		pos = (pos + 1) % 34;
+		return v;
+	}
+	int next() { ++drawn; return int(step() >> 1); }
+	void skip_to(uint64_t n_drawn) { while (drawn < n_drawn) next(); }   // forward only
+};
+
 struct HostCell {   // host mirror of one REAL-candidate cell (n_genes >= min_genes_before_merge at init)
 	u32 id;
 	CellRowPod row;         // sizes as of the last device update + stat adjustments (row.barcode = packed code)
@@ -128,6 +162,8 @@ struct dropest_ctx {
 	std::vector<std::string> side;
 
 	bool initialized = false, merged = false;
+	dropest::GlibcRand rng;          // the container's own rand() sequence (random fills of N-UMIs)
+	void reseed_rng() { rng.seed(cfg.umi_merge_kind == DROPEST_UMI_MERGE_SIMPLE ? 42u : 1u); }
 
 	// ---- device results ----
 	dropest::DevBuf<dropest::CbSlot> t_slots;

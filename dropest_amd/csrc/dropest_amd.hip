@@ -77,9 +77,9 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 	if (c.device < 0 || c.device >= ndev) throw InvalidError("device ordinal out of range");
 	HIP_CHECK(hipSetDevice(c.device));
 	HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-	// MergeUMIsStrategySimple's constructor (MergeUMIsStrategySimple.cpp:15-19): random fills use glibc rand();
-	// MergeUMIsStrategyDirectional does not seed
-	if (c.umi_merge_kind == DROPEST_UMI_MERGE_SIMPLE) srand(42);
+	// MergeUMIsStrategySimple's constructor seeds rand() with 42 (MergeUMIsStrategySimple.cpp:15-19); MergeUMIsStrategyDirectional
+	// does not seed, i.e. a fresh reference process draws from srand(1).  The container keeps its own restated generator.
+	reseed_rng();
 }
 
 dropest_ctx::~dropest_ctx() {
@@ -157,6 +157,7 @@ void dropest_ctx::concat_chunks() {
 void dropest_ctx::free_results() {
 	invalidate_prefetch();
 	initialized = merged = ingested = external_merge_done = false;
+	reseed_rng();    // a second pass over the same reads reproduces the first
 	shard.reset();
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
 	real.clear(); filtered.clear(); filtered_valid = false; merge_pairs.clear(); reassign.clear(); umi_overrides.clear(); n_real_now = 0;
@@ -1012,10 +1013,6 @@ void dropest_cfg_defaults(dropest_cfg *cfg) {
 dropest_status dropest_ctx_create(const dropest_cfg *cfg, dropest_ctx **out) {
 	if (!cfg || !out) { g_last_error = "null argument"; return DROPEST_ERR_INVALID; }
 	*out = nullptr;
-	// Polled completion signals (no effect if the process initialised the ROCm runtime before, or set the variable
-	// itself): a pass has ~15 host waits; a thread blocked on the interrupt occasionally takes 5-10 ms to run again on a
-	// busy host, a third of a C2 pass.
-	setenv("HSA_ENABLE_INTERRUPT", "0", /*overwrite=*/0);
 	return guarded([&] {
 		std::unique_ptr<dropest_ctx> c(new dropest_ctx());
 		c->init_from_cfg(*cfg);
@@ -1868,6 +1865,14 @@ dropest_status dropest_radix_plan(uint64_t varying_mask, uint32_t *n_passes, int
 		const std::vector<RadixPass> plan = plan_radix_passes(varying_mask);
 		*n_passes = u32(plan.size());
 		for (size_t i = 0; i < plan.size(); ++i) { if (shifts) shifts[i] = plan[i].shift; if (bits) bits[i] = plan[i].bits; }
+	});
+}
+
+dropest_status dropest_rand_sequence(uint32_t seed, uint64_t n, int32_t *out) {
+	return guarded([&] {
+		if (n && !out) throw InvalidError("null argument");
+		GlibcRand r(seed);
+		for (uint64_t i = 0; i < n; ++i) out[i] = r.next();
 	});
 }
 

@@ -463,6 +463,7 @@ void dropest_ctx::run_cb_merge_real() {
 
 // Unions of the merged cells' molecule sets: re-key, re-sort, re-reduce (Gene::merge, Gene.cpp:26-36).
 void dropest_ctx::reaggregate_after_merge() {
+	invalidate_prefetch();   // a cm_raw prefetch in flight reads the tables this call rewrites
 	HostStage hs(this, "cb_merge:reaggregate");
 	remap.ensure(n_cells);
 	{
@@ -542,6 +543,7 @@ bool dropest_ctx::resort_changed_rows(u64 varying_mask) {
 }
 
 void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
+	invalidate_prefetch();   // a cm_raw prefetch in flight reads the tables this call rewrites
 	u64 *keys = keys_a.p, *keys_alt = keys_b.p;
 	u32 *vals = vals_a.p, *vals_alt = vals_b.p;
 	if (!resort_changed_rows(varying_mask)) radix_sort(keys, vals, keys_alt, vals_alt, n_mol, varying_mask);

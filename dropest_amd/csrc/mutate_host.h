@@ -6,6 +6,7 @@
 #pragma once
 
 void dropest_ctx::mutate_exclude_cell(u32 cell) {
+	invalidate_prefetch();   // a cm_raw prefetch in flight reads the tables this call rewrites
 	invalidate_prefetch();
 	const long ri = real_find(cell);
 	if (ri < 0) { extra_excluded.insert(cell); return; }   // not a real-candidate cell: only the flag is observable
@@ -14,6 +15,7 @@ void dropest_ctx::mutate_exclude_cell(u32 cell) {
 }
 
 void dropest_ctx::mutate_merge_cells(u32 src, u32 tgt) {
+	invalidate_prefetch();   // a cm_raw prefetch in flight reads the tables this call rewrites
 	using namespace dropest;
 	if (src == tgt) throw InvalidError("merge_cells: source and target are the same cell");
 	const long rs = real_find(src), rt = real_find(tgt);
@@ -34,6 +36,7 @@ void dropest_ctx::mutate_merge_cells(u32 src, u32 tgt) {
 }
 
 void dropest_ctx::mutate_merge_umis(u32 cell, u32 gene, uint64_t n, const uint64_t *src, const uint64_t *tgt) {
+	invalidate_prefetch();   // a cm_raw prefetch in flight reads the tables this call rewrites
 	using namespace dropest;
 	if (gene >= layout.gene_none) throw RangeError("gene index out of range");
 	// the (cell, gene) row

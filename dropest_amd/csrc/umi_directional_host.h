@@ -37,7 +37,7 @@ unsigned banded_edit_distance(const std::string &s1, const std::string &s2, unsi
 struct DirUmi { std::string seq; size_t n_reads; };
 
 // MergeUMIsStrategyDirectional::find_target (:83-116)
-std::string directional_find_target(size_t src, const std::vector<DirUmi> &v, double mult, unsigned max_ed) {
+std::string directional_find_target(size_t src, const std::vector<DirUmi> &v, double mult, unsigned max_ed, dropest::GlibcRand &rng) {
 	const DirUmi &s = v[src];
 	const bool has_n = s.seq.find('N') != std::string::npos;
 	std::string target;
@@ -53,16 +53,16 @@ std::string directional_find_target(size_t src, const std::vector<DirUmi> &v, do
 			min_ed = ed;
 		}
 	}
-	if (has_n && target.empty()) return fix_n_with_random(s.seq);
+	if (has_n && target.empty()) return fix_n_with_random(s.seq, rng);
 	return target;
 }
 
 // MergeUMIsStrategyDirectional::find_targets (:55-81); `v` arrives in UMI-index order
-std::unordered_map<std::string, std::string> directional_find_targets(std::vector<DirUmi> &v, double mult, unsigned max_ed) {
+std::unordered_map<std::string, std::string> directional_find_targets(std::vector<DirUmi> &v, double mult, unsigned max_ed, dropest::GlibcRand &rng) {
 	std::sort(v.begin(), v.end(), [](const DirUmi &a, const DirUmi &b) { return a.n_reads < b.n_reads; });
 	std::unordered_map<std::string, std::string> out;
 	for (size_t i = 0; i < v.size(); ++i) {
-		std::string t = directional_find_target(i, v, mult, max_ed);
+		std::string t = directional_find_target(i, v, mult, max_ed, rng);
 		if (!t.empty()) out[v[i].seq] = t;
 	}
 	for (long i = long(v.size()) - 1; i >= 0; --i) {
@@ -214,7 +214,7 @@ void dropest_ctx::run_umi_merge_directional() {
 		std::sort(by_index.begin(), by_index.end(), [&](size_t x, size_t y) { return mols[x].first < mols[y].first; });
 		std::vector<DirUmi> v;
 		for (size_t i : by_index) v.push_back(DirUmi{mols[i].seq, size_t(mols[i].reads)});
-		const auto targets = directional_find_targets(v, cfg.umi_merge_multiplier, unsigned(cfg.max_umi_merge_edit_distance));
+		const auto targets = directional_find_targets(v, cfg.umi_merge_multiplier, unsigned(cfg.max_umi_merge_edit_distance), rng);
 		if (targets.empty()) continue;
 		// Cell::merge_umis + Gene::merge(src, tgt) (Cell.cpp:31-42, Gene.cpp:38-58), in the map's own iteration order
 		struct Folded { u32 reads, mark, row; };               // row: the molecule whose quality sums this one shows

@@ -96,11 +96,11 @@ unsigned hamming_n(const std::string &a, const std::string &b) {
 	return d;
 }
 
-// MergeUMIsStrategyAbstract::fix_n_umi_with_random (MergeUMIsStrategyAbstract.cpp:11-23), glibc rand()
-std::string fix_n_with_random(const std::string &umi) {
+// MergeUMIsStrategyAbstract::fix_n_umi_with_random (MergeUMIsStrategyAbstract.cpp:11-23), glibc rand() restated (context.h)
+std::string fix_n_with_random(const std::string &umi, dropest::GlibcRand &rng) {
 	static const char nt[] = "ACGT";
 	std::string t(umi);
-	for (char &c : t) if (c == 'N') c = nt[rand() % 4];
+	for (char &c : t) if (c == 'N') c = nt[rng.next() % 4];
 	return t;
 }
 
@@ -273,7 +273,7 @@ void dropest_ctx::run_umi_merge_simple() {
 			const Mol &bm = mols[mol_of.at(b)];
 			unsigned min_ed; u32 br; std::vector<size_t> best;
 			candidates_of(mols, bm, min_ed, br, best);
-			if (best.empty() || min_ed > u32(cfg.max_umi_merge_edit_distance)) { targets[b] = fix_n_with_random(b); continue; }
+			if (best.empty() || min_ed > u32(cfg.max_umi_merge_edit_distance)) { targets[b] = fix_n_with_random(b, rng); continue; }
 			size_t pick = best[0];
 			if (best.size() > 1)
 				for (size_t i : best) if (first_seen.at(mols[i].code) < first_seen.at(mols[pick].code)) pick = i;

@@ -70,9 +70,10 @@ enum { DROPEST_MERGE_NONE = 0,          /* DummyMergeStrategy.h:12-17 (no -m) */
 enum { DROPEST_BARCODES_INDROP = 0,     /* InDropBarcodesParser.cpp:15-48 */
        DROPEST_BARCODES_CONST = 1       /* ConstLengthBarcodesParser.cpp:23-68 */ };
 /* UMI-merge strategy (MergeStrategyFactory::get_umi, :105-111) */
-enum { DROPEST_UMI_MERGE_SIMPLE = 0,      /* MergeUMIsStrategySimple.cpp:21-102 (fix UMIs with N); seeds glibc rand() with 42 */
-       DROPEST_UMI_MERGE_DIRECTIONAL = 1  /* -u: MergeUMIsStrategyDirectional.cpp:18-116; random fills of N-UMIs draw from
-                                             the process's rand() state as found (the reference never seeds it here) */ };
+enum { DROPEST_UMI_MERGE_SIMPLE = 0,      /* MergeUMIsStrategySimple.cpp:21-102 (fix UMIs with N); random fills follow glibc's
+                                             rand() after srand(42) (:15-19), from a generator the context owns */
+       DROPEST_UMI_MERGE_DIRECTIONAL = 1  /* -u: MergeUMIsStrategyDirectional.cpp:18-116; the reference never seeds here, a fresh
+                                             process draws from srand(1): the context's generator starts there */ };
 
 /* Replaces the constructor arguments of CellsDataContainer (CellsDataContainer.h:82-85) together with
  * the Estimation.Merge.* keys read by MergeStrategyFactory (MergeStrategyFactory.cpp:26-58). */
@@ -106,8 +107,8 @@ const char *dropest_last_error(void);
 /* CellsDataContainer::CellsDataContainer (CellsDataContainer.cpp:20-37) + strategy construction
  * (MergeStrategyFactory.cpp:23-59, RealBarcodesMergeStrategy.cpp:12-20 loads the whitelist). */
 dropest_status dropest_ctx_create(const dropest_cfg *cfg, dropest_ctx **out);
-/* (The first dropest_ctx_create of a process puts HSA_ENABLE_INTERRUPT=0 into the environment unless the variable is
- * already set: host waits poll the completion signals instead of sleeping on an interrupt -- see DESIGN.md §5.) */
+/* (The library never changes process-global state: no environment variables, no srand().  A caller that wants polled
+ * completion signals sets HSA_ENABLE_INTERRUPT=0 itself before the ROCm runtime starts, as bench.py does -- DESIGN.md §5.) */
 void dropest_ctx_destroy(dropest_ctx *ctx);
 
 /* Side strings for escaped codes (barcodes / UMIs containing 'N' etc.); the table may only grow. */
@@ -360,6 +361,9 @@ dropest_status dropest_sort_layout(dropest_ctx *ctx, uint32_t out[6]);
 /* Digit windows (shift, bits) of the LSD radix sort for keys whose varying bits are `varying_mask` (host logic only, no
  * device needed; at most 8 passes): 8-bit windows, the top ones widened to 9 bits when that saves a pass. */
 dropest_status dropest_radix_plan(uint64_t varying_mask, uint32_t *n_passes, int32_t shifts[8], int32_t bits[8]);
+/* The first n values glibc's rand() returns after srand(seed), from the restated generator every context owns for the
+ * random fills of N-UMIs (MergeUMIsStrategyAbstract.cpp:11-23; host logic only, no device needed). */
+dropest_status dropest_rand_sequence(uint32_t seed, uint64_t n, int32_t *out);
 dropest_status dropest_set_profiling(dropest_ctx *ctx, int enabled);   /* HIP events per launch; off by default */
 /* Restrict the events to the launches whose stat name starts with `name_prefix` (NULL / "" = all launches and the
  * host stages).  Two events per launch cost ~0.5 ms per C2 pass when every kernel is timed; bench.py times only the

@@ -125,3 +125,16 @@ def test_radix_plan_covers_the_varying_bits_with_the_fewest_passes():
         if rng.random() < 0.5:
             m &= rng.getrandbits(64) | (1 << lo) | (1 << (lo + width - 1))
         check(m)
+
+
+def test_restated_glibc_rand_equals_libc():
+    """The context's own generator (context.h: GlibcRand) against libc's srand / rand: MergeUMIsStrategySimple seeds 42
+    (MergeUMIsStrategySimple.cpp:15-19), a fresh process starts from 1; srand(0) is srand(1)."""
+    libc = C.CDLL("libc.so.6")
+    libc.rand.restype = C.c_int
+    for seed in (42, 1, 0, 7, 20260928, 0xFFFFFFFF):
+        got = np.zeros(5000, np.int32)
+        assert capi.lib().dropest_rand_sequence(seed, len(got), got.ctypes.data) == 0
+        libc.srand(C.c_uint(seed))
+        want = np.array([libc.rand() for _ in range(len(got))], np.int32)
+        assert np.array_equal(got, want), seed
