@@ -32,8 +32,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-DOMINANT = "rs_scatter"        # the radix scatter pass (dropest_amd/csrc/k_radix.h)
-# algorithmic bytes of one pass = 2 x (8 B key + value bytes) per record, value bytes = 0 / 1 / 4
+# Candidates for the dominant kernel, timed with HIP events inside the timed region: the partition / finishing-sort
+# kernels of the splitter sort (dropest_amd/csrc/k_ssort.h), the scatter pass of the LSD sort (k_radix.h) and the barcode
+# table build.  Algorithmic bytes per launch are the ones DESIGN.md §2 states per kernel (e.g. a scatter pass =
+# 2 x (8 B key + value bytes) per record).
+DOMINANT = "ss_scatter|ss_local|ss_hist|rs_scatter|cb_insert|build_keys"
 
 
 def parse():
@@ -201,9 +204,11 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / max(1, args.steps) * 1e3
         value = total_reads / (elapsed / max(1, args.steps)) / 1e6
-        # the scatter pass exists in three record widths (keys only / key + 1 B / key + 4 B); the widest share of time wins
-        cands = {k: v for k, v in stats.items() if k.startswith(DOMINANT)}
-        dom_name = max(cands, key=lambda k: cands[k]["ms"]) if cands else DOMINANT
+        # dominant kernel = the candidate with the largest share of the timed region
+        # (only launches whose stat name STARTS with a candidate prefix carry events: the small sorts of the cell ids and of
+        # the splitter sample, "cell_ids:..." / "ss_sample:...", do not)
+        cands = {k: v for k, v in stats.items() if not k.startswith("host:") and v["launches"]}
+        dom_name = max(cands, key=lambda k: cands[k]["ms"]) if cands else "rs_scatter"
         dom = stats.get(dom_name, {"launches": 0, "ms": 0.0, "bytes": 0.0})
         roof = None
         if dom["launches"]:

@@ -535,9 +535,11 @@ class Context:
         return n.value, e.value, p.value
 
     def sort_layout(self):
-        out = (C.c_uint32 * 6)()
+        out = (C.c_uint32 * 7)()
         self._chk(self.L.dropest_sort_layout(self.h, out))
-        return dict(zip(("cell_bits", "gene_bits", "umi_bits", "mark_bits_in_key", "value_bytes", "passes"), map(int, out)))
+        d = dict(zip(("cell_bits", "gene_bits", "umi_bits", "mark_bits_in_key", "value_bytes", "passes", "sort"), map(int, out)))
+        d["sort"] = ("lsd", "splitter")[d["sort"]]
+        return d
 
     def set_profiling(self, on=True, only=None):
         """HIP events around the launches; only="rs_scatter": just the launches whose stat name starts with that."""

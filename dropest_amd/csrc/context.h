@@ -21,6 +21,7 @@
 #include "whitelist.h"
 #include "k_misc.h"
 #include "k_radix.h"
+#include "k_ssort.h"
 #include "k_segreduce.h"
 #include "k_mergepath.h"
 #include "util.h"
@@ -284,9 +285,13 @@ struct dropest_ctx {
 	void assign_cell_ids();
 	void plan_key_layout();
 	void build_keys();
-	u32 main_sort_passes = 0;
+	u32 main_sort_passes = 0, main_sort_kind = 0;   // kind: 0 LSD radix sort, 1 splitter sort
 	void radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes = 4,
 	                const char *stat_prefix = nullptr);
+	// splitter sort (k_ssort.h): sample, splitters, partition scratch, look-back words
+	dropest::DevBuf<u64> ss_sample_a, ss_sample_b, ss_fine, ss_coarse, ss_status;
+	dropest::DevBuf<u32> ss_base1, ss_cnt2, ss_bucket_base, ss_bucket_cnt;
+	bool splitter_sort_reduce();   // false: not applicable / fell back, the caller runs the LSD sort + seg_reduce
 	void reduce_all();
 	void reduce_molecules_to_cell_gene();
 	void reduce_cell_gene_to_cells();

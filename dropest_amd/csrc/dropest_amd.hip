@@ -93,7 +93,18 @@ dropest_ctx::~dropest_ctx() {
 
 template <class F>
 void dropest_ctx::timed(const char *name, double bytes, F &&launch) {
-	if (!profiling || (!profile_only.empty() && std::strncmp(name, profile_only.c_str(), profile_only.size()) != 0)) {
+	auto selected = [&]() {   // profile_only: prefixes separated by '|'
+		if (profile_only.empty()) return true;
+		size_t at = 0;
+		while (at <= profile_only.size()) {
+			size_t end = profile_only.find('|', at);
+			if (end == std::string::npos) end = profile_only.size();
+			if (end > at && std::strncmp(name, profile_only.c_str() + at, end - at) == 0) return true;
+			at = end + 1;
+		}
+		return false;
+	};
+	if (!profiling || !selected()) {
 		launch(); HIP_CHECK(hipGetLastError()); return;
 	}
 	auto get = [&]() {
@@ -410,6 +421,122 @@ void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_
 }
 
 // ------------------------------------------------------------------------------------------------
+// stage: splitter sort + reads -> molecules (k_ssort.h)
+// ------------------------------------------------------------------------------------------------
+// Which path sorts the reads: "splitter" (two partitions on sampled splitters + the LDS-resident finishing sort fused
+// with the molecule reduce) for the keys-only / key + mark byte layouts from DROPEST_SSORT_MIN reads on (default 2^22),
+// the LSD radix sort otherwise and as the fall-back when a fine bucket does not fit the LDS sort (one molecule with more
+// than ~8 000 reads).  DROPEST_SORT=lsd | splitter forces either (tests run both on the same streams).
+static int sort_mode_override() {   // read at every pass: tests switch it inside one process
+	const char *e = getenv("DROPEST_SORT");
+	if (!e) return 0;
+	return !strcmp(e, "lsd") ? 1 : (!strcmp(e, "splitter") ? 2 : 0);
+}
+
+bool dropest_ctx::splitter_sort_reduce() {
+	const u32 n = u32(n_reads);
+	const int mode = sort_mode_override();
+	const char *e_min = getenv("DROPEST_SSORT_MIN");
+	const uint64_t min_reads = e_min ? uint64_t(atoll(e_min)) : (uint64_t(1) << 22);
+	if (mode == 1 || !chr_from_gene || layout.val_bytes > 1) return false;
+	if (mode != 2 && n_reads < min_reads) return false;
+	if (n < 512) return false;
+	// fan-out: F^2 fine buckets of <= ~1536 records on average, F = 16 .. 512
+	int fb = 4;
+	while (fb < 9 && (uint64_t(n) >> (2 * fb)) > 1536) ++fb;
+	if ((uint64_t(n) >> (2 * fb)) > 4096) return false;   // > 1.07e9 records: buckets beyond the LDS sort
+	const u32 F = 1u << fb, F2 = F * F;
+	const int ms = layout.mark_shift, VB = layout.val_bytes;
+	const u32 os = u32(std::max<uint64_t>(1, std::min<uint64_t>(32, uint64_t(n) / (uint64_t(F2) * 2))));
+	const u32 n_sample = F2 * os;
+	const u64 order_mask = ~((1ull << ms) - 1ull);
+	const u64 varying = (counters.key_or ^ counters.key_and) & order_mask;
+
+	HostStage hs(this, "splitter_sort");
+	u64 *keys = keys_a.p, *keys_alt = keys_b.p;
+	uint8_t *vals = reinterpret_cast<uint8_t *>(vals_a.p), *vals_alt = reinterpret_cast<uint8_t *>(vals_b.p);
+
+	// sample -> sorted -> splitters
+	ss_sample_a.ensure(n_sample); ss_sample_b.ensure(n_sample); ss_fine.ensure(F2); ss_coarse.ensure(F);
+	timed("ss_sample", double(n_sample) * 16, [&] {
+		hipLaunchKernelGGL(ss_sample_kernel, dim3(div_up(n_sample, 256)), dim3(256), 0, stream, keys, n, ms, n_sample, ss_sample_a.p);
+	});
+	{
+		u64 *k = ss_sample_a.p, *k_alt = ss_sample_b.p;
+		u32 *v = nullptr, *v_alt = nullptr;
+		radix_sort(k, v, k_alt, v_alt, n_sample, varying >> ms, 0, "ss_sample:");
+		hipLaunchKernelGGL(ss_pick_splitters_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, k, os, F, ss_fine.p, ss_coarse.p);
+		HIP_CHECK(hipGetLastError());
+	}
+
+	// L1: all records into the F coarse buckets
+	const u32 n_tiles = div_up(n, SS_TILE);
+	u32 nblocks = std::min<u32>(n_tiles, 1024);
+	const u32 tpb = div_up(n_tiles, nblocks);
+	nblocks = div_up(n_tiles, tpb);
+	rs_hist.ensure(size_t(F) * nblocks); rs_row_total.ensure(SS_MAX_F); ss_base1.ensure(F + 1);
+	timed("ss_hist:L1", double(n) * 8, [&] {
+		hipLaunchKernelGGL(ss_hist_l1_kernel, dim3(nblocks), dim3(SS_T), 0, stream, keys, n, ms, fb, ss_coarse.p, tpb, rs_hist.p);
+	});
+	timed("ss_scan", double(F) * nblocks * 8, [&] {
+		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(F), dim3(256), 0, stream, rs_hist.p, nblocks, rs_row_total.p);
+		hipLaunchKernelGGL(ss_scan_totals_kernel, dim3(1), dim3(SS_MAX_F), 0, stream, rs_row_total.p, F, n, ss_base1.p);
+	});
+	timed(VB ? "ss_scatter:L1:key+1B" : "ss_scatter:L1:keys", double(n) * 2 * (8 + VB), [&] {
+		if (VB) hipLaunchKernelGGL(ss_scatter_l1_kernel<1>, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb, ss_coarse.p, tpb, rs_hist.p, ss_base1.p);
+		else hipLaunchKernelGGL(ss_scatter_l1_kernel<0>, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb, ss_coarse.p, tpb, rs_hist.p, ss_base1.p);
+	});
+
+	// L2: every coarse bucket into its F fine buckets
+	const u32 parts = std::max<u32>(1, std::min<u32>(16, 2048 / F));
+	ss_cnt2.ensure(size_t(F2) * parts); ss_bucket_base.ensure(F2); ss_bucket_cnt.ensure(F2); scalars.ensure(16);
+	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));   // [0] largest bucket, [1] look-back ticket, [2] error
+	timed("ss_hist:L2", double(n) * 8, [&] {
+		hipLaunchKernelGGL(ss_hist_l2_kernel, dim3(F * parts), dim3(SS_T), 0, stream, keys_alt, ms, fb, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
+	});
+	timed("ss_scan", double(F2) * parts * 8, [&] {
+		hipLaunchKernelGGL(ss_scan_seg_kernel, dim3(F), dim3(SS_MAX_F), 0, stream, ss_cnt2.p, F, parts, ss_base1.p, ss_bucket_base.p, ss_bucket_cnt.p, scalars.p);
+	});
+	u32 max_cnt = 0;
+	fetch(&max_cnt, scalars.p, 4);
+	if (max_cnt > SS_LOCAL_MAX) return false;   // keys_a / vals_a are untouched: the LSD sort takes over
+	timed(VB ? "ss_scatter:L2:key+1B" : "ss_scatter:L2:keys", double(n) * 2 * (8 + VB), [&] {
+		if (VB) hipLaunchKernelGGL(ss_scatter_l2_kernel<1>, dim3(F * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
+		else hipLaunchKernelGGL(ss_scatter_l2_kernel<0>, dim3(F * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
+	});
+
+	// finishing sort + molecule rows (at most one per record)
+	mol_key.ensure(size_t(n) + 1);
+	for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) b->ensure(size_t(n) + 1);
+	ss_status.ensure(F2);
+	HIP_CHECK(hipMemsetAsync(ss_status.p, 0, size_t(F2) * 8, stream));
+	SsLocalArgs a{};
+	a.keys = keys; a.vals = vals; a.bucket_base = ss_bucket_base.p; a.bucket_cnt = ss_bucket_cnt.p; a.n_buckets = F2; a.ms = ms;
+	a.status = ss_status.p; a.ticket = scalars.p + 1; a.error = scalars.p + 2;
+	a.mol_key = mol_key.p; a.mol_reads = mol_reads.p; a.mol_mark = mol_mark.p; a.mol_exon = mol_exon.p; a.mol_intron = mol_intron.p;
+	const int threads = max_cnt <= 4096 ? 256 : 512;
+	a.cap = max_cnt <= u32(threads) * 4 ? u32(threads) * 4 : (max_cnt <= u32(threads) * 8 ? u32(threads) * 8 : u32(threads) * 16);
+	const size_t lds = ss_local_lds_bytes(a.cap, threads);
+	auto launch = [&](auto kernel) {
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+		hipLaunchKernelGGL(kernel, dim3(F2), dim3(threads), lds, stream, a);
+	};
+	timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB) + double(n) * 0.42 * 24, [&] {
+		if (threads == 256) { if (VB) launch(ss_local_kernel<256, 1>); else launch(ss_local_kernel<256, 0>); }
+		else { if (VB) launch(ss_local_kernel<512, 1>); else launch(ss_local_kernel<512, 0>); }
+	});
+	struct { unsigned long long last; } tail{};
+	u32 flags[4] = {0, 0, 0, 0};
+	fetch(&tail, ss_status.p + (F2 - 1), 8);
+	fetch(flags, scalars.p, 16);
+	if (flags[2] || (tail.last >> 62) != 2) throw DeviceError("splitter sort: the look-back chain over the buckets did not complete");
+	n_mol = u32(tail.last & 0xFFFFFFFFull);
+	for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) HIP_CHECK(hipMemsetAsync(b->p + n_mol, 0, 4, stream));   // sentinel row
+	main_sort_passes = 3; main_sort_kind = 1;
+	return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // stage: segmented reduces
 // ------------------------------------------------------------------------------------------------
 // Runs count -> scan -> reduce for one policy.  `prepare(total)` allocates + zeroes the outputs and wires the
@@ -467,7 +594,14 @@ void dropest_ctx::reduce_all() {
 	// a mark folded under the key needs no ordering: its bits are masked out of the sort
 	const u64 order_mask = ~((1ull << layout.mark_shift) - 1ull);
 	const u64 varying = (counters.key_or ^ counters.key_and) & order_mask;
-	main_sort_passes = u32(plan_radix_passes(varying).size());
+	if (splitter_sort_reduce()) {
+		n_chr_rows = 0;
+		reduce_molecules_to_cell_gene();
+		reduce_cell_gene_to_cells();
+		HIP_CHECK(hipStreamSynchronize(stream));
+		return;
+	}
+	main_sort_passes = u32(plan_radix_passes(varying).size()); main_sort_kind = 0;
 	radix_sort(keys, vals, keys_alt, vals_alt, n, varying, layout.val_bytes);
 
 	if (chr_from_gene) {
@@ -1311,12 +1445,12 @@ dropest_status dropest_merge_targets(dropest_ctx *ctx, uint64_t *n, uint64_t *sr
 	});
 }
 
-dropest_status dropest_sort_layout(dropest_ctx *ctx, uint32_t out[6]) {
+dropest_status dropest_sort_layout(dropest_ctx *ctx, uint32_t out[7]) {
 	return guarded([&] {
 		need_init(ctx);
 		const KeyLayout &L = ctx->layout;
 		out[0] = L.cell_bits; out[1] = L.gene_bits; out[2] = L.umi_bits; out[3] = L.mark_shift; out[4] = L.val_bytes;
-		out[5] = ctx->main_sort_passes;
+		out[5] = ctx->main_sort_passes; out[6] = ctx->main_sort_kind;
 	});
 }
 

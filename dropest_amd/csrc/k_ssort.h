@@ -1,0 +1,462 @@
+// k_ssort.h -- splitter sort: two MSD partitions on sampled splitters + an LDS-resident finishing sort fused with the
+// reads -> molecules reduce.  Hand-written for gfx950 (64-lane waves, LDS tiles); integer / HBM-bound work, no MFMA.
+//
+// Replaces, for the main sort of the pipeline, the 7-8 LSD passes of k_radix.h (each a histogram read + a scatter
+// read/write of every record) and the seg_count / seg_reduce<ReadsToMolecules*> launches behind them by
+//   ss_sample      F*F*OS keys at a fixed stride -> sorted with the LSD sort (a few MB) -> F*F-1 fine splitters, every F-th
+//                  of them a coarse splitter
+//   L1  ss_hist / scan / ss_scatter   all records into F coarse buckets (bucket = number of coarse splitters <= key,
+//                  branch-free binary search over the splitters in LDS)
+//   L2  ss_hist / ss_scan_seg / ss_scatter   every coarse bucket into its F fine buckets (~1.5 k records each)
+//   ss_local       one workgroup per fine bucket: the bucket is loaded ONCE into LDS, sorted there (LSD over the bits
+//                  that vary inside the bucket: 3-4 passes of the wave-ballot multisplit), runs of equal molecule keys
+//                  are folded (read count, mark, exon / intron reads) and the molecule rows are written at the global
+//                  offset a decoupled look-back over the buckets provides -- the sorted reads never go back to HBM.
+// Records cross HBM 2.5 times (L1 r+w, L2 hist r, L2 r+w, local r) instead of 7 x 3: see DESIGN.md §2.
+//
+// Equal molecule keys always compare equal against every splitter, so a molecule never straddles two buckets; the
+// partitions need not be stable (what is folded per molecule is commutative), so tile ranks come from LDS atomics.
+// The reference code this stands in for: the std::map insert-position descents of Cell::genes() / Gene::_umis
+// (Estimation/Cell.h:19, Gene.h:19) and Gene::add_umi / UMI::add_read (Gene.cpp:17-24, UMI.cpp:21-34).
+#pragma once
+
+#include "util.h"
+
+namespace dropest {
+
+constexpr int SS_T = 512, SS_I = 8, SS_TILE = SS_T * SS_I;   // partition tile: 4096 records
+constexpr int SS_MAX_F = 512;                                // fan-out of one partition level (power of two, 16..512)
+constexpr uint32_t SS_LOCAL_MAX = 8192;                      // largest fine bucket the LDS sort takes (512 threads x 16)
+
+// ---- sample + splitters -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ss_sample_kernel(const unsigned long long *__restrict__ keys, uint32_t n, int ms,
+                                                        uint32_t n_sample, unsigned long long *__restrict__ out) {
+	const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= n_sample) return;
+	const uint32_t pos = uint32_t((uint64_t(j) * n + n / 2) / n_sample);
+	out[j] = keys[pos < n ? pos : n - 1] >> ms;
+}
+
+// fine[j] = sample[(j + 1) * os], j = 0 .. F*F-2 (entry F*F-1 = ~0, never compared); coarse[j] = fine[(j + 1) * F - 1]
+__global__ __launch_bounds__(256) void ss_pick_splitters_kernel(const unsigned long long *__restrict__ sorted_sample, uint32_t os, uint32_t F,
+                                                                unsigned long long *__restrict__ fine, unsigned long long *__restrict__ coarse) {
+	const uint32_t j = blockIdx.x * 256 + threadIdx.x, F2 = F * F;
+	if (j >= F2) return;
+	const unsigned long long v = j + 1 < F2 ? sorted_sample[size_t(j + 1) * os] : ~0ull;
+	fine[j] = v;
+	if ((j + 1) % F == 0) coarse[(j + 1) / F - 1] = v;
+}
+
+// number of splitters <= mk among sp[0 .. F-2] (F = 1 << fb), branch-free upper bound
+__device__ inline uint32_t ss_search(const unsigned long long *sp, int fb, unsigned long long mk) {
+	uint32_t pos = 0;
+	for (int b = fb - 1; b >= 0; --b) {
+		const uint32_t step = 1u << b;
+		if (sp[pos + step - 1] <= mk) pos += step;
+	}
+	return pos;
+}
+
+// ---- partition: histogram ------------------------------------------------------------------------------------------
+// Counts of the F buckets over records [begin, end); the caller has the splitters in LDS.
+__device__ inline void ss_hist_range(const unsigned long long *__restrict__ keys, uint32_t begin, uint32_t end, int ms, int fb,
+                                     const unsigned long long *sp, uint32_t *cnt) {
+	constexpr int U = 4;
+	for (uint32_t i0 = begin + threadIdx.x; i0 < end; i0 += SS_T * U) {
+		unsigned long long k[U];
+		uint32_t pos[U];
+#pragma unroll
+		for (int q = 0; q < U; ++q) { const uint32_t i = i0 + q * SS_T; k[q] = i < end ? keys[i] >> ms : 0ull; pos[q] = 0; }
+		for (int b = fb - 1; b >= 0; --b) {
+			const uint32_t step = 1u << b;
+#pragma unroll
+			for (int q = 0; q < U; ++q) if (sp[pos[q] + step - 1] <= k[q]) pos[q] += step;
+		}
+#pragma unroll
+		for (int q = 0; q < U; ++q) if (i0 + q * SS_T < end) atomicAdd(&cnt[pos[q]], 1u);
+	}
+}
+
+// L1: block blk owns tiles [blk * tpb, (blk + 1) * tpb) of the whole array; hist[d * gridDim.x + blk]
+__global__ __launch_bounds__(SS_T) void ss_hist_l1_kernel(const unsigned long long *__restrict__ keys, uint32_t n, int ms, int fb,
+                                                          const unsigned long long *__restrict__ coarse, uint32_t tiles_per_block,
+                                                          uint32_t *__restrict__ hist) {
+	__shared__ unsigned long long sp[SS_MAX_F];
+	__shared__ uint32_t cnt[SS_MAX_F];
+	const uint32_t F = 1u << fb;
+	for (uint32_t j = threadIdx.x; j < F; j += SS_T) { sp[j] = j + 1 < F ? coarse[j] : ~0ull; cnt[j] = 0; }
+	__syncthreads();
+	const uint64_t b64 = uint64_t(blockIdx.x) * tiles_per_block * SS_TILE;
+	uint64_t e64 = b64 + uint64_t(tiles_per_block) * SS_TILE;
+	if (e64 > n) e64 = n;
+	if (b64 < n) ss_hist_range(keys, uint32_t(b64), uint32_t(e64), ms, fb, sp, cnt);
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < F; j += SS_T) hist[j * gridDim.x + blockIdx.x] = cnt[j];
+}
+
+// row totals -> exclusive bases of the F coarse buckets; base[F] = n
+__global__ __launch_bounds__(SS_MAX_F) void ss_scan_totals_kernel(const uint32_t *__restrict__ row_total, uint32_t F, uint32_t n,
+                                                                   uint32_t *__restrict__ base) {
+	__shared__ uint32_t scratch[SS_MAX_F / 64 + 1];
+	uint32_t total;
+	const uint32_t ex = block_excl_scan_u32<SS_MAX_F>(threadIdx.x < F ? row_total[threadIdx.x] : 0u, scratch, total);
+	if (threadIdx.x < F) base[threadIdx.x] = ex;
+	if (threadIdx.x == 0) base[F] = n;
+}
+
+// part p of coarse bucket s: whole tiles of the bucket, [begin, end) in record indices
+__device__ inline void ss_l2_range(const uint32_t *__restrict__ base1, uint32_t s, uint32_t p, uint32_t parts, uint32_t &begin, uint32_t &end) {
+	const uint32_t sb = base1[s], se = base1[s + 1];
+	const uint32_t tiles = (se - sb + SS_TILE - 1) / SS_TILE, tpp = (tiles + parts - 1) / parts;
+	const uint64_t b = uint64_t(sb) + uint64_t(p) * tpp * SS_TILE, e = b + uint64_t(tpp) * SS_TILE;
+	begin = b < se ? uint32_t(b) : se;
+	end = e < se ? uint32_t(e) : se;
+}
+
+// L2: block (s, p) = blockIdx.x / parts, % parts; cnt2[(s * F + d) * parts + p]
+__global__ __launch_bounds__(SS_T) void ss_hist_l2_kernel(const unsigned long long *__restrict__ keys, int ms, int fb,
+                                                          const unsigned long long *__restrict__ fine, const uint32_t *__restrict__ base1,
+                                                          uint32_t parts, uint32_t *__restrict__ cnt2) {
+	__shared__ unsigned long long sp[SS_MAX_F];
+	__shared__ uint32_t cnt[SS_MAX_F];
+	const uint32_t F = 1u << fb, s = blockIdx.x / parts, p = blockIdx.x % parts;
+	for (uint32_t j = threadIdx.x; j < F; j += SS_T) { sp[j] = j + 1 < F ? fine[size_t(s) * F + j] : ~0ull; cnt[j] = 0; }
+	__syncthreads();
+	uint32_t begin, end;
+	ss_l2_range(base1, s, p, parts, begin, end);
+	if (begin < end) ss_hist_range(keys, begin, end, ms, fb, sp, cnt);
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < F; j += SS_T) cnt2[(size_t(s) * F + j) * parts + p] = cnt[j];
+}
+
+// One block per coarse bucket s: turns cnt2[(s, f, p)] into absolute output cursors, writes base / size of every fine
+// bucket and the largest size.
+__global__ __launch_bounds__(SS_MAX_F) void ss_scan_seg_kernel(uint32_t *__restrict__ cnt2, uint32_t F, uint32_t parts,
+                                                                const uint32_t *__restrict__ base1, uint32_t *__restrict__ bucket_base,
+                                                                uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ max_cnt) {
+	__shared__ uint32_t scratch[SS_MAX_F / 64 + 1];
+	const uint32_t s = blockIdx.x, f = threadIdx.x;
+	uint32_t *row = cnt2 + (size_t(s) * F + f) * parts;
+	uint32_t sum = 0;
+	if (f < F) for (uint32_t p = 0; p < parts; ++p) sum += row[p];
+	uint32_t total;
+	const uint32_t ex = block_excl_scan_u32<SS_MAX_F>(sum, scratch, total);
+	if (f < F) {
+		uint32_t run = base1[s] + ex;
+		bucket_base[size_t(s) * F + f] = run;
+		bucket_cnt[size_t(s) * F + f] = sum;
+		for (uint32_t p = 0; p < parts; ++p) { const uint32_t c = row[p]; row[p] = run; run += c; }
+	}
+	const unsigned long long m = wave_reduce_max_u64(sum);
+	if (lane_id() == 0 && m) atomicMax(max_cnt, uint32_t(m));
+}
+
+// ---- partition: scatter --------------------------------------------------------------------------------------------
+// Records [begin, end) go to the F buckets whose running output cursors the caller has put into goff[] (LDS).
+template <int VB>
+__device__ inline void ss_scatter_range(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
+                                        unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, uint32_t begin, uint32_t end,
+                                        int ms, int fb, const unsigned long long *sp, uint32_t *goff, uint32_t *cnt, uint32_t *tstart,
+                                        uint32_t *gdelta, uint32_t *scratch, unsigned long long *sk, uint16_t *sd, uint8_t *sv) {
+	const uint32_t F = 1u << fb, tid = threadIdx.x;
+	for (uint32_t t0 = begin; t0 < end; t0 += SS_TILE) {
+		const uint32_t in_tile = end - t0 < uint32_t(SS_TILE) ? end - t0 : uint32_t(SS_TILE);
+		if (tid < F) cnt[tid] = 0;
+		lds_barrier();
+		unsigned long long key[SS_I];
+		uint8_t val[VB ? SS_I : 1];
+		uint32_t pos[SS_I], rk[SS_I];
+#pragma unroll
+		for (int i = 0; i < SS_I; ++i) {
+			const uint32_t p = i * SS_T + tid;
+			key[i] = p < in_tile ? keys[t0 + p] : 0ull;
+			if (VB) val[i] = p < in_tile ? vals[t0 + p] : uint8_t(0);
+			pos[i] = 0;
+		}
+		for (int b = fb - 1; b >= 0; --b) {
+			const uint32_t step = 1u << b;
+#pragma unroll
+			for (int i = 0; i < SS_I; ++i) if (sp[pos[i] + step - 1] <= (key[i] >> ms)) pos[i] += step;
+		}
+#pragma unroll
+		for (int i = 0; i < SS_I; ++i) rk[i] = (i * SS_T + tid) < in_tile ? atomicAdd(&cnt[pos[i]], 1u) : 0u;
+		lds_barrier();
+		const uint32_t c = tid < F ? cnt[tid] : 0u;
+		uint32_t total;
+		const uint32_t ex = block_excl_scan_u32<SS_T, true>(c, scratch, total);
+		if (tid < F) { tstart[tid] = ex; gdelta[tid] = goff[tid] - ex; goff[tid] += c; }
+		lds_barrier();
+#pragma unroll
+		for (int i = 0; i < SS_I; ++i)
+			if ((i * SS_T + tid) < in_tile) {
+				const uint32_t q = tstart[pos[i]] + rk[i];
+				sk[q] = key[i]; sd[q] = uint16_t(pos[i]);
+				if (VB) sv[q] = val[i];
+			}
+		lds_barrier();
+		for (uint32_t q = tid; q < in_tile; q += SS_T) {
+			const uint32_t g = gdelta[sd[q]] + q;
+			okeys[g] = sk[q];
+			if (VB) ovals[g] = sv[q];
+		}
+		lds_barrier();
+	}
+}
+
+#define SS_SCATTER_LDS(VB)                                                                                  \
+	__shared__ unsigned long long sp[SS_MAX_F];                                                             \
+	__shared__ uint32_t goff[SS_MAX_F], cnt[SS_MAX_F], tstart[SS_MAX_F], gdelta[SS_MAX_F], scratch[SS_T / 64 + 1]; \
+	__shared__ unsigned long long sk[SS_TILE];                                                              \
+	__shared__ uint16_t sd[SS_TILE];                                                                        \
+	__shared__ uint8_t sv[VB ? SS_TILE : 1];
+
+template <int VB>
+__global__ __launch_bounds__(SS_T) void ss_scatter_l1_kernel(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
+                                                             unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, uint32_t n,
+                                                             int ms, int fb, const unsigned long long *__restrict__ coarse,
+                                                             uint32_t tiles_per_block, const uint32_t *__restrict__ hist,
+                                                             const uint32_t *__restrict__ base1) {
+	SS_SCATTER_LDS(VB)
+	const uint32_t F = 1u << fb;
+	for (uint32_t j = threadIdx.x; j < F; j += SS_T) {
+		sp[j] = j + 1 < F ? coarse[j] : ~0ull;
+		goff[j] = base1[j] + hist[j * gridDim.x + blockIdx.x];
+	}
+	__syncthreads();
+	const uint64_t b64 = uint64_t(blockIdx.x) * tiles_per_block * SS_TILE;
+	uint64_t e64 = b64 + uint64_t(tiles_per_block) * SS_TILE;
+	if (e64 > n) e64 = n;
+	if (b64 < n) ss_scatter_range<VB>(keys, vals, okeys, ovals, uint32_t(b64), uint32_t(e64), ms, fb, sp, goff, cnt, tstart, gdelta, scratch, sk, sd, sv);
+}
+
+template <int VB>
+__global__ __launch_bounds__(SS_T) void ss_scatter_l2_kernel(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
+                                                             unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, int ms, int fb,
+                                                             const unsigned long long *__restrict__ fine, const uint32_t *__restrict__ base1,
+                                                             uint32_t parts, const uint32_t *__restrict__ cnt2) {
+	SS_SCATTER_LDS(VB)
+	const uint32_t F = 1u << fb, s = blockIdx.x / parts, p = blockIdx.x % parts;
+	for (uint32_t j = threadIdx.x; j < F; j += SS_T) {
+		sp[j] = j + 1 < F ? fine[size_t(s) * F + j] : ~0ull;
+		goff[j] = cnt2[(size_t(s) * F + j) * parts + p];
+	}
+	__syncthreads();
+	uint32_t begin, end;
+	ss_l2_range(base1, s, p, parts, begin, end);
+	if (begin < end) ss_scatter_range<VB>(keys, vals, okeys, ovals, begin, end, ms, fb, sp, goff, cnt, tstart, gdelta, scratch, sk, sd, sv);
+}
+
+// ---- finishing sort + reads -> molecules ---------------------------------------------------------------------------
+struct SsLocalArgs {
+	const unsigned long long *keys;      // grouped by fine bucket (output of the L2 scatter)
+	const uint8_t *vals;                 // mark bytes (VB = 1)
+	const uint32_t *bucket_base, *bucket_cnt;
+	uint32_t n_buckets;
+	int ms;                              // mark bits folded under the key (VB = 0: 3)
+	uint32_t cap;                        // records the LDS of this launch holds
+	unsigned long long *status;          // [n_buckets] look-back words, zeroed before the launch
+	uint32_t *ticket, *error;            // zeroed before the launch
+	unsigned long long *mol_key;
+	uint32_t *mol_reads, *mol_mark, *mol_exon, *mol_intron;
+};
+
+constexpr unsigned long long SS_FLAG_AGG = 1ull << 62, SS_FLAG_INCL = 2ull << 62;
+constexpr uint32_t SS_SPIN_LIMIT = 1u << 21;
+
+// Decoupled look-back over the buckets in ticket order (one wave): publishes this bucket's molecule count, returns the
+// number of molecules of all earlier buckets.  Every word is ONE naturally aligned 8-byte {flag, value} granule written
+// and polled with agent-scope relaxed atomics (the data is the flag; MI355X_MICROARCH.md, inter-workgroup visibility).
+// Tickets are handed out in dispatch order, so every predecessor is running or done: the spin is bounded all the same.
+__device__ inline uint32_t ss_lookback(unsigned long long *status, uint32_t vid, uint32_t n_loc, uint32_t *error) {
+	const uint32_t lane = lane_id();
+	if (vid == 0) {
+		if (lane == 0) __hip_atomic_store(&status[0], SS_FLAG_INCL | n_loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return 0;
+	}
+	if (lane == 0) __hip_atomic_store(&status[vid], SS_FLAG_AGG | n_loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	uint32_t excl = 0, spins = 0;
+	long long pos = vid;   // window [pos - 64, pos)
+	for (;;) {
+		const long long idx = pos - 1 - lane;
+		const unsigned long long v = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SS_FLAG_INCL;
+		const uint32_t flag = uint32_t(v >> 62);
+		const unsigned long long b_incl = __ballot(flag == 2), b_empty = __ballot(flag == 0);
+		const int first_incl = b_incl ? __builtin_ctzll(b_incl) : 64;
+		const unsigned long long need = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);
+		if (b_empty & need) {
+			if (++spins > SS_SPIN_LIMIT) { if (lane == 0) atomicOr(error, 1u); break; }
+			__builtin_amdgcn_s_sleep(2);
+			continue;
+		}
+		const unsigned long long c = int(lane) <= first_incl ? (v & 0xFFFFFFFFull) : 0ull;
+		excl += uint32_t(wave_reduce_add_u64(c));
+		if (first_incl < 64) break;
+		pos -= 64;
+	}
+	if (lane == 0) __hip_atomic_store(&status[vid], SS_FLAG_INCL | (excl + n_loc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return excl;
+}
+
+// LDS of ss_local (dynamic, 16-byte aligned): sk[cap] keys -- later aliased by agg[cap] + headpos[cap] (u32 each) --,
+// wcnt[WAVES][256], tstart[256], scratch, red[], sv[cap] bytes
+template <int THREADS, int ITEMS, int VB>
+__device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t vid, uint32_t base, uint32_t cnt, unsigned char *smem) {
+	constexpr uint32_t WAVES = THREADS / 64;
+	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+	unsigned long long *sk = reinterpret_cast<unsigned long long *>(smem);
+	uint32_t *agg = reinterpret_cast<uint32_t *>(smem);
+	uint32_t *headpos = agg + a.cap;
+	uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + size_t(a.cap) * 8);   // [WAVES][256]
+	uint32_t *tstart = wcnt + WAVES * 256;                                     // [256]
+	uint32_t *scratch = tstart + 256;                                          // [THREADS / 64 + 1], then wtot[WAVES], misc[4]
+	uint32_t *wtot = scratch + (THREADS / 64 + 1);
+	uint32_t *misc = wtot + WAVES;
+	unsigned long long *red = reinterpret_cast<unsigned long long *>(misc + 4 + ((WAVES + 1) & 1u));   // [2 * WAVES], 8-byte aligned
+	uint8_t *sv = reinterpret_cast<uint8_t *>(red + 2 * WAVES);
+	const int ms = a.ms;
+
+	const uint32_t lane_off = w * (64 * ITEMS) + lane;   // position of item 0; item i sits at lane_off + 64 i: order = (wave, item, lane)
+	unsigned long long key[ITEMS];
+	uint8_t val[VB ? ITEMS : 1];
+	unsigned long long k_or = 0, k_and = ~0ull;
+#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		const uint32_t p = lane_off + i * 64;
+		const bool valid = p < cnt;
+		key[i] = valid ? a.keys[base + p] : 0ull;
+		if (VB) val[i] = valid ? a.vals[base + p] : uint8_t(0);
+		if (valid) { k_or |= key[i]; k_and &= key[i]; sk[p] = key[i]; if (VB) sv[p] = val[i]; }
+	}
+	k_or = wave_reduce_or_u64(k_or); k_and = wave_reduce_and_u64(k_and);
+	if (lane == 0) { red[2 * w] = k_or; red[2 * w + 1] = k_and; }
+	lds_barrier();
+	k_or = 0; k_and = ~0ull;
+#pragma unroll
+	for (uint32_t k = 0; k < WAVES; ++k) { k_or |= red[2 * k]; k_and &= red[2 * k + 1]; }
+	const unsigned long long vary = (k_or ^ k_and) & ~((1ull << ms) - 1ull);
+
+	// LSD over the varying bits, 8 per pass, ranks by the wave-ballot multisplit of k_radix.h (stable)
+	for (int shift = vary ? __builtin_ctzll(vary) : 64; shift < 64 && (vary >> shift) != 0; shift += 8) {
+		if (((vary >> shift) & 0xFFull) == 0) continue;
+		for (uint32_t j = tid; j < WAVES * 256; j += THREADS) wcnt[j] = 0;
+		lds_barrier();
+		uint32_t lrank[ITEMS];
+#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) {
+			const bool valid = (lane_off + i * 64) < cnt;
+			const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
+			uint32_t diff_lo = 0, diff_hi = 0;
+#pragma unroll
+			for (int b = 0; b < 8; ++b) {
+				const int32_t mine = int32_t(d << (31 - b)) >> 31;
+				const unsigned long long bal = __ballot(mine != 0);
+				diff_lo |= uint32_t(bal) ^ uint32_t(mine);
+				diff_hi |= uint32_t(bal >> 32) ^ uint32_t(mine);
+			}
+			unsigned long long m = ~(((unsigned long long)diff_hi << 32) | diff_lo);
+			m &= __ballot(valid);
+			const uint32_t before = __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+			const uint32_t old = wcnt[w * 256 + d];
+			__builtin_amdgcn_wave_barrier();
+			if (valid && before == 0) wcnt[w * 256 + d] = old + __popcll(m);
+			__builtin_amdgcn_wave_barrier();
+			lrank[i] = old + before;
+		}
+		lds_barrier();
+		uint32_t run = 0;
+		if (tid < 256) {
+#pragma unroll
+			for (uint32_t k = 0; k < WAVES; ++k) { const uint32_t c = wcnt[k * 256 + tid]; wcnt[k * 256 + tid] = run; run += c; }
+		}
+		uint32_t total;
+		const uint32_t ex = block_excl_scan_u32<THREADS, true>(tid < 256 ? run : 0u, scratch, total);
+		if (tid < 256) tstart[tid] = ex;
+		lds_barrier();
+#pragma unroll
+		for (int i = 0; i < ITEMS; ++i)
+			if ((lane_off + i * 64) < cnt) {
+				const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
+				const uint32_t q = tstart[d] + wcnt[w * 256 + d] + lrank[i];
+				sk[q] = key[i];
+				if (VB) sv[q] = val[i];
+			}
+		lds_barrier();
+#pragma unroll
+		for (int i = 0; i < ITEMS; ++i) {
+			const uint32_t p = lane_off + i * 64;
+			if (p < cnt) { key[i] = sk[p]; if (VB) val[i] = sv[p]; }
+		}
+	}
+
+	// heads: a record whose molecule key differs from its predecessor's; position order = (wave, item, lane)
+	uint32_t run = 0, pre[ITEMS], head_bits = 0;
+#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		const uint32_t p = lane_off + i * 64;
+		const bool valid = p < cnt;
+		const unsigned long long prev = (valid && p) ? sk[p - 1] : 0ull;
+		const bool head = valid && (p == 0 || (prev >> ms) != (key[i] >> ms));
+		const unsigned long long bal = __ballot(head);
+		pre[i] = run + __builtin_amdgcn_mbcnt_hi(uint32_t(bal >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bal), 0u));
+		run += uint32_t(__popcll(bal));
+		if (head) head_bits |= 1u << i;
+	}
+	if (lane == 0) wtot[w] = run;
+	lds_barrier();   // every sk[p - 1] is read: the key area may now hold the aggregates
+	uint32_t woff = 0, n_loc = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < WAVES; ++k) { const uint32_t t = wtot[k]; if (k < w) woff += t; n_loc += t; }
+	for (uint32_t m = tid; m < n_loc; m += THREADS) agg[m] = 0;
+	if (w == 0) { const uint32_t g = ss_lookback(a.status, vid, n_loc, a.error); if (lane == 0) misc[1] = g; }
+	lds_barrier();
+	const uint32_t gbase = misc[1];
+	// fold: agg = any not-annotated read (bit 0, OR) | exon reads << 1 (15 bits, +) | intron reads << 16 (15 bits, +)
+#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		const uint32_t p = lane_off + i * 64;
+		if (p >= cnt) continue;
+		const uint32_t is_head = (head_bits >> i) & 1u;
+		const uint32_t m = woff + pre[i] + is_head - 1u;
+		const uint32_t mark = VB ? uint32_t(val[i]) & 7u : uint32_t(key[i]) & 7u;
+		if (is_head) { headpos[m] = p; a.mol_key[gbase + m] = key[i] >> ms; }
+		const uint32_t add = (((mark >> 1) & 1u) << 1) | (((mark >> 2) & 1u) << 16);
+		if (add) atomicAdd(&agg[m], add);
+		if (mark & 1u) atomicOr(&agg[m], 1u);
+	}
+	lds_barrier();
+	for (uint32_t m = tid; m < n_loc; m += THREADS) {
+		const uint32_t e = m + 1 < n_loc ? headpos[m + 1] : cnt;
+		const uint32_t v = agg[m], exon = (v >> 1) & 0x7FFFu, intron = (v >> 16) & 0x7FFFu;
+		a.mol_reads[gbase + m] = e - headpos[m];
+		a.mol_mark[gbase + m] = (v & 1u) | (exon ? 2u : 0u) | (intron ? 4u : 0u);
+		a.mol_exon[gbase + m] = exon;
+		a.mol_intron[gbase + m] = intron;
+	}
+}
+
+template <int THREADS, int VB>
+__global__ __launch_bounds__(THREADS) void ss_local_kernel(SsLocalArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];
+	__shared__ uint32_t s_vid;
+	if (threadIdx.x == 0) s_vid = atomicAdd(a.ticket, 1u);
+	__syncthreads();
+	const uint32_t vid = s_vid;
+	if (vid >= a.n_buckets) return;
+	const uint32_t cnt = a.bucket_cnt[vid], base = a.bucket_base[vid];
+	if (cnt == 0) {   // an empty bucket still takes its place in the chain
+		if (threadIdx.x < 64) ss_lookback(a.status, vid, 0u, a.error);
+		return;
+	}
+	if (cnt <= uint32_t(THREADS) * 4) ss_local_run<THREADS, 4, VB>(a, vid, base, cnt, ss_smem);
+	else if (cnt <= uint32_t(THREADS) * 8) ss_local_run<THREADS, 8, VB>(a, vid, base, cnt, ss_smem);
+	else ss_local_run<THREADS, 16, VB>(a, vid, base, cnt, ss_smem);
+}
+
+// bytes of dynamic LDS ss_local_kernel<THREADS, *> needs for `cap` records
+inline size_t ss_local_lds_bytes(uint32_t cap, int threads) {
+	const size_t waves = size_t(threads) / 64;
+	size_t words = waves * 256 + 256 + (size_t(threads) / 64 + 1) + waves + 4 + ((waves + 1) & 1u);
+	return size_t(cap) * 8 + words * 4 + 2 * waves * 8 + size_t(cap) + 16;
+}
+
+}  // namespace dropest

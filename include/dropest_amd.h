@@ -356,8 +356,10 @@ typedef struct {
 } dropest_kernel_stat;
 dropest_status dropest_kernel_stats(dropest_ctx *ctx, uint32_t *n, dropest_kernel_stat *out);
 /* Sort-record layout chosen for the pushed reads: [0] cell bits [1] gene bits [2] UMI bits
- * [3] mark bits folded under the key [4] value bytes per record (0, 1 or 4) [5] radix passes of the main sort. */
-dropest_status dropest_sort_layout(dropest_ctx *ctx, uint32_t out[6]);
+ * [3] mark bits folded under the key [4] value bytes per record (0, 1 or 4) [5] passes of the main sort over the records
+ * (LSD radix passes, or 3 = two partitions + the LDS-resident finishing sort) [6] which sort ran: 0 LSD radix sort,
+ * 1 splitter sort (k_ssort.h). */
+dropest_status dropest_sort_layout(dropest_ctx *ctx, uint32_t out[7]);
 /* Digit windows (shift, bits) of the LSD radix sort for keys whose varying bits are `varying_mask` (host logic only, no
  * device needed; at most 8 passes): 8-bit windows, the top ones widened to 9 bits when that saves a pass. */
 dropest_status dropest_radix_plan(uint64_t varying_mask, uint32_t *n_passes, int32_t shifts[8], int32_t bits[8]);
@@ -365,8 +367,8 @@ dropest_status dropest_radix_plan(uint64_t varying_mask, uint32_t *n_passes, int
  * random fills of N-UMIs (MergeUMIsStrategyAbstract.cpp:11-23; host logic only, no device needed). */
 dropest_status dropest_rand_sequence(uint32_t seed, uint64_t n, int32_t *out);
 dropest_status dropest_set_profiling(dropest_ctx *ctx, int enabled);   /* HIP events per launch; off by default */
-/* Restrict the events to the launches whose stat name starts with `name_prefix` (NULL / "" = all launches and the
- * host stages).  Two events per launch cost ~0.5 ms per C2 pass when every kernel is timed; bench.py times only the
+/* Restrict the events to the launches whose stat name starts with `name_prefix` -- several prefixes may be given,
+ * separated by '|' -- (NULL / "" = all launches and the host stages).  Two events per launch cost ~0.5 ms per C2 pass when every kernel is timed; bench.py times only the
  * dominant kernel inside its timed region and collects the full table in a separate pass. */
 dropest_status dropest_set_profiling_filter(dropest_ctx *ctx, const char *name_prefix);
 /* The HIP stream all kernels of this context are launched on (hipStream_t). */

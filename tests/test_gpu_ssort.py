@@ -1,0 +1,117 @@
+"""The splitter sort (dropest_amd/csrc/k_ssort.h: sampled splitters, two partitions, LDS-resident finishing sort fused with
+the reads -> molecules reduce) against the oracle, forced on streams of every size -- by default it only takes streams of
+2^22 reads and more -- and against the LSD path on the same resident stream at BASELINE size."""
+import os
+
+import numpy as np
+import pytest
+
+from dropest_amd import capi
+from dropest_amd.synth import SynthStream
+from oracle import Oracle
+
+import parity
+import test_gpu_parity as tp
+import test_gpu_stress as ts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def splitter(monkeypatch):
+    monkeypatch.setenv("DROPEST_SORT", "splitter")
+
+
+def test_c2_shapes_use_the_splitter_path(splitter):
+    o, c = tp._both(dict(n_cells=40, n_genes=3000), 100_000, 20, 100)
+    assert c.sort_layout()["sort"] == "splitter" and c.sort_layout()["value_bytes"] == 0
+    tp._both(dict(n_cells=200, n_genes=8000), 1_000_000, 20, 100, chunks=7)
+    tp._both(dict(n_cells=8, n_genes=50, umi_len=6), 2000, 3, 5)
+    tp._both(dict(n_cells=30, n_genes=1500), 60_000, 10, 10, levels="e", reads_output=True)
+
+
+def test_key_plus_mark_byte_layout(splitter, monkeypatch):
+    """C3's layout (the key uses all 64 bits, the mark travels as one byte) forced on a small v3 stream."""
+    monkeypatch.setenv("DROPEST_FORCE_BYTE_VALUES", "1")
+    o, c = tp._both(dict(n_cells=60, n_genes=4000, umi_len=12), 150_000, 20, 50)
+    assert c.sort_layout()["sort"] == "splitter" and c.sort_layout()["value_bytes"] == 1
+
+
+def test_general_layout_keeps_the_lsd_sort(splitter, monkeypatch):
+    monkeypatch.setenv("DROPEST_FORCE_GENERAL_LAYOUT", "1")
+    o, c = tp._both(dict(n_cells=40, n_genes=3000), 100_000, 20, 100)
+    assert c.sort_layout()["value_bytes"] == 4 and c.sort_layout()["sort"] == "lsd"
+
+
+def test_merges_and_n_umis_behind_the_splitter_sort(splitter):
+    tp._both_merge(dict(n_cells=30, n_genes=2000, umi_len=12, permille_neighbour=150), 200_000, 3, 20,
+                   "10x_aug_2016_split", capi.BARCODES_CONST)
+    tp._both_merge(dict(n_cells=25, n_genes=1500, umi_len=8, permille_neighbour=120), 120_000, 3, 10,
+                   "indrop_v3", capi.BARCODES_CONST)
+    tp.test_reference_fixture_umi_merge_strategy_simple()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_small_streams(splitter, seed):
+    rng = np.random.default_rng(31000 + seed)
+    ts.run_case(rng, n=int(rng.integers(512, 9000)), n_cb=int(rng.integers(1, 60)), n_gene=int(rng.integers(1, 40)),
+                n_umi=int(rng.integers(1, 80)))
+
+
+@pytest.mark.parametrize("n", [512, 513, 4095, 4096, 4097, 8193, 16385, 40_000])
+def test_tile_boundary_sizes(splitter, n):
+    ts.run_case(np.random.default_rng(n), n=n, n_cb=7, n_gene=5, n_umi=9, min_before=0, min_after=0)
+
+
+def test_buckets_beyond_the_lds_sort_fall_back(splitter):
+    """One molecule with 20 000 reads (or only gene-less reads of one barcode) is ONE fine bucket, larger than the LDS sort
+    takes: the pass must notice before the second partition and hand over to the LSD sort."""
+    rng = np.random.default_rng(5)
+    ts.run_case(rng, n=20_000, n_cb=1, n_gene=1, n_umi=1, p_nogene=0.0, min_before=0, min_after=0)
+    ts.run_case(rng, n=20_000, n_cb=1, n_gene=1, n_umi=1, p_nogene=1.0, min_before=0, min_after=0)
+    ts.run_case(rng, n=12_000, n_cb=12_000, n_gene=3, n_umi=4, cb_len=(16, 16), min_before=0, min_after=0)
+    # a hot molecule of ~6 000 reads among others: still inside the LDS sort (512 threads x 16)
+    ts.run_case(rng, n=30_000, n_cb=3, n_gene=2, n_umi=2, p_nogene=0.0, min_before=0, min_after=0)
+
+
+def test_variable_lengths_and_ns(splitter):
+    rng = np.random.default_rng(9)
+    ts.run_case(rng, n=5000, n_cb=30, n_gene=12, n_umi=40, cb_len=(8, 19), umi_len=(6, 6), n_rate=0.05, min_before=0)
+    ts.run_case(rng, n=5000, n_cb=30, n_gene=12, n_umi=25, cb_len=(10, 10), umi_len=(4, 9), min_before=1)
+    ts.run_case(rng, n=4000, n_cb=25, n_gene=6, n_umi=12, umi_len=(5, 5), n_rate=0.3, cb_n_rate=0.1, min_before=0)
+
+
+def _digest(c):
+    import hashlib
+    h = hashlib.sha256()
+    for a in c.molecules():
+        h.update(np.ascontiguousarray(a).tobytes())
+    for filt in (True, False):
+        for a in c.count_matrix_csc(filtered=filt):
+            h.update(np.ascontiguousarray(a).tobytes())
+    h.update(np.ascontiguousarray(c.cell_rows()).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("shape", ["c2", "c3"])
+def test_splitter_equals_lsd_at_baseline_size(monkeypatch, shape):
+    """1e8 reads (C2: keys only, 57-bit key; C3 shape: 64-bit key + mark byte, with the whitelist merge): the splitter path
+    and the LSD path must produce the same molecule table, cell rows and matrices, byte for byte."""
+    if shape == "c2":
+        s = SynthStream(n_reads=100_000_000, n_cells=5000, n_genes=30000)
+        kw = dict(min_genes_before_merge=20, min_genes_after_merge=100)
+    else:
+        s = SynthStream(n_reads=100_000_000, n_cells=20000, n_genes=30000, umi_len=12, stream_id=3)
+        kw = dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST,
+                  barcodes_file=os.path.join(tp.DATA, "10x_aug_2016_split"), min_genes_before_merge=20, min_genes_after_merge=100)
+    dev = s.generate_device(0)
+    c = capi.Context(**kw)
+    c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
+    digests = {}
+    for mode in ("lsd", "splitter"):
+        monkeypatch.setenv("DROPEST_SORT", mode)
+        c.reset_results(); c.set_initialized(); c.merge_and_filter()
+        assert c.sort_layout()["sort"] == mode
+        digests[mode] = _digest(c)
+    assert digests["lsd"] == digests["splitter"]
+    dev.free()
