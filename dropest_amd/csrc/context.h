@@ -289,8 +289,8 @@ struct dropest_ctx {
 	void radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes = 4,
 	                const char *stat_prefix = nullptr);
 	// splitter sort (k_ssort.h): sample, splitters, partition scratch, look-back words
-	dropest::DevBuf<u64> ss_sample_a, ss_sample_b, ss_fine, ss_coarse, ss_status;
-	dropest::DevBuf<u32> ss_base1, ss_cnt2, ss_bucket_base, ss_bucket_cnt;
+	dropest::DevBuf<u64> ss_sample_a, ss_sample_b, ss_fine, ss_coarse;
+	dropest::DevBuf<u32> ss_base1, ss_cnt2, ss_bucket_base, ss_bucket_cnt, ss_tmp, ss_n_loc, ss_prefix, ss_chunk, ss_big_list;
 	bool splitter_sort_reduce();   // false: not applicable / fell back, the caller runs the LSD sort + seg_reduce
 	void reduce_all();
 	void reduce_molecules_to_cell_gene();

@@ -441,11 +441,13 @@ bool dropest_ctx::splitter_sort_reduce() {
 	if (mode == 1 || !chr_from_gene || layout.val_bytes > 1) return false;
 	if (mode != 2 && n_reads < min_reads) return false;
 	if (n < 512) return false;
-	// fan-out: F^2 fine buckets of <= ~1536 records on average, F = 16 .. 512
-	int fb = 4;
-	while (fb < 9 && (uint64_t(n) >> (2 * fb)) > 1536) ++fb;
-	if ((uint64_t(n) >> (2 * fb)) > 4096) return false;   // > 1.07e9 records: buckets beyond the LDS sort
-	const u32 F = 1u << fb, F2 = F * F;
+	// fan-out: F1 coarse x F2 fine buckets (powers of two, 16 .. 512 each) of <= ~900 records on average, so that all but
+	// a hot molecule's bucket fit the small finishing launch (256 threads x 4 or 8 records)
+	int tb = 8;
+	while (tb < 18 && (uint64_t(n) >> tb) > 900) ++tb;
+	if ((uint64_t(n) >> tb) > 4096) return false;   // > 1.07e9 records: buckets beyond the LDS sort
+	const int fb1 = tb / 2, fb2 = tb - fb1;
+	const u32 F1 = 1u << fb1, Ff = 1u << fb2, F2 = F1 * Ff;
 	const int ms = layout.mark_shift, VB = layout.val_bytes;
 	const u32 os = u32(std::max<uint64_t>(1, std::min<uint64_t>(32, uint64_t(n) / (uint64_t(F2) * 2))));
 	const u32 n_sample = F2 * os;
@@ -457,7 +459,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 	uint8_t *vals = reinterpret_cast<uint8_t *>(vals_a.p), *vals_alt = reinterpret_cast<uint8_t *>(vals_b.p);
 
 	// sample -> sorted -> splitters
-	ss_sample_a.ensure(n_sample); ss_sample_b.ensure(n_sample); ss_fine.ensure(F2); ss_coarse.ensure(F);
+	ss_sample_a.ensure(n_sample); ss_sample_b.ensure(n_sample); ss_fine.ensure(F2); ss_coarse.ensure(F1);
 	timed("ss_sample", double(n_sample) * 16, [&] {
 		hipLaunchKernelGGL(ss_sample_kernel, dim3(div_up(n_sample, 256)), dim3(256), 0, stream, keys, n, ms, n_sample, ss_sample_a.p);
 	});
@@ -465,72 +467,95 @@ bool dropest_ctx::splitter_sort_reduce() {
 		u64 *k = ss_sample_a.p, *k_alt = ss_sample_b.p;
 		u32 *v = nullptr, *v_alt = nullptr;
 		radix_sort(k, v, k_alt, v_alt, n_sample, varying >> ms, 0, "ss_sample:");
-		hipLaunchKernelGGL(ss_pick_splitters_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, k, os, F, ss_fine.p, ss_coarse.p);
+		hipLaunchKernelGGL(ss_pick_splitters_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, k, os, Ff, F2, ss_fine.p, ss_coarse.p);
 		HIP_CHECK(hipGetLastError());
 	}
 
-	// L1: all records into the F coarse buckets
+	// L1: all records into the F1 coarse buckets
 	const u32 n_tiles = div_up(n, SS_TILE);
 	u32 nblocks = std::min<u32>(n_tiles, 1024);
 	const u32 tpb = div_up(n_tiles, nblocks);
 	nblocks = div_up(n_tiles, tpb);
-	rs_hist.ensure(size_t(F) * nblocks); rs_row_total.ensure(SS_MAX_F); ss_base1.ensure(F + 1);
+	rs_hist.ensure(size_t(F1) * nblocks); rs_row_total.ensure(SS_MAX_F); ss_base1.ensure(F1 + 1);
 	timed("ss_hist:L1", double(n) * 8, [&] {
-		hipLaunchKernelGGL(ss_hist_l1_kernel, dim3(nblocks), dim3(SS_T), 0, stream, keys, n, ms, fb, ss_coarse.p, tpb, rs_hist.p);
+		hipLaunchKernelGGL(ss_hist_l1_kernel, dim3(nblocks), dim3(SS_T), 0, stream, keys, n, ms, fb1, ss_coarse.p, tpb, rs_hist.p);
 	});
-	timed("ss_scan", double(F) * nblocks * 8, [&] {
-		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(F), dim3(256), 0, stream, rs_hist.p, nblocks, rs_row_total.p);
-		hipLaunchKernelGGL(ss_scan_totals_kernel, dim3(1), dim3(SS_MAX_F), 0, stream, rs_row_total.p, F, n, ss_base1.p);
+	timed("ss_scan", double(F1) * nblocks * 8, [&] {
+		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(F1), dim3(256), 0, stream, rs_hist.p, nblocks, rs_row_total.p);
+		hipLaunchKernelGGL(ss_scan_totals_kernel, dim3(1), dim3(SS_MAX_F), 0, stream, rs_row_total.p, F1, n, ss_base1.p);
 	});
 	timed(VB ? "ss_scatter:L1:key+1B" : "ss_scatter:L1:keys", double(n) * 2 * (8 + VB), [&] {
-		if (VB) hipLaunchKernelGGL(ss_scatter_l1_kernel<1>, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb, ss_coarse.p, tpb, rs_hist.p, ss_base1.p);
-		else hipLaunchKernelGGL(ss_scatter_l1_kernel<0>, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb, ss_coarse.p, tpb, rs_hist.p, ss_base1.p);
+		if (VB) hipLaunchKernelGGL(ss_scatter_l1_kernel<1>, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb1, ss_coarse.p, tpb, rs_hist.p, ss_base1.p);
+		else hipLaunchKernelGGL(ss_scatter_l1_kernel<0>, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb1, ss_coarse.p, tpb, rs_hist.p, ss_base1.p);
 	});
 
-	// L2: every coarse bucket into its F fine buckets
-	const u32 parts = std::max<u32>(1, std::min<u32>(16, 2048 / F));
+	// L2: every coarse bucket into its own fine buckets
+	const u32 parts = std::max<u32>(1, std::min<u32>(16, 2048 / F1));
 	ss_cnt2.ensure(size_t(F2) * parts); ss_bucket_base.ensure(F2); ss_bucket_cnt.ensure(F2); scalars.ensure(16);
-	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));   // [0] largest bucket, [1] look-back ticket, [2] error
+	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));   // [0] largest bucket, [1] molecule total
 	timed("ss_hist:L2", double(n) * 8, [&] {
-		hipLaunchKernelGGL(ss_hist_l2_kernel, dim3(F * parts), dim3(SS_T), 0, stream, keys_alt, ms, fb, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
+		hipLaunchKernelGGL(ss_hist_l2_kernel, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
 	});
 	timed("ss_scan", double(F2) * parts * 8, [&] {
-		hipLaunchKernelGGL(ss_scan_seg_kernel, dim3(F), dim3(SS_MAX_F), 0, stream, ss_cnt2.p, F, parts, ss_base1.p, ss_bucket_base.p, ss_bucket_cnt.p, scalars.p);
+		hipLaunchKernelGGL(ss_scan_seg_kernel, dim3(F1), dim3(SS_MAX_F), 0, stream, ss_cnt2.p, Ff, parts, ss_base1.p, ss_bucket_base.p, ss_bucket_cnt.p, scalars.p);
 	});
 	u32 max_cnt = 0;
 	fetch(&max_cnt, scalars.p, 4);
 	if (max_cnt > SS_LOCAL_MAX) return false;   // keys_a / vals_a are untouched: the LSD sort takes over
 	timed(VB ? "ss_scatter:L2:key+1B" : "ss_scatter:L2:keys", double(n) * 2 * (8 + VB), [&] {
-		if (VB) hipLaunchKernelGGL(ss_scatter_l2_kernel<1>, dim3(F * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
-		else hipLaunchKernelGGL(ss_scatter_l2_kernel<0>, dim3(F * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
+		if (VB) hipLaunchKernelGGL(ss_scatter_l2_kernel<1>, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
+		else hipLaunchKernelGGL(ss_scatter_l2_kernel<0>, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
 	});
 
-	// finishing sort + molecule rows (at most one per record)
-	mol_key.ensure(size_t(n) + 1);
-	for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) b->ensure(size_t(n) + 1);
-	ss_status.ensure(F2);
-	HIP_CHECK(hipMemsetAsync(ss_status.p, 0, size_t(F2) * 8, stream));
+	// finishing sort: sparse molecule rows at each bucket's own record offset (key rows re-use the partition's alternate
+	// buffer), then scan of the per-bucket row counts and compaction into the dense table
+	const u32 SMALL_MAX = 2048;
+	ss_tmp.ensure(size_t(n) * 2 + 2); ss_n_loc.ensure(F2); ss_prefix.ensure(F2); ss_chunk.ensure(SS_MAX_F);
 	SsLocalArgs a{};
 	a.keys = keys; a.vals = vals; a.bucket_base = ss_bucket_base.p; a.bucket_cnt = ss_bucket_cnt.p; a.n_buckets = F2; a.ms = ms;
-	a.status = ss_status.p; a.ticket = scalars.p + 1; a.error = scalars.p + 2;
-	a.mol_key = mol_key.p; a.mol_reads = mol_reads.p; a.mol_mark = mol_mark.p; a.mol_exon = mol_exon.p; a.mol_intron = mol_intron.p;
-	const int threads = max_cnt <= 4096 ? 256 : 512;
-	a.cap = max_cnt <= u32(threads) * 4 ? u32(threads) * 4 : (max_cnt <= u32(threads) * 8 ? u32(threads) * 8 : u32(threads) * 16);
-	const size_t lds = ss_local_lds_bytes(a.cap, threads);
-	auto launch = [&](auto kernel) {
-		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-		hipLaunchKernelGGL(kernel, dim3(F2), dim3(threads), lds, stream, a);
-	};
-	timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB) + double(n) * 0.42 * 24, [&] {
-		if (threads == 256) { if (VB) launch(ss_local_kernel<256, 1>); else launch(ss_local_kernel<256, 0>); }
-		else { if (VB) launch(ss_local_kernel<512, 1>); else launch(ss_local_kernel<512, 0>); }
+	a.t_key = keys_alt; a.t_reads = ss_tmp.p; a.t_agg = ss_tmp.p + n; a.n_loc = ss_n_loc.p;
+	if (const char *e = getenv("DROPEST_SS_DEBUG")) a.debug = u32(atoi(e));
+	a.cap = SMALL_MAX; a.skip_above = SMALL_MAX;
+	{
+		const size_t lds = ss_local_lds_bytes(a.cap, 256);
+		timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB) + double(n) * 0.42 * 16, [&] {
+			if (VB) hipLaunchKernelGGL(ss_local_kernel<1>, dim3(F2), dim3(256), lds, stream, a);
+			else hipLaunchKernelGGL(ss_local_kernel<0>, dim3(F2), dim3(256), lds, stream, a);
+		});
+	}
+	if (max_cnt > SMALL_MAX) {   // the few buckets beyond the small launch (a hot molecule): listed by the host, 512 threads x 16
+		std::vector<u32> cnts(F2), big;
+		fetch(cnts.data(), ss_bucket_cnt.p, size_t(F2) * 4);
+		for (u32 b = 0; b < F2; ++b) if (cnts[b] > SMALL_MAX) big.push_back(b);
+		ss_big_list.ensure(big.size());
+		HIP_CHECK(hipMemcpyAsync(ss_big_list.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, stream));
+		SsLocalArgs g = a;
+		g.big_list = ss_big_list.p; g.cap = SS_LOCAL_MAX; g.skip_above = SS_LOCAL_MAX;
+		const size_t lds = ss_local_lds_bytes(g.cap, 512);
+		auto launch = [&](auto kernel) {
+			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+			hipLaunchKernelGGL(kernel, dim3(u32(big.size())), dim3(512), lds, stream, g);
+		};
+		timed("ss_local:big", 0, [&] { if (VB) launch(ss_local_big_kernel<1>); else launch(ss_local_big_kernel<0>); });
+		HIP_CHECK(hipStreamSynchronize(stream));   // `big` (host vector) must outlive its copy
+	}
+	const u32 n_chunks = div_up(F2, SS_MAX_F);
+	timed("ss_scan", double(F2) * 12, [&] {
+		hipLaunchKernelGGL(ss_chunk_sums_kernel, dim3(n_chunks), dim3(SS_MAX_F), 0, stream, ss_n_loc.p, F2, ss_chunk.p);
+		hipLaunchKernelGGL(ss_prefix_kernel, dim3(n_chunks), dim3(SS_MAX_F), 0, stream, ss_n_loc.p, F2, ss_chunk.p, n_chunks, ss_prefix.p, scalars.p + 1);
 	});
-	struct { unsigned long long last; } tail{};
-	u32 flags[4] = {0, 0, 0, 0};
-	fetch(&tail, ss_status.p + (F2 - 1), 8);
-	fetch(flags, scalars.p, 16);
-	if (flags[2] || (tail.last >> 62) != 2) throw DeviceError("splitter sort: the look-back chain over the buckets did not complete");
-	n_mol = u32(tail.last & 0xFFFFFFFFull);
+	u32 total = 0;
+	fetch(&total, scalars.p + 1, 4);
+	n_mol = total;
+	mol_key.ensure(size_t(n_mol) + 1);
+	for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) b->ensure(size_t(n_mol) + 1);
+	SsCompactArgs c{};
+	c.bucket_base = ss_bucket_base.p; c.n_loc = ss_n_loc.p; c.prefix = ss_prefix.p; c.n_buckets = F2;
+	c.t_key = keys_alt; c.t_reads = ss_tmp.p; c.t_agg = ss_tmp.p + n;
+	c.mol_key = mol_key.p; c.mol_reads = mol_reads.p; c.mol_mark = mol_mark.p; c.mol_exon = mol_exon.p; c.mol_intron = mol_intron.p;
+	timed("ss_compact", double(n_mol) * (16 + 24), [&] {
+		hipLaunchKernelGGL(ss_compact_kernel, dim3(div_up(F2, 4)), dim3(256), 0, stream, c);
+	});
 	for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) HIP_CHECK(hipMemsetAsync(b->p + n_mol, 0, 4, stream));   // sentinel row
 	main_sort_passes = 3; main_sort_kind = 1;
 	return true;

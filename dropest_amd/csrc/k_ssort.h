@@ -10,8 +10,9 @@
 //   L2  ss_hist / ss_scan_seg / ss_scatter   every coarse bucket into its F fine buckets (~1.5 k records each)
 //   ss_local       one workgroup per fine bucket: the bucket is loaded ONCE into LDS, sorted there (LSD over the bits
 //                  that vary inside the bucket: 3-4 passes of the wave-ballot multisplit), runs of equal molecule keys
-//                  are folded (read count, mark, exon / intron reads) and the molecule rows are written at the global
-//                  offset a decoupled look-back over the buckets provides -- the sorted reads never go back to HBM.
+//                  are folded (read count, mark, exon / intron reads) and written as molecule rows at the bucket's own
+//                  offset -- the sorted reads never go back to HBM
+//   ss_compact     scan of the per-bucket row counts, rows moved to the dense molecule table
 // Records cross HBM 2.5 times (L1 r+w, L2 hist r, L2 r+w, local r) instead of 7 x 3: see DESIGN.md §2.
 //
 // Equal molecule keys always compare equal against every splitter, so a molecule never straddles two buckets; the
@@ -37,10 +38,11 @@ __global__ __launch_bounds__(256) void ss_sample_kernel(const unsigned long long
 	out[j] = keys[pos < n ? pos : n - 1] >> ms;
 }
 
-// fine[j] = sample[(j + 1) * os], j = 0 .. F*F-2 (entry F*F-1 = ~0, never compared); coarse[j] = fine[(j + 1) * F - 1]
-__global__ __launch_bounds__(256) void ss_pick_splitters_kernel(const unsigned long long *__restrict__ sorted_sample, uint32_t os, uint32_t F,
+// fine[j] = sample[(j + 1) * os], j = 0 .. F2-2 (entry F2-1 = ~0, never compared); coarse[j] = fine[(j + 1) * F - 1], F = fine
+// buckets per coarse bucket
+__global__ __launch_bounds__(256) void ss_pick_splitters_kernel(const unsigned long long *__restrict__ sorted_sample, uint32_t os, uint32_t F, uint32_t F2,
                                                                 unsigned long long *__restrict__ fine, unsigned long long *__restrict__ coarse) {
-	const uint32_t j = blockIdx.x * 256 + threadIdx.x, F2 = F * F;
+	const uint32_t j = blockIdx.x * 256 + threadIdx.x;
 	if (j >= F2) return;
 	const unsigned long long v = j + 1 < F2 ? sorted_sample[size_t(j + 1) * os] : ~0ull;
 	fine[j] = v;
@@ -247,60 +249,30 @@ __global__ __launch_bounds__(SS_T) void ss_scatter_l2_kernel(const unsigned long
 }
 
 // ---- finishing sort + reads -> molecules ---------------------------------------------------------------------------
+// One workgroup per fine bucket (blockIdx = bucket).  A bucket of c records yields at most c molecules, so its rows are
+// written at the bucket's OWN record offset into scratch arrays (sparse) together with the row count; ss_compact then
+// scans the counts and moves the rows to the dense table.  (Writing dense rows straight away needs every bucket's
+// molecule count before its rows can be placed: a decoupled look-back was built and measured -- a bucket only knows its
+// count after its sort, so every workgroup waited for its slowest resident predecessor and the single ticket word
+// alone capped the launch at 88 workgroups per microsecond; 3.1-3.5 ms against 1.2 + 0.45 ms for sparse rows + compaction.)
 struct SsLocalArgs {
 	const unsigned long long *keys;      // grouped by fine bucket (output of the L2 scatter)
 	const uint8_t *vals;                 // mark bytes (VB = 1)
 	const uint32_t *bucket_base, *bucket_cnt;
+	const uint32_t *big_list;            // (big launch) bucket ids
 	uint32_t n_buckets;
 	int ms;                              // mark bits folded under the key (VB = 0: 3)
 	uint32_t cap;                        // records the LDS of this launch holds
-	unsigned long long *status;          // [n_buckets] look-back words, zeroed before the launch
-	uint32_t *ticket, *error;            // zeroed before the launch
-	unsigned long long *mol_key;
-	uint32_t *mol_reads, *mol_mark, *mol_exon, *mol_intron;
+	uint32_t skip_above;                 // small launch: buckets with more records are left to the big launch
+	uint32_t debug;                      // timing experiments only (DROPEST_SS_DEBUG): 2 no sort passes -- wrong results
+	unsigned long long *t_key;           // sparse rows: molecule key, reads, agg (bit 0 not-annotated, exon << 1, intron << 16)
+	uint32_t *t_reads, *t_agg, *n_loc;
 };
-
-constexpr unsigned long long SS_FLAG_AGG = 1ull << 62, SS_FLAG_INCL = 2ull << 62;
-constexpr uint32_t SS_SPIN_LIMIT = 1u << 21;
-
-// Decoupled look-back over the buckets in ticket order (one wave): publishes this bucket's molecule count, returns the
-// number of molecules of all earlier buckets.  Every word is ONE naturally aligned 8-byte {flag, value} granule written
-// and polled with agent-scope relaxed atomics (the data is the flag; MI355X_MICROARCH.md, inter-workgroup visibility).
-// Tickets are handed out in dispatch order, so every predecessor is running or done: the spin is bounded all the same.
-__device__ inline uint32_t ss_lookback(unsigned long long *status, uint32_t vid, uint32_t n_loc, uint32_t *error) {
-	const uint32_t lane = lane_id();
-	if (vid == 0) {
-		if (lane == 0) __hip_atomic_store(&status[0], SS_FLAG_INCL | n_loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		return 0;
-	}
-	if (lane == 0) __hip_atomic_store(&status[vid], SS_FLAG_AGG | n_loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	uint32_t excl = 0, spins = 0;
-	long long pos = vid;   // window [pos - 64, pos)
-	for (;;) {
-		const long long idx = pos - 1 - lane;
-		const unsigned long long v = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SS_FLAG_INCL;
-		const uint32_t flag = uint32_t(v >> 62);
-		const unsigned long long b_incl = __ballot(flag == 2), b_empty = __ballot(flag == 0);
-		const int first_incl = b_incl ? __builtin_ctzll(b_incl) : 64;
-		const unsigned long long need = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);
-		if (b_empty & need) {
-			if (++spins > SS_SPIN_LIMIT) { if (lane == 0) atomicOr(error, 1u); break; }
-			__builtin_amdgcn_s_sleep(2);
-			continue;
-		}
-		const unsigned long long c = int(lane) <= first_incl ? (v & 0xFFFFFFFFull) : 0ull;
-		excl += uint32_t(wave_reduce_add_u64(c));
-		if (first_incl < 64) break;
-		pos -= 64;
-	}
-	if (lane == 0) __hip_atomic_store(&status[vid], SS_FLAG_INCL | (excl + n_loc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	return excl;
-}
 
 // LDS of ss_local (dynamic, 16-byte aligned): sk[cap] keys -- later aliased by agg[cap] + headpos[cap] (u32 each) --,
 // wcnt[WAVES][256], tstart[256], scratch, red[], sv[cap] bytes
 template <int THREADS, int ITEMS, int VB>
-__device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t vid, uint32_t base, uint32_t cnt, unsigned char *smem) {
+__device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint32_t base, uint32_t cnt, unsigned char *smem) {
 	constexpr uint32_t WAVES = THREADS / 64;
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
 	unsigned long long *sk = reinterpret_cast<unsigned long long *>(smem);
@@ -325,7 +297,11 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t vid, uint32_t
 		const bool valid = p < cnt;
 		key[i] = valid ? a.keys[base + p] : 0ull;
 		if (VB) val[i] = valid ? a.vals[base + p] : uint8_t(0);
-		if (valid) { k_or |= key[i]; k_and &= key[i]; sk[p] = key[i]; if (VB) sv[p] = val[i]; }
+	}
+#pragma unroll
+	for (int i = 0; i < ITEMS; ++i) {
+		const uint32_t p = lane_off + i * 64;
+		if (p < cnt) { k_or |= key[i]; k_and &= key[i]; sk[p] = key[i]; if (VB) sv[p] = val[i]; }
 	}
 	k_or = wave_reduce_or_u64(k_or); k_and = wave_reduce_and_u64(k_and);
 	if (lane == 0) { red[2 * w] = k_or; red[2 * w + 1] = k_and; }
@@ -337,7 +313,7 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t vid, uint32_t
 
 	// LSD over the varying bits, 8 per pass, ranks by the wave-ballot multisplit of k_radix.h (stable)
 	for (int shift = vary ? __builtin_ctzll(vary) : 64; shift < 64 && (vary >> shift) != 0; shift += 8) {
-		if (((vary >> shift) & 0xFFull) == 0) continue;
+		if (((vary >> shift) & 0xFFull) == 0 || (a.debug & 2u)) continue;
 		for (uint32_t j = tid; j < WAVES * 256; j += THREADS) wcnt[j] = 0;
 		lds_barrier();
 		uint32_t lrank[ITEMS];
@@ -407,9 +383,8 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t vid, uint32_t
 #pragma unroll
 	for (uint32_t k = 0; k < WAVES; ++k) { const uint32_t t = wtot[k]; if (k < w) woff += t; n_loc += t; }
 	for (uint32_t m = tid; m < n_loc; m += THREADS) agg[m] = 0;
-	if (w == 0) { const uint32_t g = ss_lookback(a.status, vid, n_loc, a.error); if (lane == 0) misc[1] = g; }
+	if (tid == 0) a.n_loc[bucket] = n_loc;
 	lds_barrier();
-	const uint32_t gbase = misc[1];
 	// fold: agg = any not-annotated read (bit 0, OR) | exon reads << 1 (15 bits, +) | intron reads << 16 (15 bits, +)
 #pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
@@ -418,7 +393,7 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t vid, uint32_t
 		const uint32_t is_head = (head_bits >> i) & 1u;
 		const uint32_t m = woff + pre[i] + is_head - 1u;
 		const uint32_t mark = VB ? uint32_t(val[i]) & 7u : uint32_t(key[i]) & 7u;
-		if (is_head) { headpos[m] = p; a.mol_key[gbase + m] = key[i] >> ms; }
+		if (is_head) { headpos[m] = p; a.t_key[base + m] = key[i] >> ms; }
 		const uint32_t add = (((mark >> 1) & 1u) << 1) | (((mark >> 2) & 1u) << 16);
 		if (add) atomicAdd(&agg[m], add);
 		if (mark & 1u) atomicOr(&agg[m], 1u);
@@ -426,37 +401,82 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t vid, uint32_t
 	lds_barrier();
 	for (uint32_t m = tid; m < n_loc; m += THREADS) {
 		const uint32_t e = m + 1 < n_loc ? headpos[m + 1] : cnt;
-		const uint32_t v = agg[m], exon = (v >> 1) & 0x7FFFu, intron = (v >> 16) & 0x7FFFu;
-		a.mol_reads[gbase + m] = e - headpos[m];
-		a.mol_mark[gbase + m] = (v & 1u) | (exon ? 2u : 0u) | (intron ? 4u : 0u);
-		a.mol_exon[gbase + m] = exon;
-		a.mol_intron[gbase + m] = intron;
+		a.t_reads[base + m] = e - headpos[m];
+		a.t_agg[base + m] = agg[m];
 	}
 }
 
-template <int THREADS, int VB>
-__global__ __launch_bounds__(THREADS) void ss_local_kernel(SsLocalArgs a) {
+// small launch: grid = all buckets, 256 threads, buckets of up to 2048 records (larger ones are listed for the big launch)
+template <int VB>
+__global__ __launch_bounds__(256) void ss_local_kernel(SsLocalArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];
-	__shared__ uint32_t s_vid;
-	if (threadIdx.x == 0) s_vid = atomicAdd(a.ticket, 1u);
-	__syncthreads();
-	const uint32_t vid = s_vid;
-	if (vid >= a.n_buckets) return;
-	const uint32_t cnt = a.bucket_cnt[vid], base = a.bucket_base[vid];
-	if (cnt == 0) {   // an empty bucket still takes its place in the chain
-		if (threadIdx.x < 64) ss_lookback(a.status, vid, 0u, a.error);
-		return;
-	}
-	if (cnt <= uint32_t(THREADS) * 4) ss_local_run<THREADS, 4, VB>(a, vid, base, cnt, ss_smem);
-	else if (cnt <= uint32_t(THREADS) * 8) ss_local_run<THREADS, 8, VB>(a, vid, base, cnt, ss_smem);
-	else ss_local_run<THREADS, 16, VB>(a, vid, base, cnt, ss_smem);
+	const uint32_t b = blockIdx.x;
+	const uint32_t cnt = a.bucket_cnt[b], base = a.bucket_base[b];
+	if (cnt == 0) { if (threadIdx.x == 0) a.n_loc[b] = 0; return; }
+	if (cnt > a.skip_above) return;
+	if (cnt <= 1024) ss_local_run<256, 4, VB>(a, b, base, cnt, ss_smem);
+	else ss_local_run<256, 8, VB>(a, b, base, cnt, ss_smem);
+}
+// big launch: grid = listed buckets, 512 threads x 16 records
+template <int VB>
+__global__ __launch_bounds__(512) void ss_local_big_kernel(SsLocalArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];
+	const uint32_t b = a.big_list[blockIdx.x];
+	ss_local_run<512, 16, VB>(a, b, a.bucket_base[b], a.bucket_cnt[b], ss_smem);
 }
 
-// bytes of dynamic LDS ss_local_kernel<THREADS, *> needs for `cap` records
+// bytes of dynamic LDS ss_local needs for `cap` records
 inline size_t ss_local_lds_bytes(uint32_t cap, int threads) {
 	const size_t waves = size_t(threads) / 64;
 	size_t words = waves * 256 + 256 + (size_t(threads) / 64 + 1) + waves + 4 + ((waves + 1) & 1u);
 	return size_t(cap) * 8 + words * 4 + 2 * waves * 8 + size_t(cap) + 16;
+}
+
+// ---- compaction of the sparse rows ---------------------------------------------------------------------------------
+// sums of n_loc over chunks of SS_MAX_F buckets
+__global__ __launch_bounds__(SS_MAX_F) void ss_chunk_sums_kernel(const uint32_t *__restrict__ n_loc, uint32_t n_buckets, uint32_t *__restrict__ chunk_sum) {
+	__shared__ uint32_t scratch[SS_MAX_F / 64 + 1];
+	const uint32_t i = blockIdx.x * SS_MAX_F + threadIdx.x;
+	uint32_t total;
+	block_excl_scan_u32<SS_MAX_F>(i < n_buckets ? n_loc[i] : 0u, scratch, total);
+	if (threadIdx.x == 0) chunk_sum[blockIdx.x] = total;
+}
+// exclusive prefix of n_loc (chunk c adds the sums of the chunks before it: at most 512 of them); total -> *n_mol
+__global__ __launch_bounds__(SS_MAX_F) void ss_prefix_kernel(const uint32_t *__restrict__ n_loc, uint32_t n_buckets, const uint32_t *__restrict__ chunk_sum,
+                                                              uint32_t n_chunks, uint32_t *__restrict__ prefix, uint32_t *__restrict__ n_mol) {
+	__shared__ uint32_t scratch[SS_MAX_F / 64 + 1];
+	__shared__ uint32_t chunk_base;
+	uint32_t t1;
+	const uint32_t before = block_excl_scan_u32<SS_MAX_F>(threadIdx.x < n_chunks ? chunk_sum[threadIdx.x] : 0u, scratch, t1);
+	if (threadIdx.x == blockIdx.x) chunk_base = before;
+	__syncthreads();
+	const uint32_t i = blockIdx.x * SS_MAX_F + threadIdx.x;
+	uint32_t t2;
+	const uint32_t ex = block_excl_scan_u32<SS_MAX_F>(i < n_buckets ? n_loc[i] : 0u, scratch, t2);
+	if (i < n_buckets) prefix[i] = chunk_base + ex;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *n_mol = t1;
+}
+struct SsCompactArgs {
+	const uint32_t *bucket_base, *n_loc, *prefix;
+	uint32_t n_buckets;
+	const unsigned long long *t_key;
+	const uint32_t *t_reads, *t_agg;
+	unsigned long long *mol_key;
+	uint32_t *mol_reads, *mol_mark, *mol_exon, *mol_intron;
+};
+// one wave per bucket: its rows move from the sparse scratch to their place in the molecule table
+__global__ __launch_bounds__(256) void ss_compact_kernel(SsCompactArgs a) {
+	const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (b >= a.n_buckets) return;
+	const uint32_t n = a.n_loc[b], src = a.bucket_base[b], dst = a.prefix[b];
+	for (uint32_t j = lane; j < n; j += 64) {
+		const uint32_t v = a.t_agg[src + j], exon = (v >> 1) & 0x7FFFu, intron = (v >> 16) & 0x7FFFu;
+		a.mol_key[dst + j] = a.t_key[src + j];
+		a.mol_reads[dst + j] = a.t_reads[src + j];
+		a.mol_mark[dst + j] = (v & 1u) | (exon ? 2u : 0u) | (intron ? 4u : 0u);
+		a.mol_exon[dst + j] = exon;
+		a.mol_intron[dst + j] = intron;
+	}
 }
 
 }  // namespace dropest
