@@ -36,6 +36,18 @@ static dropest_status guarded(F &&f) {
 
 static inline u32 div_up(uint64_t a, uint64_t b) { return u32((a + b - 1) / b); }
 
+// Grid of a grid-stride kernel: exactly as many workgroups as are resident at once (occupancy x CUs), at most `wanted`.
+// A latency-bound kernel launched with a few more workgroups than fit pays a whole extra round for them (cb_insert with
+// 2048 workgroups where 1792 fit ran its last 256 alone: measured 8192 waves against 7168 resident).
+template <class K>
+static u32 resident_grid(K kernel, int threads, u32 wanted) {
+	int dev = 0, cus = 0, per_cu = 0;
+	HIP_CHECK(hipGetDevice(&dev));
+	HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+	HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0));
+	return std::max<u32>(1u, std::min<u32>(wanted, u32(std::max(1, cus) * std::max(1, per_cu))));
+}
+
 // ------------------------------------------------------------------------------------------------
 // context basics
 // ------------------------------------------------------------------------------------------------
@@ -183,6 +195,23 @@ static constexpr u32 GENE_CHR_CAP = 1u << 20;   // genes beyond this id fall bac
 void dropest_ctx::build_cb_table() {
 	const u32 n = u32(n_reads);
 	uint64_t cap = cfg.cb_table_capacity;
+	if (cap == 0 && n_reads >= (1u << 22) && !getenv("DROPEST_CB_NO_SAMPLE")) {
+		// size the table from the distinct barcodes of every 64th read: a new barcode shows up at most 64 times as often in
+		// the whole stream (too small an estimate is caught below: the table is rebuilt larger when its load passes 0.7)
+		const u32 stride = 64, n_s = div_up(n, stride);
+		uint64_t cap_s = 1024; while (cap_s < uint64_t(n_s) * 2) cap_s <<= 1;
+		t_slots.ensure(cap_s); scalars.ensure(16);
+		CbTable ts{t_slots.p, cap_s - 1};
+		HIP_CHECK(hipMemsetAsync(t_slots.p, 0, cap_s * sizeof(CbSlot), stream));
+		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4, stream));
+		timed("cb_sample", double(n_s) * 8, [&] {
+			hipLaunchKernelGGL(cb_sample_distinct_kernel, dim3(std::min<u32>(div_up(n_s, 256), 2048u)), dim3(256), 0, stream, d_cb, n, stride, ts, scalars.p);
+		});
+		u32 distinct = 0;
+		fetch(&distinct, scalars.p, 4);
+		const uint64_t est = std::min<uint64_t>(n_reads, uint64_t(distinct) * stride);
+		cap = 1024; while (cap < est + est / 2) cap <<= 1;   // load <= 0.67 even when the estimate is exact
+	}
 	if (cap == 0) { cap = 1024; while (cap < n_reads / 2) cap <<= 1; }
 	if (cap & (cap - 1)) throw InvalidError("cb_table_capacity must be a power of two");
 	slot.ensure(n);
@@ -197,10 +226,14 @@ void dropest_ctx::build_cb_table() {
 		HIP_CHECK(hipMemcpyAsync(d_ingest.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
 		gene_chr.ensure(GENE_CHR_CAP);
 		HIP_CHECK(hipMemsetAsync(gene_chr.p, 0xFF, size_t(GENE_CHR_CAP) * 4, stream));
-		const u32 blocks = std::min<u32>(div_up(n, 256), 256u * 16u);
+		const bool vec = ((uintptr_t(d_cb) | uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;   // adopted arrays may sit anywhere
+		static const u32 grid_v = resident_grid(cb_insert_kernel<256, true>, 256, ~0u), grid_s = resident_grid(cb_insert_kernel<256, false>, 256, ~0u);
+		const u32 blocks = std::min<u32>(div_up(n, 256 * 4), vec ? grid_v : grid_s);
 		timed("cb_insert", double(n) * (8 + 8 + 4 + 4 + 4), [&] {
-			hipLaunchKernelGGL(cb_insert_kernel<256>, dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table,
-			                   slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
+			if (vec) hipLaunchKernelGGL((cb_insert_kernel<256, true>), dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table,
+			                            slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
+			else hipLaunchKernelGGL((cb_insert_kernel<256, false>), dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table,
+			                        slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
 		});
 		fetch(&ingest, d_ingest.p, sizeof(ingest));
 		if (!ingest.overflow) break;
@@ -304,15 +337,16 @@ void dropest_ctx::build_keys() {
 	GlobalCounters init{};
 	init.key_and = ~0ull;
 	HIP_CHECK(hipMemcpyAsync(d_counters.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
-	const u32 blocks = std::min<u32>(div_up(n, 256), 256u * 16u);
+	const bool vec = ((uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;
 	timed("build_keys", double(n) * (8 + 4 + 4 + 4 + 4 + 8 + layout.val_bytes), [&] {
 		void *v = vals_a.p;
-		if (layout.val_bytes == 0)
-			hipLaunchKernelGGL((build_keys_kernel<256, 0>), dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p);
-		else if (layout.val_bytes == 1)
-			hipLaunchKernelGGL((build_keys_kernel<256, 1>), dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p);
-		else
-			hipLaunchKernelGGL((build_keys_kernel<256, 4>), dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p);
+		auto go = [&](auto kernel) {
+			const u32 blocks = resident_grid(kernel, 256, div_up(n, 256 * 4));
+			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p);
+		};
+		if (layout.val_bytes == 0) { if (vec) go(build_keys_kernel<256, 0, true>); else go(build_keys_kernel<256, 0, false>); }
+		else if (layout.val_bytes == 1) { if (vec) go(build_keys_kernel<256, 1, true>); else go(build_keys_kernel<256, 1, false>); }
+		else { if (vec) go(build_keys_kernel<256, 4, true>); else go(build_keys_kernel<256, 4, false>); }
 	});
 	fetch(&counters, d_counters.p, sizeof(counters));
 }
@@ -441,10 +475,12 @@ bool dropest_ctx::splitter_sort_reduce() {
 	if (mode == 1 || !chr_from_gene || layout.val_bytes > 1) return false;
 	if (mode != 2 && n_reads < min_reads) return false;
 	if (n < 512) return false;
-	// fan-out: F1 coarse x F2 fine buckets (powers of two, 16 .. 512 each) of <= ~900 records on average, so that all but
-	// a hot molecule's bucket fit the small finishing launch (256 threads x 4 or 8 records)
+	// fan-out: F1 coarse x F2 fine buckets (powers of two, 16 .. 512 each) of <= ~1600 records on average: nearly all fit
+	// the small finishing launch (256 threads x 4 or 8 records), the tail and a hot molecule's bucket go to the big one.
+	// (Measured at 1e8 reads: 256 x 256 buckets 4.05 ms for the whole sort, 256 x 512 buckets 4.2 ms -- the finer second
+	// partition costs what the finishing launch gains.)
 	int tb = 8;
-	while (tb < 18 && (uint64_t(n) >> tb) > 900) ++tb;
+	while (tb < 18 && (uint64_t(n) >> tb) > 1600) ++tb;
 	if ((uint64_t(n) >> tb) > 4096) return false;   // > 1.07e9 records: buckets beyond the LDS sort
 	const int fb1 = tb / 2, fb2 = tb - fb1;
 	const u32 F1 = 1u << fb1, Ff = 1u << fb2, F2 = F1 * Ff;

@@ -73,9 +73,12 @@ __device__ inline uint32_t cb_find(const CbTable &t, unsigned long long k) {   /
 	return 0xFFFFFFFFu;
 }
 
-// One pass over (cb, umi, gene): table insert + first ordinal + ingest statistics.  Four reads per thread and
-// iteration: their first probes are independent 16-byte loads in flight together (the kernel is latency-bound).
-template <int THREADS>
+// One pass over (cb, umi, gene): table insert + first ordinal + ingest statistics.  Each thread takes FOUR CONSECUTIVE
+// reads per iteration: with 16-byte-aligned arrays (VEC) every streaming access is a 16-byte load / store per lane (two
+// barcodes, two UMIs, four gene ids, four aux words, four slot indices) -- with one read per lane the 4- and 8-byte
+// accesses left the kernel at 1.4 TB/s whatever else it did (the table probes cost nothing: measured with the probe
+// switched off) -- and the four table probes are independent 16-byte loads in flight together.
+template <int THREADS, bool VEC>
 __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long long *__restrict__ cb,
                                                             const unsigned long long *__restrict__ umi,
                                                             const uint32_t *__restrict__ gene,
@@ -86,39 +89,51 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 	unsigned long long umin = ~0ull, umax = 0ull, uesc = 0ull, cbesc = 0ull;
 	uint32_t gmax = 0, cmax = 0;
 	bool ok = true, chr_conflict = false;
-	const uint64_t stride = uint64_t(gridDim.x) * THREADS;
-	for (uint64_t r0 = uint64_t(blockIdx.x) * THREADS + threadIdx.x; r0 < n; r0 += stride * ILP) {
+	const uint64_t stride = uint64_t(gridDim.x) * THREADS * ILP;
+	for (uint64_t r0 = (uint64_t(blockIdx.x) * THREADS + threadIdx.x) * ILP; r0 < n; r0 += stride) {
 		unsigned long long k[ILP], u[ILP];
 		uint64_t h[ILP];
 		uint4 v[ILP];
-		uint32_t g[ILP], a[ILP];
+		uint32_t g[ILP], a[ILP], sl[ILP];
+		const bool full = r0 + ILP <= n;
+		if (VEC && full) {
+			const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(cb + r0), k23 = *reinterpret_cast<const ulonglong2 *>(cb + r0 + 2);
+			k[0] = k01.x; k[1] = k01.y; k[2] = k23.x; k[3] = k23.y;
+		} else {
 #pragma unroll
-		for (int j = 0; j < ILP; ++j) {
-			const uint64_t r = r0 + uint64_t(j) * stride;
-			k[j] = r < n ? cb[r] : 0ull;
+			for (int j = 0; j < ILP; ++j) k[j] = r0 + j < n ? cb[r0 + j] : 0ull;
 		}
 #pragma unroll
 		for (int j = 0; j < ILP; ++j) {
 			h[j] = mix64(k[j]) & t.mask;
 			v[j] = *reinterpret_cast<const uint4 *>(&t.slots[h[j]]);   // key + ~first in one access
 		}
+		if (VEC && full) {
+			const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + r0), u23 = *reinterpret_cast<const ulonglong2 *>(umi + r0 + 2);
+			const uint4 g4 = *reinterpret_cast<const uint4 *>(gene + r0), a4 = *reinterpret_cast<const uint4 *>(aux + r0);
+			u[0] = u01.x; u[1] = u01.y; u[2] = u23.x; u[3] = u23.y;
+			g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+			a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
+		} else {
 #pragma unroll
-		for (int j = 0; j < ILP; ++j) {
-			const uint64_t r = r0 + uint64_t(j) * stride;
-			u[j] = r < n ? umi[r] : 0ull;
-			g[j] = r < n ? gene[r] : NO_GENE;
-			a[j] = r < n ? aux[r] : 0u;
+			for (int j = 0; j < ILP; ++j) {
+				const uint64_t r = r0 + j;
+				u[j] = r < n ? umi[r] : 0ull;
+				g[j] = r < n ? gene[r] : NO_GENE;
+				a[j] = r < n ? aux[r] : 0u;
+			}
 		}
 #pragma unroll
 		for (int j = 0; j < ILP; ++j) {
-			const uint64_t r = r0 + uint64_t(j) * stride;
+			const uint64_t r = r0 + j;
+			sl[j] = 0;
 			if (r >= n) continue;
 			const unsigned long long cur = (unsigned long long)v[j].x | ((unsigned long long)v[j].y << 32);
 			uint32_t s;
 			uint32_t first_hint = 0xFFFFFFFFu;
 			if (cur == k[j]) { s = uint32_t(h[j]); first_hint = ~v[j].z; }
 			else s = cb_find_or_insert(t, k[j], h[j], ok);
-			slot_out[r] = s;
+			sl[j] = s;
 			// stale (too large) hints only cost an extra atomic; ordinals only ever decrease
 			if (uint32_t(r) < first_hint) atomicMax(&t.slots[s].nfirst, ~uint32_t(r));
 			if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
@@ -133,11 +148,16 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 				if (chr + 1 > cmax) cmax = chr + 1;
 				if (g[j] >= gene_chr_cap) chr_conflict = true;
 				else {
-					uint32_t cur = gene_chr[g[j]];            // L1/L2-hot table; the CAS runs once per gene
-					if (cur == GENE_CHR_UNSET) cur = atomicCAS(&gene_chr[g[j]], GENE_CHR_UNSET, chr), cur = cur == GENE_CHR_UNSET ? chr : cur;
-					if (cur != chr) chr_conflict = true;
+					uint32_t cur2 = gene_chr[g[j]];            // L1/L2-hot table; the CAS runs once per gene
+					if (cur2 == GENE_CHR_UNSET) cur2 = atomicCAS(&gene_chr[g[j]], GENE_CHR_UNSET, chr), cur2 = cur2 == GENE_CHR_UNSET ? chr : cur2;
+					if (cur2 != chr) chr_conflict = true;
 				}
 			}
+		}
+		if (VEC && full) *reinterpret_cast<uint4 *>(slot_out + r0) = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+		else {
+#pragma unroll
+			for (int j = 0; j < ILP; ++j) if (r0 + j < n) slot_out[r0 + j] = sl[j];
 		}
 	}
 	umin = wave_reduce_min_u64(umin); umax = wave_reduce_max_u64(umax); uesc = wave_reduce_max_u64(uesc);
@@ -156,6 +176,31 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 		if (c64) atomicMax(&stats->chr_max_plus1, uint32_t(c64));
 		if (conf) atomicMax(&stats->gene_chr_conflict, 1u);
 	}
+}
+
+// Distinct barcodes among every `stride`-th read (inserted into a scratch table): sizes the real table.  A table of
+// n / 2 slots for a stream whose 1e8 reads carry 3e6 barcodes is 1 GB of 16-byte slots at 5 % load -- every probe of a
+// rare barcode a certain HBM miss, 1 GB to clear and 1 GB to scan for the occupied slots; sized from the sample it is
+// 128 MB and lives in the 256 MB Infinity Cache.
+__global__ __launch_bounds__(256) void cb_sample_distinct_kernel(const unsigned long long *__restrict__ cb, uint32_t n, uint32_t stride,
+                                                                 CbTable t, uint32_t *__restrict__ distinct) {
+	uint32_t mine = 0;
+	for (uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x; j * stride < n; j += uint64_t(gridDim.x) * 256) {
+		const unsigned long long k = cb[j * stride];
+		uint64_t h = mix64(k) & t.mask;
+		for (uint32_t probe = 0; probe < CB_MAX_PROBE; ++probe) {
+			const unsigned long long cur = t.slots[h].key;
+			if (cur == k) break;
+			if (cur == 0ull) {
+				const unsigned long long prev = atomicCAS(&t.slots[h].key, 0ull, k);
+				if (prev == 0ull) { ++mine; break; }
+				if (prev == k) break;
+			}
+			h = (h + 1) & t.mask;
+		}
+	}
+	const unsigned long long tot = wave_reduce_add_u64(mine);
+	if (lane_id() == 0 && tot) atomicAdd(distinct, uint32_t(tot));
 }
 
 // ---- cell ids from the table alone ---------------------------------------------------------------------------

@@ -47,7 +47,7 @@ struct GlobalCounters {   // CellsDataContainer.cpp:73-78, :309-327
 	unsigned long long key_or, key_and;
 };
 
-template <int THREADS, int VB>
+template <int THREADS, int VB, bool VEC>
 __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long long *__restrict__ umi,
                                                              const uint32_t *__restrict__ gene,
                                                              const uint32_t *__restrict__ aux,
@@ -55,23 +55,37 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
                                                              KeyLayout L, unsigned long long *__restrict__ keys,
                                                              void *__restrict__ vals_, GlobalCounters *gc) {
 	unsigned long long c_inter = 0, c_exon = 0, c_intron = 0, c_na = 0, k_or = 0, k_and = ~0ull;
-	// four records per thread and iteration: their 16 streaming loads are issued together, then the four dependent
-	// gathers of the cell ids -- the kernel is bound by the latency of that chain, not by bytes
+	// four CONSECUTIVE records per thread and iteration: 16-byte accesses per lane on every stream when the arrays are
+	// 16-byte aligned (VEC), then the four dependent gathers of the cell ids
 	constexpr int U = 4;
-	const uint32_t stride = gridDim.x * THREADS * U;
-	for (uint32_t base = blockIdx.x * THREADS * U + threadIdx.x; base < n; base += stride) {
+	const uint64_t stride = uint64_t(gridDim.x) * THREADS * U;
+	for (uint64_t base = (uint64_t(blockIdx.x) * THREADS + threadIdx.x) * U; base < n; base += stride) {
 		uint32_t sl[U], g[U], a[U];
-		unsigned long long u[U], cell[U];
+		unsigned long long u[U], cell[U], kk[U];
+		uint32_t vv[U] = {0, 0, 0, 0};
+		const bool full = base + U <= n;
+		if (VEC && full) {
+			const uint4 s4 = *reinterpret_cast<const uint4 *>(slot + base), g4 = *reinterpret_cast<const uint4 *>(gene + base),
+			            a4 = *reinterpret_cast<const uint4 *>(aux + base);
+			const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + base), u23 = *reinterpret_cast<const ulonglong2 *>(umi + base + 2);
+			sl[0] = s4.x; sl[1] = s4.y; sl[2] = s4.z; sl[3] = s4.w;
+			g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+			a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
+			u[0] = u01.x; u[1] = u01.y; u[2] = u23.x; u[3] = u23.y;
+		} else {
 #pragma unroll
-		for (int q = 0; q < U; ++q) {
-			const uint32_t r = base + q * THREADS;
-			if (r < n) { sl[q] = slot[r]; g[q] = gene[r]; a[q] = aux[r]; u[q] = umi[r]; }
+			for (int q = 0; q < U; ++q) {
+				const uint64_t r = base + q;
+				sl[q] = 0; g[q] = NO_GENE; a[q] = 0; u[q] = 0;
+				if (r < n) { sl[q] = slot[r]; g[q] = gene[r]; a[q] = aux[r]; u[q] = umi[r]; }
+			}
 		}
 #pragma unroll
-		for (int q = 0; q < U; ++q) if (base + q * THREADS < n) cell[q] = t.slots[sl[q]].cell_id;
+		for (int q = 0; q < U; ++q) cell[q] = base + q < n ? t.slots[sl[q]].cell_id : 0u;
 #pragma unroll
 		for (int q = 0; q < U; ++q) {
-			const uint32_t r = base + q * THREADS;
+			const uint64_t r = base + q;
+			kk[q] = 0;
 			if (r >= n) continue;
 			uint32_t mark = (a[q] >> 16) & 0xFFu;
 			unsigned long long gcode, ucode;
@@ -86,10 +100,22 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 			}
 			unsigned long long k = (cell[q] << (L.gene_bits + L.umi_bits)) | (gcode << L.umi_bits) | ucode;
 			if (VB == 0) k = (k << 3) | (mark & 7u);
-			keys[r] = k;
-			if (VB == 1) static_cast<uint8_t *>(vals_)[r] = uint8_t(mark);
-			if (VB == 4) static_cast<uint32_t *>(vals_)[r] = a[q] & 0x00FFFFFFu;
+			kk[q] = k;
+			vv[q] = VB == 1 ? mark & 0xFFu : a[q] & 0x00FFFFFFu;
+			if (!(VEC && full)) {
+				if (VB == 1) static_cast<uint8_t *>(vals_)[r] = uint8_t(mark);
+				if (VB == 4) static_cast<uint32_t *>(vals_)[r] = a[q] & 0x00FFFFFFu;
+			}
 			k_or |= k; k_and &= k;
+		}
+		if (VEC && full) {
+			if (VB == 1) *reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(vals_) + base) = vv[0] | (vv[1] << 8) | (vv[2] << 16) | (vv[3] << 24);
+			if (VB == 4) *reinterpret_cast<uint4 *>(static_cast<uint32_t *>(vals_) + base) = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+			*reinterpret_cast<ulonglong2 *>(keys + base) = make_ulonglong2(kk[0], kk[1]);
+			*reinterpret_cast<ulonglong2 *>(keys + base + 2) = make_ulonglong2(kk[2], kk[3]);
+		} else {
+#pragma unroll
+			for (int q = 0; q < U; ++q) if (base + q < n) keys[base + q] = kk[q];
 		}
 	}
 	c_inter = wave_reduce_add_u64(c_inter); c_exon = wave_reduce_add_u64(c_exon);

@@ -1,0 +1,32 @@
+#!/bin/bash
+# SQ / TCC counters of selected kernels over one set_initialized at C2 size (separate --pmc passes, kernel-trace only).
+# usage on the GPU box: bash scripts/pmc_kernels.sh "cb_insert|build_keys|ss_local"
+set -u
+PAT=${1:-cb_insert}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/pmc
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+export PYTHONPATH=$R
+i=0
+for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCC_EA0_RDREQ_sum" "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_EA0_WRREQ_sum" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  i=$((i+1))
+  VARIANTS=0 timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/p$i -o r -- python $R/scripts/ss_probe.py > $OUT/p$i.log 2>&1
+done
+cd $R
+python - "$PAT" <<'PY'
+import csv, glob, re, sys, collections
+pat = re.compile(sys.argv[1])
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmc/p*/**/*counter_collection.csv", recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row.get("Kernel_Name", "")
+        if pat.search(k):
+            agg[re.sub(r"\(.*", "", k)[:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for k, d in agg.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print("   %-24s %.4g (x%d launches, mean)" % (c, sum(v) / len(v), len(v)))
+PY
