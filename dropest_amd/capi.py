@@ -156,6 +156,18 @@ def lib():
         "dropest_dev_count": (C.c_int, []),
         "dropest_dev_sync": (C.c_int, [C.c_int]),
         "dropest_rand_sequence": (C.c_int, [C.c_uint32, C.c_uint64, vp]),
+        "dropest_shard_unique_id": (C.c_int, [vp]),
+        "dropest_shard_create": (C.c_int, [P(Cfg), C.c_int32, C.c_int32, vp, P(vp)]),
+        "dropest_shard_group_create": (C.c_int, [P(Cfg), C.c_int32, vp, vp]),
+        "dropest_shard_destroy": (None, [vp]),
+        "dropest_shard_ctx": (vp, [vp]),
+        "dropest_shard_set_reads_device": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64]),
+        "dropest_shard_step": (C.c_int, [vp]),
+        "dropest_shard_group_step": (C.c_int, [vp, C.c_int32]),
+        "dropest_shard_matrix": (C.c_int, [vp, C.c_int, u64p, u64p, P(vp), P(vp), P(vp), P(vp)]),
+        "dropest_shard_merged_barcodes": (C.c_int, [vp, u64p, vp, vp]),
+        "dropest_shard_phase_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
+        "dropest_shard_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -183,6 +195,9 @@ EXPORTED_SYMBOLS = [
     "dropest_synth_generate_host", "dropest_synth_generate_device", "dropest_dev_alloc", "dropest_dev_free",
     "dropest_dev_copy_to_host", "dropest_dev_copy_from_host", "dropest_dev_count", "dropest_dev_sync",
     "dropest_rand_sequence",
+    "dropest_shard_unique_id", "dropest_shard_create", "dropest_shard_group_create", "dropest_shard_destroy", "dropest_shard_ctx",
+    "dropest_shard_set_reads_device", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix",
+    "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option",
 ]
 
 
@@ -211,39 +226,49 @@ def unpack_code(code, side=()):
     return "".join("ACGT"[(code >> (2 * (n - 1 - i))) & 3] for i in range(n))
 
 
+def make_cfg(device=0, merge_kind=MERGE_NONE, barcodes_kind=BARCODES_INDROP, barcodes_file=None,
+             min_genes_before_merge=10, min_genes_after_merge=10, min_merge_fraction=0.2,
+             max_cb_merge_edit_distance=2, max_umi_merge_edit_distance=1, gene_match_levels="eEBA",
+             max_cells=-1, cb_table_capacity=0, umi_merge_kind=UMI_MERGE_SIMPLE, umi_merge_multiplier=2.0,
+             max_merge_prob=1e-4, max_real_merge_prob=1e-7):
+    """dropest_cfg from keyword arguments; returns (cfg, the byte strings it points to -- keep them alive)."""
+    cfg = Cfg()
+    lib().dropest_cfg_defaults(C.byref(cfg))
+    cfg.device = device; cfg.merge_kind = merge_kind; cfg.barcodes_kind = barcodes_kind
+    bf = barcodes_file.encode() if barcodes_file else None
+    ml = gene_match_levels.encode()
+    cfg.barcodes_file = bf; cfg.gene_match_levels = ml
+    cfg.min_genes_before_merge = min_genes_before_merge; cfg.min_genes_after_merge = min_genes_after_merge
+    cfg.min_merge_fraction = min_merge_fraction; cfg.max_cb_merge_edit_distance = max_cb_merge_edit_distance
+    cfg.max_umi_merge_edit_distance = max_umi_merge_edit_distance; cfg.max_cells = max_cells
+    cfg.cb_table_capacity = cb_table_capacity
+    cfg.umi_merge_kind = umi_merge_kind; cfg.umi_merge_multiplier = umi_merge_multiplier
+    cfg.max_merge_prob = max_merge_prob; cfg.max_real_merge_prob = max_real_merge_prob
+    return cfg, (bf, ml)
+
+
 class Context:
     """One container on one GPU.  Method names follow Estimation::CellsDataContainer."""
 
-    def __init__(self, device=0, merge_kind=MERGE_NONE, barcodes_kind=BARCODES_INDROP, barcodes_file=None,
-                 min_genes_before_merge=10, min_genes_after_merge=10, min_merge_fraction=0.2,
-                 max_cb_merge_edit_distance=2, max_umi_merge_edit_distance=1, gene_match_levels="eEBA",
-                 max_cells=-1, cb_table_capacity=0, umi_merge_kind=UMI_MERGE_SIMPLE, umi_merge_multiplier=2.0,
-                 max_merge_prob=1e-4, max_real_merge_prob=1e-7):
+    def __init__(self, device=0, _borrowed=None, **kw):
         self.L = lib()
         self.device = device
-        cfg = Cfg()
-        self.L.dropest_cfg_defaults(C.byref(cfg))
-        cfg.device = device; cfg.merge_kind = merge_kind; cfg.barcodes_kind = barcodes_kind
-        self._bf = barcodes_file.encode() if barcodes_file else None
-        self._ml = gene_match_levels.encode()
-        cfg.barcodes_file = self._bf; cfg.gene_match_levels = self._ml
-        cfg.min_genes_before_merge = min_genes_before_merge; cfg.min_genes_after_merge = min_genes_after_merge
-        cfg.min_merge_fraction = min_merge_fraction; cfg.max_cb_merge_edit_distance = max_cb_merge_edit_distance
-        cfg.max_umi_merge_edit_distance = max_umi_merge_edit_distance; cfg.max_cells = max_cells
-        cfg.cb_table_capacity = cb_table_capacity
-        cfg.umi_merge_kind = umi_merge_kind; cfg.umi_merge_multiplier = umi_merge_multiplier
-        cfg.max_merge_prob = max_merge_prob; cfg.max_real_merge_prob = max_real_merge_prob
-        h = C.c_void_p()
-        self.h = None
-        self._chk(self.L.dropest_ctx_create(C.byref(cfg), C.byref(h)))
-        self.h = h
         self.side = []
         self._keep = []
+        self.h = None
+        self._owned = _borrowed is None
+        if _borrowed is not None:          # the context of a shard (dropest_shard_ctx): accessors only, never destroyed here
+            self.h = C.c_void_p(_borrowed)
+            return
+        cfg, self._cfg_keep = make_cfg(device=device, **kw)
+        h = C.c_void_p()
+        self._chk(self.L.dropest_ctx_create(C.byref(cfg), C.byref(h)))
+        self.h = h
 
     def close(self):
-        if self.h:
+        if self.h and self._owned:
             self.L.dropest_ctx_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -608,6 +633,16 @@ class DeviceArrays:
         for p in self.ptrs:
             self.L.dropest_dev_free(self.device, p)
         self.ptrs = []
+
+    @classmethod
+    def from_host(cls, device, cb, umi, gene, aux):
+        """Uploads four host arrays (used by tests to give every shard its range of an arbitrary stream)."""
+        self = cls(device, len(cb))
+        for a, p, dt in zip((cb, umi, gene, aux), self.ptrs, (np.uint64, np.uint64, np.uint32, np.uint32)):
+            a = np.ascontiguousarray(a, dt)
+            if len(a) and self.L.dropest_dev_copy_from_host(device, p, a.ctypes.data, a.nbytes) != 0:
+                raise DropestError(3, "host-to-device copy failed")
+        return self
 
     def to_host(self):
         out = [np.zeros(self.n, np.uint64), np.zeros(self.n, np.uint64), np.zeros(self.n, np.uint32),

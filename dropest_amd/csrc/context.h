@@ -342,6 +342,14 @@ struct dropest_ctx {
 	                        const uint32_t *const d_cols[4]);
 	void reaggregate_after_merge();
 	void run_umi_merge_simple();
+	std::vector<u32> umi_first_positions(const std::vector<u64> &sorted_codes);
+	// sharded runs (shard_run.h): the two places where the N-UMI merge needs the other shards
+	struct ShardHooks {
+		std::function<std::vector<u64>(const std::vector<u64> &)> first_seen_global;   // sorted UMI codes -> smallest global ordinal each
+		std::function<std::vector<u64>(const std::vector<u32> &, const std::vector<u32> &, const std::vector<u32> &)> rng_offsets;   // (cell first read, gene, draws) per group -> offset in the one rand() sequence
+	};
+	std::shared_ptr<ShardHooks> hooks;
+	void emit_columns_device(bool filtered_m, bool reads_output, const std::vector<u32> &col_cell, const std::vector<u32> &col_start, uint64_t nnz);
 	struct GatheredGroups { std::vector<u32> size, off, begin, hr, hm, hfirst; std::vector<u64> hk; };   // begin: first molecule row of the group
 	void umi_gather_groups(const std::vector<u32> &groups, GatheredGroups &G, const u32 *d_first_table);
 	void umi_patch_groups(const std::vector<u32> &p_idx, const std::vector<u32> &p_all, const std::vector<u32> &p_req,

@@ -36,6 +36,10 @@ static dropest_status guarded(F &&f) {
 
 static inline u32 div_up(uint64_t a, uint64_t b) { return u32((a + b - 1) / b); }
 
+static void partition_by_owner_on(int device, hipStream_t st, const u64 *d_cb, const u64 *d_umi, const u32 *d_gene, const u32 *d_aux, uint64_t n64,
+                                  u32 n_parts, u64 *d_out_cb, u64 *d_out_umi, u32 *d_out_gene, u32 *d_out_aux, u32 *d_out_idx, uint64_t *counts,
+                                  void *d_scratch, uint64_t scratch_bytes);
+
 // Grid of a grid-stride kernel: exactly as many workgroups as are resident at once (occupancy x CUs), at most `wanted`.
 // A latency-bound kernel launched with a few more workgroups than fit pays a whole extra round for them (cb_insert with
 // 2048 workgroups where 1792 fit ran its last 256 alone: measured 8192 waves against 7168 resident).
@@ -1093,6 +1097,28 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host) 
 	collect_timings();
 }
 
+// Sharded runs: the columns of a caller-given list of cells, emitted compactly into the device staging of matrix slot
+// (filtered: cm values and zero-skipping; else cm_raw) -- the caller places them in the global matrix.
+void dropest_ctx::emit_columns_device(bool filtered_m, bool reads_output, const std::vector<u32> &col_cell, const std::vector<u32> &col_start, uint64_t nnz) {
+	invalidate_prefetch();
+	MatrixResult &M = mat[filtered_m ? 0 : 1];
+	const u32 ncols = u32(col_cell.size());
+	if (!ncols || !nnz) return;
+	m_col_cell.ensure(ncols); m_col_start.ensure(ncols);
+	M.d_row.ensure(nnz); M.d_val.ensure(nnz);
+	HIP_CHECK(hipMemcpyAsync(m_col_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemcpyAsync(m_col_start.p, col_start.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
+	MatrixArgs a{};
+	a.col_cell = m_col_cell.p; a.col_start = m_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
+	a.value = filtered_m ? (reads_output ? cg_reads_req.p : cg_n_req.p) : (reads_output ? cg_reads_all.p : cg_n_all.p);
+	a.gene_mask = layout.gene_none; a.skip_zero = filtered_m ? 1 : 0;
+	a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
+	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * 20, [&] {
+		hipLaunchKernelGGL(emit_matrix_kernel, dim3(ncols), dim3(256), 0, stream, a);
+	});
+	HIP_CHECK(hipStreamSynchronize(stream));   // the host vectors must outlive their copies
+}
+
 // ResultsPrinter::get_count_matrix_filtered(container, query_marks) (ResultsPrinter.cpp:333-361) for a query other than
 // the container's own: columns = the filtered cells, values = UMIs (reads) of each gene whose mark matches, zero
 // entries dropped (Cell::requested_umis_per_gene, Cell.cpp:54-68).
@@ -1899,6 +1925,17 @@ dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, cons
                                           uint64_t *d_out_umi, uint32_t *d_out_gene, uint32_t *d_out_aux, uint32_t *d_out_idx,
                                           uint64_t *counts, void *d_scratch, uint64_t scratch_bytes) {
 	return guarded([&] {
+		partition_by_owner_on(device, nullptr, reinterpret_cast<const u64 *>(d_cb), reinterpret_cast<const u64 *>(d_umi), d_gene, d_aux, n64, n_parts,
+		                      reinterpret_cast<u64 *>(d_out_cb), reinterpret_cast<u64 *>(d_out_umi), d_out_gene, d_out_aux, d_out_idx, counts, d_scratch, scratch_bytes);
+	});
+}
+
+}  // extern "C"
+
+static void partition_by_owner_on(int device, hipStream_t st, const u64 *d_cb, const u64 *d_umi, const u32 *d_gene, const u32 *d_aux, uint64_t n64,
+                                  u32 n_parts, u64 *d_out_cb, u64 *d_out_umi, u32 *d_out_gene, u32 *d_out_aux, u32 *d_out_idx, uint64_t *counts,
+                                  void *d_scratch, uint64_t scratch_bytes) {
+	{
 		if (n_parts == 0 || n_parts > 256) throw InvalidError("n_parts must be in 1..256");
 		if (n64 >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads per GPU");
 		HIP_CHECK(hipSetDevice(device));
@@ -1913,22 +1950,22 @@ dropest_status dropest_partition_by_owner(int device, const uint64_t *d_cb, cons
 		u64 *k0 = reinterpret_cast<u64 *>(base), *k1 = reinterpret_cast<u64 *>(base + off_k1);
 		u32 *hist = reinterpret_cast<u32 *>(base + off_hist), *row_total = reinterpret_cast<u32 *>(base + off_row);
 		u32 *digit_base = reinterpret_cast<u32 *>(base + off_base);
-		hipStream_t st = nullptr;
-		hipLaunchKernelGGL(owner_keys_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st,
-		                   reinterpret_cast<const u64 *>(d_cb), n, n_parts, k0);
+		hipLaunchKernelGGL(owner_keys_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st, d_cb, n, n_parts, k0);
 		hipLaunchKernelGGL(rs_hist_kernel<8>, dim3(nblocks), dim3(RS_THREADS), 0, st, k0, n, 0, tpb, u32(RS_TILE_REC), hist);
 		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, st, hist, nblocks, row_total);
 		hipLaunchKernelGGL(rs_scan_totals_kernel<256>, dim3(1), dim3(256), 0, st, row_total, digit_base);
 		rs_launch(0, 8, dim3(nblocks), st, k0, nullptr, k1, nullptr, n, 0, tpb, hist, digit_base);
 		hipLaunchKernelGGL(gather_reads_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st, k1, n,
-		                   reinterpret_cast<const u64 *>(d_cb), reinterpret_cast<const u64 *>(d_umi), d_gene, d_aux,
-		                   reinterpret_cast<u64 *>(d_out_cb), reinterpret_cast<u64 *>(d_out_umi), d_out_gene, d_out_aux, d_out_idx);
+		                   d_cb, d_umi, d_gene, d_aux, d_out_cb, d_out_umi, d_out_gene, d_out_aux, d_out_idx);
 		HIP_CHECK(hipGetLastError());
 		std::vector<u32> totals(RS_RADIX);
-		HIP_CHECK(hipMemcpy(totals.data(), row_total, RS_RADIX * 4, hipMemcpyDeviceToHost));
+		HIP_CHECK(hipMemcpyAsync(totals.data(), row_total, RS_RADIX * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipStreamSynchronize(st));
 		for (u32 p = 0; p < n_parts; ++p) counts[p] = totals[p];
-	});
+	}
 }
+
+extern "C" {
 
 dropest_status dropest_real_candidate_rows(dropest_ctx *ctx, uint64_t *n, uint64_t *ids, dropest_cell_row *rows) {
 	return guarded([&] {
@@ -2082,3 +2119,5 @@ dropest_status dropest_set_profiling_filter(dropest_ctx *ctx, const char *name_p
 void *dropest_stream(dropest_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
 
 }  // extern "C"
+
+#include "shard_run.h"

@@ -1,0 +1,994 @@
+// shard_run.h -- the Estimation hot path sharded by cell barcode over several MI355X (included by dropest_amd.hip).
+//
+// The reference has ONE container fed by one thread (Estimation/CellsDataContainer.h:33-123, dropest.cpp:245-252); every
+// per-read step of the path is independent per barcode, so the reads are sharded by owner(cb) = mix64(cb) mod n
+// (SURVEY.md §8e).  One ShardRun = one shard = one dropest_ctx on one GPU, driven by one host thread -- a process per GPU
+// (bench.py under torch.distributed.run: the communicator comes from an ncclUniqueId the launcher distributes) or the
+// threads of one process (the C++ facade owning N GPUs; tests put several shards on ONE device).  Everything between the
+// collectives is the single-GPU pipeline; the collectives go through a Transport:
+//   RcclTransport   RCCL over xGMI: one grouped ncclSend / ncclRecv all-to-all(v) of the five read arrays (the only
+//                   data-path collective), all-gathers of small tables, molecule rows of merged cells
+//   LocalTransport  shards inside one process: device-to-device copies and a host barrier (several shards per device)
+// Steps of one pass: partition by owner (stable) -> all-to-all -> barcode table + key-field agreement -> sort / reduce ->
+// whitelist CB merge across shards (search / export / intersect / decide / apply / finish, merge_shard.h) -> UMI merge
+// (N-UMIs: random fills follow ONE rand() sequence in global cell order) and filter -> global column order -> every
+// shard writes ITS columns of both matrices into host memory shared by the node's shards (all PCIe links at once).
+#pragma once
+
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <mutex>
+#include <sys/mman.h>
+#include <unistd.h>
+
+namespace dropest {
+
+// ---- RCCL, bound at run time (the library also works on hosts without it: single-GPU use never touches it) -----------
+struct RcclApi {
+	void *handle = nullptr;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+	static RcclApi &get() {
+		static RcclApi api = [] {
+			RcclApi a;
+			// The RCCL that belongs to the HIP runtime this library runs on: a process may hold two ROCm trees (PyTorch ships its
+			// own next to /opt/rocm), and an RCCL from the other tree opens ITS libhsa-runtime64 -- not initialised -- and fails
+			// with "no ROCm-capable device".  So: the directory libamdhip64 was loaded from first, then the default search.
+			Dl_info hip{};
+			if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &hip) && hip.dli_fname) {
+				std::string dir(hip.dli_fname);
+				const size_t slash = dir.rfind('/');
+				if (slash != std::string::npos) {
+					dir.resize(slash + 1);
+					for (const char *name : {"librccl.so.1", "librccl.so"}) if ((a.handle = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
+				}
+			}
+			if (!a.handle) for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if ((a.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+			if (!a.handle) return a;
+			auto sym = [&](const char *n) { return dlsym(a.handle, n); };
+			a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+			a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+			a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+			a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+			a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+			a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+			a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+			a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
+			a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+			if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.GroupStart || !a.GroupEnd || !a.Send || !a.Recv || !a.AllGather) a.handle = nullptr;
+			return a;
+		}();
+		if (!api.handle) throw DeviceError("RCCL (librccl.so) is not available: sharded runs over several GPUs need it");
+		return api;
+	}
+	void check(ncclResult_t r, const char *what) const {
+		if (r != ncclSuccess) throw DeviceError(std::string("RCCL ") + what + ": " + (GetErrorString ? GetErrorString(r) : "error"));
+	}
+};
+
+// ---- transports --------------------------------------------------------------------------------------------------------
+struct Transport {
+	int rank = 0, world = 1;
+	virtual ~Transport() {}
+	virtual const char *name() const = 0;
+	// all-to-all(v) of n_arrays device arrays at once: array a has elem[a]-byte elements; the block for peer p starts at
+	// element sum(send_cnt[< p]) of d_send[a] and lands at element sum(recv_cnt[< p]) of d_recv[a].  Returns when done.
+	virtual void exchange(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
+	                      const uint64_t *recv_cnt, hipStream_t st) = 0;
+	virtual void gather_host(const void *mine, size_t bytes, void *all) = 0;   // all: world x bytes, rank order
+	// every shard's device block to every shard: block of rank p = bytes[p] at d_all + off[p]
+	virtual void gather_dev(const void *d_mine, void *d_all, const size_t *off, const size_t *bytes, hipStream_t st) = 0;
+	virtual void barrier() = 0;
+	// host memory shared by the shards of the node (collective call; at least `bytes`); *d_ptr = this shard's device view
+	virtual void *shared_host(int slot, size_t bytes, void **d_ptr) = 0;
+
+	template <class T>
+	void gather_vec(const std::vector<T> &mine, std::vector<T> &all, std::vector<size_t> &count) {   // variable-length host rows
+		uint64_t n = mine.size();
+		std::vector<uint64_t> ns(size_t(world), 0);
+		gather_host(&n, 8, ns.data());
+		uint64_t mx = 1;
+		for (uint64_t x : ns) mx = std::max(mx, x);
+		std::vector<T> pad(mx), buf(size_t(mx) * size_t(world));
+		if (n) std::memcpy(pad.data(), mine.data(), size_t(n) * sizeof(T));
+		gather_host(pad.data(), size_t(mx) * sizeof(T), buf.data());
+		count.assign(size_t(world), 0);
+		all.clear();
+		for (int p = 0; p < world; ++p) {
+			count[size_t(p)] = size_t(ns[size_t(p)]);
+			all.insert(all.end(), buf.begin() + size_t(p) * mx, buf.begin() + size_t(p) * mx + ns[size_t(p)]);
+		}
+	}
+};
+
+// Shards inside one process.  One hub per group; every member runs on its own host thread.
+struct LocalHub {
+	int n;
+	std::mutex m;
+	std::condition_variable cv;
+	int arrived = 0;
+	uint64_t generation = 0;
+	std::vector<const void *> p0, p1;   // per rank: pointers published for the current collective
+	struct Shared { void *host = nullptr; size_t bytes = 0; } shared[4];
+	bool failed = false;                // a member threw: wake the others instead of deadlocking
+	explicit LocalHub(int n_) : n(n_), p0(size_t(n_), nullptr), p1(size_t(n_), nullptr) {}
+	~LocalHub() { for (auto &s : shared) if (s.host) (void)hipHostFree(s.host); }
+	void barrier() {
+		std::unique_lock<std::mutex> lk(m);
+		if (failed) throw DeviceError("another shard of the group failed");
+		const uint64_t g = generation;
+		if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); return; }
+		cv.wait(lk, [&] { return generation != g || failed; });
+		if (failed && generation == g) throw DeviceError("another shard of the group failed");
+	}
+	void fail() { std::lock_guard<std::mutex> lk(m); failed = true; cv.notify_all(); }
+};
+
+struct LocalTransport : Transport {
+	std::shared_ptr<LocalHub> hub;
+	LocalTransport(std::shared_ptr<LocalHub> h, int r) : hub(std::move(h)) { rank = r; world = hub->n; }
+	const char *name() const override { return "local"; }
+	struct Pub { const void *const *d_send; const size_t *elem; const uint64_t *send_cnt; };
+	void exchange(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
+	              const uint64_t *recv_cnt, hipStream_t st) override {
+		Pub pub{d_send, elem, send_cnt};
+		hub->p0[size_t(rank)] = &pub;
+		hub->barrier();
+		uint64_t roff = 0;
+		for (int p = 0; p < world; ++p) {
+			const Pub *src = static_cast<const Pub *>(hub->p0[size_t(p)]);
+			uint64_t soff = 0;
+			for (int q = 0; q < rank; ++q) soff += src->send_cnt[q];
+			for (int a = 0; a < n_arrays; ++a)
+				if (recv_cnt[p])
+					HIP_CHECK(hipMemcpyAsync(static_cast<char *>(d_recv[a]) + roff * elem[a], static_cast<const char *>(src->d_send[a]) + soff * elem[a],
+					                         size_t(recv_cnt[p]) * elem[a], hipMemcpyDefault, st));
+			roff += recv_cnt[p];
+		}
+		HIP_CHECK(hipStreamSynchronize(st));
+		hub->barrier();   // the senders' buffers may be reused
+	}
+	void gather_host(const void *mine, size_t bytes, void *all) override {
+		hub->p0[size_t(rank)] = mine;
+		hub->barrier();
+		for (int p = 0; p < world; ++p) std::memcpy(static_cast<char *>(all) + size_t(p) * bytes, hub->p0[size_t(p)], bytes);
+		hub->barrier();
+	}
+	void gather_dev(const void *d_mine, void *d_all, const size_t *off, const size_t *bytes, hipStream_t st) override {
+		hub->p1[size_t(rank)] = d_mine;
+		hub->barrier();
+		for (int p = 0; p < world; ++p)
+			if (bytes[p]) HIP_CHECK(hipMemcpyAsync(static_cast<char *>(d_all) + off[p], hub->p1[size_t(p)], bytes[p], hipMemcpyDefault, st));
+		HIP_CHECK(hipStreamSynchronize(st));
+		hub->barrier();
+	}
+	void barrier() override { hub->barrier(); }
+	void *shared_host(int slot, size_t bytes, void **d_ptr) override {
+		hub->barrier();
+		if (rank == 0) {
+			LocalHub::Shared &s = hub->shared[slot];
+			if (s.bytes < bytes) {
+				if (s.host) HIP_CHECK(hipHostFree(s.host));
+				s.host = nullptr; s.bytes = 0;
+				const size_t cap = bytes + bytes / 4 + 4096;
+				HIP_CHECK(hipHostMalloc(&s.host, cap, hipHostMallocPortable | hipHostMallocMapped));
+				s.bytes = cap;
+			}
+		}
+		hub->barrier();
+		void *host = hub->shared[slot].host;
+		HIP_CHECK(hipHostGetDevicePointer(d_ptr, host, 0));
+		return host;
+	}
+};
+
+// One process per GPU: RCCL for the device data, and -- no second runtime -- RCCL all-gathers of staged bytes for the
+// small host tables.  Shared host memory: a POSIX shm object mapped and registered by every process of the node.
+struct RcclTransport : Transport {
+	ncclComm_t comm = nullptr;
+	hipStream_t st0 = nullptr;          // the owning context's stream
+	DevBuf<unsigned char> stage_in, stage_out;
+	PinnedBuf<unsigned char> h_in, h_out;
+	uint64_t token = 0;
+	struct Shm { void *host = nullptr; size_t bytes = 0; int gen = 0; } shm[4];
+	RcclTransport(int r, int w, const uint8_t id_bytes[128], hipStream_t st) : st0(st) {
+		rank = r; world = w;
+		const RcclApi &api = RcclApi::get();
+		ncclUniqueId id;
+		static_assert(sizeof(id) == 128, "ncclUniqueId");
+		std::memcpy(&id, id_bytes, 128);
+		api.check(api.CommInitRank(&comm, w, id, r), "ncclCommInitRank");
+		for (int i = 0; i < 128; ++i) token = token * 1099511628211ull + id_bytes[i];
+	}
+	~RcclTransport() override {
+		for (auto &s : shm) if (s.host) { (void)hipHostUnregister(s.host); munmap(s.host, s.bytes); }
+		if (comm) (void)RcclApi::get().CommDestroy(comm);
+	}
+	const char *name() const override { return "rccl"; }
+	void exchange(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
+	              const uint64_t *recv_cnt, hipStream_t st) override {
+		const RcclApi &api = RcclApi::get();
+		api.check(api.GroupStart(), "ncclGroupStart");
+		for (int a = 0; a < n_arrays; ++a) {
+			uint64_t soff = 0, roff = 0;
+			for (int p = 0; p < world; ++p) {
+				if (send_cnt[p]) api.check(api.Send(static_cast<const char *>(d_send[a]) + soff * elem[a], size_t(send_cnt[p]) * elem[a], ncclUint8, p, comm, st), "ncclSend");
+				if (recv_cnt[p]) api.check(api.Recv(static_cast<char *>(d_recv[a]) + roff * elem[a], size_t(recv_cnt[p]) * elem[a], ncclUint8, p, comm, st), "ncclRecv");
+				soff += send_cnt[p]; roff += recv_cnt[p];
+			}
+		}
+		api.check(api.GroupEnd(), "ncclGroupEnd");
+		HIP_CHECK(hipStreamSynchronize(st));
+	}
+	void gather_host(const void *mine, size_t bytes, void *all) override {
+		const RcclApi &api = RcclApi::get();
+		const size_t b = std::max<size_t>(bytes, 1);
+		stage_in.ensure(b); stage_out.ensure(b * size_t(world)); h_in.ensure(b); h_out.ensure(b * size_t(world));
+		std::memcpy(h_in.p, mine, bytes);
+		HIP_CHECK(hipMemcpyAsync(stage_in.p, h_in.p, b, hipMemcpyHostToDevice, st0));
+		api.check(api.AllGather(stage_in.p, stage_out.p, b, ncclUint8, comm, st0), "ncclAllGather");
+		HIP_CHECK(hipMemcpyAsync(h_out.p, stage_out.p, b * size_t(world), hipMemcpyDeviceToHost, st0));
+		HIP_CHECK(hipStreamSynchronize(st0));
+		for (int p = 0; p < world; ++p) std::memcpy(static_cast<char *>(all) + size_t(p) * bytes, h_out.p + size_t(p) * b, bytes);
+	}
+	void gather_dev(const void *d_mine, void *d_all, const size_t *off, const size_t *bytes, hipStream_t st) override {
+		const RcclApi &api = RcclApi::get();
+		api.check(api.GroupStart(), "ncclGroupStart");
+		for (int p = 0; p < world; ++p) {
+			if (bytes[rank]) api.check(api.Send(d_mine, bytes[rank], ncclUint8, p, comm, st), "ncclSend");
+			if (bytes[p]) api.check(api.Recv(static_cast<char *>(d_all) + off[p], bytes[p], ncclUint8, p, comm, st), "ncclRecv");
+		}
+		api.check(api.GroupEnd(), "ncclGroupEnd");
+		HIP_CHECK(hipStreamSynchronize(st));
+	}
+	void barrier() override { unsigned char x = 0; std::vector<unsigned char> all(static_cast<size_t>(world)); gather_host(&x, 1, all.data()); }
+	void *shared_host(int slot, size_t bytes, void **d_ptr) override {
+		Shm &s = shm[slot];
+		// every rank must take the same branch: agree on the capacity first
+		uint64_t want = s.bytes >= bytes ? 0 : uint64_t(bytes + bytes / 4 + 4096);
+		std::vector<uint64_t> wants(static_cast<size_t>(world));
+		gather_host(&want, 8, wants.data());
+		uint64_t cap = 0;
+		for (uint64_t w : wants) cap = std::max(cap, w);
+		if (cap) {
+			cap = std::max<uint64_t>(cap, s.bytes);
+			if (s.host) { HIP_CHECK(hipHostUnregister(s.host)); munmap(s.host, s.bytes); s.host = nullptr; s.bytes = 0; }
+			++s.gen;
+			uint64_t pid0 = uint64_t(getpid());
+			std::vector<uint64_t> pids(static_cast<size_t>(world));
+			gather_host(&pid0, 8, pids.data());
+			char path[128];
+			std::snprintf(path, sizeof(path), "/dropest_%llx_%llu_%d_%d", (unsigned long long)token, (unsigned long long)pids[0], slot, s.gen);
+			uint64_t ok = 1;
+			int fd = -1;
+			if (rank == 0) {
+				fd = shm_open(path, O_CREAT | O_EXCL | O_RDWR, 0600);
+				if (fd < 0 || posix_fallocate(fd, 0, off_t(cap)) != 0) ok = 0;   // reserve the pages now: a full tmpfs fails here, not with SIGBUS later
+			}
+			std::vector<uint64_t> oks(static_cast<size_t>(world));
+			gather_host(&ok, 8, oks.data());
+			if (!oks[0]) { if (fd >= 0) { close(fd); shm_unlink(path); } throw DeviceError("cannot reserve the shared result buffer in /dev/shm"); }
+			if (rank != 0) fd = shm_open(path, O_RDWR, 0600);
+			void *host = fd >= 0 ? mmap(nullptr, size_t(cap), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0) : MAP_FAILED;
+			if (fd >= 0) close(fd);
+			ok = host != MAP_FAILED && hipHostRegister(host, size_t(cap), hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess;
+			gather_host(&ok, 8, oks.data());
+			if (rank == 0) shm_unlink(path);   // the mappings keep it alive; nothing is left behind on a crash
+			for (uint64_t o : oks) if (!o) throw DeviceError("cannot map / register the shared result buffer");
+			s.host = host; s.bytes = size_t(cap);
+		}
+		HIP_CHECK(hipHostGetDevicePointer(d_ptr, s.host, 0));
+		return s.host;
+	}
+};
+
+// ---- small kernels ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void take_u32_kernel(const uint32_t *__restrict__ table, const uint32_t *__restrict__ pos, uint32_t n, uint32_t *__restrict__ out) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) out[i] = table[pos[i]];
+}
+struct ImportGatherArgs { const uint32_t *row; uint32_t n; const unsigned long long *low_all; const uint32_t *col_all[4]; unsigned long long *o_low; uint32_t *o_col[4]; };
+__global__ __launch_bounds__(256) void import_gather_kernel(ImportGatherArgs a) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= a.n) return;
+	const uint32_t r = a.row[i];
+	a.o_low[i] = a.low_all[r];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) a.o_col[k][i] = a.col_all[k][r];
+}
+// desc[3c .. 3c+2] = (src_start, dst_start, len) of column c; rows / values go to their places in the global matrix
+__global__ __launch_bounds__(256) void place_columns_kernel(const unsigned long long *__restrict__ desc, const uint32_t *__restrict__ src_rows,
+                                                            const uint32_t *__restrict__ src_vals, uint32_t *__restrict__ dst_rows, uint32_t *__restrict__ dst_vals) {
+	const unsigned long long s = desc[3ull * blockIdx.x], d = desc[3ull * blockIdx.x + 1], len = desc[3ull * blockIdx.x + 2];
+	for (unsigned long long t = threadIdx.x; t < len; t += 256) { dst_rows[d + t] = src_rows[s + t]; dst_vals[d + t] = src_vals[s + t]; }
+}
+// local read position -> global stream ordinal: position p came from source rank s = the block [recv_off[s], recv_off[s+1])
+// it lies in, as that rank's idx[p]-th resident read
+struct OrdinalMap { const uint32_t *idx; uint32_t world; uint64_t recv_off[65]; uint64_t first_ord[64]; };
+__device__ inline unsigned long long to_global_ordinal(const OrdinalMap &m, uint32_t p) {
+	uint32_t s = 0;
+	while (s + 1 < m.world && p >= m.recv_off[s + 1]) ++s;
+	return m.first_ord[s] + (m.idx ? m.idx[p] : p - uint32_t(m.recv_off[s]));
+}
+__global__ __launch_bounds__(256) void ordinals_kernel(OrdinalMap m, const uint32_t *__restrict__ pos, uint32_t n, unsigned long long *__restrict__ out) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) out[i] = pos[i] == 0xFFFFFFFFu ? ~0ull : to_global_ordinal(m, pos[i]);
+}
+
+}  // namespace dropest
+
+// ---- one shard ---------------------------------------------------------------------------------------------------------
+struct dropest_shard {
+	using u64 = dropest::u64;
+	using u32 = dropest::u32;
+	std::unique_ptr<dropest_ctx> ctx;
+	std::unique_ptr<dropest::Transport> tr;
+	int rank = 0, world = 1;
+	bool force_exchange = false, trace = false;
+	// this shard's contiguous range of the stream (resident, adopted)
+	const u64 *r_cb = nullptr, *r_umi = nullptr;
+	const u32 *r_gene = nullptr, *r_aux = nullptr;
+	uint64_t n_res = 0, first_ordinal = 0;
+	// partition / exchange buffers
+	dropest::DevBuf<u64> p_cb, p_umi, x_cb, x_umi;
+	dropest::DevBuf<u32> p_gene, p_aux, p_idx, x_gene, x_aux, x_idx;
+	dropest::DevBuf<unsigned char> part_scratch;
+	std::vector<uint64_t> send_cnt, recv_cnt, recv_off, first_ord;   // first_ord[p]: first stream ordinal of rank p's range
+	bool exchanged = false;
+	// global table of the real cells (identical on every shard after a step)
+	struct GRow {
+		u64 barcode, first_global;
+		u32 n_genes, req_genes, req_umis, local_id;
+		int32_t total_umis, total_reads;
+		u32 rank, pad;
+	};
+	std::vector<GRow> G;
+	// results: global CSC of both matrices (rows / values in the node-shared host buffer)
+	struct Mat { uint64_t ncols = 0, nnz = 0; std::vector<u64> colptr, col_barcode; const u32 *rows = nullptr, *vals = nullptr; } mat[2];
+	std::vector<std::pair<u64, u64>> merged_barcodes;   // (source, target) barcode of every merged cell, ascending source
+	dropest::DevBuf<u64> d_desc;
+	dropest::PinnedBuf<u64> h_desc;
+	dropest::DevBuf<u32> d_tmp32;
+	std::map<std::string, dropest::KernelStat> phases;
+
+	struct Phase {
+		dropest_shard *s; const char *name; std::chrono::steady_clock::time_point t0;
+		Phase(dropest_shard *sh, const char *n) : s(sh), name(n), t0(std::chrono::steady_clock::now()) {}
+		~Phase() {
+			if (s->trace) (void)hipStreamSynchronize(s->ctx->stream);
+			auto &st = s->phases[name];
+			st.launches++;
+			st.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		}
+	};
+
+	void step();
+	void partition_and_exchange();
+	void agree_on_key_fields();
+	void cb_merge();
+	void build_global_table();
+	void assemble_matrix(bool filtered_m);
+	std::vector<u32> order_rows(const std::vector<u32> &sel, bool by_first);
+	std::vector<u64> global_ordinals(const std::vector<u32> &local_pos);
+	void install_umi_hooks();
+};
+
+std::vector<dropest::u64> dropest_shard::global_ordinals(const std::vector<u32> &local_pos) {
+	using namespace dropest;
+	std::vector<u64> out(local_pos.size());
+	if (local_pos.empty()) return out;
+	dropest_ctx &c = *ctx;
+	OrdinalMap m{};
+	m.idx = exchanged ? x_idx.p : nullptr;
+	m.world = exchanged ? u32(world) : 1u;
+	if (exchanged) { for (int p = 0; p <= world; ++p) m.recv_off[p] = recv_off[size_t(p)]; for (int p = 0; p < world; ++p) m.first_ord[p] = first_ord[size_t(p)]; }
+	else { m.recv_off[0] = 0; m.recv_off[1] = n_res; m.first_ord[0] = first_ordinal; }
+	const u32 n = u32(local_pos.size());
+	DevBuf<u32> d_pos; DevBuf<u64> d_out;
+	d_pos.alloc(n); d_out.alloc(n);
+	HIP_CHECK(hipMemcpyAsync(d_pos.p, local_pos.data(), size_t(n) * 4, hipMemcpyHostToDevice, c.stream));
+	hipLaunchKernelGGL(ordinals_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, m, d_pos.p, n, d_out.p);
+	HIP_CHECK(hipGetLastError());
+	c.fetch(out.data(), d_out.p, size_t(n) * 8);
+	return out;
+}
+
+// 1-2. partition by owner (stable: reads of one owner keep stream order), one all-to-all(v) of the five arrays
+void dropest_shard::partition_and_exchange() {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	const u32 n = u32(n_res);
+	send_cnt.assign(size_t(world), 0);
+	{
+		Phase ph(this, "partition");
+		for (DevBuf<u64> *b : {&p_cb, &p_umi}) b->ensure(std::max<size_t>(n, 1));
+		for (DevBuf<u32> *b : {&p_gene, &p_aux, &p_idx}) b->ensure(std::max<size_t>(n, 1));
+		uint64_t need = 0;
+		if (dropest_partition_scratch_bytes(n, &need) != DROPEST_OK) throw UnsupportedError("more than 2^32-2 reads per GPU");
+		part_scratch.ensure(size_t(need));
+		partition_by_owner_on(c.cfg.device, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p,
+		                      send_cnt.data(), part_scratch.p, need);
+	}
+	Phase ph(this, "all_to_all");
+	std::vector<uint64_t> all_cnt(size_t(world) * size_t(world));
+	tr->gather_host(send_cnt.data(), size_t(world) * 8, all_cnt.data());
+	recv_cnt.assign(size_t(world), 0); recv_off.assign(size_t(world) + 1, 0);
+	for (int p = 0; p < world; ++p) { recv_cnt[size_t(p)] = all_cnt[size_t(p) * size_t(world) + size_t(rank)]; recv_off[size_t(p) + 1] = recv_off[size_t(p)] + recv_cnt[size_t(p)]; }
+	const uint64_t n_recv = recv_off[size_t(world)];
+	if (n_recv >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads on one shard after the exchange");
+	for (DevBuf<u64> *b : {&x_cb, &x_umi}) b->ensure(std::max<size_t>(n_recv, 1));
+	for (DevBuf<u32> *b : {&x_gene, &x_aux, &x_idx}) b->ensure(std::max<size_t>(n_recv, 1));
+	const void *snd[5] = {p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p};
+	void *rcv[5] = {x_cb.p, x_umi.p, x_gene.p, x_aux.p, x_idx.p};
+	const size_t elem[5] = {8, 8, 4, 4, 4};
+	tr->exchange(5, snd, rcv, elem, send_cnt.data(), recv_cnt.data(), c.stream);
+	auto &st = phases["all_to_all"];
+	uint64_t out = 0;
+	for (int p = 0; p < world; ++p) if (p != rank) out += send_cnt[size_t(p)];
+	st.bytes += double(out) * 28;   // bytes this shard put on the links (self block excluded)
+	exchanged = true;
+}
+
+// 3b. all shards must lay out the gene / UMI fields of the sort key identically (molecule rows move between shards in a
+// merge) and agree on whether a gene determines its chromosome
+void dropest_shard::agree_on_key_fields() {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	uint64_t mine[6] = {c.ingest.umi_clean_min, c.ingest.umi_clean_max, c.ingest.umi_escape_max_plus1, c.ingest.gene_max_plus1,
+	                    c.ingest.chr_max_plus1, c.ingest.gene_chr_conflict};
+	std::vector<uint64_t> all(size_t(world) * 6);
+	tr->gather_host(mine, sizeof(mine), all.data());
+	uint64_t g[6] = {~0ull, 0, 0, 0, 0, 0};
+	for (int p = 0; p < world; ++p) {
+		g[0] = std::min(g[0], all[size_t(p) * 6]);
+		for (int k = 1; k < 6; ++k) g[k] = std::max(g[k], all[size_t(p) * 6 + size_t(k)]);
+	}
+	const u32 n_genes = u32(std::min<uint64_t>(g[3], GENE_CHR_CAP));
+	if (n_genes && !g[5]) {
+		if (!c.gene_chr.p) {   // a shard without reads: an all-unset table
+			c.gene_chr.ensure(GENE_CHR_CAP);
+			HIP_CHECK(hipMemsetAsync(c.gene_chr.p, 0xFF, size_t(GENE_CHR_CAP) * 4, c.stream));
+		}
+		std::vector<u32> tab(n_genes), tabs(size_t(n_genes) * size_t(world));
+		c.fetch(tab.data(), c.gene_chr.p, size_t(n_genes) * 4);
+		tr->gather_host(tab.data(), size_t(n_genes) * 4, tabs.data());
+		bool conflict = false;
+		for (u32 i = 0; i < n_genes; ++i) {
+			u32 v = GENE_CHR_UNSET;
+			for (int p = 0; p < world; ++p) {
+				const u32 x = tabs[size_t(p) * n_genes + i];
+				if (x == GENE_CHR_UNSET) continue;
+				if (v == GENE_CHR_UNSET) v = x; else if (v != x) conflict = true;   // one gene on two chromosomes, seen by different shards
+			}
+			tab[i] = v;
+		}
+		if (conflict) g[5] = 1;
+		else {
+			HIP_CHECK(hipMemcpyAsync(c.gene_chr.p, tab.data(), size_t(n_genes) * 4, hipMemcpyHostToDevice, c.stream));
+			HIP_CHECK(hipStreamSynchronize(c.stream));
+		}
+	}
+	if (g[3] > GENE_CHR_CAP) g[5] = 1;
+	c.ingest.umi_clean_min = g[0]; c.ingest.umi_clean_max = g[1]; c.ingest.umi_escape_max_plus1 = g[2];
+	c.ingest.gene_max_plus1 = u32(g[3]); c.ingest.chr_max_plus1 = u32(g[4]); c.ingest.gene_chr_conflict = u32(g[5]);
+}
+
+// Order of table rows `sel` (indices into G): by_first = ascending global first ordinal (cell-id order of ONE container);
+// else CellsDataContainer::compare_cells (CellsDataContainer.cpp:329-344): (requested_genes, requested_umis, umis_number,
+// barcode string) ascending.  Large tables of clean equal-length barcodes are sorted on the device (three stable radix
+// sorts, as dropest_ctx::sort_filtered does); anything else on the host with the strings decoded.
+std::vector<dropest::u32> dropest_shard::order_rows(const std::vector<u32> &sel, bool by_first) {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	const size_t m = sel.size();
+	std::vector<u32> out(sel);
+	if (m < 2) return out;
+	if (by_first) {
+		std::sort(out.begin(), out.end(), [&](u32 a, u32 b) { return G[a].first_global < G[b].first_global; });
+		return out;
+	}
+	size_t device_min = 50000;
+	if (const char *e = getenv("DROPEST_DEVICE_SORT_MIN")) device_min = size_t(std::max(1, atoi(e)));
+	bool uniform = true; u64 any = 0;
+	const int bl0 = bit_length(G[sel[0]].barcode);
+	for (u32 i : sel) { any |= G[i].barcode; uniform &= bit_length(G[i].barcode) == bl0; }
+	if (m >= device_min && m < 0xFFFFFFF0ull && uniform && !(any & ESCAPE_BIT)) {
+		const u32 mm = u32(m);
+		c.sort_stage.ensure(size_t(mm) * 3); c.sort_cols.ensure(size_t(mm) * 3);
+		c.keys_a.ensure(mm); c.keys_b.ensure(mm); c.vals_a.ensure(mm); c.vals_b.ensure(mm);
+		u64 *h_code = c.sort_stage.p, *h_umis = c.sort_stage.p + mm, *h_sizes = c.sort_stage.p + 2 * size_t(mm);
+		u64 o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull};
+		for (u32 k = 0; k < mm; ++k) {
+			const GRow &r = G[sel[k]];
+			h_code[k] = r.barcode; h_umis[k] = u64(size_t(r.total_umis)); h_sizes[k] = (u64(r.req_genes) << 32) | r.req_umis;
+			o[0] |= h_code[k]; a[0] &= h_code[k]; o[1] |= h_umis[k]; a[1] &= h_umis[k]; o[2] |= h_sizes[k]; a[2] &= h_sizes[k];
+		}
+		HIP_CHECK(hipMemcpyAsync(c.sort_cols.p, c.sort_stage.p, size_t(mm) * 3 * 8, hipMemcpyHostToDevice, c.stream));
+		const u64 *d_code = c.sort_cols.p, *d_umis = c.sort_cols.p + mm, *d_sizes = c.sort_cols.p + 2 * size_t(mm);
+		u64 *k = c.keys_a.p, *k_alt = c.keys_b.p;
+		u32 *v = c.vals_a.p, *v_alt = c.vals_b.p;
+		hipLaunchKernelGGL(iota_kernel, dim3(div_up(mm, 256)), dim3(256), 0, c.stream, v, mm);
+		HIP_CHECK(hipMemcpyAsync(k, d_code, size_t(mm) * 8, hipMemcpyDeviceToDevice, c.stream));
+		c.radix_sort(k, v, k_alt, v_alt, mm, o[0] ^ a[0]);
+		const std::pair<const u64 *, u64> more[2] = {{d_umis, o[1] ^ a[1]}, {d_sizes, o[2] ^ a[2]}};
+		for (auto const &nx : more) {
+			hipLaunchKernelGGL(gather_u64_kernel, dim3(div_up(mm, 256)), dim3(256), 0, c.stream, nx.first, v, mm, k);
+			HIP_CHECK(hipGetLastError());
+			c.radix_sort(k, v, k_alt, v_alt, mm, nx.second);
+		}
+		u32 *perm = reinterpret_cast<u32 *>(c.sort_stage.p);
+		HIP_CHECK(hipMemcpyAsync(perm, v, size_t(mm) * 4, hipMemcpyDeviceToHost, c.stream));
+		HIP_CHECK(hipStreamSynchronize(c.stream));
+		for (u32 kk = 0; kk < mm; ++kk) out[kk] = sel[perm[kk]];
+		return out;
+	}
+	auto less = [&](u32 x, u32 y) {
+		const GRow &p = G[x], &q = G[y];
+		if (p.req_genes != q.req_genes) return p.req_genes < q.req_genes;
+		if (p.req_umis != q.req_umis) return p.req_umis < q.req_umis;
+		const u64 pu = u64(size_t(p.total_umis)), qu = u64(size_t(q.total_umis));   // Cell::umis_number casts the int stat to size_t
+		if (pu != qu) return pu < qu;
+		const bool plain = !((p.barcode | q.barcode) & ESCAPE_BIT) && bit_length(p.barcode) == bit_length(q.barcode);
+		if (plain) return p.barcode < q.barcode;
+		return decode_code(p.barcode, c.side) < decode_code(q.barcode, c.side);   // barcodes of several lengths: string order
+	};
+	std::sort(out.begin(), out.end(), less);
+	return out;
+}
+
+// 5. RealBarcodes CB merge over all shards (MergeStrategyBase::merge_inited, MergeStrategyBase.cpp:11-57); phases in
+// merge_shard.h.  Every shard ends with the same global picture and applies the part that concerns its cells.
+void dropest_shard::cb_merge() {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	struct LRow { u64 barcode; u32 n_genes, req_genes, req_umis, local_id; int32_t total_umis, total_reads; };
+	std::vector<LRow> local, Gm;
+	for (const HostCell &h : c.real) {
+		if (h.merged || h.excluded || h.row.n_genes < c.min_before) continue;
+		if (h.row.barcode & ESCAPE_BIT) throw UnsupportedError("barcodes with N are not supported in sharded whitelist merges");
+		local.push_back(LRow{h.row.barcode, h.row.n_genes, h.row.requested_genes, h.row.requested_umis, h.id, h.row.total_umis, h.row.total_reads});
+	}
+	std::vector<size_t> cnt;
+	{ Phase ph(this, "cbm:gather_cells"); tr->gather_vec(local, Gm, cnt); }
+	const u32 nG = u32(Gm.size());
+	std::vector<size_t> goff(size_t(world) + 1, 0);
+	for (int p = 0; p < world; ++p) goff[size_t(p) + 1] = goff[size_t(p)] + cnt[size_t(p)];
+	const u32 lo = u32(goff[size_t(rank)]), hi = u32(goff[size_t(rank) + 1]);
+	// search: my real cells against everybody's
+	std::vector<uint64_t> g_bc(nG); std::vector<u32> g_ng(nG); std::vector<int32_t> g_tu(nG);
+	for (u32 i = 0; i < nG; ++i) { g_bc[i] = Gm[i].barcode; g_ng[i] = Gm[i].n_genes; g_tu[i] = Gm[i].total_umis; }
+	std::vector<u32> base_g(hi - lo), base_l(hi - lo);
+	for (u32 i = lo; i < hi; ++i) { base_g[i - lo] = i; base_l[i - lo] = Gm[i].local_id; }
+	uint64_t n_pairs = 0;
+	{ Phase ph(this, "cbm:search"); c.shard_merge_search(nG, g_bc.data(), g_ng.data(), g_tu.data(), hi - lo, base_g.data(), base_l.data(), &n_pairs); }
+	dropest_ctx::ShardMerge &M = *c.shard;
+	struct Pair { u32 base, cand; };
+	std::vector<Pair> my_pairs(static_cast<size_t>(n_pairs)), allp;
+	for (size_t p = 0; p < n_pairs; ++p) my_pairs[p] = Pair{M.base_g[M.S.pair_base[p]], M.S.pair_cand[p]};
+	struct Listed { u32 g; uint64_t b, e; };
+	std::vector<Listed> my_listed(M.listed_f.size()), all_listed;
+	for (size_t i = 0; i < M.listed_f.size(); ++i) my_listed[i] = Listed{M.base_g[M.listed_f[i]], M.row_offset[i], M.row_offset[i + 1]};
+	std::vector<size_t> pcnt, lcnt;
+	DevBuf<u64> low_all; DevBuf<u32> col_all[4];
+	std::vector<uint64_t> beg(nG, ~0ull), end(nG, ~0ull);
+	{
+		Phase ph(this, "cbm:gather_rows");
+		tr->gather_vec(my_pairs, allp, pcnt);
+		tr->gather_vec(my_listed, all_listed, lcnt);
+		uint64_t my_rows = M.row_offset.empty() ? 0 : M.row_offset.back();
+		std::vector<uint64_t> rows(static_cast<size_t>(world));
+		tr->gather_host(&my_rows, 8, rows.data());
+		std::vector<size_t> off8(static_cast<size_t>(world)), b8(static_cast<size_t>(world)), off4(static_cast<size_t>(world)), b4(static_cast<size_t>(world));
+		uint64_t total = 0;
+		std::vector<uint64_t> row_base(size_t(world) + 1, 0);
+		for (int p = 0; p < world; ++p) { row_base[size_t(p) + 1] = row_base[size_t(p)] + rows[size_t(p)]; total += rows[size_t(p)]; }
+		if (total > 0xFFFFFFF0ull) throw UnsupportedError("more than 2^32 molecule rows travel in the sharded merge");
+		for (int p = 0; p < world; ++p) { off8[size_t(p)] = size_t(row_base[size_t(p)]) * 8; b8[size_t(p)] = size_t(rows[size_t(p)]) * 8; off4[size_t(p)] = size_t(row_base[size_t(p)]) * 4; b4[size_t(p)] = size_t(rows[size_t(p)]) * 4; }
+		low_all.alloc(std::max<size_t>(total, 1));
+		for (auto &b : col_all) b.alloc(std::max<size_t>(total, 1));
+		tr->gather_dev(M.x_low.p, low_all.p, off8.data(), b8.data(), c.stream);
+		for (int k = 0; k < 4; ++k) tr->gather_dev(M.x_col[k].p, col_all[k].p, off4.data(), b4.data(), c.stream);
+		size_t at = 0;
+		for (int p = 0; p < world; ++p)
+			for (size_t i = 0; i < lcnt[size_t(p)]; ++i, ++at) { beg[all_listed[at].g] = all_listed[at].b + row_base[size_t(p)]; end[all_listed[at].g] = all_listed[at].e + row_base[size_t(p)]; }
+	}
+	// intersect: the pairs whose candidate is mine
+	std::vector<size_t> poff(size_t(world) + 1, 0);
+	for (int p = 0; p < world; ++p) poff[size_t(p) + 1] = poff[size_t(p)] + pcnt[size_t(p)];
+	struct Ans { uint64_t pair; u32 inter, pad; };
+	std::vector<Ans> my_ans, all_ans;
+	{
+		Phase ph(this, "cbm:intersect");
+		std::vector<u32> cand_local; std::vector<uint64_t> bb, be;
+		std::vector<uint64_t> which;
+		for (size_t i = 0; i < allp.size(); ++i)
+			if (allp[i].cand >= lo && allp[i].cand < hi) {
+				which.push_back(i); cand_local.push_back(Gm[allp[i].cand].local_id);
+				if (beg[allp[i].base] == ~0ull) throw InvalidError("internal: a base's molecule rows were not exported");
+				bb.push_back(beg[allp[i].base]); be.push_back(end[allp[i].base]);
+			}
+		std::vector<u32> inter(which.size());
+		c.shard_merge_intersect(which.size(), cand_local.data(), bb.data(), be.data(), reinterpret_cast<const uint64_t *>(low_all.p), inter.data());
+		my_ans.resize(which.size());
+		for (size_t i = 0; i < which.size(); ++i) my_ans[i] = Ans{which[i], inter[i], 0};
+		std::vector<size_t> acnt;
+		tr->gather_vec(my_ans, all_ans, acnt);
+	}
+	std::vector<u32> inter_all(allp.size(), 0);
+	for (const Ans &a : all_ans) inter_all[size_t(a.pair)] = a.inter;
+	// decide: targets of my bases; then the same sequential application everywhere
+	std::vector<int64_t> my_tgt(hi - lo, -1), target;
+	{
+		Phase ph(this, "cbm:decide");
+		c.shard_merge_decide(inter_all.data() + poff[size_t(rank)], my_tgt.data());
+		std::vector<size_t> tcnt;
+		tr->gather_vec(my_tgt, target, tcnt);
+	}
+	std::vector<u32> final_t(nG); std::vector<uint8_t> excl(nG);
+	std::vector<int32_t> reads(nG), umis(nG);
+	{
+		Phase ph(this, "cbm:order+apply");
+		// all real cells are "filtered" before the merge (threshold 0): ascending compare_cells order
+		G.resize(nG);
+		for (u32 i = 0; i < nG; ++i) { GRow r{}; r.barcode = Gm[i].barcode; r.req_genes = Gm[i].req_genes; r.req_umis = Gm[i].req_umis; r.total_umis = Gm[i].total_umis; G[i] = r; }
+		std::vector<u32> sel(nG);
+		for (u32 i = 0; i < nG; ++i) sel[i] = i;
+		const std::vector<u32> order = order_rows(sel, false);
+		std::vector<int64_t> tgt_in_order(nG);
+		for (u32 i = 0; i < nG; ++i) { tgt_in_order[i] = target[order[i]]; reads[i] = Gm[i].total_reads; umis[i] = Gm[i].total_umis; }
+		apply_merge_order(nG, nG, order.data(), tgt_in_order.data(), reads.data(), umis.data(), final_t.data(), excl.data());
+	}
+	Phase ph(this, "cbm:finish");
+	std::vector<u32> local_id, move_src, move_tgt, import_row, import_cell;
+	std::vector<uint8_t> l_excl, l_merged; std::vector<int32_t> l_reads, l_umis;
+	merged_barcodes.clear();
+	for (u32 i = 0; i < nG; ++i) {
+		const bool mine = i >= lo && i < hi;
+		if (mine) { local_id.push_back(Gm[i].local_id); l_excl.push_back(excl[i]); l_merged.push_back(final_t[i] != i); l_reads.push_back(reads[i]); l_umis.push_back(umis[i]); }
+		if (final_t[i] == i) continue;
+		merged_barcodes.emplace_back(Gm[i].barcode, Gm[final_t[i]].barcode);
+		const u32 t = final_t[i];
+		if (!(t >= lo && t < hi)) continue;
+		if (mine) { move_src.push_back(Gm[i].local_id); move_tgt.push_back(Gm[t].local_id); continue; }
+		if (beg[i] == ~0ull) throw InvalidError("internal: a merged cell's molecule rows were not exported");
+		for (uint64_t r = beg[i]; r < end[i]; ++r) { import_row.push_back(u32(r)); import_cell.push_back(Gm[t].local_id); }
+	}
+	std::sort(merged_barcodes.begin(), merged_barcodes.end());
+	const u32 ni = u32(import_row.size());
+	DevBuf<u32> d_row, d_cell, d_col[4]; DevBuf<u64> d_low;
+	d_row.alloc(std::max<u32>(ni, 1)); d_cell.alloc(std::max<u32>(ni, 1)); d_low.alloc(std::max<u32>(ni, 1));
+	for (auto &b : d_col) b.alloc(std::max<u32>(ni, 1));
+	if (ni) {
+		HIP_CHECK(hipMemcpyAsync(d_row.p, import_row.data(), size_t(ni) * 4, hipMemcpyHostToDevice, c.stream));
+		HIP_CHECK(hipMemcpyAsync(d_cell.p, import_cell.data(), size_t(ni) * 4, hipMemcpyHostToDevice, c.stream));
+		ImportGatherArgs a{};
+		a.row = d_row.p; a.n = ni; a.low_all = low_all.p; a.o_low = d_low.p;
+		for (int k = 0; k < 4; ++k) { a.col_all[k] = col_all[k].p; a.o_col[k] = d_col[k].p; }
+		hipLaunchKernelGGL(import_gather_kernel, dim3(div_up(ni, 256)), dim3(256), 0, c.stream, a);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipStreamSynchronize(c.stream));
+	}
+	const u32 *cols[4] = {d_col[0].p, d_col[1].p, d_col[2].p, d_col[3].p};
+	c.shard_merge_finish(local_id.size(), local_id.data(), l_excl.data(), l_merged.data(), l_reads.data(), l_umis.data(), move_src.size(),
+	                     move_src.data(), move_tgt.data(), ni, d_cell.p, reinterpret_cast<const uint64_t *>(d_low.p), cols);
+}
+
+// 7. global view of the real cells: every shard's rows, all-gathered; first_global = the stream ordinal of the cell's first read
+void dropest_shard::build_global_table() {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	Phase ph(this, "cells_allgather");
+	std::vector<GRow> mine;
+	std::vector<u32> pos;
+	for (const HostCell &h : c.real) {
+		if (h.merged || h.excluded || h.row.n_genes < c.min_before) continue;
+		GRow r{};
+		r.barcode = h.row.barcode; r.n_genes = h.row.n_genes; r.req_genes = h.row.requested_genes; r.req_umis = h.row.requested_umis;
+		r.local_id = h.id; r.total_umis = h.row.total_umis; r.total_reads = h.row.total_reads; r.rank = u32(rank);
+		mine.push_back(r); pos.push_back(h.row.first_read);
+	}
+	const std::vector<u64> ord = global_ordinals(pos);
+	for (size_t i = 0; i < mine.size(); ++i) mine[i].first_global = ord[i];
+	std::vector<size_t> cnt;
+	tr->gather_vec(mine, G, cnt);
+}
+
+// 8. one matrix: global column order (identical on every shard), this shard's columns emitted on the device and written to
+// their places in the node-shared host buffer
+void dropest_shard::assemble_matrix(bool filtered_m) {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	const int slot = filtered_m ? 0 : 1;
+	Mat &M = mat[slot];
+	std::vector<u32> sel;
+	for (u32 i = 0; i < G.size(); ++i) if (!filtered_m || G[i].req_genes >= c.min_after) sel.push_back(i);
+	std::vector<u32> order;
+	{
+		Phase ph(this, filtered_m ? "order:cm" : "order:cm_raw");
+		order = order_rows(sel, !filtered_m);
+		if (filtered_m && c.cfg.max_cells > 0 && size_t(c.cfg.max_cells) < order.size())   // -C: the largest max_cells cells (CellsDataContainer.cpp:269-273)
+			order.erase(order.begin(), order.end() - c.cfg.max_cells);
+	}
+	Phase ph(this, filtered_m ? "matrix:cm" : "matrix:cm_raw");
+	const size_t ncols = order.size();
+	M.ncols = ncols; M.colptr.assign(ncols + 1, 0); M.col_barcode.resize(ncols);
+	std::vector<u32> col_cell, col_start;
+	std::vector<u64> desc;
+	uint64_t local_nnz = 0;
+	for (size_t j = 0; j < ncols; ++j) {
+		const GRow &r = G[order[j]];
+		const u32 len = filtered_m ? r.req_genes : r.n_genes;
+		M.col_barcode[j] = r.barcode;
+		M.colptr[j + 1] = M.colptr[j] + len;
+		if (int(r.rank) != rank) continue;
+		col_cell.push_back(r.local_id); col_start.push_back(u32(local_nnz));
+		desc.push_back(local_nnz); desc.push_back(M.colptr[j]); desc.push_back(len);
+		local_nnz += len;
+	}
+	M.nnz = M.colptr[ncols];
+	if (M.nnz > 0xFFFFFFF0ull || local_nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
+	void *d_shared = nullptr;
+	char *host = static_cast<char *>(tr->shared_host(slot, std::max<size_t>(size_t(M.nnz), 1) * 8, &d_shared));
+	M.rows = reinterpret_cast<const u32 *>(host); M.vals = reinterpret_cast<const u32 *>(host) + M.nnz;
+	if (!col_cell.empty() && local_nnz) {
+		const u32 nc = u32(col_cell.size());
+		c.emit_columns_device(filtered_m, false, col_cell, col_start, local_nnz);
+		d_desc.ensure(desc.size()); h_desc.ensure(desc.size());
+		std::memcpy(h_desc.p, desc.data(), desc.size() * 8);
+		HIP_CHECK(hipMemcpyAsync(d_desc.p, h_desc.p, desc.size() * 8, hipMemcpyHostToDevice, c.stream));
+		const dropest_ctx::MatrixResult &R = c.mat[slot];
+		hipLaunchKernelGGL(place_columns_kernel, dim3(nc), dim3(256), 0, c.stream, d_desc.p, R.d_row.p, R.d_val.p,
+		                   static_cast<u32 *>(d_shared), static_cast<u32 *>(d_shared) + M.nnz);
+		HIP_CHECK(hipGetLastError());
+	}
+}
+
+void dropest_shard::step() {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	HIP_CHECK(hipSetDevice(c.cfg.device));
+	Phase whole(this, "step");
+	// the ordinal ranges of all shards (ordinals name reads across shards: first-seen order, N-UMI tie breaks)
+	first_ord.assign(size_t(world), 0);
+	{ uint64_t f = first_ordinal; tr->gather_host(&f, 8, first_ord.data()); }
+	// forget the previous pass
+	c.free_results(); c.chunks.clear(); c.n_reads = 0;
+	c.d_cb = c.d_umi = nullptr; c.d_gene = c.d_aux = nullptr;
+	exchanged = false;
+	ReadChunk ch;
+	if (world > 1 || force_exchange) {
+		partition_and_exchange();
+		ch.p_cb = x_cb.p; ch.p_umi = x_umi.p; ch.p_gene = x_gene.p; ch.p_aux = x_aux.p; ch.n = recv_off[size_t(world)];
+	} else {   // one shard: every read is at home already
+		ch.p_cb = r_cb; ch.p_umi = r_umi; ch.p_gene = r_gene; ch.p_aux = r_aux; ch.n = n_res;
+	}
+	if (ch.n) { c.n_reads = ch.n; c.chunks.push_back(std::move(ch)); }
+	{ Phase ph(this, "ingest"); c.run_ingest(); if (world > 1) agree_on_key_fields(); }
+	install_umi_hooks();
+	{ Phase ph(this, "pipeline"); c.run_set_initialized(); }
+	merged_barcodes.clear();
+	if (c.cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && world > 1) { Phase ph(this, "cb_merge"); cb_merge(); }
+	else if (c.cfg.merge_kind != DROPEST_MERGE_NONE && world > 1)
+		throw UnsupportedError("sharded runs support -m with a barcode whitelist (RealBarcodes) only; run the other merge strategies on one GPU");
+	if (c.cfg.umi_merge_kind == DROPEST_UMI_MERGE_DIRECTIONAL && world > 1) throw UnsupportedError("-u is not supported in sharded runs");
+	if (c.have_qual && world > 1) throw UnsupportedError("UMI qualities are not supported in sharded runs");
+	{ Phase ph(this, "finalize"); c.run_merge_and_filter(); }
+	if (world == 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE) {
+		std::vector<u64> bc(c.n_cells);
+		if (c.n_cells) c.fetch(bc.data(), c.cell_cb.p, size_t(c.n_cells) * 8);
+		for (auto const &pr : c.merge_pairs) merged_barcodes.emplace_back(bc[size_t(pr.first)], bc[size_t(pr.second)]);
+		std::sort(merged_barcodes.begin(), merged_barcodes.end());
+	}
+	build_global_table();
+	assemble_matrix(true);
+	assemble_matrix(false);
+	{ Phase ph(this, "matrix:wait"); HIP_CHECK(hipStreamSynchronize(c.stream)); tr->barrier(); }
+	c.collect_timings();
+}
+
+// N-UMI merge across shards (umi_merge_host.h): global first occurrences of the tie candidates, offsets into the ONE rand()
+// sequence the reference draws the random fills from
+void dropest_shard::install_umi_hooks() {
+	using namespace dropest;
+	if (world == 1) { ctx->hooks.reset(); return; }
+	auto h = std::make_shared<dropest_ctx::ShardHooks>();
+	h->first_seen_global = [this](const std::vector<u64> &codes) {
+		Phase ph(this, "umi:first_seen");
+		std::vector<u64> all;
+		std::vector<size_t> cnt;
+		tr->gather_vec(codes, all, cnt);
+		std::sort(all.begin(), all.end());
+		all.erase(std::unique(all.begin(), all.end()), all.end());
+		const std::vector<u32> pos = ctx->umi_first_positions(all);
+		std::vector<u64> ord = global_ordinals(pos);
+		std::vector<u64> every(std::max<size_t>(all.size(), 1) * size_t(world), ~0ull);
+		ord.resize(std::max<size_t>(all.size(), 1), ~0ull);
+		tr->gather_host(ord.data(), ord.size() * 8, every.data());
+		for (size_t i = 0; i < all.size(); ++i)
+			for (int p = 0; p < world; ++p) ord[i] = std::min(ord[i], every[size_t(p) * ord.size() + i]);
+		std::vector<u64> out(codes.size());
+		for (size_t i = 0; i < codes.size(); ++i) out[i] = ord[size_t(std::lower_bound(all.begin(), all.end(), codes[i]) - all.begin())];
+		return out;
+	};
+	h->rng_offsets = [this](const std::vector<u32> &cell_first, const std::vector<u32> &gene, const std::vector<u32> &draws) {
+		Phase ph(this, "umi:rng_offsets");
+		struct Key { u64 first_global; u32 gene, draws, rank, idx; };
+		const std::vector<u64> ord = global_ordinals(cell_first);
+		std::vector<Key> mine, all;
+		for (size_t g = 0; g < draws.size(); ++g) if (draws[g]) mine.push_back(Key{ord[g], gene[g], draws[g], u32(rank), u32(g)});
+		std::vector<size_t> cnt;
+		tr->gather_vec(mine, all, cnt);
+		std::sort(all.begin(), all.end(), [](const Key &a, const Key &b) { return a.first_global != b.first_global ? a.first_global < b.first_global : a.gene < b.gene; });
+		std::vector<u64> out(draws.size(), 0);
+		u64 at = 0;
+		for (const Key &k : all) { if (int(k.rank) == rank) out[k.idx] = at; at += k.draws; }
+		// groups without draws: wherever the sequence stands when they are reached (skip_to never goes back)
+		return out;
+	};
+	ctx->hooks = h;
+}
+
+// ---- C-ABI of the sharded runner (include/dropest_amd.h) ---------------------------------------------------------------
+static dropest_shard *make_shard(const dropest_cfg *cfg, int rank, int world) {
+	std::unique_ptr<dropest_shard> s(new dropest_shard());
+	s->ctx.reset(new dropest_ctx());
+	s->ctx->init_from_cfg(*cfg);
+	s->rank = rank; s->world = world;
+	if (const char *e = getenv("DROPEST_SHARD_TRACE")) s->trace = atoi(e) != 0;
+	if (const char *e = getenv("DROPEST_SHARD_FORCE_EXCHANGE")) s->force_exchange = atoi(e) != 0;
+	return s.release();
+}
+
+extern "C" {
+
+dropest_status dropest_shard_unique_id(uint8_t id[128]) {
+	return guarded([&] {
+		if (!id) throw InvalidError("null argument");
+		const dropest::RcclApi &api = dropest::RcclApi::get();
+		ncclUniqueId u;
+		api.check(api.GetUniqueId(&u), "ncclGetUniqueId");
+		std::memcpy(id, &u, 128);
+	});
+}
+
+dropest_status dropest_shard_create(const dropest_cfg *cfg, int32_t rank, int32_t world, const uint8_t id[128], dropest_shard **out) {
+	if (!cfg || !out) { g_last_error = "null argument"; return DROPEST_ERR_INVALID; }
+	*out = nullptr;
+	return guarded([&] {
+		if (world < 1 || world > 64 || rank < 0 || rank >= world) throw InvalidError("rank / world out of range (1..64 shards)");
+		if (!id) throw InvalidError("the RCCL unique id of the run is needed (dropest_shard_unique_id on rank 0, distributed by the launcher)");
+		std::unique_ptr<dropest_shard> s(make_shard(cfg, rank, world));
+		s->tr.reset(new dropest::RcclTransport(rank, world, id, s->ctx->stream));
+		*out = s.release();
+	});
+}
+
+dropest_status dropest_shard_group_create(const dropest_cfg *cfg, int32_t n, const int32_t *devices, dropest_shard **out) {
+	if (!cfg || !out || !devices) { g_last_error = "null argument"; return DROPEST_ERR_INVALID; }
+	return guarded([&] {
+		if (n < 1 || n > 64) throw InvalidError("1..64 shards");
+		auto hub = std::make_shared<dropest::LocalHub>(n);
+		std::vector<std::unique_ptr<dropest_shard>> made;
+		for (int i = 0; i < n; ++i) {
+			dropest_cfg c = *cfg;
+			c.device = devices[i];
+			made.emplace_back(make_shard(&c, i, n));
+			made.back()->tr.reset(new dropest::LocalTransport(hub, i));
+		}
+		// shards on different devices copy to each other directly (xGMI peer access)
+		for (int i = 0; i < n; ++i)
+			for (int j = 0; j < n; ++j)
+				if (devices[i] != devices[j]) {
+					int can = 0;
+					HIP_CHECK(hipDeviceCanAccessPeer(&can, devices[i], devices[j]));
+					if (!can) continue;
+					HIP_CHECK(hipSetDevice(devices[i]));
+					const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+					if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_CHECK(e);
+					(void)hipGetLastError();
+				}
+		for (int i = 0; i < n; ++i) out[i] = made[size_t(i)].release();
+	});
+}
+
+void dropest_shard_destroy(dropest_shard *s) {
+	if (!s) return;
+	(void)hipSetDevice(s->ctx->cfg.device);
+	delete s;
+}
+
+dropest_ctx *dropest_shard_ctx(dropest_shard *s) { return s ? s->ctx.get() : nullptr; }
+
+dropest_status dropest_shard_set_reads_device(dropest_shard *s, const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene,
+                                              const uint32_t *d_aux, uint64_t n, uint64_t first_ordinal) {
+	return guarded([&] {
+		if (!s) throw InvalidError("null shard");
+		if (n && (!d_cb || !d_umi || !d_gene || !d_aux)) throw InvalidError("null read array");
+		if (n >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads per shard");
+		s->r_cb = reinterpret_cast<const dropest::u64 *>(d_cb); s->r_umi = reinterpret_cast<const dropest::u64 *>(d_umi);
+		s->r_gene = d_gene; s->r_aux = d_aux; s->n_res = n; s->first_ordinal = first_ordinal;
+	});
+}
+
+dropest_status dropest_shard_step(dropest_shard *s) {
+	return guarded([&] {
+		if (!s) throw InvalidError("null shard");
+		try { s->step(); }
+		catch (...) {   // the other members of an in-process group must not wait for this one forever
+			if (auto *lt = dynamic_cast<dropest::LocalTransport *>(s->tr.get())) lt->hub->fail();
+			throw;
+		}
+	});
+}
+
+dropest_status dropest_shard_group_step(dropest_shard *const *shards, int32_t n) {
+	return guarded([&] {
+		if (!shards || n < 1) throw InvalidError("null argument");
+		std::vector<dropest_status> rc(size_t(n), DROPEST_OK);
+		std::vector<std::string> msg(static_cast<size_t>(n));
+		std::vector<std::thread> pool;
+		for (int i = 0; i < n; ++i)
+			pool.emplace_back([&, i] { rc[size_t(i)] = dropest_shard_step(shards[i]); if (rc[size_t(i)] != DROPEST_OK) msg[size_t(i)] = dropest_last_error(); });
+		for (auto &t : pool) t.join();
+		for (int i = 0; i < n; ++i)
+			if (rc[size_t(i)] != DROPEST_OK && msg[size_t(i)].find("another shard of the group failed") == std::string::npos)
+				throw InvalidError("shard " + std::to_string(i) + ": " + msg[size_t(i)]);
+		for (int i = 0; i < n; ++i) if (rc[size_t(i)] != DROPEST_OK) throw InvalidError("shard " + std::to_string(i) + ": " + msg[size_t(i)]);
+	});
+}
+
+dropest_status dropest_shard_matrix(dropest_shard *s, int filtered, uint64_t *ncols, uint64_t *nnz, const uint64_t **colptr,
+                                    const uint32_t **rowidx, const uint32_t **values, const uint64_t **col_barcodes) {
+	return guarded([&] {
+		if (!s || !ncols || !nnz) throw InvalidError("null argument");
+		const dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
+		*ncols = M.ncols; *nnz = M.nnz;
+		if (colptr) *colptr = reinterpret_cast<const uint64_t *>(M.colptr.data());
+		if (rowidx) *rowidx = M.rows;
+		if (values) *values = M.vals;
+		if (col_barcodes) *col_barcodes = reinterpret_cast<const uint64_t *>(M.col_barcode.data());
+	});
+}
+
+dropest_status dropest_shard_merged_barcodes(dropest_shard *s, uint64_t *n, uint64_t *source, uint64_t *target) {
+	return guarded([&] {
+		if (!s || !n) throw InvalidError("null argument");
+		*n = s->merged_barcodes.size();
+		if (source && target) for (size_t i = 0; i < s->merged_barcodes.size(); ++i) { source[i] = s->merged_barcodes[i].first; target[i] = s->merged_barcodes[i].second; }
+	});
+}
+
+dropest_status dropest_shard_phase_stats(dropest_shard *s, uint32_t *n, dropest_kernel_stat *out) {
+	return guarded([&] {
+		if (!s || !n) throw InvalidError("null argument");
+		uint32_t i = 0;
+		for (auto &kv : s->phases) {
+			if (out) { out[i].name = kv.first.c_str(); out[i].launches = kv.second.launches; out[i].ms = kv.second.ms; out[i].bytes = kv.second.bytes; }
+			++i;
+		}
+		*n = i;
+	});
+}
+
+dropest_status dropest_shard_set_option(dropest_shard *s, const char *key, int64_t value) {
+	return guarded([&] {
+		if (!s || !key) throw InvalidError("null argument");
+		const std::string k(key);
+		if (k == "trace") s->trace = value != 0;
+		else if (k == "force_exchange") s->force_exchange = value != 0;
+		else if (k == "reset_phase_stats") s->phases.clear();
+		else throw InvalidError("unknown shard option: " + k);
+	});
+}
+
+}  // extern "C"

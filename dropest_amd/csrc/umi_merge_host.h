@@ -170,9 +170,29 @@ void dropest_ctx::umi_patch_groups(const std::vector<u32> &p_idx, const std::vec
 	for (auto &kv : umis_removed) real[real_at(kv.first)].row.total_umis -= kv.second;
 }
 
+// position (in the resident reads) of the first gene-bearing read of each UMI code of a sorted list, 0xFFFFFFFF if none
+std::vector<dropest::u32> dropest_ctx::umi_first_positions(const std::vector<u64> &sorted_codes) {
+	const u32 nq = u32(sorted_codes.size());
+	std::vector<u32> f(nq, 0xFFFFFFFFu);
+	if (!nq || !n_reads) return f;
+	DevBuf<u64> d_q; DevBuf<u32> d_first;
+	d_q.alloc(nq); d_first.alloc(nq);
+	HIP_CHECK(hipMemcpyAsync(d_q.p, sorted_codes.data(), size_t(nq) * 8, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemsetAsync(d_first.p, 0xFF, size_t(nq) * 4, stream));
+	const u32 n = u32(n_reads);
+	timed("umi_first_seen", double(n) * 12, [&] {
+		hipLaunchKernelGGL(umi_first_seen_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n,
+		                   d_q.p, nq, d_first.p);
+	});
+	HIP_CHECK(hipMemcpyAsync(f.data(), d_first.p, size_t(nq) * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	return f;
+}
+
 void dropest_ctx::run_umi_merge_simple() {
 	umi_overrides.clear();
-	if (ingest.umi_escape_max_plus1 == 0 || n_cg == 0) return;   // no escaped UMI anywhere: nothing can contain an N
+	if (ingest.umi_escape_max_plus1 == 0) return;   // no escaped UMI anywhere (on any shard): nothing can contain an N
+	if (n_cg == 0 && !hooks) return;
 
 	// 1. affected (cell, gene) groups of the cells that are real NOW (after the CB merge)
 	std::vector<u32> flags(n_cells, 0);
@@ -184,16 +204,16 @@ void dropest_ctx::run_umi_merge_simple() {
 	scalars.ensure(16);
 	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4, stream));
 	const u64 umask = layout.umi_bits ? ((1ull << layout.umi_bits) - 1ull) : 0ull;
-	timed("flag_n_groups", double(n_cg) * 24, [&] {
+	if (n_cg) timed("flag_n_groups", double(n_cg) * 24, [&] {
 		hipLaunchKernelGGL(flag_n_groups_kernel, dim3(div_up(n_cg, 256)), dim3(256), 0, stream, cg_key.p, cg_mol_begin.p, mol_key.p,
 		                   n_cg, remap.p, layout.gene_bits, layout.gene_none, umask, layout.umi_escape_base, d_list.p, scalars.p);
 	});
 	u32 n_groups = 0;
 	HIP_CHECK(hipMemcpyAsync(&n_groups, scalars.p, 4, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
-	if (n_groups == 0) return;
+	if (n_groups == 0 && !hooks) return;
 	std::vector<u32> groups(n_groups);
-	HIP_CHECK(hipMemcpy(groups.data(), d_list.p, size_t(n_groups) * 4, hipMemcpyDeviceToHost));
+	if (n_groups) HIP_CHECK(hipMemcpy(groups.data(), d_list.p, size_t(n_groups) * 4, hipMemcpyDeviceToHost));
 	std::sort(groups.begin(), groups.end());   // (cell id, gene id) ascending == the reference's iteration order
 
 	// 2. their molecules
@@ -236,38 +256,60 @@ void dropest_ctx::run_umi_merge_simple() {
 			if (best.size() > 1 && min_ed <= u32(cfg.max_umi_merge_edit_distance))
 				for (size_t i : best) tie_codes.push_back(G[g][i].code);
 		}
-	std::unordered_map<u64, u32> first_seen;
-	if (!tie_codes.empty()) {
+	// (one container: positions in the resident reads order like stream ordinals; sharded runs: the smallest GLOBAL ordinal
+	// over all shards -- a UMI's first occurrence may sit on any of them)
+	std::unordered_map<u64, u64> first_seen;
+	if (!tie_codes.empty() || hooks) {
 		std::sort(tie_codes.begin(), tie_codes.end());
 		tie_codes.erase(std::unique(tie_codes.begin(), tie_codes.end()), tie_codes.end());
-		const u32 nq = u32(tie_codes.size());
-		DevBuf<u64> d_q; DevBuf<u32> d_first;
-		d_q.alloc(nq); d_first.alloc(nq);
-		HIP_CHECK(hipMemcpyAsync(d_q.p, tie_codes.data(), size_t(nq) * 8, hipMemcpyHostToDevice, stream));
-		HIP_CHECK(hipMemsetAsync(d_first.p, 0xFF, size_t(nq) * 4, stream));
-		const u32 n = u32(n_reads);
-		timed("umi_first_seen", double(n) * 12, [&] {
-			hipLaunchKernelGGL(umi_first_seen_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n,
-			                   d_q.p, nq, d_first.p);
-		});
-		std::vector<u32> f(nq);
-		HIP_CHECK(hipMemcpyAsync(f.data(), d_first.p, size_t(nq) * 4, hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipStreamSynchronize(stream));
-		for (u32 i = 0; i < nq; ++i) first_seen[tie_codes[i]] = f[i];
+		if (hooks) {
+			const std::vector<u64> f = hooks->first_seen_global(tie_codes);
+			for (size_t i = 0; i < tie_codes.size(); ++i) first_seen[tie_codes[i]] = f[i];
+		} else {
+			const std::vector<u32> f = umi_first_positions(tie_codes);
+			for (size_t i = 0; i < tie_codes.size(); ++i) first_seen[tie_codes[i]] = f[i];
+		}
 	}
 
 	// 4. the reference's per-group decision and re-keying (MergeUMIsStrategySimple::merge / find_targets)
 	std::vector<u32> p_idx, p_all, p_req, p_rreq;
 	std::unordered_map<u32, int> umis_removed;   // per cell: TOTAL_UMIS decrements (Cell::merge_umis, Cell.cpp:31-42)
+	// the bad UMIs of every group, in the container the reference iterates: they enter the unordered_set in UMI-index order
+	// = first-seen order = ascending escape id
+	std::vector<std::unordered_set<std::string>> bad_of(n_groups);
+	std::vector<std::unordered_map<std::string, size_t>> mol_of_g(n_groups);
 	for (u32 g = 0; g < n_groups; ++g) {
 		std::vector<Mol> &mols = G[g];
-		// bad UMIs enter the unordered_set in UMI-index order = first-seen order = ascending escape id
 		std::vector<size_t> bad_idx;
 		for (size_t i = 0; i < mols.size(); ++i) if (mols[i].bad) bad_idx.push_back(i);
 		std::sort(bad_idx.begin(), bad_idx.end(), [&](size_t x, size_t y) { return (mols[x].code & ~ESCAPE_BIT) < (mols[y].code & ~ESCAPE_BIT); });
-		std::unordered_set<std::string> bad;
-		std::unordered_map<std::string, size_t> mol_of;
-		for (size_t i : bad_idx) { bad.insert(mols[i].seq); mol_of[mols[i].seq] = i; }
+		for (size_t i : bad_idx) { bad_of[g].insert(mols[i].seq); mol_of_g[g][mols[i].seq] = i; }
+	}
+	// Sharded runs: the reference draws every random fill from ONE rand() sequence, walking the cells in cell-id order and
+	// the genes in gene-index order (MergeUMIsStrategySimple.cpp:25-53).  Which UMIs fall to a random fill, and with how
+	// many draws, is decided by the group alone; the shards exchange (first ordinal of the cell, gene, draws) and every
+	// group starts at its offset in the one sequence.
+	std::vector<u64> rng_offset;
+	if (hooks) {
+		std::vector<u32> cell_first(n_groups), gene_of(n_groups), draws(n_groups, 0);
+		for (u32 g = 0; g < n_groups; ++g) {
+			const u64 cgk = hk[off[g]] >> layout.umi_bits;
+			const u32 cell = u32(cgk >> layout.gene_bits);
+			cell_first[g] = real[real_at(cell)].row.first_read; gene_of[g] = u32(cgk & layout.gene_none);
+			for (const std::string &b : bad_of[g]) {
+				unsigned min_ed; u32 br; std::vector<size_t> best;
+				candidates_of(G[g], G[g][mol_of_g[g].at(b)], min_ed, br, best);
+				if (best.empty() || min_ed > u32(cfg.max_umi_merge_edit_distance)) draws[g] += u32(std::count(b.begin(), b.end(), 'N'));
+			}
+		}
+		rng_offset = hooks->rng_offsets(cell_first, gene_of, draws);
+	}
+	if (n_groups == 0) return;   // (a shard without such groups still took part in the two exchanges above)
+	for (u32 g = 0; g < n_groups; ++g) {
+		std::vector<Mol> &mols = G[g];
+		const std::unordered_set<std::string> &bad = bad_of[g];
+		const std::unordered_map<std::string, size_t> &mol_of = mol_of_g[g];
+		if (hooks) rng.skip_to(rng_offset[g]);
 		std::unordered_map<std::string, std::string> targets;
 		for (const std::string &b : bad) {
 			const Mol &bm = mols[mol_of.at(b)];

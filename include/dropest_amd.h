@@ -374,6 +374,44 @@ dropest_status dropest_set_profiling_filter(dropest_ctx *ctx, const char *name_p
 /* The HIP stream all kernels of this context are launched on (hipStream_t). */
 void *dropest_stream(dropest_ctx *ctx);
 
+/* ---- the sharded runner: one dropest_shard = one shard = one context on one GPU (csrc/shard_run.h) -----------------
+ * The reference has one CellsDataContainer fed by one thread (CellsDataContainer.h:33-123, dropest.cpp:245-252).  Here the
+ * stream is cut into contiguous ordinal ranges, one per shard; a pass re-distributes the reads by owner(cb) =
+ * dropest_owner_of(cb, world) with ONE all-to-all(v) over RCCL / xGMI, runs the single-GPU pipeline on every shard, merges
+ * barcodes across shards (-m with a whitelist), resolves N-UMIs against the one global rand() sequence, and lets every
+ * shard write ITS columns of the two count matrices into host memory shared by the node's shards.  Results equal ONE
+ * container over the whole stream.
+ *   dropest_shard_create        one process per GPU: `id` = the 128 bytes of dropest_shard_unique_id (called on rank 0,
+ *                               distributed by the launcher -- torch.distributed, MPI, a file); builds the RCCL communicator
+ *   dropest_shard_group_create  all shards in THIS process (the C++ facade owning N GPUs; several shards may share a device):
+ *                               device-to-device / xGMI peer copies and a host barrier; drive each member from its own
+ *                               host thread (dropest_shard_step) or all of them with dropest_shard_group_step
+ *   dropest_shard_step          collective: every shard of the run calls it once per pass
+ *   dropest_shard_matrix        (shard 0) the GLOBAL matrix in CSC form: colptr[ncols + 1], rowidx / values in the shared host
+ *                               buffer, col_barcodes[ncols] = packed barcode of every column; valid until the next step
+ * Not in sharded runs: -u, -M, -m without a whitelist, UMI qualities, barcodes with N in a whitelist merge (single GPU). */
+typedef struct dropest_shard dropest_shard;
+dropest_status dropest_shard_unique_id(uint8_t id[128]);
+dropest_status dropest_shard_create(const dropest_cfg *cfg, int32_t rank, int32_t world, const uint8_t id[128], dropest_shard **out);
+dropest_status dropest_shard_group_create(const dropest_cfg *cfg, int32_t n, const int32_t *devices, dropest_shard **out /* [n] */);
+void dropest_shard_destroy(dropest_shard *shard);
+dropest_ctx *dropest_shard_ctx(dropest_shard *shard);   /* the shard's context: accessors, kernel statistics */
+/* this shard's contiguous range of the stream, resident in ITS GPU's HBM (used in place: keep it alive); first_ordinal =
+ * stream ordinal of its first read (ordinals define first-seen cell ids and N-UMI tie breaks across shards) */
+dropest_status dropest_shard_set_reads_device(dropest_shard *shard, const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene,
+                                              const uint32_t *d_aux, uint64_t n, uint64_t first_ordinal);
+dropest_status dropest_shard_step(dropest_shard *shard);
+dropest_status dropest_shard_group_step(dropest_shard *const *shards, int32_t n);   /* one host thread per shard */
+dropest_status dropest_shard_matrix(dropest_shard *shard, int filtered, uint64_t *ncols, uint64_t *nnz, const uint64_t **colptr,
+                                    const uint32_t **rowidx, const uint32_t **values, const uint64_t **col_barcodes);
+/* (source, target) barcodes of the cells the CB merge folded, ascending source: CellsDataContainer::merge_targets by barcode */
+dropest_status dropest_shard_merged_barcodes(dropest_shard *shard, uint64_t *n, uint64_t *source, uint64_t *target);
+/* wall time per phase of the steps so far (name, steps, ms; bytes = what this shard put on the links in "all_to_all") */
+dropest_status dropest_shard_phase_stats(dropest_shard *shard, uint32_t *n, dropest_kernel_stat *out);
+/* "trace" (synchronise the device at every phase boundary: diagnostic), "force_exchange" (partition + all-to-all even with
+ * one shard: measures what a second shard would add), "reset_phase_stats" */
+dropest_status dropest_shard_set_option(dropest_shard *shard, const char *key, int64_t value);
+
 #ifdef __cplusplus
 }
 #endif

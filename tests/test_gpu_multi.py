@@ -1,17 +1,17 @@
-"""Two ranks of the sharded run with the REAL engine (HIP path) on one GPU: the collectives hop through host memory
-over gloo (two ranks cannot share a device under RCCL), everything else is the production code path.  The assembled
-matrices must equal a single-context run over the whole stream."""
+"""The sharded runner (csrc/shard_run.h through dropest_shard_*): two / three shards -- all on ONE GPU, which an in-process
+group allows -- must assemble exactly what a single context computes over the whole stream: both matrices, their column
+barcodes, the merged barcodes.  Whitelist merges whose targets live on other shards, N-UMIs (one global rand() sequence,
+global first occurrences), barcodes of several lengths, -C; and one shard over RCCL (a world of one process)."""
 import os
-import socket
 
 import numpy as np
 import pytest
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from dropest_amd import capi
-from dropest_amd.multi import ShardedRun
-from dropest_amd.synth import SynthStream
+from dropest_amd.multi import ShardGroup, ShardedRun, cfg_kwargs
+from dropest_amd.synth import SynthStream, inject_n
+
+import parity
 
 pytestmark = pytest.mark.gpu
 
@@ -19,8 +19,6 @@ pytestmark = pytest.mark.gpu
 SCALE = int(os.environ.get("DROPEST_MULTI_SCALE", "1"))
 CFG = {"min_before": 10, "min_after": 30}
 STREAM = dict(n_reads=400_000 * SCALE, n_cells=60 * SCALE, n_genes=3000)
-
-
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropest_amd", "data", "barcodes")
 MERGE_CASES = {
     # name: (stream parameters, whitelist file, barcodes kind, thresholds)
@@ -31,86 +29,146 @@ MERGE_CASES = {
 }
 
 
-def _worker(rank, world, port, path, case=None, output="shm"):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    os.environ["DROPEST_SHARD_OUTPUT"] = output
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        if case is None:
-            kw, cfg = STREAM, CFG
-        else:
-            kw, wl, kind, cfg = MERGE_CASES[case]
-            cfg = dict(cfg, merge={"barcodes_kind": kind, "barcodes_file": os.path.join(DATA, wl)})
-        stream = SynthStream(**kw)
-        run = ShardedRun(stream, rank, world, 0, kw["n_reads"] // world, cfg, dist, staging="cpu")
-        for _ in range(2):                      # a second step exercises clear_reads / buffer reuse
-            cm, cm_raw, cols = run.step()
-        if rank == 0:
-            extra = {}
-            if run.merge_pairs is not None:
-                extra = dict(m_src=run.merge_pairs[0], m_tgt=run.merge_pairs[1])
-            np.savez(path, cm_p=cm[0], cm_i=cm[1], cm_x=cm[2], cm_cols=cm[3], raw_p=cm_raw[0], raw_i=cm_raw[1],
-                     raw_x=cm_raw[2], raw_cols=cm_raw[3], **extra)
-        dist.barrier()
-    finally:
-        dist.destroy_process_group()
+def run_group(world, arrays, cfg_kw, side=(), steps=2):
+    """arrays = (cb, umi, gene, aux) of the whole stream (host): shard i gets the i-th contiguous range."""
+    n = len(arrays[0])
+    bounds = [n * i // world for i in range(world + 1)]
+    g = ShardGroup([0] * world, **cfg_kw)
+    for i, s in enumerate(g.shards):
+        if side:
+            s.set_side_strings(side)
+        s.set_reads(capi.DeviceArrays.from_host(0, *[a[bounds[i]:bounds[i + 1]] for a in arrays]), bounds[i])
+    for _ in range(steps):                      # a second step exercises buffer reuse
+        g.step()
+    s0 = g.shards[0]
+    out = {"cm": [x.copy() for x in s0.matrix(True)], "raw": [x.copy() for x in s0.matrix(False)], "merged": s0.merged_barcodes(),
+           "phases": s0.phase_stats()}
+    g.close()
+    return out
 
 
-@pytest.mark.parametrize("output", ["shm", "gather"])
-def test_two_ranks_on_one_gpu_match_single_context(output, tmp_path):
-    """output = "shm": every rank writes its columns into host memory shared by the ranks (registered /dev/shm
-    mapping); "gather": the columns are gathered on rank 0's GPU first."""
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    path = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(2, port, path, None, output), nprocs=2, join=True)
-    got = np.load(path)
-    stream = SynthStream(**STREAM)
-    dev = stream.generate_device(0)
-    c = capi.Context(min_genes_before_merge=CFG["min_before"], min_genes_after_merge=CFG["min_after"])
-    c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
+def single(arrays, cfg_kw, side=()):
+    c = capi.Context(**cfg_kw)
+    if side:
+        c.set_side_strings(side)
+    c.push_reads(*arrays)
     c.set_initialized(); c.merge_and_filter()
+    return c
+
+
+def check(got, c):
     rows = c.cell_rows()
-    for filt, pre in ((True, "cm"), (False, "raw")):
+    for filt, name in ((True, "cm"), (False, "raw")):
         p, i, x = c.count_matrix_csc(filtered=filt)
-        assert np.array_equal(got[pre + "_p"].astype(np.uint32), p)
-        assert np.array_equal(got[pre + "_i"], i) and np.array_equal(got[pre + "_x"], x)
-    assert [int(b) for b in got["cm_cols"]] == [int(rows["barcode"][int(k)]) for k in c.filtered_cells()]
-    assert [int(b) for b in got["raw_cols"]] == [int(b) for b in rows["barcode"][rows["is_real"].astype(bool)]]
-    assert len(got["cm_cols"]) > 20
-    dev.free()
+        gp, gi, gx, gb = got[name]
+        assert np.array_equal(gp.astype(np.uint64), p.astype(np.uint64)), name
+        assert np.array_equal(gi, i) and np.array_equal(gx, x), name
+    assert [int(b) for b in got["cm"][3]] == [int(rows["barcode"][int(k)]) for k in c.filtered_cells()]
+    assert [int(b) for b in got["raw"][3]] == [int(b) for b in rows["barcode"][rows["is_real"].astype(bool)]]
+    mt = c.merge_targets()
+    src = np.flatnonzero(mt != np.arange(len(mt)))
+    want = {int(rows["barcode"][k]): int(rows["barcode"][int(mt[k])]) for k in src}
+    have = dict(zip((int(b) for b in got["merged"][0]), (int(b) for b in got["merged"][1])))
+    assert have == want
+    return want
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_shards_on_one_gpu_match_single_context(world):
+    arrays = parity.canonical_stream(*SynthStream(**STREAM).generate_host())
+    kw = cfg_kwargs(CFG)
+    got = run_group(world, arrays, kw)
+    check(got, single(arrays, kw))
+    assert len(got["cm"][3]) > 20
+    if world > 1:
+        assert got["phases"]["all_to_all"]["bytes"] > 0          # reads really moved between the shards
 
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("case", sorted(MERGE_CASES))
-def test_sharded_whitelist_merge_matches_single_context(case, world, tmp_path):
-    """-m with a whitelist over 2 / 3 shards: merge targets on other shards, molecule rows moving between shards.
-    Reference result: ONE context over the whole stream (itself pinned on the oracle in test_gpu_parity.py)."""
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    path = str(tmp_path / "res.npz")
-    mp.spawn(_worker, args=(world, port, path, case), nprocs=world, join=True)
-    got = np.load(path)
+def test_sharded_whitelist_merge_matches_single_context(case, world):
+    """-m with a whitelist over 2 / 3 shards: merge targets on other shards, molecule rows moving between shards."""
     kw, wl, kind, cfg = MERGE_CASES[case]
-    stream = SynthStream(**kw)
-    n = (kw["n_reads"] // world) * world
-    dev = stream.generate_device(0, first=0, n=n)
-    c = capi.Context(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=kind, barcodes_file=os.path.join(DATA, wl),
-                     min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"])
+    arrays = parity.canonical_stream(*SynthStream(**kw).generate_host())
+    ckw = cfg_kwargs(dict(cfg, merge={"barcodes_kind": kind, "barcodes_file": os.path.join(DATA, wl)}))
+    got = run_group(world, arrays, ckw)
+    c = single(arrays, ckw)
+    want = check(got, c)
+    assert len(want) > 20 and int(c.cell_rows()["is_excluded"].sum()) > 0
+    owner = lambda b: capi.lib().dropest_owner_of(int(b), world)           # noqa: E731
+    assert sum(owner(a) != owner(b) for a, b in want.items()) > 5          # the merge really crossed shards
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("rate,n_reads", [(1e-2, 120_000), (1e-3, 600_000)])
+def test_n_umis_across_shards(world, rate, n_reads):
+    """UMIs with N are the reference's DEFAULT UMI merge (MergeUMIsStrategySimple.cpp:21-102): random fills follow one
+    srand(42) sequence in global cell order, ties go to the UMI seen first in the WHOLE stream."""
+    s = SynthStream(n_reads=n_reads * SCALE, n_cells=40 * SCALE, n_genes=1500, umi_len=8)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    umi, side = inject_n(umi, gene, rate, 7, 8)
+    assert len(side) > 20
+    kw = cfg_kwargs({"min_before": 10, "min_after": 20})
+    got = run_group(world, (cb, umi, gene, aux), kw, side)
+    c = single((cb, umi, gene, aux), kw, side)
+    check(got, c)
+    # (the single context itself is pinned on the oracle for these streams: test_gpu_parity.py::test_n_umis_synthetic)
+
+
+def test_n_umis_with_whitelist_merge_across_shards():
+    s = SynthStream(n_reads=150_000 * SCALE, n_cells=25 * SCALE, n_genes=1200, umi_len=8, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    umi, side = inject_n(umi, gene, 5e-3, 11, 8)
+    ckw = cfg_kwargs({"min_before": 3, "min_after": 10, "merge": {"barcodes_kind": capi.BARCODES_CONST,
+                                                                  "barcodes_file": os.path.join(DATA, "10x_aug_2016_split")}})
+    got = run_group(3, (cb, umi, gene, aux), ckw, side)
+    want = check(got, single((cb, umi, gene, aux), ckw, side))
+    assert len(want) > 10
+
+
+def test_barcodes_of_several_lengths_and_max_cells():
+    """compare_cells orders barcode STRINGS (CellsDataContainer.cpp:329-344): with barcodes of several lengths the packed codes
+    do not order like the strings, ties on the sizes must still come out as in one container; -C keeps the largest cells."""
+    import test_gpu_stress as ts
+    rng = np.random.default_rng(77)
+    cb, umi, gene, aux, side = ts.random_stream(rng, n=60_000, n_cb=400, n_gene=6, n_umi=3, cb_len=(8, 11), umi_len=(6, 6), p_nogene=0.05)
+    for max_cells in (-1, 25):
+        kw = cfg_kwargs({"min_before": 1, "min_after": 2, "max_cells": max_cells})
+        got = run_group(2, (cb, umi, gene, aux), kw, side, steps=1)
+        c = single((cb, umi, gene, aux), kw, side)
+        check(got, c)
+        rows = c.cell_rows()
+        f = c.filtered_cells().astype(np.int64)
+        sizes = list(zip(rows["requested_genes"][f].tolist(), rows["requested_umis"][f].tolist(), rows["total_umis"][f].tolist()))
+        assert len(set(sizes)) < len(sizes)                   # the order really depended on the barcode strings
+        assert len({len(capi.unpack_code(b, side)) for b in rows["barcode"][f]}) > 1
+
+
+def test_device_ordering_of_the_global_table(monkeypatch):
+    monkeypatch.setenv("DROPEST_DEVICE_SORT_MIN", "1")
+    kw, wl, kind, cfg = MERGE_CASES["10x"]
+    arrays = parity.canonical_stream(*SynthStream(**kw).generate_host())
+    ckw = cfg_kwargs(dict(cfg, merge={"barcodes_kind": kind, "barcodes_file": os.path.join(DATA, wl)}))
+    check(run_group(2, arrays, ckw, steps=1), single(arrays, ckw))
+
+
+def test_one_shard_over_rccl_and_forced_exchange():
+    """A world of one process: the RCCL communicator, the grouped send / recv all-to-all (to itself), the staged all-gathers
+    and the POSIX shared-memory result buffer are the production code paths of bench.py --gpus N."""
+    s = SynthStream(**STREAM)
+    run = ShardedRun(s, 0, 1, 0, STREAM["n_reads"], CFG)
+    run.shard.set_option("force_exchange", 1)
+    for _ in range(2):
+        cm, raw, cols = run.step()
+    arrays = parity.canonical_stream(*s.generate_host())
+    # the device generator numbers genes / chromosomes as the host generator does before canonical_stream: compare with a
+    # context fed from the same device arrays
+    c = capi.Context(**cfg_kwargs(CFG))
+    dev = s.generate_device(0)
     c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
     c.set_initialized(); c.merge_and_filter()
-    rows = c.cell_rows()
-    for filt, pre in ((True, "cm"), (False, "raw")):
-        p, i, x = c.count_matrix_csc(filtered=filt)
-        assert np.array_equal(got[pre + "_p"].astype(np.uint32), p)
-        assert np.array_equal(got[pre + "_i"], i) and np.array_equal(got[pre + "_x"], x)
-    assert [int(b) for b in got["cm_cols"]] == [int(rows["barcode"][int(k)]) for k in c.filtered_cells()]
-    assert [int(b) for b in got["raw_cols"]] == [int(b) for b in rows["barcode"][rows["is_real"].astype(bool)]]
-    mt = c.merge_targets()
-    src = np.flatnonzero(mt != np.arange(len(mt)))
-    want = {int(rows["barcode"][k]): int(rows["barcode"][int(mt[k])]) for k in src}
-    have = dict(zip((int(b) for b in got["m_src"]), (int(b) for b in got["m_tgt"])))
-    assert have == want and len(want) > 20
-    assert int(rows["is_excluded"].sum()) > 0
-    # the sharded merge really crossed shards
-    owner = lambda b: capi.lib().dropest_owner_of(int(b), world)           # noqa: E731
-    assert sum(owner(a) != owner(b) for a, b in want.items()) > 5
+    got = {"cm": cm, "raw": raw, "merged": run.merge_pairs}
+    check(got, c)
+    ph = run.shard.phase_stats()
+    assert ph["partition"]["steps"] == 2 and ph["all_to_all"]["steps"] == 2
     dev.free()
