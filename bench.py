@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--poisson", action="store_true", help="c3 / c4: -M (PoissonRealBarcodesMergeStrategy) instead of -m, single GPU")
     ap.add_argument("--no-whitelist", action="store_true", help="c3 / c4: -m WITHOUT the barcode whitelist (SimpleMergeStrategy, single GPU)")
     ap.add_argument("--merge-umi", action="store_true", help="-u: directional UMI correction (single-GPU configs only)")
+    ap.add_argument("--sharded", action="store_true",
+                    help="N = 1 only: run the pass through the sharded runner (partition by owner + RCCL all-to-all to itself + "
+                         "shared result buffer) instead of the plain context: what a second GPU would add, measured on one")
     ap.add_argument("--cpu-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_CPU_SAMPLE", 6e6)),
                     help="reads of the same stream timed on the CPU oracle (rank 0, N=1 only; 0 disables)")
     return ap.parse_args()
@@ -71,14 +74,17 @@ def one_step(ctx):
     return cm, cm_raw, ctx.filtered_cells()
 
 
-def cpu_baseline(stream, n_sample, cfg):
+def cpu_baseline(stream, n_sample, cfg, name="C2"):
     """The CPU oracle (oracle/dropest_oracle.cpp, a single-threaded restatement of the reference) timed on the
     first n_sample reads of the same stream: ingest + set_initialized + merge_and_filter + both matrices."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import parity
     from oracle import Oracle
     cb, umi, gene, aux = parity.canonical_stream(*stream.generate_host(0, n_sample))
-    o = Oracle(merge_kind=0, min_genes_before=cfg["min_before"], min_genes_after=cfg["min_after"])
+    m = cfg.get("merge")
+    mkw = dict(merge_kind=1, barcodes_kind=m["barcodes_kind"], barcodes_file=m["barcodes_file"],
+               min_merge_fraction=m.get("min_merge_fraction", 0.2)) if m else dict(merge_kind=0)
+    o = Oracle(min_genes_before=cfg["min_before"], min_genes_after=cfg["min_after"], **mkw)
     t0 = time.perf_counter()
     o.add_packed(cb, umi, gene, aux)
     t1 = time.perf_counter()
@@ -86,9 +92,9 @@ def cpu_baseline(stream, n_sample, cfg):
     o.count_matrix(filtered=True); o.count_matrix(filtered=False)
     t2 = time.perf_counter()
     return {"value": round(n_sample / (t2 - t0) / 1e6, 4), "unit": "Mreads/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads of the same synthetic C2 stream; oracle/dropest_oracle.cpp single thread; "
+            "sample": "first %d reads of the same synthetic %s stream%s; oracle/dropest_oracle.cpp single thread; "
                       "ingest %.2f s + finalize/matrices %.2f s; host has %d cores"
-                      % (n_sample, t1 - t0, t2 - t1, os.cpu_count() or 0)}
+                      % (n_sample, name, " (with the whitelist CB merge)" if m else "", t1 - t0, t2 - t1, os.cpu_count() or 0)}
 
 
 def main():
@@ -109,7 +115,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the dropEst hot path has no CPU implementation")
     torch.cuda.set_device(local_rank)
     dist = None
-    force_sharded = os.environ.get("DROPEST_BENCH_FORCE_SHARDED") == "1" and "RANK" in os.environ
+    force_sharded = world == 1 and (args.sharded or os.environ.get("DROPEST_BENCH_FORCE_SHARDED") == "1")
     saved_stdout = None
     if world > 1 or force_sharded:
         # RCCL prints a version banner on stdout when the first communicator comes up; stdout carries exactly one
@@ -117,6 +123,9 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
+    if world > 1:
+        # torch.distributed carries the launch only: the barrier around the timed region and the broadcast of the RCCL
+        # unique id; every collective of the pass itself is issued by the library (csrc/shard_run.h)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -159,14 +168,18 @@ def main():
         if args.merge_umi:
             raise SystemExit("-u is not supported in sharded runs (the UMI first-occurrence table would have to be reduced over ranks)")
         run = ShardedRun(stream, rank, world, local_rank, reads_per_gpu, cfg, dist)
+        if force_sharded:
+            run.shard.set_option("force_exchange", 1)
         step = run.step
         get_stats = run.kernel_stats
-        get_layout = run.engine.ctx.sort_layout
+        get_layout = run.ctx.sort_layout
+        ctx = run.ctx
         def set_prof(on, only=None):
             run.set_profiling(on, only=only)
-            # the per-stage trace synchronises the device at every stage boundary: a diagnostic of the one-GPU sharded run
-            # only (the untimed table pass), never part of a timing
-            run.trace = {} if (on and only is None and world == 1) else None
+            # phase times: in the untimed table pass the device is synchronised at every phase boundary (a diagnostic);
+            # inside the timed region the phases are host wall times only
+            run.shard.set_option("trace", 1 if (on and only is None) else 0)
+            run.shard.set_option("reset_phase_stats", 1)
 
     def fence():
         if dist is not None:
@@ -194,7 +207,8 @@ def main():
         step()
     fence()
     table = get_stats()
-    shard_trace = dict(getattr(run, "trace", None) or {}) if (world > 1 or force_sharded) else {}
+    shard_phases = run.shard.phase_stats() if (world > 1 or force_sharded) else {}
+    sizes = ctx.table_sizes()
     set_prof(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -228,14 +242,45 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"]}
+        # whole-pipeline roofline: compulsory traffic = every packed record read once, every output item
+        # written once: 24 B/read + 24 B/molecule + 12 B/matrix entry + 40 B/cell, over the sum of the kernel times
+        cm_nnz, raw_nnz = int(len(out[0][1])), int(len(out[1][1]))
+        compulsory = 24.0 * sizes["reads"] + 24.0 * sizes["molecules"] + 12.0 * (cm_nnz + raw_nnz) / max(1, world) + 40.0 * sizes["cells"]
+        t_kernels_ms = sum(v["ms"] for k, v in table.items() if not k.startswith("host:")) / table_steps
+        measured = None
+        pmc_all = os.path.join(ROOT, "profiles", "pmc_pipeline.json")
+        if os.path.exists(pmc_all):
+            try:
+                rec = json.load(open(pmc_all))
+                if rec.get("workload") == args.config and rec.get("reads_per_gpu") == reads_per_gpu and rec.get("sort") == get_layout()["sort"]:
+                    measured = rec.get("hbm_bytes_per_step")
+            except Exception:
+                measured = None
+        if roof is not None and t_kernels_ms > 0:
+            roof["pipeline"] = {"compulsory_bytes": compulsory, "kernel_ms_per_step": round(t_kernels_ms, 3),
+                                "achieved_GBps": round(compulsory / (t_kernels_ms * 1e-3) / 1e9, 1),
+                                "achieved_frac": round(compulsory / (t_kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "measured_bytes": measured,
+                                "measured_hbm_frac": None if measured is None else round(measured / (t_kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "amplification": None if measured is None else round(measured / compulsory, 2),
+                                "bytes_per_read_compulsory": round(compulsory / max(1, sizes["reads"]), 1),
+                                "bytes_per_read_measured": None if measured is None else round(measured / max(1, sizes["reads"]), 1),
+                                "molecules": sizes["molecules"], "cells": sizes["cells"]}
         kernels = {k: {"ms_per_step": round(v["ms"] / table_steps, 4), "launches_per_step": v["launches"] / table_steps}
                    for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]) if not k.startswith("host:")}
         host_stages = {k[5:]: round(v["ms"] / table_steps, 3) for k, v in table.items() if k.startswith("host:")}
+        exchange = None
         if world > 1 or force_sharded:
-            host_stages.update({"shard:" + k: round(v / table_steps, 3) for k, v in shard_trace.items()})
+            host_stages.update({"shard:" + k: round(v["ms"] / max(1, v["steps"]), 3) for k, v in shard_phases.items()})
+            a2a = shard_phases.get("all_to_all")
+            if a2a and a2a["ms"] > 0:
+                links = max(1, world - 1)      # xGMI is point-to-point: one link per peer
+                exchange = {"bytes_out_per_gpu_per_step": a2a["bytes"] / max(1, a2a["steps"]), "ms_per_step": round(a2a["ms"] / max(1, a2a["steps"]), 3),
+                            "GB_per_s_per_gpu": round(a2a["bytes"] / a2a["ms"] / 1e6, 1), "GB_per_s_per_link": round(a2a["bytes"] / a2a["ms"] / 1e6 / links, 1),
+                            "links": links, "transport": "RCCL grouped ncclSend/ncclRecv over xGMI" if world > 1 else "RCCL to itself (one GPU)"}
         cpu = None
         if world == 1 and args.cpu_sample > 0:
-            cpu = cpu_baseline(stream, int(min(args.cpu_sample, total_reads)), cfg)
+            cpu = cpu_baseline(stream, int(min(args.cpu_sample, total_reads)), cfg, args.config.upper())
         cm = out[0]
         line = {
             "metric": "Mreads/s processed to final count matrix", "value": round(value, 2), "unit": "Mreads/s",
@@ -249,9 +294,9 @@ def main():
                                     "no CB merge, -L eEBA") % (reads_per_gpu, args.cells) + (", -u" if args.merge_umi else "")
                                    + (", no whitelist (SimpleMergeStrategy)" if args.no_whitelist else "")
                                    + (", -M (Poisson decisions)" if args.poisson else ""),
-                       "reads_total": total_reads, "parallelism": "cb-hash-shard x%d" % world,
+                       "reads_total": total_reads, "parallelism": "cb-hash-shard x%d%s" % (world, " (sharded runner, forced exchange)" if force_sharded else ""),
                        "cm_nnz": int(len(cm[1])), "filtered_cells": int(len(out[2])), "sort_layout": get_layout()},
-            "roofline": roof, "cpu_baseline": cpu, "step_ms": step_ms, "kernels_ms_per_step": kernels,
+            "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "step_ms": step_ms, "kernels_ms_per_step": kernels,
             "kernel_table": "separate pass of %d steps after the timed region, events on every launch" % table_steps,
             "host_stage_wall_ms_per_step": host_stages,
         }
@@ -259,6 +304,8 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)          # whatever RCCL still prints while the communicator goes down belongs on stderr
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

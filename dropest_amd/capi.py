@@ -156,6 +156,7 @@ def lib():
         "dropest_dev_count": (C.c_int, []),
         "dropest_dev_sync": (C.c_int, [C.c_int]),
         "dropest_rand_sequence": (C.c_int, [C.c_uint32, C.c_uint64, vp]),
+        "dropest_table_sizes": (C.c_int, [vp, vp]),
         "dropest_shard_unique_id": (C.c_int, [vp]),
         "dropest_shard_create": (C.c_int, [P(Cfg), C.c_int32, C.c_int32, vp, P(vp)]),
         "dropest_shard_group_create": (C.c_int, [P(Cfg), C.c_int32, vp, vp]),
@@ -168,6 +169,7 @@ def lib():
         "dropest_shard_merged_barcodes": (C.c_int, [vp, u64p, vp, vp]),
         "dropest_shard_phase_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
         "dropest_shard_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+        "dropest_plan_columns": (C.c_int, [C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_int, C.c_uint32, C.c_int32, vp, C.c_uint64, u64p, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -194,10 +196,10 @@ EXPORTED_SYMBOLS = [
     "dropest_shard_merge_intersect", "dropest_shard_merge_decide", "dropest_merge_apply", "dropest_shard_merge_finish",
     "dropest_synth_generate_host", "dropest_synth_generate_device", "dropest_dev_alloc", "dropest_dev_free",
     "dropest_dev_copy_to_host", "dropest_dev_copy_from_host", "dropest_dev_count", "dropest_dev_sync",
-    "dropest_rand_sequence",
+    "dropest_rand_sequence", "dropest_table_sizes",
     "dropest_shard_unique_id", "dropest_shard_create", "dropest_shard_group_create", "dropest_shard_destroy", "dropest_shard_ctx",
     "dropest_shard_set_reads_device", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix",
-    "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option",
+    "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option", "dropest_plan_columns",
 ]
 
 
@@ -566,6 +568,11 @@ class Context:
         d["sort"] = ("lsd", "splitter")[d["sort"]]
         return d
 
+    def table_sizes(self):
+        out = (C.c_uint64 * 4)()
+        self._chk(self.L.dropest_table_sizes(self.h, out))
+        return dict(zip(("reads", "cells", "molecules", "cell_gene_rows"), map(int, out)))
+
     def set_profiling(self, on=True, only=None):
         """HIP events around the launches; only="rs_scatter": just the launches whose stat name starts with that."""
         self._chk(self.L.dropest_set_profiling_filter(self.h, (only or "").encode()))
@@ -593,6 +600,21 @@ def merge_apply(order, target, total_reads, total_umis):
     if rc != 0:
         raise DropestError(rc, L.dropest_last_error().decode())
     return final, excl, r, u
+
+
+def plan_columns(barcode, first_global, n_genes, req_genes, req_umis, total_umis, filtered, min_after, max_cells=-1, side=()):
+    """Row indices of the global table in the column order of cm (filtered) / cm_raw (host logic, no GPU)."""
+    cols = [np.ascontiguousarray(a, dt) for a, dt in ((barcode, np.uint64), (first_global, np.uint64), (n_genes, np.uint32),
+                                                       (req_genes, np.uint32), (req_umis, np.uint32), (total_umis, np.int32))]
+    n = len(cols[0])
+    order = np.zeros(max(n, 1), np.uint32)
+    k = C.c_uint64()
+    arr = (C.c_char_p * max(1, len(side)))(*[x.encode() for x in side])
+    rc = lib().dropest_plan_columns(n, *[c.ctypes.data for c in cols], int(filtered), int(min_after), int(max_cells), arr, len(side),
+                                    C.byref(k), order.ctypes.data)
+    if rc != 0:
+        raise DropestError(rc, lib().dropest_last_error().decode())
+    return order[:k.value].copy()
 
 
 def radix_plan(varying_mask):

@@ -2100,6 +2100,10 @@ dropest_status dropest_radix_plan(uint64_t varying_mask, uint32_t *n_passes, int
 	});
 }
 
+dropest_status dropest_table_sizes(dropest_ctx *ctx, uint64_t out[4]) {
+	return guarded([&] { need_init(ctx); out[0] = ctx->n_reads; out[1] = ctx->n_cells; out[2] = ctx->n_mol; out[3] = ctx->n_cg; });
+}
+
 dropest_status dropest_rand_sequence(uint32_t seed, uint64_t n, int32_t *out) {
 	return guarded([&] {
 		if (n && !out) throw InvalidError("null argument");

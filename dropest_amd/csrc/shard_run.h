@@ -218,10 +218,19 @@ struct RcclTransport : Transport {
 	void exchange(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
 	              const uint64_t *recv_cnt, hipStream_t st) override {
 		const RcclApi &api = RcclApi::get();
+		// the block a shard keeps never leaves the device: a plain copy (a self send / recv pair moves it at a fifth of the rate)
+		{
+			uint64_t soff = 0, roff = 0;
+			for (int p = 0; p < rank; ++p) { soff += send_cnt[p]; roff += recv_cnt[p]; }
+			for (int a = 0; a < n_arrays; ++a)
+				if (send_cnt[rank]) HIP_CHECK(hipMemcpyAsync(static_cast<char *>(d_recv[a]) + roff * elem[a], static_cast<const char *>(d_send[a]) + soff * elem[a],
+				                                             size_t(send_cnt[rank]) * elem[a], hipMemcpyDeviceToDevice, st));
+		}
 		api.check(api.GroupStart(), "ncclGroupStart");
 		for (int a = 0; a < n_arrays; ++a) {
 			uint64_t soff = 0, roff = 0;
 			for (int p = 0; p < world; ++p) {
+				if (p == rank) { soff += send_cnt[p]; roff += recv_cnt[p]; continue; }
 				if (send_cnt[p]) api.check(api.Send(static_cast<const char *>(d_send[a]) + soff * elem[a], size_t(send_cnt[p]) * elem[a], ncclUint8, p, comm, st), "ncclSend");
 				if (recv_cnt[p]) api.check(api.Recv(static_cast<char *>(d_recv[a]) + roff * elem[a], size_t(recv_cnt[p]) * elem[a], ncclUint8, p, comm, st), "ncclRecv");
 				soff += send_cnt[p]; roff += recv_cnt[p];
@@ -326,6 +335,19 @@ __global__ __launch_bounds__(256) void ordinals_kernel(OrdinalMap m, const uint3
 }
 
 }  // namespace dropest
+
+// CellsDataContainer::compare_cells (CellsDataContainer.cpp:329-344) on table rows: (requested_genes, requested_umis,
+// umis_number, barcode STRING) ascending.  Clean codes of one length order like their strings; anything else is decoded.
+template <class Row>
+static bool compare_cells_rows(const Row &p, const Row &q, const std::vector<std::string> &side) {
+	if (p.req_genes != q.req_genes) return p.req_genes < q.req_genes;
+	if (p.req_umis != q.req_umis) return p.req_umis < q.req_umis;
+	const dropest::u64 pu = dropest::u64(size_t(p.total_umis)), qu = dropest::u64(size_t(q.total_umis));   // Cell::umis_number casts the int stat to size_t
+	if (pu != qu) return pu < qu;
+	const bool plain = !((p.barcode | q.barcode) & dropest::ESCAPE_BIT) && dropest::bit_length(p.barcode) == dropest::bit_length(q.barcode);
+	if (plain) return p.barcode < q.barcode;
+	return dropest::decode_code(p.barcode, side) < dropest::decode_code(q.barcode, side);
+}
 
 // ---- one shard ---------------------------------------------------------------------------------------------------------
 struct dropest_shard {
@@ -532,17 +554,7 @@ std::vector<dropest::u32> dropest_shard::order_rows(const std::vector<u32> &sel,
 		for (u32 kk = 0; kk < mm; ++kk) out[kk] = sel[perm[kk]];
 		return out;
 	}
-	auto less = [&](u32 x, u32 y) {
-		const GRow &p = G[x], &q = G[y];
-		if (p.req_genes != q.req_genes) return p.req_genes < q.req_genes;
-		if (p.req_umis != q.req_umis) return p.req_umis < q.req_umis;
-		const u64 pu = u64(size_t(p.total_umis)), qu = u64(size_t(q.total_umis));   // Cell::umis_number casts the int stat to size_t
-		if (pu != qu) return pu < qu;
-		const bool plain = !((p.barcode | q.barcode) & ESCAPE_BIT) && bit_length(p.barcode) == bit_length(q.barcode);
-		if (plain) return p.barcode < q.barcode;
-		return decode_code(p.barcode, c.side) < decode_code(q.barcode, c.side);   // barcodes of several lengths: string order
-	};
-	std::sort(out.begin(), out.end(), less);
+	std::sort(out.begin(), out.end(), [&](u32 x, u32 y) { return compare_cells_rows(G[x], G[y], c.side); });
 	return out;
 }
 
@@ -977,6 +989,35 @@ dropest_status dropest_shard_phase_stats(dropest_shard *s, uint32_t *n, dropest_
 			++i;
 		}
 		*n = i;
+	});
+}
+
+// Column order of a global matrix from the all-gathered table of real cells -- the host path of dropest_shard::order_rows
+// + the selection of assemble_matrix, without a device (the world-size-2 gloo tests on CPU drive it).
+dropest_status dropest_plan_columns(uint64_t n, const uint64_t *barcode, const uint64_t *first_global, const uint32_t *n_genes,
+                                    const uint32_t *req_genes, const uint32_t *req_umis, const int32_t *total_umis, int filtered,
+                                    uint32_t min_genes_after_merge, int32_t max_cells, const char *const *side_strings, uint64_t n_side,
+                                    uint64_t *n_cols, uint32_t *order) {
+	return guarded([&] {
+		if (!n_cols || (n && (!barcode || !first_global || !n_genes || !req_genes || !req_umis || !total_umis))) throw InvalidError("null argument");
+		if (n >= 0xFFFFFFF0ull) throw UnsupportedError("too many cells");
+		struct Row { dropest::u64 barcode, first_global; dropest::u32 req_genes, req_umis; int32_t total_umis; };
+		std::vector<std::string> side;
+		for (uint64_t i = 0; i < n_side; ++i) side.emplace_back(side_strings[i]);
+		std::vector<Row> rows(n);
+		std::vector<dropest::u32> sel;
+		for (uint64_t i = 0; i < n; ++i) {
+			rows[i] = Row{barcode[i], first_global[i], req_genes[i], req_umis[i], total_umis[i]};
+			if (!filtered || req_genes[i] >= min_genes_after_merge) sel.push_back(dropest::u32(i));
+		}
+		if (filtered) {
+			std::sort(sel.begin(), sel.end(), [&](dropest::u32 x, dropest::u32 y) { return compare_cells_rows(rows[x], rows[y], side); });
+			if (max_cells > 0 && size_t(max_cells) < sel.size()) sel.erase(sel.begin(), sel.end() - max_cells);
+		} else {
+			std::sort(sel.begin(), sel.end(), [&](dropest::u32 x, dropest::u32 y) { return rows[x].first_global < rows[y].first_global; });
+		}
+		*n_cols = sel.size();
+		if (order) std::copy(sel.begin(), sel.end(), order);
 	});
 }
 

@@ -366,6 +366,9 @@ dropest_status dropest_radix_plan(uint64_t varying_mask, uint32_t *n_passes, int
 /* The first n values glibc's rand() returns after srand(seed), from the restated generator every context owns for the
  * random fills of N-UMIs (MergeUMIsStrategyAbstract.cpp:11-23; host logic only, no device needed). */
 dropest_status dropest_rand_sequence(uint32_t seed, uint64_t n, int32_t *out);
+/* Sizes of the container's tables after set_initialized: [0] reads [1] cells (distinct barcodes) [2] molecules
+ * [3] (cell, gene) rows -- the terms of the compulsory-traffic figure of the pipeline roofline. */
+dropest_status dropest_table_sizes(dropest_ctx *ctx, uint64_t out[4]);
 dropest_status dropest_set_profiling(dropest_ctx *ctx, int enabled);   /* HIP events per launch; off by default */
 /* Restrict the events to the launches whose stat name starts with `name_prefix` -- several prefixes may be given,
  * separated by '|' -- (NULL / "" = all launches and the host stages).  Two events per launch cost ~0.5 ms per C2 pass when every kernel is timed; bench.py times only the
@@ -406,6 +409,14 @@ dropest_status dropest_shard_matrix(dropest_shard *shard, int filtered, uint64_t
                                     const uint32_t **rowidx, const uint32_t **values, const uint64_t **col_barcodes);
 /* (source, target) barcodes of the cells the CB merge folded, ascending source: CellsDataContainer::merge_targets by barcode */
 dropest_status dropest_shard_merged_barcodes(dropest_shard *shard, uint64_t *n, uint64_t *source, uint64_t *target);
+/* The column order of a global matrix from the all-gathered table of the real cells, as every shard computes it (host logic
+ * only, no device): filtered = 1: cells with req_genes >= min_genes_after_merge in CellsDataContainer::compare_cells order
+ * (CellsDataContainer.cpp:329-344, barcodes compared as strings), the last max_cells of them when max_cells > 0
+ * (:269-273); filtered = 0: all rows by first_global = cell-id order of ONE container.  order[n_cols] = row indices. */
+dropest_status dropest_plan_columns(uint64_t n, const uint64_t *barcode, const uint64_t *first_global, const uint32_t *n_genes,
+                                    const uint32_t *req_genes, const uint32_t *req_umis, const int32_t *total_umis, int filtered,
+                                    uint32_t min_genes_after_merge, int32_t max_cells, const char *const *side_strings, uint64_t n_side,
+                                    uint64_t *n_cols, uint32_t *order);
 /* wall time per phase of the steps so far (name, steps, ms; bytes = what this shard put on the links in "all_to_all") */
 dropest_status dropest_shard_phase_stats(dropest_shard *shard, uint32_t *n, dropest_kernel_stat *out);
 /* "trace" (synchronise the device at every phase boundary: diagnostic), "force_exchange" (partition + all-to-all even with
