@@ -164,6 +164,8 @@ def lib():
         "dropest_shard_ctx": (vp, [vp]),
         "dropest_shard_set_reads_device": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64]),
         "dropest_shard_step": (C.c_int, [vp]),
+        "dropest_shard_push_reads": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64]),
+        "dropest_reserve_reads": (C.c_int, [vp, C.c_uint64]),
         "dropest_shard_group_step": (C.c_int, [vp, C.c_int32]),
         "dropest_shard_matrix": (C.c_int, [vp, C.c_int, u64p, u64p, P(vp), P(vp), P(vp), P(vp)]),
         "dropest_shard_merged_barcodes": (C.c_int, [vp, u64p, vp, vp]),
@@ -198,7 +200,7 @@ EXPORTED_SYMBOLS = [
     "dropest_dev_copy_to_host", "dropest_dev_copy_from_host", "dropest_dev_count", "dropest_dev_sync",
     "dropest_rand_sequence", "dropest_table_sizes",
     "dropest_shard_unique_id", "dropest_shard_create", "dropest_shard_group_create", "dropest_shard_destroy", "dropest_shard_ctx",
-    "dropest_shard_set_reads_device", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix",
+    "dropest_shard_set_reads_device", "dropest_shard_push_reads", "dropest_reserve_reads", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix",
     "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option", "dropest_plan_columns",
 ]
 

@@ -41,6 +41,76 @@ struct ReadChunk {
 
 struct KernelStat { u32 launches = 0; double ms = 0, bytes = 0; };
 
+// Pushed reads (CellsDataContainer::add_record, batched): ONE set of device arrays that grows geometrically -- no
+// allocation per batch, nothing to concatenate later -- fed over PCIe on its own stream.  Host arrays that are already
+// pinned are copied from in place; pageable ones go through two pinned staging buffers, the host memcpy of batch k + 1
+// running under the transfer of batch k.
+struct ReadStore {
+	DevBuf<u64> cb, umi;
+	DevBuf<u32> gene, aux;
+	size_t n = 0;
+	hipStream_t copy = nullptr;
+	PinnedBuf<unsigned char> stage[2];
+	hipEvent_t done[2] = {nullptr, nullptr};
+	int cur = 0;
+	~ReadStore() { for (auto e : done) if (e) (void)hipEventDestroy(e); if (copy) (void)hipStreamDestroy(copy); }
+	size_t capacity() const { return cb.n; }
+	void reserve(size_t want) {
+		if (want <= capacity() && cb.p) return;
+		size_t cap = std::max<size_t>(want, std::max<size_t>(capacity() * 2, size_t(1) << 20));
+		if (!copy) HIP_CHECK(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+		HIP_CHECK(hipStreamSynchronize(copy));
+		DevBuf<u64> ncb, numi; DevBuf<u32> ngene, naux;
+		ncb.alloc(cap); numi.alloc(cap); ngene.alloc(cap); naux.alloc(cap);
+		if (n) {
+			HIP_CHECK(hipMemcpyAsync(ncb.p, cb.p, n * 8, hipMemcpyDeviceToDevice, copy));
+			HIP_CHECK(hipMemcpyAsync(numi.p, umi.p, n * 8, hipMemcpyDeviceToDevice, copy));
+			HIP_CHECK(hipMemcpyAsync(ngene.p, gene.p, n * 4, hipMemcpyDeviceToDevice, copy));
+			HIP_CHECK(hipMemcpyAsync(naux.p, aux.p, n * 4, hipMemcpyDeviceToDevice, copy));
+			HIP_CHECK(hipStreamSynchronize(copy));
+		}
+		cb = std::move(ncb); umi = std::move(numi); gene = std::move(ngene); aux = std::move(naux);
+	}
+	static bool is_pinned(const void *p) {
+		hipPointerAttribute_t a{};
+		if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+		return a.type == hipMemoryTypeHost;
+	}
+	void push(const uint64_t *h_cb, const uint64_t *h_umi, const uint32_t *h_gene, const uint32_t *h_aux, size_t count) {
+		if (!count) return;
+		reserve(n + count);
+		if (is_pinned(h_cb) && is_pinned(h_umi) && is_pinned(h_gene) && is_pinned(h_aux)) {
+			HIP_CHECK(hipMemcpyAsync(cb.p + n, h_cb, count * 8, hipMemcpyHostToDevice, copy));
+			HIP_CHECK(hipMemcpyAsync(umi.p + n, h_umi, count * 8, hipMemcpyHostToDevice, copy));
+			HIP_CHECK(hipMemcpyAsync(gene.p + n, h_gene, count * 4, hipMemcpyHostToDevice, copy));
+			HIP_CHECK(hipMemcpyAsync(aux.p + n, h_aux, count * 4, hipMemcpyHostToDevice, copy));
+			HIP_CHECK(hipStreamSynchronize(copy));   // the caller keeps ownership of its arrays
+			n += count;
+			return;
+		}
+		const size_t piece_max = size_t(4) << 20;   // reads per staging buffer (96 MB)
+		for (size_t at = 0; at < count; at += piece_max) {
+			const size_t m = std::min(piece_max, count - at);
+			PinnedBuf<unsigned char> &st = stage[cur];
+			if (!done[cur]) HIP_CHECK(hipEventCreateWithFlags(&done[cur], hipEventDisableTiming));
+			else HIP_CHECK(hipEventSynchronize(done[cur]));   // the transfer that used this buffer two pieces ago
+			st.ensure(m * 24);
+			unsigned char *b = st.p;
+			std::memcpy(b, h_cb + at, m * 8); std::memcpy(b + m * 8, h_umi + at, m * 8);
+			std::memcpy(b + m * 16, h_gene + at, m * 4); std::memcpy(b + m * 20, h_aux + at, m * 4);
+			HIP_CHECK(hipMemcpyAsync(cb.p + n, b, m * 8, hipMemcpyHostToDevice, copy));
+			HIP_CHECK(hipMemcpyAsync(umi.p + n, b + m * 8, m * 8, hipMemcpyHostToDevice, copy));
+			HIP_CHECK(hipMemcpyAsync(gene.p + n, b + m * 16, m * 4, hipMemcpyHostToDevice, copy));
+			HIP_CHECK(hipMemcpyAsync(aux.p + n, b + m * 20, m * 4, hipMemcpyHostToDevice, copy));
+			HIP_CHECK(hipEventRecord(done[cur], copy));
+			cur ^= 1;
+			n += m;
+		}
+	}
+	void wait() { if (copy) HIP_CHECK(hipStreamSynchronize(copy)); }
+	void clear() { wait(); n = 0; }
+};
+
 // decode a packed 2-bit code (include/dropest_amd.h) to text
 inline std::string decode_code(u64 code, const std::vector<std::string> &side) {
 	if (code & ESCAPE_BIT) {
@@ -155,6 +225,8 @@ struct dropest_ctx {
 	hipStream_t stream = nullptr;
 
 	std::vector<dropest::ReadChunk> chunks;
+	dropest::ReadStore store;        // reads pushed from host memory: one chunk of `chunks`, growing in place
+	long store_chunk = -1;           // its index in `chunks`
 	uint64_t n_reads = 0;
 	dropest::DevBuf<u64> cat_cb, cat_umi;
 	dropest::DevBuf<u32> cat_gene, cat_aux;

@@ -159,6 +159,11 @@ void dropest_ctx::collect_timings() {
 void dropest_ctx::concat_chunks() {
 	if (d_cb) return;
 	if (n_reads == 0) return;
+	store.wait();   // pushed batches still on their way over PCIe
+	if (store_chunk >= 0) {
+		dropest::ReadChunk &c = chunks[size_t(store_chunk)];
+		c.p_cb = store.cb.p; c.p_umi = store.umi.p; c.p_gene = store.gene.p; c.p_aux = store.aux.p; c.n = store.n;
+	}
 	if (n_reads >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads in one context (shard across GPUs)");
 	if (chunks.size() == 1) {
 		d_cb = chunks[0].p_cb; d_umi = chunks[0].p_umi; d_gene = chunks[0].p_gene; d_aux = chunks[0].p_aux;
@@ -1269,16 +1274,35 @@ dropest_status dropest_push_reads(dropest_ctx *ctx, const uint64_t *cb, const ui
 		push_common(ctx, n);
 		if (n == 0) return;
 		if (!cb || !umi || !gene || !aux) throw InvalidError("null read array");
-		ReadChunk c;
-		c.cb.alloc(n); c.umi.alloc(n); c.gene.alloc(n); c.aux.alloc(n);
-		HIP_CHECK(hipMemcpyAsync(c.cb.p, cb, n * 8, hipMemcpyHostToDevice, ctx->stream));
-		HIP_CHECK(hipMemcpyAsync(c.umi.p, umi, n * 8, hipMemcpyHostToDevice, ctx->stream));
-		HIP_CHECK(hipMemcpyAsync(c.gene.p, gene, n * 4, hipMemcpyHostToDevice, ctx->stream));
-		HIP_CHECK(hipMemcpyAsync(c.aux.p, aux, n * 4, hipMemcpyHostToDevice, ctx->stream));
-		HIP_CHECK(hipStreamSynchronize(ctx->stream));   // caller keeps ownership of the host arrays
-		c.p_cb = c.cb.p; c.p_umi = c.umi.p; c.p_gene = c.gene.p; c.p_aux = c.aux.p; c.n = n;
-		ctx->chunks.push_back(std::move(c));
+		// one growing device buffer, fed on the copy stream: no allocation per batch, nothing to concatenate afterwards.  A
+		// batch pushed between two adopted device chunks would have to keep its place in the stream: such mixes take a
+		// chunk of their own.
+		if (ctx->store_chunk >= 0 && size_t(ctx->store_chunk) + 1 != ctx->chunks.size()) {
+			ReadChunk c;
+			c.cb.alloc(n); c.umi.alloc(n); c.gene.alloc(n); c.aux.alloc(n);
+			HIP_CHECK(hipMemcpyAsync(c.cb.p, cb, n * 8, hipMemcpyHostToDevice, ctx->stream));
+			HIP_CHECK(hipMemcpyAsync(c.umi.p, umi, n * 8, hipMemcpyHostToDevice, ctx->stream));
+			HIP_CHECK(hipMemcpyAsync(c.gene.p, gene, n * 4, hipMemcpyHostToDevice, ctx->stream));
+			HIP_CHECK(hipMemcpyAsync(c.aux.p, aux, n * 4, hipMemcpyHostToDevice, ctx->stream));
+			HIP_CHECK(hipStreamSynchronize(ctx->stream));
+			c.p_cb = c.cb.p; c.p_umi = c.umi.p; c.p_gene = c.gene.p; c.p_aux = c.aux.p; c.n = n;
+			ctx->chunks.push_back(std::move(c));
+			ctx->n_reads += n;
+			return;
+		}
+		if (ctx->store_chunk < 0) { ctx->store_chunk = long(ctx->chunks.size()); ctx->chunks.emplace_back(); }
+		ctx->store.push(cb, umi, gene, aux, n);
+		ctx->chunks[size_t(ctx->store_chunk)].n = ctx->store.n;   // the pointers are set when the reads are frozen (the buffer may still move)
 		ctx->n_reads += n;
+	});
+}
+
+dropest_status dropest_reserve_reads(dropest_ctx *ctx, uint64_t n_total) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		if (n_total >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads in one context (shard across GPUs)");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		ctx->store.reserve(size_t(n_total));
 	});
 }
 
@@ -1995,6 +2019,7 @@ dropest_status dropest_clear_reads(dropest_ctx *ctx) {
 		if (!ctx) throw InvalidError("null context");
 		ctx->free_results();
 		ctx->chunks.clear();
+		ctx->store.clear(); ctx->store_chunk = -1;
 		ctx->n_reads = 0;
 		ctx->d_cb = ctx->d_umi = nullptr; ctx->d_gene = ctx->d_aux = nullptr;
 	});

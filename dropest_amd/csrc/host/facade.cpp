@@ -122,7 +122,52 @@ CellsDataContainer::CellsDataContainer(const std::shared_ptr<Merge::MergeStrateg
 	check(dropest_ctx_create(&cfg, &_ctx));
 }
 
-CellsDataContainer::~CellsDataContainer() { dropest_ctx_destroy(_ctx); }
+CellsDataContainer::CellsDataContainer(const std::shared_ptr<Merge::MergeStrategyAbstract> &merge_strategy,
+                                       const std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> &umi_merge_strategy,
+                                       const std::vector<UMI::Mark> &gene_match_levels, bool /*save_umi_merge_targets*/,
+                                       int max_cells_num, const std::vector<int> &devices)
+	: _merge_strategy(merge_strategy), _umi_merge_strategy(umi_merge_strategy), _query_marks(gene_match_levels) {
+	if (devices.empty()) throw std::runtime_error("no device given");
+	dropest_cfg cfg;
+	dropest_cfg_defaults(&cfg);
+	cfg.device = devices[0];
+	merge_strategy->fill(cfg);
+	umi_merge_strategy->fill(cfg);
+	cfg.min_genes_before_merge = int(merge_strategy->min_genes_before_merge());
+	cfg.min_genes_after_merge = int(merge_strategy->min_genes_after_merge());
+	const std::string levels = UMI::Mark::to_code(gene_match_levels);
+	cfg.gene_match_levels = levels.c_str();
+	cfg.max_cells = max_cells_num;
+	if (devices.size() == 1) { check(dropest_ctx_create(&cfg, &_ctx)); return; }
+	std::vector<int32_t> dev(devices.begin(), devices.end());
+	_shards.assign(devices.size(), nullptr);
+	check(dropest_shard_group_create(&cfg, int32_t(dev.size()), dev.data(), _shards.data()));
+}
+
+CellsDataContainer::~CellsDataContainer() {
+	for (dropest_shard *s : _shards) dropest_shard_destroy(s);
+	dropest_ctx_destroy(_ctx);
+}
+
+void CellsDataContainer::single_only(const char *what) const {
+	throw std::runtime_error(std::string(what) + " is not available on a container sharded over several GPUs");
+}
+
+std::vector<std::pair<std::string, std::string>> CellsDataContainer::merged_barcodes() const {
+	std::vector<std::pair<std::string, std::string>> out;
+	if (sharded()) {
+		uint64_t n = 0;
+		check(dropest_shard_merged_barcodes(_shards[0], &n, nullptr, nullptr));
+		std::vector<uint64_t> src(n), tgt(n);
+		if (n) check(dropest_shard_merged_barcodes(_shards[0], &n, src.data(), tgt.data()));
+		for (uint64_t i = 0; i < n; ++i) out.emplace_back(decode(src[i]), decode(tgt[i]));
+		return out;
+	}
+	const ids_t &t = merge_targets();
+	for (size_t i = 0; i < t.size(); ++i) if (t[i] != i) out.emplace_back(cell(i).barcode(), cell(t[i]).barcode());
+	std::sort(out.begin(), out.end());
+	return out;
+}
 
 void CellsDataContainer::add_record(const ReadInfo &r) {   // CellsDataContainer.cpp:59-88
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
@@ -236,6 +281,17 @@ void CellsDataContainer::flush() {
 	if (_cb.empty()) return;
 	std::vector<const char *> ptrs(_side.size());
 	for (size_t i = 0; i < _side.size(); ++i) ptrs[i] = _side[i].c_str();
+	if (sharded()) {
+		// Every shard holds ONE contiguous range of the stream, ascending with the shard: the first SHARD_QUOTA reads go to
+		// shard 0, the next to shard 1, ... (the stream's length is not known while it arrives; the pass re-distributes the
+		// reads by barcode owner anyway, so WHERE they wait only decides which PCIe link carried them).
+		if (_side.size() != _side_sent) { for (dropest_shard *s : _shards) check(dropest_set_side_strings(dropest_shard_ctx(s), ptrs.data(), ptrs.size())); _side_sent = _side.size(); }
+		const size_t shard = std::min<size_t>(_shards.size() - 1, size_t(_batches / (shard_quota / BATCH)));
+		check(dropest_shard_push_reads(_shards[shard], _cb.data(), _umi.data(), _gene.data(), _aux.data(), _cb.size(), _batches * BATCH));
+		++_batches;
+		_cb.clear(); _umi.clear(); _gene.clear(); _aux.clear();
+		return;
+	}
 	check(dropest_set_side_strings(_ctx, ptrs.data(), ptrs.size()));
 	check(dropest_push_reads(_ctx, _cb.data(), _umi.data(), _gene.data(), _aux.data(), _cb.size()));
 	_cb.clear(); _umi.clear(); _gene.clear(); _aux.clear();
@@ -244,6 +300,11 @@ void CellsDataContainer::flush() {
 void CellsDataContainer::set_initialized() {   // CellsDataContainer.cpp:163-175
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
 	flush();
+	if (sharded()) {
+		if (_umi_quality_length != size_t(-1) && _umi_quality_length > 0) single_only("UMI qualities");
+		_is_initialized = true;   // the sharded pass (partition, exchange, pipeline, merges) runs as one piece in merge_and_filter
+		return;
+	}
 	if (_umi_quality_length != size_t(-1) && _umi_quality_length > 0) {
 		check(dropest_set_umi_qualities(_ctx, _qual.data(), uint32_t(_umi_quality_length), _qual.size() / _umi_quality_length));
 		std::vector<uint8_t>().swap(_qual);
@@ -254,13 +315,14 @@ void CellsDataContainer::set_initialized() {   // CellsDataContainer.cpp:163-175
 
 void CellsDataContainer::merge_and_filter() {   // CellsDataContainer.cpp:39-57
 	if (!_is_initialized) throw std::runtime_error("You must initialize container");
+	if (sharded()) { check(dropest_shard_group_step(_shards.data(), int32_t(_shards.size()))); return; }
 	check(dropest_merge_and_filter(_ctx));
 }
 
-size_t CellsDataContainer::total_cells_number() const { uint64_t n = 0; check(dropest_total_cells(_ctx, &n)); return size_t(n); }
-size_t CellsDataContainer::real_cells_number() const { uint64_t n = 0; check(dropest_real_cells(_ctx, &n)); return size_t(n); }
+size_t CellsDataContainer::total_cells_number() const { if (sharded()) single_only("total_cells_number"); uint64_t n = 0; check(dropest_total_cells(_ctx, &n)); return size_t(n); }
+size_t CellsDataContainer::real_cells_number() const { if (sharded()) single_only("real_cells_number"); uint64_t n = 0; check(dropest_real_cells(_ctx, &n)); return size_t(n); }
 
-size_t CellsDataContainer::cell_id_by_cb(const std::string &barcode) const {
+size_t CellsDataContainer::cell_id_by_cb(const std::string &barcode) const { if (sharded()) single_only("string &barcode) const {");
 	uint64_t code;
 	if (!pack2(barcode, code)) {
 		auto it = _side_cb.find(barcode);
@@ -273,7 +335,7 @@ size_t CellsDataContainer::cell_id_by_cb(const std::string &barcode) const {
 	return size_t(id);
 }
 
-const CellsDataContainer::ids_t &CellsDataContainer::filtered_cells() const {
+const CellsDataContainer::ids_t &CellsDataContainer::filtered_cells() const { if (sharded()) single_only("filtered_cells");
 	uint64_t n = 0;
 	check(dropest_filtered_cells(_ctx, &n, nullptr));
 	std::vector<uint64_t> ids(n);
@@ -282,7 +344,7 @@ const CellsDataContainer::ids_t &CellsDataContainer::filtered_cells() const {
 	return _filtered_cache;
 }
 
-const CellsDataContainer::ids_t &CellsDataContainer::merge_targets() const {
+const CellsDataContainer::ids_t &CellsDataContainer::merge_targets() const { if (sharded()) single_only("merge_targets");
 	uint64_t n = 0;
 	check(dropest_merge_targets(_ctx, &n, nullptr, nullptr));
 	std::vector<uint64_t> src(n), tgt(n);
@@ -433,7 +495,13 @@ std::unordered_map<std::string, size_t> Cell::requested_umis_per_gene(const UMI:
 }
 
 // ---- ResultsPrinter ---------------------------------------------------------------------------------
+static ResultsPrinter::SparseMatrix sharded_matrix(const CellsDataContainer &c, dropest_shard *s0, bool filtered);
+
 ResultsPrinter::SparseMatrix ResultsPrinter::get_count_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order) const {
+	if (c.sharded()) {
+		if (reads_output) throw std::runtime_error("reads_output is not available on a container sharded over several GPUs");
+		return sharded_matrix(c, c.shard0(), filtered);
+	}
 	uint64_t ncols = 0, nnz = 0;
 	const uint32_t *colptr = nullptr, *rowidx = nullptr, *values = nullptr;
 	if (dropest_count_matrix_csc(c.handle(), filtered ? 1 : 0, reads_output ? 1 : 0, &ncols, &nnz, &colptr, &rowidx, &values) != DROPEST_OK)
@@ -459,6 +527,28 @@ ResultsPrinter::SparseMatrix ResultsPrinter::get_count_matrix_filtered(const Cel
 	if (dropest_count_matrix_csc_levels(c.handle(), levels_code(query).c_str(), reads_output ? 1 : 0, &ncols, &nnz, &colptr, &rowidx, &values) != DROPEST_OK)
 		throw std::runtime_error(dropest_last_error());
 	return named_matrix(c, true, reference_row_order, ncols, nnz, colptr, rowidx, values);
+}
+
+// the global matrix of a sharded container: columns = the cells' barcodes in the order of ONE container, rows = the genes that
+// occur, in gene-index order
+static ResultsPrinter::SparseMatrix sharded_matrix(const CellsDataContainer &c, dropest_shard *s0, bool filtered) {
+	ResultsPrinter::SparseMatrix M;
+	uint64_t ncols = 0, nnz = 0;
+	const uint64_t *colptr = nullptr, *bc = nullptr;
+	const uint32_t *rowidx = nullptr, *values = nullptr;
+	if (dropest_shard_matrix(s0, filtered ? 1 : 0, &ncols, &nnz, &colptr, &rowidx, &values, &bc) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+	for (uint64_t j = 0; j < ncols; ++j) M.col_names.push_back(c.decode(bc[j]));
+	M.colptr.resize(ncols + 1);
+	for (uint64_t j = 0; j <= ncols; ++j) M.colptr[j] = uint32_t(colptr ? colptr[j] : 0);
+	M.values.assign(values, values + nnz);
+	M.rowidx.resize(nnz);
+	const auto &genes = c.gene_indexer().values();
+	std::vector<uint32_t> row_of_gene(genes.size(), 0xFFFFFFFFu);
+	std::vector<char> seen(genes.size(), 0);
+	for (uint64_t k = 0; k < nnz; ++k) seen[rowidx[k]] = 1;
+	for (uint32_t g = 0; g < genes.size(); ++g) if (seen[g]) { row_of_gene[g] = uint32_t(M.row_names.size()); M.row_names.push_back(genes[g]); }
+	for (uint64_t k = 0; k < nnz; ++k) M.rowidx[k] = row_of_gene[rowidx[k]];
+	return M;
 }
 
 ResultsPrinter::SparseMatrix ResultsPrinter::named_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order, uint64_t ncols,

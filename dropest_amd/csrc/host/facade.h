@@ -276,6 +276,12 @@ private:
 	std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> _umi_merge_strategy;
 	UMI::Mark::query_t _query_marks;
 	dropest_ctx *_ctx = nullptr;
+	// N GPUs behind the one container: the batches of the stream are dealt to the shards round-robin; merge_and_filter runs the
+	// sharded pass (include/dropest_amd.h: dropest_shard_*), one host thread per GPU
+	std::vector<dropest_shard *> _shards;
+	uint64_t _batches = 0;
+	size_t _side_sent = 0;
+	[[noreturn]] void single_only(const char *what) const;
 	bool _is_initialized = false;
 	// host-side dictionaries (strings never reach the device)
 	StringIndexer _gene_indexer, _chr_indexer;
@@ -300,11 +306,24 @@ private:
 
 public:
 	static const size_t BATCH = size_t(1) << 20;
+	size_t shard_quota = size_t(1) << 27;   // sharded container: reads (a multiple of BATCH) a shard takes before the next one starts
 
 	CellsDataContainer(const std::shared_ptr<Merge::MergeStrategyAbstract> &merge_strategy,
 	                   const std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> &umi_merge_strategy,
 	                   const std::vector<UMI::Mark> &gene_match_levels, bool save_umi_merge_targets = false,
 	                   int max_cells_num = -1, int device = 0);
+	// The same container over several GPUs (the path shards by cell barcode): `devices` = one HIP ordinal per shard.  add_record,
+	// set_initialized, merge_and_filter and ResultsPrinter::get_count_matrix / save_mtx work as on one GPU -- results are those of
+	// ONE container over the whole stream --; the per-cell accessors (cell(i), merge_targets(), ...) and the strategies other than
+	// Dummy / RealBarcodes + the default UMI merge need the single-GPU container and throw std::runtime_error here.
+	CellsDataContainer(const std::shared_ptr<Merge::MergeStrategyAbstract> &merge_strategy,
+	                   const std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> &umi_merge_strategy,
+	                   const std::vector<UMI::Mark> &gene_match_levels, bool save_umi_merge_targets, int max_cells_num,
+	                   const std::vector<int> &devices);
+	bool sharded() const { return !_shards.empty(); }
+	dropest_shard *shard0() const { return _shards.empty() ? nullptr : _shards[0]; }
+	// (source, target) barcodes of the cells the CB merge folded: merge_targets() by barcode, also on a sharded container
+	std::vector<std::pair<std::string, std::string>> merged_barcodes() const;
 	~CellsDataContainer();
 	CellsDataContainer(const CellsDataContainer &) = delete;              // pointer-stable, like the reference needs to be
 	CellsDataContainer &operator=(const CellsDataContainer &) = delete;

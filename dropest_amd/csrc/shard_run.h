@@ -323,6 +323,9 @@ __global__ __launch_bounds__(256) void place_columns_kernel(const unsigned long 
 }
 // local read position -> global stream ordinal: position p came from source rank s = the block [recv_off[s], recv_off[s+1])
 // it lies in, as that rank's idx[p]-th resident read
+// (every shard's resident reads are ONE contiguous range of the stream and the ranges ascend with the rank: the blocks a
+// shard receives, concatenated in source-rank order, are then in stream order, which is what makes a read's POSITION
+// on its shard a valid first-seen ordinal there)
 struct OrdinalMap { const uint32_t *idx; uint32_t world; uint64_t recv_off[65]; uint64_t first_ord[64]; };
 __device__ inline unsigned long long to_global_ordinal(const OrdinalMap &m, uint32_t p) {
 	uint32_t s = 0;
@@ -361,6 +364,7 @@ struct dropest_shard {
 	const u64 *r_cb = nullptr, *r_umi = nullptr;
 	const u32 *r_gene = nullptr, *r_aux = nullptr;
 	uint64_t n_res = 0, first_ordinal = 0;
+	dropest::ReadStore pushed;       // reads pushed from host memory (dropest_shard_push_reads)
 	// partition / exchange buffers
 	dropest::DevBuf<u64> p_cb, p_umi, x_cb, x_umi;
 	dropest::DevBuf<u32> p_gene, p_aux, p_idx, x_gene, x_aux, x_idx;
@@ -771,10 +775,25 @@ void dropest_shard::step() {
 	HIP_CHECK(hipSetDevice(c.cfg.device));
 	Phase whole(this, "step");
 	// the ordinal ranges of all shards (ordinals name reads across shards: first-seen order, N-UMI tie breaks)
+	if (pushed.n) {   // reads pushed from host memory: wait for the last batch, use the store in place
+		pushed.wait();
+		r_cb = pushed.cb.p; r_umi = pushed.umi.p; r_gene = pushed.gene.p; r_aux = pushed.aux.p; n_res = pushed.n;
+	}
 	first_ord.assign(size_t(world), 0);
-	{ uint64_t f = first_ordinal; tr->gather_host(&f, 8, first_ord.data()); }
+	{
+		uint64_t mine[2] = {first_ordinal, n_res};
+		std::vector<uint64_t> all(size_t(world) * 2);
+		tr->gather_host(mine, sizeof(mine), all.data());
+		uint64_t reach = 0;
+		for (int p = 0; p < world; ++p) {
+			first_ord[size_t(p)] = all[size_t(p) * 2];
+			if (all[size_t(p) * 2 + 1] == 0) continue;   // an empty shard has no place in the order
+			if (first_ord[size_t(p)] < reach) throw InvalidError("the shards' ordinal ranges must ascend with the rank and must not overlap");
+			reach = first_ord[size_t(p)] + all[size_t(p) * 2 + 1];
+		}
+	}
 	// forget the previous pass
-	c.free_results(); c.chunks.clear(); c.n_reads = 0;
+	c.free_results(); c.chunks.clear(); c.n_reads = 0; c.store.clear(); c.store_chunk = -1;
 	c.d_cb = c.d_umi = nullptr; c.d_gene = c.d_aux = nullptr;
 	exchanged = false;
 	ReadChunk ch;
@@ -929,6 +948,21 @@ dropest_status dropest_shard_set_reads_device(dropest_shard *s, const uint64_t *
 		if (n >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads per shard");
 		s->r_cb = reinterpret_cast<const dropest::u64 *>(d_cb); s->r_umi = reinterpret_cast<const dropest::u64 *>(d_umi);
 		s->r_gene = d_gene; s->r_aux = d_aux; s->n_res = n; s->first_ordinal = first_ordinal;
+		s->pushed.clear();
+	});
+}
+
+dropest_status dropest_shard_push_reads(dropest_shard *s, const uint64_t *cb, const uint64_t *umi, const uint32_t *gene, const uint32_t *aux,
+                                        uint64_t n, uint64_t first_ordinal) {
+	return guarded([&] {
+		if (!s) throw InvalidError("null shard");
+		if (!n) return;
+		if (!cb || !umi || !gene || !aux) throw InvalidError("null read array");
+		if (s->pushed.n + n >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads per shard");
+		HIP_CHECK(hipSetDevice(s->ctx->cfg.device));
+		if (s->pushed.n == 0) s->first_ordinal = first_ordinal;
+		else if (first_ordinal != s->first_ordinal + s->pushed.n) throw InvalidError("the batches pushed to a shard must continue its ordinal range without a gap");
+		s->pushed.push(cb, umi, gene, aux, size_t(n));
 	});
 }
 

@@ -56,6 +56,11 @@ class Shard:
         self._reads = arrays
         self._chk(self.L.dropest_shard_set_reads_device(self.h, *arrays.ptrs, arrays.n, first_ordinal))
 
+    def push_reads(self, cb, umi, gene, aux, first_ordinal):
+        """One batch from host memory (see dropest_shard_push_reads: equal batch lengths, equally spaced first ordinals)."""
+        arrs = [np.ascontiguousarray(a, dt) for a, dt in ((cb, np.uint64), (umi, np.uint64), (gene, np.uint32), (aux, np.uint32))]
+        self._chk(self.L.dropest_shard_push_reads(self.h, *[a.ctypes.data for a in arrs], len(arrs[0]), int(first_ordinal)))
+
     def set_side_strings(self, strings):
         self.ctx.set_side_strings(strings)
 

@@ -114,11 +114,15 @@ void dropest_ctx_destroy(dropest_ctx *ctx);
 /* Side strings for escaped codes (barcodes / UMIs containing 'N' etc.); the table may only grow. */
 dropest_status dropest_set_side_strings(dropest_ctx *ctx, const char *const *strings, uint64_t n);
 
-/* CellsDataContainer::add_record (CellsDataContainer.cpp:59-88), batched.  Host pointers; the batch is
- * copied to the device, the caller keeps ownership.  Fails with DROPEST_ERR_INVALID after
- * dropest_set_initialized ("Container is already initialized", :61-62). */
+/* CellsDataContainer::add_record (CellsDataContainer.cpp:59-88), batched.  Host pointers; the batch is copied into ONE
+ * growing set of device arrays on a copy stream of its own -- straight from the caller's arrays when they are pinned
+ * (hipHostMalloc / hipHostRegister), through two pinned staging buffers otherwise -- and the caller keeps ownership: the
+ * arrays may be reused when the call returns.  Fails with DROPEST_ERR_INVALID after dropest_set_initialized
+ * ("Container is already initialized", :61-62). */
 dropest_status dropest_push_reads(dropest_ctx *ctx, const uint64_t *cb, const uint64_t *umi,
                                   const uint32_t *gene, const uint32_t *aux, uint64_t n);
+/* Optional: room for n_total pushed reads up front (otherwise the device arrays grow geometrically while reads arrive). */
+dropest_status dropest_reserve_reads(dropest_ctx *ctx, uint64_t n_total);
 /* Same, for arrays already resident in this GPU's HBM (device pointers).  With adopt != 0 the context
  * uses the caller's buffers in place (no copy); they must stay alive and unmodified until destroy. */
 dropest_status dropest_push_reads_device(dropest_ctx *ctx, const uint64_t *d_cb, const uint64_t *d_umi,
@@ -403,6 +407,13 @@ dropest_ctx *dropest_shard_ctx(dropest_shard *shard);   /* the shard's context: 
  * stream ordinal of its first read (ordinals define first-seen cell ids and N-UMI tie breaks across shards) */
 dropest_status dropest_shard_set_reads_device(dropest_shard *shard, const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene,
                                               const uint32_t *d_aux, uint64_t n, uint64_t first_ordinal);
+/* The same from host memory, batch by batch (pinned arrays are copied from in place, pageable ones staged; the copies run
+ * on their own stream under the caller's next batch): every batch continues the shard's range (first_ordinal = end of the
+ * previous batch).  The ranges of the shards must ascend with the rank and must not overlap -- received blocks, concatenated
+ * in source-rank order, are then in stream order; dropest_shard_step checks it.  Ranges may be of any length (a feeder
+ * that does not know the stream's length fills shard 0 up to a quota, then shard 1, ...: the exchange spreads the work). */
+dropest_status dropest_shard_push_reads(dropest_shard *shard, const uint64_t *cb, const uint64_t *umi, const uint32_t *gene,
+                                        const uint32_t *aux, uint64_t n, uint64_t first_ordinal);
 dropest_status dropest_shard_step(dropest_shard *shard);
 dropest_status dropest_shard_group_step(dropest_shard *const *shards, int32_t n);   /* one host thread per shard */
 dropest_status dropest_shard_matrix(dropest_shard *shard, int filtered, uint64_t *ncols, uint64_t *nnz, const uint64_t **colptr,

@@ -264,6 +264,70 @@ static void testPoissonMerge() {   // Tests/TestEstimationMergeProbs.cpp:30-91 (
 	CHECK_EQ(c.get_merge_target(7), long(-1));                                                          // :136-140
 }
 
+// The container over several GPUs (here: three shards on GPU 0): the reference's merge fixture (Tests/TestEstimation.cpp:33-80,
+// :241-261) and a synthetic stream of a few batches with N-UMIs must give the matrices and merged barcodes of ONE container.
+static void testShardedContainer() {
+	// (no UMI qualities here: they are a single-GPU feature)
+	auto read_info = [](const std::string &cb, const std::string &umi, const std::string &gene, const std::string &chr) {
+		return ReadInfo(Tools::ReadParameters(cb, umi), gene, chr, Mark(Mark::HAS_EXONS));
+	};
+	auto make = [&](const std::vector<int> &devices) {
+		auto strat = std::make_shared<Merge::RealBarcodesMergeStrategy>(Merge::RealBarcodesMergeStrategy::INDROP, g_data + "/test_est", 0, 0, 7, 0);
+		auto umis = std::make_shared<Merge::UMIs::MergeUMIsStrategySimple>(1);
+		return std::make_shared<CellsDataContainer>(strat, umis, Mark::get_by_code(Mark::DEFAULT_CODE), false, -1, devices);
+	};
+	auto feed = [&](CellsDataContainer &c) {
+		const char *reads[][3] = {{"AAATTAGGTCCA", "AAACCT", "Gene1"}, {"AAATTAGGTCCA", "CCCCCT", "Gene2"}, {"AAATTAGGTCCA", "ACCCCT", "Gene3"},
+			{"AAATTAGGTCCA", "ACCCCT", "Gene4"}, {"AAATTAGGTCCC", "CAACCT", "Gene1"}, {"AAATTAGGTCCC", "CAACCT", "Gene10"}, {"AAATTAGGTCCC", "CAACCT", "Gene20"},
+			{"AAATTAGGTCCG", "CAACCT", "Gene1"}, {"AAATTAGGTCGG", "AAACCT", "Gene1"}, {"AAATTAGGTCGG", "CCCCCT", "Gene2"}, {"CCCTTAGGTCCA", "CCATTC", "Gene3"},
+			{"CCCTTAGGTCCA", "CCCCCT", "Gene2"}, {"CCCTTAGGTCCA", "ACCCCT", "Gene3"}, {"CAATTAGGTCCG", "CAACCT", "Gene1"}, {"CAATTAGGTCCG", "AAACCT", "Gene1"},
+			{"CAATTAGGTCCG", "CCCCCT", "Gene2"}, {"AAAAAAAAAAAA", "CCCCCT", "Gene2"}};
+		for (auto &r : reads) c.add_record(read_info(r[0], r[1], r[2], "chr1"));
+		c.set_initialized(); c.merge_and_filter();
+	};
+	auto one = make({0}), three = make({0, 0, 0});
+	feed(*one); feed(*three);
+	CHECK(three->sharded() && !one->sharded());
+	ResultsPrinter printer(true, false);
+	for (bool filtered : {true, false}) {
+		const auto a = printer.get_count_matrix(*one, filtered, false), b = printer.get_count_matrix(*three, filtered, false);
+		CHECK(a.col_names == b.col_names); CHECK(a.row_names == b.row_names);
+		CHECK(a.colptr == b.colptr); CHECK(a.rowidx == b.rowidx); CHECK(a.values == b.values);
+		CHECK(!a.col_names.empty());
+	}
+	CHECK(one->merged_barcodes() == three->merged_barcodes());
+	CHECK_EQ(three->merged_barcodes().size(), size_t(4));          // targets 0 1 1 0 0 0 6: four cells merged away (:227-235)
+	CHECK_THROWS(three->cell(0), std::runtime_error);
+	CHECK_THROWS(three->filtered_cells(), std::runtime_error);
+
+	// several batches (BATCH = 2^20 reads each; shard k takes its quota of the stream, then shard k + 1), UMIs with N, no CB merge
+	auto big = [&](const std::vector<int> &devices) {
+		auto strat = std::make_shared<Merge::DummyMergeStrategy>(3, 5);
+		auto umis = std::make_shared<Merge::UMIs::MergeUMIsStrategySimple>(1);
+		auto c = std::make_shared<CellsDataContainer>(strat, umis, Mark::get_by_code(Mark::DEFAULT_CODE), false, -1, devices);
+		c->shard_quota = CellsDataContainer::BATCH;             // one batch per shard, the rest on the last one
+		uint64_t x = 88172645463325252ull;
+		auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+		auto seq = [&](uint64_t v, int len) { std::string s(size_t(len), 'A'); for (int i = 0; i < len; ++i) { s[size_t(i)] = "ACGT"[v & 3]; v >>= 2; } return s; };
+		const size_t n = 2 * CellsDataContainer::BATCH + 12345;
+		for (size_t i = 0; i < n; ++i) {
+			const uint64_t r = rnd();
+			std::string umi = seq(r >> 20, 6);
+			if ((r >> 50) % 200 == 0) umi[size_t((r >> 40) % 6)] = 'N';
+			c->add_record(read_info(seq((r % 300) * 7919 + 13, 12), umi, "G" + std::to_string((r >> 12) % 40), "chr" + std::to_string((r >> 8) % 3)));
+		}
+		c->set_initialized(); c->merge_and_filter();
+		return c;
+	};
+	auto b1 = big({0}), b2 = big({0, 0});
+	for (bool filtered : {true, false}) {
+		const auto a = printer.get_count_matrix(*b1, filtered, false), b = printer.get_count_matrix(*b2, filtered, false);
+		CHECK(a.col_names == b.col_names); CHECK(a.row_names == b.row_names);
+		CHECK(a.colptr == b.colptr); CHECK(a.rowidx == b.rowidx); CHECK(a.values == b.values);
+		CHECK(a.col_names.size() > 100);
+	}
+}
+
 int main(int argc, char **argv) {
 	g_data = argc > 1 ? argv[1] : "dropest_amd/data/barcodes";
 	const std::string tmp = argc > 2 ? argv[2] : "/tmp";
@@ -279,6 +343,7 @@ int main(int argc, char **argv) {
 		testPoissonMerge();
 		testUMIMerge();
 		testMergeAndExcludeCells();
+		testShardedContainer();
 	} catch (const std::exception &e) {
 		std::printf("UNEXPECTED EXCEPTION: %s\n", e.what());
 		return 2;

@@ -172,3 +172,54 @@ def test_one_shard_over_rccl_and_forced_exchange():
     ph = run.shard.phase_stats()
     assert ph["partition"]["steps"] == 2 and ph["all_to_all"]["steps"] == 2
     dev.free()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_batches_pushed_from_host(world):
+    """What the C++ facade does when it owns N GPUs: the stream arrives in batches from HOST memory (dropest_shard_push_reads);
+    a shard takes batches up to its quota, then the next shard starts -- ranges of unequal length, the last shard may get
+    nothing."""
+    s = SynthStream(n_reads=250_000, n_cells=40, n_genes=1500, umi_len=8)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    umi, side = inject_n(umi, gene, 5e-3, 3, 8)
+    kw = cfg_kwargs({"min_before": 10, "min_after": 20})
+    B = 40_000
+    g = ShardGroup([0] * world, **kw)
+    for sh in g.shards:
+        sh.set_side_strings(side)
+    quota = [3, 2][:world - 1]                       # batches per shard; the last shard takes the rest (world 3: two of them, one short)
+    shard_of = [i for i, q in enumerate(quota) for _ in range(q)]
+    for k, a in enumerate(range(0, len(cb), B)):
+        g.shards[shard_of[k] if k < len(shard_of) else world - 1].push_reads(cb[a:a + B], umi[a:a + B], gene[a:a + B], aux[a:a + B], a)
+    with pytest.raises(capi.DropestError):           # a batch that does not continue the shard's range
+        g.shards[0].push_reads(cb[:10], umi[:10], gene[:10], aux[:10], 5)
+    g.step()
+    s0 = g.shards[0]
+    got = {"cm": [x.copy() for x in s0.matrix(True)], "raw": [x.copy() for x in s0.matrix(False)], "merged": s0.merged_barcodes()}
+    g.close()
+    check(got, single((cb, umi, gene, aux), kw, side))
+
+
+def test_push_reads_from_pinned_and_pageable_memory_agree():
+    """dropest_push_reads copies from pinned arrays in place and stages pageable ones: same container either way, also when
+    the device arrays have to grow between batches."""
+    import ctypes as C
+    s = SynthStream(n_reads=3_000_000, n_cells=50, n_genes=2000)
+    arrays = [np.ascontiguousarray(a) for a in parity.canonical_stream(*s.generate_host())]
+    kw = cfg_kwargs(CFG)
+    ref = single(arrays, kw)                                     # pageable numpy memory: the staged path
+    L = capi.lib()
+    for a in arrays:                                             # page-lock the same arrays (hipHostRegister): the in-place path
+        d = C.c_void_p()
+        assert L.dropest_host_register(0, a.ctypes.data, a.nbytes, C.byref(d)) == 0
+    try:
+        c = capi.Context(**kw)
+        for at in range(0, len(arrays[0]), 700_000):
+            c.push_reads(*[a[at:at + 700_000] for a in arrays])
+        c.set_initialized(); c.merge_and_filter()
+        for filt in (True, False):
+            for x, y in zip(ref.count_matrix_csc(filtered=filt), c.count_matrix_csc(filtered=filt)):
+                assert np.array_equal(x, y)
+    finally:
+        for a in arrays:
+            L.dropest_host_unregister(0, a.ctypes.data)
