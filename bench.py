@@ -97,6 +97,34 @@ def cpu_baseline(stream, n_sample, cfg, name="C2"):
                       % (n_sample, name, " (with the whitelist CB merge)" if m else "", t1 - t0, t2 - t1, os.cpu_count() or 0)}
 
 
+# kernel-stat name (dropest_kernel_stats) -> start of the kernel's name in a rocprofv3 trace
+ROCPROF_NAME = {"cb_insert": "cb_insert_kernel", "build_keys": "build_keys_kernel", "ss_local:keys": "ss_local_kernel<0>",
+                "ss_local:key+1B": "ss_local_kernel<1>", "ss_scatter:L1:keys": "ss_scatter_l1_kernel<0", "ss_scatter:L2:keys": "ss_scatter_l2_kernel<0",
+                "ss_scatter:L1:key+1B": "ss_scatter_l1_kernel<1", "ss_scatter:L2:key+1B": "ss_scatter_l2_kernel<1", "ss_hist:L1": "ss_hist_l1_kernel",
+                "ss_hist:L2": "ss_hist_l2_kernel", "rs_scatter:keys": "rs_scatter_kernel_t<512, 8, false, 0, 8>",
+                "rs_scatter:key+1B": "rs_scatter_kernel_t<512, 8, false, 1, 8>", "rs_scatter": "rs_scatter_kernel_t<512, 16, true, 4, 8>"}
+
+
+def pmc_record(config, reads_per_gpu, sort):
+    """profiles/pmc_pipeline.json (scripts/pmc_summary.py) when it was taken on this workload, size and sort path."""
+    path = os.path.join(ROOT, "profiles", "pmc_pipeline.json")
+    try:
+        rec = json.load(open(path))
+    except Exception:
+        return None
+    if rec.get("workload") == config and rec.get("reads_per_gpu") == reads_per_gpu and rec.get("sort") == sort:
+        return rec
+    return None
+
+
+def pmc_kernel_bytes(stat_name, config, reads_per_gpu, sort):
+    rec, prefix = pmc_record(config, reads_per_gpu, sort), ROCPROF_NAME.get(stat_name)
+    if not rec or not prefix:
+        return None
+    hits = [v["hbm_bytes_per_launch"] for k, v in rec["per_kernel"].items() if k.startswith(prefix)]
+    return max(hits) if hits else None          # several grid sizes: the main launch
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -228,16 +256,7 @@ def main():
         if dom["launches"]:
             avg_ms = dom["ms"] / dom["launches"]
             achieved = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_rs_scatter.json")
-            if os.path.exists(pmc):
-                try:
-                    rec = json.load(open(pmc))
-                    # the PMC passes were taken on one kernel variant at one size: only quote them for that case
-                    if rec.get("kernel_stat_name") == dom_name and rec.get("records_per_launch") == reads_per_gpu:
-                        traffic = rec.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
+            traffic = pmc_kernel_bytes(dom_name, args.config, reads_per_gpu, get_layout()["sort"])
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
@@ -247,15 +266,8 @@ def main():
         cm_nnz, raw_nnz = int(len(out[0][1])), int(len(out[1][1]))
         compulsory = 24.0 * sizes["reads"] + 24.0 * sizes["molecules"] + 12.0 * (cm_nnz + raw_nnz) / max(1, world) + 40.0 * sizes["cells"]
         t_kernels_ms = sum(v["ms"] for k, v in table.items() if not k.startswith("host:")) / table_steps
-        measured = None
-        pmc_all = os.path.join(ROOT, "profiles", "pmc_pipeline.json")
-        if os.path.exists(pmc_all):
-            try:
-                rec = json.load(open(pmc_all))
-                if rec.get("workload") == args.config and rec.get("reads_per_gpu") == reads_per_gpu and rec.get("sort") == get_layout()["sort"]:
-                    measured = rec.get("hbm_bytes_per_step")
-            except Exception:
-                measured = None
+        rec = pmc_record(args.config, reads_per_gpu, get_layout()["sort"])
+        measured = rec["hbm_bytes_per_step"] if rec else None
         if roof is not None and t_kernels_ms > 0:
             roof["pipeline"] = {"compulsory_bytes": compulsory, "kernel_ms_per_step": round(t_kernels_ms, 3),
                                 "achieved_GBps": round(compulsory / (t_kernels_ms * 1e-3) / 1e9, 1),

@@ -489,9 +489,11 @@ bool dropest_ctx::splitter_sort_reduce() {
 	// (Measured at 1e8 reads: 256 x 256 buckets 4.05 ms for the whole sort, 256 x 512 buckets 4.2 ms -- the finer second
 	// partition costs what the finishing launch gains.)
 	int tb = 8;
-	while (tb < 18 && (uint64_t(n) >> tb) > 1600) ++tb;
-	if ((uint64_t(n) >> tb) > 4096) return false;   // > 1.07e9 records: buckets beyond the LDS sort
+	while (tb < 20 && (uint64_t(n) >> tb) > 1600) ++tb;
+	if (const char *e = getenv("DROPEST_SSORT_TB")) tb = std::min(20, std::max(8, atoi(e)));   // tests: any fan-out on any stream
+	if ((uint64_t(n) >> tb) > 4096) return false;   // > 4.3e9 records (never: a context holds < 2^32 reads)
 	const int fb1 = tb / 2, fb2 = tb - fb1;
+	const bool wide = fb2 > 9;                        // more than 512 buckets per level: the MAXF = 1024 kernels
 	const u32 F1 = 1u << fb1, Ff = 1u << fb2, F2 = F1 * Ff;
 	const int ms = layout.mark_shift, VB = layout.val_bytes;
 	const u32 os = u32(std::max<uint64_t>(1, std::min<uint64_t>(32, uint64_t(n) / (uint64_t(F2) * 2))));
@@ -521,17 +523,20 @@ bool dropest_ctx::splitter_sort_reduce() {
 	u32 nblocks = std::min<u32>(n_tiles, 1024);
 	const u32 tpb = div_up(n_tiles, nblocks);
 	nblocks = div_up(n_tiles, tpb);
-	rs_hist.ensure(size_t(F1) * nblocks); rs_row_total.ensure(SS_MAX_F); ss_base1.ensure(F1 + 1);
+	rs_hist.ensure(size_t(F1) * nblocks); rs_row_total.ensure(1024); ss_base1.ensure(F1 + 1);
 	timed("ss_hist:L1", double(n) * 8, [&] {
-		hipLaunchKernelGGL(ss_hist_l1_kernel, dim3(nblocks), dim3(SS_T), 0, stream, keys, n, ms, fb1, ss_coarse.p, tpb, rs_hist.p);
+		if (wide) hipLaunchKernelGGL(ss_hist_l1_kernel<1024>, dim3(nblocks), dim3(SS_T), 0, stream, keys, n, ms, fb1, ss_coarse.p, tpb, rs_hist.p);
+		else hipLaunchKernelGGL(ss_hist_l1_kernel<512>, dim3(nblocks), dim3(SS_T), 0, stream, keys, n, ms, fb1, ss_coarse.p, tpb, rs_hist.p);
 	});
 	timed("ss_scan", double(F1) * nblocks * 8, [&] {
 		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(F1), dim3(256), 0, stream, rs_hist.p, nblocks, rs_row_total.p);
-		hipLaunchKernelGGL(ss_scan_totals_kernel, dim3(1), dim3(SS_MAX_F), 0, stream, rs_row_total.p, F1, n, ss_base1.p);
+		if (wide) hipLaunchKernelGGL(ss_scan_totals_kernel<1024>, dim3(1), dim3(1024), 0, stream, rs_row_total.p, F1, n, ss_base1.p);
+		else hipLaunchKernelGGL(ss_scan_totals_kernel<512>, dim3(1), dim3(512), 0, stream, rs_row_total.p, F1, n, ss_base1.p);
 	});
 	timed(VB ? "ss_scatter:L1:key+1B" : "ss_scatter:L1:keys", double(n) * 2 * (8 + VB), [&] {
-		if (VB) hipLaunchKernelGGL(ss_scatter_l1_kernel<1>, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb1, ss_coarse.p, tpb, rs_hist.p, ss_base1.p);
-		else hipLaunchKernelGGL(ss_scatter_l1_kernel<0>, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb1, ss_coarse.p, tpb, rs_hist.p, ss_base1.p);
+		auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb1, ss_coarse.p, tpb, rs_hist.p, ss_base1.p); };
+		if (wide) { if (VB) go(ss_scatter_l1_kernel<1, 1024>); else go(ss_scatter_l1_kernel<0, 1024>); }
+		else { if (VB) go(ss_scatter_l1_kernel<1, 512>); else go(ss_scatter_l1_kernel<0, 512>); }
 	});
 
 	// L2: every coarse bucket into its own fine buckets
@@ -539,23 +544,26 @@ bool dropest_ctx::splitter_sort_reduce() {
 	ss_cnt2.ensure(size_t(F2) * parts); ss_bucket_base.ensure(F2); ss_bucket_cnt.ensure(F2); scalars.ensure(16);
 	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));   // [0] largest bucket, [1] molecule total
 	timed("ss_hist:L2", double(n) * 8, [&] {
-		hipLaunchKernelGGL(ss_hist_l2_kernel, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
+		if (wide) hipLaunchKernelGGL(ss_hist_l2_kernel<1024>, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
+		else hipLaunchKernelGGL(ss_hist_l2_kernel<512>, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
 	});
 	timed("ss_scan", double(F2) * parts * 8, [&] {
-		hipLaunchKernelGGL(ss_scan_seg_kernel, dim3(F1), dim3(SS_MAX_F), 0, stream, ss_cnt2.p, Ff, parts, ss_base1.p, ss_bucket_base.p, ss_bucket_cnt.p, scalars.p);
+		if (wide) hipLaunchKernelGGL(ss_scan_seg_kernel<1024>, dim3(F1), dim3(1024), 0, stream, ss_cnt2.p, Ff, parts, ss_base1.p, ss_bucket_base.p, ss_bucket_cnt.p, scalars.p);
+		else hipLaunchKernelGGL(ss_scan_seg_kernel<512>, dim3(F1), dim3(512), 0, stream, ss_cnt2.p, Ff, parts, ss_base1.p, ss_bucket_base.p, ss_bucket_cnt.p, scalars.p);
 	});
 	u32 max_cnt = 0;
 	fetch(&max_cnt, scalars.p, 4);
 	if (max_cnt > SS_LOCAL_MAX) return false;   // keys_a / vals_a are untouched: the LSD sort takes over
 	timed(VB ? "ss_scatter:L2:key+1B" : "ss_scatter:L2:keys", double(n) * 2 * (8 + VB), [&] {
-		if (VB) hipLaunchKernelGGL(ss_scatter_l2_kernel<1>, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
-		else hipLaunchKernelGGL(ss_scatter_l2_kernel<0>, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
+		auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p); };
+		if (wide) { if (VB) go(ss_scatter_l2_kernel<1, 1024>); else go(ss_scatter_l2_kernel<0, 1024>); }
+		else { if (VB) go(ss_scatter_l2_kernel<1, 512>); else go(ss_scatter_l2_kernel<0, 512>); }
 	});
 
 	// finishing sort: sparse molecule rows at each bucket's own record offset (key rows re-use the partition's alternate
 	// buffer), then scan of the per-bucket row counts and compaction into the dense table
 	const u32 SMALL_MAX = 2048;
-	ss_tmp.ensure(size_t(n) * 2 + 2); ss_n_loc.ensure(F2); ss_prefix.ensure(F2); ss_chunk.ensure(SS_MAX_F);
+	ss_tmp.ensure(size_t(n) * 2 + 2); ss_n_loc.ensure(F2); ss_prefix.ensure(F2); ss_chunk.ensure(1024);
 	SsLocalArgs a{};
 	a.keys = keys; a.vals = vals; a.bucket_base = ss_bucket_base.p; a.bucket_cnt = ss_bucket_cnt.p; a.n_buckets = F2; a.ms = ms;
 	a.t_key = keys_alt; a.t_reads = ss_tmp.p; a.t_agg = ss_tmp.p + n; a.n_loc = ss_n_loc.p;
@@ -584,10 +592,10 @@ bool dropest_ctx::splitter_sort_reduce() {
 		timed("ss_local:big", 0, [&] { if (VB) launch(ss_local_big_kernel<1>); else launch(ss_local_big_kernel<0>); });
 		HIP_CHECK(hipStreamSynchronize(stream));   // `big` (host vector) must outlive its copy
 	}
-	const u32 n_chunks = div_up(F2, SS_MAX_F);
+	const u32 n_chunks = div_up(F2, 1024);
 	timed("ss_scan", double(F2) * 12, [&] {
-		hipLaunchKernelGGL(ss_chunk_sums_kernel, dim3(n_chunks), dim3(SS_MAX_F), 0, stream, ss_n_loc.p, F2, ss_chunk.p);
-		hipLaunchKernelGGL(ss_prefix_kernel, dim3(n_chunks), dim3(SS_MAX_F), 0, stream, ss_n_loc.p, F2, ss_chunk.p, n_chunks, ss_prefix.p, scalars.p + 1);
+		hipLaunchKernelGGL(ss_chunk_sums_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_n_loc.p, F2, ss_chunk.p);
+		hipLaunchKernelGGL(ss_prefix_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_n_loc.p, F2, ss_chunk.p, n_chunks, ss_prefix.p, scalars.p + 1);
 	});
 	u32 total = 0;
 	fetch(&total, scalars.p + 1, 4);

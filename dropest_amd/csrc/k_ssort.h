@@ -26,7 +26,8 @@
 namespace dropest {
 
 constexpr int SS_T = 512, SS_I = 8, SS_TILE = SS_T * SS_I;   // partition tile: 4096 records
-constexpr int SS_MAX_F = 512;                                // fan-out of one partition level (power of two, 16..512)
+constexpr int SS_MAX_F = 512;                                // fan-out of one partition level (power of two, 16..512): kernels templated
+                                                             // on MAXF = 512; MAXF = 1024 serves streams beyond ~4e8 reads (two LDS slots per thread)
 constexpr uint32_t SS_LOCAL_MAX = 8192;                      // largest fine bucket the LDS sort takes (512 threads x 16)
 
 // ---- sample + splitters -----------------------------------------------------------------------------------------
@@ -80,11 +81,12 @@ __device__ inline void ss_hist_range(const unsigned long long *__restrict__ keys
 }
 
 // L1: block blk owns tiles [blk * tpb, (blk + 1) * tpb) of the whole array; hist[d * gridDim.x + blk]
+template <int MAXF>
 __global__ __launch_bounds__(SS_T) void ss_hist_l1_kernel(const unsigned long long *__restrict__ keys, uint32_t n, int ms, int fb,
                                                           const unsigned long long *__restrict__ coarse, uint32_t tiles_per_block,
                                                           uint32_t *__restrict__ hist) {
-	__shared__ unsigned long long sp[SS_MAX_F];
-	__shared__ uint32_t cnt[SS_MAX_F];
+	__shared__ unsigned long long sp[MAXF];
+	__shared__ uint32_t cnt[MAXF];
 	const uint32_t F = 1u << fb;
 	for (uint32_t j = threadIdx.x; j < F; j += SS_T) { sp[j] = j + 1 < F ? coarse[j] : ~0ull; cnt[j] = 0; }
 	__syncthreads();
@@ -97,11 +99,12 @@ __global__ __launch_bounds__(SS_T) void ss_hist_l1_kernel(const unsigned long lo
 }
 
 // row totals -> exclusive bases of the F coarse buckets; base[F] = n
-__global__ __launch_bounds__(SS_MAX_F) void ss_scan_totals_kernel(const uint32_t *__restrict__ row_total, uint32_t F, uint32_t n,
-                                                                   uint32_t *__restrict__ base) {
-	__shared__ uint32_t scratch[SS_MAX_F / 64 + 1];
+template <int MAXF>
+__global__ __launch_bounds__(MAXF) void ss_scan_totals_kernel(const uint32_t *__restrict__ row_total, uint32_t F, uint32_t n,
+                                                               uint32_t *__restrict__ base) {
+	__shared__ uint32_t scratch[MAXF / 64 + 1];
 	uint32_t total;
-	const uint32_t ex = block_excl_scan_u32<SS_MAX_F>(threadIdx.x < F ? row_total[threadIdx.x] : 0u, scratch, total);
+	const uint32_t ex = block_excl_scan_u32<MAXF>(threadIdx.x < F ? row_total[threadIdx.x] : 0u, scratch, total);
 	if (threadIdx.x < F) base[threadIdx.x] = ex;
 	if (threadIdx.x == 0) base[F] = n;
 }
@@ -116,11 +119,12 @@ __device__ inline void ss_l2_range(const uint32_t *__restrict__ base1, uint32_t 
 }
 
 // L2: block (s, p) = blockIdx.x / parts, % parts; cnt2[(s * F + d) * parts + p]
+template <int MAXF>
 __global__ __launch_bounds__(SS_T) void ss_hist_l2_kernel(const unsigned long long *__restrict__ keys, int ms, int fb,
                                                           const unsigned long long *__restrict__ fine, const uint32_t *__restrict__ base1,
                                                           uint32_t parts, uint32_t *__restrict__ cnt2) {
-	__shared__ unsigned long long sp[SS_MAX_F];
-	__shared__ uint32_t cnt[SS_MAX_F];
+	__shared__ unsigned long long sp[MAXF];
+	__shared__ uint32_t cnt[MAXF];
 	const uint32_t F = 1u << fb, s = blockIdx.x / parts, p = blockIdx.x % parts;
 	for (uint32_t j = threadIdx.x; j < F; j += SS_T) { sp[j] = j + 1 < F ? fine[size_t(s) * F + j] : ~0ull; cnt[j] = 0; }
 	__syncthreads();
@@ -133,16 +137,17 @@ __global__ __launch_bounds__(SS_T) void ss_hist_l2_kernel(const unsigned long lo
 
 // One block per coarse bucket s: turns cnt2[(s, f, p)] into absolute output cursors, writes base / size of every fine
 // bucket and the largest size.
-__global__ __launch_bounds__(SS_MAX_F) void ss_scan_seg_kernel(uint32_t *__restrict__ cnt2, uint32_t F, uint32_t parts,
-                                                                const uint32_t *__restrict__ base1, uint32_t *__restrict__ bucket_base,
-                                                                uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ max_cnt) {
-	__shared__ uint32_t scratch[SS_MAX_F / 64 + 1];
+template <int MAXF>
+__global__ __launch_bounds__(MAXF) void ss_scan_seg_kernel(uint32_t *__restrict__ cnt2, uint32_t F, uint32_t parts,
+                                                            const uint32_t *__restrict__ base1, uint32_t *__restrict__ bucket_base,
+                                                            uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ max_cnt) {
+	__shared__ uint32_t scratch[MAXF / 64 + 1];
 	const uint32_t s = blockIdx.x, f = threadIdx.x;
 	uint32_t *row = cnt2 + (size_t(s) * F + f) * parts;
 	uint32_t sum = 0;
 	if (f < F) for (uint32_t p = 0; p < parts; ++p) sum += row[p];
 	uint32_t total;
-	const uint32_t ex = block_excl_scan_u32<SS_MAX_F>(sum, scratch, total);
+	const uint32_t ex = block_excl_scan_u32<MAXF>(sum, scratch, total);
 	if (f < F) {
 		uint32_t run = base1[s] + ex;
 		bucket_base[size_t(s) * F + f] = run;
@@ -155,15 +160,16 @@ __global__ __launch_bounds__(SS_MAX_F) void ss_scan_seg_kernel(uint32_t *__restr
 
 // ---- partition: scatter --------------------------------------------------------------------------------------------
 // Records [begin, end) go to the F buckets whose running output cursors the caller has put into goff[] (LDS).
-template <int VB>
+template <int VB, int MAXF>
 __device__ inline void ss_scatter_range(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
                                         unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, uint32_t begin, uint32_t end,
                                         int ms, int fb, const unsigned long long *sp, uint32_t *goff, uint32_t *cnt, uint32_t *tstart,
                                         uint32_t *gdelta, uint32_t *scratch, unsigned long long *sk, uint16_t *sd, uint8_t *sv) {
+	constexpr int PER = MAXF / SS_T;   // table entries per thread: 1, or 2 with 1024 buckets
 	const uint32_t F = 1u << fb, tid = threadIdx.x;
 	for (uint32_t t0 = begin; t0 < end; t0 += SS_TILE) {
 		const uint32_t in_tile = end - t0 < uint32_t(SS_TILE) ? end - t0 : uint32_t(SS_TILE);
-		if (tid < F) cnt[tid] = 0;
+		for (uint32_t j = tid; j < F; j += SS_T) cnt[j] = 0;
 		lds_barrier();
 		unsigned long long key[SS_I];
 		uint8_t val[VB ? SS_I : 1];
@@ -183,10 +189,17 @@ __device__ inline void ss_scatter_range(const unsigned long long *__restrict__ k
 #pragma unroll
 		for (int i = 0; i < SS_I; ++i) rk[i] = (i * SS_T + tid) < in_tile ? atomicAdd(&cnt[pos[i]], 1u) : 0u;
 		lds_barrier();
-		const uint32_t c = tid < F ? cnt[tid] : 0u;
+		uint32_t c[PER], mine = 0;
+#pragma unroll
+		for (int k = 0; k < PER; ++k) { const uint32_t e = tid * PER + k; c[k] = e < F ? cnt[e] : 0u; mine += c[k]; }
 		uint32_t total;
-		const uint32_t ex = block_excl_scan_u32<SS_T, true>(c, scratch, total);
-		if (tid < F) { tstart[tid] = ex; gdelta[tid] = goff[tid] - ex; goff[tid] += c; }
+		uint32_t ex = block_excl_scan_u32<SS_T, true>(mine, scratch, total);
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			const uint32_t e = tid * PER + k;
+			if (e < F) { tstart[e] = ex; gdelta[e] = goff[e] - ex; goff[e] += c[k]; }
+			ex += c[k];
+		}
 		lds_barrier();
 #pragma unroll
 		for (int i = 0; i < SS_I; ++i)
@@ -205,20 +218,20 @@ __device__ inline void ss_scatter_range(const unsigned long long *__restrict__ k
 	}
 }
 
-#define SS_SCATTER_LDS(VB)                                                                                  \
-	__shared__ unsigned long long sp[SS_MAX_F];                                                             \
-	__shared__ uint32_t goff[SS_MAX_F], cnt[SS_MAX_F], tstart[SS_MAX_F], gdelta[SS_MAX_F], scratch[SS_T / 64 + 1]; \
+#define SS_SCATTER_LDS(VB, MAXF)                                                                            \
+	__shared__ unsigned long long sp[MAXF];                                                                 \
+	__shared__ uint32_t goff[MAXF], cnt[MAXF], tstart[MAXF], gdelta[MAXF], scratch[SS_T / 64 + 1];          \
 	__shared__ unsigned long long sk[SS_TILE];                                                              \
 	__shared__ uint16_t sd[SS_TILE];                                                                        \
 	__shared__ uint8_t sv[VB ? SS_TILE : 1];
 
-template <int VB>
+template <int VB, int MAXF>
 __global__ __launch_bounds__(SS_T) void ss_scatter_l1_kernel(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
                                                              unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, uint32_t n,
                                                              int ms, int fb, const unsigned long long *__restrict__ coarse,
                                                              uint32_t tiles_per_block, const uint32_t *__restrict__ hist,
                                                              const uint32_t *__restrict__ base1) {
-	SS_SCATTER_LDS(VB)
+	SS_SCATTER_LDS(VB, MAXF)
 	const uint32_t F = 1u << fb;
 	for (uint32_t j = threadIdx.x; j < F; j += SS_T) {
 		sp[j] = j + 1 < F ? coarse[j] : ~0ull;
@@ -228,15 +241,15 @@ __global__ __launch_bounds__(SS_T) void ss_scatter_l1_kernel(const unsigned long
 	const uint64_t b64 = uint64_t(blockIdx.x) * tiles_per_block * SS_TILE;
 	uint64_t e64 = b64 + uint64_t(tiles_per_block) * SS_TILE;
 	if (e64 > n) e64 = n;
-	if (b64 < n) ss_scatter_range<VB>(keys, vals, okeys, ovals, uint32_t(b64), uint32_t(e64), ms, fb, sp, goff, cnt, tstart, gdelta, scratch, sk, sd, sv);
+	if (b64 < n) ss_scatter_range<VB, MAXF>(keys, vals, okeys, ovals, uint32_t(b64), uint32_t(e64), ms, fb, sp, goff, cnt, tstart, gdelta, scratch, sk, sd, sv);
 }
 
-template <int VB>
+template <int VB, int MAXF>
 __global__ __launch_bounds__(SS_T) void ss_scatter_l2_kernel(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
                                                              unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, int ms, int fb,
                                                              const unsigned long long *__restrict__ fine, const uint32_t *__restrict__ base1,
                                                              uint32_t parts, const uint32_t *__restrict__ cnt2) {
-	SS_SCATTER_LDS(VB)
+	SS_SCATTER_LDS(VB, MAXF)
 	const uint32_t F = 1u << fb, s = blockIdx.x / parts, p = blockIdx.x % parts;
 	for (uint32_t j = threadIdx.x; j < F; j += SS_T) {
 		sp[j] = j + 1 < F ? fine[size_t(s) * F + j] : ~0ull;
@@ -245,7 +258,7 @@ __global__ __launch_bounds__(SS_T) void ss_scatter_l2_kernel(const unsigned long
 	__syncthreads();
 	uint32_t begin, end;
 	ss_l2_range(base1, s, p, parts, begin, end);
-	if (begin < end) ss_scatter_range<VB>(keys, vals, okeys, ovals, begin, end, ms, fb, sp, goff, cnt, tstart, gdelta, scratch, sk, sd, sv);
+	if (begin < end) ss_scatter_range<VB, MAXF>(keys, vals, okeys, ovals, begin, end, ms, fb, sp, goff, cnt, tstart, gdelta, scratch, sk, sd, sv);
 }
 
 // ---- finishing sort + reads -> molecules ---------------------------------------------------------------------------
@@ -433,26 +446,28 @@ inline size_t ss_local_lds_bytes(uint32_t cap, int threads) {
 }
 
 // ---- compaction of the sparse rows ---------------------------------------------------------------------------------
-// sums of n_loc over chunks of SS_MAX_F buckets
-__global__ __launch_bounds__(SS_MAX_F) void ss_chunk_sums_kernel(const uint32_t *__restrict__ n_loc, uint32_t n_buckets, uint32_t *__restrict__ chunk_sum) {
-	__shared__ uint32_t scratch[SS_MAX_F / 64 + 1];
-	const uint32_t i = blockIdx.x * SS_MAX_F + threadIdx.x;
+// sums of n_loc over chunks of MAXF buckets
+template <int MAXF>
+__global__ __launch_bounds__(MAXF) void ss_chunk_sums_kernel(const uint32_t *__restrict__ n_loc, uint32_t n_buckets, uint32_t *__restrict__ chunk_sum) {
+	__shared__ uint32_t scratch[MAXF / 64 + 1];
+	const uint32_t i = blockIdx.x * MAXF + threadIdx.x;
 	uint32_t total;
-	block_excl_scan_u32<SS_MAX_F>(i < n_buckets ? n_loc[i] : 0u, scratch, total);
+	block_excl_scan_u32<MAXF>(i < n_buckets ? n_loc[i] : 0u, scratch, total);
 	if (threadIdx.x == 0) chunk_sum[blockIdx.x] = total;
 }
 // exclusive prefix of n_loc (chunk c adds the sums of the chunks before it: at most 512 of them); total -> *n_mol
-__global__ __launch_bounds__(SS_MAX_F) void ss_prefix_kernel(const uint32_t *__restrict__ n_loc, uint32_t n_buckets, const uint32_t *__restrict__ chunk_sum,
-                                                              uint32_t n_chunks, uint32_t *__restrict__ prefix, uint32_t *__restrict__ n_mol) {
-	__shared__ uint32_t scratch[SS_MAX_F / 64 + 1];
+template <int MAXF>
+__global__ __launch_bounds__(MAXF) void ss_prefix_kernel(const uint32_t *__restrict__ n_loc, uint32_t n_buckets, const uint32_t *__restrict__ chunk_sum,
+                                                          uint32_t n_chunks, uint32_t *__restrict__ prefix, uint32_t *__restrict__ n_mol) {
+	__shared__ uint32_t scratch[MAXF / 64 + 1];
 	__shared__ uint32_t chunk_base;
 	uint32_t t1;
-	const uint32_t before = block_excl_scan_u32<SS_MAX_F>(threadIdx.x < n_chunks ? chunk_sum[threadIdx.x] : 0u, scratch, t1);
+	const uint32_t before = block_excl_scan_u32<MAXF>(threadIdx.x < n_chunks ? chunk_sum[threadIdx.x] : 0u, scratch, t1);
 	if (threadIdx.x == blockIdx.x) chunk_base = before;
 	__syncthreads();
-	const uint32_t i = blockIdx.x * SS_MAX_F + threadIdx.x;
+	const uint32_t i = blockIdx.x * MAXF + threadIdx.x;
 	uint32_t t2;
-	const uint32_t ex = block_excl_scan_u32<SS_MAX_F>(i < n_buckets ? n_loc[i] : 0u, scratch, t2);
+	const uint32_t ex = block_excl_scan_u32<MAXF>(i < n_buckets ? n_loc[i] : 0u, scratch, t2);
 	if (i < n_buckets) prefix[i] = chunk_base + ex;
 	if (blockIdx.x == 0 && threadIdx.x == 0) *n_mol = t1;
 }

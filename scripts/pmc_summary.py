@@ -1,6 +1,6 @@
 """Turns two rocprofv3 counter passes (FETCH_SIZE and WRITE_SIZE, collected separately as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes) into profiles/<round>_pmc_summary.csv and the per-launch HBM
-traffic record of the dominant kernel that bench.py quotes (profiles/pmc_rs_scatter.json).
+traffic records bench.py quotes (profiles/pmc_pipeline.json: every kernel of one step, and their sum).
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc/fetch -o r -- python bench.py --steps 1 --warmup 0 --cpu-sample 0
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc/write -o r -- python bench.py --steps 1 --warmup 0 --cpu-sample 0
@@ -71,29 +71,27 @@ def main():
         for r in rows:
             out.write('"%s",%d,%.1f,%.1f,%.1f,%.4g\n' % r)
     print("wrote", path)
-    # calibration check + dominant kernel record
+    # calibration check (kernels whose traffic is known exactly) + the records bench.py quotes
     by = {r[0]: r for r in rows}
-    hist = max((r for k, r in by.items() if k.startswith("rs_hist_kernel")), key=lambda r: r[2], default=None)
-    if hist:
-        print("calibration: rs_hist FETCH raw %.1f KB vs exact %.1f KB -> x%.3f" % (hist[2], 8.0 * n_records / 1024, 8.0 * n_records / 1024 / hist[2]))
-    # template arguments: <THREADS, ITEMS, PREFETCH, VB, RB>; the 8-bit-digit launches are the bulk of a sort
-    variants = {"rs_scatter:keys": (", 0, 8>", 16), "rs_scatter:key+1B": (", 1, 8>", 18), "rs_scatter": (", 4, 8>", 24)}
-    best = None
-    for stat_name, (suffix, bytes_per_rec) in variants.items():
-        for k, r in by.items():
-            base = k.split(" [grid")[0]
-            if base.startswith("rs_scatter_kernel_t") and base.endswith(suffix) and (best is None or r[5] > best[1][5]):
-                best = (stat_name, r, bytes_per_rec, k)   # the launches with the most traffic = the main sort's
-    if best:
-        stat_name, r, bpr, k = best
-        rec = {"kernel": k, "kernel_stat_name": stat_name, "records_per_launch": n_records, "workload": tag,
-               "fetch_kb_raw": r[2], "fetch_correction": 2.0, "write_kb": r[4], "hbm_bytes_per_launch": r[5],
-               "algorithmic_bytes_per_launch": float(bpr) * n_records, "amplification": r[5] / (float(bpr) * n_records),
-               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950), calibrated on "
-                         "rs_hist (8 B x N reads) and synth_kernel (24 B x N writes); see profiles/%s_pmc_summary.csv" % tag}
-        with open(os.path.join(out_dir, "pmc_rs_scatter.json"), "w") as out:
-            json.dump(rec, out, indent=1)
-        print("dominant:", json.dumps(rec))
+    for probe, exact in (("ss_hist_l1_kernel", 8.0 * n_records), ("rs_hist_kernel", 8.0 * n_records)):
+        hit = max((r for k, r in by.items() if k.startswith(probe)), key=lambda r: r[2], default=None)
+        if hit:
+            print("calibration: %s FETCH raw %.1f KB vs exact %.1f KB -> x%.3f" % (probe, hit[2], exact / 1024, exact / 1024 / hit[2]))
+    # everything one step launched, generator kernels aside: the pipeline's measured HBM traffic
+    skip = ("synth_kernel", "__amd_rocclr")
+    per_kernel = {k: {"launches": r[1], "hbm_bytes_per_launch": r[5]} for k, r in by.items() if not k.startswith(skip)}
+    copies = sum(r[1] * r[5] for k, r in by.items() if k.startswith("__amd_rocclr"))
+    total = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in per_kernel.values())
+    sort = "splitter" if any(k.startswith("ss_local_kernel") for k in by) else "lsd"
+    rec = {"workload": os.environ.get("DROPEST_PMC_WORKLOAD", "c2"), "reads_per_gpu": n_records, "sort": sort, "tag": tag,
+           "hbm_bytes_per_step": total, "runtime_copies_and_fills_bytes": copies, "per_kernel": per_kernel,
+           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over ONE bench.py step (--steps 1 --warmup 0); "
+                     "bytes = 1024 x (2 x FETCH_SIZE + WRITE_SIZE): FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section; checked on "
+                     "ss_hist_l1 = 8 B x N reads), WRITE_SIZE exact (checked on synth_kernel = 24 B x N writes); "
+                     "see profiles/%s_pmc_summary.csv" % tag}
+    with open(os.path.join(out_dir, "pmc_pipeline.json"), "w") as out:
+        json.dump(rec, out, indent=1)
+    print("pipeline: %.3f GB per step over %d kernels (%s sort); runtime copies / fills %.3f GB" % (total / 1e9, len(per_kernel), sort, copies / 1e9))
 
 
 if __name__ == "__main__":

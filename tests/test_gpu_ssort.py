@@ -30,6 +30,18 @@ def test_c2_shapes_use_the_splitter_path(splitter):
     tp._both(dict(n_cells=30, n_genes=1500), 60_000, 10, 10, levels="e", reads_output=True)
 
 
+@pytest.mark.parametrize("tb", [9, 13, 19, 20])
+def test_every_fan_out(splitter, monkeypatch, tb):
+    """F1 x F2 buckets with F1 = 2^(tb / 2), F2 = 2^(tb - tb / 2): odd splits, and the 1024-bucket kernels (tb 19, 20) that streams
+    beyond 4e8 reads take, forced on a small stream (most buckets empty or a handful of records)."""
+    monkeypatch.setenv("DROPEST_SSORT_TB", str(tb))
+    o, c = tp._both(dict(n_cells=60, n_genes=3000), 300_000, 10, 30)
+    assert c.sort_layout()["sort"] == "splitter"
+    if tb == 20:
+        monkeypatch.setenv("DROPEST_FORCE_BYTE_VALUES", "1")
+        tp._both(dict(n_cells=60, n_genes=4000, umi_len=12), 150_000, 20, 50)
+
+
 def test_key_plus_mark_byte_layout(splitter, monkeypatch):
     """C3's layout (the key uses all 64 bits, the mark travels as one byte) forced on a small v3 stream."""
     monkeypatch.setenv("DROPEST_FORCE_BYTE_VALUES", "1")
