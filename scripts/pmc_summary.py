@@ -81,7 +81,13 @@ def main():
     skip = ("synth_kernel", "__amd_rocclr")
     per_kernel = {k: {"launches": r[1], "hbm_bytes_per_launch": r[5]} for k, r in by.items() if not k.startswith(skip)}
     copies = sum(r[1] * r[5] for k, r in by.items() if k.startswith("__amd_rocclr"))
-    total = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in per_kernel.values())
+    # bench.py --steps 1 --warmup 0 runs the pass twice (the timed step + the kernel-table step): kernels launched once per
+    # pass tell how many passes the trace holds
+    passes = max([v["launches"] for k, v in per_kernel.items() if k.startswith(("cb_insert_kernel", "build_keys_kernel"))] + [1])
+    total = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in per_kernel.values()) / passes
+    copies /= passes
+    for v in per_kernel.values():
+        v["launches_per_step"] = v.pop("launches") / passes
     sort = "splitter" if any(k.startswith("ss_local_kernel") for k in by) else "lsd"
     rec = {"workload": os.environ.get("DROPEST_PMC_WORKLOAD", "c2"), "reads_per_gpu": n_records, "sort": sort, "tag": tag,
            "hbm_bytes_per_step": total, "runtime_copies_and_fills_bytes": copies, "per_kernel": per_kernel,
@@ -89,9 +95,10 @@ def main():
                      "bytes = 1024 x (2 x FETCH_SIZE + WRITE_SIZE): FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section; checked on "
                      "ss_hist_l1 = 8 B x N reads), WRITE_SIZE exact (checked on synth_kernel = 24 B x N writes); "
                      "see profiles/%s_pmc_summary.csv" % tag}
+    rec["passes_in_trace"] = passes
     with open(os.path.join(out_dir, "pmc_pipeline.json"), "w") as out:
         json.dump(rec, out, indent=1)
-    print("pipeline: %.3f GB per step over %d kernels (%s sort); runtime copies / fills %.3f GB" % (total / 1e9, len(per_kernel), sort, copies / 1e9))
+    print("pipeline: %.3f GB per step over %d kernels (%s sort, %d passes in the trace); runtime copies / fills %.3f GB per step" % (total / 1e9, len(per_kernel), sort, passes, copies / 1e9))
 
 
 if __name__ == "__main__":
