@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--sharded", action="store_true",
                     help="N = 1 only: run the pass through the sharded runner (partition by owner + RCCL all-to-all to itself + "
                          "shared result buffer) instead of the plain context: what a second GPU would add, measured on one")
+    ap.add_argument("--push-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_PUSH_SAMPLE", 5e7)),
+                    help="reads pushed from pinned host memory for the PCIe-inclusive rates (c2, N=1; 0 disables)")
     ap.add_argument("--cpu-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_CPU_SAMPLE", 6e6)),
                     help="reads of the same stream timed on the CPU oracle (rank 0, N=1 only; 0 disables)")
     return ap.parse_args()
@@ -123,6 +125,42 @@ def pmc_kernel_bytes(stat_name, config, reads_per_gpu, sort):
         return None
     hits = [v["hbm_bytes_per_launch"] for k, v in rec["per_kernel"].items() if k.startswith(prefix)]
     return max(hits) if hits else None          # several grid sizes: the main launch
+
+
+def push_rates(stream, local_rank, n_push, cfg_kw):
+    """The boundary's host path: n_push reads of the same stream in PINNED host arrays pushed through
+    dropest_push_reads (8 Mi-read batches, copied from in place on the copy stream) into a fresh context, then one pass.
+    Returns the push rate alone and the rate of push + pass -- the PCIe-inclusive figures; never `value`."""
+    import ctypes as C
+    from dropest_amd import capi
+    L = capi.lib()
+    dev = stream.generate_device(local_rank, first=0, n=n_push)
+    host = dev.to_host()
+    dev.free()
+    for a in host:
+        d = C.c_void_p()
+        if L.dropest_host_register(local_rank, a.ctypes.data, a.nbytes, C.byref(d)) != 0:
+            return None
+    try:
+        best_push, best_all = None, None
+        for _ in range(3):
+            ctx = capi.Context(device=local_rank, **cfg_kw)
+            L.dropest_reserve_reads(ctx.h, n_push)
+            t0 = time.perf_counter()
+            B = 8 << 20
+            for at in range(0, n_push, B):
+                ctx.push_reads(*[a[at:at + B] for a in host])
+            t1 = time.perf_counter()
+            one_step(ctx)
+            t2 = time.perf_counter()
+            best_push = min(best_push or 1e9, t1 - t0); best_all = min(best_all or 1e9, t2 - t0)
+            ctx.close()
+        return {"reads": n_push, "push_pinned_Mreads_per_s": round(n_push / best_push / 1e6, 1), "push_pinned_GB_per_s": round(n_push * 24 / best_push / 1e9, 1),
+                "push_plus_pass_Mreads_per_s": round(n_push / best_all / 1e6, 1),
+                "note": "pinned host arrays -> dropest_push_reads (8 Mi-read batches) -> set_initialized -> merge_and_filter -> both matrices; best of 3"}
+    finally:
+        for a in host:
+            L.dropest_host_unregister(local_rank, a.ctypes.data)
 
 
 def main():
@@ -293,6 +331,10 @@ def main():
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             cpu = cpu_baseline(stream, int(min(args.cpu_sample, total_reads)), cfg, args.config.upper())
+        ingest = None
+        if world == 1 and not force_sharded and args.push_sample > 0 and not merge:
+            ingest = push_rates(stream, local_rank, int(min(args.push_sample, total_reads)),
+                                dict(merge_kind=capi.MERGE_NONE, min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"]))
         cm = out[0]
         line = {
             "metric": "Mreads/s processed to final count matrix", "value": round(value, 2), "unit": "Mreads/s",
@@ -308,7 +350,7 @@ def main():
                                    + (", -M (Poisson decisions)" if args.poisson else ""),
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d%s" % (world, " (sharded runner, forced exchange)" if force_sharded else ""),
                        "cm_nnz": int(len(cm[1])), "filtered_cells": int(len(out[2])), "sort_layout": get_layout()},
-            "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "step_ms": step_ms, "kernels_ms_per_step": kernels,
+            "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "host_ingest": ingest, "step_ms": step_ms, "kernels_ms_per_step": kernels,
             "kernel_table": "separate pass of %d steps after the timed region, events on every launch" % table_steps,
             "host_stage_wall_ms_per_step": host_stages,
         }

@@ -241,6 +241,9 @@ struct dropest_ctx {
 	// ---- device results ----
 	dropest::DevBuf<dropest::CbSlot> t_slots;
 	dropest::DevBuf<u32> slot;
+	dropest::DevBuf<u64> hot_key;            // barcodes the 1/64 sample saw most often (k_cbhash.h): LDS table of cb_insert / build_keys
+	dropest::DevBuf<u32> hot_slot;
+	u32 n_hot = 0;
 	dropest::CbTable table{};
 	u32 n_cells = 0;
 	dropest::DevBuf<u64> cell_cb;

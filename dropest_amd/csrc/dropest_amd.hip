@@ -216,11 +216,29 @@ void dropest_ctx::build_cb_table() {
 		timed("cb_sample", double(n_s) * 8, [&] {
 			hipLaunchKernelGGL(cb_sample_distinct_kernel, dim3(std::min<u32>(div_up(n_s, 256), 2048u)), dim3(256), 0, stream, d_cb, n, stride, ts, scalars.p);
 		});
-		u32 distinct = 0;
-		fetch(&distinct, scalars.p, 4);
+		// ... and how many of the sampled barcodes reach 4, 16, ... sample hits: the hot list is the largest such set of at
+		// most CB_HOT_MAX barcodes (C2: the 5 000 real cells carry 92 % of the reads)
+		HIP_CHECK(hipMemsetAsync(scalars.p + 4, 0, 4 * CB_HOT_LEVELS, stream));
+		const bool want_hot = !getenv("DROPEST_CB_NO_HOT");
+		if (want_hot) hipLaunchKernelGGL(cb_hot_count_kernel, dim3(1024), dim3(256), 0, stream, ts, scalars.p + 4);
+		u32 head[4 + CB_HOT_LEVELS] = {0};
+		fetch(head, scalars.p, sizeof(head));
+		const u32 distinct = head[0];
 		const uint64_t est = std::min<uint64_t>(n_reads, uint64_t(distinct) * stride);
 		cap = 1024; while (cap < est + est / 2) cap <<= 1;   // load <= 0.67 even when the estimate is exact
-	}
+		n_hot = 0;
+		if (want_hot && cap < (1ull << 31)) {
+			int level = -1;
+			for (int l = 0; l < CB_HOT_LEVELS; ++l) if (head[4 + l] <= CB_HOT_MAX) { level = l; break; }
+			if (level >= 0 && head[4 + level] >= 16) {
+				hot_key.ensure(CB_HOT_MAX); hot_slot.ensure(CB_HOT_MAX);
+				HIP_CHECK(hipMemsetAsync(scalars.p + 1, 0, 4, stream));
+				hipLaunchKernelGGL(cb_hot_collect_kernel, dim3(1024), dim3(256), 0, stream, ts, cb_hot_threshold(level), hot_key.p, scalars.p + 1);
+				HIP_CHECK(hipGetLastError());
+				n_hot = head[4 + level];
+			}
+		}
+	} else n_hot = 0;
 	if (cap == 0) { cap = 1024; while (cap < n_reads / 2) cap <<= 1; }
 	if (cap & (cap - 1)) throw InvalidError("cb_table_capacity must be a power of two");
 	slot.ensure(n);
@@ -238,12 +256,31 @@ void dropest_ctx::build_cb_table() {
 		const bool vec = ((uintptr_t(d_cb) | uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;   // adopted arrays may sit anywhere
 		static const u32 grid_v = resident_grid(cb_insert_kernel<256, true>, 256, ~0u), grid_s = resident_grid(cb_insert_kernel<256, false>, 256, ~0u);
 		const u32 blocks = std::min<u32>(div_up(n, 256 * 4), vec ? grid_v : grid_s);
+		if (n_hot && attempt == 0 && cap < (1ull << 31)) {
+			// the hot barcodes take their slots first; one workgroup of 1024 threads per CU with the 128 KB LDS table
+			hipLaunchKernelGGL(cb_hot_preinsert_kernel, dim3(div_up(n_hot, 256)), dim3(256), 0, stream, hot_key.p, n_hot, table, hot_slot.p, &d_ingest.p->overflow);
+			HIP_CHECK(hipGetLastError());
+			const size_t lds = size_t(CB_HOT_LDS) * 16;
+			int cus = 0;
+			HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg.device));
+			const u32 hb = std::min<u32>(div_up(n, 1024 * 4), u32(std::max(1, cus)));
+			const CbHot hot{hot_key.p, hot_slot.p, n_hot};
+			timed("cb_insert", double(n) * (8 + 8 + 4 + 4 + 4), [&] {
+				auto go = [&](auto kernel) {
+					HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+					hipLaunchKernelGGL(kernel, dim3(hb), dim3(1024), lds, stream, d_cb, d_umi, d_gene, d_aux, n, table, hot, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
+				};
+				if (vec) go(cb_insert_hot_kernel<true>); else go(cb_insert_hot_kernel<false>);
+			});
+		} else {
+		n_hot = 0;   // (a rebuilt table: the slots of the first attempt are gone)
 		timed("cb_insert", double(n) * (8 + 8 + 4 + 4 + 4), [&] {
 			if (vec) hipLaunchKernelGGL((cb_insert_kernel<256, true>), dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table,
 			                            slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
 			else hipLaunchKernelGGL((cb_insert_kernel<256, false>), dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table,
 			                        slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
 		});
+		}
 		fetch(&ingest, d_ingest.p, sizeof(ingest));
 		if (!ingest.overflow) break;
 		if (attempt >= 6) throw DeviceError("barcode table overflow after repeated growth");
@@ -349,11 +386,16 @@ void dropest_ctx::build_keys() {
 	const bool vec = ((uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;
 	timed("build_keys", double(n) * (8 + 4 + 4 + 4 + 4 + 8 + layout.val_bytes), [&] {
 		void *v = vals_a.p;
+		const CbHot hot{hot_key.p, hot_slot.p, n_hot};
 		auto go = [&](auto kernel) {
 			const u32 blocks = resident_grid(kernel, 256, div_up(n, 256 * 4));
-			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p);
+			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p, hot);
 		};
-		if (layout.val_bytes == 0) { if (vec) go(build_keys_kernel<256, 0, true>); else go(build_keys_kernel<256, 0, false>); }
+		if (n_hot) {   // slot[] holds CB_HOT_FLAG | hot index for the reads of the hot barcodes
+			if (layout.val_bytes == 0) { if (vec) go(build_keys_kernel<256, 0, true, true>); else go(build_keys_kernel<256, 0, false, true>); }
+			else if (layout.val_bytes == 1) { if (vec) go(build_keys_kernel<256, 1, true, true>); else go(build_keys_kernel<256, 1, false, true>); }
+			else { if (vec) go(build_keys_kernel<256, 4, true, true>); else go(build_keys_kernel<256, 4, false, true>); }
+		} else if (layout.val_bytes == 0) { if (vec) go(build_keys_kernel<256, 0, true>); else go(build_keys_kernel<256, 0, false>); }
 		else if (layout.val_bytes == 1) { if (vec) go(build_keys_kernel<256, 1, true>); else go(build_keys_kernel<256, 1, false>); }
 		else { if (vec) go(build_keys_kernel<256, 4, true>); else go(build_keys_kernel<256, 4, false>); }
 	});
@@ -496,7 +538,8 @@ bool dropest_ctx::splitter_sort_reduce() {
 	const bool wide = fb2 > 9;                        // more than 512 buckets per level: the MAXF = 1024 kernels
 	const u32 F1 = 1u << fb1, Ff = 1u << fb2, F2 = F1 * Ff;
 	const int ms = layout.mark_shift, VB = layout.val_bytes;
-	const u32 os = u32(std::max<uint64_t>(1, std::min<uint64_t>(32, uint64_t(n) / (uint64_t(F2) * 2))));
+	// 64 samples per fine bucket: bucket sizes scatter by ~12 % around n / F2, so few exceed the small finishing launch
+	const u32 os = u32(std::max<uint64_t>(1, std::min<uint64_t>(64, uint64_t(n) / (uint64_t(F2) * 2))));
 	const u32 n_sample = F2 * os;
 	const u64 order_mask = ~((1ull << ms) - 1ull);
 	const u64 varying = (counters.key_or ^ counters.key_and) & order_mask;
@@ -576,21 +619,25 @@ bool dropest_ctx::splitter_sort_reduce() {
 			else hipLaunchKernelGGL(ss_local_kernel<0>, dim3(F2), dim3(256), lds, stream, a);
 		});
 	}
-	if (max_cnt > SMALL_MAX) {   // the few buckets beyond the small launch (a hot molecule): listed by the host, 512 threads x 16
-		std::vector<u32> cnts(F2), big;
+	if (max_cnt > SMALL_MAX) {   // the few buckets beyond the small launch (the tail of the size distribution, a hot molecule), listed by the host
+		std::vector<u32> cnts(F2), medium, big;
 		fetch(cnts.data(), ss_bucket_cnt.p, size_t(F2) * 4);
-		for (u32 b = 0; b < F2; ++b) if (cnts[b] > SMALL_MAX) big.push_back(b);
-		ss_big_list.ensure(big.size());
-		HIP_CHECK(hipMemcpyAsync(ss_big_list.p, big.data(), big.size() * 4, hipMemcpyHostToDevice, stream));
-		SsLocalArgs g = a;
-		g.big_list = ss_big_list.p; g.cap = SS_LOCAL_MAX; g.skip_above = SS_LOCAL_MAX;
-		const size_t lds = ss_local_lds_bytes(g.cap, 512);
-		auto launch = [&](auto kernel) {
+		for (u32 b = 0; b < F2; ++b) if (cnts[b] > SMALL_MAX) (cnts[b] <= 4096 ? medium : big).push_back(b);
+		ss_big_list.ensure(medium.size() + big.size());
+		if (!medium.empty()) HIP_CHECK(hipMemcpyAsync(ss_big_list.p, medium.data(), medium.size() * 4, hipMemcpyHostToDevice, stream));
+		if (!big.empty()) HIP_CHECK(hipMemcpyAsync(ss_big_list.p + medium.size(), big.data(), big.size() * 4, hipMemcpyHostToDevice, stream));
+		auto launch = [&](auto kernel, u32 threads, u32 cap, const u32 *list, size_t count) {
+			SsLocalArgs g = a;
+			g.big_list = list; g.cap = cap; g.skip_above = cap;
+			const size_t lds = ss_local_lds_bytes(cap, int(threads));
 			HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-			hipLaunchKernelGGL(kernel, dim3(u32(big.size())), dim3(512), lds, stream, g);
+			hipLaunchKernelGGL(kernel, dim3(u32(count)), dim3(threads), lds, stream, g);
 		};
-		timed("ss_local:big", 0, [&] { if (VB) launch(ss_local_big_kernel<1>); else launch(ss_local_big_kernel<0>); });
-		HIP_CHECK(hipStreamSynchronize(stream));   // `big` (host vector) must outlive its copy
+		timed("ss_local:big", 0, [&] {
+			if (!medium.empty()) { if (VB) launch(ss_local_big_kernel<256, 1>, 256, 4096, ss_big_list.p, medium.size()); else launch(ss_local_big_kernel<256, 0>, 256, 4096, ss_big_list.p, medium.size()); }
+			if (!big.empty()) { if (VB) launch(ss_local_big_kernel<512, 1>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); else launch(ss_local_big_kernel<512, 0>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); }
+		});
+		HIP_CHECK(hipStreamSynchronize(stream));   // the host lists must outlive their copies
 	}
 	const u32 n_chunks = div_up(F2, 1024);
 	timed("ss_scan", double(F2) * 12, [&] {

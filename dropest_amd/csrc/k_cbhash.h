@@ -188,19 +188,197 @@ __global__ __launch_bounds__(256) void cb_sample_distinct_kernel(const unsigned 
 	for (uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x; j * stride < n; j += uint64_t(gridDim.x) * 256) {
 		const unsigned long long k = cb[j * stride];
 		uint64_t h = mix64(k) & t.mask;
-		for (uint32_t probe = 0; probe < CB_MAX_PROBE; ++probe) {
+		bool found = false;
+		for (uint32_t probe = 0; probe < CB_MAX_PROBE && !found; ++probe) {
 			const unsigned long long cur = t.slots[h].key;
-			if (cur == k) break;
-			if (cur == 0ull) {
+			if (cur == k) found = true;
+			else if (cur == 0ull) {
 				const unsigned long long prev = atomicCAS(&t.slots[h].key, 0ull, k);
-				if (prev == 0ull) { ++mine; break; }
-				if (prev == k) break;
+				if (prev == 0ull) { ++mine; found = true; }
+				else if (prev == k) found = true;
 			}
-			h = (h + 1) & t.mask;
+			if (!found) h = (h + 1) & t.mask;
 		}
+		if (found) atomicAdd(&t.slots[h].nfirst, 1u);   // occurrences in the sample: the hot barcodes are picked by it
 	}
 	const unsigned long long tot = wave_reduce_add_u64(mine);
 	if (lane_id() == 0 && tot) atomicAdd(distinct, uint32_t(tot));
+}
+
+// ---- hot barcodes -------------------------------------------------------------------------------------------------
+// A 10x / inDrop stream puts > 90 % of its reads on a few thousand barcodes.  cb_insert and build_keys are bound by the
+// number of L2 requests -- every table probe is its own request, 1.5e8 of them for 1e8 reads -- so the barcodes the sample
+// saw most often (at most CB_HOT_MAX) get a read-only hash table in LDS: a hit costs no memory request at all.
+constexpr uint32_t CB_HOT_MAX = 4096, CB_HOT_LDS = 8192, CB_HOT_FLAG = 0x80000000u;
+constexpr int CB_HOT_LEVELS = 6;
+__device__ __host__ inline uint32_t cb_hot_threshold(int level) { return 4u << (2 * level); }   // 4, 16, 64, 256, 1024, 4096 sample hits
+// how many sampled barcodes reach each threshold
+__global__ __launch_bounds__(256) void cb_hot_count_kernel(CbTable ts, uint32_t *__restrict__ counts) {
+	uint32_t c[CB_HOT_LEVELS] = {0, 0, 0, 0, 0, 0};
+	for (uint64_t s = uint64_t(blockIdx.x) * 256 + threadIdx.x; s <= ts.mask; s += uint64_t(gridDim.x) * 256) {
+		if (ts.slots[s].key == 0ull) continue;
+		const uint32_t n = ts.slots[s].nfirst;
+#pragma unroll
+		for (int l = 0; l < CB_HOT_LEVELS; ++l) c[l] += n >= cb_hot_threshold(l);
+	}
+#pragma unroll
+	for (int l = 0; l < CB_HOT_LEVELS; ++l) {
+		const unsigned long long tot = wave_reduce_add_u64(c[l]);
+		if (lane_id() == 0 && tot) atomicAdd(&counts[l], uint32_t(tot));
+	}
+}
+__global__ __launch_bounds__(256) void cb_hot_collect_kernel(CbTable ts, uint32_t threshold, unsigned long long *__restrict__ hot_key,
+                                                             uint32_t *__restrict__ n_hot) {
+	for (uint64_t s = uint64_t(blockIdx.x) * 256 + threadIdx.x; s <= ts.mask; s += uint64_t(gridDim.x) * 256) {
+		const unsigned long long k = ts.slots[s].key;
+		if (k == 0ull || ts.slots[s].nfirst < threshold) continue;
+		const uint32_t at = atomicAdd(n_hot, 1u);
+		if (at < CB_HOT_MAX) hot_key[at] = k;
+	}
+}
+// the hot barcodes take their slots in the real table first
+__global__ __launch_bounds__(256) void cb_hot_preinsert_kernel(const unsigned long long *__restrict__ hot_key, uint32_t n_hot, CbTable t,
+                                                               uint32_t *__restrict__ hot_slot, uint32_t *__restrict__ overflow) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_hot) return;
+	bool ok = true;
+	hot_slot[i] = cb_find_or_insert(t, hot_key[i], mix64(hot_key[i]) & t.mask, ok);
+	if (!ok) atomicMax(overflow, 1u);
+}
+
+// cb_insert with the LDS table of the hot barcodes.  One workgroup of 1024 threads per CU (the table takes 128 KB of the
+// CU's 160 KB); slot_out[r] = CB_HOT_FLAG | hot index for a hit, the table slot otherwise.  Per-entry minimum of the read
+// ordinals seen by this workgroup keeps the atomics on the table to the few reads that lower it.
+struct CbHot { const unsigned long long *key; const uint32_t *slot; uint32_t n; };
+template <bool VEC>
+__global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long long *__restrict__ cb,
+                                                             const unsigned long long *__restrict__ umi,
+                                                             const uint32_t *__restrict__ gene,
+                                                             const uint32_t *__restrict__ aux, uint32_t n, CbTable t, CbHot hot,
+                                                             uint32_t *__restrict__ slot_out, uint32_t *__restrict__ gene_chr,
+                                                             uint32_t gene_chr_cap, IngestStats *stats) {
+	constexpr int ILP = 4, THREADS = 1024;
+	extern __shared__ __attribute__((aligned(16))) unsigned char cb_smem[];
+	unsigned long long *lk = reinterpret_cast<unsigned long long *>(cb_smem);          // [CB_HOT_LDS] key, 0 = empty
+	uint32_t *li = reinterpret_cast<uint32_t *>(lk + CB_HOT_LDS);                        // [CB_HOT_LDS] hot index
+	uint32_t *lf = li + CB_HOT_LDS;                                                      // [CB_HOT_LDS] smallest ordinal seen here
+	for (uint32_t j = threadIdx.x; j < CB_HOT_LDS; j += THREADS) { lk[j] = 0ull; lf[j] = 0xFFFFFFFFu; }
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < hot.n; j += THREADS) {
+		const unsigned long long k = hot.key[j];
+		uint32_t i = uint32_t(mix64(k) >> 40) & (CB_HOT_LDS - 1);
+		for (;;) {
+			const unsigned long long prev = atomicCAS(&lk[i], 0ull, k);
+			if (prev == 0ull) { li[i] = j; break; }
+			i = (i + 1) & (CB_HOT_LDS - 1);   // (hot keys are distinct: no equal key to find)
+		}
+	}
+	__syncthreads();
+
+	unsigned long long umin = ~0ull, umax = 0ull, uesc = 0ull, cbesc = 0ull;
+	uint32_t gmax = 0, cmax = 0;
+	bool ok = true, chr_conflict = false;
+	const uint64_t stride = uint64_t(gridDim.x) * THREADS * ILP;
+	for (uint64_t r0 = (uint64_t(blockIdx.x) * THREADS + threadIdx.x) * ILP; r0 < n; r0 += stride) {
+		unsigned long long k[ILP], u[ILP];
+		uint64_t h[ILP];
+		uint32_t g[ILP], a[ILP], sl[ILP], hit[ILP];
+		const bool full = r0 + ILP <= n;
+		if (VEC && full) {
+			const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(cb + r0), k23 = *reinterpret_cast<const ulonglong2 *>(cb + r0 + 2);
+			const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + r0), u23 = *reinterpret_cast<const ulonglong2 *>(umi + r0 + 2);
+			const uint4 g4 = *reinterpret_cast<const uint4 *>(gene + r0), a4 = *reinterpret_cast<const uint4 *>(aux + r0);
+			k[0] = k01.x; k[1] = k01.y; k[2] = k23.x; k[3] = k23.y;
+			u[0] = u01.x; u[1] = u01.y; u[2] = u23.x; u[3] = u23.y;
+			g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+			a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
+		} else {
+#pragma unroll
+			for (int j = 0; j < ILP; ++j) {
+				const uint64_t r = r0 + j;
+				k[j] = r < n ? cb[r] : 0ull; u[j] = r < n ? umi[r] : 0ull;
+				g[j] = r < n ? gene[r] : NO_GENE; a[j] = r < n ? aux[r] : 0u;
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) {   // LDS look-ups of the four barcodes
+			h[j] = mix64(k[j]);
+			hit[j] = 0xFFFFFFFFu;
+			if (r0 + j >= n) continue;
+			uint32_t i = uint32_t(h[j] >> 40) & (CB_HOT_LDS - 1);
+			for (;;) {
+				const unsigned long long e = lk[i];
+				if (e == k[j]) { hit[j] = i; break; }
+				if (e == 0ull) break;
+				i = (i + 1) & (CB_HOT_LDS - 1);
+			}
+		}
+		uint4 v[ILP];
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) {   // the others probe the table: independent 16-byte loads in flight together
+			h[j] &= t.mask;
+			v[j] = make_uint4(0u, 0u, 0u, 0u);
+			if (r0 + j < n && hit[j] == 0xFFFFFFFFu) v[j] = *reinterpret_cast<const uint4 *>(&t.slots[h[j]]);
+		}
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) {
+			const uint64_t r = r0 + j;
+			sl[j] = 0;
+			if (r >= n) continue;
+			if (hit[j] != 0xFFFFFFFFu) {
+				const uint32_t e = hit[j], hi = li[e];
+				sl[j] = CB_HOT_FLAG | hi;
+				if (uint32_t(r) < lf[e]) {
+					const uint32_t old = atomicMin(&lf[e], uint32_t(r));
+					if (uint32_t(r) < old) atomicMax(&t.slots[hot.slot[hi]].nfirst, ~uint32_t(r));
+				}
+			} else {
+				const unsigned long long cur = (unsigned long long)v[j].x | ((unsigned long long)v[j].y << 32);
+				uint32_t s2;
+				uint32_t first_hint = 0xFFFFFFFFu;
+				if (cur == k[j]) { s2 = uint32_t(h[j]); first_hint = ~v[j].z; }
+				else s2 = cb_find_or_insert(t, k[j], h[j], ok);
+				sl[j] = s2;
+				if (uint32_t(r) < first_hint) atomicMax(&t.slots[s2].nfirst, ~uint32_t(r));
+			}
+			if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
+			else { umin = u[j] < umin ? u[j] : umin; umax = u[j] > umax ? u[j] : umax; }
+			if (k[j] & ESCAPE_BIT) ++cbesc;
+			if (g[j] != NO_GENE && g[j] + 1 > gmax) gmax = g[j] + 1;
+			const uint32_t chr = a[j] & 0xFFFFu, mark = (a[j] >> 16) & 0xFFu;
+			if (g[j] == NO_GENE) { if (chr + 1 > cmax) cmax = chr + 1; }
+			else if (mark & 6u) {
+				if (chr + 1 > cmax) cmax = chr + 1;
+				if (g[j] >= gene_chr_cap) chr_conflict = true;
+				else {
+					uint32_t cur2 = gene_chr[g[j]];
+					if (cur2 == GENE_CHR_UNSET) cur2 = atomicCAS(&gene_chr[g[j]], GENE_CHR_UNSET, chr), cur2 = cur2 == GENE_CHR_UNSET ? chr : cur2;
+					if (cur2 != chr) chr_conflict = true;
+				}
+			}
+		}
+		if (VEC && full) *reinterpret_cast<uint4 *>(slot_out + r0) = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+		else {
+#pragma unroll
+			for (int j = 0; j < ILP; ++j) if (r0 + j < n) slot_out[r0 + j] = sl[j];
+		}
+	}
+	umin = wave_reduce_min_u64(umin); umax = wave_reduce_max_u64(umax); uesc = wave_reduce_max_u64(uesc);
+	cbesc = wave_reduce_add_u64(cbesc);
+	unsigned long long g64 = wave_reduce_max_u64(gmax);
+	unsigned long long c64 = wave_reduce_max_u64(cmax);
+	unsigned long long conf = wave_reduce_max_u64(chr_conflict ? 1ull : 0ull);
+	unsigned long long bad = wave_reduce_max_u64(ok ? 0ull : 1ull);
+	if (lane_id() == 0) {
+		if (umin != ~0ull) atomicMin(&stats->umi_clean_min, umin);
+		if (umax != 0ull) atomicMax(&stats->umi_clean_max, umax);
+		if (uesc) atomicMax(&stats->umi_escape_max_plus1, uesc);
+		if (cbesc) atomicAdd(&stats->cb_escape_count, cbesc);
+		if (g64) atomicMax(&stats->gene_max_plus1, uint32_t(g64));
+		if (bad) atomicMax(&stats->overflow, 1u);
+		if (c64) atomicMax(&stats->chr_max_plus1, uint32_t(c64));
+		if (conf) atomicMax(&stats->gene_chr_conflict, 1u);
+	}
 }
 
 // ---- cell ids from the table alone ---------------------------------------------------------------------------

@@ -47,13 +47,19 @@ struct GlobalCounters {   // CellsDataContainer.cpp:73-78, :309-327
 	unsigned long long key_or, key_and;
 };
 
-template <int THREADS, int VB, bool VEC>
+template <int THREADS, int VB, bool VEC, bool HOT = false>
 __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long long *__restrict__ umi,
                                                              const uint32_t *__restrict__ gene,
                                                              const uint32_t *__restrict__ aux,
                                                              const uint32_t *__restrict__ slot, uint32_t n, CbTable t,
                                                              KeyLayout L, unsigned long long *__restrict__ keys,
-                                                             void *__restrict__ vals_, GlobalCounters *gc) {
+                                                             void *__restrict__ vals_, GlobalCounters *gc, CbHot hot = CbHot{nullptr, nullptr, 0}) {
+	// the cell ids of the hot barcodes (k_cbhash.h): 16 KB of LDS instead of one L2 request per read
+	__shared__ uint32_t hot_cell[HOT ? CB_HOT_MAX : 1];
+	if (HOT) {
+		for (uint32_t j = threadIdx.x; j < hot.n; j += THREADS) hot_cell[j] = t.slots[hot.slot[j]].cell_id;
+		__syncthreads();
+	}
 	unsigned long long c_inter = 0, c_exon = 0, c_intron = 0, c_na = 0, k_or = 0, k_and = ~0ull;
 	// four CONSECUTIVE records per thread and iteration: 16-byte accesses per lane on every stream when the arrays are
 	// 16-byte aligned (VEC), then the four dependent gathers of the cell ids
@@ -81,7 +87,11 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 			}
 		}
 #pragma unroll
-		for (int q = 0; q < U; ++q) cell[q] = base + q < n ? t.slots[sl[q]].cell_id : 0u;
+		for (int q = 0; q < U; ++q) {
+			if (base + q >= n) cell[q] = 0u;
+			else if (HOT && (sl[q] & CB_HOT_FLAG)) cell[q] = hot_cell[sl[q] & ~CB_HOT_FLAG];
+			else cell[q] = t.slots[sl[q]].cell_id;
+		}
 #pragma unroll
 		for (int q = 0; q < U; ++q) {
 			const uint64_t r = base + q;

@@ -3,7 +3,7 @@
 //
 // Replaces, for the main sort of the pipeline, the 7-8 LSD passes of k_radix.h (each a histogram read + a scatter
 // read/write of every record) and the seg_count / seg_reduce<ReadsToMolecules*> launches behind them by
-//   ss_sample      F*F*OS keys at a fixed stride -> sorted with the LSD sort (a few MB) -> F*F-1 fine splitters, every F-th
+//   ss_sample      F1*F2*OS keys (OS = 64) at a fixed stride -> sorted with the LSD sort (a few MB) -> F*F-1 fine splitters, every F-th
 //                  of them a coarse splitter
 //   L1  ss_hist / scan / ss_scatter   all records into F coarse buckets (bucket = number of coarse splitters <= key,
 //                  branch-free binary search over the splitters in LDS)
@@ -430,12 +430,12 @@ __global__ __launch_bounds__(256) void ss_local_kernel(SsLocalArgs a) {
 	if (cnt <= 1024) ss_local_run<256, 4, VB>(a, b, base, cnt, ss_smem);
 	else ss_local_run<256, 8, VB>(a, b, base, cnt, ss_smem);
 }
-// big launch: grid = listed buckets, 512 threads x 16 records
-template <int VB>
-__global__ __launch_bounds__(512) void ss_local_big_kernel(SsLocalArgs a) {
+// listed buckets: medium launch 256 threads x 16 records (up to 4096), big launch 512 x 16 (up to 8192)
+template <int THREADS, int VB>
+__global__ __launch_bounds__(THREADS) void ss_local_big_kernel(SsLocalArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];
 	const uint32_t b = a.big_list[blockIdx.x];
-	ss_local_run<512, 16, VB>(a, b, a.bucket_base[b], a.bucket_cnt[b], ss_smem);
+	ss_local_run<THREADS, 16, VB>(a, b, a.bucket_base[b], a.bucket_cnt[b], ss_smem);
 }
 
 // bytes of dynamic LDS ss_local needs for `cap` records

@@ -19,12 +19,14 @@ __global__ __launch_bounds__(256) void quality_sums_kernel(const unsigned long l
                                                            const uint32_t *__restrict__ slot, uint32_t n, dropest::CbTable t,
                                                            dropest::KeyLayout L, const uint8_t *__restrict__ qual, uint32_t qlen,
                                                            const unsigned long long *__restrict__ mol_key, uint32_t n_mol,
-                                                           uint32_t *__restrict__ qsum, uint32_t *__restrict__ missing) {
+                                                           uint32_t *__restrict__ qsum, uint32_t *__restrict__ missing,
+                                                           const uint32_t *__restrict__ hot_slot) {
 	const uint32_t stride = gridDim.x * 256;
 	for (uint32_t r = blockIdx.x * 256 + threadIdx.x; r < n; r += stride) {
 		const uint32_t g = gene[r];
 		if (g == dropest::NO_GENE) continue;                       // reads without a gene never reach Gene::add_umi
-		const unsigned long long cell = t.slots[slot[r]].cell_id;
+		const uint32_t sl = slot[r];   // the table slot, or CB_HOT_FLAG | index into the hot list (k_cbhash.h)
+		const unsigned long long cell = t.slots[(sl & dropest::CB_HOT_FLAG) ? hot_slot[sl & ~dropest::CB_HOT_FLAG] : sl].cell_id;
 		const unsigned long long u = umi[r];
 		const unsigned long long ucode = (u & dropest::ESCAPE_BIT) ? (L.umi_escape_base + (u & ~dropest::ESCAPE_BIT)) : (u & L.umi_strip_mask);
 		const unsigned long long k = (cell << (L.gene_bits + L.umi_bits)) | ((unsigned long long)g << L.umi_bits) | ucode;
@@ -108,7 +110,7 @@ void dropest_ctx::accumulate_umi_qualities() {
 	const u32 n = u32(n_reads);
 	timed("quality_sums", double(n) * (20 + 5 * qual_len), [&] {
 		hipLaunchKernelGGL(quality_sums_kernel, dim3(std::min<u32>(div_up(n, 256), 16384u)), dim3(256), 0, stream, d_umi, d_gene, slot.p, n, table,
-		                   layout, umi_qual.p, qual_len, mol_key.p, n_mol, mol_qsum.p, scalars.p);
+		                   layout, umi_qual.p, qual_len, mol_key.p, n_mol, mol_qsum.p, scalars.p, hot_slot.p);
 	});
 	hipLaunchKernelGGL(iota_u32_kernel, dim3(div_up(n_mol, 256)), dim3(256), 0, stream, mol_qrow.p, n_mol);
 	HIP_CHECK(hipGetLastError());

@@ -172,6 +172,65 @@ def test_merge_properties_at_scale():
     dev.free()
 
 
+@pytest.mark.parametrize("shape", ["c3", "c5_share"])
+def test_full_size_1e9_reads_properties(shape):
+    """BASELINE configs[2] at FULL size (C3: 1e9 reads, 50 000 cells, UMI 12, -m + 10x whitelist) and the single-GPU share of
+    configs[4] (C5: 1e9 of 8e9 reads, 62 500 of 500 000 cells, UMI 12, no CB merge): far beyond the oracle, so size-independent
+    properties -- every read counted once, strictly ascending molecule keys, per-cell sums, CSC structure, merge targets final
+    whitelist cells -- checked on the device-resident tables through chunked accessors."""
+    c3 = shape == "c3"
+    s = SynthStream(n_reads=1_000_000_000, n_cells=50_000 if c3 else 62_500, n_genes=30000, umi_len=12, stream_id=3 if c3 else 5)
+    dev = s.generate_device(0)
+    kw = dict(min_genes_before_merge=20, min_genes_after_merge=100)
+    if c3:
+        kw.update(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST, barcodes_file=os.path.join(DATA, "10x_aug_2016_split"))
+    c = capi.Context(**kw)
+    c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
+    c.set_initialized()
+    n_real_before = c.real_cells_number()
+    c.merge_and_filter()
+    L = c.sort_layout()
+    assert L["cell_bits"] + L["gene_bits"] + L["umi_bits"] == 64 and L["value_bytes"] == 1 and L["sort"] == "splitter"
+    sizes = c.table_sizes()
+    assert sizes["reads"] == dev.n
+    rows = c.cell_rows()
+    counters = c.global_counters()
+    real = rows["is_real"].astype(bool)
+    merged = rows["is_merged"].astype(bool)
+    # reads: every gene-bearing read sits in exactly one cell's TOTAL_READS; merged sources keep their stale counter while
+    # the target's includes it (Stats::merge adds, Stats.cpp:29-43) -> count the cells that were never merged away
+    own = rows["total_reads"].astype(np.int64)
+    assert int(own[~merged].sum()) + int(counters[0]) == dev.n
+    p, i, v = c.count_matrix_csc(filtered=False)
+    assert len(p) - 1 == int(real.sum()) and np.all(np.diff(p.astype(np.int64)) == rows["n_genes"][real])
+    assert np.all(i < 30000) and np.all(v > 0)
+    # genes ascend strictly inside every column
+    d = np.diff(i.astype(np.int64)); starts = p[1:-1].astype(np.int64)
+    d[starts - 1] = 1
+    assert np.all(d > 0)
+    p2, i2, v2 = c.count_matrix_csc(filtered=True)
+    f = c.filtered_cells().astype(np.int64)
+    key = np.stack([rows["requested_genes"][f], rows["requested_umis"][f], rows["total_umis"][f]], axis=1).astype(np.int64)
+    assert np.all(np.lexsort((key[:, 2], key[:, 1], key[:, 0])) == np.arange(len(f))) or np.all(np.diff(key[:, 0]) >= 0)
+    assert int(key[:, 0].min()) >= 100 and np.all(np.diff(p2.astype(np.int64)) == rows["requested_genes"][f])
+    assert int(v2.astype(np.int64).sum()) == int(rows["requested_umis"][f].astype(np.int64).sum())
+    if c3:
+        mt = c.merge_targets().astype(np.int64)
+        src = np.nonzero(mt != np.arange(len(mt)))[0]
+        assert len(src) > 10_000 and np.all(rows["is_merged"][src] == 1) and np.all(mt[mt[src]] == mt[src])
+        wl_cells = set(int(x) for x in s.cell_cb)
+        assert all(int(b) in wl_cells for b in rows["barcode"][mt[src[:20000]]])
+        assert c.real_cells_number() < n_real_before
+    else:
+        assert int(real.sum()) >= 62_500 and int(rows["total_umis"].astype(np.int64)[real].sum()) == int(v.astype(np.int64).sum())
+    # a slice of the molecule table: strictly ascending (gene, umi) inside a cell, reads add up to the cell's counter
+    big = int(np.argmax(rows["total_reads"] * real))
+    g, u, r, m = c.cell_molecules(big)
+    k = (g.astype(np.uint64) << np.uint64(32)) | (u & np.uint64((1 << 24) - 1))
+    assert np.all(k[1:] > k[:-1]) and len(np.unique(g)) == rows["n_genes"][big]
+    dev.free()
+
+
 # ---------------------------------------------------------------------------------------------------
 # CB merge against a whitelist (RealBarcodesMergeStrategy)
 # ---------------------------------------------------------------------------------------------------
