@@ -1978,13 +1978,13 @@ dropest_status dropest_merge_target(dropest_ctx *ctx, uint64_t cell, int64_t *ta
 uint32_t dropest_owner_of(uint64_t barcode, uint32_t n_parts) { return n_parts ? uint32_t(mix64(barcode) % n_parts) : 0u; }
 
 static void partition_plan(u32 n, u32 &nblocks, u32 &tpb, size_t &off_k1, size_t &off_hist, size_t &off_row, size_t &off_base, size_t &total) {
-	const u32 n_tiles = div_up(n, RS_TILE_REC);
+	const u32 n_tiles = div_up(n, OP_TILE);
 	nblocks = std::min<u32>(std::max<u32>(n_tiles, 1u), 1024);
 	tpb = div_up(std::max<u32>(n_tiles, 1u), nblocks);
 	nblocks = div_up(std::max<u32>(n_tiles, 1u), tpb);
 	auto up = [](size_t x) { return (x + 255) & ~size_t(255); };
-	off_k1 = up(size_t(n) * 8);
-	off_hist = off_k1 + up(size_t(n) * 8);
+	off_k1 = 0;
+	off_hist = 0;
 	off_row = off_hist + up(size_t(RS_RADIX) * nblocks * 4);
 	off_base = off_row + up(size_t(RS_RADIX) * 4);
 	total = off_base + up(size_t(RS_RADIX) * 4);
@@ -2021,21 +2021,19 @@ static void partition_by_owner_on(int device, hipStream_t st, const u64 *d_cb, c
 		const u32 n = u32(n64);
 		for (u32 p = 0; p < n_parts; ++p) counts[p] = 0;
 		if (n == 0) return;
-		// one stable keys-only radix pass on the owner digit over (position, owner) records, then a gather of the four arrays
+		// owner histogram per workgroup, scans, then ONE pass that writes every read to its place (k_misc.h)
 		u32 nblocks, tpb; size_t off_k1, off_hist, off_row, off_base, total;
 		partition_plan(n, nblocks, tpb, off_k1, off_hist, off_row, off_base, total);
 		if (!d_scratch || scratch_bytes < total) throw InvalidError("partition scratch too small (dropest_partition_scratch_bytes)");
 		char *base = static_cast<char *>(d_scratch);
-		u64 *k0 = reinterpret_cast<u64 *>(base), *k1 = reinterpret_cast<u64 *>(base + off_k1);
 		u32 *hist = reinterpret_cast<u32 *>(base + off_hist), *row_total = reinterpret_cast<u32 *>(base + off_row);
 		u32 *digit_base = reinterpret_cast<u32 *>(base + off_base);
-		hipLaunchKernelGGL(owner_keys_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st, d_cb, n, n_parts, k0);
-		hipLaunchKernelGGL(rs_hist_kernel<8>, dim3(nblocks), dim3(RS_THREADS), 0, st, k0, n, 0, tpb, u32(RS_TILE_REC), hist);
+		const int owner_bits = std::max(1, bit_length(uint64_t(n_parts - 1)));
+		hipLaunchKernelGGL(owner_hist_kernel, dim3(nblocks), dim3(OP_T), 0, st, d_cb, n, n_parts, tpb, hist);
 		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, st, hist, nblocks, row_total);
 		hipLaunchKernelGGL(rs_scan_totals_kernel<256>, dim3(1), dim3(256), 0, st, row_total, digit_base);
-		rs_launch(0, 8, dim3(nblocks), st, k0, nullptr, k1, nullptr, n, 0, tpb, hist, digit_base);
-		hipLaunchKernelGGL(gather_reads_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, st, k1, n,
-		                   d_cb, d_umi, d_gene, d_aux, d_out_cb, d_out_umi, d_out_gene, d_out_aux, d_out_idx);
+		hipLaunchKernelGGL(owner_scatter_kernel, dim3(nblocks), dim3(OP_T), 0, st, d_cb, d_umi, d_gene, d_aux, n, n_parts, owner_bits, tpb, hist, digit_base,
+		                   d_out_cb, d_out_umi, d_out_gene, d_out_aux, d_out_idx);
 		HIP_CHECK(hipGetLastError());
 		std::vector<u32> totals(RS_RADIX);
 		HIP_CHECK(hipMemcpyAsync(totals.data(), row_total, RS_RADIX * 4, hipMemcpyDeviceToHost, st));

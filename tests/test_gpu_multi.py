@@ -223,3 +223,38 @@ def test_push_reads_from_pinned_and_pageable_memory_agree():
     finally:
         for a in arrays:
             L.dropest_host_unregister(0, a.ctypes.data)
+
+
+@pytest.mark.parametrize("n_parts", [1, 2, 3, 8, 64, 256])
+def test_partition_by_owner_is_stable_and_complete(n_parts):
+    """dropest_partition_by_owner: reads grouped by owner(cb) = mix64(cb) mod n, each owner's reads in stream order, every
+    read exactly once with its position -- at a size that is not a multiple of the tile."""
+    import ctypes as C
+    s = SynthStream(n_reads=1_000_003, n_cells=300, n_genes=2000)
+    arrays = s.generate_host()
+    n = len(arrays[0])
+    L = capi.lib()
+    src = capi.DeviceArrays.from_host(0, *arrays)
+    dst = capi.DeviceArrays(0, n)
+    idx = C.c_void_p(); scratch = C.c_void_p()
+    need = C.c_uint64()
+    assert L.dropest_partition_scratch_bytes(n, C.byref(need)) == 0
+    assert L.dropest_dev_alloc(0, n * 4, C.byref(idx)) == 0 and L.dropest_dev_alloc(0, max(need.value, 1), C.byref(scratch)) == 0
+    counts = np.zeros(n_parts, np.uint64)
+    rc = L.dropest_partition_by_owner(0, *src.ptrs, n, n_parts, *dst.ptrs, idx, counts.ctypes.data, scratch, need.value)
+    assert rc == 0, L.dropest_last_error()
+    out = dst.to_host()
+    pos = np.zeros(n, np.uint32)
+    assert L.dropest_dev_copy_to_host(0, pos.ctypes.data, idx, n * 4) == 0
+    owner = np.array([L.dropest_owner_of(int(c), n_parts) for c in arrays[0][:2000]])      # the library's own owner function ...
+    import test_multi_gloo as tg
+    all_owner = (tg.mix64(arrays[0].copy()) % np.uint64(n_parts)).astype(np.int64)           # ... equals mix64 mod n
+    assert np.array_equal(owner, all_owner[:2000])
+    assert np.array_equal(counts.astype(np.int64), np.bincount(all_owner, minlength=n_parts))
+    want = np.argsort(all_owner, kind="stable")
+    assert np.array_equal(pos.astype(np.int64), want)
+    for a, b in zip(arrays, out):
+        assert np.array_equal(a[want], b)
+    for p in (idx, scratch):
+        L.dropest_dev_free(0, p)
+    src.free(); dst.free()
