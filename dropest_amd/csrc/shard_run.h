@@ -519,12 +519,29 @@ std::vector<dropest::u32> dropest_shard::order_rows(const std::vector<u32> &sel,
 	const size_t m = sel.size();
 	std::vector<u32> out(sel);
 	if (m < 2) return out;
+	size_t device_min = 50000;
+	if (const char *e = getenv("DROPEST_DEVICE_SORT_MIN")) device_min = size_t(std::max(1, atoi(e)));
 	if (by_first) {
+		// every shard orders the real cells of ALL shards: at 8 GPUs that is ~10^6 rows -- one device radix sort, not a host sort
+		if (m >= device_min && m < 0xFFFFFFF0ull) {
+			const u32 mm = u32(m);
+			c.sort_stage.ensure(size_t(mm)); c.keys_a.ensure(mm); c.keys_b.ensure(mm); c.vals_a.ensure(mm); c.vals_b.ensure(mm);
+			u64 o = 0, a = ~0ull;
+			for (u32 k = 0; k < mm; ++k) { const u64 f = G[sel[k]].first_global; c.sort_stage.p[k] = f; o |= f; a &= f; }
+			u64 *k = c.keys_a.p, *k_alt = c.keys_b.p;
+			u32 *v = c.vals_a.p, *v_alt = c.vals_b.p;
+			HIP_CHECK(hipMemcpyAsync(k, c.sort_stage.p, size_t(mm) * 8, hipMemcpyHostToDevice, c.stream));
+			hipLaunchKernelGGL(iota_kernel, dim3(div_up(mm, 256)), dim3(256), 0, c.stream, v, mm);
+			c.radix_sort(k, v, k_alt, v_alt, mm, o ^ a);
+			u32 *perm = reinterpret_cast<u32 *>(c.sort_stage.p);
+			HIP_CHECK(hipMemcpyAsync(perm, v, size_t(mm) * 4, hipMemcpyDeviceToHost, c.stream));
+			HIP_CHECK(hipStreamSynchronize(c.stream));
+			for (u32 kk = 0; kk < mm; ++kk) out[kk] = sel[perm[kk]];
+			return out;
+		}
 		std::sort(out.begin(), out.end(), [&](u32 a, u32 b) { return G[a].first_global < G[b].first_global; });
 		return out;
 	}
-	size_t device_min = 50000;
-	if (const char *e = getenv("DROPEST_DEVICE_SORT_MIN")) device_min = size_t(std::max(1, atoi(e)));
 	bool uniform = true; u64 any = 0;
 	const int bl0 = bit_length(G[sel[0]].barcode);
 	for (u32 i : sel) { any |= G[i].barcode; uniform &= bit_length(G[i].barcode) == bl0; }
