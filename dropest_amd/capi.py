@@ -171,6 +171,8 @@ def lib():
         "dropest_shard_merged_barcodes": (C.c_int, [vp, u64p, vp, vp]),
         "dropest_shard_phase_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
         "dropest_shard_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+        "dropest_key_width": (C.c_int, [vp, P(C.c_uint32), P(C.c_uint32), P(C.c_uint32)]),
+        "dropest_ctx_split": (C.c_int, [vp, C.c_int32, vp]),
         "dropest_plan_columns": (C.c_int, [C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_int, C.c_uint32, C.c_int32, vp, C.c_uint64, u64p, vp]),
     }
     for name, (res, args) in sig.items():
@@ -202,6 +204,7 @@ EXPORTED_SYMBOLS = [
     "dropest_shard_unique_id", "dropest_shard_create", "dropest_shard_group_create", "dropest_shard_destroy", "dropest_shard_ctx",
     "dropest_shard_set_reads_device", "dropest_shard_push_reads", "dropest_reserve_reads", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix",
     "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option", "dropest_plan_columns",
+    "dropest_key_width", "dropest_ctx_split",
 ]
 
 
@@ -302,6 +305,12 @@ class Context:
 
     def set_initialized(self):
         self._chk(self.L.dropest_set_initialized(self.h))
+
+    def key_width(self):
+        """(cell, gene, UMI) field widths of the last key-layout plan, also of one that did not fit 64 bits."""
+        c, g, u = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.L.dropest_key_width(self.h, C.byref(c), C.byref(g), C.byref(u)))
+        return c.value, g.value, u.value
 
     def merge_and_filter(self):
         self._chk(self.L.dropest_merge_and_filter(self.h))

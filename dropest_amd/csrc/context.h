@@ -250,6 +250,7 @@ struct dropest_ctx {
 	dropest::DevBuf<u32> cell_first;
 	dropest::KeyLayout layout{};
 	int umi_clean_bits = 0;          // bits of a clean UMI code inside the key
+	u32 wanted_bits[3] = {0, 0, 0};  // cell / gene / UMI field widths of the last layout plan (also when it did not fit 64 bits)
 	bool umi_sentinel_stripped = false;
 	dropest::IngestStats ingest{};
 	dropest::GlobalCounters counters{};
@@ -353,6 +354,12 @@ struct dropest_ctx {
 
 	void concat_chunks();
 	void free_results();
+	// gives the large per-read / per-molecule tables back (the reads stay): a context that hands its reads to split shards
+	void release_tables() {
+		t_slots.release(); slot.release(); keys_a.release(); keys_b.release(); vals_a.release(); vals_b.release();
+		mol_key.release(); mol_reads.release(); mol_mark.release(); mol_key2.release(); mol_reads2.release(); mol_mark2.release();
+		mol_exon.release(); mol_intron.release(); mol_exon2.release(); mol_intron2.release();
+	}
 	void run_set_initialized();
 	void run_merge_and_filter();
 

@@ -349,10 +349,11 @@ void dropest_ctx::plan_key_layout() {
 	if (L.gene_bits == 0) L.gene_bits = 1;
 	L.gene_none = (1ull << L.gene_bits) - 1ull;
 	L.cell_bits = std::max(1, bit_length(uint64_t(n_cells ? n_cells - 1 : 0)));
+	wanted_bits[0] = u32(L.cell_bits); wanted_bits[1] = u32(L.gene_bits); wanted_bits[2] = u32(L.umi_bits);
 	if (L.umi_bits + L.gene_bits + L.cell_bits > 64)
 		throw UnsupportedError("sort key needs " + std::to_string(L.umi_bits + L.gene_bits + L.cell_bits) +
 		                       " bits (cell " + std::to_string(L.cell_bits) + " + gene " + std::to_string(L.gene_bits) +
-		                       " + UMI " + std::to_string(L.umi_bits) + "); this build sorts 64-bit keys");
+		                       " + UMI " + std::to_string(L.umi_bits) + "); one context sorts 64-bit keys -- the cell field shrinks when the stream is split by barcode: dropest_ctx_split");
 	if (L.gene_bits + L.umi_bits >= 64) throw UnsupportedError("gene + UMI field too wide");
 	// sort-record layout (k_misc.h): derive the chromosome from the gene when that is a function and the chromosome
 	// of a gene-less read fits the UMI field; then the mark rides in the key if 3 bits are free, else as one byte

@@ -309,13 +309,43 @@ void CellsDataContainer::set_initialized() {   // CellsDataContainer.cpp:163-175
 		check(dropest_set_umi_qualities(_ctx, _qual.data(), uint32_t(_umi_quality_length), _qual.size() / _umi_quality_length));
 		std::vector<uint8_t>().swap(_qual);
 	}
-	check(dropest_set_initialized(_ctx));
+	const dropest_status st = dropest_set_initialized(_ctx);
+	if (st == DROPEST_ERR_UNSUPPORTED && std::strstr(dropest_last_error(), "sort key needs")) {
+		// cell id + gene + UMI do not fit the 64-bit key of one context: the same reads as 2^k shards on the same device
+		// (dropest_ctx_split; every shard numbers 1 / 2^k of the barcodes).  merge_and_filter doubles k while a shard still fails.
+		uint32_t cb = 0, gb = 0, ub = 0;
+		check(dropest_key_width(_ctx, &cb, &gb, &ub));
+		_split_parts = 1;
+		while (_split_parts < 64 && int(cb + gb + ub) - 64 > int(__builtin_ctz(unsigned(_split_parts)))) _split_parts *= 2;
+		split_for_wide_keys();
+		_is_initialized = true;
+		return;
+	}
+	check(st);
 	_is_initialized = true;
+}
+
+void CellsDataContainer::split_for_wide_keys() {
+	for (dropest_shard *s : _shards) dropest_shard_destroy(s);
+	_shards.assign(size_t(_split_parts), nullptr);
+	const dropest_status st = dropest_ctx_split(_ctx, int32_t(_split_parts), _shards.data());
+	if (st != DROPEST_OK) { _shards.clear(); fail(st); }
 }
 
 void CellsDataContainer::merge_and_filter() {   // CellsDataContainer.cpp:39-57
 	if (!_is_initialized) throw std::runtime_error("You must initialize container");
-	if (sharded()) { check(dropest_shard_group_step(_shards.data(), int32_t(_shards.size()))); return; }
+	if (sharded()) {
+		for (;;) {
+			const dropest_status st = dropest_shard_group_step(_shards.data(), int32_t(_shards.size()));
+			if (st == DROPEST_ERR_UNSUPPORTED && _split_parts && _split_parts < 64 && std::strstr(dropest_last_error(), "sort key needs")) {
+				_split_parts *= 2;   // owners are not perfectly even: one more bit
+				split_for_wide_keys();
+				continue;
+			}
+			check(st);
+			return;
+		}
+	}
 	check(dropest_merge_and_filter(_ctx));
 }
 

@@ -281,6 +281,8 @@ private:
 	std::vector<dropest_shard *> _shards;
 	uint64_t _batches = 0;
 	size_t _side_sent = 0;
+	int _split_parts = 0;     // > 0: one device, the stream split over this many shards because the sort key passed 64 bits
+	void split_for_wide_keys();
 	[[noreturn]] void single_only(const char *what) const;
 	bool _is_initialized = false;
 	// host-side dictionaries (strings never reach the device)
@@ -320,6 +322,8 @@ public:
 	                   const std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> &umi_merge_strategy,
 	                   const std::vector<UMI::Mark> &gene_match_levels, bool save_umi_merge_targets, int max_cells_num,
 	                   const std::vector<int> &devices);
+	// A container on ONE device whose sort key (cell id + gene + UMI fields) passes 64 bits turns itself into such a sharded
+	// container at set_initialized(): the same reads as 2^k shards on that device (dropest_ctx_split), same restrictions.
 	bool sharded() const { return !_shards.empty(); }
 	dropest_shard *shard0() const { return _shards.empty() ? nullptr : _shards[0]; }
 	// (source, target) barcodes of the cells the CB merge folded: merge_targets() by barcode, also on a sharded container

@@ -949,6 +949,44 @@ dropest_status dropest_shard_group_create(const dropest_cfg *cfg, int32_t n, con
 	});
 }
 
+// Keys wider than 64 bits.  Of the three key fields only the cell field depends on how much of the stream a context sees:
+// split by barcode owner over `parts` shards ON THE CONTEXT'S OWN DEVICE, every shard numbers 1/parts of the cells.  The
+// shards read the context's resident reads in place (contiguous ordinal ranges, ascending with the shard).
+dropest_status dropest_ctx_split(dropest_ctx *ctx, int32_t parts, dropest_shard **out) {
+	if (!ctx || !out) { g_last_error = "null argument"; return DROPEST_ERR_INVALID; }
+	return guarded([&] {
+		if (parts < 2 || parts > 64) throw InvalidError("2..64 parts");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		if (ctx->n_reads == 0) throw InvalidError("no reads to split");
+		if (ctx->qual_len) throw UnsupportedError("UMI qualities are not carried by a split run");
+		ctx->concat_chunks();
+		ctx->free_results();
+		ctx->release_tables();   // the shards need the room; the reads stay
+		auto hub = std::make_shared<dropest::LocalHub>(parts);
+		std::vector<std::unique_ptr<dropest_shard>> made;
+		const uint64_t n = ctx->n_reads;
+		for (int i = 0; i < parts; ++i) {
+			made.emplace_back(make_shard(&ctx->cfg, i, parts));
+			dropest_shard &s = *made.back();
+			s.tr.reset(new dropest::LocalTransport(hub, i));
+			s.ctx->side = ctx->side;
+			const uint64_t a = n * uint64_t(i) / uint64_t(parts), b = n * uint64_t(i + 1) / uint64_t(parts);
+			s.r_cb = ctx->d_cb + a; s.r_umi = ctx->d_umi + a; s.r_gene = ctx->d_gene + a; s.r_aux = ctx->d_aux + a;
+			s.n_res = b - a; s.first_ordinal = a;
+		}
+		for (int i = 0; i < parts; ++i) out[i] = made[size_t(i)].release();
+	});
+}
+
+dropest_status dropest_key_width(dropest_ctx *ctx, uint32_t *cell_bits, uint32_t *gene_bits, uint32_t *umi_bits) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		if (cell_bits) *cell_bits = ctx->wanted_bits[0];
+		if (gene_bits) *gene_bits = ctx->wanted_bits[1];
+		if (umi_bits) *umi_bits = ctx->wanted_bits[2];
+	});
+}
+
 void dropest_shard_destroy(dropest_shard *s) {
 	if (!s) return;
 	(void)hipSetDevice(s->ctx->cfg.device);
@@ -1004,8 +1042,10 @@ dropest_status dropest_shard_group_step(dropest_shard *const *shards, int32_t n)
 			pool.emplace_back([&, i] { rc[size_t(i)] = dropest_shard_step(shards[i]); if (rc[size_t(i)] != DROPEST_OK) msg[size_t(i)] = dropest_last_error(); });
 		for (auto &t : pool) t.join();
 		for (int i = 0; i < n; ++i)
-			if (rc[size_t(i)] != DROPEST_OK && msg[size_t(i)].find("another shard of the group failed") == std::string::npos)
+			if (rc[size_t(i)] != DROPEST_OK && msg[size_t(i)].find("another shard of the group failed") == std::string::npos) {
+				if (rc[size_t(i)] == DROPEST_ERR_UNSUPPORTED) throw UnsupportedError("shard " + std::to_string(i) + ": " + msg[size_t(i)]);
 				throw InvalidError("shard " + std::to_string(i) + ": " + msg[size_t(i)]);
+			}
 		for (int i = 0; i < n; ++i) if (rc[size_t(i)] != DROPEST_OK) throw InvalidError("shard " + std::to_string(i) + ": " + msg[size_t(i)]);
 	});
 }

@@ -103,6 +103,20 @@ class Shard:
 class ShardGroup:
     """n shards in this process; devices[i] = GPU of shard i (several shards may share one)."""
 
+    @classmethod
+    def split(cls, ctx, parts):
+        """dropest_ctx_split: the reads of `ctx` (one context whose key did not fit 64 bits) as `parts` shards on its device."""
+        g = cls.__new__(cls)
+        g.L = capi.lib()
+        g._keep = ctx
+        out = (C.c_void_p * parts)()
+        rc = g.L.dropest_ctx_split(ctx.h, parts, out)
+        if rc != 0:
+            raise capi.DropestError(rc, g.L.dropest_last_error().decode())
+        g.shards = [Shard(out[i]) for i in range(parts)]
+        g._handles = (C.c_void_p * parts)(*[s.h.value for s in g.shards])
+        return g
+
     def __init__(self, devices, **cfg_kw):
         self.L = capi.lib()
         cfg, self._keep = capi.make_cfg(**cfg_kw)

@@ -434,6 +434,19 @@ dropest_status dropest_shard_phase_stats(dropest_shard *shard, uint32_t *n, drop
  * one shard: measures what a second shard would add), "reset_phase_stats" */
 dropest_status dropest_shard_set_option(dropest_shard *shard, const char *key, int64_t value);
 
+/* Sort keys wider than 64 bits.  The reference's containers have no such limit (StringIndexer.cpp:10-18: ids are size_t); one
+ * context packs cell id | gene | UMI into one 64-bit sort key and dropest_set_initialized fails with DROPEST_ERR_UNSUPPORTED
+ * ("sort key needs ... bits") when the three fields do not fit.  dropest_key_width reports the field widths of that plan.  Only
+ * the cell field depends on how much of the stream a context sees: dropest_ctx_split runs the SAME reads as `parts` (2..64)
+ * shards on the context's own device -- split by barcode owner like a multi-GPU run, every shard numbering 1/parts of the
+ * barcodes -- and writes the shard handles to out[parts]; drive them with dropest_shard_group_step and read the result with
+ * dropest_shard_matrix / dropest_shard_merged_barcodes on out[0].  The shards borrow the context's device-resident reads: the
+ * context must outlive them and must not be used for anything else meanwhile (its own tables are released).  What a sharded
+ * run does not support (-u, -M, -m without a whitelist, UMI qualities) is not supported here either; the gene + UMI fields
+ * alone must leave room for the cells of a shard. */
+dropest_status dropest_key_width(dropest_ctx *ctx, uint32_t *cell_bits, uint32_t *gene_bits, uint32_t *umi_bits);
+dropest_status dropest_ctx_split(dropest_ctx *ctx, int32_t parts, dropest_shard **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -328,6 +328,39 @@ static void testShardedContainer() {
 	}
 }
 
+static void testWideKeyContainer() {
+	// cell id + gene + UMI fields beyond 64 bits: the container splits itself over shards on its one device.  The same stream
+	// with the UMIs cut to their varying tail fits one context and must give the same matrices.
+	auto read_info = [](const std::string &cb, const std::string &umi, const std::string &gene, const std::string &chr) {
+		return ReadInfo(Tools::ReadParameters(cb, umi), gene, chr, Mark(Mark::HAS_EXONS));
+	};
+	auto run = [&](const std::string &umi_prefix) {
+		auto strat = std::make_shared<Merge::DummyMergeStrategy>(3, 5);
+		auto umis = std::make_shared<Merge::UMIs::MergeUMIsStrategySimple>(1);
+		auto c = std::make_shared<CellsDataContainer>(strat, umis, Mark::get_by_code(Mark::DEFAULT_CODE), false, -1, 0);
+		uint64_t x = 0x9E3779B97F4A7C15ull;
+		auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+		auto seq = [&](uint64_t v, int len) { std::string s(size_t(len), 'A'); for (int i = 0; i < len; ++i) { s[size_t(i)] = "ACGT"[v & 3]; v >>= 2; } return s; };
+		for (size_t i = 0; i < 400000; ++i) {
+			const uint64_t r = rnd();
+			std::string umi = seq(r >> 20, 6);
+			if ((r >> 50) % 300 == 0) umi[size_t((r >> 40) % 6)] = 'N';
+			c->add_record(read_info(seq((r % 2500) * 7919 + 13, 14), umi_prefix + umi, "G" + std::to_string((r >> 12) % 20000), "chr" + std::to_string((r >> 8) % 3)));
+		}
+		c->set_initialized(); c->merge_and_filter();
+		return c;
+	};
+	auto narrow = run(""), wide = run("ACGTTGCATGACCA");     // 6-base and 20-base UMIs: 13 / 41 UMI bits + 15 gene bits + 12 cell bits
+	CHECK(!narrow->sharded()); CHECK(wide->sharded());
+	ResultsPrinter printer(true, false);
+	for (bool filtered : {true, false}) {
+		const auto a = printer.get_count_matrix(*narrow, filtered, false), b = printer.get_count_matrix(*wide, filtered, false);
+		CHECK(a.col_names == b.col_names); CHECK(a.row_names == b.row_names);
+		CHECK(a.colptr == b.colptr); CHECK(a.rowidx == b.rowidx); CHECK(a.values == b.values);
+		CHECK(a.col_names.size() > 1000);
+	}
+}
+
 int main(int argc, char **argv) {
 	g_data = argc > 1 ? argv[1] : "dropest_amd/data/barcodes";
 	const std::string tmp = argc > 2 ? argv[2] : "/tmp";
@@ -344,6 +377,7 @@ int main(int argc, char **argv) {
 		testUMIMerge();
 		testMergeAndExcludeCells();
 		testShardedContainer();
+		testWideKeyContainer();
 	} catch (const std::exception &e) {
 		std::printf("UNEXPECTED EXCEPTION: %s\n", e.what());
 		return 2;
