@@ -335,11 +335,16 @@ struct dropest_ctx {
 	std::vector<hipEvent_t> event_pool;
 
 	// wall-clock time of a host stage (only while profiling); reported as "host:<name>" in the kernel stats
+	bool stage_sync = getenv("DROPEST_STAGE_SYNC") != nullptr;   // host-stage timers synchronise the stream (tuning aid, slows the pass)
 	struct HostStage {
 		dropest_ctx *c; const char *name; std::chrono::steady_clock::time_point t0;
-		HostStage(dropest_ctx *ctx, const char *n) : c(ctx), name(n), t0(std::chrono::steady_clock::now()) {}
+		HostStage(dropest_ctx *ctx, const char *n) : c(ctx), name(n) {
+			if (c->stage_sync && c->profiling) (void)hipStreamSynchronize(c->stream);   // diagnostic: charge queued work to the stage that queued it
+			t0 = std::chrono::steady_clock::now();
+		}
 		~HostStage() {
 			if (!c->profiling || !c->profile_only.empty()) return;
+			if (c->stage_sync) (void)hipStreamSynchronize(c->stream);
 			auto &s = c->stats[std::string("host:") + name];
 			s.launches++;
 			s.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

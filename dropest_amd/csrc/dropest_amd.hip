@@ -940,7 +940,9 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 			}
 			st2.reset();
 			auto st3 = std::make_unique<HostStage>(this, "sort_filtered:device");
-			HIP_CHECK(hipMemcpyAsync(sort_cols.p, sort_stage.p, size_t(m) * 3 * 8, hipMemcpyHostToDevice, stream));
+			{ HostStage sx(this, "sort_filtered:device:h2d");
+			HIP_CHECK(hipMemcpyAsync(sort_cols.p, sort_stage.p, size_t(m) * 3 * 8, hipMemcpyHostToDevice, stream)); }
+			auto sx2 = std::make_unique<HostStage>(this, "sort_filtered:device:sorts");
 			const u64 *d_code = sort_cols.p, *d_umis = sort_cols.p + m, *d_sizes = sort_cols.p + 2 * size_t(m);
 			u64 *k = keys_a.p, *k_alt = keys_b.p;
 			u32 *v = vals_a.p, *v_alt = vals_b.p;
@@ -953,7 +955,9 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 				HIP_CHECK(hipGetLastError());
 				radix_sort(k, v, k_alt, v_alt, m, nx.second);
 			}
+			sx2.reset();
 			u32 *perm = reinterpret_cast<u32 *>(sort_stage.p);              // the staging buffer is free again (stream order)
+			HostStage sx3(this, "sort_filtered:device:d2h");
 			HIP_CHECK(hipMemcpyAsync(perm, v, size_t(m) * 4, hipMemcpyDeviceToHost, stream));
 			HIP_CHECK(hipStreamSynchronize(stream));
 			st3.reset();
