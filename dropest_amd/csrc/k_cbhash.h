@@ -62,6 +62,31 @@ __device__ inline uint32_t cb_find_or_insert(const CbTable &t, unsigned long lon
 	return 0;
 }
 
+// The same for several keys of one thread at once: every round puts ONE request per unresolved key in flight before it waits
+// for any of them (one after the other, the keys of a thread cost a memory round trip each -- and nearly every wave has a
+// lane that needs one).  seen[j] = what the caller's own first load found at h[j] (0: the slot looked empty, anything else:
+// another barcode); the compare-and-swap doubles as the probe: it returns the occupant or claims the slot.
+template <int ILP>
+__device__ inline void cb_resolve_together(const CbTable &t, const unsigned long long (&k)[ILP], uint64_t (&h)[ILP],
+                                           unsigned long long (&seen)[ILP], uint32_t pending, uint32_t (&slot)[ILP], bool &ok) {
+	for (uint32_t probe = 0; pending && probe < CB_MAX_PROBE; ++probe) {
+		unsigned long long prev[ILP];
+#pragma unroll
+		for (int j = 0; j < ILP; ++j)
+			if ((pending >> j) & 1u) {
+				if (seen[j] != 0ull) h[j] = (h[j] + 1) & t.mask;
+				prev[j] = atomicCAS(&t.slots[h[j]].key, 0ull, k[j]);
+			}
+#pragma unroll
+		for (int j = 0; j < ILP; ++j)
+			if ((pending >> j) & 1u) {
+				if (prev[j] == 0ull || prev[j] == k[j]) { slot[j] = uint32_t(h[j]); pending &= ~(1u << j); }
+				else seen[j] = prev[j];
+			}
+	}
+	if (pending) ok = false;
+}
+
 __device__ inline uint32_t cb_find(const CbTable &t, unsigned long long k) {   // 0xFFFFFFFF if absent
 	uint64_t h = mix64(k) & t.mask;
 	for (uint32_t probe = 0; probe < CB_MAX_PROBE; ++probe) {
@@ -123,18 +148,25 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 				a[j] = r < n ? aux[r] : 0u;
 			}
 		}
+		uint32_t pending = 0, hinted = 0;
+		unsigned long long seen[ILP];
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) {
+			seen[j] = (unsigned long long)v[j].x | ((unsigned long long)v[j].y << 32);
+			sl[j] = uint32_t(h[j]);
+			if (r0 + j < n) {
+				if (seen[j] == k[j]) hinted |= 1u << j;   // found at once: v[j].z is a recent value of its first ordinal
+				else pending |= 1u << j;
+			}
+		}
+		if (pending) cb_resolve_together<ILP>(t, k, h, seen, pending, sl, ok);
 #pragma unroll
 		for (int j = 0; j < ILP; ++j) {
 			const uint64_t r = r0 + j;
-			sl[j] = 0;
 			if (r >= n) continue;
-			const unsigned long long cur = (unsigned long long)v[j].x | ((unsigned long long)v[j].y << 32);
-			uint32_t s;
-			uint32_t first_hint = 0xFFFFFFFFu;
-			if (cur == k[j]) { s = uint32_t(h[j]); first_hint = ~v[j].z; }
-			else s = cb_find_or_insert(t, k[j], h[j], ok);
-			sl[j] = s;
+			const uint32_t s = sl[j];
 			// stale (too large) hints only cost an extra atomic; ordinals only ever decrease
+			const uint32_t first_hint = ((hinted >> j) & 1u) ? ~v[j].z : 0xFFFFFFFFu;
 			if (uint32_t(r) < first_hint) atomicMax(&t.slots[s].nfirst, ~uint32_t(r));
 			if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
 			else { umin = u[j] < umin ? u[j] : umin; umax = u[j] > umax ? u[j] : umax; }
@@ -320,10 +352,21 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 			v[j] = make_uint4(0u, 0u, 0u, 0u);
 			if (r0 + j < n && hit[j] == 0xFFFFFFFFu) v[j] = *reinterpret_cast<const uint4 *>(&t.slots[h[j]]);
 		}
+		uint32_t pending = 0, hinted = 0;
+		unsigned long long seen[ILP];
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) {
+			seen[j] = (unsigned long long)v[j].x | ((unsigned long long)v[j].y << 32);
+			sl[j] = uint32_t(h[j]);
+			if (r0 + j < n && hit[j] == 0xFFFFFFFFu) {
+				if (seen[j] == k[j]) hinted |= 1u << j;   // found at once: v[j].z is a recent value of its first ordinal
+				else pending |= 1u << j;
+			}
+		}
+		if (pending) cb_resolve_together<ILP>(t, k, h, seen, pending, sl, ok);
 #pragma unroll
 		for (int j = 0; j < ILP; ++j) {
 			const uint64_t r = r0 + j;
-			sl[j] = 0;
 			if (r >= n) continue;
 			if (hit[j] != 0xFFFFFFFFu) {
 				const uint32_t e = hit[j], hi = li[e];
@@ -333,13 +376,8 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 					if (uint32_t(r) < old) atomicMax(&t.slots[hot.slot[hi]].nfirst, ~uint32_t(r));
 				}
 			} else {
-				const unsigned long long cur = (unsigned long long)v[j].x | ((unsigned long long)v[j].y << 32);
-				uint32_t s2;
-				uint32_t first_hint = 0xFFFFFFFFu;
-				if (cur == k[j]) { s2 = uint32_t(h[j]); first_hint = ~v[j].z; }
-				else s2 = cb_find_or_insert(t, k[j], h[j], ok);
-				sl[j] = s2;
-				if (uint32_t(r) < first_hint) atomicMax(&t.slots[s2].nfirst, ~uint32_t(r));
+				const uint32_t first_hint = ((hinted >> j) & 1u) ? ~v[j].z : 0xFFFFFFFFu;
+				if (uint32_t(r) < first_hint) atomicMax(&t.slots[sl[j]].nfirst, ~uint32_t(r));
 			}
 			if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
 			else { umin = u[j] < umin ? u[j] : umin; umax = u[j] > umax ? u[j] : umax; }
