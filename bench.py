@@ -100,7 +100,7 @@ def cpu_baseline(stream, n_sample, cfg, name="C2"):
 
 
 # kernel-stat name (dropest_kernel_stats) -> start of the kernel's name in a rocprofv3 trace
-ROCPROF_NAME = {"cb_insert": "cb_insert_kernel", "build_keys": "build_keys_kernel", "ss_local:keys": "ss_local_kernel<0>",
+ROCPROF_NAME = {"cb_insert": "cb_insert_", "build_keys": "build_keys_kernel", "ss_local:keys": "ss_local_kernel<0>",
                 "ss_local:key+1B": "ss_local_kernel<1>", "ss_scatter:L1:keys": "ss_scatter_l1_kernel<0", "ss_scatter:L2:keys": "ss_scatter_l2_kernel<0",
                 "ss_scatter:L1:key+1B": "ss_scatter_l1_kernel<1", "ss_scatter:L2:key+1B": "ss_scatter_l2_kernel<1", "ss_hist:L1": "ss_hist_l1_kernel",
                 "ss_hist:L2": "ss_hist_l2_kernel", "rs_scatter:keys": "rs_scatter_kernel_t<512, 8, false, 0, 8>",

@@ -286,7 +286,7 @@ void CellsDataContainer::flush() {
 		// shard 0, the next to shard 1, ... (the stream's length is not known while it arrives; the pass re-distributes the
 		// reads by barcode owner anyway, so WHERE they wait only decides which PCIe link carried them).
 		if (_side.size() != _side_sent) { for (dropest_shard *s : _shards) check(dropest_set_side_strings(dropest_shard_ctx(s), ptrs.data(), ptrs.size())); _side_sent = _side.size(); }
-		const size_t shard = std::min<size_t>(_shards.size() - 1, size_t(_batches / (shard_quota / BATCH)));
+		const size_t shard = std::min<size_t>(_shards.size() - 1, size_t(_batches / std::max<size_t>(1, shard_quota / BATCH)));
 		check(dropest_shard_push_reads(_shards[shard], _cb.data(), _umi.data(), _gene.data(), _aux.data(), _cb.size(), _batches * BATCH));
 		++_batches;
 		_cb.clear(); _umi.clear(); _gene.clear(); _aux.clear();
@@ -428,15 +428,70 @@ void CellsDataContainer::poisson_intersection(size_t cell1_ind, size_t cell2_ind
 }
 
 Cell CellsDataContainer::cell(size_t index) const {
+	if (sharded()) single_only("cell(index)");
 	Cell c;
-	c._owner = this; c._id = index;
+	c._owner = this; c._ctx = _ctx; c._id = index;
 	check(dropest_cell_rows(_ctx, index, 1, &c._row));   // DROPEST_ERR_RANGE -> std::out_of_range (vector::at in the reference)
 	c._barcode = decode(c._row.barcode);
 	return c;
 }
 
+std::vector<Cell> CellsDataContainer::real_cells() const {
+	std::vector<Cell> out;
+	if (!sharded()) {
+		const size_t n = total_cells_number();
+		std::vector<dropest_cell_row> rows(n);
+		if (n) check(dropest_cell_rows(_ctx, 0, n, rows.data()));
+		for (size_t i = 0; i < n; ++i) {
+			if (!rows[i].is_real) continue;
+			Cell c;
+			c._owner = this; c._ctx = _ctx; c._id = i; c._row = rows[i]; c._barcode = decode(rows[i].barcode);
+			out.push_back(std::move(c));
+		}
+		return out;
+	}
+	// the columns of the global cm_raw ARE the real cells in the cell-id order of one container
+	uint64_t ncols = 0, nnz = 0;
+	const uint64_t *bc = nullptr;
+	check(dropest_shard_matrix(_shards[0], 0, &ncols, &nnz, nullptr, nullptr, nullptr, &bc));
+	for (uint64_t j = 0; j < ncols; ++j) {
+		const uint32_t w = dropest_owner_of(bc[j], uint32_t(_shards.size()));
+		Cell c;
+		c._owner = this; c._ctx = dropest_shard_ctx(_shards[w]);
+		int64_t id = -1;
+		check(dropest_cell_id_by_cb(c._ctx, bc[j], &id));
+		if (id < 0) throw std::runtime_error("internal: a column of the global matrix is unknown to the shard that owns its barcode");
+		c._id = size_t(id);
+		check(dropest_cell_rows(c._ctx, c._id, 1, &c._row));
+		c._barcode = decode(bc[j]);
+		out.push_back(std::move(c));
+	}
+	return out;
+}
+
+std::vector<size_t> CellsDataContainer::filtered_positions(const std::vector<Cell> &real) const {
+	std::vector<size_t> out;
+	if (!sharded()) {
+		std::unordered_map<size_t, size_t> at;
+		for (size_t k = 0; k < real.size(); ++k) at.emplace(real[k]._id, k);
+		for (size_t id : filtered_cells()) out.push_back(at.at(id));
+		return out;
+	}
+	std::unordered_map<uint64_t, size_t> at;
+	for (size_t k = 0; k < real.size(); ++k) at.emplace(real[k]._row.barcode, k);
+	uint64_t ncols = 0, nnz = 0;
+	const uint64_t *bc = nullptr;
+	check(dropest_shard_matrix(_shards[0], 1, &ncols, &nnz, nullptr, nullptr, nullptr, &bc));
+	for (uint64_t j = 0; j < ncols; ++j) out.push_back(at.at(bc[j]));
+	return out;
+}
+
 CellsDataContainer::s_i_hash_t CellsDataContainer::get_stat_by_real_cells(Stats::CellStatType type) const {   // :278-289
 	s_i_hash_t res;
+	if (sharded()) {
+		for (const Cell &c : real_cells()) res[c.barcode()] = c.stat(type);
+		return res;
+	}
 	const size_t n = total_cells_number();
 	std::vector<dropest_cell_row> rows(n);
 	if (n) check(dropest_cell_rows(_ctx, 0, n, rows.data()));
@@ -447,6 +502,42 @@ CellsDataContainer::s_i_hash_t CellsDataContainer::get_stat_by_real_cells(Stats:
 
 void CellsDataContainer::get_stat_by_real_cells(Stats::CellChrStatType stat, names_t &cell_barcodes, names_t &chromosome_names,
                                                 counts_t &counts) const {   // :291-307, chromosomes in first-seen order
+	if (sharded()) {
+		// every shard reports the cells it owns; rows come out in the cell-id order of one container (real_cells())
+		struct Entry { uint64_t barcode; uint32_t chr; int32_t cnt; };
+		std::vector<Entry> entries;
+		std::vector<char> present(_chr_indexer.values().size(), 0);
+		for (dropest_shard *s : _shards) {
+			dropest_ctx *ctx = dropest_shard_ctx(s);
+			uint64_t n = 0;
+			check(dropest_chr_stats(ctx, &n, nullptr, nullptr, nullptr, nullptr));
+			std::vector<uint32_t> cell(n), kind(n), chr(n);
+			std::vector<int32_t> cnt(n);
+			if (n) check(dropest_chr_stats(ctx, &n, cell.data(), kind.data(), chr.data(), cnt.data()));
+			uint64_t nc = 0;
+			check(dropest_total_cells(ctx, &nc));
+			std::vector<dropest_cell_row> rows(nc);
+			if (nc) check(dropest_cell_rows(ctx, 0, nc, rows.data()));
+			for (size_t i = 0; i < n; ++i)
+				if (kind[i] == uint32_t(stat)) { present[chr[i]] = 1; entries.push_back(Entry{rows[cell[i]].barcode, chr[i], cnt[i]}); }
+		}
+		std::vector<int> column(present.size(), -1);
+		for (size_t c = 0; c < present.size(); ++c) if (present[c]) { column[c] = int(chromosome_names.size()); chromosome_names.push_back(_chr_indexer.get_value(c)); }
+		const size_t width = chromosome_names.size();
+		std::unordered_map<uint64_t, std::vector<int>> row_of;
+		for (const Entry &e : entries) {
+			auto it = row_of.find(e.barcode);
+			if (it == row_of.end()) it = row_of.emplace(e.barcode, std::vector<int>(width, 0)).first;
+			it->second[size_t(column[e.chr])] = e.cnt;
+		}
+		for (const Cell &c : real_cells()) {
+			auto it = row_of.find(c.barcode_code());
+			if (it == row_of.end()) continue;
+			cell_barcodes.push_back(c.barcode());
+			counts.insert(counts.end(), it->second.begin(), it->second.end());
+		}
+		return;
+	}
 	uint64_t n = 0;
 	check(dropest_chr_stats(_ctx, &n, nullptr, nullptr, nullptr, nullptr));
 	std::vector<uint32_t> cell(n), kind(n), chr(n);
@@ -489,7 +580,7 @@ size_t CellsDataContainer::has_not_annotated_reads_num() const { return size_t(c
 
 std::vector<Cell::MoleculeRow> Cell::molecules() const {
 	uint64_t n = 0;
-	dropest_ctx *h = _owner->handle();
+	dropest_ctx *h = _ctx ? _ctx : _owner->handle();
 	if (dropest_cell_molecules(h, _id, &n, nullptr, nullptr, nullptr, nullptr) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
 	std::vector<uint32_t> gene(n), reads(n);
 	std::vector<uint64_t> umi(n);
@@ -525,12 +616,11 @@ std::unordered_map<std::string, size_t> Cell::requested_umis_per_gene(const UMI:
 }
 
 // ---- ResultsPrinter ---------------------------------------------------------------------------------
-static ResultsPrinter::SparseMatrix sharded_matrix(const CellsDataContainer &c, dropest_shard *s0, bool filtered);
 
 ResultsPrinter::SparseMatrix ResultsPrinter::get_count_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order) const {
 	if (c.sharded()) {
 		if (reads_output) throw std::runtime_error("reads_output is not available on a container sharded over several GPUs");
-		return sharded_matrix(c, c.shard0(), filtered);
+		return sharded_matrix(c, filtered, reference_row_order);
 	}
 	uint64_t ncols = 0, nnz = 0;
 	const uint32_t *colptr = nullptr, *rowidx = nullptr, *values = nullptr;
@@ -559,33 +649,28 @@ ResultsPrinter::SparseMatrix ResultsPrinter::get_count_matrix_filtered(const Cel
 	return named_matrix(c, true, reference_row_order, ncols, nnz, colptr, rowidx, values);
 }
 
-// the global matrix of a sharded container: columns = the cells' barcodes in the order of ONE container, rows = the genes that
-// occur, in gene-index order
-static ResultsPrinter::SparseMatrix sharded_matrix(const CellsDataContainer &c, dropest_shard *s0, bool filtered) {
-	ResultsPrinter::SparseMatrix M;
+// the global matrix of a sharded container: columns = the cells' barcodes in the order of ONE container; rows named like on
+// one GPU
+ResultsPrinter::SparseMatrix ResultsPrinter::sharded_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order) const {
 	uint64_t ncols = 0, nnz = 0;
 	const uint64_t *colptr = nullptr, *bc = nullptr;
 	const uint32_t *rowidx = nullptr, *values = nullptr;
-	if (dropest_shard_matrix(s0, filtered ? 1 : 0, &ncols, &nnz, &colptr, &rowidx, &values, &bc) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
-	for (uint64_t j = 0; j < ncols; ++j) M.col_names.push_back(c.decode(bc[j]));
-	M.colptr.resize(ncols + 1);
-	for (uint64_t j = 0; j <= ncols; ++j) M.colptr[j] = uint32_t(colptr ? colptr[j] : 0);
-	M.values.assign(values, values + nnz);
-	M.rowidx.resize(nnz);
-	const auto &genes = c.gene_indexer().values();
-	std::vector<uint32_t> row_of_gene(genes.size(), 0xFFFFFFFFu);
-	std::vector<char> seen(genes.size(), 0);
-	for (uint64_t k = 0; k < nnz; ++k) seen[rowidx[k]] = 1;
-	for (uint32_t g = 0; g < genes.size(); ++g) if (seen[g]) { row_of_gene[g] = uint32_t(M.row_names.size()); M.row_names.push_back(genes[g]); }
-	for (uint64_t k = 0; k < nnz; ++k) M.rowidx[k] = row_of_gene[rowidx[k]];
-	return M;
+	if (dropest_shard_matrix(c.shard0(), filtered ? 1 : 0, &ncols, &nnz, &colptr, &rowidx, &values, &bc) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+	std::vector<std::string> names;
+	for (uint64_t j = 0; j < ncols; ++j) names.push_back(c.decode(bc[j]));
+	if (nnz > 0xFFFFFFF0ull) throw std::runtime_error("count matrix with more than 2^32 non-zeros");
+	std::vector<uint32_t> cp(ncols + 1, 0);
+	for (uint64_t j = 0; j <= ncols && colptr; ++j) cp[j] = uint32_t(colptr[j]);
+	return named_matrix(c, filtered, reference_row_order, ncols, nnz, cp.data(), rowidx, values, &names);
 }
 
 ResultsPrinter::SparseMatrix ResultsPrinter::named_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order, uint64_t ncols,
-                                                          uint64_t nnz, const uint32_t *colptr, const uint32_t *rowidx, const uint32_t *values) const {
+                                                          uint64_t nnz, const uint32_t *colptr, const uint32_t *rowidx, const uint32_t *values,
+                                                          const std::vector<std::string> *col_names) const {
 	SparseMatrix M;
 	// column names: filtered cells in their order / real cells in cell-id order
-	if (filtered) { for (size_t id : c.filtered_cells()) M.col_names.push_back(c.cell(id).barcode()); }
+	if (col_names) M.col_names = *col_names;
+	else if (filtered) { for (size_t id : c.filtered_cells()) M.col_names.push_back(c.cell(id).barcode()); }
 	else {
 		const size_t n = c.total_cells_number();
 		std::vector<dropest_cell_row> rows(n);
@@ -650,14 +735,12 @@ void ResultsPrinter::save_mtx(const CellsDataContainer &c, const std::string &ba
 Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 	using namespace Rds;
 	// both matrices are part of the list: cm_raw's emit + copy to the host start now, on the device's second stream, and
-	// run under the cell rows and cm
-	if (dropest_prefetch_raw_matrix(c.handle(), reads_output ? 1 : 0) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
-	const size_t n_cells = c.total_cells_number();
-	std::vector<dropest_cell_row> rows(n_cells);
-	if (n_cells && dropest_cell_rows(c.handle(), 0, n_cells, rows.data()) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
-	std::vector<size_t> real_ids;
+	// run under the cell rows and cm (a sharded container has assembled both already)
+	if (!c.sharded() && dropest_prefetch_raw_matrix(c.handle(), reads_output ? 1 : 0) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+	const std::vector<Cell> real = c.real_cells();                      // cell-id order (sharded: of ONE container over the stream)
+	const std::vector<size_t> filtered_at = c.filtered_positions(real);
 	std::vector<std::string> real_names;
-	for (size_t i = 0; i < n_cells; ++i) if (rows[i].is_real) { real_ids.push_back(i); real_names.push_back(c.decode(rows[i].barcode)); }
+	for (const Cell &cell : real) real_names.push_back(cell.barcode());
 
 	auto matrix = [&](bool filtered) {
 		const SparseMatrix M = get_count_matrix(c, filtered, true);
@@ -676,14 +759,14 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 
 	// one walk over the molecules of the real cells feeds mean_reads_per_umi, saturation_info, requested reads and
 	// (for the filtered cells) reads_per_umi_per_cell
-	std::vector<double> mean_rpu(real_ids.size());
-	std::vector<int32_t> sat_reads, req_umis(real_ids.size()), req_reads(real_ids.size());
+	std::vector<double> mean_rpu(real.size());
+	std::vector<int32_t> sat_reads, req_umis(real.size()), req_reads(real.size());
 	std::vector<std::string> sat_cbs, sat_umis;
-	std::unordered_map<size_t, std::vector<Cell::MoleculeRow>> filtered_mols;
-	std::vector<char> is_filtered(n_cells, 0);
-	for (size_t id : c.filtered_cells()) is_filtered[id] = 1;
-	for (size_t k = 0; k < real_ids.size(); ++k) {
-		const Cell cell = c.cell(real_ids[k]);
+	std::unordered_map<size_t, std::vector<Cell::MoleculeRow>> filtered_mols;   // by position in `real`
+	std::vector<char> is_filtered(real.size(), 0);
+	for (size_t k : filtered_at) is_filtered[k] = 1;
+	for (size_t k = 0; k < real.size(); ++k) {
+		const Cell &cell = real[k];
 		auto mols = cell.molecules();
 		double reads = 0;
 		size_t rr = 0;
@@ -697,17 +780,22 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 		mean_rpu[k] = reads / double(mols.size());                      // :225-249 (0/0 = NaN for a cell without UMIs, as in R)
 		req_umis[k] = int32_t(cell.requested_umis_num());               // :398-431
 		req_reads[k] = int32_t(rr);
-		if (umi_correction_info && is_filtered[real_ids[k]]) filtered_mols.emplace(real_ids[k], std::move(mols));
+		if (umi_correction_info && is_filtered[k]) filtered_mols.emplace(k, std::move(mols));
 	}
 
 	std::vector<std::pair<std::string, ValuePtr>> merged;               // :313-332: list(source barcode = target barcode)
-	{
+	if (c.sharded()) {   // (sources in barcode order: their cell ids are not part of the global table)
+		for (auto const &pr : c.merged_barcodes()) merged.emplace_back(pr.first, strings({pr.second}));
+	} else {
+		const size_t n_cells = c.total_cells_number();
+		std::vector<dropest_cell_row> rows(n_cells);
+		if (n_cells && dropest_cell_rows(c.handle(), 0, n_cells, rows.data()) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
 		const auto &mt = c.merge_targets();
 		for (size_t i = 0; i < mt.size(); ++i)
 			if (mt[i] != i) merged.emplace_back(c.decode(rows[i].barcode), strings({c.decode(rows[mt[i]].barcode)}));
 	}
-	std::vector<int32_t> aligned_reads(real_ids.size()), aligned_umis(real_ids.size());
-	for (size_t k = 0; k < real_ids.size(); ++k) { aligned_reads[k] = rows[real_ids[k]].total_reads; aligned_umis[k] = rows[real_ids[k]].total_umis; }
+	std::vector<int32_t> aligned_reads(real.size()), aligned_umis(real.size());
+	for (size_t k = 0; k < real.size(); ++k) { aligned_reads[k] = real[k].stat(Stats::TOTAL_READS_PER_CB); aligned_umis[k] = real[k].stat(Stats::TOTAL_UMIS_PER_CB); }
 
 	std::vector<std::pair<std::string, ValuePtr>> d = {
 		{"cm", matrix(true)},
@@ -730,10 +818,10 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 		StringIndexer cell_ix, gene_ix;
 		std::vector<int32_t> cell_indexes, gene_indexes;
 		std::vector<ValuePtr> per_gene;
-		for (size_t id : c.filtered_cells()) {
-			auto it = filtered_mols.find(id);
+		for (size_t k : filtered_at) {
+			auto it = filtered_mols.find(k);
 			if (it == filtered_mols.end()) continue;
-			const int32_t ci = int32_t(cell_ix.add(c.decode(rows[id].barcode)));
+			const int32_t ci = int32_t(cell_ix.add(real_names[k]));
 			std::vector<ValuePtr> umis; std::vector<std::string> umi_names;
 			std::string cur;
 			auto close = [&]() {

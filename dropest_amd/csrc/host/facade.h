@@ -237,6 +237,7 @@ class CellsDataContainer;
 class Cell {
 	friend class CellsDataContainer;
 	const CellsDataContainer *_owner = nullptr;
+	dropest_ctx *_ctx = nullptr;      // the context the cell lives in (a sharded container: the owner shard's)
 	size_t _id = 0;
 	dropest_cell_row _row{};
 	std::string _barcode;
@@ -250,6 +251,7 @@ public:
 			return res;
 		}
 	};
+	uint64_t barcode_code() const { return _row.barcode; }
 	bool is_merged() const { return _row.is_merged; }
 	bool is_excluded() const { return _row.is_excluded; }
 	bool is_real() const { return _row.is_real; }
@@ -315,9 +317,12 @@ public:
 	                   const std::vector<UMI::Mark> &gene_match_levels, bool save_umi_merge_targets = false,
 	                   int max_cells_num = -1, int device = 0);
 	// The same container over several GPUs (the path shards by cell barcode): `devices` = one HIP ordinal per shard.  add_record,
-	// set_initialized, merge_and_filter and ResultsPrinter::get_count_matrix / save_mtx work as on one GPU -- results are those of
-	// ONE container over the whole stream --; the per-cell accessors (cell(i), merge_targets(), ...) and the strategies other than
-	// Dummy / RealBarcodes + the default UMI merge need the single-GPU container and throw std::runtime_error here.
+	// set_initialized, merge_and_filter and ResultsPrinter::save_results (the whole R list: both matrices, per-chromosome frames,
+	// saturation info, per-cell counts, reads_per_umi_per_cell) / get_count_matrix / save_mtx work as on one GPU -- results are
+	// those of ONE container over the whole stream: real_cells() lists the real cells in that container's cell-id order, each
+	// answering from the shard that owns it --; accessors BY CELL ID (cell(i), merge_targets(), filtered_cells(), ...) and the
+	// strategies other than Dummy / RealBarcodes + the default UMI merge need the single-GPU container and throw
+	// std::runtime_error here.
 	CellsDataContainer(const std::shared_ptr<Merge::MergeStrategyAbstract> &merge_strategy,
 	                   const std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> &umi_merge_strategy,
 	                   const std::vector<UMI::Mark> &gene_match_levels, bool save_umi_merge_targets, int max_cells_num,
@@ -374,6 +379,11 @@ public:
 	void get_stat_by_real_cells(Stats::CellChrStatType stat, names_t &cell_barcodes, names_t &chromosome_names,
 	                            counts_t &counts) const;
 	Cell cell(size_t index) const;                                      // throws std::out_of_range
+	// every real cell in cell-id order -- also on a sharded container, where that is the order of first appearance in the WHOLE
+	// stream and every Cell answers from the shard that owns its barcode -- and the positions of the filtered cells in that list
+	// (in filtered_cells() order).  ResultsPrinter::results_list is written on these two.
+	std::vector<Cell> real_cells() const;
+	std::vector<size_t> filtered_positions(const std::vector<Cell> &real) const;
 
 	size_t intergenic_reads_num() const;
 	size_t has_exon_reads_num() const;
@@ -409,7 +419,9 @@ public:
 	void save_intron_exon_matrices(const CellsDataContainer &container, const std::string &filename) const;
 private:
 	SparseMatrix named_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order, uint64_t ncols, uint64_t nnz,
-	                          const uint32_t *colptr, const uint32_t *rowidx, const uint32_t *values) const;
+	                          const uint32_t *colptr, const uint32_t *rowidx, const uint32_t *values,
+	                          const std::vector<std::string> *col_names = nullptr) const;
+	SparseMatrix sharded_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order) const;
 public:
 	// <base>.mtx + <base>.cells.tsv + <base>.genes.tsv (what save_mtx writes through R's Matrix::writeMM)
 	void save_mtx(const CellsDataContainer &container, const std::string &filename_base) const;

@@ -1,7 +1,7 @@
 // BAM file(s) -> count matrices through the facade: BamController (native BGZF/BAM reader) -> CellsDataContainer ->
 // ResultsPrinter::save_results.  Used by tests/test_gpu_bam.py and as the timing harness of the ingest path.
 //   bam_to_counts <out_base> <filled|name> <min_genes_before> <min_genes_after> <whitelist|-> <threads> <bam> [<bam> ...]
-//   environment: DROPEST_GTF = annotation file for -g (genes from the alignment positions instead of the gene tag)
+//   environment: DROPEST_DEVICES = "0,0" shards the container over these devices; DROPEST_GTF = annotation file for -g (genes from the alignment positions instead of the gene tag)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +20,12 @@ int main(int argc, char **argv) {
 		if (wl == "-") merge = std::make_shared<Merge::DummyMergeStrategy>(min_before, min_after);
 		else merge = std::make_shared<Merge::RealBarcodesMergeStrategy>(Merge::RealBarcodesMergeStrategy::CONST_LENGTH, wl, min_before, min_after, 7, 0.2);
 		auto umi = std::make_shared<Merge::UMIs::MergeUMIsStrategySimple>(1);
-		CellsDataContainer c(merge, umi, UMI::Mark::get_by_code(UMI::Mark::DEFAULT_CODE));
+		// DROPEST_DEVICES = "0,0,0": the container sharded over these devices (several shards may share one GPU)
+		std::vector<int> devices;
+		if (const char *d = std::getenv("DROPEST_DEVICES")) { std::string t(d); size_t at = 0; while (at < t.size()) { devices.push_back(std::atoi(t.c_str() + at)); at = t.find(',', at); if (at == std::string::npos) break; ++at; } }
+		if (devices.empty()) devices.push_back(0);
+		CellsDataContainer c(merge, umi, UMI::Mark::get_by_code(UMI::Mark::DEFAULT_CODE), false, -1, devices);
+		if (const char *q = std::getenv("DROPEST_SHARD_QUOTA")) c.shard_quota = size_t(std::atoll(q));
 		BamProcessing::BamTags tags;
 		tags.read_type = "RE"; tags.intronic_read_value = "N"; tags.intergenic_read_value = "I"; tags.exonic_read_value = "E";   // configs/10x.xml style
 		const char *gtf = std::getenv("DROPEST_GTF");
@@ -40,7 +45,7 @@ int main(int argc, char **argv) {
 		const auto &k = ctl.counters();
 		std::printf("{\"total_reads\": %zu, \"cant_parse\": %zu, \"low_quality\": %zu, \"saved\": %zu, \"cells\": %zu, \"real_cells\": %zu, "
 		            "\"ingest_ms\": %.3f, \"ingest_wait_ms\": %.3f, \"ingest_parse_ms\": %.3f, \"ingest_add_ms\": %.3f, \"estimate_ms\": %.3f, \"write_ms\": %.3f}\n",
-		            k.total_reads, k.cant_parse, k.low_quality, k.saved, c.total_cells_number(), c.real_cells_number(), ms(t0, t1), k.wait_ms, k.parse_ms, k.add_ms, ms(t1, t2), ms(t2, t3));
+		            k.total_reads, k.cant_parse, k.low_quality, k.saved, c.sharded() ? size_t(0) : c.total_cells_number(), c.sharded() ? c.real_cells().size() : c.real_cells_number(), ms(t0, t1), k.wait_ms, k.parse_ms, k.add_ms, ms(t1, t2), ms(t2, t3));
 	} catch (const std::exception &e) {
 		std::fprintf(stderr, "ERROR: %s\n", e.what());
 		return 1;

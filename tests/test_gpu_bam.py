@@ -118,6 +118,54 @@ def test_read_name_encoding_and_whitelist_merge(tmp_path):
     assert len(d["merge_targets"].value) > 10
 
 
+def _plain(v):
+    """An RObject tree (rds_reader) as plain python, for equality: (kind, value, attributes)."""
+    if not isinstance(v, rr.RObject):
+        if isinstance(v, np.ndarray):
+            return [None if (isinstance(x, float) and x != x) else x for x in v.tolist()]
+        if isinstance(v, (list, tuple)):
+            return [_plain(x) for x in v]
+        return v
+    return (v.kind, _plain(v.value), {k: _plain(x) for k, x in sorted(v.attributes.items())})
+
+
+@pytest.mark.parametrize("wl", [False, True])
+def test_sharded_container_writes_the_same_rds(tmp_path, wl):
+    """ResultsPrinter::save_results of a container sharded over three shards (one GPU) = the .rds of one container: both
+    matrices with the reference's row order, per-chromosome frames, mean reads per UMI, saturation info, aligned / requested
+    counts per cell, reads_per_umi_per_cell; merge_targets as a set (the order of that list is the reference's hash order)."""
+    s = SynthStream(n_reads=60_000, n_cells=25, n_genes=300, umi_len=8, permille_neighbour=150, permille_intron=100)
+    cb, umi, gene, aux = s.generate_host()
+    refs = [("chr%d" % i, 1_000_000) for i in range(25)]
+    recs = []
+    for i in range(len(cb)):
+        c, u = capi.unpack_code(cb[i]), capi.unpack_code(umi[i])
+        if i % 97 == 0:
+            u = u[:3] + "N" + u[4:]
+        g = None if gene[i] == capi.NO_GENE else "G%d" % gene[i]
+        mark = int(aux[i] >> 16) & 7
+        tags = [("CB", "Z", c), ("UB", "Z", u)]
+        if g:
+            tags += [("GX", "Z", g), ("RE", "A", "N" if mark & 4 else "E")]
+        recs.append(bw.record(int(aux[i]) & 0xFFFF, i, "r%d" % i, tags=tags))
+    bam = str(tmp_path / "s.bam")
+    bw.write_bam(bam, refs, recs)
+    wlf = os.path.join(ROOT, "dropest_amd", "data", "barcodes", "10x_aug_2016_split") if wl else "-"
+    env = {"DROPEST_RPUPC": "1"}
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    _, cells1, st1, d1 = _run(tmp_path / "a", "filled", [bam], 3, 10, wl=wlf, threads=2, env=env)
+    _, cells3, st3, d3 = _run(tmp_path / "b", "filled", [bam], 3, 10, wl=wlf, threads=2,
+                              env=dict(env, DROPEST_DEVICES="0,0,0"))
+    assert cells1 == cells3 and len(cells1) >= 20 and st1["real_cells"] == st3["real_cells"]
+    assert d1.names == d3.names and "reads_per_umi_per_cell" in d1.names
+    for key in d1.names:
+        if key == "merge_targets":
+            a, b = ({n: _plain(x) for n, x in zip(d.names or [], d.value)} for d in (d1[key], d3[key]))
+            assert a == b and (len(a) > 10 or not wl)
+        else:
+            assert _plain(d1[key]) == _plain(d3[key]), key
+
+
 def test_bad_files(tmp_path):
     build_facade()
     p = str(tmp_path / "x.bam")
