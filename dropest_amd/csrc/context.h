@@ -434,6 +434,9 @@ struct dropest_ctx {
 	struct ShardHooks {
 		std::function<std::vector<u64>(const std::vector<u64> &)> first_seen_global;   // sorted UMI codes -> smallest global ordinal each
 		std::function<std::vector<u64>(const std::vector<u32> &, const std::vector<u32> &, const std::vector<u32> &)> rng_offsets;   // (cell first read, gene, draws) per group -> offset in the one rand() sequence
+		// -u: the device table UMI code -> position of its first read on THIS shard (0xFFFFFFFF = never) becomes, in place, the
+		// table UMI code -> rank of its first read in the WHOLE stream (the reference's UMI index order), equal on every shard
+		std::function<void(u32 *, size_t)> globalize_umi_first;
 	};
 	std::shared_ptr<ShardHooks> hooks;
 	void emit_columns_device(bool filtered_m, bool reads_output, const std::vector<u32> &col_cell, const std::vector<u32> &col_start, uint64_t nnz);

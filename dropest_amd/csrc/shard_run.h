@@ -337,6 +337,20 @@ __global__ __launch_bounds__(256) void ordinals_kernel(OrdinalMap m, const uint3
 	if (i < n) out[i] = pos[i] == 0xFFFFFFFFu ? ~0ull : to_global_ordinal(m, pos[i]);
 }
 
+// -u across shards: smallest global ordinal of every UMI over the shards' tables; then the table becomes a rank table
+__global__ __launch_bounds__(256) void min_rows_kernel(const unsigned long long *__restrict__ all, uint32_t rows, uint64_t n, unsigned long long *__restrict__ out) {
+	for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
+		unsigned long long m = ~0ull;
+		for (uint32_t r = 0; r < rows; ++r) { const unsigned long long v = all[uint64_t(r) * n + i]; m = v < m ? v : m; }
+		out[i] = m;
+	}
+}
+__global__ __launch_bounds__(256) void ranks_to_table_kernel(const unsigned long long *__restrict__ sorted_ord, const uint32_t *__restrict__ code, uint32_t n,
+                                                             uint32_t *__restrict__ table) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) table[code[i]] = sorted_ord[i] == ~0ull ? 0xFFFFFFFFu : i;
+}
+
 }  // namespace dropest
 
 // CellsDataContainer::compare_cells (CellsDataContainer.cpp:329-344) on table rows: (requested_genes, requested_umis,
@@ -406,19 +420,26 @@ struct dropest_shard {
 	void assemble_matrix(bool filtered_m);
 	std::vector<u32> order_rows(const std::vector<u32> &sel, bool by_first);
 	std::vector<u64> global_ordinals(const std::vector<u32> &local_pos);
+	dropest::OrdinalMap ordinal_map() const;
 	void install_umi_hooks();
 };
+
+dropest::OrdinalMap dropest_shard::ordinal_map() const {
+	using namespace dropest;
+	OrdinalMap m{};
+	m.idx = exchanged ? x_idx.p : nullptr;
+	m.world = exchanged ? u32(world) : 1u;
+	if (exchanged) { for (int p = 0; p <= world; ++p) m.recv_off[p] = recv_off[size_t(p)]; for (int p = 0; p < world; ++p) m.first_ord[p] = first_ord[size_t(p)]; }
+	else { m.recv_off[0] = 0; m.recv_off[1] = n_res; m.first_ord[0] = first_ordinal; }
+	return m;
+}
 
 std::vector<dropest::u64> dropest_shard::global_ordinals(const std::vector<u32> &local_pos) {
 	using namespace dropest;
 	std::vector<u64> out(local_pos.size());
 	if (local_pos.empty()) return out;
 	dropest_ctx &c = *ctx;
-	OrdinalMap m{};
-	m.idx = exchanged ? x_idx.p : nullptr;
-	m.world = exchanged ? u32(world) : 1u;
-	if (exchanged) { for (int p = 0; p <= world; ++p) m.recv_off[p] = recv_off[size_t(p)]; for (int p = 0; p < world; ++p) m.first_ord[p] = first_ord[size_t(p)]; }
-	else { m.recv_off[0] = 0; m.recv_off[1] = n_res; m.first_ord[0] = first_ordinal; }
+	const OrdinalMap m = ordinal_map();
 	const u32 n = u32(local_pos.size());
 	DevBuf<u32> d_pos; DevBuf<u64> d_out;
 	d_pos.alloc(n); d_out.alloc(n);
@@ -828,7 +849,6 @@ void dropest_shard::step() {
 	if (c.cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && world > 1) { Phase ph(this, "cb_merge"); cb_merge(); }
 	else if (c.cfg.merge_kind != DROPEST_MERGE_NONE && world > 1)
 		throw UnsupportedError("sharded runs support -m with a barcode whitelist (RealBarcodes) only; run the other merge strategies on one GPU");
-	if (c.cfg.umi_merge_kind == DROPEST_UMI_MERGE_DIRECTIONAL && world > 1) throw UnsupportedError("-u is not supported in sharded runs");
 	if (c.have_qual && world > 1) throw UnsupportedError("UMI qualities are not supported in sharded runs");
 	{ Phase ph(this, "finalize"); c.run_merge_and_filter(); }
 	if (world == 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE) {
@@ -882,6 +902,37 @@ void dropest_shard::install_umi_hooks() {
 		for (const Key &k : all) { if (int(k.rank) == rank) out[k.idx] = at; at += k.draws; }
 		// groups without draws: wherever the sequence stands when they are reached (skip_to never goes back)
 		return out;
+	};
+	h->globalize_umi_first = [this](u32 *d_table, size_t n) {
+		Phase ph(this, "umi:first_table");
+		dropest_ctx &c = *ctx;
+		if (n >= 0xFFFFFFF0ull) throw UnsupportedError("UMI table too large");
+		DevBuf<u64> mine, all;
+		mine.alloc(n); all.alloc(n * size_t(world));
+		hipLaunchKernelGGL(ordinals_kernel, dim3(u32((n + 255) / 256)), dim3(256), 0, c.stream, ordinal_map(), d_table, u32(n), mine.p);
+		HIP_CHECK(hipGetLastError());
+		std::vector<size_t> off(static_cast<size_t>(world)), bytes(static_cast<size_t>(world), n * 8);
+		for (int p = 0; p < world; ++p) off[size_t(p)] = size_t(p) * n * 8;
+		tr->gather_dev(mine.p, all.p, off.data(), bytes.data(), c.stream);
+		hipLaunchKernelGGL(min_rows_kernel, dim3(u32(std::min<size_t>((n + 255) / 256, 4096))), dim3(256), 0, c.stream, all.p, u32(world), uint64_t(n), mine.p);
+		HIP_CHECK(hipGetLastError());
+		// ranks: sort (ordinal, code) on the bits an ordinal can have; codes nobody saw (all ones) keep 0xFFFFFFFF
+		uint64_t reach = 1;
+		{
+			uint64_t mine2[2] = {first_ordinal, n_res};
+			std::vector<uint64_t> every(size_t(world) * 2);
+			tr->gather_host(mine2, sizeof(mine2), every.data());
+			for (int p = 0; p < world; ++p) reach = std::max<uint64_t>(reach, every[size_t(p) * 2] + every[size_t(p) * 2 + 1]);
+		}
+		const u64 mask = reach >= (1ull << 63) ? ~0ull : ((1ull << bit_length(reach)) - 1ull);
+		DevBuf<u64> k_alt; DevBuf<u32> v, v_alt;
+		k_alt.alloc(n); v.alloc(n); v_alt.alloc(n);
+		hipLaunchKernelGGL(iota_kernel, dim3(u32((n + 255) / 256)), dim3(256), 0, c.stream, v.p, u32(n));
+		u64 *k = mine.p, *ka = k_alt.p; u32 *vv = v.p, *va = v_alt.p;
+		c.radix_sort(k, vv, ka, va, u32(n), mask);
+		hipLaunchKernelGGL(ranks_to_table_kernel, dim3(u32((n + 255) / 256)), dim3(256), 0, c.stream, k, vv, u32(n), d_table);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipStreamSynchronize(c.stream));   // the buffers above die with this scope
 	};
 	ctx->hooks = h;
 }

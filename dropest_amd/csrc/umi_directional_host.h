@@ -79,9 +79,18 @@ std::unordered_map<std::string, std::string> directional_find_targets(std::vecto
 
 void dropest_ctx::run_umi_merge_directional() {
 	umi_overrides.clear();
-	if (n_cg == 0 || n_mol == 0) return;
-	HostStage hs(this, "umi_directional");
 	if (layout.umi_bits > 28) throw UnsupportedError("-u needs a UMI field of at most 28 bits (table of first occurrences)");
+	if (n_cg == 0 || n_mol == 0) {
+		if (hooks) {   // a shard without molecules still takes part in the two exchanges of the others
+			const size_t table = size_t(1) << layout.umi_bits;
+			umi_first.ensure(table);
+			HIP_CHECK(hipMemsetAsync(umi_first.p, 0xFF, table * 4, stream));
+			hooks->globalize_umi_first(umi_first.p, table);
+			(void)hooks->rng_offsets({}, {}, {});
+		}
+		return;
+	}
+	HostStage hs(this, "umi_directional");
 	const u64 umask = layout.umi_bits ? ((1ull << layout.umi_bits) - 1ull) : 0ull;
 
 	// 1. cells that are real NOW (after the CB merge); first read ordinal of every UMI = UMI-index order
@@ -98,6 +107,7 @@ void dropest_ctx::run_umi_merge_directional() {
 		hipLaunchKernelGGL(umi_first_table_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n,
 		                   layout, umi_first.p);
 	});
+	if (hooks) hooks->globalize_umi_first(umi_first.p, table);   // sharded run: UMI index order of the whole stream
 
 	// 2. device decision for the groups it can decide; re-keyed keys land in keys_a
 	keys_a.ensure(n_mol); keys_b.ensure(n_mol); vals_a.ensure(n_mol); vals_b.ensure(n_mol);
@@ -193,15 +203,15 @@ void dropest_ctx::run_umi_merge_directional() {
 		reaggregate_from_keys(or_and[0] ^ or_and[1]);   // the (cell, gene) rows keep their indices: groups never vanish
 		for (u32 i = 0; i < nr; ++i) if (rem[i]) real[i].row.total_umis -= int(rem[i]);
 	}
-	if (!n_host) return;
+	if (!n_host && !hooks) return;   // (a shard without such groups still takes part in the exchange of the offsets)
 
 	// 3. the remaining groups, replayed literally on the host
 	GatheredGroups GG;
 	umi_gather_groups(groups, GG, umi_first.p);
 	std::vector<u32> p_idx, p_all, p_req, p_rreq;
-	for (u32 g = 0; g < n_host; ++g) {
-		struct Mol { u64 code; std::string seq; u32 reads, mark, first, row; };
-		std::vector<Mol> mols(GG.size[g]);
+	struct Mol { u64 code; std::string seq; u32 reads, mark, first, row; };
+	auto group_molecules = [&](u32 g, std::vector<Mol> &mols, std::vector<DirUmi> &v) {
+		mols.assign(GG.size[g], Mol{});
 		for (u32 t = 0; t < GG.size[g]; ++t) {
 			Mol &m = mols[t];
 			m.row = GG.begin[g] + t;
@@ -212,8 +222,32 @@ void dropest_ctx::run_umi_merge_directional() {
 		std::vector<size_t> by_index(mols.size());
 		for (size_t i = 0; i < by_index.size(); ++i) by_index[i] = i;
 		std::sort(by_index.begin(), by_index.end(), [&](size_t x, size_t y) { return mols[x].first < mols[y].first; });
-		std::vector<DirUmi> v;
+		v.clear();
 		for (size_t i : by_index) v.push_back(DirUmi{mols[i].seq, size_t(mols[i].reads)});
+	};
+	// Sharded run: the random fills of ALL shards come from one rand() sequence, drawn group by group in (cell id, gene)
+	// order.  How many numbers a group draws does not depend on their values (a fill happens when an N-UMI finds no
+	// target): count them in a dry run, let the shards agree on every group's offset, then replay from there.
+	std::vector<u64> rng_offset;
+	if (hooks) {
+		std::vector<u32> draws(n_host, 0), cell_first_pos(n_host), gene_of(n_host), cells_of(n_host);
+		std::vector<Mol> mols; std::vector<DirUmi> v;
+		for (u32 g = 0; g < n_host; ++g) {
+			group_molecules(g, mols, v);
+			dropest::GlibcRand dry(1);
+			(void)directional_find_targets(v, cfg.umi_merge_multiplier, unsigned(cfg.max_umi_merge_edit_distance), dry);
+			draws[g] = u32(dry.drawn);
+			const u64 cgk = GG.hk[GG.off[g]] >> layout.umi_bits;
+			cells_of[g] = u32(cgk >> layout.gene_bits); gene_of[g] = u32(cgk & layout.gene_none);
+		}
+		for (u32 g = 0; g < n_host; ++g) cell_first_pos[g] = real[real_at(cells_of[g])].row.first_read;
+		rng_offset = hooks->rng_offsets(cell_first_pos, gene_of, draws);
+	}
+	for (u32 g = 0; g < n_host; ++g) {
+		std::vector<Mol> mols;
+		std::vector<DirUmi> v;
+		group_molecules(g, mols, v);
+		if (hooks) rng.skip_to(rng_offset[g]);
 		const auto targets = directional_find_targets(v, cfg.umi_merge_multiplier, unsigned(cfg.max_umi_merge_edit_distance), rng);
 		if (targets.empty()) continue;
 		// Cell::merge_umis + Gene::merge(src, tgt) (Cell.cpp:31-42, Gene.cpp:38-58), in the map's own iteration order

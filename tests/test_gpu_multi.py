@@ -126,6 +126,28 @@ def test_n_umis_with_whitelist_merge_across_shards():
     assert len(want) > 10
 
 
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("n_rate", [0.0, 2e-2])
+def test_directional_umi_correction_across_shards(world, n_rate):
+    """-u (MergeUMIsStrategyDirectional.cpp:18-116) over shards: the UMI index order is the order of first appearance in the WHOLE
+    stream (all shards' tables reduced to one rank table), random fills of N-UMIs without a target come from one rand() sequence
+    in global (cell id, gene) order."""
+    s = SynthStream(n_reads=150_000 * SCALE, n_cells=30 * SCALE, n_genes=400, umi_len=6, reads_per_molecule=3)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    side = ()
+    if n_rate:
+        umi, side = inject_n(umi, gene, n_rate, 13, 6)
+        assert len(side) > 50
+    kw = dict(cfg_kwargs({"min_before": 5, "min_after": 10}), umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL, max_umi_merge_edit_distance=1,
+              umi_merge_multiplier=2.0)
+    got = run_group(world, (cb, umi, gene, aux), kw, side)
+    c = single((cb, umi, gene, aux), kw, side)
+    check(got, c)
+    plain = single((cb, umi, gene, aux), cfg_kwargs({"min_before": 5, "min_after": 10}), side)
+    assert int(plain.count_matrix_csc(filtered=True)[2].sum()) > int(c.count_matrix_csc(filtered=True)[2].sum())   # -u really merged UMIs
+    # (the single context itself is pinned on the oracle for -u: test_gpu_parity.py::test_directional_*)
+
+
 def test_barcodes_of_several_lengths_and_max_cells():
     """compare_cells orders barcode STRINGS (CellsDataContainer.cpp:329-344): with barcodes of several lengths the packed codes
     do not order like the strings, ties on the sizes must still come out as in one container; -C keeps the largest cells."""
