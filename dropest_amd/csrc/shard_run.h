@@ -141,6 +141,7 @@ struct LocalTransport : Transport {
 	struct Pub { const void *const *d_send; const size_t *elem; const uint64_t *send_cnt; };
 	void exchange(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
 	              const uint64_t *recv_cnt, hipStream_t st) override {
+		HIP_CHECK(hipStreamSynchronize(st));   // the blocks the peers copy were written on this stream
 		Pub pub{d_send, elem, send_cnt};
 		hub->p0[size_t(rank)] = &pub;
 		hub->barrier();
@@ -165,6 +166,7 @@ struct LocalTransport : Transport {
 		hub->barrier();
 	}
 	void gather_dev(const void *d_mine, void *d_all, const size_t *off, const size_t *bytes, hipStream_t st) override {
+		HIP_CHECK(hipStreamSynchronize(st));   // what the peers are about to read was produced on this stream
 		hub->p1[size_t(rank)] = d_mine;
 		hub->barrier();
 		for (int p = 0; p < world; ++p)
