@@ -398,6 +398,17 @@ struct dropest_shard {
 	// results: global CSC of both matrices (rows / values in the node-shared host buffer)
 	struct Mat { uint64_t ncols = 0, nnz = 0; std::vector<u64> colptr, col_barcode; const u32 *rows = nullptr, *vals = nullptr; } mat[2];
 	std::vector<std::pair<u64, u64>> merged_barcodes;   // (source, target) barcode of every merged cell, ascending source
+	bool merged_pending = false;
+	void name_merged_pairs() {   // world == 1: (source id, target id) of the context -> barcodes
+		if (!merged_pending) return;
+		merged_pending = false;
+		dropest_ctx &c = *ctx;
+		HIP_CHECK(hipSetDevice(c.cfg.device));
+		std::vector<dropest::u64> bc(c.n_cells);
+		if (c.n_cells) c.fetch(bc.data(), c.cell_cb.p, size_t(c.n_cells) * 8);
+		for (auto const &pr : c.merge_pairs) merged_barcodes.emplace_back(bc[size_t(pr.first)], bc[size_t(pr.second)]);
+		std::sort(merged_barcodes.begin(), merged_barcodes.end());
+	}
 	dropest::DevBuf<u64> d_desc;
 	dropest::PinnedBuf<u64> h_desc;
 	dropest::DevBuf<u32> d_tmp32;
@@ -853,12 +864,7 @@ void dropest_shard::step() {
 		throw UnsupportedError("sharded runs support -m with a barcode whitelist (RealBarcodes) only; run the other merge strategies on one GPU");
 	if (c.have_qual && world > 1) throw UnsupportedError("UMI qualities are not supported in sharded runs");
 	{ Phase ph(this, "finalize"); c.run_merge_and_filter(); }
-	if (world == 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE) {
-		std::vector<u64> bc(c.n_cells);
-		if (c.n_cells) c.fetch(bc.data(), c.cell_cb.p, size_t(c.n_cells) * 8);
-		for (auto const &pr : c.merge_pairs) merged_barcodes.emplace_back(bc[size_t(pr.first)], bc[size_t(pr.second)]);
-		std::sort(merged_barcodes.begin(), merged_barcodes.end());
-	}
+	merged_pending = world == 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE;   // one shard: the context's own pairs, named when asked for
 	build_global_table();
 	assemble_matrix(true);
 	assemble_matrix(false);
@@ -1119,6 +1125,7 @@ dropest_status dropest_shard_matrix(dropest_shard *s, int filtered, uint64_t *nc
 dropest_status dropest_shard_merged_barcodes(dropest_shard *s, uint64_t *n, uint64_t *source, uint64_t *target) {
 	return guarded([&] {
 		if (!s || !n) throw InvalidError("null argument");
+		s->name_merged_pairs();
 		*n = s->merged_barcodes.size();
 		if (source && target) for (size_t i = 0; i < s->merged_barcodes.size(); ++i) { source[i] = s->merged_barcodes[i].first; target[i] = s->merged_barcodes[i].second; }
 	});

@@ -166,7 +166,11 @@ class ShardedRun:
         self.shard = Shard(h.value)
         self.R = int(reads_per_gpu)
         self.shard.set_reads(stream.generate_device(local_rank, first=rank * self.R, n=self.R), rank * self.R)
-        self.merge_pairs = None
+
+    @property
+    def merge_pairs(self):
+        """(source, target) barcodes of the cells the CB merge folded in the last step."""
+        return self.shard.merged_barcodes()
 
     @property
     def ctx(self):
@@ -175,7 +179,6 @@ class ShardedRun:
     def step(self):
         """One pass; on rank 0 returns (cm, cm_raw, cm column barcodes) with cm = (colptr, rowidx, values, column barcodes)."""
         self.shard.step()
-        self.merge_pairs = self.shard.merged_barcodes()
         if self.rank != 0:
             return None, None, None
         cm, raw = self.shard.matrix(True), self.shard.matrix(False)
