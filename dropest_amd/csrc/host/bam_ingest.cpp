@@ -1,5 +1,6 @@
 // bam_ingest.cpp -- see bam_ingest.h.
 #include "bam_ingest.h"
+#include <atomic>
 
 #include <zlib.h>
 
@@ -263,7 +264,11 @@ bool BamRecord::get_string_tag(const std::string &tag, std::string_view &value, 
 			if (type_out) *type_out = type;
 			if (text) { value = std::string_view(reinterpret_cast<const char *>(tags + o), len - 1); return true; }
 			if (type == 'A') { value = std::string_view(reinterpret_cast<const char *>(tags + o), 1); return true; }
-			return false;    // numeric tag: not a string (BamTools would read past it; no caller relies on that)
+			// numeric tag where a string is asked for: treated as absent; said once, the counters tell the rest
+			static std::atomic<bool> warned{false};
+			if (!warned.exchange(true))
+				std::fprintf(stderr, "WARNING: BAM tag %c%c has the numeric type '%c' where a string (Z) is expected; records with it are handled as if the tag were absent\n", t0, t1, type);
+			return false;
 		}
 		o += len;
 	}

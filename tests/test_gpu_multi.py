@@ -73,7 +73,7 @@ def check(got, c):
     return want
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
 def test_shards_on_one_gpu_match_single_context(world):
     arrays = parity.canonical_stream(*SynthStream(**STREAM).generate_host())
     kw = cfg_kwargs(CFG)
@@ -113,6 +113,19 @@ def test_n_umis_across_shards(world, rate, n_reads):
     c = single((cb, umi, gene, aux), kw, side)
     check(got, c)
     # (the single context itself is pinned on the oracle for these streams: test_gpu_parity.py::test_n_umis_synthetic)
+
+
+def test_eight_shards_whitelist_merge_n_umis_and_directional():
+    """The shard count of one node (C5's form, scaled down): whitelist merge with N-UMIs, and -u, over 8 shards on one GPU."""
+    s = SynthStream(n_reads=400_000 * SCALE, n_cells=80 * SCALE, n_genes=1500, umi_len=8, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    umi, side = inject_n(umi, gene, 3e-3, 21, 8)
+    wl = {"barcodes_kind": capi.BARCODES_CONST, "barcodes_file": os.path.join(DATA, "10x_aug_2016_split")}
+    ckw = cfg_kwargs({"min_before": 3, "min_after": 10, "merge": wl})
+    want = check(run_group(8, (cb, umi, gene, aux), ckw, side, steps=1), single((cb, umi, gene, aux), ckw, side))
+    assert len(want) > 30
+    dkw = dict(ckw, umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL, max_umi_merge_edit_distance=1, umi_merge_multiplier=2.0)
+    check(run_group(8, (cb, umi, gene, aux), dkw, side, steps=1), single((cb, umi, gene, aux), dkw, side))
 
 
 def test_n_umis_with_whitelist_merge_across_shards():
