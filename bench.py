@@ -155,12 +155,29 @@ def push_rates(stream, local_rank, n_push, cfg_kw):
             t2 = time.perf_counter()
             best_push = min(best_push or 1e9, t1 - t0); best_all = min(best_all or 1e9, t2 - t0)
             ctx.close()
-        return {"reads": n_push, "push_pinned_Mreads_per_s": round(n_push / best_push / 1e6, 1), "push_pinned_GB_per_s": round(n_push * 24 / best_push / 1e9, 1),
-                "push_plus_pass_Mreads_per_s": round(n_push / best_all / 1e6, 1),
-                "note": "pinned host arrays -> dropest_push_reads (8 Mi-read batches) -> set_initialized -> merge_and_filter -> both matrices; best of 3"}
+        out = {"reads": n_push, "push_pinned_Mreads_per_s": round(n_push / best_push / 1e6, 1), "push_pinned_GB_per_s": round(n_push * 24 / best_push / 1e9, 1),
+               "push_plus_pass_Mreads_per_s": round(n_push / best_all / 1e6, 1),
+               "note": "pinned host arrays -> dropest_push_reads (8 Mi-read batches) -> set_initialized -> merge_and_filter -> both matrices; best of 3"}
+        out.update(facade_add_record_rate())
+        return out
     finally:
         for a in host:
             L.dropest_host_unregister(local_rank, a.ctypes.data)
+
+
+def facade_add_record_rate(n=4_000_000):
+    """The C++ facade's add_record(ReadInfo) -- strings in, what BamProcessor::save_read calls per read -- on one host thread
+    (tests/cpp/add_record_rate.cpp, built next to the facade); {} when the tool is not built."""
+    import subprocess
+    tool = os.path.join(ROOT, "tests", "cpp", "add_record_rate")
+    if not os.path.exists(tool):
+        return {}
+    try:
+        res = subprocess.run([tool, str(n)], capture_output=True, text=True, timeout=120)
+        d = json.loads(res.stdout.strip().splitlines()[-1])
+        return {"facade_add_record_Mreads_per_s": d["add_record_Mreads_per_s"], "facade_add_record_reads": d["reads"]}
+    except Exception:
+        return {}
 
 
 def main():

@@ -43,6 +43,7 @@ def build(force=False, verbose=False):
 FACADE_LIB = os.path.join(LIB_DIR, "libdropest_facade.so")
 FACADE_TEST = os.path.join(HERE, "..", "tests", "cpp", "test_facade")
 BAM_TOOL = os.path.join(HERE, "..", "tests", "cpp", "bam_to_counts")
+RATE_TOOL = os.path.join(HERE, "..", "tests", "cpp", "add_record_rate")
 
 
 def build_facade(force=False, verbose=False):
@@ -55,11 +56,12 @@ def build_facade(force=False, verbose=False):
     hdr = os.path.join(CSRC, "host", "facade.h")
     test_src = os.path.join(HERE, "..", "tests", "cpp", "test_facade.cpp")
     bam_tool_src = os.path.join(HERE, "..", "tests", "cpp", "bam_to_counts.cpp")
+    rate_src = os.path.join(HERE, "..", "tests", "cpp", "add_record_rate.cpp")
     newest = max(os.path.getmtime(x) for x in (src, rds, bam, ga, os.path.join(CSRC, "host", "rds_writer.h"), os.path.join(CSRC, "host", "bam_ingest.h"),
                                                os.path.join(CSRC, "host", "gene_annotation.h"),
-                                               hdr, test_src, bam_tool_src, LIB))
-    if not force and os.path.exists(FACADE_LIB) and os.path.exists(FACADE_TEST) and os.path.exists(BAM_TOOL) and \
-            min(os.path.getmtime(FACADE_LIB), os.path.getmtime(FACADE_TEST), os.path.getmtime(BAM_TOOL)) > newest:
+                                               hdr, test_src, bam_tool_src, rate_src, LIB))
+    if not force and os.path.exists(FACADE_LIB) and os.path.exists(FACADE_TEST) and os.path.exists(BAM_TOOL) and os.path.exists(RATE_TOOL) and \
+            min(os.path.getmtime(FACADE_LIB), os.path.getmtime(FACADE_TEST), os.path.getmtime(BAM_TOOL), os.path.getmtime(RATE_TOOL)) > newest:
         return FACADE_LIB, FACADE_TEST
     cmds = [
         ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", src, rds, bam, ga, "-o", FACADE_LIB, "-L" + LIB_DIR, "-ldropest_amd", "-lz",
@@ -67,6 +69,8 @@ def build_facade(force=False, verbose=False):
         ["g++", "-O2", "-std=c++17", "-Wall", test_src, "-o", FACADE_TEST, "-L" + LIB_DIR, "-ldropest_facade", "-ldropest_amd",
          "-Wl,-rpath,$ORIGIN/../../dropest_amd/lib"],
         ["g++", "-O2", "-std=c++17", "-Wall", bam_tool_src, "-o", BAM_TOOL, "-L" + LIB_DIR, "-ldropest_facade", "-ldropest_amd",
+         "-Wl,-rpath,$ORIGIN/../../dropest_amd/lib"],
+        ["g++", "-O2", "-std=c++17", "-Wall", rate_src, "-o", RATE_TOOL, "-L" + LIB_DIR, "-ldropest_facade", "-ldropest_amd",
          "-Wl,-rpath,$ORIGIN/../../dropest_amd/lib"],
     ]
     for cmd in cmds:
