@@ -204,7 +204,9 @@ static constexpr u32 GENE_CHR_CAP = 1u << 20;   // genes beyond this id fall bac
 void dropest_ctx::build_cb_table() {
 	const u32 n = u32(n_reads);
 	uint64_t cap = cfg.cb_table_capacity;
-	if (cap == 0 && n_reads >= (1u << 22) && !getenv("DROPEST_CB_NO_SAMPLE")) {
+	uint64_t sample_min = uint64_t(1) << 22;
+	if (const char *e = getenv("DROPEST_CB_SAMPLE_MIN")) sample_min = uint64_t(std::max(1ll, atoll(e)));   // tests: the sampled sizing and the hot list on small streams
+	if (cap == 0 && n_reads >= sample_min && !getenv("DROPEST_CB_NO_SAMPLE")) {
 		// size the table from the distinct barcodes of every 64th read: a new barcode shows up at most 64 times as often in
 		// the whole stream (too small an estimate is caught below: the table is rebuilt larger when its load passes 0.7)
 		const u32 stride = 64, n_s = div_up(n, stride);
@@ -540,7 +542,9 @@ bool dropest_ctx::splitter_sort_reduce() {
 	const u32 F1 = 1u << fb1, Ff = 1u << fb2, F2 = F1 * Ff;
 	const int ms = layout.mark_shift, VB = layout.val_bytes;
 	// 64 samples per fine bucket: bucket sizes scatter by ~12 % around n / F2, so few exceed the small finishing launch
-	const u32 os = u32(std::max<uint64_t>(1, std::min<uint64_t>(64, uint64_t(n) / (uint64_t(F2) * 2))));
+	uint64_t os_max = 64;
+	if (const char *e = getenv("DROPEST_SSORT_OS")) os_max = uint64_t(std::max(1, atoi(e)));
+	const u32 os = u32(std::max<uint64_t>(1, std::min<uint64_t>(os_max, uint64_t(n) / (uint64_t(F2) * 2))));
 	const u32 n_sample = F2 * os;
 	const u64 order_mask = ~((1ull << ms) - 1ull);
 	const u64 varying = (counters.key_or ^ counters.key_and) & order_mask;

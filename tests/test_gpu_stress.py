@@ -91,6 +91,19 @@ def test_one_giant_molecule_and_all_distinct_barcodes():
     run_case(rng, n=12_000, n_cb=12_000, n_gene=3, n_umi=4, cb_len=(16, 16), min_before=0, min_after=0)   # table growth path
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_sampled_table_sizing_and_hot_list_on_small_streams(seed, monkeypatch):
+    """The barcode table sized from every 64th read and the LDS table of the hot barcodes normally start at 2^22 reads;
+    DROPEST_CB_SAMPLE_MIN brings both (with the growth retry when the sample underestimates) to streams the oracle runs in seconds:
+    skewed barcode frequencies, all-distinct barcodes, Ns in barcodes."""
+    monkeypatch.setenv("DROPEST_CB_SAMPLE_MIN", "1000")
+    rng = np.random.default_rng(8800 + seed + SEED_OFFSET)
+    run_case(rng, n=int(rng.integers(20_000, 60_000)), n_cb=int(rng.integers(200, 6000)), n_gene=int(rng.integers(5, 400)),
+             n_umi=int(rng.integers(20, 400)), cb_len=(12, 12) if seed % 2 else (9, 14), cb_n_rate=0.02 if seed == 3 else 0.0)
+    if seed == 0:
+        run_case(rng, n=30_000, n_cb=30_000, n_gene=3, n_umi=4, cb_len=(16, 16), min_before=0, min_after=0)   # nothing repeats: no hot list, growth
+
+
 def test_variable_lengths_and_ns():
     rng = np.random.default_rng(9)
     run_case(rng, n=5000, n_cb=30, n_gene=12, n_umi=40, cb_len=(8, 19), umi_len=(6, 6), n_rate=0.05, min_before=0)
