@@ -255,6 +255,10 @@ void dropest_ctx::build_cb_table() {
 		HIP_CHECK(hipMemcpyAsync(d_ingest.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
 		gene_chr.ensure(GENE_CHR_CAP);
 		HIP_CHECK(hipMemsetAsync(gene_chr.p, 0xFF, size_t(GENE_CHR_CAP) * 4, stream));
+		if (n >= (1u << 20)) {   // the popular genes' entries are set before the big pass starts (k_cbhash.h)
+			const u32 stride = 2048, n_s = div_up(n, stride);
+			hipLaunchKernelGGL(gene_chr_seed_kernel, dim3(std::min<u32>(div_up(n_s, 256), 64u)), dim3(256), 0, stream, d_gene, d_aux, n, stride, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
+		}
 		const bool vec = ((uintptr_t(d_cb) | uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;   // adopted arrays may sit anywhere
 		static const u32 grid_v = resident_grid(cb_insert_kernel<256, true>, 256, ~0u), grid_s = resident_grid(cb_insert_kernel<256, false>, 256, ~0u);
 		const u32 blocks = std::min<u32>(div_up(n, 256 * 4), vec ? grid_v : grid_s);

@@ -222,6 +222,25 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 	}
 }
 
+// The gene -> chromosome table seeded from every `stride`-th read (same protocol as cb_insert's own check).  A gene's entry
+// goes UNSET -> chromosome through one compare-and-swap, but every read that still SEES it unset sends one: when the big pass
+// starts cold, the first tiles of all waves do that for the popular genes at once -- tens of thousands of atomics on one
+// address.  A few thousand reads ahead of it set the entries of all genes that matter for that.
+__global__ __launch_bounds__(256) void gene_chr_seed_kernel(const uint32_t *__restrict__ gene, const uint32_t *__restrict__ aux, uint32_t n, uint32_t stride,
+                                                            uint32_t *__restrict__ gene_chr, uint32_t gene_chr_cap, IngestStats *stats) {
+	bool conflict = false;
+	for (uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x; j * stride < n; j += uint64_t(gridDim.x) * 256) {
+		const uint32_t g = gene[j * stride], a = aux[j * stride];
+		if (g == NO_GENE || !((a >> 16) & 6u)) continue;
+		if (g >= gene_chr_cap) { conflict = true; continue; }
+		const uint32_t chr = a & 0xFFFFu;
+		uint32_t cur = gene_chr[g];
+		if (cur == GENE_CHR_UNSET) cur = atomicCAS(&gene_chr[g], GENE_CHR_UNSET, chr), cur = cur == GENE_CHR_UNSET ? chr : cur;
+		if (cur != chr) conflict = true;
+	}
+	if (conflict) atomicMax(&stats->gene_chr_conflict, 1u);
+}
+
 // Distinct barcodes among every `stride`-th read (inserted into a scratch table): sizes the real table.  A table of
 // n / 2 slots for a stream whose 1e8 reads carry 3e6 barcodes is 1 GB of 16-byte slots at 5 % load -- every probe of a
 // rare barcode a certain HBM miss, 1 GB to clear and 1 GB to scan for the occupied slots; sized from the sample it is
