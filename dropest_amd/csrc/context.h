@@ -258,6 +258,9 @@ struct dropest_ctx {
 	dropest::DevBuf<u64> keys_a, keys_b;     // sort ping-pong
 	dropest::DevBuf<u32> vals_a, vals_b;     // values: u32, or bytes in the same storage (layout.val_bytes)
 	bool chr_from_gene = false;              // chromosome is a function of the gene: sort layouts VB 0 / 1
+	// The key layout planned from the statistics of a SAMPLE of the reads (large single-context passes): cb_insert then reads
+	// the barcodes only, the exact statistics ride along with build_keys and the plan is checked against them afterwards.
+	bool lazy_stats = false;
 	dropest::DevBuf<u32> gene_chr;           // [GENE_CHR_CAP] gene id -> chromosome id (GENE_CHR_UNSET if never counted)
 	dropest::DevBuf<u32> mol_exon, mol_intron, mol_exon2, mol_intron2, cg_exon, cg_intron;
 
@@ -371,7 +374,7 @@ struct dropest_ctx {
 	void build_cb_table();
 	void assign_cell_ids();
 	void plan_key_layout();
-	void build_keys();
+	void build_keys(bool with_stats = false);
 	u32 main_sort_passes = 0, main_sort_kind = 0;   // kind: 0 LSD radix sort, 1 splitter sort
 	void radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes = 4,
 	                const char *stat_prefix = nullptr);

@@ -255,13 +255,15 @@ void dropest_ctx::build_cb_table() {
 		HIP_CHECK(hipMemcpyAsync(d_ingest.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
 		gene_chr.ensure(GENE_CHR_CAP);
 		HIP_CHECK(hipMemsetAsync(gene_chr.p, 0xFF, size_t(GENE_CHR_CAP) * 4, stream));
-		if (n >= (1u << 20)) {   // the popular genes' entries are set before the big pass starts (k_cbhash.h)
+		if (n >= (1u << 20) || lazy_stats) {   // the popular genes' entries are set before the big pass starts (k_cbhash.h)
 			const u32 stride = 2048, n_s = div_up(n, stride);
 			hipLaunchKernelGGL(gene_chr_seed_kernel, dim3(std::min<u32>(div_up(n_s, 256), 64u)), dim3(256), 0, stream, d_gene, d_aux, n, stride, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
 		}
 		const bool vec = ((uintptr_t(d_cb) | uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;   // adopted arrays may sit anywhere
 		static const u32 grid_v = resident_grid(cb_insert_kernel<256, true>, 256, ~0u), grid_s = resident_grid(cb_insert_kernel<256, false>, 256, ~0u);
 		const u32 blocks = std::min<u32>(div_up(n, 256 * 4), vec ? grid_v : grid_s);
+		if (lazy_stats)   // the plan's statistics: every 256th read (the exact ones come with build_keys)
+			hipLaunchKernelGGL(ingest_sample_stats_kernel, dim3(std::min<u32>(div_up(div_up(n, 256u), 256), 1024u)), dim3(256), 0, stream, d_umi, d_gene, d_aux, n, 256u, d_ingest.p);
 		if (n_hot && attempt == 0 && cap < (1ull << 31)) {
 			// the hot barcodes take their slots first; one workgroup of 1024 threads per CU with the 128 KB LDS table
 			hipLaunchKernelGGL(cb_hot_preinsert_kernel, dim3(div_up(n_hot, 256)), dim3(256), 0, stream, hot_key.p, n_hot, table, hot_slot.p, &d_ingest.p->overflow);
@@ -271,20 +273,20 @@ void dropest_ctx::build_cb_table() {
 			HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg.device));
 			const u32 hb = std::min<u32>(div_up(n, 1024 * 4), u32(std::max(1, cus)));
 			const CbHot hot{hot_key.p, hot_slot.p, n_hot};
-			timed("cb_insert", double(n) * (8 + 8 + 4 + 4 + 4), [&] {
+			timed("cb_insert", double(n) * (lazy_stats ? 8 + 4 : 8 + 8 + 4 + 4 + 4), [&] {
 				auto go = [&](auto kernel) {
 					HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
 					hipLaunchKernelGGL(kernel, dim3(hb), dim3(1024), lds, stream, d_cb, d_umi, d_gene, d_aux, n, table, hot, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
 				};
-				if (vec) go(cb_insert_hot_kernel<true>); else go(cb_insert_hot_kernel<false>);
+				if (lazy_stats) { if (vec) go(cb_insert_hot_kernel<true, false>); else go(cb_insert_hot_kernel<false, false>); }
+				else if (vec) go(cb_insert_hot_kernel<true>); else go(cb_insert_hot_kernel<false>);
 			});
 		} else {
 		n_hot = 0;   // (a rebuilt table: the slots of the first attempt are gone)
-		timed("cb_insert", double(n) * (8 + 8 + 4 + 4 + 4), [&] {
-			if (vec) hipLaunchKernelGGL((cb_insert_kernel<256, true>), dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table,
-			                            slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
-			else hipLaunchKernelGGL((cb_insert_kernel<256, false>), dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table,
-			                        slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
+		timed("cb_insert", double(n) * (lazy_stats ? 8 + 4 : 8 + 8 + 4 + 4 + 4), [&] {
+			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p); };
+			if (lazy_stats) { if (vec) go(cb_insert_kernel<256, true, false>); else go(cb_insert_kernel<256, false, false>); }
+			else if (vec) go(cb_insert_kernel<256, true>); else go(cb_insert_kernel<256, false>);
 		});
 		}
 		fetch(&ingest, d_ingest.p, sizeof(ingest));
@@ -381,7 +383,7 @@ dropest_ctx::u64 dropest_ctx::unmap_umi(u64 ucode) const {
 	return ucode;
 }
 
-void dropest_ctx::build_keys() {
+void dropest_ctx::build_keys(bool with_stats) {
 	const u32 n = u32(n_reads);
 	// value buffers hold val_bytes per record (0, 1 or 4): nothing at all for the keys-only layout
 	const size_t val_words = (size_t(n) * size_t(layout.val_bytes) + 3) / 4 + 1;
@@ -390,23 +392,43 @@ void dropest_ctx::build_keys() {
 	GlobalCounters init{};
 	init.key_and = ~0ull;
 	HIP_CHECK(hipMemcpyAsync(d_counters.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
+	if (with_stats) {   // the exact ingest statistics ride along (the layout in use was planned from a sample); the gene ->
+		IngestStats zero{};   // chromosome table holds what the seed pass put there: same protocol, nothing to clear
+		zero.umi_clean_min = ~0ull;
+		zero.gene_chr_conflict = ingest.gene_chr_conflict;
+		HIP_CHECK(hipMemcpyAsync(d_ingest.p, &zero, sizeof(zero), hipMemcpyHostToDevice, stream));
+	}
 	const bool vec = ((uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;
 	timed("build_keys", double(n) * (8 + 4 + 4 + 4 + 4 + 8 + layout.val_bytes), [&] {
 		void *v = vals_a.p;
-		const CbHot hot{hot_key.p, hot_slot.p, n_hot};
+		const CbHot hot{hot_key.p, hot_slot.p, n_hot};   // n_hot: slot[] holds CB_HOT_FLAG | hot index for the reads of the hot barcodes
 		auto go = [&](auto kernel) {
 			const u32 blocks = resident_grid(kernel, 256, div_up(n, 256 * 4));
-			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p, hot);
+			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p, hot,
+			                   gene_chr.p, GENE_CHR_CAP, d_ingest.p);
 		};
-		if (n_hot) {   // slot[] holds CB_HOT_FLAG | hot index for the reads of the hot barcodes
-			if (layout.val_bytes == 0) { if (vec) go(build_keys_kernel<256, 0, true, true>); else go(build_keys_kernel<256, 0, false, true>); }
-			else if (layout.val_bytes == 1) { if (vec) go(build_keys_kernel<256, 1, true, true>); else go(build_keys_kernel<256, 1, false, true>); }
-			else { if (vec) go(build_keys_kernel<256, 4, true, true>); else go(build_keys_kernel<256, 4, false, true>); }
-		} else if (layout.val_bytes == 0) { if (vec) go(build_keys_kernel<256, 0, true>); else go(build_keys_kernel<256, 0, false>); }
-		else if (layout.val_bytes == 1) { if (vec) go(build_keys_kernel<256, 1, true>); else go(build_keys_kernel<256, 1, false>); }
-		else { if (vec) go(build_keys_kernel<256, 4, true>); else go(build_keys_kernel<256, 4, false>); }
+		auto pick = [&](auto vb) {
+			constexpr int VB = decltype(vb)::value;
+			if (with_stats) {
+				if (n_hot) { if (vec) go(build_keys_kernel<256, VB, true, true, true>); else go(build_keys_kernel<256, VB, false, true, true>); }
+				else { if (vec) go(build_keys_kernel<256, VB, true, false, true>); else go(build_keys_kernel<256, VB, false, false, true>); }
+			} else {
+				if (n_hot) { if (vec) go(build_keys_kernel<256, VB, true, true>); else go(build_keys_kernel<256, VB, false, true>); }
+				else { if (vec) go(build_keys_kernel<256, VB, true>); else go(build_keys_kernel<256, VB, false>); }
+			}
+		};
+		if (layout.val_bytes == 0) pick(std::integral_constant<int, 0>{});
+		else if (layout.val_bytes == 1) pick(std::integral_constant<int, 1>{});
+		else pick(std::integral_constant<int, 4>{});
 	});
 	fetch(&counters, d_counters.p, sizeof(counters));
+	if (with_stats) {
+		IngestStats exact{};
+		fetch(&exact, d_ingest.p, sizeof(exact));
+		exact.cb_escape_count = ingest.cb_escape_count;   // counted by cb_insert, which read the barcodes
+		exact.overflow = 0;
+		ingest = exact;
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1037,10 +1059,39 @@ void dropest_ctx::run_ingest() {
 
 void dropest_ctx::run_set_initialized() {
 	if (initialized) throw InvalidError("Container is already initialized");
+	// one context, the whole pass in one call, a stream long enough for the sampled table: the statistics move out of cb_insert
+	// (a sharded run agrees on them between the two halves and keeps the exact ones of cb_insert)
+	{
+		uint64_t sample_min = uint64_t(1) << 22;
+		if (const char *e = getenv("DROPEST_CB_SAMPLE_MIN")) sample_min = uint64_t(std::max(1ll, atoll(e)));
+		lazy_stats = !ingested && n_reads >= sample_min && !getenv("DROPEST_EXACT_INGEST_STATS");
+	}
 	run_ingest();
 	HostStage hs_all(this, "set_initialized");
 	if (n_reads > 0) {
-		{ HostStage hs(this, "keys"); plan_key_layout(); build_keys(); }
+		{
+			HostStage hs(this, "keys");
+			plan_key_layout();
+			if (lazy_stats) {
+				// the plan came from every 256th read: build the keys with it, gather the exact statistics on the way, and keep the
+				// keys if the exact plan is the same one (a different one -- a field a bit wider, a gene on two chromosomes the
+				// sample did not see, an escaped UMI it missed -- costs one more key pass, never a wrong key)
+				const KeyLayout planned = layout;
+				const bool planned_chr = chr_from_gene, planned_strip = umi_sentinel_stripped;
+				const int planned_clean = umi_clean_bits;
+				build_keys(true);
+				lazy_stats = false;
+				plan_key_layout();
+				const bool same = planned.umi_bits == layout.umi_bits && planned.gene_bits == layout.gene_bits && planned.cell_bits == layout.cell_bits &&
+				                  planned.mark_shift == layout.mark_shift && planned.val_bytes == layout.val_bytes &&
+				                  planned.umi_strip_mask == layout.umi_strip_mask && planned.umi_escape_base == layout.umi_escape_base &&
+				                  planned.gene_none == layout.gene_none;
+				if (!same || planned_chr != chr_from_gene || planned_strip != umi_sentinel_stripped || planned_clean != umi_clean_bits) {
+					if (profiling) stats["count:key_plan_redone"].launches += 1;
+					build_keys(false);
+				}
+			} else build_keys();
+		}
 		{ HostStage hs(this, "sort+reduce"); reduce_all(); }
 		accumulate_umi_qualities();
 		{ HostStage hs(this, "real_cells"); fetch_real_cells(); }

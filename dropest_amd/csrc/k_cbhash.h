@@ -110,12 +110,60 @@ __device__ inline uint32_t cb_find(const CbTable &t, unsigned long long k) {   /
 	return 0xFFFFFFFFu;
 }
 
+// Per-thread accumulator of the ingest statistics: the part of a read's (umi, gene, aux) that sizes the sort key and decides
+// whether the chromosome is a function of the gene.  Used by build_keys when the key layout was planned from a sample and the exact
+// statistics ride along with the key pass (cb_insert then reads the barcodes only), and by the sample pass itself.
+struct IngestAcc {
+	unsigned long long umin = ~0ull, umax = 0ull, uesc = 0ull;
+	uint32_t gmax = 0, cmax = 0;
+	bool chr_conflict = false;
+	__device__ inline void add(unsigned long long u, uint32_t g, uint32_t a) {
+		if (u & ESCAPE_BIT) { const unsigned long long id1 = (u & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
+		else { umin = u < umin ? u : umin; umax = u > umax ? u : umax; }
+		if (g != NO_GENE && g + 1 > gmax) gmax = g + 1;
+		const uint32_t chr = a & 0xFFFFu, mark = (a >> 16) & 0xFFu;
+		if ((g == NO_GENE || (mark & 6u)) && chr + 1 > cmax) cmax = chr + 1;
+	}
+	// Is the chromosome a function of the gene?  (Only reads that are counted per chromosome matter: reads with a gene and an
+	// exon / intron mark, CellsDataContainer.cpp:73-78, :312-321.)  One table look-up per read; the CAS runs once per gene.
+	__device__ inline void check_chromosome(uint32_t g, uint32_t a, uint32_t *__restrict__ gene_chr, uint32_t gene_chr_cap) {
+		if (g == NO_GENE || !((a >> 16) & 6u)) return;
+		if (g >= gene_chr_cap) { chr_conflict = true; return; }
+		const uint32_t chr = a & 0xFFFFu;
+		uint32_t cur = gene_chr[g];
+		if (cur == GENE_CHR_UNSET) cur = atomicCAS(&gene_chr[g], GENE_CHR_UNSET, chr), cur = cur == GENE_CHR_UNSET ? chr : cur;
+		if (cur != chr) chr_conflict = true;
+	}
+	__device__ inline void commit(IngestStats *stats) {
+		const unsigned long long mn = wave_reduce_min_u64(umin), mx = wave_reduce_max_u64(umax), es = wave_reduce_max_u64(uesc);
+		const unsigned long long g64 = wave_reduce_max_u64(gmax), c64 = wave_reduce_max_u64(cmax);
+		const unsigned long long conf = wave_reduce_max_u64(chr_conflict ? 1ull : 0ull);
+		if (lane_id() == 0) {
+			if (mn != ~0ull) atomicMin(&stats->umi_clean_min, mn);
+			if (mx != 0ull) atomicMax(&stats->umi_clean_max, mx);
+			if (es) atomicMax(&stats->umi_escape_max_plus1, es);
+			if (g64) atomicMax(&stats->gene_max_plus1, uint32_t(g64));
+			if (c64) atomicMax(&stats->chr_max_plus1, uint32_t(c64));
+			if (conf) atomicMax(&stats->gene_chr_conflict, 1u);
+		}
+	}
+};
+
+// The statistics of every `stride`-th read: what the key layout is planned from when the exact ones are gathered by the key pass.
+__global__ __launch_bounds__(256) void ingest_sample_stats_kernel(const unsigned long long *__restrict__ umi, const uint32_t *__restrict__ gene,
+                                                                  const uint32_t *__restrict__ aux, uint32_t n, uint32_t stride, IngestStats *stats) {
+	IngestAcc acc;
+	for (uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x; j * stride < n; j += uint64_t(gridDim.x) * 256)
+		acc.add(umi[j * stride], gene[j * stride], aux[j * stride]);
+	acc.commit(stats);
+}
+
 // One pass over (cb, umi, gene): table insert + first ordinal + ingest statistics.  Each thread takes FOUR CONSECUTIVE
 // reads per iteration: with 16-byte-aligned arrays (VEC) every streaming access is a 16-byte load / store per lane (two
 // barcodes, two UMIs, four gene ids, four aux words, four slot indices) -- with one read per lane the 4- and 8-byte
 // accesses left the kernel at 1.4 TB/s whatever else it did (the table probes cost nothing: measured with the probe
 // switched off) -- and the four table probes are independent 16-byte loads in flight together.
-template <int THREADS, bool VEC>
+template <int THREADS, bool VEC, bool STATS = true>
 __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long long *__restrict__ cb,
                                                             const unsigned long long *__restrict__ umi,
                                                             const uint32_t *__restrict__ gene,
@@ -145,19 +193,21 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 			h[j] = mix64(k[j]) & t.mask;
 			v[j] = *reinterpret_cast<const uint4 *>(&t.slots[h[j]]);   // key + ~first in one access
 		}
-		if (VEC && full) {
-			const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + r0), u23 = *reinterpret_cast<const ulonglong2 *>(umi + r0 + 2);
-			const uint4 g4 = *reinterpret_cast<const uint4 *>(gene + r0), a4 = *reinterpret_cast<const uint4 *>(aux + r0);
-			u[0] = u01.x; u[1] = u01.y; u[2] = u23.x; u[3] = u23.y;
-			g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
-			a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
-		} else {
+		if (STATS) {
+			if (VEC && full) {
+				const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + r0), u23 = *reinterpret_cast<const ulonglong2 *>(umi + r0 + 2);
+				const uint4 g4 = *reinterpret_cast<const uint4 *>(gene + r0), a4 = *reinterpret_cast<const uint4 *>(aux + r0);
+				u[0] = u01.x; u[1] = u01.y; u[2] = u23.x; u[3] = u23.y;
+				g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+				a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
+			} else {
 #pragma unroll
-			for (int j = 0; j < ILP; ++j) {
-				const uint64_t r = r0 + j;
-				u[j] = r < n ? umi[r] : 0ull;
-				g[j] = r < n ? gene[r] : NO_GENE;
-				a[j] = r < n ? aux[r] : 0u;
+				for (int j = 0; j < ILP; ++j) {
+					const uint64_t r = r0 + j;
+					u[j] = r < n ? umi[r] : 0ull;
+					g[j] = r < n ? gene[r] : NO_GENE;
+					a[j] = r < n ? aux[r] : 0u;
+				}
 			}
 		}
 		uint32_t pending = 0, hinted = 0;
@@ -180,22 +230,27 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 			// stale (too large) hints only cost an extra atomic; ordinals only ever decrease
 			const uint32_t first_hint = ((hinted >> j) & 1u) ? ~v[j].z : 0xFFFFFFFFu;
 			if (uint32_t(r) < first_hint) atomicMax(&t.slots[s].nfirst, ~uint32_t(r));
-			if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
-			else { umin = u[j] < umin ? u[j] : umin; umax = u[j] > umax ? u[j] : umax; }
+			if (STATS) {
+				if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
+				else { umin = u[j] < umin ? u[j] : umin; umax = u[j] > umax ? u[j] : umax; }
+			}
 			if (k[j] & ESCAPE_BIT) ++cbesc;
-			if (g[j] != NO_GENE && g[j] + 1 > gmax) gmax = g[j] + 1;
-			// Is the chromosome a function of the gene?  (Only reads that are counted per chromosome matter:
-			// gene-less reads and reads with an exon / intron mark, CellsDataContainer.cpp:73-78, :312-321.)
-			const uint32_t chr = a[j] & 0xFFFFu, mark = (a[j] >> 16) & 0xFFu;
-			if (g[j] == NO_GENE) { if (chr + 1 > cmax) cmax = chr + 1; }
-			else if (mark & 6u) {
-				if (chr + 1 > cmax) cmax = chr + 1;
-				if (g[j] >= gene_chr_cap) chr_conflict = true;
-				else {
-					uint32_t cur2 = gene_chr[g[j]];            // L1/L2-hot table; the CAS runs once per gene
-					if (cur2 == GENE_CHR_UNSET) cur2 = atomicCAS(&gene_chr[g[j]], GENE_CHR_UNSET, chr), cur2 = cur2 == GENE_CHR_UNSET ? chr : cur2;
-					if (cur2 != chr) chr_conflict = true;
+			if (STATS) {
+				if (g[j] != NO_GENE && g[j] + 1 > gmax) gmax = g[j] + 1;
+				// Is the chromosome a function of the gene?  (Only reads that are counted per chromosome matter:
+				// gene-less reads and reads with an exon / intron mark, CellsDataContainer.cpp:73-78, :312-321.)
+				const uint32_t chr = a[j] & 0xFFFFu, mark = (a[j] >> 16) & 0xFFu;
+				if (g[j] == NO_GENE) { if (chr + 1 > cmax) cmax = chr + 1; }
+				else if (mark & 6u) {
+					if (chr + 1 > cmax) cmax = chr + 1;
+					if (g[j] >= gene_chr_cap) chr_conflict = true;
+					else {
+						uint32_t cur2 = gene_chr[g[j]];            // L1/L2-hot table; the CAS runs once per gene
+						if (cur2 == GENE_CHR_UNSET) cur2 = atomicCAS(&gene_chr[g[j]], GENE_CHR_UNSET, chr), cur2 = cur2 == GENE_CHR_UNSET ? chr : cur2;
+						if (cur2 != chr) chr_conflict = true;
+					}
 				}
+		
 			}
 		}
 		if (VEC && full) *reinterpret_cast<uint4 *>(slot_out + r0) = make_uint4(sl[0], sl[1], sl[2], sl[3]);
@@ -313,7 +368,7 @@ __global__ __launch_bounds__(256) void cb_hot_preinsert_kernel(const unsigned lo
 // CU's 160 KB); slot_out[r] = CB_HOT_FLAG | hot index for a hit, the table slot otherwise.  Per-entry minimum of the read
 // ordinals seen by this workgroup keeps the atomics on the table to the few reads that lower it.
 struct CbHot { const unsigned long long *key; const uint32_t *slot; uint32_t n; };
-template <bool VEC>
+template <bool VEC, bool STATS = true>
 __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long long *__restrict__ cb,
                                                              const unsigned long long *__restrict__ umi,
                                                              const uint32_t *__restrict__ gene,
@@ -349,18 +404,20 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 		const bool full = r0 + ILP <= n;
 		if (VEC && full) {
 			const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(cb + r0), k23 = *reinterpret_cast<const ulonglong2 *>(cb + r0 + 2);
-			const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + r0), u23 = *reinterpret_cast<const ulonglong2 *>(umi + r0 + 2);
-			const uint4 g4 = *reinterpret_cast<const uint4 *>(gene + r0), a4 = *reinterpret_cast<const uint4 *>(aux + r0);
 			k[0] = k01.x; k[1] = k01.y; k[2] = k23.x; k[3] = k23.y;
-			u[0] = u01.x; u[1] = u01.y; u[2] = u23.x; u[3] = u23.y;
-			g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
-			a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
+			if (STATS) {
+				const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + r0), u23 = *reinterpret_cast<const ulonglong2 *>(umi + r0 + 2);
+				const uint4 g4 = *reinterpret_cast<const uint4 *>(gene + r0), a4 = *reinterpret_cast<const uint4 *>(aux + r0);
+				u[0] = u01.x; u[1] = u01.y; u[2] = u23.x; u[3] = u23.y;
+				g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+				a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
+			}
 		} else {
 #pragma unroll
 			for (int j = 0; j < ILP; ++j) {
 				const uint64_t r = r0 + j;
-				k[j] = r < n ? cb[r] : 0ull; u[j] = r < n ? umi[r] : 0ull;
-				g[j] = r < n ? gene[r] : NO_GENE; a[j] = r < n ? aux[r] : 0u;
+				k[j] = r < n ? cb[r] : 0ull;
+				if (STATS) { u[j] = r < n ? umi[r] : 0ull; g[j] = r < n ? gene[r] : NO_GENE; a[j] = r < n ? aux[r] : 0u; }
 			}
 		}
 #pragma unroll
@@ -410,20 +467,25 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 				const uint32_t first_hint = ((hinted >> j) & 1u) ? ~v[j].z : 0xFFFFFFFFu;
 				if (uint32_t(r) < first_hint) atomicMax(&t.slots[sl[j]].nfirst, ~uint32_t(r));
 			}
-			if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
-			else { umin = u[j] < umin ? u[j] : umin; umax = u[j] > umax ? u[j] : umax; }
+			if (STATS) {
+				if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
+				else { umin = u[j] < umin ? u[j] : umin; umax = u[j] > umax ? u[j] : umax; }
+			}
 			if (k[j] & ESCAPE_BIT) ++cbesc;
-			if (g[j] != NO_GENE && g[j] + 1 > gmax) gmax = g[j] + 1;
-			const uint32_t chr = a[j] & 0xFFFFu, mark = (a[j] >> 16) & 0xFFu;
-			if (g[j] == NO_GENE) { if (chr + 1 > cmax) cmax = chr + 1; }
-			else if (mark & 6u) {
-				if (chr + 1 > cmax) cmax = chr + 1;
-				if (g[j] >= gene_chr_cap) chr_conflict = true;
-				else {
-					uint32_t cur2 = gene_chr[g[j]];
-					if (cur2 == GENE_CHR_UNSET) cur2 = atomicCAS(&gene_chr[g[j]], GENE_CHR_UNSET, chr), cur2 = cur2 == GENE_CHR_UNSET ? chr : cur2;
-					if (cur2 != chr) chr_conflict = true;
+			if (STATS) {
+				if (g[j] != NO_GENE && g[j] + 1 > gmax) gmax = g[j] + 1;
+				const uint32_t chr = a[j] & 0xFFFFu, mark = (a[j] >> 16) & 0xFFu;
+				if (g[j] == NO_GENE) { if (chr + 1 > cmax) cmax = chr + 1; }
+				else if (mark & 6u) {
+					if (chr + 1 > cmax) cmax = chr + 1;
+					if (g[j] >= gene_chr_cap) chr_conflict = true;
+					else {
+						uint32_t cur2 = gene_chr[g[j]];
+						if (cur2 == GENE_CHR_UNSET) cur2 = atomicCAS(&gene_chr[g[j]], GENE_CHR_UNSET, chr), cur2 = cur2 == GENE_CHR_UNSET ? chr : cur2;
+						if (cur2 != chr) chr_conflict = true;
+					}
 				}
+		
 			}
 		}
 		if (VEC && full) *reinterpret_cast<uint4 *>(slot_out + r0) = make_uint4(sl[0], sl[1], sl[2], sl[3]);

@@ -47,13 +47,16 @@ struct GlobalCounters {   // CellsDataContainer.cpp:73-78, :309-327
 	unsigned long long key_or, key_and;
 };
 
-template <int THREADS, int VB, bool VEC, bool HOT = false>
+// STATS: the exact ingest statistics (k_cbhash.h: IngestAcc) ride along -- the layout L was planned from a sample of the reads and is
+// checked against them afterwards (dropest_ctx::run_set_initialized); cb_insert then read the barcodes only.
+template <int THREADS, int VB, bool VEC, bool HOT = false, bool STATS = false>
 __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long long *__restrict__ umi,
                                                              const uint32_t *__restrict__ gene,
                                                              const uint32_t *__restrict__ aux,
                                                              const uint32_t *__restrict__ slot, uint32_t n, CbTable t,
                                                              KeyLayout L, unsigned long long *__restrict__ keys,
-                                                             void *__restrict__ vals_, GlobalCounters *gc, CbHot hot = CbHot{nullptr, nullptr, 0}) {
+                                                             void *__restrict__ vals_, GlobalCounters *gc, CbHot hot = CbHot{nullptr, nullptr, 0},
+                                                             uint32_t *__restrict__ gene_chr = nullptr, uint32_t gene_chr_cap = 0, IngestStats *stats = nullptr) {
 	// the cell ids of the hot barcodes (k_cbhash.h): 16 KB of LDS instead of one L2 request per read
 	__shared__ uint32_t hot_cell[HOT ? CB_HOT_MAX : 1];
 	if (HOT) {
@@ -61,6 +64,7 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 		__syncthreads();
 	}
 	unsigned long long c_inter = 0, c_exon = 0, c_intron = 0, c_na = 0, k_or = 0, k_and = ~0ull;
+	IngestAcc acc;
 	// four CONSECUTIVE records per thread and iteration: 16-byte accesses per lane on every stream when the arrays are
 	// 16-byte aligned (VEC), then the four dependent gathers of the cell ids
 	constexpr int U = 4;
@@ -97,6 +101,7 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 			const uint64_t r = base + q;
 			kk[q] = 0;
 			if (r >= n) continue;
+			if (STATS) { acc.add(u[q], g[q], a[q]); acc.check_chromosome(g[q], a[q], gene_chr, gene_chr_cap); }
 			uint32_t mark = (a[q] >> 16) & 0xFFu;
 			unsigned long long gcode, ucode;
 			if (g[q] == NO_GENE) {
@@ -128,6 +133,7 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 			for (int q = 0; q < U; ++q) if (base + q < n) keys[base + q] = kk[q];
 		}
 	}
+	if (STATS) acc.commit(stats);
 	c_inter = wave_reduce_add_u64(c_inter); c_exon = wave_reduce_add_u64(c_exon);
 	c_intron = wave_reduce_add_u64(c_intron); c_na = wave_reduce_add_u64(c_na);
 	k_or = wave_reduce_or_u64(k_or); k_and = wave_reduce_and_u64(k_and);
