@@ -126,11 +126,12 @@ struct IngestAcc {
 	}
 	// Is the chromosome a function of the gene?  (Only reads that are counted per chromosome matter: reads with a gene and an
 	// exon / intron mark, CellsDataContainer.cpp:73-78, :312-321.)  One table look-up per read; the CAS runs once per gene.
-	__device__ inline void check_chromosome(uint32_t g, uint32_t a, uint32_t *__restrict__ gene_chr, uint32_t gene_chr_cap) {
+	// `loaded`: the entry as the caller read it earlier (with other loads in flight)
+	__device__ inline void check_chromosome(uint32_t g, uint32_t a, uint32_t *__restrict__ gene_chr, uint32_t gene_chr_cap, uint32_t loaded) {
 		if (g == NO_GENE || !((a >> 16) & 6u)) return;
 		if (g >= gene_chr_cap) { chr_conflict = true; return; }
 		const uint32_t chr = a & 0xFFFFu;
-		uint32_t cur = gene_chr[g];
+		uint32_t cur = loaded;
 		if (cur == GENE_CHR_UNSET) cur = atomicCAS(&gene_chr[g], GENE_CHR_UNSET, chr), cur = cur == GENE_CHR_UNSET ? chr : cur;
 		if (cur != chr) chr_conflict = true;
 	}

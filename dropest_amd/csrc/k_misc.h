@@ -90,18 +90,21 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 				if (r < n) { sl[q] = slot[r]; g[q] = gene[r]; a[q] = aux[r]; u[q] = umi[r]; }
 			}
 		}
+		uint32_t gc[U];   // STATS: the gene -> chromosome entries, in flight together with the cell-id look-ups
 #pragma unroll
 		for (int q = 0; q < U; ++q) {
 			if (base + q >= n) cell[q] = 0u;
 			else if (HOT && (sl[q] & CB_HOT_FLAG)) cell[q] = hot_cell[sl[q] & ~CB_HOT_FLAG];
 			else cell[q] = t.slots[sl[q]].cell_id;
+			gc[q] = 0u;
+			if (STATS && base + q < n && g[q] != NO_GENE && ((a[q] >> 16) & 6u) && g[q] < gene_chr_cap) gc[q] = gene_chr[g[q]];
 		}
 #pragma unroll
 		for (int q = 0; q < U; ++q) {
 			const uint64_t r = base + q;
 			kk[q] = 0;
 			if (r >= n) continue;
-			if (STATS) { acc.add(u[q], g[q], a[q]); acc.check_chromosome(g[q], a[q], gene_chr, gene_chr_cap); }
+			if (STATS) { acc.add(u[q], g[q], a[q]); acc.check_chromosome(g[q], a[q], gene_chr, gene_chr_cap, gc[q]); }
 			uint32_t mark = (a[q] >> 16) & 0xFFu;
 			unsigned long long gcode, ucode;
 			if (g[q] == NO_GENE) {
