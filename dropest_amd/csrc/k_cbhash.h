@@ -398,14 +398,30 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 	uint32_t gmax = 0, cmax = 0;
 	bool ok = true, chr_conflict = false;
 	const uint64_t stride = uint64_t(gridDim.x) * THREADS * ILP;
+	// the barcodes of the NEXT tile are in flight while this one is worked on (4 waves per SIMD do not hide the load by themselves)
+	auto load_cb = [&](uint64_t r0, unsigned long long (&kk)[ILP]) {
+		if (VEC && r0 + ILP <= n) {
+			const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(cb + r0), k23 = *reinterpret_cast<const ulonglong2 *>(cb + r0 + 2);
+			kk[0] = k01.x; kk[1] = k01.y; kk[2] = k23.x; kk[3] = k23.y;
+		} else {
+#pragma unroll
+			for (int j = 0; j < ILP; ++j) kk[j] = r0 + j < n ? cb[r0 + j] : 0ull;
+		}
+	};
+	unsigned long long k_next[ILP] = {0ull, 0ull, 0ull, 0ull};
+	{
+		const uint64_t first = (uint64_t(blockIdx.x) * THREADS + threadIdx.x) * ILP;
+		if (first < n) load_cb(first, k_next);
+	}
 	for (uint64_t r0 = (uint64_t(blockIdx.x) * THREADS + threadIdx.x) * ILP; r0 < n; r0 += stride) {
 		unsigned long long k[ILP], u[ILP];
 		uint64_t h[ILP];
 		uint32_t g[ILP], a[ILP], sl[ILP], hit[ILP];
 		const bool full = r0 + ILP <= n;
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) k[j] = k_next[j];
+		if (r0 + stride < n) load_cb(r0 + stride, k_next);
 		if (VEC && full) {
-			const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(cb + r0), k23 = *reinterpret_cast<const ulonglong2 *>(cb + r0 + 2);
-			k[0] = k01.x; k[1] = k01.y; k[2] = k23.x; k[3] = k23.y;
 			if (STATS) {
 				const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + r0), u23 = *reinterpret_cast<const ulonglong2 *>(umi + r0 + 2);
 				const uint4 g4 = *reinterpret_cast<const uint4 *>(gene + r0), a4 = *reinterpret_cast<const uint4 *>(aux + r0);
@@ -417,7 +433,6 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 #pragma unroll
 			for (int j = 0; j < ILP; ++j) {
 				const uint64_t r = r0 + j;
-				k[j] = r < n ? cb[r] : 0ull;
 				if (STATS) { u[j] = r < n ? umi[r] : 0ull; g[j] = r < n ? gene[r] : NO_GENE; a[j] = r < n ? aux[r] : 0u; }
 			}
 		}
