@@ -12,6 +12,8 @@
 #include "context.h"
 
 #include <functional>
+#include <map>
+#include <mutex>
 
 using namespace dropest;
 
@@ -547,6 +549,37 @@ static int sort_mode_override() {   // read at every pass: tests switch it insid
 	return !strcmp(e, "lsd") ? 1 : (!strcmp(e, "splitter") ? 2 : 0);
 }
 
+// Does the LDS apply the lanes of one atomic instruction that hit the same address in lane order?  (ss_local's one-instruction
+// ranking is stable only then.)  Checked once per device on 256 random digit patterns with 1 .. 64 distinct values.
+static bool lds_atomics_lane_ordered(int device, hipStream_t stream) {
+	static std::mutex mu;
+	static std::map<int, bool> known;
+	std::lock_guard<std::mutex> lk(mu);
+	auto it = known.find(device);
+	if (it != known.end()) return it->second;
+	if (getenv("DROPEST_SS_BALLOT_RANK")) return known[device] = false;
+	const u32 rounds = 256;
+	std::vector<u32> h(size_t(rounds) * 64), got(size_t(rounds) * 64);
+	u32 x = 2463534242u;
+	for (u32 r = 0; r < rounds; ++r) {
+		const u32 nd = 1u + r % 64u;
+		for (u32 l = 0; l < 64; ++l) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; h[size_t(r) * 64 + l] = (x >> 8) % nd; }
+	}
+	DevBuf<u32> d_in, d_out;
+	d_in.alloc(h.size()); d_out.alloc(h.size());
+	HIP_CHECK(hipMemcpyAsync(d_in.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, stream));
+	hipLaunchKernelGGL(ss_lds_order_probe_kernel, dim3(1), dim3(64), 0, stream, d_in.p, rounds, d_out.p);
+	HIP_CHECK(hipGetLastError());
+	HIP_CHECK(hipMemcpyAsync(got.data(), d_out.p, got.size() * 4, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(hipStreamSynchronize(stream));
+	bool ordered = true;
+	for (u32 r = 0; r < rounds && ordered; ++r) {
+		u32 seen[64] = {0};
+		for (u32 l = 0; l < 64; ++l) { const u32 d = h[size_t(r) * 64 + l]; if (got[size_t(r) * 64 + l] != seen[d]) ordered = false; ++seen[d]; }
+	}
+	return known[device] = ordered;
+}
+
 bool dropest_ctx::splitter_sort_reduce() {
 	const u32 n = u32(n_reads);
 	const int mode = sort_mode_override();
@@ -637,6 +670,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 	// finishing sort: sparse molecule rows at each bucket's own record offset (key rows re-use the partition's alternate
 	// buffer), then scan of the per-bucket row counts and compaction into the dense table
 	const u32 SMALL_MAX = 2048;
+	const bool atomic_rank = lds_atomics_lane_ordered(cfg.device, stream);
 	ss_tmp.ensure(size_t(n) * 2 + 2); ss_n_loc.ensure(F2); ss_prefix.ensure(F2); ss_chunk.ensure(1024);
 	SsLocalArgs a{};
 	a.keys = keys; a.vals = vals; a.bucket_base = ss_bucket_base.p; a.bucket_cnt = ss_bucket_cnt.p; a.n_buckets = F2; a.ms = ms;
@@ -646,7 +680,8 @@ bool dropest_ctx::splitter_sort_reduce() {
 	{
 		const size_t lds = ss_local_lds_bytes(a.cap, 256);
 		timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB) + double(n) * 0.42 * 16, [&] {
-			if (VB) hipLaunchKernelGGL(ss_local_kernel<1>, dim3(F2), dim3(256), lds, stream, a);
+			if (atomic_rank) { if (VB) hipLaunchKernelGGL((ss_local_kernel<1, true>), dim3(F2), dim3(256), lds, stream, a); else hipLaunchKernelGGL((ss_local_kernel<0, true>), dim3(F2), dim3(256), lds, stream, a); }
+			else if (VB) hipLaunchKernelGGL(ss_local_kernel<1>, dim3(F2), dim3(256), lds, stream, a);
 			else hipLaunchKernelGGL(ss_local_kernel<0>, dim3(F2), dim3(256), lds, stream, a);
 		});
 	}
@@ -665,8 +700,13 @@ bool dropest_ctx::splitter_sort_reduce() {
 			hipLaunchKernelGGL(kernel, dim3(u32(count)), dim3(threads), lds, stream, g);
 		};
 		timed("ss_local:big", 0, [&] {
-			if (!medium.empty()) { if (VB) launch(ss_local_big_kernel<256, 1>, 256, 4096, ss_big_list.p, medium.size()); else launch(ss_local_big_kernel<256, 0>, 256, 4096, ss_big_list.p, medium.size()); }
-			if (!big.empty()) { if (VB) launch(ss_local_big_kernel<512, 1>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); else launch(ss_local_big_kernel<512, 0>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); }
+			if (atomic_rank) {
+				if (!medium.empty()) { if (VB) launch(ss_local_big_kernel<256, 1, true>, 256, 4096, ss_big_list.p, medium.size()); else launch(ss_local_big_kernel<256, 0, true>, 256, 4096, ss_big_list.p, medium.size()); }
+				if (!big.empty()) { if (VB) launch(ss_local_big_kernel<512, 1, true>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); else launch(ss_local_big_kernel<512, 0, true>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); }
+			} else {
+				if (!medium.empty()) { if (VB) launch(ss_local_big_kernel<256, 1>, 256, 4096, ss_big_list.p, medium.size()); else launch(ss_local_big_kernel<256, 0>, 256, 4096, ss_big_list.p, medium.size()); }
+				if (!big.empty()) { if (VB) launch(ss_local_big_kernel<512, 1>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); else launch(ss_local_big_kernel<512, 0>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); }
+			}
 		});
 		HIP_CHECK(hipStreamSynchronize(stream));   // the host lists must outlive their copies
 	}

@@ -284,7 +284,11 @@ struct SsLocalArgs {
 
 // LDS of ss_local (dynamic, 16-byte aligned): sk[cap] keys -- later aliased by agg[cap] + headpos[cap] (u32 each) --,
 // wcnt[WAVES][256], tstart[256], scratch, red[], sv[cap] bytes
-template <int THREADS, int ITEMS, int VB>
+// ATOMIC_RANK: the rank of a record among the records of its wave with the same digit comes from ONE LDS atomic add (returning the
+// old count) instead of 8 ballots + ~50 ALU instructions.  That is stable only because the LDS applies the lanes of one instruction
+// that hit the same address in lane order -- true on gfx950, checked once per device before it is relied on
+// (dropest_amd.hip: lds_atomics_lane_ordered); the ballot ranking of k_radix.h is the fall-back.
+template <int THREADS, int ITEMS, int VB, bool ATOMIC_RANK = false>
 __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint32_t base, uint32_t cnt, unsigned char *smem) {
 	constexpr uint32_t WAVES = THREADS / 64;
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
@@ -334,6 +338,7 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint3
 		for (int i = 0; i < ITEMS; ++i) {
 			const bool valid = (lane_off + i * 64) < cnt;
 			const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
+			if (ATOMIC_RANK) { lrank[i] = valid ? atomicAdd(&wcnt[w * 256 + d], 1u) : 0u; continue; }
 			uint32_t diff_lo = 0, diff_hi = 0;
 #pragma unroll
 			for (int b = 0; b < 8; ++b) {
@@ -420,22 +425,22 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint3
 }
 
 // small launch: grid = all buckets, 256 threads, buckets of up to 2048 records (larger ones are listed for the big launch)
-template <int VB>
+template <int VB, bool ATOMIC_RANK = false>
 __global__ __launch_bounds__(256) void ss_local_kernel(SsLocalArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];
 	const uint32_t b = blockIdx.x;
 	const uint32_t cnt = a.bucket_cnt[b], base = a.bucket_base[b];
 	if (cnt == 0) { if (threadIdx.x == 0) a.n_loc[b] = 0; return; }
 	if (cnt > a.skip_above) return;
-	if (cnt <= 1024) ss_local_run<256, 4, VB>(a, b, base, cnt, ss_smem);
-	else ss_local_run<256, 8, VB>(a, b, base, cnt, ss_smem);
+	if (cnt <= 1024) ss_local_run<256, 4, VB, ATOMIC_RANK>(a, b, base, cnt, ss_smem);
+	else ss_local_run<256, 8, VB, ATOMIC_RANK>(a, b, base, cnt, ss_smem);
 }
 // listed buckets: medium launch 256 threads x 16 records (up to 4096), big launch 512 x 16 (up to 8192)
-template <int THREADS, int VB>
+template <int THREADS, int VB, bool ATOMIC_RANK = false>
 __global__ __launch_bounds__(THREADS) void ss_local_big_kernel(SsLocalArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];
 	const uint32_t b = a.big_list[blockIdx.x];
-	ss_local_run<THREADS, 16, VB>(a, b, a.bucket_base[b], a.bucket_cnt[b], ss_smem);
+	ss_local_run<THREADS, 16, VB, ATOMIC_RANK>(a, b, a.bucket_base[b], a.bucket_cnt[b], ss_smem);
 }
 
 // bytes of dynamic LDS ss_local needs for `cap` records
@@ -443,6 +448,17 @@ inline size_t ss_local_lds_bytes(uint32_t cap, int threads) {
 	const size_t waves = size_t(threads) / 64;
 	size_t words = waves * 256 + 256 + (size_t(threads) / 64 + 1) + waves + 4 + ((waves + 1) & 1u);
 	return size_t(cap) * 8 + words * 4 + 2 * waves * 8 + size_t(cap) + 16;
+}
+
+// probe of the property ATOMIC_RANK relies on: 64 lanes add 1 to counters picked by `digit`; out = what each lane got back
+__global__ __launch_bounds__(64) void ss_lds_order_probe_kernel(const uint32_t *__restrict__ digit, uint32_t rounds, uint32_t *__restrict__ out) {
+	__shared__ uint32_t cnt[64];
+	for (uint32_t r = 0; r < rounds; ++r) {
+		cnt[threadIdx.x] = 0;
+		__builtin_amdgcn_wave_barrier();
+		out[r * 64 + threadIdx.x] = atomicAdd(&cnt[digit[r * 64 + threadIdx.x] & 63u], 1u);
+		__builtin_amdgcn_wave_barrier();
+	}
 }
 
 // ---- compaction of the sparse rows ---------------------------------------------------------------------------------
