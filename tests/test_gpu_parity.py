@@ -38,6 +38,30 @@ def test_c2_shape_1m_chunked():
     _both(dict(n_cells=200, n_genes=8000), 1_000_000, 20, 100, chunks=7)
 
 
+def test_c2_shape_6m_at_natural_thresholds():
+    """Past 2^22 reads one context switches, without any environment override, to the barcode table sized from a sample, the LDS
+    table of hot barcodes, the key layout planned from a sample (exact statistics gathered with the keys) and the splitter sort with
+    its one-atomic ranking: every observable against the oracle (~15 s of oracle time)."""
+    o, c = _both(dict(n_cells=300, n_genes=30000), 6_000_000, 20, 100, chunks=3)
+    assert len(c.filtered_cells()) > 250
+    lay = c.sort_layout()
+    assert lay["sort"] == "splitter"
+
+
+def test_c3_shape_5m_with_n_umis_and_merge_at_natural_thresholds():
+    s = SynthStream(n_reads=5_000_000, n_cells=400, n_genes=20000, umi_len=12, permille_neighbour=100, stream_id=3)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    from dropest_amd.synth import inject_n
+    umi, side = inject_n(umi, gene, 2e-4, 3, 12)
+    wl = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropest_amd", "data", "barcodes", "10x_aug_2016_split")
+    o = parity.oracle_run(Oracle, dict(merge_kind=1, barcodes_kind=capi.BARCODES_CONST, barcodes_file=wl, min_genes_before=10, min_genes_after=50),
+                          cb, umi, gene, aux, side)
+    c = parity.gpu_run(dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST, barcodes_file=wl, min_genes_before_merge=10,
+                            min_genes_after_merge=50), cb, umi, gene, aux, side)
+    parity.compare(o, c, side)
+    assert int(c.cell_rows()["is_merged"].sum()) > 1000
+
+
 def test_query_levels_and_reads_output():
     _both(dict(n_cells=30, n_genes=1500), 60_000, 10, 10, levels="e", reads_output=True)
     _both(dict(n_cells=30, n_genes=1500), 60_000, 10, 10, levels="iI")
