@@ -338,7 +338,6 @@ struct dropest_ctx {
 	std::vector<hipEvent_t> event_pool;
 
 	// wall-clock time of a host stage (only while profiling); reported as "host:<name>" in the kernel stats
-	dropest::DevPool pool;   // recycled temporary device buffers of this context's stages (util.h)
 	bool stage_sync = getenv("DROPEST_STAGE_SYNC") != nullptr;   // host-stage timers synchronise the stream (tuning aid, slows the pass)
 	struct HostStage {
 		dropest_ctx *c; const char *name; std::chrono::steady_clock::time_point t0;

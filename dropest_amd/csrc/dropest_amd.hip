@@ -1086,7 +1086,6 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 void dropest_ctx::run_ingest() {
 	if (initialized) throw InvalidError("Container is already initialized");
 	if (ingested) return;
-	dropest::DevPoolScope pool_scope(&pool);
 	HostStage hs_all(this, "ingest");
 	concat_chunks();
 	ingest = IngestStats{};
@@ -1108,7 +1107,6 @@ void dropest_ctx::run_set_initialized() {
 		lazy_stats = !ingested && n_reads >= sample_min && !getenv("DROPEST_EXACT_INGEST_STATS");
 	}
 	run_ingest();
-	dropest::DevPoolScope pool_scope(&pool);
 	HostStage hs_all(this, "set_initialized");
 	if (n_reads > 0) {
 		{
@@ -1147,7 +1145,6 @@ void dropest_ctx::run_merge_and_filter() {
 	if (!initialized) throw InvalidError("You must initialize container");
 	if (merged) throw InvalidError("merge_and_filter was already run");
 	invalidate_prefetch();
-	dropest::DevPoolScope pool_scope(&pool);
 	HostStage hs(this, "merge_and_filter");
 	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells && !external_merge_done) run_cb_merge_real();
 	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL && n_cells) run_cb_merge_real();   // same loop, Poisson decisions

@@ -824,7 +824,6 @@ void dropest_shard::step() {
 	using namespace dropest;
 	dropest_ctx &c = *ctx;
 	HIP_CHECK(hipSetDevice(c.cfg.device));
-	dropest::DevPoolScope pool_scope(&c.pool);   // temporaries of this shard's thread recycle through its context's pool
 	Phase whole(this, "step");
 	// the ordinal ranges of all shards (ordinals name reads across shards: first-seen order, N-UMI tie breaks)
 	if (pushed.n) {   // reads pushed from host memory: wait for the last batch, use the store in place

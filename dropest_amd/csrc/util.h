@@ -37,76 +37,23 @@ __host__ __device__ inline int bit_length(uint64_t x) { return x ? 64 - __builti
 
 constexpr int WAVE = 64;   // gfx950 wavefront
 
-// Recycling of temporary device buffers.  The host side of a pass (merges, orderings, UMI groups) works through dozens of
-// short-lived DevBufs; every hipFree synchronises the device and every hipMalloc costs tens of microseconds -- at C3 size some
-// 20 of each per pass.  While a DevPool is ACTIVE on the calling thread (DevPoolScope: the context's own pool, for the length of
-// a stage), DevBuf::alloc takes a block from it when one fits and DevBuf::release gives the block to it instead of freeing.
-// Ownership stays simple: whoever holds a pointer frees it with hipFree unless a pool is active to take it; the pool frees
-// what it holds when it dies.
-struct DevPool {
-	struct Block { void *p; size_t bytes; };
-	std::vector<Block> blocks;
-	size_t held = 0, cap_bytes = size_t(8) << 30;
-	~DevPool() { trim(0); }
-	void trim(size_t keep) { while (held > keep && !blocks.empty()) { (void)hipFree(blocks.back().p); held -= blocks.back().bytes; blocks.pop_back(); } }
-	void *take(size_t bytes, size_t *got) {
-		size_t best = blocks.size();
-		for (size_t i = 0; i < blocks.size(); ++i)
-			if (blocks[i].bytes >= bytes && blocks[i].bytes <= bytes * 2 + (size_t(1) << 16) && (best == blocks.size() || blocks[i].bytes < blocks[best].bytes)) best = i;
-		if (best == blocks.size()) return nullptr;
-		void *p = blocks[best].p;
-		*got = blocks[best].bytes; held -= blocks[best].bytes;
-		blocks[best] = blocks.back(); blocks.pop_back();
-		return p;
-	}
-	bool give(void *p, size_t bytes) {
-		if (bytes > cap_bytes || blocks.size() >= 256) return false;
-		blocks.push_back(Block{p, bytes}); held += bytes;
-		if (held > cap_bytes) {   // drop the oldest blocks
-			size_t i = 0;
-			while (held > cap_bytes && i + 1 < blocks.size()) { (void)hipFree(blocks[i].p); held -= blocks[i].bytes; ++i; }
-			blocks.erase(blocks.begin(), blocks.begin() + long(i));
-		}
-		return true;
-	}
-};
-inline DevPool *&active_dev_pool() { static thread_local DevPool *p = nullptr; return p; }
-struct DevPoolScope {
-	DevPool *prev;
-	explicit DevPoolScope(DevPool *p) : prev(active_dev_pool()) { active_dev_pool() = p; }
-	~DevPoolScope() { active_dev_pool() = prev; }
-	DevPoolScope(const DevPoolScope &) = delete;
-	DevPoolScope &operator=(const DevPoolScope &) = delete;
-};
-
 // RAII device buffer
 template <typename T>
 struct DevBuf {
 	T *p = nullptr;
 	size_t n = 0;
-	size_t block_bytes = 0;   // size of the allocation behind p (a recycled block may be larger than n elements)
 	DevBuf() = default;
 	DevBuf(const DevBuf &) = delete;
 	DevBuf &operator=(const DevBuf &) = delete;
-	DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), block_bytes(o.block_bytes) { o.p = nullptr; o.n = 0; o.block_bytes = 0; }
-	DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; block_bytes = o.block_bytes; o.p = nullptr; o.n = 0; o.block_bytes = 0; } return *this; }
+	DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+	DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
 	~DevBuf() { release(); }
-	void release() {
-		if (!p) return;
-		DevPool *pool = active_dev_pool();
-		if (!pool || !pool->give(p, block_bytes)) (void)hipFree(p);
-		p = nullptr; n = 0; block_bytes = 0;
-	}
+	void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
 	void alloc(size_t count) {
 		release();
 		if (count == 0) count = 1;
-		const size_t bytes = count * sizeof(T);
-		if (DevPool *pool = active_dev_pool()) {
-			size_t got = 0;
-			if (void *q = pool->take(bytes, &got)) { p = static_cast<T *>(q); n = count; block_bytes = got; return; }
-		}
-		HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), bytes));
-		n = count; block_bytes = bytes;
+		HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+		n = count;
 	}
 	void ensure(size_t count) { if (count > n) alloc(count); }
 	size_t bytes() const { return n * sizeof(T); }
