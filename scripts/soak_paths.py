@@ -41,11 +41,18 @@ for it in range(int(os.environ.get("ITERS", "6"))):
     if merge:
         kw.update(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST, barcodes_file=os.path.join(DATA, "10x_aug_2016_split"))
     t0 = time.time()
+    if it < int(os.environ.get("SKIP", "0")):
+        dev.free(); continue
+    print(it, shape, kw.get("merge_kind"), flush=True)
     a = run(dev, (), kw, OLD)
-    b = run(dev, (), kw, {})
+    only = os.environ.get("NEW_ENV")           # e.g. "DROPEST_CB_NO_HOT=1,DROPEST_SORT=lsd": bisect which fast path differs
+    b = run(dev, (), kw, dict(x.split("=") for x in only.split(",")) if only else {})
     for name in ("cm", "raw"):
-        for x, y in zip(a[name], b[name]):
-            assert np.array_equal(x, y), (it, name)
+        for j, (x, y) in enumerate(zip(a[name], b[name])):
+            if not np.array_equal(x, y):
+                print("DIFF", name, j, len(x), len(y), "first at", int(np.flatnonzero(x[:min(len(x), len(y))] != y[:min(len(x), len(y))])[0]) if len(x) and len(y) else -1,
+                      "rows differ:", [k for k in a["rows"] if not np.array_equal(a["rows"][k], b["rows"][k])], a["layout"], b["layout"], flush=True)
+                raise SystemExit(1)
     for k in a["rows"]:
         assert np.array_equal(a["rows"][k], b["rows"][k]), (it, k)
     assert np.array_equal(a["filtered"], b["filtered"]) and np.array_equal(a["targets"], b["targets"]) and a["counters"] == b["counters"]
