@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -54,6 +55,10 @@ struct DevBuf {
 		if (count == 0) count = 1;
 		HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
 		n = count;
+		// DROPEST_POISON_ALLOC=<byte>: fresh device memory reads as zero pages in practice; tests run with a poison byte to find
+		// code that leans on that
+		static const int poison = [] { const char *e = getenv("DROPEST_POISON_ALLOC"); return e ? atoi(e) : -1; }();
+		if (poison >= 0) { (void)hipDeviceSynchronize(); (void)hipMemset(p, poison, count * sizeof(T)); (void)hipDeviceSynchronize(); }
 	}
 	void ensure(size_t count) { if (count > n) alloc(count); }
 	size_t bytes() const { return n * sizeof(T); }
