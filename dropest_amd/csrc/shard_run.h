@@ -855,7 +855,8 @@ void dropest_shard::step() {
 		ch.p_cb = r_cb; ch.p_umi = r_umi; ch.p_gene = r_gene; ch.p_aux = r_aux; ch.n = n_res;
 	}
 	if (ch.n) { c.n_reads = ch.n; c.chunks.push_back(std::move(ch)); }
-	{ Phase ph(this, "ingest"); c.run_ingest(); if (world > 1) agree_on_key_fields(); }
+	// (one shard has nobody to agree with: its pass runs in one piece and may plan the key layout from a sample like any context)
+	if (world > 1) { Phase ph(this, "ingest"); c.run_ingest(); agree_on_key_fields(); }
 	install_umi_hooks();
 	{ Phase ph(this, "pipeline"); c.run_set_initialized(); }
 	merged_barcodes.clear();
