@@ -12,6 +12,7 @@
 #include "context.h"
 
 #include <functional>
+#include <atomic>
 #include <map>
 #include <mutex>
 
