@@ -479,10 +479,9 @@ void dropest_ctx::reaggregate_after_merge() {
 	HostStage hs(this, "cb_merge:reaggregate");
 	remap.ensure(n_cells);
 	{
-		std::vector<u32> src(merge_pairs.size()), tgt(merge_pairs.size());
-		parallel_ranges(merge_pairs.size(), [&](size_t b, size_t e, unsigned) {
-			for (size_t i = b; i < e; ++i) { src[i] = u32(merge_pairs[i].first); tgt[i] = u32(merge_pairs[i].second); }
-		});
+		std::vector<u32> src, tgt;
+		src.reserve(merge_pairs.size()); tgt.reserve(merge_pairs.size());
+		for (auto &kv : merge_pairs) { src.push_back(u32(kv.first)); tgt.push_back(u32(kv.second)); }
 		DevBuf<u32> d_src, d_tgt; d_src.alloc(src.size()); d_tgt.alloc(tgt.size());
 		HIP_CHECK(hipMemcpyAsync(d_src.p, src.data(), src.size() * 4, hipMemcpyHostToDevice, stream));
 		HIP_CHECK(hipMemcpyAsync(d_tgt.p, tgt.data(), tgt.size() * 4, hipMemcpyHostToDevice, stream));
@@ -600,26 +599,21 @@ void dropest_ctx::refresh_real_rows() {
 	invalidate_prefetch();
 	const u32 count = u32(real.size());
 	if (!count) return;
-	// (2.4 M rows at C3 size: ids and rows go through the pinned staging buffer, the loops over a few worker threads)
-	const size_t row_bytes = size_t(count) * sizeof(CellRowPod);
-	h_stage.ensure(std::max(row_bytes, size_t(count) * 4));
-	u32 *ids = reinterpret_cast<u32 *>(h_stage.p);
-	parallel_ranges(count, [&](size_t b, size_t e, unsigned) { for (size_t i = b; i < e; ++i) ids[i] = real[i].id; });
+	std::vector<u32> ids(count);
+	for (u32 i = 0; i < count; ++i) ids[i] = real[i].id;
 	real_list.ensure(count); real_rows_dev.ensure(count);
-	HIP_CHECK(hipMemcpyAsync(real_list.p, ids, size_t(count) * 4, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemcpyAsync(real_list.p, ids.data(), size_t(count) * 4, hipMemcpyHostToDevice, stream));
 	CellArrays a{cell_cb.p, cell_first.p, cell_n_genes.p, cell_req_genes.p, cell_req_umis.p, cell_total_umis.p, cell_total_reads.p};
 	hipLaunchKernelGGL(gather_cell_rows_kernel, dim3(div_up(count, 256)), dim3(256), 0, stream, a, real_list.p, 0u, count,
 	                   real_rows_dev.p);
 	HIP_CHECK(hipGetLastError());
-	HIP_CHECK(hipMemcpyAsync(h_stage.p, real_rows_dev.p, row_bytes, hipMemcpyDeviceToHost, stream));   // (stream order: after the ids went up)
+	std::vector<CellRowPod> rows(count);
+	HIP_CHECK(hipMemcpyAsync(rows.data(), real_rows_dev.p, size_t(count) * sizeof(CellRowPod), hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipStreamSynchronize(stream));
-	const CellRowPod *rows = reinterpret_cast<const CellRowPod *>(h_stage.p);
-	parallel_ranges(count, [&](size_t b, size_t e, unsigned) {
-		for (size_t i = b; i < e; ++i) {
-			if (real[i].merged) continue;   // the reference keeps a merged source's stale sizes; nothing reads them again
-			real[i].row.n_genes = rows[i].n_genes;
-			real[i].row.requested_genes = rows[i].requested_genes;
-			real[i].row.requested_umis = rows[i].requested_umis;
-		}
-	});
+	for (u32 i = 0; i < count; ++i) {
+		if (real[i].merged) continue;   // the reference keeps a merged source's stale sizes; nothing reads them again
+		real[i].row.n_genes = rows[i].n_genes;
+		real[i].row.requested_genes = rows[i].requested_genes;
+		real[i].row.requested_umis = rows[i].requested_umis;
+	}
 }
