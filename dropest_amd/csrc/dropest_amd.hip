@@ -12,7 +12,6 @@
 #include "context.h"
 
 #include <functional>
-#include <atomic>
 #include <map>
 #include <mutex>
 

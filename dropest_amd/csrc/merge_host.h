@@ -190,38 +190,26 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 	// 3. pairs (base, candidate) whose UMI-gene intersection is needed
 	st_search.reset();
 	HostStage st_pairs(this, "cb_merge:targets:pairs");
-	// two passes over the bases on a few worker threads (2.4 M bases at C3 size): how many pairs each base contributes, then the
-	// pairs at their places -- the same order as one thread walking the bases would produce
+	S.pair_base.clear(); S.pair_cand.clear(); S.pair_umis.clear(); S.pair_ridx.clear();
 	S.pair_first.assign(size_t(F) + 1, 0); S.self_ridx.assign(F, 0xFFFFFFFFu);
-	const bool poisson = cfg.merge_kind == DROPEST_MERGE_POISSON_REAL;
-	std::atomic<bool> too_many{false};
-	parallel_ranges(F, [&](size_t b, size_t e, unsigned) {
-		for (size_t f = b; f < e; ++f) {
-			if (S.cnt[f] > u32(WL_CAND_CAP)) { too_many = true; continue; }
-			bool self = false;
-			for (u32 k = 0; k < S.cnt[f]; ++k)
-				if (S.fcell[S.off[f] + k] == cells[f]) { self = true; S.self_ridx[f] = S.fridx[S.off[f] + k]; }
-			// the base is itself a whitelist barcode: neighbour_cells[0] == base (RealBarcodesMergeStrategy.cpp:34-35) ends the
-			// decision there; the Poisson estimator goes on to its other neighbours (PoissonTargetEstimator.cpp:26-29)
-			S.pair_first[f + 1] = (self && !poisson) ? 0u : S.cnt[f] - (self ? 1u : 0u);
+	S.pair_base.reserve(F); S.pair_cand.reserve(F); S.pair_umis.reserve(F); S.pair_ridx.reserve(F);
+	for (u32 f = 0; f < F; ++f) {
+		S.pair_first[f] = u32(S.pair_base.size());
+		if (S.cnt[f] > u32(WL_CAND_CAP))
+			throw UnsupportedError("more than " + std::to_string(WL_CAND_CAP) + " merge candidates for one barcode");
+		bool self = false;
+		for (u32 k = 0; k < S.cnt[f]; ++k)
+			if (S.fcell[S.off[f] + k] == cells[f]) { self = true; S.self_ridx[f] = S.fridx[S.off[f] + k]; }
+		// the base is itself a whitelist barcode: neighbour_cells[0] == base (RealBarcodesMergeStrategy.cpp:34-35) ends the
+		// decision there; the Poisson estimator goes on to its other neighbours (PoissonTargetEstimator.cpp:26-29)
+		if (self && cfg.merge_kind != DROPEST_MERGE_POISSON_REAL) continue;
+		for (u32 k = 0; k < S.cnt[f]; ++k) {
+			if (S.fcell[S.off[f] + k] == cells[f]) continue;
+			S.pair_base.push_back(f); S.pair_cand.push_back(S.fcell[S.off[f] + k]); S.pair_umis.push_back(S.fumis[S.off[f] + k]);
+			S.pair_ridx.push_back(S.fridx[S.off[f] + k]);
 		}
-	});
-	if (too_many) throw UnsupportedError("more than " + std::to_string(WL_CAND_CAP) + " merge candidates for one barcode");
-	for (u32 f = 0; f < F; ++f) S.pair_first[f + 1] += S.pair_first[f];
-	const size_t NPAIRS = S.pair_first[F];
-	S.pair_base.resize(NPAIRS); S.pair_cand.resize(NPAIRS); S.pair_umis.resize(NPAIRS); S.pair_ridx.resize(NPAIRS);
-	parallel_ranges(F, [&](size_t b, size_t e, unsigned) {
-		for (size_t f = b; f < e; ++f) {
-			size_t at = S.pair_first[f];
-			if (at == S.pair_first[f + 1]) continue;
-			for (u32 k = 0; k < S.cnt[f]; ++k) {
-				if (S.fcell[S.off[f] + k] == cells[f]) continue;
-				S.pair_base[at] = u32(f); S.pair_cand[at] = S.fcell[S.off[f] + k]; S.pair_umis[at] = S.fumis[S.off[f] + k];
-				S.pair_ridx[at] = S.fridx[S.off[f] + k];
-				++at;
-			}
-		}
-	});
+	}
+	S.pair_first[F] = u32(S.pair_base.size());
 }
 
 // The reference's candidate order (a replay of its two unstable std::sorts) for the bases in `need_order`: the
