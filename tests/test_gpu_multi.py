@@ -115,6 +115,27 @@ def test_n_umis_across_shards(world, rate, n_reads):
     # (the single context itself is pinned on the oracle for these streams: test_gpu_parity.py::test_n_umis_synthetic)
 
 
+@pytest.mark.parametrize("case", ["c2", "c4"])
+def test_two_shards_at_2e7_reads_match_single_context(case):
+    """Past the size thresholds of one context (sampled table, hot list, planned key layout, splitter sort) the shards still run
+    the exact-statistics ingest and agree on the key fields: 2e7 reads over two shards against one context, both matrices and the
+    merged barcodes."""
+    if case == "c2":
+        s = SynthStream(n_reads=20_000_000, n_cells=1000, n_genes=30000)
+        kw = cfg_kwargs({"min_before": 20, "min_after": 100})
+    else:
+        s = SynthStream(n_reads=12_000_000, n_cells=800, n_genes=20000, umi_len=8, whitelist="indrop_v3", permille_neighbour=100)
+        kw = cfg_kwargs({"min_before": 10, "min_after": 50, "merge": {"barcodes_kind": capi.BARCODES_CONST, "barcodes_file": os.path.join(DATA, "indrop_v3")}})
+    dev = s.generate_device(0)
+    arrays = tuple(a.copy() for a in dev.to_host())
+    dev.free()
+    got = run_group(2, arrays, kw, steps=1)
+    c = single(arrays, kw)
+    assert c.sort_layout()["sort"] == "splitter"
+    want = check(got, c)
+    assert len(got["cm"][3]) > 500 and (case == "c2" or len(want) > 1000)
+
+
 def test_eight_shards_whitelist_merge_n_umis_and_directional():
     """The shard count of one node (C5's form, scaled down): whitelist merge with N-UMIs, and -u, over 8 shards on one GPU."""
     s = SynthStream(n_reads=400_000 * SCALE, n_cells=80 * SCALE, n_genes=1500, umi_len=8, permille_neighbour=150)
