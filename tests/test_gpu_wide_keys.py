@@ -112,7 +112,8 @@ def test_gene_and_umi_alone_too_wide_stays_refused():
     g.close()
 
 
-@pytest.mark.skipif(bool(os.environ.get("DROPEST_SKIP_SLOW")), reason="2^25 barcodes: ~3 minutes, most of it the oracle (DROPEST_SKIP_SLOW=1)")
+@pytest.mark.skipif(not os.environ.get("DROPEST_WIDE_FULL"), reason="2^25 barcodes: ~3 minutes, most of it the oracle; DROPEST_WIDE_FULL=1 runs it "
+                    "(last run: profiles/r02b_wide_key_2_25.log)")
 def test_wide_key_at_2_25_barcodes():
     """40 000 genes (16 bits), 12-base UMIs (24 bits), >= 2^25 distinct barcodes (26 bits) = 66 bits."""
     n_cb = (1 << 25) + 1000
