@@ -62,6 +62,37 @@ def test_c3_shape_5m_with_n_umis_and_merge_at_natural_thresholds():
     assert int(c.cell_rows()["is_merged"].sum()) > 1000
 
 
+def test_context_reused_for_another_stream_equals_a_fresh_context():
+    """dropest_clear_reads + a different stream on the same context: its buffers hold what the previous stream left (molecule
+    tables, barcode table, sort scratch of another size), the result must be that of a fresh context."""
+    wl = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropest_amd", "data", "barcodes", "10x_aug_2016_split")
+    kw = dict(min_genes_before_merge=10, min_genes_after_merge=60, merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST, barcodes_file=wl)
+
+    def outputs(c):
+        rows = c.cell_rows()
+        return [x.copy() for x in c.count_matrix_csc(filtered=True)] + [x.copy() for x in c.count_matrix_csc(filtered=False)] + \
+               [rows[k].copy() for k in rows.dtype.names] + [np.array(c.merge_targets()), np.array(c.filtered_cells())]
+    shapes = [dict(n_reads=24_000_000, n_cells=6000, n_genes=20000, umi_len=12, stream_id=11, permille_neighbour=120),
+              dict(n_reads=9_000_000, n_cells=900, n_genes=4000, umi_len=8, stream_id=12, permille_neighbour=60),
+              dict(n_reads=17_000_000, n_cells=15000, n_genes=30000, umi_len=10, stream_id=13, permille_neighbour=180)]
+    c = capi.Context(**kw)
+    for shape in shapes:
+        dev = SynthStream(**shape).generate_device(0)
+        c.clear_reads()
+        c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
+        c.set_initialized(); c.merge_and_filter()
+        a = outputs(c)
+        f = capi.Context(**kw)
+        f.push_reads_device(*dev.ptrs, dev.n, adopt=True)
+        f.set_initialized(); f.merge_and_filter()
+        b = outputs(f)
+        f.close()
+        assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)), shape
+        c.clear_reads()
+        dev.free()
+    c.close()
+
+
 def test_query_levels_and_reads_output():
     _both(dict(n_cells=30, n_genes=1500), 60_000, 10, 10, levels="e", reads_output=True)
     _both(dict(n_cells=30, n_genes=1500), 60_000, 10, 10, levels="iI")
