@@ -21,12 +21,9 @@ import time
 
 import numpy as np
 
-# Completion signals are polled, not interrupt-driven: a step has ~15 host waits, and on the shared hosts of the GPU
-# boxes a blocked thread occasionally takes 5-10 ms to be scheduled again after the interrupt (3 of 30 steps in an A/B,
-# none with polling).  Must be in the environment before the ROCm runtime initialises, i.e. before torch touches the GPU.
-# (Single-process runs only: the multi-rank RCCL runs keep the ROCm defaults they were validated with.)
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+# (HSA_ENABLE_INTERRUPT is left at the ROCm default: the library's host waits poll the stream's completion signal themselves,
+# csrc/util.h stream_wait -- a pass has about a dozen of them and a thread blocked on an interrupt takes 50-100 us, on the
+# loaded hosts of the GPU boxes sometimes milliseconds, to run again.)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -57,6 +54,7 @@ def parse():
     ap.add_argument("--sharded", action="store_true",
                     help="N = 1 only: run the pass through the sharded runner (partition by owner + RCCL all-to-all to itself + "
                          "shared result buffer) instead of the plain context: what a second GPU would add, measured on one")
+    ap.add_argument("--no-secondary", action="store_true", help="default run only: skip the C3 line at 1e9 reads (secondary.c3_1e9)")
     ap.add_argument("--push-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_PUSH_SAMPLE", 5e7)),
                     help="reads pushed from pinned host memory for the PCIe-inclusive rates (c2, N=1; 0 disables)")
     ap.add_argument("--cpu-sample", type=float, default=float(os.environ.get("DROPEST_BENCH_CPU_SAMPLE", 6e6)),
@@ -65,14 +63,22 @@ def parse():
 
 
 def one_step(ctx):
-    """One pass of the hot path over the resident stream; returns what lands on the host."""
+    """One pass of the hot path over the resident stream; returns what lands on the host: both count matrices in CSC form --
+    16-bit row indices and values + exact overflow list when every gene id fits 16 bits (dropest_count_matrix_csc_narrow: what
+    the facade's ResultsPrinter reads; it turns entries into doubles either way), the 32-bit form otherwise or with
+    DROPEST_BENCH_WIDE_MATRIX=1 -- and the filtered cells."""
     ctx.reset_results()
     ctx.set_initialized()
     ctx.merge_and_filter()
+    narrow = ctx.narrow_matrix_possible() and not os.environ.get("DROPEST_BENCH_WIDE_MATRIX")
     if not os.environ.get("DROPEST_BENCH_NO_PREFETCH"):
-        ctx.prefetch_raw_matrix()                 # cm_raw's copy to the host runs under the preparation of cm
-    cm = ctx.count_matrix_csc(filtered=True)
-    cm_raw = ctx.count_matrix_csc(filtered=False)
+        ctx.prefetch_raw_matrix(narrow=narrow)    # cm_raw's copy to the host runs under the preparation of cm
+    if narrow:
+        cm = ctx.count_matrix_csc_narrow(filtered=True)
+        cm_raw = ctx.count_matrix_csc_narrow(filtered=False)
+    else:
+        cm = ctx.count_matrix_csc(filtered=True)
+        cm_raw = ctx.count_matrix_csc(filtered=False)
     return cm, cm_raw, ctx.filtered_cells()
 
 
@@ -180,52 +186,26 @@ def facade_add_record_rate(n=4_000_000):
         return {}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-
+def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, local_rank, dist, force_sharded, with_ingest):
+    """Times `steps` passes of one workload; returns the bench line (rank 0) or None."""
     import torch
     from dropest_amd import capi
     from dropest_amd.synth import SynthStream
 
-    if not torch.cuda.is_available() or capi.lib().dropest_dev_count() < 1:
-        raise SystemExit("bench.py needs a GPU: the dropEst hot path has no CPU implementation")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    force_sharded = world == 1 and (args.sharded or os.environ.get("DROPEST_BENCH_FORCE_SHARDED") == "1")
-    saved_stdout = None
-    if world > 1 or force_sharded:
-        # RCCL prints a version banner on stdout when the first communicator comes up; stdout carries exactly one
-        # JSON line, so everything before it goes to stderr
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-    if world > 1:
-        # torch.distributed carries the launch only: the barrier around the timed region and the broadcast of the RCCL
-        # unique id; every collective of the pass itself is issued by the library (csrc/shard_run.h)
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    reads_per_gpu = int(args.reads)
     total_reads = reads_per_gpu * world
     cfg = {"min_before": 20, "min_after": 100}    # configs/10x.xml:26-27
-    c3, c4 = args.config == "c3", args.config == "c4"
+    c3, c4 = config == "c3", config == "c4"
     merge = c3 or c4
-    if not args.cells:
-        args.cells = 50000 if c3 else 5000
+    if not cells:
+        cells = 50000 if c3 else 5000
     wl_name = "indrop_v3" if c4 else "10x_aug_2016_split"
     wl = os.path.join(ROOT, "dropest_amd", "data", "barcodes", wl_name)
     if merge:
         cfg["merge"] = {"barcodes_kind": capi.BARCODES_CONST, "barcodes_file": wl, "min_merge_fraction": 0.2}
-    stream = SynthStream(n_reads=total_reads, n_cells=args.cells * world, n_genes=30000, cb_len=16, whitelist=wl_name,
-                         umi_len=12 if c3 else (8 if c4 else 10), stream_id={"c2": 2, "c3": 3, "c4": 4}[args.config])
+    stream = SynthStream(n_reads=total_reads, n_cells=cells * world, n_genes=30000, cb_len=16, whitelist=wl_name,
+                         umi_len=12 if c3 else (8 if c4 else 10), stream_id={"c2": 2, "c3": 3, "c4": 4}[config])
 
+    dev = run = None
     if world == 1 and not force_sharded:
         from dropest_amd.capi import Context
         dev = stream.generate_device(local_rank, first=0, n=reads_per_gpu)
@@ -248,9 +228,8 @@ def main():
         get_layout = ctx.sort_layout
     else:
         from dropest_amd.multi import ShardedRun
-        if args.merge_umi:
-            raise SystemExit("-u is not supported in sharded runs (the UMI first-occurrence table would have to be reduced over ranks)")
-        run = ShardedRun(stream, rank, world, local_rank, reads_per_gpu, cfg, dist)
+        ukw = dict(umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL) if args.merge_umi else {}
+        run = ShardedRun(stream, rank, world, local_rank, reads_per_gpu, cfg, dist, **ukw)
         if force_sharded:
             run.shard.set_option("force_exchange", 1)
         step = run.step
@@ -269,7 +248,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     # inside the timed region only the dominant kernel carries HIP events (two events around every launch of a pass cost
     # ~0.5 ms per step); the table of all kernels and host stages comes from a separate pass after the clock has stopped
@@ -277,14 +256,15 @@ def main():
     fence()
     t0 = time.perf_counter()
     step_ms = []
-    for _ in range(args.steps):
+    out = None
+    for _ in range(steps):
         ts = time.perf_counter()
         out = step()
         step_ms.append(round((time.perf_counter() - ts) * 1e3, 3))     # host clock; a step ends with its results on the host
     fence()
     elapsed = time.perf_counter() - t0
     stats = get_stats()
-    table_steps = max(1, min(3, args.steps))
+    table_steps = max(1, min(3, steps))
     set_prof(True)
     for _ in range(table_steps):
         step()
@@ -298,9 +278,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    line = None
     if rank == 0:
-        ms_per_step = elapsed / max(1, args.steps) * 1e3
-        value = total_reads / (elapsed / max(1, args.steps)) / 1e6
+        ms_per_step = elapsed / max(1, steps) * 1e3
+        value = total_reads / (elapsed / max(1, steps)) / 1e6
         # dominant kernel = the candidate with the largest share of the timed region
         # (only launches whose stat name STARTS with a candidate prefix carry events: the small sorts of the cell ids and of
         # the splitter sample, "cell_ids:..." / "ss_sample:...", do not)
@@ -311,9 +292,11 @@ def main():
         if dom["launches"]:
             avg_ms = dom["ms"] / dom["launches"]
             achieved = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
-            traffic = pmc_kernel_bytes(dom_name, args.config, reads_per_gpu, get_layout()["sort"])
+            traffic = pmc_kernel_bytes(dom_name, config, reads_per_gpu, get_layout()["sort"])
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": None if traffic is None else "profiles/pmc_pipeline.json: rocprofv3 --pmc passes of this workload taken by "
+                                      "scripts/refresh_profiles.sh (builder-run, not counters of this run)",
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"]}
         # whole-pipeline roofline: compulsory traffic = every packed record read once, every output item
@@ -321,7 +304,7 @@ def main():
         cm_nnz, raw_nnz = int(len(out[0][1])), int(len(out[1][1]))
         compulsory = 24.0 * sizes["reads"] + 24.0 * sizes["molecules"] + 12.0 * (cm_nnz + raw_nnz) / max(1, world) + 40.0 * sizes["cells"]
         t_kernels_ms = sum(v["ms"] for k, v in table.items() if not k.startswith("host:")) / table_steps
-        rec = pmc_record(args.config, reads_per_gpu, get_layout()["sort"])
+        rec = pmc_record(config, reads_per_gpu, get_layout()["sort"])
         measured = rec["hbm_bytes_per_step"] if rec else None
         if roof is not None and t_kernels_ms > 0:
             roof["pipeline"] = {"compulsory_bytes": compulsory, "kernel_ms_per_step": round(t_kernels_ms, 3),
@@ -347,30 +330,87 @@ def main():
                             "links": links, "transport": "RCCL grouped ncclSend/ncclRecv over xGMI" if world > 1 else "RCCL to itself (one GPU)"}
         cpu = None
         if world == 1 and args.cpu_sample > 0:
-            cpu = cpu_baseline(stream, int(min(args.cpu_sample, total_reads)), cfg, args.config.upper())
+            cpu = cpu_baseline(stream, int(min(args.cpu_sample, total_reads)), cfg, config.upper())
         ingest = None
-        if world == 1 and not force_sharded and args.push_sample > 0 and not merge:
+        if with_ingest and world == 1 and not force_sharded and args.push_sample > 0 and not merge:
             ingest = push_rates(stream, local_rank, int(min(args.push_sample, total_reads)),
                                 dict(merge_kind=capi.MERGE_NONE, min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"]))
         cm = out[0]
+        narrow = len(cm) == 5
         line = {
             "metric": "Mreads/s processed to final count matrix", "value": round(value, 2), "unit": "Mreads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": ("C3: synthetic 10x v3, %d reads/GPU, %d cells/GPU, 16bp CB + 12bp UMI, 30000 genes, "
                                     "-m + 10x whitelist (RealBarcodes merge), -L eEBA" if c3 else
                                     "C4: synthetic inDrop v3, %d reads/GPU, %d cells/GPU, 8+8bp split CB + 8bp UMI, 30000 genes, "
                                     "-m + inDrop v3 whitelist (RealBarcodes merge), -L eEBA" if c4 else
                                     "C2: synthetic 10x v2, %d reads/GPU, %d cells/GPU, 16bp CB + 10bp UMI, 30000 genes, "
-                                    "no CB merge, -L eEBA") % (reads_per_gpu, args.cells) + (", -u" if args.merge_umi else "")
+                                    "no CB merge, -L eEBA") % (reads_per_gpu, cells) + (", -u" if args.merge_umi else "")
                                    + (", no whitelist (SimpleMergeStrategy)" if args.no_whitelist else "")
                                    + (", -M (Poisson decisions)" if args.poisson else ""),
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d%s" % (world, " (sharded runner, forced exchange)" if force_sharded else ""),
-                       "cm_nnz": int(len(cm[1])), "filtered_cells": int(len(out[2])), "sort_layout": get_layout()},
+                       "cm_nnz": int(len(cm[1])), "cm_raw_nnz": raw_nnz, "filtered_cells": int(len(out[2])), "sort_layout": get_layout(),
+                       "matrix_form": ("CSC in pinned host memory, u32 colptr + u16 row index + u16 value + exact overflow list (%d + %d entries beyond 65534)"
+                                       % (len(cm[3]), len(out[1][3]))) if narrow else "CSC in pinned host memory, u32 colptr + u32 row index + u32 value"},
             "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "host_ingest": ingest, "step_ms": step_ms, "kernels_ms_per_step": kernels,
             "kernel_table": "separate pass of %d steps after the timed region, events on every launch" % table_steps,
             "host_stage_wall_ms_per_step": host_stages,
         }
+    # give the device memory back before another workload is measured
+    out = None
+    if run is not None:
+        run.close()
+    else:
+        ctx.close()
+    if dev is not None:
+        dev.free()
+    return line
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    from dropest_amd import capi
+
+    if not torch.cuda.is_available() or capi.lib().dropest_dev_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the dropEst hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    force_sharded = world == 1 and (args.sharded or os.environ.get("DROPEST_BENCH_FORCE_SHARDED") == "1")
+    saved_stdout = None
+    if world > 1 or force_sharded:
+        # RCCL prints a version banner on stdout when the first communicator comes up; stdout carries exactly one
+        # JSON line, so everything before it goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+    if world > 1:
+        # torch.distributed carries the launch only: the barrier around the timed region and the broadcast of the RCCL
+        # unique id; every collective of the pass itself is issued by the library (csrc/shard_run.h)
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    line = measure(args, args.config, int(args.reads), args.cells, args.steps, args.warmup, world, rank, local_rank, dist, force_sharded, True)
+    # The largest single-GPU configuration of BASELINE.json (configs[2], "C3": 1e9 reads, 50 000 cells, whitelist CB merge) rides
+    # along with the default run as `secondary.c3_1e9` -- same clock, same fences, 3 timed steps after 1 warm-up (24 GB of reads).
+    if (line is not None and world == 1 and not force_sharded and args.config == "c2" and int(args.reads) == 100_000_000 and not args.no_secondary
+            and not args.merge_umi):
+        try:
+            sec = measure(args, "c3", 1_000_000_000, 50000, 3, 1, world, rank, local_rank, dist, False, False)
+            line["secondary"] = {"c3_1e9": {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "step_ms", "config", "roofline", "cpu_baseline",
+                                                                "kernels_ms_per_step", "host_stage_wall_ms_per_step")}}
+        except Exception as e:   # the primary line must not be lost to the secondary workload
+            line["secondary"] = {"c3_1e9": {"error": "%s: %s" % (type(e).__name__, e)}}
+    if rank == 0:
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)

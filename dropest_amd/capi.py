@@ -130,7 +130,14 @@ def lib():
         "dropest_kernel_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
         "dropest_set_profiling": (C.c_int, [vp, C.c_int]),
         "dropest_set_profiling_filter": (C.c_int, [vp, C.c_char_p]),
+        "dropest_debug_poison_scratch": (C.c_int, [C.c_uint64, u64p]),
+        "dropest_debug_trim_pool": (C.c_int, []),
+        "dropest_debug_alloc_ordinal": (C.c_int, [u64p]),
+        "dropest_debug_alloc_site": (C.c_int, [C.c_uint64, C.c_char_p, C.c_uint64]),
         "dropest_prefetch_raw_matrix": (C.c_int, [vp, C.c_int]),
+        "dropest_prefetch_raw_matrix_narrow": (C.c_int, [vp, C.c_int]),
+        "dropest_narrow_matrix_possible": (C.c_int, [vp, P(C.c_int)]),
+        "dropest_count_matrix_csc_narrow": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp), u64p, P(vp), P(vp)]),
         "dropest_radix_plan": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "dropest_sort_layout": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "dropest_stream": (vp, [vp]),
@@ -204,7 +211,8 @@ EXPORTED_SYMBOLS = [
     "dropest_shard_unique_id", "dropest_shard_create", "dropest_shard_group_create", "dropest_shard_destroy", "dropest_shard_ctx",
     "dropest_shard_set_reads_device", "dropest_shard_push_reads", "dropest_reserve_reads", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix",
     "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option", "dropest_plan_columns",
-    "dropest_key_width", "dropest_ctx_split",
+    "dropest_key_width", "dropest_ctx_split", "dropest_prefetch_raw_matrix_narrow", "dropest_narrow_matrix_possible", "dropest_count_matrix_csc_narrow",
+    "dropest_debug_poison_scratch", "dropest_debug_trim_pool", "dropest_debug_alloc_ordinal", "dropest_debug_alloc_site",
 ]
 
 
@@ -407,9 +415,39 @@ class Context:
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n,))
         return view(pc, ncols.value + 1), view(pr, nnz.value), view(pv, nnz.value)
 
-    def prefetch_raw_matrix(self, reads_output=False):
+    def prefetch_raw_matrix(self, reads_output=False, narrow=False):
         """Start cm_raw (emit + copy to the host) on a second stream; count_matrix_csc(filtered=False) then only waits."""
-        self._chk(self.L.dropest_prefetch_raw_matrix(self.h, int(reads_output)))
+        if narrow:
+            self._chk(self.L.dropest_prefetch_raw_matrix_narrow(self.h, int(reads_output)))
+        else:
+            self._chk(self.L.dropest_prefetch_raw_matrix(self.h, int(reads_output)))
+
+    def narrow_matrix_possible(self):
+        v = C.c_int()
+        self._chk(self.L.dropest_narrow_matrix_possible(self.h, C.byref(v)))
+        return bool(v.value)
+
+    def count_matrix_csc_narrow(self, filtered=True, reads_output=False):
+        """(colptr u32, rowidx u16, values u16, overflow_pos u32, overflow_val u32): zero-copy views of context-owned pinned
+        memory; values[overflow_pos[k]] == 0xFFFF stands for overflow_val[k]."""
+        ncols, nnz, novf = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        pc, pr, pv, po, pw = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.L.dropest_count_matrix_csc_narrow(self.h, int(filtered), int(reads_output), C.byref(ncols), C.byref(nnz),
+                                                         C.byref(pc), C.byref(pr), C.byref(pv), C.byref(novf), C.byref(po), C.byref(pw)))
+        def view(ptr, n, ct, dt):
+            if n == 0 or not ptr.value:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,))
+        return (view(pc, ncols.value + 1, C.c_uint32, np.uint32), view(pr, nnz.value, C.c_uint16, np.uint16), view(pv, nnz.value, C.c_uint16, np.uint16),
+                view(po, novf.value, C.c_uint32, np.uint32), view(pw, novf.value, C.c_uint32, np.uint32))
+
+    @staticmethod
+    def widen(narrow):
+        """The 32-bit (colptr, rowidx, values) of a narrow matrix."""
+        colptr, r16, v16, opos, oval = narrow
+        vals = v16.astype(np.uint32)
+        vals[opos] = oval
+        return colptr, r16.astype(np.uint32), vals
 
     def count_matrix_levels(self, levels, reads_output=False):
         """Filtered count matrix under another mark query, as triplets (gene, column, value) in column-major order."""

@@ -59,15 +59,16 @@ struct ReadStore {
 		if (want <= capacity() && cb.p) return;
 		size_t cap = std::max<size_t>(want, std::max<size_t>(capacity() * 2, size_t(1) << 20));
 		if (!copy) HIP_CHECK(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
-		HIP_CHECK(hipStreamSynchronize(copy));
+		HIP_CHECK(stream_wait(copy));
 		DevBuf<u64> ncb, numi; DevBuf<u32> ngene, naux;
 		ncb.alloc(cap); numi.alloc(cap); ngene.alloc(cap); naux.alloc(cap);
+		ncb.mark_persistent(); numi.mark_persistent(); ngene.mark_persistent(); naux.mark_persistent();
 		if (n) {
 			HIP_CHECK(hipMemcpyAsync(ncb.p, cb.p, n * 8, hipMemcpyDeviceToDevice, copy));
 			HIP_CHECK(hipMemcpyAsync(numi.p, umi.p, n * 8, hipMemcpyDeviceToDevice, copy));
 			HIP_CHECK(hipMemcpyAsync(ngene.p, gene.p, n * 4, hipMemcpyDeviceToDevice, copy));
 			HIP_CHECK(hipMemcpyAsync(naux.p, aux.p, n * 4, hipMemcpyDeviceToDevice, copy));
-			HIP_CHECK(hipStreamSynchronize(copy));
+			HIP_CHECK(stream_wait(copy));
 		}
 		cb = std::move(ncb); umi = std::move(numi); gene = std::move(ngene); aux = std::move(naux);
 	}
@@ -84,7 +85,7 @@ struct ReadStore {
 			HIP_CHECK(hipMemcpyAsync(umi.p + n, h_umi, count * 8, hipMemcpyHostToDevice, copy));
 			HIP_CHECK(hipMemcpyAsync(gene.p + n, h_gene, count * 4, hipMemcpyHostToDevice, copy));
 			HIP_CHECK(hipMemcpyAsync(aux.p + n, h_aux, count * 4, hipMemcpyHostToDevice, copy));
-			HIP_CHECK(hipStreamSynchronize(copy));   // the caller keeps ownership of its arrays
+			HIP_CHECK(stream_wait(copy));   // the caller keeps ownership of its arrays
 			n += count;
 			return;
 		}
@@ -93,7 +94,7 @@ struct ReadStore {
 			const size_t m = std::min(piece_max, count - at);
 			PinnedBuf<unsigned char> &st = stage[cur];
 			if (!done[cur]) HIP_CHECK(hipEventCreateWithFlags(&done[cur], hipEventDisableTiming));
-			else HIP_CHECK(hipEventSynchronize(done[cur]));   // the transfer that used this buffer two pieces ago
+			else HIP_CHECK(event_wait(done[cur]));   // the transfer that used this buffer two pieces ago
 			st.ensure(m * 24);
 			unsigned char *b = st.p;
 			std::memcpy(b, h_cb + at, m * 8); std::memcpy(b + m * 8, h_umi + at, m * 8);
@@ -107,7 +108,7 @@ struct ReadStore {
 			n += m;
 		}
 	}
-	void wait() { if (copy) HIP_CHECK(hipStreamSynchronize(copy)); }
+	void wait() { if (copy) HIP_CHECK(stream_wait(copy)); }
 	void clear() { wait(); n = 0; }
 };
 
@@ -149,12 +150,16 @@ struct MergeUniverse {
 	std::function<int32_t(u32)> base_total_umis;       // TOTAL_UMIS stat of base f (position in the searched list)
 	std::function<u64(u32)> barcode_code;              // packed barcode of a universe cell
 	std::function<std::string(u32)> base_barcode_text; // text of base f's barcode
+	// host look-up of a barcode code among the universe's cells (single context only; whitelists of more parts than the device
+	// kernel takes search on the host): universe index or -1, with the cell's n_genes, TOTAL_UMIS and index in `real`
+	std::function<long(u64, u32 &, int32_t &, u32 &)> find_cell;
 };
 struct MergeSearch {                                   // neighbour search result (merge_host.h)
 	u32 F = 0, ntot = 0;
 	size_t lds = 0;
 	std::vector<u32> cells, cnt, off, fcell, fumis, fridx, self_ridx;
 	std::vector<u32> pair_base /* position f */, pair_cand, pair_umis, pair_ridx, pair_first;
+	std::vector<std::vector<u32>> host_order;          // host search: the candidates of every base in the reference's own order
 	DevBuf<WlBase> d_bases;
 	WlArgs args{};
 };
@@ -298,6 +303,13 @@ struct dropest_ctx {
 	struct MatrixResult {
 		dropest::DevBuf<u32> d_row, d_val;
 		dropest::PinnedBuf<u32> h_row, h_val;
+		// the narrow form (dropest_count_matrix_csc_narrow): 16-bit rows / values, [0] overflow count, then positions, then values
+		dropest::DevBuf<uint16_t> d_row16, d_val16;
+		dropest::PinnedBuf<uint16_t> h_row16, h_val16;
+		dropest::DevBuf<u32> d_ovf;
+		dropest::PinnedBuf<u32> h_ovf;
+		bool narrow = false;
+		u32 n_ovf = 0;
 		std::vector<u32> colptr;
 		uint64_t nnz = 0, ncols = 0;
 	} mat[3];   // cm, cm_raw, and the filtered matrix under another mark query (emit_matrix_levels)
@@ -342,12 +354,12 @@ struct dropest_ctx {
 	struct HostStage {
 		dropest_ctx *c; const char *name; std::chrono::steady_clock::time_point t0;
 		HostStage(dropest_ctx *ctx, const char *n) : c(ctx), name(n) {
-			if (c->stage_sync && c->profiling) (void)hipStreamSynchronize(c->stream);   // diagnostic: charge queued work to the stage that queued it
+			if (c->stage_sync && c->profiling) (void)dropest::stream_wait(c->stream);   // diagnostic: charge queued work to the stage that queued it
 			t0 = std::chrono::steady_clock::now();
 		}
 		~HostStage() {
 			if (!c->profiling || !c->profile_only.empty()) return;
-			if (c->stage_sync) (void)hipStreamSynchronize(c->stream);
+			if (c->stage_sync) (void)dropest::stream_wait(c->stream);
 			auto &s = c->stats[std::string("host:") + name];
 			s.launches++;
 			s.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -388,6 +400,8 @@ struct dropest_ctx {
 	void refresh_real_rows();
 	void upload_whitelist();
 	void search_merge_candidates(const std::vector<u32> &cells, const dropest::MergeUniverse &U, dropest::MergeSearch &S);
+	void search_merge_candidates_host(const std::vector<u32> &cells, const dropest::MergeUniverse &U, dropest::MergeSearch &S);
+	void build_merge_pairs(const std::vector<u32> &cells, dropest::MergeSearch &S);
 	void decide_merge_targets(const dropest::MergeUniverse &U, dropest::MergeSearch &S, const std::vector<u32> &inter,
 	                          std::vector<long> &targets, std::vector<u32> &target_ridx);
 	std::vector<std::vector<u32>> replay_candidate_orders(const dropest::MergeUniverse &U, dropest::MergeSearch &S,
@@ -470,15 +484,19 @@ struct dropest_ctx {
 	void fetch_real_cells();
 	void request_filtered(u32 genes_threshold, int max_cells);   // CellsDataContainer::update_filtered_gene_counts, lazily
 	void sort_filtered(u32 genes_threshold, int max_cells);
-	void emit_matrix(bool filtered_m, bool reads_output, bool to_host = true);
+	void emit_matrix(bool filtered_m, bool reads_output, bool to_host = true, bool narrow = false);
+	bool narrow_possible() const;
+	void matrix_outputs(MatrixResult &M, uint64_t nnz, bool narrow, bool to_host, dropest::MatrixArgs &a);
+	void matrix_copy_out(MatrixResult &M, uint64_t nnz, hipStream_t st);
+	void matrix_finish_overflow(MatrixResult &M, hipStream_t st);
 	// columns of a count matrix from the host rows: cell id of every column, start of every column, number of entries
 	void matrix_columns(bool filtered_m, std::vector<u32> &col_cell, std::vector<u32> &colptr, uint64_t &nnz);
 	// cm_raw produced and copied to the host on a second stream while the caller goes on (dropest_prefetch_raw_matrix)
-	struct RawPrefetch { bool valid = false, reads_output = false, in_flight = false; std::vector<u32> col_cell; } raw_pf;
+	struct RawPrefetch { bool valid = false, reads_output = false, in_flight = false, narrow = false; std::vector<u32> col_cell; } raw_pf;
 	hipStream_t stream2 = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_raw = nullptr;
 	dropest::DevBuf<u32> m2_col_cell, m2_col_start;
-	void prefetch_raw_matrix(bool reads_output);
+	void prefetch_raw_matrix(bool reads_output, bool narrow = false);
 	void invalidate_prefetch();
 	u64 unmap_umi(u64 ucode) const;
 };

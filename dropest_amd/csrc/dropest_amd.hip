@@ -103,7 +103,7 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 dropest_ctx::~dropest_ctx() {
 	for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for (auto e : event_pool) (void)hipEventDestroy(e);
-	if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); }
+	if (stream2) { (void)stream_wait(stream2); (void)hipStreamDestroy(stream2); }
 	if (ev_fork) (void)hipEventDestroy(ev_fork);
 	if (ev_raw) (void)hipEventDestroy(ev_raw);
 	if (stream) (void)hipStreamDestroy(stream);
@@ -141,13 +141,13 @@ void dropest_ctx::fetch(void *dst, const void *d_src, size_t bytes) {
 	if (!bytes) return;
 	h_stage.ensure(std::max<size_t>(bytes, 4096));
 	HIP_CHECK(hipMemcpyAsync(h_stage.p, d_src, bytes, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	std::memcpy(dst, h_stage.p, bytes);
 }
 
 void dropest_ctx::collect_timings() {
 	if (pending.empty()) return;
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	for (auto &p : pending) {
 		float ms = 0;
 		HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
@@ -172,6 +172,7 @@ void dropest_ctx::concat_chunks() {
 		return;
 	}
 	cat_cb.alloc(n_reads); cat_umi.alloc(n_reads); cat_gene.alloc(n_reads); cat_aux.alloc(n_reads);
+	cat_cb.mark_persistent(); cat_umi.mark_persistent(); cat_gene.mark_persistent(); cat_aux.mark_persistent();
 	uint64_t off = 0;
 	for (auto &c : chunks) {
 		HIP_CHECK(hipMemcpyAsync(cat_cb.p + off, c.p_cb, c.n * 8, hipMemcpyDeviceToDevice, stream));
@@ -180,7 +181,7 @@ void dropest_ctx::concat_chunks() {
 		HIP_CHECK(hipMemcpyAsync(cat_aux.p + off, c.p_aux, c.n * 4, hipMemcpyDeviceToDevice, stream));
 		off += c.n;
 	}
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	chunks.clear();
 	chunks.emplace_back();
 	chunks[0].p_cb = cat_cb.p; chunks[0].p_umi = cat_umi.p; chunks[0].p_gene = cat_gene.p; chunks[0].p_aux = cat_aux.p;
@@ -196,6 +197,7 @@ void dropest_ctx::free_results() {
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
 	real.clear(); filtered.clear(); filtered_valid = false; merge_pairs.clear(); reassign.clear(); umi_overrides.clear(); n_real_now = 0;
 	merge_rank.clear(); reagg_prio = nullptr; extra_excluded.clear(); explicit_sources.clear(); mol_sorted_rows = 0xFFFFFFFFu;
+	layout = dropest::KeyLayout{}; umi_clean_bits = 0; umi_sentinel_stripped = false; chr_from_gene = false;   // nothing of the previous pass's key plan survives
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -551,9 +553,13 @@ static int sort_mode_override() {   // read at every pass: tests switch it insid
 
 // Does the LDS apply the lanes of one atomic instruction that hit the same address in lane order?  (ss_local's one-instruction
 // ranking is stable only then.)  Checked once per device on 256 random digit patterns with 1 .. 64 distinct values.
+static std::mutex g_lds_order_mu;
+static std::map<int, bool> g_lds_order_known;
+// a pass found a bucket out of order behind the one-atomic ranking: this device ranks with ballots from now on
+static void lds_atomics_mark_unordered(int device) { std::lock_guard<std::mutex> lk(g_lds_order_mu); g_lds_order_known[device] = false; }
 static bool lds_atomics_lane_ordered(int device, hipStream_t stream) {
-	static std::mutex mu;
-	static std::map<int, bool> known;
+	std::mutex &mu = g_lds_order_mu;
+	std::map<int, bool> &known = g_lds_order_known;
 	std::lock_guard<std::mutex> lk(mu);
 	auto it = known.find(device);
 	if (it != known.end()) return it->second;
@@ -571,7 +577,7 @@ static bool lds_atomics_lane_ordered(int device, hipStream_t stream) {
 	hipLaunchKernelGGL(ss_lds_order_probe_kernel, dim3(1), dim3(64), 0, stream, d_in.p, rounds, d_out.p);
 	HIP_CHECK(hipGetLastError());
 	HIP_CHECK(hipMemcpyAsync(got.data(), d_out.p, got.size() * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	bool ordered = true;
 	for (u32 r = 0; r < rounds && ordered; ++r) {
 		u32 seen[64] = {0};
@@ -649,7 +655,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 	// L2: every coarse bucket into its own fine buckets
 	const u32 parts = std::max<u32>(1, std::min<u32>(16, 2048 / F1));
 	ss_cnt2.ensure(size_t(F2) * parts); ss_bucket_base.ensure(F2); ss_bucket_cnt.ensure(F2); scalars.ensure(16);
-	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));   // [0] largest bucket, [1] molecule total
+	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));   // [0] largest bucket, [1] molecule total, [2] a bucket was out of order after its sort
 	timed("ss_hist:L2", double(n) * 8, [&] {
 		if (wide) hipLaunchKernelGGL(ss_hist_l2_kernel<1024>, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
 		else hipLaunchKernelGGL(ss_hist_l2_kernel<512>, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
@@ -676,6 +682,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 	a.keys = keys; a.vals = vals; a.bucket_base = ss_bucket_base.p; a.bucket_cnt = ss_bucket_cnt.p; a.n_buckets = F2; a.ms = ms;
 	a.t_key = keys_alt; a.t_reads = ss_tmp.p; a.t_agg = ss_tmp.p + n; a.n_loc = ss_n_loc.p;
 	if (const char *e = getenv("DROPEST_SS_DEBUG")) a.debug = u32(atoi(e));
+	a.order_flag = scalars.p + 2;
 	a.cap = SMALL_MAX; a.skip_above = SMALL_MAX;
 	{
 		const size_t lds = ss_local_lds_bytes(a.cap, 256);
@@ -708,15 +715,24 @@ bool dropest_ctx::splitter_sort_reduce() {
 				if (!big.empty()) { if (VB) launch(ss_local_big_kernel<512, 1>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); else launch(ss_local_big_kernel<512, 0>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); }
 			}
 		});
-		HIP_CHECK(hipStreamSynchronize(stream));   // the host lists must outlive their copies
+		HIP_CHECK(stream_wait(stream));   // the host lists must outlive their copies
 	}
 	const u32 n_chunks = div_up(F2, 1024);
 	timed("ss_scan", double(F2) * 12, [&] {
 		hipLaunchKernelGGL(ss_chunk_sums_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_n_loc.p, F2, ss_chunk.p);
 		hipLaunchKernelGGL(ss_prefix_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_n_loc.p, F2, ss_chunk.p, n_chunks, ss_prefix.p, scalars.p + 1);
 	});
-	u32 total = 0;
-	fetch(&total, scalars.p + 1, 4);
+	u32 total_flag[2] = {0, 0};
+	fetch(total_flag, scalars.p + 1, 8);
+	if (total_flag[1]) {
+		// A bucket came out of its LDS sort unsorted (the in-kernel check of ss_local, every pass): never silently.  The partitions
+		// consumed the keys, so they are built again and the LSD sort takes the pass; the one-atomic ranking is off for this device.
+		if (atomic_rank) lds_atomics_mark_unordered(cfg.device);
+		stats["count:ss_order_violation"].launches += 1;
+		build_keys(false);
+		return false;
+	}
+	const u32 total = total_flag[0];
 	n_mol = total;
 	mol_key.ensure(size_t(n_mol) + 1);
 	for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) b->ensure(size_t(n_mol) + 1);
@@ -794,7 +810,7 @@ void dropest_ctx::reduce_all() {
 		n_chr_rows = 0;
 		reduce_molecules_to_cell_gene();
 		reduce_cell_gene_to_cells();
-		HIP_CHECK(hipStreamSynchronize(stream));
+		HIP_CHECK(stream_wait(stream));
 		return;
 	}
 	main_sort_passes = u32(plan_radix_passes(varying).size()); main_sort_kind = 0;
@@ -835,7 +851,7 @@ void dropest_ctx::reduce_all() {
 	}
 	reduce_molecules_to_cell_gene();
 	reduce_cell_gene_to_cells();
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	// the sort ping-pong buffers stay allocated: the next run_set_initialized on this context reuses them
 }
 
@@ -1029,7 +1045,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 			u32 *perm = reinterpret_cast<u32 *>(sort_stage.p);              // the staging buffer is free again (stream order)
 			HostStage sx3(this, "sort_filtered:device:d2h");
 			HIP_CHECK(hipMemcpyAsync(perm, v, size_t(m) * 4, hipMemcpyDeviceToHost, stream));
-			HIP_CHECK(hipStreamSynchronize(stream));
+			HIP_CHECK(stream_wait(stream));
 			st3.reset();
 			HostStage st4(this, "sort_filtered:gather");
 			size_t start = 0;
@@ -1135,6 +1151,11 @@ void dropest_ctx::run_set_initialized() {
 		{ HostStage hs(this, "sort+reduce"); reduce_all(); }
 		accumulate_umi_qualities();
 		{ HostStage hs(this, "real_cells"); fetch_real_cells(); }
+	} else {
+		// no reads (a shard that owns no barcode): the key fields are still laid out from the statistics the shards agreed on
+		// (or from nothing), so that the tables the later stages size from the layout -- the UMI first-occurrence table of -u
+		// that every shard all-gathers -- have the same shape on every shard
+		plan_key_layout();
 	}
 	request_filtered(0, -1);   // update_cell_sizes(query, 0, -1), CellsDataContainer.cpp:168
 	initialized = true;
@@ -1180,19 +1201,70 @@ void dropest_ctx::matrix_columns(bool filtered_m, std::vector<u32> &col_cell, st
 }
 
 void dropest_ctx::invalidate_prefetch() {
-	if (raw_pf.in_flight && stream2) HIP_CHECK(hipStreamSynchronize(stream2));   // its buffers are about to be reused
+	if (raw_pf.in_flight && stream2) HIP_CHECK(stream_wait(stream2));   // its buffers are about to be reused
 	raw_pf.valid = raw_pf.in_flight = false;
+}
+
+// Narrow CSC (16-bit row indices and values + an exact overflow list) is possible when every gene id fits 16 bits.
+bool dropest_ctx::narrow_possible() const { return n_reads == 0 || ingest.gene_max_plus1 <= 0x10000u; }
+
+static constexpr u32 MATRIX_OVF_CAP = 1u << 20;
+
+// Wires the output side of an emit launch for matrix slot M (wide or narrow) and makes sure the buffers exist.
+void dropest_ctx::matrix_outputs(MatrixResult &M, uint64_t nnz, bool narrow, bool to_host, dropest::MatrixArgs &a) {
+	M.narrow = narrow; M.n_ovf = 0;
+	if (narrow) {
+		M.d_row16.ensure(nnz); M.d_val16.ensure(nnz); M.d_ovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP));
+		if (to_host) { M.h_row16.ensure(nnz); M.h_val16.ensure(nnz); M.h_ovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP)); }
+		a.t_gene16 = M.d_row16.p; a.t_val16 = M.d_val16.p;
+		a.ovf_count = M.d_ovf.p; a.ovf_pos = M.d_ovf.p + 1; a.ovf_val = M.d_ovf.p + 1 + MATRIX_OVF_CAP; a.ovf_cap = MATRIX_OVF_CAP;
+	} else {
+		M.d_row.ensure(nnz); M.d_val.ensure(nnz);
+		if (to_host) { M.h_row.ensure(nnz); M.h_val.ensure(nnz); }
+		a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
+	}
+}
+
+// Device-to-host copies of a matrix slot on stream `st` (after its emit launch).  Narrow: the overflow count travels with the
+// first 64 listed entries (values beyond 65534 are rare); a longer list is fetched by matrix_finish_overflow.
+void dropest_ctx::matrix_copy_out(MatrixResult &M, uint64_t nnz, hipStream_t st) {
+	if (M.narrow) {
+		HIP_CHECK(hipMemcpyAsync(M.h_row16.p, M.d_row16.p, nnz * 2, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(M.h_val16.p, M.d_val16.p, nnz * 2, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(M.h_ovf.p, M.d_ovf.p, 4, hipMemcpyDeviceToHost, st));
+	} else {
+		HIP_CHECK(hipMemcpyAsync(M.h_row.p, M.d_row.p, nnz * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(M.h_val.p, M.d_val.p, nnz * 4, hipMemcpyDeviceToHost, st));
+	}
+}
+
+// After the copies of matrix_copy_out have been waited for: the overflow list of a narrow matrix (usually empty).
+void dropest_ctx::matrix_finish_overflow(MatrixResult &M, hipStream_t st) {
+	if (!M.narrow || !M.nnz) { M.n_ovf = 0; return; }
+	const u32 count = M.h_ovf.p[0];
+	if (count > MATRIX_OVF_CAP) throw UnsupportedError("more than 2^20 matrix entries beyond 65534: use the 32-bit form (dropest_count_matrix_csc)");
+	M.n_ovf = count;
+	if (!count) return;
+	HIP_CHECK(hipMemcpyAsync(M.h_ovf.p + 1, M.d_ovf.p + 1, size_t(count) * 4, hipMemcpyDeviceToHost, st));
+	HIP_CHECK(hipMemcpyAsync(M.h_ovf.p + 1 + MATRIX_OVF_CAP, M.d_ovf.p + 1 + MATRIX_OVF_CAP, size_t(count) * 4, hipMemcpyDeviceToHost, st));
+	HIP_CHECK(stream_wait(st));
+	// the list is filled in the order the atomics landed: sorted by position, so that the result does not depend on it
+	std::vector<std::pair<u32, u32>> ov(count);
+	for (u32 i = 0; i < count; ++i) ov[i] = {M.h_ovf.p[1 + i], M.h_ovf.p[1 + MATRIX_OVF_CAP + i]};
+	std::sort(ov.begin(), ov.end());
+	for (u32 i = 0; i < count; ++i) { M.h_ovf.p[1 + i] = ov[i].first; M.h_ovf.p[1 + MATRIX_OVF_CAP + i] = ov[i].second; }
 }
 
 // cm_raw on a second stream: emit + device-to-host copy start now and run under whatever the caller does next (ordering
 // the filtered cells, emitting cm); dropest_count_matrix_csc(filtered = 0) later only waits for the copy.
-void dropest_ctx::prefetch_raw_matrix(bool reads_output) {
+void dropest_ctx::prefetch_raw_matrix(bool reads_output, bool narrow) {
 	invalidate_prefetch();
+	if (narrow && !narrow_possible()) throw UnsupportedError("gene ids beyond 65535: the narrow matrix form is not available");
 	MatrixResult &M = mat[1];
 	uint64_t nnz = 0;
 	matrix_columns(false, raw_pf.col_cell, M.colptr, nnz);
-	M.nnz = nnz; M.ncols = raw_pf.col_cell.size();
-	raw_pf.valid = true; raw_pf.reads_output = reads_output;
+	M.nnz = nnz; M.ncols = raw_pf.col_cell.size(); M.narrow = narrow; M.n_ovf = 0;
+	raw_pf.valid = true; raw_pf.reads_output = reads_output; raw_pf.narrow = narrow;
 	if (nnz == 0) return;
 	if (!stream2) {
 		HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
@@ -1201,35 +1273,36 @@ void dropest_ctx::prefetch_raw_matrix(bool reads_output) {
 	}
 	const u32 ncols = u32(raw_pf.col_cell.size());
 	m2_col_cell.ensure(ncols); m2_col_start.ensure(ncols);
-	M.d_row.ensure(nnz); M.d_val.ensure(nnz); M.h_row.ensure(nnz); M.h_val.ensure(nnz);
+	MatrixArgs a{};
+	matrix_outputs(M, nnz, narrow, true, a);
 	HIP_CHECK(hipEventRecord(ev_fork, stream));                // everything enqueued so far (the tables) comes first
 	HIP_CHECK(hipStreamWaitEvent(stream2, ev_fork, 0));
 	HIP_CHECK(hipMemcpyAsync(m2_col_cell.p, raw_pf.col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream2));
 	HIP_CHECK(hipMemcpyAsync(m2_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream2));
-	MatrixArgs a{};
+	if (narrow) HIP_CHECK(hipMemsetAsync(M.d_ovf.p, 0, 4, stream2));
 	a.col_cell = m2_col_cell.p; a.col_start = m2_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
 	a.value = reads_output ? cg_reads_all.p : cg_n_all.p;
 	a.gene_mask = layout.gene_none; a.skip_zero = 0;
-	a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
-	hipLaunchKernelGGL(emit_matrix_kernel, dim3(ncols), dim3(256), 0, stream2, a);
+	if (narrow) hipLaunchKernelGGL(emit_matrix_kernel<true>, dim3(ncols), dim3(256), 0, stream2, a);
+	else hipLaunchKernelGGL(emit_matrix_kernel<false>, dim3(ncols), dim3(256), 0, stream2, a);
 	HIP_CHECK(hipGetLastError());
-	HIP_CHECK(hipMemcpyAsync(M.h_row.p, M.d_row.p, nnz * 4, hipMemcpyDeviceToHost, stream2));
-	HIP_CHECK(hipMemcpyAsync(M.h_val.p, M.d_val.p, nnz * 4, hipMemcpyDeviceToHost, stream2));
+	matrix_copy_out(M, nnz, stream2);
 	HIP_CHECK(hipEventRecord(ev_raw, stream2));
 	raw_pf.in_flight = true;
 }
 
-void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host) {
+void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, bool narrow) {
 	HostStage hs(this, filtered_m ? "matrix:cm" : "matrix:cm_raw");
+	if (narrow && !narrow_possible()) throw UnsupportedError("gene ids beyond 65535: the narrow matrix form is not available");
 	MatrixResult &M = mat[filtered_m ? 0 : 1];
 	std::vector<u32> col_cell;
 	uint64_t nnz = 0;
 	if (!filtered_m && raw_pf.valid) {
-		// a prefetched cm_raw is used if it is what this call would produce: same columns, same sizes, same value kind
+		// a prefetched cm_raw is used if it is what this call would produce: same columns, same sizes, same value kind and form
 		std::vector<u32> colptr;
 		matrix_columns(false, col_cell, colptr, nnz);
-		if (to_host && raw_pf.reads_output == reads_output && col_cell == raw_pf.col_cell && colptr == M.colptr) {
-			if (raw_pf.in_flight) { HIP_CHECK(hipEventSynchronize(ev_raw)); raw_pf.in_flight = false; }
+		if (to_host && raw_pf.reads_output == reads_output && raw_pf.narrow == narrow && col_cell == raw_pf.col_cell && colptr == M.colptr) {
+			if (raw_pf.in_flight) { HIP_CHECK(event_wait(ev_raw)); raw_pf.in_flight = false; matrix_finish_overflow(M, stream2); }
 			return;
 		}
 		invalidate_prefetch();
@@ -1237,27 +1310,25 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host) 
 	} else {
 		matrix_columns(filtered_m, col_cell, M.colptr, nnz);
 	}
-	M.nnz = nnz; M.ncols = col_cell.size();
+	M.nnz = nnz; M.ncols = col_cell.size(); M.narrow = narrow; M.n_ovf = 0;
 	if (nnz == 0) return;
 	const u32 ncols = u32(col_cell.size());
 	m_col_cell.ensure(ncols); m_col_start.ensure(ncols);
-	M.d_row.ensure(nnz); M.d_val.ensure(nnz);
+	MatrixArgs a{};
+	matrix_outputs(M, nnz, narrow, to_host, a);
 	HIP_CHECK(hipMemcpyAsync(m_col_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(m_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
-	MatrixArgs a{};
+	if (narrow) HIP_CHECK(hipMemsetAsync(M.d_ovf.p, 0, 4, stream));
 	a.col_cell = m_col_cell.p; a.col_start = m_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
 	a.value = filtered_m ? (reads_output ? cg_reads_req.p : cg_n_req.p) : (reads_output ? cg_reads_all.p : cg_n_all.p);
 	a.gene_mask = layout.gene_none; a.skip_zero = filtered_m ? 1 : 0;
-	a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
-	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * 20, [&] {
-		hipLaunchKernelGGL(emit_matrix_kernel, dim3(ncols), dim3(256), 0, stream, a);
+	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * (narrow ? 16 : 20), [&] {
+		if (narrow) hipLaunchKernelGGL(emit_matrix_kernel<true>, dim3(ncols), dim3(256), 0, stream, a);
+		else hipLaunchKernelGGL(emit_matrix_kernel<false>, dim3(ncols), dim3(256), 0, stream, a);
 	});
-	if (to_host) {
-		M.h_row.ensure(nnz); M.h_val.ensure(nnz);
-		HIP_CHECK(hipMemcpyAsync(M.h_row.p, M.d_row.p, nnz * 4, hipMemcpyDeviceToHost, stream));
-		HIP_CHECK(hipMemcpyAsync(M.h_val.p, M.d_val.p, nnz * 4, hipMemcpyDeviceToHost, stream));
-	}
-	HIP_CHECK(hipStreamSynchronize(stream));   // col_cell (host vector) must outlive the H2D copy
+	if (to_host) matrix_copy_out(M, nnz, stream);
+	HIP_CHECK(stream_wait(stream));   // col_cell (host vector) must outlive the H2D copy
+	if (to_host) matrix_finish_overflow(M, stream);
 	collect_timings();
 }
 
@@ -1269,7 +1340,7 @@ void dropest_ctx::emit_columns_device(bool filtered_m, bool reads_output, const 
 	const u32 ncols = u32(col_cell.size());
 	if (!ncols || !nnz) return;
 	m_col_cell.ensure(ncols); m_col_start.ensure(ncols);
-	M.d_row.ensure(nnz); M.d_val.ensure(nnz);
+	M.d_row.ensure(nnz); M.d_val.ensure(nnz); M.narrow = false; M.n_ovf = 0;
 	HIP_CHECK(hipMemcpyAsync(m_col_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(m_col_start.p, col_start.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	MatrixArgs a{};
@@ -1278,9 +1349,9 @@ void dropest_ctx::emit_columns_device(bool filtered_m, bool reads_output, const 
 	a.gene_mask = layout.gene_none; a.skip_zero = filtered_m ? 1 : 0;
 	a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
 	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * 20, [&] {
-		hipLaunchKernelGGL(emit_matrix_kernel, dim3(ncols), dim3(256), 0, stream, a);
+		hipLaunchKernelGGL(emit_matrix_kernel<false>, dim3(ncols), dim3(256), 0, stream, a);
 	});
-	HIP_CHECK(hipStreamSynchronize(stream));   // the host vectors must outlive their copies
+	HIP_CHECK(stream_wait(stream));   // the host vectors must outlive their copies
 }
 
 // ResultsPrinter::get_count_matrix_filtered(container, query_marks) (ResultsPrinter.cpp:333-361) for a query other than
@@ -1336,11 +1407,11 @@ void dropest_ctx::emit_matrix_levels(u32 mask, bool reads_output) {
 	a.col_cell = m_col_cell.p; a.col_start = m_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
 	a.value = d_value.p; a.gene_mask = layout.gene_none; a.skip_zero = 1;
 	a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
-	hipLaunchKernelGGL(emit_matrix_kernel, dim3(ncols), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(emit_matrix_kernel<false>, dim3(ncols), dim3(256), 0, stream, a);
 	HIP_CHECK(hipGetLastError());
 	HIP_CHECK(hipMemcpyAsync(M.h_row.p, M.d_row.p, nnz * 4, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipMemcpyAsync(M.h_val.p, M.d_val.p, nnz * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 }
 
 // Walks a fetched slice of the molecule table in order, skipping the pseudo rows of gene-less reads and replacing
@@ -1439,11 +1510,12 @@ dropest_status dropest_push_reads(dropest_ctx *ctx, const uint64_t *cb, const ui
 		if (ctx->store_chunk >= 0 && size_t(ctx->store_chunk) + 1 != ctx->chunks.size()) {
 			ReadChunk c;
 			c.cb.alloc(n); c.umi.alloc(n); c.gene.alloc(n); c.aux.alloc(n);
+			c.cb.mark_persistent(); c.umi.mark_persistent(); c.gene.mark_persistent(); c.aux.mark_persistent();
 			HIP_CHECK(hipMemcpyAsync(c.cb.p, cb, n * 8, hipMemcpyHostToDevice, ctx->stream));
 			HIP_CHECK(hipMemcpyAsync(c.umi.p, umi, n * 8, hipMemcpyHostToDevice, ctx->stream));
 			HIP_CHECK(hipMemcpyAsync(c.gene.p, gene, n * 4, hipMemcpyHostToDevice, ctx->stream));
 			HIP_CHECK(hipMemcpyAsync(c.aux.p, aux, n * 4, hipMemcpyHostToDevice, ctx->stream));
-			HIP_CHECK(hipStreamSynchronize(ctx->stream));
+			HIP_CHECK(stream_wait(ctx->stream));
 			c.p_cb = c.cb.p; c.p_umi = c.umi.p; c.p_gene = c.gene.p; c.p_aux = c.aux.p; c.n = n;
 			ctx->chunks.push_back(std::move(c));
 			ctx->n_reads += n;
@@ -1478,11 +1550,12 @@ dropest_status dropest_push_reads_device(dropest_ctx *ctx, const uint64_t *d_cb,
 			c.p_gene = d_gene; c.p_aux = d_aux;
 		} else {
 			c.cb.alloc(n); c.umi.alloc(n); c.gene.alloc(n); c.aux.alloc(n);
+			c.cb.mark_persistent(); c.umi.mark_persistent(); c.gene.mark_persistent(); c.aux.mark_persistent();
 			HIP_CHECK(hipMemcpyAsync(c.cb.p, d_cb, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
 			HIP_CHECK(hipMemcpyAsync(c.umi.p, d_umi, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
 			HIP_CHECK(hipMemcpyAsync(c.gene.p, d_gene, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
 			HIP_CHECK(hipMemcpyAsync(c.aux.p, d_aux, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-			HIP_CHECK(hipStreamSynchronize(ctx->stream));
+			HIP_CHECK(stream_wait(ctx->stream));
 			c.p_cb = c.cb.p; c.p_umi = c.umi.p; c.p_gene = c.gene.p; c.p_aux = c.aux.p;
 		}
 		ctx->chunks.push_back(std::move(c));
@@ -1540,7 +1613,7 @@ dropest_status dropest_gene_chr_table(dropest_ctx *ctx, uint32_t **d_table, uint
 		if (!ctx->gene_chr.p) {   // a shard without reads: an all-unset table
 			ctx->gene_chr.ensure(GENE_CHR_CAP);
 			HIP_CHECK(hipMemsetAsync(ctx->gene_chr.p, 0xFF, size_t(GENE_CHR_CAP) * 4, ctx->stream));
-			HIP_CHECK(hipStreamSynchronize(ctx->stream));
+			HIP_CHECK(stream_wait(ctx->stream));
 		}
 		*d_table = ctx->gene_chr.p; *n = GENE_CHR_CAP;
 	});
@@ -1658,7 +1731,7 @@ dropest_status dropest_cell_rows(dropest_ctx *ctx, uint64_t first, uint64_t coun
 		                   static_cast<const u32 *>(nullptr), u32(first), u32(count), rows.p);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipMemcpyAsync(out, rows.p, count * sizeof(CellRowPod), hipMemcpyDeviceToHost, ctx->stream));
-		HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		HIP_CHECK(stream_wait(ctx->stream));
 		for (uint64_t j = 0; j < count; ++j) {   // overlay the host-tracked state of real-candidate cells
 			const long ri = ctx->real_find(u32(first + j));
 			if (ri < 0) continue;
@@ -1739,7 +1812,7 @@ static void fetch_molecule_range(dropest_ctx *ctx, u32 mb, u32 me, std::vector<u
 	HIP_CHECK(hipMemcpyAsync(k.data(), ctx->mol_key.p + mb, size_t(cnt) * 8, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_CHECK(hipMemcpyAsync(r.data(), ctx->mol_reads.p + mb, size_t(cnt) * 4, hipMemcpyDeviceToHost, ctx->stream));
 	HIP_CHECK(hipMemcpyAsync(m.data(), ctx->mol_mark.p + mb, size_t(cnt) * 4, hipMemcpyDeviceToHost, ctx->stream));
-	HIP_CHECK(hipStreamSynchronize(ctx->stream));
+	HIP_CHECK(stream_wait(ctx->stream));
 }
 
 dropest_status dropest_molecules(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, uint32_t *gene, uint64_t *umi,
@@ -1823,9 +1896,9 @@ dropest_status dropest_set_umi_qualities(dropest_ctx *ctx, const uint8_t *qualit
 		ctx->qual_len = quality_length; ctx->qual_reads = n_reads; ctx->have_qual = true;
 		const size_t bytes = size_t(n_reads) * quality_length;
 		if (bytes) {
-			ctx->umi_qual.alloc(bytes);
+			ctx->umi_qual.alloc(bytes); ctx->umi_qual.mark_persistent();
 			HIP_CHECK(hipMemcpyAsync(ctx->umi_qual.p, qualities, bytes, hipMemcpyHostToDevice, ctx->stream));
-			HIP_CHECK(hipStreamSynchronize(ctx->stream));
+			HIP_CHECK(stream_wait(ctx->stream));
 		}
 	});
 }
@@ -1872,7 +1945,32 @@ dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int read
 dropest_status dropest_prefetch_raw_matrix(dropest_ctx *ctx, int reads_output) {
 	return guarded([&] {
 		need_init(ctx);
-		ctx->prefetch_raw_matrix(reads_output != 0);
+		ctx->prefetch_raw_matrix(reads_output != 0, false);
+	});
+}
+
+dropest_status dropest_prefetch_raw_matrix_narrow(dropest_ctx *ctx, int reads_output) {
+	return guarded([&] {
+		need_init(ctx);
+		ctx->prefetch_raw_matrix(reads_output != 0, true);
+	});
+}
+
+dropest_status dropest_narrow_matrix_possible(dropest_ctx *ctx, int *possible) {
+	return guarded([&] { need_init(ctx); if (!possible) throw InvalidError("null argument"); *possible = ctx->narrow_possible() ? 1 : 0; });
+}
+
+dropest_status dropest_count_matrix_csc_narrow(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *ncols, uint64_t *nnz,
+                                               const uint32_t **colptr, const uint16_t **rowidx, const uint16_t **values,
+                                               uint64_t *n_overflow, const uint32_t **overflow_pos, const uint32_t **overflow_val) {
+	return guarded([&] {
+		need_init(ctx);
+		if (!ncols || !nnz || !colptr || !rowidx || !values || !n_overflow || !overflow_pos || !overflow_val) throw InvalidError("null argument");
+		ctx->emit_matrix(filtered != 0, reads_output != 0, true, true);
+		const dropest_ctx::MatrixResult &M = ctx->mat[filtered ? 0 : 1];
+		*ncols = M.ncols; *nnz = M.nnz;
+		*colptr = M.colptr.data(); *rowidx = M.h_row16.p; *values = M.h_val16.p;
+		*n_overflow = M.n_ovf; *overflow_pos = M.h_ovf.p ? M.h_ovf.p + 1 : nullptr; *overflow_val = M.h_ovf.p ? M.h_ovf.p + 1 + MATRIX_OVF_CAP : nullptr;
 	});
 }
 
@@ -1944,7 +2042,7 @@ dropest_status dropest_chr_stats(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, 
 		HIP_CHECK(hipGetLastError());
 		std::vector<u32> t(tab);
 		HIP_CHECK(hipMemcpyAsync(t.data(), d_tab.p, tab * 4, hipMemcpyDeviceToHost, ctx->stream));
-		HIP_CHECK(hipStreamSynchronize(ctx->stream));
+		HIP_CHECK(stream_wait(ctx->stream));
 		uint64_t cnt = 0;
 		for (size_t ci = 0; ci < cells_n; ++ci)
 			for (u32 k = 0; k < 3; ++k)
@@ -2141,7 +2239,7 @@ static void partition_by_owner_on(int device, hipStream_t st, const u64 *d_cb, c
 		HIP_CHECK(hipGetLastError());
 		std::vector<u32> totals(RS_RADIX);
 		HIP_CHECK(hipMemcpyAsync(totals.data(), row_total, RS_RADIX * 4, hipMemcpyDeviceToHost, st));
-		HIP_CHECK(hipStreamSynchronize(st));
+		HIP_CHECK(stream_wait(st));
 		for (u32 p = 0; p < n_parts; ++p) counts[p] = totals[p];
 	}
 }
@@ -2292,6 +2390,32 @@ dropest_status dropest_rand_sequence(uint32_t seed, uint64_t n, int32_t *out) {
 		GlibcRand r(seed);
 		for (uint64_t i = 0; i < n; ++i) out[i] = r.next();
 	});
+}
+
+dropest_status dropest_debug_poison_scratch(uint64_t seed, uint64_t *n_blocks) {
+	return guarded([&] {
+		HIP_CHECK(hipDeviceSynchronize());
+		const size_t d = DevRegistry::get().poison_all(seed), h = PinnedRegistry::get().poison_all(seed);
+		if (n_blocks) *n_blocks = d + h;
+	});
+}
+
+dropest_status dropest_debug_alloc_ordinal(uint64_t *next_ordinal) {
+	return guarded([&] { auto &r = DevRegistry::get(); std::lock_guard<std::mutex> lk(r.mu); *next_ordinal = r.next; });
+}
+
+dropest_status dropest_debug_alloc_site(uint64_t ordinal, char *out, uint64_t out_bytes) {
+	return guarded([&] {
+		auto &r = DevRegistry::get();
+		std::lock_guard<std::mutex> lk(r.mu);
+		std::string text = "unknown (set DROPEST_ALLOC_TRACE=1)";
+		for (auto const &s : r.sites) if (s.ordinal == ordinal) text = std::string(s.file) + ":" + std::to_string(s.line) + " " + std::to_string(s.bytes) + " B" + (s.recycled ? " recycled" : " fresh");
+		if (out && out_bytes) { std::snprintf(out, size_t(out_bytes), "%s", text.c_str()); }
+	});
+}
+
+dropest_status dropest_debug_trim_pool(void) {
+	return guarded([&] { DevRegistry::get().trim_pool(); });
 }
 
 dropest_status dropest_set_profiling_filter(dropest_ctx *ctx, const char *name_prefix) {

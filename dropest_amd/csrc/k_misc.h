@@ -218,7 +218,13 @@ struct MatrixArgs {
 	unsigned long long gene_mask;
 	int skip_zero;                  // filtered matrix omits zero entries (Cell.cpp:59-62)
 	uint32_t *t_gene, *t_val;
+	// NARROW output (gene ids below 65536): 16-bit row indices and values, 4 bytes per entry over PCIe instead of 8.  A value
+	// beyond 65534 is stored as 0xFFFF and listed exactly in (ovf_pos, ovf_val) -- at most ovf_cap entries; ovf_count keeps counting.
+	uint16_t *t_gene16, *t_val16;
+	uint32_t *ovf_count, *ovf_pos, *ovf_val;
+	uint32_t ovf_cap;
 };
+template <bool NARROW>
 __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
 	__shared__ uint32_t scratch[256 / 64 + 1];
 	const uint32_t col = blockIdx.x;
@@ -236,7 +242,16 @@ __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
 		}
 		uint32_t total;
 		const uint32_t ex = block_excl_scan_u32<256>(keep ? 1u : 0u, scratch, total);
-		if (keep) { a.t_gene[out + ex] = g; a.t_val[out + ex] = v; }
+		if (keep) {
+			if (NARROW) {
+				a.t_gene16[out + ex] = uint16_t(g);
+				a.t_val16[out + ex] = v >= 0xFFFFu ? uint16_t(0xFFFFu) : uint16_t(v);
+				if (v >= 0xFFFFu) {
+					const uint32_t at = atomicAdd(a.ovf_count, 1u);
+					if (at < a.ovf_cap) { a.ovf_pos[at] = out + ex; a.ovf_val[at] = v; }
+				}
+			} else { a.t_gene[out + ex] = g; a.t_val[out + ex] = v; }
+		}
 		out += total;
 	}
 }

@@ -277,7 +277,8 @@ struct SsLocalArgs {
 	int ms;                              // mark bits folded under the key (VB = 0: 3)
 	uint32_t cap;                        // records the LDS of this launch holds
 	uint32_t skip_above;                 // small launch: buckets with more records are left to the big launch
-	uint32_t debug;                      // timing experiments only (DROPEST_SS_DEBUG): 2 no sort passes -- wrong results
+	uint32_t debug;                      // DROPEST_SS_DEBUG: 2 = skip the sort passes (the order check below must then catch it: tests)
+	uint32_t *order_flag;                // set to 1 when a bucket is found out of order after its sort (checked on EVERY pass)
 	unsigned long long *t_key;           // sparse rows: molecule key, reads, agg (bit 0 not-annotated, exon << 1, intron << 16)
 	uint32_t *t_reads, *t_agg, *n_loc;
 };
@@ -382,13 +383,19 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint3
 		}
 	}
 
-	// heads: a record whose molecule key differs from its predecessor's; position order = (wave, item, lane)
+	// heads: a record whose molecule key differs from its predecessor's; position order = (wave, item, lane).
+	// The same comparison verifies the sort: a bucket is sorted iff no record is smaller than its predecessor -- one compare per
+	// record, OR-reduced into a device flag the host reads together with the molecule count.  The one-atomic ranking above leans on
+	// the LDS applying same-address lanes of one instruction in lane order (undocumented); should that ever fail, molecules would
+	// silently split into several runs.  With this check it cannot be silent: the host falls back to the LSD sort.
 	uint32_t run = 0, pre[ITEMS], head_bits = 0;
+	bool out_of_order = false;
 #pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
 		const uint32_t p = lane_off + i * 64;
 		const bool valid = p < cnt;
 		const unsigned long long prev = (valid && p) ? sk[p - 1] : 0ull;
+		out_of_order |= valid && p && (prev >> ms) > (key[i] >> ms);
 		const bool head = valid && (p == 0 || (prev >> ms) != (key[i] >> ms));
 		const unsigned long long bal = __ballot(head);
 		pre[i] = run + __builtin_amdgcn_mbcnt_hi(uint32_t(bal >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bal), 0u));
@@ -396,6 +403,7 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint3
 		if (head) head_bits |= 1u << i;
 	}
 	if (lane == 0) wtot[w] = run;
+	if (__ballot(out_of_order) && lane == 0) atomicOr(a.order_flag, 1u);
 	lds_barrier();   // every sk[p - 1] is read: the key area may now hold the aggregates
 	uint32_t woff = 0, n_loc = 0;
 #pragma unroll

@@ -10,6 +10,31 @@
 
 namespace {
 
+// Tools::edit_distance (Tools/UtilFunctions.cpp:32-65): banded dynamic programme with N wildcards, restated with its
+// band handling (cells outside the band keep what earlier columns left there; the lower band edge is set to the
+// column number) and its early exit, because values at and above max_ed decide which UMIs are skipped.
+unsigned banded_edit_distance(const std::string &s1, const std::string &s2, unsigned max_ed) {
+	const int n1 = int(s1.size()), n2 = int(s2.size());
+	std::vector<int> column(size_t(n1) + 1);
+	for (int i = 0; i <= n1; ++i) column[size_t(i)] = i;
+	for (int j = 1; j <= n2; ++j) {
+		const int lower = std::max(0, j - int(max_ed)), upper = std::min(n1, j + int(max_ed));
+		int lastdiag = column[size_t(lower)];
+		column[size_t(lower)] = j;
+		int min_ed = j;
+		for (int i = lower + 1; i <= upper; ++i) {
+			const int olddiag = column[size_t(i)];
+			const bool match = s1[size_t(i - 1)] == s2[size_t(j - 1)] || s1[size_t(i - 1)] == 'N' || s2[size_t(j - 1)] == 'N';
+			const int v = std::min(std::min(column[size_t(i)] + 1, column[size_t(i - 1)] + 1), lastdiag + int(!match));
+			min_ed = std::min(min_ed, v + std::abs(i - j));
+			column[size_t(i)] = v;
+			lastdiag = olddiag;
+		}
+		if (min_ed > int(max_ed)) return unsigned(min_ed);
+	}
+	return unsigned(column[size_t(n1)]);
+}
+
 struct PartDistH { size_t index; long value; };            // Tools/IndexedValue.h
 struct ComboH { size_t idx[dropest::WL_MAX_PARTS]; unsigned ed; };   // BarcodesParser::BarcodesDistance
 
@@ -87,7 +112,7 @@ void dropest_ctx::upload_whitelist() {
 			std::memset(h[i].seq, 0, sizeof(h[i].seq));
 			std::memcpy(h[i].seq, wl.parts[size_t(p)][i].data(), wl.parts[size_t(p)][i].size());
 		}
-		d_wl[p].alloc(h.size());
+		d_wl[p].alloc(h.size()); d_wl[p].mark_persistent();
 		HIP_CHECK(hipMemcpy(d_wl[p].p, h.data(), h.size() * sizeof(WlEntry), hipMemcpyHostToDevice));
 		// packed copies for the branch-free distance loop (entries of up to 29 clean bases; the others keep the string path)
 		std::vector<u64> codes(h.size(), ~0ull);
@@ -101,7 +126,7 @@ void dropest_ctx::upload_whitelist() {
 			}
 			if (clean) codes[i] = (u64(e.size()) << 58) | c;
 		}
-		d_wl_code[p].alloc(codes.size());
+		d_wl_code[p].alloc(codes.size()); d_wl_code[p].mark_persistent();
 		HIP_CHECK(hipMemcpy(d_wl_code[p].p, codes.data(), codes.size() * 8, hipMemcpyHostToDevice));
 	}
 }
@@ -111,6 +136,11 @@ void dropest_ctx::upload_whitelist() {
 // with the number of filtered cells (10^5..10^6 at BASELINE sizes) is done on the device; the host only walks flat
 // arrays.  Fills the candidate lists and the (base, candidate) pairs whose UMI-gene intersection is needed.
 void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const MergeUniverse &U, MergeSearch &S) {
+	if (!wl.loaded) {
+		if (barcodes_file.empty()) throw InvalidError("merge_kind = REAL_BARCODES needs barcodes_file");
+		wl.load(cfg.barcodes_kind, barcodes_file);
+	}
+	if (wl.parts.size() > size_t(WL_MAX_PARTS)) return search_merge_candidates_host(cells, U, S);
 	upload_whitelist();
 	const u32 F = u32(cells.size());
 	S.F = F;
@@ -189,6 +219,11 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 
 	// 3. pairs (base, candidate) whose UMI-gene intersection is needed
 	st_search.reset();
+	build_merge_pairs(cells, S);
+}
+
+void dropest_ctx::build_merge_pairs(const std::vector<u32> &cells, MergeSearch &S) {
+	const u32 F = S.F;
 	HostStage st_pairs(this, "cb_merge:targets:pairs");
 	S.pair_base.clear(); S.pair_cand.clear(); S.pair_umis.clear(); S.pair_ridx.clear();
 	S.pair_first.assign(size_t(F) + 1, 0); S.self_ridx.assign(F, 0xFFFFFFFFu);
@@ -212,10 +247,85 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 	S.pair_first[F] = u32(S.pair_base.size());
 }
 
+// The same search on the host, literally as the reference runs it (BarcodesParser::get_distances_to_barcode / push_remaining_dists,
+// BarcodesParser.cpp:21-74; RealBarcodesMergeStrategy::get_real_neighbour_cbs, RealBarcodesMergeStrategy.cpp:63-109) with the same
+// libstdc++ sorts on the same sequences: for whitelists of MORE parts than the device kernel is built for (WL_MAX_PARTS; the
+// reference has no limit, ConstLengthBarcodesParser.cpp:50-68).  One context only.
+void dropest_ctx::search_merge_candidates_host(const std::vector<u32> &cells, const MergeUniverse &U, MergeSearch &S) {
+	if (!U.find_cell) throw UnsupportedError("whitelists of more than " + std::to_string(WL_MAX_PARTS) + " parts are searched on the host: one context only, not in sharded runs");
+	HostStage st(this, "cb_merge:targets:host_search");
+	const u32 F = u32(cells.size());
+	const size_t P = wl.parts.size();
+	const bool poisson = cfg.merge_kind == DROPEST_MERGE_POISSON_REAL;
+	S.F = F; S.cells = cells;
+	S.cnt.assign(F, 0); S.off.assign(F, 0); S.fcell.clear(); S.fumis.clear(); S.fridx.clear();
+	S.host_order.assign(F, {});
+	S.ntot = 0;
+	for (auto const &part : wl.parts) S.ntot += u32(part.size());
+	std::vector<std::vector<std::string>> all_pieces(F);
+	for (u32 f = 0; f < F; ++f) all_pieces[f] = wl.split(U.base_barcode_text(f));   // throws the reference's length errors (caller's thread)
+	auto search_base = [&](u32 f, std::vector<u32> &cand, std::vector<u32> &umis, std::vector<u32> &ridx) {
+		const std::vector<std::string> &pieces = all_pieces[f];
+		std::vector<std::vector<PartDistH>> d(P);
+		for (size_t p = 0; p < P; ++p) {
+			for (size_t i = 0; i < wl.parts[p].size(); ++i)
+				d[p].push_back(PartDistH{i, long(banded_edit_distance(pieces[p], wl.parts[p][i], 10000u))});   // Tools::edit_distance, default max_ed
+			std::sort(d[p].begin(), d[p].end(), [](const PartDistH &x, const PartDistH &y) { return x.value < y.value; });
+		}
+		std::vector<size_t> idx(P, 0);
+		// push_remaining_dists over any number of parts (the fixed-size ComboH of the tie replay holds WL_MAX_PARTS)
+		struct Combo { std::vector<size_t> idx; unsigned ed; };
+		std::vector<Combo> all;
+		std::function<void(size_t, unsigned)> walk = [&](size_t part, unsigned ed) {
+			if (part == P) { all.push_back(Combo{idx, ed}); return; }
+			for (const PartDistH &x : d[part]) {
+				const unsigned cur_ed = ed + unsigned(x.value);
+				if (cur_ed > unsigned(WL_MAX_DIST)) return;
+				idx[part] = x.index;
+				walk(part + 1, cur_ed);
+			}
+		};
+		walk(0, 0);
+		if (all.empty()) return;
+		std::sort(all.begin(), all.end(), [](const Combo &x, const Combo &y) { return x.ed < y.ed; });
+		unsigned max_dist = all.front().ed;
+		if (poisson) max_dist = max_dist == 0 ? 2 : max_dist + 1;   // PoissonRealBarcodesMergeStrategy::get_max_merge_dist (:20-23)
+		const int32_t base_umis = U.base_total_umis(f);
+		for (const Combo &c : all) {
+			if (c.ed > max_dist && !cand.empty()) break;
+			std::string cb;
+			for (size_t p = 0; p < P; ++p) cb += wl.parts[p][c.idx[p]];
+			u64 code = 0;
+			if (encode_code(cb, code)) {
+				u32 ng = 0, ri = 0; int32_t tu = 0;
+				const long cell = U.find_cell(code, ng, tu, ri);
+				if (cell >= 0 && ng >= min_before && size_t(tu) >= size_t(base_umis)) { cand.push_back(u32(cell)); umis.push_back(u32(tu)); ridx.push_back(ri); }
+			}
+			max_dist = std::max(max_dist, c.ed);
+		}
+	};
+	std::vector<std::vector<u32>> cand(F), umis(F), ridx(F);
+	parallel_ranges(F, [&](size_t b, size_t e, unsigned) { for (size_t f = b; f < e; ++f) search_base(u32(f), cand[f], umis[f], ridx[f]); }, 64, 16);
+	for (u32 f = 0; f < F; ++f) {
+		S.off[f] = u32(S.fcell.size()); S.cnt[f] = u32(cand[f].size());
+		S.fcell.insert(S.fcell.end(), cand[f].begin(), cand[f].end());
+		S.fumis.insert(S.fumis.end(), umis[f].begin(), umis[f].end());
+		S.fridx.insert(S.fridx.end(), ridx[f].begin(), ridx[f].end());
+		S.host_order[f] = std::move(cand[f]);
+	}
+	build_merge_pairs(cells, S);
+}
+
 // The reference's candidate order (a replay of its two unstable std::sorts) for the bases in `need_order`: the
 // kernel runs again for those bases only and dumps the per-part distances.  Only candidates that are part of S's
 // pairs appear (the base itself is skipped like PoissonTargetEstimator.cpp:28-29 does).
 std::vector<std::vector<u32>> dropest_ctx::replay_candidate_orders(const MergeUniverse &U, MergeSearch &S, const std::vector<u32> &need_order) {
+	if (!S.host_order.empty()) {   // the host search already walked the reference's order; the base itself is not a pair
+		std::vector<std::vector<u32>> orders(need_order.size());
+		for (size_t r = 0; r < need_order.size(); ++r)
+			for (u32 c : S.host_order[need_order[r]]) if (c != S.cells[need_order[r]]) orders[r].push_back(c);
+		return orders;
+	}
 	const u32 R = u32(need_order.size()), ntot = S.ntot;
 	std::vector<WlBase> rb(R);
 	for (u32 r = 0; r < R; ++r) HIP_CHECK(hipMemcpy(&rb[r], S.d_bases.p + need_order[r], sizeof(WlBase), hipMemcpyDeviceToHost));
@@ -346,7 +456,7 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 		HIP_CHECK(hipMemsetAsync(cell_real_index.p, 0xFF, size_t(n_cells) * 4, stream));
 		hipLaunchKernelGGL(scatter_index_kernel, dim3(div_up(nr, 256)), dim3(256), 0, stream, real_list.p, nr, cell_real_index.p);
 		HIP_CHECK(hipGetLastError());
-		HIP_CHECK(hipStreamSynchronize(stream));
+		HIP_CHECK(stream_wait(stream));
 	}
 	HostStage st_universe(this, "cb_merge:targets:universe");
 	MergeUniverse U;
@@ -355,6 +465,19 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 	U.base_total_umis = [&](u32 f) { return real[ridx[f]].row.total_umis; };
 	U.barcode_code = [&](u32 cell) { return u64(real[real_at(cell)].row.barcode); };
 	U.base_barcode_text = [&](u32 f) { return barcode_of(real[ridx[f]]); };
+	std::unordered_map<u64, u32> real_by_code;   // filled on first use (host search only)
+	U.find_cell = [&](u64 code, u32 &ng, int32_t &tu, u32 &ri) -> long {
+		static std::mutex mu;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			if (real_by_code.empty()) for (u32 i = 0; i < real.size(); ++i) real_by_code.emplace(u64(real[i].row.barcode), i);
+		}
+		auto it = real_by_code.find(code);
+		if (it == real_by_code.end()) return -1;   // not a real-candidate cell: fewer genes than min_genes_before_merge, never qualifies
+		const HostCell &h = real[it->second];
+		ng = h.row.n_genes; tu = h.row.total_umis; ri = it->second;
+		return long(h.id);
+	};
 	MergeSearch S;
 	search_merge_candidates(cells, U, S);
 
@@ -477,7 +600,7 @@ void dropest_ctx::reaggregate_after_merge() {
 		hipLaunchKernelGGL(scatter_pairs_kernel, dim3(div_up(u32(src.size()), 256)), dim3(256), 0, stream, d_src.p, d_tgt.p,
 		                   u32(src.size()), remap.p);
 		HIP_CHECK(hipGetLastError());
-		HIP_CHECK(hipStreamSynchronize(stream));   // src / tgt are host vectors
+		HIP_CHECK(stream_wait(stream));   // src / tgt are host vectors
 	}
 	if (have_qual && qual_len && n_mol) {   // which member's quality sums a folded molecule keeps (quality.h)
 		if (merge_rank.size() != n_cells) merge_rank.assign(n_cells, 0);
@@ -487,7 +610,7 @@ void dropest_ctx::reaggregate_after_merge() {
 		hipLaunchKernelGGL(prio_from_cell_kernel, dim3(div_up(n_mol, 256)), dim3(256), 0, stream, mol_key.p, n_mol,
 		                   layout.gene_bits + layout.umi_bits, d_rank.p, reagg_prio_buf.p);
 		HIP_CHECK(hipGetLastError());
-		HIP_CHECK(hipStreamSynchronize(stream));
+		HIP_CHECK(stream_wait(stream));
 		reagg_prio = reagg_prio_buf.p;
 	}
 	keys_a.ensure(n_mol); keys_b.ensure(n_mol); vals_a.ensure(n_mol); vals_b.ensure(n_mol);
@@ -502,7 +625,7 @@ void dropest_ctx::reaggregate_after_merge() {
 	});
 	u64 or_and[2];
 	HIP_CHECK(hipMemcpyAsync(or_and, d_or_and, 16, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	reaggregate_from_keys(or_and[0] ^ or_and[1]);
 }
 
@@ -559,7 +682,7 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 			for (DevBuf<u32> *b : {&mol_reads2, &mol_mark2, &mol_exon2, &mol_intron2}) b->ensure(cap);
 			p.mol_key = mol_key2.p; p.out[0] = mol_reads2.p; p.out[1] = mol_mark2.p; p.out[2] = mol_exon2.p; p.out[3] = mol_intron2.p;
 		});
-		HIP_CHECK(hipStreamSynchronize(stream));
+		HIP_CHECK(stream_wait(stream));
 		std::swap(mol_exon, mol_exon2); std::swap(mol_intron, mol_intron2);
 	} else {
 		RekeyedToMolecules p{};
@@ -569,7 +692,7 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 			mol_key2.ensure(cap); mol_reads2.ensure(cap); mol_mark2.ensure(cap);
 			p.mol_key = mol_key2.p; p.out[0] = mol_reads2.p; p.out[1] = mol_mark2.p;
 		});
-		HIP_CHECK(hipStreamSynchronize(stream));
+		HIP_CHECK(stream_wait(stream));
 	}
 	mol_sorted_rows = 0xFFFFFFFFu;   // the folded table is sorted throughout
 	requality_after_fold(keys, vals, n_mol, mol_key2.p, new_n);
@@ -577,7 +700,7 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
 	n_mol = new_n;
 	reduce_molecules_to_cell_gene();
 	reduce_cell_gene_to_cells();
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	refresh_real_rows();
 }
 
@@ -597,7 +720,7 @@ void dropest_ctx::refresh_real_rows() {
 	HIP_CHECK(hipGetLastError());
 	std::vector<CellRowPod> rows(count);
 	HIP_CHECK(hipMemcpyAsync(rows.data(), real_rows_dev.p, size_t(count) * sizeof(CellRowPod), hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	for (u32 i = 0; i < count; ++i) {
 		if (real[i].merged) continue;   // the reference keeps a merged source's stale sizes; nothing reads them again
 		real[i].row.n_genes = rows[i].n_genes;

@@ -86,7 +86,7 @@ void grow_preserving(dropest::DevBuf<T> &b, size_t keep, size_t want, hipStream_
 	dropest::DevBuf<T> nb;
 	nb.alloc(want + want / 8);
 	if (keep) HIP_CHECK(hipMemcpyAsync(nb.p, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, st));
-	HIP_CHECK(hipStreamSynchronize(st));
+	HIP_CHECK(stream_wait(st));
 	b = std::move(nb);
 }
 
@@ -198,7 +198,7 @@ void dropest_ctx::shard_merge_search(uint64_t n_global, const uint64_t *g_barcod
 		timed("shard_merge:export", double(rows) * 48, [&] {
 			hipLaunchKernelGGL(export_rows_kernel, dim3(nl), dim3(256), 0, stream, a);
 		});
-		HIP_CHECK(hipStreamSynchronize(stream));
+		HIP_CHECK(stream_wait(stream));
 	}
 	collect_timings();
 }
@@ -281,7 +281,7 @@ void dropest_ctx::shard_merge_finish(uint64_t n_local, const uint32_t *local_id,
 			HIP_CHECK(hipMemcpyAsync(mol_exon.p + n_mol, d_cols[2], size_t(ni) * 4, hipMemcpyDeviceToDevice, stream));
 			HIP_CHECK(hipMemcpyAsync(mol_intron.p + n_mol, d_cols[3], size_t(ni) * 4, hipMemcpyDeviceToDevice, stream));
 		}
-		HIP_CHECK(hipStreamSynchronize(stream));
+		HIP_CHECK(stream_wait(stream));
 		mol_sorted_rows = n_mol;   // the imported rows sit behind the sorted table
 		n_mol = total;
 	}

@@ -95,7 +95,7 @@ void dropest_ctx::mutate_merge_umis(u32 cell, u32 gene, uint64_t n, const uint64
 	}
 	keys_a.ensure(n_mol); keys_b.ensure(n_mol); vals_a.ensure(n_mol); vals_b.ensure(n_mol);
 	HIP_CHECK(hipMemcpyAsync(keys_a.p, mol_key.p, size_t(n_mol) * 8, hipMemcpyDeviceToDevice, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	for (auto const &pr : patch) HIP_CHECK(hipMemcpy(keys_a.p + pr.first, &pr.second, 8, hipMemcpyHostToDevice));
 	scalars.ensure(16);
 	u64 init[2] = {0ull, ~0ull};

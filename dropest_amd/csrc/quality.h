@@ -130,7 +130,7 @@ void dropest_ctx::requality_after_fold(const u64 *sorted_key, const u32 *old_row
 	                   reagg_prio, best.p);
 	hipLaunchKernelGGL(take_best_qrow_kernel, dim3(div_up(n_new, 256)), dim3(256), 0, stream, best.p, n_new, mol_qrow.p, mol_qrow2.p);
 	HIP_CHECK(hipGetLastError());
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	std::swap(mol_qrow, mol_qrow2);
 	reagg_prio = nullptr;
 }

@@ -141,7 +141,7 @@ struct LocalTransport : Transport {
 	struct Pub { const void *const *d_send; const size_t *elem; const uint64_t *send_cnt; };
 	void exchange(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
 	              const uint64_t *recv_cnt, hipStream_t st) override {
-		HIP_CHECK(hipStreamSynchronize(st));   // the blocks the peers copy were written on this stream
+		HIP_CHECK(stream_wait(st));   // the blocks the peers copy were written on this stream
 		Pub pub{d_send, elem, send_cnt};
 		hub->p0[size_t(rank)] = &pub;
 		hub->barrier();
@@ -156,7 +156,7 @@ struct LocalTransport : Transport {
 					                         size_t(recv_cnt[p]) * elem[a], hipMemcpyDefault, st));
 			roff += recv_cnt[p];
 		}
-		HIP_CHECK(hipStreamSynchronize(st));
+		HIP_CHECK(stream_wait(st));
 		hub->barrier();   // the senders' buffers may be reused
 	}
 	void gather_host(const void *mine, size_t bytes, void *all) override {
@@ -166,12 +166,12 @@ struct LocalTransport : Transport {
 		hub->barrier();
 	}
 	void gather_dev(const void *d_mine, void *d_all, const size_t *off, const size_t *bytes, hipStream_t st) override {
-		HIP_CHECK(hipStreamSynchronize(st));   // what the peers are about to read was produced on this stream
+		HIP_CHECK(stream_wait(st));   // what the peers are about to read was produced on this stream
 		hub->p1[size_t(rank)] = d_mine;
 		hub->barrier();
 		for (int p = 0; p < world; ++p)
 			if (bytes[p]) HIP_CHECK(hipMemcpyAsync(static_cast<char *>(d_all) + off[p], hub->p1[size_t(p)], bytes[p], hipMemcpyDefault, st));
-		HIP_CHECK(hipStreamSynchronize(st));
+		HIP_CHECK(stream_wait(st));
 		hub->barrier();
 	}
 	void barrier() override { hub->barrier(); }
@@ -239,7 +239,7 @@ struct RcclTransport : Transport {
 			}
 		}
 		api.check(api.GroupEnd(), "ncclGroupEnd");
-		HIP_CHECK(hipStreamSynchronize(st));
+		HIP_CHECK(stream_wait(st));
 	}
 	void gather_host(const void *mine, size_t bytes, void *all) override {
 		const RcclApi &api = RcclApi::get();
@@ -249,7 +249,7 @@ struct RcclTransport : Transport {
 		HIP_CHECK(hipMemcpyAsync(stage_in.p, h_in.p, b, hipMemcpyHostToDevice, st0));
 		api.check(api.AllGather(stage_in.p, stage_out.p, b, ncclUint8, comm, st0), "ncclAllGather");
 		HIP_CHECK(hipMemcpyAsync(h_out.p, stage_out.p, b * size_t(world), hipMemcpyDeviceToHost, st0));
-		HIP_CHECK(hipStreamSynchronize(st0));
+		HIP_CHECK(stream_wait(st0));
 		for (int p = 0; p < world; ++p) std::memcpy(static_cast<char *>(all) + size_t(p) * bytes, h_out.p + size_t(p) * b, bytes);
 	}
 	void gather_dev(const void *d_mine, void *d_all, const size_t *off, const size_t *bytes, hipStream_t st) override {
@@ -260,7 +260,7 @@ struct RcclTransport : Transport {
 			if (bytes[p]) api.check(api.Recv(static_cast<char *>(d_all) + off[p], bytes[p], ncclUint8, p, comm, st), "ncclRecv");
 		}
 		api.check(api.GroupEnd(), "ncclGroupEnd");
-		HIP_CHECK(hipStreamSynchronize(st));
+		HIP_CHECK(stream_wait(st));
 	}
 	void barrier() override { unsigned char x = 0; std::vector<unsigned char> all(static_cast<size_t>(world)); gather_host(&x, 1, all.data()); }
 	void *shared_host(int slot, size_t bytes, void **d_ptr) override {
@@ -418,7 +418,7 @@ struct dropest_shard {
 		dropest_shard *s; const char *name; std::chrono::steady_clock::time_point t0;
 		Phase(dropest_shard *sh, const char *n) : s(sh), name(n), t0(std::chrono::steady_clock::now()) {}
 		~Phase() {
-			if (s->trace) (void)hipStreamSynchronize(s->ctx->stream);
+			if (s->trace) (void)stream_wait(s->ctx->stream);
 			auto &st = s->phases[name];
 			st.launches++;
 			st.ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -535,7 +535,7 @@ void dropest_shard::agree_on_key_fields() {
 		if (conflict) g[5] = 1;
 		else {
 			HIP_CHECK(hipMemcpyAsync(c.gene_chr.p, tab.data(), size_t(n_genes) * 4, hipMemcpyHostToDevice, c.stream));
-			HIP_CHECK(hipStreamSynchronize(c.stream));
+			HIP_CHECK(stream_wait(c.stream));
 		}
 	}
 	if (g[3] > GENE_CHR_CAP) g[5] = 1;
@@ -569,7 +569,7 @@ std::vector<dropest::u32> dropest_shard::order_rows(const std::vector<u32> &sel,
 			c.radix_sort(k, v, k_alt, v_alt, mm, o ^ a);
 			u32 *perm = reinterpret_cast<u32 *>(c.sort_stage.p);
 			HIP_CHECK(hipMemcpyAsync(perm, v, size_t(mm) * 4, hipMemcpyDeviceToHost, c.stream));
-			HIP_CHECK(hipStreamSynchronize(c.stream));
+			HIP_CHECK(stream_wait(c.stream));
 			for (u32 kk = 0; kk < mm; ++kk) out[kk] = sel[perm[kk]];
 			return out;
 		}
@@ -605,7 +605,7 @@ std::vector<dropest::u32> dropest_shard::order_rows(const std::vector<u32> &sel,
 		}
 		u32 *perm = reinterpret_cast<u32 *>(c.sort_stage.p);
 		HIP_CHECK(hipMemcpyAsync(perm, v, size_t(mm) * 4, hipMemcpyDeviceToHost, c.stream));
-		HIP_CHECK(hipStreamSynchronize(c.stream));
+		HIP_CHECK(stream_wait(c.stream));
 		for (u32 kk = 0; kk < mm; ++kk) out[kk] = sel[perm[kk]];
 		return out;
 	}
@@ -743,7 +743,7 @@ void dropest_shard::cb_merge() {
 		for (int k = 0; k < 4; ++k) { a.col_all[k] = col_all[k].p; a.o_col[k] = d_col[k].p; }
 		hipLaunchKernelGGL(import_gather_kernel, dim3(div_up(ni, 256)), dim3(256), 0, c.stream, a);
 		HIP_CHECK(hipGetLastError());
-		HIP_CHECK(hipStreamSynchronize(c.stream));
+		HIP_CHECK(stream_wait(c.stream));
 	}
 	const u32 *cols[4] = {d_col[0].p, d_col[1].p, d_col[2].p, d_col[3].p};
 	c.shard_merge_finish(local_id.size(), local_id.data(), l_excl.data(), l_merged.data(), l_reads.data(), l_umis.data(), move_src.size(),
@@ -869,7 +869,7 @@ void dropest_shard::step() {
 	build_global_table();
 	assemble_matrix(true);
 	assemble_matrix(false);
-	{ Phase ph(this, "matrix:wait"); HIP_CHECK(hipStreamSynchronize(c.stream)); tr->barrier(); }
+	{ Phase ph(this, "matrix:wait"); HIP_CHECK(stream_wait(c.stream)); tr->barrier(); }
 	c.collect_timings();
 }
 
@@ -916,6 +916,12 @@ void dropest_shard::install_umi_hooks() {
 		Phase ph(this, "umi:first_table");
 		dropest_ctx &c = *ctx;
 		if (n >= 0xFFFFFFF0ull) throw UnsupportedError("UMI table too large");
+		{   // the tables are all-gathered with ONE size: a shard that laid its UMI field out differently must not get this far
+			uint64_t mine_n = n;
+			std::vector<uint64_t> every(static_cast<size_t>(world));
+			tr->gather_host(&mine_n, 8, every.data());
+			for (uint64_t x : every) if (x != n) throw InvalidError("internal: the shards disagree on the size of the UMI first-occurrence table (" + std::to_string(x) + " vs " + std::to_string(n) + ")");
+		}
 		DevBuf<u64> mine, all;
 		mine.alloc(n); all.alloc(n * size_t(world));
 		hipLaunchKernelGGL(ordinals_kernel, dim3(u32((n + 255) / 256)), dim3(256), 0, c.stream, ordinal_map(), d_table, u32(n), mine.p);
@@ -941,7 +947,7 @@ void dropest_shard::install_umi_hooks() {
 		c.radix_sort(k, vv, ka, va, u32(n), mask);
 		hipLaunchKernelGGL(ranks_to_table_kernel, dim3(u32((n + 255) / 256)), dim3(256), 0, c.stream, k, vv, u32(n), d_table);
 		HIP_CHECK(hipGetLastError());
-		HIP_CHECK(hipStreamSynchronize(c.stream));   // the buffers above die with this scope
+		HIP_CHECK(stream_wait(c.stream));   // the buffers above die with this scope
 	};
 	ctx->hooks = h;
 }

@@ -9,31 +9,6 @@
 
 namespace {
 
-// Tools::edit_distance (Tools/UtilFunctions.cpp:32-65): banded dynamic programme with N wildcards, restated with its
-// band handling (cells outside the band keep what earlier columns left there; the lower band edge is set to the
-// column number) and its early exit, because values at and above max_ed decide which UMIs are skipped.
-unsigned banded_edit_distance(const std::string &s1, const std::string &s2, unsigned max_ed) {
-	const int n1 = int(s1.size()), n2 = int(s2.size());
-	std::vector<int> column(size_t(n1) + 1);
-	for (int i = 0; i <= n1; ++i) column[size_t(i)] = i;
-	for (int j = 1; j <= n2; ++j) {
-		const int lower = std::max(0, j - int(max_ed)), upper = std::min(n1, j + int(max_ed));
-		int lastdiag = column[size_t(lower)];
-		column[size_t(lower)] = j;
-		int min_ed = j;
-		for (int i = lower + 1; i <= upper; ++i) {
-			const int olddiag = column[size_t(i)];
-			const bool match = s1[size_t(i - 1)] == s2[size_t(j - 1)] || s1[size_t(i - 1)] == 'N' || s2[size_t(j - 1)] == 'N';
-			const int v = std::min(std::min(column[size_t(i)] + 1, column[size_t(i - 1)] + 1), lastdiag + int(!match));
-			min_ed = std::min(min_ed, v + std::abs(i - j));
-			column[size_t(i)] = v;
-			lastdiag = olddiag;
-		}
-		if (min_ed > int(max_ed)) return unsigned(min_ed);
-	}
-	return unsigned(column[size_t(n1)]);
-}
-
 struct DirUmi { std::string seq; size_t n_reads; };
 
 // MergeUMIsStrategyDirectional::find_target (:83-116)
@@ -161,7 +136,7 @@ void dropest_ctx::run_umi_merge_directional() {
 		timed("umi_directional:huge", double(total) * 20, [&] {
 			hipLaunchKernelGGL(directional_huge_kernel, dim3(n_huge), dim3(256), 0, stream, bg);
 		});
-		HIP_CHECK(hipStreamSynchronize(stream));   // off (host vector) and the scratch buffers outlive the launch
+		HIP_CHECK(stream_wait(stream));   // off (host vector) and the scratch buffers outlive the launch
 	}
 	if (n_big || n_huge) fetch(counts, scalars.p, 16);
 	const u32 n_host = counts[0], n_changed = counts[1];

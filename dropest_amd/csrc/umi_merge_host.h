@@ -121,7 +121,7 @@ void dropest_ctx::umi_gather_groups(const std::vector<u32> &groups, GatheredGrou
 	G.begin.assign(n_groups, 0);
 	HIP_CHECK(hipMemcpyAsync(G.size.data(), d_size.p, size_t(n_groups) * 4, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipMemcpyAsync(G.begin.data(), d_begin.p, size_t(n_groups) * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	uint64_t total = 0;
 	for (u32 g = 0; g < n_groups; ++g) { G.off[g] = u32(total); total += G.size[g]; }
 	if (total > 0xFFFFFFF0ull) throw UnsupportedError("too many molecules in the groups handled on the host");
@@ -144,7 +144,7 @@ void dropest_ctx::umi_gather_groups(const std::vector<u32> &groups, GatheredGrou
 		G.hfirst.resize(total);
 		HIP_CHECK(hipMemcpyAsync(G.hfirst.data(), s_first.p, total * 4, hipMemcpyDeviceToHost, stream));
 	}
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 }
 
 // Writes the host-decided contents of re-keyed groups back: patched (cell, gene) rows, recomputed cell sizes, and the
@@ -162,10 +162,10 @@ void dropest_ctx::umi_patch_groups(const std::vector<u32> &p_idx, const std::vec
 		hipLaunchKernelGGL(patch_cg_kernel, dim3(div_up(n_groups, 256)), dim3(256), 0, stream, d_idx.p, d_pa.p, d_pr.p, d_prr.p, n_groups,
 		                   cg_n_all.p, cg_n_req.p, cg_reads_req.p);
 		HIP_CHECK(hipGetLastError());
-		HIP_CHECK(hipStreamSynchronize(stream));   // the host vectors must outlive the copies
+		HIP_CHECK(stream_wait(stream));   // the host vectors must outlive the copies
 	}
 	reduce_cell_gene_to_cells();
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	refresh_real_rows();
 	for (auto &kv : umis_removed) real[real_at(kv.first)].row.total_umis -= kv.second;
 }
@@ -185,7 +185,7 @@ std::vector<dropest::u32> dropest_ctx::umi_first_positions(const std::vector<u64
 		                   d_q.p, nq, d_first.p);
 	});
 	HIP_CHECK(hipMemcpyAsync(f.data(), d_first.p, size_t(nq) * 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	return f;
 }
 
@@ -210,7 +210,7 @@ void dropest_ctx::run_umi_merge_simple() {
 	});
 	u32 n_groups = 0;
 	HIP_CHECK(hipMemcpyAsync(&n_groups, scalars.p, 4, hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(hipStreamSynchronize(stream));
+	HIP_CHECK(stream_wait(stream));
 	if (n_groups == 0 && !hooks) return;
 	std::vector<u32> groups(n_groups);
 	if (n_groups) HIP_CHECK(hipMemcpy(groups.data(), d_list.p, size_t(n_groups) * 4, hipMemcpyDeviceToHost));

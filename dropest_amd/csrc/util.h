@@ -6,6 +6,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <algorithm>
+#include <chrono>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -38,6 +42,138 @@ __host__ __device__ inline int bit_length(uint64_t x) { return x ? 64 - __builti
 
 constexpr int WAVE = 64;   // gfx950 wavefront
 
+// Waiting for a stream / an event WITHOUT going to sleep on an interrupt.  A pass has about a dozen points where the host needs
+// a count from the device before it can size the next launch; with the ROCm default (HSA_ENABLE_INTERRUPT=1) a blocked thread
+// takes 50-100 us -- on a loaded host milliseconds -- to run again after the signal, and the GPU idles meanwhile.  Polling the
+// completion signal (hipStreamQuery / hipEventQuery read it without blocking) is local to the calling thread and needs no
+// process-wide setting; after 50 ms of polling the wait falls back to the blocking call.  DROPEST_NO_SPIN_WAIT=1: always block.
+inline bool spin_wait_enabled() { static const bool on = getenv("DROPEST_NO_SPIN_WAIT") == nullptr; return on; }
+inline hipError_t stream_wait(hipStream_t st) {
+	if (spin_wait_enabled()) {
+		const auto t0 = std::chrono::steady_clock::now();
+		for (uint32_t it = 0;; ++it) {
+			const hipError_t e = hipStreamQuery(st);
+			if (e != hipErrorNotReady) return e;
+			if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+			__builtin_ia32_pause();
+		}
+	}
+	return hipStreamSynchronize(st);
+}
+inline hipError_t event_wait(hipEvent_t ev) {
+	if (spin_wait_enabled()) {
+		const auto t0 = std::chrono::steady_clock::now();
+		for (uint32_t it = 0;; ++it) {
+			const hipError_t e = hipEventQuery(ev);
+			if (e != hipErrorNotReady) return e;
+			if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+			__builtin_ia32_pause();
+		}
+	}
+	return hipEventSynchronize(ev);
+}
+
+// ---- debug allocator (tests and soak scripts; every switch is an environment variable read at allocation time) ----
+// Every DevBuf allocation is numbered and registered (pointer, bytes, ordinal, call site).  On top of that:
+//   DROPEST_POISON_ALLOC=<byte>   fill every fresh allocation with one byte (round 2)
+//   DROPEST_POISON_SEED=<s>       fill every allocation -- fresh or recycled -- with a pseudo-random pattern of (s, ordinal)
+//   DROPEST_DEBUG_POOL=1          released blocks are recycled WITHOUT being cleared (what a buffer pool does: a block then
+//                                 holds real stale data of an earlier stage, the adversary that found the round-2 bug)
+//   DROPEST_POISON_ZERO=a:b       allocations with ordinal in [a, b) are zero-filled instead (bisecting a dependence)
+//   DROPEST_ALLOC_TRACE=1         one stderr line per allocation: ordinal, bytes, file:line of the caller
+// dev_debug_poison_all(seed) overwrites every live, non-persistent registered block (the buffers ensure() keeps across
+// passes of a context): dropest_debug_poison_scratch in the C-ABI.  None of this is on the product path: with no variable set
+// the cost is one map insert per hipMalloc.
+static __global__ void poison_fill_kernel(uint32_t *p, size_t words, uint64_t seed) {
+	for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < words; i += size_t(gridDim.x) * blockDim.x)
+		p[i] = uint32_t(mix64(seed + i * 0x9E3779B97F4A7C15ull) >> 16);
+}
+struct DevRegistry {
+	struct Entry { size_t bytes; uint64_t ordinal; bool persistent; };
+	struct Block { void *p; size_t bytes; int device; };
+	std::mutex mu;
+	std::map<void *, Entry> live;
+	std::vector<Block> pool;
+	struct Site { uint64_t ordinal; size_t bytes; const char *file; int line; bool recycled; };
+	std::vector<Site> sites;   // DROPEST_ALLOC_TRACE: call site of every allocation, kept for dropest_debug_alloc_site
+	uint64_t next = 0;
+	static DevRegistry &get() { static DevRegistry r; return r; }
+	static void fill_random(void *p, size_t bytes, uint64_t seed) {
+		(void)hipDeviceSynchronize();
+		const size_t words = bytes / 4;
+		if (words) hipLaunchKernelGGL(poison_fill_kernel, dim3(unsigned(std::min<size_t>((words + 255) / 256, 4096))), dim3(256), 0, nullptr, static_cast<uint32_t *>(p), words, seed);
+		if (bytes & 3) (void)hipMemset(static_cast<char *>(p) + words * 4, int(seed & 0xFF), bytes & 3);
+		(void)hipDeviceSynchronize();
+	}
+	void *allocate(size_t bytes, const char *file, int line) {
+		void *p = nullptr;
+		bool recycled = false;
+		uint64_t ordinal;
+		int device = 0;
+		(void)hipGetDevice(&device);
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			ordinal = next++;
+			if (getenv("DROPEST_DEBUG_POOL")) {   // smallest block that fits and is not more than twice as large
+				size_t best = pool.size();
+				for (size_t i = 0; i < pool.size(); ++i)
+					if (pool[i].device == device && pool[i].bytes >= bytes && pool[i].bytes <= bytes * 2 + (size_t(1) << 16) && (best == pool.size() || pool[i].bytes < pool[best].bytes)) best = i;
+				if (best != pool.size()) { p = pool[best].p; pool[best] = pool.back(); pool.pop_back(); recycled = true; }
+			}
+		}
+		if (!p) {
+			hipError_t e = hipMalloc(&p, bytes);
+			if (e != hipSuccess) {   // give the recycled blocks back before giving up
+				trim_pool();
+				e = hipMalloc(&p, bytes);
+			}
+			if (e != hipSuccess) throw DeviceError(std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e) + " (" + file + ":" + std::to_string(line) + ")");
+		}
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			live[p] = Entry{bytes, ordinal, false};
+		}
+		if (const char *t = getenv("DROPEST_ALLOC_TRACE")) {
+			if (atoi(t) > 1) fprintf(stderr, "[alloc] #%llu %zu B %s %s:%d\n", (unsigned long long)ordinal, bytes, recycled ? "recycled" : "fresh", file, line);
+			std::lock_guard<std::mutex> lk(mu);
+			sites.push_back(Site{ordinal, bytes, file, line, recycled});
+		}
+		bool zero = false;
+		if (const char *z = getenv("DROPEST_POISON_ZERO")) {
+			unsigned long long a = 0, b = 0;
+			if (sscanf(z, "%llu:%llu", &a, &b) == 2 && ordinal >= a && ordinal < b) zero = true;
+		}
+		if (zero) { (void)hipDeviceSynchronize(); (void)hipMemset(p, 0, bytes); (void)hipDeviceSynchronize(); }
+		else if (const char *s = getenv("DROPEST_POISON_SEED")) fill_random(p, bytes, mix64(uint64_t(atoll(s)) * 0x100000001B3ull + ordinal));
+		else if (const char *b = getenv("DROPEST_POISON_ALLOC")) { if (!recycled) { (void)hipDeviceSynchronize(); (void)hipMemset(p, atoi(b), bytes); (void)hipDeviceSynchronize(); } }
+		return p;
+	}
+	void release(void *p) {
+		size_t bytes = 0;
+		int device = 0;
+		(void)hipGetDevice(&device);
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			auto it = live.find(p);
+			if (it != live.end()) { bytes = it->second.bytes; live.erase(it); }
+			if (bytes && getenv("DROPEST_DEBUG_POOL") && pool.size() < 512) { pool.push_back(Block{p, bytes, device}); return; }
+		}
+		(void)hipFree(p);
+	}
+	void trim_pool() {
+		std::vector<Block> drop;
+		{ std::lock_guard<std::mutex> lk(mu); drop.swap(pool); }
+		for (auto &b : drop) (void)hipFree(b.p);
+	}
+	void set_persistent(void *p) { std::lock_guard<std::mutex> lk(mu); auto it = live.find(p); if (it != live.end()) it->second.persistent = true; }
+	size_t poison_all(uint64_t seed) {   // every live block that is not marked persistent
+		std::vector<std::pair<void *, Entry>> todo;
+		{ std::lock_guard<std::mutex> lk(mu); for (auto &kv : live) if (!kv.second.persistent) todo.push_back(kv); }
+		for (auto &kv : todo) fill_random(kv.first, kv.second.bytes, mix64(seed * 0x100000001B3ull + kv.second.ordinal));
+		return todo.size();
+	}
+};
+
 // RAII device buffer
 template <typename T>
 struct DevBuf {
@@ -49,22 +185,33 @@ struct DevBuf {
 	DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
 	DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
 	~DevBuf() { release(); }
-	void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
-	void alloc(size_t count) {
+	void release() { if (p) { DevRegistry::get().release(p); p = nullptr; n = 0; } }
+	void alloc(size_t count, const char *file = __builtin_FILE(), int line = __builtin_LINE()) {
 		release();
 		if (count == 0) count = 1;
-		HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+		p = static_cast<T *>(DevRegistry::get().allocate(count * sizeof(T), file, line));
 		n = count;
-		// DROPEST_POISON_ALLOC=<byte>: fresh device memory reads as zero pages in practice; tests run with a poison byte to find
-		// code that leans on that
-		static const int poison = [] { const char *e = getenv("DROPEST_POISON_ALLOC"); return e ? atoi(e) : -1; }();
-		if (poison >= 0) { (void)hipDeviceSynchronize(); (void)hipMemset(p, poison, count * sizeof(T)); (void)hipDeviceSynchronize(); }
 	}
-	void ensure(size_t count) { if (count > n) alloc(count); }
+	void ensure(size_t count, const char *file = __builtin_FILE(), int line = __builtin_LINE()) { if (count > n) alloc(count, file, line); }
+	// inputs that outlive a pass (reads, whitelists, qualities): dev_debug_poison_all leaves them alone
+	void mark_persistent() { if (p) DevRegistry::get().set_persistent(p); }
 	size_t bytes() const { return n * sizeof(T); }
 };
 
 // RAII pinned host buffer (results land here so that D2H runs at PCIe rate and callers get zero-copy views)
+struct PinnedRegistry {
+	std::mutex mu;
+	std::map<void *, size_t> live;
+	static PinnedRegistry &get() { static PinnedRegistry r; return r; }
+	size_t poison_all(uint64_t seed) {   // debug: staging buffers kept across passes hold what the previous pass left
+		std::lock_guard<std::mutex> lk(mu);
+		for (auto &kv : live) {
+			uint32_t *w = static_cast<uint32_t *>(kv.first);
+			for (size_t i = 0; i < kv.second / 4; ++i) w[i] = uint32_t(mix64(seed + i) >> 16);
+		}
+		return live.size();
+	}
+};
 template <typename T>
 struct PinnedBuf {
 	T *p = nullptr;
@@ -73,13 +220,18 @@ struct PinnedBuf {
 	PinnedBuf(const PinnedBuf &) = delete;
 	PinnedBuf &operator=(const PinnedBuf &) = delete;
 	~PinnedBuf() { release(); }
-	void release() { if (p) { (void)hipHostFree(p); p = nullptr; n = 0; } }
+	void release() {
+		if (!p) return;
+		{ auto &r = PinnedRegistry::get(); std::lock_guard<std::mutex> lk(r.mu); r.live.erase(p); }
+		(void)hipHostFree(p); p = nullptr; n = 0;
+	}
 	void ensure(size_t count) {
 		if (count <= n) return;
 		release();
 		size_t cap = count + count / 8 + 16;
 		HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), cap * sizeof(T), hipHostMallocDefault));
 		n = cap;
+		{ auto &r = PinnedRegistry::get(); std::lock_guard<std::mutex> lk(r.mu); r.live[p] = cap * sizeof(T); }
 	}
 };
 

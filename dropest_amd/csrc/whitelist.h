@@ -75,9 +75,8 @@ struct Whitelist {
 				if (s.find('N') != std::string::npos) throw UnsupportedError("whitelist entries containing N are not supported");
 			}
 		}
-		if (parts.size() > size_t(WL_MAX_PARTS))
-			throw UnsupportedError("this build handles whitelists of up to " + std::to_string(WL_MAX_PARTS) + " parts (got " +
-			                       std::to_string(parts.size()) + ")");
+		// (more than WL_MAX_PARTS parts: the neighbour search runs on the host, merge_host.h search_merge_candidates_host -- the
+		// reference has no limit, ConstLengthBarcodesParser.cpp:50-68)
 		for (auto &p : parts) if (p.size() > 65535) throw UnsupportedError("whitelist part with more than 65535 entries");
 		loaded = true;
 	}

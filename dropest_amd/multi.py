@@ -143,7 +143,7 @@ class ShardedRun:
     """One process per GPU: rank `rank` of `world`, its GPU = local_rank.  The stream's ordinal range
     [rank * reads_per_gpu, (rank + 1) * reads_per_gpu) is generated on the device once and stays resident."""
 
-    def __init__(self, stream, rank, world, local_rank, reads_per_gpu, cfg, dist=None):
+    def __init__(self, stream, rank, world, local_rank, reads_per_gpu, cfg, dist=None, **extra_cfg):
         import torch
         self.rank, self.world = rank, world
         L = capi.lib()
@@ -158,7 +158,7 @@ class ShardedRun:
                 t = t.to(torch.device("cuda", local_rank))
             dist.broadcast(t, src=0)
             uid = t.cpu().numpy().copy()
-        c, self._keep = capi.make_cfg(device=local_rank, **cfg_kwargs(cfg))
+        c, self._keep = capi.make_cfg(device=local_rank, **dict(cfg_kwargs(cfg), **extra_cfg))
         h = C.c_void_p()
         rc = L.dropest_shard_create(C.byref(c), rank, world, uid.ctypes.data, C.byref(h))
         if rc != 0:
@@ -166,6 +166,13 @@ class ShardedRun:
         self.shard = Shard(h.value)
         self.R = int(reads_per_gpu)
         self.shard.set_reads(stream.generate_device(local_rank, first=rank * self.R, n=self.R), rank * self.R)
+
+    def close(self):
+        reads = self.shard._reads
+        self.shard.close()
+        if reads is not None:
+            reads.free()
+            self.shard._reads = None
 
     @property
     def merge_pairs(self):

@@ -216,6 +216,19 @@ dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int read
  * reads_output) only waits for it; any call that changes the container in between discards the prefetch. */
 dropest_status dropest_prefetch_raw_matrix(dropest_ctx *ctx, int reads_output);
 
+/* The NARROW form of the same CSC matrices: 16-bit row indices and 16-bit values -- 4 bytes per entry over PCIe instead of 8,
+ * which is what bounds a pass once the kernels are done (the two matrices of C2 are 0.29 GB as 2 x u32).  ResultsPrinter turns
+ * every entry into a double anyway (Eigen triplets -> dgCMatrix, ResultsPrinter.cpp:433-442), so its writers read this form
+ * directly.  Lossless: a value beyond 65534 is stored as 0xFFFF and listed exactly in (overflow_pos[k] = entry index,
+ * overflow_val[k]), k < n_overflow, ascending by position.  Available when every gene id is below 65536
+ * (dropest_narrow_matrix_possible); DROPEST_ERR_UNSUPPORTED otherwise, and the 32-bit form always works.  Pointers refer
+ * to context-owned pinned memory, valid until the next matrix call for the same `filtered`. */
+dropest_status dropest_narrow_matrix_possible(dropest_ctx *ctx, int *possible);
+dropest_status dropest_count_matrix_csc_narrow(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *ncols, uint64_t *nnz,
+                                               const uint32_t **colptr, const uint16_t **rowidx, const uint16_t **values,
+                                               uint64_t *n_overflow, const uint32_t **overflow_pos, const uint32_t **overflow_val);
+dropest_status dropest_prefetch_raw_matrix_narrow(dropest_ctx *ctx, int reads_output);
+
 /* ResultsPrinter::get_count_matrix_filtered(container, query_marks) (ResultsPrinter.cpp:333-361) for a mark query other
  * than the container's own -- what ResultsPrinter::save_intron_exon_matrices asks for (-V: "e", "i", "BA",
  * ResultsPrinter.cpp:455-474).  Columns = the filtered cells in their order, zero entries dropped; same CSC
@@ -378,6 +391,17 @@ dropest_status dropest_set_profiling(dropest_ctx *ctx, int enabled);   /* HIP ev
  * separated by '|' -- (NULL / "" = all launches and the host stages).  Two events per launch cost ~0.5 ms per C2 pass when every kernel is timed; bench.py times only the
  * dominant kernel inside its timed region and collects the full table in a separate pass. */
 dropest_status dropest_set_profiling_filter(dropest_ctx *ctx, const char *name_prefix);
+/* Debug aids of the device allocator (csrc/util.h; not on the product path).  dropest_debug_poison_scratch overwrites every
+ * live device buffer of the process that is not an input (reads, whitelists, qualities stay) and every pinned staging buffer
+ * with a pseudo-random pattern of `seed` -- between two passes of one context this turns "a buffer kept across passes still
+ * holds the previous pass" into "it holds garbage"; a pass must give the same results either way (tests/test_gpu_reuse.py).
+ * Only meaningful while no pass is in flight.  dropest_debug_trim_pool frees the blocks DROPEST_DEBUG_POOL=1 recycles. */
+dropest_status dropest_debug_poison_scratch(uint64_t seed, uint64_t *n_blocks);
+dropest_status dropest_debug_trim_pool(void);
+/* Allocations are numbered; with DROPEST_ALLOC_TRACE=1 the call site of each is kept: `next ordinal` brackets a pass, and
+ * DROPEST_POISON_ZERO=a:b zero-fills the allocations numbered [a, b) -- how scripts/hunt_stale.py bisects a dependence. */
+dropest_status dropest_debug_alloc_ordinal(uint64_t *next_ordinal);
+dropest_status dropest_debug_alloc_site(uint64_t ordinal, char *out, uint64_t out_bytes);
 /* The HIP stream all kernels of this context are launched on (hipStream_t). */
 void *dropest_stream(dropest_ctx *ctx);
 

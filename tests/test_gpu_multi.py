@@ -182,6 +182,24 @@ def test_directional_umi_correction_across_shards(world, n_rate):
     # (the single context itself is pinned on the oracle for -u: test_gpu_parity.py::test_directional_*)
 
 
+@pytest.mark.parametrize("n_rate", [0.0, 3e-2])
+def test_directional_with_more_shards_than_barcodes(n_rate):
+    """-u over 8 shards when only 3 barcodes exist: most shards own no read at all, yet take part in the all-gather of the UMI
+    first-occurrence table -- with the key fields the shards agreed on, not a stale or empty layout."""
+    s = SynthStream(n_reads=20_000, n_cells=3, n_genes=60, umi_len=6, reads_per_molecule=3, permille_neighbour=0, permille_ambient=0)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    assert len(np.unique(cb)) <= 3
+    side = ()
+    if n_rate:
+        umi, side = inject_n(umi, gene, n_rate, 5, 6)
+    kw = dict(cfg_kwargs({"min_before": 2, "min_after": 3}), umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL, max_umi_merge_edit_distance=1,
+              umi_merge_multiplier=2.0)
+    got = run_group(8, (cb, umi, gene, aux), kw, side)
+    c = single((cb, umi, gene, aux), kw, side)
+    check(got, c)
+    assert len(c.filtered_cells()) >= 2
+
+
 def test_barcodes_of_several_lengths_and_max_cells():
     """compare_cells orders barcode STRINGS (CellsDataContainer.cpp:329-344): with barcodes of several lengths the packed codes
     do not order like the strings, ties on the sizes must still come out as in one container; -C keeps the largest cells."""

@@ -1,0 +1,88 @@
+"""The narrow CSC form (dropest_count_matrix_csc_narrow: 16-bit rows and values + an exact overflow list) must widen to exactly
+the 32-bit matrices of dropest_count_matrix_csc -- what ResultsPrinter::create_matrix builds (ResultsPrinter.cpp:433-442)."""
+import numpy as np
+import pytest
+
+from dropest_amd import capi
+from dropest_amd.synth import SynthStream
+
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def both_forms(c, reads_output=False, prefetch=False):
+    for filt in (True, False):
+        if prefetch and not filt:
+            c.prefetch_raw_matrix(reads_output, narrow=True)
+        n = c.count_matrix_csc_narrow(filtered=filt, reads_output=reads_output)
+        got = [x.copy() for x in capi.Context.widen(n)]
+        n_ovf = len(n[3])
+        want = [x.copy() for x in c.count_matrix_csc(filtered=filt, reads_output=reads_output)]
+        for g, w in zip(got, want):
+            assert g.dtype == w.dtype and np.array_equal(g, w), (filt, reads_output)
+        yield filt, n_ovf, want
+
+
+@pytest.mark.parametrize("reads_output", [False, True])
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_narrow_equals_wide_on_a_c2_shape(reads_output, prefetch):
+    s = SynthStream(n_reads=3_000_000, n_cells=300, n_genes=20000)
+    c = capi.Context(min_genes_before_merge=20, min_genes_after_merge=100)
+    c.push_reads(*parity.canonical_stream(*s.generate_host()))
+    c.set_initialized(); c.merge_and_filter()
+    assert c.narrow_matrix_possible()
+    seen = list(both_forms(c, reads_output, prefetch))
+    assert all(len(w[1]) > 100000 for _, _, w in seen)
+    # a wide call after a narrow prefetch, and the other way round, still give the right form
+    c.prefetch_raw_matrix(reads_output, narrow=True)
+    wide = [x.copy() for x in c.count_matrix_csc(filtered=False, reads_output=reads_output)]
+    c.prefetch_raw_matrix(reads_output, narrow=False)
+    nar = capi.Context.widen(c.count_matrix_csc_narrow(filtered=False, reads_output=reads_output))
+    assert all(np.array_equal(a, b) for a, b in zip(wide, nar))
+    c.close()
+
+
+def test_values_beyond_16_bits_go_through_the_overflow_list():
+    """One cell whose gene 0 has 70 000 molecules (one read each) and gene 1 has one molecule of 66 000 reads: both matrices, UMI
+    counts and read counts, carry entries > 65534; a third gene stays small."""
+    P = capi.pack_seq
+    rng = np.random.default_rng(5)
+    n0 = 70_000
+    umis0 = np.arange(n0, dtype=np.uint64) | np.uint64(1 << 20)           # 70 000 distinct 10-base codes (sentinel bit 20)
+    cb = np.full(n0 + 66_000 + 3, P("ACGTACGTACGTACGT"), np.uint64)
+    umi = np.concatenate([umis0, np.full(66_000, P("TTTTTTTTTT"), np.uint64), np.array([P("AAAAAAAAAC"), P("AAAAAAAAAG"), P("AAAAAAAAAT")], np.uint64)])
+    gene = np.concatenate([np.zeros(n0, np.uint32), np.ones(66_000, np.uint32), np.full(3, 2, np.uint32)])
+    aux = np.full(len(cb), 0 | (2 << 16), np.uint32)
+    perm = rng.permutation(len(cb))
+    cb, umi, gene, aux = parity.canonical_stream(cb[perm], umi[perm], gene[perm], aux[perm])
+    c = capi.Context(min_genes_before_merge=1, min_genes_after_merge=1)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_initialized(); c.merge_and_filter()
+    for reads_output, n_over in ((False, 1), (True, 2)):
+        for filt, n_ovf, want in both_forms(c, reads_output):
+            assert n_ovf == n_over, (reads_output, filt, n_ovf)
+            assert int(want[2].max()) == (70_000 if not reads_output else 70_000)
+    c.close()
+
+
+def test_gene_ids_beyond_16_bits_refuse_the_narrow_form():
+    cb = np.array([capi.pack_seq("ACGTACGTACGTACGT")] * 2, np.uint64)
+    umi = np.array([capi.pack_seq("ACGTACGTAC"), capi.pack_seq("ACGTACGTAA")], np.uint64)
+    gene = np.array([3, 70_000], np.uint32); aux = np.array([2 << 16, 2 << 16], np.uint32)
+    c = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_initialized(); c.merge_and_filter()
+    assert not c.narrow_matrix_possible()
+    with pytest.raises(capi.DropestError):
+        c.count_matrix_csc_narrow(filtered=True)
+    assert len(c.count_matrix_csc(filtered=True)[1]) == 2
+    c.close()
+
+
+def test_empty_container_narrow():
+    e = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
+    e.set_initialized(); e.merge_and_filter()
+    n = e.count_matrix_csc_narrow(filtered=True)
+    assert len(n[1]) == 0 and len(n[3]) == 0
+    e.close()

@@ -127,3 +127,16 @@ def test_splitter_equals_lsd_at_baseline_size(monkeypatch, shape):
         digests[mode] = _digest(c)
     assert digests["lsd"] == digests["splitter"]
     dev.free()
+
+
+def test_a_bucket_left_unsorted_is_caught_and_the_lsd_sort_takes_over(splitter, monkeypatch):
+    """DROPEST_SS_DEBUG=2 makes ss_local skip its sort passes: every bucket reaches the head detection unsorted.  The in-kernel
+    order check (one compare per record, every pass) must raise the device flag, the host must rebuild the keys and hand the pass
+    to the LSD sort -- results equal the oracle's, and the violation is counted.  (What the check guards: the one-atomic ranking
+    of ss_local leans on the LDS applying same-address lanes of one instruction in lane order.)"""
+    monkeypatch.setenv("DROPEST_SS_DEBUG", "2")
+    o, c = tp._both(dict(n_cells=60, n_genes=3000), 300_000, 10, 30)
+    assert c.sort_layout()["sort"] == "lsd"
+    monkeypatch.delenv("DROPEST_SS_DEBUG")
+    o, c = tp._both(dict(n_cells=60, n_genes=3000), 300_000, 10, 30)
+    assert c.sort_layout()["sort"] == "splitter"
