@@ -110,6 +110,8 @@ def lib():
         "dropest_merge_target": (C.c_int, [vp, C.c_uint64, P(C.c_int64)]),
         "dropest_exclude_cell": (C.c_int, [vp, C.c_uint64]), "dropest_merge_cells": (C.c_int, [vp, C.c_uint64, C.c_uint64]),
         "dropest_merge_umis": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint64, vp, vp]),
+        "dropest_add_umi_to_cell": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, vp, C.c_uint32]),
+        "dropest_umi_first_seen": (C.c_int, [vp, u64p, vp]),
         "dropest_set_umi_qualities": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64]),
         "dropest_umi_quality_length": (C.c_int, [vp, P(C.c_uint32)]),
         "dropest_cell_molecule_qualities": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp]),
@@ -121,6 +123,7 @@ def lib():
                                                  C.c_uint64]),
         "dropest_partition_scratch_bytes": (C.c_int, [C.c_uint64, u64p]),
         "dropest_clear_reads": (C.c_int, [vp]),
+        "dropest_resident_reads": (C.c_int, [vp, P(vp), P(vp), P(vp), P(vp), u64p]),
         "dropest_count_matrix_device": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp)]),
         "dropest_cell_first_reads_device": (C.c_int, [vp, u64p, P(vp)]),
         "dropest_assemble_columns": (C.c_int, [C.c_int, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]),
@@ -211,7 +214,7 @@ EXPORTED_SYMBOLS = [
     "dropest_shard_unique_id", "dropest_shard_create", "dropest_shard_group_create", "dropest_shard_destroy", "dropest_shard_ctx",
     "dropest_shard_set_reads_device", "dropest_shard_push_reads", "dropest_reserve_reads", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix",
     "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option", "dropest_plan_columns",
-    "dropest_key_width", "dropest_ctx_split", "dropest_prefetch_raw_matrix_narrow", "dropest_narrow_matrix_possible", "dropest_count_matrix_csc_narrow",
+    "dropest_key_width", "dropest_ctx_split", "dropest_shard_matrix_narrow", "dropest_add_umi_to_cell", "dropest_umi_first_seen", "dropest_resident_reads", "dropest_prefetch_raw_matrix_narrow", "dropest_narrow_matrix_possible", "dropest_count_matrix_csc_narrow",
     "dropest_debug_poison_scratch", "dropest_debug_trim_pool", "dropest_debug_alloc_ordinal", "dropest_debug_alloc_site",
 ]
 
@@ -586,6 +589,19 @@ class Context:
         """pairs: [(source code, target code)] applied in order (Cell::merge_umis walks the caller's map)."""
         s = np.array([p[0] for p in pairs], np.uint64); t = np.array([p[1] for p in pairs], np.uint64)
         self._chk(self.L.dropest_merge_umis(self.h, cell, gene, len(pairs), s.ctypes.data, t.ctypes.data))
+
+    def add_umi_to_cell(self, cell, gene, umi_code, mark, quality=b""):
+        q = np.frombuffer(bytes(quality), np.uint8)
+        self._chk(self.L.dropest_add_umi_to_cell(self.h, int(cell), int(gene), int(umi_code), int(mark), q.ctypes.data if len(q) else None, len(q)))
+
+    def umi_first_seen(self):
+        """UMI codes in umi_indexer() order."""
+        n = C.c_uint64()
+        self._chk(self.L.dropest_umi_first_seen(self.h, C.byref(n), None))
+        out = np.zeros(n.value, np.uint64)
+        if n.value:
+            self._chk(self.L.dropest_umi_first_seen(self.h, C.byref(n), out.ctypes.data))
+        return out
 
     def set_umi_qualities(self, qual):
         """qual: uint8 array [n_reads, quality_length] (phred+33 characters), read order."""

@@ -285,6 +285,8 @@ struct dropest_ctx {
 	dropest::Whitelist wl;
 	dropest::DevBuf<dropest::WlEntry> d_wl[dropest::WL_MAX_PARTS];
 	dropest::DevBuf<u64> d_wl_code[dropest::WL_MAX_PARTS];            // packed copies of the whitelist parts (k_merge.h: wl_edit_distance_code)
+	dropest::DevBuf<dropest::WlTabRow> d_wl_tab[dropest::WL_MAX_PARTS];   // neighbour tables: one row per possible value of a part (k_merge.h)
+	bool wl_tab_ok = false;
 	dropest::DevBuf<u64> mol_key2;           // re-keyed molecule table (swapped in after a merge)
 	dropest::DevBuf<u32> mol_reads2, mol_mark2, remap;
 	std::unordered_map<u32, u32> reassign;   // merged cell -> final target (MergeStrategyBase cb_reassign_targets, sparse)
@@ -429,6 +431,8 @@ struct dropest_ctx {
 	void mutate_exclude_cell(u32 cell);
 	void mutate_merge_cells(u32 src, u32 tgt);
 	void mutate_merge_umis(u32 cell, u32 gene, uint64_t n, const uint64_t *src, const uint64_t *tgt);
+	void mutate_add_umi_to_cell(u32 cell, u32 gene, uint64_t umi_code, u32 mark, const uint8_t *quality, u32 quality_length);
+	u32 n_qsum_rows = 0;                        // rows of mol_qsum (molecules at initialisation + reads added by add_umi_to_cell)
 	void emit_matrix_levels(u32 query_mask, bool reads_output);   // get_count_matrix_filtered(container, query)
 	// sharded runs (merge_shard.h): ingest / merge phases with collectives between them
 	struct ShardMerge;

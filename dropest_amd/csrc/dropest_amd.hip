@@ -994,7 +994,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 			offset[w] = m64; m64 += count[w]; any_all |= any[w];
 			if (count[w]) { if (bl_all < 0) bl_all = bl[w]; device_sort &= uniform[w] && bl[w] == bl_all; }
 		}
-		if (m64 >= device_min && m64 < 0xFFFFFFF0ull && device_sort && !(any_all & ESCAPE_BIT)) {
+		if (m64 >= device_min && m64 < 0x50000000ull && device_sort && !(any_all & ESCAPE_BIT)) {
 			const u32 m = u32(m64);
 			st1.reset();
 			auto st2 = std::make_unique<HostStage>(this, "sort_filtered:fill");
@@ -1027,7 +1027,9 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 			st2.reset();
 			auto st3 = std::make_unique<HostStage>(this, "sort_filtered:device");
 			{ HostStage sx(this, "sort_filtered:device:h2d");
-			HIP_CHECK(hipMemcpyAsync(sort_cols.p, sort_stage.p, size_t(m) * 3 * 8, hipMemcpyHostToDevice, stream)); }
+			// read from the pinned buffer by a kernel, not by the copy engine (busy with cm_raw's prefetch for tens of milliseconds at C3 size)
+			hipLaunchKernelGGL(load_u64_from_host_kernel, dim3(std::min<u32>(div_up(m * 3u, 256), 4096u)), dim3(256), 0, stream, sort_stage.p, m * 3u, sort_cols.p);
+			HIP_CHECK(hipGetLastError()); }
 			auto sx2 = std::make_unique<HostStage>(this, "sort_filtered:device:sorts");
 			const u64 *d_code = sort_cols.p, *d_umis = sort_cols.p + m, *d_sizes = sort_cols.p + 2 * size_t(m);
 			u64 *k = keys_a.p, *k_alt = keys_b.p;
@@ -1044,7 +1046,9 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 			sx2.reset();
 			u32 *perm = reinterpret_cast<u32 *>(sort_stage.p);              // the staging buffer is free again (stream order)
 			HostStage sx3(this, "sort_filtered:device:d2h");
-			HIP_CHECK(hipMemcpyAsync(perm, v, size_t(m) * 4, hipMemcpyDeviceToHost, stream));
+			// written by a kernel, not by the copy engine: cm_raw's prefetch may hold that for tens of milliseconds
+			hipLaunchKernelGGL(store_u32_to_host_kernel, dim3(std::min<u32>(div_up(m, 256), 2048u)), dim3(256), 0, stream, v, m, perm);
+			HIP_CHECK(hipGetLastError());
 			HIP_CHECK(stream_wait(stream));
 			st3.reset();
 			HostStage st4(this, "sort_filtered:gather");
@@ -1191,10 +1195,24 @@ void dropest_ctx::matrix_columns(bool filtered_m, std::vector<u32> &col_cell, st
 			col_cell.push_back(h.id); colptr.push_back(u32(nnz)); nnz += h.row.requested_genes;
 		}
 	} else {
-		for (const HostCell &h : real) {
-			if (h.merged || h.excluded || h.row.n_genes < min_before) continue;
-			col_cell.push_back(h.id); colptr.push_back(u32(nnz)); nnz += h.row.n_genes;
-		}
+		// every real cell in cell-id order: millions of rows at C3 size -- counted and filled over contiguous ranges on a few threads
+		constexpr unsigned W = 8;
+		size_t cols[W] = {0}; uint64_t sums[W] = {0};
+		auto is_col = [&](const HostCell &h) { return !(h.merged || h.excluded || h.row.n_genes < min_before); };
+		const unsigned workers = parallel_ranges(real.size(), [&](size_t b, size_t e, unsigned w) {
+			size_t c = 0; uint64_t s = 0;
+			for (size_t i = b; i < e; ++i) if (is_col(real[i])) { ++c; s += real[i].row.n_genes; }
+			cols[w] = c; sums[w] = s;
+		}, 100000, W);
+		size_t col0[W + 1] = {0}; uint64_t nnz0[W + 1] = {0};
+		for (unsigned w = 0; w < workers; ++w) { col0[w + 1] = col0[w] + cols[w]; nnz0[w + 1] = nnz0[w] + sums[w]; }
+		nnz = nnz0[workers];
+		if (nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
+		col_cell.resize(col0[workers]); colptr.resize(col0[workers]);
+		parallel_ranges(real.size(), [&](size_t b, size_t e, unsigned w) {   // same n and limits: the same ranges
+			size_t at = col0[w]; uint64_t run = nnz0[w];
+			for (size_t i = b; i < e; ++i) if (is_col(real[i])) { col_cell[at] = real[i].id; colptr[at] = u32(run); run += real[i].row.n_genes; ++at; }
+		}, 100000, W);
 	}
 	if (nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
 	colptr.push_back(u32(nnz));
@@ -1297,19 +1315,15 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, 
 	MatrixResult &M = mat[filtered_m ? 0 : 1];
 	std::vector<u32> col_cell;
 	uint64_t nnz = 0;
-	if (!filtered_m && raw_pf.valid) {
-		// a prefetched cm_raw is used if it is what this call would produce: same columns, same sizes, same value kind and form
-		std::vector<u32> colptr;
-		matrix_columns(false, col_cell, colptr, nnz);
-		if (to_host && raw_pf.reads_output == reads_output && raw_pf.narrow == narrow && col_cell == raw_pf.col_cell && colptr == M.colptr) {
-			if (raw_pf.in_flight) { HIP_CHECK(event_wait(ev_raw)); raw_pf.in_flight = false; matrix_finish_overflow(M, stream2); }
-			return;
-		}
-		invalidate_prefetch();
-		M.colptr = colptr;
-	} else {
-		matrix_columns(filtered_m, col_cell, M.colptr, nnz);
+	if (!filtered_m && raw_pf.valid && to_host && raw_pf.reads_output == reads_output && raw_pf.narrow == narrow) {
+		// A prefetched cm_raw of the same value kind and form IS what this call would produce: whatever changes the container
+		// (merges, mutators, a new pass) discards the prefetch on its way in (invalidate_prefetch), so a valid one is current.
+		// (Round 2 rebuilt and compared the column lists here: two walks over 2.5 M cells, 10 ms of a C3 pass.)
+		if (raw_pf.in_flight) { HIP_CHECK(event_wait(ev_raw)); raw_pf.in_flight = false; matrix_finish_overflow(M, stream2); }
+		return;
 	}
+	if (!filtered_m) invalidate_prefetch();
+	matrix_columns(filtered_m, col_cell, M.colptr, nnz);
 	M.nnz = nnz; M.ncols = col_cell.size(); M.narrow = narrow; M.n_ovf = 0;
 	if (nnz == 0) return;
 	const u32 ncols = u32(col_cell.size());
@@ -2121,6 +2135,69 @@ dropest_status dropest_umi_distribution(dropest_ctx *ctx, uint64_t *n, uint64_t 
 	});
 }
 
+// CellsDataContainer::umi_indexer() (CellsDataContainer.h:118): the UMIs in index order = order of first appearance among the
+// gene-bearing reads (Gene::add_umi -> StringIndexer::add, Gene.cpp:19), followed by the UMIs only merges brought in (random
+// fills of N-UMIs, explicit merge_umis targets: Gene.cpp:47) -- those in (cell id, gene id, UMI code) order of their groups.
+dropest_status dropest_umi_first_seen(dropest_ctx *ctx, uint64_t *n_out, uint64_t *umi_codes) {
+	return guarded([&] {
+		need_init(ctx);
+		if (!n_out) throw InvalidError("null argument");
+		*n_out = 0;
+		dropest_ctx &c = *ctx;
+		std::vector<u64> codes;
+		if (c.n_reads && c.ingest.gene_max_plus1) {
+			const u32 n = u32(c.n_reads);
+			// distinct UMI codes are bounded by the UMI field of the key layout
+			const uint64_t field = c.umi_clean_bits >= 40 ? c.n_reads : std::min<uint64_t>(c.n_reads, (uint64_t(1) << (c.umi_clean_bits + (c.umi_sentinel_stripped ? 0 : 1))) + c.ingest.umi_escape_max_plus1);
+			uint64_t cap = 1024; while (cap < field * 2) cap <<= 1;
+			for (int attempt = 0;; ++attempt) {
+				if (cap > (1ull << 32)) throw UnsupportedError("UMI table would exceed 2^32 slots");
+				DevBuf<CbSlot> slots; slots.alloc(cap);
+				CbTable t{slots.p, cap - 1};
+				HIP_CHECK(hipMemsetAsync(slots.p, 0, cap * sizeof(CbSlot), c.stream));
+				c.scalars.ensure(16);
+				HIP_CHECK(hipMemsetAsync(c.scalars.p, 0, 8, c.stream));
+				hipLaunchKernelGGL(umi_insert_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, c.stream, c.d_umi, c.d_gene, n, t, c.scalars.p + 1);
+				c.keys_a.ensure(std::max<size_t>(n, 1)); c.keys_b.ensure(std::max<size_t>(n, 1)); c.vals_a.ensure(1); c.vals_b.ensure(1);
+				hipLaunchKernelGGL(cb_compact_slots_kernel, dim3(u32(std::min<uint64_t>((cap + 4095) / 4096, 4096))), dim3(256), 0, c.stream, t, c.keys_a.p, c.scalars.p);
+				HIP_CHECK(hipGetLastError());
+				u32 head[2] = {0, 0};
+				c.fetch(head, c.scalars.p, 8);
+				if (head[1]) { if (attempt >= 4) throw DeviceError("UMI table overflow"); cap <<= 2; continue; }
+				const u32 distinct = head[0];
+				u64 *k = c.keys_a.p, *k_alt = c.keys_b.p;
+				u32 *v = c.vals_a.p, *v_alt = c.vals_b.p;
+				const int ord_bits = std::max(1, bit_length(uint64_t(n ? n - 1 : 0)));
+				c.radix_sort(k, v, k_alt, v_alt, distinct, ((1ull << ord_bits) - 1ull) << 32, 0, "umi_index:");
+				DevBuf<u64> out; out.alloc(std::max<u32>(distinct, 1));
+				hipLaunchKernelGGL(gather_slot_keys_kernel, dim3(div_up(std::max<u32>(distinct, 1), 256)), dim3(256), 0, c.stream, k, distinct, t, out.p);
+				HIP_CHECK(hipGetLastError());
+				codes.resize(distinct);
+				c.fetch(codes.data(), out.p, size_t(distinct) * 8);
+				break;
+			}
+		}
+		if (!c.umi_overrides.empty()) {   // UMIs that exist only because a merge created them
+			std::unordered_set<u64> known(codes.begin(), codes.end());
+			std::vector<u64> groups;
+			for (auto const &kv : c.umi_overrides) groups.push_back(kv.first);
+			std::sort(groups.begin(), groups.end());
+			for (u64 g : groups) for (const UmiOverride &o : c.umi_overrides.at(g)) if (known.insert(o.umi).second) codes.push_back(o.umi);
+		}
+		*n_out = codes.size();
+		if (umi_codes) std::copy(codes.begin(), codes.end(), umi_codes);
+	});
+}
+
+dropest_status dropest_add_umi_to_cell(dropest_ctx *ctx, uint64_t cell, uint32_t gene, uint64_t umi_code, uint32_t mark,
+                                       const uint8_t *umi_quality, uint32_t quality_length) {
+	return guarded([&] {
+		need_init(ctx);
+		if (cell >= ctx->n_cells) throw RangeError("cell index out of range");
+		ctx->mutate_add_umi_to_cell(u32(cell), gene, umi_code, mark, umi_quality, quality_length);
+	});
+}
+
 dropest_status dropest_collisions_adjusted_sizes(int device, const double *umi_probabilities, uint64_t n, uint64_t max_expression,
                                                  uint64_t *adjusted_sizes) {
 	return guarded([&] {
@@ -2266,6 +2343,25 @@ dropest_status dropest_dev_copy_device(int device, void *d_dst, const void *d_sr
 	return guarded([&] {
 		HIP_CHECK(hipSetDevice(device));
 		if (bytes) HIP_CHECK(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+	});
+}
+
+// The device arrays of the reads pushed so far (dropest_push_reads), for a second context that looks at the same reads in
+// place (dropest_push_reads_device(..., adopt = 1)): the facade's view of a container that is not initialised yet.  Valid
+// until the next push.
+dropest_status dropest_resident_reads(dropest_ctx *ctx, const uint64_t **d_cb, const uint64_t **d_umi, const uint32_t **d_gene,
+                                      const uint32_t **d_aux, uint64_t *n) {
+	return guarded([&] {
+		if (!ctx || !d_cb || !d_umi || !d_gene || !d_aux || !n) throw InvalidError("null argument");
+		HIP_CHECK(hipSetDevice(ctx->cfg.device));
+		*n = ctx->n_reads;
+		*d_cb = *d_umi = nullptr; *d_gene = *d_aux = nullptr;
+		if (ctx->n_reads == 0) return;
+		if (ctx->d_cb) { *d_cb = reinterpret_cast<const uint64_t *>(ctx->d_cb); *d_umi = reinterpret_cast<const uint64_t *>(ctx->d_umi); *d_gene = ctx->d_gene; *d_aux = ctx->d_aux; return; }
+		if (ctx->chunks.size() != 1 || ctx->store_chunk != 0) throw UnsupportedError("the reads are not one pushed block (device chunks were adopted in between)");
+		ctx->store.wait();
+		*d_cb = reinterpret_cast<const uint64_t *>(ctx->store.cb.p); *d_umi = reinterpret_cast<const uint64_t *>(ctx->store.umi.p);
+		*d_gene = ctx->store.gene.p; *d_aux = ctx->store.aux.p;
 	});
 }
 

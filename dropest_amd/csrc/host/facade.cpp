@@ -104,21 +104,26 @@ void CellsDataContainer::fail(dropest_status st) const {
 	throw std::runtime_error(msg);
 }
 
+void CellsDataContainer::fill_cfg(dropest_cfg &cfg, std::string &levels) const {
+	dropest_cfg_defaults(&cfg);
+	cfg.device = _device;
+	_merge_strategy->fill(cfg);
+	_umi_merge_strategy->fill(cfg);
+	cfg.min_genes_before_merge = int(_merge_strategy->min_genes_before_merge());
+	cfg.min_genes_after_merge = int(_merge_strategy->min_genes_after_merge());
+	levels = UMI::Mark::to_code(_query_marks);
+	cfg.gene_match_levels = levels.c_str();
+	cfg.max_cells = _max_cells_num;
+}
+
 CellsDataContainer::CellsDataContainer(const std::shared_ptr<Merge::MergeStrategyAbstract> &merge_strategy,
                                        const std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> &umi_merge_strategy,
                                        const std::vector<UMI::Mark> &gene_match_levels, bool /*save_umi_merge_targets*/,
                                        int max_cells_num, int device)
 	: _merge_strategy(merge_strategy), _umi_merge_strategy(umi_merge_strategy), _query_marks(gene_match_levels) {
-	dropest_cfg cfg;
-	dropest_cfg_defaults(&cfg);
-	cfg.device = device;
-	merge_strategy->fill(cfg);
-	umi_merge_strategy->fill(cfg);
-	cfg.min_genes_before_merge = int(merge_strategy->min_genes_before_merge());
-	cfg.min_genes_after_merge = int(merge_strategy->min_genes_after_merge());
-	const std::string levels = UMI::Mark::to_code(gene_match_levels);
-	cfg.gene_match_levels = levels.c_str();
-	cfg.max_cells = max_cells_num;
+	_device = device; _max_cells_num = max_cells_num;
+	dropest_cfg cfg; std::string levels;
+	fill_cfg(cfg, levels);
 	check(dropest_ctx_create(&cfg, &_ctx));
 }
 
@@ -128,23 +133,69 @@ CellsDataContainer::CellsDataContainer(const std::shared_ptr<Merge::MergeStrateg
                                        int max_cells_num, const std::vector<int> &devices)
 	: _merge_strategy(merge_strategy), _umi_merge_strategy(umi_merge_strategy), _query_marks(gene_match_levels) {
 	if (devices.empty()) throw std::runtime_error("no device given");
-	dropest_cfg cfg;
-	dropest_cfg_defaults(&cfg);
-	cfg.device = devices[0];
-	merge_strategy->fill(cfg);
-	umi_merge_strategy->fill(cfg);
-	cfg.min_genes_before_merge = int(merge_strategy->min_genes_before_merge());
-	cfg.min_genes_after_merge = int(merge_strategy->min_genes_after_merge());
-	const std::string levels = UMI::Mark::to_code(gene_match_levels);
-	cfg.gene_match_levels = levels.c_str();
-	cfg.max_cells = max_cells_num;
+	_device = devices[0]; _max_cells_num = max_cells_num;
+	dropest_cfg cfg; std::string levels;
+	fill_cfg(cfg, levels);
 	if (devices.size() == 1) { check(dropest_ctx_create(&cfg, &_ctx)); return; }
 	std::vector<int32_t> dev(devices.begin(), devices.end());
 	_shards.assign(devices.size(), nullptr);
 	check(dropest_shard_group_create(&cfg, int32_t(dev.size()), dev.data(), _shards.data()));
 }
 
+void CellsDataContainer::send_side_strings(dropest_ctx *ctx) const {
+	std::vector<const char *> ptrs(_side.size());
+	for (size_t i = 0; i < _side.size(); ++i) ptrs[i] = _side[i].c_str();
+	check(dropest_set_side_strings(ctx, ptrs.data(), ptrs.size()));
+}
+
+// The context accessors read.  Initialised container: its own.  Before that: the preview (see facade.h).
+dropest_ctx *CellsDataContainer::view() const {
+	if (_is_initialized) return _ctx;
+	if (sharded()) single_only("accessors before set_initialized");
+	if (_preview_valid) return _preview;
+	CellsDataContainer *self = const_cast<CellsDataContainer *>(this);   // flushing the pending batch changes nothing observable
+	self->flush();
+	if (_preview) { dropest_ctx_destroy(_preview); _preview = nullptr; }
+	dropest_cfg cfg; std::string levels;
+	fill_cfg(cfg, levels);
+	check(dropest_ctx_create(&cfg, &_preview));
+	send_side_strings(_preview);
+	const uint64_t *cb = nullptr, *umi = nullptr; const uint32_t *gene = nullptr, *aux = nullptr; uint64_t n = 0;
+	check(dropest_resident_reads(_ctx, &cb, &umi, &gene, &aux, &n));
+	if (n) check(dropest_push_reads_device(_preview, cb, umi, gene, aux, n, 1));
+	check(dropest_set_initialized(_preview));
+	for (const PendingMutation &m : _pending) self->apply_mutation(_preview, m);
+	_preview_valid = true;
+	return _preview;
+}
+
+void CellsDataContainer::apply_mutation(dropest_ctx *ctx, const PendingMutation &m) {
+	switch (m.kind) {
+		case 0: check(dropest_exclude_cell(ctx, m.a)); break;
+		case 1: check(dropest_merge_cells(ctx, m.a, m.b)); break;
+		case 2: {
+			std::vector<uint64_t> src, tgt;
+			for (auto const &t : m.targets) {   // the map's own iteration order, like Cell::merge_umis
+				src.push_back(encode(t.first, _side_umi));
+				tgt.push_back(encode(t.second, _side_umi));
+			}
+			send_side_strings(ctx);          // a target with N registers a new side string
+			check(dropest_merge_umis(ctx, m.a, uint32_t(m.b), src.size(), src.data(), tgt.data()));
+			break;
+		}
+		case 3: {
+			const size_t gene = _gene_indexer.add(m.gene);
+			const uint64_t umi = encode(m.umi, _side_umi);
+			send_side_strings(ctx);
+			check(dropest_add_umi_to_cell(ctx, m.a, uint32_t(gene), umi, m.mark, reinterpret_cast<const uint8_t *>(m.quality.data()), uint32_t(m.quality.size())));
+			break;
+		}
+		default: throw std::runtime_error("internal: unknown pending mutation");
+	}
+}
+
 CellsDataContainer::~CellsDataContainer() {
+	if (_preview) dropest_ctx_destroy(_preview);
 	for (dropest_shard *s : _shards) dropest_shard_destroy(s);
 	dropest_ctx_destroy(_ctx);
 }
@@ -171,6 +222,7 @@ std::vector<std::pair<std::string, std::string>> CellsDataContainer::merged_barc
 
 void CellsDataContainer::add_record(const ReadInfo &r) {   // CellsDataContainer.cpp:59-88
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
+	_preview_valid = false;
 	const uint8_t mark = uint8_t(r.umi_mark.bits());
 	const bool has_gene = !r.gene.empty();
 	_cb.push_back(encode(r.params.cell_barcode(), _side_cb));
@@ -228,6 +280,7 @@ void CellsDataContainer::set_reference_names(const std::vector<std::string> &nam
 
 void CellsDataContainer::add_record(const ParsedRead &r) {   // same statements as add_record(const ReadInfo&), on parsed fields
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
+	_preview_valid = false;
 	if (r.ref_id < 0 || size_t(r.ref_id) >= _ref_names.size()) throw std::out_of_range("reference id outside set_reference_names");
 	const bool has_gene = !r.gene.empty();
 	_cb.push_back(r.cb_code ? r.cb_code : encode(std::string(r.cb), _side_cb));
@@ -323,6 +376,9 @@ void CellsDataContainer::set_initialized() {   // CellsDataContainer.cpp:163-175
 	}
 	check(st);
 	_is_initialized = true;
+	if (_preview) { dropest_ctx_destroy(_preview); _preview = nullptr; _preview_valid = false; }
+	for (const PendingMutation &m : _pending) apply_mutation(_ctx, m);   // what was merged / excluded before the initialisation
+	_pending.clear();
 }
 
 void CellsDataContainer::split_for_wide_keys() {
@@ -346,13 +402,14 @@ void CellsDataContainer::merge_and_filter() {   // CellsDataContainer.cpp:39-57
 			return;
 		}
 	}
+	_umi_indexer_valid = false;
 	check(dropest_merge_and_filter(_ctx));
 }
 
-size_t CellsDataContainer::total_cells_number() const { if (sharded()) single_only("total_cells_number"); uint64_t n = 0; check(dropest_total_cells(_ctx, &n)); return size_t(n); }
+size_t CellsDataContainer::total_cells_number() const { if (sharded()) single_only("total_cells_number"); uint64_t n = 0; check(dropest_total_cells(view(), &n)); return size_t(n); }
 size_t CellsDataContainer::real_cells_number() const { if (sharded()) single_only("real_cells_number"); uint64_t n = 0; check(dropest_real_cells(_ctx, &n)); return size_t(n); }
 
-size_t CellsDataContainer::cell_id_by_cb(const std::string &barcode) const { if (sharded()) single_only("string &barcode) const {");
+size_t CellsDataContainer::cell_id_by_cb(const std::string &barcode) const { if (sharded()) single_only("cell_id_by_cb");
 	uint64_t code;
 	if (!pack2(barcode, code)) {
 		auto it = _side_cb.find(barcode);
@@ -360,7 +417,7 @@ size_t CellsDataContainer::cell_id_by_cb(const std::string &barcode) const { if 
 		code = it->second;
 	}
 	int64_t id = -1;
-	check(dropest_cell_id_by_cb(_ctx, code, &id));
+	check(dropest_cell_id_by_cb(view(), code, &id));
 	if (id < 0) throw std::out_of_range("unknown barcode: " + barcode);
 	return size_t(id);
 }
@@ -385,27 +442,55 @@ const CellsDataContainer::ids_t &CellsDataContainer::merge_targets() const { if 
 	return _merge_targets_cache;
 }
 
+// The public mutators (CellsDataContainer.h:88-95).  On an initialised container they act on it; before that (the reference
+// takes them from the first add_record on) they act on the preview -- so that errors surface where the reference throws them --
+// and are replayed on the real context by set_initialized().
 void CellsDataContainer::exclude_cell(size_t index) {   // CellsDataContainer.cpp:106-109
-	if (!_is_initialized) throw std::runtime_error("You must initialize container");
-	check(dropest_exclude_cell(_ctx, index));
+	if (sharded()) single_only("exclude_cell");
+	PendingMutation m; m.kind = 0; m.a = index;
+	apply_mutation(view(), m);
+	if (!_is_initialized) _pending.push_back(m);
 }
 
 void CellsDataContainer::merge_cells(size_t source_cell_ind, size_t target_cell_ind) {   // :90-104
+	if (sharded()) single_only("merge_cells");
+	PendingMutation m; m.kind = 1; m.a = source_cell_ind; m.b = target_cell_ind;
+	_umi_indexer_valid = false;
+	apply_mutation(view(), m);
+	if (!_is_initialized) _pending.push_back(m);
+}
+
+void CellsDataContainer::add_umi_to_cell(size_t cell_id, const ReadInfo &read_info) {   // :356-364
+	if (sharded()) single_only("add_umi_to_cell");
+	if (read_info.gene.empty()) throw std::runtime_error("add_umi_to_cell: the read has no gene");
+	PendingMutation m; m.kind = 3; m.a = cell_id; m.gene = read_info.gene; m.umi = read_info.params.umi(); m.mark = uint8_t(read_info.umi_mark.bits());
+	m.quality = read_info.params.umi_quality();
+	_umi_indexer_valid = false;
+	apply_mutation(view(), m);
+	if (!_is_initialized) _pending.push_back(m);
+}
+
+const StringIndexer &CellsDataContainer::umi_indexer() const {
+	if (sharded()) single_only("umi_indexer");
 	if (!_is_initialized) throw std::runtime_error("You must initialize container");
-	check(dropest_merge_cells(_ctx, source_cell_ind, target_cell_ind));
+	if (!_umi_indexer_valid) {
+		uint64_t n = 0;
+		check(dropest_umi_first_seen(_ctx, &n, nullptr));
+		std::vector<uint64_t> codes(n);
+		if (n) check(dropest_umi_first_seen(_ctx, &n, codes.data()));
+		_umi_indexer_cache = StringIndexer();
+		for (uint64_t c : codes) _umi_indexer_cache.add(decode(c));
+		_umi_indexer_valid = true;
+	}
+	return _umi_indexer_cache;
 }
 
 void CellsDataContainer::merge_umis(size_t cell_id, size_t gene, const s_s_hash_t &merge_targets) {   // :209-213, Cell.cpp:31-42
-	if (!_is_initialized) throw std::runtime_error("You must initialize container");
-	std::vector<uint64_t> src, tgt;
-	for (auto const &t : merge_targets) {   // the map's own iteration order, like Cell::merge_umis
-		src.push_back(encode(t.first, _side_umi));
-		tgt.push_back(encode(t.second, _side_umi));
-	}
-	std::vector<const char *> ptrs(_side.size());          // a target with N registers a new side string
-	for (size_t i = 0; i < _side.size(); ++i) ptrs[i] = _side[i].c_str();
-	check(dropest_set_side_strings(_ctx, ptrs.data(), ptrs.size()));
-	check(dropest_merge_umis(_ctx, cell_id, uint32_t(gene), src.size(), src.data(), tgt.data()));
+	if (sharded()) single_only("merge_umis");
+	PendingMutation m; m.kind = 2; m.a = cell_id; m.b = gene; m.targets = merge_targets;
+	_umi_indexer_valid = false;
+	apply_mutation(view(), m);
+	if (!_is_initialized) _pending.push_back(m);
 }
 
 long CellsDataContainer::get_merge_target(size_t base_cell_ind) const {
@@ -430,10 +515,16 @@ void CellsDataContainer::poisson_intersection(size_t cell1_ind, size_t cell2_ind
 Cell CellsDataContainer::cell(size_t index) const {
 	if (sharded()) single_only("cell(index)");
 	Cell c;
-	c._owner = this; c._ctx = _ctx; c._id = index;
-	check(dropest_cell_rows(_ctx, index, 1, &c._row));   // DROPEST_ERR_RANGE -> std::out_of_range (vector::at in the reference)
+	c._owner = this; c._ctx = view(); c._id = index;
+	check(dropest_cell_rows(c._ctx, index, 1, &c._row));   // DROPEST_ERR_RANGE -> std::out_of_range (vector::at in the reference)
 	c._barcode = decode(c._row.barcode);
 	return c;
+}
+
+Cell &CellsDataContainer::cell(size_t index) {
+	Cell &slot = _cell_cache[index];
+	slot = static_cast<const CellsDataContainer *>(this)->cell(index);
+	return slot;
 }
 
 std::vector<Cell> CellsDataContainer::real_cells() const {

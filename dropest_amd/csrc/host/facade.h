@@ -302,6 +302,23 @@ private:
 	std::vector<int32_t> _ref_chr;                            // ... -> index in _chr_indexer, -1 = not met yet
 	std::unordered_map<uint64_t, uint32_t> _gene_by_hash;     // name hash -> gene index (verified against the name)
 	mutable ids_t _filtered_cache, _merge_targets_cache;
+	// Before set_initialized the reference's container already answers accessors and takes mutators (its cells exist from the
+	// first add_record).  Here the device tables exist only once the container is initialised, so such calls look at a PREVIEW:
+	// a second context over the reads pushed so far (adopted in place), initialised on demand, with the mutators called so far
+	// replayed on it; the same mutators are replayed on the real context when set_initialized() runs.
+	struct PendingMutation { int kind; size_t a = 0, b = 0; std::unordered_map<std::string, std::string> targets; std::string umi, gene, quality; uint8_t mark = 0; };
+	std::vector<PendingMutation> _pending;
+	mutable dropest_ctx *_preview = nullptr;
+	mutable bool _preview_valid = false;
+	int _device = 0;
+	int _max_cells_num = -1;
+	void fill_cfg(dropest_cfg &cfg, std::string &levels) const;
+	dropest_ctx *view() const;                                 // the context accessors read: the real one, or the preview
+	void apply_mutation(dropest_ctx *ctx, const PendingMutation &m);
+	void send_side_strings(dropest_ctx *ctx) const;
+	mutable StringIndexer _umi_indexer_cache;                 // umi_indexer(): built on demand from dropest_umi_first_seen
+	mutable bool _umi_indexer_valid = false;
+	mutable std::unordered_map<size_t, Cell> _cell_cache;     // Cell &cell(index): container-owned snapshots
 
 	uint64_t encode(const std::string &s, std::unordered_map<std::string, uint64_t> &escapes);
 	void flush();
@@ -374,11 +391,18 @@ public:
 	void exclude_cell(size_t index);
 	void merge_cells(size_t source_cell_ind, size_t target_cell_ind);
 	void merge_umis(size_t cell_id, size_t gene, const s_s_hash_t &merge_targets);                  // RealBarcodesMergeStrategy::get_merge_target
+	// CellsDataContainer.h:90 (CellsDataContainer.cpp:356-364): one more read of read_info's UMI for read_info's gene in cell
+	// `cell_id` -- a new molecule (TOTAL_UMIS_PER_CB + 1) or read count + 1 / mark OR; no read counters, no chromosome statistics.
+	// Cell ids exist once the container is initialised (they are assigned on the device): std::runtime_error before that.
+	void add_umi_to_cell(size_t cell_id, const ReadInfo &read_info);
 
 	s_i_hash_t get_stat_by_real_cells(Stats::CellStatType type) const;
 	void get_stat_by_real_cells(Stats::CellChrStatType stat, names_t &cell_barcodes, names_t &chromosome_names,
 	                            counts_t &counts) const;
 	Cell cell(size_t index) const;                                      // throws std::out_of_range
+	// CellsDataContainer.h:107: a reference to a container-owned snapshot of the cell, refreshed by every call for that index
+	// (what Cell exposes here is read-only; changes go through the container's mutators above)
+	Cell &cell(size_t index);
 	// every real cell in cell-id order -- also on a sharded container, where that is the order of first appearance in the WHOLE
 	// stream and every Cell answers from the shard that owns its barcode -- and the positions of the filtered cells in that list
 	// (in filtered_cells() order).  ResultsPrinter::results_list is written on these two.
@@ -392,6 +416,9 @@ public:
 	size_t real_cells_number() const;
 	std::string merge_type() const { return _merge_strategy->merge_type(); }
 	const StringIndexer &gene_indexer() const { return _gene_indexer; }
+	// CellsDataContainer.h:118: UMIs in index order (first appearance among the gene-bearing reads, then the UMIs merges
+	// brought in); materialised on the first call after the container last changed
+	const StringIndexer &umi_indexer() const;
 	s_ul_hash_t umi_distribution() const;                               // CellsDataContainer.cpp:182-197
 	const std::vector<std::string> &side_strings() const { return _side; }
 	dropest_ctx *handle() const { return _ctx; }

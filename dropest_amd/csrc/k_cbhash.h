@@ -568,4 +568,23 @@ __global__ __launch_bounds__(256) void cb_assign_sorted_kernel(const unsigned lo
 	cell_first[i] = uint32_t(sorted[i] >> 32);
 }
 
+// ---- StringIndexer _umi_indexer (CellsDataContainer.h:66, Gene.cpp:19): UMIs in the order of first appearance among the
+// gene-bearing reads.  The same table protocol with the UMI code as the key; produced on demand (dropest_umi_first_seen).
+__global__ __launch_bounds__(256) void umi_insert_kernel(const unsigned long long *__restrict__ umi, const uint32_t *__restrict__ gene, uint32_t n,
+                                                         CbTable t, uint32_t *__restrict__ overflow) {
+	bool ok = true;
+	for (uint64_t r = uint64_t(blockIdx.x) * 256 + threadIdx.x; r < n; r += uint64_t(gridDim.x) * 256) {
+		if (gene[r] == NO_GENE) continue;   // reads without a gene never reach Gene::add_umi (CellsDataContainer.cpp:73-78)
+		const unsigned long long k = umi[r];
+		const uint32_t s = cb_find_or_insert(t, k, mix64(k) & t.mask, ok);
+		if (ok && uint32_t(r) < ~t.slots[s].nfirst) atomicMax(&t.slots[s].nfirst, ~uint32_t(r));
+	}
+	if (!ok) atomicMax(overflow, 1u);
+}
+__global__ __launch_bounds__(256) void gather_slot_keys_kernel(const unsigned long long *__restrict__ sorted, uint32_t n, CbTable t,
+                                                               unsigned long long *__restrict__ out) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) out[i] = t.slots[uint32_t(sorted[i])].key;
+}
+
 }  // namespace dropest

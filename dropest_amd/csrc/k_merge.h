@@ -128,6 +128,7 @@ struct WlArgs {
 	const uint32_t *cell_real_index;   // [n_cells] cell id -> that index (0xFFFFFFFF for the others)
 	uint32_t *flat_total;    // running size of the flat lists (atomic)
 	uint32_t flat_cap;
+	const uint32_t *base_list;   // optional: block i works on base base_list[i] (the bases the table search left over)
 	uint8_t *dist_dump;      // optional [n_bases][part_size[0] + part_size[1]] per-part distances (tie replay), or null
 	int poisson;             // PoissonRealBarcodesMergeStrategy::get_max_merge_dist: all levels up to (min == 0 ? 2 : min + 1)
 };
@@ -151,7 +152,8 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 	__shared__ uint32_t found[WL_CAND_CAP];
 	__shared__ uint32_t flat_base;
 
-	const WlBase &b = a.bases[blockIdx.x];
+	const uint32_t bi = a.base_list ? a.base_list[blockIdx.x] : blockIdx.x;
+	const WlBase &b = a.bases[bi];
 	const uint32_t tid = threadIdx.x;
 	if (tid < WL_MAX_PARTS * (WL_MAX_DIST + 2)) { (&cnt[0][0])[tid] = 0; (&fill[0][0])[tid] = 0; }
 	if (tid == 0) n_found = 0;
@@ -261,9 +263,9 @@ __global__ __launch_bounds__(WL_THREADS) void wl_neighbours_kernel(WlArgs a) {
 	// append this cell's candidates to the flat lists
 	const uint32_t keep = n_found < uint32_t(WL_CAND_CAP) ? n_found : uint32_t(WL_CAND_CAP);
 	if (tid == 0) {
-		a.cand_count[blockIdx.x] = n_found; a.cand_level[blockIdx.x] = level;
+		a.cand_count[bi] = n_found; a.cand_level[bi] = level;
 		flat_base = keep ? atomicAdd(a.flat_total, keep) : 0u;
-		a.cand_off[blockIdx.x] = flat_base;
+		a.cand_off[bi] = flat_base;
 	}
 	__syncthreads();
 	for (uint32_t k = tid; k < keep; k += WL_THREADS) {
@@ -281,6 +283,157 @@ inline void wl_neighbours_launch(const WlArgs &a, uint32_t n_blocks, size_t lds,
 		case 3: hipLaunchKernelGGL(wl_neighbours_kernel<3>, dim3(n_blocks), dim3(WL_THREADS), lds, stream, a); break;
 		default: hipLaunchKernelGGL(wl_neighbours_kernel<4>, dim3(n_blocks), dim3(WL_THREADS), lds, stream, a); break;
 	}
+}
+
+// ---- neighbour tables ------------------------------------------------------------------------------------------------
+// wl_neighbours_kernel measures every base against every whitelist entry: 2.5 M bases x 2 016 entries at C3 size, 13 ms --
+// yet a barcode part of L bases takes one of only 4^L values (10x: 4^7 and 4^9), and nearly every base is decided by its
+// CLOSE neighbours (a real barcode: itself at distance 0; a sequencing error of one: its origin at distance 1).  So, once per
+// whitelist, every possible value of a part gets a row: how many entries lie at distance 0, 1, 2, 3 and which (WL_TAB_LIST of
+// them at most).  A base whose levels end at total distance <= WL_TAB_DMAX with few candidates is then decided by one THREAD
+// from two rows; everything else -- parts of another length, N, rows that overflowed, levels beyond WL_TAB_DMAX, more than
+// WL_TAB_FOUND candidates -- is left, exactly as before, to wl_neighbours_kernel (cand_count = WL_TAB_TODO marks them).
+constexpr int WL_TAB_DMAX = 3, WL_TAB_LIST = 60, WL_TAB_MAX_LEN = 9, WL_TAB_FOUND = 12;
+constexpr uint32_t WL_TAB_TODO = 0xFFFFFFFFu;
+struct WlTabRow { uint16_t cnt[WL_TAB_DMAX + 1]; uint16_t list[WL_TAB_LIST]; };   // cnt[0] == 0xFFFF: unusable (overflow)
+static_assert(sizeof(WlTabRow) == 128, "row layout");
+
+// one wave per value v of a part of length L: distances to the np entries, those within WL_TAB_DMAX grouped by distance
+__global__ __launch_bounds__(256) void wl_table_build_kernel(const unsigned long long *__restrict__ part_code, uint32_t np, int L, uint32_t n_values,
+                                                             WlTabRow *__restrict__ rows) {
+	__shared__ uint32_t s_cnt[4][WL_TAB_DMAX + 1];
+	__shared__ uint32_t s_item[4][WL_TAB_LIST];
+	__shared__ uint32_t s_n[4];
+	const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, v = blockIdx.x * 4 + w;
+	if (lane <= WL_TAB_DMAX) s_cnt[w][lane] = 0;
+	if (lane == 0) s_n[w] = 0;
+	__builtin_amdgcn_wave_barrier();
+	if (v >= n_values) return;
+	uint32_t peq[5] = {0, 0, 0, 0, 0};
+	for (int i = 0; i < L; ++i) peq[(v >> (2 * (L - 1 - i))) & 3u] |= 1u << i;   // pattern = the value's bases, first base = bit 0
+	peq[4] = (1u << L) - 1u;
+	for (uint32_t i = lane; i < np; i += 64) {
+		const unsigned long long pc = part_code[i];
+		if (pc == ~0ull) continue;                                                  // (tables are only built for clean whitelists)
+		const uint32_t d = wl_edit_distance_code(peq, L, pc & ((1ull << 58) - 1ull), int(pc >> 58));
+		if (d > uint32_t(WL_TAB_DMAX)) continue;
+		atomicAdd(&s_cnt[w][d], 1u);
+		const uint32_t at = atomicAdd(&s_n[w], 1u);
+		if (at < uint32_t(WL_TAB_LIST)) s_item[w][at] = (d << 16) | i;
+	}
+	__builtin_amdgcn_s_waitcnt(0xC07F);
+	__builtin_amdgcn_wave_barrier();
+	WlTabRow &row = rows[v];
+	const uint32_t n = s_n[w];
+	if (n > uint32_t(WL_TAB_LIST)) { if (lane == 0) row.cnt[0] = 0xFFFFu; return; }
+	if (lane <= uint32_t(WL_TAB_DMAX)) row.cnt[lane] = uint16_t(s_cnt[w][lane]);
+	// grouped by distance, ascending entry index inside a group (any order would do: candidates form a set)
+	if (lane == 0) {
+		uint32_t at = 0;
+		for (uint32_t d = 0; d <= uint32_t(WL_TAB_DMAX); ++d) {
+			const uint32_t first = at;
+			for (uint32_t k = 0; k < n; ++k) if ((s_item[w][k] >> 16) == d) row.list[at++] = uint16_t(s_item[w][k]);
+			for (uint32_t x = first + 1; x < at; ++x) {   // insertion sort of a handful of indices
+				const uint16_t key = row.list[x]; uint32_t y = x;
+				while (y > first && row.list[y - 1] > key) { row.list[y] = row.list[y - 1]; --y; }
+				row.list[y] = key;
+			}
+		}
+	}
+}
+
+// the bases the table search left over, as a list for wl_neighbours_kernel (order irrelevant)
+__global__ __launch_bounds__(256) void wl_collect_todo_kernel(const uint32_t *__restrict__ cand_count, uint32_t n, uint32_t *__restrict__ list, uint32_t *__restrict__ n_todo) {
+	const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+	const bool mine = f < n && cand_count[f] == WL_TAB_TODO;
+	const unsigned long long bal = __ballot(mine);
+	if (!bal) return;
+	uint32_t base = 0;
+	if ((threadIdx.x & 63u) == 0) base = atomicAdd(n_todo, uint32_t(__popcll(bal)));
+	base = __shfl(base, 0, 64);
+	if (mine) list[base + __builtin_amdgcn_mbcnt_hi(uint32_t(bal >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bal), 0u))] = f;
+}
+
+struct WlTabArgs {
+	const WlTabRow *rows[WL_MAX_PARTS];
+	int len[WL_MAX_PARTS];
+};
+
+// one thread per base; same decisions as wl_neighbours_kernel for the bases it takes
+template <uint32_t P>
+__global__ __launch_bounds__(256) void wl_table_search_kernel(WlArgs a, WlTabArgs t) {
+	const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+	if (f >= a.n_bases) return;
+	const WlBase &b = a.bases[f];
+	auto todo = [&]() { a.cand_count[f] = WL_TAB_TODO; };
+	const WlTabRow *row[P];
+	uint32_t start[P][WL_TAB_DMAX + 2];
+#pragma unroll
+	for (uint32_t p = 0; p < P; ++p) {
+		if (int(b.len[p]) != t.len[p]) return todo();
+		uint32_t v = 0;
+		for (int i = 0; i < t.len[p]; ++i) {
+			const char c = b.part[p][i];
+			const uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+			if (code > 3u) return todo();
+			v = (v << 2) | code;
+		}
+		row[p] = t.rows[p] + v;
+		if (row[p]->cnt[0] == 0xFFFFu) return todo();
+		uint32_t run = 0;
+		for (int d = 0; d <= WL_TAB_DMAX; ++d) { start[p][d] = run; run += row[p]->cnt[d]; }
+		start[p][WL_TAB_DMAX + 1] = run;
+	}
+	const uint32_t base_umis = a.cell_total_umis[b.cell];
+	uint32_t min_level = 0;
+#pragma unroll
+	for (uint32_t p = 0; p < P; ++p) {
+		uint32_t m = WL_TAB_DMAX + 1;
+		for (int d = 0; d <= WL_TAB_DMAX; ++d) if (row[p]->cnt[d]) { m = uint32_t(d); break; }
+		if (m > uint32_t(WL_TAB_DMAX)) return todo();     // nothing that close in this part: the exact minimum is not in the table
+		min_level += m;
+	}
+	uint32_t max_dist = a.poisson ? (min_level == 0 ? 2u : min_level + 1u) : min_level;
+	uint32_t found[WL_TAB_FOUND], n_found = 0, level = min_level, last_level = min_level;
+	uint32_t n_tuples = 1;
+#pragma unroll
+	for (uint32_t p = 0; p < P; ++p) n_tuples *= WL_TAB_DMAX + 1;
+	for (;; ++level) {
+		if (level > uint32_t(WL_TAB_DMAX)) return todo();   // a level the table does not describe completely
+		last_level = level;
+		for (uint32_t tup = 0; tup < n_tuples; ++tup) {
+			uint32_t dd[P], cc[P], sum = 0, x = tup, combos = 1;
+#pragma unroll
+			for (uint32_t p = 0; p < P; ++p) { dd[p] = x % (WL_TAB_DMAX + 1); x /= WL_TAB_DMAX + 1; sum += dd[p]; cc[p] = row[p]->cnt[dd[p]]; combos *= cc[p]; }
+			if (sum != level || combos == 0) continue;
+			for (uint32_t q = 0; q < combos; ++q) {
+				unsigned long long code = 1ull;
+				uint32_t r = q;
+#pragma unroll
+				for (uint32_t p = 0; p < P; ++p) {
+					const uint32_t pick = r % cc[p]; r /= cc[p];
+					const unsigned long long pc = a.part_code[p][row[p]->list[start[p][dd[p]] + pick]];
+					const int n = int(pc >> 58);
+					code = (code << (2 * n)) | (pc & ((1ull << (2 * n)) - 1ull));
+				}
+				const uint32_t s = cb_find(a.table, code);
+				if (s == 0xFFFFFFFFu) continue;
+				const uint32_t c = a.table.slots[s].cell_id;
+				if (a.cell_n_genes[c] >= a.min_genes && a.cell_total_umis[c] >= base_umis) {
+					if (n_found >= uint32_t(WL_TAB_FOUND)) return todo();
+					found[n_found++] = c;
+				}
+			}
+		}
+		if (level > max_dist) max_dist = level;
+		if (level + 1 > max_dist && n_found) break;
+		if (level == uint32_t(WL_MAX_DIST)) break;          // (unreachable: WL_TAB_DMAX < WL_MAX_DIST sends such bases to the full search)
+	}
+	a.cand_count[f] = n_found; a.cand_level[f] = last_level;
+	const uint32_t o = n_found ? atomicAdd(a.flat_total, n_found) : 0u;
+	a.cand_off[f] = o;
+	for (uint32_t k = 0; k < n_found; ++k)
+		if (o + k < a.flat_cap) { a.flat_cell[o + k] = found[k]; a.flat_umis[o + k] = a.cell_total_umis[found[k]]; a.flat_ridx[o + k] = a.cell_real_index[found[k]]; }
 }
 
 // Splits the barcodes of a list of cells into the whitelist's parts on the device

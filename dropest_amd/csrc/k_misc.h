@@ -427,6 +427,17 @@ __global__ __launch_bounds__(256) void gather_u64_kernel(const unsigned long lon
 	if (i < n) keys_out[i] = table[idx[i]];
 }
 
+// A small result written STRAIGHT into pinned host memory by the compute queue (the pointer is the host buffer's device view):
+// for read-backs that must not queue behind a large device-to-host copy on the DMA engine (the permutation of sort_filtered
+// while cm_raw's prefetch holds the copy engine: 15 ms of waiting for 10 MB at C3 size).
+__global__ __launch_bounds__(256) void store_u32_to_host_kernel(const uint32_t *__restrict__ src, uint32_t n, uint32_t *__restrict__ host_dst) {
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) host_dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void load_u64_from_host_kernel(const unsigned long long *__restrict__ host_src, uint32_t n, unsigned long long *__restrict__ dst) {
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = host_src[i];
+}
+
 // Same table, chromosome derived from the gene: exon / intron read counts come from the (cell, gene) rows, the
 // gene-less reads of a cell from its pseudo-molecules (cell, NONE, chromosome) whose read count is the answer.
 struct ChrFromGeneArgs {

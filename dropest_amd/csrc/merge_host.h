@@ -129,6 +129,27 @@ void dropest_ctx::upload_whitelist() {
 		d_wl_code[p].alloc(codes.size()); d_wl_code[p].mark_persistent();
 		HIP_CHECK(hipMemcpy(d_wl_code[p].p, codes.data(), codes.size() * 8, hipMemcpyHostToDevice));
 	}
+	// neighbour tables (k_merge.h), once per whitelist: every part of one length of at most WL_TAB_MAX_LEN clean bases
+	if (!wl_tab_ok && !d_wl_tab[0].p && !getenv("DROPEST_WL_NO_TABLE")) {
+		bool ok = wl.parts.size() <= size_t(WL_MAX_PARTS);
+		for (auto const &part : wl.parts) {
+			const size_t L = part[0].size();
+			ok = ok && L >= 1 && L <= size_t(WL_TAB_MAX_LEN);
+			for (auto const &e : part) ok = ok && e.size() == L && e.find_first_not_of("ACGT") == std::string::npos;
+		}
+		if (ok) {
+			for (size_t p = 0; p < wl.parts.size(); ++p) {
+				const int L = int(wl.parts[p][0].size());
+				const u32 n_values = 1u << (2 * L);
+				d_wl_tab[p].alloc(n_values); d_wl_tab[p].mark_persistent();
+				timed("wl_table_build", double(n_values) * wl.parts[p].size() * 8, [&] {
+					hipLaunchKernelGGL(wl_table_build_kernel, dim3(div_up(n_values, 4)), dim3(256), 0, stream, d_wl_code[p].p, u32(wl.parts[p].size()), L, n_values, d_wl_tab[p].p);
+				});
+			}
+			HIP_CHECK(stream_wait(stream));
+			wl_tab_ok = true;
+		}
+	}
 }
 
 // Neighbour search of RealBarcodesMergeStrategy::get_merge_target for a list of base cells, over a universe of
@@ -181,7 +202,7 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 	// 2. neighbour search; candidates land in flat lists
 	st_bases.reset();
 	auto st_search = std::make_unique<HostStage>(this, "cb_merge:targets:search");
-	DevBuf<u32> d_cnt, d_lvl, d_off, d_fcell, d_fumis, d_fridx;
+	DevBuf<u32> d_cnt, d_lvl, d_off, d_fcell, d_fumis, d_fridx, d_lvl_todo;
 	u32 flat_cap = std::max<u32>(F * 2u, 1024u);
 	S.cnt.resize(F); S.off.resize(F);
 	WlArgs &a = S.args;
@@ -200,9 +221,35 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 		a.flat_ridx = d_fridx.p; a.cell_real_index = U.real_index;
 		a.flat_total = scalars.p; a.flat_cap = flat_cap; a.dist_dump = nullptr;
 		a.poisson = cfg.merge_kind == DROPEST_MERGE_POISSON_REAL ? 1 : 0;
-		timed("wl_neighbours", double(F) * S.ntot * 32, [&] {
-			wl_neighbours_launch(a, F, S.lds, stream);
-		});
+		a.base_list = nullptr;
+		if (wl_tab_ok) {
+			// most bases are decided from the neighbour tables by one thread each; the rest goes through the full search
+			WlTabArgs ta{};
+			for (u32 p = 0; p < P; ++p) { ta.rows[p] = d_wl_tab[p].p; ta.len[p] = int(wl.part_lengths[p]); }
+			timed("wl_table_search", double(F) * (sizeof(WlBase) + 2 * sizeof(WlTabRow)), [&] {
+				switch (P) {
+					case 1: hipLaunchKernelGGL(wl_table_search_kernel<1>, dim3(div_up(F, 256)), dim3(256), 0, stream, a, ta); break;
+					case 2: hipLaunchKernelGGL(wl_table_search_kernel<2>, dim3(div_up(F, 256)), dim3(256), 0, stream, a, ta); break;
+					case 3: hipLaunchKernelGGL(wl_table_search_kernel<3>, dim3(div_up(F, 256)), dim3(256), 0, stream, a, ta); break;
+					default: hipLaunchKernelGGL(wl_table_search_kernel<4>, dim3(div_up(F, 256)), dim3(256), 0, stream, a, ta); break;
+				}
+			});
+			DevBuf<u32> &todo = d_lvl_todo;
+			todo.ensure(F);
+			hipLaunchKernelGGL(wl_collect_todo_kernel, dim3(div_up(F, 256)), dim3(256), 0, stream, d_cnt.p, F, todo.p, scalars.p + 1);
+			HIP_CHECK(hipGetLastError());
+			u32 n_todo = 0;
+			fetch(&n_todo, scalars.p + 1, 4);
+			if (profiling) stats["count:wl_bases_full_search"].launches += n_todo;
+			if (n_todo) {
+				a.base_list = todo.p;
+				timed("wl_neighbours", double(n_todo) * S.ntot * 32, [&] { wl_neighbours_launch(a, n_todo, S.lds, stream); });
+			}
+		} else {
+			timed("wl_neighbours", double(F) * S.ntot * 32, [&] {
+				wl_neighbours_launch(a, F, S.lds, stream);
+			});
+		}
 		u32 total = 0;
 		fetch(&total, scalars.p, 4);
 		if (total <= flat_cap) {
@@ -225,26 +272,48 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 void dropest_ctx::build_merge_pairs(const std::vector<u32> &cells, MergeSearch &S) {
 	const u32 F = S.F;
 	HostStage st_pairs(this, "cb_merge:targets:pairs");
-	S.pair_base.clear(); S.pair_cand.clear(); S.pair_umis.clear(); S.pair_ridx.clear();
 	S.pair_first.assign(size_t(F) + 1, 0); S.self_ridx.assign(F, 0xFFFFFFFFu);
-	S.pair_base.reserve(F); S.pair_cand.reserve(F); S.pair_umis.reserve(F); S.pair_ridx.reserve(F);
-	for (u32 f = 0; f < F; ++f) {
-		S.pair_first[f] = u32(S.pair_base.size());
-		if (S.cnt[f] > u32(WL_CAND_CAP))
-			throw UnsupportedError("more than " + std::to_string(WL_CAND_CAP) + " merge candidates for one barcode");
-		bool self = false;
-		for (u32 k = 0; k < S.cnt[f]; ++k)
-			if (S.fcell[S.off[f] + k] == cells[f]) { self = true; S.self_ridx[f] = S.fridx[S.off[f] + k]; }
-		// the base is itself a whitelist barcode: neighbour_cells[0] == base (RealBarcodesMergeStrategy.cpp:34-35) ends the
-		// decision there; the Poisson estimator goes on to its other neighbours (PoissonTargetEstimator.cpp:26-29)
-		if (self && cfg.merge_kind != DROPEST_MERGE_POISSON_REAL) continue;
-		for (u32 k = 0; k < S.cnt[f]; ++k) {
-			if (S.fcell[S.off[f] + k] == cells[f]) continue;
-			S.pair_base.push_back(f); S.pair_cand.push_back(S.fcell[S.off[f] + k]); S.pair_umis.push_back(S.fumis[S.off[f] + k]);
-			S.pair_ridx.push_back(S.fridx[S.off[f] + k]);
+	// two passes over contiguous ranges on a few threads (2.4 M bases at C3 size): pairs per base, then the flat lists
+	constexpr unsigned W = 8;
+	size_t per_worker[W + 1] = {0};
+	bool too_many = false;
+	std::vector<u32> n_pairs(F);
+	const unsigned workers = parallel_ranges(F, [&](size_t b, size_t e, unsigned w) {
+		size_t mine = 0; bool over = false;
+		for (size_t f = b; f < e; ++f) {
+			if (S.cnt[f] > u32(WL_CAND_CAP)) { over = true; continue; }
+			bool self = false;
+			for (u32 k = 0; k < S.cnt[f]; ++k)
+				if (S.fcell[S.off[f] + k] == cells[f]) { self = true; S.self_ridx[f] = S.fridx[S.off[f] + k]; }
+			// the base is itself a whitelist barcode: neighbour_cells[0] == base (RealBarcodesMergeStrategy.cpp:34-35) ends the
+			// decision there; the Poisson estimator goes on to its other neighbours (PoissonTargetEstimator.cpp:26-29)
+			u32 np = 0;
+			if (!(self && cfg.merge_kind != DROPEST_MERGE_POISSON_REAL)) np = S.cnt[f] - (self ? 1u : 0u);
+			n_pairs[f] = np; mine += np;
 		}
-	}
-	S.pair_first[F] = u32(S.pair_base.size());
+		per_worker[w] = mine;
+		if (over) too_many = true;
+	}, 100000, W);
+	if (too_many) throw UnsupportedError("more than " + std::to_string(WL_CAND_CAP) + " merge candidates for one barcode");
+	size_t start[W + 1] = {0};
+	for (unsigned w = 0; w < workers; ++w) start[w + 1] = start[w] + per_worker[w];
+	const size_t NP = start[workers];
+	if (NP > 0xFFFFFFF0ull) throw UnsupportedError("more than 2^32 (base, candidate) pairs");
+	S.pair_base.resize(NP); S.pair_cand.resize(NP); S.pair_umis.resize(NP); S.pair_ridx.resize(NP);
+	parallel_ranges(F, [&](size_t b, size_t e, unsigned w) {   // same n and limits as above: the same ranges
+		size_t at = start[w];
+		for (size_t f = b; f < e; ++f) {
+			S.pair_first[f] = u32(at);
+			if (!n_pairs[f]) continue;
+			for (u32 k = 0; k < S.cnt[f]; ++k) {
+				if (S.fcell[S.off[f] + k] == cells[f]) continue;
+				S.pair_base[at] = u32(f); S.pair_cand[at] = S.fcell[S.off[f] + k]; S.pair_umis[at] = S.fumis[S.off[f] + k];
+				S.pair_ridx[at] = S.fridx[S.off[f] + k];
+				++at;
+			}
+		}
+	}, 100000, W);
+	S.pair_first[F] = u32(NP);
 }
 
 // The same search on the host, literally as the reference runs it (BarcodesParser::get_distances_to_barcode / push_remaining_dists,
@@ -597,8 +666,9 @@ void dropest_ctx::reaggregate_after_merge() {
 		HIP_CHECK(hipMemcpyAsync(d_src.p, src.data(), src.size() * 4, hipMemcpyHostToDevice, stream));
 		HIP_CHECK(hipMemcpyAsync(d_tgt.p, tgt.data(), tgt.size() * 4, hipMemcpyHostToDevice, stream));
 		hipLaunchKernelGGL(iota_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, stream, remap.p, n_cells);
-		hipLaunchKernelGGL(scatter_pairs_kernel, dim3(div_up(u32(src.size()), 256)), dim3(256), 0, stream, d_src.p, d_tgt.p,
-		                   u32(src.size()), remap.p);
+		if (!src.empty())
+			hipLaunchKernelGGL(scatter_pairs_kernel, dim3(div_up(u32(src.size()), 256)), dim3(256), 0, stream, d_src.p, d_tgt.p,
+			                   u32(src.size()), remap.p);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(stream_wait(stream));   // src / tgt are host vectors
 	}

@@ -7,7 +7,6 @@
 
 void dropest_ctx::mutate_exclude_cell(u32 cell) {
 	invalidate_prefetch();   // a cm_raw prefetch in flight reads the tables this call rewrites
-	invalidate_prefetch();
 	const long ri = real_find(cell);
 	if (ri < 0) { extra_excluded.insert(cell); return; }   // not a real-candidate cell: only the flag is observable
 	real[size_t(ri)].excluded = true;
@@ -112,5 +111,74 @@ void dropest_ctx::mutate_merge_umis(u32 cell, u32 gene, uint64_t n, const uint64
 	fetch(or_and, d_or_and, 16);
 	reaggregate_from_keys(or_and[0] ^ or_and[1]);
 	real[size_t(ri)].row.total_umis -= removed;
+	request_filtered(filtered_threshold, filtered_max_cells);
+}
+
+// CellsDataContainer::add_umi_to_cell (CellsDataContainer.cpp:356-364) on the initialised container: one more read of UMI
+// `umi_code` for gene `gene` in cell `cell` -- Gene::add_umi: a new molecule (TOTAL_UMIS_PER_CB++) or read_count++ / mark |=
+// of the existing one (UMI::add_read: the read's quality bytes are added to the molecule's sums, its length checked against
+// them, UMI.cpp:21-34).  Like the reference's member it touches nothing else: no read counters, no chromosome statistics.
+// The read becomes one row appended behind the sorted molecule table, folded by the machinery every merge uses.
+void dropest_ctx::mutate_add_umi_to_cell(u32 cell, u32 gene, uint64_t umi_code, u32 mark, const uint8_t *quality, u32 quality_length) {
+	invalidate_prefetch();
+	using namespace dropest;
+	const bool with_qual = have_qual && qual_len;
+	if (have_qual && quality_length != qual_len)   // UMI.cpp:26-28 (one quality length per container here)
+		throw InvalidError("Wrong quality length: " + std::to_string(quality_length) + ", expected: " + std::to_string(qual_len));
+	if (with_qual && !quality) throw InvalidError("null quality string");
+	if (!chr_from_gene) throw UnsupportedError("add_umi_to_cell needs the chromosome-from-gene record layout (a gene on two chromosomes was seen)");
+	if (gene >= layout.gene_none) throw UnsupportedError("add_umi_to_cell: the gene index does not fit the key layout of this container");
+	if (mark > 7u) throw InvalidError("add_umi_to_cell: mark out of range");
+	const u64 umask = layout.umi_bits ? ((1ull << layout.umi_bits) - 1ull) : 0ull;
+	u64 field;
+	if (umi_code & ESCAPE_BIT) {
+		const u64 id = umi_code & ~ESCAPE_BIT;
+		if (id >= ingest.umi_escape_max_plus1) throw UnsupportedError("add_umi_to_cell: a UMI with N that no read of the container carries");
+		field = layout.umi_escape_base + id;
+	} else {
+		if (umi_sentinel_stripped && bit_length(umi_code) - 1 != umi_clean_bits) throw UnsupportedError("add_umi_to_cell: a UMI of another length than the container's");
+		field = umi_code & layout.umi_strip_mask;
+		if (field > umask || (ingest.umi_escape_max_plus1 && field >= layout.umi_escape_base)) throw UnsupportedError("add_umi_to_cell: the UMI does not fit the key layout");
+	}
+	const u64 cg = (u64(cell) << layout.gene_bits) | gene;
+	if (umi_overrides.count(cg)) throw UnsupportedError("add_umi_to_cell on a group that the UMI merge strategy rewrote");
+	if (n_mol >= 0xFFFFFFF0u) throw UnsupportedError("molecule table would exceed 2^32 rows");
+	const u64 key = (cg << layout.umi_bits) | field;
+	const u32 row_vals[4] = {1u, mark, (mark >> 1) & 1u, (mark >> 2) & 1u};
+	const u32 total = n_mol + 1;
+	grow_preserving(mol_key, n_mol, size_t(total) + 1, stream);
+	DevBuf<u32> *cols[4] = {&mol_reads, &mol_mark, &mol_exon, &mol_intron};
+	for (int k = 0; k < 4; ++k) grow_preserving(*cols[k], n_mol, size_t(total) + 1, stream);
+	HIP_CHECK(hipMemcpyAsync(mol_key.p + n_mol, &key, 8, hipMemcpyHostToDevice, stream));
+	for (int k = 0; k < 4; ++k) HIP_CHECK(hipMemcpyAsync(cols[k]->p + n_mol, &row_vals[k], 4, hipMemcpyHostToDevice, stream));
+	const size_t qstride = (size_t(qual_len) + 1) & ~size_t(1);
+	DevBuf<u32> d_q;
+	std::vector<u32> q32(qstride, 0);
+	if (with_qual) {
+		// the read arrives with a sums row of its own (a new molecule keeps it; folded into an existing one, its bytes are added to
+		// that molecule's row afterwards: the fold itself keeps the row of the member with the smaller index, the existing one)
+		for (u32 i = 0; i < qual_len; ++i) q32[i] = quality[i];
+		grow_preserving(mol_qsum, size_t(n_qsum_rows) * qstride, size_t(n_qsum_rows + 1) * qstride, stream);
+		HIP_CHECK(hipMemcpyAsync(mol_qsum.p + size_t(n_qsum_rows) * qstride, q32.data(), qstride * 4, hipMemcpyHostToDevice, stream));
+		grow_preserving(mol_qrow, n_mol, size_t(total), stream);
+		HIP_CHECK(hipMemcpyAsync(mol_qrow.p + n_mol, &n_qsum_rows, 4, hipMemcpyHostToDevice, stream));
+		d_q.alloc(qstride);
+		HIP_CHECK(hipMemcpyAsync(d_q.p, q32.data(), qstride * 4, hipMemcpyHostToDevice, stream));
+	}
+	HIP_CHECK(stream_wait(stream));
+	if (with_qual) ++n_qsum_rows;
+	const u32 before = n_mol;
+	if (mol_sorted_rows > n_mol) mol_sorted_rows = n_mol;   // the new row sits behind the sorted table
+	n_mol = total;
+	reaggregate_after_merge();          // identity remap apart from the recorded merges: sorts the row in, folds equal keys
+	const bool is_new = n_mol == before + 1;
+	if (with_qual && !is_new) {
+		scalars.ensure(16);
+		hipLaunchKernelGGL(find_molecule_row_kernel, dim3(1), dim3(1), 0, stream, mol_key.p, n_mol, key, scalars.p);
+		hipLaunchKernelGGL(add_quality_row_kernel, dim3(1), dim3(256), 0, stream, mol_qsum.p, mol_qrow.p, scalars.p, u32(qstride), d_q.p, qual_len);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(stream_wait(stream));
+	}
+	if (is_new) { const long ri = real_find(cell); if (ri >= 0) real[size_t(ri)].row.total_umis += 1; }   // TOTAL_UMIS_PER_CB (:360-363)
 	request_filtered(filtered_threshold, filtered_max_cells);
 }

@@ -90,6 +90,18 @@ __global__ __launch_bounds__(256) void gather_quality_rows_kernel(const uint32_t
 	out[i] = qsum[size_t(qrow[rows[m]]) * ((qlen + 1u) & ~1u) + p];
 }
 
+// add_umi_to_cell on a container with qualities: the molecule row that holds `key`, and a read's bytes added to a sums row
+__global__ void find_molecule_row_kernel(const unsigned long long *__restrict__ mol_key, uint32_t n_mol, unsigned long long key, uint32_t *__restrict__ out) {
+	uint32_t lo = 0, hi = n_mol;
+	while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (mol_key[mid] < key) lo = mid + 1; else hi = mid; }
+	*out = (lo < n_mol && mol_key[lo] == key) ? lo : 0xFFFFFFFFu;
+}
+__global__ void add_quality_row_kernel(uint32_t *__restrict__ qsum, const uint32_t *__restrict__ qrow, const uint32_t *__restrict__ row, uint32_t qstride,
+                                       const uint32_t *__restrict__ add, uint32_t qlen) {
+	const uint32_t i = threadIdx.x;
+	if (i < qlen && *row != 0xFFFFFFFFu) qsum[size_t(qrow[*row]) * qstride + i] += add[i];
+}
+
 }  // namespace
 
 // After the first reduce of set_initialized: sums per molecule row, identity row references.
@@ -98,7 +110,7 @@ void dropest_ctx::accumulate_umi_qualities() {
 	if (!have_qual) return;
 	if (qual_reads != n_reads) throw InvalidError("UMI qualities were given for " + std::to_string(qual_reads) + " reads, the container holds " +
 	                                              std::to_string(n_reads));
-	n_mol_at_init = n_mol;
+	n_mol_at_init = n_mol; n_qsum_rows = n_mol;
 	if (!n_mol || !qual_len) return;
 	HostStage hs(this, "umi_qualities");
 	const size_t qstride = (size_t(qual_len) + 1) & ~size_t(1);   // padded to whole 64-bit pairs

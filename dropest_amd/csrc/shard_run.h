@@ -323,6 +323,23 @@ __global__ __launch_bounds__(256) void place_columns_kernel(const unsigned long 
 	const unsigned long long s = desc[3ull * blockIdx.x], d = desc[3ull * blockIdx.x + 1], len = desc[3ull * blockIdx.x + 2];
 	for (unsigned long long t = threadIdx.x; t < len; t += 256) { dst_rows[d + t] = src_rows[s + t]; dst_vals[d + t] = src_vals[s + t]; }
 }
+// The same, narrowing on the way out (16-bit row indices and values: half the bytes over this shard's PCIe link); a value beyond
+// 65534 is stored as 0xFFFF and listed exactly with its GLOBAL entry index (ovf[0] = count, then (position lo, position hi,
+// value) triples, at most ovf_cap of them).
+__global__ __launch_bounds__(256) void place_columns_narrow_kernel(const unsigned long long *__restrict__ desc, const uint32_t *__restrict__ src_rows,
+                                                                   const uint32_t *__restrict__ src_vals, uint16_t *__restrict__ dst_rows, uint16_t *__restrict__ dst_vals,
+                                                                   uint32_t *__restrict__ ovf, uint32_t ovf_cap) {
+	const unsigned long long s = desc[3ull * blockIdx.x], d = desc[3ull * blockIdx.x + 1], len = desc[3ull * blockIdx.x + 2];
+	for (unsigned long long t = threadIdx.x; t < len; t += 256) {
+		const uint32_t v = src_vals[s + t];
+		dst_rows[d + t] = uint16_t(src_rows[s + t]);
+		dst_vals[d + t] = v >= 0xFFFFu ? uint16_t(0xFFFFu) : uint16_t(v);
+		if (v >= 0xFFFFu) {
+			const uint32_t at = atomicAdd(ovf, 1u);
+			if (at < ovf_cap) { ovf[1 + 3 * at] = uint32_t(d + t); ovf[2 + 3 * at] = uint32_t((d + t) >> 32); ovf[3 + 3 * at] = v; }
+		}
+	}
+}
 // local read position -> global stream ordinal: position p came from source rank s = the block [recv_off[s], recv_off[s+1])
 // it lies in, as that rank's idx[p]-th resident read
 // (every shard's resident reads are ONE contiguous range of the stream and the ranges ascend with the rank: the blocks a
@@ -396,7 +413,16 @@ struct dropest_shard {
 	};
 	std::vector<GRow> G;
 	// results: global CSC of both matrices (rows / values in the node-shared host buffer)
-	struct Mat { uint64_t ncols = 0, nnz = 0; std::vector<u64> colptr, col_barcode; const u32 *rows = nullptr, *vals = nullptr; } mat[2];
+	struct Mat {
+		uint64_t ncols = 0, nnz = 0; std::vector<u64> colptr, col_barcode;
+		const u32 *rows = nullptr, *vals = nullptr;               // 32-bit form (in the shared buffer, or widened on demand)
+		bool narrow = false;                                      // the shared buffer holds the 16-bit form
+		const uint16_t *rows16 = nullptr, *vals16 = nullptr;
+		std::vector<u64> ovf_pos; std::vector<u32> ovf_val;       // entries beyond 65534, ascending position
+		std::vector<u32> wide_rows, wide_vals; bool widened = false;
+	} mat[2];
+	bool narrow_matrix = true;                                    // option "narrow_matrix": 16-bit matrices when every gene id fits
+	dropest::DevBuf<u32> d_ovf;
 	std::vector<std::pair<u64, u64>> merged_barcodes;   // (source, target) barcode of every merged cell, ascending source
 	bool merged_pending = false;
 	void name_merged_pairs() {   // world == 1: (source id, target id) of the context -> barcodes
@@ -805,8 +831,14 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 	M.nnz = M.colptr[ncols];
 	if (M.nnz > 0xFFFFFFF0ull || local_nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
 	void *d_shared = nullptr;
-	char *host = static_cast<char *>(tr->shared_host(slot, std::max<size_t>(size_t(M.nnz), 1) * 8, &d_shared));
-	M.rows = reinterpret_cast<const u32 *>(host); M.vals = reinterpret_cast<const u32 *>(host) + M.nnz;
+	// every shard takes the same decision: the gene ids are the agreed ones (one shard: its own)
+	const bool narrow = narrow_matrix && c.narrow_possible();
+	char *host = static_cast<char *>(tr->shared_host(slot, std::max<size_t>(size_t(M.nnz), 1) * (narrow ? 4 : 8), &d_shared));
+	M.narrow = narrow; M.widened = false; M.ovf_pos.clear(); M.ovf_val.clear();
+	if (narrow) { M.rows16 = reinterpret_cast<const uint16_t *>(host); M.vals16 = reinterpret_cast<const uint16_t *>(host) + M.nnz; M.rows = M.vals = nullptr; }
+	else { M.rows = reinterpret_cast<const u32 *>(host); M.vals = reinterpret_cast<const u32 *>(host) + M.nnz; M.rows16 = M.vals16 = nullptr; }
+	constexpr u32 OVF_CAP = 1u << 16;
+	bool placed = false;
 	if (!col_cell.empty() && local_nnz) {
 		const u32 nc = u32(col_cell.size());
 		c.emit_columns_device(filtered_m, false, col_cell, col_start, local_nnz);
@@ -814,9 +846,34 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 		std::memcpy(h_desc.p, desc.data(), desc.size() * 8);
 		HIP_CHECK(hipMemcpyAsync(d_desc.p, h_desc.p, desc.size() * 8, hipMemcpyHostToDevice, c.stream));
 		const dropest_ctx::MatrixResult &R = c.mat[slot];
-		hipLaunchKernelGGL(place_columns_kernel, dim3(nc), dim3(256), 0, c.stream, d_desc.p, R.d_row.p, R.d_val.p,
-		                   static_cast<u32 *>(d_shared), static_cast<u32 *>(d_shared) + M.nnz);
+		if (narrow) {
+			d_ovf.ensure(1 + 3 * size_t(OVF_CAP));
+			HIP_CHECK(hipMemsetAsync(d_ovf.p, 0, 4, c.stream));
+			hipLaunchKernelGGL(place_columns_narrow_kernel, dim3(nc), dim3(256), 0, c.stream, d_desc.p, R.d_row.p, R.d_val.p,
+			                   static_cast<uint16_t *>(d_shared), static_cast<uint16_t *>(d_shared) + M.nnz, d_ovf.p, OVF_CAP);
+			placed = true;
+		} else
+			hipLaunchKernelGGL(place_columns_kernel, dim3(nc), dim3(256), 0, c.stream, d_desc.p, R.d_row.p, R.d_val.p,
+			                   static_cast<u32 *>(d_shared), static_cast<u32 *>(d_shared) + M.nnz);
 		HIP_CHECK(hipGetLastError());
+	}
+	if (narrow) {   // the (rare) entries beyond 16 bits of every shard, gathered on the host
+		struct Ovf { u64 pos; u32 val, pad; };
+		std::vector<Ovf> mine, all;
+		if (placed) {
+			u32 count = 0;
+			c.fetch(&count, d_ovf.p, 4);
+			if (count > OVF_CAP) throw UnsupportedError("more than 2^16 matrix entries beyond 65534 on one shard: set the shard option narrow_matrix to 0");
+			if (count) {
+				std::vector<u32> raw(3 * size_t(count));
+				c.fetch(raw.data(), d_ovf.p + 1, raw.size() * 4);
+				for (u32 i = 0; i < count; ++i) mine.push_back(Ovf{u64(raw[3 * i]) | (u64(raw[3 * i + 1]) << 32), raw[3 * i + 2], 0});
+			}
+		}
+		std::vector<size_t> cnt;
+		tr->gather_vec(mine, all, cnt);
+		std::sort(all.begin(), all.end(), [](const Ovf &a, const Ovf &b) { return a.pos < b.pos; });
+		for (const Ovf &o : all) { M.ovf_pos.push_back(o.pos); M.ovf_val.push_back(o.val); }
 	}
 }
 
@@ -1120,12 +1177,34 @@ dropest_status dropest_shard_matrix(dropest_shard *s, int filtered, uint64_t *nc
                                     const uint32_t **rowidx, const uint32_t **values, const uint64_t **col_barcodes) {
 	return guarded([&] {
 		if (!s || !ncols || !nnz) throw InvalidError("null argument");
-		const dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
+		dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
 		*ncols = M.ncols; *nnz = M.nnz;
 		if (colptr) *colptr = reinterpret_cast<const uint64_t *>(M.colptr.data());
+		if (M.narrow && (rowidx || values) && !M.widened) {   // the pass produced the 16-bit form: the 32-bit view is made here, once
+			M.wide_rows.resize(M.nnz); M.wide_vals.resize(M.nnz);
+			dropest::parallel_ranges(M.nnz, [&](size_t b, size_t e, unsigned) { for (size_t i = b; i < e; ++i) { M.wide_rows[i] = M.rows16[i]; M.wide_vals[i] = M.vals16[i]; } }, 1 << 20, 16);
+			for (size_t k = 0; k < M.ovf_pos.size(); ++k) M.wide_vals[M.ovf_pos[k]] = M.ovf_val[k];
+			M.rows = M.wide_rows.data(); M.vals = M.wide_vals.data(); M.widened = true;
+		}
 		if (rowidx) *rowidx = M.rows;
 		if (values) *values = M.vals;
 		if (col_barcodes) *col_barcodes = reinterpret_cast<const uint64_t *>(M.col_barcode.data());
+	});
+}
+
+dropest_status dropest_shard_matrix_narrow(dropest_shard *s, int filtered, uint64_t *ncols, uint64_t *nnz, const uint64_t **colptr,
+                                           const uint16_t **rowidx, const uint16_t **values, const uint64_t **col_barcodes,
+                                           uint64_t *n_overflow, const uint64_t **overflow_pos, const uint32_t **overflow_val) {
+	return guarded([&] {
+		if (!s || !ncols || !nnz || !rowidx || !values || !n_overflow || !overflow_pos || !overflow_val) throw InvalidError("null argument");
+		const dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
+		if (!M.narrow && M.nnz) throw UnsupportedError("the last step produced the 32-bit matrices (gene ids beyond 65535, or the option narrow_matrix is off)");
+		*ncols = M.ncols; *nnz = M.nnz;
+		if (colptr) *colptr = reinterpret_cast<const uint64_t *>(M.colptr.data());
+		*rowidx = M.rows16; *values = M.vals16;
+		if (col_barcodes) *col_barcodes = reinterpret_cast<const uint64_t *>(M.col_barcode.data());
+		*n_overflow = M.ovf_pos.size();
+		*overflow_pos = reinterpret_cast<const uint64_t *>(M.ovf_pos.data()); *overflow_val = M.ovf_val.data();
 	});
 }
 
@@ -1186,6 +1265,7 @@ dropest_status dropest_shard_set_option(dropest_shard *s, const char *key, int64
 		if (k == "trace") s->trace = value != 0;
 		else if (k == "force_exchange") s->force_exchange = value != 0;
 		else if (k == "reset_phase_stats") s->phases.clear();
+		else if (k == "narrow_matrix") s->narrow_matrix = value != 0;
 		else throw InvalidError("unknown shard option: " + k);
 	});
 }

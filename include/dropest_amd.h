@@ -178,6 +178,21 @@ dropest_status dropest_exclude_cell(dropest_ctx *ctx, uint64_t cell);
 dropest_status dropest_merge_cells(dropest_ctx *ctx, uint64_t source_cell, uint64_t target_cell);
 dropest_status dropest_merge_umis(dropest_ctx *ctx, uint64_t cell, uint32_t gene, uint64_t n, const uint64_t *source_umis,
                                   const uint64_t *target_umis);
+/* CellsDataContainer::add_umi_to_cell (CellsDataContainer.h:90, CellsDataContainer.cpp:356-364) on the initialised container:
+ * one more read of `umi_code` (packed as on the way in) for gene index `gene` in cell `cell` with mark bits `mark` --
+ * Gene::add_umi: a new molecule (TOTAL_UMIS_PER_CB + 1) or read_count + 1 / mark OR of the existing one; like the reference's
+ * member it touches no read counter and no chromosome statistic.  The gene index and the UMI must fit the key layout the
+ * container was initialised with (a UMI of the container's length, a gene index below the next power of two);
+ * DROPEST_ERR_UNSUPPORTED otherwise.  On a container with UMI qualities the read's quality string is added to the molecule's
+ * sums (UMI::add_read, UMI.cpp:21-34); a length other than the container's fails with the reference's message. */
+dropest_status dropest_add_umi_to_cell(dropest_ctx *ctx, uint64_t cell, uint32_t gene, uint64_t umi_code, uint32_t mark,
+                                       const uint8_t *umi_quality, uint32_t quality_length);
+/* CellsDataContainer::umi_indexer() (CellsDataContainer.h:118): the UMIs in index order -- the order of first appearance among
+ * the gene-bearing reads (Gene::add_umi -> StringIndexer::add, Gene.cpp:19), followed by the UMIs that only a merge brought in
+ * (random fills of N-UMIs: Gene.cpp:47), those in (cell id, gene index, UMI code) order of their groups (the reference appends
+ * them in the iteration order of its merge; no reference test pins that order).  Produced on demand: one pass over the resident
+ * UMI column.  umi_codes = NULL returns the count. */
+dropest_status dropest_umi_first_seen(dropest_ctx *ctx, uint64_t *n, uint64_t *umi_codes);
 
 /* UMI base qualities (ReadParameters::umi_quality, Tools/ReadParameters.h:9-50): one fixed-length string per pushed
  * read, in push order, quality_length bytes each (host memory; raw phred+33 characters as in the BAM tag).  Call after
@@ -284,6 +299,12 @@ dropest_status dropest_real_candidate_rows(dropest_ctx *ctx, uint64_t *n, uint64
 dropest_status dropest_dev_copy_device(int device, void *d_dst, const void *d_src, uint64_t bytes);
 /* Forgets the pushed reads (and all results) so that a new batch can be pushed into the same context. */
 dropest_status dropest_clear_reads(dropest_ctx *ctx);
+/* The device arrays of the reads pushed so far, for a second context that adopts them in place (dropest_push_reads_device
+ * with adopt = 1): how the C++ facade answers accessors and mutators BEFORE set_initialized, which the reference allows
+ * (its containers exist from the first add_record; Tests/TestEstimation.cpp:468-488 merges UMIs before initialising).  Valid
+ * until the next push. */
+dropest_status dropest_resident_reads(dropest_ctx *ctx, const uint64_t **d_cb, const uint64_t **d_umi, const uint32_t **d_gene,
+                                      const uint32_t **d_aux, uint64_t *n);
 /* As dropest_count_matrix_csc, but rowidx / values stay in HBM (device pointers) for a gather over RCCL;
  * colptr is a host pointer. */
 dropest_status dropest_count_matrix_device(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *ncols,
@@ -444,6 +465,12 @@ dropest_status dropest_shard_step(dropest_shard *shard);
 dropest_status dropest_shard_group_step(dropest_shard *const *shards, int32_t n);   /* one host thread per shard */
 dropest_status dropest_shard_matrix(dropest_shard *shard, int filtered, uint64_t *ncols, uint64_t *nnz, const uint64_t **colptr,
                                     const uint32_t **rowidx, const uint32_t **values, const uint64_t **col_barcodes);
+/* The same matrix in the narrow form (see dropest_count_matrix_csc_narrow): what the step writes when every gene id fits 16 bits
+ * and the shard option "narrow_matrix" is on (the default) -- each shard then puts half the bytes on its PCIe link; with it
+ * dropest_shard_matrix widens on the host on first use.  overflow_pos = GLOBAL entry indices, ascending. */
+dropest_status dropest_shard_matrix_narrow(dropest_shard *shard, int filtered, uint64_t *ncols, uint64_t *nnz, const uint64_t **colptr,
+                                           const uint16_t **rowidx, const uint16_t **values, const uint64_t **col_barcodes,
+                                           uint64_t *n_overflow, const uint64_t **overflow_pos, const uint32_t **overflow_val);
 /* (source, target) barcodes of the cells the CB merge folded, ascending source: CellsDataContainer::merge_targets by barcode */
 dropest_status dropest_shard_merged_barcodes(dropest_shard *shard, uint64_t *n, uint64_t *source, uint64_t *target);
 /* The column order of a global matrix from the all-gathered table of the real cells, as every shard computes it (host logic

@@ -208,14 +208,13 @@ static void testUmiDistributionAndCollisions() {   // CellsDataContainer.cpp:182
 	CHECK(adj.estimate_adjusted_gene_expression(1000) < size_t(1300));
 }
 
-static void testUMIMerge() {   // Tests/TestEstimation.cpp:468-488 (here the container is initialised first: the mutators act on the built state)
+static void testUMIMerge() {   // Tests/TestEstimation.cpp:468-488, statement by statement: merge_umis BEFORE set_initialized
 	Fixture f;
 	CellsDataContainer container(f.real_cb_strat, f.umi_merge_strat, f.any_mark);
 	container.add_record(read_info("AAATTAGGTCCA", "AAACCT", "Gene1"));
 	container.add_record(read_info("AAATTAGGTCCA", "CCCCCT", "Gene1"));
 	container.add_record(read_info("AAATTAGGTCCA", "AAATTN", "Gene1"));
 	container.add_record(read_info("AAATTAGGTCCA", "ACCCCT", "Gene1"));
-	container.set_initialized();
 	CellsDataContainer::s_s_hash_t merge_targets;
 	merge_targets["AAACCT"] = "CCCCCT";
 	merge_targets["AAATTN"] = "GGGGGG";
@@ -227,6 +226,57 @@ static void testUMIMerge() {   // Tests/TestEstimation.cpp:468-488 (here the con
 	CHECK_EQ(g.at("Gene1").at("GGGGGG"), size_t(1));
 	CHECK_EQ(g.at("Gene1").at("ACCCCT"), size_t(1));
 	CHECK_THROWS(container.merge_umis(0, container.gene_indexer().get_index("Gene1"), merge_targets), std::runtime_error);   // sources are gone
+	// more reads may still arrive, and the initialisation keeps what was merged before it
+	container.add_record(read_info("AAATTAGGTCCA", "TTTTTT", "Gene1"));
+	container.add_record(read_info("CCCTTAGGTCCA", "ACCCCT", "Gene2"));
+	container.set_initialized();
+	g = by_gene(container.cell(0));
+	CHECK_EQ(g.at("Gene1").size(), size_t(4));
+	CHECK_EQ(g.at("Gene1").at("CCCCCT"), size_t(2));
+	CHECK_EQ(g.at("Gene1").at("GGGGGG"), size_t(1));
+	CHECK_EQ(g.at("Gene1").at("TTTTTT"), size_t(1));
+	CHECK_EQ(container.total_cells_number(), size_t(2));
+}
+
+static void testBoundaryLeftovers() {   // CellsDataContainer.h:90 add_umi_to_cell, :107 Cell &cell(size_t), :118 umi_indexer()
+	Fixture f;
+	CellsDataContainer container(f.real_cb_strat, f.umi_merge_strat, f.any_mark);
+	container.add_record(read_info("AAATTAGGTCCA", "AAACCT", "Gene1"));
+	container.add_record(read_info("AAATTAGGTCCA", "CCCCCT", "Gene2"));
+	container.add_record(read_info("CCCTTAGGTCCA", "AAACCT", "Gene2"));
+	container.add_record(read_info("CCCTTAGGTCCA", "GGGCCT", ""));           // no gene: its UMI never reaches the indexer
+	container.add_record(read_info("CCCTTAGGTCCA", "TTTCCT", "Gene1"));
+	container.set_initialized();
+	const StringIndexer &ui = container.umi_indexer();
+	CHECK_EQ(ui.values().size(), size_t(3));
+	CHECK_EQ(ui.get_value(0), std::string("AAACCT")); CHECK_EQ(ui.get_value(1), std::string("CCCCCT")); CHECK_EQ(ui.get_value(2), std::string("TTTCCT"));
+	CHECK_EQ(ui.get_index("CCCCCT"), size_t(1));
+	CHECK_THROWS(ui.get_index("GGGCCT"), std::out_of_range);
+	// add_umi_to_cell: a second read of an existing molecule, then a new molecule
+	const int umis_before = container.cell(1).stat(Stats::TOTAL_UMIS_PER_CB), reads_before = container.cell(1).stat(Stats::TOTAL_READS_PER_CB);
+	container.add_umi_to_cell(1, read_info("ignored", "TTTCCT", "Gene1", "", Mark(Mark::HAS_INTRONS)));
+	auto g = by_gene(container.cell(1));
+	CHECK_EQ(g.at("Gene1").at("TTTCCT"), size_t(2));
+	CHECK_EQ(container.cell(1).stat(Stats::TOTAL_UMIS_PER_CB), umis_before);
+	container.add_umi_to_cell(1, read_info("ignored", "CCCCCT", "Gene1"));
+	g = by_gene(container.cell(1));
+	CHECK_EQ(g.at("Gene1").size(), size_t(2));
+	CHECK_EQ(g.at("Gene1").at("CCCCCT"), size_t(1));
+	CHECK_EQ(container.cell(1).stat(Stats::TOTAL_UMIS_PER_CB), umis_before + 1);
+	CHECK_EQ(container.cell(1).stat(Stats::TOTAL_READS_PER_CB), reads_before);   // the member touches no read counter (CellsDataContainer.cpp:356-364)
+	for (auto const &m : container.cell(1).molecules()) {
+		if (m.gene == "Gene1" && m.umi == "TTTCCT") {
+			CHECK(m.mark.check(Mark::HAS_INTRONS)); CHECK(m.mark.check(Mark::HAS_EXONS));
+			CHECK_EQ(m.sum_quality.size(), size_t(6));                      // the fixture's reads carry their UMI as the quality string
+			if (m.sum_quality.size() == 6) { CHECK_EQ(m.sum_quality[0], unsigned(2 * 'T')); CHECK_EQ(m.sum_quality[3], unsigned(2 * 'C')); }
+		}
+		if (m.gene == "Gene1" && m.umi == "CCCCCT" && m.sum_quality.size() == 6) { CHECK_EQ(m.sum_quality[0], unsigned('C')); CHECK_EQ(m.sum_quality[5], unsigned('T')); }
+	}
+	CHECK_THROWS(container.add_umi_to_cell(1, ReadInfo(Tools::ReadParameters("ignored", "CCCCCT", "", "CCC"), "Gene1", "", Mark(Mark::HAS_EXONS))), std::runtime_error);   // "Wrong quality length: 3, expected: 6" (UMI.cpp:26-28)
+	CHECK_THROWS(container.add_umi_to_cell(7, read_info("ignored", "CCCCCT", "Gene1")), std::out_of_range);
+	Cell &ref = container.cell(1);           // the non-const overload
+	CHECK_EQ(ref.barcode(), std::string("CCCTTAGGTCCA"));
+	CHECK_EQ(&container.cell(1), &ref);
 }
 
 static void testMergeAndExcludeCells() {   // CellsDataContainer::merge_cells / exclude_cell (:90-109), as the strategies call them
@@ -375,6 +425,7 @@ int main(int argc, char **argv) {
 		testUmiDistributionAndCollisions();
 		testPoissonMerge();
 		testUMIMerge();
+		testBoundaryLeftovers();
 		testMergeAndExcludeCells();
 		testShardedContainer();
 		testWideKeyContainer();

@@ -156,8 +156,18 @@ def test_key_wider_than_64_bits_is_refused_loudly():
 
 
 @pytest.mark.parametrize("poisson", [False, True])
+@pytest.mark.parametrize("n_parts", [5, 6, 8])
+def test_whitelists_of_more_than_four_parts(n_parts, poisson, tmp_path):
+    """The reference's const-length whitelist files have one part per line and no limit on the lines
+    (ConstLengthBarcodesParser.cpp:50-68); beyond the four parts the device kernel is built for the neighbour search runs on
+    the host (merge_host.h: search_merge_candidates_host), literally as the reference runs it."""
+    for seed in range(3):
+        test_random_whitelist_merges(100 * n_parts + seed, poisson, tmp_path, force_parts=n_parts)
+
+
+@pytest.mark.parametrize("poisson", [False, True])
 @pytest.mark.parametrize("seed", range(10))
-def test_random_whitelist_merges(seed, poisson, tmp_path):
+def test_random_whitelist_merges(seed, poisson, tmp_path, force_parts=None):
     """Random small whitelists (inDrop-style two lines, variable first-part length allowed) and barcodes that are exact,
     mutated (substitution / insertion / deletion -> different length) or carry an N: stresses the neighbour search,
     the tie replay (min_merge_fraction 0 half of the time) and the sequential merge application."""
@@ -165,13 +175,15 @@ def test_random_whitelist_merges(seed, poisson, tmp_path):
     rc = {"A": "T", "C": "G", "G": "C", "T": "A"}
     def rnd(L):
         return "".join(rng.choice(list("ACGT"), L))
-    const_kind = bool(rng.integers(0, 2))
+    const_kind = bool(rng.integers(0, 2)) or force_parts is not None
     l1 = int(rng.integers(3, 7)); l2 = int(rng.integers(5, 9))
+    if force_parts:
+        l1, l2 = 3, 3
     p1 = sorted({rnd(l1 if const_kind else int(rng.integers(l1, l1 + 2))) for _ in range(int(rng.integers(3, 9)))})
     p2 = sorted({rnd(l2) for _ in range(int(rng.integers(3, 10)))})
     lines = [p1, p2]
-    if const_kind and seed % 3 != 1:   # const-length files may have any number of lines: one, three or four parts too
-        n_parts = int(rng.choice([1, 3, 4]))
+    if force_parts or (const_kind and seed % 3 != 1):   # const-length files may have any number of lines: one, three or four parts too
+        n_parts = force_parts or int(rng.choice([1, 3, 4]))
         lines = ([p1] if n_parts == 1 else
                  [p1, p2] + [sorted({rnd(int(rng.integers(2, 5)) if k == 0 else 3) for _ in range(int(rng.integers(2, 6)))}) for k in range(n_parts - 2)])
         for k in range(2, len(lines)):     # one length per line
@@ -184,6 +196,8 @@ def test_random_whitelist_merges(seed, poisson, tmp_path):
         real = [a + b for a in real for b in part]
     rng.shuffle(real)
     real = real[:max(2, len(real) // 2)]
+    if force_parts:
+        real = real[:400]
 
     def mutate(s):
         k = rng.integers(0, 5)
