@@ -250,6 +250,7 @@ struct dropest_ctx {
 	dropest::DevBuf<u32> hot_slot;
 	u32 n_hot = 0;
 	dropest::CbTable table{};
+	uint64_t forced_table_capacity = 0;      // a pass whose table came out too full rebuilds it larger (this pass only)
 	u32 n_cells = 0;
 	dropest::DevBuf<u64> cell_cb;
 	dropest::DevBuf<u32> cell_first;

@@ -190,6 +190,7 @@ void dropest_ctx::concat_chunks() {
 }
 
 void dropest_ctx::free_results() {
+	HostStage hs(this, "reset");
 	invalidate_prefetch();
 	initialized = merged = ingested = external_merge_done = false;
 	reseed_rng();    // a second pass over the same reads reproduces the first
@@ -207,7 +208,7 @@ static constexpr u32 GENE_CHR_CAP = 1u << 20;   // genes beyond this id fall bac
 
 void dropest_ctx::build_cb_table() {
 	const u32 n = u32(n_reads);
-	uint64_t cap = cfg.cb_table_capacity;
+	uint64_t cap = forced_table_capacity ? forced_table_capacity : cfg.cb_table_capacity;
 	uint64_t sample_min = uint64_t(1) << 22;
 	if (const char *e = getenv("DROPEST_CB_SAMPLE_MIN")) sample_min = uint64_t(std::max(1ll, atoll(e)));   // tests: the sampled sizing and the hot list on small streams
 	if (cap == 0 && n_reads >= sample_min && !getenv("DROPEST_CB_NO_SAMPLE")) {
@@ -269,6 +270,16 @@ void dropest_ctx::build_cb_table() {
 		if (lazy_stats)   // the plan's statistics: every 256th read (the exact ones come with build_keys)
 			hipLaunchKernelGGL(ingest_sample_stats_kernel, dim3(std::min<u32>(div_up(div_up(n, 256u), 256), 1024u)), dim3(256), 0, stream, d_umi, d_gene, d_aux, n, 256u, d_ingest.p);
 		if (n_hot && attempt == 0 && cap < (1ull << 31)) {
+			// the hot list needs 128 KB of dynamic LDS in one workgroup: a device (or partition mode) that does not grant it takes the
+			// plain kernel instead of failing the pass
+			const int want = int(size_t(CB_HOT_LDS) * 16);
+			bool granted = true;
+			for (const void *k : {reinterpret_cast<const void *>(cb_insert_hot_kernel<true, false>), reinterpret_cast<const void *>(cb_insert_hot_kernel<false, false>),
+			                      reinterpret_cast<const void *>(cb_insert_hot_kernel<true>), reinterpret_cast<const void *>(cb_insert_hot_kernel<false>)})
+				if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess) { (void)hipGetLastError(); granted = false; }
+			if (!granted) n_hot = 0;
+		}
+		if (n_hot && attempt == 0 && cap < (1ull << 31)) {
 			// the hot barcodes take their slots first; one workgroup of 1024 threads per CU with the 128 KB LDS table
 			hipLaunchKernelGGL(cb_hot_preinsert_kernel, dim3(div_up(n_hot, 256)), dim3(256), 0, stream, hot_key.p, n_hot, table, hot_slot.p, &d_ingest.p->overflow);
 			HIP_CHECK(hipGetLastError());
@@ -317,7 +328,7 @@ void dropest_ctx::assign_cell_ids() {
 	n_cells = total;
 	if (uint64_t(n_cells) * 10 > cap * 7)   // load factor > 0.7: rebuild larger for short probe chains
 	{
-		cfg.cb_table_capacity = cap << 2;
+		forced_table_capacity = cap << 2;   // for THIS pass only (the configuration is not touched: later passes size from their own sample)
 		build_cb_table();
 		return assign_cell_ids();
 	}
@@ -686,7 +697,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 	a.cap = SMALL_MAX; a.skip_above = SMALL_MAX;
 	{
 		const size_t lds = ss_local_lds_bytes(a.cap, 256);
-		timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB) + double(n) * 0.42 * 16, [&] {
+		timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB), [&] {   // + 16 B per molecule row, added below once n_mol is known
 			if (atomic_rank) { if (VB) hipLaunchKernelGGL((ss_local_kernel<1, true>), dim3(F2), dim3(256), lds, stream, a); else hipLaunchKernelGGL((ss_local_kernel<0, true>), dim3(F2), dim3(256), lds, stream, a); }
 			else if (VB) hipLaunchKernelGGL(ss_local_kernel<1>, dim3(F2), dim3(256), lds, stream, a);
 			else hipLaunchKernelGGL(ss_local_kernel<0>, dim3(F2), dim3(256), lds, stream, a);
@@ -734,6 +745,8 @@ bool dropest_ctx::splitter_sort_reduce() {
 	}
 	const u32 total = total_flag[0];
 	n_mol = total;
+	for (auto it = pending.rbegin(); it != pending.rend(); ++it)   // the sparse rows ss_local wrote: 16 B per molecule (profiling only)
+		if (it->name.compare(0, 10, "ss_local:k") == 0) { it->bytes += double(n_mol) * 16; break; }
 	mol_key.ensure(size_t(n_mol) + 1);
 	for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) b->ensure(size_t(n_mol) + 1);
 	SsCompactArgs c{};
@@ -1110,6 +1123,7 @@ void dropest_ctx::run_ingest() {
 	concat_chunks();
 	ingest = IngestStats{};
 	ingest.umi_clean_min = ~0ull;
+	forced_table_capacity = 0;
 	if (n_reads > 0) {
 		{ HostStage hs(this, "cb_table"); build_cb_table(); }
 		{ HostStage hs(this, "cell_ids"); assign_cell_ids(); }
@@ -1276,6 +1290,7 @@ void dropest_ctx::matrix_finish_overflow(MatrixResult &M, hipStream_t st) {
 // cm_raw on a second stream: emit + device-to-host copy start now and run under whatever the caller does next (ordering
 // the filtered cells, emitting cm); dropest_count_matrix_csc(filtered = 0) later only waits for the copy.
 void dropest_ctx::prefetch_raw_matrix(bool reads_output, bool narrow) {
+	HostStage hs(this, "prefetch:cm_raw");
 	invalidate_prefetch();
 	if (narrow && !narrow_possible()) throw UnsupportedError("gene ids beyond 65535: the narrow matrix form is not available");
 	MatrixResult &M = mat[1];

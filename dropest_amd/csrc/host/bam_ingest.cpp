@@ -14,6 +14,9 @@
 #include <stdexcept>
 #include <thread>
 #include <unordered_set>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 
 namespace Estimation {
 namespace BamProcessing {
@@ -63,13 +66,63 @@ void inflate_block(const RawBlock &b, uint8_t *out) {
 	if (crc32(crc32(0L, Z_NULL, 0), out, b.isize) != b.crc) throw std::runtime_error("Corrupt BGZF block (CRC)");
 }
 
+// Worker threads that live as long as the reader / controller: a window of records comes every few milliseconds at the rates
+// this path is built for, and creating 64 threads per window costs more than parsing it.  run(fn) executes fn(worker) on every
+// worker and returns when all are done; an exception of a worker is rethrown on the caller's thread.
+class WorkerPool {
+	std::vector<std::thread> threads;
+	std::mutex m;
+	std::condition_variable cv_go, cv_done;
+	std::function<void(unsigned)> job;
+	uint64_t generation = 0;
+	unsigned pending = 0;
+	bool stop = false;
+	std::vector<std::string> errors;
+public:
+	explicit WorkerPool(unsigned n) : errors(n) {
+		for (unsigned t = 0; t < n; ++t)
+			threads.emplace_back([this, t] {
+				uint64_t seen = 0;
+				for (;;) {
+					std::function<void(unsigned)> fn;
+					{
+						std::unique_lock<std::mutex> lk(m);
+						cv_go.wait(lk, [&] { return stop || generation != seen; });
+						if (stop) return;
+						seen = generation; fn = job;
+					}
+					try { fn(t); } catch (const std::exception &e) { errors[t] = e.what(); } catch (...) { errors[t] = "unknown error"; }
+					{ std::lock_guard<std::mutex> lk(m); if (--pending == 0) cv_done.notify_all(); }
+				}
+			});
+	}
+	~WorkerPool() {
+		{ std::lock_guard<std::mutex> lk(m); stop = true; }
+		cv_go.notify_all();
+		for (auto &t : threads) t.join();
+	}
+	unsigned size() const { return unsigned(threads.size()); }
+	void run(const std::function<void(unsigned)> &fn) {
+		{
+			std::lock_guard<std::mutex> lk(m);
+			job = fn; pending = unsigned(threads.size()); ++generation;
+			for (auto &e : errors) e.clear();
+		}
+		cv_go.notify_all();
+		std::unique_lock<std::mutex> lk(m);
+		cv_done.wait(lk, [&] { return pending == 0; });
+		for (auto const &e : errors) if (!e.empty()) throw std::runtime_error(e);
+	}
+};
+
 }  // namespace
 
 struct BamReader::Impl {
 	std::string path;
 	FILE *f = nullptr;
 	unsigned threads = 1;
-	static constexpr size_t BATCH_BLOCKS = 512;        // <= 32 MB of BAM per batch
+	static constexpr size_t BATCH_BLOCKS = 512;        // <= 32 MB of BAM per batch (a window of ~2e5 records; the workers are persistent: a dispatch costs microseconds)
+	std::unique_ptr<WorkerPool> pool;                  // inflate workers (only touched by the one batch loader running at a time)
 	static constexpr size_t HEADROOM = 1 << 20;
 	// Decompressed windows live in a few recycled buffers (a fresh 32 MB allocation per batch would spend more time in
 	// page faults than the inflate takes).  A batch leaves HEADROOM bytes free in front: the unconsumed tail of the
@@ -96,17 +149,14 @@ struct BamReader::Impl {
 		for (size_t i = 0; i < blocks.size(); ++i) off[i + 1] = off[i] + blocks[i].isize;
 		out.need(off.back());
 		out.size = off.back();
-		const unsigned nt = unsigned(std::min<size_t>(threads, std::max<size_t>(1, blocks.size() / 8)));
-		std::vector<std::thread> pool;
-		std::vector<std::string> errors(nt);
 		uint8_t *base = out.p.get();
-		for (unsigned t = 0; t < nt; ++t)
-			pool.emplace_back([&, t] {
-				try { for (size_t i = t; i < blocks.size(); i += nt) inflate_block(blocks[i], base + off[i]); }
-				catch (const std::exception &e) { errors[t] = e.what(); }
-			});
-		for (auto &th : pool) th.join();
-		for (auto const &e : errors) if (!e.empty()) throw std::runtime_error(e + ": " + path);
+		if (!pool) pool.reset(new WorkerPool(std::max(1u, threads)));
+		const unsigned nt = pool->size();
+		std::atomic<size_t> next_block{0};            // blocks differ in cost: taken one at a time
+		try {
+			pool->run([&](unsigned) { for (size_t i; (i = next_block.fetch_add(1)) < blocks.size();) inflate_block(blocks[i], base + off[i]); });
+		} catch (const std::exception &e) { throw std::runtime_error(std::string(e.what()) + ": " + path); }
+		(void)nt;
 		return out;
 	}
 	Buf take_spare() {
@@ -275,6 +325,47 @@ bool BamRecord::get_string_tag(const std::string &tag, std::string_view &value, 
 	return false;
 }
 
+void BamRecord::get_string_tags(const uint16_t *wanted, int n_wanted, std::string_view *values, bool *found) const {
+	for (int k = 0; k < n_wanted; ++k) found[k] = false;
+	bool closed[16] = {false};   // a tag met with a numeric type counts as absent, and later records of the same name are not looked at
+	size_t o = 0;
+	while (o + 3 <= tags_size) {
+		const uint16_t name = uint16_t(tags[o] | (tags[o + 1] << 8));
+		const char type = char(tags[o + 2]);
+		o += 3;
+		size_t len = 0;
+		bool text = false;
+		switch (type) {
+			case 'A': case 'c': case 'C': len = 1; break;
+			case 's': case 'S': len = 2; break;
+			case 'i': case 'I': case 'f': len = 4; break;
+			case 'Z': case 'H': { const void *e = std::memchr(tags + o, 0, tags_size - o); if (!e) return; len = size_t(static_cast<const uint8_t *>(e) - (tags + o)) + 1; text = true; break; }
+			case 'B': {
+				if (o + 5 > tags_size) return;
+				const char sub = char(tags[o]);
+				const uint32_t cnt = le32(tags + o + 1);
+				const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+				len = 5 + size_t(cnt) * w;
+				break;
+			}
+			default: return;   // unknown type: cannot skip safely
+		}
+		if (o + len > tags_size) return;
+		for (int k = 0; k < n_wanted && k < 16; ++k) {
+			if (wanted[k] != name || !wanted[k] || found[k] || closed[k]) continue;
+			if (text) { values[k] = std::string_view(reinterpret_cast<const char *>(tags + o), len - 1); found[k] = true; }
+			else if (type == 'A') { values[k] = std::string_view(reinterpret_cast<const char *>(tags + o), 1); found[k] = true; }
+			else {
+				closed[k] = true;
+				static std::atomic<bool> warned{false};
+				if (!warned.exchange(true))
+					std::fprintf(stderr, "WARNING: BAM tag %c%c has the numeric type '%c' where a string (Z) is expected; records with it are handled as if the tag were absent\n", char(name & 0xFF), char(name >> 8), type);
+			}
+		}
+		o += len;
+	}
+}
+
 bool BamRecord::get_string_tag(const std::string &tag, std::string &value, char *type_out) const {
 	std::string_view v;
 	if (!get_string_tag(tag, v, type_out)) return false;
@@ -351,6 +442,9 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 		const uint8_t *data = nullptr;
 		std::vector<uint32_t> offsets;
 		std::vector<Parsed> parsed;
+		auto tag16 = [](const std::string &t) { return t.size() == 2 ? uint16_t(uint8_t(t[0]) | (uint8_t(t[1]) << 8)) : uint16_t(0); };
+		const uint16_t wanted_tags[6] = {tag16(_tags.cell_barcode), tag16(_tags.umi), tag16(_tags.cell_barcode_quality), tag16(_tags.umi_quality),
+		                                 tag16(_tags.gene), tag16(_tags.read_type)};
 		// one record -> Parsed; runs on the worker threads (reads `data`, writes only its own slot)
 		auto parse_one = [&](const uint8_t *at, Parsed &out) {
 			BamRecord al;
@@ -362,11 +456,16 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			r.ref_id = al.ref_id;
 			const std::string &chr_name = refs[size_t(al.ref_id)];
 			bool pass_quality = true;
+			// every tag the record may be asked for, in one walk over its aux data
+			enum { T_CB, T_UMI, T_CBQ, T_UMIQ, T_GENE, T_TYPE, T_N };
+			std::string_view tv[T_N]; bool tf[T_N];
+			al.get_string_tags(wanted_tags, T_N, tv, tf);
 			if (_filled_bam) {                                            // FilledBamParamsParser.cpp:12-40
 				std::string_view cbq, umiq;
-				if (!al.get_string_tag(_tags.cell_barcode, r.cb) || !al.get_string_tag(_tags.umi, r.umi)) { out.status = CANT_PARSE; return; }
-				al.get_string_tag(_tags.cell_barcode_quality, cbq);
-				al.get_string_tag(_tags.umi_quality, umiq);
+				if (!tf[T_CB] || !tf[T_UMI]) { out.status = CANT_PARSE; return; }
+				r.cb = tv[T_CB]; r.umi = tv[T_UMI];
+				if (tf[T_CBQ]) cbq = tv[T_CBQ];
+				if (tf[T_UMIQ]) umiq = tv[T_UMIQ];
 				if (r.cb.empty() || r.umi.empty()) { out.status = CANT_PARSE; return; }       // ReadParameters ctor throws -> false
 				if (_min_barcode_phred > quality_offset) {                 // ReadParameters::check_quality (:118-136)
 					for (char q : cbq) pass_quality &= q >= char(_min_barcode_phred);
@@ -399,12 +498,14 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				if (bits & 2) mark.add(UMI::Mark::HAS_EXONS);
 				if (bits & 4) mark.add(UMI::Mark::HAS_INTRONS);
 				r.gene = out.gene;
-			} else if (!al.get_string_tag(_tags.gene, r.gene)) {
+			} else if (!tf[T_GENE]) {
 				r.gene = std::string_view();
 				mark.add(UMI::Mark::HAS_NOT_ANNOTATED);
 			} else {
+				r.gene = tv[T_GENE];
 				std::string_view read_type;
-				if (_tags.read_type.empty() || !al.get_string_tag(_tags.read_type, read_type)) mark.add(UMI::Mark::HAS_EXONS);
+				if (tf[T_TYPE]) read_type = tv[T_TYPE];
+				if (_tags.read_type.empty() || !tf[T_TYPE]) mark.add(UMI::Mark::HAS_EXONS);
 				else if (read_type == _tags.intronic_read_value) mark.add(UMI::Mark::HAS_INTRONS);
 				else if (!_tags.intergenic_read_value.empty() && read_type == _tags.intergenic_read_value) mark.add(UMI::Mark::HAS_NOT_ANNOTATED);
 				else mark.add(UMI::Mark::HAS_EXONS);
@@ -421,10 +522,97 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 		};
 		using clk = std::chrono::steady_clock;
 		auto since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+		// ---- fast path: the workers write packed records, the caller's thread only resolves what is NEW ----
+		// A record needs the caller's thread when it brings something the dictionaries have not seen: a gene name that is not in the
+		// gene dictionary yet, a chromosome no counted read touched before, a barcode / UMI that does not pack into a 2-bit code (N).
+		// After the first windows that is a handful of records per million.  Everything else -- parsing, packing, gene look-up,
+		// the chromosome index, the compaction of the accepted records -- runs on the workers; the container receives whole arrays
+		// (CellsDataContainer::add_records_packed).  Order of every dictionary operation = file order, as add_record read by read.
+		struct Need { uint32_t idx; uint8_t what; std::string_view cb, umi, gene; uint64_t gene_hash; std::string gene_owned; /* -g: the annotation's answer lives in the worker's scratch record */ };
+		enum : uint8_t { NEED_CB = 1, NEED_UMI = 2, NEED_GENE = 4, NEED_CHR = 8 };
+		WorkerPool workers(nthreads);
+		const unsigned NT = workers.size();
+		std::vector<std::vector<Need>> needs(NT);
+		std::vector<uint64_t> w_cb, w_umi, o_cb, o_umi;
+		std::vector<uint32_t> w_gene, w_aux, o_gene, o_aux;
+		std::vector<int32_t> w_ref;
+		std::vector<uint8_t> w_status;
+		struct Tally { size_t total = 0, cant = 0, low = 0, ok = 0; bool quality = false; char pad[64]; };
+		std::vector<Tally> tally(NT);
+		auto fast_window = [&](size_t n) -> bool {
+			if (w_cb.size() < n) { w_cb.resize(n); w_umi.resize(n); w_gene.resize(n); w_aux.resize(n); w_ref.resize(n); w_status.resize(n); }   // (never shrunk: no refill per window)
+			workers.run([&](unsigned t) {
+				Parsed tmp;
+				std::vector<Need> &mine = needs[t];
+				mine.clear();
+				Tally tl;
+				for (size_t i = n * t / NT; i < n * (t + 1) / NT; ++i) {
+					parse_one(data + offsets[i], tmp);
+					w_status[i] = tmp.status;
+					switch (tmp.status) {
+						case SKIP: continue;
+						case CANT_PARSE_NO_COUNT: ++tl.cant; continue;
+						case CANT_PARSE: ++tl.total; ++tl.cant; continue;
+						case LOW_QUALITY: ++tl.total; ++tl.low; continue;
+						default: break;
+					}
+					++tl.total; ++tl.ok;
+					const CellsDataContainer::ParsedRead &r = tmp.r;
+					if (r.umi_quality_length) tl.quality = true;
+					const bool has_gene = !r.gene.empty();
+					uint8_t what = 0;
+					w_cb[i] = r.cb_code; if (!r.cb_code) what |= NEED_CB;
+					if (has_gene) {
+						w_umi[i] = r.umi_code; if (!r.umi_code) what |= NEED_UMI;
+						if (r.gene_id >= 0) w_gene[i] = uint32_t(r.gene_id); else what |= NEED_GENE;
+					} else { w_umi[i] = 1; w_gene[i] = DROPEST_NO_GENE; }
+					const bool touches = !has_gene || (r.mark & (UMI::Mark::HAS_EXONS | UMI::Mark::HAS_INTRONS));
+					w_ref[i] = touches ? r.ref_id : -1;
+					if (touches && container.chromosome_of_ref(r.ref_id) < 0) what |= NEED_CHR;
+					w_aux[i] = uint32_t(r.mark) << 16;
+					if (what) mine.push_back(Need{uint32_t(i), what, r.cb, r.umi, r.gene, r.gene_hash, (what & NEED_GENE) && !_genes.is_empty() ? std::string(r.gene) : std::string()});
+				}
+				tally[t] = tl;
+			});
+			for (unsigned t = 0; t < NT; ++t) if (tally[t].quality) return false;   // UMI quality strings: the record-by-record path keeps them
+			// in file order: what the dictionaries have not seen (per record: barcode, then UMI, gene, chromosome -- the order of add_record)
+			for (unsigned t = 0; t < NT; ++t)
+				for (const Need &nd : needs[t]) {
+					if (nd.what & NEED_CB) w_cb[nd.idx] = container.intern_barcode(std::string(nd.cb));
+					if (nd.what & NEED_UMI) w_umi[nd.idx] = container.intern_umi(std::string(nd.umi));
+					if (nd.what & NEED_GENE) w_gene[nd.idx] = container.intern_gene(nd.gene_owned.empty() ? nd.gene : std::string_view(nd.gene_owned), nd.gene_hash);
+					if (nd.what & NEED_CHR) container.intern_chromosome_of_ref(w_ref[nd.idx]);
+				}
+			size_t start[257] = {0};
+			for (unsigned t = 0; t < NT; ++t) start[t + 1] = start[t] + tally[t].ok;
+			const size_t n_ok = start[NT];
+			if (o_cb.size() < n_ok) { o_cb.resize(n_ok); o_umi.resize(n_ok); o_gene.resize(n_ok); o_aux.resize(n_ok); }
+			workers.run([&](unsigned t) {
+				size_t at = start[t];
+				for (size_t i = n * t / NT; i < n * (t + 1) / NT; ++i) {
+					if (w_status[i] != OK) continue;
+					o_cb[at] = w_cb[i]; o_umi[at] = w_umi[i]; o_gene[at] = w_gene[i];
+					o_aux[at] = w_aux[i] | (w_ref[i] >= 0 ? uint32_t(container.chromosome_of_ref(w_ref[i])) : 0u);
+					++at;
+				}
+			});
+			container.add_records_packed(o_cb.data(), o_umi.data(), o_gene.data(), o_aux.data(), n_ok);
+			for (unsigned t = 0; t < NT; ++t) {
+				_counters.total_reads += tally[t].total; _counters.cant_parse += tally[t].cant; _counters.low_quality += tally[t].low; _counters.saved += tally[t].ok;
+			}
+			return true;
+		};
+		static const bool force_slow = getenv("DROPEST_BAM_RECORD_BY_RECORD") != nullptr;   // tests: the two paths agree
 		for (;;) {
 			auto t_wait = clk::now();
 			if (!reader.next_window(data, offsets)) break;
 			_counters.wait_ms += since(t_wait);
+			if (!_params_from_files && !force_slow && NT <= 256 && container.bulk_ingest_possible()) {
+				auto t_fast = clk::now();
+				const bool done = fast_window(offsets.size());
+				_counters.parse_ms += since(t_fast);
+				if (done) continue;
+			}
 			auto t_parse = clk::now();
 			const size_t n = offsets.size();
 			parsed.resize(n);

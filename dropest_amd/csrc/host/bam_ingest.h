@@ -49,6 +49,9 @@ struct BamRecord {
 	// Z / A / H tags as text (BamAlignment::GetTag(tag, std::string&)); false if absent or numeric
 	bool get_string_tag(const std::string &tag, std::string &value, char *type = nullptr) const;
 	bool get_string_tag(const std::string &tag, std::string_view &value, char *type = nullptr) const;   // view into `tags`
+	// several tags in ONE walk over the aux data (the walk is most of a record's parse time when six tags are asked for one by
+	// one): wanted[k] = the two tag letters packed as lo | hi << 8, 0 = not asked; same answers as get_string_tag per tag
+	void get_string_tags(const uint16_t *wanted, int n_wanted, std::string_view *values, bool *found) const;
 };
 
 class BamReader {

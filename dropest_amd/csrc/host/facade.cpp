@@ -273,6 +273,37 @@ int64_t CellsDataContainer::lookup_gene(uint64_t gene_hash, std::string_view nam
 	return -1;
 }
 
+uint32_t CellsDataContainer::intern_gene(std::string_view name, uint64_t hash) {   // the gene branch of add_record(ParsedRead)
+	auto it = _gene_by_hash.find(hash);
+	if (it != _gene_by_hash.end() && _gene_indexer.get_value(it->second) == name) return it->second;
+	const uint32_t gid = uint32_t(_gene_indexer.add(std::string(name)));
+	if (it == _gene_by_hash.end()) _gene_by_hash.emplace(hash, gid);   // (a colliding name keeps taking the slow path)
+	return gid;
+}
+
+uint32_t CellsDataContainer::intern_chromosome_of_ref(int32_t ref_id) {
+	if (ref_id < 0 || size_t(ref_id) >= _ref_names.size()) throw std::out_of_range("reference id outside set_reference_names");
+	int32_t &slot = _ref_chr[size_t(ref_id)];
+	if (slot < 0) slot = int32_t(_chr_indexer.add(_ref_names[size_t(ref_id)]));
+	if (slot > 0xFFFF) throw std::runtime_error("more than 65536 chromosome names");
+	return uint32_t(slot);
+}
+
+void CellsDataContainer::add_records_packed(const uint64_t *cb, const uint64_t *umi, const uint32_t *gene, const uint32_t *aux, size_t n) {
+	if (_is_initialized) throw std::runtime_error("Container is already initialized");
+	if (!bulk_ingest_possible()) throw std::runtime_error("add_records_packed: the container is sharded or carries UMI qualities (use add_record)");
+	_preview_valid = false;
+	if (!n) return;
+	flush();                                   // whatever add_record collected comes first
+	if (_umi_quality_length == size_t(-1))     // the first gene-bearing read fixes the quality length: 0 (no quality strings)
+		for (size_t i = 0; i < n; ++i) if (gene[i] != DROPEST_NO_GENE) { _umi_quality_length = 0; _qual_pending = 0; break; }
+	send_side_strings(_ctx);
+	for (size_t at = 0; at < n; at += BATCH * 8) {
+		const size_t m = std::min(n - at, BATCH * 8);
+		check(dropest_push_reads(_ctx, cb + at, umi + at, gene + at, aux + at, m));
+	}
+}
+
 void CellsDataContainer::set_reference_names(const std::vector<std::string> &names) {
 	_ref_names = names;
 	_ref_chr.assign(names.size(), -1);

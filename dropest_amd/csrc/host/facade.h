@@ -373,6 +373,20 @@ public:
 	// index of a gene that is ALREADY in the dictionary, -1 otherwise; safe to call from several threads as long as no
 	// add_record runs at the same time
 	int64_t lookup_gene(uint64_t gene_hash, std::string_view name) const;
+	// ---- bulk ingest (the BAM reader's fast path) ----------------------------------------------------------------------
+	// add_record read by read costs a handful of vector appends and dictionary look-ups per read on ONE thread; a caller that
+	// parses records on many threads resolves the dictionaries itself -- the few reads per window that bring something new
+	// (an unseen gene name or chromosome, a barcode / UMI with N), in stream order, through the intern_* members -- and hands
+	// whole arrays of packed records over.  Same effect as add_record(ParsedRead) read by read, in the same order.
+	bool bulk_ingest_possible() const { return !sharded() && !_is_initialized && (_umi_quality_length == size_t(-1) || _umi_quality_length == 0); }
+	uint64_t intern_barcode(const std::string &s) { return encode(s, _side_cb); }
+	uint64_t intern_umi(const std::string &s) { return encode(s, _side_umi); }
+	uint32_t intern_gene(std::string_view name, uint64_t hash);
+	int32_t chromosome_of_ref(int32_t ref_id) const { return _ref_chr[size_t(ref_id)]; }        // -1: no read touched it yet
+	uint32_t intern_chromosome_of_ref(int32_t ref_id);
+	// n records, every id resolved (gene: dictionary index or DROPEST_NO_GENE; aux = chromosome index | mark << 16); the reads
+	// carry no UMI qualities (quality length 0, like add_record of a read with an empty quality string)
+	void add_records_packed(const uint64_t *cb, const uint64_t *umi, const uint32_t *gene, const uint32_t *aux, size_t n);
 	static bool pack_code(std::string_view s, uint64_t &code);
 	static uint64_t hash_name(std::string_view s);
 	void set_initialized();

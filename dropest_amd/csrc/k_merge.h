@@ -291,14 +291,17 @@ inline void wl_neighbours_launch(const WlArgs &a, uint32_t n_blocks, size_t lds,
 // CLOSE neighbours (a real barcode: itself at distance 0; a sequencing error of one: its origin at distance 1).  So, once per
 // whitelist, every possible value of a part gets a row: how many entries lie at distance 0, 1, 2, 3 and which (WL_TAB_LIST of
 // them at most).  A base whose levels end at total distance <= WL_TAB_DMAX with few candidates is then decided by one THREAD
-// from two rows; everything else -- parts of another length, N, rows that overflowed, levels beyond WL_TAB_DMAX, more than
-// WL_TAB_FOUND candidates -- is left, exactly as before, to wl_neighbours_kernel (cand_count = WL_TAB_TODO marks them).
+// from two rows; everything else -- parts of another length, N, a needed distance group that did not fit its row, levels beyond
+// WL_TAB_DMAX, more than WL_TAB_FOUND candidates -- is left, exactly as before, to wl_neighbours_kernel (cand_count =
+// WL_TAB_TODO marks them).
 constexpr int WL_TAB_DMAX = 3, WL_TAB_LIST = 60, WL_TAB_MAX_LEN = 9, WL_TAB_FOUND = 12;
 constexpr uint32_t WL_TAB_TODO = 0xFFFFFFFFu;
-struct WlTabRow { uint16_t cnt[WL_TAB_DMAX + 1]; uint16_t list[WL_TAB_LIST]; };   // cnt[0] == 0xFFFF: unusable (overflow)
+struct WlTabRow { uint16_t cnt[WL_TAB_DMAX + 1]; uint16_t list[WL_TAB_LIST]; };   // group d is listed iff cnt[0] + .. + cnt[d] <= WL_TAB_LIST
 static_assert(sizeof(WlTabRow) == 128, "row layout");
 
-// one wave per value v of a part of length L: distances to the np entries, those within WL_TAB_DMAX grouped by distance
+// one wave per value v of a part of length L: exact counts of the entries at distance 0 .. WL_TAB_DMAX, and the entries
+// themselves grouped by distance for as many of the CLOSEST groups as fit the row (a short part has dozens of entries within
+// three edits of anything: its rows then list distances 0 .. 2 only, and a base that needs the third group takes the full search)
 __global__ __launch_bounds__(256) void wl_table_build_kernel(const unsigned long long *__restrict__ part_code, uint32_t np, int L, uint32_t n_values,
                                                              WlTabRow *__restrict__ rows) {
 	__shared__ uint32_t s_cnt[4][WL_TAB_DMAX + 1];
@@ -316,21 +319,27 @@ __global__ __launch_bounds__(256) void wl_table_build_kernel(const unsigned long
 		const unsigned long long pc = part_code[i];
 		if (pc == ~0ull) continue;                                                  // (tables are only built for clean whitelists)
 		const uint32_t d = wl_edit_distance_code(peq, L, pc & ((1ull << 58) - 1ull), int(pc >> 58));
-		if (d > uint32_t(WL_TAB_DMAX)) continue;
-		atomicAdd(&s_cnt[w][d], 1u);
-		const uint32_t at = atomicAdd(&s_n[w], 1u);
-		if (at < uint32_t(WL_TAB_LIST)) s_item[w][at] = (d << 16) | i;
+		if (d <= uint32_t(WL_TAB_DMAX)) atomicAdd(&s_cnt[w][d], 1u);
+	}
+	__builtin_amdgcn_s_waitcnt(0xC07F);
+	__builtin_amdgcn_wave_barrier();
+	uint32_t keep_d = 0, run = 0;                  // groups 0 .. keep_d - 1 fit the list
+	for (uint32_t d = 0; d <= uint32_t(WL_TAB_DMAX); ++d) { run += s_cnt[w][d]; if (run > uint32_t(WL_TAB_LIST)) break; keep_d = d + 1; }
+	for (uint32_t i = lane; i < np && keep_d; i += 64) {
+		const unsigned long long pc = part_code[i];
+		if (pc == ~0ull) continue;
+		const uint32_t d = wl_edit_distance_code(peq, L, pc & ((1ull << 58) - 1ull), int(pc >> 58));
+		if (d < keep_d) s_item[w][atomicAdd(&s_n[w], 1u)] = (d << 16) | i;
 	}
 	__builtin_amdgcn_s_waitcnt(0xC07F);
 	__builtin_amdgcn_wave_barrier();
 	WlTabRow &row = rows[v];
 	const uint32_t n = s_n[w];
-	if (n > uint32_t(WL_TAB_LIST)) { if (lane == 0) row.cnt[0] = 0xFFFFu; return; }
-	if (lane <= uint32_t(WL_TAB_DMAX)) row.cnt[lane] = uint16_t(s_cnt[w][lane]);
+	if (lane <= uint32_t(WL_TAB_DMAX)) row.cnt[lane] = uint16_t(s_cnt[w][lane] > 0xFFFEu ? 0xFFFEu : s_cnt[w][lane]);
 	// grouped by distance, ascending entry index inside a group (any order would do: candidates form a set)
 	if (lane == 0) {
 		uint32_t at = 0;
-		for (uint32_t d = 0; d <= uint32_t(WL_TAB_DMAX); ++d) {
+		for (uint32_t d = 0; d < keep_d; ++d) {
 			const uint32_t first = at;
 			for (uint32_t k = 0; k < n; ++k) if ((s_item[w][k] >> 16) == d) row.list[at++] = uint16_t(s_item[w][k]);
 			for (uint32_t x = first + 1; x < at; ++x) {   // insertion sort of a handful of indices
@@ -379,7 +388,6 @@ __global__ __launch_bounds__(256) void wl_table_search_kernel(WlArgs a, WlTabArg
 			v = (v << 2) | code;
 		}
 		row[p] = t.rows[p] + v;
-		if (row[p]->cnt[0] == 0xFFFFu) return todo();
 		uint32_t run = 0;
 		for (int d = 0; d <= WL_TAB_DMAX; ++d) { start[p][d] = run; run += row[p]->cnt[d]; }
 		start[p][WL_TAB_DMAX + 1] = run;
@@ -403,9 +411,14 @@ __global__ __launch_bounds__(256) void wl_table_search_kernel(WlArgs a, WlTabArg
 		last_level = level;
 		for (uint32_t tup = 0; tup < n_tuples; ++tup) {
 			uint32_t dd[P], cc[P], sum = 0, x = tup, combos = 1;
+			bool empty = false;
 #pragma unroll
-			for (uint32_t p = 0; p < P; ++p) { dd[p] = x % (WL_TAB_DMAX + 1); x /= WL_TAB_DMAX + 1; sum += dd[p]; cc[p] = row[p]->cnt[dd[p]]; combos *= cc[p]; }
-			if (sum != level || combos == 0) continue;
+			for (uint32_t p = 0; p < P; ++p) { dd[p] = x % (WL_TAB_DMAX + 1); x /= WL_TAB_DMAX + 1; sum += dd[p]; cc[p] = row[p]->cnt[dd[p]]; empty |= cc[p] == 0; }
+			if (sum != level || empty) continue;
+#pragma unroll
+			for (uint32_t p = 0; p < P; ++p) if (start[p][dd[p] + 1] > uint32_t(WL_TAB_LIST)) return todo();   // a group the row does not list
+#pragma unroll
+			for (uint32_t p = 0; p < P; ++p) combos *= cc[p];   // every factor <= WL_TAB_LIST now
 			for (uint32_t q = 0; q < combos; ++q) {
 				unsigned long long code = 1ull;
 				uint32_t r = q;

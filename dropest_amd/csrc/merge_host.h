@@ -250,6 +250,7 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 				wl_neighbours_launch(a, F, S.lds, stream);
 			});
 		}
+		a.base_list = nullptr;   // (S.args outlives this call: the tie replay launches from it)
 		u32 total = 0;
 		fetch(&total, scalars.p, 4);
 		if (total <= flat_cap) {
@@ -408,6 +409,7 @@ std::vector<std::vector<u32>> dropest_ctx::replay_candidate_orders(const MergeUn
 	WlArgs a2 = S.args;
 	a2.bases = d_rb.p; a2.n_bases = R; a2.cand_count = d_c2.p; a2.cand_level = d_l2.p; a2.cand_off = d_o2.p;
 	a2.flat_cell = d_f2.p; a2.flat_umis = d_u2.p; a2.flat_ridx = d_r2.p; a2.flat_cap = R * u32(WL_CAND_CAP); a2.dist_dump = d_dump.p;
+	a2.base_list = nullptr;   // block r works on replay base r (the list of the main search is gone)
 	wl_neighbours_launch(a2, R, S.lds, stream);
 	HIP_CHECK(hipGetLastError());
 	std::vector<uint8_t> dump(size_t(R) * ntot);

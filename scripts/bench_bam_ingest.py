@@ -31,13 +31,20 @@ for i in range(n):
     recs.append(bw.record(int(aux[i]) & 0xFFFF, i, "A00000:1:HXXXX:1:1101:%d:%d" % (i, i), seq="ACGT" * 24 + "AC", tags=tags))
 tmp = tempfile.mkdtemp()
 bam = os.path.join(tmp, "synth.bam")
-bw.write_bam(bam, refs, recs)
+copies = int(os.environ.get("COPIES", "16"))
+bw.write_bam(bam, refs, recs, repeat=copies)
 print("wrote %s: %d reads, %.1f MB, %.1f s" % (bam, n, os.path.getsize(bam) / 1e6, time.time() - t0), file=sys.stderr)
-for threads in (1, 4, 16):
-    res = subprocess.run([os.path.join(ROOT, "tests", "cpp", "bam_to_counts"), os.path.join(tmp, "out"), "filled", "20", "100", "-",
-                          str(threads), bam], capture_output=True, text=True)
-    if res.returncode:
-        raise SystemExit(res.stderr)
-    st = json.loads(res.stdout.strip().splitlines()[-1])
-    st.update(threads=threads, ingest_mreads_per_s=round(n / st["ingest_ms"] / 1e3, 3), bam_mb=round(os.path.getsize(bam) / 1e6, 1))
-    print(json.dumps(st))
+# (the records are written `copies` times into ONE file -- bam_writer.write_bam(repeat=...) -- so that a rate of tens of Mreads/s
+# is measured over seconds, and inflate / parse / push pipeline as they do on a real multi-gigabyte BAM)
+thread_counts = [int(x) for x in os.environ.get("THREADS", "1,4,16,64").split(",")]
+for threads in thread_counts:
+    for env, label in (({}, "bulk"), ({"DROPEST_BAM_RECORD_BY_RECORD": "1"}, "record-by-record")):
+        if label != "bulk" and threads not in (16,):
+            continue
+        res = subprocess.run([os.path.join(ROOT, "tests", "cpp", "bam_to_counts"), os.path.join(tmp, "out"), "filled", "20", "100", "-",
+                              str(threads), bam], capture_output=True, text=True, env=dict(os.environ, **env))
+        if res.returncode:
+            raise SystemExit(res.stderr)
+        st = json.loads(res.stdout.strip().splitlines()[-1])
+        st.update(threads=threads, path=label, reads=n * copies, ingest_mreads_per_s=round(n * copies / st["ingest_ms"] / 1e3, 3), bam_mb=round(os.path.getsize(bam) / 1e6, 1))
+        print(json.dumps(st), flush=True)

@@ -47,11 +47,22 @@ def record(ref_id, pos, name, flag=0, mapq=255, seq="ACGT" * 10, tags=(), cigar=
     return struct.pack("<I", len(body)) + body
 
 
-def write_bam(path, refs, records, block=0xFF00, header_text="@HD\tVN:1.6\tSO:unsorted\n"):
+def write_bam(path, refs, records, block=0xFF00, header_text="@HD\tVN:1.6\tSO:unsorted\n", repeat=1):
     text = header_text + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, ln) for n, ln in refs)
     raw = b"BAM\x01" + struct.pack("<I", len(text)) + text.encode() + struct.pack("<I", len(refs))
     for n, ln in refs:
         raw += struct.pack("<I", len(n) + 1) + n.encode() + b"\x00" + struct.pack("<I", ln)
+    if repeat > 1:      # the records `repeat` times over (benchmarks): the header in blocks of its own, the records' blocks written again and again
+        body = b"".join(records)
+        blocks = [_bgzf_block(body[o:o + block]) for o in range(0, len(body), block)]
+        with open(path, "wb") as f:
+            for o in range(0, len(raw), block):
+                f.write(_bgzf_block(raw[o:o + block]))
+            for _ in range(repeat):
+                for b in blocks:
+                    f.write(b)
+            f.write(_bgzf_block(b""))
+        return
     raw += b"".join(records)
     with open(path, "wb") as f:
         for o in range(0, len(raw), block):

@@ -44,6 +44,7 @@ def _oracle(reads, min_before, min_after, wl=None):
 
 def _run(tmp_path, mode, bams, min_before, min_after, wl="-", threads=3, env=None):
     build_facade()
+    os.makedirs(str(tmp_path), exist_ok=True)
     out = str(tmp_path / "res")
     res = subprocess.run([TOOL, out, mode, str(min_before), str(min_after), wl, str(threads)] + bams, capture_output=True, text=True, timeout=300,
                          env=dict(os.environ, **(env or {})))
@@ -92,6 +93,12 @@ def test_filled_bam_tags(tmp_path):
     assert 0 < stats["cant_parse"] < n_skipped                 # missing CB tag + unknown chromosome; unmapped / secondary are not counted
     chr_frames = d["reads_per_chr_per_cells"]
     assert len(chr_frames["Intron"].value) > 0 and len(chr_frames["Intergenic"].value) > 0
+    # the record-by-record path (add_record per read on the caller's thread) and the bulk path (workers write packed records, the
+    # caller resolves only what is new to the dictionaries) give the same container; several worker counts
+    for env, threads in (({"DROPEST_BAM_RECORD_BY_RECORD": "1"}, 3), ({}, 1), ({}, 7)):
+        got2, cells2, stats2, _ = _run(tmp_path / ("again%d%d" % (threads, len(env))), "filled", [b1, b2], 5, 10, threads=threads, env=env)
+        assert cells2 == cells and got2 == got
+        assert {k: stats2[k] for k in ("total_reads", "cant_parse", "low_quality", "saved")} == {k: stats[k] for k in ("total_reads", "cant_parse", "low_quality", "saved")}
 
 
 def test_read_name_encoding_and_whitelist_merge(tmp_path):
