@@ -325,7 +325,9 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
             a2a = shard_phases.get("all_to_all")
             if a2a and a2a["ms"] > 0:
                 links = max(1, world - 1)      # xGMI is point-to-point: one link per peer
-                exchange = {"bytes_out_per_gpu_per_step": a2a["bytes"] / max(1, a2a["steps"]), "ms_per_step": round(a2a["ms"] / max(1, a2a["steps"]), 3),
+                rec = shard_phases.get("exchange_record_bytes", {}).get("bytes", 28.0)
+                exchange = {"record_bytes": rec, "bytes_out_per_gpu_per_step": a2a["bytes"] / max(1, a2a["steps"]), "ms_per_step": round(a2a["ms"] / max(1, a2a["steps"]), 3),
+                            "bytes_a_gpu_would_put_on_its_links_at_world_N": {str(N): reads_per_gpu * rec * (N - 1) / N for N in (2, 4, 8)},
                             "GB_per_s_per_gpu": round(a2a["bytes"] / a2a["ms"] / 1e6, 1), "GB_per_s_per_link": round(a2a["bytes"] / a2a["ms"] / 1e6 / links, 1),
                             "links": links, "transport": "RCCL grouped ncclSend/ncclRecv over xGMI" if world > 1 else "RCCL to itself (one GPU)"}
         cpu = None
@@ -336,7 +338,7 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
             ingest = push_rates(stream, local_rank, int(min(args.push_sample, total_reads)),
                                 dict(merge_kind=capi.MERGE_NONE, min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"]))
         cm = out[0]
-        narrow = len(cm) == 5
+        narrow = len(cm) in (5, 6)    # (context: 5 arrays, sharded runner: 6 with the column barcodes)
         line = {
             "metric": "Mreads/s processed to final count matrix", "value": round(value, 2), "unit": "Mreads/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3),
@@ -352,7 +354,7 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d%s" % (world, " (sharded runner, forced exchange)" if force_sharded else ""),
                        "cm_nnz": int(len(cm[1])), "cm_raw_nnz": raw_nnz, "filtered_cells": int(len(out[2])), "sort_layout": get_layout(),
                        "matrix_form": ("CSC in pinned host memory, u32 colptr + u16 row index + u16 value + exact overflow list (%d + %d entries beyond 65534)"
-                                       % (len(cm[3]), len(out[1][3]))) if narrow else "CSC in pinned host memory, u32 colptr + u32 row index + u32 value"},
+                                       % (len(cm[-2]), len(out[1][-2]))) if narrow else "CSC in pinned host memory, u32 colptr + u32 row index + u32 value"},
             "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "host_ingest": ingest, "step_ms": step_ms, "kernels_ms_per_step": kernels,
             "kernel_table": "separate pass of %d steps after the timed region, events on every launch" % table_steps,
             "host_stage_wall_ms_per_step": host_stages,

@@ -178,6 +178,7 @@ def lib():
         "dropest_reserve_reads": (C.c_int, [vp, C.c_uint64]),
         "dropest_shard_group_step": (C.c_int, [vp, C.c_int32]),
         "dropest_shard_matrix": (C.c_int, [vp, C.c_int, u64p, u64p, P(vp), P(vp), P(vp), P(vp)]),
+        "dropest_shard_matrix_narrow": (C.c_int, [vp, C.c_int, u64p, u64p, P(vp), P(vp), P(vp), P(vp), u64p, P(vp), P(vp)]),
         "dropest_shard_merged_barcodes": (C.c_int, [vp, u64p, vp, vp]),
         "dropest_shard_phase_stats": (C.c_int, [vp, P(C.c_uint32), vp]),
         "dropest_shard_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),

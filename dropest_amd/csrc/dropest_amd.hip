@@ -2326,8 +2326,8 @@ static void partition_by_owner_on(int device, hipStream_t st, const u64 *d_cb, c
 		hipLaunchKernelGGL(owner_hist_kernel, dim3(nblocks), dim3(OP_T), 0, st, d_cb, n, n_parts, tpb, hist);
 		hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, st, hist, nblocks, row_total);
 		hipLaunchKernelGGL(rs_scan_totals_kernel<256>, dim3(1), dim3(256), 0, st, row_total, digit_base);
-		hipLaunchKernelGGL(owner_scatter_kernel, dim3(nblocks), dim3(OP_T), 0, st, d_cb, d_umi, d_gene, d_aux, n, n_parts, owner_bits, tpb, hist, digit_base,
-		                   d_out_cb, d_out_umi, d_out_gene, d_out_aux, d_out_idx);
+		hipLaunchKernelGGL(owner_scatter_kernel<false>, dim3(nblocks), dim3(OP_T), 0, st, d_cb, d_umi, d_gene, d_aux, n, n_parts, owner_bits, tpb, hist, digit_base,
+		                   d_out_cb, d_out_umi, d_out_gene, d_out_aux, d_out_idx, ExchangePack{});
 		HIP_CHECK(hipGetLastError());
 		std::vector<u32> totals(RS_RADIX);
 		HIP_CHECK(hipMemcpyAsync(totals.data(), row_total, RS_RADIX * 4, hipMemcpyDeviceToHost, st));

@@ -3,6 +3,10 @@
 #include <atomic>
 
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -26,42 +30,50 @@ namespace {
 inline uint16_t le16(const uint8_t *p) { return uint16_t(p[0] | (p[1] << 8)); }
 inline uint32_t le32(const uint8_t *p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24); }
 
-struct RawBlock { std::vector<uint8_t> cdata; uint32_t isize = 0, crc = 0; };
+struct RawBlock { const uint8_t *cdata = nullptr; size_t clen = 0; uint32_t isize = 0, crc = 0; };
 
-// one BGZF block (SAMv1 §4.1): gzip member, FEXTRA with subfield 'B','C' = total block size - 1
-bool read_block(FILE *f, RawBlock &b, const std::string &path) {
-	uint8_t h[12];
-	const size_t got = fread(h, 1, 12, f);
-	if (got == 0) return false;
-	if (got != 12 || h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("Not a BGZF/BAM file: " + path);
+// one BGZF block (SAMv1 §4.1): gzip member, FEXTRA with subfield 'B','C' = total block size - 1.  The file is MAPPED: a block
+// is described in place (header walk only), the inflating workers read the compressed bytes straight from the page cache --
+// a serial fread of every block into a vector of its own capped the reader at ~2 GB/s of BAM whatever the thread count.
+bool read_block(const uint8_t *map, size_t size, size_t &at, RawBlock &b, const std::string &path) {
+	if (at >= size) return false;
+	if (size - at < 12) throw std::runtime_error("Not a BGZF/BAM file: " + path);
+	const uint8_t *h = map + at;
+	if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) throw std::runtime_error("Not a BGZF/BAM file: " + path);
 	const uint16_t xlen = le16(h + 10);
-	std::vector<uint8_t> extra(xlen);
-	if (fread(extra.data(), 1, xlen, f) != xlen) throw std::runtime_error("Truncated BGZF header: " + path);
+	if (size - at < size_t(12) + xlen) throw std::runtime_error("Truncated BGZF header: " + path);
+	const uint8_t *extra = h + 12;
 	int bsize = -1;
-	for (size_t o = 0; o + 4 <= extra.size();) {
-		const uint16_t slen = le16(extra.data() + o + 2);
-		if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= extra.size()) bsize = le16(extra.data() + o + 4);
+	for (size_t o = 0; o + 4 <= xlen;) {
+		const uint16_t slen = le16(extra + o + 2);
+		if (extra[o] == 'B' && extra[o + 1] == 'C' && slen == 2 && o + 6 <= xlen) bsize = le16(extra + o + 4);
 		o += 4u + slen;
 	}
 	if (bsize < 0) throw std::runtime_error("BGZF block without BC subfield: " + path);
 	const long clen = long(bsize) - long(xlen) - 19;
 	if (clen < 0) throw std::runtime_error("Corrupt BGZF block size: " + path);
-	b.cdata.resize(size_t(clen));
-	uint8_t tail[8];
-	if (fread(b.cdata.data(), 1, size_t(clen), f) != size_t(clen) || fread(tail, 1, 8, f) != 8) throw std::runtime_error("Truncated BGZF block: " + path);
+	if (size - at < size_t(12) + xlen + size_t(clen) + 8) throw std::runtime_error("Truncated BGZF block: " + path);
+	b.cdata = extra + xlen; b.clen = size_t(clen);
+	const uint8_t *tail = b.cdata + clen;
 	b.crc = le32(tail); b.isize = le32(tail + 4);
+	at += size_t(12) + xlen + size_t(clen) + 8;
 	return true;
 }
 
 void inflate_block(const RawBlock &b, uint8_t *out) {
 	if (b.isize == 0) return;
-	z_stream zs;
-	std::memset(&zs, 0, sizeof(zs));
-	if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("zlib: inflateInit2 failed");
-	zs.next_in = const_cast<Bytef *>(b.cdata.data()); zs.avail_in = uInt(b.cdata.size());
+	// one inflate state per thread, reset per block (inflateInit2 allocates its 40 KB window every time)
+	struct State { z_stream zs; bool ready = false; ~State() { if (ready) inflateEnd(&zs); } };
+	static thread_local State st;
+	z_stream &zs = st.zs;
+	if (!st.ready) {
+		std::memset(&zs, 0, sizeof(zs));
+		if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("zlib: inflateInit2 failed");
+		st.ready = true;
+	} else if (inflateReset2(&zs, -15) != Z_OK) throw std::runtime_error("zlib: inflateReset2 failed");
+	zs.next_in = const_cast<Bytef *>(b.cdata); zs.avail_in = uInt(b.clen);
 	zs.next_out = out; zs.avail_out = b.isize;
 	const int rc = inflate(&zs, Z_FINISH);
-	inflateEnd(&zs);
 	if (rc != Z_STREAM_END || zs.total_out != b.isize) throw std::runtime_error("Corrupt BGZF block (inflate)");
 	if (crc32(crc32(0L, Z_NULL, 0), out, b.isize) != b.crc) throw std::runtime_error("Corrupt BGZF block (CRC)");
 }
@@ -119,7 +131,8 @@ public:
 
 struct BamReader::Impl {
 	std::string path;
-	FILE *f = nullptr;
+	const uint8_t *map = nullptr;                      // the whole file, mapped read-only
+	size_t map_size = 0, map_at = 0;
 	unsigned threads = 1;
 	static constexpr size_t BATCH_BLOCKS = 512;        // <= 32 MB of BAM per batch (a window of ~2e5 records; the workers are persistent: a dispatch costs microseconds)
 	std::unique_ptr<WorkerPool> pool;                  // inflate workers (only touched by the one batch loader running at a time)
@@ -137,14 +150,17 @@ struct BamReader::Impl {
 	std::string text;
 	const uint8_t *bytes() const { return cur.p.get(); }
 
+	double load_ms = 0, discover_ms = 0; size_t n_batches = 0;   // diagnostics (DROPEST_BAM_TRACE)
 	Buf load_batch(Buf out) {
+		const auto t_begin = std::chrono::steady_clock::now();
 		std::vector<RawBlock> blocks;
 		blocks.reserve(BATCH_BLOCKS);
 		while (blocks.size() < BATCH_BLOCKS) {
 			RawBlock b;
-			if (!read_block(f, b, path)) { file_done = true; break; }
+			if (!read_block(map, map_size, map_at, b, path)) { file_done = true; break; }
 			blocks.push_back(std::move(b));
 		}
+		discover_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 		std::vector<size_t> off(blocks.size() + 1, HEADROOM);
 		for (size_t i = 0; i < blocks.size(); ++i) off[i + 1] = off[i] + blocks[i].isize;
 		out.need(off.back());
@@ -157,6 +173,7 @@ struct BamReader::Impl {
 			pool->run([&](unsigned) { for (size_t i; (i = next_block.fetch_add(1)) < blocks.size();) inflate_block(blocks[i], base + off[i]); });
 		} catch (const std::exception &e) { throw std::runtime_error(std::string(e.what()) + ": " + path); }
 		(void)nt;
+		load_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); ++n_batches;
 		return out;
 	}
 	Buf take_spare() {
@@ -198,8 +215,17 @@ struct BamReader::Impl {
 BamReader::BamReader(const std::string &path, unsigned threads) : impl(new Impl()) {
 	impl->path = path;
 	impl->threads = threads ? threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-	impl->f = fopen(path.c_str(), "rb");
-	if (!impl->f) { delete impl; throw std::runtime_error("Can't open BAM file: " + path); }
+	{
+		const int fd = open(path.c_str(), O_RDONLY);
+		struct stat sb;
+		if (fd < 0 || fstat(fd, &sb) != 0) { if (fd >= 0) close(fd); delete impl; throw std::runtime_error("Can't open BAM file: " + path); }
+		impl->map_size = size_t(sb.st_size);
+		void *m = impl->map_size ? mmap(nullptr, impl->map_size, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+		close(fd);
+		if (impl->map_size && m == MAP_FAILED) { delete impl; throw std::runtime_error("Can't open BAM file: " + path); }
+		impl->map = static_cast<const uint8_t *>(m);
+		if (m) (void)madvise(m, impl->map_size, MADV_SEQUENTIAL);
+	}
 	try {
 		Impl &m = *impl;
 		if (!m.ensure(12) || std::memcmp(m.bytes() + m.pos, "BAM\1", 4) != 0) throw std::runtime_error("Can't open BAM file: " + path);
@@ -217,13 +243,15 @@ BamReader::BamReader(const std::string &path, unsigned threads) : impl(new Impl(
 		}
 	} catch (...) {
 		if (impl->ahead.valid()) impl->ahead.wait();
-		fclose(impl->f); delete impl; throw;
+		if (impl->map) munmap(const_cast<uint8_t *>(impl->map), impl->map_size);
+		delete impl; throw;
 	}
 }
 
 BamReader::~BamReader() {
 	if (impl->ahead.valid()) { try { impl->ahead.get(); } catch (...) {} }
-	if (impl->f) fclose(impl->f);
+	if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] %zu batches, load %.1f ms (block discovery %.1f ms), %u inflate threads\n", impl->n_batches, impl->load_ms, impl->discover_ms, impl->threads);
+	if (impl->map) munmap(const_cast<uint8_t *>(impl->map), impl->map_size);
 	delete impl;
 }
 

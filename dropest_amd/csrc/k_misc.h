@@ -325,12 +325,76 @@ __global__ __launch_bounds__(OP_T) void owner_hist_kernel(const unsigned long lo
 	__syncthreads();
 	if (threadIdx.x < 256) hist[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
+// The same histogram, and on the way the widths of the four fields over ALL resident reads (the sharded pass packs a read into
+// 12 bytes for the exchange when they allow it): stats[0] largest barcode code, [1] largest UMI code, [2] 1 + largest gene id,
+// [3] largest chromosome id, [4] OR of the aux bits above chromosome and 3-bit mark (must be zero).
+__global__ __launch_bounds__(OP_T) void owner_hist_stats_kernel(const unsigned long long *__restrict__ cb, const unsigned long long *__restrict__ umi,
+                                                                const uint32_t *__restrict__ gene, const uint32_t *__restrict__ aux, uint32_t n, uint32_t n_parts,
+                                                                uint32_t tiles_per_block, uint32_t *__restrict__ hist /* [256][gridDim.x] */,
+                                                                unsigned long long *__restrict__ stats) {
+	__shared__ uint32_t h[256];
+	if (threadIdx.x < 256) h[threadIdx.x] = 0;
+	__syncthreads();
+	const uint64_t begin = uint64_t(blockIdx.x) * tiles_per_block * OP_TILE;
+	uint64_t end = begin + uint64_t(tiles_per_block) * OP_TILE;
+	if (end > n) end = n;
+	unsigned long long cmax = 0, umax = 0, gmax = 0, chmax = 0, hi = 0;
+	for (uint64_t i = begin + threadIdx.x; i < end; i += OP_T) {
+		const unsigned long long k = cb[i], u = umi[i];
+		const uint32_t g = gene[i], a = aux[i];
+		atomicAdd(&h[mix64(k) % n_parts], 1u);
+		cmax = k > cmax ? k : cmax; umax = u > umax ? u : umax;
+		if (g != 0xFFFFFFFFu && (unsigned long long)g + 1 > gmax) gmax = (unsigned long long)g + 1;
+		const unsigned long long ch = a & 0xFFFFu;
+		chmax = ch > chmax ? ch : chmax;
+		hi |= a >> 19;
+	}
+	cmax = wave_reduce_max_u64(cmax); umax = wave_reduce_max_u64(umax); gmax = wave_reduce_max_u64(gmax); chmax = wave_reduce_max_u64(chmax);
+	hi = wave_reduce_or_u64(hi);
+	if (lane_id() == 0) {
+		if (cmax) atomicMax(&stats[0], cmax);
+		if (umax) atomicMax(&stats[1], umax);
+		if (gmax) atomicMax(&stats[2], gmax);
+		if (chmax) atomicMax(&stats[3], chmax);
+		if (hi) atomicOr(&stats[4], hi);
+	}
+	__syncthreads();
+	if (threadIdx.x < 256) hist[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
+}
+
+// A read packed for the exchange: w0 = barcode code | UMI code << cb_bits (64 bits), w1 = gene | mark << gene_bits | chromosome
+// << (gene_bits + 3) (32 bits; "no gene" = all ones of the gene field) -- 12 bytes where the five arrays are 28.
+struct ExchangePack { int cb_bits, gene_bits; };
+__device__ inline void exchange_pack(const ExchangePack &p, unsigned long long cb, unsigned long long umi, uint32_t gene, uint32_t aux, unsigned long long &w0, uint32_t &w1) {
+	const uint32_t gmask = (1u << p.gene_bits) - 1u;
+	w0 = cb | (umi << p.cb_bits);
+	w1 = (gene == 0xFFFFFFFFu ? gmask : gene) | (((aux >> 16) & 7u) << p.gene_bits) | ((aux & 0xFFFFu) << (p.gene_bits + 3));
+}
+__global__ __launch_bounds__(256) void exchange_unpack_kernel(const unsigned long long *__restrict__ w0, const uint32_t *__restrict__ w1, uint32_t n, ExchangePack p,
+                                                              unsigned long long *__restrict__ cb, unsigned long long *__restrict__ umi,
+                                                              uint32_t *__restrict__ gene, uint32_t *__restrict__ aux) {
+	const uint32_t gmask = (1u << p.gene_bits) - 1u;
+	const unsigned long long cmask = p.cb_bits >= 64 ? ~0ull : ((1ull << p.cb_bits) - 1ull);
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+		const unsigned long long a = w0[i];
+		const uint32_t b = w1[i];
+		cb[i] = a & cmask;
+		umi[i] = p.cb_bits >= 64 ? 0ull : a >> p.cb_bits;
+		const uint32_t g = b & gmask;
+		gene[i] = g == gmask ? 0xFFFFFFFFu : g;
+		aux[i] = (b >> (p.gene_bits + 3)) | (((b >> p.gene_bits) & 7u) << 16);
+	}
+}
+
+// PACKED: o_cb receives w0, o_gene receives w1 (o_umi / o_aux unused); the index array is written either way
+template <bool PACKED>
 __global__ __launch_bounds__(OP_T) void owner_scatter_kernel(const unsigned long long *__restrict__ cb, const unsigned long long *__restrict__ umi,
                                                              const uint32_t *__restrict__ gene, const uint32_t *__restrict__ aux, uint32_t n,
                                                              uint32_t n_parts, int owner_bits, uint32_t tiles_per_block,
                                                              const uint32_t *__restrict__ hist, const uint32_t *__restrict__ owner_base,
                                                              unsigned long long *__restrict__ o_cb, unsigned long long *__restrict__ o_umi,
-                                                             uint32_t *__restrict__ o_gene, uint32_t *__restrict__ o_aux, uint32_t *__restrict__ o_idx) {
+                                                             uint32_t *__restrict__ o_gene, uint32_t *__restrict__ o_aux, uint32_t *__restrict__ o_idx,
+                                                             ExchangePack pack) {
 	constexpr uint32_t WAVES = OP_T / 64;
 	__shared__ uint32_t wcnt[WAVES][256], goff[256], tcnt[256];
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
@@ -385,7 +449,12 @@ __global__ __launch_bounds__(OP_T) void owner_scatter_kernel(const unsigned long
 			const uint32_t r = t0 + lane_off + i * 64;
 			if (r >= n) continue;
 			const uint32_t dst = goff[own[i]] + wcnt[w][own[i]] + lrank[i];
-			o_cb[dst] = k[i]; o_umi[dst] = u[i]; o_gene[dst] = g[i]; o_aux[dst] = a[i]; o_idx[dst] = r;
+			if (PACKED) {
+				unsigned long long w0; uint32_t w1;
+				exchange_pack(pack, k[i], u[i], g[i], a[i], w0, w1);
+				o_cb[dst] = w0; o_gene[dst] = w1;
+			} else { o_cb[dst] = k[i]; o_umi[dst] = u[i]; o_gene[dst] = g[i]; o_aux[dst] = a[i]; }
+			o_idx[dst] = r;
 		}
 		lds_barrier();
 		if (tid < 256) goff[tid] += tcnt[tid];

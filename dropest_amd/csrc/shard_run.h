@@ -94,16 +94,32 @@ struct Transport {
 
 	template <class T>
 	void gather_vec(const std::vector<T> &mine, std::vector<T> &all, std::vector<size_t> &count) {   // variable-length host rows
-		uint64_t n = mine.size();
+		// ONE collective when every rank's rows fit a small fixed slot (the length travels in front of them) -- most of a pass's
+		// host gathers are a few hundred bytes, and a collective of staged bytes costs its latency, not its size; a second one
+		// with the padded rows only when somebody's did not fit.
+		constexpr size_t SLOT = 16384;
+		const uint64_t n = mine.size();
+		const size_t fit = (SLOT - 8) / sizeof(T);
+		std::vector<unsigned char> slot(SLOT, 0), slots(SLOT * size_t(world));
+		std::memcpy(slot.data(), &n, 8);
+		if (n && n <= fit) std::memcpy(slot.data() + 8, mine.data(), size_t(n) * sizeof(T));
+		gather_host(slot.data(), SLOT, slots.data());
 		std::vector<uint64_t> ns(size_t(world), 0);
-		gather_host(&n, 8, ns.data());
-		uint64_t mx = 1;
-		for (uint64_t x : ns) mx = std::max(mx, x);
-		std::vector<T> pad(mx), buf(size_t(mx) * size_t(world));
-		if (n) std::memcpy(pad.data(), mine.data(), size_t(n) * sizeof(T));
-		gather_host(pad.data(), size_t(mx) * sizeof(T), buf.data());
+		uint64_t mx = 0;
+		for (int p = 0; p < world; ++p) { std::memcpy(&ns[size_t(p)], slots.data() + size_t(p) * SLOT, 8); mx = std::max(mx, ns[size_t(p)]); }
 		count.assign(size_t(world), 0);
 		all.clear();
+		if (mx <= fit) {
+			for (int p = 0; p < world; ++p) {
+				count[size_t(p)] = size_t(ns[size_t(p)]);
+				const T *rows = reinterpret_cast<const T *>(slots.data() + size_t(p) * SLOT + 8);
+				all.insert(all.end(), rows, rows + ns[size_t(p)]);
+			}
+			return;
+		}
+		std::vector<T> pad(mx), buf(size_t(mx) * size_t(world));
+		if (n) std::memcpy(static_cast<void *>(pad.data()), mine.data(), size_t(n) * sizeof(T));
+		gather_host(pad.data(), size_t(mx) * sizeof(T), buf.data());
 		for (int p = 0; p < world; ++p) {
 			count[size_t(p)] = size_t(ns[size_t(p)]);
 			all.insert(all.end(), buf.begin() + size_t(p) * mx, buf.begin() + size_t(p) * mx + ns[size_t(p)]);
@@ -404,6 +420,14 @@ struct dropest_shard {
 	dropest::DevBuf<unsigned char> part_scratch;
 	std::vector<uint64_t> send_cnt, recv_cnt, recv_off, first_ord;   // first_ord[p]: first stream ordinal of rank p's range
 	bool exchanged = false;
+	// the exchange record: 12 bytes per read (w0 u64 + w1 u32, k_misc.h ExchangePack) when the field widths of ALL shards allow
+	// it, the five arrays (28 bytes) otherwise; the read's position in its source range (idx) only travels when a whole-table
+	// conversion needs it on the device (-u) -- the few positions the pass asks about otherwise are resolved by asking the source
+	dropest::DevBuf<u64> p_w0, x_w0;
+	dropest::DevBuf<u32> p_w1, x_w1;
+	bool packed = false, idx_exchanged = false, allow_packed = true;
+	int rec_bytes = 28;
+	std::vector<uint64_t> send_off;                                  // first read of every destination's block in p_idx
 	// global table of the real cells (identical on every shard after a step)
 	struct GRow {
 		u64 barcode, first_global;
@@ -466,6 +490,7 @@ struct dropest_shard {
 dropest::OrdinalMap dropest_shard::ordinal_map() const {
 	using namespace dropest;
 	OrdinalMap m{};
+	if (exchanged && !idx_exchanged) throw InvalidError("internal: device ordinals asked for, but the read positions did not travel with this exchange");
 	m.idx = exchanged ? x_idx.p : nullptr;
 	m.world = exchanged ? u32(world) : 1u;
 	if (exchanged) { for (int p = 0; p <= world; ++p) m.recv_off[p] = recv_off[size_t(p)]; for (int p = 0; p < world; ++p) m.first_ord[p] = first_ord[size_t(p)]; }
@@ -476,8 +501,46 @@ dropest::OrdinalMap dropest_shard::ordinal_map() const {
 std::vector<dropest::u64> dropest_shard::global_ordinals(const std::vector<u32> &local_pos) {
 	using namespace dropest;
 	std::vector<u64> out(local_pos.size());
-	if (local_pos.empty()) return out;
 	dropest_ctx &c = *ctx;
+	if (exchanged && !idx_exchanged) {
+		// COLLECTIVE.  The positions did not travel: a read at local position p came from source s = the block [recv_off[s],
+		// recv_off[s + 1]) it lies in, as the (p - recv_off[s])-th read s sent here -- s still holds the index array of its stable
+		// partition and answers.  A pass asks for a few thousand positions (first reads of the real cells, tie candidates of the
+		// N-UMI merge), against 4 bytes for every read of the stream if the array travelled.
+		struct Query { u32 src, dst, q, tag; };
+		struct Answer { u32 dst, tag, idx, pad; };
+		std::vector<Query> mine, all;
+		for (size_t i = 0; i < local_pos.size(); ++i) {
+			const u32 p = local_pos[i];
+			if (p == 0xFFFFFFFFu) { out[i] = ~0ull; continue; }
+			u32 src = 0;
+			while (src + 1 < u32(world) && p >= recv_off[size_t(src) + 1]) ++src;
+			mine.push_back(Query{src, u32(rank), u32(p - recv_off[src]), u32(i)});
+		}
+		std::vector<size_t> cnt;
+		tr->gather_vec(mine, all, cnt);
+		std::vector<u32> pos; std::vector<Answer> my_ans, all_ans;
+		for (const Query &q : all) if (int(q.src) == rank) { pos.push_back(u32(send_off[q.dst] + q.q)); my_ans.push_back(Answer{q.dst, q.tag, 0, 0}); }
+		if (!pos.empty()) {
+			const u32 n = u32(pos.size());
+			DevBuf<u32> d_pos, d_out;
+			d_pos.alloc(n); d_out.alloc(n);
+			HIP_CHECK(hipMemcpyAsync(d_pos.p, pos.data(), size_t(n) * 4, hipMemcpyHostToDevice, c.stream));
+			hipLaunchKernelGGL(take_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, p_idx.p, d_pos.p, n, d_out.p);
+			HIP_CHECK(hipGetLastError());
+			std::vector<u32> got(n);
+			c.fetch(got.data(), d_out.p, size_t(n) * 4);
+			for (u32 k = 0; k < n; ++k) my_ans[k].idx = got[k];
+		}
+		tr->gather_vec(my_ans, all_ans, cnt);
+		// the answers of source s come back in the order its queries stood in the gathered list: rank blocks in rank order
+		size_t at = 0;
+		for (int s = 0; s < world; ++s)
+			for (size_t k = 0; k < cnt[size_t(s)]; ++k, ++at)
+				if (int(all_ans[at].dst) == rank) out[all_ans[at].tag] = first_ord[size_t(s)] + all_ans[at].idx;
+		return out;
+	}
+	if (local_pos.empty()) return out;
 	const OrdinalMap m = ordinal_map();
 	const u32 n = u32(local_pos.size());
 	DevBuf<u32> d_pos; DevBuf<u64> d_out;
@@ -489,39 +552,106 @@ std::vector<dropest::u64> dropest_shard::global_ordinals(const std::vector<u32> 
 	return out;
 }
 
-// 1-2. partition by owner (stable: reads of one owner keep stream order), one all-to-all(v) of the five arrays
+// 1-2. partition by owner (stable: reads of one owner keep stream order), one all-to-all(v).  The histogram pass also measures
+// the field widths of the resident reads; the shards agree on them (the same collective that exchanges the block sizes) and, when
+// barcode + UMI fit 64 bits and gene + mark + chromosome fit 32, every read crosses the links as 12 bytes instead of 28.
 void dropest_shard::partition_and_exchange() {
 	using namespace dropest;
 	dropest_ctx &c = *ctx;
 	const u32 n = u32(n_res);
 	send_cnt.assign(size_t(world), 0);
+	const bool want_idx = c.cfg.umi_merge_kind == DROPEST_UMI_MERGE_DIRECTIONAL;   // -u turns a whole table of positions into ordinals on the device
+	std::vector<uint64_t> all_cnt(size_t(world) * size_t(world));
+	ExchangePack pack{};
 	{
 		Phase ph(this, "partition");
-		for (DevBuf<u64> *b : {&p_cb, &p_umi}) b->ensure(std::max<size_t>(n, 1));
-		for (DevBuf<u32> *b : {&p_gene, &p_aux, &p_idx}) b->ensure(std::max<size_t>(n, 1));
 		uint64_t need = 0;
 		if (dropest_partition_scratch_bytes(n, &need) != DROPEST_OK) throw UnsupportedError("more than 2^32-2 reads per GPU");
-		part_scratch.ensure(size_t(need));
-		partition_by_owner_on(c.cfg.device, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p,
-		                      send_cnt.data(), part_scratch.p, need);
+		part_scratch.ensure(size_t(need) + 64);
+		u32 nblocks, tpb; size_t off_k1, off_hist, off_row, off_base, total;
+		partition_plan(n, nblocks, tpb, off_k1, off_hist, off_row, off_base, total);
+		char *base = reinterpret_cast<char *>(part_scratch.p);
+		u32 *hist = reinterpret_cast<u32 *>(base + off_hist), *row_total = reinterpret_cast<u32 *>(base + off_row), *digit_base = reinterpret_cast<u32 *>(base + off_base);
+		u64 *d_stats = reinterpret_cast<u64 *>(base + ((total + 7) & ~size_t(7)));
+		uint64_t stats[5] = {0, 0, 0, 0, 0};
+		std::vector<u32> totals(RS_RADIX, 0);
+		if (n) {
+			HIP_CHECK(hipMemsetAsync(d_stats, 0, 40, c.stream));
+			hipLaunchKernelGGL(owner_hist_stats_kernel, dim3(nblocks), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), tpb, hist, d_stats);
+			hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, c.stream, hist, nblocks, row_total);
+			hipLaunchKernelGGL(rs_scan_totals_kernel<256>, dim3(1), dim3(256), 0, c.stream, row_total, digit_base);
+			HIP_CHECK(hipGetLastError());
+			HIP_CHECK(hipMemcpyAsync(totals.data(), row_total, RS_RADIX * 4, hipMemcpyDeviceToHost, c.stream));
+			c.fetch(stats, d_stats, 40);
+		}
+		for (int p = 0; p < world; ++p) send_cnt[size_t(p)] = totals[size_t(p)];
+		// block sizes and field widths of everybody, in one collective
+		std::vector<uint64_t> mine(size_t(world) + 5), every((size_t(world) + 5) * size_t(world));
+		for (int p = 0; p < world; ++p) mine[size_t(p)] = send_cnt[size_t(p)];
+		for (int k = 0; k < 5; ++k) mine[size_t(world) + size_t(k)] = stats[k];
+		tr->gather_host(mine.data(), mine.size() * 8, every.data());
+		uint64_t g[5] = {0, 0, 0, 0, 0};
+		for (int p = 0; p < world; ++p) {
+			for (int q = 0; q < world; ++q) all_cnt[size_t(p) * size_t(world) + size_t(q)] = every[size_t(p) * (size_t(world) + 5) + size_t(q)];
+			for (int k = 0; k < 4; ++k) g[k] = std::max(g[k], every[size_t(p) * (size_t(world) + 5) + size_t(world) + size_t(k)]);
+			g[4] |= every[size_t(p) * (size_t(world) + 5) + size_t(world) + 4];
+		}
+		const int cb_bits = std::max(1, bit_length(g[0])), umi_bits = std::max(1, bit_length(g[1]));
+		const int gene_bits = std::max(1, bit_length(g[2])), chr_bits = std::max(1, bit_length(g[3]));
+		packed = allow_packed && !g[4] && cb_bits + umi_bits <= 64 && gene_bits + 3 + chr_bits <= 32;   // (a code with N has bit 63 set: never packed)
+		idx_exchanged = want_idx || !packed;
+		pack.cb_bits = cb_bits; pack.gene_bits = gene_bits;
+		rec_bytes = packed ? (idx_exchanged ? 16 : 12) : 28;
+		send_off.assign(size_t(world) + 1, 0);
+		for (int p = 0; p < world; ++p) send_off[size_t(p) + 1] = send_off[size_t(p)] + send_cnt[size_t(p)];
+		p_idx.ensure(std::max<size_t>(n, 1));
+		if (packed) { p_w0.ensure(std::max<size_t>(n, 1)); p_w1.ensure(std::max<size_t>(n, 1)); }
+		else {
+			for (DevBuf<u64> *b : {&p_cb, &p_umi}) b->ensure(std::max<size_t>(n, 1));
+			for (DevBuf<u32> *b : {&p_gene, &p_aux}) b->ensure(std::max<size_t>(n, 1));
+		}
+		if (n) {
+			const int owner_bits = std::max(1, bit_length(uint64_t(world - 1)));
+			if (packed) hipLaunchKernelGGL(owner_scatter_kernel<true>, dim3(nblocks), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), owner_bits, tpb, hist, digit_base,
+			                               p_w0.p, static_cast<u64 *>(nullptr), p_w1.p, static_cast<u32 *>(nullptr), p_idx.p, pack);
+			else hipLaunchKernelGGL(owner_scatter_kernel<false>, dim3(nblocks), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), owner_bits, tpb, hist, digit_base,
+			                        p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p, pack);
+			HIP_CHECK(hipGetLastError());
+		}
 	}
-	Phase ph(this, "all_to_all");
-	std::vector<uint64_t> all_cnt(size_t(world) * size_t(world));
-	tr->gather_host(send_cnt.data(), size_t(world) * 8, all_cnt.data());
-	recv_cnt.assign(size_t(world), 0); recv_off.assign(size_t(world) + 1, 0);
-	for (int p = 0; p < world; ++p) { recv_cnt[size_t(p)] = all_cnt[size_t(p) * size_t(world) + size_t(rank)]; recv_off[size_t(p) + 1] = recv_off[size_t(p)] + recv_cnt[size_t(p)]; }
-	const uint64_t n_recv = recv_off[size_t(world)];
-	if (n_recv >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads on one shard after the exchange");
-	for (DevBuf<u64> *b : {&x_cb, &x_umi}) b->ensure(std::max<size_t>(n_recv, 1));
-	for (DevBuf<u32> *b : {&x_gene, &x_aux, &x_idx}) b->ensure(std::max<size_t>(n_recv, 1));
-	const void *snd[5] = {p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p};
-	void *rcv[5] = {x_cb.p, x_umi.p, x_gene.p, x_aux.p, x_idx.p};
-	const size_t elem[5] = {8, 8, 4, 4, 4};
-	tr->exchange(5, snd, rcv, elem, send_cnt.data(), recv_cnt.data(), c.stream);
-	auto &st = phases["all_to_all"];
-	uint64_t out = 0;
-	for (int p = 0; p < world; ++p) if (p != rank) out += send_cnt[size_t(p)];
-	st.bytes += double(out) * 28;   // bytes this shard put on the links (self block excluded)
+	{
+		Phase ph(this, "all_to_all");
+		recv_cnt.assign(size_t(world), 0); recv_off.assign(size_t(world) + 1, 0);
+		for (int p = 0; p < world; ++p) { recv_cnt[size_t(p)] = all_cnt[size_t(p) * size_t(world) + size_t(rank)]; recv_off[size_t(p) + 1] = recv_off[size_t(p)] + recv_cnt[size_t(p)]; }
+		const uint64_t n_recv = recv_off[size_t(world)];
+		if (n_recv >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads on one shard after the exchange");
+		for (DevBuf<u64> *b : {&x_cb, &x_umi}) b->ensure(std::max<size_t>(n_recv, 1));
+		for (DevBuf<u32> *b : {&x_gene, &x_aux}) b->ensure(std::max<size_t>(n_recv, 1));
+		if (idx_exchanged) x_idx.ensure(std::max<size_t>(n_recv, 1));
+		if (packed) {
+			x_w0.ensure(std::max<size_t>(n_recv, 1)); x_w1.ensure(std::max<size_t>(n_recv, 1));
+			const void *snd[3] = {p_w0.p, p_w1.p, p_idx.p};
+			void *rcv[3] = {x_w0.p, x_w1.p, x_idx.p};
+			const size_t elem[3] = {8, 4, 4};
+			tr->exchange(idx_exchanged ? 3 : 2, snd, rcv, elem, send_cnt.data(), recv_cnt.data(), c.stream);
+		} else {
+			const void *snd[5] = {p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p};
+			void *rcv[5] = {x_cb.p, x_umi.p, x_gene.p, x_aux.p, x_idx.p};
+			const size_t elem[5] = {8, 8, 4, 4, 4};
+			tr->exchange(5, snd, rcv, elem, send_cnt.data(), recv_cnt.data(), c.stream);
+		}
+		auto &st = phases["all_to_all"];
+		uint64_t out = 0;
+		for (int p = 0; p < world; ++p) if (p != rank) out += send_cnt[size_t(p)];
+		st.bytes += double(out) * rec_bytes;   // bytes this shard put on the links (self block excluded)
+		phases["exchange_record_bytes"].bytes = double(rec_bytes);
+		if (packed && n_recv) {
+			Phase ph2(this, "unpack");
+			hipLaunchKernelGGL(exchange_unpack_kernel, dim3(u32(std::min<uint64_t>((n_recv + 255) / 256, 8192))), dim3(256), 0, c.stream, x_w0.p, x_w1.p, u32(n_recv), pack,
+			                   x_cb.p, x_umi.p, x_gene.p, x_aux.p);
+			HIP_CHECK(hipGetLastError());
+		}
+	}
 	exchanged = true;
 }
 
@@ -1266,6 +1396,7 @@ dropest_status dropest_shard_set_option(dropest_shard *s, const char *key, int64
 		else if (k == "force_exchange") s->force_exchange = value != 0;
 		else if (k == "reset_phase_stats") s->phases.clear();
 		else if (k == "narrow_matrix") s->narrow_matrix = value != 0;
+		else if (k == "packed_exchange") s->allow_packed = value != 0;
 		else throw InvalidError("unknown shard option: " + k);
 	});
 }

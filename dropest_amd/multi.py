@@ -84,6 +84,21 @@ class Shard:
         return (view(p, ncols.value + 1, C.c_uint64, np.uint64), view(r, nnz.value, C.c_uint32, np.uint32),
                 view(v, nnz.value, C.c_uint32, np.uint32), view(b, ncols.value, C.c_uint64, np.uint64))
 
+    def matrix_narrow(self, filtered):
+        """(colptr u64, rowidx u16, values u16, column barcodes u64, overflow_pos u64, overflow_val u32) of the GLOBAL matrix in the
+        narrow form the step wrote (dropest_shard_matrix_narrow); raises DropestError when the step produced the 32-bit form."""
+        ncols, nnz, novf = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        p, r, v, b, op, ov = (C.c_void_p() for _ in range(6))
+        self._chk(self.L.dropest_shard_matrix_narrow(self.h, int(filtered), C.byref(ncols), C.byref(nnz), C.byref(p), C.byref(r), C.byref(v), C.byref(b),
+                                                      C.byref(novf), C.byref(op), C.byref(ov)))
+
+        def view(ptr, n, ct, dt):
+            if not n or not ptr.value:
+                return np.zeros(0, dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,))
+        return (view(p, ncols.value + 1, C.c_uint64, np.uint64), view(r, nnz.value, C.c_uint16, np.uint16), view(v, nnz.value, C.c_uint16, np.uint16),
+                view(b, ncols.value, C.c_uint64, np.uint64), view(op, novf.value, C.c_uint64, np.uint64), view(ov, novf.value, C.c_uint32, np.uint32))
+
     def merged_barcodes(self):
         n = C.c_uint64()
         self._chk(self.L.dropest_shard_merged_barcodes(self.h, C.byref(n), None, None))
@@ -98,6 +113,16 @@ class Shard:
         arr = (capi.KernelStat * max(1, n.value))()
         self._chk(self.L.dropest_shard_phase_stats(self.h, C.byref(n), arr))
         return {arr[i].name.decode(): {"steps": arr[i].launches, "ms": arr[i].ms, "bytes": arr[i].bytes} for i in range(n.value)}
+
+
+def widen_shard_matrix(m):
+    """(colptr, rowidx u32, values u32, column barcodes) from what ShardedRun.step returns (narrow 6-tuple or wide 4-tuple)."""
+    if len(m) == 4:
+        return m
+    colptr, r16, v16, bc, opos, oval = m
+    vals = v16.astype(np.uint32)
+    vals[opos.astype(np.int64)] = oval
+    return colptr, r16.astype(np.uint32), vals, bc
 
 
 class ShardGroup:
@@ -188,7 +213,10 @@ class ShardedRun:
         self.shard.step()
         if self.rank != 0:
             return None, None, None
-        cm, raw = self.shard.matrix(True), self.shard.matrix(False)
+        try:      # the narrow form when the step wrote it (every gene id below 65536): no widening on the host
+            cm, raw = self.shard.matrix_narrow(True), self.shard.matrix_narrow(False)
+        except capi.DropestError:
+            cm, raw = self.shard.matrix(True), self.shard.matrix(False)
         return cm, raw, cm[3]
 
     def set_profiling(self, on, only=None):

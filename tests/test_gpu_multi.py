@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from dropest_amd import capi
-from dropest_amd.multi import ShardGroup, ShardedRun, cfg_kwargs
+from dropest_amd.multi import ShardGroup, ShardedRun, cfg_kwargs, widen_shard_matrix
 from dropest_amd.synth import SynthStream, inject_n
 
 import parity
@@ -241,9 +241,13 @@ def test_one_shard_over_rccl_and_forced_exchange():
     dev = s.generate_device(0)
     c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
     c.set_initialized(); c.merge_and_filter()
-    got = {"cm": cm, "raw": raw, "merged": run.merge_pairs}
+    assert len(cm) == 6 and cm[1].dtype == np.uint16        # the step wrote the narrow form (gene ids below 65536)
+    got = {"cm": widen_shard_matrix(cm), "raw": widen_shard_matrix(raw), "merged": run.merge_pairs}
     check(got, c)
+    wide = run.shard.matrix(True)                            # ... and the 32-bit accessor widens it on the host
+    assert all(np.array_equal(a, b) for a, b in zip(wide, got["cm"]))
     ph = run.shard.phase_stats()
+    assert ph["exchange_record_bytes"]["bytes"] == 12        # barcode + UMI in 64 bits, gene + mark + chromosome in 32
     assert ph["partition"]["steps"] == 2 and ph["all_to_all"]["steps"] == 2
     dev.free()
 
