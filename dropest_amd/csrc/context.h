@@ -302,6 +302,8 @@ struct dropest_ctx {
 	dropest::DevBuf<u32> tile_counts, tile_prefix, scalars, rs_hist, rs_row_total, rs_digit_base;
 	dropest::DevBuf<u32> real_list, m_col_cell, m_col_start;
 	dropest::DevBuf<dropest::CellRowPod> real_rows_dev;
+	dropest::DevBuf<u32> sizes_dev;
+	bool real_list_current = false;          // real_list holds the ids of `real`, in order
 	// count matrices in CSC form: [0] filtered (cm), [1] raw (cm_raw); device staging + pinned host result
 	struct MatrixResult {
 		dropest::DevBuf<u32> d_row, d_val;

@@ -204,6 +204,14 @@ __global__ __launch_bounds__(256) void gather_cell_rows_kernel(CellArrays a, con
 	out[j] = r;
 }
 
+// the three sizes a merge changes (n_genes, requested_genes, requested_umis) of the listed cells: 12 bytes per cell instead of a whole row
+__global__ __launch_bounds__(256) void gather_cell_sizes_kernel(CellArrays a, const uint32_t *__restrict__ ids, uint32_t count, uint32_t *__restrict__ out) {
+	const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+	if (j >= count) return;
+	const uint32_t i = ids[j];
+	out[3 * size_t(j)] = a.n_genes[i]; out[3 * size_t(j) + 1] = a.req_genes[i]; out[3 * size_t(j) + 2] = a.req_umis[i];
+}
+
 // ---- count matrix (ResultsPrinter::get_count_matrix_filtered / _raw, ResultsPrinter.cpp:334-396) -------
 // One block per matrix column.  The column's cell owns the contiguous (cell, gene) rows
 // [cg_begin[cell], cg_begin[cell+1]); rows are already gene-ascending.  `col_start` is the exclusive

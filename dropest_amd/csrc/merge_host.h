@@ -520,10 +520,15 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 	// cell id -> index in `real`
 	{
 		const u32 nr = u32(real.size());
-		std::vector<u32> ids(nr);
-		for (u32 i = 0; i < nr; ++i) ids[i] = real[i].id;
-		real_list.ensure(nr); cell_real_index.ensure(n_cells);
-		HIP_CHECK(hipMemcpyAsync(real_list.p, ids.data(), size_t(nr) * 4, hipMemcpyHostToDevice, stream));
+		std::vector<u32> ids;
+		cell_real_index.ensure(n_cells);
+		if (!real_list_current) {   // (fetch_real_cells left the ids on the device: usually nothing to upload)
+			ids.resize(nr);
+			for (u32 i = 0; i < nr; ++i) ids[i] = real[i].id;
+			real_list.ensure(nr);
+			HIP_CHECK(hipMemcpyAsync(real_list.p, ids.data(), size_t(nr) * 4, hipMemcpyHostToDevice, stream));
+			real_list_current = true;
+		}
 		HIP_CHECK(hipMemsetAsync(cell_real_index.p, 0xFF, size_t(n_cells) * 4, stream));
 		hipLaunchKernelGGL(scatter_index_kernel, dim3(div_up(nr, 256)), dim3(256), 0, stream, real_list.p, nr, cell_real_index.p);
 		HIP_CHECK(hipGetLastError());
@@ -661,9 +666,10 @@ void dropest_ctx::reaggregate_after_merge() {
 	HostStage hs(this, "cb_merge:reaggregate");
 	remap.ensure(n_cells);
 	{
-		std::vector<u32> src, tgt;
-		src.reserve(merge_pairs.size()); tgt.reserve(merge_pairs.size());
-		for (auto &kv : merge_pairs) { src.push_back(u32(kv.first)); tgt.push_back(u32(kv.second)); }
+		std::vector<u32> src(merge_pairs.size()), tgt(merge_pairs.size());
+		parallel_ranges(merge_pairs.size(), [&](size_t b, size_t e, unsigned) {
+			for (size_t i = b; i < e; ++i) { src[i] = u32(merge_pairs[i].first); tgt[i] = u32(merge_pairs[i].second); }
+		});
 		DevBuf<u32> d_src, d_tgt; d_src.alloc(src.size()); d_tgt.alloc(tgt.size());
 		HIP_CHECK(hipMemcpyAsync(d_src.p, src.data(), src.size() * 4, hipMemcpyHostToDevice, stream));
 		HIP_CHECK(hipMemcpyAsync(d_tgt.p, tgt.data(), tgt.size() * 4, hipMemcpyHostToDevice, stream));
@@ -782,21 +788,29 @@ void dropest_ctx::refresh_real_rows() {
 	invalidate_prefetch();
 	const u32 count = u32(real.size());
 	if (!count) return;
-	std::vector<u32> ids(count);
-	for (u32 i = 0; i < count; ++i) ids[i] = real[i].id;
-	real_list.ensure(count); real_rows_dev.ensure(count);
-	HIP_CHECK(hipMemcpyAsync(real_list.p, ids.data(), size_t(count) * 4, hipMemcpyHostToDevice, stream));
-	CellArrays a{cell_cb.p, cell_first.p, cell_n_genes.p, cell_req_genes.p, cell_req_umis.p, cell_total_umis.p, cell_total_reads.p};
-	hipLaunchKernelGGL(gather_cell_rows_kernel, dim3(div_up(count, 256)), dim3(256), 0, stream, a, real_list.p, 0u, count,
-	                   real_rows_dev.p);
-	HIP_CHECK(hipGetLastError());
-	std::vector<CellRowPod> rows(count);
-	HIP_CHECK(hipMemcpyAsync(rows.data(), real_rows_dev.p, size_t(count) * sizeof(CellRowPod), hipMemcpyDeviceToHost, stream));
-	HIP_CHECK(stream_wait(stream));
-	for (u32 i = 0; i < count; ++i) {
-		if (real[i].merged) continue;   // the reference keeps a merged source's stale sizes; nothing reads them again
-		real[i].row.n_genes = rows[i].n_genes;
-		real[i].row.requested_genes = rows[i].requested_genes;
-		real[i].row.requested_umis = rows[i].requested_umis;
+	HostStage hs(this, "refresh_real_rows");
+	// the ids of the real-candidate cells sit on the device since fetch_real_cells (real_list; compute_merge_targets re-uploads the
+	// same list): only the three sizes a merge changes come back, 12 bytes per cell
+	if (!real_list_current) {
+		std::vector<u32> ids(count);
+		parallel_ranges(count, [&](size_t b, size_t e, unsigned) { for (size_t i = b; i < e; ++i) ids[i] = real[i].id; });
+		real_list.ensure(count);
+		HIP_CHECK(hipMemcpyAsync(real_list.p, ids.data(), size_t(count) * 4, hipMemcpyHostToDevice, stream));
+		HIP_CHECK(stream_wait(stream));
+		real_list_current = true;
 	}
+	sizes_dev.ensure(size_t(count) * 3);
+	CellArrays a{cell_cb.p, cell_first.p, cell_n_genes.p, cell_req_genes.p, cell_req_umis.p, cell_total_umis.p, cell_total_reads.p};
+	hipLaunchKernelGGL(gather_cell_sizes_kernel, dim3(div_up(count, 256)), dim3(256), 0, stream, a, real_list.p, count, sizes_dev.p);
+	HIP_CHECK(hipGetLastError());
+	h_stage.ensure(size_t(count) * 12);
+	HIP_CHECK(hipMemcpyAsync(h_stage.p, sizes_dev.p, size_t(count) * 12, hipMemcpyDeviceToHost, stream));
+	HIP_CHECK(stream_wait(stream));
+	const u32 *sz = reinterpret_cast<const u32 *>(h_stage.p);
+	parallel_ranges(count, [&](size_t b, size_t e, unsigned) {
+		for (size_t i = b; i < e; ++i) {
+			if (real[i].merged) continue;   // the reference keeps a merged source's stale sizes; nothing reads them again
+			real[i].row.n_genes = sz[3 * i]; real[i].row.requested_genes = sz[3 * i + 1]; real[i].row.requested_umis = sz[3 * i + 2];
+		}
+	});
 }

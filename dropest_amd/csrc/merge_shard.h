@@ -128,7 +128,6 @@ void dropest_ctx::shard_merge_search(uint64_t n_global, const uint64_t *g_barcod
 		if (base_g[f] >= nG) throw RangeError("base outside the global cell list");
 		if (base_local[f] >= n_cells) throw RangeError("base is not a cell of this shard");
 	}
-	for (u32 g = 0; g < nG; ++g) if (g_barcode[g] & ESCAPE_BIT) throw UnsupportedError("escaped barcodes are not supported in sharded merges");
 	*n_pairs = 0;
 	if (nG == 0 || n_bases == 0) { M.S.F = 0; M.S.pair_first.assign(1, 0); return; }
 
@@ -153,7 +152,11 @@ void dropest_ctx::shard_merge_search(uint64_t n_global, const uint64_t *g_barcod
 
 	MergeUniverse &U = M.U;
 	U.table = t; U.cell_cb = M.d_cb.p; U.n_genes = M.d_n_genes.p;
-	U.total_umis = M.d_total_umis.p; U.real_index = M.d_iota.p; U.any_escaped = false;
+	U.total_umis = M.d_total_umis.p; U.real_index = M.d_iota.p;
+	// barcodes with N (escaped codes; every shard holds the whole side-string table): such a BASE is split into the whitelist's
+	// parts on the host like on one GPU (Tools::edit_distance treats N as a wildcard); candidates are whitelist barcodes, never escaped
+	U.any_escaped = false;
+	for (u32 f = 0; f < n_bases; ++f) if (g_barcode[base_g[f]] & ESCAPE_BIT) U.any_escaped = true;
 	ShardMerge *pm = &M;
 	U.base_total_umis = [pm](u32 f) { return pm->g_total_umis[pm->base_g[f]]; };
 	U.barcode_code = [pm](u32 g) { return pm->g_barcode[g]; };

@@ -778,7 +778,6 @@ void dropest_shard::cb_merge() {
 	std::vector<LRow> local, Gm;
 	for (const HostCell &h : c.real) {
 		if (h.merged || h.excluded || h.row.n_genes < c.min_before) continue;
-		if (h.row.barcode & ESCAPE_BIT) throw UnsupportedError("barcodes with N are not supported in sharded whitelist merges");
 		local.push_back(LRow{h.row.barcode, h.row.n_genes, h.row.requested_genes, h.row.requested_umis, h.id, h.row.total_umis, h.row.total_reads});
 	}
 	std::vector<size_t> cnt;

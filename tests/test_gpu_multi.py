@@ -149,6 +149,33 @@ def test_eight_shards_whitelist_merge_n_umis_and_directional():
     check(run_group(8, (cb, umi, gene, aux), dkw, side, steps=1), single((cb, umi, gene, aux), dkw, side))
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_barcodes_with_n_in_a_sharded_whitelist_merge(world):
+    """Cells whose barcode carries an N (an escaped code; Tools::edit_distance treats N as a wildcard, UtilFunctions.cpp:48) as
+    BASES of a whitelist merge whose targets live on other shards (refused in rounds 1-2)."""
+    stream_kw, wl, kind, cfg = MERGE_CASES["10x"]
+    cb, umi, gene, aux = parity.canonical_stream(*SynthStream(**stream_kw).generate_host())
+    rng = np.random.default_rng(3)
+    codes, counts = np.unique(cb, return_counts=True)
+    busy = codes[counts >= 150]
+    chosen = rng.choice(busy, min(25, len(busy)), replace=False)
+    side = []
+    cb = cb.copy()
+    for c in chosen:            # 40 % of the barcode's reads get one N-variant of it: a smaller cell next to the original one
+        s = capi.unpack_code(int(c))
+        p = int(rng.integers(0, len(s)))
+        side.append(s[:p] + "N" + s[p + 1:])
+        where = np.flatnonzero(cb == c)
+        cb[where[:int(len(where) * 0.4)]] = capi.ESCAPE | (len(side) - 1)
+    kw = dict(cfg_kwargs(dict(cfg, merge={"barcodes_kind": kind, "barcodes_file": os.path.join(DATA, wl), "min_merge_fraction": 0.0})))
+    got = run_group(world, (cb, umi, gene, aux), kw, side)
+    c = single((cb, umi, gene, aux), kw, side)
+    want = check(got, c)
+    rows = c.cell_rows()
+    n_escaped_merged = sum(1 for b in want if b & capi.ESCAPE)
+    assert n_escaped_merged >= 5, n_escaped_merged           # N-barcodes really were merged into whitelist cells
+
+
 def test_n_umis_with_whitelist_merge_across_shards():
     s = SynthStream(n_reads=150_000 * SCALE, n_cells=25 * SCALE, n_genes=1200, umi_len=8, permille_neighbour=150)
     cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
