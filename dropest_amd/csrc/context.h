@@ -3,7 +3,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -161,19 +163,76 @@ struct MergeSearch {                                   // neighbour search resul
 	std::vector<u32> pair_base /* position f */, pair_cand, pair_umis, pair_ridx, pair_first;
 	std::vector<std::vector<u32>> host_order;          // host search: the candidates of every base in the reference's own order
 	DevBuf<WlBase> d_bases;
+	DevBuf<u32> d_cells, d_cnt, d_lvl, d_off, d_fcell, d_fumis, d_fridx, d_todo;   // device side of the search, kept with the object
 	WlArgs args{};
 };
 
-// Host loops over millions of cells (C3 size: 2.5 M real-candidate cells): contiguous ranges on a few worker threads.
-// fn(begin, end, worker); ranges are in worker order, so per-worker results can be concatenated in input order.
+// Host loops over millions of cells (C3 size: 2.5 M real-candidate cells): contiguous ranges on worker threads.
+// fn(begin, end, worker); ranges are in worker order, so per-worker results can be concatenated in input order; two calls with
+// the same n and limits cut the same ranges.  The workers are persistent (one pool per process, created on first use): a C3 pass
+// makes about twenty such calls and creating eight threads for each cost more than some of the loops.  One job at a time; a
+// caller that finds the pool busy (several shards of one process) runs its loop inline.
+class HostPool {
+	std::vector<std::thread> threads;
+	std::mutex m, job_m;
+	std::condition_variable cv_go, cv_done;
+	std::function<void(unsigned)> job;
+	uint64_t generation = 0;
+	unsigned pending = 0, active = 0;
+	bool stop = false;
+	std::string error;
+	HostPool() {
+		const unsigned n = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+		for (unsigned t = 0; t < n; ++t)
+			threads.emplace_back([this, t] {
+				uint64_t seen = 0;
+				for (;;) {
+					std::function<void(unsigned)> fn;
+					{
+						std::unique_lock<std::mutex> lk(m);
+						cv_go.wait(lk, [&] { return stop || generation != seen; });
+						if (stop) return;
+						seen = generation;
+						if (t >= active) continue;
+						fn = job;
+					}
+					try { fn(t); } catch (const std::exception &e) { std::lock_guard<std::mutex> lk(m); error = e.what(); } catch (...) { std::lock_guard<std::mutex> lk(m); error = "unknown error"; }
+					{ std::lock_guard<std::mutex> lk(m); if (--pending == 0) cv_done.notify_all(); }
+				}
+			});
+	}
+public:
+	static constexpr unsigned MAX = 16;
+	~HostPool() {
+		{ std::lock_guard<std::mutex> lk(m); stop = true; }
+		cv_go.notify_all();
+		for (auto &t : threads) t.join();
+	}
+	static HostPool &get() { static HostPool p; return p; }
+	unsigned size() const { return unsigned(threads.size()); }
+	// false: the pool is busy with somebody else's job
+	bool run(unsigned workers, const std::function<void(unsigned)> &fn) {
+		std::unique_lock<std::mutex> one(job_m, std::try_to_lock);
+		if (!one.owns_lock()) return false;
+		{
+			std::lock_guard<std::mutex> lk(m);
+			job = fn; active = workers; pending = workers; ++generation; error.clear();
+		}
+		cv_go.notify_all();
+		std::unique_lock<std::mutex> lk(m);
+		cv_done.wait(lk, [&] { return pending == 0; });
+		if (!error.empty()) throw std::runtime_error(error);
+		return true;
+	}
+};
 template <class F>
 inline unsigned parallel_ranges(size_t n, F &&fn, size_t min_per_worker = 100000, unsigned max_workers = 8) {
-	unsigned workers = unsigned(std::min<size_t>(std::min<size_t>(max_workers, std::max(1u, std::thread::hardware_concurrency())),
-	                                             std::max<size_t>(1, n / std::max<size_t>(1, min_per_worker))));
+	HostPool &pool = HostPool::get();
+	unsigned workers = unsigned(std::min<size_t>(std::min<size_t>(max_workers, pool.size()), std::max<size_t>(1, n / std::max<size_t>(1, min_per_worker))));
 	if (workers <= 1) { fn(size_t(0), n, 0u); return 1; }
-	std::vector<std::thread> pool;
-	for (unsigned w = 0; w < workers; ++w) pool.emplace_back([&, w] { fn(n * w / workers, n * (w + 1) / workers, w); });
-	for (auto &t : pool) t.join();
+	// (the number of workers -- hence the ranges -- must not depend on whether the pool was free: callers pair two calls)
+	if (pool.run(workers, [&](unsigned w) { fn(n * w / workers, n * (w + 1) / workers, w); })) return workers;
+	for (unsigned w = 0; w < workers; ++w) fn(n * w / workers, n * (w + 1) / workers, w);   // pool busy: the same ranges, one after the other
 	return workers;
 }
 
@@ -297,6 +356,8 @@ struct dropest_ctx {
 	// pinned staging for the small device->host read-backs of the hot path (pageable copies cost ~0.5 ms each)
 	dropest::PinnedBuf<unsigned char> h_stage;
 	void fetch(void *dst, const void *d_src, size_t bytes);   // D2H through h_stage + stream sync
+	dropest::PinnedBuf<unsigned char> h_up;
+	void upload(void *d_dst, const void *src, size_t bytes);  // H2D of a large pageable array through pinned staging (returns when done)
 
 	// scratch
 	dropest::DevBuf<u32> tile_counts, tile_prefix, scalars, rs_hist, rs_row_total, rs_digit_base;
@@ -412,13 +473,27 @@ struct dropest_ctx {
 	std::vector<std::vector<u32>> replay_candidate_orders(const dropest::MergeUniverse &U, dropest::MergeSearch &S,
 	                                                      const std::vector<u32> &need_order);
 	std::vector<u32> pair_intersections(const std::vector<u32> &pair_base_cell, const std::vector<u32> &pair_cand_cell);
+	void pair_intersections(const std::vector<u32> &pair_base_cell, const std::vector<u32> &pair_cand_cell, std::vector<u32> &inter);
 	// PoissonRealBarcodesMergeStrategy (poisson_merge.h)
 	std::vector<double> poisson_expected_intersections(const std::vector<u32> &pair_base_cell, const std::vector<u32> &pair_cand_cell);
 	void decide_poisson_targets(const dropest::MergeUniverse &U, dropest::MergeSearch &S, const std::vector<u32> &inter,
 	                            const std::vector<double> &expected, std::vector<long> &targets, std::vector<u32> &target_ridx);
 	std::vector<long> compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx,
 	                                        std::vector<u32> *target_ridx = nullptr);
+	void compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx, std::vector<long> &targets,
+	                           std::vector<u32> *target_ridx);
 	dropest::DevBuf<u32> cell_real_index;   // [n_cells] cell id -> index in `real` (0xFFFFFFFF otherwise)
+	// Host scratch of the CB merge, kept across passes.  At C3 size the merge works on a dozen arrays of 2.4 M entries; as
+	// locals they were 300 MB of fresh anonymous memory per pass -- every page faulted in again, tens of milliseconds of
+	// kernel time that swing with the load of the host.  Kept, they are written into warm pages.
+	struct MergeScratch {
+		dropest::MergeSearch S;
+		std::vector<u32> pb, inter, tr, cells, ridx, target_ridx, cur, rank, src, tgt32, lists;
+		std::vector<long> targets;
+		std::vector<int64_t> tgt;
+		std::vector<int32_t> reads, umis;
+		std::vector<uint8_t> excl;
+	} ms;
 	void run_cb_merge_real();
 	void run_cb_merge_simple();                  // SimpleMergeStrategy (simple_merge.h)
 	void run_cb_merge_all();                     // MergeAllMergeStrategy (merge_all.h)

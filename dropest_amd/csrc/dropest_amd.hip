@@ -142,7 +142,20 @@ void dropest_ctx::fetch(void *dst, const void *d_src, size_t bytes) {
 	h_stage.ensure(std::max<size_t>(bytes, 4096));
 	HIP_CHECK(hipMemcpyAsync(h_stage.p, d_src, bytes, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(stream_wait(stream));
-	std::memcpy(dst, h_stage.p, bytes);
+	if (bytes < (size_t(4) << 20)) std::memcpy(dst, h_stage.p, bytes);
+	else   // tens of megabytes (candidate lists, cell rows at C3 size): the copy out of the staging buffer on several threads
+		dropest::parallel_ranges(bytes, [&](size_t b, size_t e, unsigned) { std::memcpy(static_cast<char *>(dst) + b, h_stage.p + b, e - b); }, size_t(2) << 20, dropest::HostPool::MAX);
+}
+
+// Megabytes of a pageable host array to the device: staged through pinned memory on several threads, then one DMA (the
+// runtime's own path for pageable memory runs at a fifth of the PCIe rate).  Returns when the copy is done.
+void dropest_ctx::upload(void *d_dst, const void *src, size_t bytes) {
+	if (!bytes) return;
+	if (bytes < (size_t(1) << 20)) { HIP_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, stream)); HIP_CHECK(stream_wait(stream)); return; }
+	h_up.ensure(bytes);
+	dropest::parallel_ranges(bytes, [&](size_t b, size_t e, unsigned) { std::memcpy(h_up.p + b, static_cast<const char *>(src) + b, e - b); }, size_t(2) << 20, dropest::HostPool::MAX);
+	HIP_CHECK(hipMemcpyAsync(d_dst, h_up.p, bytes, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(stream_wait(stream));
 }
 
 void dropest_ctx::collect_timings() {
@@ -991,7 +1004,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 	// The host side of it (two passes over `real`, one over the result) runs on a few worker threads.
 	const size_t R = real.size();
 	if (R >= device_min) {
-		constexpr unsigned W = 8;
+		constexpr unsigned W = dropest::HostPool::MAX;
 		auto st1 = std::make_unique<HostStage>(this, "sort_filtered:scan");
 		size_t count[W] = {0};
 		u64 any[W] = {0}; int bl[W]; bool uniform[W];
@@ -1217,7 +1230,7 @@ void dropest_ctx::matrix_columns(bool filtered_m, std::vector<u32> &col_cell, st
 		}
 	} else {
 		// every real cell in cell-id order: millions of rows at C3 size -- counted and filled over contiguous ranges on a few threads
-		constexpr unsigned W = 8;
+		constexpr unsigned W = dropest::HostPool::MAX;
 		size_t cols[W] = {0}; uint64_t sums[W] = {0};
 		auto is_col = [&](const HostCell &h) { return !(h.merged || h.excluded || h.row.n_genes < min_before); };
 		const unsigned workers = parallel_ranges(real.size(), [&](size_t b, size_t e, unsigned w) {

@@ -151,6 +151,7 @@ struct BamReader::Impl {
 	const uint8_t *bytes() const { return cur.p.get(); }
 
 	double load_ms = 0, discover_ms = 0; size_t n_batches = 0;   // diagnostics (DROPEST_BAM_TRACE)
+	size_t first_batch_compressed = 0;                           // bytes of the file the first batch covered (read-count estimate)
 	Buf load_batch(Buf out) {
 		const auto t_begin = std::chrono::steady_clock::now();
 		std::vector<RawBlock> blocks;
@@ -160,6 +161,7 @@ struct BamReader::Impl {
 			if (!read_block(map, map_size, map_at, b, path)) { file_done = true; break; }
 			blocks.push_back(std::move(b));
 		}
+		if (!n_batches) first_batch_compressed = map_at;
 		discover_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
 		std::vector<size_t> off(blocks.size() + 1, HEADROOM);
 		for (size_t i = 0; i < blocks.size(); ++i) off[i + 1] = off[i] + blocks[i].isize;
@@ -256,6 +258,7 @@ BamReader::~BamReader() {
 }
 
 const std::vector<std::string> &BamReader::reference_names() const { return impl->refs; }
+double BamReader::file_over_first_batch() const { return impl->first_batch_compressed ? double(impl->map_size) / double(impl->first_batch_compressed) : 1.0; }
 const std::string &BamReader::header_text() const { return impl->text; }
 
 void BamReader::parse_record(const uint8_t *at, BamRecord &rec) {
@@ -631,10 +634,17 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			return true;
 		};
 		static const bool force_slow = getenv("DROPEST_BAM_RECORD_BY_RECORD") != nullptr;   // tests: the two paths agree
+		bool first_window = true;
 		for (;;) {
 			auto t_wait = clk::now();
 			if (!reader.next_window(data, offsets)) break;
 			_counters.wait_ms += since(t_wait);
+			if (first_window && &bam_name == &bam_files.front()) {
+				// a container over several GPUs deals contiguous ranges of the stream to its shards: tell it how long the stream
+				// will roughly be (records of the first window x file bytes / bytes the window covered, x the number of files)
+				container.expect_reads(size_t(double(offsets.size()) * reader.file_over_first_batch() * double(bam_files.size()) * 1.05));
+			}
+			first_window = false;
 			if (!_params_from_files && !force_slow && NT <= 256 && container.bulk_ingest_possible()) {
 				auto t_fast = clk::now();
 				const bool done = fast_window(offsets.size());

@@ -64,6 +64,7 @@ public:
 	BamReader &operator=(const BamReader &) = delete;
 	const std::vector<std::string> &reference_names() const;
 	const std::string &header_text() const;
+	double file_over_first_batch() const;                                // file bytes / bytes the first decompressed batch covered (>= 1)
 	bool next(BamRecord &rec);                                           // false at end of file
 	// A run of whole records (as many as the decompressed window holds), valid until the next call of next / next_window;
 	// offsets[i] = start of record i (its block_size field) relative to data

@@ -278,8 +278,9 @@ private:
 	std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> _umi_merge_strategy;
 	UMI::Mark::query_t _query_marks;
 	dropest_ctx *_ctx = nullptr;
-	// N GPUs behind the one container: the batches of the stream are dealt to the shards round-robin; merge_and_filter runs the
-	// sharded pass (include/dropest_amd.h: dropest_shard_*), one host thread per GPU
+	// N GPUs behind the one container: every shard takes ONE contiguous range of the stream (shard_quota reads, the last shard
+	// the rest; expect_reads() sizes the quota so that the ranges come out even); merge_and_filter runs the sharded pass
+	// (include/dropest_amd.h: dropest_shard_*), one host thread per GPU
 	std::vector<dropest_shard *> _shards;
 	uint64_t _batches = 0;
 	size_t _side_sent = 0;
@@ -328,6 +329,15 @@ private:
 public:
 	static const size_t BATCH = size_t(1) << 20;
 	size_t shard_quota = size_t(1) << 27;   // sharded container: reads (a multiple of BATCH) a shard takes before the next one starts
+	// A caller that knows roughly how many reads will come (a BAM's size, a previous run) says so before the first add_record: the
+	// quota becomes ceil(expected / shards) rounded up to whole batches, so that every GPU and every PCIe link carries its share
+	// (with the default quota a stream shorter than 2^27 reads lands on shard 0 alone and a very long one piles onto the last).
+	// An under-estimate only makes the last shard longer; results do not depend on where reads waited.
+	void expect_reads(size_t expected) {
+		if (!sharded() || _batches) return;
+		const size_t per = (expected + _shards.size() - 1) / _shards.size();
+		shard_quota = std::max<size_t>(BATCH, (per + BATCH - 1) / BATCH * BATCH);
+	}
 
 	CellsDataContainer(const std::shared_ptr<Merge::MergeStrategyAbstract> &merge_strategy,
 	                   const std::shared_ptr<Merge::UMIs::MergeUMIsStrategyAbstract> &umi_merge_strategy,

@@ -169,10 +169,10 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 
 	// 1. barcodes split into the two parts (device; escaped barcodes patched by the host)
 	auto st_bases = std::make_unique<HostStage>(this, "cb_merge:targets:bases");
-	DevBuf<u32> d_cells; d_cells.alloc(F);
-	S.d_bases.alloc(F);
+	DevBuf<u32> &d_cells = S.d_cells; d_cells.ensure(F);
+	S.d_bases.ensure(F);
 	scalars.ensure(16);
-	HIP_CHECK(hipMemcpyAsync(d_cells.p, cells.data(), size_t(F) * 4, hipMemcpyHostToDevice, stream));
+	upload(d_cells.p, cells.data(), size_t(F) * 4);
 	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
 	const u32 P = u32(wl.parts.size());
 	WlSplit sp{};
@@ -202,7 +202,7 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 	// 2. neighbour search; candidates land in flat lists
 	st_bases.reset();
 	auto st_search = std::make_unique<HostStage>(this, "cb_merge:targets:search");
-	DevBuf<u32> d_cnt, d_lvl, d_off, d_fcell, d_fumis, d_fridx, d_lvl_todo;
+	DevBuf<u32> &d_cnt = S.d_cnt, &d_lvl = S.d_lvl, &d_off = S.d_off, &d_fcell = S.d_fcell, &d_fumis = S.d_fumis, &d_fridx = S.d_fridx, &d_lvl_todo = S.d_todo;
 	u32 flat_cap = std::max<u32>(F * 2u, 1024u);
 	S.cnt.resize(F); S.off.resize(F);
 	WlArgs &a = S.args;
@@ -210,7 +210,7 @@ void dropest_ctx::search_merge_candidates(const std::vector<u32> &cells, const M
 	for (auto const &part : wl.parts) S.ntot += u32(part.size());
 	S.lds = ((S.ntot + 15u) & ~15u) + size_t(S.ntot) * 2;
 	for (;;) {
-		d_cnt.alloc(F); d_lvl.alloc(F); d_off.alloc(F); d_fcell.alloc(flat_cap); d_fumis.alloc(flat_cap); d_fridx.alloc(flat_cap);
+		d_cnt.ensure(F); d_lvl.ensure(F); d_off.ensure(F); d_fcell.ensure(flat_cap); d_fumis.ensure(flat_cap); d_fridx.ensure(flat_cap);
 		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));
 		a = WlArgs{};
 		a.bases = S.d_bases.p; a.n_bases = F;
@@ -275,7 +275,7 @@ void dropest_ctx::build_merge_pairs(const std::vector<u32> &cells, MergeSearch &
 	HostStage st_pairs(this, "cb_merge:targets:pairs");
 	S.pair_first.assign(size_t(F) + 1, 0); S.self_ridx.assign(F, 0xFFFFFFFFu);
 	// two passes over contiguous ranges on a few threads (2.4 M bases at C3 size): pairs per base, then the flat lists
-	constexpr unsigned W = 8;
+	constexpr unsigned W = dropest::HostPool::MAX;
 	size_t per_worker[W + 1] = {0};
 	bool too_many = false;
 	std::vector<u32> n_pairs(F);
@@ -454,19 +454,14 @@ void dropest_ctx::decide_merge_targets(const MergeUniverse &U, MergeSearch &S, c
 			ties.push_back(f);   // tie at the maximum (or all fractions zero with a non-positive threshold)
 		}
 	};
-	const unsigned n_workers = F >= 200000 ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-	if (n_workers == 1) decide_range(0, F, need_order);
-	else {
-		std::vector<std::vector<u32>> ties(n_workers);
-		std::vector<std::thread> pool;
-		for (unsigned w = 0; w < n_workers; ++w)
-			pool.emplace_back([&, w] {
-				std::vector<u32> mine;   // local: the slots' vector headers share cache lines
-				decide_range(u32(uint64_t(F) * w / n_workers), u32(uint64_t(F) * (w + 1) / n_workers), mine);
-				ties[w] = std::move(mine);
-			});
-		for (auto &t : pool) t.join();
-		for (auto &t : ties) need_order.insert(need_order.end(), t.begin(), t.end());
+	{
+		std::vector<std::vector<u32>> ties(dropest::HostPool::MAX);
+		const unsigned workers = parallel_ranges(F, [&](size_t b, size_t e, unsigned w) {
+			std::vector<u32> mine;   // local: the slots' vector headers share cache lines
+			decide_range(u32(b), u32(e), mine);
+			ties[w] = std::move(mine);
+		}, 50000, dropest::HostPool::MAX);
+		for (unsigned w = 0; w < workers; ++w) need_order.insert(need_order.end(), ties[w].begin(), ties[w].end());
 	}
 	if (need_order.empty()) return;
 	HostStage st_replay(this, "cb_merge:targets:replay");
@@ -490,13 +485,18 @@ void dropest_ctx::decide_merge_targets(const MergeUniverse &U, MergeSearch &S, c
 
 // CellsDataContainer.cpp:320-350 (get_umigs_intersect_size) for a list of cell pairs of this context
 std::vector<u32> dropest_ctx::pair_intersections(const std::vector<u32> &pb, const std::vector<u32> &pc) {
+	std::vector<u32> inter;
+	pair_intersections(pb, pc, inter);
+	return inter;
+}
+void dropest_ctx::pair_intersections(const std::vector<u32> &pb, const std::vector<u32> &pc, std::vector<u32> &inter) {
 	const u32 NP = u32(pb.size());
-	std::vector<u32> inter(NP);
-	if (!NP) return inter;
+	inter.resize(NP);
+	if (!NP) return;
 	DevBuf<u32> d_pb, d_pc, d_inter; DevBuf<PairRange> d_pr;
 	d_pb.alloc(NP); d_pc.alloc(NP); d_inter.alloc(NP); d_pr.alloc(NP);
-	HIP_CHECK(hipMemcpyAsync(d_pb.p, pb.data(), size_t(NP) * 4, hipMemcpyHostToDevice, stream));
-	HIP_CHECK(hipMemcpyAsync(d_pc.p, pc.data(), size_t(NP) * 4, hipMemcpyHostToDevice, stream));
+	upload(d_pb.p, pb.data(), size_t(NP) * 4);
+	upload(d_pc.p, pc.data(), size_t(NP) * 4);
 	hipLaunchKernelGGL(pair_ranges_kernel, dim3(div_up(NP, 256)), dim3(256), 0, stream, d_pb.p, d_pc.p, NP, cell_cg_begin.p,
 	                   cell_cg_count.p, cg_mol_begin.p, d_pr.p);
 	HIP_CHECK(hipGetLastError());
@@ -506,16 +506,20 @@ std::vector<u32> dropest_ctx::pair_intersections(const std::vector<u32> &pb, con
 		                   (1ull << low_bits) - 1ull, layout.umi_bits, layout.gene_none, d_inter.p);
 	});
 	fetch(inter.data(), d_inter.p, size_t(NP) * 4);
-	return inter;
 }
 
 // RealBarcodesMergeStrategy::get_merge_target for a list of this context's cells, on the current (unmerged) device
 // state.  `ridx[f]` = index of cells[f] in `real`.
-std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx,
-                                                     std::vector<u32> *target_ridx) {
-	std::vector<long> targets(cells.size(), -1);
+std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx, std::vector<u32> *target_ridx) {
+	std::vector<long> targets;
+	compute_merge_targets(cells, ridx, targets, target_ridx);
+	return targets;
+}
+void dropest_ctx::compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx, std::vector<long> &targets,
+                                        std::vector<u32> *target_ridx) {
+	targets.assign(cells.size(), -1);
 	if (target_ridx) target_ridx->assign(cells.size(), 0xFFFFFFFFu);
-	if (cells.empty()) return targets;
+	if (cells.empty()) return;
 
 	// cell id -> index in `real`
 	{
@@ -554,23 +558,24 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 		ng = h.row.n_genes; tu = h.row.total_umis; ri = it->second;
 		return long(h.id);
 	};
-	MergeSearch S;
+	MergeSearch &S = ms.S;            // (kept across passes: see MergeScratch)
+	S.host_order.clear();
 	search_merge_candidates(cells, U, S);
 
 	const u32 NP = u32(S.pair_base.size());
-	std::vector<u32> pb(NP);
-	for (u32 p = 0; p < NP; ++p) pb[p] = cells[S.pair_base[p]];
-	std::vector<u32> inter;
-	{ HostStage st(this, "cb_merge:targets:intersect"); inter = pair_intersections(pb, S.pair_cand); }
+	std::vector<u32> &pb = ms.pb;
+	pb.resize(NP);
+	parallel_ranges(NP, [&](size_t b, size_t e, unsigned) { for (size_t p = b; p < e; ++p) pb[p] = cells[S.pair_base[p]]; }, 100000, dropest::HostPool::MAX);
+	std::vector<u32> &inter = ms.inter;
+	{ HostStage st(this, "cb_merge:targets:intersect"); pair_intersections(pb, S.pair_cand, inter); }
 	HostStage st_decide(this, "cb_merge:targets:decide");
-	std::vector<u32> tr;
+	std::vector<u32> &tr = ms.tr;
 	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL) {
 		const std::vector<double> expected = poisson_expected_intersections(pb, S.pair_cand);
 		decide_poisson_targets(U, S, inter, expected, targets, tr);
 	} else
 		decide_merge_targets(U, S, inter, targets, tr);
-	if (target_ridx) *target_ridx = tr;
-	return targets;
+	if (target_ridx) target_ridx->assign(tr.begin(), tr.end());
 }
 
 // MergeStrategyBase::merge_inited second loop (:30-51) + reassign (:64-82), on flat arrays indexed by the position
@@ -579,9 +584,13 @@ std::vector<long> dropest_ctx::compute_merge_targets(const std::vector<u32> &cel
 // a target form an intrusive list so that a later merge of that target moves them along.  Stats::merge adds
 // every int counter, TOTAL_UMIS included (Stats.cpp:29-43).  Returns whether anything was merged.
 static bool apply_merge_order(u32 n_cells, size_t n_order, const u32 *order, const int64_t *target, int32_t *total_reads,
-                              int32_t *total_umis, u32 *final_target, uint8_t *excluded, u32 *rank = nullptr) {
+                              int32_t *total_umis, u32 *final_target, uint8_t *excluded, u32 *rank = nullptr,
+                              std::vector<u32> *scratch = nullptr /* 3 x n_cells, kept by the caller across passes */) {
 	const u32 NIL = 0xFFFFFFFFu;
-	std::vector<u32> head(n_cells, NIL), tail(n_cells, NIL), next(n_cells, NIL);
+	std::vector<u32> own;
+	std::vector<u32> &lists = scratch ? *scratch : own;
+	lists.assign(size_t(n_cells) * 3, NIL);
+	u32 *head = lists.data(), *tail = head + n_cells, *next = tail + n_cells;
 	u32 *cur = final_target;
 	for (u32 i = 0; i < n_cells; ++i) { cur[i] = i; excluded[i] = 0; }
 	auto append = [&](u32 tgt, u32 x) { if (head[tgt] == NIL) head[tgt] = x; else next[tail[tgt]] = x; tail[tgt] = x; next[x] = NIL; };
@@ -616,47 +625,58 @@ static bool apply_merge_order(u32 n_cells, size_t n_order, const u32 *order, con
 void dropest_ctx::run_cb_merge_real() {
 	HostStage hs(this, "cb_merge");
 	const std::vector<uint64_t> &order = filtered_cells();
-	std::vector<u32> cells(order.begin(), order.end());
-	const std::vector<u32> ridx = filtered_ridx;
-	std::vector<long> targets;
-	std::vector<u32> target_ridx;
-	{ HostStage hs2(this, "cb_merge:targets"); targets = compute_merge_targets(cells, ridx, &target_ridx); }
+	std::vector<u32> &cells = ms.cells;
+	cells.assign(order.begin(), order.end());
+	std::vector<u32> &ridx = ms.ridx;
+	ridx.assign(filtered_ridx.begin(), filtered_ridx.end());
+	std::vector<long> &targets = ms.targets;
+	std::vector<u32> &target_ridx = ms.target_ridx;
+	{ HostStage hs2(this, "cb_merge:targets"); compute_merge_targets(cells, ridx, targets, &target_ridx); }
 
 	HostStage hs3(this, "cb_merge:apply");
 	const u32 nR = u32(real.size());
-	std::vector<int64_t> tgt(cells.size());
+	std::vector<int64_t> &tgt = ms.tgt;
+	tgt.resize(cells.size());
 	parallel_ranges(cells.size(), [&](size_t b, size_t e, unsigned) {
 		for (size_t i = b; i < e; ++i) tgt[i] = targets[i] < 0 ? -1 : int64_t(target_ridx[i]);
-	});
-	std::vector<int32_t> reads(nR), umis(nR);
+	}, 100000, dropest::HostPool::MAX);
+	std::vector<int32_t> &reads = ms.reads, &umis = ms.umis;
+	reads.resize(nR); umis.resize(nR);
 	parallel_ranges(nR, [&](size_t b, size_t e, unsigned) {
 		for (size_t i = b; i < e; ++i) { reads[i] = real[i].row.total_reads; umis[i] = real[i].row.total_umis; }
-	});
-	std::vector<u32> cur(nR);
-	std::vector<uint8_t> excl(nR);
-	std::vector<u32> rank(have_qual ? nR : 0u);   // only the quality sums need the merge order (quality.h)
+	}, 100000, dropest::HostPool::MAX);
+	std::vector<u32> &cur = ms.cur;
+	std::vector<uint8_t> &excl = ms.excl;
+	std::vector<u32> &rank = ms.rank;   // only the quality sums need the merge order (quality.h)
+	cur.resize(nR); excl.resize(nR); rank.resize(have_qual ? nR : 0u);
 	const bool any_merge = apply_merge_order(nR, cells.size(), ridx.data(), tgt.data(), reads.data(), umis.data(), cur.data(), excl.data(),
-	                                         have_qual ? rank.data() : nullptr);
+	                                         have_qual ? rank.data() : nullptr, &ms.lists);
 	if (have_qual) {
 		merge_rank.assign(n_cells, 0);
 		for (u32 i = 0; i < nR; ++i) merge_rank[real[i].id] = rank[i];
 	}
 	reassign.clear();
 	clear_strategy_pairs();
-	std::vector<std::vector<std::pair<uint64_t, uint64_t>>> moved(8);
+	// the (source, target) pairs in ascending source id: counted and filled over the same contiguous ranges
+	constexpr unsigned W = dropest::HostPool::MAX;
+	size_t n_of[W + 1] = {0};
 	const unsigned workers = parallel_ranges(nR, [&](size_t b, size_t e, unsigned w) {
-		std::vector<std::pair<uint64_t, uint64_t>> mine;   // local: the slots' vector headers share cache lines
+		size_t c = 0;
 		for (size_t i = b; i < e; ++i) {
 			real[i].row.total_reads = reads[i]; real[i].row.total_umis = umis[i];
 			if (excl[i]) real[i].excluded = true;
-			if (cur[i] != i) { real[i].merged = true; mine.emplace_back(real[i].id, real[cur[i]].id); }
+			if (cur[i] != i) { real[i].merged = true; ++c; }
 		}
-		moved[w] = std::move(mine);
-	});
-	size_t n_moved = 0;
-	for (unsigned w = 0; w < workers; ++w) n_moved += moved[w].size();
-	merge_pairs.reserve(n_moved);
-	for (unsigned w = 0; w < workers; ++w) merge_pairs.insert(merge_pairs.end(), moved[w].begin(), moved[w].end());   // ascending source id
+		n_of[w] = c;
+	}, 100000, W);
+	size_t start[W + 1] = {0};
+	const size_t kept = merge_pairs.size();   // pairs merged by hand stay in front (clear_strategy_pairs)
+	for (unsigned w = 0; w < workers; ++w) start[w + 1] = start[w] + n_of[w];
+	merge_pairs.resize(kept + start[workers]);
+	parallel_ranges(nR, [&](size_t b, size_t e, unsigned w) {
+		size_t at = kept + start[w];
+		for (size_t i = b; i < e; ++i) if (cur[i] != i) merge_pairs[at++] = {real[i].id, real[cur[i]].id};
+	}, 100000, W);
 	if (any_merge) reaggregate_after_merge();
 }
 
@@ -666,13 +686,14 @@ void dropest_ctx::reaggregate_after_merge() {
 	HostStage hs(this, "cb_merge:reaggregate");
 	remap.ensure(n_cells);
 	{
-		std::vector<u32> src(merge_pairs.size()), tgt(merge_pairs.size());
+		std::vector<u32> &src = ms.src, &tgt = ms.tgt32;
+		src.resize(merge_pairs.size()); tgt.resize(merge_pairs.size());
 		parallel_ranges(merge_pairs.size(), [&](size_t b, size_t e, unsigned) {
 			for (size_t i = b; i < e; ++i) { src[i] = u32(merge_pairs[i].first); tgt[i] = u32(merge_pairs[i].second); }
 		});
 		DevBuf<u32> d_src, d_tgt; d_src.alloc(src.size()); d_tgt.alloc(tgt.size());
-		HIP_CHECK(hipMemcpyAsync(d_src.p, src.data(), src.size() * 4, hipMemcpyHostToDevice, stream));
-		HIP_CHECK(hipMemcpyAsync(d_tgt.p, tgt.data(), tgt.size() * 4, hipMemcpyHostToDevice, stream));
+		upload(d_src.p, src.data(), src.size() * 4);
+		upload(d_tgt.p, tgt.data(), tgt.size() * 4);
 		hipLaunchKernelGGL(iota_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, stream, remap.p, n_cells);
 		if (!src.empty())
 			hipLaunchKernelGGL(scatter_pairs_kernel, dim3(div_up(u32(src.size()), 256)), dim3(256), 0, stream, d_src.p, d_tgt.p,
