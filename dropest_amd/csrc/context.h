@@ -493,6 +493,8 @@ struct dropest_ctx {
 		std::vector<int64_t> tgt;
 		std::vector<int32_t> reads, umis;
 		std::vector<uint8_t> excl;
+		dropest::DevBuf<u32> d_pb, d_pc, d_inter, d_src, d_tgt;   // device side, kept as well (a hipFree synchronises the device)
+		dropest::DevBuf<dropest::PairRange> d_pr;
 	} ms;
 	void run_cb_merge_real();
 	void run_cb_merge_simple();                  // SimpleMergeStrategy (simple_merge.h)

@@ -493,8 +493,8 @@ void dropest_ctx::pair_intersections(const std::vector<u32> &pb, const std::vect
 	const u32 NP = u32(pb.size());
 	inter.resize(NP);
 	if (!NP) return;
-	DevBuf<u32> d_pb, d_pc, d_inter; DevBuf<PairRange> d_pr;
-	d_pb.alloc(NP); d_pc.alloc(NP); d_inter.alloc(NP); d_pr.alloc(NP);
+	DevBuf<u32> &d_pb = ms.d_pb, &d_pc = ms.d_pc, &d_inter = ms.d_inter; DevBuf<PairRange> &d_pr = ms.d_pr;
+	d_pb.ensure(NP); d_pc.ensure(NP); d_inter.ensure(NP); d_pr.ensure(NP);
 	upload(d_pb.p, pb.data(), size_t(NP) * 4);
 	upload(d_pc.p, pc.data(), size_t(NP) * 4);
 	hipLaunchKernelGGL(pair_ranges_kernel, dim3(div_up(NP, 256)), dim3(256), 0, stream, d_pb.p, d_pc.p, NP, cell_cg_begin.p,
@@ -691,7 +691,7 @@ void dropest_ctx::reaggregate_after_merge() {
 		parallel_ranges(merge_pairs.size(), [&](size_t b, size_t e, unsigned) {
 			for (size_t i = b; i < e; ++i) { src[i] = u32(merge_pairs[i].first); tgt[i] = u32(merge_pairs[i].second); }
 		});
-		DevBuf<u32> d_src, d_tgt; d_src.alloc(src.size()); d_tgt.alloc(tgt.size());
+		DevBuf<u32> &d_src = ms.d_src, &d_tgt = ms.d_tgt; d_src.ensure(std::max<size_t>(src.size(), 1)); d_tgt.ensure(std::max<size_t>(tgt.size(), 1));
 		upload(d_src.p, src.data(), src.size() * 4);
 		upload(d_tgt.p, tgt.data(), tgt.size() * 4);
 		hipLaunchKernelGGL(iota_kernel, dim3(div_up(n_cells, 256)), dim3(256), 0, stream, remap.p, n_cells);
