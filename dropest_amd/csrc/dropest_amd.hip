@@ -229,7 +229,7 @@ void dropest_ctx::build_cb_table() {
 		// the whole stream (too small an estimate is caught below: the table is rebuilt larger when its load passes 0.7)
 		const u32 stride = 64, n_s = div_up(n, stride);
 		uint64_t cap_s = 1024; while (cap_s < uint64_t(n_s) * 2) cap_s <<= 1;
-		t_slots.ensure(cap_s); scalars.ensure(16);
+		t_slots.ensure(cap_s); scalars.ensure(4 + CB_HOT_LEVELS + 4);
 		CbTable ts{t_slots.p, cap_s - 1};
 		HIP_CHECK(hipMemsetAsync(t_slots.p, 0, cap_s * sizeof(CbSlot), stream));
 		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4, stream));
@@ -258,6 +258,7 @@ void dropest_ctx::build_cb_table() {
 				n_hot = head[4 + level];
 			}
 		}
+		if (profiling) stats["count:hot_barcodes"].launches = n_hot;
 	} else n_hot = 0;
 	if (cap == 0) { cap = 1024; while (cap < n_reads / 2) cap <<= 1; }
 	if (cap & (cap - 1)) throw InvalidError("cb_table_capacity must be a power of two");
@@ -430,14 +431,25 @@ void dropest_ctx::build_keys(bool with_stats) {
 	timed("build_keys", double(n) * (8 + 4 + 4 + 4 + 4 + 8 + layout.val_bytes), [&] {
 		void *v = vals_a.p;
 		const CbHot hot{hot_key.p, hot_slot.p, n_hot};   // n_hot: slot[] holds CB_HOT_FLAG | hot index for the reads of the hot barcodes
-		auto go = [&](auto kernel) {
-			const u32 blocks = resident_grid(kernel, 256, div_up(n, 256 * 4));
-			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p, hot,
-			                   gene_chr.p, GENE_CHR_CAP, d_ingest.p);
+		// 12-16 waves per CU run this pass fastest (scripts/probe/bk_probe.hip: 0.74 ms with the 32 that fit, 0.68 with 16, 0.66 with 8
+		// at the C2 shape): at most four workgroups per CU
+		int cus = 0, dev = 0;
+		HIP_CHECK(hipGetDevice(&dev));
+		HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+		// the gene -> chromosome check out of LDS (k_misc.h: GCL) when the sample's genes fit the byte table; later genes take the exact path
+		const u32 lds_genes = with_stats && !getenv("DROPEST_NO_LDS_GENE_TABLE") ? std::min<u32>((ingest.gene_max_plus1 + 3u) & ~3u, BK_LDS_GENES_MAX) : 0u;
+		auto go = [&](auto kernel, u32 lds = 0u) {
+			int per_cu = 0;
+			HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds));
+			const u32 blocks = std::max<u32>(1u, std::min<u32>(div_up(n, 256 * 4), u32(std::max(1, cus) * std::max(1, std::min(per_cu, 4)))));
+			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p, hot,
+			                   gene_chr.p, GENE_CHR_CAP, d_ingest.p, lds);
 		};
 		auto pick = [&](auto vb) {
 			constexpr int VB = decltype(vb)::value;
-			if (with_stats) {
+			if (with_stats && lds_genes && vec) {
+				if (n_hot) go(build_keys_kernel<256, VB, true, true, true, true>, lds_genes); else go(build_keys_kernel<256, VB, true, false, true, true>, lds_genes);
+			} else if (with_stats) {
 				if (n_hot) { if (vec) go(build_keys_kernel<256, VB, true, true, true>); else go(build_keys_kernel<256, VB, false, true, true>); }
 				else { if (vec) go(build_keys_kernel<256, VB, true, false, true>); else go(build_keys_kernel<256, VB, false, false, true>); }
 			} else {

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 		
 			}
 		}
-		if (VEC && full) *reinterpret_cast<uint4 *>(slot_out + r0) = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+		if (VEC && full) stream_store_u32x4(slot_out + r0, sl[0], sl[1], sl[2], sl[3]);
 		else {
 #pragma unroll
 			for (int j = 0; j < ILP; ++j) if (r0 + j < n) slot_out[r0 + j] = sl[j];
@@ -329,11 +329,13 @@ __global__ __launch_bounds__(256) void cb_sample_distinct_kernel(const unsigned 
 // number of L2 requests -- every table probe is its own request, 1.5e8 of them for 1e8 reads -- so the barcodes the sample
 // saw most often (at most CB_HOT_MAX) get a read-only hash table in LDS: a hit costs no memory request at all.
 constexpr uint32_t CB_HOT_MAX = 4096, CB_HOT_LDS = 8192, CB_HOT_FLAG = 0x80000000u;
-constexpr int CB_HOT_LEVELS = 6;
-__device__ __host__ inline uint32_t cb_hot_threshold(int level) { return 4u << (2 * level); }   // 4, 16, 64, 256, 1024, 4096 sample hits
+constexpr int CB_HOT_LEVELS = 24;
+// 4, 6, 8, 12, 16, 24, ... sample hits (steps of 1.33-1.5x; with the steps of 4x of earlier rounds the C2 stream listed 754 barcodes, now
+// 1 080, C3 134 -> 455).  The cells of one experiment are of similar size: one step further down admits nearly all of them at once.
+__device__ __host__ inline uint32_t cb_hot_threshold(int level) { return ((level & 1) ? 6u : 4u) << (level >> 1); }
 // how many sampled barcodes reach each threshold
 __global__ __launch_bounds__(256) void cb_hot_count_kernel(CbTable ts, uint32_t *__restrict__ counts) {
-	uint32_t c[CB_HOT_LEVELS] = {0, 0, 0, 0, 0, 0};
+	uint32_t c[CB_HOT_LEVELS] = {};
 	for (uint64_t s = uint64_t(blockIdx.x) * 256 + threadIdx.x; s <= ts.mask; s += uint64_t(gridDim.x) * 256) {
 		if (ts.slots[s].key == 0ull) continue;
 		const uint32_t n = ts.slots[s].nfirst;
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 	// the barcodes of the NEXT tile are in flight while this one is worked on (4 waves per SIMD do not hide the load by themselves)
 	auto load_cb = [&](uint64_t r0, unsigned long long (&kk)[ILP]) {
 		if (VEC && r0 + ILP <= n) {
-			const ulonglong2 k01 = *reinterpret_cast<const ulonglong2 *>(cb + r0), k23 = *reinterpret_cast<const ulonglong2 *>(cb + r0 + 2);
+			const ulonglong2 k01 = stream_load_u64x2(cb + r0), k23 = stream_load_u64x2(cb + r0 + 2);   // (the table lines stay in L2, the stream passes)
 			kk[0] = k01.x; kk[1] = k01.y; kk[2] = k23.x; kk[3] = k23.y;
 		} else {
 #pragma unroll
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 		
 			}
 		}
-		if (VEC && full) *reinterpret_cast<uint4 *>(slot_out + r0) = make_uint4(sl[0], sl[1], sl[2], sl[3]);
+		if (VEC && full) stream_store_u32x4(slot_out + r0, sl[0], sl[1], sl[2], sl[3]);
 		else {
 #pragma unroll
 			for (int j = 0; j < ILP; ++j) if (r0 + j < n) slot_out[r0 + j] = sl[j];

@@ -49,20 +49,33 @@ struct GlobalCounters {   // CellsDataContainer.cpp:73-78, :309-327
 
 // STATS: the exact ingest statistics (k_cbhash.h: IngestAcc) ride along -- the layout L was planned from a sample of the reads and is
 // checked against them afterwards (dropest_ctx::run_set_initialized); cb_insert then read the barcodes only.
-template <int THREADS, int VB, bool VEC, bool HOT = false, bool STATS = false>
+// GCL (with STATS): the gene -> chromosome check reads a byte table in LDS (the first `lds_genes` genes, chromosomes below 255; 0xFF =
+// "ask the table in memory") instead of one gather per read from gene_chr[] -- the gather was a quarter of the kernel at the C2 shape
+// (scripts/probe/bk_probe.hip: 0.97 -> 0.73 ms without it).  Anything the byte table cannot answer takes the exact path below.
+constexpr uint32_t BK_LDS_GENES_MAX = 49152;   // with the 16 KB of hot cell ids: 64 KB of LDS per workgroup at most
+template <int THREADS, int VB, bool VEC, bool HOT = false, bool STATS = false, bool GCL = false>
 __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long long *__restrict__ umi,
                                                              const uint32_t *__restrict__ gene,
                                                              const uint32_t *__restrict__ aux,
                                                              const uint32_t *__restrict__ slot, uint32_t n, CbTable t,
                                                              KeyLayout L, unsigned long long *__restrict__ keys,
                                                              void *__restrict__ vals_, GlobalCounters *gc, CbHot hot = CbHot{nullptr, nullptr, 0},
-                                                             uint32_t *__restrict__ gene_chr = nullptr, uint32_t gene_chr_cap = 0, IngestStats *stats = nullptr) {
+                                                             uint32_t *__restrict__ gene_chr = nullptr, uint32_t gene_chr_cap = 0, IngestStats *stats = nullptr,
+                                                             uint32_t lds_genes = 0) {
+	static_assert(!GCL || STATS, "the LDS gene table serves the statistics only");
 	// the cell ids of the hot barcodes (k_cbhash.h): 16 KB of LDS instead of one L2 request per read
 	__shared__ uint32_t hot_cell[HOT ? CB_HOT_MAX : 1];
-	if (HOT) {
+	extern __shared__ uint8_t bk_gene_chr8[];   // [lds_genes] (GCL)
+	if (HOT)
 		for (uint32_t j = threadIdx.x; j < hot.n; j += THREADS) hot_cell[j] = t.slots[hot.slot[j]].cell_id;
-		__syncthreads();
+	if (GCL) {
+		for (uint32_t g0 = threadIdx.x * 4; g0 < lds_genes; g0 += THREADS * 4) {   // (lds_genes is a multiple of 4, gene_chr_cap >= it)
+			const uint4 c = *reinterpret_cast<const uint4 *>(gene_chr + g0);
+			*reinterpret_cast<uint32_t *>(bk_gene_chr8 + g0) = (c.x < 255u ? c.x : 255u) | ((c.y < 255u ? c.y : 255u) << 8) | ((c.z < 255u ? c.z : 255u) << 16) |
+			                                                   ((c.w < 255u ? c.w : 255u) << 24);
+		}
 	}
+	if (HOT || GCL) __syncthreads();
 	unsigned long long c_inter = 0, c_exon = 0, c_intron = 0, c_na = 0, k_or = 0, k_and = ~0ull;
 	IngestAcc acc;
 	// four CONSECUTIVE records per thread and iteration: 16-byte accesses per lane on every stream when the arrays are
@@ -75,9 +88,8 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 		uint32_t vv[U] = {0, 0, 0, 0};
 		const bool full = base + U <= n;
 		if (VEC && full) {
-			const uint4 s4 = *reinterpret_cast<const uint4 *>(slot + base), g4 = *reinterpret_cast<const uint4 *>(gene + base),
-			            a4 = *reinterpret_cast<const uint4 *>(aux + base);
-			const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + base), u23 = *reinterpret_cast<const ulonglong2 *>(umi + base + 2);
+			const uint4 s4 = stream_load_u32x4(slot + base), g4 = stream_load_u32x4(gene + base), a4 = stream_load_u32x4(aux + base);
+			const ulonglong2 u01 = stream_load_u64x2(umi + base), u23 = stream_load_u64x2(umi + base + 2);
 			sl[0] = s4.x; sl[1] = s4.y; sl[2] = s4.z; sl[3] = s4.w;
 			g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
 			a[0] = a4.x; a[1] = a4.y; a[2] = a4.z; a[3] = a4.w;
@@ -97,14 +109,25 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 			else if (HOT && (sl[q] & CB_HOT_FLAG)) cell[q] = hot_cell[sl[q] & ~CB_HOT_FLAG];
 			else cell[q] = t.slots[sl[q]].cell_id;
 			gc[q] = 0u;
-			if (STATS && base + q < n && g[q] != NO_GENE && ((a[q] >> 16) & 6u) && g[q] < gene_chr_cap) gc[q] = gene_chr[g[q]];
+			if (STATS && !GCL && base + q < n && g[q] != NO_GENE && ((a[q] >> 16) & 6u) && g[q] < gene_chr_cap) gc[q] = gene_chr[g[q]];
 		}
 #pragma unroll
 		for (int q = 0; q < U; ++q) {
 			const uint64_t r = base + q;
 			kk[q] = 0;
 			if (r >= n) continue;
-			if (STATS) { acc.add(u[q], g[q], a[q]); acc.check_chromosome(g[q], a[q], gene_chr, gene_chr_cap, gc[q]); }
+			if (STATS) {
+				acc.add(u[q], g[q], a[q]);
+				if (!GCL) acc.check_chromosome(g[q], a[q], gene_chr, gene_chr_cap, gc[q]);
+				else if (g[q] != NO_GENE && ((a[q] >> 16) & 6u)) {
+					const uint32_t c8 = g[q] < lds_genes ? bk_gene_chr8[g[q]] : 255u;
+					if (c8 != 255u) acc.chr_conflict |= c8 != (a[q] & 0xFFFFu);
+					else {   // a gene the sample did not see, a chromosome id past 254, a gene past the byte table: the exact protocol
+						acc.check_chromosome(g[q], a[q], gene_chr, gene_chr_cap, g[q] < gene_chr_cap ? gene_chr[g[q]] : 0u);
+						if (g[q] < lds_genes) { const uint32_t now = gene_chr[g[q]]; if (now < 255u) bk_gene_chr8[g[q]] = uint8_t(now); }
+					}
+				}
+			}
 			uint32_t mark = (a[q] >> 16) & 0xFFu;
 			unsigned long long gcode, ucode;
 			if (g[q] == NO_GENE) {
@@ -127,10 +150,10 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 			k_or |= k; k_and &= k;
 		}
 		if (VEC && full) {
-			if (VB == 1) *reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(vals_) + base) = vv[0] | (vv[1] << 8) | (vv[2] << 16) | (vv[3] << 24);
-			if (VB == 4) *reinterpret_cast<uint4 *>(static_cast<uint32_t *>(vals_) + base) = make_uint4(vv[0], vv[1], vv[2], vv[3]);
-			*reinterpret_cast<ulonglong2 *>(keys + base) = make_ulonglong2(kk[0], kk[1]);
-			*reinterpret_cast<ulonglong2 *>(keys + base + 2) = make_ulonglong2(kk[2], kk[3]);
+			if (VB == 1) stream_store_u32(reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(vals_) + base), vv[0] | (vv[1] << 8) | (vv[2] << 16) | (vv[3] << 24));
+			if (VB == 4) stream_store_u32x4(static_cast<uint32_t *>(vals_) + base, vv[0], vv[1], vv[2], vv[3]);
+			stream_store_u64x2(keys + base, kk[0], kk[1]);
+			stream_store_u64x2(keys + base + 2, kk[2], kk[3]);
 		} else {
 #pragma unroll
 			for (int q = 0; q < U; ++q) if (base + q < n) keys[base + q] = kk[q];

@@ -238,6 +238,53 @@ struct PinnedBuf {
 // ---- wave / block primitives (256- or 512-thread blocks, 64-lane waves) ----
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
+// Streaming accesses (data read or written exactly once per pass): the non-temporal forms keep them from displacing the
+// randomly accessed tables (barcode table, gene -> chromosome) in L2.  DROPEST_STREAM_NT=0 at compile time restores plain accesses.
+#ifndef DROPEST_STREAM_NT
+#define DROPEST_STREAM_NT 1
+#endif
+typedef uint32_t nt_v4u32 __attribute__((ext_vector_type(4)));
+typedef unsigned long long nt_v2u64 __attribute__((ext_vector_type(2)));
+__device__ inline uint4 stream_load_u32x4(const uint32_t *p) {
+#if DROPEST_STREAM_NT
+	const nt_v4u32 v = __builtin_nontemporal_load(reinterpret_cast<const nt_v4u32 *>(p));
+#else
+	const nt_v4u32 v = *reinterpret_cast<const nt_v4u32 *>(p);
+#endif
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ inline ulonglong2 stream_load_u64x2(const unsigned long long *p) {
+#if DROPEST_STREAM_NT
+	const nt_v2u64 v = __builtin_nontemporal_load(reinterpret_cast<const nt_v2u64 *>(p));
+#else
+	const nt_v2u64 v = *reinterpret_cast<const nt_v2u64 *>(p);
+#endif
+	return make_ulonglong2(v.x, v.y);
+}
+__device__ inline void stream_store_u64x2(unsigned long long *p, unsigned long long a, unsigned long long b) {
+	nt_v2u64 v; v.x = a; v.y = b;
+#if DROPEST_STREAM_NT
+	__builtin_nontemporal_store(v, reinterpret_cast<nt_v2u64 *>(p));
+#else
+	*reinterpret_cast<nt_v2u64 *>(p) = v;
+#endif
+}
+__device__ inline void stream_store_u32x4(uint32_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+	nt_v4u32 v; v.x = a; v.y = b; v.z = c; v.w = d;
+#if DROPEST_STREAM_NT
+	__builtin_nontemporal_store(v, reinterpret_cast<nt_v4u32 *>(p));
+#else
+	*reinterpret_cast<nt_v4u32 *>(p) = v;
+#endif
+}
+__device__ inline void stream_store_u32(uint32_t *p, uint32_t a) {
+#if DROPEST_STREAM_NT
+	__builtin_nontemporal_store(a, p);
+#else
+	*p = a;
+#endif
+}
+
 __device__ inline uint32_t wave_id() { return threadIdx.x >> 6; }
 
 __device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {

@@ -104,11 +104,14 @@ def test_sampled_table_sizing_and_hot_list_on_small_streams(seed, monkeypatch):
         run_case(rng, n=30_000, n_cb=30_000, n_gene=3, n_umi=4, cb_len=(16, 16), min_before=0, min_after=0)   # nothing repeats: no hot list, growth
 
 
-@pytest.mark.parametrize("twist", ["longer_umi", "escaped_umi", "gene_on_two_chromosomes", "higher_gene_id", "none"])
+@pytest.mark.parametrize("twist", ["longer_umi", "escaped_umi", "gene_on_two_chromosomes", "higher_gene_id", "none",
+                                   "chromosome_ids_past_254", "chromosome_ids_past_254_gene_on_two", "rare_gene_on_two_chromosomes"])
 def test_key_layout_planned_from_a_sample_is_checked(twist, monkeypatch):
     """Large single-context passes plan the key layout from every 256th read and gather the exact statistics with the key pass
     (cb_insert then reads the barcodes only).  What the sample cannot see -- one longer UMI, the only UMI with an N, a gene that
-    also occurs on a second chromosome, a gene id one bit wider -- must lead to a second key pass, never to a wrong key."""
+    also occurs on a second chromosome, a gene id one bit wider -- must lead to a second key pass, never to a wrong key.  The key pass
+    answers "same chromosome as before?" from a byte table in LDS (k_misc.h: GCL); chromosome ids that do not fit a byte, genes the sample
+    never saw and genes past the table take the exact path."""
     monkeypatch.setenv("DROPEST_CB_SAMPLE_MIN", "1000")
     rng = np.random.default_rng(4242)
     cb, umi, gene, aux, side = random_stream(rng, n=30_000, n_cb=300, n_gene=100, n_umi=200, cb_len=(12, 12), umi_len=(6, 6), p_nogene=0.05)
@@ -127,12 +130,21 @@ def test_key_layout_planned_from_a_sample_is_checked(twist, monkeypatch):
         aux[at] = (aux[at] & np.uint32(0xFFFF0000)) | np.uint32(((int(aux[at]) & 0xFFFF) + 1) % 5) | np.uint32(2 << 16)
     elif twist == "higher_gene_id":
         gene[at] = 100 + 200                                  # ids stay first-seen dense enough for the test: canonical_stream below
+    elif twist.startswith("chromosome_ids_past_254"):
+        aux = np.where(has, aux + np.uint32(300), aux).astype(np.uint32)       # 300 .. 304: no byte of the LDS table can hold them
+        if twist.endswith("gene_on_two"):
+            aux[at] = (aux[at] & np.uint32(0xFFFF0000)) | np.uint32(300 + ((int(aux[at]) & 0xFFFF) - 300 + 1) % 5) | np.uint32(2 << 16)
+    elif twist == "rare_gene_on_two_chromosomes":
+        for k, pos in enumerate((at, at + 4001)):             # a gene with two reads only, on two chromosomes, neither read in a sample
+            assert pos % 256 and pos % 2048
+            gene[pos] = 100; aux[pos] = np.uint32((2 << 16) | (1 + k))
     cb, umi, gene, aux = parity.canonical_stream(cb, umi, gene, aux)
     o = parity.oracle_run(Oracle, dict(min_genes_before=1, min_genes_after=2), cb, umi, gene, aux, side)
     c = parity.gpu_run(dict(min_genes_before_merge=1, min_genes_after_merge=2), cb, umi, gene, aux, side, profile=True)
     parity.compare(o, c, side)
     redone = c.kernel_stats().get("count:key_plan_redone", {"launches": 0})["launches"]
-    assert (redone >= 1) == (twist in ("longer_umi", "escaped_umi", "gene_on_two_chromosomes")), (twist, redone)
+    assert (redone >= 1) == (twist in ("longer_umi", "escaped_umi", "gene_on_two_chromosomes", "chromosome_ids_past_254_gene_on_two",
+                                       "rare_gene_on_two_chromosomes")), (twist, redone)
 
 
 def test_variable_lengths_and_ns():
