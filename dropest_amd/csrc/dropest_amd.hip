@@ -244,6 +244,11 @@ void dropest_ctx::build_cb_table() {
 		u32 head[4 + CB_HOT_LEVELS] = {0};
 		fetch(head, scalars.p, sizeof(head));
 		const u32 distinct = head[0];
+		if (getenv("DROPEST_CB_TRACE")) {
+			fprintf(stderr, "[cb] sample of %u reads: %u distinct; barcodes with >= t sample hits:", n_s, distinct);
+			for (int l = 0; l < CB_HOT_LEVELS; ++l) fprintf(stderr, " %u:%u", cb_hot_threshold(l), head[4 + l]);
+			fprintf(stderr, "\n");
+		}
 		const uint64_t est = std::min<uint64_t>(n_reads, uint64_t(distinct) * stride);
 		cap = 1024; while (cap < est + est / 2) cap <<= 1;   // load <= 0.67 even when the estimate is exact
 		n_hot = 0;
@@ -310,6 +315,23 @@ void dropest_ctx::build_cb_table() {
 				if (lazy_stats) { if (vec) go(cb_insert_hot_kernel<true, false>); else go(cb_insert_hot_kernel<false, false>); }
 				else if (vec) go(cb_insert_hot_kernel<true>); else go(cb_insert_hot_kernel<false>);
 			});
+#ifdef DROPEST_CBI_PROBE
+			// tuning aid (DROPEST_EXTRA_HIPCC_FLAGS=-DDROPEST_CBI_PROBE at build time, DROPEST_CBI_PROBE=1 at run time): the same pass again
+			// over the finished table with parts of it switched off, slots into a scratch array -- what each part costs (profiles/NOTES_r03.md)
+			if (lazy_stats && vec && getenv("DROPEST_CBI_PROBE")) {
+				keys_a.ensure(n);
+				auto again = [&](const char *name, auto kernel) {
+					HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+					timed(name, double(n) * 12, [&] { hipLaunchKernelGGL(kernel, dim3(hb), dim3(1024), lds, stream, d_cb, d_umi, d_gene, d_aux, n, table, hot, reinterpret_cast<u32 *>(keys_a.p), gene_chr.p, GENE_CHR_CAP, d_ingest.p); });
+				};
+				again("cbi:again", cb_insert_hot_kernel<true, false, 0>);
+				again("cbi:no_probe", cb_insert_hot_kernel<true, false, 1>);
+				again("cbi:no_lds", cb_insert_hot_kernel<true, false, 2>);
+				again("cbi:no_atomics", cb_insert_hot_kernel<true, false, 4>);
+				again("cbi:no_probe_no_lds", cb_insert_hot_kernel<true, false, 3>);
+				again("cbi:no_probe_no_atomics", cb_insert_hot_kernel<true, false, 5>);
+			}
+#endif
 		} else {
 		n_hot = 0;   // (a rebuilt table: the slots of the first attempt are gone)
 		timed("cb_insert", double(n) * (lazy_stats ? 8 + 4 : 8 + 8 + 4 + 4 + 4), [&] {

@@ -330,8 +330,8 @@ __global__ __launch_bounds__(256) void cb_sample_distinct_kernel(const unsigned 
 // saw most often (at most CB_HOT_MAX) get a read-only hash table in LDS: a hit costs no memory request at all.
 constexpr uint32_t CB_HOT_MAX = 4096, CB_HOT_LDS = 8192, CB_HOT_FLAG = 0x80000000u;
 constexpr int CB_HOT_LEVELS = 24;
-// 4, 6, 8, 12, 16, 24, ... sample hits (steps of 1.33-1.5x; with the steps of 4x of earlier rounds the C2 stream listed 754 barcodes, now
-// 1 080, C3 134 -> 455).  The cells of one experiment are of similar size: one step further down admits nearly all of them at once.
+// 4, 6, 8, 12, 16, 24, ... sample hits (steps of 1.33-1.5x; with the steps of 4x of earlier rounds the C2 stream listed 2 262 of its
+// 5 000 real cells, now 3 240; C3 at 1e9 reads 401 -> 1 365 of 50 000).  DROPEST_CB_TRACE=1 prints the counts per threshold.
 __device__ __host__ inline uint32_t cb_hot_threshold(int level) { return ((level & 1) ? 6u : 4u) << (level >> 1); }
 // how many sampled barcodes reach each threshold
 __global__ __launch_bounds__(256) void cb_hot_count_kernel(CbTable ts, uint32_t *__restrict__ counts) {
@@ -371,7 +371,9 @@ __global__ __launch_bounds__(256) void cb_hot_preinsert_kernel(const unsigned lo
 // CU's 160 KB); slot_out[r] = CB_HOT_FLAG | hot index for a hit, the table slot otherwise.  Per-entry minimum of the read
 // ordinals seen by this workgroup keeps the atomics on the table to the few reads that lower it.
 struct CbHot { const unsigned long long *key; const uint32_t *slot; uint32_t n; };
-template <bool VEC, bool STATS = true>
+// EXP (timing probes, results not usable; launched only by builds with -DDROPEST_CBI_PROBE, see dropest_ctx::build_cb_table):
+// 1 no table probe, 2 no LDS look-up, 4 no atomics
+template <bool VEC, bool STATS = true, int EXP = 0>
 __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long long *__restrict__ cb,
                                                              const unsigned long long *__restrict__ umi,
                                                              const uint32_t *__restrict__ gene,
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 		for (int j = 0; j < ILP; ++j) {   // LDS look-ups of the four barcodes
 			h[j] = mix64(k[j]);
 			hit[j] = 0xFFFFFFFFu;
-			if (r0 + j >= n) continue;
+			if (r0 + j >= n || (EXP & 2)) continue;
 			uint32_t i = uint32_t(h[j] >> 40) & (CB_HOT_LDS - 1);
 			for (;;) {
 				const unsigned long long e = lk[i];
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 		for (int j = 0; j < ILP; ++j) {   // the others probe the table: independent 16-byte loads in flight together
 			h[j] &= t.mask;
 			v[j] = make_uint4(0u, 0u, 0u, 0u);
-			if (r0 + j < n && hit[j] == 0xFFFFFFFFu) v[j] = *reinterpret_cast<const uint4 *>(&t.slots[h[j]]);
+			if (!(EXP & 1) && r0 + j < n && hit[j] == 0xFFFFFFFFu) v[j] = *reinterpret_cast<const uint4 *>(&t.slots[h[j]]);
 		}
 		uint32_t pending = 0, hinted = 0;
 		unsigned long long seen[ILP];
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 		for (int j = 0; j < ILP; ++j) {
 			seen[j] = (unsigned long long)v[j].x | ((unsigned long long)v[j].y << 32);
 			sl[j] = uint32_t(h[j]);
-			if (r0 + j < n && hit[j] == 0xFFFFFFFFu) {
+			if (!(EXP & 1) && r0 + j < n && hit[j] == 0xFFFFFFFFu) {
 				if (seen[j] == k[j]) hinted |= 1u << j;   // found at once: v[j].z is a recent value of its first ordinal
 				else pending |= 1u << j;
 			}
@@ -477,13 +479,13 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 			if (hit[j] != 0xFFFFFFFFu) {
 				const uint32_t e = hit[j], hi = li[e];
 				sl[j] = CB_HOT_FLAG | hi;
-				if (uint32_t(r) < lf[e]) {
+				if (!(EXP & 4) && uint32_t(r) < lf[e]) {
 					const uint32_t old = atomicMin(&lf[e], uint32_t(r));
 					if (uint32_t(r) < old) atomicMax(&t.slots[hot.slot[hi]].nfirst, ~uint32_t(r));
 				}
 			} else {
 				const uint32_t first_hint = ((hinted >> j) & 1u) ? ~v[j].z : 0xFFFFFFFFu;
-				if (uint32_t(r) < first_hint) atomicMax(&t.slots[sl[j]].nfirst, ~uint32_t(r));
+				if (!(EXP & 5) && uint32_t(r) < first_hint) atomicMax(&t.slots[sl[j]].nfirst, ~uint32_t(r));
 			}
 			if (STATS) {
 				if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
