@@ -113,6 +113,8 @@ def lib():
         "dropest_add_umi_to_cell": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, vp, C.c_uint32]),
         "dropest_umi_first_seen": (C.c_int, [vp, u64p, vp]),
         "dropest_set_umi_qualities": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64]),
+        "dropest_set_umi_qualities_var": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64]),
+        "dropest_cell_molecule_quality_lengths": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp]),
         "dropest_umi_quality_length": (C.c_int, [vp, P(C.c_uint32)]),
         "dropest_cell_molecule_qualities": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp]),
         "dropest_poisson_intersection_prob": (C.c_int, [vp, C.c_uint64, C.c_uint64, u64p, P(C.c_double), P(C.c_double)]),
@@ -204,6 +206,7 @@ EXPORTED_SYMBOLS = [
     "dropest_real_candidate_rows", "dropest_dev_copy_device", "dropest_umi_distribution",
     "dropest_collisions_adjusted_sizes", "dropest_poisson_intersection_prob",
     "dropest_set_umi_qualities", "dropest_umi_quality_length", "dropest_cell_molecule_qualities",
+    "dropest_set_umi_qualities_var", "dropest_cell_molecule_quality_lengths",
     "dropest_exclude_cell", "dropest_merge_cells", "dropest_merge_umis",
     "dropest_chr_stats", "dropest_merge_target", "dropest_kernel_stats", "dropest_set_profiling", "dropest_set_profiling_filter", "dropest_prefetch_raw_matrix", "dropest_radix_plan", "dropest_stream",
     "dropest_sort_layout", "dropest_host_register", "dropest_host_unregister", "dropest_ingest", "dropest_ingest_summary_get", "dropest_ingest_summary_set",
@@ -604,16 +607,26 @@ class Context:
             self._chk(self.L.dropest_umi_first_seen(self.h, C.byref(n), out.ctypes.data))
         return out
 
-    def set_umi_qualities(self, qual):
-        """qual: uint8 array [n_reads, quality_length] (phred+33 characters), read order."""
+    def set_umi_qualities(self, qual, lengths=None):
+        """qual: uint8 array [n_reads, quality_length] (phred+33 characters), read order; lengths: per read, when the strings differ in length."""
         qual = np.ascontiguousarray(qual, np.uint8)
         assert qual.ndim == 2
-        self._chk(self.L.dropest_set_umi_qualities(self.h, qual.ctypes.data, qual.shape[1], qual.shape[0]))
+        if lengths is None:
+            self._chk(self.L.dropest_set_umi_qualities(self.h, qual.ctypes.data, qual.shape[1], qual.shape[0]))
+        else:
+            lengths = np.ascontiguousarray(lengths, np.uint8)
+            assert lengths.shape == (qual.shape[0],)
+            self._chk(self.L.dropest_set_umi_qualities_var(self.h, qual.ctypes.data, qual.shape[1], lengths.ctypes.data, qual.shape[0]))
 
     def umi_quality_length(self):
         q = C.c_uint32()
         self._chk(self.L.dropest_umi_quality_length(self.h, C.byref(q)))
         return q.value
+
+    def cell_molecule_quality_lengths(self, cell, n):
+        out = np.zeros(n, np.uint32)
+        self._chk(self.L.dropest_cell_molecule_quality_lengths(self.h, cell, n, out.ctypes.data))
+        return out
 
     def cell_molecule_qualities(self, cell, n):
         """Quality sums [n, quality_length] of the cell's molecules, in the order of cell_molecules()."""

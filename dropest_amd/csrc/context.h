@@ -553,6 +553,9 @@ struct dropest_ctx {
 	dropest::DevBuf<u32> mp_bv, mp_bv2, mp_astart;
 	// UMI quality sums (quality.h)
 	dropest::DevBuf<uint8_t> umi_qual;          // [qual_reads][qual_len], read order
+	dropest::DevBuf<uint8_t> umi_qual_lens;     // [qual_reads] (qual_var) the length of every read's string, <= qual_len
+	bool qual_var = false;                      // dropest_set_umi_qualities_var: strings of several lengths, rows padded to qual_len
+	u32 qual_stride() const { return (qual_len + 2u) & ~1u; }   // words of a sums row: the sums, padding to whole pairs, the molecule's length last
 	u32 qual_len = 0;
 	uint64_t qual_reads = 0;
 	bool have_qual = false;
@@ -563,7 +566,7 @@ struct dropest_ctx {
 	std::vector<u32> merge_rank;                // per cell id: position in its target's merge order (0 = not merged away)
 	void accumulate_umi_qualities();
 	void requality_after_fold(const u64 *sorted_key, const u32 *old_row, u32 n_old, const u64 *new_key, u32 n_new);
-	void fetch_quality_rows(const std::vector<u32> &rows, uint32_t *out);
+	void fetch_quality_rows(const std::vector<u32> &rows, uint32_t *out, uint32_t *out_len = nullptr);
 	dropest::DevBuf<u32> umi_first;
 	void fetch_real_cells();
 	void request_filtered(u32 genes_threshold, int max_cells);   // CellsDataContainer::update_filtered_gene_counts, lazily

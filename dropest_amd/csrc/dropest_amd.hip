@@ -1976,13 +1976,28 @@ dropest_status dropest_set_umi_qualities(dropest_ctx *ctx, const uint8_t *qualit
 		if (quality_length > 255) throw UnsupportedError("UMI quality strings longer than 255");
 		if (n_reads && quality_length && !qualities) throw InvalidError("null quality array");
 		HIP_CHECK(hipSetDevice(ctx->cfg.device));
-		ctx->qual_len = quality_length; ctx->qual_reads = n_reads; ctx->have_qual = true;
+		ctx->qual_len = quality_length; ctx->qual_reads = n_reads; ctx->have_qual = true; ctx->qual_var = false;
 		const size_t bytes = size_t(n_reads) * quality_length;
 		if (bytes) {
 			ctx->umi_qual.alloc(bytes); ctx->umi_qual.mark_persistent();
 			HIP_CHECK(hipMemcpyAsync(ctx->umi_qual.p, qualities, bytes, hipMemcpyHostToDevice, ctx->stream));
 			HIP_CHECK(stream_wait(ctx->stream));
 		}
+	});
+}
+
+dropest_status dropest_set_umi_qualities_var(dropest_ctx *ctx, const uint8_t *qualities, uint32_t row_bytes, const uint8_t *lengths, uint64_t n_reads) {
+	const dropest_status st = dropest_set_umi_qualities(ctx, qualities, row_bytes, n_reads);
+	if (st != DROPEST_OK || !lengths) return st;
+	return guarded([&] {
+		for (uint64_t i = 0; i < n_reads; ++i)
+			if (lengths[i] > row_bytes) throw InvalidError("a quality length beyond the row width (" + std::to_string(row_bytes) + ")");
+		if (n_reads) {
+			ctx->umi_qual_lens.alloc(n_reads); ctx->umi_qual_lens.mark_persistent();
+			HIP_CHECK(hipMemcpyAsync(ctx->umi_qual_lens.p, lengths, n_reads, hipMemcpyHostToDevice, ctx->stream));
+			HIP_CHECK(stream_wait(ctx->stream));
+		}
+		ctx->qual_var = true;
 	});
 }
 
@@ -1993,8 +2008,22 @@ dropest_status dropest_umi_quality_length(dropest_ctx *ctx, uint32_t *quality_le
 	});
 }
 
+static void cell_molecule_quality_fetch(dropest_ctx *ctx, uint64_t cell_id, uint64_t n, uint32_t *quality_sums, uint32_t *lengths);
 dropest_status dropest_cell_molecule_qualities(dropest_ctx *ctx, uint64_t cell_id, uint64_t n, uint32_t *quality_sums) {
 	return guarded([&] {
+		if (!quality_sums && ctx && ctx->have_qual && ctx->qual_len) throw InvalidError("null output array");
+		cell_molecule_quality_fetch(ctx, cell_id, n, quality_sums, nullptr);
+	});
+}
+dropest_status dropest_cell_molecule_quality_lengths(dropest_ctx *ctx, uint64_t cell_id, uint64_t n, uint32_t *lengths) {
+	return guarded([&] {
+		if (!lengths) throw InvalidError("null output array");
+		for (uint64_t i = 0; i < n; ++i) lengths[i] = 0;
+		cell_molecule_quality_fetch(ctx, cell_id, n, nullptr, lengths);
+	});
+}
+static void cell_molecule_quality_fetch(dropest_ctx *ctx, uint64_t cell_id, uint64_t n, uint32_t *quality_sums, uint32_t *lengths) {
+	{
 		need_init(ctx);
 		if (cell_id >= ctx->n_cells) throw RangeError("cell index out of range");
 		if (!ctx->have_qual || ctx->qual_len == 0) { if (n) { /* nothing to write: quality length 0 */ } return; }
@@ -2009,9 +2038,8 @@ dropest_status dropest_cell_molecule_qualities(dropest_ctx *ctx, uint64_t cell_i
 		fetch_molecule_range(ctx, mb, me, k, r, m);
 		for_each_molecule(ctx, k, r, m, [&](u32, u32, u64, u32, uint8_t, u32 row) { rows.push_back(row); }, mb);
 		if (rows.size() != n) throw InvalidError("the cell has " + std::to_string(rows.size()) + " molecules, not " + std::to_string(n));
-		if (!quality_sums) throw InvalidError("null output array");
-		ctx->fetch_quality_rows(rows, quality_sums);
-	});
+		ctx->fetch_quality_rows(rows, quality_sums, lengths);
+	}
 }
 
 dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *ncols, uint64_t *nnz,
@@ -2442,6 +2470,7 @@ dropest_status dropest_clear_reads(dropest_ctx *ctx) {
 		ctx->store.clear(); ctx->store_chunk = -1;
 		ctx->n_reads = 0;
 		ctx->d_cb = ctx->d_umi = nullptr; ctx->d_gene = ctx->d_aux = nullptr;
+		ctx->have_qual = ctx->qual_var = false; ctx->qual_len = 0; ctx->qual_reads = 0;   // the qualities belonged to those reads
 	});
 }
 

@@ -228,11 +228,8 @@ void CellsDataContainer::add_record(const ReadInfo &r) {   // CellsDataContainer
 	_cb.push_back(encode(r.params.cell_barcode(), _side_cb));
 	uint32_t chr = 0;
 	if (has_gene) {
-		// UMI::add_read checks the quality length per molecule (UMI.cpp:26-28); here: one length per container
 		const size_t ql = r.params.umi_quality().size();
-		if (_umi_quality_length == size_t(-1)) _umi_quality_length = ql;
-		else if (ql != _umi_quality_length)
-			throw std::runtime_error("Wrong quality length: " + std::to_string(ql) + ", expected: " + std::to_string(_umi_quality_length));
+		note_quality_length(ql);
 		append_quality(r.params.umi_quality().data(), ql, true);
 		_umi.push_back(encode(r.params.umi(), _side_umi));   // UMI side strings: first seen on gene-bearing reads only
 		_gene.push_back(uint32_t(_gene_indexer.add(r.gene)));
@@ -297,6 +294,9 @@ void CellsDataContainer::add_records_packed(const uint64_t *cb, const uint64_t *
 	flush();                                   // whatever add_record collected comes first
 	if (_umi_quality_length == size_t(-1))     // the first gene-bearing read fixes the quality length: 0 (no quality strings)
 		for (size_t i = 0; i < n; ++i) if (gene[i] != DROPEST_NO_GENE) { _umi_quality_length = 0; _qual_pending = 0; break; }
+	if (_umi_quality_length == size_t(-1)) _qual_pending += n;   // (only gene-less reads so far: still no length)
+	_qual_reads += n;                                            // these reads carry no quality string: rows of length 0
+	if (!_qual_lens.empty()) _qual_lens.insert(_qual_lens.end(), n, uint8_t(0));
 	send_side_strings(_ctx);
 	for (size_t at = 0; at < n; at += BATCH * 8) {
 		const size_t m = std::min(n - at, BATCH * 8);
@@ -323,9 +323,7 @@ void CellsDataContainer::add_record(const ParsedRead &r) {   // same statements 
 	uint32_t chr = 0;
 	if (has_gene) {
 		const size_t ql = r.umi_quality_length;
-		if (_umi_quality_length == size_t(-1)) _umi_quality_length = ql;
-		else if (ql != _umi_quality_length)
-			throw std::runtime_error("Wrong quality length: " + std::to_string(ql) + ", expected: " + std::to_string(_umi_quality_length));
+		note_quality_length(ql);
 		append_quality(r.umi_quality.data(), ql, true);
 		_umi.push_back(r.umi_code ? r.umi_code : encode(std::string(r.umi), _side_umi));
 		uint32_t gid;
@@ -352,6 +350,8 @@ void CellsDataContainer::add_record(const ParsedRead &r) {   // same statements 
 // One fixed-length quality row per read for dropest_set_umi_qualities: the bytes of gene-bearing reads, zeros for reads
 // without a gene (never read: they do not reach Gene::add_umi).
 void CellsDataContainer::append_quality(const char *q, size_t len, bool has_gene) {
+	++_qual_reads;
+	if (!_qual_lens.empty()) _qual_lens.push_back(uint8_t(has_gene ? len : 0));
 	if (!has_gene) {
 		if (_umi_quality_length == size_t(-1)) ++_qual_pending;
 		else _qual.insert(_qual.end(), _umi_quality_length, uint8_t(0));
@@ -359,6 +359,26 @@ void CellsDataContainer::append_quality(const char *q, size_t len, bool has_gene
 	}
 	if (_qual_pending) { _qual.insert(_qual.end(), _qual_pending * _umi_quality_length, uint8_t(0)); _qual_pending = 0; }
 	_qual.insert(_qual.end(), reinterpret_cast<const uint8_t *>(q), reinterpret_cast<const uint8_t *>(q) + len);
+	if (len < _umi_quality_length) _qual.insert(_qual.end(), _umi_quality_length - len, uint8_t(0));   // (only with several lengths)
+}
+
+// The quality length is a property of the MOLECULE in the reference (fixed by the read that creates it, Gene.cpp:20; UMI::add_read throws
+// "Wrong quality length" for a later read of the same molecule with another one, UMI.cpp:26-28).  Reads of different molecules may differ:
+// from the first such read on, the length of every read is kept beside the rows (widened to the longest string), and the per-molecule
+// check runs on the device in set_initialized (dropest_set_umi_qualities_var) -- same exception text, for the read the reference would have
+// stopped at.
+void CellsDataContainer::note_quality_length(size_t ql) {
+	if (ql > 255) throw std::runtime_error("UMI quality strings longer than 255");
+	if (_umi_quality_length == size_t(-1)) { _umi_quality_length = ql; return; }
+	if (ql == _umi_quality_length && _qual_lens.empty()) return;
+	if (_qual_lens.empty()) _qual_lens.assign(_qual_reads, uint8_t(_umi_quality_length));   // (rows of gene-less reads are never looked at)
+	if (ql > _umi_quality_length) {   // widen the rows
+		const size_t old = _umi_quality_length, rows = _qual_reads - _qual_pending;
+		std::vector<uint8_t> wide(rows * ql, uint8_t(0));
+		for (size_t i = 0; old && i < rows; ++i) std::memcpy(wide.data() + i * ql, _qual.data() + i * old, old);
+		_qual.swap(wide);
+		_umi_quality_length = ql;
+	}
 }
 
 void CellsDataContainer::flush() {
@@ -390,7 +410,8 @@ void CellsDataContainer::set_initialized() {   // CellsDataContainer.cpp:163-175
 		return;
 	}
 	if (_umi_quality_length != size_t(-1) && _umi_quality_length > 0) {
-		check(dropest_set_umi_qualities(_ctx, _qual.data(), uint32_t(_umi_quality_length), _qual.size() / _umi_quality_length));
+		if (_qual_lens.empty()) check(dropest_set_umi_qualities(_ctx, _qual.data(), uint32_t(_umi_quality_length), _qual.size() / _umi_quality_length));
+		else check(dropest_set_umi_qualities_var(_ctx, _qual.data(), uint32_t(_umi_quality_length), _qual_lens.data(), _qual_lens.size()));
 		std::vector<uint8_t>().swap(_qual);
 	}
 	const dropest_status st = dropest_set_initialized(_ctx);
@@ -711,8 +732,9 @@ std::vector<Cell::MoleculeRow> Cell::molecules() const {
 		throw std::runtime_error(dropest_last_error());
 	uint32_t ql = 0;
 	if (dropest_umi_quality_length(h, &ql) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
-	std::vector<uint32_t> qsum(size_t(n) * ql);
+	std::vector<uint32_t> qsum(size_t(n) * ql), qlen(n, 0u);
 	if (n && ql && dropest_cell_molecule_qualities(h, _id, n, qsum.data()) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+	if (n && ql && dropest_cell_molecule_quality_lengths(h, _id, n, qlen.data()) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
 	std::vector<MoleculeRow> out;
 	for (size_t i = 0; i < n; ++i) {
 		UMI::Mark m;
@@ -720,7 +742,7 @@ std::vector<Cell::MoleculeRow> Cell::molecules() const {
 		if (mark[i] & 2) m.add(UMI::Mark::HAS_EXONS);
 		if (mark[i] & 4) m.add(UMI::Mark::HAS_INTRONS);
 		out.push_back(MoleculeRow{_owner->gene_indexer().get_value(gene[i]), _owner->decode(umi[i]), reads[i], m,
-		                          std::vector<unsigned>(qsum.begin() + long(i * ql), qsum.begin() + long((i + 1) * ql))});
+		                          std::vector<unsigned>(qsum.begin() + long(i * ql), qsum.begin() + long(i * ql + qlen[i]))});   // _sum_quality of ITS length
 	}
 	return out;
 }

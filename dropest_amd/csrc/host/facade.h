@@ -295,9 +295,12 @@ private:
 	// pending batch
 	std::vector<uint64_t> _cb, _umi;
 	std::vector<uint32_t> _gene, _aux;
-	size_t _umi_quality_length = size_t(-1);
+	size_t _umi_quality_length = size_t(-1);  // row width of _qual: the longest UMI quality string so far (-1: no gene-bearing read yet)
 	std::vector<uint8_t> _qual;               // qualities of every read so far, _umi_quality_length bytes each
 	size_t _qual_pending = 0;                 // gene-less reads seen before the length was known
+	size_t _qual_reads = 0;                   // reads that went through append_quality
+	std::vector<uint8_t> _qual_lens;          // per read, once two gene-bearing reads differed in length (UMI.cpp:26-28 is a per-molecule check)
+	void note_quality_length(size_t ql);
 	void append_quality(const char *q, size_t len, bool has_gene);
 	std::vector<std::string> _ref_names;                      // ParsedRead::ref_id -> chromosome name
 	std::vector<int32_t> _ref_chr;                            // ... -> index in _chr_indexer, -1 = not met yet

@@ -123,9 +123,12 @@ void dropest_ctx::mutate_add_umi_to_cell(u32 cell, u32 gene, uint64_t umi_code, 
 	invalidate_prefetch();
 	using namespace dropest;
 	const bool with_qual = have_qual && qual_len;
-	if (have_qual && quality_length != qual_len)   // UMI.cpp:26-28 (one quality length per container here)
-		throw InvalidError("Wrong quality length: " + std::to_string(quality_length) + ", expected: " + std::to_string(qual_len));
-	if (with_qual && !quality) throw InvalidError("null quality string");
+	// UMI.cpp:26-28: the length of a molecule's quality sums is fixed by the read that created it (checked below, once the row is known);
+	// a NEW molecule may bring any length the rows of this container can hold
+	if (have_qual && quality_length > qual_len)
+		throw UnsupportedError("add_umi_to_cell: a quality string of " + std::to_string(quality_length) + " characters, the rows of this container hold " +
+		                       std::to_string(qual_len));
+	if (with_qual && quality_length && !quality) throw InvalidError("null quality string");
 	if (!chr_from_gene) throw UnsupportedError("add_umi_to_cell needs the chromosome-from-gene record layout (a gene on two chromosomes was seen)");
 	if (gene >= layout.gene_none) throw UnsupportedError("add_umi_to_cell: the gene index does not fit the key layout of this container");
 	if (mark > 7u) throw InvalidError("add_umi_to_cell: mark out of range");
@@ -144,6 +147,16 @@ void dropest_ctx::mutate_add_umi_to_cell(u32 cell, u32 gene, uint64_t umi_code, 
 	if (umi_overrides.count(cg)) throw UnsupportedError("add_umi_to_cell on a group that the UMI merge strategy rewrote");
 	if (n_mol >= 0xFFFFFFF0u) throw UnsupportedError("molecule table would exceed 2^32 rows");
 	const u64 key = (cg << layout.umi_bits) | field;
+	if (with_qual) {   // an existing molecule: UMI::add_read's length check against the length it was created with
+		scalars.ensure(16);
+		hipLaunchKernelGGL(find_molecule_row_kernel, dim3(1), dim3(1), 0, stream, mol_key.p, n_mol, key, scalars.p);
+		hipLaunchKernelGGL(molecule_quality_length_kernel, dim3(1), dim3(1), 0, stream, mol_qsum.p, mol_qrow.p, scalars.p, qual_stride(), scalars.p + 1);
+		HIP_CHECK(hipGetLastError());
+		u32 expected = 0;
+		fetch(&expected, scalars.p + 1, 4);
+		if (expected != 0xFFFFFFFFu && expected != quality_length)
+			throw InvalidError("Wrong quality length: " + std::to_string(quality_length) + ", expected: " + std::to_string(expected));
+	}
 	const u32 row_vals[4] = {1u, mark, (mark >> 1) & 1u, (mark >> 2) & 1u};
 	const u32 total = n_mol + 1;
 	grow_preserving(mol_key, n_mol, size_t(total) + 1, stream);
@@ -151,13 +164,14 @@ void dropest_ctx::mutate_add_umi_to_cell(u32 cell, u32 gene, uint64_t umi_code, 
 	for (int k = 0; k < 4; ++k) grow_preserving(*cols[k], n_mol, size_t(total) + 1, stream);
 	HIP_CHECK(hipMemcpyAsync(mol_key.p + n_mol, &key, 8, hipMemcpyHostToDevice, stream));
 	for (int k = 0; k < 4; ++k) HIP_CHECK(hipMemcpyAsync(cols[k]->p + n_mol, &row_vals[k], 4, hipMemcpyHostToDevice, stream));
-	const size_t qstride = (size_t(qual_len) + 1) & ~size_t(1);
+	const size_t qstride = qual_stride();
 	DevBuf<u32> d_q;
 	std::vector<u32> q32(qstride, 0);
 	if (with_qual) {
 		// the read arrives with a sums row of its own (a new molecule keeps it; folded into an existing one, its bytes are added to
 		// that molecule's row afterwards: the fold itself keeps the row of the member with the smaller index, the existing one)
-		for (u32 i = 0; i < qual_len; ++i) q32[i] = quality[i];
+		for (u32 i = 0; i < quality_length; ++i) q32[i] = quality[i];
+		q32[qstride - 1] = quality_length;
 		grow_preserving(mol_qsum, size_t(n_qsum_rows) * qstride, size_t(n_qsum_rows + 1) * qstride, stream);
 		HIP_CHECK(hipMemcpyAsync(mol_qsum.p + size_t(n_qsum_rows) * qstride, q32.data(), qstride * 4, hipMemcpyHostToDevice, stream));
 		grow_preserving(mol_qrow, n_mol, size_t(total), stream);
@@ -175,7 +189,7 @@ void dropest_ctx::mutate_add_umi_to_cell(u32 cell, u32 gene, uint64_t umi_code, 
 	if (with_qual && !is_new) {
 		scalars.ensure(16);
 		hipLaunchKernelGGL(find_molecule_row_kernel, dim3(1), dim3(1), 0, stream, mol_key.p, n_mol, key, scalars.p);
-		hipLaunchKernelGGL(add_quality_row_kernel, dim3(1), dim3(256), 0, stream, mol_qsum.p, mol_qrow.p, scalars.p, u32(qstride), d_q.p, qual_len);
+		hipLaunchKernelGGL(add_quality_row_kernel, dim3(1), dim3(256), 0, stream, mol_qsum.p, mol_qrow.p, scalars.p, u32(qstride), d_q.p, quality_length);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(stream_wait(stream));
 	}

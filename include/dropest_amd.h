@@ -202,11 +202,20 @@ dropest_status dropest_umi_first_seen(dropest_ctx *ctx, uint64_t *n, uint64_t *u
  * (Gene.cpp:26-58).  The reference allows a different length per molecule and throws on a mismatch inside one
  * (UMI.cpp:26-28); one length per container covers what its BAM readers produce. */
 dropest_status dropest_set_umi_qualities(dropest_ctx *ctx, const uint8_t *qualities, uint32_t quality_length, uint64_t n_reads);
-dropest_status dropest_umi_quality_length(dropest_ctx *ctx, uint32_t *quality_length);   /* 0 when none were given */
+/* The same for strings of several lengths: rows of row_bytes bytes (shorter strings padded with anything), lengths[i] <= row_bytes
+ * characters of read i count.  The reference fixes a molecule's quality length when the molecule is created (Gene::add_umi, Gene.cpp:20:
+ * UMI(read_info.params.umi_quality().length(), 0)) and throws "Wrong quality length: <got>, expected: <molecule's>" at the first later read
+ * of the molecule with another length (UMI::add_read, UMI.cpp:26-28).  Here the check runs in set_initialized: DROPEST_ERR_INVALID with
+ * exactly that text for the EARLIEST such read of the stream -- the read whose add_record would have thrown.  lengths = NULL: all row_bytes. */
+dropest_status dropest_set_umi_qualities_var(dropest_ctx *ctx, const uint8_t *qualities, uint32_t row_bytes, const uint8_t *lengths, uint64_t n_reads);
+dropest_status dropest_umi_quality_length(dropest_ctx *ctx, uint32_t *quality_length);   /* the row width (the longest string); 0 when none were given */
 /* UMI::_sum_quality of the molecules of one cell, in the order of dropest_cell_molecules: n x quality_length sums
  * (UMI::mean_quality, UMI.cpp:46-55, is (sum - 33) / read_count in unsigned integer arithmetic).  n must equal the
  * cell's molecule count. */
 dropest_status dropest_cell_molecule_qualities(dropest_ctx *ctx, uint64_t cell_id, uint64_t n, uint32_t *quality_sums);
+/* UMI::_sum_quality.size() of the same molecules (one length per container unless dropest_set_umi_qualities_var gave several: a molecule
+ * keeps the length of the read that created it; sums beyond it are 0); all 0 on a container without qualities. */
+dropest_status dropest_cell_molecule_quality_lengths(dropest_ctx *ctx, uint64_t cell_id, uint64_t n, uint32_t *lengths);
 /* Whole molecule table, ascending (cell id, gene id, umi code). */
 dropest_status dropest_molecules(dropest_ctx *ctx, uint64_t *n, uint32_t *cell, uint32_t *gene, uint64_t *umi,
                                  uint32_t *reads, uint8_t *mark);

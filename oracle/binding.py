@@ -79,6 +79,8 @@ def oracle_lib():
         "orc_merge_cells_explicit": (C.c_int, [vp, u64, u64]), "orc_exclude_cell_explicit": (C.c_int, [vp, u64]),
         "orc_count_matrix_levels": (u64, [vp, C.c_char_p, C.c_int, vp, vp, vp]),
         "orc_add_packed_q": (C.c_int, [vp, vp, vp, vp, vp, u64, C.POINTER(C.c_char_p), vp, C.c_uint32]),
+        "orc_add_packed_qvar": (C.c_int, [vp, vp, vp, vp, vp, u64, C.POINTER(C.c_char_p), vp, C.c_uint32, vp]),
+        "orc_molecule_qualities_var": (C.c_int, [vp, C.c_uint32, vp, vp]),
         "orc_molecule_qualities": (C.c_int, [vp, C.c_uint32, vp]),
         "orc_poisson_init": (C.c_int, [vp]), "orc_poisson_distribution_size": (u64, [vp]),
         "orc_poisson_gene_intersection": (C.c_double, [vp, u64, u64]),
@@ -150,6 +152,22 @@ class Oracle:
         arr = (C.c_char_p * max(1, len(side)))(*[s.encode() for s in side])
         self._chk(self.L.orc_add_packed_q(self.h, cb.ctypes.data, umi.ctypes.data, gene.ctypes.data, aux.ctypes.data, len(cb), arr,
                                           qual.ctypes.data, qual.shape[1]))
+
+    def add_packed_qvar(self, cb, umi, gene, aux, qual, lens, side=()):
+        """Like add_packed_q for strings of several lengths: qual uint8 [n, stride], lens uint8 [n]."""
+        cb = np.ascontiguousarray(cb, np.uint64); umi = np.ascontiguousarray(umi, np.uint64)
+        gene = np.ascontiguousarray(gene, np.uint32); aux = np.ascontiguousarray(aux, np.uint32)
+        qual = np.ascontiguousarray(qual, np.uint8); lens = np.ascontiguousarray(lens, np.uint8)
+        arr = (C.c_char_p * max(1, len(side)))(*[s.encode() for s in side])
+        self._chk(self.L.orc_add_packed_qvar(self.h, cb.ctypes.data, umi.ctypes.data, gene.ctypes.data, aux.ctypes.data, len(cb), arr,
+                                             qual.ctypes.data, qual.shape[1], lens.ctypes.data))
+
+    def molecule_qualities_var(self, n_molecules, stride):
+        """(sums [n, stride], lengths [n]) of every molecule, in the order of molecules()."""
+        out = np.zeros((n_molecules, stride), np.uint32); lens = np.zeros(n_molecules, np.uint32)
+        if self.L.orc_molecule_qualities_var(self.h, stride, out.ctypes.data, lens.ctypes.data) != 0:
+            raise RuntimeError("a molecule's quality is longer than the stride")
+        return out, lens
 
     def molecule_qualities(self, n_molecules, qlen):
         """UMI::_sum_quality of every molecule, in the order of molecules()."""

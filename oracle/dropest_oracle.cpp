@@ -931,6 +931,33 @@ int orc_molecule_qualities(void *h, uint32_t qlen, uint32_t *out) {
 	return 0;
 }
 
+// strings of several lengths: rows of `stride` bytes, lens[i] characters of read i count (UMI.cpp:21-34 per molecule)
+int orc_add_packed_qvar(void *h, const uint64_t *cb, const uint64_t *umi, const uint32_t *gene, const uint32_t *aux,
+                        uint64_t n, const char *const *side, const uint8_t *qual, uint32_t stride, const uint8_t *lens) {
+	ORC_TRY
+	auto *c = static_cast<orc::Container *>(h);
+	for (uint64_t i = 0; i < n; ++i) {
+		std::string g = gene[i] == 0xFFFFFFFFu ? std::string() : "G" + std::to_string(gene[i]);
+		c->add_record(unpack2(cb[i], side), unpack2(umi[i], side), std::string(reinterpret_cast<const char *>(qual) + size_t(i) * stride, lens[i]), g,
+		              "chr" + std::to_string(aux[i] & 0xFFFFu), uint8_t((aux[i] >> 16) & 0xFF));
+	}
+	ORC_CATCH
+}
+// ... and their sums: `stride` values per molecule (zeros beyond its own length) and the length itself
+int orc_molecule_qualities_var(void *h, uint32_t stride, uint32_t *out, uint32_t *out_len) {
+	auto *c = static_cast<orc::Container *>(h);
+	uint64_t n = 0;
+	for (size_t i = 0; i < c->cells.size(); ++i)
+		for (auto const &g : c->cells[i].genes)
+			for (auto const &u : g.second) {
+				if (u.second.qual_sum.size() > stride) return -1;
+				for (uint32_t p = 0; p < stride; ++p) out[n * stride + p] = p < u.second.qual_sum.size() ? u.second.qual_sum[p] : 0u;
+				out_len[n] = uint32_t(u.second.qual_sum.size());
+				++n;
+			}
+	return 0;
+}
+
 int orc_set_initialized(void *h) { ORC_TRY static_cast<orc::Container *>(h)->set_initialized(); ORC_CATCH }
 int orc_merge_and_filter(void *h) { ORC_TRY static_cast<orc::Container *>(h)->merge_and_filter(); ORC_CATCH }
 int orc_merge_umis_only(void *h) {   // Tests/TestEstimation.cpp:525 calls the UMI strategy alone

@@ -279,6 +279,39 @@ static void testBoundaryLeftovers() {   // CellsDataContainer.h:90 add_umi_to_ce
 	CHECK_EQ(&container.cell(1), &ref);
 }
 
+static void testQualityLengthPerMolecule() {   // UMI.cpp:21-34 + Gene.cpp:20: the quality length belongs to the molecule
+	auto mk = [](const char *cb, const char *umi, const char *qual, const char *gene) {
+		return ReadInfo(Tools::ReadParameters(cb, umi, "", qual), gene, "chr1", Mark(Mark::HAS_EXONS));
+	};
+	{
+		CellsDataContainer c(std::make_shared<Merge::DummyMergeStrategy>(0, 0), std::make_shared<Merge::UMIs::MergeUMIsStrategySimple>(1),
+		                     Mark::get_by_code(Mark::DEFAULT_CODE));
+		c.add_record(mk("AAATTAGGTCCA", "AAACCT", "IIIIII", "Gene1"));
+		c.add_record(mk("AAATTAGGTCCA", "CCCCCT", "III", "Gene1"));        // another molecule, another length: fine in the reference
+		c.add_record(mk("AAATTAGGTCCA", "AAACCT", "JJJJJJ", "Gene1"));
+		c.add_record(mk("AAATTAGGTCCA", "CCCCCT", "JJJ", "Gene1"));
+		c.add_record(mk("AAATTAGGTCCA", "GGGCCT", "", "Gene2"));           // and one without any quality
+		c.set_initialized();
+		size_t seen = 0;
+		for (auto const &m : c.cell(0).molecules()) {
+			if (m.umi == "AAACCT") { ++seen; CHECK_EQ(m.sum_quality.size(), size_t(6)); if (m.sum_quality.size() == 6) CHECK_EQ(m.sum_quality[5], unsigned('I' + 'J')); }
+			if (m.umi == "CCCCCT") { ++seen; CHECK_EQ(m.sum_quality.size(), size_t(3)); if (m.sum_quality.size() == 3) CHECK_EQ(m.sum_quality[0], unsigned('I' + 'J')); }
+			if (m.umi == "GGGCCT") { ++seen; CHECK_EQ(m.sum_quality.size(), size_t(0)); }
+		}
+		CHECK_EQ(seen, size_t(3));
+	}
+	{
+		CellsDataContainer c(std::make_shared<Merge::DummyMergeStrategy>(0, 0), std::make_shared<Merge::UMIs::MergeUMIsStrategySimple>(1),
+		                     Mark::get_by_code(Mark::DEFAULT_CODE));
+		c.add_record(mk("AAATTAGGTCCA", "AAACCT", "IIIIII", "Gene1"));
+		c.add_record(mk("AAATTAGGTCCA", "CCCCCT", "III", "Gene1"));
+		c.add_record(mk("AAATTAGGTCCA", "AAACCT", "JJJJ", "Gene1"));       // the reference throws here, in add_record; this container in set_initialized
+		std::string what;
+		try { c.set_initialized(); } catch (const std::runtime_error &e) { what = e.what(); }
+		CHECK_EQ(what, std::string("Wrong quality length: 4, expected: 6"));
+	}
+}
+
 static void testMergeAndExcludeCells() {   // CellsDataContainer::merge_cells / exclude_cell (:90-109), as the strategies call them
 	Fixture f;
 	auto &c = *f.container_full;
@@ -426,6 +459,7 @@ int main(int argc, char **argv) {
 		testPoissonMerge();
 		testUMIMerge();
 		testBoundaryLeftovers();
+		testQualityLengthPerMolecule();
 		testMergeAndExcludeCells();
 		testShardedContainer();
 		testWideKeyContainer();

@@ -184,3 +184,98 @@ def test_random_streams_with_qualities(seed):
     c.merge_and_filter()
     parity.compare(o, c, side)
     _compare_qualities(o, c, umi_len, side)
+
+
+def _molecule_lengths(cb, umi, gene, seed, lo, hi):
+    """One quality length per molecule (cell barcode, gene, UMI): every read of a molecule carries the same one."""
+    h = (cb.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ (umi.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)) ^ \
+        (gene.astype(np.uint64) * np.uint64(0x165667B19E3779F9)) ^ np.uint64(seed)
+    h ^= h >> np.uint64(29)
+    return (np.uint64(lo) + (h % np.uint64(hi - lo + 1))).astype(np.uint8)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_quality_length_is_a_property_of_the_molecule(seed):
+    """UMI(quality_length) is fixed by the read that creates the molecule (Gene.cpp:20) and checked for every later read of it
+    (UMI.cpp:26-28): molecules of different lengths live side by side, through CB merges and UMI merges."""
+    import ctypes
+    from test_gpu_stress import random_stream
+    rng = np.random.default_rng(13000 + seed)
+    cb, umi, gene, aux, side = random_stream(
+        rng, n=int(rng.integers(500, 6000)), n_cb=int(rng.integers(2, 40)), n_gene=int(rng.integers(1, 12)),
+        n_umi=int(rng.integers(2, 60)), cb_len=(8, 8), umi_len=(6, 6), n_rate=0.05 if seed % 2 else 0.0)
+    stride = 9 if seed % 2 else 6                                    # odd and even row widths
+    lens = _molecule_lengths(cb, umi, gene, seed, 0 if seed == 3 else 2, stride)   # (seed 3: some molecules without any quality)
+    qual = _qualities(len(cb), stride, 200 + seed)
+    directional = seed % 3 == 0
+    okw = dict(merge_kind=2, max_cb_merge_ed=int(rng.integers(1, 6)), min_merge_fraction=float(rng.choice([0.0, 0.1, 0.3])),
+               min_genes_before=int(rng.integers(0, 3)), min_genes_after=0, umi_merge_kind=1 if directional else 0)
+    gkw = dict(merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=okw["max_cb_merge_ed"], min_merge_fraction=okw["min_merge_fraction"],
+               min_genes_before_merge=okw["min_genes_before"], min_genes_after_merge=0,
+               umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL if directional else capi.UMI_MERGE_SIMPLE)
+    libc = ctypes.CDLL("libc.so.6")
+    o = Oracle(**okw)
+    o.add_packed_qvar(cb, umi, gene, aux, qual, lens, side)
+    o.set_initialized()
+    if directional:
+        libc.srand(1)
+    o.merge_and_filter()
+    c = capi.Context(**gkw)
+    if side:
+        c.set_side_strings(side)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_umi_qualities(qual, lens)
+    c.set_initialized()
+    if directional:
+        libc.srand(1)
+    c.merge_and_filter()
+    parity.compare(o, c, side)
+    oc, og, ou, orr, om = o.molecules()
+    oq, ol = o.molecule_qualities_var(len(oc), stride)
+    merged = o.cell_rows()[:, 0] != 0
+    want = {(int(oc[i]), int(og[i]), ou[i]): (int(orr[i]), int(ol[i]), tuple(int(x) for x in oq[i])) for i in range(len(oc)) if not merged[int(oc[i])]}
+    got = {}
+    for cell in sorted({k[0] for k in want}):
+        g, u, r, m = c.cell_molecules(cell)
+        q = c.cell_molecule_qualities(cell, len(g)); ql = c.cell_molecule_quality_lengths(cell, len(g))
+        for j in range(len(g)):
+            got[(cell, int(g[j]), capi.unpack_code(u[j], side))] = (int(r[j]), int(ql[j]), tuple(int(x) for x in q[j]))
+    assert len(got) == len(want) and len({v[1] for v in want.values()}) > 1
+    bad = [k for k in want if got.get(k) != want[k]]
+    assert not bad, "quality sums / lengths differ for %d molecules, e.g. %s: got %s want %s" % (len(bad), bad[0], got.get(bad[0]), want[bad[0]])
+
+
+def test_a_read_with_another_quality_length_than_its_molecule_is_the_reference_exception():
+    """The earliest read of the stream whose length differs from its molecule's: the text of UMI::add_read's exception (UMI.cpp:27-28)."""
+    P = capi.pack_seq
+    cbs = [P("ACGTACGTACGT"), P("TTGTACGTACGA")]
+    cb = np.array([cbs[0], cbs[1], cbs[0], cbs[1], cbs[0], cbs[1]], np.uint64)
+    umi = np.array([P("ACGTAC")] * 6, np.uint64)
+    gene = np.zeros(6, np.uint32); aux = np.full(6, 2 << 16, np.uint32)
+    qual = np.full((6, 8), 40, np.uint8)
+    lens = np.array([5, 8, 5, 8, 5, 8], np.uint8)                     # two molecules, lengths 5 and 8: fine
+    o = Oracle(); o.add_packed_qvar(cb, umi, gene, aux, qual, lens)
+    c = capi.Context(); c.push_reads(cb, umi, gene, aux); c.set_umi_qualities(qual, lens); c.set_initialized()
+    assert c.cell_molecule_quality_lengths(0, 1).tolist() == [5] and c.cell_molecule_quality_lengths(1, 1).tolist() == [8]
+    assert c.cell_molecule_qualities(0, 1).tolist() == [[120] * 5 + [0] * 3]
+    # add_umi_to_cell on the initialised container: same check against the molecule's own length
+    with pytest.raises(capi.DropestError) as e:
+        c.add_umi_to_cell(0, 0, P("ACGTAC"), 2, bytes([40] * 8))
+    assert "Wrong quality length: 8, expected: 5" in str(e.value)
+    c.add_umi_to_cell(0, 0, P("ACGTAC"), 2, bytes([40] * 5))
+    assert c.cell_molecule_qualities(0, 1).tolist() == [[160] * 5 + [0] * 3]
+    c.add_umi_to_cell(0, 0, P("ACGTTT"), 2, bytes([50] * 3))          # a new molecule brings its own length
+    assert sorted(c.cell_molecule_quality_lengths(0, 2).tolist()) == [3, 5]
+    for bad_at, bad_len in ((4, 8), (3, 6)):
+        lens2 = lens.copy(); lens2[bad_at] = bad_len
+        lens2[5] = 7                                                   # a later offender of the other molecule: not the one reported
+        want = None
+        try:
+            Oracle().add_packed_qvar(cb, umi, gene, aux, qual, lens2)
+        except Exception as ex:                                        # noqa: BLE001 (the oracle raises RuntimeError with the reference's text)
+            want = str(ex)
+        assert want and "Wrong quality length" in want
+        c = capi.Context(); c.push_reads(cb, umi, gene, aux); c.set_umi_qualities(qual, lens2)
+        with pytest.raises(capi.DropestError) as e:
+            c.set_initialized()
+        assert want.split("Wrong")[1] in str(e.value), (want, str(e.value))
