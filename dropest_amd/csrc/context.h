@@ -476,6 +476,17 @@ struct dropest_ctx {
 	void pair_intersections(const std::vector<u32> &pair_base_cell, const std::vector<u32> &pair_cand_cell, std::vector<u32> &inter);
 	// PoissonRealBarcodesMergeStrategy (poisson_merge.h)
 	std::vector<double> poisson_expected_intersections(const std::vector<u32> &pair_base_cell, const std::vector<u32> &pair_cand_cell);
+	// the estimator's tables (poisson_merge.h): built from the UMI counts of this context, or of all shards (merge_shard.h)
+	struct PoissonTables { dropest::DevBuf<double> p, mult, np; dropest::DevBuf<u64> adj; u32 n_classes = 0, max_size = 0; bool ready = false; } ptab;
+	void poisson_local_umis(u32 &kept, u32 &max_size);
+	void poisson_build_tables(const u32 *d_counts, u32 n_counts, double total, u32 max_size);
+	void poisson_expected_from_keys(const u32 *d_off, u32 NP, const u64 *d_keys, u32 NK, double *expected_host);
+	// sharded -M (merge_shard.h): this shard's dense UMI histogram; the tables from the summed one; expected sizes of pairs with shipped base rows
+	void shard_merge_umi_histogram(dropest::DevBuf<u32> &hist, uint64_t &kept, u32 &max_size);
+	void shard_merge_set_umi_distribution(const u32 *d_counts, uint64_t n_counts, uint64_t kept_total, u32 max_size);
+	void shard_merge_expected(uint64_t n_pairs, const uint32_t *cand_local, const uint64_t *base_begin, const uint64_t *base_end,
+	                          const uint64_t *d_base_low, double *expected);
+	void shard_merge_decide_poisson(const uint32_t *inter, const double *expected, int64_t *target_g);
 	void decide_poisson_targets(const dropest::MergeUniverse &U, dropest::MergeSearch &S, const std::vector<u32> &inter,
 	                            const std::vector<double> &expected, std::vector<long> &targets, std::vector<u32> &target_ridx);
 	std::vector<long> compute_merge_targets(const std::vector<u32> &cells, const std::vector<u32> &ridx,

@@ -1240,7 +1240,7 @@ void dropest_ctx::run_merge_and_filter() {
 	invalidate_prefetch();
 	HostStage hs(this, "merge_and_filter");
 	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells && !external_merge_done) run_cb_merge_real();
-	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL && n_cells) run_cb_merge_real();   // same loop, Poisson decisions
+	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL && n_cells && !external_merge_done) run_cb_merge_real();   // same loop, Poisson decisions
 	if ((cfg.merge_kind == DROPEST_MERGE_SIMPLE || cfg.merge_kind == DROPEST_MERGE_POISSON_SIMPLE) && n_cells) run_cb_merge_simple();
 	if (cfg.merge_kind == DROPEST_MERGE_ALL && n_cells) run_cb_merge_all();
 	// MergeUMIsStrategy*::merge, after the CB merge (CellsDataContainer.cpp:45)

@@ -113,7 +113,8 @@ void dropest_ctx::shard_merge_search(uint64_t n_global, const uint64_t *g_barcod
                                      uint64_t n_bases, const uint32_t *base_g, const uint32_t *base_local, uint64_t *n_pairs) {
 	if (!initialized) throw InvalidError("You must initialize container");
 	if (merged) throw InvalidError("merge_and_filter was already run");
-	if (cfg.merge_kind != DROPEST_MERGE_REAL_BARCODES) throw InvalidError("shard merge needs merge_kind = REAL_BARCODES");
+	if (cfg.merge_kind != DROPEST_MERGE_REAL_BARCODES && cfg.merge_kind != DROPEST_MERGE_POISSON_REAL)
+		throw InvalidError("shard merge needs a barcode whitelist (merge_kind REAL_BARCODES or POISSON_REAL)");
 	if (n_global >= 0x7FFFFFFFull) throw UnsupportedError("more than 2^31 real cells");
 	HostStage hs(this, "shard_merge:search");
 	shard.reset(new ShardMerge());

@@ -380,6 +380,14 @@ __global__ __launch_bounds__(256) void min_rows_kernel(const unsigned long long 
 		out[i] = m;
 	}
 }
+// -M across shards: the UMI histograms of the shards added up
+__global__ __launch_bounds__(256) void sum_rows_kernel(const uint32_t *__restrict__ all, uint32_t rows, uint64_t n, uint32_t *__restrict__ out) {
+	for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
+		uint32_t sum = 0;
+		for (uint32_t r = 0; r < rows; ++r) sum += all[uint64_t(r) * n + i];
+		out[i] = sum;
+	}
+}
 __global__ __launch_bounds__(256) void ranks_to_table_kernel(const unsigned long long *__restrict__ sorted_ord, const uint32_t *__restrict__ code, uint32_t n,
                                                              uint32_t *__restrict__ table) {
 	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -824,10 +832,35 @@ void dropest_shard::cb_merge() {
 		for (int p = 0; p < world; ++p)
 			for (size_t i = 0; i < lcnt[size_t(p)]; ++i, ++at) { beg[all_listed[at].g] = all_listed[at].b + row_base[size_t(p)]; end[all_listed[at].g] = all_listed[at].e + row_base[size_t(p)]; }
 	}
+	const bool poisson = c.cfg.merge_kind == DROPEST_MERGE_POISSON_REAL;
+	if (poisson) {
+		// -M: the estimator works on the UMI distribution of ALL filtered cells and on the largest gene of any cell (PoissonTargetEstimator::init,
+		// PoissonTargetEstimator.cpp:46-59): dense histograms over the UMI field, all-gathered and added; every shard builds the same tables
+		Phase ph(this, "cbm:umi_distribution");
+		DevBuf<u32> hist, all, sum;
+		uint64_t kept = 0; u32 max_size = 0;
+		c.shard_merge_umi_histogram(hist, kept, max_size);
+		const size_t n = size_t(1) << c.layout.umi_bits;
+		uint64_t mine[3] = {kept, max_size, n};
+		std::vector<uint64_t> every(size_t(world) * 3);
+		tr->gather_host(mine, sizeof(mine), every.data());
+		uint64_t kept_total = 0; u32 max_all = 0;
+		for (int p = 0; p < world; ++p) {
+			if (every[size_t(p) * 3 + 2] != n) throw InvalidError("internal: the shards disagree on the width of the UMI field");
+			kept_total += every[size_t(p) * 3]; max_all = std::max<u32>(max_all, u32(every[size_t(p) * 3 + 1]));
+		}
+		all.alloc(n * size_t(world)); sum.alloc(n);
+		std::vector<size_t> off(static_cast<size_t>(world)), bytes(static_cast<size_t>(world), n * 4);
+		for (int p = 0; p < world; ++p) off[size_t(p)] = size_t(p) * n * 4;
+		tr->gather_dev(hist.p, all.p, off.data(), bytes.data(), c.stream);
+		hipLaunchKernelGGL(sum_rows_kernel, dim3(u32(std::min<size_t>((n + 255) / 256, 4096))), dim3(256), 0, c.stream, all.p, u32(world), uint64_t(n), sum.p);
+		HIP_CHECK(hipGetLastError());
+		c.shard_merge_set_umi_distribution(sum.p, n, kept_total, max_all);
+	}
 	// intersect: the pairs whose candidate is mine
 	std::vector<size_t> poff(size_t(world) + 1, 0);
 	for (int p = 0; p < world; ++p) poff[size_t(p) + 1] = poff[size_t(p)] + pcnt[size_t(p)];
-	struct Ans { uint64_t pair; u32 inter, pad; };
+	struct Ans { uint64_t pair; u32 inter, pad; double expected; };
 	std::vector<Ans> my_ans, all_ans;
 	{
 		Phase ph(this, "cbm:intersect");
@@ -840,19 +873,23 @@ void dropest_shard::cb_merge() {
 				bb.push_back(beg[allp[i].base]); be.push_back(end[allp[i].base]);
 			}
 		std::vector<u32> inter(which.size());
+		std::vector<double> expected(which.size(), 0.0);
 		c.shard_merge_intersect(which.size(), cand_local.data(), bb.data(), be.data(), reinterpret_cast<const uint64_t *>(low_all.p), inter.data());
+		if (poisson) c.shard_merge_expected(which.size(), cand_local.data(), bb.data(), be.data(), reinterpret_cast<const uint64_t *>(low_all.p), expected.data());
 		my_ans.resize(which.size());
-		for (size_t i = 0; i < which.size(); ++i) my_ans[i] = Ans{which[i], inter[i], 0};
+		for (size_t i = 0; i < which.size(); ++i) my_ans[i] = Ans{which[i], inter[i], 0, expected[i]};
 		std::vector<size_t> acnt;
 		tr->gather_vec(my_ans, all_ans, acnt);
 	}
 	std::vector<u32> inter_all(allp.size(), 0);
-	for (const Ans &a : all_ans) inter_all[size_t(a.pair)] = a.inter;
+	std::vector<double> expected_all(poisson ? allp.size() : 0, 0.0);
+	for (const Ans &a : all_ans) { inter_all[size_t(a.pair)] = a.inter; if (poisson) expected_all[size_t(a.pair)] = a.expected; }
 	// decide: targets of my bases; then the same sequential application everywhere
 	std::vector<int64_t> my_tgt(hi - lo, -1), target;
 	{
 		Phase ph(this, "cbm:decide");
-		c.shard_merge_decide(inter_all.data() + poff[size_t(rank)], my_tgt.data());
+		if (poisson) c.shard_merge_decide_poisson(inter_all.data() + poff[size_t(rank)], expected_all.data() + poff[size_t(rank)], my_tgt.data());
+		else c.shard_merge_decide(inter_all.data() + poff[size_t(rank)], my_tgt.data());
 		std::vector<size_t> tcnt;
 		tr->gather_vec(my_tgt, target, tcnt);
 	}
@@ -1046,9 +1083,9 @@ void dropest_shard::step() {
 	install_umi_hooks();
 	{ Phase ph(this, "pipeline"); c.run_set_initialized(); }
 	merged_barcodes.clear();
-	if (c.cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && world > 1) { Phase ph(this, "cb_merge"); cb_merge(); }
+	if ((c.cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES || c.cfg.merge_kind == DROPEST_MERGE_POISSON_REAL) && world > 1) { Phase ph(this, "cb_merge"); cb_merge(); }
 	else if (c.cfg.merge_kind != DROPEST_MERGE_NONE && world > 1)
-		throw UnsupportedError("sharded runs support -m with a barcode whitelist (RealBarcodes) only; run the other merge strategies on one GPU");
+		throw UnsupportedError("sharded runs support the merges with a barcode whitelist (-m, -M with barcodes) only; run the other merge strategies on one GPU");
 	if (c.have_qual && world > 1) throw UnsupportedError("UMI qualities are not supported in sharded runs");
 	{ Phase ph(this, "finalize"); c.run_merge_and_filter(); }
 	merged_pending = world == 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE;   // one shard: the context's own pairs, named when asked for

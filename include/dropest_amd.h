@@ -451,8 +451,9 @@ void *dropest_stream(dropest_ctx *ctx);
  *   dropest_shard_matrix        (shard 0) the GLOBAL matrix in CSC form: colptr[ncols + 1], rowidx / values in the shared host
  *                               buffer, col_barcodes[ncols] = packed barcode of every column; valid until the next step
  * -u runs sharded too (the shards' UMI first-occurrence tables are reduced to one rank table, random fills come from agreed
- * offsets of the one rand() sequence).  Not in sharded runs: -M, -m without a whitelist, UMI qualities, barcodes with N in a
- * whitelist merge (single GPU). */
+ * offsets of the one rand() sequence), and so does -M with a whitelist (PoissonRealBarcodesMergeStrategy: the UMI histograms of the shards
+ * are added, every shard builds the same estimator tables; UMI fields of at most 26 bits).  Not in sharded runs: the merges without a
+ * whitelist (-m / -M without barcodes, merge-all: their candidates come from UMIs shared between ANY two cells), UMI qualities. */
 typedef struct dropest_shard dropest_shard;
 dropest_status dropest_shard_unique_id(uint8_t id[128]);
 dropest_status dropest_shard_create(const dropest_cfg *cfg, int32_t rank, int32_t world, const uint8_t id[128], dropest_shard **out);
@@ -504,7 +505,7 @@ dropest_status dropest_shard_set_option(dropest_shard *shard, const char *key, i
  * barcodes -- and writes the shard handles to out[parts]; drive them with dropest_shard_group_step and read the result with
  * dropest_shard_matrix / dropest_shard_merged_barcodes on out[0].  The shards borrow the context's device-resident reads: the
  * context must outlive them and must not be used for anything else meanwhile (its own tables are released).  What a sharded
- * run does not support (-M, -m without a whitelist, UMI qualities) is not supported here either; the gene + UMI fields
+ * run does not support (merges without a whitelist, UMI qualities) is not supported here either; the gene + UMI fields
  * alone must leave room for the cells of a shard. */
 dropest_status dropest_key_width(dropest_ctx *ctx, uint32_t *cell_bits, uint32_t *gene_bits, uint32_t *umi_bits);
 dropest_status dropest_ctx_split(dropest_ctx *ctx, int32_t parts, dropest_shard **out);

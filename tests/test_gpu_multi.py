@@ -100,6 +100,27 @@ def test_sharded_whitelist_merge_matches_single_context(case, world):
 
 
 @pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", sorted(MERGE_CASES))
+def test_sharded_poisson_whitelist_merge_matches_single_context(case, world):
+    """-M with a whitelist (PoissonRealBarcodesMergeStrategy) over 2 / 3 shards: the UMI distribution and the largest gene are those of ALL
+    shards (histograms added, every shard builds the same estimator tables), the expected intersection of a pair is computed where the
+    candidate lives from the base's shipped rows, the decision where the base lives.  Same targets, same matrices as one context."""
+    kw, wl, kind, cfg = MERGE_CASES[case]
+    arrays = parity.canonical_stream(*SynthStream(**kw).generate_host())
+    ckw = cfg_kwargs(dict(cfg, merge={"barcodes_kind": kind, "barcodes_file": os.path.join(DATA, wl)}))
+    ckw.update(merge_kind=capi.MERGE_POISSON_REAL)
+    got = run_group(world, arrays, ckw)
+    c = single(arrays, ckw)
+    want = check(got, c)
+    assert len(want) > 20
+    owner = lambda b: capi.lib().dropest_owner_of(int(b), world)           # noqa: E731
+    assert sum(owner(a) != owner(b) for a, b in want.items()) > 5          # the merge really crossed shards
+    # not the plain whitelist merge's answer by accident: -M decides differently on this stream
+    plain = single(arrays, dict(ckw, merge_kind=capi.MERGE_REAL_BARCODES))
+    assert not np.array_equal(plain.merge_targets(), c.merge_targets())
+
+
+@pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("rate,n_reads", [(1e-2, 120_000), (1e-3, 600_000)])
 def test_n_umis_across_shards(world, rate, n_reads):
     """UMIs with N are the reference's DEFAULT UMI merge (MergeUMIsStrategySimple.cpp:21-102): random fills follow one
