@@ -382,6 +382,18 @@ static void testShardedContainer() {
 	CHECK_EQ(three->merged_barcodes().size(), size_t(4));          // targets 0 1 1 0 0 0 6: four cells merged away (:227-235)
 	CHECK_THROWS(three->cell(0), std::runtime_error);
 	CHECK_THROWS(three->filtered_cells(), std::runtime_error);
+	{   // -M with the whitelist over three shards (the estimator's UMI distribution is the one of all shards)
+		auto make_m = [&](const std::vector<int> &devices) {
+			Merge::PoissonTargetEstimator estimator(1.0e-4, 1.0e-7);
+			auto strat = std::make_shared<Merge::PoissonRealBarcodesMergeStrategy>(estimator, Merge::RealBarcodesMergeStrategy::INDROP, g_data + "/test_est", 0, 0, 7);
+			return std::make_shared<CellsDataContainer>(strat, std::make_shared<Merge::UMIs::MergeUMIsStrategySimple>(1), Mark::get_by_code(Mark::DEFAULT_CODE), false, -1, devices);
+		};
+		auto m1 = make_m({0}), m3 = make_m({0, 0, 0});
+		feed(*m1); feed(*m3);
+		CHECK(m1->merged_barcodes() == m3->merged_barcodes());
+		const auto a = printer.get_count_matrix(*m1, true, false), b = printer.get_count_matrix(*m3, true, false);
+		CHECK(a.col_names == b.col_names); CHECK(a.colptr == b.colptr); CHECK(a.rowidx == b.rowidx); CHECK(a.values == b.values);
+	}
 
 	// several batches (BATCH = 2^20 reads each; shard k takes its quota of the stream, then shard k + 1), UMIs with N, no CB merge
 	auto big = [&](const std::vector<int> &devices) {
