@@ -62,24 +62,50 @@ def parse():
     return ap.parse_args()
 
 
-def one_step(ctx):
-    """One pass of the hot path over the resident stream; returns what lands on the host: both count matrices in CSC form --
-    16-bit row indices and values + exact overflow list when every gene id fits 16 bits (dropest_count_matrix_csc_narrow: what
-    the facade's ResultsPrinter reads; it turns entries into doubles either way), the 32-bit form otherwise or with
-    DROPEST_BENCH_WIDE_MATRIX=1 -- and the filtered cells."""
+def matrix_form():
+    """What the step hands to the host (DROPEST_BENCH_MATRIX_FORM): "bytes" (default; dropest_count_matrix_csc_bytes), "u16", "u32"."""
+    return os.environ.get("DROPEST_BENCH_MATRIX_FORM", "u32" if os.environ.get("DROPEST_BENCH_WIDE_MATRIX") else "bytes")
+
+
+def one_step(ctx, form=None):
+    """One pass of the hot path over the resident stream; returns what lands on the host: both count matrices in CSC form and the
+    filtered cells.  The matrices arrive in the byte form (include/dropest_amd.h: dropest_matrix_bytes -- one byte of row delta and one
+    byte of count per entry plus two exact lists; lossless, decoded by dropest_matrix_bytes_widen or by the reader itself: the facade's
+    ResultsPrinter turns entries into doubles either way); form = "u16" / "u32" selects the 16-bit / 32-bit forms."""
+    form = form or matrix_form()
     ctx.reset_results()
     ctx.set_initialized()
     ctx.merge_and_filter()
-    narrow = ctx.narrow_matrix_possible() and not os.environ.get("DROPEST_BENCH_WIDE_MATRIX")
+    if form == "u16" and not ctx.narrow_matrix_possible():
+        form = "u32"
+    code = {"u32": 0, "u16": 1, "bytes": 2}[form]
     if not os.environ.get("DROPEST_BENCH_NO_PREFETCH"):
-        ctx.prefetch_raw_matrix(narrow=narrow)    # cm_raw's copy to the host runs under the preparation of cm
-    if narrow:
+        ctx.prefetch_raw_matrix(form=code)    # cm_raw's copy to the host runs under the preparation of cm
+    if form == "bytes":
+        cm = ctx.count_matrix_csc_bytes(filtered=True)
+        cm_raw = ctx.count_matrix_csc_bytes(filtered=False)
+    elif form == "u16":
         cm = ctx.count_matrix_csc_narrow(filtered=True)
         cm_raw = ctx.count_matrix_csc_narrow(filtered=False)
     else:
         cm = ctx.count_matrix_csc(filtered=True)
         cm_raw = ctx.count_matrix_csc(filtered=False)
     return cm, cm_raw, ctx.filtered_cells()
+
+
+def nnz_of(m):
+    return int(m.nnz) if hasattr(m, "nnz") else int(len(m[1]))
+
+
+def form_text(cm, cm_raw):
+    if hasattr(cm, "nnz"):
+        return ("CSC in pinned host memory, byte form (dropest_matrix_bytes): u32 colptr + u8 row delta + u8 value + exact lists "
+                "(rows listed: %d + %d, values listed: %d + %d of %d + %d entries)"
+                % (cm.n_row_listed, cm_raw.n_row_listed, cm.n_value_listed, cm_raw.n_value_listed, cm.nnz, cm_raw.nnz))
+    if len(cm) in (5, 6):    # (context: 5 arrays, sharded runner: 6 with the column barcodes)
+        return ("CSC in pinned host memory, u32 colptr + u16 row index + u16 value + exact overflow list (%d + %d entries beyond 65534)"
+                % (len(cm[-2]), len(cm_raw[-2])))
+    return "CSC in pinned host memory, u32 colptr + u32 row index + u32 value"
 
 
 def cpu_baseline(stream, n_sample, cfg, name="C2"):
@@ -301,7 +327,7 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"]}
         # whole-pipeline roofline: compulsory traffic = every packed record read once, every output item
         # written once: 24 B/read + 24 B/molecule + 12 B/matrix entry + 40 B/cell, over the sum of the kernel times
-        cm_nnz, raw_nnz = int(len(out[0][1])), int(len(out[1][1]))
+        cm_nnz, raw_nnz = nnz_of(out[0]), nnz_of(out[1])
         compulsory = 24.0 * sizes["reads"] + 24.0 * sizes["molecules"] + 12.0 * (cm_nnz + raw_nnz) / max(1, world) + 40.0 * sizes["cells"]
         t_kernels_ms = sum(v["ms"] for k, v in table.items() if not k.startswith("host:")) / table_steps
         rec = pmc_record(config, reads_per_gpu, get_layout()["sort"])
@@ -338,7 +364,27 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
             ingest = push_rates(stream, local_rank, int(min(args.push_sample, total_reads)),
                                 dict(merge_kind=capi.MERGE_NONE, min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"]))
         cm = out[0]
-        narrow = len(cm) in (5, 6)    # (context: 5 arrays, sharded runner: 6 with the column barcodes)
+        forms = None
+        if world == 1 and not force_sharded and hasattr(cm, "nnz") and not os.environ.get("DROPEST_BENCH_NO_FORMS"):
+            # the same step with the matrices in the wider forms, and the host-side decode of the byte form (3 steps each, after the timed region)
+            forms = {}
+            for f in ("u16", "u32"):
+                one_step(ctx, f)
+                fence(); t0 = time.perf_counter()
+                for _ in range(3):
+                    one_step(ctx, f)
+                fence(); forms[f + "_ms_per_step"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+            o2 = one_step(ctx, "bytes")
+            import numpy as np
+            bufs = [(np.ones(int(m.nnz), np.uint32), np.ones(int(m.nnz), np.uint32)) for m in (o2[0], o2[1])]   # (touched: no page faults in the timing)
+            t0 = time.perf_counter()
+            for m, b in zip((o2[0], o2[1]), bufs):
+                ctx.widen_bytes(m, out=b)
+            forms["bytes_decode_to_u32_on_host_threads_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+            bufs = None
+            forms["note"] = "value / ms_per_step are measured with the byte form; the decode is what a consumer that wants 32-bit slots pays on its side"
+            out = o2
+            cm = out[0]
         line = {
             "metric": "Mreads/s processed to final count matrix", "value": round(value, 2), "unit": "Mreads/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3),
@@ -352,9 +398,8 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
                                    + (", no whitelist (SimpleMergeStrategy)" if args.no_whitelist else "")
                                    + (", -M (Poisson decisions)" if args.poisson else ""),
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d%s" % (world, " (sharded runner, forced exchange)" if force_sharded else ""),
-                       "cm_nnz": int(len(cm[1])), "cm_raw_nnz": raw_nnz, "filtered_cells": int(len(out[2])), "sort_layout": get_layout(),
-                       "matrix_form": ("CSC in pinned host memory, u32 colptr + u16 row index + u16 value + exact overflow list (%d + %d entries beyond 65534)"
-                                       % (len(cm[-2]), len(out[1][-2]))) if narrow else "CSC in pinned host memory, u32 colptr + u32 row index + u32 value"},
+                       "cm_nnz": nnz_of(cm), "cm_raw_nnz": raw_nnz, "filtered_cells": int(len(out[2])), "sort_layout": get_layout(),
+                       "matrix_form": form_text(cm, out[1]), "matrix_forms": forms},
             "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "host_ingest": ingest, "step_ms": step_ms, "kernels_ms_per_step": kernels,
             "kernel_table": "separate pass of %d steps after the timed region, events on every launch" % table_steps,
             "host_stage_wall_ms_per_step": host_stages,

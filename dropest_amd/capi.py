@@ -17,6 +17,13 @@ UMI_MERGE_SIMPLE, UMI_MERGE_DIRECTIONAL = 0, 1
 _STATUS = {1: "INVALID", 2: "RANGE", 3: "DEVICE", 4: "UNSUPPORTED", 5: "IO"}
 
 
+class MatrixBytes(C.Structure):
+    """dropest_matrix_bytes (include/dropest_amd.h)."""
+    _fields_ = [("ncols", C.c_uint64), ("nnz", C.c_uint64), ("colptr", C.c_void_p), ("row_delta", C.c_void_p), ("value", C.c_void_p),
+                ("n_row_listed", C.c_uint64), ("row_listed_pos", C.c_void_p), ("row_listed_row", C.c_void_p),
+                ("n_value_listed", C.c_uint64), ("value_listed_pos", C.c_void_p), ("value_listed_value", C.c_void_p)]
+
+
 class DropestError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__("dropest_amd [%s]: %s" % (_STATUS.get(status, status), msg))
@@ -142,6 +149,9 @@ def lib():
         "dropest_prefetch_raw_matrix": (C.c_int, [vp, C.c_int]),
         "dropest_prefetch_raw_matrix_narrow": (C.c_int, [vp, C.c_int]),
         "dropest_narrow_matrix_possible": (C.c_int, [vp, P(C.c_int)]),
+        "dropest_prefetch_raw_matrix_bytes": (C.c_int, [vp, C.c_int]),
+        "dropest_count_matrix_csc_bytes": (C.c_int, [vp, C.c_int, C.c_int, vp]),
+        "dropest_matrix_bytes_widen": (C.c_int, [vp, vp, vp]),
         "dropest_count_matrix_csc_narrow": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp), u64p, P(vp), P(vp)]),
         "dropest_radix_plan": (C.c_int, [C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "dropest_sort_layout": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
@@ -219,6 +229,7 @@ EXPORTED_SYMBOLS = [
     "dropest_shard_set_reads_device", "dropest_shard_push_reads", "dropest_reserve_reads", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix",
     "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option", "dropest_plan_columns",
     "dropest_key_width", "dropest_ctx_split", "dropest_shard_matrix_narrow", "dropest_add_umi_to_cell", "dropest_umi_first_seen", "dropest_resident_reads", "dropest_prefetch_raw_matrix_narrow", "dropest_narrow_matrix_possible", "dropest_count_matrix_csc_narrow",
+    "dropest_prefetch_raw_matrix_bytes", "dropest_count_matrix_csc_bytes", "dropest_matrix_bytes_widen",
     "dropest_debug_poison_scratch", "dropest_debug_trim_pool", "dropest_debug_alloc_ordinal", "dropest_debug_alloc_site",
 ]
 
@@ -422,9 +433,12 @@ class Context:
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), shape=(n,))
         return view(pc, ncols.value + 1), view(pr, nnz.value), view(pv, nnz.value)
 
-    def prefetch_raw_matrix(self, reads_output=False, narrow=False):
-        """Start cm_raw (emit + copy to the host) on a second stream; count_matrix_csc(filtered=False) then only waits."""
-        if narrow:
+    def prefetch_raw_matrix(self, reads_output=False, narrow=False, form=None):
+        """Start cm_raw (emit + copy to the host) on a second stream; count_matrix_csc(filtered=False) then only waits.
+        form: 0 32-bit, 1 16-bit (= narrow), 2 bytes."""
+        if form == 2:
+            self._chk(self.L.dropest_prefetch_raw_matrix_bytes(self.h, int(reads_output)))
+        elif narrow or form == 1:
             self._chk(self.L.dropest_prefetch_raw_matrix_narrow(self.h, int(reads_output)))
         else:
             self._chk(self.L.dropest_prefetch_raw_matrix(self.h, int(reads_output)))
@@ -447,6 +461,20 @@ class Context:
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n,))
         return (view(pc, ncols.value + 1, C.c_uint32, np.uint32), view(pr, nnz.value, C.c_uint16, np.uint16), view(pv, nnz.value, C.c_uint16, np.uint16),
                 view(po, novf.value, C.c_uint32, np.uint32), view(pw, novf.value, C.c_uint32, np.uint32))
+
+    def count_matrix_csc_bytes(self, filtered=True, reads_output=False):
+        """The byte form (include/dropest_amd.h: dropest_matrix_bytes) as a MatrixBytes structure; its arrays are context-owned pinned
+        memory.  widen_bytes() decodes it into (colptr, rowidx, values) of 32 bits on the library's host threads."""
+        m = MatrixBytes()
+        self._chk(self.L.dropest_count_matrix_csc_bytes(self.h, int(filtered), int(reads_output), C.byref(m)))
+        return m
+
+    def widen_bytes(self, m, out=None):
+        colptr = np.ctypeslib.as_array(C.cast(m.colptr, C.POINTER(C.c_uint32)), shape=(m.ncols + 1,)) if m.ncols else np.zeros(1, np.uint32)
+        rows, vals = out if out is not None else (np.zeros(m.nnz, np.uint32), np.zeros(m.nnz, np.uint32))
+        assert len(rows) >= m.nnz and len(vals) >= m.nnz
+        self._chk(self.L.dropest_matrix_bytes_widen(C.byref(m), rows.ctypes.data, vals.ctypes.data))
+        return colptr, rows, vals
 
     @staticmethod
     def widen(narrow):

@@ -374,8 +374,13 @@ struct dropest_ctx {
 		dropest::PinnedBuf<uint16_t> h_row16, h_val16;
 		dropest::DevBuf<u32> d_ovf;
 		dropest::PinnedBuf<u32> h_ovf;
-		bool narrow = false;
-		u32 n_ovf = 0;
+		// the byte form (dropest_count_matrix_csc_bytes): row deltas / values of one byte, the value list above and a second list of exact rows
+		dropest::DevBuf<uint8_t> d_drow8, d_val8;
+		dropest::PinnedBuf<uint8_t> h_drow8, h_val8;
+		dropest::DevBuf<u32> d_rovf;
+		dropest::PinnedBuf<u32> h_rovf;
+		int narrow = 0;                 // the form of the last emit: 0 32-bit, 1 16-bit, 2 bytes
+		u32 n_ovf = 0, n_rovf = 0;
 		std::vector<u32> colptr;
 		uint64_t nnz = 0, ncols = 0;
 	} mat[3];   // cm, cm_raw, and the filtered matrix under another mark query (emit_matrix_levels)
@@ -582,19 +587,19 @@ struct dropest_ctx {
 	void fetch_real_cells();
 	void request_filtered(u32 genes_threshold, int max_cells);   // CellsDataContainer::update_filtered_gene_counts, lazily
 	void sort_filtered(u32 genes_threshold, int max_cells);
-	void emit_matrix(bool filtered_m, bool reads_output, bool to_host = true, bool narrow = false);
+	void emit_matrix(bool filtered_m, bool reads_output, bool to_host = true, int form = 0);
 	bool narrow_possible() const;
-	void matrix_outputs(MatrixResult &M, uint64_t nnz, bool narrow, bool to_host, dropest::MatrixArgs &a);
+	void matrix_outputs(MatrixResult &M, uint64_t nnz, int form, bool to_host, dropest::MatrixArgs &a);
 	void matrix_copy_out(MatrixResult &M, uint64_t nnz, hipStream_t st);
 	void matrix_finish_overflow(MatrixResult &M, hipStream_t st);
 	// columns of a count matrix from the host rows: cell id of every column, start of every column, number of entries
 	void matrix_columns(bool filtered_m, std::vector<u32> &col_cell, std::vector<u32> &colptr, uint64_t &nnz);
 	// cm_raw produced and copied to the host on a second stream while the caller goes on (dropest_prefetch_raw_matrix)
-	struct RawPrefetch { bool valid = false, reads_output = false, in_flight = false, narrow = false; std::vector<u32> col_cell; } raw_pf;
+	struct RawPrefetch { bool valid = false, reads_output = false, in_flight = false; int narrow = 0; std::vector<u32> col_cell; } raw_pf;
 	hipStream_t stream2 = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_raw = nullptr;
 	dropest::DevBuf<u32> m2_col_cell, m2_col_start;
-	void prefetch_raw_matrix(bool reads_output, bool narrow = false);
+	void prefetch_raw_matrix(bool reads_output, int form = 0);   // form: 0 32-bit, 1 16-bit, 2 bytes
 	void invalidate_prefetch();
 	u64 unmap_umi(u64 ucode) const;
 };

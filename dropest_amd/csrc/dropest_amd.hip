@@ -11,6 +11,7 @@
 
 #include "context.h"
 
+#include <atomic>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -1296,14 +1297,23 @@ bool dropest_ctx::narrow_possible() const { return n_reads == 0 || ingest.gene_m
 
 static constexpr u32 MATRIX_OVF_CAP = 1u << 20;
 
-// Wires the output side of an emit launch for matrix slot M (wide or narrow) and makes sure the buffers exist.
-void dropest_ctx::matrix_outputs(MatrixResult &M, uint64_t nnz, bool narrow, bool to_host, dropest::MatrixArgs &a) {
-	M.narrow = narrow; M.n_ovf = 0;
-	if (narrow) {
-		M.d_row16.ensure(nnz); M.d_val16.ensure(nnz); M.d_ovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP));
-		if (to_host) { M.h_row16.ensure(nnz); M.h_val16.ensure(nnz); M.h_ovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP)); }
-		a.t_gene16 = M.d_row16.p; a.t_val16 = M.d_val16.p;
+// Wires the output side of an emit launch for matrix slot M (form 0 / 1 / 2) and makes sure the buffers exist.
+void dropest_ctx::matrix_outputs(MatrixResult &M, uint64_t nnz, int form, bool to_host, dropest::MatrixArgs &a) {
+	M.narrow = form; M.n_ovf = M.n_rovf = 0;
+	if (form) {
+		M.d_ovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP));
+		if (to_host) M.h_ovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP));
 		a.ovf_count = M.d_ovf.p; a.ovf_pos = M.d_ovf.p + 1; a.ovf_val = M.d_ovf.p + 1 + MATRIX_OVF_CAP; a.ovf_cap = MATRIX_OVF_CAP;
+	}
+	if (form == 2) {
+		M.d_drow8.ensure(nnz); M.d_val8.ensure(nnz); M.d_rovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP));
+		if (to_host) { M.h_drow8.ensure(nnz); M.h_val8.ensure(nnz); M.h_rovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP)); }
+		a.t_drow8 = M.d_drow8.p; a.t_val8 = M.d_val8.p;
+		a.rovf_count = M.d_rovf.p; a.rovf_pos = M.d_rovf.p + 1; a.rovf_row = M.d_rovf.p + 1 + MATRIX_OVF_CAP;
+	} else if (form == 1) {
+		M.d_row16.ensure(nnz); M.d_val16.ensure(nnz);
+		if (to_host) { M.h_row16.ensure(nnz); M.h_val16.ensure(nnz); }
+		a.t_gene16 = M.d_row16.p; a.t_val16 = M.d_val16.p;
 	} else {
 		M.d_row.ensure(nnz); M.d_val.ensure(nnz);
 		if (to_host) { M.h_row.ensure(nnz); M.h_val.ensure(nnz); }
@@ -1311,10 +1321,15 @@ void dropest_ctx::matrix_outputs(MatrixResult &M, uint64_t nnz, bool narrow, boo
 	}
 }
 
-// Device-to-host copies of a matrix slot on stream `st` (after its emit launch).  Narrow: the overflow count travels with the
-// first 64 listed entries (values beyond 65534 are rare); a longer list is fetched by matrix_finish_overflow.
+// Device-to-host copies of a matrix slot on stream `st` (after its emit launch).  Forms 1 / 2: the counts of the overflow lists travel
+// with the arrays (listed entries are rare); the lists themselves are fetched by matrix_finish_overflow.
 void dropest_ctx::matrix_copy_out(MatrixResult &M, uint64_t nnz, hipStream_t st) {
-	if (M.narrow) {
+	if (M.narrow == 2) {
+		HIP_CHECK(hipMemcpyAsync(M.h_drow8.p, M.d_drow8.p, nnz, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(M.h_val8.p, M.d_val8.p, nnz, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(M.h_ovf.p, M.d_ovf.p, 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(M.h_rovf.p, M.d_rovf.p, 4, hipMemcpyDeviceToHost, st));
+	} else if (M.narrow == 1) {
 		HIP_CHECK(hipMemcpyAsync(M.h_row16.p, M.d_row16.p, nnz * 2, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipMemcpyAsync(M.h_val16.p, M.d_val16.p, nnz * 2, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(hipMemcpyAsync(M.h_ovf.p, M.d_ovf.p, 4, hipMemcpyDeviceToHost, st));
@@ -1324,29 +1339,37 @@ void dropest_ctx::matrix_copy_out(MatrixResult &M, uint64_t nnz, hipStream_t st)
 	}
 }
 
-// After the copies of matrix_copy_out have been waited for: the overflow list of a narrow matrix (usually empty).
+// After the copies of matrix_copy_out have been waited for: the overflow lists of a form 1 / 2 matrix (short or empty).
 void dropest_ctx::matrix_finish_overflow(MatrixResult &M, hipStream_t st) {
-	if (!M.narrow || !M.nnz) { M.n_ovf = 0; return; }
-	const u32 count = M.h_ovf.p[0];
-	if (count > MATRIX_OVF_CAP) throw UnsupportedError("more than 2^20 matrix entries beyond 65534: use the 32-bit form (dropest_count_matrix_csc)");
-	M.n_ovf = count;
-	if (!count) return;
-	HIP_CHECK(hipMemcpyAsync(M.h_ovf.p + 1, M.d_ovf.p + 1, size_t(count) * 4, hipMemcpyDeviceToHost, st));
-	HIP_CHECK(hipMemcpyAsync(M.h_ovf.p + 1 + MATRIX_OVF_CAP, M.d_ovf.p + 1 + MATRIX_OVF_CAP, size_t(count) * 4, hipMemcpyDeviceToHost, st));
-	HIP_CHECK(stream_wait(st));
-	// the list is filled in the order the atomics landed: sorted by position, so that the result does not depend on it
-	std::vector<std::pair<u32, u32>> ov(count);
-	for (u32 i = 0; i < count; ++i) ov[i] = {M.h_ovf.p[1 + i], M.h_ovf.p[1 + MATRIX_OVF_CAP + i]};
-	std::sort(ov.begin(), ov.end());
-	for (u32 i = 0; i < count; ++i) { M.h_ovf.p[1 + i] = ov[i].first; M.h_ovf.p[1 + MATRIX_OVF_CAP + i] = ov[i].second; }
+	M.n_ovf = M.n_rovf = 0;
+	if (!M.narrow || !M.nnz) return;
+	auto finish = [&](dropest::DevBuf<u32> &d, dropest::PinnedBuf<u32> &h, u32 &n_out, const char *what) {
+		const u32 count = h.p[0];
+		if (count > MATRIX_OVF_CAP) throw UnsupportedError(std::string("more than 2^20 matrix entries with ") + what + ": use a wider form of the count matrix");
+		n_out = count;
+		if (!count) return;
+		HIP_CHECK(hipMemcpyAsync(h.p + 1, d.p + 1, size_t(count) * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(h.p + 1 + MATRIX_OVF_CAP, d.p + 1 + MATRIX_OVF_CAP, size_t(count) * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(stream_wait(st));
+		// The list is filled in the order the atomics landed.  The 16-bit form promises it sorted by position (a handful of entries).  The
+		// byte form does not: the small cells of cm_raw list 4e5 rows at C2 (25 ms of std::sort here, 0.9 ms of radix passes and their
+		// waits on the device), and its decoder needs no order (dropest_matrix_bytes_widen).
+		if (M.narrow == 2) return;
+		std::vector<std::pair<u32, u32>> ov(count);
+		for (u32 i = 0; i < count; ++i) ov[i] = {h.p[1 + i], h.p[1 + MATRIX_OVF_CAP + i]};
+		std::sort(ov.begin(), ov.end());
+		for (u32 i = 0; i < count; ++i) { h.p[1 + i] = ov[i].first; h.p[1 + MATRIX_OVF_CAP + i] = ov[i].second; }
+	};
+	finish(M.d_ovf, M.h_ovf, M.n_ovf, M.narrow == 2 ? "a count beyond 254" : "a count beyond 65534");
+	if (M.narrow == 2) finish(M.d_rovf, M.h_rovf, M.n_rovf, "a row gap beyond 254");
 }
 
 // cm_raw on a second stream: emit + device-to-host copy start now and run under whatever the caller does next (ordering
 // the filtered cells, emitting cm); dropest_count_matrix_csc(filtered = 0) later only waits for the copy.
-void dropest_ctx::prefetch_raw_matrix(bool reads_output, bool narrow) {
+void dropest_ctx::prefetch_raw_matrix(bool reads_output, int narrow) {
 	HostStage hs(this, "prefetch:cm_raw");
 	invalidate_prefetch();
-	if (narrow && !narrow_possible()) throw UnsupportedError("gene ids beyond 65535: the narrow matrix form is not available");
+	if (narrow == 1 && !narrow_possible()) throw UnsupportedError("gene ids beyond 65535: the narrow matrix form is not available");
 	MatrixResult &M = mat[1];
 	uint64_t nnz = 0;
 	matrix_columns(false, raw_pf.col_cell, M.colptr, nnz);
@@ -1367,20 +1390,22 @@ void dropest_ctx::prefetch_raw_matrix(bool reads_output, bool narrow) {
 	HIP_CHECK(hipMemcpyAsync(m2_col_cell.p, raw_pf.col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream2));
 	HIP_CHECK(hipMemcpyAsync(m2_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream2));
 	if (narrow) HIP_CHECK(hipMemsetAsync(M.d_ovf.p, 0, 4, stream2));
+	if (narrow == 2) HIP_CHECK(hipMemsetAsync(M.d_rovf.p, 0, 4, stream2));
 	a.col_cell = m2_col_cell.p; a.col_start = m2_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
 	a.value = reads_output ? cg_reads_all.p : cg_n_all.p;
 	a.gene_mask = layout.gene_none; a.skip_zero = 0;
-	if (narrow) hipLaunchKernelGGL(emit_matrix_kernel<true>, dim3(ncols), dim3(256), 0, stream2, a);
-	else hipLaunchKernelGGL(emit_matrix_kernel<false>, dim3(ncols), dim3(256), 0, stream2, a);
+	if (narrow == 2) hipLaunchKernelGGL(emit_matrix_kernel<2>, dim3(ncols), dim3(256), 0, stream2, a);
+	else if (narrow == 1) hipLaunchKernelGGL(emit_matrix_kernel<1>, dim3(ncols), dim3(256), 0, stream2, a);
+	else hipLaunchKernelGGL(emit_matrix_kernel<0>, dim3(ncols), dim3(256), 0, stream2, a);
 	HIP_CHECK(hipGetLastError());
 	matrix_copy_out(M, nnz, stream2);
 	HIP_CHECK(hipEventRecord(ev_raw, stream2));
 	raw_pf.in_flight = true;
 }
 
-void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, bool narrow) {
+void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, int narrow) {
 	HostStage hs(this, filtered_m ? "matrix:cm" : "matrix:cm_raw");
-	if (narrow && !narrow_possible()) throw UnsupportedError("gene ids beyond 65535: the narrow matrix form is not available");
+	if (narrow == 1 && !narrow_possible()) throw UnsupportedError("gene ids beyond 65535: the narrow matrix form is not available");
 	MatrixResult &M = mat[filtered_m ? 0 : 1];
 	std::vector<u32> col_cell;
 	uint64_t nnz = 0;
@@ -1402,12 +1427,14 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, 
 	HIP_CHECK(hipMemcpyAsync(m_col_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(m_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	if (narrow) HIP_CHECK(hipMemsetAsync(M.d_ovf.p, 0, 4, stream));
+	if (narrow == 2) HIP_CHECK(hipMemsetAsync(M.d_rovf.p, 0, 4, stream));
 	a.col_cell = m_col_cell.p; a.col_start = m_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
 	a.value = filtered_m ? (reads_output ? cg_reads_req.p : cg_n_req.p) : (reads_output ? cg_reads_all.p : cg_n_all.p);
 	a.gene_mask = layout.gene_none; a.skip_zero = filtered_m ? 1 : 0;
-	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * (narrow ? 16 : 20), [&] {
-		if (narrow) hipLaunchKernelGGL(emit_matrix_kernel<true>, dim3(ncols), dim3(256), 0, stream, a);
-		else hipLaunchKernelGGL(emit_matrix_kernel<false>, dim3(ncols), dim3(256), 0, stream, a);
+	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * (narrow == 2 ? 14 : narrow ? 16 : 20), [&] {
+		if (narrow == 2) hipLaunchKernelGGL(emit_matrix_kernel<2>, dim3(ncols), dim3(256), 0, stream, a);
+		else if (narrow == 1) hipLaunchKernelGGL(emit_matrix_kernel<1>, dim3(ncols), dim3(256), 0, stream, a);
+		else hipLaunchKernelGGL(emit_matrix_kernel<0>, dim3(ncols), dim3(256), 0, stream, a);
 	});
 	if (to_host) matrix_copy_out(M, nnz, stream);
 	HIP_CHECK(stream_wait(stream));   // col_cell (host vector) must outlive the H2D copy
@@ -1423,7 +1450,7 @@ void dropest_ctx::emit_columns_device(bool filtered_m, bool reads_output, const 
 	const u32 ncols = u32(col_cell.size());
 	if (!ncols || !nnz) return;
 	m_col_cell.ensure(ncols); m_col_start.ensure(ncols);
-	M.d_row.ensure(nnz); M.d_val.ensure(nnz); M.narrow = false; M.n_ovf = 0;
+	M.d_row.ensure(nnz); M.d_val.ensure(nnz); M.narrow = 0; M.n_ovf = 0;
 	HIP_CHECK(hipMemcpyAsync(m_col_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(m_col_start.p, col_start.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	MatrixArgs a{};
@@ -1432,7 +1459,7 @@ void dropest_ctx::emit_columns_device(bool filtered_m, bool reads_output, const 
 	a.gene_mask = layout.gene_none; a.skip_zero = filtered_m ? 1 : 0;
 	a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
 	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * 20, [&] {
-		hipLaunchKernelGGL(emit_matrix_kernel<false>, dim3(ncols), dim3(256), 0, stream, a);
+		hipLaunchKernelGGL(emit_matrix_kernel<0>, dim3(ncols), dim3(256), 0, stream, a);
 	});
 	HIP_CHECK(stream_wait(stream));   // the host vectors must outlive their copies
 }
@@ -1490,7 +1517,7 @@ void dropest_ctx::emit_matrix_levels(u32 mask, bool reads_output) {
 	a.col_cell = m_col_cell.p; a.col_start = m_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
 	a.value = d_value.p; a.gene_mask = layout.gene_none; a.skip_zero = 1;
 	a.t_gene = M.d_row.p; a.t_val = M.d_val.p;
-	hipLaunchKernelGGL(emit_matrix_kernel<false>, dim3(ncols), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(emit_matrix_kernel<0>, dim3(ncols), dim3(256), 0, stream, a);
 	HIP_CHECK(hipGetLastError());
 	HIP_CHECK(hipMemcpyAsync(M.h_row.p, M.d_row.p, nnz * 4, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipMemcpyAsync(M.h_val.p, M.d_val.p, nnz * 4, hipMemcpyDeviceToHost, stream));
@@ -2056,14 +2083,14 @@ dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int read
 dropest_status dropest_prefetch_raw_matrix(dropest_ctx *ctx, int reads_output) {
 	return guarded([&] {
 		need_init(ctx);
-		ctx->prefetch_raw_matrix(reads_output != 0, false);
+		ctx->prefetch_raw_matrix(reads_output != 0, 0);
 	});
 }
 
 dropest_status dropest_prefetch_raw_matrix_narrow(dropest_ctx *ctx, int reads_output) {
 	return guarded([&] {
 		need_init(ctx);
-		ctx->prefetch_raw_matrix(reads_output != 0, true);
+		ctx->prefetch_raw_matrix(reads_output != 0, 1);
 	});
 }
 
@@ -2077,11 +2104,65 @@ dropest_status dropest_count_matrix_csc_narrow(dropest_ctx *ctx, int filtered, i
 	return guarded([&] {
 		need_init(ctx);
 		if (!ncols || !nnz || !colptr || !rowidx || !values || !n_overflow || !overflow_pos || !overflow_val) throw InvalidError("null argument");
-		ctx->emit_matrix(filtered != 0, reads_output != 0, true, true);
+		ctx->emit_matrix(filtered != 0, reads_output != 0, true, 1);
 		const dropest_ctx::MatrixResult &M = ctx->mat[filtered ? 0 : 1];
 		*ncols = M.ncols; *nnz = M.nnz;
 		*colptr = M.colptr.data(); *rowidx = M.h_row16.p; *values = M.h_val16.p;
 		*n_overflow = M.n_ovf; *overflow_pos = M.h_ovf.p ? M.h_ovf.p + 1 : nullptr; *overflow_val = M.h_ovf.p ? M.h_ovf.p + 1 + MATRIX_OVF_CAP : nullptr;
+	});
+}
+
+dropest_status dropest_prefetch_raw_matrix_bytes(dropest_ctx *ctx, int reads_output) {
+	return guarded([&] {
+		need_init(ctx);
+		ctx->prefetch_raw_matrix(reads_output != 0, 2);
+	});
+}
+
+dropest_status dropest_count_matrix_csc_bytes(dropest_ctx *ctx, int filtered, int reads_output, dropest_matrix_bytes *out) {
+	return guarded([&] {
+		need_init(ctx);
+		if (!out) throw InvalidError("null argument");
+		ctx->emit_matrix(filtered != 0, reads_output != 0, true, 2);
+		const dropest_ctx::MatrixResult &M = ctx->mat[filtered ? 0 : 1];
+		out->ncols = M.ncols; out->nnz = M.nnz; out->colptr = M.colptr.data();
+		out->row_delta = M.h_drow8.p; out->value = M.h_val8.p;
+		out->n_row_listed = M.n_rovf; out->row_listed_pos = M.h_rovf.p ? M.h_rovf.p + 1 : nullptr; out->row_listed_row = M.h_rovf.p ? M.h_rovf.p + 1 + MATRIX_OVF_CAP : nullptr;
+		out->n_value_listed = M.n_ovf; out->value_listed_pos = M.h_ovf.p ? M.h_ovf.p + 1 : nullptr; out->value_listed_value = M.h_ovf.p ? M.h_ovf.p + 1 + MATRIX_OVF_CAP : nullptr;
+	});
+}
+
+// dgCMatrix slots i / x from the byte form.  The listed entries come in no particular order: they are written to their places first, then
+// every column is walked once (a column's first delta counts from row -1; a 255 takes what the first phase put there).
+dropest_status dropest_matrix_bytes_widen(const dropest_matrix_bytes *m, uint32_t *rowidx, uint32_t *values) {
+	return guarded([&] {
+		if (!m || (m->nnz && (!rowidx || !values))) throw InvalidError("null argument");
+		if (!m->nnz) return;
+		std::atomic<int> bad{0};   // (an exception must not leave a worker thread)
+		const uint64_t nnz = m->nnz;
+		parallel_ranges(m->n_row_listed, [&](size_t b, size_t e, unsigned) {
+			for (size_t i = b; i < e; ++i) { const uint32_t k = m->row_listed_pos[i]; if (k >= nnz || m->row_delta[k] != 255u) { bad = 1; return; } rowidx[k] = m->row_listed_row[i]; }
+		}, 65536, dropest::HostPool::MAX);
+		parallel_ranges(m->n_value_listed, [&](size_t b, size_t e, unsigned) {
+			for (size_t i = b; i < e; ++i) { const uint32_t k = m->value_listed_pos[i]; if (k >= nnz || m->value[k] != 255u) { bad = 2; return; } values[k] = m->value_listed_value[i]; }
+		}, 65536, dropest::HostPool::MAX);
+		if (bad) throw InvalidError(bad == 1 ? "byte matrix: a listed row does not stand on a 255" : "byte matrix: a listed value does not stand on a 255");
+		const uint8_t *__restrict rd = m->row_delta, *__restrict vb = m->value;   // (locals: the stores below must not force reloads of m's fields)
+		const uint32_t *__restrict cp = m->colptr;
+		uint32_t *__restrict ro = rowidx, *__restrict vo = values;
+		parallel_ranges(m->ncols, [&](size_t cb, size_t ce, unsigned) {
+			for (size_t c = cb; c < ce; ++c) {
+				uint32_t prev1 = 0;   // previous row + 1
+				const uint32_t k1 = cp[c + 1];
+				for (uint32_t k = cp[c]; k < k1; ++k) {
+					const uint32_t d = rd[k], v = vb[k];
+					const uint32_t row = d == 255u ? ro[k] : prev1 + d - 1u;
+					prev1 = row + 1u;
+					ro[k] = row;
+					if (v != 255u) vo[k] = v;
+				}
+			}
+		}, 32, dropest::HostPool::MAX);   // (columns differ in length by orders of magnitude: small ranges, every worker gets some of each kind)
 	});
 }
 

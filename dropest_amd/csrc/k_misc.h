@@ -254,14 +254,24 @@ struct MatrixArgs {
 	uint16_t *t_gene16, *t_val16;
 	uint32_t *ovf_count, *ovf_pos, *ovf_val;
 	uint32_t ovf_cap;
+	// BYTE output (FORM 2; any gene id): per entry one byte of row DELTA (row - previous row of the column, the first entry against -1;
+	// 255 = "listed": the exact ROW stands in (rovf_pos, rovf_row)) and one byte of value (255 = listed in (ovf_pos, ovf_val)): 2 bytes per
+	// entry over PCIe.  Rows of a column ascend, a cell with a few thousand of 30 000 genes has gaps of ~10 and counts of a few UMIs:
+	// well under 1 % of the entries are listed.
+	uint8_t *t_drow8, *t_val8;
+	uint32_t *rovf_count, *rovf_pos, *rovf_row;
 };
-template <bool NARROW>
+template <int FORM>   // 0: 32-bit, 1: 16-bit (NARROW), 2: bytes
 __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
+	constexpr bool NARROW = FORM == 1;
 	__shared__ uint32_t scratch[256 / 64 + 1];
+	__shared__ uint32_t kept_row[FORM == 2 ? 257 : 1];   // [0] last kept row of the previous round (+1), [1 + ex] the rows kept in this one
+	__shared__ uint8_t stage_d[FORM == 2 ? 256 : 1], stage_v[FORM == 2 ? 256 : 1];
 	const uint32_t col = blockIdx.x;
 	const uint32_t cell = a.col_cell[col];
 	const uint32_t b = a.cell_cg_begin[cell], e = b + a.cell_cg_count[cell];
 	uint32_t out = a.col_start[col];
+	if (FORM == 2) { if (threadIdx.x == 0) kept_row[0] = 0u; }   // (row + 1 of "no entry yet": the first delta is row - (-1))
 	for (uint32_t base = b; base < e; base += 256) {
 		const uint32_t i = base + threadIdx.x;
 		bool keep = false;
@@ -273,7 +283,30 @@ __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
 		}
 		uint32_t total;
 		const uint32_t ex = block_excl_scan_u32<256>(keep ? 1u : 0u, scratch, total);
-		if (keep) {
+		if (FORM == 2) {
+			if (keep) kept_row[1 + ex] = g + 1u;
+			__syncthreads();
+			if (keep) {
+				const uint32_t delta = g + 1u - kept_row[ex];   // kept_row[ex]: the entry before this one (+1), kept_row[0] from the round before
+				stage_d[ex] = delta >= 255u ? uint8_t(255u) : uint8_t(delta);
+				stage_v[ex] = v >= 255u ? uint8_t(255u) : uint8_t(v);
+				if (delta >= 255u) { const uint32_t at = atomicAdd(a.rovf_count, 1u); if (at < a.ovf_cap) { a.rovf_pos[at] = out + ex; a.rovf_row[at] = g; } }
+				if (v >= 255u) { const uint32_t at = atomicAdd(a.ovf_count, 1u); if (at < a.ovf_cap) { a.ovf_pos[at] = out + ex; a.ovf_val[at] = v; } }
+			}
+			__syncthreads();
+			{   // the round's bytes leave as aligned 4-byte words (one-byte stores of 256 threads cost 3x the 16-bit form's kernel time)
+				const uint32_t head = min(total, (4u - (out & 3u)) & 3u), nw = (total - head) >> 2, tail0 = head + 4u * nw, t = threadIdx.x;
+				if (t < head) { a.t_drow8[out + t] = stage_d[t]; a.t_val8[out + t] = stage_v[t]; }
+				if (t < nw) {
+					const uint32_t i = head + 4u * t;
+					*reinterpret_cast<uint32_t *>(a.t_drow8 + out + i) = uint32_t(stage_d[i]) | (uint32_t(stage_d[i + 1]) << 8) | (uint32_t(stage_d[i + 2]) << 16) | (uint32_t(stage_d[i + 3]) << 24);
+					*reinterpret_cast<uint32_t *>(a.t_val8 + out + i) = uint32_t(stage_v[i]) | (uint32_t(stage_v[i + 1]) << 8) | (uint32_t(stage_v[i + 2]) << 16) | (uint32_t(stage_v[i + 3]) << 24);
+				}
+				if (t < total - tail0) { a.t_drow8[out + tail0 + t] = stage_d[tail0 + t]; a.t_val8[out + tail0 + t] = stage_v[tail0 + t]; }
+			}
+			if (threadIdx.x == 0 && total) kept_row[0] = kept_row[total];
+			// (the next round's block scan synchronises before anyone touches kept_row / the stages again)
+		} else if (keep) {
 			if (NARROW) {
 				a.t_gene16[out + ex] = uint16_t(g);
 				a.t_val16[out + ex] = v >= 0xFFFFu ? uint16_t(0xFFFFu) : uint16_t(v);

@@ -252,6 +252,28 @@ dropest_status dropest_count_matrix_csc_narrow(dropest_ctx *ctx, int filtered, i
                                                const uint32_t **colptr, const uint16_t **rowidx, const uint16_t **values,
                                                uint64_t *n_overflow, const uint32_t **overflow_pos, const uint32_t **overflow_val);
 dropest_status dropest_prefetch_raw_matrix_narrow(dropest_ctx *ctx, int reads_output);
+/* The same matrix in the BYTE form: two bytes per entry over PCIe instead of eight, for any gene id.  Entry k of column c
+ * (colptr[c] <= k < colptr[c + 1]; rows of a column ascend) carries
+ *   row_delta[k] = row[k] - row[k - 1]  (the column's first entry: row[k] + 1, i.e. counted from row -1); 255 = listed: the exact ROW stands in
+ *                  (row_listed_pos, row_listed_row), and the deltas after it count from that row
+ *   value[k]     = the count; 255 = listed in (value_listed_pos, value_listed_value)
+ * The lists come in no particular order (the device appends to them as it goes).  A cell with a few thousand of 30 000 genes has row gaps of ~10 and counts of a few UMIs: well under
+ * 1 % of the entries are listed.  dropest_matrix_bytes_widen decodes into the dgCMatrix slots i / x on host threads (what ResultsPrinter
+ * does while it writes its doubles); tests/test_gpu_narrow.py checks it against dropest_count_matrix_csc bit for bit.  More than 2^20
+ * listed entries of a kind: DROPEST_ERR_UNSUPPORTED (take the 16-bit or the 32-bit form).  Pointers refer to pinned host memory of the
+ * context, valid until the next emit of the same matrix. */
+typedef struct dropest_matrix_bytes {
+	uint64_t ncols, nnz;
+	const uint32_t *colptr;
+	const uint8_t *row_delta, *value;
+	uint64_t n_row_listed;
+	const uint32_t *row_listed_pos, *row_listed_row;
+	uint64_t n_value_listed;
+	const uint32_t *value_listed_pos, *value_listed_value;
+} dropest_matrix_bytes;
+dropest_status dropest_count_matrix_csc_bytes(dropest_ctx *ctx, int filtered, int reads_output, dropest_matrix_bytes *out);
+dropest_status dropest_prefetch_raw_matrix_bytes(dropest_ctx *ctx, int reads_output);
+dropest_status dropest_matrix_bytes_widen(const dropest_matrix_bytes *m, uint32_t *rowidx, uint32_t *values);
 
 /* ResultsPrinter::get_count_matrix_filtered(container, query_marks) (ResultsPrinter.cpp:333-361) for a mark query other
  * than the container's own -- what ResultsPrinter::save_intron_exon_matrices asks for (-V: "e", "i", "BA",

@@ -86,3 +86,81 @@ def test_empty_container_narrow():
     n = e.count_matrix_csc_narrow(filtered=True)
     assert len(n[1]) == 0 and len(n[3]) == 0
     e.close()
+
+
+# ---- the byte form (dropest_count_matrix_csc_bytes): one byte of row delta, one byte of value, two exact lists -----------------------------
+def _bytes_equal_wide(c, reads_output=False, prefetch=False):
+    out = []
+    for filt in (True, False):
+        if prefetch and not filt:
+            c.prefetch_raw_matrix(reads_output, form=2)
+        m = c.count_matrix_csc_bytes(filtered=filt, reads_output=reads_output)
+        got = [x.copy() for x in c.widen_bytes(m)]
+        listed = (int(m.n_row_listed), int(m.n_value_listed), int(m.nnz))
+        want = [x.copy() for x in c.count_matrix_csc(filtered=filt, reads_output=reads_output)]
+        for g, w in zip(got, want):
+            assert g.dtype == w.dtype and np.array_equal(g, w), (filt, reads_output)
+        out.append((filt, listed, want))
+    return out
+
+
+@pytest.mark.parametrize("reads_output", [False, True])
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_byte_form_equals_wide_on_a_c2_shape(reads_output, prefetch):
+    s = SynthStream(n_reads=3_000_000, n_cells=300, n_genes=20000)
+    c = capi.Context(min_genes_before_merge=20, min_genes_after_merge=100)
+    c.push_reads(*parity.canonical_stream(*s.generate_host()))
+    c.set_initialized(); c.merge_and_filter()
+    seen = _bytes_equal_wide(c, reads_output, prefetch)
+    for _, (n_rows, n_vals, nnz), w in seen:
+        assert nnz > 100000 and n_rows < nnz // 20 and n_vals < nnz // 20    # the lists stay short: that is the point of the form
+    # the three forms after one another, prefetches of another form in between
+    c.prefetch_raw_matrix(reads_output, form=2)
+    wide = [x.copy() for x in c.count_matrix_csc(filtered=False, reads_output=reads_output)]
+    c.prefetch_raw_matrix(reads_output, narrow=True)
+    b = [x.copy() for x in c.widen_bytes(c.count_matrix_csc_bytes(filtered=False, reads_output=reads_output))]
+    nar = capi.Context.widen(c.count_matrix_csc_narrow(filtered=False, reads_output=reads_output))
+    assert all(np.array_equal(x, y) for x, y in zip(wide, b)) and all(np.array_equal(x, y) for x, y in zip(wide, nar))
+    c.close()
+
+
+def test_byte_form_lists_large_gaps_large_counts_and_columns_longer_than_a_round():
+    """Gene ids up to 200 000 (no 16-bit form possible), gaps of every size around 255, counts around 255, a cell with more than 256
+    genes (several rounds of the emit kernel: the delta crosses a round boundary), cells with a single gene."""
+    P = capi.pack_seq
+    rows = []
+    cells = ["ACGTACGTACGTACG" + x for x in "ACGT"]
+    genes0 = [0, 253, 507, 762, 1018, 1019, 1500, 70_000, 70_254, 70_509, 200_000]          # gaps 1(-1->0), 253, 254, 255, 256, 1, ...
+    counts0 = [1, 253, 254, 255, 256, 300, 2, 254, 255, 1, 70_000]
+    for g, n in zip(genes0, counts0):
+        rows += [(cells[0], int(u), g) for u in range(n)]
+    rows += [(cells[1], 0, 123_456)]                                                       # one gene, far away: listed row, first entry
+    rows += [(cells[2], 0, 254)]                                                           # first delta exactly 255 -> listed
+    rows += [(cells[2], 1, 253 + 255)]                                                     # ... and a delta of 254 after a listed row
+    rng = np.random.default_rng(11)
+    many = np.sort(rng.choice(150_000, size=900, replace=False))
+    rows += [(cells[3], int(k % 7), int(g)) for k, g in enumerate(many)]
+    cb = np.array([P(r[0]) for r in rows], np.uint64)
+    umi = np.array([np.uint64(r[1]) | np.uint64(1 << 34) for r in rows], np.uint64)        # 17-base codes: room for 70 000 distinct UMIs
+    gene = np.array([r[2] for r in rows], np.uint32)
+    aux = np.full(len(rows), 2 << 16, np.uint32)
+    perm = rng.permutation(len(rows))
+    # (gene ids stay as given: first-seen renumbering would close the gaps this test is about)
+    c = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
+    c.push_reads(cb[perm], umi[perm], gene[perm], aux[perm])
+    c.set_initialized(); c.merge_and_filter()
+    assert not c.narrow_matrix_possible()
+    for reads_output in (False, True):
+        seen = _bytes_equal_wide(c, reads_output)
+        for filt, (n_rows, n_vals, nnz), want in seen:
+            assert nnz == len(genes0) + 1 + 2 + 900
+            assert n_rows >= 6 and n_vals == 5, (n_rows, n_vals)      # 255 (twice), 256, 300, 70 000 are listed; 253 / 254 are not
+    c.close()
+
+
+def test_byte_form_of_an_empty_container():
+    c = capi.Context()
+    c.set_initialized(); c.merge_and_filter()
+    m = c.count_matrix_csc_bytes(filtered=True)
+    assert m.nnz == 0 and m.ncols == 0
+    c.close()
