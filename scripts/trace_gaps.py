@@ -1,0 +1,28 @@
+"""Idle time of the device inside one pass: from a rocprofv3 --kernel-trace CSV (kernel start / end timestamps) of a bench run, the gaps
+between consecutive kernels of the last pass, largest first, with the kernels on either side.  usage: trace_gaps.py <dir with *kernel_trace.csv>"""
+import csv, glob, sys
+rows = []
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+# the last pass: from the last cb_sample_distinct launch on
+starts = [i for i, r in enumerate(rows) if "cb_sample_distinct" in r[2]]
+lo = starts[-1]
+hi = len(rows)
+seg = rows[lo:hi]
+busy = sum(e - s for s, e, _ in seg)
+span = max(e for _, e, _ in seg) - seg[0][0]
+print("kernels %d, span %.3f ms, busy %.3f ms, idle %.3f ms" % (len(seg), span / 1e6, busy / 1e6, (span - busy) / 1e6))
+gaps = []
+end = seg[0][1]
+for i in range(1, len(seg)):
+    s, e, n = seg[i]
+    if s > end:
+        gaps.append((s - end, seg[i - 1][2][:60], n[:60]))
+    end = max(end, e)
+gaps.sort(reverse=True)
+for g, a, b in gaps[:25]:
+    print("%8.1f us  after %-60s before %s" % (g / 1e3, a, b))
+print("gaps > 20 us: %d, their sum %.3f ms; gaps <= 20 us: sum %.3f ms" % (sum(1 for g in gaps if g[0] > 20000), sum(g[0] for g in gaps if g[0] > 20000) / 1e6,
+                                                                        sum(g[0] for g in gaps if g[0] <= 20000) / 1e6))
