@@ -73,6 +73,7 @@ def one_step(ctx, form=None):
     byte of count per entry plus two exact lists; lossless, decoded by dropest_matrix_bytes_widen or by the reader itself: the facade's
     ResultsPrinter turns entries into doubles either way); form = "u16" / "u32" selects the 16-bit / 32-bit forms."""
     form = form or matrix_form()
+    ctx.set_raw_matrix_prefetch({"u32": 0, "u16": 1, "bytes": 2}[form] if not os.environ.get("DROPEST_BENCH_NO_PREFETCH") else -1)
     ctx.reset_results()
     ctx.set_initialized()
     ctx.merge_and_filter()

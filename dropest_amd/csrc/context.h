@@ -598,8 +598,13 @@ struct dropest_ctx {
 	struct RawPrefetch { bool valid = false, reads_output = false, in_flight = false; int narrow = 0; std::vector<u32> col_cell; } raw_pf;
 	hipStream_t stream2 = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_raw = nullptr;
-	dropest::DevBuf<u32> m2_col_cell, m2_col_start;
+	dropest::DevBuf<u32> m2_col_cell, m2_col_start, m2_col_list, m_col_list;
+	std::vector<u32> m2_col_list_host, m_col_list_host;   // (host sides of asynchronous uploads: kept with the context)
+	void launch_emit_bytes(dropest::MatrixArgs a, const std::vector<u32> &rows_per_column, dropest::DevBuf<u32> &list, std::vector<u32> &host_list, hipStream_t st);
 	void prefetch_raw_matrix(bool reads_output, int form = 0);   // form: 0 32-bit, 1 16-bit, 2 bytes
+	int auto_pf_form = -1;          // dropest_set_raw_matrix_prefetch: the form cm_raw will be asked for (-1: not announced)
+	bool auto_pf_reads = false;
+	bool merge_phase_changes_nothing() const;
 	void invalidate_prefetch();
 	u64 unmap_umi(u64 ucode) const;
 };

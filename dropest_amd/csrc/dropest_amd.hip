@@ -1232,13 +1232,22 @@ void dropest_ctx::run_set_initialized() {
 	}
 	request_filtered(0, -1);   // update_cell_sizes(query, 0, -1), CellsDataContainer.cpp:168
 	initialized = true;
+	// cm_raw announced (dropest_set_raw_matrix_prefetch) and nothing in merge_and_filter can change it: its emit and its copy to the
+	// host start now and run under the rest of the pass (the host work of ordering the filtered cells, the emit of cm)
+	if (auto_pf_form >= 0 && n_reads && merge_phase_changes_nothing() && (auto_pf_form != 1 || narrow_possible())) prefetch_raw_matrix(auto_pf_reads, auto_pf_form);
 	collect_timings();
+}
+
+// No CB merge, the Simple UMI merge and no UMI with N anywhere: merge_and_filter only re-filters the cells.
+bool dropest_ctx::merge_phase_changes_nothing() const {
+	return cfg.merge_kind == DROPEST_MERGE_NONE && cfg.umi_merge_kind != DROPEST_UMI_MERGE_DIRECTIONAL && ingest.umi_escape_max_plus1 == 0 && !hooks &&
+	       !external_merge_done;
 }
 
 void dropest_ctx::run_merge_and_filter() {
 	if (!initialized) throw InvalidError("You must initialize container");
 	if (merged) throw InvalidError("merge_and_filter was already run");
-	invalidate_prefetch();
+	if (!merge_phase_changes_nothing()) invalidate_prefetch();   // (whatever rewrites the tables discards a prefetch on its own way in, too)
 	HostStage hs(this, "merge_and_filter");
 	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells && !external_merge_done) run_cb_merge_real();
 	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL && n_cells && !external_merge_done) run_cb_merge_real();   // same loop, Poisson decisions
@@ -1248,6 +1257,7 @@ void dropest_ctx::run_merge_and_filter() {
 	if (cfg.umi_merge_kind == DROPEST_UMI_MERGE_DIRECTIONAL) run_umi_merge_directional(); else run_umi_merge_simple();
 	request_filtered(min_after, cfg.max_cells);   // CellsDataContainer.cpp:47-49
 	merged = true;
+	if (auto_pf_form >= 0 && n_reads && !raw_pf.valid && (auto_pf_form != 1 || narrow_possible())) prefetch_raw_matrix(auto_pf_reads, auto_pf_form);
 	collect_timings();
 }
 
@@ -1364,9 +1374,30 @@ void dropest_ctx::matrix_finish_overflow(MatrixResult &M, hipStream_t st) {
 	if (M.narrow == 2) finish(M.d_rovf, M.h_rovf, M.n_rovf, "a row gap beyond 254");
 }
 
+// Byte form: long columns by the workgroup-per-column kernel, short ones (fewer than 256 (cell, gene) rows) by the wave-per-column kernel.
+// `list` (device, >= ncols words; filled here) holds the long columns first, then the short ones.
+void dropest_ctx::launch_emit_bytes(dropest::MatrixArgs a, const std::vector<u32> &col_cell_rows /* rows per column */, dropest::DevBuf<u32> &list,
+                                    std::vector<u32> &host_list, hipStream_t st) {
+	using namespace dropest;
+	const u32 ncols = u32(col_cell_rows.size());
+	host_list.resize(ncols);
+	u32 n_long = 0;
+	for (u32 j = 0; j < ncols; ++j) if (col_cell_rows[j] >= 256u) host_list[n_long++] = j;
+	u32 at = n_long;
+	for (u32 j = 0; j < ncols; ++j) if (col_cell_rows[j] < 256u) host_list[at++] = j;
+	list.ensure(ncols);
+	HIP_CHECK(hipMemcpyAsync(list.p, host_list.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, st));
+	if (n_long) { a.col_list = list.p; a.n_list = n_long; hipLaunchKernelGGL(emit_matrix_kernel<2>, dim3(n_long), dim3(256), 0, st, a); }
+	if (ncols > n_long) {
+		a.col_list = list.p + n_long; a.n_list = ncols - n_long;
+		hipLaunchKernelGGL(emit_matrix_bytes_short_kernel, dim3(div_up(a.n_list, EMS_COLS)), dim3(256), 0, st, a);
+	}
+}
+
 // cm_raw on a second stream: emit + device-to-host copy start now and run under whatever the caller does next (ordering
 // the filtered cells, emitting cm); dropest_count_matrix_csc(filtered = 0) later only waits for the copy.
 void dropest_ctx::prefetch_raw_matrix(bool reads_output, int narrow) {
+	if (raw_pf.valid && raw_pf.reads_output == reads_output && raw_pf.narrow == narrow) return;   // already under way (dropest_set_raw_matrix_prefetch)
 	HostStage hs(this, "prefetch:cm_raw");
 	invalidate_prefetch();
 	if (narrow == 1 && !narrow_possible()) throw UnsupportedError("gene ids beyond 65535: the narrow matrix form is not available");
@@ -1394,7 +1425,11 @@ void dropest_ctx::prefetch_raw_matrix(bool reads_output, int narrow) {
 	a.col_cell = m2_col_cell.p; a.col_start = m2_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
 	a.value = reads_output ? cg_reads_all.p : cg_n_all.p;
 	a.gene_mask = layout.gene_none; a.skip_zero = 0;
-	if (narrow == 2) hipLaunchKernelGGL(emit_matrix_kernel<2>, dim3(ncols), dim3(256), 0, stream2, a);
+	if (narrow == 2) {
+		std::vector<u32> rows(ncols);   // (an upper bound of every column's entries: cm_raw keeps all of a cell's genes)
+		for (u32 j = 0; j < ncols; ++j) rows[j] = M.colptr[j + 1] - M.colptr[j];
+		launch_emit_bytes(a, rows, m2_col_list, m2_col_list_host, stream2);
+	}
 	else if (narrow == 1) hipLaunchKernelGGL(emit_matrix_kernel<1>, dim3(ncols), dim3(256), 0, stream2, a);
 	else hipLaunchKernelGGL(emit_matrix_kernel<0>, dim3(ncols), dim3(256), 0, stream2, a);
 	HIP_CHECK(hipGetLastError());
@@ -1432,7 +1467,11 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, 
 	a.value = filtered_m ? (reads_output ? cg_reads_req.p : cg_n_req.p) : (reads_output ? cg_reads_all.p : cg_n_all.p);
 	a.gene_mask = layout.gene_none; a.skip_zero = filtered_m ? 1 : 0;
 	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * (narrow == 2 ? 14 : narrow ? 16 : 20), [&] {
-		if (narrow == 2) hipLaunchKernelGGL(emit_matrix_kernel<2>, dim3(ncols), dim3(256), 0, stream, a);
+		if (narrow == 2) {
+			std::vector<u32> rows(ncols);   // entries per column (cm: the requested genes; the kernel walks a few more rows and drops the zeros)
+			for (u32 j = 0; j < ncols; ++j) rows[j] = M.colptr[j + 1] - M.colptr[j];
+			launch_emit_bytes(a, rows, m_col_list, m_col_list_host, stream);
+		}
 		else if (narrow == 1) hipLaunchKernelGGL(emit_matrix_kernel<1>, dim3(ncols), dim3(256), 0, stream, a);
 		else hipLaunchKernelGGL(emit_matrix_kernel<0>, dim3(ncols), dim3(256), 0, stream, a);
 	});
@@ -2109,6 +2148,14 @@ dropest_status dropest_count_matrix_csc_narrow(dropest_ctx *ctx, int filtered, i
 		*ncols = M.ncols; *nnz = M.nnz;
 		*colptr = M.colptr.data(); *rowidx = M.h_row16.p; *values = M.h_val16.p;
 		*n_overflow = M.n_ovf; *overflow_pos = M.h_ovf.p ? M.h_ovf.p + 1 : nullptr; *overflow_val = M.h_ovf.p ? M.h_ovf.p + 1 + MATRIX_OVF_CAP : nullptr;
+	});
+}
+
+dropest_status dropest_set_raw_matrix_prefetch(dropest_ctx *ctx, int form, int reads_output) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		if (form < -1 || form > 2) throw InvalidError("form: -1 (off), 0 (32-bit), 1 (16-bit), 2 (bytes)");
+		ctx->auto_pf_form = form; ctx->auto_pf_reads = reads_output != 0;
 	});
 }
 

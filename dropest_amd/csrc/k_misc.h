@@ -260,14 +260,30 @@ struct MatrixArgs {
 	// well under 1 % of the entries are listed.
 	uint8_t *t_drow8, *t_val8;
 	uint32_t *rovf_count, *rovf_pos, *rovf_row;
+	const uint32_t *col_list;       // non-null: the launch covers these columns only (n_list of them)
+	uint32_t n_list;
 };
+// appends (pos, val) of the lanes with `listed` to a list: ONE atomic per wave (all lists of a launch share one counter word: with an atomic per
+// entry the 4e5 listed rows of cm_raw at C2 were most of the kernel's time)
+__device__ inline void matrix_list_append(bool listed, uint32_t pos, uint32_t val, uint32_t *count, uint32_t *list_pos, uint32_t *list_val, uint32_t cap) {
+	const unsigned long long m = __ballot(listed);
+	if (!m) return;
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t base = 0;
+	if (lane == uint32_t(__builtin_ctzll(m))) base = atomicAdd(count, uint32_t(__popcll(m)));
+	base = uint32_t(__shfl(int(base), __builtin_ctzll(m), 64));
+	if (listed) {
+		const uint32_t at = base + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+		if (at < cap) { list_pos[at] = pos; list_val[at] = val; }
+	}
+}
 template <int FORM>   // 0: 32-bit, 1: 16-bit (NARROW), 2: bytes
 __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
 	constexpr bool NARROW = FORM == 1;
 	__shared__ uint32_t scratch[256 / 64 + 1];
 	__shared__ uint32_t kept_row[FORM == 2 ? 257 : 1];   // [0] last kept row of the previous round (+1), [1 + ex] the rows kept in this one
 	__shared__ uint8_t stage_d[FORM == 2 ? 256 : 1], stage_v[FORM == 2 ? 256 : 1];
-	const uint32_t col = blockIdx.x;
+	const uint32_t col = a.col_list ? a.col_list[blockIdx.x] : blockIdx.x;
 	const uint32_t cell = a.col_cell[col];
 	const uint32_t b = a.cell_cg_begin[cell], e = b + a.cell_cg_count[cell];
 	uint32_t out = a.col_start[col];
@@ -286,13 +302,13 @@ __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
 		if (FORM == 2) {
 			if (keep) kept_row[1 + ex] = g + 1u;
 			__syncthreads();
+			const uint32_t delta = keep ? g + 1u - kept_row[ex] : 0u;   // kept_row[ex]: the entry before this one (+1), kept_row[0] from the round before
 			if (keep) {
-				const uint32_t delta = g + 1u - kept_row[ex];   // kept_row[ex]: the entry before this one (+1), kept_row[0] from the round before
 				stage_d[ex] = delta >= 255u ? uint8_t(255u) : uint8_t(delta);
 				stage_v[ex] = v >= 255u ? uint8_t(255u) : uint8_t(v);
-				if (delta >= 255u) { const uint32_t at = atomicAdd(a.rovf_count, 1u); if (at < a.ovf_cap) { a.rovf_pos[at] = out + ex; a.rovf_row[at] = g; } }
-				if (v >= 255u) { const uint32_t at = atomicAdd(a.ovf_count, 1u); if (at < a.ovf_cap) { a.ovf_pos[at] = out + ex; a.ovf_val[at] = v; } }
 			}
+			matrix_list_append(keep && delta >= 255u, out + ex, g, a.rovf_count, a.rovf_pos, a.rovf_row, a.ovf_cap);
+			matrix_list_append(keep && v >= 255u, out + ex, v, a.ovf_count, a.ovf_pos, a.ovf_val, a.ovf_cap);
 			__syncthreads();
 			{   // the round's bytes leave as aligned 4-byte words (one-byte stores of 256 threads cost 3x the 16-bit form's kernel time)
 				const uint32_t head = min(total, (4u - (out & 3u)) & 3u), nw = (total - head) >> 2, tail0 = head + 4u * nw, t = threadIdx.x;
@@ -317,6 +333,60 @@ __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
 			} else { a.t_gene[out + ex] = g; a.t_val[out + ex] = v; }
 		}
 		out += total;
+	}
+}
+
+// Byte form, short columns: one WAVE per column (eight columns per workgroup), no workgroup barrier while the columns are walked.  cm_raw
+// of a 10x run has 5 000 cells of thousands of genes and 10^5 of a few dozen, whose sparse rows are mostly LISTED (gaps beyond 254):
+// 4e5 list entries at C2.  Appending them with one atomic each -- or one per wave -- on the list's single counter word was the kernel's
+// time (0.87 / 0.74 ms against 0.16 ms for the same matrix in the 16-bit form): the listed entries of a workgroup are staged in LDS and
+// leave with ONE atomic.
+constexpr uint32_t EMS_COLS = 8, EMS_STAGE = EMS_COLS * 255u;   // columns per workgroup; a short column lists at most 255 entries of a kind
+__global__ __launch_bounds__(256) void emit_matrix_bytes_short_kernel(MatrixArgs a) {
+	__shared__ uint32_t st_pos[2][EMS_STAGE], st_val[2][EMS_STAGE];   // [0] rows, [1] values
+	__shared__ uint32_t st_n[2], st_base[2];
+	const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+	if (threadIdx.x < 2) st_n[threadIdx.x] = 0;
+	__syncthreads();
+	for (uint32_t c = w; c < EMS_COLS; c += 4) {
+		const uint32_t idx = blockIdx.x * EMS_COLS + c;
+		if (idx >= a.n_list) break;
+		const uint32_t col = a.col_list[idx];
+		const uint32_t cell = a.col_cell[col];
+		const uint32_t b = a.cell_cg_begin[cell], e = b + a.cell_cg_count[cell];
+		uint32_t out = a.col_start[col], prev1 = 0;   // prev1: row + 1 of the last entry kept so far (wave-uniform)
+		for (uint32_t base = b; base < e; base += 64) {
+			const uint32_t i = base + lane;
+			bool keep = false;
+			uint32_t g = 0, v = 0;
+			if (i < e) {
+				g = uint32_t(a.cg_key[i] & a.gene_mask);
+				v = a.value[i];
+				keep = (a.cg_key[i] & a.gene_mask) != a.gene_mask && !(a.skip_zero && v == 0);
+			}
+			const unsigned long long bal = __ballot(keep);
+			if (!bal) continue;
+			const unsigned long long below = bal & ((1ull << lane) - 1ull);
+			const uint32_t ex = uint32_t(__popcll(below));
+			const int src = below ? 63 - __builtin_clzll(below) : int(lane);   // the kept lane before this one
+			const uint32_t before1 = uint32_t(__shfl(int(g + 1u), src, 64));
+			const uint32_t delta = keep ? g + 1u - (below ? before1 : prev1) : 0u;
+			if (keep) {
+				a.t_drow8[out + ex] = delta >= 255u ? uint8_t(255u) : uint8_t(delta);
+				a.t_val8[out + ex] = v >= 255u ? uint8_t(255u) : uint8_t(v);
+				if (delta >= 255u) { const uint32_t at = atomicAdd(&st_n[0], 1u); st_pos[0][at] = out + ex; st_val[0][at] = g; }
+				if (v >= 255u) { const uint32_t at = atomicAdd(&st_n[1], 1u); st_pos[1][at] = out + ex; st_val[1][at] = v; }
+			}
+			prev1 = uint32_t(__shfl(int(g + 1u), 63 - __builtin_clzll(bal), 64));
+			out += uint32_t(__popcll(bal));
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < 2 && st_n[threadIdx.x]) st_base[threadIdx.x] = atomicAdd(threadIdx.x ? a.ovf_count : a.rovf_count, st_n[threadIdx.x]);
+	__syncthreads();
+	for (uint32_t k = 0; k < 2; ++k) {
+		uint32_t *lp = k ? a.ovf_pos : a.rovf_pos, *lv = k ? a.ovf_val : a.rovf_row;
+		for (uint32_t j = threadIdx.x; j < st_n[k]; j += 256) { const uint32_t at = st_base[k] + j; if (at < a.ovf_cap) { lp[at] = st_pos[k][j]; lv[at] = st_val[k][j]; } }
 	}
 }
 

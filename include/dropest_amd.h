@@ -274,6 +274,12 @@ typedef struct dropest_matrix_bytes {
 dropest_status dropest_count_matrix_csc_bytes(dropest_ctx *ctx, int filtered, int reads_output, dropest_matrix_bytes *out);
 dropest_status dropest_prefetch_raw_matrix_bytes(dropest_ctx *ctx, int reads_output);
 dropest_status dropest_matrix_bytes_widen(const dropest_matrix_bytes *m, uint32_t *rowidx, uint32_t *values);
+/* Announces that cm_raw will be asked for in `form` (0: 32-bit, 1: 16-bit, 2: bytes; -1 takes the announcement back) with UMI counts
+ * (reads_output = 0) or read counts: the container then starts the prefetch by itself as early as the matrix is final -- at the end of
+ * set_initialized when merge_and_filter cannot change it (no CB merge, the Simple UMI merge, no UMI with N: merge_and_filter then only
+ * re-filters the cells), at the end of merge_and_filter otherwise -- and the copy to the host runs under the host work in between.
+ * A setting of the context: it survives dropest_reset_results / dropest_clear_reads.  Results are the same with and without. */
+dropest_status dropest_set_raw_matrix_prefetch(dropest_ctx *ctx, int form, int reads_output);
 
 /* ResultsPrinter::get_count_matrix_filtered(container, query_marks) (ResultsPrinter.cpp:333-361) for a mark query other
  * than the container's own -- what ResultsPrinter::save_intron_exon_matrices asks for (-V: "e", "i", "BA",

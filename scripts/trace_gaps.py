@@ -24,5 +24,9 @@ for i in range(1, len(seg)):
 gaps.sort(reverse=True)
 for g, a, b in gaps[:25]:
     print("%8.1f us  after %-60s before %s" % (g / 1e3, a, b))
+if len(sys.argv) > 2:   # the last kernels of the pass on a time line (ms before the end of the pass)
+    t_end = max(e for _, e, _ in seg)
+    for s_, e_, n_ in seg[-int(sys.argv[2]):]:
+        print("  start -%7.3f ms  dur %7.3f ms  %s" % ((t_end - s_) / 1e6, (e_ - s_) / 1e6, n_[:70]))
 print("gaps > 20 us: %d, their sum %.3f ms; gaps <= 20 us: sum %.3f ms" % (sum(1 for g in gaps if g[0] > 20000), sum(g[0] for g in gaps if g[0] > 20000) / 1e6,
                                                                         sum(g[0] for g in gaps if g[0] <= 20000) / 1e6))

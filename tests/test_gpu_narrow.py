@@ -164,3 +164,40 @@ def test_byte_form_of_an_empty_container():
     m = c.count_matrix_csc_bytes(filtered=True)
     assert m.nnz == 0 and m.ncols == 0
     c.close()
+
+
+@pytest.mark.parametrize("with_n", [False, True])
+@pytest.mark.parametrize("form", [0, 1, 2])
+def test_announced_cm_raw_prefetch_changes_nothing(form, with_n):
+    """dropest_set_raw_matrix_prefetch: the container starts cm_raw's prefetch by itself -- at the end of set_initialized when
+    merge_and_filter cannot change the matrix, after it otherwise (UMIs with N are merged there) -- and every form of both matrices is
+    what a context without the announcement gives; the announcement survives a second pass over the same reads."""
+    from dropest_amd.synth import inject_n
+    s = SynthStream(n_reads=1_500_000, n_cells=200, n_genes=8000)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    side = ()
+    if with_n:
+        umi, side = inject_n(umi, gene, 1e-3, 5, 10)
+    def make(announce):
+        c = capi.Context(min_genes_before_merge=20, min_genes_after_merge=100)
+        if side:
+            c.set_side_strings(side)
+        c.push_reads(cb, umi, gene, aux)
+        if announce:
+            c.set_raw_matrix_prefetch(form)
+        c.set_initialized(); c.merge_and_filter()
+        return c
+    ref = make(False)
+    want = {f: [x.copy() for x in ref.count_matrix_csc(filtered=f)] for f in (True, False)}
+    c = make(True)
+    for rounds in range(2):
+        for filt in (True, False):
+            if form == 2:
+                got = c.widen_bytes(c.count_matrix_csc_bytes(filtered=filt))
+            elif form == 1:
+                got = capi.Context.widen(c.count_matrix_csc_narrow(filtered=filt))
+            else:
+                got = c.count_matrix_csc(filtered=filt)
+            assert all(np.array_equal(a, b) for a, b in zip(got, want[filt])), (form, with_n, filt, rounds)
+        c.reset_results(); c.set_initialized(); c.merge_and_filter()
+    c.close(); ref.close()
