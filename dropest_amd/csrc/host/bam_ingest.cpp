@@ -1,5 +1,6 @@
 // bam_ingest.cpp -- see bam_ingest.h.
 #include "bam_ingest.h"
+#include "fast_inflate.h"
 #include <atomic>
 
 #include <zlib.h>
@@ -62,6 +63,13 @@ bool read_block(const uint8_t *map, size_t size, size_t &at, RawBlock &b, const 
 
 void inflate_block(const RawBlock &b, uint8_t *out) {
 	if (b.isize == 0) return;
+	// the block decoder of fast_inflate.h first (about three times zlib 1.2.11's rate); a block it refuses -- and any block when
+	// DROPEST_BAM_ZLIB is set -- goes through zlib below.  Either way CRC-32 and ISIZE of the block are checked.
+	static const bool force_zlib = getenv("DROPEST_BAM_ZLIB") != nullptr;
+	if (!force_zlib && fastinflate::inflate_raw(b.cdata, b.clen, out, b.isize)) {
+		if (fastinflate::crc32(out, b.isize) != b.crc) throw std::runtime_error("Corrupt BGZF block (CRC)");
+		return;
+	}
 	// one inflate state per thread, reset per block (inflateInit2 allocates its 40 KB window every time)
 	struct State { z_stream zs; bool ready = false; ~State() { if (ready) inflateEnd(&zs); } };
 	static thread_local State st;
@@ -140,7 +148,15 @@ struct BamReader::Impl {
 	// Decompressed windows live in a few recycled buffers (a fresh 32 MB allocation per batch would spend more time in
 	// page faults than the inflate takes).  A batch leaves HEADROOM bytes free in front: the unconsumed tail of the
 	// previous window (a partial record) is copied there, so a new batch is adopted without moving it.
-	struct Buf { std::unique_ptr<uint8_t[]> p; size_t cap = 0, size = 0; void need(size_t n) { if (n > cap) { p.reset(new uint8_t[n]); cap = n; } } };
+	struct Buf {
+		std::unique_ptr<uint8_t[]> p; size_t cap = 0, size = 0;
+		void need(size_t n) { if (n > cap) { p.reset(new uint8_t[n]); cap = n; } }
+		// Record boundaries found by the loader (walk_records): starts of the COMPLETE records that begin in this batch (buffer offsets),
+		// first_start = the first of them or tail_start, tail_start = where the unfinished last record begins (= size if none).
+		std::vector<uint32_t> rec_off;
+		bool walked = false, consumed = false;
+		size_t first_start = 0, tail_start = 0;
+	};
 	Buf cur;                                           // window being parsed: bytes [pos, cur.size)
 	std::vector<Buf> spare;                            // touched by the caller's thread only
 	size_t pos = 0;
@@ -150,7 +166,15 @@ struct BamReader::Impl {
 	std::string text;
 	const uint8_t *bytes() const { return cur.p.get(); }
 
-	double load_ms = 0, discover_ms = 0; size_t n_batches = 0;   // diagnostics (DROPEST_BAM_TRACE)
+	// The walk over the records (every record's length says where the next one starts: a dependent chain) used to run on the caller's
+	// thread over data the inflate workers had just written on other cores -- 4 ms per 32 MB window, the floor of the whole ingest
+	// (profiles/NOTES_r03.md).  Now every worker, after inflating block i, waits for the position block i - 1's walker ended at, walks
+	// ITS block while it is hot in its own cache and hands the position on; the loader of a batch knows where the last record of the
+	// batch before was cut.  walk_state: what the next batch needs to know about that cut.
+	bool loader_walks = getenv("DROPEST_BAM_CALLER_WALKS") == nullptr;
+	struct WalkState { bool valid = false; size_t tail_len = 0; uint8_t tail[4] = {0, 0, 0, 0}; uint32_t tail_record = 0; } walk_state;
+	std::vector<std::vector<uint32_t>> block_starts;
+	double load_ms = 0, discover_ms = 0; size_t n_batches = 0, n_walked = 0;   // diagnostics (DROPEST_BAM_TRACE)
 	size_t first_batch_compressed = 0;                           // bytes of the file the first batch covered (read-count estimate)
 	Buf load_batch(Buf out) {
 		const auto t_begin = std::chrono::steady_clock::now();
@@ -168,15 +192,123 @@ struct BamReader::Impl {
 		out.need(off.back());
 		out.size = off.back();
 		uint8_t *base = out.p.get();
-		if (!pool) pool.reset(new WorkerPool(std::max(1u, threads)));
+		// (inflate + the walk chain stop scaling at about 16 workers -- the chain is serial -- and more of them only take cores from
+		// the parsers, which do scale: 64 inflate workers measured a third of the rate of 16)
+		if (!pool) pool.reset(new WorkerPool(std::max(1u, std::min(threads, 16u))));
 		const unsigned nt = pool->size();
-		std::atomic<size_t> next_block{0};            // blocks differ in cost: taken one at a time
+		std::atomic<size_t> next_block{0};            // blocks differ in cost: taken one at a time, in file order
+		out.walked = out.consumed = false; out.rec_off.clear();
+		// where this batch's first record starts (buffer offset), if the batch before told us; batch 0 holds the header: walked below
+		const size_t NB = blocks.size();
+		bool chain = loader_walks && n_batches > 0 && walk_state.valid && NB > 0;
+		size_t p0 = HEADROOM;
+		bool size_from_new = false;                   // the cut went through the length field: its missing bytes open this batch
+		if (chain) {
+			if (walk_state.tail_len >= 4) p0 = HEADROOM + 4 + size_t(walk_state.tail_record) - walk_state.tail_len;
+			else if (walk_state.tail_len > 0) size_from_new = true;
+		}
+		std::unique_ptr<std::atomic<uint64_t>[]> carry;   // carry[i] = 1 + position the walker of block i starts at (0: not known yet)
+		std::atomic<bool> abort_walk{false}, corrupt{false};
+		if (chain) {
+			carry.reset(new std::atomic<uint64_t>[NB + 1]);
+			for (size_t i = 0; i <= NB; ++i) carry[i].store(0, std::memory_order_relaxed);
+			if (!size_from_new) carry[0].store(uint64_t(p0) + 1, std::memory_order_release);
+			if (block_starts.size() < NB) block_starts.resize(NB);
+		}
 		try {
-			pool->run([&](unsigned) { for (size_t i; (i = next_block.fetch_add(1)) < blocks.size();) inflate_block(blocks[i], base + off[i]); });
+			pool->run([&](unsigned) {
+				for (size_t i; (i = next_block.fetch_add(1)) < NB;) {
+					try { inflate_block(blocks[i], base + off[i]); } catch (...) { abort_walk = true; throw; }
+					if (!chain) continue;
+					if (i == 0 && size_from_new) {
+						const size_t missing = 4 - walk_state.tail_len;
+						if (off[1] - off[0] < missing) { abort_walk = true; continue; }   // (a block shorter than the rest of a length field: the caller walks this batch)
+						uint8_t sz[4];
+						std::memcpy(sz, walk_state.tail, walk_state.tail_len);
+						std::memcpy(sz + walk_state.tail_len, base + HEADROOM, missing);
+						carry[0].store(uint64_t(HEADROOM + 4 + size_t(le32(sz)) - walk_state.tail_len) + 1, std::memory_order_release);
+					}
+					uint64_t c;
+					for (unsigned spins = 0; (c = carry[i].load(std::memory_order_acquire)) == 0; ++spins) {
+						if (abort_walk.load(std::memory_order_relaxed)) break;
+						if (spins < 2000) __builtin_ia32_pause(); else std::this_thread::yield();   // (the walker before us may have lost its core)
+					}
+					if (c == 0) continue;
+					size_t P = size_t(c - 1);
+					std::vector<uint32_t> &st = block_starts[i];
+					st.clear();
+					const size_t end_i = off[i + 1];
+					while (P + 4 <= end_i) {
+						const uint32_t bs = le32(base + P);
+						if (bs < 32 || P > 0xFFFFFFF0ull) { corrupt = true; abort_walk = true; break; }
+						st.push_back(uint32_t(P));
+						P += 4 + size_t(bs);
+					}
+					carry[i + 1].store(uint64_t(P) + 1, std::memory_order_release);
+				}
+			});
 		} catch (const std::exception &e) { throw std::runtime_error(std::string(e.what()) + ": " + path); }
 		(void)nt;
+		if (corrupt) throw std::runtime_error("Corrupt BAM record: " + path);
+		if (chain && !abort_walk) {
+			size_t total = 0;
+			for (size_t i = 0; i < NB; ++i) total += block_starts[i].size();
+			out.rec_off.resize(total);
+			size_t at = 0;
+			for (size_t i = 0; i < NB; ++i) { if (!block_starts[i].empty()) std::memcpy(out.rec_off.data() + at, block_starts[i].data(), block_starts[i].size() * 4); at += block_starts[i].size(); }
+			finish_walk(out, size_t(carry[NB].load() - 1));
+		} else if (loader_walks && n_batches == 0 && NB > 0) walk_first_batch(out);
+		else walk_state.valid = false;                 // (the caller walks; a later batch cannot know where its records start)
 		load_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); ++n_batches;
 		return out;
+	}
+	// After the starts are known: drop the ones whose record does not end inside the batch (they are the tail), remember the cut.
+	void finish_walk(Buf &out, size_t next_start) {
+		const uint8_t *base = out.p.get();
+		size_t tail_start = next_start;              // the position after the last started record (its length field may be cut: < 4 bytes left)
+		while (!out.rec_off.empty()) {
+			const size_t s = out.rec_off.back();
+			if (s + 4 + size_t(le32(base + s)) <= out.size) break;
+			tail_start = s;
+			out.rec_off.pop_back();
+		}
+		if (tail_start > out.size) {                 // a record that runs past this whole batch: the caller's path handles such giants
+			out.rec_off.clear(); out.walked = false; walk_state.valid = false;
+			return;
+		}
+		out.walked = true; out.tail_start = tail_start; ++n_walked;
+		out.first_start = !out.rec_off.empty() ? size_t(out.rec_off.front()) : tail_start;
+		walk_state.valid = true;
+		walk_state.tail_len = out.size - tail_start;
+		if (walk_state.tail_len >= 4) walk_state.tail_record = le32(base + tail_start);
+		else std::memcpy(walk_state.tail, base + tail_start, walk_state.tail_len);
+	}
+	// Batch 0 starts with the header (magic, text, reference names): parsed here only to find the first record, then one serial walk.
+	void walk_first_batch(Buf &out) {
+		walk_state.valid = false;
+		const uint8_t *base = out.p.get();
+		size_t o = HEADROOM;
+		auto have = [&](size_t n) { return o + n <= out.size; };
+		if (!have(12) || std::memcmp(base + o, "BAM\1", 4) != 0) return;
+		const size_t l_text = le32(base + o + 4);
+		if (!have(12 + l_text)) return;
+		const uint32_t n_ref = le32(base + o + 8 + l_text);
+		o += 12 + l_text;
+		for (uint32_t r = 0; r < n_ref; ++r) {
+			if (!have(4)) return;
+			const size_t l_name = le32(base + o);
+			if (!have(8 + l_name)) return;
+			o += 8 + l_name;
+		}
+		size_t P = o;
+		while (P + 4 <= out.size) {
+			const uint32_t bs = le32(base + P);
+			if (bs < 32 || P > 0xFFFFFFF0ull) throw std::runtime_error("Corrupt BAM record: " + path);
+			out.rec_off.push_back(uint32_t(P));
+			P += 4 + size_t(bs);
+		}
+		finish_walk(out, P);
+		if (out.walked && out.rec_off.empty()) out.first_start = out.tail_start;
 	}
 	Buf take_spare() {
 		if (spare.empty()) return Buf();
@@ -252,7 +384,7 @@ BamReader::BamReader(const std::string &path, unsigned threads) : impl(new Impl(
 
 BamReader::~BamReader() {
 	if (impl->ahead.valid()) { try { impl->ahead.get(); } catch (...) {} }
-	if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] %zu batches, load %.1f ms (block discovery %.1f ms), %u inflate threads\n", impl->n_batches, impl->load_ms, impl->discover_ms, impl->threads);
+	if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] %zu batches (%zu with the record boundaries from the loader), load %.1f ms (block discovery %.1f ms), %u inflate threads\n", impl->n_batches, impl->n_walked, impl->load_ms, impl->discover_ms, impl->threads);
 	if (impl->map) munmap(const_cast<uint8_t *>(impl->map), impl->map_size);
 	delete impl;
 }
@@ -299,7 +431,26 @@ bool BamReader::next(BamRecord &rec) {
 bool BamReader::next_window(const uint8_t *&data, std::vector<uint32_t> &offsets) {
 	Impl &m = *impl;
 	offsets.clear();
-	if (!m.ensure(4)) return false;
+	if (m.cur.walked && m.cur.consumed) {   // the window handed out last time was the whole batch: what is left is the cut record
+		const size_t tail = m.cur.size - m.pos;
+		if (!m.ensure(tail + 1)) { if (tail) throw std::runtime_error("Truncated BAM record: " + m.path); return false; }
+	} else if (!m.ensure(4)) return false;
+	if (m.cur.walked && !m.cur.consumed) {
+		// records of this batch as its loader found them; in front of them the record the last batch was cut in (its head was copied
+		// to just before this batch's first byte, its end is where this batch's first own record starts)
+		data = m.bytes() + m.pos;
+		if (m.pos < m.cur.first_start) {
+			const uint32_t bs = le32(data);
+			if (bs < 32 || m.pos + 4 + size_t(bs) != m.cur.first_start) throw std::runtime_error("Corrupt BAM record: " + m.path);
+			offsets.push_back(0);
+		}
+		offsets.reserve(offsets.size() + m.cur.rec_off.size());
+		for (uint32_t s : m.cur.rec_off) offsets.push_back(uint32_t(s - m.pos));
+		m.pos = m.cur.tail_start;
+		m.cur.consumed = true;
+		if (!offsets.empty()) return true;
+		return next_window(data, offsets);       // (a batch without a single complete record: go on with the next one)
+	}
 	const uint32_t first_size = le32(m.bytes() + m.pos);
 	if (first_size < 32) throw std::runtime_error("Corrupt BAM record: " + m.path);
 	if (!m.ensure(4 + size_t(first_size))) throw std::runtime_error("Truncated BAM record: " + m.path);
@@ -703,3 +854,9 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 
 }  // namespace BamProcessing
 }  // namespace Estimation
+
+// test hooks (tests/test_fast_inflate.py): the block decoder and the CRC against zlib's
+extern "C" int dropest_test_fast_inflate(const uint8_t *in, uint64_t in_len, uint8_t *out, uint64_t out_len) {
+	return fastinflate::inflate_raw(in, size_t(in_len), out, size_t(out_len)) ? 1 : 0;
+}
+extern "C" uint32_t dropest_test_crc32(const uint8_t *p, uint64_t n) { return fastinflate::crc32(p, size_t(n)); }

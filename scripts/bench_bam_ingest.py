@@ -45,6 +45,9 @@ for threads in thread_counts:
                               str(threads), bam], capture_output=True, text=True, env=dict(os.environ, **env))
         if res.returncode:
             raise SystemExit(res.stderr)
+        for line in res.stderr.splitlines():
+            if line.startswith("[bam]"):
+                print(line, file=sys.stderr)
         st = json.loads(res.stdout.strip().splitlines()[-1])
         st.update(threads=threads, path=label, reads=n * copies, ingest_mreads_per_s=round(n * copies / st["ingest_ms"] / 1e3, 3), bam_mb=round(os.path.getsize(bam) / 1e6, 1))
         print(json.dumps(st), flush=True)

@@ -101,6 +101,31 @@ def test_filled_bam_tags(tmp_path):
         assert {k: stats2[k] for k in ("total_reads", "cant_parse", "low_quality", "saved")} == {k: stats[k] for k in ("total_reads", "cant_parse", "low_quality", "saved")}
 
 
+@pytest.mark.parametrize("block", [3, 61, 997, 4093])
+def test_record_boundaries_found_by_the_loader(tmp_path, block):
+    """The reader inflates 512 BGZF blocks per batch and its workers hand the position of the next record from block to block
+    (bam_ingest.cpp: loader_walks).  Files of thousands of tiny blocks put every case in front of it: records and their 4-byte length
+    fields cut by block and by batch boundaries, blocks shorter than a length field, batches without a complete record's start.
+    Same container as when the caller's thread walks the records (DROPEST_BAM_CALLER_WALKS), same as the oracle."""
+    reads = _reads(12_000 if block < 100 else 30_000)
+    refs = [("chr%d" % i, 1_000_000) for i in range(25)]
+    recs, kept = [], []
+    for i, (cb, umi, g, chr_, mark) in enumerate(reads):
+        tags = [("CB", "Z", cb), ("UB", "Z", umi)] + ([("GX", "Z", g)] if g else [])
+        recs.append(bw.record(int(chr_[3:]), i, "read%d" % i, seq="ACGT" * (1 + i % 9), tags=tags))   # records of different lengths
+        kept.append((cb, umi, g, chr_, 1 if g is None else 2))
+    bam = str(tmp_path / "tiny_blocks.bam")
+    bw.write_bam(bam, refs, recs, block=block)
+    assert os.path.getsize(bam) // max(1, (block + 26)) > 1100 or block > 997          # well over two batches of 512 blocks (the largest block size: 3+)
+    got, cells, stats, _ = _run(tmp_path, "filled", [bam], 3, 5, threads=5)
+    want, cols = _oracle(kept, 3, 5)
+    assert stats["saved"] == len(kept) and cells == cols and got == want and len(want) > 200
+    got2, cells2, stats2, _ = _run(tmp_path / "caller", "filled", [bam], 3, 5, threads=5, env={"DROPEST_BAM_CALLER_WALKS": "1"})
+    assert cells2 == cells and got2 == got and stats2["saved"] == stats["saved"]
+    got3, cells3, _, _ = _run(tmp_path / "zlib", "filled", [bam], 3, 5, threads=2, env={"DROPEST_BAM_ZLIB": "1"})
+    assert cells3 == cells and got3 == got
+
+
 def test_read_name_encoding_and_whitelist_merge(tmp_path):
     """Without -f the barcodes come from the read name "id!CB#UMI" (ReadParamsParser.cpp:20-33); with -m + whitelist."""
     s = SynthStream(n_reads=40_000, n_cells=20, n_genes=300, umi_len=8, permille_neighbour=150)
