@@ -110,6 +110,37 @@ struct ReadStore {
 			n += m;
 		}
 	}
+	// The same for several host ranges that follow one another in the stream (dropest_push_reads_gather): they meet in ONE staging buffer
+	// and leave with one set of copies -- a BAM reader's workers each hold a dense run of records, and a push per run cost ~50 us of
+	// pointer queries, event waits and four small copies each.
+	void push_segments(size_t n_seg, const uint64_t *const *h_cb, const uint64_t *const *h_umi, const uint32_t *const *h_gene, const uint32_t *const *h_aux,
+	                   const uint64_t *counts) {
+		size_t total = 0;
+		for (size_t k = 0; k < n_seg; ++k) total += size_t(counts[k]);
+		if (!total) return;
+		if (total > (size_t(4) << 20)) { for (size_t k = 0; k < n_seg; ++k) push(h_cb[k], h_umi[k], h_gene[k], h_aux[k], size_t(counts[k])); return; }
+		reserve(n + total);
+		PinnedBuf<unsigned char> &st = stage[cur];
+		if (!done[cur]) HIP_CHECK(hipEventCreateWithFlags(&done[cur], hipEventDisableTiming));
+		else HIP_CHECK(event_wait(done[cur]));
+		st.ensure(total * 24);
+		unsigned char *b = st.p;
+		size_t at = 0;
+		for (size_t k = 0; k < n_seg; ++k) {
+			const size_t m = size_t(counts[k]);
+			if (!m) continue;
+			std::memcpy(b + at * 8, h_cb[k], m * 8); std::memcpy(b + total * 8 + at * 8, h_umi[k], m * 8);
+			std::memcpy(b + total * 16 + at * 4, h_gene[k], m * 4); std::memcpy(b + total * 20 + at * 4, h_aux[k], m * 4);
+			at += m;
+		}
+		HIP_CHECK(hipMemcpyAsync(cb.p + n, b, total * 8, hipMemcpyHostToDevice, copy));
+		HIP_CHECK(hipMemcpyAsync(umi.p + n, b + total * 8, total * 8, hipMemcpyHostToDevice, copy));
+		HIP_CHECK(hipMemcpyAsync(gene.p + n, b + total * 16, total * 4, hipMemcpyHostToDevice, copy));
+		HIP_CHECK(hipMemcpyAsync(aux.p + n, b + total * 20, total * 4, hipMemcpyHostToDevice, copy));
+		HIP_CHECK(hipEventRecord(done[cur], copy));
+		cur ^= 1;
+		n += total;
+	}
 	void wait() { if (copy) HIP_CHECK(stream_wait(copy)); }
 	void clear() { wait(); n = 0; }
 };

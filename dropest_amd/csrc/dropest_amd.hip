@@ -1677,6 +1677,22 @@ dropest_status dropest_push_reads(dropest_ctx *ctx, const uint64_t *cb, const ui
 	});
 }
 
+dropest_status dropest_push_reads_gather(dropest_ctx *ctx, uint64_t n_segments, const uint64_t *const *cb, const uint64_t *const *umi,
+                                         const uint32_t *const *gene, const uint32_t *const *aux, const uint64_t *counts) {
+	return guarded([&] {
+		if (n_segments && (!cb || !umi || !gene || !aux || !counts)) throw InvalidError("null segment array");
+		uint64_t n = 0;
+		for (uint64_t k = 0; k < n_segments; ++k) { n += counts[k]; if (counts[k] && (!cb[k] || !umi[k] || !gene[k] || !aux[k])) throw InvalidError("null read array"); }
+		push_common(ctx, n);
+		if (n == 0) return;
+		if (ctx->store_chunk >= 0 && size_t(ctx->store_chunk) + 1 != ctx->chunks.size()) throw InvalidError("dropest_push_reads_gather after an adopted device chunk: push the segments one by one");
+		if (ctx->store_chunk < 0) { ctx->store_chunk = long(ctx->chunks.size()); ctx->chunks.emplace_back(); }
+		ctx->store.push_segments(size_t(n_segments), cb, umi, gene, aux, counts);
+		ctx->chunks[size_t(ctx->store_chunk)].n = ctx->store.n;
+		ctx->n_reads += n;
+	});
+}
+
 dropest_status dropest_reserve_reads(dropest_ctx *ctx, uint64_t n_total) {
 	return guarded([&] {
 		if (!ctx) throw InvalidError("null context");

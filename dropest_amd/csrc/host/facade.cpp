@@ -286,6 +286,25 @@ uint32_t CellsDataContainer::intern_chromosome_of_ref(int32_t ref_id) {
 	return uint32_t(slot);
 }
 
+void CellsDataContainer::add_records_packed(const std::vector<PackedRun> &runs) {
+	if (_is_initialized) throw std::runtime_error("Container is already initialized");
+	if (!bulk_ingest_possible()) throw std::runtime_error("add_records_packed: the container is sharded or carries UMI qualities (use add_record)");
+	size_t n = 0;
+	for (const PackedRun &r : runs) n += r.n;
+	if (!n) return;
+	_preview_valid = false;
+	flush();                                   // whatever add_record collected comes first
+	if (_umi_quality_length == size_t(-1))     // the first gene-bearing read fixes the quality length: 0 (no quality strings)
+		for (const PackedRun &r : runs) { for (size_t i = 0; i < r.n; ++i) if (r.gene[i] != DROPEST_NO_GENE) { _umi_quality_length = 0; _qual_pending = 0; break; } if (_umi_quality_length == 0) break; }
+	if (_umi_quality_length == size_t(-1)) _qual_pending += n;
+	_qual_reads += n;
+	if (!_qual_lens.empty()) _qual_lens.insert(_qual_lens.end(), n, uint8_t(0));
+	send_side_strings(_ctx);
+	std::vector<const uint64_t *> pc, pu; std::vector<const uint32_t *> pg, pa; std::vector<uint64_t> cnt;
+	for (const PackedRun &r : runs) { pc.push_back(r.cb); pu.push_back(r.umi); pg.push_back(r.gene); pa.push_back(r.aux); cnt.push_back(r.n); }
+	check(dropest_push_reads_gather(_ctx, runs.size(), pc.data(), pu.data(), pg.data(), pa.data(), cnt.data()));
+}
+
 void CellsDataContainer::add_records_packed(const uint64_t *cb, const uint64_t *umi, const uint32_t *gene, const uint32_t *aux, size_t n) {
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
 	if (!bulk_ingest_possible()) throw std::runtime_error("add_records_packed: the container is sharded or carries UMI qualities (use add_record)");

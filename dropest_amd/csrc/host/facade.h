@@ -400,6 +400,9 @@ public:
 	// n records, every id resolved (gene: dictionary index or DROPEST_NO_GENE; aux = chromosome index | mark << 16); the reads
 	// carry no UMI qualities (quality length 0, like add_record of a read with an empty quality string)
 	void add_records_packed(const uint64_t *cb, const uint64_t *umi, const uint32_t *gene, const uint32_t *aux, size_t n);
+	// ... several such runs that follow one another in the stream, handed over in one piece (dropest_push_reads_gather)
+	struct PackedRun { const uint64_t *cb, *umi; const uint32_t *gene, *aux; size_t n; };
+	void add_records_packed(const std::vector<PackedRun> &runs);
 	static bool pack_code(std::string_view s, uint64_t &code);
 	static uint64_t hash_name(std::string_view s);
 	void set_initialized();

@@ -122,6 +122,11 @@ dropest_status dropest_set_side_strings(dropest_ctx *ctx, const char *const *str
 dropest_status dropest_push_reads(dropest_ctx *ctx, const uint64_t *cb, const uint64_t *umi,
                                   const uint32_t *gene, const uint32_t *aux, uint64_t n);
 /* Optional: room for n_total pushed reads up front (otherwise the device arrays grow geometrically while reads arrive). */
+/* Several host ranges that follow one another in the stream, in one call (same meaning as dropest_push_reads on each of them in turn):
+ * cb[k] .. aux[k] hold counts[k] reads.  A reader whose worker threads each produce a dense run of records hands them over without
+ * concatenating them first. */
+dropest_status dropest_push_reads_gather(dropest_ctx *ctx, uint64_t n_segments, const uint64_t *const *cb, const uint64_t *const *umi,
+                                         const uint32_t *const *gene, const uint32_t *const *aux, const uint64_t *counts);
 dropest_status dropest_reserve_reads(dropest_ctx *ctx, uint64_t n_total);
 /* Same, for arrays already resident in this GPU's HBM (device pointers).  With adopt != 0 the context
  * uses the caller's buffers in place (no copy); they must stay alive and unmodified until destroy. */
