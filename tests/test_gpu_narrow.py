@@ -201,3 +201,21 @@ def test_announced_cm_raw_prefetch_changes_nothing(form, with_n):
             assert all(np.array_equal(a, b) for a, b in zip(got, want[filt])), (form, with_n, filt, rounds)
         c.reset_results(); c.set_initialized(); c.merge_and_filter()
     c.close(); ref.close()
+
+
+def test_push_reads_gather_equals_one_push():
+    """dropest_push_reads_gather: runs that follow one another in the stream, handed over in one call, are the stream."""
+    s = SynthStream(n_reads=400_000, n_cells=80, n_genes=3000)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    cuts = [0, 1, 1, 70_001, 200_000, 399_999, 400_000]                     # (an empty run, runs of one read)
+    a = capi.Context(min_genes_before_merge=10, min_genes_after_merge=30)
+    a.push_reads(cb, umi, gene, aux)
+    b = capi.Context(min_genes_before_merge=10, min_genes_after_merge=30)
+    b.push_reads_gather([(cb[i:j], umi[i:j], gene[i:j], aux[i:j]) for i, j in zip(cuts[:-1], cuts[1:])][:3])
+    b.push_reads_gather([(cb[i:j], umi[i:j], gene[i:j], aux[i:j]) for i, j in zip(cuts[:-1], cuts[1:])][3:])
+    for c in (a, b):
+        c.set_initialized(); c.merge_and_filter()
+    for filt in (True, False):
+        assert all(np.array_equal(x, y) for x, y in zip(a.count_matrix_csc(filtered=filt), b.count_matrix_csc(filtered=filt)))
+    assert np.array_equal(a.filtered_cells(), b.filtered_cells())
+    a.close(); b.close()
