@@ -192,10 +192,34 @@ def push_rates(stream, local_rank, n_push, cfg_kw):
                "push_plus_pass_Mreads_per_s": round(n_push / best_all / 1e6, 1),
                "note": "pinned host arrays -> dropest_push_reads (8 Mi-read batches) -> set_initialized -> merge_and_filter -> both matrices; best of 3"}
         out.update(facade_add_record_rate())
+        out.update(bam_ingest_rate())
         return out
     finally:
         for a in host:
             L.dropest_host_unregister(local_rank, a.ctypes.data)
+
+
+def bam_ingest_rate(n=250_000, copies=32, threads=16):
+    """BAM file -> container through the native reader (scripts/bench_bam_ingest.py: BGZF inflate, record boundaries, tag parsing, 2-bit
+    packing, push): n synthetic 10x-style records written `copies` times into one file.  {} when the tool is not built or
+    DROPEST_BENCH_NO_BAM is set."""
+    import subprocess
+    if os.environ.get("DROPEST_BENCH_NO_BAM") or not os.path.exists(os.path.join(ROOT, "tests", "cpp", "bam_to_counts")):
+        return {}
+    try:
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_bam_ingest.py"), str(n)], capture_output=True, text=True, timeout=240,
+                             env=dict(os.environ, COPIES=str(copies), THREADS=str(threads)))
+        best = None
+        for line in res.stdout.splitlines():
+            d = json.loads(line)
+            if d.get("path") == "bulk":
+                best = d
+        if not best:
+            return {}
+        return {"bam_ingest_Mreads_per_s": best["ingest_mreads_per_s"], "bam_ingest_reads": best["reads"], "bam_ingest_threads": threads,
+                "bam_ingest_file_MB": best["bam_mb"], "bam_ingest_note": "BAM -> container, native reader, %d host threads; the record-by-record path and other thread counts: scripts/bench_bam_ingest.py" % threads}
+    except Exception:   # noqa: BLE001 (a missing tool or a timeout must not cost the bench line)
+        return {}
 
 
 def facade_add_record_rate(n=4_000_000):
