@@ -295,8 +295,7 @@ void dropest_ctx::build_cb_table() {
 			const int want = int(size_t(CB_HOT_LDS) * 16);
 			bool granted = true;
 			for (const void *k : {reinterpret_cast<const void *>(cb_insert_hot_kernel<true, false>), reinterpret_cast<const void *>(cb_insert_hot_kernel<false, false>),
-			                      reinterpret_cast<const void *>(cb_insert_hot_kernel<true>), reinterpret_cast<const void *>(cb_insert_hot_kernel<false>),
-			                      reinterpret_cast<const void *>(cb_insert_hot_kernel<true, false, 0, true>)})
+			                      reinterpret_cast<const void *>(cb_insert_hot_kernel<true>), reinterpret_cast<const void *>(cb_insert_hot_kernel<false>)})
 				if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, want) != hipSuccess) { (void)hipGetLastError(); granted = false; }
 			if (!granted) n_hot = 0;
 		}
@@ -314,9 +313,7 @@ void dropest_ctx::build_cb_table() {
 					HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
 					hipLaunchKernelGGL(kernel, dim3(hb), dim3(1024), lds, stream, d_cb, d_umi, d_gene, d_aux, n, table, hot, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
 				};
-				static const bool pipe = getenv("DROPEST_CB_PIPE") != nullptr;
-				if (lazy_stats && vec && pipe) go(cb_insert_hot_kernel<true, false, 0, true>);
-				else if (lazy_stats) { if (vec) go(cb_insert_hot_kernel<true, false>); else go(cb_insert_hot_kernel<false, false>); }
+				if (lazy_stats) { if (vec) go(cb_insert_hot_kernel<true, false>); else go(cb_insert_hot_kernel<false, false>); }
 				else if (vec) go(cb_insert_hot_kernel<true>); else go(cb_insert_hot_kernel<false>);
 			});
 #ifdef DROPEST_CBI_PROBE

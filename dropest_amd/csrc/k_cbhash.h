@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void cb_hot_preinsert_kernel(const unsigned lo
 struct CbHot { const unsigned long long *key; const uint32_t *slot; uint32_t n; };
 // EXP (timing probes, results not usable; launched only by builds with -DDROPEST_CBI_PROBE, see dropest_ctx::build_cb_table):
 // 1 no table probe, 2 no LDS look-up, 4 no atomics
-template <bool VEC, bool STATS = true, int EXP = 0, bool PIPE = false>
+template <bool VEC, bool STATS = true, int EXP = 0>
 __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long long *__restrict__ cb,
                                                              const unsigned long long *__restrict__ umi,
                                                              const uint32_t *__restrict__ gene,
@@ -412,62 +412,19 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 			for (int j = 0; j < ILP; ++j) kk[j] = r0 + j < n ? cb[r0 + j] : 0ull;
 		}
 	};
-	// first half of a tile's work: hash, LDS look-up, and the table probes of the barcodes LDS does not know put in flight
-	auto stage_a = [&](uint64_t r0, const unsigned long long (&k)[ILP], uint64_t (&h)[ILP], uint32_t (&hit)[ILP], uint4 (&v)[ILP]) {
-#pragma unroll
-		for (int j = 0; j < ILP; ++j) {   // LDS look-ups of the four barcodes
-			h[j] = mix64(k[j]);
-			hit[j] = 0xFFFFFFFFu;
-			if (r0 + j >= n || (EXP & 2)) continue;
-			uint32_t i = uint32_t(h[j] >> 40) & (CB_HOT_LDS - 1);
-			for (;;) {
-				const unsigned long long e = lk[i];
-				if (e == k[j]) { hit[j] = i; break; }
-				if (e == 0ull) break;
-				i = (i + 1) & (CB_HOT_LDS - 1);
-			}
-		}
-#pragma unroll
-		for (int j = 0; j < ILP; ++j) {   // the others probe the table: independent 16-byte loads in flight together
-			h[j] &= t.mask;
-			v[j] = make_uint4(0u, 0u, 0u, 0u);
-			if (!(EXP & 1) && r0 + j < n && hit[j] == 0xFFFFFFFFu) v[j] = *reinterpret_cast<const uint4 *>(&t.slots[h[j]]);
-		}
-	};
 	unsigned long long k_next[ILP] = {0ull, 0ull, 0ull, 0ull};
-	// PIPE: the probes of tile i + 1 are in flight while tile i is resolved (two tiles of state in registers).  The ablation of this
-	// kernel (profiles/NOTES_r03.md) put most of its time into waiting for those probes with 16 waves per CU to hide them.
-	unsigned long long pk[ILP] = {0ull, 0ull, 0ull, 0ull};
-	uint64_t ph[ILP] = {0, 0, 0, 0};
-	uint32_t phit[ILP] = {0, 0, 0, 0};
-	uint4 pv[ILP];
 	{
 		const uint64_t first = (uint64_t(blockIdx.x) * THREADS + threadIdx.x) * ILP;
-		if (PIPE) {
-			if (first < n) { load_cb(first, pk); stage_a(first, pk, ph, phit, pv); }
-			if (first + stride < n) load_cb(first + stride, k_next);
-		} else if (first < n) load_cb(first, k_next);
+		if (first < n) load_cb(first, k_next);
 	}
 	for (uint64_t r0 = (uint64_t(blockIdx.x) * THREADS + threadIdx.x) * ILP; r0 < n; r0 += stride) {
 		unsigned long long k[ILP], u[ILP];
 		uint64_t h[ILP];
 		uint32_t g[ILP], a[ILP], sl[ILP], hit[ILP];
-		uint4 v[ILP];
 		const bool full = r0 + ILP <= n;
-		if (PIPE) {
 #pragma unroll
-			for (int j = 0; j < ILP; ++j) { k[j] = pk[j]; h[j] = ph[j]; hit[j] = phit[j]; v[j] = pv[j]; }
-			if (r0 + stride < n) {
-#pragma unroll
-				for (int j = 0; j < ILP; ++j) pk[j] = k_next[j];
-				if (r0 + 2 * stride < n) load_cb(r0 + 2 * stride, k_next);
-				stage_a(r0 + stride, pk, ph, phit, pv);
-			}
-		} else {
-#pragma unroll
-			for (int j = 0; j < ILP; ++j) k[j] = k_next[j];
-			if (r0 + stride < n) load_cb(r0 + stride, k_next);
-		}
+		for (int j = 0; j < ILP; ++j) k[j] = k_next[j];
+		if (r0 + stride < n) load_cb(r0 + stride, k_next);
 		if (VEC && full) {
 			if (STATS) {
 				const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + r0), u23 = *reinterpret_cast<const ulonglong2 *>(umi + r0 + 2);
@@ -483,7 +440,26 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 				if (STATS) { u[j] = r < n ? umi[r] : 0ull; g[j] = r < n ? gene[r] : NO_GENE; a[j] = r < n ? aux[r] : 0u; }
 			}
 		}
-		if (!PIPE) stage_a(r0, k, h, hit, v);
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) {   // LDS look-ups of the four barcodes
+			h[j] = mix64(k[j]);
+			hit[j] = 0xFFFFFFFFu;
+			if (r0 + j >= n || (EXP & 2)) continue;
+			uint32_t i = uint32_t(h[j] >> 40) & (CB_HOT_LDS - 1);
+			for (;;) {
+				const unsigned long long e = lk[i];
+				if (e == k[j]) { hit[j] = i; break; }
+				if (e == 0ull) break;
+				i = (i + 1) & (CB_HOT_LDS - 1);
+			}
+		}
+		uint4 v[ILP];
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) {   // the others probe the table: independent 16-byte loads in flight together
+			h[j] &= t.mask;
+			v[j] = make_uint4(0u, 0u, 0u, 0u);
+			if (!(EXP & 1) && r0 + j < n && hit[j] == 0xFFFFFFFFu) v[j] = *reinterpret_cast<const uint4 *>(&t.slots[h[j]]);
+		}
 		uint32_t pending = 0, hinted = 0;
 		unsigned long long seen[ILP];
 #pragma unroll
