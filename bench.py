@@ -350,6 +350,10 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
                                       "scripts/refresh_profiles.sh (builder-run, not counters of this run)",
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"]}
+            # the candidates next to it (same events, same region): at C2 three kernels of about 1 ms each take turns at the top from box to box
+            roof["candidates"] = {k: {"ms_per_step": round(v["ms"] / max(1, steps), 4),
+                                      "frac": round(v["bytes"] / v["launches"] / (v["ms"] / v["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                  for k, v in sorted(cands.items(), key=lambda kv: -kv[1]["ms"])[:6] if v["ms"] > 0}
         # whole-pipeline roofline: compulsory traffic = every packed record read once, every output item
         # written once: 24 B/read + 24 B/molecule + 12 B/matrix entry + 40 B/cell, over the sum of the kernel times
         cm_nnz, raw_nnz = nnz_of(out[0]), nnz_of(out[1])
