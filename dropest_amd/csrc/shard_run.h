@@ -380,6 +380,14 @@ __global__ __launch_bounds__(256) void min_rows_kernel(const unsigned long long 
 		out[i] = m;
 	}
 }
+// rows of `len` bytes gathered by index: out[i] = in[idx[i]] (the quality strings follow the stable partition of their reads)
+__global__ __launch_bounds__(256) void gather_byte_rows_kernel(const uint8_t *__restrict__ in, const uint32_t *__restrict__ idx, uint32_t n, uint32_t len,
+                                                               uint8_t *__restrict__ out) {
+	for (uint64_t k = uint64_t(blockIdx.x) * 256 + threadIdx.x; k < uint64_t(n) * len; k += uint64_t(gridDim.x) * 256) {
+		const uint32_t i = uint32_t(k / len), b = uint32_t(k % len);
+		out[k] = in[uint64_t(idx[i]) * len + b];
+	}
+}
 // -M across shards: the UMI histograms of the shards added up
 __global__ __launch_bounds__(256) void sum_rows_kernel(const uint32_t *__restrict__ all, uint32_t rows, uint64_t n, uint32_t *__restrict__ out) {
 	for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
@@ -422,6 +430,11 @@ struct dropest_shard {
 	const u32 *r_gene = nullptr, *r_aux = nullptr;
 	uint64_t n_res = 0, first_ordinal = 0;
 	dropest::ReadStore pushed;       // reads pushed from host memory (dropest_shard_push_reads)
+	// UMI quality strings of the resident reads (dropest_shard_set_umi_qualities): they travel with their reads in the exchange
+	dropest::DevBuf<uint8_t> r_qual, p_qual, x_qual;
+	u32 r_qlen = 0;
+	uint64_t r_qual_reads = 0;
+	bool r_have_qual = false;
 	// partition / exchange buffers
 	dropest::DevBuf<u64> p_cb, p_umi, x_cb, x_umi;
 	dropest::DevBuf<u32> p_gene, p_aux, p_idx, x_gene, x_aux, x_idx;
@@ -653,6 +666,21 @@ void dropest_shard::partition_and_exchange() {
 		for (int p = 0; p < world; ++p) if (p != rank) out += send_cnt[size_t(p)];
 		st.bytes += double(out) * rec_bytes;   // bytes this shard put on the links (self block excluded)
 		phases["exchange_record_bytes"].bytes = double(rec_bytes);
+		if (r_have_qual && r_qlen) {   // the quality strings: gathered into the order of the partition, exchanged with the same counts
+			p_qual.ensure(std::max<size_t>(size_t(n) * r_qlen, 1)); x_qual.ensure(std::max<size_t>(size_t(n_recv) * r_qlen, 1));
+			if (n) {
+				hipLaunchKernelGGL(gather_byte_rows_kernel, dim3(u32(std::min<uint64_t>((uint64_t(n) * r_qlen + 255) / 256, 16384))), dim3(256), 0, c.stream,
+				                   r_qual.p, p_idx.p, n, r_qlen, p_qual.p);
+				HIP_CHECK(hipGetLastError());
+			}
+			const void *snd[1] = {p_qual.p};
+			void *rcv[1] = {x_qual.p};
+			const size_t elem[1] = {r_qlen};
+			tr->exchange(1, snd, rcv, elem, send_cnt.data(), recv_cnt.data(), c.stream);
+			uint64_t out_q = 0;
+			for (int p = 0; p < world; ++p) if (p != rank) out_q += send_cnt[size_t(p)];
+			st.bytes += double(out_q) * r_qlen;
+		}
 		if (packed && n_recv) {
 			Phase ph2(this, "unpack");
 			hipLaunchKernelGGL(exchange_unpack_kernel, dim3(u32(std::min<uint64_t>((n_recv + 255) / 256, 8192))), dim3(256), 0, c.stream, x_w0.p, x_w1.p, u32(n_recv), pack,
@@ -1066,6 +1094,16 @@ void dropest_shard::step() {
 			reach = first_ord[size_t(p)] + all[size_t(p) * 2 + 1];
 		}
 	}
+	{   // UMI qualities: all shards or none, one length, one string per resident read
+		uint64_t mine[2] = {r_have_qual ? 1ull : 0ull, r_qlen};
+		std::vector<uint64_t> all(size_t(world) * 2);
+		tr->gather_host(mine, sizeof(mine), all.data());
+		for (int p = 0; p < world; ++p)
+			if (all[size_t(p) * 2] != mine[0] || all[size_t(p) * 2 + 1] != mine[1])
+				throw InvalidError("UMI qualities must be given to every shard of the run, with one length (dropest_shard_set_umi_qualities)");
+		if (r_have_qual && r_qual_reads != n_res)
+			throw InvalidError("UMI qualities were given for " + std::to_string(r_qual_reads) + " reads, the shard holds " + std::to_string(n_res));
+	}
 	// forget the previous pass
 	c.free_results(); c.chunks.clear(); c.n_reads = 0; c.store.clear(); c.store_chunk = -1;
 	c.d_cb = c.d_umi = nullptr; c.d_gene = c.d_aux = nullptr;
@@ -1078,6 +1116,16 @@ void dropest_shard::step() {
 		ch.p_cb = r_cb; ch.p_umi = r_umi; ch.p_gene = r_gene; ch.p_aux = r_aux; ch.n = n_res;
 	}
 	if (ch.n) { c.n_reads = ch.n; c.chunks.push_back(std::move(ch)); }
+	// UMI qualities: one string per read of this shard AFTER the exchange, in the order of its reads
+	c.have_qual = false; c.qual_var = false; c.qual_len = 0; c.qual_reads = 0;
+	if (r_have_qual) {
+		c.have_qual = true; c.qual_len = r_qlen; c.qual_reads = c.n_reads;
+		const size_t bytes = size_t(c.n_reads) * r_qlen;
+		if (bytes) {
+			c.umi_qual.ensure(bytes);
+			HIP_CHECK(hipMemcpyAsync(c.umi_qual.p, exchanged ? x_qual.p : r_qual.p, bytes, hipMemcpyDeviceToDevice, c.stream));
+		}
+	}
 	// (one shard has nobody to agree with: its pass runs in one piece and may plan the key layout from a sample like any context)
 	if (world > 1) { Phase ph(this, "ingest"); c.run_ingest(); agree_on_key_fields(); }
 	install_umi_hooks();
@@ -1086,7 +1134,8 @@ void dropest_shard::step() {
 	if ((c.cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES || c.cfg.merge_kind == DROPEST_MERGE_POISSON_REAL) && world > 1) { Phase ph(this, "cb_merge"); cb_merge(); }
 	else if (c.cfg.merge_kind != DROPEST_MERGE_NONE && world > 1)
 		throw UnsupportedError("sharded runs support the merges with a barcode whitelist (-m, -M with barcodes) only; run the other merge strategies on one GPU");
-	if (c.have_qual && world > 1) throw UnsupportedError("UMI qualities are not supported in sharded runs");
+	if (c.have_qual && world > 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE)
+		throw UnsupportedError("UMI qualities with a barcode merge are not supported in sharded runs");
 	{ Phase ph(this, "finalize"); c.run_merge_and_filter(); }
 	merged_pending = world == 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE;   // one shard: the context's own pairs, named when asked for
 	build_global_table();
@@ -1307,6 +1356,21 @@ dropest_status dropest_shard_push_reads(dropest_shard *s, const uint64_t *cb, co
 		if (s->pushed.n == 0) s->first_ordinal = first_ordinal;
 		else if (first_ordinal != s->first_ordinal + s->pushed.n) throw InvalidError("the batches pushed to a shard must continue its ordinal range without a gap");
 		s->pushed.push(cb, umi, gene, aux, size_t(n));
+	});
+}
+
+dropest_status dropest_shard_set_umi_qualities(dropest_shard *s, const uint8_t *qualities, uint32_t quality_length, uint64_t n_reads) {
+	return guarded([&] {
+		if (!s) throw InvalidError("null shard");
+		if (quality_length > 255) throw UnsupportedError("UMI quality strings longer than 255");
+		if (n_reads && quality_length && !qualities) throw InvalidError("null quality array");
+		HIP_CHECK(hipSetDevice(s->ctx->cfg.device));
+		s->r_have_qual = true; s->r_qlen = quality_length; s->r_qual_reads = n_reads;
+		const size_t bytes = size_t(n_reads) * quality_length;
+		if (bytes) {
+			s->r_qual.ensure(bytes);
+			HIP_CHECK(hipMemcpy(s->r_qual.p, qualities, bytes, hipMemcpyHostToDevice));
+		}
 	});
 }
 

@@ -64,6 +64,12 @@ class Shard:
     def set_side_strings(self, strings):
         self.ctx.set_side_strings(strings)
 
+    def set_umi_qualities(self, qual):
+        """qual: uint8 [n_reads of this shard, quality_length], in the order of its reads."""
+        qual = np.ascontiguousarray(qual, np.uint8)
+        assert qual.ndim == 2
+        self._chk(self.L.dropest_shard_set_umi_qualities(self.h, qual.ctypes.data, qual.shape[1], qual.shape[0]))
+
     def step(self):
         self._chk(self.L.dropest_shard_step(self.h))
 

@@ -504,6 +504,11 @@ dropest_status dropest_shard_set_reads_device(dropest_shard *shard, const uint64
  * that does not know the stream's length fills shard 0 up to a quota, then shard 1, ...: the exchange spreads the work). */
 dropest_status dropest_shard_push_reads(dropest_shard *shard, const uint64_t *cb, const uint64_t *umi, const uint32_t *gene,
                                         const uint32_t *aux, uint64_t n, uint64_t first_ordinal);
+/* UMI quality strings of the shard's resident reads (see dropest_set_umi_qualities): quality_length bytes per read, in the order the reads
+ * were pushed / set; call on EVERY shard of the run (a shard without reads: n_reads = 0), same length everywhere, before
+ * dropest_shard_step.  The strings travel with their reads in the exchange; the sums are accumulated where the cell lives and follow
+ * the UMI merges there.  Not yet with a barcode merge across shards. */
+dropest_status dropest_shard_set_umi_qualities(dropest_shard *shard, const uint8_t *qualities, uint32_t quality_length, uint64_t n_reads);
 dropest_status dropest_shard_step(dropest_shard *shard);
 dropest_status dropest_shard_group_step(dropest_shard *const *shards, int32_t n);   /* one host thread per shard */
 dropest_status dropest_shard_matrix(dropest_shard *shard, int filtered, uint64_t *ncols, uint64_t *nnz, const uint64_t **colptr,

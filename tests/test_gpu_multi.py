@@ -384,3 +384,61 @@ def test_partition_by_owner_is_stable_and_complete(n_parts):
     for p in (idx, scratch):
         L.dropest_dev_free(0, p)
     src.free(); dst.free()
+
+
+def _quality_table(ctx, side=()):
+    """{(barcode, gene, UMI): (reads, quality sums)} of every real cell of a context."""
+    rows = ctx.cell_rows()
+    out = {}
+    for cell in np.flatnonzero(rows["is_real"].astype(bool) & ~rows["is_merged"].astype(bool)):
+        g, u, r, m = ctx.cell_molecules(int(cell))
+        q = ctx.cell_molecule_qualities(int(cell), len(g))
+        for j in range(len(g)):
+            out[(int(rows["barcode"][cell]), int(g[j]), capi.unpack_code(u[j], side))] = (int(r[j]), tuple(int(x) for x in q[j]))
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("variant", ["plain", "n_umis", "directional"])
+def test_umi_qualities_travel_with_the_reads(world, variant):
+    """UMI quality strings in a sharded run: every shard is given the strings of ITS reads, they follow the reads through the exchange,
+    the sums are accumulated where the cell lives and follow the UMI merges there -- same sums per molecule as one context."""
+    import ctypes
+    s = SynthStream(n_reads=200_000 * SCALE, n_cells=40 * SCALE, n_genes=800, umi_len=8)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    side = ()
+    if variant != "plain":
+        umi, side = inject_n(umi, gene, 5e-3, 11, 8)
+    qual = np.random.default_rng(77).integers(33, 75, size=(len(cb), 8), dtype=np.uint8)
+    kw = cfg_kwargs({"min_before": 10, "min_after": 20})
+    if variant == "directional":
+        kw["umi_merge_kind"] = capi.UMI_MERGE_DIRECTIONAL
+    libc = ctypes.CDLL("libc.so.6")
+    c = capi.Context(**kw)
+    if side:
+        c.set_side_strings(side)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_umi_qualities(qual)
+    c.set_initialized()
+    libc.srand(1)
+    c.merge_and_filter()
+    want = _quality_table(c, side)
+    n = len(cb)
+    bounds = [n * i // world for i in range(world + 1)]
+    g = ShardGroup([0] * world, **kw)
+    for i, sh in enumerate(g.shards):
+        if side:
+            sh.set_side_strings(side)
+        sh.set_reads(capi.DeviceArrays.from_host(0, cb[bounds[i]:bounds[i + 1]], umi[bounds[i]:bounds[i + 1]], gene[bounds[i]:bounds[i + 1]], aux[bounds[i]:bounds[i + 1]]), bounds[i])
+        sh.set_umi_qualities(qual[bounds[i]:bounds[i + 1]])
+    for _ in range(2):
+        libc.srand(1)
+        g.step()
+    got = {}
+    for sh in g.shards:
+        got.update(_quality_table(sh.ctx, side))
+    assert len(want) > 5000 and len(got) == len(want)
+    bad = [k for k in want if got.get(k) != want[k]]
+    assert not bad, (len(bad), bad[0], got.get(bad[0]), want[bad[0]])
+    check({"cm": [x.copy() for x in g.shards[0].matrix(True)], "raw": [x.copy() for x in g.shards[0].matrix(False)], "merged": g.shards[0].merged_barcodes()}, c)
+    g.close()
