@@ -571,6 +571,9 @@ struct dropest_ctx {
 	void shard_merge_intersect(uint64_t n_pairs, const uint32_t *cand_local, const uint64_t *base_begin, const uint64_t *base_end,
 	                           const uint64_t *d_base_low, uint32_t *inter);
 	void shard_merge_decide(const uint32_t *inter, int64_t *target_g);
+	void shard_merge_quality_import(uint64_t n_local, const uint32_t *local_rank, const uint32_t *d_import_rank, const uint32_t *d_import_q);
+	const u32 *reagg_import_prio = nullptr;     // (device) merge-order places of the rows a sharded merge appended, for the next re-aggregation
+	u32 reagg_import_from = 0, reagg_import_n = 0;
 	void shard_merge_finish(uint64_t n_local, const uint32_t *local_id, const uint8_t *excluded, const uint8_t *merged_away,
 	                        const int32_t *total_reads, const int32_t *total_umis, uint64_t n_moves, const uint32_t *move_src,
 	                        const uint32_t *move_tgt, uint64_t n_import, const uint32_t *d_cell, const uint64_t *d_low,

@@ -411,6 +411,8 @@ void CellsDataContainer::flush() {
 		if (_side.size() != _side_sent) { for (dropest_shard *s : _shards) check(dropest_set_side_strings(dropest_shard_ctx(s), ptrs.data(), ptrs.size())); _side_sent = _side.size(); }
 		const size_t shard = std::min<size_t>(_shards.size() - 1, size_t(_batches / std::max<size_t>(1, shard_quota / BATCH)));
 		check(dropest_shard_push_reads(_shards[shard], _cb.data(), _umi.data(), _gene.data(), _aux.data(), _cb.size(), _batches * BATCH));
+		if (_shard_reads.size() != _shards.size()) _shard_reads.assign(_shards.size(), 0);
+		_shard_reads[shard] += _cb.size();
 		++_batches;
 		_cb.clear(); _umi.clear(); _gene.clear(); _aux.clear();
 		return;
@@ -424,7 +426,19 @@ void CellsDataContainer::set_initialized() {   // CellsDataContainer.cpp:163-175
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
 	flush();
 	if (sharded()) {
-		if (_umi_quality_length != size_t(-1) && _umi_quality_length > 0) single_only("UMI qualities");
+		if (_umi_quality_length != size_t(-1) && _umi_quality_length > 0) {
+			// every shard gets the strings of ITS range of the stream (they travel with the reads in the exchange)
+			if (!_qual_lens.empty()) single_only("UMI quality strings of several lengths");
+			const size_t ql = _umi_quality_length;
+			if (_shard_reads.size() != _shards.size()) _shard_reads.assign(_shards.size(), 0);
+			size_t at = 0;
+			for (size_t k = 0; k < _shards.size(); ++k) {
+				if ((at + _shard_reads[k]) * ql > _qual.size()) throw std::runtime_error("internal: fewer UMI quality rows than reads");
+				check(dropest_shard_set_umi_qualities(_shards[k], _qual.data() + at * ql, uint32_t(ql), _shard_reads[k]));
+				at += _shard_reads[k];
+			}
+			std::vector<uint8_t>().swap(_qual);
+		}
 		_is_initialized = true;   // the sharded pass (partition, exchange, pipeline, merges) runs as one piece in merge_and_filter
 		return;
 	}

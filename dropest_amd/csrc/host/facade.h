@@ -299,6 +299,7 @@ private:
 	std::vector<uint8_t> _qual;               // qualities of every read so far, _umi_quality_length bytes each
 	size_t _qual_pending = 0;                 // gene-less reads seen before the length was known
 	size_t _qual_reads = 0;                   // reads that went through append_quality
+	std::vector<size_t> _shard_reads;         // sharded container: reads dealt to every shard so far (ranges of the stream, in shard order)
 	std::vector<uint8_t> _qual_lens;          // per read, once two gene-bearing reads differed in length (UMI.cpp:26-28 is a per-molecule check)
 	void note_quality_length(size_t ql);
 	void append_quality(const char *q, size_t len, bool has_gene);

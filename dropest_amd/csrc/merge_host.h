@@ -709,6 +709,9 @@ void dropest_ctx::reaggregate_after_merge() {
 		hipLaunchKernelGGL(prio_from_cell_kernel, dim3(div_up(n_mol, 256)), dim3(256), 0, stream, mol_key.p, n_mol,
 		                   layout.gene_bits + layout.umi_bits, d_rank.p, reagg_prio_buf.p);
 		HIP_CHECK(hipGetLastError());
+		if (reagg_import_prio && reagg_import_n && reagg_import_from + reagg_import_n <= n_mol)   // rows a sharded merge brought in: keyed to their TARGET already
+			HIP_CHECK(hipMemcpyAsync(reagg_prio_buf.p + reagg_import_from, reagg_import_prio, size_t(reagg_import_n) * 4, hipMemcpyDeviceToDevice, stream));
+		reagg_import_prio = nullptr; reagg_import_n = 0;
 		HIP_CHECK(stream_wait(stream));
 		reagg_prio = reagg_prio_buf.p;
 	}

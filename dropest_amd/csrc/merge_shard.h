@@ -60,6 +60,21 @@ __global__ __launch_bounds__(256) void export_rows_kernel(ExportArgs a) {
 	}
 }
 
+// the quality sums rows (quality.h: qstride words, the molecule's length last) of the exported molecule rows
+__global__ __launch_bounds__(256) void export_quality_kernel(const uint32_t *__restrict__ begin, const uint32_t *__restrict__ out_off, const uint32_t *__restrict__ mol_qrow,
+                                                             const uint32_t *__restrict__ mol_qsum, uint32_t qstride, uint32_t *__restrict__ o_q) {
+	const uint32_t c = blockIdx.x;
+	const uint32_t b = begin[c], o = out_off[c], len = out_off[c + 1] - o;
+	for (uint32_t k = threadIdx.x; k < len * qstride; k += 256) {
+		const uint32_t i = k / qstride, w = k % qstride;
+		o_q[size_t(o + i) * qstride + w] = mol_qsum[size_t(mol_qrow[b + i]) * qstride + w];
+	}
+}
+__global__ __launch_bounds__(256) void iota_from_kernel(uint32_t *out, uint32_t n, uint32_t first) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i < n) out[i] = first + i;
+}
+
 __global__ __launch_bounds__(256) void pair_ranges_ext_kernel(const uint32_t *__restrict__ cand_cell, const uint32_t *__restrict__ base_begin,
                                                               const uint32_t *__restrict__ base_end, uint32_t n,
                                                               const uint32_t *__restrict__ cell_cg_begin,
@@ -107,6 +122,12 @@ struct dropest_ctx::ShardMerge {
 	std::vector<uint64_t> row_offset;   // [listed + 1]
 	dropest::DevBuf<u64> x_low;
 	dropest::DevBuf<u32> x_col[4];
+	dropest::DevBuf<u32> x_q;           // UMI qualities: the sums rows of the exported molecule rows
+	// UMI qualities, set by the driver before shard_merge_finish (shard_merge_quality_import): the place of every listed local cell in its
+	// target's merge order, and of every imported row's source; the sums rows of the imported rows
+	std::vector<u32> local_rank;
+	const u32 *d_import_rank = nullptr, *d_import_q = nullptr;
+	bool quality_import_set = false;
 };
 
 void dropest_ctx::shard_merge_search(uint64_t n_global, const uint64_t *g_barcode, const uint32_t *g_n_genes, const int32_t *g_total_umis,
@@ -202,6 +223,11 @@ void dropest_ctx::shard_merge_search(uint64_t n_global, const uint64_t *g_barcod
 		timed("shard_merge:export", double(rows) * 48, [&] {
 			hipLaunchKernelGGL(export_rows_kernel, dim3(nl), dim3(256), 0, stream, a);
 		});
+		if (have_qual && qual_len) {
+			M.x_q.alloc(std::max<size_t>(size_t(rows) * qual_stride(), 1));
+			hipLaunchKernelGGL(export_quality_kernel, dim3(nl), dim3(256), 0, stream, d_b.p, d_off.p, mol_qrow.p, mol_qsum.p, qual_stride(), M.x_q.p);
+			HIP_CHECK(hipGetLastError());
+		}
 		HIP_CHECK(stream_wait(stream));
 	}
 	collect_timings();
@@ -250,6 +276,16 @@ void dropest_ctx::shard_merge_decide(const uint32_t *inter, int64_t *target_g) {
 	for (u32 f = 0; f < M.S.F; ++f) target_g[f] = targets[f];
 }
 
+// UMI qualities across shards (quality.h): a molecule the target has keeps the target's sums, one that only merged cells had takes the
+// sums of the FIRST of them in merge order (Gene::merge, Gene.cpp:26-36) -- wherever those cells lived.  local_rank[i] belongs to
+// local_id[i] of the shard_merge_finish call that follows; import_rank / import_q (device) to its imported rows.
+void dropest_ctx::shard_merge_quality_import(uint64_t n_local, const uint32_t *local_rank, const uint32_t *d_import_rank, const uint32_t *d_import_q) {
+	if (!shard) throw InvalidError("dropest_shard_merge_search was not run");
+	shard->local_rank.assign(local_rank, local_rank + n_local);
+	shard->d_import_rank = d_import_rank; shard->d_import_q = d_import_q;
+	shard->quality_import_set = true;
+}
+
 void dropest_ctx::shard_merge_finish(uint64_t n_local, const uint32_t *local_id, const uint8_t *excluded, const uint8_t *merged_away,
                                      const int32_t *total_reads, const int32_t *total_umis, uint64_t n_moves,
                                      const uint32_t *move_src, const uint32_t *move_tgt, uint64_t n_import,
@@ -261,6 +297,13 @@ void dropest_ctx::shard_merge_finish(uint64_t n_local, const uint32_t *local_id,
 		HostCell &h = real[real_at(local_id[i])];
 		h.excluded = excluded[i] != 0; h.merged = merged_away[i] != 0;
 		h.row.total_reads = total_reads[i]; h.row.total_umis = total_umis[i];
+	}
+	const bool with_qual = have_qual && qual_len;
+	if (with_qual) {
+		if (!shard || !shard->quality_import_set || shard->local_rank.size() != n_local)
+			throw UnsupportedError("a sharded barcode merge on a container with UMI qualities needs shard_merge_quality_import first");
+		merge_rank.assign(n_cells, 0);
+		for (uint64_t i = 0; i < n_local; ++i) merge_rank[local_id[i]] = shard->local_rank[i];
 	}
 	clear_strategy_pairs();
 	for (uint64_t i = 0; i < n_moves; ++i) {
@@ -284,6 +327,16 @@ void dropest_ctx::shard_merge_finish(uint64_t n_local, const uint32_t *local_id,
 			grow_preserving(mol_intron, n_mol, size_t(total) + 1, stream);
 			HIP_CHECK(hipMemcpyAsync(mol_exon.p + n_mol, d_cols[2], size_t(ni) * 4, hipMemcpyDeviceToDevice, stream));
 			HIP_CHECK(hipMemcpyAsync(mol_intron.p + n_mol, d_cols[3], size_t(ni) * 4, hipMemcpyDeviceToDevice, stream));
+		}
+		if (with_qual) {   // the imported rows bring their sums rows along; their place in the merge order decides who keeps what in the fold
+			const size_t qs = qual_stride();
+			grow_preserving(mol_qsum, size_t(n_qsum_rows) * qs, size_t(n_qsum_rows + ni) * qs, stream);
+			HIP_CHECK(hipMemcpyAsync(mol_qsum.p + size_t(n_qsum_rows) * qs, shard->d_import_q, size_t(ni) * qs * 4, hipMemcpyDeviceToDevice, stream));
+			grow_preserving(mol_qrow, n_mol, size_t(total), stream);
+			hipLaunchKernelGGL(iota_from_kernel, dim3(div_up(ni, 256)), dim3(256), 0, stream, mol_qrow.p + n_mol, ni, n_qsum_rows);
+			HIP_CHECK(hipGetLastError());
+			n_qsum_rows += ni;
+			reagg_import_prio = shard->d_import_rank; reagg_import_from = n_mol; reagg_import_n = ni;
 		}
 		HIP_CHECK(stream_wait(stream));
 		mol_sorted_rows = n_mol;   // the imported rows sit behind the sorted table

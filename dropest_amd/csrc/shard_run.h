@@ -324,6 +324,11 @@ __global__ __launch_bounds__(256) void take_u32_kernel(const uint32_t *__restric
 	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
 	if (i < n) out[i] = table[pos[i]];
 }
+__global__ __launch_bounds__(256) void gather_u32_rows_kernel(const uint32_t *__restrict__ in, const uint32_t *__restrict__ row, uint32_t n, uint32_t width,
+                                                              uint32_t *__restrict__ out) {
+	for (uint64_t k = uint64_t(blockIdx.x) * 256 + threadIdx.x; k < uint64_t(n) * width; k += uint64_t(gridDim.x) * 256)
+		out[k] = in[uint64_t(row[k / width]) * width + k % width];
+}
 struct ImportGatherArgs { const uint32_t *row; uint32_t n; const unsigned long long *low_all; const uint32_t *col_all[4]; unsigned long long *o_low; uint32_t *o_col[4]; };
 __global__ __launch_bounds__(256) void import_gather_kernel(ImportGatherArgs a) {
 	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -837,7 +842,8 @@ void dropest_shard::cb_merge() {
 	std::vector<Listed> my_listed(M.listed_f.size()), all_listed;
 	for (size_t i = 0; i < M.listed_f.size(); ++i) my_listed[i] = Listed{M.base_g[M.listed_f[i]], M.row_offset[i], M.row_offset[i + 1]};
 	std::vector<size_t> pcnt, lcnt;
-	DevBuf<u64> low_all; DevBuf<u32> col_all[4];
+	DevBuf<u64> low_all; DevBuf<u32> col_all[4], q_all;
+	const bool with_qual = c.have_qual && c.qual_len;
 	std::vector<uint64_t> beg(nG, ~0ull), end(nG, ~0ull);
 	{
 		Phase ph(this, "cbm:gather_rows");
@@ -856,6 +862,13 @@ void dropest_shard::cb_merge() {
 		for (auto &b : col_all) b.alloc(std::max<size_t>(total, 1));
 		tr->gather_dev(M.x_low.p, low_all.p, off8.data(), b8.data(), c.stream);
 		for (int k = 0; k < 4; ++k) tr->gather_dev(M.x_col[k].p, col_all[k].p, off4.data(), b4.data(), c.stream);
+		if (with_qual) {   // the sums rows of the travelling molecules
+			const size_t qs = c.qual_stride();
+			std::vector<size_t> offq(static_cast<size_t>(world)), bq(static_cast<size_t>(world));
+			for (int p = 0; p < world; ++p) { offq[size_t(p)] = off4[size_t(p)] * qs; bq[size_t(p)] = b4[size_t(p)] * qs; }
+			q_all.alloc(std::max<size_t>(total * qs, 1));
+			tr->gather_dev(M.x_q.p, q_all.p, offq.data(), bq.data(), c.stream);
+		}
 		size_t at = 0;
 		for (int p = 0; p < world; ++p)
 			for (size_t i = 0; i < lcnt[size_t(p)]; ++i, ++at) { beg[all_listed[at].g] = all_listed[at].b + row_base[size_t(p)]; end[all_listed[at].g] = all_listed[at].e + row_base[size_t(p)]; }
@@ -923,6 +936,7 @@ void dropest_shard::cb_merge() {
 	}
 	std::vector<u32> final_t(nG); std::vector<uint8_t> excl(nG);
 	std::vector<int32_t> reads(nG), umis(nG);
+	std::vector<u32> mrank(with_qual ? nG : 0u);   // place of every cell in its target's merge order (0: not merged away)
 	{
 		Phase ph(this, "cbm:order+apply");
 		// all real cells are "filtered" before the merge (threshold 0): ascending compare_cells order
@@ -933,22 +947,23 @@ void dropest_shard::cb_merge() {
 		const std::vector<u32> order = order_rows(sel, false);
 		std::vector<int64_t> tgt_in_order(nG);
 		for (u32 i = 0; i < nG; ++i) { tgt_in_order[i] = target[order[i]]; reads[i] = Gm[i].total_reads; umis[i] = Gm[i].total_umis; }
-		apply_merge_order(nG, nG, order.data(), tgt_in_order.data(), reads.data(), umis.data(), final_t.data(), excl.data());
+		apply_merge_order(nG, nG, order.data(), tgt_in_order.data(), reads.data(), umis.data(), final_t.data(), excl.data(), with_qual ? mrank.data() : nullptr);
 	}
 	Phase ph(this, "cbm:finish");
-	std::vector<u32> local_id, move_src, move_tgt, import_row, import_cell;
+	std::vector<u32> local_id, move_src, move_tgt, import_row, import_cell, local_rank, import_rank;
 	std::vector<uint8_t> l_excl, l_merged; std::vector<int32_t> l_reads, l_umis;
 	merged_barcodes.clear();
 	for (u32 i = 0; i < nG; ++i) {
 		const bool mine = i >= lo && i < hi;
-		if (mine) { local_id.push_back(Gm[i].local_id); l_excl.push_back(excl[i]); l_merged.push_back(final_t[i] != i); l_reads.push_back(reads[i]); l_umis.push_back(umis[i]); }
+		if (mine) { local_id.push_back(Gm[i].local_id); l_excl.push_back(excl[i]); l_merged.push_back(final_t[i] != i); l_reads.push_back(reads[i]); l_umis.push_back(umis[i]);
+		            if (with_qual) local_rank.push_back(mrank[i]); }
 		if (final_t[i] == i) continue;
 		merged_barcodes.emplace_back(Gm[i].barcode, Gm[final_t[i]].barcode);
 		const u32 t = final_t[i];
 		if (!(t >= lo && t < hi)) continue;
 		if (mine) { move_src.push_back(Gm[i].local_id); move_tgt.push_back(Gm[t].local_id); continue; }
 		if (beg[i] == ~0ull) throw InvalidError("internal: a merged cell's molecule rows were not exported");
-		for (uint64_t r = beg[i]; r < end[i]; ++r) { import_row.push_back(u32(r)); import_cell.push_back(Gm[t].local_id); }
+		for (uint64_t r = beg[i]; r < end[i]; ++r) { import_row.push_back(u32(r)); import_cell.push_back(Gm[t].local_id); if (with_qual) import_rank.push_back(mrank[i]); }
 	}
 	std::sort(merged_barcodes.begin(), merged_barcodes.end());
 	const u32 ni = u32(import_row.size());
@@ -964,6 +979,18 @@ void dropest_shard::cb_merge() {
 		hipLaunchKernelGGL(import_gather_kernel, dim3(div_up(ni, 256)), dim3(256), 0, c.stream, a);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(stream_wait(c.stream));
+	}
+	DevBuf<u32> d_irank, d_iq;
+	if (with_qual) {
+		const u32 qs = c.qual_stride();
+		d_irank.alloc(std::max<u32>(ni, 1)); d_iq.alloc(std::max<size_t>(size_t(ni) * qs, 1));
+		if (ni) {
+			HIP_CHECK(hipMemcpyAsync(d_irank.p, import_rank.data(), size_t(ni) * 4, hipMemcpyHostToDevice, c.stream));
+			hipLaunchKernelGGL(gather_u32_rows_kernel, dim3(u32(std::min<uint64_t>((uint64_t(ni) * qs + 255) / 256, 16384))), dim3(256), 0, c.stream, q_all.p, d_row.p, ni, qs, d_iq.p);
+			HIP_CHECK(hipGetLastError());
+			HIP_CHECK(stream_wait(c.stream));
+		}
+		c.shard_merge_quality_import(local_id.size(), local_rank.data(), d_irank.p, d_iq.p);
 	}
 	const u32 *cols[4] = {d_col[0].p, d_col[1].p, d_col[2].p, d_col[3].p};
 	c.shard_merge_finish(local_id.size(), local_id.data(), l_excl.data(), l_merged.data(), l_reads.data(), l_umis.data(), move_src.size(),
@@ -1134,8 +1161,6 @@ void dropest_shard::step() {
 	if ((c.cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES || c.cfg.merge_kind == DROPEST_MERGE_POISSON_REAL) && world > 1) { Phase ph(this, "cb_merge"); cb_merge(); }
 	else if (c.cfg.merge_kind != DROPEST_MERGE_NONE && world > 1)
 		throw UnsupportedError("sharded runs support the merges with a barcode whitelist (-m, -M with barcodes) only; run the other merge strategies on one GPU");
-	if (c.have_qual && world > 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE)
-		throw UnsupportedError("UMI qualities with a barcode merge are not supported in sharded runs");
 	{ Phase ph(this, "finalize"); c.run_merge_and_filter(); }
 	merged_pending = world == 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE;   // one shard: the context's own pairs, named when asked for
 	build_global_table();

@@ -507,7 +507,8 @@ dropest_status dropest_shard_push_reads(dropest_shard *shard, const uint64_t *cb
 /* UMI quality strings of the shard's resident reads (see dropest_set_umi_qualities): quality_length bytes per read, in the order the reads
  * were pushed / set; call on EVERY shard of the run (a shard without reads: n_reads = 0), same length everywhere, before
  * dropest_shard_step.  The strings travel with their reads in the exchange; the sums are accumulated where the cell lives and follow
- * the UMI merges there.  Not yet with a barcode merge across shards. */
+ * the UMI merges there; in a barcode merge across shards the sums rows of the molecules that change shards travel with them, and a molecule
+ * several merged cells had keeps the sums of the first of them in merge order, wherever they lived (Gene::merge, Gene.cpp:26-36). */
 dropest_status dropest_shard_set_umi_qualities(dropest_shard *shard, const uint8_t *qualities, uint32_t quality_length, uint64_t n_reads);
 dropest_status dropest_shard_step(dropest_shard *shard);
 dropest_status dropest_shard_group_step(dropest_shard *const *shards, int32_t n);   /* one host thread per shard */

@@ -161,11 +161,14 @@ def _plain(v):
     return (v.kind, _plain(v.value), {k: _plain(x) for k, x in sorted(v.attributes.items())})
 
 
-@pytest.mark.parametrize("wl", [False, True])
-def test_sharded_container_writes_the_same_rds(tmp_path, wl):
+@pytest.mark.parametrize("wl,qual", [(False, False), (True, False), (False, True), (True, True)])
+def test_sharded_container_writes_the_same_rds(tmp_path, wl, qual):
     """ResultsPrinter::save_results of a container sharded over three shards (one GPU) = the .rds of one container: both
     matrices with the reference's row order, per-chromosome frames, mean reads per UMI, saturation info, aligned / requested
-    counts per cell, reads_per_umi_per_cell; merge_targets as a set (the order of that list is the reference's hash order)."""
+    counts per cell, reads_per_umi_per_cell; merge_targets as a set (the order of that list is the reference's hash order).
+    With UQ tags (qual) the mean qualities of reads_per_umi_per_cell must agree too: every shard gets the strings of its own
+    range of reads, and under the whitelist merge (wl) the quality sums follow the molecules across shards."""
+    qrng = np.random.default_rng(31)
     s = SynthStream(n_reads=60_000, n_cells=25, n_genes=300, umi_len=8, permille_neighbour=150, permille_intron=100)
     cb, umi, gene, aux = s.generate_host()
     refs = [("chr%d" % i, 1_000_000) for i in range(25)]
@@ -177,6 +180,8 @@ def test_sharded_container_writes_the_same_rds(tmp_path, wl):
         g = None if gene[i] == capi.NO_GENE else "G%d" % gene[i]
         mark = int(aux[i] >> 16) & 7
         tags = [("CB", "Z", c), ("UB", "Z", u)]
+        if qual:
+            tags.append(("UQ", "Z", "".join(chr(int(x)) for x in qrng.integers(35, 74, 8))))
         if g:
             tags += [("GX", "Z", g), ("RE", "A", "N" if mark & 4 else "E")]
         recs.append(bw.record(int(aux[i]) & 0xFFFF, i, "r%d" % i, tags=tags))
@@ -196,6 +201,9 @@ def test_sharded_container_writes_the_same_rds(tmp_path, wl):
             assert a == b and (len(a) > 10 or not wl)
         else:
             assert _plain(d1[key]) == _plain(d3[key]), key
+    per_gene = d3["reads_per_umi_per_cell"]["reads_per_umi"].value
+    with_quality = sum(1 for g in per_gene for e in g.value if len(e.value[1].value) == 8)
+    assert (with_quality > 1000) if qual else (with_quality == 0)
 
 
 def test_bad_files(tmp_path):

@@ -442,3 +442,42 @@ def test_umi_qualities_travel_with_the_reads(world, variant):
     assert not bad, (len(bad), bad[0], got.get(bad[0]), want[bad[0]])
     check({"cm": [x.copy() for x in g.shards[0].matrix(True)], "raw": [x.copy() for x in g.shards[0].matrix(False)], "merged": g.shards[0].merged_barcodes()}, c)
     g.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("poisson", [False, True])
+def test_umi_qualities_follow_a_barcode_merge_across_shards(world, poisson):
+    """-m / -M with a whitelist and UMI qualities over 2 / 3 shards: the sums rows of the molecules that change shards travel with them; a
+    molecule the target already has keeps the target's sums, one that only merged cells had takes those of the first of them in merge
+    order (Gene::merge, Gene.cpp:26-36) -- whichever shards those cells lived on.  Same sums per molecule as one context."""
+    kw_s, wl, kind, cfg = MERGE_CASES["10x"]
+    s = SynthStream(**dict(kw_s, n_genes=60, umi_len=6, permille_neighbour=250))     # few genes and UMIs: many molecules shared between merged cells
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    qual = np.random.default_rng(78).integers(33, 75, size=(len(cb), 6), dtype=np.uint8)
+    ckw = cfg_kwargs(dict(cfg, merge={"barcodes_kind": kind, "barcodes_file": os.path.join(DATA, wl)}))
+    if poisson:
+        ckw.update(merge_kind=capi.MERGE_POISSON_REAL)
+    c = capi.Context(**ckw)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_umi_qualities(qual)
+    c.set_initialized(); c.merge_and_filter()
+    want = _quality_table(c)
+    n = len(cb)
+    bounds = [n * i // world for i in range(world + 1)]
+    g = ShardGroup([0] * world, **ckw)
+    for i, sh in enumerate(g.shards):
+        sh.set_reads(capi.DeviceArrays.from_host(0, cb[bounds[i]:bounds[i + 1]], umi[bounds[i]:bounds[i + 1]], gene[bounds[i]:bounds[i + 1]], aux[bounds[i]:bounds[i + 1]]), bounds[i])
+        sh.set_umi_qualities(qual[bounds[i]:bounds[i + 1]])
+    for _ in range(2):
+        g.step()
+    got = {}
+    for sh in g.shards:
+        got.update(_quality_table(sh.ctx))
+    merged = check({"cm": [x.copy() for x in g.shards[0].matrix(True)], "raw": [x.copy() for x in g.shards[0].matrix(False)], "merged": g.shards[0].merged_barcodes()}, c)
+    owner = lambda b: capi.lib().dropest_owner_of(int(b), world)           # noqa: E731
+    assert sum(owner(a) != owner(b) for a, b in merged.items()) > 5        # molecules really changed shards
+    assert len(want) > 2000 and len(got) == len(want)
+    bad = [k for k in want if got.get(k) != want[k]]
+    assert not bad, (len(bad), bad[0], got.get(bad[0]), want[bad[0]])
+    # and not trivially: some kept molecule's sums differ from what its reads alone in the target would give (a fold happened)
+    g.close()
