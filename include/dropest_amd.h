@@ -486,7 +486,8 @@ void *dropest_stream(dropest_ctx *ctx);
  * -u runs sharded too (the shards' UMI first-occurrence tables are reduced to one rank table, random fills come from agreed
  * offsets of the one rand() sequence), and so does -M with a whitelist (PoissonRealBarcodesMergeStrategy: the UMI histograms of the shards
  * are added, every shard builds the same estimator tables; UMI fields of at most 26 bits).  Not in sharded runs: the merges without a
- * whitelist (-m / -M without barcodes, merge-all: their candidates come from UMIs shared between ANY two cells), UMI qualities. */
+ * whitelist (-m / -M without barcodes, merge-all: their candidates come from UMIs shared between ANY two cells), UMI quality strings of
+ * several lengths (one length per run: dropest_shard_set_umi_qualities). */
 typedef struct dropest_shard dropest_shard;
 dropest_status dropest_shard_unique_id(uint8_t id[128]);
 dropest_status dropest_shard_create(const dropest_cfg *cfg, int32_t rank, int32_t world, const uint8_t id[128], dropest_shard **out);
