@@ -361,6 +361,99 @@ __global__ __launch_bounds__(256) void place_columns_narrow_kernel(const unsigne
 		}
 	}
 }
+// The BYTE form (dropest_matrix_bytes, include/dropest_amd.h): u8 row delta + u8 value at the entry's GLOBAL place, two bytes per entry
+// on the PCIe link.  A workgroup takes one column and walks it in aligned 4-entry words (one u32 store per array and lane; the
+// ragged ends of a column as bytes -- the neighbouring column may be another shard's).  Entries that do not fit a byte (255 =
+// listed) go to this shard's segment of the shared buffer with their global position: staged in LDS, one atomic per workgroup
+// and round on the shard's counters; the readers concatenate the segments (the lists carry no order).
+constexpr uint32_t PCB_STAGE = 1024;   // 256 lanes x 4 entries: a round cannot stage more
+__global__ __launch_bounds__(256) void place_columns_bytes_kernel(const unsigned long long *__restrict__ desc, const uint32_t *__restrict__ src_rows,
+                                                                  const uint32_t *__restrict__ src_vals, uint8_t *__restrict__ dst_delta,
+                                                                  uint8_t *__restrict__ dst_val, uint32_t *__restrict__ counters /* [2] */,
+                                                                  uint32_t *__restrict__ rl_pos, uint32_t *__restrict__ rl_row,
+                                                                  uint32_t *__restrict__ vl_pos, uint32_t *__restrict__ vl_val, uint32_t cap) {
+	__shared__ uint32_t st_pos[2][PCB_STAGE], st_x[2][PCB_STAGE];
+	__shared__ uint32_t st_n[2], st_base[2];
+	const unsigned long long s = desc[3ull * blockIdx.x], d = desc[3ull * blockIdx.x + 1], len = desc[3ull * blockIdx.x + 2];
+	if (threadIdx.x < 2) st_n[threadIdx.x] = 0;
+	__syncthreads();
+	const unsigned long long w0 = d >> 2, w1 = (d + len + 3) >> 2;
+	for (unsigned long long wb = w0; wb < w1; wb += 256) {
+		const unsigned long long w = wb + threadIdx.x;
+		int staged = 0;
+		if (w < w1) {
+			uint32_t dd = 0, vv = 0, inside = 0;
+			for (uint32_t b = 0; b < 4; ++b) {
+				const unsigned long long g = 4 * w + b;
+				if (g < d || g >= d + len) continue;
+				const unsigned long long t = g - d;
+				const uint32_t row = src_rows[s + t], prev = t ? src_rows[s + t - 1] : 0xFFFFFFFFu, v = src_vals[s + t];
+				const uint32_t delta = row - prev;
+				inside |= 1u << b;
+				dd |= (delta >= 255u ? 255u : delta) << (8 * b);
+				vv |= (v >= 255u ? 255u : v) << (8 * b);
+				if (delta >= 255u) { const uint32_t at = atomicAdd(&st_n[0], 1u); st_pos[0][at] = uint32_t(g); st_x[0][at] = row; staged = 1; }
+				if (v >= 255u) { const uint32_t at = atomicAdd(&st_n[1], 1u); st_pos[1][at] = uint32_t(g); st_x[1][at] = v; staged = 1; }
+			}
+			if (inside == 0xFu) {
+				reinterpret_cast<uint32_t *>(dst_delta)[w] = dd;
+				reinterpret_cast<uint32_t *>(dst_val)[w] = vv;
+			} else
+				for (uint32_t b = 0; b < 4; ++b) if (inside >> b & 1u) { dst_delta[4 * w + b] = uint8_t(dd >> (8 * b)); dst_val[4 * w + b] = uint8_t(vv >> (8 * b)); }
+		}
+		if (__syncthreads_or(staged)) {
+			if (threadIdx.x < 2) st_base[threadIdx.x] = st_n[threadIdx.x] ? atomicAdd(&counters[threadIdx.x], st_n[threadIdx.x]) : 0u;
+			__syncthreads();
+			for (uint32_t k = 0; k < 2; ++k) {
+				uint32_t *pos = k ? vl_pos : rl_pos, *x = k ? vl_val : rl_row;
+				const uint32_t n = st_n[k], base = st_base[k];
+				for (uint32_t i = threadIdx.x; i < n; i += 256) if (base + i < cap) { pos[base + i] = st_pos[k][i]; x[base + i] = st_x[k][i]; }
+			}
+			__syncthreads();
+			if (threadIdx.x < 2) st_n[threadIdx.x] = 0;
+			__syncthreads();
+		}
+	}
+}
+// cm_raw planned on the device (assemble_raw_device): the shards' real cells, each list ascending by the stream ordinal of the cell's
+// first read, merged by rank -- a cell's global column = its local place + the cells of every other shard that come before it.
+struct RawPlanTable { uint32_t world, rank; uint64_t off[64]; uint32_t n[64]; };   // shard s: first[n] at all + off, nnz prefix[n + 1] behind it
+struct QueryTable { uint32_t world; uint64_t in_off[65], part_off[64], out_off[65], first_ord[64]; };
+__global__ __launch_bounds__(256) void answer_queries_kernel(QueryTable t, const uint32_t *__restrict__ q_in, uint32_t n, const uint32_t *__restrict__ part_idx,
+                                                             uint32_t *__restrict__ out) {
+	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= n) return;
+	uint32_t p = 0;
+	while (p + 1 < t.world && k >= t.in_off[p + 1]) ++p;
+	out[k] = part_idx[t.part_off[p] + q_in[k]];
+}
+__global__ __launch_bounds__(256) void ordinals_from_answers_kernel(QueryTable t, const uint32_t *__restrict__ back, uint32_t n, unsigned long long *__restrict__ first) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	uint32_t s = 0;
+	while (s + 1 < t.world && i >= t.out_off[s + 1]) ++s;
+	first[i] = t.first_ord[s] + back[i];
+}
+__global__ __launch_bounds__(256) void plan_raw_columns_kernel(RawPlanTable t, const unsigned long long *__restrict__ all, const uint32_t *__restrict__ col_cell,
+                                                               const unsigned long long *__restrict__ cell_barcode, uint32_t n,
+                                                               unsigned long long *__restrict__ desc, unsigned long long *__restrict__ colptr64,
+                                                               uint32_t *__restrict__ colptr32, unsigned long long *__restrict__ barcodes) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	const unsigned long long *mine = all + t.off[t.rank], *my_pre = mine + t.n[t.rank];
+	const unsigned long long f = mine[i];
+	unsigned long long col = i, at = my_pre[i];
+	for (uint32_t s = 0; s < t.world; ++s) {
+		if (s == t.rank) continue;
+		const unsigned long long *fs = all + t.off[s];
+		uint32_t lo = 0, hi = t.n[s];
+		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (fs[mid] < f) lo = mid + 1; else hi = mid; }
+		col += lo; at += fs[t.n[s] + lo];
+	}
+	desc[3ull * i] = my_pre[i]; desc[3ull * i + 1] = at; desc[3ull * i + 2] = my_pre[i + 1] - my_pre[i];
+	colptr64[col] = at; colptr32[col] = uint32_t(at); barcodes[col] = cell_barcode[col_cell[i]];
+}
+__global__ void copy_words_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t n) { if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x]; }
 // local read position -> global stream ordinal: position p came from source rank s = the block [recv_off[s], recv_off[s+1])
 // it lies in, as that rank's idx[p]-th resident read
 // (every shard's resident reads are ONE contiguous range of the stream and the ranges ascend with the rank: the blocks a
@@ -465,13 +558,33 @@ struct dropest_shard {
 	// results: global CSC of both matrices (rows / values in the node-shared host buffer)
 	struct Mat {
 		uint64_t ncols = 0, nnz = 0; std::vector<u64> colptr, col_barcode;
+		// what the accessors hand out: the vectors above, or (cm_raw planned on the device) arrays in the shared buffer
+		const u64 *colptr_p = nullptr, *barcode_p = nullptr; const u32 *colptr32_p = nullptr;
 		const u32 *rows = nullptr, *vals = nullptr;               // 32-bit form (in the shared buffer, or widened on demand)
 		bool narrow = false;                                      // the shared buffer holds the 16-bit form
 		const uint16_t *rows16 = nullptr, *vals16 = nullptr;
 		std::vector<u64> ovf_pos; std::vector<u32> ovf_val;       // entries beyond 65534, ascending position
 		std::vector<u32> wide_rows, wide_vals; bool widened = false;
+		// the byte form (dropest_matrix_bytes): deltas / values in the shared buffer, every shard's lists in its segment behind them
+		bool bytes = false, lists_ready = false;
+		const uint8_t *delta8 = nullptr, *vals8 = nullptr; const char *segments = nullptr; size_t seg_bytes = 0; u32 list_cap = 0;
+		std::vector<u32> colptr32, rl_pos, rl_row, vl_pos, vl_val;
 	} mat[2];
 	bool narrow_matrix = true;                                    // option "narrow_matrix": 16-bit matrices when every gene id fits
+	bool byte_matrix = true;                                      // option "byte_matrix": the byte form (any gene id); wins over narrow_matrix
+	uint64_t byte_list_cap = 0;                                   // option "byte_list_cap": entries a shard may list per kind (0: 2^20)
+	dropest::DevBuf<u32> d_list_count;
+	void collect_lists(Mat &M);
+	// cm_raw without a host table of all the real cells (option "raw_on_device", on): see assemble_raw_device
+	bool raw_on_device = true, raw_device_now = false;
+	struct RawPlan { std::vector<u32> col_cell, col_start, query; std::vector<u64> pre; std::vector<uint64_t> counts, q_out, q_in; uint64_t ncols = 0, nnz = 0; } raw_plan;
+	bool plan_raw();
+	void assemble_raw_device();
+	struct SharedLayout { char *host; void *dev; size_t base, off_val, off_seg, seg_bytes; dropest::u32 list_cap; bool bytes, narrow; };
+	SharedLayout open_shared(Mat &M, int slot, size_t head_bytes);
+	void place_columns(Mat &M, int slot, bool filtered_m, const SharedLayout &L, const unsigned long long *d_descr, dropest::u32 nc, uint64_t local_nnz);
+	dropest::DevBuf<u64> d_plan_mine, d_plan_all;
+	dropest::DevBuf<u32> d_q, d_q_in, d_q_ans, d_q_back, d_col_cell;
 	dropest::DevBuf<u32> d_ovf;
 	std::vector<std::pair<u64, u64>> merged_barcodes;   // (source, target) barcode of every merged cell, ascending source
 	bool merged_pending = false;
@@ -486,7 +599,7 @@ struct dropest_shard {
 		std::sort(merged_barcodes.begin(), merged_barcodes.end());
 	}
 	dropest::DevBuf<u64> d_desc;
-	dropest::PinnedBuf<u64> h_desc;
+	dropest::PinnedBuf<u64> h_desc, h_plan;
 	dropest::DevBuf<u32> d_tmp32;
 	std::map<std::string, dropest::KernelStat> phases;
 
@@ -1006,15 +1119,18 @@ void dropest_shard::build_global_table() {
 	std::vector<u32> pos;
 	for (const HostCell &h : c.real) {
 		if (h.merged || h.excluded || h.row.n_genes < c.min_before) continue;
+		if (raw_device_now && h.row.requested_genes < c.min_after) continue;   // cm_raw is planned on the device: the table serves cm only
 		GRow r{};
 		r.barcode = h.row.barcode; r.n_genes = h.row.n_genes; r.req_genes = h.row.requested_genes; r.req_umis = h.row.requested_umis;
 		r.local_id = h.id; r.total_umis = h.row.total_umis; r.total_reads = h.row.total_reads; r.rank = u32(rank);
 		mine.push_back(r); pos.push_back(h.row.first_read);
 	}
+	{ Phase p2(this, "cells:ordinals");
 	const std::vector<u64> ord = global_ordinals(pos);
-	for (size_t i = 0; i < mine.size(); ++i) mine[i].first_global = ord[i];
+	for (size_t i = 0; i < mine.size(); ++i) mine[i].first_global = ord[i]; }
 	std::vector<size_t> cnt;
-	tr->gather_vec(mine, G, cnt);
+	{ Phase p3(this, "cells:gather"); tr->gather_vec(mine, G, cnt); }
+	if (std::getenv("DROPEST_SHARD_TRACE")) fprintf(stderr, "[shard %d] real rows %zu of %zu, G %zu\n", rank, mine.size(), c.real.size(), G.size());
 }
 
 // 8. one matrix: global column order (identical on every shard), this shard's columns emitted on the device and written to
@@ -1051,37 +1167,90 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 	}
 	M.nnz = M.colptr[ncols];
 	if (M.nnz > 0xFFFFFFF0ull || local_nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
-	void *d_shared = nullptr;
-	// every shard takes the same decision: the gene ids are the agreed ones (one shard: its own)
-	const bool narrow = narrow_matrix && c.narrow_possible();
-	char *host = static_cast<char *>(tr->shared_host(slot, std::max<size_t>(size_t(M.nnz), 1) * (narrow ? 4 : 8), &d_shared));
-	M.narrow = narrow; M.widened = false; M.ovf_pos.clear(); M.ovf_val.clear();
-	if (narrow) { M.rows16 = reinterpret_cast<const uint16_t *>(host); M.vals16 = reinterpret_cast<const uint16_t *>(host) + M.nnz; M.rows = M.vals = nullptr; }
-	else { M.rows = reinterpret_cast<const u32 *>(host); M.vals = reinterpret_cast<const u32 *>(host) + M.nnz; M.rows16 = M.vals16 = nullptr; }
-	constexpr u32 OVF_CAP = 1u << 16;
-	bool placed = false;
-	if (!col_cell.empty() && local_nnz) {
-		const u32 nc = u32(col_cell.size());
+	M.colptr_p = M.colptr.data(); M.barcode_p = M.col_barcode.data();
+	M.colptr32.resize(ncols + 1);
+	for (size_t j = 0; j <= ncols; ++j) M.colptr32[j] = u32(M.colptr[j]);
+	M.colptr32_p = M.colptr32.data();
+	const SharedLayout L = open_shared(M, slot, 0);
+	const u32 nc = u32(col_cell.size());
+	if (nc && local_nnz) {
 		c.emit_columns_device(filtered_m, false, col_cell, col_start, local_nnz);
 		d_desc.ensure(desc.size()); h_desc.ensure(desc.size());
 		std::memcpy(h_desc.p, desc.data(), desc.size() * 8);
 		HIP_CHECK(hipMemcpyAsync(d_desc.p, h_desc.p, desc.size() * 8, hipMemcpyHostToDevice, c.stream));
-		const dropest_ctx::MatrixResult &R = c.mat[slot];
-		if (narrow) {
+	}
+	place_columns(M, slot, filtered_m, L, d_desc.p, nc, local_nnz);
+}
+
+// The node-shared host buffer of one matrix (collective: every shard takes the same decisions -- the gene ids are the agreed ones).
+// [head_bytes of the caller][payload][byte form: one segment per shard].  Payload: 32-bit rows | values; 16-bit rows | values; byte form:
+// deltas | values (each padded to 16 bytes).  A segment = 4 words (rows listed, values listed, 0, 0) + 4 arrays of list_cap words (row
+// positions, rows, value positions, values); list_cap comes from the GLOBAL nnz: the same on every shard.
+dropest_shard::SharedLayout dropest_shard::open_shared(Mat &M, int slot, size_t head_bytes) {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	SharedLayout L{};
+	L.bytes = byte_matrix;
+	L.narrow = !L.bytes && narrow_matrix && c.narrow_possible();
+	L.base = (head_bytes + 15) & ~size_t(15);
+	L.list_cap = u32(std::min<uint64_t>(byte_list_cap ? byte_list_cap : (1u << 20), (M.nnz + 15) & ~15ull));
+	L.off_val = (size_t(M.nnz) + 15) & ~size_t(15); L.off_seg = 2 * L.off_val; L.seg_bytes = 16 + 16 * size_t(L.list_cap);
+	const size_t payload = L.bytes ? L.off_seg + L.seg_bytes * size_t(world) : std::max<size_t>(size_t(M.nnz), 1) * (L.narrow ? 4 : 8);
+	L.host = static_cast<char *>(tr->shared_host(slot, L.base + payload, &L.dev));
+	char *host = L.host + L.base;
+	M.narrow = L.narrow; M.widened = false; M.ovf_pos.clear(); M.ovf_val.clear();
+	M.bytes = L.bytes; M.lists_ready = false;
+	M.rows = M.vals = nullptr; M.rows16 = M.vals16 = nullptr; M.delta8 = M.vals8 = nullptr;
+	if (L.bytes) {
+		M.delta8 = reinterpret_cast<const uint8_t *>(host); M.vals8 = reinterpret_cast<const uint8_t *>(host) + L.off_val;
+		M.segments = host + L.off_seg; M.seg_bytes = L.seg_bytes; M.list_cap = L.list_cap;
+	} else if (L.narrow) { M.rows16 = reinterpret_cast<const uint16_t *>(host); M.vals16 = reinterpret_cast<const uint16_t *>(host) + M.nnz; }
+	else { M.rows = reinterpret_cast<const u32 *>(host); M.vals = reinterpret_cast<const u32 *>(host) + M.nnz; }
+	return L;
+}
+
+// this shard's columns (emitted into c.mat[slot] on the device; d_descr: local offset, global offset, length of each) -> their global
+// places in the shared buffer, in the form open_shared chose
+void dropest_shard::place_columns(Mat &M, int slot, bool filtered_m, const SharedLayout &L, const unsigned long long *d_descr, dropest::u32 nc, uint64_t local_nnz) {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	char *d_payload = static_cast<char *>(L.dev) + L.base;
+	const dropest_ctx::MatrixResult &R = c.mat[slot];
+	const bool work = nc && local_nnz;
+	if (L.bytes) {
+		u32 *seg_words = reinterpret_cast<u32 *>(d_payload + L.off_seg + L.seg_bytes * size_t(rank));
+		d_list_count.ensure(8);
+		u32 *cnt = d_list_count.p + 4 * slot;
+		HIP_CHECK(hipMemsetAsync(cnt, 0, 16, c.stream));
+		if (work) {
+			u32 *lists = seg_words + 4;
+			const size_t cap = L.list_cap;
+			c.timed(filtered_m ? "place_columns:cm" : "place_columns:cm_raw", double(local_nnz) * 10, [&] {
+				hipLaunchKernelGGL(place_columns_bytes_kernel, dim3(nc), dim3(256), 0, c.stream, d_descr, R.d_row.p, R.d_val.p,
+				                   reinterpret_cast<uint8_t *>(d_payload), reinterpret_cast<uint8_t *>(d_payload) + L.off_val, cnt,
+				                   lists, lists + cap, lists + 2 * cap, lists + 3 * cap, L.list_cap);
+			});
+		}
+		hipLaunchKernelGGL(copy_words_kernel, dim3(1), dim3(64), 0, c.stream, cnt, seg_words, 4u);   // the counts, behind the lists on the stream
+		HIP_CHECK(hipGetLastError());
+		return;
+	}
+	constexpr u32 OVF_CAP = 1u << 16;
+	if (work) {
+		if (L.narrow) {
 			d_ovf.ensure(1 + 3 * size_t(OVF_CAP));
 			HIP_CHECK(hipMemsetAsync(d_ovf.p, 0, 4, c.stream));
-			hipLaunchKernelGGL(place_columns_narrow_kernel, dim3(nc), dim3(256), 0, c.stream, d_desc.p, R.d_row.p, R.d_val.p,
-			                   static_cast<uint16_t *>(d_shared), static_cast<uint16_t *>(d_shared) + M.nnz, d_ovf.p, OVF_CAP);
-			placed = true;
+			hipLaunchKernelGGL(place_columns_narrow_kernel, dim3(nc), dim3(256), 0, c.stream, d_descr, R.d_row.p, R.d_val.p,
+			                   reinterpret_cast<uint16_t *>(d_payload), reinterpret_cast<uint16_t *>(d_payload) + M.nnz, d_ovf.p, OVF_CAP);
 		} else
-			hipLaunchKernelGGL(place_columns_kernel, dim3(nc), dim3(256), 0, c.stream, d_desc.p, R.d_row.p, R.d_val.p,
-			                   static_cast<u32 *>(d_shared), static_cast<u32 *>(d_shared) + M.nnz);
+			hipLaunchKernelGGL(place_columns_kernel, dim3(nc), dim3(256), 0, c.stream, d_descr, R.d_row.p, R.d_val.p,
+			                   reinterpret_cast<u32 *>(d_payload), reinterpret_cast<u32 *>(d_payload) + M.nnz);
 		HIP_CHECK(hipGetLastError());
 	}
-	if (narrow) {   // the (rare) entries beyond 16 bits of every shard, gathered on the host
+	if (L.narrow) {   // the (rare) entries beyond 16 bits of every shard, gathered on the host
 		struct Ovf { u64 pos; u32 val, pad; };
 		std::vector<Ovf> mine, all;
-		if (placed) {
+		if (work) {
 			u32 count = 0;
 			c.fetch(&count, d_ovf.p, 4);
 			if (count > OVF_CAP) throw UnsupportedError("more than 2^16 matrix entries beyond 65534 on one shard: set the shard option narrow_matrix to 0");
@@ -1096,6 +1265,136 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 		std::sort(all.begin(), all.end(), [](const Ovf &a, const Ovf &b) { return a.pos < b.pos; });
 		for (const Ovf &o : all) { M.ovf_pos.push_back(o.pos); M.ovf_val.push_back(o.val); }
 	}
+}
+
+// cm_raw without a host table of all the real cells.  Its columns are the real cells of ALL shards in the order of ONE container's cell
+// ids = the stream ordinal of every cell's first read; on a shard the real cells stand in that order already (local ids are first-seen
+// ranks, and the blocks a shard received stand in stream order).  So the global matrix is a merge of `world` ascending lists:
+//   plan_raw           (host) this shard's columns, their nnz prefix; ONE small collective: columns, nnz and ordinal queries per shard
+//   assemble_raw_device        first-read ordinals on the device (the positions did not travel with a packed exchange: two small
+//                              device all-to-alls ask the sources), all-gather of (ordinal, nnz prefix) of every shard's columns --
+//                              16 bytes per column over the links --, then one thread per local column: binary searches in the other
+//                              shards' lists give its global place and nnz offset; it writes colptr / barcode of its column into
+//                              the shared buffer and the descriptor the placing kernel reads.
+// The host table (build_global_table) then holds the filtered candidates only.  Falls back to the host plan when a shard's cells are
+// not in ordinal order (never seen: a guard) or the option raw_on_device is off.
+bool dropest_shard::plan_raw() {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	Phase ph(this, "raw:plan");
+	RawPlan &P = raw_plan;
+	P.col_cell.clear(); P.col_start.clear(); P.query.clear(); P.pre.assign(1, 0);
+	const bool ask = exchanged && !idx_exchanged;
+	P.q_out.assign(size_t(world), 0);
+	uint64_t ok = raw_on_device ? 1 : 0;
+	u32 last = 0, src = 0;
+	for (const HostCell &h : c.real) {
+		if (h.merged || h.excluded || h.row.n_genes < c.min_before) continue;
+		const u32 pos = h.row.first_read;
+		if (pos == 0xFFFFFFFFu || (!P.col_cell.empty() && pos <= last)) { ok = 0; break; }
+		last = pos;
+		if (P.pre.back() + h.row.n_genes > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
+		P.col_cell.push_back(h.id); P.col_start.push_back(u32(P.pre.back())); P.pre.push_back(P.pre.back() + h.row.n_genes);
+		if (ask) {
+			while (src + 1 < u32(world) && pos >= recv_off[size_t(src) + 1]) ++src;
+			P.query.push_back(u32(pos - recv_off[src])); ++P.q_out[src];
+		} else
+			P.query.push_back(pos);
+	}
+	// [ok, columns, nnz, queries to shard 0 .. world-1] of every shard
+	const size_t w = 3 + size_t(world);
+	std::vector<uint64_t> mine(w, 0);
+	mine[0] = ok; mine[1] = P.col_cell.size(); mine[2] = P.pre.back();
+	for (int p = 0; p < world; ++p) mine[3 + size_t(p)] = P.q_out[size_t(p)];
+	P.counts.assign(w * size_t(world), 0);
+	tr->gather_host(mine.data(), w * 8, P.counts.data());
+	P.ncols = P.nnz = 0;
+	P.q_in.assign(size_t(world), 0);
+	for (int p = 0; p < world; ++p) {
+		const uint64_t *row = P.counts.data() + w * size_t(p);
+		ok &= row[0]; P.ncols += row[1]; P.nnz += row[2]; P.q_in[size_t(p)] = row[3 + size_t(rank)];
+	}
+	if (P.nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
+	return ok != 0;
+}
+
+void dropest_shard::assemble_raw_device() {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	Phase ph(this, "matrix:cm_raw");
+	RawPlan &P = raw_plan;
+	Mat &M = mat[1];
+	const size_t w = 3 + size_t(world);
+	const u32 nl = u32(P.col_cell.size());
+	const uint64_t ncols = P.ncols;
+	M.ncols = ncols; M.nnz = P.nnz; M.colptr.clear(); M.col_barcode.clear(); M.colptr32.clear();
+	// head of the shared buffer: colptr64[ncols + 1] | colptr32[ncols + 1] | barcodes[ncols]
+	const size_t off_c32 = (ncols + 1) * 8, off_bc = (off_c32 + (ncols + 1) * 4 + 15) & ~size_t(15), head = off_bc + ncols * 8;
+	const SharedLayout L = open_shared(M, 1, head);
+	M.colptr_p = reinterpret_cast<const u64 *>(L.host); M.colptr32_p = reinterpret_cast<const u32 *>(L.host + off_c32);
+	M.barcode_p = reinterpret_cast<const u64 *>(L.host + off_bc);
+	if (rank == 0) {   // the closing entry is nobody's column
+		reinterpret_cast<u64 *>(L.host)[ncols] = P.nnz;
+		reinterpret_cast<u32 *>(L.host + off_c32)[ncols] = u32(P.nnz);
+	}
+	// this shard's (first-read ordinal [nl] | nnz prefix [nl + 1])
+	d_plan_mine.ensure(2 * size_t(nl) + 1); d_q.ensure(std::max<u32>(nl, 1)); d_col_cell.ensure(std::max<u32>(nl, 1));
+	h_plan.ensure(size_t(nl) + 1 + size_t(nl));   // staging of its own (cm's descriptors may still be on their way from h_desc): prefix (u64) | queries, cells (u32)
+	std::memcpy(h_plan.p, P.pre.data(), (size_t(nl) + 1) * 8);
+	u32 *h32 = reinterpret_cast<u32 *>(h_plan.p + nl + 1);
+	if (nl) { std::memcpy(h32, P.query.data(), size_t(nl) * 4); std::memcpy(h32 + nl, P.col_cell.data(), size_t(nl) * 4); }
+	HIP_CHECK(hipMemcpyAsync(d_plan_mine.p + nl, h_plan.p, (size_t(nl) + 1) * 8, hipMemcpyHostToDevice, c.stream));
+	if (nl) {
+		HIP_CHECK(hipMemcpyAsync(d_q.p, h32, size_t(nl) * 4, hipMemcpyHostToDevice, c.stream));
+		HIP_CHECK(hipMemcpyAsync(d_col_cell.p, h32 + nl, size_t(nl) * 4, hipMemcpyHostToDevice, c.stream));
+	}
+	if (exchanged && !idx_exchanged) {
+		QueryTable t{};
+		t.world = u32(world);
+		uint64_t n_in = 0;
+		for (int p = 0; p < world; ++p) {
+			t.in_off[p] = n_in; n_in += P.q_in[size_t(p)]; t.part_off[p] = send_off[size_t(p)]; t.first_ord[p] = first_ord[size_t(p)];
+			t.out_off[p + 1] = t.out_off[p] + P.q_out[size_t(p)];
+		}
+		t.in_off[world] = n_in;
+		d_q_in.ensure(std::max<uint64_t>(n_in, 1)); d_q_ans.ensure(std::max<uint64_t>(n_in, 1)); d_q_back.ensure(std::max<u32>(nl, 1));
+		{ const void *snd[1] = {d_q.p}; void *rcv[1] = {d_q_in.p}; const size_t elem[1] = {4};
+		  tr->exchange(1, snd, rcv, elem, P.q_out.data(), P.q_in.data(), c.stream); }
+		if (n_in) {
+			hipLaunchKernelGGL(answer_queries_kernel, dim3(u32((n_in + 255) / 256)), dim3(256), 0, c.stream, t, d_q_in.p, u32(n_in), p_idx.p, d_q_ans.p);
+			HIP_CHECK(hipGetLastError());
+		}
+		{ const void *snd[1] = {d_q_ans.p}; void *rcv[1] = {d_q_back.p}; const size_t elem[1] = {4};
+		  tr->exchange(1, snd, rcv, elem, P.q_in.data(), P.q_out.data(), c.stream); }
+		if (nl) hipLaunchKernelGGL(ordinals_from_answers_kernel, dim3((nl + 255) / 256), dim3(256), 0, c.stream, t, d_q_back.p, nl, reinterpret_cast<unsigned long long *>(d_plan_mine.p));
+	} else if (nl)
+		hipLaunchKernelGGL(ordinals_kernel, dim3((nl + 255) / 256), dim3(256), 0, c.stream, ordinal_map(), d_q.p, nl, reinterpret_cast<unsigned long long *>(d_plan_mine.p));
+	HIP_CHECK(hipGetLastError());
+	// every shard's block to every shard
+	RawPlanTable pt{};
+	pt.world = u32(world); pt.rank = u32(rank);
+	std::vector<size_t> off(static_cast<size_t>(world), 0), bytes(static_cast<size_t>(world), 0);
+	size_t total = 0;
+	for (int p = 0; p < world; ++p) {
+		const uint64_t n_p = P.counts[w * size_t(p) + 1];
+		pt.off[p] = total; pt.n[p] = u32(n_p);
+		off[size_t(p)] = total * 8; bytes[size_t(p)] = (2 * size_t(n_p) + 1) * 8;
+		total += 2 * size_t(n_p) + 1;
+	}
+	d_plan_all.ensure(total);
+	tr->gather_dev(d_plan_mine.p, d_plan_all.p, off.data(), bytes.data(), c.stream);
+	d_desc.ensure(std::max<size_t>(3 * size_t(nl), 1));
+	if (nl) {
+		char *d_head = static_cast<char *>(L.dev);
+		hipLaunchKernelGGL(plan_raw_columns_kernel, dim3((nl + 255) / 256), dim3(256), 0, c.stream, pt, reinterpret_cast<const unsigned long long *>(d_plan_all.p),
+		                   d_col_cell.p, reinterpret_cast<const unsigned long long *>(c.cell_cb.p), nl, reinterpret_cast<unsigned long long *>(d_desc.p),
+		                   reinterpret_cast<unsigned long long *>(d_head), reinterpret_cast<uint32_t *>(d_head + off_c32),
+		                   reinterpret_cast<unsigned long long *>(d_head + off_bc));
+		HIP_CHECK(hipGetLastError());
+	}
+	const uint64_t local_nnz = P.pre.back();
+	if (nl && local_nnz) c.emit_columns_device(false, false, P.col_cell, P.col_start, local_nnz);
+	place_columns(M, 1, false, L, reinterpret_cast<const unsigned long long *>(d_desc.p), nl, local_nnz);
 }
 
 void dropest_shard::step() {
@@ -1163,11 +1462,36 @@ void dropest_shard::step() {
 		throw UnsupportedError("sharded runs support the merges with a barcode whitelist (-m, -M with barcodes) only; run the other merge strategies on one GPU");
 	{ Phase ph(this, "finalize"); c.run_merge_and_filter(); }
 	merged_pending = world == 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE;   // one shard: the context's own pairs, named when asked for
+	raw_device_now = plan_raw();
 	build_global_table();
 	assemble_matrix(true);
-	assemble_matrix(false);
+	if (raw_device_now) assemble_raw_device(); else assemble_matrix(false);
 	{ Phase ph(this, "matrix:wait"); HIP_CHECK(stream_wait(c.stream)); tr->barrier(); }
+	if (byte_matrix) { Phase ph(this, "matrix:lists"); collect_lists(mat[0]); collect_lists(mat[1]); }
 	c.collect_timings();
+}
+
+// the byte form's lists: every shard's segment of the shared buffer (written through its PCIe link, complete after the barrier)
+// -> one list of a kind; a shard that had more than list_cap entries to list fails the step on every shard alike
+void dropest_shard::collect_lists(Mat &M) {
+	using namespace dropest;
+	if (!M.bytes || M.lists_ready) return;
+	size_t nr = 0, nv = 0;
+	for (int p = 0; p < world; ++p) {
+		const u32 *w = reinterpret_cast<const u32 *>(M.segments + M.seg_bytes * size_t(p));
+		if (w[0] > M.list_cap || w[1] > M.list_cap)
+			throw UnsupportedError("more than " + std::to_string(M.list_cap) + " listed entries of a byte-form matrix on shard " + std::to_string(p) + ": set the shard option byte_matrix to 0");
+		nr += w[0]; nv += w[1];
+	}
+	M.rl_pos.resize(nr); M.rl_row.resize(nr); M.vl_pos.resize(nv); M.vl_val.resize(nv);
+	size_t ar = 0, av = 0;
+	for (int p = 0; p < world; ++p) {
+		const u32 *w = reinterpret_cast<const u32 *>(M.segments + M.seg_bytes * size_t(p));
+		const u32 *l = w + 4;
+		if (w[0]) { std::memcpy(M.rl_pos.data() + ar, l, size_t(w[0]) * 4); std::memcpy(M.rl_row.data() + ar, l + M.list_cap, size_t(w[0]) * 4); ar += w[0]; }
+		if (w[1]) { std::memcpy(M.vl_pos.data() + av, l + 2 * size_t(M.list_cap), size_t(w[1]) * 4); std::memcpy(M.vl_val.data() + av, l + 3 * size_t(M.list_cap), size_t(w[1]) * 4); av += w[1]; }
+	}
+	M.lists_ready = true;
 }
 
 // N-UMI merge across shards (umi_merge_host.h): global first occurrences of the tie candidates, offsets into the ONE rand()
@@ -1434,7 +1758,15 @@ dropest_status dropest_shard_matrix(dropest_shard *s, int filtered, uint64_t *nc
 		if (!s || !ncols || !nnz) throw InvalidError("null argument");
 		dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
 		*ncols = M.ncols; *nnz = M.nnz;
-		if (colptr) *colptr = reinterpret_cast<const uint64_t *>(M.colptr.data());
+		if (colptr) *colptr = reinterpret_cast<const uint64_t *>(M.colptr_p ? M.colptr_p : M.colptr.data());
+		if (M.bytes && (rowidx || values) && !M.widened) {    // the pass produced the byte form: decoded here, once, on host threads
+			s->collect_lists(M);
+			M.wide_rows.resize(M.nnz); M.wide_vals.resize(M.nnz);
+			dropest_matrix_bytes mb{M.ncols, M.nnz, M.colptr32_p, M.delta8, M.vals8, M.rl_pos.size(), M.rl_pos.data(), M.rl_row.data(),
+			                        M.vl_pos.size(), M.vl_pos.data(), M.vl_val.data()};
+			if (M.nnz && dropest_matrix_bytes_widen(&mb, M.wide_rows.data(), M.wide_vals.data()) != DROPEST_OK) throw InvalidError(dropest_last_error());
+			M.rows = M.wide_rows.data(); M.vals = M.wide_vals.data(); M.widened = true;
+		}
 		if (M.narrow && (rowidx || values) && !M.widened) {   // the pass produced the 16-bit form: the 32-bit view is made here, once
 			M.wide_rows.resize(M.nnz); M.wide_vals.resize(M.nnz);
 			dropest::parallel_ranges(M.nnz, [&](size_t b, size_t e, unsigned) { for (size_t i = b; i < e; ++i) { M.wide_rows[i] = M.rows16[i]; M.wide_vals[i] = M.vals16[i]; } }, 1 << 20, 16);
@@ -1443,7 +1775,7 @@ dropest_status dropest_shard_matrix(dropest_shard *s, int filtered, uint64_t *nc
 		}
 		if (rowidx) *rowidx = M.rows;
 		if (values) *values = M.vals;
-		if (col_barcodes) *col_barcodes = reinterpret_cast<const uint64_t *>(M.col_barcode.data());
+		if (col_barcodes) *col_barcodes = reinterpret_cast<const uint64_t *>(M.barcode_p ? M.barcode_p : M.col_barcode.data());
 	});
 }
 
@@ -1453,13 +1785,26 @@ dropest_status dropest_shard_matrix_narrow(dropest_shard *s, int filtered, uint6
 	return guarded([&] {
 		if (!s || !ncols || !nnz || !rowidx || !values || !n_overflow || !overflow_pos || !overflow_val) throw InvalidError("null argument");
 		const dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
-		if (!M.narrow && M.nnz) throw UnsupportedError("the last step produced the 32-bit matrices (gene ids beyond 65535, or the option narrow_matrix is off)");
+		if (!M.narrow && M.nnz) throw UnsupportedError("the last step did not produce the 16-bit matrices (the option byte_matrix is on, gene ids beyond 65535, or the option narrow_matrix is off)");
 		*ncols = M.ncols; *nnz = M.nnz;
-		if (colptr) *colptr = reinterpret_cast<const uint64_t *>(M.colptr.data());
+		if (colptr) *colptr = reinterpret_cast<const uint64_t *>(M.colptr_p ? M.colptr_p : M.colptr.data());
 		*rowidx = M.rows16; *values = M.vals16;
-		if (col_barcodes) *col_barcodes = reinterpret_cast<const uint64_t *>(M.col_barcode.data());
+		if (col_barcodes) *col_barcodes = reinterpret_cast<const uint64_t *>(M.barcode_p ? M.barcode_p : M.col_barcode.data());
 		*n_overflow = M.ovf_pos.size();
 		*overflow_pos = reinterpret_cast<const uint64_t *>(M.ovf_pos.data()); *overflow_val = M.ovf_val.data();
+	});
+}
+
+dropest_status dropest_shard_matrix_bytes(dropest_shard *s, int filtered, dropest_matrix_bytes *out, const uint64_t **col_barcodes) {
+	return guarded([&] {
+		if (!s || !out) throw InvalidError("null argument");
+		dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
+		if (!M.bytes && M.nnz) throw UnsupportedError("the last step did not produce the byte-form matrices (the shard option byte_matrix is off)");
+		s->collect_lists(M);
+		static const uint32_t zero = 0;
+		*out = dropest_matrix_bytes{M.ncols, M.nnz, M.bytes ? M.colptr32_p : &zero, M.delta8, M.vals8, M.rl_pos.size(), M.rl_pos.data(), M.rl_row.data(),
+		                            M.vl_pos.size(), M.vl_pos.data(), M.vl_val.data()};
+		if (col_barcodes) *col_barcodes = reinterpret_cast<const uint64_t *>(M.barcode_p ? M.barcode_p : M.col_barcode.data());
 	});
 }
 
@@ -1521,6 +1866,9 @@ dropest_status dropest_shard_set_option(dropest_shard *s, const char *key, int64
 		else if (k == "force_exchange") s->force_exchange = value != 0;
 		else if (k == "reset_phase_stats") s->phases.clear();
 		else if (k == "narrow_matrix") s->narrow_matrix = value != 0;
+		else if (k == "byte_matrix") s->byte_matrix = value != 0;
+		else if (k == "raw_on_device") s->raw_on_device = value != 0;
+		else if (k == "byte_list_cap") s->byte_list_cap = value > 0 ? uint64_t((value + 15) & ~15ll) : 0;
 		else if (k == "packed_exchange") s->allow_packed = value != 0;
 		else throw InvalidError("unknown shard option: " + k);
 	});

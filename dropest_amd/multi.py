@@ -105,6 +105,14 @@ class Shard:
         return (view(p, ncols.value + 1, C.c_uint64, np.uint64), view(r, nnz.value, C.c_uint16, np.uint16), view(v, nnz.value, C.c_uint16, np.uint16),
                 view(b, ncols.value, C.c_uint64, np.uint64), view(op, novf.value, C.c_uint64, np.uint64), view(ov, novf.value, C.c_uint32, np.uint32))
 
+    def matrix_bytes(self, filtered):
+        """ShardBytes of the GLOBAL matrix in the byte form the step wrote (dropest_shard_matrix_bytes); raises DropestError when
+        the shard option byte_matrix is off."""
+        m, b = capi.MatrixBytes(), C.c_void_p()
+        self._chk(self.L.dropest_shard_matrix_bytes(self.h, int(filtered), C.byref(m), C.byref(b)))
+        bc = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint64)), shape=(m.ncols,)) if m.ncols and b.value else np.zeros(0, np.uint64)
+        return ShardBytes(self.L, m, bc)
+
     def merged_barcodes(self):
         n = C.c_uint64()
         self._chk(self.L.dropest_shard_merged_barcodes(self.h, C.byref(n), None, None))
@@ -121,8 +129,37 @@ class Shard:
         return {arr[i].name.decode(): {"steps": arr[i].launches, "ms": arr[i].ms, "bytes": arr[i].bytes} for i in range(n.value)}
 
 
+class ShardBytes:
+    """A global matrix in the byte form (dropest_matrix_bytes + the column barcodes); widen() decodes it on host threads."""
+
+    def __init__(self, lib, m, col_barcodes):
+        self.L, self.m, self.col_barcodes = lib, m, col_barcodes
+        self.ncols, self.nnz = int(m.ncols), int(m.nnz)
+        self.n_row_listed, self.n_value_listed = int(m.n_row_listed), int(m.n_value_listed)
+
+    def __len__(self):
+        return 4
+
+    def __getitem__(self, i):
+        if i == 3:
+            return self.col_barcodes
+        return self.widen()[i]
+
+    def widen(self):
+        if not hasattr(self, "_wide"):
+            colptr = (np.ctypeslib.as_array(C.cast(self.m.colptr, C.POINTER(C.c_uint32)), shape=(self.ncols + 1,)).astype(np.uint64)
+                      if self.ncols else np.zeros(1, np.uint64))
+            rows, vals = np.zeros(self.nnz, np.uint32), np.zeros(self.nnz, np.uint32)
+            if self.nnz and self.L.dropest_matrix_bytes_widen(C.byref(self.m), rows.ctypes.data, vals.ctypes.data) != 0:
+                raise capi.DropestError(-1, self.L.dropest_last_error().decode())
+            self._wide = (colptr, rows, vals, self.col_barcodes)
+        return self._wide
+
+
 def widen_shard_matrix(m):
-    """(colptr, rowidx u32, values u32, column barcodes) from what ShardedRun.step returns (narrow 6-tuple or wide 4-tuple)."""
+    """(colptr, rowidx u32, values u32, column barcodes) from what ShardedRun.step returns (byte form, narrow 6-tuple or wide 4-tuple)."""
+    if isinstance(m, ShardBytes):
+        return m.widen()
     if len(m) == 4:
         return m
     colptr, r16, v16, bc, opos, oval = m
@@ -219,11 +256,14 @@ class ShardedRun:
         self.shard.step()
         if self.rank != 0:
             return None, None, None
-        try:      # the narrow form when the step wrote it (every gene id below 65536): no widening on the host
-            cm, raw = self.shard.matrix_narrow(True), self.shard.matrix_narrow(False)
+        try:      # the form the step wrote: bytes (the default), 16-bit, or 32-bit -- no widening on the host here
+            cm, raw = self.shard.matrix_bytes(True), self.shard.matrix_bytes(False)
         except capi.DropestError:
-            cm, raw = self.shard.matrix(True), self.shard.matrix(False)
-        return cm, raw, cm[3]
+            try:
+                cm, raw = self.shard.matrix_narrow(True), self.shard.matrix_narrow(False)
+            except capi.DropestError:
+                cm, raw = self.shard.matrix(True), self.shard.matrix(False)
+        return cm, raw, (cm.col_barcodes if isinstance(cm, ShardBytes) else cm[3])
 
     def set_profiling(self, on, only=None):
         self.shard.ctx.set_profiling(on, only=only)

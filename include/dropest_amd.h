@@ -516,11 +516,18 @@ dropest_status dropest_shard_group_step(dropest_shard *const *shards, int32_t n)
 dropest_status dropest_shard_matrix(dropest_shard *shard, int filtered, uint64_t *ncols, uint64_t *nnz, const uint64_t **colptr,
                                     const uint32_t **rowidx, const uint32_t **values, const uint64_t **col_barcodes);
 /* The same matrix in the narrow form (see dropest_count_matrix_csc_narrow): what the step writes when every gene id fits 16 bits
- * and the shard option "narrow_matrix" is on (the default) -- each shard then puts half the bytes on its PCIe link; with it
+ * the shard option "narrow_matrix" is on (the default) and "byte_matrix" is OFF -- each shard then puts half the bytes on its PCIe link; with it
  * dropest_shard_matrix widens on the host on first use.  overflow_pos = GLOBAL entry indices, ascending. */
 dropest_status dropest_shard_matrix_narrow(dropest_shard *shard, int filtered, uint64_t *ncols, uint64_t *nnz, const uint64_t **colptr,
                                            const uint16_t **rowidx, const uint16_t **values, const uint64_t **col_barcodes,
                                            uint64_t *n_overflow, const uint64_t **overflow_pos, const uint32_t **overflow_val);
+/* The same matrix in the BYTE form (see dropest_matrix_bytes above; colptr is 32-bit here as there: a byte-form matrix has fewer than
+ * 2^32 entries): what the step writes by default (shard option "byte_matrix", on; it wins over "narrow_matrix") -- every shard puts two
+ * bytes per entry on its PCIe link, straight into the node-shared buffer, and appends what does not fit a byte to its own segment of
+ * that buffer; the lists returned here are the segments of all shards, one after the other.  dropest_matrix_bytes_widen decodes it;
+ * dropest_shard_matrix does that on first use.  A shard with more than min(2^20, nnz) listed entries of a kind fails the step with
+ * DROPEST_ERR_UNSUPPORTED (switch byte_matrix off). */
+dropest_status dropest_shard_matrix_bytes(dropest_shard *shard, int filtered, dropest_matrix_bytes *out, const uint64_t **col_barcodes);
 /* (source, target) barcodes of the cells the CB merge folded, ascending source: CellsDataContainer::merge_targets by barcode */
 dropest_status dropest_shard_merged_barcodes(dropest_shard *shard, uint64_t *n, uint64_t *source, uint64_t *target);
 /* The column order of a global matrix from the all-gathered table of the real cells, as every shard computes it (host logic
@@ -534,7 +541,8 @@ dropest_status dropest_plan_columns(uint64_t n, const uint64_t *barcode, const u
 /* wall time per phase of the steps so far (name, steps, ms; bytes = what this shard put on the links in "all_to_all") */
 dropest_status dropest_shard_phase_stats(dropest_shard *shard, uint32_t *n, dropest_kernel_stat *out);
 /* "trace" (synchronise the device at every phase boundary: diagnostic), "force_exchange" (partition + all-to-all even with
- * one shard: measures what a second shard would add), "reset_phase_stats" */
+ * one shard: measures what a second shard would add), "reset_phase_stats", "byte_matrix" / "narrow_matrix" (the form the step writes
+ * the matrices in: bytes by default, else 16-bit when every gene id fits, else 32-bit), "packed_exchange" */
 dropest_status dropest_shard_set_option(dropest_shard *shard, const char *key, int64_t value);
 
 /* Sort keys wider than 64 bits.  The reference's containers have no such limit (StringIndexer.cpp:10-18: ids are size_t); one

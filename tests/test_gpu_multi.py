@@ -289,15 +289,75 @@ def test_one_shard_over_rccl_and_forced_exchange():
     dev = s.generate_device(0)
     c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
     c.set_initialized(); c.merge_and_filter()
-    assert len(cm) == 6 and cm[1].dtype == np.uint16        # the step wrote the narrow form (gene ids below 65536)
+    from dropest_amd.multi import ShardBytes
+    assert isinstance(cm, ShardBytes) and cm.nnz > 1000 and raw.n_row_listed > 0   # the step wrote the byte form (the default)
     got = {"cm": widen_shard_matrix(cm), "raw": widen_shard_matrix(raw), "merged": run.merge_pairs}
     check(got, c)
     wide = run.shard.matrix(True)                            # ... and the 32-bit accessor widens it on the host
     assert all(np.array_equal(a, b) for a, b in zip(wide, got["cm"]))
+    run.shard.set_option("byte_matrix", 0)                   # the 16-bit form (gene ids below 65536) of the same pass
+    cm16, raw16, _ = run.step()
+    assert len(cm16) == 6 and cm16[1].dtype == np.uint16
+    for a, b in ((cm16, cm), (raw16, raw)):
+        assert all(np.array_equal(x, y) for x, y in zip(widen_shard_matrix(a), widen_shard_matrix(b)))
+    run.shard.set_option("narrow_matrix", 0)                 # ... and the 32-bit one
+    cm32, raw32, _ = run.step()
+    assert len(cm32) == 4 and all(np.array_equal(x, y) for x, y in zip(raw32, widen_shard_matrix(raw)))
+    run.shard.set_option("byte_matrix", 1)
     ph = run.shard.phase_stats()
     assert ph["exchange_record_bytes"]["bytes"] == 12        # barcode + UMI in 64 bits, gene + mark + chromosome in 32
-    assert ph["partition"]["steps"] == 2 and ph["all_to_all"]["steps"] == 2
+    assert ph["partition"]["steps"] == 4 and ph["all_to_all"]["steps"] == 4
     dev.free()
+
+
+def test_matrix_forms_of_a_group_agree():
+    """Three shards, the three forms the step can write the global matrices in (shard options byte_matrix / narrow_matrix): the
+    byte form -- every shard's deltas and values at their global places, its listed entries in its own segment of the shared
+    buffer -- decodes to the 16-bit and the 32-bit one; a shard that would have to list more than the segment holds fails the
+    step loudly on every shard."""
+    s = SynthStream(n_reads=400_000, n_cells=60, n_genes=9000, umi_len=8, permille_neighbour=50)
+    arrays = parity.canonical_stream(*s.generate_host())
+    arrays[0][::97] = arrays[0][0]; arrays[2][::97] = arrays[2][0]; arrays[3][::97] = arrays[3][0]   # ~4000 UMIs of one gene in one cell: a value beyond a byte
+    n = len(arrays[0])
+    bounds = [0, n // 5, n // 2, n]
+    g = ShardGroup([0, 0, 0], **cfg_kwargs({"min_before": 1, "min_after": 5}))
+    for i, sh in enumerate(g.shards):
+        sh.set_reads(capi.DeviceArrays.from_host(0, *[a[bounds[i]:bounds[i + 1]] for a in arrays]), bounds[i])
+    forms = {}
+    for name, opts in (("bytes", {"byte_matrix": 1}), ("u16", {"byte_matrix": 0, "narrow_matrix": 1}), ("u32", {"byte_matrix": 0, "narrow_matrix": 0})):
+        for sh in g.shards:
+            for k, v in opts.items():
+                sh.set_option(k, v)
+        g.step()
+        s0 = g.shards[0]
+        if name == "bytes":
+            for filtered in (True, False):
+                b = s0.matrix_bytes(filtered)
+                assert b.nnz > 5000 and b.n_row_listed > 100 and b.n_value_listed >= 1
+            with pytest.raises(capi.DropestError):
+                s0.matrix_narrow(True)
+        else:
+            with pytest.raises(capi.DropestError):
+                s0.matrix_bytes(True)
+        forms[name] = [[x.copy() for x in s0.matrix(f)] for f in (True, False)]
+    for name in ("u16", "u32"):
+        for a, b in zip(forms["bytes"], forms[name]):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), name
+    c = single(arrays, cfg_kwargs({"min_before": 1, "min_after": 5}))
+    check({"cm": forms["bytes"][0], "raw": forms["bytes"][1], "merged": (np.zeros(0, np.uint64),) * 2}, c)
+    assert forms["bytes"][0][2].max() > 1000
+    for sh in g.shards:                               # cm_raw planned on the host from the table of all real cells (the fallback)
+        sh.set_option("byte_matrix", 1); sh.set_option("raw_on_device", 0)
+    g.step()
+    ph = g.shards[0].phase_stats()
+    assert "order:cm_raw" in ph and ph["raw:plan"]["steps"] == 4
+    for f, want in zip((True, False), forms["bytes"]):
+        assert all(np.array_equal(x, y) for x, y in zip(g.shards[0].matrix(f), want))
+    for sh in g.shards:
+        sh.set_option("raw_on_device", 1); sh.set_option("byte_list_cap", 16)
+    with pytest.raises(capi.DropestError, match="listed entries"):
+        g.step()
+    g.close()
 
 
 @pytest.mark.parametrize("world", [2, 3])
