@@ -384,7 +384,7 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
                 exchange = {"record_bytes": rec, "bytes_out_per_gpu_per_step": a2a["bytes"] / max(1, a2a["steps"]), "ms_per_step": round(a2a["ms"] / max(1, a2a["steps"]), 3),
                             "bytes_a_gpu_would_put_on_its_links_at_world_N": {str(N): reads_per_gpu * rec * (N - 1) / N for N in (2, 4, 8)},
                             "GB_per_s_per_gpu": round(a2a["bytes"] / a2a["ms"] / 1e6, 1), "GB_per_s_per_link": round(a2a["bytes"] / a2a["ms"] / 1e6 / links, 1),
-                            "links": links, "transport": "RCCL grouped ncclSend/ncclRecv over xGMI" if world > 1 else "RCCL to itself (one GPU)"}
+                            "links": links, "transport": "RCCL grouped ncclSend/ncclRecv over xGMI" if world > 1 else "one GPU: no peer -- the block a shard keeps is unpacked where the partition left it (no copy), so nothing moves here; the links' share is the table above"}
         cpu = None
         if world == 1 and args.cpu_sample > 0:
             cpu = cpu_baseline(stream, int(min(args.cpu_sample, total_reads)), cfg, config.upper())
@@ -475,6 +475,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    rccl_came_up = False
     line = measure(args, args.config, int(args.reads), args.cells, args.steps, args.warmup, world, rank, local_rank, dist, force_sharded, True)
     # The largest single-GPU configuration of BASELINE.json (configs[2], "C3": 1e9 reads, 50 000 cells, whitelist CB merge) rides
     # along with the default run as `secondary.c3_1e9` -- same clock, same fences, 3 timed steps after 1 warm-up (24 GB of reads).
@@ -486,12 +487,36 @@ def main():
                                                                 "kernels_ms_per_step", "host_stage_wall_ms_per_step")}}
         except Exception as e:   # the primary line must not be lost to the secondary workload
             line["secondary"] = {"c3_1e9": {"error": "%s: %s" % (type(e).__name__, e)}}
+        # ... and the primary workload once more through the sharded runner with the exchange forced (what `--sharded` runs: partition by
+        # owner, RCCL all-to-all to itself, unpack, device-planned cm_raw, byte-form matrices into the shared buffer): what a second
+        # GPU would add to every pass, under the same clock.  `x_plain` = its ms_per_step / the primary line's.
+        try:
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)          # (RCCL's banner)
+            cpu_sample, args.cpu_sample = args.cpu_sample, 0
+            try:
+                sh = measure(args, "c2", 100_000_000, args.cells, args.steps, args.warmup, world, rank, local_rank, dist, True, False)
+            finally:
+                args.cpu_sample = cpu_sample
+                sys.stdout.flush()
+                import ctypes
+                ctypes.CDLL(None).fflush(None)   # RCCL's banner sits in the C library's buffer: out with it while fd 1 is stderr
+                os.dup2(keep, 1)
+                os.close(keep)
+                rccl_came_up = True
+            line["secondary"]["c2_sharded_runner"] = dict({k: sh[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "step_ms", "exchange")},
+                                                          x_plain=round(sh["ms_per_step"] / line["ms_per_step"], 3),
+                                                          parallelism=sh["config"]["parallelism"], matrix_form=sh["config"]["matrix_form"],
+                                                          phases_ms_per_step={k: v for k, v in sh["host_stage_wall_ms_per_step"].items() if k.startswith("shard:")})
+        except Exception as e:
+            line["secondary"]["c2_sharded_runner"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
-        if saved_stdout is not None:
+        if saved_stdout is not None or rccl_came_up:
             os.dup2(2, 1)          # whatever RCCL still prints while the communicator goes down belongs on stderr
     if dist is not None:
         dist.barrier()

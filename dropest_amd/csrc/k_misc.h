@@ -504,14 +504,19 @@ __device__ inline void exchange_pack(const ExchangePack &p, unsigned long long c
 	w0 = cb | (umi << p.cb_bits);
 	w1 = (gene == 0xFFFFFFFFu ? gmask : gene) | (((aux >> 16) & 7u) << p.gene_bits) | ((aux & 0xFFFFu) << (p.gene_bits + 3));
 }
+// records [own_lo, own_hi) are the block this shard kept: it never moved -- read where the partition left it (own_w0 / own_w1 point at
+// the record that stands at own_lo)
 __global__ __launch_bounds__(256) void exchange_unpack_kernel(const unsigned long long *__restrict__ w0, const uint32_t *__restrict__ w1, uint32_t n, ExchangePack p,
                                                               unsigned long long *__restrict__ cb, unsigned long long *__restrict__ umi,
-                                                              uint32_t *__restrict__ gene, uint32_t *__restrict__ aux) {
+                                                              uint32_t *__restrict__ gene, uint32_t *__restrict__ aux,
+                                                              uint32_t own_lo, uint32_t own_hi, const unsigned long long *__restrict__ own_w0,
+                                                              const uint32_t *__restrict__ own_w1) {
 	const uint32_t gmask = (1u << p.gene_bits) - 1u;
 	const unsigned long long cmask = p.cb_bits >= 64 ? ~0ull : ((1ull << p.cb_bits) - 1ull);
 	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-		const unsigned long long a = w0[i];
-		const uint32_t b = w1[i];
+		const bool own = i >= own_lo && i < own_hi;
+		const unsigned long long a = own ? own_w0[i - own_lo] : w0[i];
+		const uint32_t b = own ? own_w1[i - own_lo] : w1[i];
 		cb[i] = a & cmask;
 		umi[i] = p.cb_bits >= 64 ? 0ull : a >> p.cb_bits;
 		const uint32_t g = b & gmask;

@@ -83,8 +83,9 @@ struct Transport {
 	virtual const char *name() const = 0;
 	// all-to-all(v) of n_arrays device arrays at once: array a has elem[a]-byte elements; the block for peer p starts at
 	// element sum(send_cnt[< p]) of d_send[a] and lands at element sum(recv_cnt[< p]) of d_recv[a].  Returns when done.
+	// in_place: bit a set = the block of array a that stays on this shard is NOT copied (the caller reads it in d_send[a])
 	virtual void exchange(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
-	                      const uint64_t *recv_cnt, hipStream_t st) = 0;
+	                      const uint64_t *recv_cnt, hipStream_t st, uint32_t in_place = 0) = 0;
 	virtual void gather_host(const void *mine, size_t bytes, void *all) = 0;   // all: world x bytes, rank order
 	// every shard's device block to every shard: block of rank p = bytes[p] at d_all + off[p]
 	virtual void gather_dev(const void *d_mine, void *d_all, const size_t *off, const size_t *bytes, hipStream_t st) = 0;
@@ -156,7 +157,7 @@ struct LocalTransport : Transport {
 	const char *name() const override { return "local"; }
 	struct Pub { const void *const *d_send; const size_t *elem; const uint64_t *send_cnt; };
 	void exchange(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
-	              const uint64_t *recv_cnt, hipStream_t st) override {
+	              const uint64_t *recv_cnt, hipStream_t st, uint32_t in_place = 0) override {
 		HIP_CHECK(stream_wait(st));   // the blocks the peers copy were written on this stream
 		Pub pub{d_send, elem, send_cnt};
 		hub->p0[size_t(rank)] = &pub;
@@ -167,7 +168,7 @@ struct LocalTransport : Transport {
 			uint64_t soff = 0;
 			for (int q = 0; q < rank; ++q) soff += src->send_cnt[q];
 			for (int a = 0; a < n_arrays; ++a)
-				if (recv_cnt[p])
+				if (recv_cnt[p] && !(p == rank && (in_place >> a & 1u)))
 					HIP_CHECK(hipMemcpyAsync(static_cast<char *>(d_recv[a]) + roff * elem[a], static_cast<const char *>(src->d_send[a]) + soff * elem[a],
 					                         size_t(recv_cnt[p]) * elem[a], hipMemcpyDefault, st));
 			roff += recv_cnt[p];
@@ -234,14 +235,14 @@ struct RcclTransport : Transport {
 	}
 	const char *name() const override { return "rccl"; }
 	void exchange(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
-	              const uint64_t *recv_cnt, hipStream_t st) override {
+	              const uint64_t *recv_cnt, hipStream_t st, uint32_t in_place = 0) override {
 		const RcclApi &api = RcclApi::get();
 		// the block a shard keeps never leaves the device: a plain copy (a self send / recv pair moves it at a fifth of the rate)
 		{
 			uint64_t soff = 0, roff = 0;
 			for (int p = 0; p < rank; ++p) { soff += send_cnt[p]; roff += recv_cnt[p]; }
 			for (int a = 0; a < n_arrays; ++a)
-				if (send_cnt[rank]) HIP_CHECK(hipMemcpyAsync(static_cast<char *>(d_recv[a]) + roff * elem[a], static_cast<const char *>(d_send[a]) + soff * elem[a],
+				if (send_cnt[rank] && !(in_place >> a & 1u)) HIP_CHECK(hipMemcpyAsync(static_cast<char *>(d_recv[a]) + roff * elem[a], static_cast<const char *>(d_send[a]) + soff * elem[a],
 				                                             size_t(send_cnt[rank]) * elem[a], hipMemcpyDeviceToDevice, st));
 		}
 		api.check(api.GroupStart(), "ncclGroupStart");
@@ -772,7 +773,7 @@ void dropest_shard::partition_and_exchange() {
 			const void *snd[3] = {p_w0.p, p_w1.p, p_idx.p};
 			void *rcv[3] = {x_w0.p, x_w1.p, x_idx.p};
 			const size_t elem[3] = {8, 4, 4};
-			tr->exchange(idx_exchanged ? 3 : 2, snd, rcv, elem, send_cnt.data(), recv_cnt.data(), c.stream);
+			tr->exchange(idx_exchanged ? 3 : 2, snd, rcv, elem, send_cnt.data(), recv_cnt.data(), c.stream, 3u);   // w0 / w1 of the own block: unpacked in place
 		} else {
 			const void *snd[5] = {p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p};
 			void *rcv[5] = {x_cb.p, x_umi.p, x_gene.p, x_aux.p, x_idx.p};
@@ -802,7 +803,8 @@ void dropest_shard::partition_and_exchange() {
 		if (packed && n_recv) {
 			Phase ph2(this, "unpack");
 			hipLaunchKernelGGL(exchange_unpack_kernel, dim3(u32(std::min<uint64_t>((n_recv + 255) / 256, 8192))), dim3(256), 0, c.stream, x_w0.p, x_w1.p, u32(n_recv), pack,
-			                   x_cb.p, x_umi.p, x_gene.p, x_aux.p);
+			                   x_cb.p, x_umi.p, x_gene.p, x_aux.p, u32(recv_off[size_t(rank)]), u32(recv_off[size_t(rank) + 1]),
+			                   p_w0.p + send_off[size_t(rank)], p_w1.p + send_off[size_t(rank)]);
 			HIP_CHECK(hipGetLastError());
 		}
 	}
