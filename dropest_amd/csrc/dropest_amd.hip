@@ -241,7 +241,7 @@ void dropest_ctx::build_cb_table() {
 		// most CB_HOT_MAX barcodes (C2: the 5 000 real cells carry 92 % of the reads)
 		HIP_CHECK(hipMemsetAsync(scalars.p + 4, 0, 4 * CB_HOT_LEVELS, stream));
 		const bool want_hot = !getenv("DROPEST_CB_NO_HOT");
-		if (want_hot) hipLaunchKernelGGL(cb_hot_count_kernel, dim3(1024), dim3(256), 0, stream, ts, scalars.p + 4);
+		if (want_hot) timed("cb_hot_count", double(cap_s) * sizeof(CbSlot), [&] { hipLaunchKernelGGL(cb_hot_count_kernel, dim3(256), dim3(256), 0, stream, ts, scalars.p + 4); });
 		u32 head[4 + CB_HOT_LEVELS] = {0};
 		fetch(head, scalars.p, sizeof(head));
 		const u32 distinct = head[0];
@@ -259,8 +259,9 @@ void dropest_ctx::build_cb_table() {
 			if (level >= 0 && head[4 + level] >= 16) {
 				hot_key.ensure(CB_HOT_MAX); hot_slot.ensure(CB_HOT_MAX);
 				HIP_CHECK(hipMemsetAsync(scalars.p + 1, 0, 4, stream));
-				hipLaunchKernelGGL(cb_hot_collect_kernel, dim3(1024), dim3(256), 0, stream, ts, cb_hot_threshold(level), hot_key.p, scalars.p + 1);
-				HIP_CHECK(hipGetLastError());
+				timed("cb_hot_collect", double(cap_s) * sizeof(CbSlot), [&] {
+					hipLaunchKernelGGL(cb_hot_collect_kernel, dim3(1024), dim3(256), 0, stream, ts, cb_hot_threshold(level), hot_key.p, scalars.p + 1);
+				});
 				n_hot = head[4 + level];
 			}
 		}
@@ -282,13 +283,17 @@ void dropest_ctx::build_cb_table() {
 		HIP_CHECK(hipMemsetAsync(gene_chr.p, 0xFF, size_t(GENE_CHR_CAP) * 4, stream));
 		if (n >= (1u << 20) || lazy_stats) {   // the popular genes' entries are set before the big pass starts (k_cbhash.h)
 			const u32 stride = 2048, n_s = div_up(n, stride);
-			hipLaunchKernelGGL(gene_chr_seed_kernel, dim3(std::min<u32>(div_up(n_s, 256), 64u)), dim3(256), 0, stream, d_gene, d_aux, n, stride, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
+			timed("gene_chr_seed", double(n_s) * 8, [&] {
+				hipLaunchKernelGGL(gene_chr_seed_kernel, dim3(std::min<u32>(div_up(n_s, 256), 64u)), dim3(256), 0, stream, d_gene, d_aux, n, stride, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
+			});
 		}
 		const bool vec = ((uintptr_t(d_cb) | uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;   // adopted arrays may sit anywhere
 		static const u32 grid_v = resident_grid(cb_insert_kernel<256, true>, 256, ~0u), grid_s = resident_grid(cb_insert_kernel<256, false>, 256, ~0u);
 		const u32 blocks = std::min<u32>(div_up(n, 256 * 4), vec ? grid_v : grid_s);
 		if (lazy_stats)   // the plan's statistics: every 256th read (the exact ones come with build_keys)
-			hipLaunchKernelGGL(ingest_sample_stats_kernel, dim3(std::min<u32>(div_up(div_up(n, 256u), 256), 1024u)), dim3(256), 0, stream, d_umi, d_gene, d_aux, n, 256u, d_ingest.p);
+			timed("ingest_sample_stats", double(div_up(n, 256u)) * 16, [&] {
+				hipLaunchKernelGGL(ingest_sample_stats_kernel, dim3(std::min<u32>(div_up(div_up(n, 256u), 256), 1024u)), dim3(256), 0, stream, d_umi, d_gene, d_aux, n, 256u, d_ingest.p);
+			});
 		if (n_hot && attempt == 0 && cap < (1ull << 31)) {
 			// the hot list needs 128 KB of dynamic LDS in one workgroup: a device (or partition mode) that does not grant it takes the
 			// plain kernel instead of failing the pass
@@ -859,6 +864,17 @@ static u32 run_segmented_reduce(dropest_ctx &c, const char *tag, P &policy, u32 
 }
 
 static void zero_async(dropest_ctx &c, void *p, size_t bytes) { HIP_CHECK(hipMemsetAsync(p, 0, bytes, c.stream)); }
+// several u32 arrays of one length zeroed by ONE launch (a memset each is a launch or two of ~5 us: the seven per-cell arrays of a pass
+// took fourteen); the allocations are 256-byte aligned: 16-byte stores, the last words one by one
+struct ZeroArrays { uint32_t *p[8]; uint32_t n_arrays; };
+__global__ __launch_bounds__(256) void zero_arrays_kernel(ZeroArrays a, size_t words) {
+	const size_t quads = words / 4;
+	for (uint32_t k = 0; k < a.n_arrays; ++k) {
+		uint4 *q = reinterpret_cast<uint4 *>(a.p[k]);
+		for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < quads; i += size_t(gridDim.x) * 256) q[i] = make_uint4(0, 0, 0, 0);
+		if (blockIdx.x == 0 && threadIdx.x < words - quads * 4) a.p[k][quads * 4 + threadIdx.x] = 0;
+	}
+}
 
 void dropest_ctx::reduce_all() {
 	const u32 n = u32(n_reads);
@@ -954,9 +970,13 @@ void dropest_ctx::reduce_cell_gene_to_cells() {
 	const size_t nc = size_t(n_cells) + 1;
 	cell_cg_begin.ensure(nc); cell_cg_count.ensure(nc); cell_n_genes.ensure(nc); cell_req_genes.ensure(nc);
 	cell_req_umis.ensure(nc); cell_total_umis.ensure(nc); cell_total_reads.ensure(nc);
-	for (DevBuf<u32> *b : {&cell_cg_begin, &cell_cg_count, &cell_n_genes, &cell_req_genes, &cell_req_umis, &cell_total_umis,
-	                       &cell_total_reads})
-		zero_async(*this, b->p, nc * 4);
+	{
+		ZeroArrays z{};
+		for (DevBuf<u32> *b : {&cell_cg_begin, &cell_cg_count, &cell_n_genes, &cell_req_genes, &cell_req_umis, &cell_total_umis, &cell_total_reads})
+			z.p[z.n_arrays++] = b->p;
+		hipLaunchKernelGGL(zero_arrays_kernel, dim3(u32(std::min<size_t>(div_up(u32(std::min<size_t>(nc / 4 + 1, 0xFFFFFFFFull)), 256u), 2048u))), dim3(256), 0, stream, z, nc);
+		HIP_CHECK(hipGetLastError());
+	}
 	p.cell_cg_begin = cell_cg_begin.p;
 	p.out[0] = cell_n_genes.p; p.out[1] = cell_req_genes.p; p.out[2] = cell_req_umis.p;
 	p.out[3] = cell_total_umis.p; p.out[4] = cell_total_reads.p; p.out[5] = cell_cg_count.p;

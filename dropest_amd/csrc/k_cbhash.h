@@ -156,7 +156,26 @@ __global__ __launch_bounds__(256) void ingest_sample_stats_kernel(const unsigned
 	IngestAcc acc;
 	for (uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x; j * stride < n; j += uint64_t(gridDim.x) * 256)
 		acc.add(umi[j * stride], gene[j * stride], aux[j * stride]);
-	acc.commit(stats);
+	// the four waves of a workgroup meet in LDS first: one set of atomics per workgroup on the six shared words
+	__shared__ unsigned long long w_min[4], w_max[4], w_esc[4];
+	__shared__ uint32_t w_g[4], w_c[4];
+	const unsigned long long mn = wave_reduce_min_u64(acc.umin), mx = wave_reduce_max_u64(acc.umax), es = wave_reduce_max_u64(acc.uesc);
+	const unsigned long long g64 = wave_reduce_max_u64(acc.gmax), c64 = wave_reduce_max_u64(acc.cmax);
+	const uint32_t w = threadIdx.x >> 6;
+	if (lane_id() == 0) { w_min[w] = mn; w_max[w] = mx; w_esc[w] = es; w_g[w] = uint32_t(g64); w_c[w] = uint32_t(c64); }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		IngestAcc all;
+		for (int k = 0; k < 4; ++k) {
+			all.umin = w_min[k] < all.umin ? w_min[k] : all.umin; all.umax = w_max[k] > all.umax ? w_max[k] : all.umax;
+			all.uesc = w_esc[k] > all.uesc ? w_esc[k] : all.uesc; all.gmax = w_g[k] > all.gmax ? w_g[k] : all.gmax; all.cmax = w_c[k] > all.cmax ? w_c[k] : all.cmax;
+		}
+		if (all.umin != ~0ull) atomicMin(&stats->umi_clean_min, all.umin);
+		if (all.umax != 0ull) atomicMax(&stats->umi_clean_max, all.umax);
+		if (all.uesc) atomicMax(&stats->umi_escape_max_plus1, all.uesc);
+		if (all.gmax) atomicMax(&stats->gene_max_plus1, all.gmax);
+		if (all.cmax) atomicMax(&stats->chr_max_plus1, all.cmax);
+	}
 }
 
 // One pass over (cb, umi, gene): table insert + first ordinal + ingest statistics.  Each thread takes FOUR CONSECUTIVE
@@ -342,11 +361,17 @@ __global__ __launch_bounds__(256) void cb_hot_count_kernel(CbTable ts, uint32_t 
 #pragma unroll
 		for (int l = 0; l < CB_HOT_LEVELS; ++l) c[l] += n >= cb_hot_threshold(l);
 	}
+	// one global atomic per level and WORKGROUP: 24 counters took 98 000 atomics from 4 096 waves -- 0.40 ms for a 16 us scan
+	__shared__ uint32_t block_c[CB_HOT_LEVELS];
+	if (threadIdx.x < CB_HOT_LEVELS) block_c[threadIdx.x] = 0;
+	__syncthreads();
 #pragma unroll
 	for (int l = 0; l < CB_HOT_LEVELS; ++l) {
 		const unsigned long long tot = wave_reduce_add_u64(c[l]);
-		if (lane_id() == 0 && tot) atomicAdd(&counts[l], uint32_t(tot));
+		if (lane_id() == 0 && tot) atomicAdd(&block_c[l], uint32_t(tot));
 	}
+	__syncthreads();
+	if (threadIdx.x < CB_HOT_LEVELS && block_c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], block_c[threadIdx.x]);
 }
 __global__ __launch_bounds__(256) void cb_hot_collect_kernel(CbTable ts, uint32_t threshold, unsigned long long *__restrict__ hot_key,
                                                              uint32_t *__restrict__ n_hot) {
