@@ -17,7 +17,11 @@
 
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <sched.h>
+#include <sys/stat.h>
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <mutex>
@@ -211,14 +215,94 @@ struct LocalTransport : Transport {
 	}
 };
 
-// One process per GPU: RCCL for the device data, and -- no second runtime -- RCCL all-gathers of staged bytes for the
-// small host tables.  Shared host memory: a POSIX shm object mapped and registered by every process of the node.
+// The small host tables of the processes of one node meet in shared memory, not on the device: a pass makes a dozen host collectives of
+// a few bytes to a few hundred KB, and each one staged through the GPU (copy in, ncclAllGather, copy out, stream wait) costs ~50-100 us
+// of launch and synchronisation latency whatever its size.  HostMailbox: one POSIX shm object per run (named by the run's unique id;
+// rank 0 creates it, the others attach, rank 0 unlinks it once all are in), `world` slots of SLOT bytes, twice (two halves used in
+// turn), and a sense-reversing barrier on an atomic counter.  A gather = write my slot, barrier, read all slots: ONE barrier -- a rank
+// can only be two collectives ahead of another when that one has passed the barrier in between, i.e. has finished reading the half
+// about to be overwritten.  Payloads beyond SLOT bytes take the RCCL path.  A rank that does not arrive within TIMEOUT_S (a peer died)
+// fails the collective instead of hanging.
+struct HostMailbox {
+	static constexpr size_t SLOT = size_t(1) << 20;
+	static constexpr unsigned TIMEOUT_S = 300;
+	struct Header { std::atomic<uint32_t> attached, arrived, generation, failed; };
+	int rank = 0, world = 1;
+	char *base = nullptr;
+	size_t bytes = 0;
+	uint64_t phase = 0;
+	Header *hdr() const { return reinterpret_cast<Header *>(base); }
+	char *slot(uint64_t ph, int p) const { return base + 4096 + ((ph & 1) * size_t(world) + size_t(p)) * SLOT; }
+	HostMailbox(uint64_t token, int r, int w) : rank(r), world(w) {
+		bytes = 4096 + 2 * size_t(w) * SLOT;
+		char path[96];
+		std::snprintf(path, sizeof(path), "/dropest_mb_%llx_%d", (unsigned long long)token, w);
+		int fd = -1;
+		const auto t0 = std::chrono::steady_clock::now();
+		if (r == 0) {
+			shm_unlink(path);   // a leftover of a crashed run with the same id cannot be ours
+			fd = shm_open(path, O_CREAT | O_EXCL | O_RDWR, 0600);
+			if (fd < 0 || ftruncate(fd, off_t(bytes)) != 0) { if (fd >= 0) { close(fd); shm_unlink(path); } throw DeviceError("cannot create the host mailbox in /dev/shm"); }
+		} else {
+			for (;;) {   // rank 0 may not be there yet; a file that exists but is not sized yet is not ready either
+				fd = shm_open(path, O_RDWR, 0600);
+				if (fd >= 0) { struct stat st; if (fstat(fd, &st) == 0 && size_t(st.st_size) >= bytes) break; close(fd); fd = -1; }
+				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(TIMEOUT_S)) throw DeviceError("host mailbox: rank 0 did not create it");
+				usleep(200);
+			}
+		}
+		void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+		close(fd);
+		if (m == MAP_FAILED) { if (r == 0) shm_unlink(path); throw DeviceError("cannot map the host mailbox"); }
+		base = static_cast<char *>(m);   // (a fresh shm object reads as zeros: the header starts at 0 / 0 / 0 / 0)
+		hdr()->attached.fetch_add(1, std::memory_order_acq_rel);
+		wait_until([&] { return hdr()->attached.load(std::memory_order_acquire) >= uint32_t(world); }, "attach");
+		if (r == 0) shm_unlink(path);   // the mappings keep it alive; nothing is left behind on a crash
+	}
+	~HostMailbox() { if (base) munmap(base, bytes); }
+	HostMailbox(const HostMailbox &) = delete;
+	template <class F> void wait_until(F &&done, const char *what) {
+		const auto t0 = std::chrono::steady_clock::now();
+		for (uint32_t spins = 0; !done(); ++spins) {
+			if (hdr()->failed.load(std::memory_order_acquire)) throw DeviceError("another shard of the run failed");
+			if (spins < 2000) { __builtin_ia32_pause(); continue; }
+			sched_yield();
+			if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(TIMEOUT_S)) {
+				hdr()->failed.store(1, std::memory_order_release);
+				throw DeviceError(std::string("host mailbox: a shard did not arrive (") + what + ")");
+			}
+		}
+	}
+	void fail() { if (base) hdr()->failed.store(1, std::memory_order_release); }
+	void barrier() {
+		Header *h = hdr();
+		const uint32_t g = h->generation.load(std::memory_order_acquire);
+		if (h->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == uint32_t(world)) {
+			h->arrived.store(0, std::memory_order_relaxed);
+			h->generation.store(g + 1, std::memory_order_release);
+			return;
+		}
+		wait_until([&] { return h->generation.load(std::memory_order_acquire) != g; }, "barrier");
+	}
+	bool fits(size_t n) const { return n <= SLOT; }
+	void gather(const void *mine, size_t n, void *all) {   // n <= SLOT, the same on every rank
+		const uint64_t ph = phase++;
+		if (n) std::memcpy(slot(ph, rank), mine, n);
+		barrier();
+		for (int p = 0; p < world; ++p) if (n) std::memcpy(static_cast<char *>(all) + size_t(p) * n, slot(ph, p), n);
+	}
+};
+
+// One process per GPU: RCCL for the device data; the small host tables through the HostMailbox above (RCCL all-gathers of staged bytes
+// for payloads beyond its slots, or for everything with DROPEST_HOST_COLLECTIVES=rccl).  Shared host memory for the results: a POSIX
+// shm object mapped and registered by every process of the node.
 struct RcclTransport : Transport {
 	ncclComm_t comm = nullptr;
 	hipStream_t st0 = nullptr;          // the owning context's stream
 	DevBuf<unsigned char> stage_in, stage_out;
 	PinnedBuf<unsigned char> h_in, h_out;
 	uint64_t token = 0;
+	std::unique_ptr<HostMailbox> mailbox;
 	struct Shm { void *host = nullptr; size_t bytes = 0; int gen = 0; } shm[4];
 	RcclTransport(int r, int w, const uint8_t id_bytes[128], hipStream_t st) : st0(st) {
 		rank = r; world = w;
@@ -228,6 +312,8 @@ struct RcclTransport : Transport {
 		std::memcpy(&id, id_bytes, 128);
 		api.check(api.CommInitRank(&comm, w, id, r), "ncclCommInitRank");
 		for (int i = 0; i < 128; ++i) token = token * 1099511628211ull + id_bytes[i];
+		const char *hc = getenv("DROPEST_HOST_COLLECTIVES");
+		if (!(hc && std::string(hc) == "rccl")) mailbox = std::make_unique<HostMailbox>(token, r, w);
 	}
 	~RcclTransport() override {
 		for (auto &s : shm) if (s.host) { (void)hipHostUnregister(s.host); munmap(s.host, s.bytes); }
@@ -259,6 +345,7 @@ struct RcclTransport : Transport {
 		HIP_CHECK(stream_wait(st));
 	}
 	void gather_host(const void *mine, size_t bytes, void *all) override {
+		if (mailbox && mailbox->fits(bytes)) { mailbox->gather(mine, bytes, all); return; }
 		const RcclApi &api = RcclApi::get();
 		const size_t b = std::max<size_t>(bytes, 1);
 		stage_in.ensure(b); stage_out.ensure(b * size_t(world)); h_in.ensure(b); h_out.ensure(b * size_t(world));
@@ -1731,6 +1818,7 @@ dropest_status dropest_shard_step(dropest_shard *s) {
 		try { s->step(); }
 		catch (...) {   // the other members of an in-process group must not wait for this one forever
 			if (auto *lt = dynamic_cast<dropest::LocalTransport *>(s->tr.get())) lt->hub->fail();
+			if (auto *rt = dynamic_cast<dropest::RcclTransport *>(s->tr.get())) if (rt->mailbox) rt->mailbox->fail();   // (the peers' next host collective throws)
 			throw;
 		}
 	});
@@ -1817,6 +1905,24 @@ dropest_status dropest_shard_merged_barcodes(dropest_shard *s, uint64_t *n, uint
 		*n = s->merged_barcodes.size();
 		if (source && target) for (size_t i = 0; i < s->merged_barcodes.size(); ++i) { source[i] = s->merged_barcodes[i].first; target[i] = s->merged_barcodes[i].second; }
 	});
+}
+
+// test hook (tests/test_host_mailbox.py: processes on the CPU): `rounds` gathers of `bytes` patterned bytes per rank, every one checked;
+// returns 0, or the round (1-based) in which a slot did not hold what its rank wrote
+int dropest_test_host_mailbox(uint64_t token, int32_t rank, int32_t world, uint32_t rounds, uint64_t bytes) {
+	try {
+		dropest::HostMailbox mb(token, rank, world);
+		std::vector<unsigned char> mine(bytes), all(size_t(bytes) * size_t(world));
+		for (uint32_t r = 0; r < rounds; ++r) {
+			const size_t n = r % 3 == 2 ? size_t(bytes) / 2 : size_t(bytes);          // sizes change between rounds (the same on every rank)
+			for (size_t i = 0; i < n; ++i) mine[i] = (unsigned char)(rank * 131 + r * 7 + i * 13);
+			mb.gather(mine.data(), n, all.data());
+			for (int p = 0; p < world; ++p)
+				for (size_t i = 0; i < n; ++i) if (all[size_t(p) * n + i] != (unsigned char)(p * 131 + r * 7 + i * 13)) return int(r + 1);
+		}
+		mb.barrier();
+		return 0;
+	} catch (const std::exception &e) { g_last_error = e.what(); return -1; }
 }
 
 dropest_status dropest_shard_phase_stats(dropest_shard *s, uint32_t *n, dropest_kernel_stat *out) {
