@@ -161,11 +161,12 @@ inline std::string decode_code(u64 code, const std::vector<std::string> &side) {
 inline bool encode_code(const std::string &s, u64 &code) {   // false: needs an escape
 	if (s.empty() || s.size() > 31) return false;
 	u64 c = 1;
+	unsigned bad = 0;   // (no branch on a base's value: whitelists are millions of random barcodes)
 	for (char ch : s) {
-		u64 b;
-		switch (ch) { case 'A': b = 0; break; case 'C': b = 1; break; case 'G': b = 2; break; case 'T': b = 3; break; default: return false; }
-		c = (c << 2) | b;
+		const unsigned b = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 0x80u;
+		bad |= b; c = (c << 2) | (b & 3u);
 	}
+	if (bad & 0x80u) return false;
 	code = c;
 	return true;
 }

@@ -20,6 +20,7 @@
 #include <thread>
 #include <unordered_set>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <mutex>
 
@@ -158,10 +159,57 @@ struct BamReader::Impl {
 		size_t first_start = 0, tail_start = 0;
 	};
 	Buf cur;                                           // window being parsed: bytes [pos, cur.size)
-	std::vector<Buf> spare;                            // touched by the caller's thread only
+	std::vector<Buf> spare;                            // recycled buffers (under qm)
 	size_t pos = 0;
 	bool file_done = false;
-	std::future<Buf> ahead;                            // next batch, being inflated while the caller parses this one
+	// Batches are loaded by ONE background thread, strictly one after the other (block discovery, the walk chain and the cut record carry
+	// state from batch to batch), up to DEPTH ahead of the parser: with a single batch in flight every slow batch of either side -- the
+	// hosts are shared -- stalled the other (215 ms of waiting in a 950 ms ingest whose loader and parser each needed ~700).
+	static constexpr size_t DEPTH = 3;
+	std::thread loader;
+	std::mutex qm;
+	std::condition_variable q_cv;
+	std::deque<Buf> ready;
+	bool loader_started = false, loader_finished = false, loader_stop = false;
+	std::exception_ptr loader_error;
+	void loader_main() {
+		try {
+			for (;;) {
+				Buf b;
+				{
+					std::unique_lock<std::mutex> lk(qm);
+					q_cv.wait(lk, [&] { return loader_stop || ready.size() < DEPTH; });
+					if (loader_stop) break;
+					b = take_spare();
+				}
+				Buf out = load_batch(std::move(b));
+				const bool last = file_done;
+				{ std::lock_guard<std::mutex> lk(qm); ready.push_back(std::move(out)); if (last) loader_finished = true; }
+				q_cv.notify_all();
+				if (last) break;
+			}
+		} catch (...) {
+			{ std::lock_guard<std::mutex> lk(qm); loader_error = std::current_exception(); loader_finished = true; }
+			q_cv.notify_all();
+		}
+	}
+	bool next_batch(Buf &out) {   // false: the stream has ended (an error of the loader is rethrown here)
+		if (!loader_started) { loader_started = true; loader = std::thread([this] { loader_main(); }); }
+		std::unique_lock<std::mutex> lk(qm);
+		q_cv.wait(lk, [&] { return !ready.empty() || loader_finished; });
+		if (ready.empty()) { if (loader_error) std::rethrow_exception(loader_error); return false; }
+		out = std::move(ready.front());
+		ready.pop_front();
+		lk.unlock();
+		q_cv.notify_all();
+		return true;
+	}
+	void stop_loader() {
+		if (!loader_started) return;
+		{ std::lock_guard<std::mutex> lk(qm); loader_stop = true; }
+		q_cv.notify_all();
+		if (loader.joinable()) loader.join();
+	}
 	std::vector<std::string> refs;
 	std::string text;
 	const uint8_t *bytes() const { return cur.p.get(); }
@@ -320,10 +368,11 @@ struct BamReader::Impl {
 	bool ensure(size_t need) {
 		while (cur.size - pos < need) {
 			Buf next;
-			if (ahead.valid()) next = ahead.get();
-			else if (!file_done) next = load_batch(take_spare());
-			if (next.size <= HEADROOM && file_done && !ahead.valid()) return false;
-			if (!file_done) ahead = std::async(std::launch::async, [this](Buf b) { return load_batch(std::move(b)); }, take_spare());
+			if (!next_batch(next)) return false;
+			if (next.size <= HEADROOM) {   // an empty batch (the end of the file fell on a batch boundary): the next call ends the stream
+				if (next.cap) { std::lock_guard<std::mutex> lk(qm); if (spare.size() < DEPTH + 2) spare.push_back(std::move(next)); }
+				continue;
+			}
 			const size_t tail = cur.size - pos;
 			if (tail <= HEADROOM && next.size >= HEADROOM) {
 				if (tail) std::memcpy(next.p.get() + HEADROOM - tail, cur.p.get() + pos, tail);
@@ -338,9 +387,9 @@ struct BamReader::Impl {
 				big.size = tail + payload;
 				std::swap(cur, big);
 				pos = 0;
-				if (big.cap) spare.push_back(std::move(big));
+				if (big.cap) { std::lock_guard<std::mutex> lk(qm); spare.push_back(std::move(big)); }
 			}
-			if (next.cap && spare.size() < 3) spare.push_back(std::move(next));   // the old window, recycled
+			if (next.cap) { std::lock_guard<std::mutex> lk(qm); if (spare.size() < DEPTH + 2) spare.push_back(std::move(next)); }   // the old window, recycled
 		}
 		return true;
 	}
@@ -376,14 +425,14 @@ BamReader::BamReader(const std::string &path, unsigned threads) : impl(new Impl(
 			m.pos += 8 + size_t(l_name);
 		}
 	} catch (...) {
-		if (impl->ahead.valid()) impl->ahead.wait();
+		impl->stop_loader();
 		if (impl->map) munmap(const_cast<uint8_t *>(impl->map), impl->map_size);
 		delete impl; throw;
 	}
 }
 
 BamReader::~BamReader() {
-	if (impl->ahead.valid()) { try { impl->ahead.get(); } catch (...) {} }
+	impl->stop_loader();
 	if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] %zu batches (%zu with the record boundaries from the loader), load %.1f ms (block discovery %.1f ms), %u inflate threads\n", impl->n_batches, impl->n_walked, impl->load_ms, impl->discover_ms, impl->threads);
 	if (impl->map) munmap(const_cast<uint8_t *>(impl->map), impl->map_size);
 	delete impl;
