@@ -340,7 +340,12 @@ __global__ __launch_bounds__(256) void cb_sample_distinct_kernel(const unsigned 
 		if (found) atomicAdd(&t.slots[h].nfirst, 1u);   // occurrences in the sample: the hot barcodes are picked by it
 	}
 	const unsigned long long tot = wave_reduce_add_u64(mine);
-	if (lane_id() == 0 && tot) atomicAdd(distinct, uint32_t(tot));
+	__shared__ uint32_t block_new;   // (one atomic per workgroup on the one counter, not one per wave)
+	if (threadIdx.x == 0) block_new = 0;
+	__syncthreads();
+	if (lane_id() == 0 && tot) atomicAdd(&block_new, uint32_t(tot));
+	__syncthreads();
+	if (threadIdx.x == 0 && block_new) atomicAdd(distinct, block_new);
 }
 
 // ---- hot barcodes -------------------------------------------------------------------------------------------------

@@ -159,17 +159,45 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 			for (int q = 0; q < U; ++q) if (base + q < n) keys[base + q] = kk[q];
 		}
 	}
-	if (STATS) acc.commit(stats);
+	// The twelve shared words (six counters of the pass, six ingest statistics) sit in two cache lines: an atomic per word and WAVE was
+	// 49 000 atomics on those two lines at the tail of the kernel.  The waves of a workgroup meet in LDS first.
+	constexpr int WAVES = THREADS / 64;
+	__shared__ unsigned long long red[WAVES][12];
 	c_inter = wave_reduce_add_u64(c_inter); c_exon = wave_reduce_add_u64(c_exon);
 	c_intron = wave_reduce_add_u64(c_intron); c_na = wave_reduce_add_u64(c_na);
 	k_or = wave_reduce_or_u64(k_or); k_and = wave_reduce_and_u64(k_and);
+	unsigned long long s_min = ~0ull, s_max = 0, s_esc = 0, s_g = 0, s_c = 0, s_conf = 0;
+	if (STATS) {
+		s_min = wave_reduce_min_u64(acc.umin); s_max = wave_reduce_max_u64(acc.umax); s_esc = wave_reduce_max_u64(acc.uesc);
+		s_g = wave_reduce_max_u64(acc.gmax); s_c = wave_reduce_max_u64(acc.cmax); s_conf = wave_reduce_max_u64(acc.chr_conflict ? 1ull : 0ull);
+	}
+	const uint32_t wv = threadIdx.x >> 6;
 	if (lane_id() == 0) {
-		if (c_inter) atomicAdd(&gc->intergenic, c_inter);
-		if (c_exon) atomicAdd(&gc->exon, c_exon);
-		if (c_intron) atomicAdd(&gc->intron, c_intron);
-		if (c_na) atomicAdd(&gc->not_annotated, c_na);
-		atomicOr(&gc->key_or, k_or);
-		atomicAnd(&gc->key_and, k_and);
+		red[wv][0] = c_inter; red[wv][1] = c_exon; red[wv][2] = c_intron; red[wv][3] = c_na; red[wv][4] = k_or; red[wv][5] = k_and;
+		red[wv][6] = s_min; red[wv][7] = s_max; red[wv][8] = s_esc; red[wv][9] = s_g; red[wv][10] = s_c; red[wv][11] = s_conf;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w2 = 1; w2 < WAVES; ++w2) {
+			for (int k = 0; k < 4; ++k) red[0][k] += red[w2][k];
+			red[0][4] |= red[w2][4]; red[0][5] &= red[w2][5];
+			red[0][6] = red[w2][6] < red[0][6] ? red[w2][6] : red[0][6];
+			for (int k = 7; k < 12; ++k) red[0][k] = red[w2][k] > red[0][k] ? red[w2][k] : red[0][k];
+		}
+		if (red[0][0]) atomicAdd(&gc->intergenic, red[0][0]);
+		if (red[0][1]) atomicAdd(&gc->exon, red[0][1]);
+		if (red[0][2]) atomicAdd(&gc->intron, red[0][2]);
+		if (red[0][3]) atomicAdd(&gc->not_annotated, red[0][3]);
+		atomicOr(&gc->key_or, red[0][4]);
+		atomicAnd(&gc->key_and, red[0][5]);
+		if (STATS) {
+			if (red[0][6] != ~0ull) atomicMin(&stats->umi_clean_min, red[0][6]);
+			if (red[0][7] != 0ull) atomicMax(&stats->umi_clean_max, red[0][7]);
+			if (red[0][8]) atomicMax(&stats->umi_escape_max_plus1, red[0][8]);
+			if (red[0][9]) atomicMax(&stats->gene_max_plus1, uint32_t(red[0][9]));
+			if (red[0][10]) atomicMax(&stats->chr_max_plus1, uint32_t(red[0][10]));
+			if (red[0][11]) atomicMax(&stats->gene_chr_conflict, 1u);
+		}
 	}
 }
 
@@ -473,26 +501,48 @@ __global__ __launch_bounds__(OP_T) void owner_hist_stats_kernel(const unsigned l
 	uint64_t end = begin + uint64_t(tiles_per_block) * OP_TILE;
 	if (end > n) end = n;
 	unsigned long long cmax = 0, umax = 0, gmax = 0, chmax = 0, hi = 0;
+	// up to eight owners (one node): counted in registers -- an LDS atomic per read on so few addresses serialises the lanes of a wave
+	// (with ONE owner, the forced exchange of the bench, all 64 of them)
+	uint32_t c8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	const bool few = n_parts <= 8;
 	for (uint64_t i = begin + threadIdx.x; i < end; i += OP_T) {
 		const unsigned long long k = cb[i], u = umi[i];
 		const uint32_t g = gene[i], a = aux[i];
-		atomicAdd(&h[mix64(k) % n_parts], 1u);
+		const uint32_t own = uint32_t(mix64(k) % n_parts);
+		if (few) {
+#pragma unroll
+			for (uint32_t p = 0; p < 8; ++p) c8[p] += own == p;
+		} else atomicAdd(&h[own], 1u);
 		cmax = k > cmax ? k : cmax; umax = u > umax ? u : umax;
 		if (g != 0xFFFFFFFFu && (unsigned long long)g + 1 > gmax) gmax = (unsigned long long)g + 1;
 		const unsigned long long ch = a & 0xFFFFu;
 		chmax = ch > chmax ? ch : chmax;
 		hi |= a >> 19;
 	}
+	if (few) {
+#pragma unroll
+		for (uint32_t p = 0; p < 8; ++p) {
+			const unsigned long long tot = wave_reduce_add_u64(c8[p]);
+			if (lane_id() == 0 && tot) atomicAdd(&h[p], uint32_t(tot));
+		}
+	}
 	cmax = wave_reduce_max_u64(cmax); umax = wave_reduce_max_u64(umax); gmax = wave_reduce_max_u64(gmax); chmax = wave_reduce_max_u64(chmax);
 	hi = wave_reduce_or_u64(hi);
-	if (lane_id() == 0) {
-		if (cmax) atomicMax(&stats[0], cmax);
-		if (umax) atomicMax(&stats[1], umax);
-		if (gmax) atomicMax(&stats[2], gmax);
-		if (chmax) atomicMax(&stats[3], chmax);
-		if (hi) atomicOr(&stats[4], hi);
-	}
+	// the five statistics words: the waves of the workgroup meet in LDS, one set of atomics per workgroup
+	__shared__ unsigned long long wst[OP_T / 64][5];
+	if (lane_id() == 0) { const uint32_t wv = threadIdx.x >> 6; wst[wv][0] = cmax; wst[wv][1] = umax; wst[wv][2] = gmax; wst[wv][3] = chmax; wst[wv][4] = hi; }
 	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (uint32_t q = 1; q < OP_T / 64; ++q) {
+			for (int z = 0; z < 4; ++z) wst[0][z] = wst[q][z] > wst[0][z] ? wst[q][z] : wst[0][z];
+			wst[0][4] |= wst[q][4];
+		}
+		if (wst[0][0]) atomicMax(&stats[0], wst[0][0]);
+		if (wst[0][1]) atomicMax(&stats[1], wst[0][1]);
+		if (wst[0][2]) atomicMax(&stats[2], wst[0][2]);
+		if (wst[0][3]) atomicMax(&stats[3], wst[0][3]);
+		if (wst[0][4]) atomicOr(&stats[4], wst[0][4]);
+	}
 	if (threadIdx.x < 256) hist[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
 
