@@ -747,6 +747,8 @@ bool dropest_ctx::splitter_sort_reduce() {
 	a.t_key = keys_alt; a.t_reads = ss_tmp.p; a.t_agg = ss_tmp.p + n; a.n_loc = ss_n_loc.p;
 	if (const char *e = getenv("DROPEST_SS_DEBUG")) a.debug = u32(atoi(e));
 	a.order_flag = scalars.p + 2;
+	a.atomic_below = u32(ms + layout.umi_bits);   // the UMI field: random digits
+	if (const char *e = getenv("DROPEST_SS_ATOMIC_BELOW")) a.atomic_below = u32(atoi(e));
 	a.cap = SMALL_MAX; a.skip_above = SMALL_MAX;
 	{
 		const size_t lds = ss_local_lds_bytes(a.cap, 256);

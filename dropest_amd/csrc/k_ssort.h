@@ -278,6 +278,7 @@ struct SsLocalArgs {
 	uint32_t cap;                        // records the LDS of this launch holds
 	uint32_t skip_above;                 // small launch: buckets with more records are left to the big launch
 	uint32_t debug;                      // DROPEST_SS_DEBUG: 2 = skip the sort passes (the order check below must then catch it: tests)
+	uint32_t atomic_below;               // ATOMIC_RANK: passes whose digit starts below this bit rank by the LDS atomic, the others by ballots
 	uint32_t *order_flag;                // set to 1 when a bucket is found out of order after its sort (checked on EVERY pass)
 	unsigned long long *t_key;           // sparse rows: molecule key, reads, agg (bit 0 not-annotated, exon << 1, intron << 16)
 	uint32_t *t_reads, *t_agg, *n_loc;
@@ -335,14 +336,19 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint3
 		for (uint32_t j = tid; j < WAVES * 256; j += THREADS) wcnt[j] = 0;
 		lds_barrier();
 		uint32_t lrank[ITEMS];
+		// The one-atomic rank costs a cycle per lane that shares the digit: nothing on the random UMI bits, up to 64 on the digits above
+		// them (a bucket is ~1500 consecutive records of the sorted order: one or two cells, a window of genes).  Those passes rank by
+		// ballots -- over the VARYING bits of the digit only, often two or three.
+		const bool by_atomic = ATOMIC_RANK && uint32_t(shift) < a.atomic_below;
+		const uint32_t vbits = uint32_t(vary >> shift) & 0xFFu;
 #pragma unroll
 		for (int i = 0; i < ITEMS; ++i) {
 			const bool valid = (lane_off + i * 64) < cnt;
 			const uint32_t d = uint32_t(key[i] >> shift) & 0xFFu;
-			if (ATOMIC_RANK) { lrank[i] = valid ? atomicAdd(&wcnt[w * 256 + d], 1u) : 0u; continue; }
+			if (by_atomic) { lrank[i] = valid ? atomicAdd(&wcnt[w * 256 + d], 1u) : 0u; continue; }
 			uint32_t diff_lo = 0, diff_hi = 0;
-#pragma unroll
-			for (int b = 0; b < 8; ++b) {
+			for (uint32_t left = vbits; left; left &= left - 1u) {
+				const int b = __builtin_ctz(left);
 				const int32_t mine = int32_t(d << (31 - b)) >> 31;
 				const unsigned long long bal = __ballot(mine != 0);
 				diff_lo |= uint32_t(bal) ^ uint32_t(mine);
