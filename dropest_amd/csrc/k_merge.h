@@ -540,7 +540,10 @@ __global__ __launch_bounds__(256) void rekey_molecules_kernel(const unsigned lon
 		k_or |= nk; k_and &= nk;
 	}
 	k_or = wave_reduce_or_u64(k_or); k_and = wave_reduce_and_u64(k_and);
-	if (lane_id() == 0) { atomicOr(&key_or_and[0], k_or); atomicAnd(&key_or_and[1], k_and); }
+	__shared__ unsigned long long w_or[4], w_and[4];   // (256 threads: the four waves meet here, one pair of atomics per workgroup)
+	if (lane_id() == 0) { w_or[threadIdx.x >> 6] = k_or; w_and[threadIdx.x >> 6] = k_and; }
+	__syncthreads();
+	if (threadIdx.x == 0) { atomicOr(&key_or_and[0], w_or[0] | w_or[1] | w_or[2] | w_or[3]); atomicAnd(&key_or_and[1], w_and[0] & w_and[1] & w_and[2] & w_and[3]); }
 }
 
 }  // namespace dropest
