@@ -619,7 +619,7 @@ struct dropest_ctx {
 	void requality_after_fold(const u64 *sorted_key, const u32 *old_row, u32 n_old, const u64 *new_key, u32 n_new);
 	void fetch_quality_rows(const std::vector<u32> &rows, uint32_t *out, uint32_t *out_len = nullptr);
 	dropest::DevBuf<u32> umi_first;
-	void fetch_real_cells();
+	void fetch_real_cells(bool at_init = false);
 	void request_filtered(u32 genes_threshold, int max_cells);   // CellsDataContainer::update_filtered_gene_counts, lazily
 	void sort_filtered(u32 genes_threshold, int max_cells);
 	void emit_matrix(bool filtered_m, bool reads_output, bool to_host = true, int form = 0);
@@ -636,7 +636,8 @@ struct dropest_ctx {
 	dropest::DevBuf<u32> m2_col_cell, m2_col_start, m2_col_list, m_col_list;
 	std::vector<u32> m2_col_list_host, m_col_list_host;   // (host sides of asynchronous uploads: kept with the context)
 	void launch_emit_bytes(dropest::MatrixArgs a, const std::vector<u32> &rows_per_column, dropest::DevBuf<u32> &list, std::vector<u32> &host_list, hipStream_t st);
-	void prefetch_raw_matrix(bool reads_output, int form = 0);   // form: 0 32-bit, 1 16-bit, 2 bytes
+	void prefetch_raw_matrix(bool reads_output, int form = 0, const dropest::CellRowPod *rows = nullptr, const dropest::u32 *ids = nullptr,
+	                         dropest::u32 count = 0);   // form: 0 32-bit, 1 16-bit, 2 bytes; rows / ids: the real cells as fetch_real_cells just received them
 	int auto_pf_form = -1;          // dropest_set_raw_matrix_prefetch: the form cm_raw will be asked for (-1: not announced)
 	bool auto_pf_reads = false;
 	bool merge_phase_changes_nothing() const;

@@ -993,7 +993,7 @@ void dropest_ctx::reduce_cell_gene_to_cells() {
 // ------------------------------------------------------------------------------------------------
 // stage: real cells to the host; ordering (CellsDataContainer::update_filtered_gene_counts)
 // ------------------------------------------------------------------------------------------------
-void dropest_ctx::fetch_real_cells() {
+void dropest_ctx::fetch_real_cells(bool at_init) {
 	invalidate_prefetch();
 	real.clear(); real_list_current = false;
 	if (n_cells == 0) return;
@@ -1023,6 +1023,11 @@ void dropest_ctx::fetch_real_cells() {
 	HIP_CHECK(stream_wait(stream));
 	const CellRowPod *host_rows = reinterpret_cast<const CellRowPod *>(h_stage.p);
 	const u32 *ids = reinterpret_cast<const u32 *>(h_stage.p + id_off);
+	// cm_raw announced (dropest_set_raw_matrix_prefetch) and nothing in merge_and_filter can change it: its columns are exactly these
+	// rows, in this order -- the emit and the copy to the host start HERE, before the host mirror below is filled (the matrices' way
+	// over PCIe is the tail of a pass: every microsecond the first byte leaves earlier is one off the pass)
+	if (at_init && auto_pf_form >= 0 && n_reads && merge_phase_changes_nothing() && (auto_pf_form != 1 || narrow_possible()))
+		prefetch_raw_matrix(auto_pf_reads, auto_pf_form, host_rows, ids, count);
 	real.resize(count);   // ids arrive ascending (ordered compaction)
 	parallel_ranges(count, [&](size_t b, size_t e, unsigned) {
 		for (size_t i = b; i < e; ++i) {
@@ -1245,7 +1250,7 @@ void dropest_ctx::run_set_initialized() {
 		}
 		{ HostStage hs(this, "sort+reduce"); reduce_all(); }
 		accumulate_umi_qualities();
-		{ HostStage hs(this, "real_cells"); fetch_real_cells(); }
+		{ HostStage hs(this, "real_cells"); fetch_real_cells(true); }
 	} else {
 		// no reads (a shard that owns no barcode): the key fields are still laid out from the statistics the shards agreed on
 		// (or from nothing), so that the tables the later stages size from the layout -- the UMI first-occurrence table of -u
@@ -1418,14 +1423,21 @@ void dropest_ctx::launch_emit_bytes(dropest::MatrixArgs a, const std::vector<u32
 
 // cm_raw on a second stream: emit + device-to-host copy start now and run under whatever the caller does next (ordering
 // the filtered cells, emitting cm); dropest_count_matrix_csc(filtered = 0) later only waits for the copy.
-void dropest_ctx::prefetch_raw_matrix(bool reads_output, int narrow) {
+void dropest_ctx::prefetch_raw_matrix(bool reads_output, int narrow, const dropest::CellRowPod *rows, const u32 *ids, u32 count) {
 	if (raw_pf.valid && raw_pf.reads_output == reads_output && raw_pf.narrow == narrow) return;   // already under way (dropest_set_raw_matrix_prefetch)
 	HostStage hs(this, "prefetch:cm_raw");
 	invalidate_prefetch();
 	if (narrow == 1 && !narrow_possible()) throw UnsupportedError("gene ids beyond 65535: the narrow matrix form is not available");
 	MatrixResult &M = mat[1];
 	uint64_t nnz = 0;
-	matrix_columns(false, raw_pf.col_cell, M.colptr, nnz);
+	if (rows) {   // straight from the rows fetch_real_cells just received (every one of them a column: n_genes >= min_genes_before_merge, nothing merged or excluded yet)
+		raw_pf.col_cell.assign(ids, ids + count);
+		M.colptr.resize(size_t(count) + 1);
+		for (u32 i = 0; i < count; ++i) { M.colptr[i] = u32(nnz); nnz += rows[i].n_genes; }
+		if (nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
+		M.colptr[count] = u32(nnz);
+	} else
+		matrix_columns(false, raw_pf.col_cell, M.colptr, nnz);
 	M.nnz = nnz; M.ncols = raw_pf.col_cell.size(); M.narrow = narrow; M.n_ovf = 0;
 	raw_pf.valid = true; raw_pf.reads_output = reads_output; raw_pf.narrow = narrow;
 	if (nnz == 0) return;
