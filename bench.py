@@ -199,7 +199,7 @@ def push_rates(stream, local_rank, n_push, cfg_kw):
             L.dropest_host_unregister(local_rank, a.ctypes.data)
 
 
-def bam_ingest_rate(n=250_000, copies=32, threads=16):
+def bam_ingest_rate(n=250_000, copies=96, threads=16):
     """BAM file -> container through the native reader (scripts/bench_bam_ingest.py: BGZF inflate, record boundaries, tag parsing, 2-bit
     packing, push): n synthetic 10x-style records written `copies` times into one file.  {} when the tool is not built or
     DROPEST_BENCH_NO_BAM is set."""
