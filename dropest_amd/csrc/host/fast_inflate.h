@@ -205,7 +205,10 @@ inline bool inflate_raw(const uint8_t *in, size_t in_len, uint8_t *out, size_t o
 				const uint8_t *s = o - dist;
 				uint8_t *t = o;
 				o += len;
-				if (dist >= 8) {
+				if (dist >= 16) {   // sixteen bytes a step (BAM records repeat each other at distances of a record or more: matches are long)
+					struct W16 { uint64_t a, b; } w;
+					do { std::memcpy(&w, s, 16); std::memcpy(t, &w, 16); s += 16; t += 16; } while (t < o);
+				} else if (dist >= 8) {
 					uint64_t w;
 					std::memcpy(&w, s, 8); std::memcpy(t, &w, 8);
 					std::memcpy(&w, s + 8, 8); std::memcpy(t + 8, &w, 8);
