@@ -1160,6 +1160,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 
 	struct Key { u64 sizes; u64 umis; u64 code; u32 idx; };
 	std::vector<Key> keys;
+	keys.reserve(8192);
 	for (u32 i = 0; i < real.size(); ++i) {
 		const HostCell &h = real[i];
 		if (!passes(h)) continue;
@@ -1175,7 +1176,30 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 		if (plain) return a.code < b.code;
 		return barcode_of(real[a.idx]) < barcode_of(real[b.idx]);
 	};
-	std::sort(keys.begin(), keys.end(), less);
+	// The sizes decide almost every comparison: a stable LSD counting sort on their varying bytes (three or four passes over a few
+	// thousand keys), then only the runs of equal sizes by the full comparison.  std::sort on the 32-byte keys was 0.25 ms for the
+	// 5 001 filtered cells of C2 -- host time between cm_raw's copy and cm's emit, with the PCIe link waiting at the end of the pass.
+	if (keys.size() > 64) {
+		u64 o = 0, a = ~0ull;
+		for (const Key &k : keys) { o |= k.sizes; a &= k.sizes; }
+		const u64 vary = o ^ a;
+		std::vector<Key> other(keys.size());
+		for (int shift = 0; shift < 64; shift += 8) {
+			if (!((vary >> shift) & 0xFFull)) continue;
+			size_t cnt[257] = {0};
+			for (const Key &k : keys) ++cnt[((k.sizes >> shift) & 0xFFull) + 1];
+			for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+			for (const Key &k : keys) other[cnt[(k.sizes >> shift) & 0xFFull]++] = k;
+			keys.swap(other);
+		}
+		for (size_t i = 0; i < keys.size();) {
+			size_t j = i + 1;
+			while (j < keys.size() && keys[j].sizes == keys[i].sizes) ++j;
+			if (j - i > 1) std::sort(keys.begin() + long(i), keys.begin() + long(j), less);
+			i = j;
+		}
+	} else
+		std::sort(keys.begin(), keys.end(), less);
 	filtered.clear(); filtered_ridx.clear();
 	size_t start = 0;
 	if (max_cells > 0 && size_t(max_cells) < keys.size()) start = keys.size() - size_t(max_cells);

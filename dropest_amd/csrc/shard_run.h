@@ -1008,7 +1008,31 @@ std::vector<dropest::u32> dropest_shard::order_rows(const std::vector<u32> &sel,
 		for (u32 kk = 0; kk < mm; ++kk) out[kk] = sel[perm[kk]];
 		return out;
 	}
-	std::sort(out.begin(), out.end(), [&](u32 x, u32 y) { return compare_cells_rows(G[x], G[y], c.side); });
+	// (requested genes, requested UMIs) decide almost every comparison: a stable LSD counting sort on their varying bytes, then only the
+	// runs of equal sizes by the full comparison (as dropest_ctx::sort_filtered does)
+	auto less = [&](u32 x, u32 y) { return compare_cells_rows(G[x], G[y], c.side); };
+	if (m > 64) {
+		auto sizes_of = [&](u32 i) { return (u64(G[i].req_genes) << 32) | G[i].req_umis; };
+		u64 o = 0, a = ~0ull;
+		for (u32 i : out) { o |= sizes_of(i); a &= sizes_of(i); }
+		const u64 vary = o ^ a;
+		std::vector<u32> other(m);
+		for (int shift = 0; shift < 64; shift += 8) {
+			if (!((vary >> shift) & 0xFFull)) continue;
+			size_t cnt[257] = {0};
+			for (u32 i : out) ++cnt[((sizes_of(i) >> shift) & 0xFFull) + 1];
+			for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+			for (u32 i : out) other[cnt[(sizes_of(i) >> shift) & 0xFFull]++] = i;
+			out.swap(other);
+		}
+		for (size_t i = 0; i < m;) {
+			size_t j = i + 1;
+			while (j < m && sizes_of(out[j]) == sizes_of(out[i])) ++j;
+			if (j - i > 1) std::sort(out.begin() + long(i), out.begin() + long(j), less);
+			i = j;
+		}
+	} else
+		std::sort(out.begin(), out.end(), less);
 	return out;
 }
 
