@@ -63,8 +63,10 @@ def parse():
 
 
 def matrix_form():
-    """What the step hands to the host (DROPEST_BENCH_MATRIX_FORM): "bytes" (default; dropest_count_matrix_csc_bytes), "u16", "u32"."""
-    return os.environ.get("DROPEST_BENCH_MATRIX_FORM", "u32" if os.environ.get("DROPEST_BENCH_WIDE_MATRIX") else "bytes")
+    """What the step hands to the host (DROPEST_BENCH_MATRIX_FORM): "u32" (default: dropest_count_matrix_csc, the dgCMatrix slots i / x as
+    32-bit arrays -- what ResultsPrinter::create_matrix fills, ResultsPrinter.cpp:433-442), "u32_direct" (the same arrays copied over PCIe as
+    they are instead of as bytes widened on host threads), "u16", "bytes" (the wire forms alone: their consumer still has to decode)."""
+    return os.environ.get("DROPEST_BENCH_MATRIX_FORM", "u32")
 
 
 def one_step(ctx, form=None):
@@ -73,13 +75,14 @@ def one_step(ctx, form=None):
     byte of count per entry plus two exact lists; lossless, decoded by dropest_matrix_bytes_widen or by the reader itself: the facade's
     ResultsPrinter turns entries into doubles either way); form = "u16" / "u32" selects the 16-bit / 32-bit forms."""
     form = form or matrix_form()
-    ctx.set_raw_matrix_prefetch({"u32": 0, "u16": 1, "bytes": 2}[form] if not os.environ.get("DROPEST_BENCH_NO_PREFETCH") else -1)
+    ctx.set_matrix_wire(form != "u32_direct")
+    ctx.set_raw_matrix_prefetch({"u32": 0, "u32_direct": 0, "u16": 1, "bytes": 2}[form] if not os.environ.get("DROPEST_BENCH_NO_PREFETCH") else -1)
     ctx.reset_results()
     ctx.set_initialized()
     ctx.merge_and_filter()
     if form == "u16" and not ctx.narrow_matrix_possible():
         form = "u32"
-    code = {"u32": 0, "u16": 1, "bytes": 2}[form]
+    code = {"u32": 0, "u32_direct": 0, "u16": 1, "bytes": 2}[form]
     if not os.environ.get("DROPEST_BENCH_NO_PREFETCH"):
         ctx.prefetch_raw_matrix(form=code)    # cm_raw's copy to the host runs under the preparation of cm
     if form == "bytes":
@@ -106,7 +109,8 @@ def form_text(cm, cm_raw):
     if len(cm) in (5, 6):    # (context: 5 arrays, sharded runner: 6 with the column barcodes)
         return ("CSC in pinned host memory, u32 colptr + u16 row index + u16 value + exact overflow list (%d + %d entries beyond 65534)"
                 % (len(cm[-2]), len(cm_raw[-2])))
-    return "CSC in pinned host memory, u32 colptr + u32 row index + u32 value"
+    return ("CSC in pinned host memory, u32 colptr + u32 row index + u32 value (the dgCMatrix slots i / x; sent over PCIe as bytes and widened "
+            "by the library's host threads inside the step)")
 
 
 def cpu_baseline(stream, n_sample, cfg, name="C2"):
@@ -394,25 +398,19 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
                                 dict(merge_kind=capi.MERGE_NONE, min_genes_before_merge=cfg["min_before"], min_genes_after_merge=cfg["min_after"]))
         cm = out[0]
         forms = None
-        if world == 1 and not force_sharded and hasattr(cm, "nnz") and not os.environ.get("DROPEST_BENCH_NO_FORMS"):
-            # the same step with the matrices in the wider forms, and the host-side decode of the byte form (3 steps each, after the timed region)
+        if world == 1 and not force_sharded and matrix_form() == "u32" and not os.environ.get("DROPEST_BENCH_NO_FORMS"):
+            # the same step with the matrices leaving in the other forms (3 steps each, after the timed region): the wire forms alone (their
+            # consumer still has to decode them) and the 32-bit arrays copied over PCIe as they are
             forms = {}
-            for f in ("u16", "u32"):
+            for f in ("bytes", "u16", "u32_direct"):
                 one_step(ctx, f)
                 fence(); t0 = time.perf_counter()
                 for _ in range(3):
                     one_step(ctx, f)
                 fence(); forms[f + "_ms_per_step"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
-            o2 = one_step(ctx, "bytes")
-            import numpy as np
-            bufs = [(np.ones(int(m.nnz), np.uint32), np.ones(int(m.nnz), np.uint32)) for m in (o2[0], o2[1])]   # (touched: no page faults in the timing)
-            t0 = time.perf_counter()
-            for m, b in zip((o2[0], o2[1]), bufs):
-                ctx.widen_bytes(m, out=b)
-            forms["bytes_decode_to_u32_on_host_threads_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
-            bufs = None
-            forms["note"] = "value / ms_per_step are measured with the byte form; the decode is what a consumer that wants 32-bit slots pays on its side"
-            out = o2
+            forms["note"] = ("value / ms_per_step are measured with the 32-bit slots on the host (bytes on the wire, widened under the copy); "
+                             "bytes / u16: the step ends with the wire form on the host, undecoded; u32_direct: 8 bytes per entry over PCIe")
+            out = one_step(ctx, "u32")
             cm = out[0]
         line = {
             "metric": "Mreads/s processed to final count matrix", "value": round(value, 2), "unit": "Mreads/s",

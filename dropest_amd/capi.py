@@ -153,6 +153,7 @@ def lib():
         "dropest_count_matrix_csc_bytes": (C.c_int, [vp, C.c_int, C.c_int, vp]),
         "dropest_matrix_bytes_widen": (C.c_int, [vp, vp, vp]),
         "dropest_set_raw_matrix_prefetch": (C.c_int, [vp, C.c_int, C.c_int]),
+        "dropest_set_matrix_wire": (C.c_int, [vp, C.c_int]),
         "dropest_push_reads_gather": (C.c_int, [vp, C.c_uint64, vp, vp, vp, vp, vp]),
         "dropest_shard_set_umi_qualities": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64]),
         "dropest_count_matrix_csc_narrow": (C.c_int, [vp, C.c_int, C.c_int, u64p, u64p, P(vp), P(vp), P(vp), u64p, P(vp), P(vp)]),
@@ -233,7 +234,7 @@ EXPORTED_SYMBOLS = [
     "dropest_shard_set_reads_device", "dropest_shard_push_reads", "dropest_reserve_reads", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix",
     "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option", "dropest_plan_columns",
     "dropest_key_width", "dropest_ctx_split", "dropest_shard_matrix_narrow", "dropest_shard_matrix_bytes", "dropest_add_umi_to_cell", "dropest_umi_first_seen", "dropest_resident_reads", "dropest_prefetch_raw_matrix_narrow", "dropest_narrow_matrix_possible", "dropest_count_matrix_csc_narrow",
-    "dropest_prefetch_raw_matrix_bytes", "dropest_count_matrix_csc_bytes", "dropest_matrix_bytes_widen", "dropest_set_raw_matrix_prefetch", "dropest_push_reads_gather", "dropest_shard_set_umi_qualities",
+    "dropest_prefetch_raw_matrix_bytes", "dropest_count_matrix_csc_bytes", "dropest_matrix_bytes_widen", "dropest_set_raw_matrix_prefetch", "dropest_set_matrix_wire", "dropest_push_reads_gather", "dropest_shard_set_umi_qualities",
     "dropest_debug_poison_scratch", "dropest_debug_trim_pool", "dropest_debug_alloc_ordinal", "dropest_debug_alloc_site",
 ]
 
@@ -455,6 +456,10 @@ class Context:
         cols = [P(*[s[k].ctypes.data for s in segs]) for k in range(4)]
         counts = (C.c_uint64 * max(1, n))(*[len(s[0]) for s in segs])
         self._chk(self.L.dropest_push_reads_gather(self.h, n, cols[0], cols[1], cols[2], cols[3], counts))
+
+    def set_matrix_wire(self, on=True):
+        """dropest_set_matrix_wire: large 32-bit matrices cross PCIe as bytes and are widened by host threads under the copy (default on)."""
+        self._chk(self.L.dropest_set_matrix_wire(self.h, int(bool(on))))
 
     def set_raw_matrix_prefetch(self, form=2, reads_output=False):
         """Announce the form cm_raw will be asked for (0 / 1 / 2; -1: off): the container starts its prefetch by itself."""

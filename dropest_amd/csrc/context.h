@@ -26,6 +26,7 @@
 #include "k_ssort.h"
 #include "k_segreduce.h"
 #include "k_mergepath.h"
+#include "matrix_decode.h"
 #include "util.h"
 
 namespace dropest {
@@ -411,8 +412,15 @@ struct dropest_ctx {
 		dropest::PinnedBuf<uint8_t> h_drow8, h_val8;
 		dropest::DevBuf<u32> d_rovf;
 		dropest::PinnedBuf<u32> h_rovf;
-		int narrow = 0;                 // the form of the last emit: 0 32-bit, 1 16-bit, 2 bytes
+		int narrow = 0;                 // the form of the last emit as the caller sees it: 0 32-bit, 1 16-bit, 2 bytes
 		u32 n_ovf = 0, n_rovf = 0;
+		u32 rcap = 0, vcap = 0;         // capacities of the row / value lists of the last byte-form emit
+		// 32-bit slots that travel as bytes (matrix_decode.h): the chunked copy's events and the job that widens into h_row / h_val
+		bool wire = false;
+		std::shared_ptr<dropest::DecodeJob> job;
+		std::vector<hipEvent_t> ev_chunk;
+		hipEvent_t ev_lists = nullptr;
+		~MatrixResult() { for (auto e : ev_chunk) (void)hipEventDestroy(e); if (ev_lists) (void)hipEventDestroy(ev_lists); }
 		std::vector<u32> colptr;
 		uint64_t nnz = 0, ncols = 0;
 	} mat[3];   // cm, cm_raw, and the filtered matrix under another mark query (emit_matrix_levels)
@@ -622,11 +630,16 @@ struct dropest_ctx {
 	void fetch_real_cells(bool at_init = false);
 	void request_filtered(u32 genes_threshold, int max_cells);   // CellsDataContainer::update_filtered_gene_counts, lazily
 	void sort_filtered(u32 genes_threshold, int max_cells);
-	void emit_matrix(bool filtered_m, bool reads_output, bool to_host = true, int form = 0);
+	void emit_matrix(bool filtered_m, bool reads_output, bool to_host = true, int form = 0, bool direct = false);
 	bool narrow_possible() const;
 	void matrix_outputs(MatrixResult &M, uint64_t nnz, int form, bool to_host, dropest::MatrixArgs &a);
 	void matrix_copy_out(MatrixResult &M, uint64_t nnz, hipStream_t st);
 	void matrix_finish_overflow(MatrixResult &M, hipStream_t st);
+	// 32-bit slots over the wire as bytes: true when this matrix takes that way (large enough, not switched off)
+	bool wire_wanted(uint64_t nnz, int form, bool to_host) const;
+	bool matrix_wire = true;        // dropest_set_matrix_wire
+	void wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_t st);   // after the byte-form emit on `st`: lists, chunked copies, the job
+	bool wire_finish(MatrixResult &M);                                          // waits for the job; false: the lists overflowed (emit the slots directly)
 	// columns of a count matrix from the host rows: cell id of every column, start of every column, number of entries
 	void matrix_columns(bool filtered_m, std::vector<u32> &col_cell, std::vector<u32> &colptr, uint64_t &nnz);
 	// cm_raw produced and copied to the host on a second stream while the caller goes on (dropest_prefetch_raw_matrix)

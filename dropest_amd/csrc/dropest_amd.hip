@@ -104,6 +104,7 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 dropest_ctx::~dropest_ctx() {
 	for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for (auto e : event_pool) (void)hipEventDestroy(e);
+	for (auto &M : mat) if (M.job) { (void)M.job->wait(); M.job.reset(); }
 	if (stream2) { (void)stream_wait(stream2); (void)hipStreamDestroy(stream2); }
 	if (ev_fork) (void)hipEventDestroy(ev_fork);
 	if (ev_raw) (void)hipEventDestroy(ev_raw);
@@ -1350,27 +1351,36 @@ void dropest_ctx::matrix_columns(bool filtered_m, std::vector<u32> &col_cell, st
 
 void dropest_ctx::invalidate_prefetch() {
 	if (raw_pf.in_flight && stream2) HIP_CHECK(stream_wait(stream2));   // its buffers are about to be reused
+	if (mat[1].job) { (void)mat[1].job->wait(); mat[1].job.reset(); }   // ... also by the host threads that widen them
 	raw_pf.valid = raw_pf.in_flight = false;
 }
 
 // Narrow CSC (16-bit row indices and values + an exact overflow list) is possible when every gene id fits 16 bits.
 bool dropest_ctx::narrow_possible() const { return n_reads == 0 || ingest.gene_max_plus1 <= 0x10000u; }
 
-static constexpr u32 MATRIX_OVF_CAP = 1u << 20;
+static constexpr u32 MATRIX_OVF_CAP = 1u << 20;   // value lists (a count beyond 254 / 65534 is rare in every matrix)
+// Row lists of the byte form.  A sparse column (a small cell of cm_raw: a few dozen of 30 000 genes) lists most of its rows; an eighth of
+// all entries listed costs as much again as the bytes themselves, and beyond that a wider form is the better wire.
+static u32 matrix_row_list_cap(uint64_t nnz) {
+	if (const char *e = getenv("DROPEST_MATRIX_ROW_LIST_CAP")) return u32(std::max(1L, atol(e)));   // (tests: a small list overflows on a small matrix)
+	return u32(std::min<uint64_t>(std::max<uint64_t>(nnz / 8, MATRIX_OVF_CAP), 1ull << 25));
+}
 
-// Wires the output side of an emit launch for matrix slot M (form 0 / 1 / 2) and makes sure the buffers exist.
+// Wires the output side of an emit launch for matrix slot M (device form 0 / 1 / 2) and makes sure the buffers exist.
 void dropest_ctx::matrix_outputs(MatrixResult &M, uint64_t nnz, int form, bool to_host, dropest::MatrixArgs &a) {
-	M.narrow = form; M.n_ovf = M.n_rovf = 0;
+	M.n_ovf = M.n_rovf = 0;
 	if (form) {
-		M.d_ovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP));
-		if (to_host) M.h_ovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP));
-		a.ovf_count = M.d_ovf.p; a.ovf_pos = M.d_ovf.p + 1; a.ovf_val = M.d_ovf.p + 1 + MATRIX_OVF_CAP; a.ovf_cap = MATRIX_OVF_CAP;
+		M.vcap = MATRIX_OVF_CAP;
+		M.d_ovf.ensure(1 + 2 * size_t(M.vcap));
+		if (to_host) M.h_ovf.ensure(1 + 2 * size_t(M.vcap));
+		a.ovf_count = M.d_ovf.p; a.ovf_pos = M.d_ovf.p + 1; a.ovf_val = M.d_ovf.p + 1 + M.vcap; a.ovf_cap = M.vcap;
 	}
 	if (form == 2) {
-		M.d_drow8.ensure(nnz); M.d_val8.ensure(nnz); M.d_rovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP));
-		if (to_host) { M.h_drow8.ensure(nnz); M.h_val8.ensure(nnz); M.h_rovf.ensure(1 + 2 * size_t(MATRIX_OVF_CAP)); }
+		M.rcap = matrix_row_list_cap(nnz);
+		M.d_drow8.ensure(nnz); M.d_val8.ensure(nnz); M.d_rovf.ensure(1 + 2 * size_t(M.rcap));
+		if (to_host) { M.h_drow8.ensure(nnz); M.h_val8.ensure(nnz); M.h_rovf.ensure(1 + 2 * size_t(M.rcap)); }
 		a.t_drow8 = M.d_drow8.p; a.t_val8 = M.d_val8.p;
-		a.rovf_count = M.d_rovf.p; a.rovf_pos = M.d_rovf.p + 1; a.rovf_row = M.d_rovf.p + 1 + MATRIX_OVF_CAP;
+		a.rovf_count = M.d_rovf.p; a.rovf_pos = M.d_rovf.p + 1; a.rovf_row = M.d_rovf.p + 1 + M.rcap; a.rovf_cap = M.rcap;
 	} else if (form == 1) {
 		M.d_row16.ensure(nnz); M.d_val16.ensure(nnz);
 		if (to_host) { M.h_row16.ensure(nnz); M.h_val16.ensure(nnz); }
@@ -1404,25 +1414,86 @@ void dropest_ctx::matrix_copy_out(MatrixResult &M, uint64_t nnz, hipStream_t st)
 void dropest_ctx::matrix_finish_overflow(MatrixResult &M, hipStream_t st) {
 	M.n_ovf = M.n_rovf = 0;
 	if (!M.narrow || !M.nnz) return;
-	auto finish = [&](dropest::DevBuf<u32> &d, dropest::PinnedBuf<u32> &h, u32 &n_out, const char *what) {
+	auto finish = [&](dropest::DevBuf<u32> &d, dropest::PinnedBuf<u32> &h, u32 cap, u32 &n_out, const char *what) {
 		const u32 count = h.p[0];
-		if (count > MATRIX_OVF_CAP) throw UnsupportedError(std::string("more than 2^20 matrix entries with ") + what + ": use a wider form of the count matrix");
+		if (count > cap) throw UnsupportedError(std::string("more than ") + std::to_string(cap) + " matrix entries with " + what + ": take the 32-bit form of the count matrix (dropest_count_matrix_csc)");
 		n_out = count;
 		if (!count) return;
 		HIP_CHECK(hipMemcpyAsync(h.p + 1, d.p + 1, size_t(count) * 4, hipMemcpyDeviceToHost, st));
-		HIP_CHECK(hipMemcpyAsync(h.p + 1 + MATRIX_OVF_CAP, d.p + 1 + MATRIX_OVF_CAP, size_t(count) * 4, hipMemcpyDeviceToHost, st));
+		HIP_CHECK(hipMemcpyAsync(h.p + 1 + cap, d.p + 1 + cap, size_t(count) * 4, hipMemcpyDeviceToHost, st));
 		HIP_CHECK(stream_wait(st));
 		// The list is filled in the order the atomics landed.  The 16-bit form promises it sorted by position (a handful of entries).  The
 		// byte form does not: the small cells of cm_raw list 4e5 rows at C2 (25 ms of std::sort here, 0.9 ms of radix passes and their
 		// waits on the device), and its decoder needs no order (dropest_matrix_bytes_widen).
 		if (M.narrow == 2) return;
 		std::vector<std::pair<u32, u32>> ov(count);
-		for (u32 i = 0; i < count; ++i) ov[i] = {h.p[1 + i], h.p[1 + MATRIX_OVF_CAP + i]};
+		for (u32 i = 0; i < count; ++i) ov[i] = {h.p[1 + i], h.p[1 + cap + i]};
 		std::sort(ov.begin(), ov.end());
-		for (u32 i = 0; i < count; ++i) { h.p[1 + i] = ov[i].first; h.p[1 + MATRIX_OVF_CAP + i] = ov[i].second; }
+		for (u32 i = 0; i < count; ++i) { h.p[1 + i] = ov[i].first; h.p[1 + cap + i] = ov[i].second; }
 	};
-	finish(M.d_ovf, M.h_ovf, M.n_ovf, M.narrow == 2 ? "a count beyond 254" : "a count beyond 65534");
-	if (M.narrow == 2) finish(M.d_rovf, M.h_rovf, M.n_rovf, "a row gap beyond 254");
+	finish(M.d_ovf, M.h_ovf, M.vcap, M.n_ovf, M.narrow == 2 ? "a count beyond 254" : "a count beyond 65534");
+	if (M.narrow == 2) finish(M.d_rovf, M.h_rovf, M.rcap, M.n_rovf, "a row gap beyond 254");
+}
+
+// ---- 32-bit slots that cross PCIe as bytes (matrix_decode.h) ----
+// dropest_count_matrix_csc hands out the dgCMatrix slots i / x as 32-bit arrays (ResultsPrinter.cpp:433-442).  As such they are 8 bytes
+// per entry on a link of ~50 GB/s -- 6 ms for the 3.8e7 entries of C2, the longest single piece of a 10 ms pass.  So a large matrix is
+// emitted in the byte form (2 bytes per entry), copied in chunks of whole columns with an event behind each, and widened into the slots by
+// host threads while the next chunk is on the link.  Lists longer than their capacity (a matrix of very sparse columns): the slots are emitted
+// directly instead, as before (wire_finish returns false).  DROPEST_MATRIX_DIRECT=1 switches the detour off.
+bool dropest_ctx::wire_wanted(uint64_t nnz, int form, bool to_host) const {
+	static const bool off = getenv("DROPEST_MATRIX_DIRECT") != nullptr;
+	return form == 0 && to_host && !off && matrix_wire && nnz >= (1u << 18);
+}
+
+void dropest_ctx::wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_t st) {
+	using namespace dropest;
+	M.h_row.ensure(nnz); M.h_val.ensure(nnz);
+	if (!M.ev_lists) HIP_CHECK(hipEventCreateWithFlags(&M.ev_lists, hipEventDisableTiming));
+	hipLaunchKernelGGL(matrix_lists_out_kernel, dim3(64), dim3(256), 0, st, M.d_rovf.p, M.rcap, M.h_rovf.p, M.d_ovf.p, M.vcap, M.h_ovf.p);
+	HIP_CHECK(hipGetLastError());
+	HIP_CHECK(hipEventRecord(M.ev_lists, st));
+	auto job = std::make_shared<DecodeJob>();
+	HIP_CHECK(hipGetDevice(&job->device));
+	job->m.rd = M.h_drow8.p; job->m.vb = M.h_val8.p; job->m.colptr = M.colptr.data(); job->m.ncols = M.ncols; job->m.nnz = nnz;
+	job->ro = M.h_row.p; job->vo = M.h_val.p;
+	job->r_count = M.h_rovf.p; job->r_pos = M.h_rovf.p + 1; job->r_val = M.h_rovf.p + 1 + M.rcap; job->rcap = M.rcap;
+	job->v_count = M.h_ovf.p; job->v_pos = M.h_ovf.p + 1; job->v_val = M.h_ovf.p + 1 + M.vcap; job->vcap = M.vcap;
+	job->ev_lists = M.ev_lists;
+	static const uint64_t n_chunks = [] { const char *e = getenv("DROPEST_WIRE_CHUNKS"); return uint64_t(e ? std::max(1, atoi(e)) : 12); }();
+	cut_columns(M.colptr.data(), 0, size_t(M.ncols), std::max<uint64_t>(nnz / n_chunks + 1, uint64_t(1) << 19), job->chunk_end);
+	while (M.ev_chunk.size() < job->chunk_end.size()) {
+		hipEvent_t e = nullptr;
+		HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		M.ev_chunk.push_back(e);
+	}
+	u32 c0 = 0;
+	for (size_t j = 0; j < job->chunk_end.size(); ++j) {
+		const u32 c1 = job->chunk_end[j];
+		const size_t k0 = M.colptr[c0], k1 = M.colptr[c1];
+		if (k1 > k0) {
+			HIP_CHECK(hipMemcpyAsync(M.h_drow8.p + k0, M.d_drow8.p + k0, k1 - k0, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(M.h_val8.p + k0, M.d_val8.p + k0, k1 - k0, hipMemcpyDeviceToHost, st));
+		}
+		HIP_CHECK(hipEventRecord(M.ev_chunk[j], st));
+		job->ev_chunk.push_back(M.ev_chunk[j]);
+		c0 = c1;
+	}
+	job->prepare(uint64_t(1) << 16);
+	M.job = job; M.wire = true;
+	DecodePool::get().submit(job);
+}
+
+bool dropest_ctx::wire_finish(MatrixResult &M) {
+	using dropest::DecodeJob;
+	if (!M.job) return true;
+	HostStage hs(this, "matrix:decode_wait");
+	const int st = M.job->wait();
+	M.n_rovf = M.job->n_r; M.n_ovf = M.job->n_v;
+	M.job.reset();
+	if (st == DecodeJob::DONE) return true;
+	if (st == DecodeJob::OVERFLOW) return false;
+	throw DeviceError(st == DecodeJob::FAILED ? "count matrix: a copy of the byte form failed" : "count matrix: a listed entry of the byte form lies outside the matrix");
 }
 
 // Byte form: long columns by the workgroup-per-column kernel, short ones (fewer than 256 (cell, gene) rows) by the wave-per-column kernel.
@@ -1446,7 +1517,8 @@ void dropest_ctx::launch_emit_bytes(dropest::MatrixArgs a, const std::vector<u32
 }
 
 // cm_raw on a second stream: emit + device-to-host copy start now and run under whatever the caller does next (ordering
-// the filtered cells, emitting cm); dropest_count_matrix_csc(filtered = 0) later only waits for the copy.
+// the filtered cells, emitting cm); dropest_count_matrix_csc(filtered = 0) later only waits for the copy (and, for the 32-bit
+// slots that travel as bytes, for the host threads that widen them).
 void dropest_ctx::prefetch_raw_matrix(bool reads_output, int narrow, const dropest::CellRowPod *rows, const u32 *ids, u32 count) {
 	if (raw_pf.valid && raw_pf.reads_output == reads_output && raw_pf.narrow == narrow) return;   // already under way (dropest_set_raw_matrix_prefetch)
 	HostStage hs(this, "prefetch:cm_raw");
@@ -1462,7 +1534,7 @@ void dropest_ctx::prefetch_raw_matrix(bool reads_output, int narrow, const drope
 		M.colptr[count] = u32(nnz);
 	} else
 		matrix_columns(false, raw_pf.col_cell, M.colptr, nnz);
-	M.nnz = nnz; M.ncols = raw_pf.col_cell.size(); M.narrow = narrow; M.n_ovf = 0;
+	M.nnz = nnz; M.ncols = raw_pf.col_cell.size(); M.narrow = narrow; M.n_ovf = M.n_rovf = 0; M.wire = false;
 	raw_pf.valid = true; raw_pf.reads_output = reads_output; raw_pf.narrow = narrow;
 	if (nnz == 0) return;
 	if (!stream2) {
@@ -1473,70 +1545,82 @@ void dropest_ctx::prefetch_raw_matrix(bool reads_output, int narrow, const drope
 	const u32 ncols = u32(raw_pf.col_cell.size());
 	m2_col_cell.ensure(ncols); m2_col_start.ensure(ncols);
 	MatrixArgs a{};
-	matrix_outputs(M, nnz, narrow, true, a);
+	const bool wire = wire_wanted(nnz, narrow, true);
+	const int dev_form = wire ? 2 : narrow;
+	matrix_outputs(M, nnz, dev_form, true, a);
 	HIP_CHECK(hipEventRecord(ev_fork, stream));                // everything enqueued so far (the tables) comes first
 	HIP_CHECK(hipStreamWaitEvent(stream2, ev_fork, 0));
 	HIP_CHECK(hipMemcpyAsync(m2_col_cell.p, raw_pf.col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream2));
 	HIP_CHECK(hipMemcpyAsync(m2_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream2));
-	if (narrow) HIP_CHECK(hipMemsetAsync(M.d_ovf.p, 0, 4, stream2));
-	if (narrow == 2) HIP_CHECK(hipMemsetAsync(M.d_rovf.p, 0, 4, stream2));
+	if (dev_form) HIP_CHECK(hipMemsetAsync(M.d_ovf.p, 0, 4, stream2));
+	if (dev_form == 2) HIP_CHECK(hipMemsetAsync(M.d_rovf.p, 0, 4, stream2));
 	a.col_cell = m2_col_cell.p; a.col_start = m2_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
 	a.value = reads_output ? cg_reads_all.p : cg_n_all.p;
 	a.gene_mask = layout.gene_none; a.skip_zero = 0;
-	if (narrow == 2) {
+	if (dev_form == 2) {
 		std::vector<u32> rows(ncols);   // (an upper bound of every column's entries: cm_raw keeps all of a cell's genes)
 		for (u32 j = 0; j < ncols; ++j) rows[j] = M.colptr[j + 1] - M.colptr[j];
 		launch_emit_bytes(a, rows, m2_col_list, m2_col_list_host, stream2);
 	}
-	else if (narrow == 1) hipLaunchKernelGGL(emit_matrix_kernel<1>, dim3(ncols), dim3(256), 0, stream2, a);
+	else if (dev_form == 1) hipLaunchKernelGGL(emit_matrix_kernel<1>, dim3(ncols), dim3(256), 0, stream2, a);
 	else hipLaunchKernelGGL(emit_matrix_kernel<0>, dim3(ncols), dim3(256), 0, stream2, a);
 	HIP_CHECK(hipGetLastError());
-	matrix_copy_out(M, nnz, stream2);
+	if (wire) wire_copy_and_decode(M, nnz, stream2); else matrix_copy_out(M, nnz, stream2);
 	HIP_CHECK(hipEventRecord(ev_raw, stream2));
 	raw_pf.in_flight = true;
 }
 
-void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, int narrow) {
+void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, int narrow, bool direct) {
 	HostStage hs(this, filtered_m ? "matrix:cm" : "matrix:cm_raw");
 	if (narrow == 1 && !narrow_possible()) throw UnsupportedError("gene ids beyond 65535: the narrow matrix form is not available");
 	MatrixResult &M = mat[filtered_m ? 0 : 1];
 	std::vector<u32> col_cell;
 	uint64_t nnz = 0;
-	if (!filtered_m && raw_pf.valid && to_host && raw_pf.reads_output == reads_output && raw_pf.narrow == narrow) {
+	if (!direct && !filtered_m && raw_pf.valid && to_host && raw_pf.reads_output == reads_output && raw_pf.narrow == narrow) {
 		// A prefetched cm_raw of the same value kind and form IS what this call would produce: whatever changes the container
 		// (merges, mutators, a new pass) discards the prefetch on its way in (invalidate_prefetch), so a valid one is current.
 		// (Round 2 rebuilt and compared the column lists here: two walks over 2.5 M cells, 10 ms of a C3 pass.)
-		if (raw_pf.in_flight) { HIP_CHECK(event_wait(ev_raw)); raw_pf.in_flight = false; matrix_finish_overflow(M, stream2); }
-		return;
+		bool ok = true;
+		if (raw_pf.in_flight) {
+			HIP_CHECK(event_wait(ev_raw)); raw_pf.in_flight = false;
+			if (M.wire) ok = wire_finish(M); else matrix_finish_overflow(M, stream2);
+		}
+		if (ok) return;
+		direct = true;   // the lists of the byte form overflowed: the slots come directly
 	}
 	if (!filtered_m) invalidate_prefetch();
+	if (M.job) { (void)M.job->wait(); M.job.reset(); }
 	matrix_columns(filtered_m, col_cell, M.colptr, nnz);
-	M.nnz = nnz; M.ncols = col_cell.size(); M.narrow = narrow; M.n_ovf = 0;
+	M.nnz = nnz; M.ncols = col_cell.size(); M.narrow = narrow; M.n_ovf = M.n_rovf = 0; M.wire = false;
 	if (nnz == 0) return;
 	const u32 ncols = u32(col_cell.size());
 	m_col_cell.ensure(ncols); m_col_start.ensure(ncols);
 	MatrixArgs a{};
-	matrix_outputs(M, nnz, narrow, to_host, a);
+	const bool wire = !direct && wire_wanted(nnz, narrow, to_host);
+	const int dev_form = wire ? 2 : narrow;
+	matrix_outputs(M, nnz, dev_form, to_host, a);
 	HIP_CHECK(hipMemcpyAsync(m_col_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
 	HIP_CHECK(hipMemcpyAsync(m_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
-	if (narrow) HIP_CHECK(hipMemsetAsync(M.d_ovf.p, 0, 4, stream));
-	if (narrow == 2) HIP_CHECK(hipMemsetAsync(M.d_rovf.p, 0, 4, stream));
+	if (dev_form) HIP_CHECK(hipMemsetAsync(M.d_ovf.p, 0, 4, stream));
+	if (dev_form == 2) HIP_CHECK(hipMemsetAsync(M.d_rovf.p, 0, 4, stream));
 	a.col_cell = m_col_cell.p; a.col_start = m_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
 	a.value = filtered_m ? (reads_output ? cg_reads_req.p : cg_n_req.p) : (reads_output ? cg_reads_all.p : cg_n_all.p);
 	a.gene_mask = layout.gene_none; a.skip_zero = filtered_m ? 1 : 0;
-	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * (narrow == 2 ? 14 : narrow ? 16 : 20), [&] {
-		if (narrow == 2) {
+	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * (dev_form == 2 ? 14 : dev_form ? 16 : 20), [&] {
+		if (dev_form == 2) {
 			std::vector<u32> rows(ncols);   // entries per column (cm: the requested genes; the kernel walks a few more rows and drops the zeros)
 			for (u32 j = 0; j < ncols; ++j) rows[j] = M.colptr[j + 1] - M.colptr[j];
 			launch_emit_bytes(a, rows, m_col_list, m_col_list_host, stream);
 		}
-		else if (narrow == 1) hipLaunchKernelGGL(emit_matrix_kernel<1>, dim3(ncols), dim3(256), 0, stream, a);
+		else if (dev_form == 1) hipLaunchKernelGGL(emit_matrix_kernel<1>, dim3(ncols), dim3(256), 0, stream, a);
 		else hipLaunchKernelGGL(emit_matrix_kernel<0>, dim3(ncols), dim3(256), 0, stream, a);
 	});
-	if (to_host) matrix_copy_out(M, nnz, stream);
+	if (to_host) { if (wire) wire_copy_and_decode(M, nnz, stream); else matrix_copy_out(M, nnz, stream); }
 	HIP_CHECK(stream_wait(stream));   // col_cell (host vector) must outlive the H2D copy
-	if (to_host) matrix_finish_overflow(M, stream);
+	bool ok = true;
+	if (to_host) { if (wire) ok = wire_finish(M); else matrix_finish_overflow(M, stream); }
 	collect_timings();
+	if (!ok) emit_matrix(filtered_m, reads_output, to_host, narrow, true);
 }
 
 // Sharded runs: the columns of a caller-given list of cells, emitted compactly into the device staging of matrix slot
@@ -2221,7 +2305,7 @@ dropest_status dropest_count_matrix_csc_narrow(dropest_ctx *ctx, int filtered, i
 		const dropest_ctx::MatrixResult &M = ctx->mat[filtered ? 0 : 1];
 		*ncols = M.ncols; *nnz = M.nnz;
 		*colptr = M.colptr.data(); *rowidx = M.h_row16.p; *values = M.h_val16.p;
-		*n_overflow = M.n_ovf; *overflow_pos = M.h_ovf.p ? M.h_ovf.p + 1 : nullptr; *overflow_val = M.h_ovf.p ? M.h_ovf.p + 1 + MATRIX_OVF_CAP : nullptr;
+		*n_overflow = M.n_ovf; *overflow_pos = M.h_ovf.p ? M.h_ovf.p + 1 : nullptr; *overflow_val = M.h_ovf.p ? M.h_ovf.p + 1 + M.vcap : nullptr;
 	});
 }
 
@@ -2230,6 +2314,14 @@ dropest_status dropest_set_raw_matrix_prefetch(dropest_ctx *ctx, int form, int r
 		if (!ctx) throw InvalidError("null context");
 		if (form < -1 || form > 2) throw InvalidError("form: -1 (off), 0 (32-bit), 1 (16-bit), 2 (bytes)");
 		ctx->auto_pf_form = form; ctx->auto_pf_reads = reads_output != 0;
+	});
+}
+
+dropest_status dropest_set_matrix_wire(dropest_ctx *ctx, int enabled) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		ctx->invalidate_prefetch();
+		ctx->matrix_wire = enabled != 0;
 	});
 }
 
@@ -2248,42 +2340,35 @@ dropest_status dropest_count_matrix_csc_bytes(dropest_ctx *ctx, int filtered, in
 		const dropest_ctx::MatrixResult &M = ctx->mat[filtered ? 0 : 1];
 		out->ncols = M.ncols; out->nnz = M.nnz; out->colptr = M.colptr.data();
 		out->row_delta = M.h_drow8.p; out->value = M.h_val8.p;
-		out->n_row_listed = M.n_rovf; out->row_listed_pos = M.h_rovf.p ? M.h_rovf.p + 1 : nullptr; out->row_listed_row = M.h_rovf.p ? M.h_rovf.p + 1 + MATRIX_OVF_CAP : nullptr;
-		out->n_value_listed = M.n_ovf; out->value_listed_pos = M.h_ovf.p ? M.h_ovf.p + 1 : nullptr; out->value_listed_value = M.h_ovf.p ? M.h_ovf.p + 1 + MATRIX_OVF_CAP : nullptr;
+		out->n_row_listed = M.n_rovf; out->row_listed_pos = M.h_rovf.p ? M.h_rovf.p + 1 : nullptr; out->row_listed_row = M.h_rovf.p ? M.h_rovf.p + 1 + M.rcap : nullptr;
+		out->n_value_listed = M.n_ovf; out->value_listed_pos = M.h_ovf.p ? M.h_ovf.p + 1 : nullptr; out->value_listed_value = M.h_ovf.p ? M.h_ovf.p + 1 + M.vcap : nullptr;
 	});
 }
 
 // dgCMatrix slots i / x from the byte form.  The listed entries come in no particular order: they are written to their places first, then
-// every column is walked once (a column's first delta counts from row -1; a 255 takes what the first phase put there).
+// every column is walked once (a column's first delta counts from row -1; a 255 takes what the first phase put there).  The walk is the one
+// dropest_count_matrix_csc runs under its copies (matrix_decode.h), here with everything already on the host; the calling thread takes part.
 dropest_status dropest_matrix_bytes_widen(const dropest_matrix_bytes *m, uint32_t *rowidx, uint32_t *values) {
 	return guarded([&] {
 		if (!m || (m->nnz && (!rowidx || !values))) throw InvalidError("null argument");
 		if (!m->nnz) return;
-		std::atomic<int> bad{0};   // (an exception must not leave a worker thread)
-		const uint64_t nnz = m->nnz;
-		parallel_ranges(m->n_row_listed, [&](size_t b, size_t e, unsigned) {
-			for (size_t i = b; i < e; ++i) { const uint32_t k = m->row_listed_pos[i]; if (k >= nnz || m->row_delta[k] != 255u) { bad = 1; return; } rowidx[k] = m->row_listed_row[i]; }
-		}, 65536, dropest::HostPool::MAX);
-		parallel_ranges(m->n_value_listed, [&](size_t b, size_t e, unsigned) {
-			for (size_t i = b; i < e; ++i) { const uint32_t k = m->value_listed_pos[i]; if (k >= nnz || m->value[k] != 255u) { bad = 2; return; } values[k] = m->value_listed_value[i]; }
-		}, 65536, dropest::HostPool::MAX);
-		if (bad) throw InvalidError(bad == 1 ? "byte matrix: a listed row does not stand on a 255" : "byte matrix: a listed value does not stand on a 255");
-		const uint8_t *__restrict rd = m->row_delta, *__restrict vb = m->value;   // (locals: the stores below must not force reloads of m's fields)
-		const uint32_t *__restrict cp = m->colptr;
-		uint32_t *__restrict ro = rowidx, *__restrict vo = values;
-		parallel_ranges(m->ncols, [&](size_t cb, size_t ce, unsigned) {
-			for (size_t c = cb; c < ce; ++c) {
-				uint32_t prev1 = 0;   // previous row + 1
-				const uint32_t k1 = cp[c + 1];
-				for (uint32_t k = cp[c]; k < k1; ++k) {
-					const uint32_t d = rd[k], v = vb[k];
-					const uint32_t row = d == 255u ? ro[k] : prev1 + d - 1u;
-					prev1 = row + 1u;
-					ro[k] = row;
-					if (v != 255u) vo[k] = v;
-				}
-			}
-		}, 32, dropest::HostPool::MAX);   // (columns differ in length by orders of magnitude: small ranges, every worker gets some of each kind)
+		if (m->n_row_listed > 0xFFFFFFFFull || m->n_value_listed > 0xFFFFFFFFull) throw InvalidError("byte matrix: a list longer than the matrix");
+		auto job = std::make_shared<dropest::DecodeJob>();
+		(void)hipGetDevice(&job->device);
+		(void)hipGetLastError();   // (no device: the walk needs none)
+		job->m.rd = m->row_delta; job->m.vb = m->value; job->m.colptr = m->colptr; job->m.ncols = m->ncols; job->m.nnz = m->nnz;
+		job->ro = rowidx; job->vo = values;
+		const uint32_t nr = uint32_t(m->n_row_listed), nv = uint32_t(m->n_value_listed);
+		job->r_count = &nr; job->r_pos = m->row_listed_pos; job->r_val = m->row_listed_row; job->rcap = nr;
+		job->v_count = &nv; job->v_pos = m->value_listed_pos; job->v_val = m->value_listed_value; job->vcap = nv;
+		job->check_marks = true;
+		job->prepare(uint64_t(1) << 16);
+		dropest::DecodePool::get().submit(job);
+		job->work();
+		const int st = job->wait();
+		if (st == dropest::DecodeJob::BAD_ROW) throw InvalidError("byte matrix: a listed row does not stand on a 255");
+		if (st == dropest::DecodeJob::BAD_VALUE) throw InvalidError("byte matrix: a listed value does not stand on a 255");
+		if (st != dropest::DecodeJob::DONE) throw InvalidError("byte matrix: the decode failed");
 	});
 }
 

@@ -793,12 +793,14 @@ ResultsPrinter::SparseMatrix ResultsPrinter::get_count_matrix(const CellsDataCon
 		if (reads_output) throw std::runtime_error("reads_output is not available on a container sharded over several GPUs");
 		return sharded_matrix(c, filtered, reference_row_order);
 	}
-	// the byte form over PCIe (2 bytes per entry instead of 8), widened here on the library's host threads: the slots i / x of the dgCMatrix
-	dropest_matrix_bytes mb{};
-	if (dropest_count_matrix_csc_bytes(c.handle(), filtered ? 1 : 0, reads_output ? 1 : 0, &mb) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
-	std::vector<uint32_t> rowidx(mb.nnz), values(mb.nnz);
-	if (dropest_matrix_bytes_widen(&mb, rowidx.data(), values.data()) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
-	return named_matrix(c, filtered, reference_row_order, mb.ncols, mb.nnz, mb.colptr, rowidx.data(), values.data());
+	// the dgCMatrix slots i / x (ResultsPrinter.cpp:433-442).  The library sends a large matrix over PCIe as bytes (2 per entry instead of 8)
+	// and widens it into these slots on its host threads while the copy is still running; a matrix whose sparse columns do not suit the byte
+	// form comes as 32-bit arrays directly -- either way this call cannot fail for the shape of the data.
+	uint64_t ncols = 0, nnz = 0;
+	const uint32_t *colptr = nullptr, *rowidx = nullptr, *values = nullptr;
+	if (dropest_count_matrix_csc(c.handle(), filtered ? 1 : 0, reads_output ? 1 : 0, &ncols, &nnz, &colptr, &rowidx, &values) != DROPEST_OK)
+		throw std::runtime_error(dropest_last_error());
+	return named_matrix(c, filtered, reference_row_order, ncols, nnz, colptr, rowidx, values);
 }
 
 static std::string levels_code(const UMI::Mark::query_t &query) {   // inverse of UMI::Mark::get_by_code (UMI.cpp:112-154)
@@ -908,7 +910,7 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 	using namespace Rds;
 	// both matrices are part of the list: cm_raw's emit + copy to the host start now, on the device's second stream, and
 	// run under the cell rows and cm (a sharded container has assembled both already)
-	if (!c.sharded() && dropest_prefetch_raw_matrix_bytes(c.handle(), reads_output ? 1 : 0) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+	if (!c.sharded() && dropest_prefetch_raw_matrix(c.handle(), reads_output ? 1 : 0) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
 	const std::vector<Cell> real = c.real_cells();                      // cell-id order (sharded: of ONE container over the stream)
 	const std::vector<size_t> filtered_at = c.filtered_positions(real);
 	std::vector<std::string> real_names;

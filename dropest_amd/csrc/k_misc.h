@@ -288,6 +288,7 @@ struct MatrixArgs {
 	// well under 1 % of the entries are listed.
 	uint8_t *t_drow8, *t_val8;
 	uint32_t *rovf_count, *rovf_pos, *rovf_row;
+	uint32_t rovf_cap;              // capacity of the row list (the value list: ovf_cap)
 	const uint32_t *col_list;       // non-null: the launch covers these columns only (n_list of them)
 	uint32_t n_list;
 };
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(256) void emit_matrix_kernel(MatrixArgs a) {
 				stage_d[ex] = delta >= 255u ? uint8_t(255u) : uint8_t(delta);
 				stage_v[ex] = v >= 255u ? uint8_t(255u) : uint8_t(v);
 			}
-			matrix_list_append(keep && delta >= 255u, out + ex, g, a.rovf_count, a.rovf_pos, a.rovf_row, a.ovf_cap);
+			matrix_list_append(keep && delta >= 255u, out + ex, g, a.rovf_count, a.rovf_pos, a.rovf_row, a.rovf_cap);
 			matrix_list_append(keep && v >= 255u, out + ex, v, a.ovf_count, a.ovf_pos, a.ovf_val, a.ovf_cap);
 			__syncthreads();
 			{   // the round's bytes leave as aligned 4-byte words (one-byte stores of 256 threads cost 3x the 16-bit form's kernel time)
@@ -414,8 +415,21 @@ __global__ __launch_bounds__(256) void emit_matrix_bytes_short_kernel(MatrixArgs
 	__syncthreads();
 	for (uint32_t k = 0; k < 2; ++k) {
 		uint32_t *lp = k ? a.ovf_pos : a.rovf_pos, *lv = k ? a.ovf_val : a.rovf_row;
-		for (uint32_t j = threadIdx.x; j < st_n[k]; j += 256) { const uint32_t at = st_base[k] + j; if (at < a.ovf_cap) { lp[at] = st_pos[k][j]; lv[at] = st_val[k][j]; } }
+		const uint32_t cap = k ? a.ovf_cap : a.rovf_cap;
+		for (uint32_t j = threadIdx.x; j < st_n[k]; j += 256) { const uint32_t at = st_base[k] + j; if (at < cap) { lp[at] = st_pos[k][j]; lv[at] = st_val[k][j]; } }
 	}
+}
+
+// The two lists of a byte-form emit -> pinned host memory, with their exact lengths read on the device: no host round trip between the
+// emit and the copies that follow it on the stream.  A list longer than its capacity sends its count only (the host then asks for a wider form).
+// d / h: [0] count, [1 ..] positions, [1 + cap ..] rows / values.
+__global__ __launch_bounds__(256) void matrix_lists_out_kernel(const uint32_t *__restrict__ d_r, uint32_t rcap, uint32_t *__restrict__ h_r,
+                                                               const uint32_t *__restrict__ d_v, uint32_t vcap, uint32_t *__restrict__ h_v) {
+	const uint32_t t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+	const uint32_t nr = d_r[0], nv = d_v[0];
+	if (t == 0) { h_r[0] = nr; h_v[0] = nv; }
+	if (nr <= rcap) for (uint32_t i = t; i < nr; i += stride) { h_r[1 + i] = d_r[1 + i]; h_r[1 + size_t(rcap) + i] = d_r[1 + size_t(rcap) + i]; }
+	if (nv <= vcap) for (uint32_t i = t; i < nv; i += stride) { h_v[1 + i] = d_v[1 + i]; h_v[1 + size_t(vcap) + i] = d_v[1 + size_t(vcap) + i]; }
 }
 
 // requested UMIs / reads of every (cell, gene) row under ANOTHER mark query than the container's own

@@ -238,6 +238,12 @@ dropest_status dropest_count_matrix(dropest_ctx *ctx, int filtered, int reads_ou
 dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int reads_output, uint64_t *ncols,
                                         uint64_t *nnz, const uint32_t **colptr, const uint32_t **rowidx,
                                         const uint32_t **values);
+/* How the 32-bit slots of a large matrix (>= 2^18 entries) reach the host.  On (the default): the device emits the byte form
+ * below, the copy is cut into chunks of whole columns and the library's host threads widen every chunk into rowidx / values as
+ * soon as it has landed (csrc/matrix_decode.h) -- 2 bytes per entry on the PCIe link instead of 8, the decode hidden under the
+ * copy; a matrix whose row list would not fit (very sparse columns) is emitted as 32-bit arrays after all.  Off: always 32-bit
+ * arrays over the link.  Same results either way; DROPEST_MATRIX_DIRECT=1 in the environment switches it off for the process. */
+dropest_status dropest_set_matrix_wire(dropest_ctx *ctx, int enabled);
 
 /* ResultsPrinter::save_results (ResultsPrinter.cpp:23-79) always builds both matrices.  This call starts cm_raw on a
  * second stream -- emit kernel and the device-to-host copy -- and returns at once; what the caller does next (the
@@ -264,8 +270,8 @@ dropest_status dropest_prefetch_raw_matrix_narrow(dropest_ctx *ctx, int reads_ou
  *   value[k]     = the count; 255 = listed in (value_listed_pos, value_listed_value)
  * The lists come in no particular order (the device appends to them as it goes).  A cell with a few thousand of 30 000 genes has row gaps of ~10 and counts of a few UMIs: well under
  * 1 % of the entries are listed.  dropest_matrix_bytes_widen decodes into the dgCMatrix slots i / x on host threads (what ResultsPrinter
- * does while it writes its doubles); tests/test_gpu_narrow.py checks it against dropest_count_matrix_csc bit for bit.  More than 2^20
- * listed entries of a kind: DROPEST_ERR_UNSUPPORTED (take the 16-bit or the 32-bit form).  Pointers refer to pinned host memory of the
+ * does while it writes its doubles); tests/test_gpu_narrow.py checks it against dropest_count_matrix_csc bit for bit.  More than
+ * max(2^20, nnz / 8) listed rows or 2^20 listed values: DROPEST_ERR_UNSUPPORTED (take the 32-bit form: dropest_count_matrix_csc never refuses).  Pointers refer to pinned host memory of the
  * context, valid until the next emit of the same matrix. */
 typedef struct dropest_matrix_bytes {
 	uint64_t ncols, nnz;

@@ -194,7 +194,27 @@ def test_sortedness_and_checksum_at_scale():
     c.reset_results(); c.set_initialized(); c.merge_and_filter()
     p2, i2, v2 = c.count_matrix_csc(filtered=True)
     assert np.array_equal(p, p2) and np.array_equal(i1, i2) and np.array_equal(v1, v2)
+    _wire_equals_direct(c)
     dev.free()
+
+
+def _wire_equals_direct(c):
+    """Both matrices as dropest_count_matrix_csc hands them out by default at this size -- bytes over PCIe, widened by host threads under
+    the copy (csrc/matrix_decode.h) -- against the same call with the 32-bit arrays copied as they are, and against the public byte form
+    decoded by dropest_matrix_bytes_widen: the form bench.py times, verified at the size bench.py runs."""
+    for filt in (False, True):
+        c.set_matrix_wire(True)
+        wire = [x.copy() for x in c.count_matrix_csc(filtered=filt)]
+        m = c.count_matrix_csc_bytes(filtered=filt)
+        listed = int(m.n_row_listed)
+        byt = [x.copy() for x in c.widen_bytes(m)]
+        c.set_matrix_wire(False)
+        direct = c.count_matrix_csc(filtered=filt)
+        assert len(direct[1]) > 1_000_000
+        for a, b, d in zip(wire, byt, direct):
+            assert np.array_equal(a, d) and np.array_equal(b, d), (filt, listed)
+        c.set_matrix_wire(True)
+        del wire, byt, direct
 
 
 def test_merge_properties_at_scale():
@@ -283,6 +303,8 @@ def test_full_size_1e9_reads_properties(shape):
     g, u, r, m = c.cell_molecules(big)
     k = (g.astype(np.uint64) << np.uint64(32)) | (u & np.uint64((1 << 24) - 1))
     assert np.all(k[1:] > k[:-1]) and len(np.unique(g)) == rows["n_genes"][big]
+    del p, i, v, p2, i2, v2, d
+    _wire_equals_direct(c)
     dev.free()
 
 
