@@ -504,6 +504,8 @@ struct dropest_ctx {
 	// splitter sort (k_ssort.h): sample, splitters, partition scratch, look-back words
 	dropest::DevBuf<u64> ss_sample_a, ss_sample_b, ss_fine, ss_coarse;
 	dropest::DevBuf<u32> ss_base1, ss_cnt2, ss_bucket_base, ss_bucket_cnt, ss_tmp, ss_n_loc, ss_prefix, ss_chunk, ss_big_list;
+	dropest::DevBuf<u32> ss_cursors;   // partitions by reservation: the regions' cursors (k_ssort.h)
+	bool ss_no_reserve = false;        // a region overflowed in this pass: the counting partitions from here on
 	bool splitter_sort_reduce();   // false: not applicable / fell back, the caller runs the LSD sort + seg_reduce
 	void reduce_all();
 	void reduce_molecules_to_cell_gene();

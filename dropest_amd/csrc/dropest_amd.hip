@@ -208,6 +208,7 @@ void dropest_ctx::free_results() {
 	HostStage hs(this, "reset");
 	invalidate_prefetch();
 	initialized = merged = ingested = external_merge_done = false;
+	ss_no_reserve = false;
 	reseed_rng();    // a second pass over the same reads reproduces the first
 	shard.reset();
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
@@ -441,11 +442,46 @@ dropest_ctx::u64 dropest_ctx::unmap_umi(u64 ucode) const {
 	return ucode;
 }
 
+static int sort_mode_override() {   // read at every pass: tests switch it inside one process
+	const char *e = getenv("DROPEST_SORT");
+	if (!e) return 0;
+	return !strcmp(e, "lsd") ? 1 : (!strcmp(e, "splitter") ? 2 : 0);
+}
+
+// The splitter sort's fan-out for n records and, when the partitions place their records by reservation (k_ssort.h: no histogram
+// passes), the capacities of the bucket regions.  build_keys sizes the key buffers from it: the regions of the second level take 1.75 n
+// records of address space.  DROPEST_SS_NO_RESERVE=1: always the counting partitions.
+struct SsPlan { bool applicable = false, reserve = false; int tb = 0, fb1 = 0, fb2 = 0; uint64_t cap1 = 0, cap2 = 0, span = 0; };
+static SsPlan ss_plan(uint64_t n_reads, bool chr_from_gene, int val_bytes) {
+	SsPlan P;
+	const int mode = sort_mode_override();
+	const char *e_min = getenv("DROPEST_SSORT_MIN");
+	const uint64_t min_reads = e_min ? uint64_t(atoll(e_min)) : (uint64_t(1) << 22);
+	if (mode == 1 || !chr_from_gene || val_bytes > 1) return P;
+	if (mode != 2 && n_reads < min_reads) return P;
+	if (n_reads < 512 || n_reads >= 0xFFFFFFFEull) return P;
+	int tb = 8;
+	while (tb < 20 && (n_reads >> tb) > 1600) ++tb;
+	if (const char *e = getenv("DROPEST_SSORT_TB")) tb = std::min(20, std::max(8, atoi(e)));
+	if ((n_reads >> tb) > 4096) return P;
+	P.applicable = true; P.tb = tb; P.fb1 = tb / 2; P.fb2 = tb - P.fb1;
+	const uint64_t F1 = 1ull << P.fb1, F2 = 1ull << tb, mean1 = (n_reads + F1 - 1) / F1, mean2 = (n_reads + F2 - 1) / F2;
+	P.cap1 = (mean1 + mean1 / 16 + 2 * SS_TILE + 15) & ~15ull;
+	P.cap2 = (mean2 + mean2 * 3 / 4 + 64 + 15) & ~15ull;
+	if (const char *e = getenv("DROPEST_SS_CAP2_PERCENT")) P.cap2 = (mean2 * uint64_t(std::max(100, atoi(e))) / 100 + 15) & ~15ull;   // tests: regions that overflow
+	P.span = std::max(F1 * P.cap1, F2 * P.cap2);
+	P.reserve = !getenv("DROPEST_SS_NO_RESERVE") && P.span < 0xFFFFFFF0ull;
+	if (!P.reserve) P.span = n_reads;
+	return P;
+}
+
 void dropest_ctx::build_keys(bool with_stats) {
 	const u32 n = u32(n_reads);
 	// value buffers hold val_bytes per record (0, 1 or 4): nothing at all for the keys-only layout
-	const size_t val_words = (size_t(n) * size_t(layout.val_bytes) + 3) / 4 + 1;
-	keys_a.ensure(n); keys_b.ensure(n); vals_a.ensure(val_words); vals_b.ensure(val_words);
+	// (the splitter sort's partitions by reservation write into bucket regions with gaps: up to 1.75 n records of address space)
+	const size_t span = std::max<size_t>(n, ss_no_reserve ? 0 : size_t(ss_plan(n_reads, chr_from_gene, layout.val_bytes).span));
+	const size_t val_words = (span * size_t(layout.val_bytes) + 3) / 4 + 1;
+	keys_a.ensure(span); keys_b.ensure(span); vals_a.ensure(val_words); vals_b.ensure(val_words);
 	d_counters.ensure(1);
 	GlobalCounters init{};
 	init.key_and = ~0ull;
@@ -610,12 +646,6 @@ void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_
 // with the molecule reduce) for the keys-only / key + mark byte layouts from DROPEST_SSORT_MIN reads on (default 2^22),
 // the LSD radix sort otherwise and as the fall-back when a fine bucket does not fit the LDS sort (one molecule with more
 // than ~8 000 reads).  DROPEST_SORT=lsd | splitter forces either (tests run both on the same streams).
-static int sort_mode_override() {   // read at every pass: tests switch it inside one process
-	const char *e = getenv("DROPEST_SORT");
-	if (!e) return 0;
-	return !strcmp(e, "lsd") ? 1 : (!strcmp(e, "splitter") ? 2 : 0);
-}
-
 // Does the LDS apply the lanes of one atomic instruction that hit the same address in lane order?  (ss_local's one-instruction
 // ranking is stable only then.)  Checked once per device on 256 random digit patterns with 1 .. 64 distinct values.
 static std::mutex g_lds_order_mu;
@@ -653,24 +683,17 @@ static bool lds_atomics_lane_ordered(int device, hipStream_t stream) {
 
 bool dropest_ctx::splitter_sort_reduce() {
 	const u32 n = u32(n_reads);
-	const int mode = sort_mode_override();
-	const char *e_min = getenv("DROPEST_SSORT_MIN");
-	const uint64_t min_reads = e_min ? uint64_t(atoll(e_min)) : (uint64_t(1) << 22);
-	if (mode == 1 || !chr_from_gene || layout.val_bytes > 1) return false;
-	if (mode != 2 && n_reads < min_reads) return false;
-	if (n < 512) return false;
 	// fan-out: F1 coarse x F2 fine buckets (powers of two, 16 .. 512 each) of <= ~1600 records on average: nearly all fit
 	// the small finishing launch (256 threads x 4 or 8 records), the tail and a hot molecule's bucket go to the big one.
 	// (Measured at 1e8 reads: 256 x 256 buckets 4.05 ms for the whole sort, 256 x 512 buckets 4.2 ms -- the finer second
 	// partition costs what the finishing launch gains.)
-	int tb = 8;
-	while (tb < 20 && (uint64_t(n) >> tb) > 1600) ++tb;
-	if (const char *e = getenv("DROPEST_SSORT_TB")) tb = std::min(20, std::max(8, atoi(e)));   // tests: any fan-out on any stream
-	if ((uint64_t(n) >> tb) > 4096) return false;   // > 4.3e9 records (never: a context holds < 2^32 reads)
-	const int fb1 = tb / 2, fb2 = tb - fb1;
+	const SsPlan plan = ss_plan(n_reads, chr_from_gene, layout.val_bytes);
+	if (!plan.applicable) return false;
+	const int tb = plan.tb, fb1 = plan.fb1, fb2 = plan.fb2;
 	const bool wide = fb2 > 9;                        // more than 512 buckets per level: the MAXF = 1024 kernels
 	const u32 F1 = 1u << fb1, Ff = 1u << fb2, F2 = F1 * Ff;
 	const int ms = layout.mark_shift, VB = layout.val_bytes;
+	(void)tb;
 	// 64 samples per fine bucket: bucket sizes scatter by ~12 % around n / F2, so few exceed the small finishing launch
 	uint64_t os_max = 64;
 	if (const char *e = getenv("DROPEST_SSORT_OS")) os_max = uint64_t(std::max(1, atoi(e)));
@@ -678,6 +701,10 @@ bool dropest_ctx::splitter_sort_reduce() {
 	const u32 n_sample = F2 * os;
 	const u64 order_mask = ~((1ull << ms) - 1ull);
 	const u64 varying = (counters.key_or ^ counters.key_and) & order_mask;
+	// by reservation only when build_keys sized the buffers for it (same plan, same pass) and no region overflowed earlier in this pass
+	const bool reserve = plan.reserve && !ss_no_reserve && keys_a.n >= plan.span && keys_b.n >= plan.span &&
+	                     (!VB || (vals_a.bytes() >= plan.span && vals_b.bytes() >= plan.span));
+	const size_t span = reserve ? size_t(plan.span) : size_t(n);   // address space of the fine buckets (and of ss_local's sparse rows)
 
 	HostStage hs(this, "splitter_sort");
 	u64 *keys = keys_a.p, *keys_alt = keys_b.p;
@@ -696,11 +723,48 @@ bool dropest_ctx::splitter_sort_reduce() {
 		HIP_CHECK(hipGetLastError());
 	}
 
-	// L1: all records into the F1 coarse buckets
 	const u32 n_tiles = div_up(n, SS_TILE);
 	u32 nblocks = std::min<u32>(n_tiles, 1024);
 	const u32 tpb = div_up(n_tiles, nblocks);
 	nblocks = div_up(n_tiles, tpb);
+	const u32 parts = std::max<u32>(1, std::min<u32>(16, 2048 / F1));
+	ss_bucket_base.ensure(F2); ss_bucket_cnt.ensure(F2); scalars.ensure(16);
+	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));   // [0] largest bucket, [1] molecule total, [2] a bucket was out of order after its sort, [3] a region overflowed
+	u32 max_cnt = 0;
+	if (reserve) {
+		// both partitions by reservation (k_ssort.h): a tile takes its places in the buckets' regions with one atomic per bucket; no histograms
+		const u32 cap1 = u32(plan.cap1), cap2 = u32(plan.cap2), CS1 = 32;
+		ss_cursors.ensure(size_t(F1) * CS1 + F2);
+		HIP_CHECK(hipMemsetAsync(ss_cursors.p, 0, (size_t(F1) * CS1 + F2) * 4, stream));
+		u32 *cur1 = ss_cursors.p, *cur2 = ss_cursors.p + size_t(F1) * CS1;
+		const SsReserve r1{cur1, CS1, cap1, 0u, scalars.p + 3}, r2{cur2, 1u, cap2, 0u, scalars.p + 3};
+		timed(VB ? "ss_scatter:L1:key+1B" : "ss_scatter:L1:keys", double(n) * 2 * (8 + VB), [&] {
+			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb1, ss_coarse.p, tpb, r1); };
+			if (wide) { if (VB) go(ss_scatter_res_l1_kernel<1, 1024>); else go(ss_scatter_res_l1_kernel<0, 1024>); }
+			else { if (VB) go(ss_scatter_res_l1_kernel<1, 512>); else go(ss_scatter_res_l1_kernel<0, 512>); }
+		});
+		timed(VB ? "ss_scatter:L2:key+1B" : "ss_scatter:L2:keys", double(n) * 2 * (8 + VB), [&] {
+			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb2, ss_fine.p, cur1, CS1, cap1, parts, r2); };
+			if (wide) { if (VB) go(ss_scatter_res_l2_kernel<1, 1024>); else go(ss_scatter_res_l2_kernel<0, 1024>); }
+			else { if (VB) go(ss_scatter_res_l2_kernel<1, 512>); else go(ss_scatter_res_l2_kernel<0, 512>); }
+		});
+		timed("ss_scan", double(F2) * 12, [&] {
+			hipLaunchKernelGGL(ss_res_buckets_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, cur2, F2, cap2, ss_bucket_base.p, ss_bucket_cnt.p, scalars.p);
+		});
+		u32 head[4] = {0, 0, 0, 0};
+		fetch(head, scalars.p, 16);
+		max_cnt = head[0];
+		if (head[3]) {
+			// A bucket outgrew its region (a heavy key: the sample's quantiles say nothing about a molecule with a good share of all reads).
+			// The partitions consumed the keys: they are built again and this pass takes the counting partitions.
+			stats["count:ss_reserve_overflow"].launches += 1;
+			ss_no_reserve = true;
+			build_keys(false);
+			return splitter_sort_reduce();
+		}
+		if (max_cnt > SS_LOCAL_MAX) { build_keys(false); return false; }   // (cannot happen while a region holds fewer records than the LDS sort takes)
+	} else {
+	// L1: all records into the F1 coarse buckets
 	rs_hist.ensure(size_t(F1) * nblocks); rs_row_total.ensure(1024); ss_base1.ensure(F1 + 1);
 	timed("ss_hist:L1", double(n) * 8, [&] {
 		if (wide) hipLaunchKernelGGL(ss_hist_l1_kernel<1024>, dim3(nblocks), dim3(SS_T), 0, stream, keys, n, ms, fb1, ss_coarse.p, tpb, rs_hist.p);
@@ -718,9 +782,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 	});
 
 	// L2: every coarse bucket into its own fine buckets
-	const u32 parts = std::max<u32>(1, std::min<u32>(16, 2048 / F1));
-	ss_cnt2.ensure(size_t(F2) * parts); ss_bucket_base.ensure(F2); ss_bucket_cnt.ensure(F2); scalars.ensure(16);
-	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));   // [0] largest bucket, [1] molecule total, [2] a bucket was out of order after its sort
+	ss_cnt2.ensure(size_t(F2) * parts);
 	timed("ss_hist:L2", double(n) * 8, [&] {
 		if (wide) hipLaunchKernelGGL(ss_hist_l2_kernel<1024>, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
 		else hipLaunchKernelGGL(ss_hist_l2_kernel<512>, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, ms, fb2, ss_fine.p, ss_base1.p, parts, ss_cnt2.p);
@@ -729,7 +791,6 @@ bool dropest_ctx::splitter_sort_reduce() {
 		if (wide) hipLaunchKernelGGL(ss_scan_seg_kernel<1024>, dim3(F1), dim3(1024), 0, stream, ss_cnt2.p, Ff, parts, ss_base1.p, ss_bucket_base.p, ss_bucket_cnt.p, scalars.p);
 		else hipLaunchKernelGGL(ss_scan_seg_kernel<512>, dim3(F1), dim3(512), 0, stream, ss_cnt2.p, Ff, parts, ss_base1.p, ss_bucket_base.p, ss_bucket_cnt.p, scalars.p);
 	});
-	u32 max_cnt = 0;
 	fetch(&max_cnt, scalars.p, 4);
 	if (max_cnt > SS_LOCAL_MAX) return false;   // keys_a / vals_a are untouched: the LSD sort takes over
 	timed(VB ? "ss_scatter:L2:key+1B" : "ss_scatter:L2:keys", double(n) * 2 * (8 + VB), [&] {
@@ -737,15 +798,16 @@ bool dropest_ctx::splitter_sort_reduce() {
 		if (wide) { if (VB) go(ss_scatter_l2_kernel<1, 1024>); else go(ss_scatter_l2_kernel<0, 1024>); }
 		else { if (VB) go(ss_scatter_l2_kernel<1, 512>); else go(ss_scatter_l2_kernel<0, 512>); }
 	});
+	}
 
 	// finishing sort: sparse molecule rows at each bucket's own record offset (key rows re-use the partition's alternate
 	// buffer), then scan of the per-bucket row counts and compaction into the dense table
 	const u32 SMALL_MAX = 2048;
 	const bool atomic_rank = lds_atomics_lane_ordered(cfg.device, stream);
-	ss_tmp.ensure(size_t(n) * 2 + 2); ss_n_loc.ensure(F2); ss_prefix.ensure(F2); ss_chunk.ensure(1024);
+	ss_tmp.ensure(span * 2 + 2); ss_n_loc.ensure(F2); ss_prefix.ensure(F2); ss_chunk.ensure(1024);
 	SsLocalArgs a{};
 	a.keys = keys; a.vals = vals; a.bucket_base = ss_bucket_base.p; a.bucket_cnt = ss_bucket_cnt.p; a.n_buckets = F2; a.ms = ms;
-	a.t_key = keys_alt; a.t_reads = ss_tmp.p; a.t_agg = ss_tmp.p + n; a.n_loc = ss_n_loc.p;
+	a.t_key = keys_alt; a.t_reads = ss_tmp.p; a.t_agg = ss_tmp.p + span; a.n_loc = ss_n_loc.p;
 	if (const char *e = getenv("DROPEST_SS_DEBUG")) a.debug = u32(atoi(e));
 	a.order_flag = scalars.p + 2;
 	a.atomic_below = u32(ms + layout.umi_bits);   // the UMI field: random digits
@@ -807,7 +869,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 	for (DevBuf<u32> *b : {&mol_reads, &mol_mark, &mol_exon, &mol_intron}) b->ensure(size_t(n_mol) + 1);
 	SsCompactArgs c{};
 	c.bucket_base = ss_bucket_base.p; c.n_loc = ss_n_loc.p; c.prefix = ss_prefix.p; c.n_buckets = F2;
-	c.t_key = keys_alt; c.t_reads = ss_tmp.p; c.t_agg = ss_tmp.p + n;
+	c.t_key = keys_alt; c.t_reads = ss_tmp.p; c.t_agg = ss_tmp.p + span;
 	c.mol_key = mol_key.p; c.mol_reads = mol_reads.p; c.mol_mark = mol_mark.p; c.mol_exon = mol_exon.p; c.mol_intron = mol_intron.p;
 	timed("ss_compact", double(n_mol) * (16 + 24), [&] {
 		hipLaunchKernelGGL(ss_compact_kernel, dim3(div_up(F2, 4)), dim3(256), 0, stream, c);

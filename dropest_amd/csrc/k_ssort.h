@@ -261,6 +261,144 @@ __global__ __launch_bounds__(SS_T) void ss_scatter_l2_kernel(const unsigned long
 	if (begin < end) ss_scatter_range<VB, MAXF>(keys, vals, okeys, ovals, begin, end, ms, fb, sp, goff, cnt, tstart, gdelta, scratch, sk, sd, sv);
 }
 
+// ---- partition by RESERVATION: no histogram pass ---------------------------------------------------------------------
+// The splitters are quantiles of a sample, so every bucket of a level expects the same number of records: n / F1 per coarse bucket
+// (16 384 sample points each: +- 0.8 %), n / F2 per fine bucket (64 sample points: +- 12 %).  Instead of counting first (one more read of
+// all keys per level: ss_hist_l1 / ss_hist_l2, 0.28 ms each per 1e8 reads) every bucket gets a REGION of fixed capacity -- the mean plus
+// 1/16 at the first level, 1.75 x the mean at the second -- and a tile takes its places in the regions it feeds with one atomic add per
+// bucket on the bucket's cursor (issued before the tile is regrouped in LDS, needed only when it is written out).  A bucket that
+// outgrows its region raises a flag (records beyond the region are dropped, nothing is overwritten): the host then rebuilds the keys
+// and takes the counting path -- a stream with a heavy key (one molecule with a good share of all reads) does that.  What follows the
+// partition (ss_local, ss_compact) addresses buckets by (base, count) anyway; the regions' gaps cost address space, not traffic.
+struct SsReserve {
+	uint32_t *cursor;       // per bucket: records placed so far
+	uint32_t cstride;       // words between the cursors of neighbouring buckets (32 at the first level: one cache line each)
+	uint32_t cap;           // records a region holds
+	uint32_t first;         // index of this block's first bucket among all regions of the level
+	uint32_t *overflow;
+};
+template <int VB, int MAXF>
+__device__ inline void ss_scatter_res_range(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
+                                            unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, uint32_t begin, uint32_t end,
+                                            int ms, int fb, const unsigned long long *sp, const SsReserve rs, uint32_t *cnt, uint32_t *tstart,
+                                            uint32_t *gdelta, uint32_t *scratch, unsigned long long *sk, uint16_t *sd, uint8_t *sv) {
+	constexpr int PER = MAXF / SS_T;
+	const uint32_t F = 1u << fb, tid = threadIdx.x;
+	for (uint32_t t0 = begin; t0 < end; t0 += SS_TILE) {
+		const uint32_t in_tile = end - t0 < uint32_t(SS_TILE) ? end - t0 : uint32_t(SS_TILE);
+		for (uint32_t j = tid; j < F; j += SS_T) cnt[j] = 0;
+		lds_barrier();
+		unsigned long long key[SS_I];
+		uint8_t val[VB ? SS_I : 1];
+		uint32_t pos[SS_I], rk[SS_I];
+#pragma unroll
+		for (int i = 0; i < SS_I; ++i) {
+			const uint32_t p = i * SS_T + tid;
+			key[i] = p < in_tile ? keys[t0 + p] : 0ull;
+			if (VB) val[i] = p < in_tile ? vals[t0 + p] : uint8_t(0);
+			pos[i] = 0;
+		}
+		for (int b = fb - 1; b >= 0; --b) {
+			const uint32_t step = 1u << b;
+#pragma unroll
+			for (int i = 0; i < SS_I; ++i) if (sp[pos[i] + step - 1] <= (key[i] >> ms)) pos[i] += step;
+		}
+#pragma unroll
+		for (int i = 0; i < SS_I; ++i) rk[i] = (i * SS_T + tid) < in_tile ? atomicAdd(&cnt[pos[i]], 1u) : 0u;
+		lds_barrier();
+		uint32_t c[PER], got[PER], mine = 0;
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {   // the tile's places in the regions: in flight while the tile is regrouped
+			const uint32_t e = tid * PER + k;
+			c[k] = e < F ? cnt[e] : 0u; mine += c[k];
+			got[k] = c[k] ? atomicAdd(&rs.cursor[size_t(rs.first + e) * rs.cstride], c[k]) : 0u;
+		}
+		uint32_t total;
+		uint32_t ex = block_excl_scan_u32<SS_T, true>(mine, scratch, total);
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			const uint32_t e = tid * PER + k;
+			if (e < F) tstart[e] = ex;
+			ex += c[k];
+		}
+		lds_barrier();
+#pragma unroll
+		for (int i = 0; i < SS_I; ++i)
+			if ((i * SS_T + tid) < in_tile) {
+				const uint32_t q = tstart[pos[i]] + rk[i];
+				sk[q] = key[i]; sd[q] = uint16_t(pos[i]);
+				if (VB) sv[q] = val[i];
+			}
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {
+			const uint32_t e = tid * PER + k;
+			if (e < F) {
+				gdelta[e] = (rs.first + e) * rs.cap + got[k] - tstart[e];
+				if (got[k] + c[k] > rs.cap) atomicOr(rs.overflow, 1u);
+			}
+		}
+		lds_barrier();
+		for (uint32_t q = tid; q < in_tile; q += SS_T) {
+			const uint32_t d = sd[q], g = gdelta[d] + q;
+			if (g < (rs.first + d + 1u) * rs.cap) {
+				okeys[g] = sk[q];
+				if (VB) ovals[g] = sv[q];
+			}
+		}
+		lds_barrier();
+	}
+}
+
+#define SS_SCATTER_RES_LDS(VB, MAXF)                                                                        \
+	__shared__ unsigned long long sp[MAXF];                                                                 \
+	__shared__ uint32_t cnt[MAXF], tstart[MAXF], gdelta[MAXF], scratch[SS_T / 64 + 1];                      \
+	__shared__ unsigned long long sk[SS_TILE];                                                              \
+	__shared__ uint16_t sd[SS_TILE];                                                                        \
+	__shared__ uint8_t sv[VB ? SS_TILE : 1];
+
+// first level: block blk owns tiles [blk * tpb, (blk + 1) * tpb); bucket j's region = [j * cap, (j + 1) * cap) of okeys
+template <int VB, int MAXF>
+__global__ __launch_bounds__(SS_T) void ss_scatter_res_l1_kernel(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
+                                                                 unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, uint32_t n,
+                                                                 int ms, int fb, const unsigned long long *__restrict__ coarse,
+                                                                 uint32_t tiles_per_block, SsReserve rs) {
+	SS_SCATTER_RES_LDS(VB, MAXF)
+	const uint32_t F = 1u << fb;
+	for (uint32_t j = threadIdx.x; j < F; j += SS_T) sp[j] = j + 1 < F ? coarse[j] : ~0ull;
+	__syncthreads();
+	const uint64_t b64 = uint64_t(blockIdx.x) * tiles_per_block * SS_TILE;
+	uint64_t e64 = b64 + uint64_t(tiles_per_block) * SS_TILE;
+	if (e64 > n) e64 = n;
+	if (b64 < n) ss_scatter_res_range<VB, MAXF>(keys, vals, okeys, ovals, uint32_t(b64), uint32_t(e64), ms, fb, sp, rs, cnt, tstart, gdelta, scratch, sk, sd, sv);
+}
+// second level: block (s, p) takes part p of coarse region s (cur1 = the first level's cursors = the regions' fills)
+template <int VB, int MAXF>
+__global__ __launch_bounds__(SS_T) void ss_scatter_res_l2_kernel(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
+                                                                 unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, int ms, int fb,
+                                                                 const unsigned long long *__restrict__ fine, const uint32_t *__restrict__ cur1,
+                                                                 uint32_t cstride1, uint32_t cap1, uint32_t parts, SsReserve rs) {
+	SS_SCATTER_RES_LDS(VB, MAXF)
+	const uint32_t F = 1u << fb, s = blockIdx.x / parts, p = blockIdx.x % parts;
+	for (uint32_t j = threadIdx.x; j < F; j += SS_T) sp[j] = j + 1 < F ? fine[size_t(s) * F + j] : ~0ull;
+	__syncthreads();
+	const uint32_t fill = cur1[size_t(s) * cstride1], sb = s * cap1, se = sb + (fill < cap1 ? fill : cap1);
+	const uint32_t tiles = (se - sb + SS_TILE - 1) / SS_TILE, tpp = (tiles + parts - 1) / parts;
+	const uint64_t b = uint64_t(sb) + uint64_t(p) * tpp * SS_TILE, e = b + uint64_t(tpp) * SS_TILE;
+	const uint32_t begin = b < se ? uint32_t(b) : se, end = e < se ? uint32_t(e) : se;
+	SsReserve mine = rs;
+	mine.first = s * F;
+	if (begin < end) ss_scatter_res_range<VB, MAXF>(keys, vals, okeys, ovals, begin, end, ms, fb, sp, mine, cnt, tstart, gdelta, scratch, sk, sd, sv);
+}
+// the fine regions as ss_local's buckets: base = b * cap, count = the region's fill; the largest count
+__global__ __launch_bounds__(256) void ss_res_buckets_kernel(const uint32_t *__restrict__ cur2, uint32_t n_buckets, uint32_t cap,
+                                                             uint32_t *__restrict__ bucket_base, uint32_t *__restrict__ bucket_cnt, uint32_t *__restrict__ max_cnt) {
+	const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+	uint32_t c = 0;
+	if (b < n_buckets) { c = cur2[b] < cap ? cur2[b] : cap; bucket_base[b] = b * cap; bucket_cnt[b] = c; }
+	const unsigned long long m = wave_reduce_max_u64(c);
+	if (lane_id() == 0 && m) atomicMax(max_cnt, uint32_t(m));
+}
+
 // ---- finishing sort + reads -> molecules ---------------------------------------------------------------------------
 // One workgroup per fine bucket (blockIdx = bucket).  A bucket of c records yields at most c molecules, so its rows are
 // written at the bucket's OWN record offset into scratch arrays (sparse) together with the row count; ss_compact then

@@ -140,3 +140,48 @@ def test_a_bucket_left_unsorted_is_caught_and_the_lsd_sort_takes_over(splitter, 
     monkeypatch.delenv("DROPEST_SS_DEBUG")
     o, c = tp._both(dict(n_cells=60, n_genes=3000), 300_000, 10, 30)
     assert c.sort_layout()["sort"] == "splitter"
+
+
+# ---- partitions by reservation (k_ssort.h: no histogram passes; every bucket a region of fixed capacity) -----------------------------
+def test_reservation_equals_the_counting_partitions(monkeypatch):
+    """2e7 reads of the C2 shape and of the C3 shape (mark byte beside the key): the same pass with the partitions placing their records by
+    reservation (the default) and by counting first (DROPEST_SS_NO_RESERVE=1) gives the same molecule table, cell rows and matrices,
+    byte for byte; the reservation pass runs no histogram kernel."""
+    for kw_s, force_byte in ((dict(n_cells=1000, n_genes=30000), False), (dict(n_cells=4000, n_genes=30000, umi_len=12, stream_id=3), True)):
+        if force_byte:
+            monkeypatch.setenv("DROPEST_FORCE_BYTE_VALUES", "1")
+        s = SynthStream(n_reads=20_000_000, **kw_s)
+        dev = s.generate_device(0)
+        c = capi.Context(min_genes_before_merge=20, min_genes_after_merge=100)
+        c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
+        digests = {}
+        for mode in ("reserve", "count"):
+            if mode == "count":
+                monkeypatch.setenv("DROPEST_SS_NO_RESERVE", "1")
+            c.set_profiling(True)
+            c.reset_results(); c.set_initialized(); c.merge_and_filter()
+            assert c.sort_layout()["sort"] == "splitter" and c.sort_layout()["value_bytes"] == (1 if force_byte else 0)
+            names = set(c.kernel_stats())
+            assert ("ss_hist:L1" in names) == (mode == "count") and "count:ss_reserve_overflow" not in names, names
+            digests[mode] = _digest(c)
+            c.set_profiling(False)
+        monkeypatch.delenv("DROPEST_SS_NO_RESERVE")
+        assert digests["reserve"] == digests["count"]
+        c.close(); dev.free()
+        monkeypatch.delenv("DROPEST_FORCE_BYTE_VALUES", raising=False)
+
+
+def test_a_region_that_overflows_is_noticed_and_the_counting_partitions_take_over(splitter, monkeypatch):
+    """Regions of 101 % of the mean bucket size overflow on any stream (fine buckets scatter by 12 %): the flag must come back, the keys
+    must be rebuilt and the counting partitions must finish the pass -- results equal the oracle's, the overflow is counted."""
+    monkeypatch.setenv("DROPEST_SS_CAP2_PERCENT", "101")
+    cb, umi, gene, aux = parity.canonical_stream(*SynthStream(n_reads=400_000, n_cells=60, n_genes=3000).generate_host())
+    o = parity.oracle_run(Oracle, dict(merge_kind=0, min_genes_before=10, min_genes_after=30), cb, umi, gene, aux)
+    c = capi.Context(min_genes_before_merge=10, min_genes_after_merge=30)
+    c.set_profiling(True)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_initialized(); c.merge_and_filter()
+    parity.compare(o, c)
+    st = c.kernel_stats()
+    assert c.sort_layout()["sort"] == "splitter" and "count:ss_reserve_overflow" in st and "ss_hist:L1" in st
+    c.close()
