@@ -418,6 +418,7 @@ struct dropest_ctx {
 		// 32-bit slots that travel as bytes (matrix_decode.h): the chunked copy's events and the job that widens into h_row / h_val
 		bool wire = false;
 		std::shared_ptr<dropest::DecodeJob> job;
+		std::chrono::steady_clock::time_point job_t0;
 		std::vector<hipEvent_t> ev_chunk;
 		hipEvent_t ev_lists = nullptr;
 		~MatrixResult() { for (auto e : ev_chunk) (void)hipEventDestroy(e); if (ev_lists) (void)hipEventDestroy(ev_lists); }

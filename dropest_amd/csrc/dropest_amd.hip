@@ -1529,20 +1529,31 @@ void dropest_ctx::wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_
 		HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 		M.ev_chunk.push_back(e);
 	}
+	// the chunks leave by a kernel that writes the pinned buffers itself (k_misc.h: no copy-engine set-up per chunk); DROPEST_WIRE_SDMA=1: hipMemcpyAsync
+	static const bool by_kernel = getenv("DROPEST_WIRE_SDMA") == nullptr;
 	u32 c0 = 0;
 	for (size_t j = 0; j < job->chunk_end.size(); ++j) {
 		const u32 c1 = job->chunk_end[j];
 		const size_t k0 = M.colptr[c0], k1 = M.colptr[c1];
 		if (k1 > k0) {
-			HIP_CHECK(hipMemcpyAsync(M.h_drow8.p + k0, M.d_drow8.p + k0, k1 - k0, hipMemcpyDeviceToHost, st));
-			HIP_CHECK(hipMemcpyAsync(M.h_val8.p + k0, M.d_val8.p + k0, k1 - k0, hipMemcpyDeviceToHost, st));
+			if (by_kernel) {
+				hipLaunchKernelGGL(matrix_chunk_to_host_kernel, dim3(u32(std::min<size_t>(128, (k1 - k0 + 4095) / 4096))), dim3(256), 0, st, M.d_drow8.p, M.d_val8.p,
+				                   M.h_drow8.p, M.h_val8.p, k0, k1);
+				HIP_CHECK(hipGetLastError());
+			} else {
+				HIP_CHECK(hipMemcpyAsync(M.h_drow8.p + k0, M.d_drow8.p + k0, k1 - k0, hipMemcpyDeviceToHost, st));
+				HIP_CHECK(hipMemcpyAsync(M.h_val8.p + k0, M.d_val8.p + k0, k1 - k0, hipMemcpyDeviceToHost, st));
+			}
 		}
 		HIP_CHECK(hipEventRecord(M.ev_chunk[j], st));
 		job->ev_chunk.push_back(M.ev_chunk[j]);
 		c0 = c1;
 	}
+	static const bool trace = getenv("DROPEST_WIRE_TRACE") != nullptr;
+	job->trace = trace;
 	job->prepare(uint64_t(1) << 16);
 	M.job = job; M.wire = true;
+	M.job_t0 = std::chrono::steady_clock::now();
 	DecodePool::get().submit(job);
 }
 
@@ -1550,7 +1561,14 @@ bool dropest_ctx::wire_finish(MatrixResult &M) {
 	using dropest::DecodeJob;
 	if (!M.job) return true;
 	HostStage hs(this, "matrix:decode_wait");
+	const auto w0 = std::chrono::steady_clock::now();
 	const int st = M.job->wait();
+	if (M.job->trace) {
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "[wire] nnz %llu: submit -> done %.3f ms, waited %.3f ms, slowest slice %.3f ms of %zu slices in %zu chunks\n", (unsigned long long)M.nnz,
+		        std::chrono::duration<double, std::milli>(now - M.job_t0).count(), std::chrono::duration<double, std::milli>(now - w0).count(),
+		        double(M.job->slowest_slice_ns.load()) * 1e-6, M.job->slice_end.size(), M.job->chunk_end.size());
+	}
 	M.n_rovf = M.job->n_r; M.n_ovf = M.job->n_v;
 	M.job.reset();
 	if (st == DecodeJob::DONE) return true;

@@ -432,6 +432,26 @@ __global__ __launch_bounds__(256) void matrix_lists_out_kernel(const uint32_t *_
 	if (nv <= vcap) for (uint32_t i = t; i < nv; i += stride) { h_v[1 + i] = d_v[1 + i]; h_v[1 + size_t(vcap) + i] = d_v[1 + size_t(vcap) + i]; }
 }
 
+// One chunk of a byte-form matrix (entries [k0, k1) of both byte arrays) from device memory to pinned host memory, by a kernel: a
+// device-to-host hipMemcpyAsync costs ~20 us of copy-engine set-up whatever its size, and the chunked copy (matrix_decode.h) makes two
+// dozen of them per matrix -- 0.5 ms on a 10 ms pass.  Source and destination are equally aligned (same index into arrays that both
+// start on a page), so the body moves 16 bytes per lane; the ragged ends go byte by byte.
+__global__ __launch_bounds__(256) void matrix_chunk_to_host_kernel(const uint8_t *__restrict__ d_a, const uint8_t *__restrict__ d_b, uint8_t *__restrict__ h_a,
+                                                                   uint8_t *__restrict__ h_b, size_t k0, size_t k1) {
+	const size_t a0 = (k0 + 15) & ~size_t(15), a1 = k1 & ~size_t(15);
+	const size_t t = size_t(blockIdx.x) * 256 + threadIdx.x, stride = size_t(gridDim.x) * 256;
+	if (a0 >= a1) {   // shorter than a line: bytes
+		for (size_t k = k0 + t; k < k1; k += stride) { h_a[k] = d_a[k]; h_b[k] = d_b[k]; }
+		return;
+	}
+	for (size_t k = k0 + t; k < a0; k += stride) { h_a[k] = d_a[k]; h_b[k] = d_b[k]; }
+	for (size_t k = a1 + t; k < k1; k += stride) { h_a[k] = d_a[k]; h_b[k] = d_b[k]; }
+	const uint4 *sa = reinterpret_cast<const uint4 *>(d_a + a0), *sb = reinterpret_cast<const uint4 *>(d_b + a0);
+	uint4 *da = reinterpret_cast<uint4 *>(h_a + a0), *db = reinterpret_cast<uint4 *>(h_b + a0);
+	const size_t n16 = (a1 - a0) >> 4;
+	for (size_t i = t; i < n16; i += stride) { da[i] = sa[i]; db[i] = sb[i]; }
+}
+
 // requested UMIs / reads of every (cell, gene) row under ANOTHER mark query than the container's own
 // (ResultsPrinter::save_intron_exon_matrices asks for "e", "i" and "BA", ResultsPrinter.cpp:455-474)
 __global__ __launch_bounds__(256) void cg_requested_by_mask_kernel(const uint32_t *__restrict__ cg_mol_begin, uint32_t n_cg,

@@ -13,8 +13,10 @@
 #include <immintrin.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstring>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -116,16 +118,78 @@ __attribute__((target("avx2"))) inline void widen_columns_avx2(const ByteMatrixV
 	if (nt) _mm_sfence();
 }
 
-inline bool decode_use_avx2() {
-	static const bool on = __builtin_cpu_supports("avx2") && getenv("DROPEST_DECODE_SCALAR") == nullptr;
+// The same with 512-bit registers (the hosts of the GPU boxes are Zen 5): sixteen entries per step as ONE register of sixteen 32-bit
+// sums, and -- NT -- one full 64-byte line per store: a non-temporal store that fills a whole line needs no read for ownership and no
+// write-combining across instructions (the 32-byte halves of the AVX2 walk reached memory as partial lines whenever a line's halves
+// were written by different steps: slower than plain stores on those hosts).
+__attribute__((target("avx512f,avx512bw,avx512vl"))) inline void widen_columns_avx512(const ByteMatrixView &m, size_t c0, size_t c1, uint32_t *__restrict ro,
+                                                                                      uint32_t *__restrict vo, bool nt) {
+	const uint8_t *__restrict rd = m.rd, *__restrict vb = m.vb;
+	const uint32_t *__restrict cp = m.colptr;
+	if (nt && ((reinterpret_cast<uintptr_t>(ro) ^ reinterpret_cast<uintptr_t>(vo)) & 63u)) nt = false;
+	const __m128i ff = _mm_set1_epi8(char(0xFF));
+	const __m512i zero = _mm512_setzero_si512();
+	for (size_t c = c0; c < c1; ++c) {
+		uint32_t prev1 = 0;
+		uint32_t k = cp[c];
+		const uint32_t k1 = cp[c + 1];
+		auto scalar_to = [&](uint32_t end) {
+			for (; k < end; ++k) {
+				const uint32_t d = rd[k], v = vb[k];
+				const uint32_t row = d == 255u ? ro[k] : prev1 + d - 1u;
+				prev1 = row + 1u;
+				ro[k] = row;
+				if (v != 255u) vo[k] = v;
+			}
+		};
+		if (k1 - k >= 48u) {
+			const uint32_t mis = uint32_t((reinterpret_cast<uintptr_t>(ro + k) >> 2) & 15u);   // up to the next 64-byte line of the outputs
+			if (mis) scalar_to(std::min(k1, k + (16u - mis)));
+			while (k + 16u <= k1) {
+				const __m128i d8 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(rd + k));
+				const __m128i v8 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(vb + k));
+				if (_mm_movemask_epi8(_mm_or_si128(_mm_cmpeq_epi8(d8, ff), _mm_cmpeq_epi8(v8, ff)))) { scalar_to(k + 16u); continue; }
+				__m512i s = _mm512_cvtepu8_epi32(d8);
+				s = _mm512_add_epi32(s, _mm512_alignr_epi32(s, zero, 15));    // lane i += lane i - 1
+				s = _mm512_add_epi32(s, _mm512_alignr_epi32(s, zero, 14));
+				s = _mm512_add_epi32(s, _mm512_alignr_epi32(s, zero, 12));
+				s = _mm512_add_epi32(s, _mm512_alignr_epi32(s, zero, 8));     // inclusive sums of the sixteen deltas
+				const __m512i rows = _mm512_add_epi32(s, _mm512_set1_epi32(int(prev1 - 1u)));
+				const __m512i x = _mm512_cvtepu8_epi32(v8);
+				if (nt) { _mm512_stream_si512(reinterpret_cast<__m512i *>(ro + k), rows); _mm512_stream_si512(reinterpret_cast<__m512i *>(vo + k), x); }
+				else { _mm512_storeu_si512(ro + k, rows); _mm512_storeu_si512(vo + k, x); }
+				prev1 += uint32_t(_mm_extract_epi32(_mm512_extracti32x4_epi32(s, 3), 3));
+				k += 16u;
+			}
+		}
+		scalar_to(k1);
+	}
+	if (nt) _mm_sfence();
+}
+
+// DROPEST_DECODE=scalar | avx2 | avx512 picks the walk (default: the widest the CPU has); DROPEST_DECODE_NT=0 / 1 the stores (default:
+// non-temporal with 512-bit registers -- whole lines --, plain otherwise; measured on the GPU boxes, see profiles/NOTES_r04.md)
+inline int decode_isa() {
+	static const int isa = [] {
+		const char *e = getenv("DROPEST_DECODE");
+		const bool has512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
+		const bool has2 = __builtin_cpu_supports("avx2");
+		if (e && !strcmp(e, "scalar")) return 0;
+		if (e && !strcmp(e, "avx2")) return has2 ? 1 : 0;
+		return has512 ? 2 : (has2 ? 1 : 0);
+	}();
+	return isa;
+}
+inline bool decode_use_nt() {
+	static const bool on = [] { const char *e = getenv("DROPEST_DECODE_NT"); return e ? atoi(e) != 0 : decode_isa() == 2; }();
 	return on;
 }
-// (measured on the GPU boxes -- 2 x EPYC 9575F, the process under a quota of 16 CPUs: C2 step 10.44 ms with plain stores, 10.77 ms with
-// non-temporal ones, 12 threads; plain is the default, DROPEST_DECODE_NT=1 switches)
-inline bool decode_use_nt() { static const bool on = getenv("DROPEST_DECODE_NT") != nullptr; return on; }
 inline void widen_columns(const ByteMatrixView &m, size_t c0, size_t c1, uint32_t *ro, uint32_t *vo) {
-	if (decode_use_avx2()) widen_columns_avx2(m, c0, c1, ro, vo, decode_use_nt());
-	else widen_columns_scalar(m, c0, c1, ro, vo);
+	switch (decode_isa()) {
+	case 2: widen_columns_avx512(m, c0, c1, ro, vo, decode_use_nt()); break;
+	case 1: widen_columns_avx2(m, c0, c1, ro, vo, decode_use_nt()); break;
+	default: widen_columns_scalar(m, c0, c1, ro, vo);
+	}
 }
 
 // Cuts the columns [c0, c1) into runs of about `target` entries (whole columns: a long column is a run by itself).
@@ -233,15 +297,44 @@ struct DecodeJob {
 			const uint32_t s = slice_next.fetch_add(1, std::memory_order_relaxed);
 			if (s >= n_slices) break;
 			const uint32_t j = slice_chunk[s];
-			if (!chunk_ready[j].load(std::memory_order_acquire)) {
-				if (!poll_event(ev_chunk[j], status)) { if (running()) finish(FAILED); return; }
-				chunk_ready[j].store(1, std::memory_order_release);
-			}
+			if (!wait_chunk(j)) { if (running()) finish(FAILED); return; }
+			const auto t0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
 			widen_columns(m, s ? slice_end[s - 1] : 0u, slice_end[s], ro, vo);
+			if (trace) {
+				const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+				uint64_t cur = slowest_slice_ns.load(std::memory_order_relaxed);
+				while (uint64_t(us * 1e3) > cur && !slowest_slice_ns.compare_exchange_weak(cur, uint64_t(us * 1e3))) {}
+			}
 			if (slice_done.fetch_add(1, std::memory_order_acq_rel) + 1u == n_slices) finish(DONE);
 		}
 	}
+	// Chunk j's bytes are on the host.  ONE thread at a time asks the runtime (hipEventQuery takes the runtime's locks: a dozen threads
+	// polling events slowed the owner's own launches and copies down); the others watch the flags it sets.
+	std::atomic<uint32_t> poller{0}, next_event{0};
+	bool wait_chunk(uint32_t j) {
+		for (uint32_t it = 0;; ++it) {
+			if (chunk_ready[j].load(std::memory_order_acquire)) return true;
+			if (!running()) return false;
+			uint32_t free_ = 0;
+			if (poller.compare_exchange_strong(free_, 1u, std::memory_order_acquire)) {
+				bool ok = true;
+				for (uint32_t e = next_event.load(std::memory_order_relaxed); e < ev_chunk.size(); ++e) {   // the events fire in order
+					const hipError_t r = hipEventQuery(ev_chunk[e]);
+					if (r == hipErrorNotReady) break;
+					if (r != hipSuccess) { ok = false; break; }
+					chunk_ready[e].store(1, std::memory_order_release);
+					next_event.store(e + 1, std::memory_order_relaxed);
+				}
+				poller.store(0u, std::memory_order_release);
+				if (!ok) return false;
+			}
+			cpu_relax();
+			if ((it & 1023u) == 1023u) std::this_thread::yield();
+		}
+	}
 	bool check_marks = false;
+	bool trace = false;                              // DROPEST_WIRE_TRACE: the slowest slice of the job (a descheduled worker shows here)
+	std::atomic<uint64_t> slowest_slice_ns{0};
 	int wait() {
 		for (uint32_t it = 0; it < (1u << 16); ++it) { if (!running()) return status.load(); cpu_relax(); }
 		std::unique_lock<std::mutex> lk(mu);
@@ -251,7 +344,7 @@ struct DecodeJob {
 };
 
 // The threads that widen.  Jobs are taken in the order they were submitted; every thread works on the oldest unfinished job until it
-// has nothing left to claim there.  DROPEST_DECODE_THREADS sets the number (default: 12, at most the hardware threads - 2, at least 1).
+// has nothing left to claim there.  DROPEST_DECODE_THREADS sets the number (default: 14 -- the GPU boxes give a process 16 CPUs --, at most the hardware threads - 2, at least 1).
 class DecodePool {
 	std::vector<std::thread> threads;
 	std::mutex mu;
@@ -260,7 +353,7 @@ class DecodePool {
 	uint64_t next_id = 0;
 	bool stop = false;
 	DecodePool() {
-		unsigned n = 12;
+		unsigned n = 14;
 		if (const char *e = getenv("DROPEST_DECODE_THREADS")) n = unsigned(std::max(1, atoi(e)));
 		const unsigned hw = std::thread::hardware_concurrency();
 		if (hw > 2) n = std::min(n, hw - 2); else n = 1;

@@ -79,13 +79,14 @@ def test_a_listed_entry_that_does_not_stand_on_a_255_is_refused():
 
 
 def test_scalar_walk_equals_the_vector_walk(monkeypatch):
-    """DROPEST_DECODE_SCALAR / DROPEST_DECODE_NO_NT are read once per process: a child runs the same matrix through the scalar walk."""
+    """DROPEST_DECODE / DROPEST_DECODE_NT are read once per process: children run the same matrix through every walk the CPU has."""
     import subprocess, sys, os
     code = ("import numpy as np, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import test_matrix_decode_cpu as t\n"
             "rng = np.random.default_rng(11); colptr, rows, vals = t.random_matrix(rng, 4000, 30000, 60)\n"
             "st, ro, vo = t.widen(colptr, *t.encode(colptr, rows, vals, rng))\n"
             "assert st == 0 and np.array_equal(ro, rows) and np.array_equal(vo, vals)\n") % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__))
-    for env in ({"DROPEST_DECODE_SCALAR": "1"}, {"DROPEST_DECODE_NT": "1"}, {"DROPEST_DECODE_THREADS": "1"}):
+    for env in ({"DROPEST_DECODE": "scalar"}, {"DROPEST_DECODE": "avx2", "DROPEST_DECODE_NT": "1"}, {"DROPEST_DECODE": "avx2", "DROPEST_DECODE_NT": "0"},
+                {"DROPEST_DECODE_NT": "0"}, {"DROPEST_DECODE_NT": "1"}, {"DROPEST_DECODE_THREADS": "1"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
