@@ -419,9 +419,8 @@ struct dropest_ctx {
 		bool wire = false;
 		std::shared_ptr<dropest::DecodeJob> job;
 		std::chrono::steady_clock::time_point job_t0;
-		std::vector<hipEvent_t> ev_chunk;
-		hipEvent_t ev_lists = nullptr;
-		~MatrixResult() { for (auto e : ev_chunk) (void)hipEventDestroy(e); if (ev_lists) (void)hipEventDestroy(ev_lists); }
+		dropest::PinnedBuf<u32> h_flags;   // arrival flags the device raises between the chunks
+		u32 wire_epoch = 0;
 		std::vector<u32> colptr;
 		uint64_t nnz = 0, ncols = 0;
 	} mat[3];   // cm, cm_raw, and the filtered matrix under another mark query (emit_matrix_levels)

@@ -12,6 +12,8 @@
 #include "context.h"
 
 #include <atomic>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <functional>
 #include <map>
 #include <mutex>
@@ -158,6 +160,16 @@ void dropest_ctx::upload(void *d_dst, const void *src, size_t bytes) {
 	dropest::parallel_ranges(bytes, [&](size_t b, size_t e, unsigned) { std::memcpy(h_up.p + b, static_cast<const char *>(src) + b, e - b); }, size_t(2) << 20, dropest::HostPool::MAX);
 	HIP_CHECK(hipMemcpyAsync(d_dst, h_up.p, bytes, hipMemcpyHostToDevice, stream));
 	HIP_CHECK(stream_wait(stream));
+}
+
+// DROPEST_TAIL_TRACE=1: host time stamps (us since the pass's first mark) along the end of a pass, to stderr
+static void tail_mark(const char *what, bool restart = false) {
+	static const bool on = getenv("DROPEST_TAIL_TRACE") != nullptr;
+	if (!on) return;
+	static thread_local std::chrono::steady_clock::time_point t0;
+	const auto now = std::chrono::steady_clock::now();
+	if (restart) t0 = now;
+	fprintf(stderr, "[tail] %9.1f us  %s\n", std::chrono::duration<double, std::micro>(now - t0).count(), what);
 }
 
 void dropest_ctx::collect_timings() {
@@ -737,15 +749,19 @@ bool dropest_ctx::splitter_sort_reduce() {
 		ss_cursors.ensure(size_t(F1) * CS1 + F2);
 		HIP_CHECK(hipMemsetAsync(ss_cursors.p, 0, (size_t(F1) * CS1 + F2) * 4, stream));
 		u32 *cur1 = ss_cursors.p, *cur2 = ss_cursors.p + size_t(F1) * CS1;
-		const SsReserve r1{cur1, CS1, cap1, 0u, scalars.p + 3}, r2{cur2, 1u, cap2, 0u, scalars.p + 3};
+		const u32 probe = [] { const char *e = getenv("DROPEST_SS_PROBE"); return e ? u32(atoi(e)) : 0u; }();
+		const bool no256 = getenv("DROPEST_SS_NO_F256") != nullptr;
+		const SsReserve r1{cur1, CS1, cap1, 0u, scalars.p + 3, probe}, r2{cur2, 1u, cap2, 0u, scalars.p + 3, probe};
 		timed(VB ? "ss_scatter:L1:key+1B" : "ss_scatter:L1:keys", double(n) * 2 * (8 + VB), [&] {
 			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb1, ss_coarse.p, tpb, r1); };
 			if (wide) { if (VB) go(ss_scatter_res_l1_kernel<1, 1024>); else go(ss_scatter_res_l1_kernel<0, 1024>); }
+			else if (fb1 <= 8 && !no256) { if (VB) go(ss_scatter_res_l1_kernel<1, 256>); else go(ss_scatter_res_l1_kernel<0, 256>); }   // 45 KB of LDS: three workgroups per CU
 			else { if (VB) go(ss_scatter_res_l1_kernel<1, 512>); else go(ss_scatter_res_l1_kernel<0, 512>); }
 		});
 		timed(VB ? "ss_scatter:L2:key+1B" : "ss_scatter:L2:keys", double(n) * 2 * (8 + VB), [&] {
 			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb2, ss_fine.p, cur1, CS1, cap1, parts, r2); };
 			if (wide) { if (VB) go(ss_scatter_res_l2_kernel<1, 1024>); else go(ss_scatter_res_l2_kernel<0, 1024>); }
+			else if (fb2 <= 8 && !no256) { if (VB) go(ss_scatter_res_l2_kernel<1, 256>); else go(ss_scatter_res_l2_kernel<0, 256>); }
 			else { if (VB) go(ss_scatter_res_l2_kernel<1, 512>); else go(ss_scatter_res_l2_kernel<0, 512>); }
 		});
 		timed("ss_scan", double(F2) * 12, [&] {
@@ -1070,8 +1086,10 @@ void dropest_ctx::fetch_real_cells(bool at_init) {
 		hipLaunchKernelGGL(write_real_kernel, dim3(tiles), dim3(RC_THREADS), 0, stream, cell_n_genes.p, n_cells, min_before,
 		                   tile_prefix.p, list.p);
 	});
+	tail_mark("fetch_real_cells: flag kernels enqueued", true);
 	u32 count = 0;
 	fetch(&count, scalars.p, 4);
+	tail_mark("count fetched");
 	if (count == 0) return;
 	DevBuf<CellRowPod> &rows = real_rows_dev; rows.ensure(count);
 	CellArrays a{cell_cb.p, cell_first.p, cell_n_genes.p, cell_req_genes.p, cell_req_umis.p, cell_total_umis.p, cell_total_reads.p};
@@ -1084,6 +1102,7 @@ void dropest_ctx::fetch_real_cells(bool at_init) {
 	HIP_CHECK(hipMemcpyAsync(h_stage.p, rows.p, row_bytes, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(hipMemcpyAsync(h_stage.p + id_off, list.p, size_t(count) * 4, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(stream_wait(stream));
+	tail_mark("rows on the host");
 	const CellRowPod *host_rows = reinterpret_cast<const CellRowPod *>(h_stage.p);
 	const u32 *ids = reinterpret_cast<const u32 *>(h_stage.p + id_off);
 	// cm_raw announced (dropest_set_raw_matrix_prefetch) and nothing in merge_and_filter can change it: its columns are exactly these
@@ -1091,6 +1110,7 @@ void dropest_ctx::fetch_real_cells(bool at_init) {
 	// over PCIe is the tail of a pass: every microsecond the first byte leaves earlier is one off the pass)
 	if (at_init && auto_pf_form >= 0 && n_reads && merge_phase_changes_nothing() && (auto_pf_form != 1 || narrow_possible()))
 		prefetch_raw_matrix(auto_pf_reads, auto_pf_form, host_rows, ids, count);
+	tail_mark("prefetch enqueued");
 	real.resize(count);   // ids arrive ascending (ordered compaction)
 	parallel_ranges(count, [&](size_t b, size_t e, unsigned) {
 		for (size_t i = b; i < e; ++i) {
@@ -1101,6 +1121,7 @@ void dropest_ctx::fetch_real_cells(bool at_init) {
 		}
 	});
 	real_list_current = true;   // (real_list holds exactly these ids)
+	tail_mark("host mirror filled");
 }
 
 void dropest_ctx::request_filtered(u32 genes_threshold, int max_cells) {
@@ -1363,6 +1384,7 @@ void dropest_ctx::run_merge_and_filter() {
 	if (merged) throw InvalidError("merge_and_filter was already run");
 	if (!merge_phase_changes_nothing()) invalidate_prefetch();   // (whatever rewrites the tables discards a prefetch on its own way in, too)
 	HostStage hs(this, "merge_and_filter");
+	tail_mark("merge_and_filter entered");
 	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells && !external_merge_done) run_cb_merge_real();
 	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL && n_cells && !external_merge_done) run_cb_merge_real();   // same loop, Poisson decisions
 	if ((cfg.merge_kind == DROPEST_MERGE_SIMPLE || cfg.merge_kind == DROPEST_MERGE_POISSON_SIMPLE) && n_cells) run_cb_merge_simple();
@@ -1511,49 +1533,40 @@ bool dropest_ctx::wire_wanted(uint64_t nnz, int form, bool to_host) const {
 void dropest_ctx::wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_t st) {
 	using namespace dropest;
 	M.h_row.ensure(nnz); M.h_val.ensure(nnz);
-	if (!M.ev_lists) HIP_CHECK(hipEventCreateWithFlags(&M.ev_lists, hipEventDisableTiming));
 	hipLaunchKernelGGL(matrix_lists_out_kernel, dim3(64), dim3(256), 0, st, M.d_rovf.p, M.rcap, M.h_rovf.p, M.d_ovf.p, M.vcap, M.h_ovf.p);
 	HIP_CHECK(hipGetLastError());
-	HIP_CHECK(hipEventRecord(M.ev_lists, st));
 	auto job = std::make_shared<DecodeJob>();
 	HIP_CHECK(hipGetDevice(&job->device));
 	job->m.rd = M.h_drow8.p; job->m.vb = M.h_val8.p; job->m.colptr = M.colptr.data(); job->m.ncols = M.ncols; job->m.nnz = nnz;
 	job->ro = M.h_row.p; job->vo = M.h_val.p;
 	job->r_count = M.h_rovf.p; job->r_pos = M.h_rovf.p + 1; job->r_val = M.h_rovf.p + 1 + M.rcap; job->rcap = M.rcap;
 	job->v_count = M.h_ovf.p; job->v_pos = M.h_ovf.p + 1; job->v_val = M.h_ovf.p + 1 + M.vcap; job->vcap = M.vcap;
-	job->ev_lists = M.ev_lists;
 	static const uint64_t n_chunks = [] { const char *e = getenv("DROPEST_WIRE_CHUNKS"); return uint64_t(e ? std::max(1, atoi(e)) : 12); }();
 	cut_columns(M.colptr.data(), 0, size_t(M.ncols), std::max<uint64_t>(nnz / n_chunks + 1, uint64_t(1) << 19), job->chunk_end);
-	while (M.ev_chunk.size() < job->chunk_end.size()) {
-		hipEvent_t e = nullptr;
-		HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-		M.ev_chunk.push_back(e);
-	}
-	// the chunks leave by a kernel that writes the pinned buffers itself (k_misc.h: no copy-engine set-up per chunk); DROPEST_WIRE_SDMA=1: hipMemcpyAsync
-	static const bool by_kernel = getenv("DROPEST_WIRE_SDMA") == nullptr;
+	// Arrival flags (matrix_decode.h): [0] the lists, [1 + j] chunk j; the value of this emit is a number no earlier emit of the slot used.
+	const size_t K = job->chunk_end.size();
+	M.h_flags.ensure(K + 2);
+	for (size_t j = 0; j < K + 2; ++j) M.h_flags.p[j] = 0;   // (the slot's previous job is complete: nobody reads or writes these now)
+	M.wire_epoch = M.wire_epoch + 1 ? M.wire_epoch + 1 : 1;
+	job->flags = M.h_flags.p; job->epoch = M.wire_epoch;
+	// Every chunk leaves by a kernel that writes the pinned buffers itself (k_misc.h: a device-to-host hipMemcpyAsync costs ~20 us of
+	// copy-engine set-up each, two dozen of them per matrix) and starts by raising the flag of what came before it on the stream.
 	u32 c0 = 0;
-	for (size_t j = 0; j < job->chunk_end.size(); ++j) {
+	for (size_t j = 0; j < K; ++j) {
 		const u32 c1 = job->chunk_end[j];
 		const size_t k0 = M.colptr[c0], k1 = M.colptr[c1];
-		if (k1 > k0) {
-			if (by_kernel) {
-				hipLaunchKernelGGL(matrix_chunk_to_host_kernel, dim3(u32(std::min<size_t>(128, (k1 - k0 + 4095) / 4096))), dim3(256), 0, st, M.d_drow8.p, M.d_val8.p,
-				                   M.h_drow8.p, M.h_val8.p, k0, k1);
-				HIP_CHECK(hipGetLastError());
-			} else {
-				HIP_CHECK(hipMemcpyAsync(M.h_drow8.p + k0, M.d_drow8.p + k0, k1 - k0, hipMemcpyDeviceToHost, st));
-				HIP_CHECK(hipMemcpyAsync(M.h_val8.p + k0, M.d_val8.p + k0, k1 - k0, hipMemcpyDeviceToHost, st));
-			}
-		}
-		HIP_CHECK(hipEventRecord(M.ev_chunk[j], st));
-		job->ev_chunk.push_back(M.ev_chunk[j]);
+		hipLaunchKernelGGL(matrix_chunk_to_host_kernel, dim3(u32(std::max<size_t>(1, std::min<size_t>(128, (k1 - k0 + 4095) / 4096)))), dim3(256), 0, st, M.d_drow8.p, M.d_val8.p,
+		                   M.h_drow8.p, M.h_val8.p, k0, k1, M.h_flags.p + j, M.wire_epoch);
 		c0 = c1;
 	}
+	hipLaunchKernelGGL(matrix_flag_kernel, dim3(1), dim3(1), 0, st, M.h_flags.p + K, M.wire_epoch);
+	HIP_CHECK(hipGetLastError());
 	static const bool trace = getenv("DROPEST_WIRE_TRACE") != nullptr;
 	job->trace = trace;
 	job->prepare(uint64_t(1) << 16);
 	M.job = job; M.wire = true;
 	M.job_t0 = std::chrono::steady_clock::now();
+	DecodePool::get().prefer_node_of(M.h_row.p);
 	DecodePool::get().submit(job);
 }
 
@@ -1562,9 +1575,22 @@ bool dropest_ctx::wire_finish(MatrixResult &M) {
 	if (!M.job) return true;
 	HostStage hs(this, "matrix:decode_wait");
 	const auto w0 = std::chrono::steady_clock::now();
+	M.job->work(true);   // the caller takes part: what is unclaimed, then what a straggler holds
 	const int st = M.job->wait();
 	if (M.job->trace) {
 		const auto now = std::chrono::steady_clock::now();
+		{   // where the buffers live (NUMA node of a few pages each) and where this thread runs
+			auto node_of = [](const void *p, size_t bytes) {
+				void *pages[8]; int status[8] = {-9, -9, -9, -9, -9, -9, -9, -9};
+				for (int i = 0; i < 8; ++i) pages[i] = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(p) + bytes / 8 * size_t(i)) & ~uintptr_t(4095));
+				(void)syscall(SYS_move_pages, 0, 8ul, pages, nullptr, status, 0);
+				std::string out;
+				for (int i = 0; i < 8; ++i) out += std::to_string(status[i]) + (i < 7 ? "," : "");
+				return out;
+			};
+			fprintf(stderr, "[wire] nodes: rows %s | values %s | delta bytes %s | caller on cpu %d\n", node_of(M.h_row.p, M.nnz * 4).c_str(),
+			        node_of(M.h_val.p, M.nnz * 4).c_str(), node_of(M.h_drow8.p, M.nnz).c_str(), sched_getcpu());
+		}
 		fprintf(stderr, "[wire] nnz %llu: submit -> done %.3f ms, waited %.3f ms, slowest slice %.3f ms of %zu slices in %zu chunks\n", (unsigned long long)M.nnz,
 		        std::chrono::duration<double, std::milli>(now - M.job_t0).count(), std::chrono::duration<double, std::milli>(now - w0).count(),
 		        double(M.job->slowest_slice_ns.load()) * 1e-6, M.job->slice_end.size(), M.job->chunk_end.size());
@@ -1670,7 +1696,9 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, 
 	}
 	if (!filtered_m) invalidate_prefetch();
 	if (M.job) { (void)M.job->wait(); M.job.reset(); }
+	tail_mark(filtered_m ? "emit_matrix(cm) entered" : "emit_matrix(cm_raw) entered");
 	matrix_columns(filtered_m, col_cell, M.colptr, nnz);
+	tail_mark("columns known");
 	M.nnz = nnz; M.ncols = col_cell.size(); M.narrow = narrow; M.n_ovf = M.n_rovf = 0; M.wire = false;
 	if (nnz == 0) return;
 	const u32 ncols = u32(col_cell.size());
@@ -1695,10 +1723,14 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, 
 		else if (dev_form == 1) hipLaunchKernelGGL(emit_matrix_kernel<1>, dim3(ncols), dim3(256), 0, stream, a);
 		else hipLaunchKernelGGL(emit_matrix_kernel<0>, dim3(ncols), dim3(256), 0, stream, a);
 	});
+	tail_mark("emit enqueued");
 	if (to_host) { if (wire) wire_copy_and_decode(M, nnz, stream); else matrix_copy_out(M, nnz, stream); }
+	tail_mark("copies enqueued");
 	HIP_CHECK(stream_wait(stream));   // col_cell (host vector) must outlive the H2D copy
+	tail_mark("stream drained");
 	bool ok = true;
 	if (to_host) { if (wire) ok = wire_finish(M); else matrix_finish_overflow(M, stream); }
+	tail_mark("matrix done");
 	collect_timings();
 	if (!ok) emit_matrix(filtered_m, reads_output, to_host, narrow, true);
 }
@@ -2444,7 +2476,7 @@ dropest_status dropest_matrix_bytes_widen(const dropest_matrix_bytes *m, uint32_
 		job->check_marks = true;
 		job->prepare(uint64_t(1) << 16);
 		dropest::DecodePool::get().submit(job);
-		job->work();
+		job->work(true);
 		const int st = job->wait();
 		if (st == dropest::DecodeJob::BAD_ROW) throw InvalidError("byte matrix: a listed row does not stand on a 255");
 		if (st == dropest::DecodeJob::BAD_VALUE) throw InvalidError("byte matrix: a listed value does not stand on a 255");

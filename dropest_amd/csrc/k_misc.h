@@ -436,8 +436,11 @@ __global__ __launch_bounds__(256) void matrix_lists_out_kernel(const uint32_t *_
 // device-to-host hipMemcpyAsync costs ~20 us of copy-engine set-up whatever its size, and the chunked copy (matrix_decode.h) makes two
 // dozen of them per matrix -- 0.5 ms on a 10 ms pass.  Source and destination are equally aligned (same index into arrays that both
 // start on a page), so the body moves 16 bytes per lane; the ragged ends go byte by byte.
+// flag / epoch: the arrival flag of what came BEFORE this kernel on the stream (the lists, the previous chunk) -- this kernel runs, so that is
+// complete and visible to the host; the host's decoding threads watch the flags (matrix_decode.h) instead of asking the runtime about events.
 __global__ __launch_bounds__(256) void matrix_chunk_to_host_kernel(const uint8_t *__restrict__ d_a, const uint8_t *__restrict__ d_b, uint8_t *__restrict__ h_a,
-                                                                   uint8_t *__restrict__ h_b, size_t k0, size_t k1) {
+                                                                   uint8_t *__restrict__ h_b, size_t k0, size_t k1, uint32_t *flag, uint32_t epoch) {
+	if (flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	const size_t a0 = (k0 + 15) & ~size_t(15), a1 = k1 & ~size_t(15);
 	const size_t t = size_t(blockIdx.x) * 256 + threadIdx.x, stride = size_t(gridDim.x) * 256;
 	if (a0 >= a1) {   // shorter than a line: bytes
@@ -451,6 +454,8 @@ __global__ __launch_bounds__(256) void matrix_chunk_to_host_kernel(const uint8_t
 	const size_t n16 = (a1 - a0) >> 4;
 	for (size_t i = t; i < n16; i += stride) { da[i] = sa[i]; db[i] = sb[i]; }
 }
+
+__global__ void matrix_flag_kernel(uint32_t *flag, uint32_t epoch) { __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // requested UMIs / reads of every (cell, gene) row under ANOTHER mark query than the container's own
 // (ResultsPrinter::save_intron_exon_matrices asks for "e", "i" and "BA", ResultsPrinter.cpp:455-474)

@@ -276,32 +276,53 @@ struct SsReserve {
 	uint32_t cap;           // records a region holds
 	uint32_t first;         // index of this block's first bucket among all regions of the level
 	uint32_t *overflow;
+	uint32_t dbg;           // timing probes (DROPEST_SS_PROBE; results unusable): 1 no splitter search, 2 no LDS regrouping
 };
 template <int VB, int MAXF>
 __device__ inline void ss_scatter_res_range(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
                                             unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, uint32_t begin, uint32_t end,
                                             int ms, int fb, const unsigned long long *sp, const SsReserve rs, uint32_t *cnt, uint32_t *tstart,
                                             uint32_t *gdelta, uint32_t *scratch, unsigned long long *sk, uint16_t *sd, uint8_t *sv) {
-	constexpr int PER = MAXF / SS_T;
+	constexpr int PER = (MAXF + SS_T - 1) / SS_T;   // table entries per thread (MAXF = 256: the upper half of the threads has none)
 	const uint32_t F = 1u << fb, tid = threadIdx.x;
-	for (uint32_t t0 = begin; t0 < end; t0 += SS_TILE) {
+	// The records of the NEXT tile are requested as soon as this tile's have moved from registers to LDS: they are on their way while this
+	// tile is written out and the next one's buckets are counted.  (Every kernel of the pass spends most of its wave cycles parked on
+	// memory -- rocprofv3 SQ_WAIT_ANY 59-66 % here --: what helps is more requests in flight per CU, not fewer instructions.)
+	unsigned long long key[SS_I];
+	uint8_t val[VB ? SS_I : 1];
+	auto load_tile = [&](uint32_t t0) {
 		const uint32_t in_tile = end - t0 < uint32_t(SS_TILE) ? end - t0 : uint32_t(SS_TILE);
-		for (uint32_t j = tid; j < F; j += SS_T) cnt[j] = 0;
-		lds_barrier();
-		unsigned long long key[SS_I];
-		uint8_t val[VB ? SS_I : 1];
-		uint32_t pos[SS_I], rk[SS_I];
 #pragma unroll
 		for (int i = 0; i < SS_I; ++i) {
 			const uint32_t p = i * SS_T + tid;
 			key[i] = p < in_tile ? keys[t0 + p] : 0ull;
 			if (VB) val[i] = p < in_tile ? vals[t0 + p] : uint8_t(0);
-			pos[i] = 0;
 		}
+	};
+	if (begin < end) load_tile(begin);
+	for (uint32_t t0 = begin; t0 < end; t0 += SS_TILE) {
+		const uint32_t in_tile = end - t0 < uint32_t(SS_TILE) ? end - t0 : uint32_t(SS_TILE);
+		for (uint32_t j = tid; j < F; j += SS_T) cnt[j] = 0;
+		lds_barrier();
+		uint32_t pos[SS_I], rk[SS_I];
+#pragma unroll
+		for (int i = 0; i < SS_I; ++i) pos[i] = 0;
 		for (int b = fb - 1; b >= 0; --b) {
 			const uint32_t step = 1u << b;
 #pragma unroll
 			for (int i = 0; i < SS_I; ++i) if (sp[pos[i] + step - 1] <= (key[i] >> ms)) pos[i] += step;
+		}
+		if (rs.dbg & 1u) {   // probe: the search a second time (what it costs = what the launch gains in time)
+			uint32_t pos2[SS_I];
+#pragma unroll
+			for (int i = 0; i < SS_I; ++i) pos2[i] = 0;
+			for (int b = fb - 1; b >= 0; --b) {
+				const uint32_t step = 1u << b;
+#pragma unroll
+				for (int i = 0; i < SS_I; ++i) if (sp[pos2[i] + step - 1] <= ((key[i] ^ (rs.dbg >> 8)) >> ms)) pos2[i] += step;
+			}
+#pragma unroll
+			for (int i = 0; i < SS_I; ++i) pos[i] = (pos[i] + pos2[i]) >> 1;
 		}
 #pragma unroll
 		for (int i = 0; i < SS_I; ++i) rk[i] = (i * SS_T + tid) < in_tile ? atomicAdd(&cnt[pos[i]], 1u) : 0u;
@@ -329,6 +350,7 @@ __device__ inline void ss_scatter_res_range(const unsigned long long *__restrict
 				sk[q] = key[i]; sd[q] = uint16_t(pos[i]);
 				if (VB) sv[q] = val[i];
 			}
+		if (!(rs.dbg & 2u) && t0 + SS_TILE < end) load_tile(t0 + SS_TILE);   // (probe 2: no prefetch)
 #pragma unroll
 		for (int k = 0; k < PER; ++k) {
 			const uint32_t e = tid * PER + k;
@@ -345,6 +367,7 @@ __device__ inline void ss_scatter_res_range(const unsigned long long *__restrict
 				if (VB) ovals[g] = sv[q];
 			}
 		}
+		if ((rs.dbg & 2u) && t0 + SS_TILE < end) load_tile(t0 + SS_TILE);
 		lds_barrier();
 	}
 }

@@ -11,6 +11,10 @@
 
 #include <hip/hip_runtime.h>
 #include <immintrin.h>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -214,12 +218,18 @@ struct DecodeJob {
 	// the two lists (positions, rows / values); their lengths are read from *r_count / *v_count once ev_lists has fired
 	const uint32_t *r_count = nullptr, *r_pos = nullptr, *r_val = nullptr, *v_count = nullptr, *v_pos = nullptr, *v_val = nullptr;
 	uint32_t rcap = 0, vcap = 0;
-	hipEvent_t ev_lists = nullptr;                  // fires when both lists are on the host (null: they already are)
-	std::vector<hipEvent_t> ev_chunk;               // fires when the bytes of chunk j are on the host (empty: everything already is)
+	// Arrival flags in pinned host memory, written by the device between the kernels that move the data (k_misc.h: the kernel of chunk
+	// j + 1 starts by writing chunk j's flag -- a kernel starts when its predecessor on the stream is complete and visible): flags[0] ==
+	// epoch: both lists are on the host; flags[1 + j] == epoch: the bytes of chunk j are.  The workers read memory, never the runtime
+	// (a dozen threads asking hipEventQuery held the runtime's locks under the owner's own launches: passes of 16 ms among passes of 9).
+	// flags == nullptr: everything is on the host already.
+	const volatile uint32_t *flags = nullptr;
+	uint32_t epoch = 0;
 	std::vector<uint32_t> chunk_end;                // chunk j = columns [chunk_end[j - 1], chunk_end[j])
 	// ---- set by prepare() ----
 	std::vector<uint32_t> slice_end, slice_chunk;   // slice s = columns [slice_end[s - 1], slice_end[s]) of chunk slice_chunk[s]
 	std::unique_ptr<std::atomic<uint8_t>[]> chunk_ready;
+	std::unique_ptr<std::atomic<uint8_t>[]> slice_state;   // 0 unclaimed, 1 somebody walks it, 2 done
 	std::atomic<uint32_t> lists_state{0};           // 0 nobody looks, 1 somebody waits for the event, 2 counts known
 	std::atomic<uint32_t> list_next{0}, list_done{0}, slice_next{0}, slice_done{0};
 	uint32_t n_r = 0, n_v = 0, n_list_ranges = 0, n_r_ranges = 0;
@@ -238,8 +248,10 @@ struct DecodeJob {
 			(void)before;
 			c0 = chunk_end[j];
 		}
+		slice_state.reset(new std::atomic<uint8_t>[slice_end.size() + 1]);
+		for (size_t k = 0; k < slice_end.size(); ++k) slice_state[k].store(0, std::memory_order_relaxed);
 		chunk_ready.reset(new std::atomic<uint8_t>[chunk_end.size()]);
-		for (size_t j = 0; j < chunk_end.size(); ++j) chunk_ready[j].store(ev_chunk.empty() ? 1 : 0, std::memory_order_relaxed);
+		for (size_t j = 0; j < chunk_end.size(); ++j) chunk_ready[j].store(flags ? 0 : 1, std::memory_order_relaxed);
 		if (slice_end.empty()) finish(DONE);
 	}
 	void finish(int st) {
@@ -247,89 +259,108 @@ struct DecodeJob {
 		if (status.compare_exchange_strong(expect, st)) { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
 	}
 	bool running() const { return status.load(std::memory_order_acquire) == RUNNING; }
-	static bool poll_event(hipEvent_t ev, const std::atomic<int> &st) {   // false: the job ended meanwhile or the event failed
-		for (uint32_t it = 0;; ++it) {
-			const hipError_t e = hipEventQuery(ev);
-			if (e == hipSuccess) return true;
-			if (e != hipErrorNotReady) return false;
-			if (st.load(std::memory_order_relaxed) != RUNNING) return false;
-			cpu_relax();
-			if ((it & 1023u) == 1023u) std::this_thread::yield();
+	// No stage of the job may hang on ONE thread making progress: the hosts are shared, a worker (or the one thread that happens to poll
+	// an event) loses its CPU for milliseconds now and then -- seen as passes of 16 ms among passes of 9.  So every wait below has a
+	// patience: whoever has waited PATIENCE spins does the thing itself (everything here can be done twice with the same result).
+	static constexpr uint32_t PATIENCE = 4096;   // ~ 100 us of pause instructions
+	void scatter_list_range(uint32_t i, bool &bad) {
+		const bool rows = i < n_r_ranges;
+		const uint32_t *lpos = rows ? r_pos : v_pos, *lval = rows ? r_val : v_val;
+		const uint8_t *mark = rows ? m.rd : m.vb;
+		uint32_t *out = rows ? ro : vo;
+		const uint32_t n = rows ? n_r : n_v, b = (rows ? i : i - n_r_ranges) * LIST_RANGE, e = std::min(n, b + LIST_RANGE);
+		// (the bytes themselves may still be on their way: whether a listed entry stands on a 255 is checked only by
+		// dropest_matrix_bytes_widen, where everything is there; here a wrong position shows as a position beyond the matrix)
+		for (uint32_t k = b; k < e; ++k) {
+			const uint32_t pos = lpos[k];
+			if (pos >= m.nnz || (check_marks && mark[pos] != 255u)) { finish(rows ? BAD_ROW : BAD_VALUE); bad = true; return; }
+			out[pos] = lval[k];
 		}
 	}
-	// A worker's share of the job; returns when there is nothing left to claim.
-	void work() {
+	// A thread's share of the job; returns when there is nothing left to do for it.  rescue: the caller owns the job (it has nothing else
+	// to do until the matrix is complete) and walks what others hold at once instead of after a patience.
+	void work(bool rescue = false) {
 		if (!running()) return;
-		// the lists: one worker waits for them, the others for it
-		uint32_t zero = 0;
-		if (lists_state.load(std::memory_order_acquire) != 2u) {
-			if (lists_state.compare_exchange_strong(zero, 1u)) {
-				if (ev_lists && !poll_event(ev_lists, status)) { finish(FAILED); return; }
-				n_r = r_count ? *r_count : 0u; n_v = v_count ? *v_count : 0u;
-				if (n_r > rcap || n_v > vcap) { finish(OVERFLOW); return; }
-				n_r_ranges = (n_r + LIST_RANGE - 1) / LIST_RANGE;
-				n_list_ranges = n_r_ranges + (n_v + LIST_RANGE - 1) / LIST_RANGE;
+		// 1. the lists have landed: their lengths
+		for (uint32_t it = 0; lists_state.load(std::memory_order_acquire) != 2u; ++it) {
+			if (!running()) return;
+			if (!flags || flags[0] == epoch) {
+				std::atomic_thread_fence(std::memory_order_acquire);
+				const uint32_t nr = r_count ? *r_count : 0u, nv = v_count ? *v_count : 0u;
+				if (nr > rcap || nv > vcap) { finish(OVERFLOW); return; }
+				n_r = nr; n_v = nv;   // (several threads may write the same numbers)
+				n_r_ranges = (nr + LIST_RANGE - 1) / LIST_RANGE;
+				n_list_ranges = n_r_ranges + (nv + LIST_RANGE - 1) / LIST_RANGE;
 				lists_state.store(2u, std::memory_order_release);
-			} else
-				while (lists_state.load(std::memory_order_acquire) != 2u) { if (!running()) return; cpu_relax(); }
+				break;
+			}
+			idle(it);
 		}
+		// 2. the listed entries to their places
+		bool bad = false;
 		for (;;) {
 			const uint32_t i = list_next.fetch_add(1, std::memory_order_relaxed);
 			if (i >= n_list_ranges) break;
-			const bool rows = i < n_r_ranges;
-			const uint32_t *lpos = rows ? r_pos : v_pos, *lval = rows ? r_val : v_val;
-			const uint8_t *mark = rows ? m.rd : m.vb;
-			uint32_t *out = rows ? ro : vo;
-			const uint32_t n = rows ? n_r : n_v, b = (rows ? i : i - n_r_ranges) * LIST_RANGE, e = std::min(n, b + LIST_RANGE);
-			// (the bytes themselves may still be on their way: whether a listed entry stands on a 255 is checked by the walk's owner only in
-			// dropest_matrix_bytes_widen, where everything is there; here a wrong position shows as a position beyond the matrix)
-			for (uint32_t k = b; k < e; ++k) {
-				const uint32_t pos = lpos[k];
-				if (pos >= m.nnz) { finish(rows ? BAD_ROW : BAD_VALUE); return; }
-				if (check_marks && mark[pos] != 255u) { finish(rows ? BAD_ROW : BAD_VALUE); return; }
-				out[pos] = lval[k];
-			}
+			scatter_list_range(i, bad);
+			if (bad) return;
 			list_done.fetch_add(1, std::memory_order_release);
 		}
-		while (list_done.load(std::memory_order_acquire) < n_list_ranges) { if (!running()) return; cpu_relax(); }
+		for (uint32_t it = 0; list_done.load(std::memory_order_acquire) < n_list_ranges; ++it) {
+			if (!running()) return;
+			if (it > PATIENCE) {   // somebody sits on a range: all of them again, here
+				for (uint32_t i = 0; i < n_list_ranges && !bad; ++i) scatter_list_range(i, bad);
+				if (bad) return;
+				break;
+			}
+			cpu_relax();
+		}
+		// 3. the columns, slice by slice as their chunks land
 		const uint32_t n_slices = uint32_t(slice_end.size());
 		for (;;) {
 			const uint32_t s = slice_next.fetch_add(1, std::memory_order_relaxed);
 			if (s >= n_slices) break;
-			const uint32_t j = slice_chunk[s];
-			if (!wait_chunk(j)) { if (running()) finish(FAILED); return; }
-			const auto t0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-			widen_columns(m, s ? slice_end[s - 1] : 0u, slice_end[s], ro, vo);
-			if (trace) {
-				const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-				uint64_t cur = slowest_slice_ns.load(std::memory_order_relaxed);
-				while (uint64_t(us * 1e3) > cur && !slowest_slice_ns.compare_exchange_weak(cur, uint64_t(us * 1e3))) {}
+			if (!wait_chunk(slice_chunk[s])) { if (running()) finish(FAILED); return; }
+			slice_state[s].store(1, std::memory_order_relaxed);
+			walk_slice(s, n_slices);
+		}
+		// Nothing left to claim: the slices others have claimed and not finished, oldest first (a slice walked twice gets the same values twice)
+		for (uint32_t it = 0; running(); ++it) {
+			if (rescue || it > PATIENCE) {
+				for (uint32_t s = 0; s < n_slices && running(); ++s) {
+					uint8_t st = slice_state[s].load(std::memory_order_acquire);
+					if (st == 0 && s < slice_next.load(std::memory_order_relaxed)) st = 1;   // claimed, its owner still waits for the chunk (or lost its CPU there)
+					if (st == 1 && wait_chunk(slice_chunk[s])) walk_slice(s, n_slices);
+				}
+				if (!rescue) return;
+				it = 0;
 			}
-			if (slice_done.fetch_add(1, std::memory_order_acq_rel) + 1u == n_slices) finish(DONE);
+			if (!rescue && it == 0) { /* a worker gives the others PATIENCE spins before it doubles their work */ }
+			cpu_relax();
 		}
 	}
-	// Chunk j's bytes are on the host.  ONE thread at a time asks the runtime (hipEventQuery takes the runtime's locks: a dozen threads
-	// polling events slowed the owner's own launches and copies down); the others watch the flags it sets.
-	std::atomic<uint32_t> poller{0}, next_event{0};
+	void walk_slice(uint32_t s, uint32_t n_slices) {
+		const auto t0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+		widen_columns(m, s ? slice_end[s - 1] : 0u, slice_end[s], ro, vo);
+		if (trace) {
+			const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+			uint64_t cur = slowest_slice_ns.load(std::memory_order_relaxed);
+			while (uint64_t(us * 1e3) > cur && !slowest_slice_ns.compare_exchange_weak(cur, uint64_t(us * 1e3))) {}
+		}
+		if (slice_state[s].exchange(2, std::memory_order_acq_rel) != 2 && slice_done.fetch_add(1, std::memory_order_acq_rel) + 1u == n_slices) finish(DONE);
+	}
+	// Waiting for data that is still on the link: a short spin, then naps -- fourteen spinning threads take the cores (and their SMT
+	// siblings) from the owner's thread, which is preparing the next matrix at that very time.
+	static void idle(uint32_t it) {
+		if (it < 2048u) { cpu_relax(); return; }
+		std::this_thread::sleep_for(std::chrono::microseconds(20));
+	}
+	// Chunk j's bytes are on the host.
 	bool wait_chunk(uint32_t j) {
 		for (uint32_t it = 0;; ++it) {
 			if (chunk_ready[j].load(std::memory_order_acquire)) return true;
 			if (!running()) return false;
-			uint32_t free_ = 0;
-			if (poller.compare_exchange_strong(free_, 1u, std::memory_order_acquire)) {
-				bool ok = true;
-				for (uint32_t e = next_event.load(std::memory_order_relaxed); e < ev_chunk.size(); ++e) {   // the events fire in order
-					const hipError_t r = hipEventQuery(ev_chunk[e]);
-					if (r == hipErrorNotReady) break;
-					if (r != hipSuccess) { ok = false; break; }
-					chunk_ready[e].store(1, std::memory_order_release);
-					next_event.store(e + 1, std::memory_order_relaxed);
-				}
-				poller.store(0u, std::memory_order_release);
-				if (!ok) return false;
-			}
-			cpu_relax();
-			if ((it & 1023u) == 1023u) std::this_thread::yield();
+			if (flags[1 + j] == epoch) { std::atomic_thread_fence(std::memory_order_acquire); chunk_ready[j].store(1, std::memory_order_release); return true; }
+			idle(it);
 		}
 	}
 	bool check_marks = false;
@@ -352,6 +383,43 @@ class DecodePool {
 	std::deque<std::pair<uint64_t, std::shared_ptr<DecodeJob>>> jobs;
 	uint64_t next_id = 0;
 	bool stop = false;
+	// The workers run on the NUMA node that holds the buffers they write (ROCm puts pinned host memory on the GPU's node; a worker on
+	// the other socket writes it at about half the rate -- measured: the same pass 9.4 ms or 10.7 ms depending on where the scheduler had
+	// put the threads).  prefer_node_of(p) is called by the owner of a job with its output buffer; the workers move when the node changes.
+	// DROPEST_DECODE_NUMA=0 leaves them where the scheduler puts them.
+	static std::vector<int> cpus_of_node(int node) {
+		std::vector<int> list;
+		char path[96];
+		snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+		FILE *f = fopen(path, "r");
+		if (!f) return list;
+		char buf[4096] = {0};
+		const bool got = fgets(buf, sizeof(buf), f) != nullptr;
+		fclose(f);
+		if (!got) return list;
+		for (char *p = buf; *p;) {
+			char *end = nullptr;
+			const long a = strtol(p, &end, 10);
+			if (end == p) break;
+			long b = a;
+			if (*end == '-') { p = end + 1; b = strtol(p, &end, 10); }
+			for (long c = a; c <= b; ++c) list.push_back(int(c));
+			if (*end != ',') break;
+			p = end + 1;
+		}
+		return list;
+	}
+	std::atomic<int> wanted_node{-1};
+public:
+	void prefer_node_of(const void *p) {
+		static const bool off = [] { const char *e = getenv("DROPEST_DECODE_NUMA"); return e && atoi(e) == 0; }();
+		if (off || !p) return;
+		void *page = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(p) & ~uintptr_t(4095));
+		int status = -1;
+		if (syscall(SYS_move_pages, 0, 1ul, &page, nullptr, &status, 0) != 0 || status < 0) return;
+		wanted_node.store(status, std::memory_order_relaxed);
+	}
+private:
 	DecodePool() {
 		unsigned n = 14;
 		if (const char *e = getenv("DROPEST_DECODE_THREADS")) n = unsigned(std::max(1, atoi(e)));
@@ -360,7 +428,7 @@ class DecodePool {
 		for (unsigned t = 0; t < n; ++t)
 			threads.emplace_back([this] {
 				uint64_t want = 0;
-				int device = -1;
+				int device = -1, node = -1;
 				for (;;) {
 					std::shared_ptr<DecodeJob> job;
 					{
@@ -371,6 +439,15 @@ class DecodePool {
 					}
 					if (!job) continue;
 					if (job->device != device) { device = job->device; (void)hipSetDevice(device); }
+					const int wn = wanted_node.load(std::memory_order_relaxed);
+					if (wn != node && wn >= 0) {
+						node = wn;
+						const std::vector<int> cpus = cpus_of_node(node);
+						cpu_set_t set;
+						CPU_ZERO(&set);
+						for (int c : cpus) if (c < CPU_SETSIZE) CPU_SET(c, &set);
+						if (cpus.size() >= 4) (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+					}
 					try { job->work(); } catch (...) { job->finish(DecodeJob::FAILED); }
 				}
 			});
