@@ -3007,6 +3007,10 @@ dropest_status dropest_debug_alloc_site(uint64_t ordinal, char *out, uint64_t ou
 	});
 }
 
+dropest_status dropest_debug_refresh(void) {
+	return guarded([&] { dropest::DevDebug::refresh(); });
+}
+
 dropest_status dropest_debug_trim_pool(void) {
 	return guarded([&] { DevRegistry::get().trim_pool(); });
 }

@@ -24,6 +24,14 @@
 #include <functional>
 #include <mutex>
 
+static inline void bam_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+	__builtin_ia32_pause();
+#elif defined(__aarch64__)
+	__asm__ __volatile__("yield");
+#endif
+}
+
 namespace Estimation {
 namespace BamProcessing {
 
@@ -279,7 +287,7 @@ struct BamReader::Impl {
 					uint64_t c;
 					for (unsigned spins = 0; (c = carry[i].load(std::memory_order_acquire)) == 0; ++spins) {
 						if (abort_walk.load(std::memory_order_relaxed)) break;
-						if (spins < 2000) __builtin_ia32_pause(); else std::this_thread::yield();   // (the walker before us may have lost its core)
+						if (spins < 2000) bam_cpu_relax(); else std::this_thread::yield();   // (the walker before us may have lost its core)
 					}
 					if (c == 0) continue;
 					size_t P = size_t(c - 1);
@@ -500,6 +508,8 @@ bool BamReader::next_window(const uint8_t *&data, std::vector<uint32_t> &offsets
 		if (!offsets.empty()) return true;
 		return next_window(data, offsets);       // (a batch without a single complete record: go on with the next one)
 	}
+	// (after a consumed batch only tail + 1 bytes are known to be there: the length field itself may be cut by the end of the file)
+	if (!m.ensure(4)) { if (m.cur.size > m.pos) throw std::runtime_error("Truncated BAM record: " + m.path); return false; }
 	const uint32_t first_size = le32(m.bytes() + m.pos);
 	if (first_size < 32) throw std::runtime_error("Corrupt BAM record: " + m.path);
 	if (!m.ensure(4 + size_t(first_size))) throw std::runtime_error("Truncated BAM record: " + m.path);

@@ -229,17 +229,22 @@ void CellsDataContainer::add_record(const ReadInfo &r) {   // CellsDataContainer
 	_preview_valid = false;
 	const uint8_t mark = uint8_t(r.umi_mark.bits());
 	const bool has_gene = !r.gene.empty();
-	_cb.push_back(encode(r.params.cell_barcode(), _side_cb));
+	const uint64_t cb_code = encode(r.params.cell_barcode(), _side_cb);
 	uint32_t chr = 0;
 	if (has_gene) {
 		const size_t ql = r.params.umi_quality().size();
+		const uint64_t umi_code = encode(r.params.umi(), _side_umi);   // UMI side strings: first seen on gene-bearing reads only
+		const uint32_t gid = uint32_t(_gene_indexer.add(r.gene));
+		check_molecule_quality_length(cb_code, gid, umi_code, ql);   // throws where UMI::add_read would (UMI.cpp:26-28)
+		_cb.push_back(cb_code);
 		note_quality_length(ql);
 		append_quality(r.params.umi_quality().data(), ql, true);
-		_umi.push_back(encode(r.params.umi(), _side_umi));   // UMI side strings: first seen on gene-bearing reads only
-		_gene.push_back(uint32_t(_gene_indexer.add(r.gene)));
+		_umi.push_back(umi_code);
+		_gene.push_back(gid);
 		// Stats::inc(chr) is reached only for exon / intron reads (CellsDataContainer.cpp:312-321)
 		if (mark & (UMI::Mark::HAS_EXONS | UMI::Mark::HAS_INTRONS)) chr = uint32_t(_chr_indexer.add(r.chromosome_name));
 	} else {
+		_cb.push_back(cb_code);
 		append_quality(nullptr, 0, false);
 		_umi.push_back(1);   // ignored by the device for gene-less reads
 		_gene.push_back(DROPEST_NO_GENE);
@@ -327,7 +332,7 @@ void CellsDataContainer::add_record(const ParsedRead &r) {   // same statements 
 	_preview_valid = false;
 	if (r.ref_id < 0 || size_t(r.ref_id) >= _ref_names.size()) throw std::out_of_range("reference id outside set_reference_names");
 	const bool has_gene = !r.gene.empty();
-	_cb.push_back(r.cb_code ? r.cb_code : encode(std::string(r.cb), _side_cb));
+	const uint64_t cb_code = r.cb_code ? r.cb_code : encode(std::string(r.cb), _side_cb);
 	auto chr_index = [&]() {
 		int32_t &slot = _ref_chr[size_t(r.ref_id)];
 		if (slot < 0) slot = int32_t(_chr_indexer.add(_ref_names[size_t(r.ref_id)]));
@@ -336,9 +341,7 @@ void CellsDataContainer::add_record(const ParsedRead &r) {   // same statements 
 	uint32_t chr = 0;
 	if (has_gene) {
 		const size_t ql = r.umi_quality_length;
-		note_quality_length(ql);
-		append_quality(r.umi_quality.data(), ql, true);
-		_umi.push_back(r.umi_code ? r.umi_code : encode(std::string(r.umi), _side_umi));
+		const uint64_t umi_code = r.umi_code ? r.umi_code : encode(std::string(r.umi), _side_umi);
 		uint32_t gid;
 		auto it = r.gene_id >= 0 ? _gene_by_hash.end() : _gene_by_hash.find(r.gene_hash);
 		if (r.gene_id >= 0) gid = uint32_t(r.gene_id);
@@ -347,9 +350,15 @@ void CellsDataContainer::add_record(const ParsedRead &r) {   // same statements 
 			gid = uint32_t(_gene_indexer.add(std::string(r.gene)));
 			if (it == _gene_by_hash.end()) _gene_by_hash.emplace(r.gene_hash, gid);   // (a colliding name keeps taking the slow path)
 		}
+		check_molecule_quality_length(cb_code, gid, umi_code, ql);
+		_cb.push_back(cb_code);
+		note_quality_length(ql);
+		append_quality(r.umi_quality.data(), ql, true);
+		_umi.push_back(umi_code);
 		_gene.push_back(gid);
 		if (r.mark & (UMI::Mark::HAS_EXONS | UMI::Mark::HAS_INTRONS)) chr = chr_index();
 	} else {
+		_cb.push_back(cb_code);
 		append_quality(nullptr, 0, false);
 		_umi.push_back(1);
 		_gene.push_back(DROPEST_NO_GENE);
@@ -380,6 +389,36 @@ void CellsDataContainer::append_quality(const char *q, size_t len, bool has_gene
 // from the first such read on, the length of every read is kept beside the rows (widened to the longest string), and the per-molecule
 // check runs on the device in set_initialized (dropest_set_umi_qualities_var) -- same exception text, for the read the reference would have
 // stopped at.
+// The quality length of every molecule, from the moment two gene-bearing reads differ in it.  Until then every molecule has the one
+// length seen so far, so nothing is kept; at that moment the molecules that exist are read from the preview (a second context over the
+// reads pushed so far: one pass on the device -- the reference's per-read std::map look-ups are not restated on the host for the
+// common case of one length).  From then on each gene-bearing read looks its molecule up here: an existing molecule with another
+// length is UMI::add_read's exception (UMI.cpp:26-28), raised by the add_record that the reference raises it from.
+void CellsDataContainer::check_molecule_quality_length(uint64_t cb_code, uint32_t gene, uint64_t umi_code, size_t ql) {
+	if (_umi_quality_length == size_t(-1) || sharded()) return;          // no molecule yet / sharded containers check in the step
+	if (!_mol_qlen_tracking) {
+		if (ql == _umi_quality_length) return;
+		if (ql > 255) throw std::runtime_error("UMI quality strings longer than 255");
+		dropest_ctx *pv = view();                                          // flushes the pending batch; the current read is not in it
+		uint64_t n_mol = 0, n_cells = 0;
+		check(dropest_molecules(pv, &n_mol, nullptr, nullptr, nullptr, nullptr, nullptr));
+		check(dropest_total_cells(pv, &n_cells));
+		std::vector<uint32_t> cell(n_mol), g(n_mol), reads(n_mol);
+		std::vector<uint64_t> umi(n_mol);
+		std::vector<uint8_t> mark(n_mol);
+		if (n_mol) check(dropest_molecules(pv, &n_mol, cell.data(), g.data(), umi.data(), reads.data(), mark.data()));
+		std::vector<dropest_cell_row> rows(n_cells);
+		if (n_cells) check(dropest_cell_rows(pv, 0, n_cells, rows.data()));
+		_mol_qlen.reserve(size_t(n_mol) * 2);
+		for (uint64_t i = 0; i < n_mol; ++i) _mol_qlen.emplace(MolKey{rows[cell[i]].barcode, umi[i], g[i]}, uint8_t(_umi_quality_length));
+		_mol_qlen_tracking = true;
+		_preview_valid = false;                                            // (the next accessor sees the read that follows)
+	}
+	auto ins = _mol_qlen.emplace(MolKey{cb_code, umi_code, gene}, uint8_t(ql));
+	if (!ins.second && ins.first->second != ql)
+		throw std::runtime_error("Wrong quality length: " + std::to_string(ql) + ", expected: " + std::to_string(unsigned(ins.first->second)));
+}
+
 void CellsDataContainer::note_quality_length(size_t ql) {
 	if (ql > 255) throw std::runtime_error("UMI quality strings longer than 255");
 	if (_umi_quality_length == size_t(-1)) { _umi_quality_length = ql; return; }

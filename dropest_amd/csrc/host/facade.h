@@ -302,6 +302,14 @@ private:
 	std::vector<size_t> _shard_reads;         // sharded container: reads dealt to every shard so far (ranges of the stream, in shard order)
 	std::vector<uint8_t> _qual_lens;          // per read, once two gene-bearing reads differed in length (UMI.cpp:26-28 is a per-molecule check)
 	void note_quality_length(size_t ql);
+	// UMI::add_read's "Wrong quality length" (UMI.cpp:26-28) from the add_record that meets it: once two gene-bearing reads have differed
+	// in length, the length of every molecule is kept here (the molecules before that moment come from the preview: they all have the
+	// first length)
+	struct MolKey { uint64_t cb, umi; uint32_t gene; bool operator==(const MolKey &o) const { return cb == o.cb && umi == o.umi && gene == o.gene; } };
+	struct MolKeyHash { size_t operator()(const MolKey &k) const { uint64_t h = k.cb * 0x9E3779B97F4A7C15ull ^ (k.umi + 0x632BE59BD9B4E019ull) * 0xC2B2AE3D27D4EB4Full ^ uint64_t(k.gene) * 0x165667B19E3779F9ull; return size_t(h ^ (h >> 29)); } };
+	std::unordered_map<MolKey, uint8_t, MolKeyHash> _mol_qlen;
+	bool _mol_qlen_tracking = false;
+	void check_molecule_quality_length(uint64_t cb_code, uint32_t gene, uint64_t umi_code, size_t ql);
 	void append_quality(const char *q, size_t len, bool has_gene);
 	std::vector<std::string> _ref_names;                      // ParsedRead::ref_id -> chromosome name
 	std::vector<int32_t> _ref_chr;                            // ... -> index in _chr_indexer, -1 = not met yet

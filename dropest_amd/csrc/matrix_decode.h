@@ -31,15 +31,7 @@
 
 namespace dropest {
 
-inline void cpu_relax() {
-#if defined(__x86_64__) || defined(__i386__)
-	__builtin_ia32_pause();
-#elif defined(__aarch64__)
-	__asm__ __volatile__("yield");
-#else
-	std::this_thread::yield();
-#endif
-}
+inline void cpu_relax() { host_cpu_relax(); }
 
 struct ByteMatrixView {
 	const uint8_t *rd = nullptr, *vb = nullptr;   // row deltas, values

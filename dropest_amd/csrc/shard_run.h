@@ -226,7 +226,8 @@ struct LocalTransport : Transport {
 struct HostMailbox {
 	static constexpr size_t SLOT = size_t(1) << 20;
 	static constexpr unsigned TIMEOUT_S = 300;
-	struct Header { std::atomic<uint32_t> attached, arrived, generation, failed; };
+	struct Header { std::atomic<uint32_t> attached, arrived, generation, failed; std::atomic<uint64_t> magic; };
+	static uint64_t magic_of(uint64_t token) { return mix64(token ^ 0x6d61696c626f7821ull) | 1ull; }   // never 0: a fresh object reads as zeros
 	int rank = 0, world = 1;
 	char *base = nullptr;
 	size_t bytes = 0;
@@ -255,17 +256,21 @@ struct HostMailbox {
 		close(fd);
 		if (m == MAP_FAILED) { if (r == 0) shm_unlink(path); throw DeviceError("cannot map the host mailbox"); }
 		base = static_cast<char *>(m);   // (a fresh shm object reads as zeros: the header starts at 0 / 0 / 0 / 0)
+		// rank 0 signs the object it has just created; the others attach only to a signed one (an object of the same name that rank 0 is
+		// about to unlink and replace -- a leftover -- never carries this run's word)
+		if (r == 0) hdr()->magic.store(magic_of(token), std::memory_order_release);
+		else wait_until([&] { return hdr()->magic.load(std::memory_order_acquire) == magic_of(token); }, "signature", false);
 		hdr()->attached.fetch_add(1, std::memory_order_acq_rel);
 		wait_until([&] { return hdr()->attached.load(std::memory_order_acquire) >= uint32_t(world); }, "attach");
 		if (r == 0) shm_unlink(path);   // the mappings keep it alive; nothing is left behind on a crash
 	}
 	~HostMailbox() { if (base) munmap(base, bytes); }
 	HostMailbox(const HostMailbox &) = delete;
-	template <class F> void wait_until(F &&done, const char *what) {
+	template <class F> void wait_until(F &&done, const char *what, bool heed_failed = true) {
 		const auto t0 = std::chrono::steady_clock::now();
 		for (uint32_t spins = 0; !done(); ++spins) {
-			if (hdr()->failed.load(std::memory_order_acquire)) throw DeviceError("another shard of the run failed");
-			if (spins < 2000) { __builtin_ia32_pause(); continue; }
+			if (heed_failed && hdr()->failed.load(std::memory_order_acquire)) throw DeviceError("another shard of the run failed");
+			if (spins < 2000) { dropest::host_cpu_relax(); continue; }
 			sched_yield();
 			if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(TIMEOUT_S)) {
 				hdr()->failed.store(1, std::memory_order_release);
@@ -313,7 +318,21 @@ struct RcclTransport : Transport {
 		api.check(api.CommInitRank(&comm, w, id, r), "ncclCommInitRank");
 		for (int i = 0; i < 128; ++i) token = token * 1099511628211ull + id_bytes[i];
 		const char *hc = getenv("DROPEST_HOST_COLLECTIVES");
-		if (!(hc && std::string(hc) == "rccl")) mailbox = std::make_unique<HostMailbox>(token, r, w);
+		bool use_mailbox = !(hc && std::string(hc) == "rccl");
+		if (use_mailbox && w > 1) {
+			// The mailbox is POSIX shared memory: every rank must be on ONE host.  The ranks compare a word that names the host's running
+			// kernel instance (boot id, else the host name) over the communicator first; ranks on several hosts keep the RCCL path for
+			// their host collectives instead of waiting 300 s for a shm object that will never show up.
+			uint64_t mine = 1469598103934665603ull;
+			auto fold = [&](const char *s) { for (; *s; ++s) { mine ^= (unsigned char)*s; mine *= 1099511628211ull; } };
+			char buf[256] = {0};
+			if (FILE *f = fopen("/proc/sys/kernel/random/boot_id", "r")) { if (fgets(buf, sizeof(buf), f)) fold(buf); fclose(f); }
+			if (!buf[0] && gethostname(buf, sizeof(buf) - 1) == 0) fold(buf);
+			std::vector<uint64_t> all(size_t(w), 0);
+			gather_host(&mine, 8, all.data());   // (no mailbox yet: the staged RCCL all-gather)
+			for (int p = 0; p < w; ++p) use_mailbox &= all[size_t(p)] == mine;
+		}
+		if (use_mailbox) mailbox = std::make_unique<HostMailbox>(token, r, w);
 	}
 	~RcclTransport() override {
 		for (auto &s : shm) if (s.host) { (void)hipHostUnregister(s.host); munmap(s.host, s.bytes); }

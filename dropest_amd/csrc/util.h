@@ -42,6 +42,15 @@ __host__ __device__ inline int bit_length(uint64_t x) { return x ? 64 - __builti
 
 constexpr int WAVE = 64;   // gfx950 wavefront
 
+// one spin of a polling loop on the host
+inline void host_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+	__builtin_ia32_pause();
+#elif defined(__aarch64__)
+	__asm__ __volatile__("yield");
+#endif
+}
+
 // Waiting for a stream / an event WITHOUT going to sleep on an interrupt.  A pass has about a dozen points where the host needs
 // a count from the device before it can size the next launch; with the ROCm default (HSA_ENABLE_INTERRUPT=1) a blocked thread
 // takes 50-100 us -- on a loaded host milliseconds -- to run again after the signal, and the GPU idles meanwhile.  Polling the
@@ -55,7 +64,7 @@ inline hipError_t stream_wait(hipStream_t st) {
 			const hipError_t e = hipStreamQuery(st);
 			if (e != hipErrorNotReady) return e;
 			if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
-			__builtin_ia32_pause();
+			host_cpu_relax();
 		}
 	}
 	return hipStreamSynchronize(st);
@@ -67,7 +76,7 @@ inline hipError_t event_wait(hipEvent_t ev) {
 			const hipError_t e = hipEventQuery(ev);
 			if (e != hipErrorNotReady) return e;
 			if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
-			__builtin_ia32_pause();
+			host_cpu_relax();
 		}
 	}
 	return hipEventSynchronize(ev);
@@ -88,8 +97,30 @@ static __global__ void poison_fill_kernel(uint32_t *p, size_t words, uint64_t se
 	for (size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x; i < words; i += size_t(gridDim.x) * blockDim.x)
 		p[i] = uint32_t(mix64(seed + i * 0x9E3779B97F4A7C15ull) >> 16);
 }
+// The debug switches, read once (and again on dropest_debug_refresh): they were five getenv() calls per allocation, one under the registry's lock.
+// With none of them set -- the product path -- allocations do not touch the registry at all: no lock shared by the threads of all
+// shards, no map.  dropest_debug_poison_scratch needs the registry: it asks for DROPEST_DEBUG_REGISTRY=1 (or any other switch).
+struct DevDebug {
+	bool pool, trace, trace_verbose, poison_seed, poison_alloc, poison_zero, any;
+	long long seed; int alloc_byte; unsigned long long zero_a, zero_b;
+	static DevDebug read_env() {
+		{
+			DevDebug x{};
+			x.pool = getenv("DROPEST_DEBUG_POOL") != nullptr;
+			if (const char *t = getenv("DROPEST_ALLOC_TRACE")) { x.trace = true; x.trace_verbose = atoi(t) > 1; }
+			if (const char *s = getenv("DROPEST_POISON_SEED")) { x.poison_seed = true; x.seed = atoll(s); }
+			if (const char *b = getenv("DROPEST_POISON_ALLOC")) { x.poison_alloc = true; x.alloc_byte = atoi(b); }
+			if (const char *z = getenv("DROPEST_POISON_ZERO")) x.poison_zero = sscanf(z, "%llu:%llu", &x.zero_a, &x.zero_b) == 2;
+			x.any = x.pool || x.trace || x.poison_seed || x.poison_alloc || x.poison_zero || getenv("DROPEST_DEBUG_REGISTRY") != nullptr;
+			return x;
+		}
+	}
+	static DevDebug &slot() { static DevDebug d = read_env(); return d; }
+	static const DevDebug &get() { return slot(); }
+	static void refresh() { slot() = read_env(); }   // dropest_debug_refresh: tests switch the variables inside one process
+};
 struct DevRegistry {
-	struct Entry { size_t bytes; uint64_t ordinal; bool persistent; };
+	struct Entry { size_t bytes; uint64_t ordinal; bool persistent; int device; };
 	struct Block { void *p; size_t bytes; int device; };
 	std::mutex mu;
 	std::map<void *, Entry> live;
@@ -106,6 +137,13 @@ struct DevRegistry {
 		(void)hipDeviceSynchronize();
 	}
 	void *allocate(size_t bytes, const char *file, int line) {
+		const DevDebug &dbg = DevDebug::get();
+		if (!dbg.any) {   // the product path: hipMalloc and nothing else
+			void *p = nullptr;
+			const hipError_t e = hipMalloc(&p, bytes);
+			if (e != hipSuccess) throw DeviceError(std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e) + " (" + file + ":" + std::to_string(line) + ")");
+			return p;
+		}
 		void *p = nullptr;
 		bool recycled = false;
 		uint64_t ordinal;
@@ -114,7 +152,7 @@ struct DevRegistry {
 		{
 			std::lock_guard<std::mutex> lk(mu);
 			ordinal = next++;
-			if (getenv("DROPEST_DEBUG_POOL")) {   // smallest block that fits and is not more than twice as large
+			if (dbg.pool) {   // smallest block that fits and is not more than twice as large
 				size_t best = pool.size();
 				for (size_t i = 0; i < pool.size(); ++i)
 					if (pool[i].device == device && pool[i].bytes >= bytes && pool[i].bytes <= bytes * 2 + (size_t(1) << 16) && (best == pool.size() || pool[i].bytes < pool[best].bytes)) best = i;
@@ -131,32 +169,25 @@ struct DevRegistry {
 		}
 		{
 			std::lock_guard<std::mutex> lk(mu);
-			live[p] = Entry{bytes, ordinal, false};
+			live[p] = Entry{bytes, ordinal, false, device};   // (the device it was allocated on: what a pooled block is recycled for)
+			if (dbg.trace && sites.size() < (size_t(1) << 20)) sites.push_back(Site{ordinal, bytes, file, line, recycled});
 		}
-		if (const char *t = getenv("DROPEST_ALLOC_TRACE")) {
-			if (atoi(t) > 1) fprintf(stderr, "[alloc] #%llu %zu B %s %s:%d\n", (unsigned long long)ordinal, bytes, recycled ? "recycled" : "fresh", file, line);
-			std::lock_guard<std::mutex> lk(mu);
-			sites.push_back(Site{ordinal, bytes, file, line, recycled});
-		}
-		bool zero = false;
-		if (const char *z = getenv("DROPEST_POISON_ZERO")) {
-			unsigned long long a = 0, b = 0;
-			if (sscanf(z, "%llu:%llu", &a, &b) == 2 && ordinal >= a && ordinal < b) zero = true;
-		}
-		if (zero) { (void)hipDeviceSynchronize(); (void)hipMemset(p, 0, bytes); (void)hipDeviceSynchronize(); }
-		else if (const char *s = getenv("DROPEST_POISON_SEED")) fill_random(p, bytes, mix64(uint64_t(atoll(s)) * 0x100000001B3ull + ordinal));
-		else if (const char *b = getenv("DROPEST_POISON_ALLOC")) { if (!recycled) { (void)hipDeviceSynchronize(); (void)hipMemset(p, atoi(b), bytes); (void)hipDeviceSynchronize(); } }
+		if (dbg.trace_verbose) fprintf(stderr, "[alloc] #%llu %zu B %s %s:%d\n", (unsigned long long)ordinal, bytes, recycled ? "recycled" : "fresh", file, line);
+		if (dbg.poison_zero && ordinal >= dbg.zero_a && ordinal < dbg.zero_b) { (void)hipDeviceSynchronize(); (void)hipMemset(p, 0, bytes); (void)hipDeviceSynchronize(); }
+		else if (dbg.poison_seed) fill_random(p, bytes, mix64(uint64_t(dbg.seed) * 0x100000001B3ull + ordinal));
+		else if (dbg.poison_alloc) { if (!recycled) { (void)hipDeviceSynchronize(); (void)hipMemset(p, dbg.alloc_byte, bytes); (void)hipDeviceSynchronize(); } }
 		return p;
 	}
 	void release(void *p) {
+		const DevDebug &dbg = DevDebug::get();
+		if (!dbg.any) { (void)hipFree(p); return; }
 		size_t bytes = 0;
 		int device = 0;
-		(void)hipGetDevice(&device);
 		{
 			std::lock_guard<std::mutex> lk(mu);
 			auto it = live.find(p);
-			if (it != live.end()) { bytes = it->second.bytes; live.erase(it); }
-			if (bytes && getenv("DROPEST_DEBUG_POOL") && pool.size() < 512) { pool.push_back(Block{p, bytes, device}); return; }
+			if (it != live.end()) { bytes = it->second.bytes; device = it->second.device; live.erase(it); }
+			if (bytes && dbg.pool && pool.size() < 512) { pool.push_back(Block{p, bytes, device}); return; }
 		}
 		(void)hipFree(p);
 	}
@@ -165,7 +196,7 @@ struct DevRegistry {
 		{ std::lock_guard<std::mutex> lk(mu); drop.swap(pool); }
 		for (auto &b : drop) (void)hipFree(b.p);
 	}
-	void set_persistent(void *p) { std::lock_guard<std::mutex> lk(mu); auto it = live.find(p); if (it != live.end()) it->second.persistent = true; }
+	void set_persistent(void *p) { if (!DevDebug::get().any) return; std::lock_guard<std::mutex> lk(mu); auto it = live.find(p); if (it != live.end()) it->second.persistent = true; }
 	size_t poison_all(uint64_t seed) {   // every live block that is not marked persistent
 		std::vector<std::pair<void *, Entry>> todo;
 		{ std::lock_guard<std::mutex> lk(mu); for (auto &kv : live) if (!kv.second.persistent) todo.push_back(kv); }

@@ -467,6 +467,10 @@ dropest_status dropest_set_profiling_filter(dropest_ctx *ctx, const char *name_p
  * Only meaningful while no pass is in flight.  dropest_debug_trim_pool frees the blocks DROPEST_DEBUG_POOL=1 recycles. */
 dropest_status dropest_debug_poison_scratch(uint64_t seed, uint64_t *n_blocks);
 dropest_status dropest_debug_trim_pool(void);
+/* The debug allocator's environment switches (csrc/util.h) are read when the library first allocates; a process that changes them
+ * afterwards (the test suite does) calls this to have them read again.  DROPEST_DEBUG_REGISTRY=1 alone turns the registry on, which
+ * dropest_debug_poison_scratch needs: without any switch allocations go straight to hipMalloc and are not tracked. */
+dropest_status dropest_debug_refresh(void);
 /* Allocations are numbered; with DROPEST_ALLOC_TRACE=1 the call site of each is kept: `next ordinal` brackets a pass, and
  * DROPEST_POISON_ZERO=a:b zero-fills the allocations numbered [a, b) -- how scripts/hunt_stale.py bisects a dependence. */
 dropest_status dropest_debug_alloc_ordinal(uint64_t *next_ordinal);

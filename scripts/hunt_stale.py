@@ -19,6 +19,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 os.environ["DROPEST_ALLOC_TRACE"] = "1"
+os.environ["DROPEST_DEBUG_REGISTRY"] = "1"
 import numpy as np
 
 from dropest_amd import capi
@@ -62,6 +63,7 @@ def one_pass(dev, kw, env, ctx=None, keep=False):
     for k in DEBUG_VARS:
         os.environ.pop(k, None)
     os.environ.update(env)
+    capi.lib().dropest_debug_refresh()
     o0 = next_ordinal()
     c = ctx or capi.Context(**kw)
     if ctx is None:

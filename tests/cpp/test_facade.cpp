@@ -305,10 +305,27 @@ static void testQualityLengthPerMolecule() {   // UMI.cpp:21-34 + Gene.cpp:20: t
 		                     Mark::get_by_code(Mark::DEFAULT_CODE));
 		c.add_record(mk("AAATTAGGTCCA", "AAACCT", "IIIIII", "Gene1"));
 		c.add_record(mk("AAATTAGGTCCA", "CCCCCT", "III", "Gene1"));
-		c.add_record(mk("AAATTAGGTCCA", "AAACCT", "JJJJ", "Gene1"));       // the reference throws here, in add_record; this container in set_initialized
 		std::string what;
-		try { c.set_initialized(); } catch (const std::runtime_error &e) { what = e.what(); }
+		try { c.add_record(mk("AAATTAGGTCCA", "AAACCT", "JJJJ", "Gene1")); } catch (const std::runtime_error &e) { what = e.what(); }   // the reference throws here, from add_record (UMI.cpp:26-28): so does this container
 		CHECK_EQ(what, std::string("Wrong quality length: 4, expected: 6"));
+	}
+	{   // ... also when the molecule was created AFTER the lengths began to differ, and for a molecule of the first length met later
+		CellsDataContainer c(std::make_shared<Merge::DummyMergeStrategy>(0, 0), std::make_shared<Merge::UMIs::MergeUMIsStrategySimple>(1),
+		                     Mark::get_by_code(Mark::DEFAULT_CODE));
+		c.add_record(mk("AAATTAGGTCCA", "AAACCT", "IIIIII", "Gene1"));
+		c.add_record(mk("CCCTTAGGTCCA", "TTTCCT", "IIIIII", "Gene2"));
+		c.add_record(mk("AAATTAGGTCCA", "CCCCCT", "III", "Gene1"));        // lengths differ from here on
+		c.add_record(mk("AAATTAGGTCCA", "GGGGGT", "IIII", "Gene1"));       // a new molecule of a third length
+		c.add_record(mk("AAATTAGGTCCA", "GGGGGT", "JJJJ", "Gene1"));       // the same length again: fine
+		std::string what;
+		try { c.add_record(mk("AAATTAGGTCCA", "GGGGGT", "JJJ", "Gene1")); } catch (const std::runtime_error &e) { what = e.what(); }
+		CHECK_EQ(what, std::string("Wrong quality length: 3, expected: 4"));
+		what.clear();
+		try { c.add_record(mk("CCCTTAGGTCCA", "TTTCCT", "II", "Gene2")); } catch (const std::runtime_error &e) { what = e.what(); }   // a molecule from before the lengths differed
+		CHECK_EQ(what, std::string("Wrong quality length: 2, expected: 6"));
+		c.add_record(mk("CCCTTAGGTCCA", "TTTCCT", "JJJJJJ", "Gene2"));     // the container is still usable for reads that fit
+		c.set_initialized();
+		for (auto const &m : c.cell(1).molecules()) if (m.umi == "TTTCCT") CHECK_EQ(m.sum_quality.size(), size_t(6));
 	}
 }
 

@@ -541,3 +541,54 @@ def test_umi_qualities_follow_a_barcode_merge_across_shards(world, poisson):
     assert not bad, (len(bad), bad[0], got.get(bad[0]), want[bad[0]])
     # and not trivially: some kept molecule's sums differ from what its reads alone in the target would give (a fold happened)
     g.close()
+
+
+def test_c4_at_its_per_gpu_size_single_context_and_four_shards():
+    """BASELINE configs[3] ("C4": inDrop v3, split 8 + 8 bp barcode, 8 bp UMI, -m + the inDrop v3 whitelist) at the size ONE of its four GPUs
+    holds: 1.25e8 reads, 5 000 cells.  Far beyond the oracle, so (a) size-independent properties of the single context -- every read counted
+    once, targets final whitelist cells, CSC structure -- and (b) the same stream cut into four contiguous ranges on four in-process shards
+    (all on this GPU: partition by owner, all-to-all, sharded whitelist merge, device-planned cm_raw) must assemble the same two matrices,
+    column barcodes and merged barcodes, entry for entry."""
+    n, world = 125_000_000, 4
+    s = SynthStream(n_reads=n, n_cells=5000, n_genes=30000, cb_len=16, whitelist="indrop_v3", umi_len=8, stream_id=4)
+    cfg = {"min_before": 20, "min_after": 100, "merge": {"barcodes_kind": capi.BARCODES_CONST, "barcodes_file": os.path.join(DATA, "indrop_v3")}}
+    kw = cfg_kwargs(cfg)
+    dev = s.generate_device(0)
+    c = capi.Context(**kw)
+    c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
+    c.set_initialized()
+    n_real_before = c.real_cells_number()
+    c.merge_and_filter()
+    rows = c.cell_rows()
+    merged = rows["is_merged"].astype(bool)
+    assert int(rows["total_reads"].astype(np.int64)[~merged].sum()) + int(c.global_counters()[0]) == n      # every read once
+    mt = c.merge_targets().astype(np.int64)
+    src = np.flatnonzero(mt != np.arange(len(mt)))
+    assert len(src) > 1000 and np.all(mt[mt[src]] == mt[src]) and c.real_cells_number() < n_real_before
+    wl_cells = set(int(x) for x in s.cell_cb)
+    assert all(int(b) in wl_cells for b in rows["barcode"][mt[src[:20000]]])
+    want = {}
+    for filt, name in ((True, "cm"), (False, "raw")):
+        p, i, x = c.count_matrix_csc(filtered=filt)
+        d = np.diff(i.astype(np.int64)); d[p[1:-1].astype(np.int64) - 1] = 1
+        assert np.all(d > 0) and np.all(x > 0) and len(i) > 1_000_000                                        # genes ascend inside a column
+        want[name] = (p.astype(np.uint64).copy(), i.copy(), x.copy())
+    want["cm_bc"] = [int(rows["barcode"][int(k)]) for k in c.filtered_cells()]
+    want["raw_bc"] = [int(b) for b in rows["barcode"][rows["is_real"].astype(bool)]]
+    want["merged"] = {int(rows["barcode"][k]): int(rows["barcode"][int(mt[k])]) for k in src}
+    c.close(); dev.free()
+    # four shards on this GPU, each with its contiguous quarter of the stream
+    g = ShardGroup([0] * world, **kw)
+    bounds = [n * k // world for k in range(world + 1)]
+    for k, sh in enumerate(g.shards):
+        sh.set_reads(s.generate_device(0, first=bounds[k], n=bounds[k + 1] - bounds[k]), bounds[k])
+    g.step()
+    s0 = g.shards[0]
+    for filt, name in ((True, "cm"), (False, "raw")):
+        gp, gi, gx, gb = s0.matrix(filt)
+        assert np.array_equal(gp.astype(np.uint64), want[name][0]) and np.array_equal(gi, want[name][1]) and np.array_equal(gx, want[name][2]), name
+        assert [int(b) for b in gb] == want[name + "_bc"], name
+    ms, mt2 = s0.merged_barcodes()
+    assert dict(zip((int(b) for b in ms), (int(b) for b in mt2))) == want["merged"]
+    assert s0.phase_stats()["all_to_all"]["bytes"] > 0
+    g.close()

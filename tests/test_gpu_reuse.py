@@ -41,7 +41,9 @@ def poison(seed):
 
 @pytest.fixture(autouse=True)
 def clean_env():
-    saved = {k: os.environ.get(k) for k in DEBUG_VARS + tuple(OLD_PATHS)}
+    saved = {k: os.environ.get(k) for k in DEBUG_VARS + tuple(OLD_PATHS) + ("DROPEST_DEBUG_REGISTRY",)}
+    os.environ["DROPEST_DEBUG_REGISTRY"] = "1"     # every allocation of these tests is tracked: dropest_debug_poison_scratch overwrites what is live
+    capi.lib().dropest_debug_refresh()            # (the library reads the debug switches once; this has them read again)
     yield
     for k, v in saved.items():
         if v is None:
@@ -49,6 +51,7 @@ def clean_env():
         else:
             os.environ[k] = v
     capi.lib().dropest_debug_trim_pool()
+    capi.lib().dropest_debug_refresh()
 
 
 def merge_kw(before=10, after=60):
@@ -89,6 +92,7 @@ def test_allocator_state_does_not_change_the_result(mode, paths):
         for k in DEBUG_VARS:
             os.environ.pop(k, None)
         os.environ.update(env)
+        capi.lib().dropest_debug_refresh()
         c = capi.Context(**merge_kw())
         c.push_reads_device(*d.ptrs, d.n, adopt=True)
         c.set_initialized(); c.merge_and_filter()
@@ -96,6 +100,7 @@ def test_allocator_state_does_not_change_the_result(mode, paths):
         c.close()
         for k in DEBUG_VARS:
             os.environ.pop(k, None)
+        capi.lib().dropest_debug_refresh()
         return out
     ref = run(dev, {})
     env = {"random-1": {"DROPEST_POISON_SEED": "1"}, "random-2": {"DROPEST_POISON_SEED": "2"}, "recycled": {"DROPEST_DEBUG_POOL": "1"},
