@@ -137,22 +137,26 @@ def cpu_baseline(stream, n_sample, cfg, name="C2"):
 
 
 # kernel-stat name (dropest_kernel_stats) -> start of the kernel's name in a rocprofv3 trace
-ROCPROF_NAME = {"cb_insert": "cb_insert_", "build_keys": "build_keys_kernel", "ss_local:keys": "ss_local_kernel<0>",
-                "ss_local:key+1B": "ss_local_kernel<1>", "ss_scatter:L1:keys": "ss_scatter_l1_kernel<0", "ss_scatter:L2:keys": "ss_scatter_l2_kernel<0",
-                "ss_scatter:L1:key+1B": "ss_scatter_l1_kernel<1", "ss_scatter:L2:key+1B": "ss_scatter_l2_kernel<1", "ss_hist:L1": "ss_hist_l1_kernel",
+ROCPROF_NAME = {"cb_insert": "cb_insert_", "build_keys": "build_keys_kernel", "ss_local:keys": "ss_local_kernel<0",
+                "ss_local:key+1B": "ss_local_kernel<1", "ss_scatter:L1:keys": ("ss_scatter_res_l1_kernel<0", "ss_scatter_l1_kernel<0"),
+                "ss_scatter:L2:keys": ("ss_scatter_res_l2_kernel<0", "ss_scatter_l2_kernel<0"),
+                "ss_scatter:L1:key+1B": ("ss_scatter_res_l1_kernel<1", "ss_scatter_l1_kernel<1"), "ss_scatter:L2:key+1B": ("ss_scatter_res_l2_kernel<1", "ss_scatter_l2_kernel<1"),
+                "ss_hist:L1": "ss_hist_l1_kernel",
                 "ss_hist:L2": "ss_hist_l2_kernel", "rs_scatter:keys": "rs_scatter_kernel_t<512, 8, false, 0, 8>",
                 "rs_scatter:key+1B": "rs_scatter_kernel_t<512, 8, false, 1, 8>", "rs_scatter": "rs_scatter_kernel_t<512, 16, true, 4, 8>"}
 
 
 def pmc_record(config, reads_per_gpu, sort):
-    """profiles/pmc_pipeline.json (scripts/pmc_summary.py) when it was taken on this workload, size and sort path."""
-    path = os.path.join(ROOT, "profiles", "pmc_pipeline.json")
-    try:
-        rec = json.load(open(path))
-    except Exception:
-        return None
-    if rec.get("workload") == config and rec.get("reads_per_gpu") == reads_per_gpu and rec.get("sort") == sort:
-        return rec
+    """The counter record (scripts/pmc_summary.py: profiles/pmc_pipeline*.json) taken on this workload, size and sort path, if there is one."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_pipeline*.json"))):
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        if rec.get("workload") == config and rec.get("reads_per_gpu") == reads_per_gpu and rec.get("sort") == sort:
+            rec["file"] = "profiles/" + os.path.basename(path)
+            return rec
     return None
 
 
@@ -160,7 +164,7 @@ def pmc_kernel_bytes(stat_name, config, reads_per_gpu, sort):
     rec, prefix = pmc_record(config, reads_per_gpu, sort), ROCPROF_NAME.get(stat_name)
     if not rec or not prefix:
         return None
-    hits = [v["hbm_bytes_per_launch"] for k, v in rec["per_kernel"].items() if k.startswith(prefix)]
+    hits = [v["hbm_bytes_per_launch"] for k, v in rec["per_kernel"].items() if k.startswith(prefix)]   # (prefix: a string or a tuple of them)
     return max(hits) if hits else None          # several grid sizes: the main launch
 
 
@@ -203,7 +207,7 @@ def push_rates(stream, local_rank, n_push, cfg_kw):
             L.dropest_host_unregister(local_rank, a.ctypes.data)
 
 
-def bam_ingest_rate(n=250_000, copies=96, threads=16):
+def bam_ingest_rate(n=250_000, copies=48, threads=16):
     """BAM file -> container through the native reader (scripts/bench_bam_ingest.py: BGZF inflate, record boundaries, tag parsing, 2-bit
     packing, push): n synthetic 10x-style records written `copies` times into one file.  {} when the tool is not built or
     DROPEST_BENCH_NO_BAM is set."""
@@ -350,8 +354,8 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
             traffic = pmc_kernel_bytes(dom_name, config, reads_per_gpu, get_layout()["sort"])
             roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": None if traffic is None else "profiles/pmc_pipeline.json: rocprofv3 --pmc passes of this workload taken by "
-                                      "scripts/refresh_profiles.sh (builder-run, not counters of this run)",
+                    "traffic_source": None if traffic is None else "%s: rocprofv3 --pmc passes of this workload taken by "
+                                      "scripts/refresh_profiles.sh (builder-run, not counters of this run)" % (pmc_record(config, reads_per_gpu, get_layout()["sort"]) or {}).get("file"),
                     "avg_launch_ms": round(avg_ms, 4), "launches": dom["launches"],
                     "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"]}
             # the candidates next to it (same events, same region): at C2 three kernels of about 1 ms each take turns at the top from box to box
@@ -476,11 +480,11 @@ def main():
     rccl_came_up = False
     line = measure(args, args.config, int(args.reads), args.cells, args.steps, args.warmup, world, rank, local_rank, dist, force_sharded, True)
     # The largest single-GPU configuration of BASELINE.json (configs[2], "C3": 1e9 reads, 50 000 cells, whitelist CB merge) rides
-    # along with the default run as `secondary.c3_1e9` -- same clock, same fences, 3 timed steps after 1 warm-up (24 GB of reads).
+    # along with the default run as `secondary.c3_1e9` -- same clock, same fences, 5 timed steps after 1 warm-up (24 GB of reads).
     if (line is not None and world == 1 and not force_sharded and args.config == "c2" and int(args.reads) == 100_000_000 and not args.no_secondary
             and not args.merge_umi):
         try:
-            sec = measure(args, "c3", 1_000_000_000, 50000, 3, 1, world, rank, local_rank, dist, False, False)
+            sec = measure(args, "c3", 1_000_000_000, 50000, 5, 1, world, rank, local_rank, dist, False, False)
             line["secondary"] = {"c3_1e9": {k: sec[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "step_ms", "config", "roofline", "cpu_baseline",
                                                                 "kernels_ms_per_step", "host_stage_wall_ms_per_step")}}
         except Exception as e:   # the primary line must not be lost to the secondary workload

@@ -1141,10 +1141,12 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 	auto passes = [&](const HostCell &h) {
 		return !(h.merged || h.excluded || h.row.n_genes < min_before) && h.row.requested_genes >= genes_threshold;
 	};
-	size_t device_min = 50000;
+	// (Up to a few 10^5 cells the host orders them in a millisecond or two; the device path's read-back crosses PCIe behind cm_raw's
+	// prefetch -- 10 ms of waiting for 200 KB at C3 size -- so it starts where the host sort would cost more than that.)
+	size_t device_min = 2000000;
 	if (const char *e = getenv("DROPEST_DEVICE_SORT_MIN")) device_min = size_t(std::max(1, atoi(e)));   // tests force the device path
 
-	// Large lists (10^5..10^6 cells at BASELINE sizes) are ordered on the device: three stable LSD radix sorts
+	// Very large lists (millions of filtered cells) are ordered on the device: three stable LSD radix sorts
 	// (barcode, then TOTAL_UMIS, then the packed sizes) when every barcode is a clean code of one length, so that
 	// the numeric order of the codes IS the string order.  The key is total, so any correct sort gives the same list.
 	// The host side of it (two passes over `real`, one over the result) runs on a few worker threads.
@@ -1244,13 +1246,29 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 
 	struct Key { u64 sizes; u64 umis; u64 code; u32 idx; };
 	std::vector<Key> keys;
-	keys.reserve(8192);
-	for (u32 i = 0; i < real.size(); ++i) {
+	auto key_of = [&](u32 i) {
 		const HostCell &h = real[i];
-		if (!passes(h)) continue;
-		keys.push_back(Key{(u64(h.row.requested_genes) << 32) | h.row.requested_umis,
-		                   u64(size_t(h.row.total_umis)),   // Cell::umis_number casts the int stat to size_t
-		                   h.row.barcode, i});
+		return Key{(u64(h.row.requested_genes) << 32) | h.row.requested_umis,
+		           u64(size_t(h.row.total_umis)),   // Cell::umis_number casts the int stat to size_t
+		           h.row.barcode, i};
+	};
+	if (R >= 200000) {   // millions of real-candidate cells (C3: 2.5 M), a few 10^4 of them filtered: counted and collected on worker threads
+		constexpr unsigned W = dropest::HostPool::MAX;
+		size_t count[W] = {0}, offset[W + 1] = {0};
+		const unsigned workers = parallel_ranges(R, [&](size_t b, size_t e, unsigned w) {
+			size_t c = 0;
+			for (size_t i = b; i < e; ++i) c += passes(real[i]) ? 1 : 0;
+			count[w] = c;
+		}, 100000, W);
+		for (unsigned w = 0; w < workers; ++w) offset[w + 1] = offset[w] + count[w];
+		keys.resize(offset[workers]);
+		parallel_ranges(R, [&](size_t b, size_t e, unsigned w) {
+			size_t at = offset[w];
+			for (size_t i = b; i < e; ++i) if (passes(real[i])) keys[at++] = key_of(u32(i));
+		}, 100000, W);   // same n and limits: the same ranges
+	} else {
+		keys.reserve(8192);
+		for (u32 i = 0; i < real.size(); ++i) if (passes(real[i])) keys.push_back(key_of(i));
 	}
 	auto less = [&](const Key &a, const Key &b) {
 		if (a.sizes != b.sizes) return a.sizes < b.sizes;

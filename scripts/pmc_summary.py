@@ -73,7 +73,9 @@ def main():
     print("wrote", path)
     # calibration check (kernels whose traffic is known exactly) + the records bench.py quotes
     by = {r[0]: r for r in rows}
-    for probe, exact in (("ss_hist_l1_kernel", 8.0 * n_records), ("rs_hist_kernel", 8.0 * n_records)):
+    for probe, exact in (("ss_hist_l1_kernel", 8.0 * n_records), ("rs_hist_kernel", 8.0 * n_records), ("cb_insert_hot_kernel", None)):
+        if exact is None:
+            continue
         hit = max((r for k, r in by.items() if k.startswith(probe)), key=lambda r: r[2], default=None)
         if hit:
             print("calibration: %s FETCH raw %.1f KB vs exact %.1f KB -> x%.3f" % (probe, hit[2], exact / 1024, exact / 1024 / hit[2]))
@@ -96,7 +98,7 @@ def main():
                      "ss_hist_l1 = 8 B x N reads), WRITE_SIZE exact (checked on synth_kernel = 24 B x N writes); "
                      "see profiles/%s_pmc_summary.csv" % tag}
     rec["passes_in_trace"] = passes
-    with open(os.path.join(out_dir, "pmc_pipeline.json"), "w") as out:
+    with open(os.path.join(out_dir, os.environ.get("DROPEST_PMC_FILE", "pmc_pipeline.json")), "w") as out:
         json.dump(rec, out, indent=1)
     print("pipeline: %.3f GB per step over %d kernels (%s sort, %d passes in the trace); runtime copies / fills %.3f GB per step" % (total / 1e9, len(per_kernel), sort, passes, copies / 1e9))
 

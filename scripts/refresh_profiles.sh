@@ -21,17 +21,23 @@ python scripts/pmc_summary.py $OUT/fetch $OUT/write $OUT $TAG 100000000 > $OUT/p
 cp $OUT/pmc_pipeline.json profiles/pmc_pipeline.json 2>/dev/null    # so that the bench lines below quote the fresh traffic
 python scripts/roofline_table.py $OUT/${TAG}_pmc_summary.csv > $OUT/${TAG}_roofline_by_kernel.md 2> $OUT/roofline.err
 if [ -n "${ONLY_PMC:-}" ]; then rm -rf $OUT/kt $OUT/fetch $OUT/write; tail -4 $OUT/pmc_summary.log; exit 0; fi
-timeout 900 python bench.py 2> $OUT/bench.err | head -1 > $OUT/${TAG}_bench_c2.json     # the default run: C2 + secondary.c3_1e9
 timeout 600 python bench.py --sharded --cpu-sample 0 2> /dev/null | head -1 > $OUT/${TAG}_bench_c2_sharded_runner.json
 DROPEST_SORT=lsd timeout 600 python bench.py --cpu-sample 0 --no-secondary 2> /dev/null | head -1 > $OUT/${TAG}_bench_c2_lsd_sort.json
 rm -rf $OUT/kt $OUT/fetch $OUT/write
-ls -la $OUT; tail -4 $OUT/pmc_summary.log; tail -c 900 $OUT/${TAG}_bench_c2.json
+ls -la $OUT; tail -4 $OUT/pmc_summary.log
 timeout 900 python bench.py --config c3 --reads 1e9 --steps 3 --warmup 1 --cpu-sample 3e6 2> /dev/null | head -1 > $OUT/${TAG}_bench_c3_1e9.json
 # kernel-trace stats of the C3 pass at 1e9 reads
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt3 -o r -- python $R/bench.py --config c3 --reads 1e9 --steps 3 --warmup 1 --cpu-sample 0 > /dev/null 2> $OUT/kt3.err)
 cp $(find $OUT/kt3 -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_c3_1e9_kernel_stats.csv 2>/dev/null; rm -rf $OUT/kt3
+# HBM counters of the C3 pass at 1e9 reads (separate passes, kernel-trace only): profiles/pmc_pipeline_c3_1e9.json, which bench.py quotes for secondary.c3_1e9
+(cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch3 -o r -- python $R/bench.py --config c3 --reads 1e9 --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2> $OUT/fetch3.err)
+(cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write3 -o r -- python $R/bench.py --config c3 --reads 1e9 --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2> $OUT/write3.err)
+DROPEST_PMC_WORKLOAD=c3 DROPEST_PMC_FILE=pmc_pipeline_c3_1e9.json python scripts/pmc_summary.py $OUT/fetch3 $OUT/write3 $OUT ${TAG}_c3_1e9 1000000000 > $OUT/pmc_summary_c3.log 2>&1
+cp $OUT/pmc_pipeline_c3_1e9.json profiles/pmc_pipeline_c3_1e9.json 2>/dev/null
+rm -rf $OUT/fetch3 $OUT/write3; tail -3 $OUT/pmc_summary_c3.log
 timeout 600 python bench.py --config c4 --reads 1.25e8 --steps 5 --warmup 2 --cpu-sample 3e6 2> /dev/null | head -1 > $OUT/${TAG}_bench_c4_1gpu.json
 timeout 600 python bench.py --config c4 --reads 1.25e8 --steps 5 --warmup 2 --cpu-sample 0 --sharded 2> /dev/null | head -1 > $OUT/${TAG}_bench_c4_sharded_runner.json
+timeout 1200 python bench.py --steps 20 --warmup 5 2> $OUT/bench.err | head -1 > $OUT/${TAG}_bench_c2.json     # the driver's command: C2 + secondary.c3_1e9 + the sharded runner
 python - <<PY
 import json
 for n in ("c2", "c2_sharded_runner", "c2_lsd_sort", "c3_1e9", "c4_1gpu", "c4_sharded_runner"):
