@@ -417,8 +417,12 @@ struct dropest_ctx {
 		u32 rcap = 0, vcap = 0;         // capacities of the row / value lists of the last byte-form emit
 		// 32-bit slots that travel as bytes (matrix_decode.h): the chunked copy's events and the job that widens into h_row / h_val
 		bool wire = false;
-		std::shared_ptr<dropest::DecodeJob> job;
+		std::shared_ptr<dropest::DecodeJob> job, late_job;   // late_job: finished, but a decoding thread may not have left it yet
 		std::chrono::steady_clock::time_point job_t0;
+		void settle() {   // nobody reads or writes this slot's host buffers any more
+			if (job) { (void)job->wait(); job->quiesce(); job.reset(); }
+			if (late_job) { late_job->quiesce(); late_job.reset(); }
+		}
 		dropest::PinnedBuf<u32> h_flags;   // arrival flags the device raises between the chunks
 		u32 wire_epoch = 0;
 		std::vector<u32> colptr;

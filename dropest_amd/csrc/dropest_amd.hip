@@ -106,7 +106,7 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 dropest_ctx::~dropest_ctx() {
 	for (auto &p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 	for (auto e : event_pool) (void)hipEventDestroy(e);
-	for (auto &M : mat) if (M.job) { (void)M.job->wait(); M.job.reset(); }
+	for (auto &M : mat) M.settle();
 	if (stream2) { (void)stream_wait(stream2); (void)hipStreamDestroy(stream2); }
 	if (ev_fork) (void)hipEventDestroy(ev_fork);
 	if (ev_raw) (void)hipEventDestroy(ev_raw);
@@ -1453,7 +1453,7 @@ void dropest_ctx::matrix_columns(bool filtered_m, std::vector<u32> &col_cell, st
 
 void dropest_ctx::invalidate_prefetch() {
 	if (raw_pf.in_flight && stream2) HIP_CHECK(stream_wait(stream2));   // its buffers are about to be reused
-	if (mat[1].job) { (void)mat[1].job->wait(); mat[1].job.reset(); }   // ... also by the host threads that widen them
+	mat[1].settle();   // ... also by the host threads that widen them
 	raw_pf.valid = raw_pf.in_flight = false;
 }
 
@@ -1470,6 +1470,7 @@ static u32 matrix_row_list_cap(uint64_t nnz) {
 
 // Wires the output side of an emit launch for matrix slot M (device form 0 / 1 / 2) and makes sure the buffers exist.
 void dropest_ctx::matrix_outputs(MatrixResult &M, uint64_t nnz, int form, bool to_host, dropest::MatrixArgs &a) {
+	M.settle();   // (a decoding thread may still be leaving the slot's previous job: its buffers are about to be rewritten or regrown)
 	M.n_ovf = M.n_rovf = 0;
 	if (form) {
 		M.vcap = MATRIX_OVF_CAP;
@@ -1614,6 +1615,7 @@ bool dropest_ctx::wire_finish(MatrixResult &M) {
 		        double(M.job->slowest_slice_ns.load()) * 1e-6, M.job->slice_end.size(), M.job->chunk_end.size());
 	}
 	M.n_rovf = M.job->n_r; M.n_ovf = M.job->n_v;
+	M.late_job = std::move(M.job);   // complete; a straggler may still be inside (settle() before the buffers are touched again)
 	M.job.reset();
 	if (st == DecodeJob::DONE) return true;
 	if (st == DecodeJob::OVERFLOW) return false;
@@ -1713,7 +1715,7 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, 
 		direct = true;   // the lists of the byte form overflowed: the slots come directly
 	}
 	if (!filtered_m) invalidate_prefetch();
-	if (M.job) { (void)M.job->wait(); M.job.reset(); }
+	M.settle();
 	tail_mark(filtered_m ? "emit_matrix(cm) entered" : "emit_matrix(cm_raw) entered");
 	matrix_columns(filtered_m, col_cell, M.colptr, nnz);
 	tail_mark("columns known");
@@ -2496,6 +2498,7 @@ dropest_status dropest_matrix_bytes_widen(const dropest_matrix_bytes *m, uint32_
 		dropest::DecodePool::get().submit(job);
 		job->work(true);
 		const int st = job->wait();
+		job->quiesce();   // the caller's arrays are its own again when this returns
 		if (st == dropest::DecodeJob::BAD_ROW) throw InvalidError("byte matrix: a listed row does not stand on a 255");
 		if (st == dropest::DecodeJob::BAD_VALUE) throw InvalidError("byte matrix: a listed value does not stand on a 255");
 		if (st != dropest::DecodeJob::DONE) throw InvalidError("byte matrix: the decode failed");

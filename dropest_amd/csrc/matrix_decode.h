@@ -271,7 +271,15 @@ struct DecodeJob {
 	}
 	// A thread's share of the job; returns when there is nothing left to do for it.  rescue: the caller owns the job (it has nothing else
 	// to do until the matrix is complete) and walks what others hold at once instead of after a patience.
+	// Threads inside work(): a slice somebody else has finished meanwhile (rescue) may still be under a straggler's pen when the job is
+	// DONE -- the results are complete, but the buffers must not be freed or rewritten until quiesce() has seen everybody leave.
+	std::atomic<int> inside{0};
+	struct Inside { std::atomic<int> &n; explicit Inside(std::atomic<int> &x) : n(x) { n.fetch_add(1, std::memory_order_acq_rel); } ~Inside() { n.fetch_sub(1, std::memory_order_acq_rel); } };
+	void quiesce() const {
+		for (uint32_t it = 0; inside.load(std::memory_order_acquire) != 0; ++it) { if (it < 4096u) cpu_relax(); else std::this_thread::yield(); }
+	}
 	void work(bool rescue = false) {
+		Inside guard(inside);
 		if (!running()) return;
 		// 1. the lists have landed: their lengths
 		for (uint32_t it = 0; lists_state.load(std::memory_order_acquire) != 2u; ++it) {

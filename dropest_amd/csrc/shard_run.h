@@ -309,14 +309,62 @@ struct RcclTransport : Transport {
 	uint64_t token = 0;
 	std::unique_ptr<HostMailbox> mailbox;
 	struct Shm { void *host = nullptr; size_t bytes = 0; int gen = 0; } shm[4];
+	// DROPEST_SHARD_DATAPLANE=shm: the device data of the collectives (exchange, gather_dev) crosses through POSIX shared memory instead of
+	// RCCL -- every process stages what it sends in a segment of its own, the peers read it after a barrier.  For runs whose processes
+	// share GPUs (RCCL refuses two ranks on one device): the multi-process tests on a one-GPU box run the whole step this way -- the
+	// mailbox, the shared result buffers, the sequence of collectives are the real ones, only ncclSend / ncclRecv are stood in for.
+	bool shm_plane = false;
+	struct Stage { void *host = nullptr; size_t bytes = 0; uint64_t gen = 0; };
+	Stage my_stage;
+	std::vector<Stage> peer_stage;
+	static void stage_path(char *out, size_t n, uint64_t token, int rank, uint64_t gen) { std::snprintf(out, n, "/dropest_dp_%llx_%d_%llu", (unsigned long long)token, rank, (unsigned long long)gen); }
+	// collective: every rank makes sure its segment holds `need` bytes, then maps the peers' segments (again) where they were replaced
+	void stage_prepare(size_t need) {
+		uint64_t row[2] = {my_stage.gen, 0};
+		if (need > my_stage.bytes) {
+			if (my_stage.host) { char old[128]; stage_path(old, sizeof(old), token, rank, my_stage.gen); munmap(my_stage.host, my_stage.bytes); shm_unlink(old); my_stage.host = nullptr; }
+			const size_t cap = need + need / 4 + 4096;
+			char path[128];
+			stage_path(path, sizeof(path), token, rank, my_stage.gen + 1);
+			shm_unlink(path);
+			const int fd = shm_open(path, O_CREAT | O_EXCL | O_RDWR, 0600);
+			if (fd < 0 || posix_fallocate(fd, 0, off_t(cap)) != 0) { if (fd >= 0) { close(fd); shm_unlink(path); } throw DeviceError("cannot create the staging segment of the shm data plane"); }
+			void *m = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+			close(fd);
+			if (m == MAP_FAILED) { shm_unlink(path); throw DeviceError("cannot map the staging segment of the shm data plane"); }
+			my_stage.host = m; my_stage.bytes = cap; ++my_stage.gen;
+			row[0] = my_stage.gen;
+		}
+		row[1] = my_stage.bytes;
+		std::vector<uint64_t> all(size_t(world) * 2);
+		gather_host(row, 16, all.data());
+		peer_stage.resize(size_t(world));
+		for (int p = 0; p < world; ++p) {
+			if (p == rank) continue;
+			Stage &ps = peer_stage[size_t(p)];
+			if (ps.gen == all[size_t(p) * 2] && ps.host) continue;
+			if (ps.host) { munmap(ps.host, ps.bytes); ps.host = nullptr; }
+			ps.gen = all[size_t(p) * 2]; ps.bytes = size_t(all[size_t(p) * 2 + 1]);
+			if (!ps.gen) continue;
+			char path[128];
+			stage_path(path, sizeof(path), token, p, ps.gen);
+			const int fd = shm_open(path, O_RDONLY, 0600);
+			void *m = fd >= 0 ? mmap(nullptr, ps.bytes, PROT_READ, MAP_SHARED, fd, 0) : MAP_FAILED;
+			if (fd >= 0) close(fd);
+			if (m == MAP_FAILED) throw DeviceError("cannot map a peer's staging segment of the shm data plane");
+			ps.host = m;
+		}
+	}
 	RcclTransport(int r, int w, const uint8_t id_bytes[128], hipStream_t st) : st0(st) {
 		rank = r; world = w;
+		for (int i = 0; i < 128; ++i) token = token * 1099511628211ull + id_bytes[i];
+		{ const char *dp = getenv("DROPEST_SHARD_DATAPLANE"); shm_plane = dp && std::string(dp) == "shm"; }
+		if (shm_plane) { mailbox = std::make_unique<HostMailbox>(token, r, w); return; }   // one host by construction; no communicator
 		const RcclApi &api = RcclApi::get();
 		ncclUniqueId id;
 		static_assert(sizeof(id) == 128, "ncclUniqueId");
 		std::memcpy(&id, id_bytes, 128);
 		api.check(api.CommInitRank(&comm, w, id, r), "ncclCommInitRank");
-		for (int i = 0; i < 128; ++i) token = token * 1099511628211ull + id_bytes[i];
 		const char *hc = getenv("DROPEST_HOST_COLLECTIVES");
 		bool use_mailbox = !(hc && std::string(hc) == "rccl");
 		if (use_mailbox && w > 1) {
@@ -335,12 +383,60 @@ struct RcclTransport : Transport {
 		if (use_mailbox) mailbox = std::make_unique<HostMailbox>(token, r, w);
 	}
 	~RcclTransport() override {
+		for (auto &ps : peer_stage) if (ps.host) munmap(ps.host, ps.bytes);
+		if (my_stage.host) { char path[128]; stage_path(path, sizeof(path), token, rank, my_stage.gen); munmap(my_stage.host, my_stage.bytes); shm_unlink(path); }
 		for (auto &s : shm) if (s.host) { (void)hipHostUnregister(s.host); munmap(s.host, s.bytes); }
 		if (comm) (void)RcclApi::get().CommDestroy(comm);
 	}
-	const char *name() const override { return "rccl"; }
+	const char *name() const override { return shm_plane ? "shm" : "rccl"; }
+	// the shm data plane's all-to-all(v): [header: my send counts][array 0, all destinations][array 1 ...] in my segment, a barrier, then
+	// every rank copies the blocks addressed to it out of its peers' segments
+	void exchange_shm(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
+	                  const uint64_t *recv_cnt, hipStream_t st) {
+		uint64_t total = 0;
+		for (int p = 0; p < world; ++p) total += send_cnt[p];
+		size_t need = size_t(world) * 8;
+		for (int a = 0; a < n_arrays; ++a) need += ((size_t(total) * elem[a] + 63) & ~size_t(63));
+		stage_prepare(need);
+		char *mine = static_cast<char *>(my_stage.host);
+		std::memcpy(mine, send_cnt, size_t(world) * 8);
+		size_t at = size_t(world) * 8;
+		HIP_CHECK(stream_wait(st));   // what is sent was produced on this stream
+		for (int a = 0; a < n_arrays; ++a) {
+			if (total) HIP_CHECK(hipMemcpy(mine + at, d_send[a], size_t(total) * elem[a], hipMemcpyDeviceToHost));
+			at += (size_t(total) * elem[a] + 63) & ~size_t(63);
+		}
+		barrier();
+		uint64_t roff = 0;
+		for (int p = 0; p < world; ++p) {
+			if (p != rank && recv_cnt[p]) {
+				const char *peer = static_cast<const char *>(peer_stage[size_t(p)].host);
+				const uint64_t *pc = reinterpret_cast<const uint64_t *>(peer);
+				uint64_t ptotal = 0, poff = 0;
+				for (int q = 0; q < world; ++q) { if (q < rank) poff += pc[q]; ptotal += pc[q]; }
+				if (pc[rank] != recv_cnt[p]) throw DeviceError("shm data plane: a peer's send count differs from the agreed one");
+				size_t pat = size_t(world) * 8;
+				for (int a = 0; a < n_arrays; ++a) {
+					HIP_CHECK(hipMemcpy(static_cast<char *>(d_recv[a]) + roff * elem[a], peer + pat + size_t(poff) * elem[a], size_t(recv_cnt[p]) * elem[a], hipMemcpyHostToDevice));
+					pat += (size_t(ptotal) * elem[a] + 63) & ~size_t(63);
+				}
+			}
+			roff += recv_cnt[p];
+		}
+		barrier();   // nobody overwrites its segment while a peer still reads it
+	}
 	void exchange(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
 	              const uint64_t *recv_cnt, hipStream_t st, uint32_t in_place = 0) override {
+		if (shm_plane) {
+			uint64_t soff = 0, roff = 0;
+			for (int p = 0; p < rank; ++p) { soff += send_cnt[p]; roff += recv_cnt[p]; }
+			for (int a = 0; a < n_arrays; ++a)
+				if (send_cnt[rank] && !(in_place >> a & 1u)) HIP_CHECK(hipMemcpyAsync(static_cast<char *>(d_recv[a]) + roff * elem[a], static_cast<const char *>(d_send[a]) + soff * elem[a],
+				                                             size_t(send_cnt[rank]) * elem[a], hipMemcpyDeviceToDevice, st));
+			exchange_shm(n_arrays, d_send, d_recv, elem, send_cnt, recv_cnt, st);
+			HIP_CHECK(stream_wait(st));
+			return;
+		}
 		const RcclApi &api = RcclApi::get();
 		// the block a shard keeps never leaves the device: a plain copy (a self send / recv pair moves it at a fifth of the rate)
 		{
@@ -365,6 +461,15 @@ struct RcclTransport : Transport {
 	}
 	void gather_host(const void *mine, size_t bytes, void *all) override {
 		if (mailbox && mailbox->fits(bytes)) { mailbox->gather(mine, bytes, all); return; }
+		if (shm_plane) {   // no communicator: a payload beyond a slot goes through the mailbox slot by slot
+			std::vector<unsigned char> part(HostMailbox::SLOT * size_t(world));
+			for (size_t at = 0; at < bytes; at += HostMailbox::SLOT) {
+				const size_t n = std::min(HostMailbox::SLOT, bytes - at);
+				mailbox->gather(static_cast<const char *>(mine) + at, n, part.data());
+				for (int p = 0; p < world; ++p) std::memcpy(static_cast<char *>(all) + size_t(p) * bytes + at, part.data() + size_t(p) * n, n);
+			}
+			return;
+		}
 		const RcclApi &api = RcclApi::get();
 		const size_t b = std::max<size_t>(bytes, 1);
 		stage_in.ensure(b); stage_out.ensure(b * size_t(world)); h_in.ensure(b); h_out.ensure(b * size_t(world));
@@ -376,6 +481,19 @@ struct RcclTransport : Transport {
 		for (int p = 0; p < world; ++p) std::memcpy(static_cast<char *>(all) + size_t(p) * bytes, h_out.p + size_t(p) * b, bytes);
 	}
 	void gather_dev(const void *d_mine, void *d_all, const size_t *off, const size_t *bytes, hipStream_t st) override {
+		if (shm_plane) {
+			stage_prepare(bytes[rank] + 64);
+			HIP_CHECK(stream_wait(st));
+			if (bytes[rank]) HIP_CHECK(hipMemcpy(my_stage.host, d_mine, bytes[rank], hipMemcpyDeviceToHost));
+			barrier();
+			for (int p = 0; p < world; ++p) {
+				if (!bytes[p]) continue;
+				if (p == rank) HIP_CHECK(hipMemcpy(static_cast<char *>(d_all) + off[p], d_mine, bytes[p], hipMemcpyDeviceToDevice));
+				else HIP_CHECK(hipMemcpy(static_cast<char *>(d_all) + off[p], peer_stage[size_t(p)].host, bytes[p], hipMemcpyHostToDevice));
+			}
+			barrier();
+			return;
+		}
 		const RcclApi &api = RcclApi::get();
 		api.check(api.GroupStart(), "ncclGroupStart");
 		for (int p = 0; p < world; ++p) {
