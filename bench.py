@@ -507,8 +507,13 @@ def main():
                 os.dup2(keep, 1)
                 os.close(keep)
                 rccl_came_up = True
+            plain_bytes = (line["config"].get("matrix_forms") or {}).get("bytes_ms_per_step")
             line["secondary"]["c2_sharded_runner"] = dict({k: sh[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "step_ms", "exchange")},
                                                           x_plain=round(sh["ms_per_step"] / line["ms_per_step"], 3),
+                                                          x_plain_same_end_point=None if not plain_bytes else round(sh["ms_per_step"] / plain_bytes, 3),
+                                                          end_point="the sharded step ends with the byte form in the node-shared host buffer (every shard writes its columns over its own "
+                                                                    "PCIe link); the plain step of the headline ends with the 32-bit slots -- x_plain_same_end_point divides by the plain step "
+                                                                    "that also ends at the byte form (config.matrix_forms.bytes_ms_per_step, 3 steps)",
                                                           parallelism=sh["config"]["parallelism"], matrix_form=sh["config"]["matrix_form"],
                                                           phases_ms_per_step={k: v for k, v in sh["host_stage_wall_ms_per_step"].items() if k.startswith("shard:")})
         except Exception as e:

@@ -807,7 +807,14 @@ struct dropest_shard {
 	void assemble_raw_device();
 	struct SharedLayout { char *host; void *dev; size_t base, off_val, off_seg, seg_bytes; dropest::u32 list_cap; bool bytes, narrow; };
 	SharedLayout open_shared(Mat &M, int slot, size_t head_bytes);
-	void place_columns(Mat &M, int slot, bool filtered_m, const SharedLayout &L, const unsigned long long *d_descr, dropest::u32 nc, uint64_t local_nnz);
+	void place_columns(Mat &M, int slot, bool filtered_m, const SharedLayout &L, const unsigned long long *d_descr, dropest::u32 nc, uint64_t local_nnz, hipStream_t st = nullptr);
+	// cm_raw's columns leave on a stream of their own, under the host collectives and the assembly of cm (the plain context's prefetch,
+	// for shards): the placing kernel is the longest piece of the end of a pass and needs nothing of what follows it
+	hipStream_t place_stream = nullptr;
+	hipEvent_t ev_place = nullptr;
+	~dropest_shard() { if (place_stream) { (void)dropest::stream_wait(place_stream); (void)hipStreamDestroy(place_stream); } if (ev_place) (void)hipEventDestroy(ev_place); }
+	dropest::DevBuf<u64> d_desc_raw, d_ord_out64;
+	dropest::DevBuf<u32> d_ord_pos, d_ord_out;
 	dropest::DevBuf<u64> d_plan_mine, d_plan_all;
 	dropest::DevBuf<u32> d_q, d_q_in, d_q_ans, d_q_back, d_col_cell;
 	dropest::DevBuf<u32> d_ovf;
@@ -887,8 +894,8 @@ std::vector<dropest::u64> dropest_shard::global_ordinals(const std::vector<u32> 
 		for (const Query &q : all) if (int(q.src) == rank) { pos.push_back(u32(send_off[q.dst] + q.q)); my_ans.push_back(Answer{q.dst, q.tag, 0, 0}); }
 		if (!pos.empty()) {
 			const u32 n = u32(pos.size());
-			DevBuf<u32> d_pos, d_out;
-			d_pos.alloc(n); d_out.alloc(n);
+			DevBuf<u32> &d_pos = d_ord_pos, &d_out = d_ord_out;   // kept: a hipFree synchronises the whole device -- cm_raw's columns are on their way on another stream
+			d_pos.ensure(n); d_out.ensure(n);
 			HIP_CHECK(hipMemcpyAsync(d_pos.p, pos.data(), size_t(n) * 4, hipMemcpyHostToDevice, c.stream));
 			hipLaunchKernelGGL(take_u32_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, p_idx.p, d_pos.p, n, d_out.p);
 			HIP_CHECK(hipGetLastError());
@@ -907,8 +914,8 @@ std::vector<dropest::u64> dropest_shard::global_ordinals(const std::vector<u32> 
 	if (local_pos.empty()) return out;
 	const OrdinalMap m = ordinal_map();
 	const u32 n = u32(local_pos.size());
-	DevBuf<u32> d_pos; DevBuf<u64> d_out;
-	d_pos.alloc(n); d_out.alloc(n);
+	DevBuf<u32> &d_pos = d_ord_pos; DevBuf<u64> &d_out = d_ord_out64;
+	d_pos.ensure(n); d_out.ensure(n);
 	HIP_CHECK(hipMemcpyAsync(d_pos.p, local_pos.data(), size_t(n) * 4, hipMemcpyHostToDevice, c.stream));
 	hipLaunchKernelGGL(ordinals_kernel, dim3((n + 255) / 256), dim3(256), 0, c.stream, m, d_pos.p, n, d_out.p);
 	HIP_CHECK(hipGetLastError());
@@ -1461,9 +1468,10 @@ dropest_shard::SharedLayout dropest_shard::open_shared(Mat &M, int slot, size_t 
 
 // this shard's columns (emitted into c.mat[slot] on the device; d_descr: local offset, global offset, length of each) -> their global
 // places in the shared buffer, in the form open_shared chose
-void dropest_shard::place_columns(Mat &M, int slot, bool filtered_m, const SharedLayout &L, const unsigned long long *d_descr, dropest::u32 nc, uint64_t local_nnz) {
+void dropest_shard::place_columns(Mat &M, int slot, bool filtered_m, const SharedLayout &L, const unsigned long long *d_descr, dropest::u32 nc, uint64_t local_nnz, hipStream_t st) {
 	using namespace dropest;
 	dropest_ctx &c = *ctx;
+	if (!st) st = c.stream;
 	char *d_payload = static_cast<char *>(L.dev) + L.base;
 	const dropest_ctx::MatrixResult &R = c.mat[slot];
 	const bool work = nc && local_nnz;
@@ -1471,17 +1479,19 @@ void dropest_shard::place_columns(Mat &M, int slot, bool filtered_m, const Share
 		u32 *seg_words = reinterpret_cast<u32 *>(d_payload + L.off_seg + L.seg_bytes * size_t(rank));
 		d_list_count.ensure(8);
 		u32 *cnt = d_list_count.p + 4 * slot;
-		HIP_CHECK(hipMemsetAsync(cnt, 0, 16, c.stream));
+		HIP_CHECK(hipMemsetAsync(cnt, 0, 16, st));
 		if (work) {
 			u32 *lists = seg_words + 4;
 			const size_t cap = L.list_cap;
-			c.timed(filtered_m ? "place_columns:cm" : "place_columns:cm_raw", double(local_nnz) * 10, [&] {
-				hipLaunchKernelGGL(place_columns_bytes_kernel, dim3(nc), dim3(256), 0, c.stream, d_descr, R.d_row.p, R.d_val.p,
+			auto launch = [&] {
+				hipLaunchKernelGGL(place_columns_bytes_kernel, dim3(nc), dim3(256), 0, st, d_descr, R.d_row.p, R.d_val.p,
 				                   reinterpret_cast<uint8_t *>(d_payload), reinterpret_cast<uint8_t *>(d_payload) + L.off_val, cnt,
 				                   lists, lists + cap, lists + 2 * cap, lists + 3 * cap, L.list_cap);
-			});
+			};
+			if (st == c.stream) c.timed(filtered_m ? "place_columns:cm" : "place_columns:cm_raw", double(local_nnz) * 10, launch);
+			else launch();   // (the context's launch timer brackets its own stream)
 		}
-		hipLaunchKernelGGL(copy_words_kernel, dim3(1), dim3(64), 0, c.stream, cnt, seg_words, 4u);   // the counts, behind the lists on the stream
+		hipLaunchKernelGGL(copy_words_kernel, dim3(1), dim3(64), 0, st, cnt, seg_words, 4u);   // the counts, behind the lists on the stream
 		HIP_CHECK(hipGetLastError());
 		return;
 	}
@@ -1633,18 +1643,26 @@ void dropest_shard::assemble_raw_device() {
 	}
 	d_plan_all.ensure(total);
 	tr->gather_dev(d_plan_mine.p, d_plan_all.p, off.data(), bytes.data(), c.stream);
-	d_desc.ensure(std::max<size_t>(3 * size_t(nl), 1));
+	d_desc_raw.ensure(std::max<size_t>(3 * size_t(nl), 1));
 	if (nl) {
 		char *d_head = static_cast<char *>(L.dev);
 		hipLaunchKernelGGL(plan_raw_columns_kernel, dim3((nl + 255) / 256), dim3(256), 0, c.stream, pt, reinterpret_cast<const unsigned long long *>(d_plan_all.p),
-		                   d_col_cell.p, reinterpret_cast<const unsigned long long *>(c.cell_cb.p), nl, reinterpret_cast<unsigned long long *>(d_desc.p),
+		                   d_col_cell.p, reinterpret_cast<const unsigned long long *>(c.cell_cb.p), nl, reinterpret_cast<unsigned long long *>(d_desc_raw.p),
 		                   reinterpret_cast<unsigned long long *>(d_head), reinterpret_cast<uint32_t *>(d_head + off_c32),
 		                   reinterpret_cast<unsigned long long *>(d_head + off_bc));
 		HIP_CHECK(hipGetLastError());
 	}
 	const uint64_t local_nnz = P.pre.back();
 	if (nl && local_nnz) c.emit_columns_device(false, false, P.col_cell, P.col_start, local_nnz);
-	place_columns(M, 1, false, L, reinterpret_cast<const unsigned long long *>(d_desc.p), nl, local_nnz);
+	// the placing kernel on its own stream (byte form: nothing on the host waits for it before the end of the step)
+	hipStream_t st = c.stream;
+	if (L.bytes && !getenv("DROPEST_SHARD_NO_PLACE_STREAM")) {
+		if (!place_stream) { HIP_CHECK(hipStreamCreateWithFlags(&place_stream, hipStreamNonBlocking)); HIP_CHECK(hipEventCreateWithFlags(&ev_place, hipEventDisableTiming)); }
+		HIP_CHECK(hipEventRecord(ev_place, c.stream));
+		HIP_CHECK(hipStreamWaitEvent(place_stream, ev_place, 0));
+		st = place_stream;
+	}
+	place_columns(M, 1, false, L, reinterpret_cast<const unsigned long long *>(d_desc_raw.p), nl, local_nnz, st);
 }
 
 void dropest_shard::step() {
@@ -1713,10 +1731,15 @@ void dropest_shard::step() {
 	{ Phase ph(this, "finalize"); c.run_merge_and_filter(); }
 	merged_pending = world == 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE;   // one shard: the context's own pairs, named when asked for
 	raw_device_now = plan_raw();
+	// cm_raw first when it is planned on the device: its columns are on their way to the host (own stream) while the filtered
+	// candidates are gathered and ordered and cm is assembled -- every shard issues its collectives in this same order.  (Measured at
+	// C2 through one shard: 12.2 ms with everything on one stream, 11.75 this way, 11.9 with the table before cm_raw -- cm's emit then
+	// shares the CUs with the placing kernel.)
+	if (raw_device_now) assemble_raw_device();
 	build_global_table();
 	assemble_matrix(true);
-	if (raw_device_now) assemble_raw_device(); else assemble_matrix(false);
-	{ Phase ph(this, "matrix:wait"); HIP_CHECK(stream_wait(c.stream)); tr->barrier(); }
+	if (!raw_device_now) assemble_matrix(false);
+	{ Phase ph(this, "matrix:wait"); HIP_CHECK(stream_wait(c.stream)); if (place_stream) HIP_CHECK(stream_wait(place_stream)); tr->barrier(); }
 	if (byte_matrix) { Phase ph(this, "matrix:lists"); collect_lists(mat[0]); collect_lists(mat[1]); }
 	c.collect_timings();
 }

@@ -1,3 +1,11 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-for i in 1 2 3; do timeout 900 python -m pytest tests/test_gpu_multiproc.py tests/test_gpu_multi.py tests/test_gpu_wire.py tests/test_gpu_narrow.py -x -q -k "not c4_at" 2>&1 | tail -3; echo "rc $?"; done
+timeout 900 python -m pytest tests/test_gpu_multiproc.py tests/test_gpu_multi.py -x -q -k "not c4_at" > gpurun_out/mp_tests.log 2>&1; echo "tests rc $?"; grep -E "passed|failed|error" gpurun_out/mp_tests.log | tail -3
+B="python bench.py --no-secondary --steps 20 --warmup 3 --cpu-sample 0 --push-sample 0"
+export DROPEST_BENCH_NO_FORMS=1
+for i in 1 2; do
+$B --sharded 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=sorted(d['step_ms']); h=d['host_stage_wall_ms_per_step']; print('sharded', d['ms_per_step'], s[10], {k:v for k,v in h.items() if k.startswith('shard:') and v>0.1})"
+DROPEST_SHARD_NO_PLACE_STREAM=1 $B --sharded 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=sorted(d['step_ms']); print('sharded same stream', d['ms_per_step'], s[10])"
+done
+DROPEST_BENCH_MATRIX_FORM=bytes $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=sorted(d['step_ms']); print('plain bytes', d['ms_per_step'], s[10])"
+$B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=sorted(d['step_ms']); print('plain u32', d['ms_per_step'], s[10])"
