@@ -1141,12 +1141,13 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 	auto passes = [&](const HostCell &h) {
 		return !(h.merged || h.excluded || h.row.n_genes < min_before) && h.row.requested_genes >= genes_threshold;
 	};
-	// (Up to a few 10^5 cells the host orders them in a millisecond or two; the device path's read-back crosses PCIe behind cm_raw's
-	// prefetch -- 10 ms of waiting for 200 KB at C3 size -- so it starts where the host sort would cost more than that.)
-	size_t device_min = 2000000;
+	// (Up to 2e5 cells the host orders them in a millisecond or two -- the 5e4 filtered cells of C3 AFTER the merge, whose device
+	// read-back would cross PCIe behind cm_raw's prefetch: 10 ms of waiting for 200 KB.  The 2.4e6 candidates BEFORE the merge take the
+	// device path: 3 ms against 60 on the host, and nothing else is on the link then.)
+	size_t device_min = 200000;
 	if (const char *e = getenv("DROPEST_DEVICE_SORT_MIN")) device_min = size_t(std::max(1, atoi(e)));   // tests force the device path
 
-	// Very large lists (millions of filtered cells) are ordered on the device: three stable LSD radix sorts
+	// Large lists (10^5..10^6 cells at BASELINE sizes) are ordered on the device: three stable LSD radix sorts
 	// (barcode, then TOTAL_UMIS, then the packed sizes) when every barcode is a clean code of one length, so that
 	// the numeric order of the codes IS the string order.  The key is total, so any correct sort gives the same list.
 	// The host side of it (two passes over `real`, one over the result) runs on a few worker threads.
