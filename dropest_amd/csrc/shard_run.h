@@ -225,7 +225,8 @@ struct LocalTransport : Transport {
 // fails the collective instead of hanging.
 struct HostMailbox {
 	static constexpr size_t SLOT = size_t(1) << 20;
-	static constexpr unsigned TIMEOUT_S = 300;
+	// seconds a rank waits for the others (attach, barrier) before it fails the collective for everybody; DROPEST_MAILBOX_TIMEOUT_S (tests)
+	static unsigned timeout_s() { static const unsigned t = [] { const char *e = getenv("DROPEST_MAILBOX_TIMEOUT_S"); return e ? unsigned(std::max(1, atoi(e))) : 300u; }(); return t; }
 	struct Header { std::atomic<uint32_t> attached, arrived, generation, failed; std::atomic<uint64_t> magic; };
 	static uint64_t magic_of(uint64_t token) { return mix64(token ^ 0x6d61696c626f7821ull) | 1ull; }   // never 0: a fresh object reads as zeros
 	int rank = 0, world = 1;
@@ -248,7 +249,7 @@ struct HostMailbox {
 			for (;;) {   // rank 0 may not be there yet; a file that exists but is not sized yet is not ready either
 				fd = shm_open(path, O_RDWR, 0600);
 				if (fd >= 0) { struct stat st; if (fstat(fd, &st) == 0 && size_t(st.st_size) >= bytes) break; close(fd); fd = -1; }
-				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(TIMEOUT_S)) throw DeviceError("host mailbox: rank 0 did not create it");
+				if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s())) throw DeviceError("host mailbox: rank 0 did not create it");
 				usleep(200);
 			}
 		}
@@ -272,7 +273,7 @@ struct HostMailbox {
 			if (heed_failed && hdr()->failed.load(std::memory_order_acquire)) throw DeviceError("another shard of the run failed");
 			if (spins < 2000) { dropest::host_cpu_relax(); continue; }
 			sched_yield();
-			if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(TIMEOUT_S)) {
+			if ((spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s())) {
 				hdr()->failed.store(1, std::memory_order_release);
 				throw DeviceError(std::string("host mailbox: a shard did not arrive (") + what + ")");
 			}
