@@ -1,5 +1,6 @@
-"""Differential soak at sizes the oracle does not reach: the round-2 fast paths of one context (barcode table sized from a sample, LDS
-table of hot barcodes, key layout planned from a sample, splitter sort with the one-atomic ranking) against the conservative paths
+"""Differential soak at sizes the oracle does not reach: the fast paths of one context (barcode table sized from a sample, LDS
+table of hot barcodes, key layout planned from a sample, splitter sort with partitions by reservation and the one-atomic ranking,
+matrices over PCIe as bytes widened on host threads) against the conservative paths
 of the same library (exact ingest statistics in cb_insert, no hot list, LSD sort) on random large streams: every observable equal."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +20,7 @@ def run(dev, side, kw, env):
     c = capi.Context(**kw)
     if side:
         c.set_side_strings(side)
+    c.set_matrix_wire(not env)          # round 4: the conservative side copies the 32-bit matrices as they are; the fast side sends bytes and widens on host threads
     c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
     c.set_initialized(); c.merge_and_filter()
     rows = c.cell_rows()
