@@ -330,6 +330,17 @@ struct dropest_ctx {
 	const u64 *d_cb = nullptr, *d_umi = nullptr;
 	const u32 *d_gene = nullptr, *d_aux = nullptr;
 	std::vector<std::string> side;
+	// Reads that came out of a sharded run's exchange as 12-byte records (k_cbhash.h: ReadPack): d_cb and d_umi both point at w0, d_gene
+	// at w1.  The hot kernels (cb_sample, cb_insert, the sampled statistics, build_keys) read the records as they are; everything else
+	// calls need_columns() first, which has the owner restore the four columns.
+	dropest::ReadPack rpack{};
+	std::function<void()> unpack_reads;
+	void need_columns() {
+		if (!rpack.on()) return;
+		if (!unpack_reads) throw dropest::InvalidError("internal: packed reads without an unpacker");
+		unpack_reads();
+		rpack = dropest::ReadPack{};
+	}
 
 	bool initialized = false, merged = false;
 	dropest::GlibcRand rng;          // the container's own rand() sequence (random fills of N-UMIs)

@@ -249,7 +249,7 @@ void dropest_ctx::build_cb_table() {
 		HIP_CHECK(hipMemsetAsync(t_slots.p, 0, cap_s * sizeof(CbSlot), stream));
 		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4, stream));
 		timed("cb_sample", double(n_s) * 8, [&] {
-			hipLaunchKernelGGL(cb_sample_distinct_kernel, dim3(std::min<u32>(div_up(n_s, 256), 2048u)), dim3(256), 0, stream, d_cb, n, stride, ts, scalars.p);
+			hipLaunchKernelGGL(cb_sample_distinct_kernel, dim3(std::min<u32>(div_up(n_s, 256), 2048u)), dim3(256), 0, stream, d_cb, n, stride, ts, scalars.p, rpack);
 		});
 		// ... and how many of the sampled barcodes reach 4, 16, ... sample hits: the hot list is the largest such set of at
 		// most CB_HOT_MAX barcodes (C2: the 5 000 real cells carry 92 % of the reads)
@@ -298,7 +298,7 @@ void dropest_ctx::build_cb_table() {
 		if (n >= (1u << 20) || lazy_stats) {   // the popular genes' entries are set before the big pass starts (k_cbhash.h)
 			const u32 stride = 2048, n_s = div_up(n, stride);
 			timed("gene_chr_seed", double(n_s) * 8, [&] {
-				hipLaunchKernelGGL(gene_chr_seed_kernel, dim3(std::min<u32>(div_up(n_s, 256), 64u)), dim3(256), 0, stream, d_gene, d_aux, n, stride, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
+				hipLaunchKernelGGL(gene_chr_seed_kernel, dim3(std::min<u32>(div_up(n_s, 256), 64u)), dim3(256), 0, stream, d_gene, d_aux, n, stride, gene_chr.p, GENE_CHR_CAP, d_ingest.p, rpack);
 			});
 		}
 		const bool vec = ((uintptr_t(d_cb) | uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;   // adopted arrays may sit anywhere
@@ -306,7 +306,7 @@ void dropest_ctx::build_cb_table() {
 		const u32 blocks = std::min<u32>(div_up(n, 256 * 4), vec ? grid_v : grid_s);
 		if (lazy_stats)   // the plan's statistics: every 256th read (the exact ones come with build_keys)
 			timed("ingest_sample_stats", double(div_up(n, 256u)) * 16, [&] {
-				hipLaunchKernelGGL(ingest_sample_stats_kernel, dim3(std::min<u32>(div_up(div_up(n, 256u), 256), 1024u)), dim3(256), 0, stream, d_umi, d_gene, d_aux, n, 256u, d_ingest.p);
+				hipLaunchKernelGGL(ingest_sample_stats_kernel, dim3(std::min<u32>(div_up(div_up(n, 256u), 256), 1024u)), dim3(256), 0, stream, d_umi, d_gene, d_aux, n, 256u, d_ingest.p, rpack);
 			});
 		if (n_hot && attempt == 0 && cap < (1ull << 31)) {
 			// the hot list needs 128 KB of dynamic LDS in one workgroup: a device (or partition mode) that does not grant it takes the
@@ -330,7 +330,7 @@ void dropest_ctx::build_cb_table() {
 			timed("cb_insert", double(n) * (lazy_stats ? 8 + 4 : 8 + 8 + 4 + 4 + 4), [&] {
 				auto go = [&](auto kernel) {
 					HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-					hipLaunchKernelGGL(kernel, dim3(hb), dim3(1024), lds, stream, d_cb, d_umi, d_gene, d_aux, n, table, hot, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p);
+					hipLaunchKernelGGL(kernel, dim3(hb), dim3(1024), lds, stream, d_cb, d_umi, d_gene, d_aux, n, table, hot, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p, rpack);
 				};
 				if (lazy_stats) { if (vec) go(cb_insert_hot_kernel<true, false>); else go(cb_insert_hot_kernel<false, false>); }
 				else if (vec) go(cb_insert_hot_kernel<true>); else go(cb_insert_hot_kernel<false>);
@@ -355,7 +355,7 @@ void dropest_ctx::build_cb_table() {
 		} else {
 		n_hot = 0;   // (a rebuilt table: the slots of the first attempt are gone)
 		timed("cb_insert", double(n) * (lazy_stats ? 8 + 4 : 8 + 8 + 4 + 4 + 4), [&] {
-			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p); };
+			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p, rpack); };
 			if (lazy_stats) { if (vec) go(cb_insert_kernel<256, true, false>); else go(cb_insert_kernel<256, false, false>); }
 			else if (vec) go(cb_insert_kernel<256, true>); else go(cb_insert_kernel<256, false>);
 		});
@@ -520,7 +520,7 @@ void dropest_ctx::build_keys(bool with_stats) {
 			HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds));
 			const u32 blocks = std::max<u32>(1u, std::min<u32>(div_up(n, 256 * 4), u32(std::max(1, cus) * std::max(1, std::min(per_cu, 4)))));
 			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p, hot,
-			                   gene_chr.p, GENE_CHR_CAP, d_ingest.p, lds);
+			                   gene_chr.p, GENE_CHR_CAP, d_ingest.p, lds, rpack);
 		};
 		auto pick = [&](auto vb) {
 			constexpr int VB = decltype(vb)::value;
@@ -2675,6 +2675,7 @@ dropest_status dropest_umi_first_seen(dropest_ctx *ctx, uint64_t *n_out, uint64_
 				HIP_CHECK(hipMemsetAsync(slots.p, 0, cap * sizeof(CbSlot), c.stream));
 				c.scalars.ensure(16);
 				HIP_CHECK(hipMemsetAsync(c.scalars.p, 0, 8, c.stream));
+				c.need_columns();
 				hipLaunchKernelGGL(umi_insert_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, c.stream, c.d_umi, c.d_gene, n, t, c.scalars.p + 1);
 				c.keys_a.ensure(std::max<size_t>(n, 1)); c.keys_b.ensure(std::max<size_t>(n, 1)); c.vals_a.ensure(1); c.vals_b.ensure(1);
 				hipLaunchKernelGGL(cb_compact_slots_kernel, dim3(u32(std::min<uint64_t>((cap + 4095) / 4096, 4096))), dim3(256), 0, c.stream, t, c.keys_a.p, c.scalars.p);
@@ -2875,6 +2876,7 @@ dropest_status dropest_resident_reads(dropest_ctx *ctx, const uint64_t **d_cb, c
 		*n = ctx->n_reads;
 		*d_cb = *d_umi = nullptr; *d_gene = *d_aux = nullptr;
 		if (ctx->n_reads == 0) return;
+		ctx->need_columns();
 		if (ctx->d_cb) { *d_cb = reinterpret_cast<const uint64_t *>(ctx->d_cb); *d_umi = reinterpret_cast<const uint64_t *>(ctx->d_umi); *d_gene = ctx->d_gene; *d_aux = ctx->d_aux; return; }
 		if (ctx->chunks.size() != 1 || ctx->store_chunk != 0) throw UnsupportedError("the reads are not one pushed block (device chunks were adopted in between)");
 		ctx->store.wait();

@@ -42,6 +42,19 @@ struct IngestStats {
 
 constexpr uint32_t GENE_CHR_UNSET = 0xFFFFFFFFu;
 
+// Reads as they come out of a sharded run's exchange (k_misc.h: ExchangePack): w0 = barcode | UMI << cb_bits, w1 = gene | mark <<
+// gene_bits | chromosome << (gene_bits + 3).  The kernels of the hot path read such records as they are (the `cb` / `umi` arguments
+// both point at w0, `gene` at w1, `aux` is not read): unpacking them into four columns first was a pass of 36 bytes per read.
+// cb_bits < 0: plain columns.
+struct ReadPack {
+	int cb_bits = -1, gene_bits = 0;
+	__host__ __device__ bool on() const { return cb_bits >= 0; }
+	__device__ unsigned long long cb(unsigned long long w0) const { return cb_bits >= 64 || cb_bits < 0 ? w0 : (w0 & ((1ull << cb_bits) - 1ull)); }
+	__device__ unsigned long long umi(unsigned long long w0) const { return cb_bits >= 64 ? 0ull : (w0 >> cb_bits); }
+	__device__ uint32_t gene(uint32_t w1) const { const uint32_t gm = (1u << gene_bits) - 1u, g = w1 & gm; return g == gm ? 0xFFFFFFFFu : g; }
+	__device__ uint32_t aux(uint32_t w1) const { return (w1 >> (gene_bits + 3)) | (((w1 >> gene_bits) & 7u) << 16); }
+};
+
 constexpr uint32_t CB_MAX_PROBE = 8192;
 constexpr uint64_t ESCAPE_BIT = 0x8000000000000000ull;
 constexpr uint32_t NO_GENE = 0xFFFFFFFFu;
@@ -152,10 +165,13 @@ struct IngestAcc {
 
 // The statistics of every `stride`-th read: what the key layout is planned from when the exact ones are gathered by the key pass.
 __global__ __launch_bounds__(256) void ingest_sample_stats_kernel(const unsigned long long *__restrict__ umi, const uint32_t *__restrict__ gene,
-                                                                  const uint32_t *__restrict__ aux, uint32_t n, uint32_t stride, IngestStats *stats) {
+                                                                  const uint32_t *__restrict__ aux, uint32_t n, uint32_t stride, IngestStats *stats,
+                                                                  ReadPack pk = ReadPack{}) {
 	IngestAcc acc;
-	for (uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x; j * stride < n; j += uint64_t(gridDim.x) * 256)
-		acc.add(umi[j * stride], gene[j * stride], aux[j * stride]);
+	for (uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x; j * stride < n; j += uint64_t(gridDim.x) * 256) {
+		if (pk.on()) { const uint32_t w1 = gene[j * stride]; acc.add(pk.umi(umi[j * stride]), pk.gene(w1), pk.aux(w1)); }
+		else acc.add(umi[j * stride], gene[j * stride], aux[j * stride]);
+	}
 	// the four waves of a workgroup meet in LDS first: one set of atomics per workgroup on the six shared words
 	__shared__ unsigned long long w_min[4], w_max[4], w_esc[4];
 	__shared__ uint32_t w_g[4], w_c[4];
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
                                                             const uint32_t *__restrict__ gene,
                                                             const uint32_t *__restrict__ aux, uint32_t n, CbTable t,
                                                             uint32_t *__restrict__ slot_out, uint32_t *__restrict__ gene_chr,
-                                                            uint32_t gene_chr_cap, IngestStats *stats) {
+                                                            uint32_t gene_chr_cap, IngestStats *stats, ReadPack pk = ReadPack{}) {
 	constexpr int ILP = 4;
 	unsigned long long umin = ~0ull, umax = 0ull, uesc = 0ull, cbesc = 0ull;
 	uint32_t gmax = 0, cmax = 0;
@@ -208,13 +224,22 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 #pragma unroll
 			for (int j = 0; j < ILP; ++j) k[j] = r0 + j < n ? cb[r0 + j] : 0ull;
 		}
+		unsigned long long kraw[ILP];   // (packed records: the UMI sits above the barcode in the same word)
+#pragma unroll
+		for (int j = 0; j < ILP; ++j) { kraw[j] = k[j]; k[j] = pk.cb(k[j]); }
 #pragma unroll
 		for (int j = 0; j < ILP; ++j) {
 			h[j] = mix64(k[j]) & t.mask;
 			v[j] = *reinterpret_cast<const uint4 *>(&t.slots[h[j]]);   // key + ~first in one access
 		}
 		if (STATS) {
-			if (VEC && full) {
+			if (pk.on()) {
+#pragma unroll
+				for (int j = 0; j < ILP; ++j) {
+					const uint32_t w1 = r0 + j < n ? gene[r0 + j] : 0xFFFFFFFFu;
+					u[j] = pk.umi(kraw[j]); g[j] = r0 + j < n ? pk.gene(w1) : NO_GENE; a[j] = r0 + j < n ? pk.aux(w1) : 0u;
+				}
+			} else if (VEC && full) {
 				const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + r0), u23 = *reinterpret_cast<const ulonglong2 *>(umi + r0 + 2);
 				const uint4 g4 = *reinterpret_cast<const uint4 *>(gene + r0), a4 = *reinterpret_cast<const uint4 *>(aux + r0);
 				u[0] = u01.x; u[1] = u01.y; u[2] = u23.x; u[3] = u23.y;
@@ -302,10 +327,11 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 // starts cold, the first tiles of all waves do that for the popular genes at once -- tens of thousands of atomics on one
 // address.  A few thousand reads ahead of it set the entries of all genes that matter for that.
 __global__ __launch_bounds__(256) void gene_chr_seed_kernel(const uint32_t *__restrict__ gene, const uint32_t *__restrict__ aux, uint32_t n, uint32_t stride,
-                                                            uint32_t *__restrict__ gene_chr, uint32_t gene_chr_cap, IngestStats *stats) {
+                                                            uint32_t *__restrict__ gene_chr, uint32_t gene_chr_cap, IngestStats *stats, ReadPack pk = ReadPack{}) {
 	bool conflict = false;
 	for (uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x; j * stride < n; j += uint64_t(gridDim.x) * 256) {
-		const uint32_t g = gene[j * stride], a = aux[j * stride];
+		const uint32_t w = gene[j * stride];
+		const uint32_t g = pk.on() ? pk.gene(w) : w, a = pk.on() ? pk.aux(w) : aux[j * stride];
 		if (g == NO_GENE || !((a >> 16) & 6u)) continue;
 		if (g >= gene_chr_cap) { conflict = true; continue; }
 		const uint32_t chr = a & 0xFFFFu;
@@ -321,10 +347,10 @@ __global__ __launch_bounds__(256) void gene_chr_seed_kernel(const uint32_t *__re
 // rare barcode a certain HBM miss, 1 GB to clear and 1 GB to scan for the occupied slots; sized from the sample it is
 // 128 MB and lives in the 256 MB Infinity Cache.
 __global__ __launch_bounds__(256) void cb_sample_distinct_kernel(const unsigned long long *__restrict__ cb, uint32_t n, uint32_t stride,
-                                                                 CbTable t, uint32_t *__restrict__ distinct) {
+                                                                 CbTable t, uint32_t *__restrict__ distinct, ReadPack pk = ReadPack{}) {
 	uint32_t mine = 0;
 	for (uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x; j * stride < n; j += uint64_t(gridDim.x) * 256) {
-		const unsigned long long k = cb[j * stride];
+		const unsigned long long k = pk.cb(cb[j * stride]);
 		uint64_t h = mix64(k) & t.mask;
 		bool found = false;
 		for (uint32_t probe = 0; probe < CB_MAX_PROBE && !found; ++probe) {
@@ -409,7 +435,7 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
                                                              const uint32_t *__restrict__ gene,
                                                              const uint32_t *__restrict__ aux, uint32_t n, CbTable t, CbHot hot,
                                                              uint32_t *__restrict__ slot_out, uint32_t *__restrict__ gene_chr,
-                                                             uint32_t gene_chr_cap, IngestStats *stats) {
+                                                             uint32_t gene_chr_cap, IngestStats *stats, ReadPack pk = ReadPack{}) {
 	constexpr int ILP = 4, THREADS = 1024;
 	extern __shared__ __attribute__((aligned(16))) unsigned char cb_smem[];
 	unsigned long long *lk = reinterpret_cast<unsigned long long *>(cb_smem);          // [CB_HOT_LDS] key, 0 = empty
@@ -452,10 +478,17 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 		uint64_t h[ILP];
 		uint32_t g[ILP], a[ILP], sl[ILP], hit[ILP];
 		const bool full = r0 + ILP <= n;
+		unsigned long long kraw[ILP];   // (packed records: the UMI sits above the barcode in the same word)
 #pragma unroll
-		for (int j = 0; j < ILP; ++j) k[j] = k_next[j];
+		for (int j = 0; j < ILP; ++j) { kraw[j] = k_next[j]; k[j] = pk.cb(k_next[j]); }
 		if (r0 + stride < n) load_cb(r0 + stride, k_next);
-		if (VEC && full) {
+		if (STATS && pk.on()) {
+#pragma unroll
+			for (int j = 0; j < ILP; ++j) {
+				const uint32_t w1 = r0 + j < n ? gene[r0 + j] : 0xFFFFFFFFu;
+				u[j] = pk.umi(kraw[j]); g[j] = r0 + j < n ? pk.gene(w1) : NO_GENE; a[j] = r0 + j < n ? pk.aux(w1) : 0u;
+			}
+		} else if (VEC && full) {
 			if (STATS) {
 				const ulonglong2 u01 = *reinterpret_cast<const ulonglong2 *>(umi + r0), u23 = *reinterpret_cast<const ulonglong2 *>(umi + r0 + 2);
 				const uint4 g4 = *reinterpret_cast<const uint4 *>(gene + r0), a4 = *reinterpret_cast<const uint4 *>(aux + r0);

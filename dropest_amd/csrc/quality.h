@@ -166,6 +166,7 @@ void dropest_ctx::accumulate_umi_qualities() {
 	n_mol_at_init = n_mol; n_qsum_rows = n_mol;
 	if (!n_mol || !qual_len) return;
 	HostStage hs(this, "umi_qualities");
+	need_columns();   // (a sharded run's reads may still be packed records)
 	const u32 qstride = qual_stride();   // the sums padded to whole 64-bit pairs, the molecule's quality length in the last word
 	mol_qsum.ensure(size_t(n_mol) * qstride);
 	HIP_CHECK(hipMemsetAsync(mol_qsum.p, 0, size_t(n_mol) * qstride * 4, stream));

@@ -770,7 +770,9 @@ struct dropest_shard {
 	// conversion needs it on the device (-u) -- the few positions the pass asks about otherwise are resolved by asking the source
 	dropest::DevBuf<u64> p_w0, x_w0;
 	dropest::DevBuf<u32> p_w1, x_w1;
-	bool packed = false, idx_exchanged = false, allow_packed = true;
+	bool packed = false, idx_exchanged = false, allow_packed = true, unpacked = false;
+	dropest::ExchangePack exch_pack{};
+	void unpack_exchanged();
 	int rec_bytes = 28;
 	std::vector<uint64_t> send_off;                                  // first read of every destination's block in p_idx
 	// global table of the real cells (identical on every shard after a step)
@@ -976,16 +978,26 @@ void dropest_shard::partition_and_exchange() {
 		rec_bytes = packed ? (idx_exchanged ? 16 : 12) : 28;
 		send_off.assign(size_t(world) + 1, 0);
 		for (int p = 0; p < world; ++p) send_off[size_t(p) + 1] = send_off[size_t(p)] + send_cnt[size_t(p)];
+		// what this shard will receive is known from the same collective: the receive arrays exist before the scatter, which writes the
+		// block the shard keeps straight into them
+		recv_cnt.assign(size_t(world), 0); recv_off.assign(size_t(world) + 1, 0);
+		for (int p = 0; p < world; ++p) { recv_cnt[size_t(p)] = all_cnt[size_t(p) * size_t(world) + size_t(rank)]; recv_off[size_t(p) + 1] = recv_off[size_t(p)] + recv_cnt[size_t(p)]; }
+		const uint64_t n_recv0 = recv_off[size_t(world)];
+		if (n_recv0 >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads on one shard after the exchange");
 		p_idx.ensure(std::max<size_t>(n, 1));
-		if (packed) { p_w0.ensure(std::max<size_t>(n, 1)); p_w1.ensure(std::max<size_t>(n, 1)); }
+		if (packed) { p_w0.ensure(std::max<size_t>(n, 1)); p_w1.ensure(std::max<size_t>(n, 1)); x_w0.ensure(std::max<size_t>(n_recv0, 1)); x_w1.ensure(std::max<size_t>(n_recv0, 1)); }
 		else {
 			for (DevBuf<u64> *b : {&p_cb, &p_umi}) b->ensure(std::max<size_t>(n, 1));
 			for (DevBuf<u32> *b : {&p_gene, &p_aux}) b->ensure(std::max<size_t>(n, 1));
 		}
 		if (n) {
 			const int owner_bits = std::max(1, bit_length(uint64_t(world - 1)));
+			OwnerSelf self{};
+			self.owner = u32(rank);
+			self.w0 = x_w0.p + recv_off[size_t(rank)] - send_off[size_t(rank)];     // (index = position in the partition's output)
+			self.w1 = x_w1.p + recv_off[size_t(rank)] - send_off[size_t(rank)];
 			if (packed) hipLaunchKernelGGL(owner_scatter_kernel<true>, dim3(nblocks), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), owner_bits, tpb, hist, digit_base,
-			                               p_w0.p, static_cast<u64 *>(nullptr), p_w1.p, static_cast<u32 *>(nullptr), p_idx.p, pack);
+			                               p_w0.p, static_cast<u64 *>(nullptr), p_w1.p, static_cast<u32 *>(nullptr), p_idx.p, pack, self);
 			else hipLaunchKernelGGL(owner_scatter_kernel<false>, dim3(nblocks), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), owner_bits, tpb, hist, digit_base,
 			                        p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p, pack);
 			HIP_CHECK(hipGetLastError());
@@ -993,19 +1005,17 @@ void dropest_shard::partition_and_exchange() {
 	}
 	{
 		Phase ph(this, "all_to_all");
-		recv_cnt.assign(size_t(world), 0); recv_off.assign(size_t(world) + 1, 0);
-		for (int p = 0; p < world; ++p) { recv_cnt[size_t(p)] = all_cnt[size_t(p) * size_t(world) + size_t(rank)]; recv_off[size_t(p) + 1] = recv_off[size_t(p)] + recv_cnt[size_t(p)]; }
 		const uint64_t n_recv = recv_off[size_t(world)];
-		if (n_recv >= 0xFFFFFFFEull) throw UnsupportedError("more than 2^32-2 reads on one shard after the exchange");
-		for (DevBuf<u64> *b : {&x_cb, &x_umi}) b->ensure(std::max<size_t>(n_recv, 1));
-		for (DevBuf<u32> *b : {&x_gene, &x_aux}) b->ensure(std::max<size_t>(n_recv, 1));
+		if (!packed) {
+			for (DevBuf<u64> *b : {&x_cb, &x_umi}) b->ensure(std::max<size_t>(n_recv, 1));
+			for (DevBuf<u32> *b : {&x_gene, &x_aux}) b->ensure(std::max<size_t>(n_recv, 1));
+		}
 		if (idx_exchanged) x_idx.ensure(std::max<size_t>(n_recv, 1));
 		if (packed) {
-			x_w0.ensure(std::max<size_t>(n_recv, 1)); x_w1.ensure(std::max<size_t>(n_recv, 1));
 			const void *snd[3] = {p_w0.p, p_w1.p, p_idx.p};
 			void *rcv[3] = {x_w0.p, x_w1.p, x_idx.p};
 			const size_t elem[3] = {8, 4, 4};
-			tr->exchange(idx_exchanged ? 3 : 2, snd, rcv, elem, send_cnt.data(), recv_cnt.data(), c.stream, 3u);   // w0 / w1 of the own block: unpacked in place
+			tr->exchange(idx_exchanged ? 3 : 2, snd, rcv, elem, send_cnt.data(), recv_cnt.data(), c.stream, 3u);   // w0 / w1 of the own block: already in place
 		} else {
 			const void *snd[5] = {p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p};
 			void *rcv[5] = {x_cb.p, x_umi.p, x_gene.p, x_aux.p, x_idx.p};
@@ -1032,15 +1042,28 @@ void dropest_shard::partition_and_exchange() {
 			for (int p = 0; p < world; ++p) if (p != rank) out_q += send_cnt[size_t(p)];
 			st.bytes += double(out_q) * r_qlen;
 		}
-		if (packed && n_recv) {
-			Phase ph2(this, "unpack");
-			hipLaunchKernelGGL(exchange_unpack_kernel, dim3(u32(std::min<uint64_t>((n_recv + 255) / 256, 8192))), dim3(256), 0, c.stream, x_w0.p, x_w1.p, u32(n_recv), pack,
-			                   x_cb.p, x_umi.p, x_gene.p, x_aux.p, u32(recv_off[size_t(rank)]), u32(recv_off[size_t(rank) + 1]),
-			                   p_w0.p + send_off[size_t(rank)], p_w1.p + send_off[size_t(rank)]);
-			HIP_CHECK(hipGetLastError());
-		}
+		// The records stay packed: cb_sample, cb_insert, the sampled statistics and build_keys read them as they are (k_cbhash.h: ReadPack);
+		// whatever else needs the four columns (UMI first-occurrence tables, quality sums) asks the context, which calls back here.
+		// DROPEST_SHARD_UNPACK_FIRST=1: the columns at once, as before.
+		exch_pack = pack;
+		if (packed && n_recv && getenv("DROPEST_SHARD_UNPACK_FIRST")) unpack_exchanged();
 	}
 	exchanged = true;
+}
+
+// the four columns of the received reads from their packed records (x_w0 / x_w1 hold every block, the kept one included)
+void dropest_shard::unpack_exchanged() {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	const uint64_t n_recv = recv_off[size_t(world)];
+	if (!packed || !n_recv) return;
+	Phase ph2(this, "unpack");
+	for (DevBuf<u64> *b : {&x_cb, &x_umi}) b->ensure(std::max<size_t>(n_recv, 1));
+	for (DevBuf<u32> *b : {&x_gene, &x_aux}) b->ensure(std::max<size_t>(n_recv, 1));
+	hipLaunchKernelGGL(exchange_unpack_kernel, dim3(u32(std::min<uint64_t>((n_recv + 255) / 256, 8192))), dim3(256), 0, c.stream, x_w0.p, x_w1.p, u32(n_recv), exch_pack,
+	                   x_cb.p, x_umi.p, x_gene.p, x_aux.p, 0u, 0u, static_cast<const unsigned long long *>(nullptr), static_cast<const uint32_t *>(nullptr));
+	HIP_CHECK(hipGetLastError());
+	unpacked = true;
 }
 
 // 3b. all shards must lay out the gene / UMI fields of the sort key identically (molecule rows move between shards in a
@@ -1705,9 +1728,23 @@ void dropest_shard::step() {
 	exchanged = false;
 	ReadChunk ch;
 	if (world > 1 || force_exchange) {
+		unpacked = false;
+		c.rpack = dropest::ReadPack{}; c.unpack_reads = nullptr;
 		partition_and_exchange();
-		ch.p_cb = x_cb.p; ch.p_umi = x_umi.p; ch.p_gene = x_gene.p; ch.p_aux = x_aux.p; ch.n = recv_off[size_t(world)];
+		ch.n = recv_off[size_t(world)];
+		if (packed && !unpacked && ch.n) {
+			// the context reads the 12-byte records as they are; the four columns are restored only if something asks for them
+			ch.p_cb = x_w0.p; ch.p_umi = x_w0.p; ch.p_gene = x_w1.p; ch.p_aux = x_w1.p;
+			c.rpack.cb_bits = exch_pack.cb_bits; c.rpack.gene_bits = exch_pack.gene_bits;
+			c.unpack_reads = [this] {
+				dropest_ctx &cc = *ctx;
+				unpack_exchanged();
+				cc.d_cb = x_cb.p; cc.d_umi = x_umi.p; cc.d_gene = x_gene.p; cc.d_aux = x_aux.p;
+				if (!cc.chunks.empty()) { cc.chunks[0].p_cb = x_cb.p; cc.chunks[0].p_umi = x_umi.p; cc.chunks[0].p_gene = x_gene.p; cc.chunks[0].p_aux = x_aux.p; }
+			};
+		} else { ch.p_cb = x_cb.p; ch.p_umi = x_umi.p; ch.p_gene = x_gene.p; ch.p_aux = x_aux.p; }
 	} else {   // one shard: every read is at home already
+		c.rpack = dropest::ReadPack{}; c.unpack_reads = nullptr;
 		ch.p_cb = r_cb; ch.p_umi = r_umi; ch.p_gene = r_gene; ch.p_aux = r_aux; ch.n = n_res;
 	}
 	if (ch.n) { c.n_reads = ch.n; c.chunks.push_back(std::move(ch)); }

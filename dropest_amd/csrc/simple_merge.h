@@ -294,6 +294,7 @@ void dropest_ctx::run_cb_merge_simple() {
 		umi_first.ensure(table);
 		HIP_CHECK(hipMemsetAsync(umi_first.p, 0xFF, table * 4, stream));
 		const u32 n = u32(n_reads);
+		need_columns();   // (a sharded run's reads may still be packed records)
 		timed("umi_first_table", double(n) * 12, [&] {
 			hipLaunchKernelGGL(umi_first_table_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n, layout, umi_first.p);
 		});

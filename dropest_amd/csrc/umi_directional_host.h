@@ -79,6 +79,7 @@ void dropest_ctx::run_umi_merge_directional() {
 	HIP_CHECK(hipMemsetAsync(umi_first.p, 0xFF, table * 4, stream));
 	const u32 n = u32(n_reads);
 	timed("umi_first_table", double(n) * 12, [&] {
+		need_columns();   // (a sharded run's reads may still be packed records)
 		hipLaunchKernelGGL(umi_first_table_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n,
 		                   layout, umi_first.p);
 	});

@@ -181,6 +181,7 @@ std::vector<dropest::u32> dropest_ctx::umi_first_positions(const std::vector<u64
 	HIP_CHECK(hipMemsetAsync(d_first.p, 0xFF, size_t(nq) * 4, stream));
 	const u32 n = u32(n_reads);
 	timed("umi_first_seen", double(n) * 12, [&] {
+		need_columns();   // (a sharded run's reads may still be packed records)
 		hipLaunchKernelGGL(umi_first_seen_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n,
 		                   d_q.p, nq, d_first.p);
 	});
