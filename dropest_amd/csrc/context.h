@@ -311,6 +311,9 @@ struct HostCell {   // host mirror of one REAL-candidate cell (n_genes >= min_ge
 
 }  // namespace dropest
 
+// simple_merge.h: common_umigs_per_cell of ALL bases at once: key = base << 32 | other, ascending; ed = device distance or 0xFFFFFFFF
+struct SimplePairs { std::vector<uint64_t> key; std::vector<uint32_t> cnt, ed; std::vector<double> prob; /* -M: per pair, 2 = not a neighbour */ };
+
 struct dropest_ctx {
 	using u64 = dropest::u64;
 	using u32 = dropest::u32;
@@ -571,7 +574,14 @@ struct dropest_ctx {
 	} ms;
 	void run_cb_merge_real();
 	void run_cb_merge_simple();                  // SimpleMergeStrategy (simple_merge.h)
+	struct SimpleReplayInput { std::vector<u64> query; std::vector<std::vector<u32>> in_order; };
+	void simple_pair_table(const u64 *sorted, u32 n_valid, int cell_bits, const u32 *d_cell_size, const u64 *d_cell_code, SimplePairs &P,
+	                       dropest::DevBuf<u64> *d_run_key, dropest::DevBuf<u32> *d_run_cnt, u32 *n_runs = nullptr);
+	void simple_pairs_to_host(const u64 *d_run_key, const u32 *d_run_cnt, u32 runs, const u64 *d_cell_code, SimplePairs &P);
+	void simple_replay_local(const std::vector<u32> &bases, SimpleReplayInput &R, bool globalize);
 	void run_cb_merge_all();                     // MergeAllMergeStrategy (merge_all.h)
+	void merge_all_targets(std::vector<u64> code, const std::vector<int32_t> &umis, const std::function<std::string(u32)> &text,
+	                       const std::vector<u32> *bases, std::vector<u32> &target_pos);
 	// public mutators of the container (mutate_host.h)
 	std::unordered_set<u32> extra_excluded;      // excluded cells outside the host mirror of real-candidate cells
 	std::unordered_set<u32> explicit_sources;    // sources of dropest_merge_cells (not part of the strategy's merge targets)
@@ -592,6 +602,8 @@ struct dropest_ctx {
 	std::shared_ptr<ShardMerge> shard;
 	bool ingested = false, external_merge_done = false;
 	void run_ingest();
+	void shard_export_rows(const std::vector<u32> &local_cells);   // merge_shard.h
+	void shard_merge_begin_free();                                    // whitelist-free merges across shards: an empty ShardMerge
 	void shard_merge_search(uint64_t n_global, const uint64_t *g_barcode, const uint32_t *g_n_genes, const int32_t *g_total_umis,
 	                        uint64_t n_bases, const uint32_t *base_g, const uint32_t *base_local, uint64_t *n_pairs);
 	void shard_merge_intersect(uint64_t n_pairs, const uint32_t *cand_local, const uint64_t *base_begin, const uint64_t *base_end,

@@ -1406,8 +1406,8 @@ void dropest_ctx::run_merge_and_filter() {
 	tail_mark("merge_and_filter entered");
 	if (cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES && n_cells && !external_merge_done) run_cb_merge_real();
 	if (cfg.merge_kind == DROPEST_MERGE_POISSON_REAL && n_cells && !external_merge_done) run_cb_merge_real();   // same loop, Poisson decisions
-	if ((cfg.merge_kind == DROPEST_MERGE_SIMPLE || cfg.merge_kind == DROPEST_MERGE_POISSON_SIMPLE) && n_cells) run_cb_merge_simple();
-	if (cfg.merge_kind == DROPEST_MERGE_ALL && n_cells) run_cb_merge_all();
+	if ((cfg.merge_kind == DROPEST_MERGE_SIMPLE || cfg.merge_kind == DROPEST_MERGE_POISSON_SIMPLE) && n_cells && !external_merge_done) run_cb_merge_simple();
+	if (cfg.merge_kind == DROPEST_MERGE_ALL && n_cells && !external_merge_done) run_cb_merge_all();
 	// MergeUMIsStrategy*::merge, after the CB merge (CellsDataContainer.cpp:45)
 	if (cfg.umi_merge_kind == DROPEST_UMI_MERGE_DIRECTIONAL) run_umi_merge_directional(); else run_umi_merge_simple();
 	request_filtered(min_after, cfg.max_cells);   // CellsDataContainer.cpp:47-49

@@ -11,10 +11,12 @@ namespace {
 
 constexpr int MA_THREADS = 256;
 
+// bases: the filtered positions this launch decides (null = all of them; a shard of a sharded run decides its own cells)
 __global__ __launch_bounds__(MA_THREADS) void merge_all_kernel(const unsigned long long *__restrict__ code, const int32_t *__restrict__ umis,
-                                                               uint32_t n, int len, uint32_t max_ed, uint32_t *__restrict__ target_pos) {
+                                                               uint32_t n, int len, uint32_t max_ed, const uint32_t *__restrict__ bases,
+                                                               uint32_t *__restrict__ target_pos) {
 	__shared__ unsigned long long wave_best[MA_THREADS / 64];
-	const uint32_t f = blockIdx.x;
+	const uint32_t f = bases ? bases[blockIdx.x] : blockIdx.x;
 	const unsigned long long base = code[f];
 	const int32_t base_umis = umis[f];
 	unsigned long long best = ~0ull;
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(MA_THREADS) void merge_all_kernel(const unsigned lo
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		for (int w = 1; w < MA_THREADS / 64; ++w) if (wave_best[w] < best) best = wave_best[w];
-		target_pos[f] = best == ~0ull ? 0xFFFFFFFFu : uint32_t(best & 0x1FFFFFFull);
+		target_pos[blockIdx.x] = best == ~0ull ? 0xFFFFFFFFu : uint32_t(best & 0x1FFFFFFull);
 	}
 }
 
@@ -62,6 +64,57 @@ unsigned banded_edit_distance_exact(const std::string &s1, const std::string &s2
 
 }  // namespace
 
+// target_pos[k] = filtered position of the target of base bases[k] (all F cells when bases is null), 0xFFFFFFFF = none.
+// code / umis: barcode codes and TOTAL_UMIS in filtered order; text(f) = the barcode string of position f.
+void dropest_ctx::merge_all_targets(std::vector<u64> code, const std::vector<int32_t> &umis, const std::function<std::string(u32)> &text,
+                                    const std::vector<u32> *bases, std::vector<u32> &target_pos) {
+	using namespace dropest;
+	const u32 F = u32(code.size()), NB = bases ? u32(bases->size()) : F;
+	if (F >= (1u << 25)) throw UnsupportedError("merge_type = all over more than 2^25 filtered cells");
+	const u32 max_ed = u32(std::max(cfg.max_cb_merge_edit_distance, 0));
+	bool uniform = true;
+	int len = -1;
+	for (u32 f = 0; f < F; ++f) {
+		if (code[f] & ESCAPE_BIT) { uniform = false; continue; }
+		const int l = (63 - __builtin_clzll(code[f])) / 2;              // bases below the sentinel bit
+		if (len < 0) len = l;
+		uniform &= l == len;
+	}
+	target_pos.assign(NB, 0xFFFFFFFFu);
+	if (!NB) return;
+	if (uniform && len > 0 && len <= 31 && max_ed < 200) {
+		HostStage hs2(this, "cb_merge:targets");
+		const u64 strip = (1ull << (2 * len)) - 1ull;
+		for (u64 &c : code) c &= strip;
+		DevBuf<u64> d_code; DevBuf<int32_t> d_umis; DevBuf<u32> d_tgt, d_bases;
+		d_code.alloc(F); d_umis.alloc(F); d_tgt.alloc(NB);
+		HIP_CHECK(hipMemcpyAsync(d_code.p, code.data(), size_t(F) * 8, hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(d_umis.p, umis.data(), size_t(F) * 4, hipMemcpyHostToDevice, stream));
+		if (bases) { d_bases.alloc(NB); HIP_CHECK(hipMemcpyAsync(d_bases.p, bases->data(), size_t(NB) * 4, hipMemcpyHostToDevice, stream)); }
+		timed("merge_all", double(NB) * F * 12, [&] {
+			hipLaunchKernelGGL(merge_all_kernel, dim3(NB), dim3(MA_THREADS), 0, stream, d_code.p, d_umis.p, F, len, max_ed,
+			                   bases ? d_bases.p : static_cast<const u32 *>(nullptr), d_tgt.p);
+		});
+		fetch(target_pos.data(), d_tgt.p, size_t(NB) * 4);
+	} else {
+		HostStage hs2(this, "cb_merge:targets_host");
+		if (F > 30000) throw UnsupportedError("merge_type = all with barcodes of several lengths / with N over more than 30000 filtered cells");
+		std::vector<std::string> txt(F);
+		for (u32 f = 0; f < F; ++f) txt[f] = text(f);
+		for (u32 k = 0; k < NB; ++k) {
+			const u32 f = bases ? (*bases)[k] : k;
+			int min_ed = std::numeric_limits<int>::max(), max_umi = 0;
+			for (u32 j = 0; j < F; ++j) {
+				if (umis[j] <= umis[f]) continue;
+				const int ed = int(banded_edit_distance_exact(txt[f], txt[j], max_ed));
+				if (ed > int(max_ed)) continue;
+				if (min_ed > ed) { min_ed = ed; max_umi = umis[j]; target_pos[k] = j; }
+				else if ((min_ed == ed) & (max_umi < umis[j])) { max_umi = umis[j]; target_pos[k] = j; }
+			}
+		}
+	}
+}
+
 void dropest_ctx::run_cb_merge_all() {
 	using namespace dropest;
 	HostStage hs(this, "cb_merge");
@@ -71,50 +124,11 @@ void dropest_ctx::run_cb_merge_all() {
 	const u32 F = u32(cells.size()), nR = u32(real.size());
 	clear_strategy_pairs();
 	if (F == 0) return;
-	if (F >= (1u << 25)) throw UnsupportedError("merge_type = all over more than 2^25 filtered cells");
-	const u32 max_ed = u32(std::max(cfg.max_cb_merge_edit_distance, 0));
-
 	std::vector<u64> code(F);
 	std::vector<int32_t> umis(F);
-	bool uniform = true;
-	int len = -1;
-	for (u32 f = 0; f < F; ++f) {
-		code[f] = u64(real[ridx[f]].row.barcode);
-		umis[f] = real[ridx[f]].row.total_umis;
-		if (code[f] & ESCAPE_BIT) { uniform = false; continue; }
-		const int l = (63 - __builtin_clzll(code[f])) / 2;              // bases below the sentinel bit
-		if (len < 0) len = l;
-		uniform &= l == len;
-	}
-	std::vector<u32> target_pos(F, 0xFFFFFFFFu);
-	if (uniform && len > 0 && len <= 31 && max_ed < 200) {
-		HostStage hs2(this, "cb_merge:targets");
-		const u64 strip = (1ull << (2 * len)) - 1ull;
-		for (u64 &c : code) c &= strip;
-		DevBuf<u64> d_code; DevBuf<int32_t> d_umis; DevBuf<u32> d_tgt;
-		d_code.alloc(F); d_umis.alloc(F); d_tgt.alloc(F);
-		HIP_CHECK(hipMemcpyAsync(d_code.p, code.data(), size_t(F) * 8, hipMemcpyHostToDevice, stream));
-		HIP_CHECK(hipMemcpyAsync(d_umis.p, umis.data(), size_t(F) * 4, hipMemcpyHostToDevice, stream));
-		timed("merge_all", double(F) * F * 12, [&] {
-			hipLaunchKernelGGL(merge_all_kernel, dim3(F), dim3(MA_THREADS), 0, stream, d_code.p, d_umis.p, F, len, max_ed, d_tgt.p);
-		});
-		fetch(target_pos.data(), d_tgt.p, size_t(F) * 4);
-	} else {
-		HostStage hs2(this, "cb_merge:targets_host");
-		if (F > 30000) throw UnsupportedError("merge_type = all with barcodes of several lengths / with N over more than 30000 filtered cells");
-		std::vector<std::string> text(F);
-		for (u32 f = 0; f < F; ++f) text[f] = barcode_of(real[ridx[f]]);
-		for (u32 f = 0; f < F; ++f) {
-			int min_ed = std::numeric_limits<int>::max(), max_umi = 0;
-			for (u32 j = 0; j < F; ++j) {
-				if (umis[j] <= umis[f]) continue;
-				const int ed = int(banded_edit_distance_exact(text[f], text[j], max_ed));
-				if (ed > int(max_ed)) continue;
-				if (min_ed > ed) { min_ed = ed; max_umi = umis[j]; target_pos[f] = j; }
-				else if ((min_ed == ed) & (max_umi < umis[j])) { max_umi = umis[j]; target_pos[f] = j; }
-			}
-		}
-	}
+	for (u32 f = 0; f < F; ++f) { code[f] = u64(real[ridx[f]].row.barcode); umis[f] = real[ridx[f]].row.total_umis; }
+	std::vector<u32> target_pos;
+	merge_all_targets(code, umis, [&](u32 f) { return barcode_of(real[ridx[f]]); }, nullptr, target_pos);
 
 	// MergeStrategyBase::merge_inited second loop
 	HostStage hs3(this, "cb_merge:apply");

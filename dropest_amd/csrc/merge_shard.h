@@ -119,6 +119,7 @@ struct dropest_ctx::ShardMerge {
 	std::vector<u32> base_g, base_local;
 	// export
 	std::vector<u32> listed_f;          // positions (in base_g) of the bases whose rows are exported
+	std::vector<u32> listed_g;          // their places in the global cell list
 	std::vector<uint64_t> row_offset;   // [listed + 1]
 	dropest::DevBuf<u64> x_low;
 	dropest::DevBuf<u32> x_col[4];
@@ -129,6 +130,52 @@ struct dropest_ctx::ShardMerge {
 	const u32 *d_import_rank = nullptr, *d_import_q = nullptr;
 	bool quality_import_set = false;
 };
+
+// molecule rows (and their quality sums rows) of the listed local cells -> the contiguous export buffers of the shard merge
+void dropest_ctx::shard_export_rows(const std::vector<u32> &cells) {
+	if (!shard) throw InvalidError("internal: no shard merge in progress");
+	ShardMerge &M = *shard;
+	const u32 nl = u32(cells.size());
+	M.row_offset.assign(size_t(nl) + 1, 0);
+	if (nl) {
+		std::vector<u32> b(nl), e(nl);
+		for (u32 i = 0; i < nl; ++i) if (cells[i] >= n_cells) throw RangeError("exported cell is not a cell of this shard");
+		DevBuf<u32> d_cells, d_b, d_e, d_off;
+		d_cells.alloc(nl); d_b.alloc(nl); d_e.alloc(nl); d_off.alloc(size_t(nl) + 1);
+		HIP_CHECK(hipMemcpyAsync(d_cells.p, cells.data(), size_t(nl) * 4, hipMemcpyHostToDevice, stream));
+		hipLaunchKernelGGL(cell_ranges_kernel, dim3(div_up(nl, 256)), dim3(256), 0, stream, d_cells.p, nl, cell_cg_begin.p,
+		                   cell_cg_count.p, cg_mol_begin.p, d_b.p, d_e.p);
+		HIP_CHECK(hipGetLastError());
+		fetch(b.data(), d_b.p, size_t(nl) * 4);
+		fetch(e.data(), d_e.p, size_t(nl) * 4);
+		std::vector<u32> off(size_t(nl) + 1, 0);
+		for (u32 i = 0; i < nl; ++i) {
+			M.row_offset[i + 1] = M.row_offset[i] + (e[i] - b[i]);
+			if (M.row_offset[i + 1] > 0xFFFFFFF0ull) throw UnsupportedError("more than 2^32 exported molecule rows");
+			off[i + 1] = u32(M.row_offset[i + 1]);
+		}
+		const u32 rows = off[nl];
+		M.x_low.alloc(std::max<u32>(rows, 1));
+		for (auto &c : M.x_col) c.alloc(std::max<u32>(rows, 1));
+		HIP_CHECK(hipMemcpyAsync(d_off.p, off.data(), (size_t(nl) + 1) * 4, hipMemcpyHostToDevice, stream));
+		ExportArgs a{};
+		a.begin = d_b.p; a.out_off = d_off.p; a.n_cells = nl; a.mol_key = mol_key.p;
+		a.col[0] = mol_reads.p; a.col[1] = mol_mark.p;
+		a.col[2] = chr_from_gene ? mol_exon.p : nullptr; a.col[3] = chr_from_gene ? mol_intron.p : nullptr;
+		a.low_mask = (1ull << (layout.gene_bits + layout.umi_bits)) - 1ull;
+		a.o_low = M.x_low.p;
+		for (int k = 0; k < 4; ++k) a.o_col[k] = M.x_col[k].p;
+		timed("shard_merge:export", double(rows) * 48, [&] {
+			hipLaunchKernelGGL(export_rows_kernel, dim3(nl), dim3(256), 0, stream, a);
+		});
+		if (have_qual && qual_len) {
+			M.x_q.alloc(std::max<size_t>(size_t(rows) * qual_stride(), 1));
+			hipLaunchKernelGGL(export_quality_kernel, dim3(nl), dim3(256), 0, stream, d_b.p, d_off.p, mol_qrow.p, mol_qsum.p, qual_stride(), M.x_q.p);
+			HIP_CHECK(hipGetLastError());
+		}
+		HIP_CHECK(stream_wait(stream));
+	}
+}
 
 void dropest_ctx::shard_merge_search(uint64_t n_global, const uint64_t *g_barcode, const uint32_t *g_n_genes, const int32_t *g_total_umis,
                                      uint64_t n_bases, const uint32_t *base_g, const uint32_t *base_local, uint64_t *n_pairs) {
@@ -190,46 +237,10 @@ void dropest_ctx::shard_merge_search(uint64_t n_global, const uint64_t *g_barcod
 	// bases whose rows travel: those with at least one pair
 	M.listed_f.clear();
 	for (u32 f = 0; f < M.S.F; ++f) if (M.S.pair_first[f] != M.S.pair_first[f + 1]) M.listed_f.push_back(f);
-	const u32 nl = u32(M.listed_f.size());
-	M.row_offset.assign(size_t(nl) + 1, 0);
-	if (nl) {
-		std::vector<u32> cells(nl), b(nl), e(nl);
-		for (u32 i = 0; i < nl; ++i) cells[i] = M.base_local[M.listed_f[i]];
-		DevBuf<u32> d_cells, d_b, d_e, d_off;
-		d_cells.alloc(nl); d_b.alloc(nl); d_e.alloc(nl); d_off.alloc(size_t(nl) + 1);
-		HIP_CHECK(hipMemcpyAsync(d_cells.p, cells.data(), size_t(nl) * 4, hipMemcpyHostToDevice, stream));
-		hipLaunchKernelGGL(cell_ranges_kernel, dim3(div_up(nl, 256)), dim3(256), 0, stream, d_cells.p, nl, cell_cg_begin.p,
-		                   cell_cg_count.p, cg_mol_begin.p, d_b.p, d_e.p);
-		HIP_CHECK(hipGetLastError());
-		fetch(b.data(), d_b.p, size_t(nl) * 4);
-		fetch(e.data(), d_e.p, size_t(nl) * 4);
-		std::vector<u32> off(size_t(nl) + 1, 0);
-		for (u32 i = 0; i < nl; ++i) {
-			M.row_offset[i + 1] = M.row_offset[i] + (e[i] - b[i]);
-			if (M.row_offset[i + 1] > 0xFFFFFFF0ull) throw UnsupportedError("more than 2^32 exported molecule rows");
-			off[i + 1] = u32(M.row_offset[i + 1]);
-		}
-		const u32 rows = off[nl];
-		M.x_low.alloc(rows);
-		for (auto &c : M.x_col) c.alloc(rows);
-		HIP_CHECK(hipMemcpyAsync(d_off.p, off.data(), (size_t(nl) + 1) * 4, hipMemcpyHostToDevice, stream));
-		ExportArgs a{};
-		a.begin = d_b.p; a.out_off = d_off.p; a.n_cells = nl; a.mol_key = mol_key.p;
-		a.col[0] = mol_reads.p; a.col[1] = mol_mark.p;
-		a.col[2] = chr_from_gene ? mol_exon.p : nullptr; a.col[3] = chr_from_gene ? mol_intron.p : nullptr;
-		a.low_mask = (1ull << (layout.gene_bits + layout.umi_bits)) - 1ull;
-		a.o_low = M.x_low.p;
-		for (int k = 0; k < 4; ++k) a.o_col[k] = M.x_col[k].p;
-		timed("shard_merge:export", double(rows) * 48, [&] {
-			hipLaunchKernelGGL(export_rows_kernel, dim3(nl), dim3(256), 0, stream, a);
-		});
-		if (have_qual && qual_len) {
-			M.x_q.alloc(std::max<size_t>(size_t(rows) * qual_stride(), 1));
-			hipLaunchKernelGGL(export_quality_kernel, dim3(nl), dim3(256), 0, stream, d_b.p, d_off.p, mol_qrow.p, mol_qsum.p, qual_stride(), M.x_q.p);
-			HIP_CHECK(hipGetLastError());
-		}
-		HIP_CHECK(stream_wait(stream));
-	}
+	std::vector<u32> cells(M.listed_f.size());
+	M.listed_g.resize(M.listed_f.size());
+	for (size_t i = 0; i < M.listed_f.size(); ++i) { cells[i] = M.base_local[M.listed_f[i]]; M.listed_g[i] = M.base_g[M.listed_f[i]]; }
+	shard_export_rows(cells);
 	collect_timings();
 }
 

@@ -852,7 +852,24 @@ struct dropest_shard {
 	void step();
 	void partition_and_exchange();
 	void agree_on_key_fields();
+	// barcode merges across shards
+	struct MergeWorld {   // the cells that take part: every shard's rows in rank order, identical on every shard
+		struct LRow { u64 barcode; u32 n_genes, req_genes, req_umis, local_id; int32_t total_umis, total_reads; u32 first_read; };
+		std::vector<LRow> Gm; std::vector<size_t> goff; u32 nG = 0, lo = 0, hi = 0;
+	};
+	struct TravelRows { dropest::DevBuf<u64> low_all; dropest::DevBuf<u32> col_all[4], q_all; std::vector<uint64_t> beg, end; };
+	struct MergeApplied { std::vector<u32> final_t, mrank; std::vector<uint8_t> excl; std::vector<int32_t> reads, umis; };
+	void merge_gather_cells(MergeWorld &W);
+	void merge_gather_rows(const MergeWorld &W, TravelRows &T);
+	std::vector<u32> merge_order(const MergeWorld &W);
+	void merge_apply(const MergeWorld &W, const std::vector<int64_t> &my_tgt, const std::vector<u32> &order, MergeApplied &A);
+	void merge_finish(const MergeWorld &W, const MergeApplied &A, TravelRows &T);
+	void merge_umi_distribution();
 	void cb_merge();
+	void cb_merge_free();                        // shard_merge_free.h: Simple / PoissonSimple / merge-all
+	void free_simple_targets(const MergeWorld &W, const std::vector<u32> &order, const std::vector<u32> &pos_of, std::vector<int64_t> &my_tgt);
+	std::vector<double> free_expected(const MergeWorld &W, const std::vector<u32> &pair_base, const std::vector<u32> &pair_other);
+	std::unique_ptr<TravelRows> free_rows;      // PoissonSimple: molecule rows gathered for the estimator, reused when the merge is applied
 	void build_global_table();
 	void assemble_matrix(bool filtered_m);
 	std::vector<u32> order_rows(const std::vector<u32> &sel, bool by_first);
@@ -934,7 +951,9 @@ void dropest_shard::partition_and_exchange() {
 	dropest_ctx &c = *ctx;
 	const u32 n = u32(n_res);
 	send_cnt.assign(size_t(world), 0);
-	const bool want_idx = c.cfg.umi_merge_kind == DROPEST_UMI_MERGE_DIRECTIONAL;   // -u turns a whole table of positions into ordinals on the device
+	// -u turns a whole table of positions into ordinals on the device; so do the tie replays of the whitelist-free merges (global cell
+	// indices, global UMI order: shard_merge_free.h)
+	const bool want_idx = c.cfg.umi_merge_kind == DROPEST_UMI_MERGE_DIRECTIONAL || c.cfg.merge_kind == DROPEST_MERGE_SIMPLE || c.cfg.merge_kind == DROPEST_MERGE_POISSON_SIMPLE;
 	std::vector<uint64_t> all_cnt(size_t(world) * size_t(world));
 	ExchangePack pack{};
 	{
@@ -1204,23 +1223,155 @@ std::vector<dropest::u32> dropest_shard::order_rows(const std::vector<u32> &sel,
 	return out;
 }
 
-// 5. RealBarcodes CB merge over all shards (MergeStrategyBase::merge_inited, MergeStrategyBase.cpp:11-57); phases in
-// merge_shard.h.  Every shard ends with the same global picture and applies the part that concerns its cells.
+// 5. CB merge over all shards (MergeStrategyBase::merge_inited, MergeStrategyBase.cpp:11-57).  Every shard ends with the same global
+// picture and applies the part that concerns its cells.  Common to every strategy: the cells that take part are all-gathered
+// (merge_gather_cells), every shard decides the targets of ITS cells, the sequential smallest-first application runs identically
+// everywhere (merge_apply), molecule rows of cells whose target lives elsewhere travel (merge_gather_rows) and are appended where the
+// target lives (merge_finish).
+void dropest_shard::merge_gather_cells(MergeWorld &W) {
+	dropest_ctx &c = *ctx;
+	std::vector<MergeWorld::LRow> local;
+	for (const HostCell &h : c.real) {
+		if (h.merged || h.excluded || h.row.n_genes < c.min_before) continue;
+		local.push_back(MergeWorld::LRow{h.row.barcode, h.row.n_genes, h.row.requested_genes, h.row.requested_umis, h.id, h.row.total_umis, h.row.total_reads, h.row.first_read});
+	}
+	std::vector<size_t> cnt;
+	{ Phase ph(this, "cbm:gather_cells"); tr->gather_vec(local, W.Gm, cnt); }
+	if (W.Gm.size() >= 0x7FFFFFFFull) throw UnsupportedError("more than 2^31 cells in a sharded merge");
+	W.nG = u32(W.Gm.size());
+	W.goff.assign(size_t(world) + 1, 0);
+	for (int p = 0; p < world; ++p) W.goff[size_t(p) + 1] = W.goff[size_t(p)] + cnt[size_t(p)];
+	W.lo = u32(W.goff[size_t(rank)]); W.hi = u32(W.goff[size_t(rank) + 1]);
+}
+
+// the export buffers of every shard's ShardMerge (rows of its listed cells), all-gathered; beg / end = row range of a listed cell
+void dropest_shard::merge_gather_rows(const MergeWorld &W, TravelRows &T) {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	dropest_ctx::ShardMerge &M = *c.shard;
+	Phase ph(this, "cbm:gather_rows");
+	struct Listed { u32 g; uint64_t b, e; };
+	std::vector<Listed> my_listed(M.listed_g.size()), all_listed;
+	for (size_t i = 0; i < M.listed_g.size(); ++i) my_listed[i] = Listed{M.listed_g[i], M.row_offset[i], M.row_offset[i + 1]};
+	std::vector<size_t> lcnt;
+	tr->gather_vec(my_listed, all_listed, lcnt);
+	const bool with_qual = c.have_qual && c.qual_len;
+	T.beg.assign(W.nG, ~0ull); T.end.assign(W.nG, ~0ull);
+	uint64_t my_rows = M.row_offset.empty() ? 0 : M.row_offset.back();
+	std::vector<uint64_t> rows(static_cast<size_t>(world));
+	tr->gather_host(&my_rows, 8, rows.data());
+	std::vector<size_t> off8(static_cast<size_t>(world)), b8(static_cast<size_t>(world)), off4(static_cast<size_t>(world)), b4(static_cast<size_t>(world));
+	uint64_t total = 0;
+	std::vector<uint64_t> row_base(size_t(world) + 1, 0);
+	for (int p = 0; p < world; ++p) { row_base[size_t(p) + 1] = row_base[size_t(p)] + rows[size_t(p)]; total += rows[size_t(p)]; }
+	if (total > 0xFFFFFFF0ull) throw UnsupportedError("more than 2^32 molecule rows travel in the sharded merge");
+	for (int p = 0; p < world; ++p) { off8[size_t(p)] = size_t(row_base[size_t(p)]) * 8; b8[size_t(p)] = size_t(rows[size_t(p)]) * 8; off4[size_t(p)] = size_t(row_base[size_t(p)]) * 4; b4[size_t(p)] = size_t(rows[size_t(p)]) * 4; }
+	T.low_all.alloc(std::max<size_t>(total, 1));
+	for (auto &b : T.col_all) b.alloc(std::max<size_t>(total, 1));
+	if (!M.x_low.p) { M.x_low.alloc(1); for (auto &b : M.x_col) b.alloc(1); }
+	tr->gather_dev(M.x_low.p, T.low_all.p, off8.data(), b8.data(), c.stream);
+	for (int k = 0; k < 4; ++k) tr->gather_dev(M.x_col[k].p, T.col_all[k].p, off4.data(), b4.data(), c.stream);
+	if (with_qual) {   // the sums rows of the travelling molecules
+		const size_t qs = c.qual_stride();
+		std::vector<size_t> offq(static_cast<size_t>(world)), bq(static_cast<size_t>(world));
+		for (int p = 0; p < world; ++p) { offq[size_t(p)] = off4[size_t(p)] * qs; bq[size_t(p)] = b4[size_t(p)] * qs; }
+		T.q_all.alloc(std::max<size_t>(total * qs, 1));
+		if (!M.x_q.p) M.x_q.alloc(1);
+		tr->gather_dev(M.x_q.p, T.q_all.p, offq.data(), bq.data(), c.stream);
+	}
+	size_t at = 0;
+	for (int p = 0; p < world; ++p)
+		for (size_t i = 0; i < lcnt[size_t(p)]; ++i, ++at) { T.beg[all_listed[at].g] = all_listed[at].b + row_base[size_t(p)]; T.end[all_listed[at].g] = all_listed[at].e + row_base[size_t(p)]; }
+}
+
+// my_tgt[i] = target (global place, or -1) of cell lo + i; the same sequential application on every shard.  `order` = the cells in
+// ascending compare_cells order (the reference's filtered order).
+void dropest_shard::merge_apply(const MergeWorld &W, const std::vector<int64_t> &my_tgt, const std::vector<u32> &order, MergeApplied &A) {
+	dropest_ctx &c = *ctx;
+	const u32 nG = W.nG;
+	std::vector<int64_t> target;
+	{ Phase ph(this, "cbm:gather_targets"); std::vector<size_t> tcnt; tr->gather_vec(my_tgt, target, tcnt); }
+	if (target.size() != nG) throw InvalidError("internal: the shards' merge targets do not cover the cell list");
+	const bool with_qual = c.have_qual && c.qual_len;
+	A.final_t.assign(nG, 0); A.excl.assign(nG, 0); A.reads.assign(nG, 0); A.umis.assign(nG, 0);
+	A.mrank.assign(with_qual ? nG : 0u, 0);   // place of every cell in its target's merge order (0: not merged away)
+	Phase ph(this, "cbm:order+apply");
+	std::vector<int64_t> tgt_in_order(nG);
+	for (u32 i = 0; i < nG; ++i) { tgt_in_order[i] = target[order[i]]; A.reads[i] = W.Gm[i].total_reads; A.umis[i] = W.Gm[i].total_umis; }
+	apply_merge_order(nG, nG, order.data(), tgt_in_order.data(), A.reads.data(), A.umis.data(), A.final_t.data(), A.excl.data(), with_qual ? A.mrank.data() : nullptr);
+}
+
+std::vector<dropest::u32> dropest_shard::merge_order(const MergeWorld &W) {
+	const u32 nG = W.nG;
+	G.resize(nG);
+	for (u32 i = 0; i < nG; ++i) { GRow r{}; r.barcode = W.Gm[i].barcode; r.req_genes = W.Gm[i].req_genes; r.req_umis = W.Gm[i].req_umis; r.total_umis = W.Gm[i].total_umis; G[i] = r; }
+	std::vector<u32> sel(nG);
+	for (u32 i = 0; i < nG; ++i) sel[i] = i;
+	return order_rows(sel, false);
+}
+
+void dropest_shard::merge_finish(const MergeWorld &W, const MergeApplied &A, TravelRows &T) {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	const u32 nG = W.nG, lo = W.lo, hi = W.hi;
+	const auto &Gm = W.Gm;
+	const bool with_qual = c.have_qual && c.qual_len;
+	Phase ph(this, "cbm:finish");
+	std::vector<u32> local_id, move_src, move_tgt, import_row, import_cell, local_rank, import_rank;
+	std::vector<uint8_t> l_excl, l_merged; std::vector<int32_t> l_reads, l_umis;
+	merged_barcodes.clear();
+	for (u32 i = 0; i < nG; ++i) {
+		const bool mine = i >= lo && i < hi;
+		if (mine) { local_id.push_back(Gm[i].local_id); l_excl.push_back(A.excl[i]); l_merged.push_back(A.final_t[i] != i); l_reads.push_back(A.reads[i]); l_umis.push_back(A.umis[i]);
+		            if (with_qual) local_rank.push_back(A.mrank[i]); }
+		if (A.final_t[i] == i) continue;
+		merged_barcodes.emplace_back(Gm[i].barcode, Gm[A.final_t[i]].barcode);
+		const u32 t = A.final_t[i];
+		if (!(t >= lo && t < hi)) continue;
+		if (mine) { move_src.push_back(Gm[i].local_id); move_tgt.push_back(Gm[t].local_id); continue; }
+		if (T.beg[i] == ~0ull) throw InvalidError("internal: a merged cell's molecule rows were not exported");
+		for (uint64_t r = T.beg[i]; r < T.end[i]; ++r) { import_row.push_back(u32(r)); import_cell.push_back(Gm[t].local_id); if (with_qual) import_rank.push_back(A.mrank[i]); }
+	}
+	std::sort(merged_barcodes.begin(), merged_barcodes.end());
+	const u32 ni = u32(import_row.size());
+	DevBuf<u32> d_row, d_cell, d_col[4]; DevBuf<u64> d_low;
+	d_row.alloc(std::max<u32>(ni, 1)); d_cell.alloc(std::max<u32>(ni, 1)); d_low.alloc(std::max<u32>(ni, 1));
+	for (auto &b : d_col) b.alloc(std::max<u32>(ni, 1));
+	if (ni) {
+		HIP_CHECK(hipMemcpyAsync(d_row.p, import_row.data(), size_t(ni) * 4, hipMemcpyHostToDevice, c.stream));
+		HIP_CHECK(hipMemcpyAsync(d_cell.p, import_cell.data(), size_t(ni) * 4, hipMemcpyHostToDevice, c.stream));
+		ImportGatherArgs a{};
+		a.row = d_row.p; a.n = ni; a.low_all = T.low_all.p; a.o_low = d_low.p;
+		for (int k = 0; k < 4; ++k) { a.col_all[k] = T.col_all[k].p; a.o_col[k] = d_col[k].p; }
+		hipLaunchKernelGGL(import_gather_kernel, dim3(div_up(ni, 256)), dim3(256), 0, c.stream, a);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(stream_wait(c.stream));
+	}
+	DevBuf<u32> d_irank, d_iq;
+	if (with_qual) {
+		const u32 qs = c.qual_stride();
+		d_irank.alloc(std::max<u32>(ni, 1)); d_iq.alloc(std::max<size_t>(size_t(ni) * qs, 1));
+		if (ni) {
+			HIP_CHECK(hipMemcpyAsync(d_irank.p, import_rank.data(), size_t(ni) * 4, hipMemcpyHostToDevice, c.stream));
+			hipLaunchKernelGGL(gather_u32_rows_kernel, dim3(u32(std::min<uint64_t>((uint64_t(ni) * qs + 255) / 256, 16384))), dim3(256), 0, c.stream, T.q_all.p, d_row.p, ni, qs, d_iq.p);
+			HIP_CHECK(hipGetLastError());
+			HIP_CHECK(stream_wait(c.stream));
+		}
+		c.shard_merge_quality_import(local_id.size(), local_rank.data(), d_irank.p, d_iq.p);
+	}
+	const u32 *cols[4] = {d_col[0].p, d_col[1].p, d_col[2].p, d_col[3].p};
+	c.shard_merge_finish(local_id.size(), local_id.data(), l_excl.data(), l_merged.data(), l_reads.data(), l_umis.data(), move_src.size(),
+	                     move_src.data(), move_tgt.data(), ni, d_cell.p, reinterpret_cast<const uint64_t *>(d_low.p), cols);
+}
+
+// RealBarcodes / PoissonRealBarcodes: phases in merge_shard.h
 void dropest_shard::cb_merge() {
 	using namespace dropest;
 	dropest_ctx &c = *ctx;
-	struct LRow { u64 barcode; u32 n_genes, req_genes, req_umis, local_id; int32_t total_umis, total_reads; };
-	std::vector<LRow> local, Gm;
-	for (const HostCell &h : c.real) {
-		if (h.merged || h.excluded || h.row.n_genes < c.min_before) continue;
-		local.push_back(LRow{h.row.barcode, h.row.n_genes, h.row.requested_genes, h.row.requested_umis, h.id, h.row.total_umis, h.row.total_reads});
-	}
-	std::vector<size_t> cnt;
-	{ Phase ph(this, "cbm:gather_cells"); tr->gather_vec(local, Gm, cnt); }
-	const u32 nG = u32(Gm.size());
-	std::vector<size_t> goff(size_t(world) + 1, 0);
-	for (int p = 0; p < world; ++p) goff[size_t(p) + 1] = goff[size_t(p)] + cnt[size_t(p)];
-	const u32 lo = u32(goff[size_t(rank)]), hi = u32(goff[size_t(rank) + 1]);
+	MergeWorld W;
+	merge_gather_cells(W);
+	const auto &Gm = W.Gm;
+	const u32 nG = W.nG, lo = W.lo, hi = W.hi;
 	// search: my real cells against everybody's
 	std::vector<uint64_t> g_bc(nG); std::vector<u32> g_ng(nG); std::vector<int32_t> g_tu(nG);
 	for (u32 i = 0; i < nG; ++i) { g_bc[i] = Gm[i].barcode; g_ng[i] = Gm[i].n_genes; g_tu[i] = Gm[i].total_umis; }
@@ -1232,65 +1383,17 @@ void dropest_shard::cb_merge() {
 	struct Pair { u32 base, cand; };
 	std::vector<Pair> my_pairs(static_cast<size_t>(n_pairs)), allp;
 	for (size_t p = 0; p < n_pairs; ++p) my_pairs[p] = Pair{M.base_g[M.S.pair_base[p]], M.S.pair_cand[p]};
-	struct Listed { u32 g; uint64_t b, e; };
-	std::vector<Listed> my_listed(M.listed_f.size()), all_listed;
-	for (size_t i = 0; i < M.listed_f.size(); ++i) my_listed[i] = Listed{M.base_g[M.listed_f[i]], M.row_offset[i], M.row_offset[i + 1]};
-	std::vector<size_t> pcnt, lcnt;
-	DevBuf<u64> low_all; DevBuf<u32> col_all[4], q_all;
-	const bool with_qual = c.have_qual && c.qual_len;
-	std::vector<uint64_t> beg(nG, ~0ull), end(nG, ~0ull);
-	{
-		Phase ph(this, "cbm:gather_rows");
-		tr->gather_vec(my_pairs, allp, pcnt);
-		tr->gather_vec(my_listed, all_listed, lcnt);
-		uint64_t my_rows = M.row_offset.empty() ? 0 : M.row_offset.back();
-		std::vector<uint64_t> rows(static_cast<size_t>(world));
-		tr->gather_host(&my_rows, 8, rows.data());
-		std::vector<size_t> off8(static_cast<size_t>(world)), b8(static_cast<size_t>(world)), off4(static_cast<size_t>(world)), b4(static_cast<size_t>(world));
-		uint64_t total = 0;
-		std::vector<uint64_t> row_base(size_t(world) + 1, 0);
-		for (int p = 0; p < world; ++p) { row_base[size_t(p) + 1] = row_base[size_t(p)] + rows[size_t(p)]; total += rows[size_t(p)]; }
-		if (total > 0xFFFFFFF0ull) throw UnsupportedError("more than 2^32 molecule rows travel in the sharded merge");
-		for (int p = 0; p < world; ++p) { off8[size_t(p)] = size_t(row_base[size_t(p)]) * 8; b8[size_t(p)] = size_t(rows[size_t(p)]) * 8; off4[size_t(p)] = size_t(row_base[size_t(p)]) * 4; b4[size_t(p)] = size_t(rows[size_t(p)]) * 4; }
-		low_all.alloc(std::max<size_t>(total, 1));
-		for (auto &b : col_all) b.alloc(std::max<size_t>(total, 1));
-		tr->gather_dev(M.x_low.p, low_all.p, off8.data(), b8.data(), c.stream);
-		for (int k = 0; k < 4; ++k) tr->gather_dev(M.x_col[k].p, col_all[k].p, off4.data(), b4.data(), c.stream);
-		if (with_qual) {   // the sums rows of the travelling molecules
-			const size_t qs = c.qual_stride();
-			std::vector<size_t> offq(static_cast<size_t>(world)), bq(static_cast<size_t>(world));
-			for (int p = 0; p < world; ++p) { offq[size_t(p)] = off4[size_t(p)] * qs; bq[size_t(p)] = b4[size_t(p)] * qs; }
-			q_all.alloc(std::max<size_t>(total * qs, 1));
-			tr->gather_dev(M.x_q.p, q_all.p, offq.data(), bq.data(), c.stream);
-		}
-		size_t at = 0;
-		for (int p = 0; p < world; ++p)
-			for (size_t i = 0; i < lcnt[size_t(p)]; ++i, ++at) { beg[all_listed[at].g] = all_listed[at].b + row_base[size_t(p)]; end[all_listed[at].g] = all_listed[at].e + row_base[size_t(p)]; }
-	}
+	std::vector<size_t> pcnt;
+	{ Phase ph(this, "cbm:gather_pairs"); tr->gather_vec(my_pairs, allp, pcnt); }
+	TravelRows T;
+	merge_gather_rows(W, T);
+	DevBuf<u64> &low_all = T.low_all;
+	std::vector<uint64_t> &beg = T.beg, &end = T.end;
 	const bool poisson = c.cfg.merge_kind == DROPEST_MERGE_POISSON_REAL;
 	if (poisson) {
 		// -M: the estimator works on the UMI distribution of ALL filtered cells and on the largest gene of any cell (PoissonTargetEstimator::init,
 		// PoissonTargetEstimator.cpp:46-59): dense histograms over the UMI field, all-gathered and added; every shard builds the same tables
-		Phase ph(this, "cbm:umi_distribution");
-		DevBuf<u32> hist, all, sum;
-		uint64_t kept = 0; u32 max_size = 0;
-		c.shard_merge_umi_histogram(hist, kept, max_size);
-		const size_t n = size_t(1) << c.layout.umi_bits;
-		uint64_t mine[3] = {kept, max_size, n};
-		std::vector<uint64_t> every(size_t(world) * 3);
-		tr->gather_host(mine, sizeof(mine), every.data());
-		uint64_t kept_total = 0; u32 max_all = 0;
-		for (int p = 0; p < world; ++p) {
-			if (every[size_t(p) * 3 + 2] != n) throw InvalidError("internal: the shards disagree on the width of the UMI field");
-			kept_total += every[size_t(p) * 3]; max_all = std::max<u32>(max_all, u32(every[size_t(p) * 3 + 1]));
-		}
-		all.alloc(n * size_t(world)); sum.alloc(n);
-		std::vector<size_t> off(static_cast<size_t>(world)), bytes(static_cast<size_t>(world), n * 4);
-		for (int p = 0; p < world; ++p) off[size_t(p)] = size_t(p) * n * 4;
-		tr->gather_dev(hist.p, all.p, off.data(), bytes.data(), c.stream);
-		hipLaunchKernelGGL(sum_rows_kernel, dim3(u32(std::min<size_t>((n + 255) / 256, 4096))), dim3(256), 0, c.stream, all.p, u32(world), uint64_t(n), sum.p);
-		HIP_CHECK(hipGetLastError());
-		c.shard_merge_set_umi_distribution(sum.p, n, kept_total, max_all);
+		merge_umi_distribution();
 	}
 	// intersect: the pairs whose candidate is mine
 	std::vector<size_t> poff(size_t(world) + 1, 0);
@@ -1320,76 +1423,44 @@ void dropest_shard::cb_merge() {
 	std::vector<double> expected_all(poisson ? allp.size() : 0, 0.0);
 	for (const Ans &a : all_ans) { inter_all[size_t(a.pair)] = a.inter; if (poisson) expected_all[size_t(a.pair)] = a.expected; }
 	// decide: targets of my bases; then the same sequential application everywhere
-	std::vector<int64_t> my_tgt(hi - lo, -1), target;
+	std::vector<int64_t> my_tgt(hi - lo, -1);
 	{
 		Phase ph(this, "cbm:decide");
 		if (poisson) c.shard_merge_decide_poisson(inter_all.data() + poff[size_t(rank)], expected_all.data() + poff[size_t(rank)], my_tgt.data());
 		else c.shard_merge_decide(inter_all.data() + poff[size_t(rank)], my_tgt.data());
-		std::vector<size_t> tcnt;
-		tr->gather_vec(my_tgt, target, tcnt);
 	}
-	std::vector<u32> final_t(nG); std::vector<uint8_t> excl(nG);
-	std::vector<int32_t> reads(nG), umis(nG);
-	std::vector<u32> mrank(with_qual ? nG : 0u);   // place of every cell in its target's merge order (0: not merged away)
-	{
-		Phase ph(this, "cbm:order+apply");
-		// all real cells are "filtered" before the merge (threshold 0): ascending compare_cells order
-		G.resize(nG);
-		for (u32 i = 0; i < nG; ++i) { GRow r{}; r.barcode = Gm[i].barcode; r.req_genes = Gm[i].req_genes; r.req_umis = Gm[i].req_umis; r.total_umis = Gm[i].total_umis; G[i] = r; }
-		std::vector<u32> sel(nG);
-		for (u32 i = 0; i < nG; ++i) sel[i] = i;
-		const std::vector<u32> order = order_rows(sel, false);
-		std::vector<int64_t> tgt_in_order(nG);
-		for (u32 i = 0; i < nG; ++i) { tgt_in_order[i] = target[order[i]]; reads[i] = Gm[i].total_reads; umis[i] = Gm[i].total_umis; }
-		apply_merge_order(nG, nG, order.data(), tgt_in_order.data(), reads.data(), umis.data(), final_t.data(), excl.data(), with_qual ? mrank.data() : nullptr);
-	}
-	Phase ph(this, "cbm:finish");
-	std::vector<u32> local_id, move_src, move_tgt, import_row, import_cell, local_rank, import_rank;
-	std::vector<uint8_t> l_excl, l_merged; std::vector<int32_t> l_reads, l_umis;
-	merged_barcodes.clear();
-	for (u32 i = 0; i < nG; ++i) {
-		const bool mine = i >= lo && i < hi;
-		if (mine) { local_id.push_back(Gm[i].local_id); l_excl.push_back(excl[i]); l_merged.push_back(final_t[i] != i); l_reads.push_back(reads[i]); l_umis.push_back(umis[i]);
-		            if (with_qual) local_rank.push_back(mrank[i]); }
-		if (final_t[i] == i) continue;
-		merged_barcodes.emplace_back(Gm[i].barcode, Gm[final_t[i]].barcode);
-		const u32 t = final_t[i];
-		if (!(t >= lo && t < hi)) continue;
-		if (mine) { move_src.push_back(Gm[i].local_id); move_tgt.push_back(Gm[t].local_id); continue; }
-		if (beg[i] == ~0ull) throw InvalidError("internal: a merged cell's molecule rows were not exported");
-		for (uint64_t r = beg[i]; r < end[i]; ++r) { import_row.push_back(u32(r)); import_cell.push_back(Gm[t].local_id); if (with_qual) import_rank.push_back(mrank[i]); }
-	}
-	std::sort(merged_barcodes.begin(), merged_barcodes.end());
-	const u32 ni = u32(import_row.size());
-	DevBuf<u32> d_row, d_cell, d_col[4]; DevBuf<u64> d_low;
-	d_row.alloc(std::max<u32>(ni, 1)); d_cell.alloc(std::max<u32>(ni, 1)); d_low.alloc(std::max<u32>(ni, 1));
-	for (auto &b : d_col) b.alloc(std::max<u32>(ni, 1));
-	if (ni) {
-		HIP_CHECK(hipMemcpyAsync(d_row.p, import_row.data(), size_t(ni) * 4, hipMemcpyHostToDevice, c.stream));
-		HIP_CHECK(hipMemcpyAsync(d_cell.p, import_cell.data(), size_t(ni) * 4, hipMemcpyHostToDevice, c.stream));
-		ImportGatherArgs a{};
-		a.row = d_row.p; a.n = ni; a.low_all = low_all.p; a.o_low = d_low.p;
-		for (int k = 0; k < 4; ++k) { a.col_all[k] = col_all[k].p; a.o_col[k] = d_col[k].p; }
-		hipLaunchKernelGGL(import_gather_kernel, dim3(div_up(ni, 256)), dim3(256), 0, c.stream, a);
-		HIP_CHECK(hipGetLastError());
-		HIP_CHECK(stream_wait(c.stream));
-	}
-	DevBuf<u32> d_irank, d_iq;
-	if (with_qual) {
-		const u32 qs = c.qual_stride();
-		d_irank.alloc(std::max<u32>(ni, 1)); d_iq.alloc(std::max<size_t>(size_t(ni) * qs, 1));
-		if (ni) {
-			HIP_CHECK(hipMemcpyAsync(d_irank.p, import_rank.data(), size_t(ni) * 4, hipMemcpyHostToDevice, c.stream));
-			hipLaunchKernelGGL(gather_u32_rows_kernel, dim3(u32(std::min<uint64_t>((uint64_t(ni) * qs + 255) / 256, 16384))), dim3(256), 0, c.stream, q_all.p, d_row.p, ni, qs, d_iq.p);
-			HIP_CHECK(hipGetLastError());
-			HIP_CHECK(stream_wait(c.stream));
-		}
-		c.shard_merge_quality_import(local_id.size(), local_rank.data(), d_irank.p, d_iq.p);
-	}
-	const u32 *cols[4] = {d_col[0].p, d_col[1].p, d_col[2].p, d_col[3].p};
-	c.shard_merge_finish(local_id.size(), local_id.data(), l_excl.data(), l_merged.data(), l_reads.data(), l_umis.data(), move_src.size(),
-	                     move_src.data(), move_tgt.data(), ni, d_cell.p, reinterpret_cast<const uint64_t *>(d_low.p), cols);
+	MergeApplied A;
+	merge_apply(W, my_tgt, merge_order(W), A);   // all real cells are "filtered" before the merge (threshold 0)
+	merge_finish(W, A, T);
 }
+
+// -M: the UMI distribution of ALL shards' filtered cells -> the estimator's tables, identical on every shard
+void dropest_shard::merge_umi_distribution() {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	Phase ph(this, "cbm:umi_distribution");
+	DevBuf<u32> hist, all, sum;
+	uint64_t kept = 0; u32 max_size = 0;
+	c.shard_merge_umi_histogram(hist, kept, max_size);
+	const size_t n = size_t(1) << c.layout.umi_bits;
+	uint64_t mine[3] = {kept, max_size, n};
+	std::vector<uint64_t> every(size_t(world) * 3);
+	tr->gather_host(mine, sizeof(mine), every.data());
+	uint64_t kept_total = 0; u32 max_all = 0;
+	for (int p = 0; p < world; ++p) {
+		if (every[size_t(p) * 3 + 2] != n) throw InvalidError("internal: the shards disagree on the width of the UMI field");
+		kept_total += every[size_t(p) * 3]; max_all = std::max<u32>(max_all, u32(every[size_t(p) * 3 + 1]));
+	}
+	all.alloc(n * size_t(world)); sum.alloc(n);
+	std::vector<size_t> off(static_cast<size_t>(world)), bytes(static_cast<size_t>(world), n * 4);
+	for (int p = 0; p < world; ++p) off[size_t(p)] = size_t(p) * n * 4;
+	tr->gather_dev(hist.p, all.p, off.data(), bytes.data(), c.stream);
+	hipLaunchKernelGGL(sum_rows_kernel, dim3(u32(std::min<size_t>((n + 255) / 256, 4096))), dim3(256), 0, c.stream, all.p, u32(world), uint64_t(n), sum.p);
+	HIP_CHECK(hipGetLastError());
+	c.shard_merge_set_umi_distribution(sum.p, n, kept_total, max_all);
+}
+
+#include "shard_merge_free.h"
 
 // 7. global view of the real cells: every shard's rows, all-gathered; first_global = the stream ordinal of the cell's first read
 void dropest_shard::build_global_table() {
@@ -1764,8 +1835,7 @@ void dropest_shard::step() {
 	{ Phase ph(this, "pipeline"); c.run_set_initialized(); }
 	merged_barcodes.clear();
 	if ((c.cfg.merge_kind == DROPEST_MERGE_REAL_BARCODES || c.cfg.merge_kind == DROPEST_MERGE_POISSON_REAL) && world > 1) { Phase ph(this, "cb_merge"); cb_merge(); }
-	else if (c.cfg.merge_kind != DROPEST_MERGE_NONE && world > 1)
-		throw UnsupportedError("sharded runs support the merges with a barcode whitelist (-m, -M with barcodes) only; run the other merge strategies on one GPU");
+	else if (c.cfg.merge_kind != DROPEST_MERGE_NONE && world > 1) { Phase ph(this, "cb_merge"); cb_merge_free(); }
 	{ Phase ph(this, "finalize"); c.run_merge_and_filter(); }
 	merged_pending = world == 1 && c.cfg.merge_kind != DROPEST_MERGE_NONE;   // one shard: the context's own pairs, named when asked for
 	raw_device_now = plan_raw();

@@ -135,11 +135,260 @@ unsigned plain_edit_distance(const std::string &a, const std::string &b) {
 	return col[a.size()];
 }
 
+// ---- decisions shared by one context and the shards of a sharded run (shard_merge_free.h) --------------------------------------------------
+// What the decisions need to know about a cell.  `id` is whatever the pair table holds: the cell id of a context, the place in the
+// global cell list of a sharded run.
+struct SimpleCells {
+	std::function<size_t(u32)> umis, genes;           // Stats::TOTAL_UMIS, Cell::size()
+	std::function<std::string(u32)> barcode;          // text (edit distance of escaped codes; replay)
+	std::function<u32(u32)> slot;                     // base -> index into the caller's per-base arrays
+	std::function<u32(u32)> filtered_pos;             // place in the filtered order (a UMI-gene's cells are emplaced in that order)
+	std::function<size_t(u32)> container_id;          // index of the cell in the reference's container: the key of its unordered containers
+	std::function<u32(size_t)> from_container_id;
+};
+
+const double SIMPLE_EPS = 0.00001;                    // SimpleMergeStrategy::EPS
+
+int simple_pair_distance(const SimplePairs &P, size_t p, const SimpleCells &C) {
+	if (P.ed[p] != 0xFFFFFFFFu) return int(P.ed[p]);
+	return int(plain_edit_distance(C.barcode(u32(P.key[p] >> 32)), C.barcode(u32(P.key[p]))));
+}
+
+// SimpleMergeStrategy::get_merge_target (:47-86) / PoissonSimpleMergeStrategy::get_merge_target (PoissonSimpleMergeStrategy.cpp:15-43)
+// for the bases whose answer does not depend on the iteration order of common_umigs_per_cell; the others land in `replay`.
+// target[slot] is preset to the base itself.  expected(bases, others) = the estimator's expected intersections (-M only).
+void simple_decide(const dropest_cfg &cfg, bool poisson, SimplePairs &P, const SimpleCells &C,
+                   const std::function<std::vector<double>(const std::vector<u32> &, const std::vector<u32> &)> &expected,
+                   std::vector<u32> &target, std::vector<u32> &nb_count, std::vector<u32> &replay) {
+	const double EPS = SIMPLE_EPS;
+	const int max_ed = cfg.max_cb_merge_edit_distance;
+	// PoissonSimple: the neighbours are the cells with common UMI-genes within the edit distance (<=, not < as below); the shared
+	// count IS the intersection size
+	if (poisson) {
+		std::vector<u32> pb, pc; std::vector<size_t> at;
+		for (size_t p = 0; p < P.key.size(); ++p) {
+			const u32 base = u32(P.key[p] >> 32), other = u32(P.key[p]);
+			if (simple_pair_distance(P, p, C) > max_ed) continue;
+			pb.push_back(base); pc.push_back(other); at.push_back(p);
+			++nb_count[C.slot(base)];
+		}
+		const std::vector<double> ex = expected(pb, pc);
+		P.prob.assign(P.key.size(), 2.0);
+		for (size_t i = 0; i < at.size(); ++i) P.prob[at[i]] = poisson_upper_tail(long(P.cnt[at[i]]), ex[i]);
+	}
+	for (size_t p = 0; poisson && p < P.key.size();) {
+		const u32 base = u32(P.key[p] >> 32);
+		size_t e = p;
+		while (e < P.key.size() && u32(P.key[e] >> 32) == base) ++e;
+		const u32 f = C.slot(base);
+		if (nb_count[f]) {
+			// the base is never its own neighbour: PoissonTargetEstimator.cpp:17-22 takes max_real_cb_merge_prob / |neighbours|
+			const double limit = cfg.max_real_merge_prob / double(nb_count[f]);
+			double min_prob = 2; size_t n_min = 0, min_p = p;
+			for (size_t q = p; q < e; ++q) {
+				if (P.prob[q] < min_prob) { min_prob = P.prob[q]; n_min = 1; min_p = q; }
+				else if (P.prob[q] == min_prob && min_prob < 2) ++n_min;
+			}
+			if (min_prob > limit) { /* -1 -> the base itself (:39-42) */ }
+			else if (n_min == 1) target[f] = u32(P.key[min_p]);
+			else replay.push_back(base);                                     // first of the minima in the map's iteration order
+		}
+		p = e;
+	}
+	for (size_t p = 0; !poisson && p < P.key.size();) {
+		const u32 base = u32(P.key[p] >> 32);
+		size_t e = p;
+		while (e < P.key.size() && u32(P.key[e] >> 32) == base) ++e;
+		const u32 f = C.slot(base);
+		double best = -1; size_t best_p = p;
+		std::vector<double> frac(e - p, -1.0);                               // admissible candidates only
+		for (size_t q = p; q < e; ++q) {
+			const u32 other = u32(P.key[q]);
+			if (simple_pair_distance(P, q, C) >= max_ed) continue;
+			frac[q - p] = 0.5 * P.cnt[q] * (1. / C.umis(base) + 1. / C.umis(other));
+			if (frac[q - p] > best) { best = frac[q - p]; best_p = q; }
+		}
+		size_t near = 0;
+		for (double x : frac) near += x >= 0 && best - x <= 2 * EPS;
+		if (best < 0) { /* nobody within the edit distance: top stays -1, returns the base */ }
+		else if (near == 1) { if (!(best < cfg.min_merge_fraction)) target[f] = u32(P.key[best_p]); }
+		else replay.push_back(base);
+		p = e;
+	}
+}
+
+// One base with a near-tie, replayed with the reference's containers filled in the reference's order.  q_in_order = the base's
+// gene-bearing molecules in (gene index, UMI index) order -- the reference's nested std::map walk -- as indices into q_off / q_cnt;
+// members[q_off[q] .. + q_cnt[q]) = the cells of that molecule's UMI-gene.  Returns the target (the base itself: none).
+u32 simple_replay_base(const dropest_cfg &cfg, bool poisson, u32 base, const std::vector<u32> &q_in_order, const std::vector<u32> &members,
+                       const std::vector<u32> &q_off, const std::vector<u32> &q_cnt, const SimpleCells &C, const SimplePairs &P, u32 nb_count) {
+	const double EPS = SIMPLE_EPS;
+	const int max_ed = cfg.max_cb_merge_edit_distance;
+	const size_t base_size = C.genes(base), base_cid = C.container_id(base);
+	std::unordered_map<size_t, size_t> common;                       // u_u_hash_t common_umigs_per_cell (:19)
+	for (u32 q : q_in_order) {
+		// sul_set_t of this UMI-gene: cells emplaced in filtered order by init() (:88-102)
+		std::vector<u32> mem(members.begin() + q_off[q], members.begin() + q_off[q] + q_cnt[q]);
+		std::sort(mem.begin(), mem.end(), [&](u32 x, u32 y) { return C.filtered_pos(x) < C.filtered_pos(y); });
+		std::unordered_set<size_t> set;
+		for (u32 c : mem) set.emplace(C.container_id(c));
+		for (size_t other : set) {
+			if (other == base_cid) continue;
+			if (C.genes(C.from_container_id(other)) >= base_size) common[other]++;
+		}
+	}
+	if (poisson) {   // neighbours in the map's order; probabilities from the pair table (sorted by (base, other))
+		double min_prob = 2; long best = -1;
+		for (auto const &c : common) {
+			const u32 other = C.from_container_id(c.first);
+			const u64 key = (u64(base) << 32) | u64(other);
+			const size_t q = size_t(std::lower_bound(P.key.begin(), P.key.end(), key) - P.key.begin());
+			if (q >= P.key.size() || P.key[q] != key) throw DeviceError("internal: replayed neighbour without a pair record");
+			if (P.prob[q] >= 2) continue;                                // beyond the edit distance
+			if (P.prob[q] < min_prob) { min_prob = P.prob[q]; best = long(other); }
+		}
+		const double limit = cfg.max_real_merge_prob / double(nb_count);
+		return (best < 0 || min_prob > limit) ? base : u32(best);
+	}
+	long top = -1, top_genes = -1;
+	double top_frac = -1;
+	for (auto const &c : common) {
+		const u32 ind = C.from_container_id(c.first);
+		const double fr = 0.5 * c.second * (1. / C.umis(base) + 1. / C.umis(ind));
+		if (fr - top_frac > EPS || (std::abs(fr - top_frac) < EPS && long(C.genes(ind)) > top_genes)) {
+			const int ed = int(plain_edit_distance(C.barcode(base), C.barcode(ind)));
+			if (ed >= max_ed) continue;
+			top = long(ind); top_frac = fr; top_genes = long(C.genes(ind));
+		}
+	}
+	return (top_frac < cfg.min_merge_fraction || top < 0) ? base : u32(top);
+}
+
 }  // namespace
+
+// common_umigs_per_cell of every base from a sorted (UMI-gene, cell) table: ordered pairs per run, sorted, run-length encoded; distances
+// of the distinct pairs.  cell_size / cell_code are indexed like the cell field of the table.  With `d_run_key` the table stays on the
+// device (a sharded run routes the partial counts to the owners of the bases) and P is left empty.
+void dropest_ctx::simple_pair_table(const u64 *sorted, u32 n_valid, int cell_bits, const u32 *d_cell_size, const u64 *d_cell_code, SimplePairs &P,
+                                    dropest::DevBuf<u64> *d_run_key, dropest::DevBuf<u32> *d_run_cnt, u32 *n_runs) {
+	if (n_runs) *n_runs = 0;
+	if (!n_valid) return;
+	const u32 tiles = div_up(n_valid, SP_THREADS);
+	tile_counts.ensure(tiles); tile_prefix.ensure(tiles);
+	scalars.ensure(16);
+	SimplePairArgs pa{sorted, n_valid, cell_bits, d_cell_size, tile_prefix.p, tile_counts.p, nullptr};
+	timed("simple:umig_pairs", double(n_valid) * 16, [&] {
+		hipLaunchKernelGGL(umig_pairs_kernel<false>, dim3(tiles), dim3(SP_THREADS), 0, stream, pa);
+		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, tile_counts.p, tile_prefix.p, tiles, scalars.p);
+	});
+	u32 NP = 0;
+	fetch(&NP, scalars.p, 4);
+	// (scan_small sums in 32 bits: refuse inputs whose pair count could have wrapped)
+	if (NP > 0xF0000000u) throw UnsupportedError("more than 2^32 shared UMI-gene pairs");
+	if (!NP) return;
+	DevBuf<u64> p_a, p_b; DevBuf<u32> dummy_a, dummy_b;
+	p_a.alloc(NP); p_b.alloc(NP); dummy_a.alloc(1); dummy_b.alloc(1);
+	pa.pairs = p_a.p;
+	timed("simple:umig_pairs", double(NP) * 8, [&] {
+		hipLaunchKernelGGL(umig_pairs_kernel<true>, dim3(tiles), dim3(SP_THREADS), 0, stream, pa);
+	});
+	u64 *pk = p_a.p, *pk_alt = p_b.p;
+	u32 *pv = dummy_a.p, *pv_alt = dummy_b.p;
+	radix_sort(pk, pv, pk_alt, pv_alt, NP, (((1ull << cell_bits) - 1ull) << 32) | ((1ull << cell_bits) - 1ull), 0);
+	UmiRuns rp{};
+	rp.keys = pk;
+	DevBuf<u64> run_key_own; DevBuf<u32> run_cnt_own, run_ed;
+	DevBuf<u64> &run_key = d_run_key ? *d_run_key : run_key_own;
+	DevBuf<u32> &run_cnt = d_run_cnt ? *d_run_cnt : run_cnt_own;
+	const u32 runs = run_segmented_reduce(*this, "simple:pair_runs", rp, NP, 8, [&](u32 total) {
+		run_key.alloc(total + 1); run_cnt.alloc(total + 1);
+		zero_async(*this, run_cnt.p, size_t(total + 1) * 4);
+		rp.run_key = run_key.p; rp.out[0] = run_cnt.p;
+	});
+	if (n_runs) *n_runs = runs;
+	if (d_run_key) { HIP_CHECK(stream_wait(stream)); return; }   // (p_a / p_b die with this scope)
+	simple_pairs_to_host(run_key.p, run_cnt.p, runs, d_cell_code, P);
+}
+
+// distances of the distinct pairs on the device, then everything to the host
+void dropest_ctx::simple_pairs_to_host(const u64 *d_run_key, const u32 *d_run_cnt, u32 runs, const u64 *d_cell_code, SimplePairs &P) {
+	P.key.resize(runs); P.cnt.resize(runs); P.ed.resize(runs);
+	if (!runs) return;
+	DevBuf<u32> run_ed;
+	run_ed.alloc(runs);
+	timed("simple:pair_distance", double(runs) * 28, [&] {
+		hipLaunchKernelGGL(pair_distance_kernel, dim3(div_up(runs, 256)), dim3(256), 0, stream, reinterpret_cast<const unsigned long long *>(d_run_key), runs,
+		                   reinterpret_cast<const unsigned long long *>(d_cell_code), run_ed.p);
+	});
+	fetch(P.key.data(), d_run_key, size_t(runs) * 8);
+	fetch(P.cnt.data(), d_run_cnt, size_t(runs) * 4);
+	fetch(P.ed.data(), run_ed.p, size_t(runs) * 4);
+}
+
+// The gene-bearing molecules of the replayed bases (local cells) in the reference's walk order: query[] = their (gene | UMI) fields,
+// in_order[r] = indices into query of base r's molecules in (gene index, UMI index) order.  The UMI index is the order of first
+// occurrence in the WHOLE stream: a sharded run (globalize) turns the table of first positions into global ranks -- a collective, so
+// every shard calls this, with an empty list when it has nothing to replay.
+void dropest_ctx::simple_replay_local(const std::vector<u32> &bases, SimpleReplayInput &R, bool globalize) {
+	if (layout.umi_bits > 28) throw UnsupportedError("tie replay of the simple merge needs a UMI field of at most 28 bits");
+	const size_t table = size_t(1) << layout.umi_bits;
+	umi_first.ensure(table);
+	HIP_CHECK(hipMemsetAsync(umi_first.p, 0xFF, table * 4, stream));
+	const u32 n = u32(n_reads);
+	need_columns();   // (a sharded run's reads may still be packed records)
+	if (n) timed("umi_first_table", double(n) * 12, [&] {
+		hipLaunchKernelGGL(umi_first_table_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n, layout, umi_first.p);
+	});
+	if (globalize) {
+		if (!hooks || !hooks->globalize_umi_first) throw InvalidError("internal: a sharded replay without the shard hooks");
+		hooks->globalize_umi_first(umi_first.p, table);
+	}
+	R.query.clear(); R.in_order.assign(bases.size(), {});
+	if (bases.empty()) return;
+	// molecules of the replayed bases: (cell, gene) rows of each base are contiguous
+	std::vector<u32> groups;                                             // cg rows of all replayed bases
+	std::vector<u32> cgb(bases.size()), cgc(bases.size());
+	{
+		DevBuf<u32> d_ids, d_b, d_c;
+		d_ids.alloc(bases.size()); d_b.alloc(bases.size()); d_c.alloc(bases.size());
+		HIP_CHECK(hipMemcpyAsync(d_ids.p, bases.data(), bases.size() * 4, hipMemcpyHostToDevice, stream));
+		hipLaunchKernelGGL(gather_u32_kernel, dim3(div_up(u32(bases.size()), 256)), dim3(256), 0, stream, cell_cg_begin.p, d_ids.p, u32(bases.size()), d_b.p);
+		hipLaunchKernelGGL(gather_u32_kernel, dim3(div_up(u32(bases.size()), 256)), dim3(256), 0, stream, cell_cg_count.p, d_ids.p, u32(bases.size()), d_c.p);
+		HIP_CHECK(hipGetLastError());
+		fetch(cgb.data(), d_b.p, bases.size() * 4);
+		fetch(cgc.data(), d_c.p, bases.size() * 4);
+	}
+	std::vector<size_t> first_group(bases.size() + 1, 0);
+	for (size_t r = 0; r < bases.size(); ++r) {
+		for (u32 j = 0; j < cgc[r]; ++j) groups.push_back(cgb[r] + j);
+		first_group[r + 1] = groups.size();
+	}
+	GatheredGroups GG;
+	umi_gather_groups(groups, GG, umi_first.p);
+	// queries: the (gene | UMI) fields of those molecules (gene-less rows are skipped below)
+	const u64 low_mask = (1ull << (layout.umi_bits + layout.gene_bits)) - 1ull;
+	R.query.resize(GG.hk.size());
+	for (size_t i = 0; i < R.query.size(); ++i) R.query[i] = GG.hk[i] & low_mask;
+	for (size_t r = 0; r < bases.size(); ++r) {
+		// molecules of the base in (gene index, UMI index) order = the reference's nested std::map walk
+		struct Q { u64 gene; u32 first; u32 q; };
+		std::vector<Q> qs;
+		for (size_t gi = first_group[r]; gi < first_group[r + 1]; ++gi)
+			for (u32 t = 0; t < GG.size[gi]; ++t) {
+				const u32 q = GG.off[gi] + t;
+				const u64 gene = (GG.hk[q] >> layout.umi_bits) & layout.gene_none;
+				if (gene == layout.gene_none) continue;
+				qs.push_back(Q{gene, GG.hfirst[q], q});
+			}
+		std::sort(qs.begin(), qs.end(), [](const Q &x, const Q &y) { return x.gene != y.gene ? x.gene < y.gene : x.first < y.first; });
+		R.in_order[r].reserve(qs.size());
+		for (const Q &q : qs) R.in_order[r].push_back(q.q);
+	}
+}
+
 
 void dropest_ctx::run_cb_merge_simple() {
 	HostStage hs(this, "cb_merge");
-	const double EPS = 0.00001;                                  // SimpleMergeStrategy::EPS
 	const std::vector<uint64_t> &order = filtered_cells();
 	std::vector<u32> cells(order.begin(), order.end());
 	const std::vector<u32> ridx = filtered_ridx;
@@ -174,160 +423,36 @@ void dropest_ctx::run_cb_merge_simple() {
 	}
 
 	// 2. shared UMI-genes: ordered pairs per run, sorted, run-length encoded
-	std::vector<u64> pair_key; std::vector<u32> pair_cnt, pair_ed;
-	if (n_valid) {
-		const u32 tiles = div_up(n_valid, SP_THREADS);
-		tile_counts.ensure(tiles); tile_prefix.ensure(tiles);
-		SimplePairArgs pa{sorted, n_valid, layout.cell_bits, cell_n_genes.p, tile_prefix.p, tile_counts.p, nullptr};
-		timed("simple:umig_pairs", double(n_valid) * 16, [&] {
-			hipLaunchKernelGGL(umig_pairs_kernel<false>, dim3(tiles), dim3(SP_THREADS), 0, stream, pa);
-			hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, tile_counts.p, tile_prefix.p, tiles, scalars.p);
-		});
-		u32 P = 0;
-		fetch(&P, scalars.p, 4);
-		// (scan_small sums in 32 bits: refuse inputs whose pair count could have wrapped)
-		if (P > 0xF0000000u) throw UnsupportedError("more than 2^32 shared UMI-gene pairs");
-		if (P) {
-			DevBuf<u64> p_a, p_b; DevBuf<u32> dummy_a, dummy_b;
-			p_a.alloc(P); p_b.alloc(P); dummy_a.alloc(1); dummy_b.alloc(1);
-			pa.pairs = p_a.p;
-			timed("simple:umig_pairs", double(P) * 8, [&] {
-				hipLaunchKernelGGL(umig_pairs_kernel<true>, dim3(tiles), dim3(SP_THREADS), 0, stream, pa);
-			});
-			u64 *pk = p_a.p, *pk_alt = p_b.p;
-			u32 *pv = dummy_a.p, *pv_alt = dummy_b.p;
-			const int cb = layout.cell_bits;
-			radix_sort(pk, pv, pk_alt, pv_alt, P, (((1ull << cb) - 1ull) << 32) | ((1ull << cb) - 1ull), 0);
-			UmiRuns rp{};
-			rp.keys = pk;
-			DevBuf<u64> run_key; DevBuf<u32> run_cnt, run_ed;
-			const u32 runs = run_segmented_reduce(*this, "simple:pair_runs", rp, P, 8, [&](u32 total) {
-				run_key.alloc(total + 1); run_cnt.alloc(total + 1);
-				zero_async(*this, run_cnt.p, size_t(total + 1) * 4);
-				rp.run_key = run_key.p; rp.out[0] = run_cnt.p;
-			});
-			run_ed.alloc(runs);
-			timed("simple:pair_distance", double(runs) * 28, [&] {
-				hipLaunchKernelGGL(pair_distance_kernel, dim3(div_up(runs, 256)), dim3(256), 0, stream, run_key.p, runs, cell_cb.p, run_ed.p);
-			});
-			pair_key.resize(runs); pair_cnt.resize(runs); pair_ed.resize(runs);
-			fetch(pair_key.data(), run_key.p, size_t(runs) * 8);
-			fetch(pair_cnt.data(), run_cnt.p, size_t(runs) * 4);
-			fetch(pair_ed.data(), run_ed.p, size_t(runs) * 4);
-		}
-	}
+	SimplePairs P;
+	simple_pair_table(sorted, n_valid, layout.cell_bits, cell_n_genes.p, cell_cb.p, P, nullptr, nullptr);
 
-	// 3. decisions (SimpleMergeStrategy::get_merge_target, :47-86) for the bases whose answer does not depend on the
-	//    iteration order of common_umigs_per_cell
-	std::vector<int64_t> target(F);
-	for (u32 f = 0; f < F; ++f) target[f] = int64_t(ridx[f]);                // no candidate: the cell itself
-	std::vector<u32> replay;
-	const int max_ed = cfg.max_cb_merge_edit_distance;
-	auto umis_of = [&](u32 cell) { return size_t(real[real_at(cell)].row.total_umis); };
-	auto ed_of = [&](size_t p, u32 base, u32 other) {
-		if (pair_ed[p] != 0xFFFFFFFFu) return int(pair_ed[p]);
-		return int(plain_edit_distance(barcode_of(real[real_at(base)]), barcode_of(real[real_at(other)])));
-	};
-	// PoissonSimpleMergeStrategy::get_merge_target (PoissonSimpleMergeStrategy.cpp:15-43): the neighbours are the cells
-	// with common UMI-genes within the edit distance (<=, not < as above); the shared count IS the intersection size
+	// 3. decisions for the bases whose answer does not depend on the iteration order of common_umigs_per_cell
+	SimpleCells C;
+	C.umis = [&](u32 cell) { return size_t(real[real_at(cell)].row.total_umis); };
+	C.genes = [&](u32 cell) { return size_t(real[real_at(cell)].row.n_genes); };
+	C.barcode = [&](u32 cell) { return barcode_of(real[real_at(cell)]); };
+	C.slot = [&](u32 cell) { return rank_of[cell]; };
+	C.filtered_pos = [&](u32 cell) { return rank_of[cell]; };
+	C.container_id = [](u32 cell) { return size_t(cell); };
+	C.from_container_id = [](size_t id) { return u32(id); };
 	const bool poisson = cfg.merge_kind == DROPEST_MERGE_POISSON_SIMPLE;
-	std::vector<double> pair_prob;                                           // per pair; 2 = not a neighbour
-	std::vector<u32> nb_count(F, 0);
-	if (poisson) {
-		std::vector<u32> pb, pc; std::vector<size_t> at;
-		for (size_t p = 0; p < pair_key.size(); ++p) {
-			const u32 base = u32(pair_key[p] >> 32), other = u32(pair_key[p]);
-			if (ed_of(p, base, other) > max_ed) continue;
-			pb.push_back(base); pc.push_back(other); at.push_back(p);
-			++nb_count[rank_of[base]];
-		}
-		const std::vector<double> expected = poisson_expected_intersections(pb, pc);
+	std::vector<u32> tgt_id(cells), nb_count(F, 0), replay;
+	simple_decide(cfg, poisson, P, C, [&](const std::vector<u32> &pb, const std::vector<u32> &pc) {
+		std::vector<double> ex = poisson_expected_intersections(pb, pc);
 		if (sorted_keep.p) sorted = sorted_keep.p;
-		pair_prob.assign(pair_key.size(), 2.0);
-		for (size_t i = 0; i < at.size(); ++i) pair_prob[at[i]] = poisson_upper_tail(long(pair_cnt[at[i]]), expected[i]);
-	}
-	for (size_t p = 0; poisson && p < pair_key.size();) {
-		const u32 base = u32(pair_key[p] >> 32);
-		size_t e = p;
-		while (e < pair_key.size() && u32(pair_key[e] >> 32) == base) ++e;
-		const u32 f = rank_of[base];
-		if (nb_count[f]) {
-			// the base is never its own neighbour: PoissonTargetEstimator.cpp:17-22 takes max_real_cb_merge_prob / |neighbours|
-			const double limit = cfg.max_real_merge_prob / double(nb_count[f]);
-			double min_prob = 2; size_t n_min = 0, min_p = p;
-			for (size_t q = p; q < e; ++q) {
-				if (pair_prob[q] < min_prob) { min_prob = pair_prob[q]; n_min = 1; min_p = q; }
-				else if (pair_prob[q] == min_prob && min_prob < 2) ++n_min;
-			}
-			if (min_prob > limit) { /* -1 -> the base itself (:39-42) */ }
-			else if (n_min == 1) target[f] = int64_t(real_at(u32(pair_key[min_p])));
-			else replay.push_back(f);                                        // first of the minima in the map's iteration order
-		}
-		p = e;
-	}
-	for (size_t p = 0; !poisson && p < pair_key.size();) {
-		const u32 base = u32(pair_key[p] >> 32);
-		size_t e = p;
-		while (e < pair_key.size() && u32(pair_key[e] >> 32) == base) ++e;
-		const u32 f = rank_of[base];
-		double best = -1; size_t best_p = p;
-		std::vector<double> frac(e - p, -1.0);                               // admissible candidates only
-		for (size_t q = p; q < e; ++q) {
-			const u32 other = u32(pair_key[q]);
-			if (ed_of(q, base, other) >= max_ed) continue;
-			frac[q - p] = 0.5 * pair_cnt[q] * (1. / umis_of(base) + 1. / umis_of(other));
-			if (frac[q - p] > best) { best = frac[q - p]; best_p = q; }
-		}
-		size_t near = 0;
-		for (double x : frac) near += x >= 0 && best - x <= 2 * EPS;
-		if (best < 0) { /* nobody within the edit distance: top stays -1, returns the base */ }
-		else if (near == 1) { if (!(best < cfg.min_merge_fraction)) target[f] = int64_t(real_at(u32(pair_key[best_p]))); }
-		else replay.push_back(f);
-		p = e;
-	}
+		return ex;
+	}, tgt_id, nb_count, replay);
 
 	// 4. replay of the bases with near-ties: same containers, same insertion order as the reference
 	if (!replay.empty()) {
 		HostStage hs2(this, "cb_merge:replay");
-		if (layout.umi_bits > 28) throw UnsupportedError("tie replay of the simple merge needs a UMI field of at most 28 bits");
-		const size_t table = size_t(1) << layout.umi_bits;
-		umi_first.ensure(table);
-		HIP_CHECK(hipMemsetAsync(umi_first.p, 0xFF, table * 4, stream));
-		const u32 n = u32(n_reads);
-		need_columns();   // (a sharded run's reads may still be packed records)
-		timed("umi_first_table", double(n) * 12, [&] {
-			hipLaunchKernelGGL(umi_first_table_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n, layout, umi_first.p);
-		});
-		// molecules of the replayed bases: (cell, gene) rows of each base are contiguous
-		std::vector<u32> groups;                                             // cg rows of all replayed bases
-		std::vector<u32> cgb(replay.size()), cgc(replay.size());
-		{
-			std::vector<u32> ids(replay.size());
-			for (size_t r = 0; r < replay.size(); ++r) ids[r] = cells[replay[r]];
-			DevBuf<u32> d_ids, d_b, d_c;
-			d_ids.alloc(ids.size()); d_b.alloc(ids.size()); d_c.alloc(ids.size());
-			HIP_CHECK(hipMemcpyAsync(d_ids.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, stream));
-			hipLaunchKernelGGL(gather_u32_kernel, dim3(div_up(u32(ids.size()), 256)), dim3(256), 0, stream, cell_cg_begin.p, d_ids.p, u32(ids.size()), d_b.p);
-			hipLaunchKernelGGL(gather_u32_kernel, dim3(div_up(u32(ids.size()), 256)), dim3(256), 0, stream, cell_cg_count.p, d_ids.p, u32(ids.size()), d_c.p);
-			HIP_CHECK(hipGetLastError());
-			fetch(cgb.data(), d_b.p, ids.size() * 4);
-			fetch(cgc.data(), d_c.p, ids.size() * 4);
-		}
-		std::vector<size_t> first_group(replay.size() + 1, 0);
-		for (size_t r = 0; r < replay.size(); ++r) {
-			for (u32 j = 0; j < cgc[r]; ++j) groups.push_back(cgb[r] + j);
-			first_group[r + 1] = groups.size();
-		}
-		GatheredGroups GG;
-		umi_gather_groups(groups, GG, umi_first.p);
-		// queries: the (gene | UMI) fields of those molecules (gene-less rows are skipped below)
-		const u64 low_mask = (1ull << low_bits) - 1ull;
-		std::vector<u64> query(GG.hk.size());
-		for (size_t i = 0; i < query.size(); ++i) query[i] = GG.hk[i] & low_mask;
-		const u32 nq = u32(query.size());
+		SimpleReplayInput R;
+		simple_replay_local(replay, R, false);
+		// members of every queried UMI-gene
+		const u32 nq = u32(R.query.size());
 		DevBuf<u64> d_q; DevBuf<u32> d_cnt, d_off, d_cells;
 		d_q.alloc(nq); d_cnt.alloc(nq); d_off.alloc(nq);
-		HIP_CHECK(hipMemcpyAsync(d_q.p, query.data(), size_t(nq) * 8, hipMemcpyHostToDevice, stream));
+		HIP_CHECK(hipMemcpyAsync(d_q.p, R.query.data(), size_t(nq) * 8, hipMemcpyHostToDevice, stream));
 		hipLaunchKernelGGL(umig_members_kernel, dim3(div_up(nq, 256)), dim3(256), 0, stream, sorted, n_valid, layout.cell_bits, d_q.p, nq,
 		                   static_cast<const u32 *>(nullptr), d_cnt.p, static_cast<u32 *>(nullptr));
 		HIP_CHECK(hipGetLastError());
@@ -343,60 +468,11 @@ void dropest_ctx::run_cb_merge_simple() {
 		HIP_CHECK(hipGetLastError());
 		std::vector<u32> members(total);
 		fetch(members.data(), d_cells.p, size_t(total) * 4);
-
-		for (size_t r = 0; r < replay.size(); ++r) {
-			const u32 f = replay[r], base = cells[f];
-			const size_t base_size = real[ridx[f]].row.n_genes;
-			// molecules of the base in (gene index, UMI index) order = the reference's nested std::map walk
-			struct Q { u64 gene; u32 first; u32 q; };
-			std::vector<Q> qs;
-			for (size_t gi = first_group[r]; gi < first_group[r + 1]; ++gi)
-				for (u32 t = 0; t < GG.size[gi]; ++t) {
-					const u32 q = GG.off[gi] + t;
-					const u64 gene = (GG.hk[q] >> layout.umi_bits) & layout.gene_none;
-					if (gene == layout.gene_none) continue;
-					qs.push_back(Q{gene, GG.hfirst[q], q});
-				}
-			std::sort(qs.begin(), qs.end(), [](const Q &x, const Q &y) { return x.gene != y.gene ? x.gene < y.gene : x.first < y.first; });
-			std::unordered_map<size_t, size_t> common;                       // u_u_hash_t common_umigs_per_cell (:19)
-			for (const Q &q : qs) {
-				// sul_set_t of this UMI-gene: cells emplaced in filtered order by init() (:88-102)
-				std::vector<u32> mem(members.begin() + q_off[q.q], members.begin() + q_off[q.q] + q_cnt[q.q]);
-				std::sort(mem.begin(), mem.end(), [&](u32 x, u32 y) { return rank_of[x] < rank_of[y]; });
-				std::unordered_set<size_t> set;
-				for (u32 c : mem) set.emplace(size_t(c));
-				for (size_t other : set) {
-					if (other == base) continue;
-					if (size_t(real[real_at(u32(other))].row.n_genes) >= base_size) common[other]++;
-				}
-			}
-			if (poisson) {   // neighbours in the map's order; probabilities from the pair table (sorted by (base, other))
-				double min_prob = 2; long best = -1;
-				for (auto const &c : common) {
-					const u64 key = (u64(base) << 32) | u64(c.first);
-					const size_t q = size_t(std::lower_bound(pair_key.begin(), pair_key.end(), key) - pair_key.begin());
-					if (q >= pair_key.size() || pair_key[q] != key) throw DeviceError("internal: replayed neighbour without a pair record");
-					if (pair_prob[q] >= 2) continue;                             // beyond the edit distance
-					if (pair_prob[q] < min_prob) { min_prob = pair_prob[q]; best = long(c.first); }
-				}
-				const double limit = cfg.max_real_merge_prob / double(nb_count[f]);
-				target[f] = (best < 0 || min_prob > limit) ? int64_t(ridx[f]) : int64_t(real_at(u32(best)));
-				continue;
-			}
-			long top = -1, top_genes = -1;
-			double top_frac = -1;
-			for (auto const &c : common) {
-				const u32 ind = u32(c.first);
-				const double fr = 0.5 * c.second * (1. / umis_of(base) + 1. / umis_of(ind));
-				if (fr - top_frac > EPS || (std::abs(fr - top_frac) < EPS && long(real[real_at(ind)].row.n_genes) > top_genes)) {
-					const int ed = int(plain_edit_distance(barcode_of(real[real_at(base)]), barcode_of(real[real_at(ind)])));
-					if (ed >= max_ed) continue;
-					top = long(ind); top_frac = fr; top_genes = long(real[real_at(ind)].row.n_genes);
-				}
-			}
-			target[f] = (top_frac < cfg.min_merge_fraction || top < 0) ? int64_t(ridx[f]) : int64_t(real_at(u32(top)));
-		}
+		for (size_t r = 0; r < replay.size(); ++r)
+			tgt_id[rank_of[replay[r]]] = simple_replay_base(cfg, poisson, replay[r], R.in_order[r], members, q_off, q_cnt, C, P, nb_count[rank_of[replay[r]]]);
 	}
+	std::vector<int64_t> target(F);
+	for (u32 f = 0; f < F; ++f) target[f] = int64_t(real_at(tgt_id[f]));
 
 	// 5. MergeStrategyBase::merge_inited second loop on the same flat arrays as the whitelist merge
 	HostStage hs3(this, "cb_merge:apply");

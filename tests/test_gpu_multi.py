@@ -120,6 +120,107 @@ def test_sharded_poisson_whitelist_merge_matches_single_context(case, world):
     assert not np.array_equal(plain.merge_targets(), c.merge_targets())
 
 
+FREE_CASES = {
+    # name: (stream, configuration): the parity cases of tests/test_gpu_parity.py for the same strategies on one context
+    "plain": (dict(n_reads=150_000 * SCALE, n_cells=25 * SCALE, n_genes=1200, umi_len=8, permille_neighbour=150),
+              dict(max_cb_merge_edit_distance=2, min_merge_fraction=0.2, min_genes_before_merge=3, min_genes_after_merge=10)),
+    "collisions": (dict(n_reads=150_000 * SCALE, n_cells=25 * SCALE, n_genes=1200, umi_len=5, permille_neighbour=150),
+                   dict(max_cb_merge_edit_distance=3, min_merge_fraction=0.05, min_genes_before_merge=3, min_genes_after_merge=10)),
+    "ties": (dict(n_reads=60_000 * SCALE, n_cells=12 * SCALE, n_genes=40, umi_len=3, permille_neighbour=250),
+             dict(max_cb_merge_edit_distance=17, min_merge_fraction=0.0, min_genes_before_merge=1, min_genes_after_merge=1)),
+}
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("case", sorted(FREE_CASES))
+def test_sharded_simple_merge_matches_single_context(case, world):
+    """-m without a whitelist (SimpleMergeStrategy.cpp:16-108) over shards: the UMI-gene index sharded by hash(UMI-gene), partial pair
+    counts routed to the owners of the bases, near-ties replayed with the reference's containers over GLOBAL cell indices and the global
+    UMI order.  Same targets, same matrices as one context."""
+    kw, cfg = FREE_CASES[case]
+    arrays = parity.canonical_stream(*SynthStream(**kw).generate_host())
+    ckw = dict(cfg, merge_kind=capi.MERGE_SIMPLE)
+    got = run_group(world, arrays, ckw)
+    c = single(arrays, ckw)
+    want = check(got, c)
+    assert len(want) > (300 if case != "ties" else 20)
+    owner = lambda b: capi.lib().dropest_owner_of(int(b), world)           # noqa: E731
+    assert sum(owner(a) != owner(b) for a, b in want.items()) > 5          # the merge really crossed shards
+    if case == "ties":
+        assert "cbm:replay" in got["phases"]                               # the replay ran across the shards
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("max_ed", [1, 2, 4])
+def test_sharded_merge_all_matches_single_context(max_ed, world):
+    """merge_type = all (MergeAllMergeStrategy.h:16-50) over shards: every shard decides its own cells against the barcodes of all."""
+    s = SynthStream(n_reads=150_000 * SCALE, whitelist="10x_aug_2016_split", n_cells=30 * SCALE, n_genes=1500, umi_len=10, permille_neighbour=150)
+    arrays = parity.canonical_stream(*s.generate_host())
+    ckw = dict(merge_kind=capi.MERGE_ALL, max_cb_merge_edit_distance=max_ed, min_genes_before_merge=3, min_genes_after_merge=10)
+    got = run_group(world, arrays, ckw)
+    want = check(got, single(arrays, ckw))
+    assert len(want) > 20
+    owner = lambda b: capi.lib().dropest_owner_of(int(b), world)           # noqa: E731
+    assert sum(owner(a) != owner(b) for a, b in want.items()) > 5
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("max_ed,p_real,umi_len", [(2, 1e-7, 10), (1, 1e-3, 8), (3, 0.5, 8)])
+def test_sharded_poisson_simple_merge_matches_single_context(max_ed, p_real, umi_len, world):
+    """-M without a whitelist (PoissonSimpleMergeStrategy.cpp:15-43) over shards: pairs from the sharded UMI-gene index, the estimator's
+    tables from the UMI distribution of all shards, every pair's expected intersection computed where the neighbour lives."""
+    s = SynthStream(n_reads=150_000 * SCALE, whitelist="10x_aug_2016_split", n_cells=30 * SCALE, n_genes=1500, umi_len=umi_len, permille_neighbour=150)
+    arrays = parity.canonical_stream(*s.generate_host())
+    ckw = dict(merge_kind=capi.MERGE_POISSON_SIMPLE, max_cb_merge_edit_distance=max_ed, max_real_merge_prob=p_real, min_genes_before_merge=3,
+               min_genes_after_merge=10)
+    got = run_group(world, arrays, ckw)
+    want = check(got, single(arrays, ckw))
+    assert len(want) > 20
+    owner = lambda b: capi.lib().dropest_owner_of(int(b), world)           # noqa: E731
+    assert sum(owner(a) != owner(b) for a, b in want.items()) > 5
+
+
+def test_sharded_poisson_simple_merge_with_ties():
+    """Few UMIs and genes: equal probabilities, the first neighbour in the reference's map order wins -- replayed across three shards."""
+    kw, _ = FREE_CASES["ties"]
+    arrays = parity.canonical_stream(*SynthStream(**kw).generate_host())
+    ckw = dict(merge_kind=capi.MERGE_POISSON_SIMPLE, max_cb_merge_edit_distance=17, max_real_merge_prob=0.9, min_genes_before_merge=1,
+               min_genes_after_merge=1)
+    got = run_group(3, arrays, ckw)
+    check(got, single(arrays, ckw))
+
+
+def _barcodes_with_n(cb, seed, n_chosen=25, min_reads=150):
+    """40 % of the reads of some busy barcodes get one N-variant of it (an escaped code): a smaller cell next to the original one."""
+    rng = np.random.default_rng(seed)
+    codes, counts = np.unique(cb, return_counts=True)
+    busy = codes[counts >= min_reads]
+    chosen = rng.choice(busy, min(n_chosen, len(busy)), replace=False)
+    side = []
+    cb = cb.copy()
+    for c in chosen:
+        s = capi.unpack_code(int(c))
+        p = int(rng.integers(0, len(s)))
+        side.append(s[:p] + "N" + s[p + 1:])
+        where = np.flatnonzero(cb == c)
+        cb[where[:int(len(where) * 0.4)]] = capi.ESCAPE | (len(side) - 1)
+    return cb, side
+
+
+@pytest.mark.parametrize("kind", ["all", "simple"])
+def test_sharded_free_merges_with_n_in_barcodes(kind):
+    """Barcodes with N (escaped codes): the host comparison of merge_type = all, the host edit distance of the simple merge; two shards."""
+    s = SynthStream(n_reads=120_000, whitelist="10x_aug_2016_split", n_cells=20, n_genes=800, umi_len=8, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    cb, side = _barcodes_with_n(cb, 4, n_chosen=12)
+    arrays = parity.canonical_stream(cb, umi, gene, aux)
+    ckw = dict(merge_kind=capi.MERGE_ALL if kind == "all" else capi.MERGE_SIMPLE, max_cb_merge_edit_distance=2, min_genes_before_merge=3,
+               min_genes_after_merge=10)
+    got = run_group(2, arrays, ckw, side=side)
+    want = check(got, single(arrays, ckw, side=side))
+    assert len(want) > 10
+
+
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("rate,n_reads", [(1e-2, 120_000), (1e-3, 600_000)])
 def test_n_umis_across_shards(world, rate, n_reads):
@@ -505,7 +606,7 @@ def test_umi_qualities_travel_with_the_reads(world, variant):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("poisson", [False, True])
+@pytest.mark.parametrize("poisson", [False, True, "simple", "all"])
 def test_umi_qualities_follow_a_barcode_merge_across_shards(world, poisson):
     """-m / -M with a whitelist and UMI qualities over 2 / 3 shards: the sums rows of the molecules that change shards travel with them; a
     molecule the target already has keeps the target's sums, one that only merged cells had takes those of the first of them in merge
@@ -515,8 +616,12 @@ def test_umi_qualities_follow_a_barcode_merge_across_shards(world, poisson):
     cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
     qual = np.random.default_rng(78).integers(33, 75, size=(len(cb), 6), dtype=np.uint8)
     ckw = cfg_kwargs(dict(cfg, merge={"barcodes_kind": kind, "barcodes_file": os.path.join(DATA, wl)}))
-    if poisson:
+    if poisson is True:
         ckw.update(merge_kind=capi.MERGE_POISSON_REAL)
+    elif poisson == "simple":   # (the whitelist-free merges share the travel of the sums rows: shard_merge_free.h)
+        ckw = dict(merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=2, min_merge_fraction=0.1, min_genes_before_merge=3, min_genes_after_merge=20)
+    elif poisson == "all":
+        ckw = dict(merge_kind=capi.MERGE_ALL, max_cb_merge_edit_distance=2, min_genes_before_merge=3, min_genes_after_merge=20)
     c = capi.Context(**ckw)
     c.push_reads(cb, umi, gene, aux)
     c.set_umi_qualities(qual)

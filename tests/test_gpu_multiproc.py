@@ -112,3 +112,21 @@ def test_processes_whitelist_merge_across_shards():
     got = run_processes(2, arrays, kw)
     want = check(got, arrays, kw)
     assert len(want) > 20
+
+
+@pytest.mark.parametrize("kind", ["simple", "poisson_simple", "all"])
+def test_processes_whitelist_free_merges_across_shards(kind):
+    """-m / -M without a whitelist and merge_type = all over three processes: the UMI-gene index, the partial pair counts and the replay
+    queries cross process borders through the transport's all-to-all and the mailbox (csrc/shard_merge_free.h)."""
+    if kind == "simple":   # few UMIs and genes: near-ties, replayed with global cell indices
+        s = SynthStream(n_reads=60_000, n_cells=12, n_genes=40, umi_len=3, permille_neighbour=250)
+        kw = dict(merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=17, min_merge_fraction=0.0, min_genes_before_merge=1, min_genes_after_merge=1)
+    else:
+        s = SynthStream(n_reads=150_000, whitelist="10x_aug_2016_split", n_cells=30, n_genes=1500, umi_len=8, permille_neighbour=150)
+        kw = dict(merge_kind=capi.MERGE_POISSON_SIMPLE if kind == "poisson_simple" else capi.MERGE_ALL, max_cb_merge_edit_distance=2,
+                  max_real_merge_prob=1e-3, min_genes_before_merge=3, min_genes_after_merge=10)
+    arrays = parity.canonical_stream(*s.generate_host())
+    got = run_processes(3, arrays, kw)
+    want = check(got, arrays, kw)
+    assert len(want) > 20
+
