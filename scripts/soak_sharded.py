@@ -1,5 +1,6 @@
 """Differential soak of the sharded runner: random streams cut into ragged contiguous ranges (empty shards included) over 2-8 shards
-on one GPU, with and without the whitelist merge (-m / -M), N-UMIs, UMI qualities, in the three matrix forms and with cm_raw planned
+on one GPU, with and without the barcode merges (-m / -M with the whitelist; Simple, PoissonSimple and merge-all without one), N-UMIs,
+-u, UMI qualities, in the three matrix forms and with cm_raw planned
 on the device or on the host -- every observable equal to ONE context over the same stream.
 usage: soak_sharded.py [iterations] [seed] [max_reads]"""
 import os, sys, time
@@ -15,6 +16,7 @@ DATA = os.path.join(ROOT, "dropest_amd", "data", "barcodes")
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260929)
 max_reads = int(float(sys.argv[3])) if len(sys.argv) > 3 else 3_000_000
+FREE = os.environ.get("SOAK_FREE_ONLY")   # only the merges without a whitelist
 
 
 def single(arrays, kw, side, qual):
@@ -44,18 +46,29 @@ def molecule_table(ctx, ql):
 fails = 0
 for it in range(iters):
     n = int(rng.integers(20_000, max_reads))
-    merge = int(rng.integers(0, 3))                     # 0 none, 1 -m, 2 -M (both with the whitelist)
+    merge = int(rng.integers(0, 6)) if FREE is None else int(rng.choice([3, 4, 5]))   # 0 none, 1 -m, 2 -M (whitelist); 3 Simple, 4 PoissonSimple, 5 all
+    free = merge >= 3
     indrop = merge and rng.random() < 0.5
+    tiny = free and rng.random() < 0.4                  # few UMIs and genes: near-ties, replays with the reference's containers
     kw = dict(n_reads=n, n_cells=int(rng.integers(5, 300)), n_genes=int(rng.integers(30, 20000)), umi_len=8 if indrop else int(rng.integers(6, 13)),
               stream_id=int(rng.integers(1, 10000)), permille_neighbour=int(rng.integers(0, 300)) if merge else 0)
+    if tiny:
+        kw.update(n_reads=min(n, 400_000), n_cells=int(rng.integers(5, 40)), n_genes=int(rng.integers(5, 80)), umi_len=int(rng.integers(3, 6)))
+        n = kw["n_reads"]
     if merge:
         kw["whitelist"] = "indrop_v3" if indrop else "10x_aug_2016_split"
     cfg = {"min_before": int(rng.integers(0, 12)), "min_after": int(rng.integers(0, 60))}
-    if merge:
+    if merge and not free:
         cfg["merge"] = {"barcodes_kind": capi.BARCODES_CONST, "barcodes_file": os.path.join(DATA, kw["whitelist"])}
     ckw = cfg_kwargs(cfg)
     if merge == 2:
         ckw.update(merge_kind=capi.MERGE_POISSON_REAL)
+    if free:
+        ckw.update(merge_kind={3: capi.MERGE_SIMPLE, 4: capi.MERGE_POISSON_SIMPLE, 5: capi.MERGE_ALL}[merge],
+                   max_cb_merge_edit_distance=int(rng.integers(1, 18 if tiny else 4)), min_merge_fraction=float(rng.choice([0.0, 0.05, 0.2])),
+                   max_real_merge_prob=float(rng.choice([1e-7, 1e-3, 0.3, 0.9])))
+    if rng.random() < 0.15:
+        ckw.update(umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL, max_umi_merge_edit_distance=1, umi_merge_multiplier=2.0)
     cb, umi, gene, aux = parity.canonical_stream(*SynthStream(**kw).generate_host())
     side = ()
     if rng.random() < 0.3:

@@ -237,7 +237,7 @@ def test_n_umis_across_shards(world, rate, n_reads):
     # (the single context itself is pinned on the oracle for these streams: test_gpu_parity.py::test_n_umis_synthetic)
 
 
-@pytest.mark.parametrize("case", ["c2", "c4"])
+@pytest.mark.parametrize("case", ["c2", "c4", "c4_simple", "c4_poisson_simple"])
 def test_two_shards_at_2e7_reads_match_single_context(case):
     """Past the size thresholds of one context (sampled table, hot list, planned key layout, splitter sort) the shards still run
     the exact-statistics ingest and agree on the key fields: 2e7 reads over two shards against one context, both matrices and the
@@ -248,6 +248,9 @@ def test_two_shards_at_2e7_reads_match_single_context(case):
     else:
         s = SynthStream(n_reads=12_000_000, n_cells=800, n_genes=20000, umi_len=8, whitelist="indrop_v3", permille_neighbour=100)
         kw = cfg_kwargs({"min_before": 10, "min_after": 50, "merge": {"barcodes_kind": capi.BARCODES_CONST, "barcodes_file": os.path.join(DATA, "indrop_v3")}})
+        if case != "c4":   # the same stream merged without the whitelist: 6e4 cells in the UMI-gene index, 5e6 molecules through the all-to-all
+            kw = dict(merge_kind=capi.MERGE_SIMPLE if case == "c4_simple" else capi.MERGE_POISSON_SIMPLE, max_cb_merge_edit_distance=2,
+                      min_merge_fraction=0.2, max_real_merge_prob=1e-7, min_genes_before_merge=10, min_genes_after_merge=50)
     dev = s.generate_device(0)
     arrays = tuple(a.copy() for a in dev.to_host())
     dev.free()
@@ -256,6 +259,9 @@ def test_two_shards_at_2e7_reads_match_single_context(case):
     assert c.sort_layout()["sort"] == "splitter"
     want = check(got, c)
     assert len(got["cm"][3]) > 500 and (case == "c2" or len(want) > 1000)
+    if case.startswith("c4_"):
+        print(case, "one context: cb_merge", {k: round(v["ms"], 2) for k, v in c.kernel_stats().items() if k.startswith("host:cb_merge")},
+              "two shards:", {k: round(v["ms"], 2) for k, v in got["phases"].items() if k.startswith("cbm:") or k == "cb_merge"})
 
 
 def test_eight_shards_whitelist_merge_n_umis_and_directional():
