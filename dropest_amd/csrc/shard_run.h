@@ -801,6 +801,8 @@ struct dropest_shard {
 	bool narrow_matrix = true;                                    // option "narrow_matrix": 16-bit matrices when every gene id fits
 	bool byte_matrix = true;                                      // option "byte_matrix": the byte form (any gene id); wins over narrow_matrix
 	uint64_t byte_list_cap = 0;                                   // option "byte_list_cap": entries a shard may list per kind (0: 2^20)
+	bool wide_now[2] = {false, false};                            // this step: a shard's lists of the matrix overflowed, its columns are placed again without the byte form
+	bool lists_overflowed(const Mat &M) const;
 	dropest::DevBuf<u32> d_list_count;
 	void collect_lists(Mat &M);
 	// cm_raw without a host table of all the real cells (option "raw_on_device", on): see assemble_raw_device
@@ -1542,7 +1544,7 @@ dropest_shard::SharedLayout dropest_shard::open_shared(Mat &M, int slot, size_t 
 	using namespace dropest;
 	dropest_ctx &c = *ctx;
 	SharedLayout L{};
-	L.bytes = byte_matrix;
+	L.bytes = byte_matrix && !wide_now[slot];
 	L.narrow = !L.bytes && narrow_matrix && c.narrow_possible();
 	L.base = (head_bytes + 15) & ~size_t(15);
 	L.list_cap = u32(std::min<uint64_t>(byte_list_cap ? byte_list_cap : (1u << 20), (M.nnz + 15) & ~15ull));
@@ -1843,25 +1845,50 @@ void dropest_shard::step() {
 	// candidates are gathered and ordered and cm is assembled -- every shard issues its collectives in this same order.  (Measured at
 	// C2 through one shard: 12.2 ms with everything on one stream, 11.75 this way, 11.9 with the table before cm_raw -- cm's emit then
 	// shares the CUs with the placing kernel.)
+	wide_now[0] = wide_now[1] = false;
 	if (raw_device_now) assemble_raw_device();
 	build_global_table();
 	assemble_matrix(true);
 	if (!raw_device_now) assemble_matrix(false);
-	{ Phase ph(this, "matrix:wait"); HIP_CHECK(stream_wait(c.stream)); if (place_stream) HIP_CHECK(stream_wait(place_stream)); tr->barrier(); }
-	if (byte_matrix) { Phase ph(this, "matrix:lists"); collect_lists(mat[0]); collect_lists(mat[1]); }
+	auto wait_all = [&] { Phase ph(this, "matrix:wait"); HIP_CHECK(stream_wait(c.stream)); if (place_stream) HIP_CHECK(stream_wait(place_stream)); tr->barrier(); };
+	wait_all();
+	if (byte_matrix) {
+		// A shard that had more to list than its segment holds (very sparse columns: a small cell lists nearly every row) shows in the
+		// segment counts, which every shard reads after the barrier: all take the same decision and place that matrix's columns again in
+		// the 16- / 32-bit form.  The step cannot fail for the shape of the data.
+		bool again = false;
+		for (int k = 0; k < 2; ++k) if (lists_overflowed(mat[k])) { wide_now[k] = true; again = true; }
+		if (again) {
+			Phase ph(this, "matrix:overflow");
+			tr->barrier();   // (nobody reopens a shared buffer while another shard still reads its counts)
+			if (wide_now[1] && raw_device_now) assemble_raw_device();
+			if (wide_now[0]) assemble_matrix(true);
+			if (wide_now[1] && !raw_device_now) assemble_matrix(false);
+			wait_all();
+		}
+		Phase ph(this, "matrix:lists"); collect_lists(mat[0]); collect_lists(mat[1]);
+	}
 	c.collect_timings();
 }
 
 // the byte form's lists: every shard's segment of the shared buffer (written through its PCIe link, complete after the barrier)
-// -> one list of a kind; a shard that had more than list_cap entries to list fails the step on every shard alike
+// -> one list of a kind (a matrix whose lists overflowed on some shard was placed again without the byte form before this: step())
+bool dropest_shard::lists_overflowed(const Mat &M) const {
+	if (!M.bytes) return false;
+	for (int p = 0; p < world; ++p) {
+		const u32 *w = reinterpret_cast<const u32 *>(M.segments + M.seg_bytes * size_t(p));
+		if (w[0] > M.list_cap || w[1] > M.list_cap) return true;
+	}
+	return false;
+}
+
 void dropest_shard::collect_lists(Mat &M) {
 	using namespace dropest;
 	if (!M.bytes || M.lists_ready) return;
 	size_t nr = 0, nv = 0;
 	for (int p = 0; p < world; ++p) {
 		const u32 *w = reinterpret_cast<const u32 *>(M.segments + M.seg_bytes * size_t(p));
-		if (w[0] > M.list_cap || w[1] > M.list_cap)
-			throw UnsupportedError("more than " + std::to_string(M.list_cap) + " listed entries of a byte-form matrix on shard " + std::to_string(p) + ": set the shard option byte_matrix to 0");
+		if (w[0] > M.list_cap || w[1] > M.list_cap) throw InvalidError("internal: a byte-form matrix kept overflowed lists");
 		nr += w[0]; nv += w[1];
 	}
 	M.rl_pos.resize(nr); M.rl_row.resize(nr); M.vl_pos.resize(nv); M.vl_val.resize(nv);

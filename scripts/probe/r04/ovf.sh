@@ -1,0 +1,5 @@
+#!/bin/bash
+cd /root/repo
+export PYTHONPATH=/root/repo
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_multi.py tests/test_gpu_multiproc.py -x -q -k "matrix_forms or overflow" > gpurun_out/ovf.log 2>&1; echo "rc $?"; tail -30 gpurun_out/ovf.log

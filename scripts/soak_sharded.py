@@ -79,7 +79,7 @@ for it in range(iters):
     cuts = np.sort(rng.integers(0, n + 1, world - 1)) if rng.random() < 0.5 else np.array([n * i // world for i in range(1, world)])
     bounds = [0] + [int(x) for x in cuts] + [n]
     opts = {"byte_matrix": int(rng.random() < 0.7), "narrow_matrix": int(rng.random() < 0.6), "raw_on_device": int(rng.random() < 0.8),
-            "packed_exchange": int(rng.random() < 0.8)}
+            "packed_exchange": int(rng.random() < 0.8), "byte_list_cap": int(rng.choice([0, 0, 0, 16, 4096]))}
     tag = "it %d: n %d world %d merge %d N-UMIs %d qual %d bounds %s opts %s %s" % (it, n, world, merge, len(side), ql, bounds, opts, kw)
     t0 = time.time()
     try:

@@ -420,8 +420,8 @@ def test_one_shard_over_rccl_and_forced_exchange():
 def test_matrix_forms_of_a_group_agree():
     """Three shards, the three forms the step can write the global matrices in (shard options byte_matrix / narrow_matrix): the
     byte form -- every shard's deltas and values at their global places, its listed entries in its own segment of the shared
-    buffer -- decodes to the 16-bit and the 32-bit one; a shard that would have to list more than the segment holds fails the
-    step loudly on every shard."""
+    buffer -- decodes to the 16-bit and the 32-bit one; when a shard would have to list more than its segment holds, the matrix is placed
+    again in a wider form."""
     s = SynthStream(n_reads=400_000, n_cells=60, n_genes=9000, umi_len=8, permille_neighbour=50)
     arrays = parity.canonical_stream(*s.generate_host())
     arrays[0][::97] = arrays[0][0]; arrays[2][::97] = arrays[2][0]; arrays[3][::97] = arrays[3][0]   # ~4000 UMIs of one gene in one cell: a value beyond a byte
@@ -460,10 +460,28 @@ def test_matrix_forms_of_a_group_agree():
     assert "order:cm_raw" in ph and ph["raw:plan"]["steps"] == 4
     for f, want in zip((True, False), forms["bytes"]):
         assert all(np.array_equal(x, y) for x, y in zip(g.shards[0].matrix(f), want))
+    # a shard that would have to list more than its segment holds: that matrix's columns are placed again in the 16-bit form, by every
+    # shard alike (the step must not fail for the shape of the data).  A cap of 16 overflows both matrices, one of 2048 only
+    # cm_raw (small real cells list nearly every row); cm_raw planned on the device and on the host.
+    for raw_dev in (1, 0):
+        for cap, wide in ((16, (True, True)), (2048, (False, True))):
+            for sh in g.shards:
+                sh.set_option("raw_on_device", raw_dev); sh.set_option("byte_list_cap", cap)
+            g.step()
+            assert "matrix:overflow" in g.shards[0].phase_stats()
+            for f, want, w in zip((True, False), forms["bytes"], wide):
+                assert all(np.array_equal(x, y) for x, y in zip(g.shards[0].matrix(f), want))
+                if w:
+                    with pytest.raises(capi.DropestError):
+                        g.shards[0].matrix_bytes(f)
+                else:
+                    assert g.shards[0].matrix_bytes(f).nnz > 5000
     for sh in g.shards:
-        sh.set_option("raw_on_device", 1); sh.set_option("byte_list_cap", 16)
-    with pytest.raises(capi.DropestError, match="listed entries"):
-        g.step()
+        sh.set_option("byte_list_cap", 0)
+    g.step()                                          # and back: the byte form again
+    assert g.shards[0].matrix_bytes(False).n_row_listed > 100
+    for f, want in zip((True, False), forms["bytes"]):
+        assert all(np.array_equal(x, y) for x, y in zip(g.shards[0].matrix(f), want))
     g.close()
 
 

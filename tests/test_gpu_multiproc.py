@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropest_amd", "data", "barcodes")
 
 
-def _worker(rank, world, uid, cfg_kw, side, npz, out, steps):
+def _worker(rank, world, uid, cfg_kw, side, npz, out, steps, opts=()):
     try:
         os.environ["DROPEST_SHARD_DATAPLANE"] = "shm"
         from dropest_amd import capi as cp
@@ -40,6 +40,8 @@ def _worker(rank, world, uid, cfg_kw, side, npz, out, steps):
         lo, hi = n * rank // world, n * (rank + 1) // world
         if side:
             sh.set_side_strings(side)
+        for k, v in opts:
+            sh.set_option(k, v)
         sh.set_reads(cp.DeviceArrays.from_host(0, d["cb"][lo:hi], d["umi"][lo:hi], d["gene"][lo:hi], d["aux"][lo:hi]), lo)
         for _ in range(steps):
             sh.step()
@@ -55,13 +57,13 @@ def _worker(rank, world, uid, cfg_kw, side, npz, out, steps):
         raise
 
 
-def run_processes(world, arrays, cfg_kw, side=(), steps=1):
+def run_processes(world, arrays, cfg_kw, side=(), steps=1, opts=()):
     tmp = tempfile.mkdtemp(prefix="dropest_mp_")
     npz, out = os.path.join(tmp, "reads.npz"), os.path.join(tmp, "out.npz")
     np.savez(npz, cb=arrays[0], umi=arrays[1], gene=arrays[2], aux=arrays[3])
     uid = np.random.default_rng(os.getpid()).integers(0, 256, 128, dtype=np.uint8).tobytes()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_worker, args=(r, world, uid, cfg_kw, tuple(side), npz, out, steps)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, uid, cfg_kw, tuple(side), npz, out, steps, tuple(opts))) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -129,4 +131,14 @@ def test_processes_whitelist_free_merges_across_shards(kind):
     got = run_processes(3, arrays, kw)
     want = check(got, arrays, kw)
     assert len(want) > 20
+
+
+def test_processes_byte_lists_overflow_falls_back():
+    """A list segment of 16 entries per shard: both matrices overflow on both processes; all of them place the columns again in the
+    16-bit form (the shared buffer is reopened larger by every process) -- same matrices as one context."""
+    s = SynthStream(n_reads=300_000, n_cells=50, n_genes=9000, umi_len=8)
+    arrays = parity.canonical_stream(*s.generate_host())
+    kw = cfg_kwargs({"min_before": 1, "min_after": 5})
+    got = run_processes(2, arrays, kw, steps=2, opts=(("byte_list_cap", 16),))
+    check(got, arrays, kw)
 
