@@ -756,6 +756,8 @@ struct dropest_shard {
 	dropest::ReadStore pushed;       // reads pushed from host memory (dropest_shard_push_reads)
 	// UMI quality strings of the resident reads (dropest_shard_set_umi_qualities): they travel with their reads in the exchange
 	dropest::DevBuf<uint8_t> r_qual, p_qual, x_qual;
+	dropest::DevBuf<uint8_t> r_qual_lens, p_qual_lens, x_qual_lens;   // (dropest_shard_set_umi_qualities_var) one length per read, <= r_qlen
+	bool r_qual_var = false;
 	u32 r_qlen = 0;
 	uint64_t r_qual_reads = 0;
 	bool r_have_qual = false;
@@ -1062,6 +1064,19 @@ void dropest_shard::partition_and_exchange() {
 			uint64_t out_q = 0;
 			for (int p = 0; p < world; ++p) if (p != rank) out_q += send_cnt[size_t(p)];
 			st.bytes += double(out_q) * r_qlen;
+			if (r_qual_var) {   // strings of several lengths: the length of every read's string travels the same way (1 byte per read)
+				p_qual_lens.ensure(std::max<size_t>(n, 1)); x_qual_lens.ensure(std::max<size_t>(n_recv, 1));
+				if (n) {
+					hipLaunchKernelGGL(gather_byte_rows_kernel, dim3(u32(std::min<uint64_t>((uint64_t(n) + 255) / 256, 16384))), dim3(256), 0, c.stream,
+					                   r_qual_lens.p, p_idx.p, n, 1u, p_qual_lens.p);
+					HIP_CHECK(hipGetLastError());
+				}
+				const void *snd1[1] = {p_qual_lens.p};
+				void *rcv1[1] = {x_qual_lens.p};
+				const size_t elem1[1] = {1};
+				tr->exchange(1, snd1, rcv1, elem1, send_cnt.data(), recv_cnt.data(), c.stream);
+				st.bytes += double(out_q);
+			}
 		}
 		// The records stay packed: cb_sample, cb_insert, the sampled statistics and build_keys read them as they are (k_cbhash.h: ReadPack);
 		// whatever else needs the four columns (UMI first-occurrence tables, quality sums) asks the context, which calls back here.
@@ -1786,12 +1801,12 @@ void dropest_shard::step() {
 		}
 	}
 	{   // UMI qualities: all shards or none, one length, one string per resident read
-		uint64_t mine[2] = {r_have_qual ? 1ull : 0ull, r_qlen};
+		uint64_t mine[2] = {(r_have_qual ? 1ull : 0ull) | (r_have_qual && r_qual_var ? 2ull : 0ull), r_qlen};
 		std::vector<uint64_t> all(size_t(world) * 2);
 		tr->gather_host(mine, sizeof(mine), all.data());
 		for (int p = 0; p < world; ++p)
 			if (all[size_t(p) * 2] != mine[0] || all[size_t(p) * 2 + 1] != mine[1])
-				throw InvalidError("UMI qualities must be given to every shard of the run, with one length (dropest_shard_set_umi_qualities)");
+				throw InvalidError("UMI qualities must be given to every shard of the run, in one way (with or without per-read lengths) and with one row width (dropest_shard_set_umi_qualities)");
 		if (r_have_qual && r_qual_reads != n_res)
 			throw InvalidError("UMI qualities were given for " + std::to_string(r_qual_reads) + " reads, the shard holds " + std::to_string(n_res));
 	}
@@ -1829,6 +1844,13 @@ void dropest_shard::step() {
 		if (bytes) {
 			c.umi_qual.ensure(bytes);
 			HIP_CHECK(hipMemcpyAsync(c.umi_qual.p, exchanged ? x_qual.p : r_qual.p, bytes, hipMemcpyDeviceToDevice, c.stream));
+		}
+		if (r_qual_var) {
+			c.qual_var = true;
+			if (c.n_reads) {
+				c.umi_qual_lens.ensure(c.n_reads);
+				HIP_CHECK(hipMemcpyAsync(c.umi_qual_lens.p, exchanged ? x_qual_lens.p : r_qual_lens.p, c.n_reads, hipMemcpyDeviceToDevice, c.stream));
+			}
 		}
 	}
 	// (one shard has nobody to agree with: its pass runs in one piece and may plan the key layout from a sample like any context)
@@ -2122,12 +2144,27 @@ dropest_status dropest_shard_set_umi_qualities(dropest_shard *s, const uint8_t *
 		if (quality_length > 255) throw UnsupportedError("UMI quality strings longer than 255");
 		if (n_reads && quality_length && !qualities) throw InvalidError("null quality array");
 		HIP_CHECK(hipSetDevice(s->ctx->cfg.device));
-		s->r_have_qual = true; s->r_qlen = quality_length; s->r_qual_reads = n_reads;
+		s->r_have_qual = true; s->r_qlen = quality_length; s->r_qual_reads = n_reads; s->r_qual_var = false;
 		const size_t bytes = size_t(n_reads) * quality_length;
 		if (bytes) {
 			s->r_qual.ensure(bytes);
 			HIP_CHECK(hipMemcpy(s->r_qual.p, qualities, bytes, hipMemcpyHostToDevice));
 		}
+	});
+}
+
+dropest_status dropest_shard_set_umi_qualities_var(dropest_shard *s, const uint8_t *qualities, uint32_t row_bytes, const uint8_t *lengths, uint64_t n_reads) {
+	const dropest_status st = dropest_shard_set_umi_qualities(s, qualities, row_bytes, n_reads);
+	if (st != DROPEST_OK) return st;
+	return guarded([&] {
+		if (n_reads && !lengths) throw InvalidError("null length array");
+		for (uint64_t i = 0; i < n_reads; ++i)
+			if (lengths[i] > row_bytes) throw InvalidError("a quality length beyond the row width (" + std::to_string(row_bytes) + ")");
+		if (n_reads) {
+			s->r_qual_lens.ensure(n_reads);
+			HIP_CHECK(hipMemcpy(s->r_qual_lens.p, lengths, n_reads, hipMemcpyHostToDevice));
+		}
+		s->r_qual_var = true;
 	});
 }
 

@@ -64,11 +64,16 @@ class Shard:
     def set_side_strings(self, strings):
         self.ctx.set_side_strings(strings)
 
-    def set_umi_qualities(self, qual):
-        """qual: uint8 [n_reads of this shard, quality_length], in the order of its reads."""
+    def set_umi_qualities(self, qual, lengths=None):
+        """qual: uint8 [n_reads of this shard, quality_length], in the order of its reads; lengths: per read, when the strings differ in length."""
         qual = np.ascontiguousarray(qual, np.uint8)
         assert qual.ndim == 2
-        self._chk(self.L.dropest_shard_set_umi_qualities(self.h, qual.ctypes.data, qual.shape[1], qual.shape[0]))
+        if lengths is None:
+            self._chk(self.L.dropest_shard_set_umi_qualities(self.h, qual.ctypes.data, qual.shape[1], qual.shape[0]))
+        else:
+            lengths = np.ascontiguousarray(lengths, np.uint8)
+            assert lengths.shape == (qual.shape[0],)
+            self._chk(self.L.dropest_shard_set_umi_qualities_var(self.h, qual.ctypes.data, qual.shape[1], lengths.ctypes.data, qual.shape[0]))
 
     def step(self):
         self._chk(self.L.dropest_shard_step(self.h))

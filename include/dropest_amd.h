@@ -495,9 +495,9 @@ void *dropest_stream(dropest_ctx *ctx);
  *                               buffer, col_barcodes[ncols] = packed barcode of every column; valid until the next step
  * -u runs sharded too (the shards' UMI first-occurrence tables are reduced to one rank table, random fills come from agreed
  * offsets of the one rand() sequence), and so does -M with a whitelist (PoissonRealBarcodesMergeStrategy: the UMI histograms of the shards
- * are added, every shard builds the same estimator tables; UMI fields of at most 26 bits).  Not in sharded runs: the merges without a
- * whitelist (-m / -M without barcodes, merge-all: their candidates come from UMIs shared between ANY two cells), UMI quality strings of
- * several lengths (one length per run: dropest_shard_set_umi_qualities). */
+ * are added, every shard builds the same estimator tables; UMI fields of at most 26 bits).  The merges without a whitelist (-m / -M without
+ * barcodes, merge-all) run sharded too: the (UMI-gene -> cells) index of SimpleMergeStrategy::init is sharded by hash(UMI-gene), partial
+ * counts of common UMI-genes travel to the owner of the base, ties are replayed over global cell indices (csrc/shard_merge_free.h). */
 typedef struct dropest_shard dropest_shard;
 dropest_status dropest_shard_unique_id(uint8_t id[128]);
 dropest_status dropest_shard_create(const dropest_cfg *cfg, int32_t rank, int32_t world, const uint8_t id[128], dropest_shard **out);
@@ -521,6 +521,10 @@ dropest_status dropest_shard_push_reads(dropest_shard *shard, const uint64_t *cb
  * the UMI merges there; in a barcode merge across shards the sums rows of the molecules that change shards travel with them, and a molecule
  * several merged cells had keeps the sums of the first of them in merge order, wherever they lived (Gene::merge, Gene.cpp:26-36). */
 dropest_status dropest_shard_set_umi_qualities(dropest_shard *shard, const uint8_t *qualities, uint32_t quality_length, uint64_t n_reads);
+/* The same with strings of several lengths (see dropest_set_umi_qualities_var): rows of row_bytes, lengths[i] <= row_bytes the length of
+ * read i's string; the lengths travel with the reads (one byte each).  Every shard of the run must use the same call and row width. */
+dropest_status dropest_shard_set_umi_qualities_var(dropest_shard *shard, const uint8_t *qualities, uint32_t row_bytes, const uint8_t *lengths,
+                                                   uint64_t n_reads);
 dropest_status dropest_shard_step(dropest_shard *shard);
 dropest_status dropest_shard_group_step(dropest_shard *const *shards, int32_t n);   /* one host thread per shard */
 dropest_status dropest_shard_matrix(dropest_shard *shard, int filtered, uint64_t *ncols, uint64_t *nnz, const uint64_t **colptr,

@@ -571,16 +571,86 @@ def test_partition_by_owner_is_stable_and_complete(n_parts):
     src.free(); dst.free()
 
 
-def _quality_table(ctx, side=()):
-    """{(barcode, gene, UMI): (reads, quality sums)} of every real cell of a context."""
+def _quality_table(ctx, side=(), lengths=False):
+    """{(barcode, gene, UMI): (reads, quality sums[, quality length])} of every real cell of a context."""
     rows = ctx.cell_rows()
     out = {}
     for cell in np.flatnonzero(rows["is_real"].astype(bool) & ~rows["is_merged"].astype(bool)):
         g, u, r, m = ctx.cell_molecules(int(cell))
         q = ctx.cell_molecule_qualities(int(cell), len(g))
+        ql = ctx.cell_molecule_quality_lengths(int(cell), len(g)) if lengths else None
         for j in range(len(g)):
-            out[(int(rows["barcode"][cell]), int(g[j]), capi.unpack_code(u[j], side))] = (int(r[j]), tuple(int(x) for x in q[j]))
+            out[(int(rows["barcode"][cell]), int(g[j]), capi.unpack_code(u[j], side))] = (int(r[j]), tuple(int(x) for x in q[j])) + ((int(ql[j]),) if lengths else ())
     return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("seed", range(6))
+def test_quality_strings_of_several_lengths_across_shards(seed, world):
+    """dropest_shard_set_umi_qualities_var: a quality length per molecule (UMI.cpp:21-34), the lengths travel with the reads (one byte each)
+    and with the molecule rows of a barcode merge; through the simple CB merge, N-UMIs and -u.  Sums and lengths per molecule as one context."""
+    import ctypes
+    from test_gpu_stress import random_stream
+    from test_gpu_quality import _molecule_lengths, _qualities
+    rng = np.random.default_rng(13000 + seed)
+    cb, umi, gene, aux, side = random_stream(
+        rng, n=int(rng.integers(500, 6000)), n_cb=int(rng.integers(2, 40)), n_gene=int(rng.integers(1, 12)),
+        n_umi=int(rng.integers(2, 60)), cb_len=(8, 8), umi_len=(6, 6), n_rate=0.05 if seed % 2 else 0.0)
+    stride = 9 if seed % 2 else 6
+    lens = _molecule_lengths(cb, umi, gene, seed, 0 if seed == 3 else 2, stride)
+    qual = _qualities(len(cb), stride, 200 + seed)
+    directional = seed % 3 == 0
+    kw = dict(merge_kind=capi.MERGE_SIMPLE, max_cb_merge_edit_distance=int(rng.integers(1, 6)), min_merge_fraction=float(rng.choice([0.0, 0.1, 0.3])),
+              min_genes_before_merge=int(rng.integers(0, 3)), min_genes_after_merge=0,
+              umi_merge_kind=capi.UMI_MERGE_DIRECTIONAL if directional else capi.UMI_MERGE_SIMPLE)
+    libc = ctypes.CDLL("libc.so.6")
+    c = capi.Context(**kw)
+    if side:
+        c.set_side_strings(side)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_umi_qualities(qual, lens)
+    c.set_initialized()
+    libc.srand(1)
+    c.merge_and_filter()
+    want = _quality_table(c, side, lengths=True)
+    n = len(cb)
+    bounds = [n * i // world for i in range(world + 1)]
+    g = ShardGroup([0] * world, **kw)
+    for i, sh in enumerate(g.shards):
+        if side:
+            sh.set_side_strings(side)
+        lo, hi = bounds[i], bounds[i + 1]
+        sh.set_reads(capi.DeviceArrays.from_host(0, cb[lo:hi], umi[lo:hi], gene[lo:hi], aux[lo:hi]), lo)
+        sh.set_umi_qualities(qual[lo:hi], lens[lo:hi])
+    for _ in range(2):
+        libc.srand(1)
+        g.step()
+    got = {}
+    for sh in g.shards:
+        got.update(_quality_table(sh.ctx, side, lengths=True))
+    assert len(got) == len(want) and len({v[2] for v in want.values()}) > 1
+    bad = [k for k in want if got.get(k) != want[k]]
+    assert not bad, (len(bad), bad[0], got.get(bad[0]), want[bad[0]])
+    check({"cm": [x.copy() for x in g.shards[0].matrix(True)], "raw": [x.copy() for x in g.shards[0].matrix(False)], "merged": g.shards[0].merged_barcodes()}, c)
+    g.close()
+
+
+def test_a_wrong_quality_length_on_a_shard_is_the_reference_exception():
+    """A read whose string has another length than its molecule's (UMI.cpp:26-28), on the second of two shards: the step fails with the text."""
+    P = capi.pack_seq
+    cbs = [P("ACGTACGTACGT"), P("TTGTACGTACGA")]
+    cb = np.array([cbs[0], cbs[1], cbs[0], cbs[1], cbs[0], cbs[1]], np.uint64)
+    umi = np.array([P("ACGTAC")] * 6, np.uint64)
+    gene = np.zeros(6, np.uint32); aux = np.full(6, 2 << 16, np.uint32)
+    qual = np.full((6, 8), 40, np.uint8)
+    lens = np.array([5, 8, 5, 8, 6, 8], np.uint8)
+    g = ShardGroup([0, 0])
+    for i, (lo, hi) in enumerate(((0, 3), (3, 6))):
+        g.shards[i].set_reads(capi.DeviceArrays.from_host(0, cb[lo:hi], umi[lo:hi], gene[lo:hi], aux[lo:hi]), lo)
+        g.shards[i].set_umi_qualities(qual[lo:hi], lens[lo:hi])
+    with pytest.raises(capi.DropestError, match="Wrong quality length: 6, expected: 5"):
+        g.step()
+    g.close()
 
 
 @pytest.mark.parametrize("world", [2, 3])
