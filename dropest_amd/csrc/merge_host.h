@@ -320,9 +320,9 @@ void dropest_ctx::build_merge_pairs(const std::vector<u32> &cells, MergeSearch &
 // The same search on the host, literally as the reference runs it (BarcodesParser::get_distances_to_barcode / push_remaining_dists,
 // BarcodesParser.cpp:21-74; RealBarcodesMergeStrategy::get_real_neighbour_cbs, RealBarcodesMergeStrategy.cpp:63-109) with the same
 // libstdc++ sorts on the same sequences: for whitelists of MORE parts than the device kernel is built for (WL_MAX_PARTS; the
-// reference has no limit, ConstLengthBarcodesParser.cpp:50-68).  One context only.
+// reference has no limit, ConstLengthBarcodesParser.cpp:50-68).  A shard searches ITS bases against the all-gathered cell list.
 void dropest_ctx::search_merge_candidates_host(const std::vector<u32> &cells, const MergeUniverse &U, MergeSearch &S) {
-	if (!U.find_cell) throw UnsupportedError("whitelists of more than " + std::to_string(WL_MAX_PARTS) + " parts are searched on the host: one context only, not in sharded runs");
+	if (!U.find_cell) throw InvalidError("internal: the host search of a whitelist needs a barcode look-up of the universe");
 	HostStage st(this, "cb_merge:targets:host_search");
 	const u32 F = u32(cells.size());
 	const size_t P = wl.parts.size();

@@ -111,6 +111,8 @@ struct dropest_ctx::ShardMerge {
 	u32 n_global = 0;
 	std::vector<u64> g_barcode;
 	std::vector<int32_t> g_total_umis;
+	std::vector<u32> g_n_genes;
+	std::unordered_map<u64, u32> by_code;   // whitelists searched on the host (more than WL_MAX_PARTS parts): barcode -> place in the global list
 	dropest::DevBuf<u64> d_cb;
 	dropest::DevBuf<u32> d_n_genes, d_total_umis, d_iota;
 	dropest::DevBuf<dropest::CbSlot> d_slots;
@@ -191,6 +193,7 @@ void dropest_ctx::shard_merge_search(uint64_t n_global, const uint64_t *g_barcod
 	M.n_global = nG;
 	M.g_barcode.assign(g_barcode, g_barcode + nG);
 	M.g_total_umis.assign(g_total_umis, g_total_umis + nG);
+	M.g_n_genes.assign(g_n_genes, g_n_genes + nG);
 	M.base_g.assign(base_g, base_g + n_bases);
 	M.base_local.assign(base_local, base_local + n_bases);
 	for (u32 f = 0; f < n_bases; ++f) {
@@ -231,6 +234,20 @@ void dropest_ctx::shard_merge_search(uint64_t n_global, const uint64_t *g_barcod
 	U.barcode_code = [pm](u32 g) { return pm->g_barcode[g]; };
 	const std::vector<std::string> *pside = &side;
 	U.base_barcode_text = [pm, pside](u32 f) { return dropest::decode_code(pm->g_barcode[pm->base_g[f]], *pside); };
+	if (!wl.loaded) {
+		if (barcodes_file.empty()) throw InvalidError("merge_kind = REAL_BARCODES needs barcodes_file");
+		wl.load(cfg.barcodes_kind, barcodes_file);
+	}
+	if (wl.parts.size() > size_t(WL_MAX_PARTS)) {   // the host search (merge_host.h) asks for cells by barcode: the global list, on the host
+		M.by_code.reserve(size_t(nG) * 2);
+		for (u32 g = 0; g < nG; ++g) M.by_code.emplace(M.g_barcode[g], g);
+		U.find_cell = [pm](u64 code, u32 &ng, int32_t &tu, u32 &ri) -> long {
+			auto it = pm->by_code.find(code);
+			if (it == pm->by_code.end()) return -1;
+			ng = pm->g_n_genes[it->second]; tu = pm->g_total_umis[it->second]; ri = it->second;
+			return long(it->second);
+		};
+	}
 	search_merge_candidates(M.base_g, U, M.S);
 	*n_pairs = M.S.pair_base.size();
 

@@ -120,6 +120,25 @@ def test_sharded_poisson_whitelist_merge_matches_single_context(case, world):
     assert not np.array_equal(plain.merge_targets(), c.merge_targets())
 
 
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("poisson", [False, True])
+@pytest.mark.parametrize("n_parts", [5, 8])
+def test_sharded_whitelists_of_more_than_four_parts(n_parts, poisson, world, tmp_path):
+    """Const-length whitelists of any number of lines (ConstLengthBarcodesParser.cpp:50-68): beyond four parts the neighbour search runs
+    on the host, every shard for its own bases against the all-gathered cell list (refused in sharded runs before round 4)."""
+    from test_gpu_stress import random_whitelist_case
+    crossed = 0
+    for seed in range(3):
+        cb, umi, gene, aux, side, _, gkw = random_whitelist_case(100 * n_parts + seed, poisson, tmp_path, force_parts=n_parts)
+        arrays = (cb, umi, gene, aux)
+        got = run_group(world, arrays, gkw, side=side)
+        want = check(got, single(arrays, gkw, side=side))
+        owner = lambda b: capi.lib().dropest_owner_of(int(b), world)       # noqa: E731
+        crossed += sum(owner(a) != owner(b) for a, b in want.items())
+    if n_parts == 5 and not poisson:
+        assert crossed > 3                                                # merges really crossed shards (the other cases: a handful of merges each)
+
+
 FREE_CASES = {
     # name: (stream, configuration): the parity cases of tests/test_gpu_parity.py for the same strategies on one context
     "plain": (dict(n_reads=150_000 * SCALE, n_cells=25 * SCALE, n_genes=1200, umi_len=8, permille_neighbour=150),

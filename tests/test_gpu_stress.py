@@ -177,12 +177,8 @@ def test_whitelists_of_more_than_four_parts(n_parts, poisson, tmp_path):
         test_random_whitelist_merges(100 * n_parts + seed, poisson, tmp_path, force_parts=n_parts)
 
 
-@pytest.mark.parametrize("poisson", [False, True])
-@pytest.mark.parametrize("seed", range(10))
-def test_random_whitelist_merges(seed, poisson, tmp_path, force_parts=None):
-    """Random small whitelists (inDrop-style two lines, variable first-part length allowed) and barcodes that are exact,
-    mutated (substitution / insertion / deletion -> different length) or carry an N: stresses the neighbour search,
-    the tie replay (min_merge_fraction 0 half of the time) and the sequential merge application."""
+def random_whitelist_case(seed, poisson, tmp_path, force_parts=None):
+    """-> (cb, umi, gene, aux, side, oracle kwargs, C-ABI kwargs) of one random whitelist merge (see test_random_whitelist_merges)."""
     rng = np.random.default_rng(7000 + seed + SEED_OFFSET)
     rc = {"A": "T", "C": "G", "G": "C", "T": "A"}
     def rnd(L):
@@ -247,19 +243,27 @@ def test_random_whitelist_merges(seed, poisson, tmp_path, force_parts=None):
     kind = capi.BARCODES_CONST if const_kind else capi.BARCODES_INDROP
     if poisson:   # PoissonRealBarcodesMergeStrategy: wider neighbour levels, real bases can merge, probability thresholds
         p_merge, p_real = float(rng.choice([1e-4, 0.05, 0.9])), float(rng.choice([1e-7, 0.05, 0.9]))
-        o = parity.oracle_run(Oracle, dict(merge_kind=3, barcodes_kind=kind, barcodes_file=str(wl), min_genes_before=min_before,
-                                           min_genes_after=min_before, max_merge_prob=p_merge, max_real_merge_prob=p_real),
-                              cb, umi, gene, aux, side)
-        c = parity.gpu_run(dict(merge_kind=capi.MERGE_POISSON_REAL, barcodes_kind=kind, barcodes_file=str(wl),
-                                min_genes_before_merge=min_before, min_genes_after_merge=min_before, max_merge_prob=p_merge,
-                                max_real_merge_prob=p_real), cb, umi, gene, aux, side)
-        parity.compare(o, c, side)
-        return
-    o = parity.oracle_run(Oracle, dict(merge_kind=1, barcodes_kind=kind, barcodes_file=str(wl), min_genes_before=min_before,
-                                       min_genes_after=min_before, min_merge_fraction=frac), cb, umi, gene, aux, side)
-    c = parity.gpu_run(dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=kind, barcodes_file=str(wl),
-                            min_genes_before_merge=min_before, min_genes_after_merge=min_before, min_merge_fraction=frac),
-                       cb, umi, gene, aux, side)
+        okw = dict(merge_kind=3, barcodes_kind=kind, barcodes_file=str(wl), min_genes_before=min_before, min_genes_after=min_before,
+                   max_merge_prob=p_merge, max_real_merge_prob=p_real)
+        gkw = dict(merge_kind=capi.MERGE_POISSON_REAL, barcodes_kind=kind, barcodes_file=str(wl), min_genes_before_merge=min_before,
+                   min_genes_after_merge=min_before, max_merge_prob=p_merge, max_real_merge_prob=p_real)
+    else:
+        okw = dict(merge_kind=1, barcodes_kind=kind, barcodes_file=str(wl), min_genes_before=min_before, min_genes_after=min_before,
+                   min_merge_fraction=frac)
+        gkw = dict(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=kind, barcodes_file=str(wl), min_genes_before_merge=min_before,
+                   min_genes_after_merge=min_before, min_merge_fraction=frac)
+    return cb, umi, gene, aux, side, okw, gkw
+
+
+@pytest.mark.parametrize("poisson", [False, True])
+@pytest.mark.parametrize("seed", range(10))
+def test_random_whitelist_merges(seed, poisson, tmp_path, force_parts=None):
+    """Random small whitelists (inDrop-style two lines, variable first-part length allowed) and barcodes that are exact,
+    mutated (substitution / insertion / deletion -> different length) or carry an N: stresses the neighbour search,
+    the tie replay (min_merge_fraction 0 half of the time) and the sequential merge application."""
+    cb, umi, gene, aux, side, okw, gkw = random_whitelist_case(seed, poisson, tmp_path, force_parts)
+    o = parity.oracle_run(Oracle, okw, cb, umi, gene, aux, side)
+    c = parity.gpu_run(gkw, cb, umi, gene, aux, side)
     parity.compare(o, c, side)
 
 
