@@ -522,9 +522,14 @@ void dropest_ctx::build_keys(bool with_stats) {
 			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p, hot,
 			                   gene_chr.p, GENE_CHR_CAP, d_ingest.p, lds, rpack);
 		};
+		if (rpack.on() && !vec) throw InvalidError("internal: packed exchange records that are not 16-byte aligned");
 		auto pick = [&](auto vb) {
 			constexpr int VB = decltype(vb)::value;
-			if (with_stats && lds_genes && vec) {
+			if (rpack.on()) {   // a sharded run's records as they arrived (PK)
+				if (with_stats && lds_genes) { if (n_hot) go(build_keys_kernel<256, VB, true, true, true, true, true>, lds_genes); else go(build_keys_kernel<256, VB, true, false, true, true, true>, lds_genes); }
+				else if (with_stats) { if (n_hot) go(build_keys_kernel<256, VB, true, true, true, false, true>); else go(build_keys_kernel<256, VB, true, false, true, false, true>); }
+				else { if (n_hot) go(build_keys_kernel<256, VB, true, true, false, false, true>); else go(build_keys_kernel<256, VB, true, false, false, false, true>); }
+			} else if (with_stats && lds_genes && vec) {
 				if (n_hot) go(build_keys_kernel<256, VB, true, true, true, true>, lds_genes); else go(build_keys_kernel<256, VB, true, false, true, true>, lds_genes);
 			} else if (with_stats) {
 				if (n_hot) { if (vec) go(build_keys_kernel<256, VB, true, true, true>); else go(build_keys_kernel<256, VB, false, true, true>); }

@@ -53,7 +53,9 @@ struct GlobalCounters {   // CellsDataContainer.cpp:73-78, :309-327
 // "ask the table in memory") instead of one gather per read from gene_chr[] -- the gather was a quarter of the kernel at the C2 shape
 // (scripts/probe/bk_probe.hip: 0.97 -> 0.73 ms without it).  Anything the byte table cannot answer takes the exact path below.
 constexpr uint32_t BK_LDS_GENES_MAX = 49152;   // with the 16 KB of hot cell ids: 64 KB of LDS per workgroup at most
-template <int THREADS, int VB, bool VEC, bool HOT = false, bool STATS = false, bool GCL = false>
+// PK: the reads are the packed 12-byte records of a sharded run (k_cbhash.h: ReadPack; umi -> w0, gene -> w1) -- a template parameter, not a
+// run-time test: the plain kernel lost 0.12 ms per 1e8 reads with the test inside its loop.
+template <int THREADS, int VB, bool VEC, bool HOT = false, bool STATS = false, bool GCL = false, bool PK = false>
 __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long long *__restrict__ umi,
                                                              const uint32_t *__restrict__ gene,
                                                              const uint32_t *__restrict__ aux,
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 		unsigned long long u[U], cell[U], kk[U];
 		uint32_t vv[U] = {0, 0, 0, 0};
 		const bool full = base + U <= n;
-		if (VEC && full && pk.on()) {   // packed records of a sharded run: 16 bytes of stream per read instead of 20 (umi -> w0, gene -> w1)
+		if (PK && VEC && full) {   // packed records of a sharded run: 16 bytes of stream per read instead of 20 (umi -> w0, gene -> w1)
 			const uint4 s4 = stream_load_u32x4(slot + base), w4 = stream_load_u32x4(gene + base);
 			const ulonglong2 u01 = stream_load_u64x2(umi + base), u23 = stream_load_u64x2(umi + base + 2);
 			sl[0] = s4.x; sl[1] = s4.y; sl[2] = s4.z; sl[3] = s4.w;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(THREADS) void build_keys_kernel(const unsigned long
 			for (int q = 0; q < U; ++q) {
 				const uint64_t r = base + q;
 				sl[q] = 0; g[q] = NO_GENE; a[q] = 0; u[q] = 0;
-				if (r < n && pk.on()) { const uint32_t w1 = gene[r]; sl[q] = slot[r]; g[q] = pk.gene(w1); a[q] = pk.aux(w1); u[q] = pk.umi(umi[r]); }
+				if (PK && r < n) { const uint32_t w1 = gene[r]; sl[q] = slot[r]; g[q] = pk.gene(w1); a[q] = pk.aux(w1); u[q] = pk.umi(umi[r]); }
 				else if (r < n) { sl[q] = slot[r]; g[q] = gene[r]; a[q] = aux[r]; u[q] = umi[r]; }
 			}
 		}
