@@ -1146,10 +1146,10 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 	auto passes = [&](const HostCell &h) {
 		return !(h.merged || h.excluded || h.row.n_genes < min_before) && h.row.requested_genes >= genes_threshold;
 	};
-	// (Up to 2e5 cells the host orders them in a millisecond or two -- the 5e4 filtered cells of C3 AFTER the merge, whose device
+	// (Up to 1e5 cells the host orders them in a millisecond or two -- the 5e4 filtered cells of C3 AFTER the merge, whose device
 	// read-back would cross PCIe behind cm_raw's prefetch: 10 ms of waiting for 200 KB.  The 2.4e6 candidates BEFORE the merge take the
 	// device path: 3 ms against 60 on the host, and nothing else is on the link then.)
-	size_t device_min = 200000;
+	size_t device_min = 100000;   // (C4's 1.5e5 candidates before the merge: 5.0 ms on the host, 1.15 on the device)
 	if (const char *e = getenv("DROPEST_DEVICE_SORT_MIN")) device_min = size_t(std::max(1, atoi(e)));   // tests force the device path
 
 	// Large lists (10^5..10^6 cells at BASELINE sizes) are ordered on the device: three stable LSD radix sorts
