@@ -524,6 +524,15 @@ __global__ __launch_bounds__(256) void chr_accumulate_kernel(const unsigned long
 // over the waves through LDS -- the order (wave, item, lane) is the order of the positions, so reads of one owner keep stream
 // order.  6 GB per 1e8 reads instead of the 10 GB of (position, owner) keys + radix pass + gather it replaces.
 constexpr int OP_T = 512, OP_I = 8, OP_TILE = OP_T * OP_I;
+// x mod n for a 64-bit x and a small n (<= 65536) without the 64-bit division (~100 instructions per read: the histogram and the scatter of
+// the owner partition were bound by it, not by memory): x = hi 2^32 + lo, so x mod n = ((hi mod n)(2^32 mod n) + lo mod n) mod n, and a
+// 32-bit a mod n = mulhi64(M a, n) with M = floor((2^64 - 1) / n) + 1 (Lemire, Kaser, Kurz: "Faster remainder by direct computation", 2019).
+struct OwnerMod {
+	unsigned long long M; uint32_t n, c;
+	__host__ __device__ explicit OwnerMod(uint32_t n_) : M(~0ull / n_ + 1ull), n(n_), c(uint32_t((1ull << 32) % n_)) {}
+	__device__ uint32_t mod32(uint32_t a) const { return uint32_t(__umul64hi(M * a, n)); }
+	__device__ uint32_t operator()(unsigned long long x) const { return mod32(mod32(uint32_t(x >> 32)) * c + mod32(uint32_t(x))); }
+};
 __global__ __launch_bounds__(OP_T) void owner_hist_kernel(const unsigned long long *__restrict__ cb, uint32_t n, uint32_t n_parts,
                                                           uint32_t tiles_per_block, uint32_t *__restrict__ hist /* [256][gridDim.x] */) {
 	__shared__ uint32_t h[256];
@@ -532,13 +541,17 @@ __global__ __launch_bounds__(OP_T) void owner_hist_kernel(const unsigned long lo
 	const uint64_t begin = uint64_t(blockIdx.x) * tiles_per_block * OP_TILE;
 	uint64_t end = begin + uint64_t(tiles_per_block) * OP_TILE;
 	if (end > n) end = n;
-	for (uint64_t i = begin + threadIdx.x; i < end; i += OP_T) atomicAdd(&h[mix64(cb[i]) % n_parts], 1u);
+	const OwnerMod owner_of(n_parts);
+	for (uint64_t i = begin + threadIdx.x; i < end; i += OP_T) atomicAdd(&h[owner_of(mix64(cb[i]))], 1u);
 	__syncthreads();
 	if (threadIdx.x < 256) hist[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
 // The same histogram, and on the way the widths of the four fields over ALL resident reads (the sharded pass packs a read into
 // 12 bytes for the exchange when they allow it): stats[0] largest barcode code, [1] largest UMI code, [2] 1 + largest gene id,
 // [3] largest chromosome id, [4] OR of the aux bits above chromosome and 3-bit mark (must be zero).
+// EVERY: the three other columns are read for every EVERY-th row of OP_T reads only (1 = all: exact statistics).  A sampled pass costs the
+// barcodes' 8 bytes per read instead of 24; what the sample missed is caught by owner_scatter, which sees every field anyway (OwnerSelf::bad).
+template <uint32_t EVERY>
 __global__ __launch_bounds__(OP_T) void owner_hist_stats_kernel(const unsigned long long *__restrict__ cb, const unsigned long long *__restrict__ umi,
                                                                 const uint32_t *__restrict__ gene, const uint32_t *__restrict__ aux, uint32_t n, uint32_t n_parts,
                                                                 uint32_t tiles_per_block, uint32_t *__restrict__ hist /* [256][gridDim.x] */,
@@ -554,15 +567,20 @@ __global__ __launch_bounds__(OP_T) void owner_hist_stats_kernel(const unsigned l
 	// (with ONE owner, the forced exchange of the bench, all 64 of them)
 	uint32_t c8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	const bool few = n_parts <= 8;
-	for (uint64_t i = begin + threadIdx.x; i < end; i += OP_T) {
-		const unsigned long long k = cb[i], u = umi[i];
-		const uint32_t g = gene[i], a = aux[i];
-		const uint32_t own = uint32_t(mix64(k) % n_parts);
+	uint32_t row = 0;
+	const OwnerMod owner_of(n_parts);
+	for (uint64_t i = begin + threadIdx.x; i < end; i += OP_T, ++row) {
+		const unsigned long long k = cb[i];
+		const uint32_t own = owner_of(mix64(k));
 		if (few) {
 #pragma unroll
 			for (uint32_t p = 0; p < 8; ++p) c8[p] += own == p;
 		} else atomicAdd(&h[own], 1u);
-		cmax = k > cmax ? k : cmax; umax = u > umax ? u : umax;
+		cmax = k > cmax ? k : cmax;
+		if (EVERY > 1 && row % EVERY) continue;
+		const unsigned long long u = umi[i];
+		const uint32_t g = gene[i], a = aux[i];
+		umax = u > umax ? u : umax;
 		if (g != 0xFFFFFFFFu && (unsigned long long)g + 1 > gmax) gmax = (unsigned long long)g + 1;
 		const unsigned long long ch = a & 0xFFFFu;
 		chmax = ch > chmax ? ch : chmax;
@@ -627,7 +645,9 @@ __global__ __launch_bounds__(256) void exchange_unpack_kernel(const unsigned lon
 // PACKED: o_cb receives w0, o_gene receives w1 (o_umi / o_aux unused); the index array is written either way.
 // self / self_w0 / self_w1 (PACKED): the records this shard keeps go straight to their place in the RECEIVE arrays (pointers shifted so
 // that the partition's own index lands there): the receive arrays are then complete without a copy of the kept block.
-struct OwnerSelf { uint32_t owner = 0xFFFFFFFFu; unsigned long long *w0 = nullptr; uint32_t *w1 = nullptr; };
+// bad (PACKED): set when a read does not fit the packed record (the field widths came from a SAMPLE of the reads): the caller repeats the
+// partition with exact widths.
+struct OwnerSelf { uint32_t owner = 0xFFFFFFFFu; unsigned long long *w0 = nullptr; uint32_t *w1 = nullptr; uint32_t *bad = nullptr; };
 template <bool PACKED>
 __global__ __launch_bounds__(OP_T) void owner_scatter_kernel(const unsigned long long *__restrict__ cb, const unsigned long long *__restrict__ umi,
                                                              const uint32_t *__restrict__ gene, const uint32_t *__restrict__ aux, uint32_t n,
@@ -642,6 +662,7 @@ __global__ __launch_bounds__(OP_T) void owner_scatter_kernel(const unsigned long
 	if (tid < 256) goff[tid] = owner_base[tid] + hist[tid * gridDim.x + blockIdx.x];
 	const uint32_t n_tiles = (n + OP_TILE - 1) / OP_TILE, first_tile = blockIdx.x * tiles_per_block;
 	const uint32_t lane_off = w * (64 * OP_I) + lane;
+	const OwnerMod owner_of(n_parts);
 	for (uint32_t tt = 0; tt < tiles_per_block; ++tt) {
 		const uint32_t tile = first_tile + tt;
 		if (tile >= n_tiles) break;
@@ -659,7 +680,7 @@ __global__ __launch_bounds__(OP_T) void owner_scatter_kernel(const unsigned long
 #pragma unroll
 		for (int i = 0; i < OP_I; ++i) {
 			const bool valid = (t0 + lane_off + i * 64) < n;
-			const uint32_t d = uint32_t(mix64(k[i]) % n_parts);
+			const uint32_t d = owner_of(mix64(k[i]));
 			own[i] = d;
 			uint32_t diff_lo = 0, diff_hi = 0;
 			for (int b = 0; b < owner_bits; ++b) {
@@ -693,6 +714,13 @@ __global__ __launch_bounds__(OP_T) void owner_scatter_kernel(const unsigned long
 			if (PACKED) {
 				unsigned long long w0; uint32_t w1;
 				exchange_pack(pack, k[i], u[i], g[i], a[i], w0, w1);
+				if (self.bad) {
+					const uint32_t gmask = (1u << pack.gene_bits) - 1u;
+					const int chr_bits = 32 - 3 - pack.gene_bits;
+					const bool fits = pack.cb_bits < 64 && (k[i] >> pack.cb_bits) == 0ull && (u[i] >> (64 - pack.cb_bits)) == 0ull &&
+					                  (g[i] == 0xFFFFFFFFu || g[i] < gmask) && (a[i] >> 19) == 0u && (chr_bits >= 16 || ((a[i] & 0xFFFFu) >> chr_bits) == 0u);
+					if (!fits) atomicOr(self.bad, 1u);
+				}
 				if (own[i] == self.owner) { self.w0[dst] = w0; self.w1[dst] = w1; }
 				else { o_cb[dst] = w0; o_gene[dst] = w1; }
 			} else { o_cb[dst] = k[i]; o_umi[dst] = u[i]; o_gene[dst] = g[i]; o_aux[dst] = a[i]; }

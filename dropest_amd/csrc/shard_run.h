@@ -773,6 +773,7 @@ struct dropest_shard {
 	dropest::DevBuf<u64> p_w0, x_w0;
 	dropest::DevBuf<u32> p_w1, x_w1;
 	bool packed = false, idx_exchanged = false, allow_packed = true, unpacked = false;
+	bool exact_widths = false;   // option "exact_widths" / after a sampled pass missed a wide field: the histogram pass reads all four columns
 	dropest::ExchangePack exch_pack{};
 	void unpack_exchanged();
 	int rec_bytes = 28;
@@ -960,7 +961,10 @@ void dropest_shard::partition_and_exchange() {
 	const bool want_idx = c.cfg.umi_merge_kind == DROPEST_UMI_MERGE_DIRECTIONAL || c.cfg.merge_kind == DROPEST_MERGE_SIMPLE || c.cfg.merge_kind == DROPEST_MERGE_POISSON_SIMPLE;
 	std::vector<uint64_t> all_cnt(size_t(world) * size_t(world));
 	ExchangePack pack{};
-	{
+	// The field widths of the packed record come from a SAMPLE of the reads (every 64th row of the histogram pass: that pass then reads
+	// the barcodes only, 8 bytes per read instead of 24); the scatter, which reads every field anyway, reports a read that does not fit.
+	// Then -- on every shard alike -- the partition is repeated with exact widths, and this shard object stays with those.
+	auto partition = [&](bool sampled) -> bool {
 		Phase ph(this, "partition");
 		uint64_t need = 0;
 		if (dropest_partition_scratch_bytes(n, &need) != DROPEST_OK) throw UnsupportedError("more than 2^32-2 reads per GPU");
@@ -971,10 +975,12 @@ void dropest_shard::partition_and_exchange() {
 		u32 *hist = reinterpret_cast<u32 *>(base + off_hist), *row_total = reinterpret_cast<u32 *>(base + off_row), *digit_base = reinterpret_cast<u32 *>(base + off_base);
 		u64 *d_stats = reinterpret_cast<u64 *>(base + ((total + 7) & ~size_t(7)));
 		uint64_t stats[5] = {0, 0, 0, 0, 0};
+		(void)sampled;
 		std::vector<u32> totals(RS_RADIX, 0);
 		if (n) {
-			HIP_CHECK(hipMemsetAsync(d_stats, 0, 40, c.stream));
-			hipLaunchKernelGGL(owner_hist_stats_kernel, dim3(nblocks), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), tpb, hist, d_stats);
+			HIP_CHECK(hipMemsetAsync(d_stats, 0, 48, c.stream));
+			if (sampled) hipLaunchKernelGGL(owner_hist_stats_kernel<64>, dim3(nblocks), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), tpb, hist, d_stats);
+			else hipLaunchKernelGGL(owner_hist_stats_kernel<1>, dim3(nblocks), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), tpb, hist, d_stats);
 			hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_RADIX), dim3(256), 0, c.stream, hist, nblocks, row_total);
 			hipLaunchKernelGGL(rs_scan_totals_kernel<256>, dim3(1), dim3(256), 0, c.stream, row_total, digit_base);
 			HIP_CHECK(hipGetLastError());
@@ -997,7 +1003,9 @@ void dropest_shard::partition_and_exchange() {
 		const int gene_bits = std::max(1, bit_length(g[2])), chr_bits = std::max(1, bit_length(g[3]));
 		packed = allow_packed && !g[4] && cb_bits + umi_bits <= 64 && gene_bits + 3 + chr_bits <= 32;   // (a code with N has bit 63 set: never packed)
 		idx_exchanged = want_idx || !packed;
-		pack.cb_bits = cb_bits; pack.gene_bits = gene_bits;
+		pack.cb_bits = cb_bits;
+		// sampled widths: the gene field takes every bit the chromosome does not need (a wider field costs nothing), the chromosome one bit of slack
+		pack.gene_bits = sampled && packed ? std::max(gene_bits, 32 - 3 - std::min(chr_bits + 1, 32 - 3 - gene_bits)) : gene_bits;
 		rec_bytes = packed ? (idx_exchanged ? 16 : 12) : 28;
 		send_off.assign(size_t(world) + 1, 0);
 		for (int p = 0; p < world; ++p) send_off[size_t(p) + 1] = send_off[size_t(p)] + send_cnt[size_t(p)];
@@ -1016,6 +1024,7 @@ void dropest_shard::partition_and_exchange() {
 		if (n) {
 			const int owner_bits = std::max(1, bit_length(uint64_t(world - 1)));
 			OwnerSelf self{};
+			if (sampled && packed) { HIP_CHECK(hipMemsetAsync(d_stats + 5, 0, 8, c.stream)); self.bad = reinterpret_cast<u32 *>(d_stats + 5); }
 			self.owner = u32(rank);
 			self.w0 = x_w0.p + recv_off[size_t(rank)] - send_off[size_t(rank)];     // (index = position in the partition's output)
 			self.w1 = x_w1.p + recv_off[size_t(rank)] - send_off[size_t(rank)];
@@ -1025,7 +1034,16 @@ void dropest_shard::partition_and_exchange() {
 			                        p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p, pack);
 			HIP_CHECK(hipGetLastError());
 		}
-	}
+		if (!(sampled && packed)) return true;
+		// did every read of every shard fit?  (one word from the device, one small collective)
+		uint64_t bad = 0;
+		if (n) { u32 b32 = 0; c.fetch(&b32, d_stats + 5, 4); bad = b32; }
+		std::vector<uint64_t> bad_of(static_cast<size_t>(world));
+		tr->gather_host(&bad, 8, bad_of.data());
+		for (uint64_t x : bad_of) if (x) return false;
+		return true;
+	};
+	if (!partition(!exact_widths)) { exact_widths = true; phases["partition:exact_again"].launches++; partition(false); }
 	{
 		Phase ph(this, "all_to_all");
 		const uint64_t n_recv = recv_off[size_t(world)];
@@ -2334,6 +2352,7 @@ dropest_status dropest_shard_set_option(dropest_shard *s, const char *key, int64
 		else if (k == "raw_on_device") s->raw_on_device = value != 0;
 		else if (k == "byte_list_cap") s->byte_list_cap = value > 0 ? uint64_t((value + 15) & ~15ll) : 0;
 		else if (k == "packed_exchange") s->allow_packed = value != 0;
+		else if (k == "exact_widths") s->exact_widths = value != 0;
 		else throw InvalidError("unknown shard option: " + k);
 	});
 }

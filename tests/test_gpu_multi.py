@@ -84,6 +84,25 @@ def test_shards_on_one_gpu_match_single_context(world):
         assert got["phases"]["all_to_all"]["bytes"] > 0          # reads really moved between the shards
 
 
+@pytest.mark.parametrize("what", ["chromosome", "umi"])
+def test_a_field_wider_than_the_sampled_reads_suggest(what):
+    """The widths of the 12-byte exchange record come from every 64th row of 512 reads; ONE read elsewhere with a chromosome id beyond them
+    is noticed by the scatter and the partition is repeated with exact widths on every shard (same results; the phase shows in the
+    statistics); afterwards the shards keep exact widths.  A longer UMI still fits (the UMI takes every bit the barcode leaves)."""
+    arrays = [a.copy() for a in parity.canonical_stream(*SynthStream(**STREAM).generate_host())]
+    at = 512 * 3 + 17                                      # a read of an unsampled row of the first shard's range
+    if what == "chromosome":
+        arrays[3][at] = (int(arrays[3][at]) & 0xFFFF0000) | 0x1FFF
+    else:
+        arrays[1][at] = int(capi.pack_seq("ACGTACGTACGTACG"))
+    kw = cfg_kwargs(CFG)
+    got = run_group(2, arrays, kw)
+    check(got, single(arrays, kw))
+    assert ("partition:exact_again" in got["phases"]) == (what == "chromosome")
+    if what == "chromosome":
+        assert got["phases"]["partition:exact_again"]["steps"] == 1     # the first step repeated its partition, the second knew better
+
+
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("case", sorted(MERGE_CASES))
 def test_sharded_whitelist_merge_matches_single_context(case, world):
