@@ -1588,7 +1588,8 @@ void dropest_ctx::wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_
 	HIP_CHECK(hipGetLastError());
 	static const bool trace = getenv("DROPEST_WIRE_TRACE") != nullptr;
 	job->trace = trace;
-	job->prepare(uint64_t(1) << 16);
+	static const uint64_t slice_entries = [] { const char *e = getenv("DROPEST_DECODE_SLICE"); return e && atoll(e) >= 1024 ? uint64_t(atoll(e)) : uint64_t(1) << 16; }();
+	job->prepare(slice_entries);
 	M.job = job; M.wire = true;
 	M.job_t0 = std::chrono::steady_clock::now();
 	DecodePool::get().prefer_node_of(M.h_row.p);
