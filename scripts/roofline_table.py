@@ -63,4 +63,4 @@ for k, v in rows:
             amp = "%.2f" % (hit[0] * v["launches"] / v["bytes"])
     print("| `%s` | %.0f | %.3f | %.3f | %.0f | %.1f | %s |" % (k, launches, ms, gb, gb / ms * 1e3 if ms else 0, gb / ms * 1e3 / PEAK * 100 if ms else 0, amp))
 print()
-print("Sum of kernel time: %.2f ms per pass (the pass also spends ~6 ms in the PCIe D2H of the two matrices)." % tot_ms)
+print("Sum of kernel time: %.2f ms per pass (the pass ends with the two matrices crossing PCIe in the byte form, ~1.5 ms, and their decode on host threads)." % tot_ms)
