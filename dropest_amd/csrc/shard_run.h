@@ -2093,7 +2093,7 @@ dropest_status dropest_ctx_split(dropest_ctx *ctx, int32_t parts, dropest_shard 
 		if (parts < 2 || parts > 64) throw InvalidError("2..64 parts");
 		HIP_CHECK(hipSetDevice(ctx->cfg.device));
 		if (ctx->n_reads == 0) throw InvalidError("no reads to split");
-		if (ctx->qual_len) throw UnsupportedError("UMI qualities are not carried by a split run");
+		if (ctx->have_qual && ctx->qual_reads != ctx->n_reads) throw InvalidError("UMI qualities were given for another number of reads than the context holds");
 		ctx->concat_chunks();
 		ctx->free_results();
 		ctx->release_tables();   // the shards need the room; the reads stay
@@ -2108,7 +2108,14 @@ dropest_status dropest_ctx_split(dropest_ctx *ctx, int32_t parts, dropest_shard 
 			const uint64_t a = n * uint64_t(i) / uint64_t(parts), b = n * uint64_t(i + 1) / uint64_t(parts);
 			s.r_cb = ctx->d_cb + a; s.r_umi = ctx->d_umi + a; s.r_gene = ctx->d_gene + a; s.r_aux = ctx->d_aux + a;
 			s.n_res = b - a; s.first_ordinal = a;
+			if (ctx->have_qual) {   // the UMI quality strings of the shard's range (and their lengths) follow their reads: a copy on the device
+				s.r_have_qual = true; s.r_qlen = ctx->qual_len; s.r_qual_reads = b - a; s.r_qual_var = ctx->qual_var;
+				const size_t bytes = size_t(b - a) * ctx->qual_len;
+				if (bytes) { s.r_qual.ensure(bytes); HIP_CHECK(hipMemcpyAsync(s.r_qual.p, ctx->umi_qual.p + size_t(a) * ctx->qual_len, bytes, hipMemcpyDeviceToDevice, ctx->stream)); }
+				if (ctx->qual_var && b > a) { s.r_qual_lens.ensure(size_t(b - a)); HIP_CHECK(hipMemcpyAsync(s.r_qual_lens.p, ctx->umi_qual_lens.p + a, size_t(b - a), hipMemcpyDeviceToDevice, ctx->stream)); }
+			}
 		}
+		if (ctx->have_qual) HIP_CHECK(stream_wait(ctx->stream));
 		for (int i = 0; i < parts; ++i) out[i] = made[size_t(i)].release();
 	});
 }

@@ -566,9 +566,9 @@ dropest_status dropest_shard_set_option(dropest_shard *shard, const char *key, i
  * shards on the context's own device -- split by barcode owner like a multi-GPU run, every shard numbering 1/parts of the
  * barcodes -- and writes the shard handles to out[parts]; drive them with dropest_shard_group_step and read the result with
  * dropest_shard_matrix / dropest_shard_merged_barcodes on out[0].  The shards borrow the context's device-resident reads: the
- * context must outlive them and must not be used for anything else meanwhile (its own tables are released).  What a sharded
- * run does not support (merges without a whitelist, UMI qualities) is not supported here either; the gene + UMI fields
- * alone must leave room for the cells of a shard. */
+ * context must outlive them and must not be used for anything else meanwhile (its own tables are released).  Every merge and
+ * the UMI qualities of the context (copied to the shards) are carried; the gene + UMI fields alone must leave room for the cells
+ * of a shard. */
 dropest_status dropest_key_width(dropest_ctx *ctx, uint32_t *cell_bits, uint32_t *gene_bits, uint32_t *umi_bits);
 dropest_status dropest_ctx_split(dropest_ctx *ctx, int32_t parts, dropest_shard **out);
 

@@ -95,6 +95,50 @@ def test_wide_key_whitelist_merge():
     assert len(want) > 20 and parts >= 2
 
 
+def test_wide_key_merge_all_with_umi_qualities():
+    """A split run carries what a sharded run carries (round 4): a merge without a whitelist (merge_type = all; the simple merges' UMI-gene
+    index needs UMI-gene + cell + shard within 63 bits and says so) and the UMI quality strings of the context, copied to the shards with
+    their reads.  Matrices, merge targets and the quality sums of every molecule against the oracle."""
+    s = SynthStream(n_reads=120_000, whitelist="10x_aug_2016_split", n_cells=30, n_genes=1500, umi_len=21, permille_neighbour=150)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    qual = np.random.default_rng(5).integers(33, 75, size=(len(cb), 7), dtype=np.uint8)
+    okw = dict(merge_kind=5, max_cb_merge_ed=2, min_genes_before=3, min_genes_after=10)
+    kw = dict(merge_kind=capi.MERGE_ALL, max_cb_merge_edit_distance=2, min_genes_before_merge=3, min_genes_after_merge=10)
+    o = Oracle(**okw)
+    o.add_packed_q(cb, umi, gene, aux, qual)
+    o.set_initialized(); o.merge_and_filter()
+    c = capi.Context(**kw)
+    c.push_reads(cb, umi, gene, aux)
+    c.set_umi_qualities(qual)
+    with pytest.raises(capi.DropestError) as e:
+        c.set_initialized()
+    assert "sort key needs" in str(e.value)
+    cell, gene_b, umi_b = c.key_width()
+    g = ShardGroup.split(c, 1 << max(1, cell + gene_b + umi_b - 64 + 1))
+    g.step(); g.step()
+    s0 = g.shards[0]
+    got = {"cm": [x.copy() for x in s0.matrix(True)], "raw": [x.copy() for x in s0.matrix(False)], "merged": s0.merged_barcodes()}
+    want = check_against_oracle(got, o)
+    assert len(want) > 20
+    oc, og, ou, orr, om = o.molecules()
+    oq = o.molecule_qualities(len(oc), 7)
+    merged = o.cell_rows()[:, 0] != 0
+    want_q = {(o.cell_barcode(int(oc[i])), int(og[i]), ou[i]): (int(orr[i]), tuple(int(x) for x in oq[i])) for i in range(len(oc)) if not merged[int(oc[i])]}
+    got_q = {}
+    for sh in g.shards:
+        rows = sh.ctx.cell_rows()
+        for cell_id in np.flatnonzero(rows["is_real"].astype(bool) & ~rows["is_merged"].astype(bool)):
+            gg, uu, rr, mm = sh.ctx.cell_molecules(int(cell_id))
+            q = sh.ctx.cell_molecule_qualities(int(cell_id), len(gg))
+            for j in range(len(gg)):
+                got_q[(capi.unpack_code(int(rows["barcode"][cell_id])), int(gg[j]), capi.unpack_code(uu[j]))] = (int(rr[j]), tuple(int(x) for x in q[j]))
+    real_keys = {k for k in want_q if k in got_q}
+    assert len(got_q) > 5000 and len(real_keys) == len(got_q)
+    bad = [k for k in real_keys if got_q[k] != want_q[k]]
+    assert not bad, (len(bad), bad[0], got_q[bad[0]], want_q[bad[0]])
+    g.close()
+
+
 def test_gene_and_umi_alone_too_wide_stays_refused():
     P = capi.pack_seq
     n = 5
