@@ -249,7 +249,8 @@ void dropest_ctx::build_cb_table() {
 		HIP_CHECK(hipMemsetAsync(t_slots.p, 0, cap_s * sizeof(CbSlot), stream));
 		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4, stream));
 		timed("cb_sample", double(n_s) * 8, [&] {
-			hipLaunchKernelGGL(cb_sample_distinct_kernel, dim3(std::min<u32>(div_up(n_s, 256), 2048u)), dim3(256), 0, stream, d_cb, n, stride, ts, scalars.p, rpack);
+			static const u32 count_every = [] { const char *e = getenv("DROPEST_CB_SAMPLE_COUNT_EVERY"); return e && atoi(e) >= 1 ? u32(atoi(e)) : 4u; }();
+			hipLaunchKernelGGL(cb_sample_distinct_kernel, dim3(std::min<u32>(div_up(n_s, 256), 2048u)), dim3(256), 0, stream, d_cb, n, stride, ts, scalars.p, rpack, count_every);
 		});
 		// ... and how many of the sampled barcodes reach 4, 16, ... sample hits: the hot list is the largest such set of at
 		// most CB_HOT_MAX barcodes (C2: the 5 000 real cells carry 92 % of the reads)

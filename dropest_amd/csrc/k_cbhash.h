@@ -346,8 +346,11 @@ __global__ __launch_bounds__(256) void gene_chr_seed_kernel(const uint32_t *__re
 // n / 2 slots for a stream whose 1e8 reads carry 3e6 barcodes is 1 GB of 16-byte slots at 5 % load -- every probe of a
 // rare barcode a certain HBM miss, 1 GB to clear and 1 GB to scan for the occupied slots; sized from the sample it is
 // 128 MB and lives in the 256 MB Infinity Cache.
+// count_every: only every count_every-th sampled read adds (count_every) to its barcode's occurrence count -- the counts pick the hot list,
+// nothing else; a real cell of a 10x run collects ~300 of these atomics on ONE word, and same-address atomics from all over the device
+// run one after the other (cb_sample was 0.2 ms per 1e8 reads for a 20 us stream).
 __global__ __launch_bounds__(256) void cb_sample_distinct_kernel(const unsigned long long *__restrict__ cb, uint32_t n, uint32_t stride,
-                                                                 CbTable t, uint32_t *__restrict__ distinct, ReadPack pk = ReadPack{}) {
+                                                                 CbTable t, uint32_t *__restrict__ distinct, ReadPack pk = ReadPack{}, uint32_t count_every = 1) {
 	uint32_t mine = 0;
 	for (uint64_t j = uint64_t(blockIdx.x) * 256 + threadIdx.x; j * stride < n; j += uint64_t(gridDim.x) * 256) {
 		const unsigned long long k = pk.cb(cb[j * stride]);
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(256) void cb_sample_distinct_kernel(const unsigned 
 			}
 			if (!found) h = (h + 1) & t.mask;
 		}
-		if (found) atomicAdd(&t.slots[h].nfirst, 1u);   // occurrences in the sample: the hot barcodes are picked by it
+		if (found && j % count_every == 0) atomicAdd(&t.slots[h].nfirst, count_every);   // occurrences in the sample: the hot barcodes are picked by it
 	}
 	const unsigned long long tot = wave_reduce_add_u64(mine);
 	__shared__ uint32_t block_new;   // (one atomic per workgroup on the one counter, not one per wave)
