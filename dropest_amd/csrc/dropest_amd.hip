@@ -256,7 +256,7 @@ void dropest_ctx::build_cb_table() {
 		// most CB_HOT_MAX barcodes (C2: the 5 000 real cells carry 92 % of the reads)
 		HIP_CHECK(hipMemsetAsync(scalars.p + 4, 0, 4 * CB_HOT_LEVELS, stream));
 		const bool want_hot = !getenv("DROPEST_CB_NO_HOT");
-		if (want_hot) timed("cb_hot_count", double(cap_s) * sizeof(CbSlot), [&] { hipLaunchKernelGGL(cb_hot_count_kernel, dim3(256), dim3(256), 0, stream, ts, scalars.p + 4); });
+		if (want_hot) timed("cb_hot_count", double(cap_s) * sizeof(CbSlot), [&] { hipLaunchKernelGGL(cb_hot_count_kernel, dim3(1024), dim3(256), 0, stream, ts, scalars.p + 4); });
 		u32 head[4 + CB_HOT_LEVELS] = {0};
 		fetch(head, scalars.p, sizeof(head));
 		const u32 distinct = head[0];

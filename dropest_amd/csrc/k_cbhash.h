@@ -609,10 +609,15 @@ __global__ __launch_bounds__(256) void cb_compact_slots_kernel(CbTable t, unsign
 	const uint64_t cap = t.mask + 1, chunk = uint64_t(256) * CS_ITEMS;
 	for (uint64_t c0 = uint64_t(blockIdx.x) * chunk; c0 < cap; c0 += uint64_t(gridDim.x) * chunk) {
 		uint32_t hits = 0, mine = 0;
+		uint32_t first[CS_ITEMS];   // the whole 16-byte slot in one load: key and first ordinal together (the second pass read the line again)
 #pragma unroll
 		for (int j = 0; j < CS_ITEMS; ++j) {
 			const uint64_t s = c0 + uint64_t(j) * 256 + threadIdx.x;
-			if (s < cap && t.slots[s].key != 0ull) { hits |= 1u << j; ++mine; }
+			first[j] = 0;
+			if (s < cap) {
+				const uint4 q = *reinterpret_cast<const uint4 *>(&t.slots[s]);
+				if ((q.x | q.y) != 0u) { hits |= 1u << j; ++mine; first[j] = ~q.z; }
+			}
 		}
 		uint32_t total;
 		const uint32_t ex = block_excl_scan_u32<256>(mine, scratch, total);
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(256) void cb_compact_slots_kernel(CbTable t, unsign
 		for (int j = 0; j < CS_ITEMS; ++j)
 			if (hits & (1u << j)) {
 				const uint32_t s = uint32_t(c0 + uint64_t(j) * 256 + threadIdx.x);
-				out[o++] = ((unsigned long long)t.first(s) << 32) | s;
+				out[o++] = ((unsigned long long)first[j] << 32) | s;
 			}
 		__syncthreads();
 	}
