@@ -749,6 +749,29 @@ bool dropest_ctx::splitter_sort_reduce() {
 	ss_bucket_base.ensure(F2); ss_bucket_cnt.ensure(F2); scalars.ensure(16);
 	HIP_CHECK(hipMemsetAsync(scalars.p, 0, 16, stream));   // [0] largest bucket, [1] molecule total, [2] a bucket was out of order after its sort, [3] a region overflowed
 	u32 max_cnt = 0;
+	// finishing sort (k_ssort.h: ss_local): sparse molecule rows at each bucket's own record offset (key rows re-use the partition's
+	// alternate buffer), then a scan of the per-bucket row counts and the compaction into the dense table.  The small launch skips buckets
+	// beyond its LDS by itself, so it is queued BEFORE the host reads the partition's scalars back (a round trip of ~25 us the device would
+	// otherwise sit out).
+	const u32 SMALL_MAX = 2048;
+	const bool atomic_rank = lds_atomics_lane_ordered(cfg.device, stream);
+	ss_tmp.ensure(span * 2 + 2); ss_n_loc.ensure(F2); ss_prefix.ensure(F2); ss_chunk.ensure(1024);
+	SsLocalArgs a{};
+	a.keys = keys; a.vals = vals; a.bucket_base = ss_bucket_base.p; a.bucket_cnt = ss_bucket_cnt.p; a.n_buckets = F2; a.ms = ms;
+	a.t_key = keys_alt; a.t_reads = ss_tmp.p; a.t_agg = ss_tmp.p + span; a.n_loc = ss_n_loc.p;
+	if (const char *e = getenv("DROPEST_SS_DEBUG")) a.debug = u32(atoi(e));
+	a.order_flag = scalars.p + 2;
+	a.atomic_below = u32(ms + layout.umi_bits);   // the UMI field: random digits
+	if (const char *e = getenv("DROPEST_SS_ATOMIC_BELOW")) a.atomic_below = u32(atoi(e));
+	a.cap = SMALL_MAX; a.skip_above = SMALL_MAX;
+	auto launch_small = [&] {
+		const size_t lds = ss_local_lds_bytes(a.cap, 256);
+		timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB), [&] {   // + 16 B per molecule row, added below once n_mol is known
+			if (atomic_rank) { if (VB) hipLaunchKernelGGL((ss_local_kernel<1, true>), dim3(F2), dim3(256), lds, stream, a); else hipLaunchKernelGGL((ss_local_kernel<0, true>), dim3(F2), dim3(256), lds, stream, a); }
+			else if (VB) hipLaunchKernelGGL(ss_local_kernel<1>, dim3(F2), dim3(256), lds, stream, a);
+			else hipLaunchKernelGGL(ss_local_kernel<0>, dim3(F2), dim3(256), lds, stream, a);
+		});
+	};
 	if (reserve) {
 		// both partitions by reservation (k_ssort.h): a tile takes its places in the buckets' regions with one atomic per bucket; no histograms
 		const u32 cap1 = u32(plan.cap1), cap2 = u32(plan.cap2), CS1 = 32;
@@ -773,6 +796,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 		timed("ss_scan", double(F2) * 12, [&] {
 			hipLaunchKernelGGL(ss_res_buckets_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, cur2, F2, cap2, ss_bucket_base.p, ss_bucket_cnt.p, scalars.p);
 		});
+		launch_small();   // (an overflowed region holds `cap` records: the launch is harmless, its rows are discarded below)
 		u32 head[4] = {0, 0, 0, 0};
 		fetch(head, scalars.p, 16);
 		max_cnt = head[0];
@@ -822,27 +846,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 	});
 	}
 
-	// finishing sort: sparse molecule rows at each bucket's own record offset (key rows re-use the partition's alternate
-	// buffer), then scan of the per-bucket row counts and compaction into the dense table
-	const u32 SMALL_MAX = 2048;
-	const bool atomic_rank = lds_atomics_lane_ordered(cfg.device, stream);
-	ss_tmp.ensure(span * 2 + 2); ss_n_loc.ensure(F2); ss_prefix.ensure(F2); ss_chunk.ensure(1024);
-	SsLocalArgs a{};
-	a.keys = keys; a.vals = vals; a.bucket_base = ss_bucket_base.p; a.bucket_cnt = ss_bucket_cnt.p; a.n_buckets = F2; a.ms = ms;
-	a.t_key = keys_alt; a.t_reads = ss_tmp.p; a.t_agg = ss_tmp.p + span; a.n_loc = ss_n_loc.p;
-	if (const char *e = getenv("DROPEST_SS_DEBUG")) a.debug = u32(atoi(e));
-	a.order_flag = scalars.p + 2;
-	a.atomic_below = u32(ms + layout.umi_bits);   // the UMI field: random digits
-	if (const char *e = getenv("DROPEST_SS_ATOMIC_BELOW")) a.atomic_below = u32(atoi(e));
-	a.cap = SMALL_MAX; a.skip_above = SMALL_MAX;
-	{
-		const size_t lds = ss_local_lds_bytes(a.cap, 256);
-		timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB), [&] {   // + 16 B per molecule row, added below once n_mol is known
-			if (atomic_rank) { if (VB) hipLaunchKernelGGL((ss_local_kernel<1, true>), dim3(F2), dim3(256), lds, stream, a); else hipLaunchKernelGGL((ss_local_kernel<0, true>), dim3(F2), dim3(256), lds, stream, a); }
-			else if (VB) hipLaunchKernelGGL(ss_local_kernel<1>, dim3(F2), dim3(256), lds, stream, a);
-			else hipLaunchKernelGGL(ss_local_kernel<0>, dim3(F2), dim3(256), lds, stream, a);
-		});
-	}
+	if (!reserve) launch_small();
 	if (max_cnt > SMALL_MAX) {   // the few buckets beyond the small launch (the tail of the size distribution, a hot molecule), listed by the host
 		std::vector<u32> cnts(F2), medium, big;
 		fetch(cnts.data(), ss_bucket_cnt.p, size_t(F2) * 4);
