@@ -452,6 +452,7 @@ struct dropest_ctx {
 	dropest::PinnedBuf<u64> sort_stage;                  // staging of sort_filtered's key columns / permutation
 	dropest::DevBuf<u64> sort_cols;
 	std::vector<u32> sort_idx;
+	std::vector<uint64_t> sort_ids;   // cell ids in the order of sort_idx (dense: the gather of the ordered list reads this, not `real`)
 	bool filtered_valid = false;
 	u32 filtered_threshold = 0;
 	int filtered_max_cells = -1;

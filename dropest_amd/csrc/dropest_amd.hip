@@ -1192,7 +1192,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 			auto st2 = std::make_unique<HostStage>(this, "sort_filtered:fill");
 			sort_stage.ensure(size_t(m) * 3);
 			sort_cols.ensure(size_t(m) * 3);
-			sort_idx.resize(m);
+			sort_idx.resize(m); sort_ids.resize(m);   // (ids in a dense array: the gather below would otherwise miss the cache once per cell in `real`)
 			keys_a.ensure(m); keys_b.ensure(m); vals_a.ensure(m); vals_b.ensure(m);
 			u64 *h_code = sort_stage.p, *h_umis = sort_stage.p + m, *h_sizes = sort_stage.p + 2 * size_t(m);
 			u64 o[W][3], a[W][3];
@@ -1204,7 +1204,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 					if (!passes(h)) continue;
 					const u64 sizes = (u64(h.row.requested_genes) << 32) | h.row.requested_umis;
 					const u64 umis = u64(size_t(h.row.total_umis));   // Cell::umis_number casts the int stat to size_t
-					h_code[at] = h.row.barcode; h_umis[at] = umis; h_sizes[at] = sizes; sort_idx[at] = u32(i);
+					h_code[at] = h.row.barcode; h_umis[at] = umis; h_sizes[at] = sizes; sort_idx[at] = u32(i); sort_ids[at] = h.id;
 					lo[0] |= h.row.barcode; la[0] &= h.row.barcode; lo[1] |= umis; la[1] &= umis; lo[2] |= sizes; la[2] &= sizes;
 					++at;
 				}
@@ -1248,7 +1248,7 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 			if (max_cells > 0 && size_t(max_cells) < size_t(m)) start = size_t(m) - size_t(max_cells);
 			filtered.resize(m - start); filtered_ridx.resize(m - start);
 			parallel_ranges(m - start, [&](size_t b, size_t e, unsigned) {
-				for (size_t i = b; i < e; ++i) { const u32 idx = sort_idx[perm[start + i]]; filtered[i] = real[idx].id; filtered_ridx[i] = idx; }
+				for (size_t i = b; i < e; ++i) { const u32 at = perm[start + i]; filtered[i] = sort_ids[at]; filtered_ridx[i] = sort_idx[at]; }
 			});
 			filtered_valid = true;
 			return;
