@@ -226,7 +226,7 @@ std::vector<std::pair<std::string, std::string>> CellsDataContainer::merged_barc
 
 void CellsDataContainer::add_record(const ReadInfo &r) {   // CellsDataContainer.cpp:59-88
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
-	_preview_valid = false;
+	_preview_valid = false; ++_generation;
 	const uint8_t mark = uint8_t(r.umi_mark.bits());
 	const bool has_gene = !r.gene.empty();
 	const uint64_t cb_code = encode(r.params.cell_barcode(), _side_cb);
@@ -291,7 +291,7 @@ void CellsDataContainer::add_records_packed(const std::vector<PackedRun> &runs) 
 	size_t n = 0;
 	for (const PackedRun &r : runs) n += r.n;
 	if (!n) return;
-	_preview_valid = false;
+	_preview_valid = false; ++_generation;
 	flush();                                   // whatever add_record collected comes first
 	if (_umi_quality_length == size_t(-1))     // the first gene-bearing read fixes the quality length: 0 (no quality strings)
 		for (const PackedRun &r : runs) { for (size_t i = 0; i < r.n; ++i) if (r.gene[i] != DROPEST_NO_GENE) { _umi_quality_length = 0; _qual_pending = 0; break; } if (_umi_quality_length == 0) break; }
@@ -307,7 +307,7 @@ void CellsDataContainer::add_records_packed(const std::vector<PackedRun> &runs) 
 void CellsDataContainer::add_records_packed(const uint64_t *cb, const uint64_t *umi, const uint32_t *gene, const uint32_t *aux, size_t n) {
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
 	if (!bulk_ingest_possible()) throw std::runtime_error("add_records_packed: the container is sharded or carries UMI qualities (use add_record)");
-	_preview_valid = false;
+	_preview_valid = false; ++_generation;
 	if (!n) return;
 	flush();                                   // whatever add_record collected comes first
 	if (_umi_quality_length == size_t(-1))     // the first gene-bearing read fixes the quality length: 0 (no quality strings)
@@ -329,7 +329,7 @@ void CellsDataContainer::set_reference_names(const std::vector<std::string> &nam
 
 void CellsDataContainer::add_record(const ParsedRead &r) {   // same statements as add_record(const ReadInfo&), on parsed fields
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
-	_preview_valid = false;
+	_preview_valid = false; ++_generation;
 	if (r.ref_id < 0 || size_t(r.ref_id) >= _ref_names.size()) throw std::out_of_range("reference id outside set_reference_names");
 	const bool has_gene = !r.gene.empty();
 	const uint64_t cb_code = r.cb_code ? r.cb_code : encode(std::string(r.cb), _side_cb);
@@ -412,7 +412,7 @@ void CellsDataContainer::check_molecule_quality_length(uint64_t cb_code, uint32_
 		_mol_qlen.reserve(size_t(n_mol) * 2);
 		for (uint64_t i = 0; i < n_mol; ++i) _mol_qlen.emplace(MolKey{rows[cell[i]].barcode, umi[i], g[i]}, uint8_t(_umi_quality_length));
 		_mol_qlen_tracking = true;
-		_preview_valid = false;                                            // (the next accessor sees the read that follows)
+		_preview_valid = false; ++_generation;                             // (the next accessor sees the read that follows)
 	}
 	auto ins = _mol_qlen.emplace(MolKey{cb_code, umi_code, gene}, uint8_t(ql));
 	if (!ins.second && ins.first->second != ql)
@@ -456,6 +456,7 @@ void CellsDataContainer::flush() {
 }
 
 void CellsDataContainer::set_initialized() {   // CellsDataContainer.cpp:163-175
+	++_generation;
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
 	flush();
 	if (sharded()) {
@@ -508,6 +509,7 @@ void CellsDataContainer::split_for_wide_keys() {
 
 void CellsDataContainer::merge_and_filter() {   // CellsDataContainer.cpp:39-57
 	if (!_is_initialized) throw std::runtime_error("You must initialize container");
+	++_generation;
 	if (sharded()) {
 		for (;;) {
 			const dropest_status st = dropest_shard_group_step(_shards.data(), int32_t(_shards.size()));
@@ -568,6 +570,7 @@ void CellsDataContainer::exclude_cell(size_t index) {   // CellsDataContainer.cp
 	PendingMutation m; m.kind = 0; m.a = index;
 	apply_mutation(view(), m);
 	if (!_is_initialized) _pending.push_back(m);
+	++_generation;
 }
 
 void CellsDataContainer::merge_cells(size_t source_cell_ind, size_t target_cell_ind) {   // :90-104
@@ -576,6 +579,7 @@ void CellsDataContainer::merge_cells(size_t source_cell_ind, size_t target_cell_
 	_umi_indexer_valid = false;
 	apply_mutation(view(), m);
 	if (!_is_initialized) _pending.push_back(m);
+	++_generation;
 }
 
 void CellsDataContainer::add_umi_to_cell(size_t cell_id, const ReadInfo &read_info) {   // :356-364
@@ -586,6 +590,7 @@ void CellsDataContainer::add_umi_to_cell(size_t cell_id, const ReadInfo &read_in
 	_umi_indexer_valid = false;
 	apply_mutation(view(), m);
 	if (!_is_initialized) _pending.push_back(m);
+	++_generation;
 }
 
 const StringIndexer &CellsDataContainer::umi_indexer() const {
@@ -609,6 +614,7 @@ void CellsDataContainer::merge_umis(size_t cell_id, size_t gene, const s_s_hash_
 	_umi_indexer_valid = false;
 	apply_mutation(view(), m);
 	if (!_is_initialized) _pending.push_back(m);
+	++_generation;
 }
 
 long CellsDataContainer::get_merge_target(size_t base_cell_ind) const {
@@ -636,7 +642,18 @@ Cell CellsDataContainer::cell(size_t index) const {
 	c._owner = this; c._ctx = view(); c._id = index;
 	check(dropest_cell_rows(c._ctx, index, 1, &c._row));   // DROPEST_ERR_RANGE -> std::out_of_range (vector::at in the reference)
 	c._barcode = decode(c._row.barcode);
+	c._gen = _generation;
 	return c;
+}
+
+// A Cell of an unsharded container is LIVE like the reference's `Cell &` (CellsDataContainer.h:107): whatever changed the container since
+// the row was read (add_record before set_initialized, the merges, the public mutators) makes the next accessor read it again.
+void Cell::sync() const {
+	if (!_owner || _gen == 0 || _owner->sharded() || _gen == _owner->_generation) return;
+	Cell *self = const_cast<Cell *>(this);
+	self->_ctx = _owner->view();
+	if (dropest_cell_rows(self->_ctx, _id, 1, &self->_row) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+	self->_gen = _owner->_generation;
 }
 
 Cell &CellsDataContainer::cell(size_t index) {
@@ -788,6 +805,7 @@ size_t CellsDataContainer::has_intron_reads_num() const { return size_t(counter(
 size_t CellsDataContainer::has_not_annotated_reads_num() const { return size_t(counter(_ctx, 3)); }
 
 std::vector<Cell::MoleculeRow> Cell::molecules() const {
+	sync();
 	uint64_t n = 0;
 	dropest_ctx *h = _ctx ? _ctx : _owner->handle();
 	if (dropest_cell_molecules(h, _id, &n, nullptr, nullptr, nullptr, nullptr) != DROPEST_OK) throw std::runtime_error(dropest_last_error());

@@ -233,14 +233,17 @@ public:
 
 class CellsDataContainer;
 
-// What Cell / Gene / UMI expose to ResultsPrinter and the tests, as a value snapshot of one cell.
+// What Cell / Gene / UMI expose to ResultsPrinter and the tests: one cell's row, read again whenever the (unsharded) container has changed
+// since -- a `Cell &` from CellsDataContainer::cell(index) shows later merges and mutations like the reference's.
 class Cell {
 	friend class CellsDataContainer;
 	const CellsDataContainer *_owner = nullptr;
-	dropest_ctx *_ctx = nullptr;      // the context the cell lives in (a sharded container: the owner shard's)
+	mutable dropest_ctx *_ctx = nullptr;      // the context the cell lives in (a sharded container: the owner shard's)
 	size_t _id = 0;
-	dropest_cell_row _row{};
+	mutable dropest_cell_row _row{};
 	std::string _barcode;
+	mutable uint64_t _gen = 0;                // the container's generation the row was read at (0: not tracked)
+	void sync() const;
 public:
 	struct MoleculeRow {
 		std::string gene, umi; size_t read_count; UMI::Mark mark;
@@ -251,16 +254,16 @@ public:
 			return res;
 		}
 	};
-	uint64_t barcode_code() const { return _row.barcode; }
-	bool is_merged() const { return _row.is_merged; }
-	bool is_excluded() const { return _row.is_excluded; }
-	bool is_real() const { return _row.is_real; }
+	uint64_t barcode_code() const { return _row.barcode; }   // (a cell's barcode never changes)
+	bool is_merged() const { sync(); return _row.is_merged; }
+	bool is_excluded() const { sync(); return _row.is_excluded; }
+	bool is_real() const { sync(); return _row.is_real; }
 	std::string barcode() const { return _barcode; }
-	size_t umis_number() const { return size_t(_row.total_umis); }
-	size_t requested_genes_num() const { return _row.requested_genes; }
-	size_t requested_umis_num() const { return _row.requested_umis; }
-	size_t size() const { return _row.n_genes; }
-	int stat(Stats::CellStatType t) const { return t == Stats::TOTAL_READS_PER_CB ? _row.total_reads : _row.total_umis; }
+	size_t umis_number() const { sync(); return size_t(_row.total_umis); }
+	size_t requested_genes_num() const { sync(); return _row.requested_genes; }
+	size_t requested_umis_num() const { sync(); return _row.requested_umis; }
+	size_t size() const { sync(); return _row.n_genes; }
+	int stat(Stats::CellStatType t) const { sync(); return t == Stats::TOTAL_READS_PER_CB ? _row.total_reads : _row.total_umis; }
 	std::vector<MoleculeRow> molecules() const;                                  // walk of genes() x umis()
 	std::unordered_map<std::string, size_t> requested_umis_per_gene(const UMI::Mark::query_t &query, bool return_reads) const;
 };
@@ -331,7 +334,9 @@ private:
 	void send_side_strings(dropest_ctx *ctx) const;
 	mutable StringIndexer _umi_indexer_cache;                 // umi_indexer(): built on demand from dropest_umi_first_seen
 	mutable bool _umi_indexer_valid = false;
-	mutable std::unordered_map<size_t, Cell> _cell_cache;     // Cell &cell(index): container-owned snapshots
+	mutable std::unordered_map<size_t, Cell> _cell_cache;     // Cell &cell(index): container-owned, live (Cell::sync)
+	mutable uint64_t _generation = 1;                         // bumped by whatever changes what a Cell shows
+	friend class Cell;
 
 	uint64_t encode(const std::string &s, std::unordered_map<std::string, uint64_t> &escapes);
 	void flush();
@@ -439,8 +444,8 @@ public:
 	void get_stat_by_real_cells(Stats::CellChrStatType stat, names_t &cell_barcodes, names_t &chromosome_names,
 	                            counts_t &counts) const;
 	Cell cell(size_t index) const;                                      // throws std::out_of_range
-	// CellsDataContainer.h:107: a reference to a container-owned snapshot of the cell, refreshed by every call for that index
-	// (what Cell exposes here is read-only; changes go through the container's mutators above)
+	// CellsDataContainer.h:107: a reference to a container-owned Cell that stays current (it reads its row again after the container
+	// changed; what Cell exposes here is read-only: changes go through the container's mutators above)
 	Cell &cell(size_t index);
 	// every real cell in cell-id order -- also on a sharded container, where that is the order of first appearance in the WHOLE
 	// stream and every Cell answers from the shard that owns its barcode -- and the positions of the filtered cells in that list

@@ -277,6 +277,32 @@ static void testBoundaryLeftovers() {   // CellsDataContainer.h:90 add_umi_to_ce
 	Cell &ref = container.cell(1);           // the non-const overload
 	CHECK_EQ(ref.barcode(), std::string("CCCTTAGGTCCA"));
 	CHECK_EQ(&container.cell(1), &ref);
+	// ... and the reference is LIVE like the reference's `Cell &` (CellsDataContainer.h:107): later changes of the container show through it
+	const int umis_ref = ref.stat(Stats::TOTAL_UMIS_PER_CB);
+	container.add_umi_to_cell(1, read_info("ignored", "GGGCCT", "Gene2"));
+	CHECK_EQ(ref.stat(Stats::TOTAL_UMIS_PER_CB), umis_ref + 1);
+	CHECK_EQ(by_gene(ref).at("Gene2").count("GGGCCT"), size_t(1));
+	Cell &other = container.cell(0);
+	CHECK(!other.is_merged()); CHECK(!ref.is_excluded());
+	container.merge_cells(0, 1);
+	CHECK(other.is_merged());
+	container.exclude_cell(1);
+	CHECK(ref.is_excluded());
+}
+
+static void testLiveCellBeforeInitialisation() {   // a `Cell &` taken while reads are still coming shows the reads that follow
+	Fixture f;
+	CellsDataContainer container(f.real_cb_strat, f.umi_merge_strat, f.any_mark);
+	container.add_record(read_info("AAATTAGGTCCA", "AAACCT", "Gene1"));
+	Cell &first = container.cell(0);
+	CHECK_EQ(first.stat(Stats::TOTAL_READS_PER_CB), 1); CHECK_EQ(first.size(), size_t(1));
+	container.add_record(read_info("AAATTAGGTCCA", "CCCCCT", "Gene2"));
+	container.add_record(read_info("AAATTAGGTCCA", "CCCCCT", "Gene2"));
+	CHECK_EQ(first.stat(Stats::TOTAL_READS_PER_CB), 3); CHECK_EQ(first.size(), size_t(2)); CHECK_EQ(first.umis_number(), size_t(2));
+	container.set_initialized();
+	CHECK_EQ(first.stat(Stats::TOTAL_READS_PER_CB), 3);            // the same numbers from the real context
+	container.merge_and_filter();
+	CHECK(first.is_real() || !first.is_real());                        // (reads its row again after the merge: must not throw)
 }
 
 static void testQualityLengthPerMolecule() {   // UMI.cpp:21-34 + Gene.cpp:20: the quality length belongs to the molecule
@@ -488,6 +514,7 @@ int main(int argc, char **argv) {
 		testPoissonMerge();
 		testUMIMerge();
 		testBoundaryLeftovers();
+		testLiveCellBeforeInitialisation();
 		testQualityLengthPerMolecule();
 		testMergeAndExcludeCells();
 		testShardedContainer();
