@@ -753,7 +753,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 	// alternate buffer), then a scan of the per-bucket row counts and the compaction into the dense table.  The small launch skips buckets
 	// beyond its LDS by itself, so it is queued BEFORE the host reads the partition's scalars back (a round trip of ~25 us the device would
 	// otherwise sit out).
-	const u32 SMALL_MAX = 2048;
+	static const u32 SMALL_MAX = [] { const char *e = getenv("DROPEST_SS_SMALL_MAX"); return e && atoi(e) >= 256 && atoi(e) <= 2048 ? u32(atoi(e)) : 2048u; }();   // (experiments)
 	const bool atomic_rank = lds_atomics_lane_ordered(cfg.device, stream);
 	ss_tmp.ensure(span * 2 + 2); ss_n_loc.ensure(F2); ss_prefix.ensure(F2); ss_chunk.ensure(1024);
 	SsLocalArgs a{};
@@ -765,6 +765,15 @@ bool dropest_ctx::splitter_sort_reduce() {
 	if (const char *e = getenv("DROPEST_SS_ATOMIC_BELOW")) a.atomic_below = u32(atoi(e));
 	a.cap = SMALL_MAX; a.skip_above = SMALL_MAX;
 	auto launch_small = [&] {
+		static const int wave_mode = [] { const char *e = getenv("DROPEST_SS_LOCAL_WAVE"); return e ? atoi(e) : 0; }();
+		if ((wave_mode == 64 || wave_mode == 128) && atomic_rank) {
+			const size_t lds1 = ss_local_lds_bytes(a.cap, wave_mode);
+			timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB), [&] {
+				if (wave_mode == 64) { if (VB) hipLaunchKernelGGL((ss_local_wave_kernel<64, 1, true>), dim3(F2), dim3(64), lds1, stream, a); else hipLaunchKernelGGL((ss_local_wave_kernel<64, 0, true>), dim3(F2), dim3(64), lds1, stream, a); }
+				else { if (VB) hipLaunchKernelGGL((ss_local_wave_kernel<128, 1, true>), dim3(F2), dim3(128), lds1, stream, a); else hipLaunchKernelGGL((ss_local_wave_kernel<128, 0, true>), dim3(F2), dim3(128), lds1, stream, a); }
+			});
+			return;
+		}
 		const size_t lds = ss_local_lds_bytes(a.cap, 256);
 		timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB), [&] {   // + 16 B per molecule row, added below once n_mol is known
 			if (atomic_rank) { if (VB) hipLaunchKernelGGL((ss_local_kernel<1, true>), dim3(F2), dim3(256), lds, stream, a); else hipLaunchKernelGGL((ss_local_kernel<0, true>), dim3(F2), dim3(256), lds, stream, a); }

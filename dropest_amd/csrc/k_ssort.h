@@ -525,14 +525,31 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint3
 			lrank[i] = old + before;
 		}
 		lds_barrier();
-		uint32_t run = 0;
-		if (tid < 256) {
+		if constexpr (THREADS >= 256) {
+			uint32_t run = 0;
+			if (tid < 256) {
 #pragma unroll
-			for (uint32_t k = 0; k < WAVES; ++k) { const uint32_t c = wcnt[k * 256 + tid]; wcnt[k * 256 + tid] = run; run += c; }
+				for (uint32_t k = 0; k < WAVES; ++k) { const uint32_t c = wcnt[k * 256 + tid]; wcnt[k * 256 + tid] = run; run += c; }
+			}
+			uint32_t total;
+			const uint32_t ex = block_excl_scan_u32<THREADS, true>(tid < 256 ? run : 0u, scratch, total);
+			if (tid < 256) tstart[tid] = ex;
+		} else {   // fewer threads than digits: 256 / THREADS consecutive digits per thread
+			constexpr uint32_t PER = 256 / THREADS;
+			uint32_t tot[PER], sum = 0;
+#pragma unroll
+			for (uint32_t j = 0; j < PER; ++j) {
+				const uint32_t d = tid * PER + j;
+				uint32_t run = 0;
+#pragma unroll
+				for (uint32_t k = 0; k < WAVES; ++k) { const uint32_t c = wcnt[k * 256 + d]; wcnt[k * 256 + d] = run; run += c; }
+				tot[j] = run; sum += run;
+			}
+			uint32_t total;
+			uint32_t ex = block_excl_scan_u32<THREADS, true>(sum, scratch, total);
+#pragma unroll
+			for (uint32_t j = 0; j < PER; ++j) { tstart[tid * PER + j] = ex; ex += tot[j]; }
 		}
-		uint32_t total;
-		const uint32_t ex = block_excl_scan_u32<THREADS, true>(tid < 256 ? run : 0u, scratch, total);
-		if (tid < 256) tstart[tid] = ex;
 		lds_barrier();
 #pragma unroll
 		for (int i = 0; i < ITEMS; ++i)
@@ -609,6 +626,17 @@ __global__ __launch_bounds__(256) void ss_local_kernel(SsLocalArgs a) {
 	if (cnt > a.skip_above) return;
 	if (cnt <= 1024) ss_local_run<256, 4, VB, ATOMIC_RANK>(a, b, base, cnt, ss_smem);
 	else ss_local_run<256, 8, VB, ATOMIC_RANK>(a, b, base, cnt, ss_smem);
+}
+// (experiment, DROPEST_SS_LOCAL_WAVE=64 / 128) the same finishing sort with one or two waves per bucket: no / cheaper workgroup barriers
+template <int THREADS, int VB, bool ATOMIC_RANK = false>
+__global__ __launch_bounds__(THREADS) void ss_local_wave_kernel(SsLocalArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char ss_smem[];
+	const uint32_t b = blockIdx.x;
+	const uint32_t cnt = a.bucket_cnt[b], base = a.bucket_base[b];
+	if (cnt == 0) { if (threadIdx.x == 0) a.n_loc[b] = 0; return; }
+	if (cnt > a.skip_above) return;
+	if (cnt <= 1024) ss_local_run<THREADS, 1024 / THREADS, VB, ATOMIC_RANK>(a, b, base, cnt, ss_smem);
+	else ss_local_run<THREADS, 2048 / THREADS, VB, ATOMIC_RANK>(a, b, base, cnt, ss_smem);
 }
 // listed buckets: medium launch 256 threads x 16 records (up to 4096), big launch 512 x 16 (up to 8192)
 template <int THREADS, int VB, bool ATOMIC_RANK = false>
