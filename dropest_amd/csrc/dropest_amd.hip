@@ -464,7 +464,7 @@ static int sort_mode_override() {   // read at every pass: tests switch it insid
 // The splitter sort's fan-out for n records and, when the partitions place their records by reservation (k_ssort.h: no histogram
 // passes), the capacities of the bucket regions.  build_keys sizes the key buffers from it: the regions of the second level take 1.75 n
 // records of address space.  DROPEST_SS_NO_RESERVE=1: always the counting partitions.
-struct SsPlan { bool applicable = false, reserve = false; int tb = 0, fb1 = 0, fb2 = 0; uint64_t cap1 = 0, cap2 = 0, span = 0; };
+struct SsPlan { bool applicable = false, reserve = false; int tb = 0, fb1 = 0, fb2 = 0; uint64_t cap1 = 0, cap2 = 0, span = 0, os = 64; };
 static SsPlan ss_plan(uint64_t n_reads, bool chr_from_gene, int val_bytes) {
 	SsPlan P;
 	const int mode = sort_mode_override();
@@ -481,6 +481,16 @@ static SsPlan ss_plan(uint64_t n_reads, bool chr_from_gene, int val_bytes) {
 	const uint64_t F1 = 1ull << P.fb1, F2 = 1ull << tb, mean1 = (n_reads + F1 - 1) / F1, mean2 = (n_reads + F2 - 1) / F2;
 	P.cap1 = (mean1 + mean1 / 16 + 2 * SS_TILE + 15) & ~15ull;
 	P.cap2 = (mean2 + mean2 * 3 / 4 + 64 + 15) & ~15ull;
+	// Samples per fine bucket.  A bucket spans `os` sample gaps: its size scatters like a Gamma(os) variable, 12.5 % at 64, 17.7 % at 32.
+	// Where the mean is at most half of what the finishing launch holds (2 048 records) -- 1e9 reads: 2^20 buckets of 954 -- half the
+	// sample does: the sample sort was 5.4 of 120 ms of kernels there, 2.6 now.  The regions then hold 2.5 x the mean
+	// (a Gamma(32) bucket beyond that: 1e-11; at 2.0 x it happened in a million buckets).
+	// (Only for large streams: below ~2.5e8 reads the sample sort is a matter of launch latencies, and the wider regions cost the second
+	// scatter what the smaller sample saves: 6e7 reads 4.77 against 4.80 ms of kernels.)
+	if (mean2 <= 1024 && n_reads >= (1ull << 28) && !getenv("DROPEST_SSORT_OS")) {
+		P.os = 32;
+		P.cap2 = (mean2 * 5 / 2 + 64 + 15) & ~15ull;
+	}
 	if (const char *e = getenv("DROPEST_SS_CAP2_PERCENT")) P.cap2 = (mean2 * uint64_t(std::max(100, atoi(e))) / 100 + 15) & ~15ull;   // tests: regions that overflow
 	P.span = std::max(F1 * P.cap1, F2 * P.cap2);
 	P.reserve = !getenv("DROPEST_SS_NO_RESERVE") && P.span < 0xFFFFFFF0ull;
@@ -713,7 +723,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 	const int ms = layout.mark_shift, VB = layout.val_bytes;
 	(void)tb;
 	// 64 samples per fine bucket: bucket sizes scatter by ~12 % around n / F2, so few exceed the small finishing launch
-	uint64_t os_max = 64;
+	uint64_t os_max = plan.os;
 	if (const char *e = getenv("DROPEST_SSORT_OS")) os_max = uint64_t(std::max(1, atoi(e)));
 	const u32 os = u32(std::max<uint64_t>(1, std::min<uint64_t>(os_max, uint64_t(n) / (uint64_t(F2) * 2))));
 	const u32 n_sample = F2 * os;
