@@ -518,6 +518,10 @@ struct dropest_ctx {
 	void plan_key_layout();
 	void build_keys(bool with_stats = false);
 	u32 main_sort_passes = 0, main_sort_kind = 0;   // kind: 0 LSD radix sort, 1 splitter sort
+	// exclusive scan of n counters (tile counts) + their total: one workgroup for short arrays, chunk sums + prefix for long ones (2e5 tile
+	// counts at C3 size took one workgroup 0.28 ms, five times a pass)
+	void scan_counts(const u32 *in, u32 *out, u32 n, u32 *total_out);
+	dropest::DevBuf<u32> scan_chunk;
 	void radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes = 4,
 	                const char *stat_prefix = nullptr);
 	// splitter sort (k_ssort.h): sample, splitters, partition scratch, look-back words

@@ -635,6 +635,17 @@ static std::vector<RadixPass> plan_radix_passes(u64 varying_mask) {
 	return wide;
 }
 
+void dropest_ctx::scan_counts(const u32 *in, u32 *out, u32 n, u32 *total_out) {
+	if (n <= 16384 || n > 1024u * 1024u) {
+		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, in, out, n, total_out);
+		return;
+	}
+	const u32 n_chunks = div_up(n, 1024);
+	scan_chunk.ensure(1024);
+	hipLaunchKernelGGL(ss_chunk_sums_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, in, n, scan_chunk.p);
+	hipLaunchKernelGGL(ss_prefix_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, in, n, scan_chunk.p, n_chunks, out, total_out);
+}
+
 void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_alt, u32 n, u64 varying_mask, int val_bytes,
                              const char *stat_prefix) {
 	if (n == 0) return;
@@ -958,8 +969,7 @@ static u32 run_segmented_reduce(dropest_ctx &c, const char *tag, P &policy, u32 
 		hipLaunchKernelGGL(seg_count_kernel<P>, dim3(tiles), dim3(SR_THREADS), 0, c.stream, policy, n, c.tile_counts.p);
 	});
 	c.timed("scan_small", double(tiles) * 8, [&] {
-		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, c.stream, c.tile_counts.p, c.tile_prefix.p, tiles,
-		                   c.scalars.p);
+		c.scan_counts(c.tile_counts.p, c.tile_prefix.p, tiles, c.scalars.p);
 	});
 	u32 total = 0;
 	c.fetch(&total, c.scalars.p, 4);
@@ -1111,7 +1121,7 @@ void dropest_ctx::fetch_real_cells(bool at_init) {
 	tile_counts.ensure(tiles); tile_prefix.ensure(tiles);
 	timed("flag_real", double(n_cells) * 8, [&] {
 		hipLaunchKernelGGL(count_real_kernel, dim3(tiles), dim3(RC_THREADS), 0, stream, cell_n_genes.p, n_cells, min_before, tile_counts.p);
-		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, tile_counts.p, tile_prefix.p, tiles, scalars.p);
+		scan_counts(tile_counts.p, tile_prefix.p, tiles, scalars.p);
 		hipLaunchKernelGGL(write_real_kernel, dim3(tiles), dim3(RC_THREADS), 0, stream, cell_n_genes.p, n_cells, min_before,
 		                   tile_prefix.p, list.p);
 	});

@@ -797,7 +797,7 @@ bool dropest_ctx::resort_changed_rows(u64 varying_mask) {
 	tile_counts.ensure(tiles); tile_prefix.ensure(tiles); scalars.ensure(16);
 	timed("mp_split_count", double(n_mol) * 16, [&] {
 		hipLaunchKernelGGL(mp_split_count_kernel, dim3(tiles), dim3(MP_THREADS), 0, stream, mol_key.p, keys_a.p, n_mol, mol_sorted_rows, tile_counts.p);
-		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, tile_counts.p, tile_prefix.p, tiles, scalars.p);
+		scan_counts(tile_counts.p, tile_prefix.p, tiles, scalars.p);
 	});
 	u32 nb = 0;
 	fetch(&nb, scalars.p, 4);

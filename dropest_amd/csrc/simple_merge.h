@@ -279,7 +279,7 @@ void dropest_ctx::simple_pair_table(const u64 *sorted, u32 n_valid, int cell_bit
 	SimplePairArgs pa{sorted, n_valid, cell_bits, d_cell_size, tile_prefix.p, tile_counts.p, nullptr};
 	timed("simple:umig_pairs", double(n_valid) * 16, [&] {
 		hipLaunchKernelGGL(umig_pairs_kernel<false>, dim3(tiles), dim3(SP_THREADS), 0, stream, pa);
-		hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, stream, tile_counts.p, tile_prefix.p, tiles, scalars.p);
+		scan_counts(tile_counts.p, tile_prefix.p, tiles, scalars.p);
 	});
 	u32 NP = 0;
 	fetch(&NP, scalars.p, 4);
