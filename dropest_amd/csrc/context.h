@@ -452,6 +452,7 @@ struct dropest_ctx {
 	dropest::PinnedBuf<u64> sort_stage;                  // staging of sort_filtered's key columns / permutation
 	dropest::DevBuf<u64> sort_cols;
 	std::vector<u32> sort_idx;
+	std::vector<int32_t> filtered_umis;   // TOTAL_UMIS of the cells of `filtered`, in that order (dense: the merge decision reads it per base)
 	std::vector<uint64_t> sort_ids;   // cell ids in the order of sort_idx (dense: the gather of the ordered list reads this, not `real`)
 	bool filtered_valid = false;
 	u32 filtered_threshold = 0;

@@ -1275,9 +1275,9 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 			HostStage st4(this, "sort_filtered:gather");
 			size_t start = 0;
 			if (max_cells > 0 && size_t(max_cells) < size_t(m)) start = size_t(m) - size_t(max_cells);
-			filtered.resize(m - start); filtered_ridx.resize(m - start);
-			parallel_ranges(m - start, [&](size_t b, size_t e, unsigned) {
-				for (size_t i = b; i < e; ++i) { const u32 at = perm[start + i]; filtered[i] = sort_ids[at]; filtered_ridx[i] = sort_idx[at]; }
+			filtered.resize(m - start); filtered_ridx.resize(m - start); filtered_umis.resize(m - start);
+			parallel_ranges(m - start, [&](size_t b, size_t e, unsigned) {   // (h_umis: the second key column, still in the staging buffer behind the permutation)
+				for (size_t i = b; i < e; ++i) { const u32 at = perm[start + i]; filtered[i] = sort_ids[at]; filtered_ridx[i] = sort_idx[at]; filtered_umis[i] = int32_t(h_umis[at]); }
 			});
 			filtered_valid = true;
 			return;
@@ -1345,7 +1345,8 @@ void dropest_ctx::sort_filtered(u32 genes_threshold, int max_cells) {
 	filtered.clear(); filtered_ridx.clear();
 	size_t start = 0;
 	if (max_cells > 0 && size_t(max_cells) < keys.size()) start = keys.size() - size_t(max_cells);
-	for (size_t i = start; i < keys.size(); ++i) { filtered.push_back(real[keys[i].idx].id); filtered_ridx.push_back(keys[i].idx); }
+	filtered_umis.clear();
+	for (size_t i = start; i < keys.size(); ++i) { filtered.push_back(real[keys[i].idx].id); filtered_ridx.push_back(keys[i].idx); filtered_umis.push_back(int32_t(keys[i].umis)); }
 	filtered_valid = true;
 }
 

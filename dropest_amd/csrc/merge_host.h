@@ -542,7 +542,11 @@ void dropest_ctx::compute_merge_targets(const std::vector<u32> &cells, const std
 	MergeUniverse U;
 	U.table = table; U.cell_cb = cell_cb.p; U.n_genes = cell_n_genes.p; U.total_umis = cell_total_umis.p;
 	U.real_index = cell_real_index.p; U.any_escaped = ingest.cb_escape_count != 0;
-	U.base_total_umis = [&](u32 f) { return real[ridx[f]].row.total_umis; };
+	// (the bases are the filtered cells in their order: their TOTAL_UMIS stand in a dense array beside the list -- 2.4e6 look-ups of
+	// real[ridx[f]] were a cache miss each in an array of fat rows, most of the 4.3 ms the decisions took at C3 size)
+	const bool dense_umis = filtered_valid && filtered_umis.size() == cells.size() && filtered_ridx.size() == ridx.size() && (ridx.empty() || (filtered_ridx.front() == ridx.front() && filtered_ridx.back() == ridx.back()));
+	const std::vector<int32_t> base_umis = dense_umis ? filtered_umis : std::vector<int32_t>();
+	U.base_total_umis = [&](u32 f) { return base_umis.empty() ? real[ridx[f]].row.total_umis : base_umis[f]; };
 	U.barcode_code = [&](u32 cell) { return u64(real[real_at(cell)].row.barcode); };
 	U.base_barcode_text = [&](u32 f) { return barcode_of(real[ridx[f]]); };
 	std::unordered_map<u64, u32> real_by_code;   // filled on first use (host search only)
