@@ -1167,7 +1167,14 @@ void dropest_ctx::request_filtered(u32 genes_threshold, int max_cells) {
 	// the real-cell count is cheap and always current; the ordering is produced when somebody reads it
 	filtered_threshold = genes_threshold; filtered_max_cells = max_cells; filtered_valid = false;
 	n_real_now = 0;
-	for (const HostCell &h : real) n_real_now += (!h.merged && !h.excluded && h.row.n_genes >= min_before);
+	constexpr unsigned W = dropest::HostPool::MAX;
+	uint64_t part[W + 1] = {0};   // (2.4e6 rows at C3 size: a millisecond or two for one thread)
+	const unsigned workers = parallel_ranges(real.size(), [&](size_t b, size_t e, unsigned w) {
+		uint64_t c = 0;
+		for (size_t i = b; i < e; ++i) { const HostCell &h = real[i]; c += (!h.merged && !h.excluded && h.row.n_genes >= min_before); }
+		part[w] = c;
+	}, 100000, W);
+	for (unsigned w = 0; w < workers; ++w) n_real_now += part[w];
 }
 
 const std::vector<uint64_t> &dropest_ctx::filtered_cells() {
