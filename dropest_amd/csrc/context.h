@@ -570,7 +570,7 @@ struct dropest_ctx {
 	// kernel time that swing with the load of the host.  Kept, they are written into warm pages.
 	struct MergeScratch {
 		dropest::MergeSearch S;
-		std::vector<u32> pb, inter, tr, cells, ridx, target_ridx, cur, rank, src, tgt32, lists;
+		std::vector<u32> pb, inter, tr, cells, ridx, target_ridx, cur, rank, src, tgt32, lists, ids_dense;
 		std::vector<long> targets;
 		std::vector<int64_t> tgt;
 		std::vector<int32_t> reads, umis;

@@ -7,7 +7,7 @@ B="python bench.py --no-secondary --cpu-sample 0 --push-sample 0"
 for i in 1 2; do
 $B --config c3 --reads 1e9 --steps 4 --warmup 1 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); h=d['host_stage_wall_ms_per_step']; s=sorted(d['step_ms'])
-print('c3', d['ms_per_step'], s, 'ksum', d['roofline']['pipeline']['kernel_ms_per_step'], {k: round(v,2) for k,v in h.items() if k.startswith('cb_merge:targets') or k.startswith('sort_filtered:g')})"
+print('c3', d['ms_per_step'], s, 'ksum', d['roofline']['pipeline']['kernel_ms_per_step'], {k: round(v,2) for k,v in h.items() if k.startswith('cb_merge:apply') or k=='cb_merge'})"
 done
 $B --config c4 --reads 1.25e8 --steps 6 --warmup 2 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=sorted(d['step_ms']); print('c4', d['ms_per_step'], s)"
