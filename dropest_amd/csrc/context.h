@@ -640,8 +640,9 @@ struct dropest_ctx {
 	void umi_patch_groups(const std::vector<u32> &p_idx, const std::vector<u32> &p_all, const std::vector<u32> &p_req,
 	                      const std::vector<u32> &p_rreq, const std::unordered_map<u32, int> &umis_removed);
 	void run_umi_merge_directional();            // -u (umi_directional_host.h)
-	void reaggregate_from_keys(u64 varying_mask); // keys_a / vals_a hold the re-keyed molecule table
-	bool resort_changed_rows(u64 varying_mask);   // split + sort the changed rows + merge (k_mergepath.h)
+	void reaggregate_from_keys(u64 varying_mask, bool sorted_already = false); // keys_a / vals_a hold the re-keyed molecule table
+	// split + sort the changed rows + merge (k_mergepath.h); d_remap: the new keys are made on the fly from the cell -> target table
+	bool resort_changed_rows(u64 varying_mask, const u32 *d_remap = nullptr, int cell_shift = 0, u64 *varying_out = nullptr);
 	u32 mol_sorted_rows = 0xFFFFFFFFu;            // rows of the molecule table below this index are sorted (a sharded merge appends behind)
 	dropest::DevBuf<u64> mp_bk, mp_bk2;
 	dropest::DevBuf<u32> mp_bv, mp_bv2, mp_astart;

@@ -786,6 +786,13 @@ void dropest_ctx::reaggregate_after_merge() {
 	u64 init[2] = {0ull, ~0ull};
 	u64 *d_or_and = reinterpret_cast<u64 *>(scalars.p + 4);
 	HIP_CHECK(hipMemcpyAsync(d_or_and, init, 16, hipMemcpyHostToDevice, stream));
+	// Only the cell field of a key changes: when few rows change, the new keys are made on the fly by the split kernels and the re-keyed
+	// array is never written (k_mergepath.h: MpRekey) -- at C3 size the rekey kernel was 1.7 ms, the arrays 6.4 GB of traffic.
+	{
+		u64 varying = 0;
+		if (resort_changed_rows(0, remap.p, layout.gene_bits + layout.umi_bits, &varying)) { reaggregate_from_keys(varying, true); return; }
+		HIP_CHECK(hipMemcpyAsync(d_or_and, init, 16, hipMemcpyHostToDevice, stream));   // (the attempt used the words)
+	}
 	const u32 blocks = std::min<u32>(div_up(n_mol, 256), 4096u);
 	timed("rekey_molecules", double(n_mol) * 28, [&] {
 		hipLaunchKernelGGL(rekey_molecules_kernel, dim3(blocks), dim3(256), 0, stream, mol_key.p, n_mol,
@@ -802,21 +809,31 @@ void dropest_ctx::reaggregate_after_merge() {
 // keys_a holds the new key of every molecule row: when only a small part of them differs from the current (sorted) keys,
 // split / sort the changed part / merge (k_mergepath.h) instead of radix-sorting everything.  Returns false when the
 // radix sort should run (many changes); else leaves the sorted (key, old row) pairs in keys_a / vals_a.
-bool dropest_ctx::resort_changed_rows(u64 varying_mask) {
+bool dropest_ctx::resort_changed_rows(u64 varying_mask, const u32 *d_remap, int cell_shift, u64 *varying_out) {
 	if (n_mol < 4 * u32(MP_TILE)) return false;
 	const u32 tiles = div_up(n_mol, u32(MP_TILE));
 	tile_counts.ensure(tiles); tile_prefix.ensure(tiles); scalars.ensure(16);
-	timed("mp_split_count", double(n_mol) * 16, [&] {
-		hipLaunchKernelGGL(mp_split_count_kernel, dim3(tiles), dim3(MP_THREADS), 0, stream, mol_key.p, keys_a.p, n_mol, mol_sorted_rows, tile_counts.p);
+	const MpRekey rk{keys_a.p, d_remap, cell_shift};
+	u64 *d_or_and = d_remap ? reinterpret_cast<u64 *>(scalars.p + 4) : nullptr;   // (reaggregate_after_merge initialised the two words)
+	timed("mp_split_count", double(n_mol) * (d_remap ? 12 : 16), [&] {
+		hipLaunchKernelGGL(mp_split_count_kernel, dim3(tiles), dim3(MP_THREADS), 0, stream, mol_key.p, rk, n_mol, mol_sorted_rows, tile_counts.p,
+		                   reinterpret_cast<unsigned long long *>(d_or_and));
 		scan_counts(tile_counts.p, tile_prefix.p, tiles, scalars.p);
 	});
-	u32 nb = 0;
-	fetch(&nb, scalars.p, 4);
+	u32 head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	fetch(head, scalars.p, 32);
+	const u32 nb = head[0];
+	if (d_remap) {
+		u64 or_and[2];
+		std::memcpy(or_and, head + 4, 16);
+		varying_mask = or_and[0] ^ or_and[1];
+		if (varying_out) *varying_out = varying_mask;
+	}
 	if (nb == 0 || nb > n_mol / 4) return false;
 	const u32 na = n_mol - nb;
 	mp_bk.ensure(nb); mp_bk2.ensure(nb); mp_bv.ensure(nb); mp_bv2.ensure(nb);
 	timed("mp_split_write", double(n_mol) * 28, [&] {
-		hipLaunchKernelGGL(mp_split_write_kernel, dim3(tiles), dim3(MP_THREADS), 0, stream, mol_key.p, keys_a.p, n_mol, mol_sorted_rows, tile_prefix.p,
+		hipLaunchKernelGGL(mp_split_write_kernel, dim3(tiles), dim3(MP_THREADS), 0, stream, mol_key.p, rk, n_mol, mol_sorted_rows, tile_prefix.p,
 		                   keys_b.p, vals_b.p, mp_bk.p, mp_bv.p);
 	});
 	u64 *bk = mp_bk.p, *bk_alt = mp_bk2.p;
@@ -833,11 +850,11 @@ bool dropest_ctx::resort_changed_rows(u64 varying_mask) {
 	return true;
 }
 
-void dropest_ctx::reaggregate_from_keys(u64 varying_mask) {
+void dropest_ctx::reaggregate_from_keys(u64 varying_mask, bool sorted_already) {
 	invalidate_prefetch();   // a cm_raw prefetch in flight reads the tables this call rewrites
 	u64 *keys = keys_a.p, *keys_alt = keys_b.p;
 	u32 *vals = vals_a.p, *vals_alt = vals_b.p;
-	if (!resort_changed_rows(varying_mask)) radix_sort(keys, vals, keys_alt, vals_alt, n_mol, varying_mask);
+	if (!sorted_already && !resort_changed_rows(varying_mask)) radix_sort(keys, vals, keys_alt, vals_alt, n_mol, varying_mask);
 	u32 new_n = 0;
 	if (chr_from_gene) {
 		RekeyedToMoleculesX p{};
