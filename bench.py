@@ -94,7 +94,9 @@ def one_step(ctx, form=None):
     else:
         cm = ctx.count_matrix_csc(filtered=True)
         cm_raw = ctx.count_matrix_csc(filtered=False)
-    return cm, cm_raw, ctx.filtered_cells()
+    # the metric names the merge targets beside the matrix: the (source, target) pairs of the CB merge are fetched inside the step
+    # (host-resident already after merge_and_filter: two arrays of 8 bytes per merged cell, none at C2, ~2.4e6 pairs at C3)
+    return cm, cm_raw, ctx.filtered_cells(), ctx.merge_target_pairs()
 
 
 def nnz_of(m):
@@ -429,7 +431,8 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
                                    + (", no whitelist (SimpleMergeStrategy)" if args.no_whitelist else "")
                                    + (", -M (Poisson decisions)" if args.poisson else ""),
                        "reads_total": total_reads, "parallelism": "cb-hash-shard x%d%s" % (world, " (sharded runner, forced exchange)" if force_sharded else ""),
-                       "cm_nnz": nnz_of(cm), "cm_raw_nnz": raw_nnz, "filtered_cells": int(len(out[2])), "sort_layout": get_layout(),
+                       "cm_nnz": nnz_of(cm), "cm_raw_nnz": raw_nnz, "filtered_cells": int(len(out[2])),
+                       "merge_targets_fetched_per_step": int(len(out[3][0])) if len(out) > 3 and out[3] is not None else None, "sort_layout": get_layout(),
                        "matrix_form": form_text(cm, out[1]), "matrix_forms": forms},
             "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "host_ingest": ingest, "step_ms": step_ms, "kernels_ms_per_step": kernels,
             "kernel_table": "separate pass of %d steps after the timed region, events on every launch" % table_steps,
@@ -443,6 +446,37 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
         ctx.close()
     if dev is not None:
         dev.free()
+    return line
+
+
+def finish_line(line):
+    """The numbers that matter stand twice in the line: as scalars inside `config` (what a reader of the parsed record keeps) and as the
+    LAST key, `summary` (what a reader of the line's tail keeps); the kernel / stage tables stand in between."""
+    if line is None:
+        return line
+    sec = line.get("secondary") or {}
+    c3, sh = sec.get("c3_1e9") or {}, sec.get("c2_sharded_runner") or {}
+    summary = {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "n_gpus": line["n_gpus"],
+               "roofline_kernel": (line.get("roofline") or {}).get("kernel"), "roofline_frac": (line.get("roofline") or {}).get("frac"),
+               "kernel_ms_per_step": ((line.get("roofline") or {}).get("pipeline") or {}).get("kernel_ms_per_step"),
+               "bytes_per_read_measured": ((line.get("roofline") or {}).get("pipeline") or {}).get("bytes_per_read_measured"),
+               "merge_targets_fetched_per_step": line["config"].get("merge_targets_fetched_per_step")}
+    if "value" in c3:
+        summary.update(c3_1e9_value=c3["value"], c3_1e9_ms_per_step=c3["ms_per_step"],
+                       c3_1e9_roofline_kernel=(c3.get("roofline") or {}).get("kernel"), c3_1e9_roofline_frac=(c3.get("roofline") or {}).get("frac"),
+                       c3_1e9_kernel_ms_per_step=((c3.get("roofline") or {}).get("pipeline") or {}).get("kernel_ms_per_step"),
+                       c3_1e9_merge_targets=c3.get("config", {}).get("merge_targets_fetched_per_step"))
+    elif "error" in c3:
+        summary["c3_1e9_error"] = c3["error"][:200]
+    if "value" in sh:
+        summary.update(c2_sharded_value=sh["value"], c2_sharded_ms_per_step=sh["ms_per_step"], c2_sharded_x_plain=sh.get("x_plain"),
+                       c2_sharded_x_plain_same_end_point=sh.get("x_plain_same_end_point"), c2_sharded_end_point=sh.get("end_point_short"))
+    elif "error" in sh:
+        summary["c2_sharded_error"] = sh["error"][:200]
+    for k, v in summary.items():           # scalars only: they survive in the parsed record's `config`
+        if k not in ("value", "unit", "ms_per_step", "n_gpus") and v is not None:
+            line["config"][k] = v
+    line["summary"] = summary              # last key of the line
     return line
 
 
@@ -526,7 +560,7 @@ def main():
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(finish_line(line)), flush=True)
         if saved_stdout is not None or rccl_came_up:
             os.dup2(2, 1)          # whatever RCCL still prints while the communicator goes down belongs on stderr
     if dist is not None:

@@ -382,13 +382,18 @@ class Context:
             self._chk(self.L.dropest_filtered_cells(self.h, C.byref(n), out.ctypes.data))
         return out
 
-    def merge_targets(self):
-        """Full merge_targets() vector of the reference (identity where nothing was merged)."""
+    def merge_target_pairs(self):
+        """(source cell ids, target cell ids) of the cells the CB merge folded: the non-identity entries of merge_targets()."""
         n = C.c_uint64()
         self._chk(self.L.dropest_merge_targets(self.h, C.byref(n), None, None))
         src = np.zeros(n.value, np.uint64); tgt = np.zeros(n.value, np.uint64)
         if n.value:
             self._chk(self.L.dropest_merge_targets(self.h, C.byref(n), src.ctypes.data, tgt.ctypes.data))
+        return src, tgt
+
+    def merge_targets(self):
+        """Full merge_targets() vector of the reference (identity where nothing was merged)."""
+        src, tgt = self.merge_target_pairs()
         full = np.arange(self.total_cells_number(), dtype=np.uint64)
         full[src.astype(np.int64)] = tgt
         return full

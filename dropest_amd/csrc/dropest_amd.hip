@@ -1631,6 +1631,8 @@ void dropest_ctx::wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_
 	static const bool trace = getenv("DROPEST_WIRE_TRACE") != nullptr;
 	job->trace = trace;
 	static const uint64_t slice_entries = [] { const char *e = getenv("DROPEST_DECODE_SLICE"); return e && atoll(e) >= 1024 ? uint64_t(atoll(e)) : uint64_t(1) << 16; }();
+	static const uint32_t test_delay = [] { const char *e = getenv("DROPEST_DECODE_TEST_DELAY_US"); return e ? uint32_t(std::max(0, atoi(e))) : 0u; }();
+	job->test_delay_us = test_delay;
 	job->prepare(slice_entries);
 	M.job = job; M.wire = true;
 	M.job_t0 = std::chrono::steady_clock::now();
@@ -2543,11 +2545,17 @@ dropest_status dropest_matrix_bytes_widen(const dropest_matrix_bytes *m, uint32_
 		job->r_count = &nr; job->r_pos = m->row_listed_pos; job->r_val = m->row_listed_row; job->rcap = nr;
 		job->v_count = &nv; job->v_pos = m->value_listed_pos; job->v_val = m->value_listed_value; job->vcap = nv;
 		job->check_marks = true;
-		job->prepare(uint64_t(1) << 16);
+		// (read at every call: tests run small slices with workers that nap between claiming a slice and walking it)
+		const char *e_slice = getenv("DROPEST_DECODE_SLICE"), *e_delay = getenv("DROPEST_DECODE_TEST_DELAY_US");
+		if (e_delay) job->test_delay_us = uint32_t(std::max(0, atoi(e_delay)));
+		job->prepare(e_slice && atoll(e_slice) >= 64 ? uint64_t(atoll(e_slice)) : uint64_t(1) << 16);
 		dropest::DecodePool::get().submit(job);
 		job->work(true);
 		const int st = job->wait();
 		job->quiesce();   // the caller's arrays are its own again when this returns
+		// every slice is counted exactly once, by whoever finished it first: a second count would have ended the job one slice early
+		if (st == dropest::DecodeJob::DONE && job->slice_done.load() != uint32_t(job->slice_end.size()))
+			throw DeviceError("byte matrix: internal: " + std::to_string(job->slice_done.load()) + " slices counted, " + std::to_string(job->slice_end.size()) + " exist");
 		if (st == dropest::DecodeJob::BAD_ROW) throw InvalidError("byte matrix: a listed row does not stand on a 255");
 		if (st == dropest::DecodeJob::BAD_VALUE) throw InvalidError("byte matrix: a listed value does not stand on a 255");
 		if (st != dropest::DecodeJob::DONE) throw InvalidError("byte matrix: the decode failed");

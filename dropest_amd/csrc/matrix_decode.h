@@ -321,7 +321,10 @@ struct DecodeJob {
 			const uint32_t s = slice_next.fetch_add(1, std::memory_order_relaxed);
 			if (s >= n_slices) break;
 			if (!wait_chunk(slice_chunk[s])) { if (running()) finish(FAILED); return; }
-			slice_state[s].store(1, std::memory_order_relaxed);
+			// never downgrade the state: a rescuer (or a worker past its patience) may have walked this slice while we waited for the chunk --
+			// a plain store of 1 over its 2 would let walk_slice count the slice a second time and finish the job one slice early
+			{ uint8_t expect = 0; (void)slice_state[s].compare_exchange_strong(expect, uint8_t(1), std::memory_order_acq_rel); }
+			if (test_delay_us) std::this_thread::sleep_for(std::chrono::microseconds(test_delay_us));   // (tests: a worker that loses its CPU right here)
 			walk_slice(s, n_slices);
 		}
 		// Nothing left to claim: the slices others have claimed and not finished, oldest first (a slice walked twice gets the same values twice)
@@ -355,16 +358,22 @@ struct DecodeJob {
 		if (it < 2048u) { cpu_relax(); return; }
 		std::this_thread::sleep_for(std::chrono::microseconds(20));
 	}
-	// Chunk j's bytes are on the host.
+	// Chunk j's bytes are on the host.  A flag that never comes (a device fault, an aborted stream: the kernel that raises it never ran)
+	// fails the job after FLAG_TIMEOUT_S instead of parking the pool's workers -- and every later settle() -- for ever.
+	static constexpr double FLAG_TIMEOUT_S = 120.0;
 	bool wait_chunk(uint32_t j) {
+		std::chrono::steady_clock::time_point t0;
 		for (uint32_t it = 0;; ++it) {
 			if (chunk_ready[j].load(std::memory_order_acquire)) return true;
 			if (!running()) return false;
 			if (flags[1 + j] == epoch) { std::atomic_thread_fence(std::memory_order_acquire); chunk_ready[j].store(1, std::memory_order_release); return true; }
+			if (it == 4096u) t0 = std::chrono::steady_clock::now();
+			else if (it > 4096u && (it & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > FLAG_TIMEOUT_S) { finish(FAILED); return false; }
 			idle(it);
 		}
 	}
 	bool check_marks = false;
+	uint32_t test_delay_us = 0;                      // DROPEST_DECODE_TEST_DELAY_US (tests only): every worker naps between claiming a slice and walking it
 	bool trace = false;                              // DROPEST_WIRE_TRACE: the slowest slice of the job (a descheduled worker shows here)
 	std::atomic<uint64_t> slowest_slice_ns{0};
 	int wait() {

@@ -259,10 +259,18 @@ struct HostMailbox {
 		base = static_cast<char *>(m);   // (a fresh shm object reads as zeros: the header starts at 0 / 0 / 0 / 0)
 		// rank 0 signs the object it has just created; the others attach only to a signed one (an object of the same name that rank 0 is
 		// about to unlink and replace -- a leftover -- never carries this run's word)
-		if (r == 0) hdr()->magic.store(magic_of(token), std::memory_order_release);
-		else wait_until([&] { return hdr()->magic.load(std::memory_order_acquire) == magic_of(token); }, "signature", false);
-		hdr()->attached.fetch_add(1, std::memory_order_acq_rel);
-		wait_until([&] { return hdr()->attached.load(std::memory_order_acquire) >= uint32_t(world); }, "attach");
+		// (a wait that times out leaves the constructor by an exception: no destructor runs, so the mapping -- and on rank 0 the name, which
+		// is otherwise unlinked only once everybody is in -- are released here)
+		try {
+			if (r == 0) hdr()->magic.store(magic_of(token), std::memory_order_release);
+			else wait_until([&] { return hdr()->magic.load(std::memory_order_acquire) == magic_of(token); }, "signature", false);
+			hdr()->attached.fetch_add(1, std::memory_order_acq_rel);
+			wait_until([&] { return hdr()->attached.load(std::memory_order_acquire) >= uint32_t(world); }, "attach");
+		} catch (...) {
+			munmap(base, bytes); base = nullptr;
+			if (r == 0) shm_unlink(path);
+			throw;
+		}
 		if (r == 0) shm_unlink(path);   // the mappings keep it alive; nothing is left behind on a crash
 	}
 	~HostMailbox() { if (base) munmap(base, bytes); }
@@ -989,15 +997,22 @@ void dropest_shard::partition_and_exchange() {
 		}
 		for (int p = 0; p < world; ++p) send_cnt[size_t(p)] = totals[size_t(p)];
 		// block sizes and field widths of everybody, in one collective
-		std::vector<uint64_t> mine(size_t(world) + 5), every((size_t(world) + 5) * size_t(world));
+		// (the sixth word: did this shard measure its widths on a sample?  A shard that took the exact path -- its exact_widths option, an
+		// earlier pass that did not fit -- must still lay the record out like the others and join their 'did everything fit' collective:
+		// the layout below follows what ANY shard did, never this shard's own option alone -- ADVICE r4)
+		const size_t W = size_t(world) + 6;
+		std::vector<uint64_t> mine(W), every(W * size_t(world));
 		for (int p = 0; p < world; ++p) mine[size_t(p)] = send_cnt[size_t(p)];
 		for (int k = 0; k < 5; ++k) mine[size_t(world) + size_t(k)] = stats[k];
+		mine[size_t(world) + 5] = sampled ? 1u : 0u;
 		tr->gather_host(mine.data(), mine.size() * 8, every.data());
 		uint64_t g[5] = {0, 0, 0, 0, 0};
+		bool any_sampled = false;
 		for (int p = 0; p < world; ++p) {
-			for (int q = 0; q < world; ++q) all_cnt[size_t(p) * size_t(world) + size_t(q)] = every[size_t(p) * (size_t(world) + 5) + size_t(q)];
-			for (int k = 0; k < 4; ++k) g[k] = std::max(g[k], every[size_t(p) * (size_t(world) + 5) + size_t(world) + size_t(k)]);
-			g[4] |= every[size_t(p) * (size_t(world) + 5) + size_t(world) + 4];
+			for (int q = 0; q < world; ++q) all_cnt[size_t(p) * size_t(world) + size_t(q)] = every[size_t(p) * W + size_t(q)];
+			for (int k = 0; k < 4; ++k) g[k] = std::max(g[k], every[size_t(p) * W + size_t(world) + size_t(k)]);
+			g[4] |= every[size_t(p) * W + size_t(world) + 4];
+			any_sampled |= every[size_t(p) * W + size_t(world) + 5] != 0;
 		}
 		const int cb_bits = std::max(1, bit_length(g[0])), umi_bits = std::max(1, bit_length(g[1]));
 		const int gene_bits = std::max(1, bit_length(g[2])), chr_bits = std::max(1, bit_length(g[3]));
@@ -1005,7 +1020,7 @@ void dropest_shard::partition_and_exchange() {
 		idx_exchanged = want_idx || !packed;
 		pack.cb_bits = cb_bits;
 		// sampled widths: the gene field takes every bit the chromosome does not need (a wider field costs nothing), the chromosome one bit of slack
-		pack.gene_bits = sampled && packed ? std::max(gene_bits, 32 - 3 - std::min(chr_bits + 1, 32 - 3 - gene_bits)) : gene_bits;
+		pack.gene_bits = any_sampled && packed ? std::max(gene_bits, 32 - 3 - std::min(chr_bits + 1, 32 - 3 - gene_bits)) : gene_bits;
 		rec_bytes = packed ? (idx_exchanged ? 16 : 12) : 28;
 		send_off.assign(size_t(world) + 1, 0);
 		for (int p = 0; p < world; ++p) send_off[size_t(p) + 1] = send_off[size_t(p)] + send_cnt[size_t(p)];
@@ -1024,7 +1039,7 @@ void dropest_shard::partition_and_exchange() {
 		if (n) {
 			const int owner_bits = std::max(1, bit_length(uint64_t(world - 1)));
 			OwnerSelf self{};
-			if (sampled && packed) { HIP_CHECK(hipMemsetAsync(d_stats + 5, 0, 8, c.stream)); self.bad = reinterpret_cast<u32 *>(d_stats + 5); }
+			if (any_sampled && packed) { HIP_CHECK(hipMemsetAsync(d_stats + 5, 0, 8, c.stream)); self.bad = reinterpret_cast<u32 *>(d_stats + 5); }
 			self.owner = u32(rank);
 			self.w0 = x_w0.p + recv_off[size_t(rank)] - send_off[size_t(rank)];     // (index = position in the partition's output)
 			self.w1 = x_w1.p + recv_off[size_t(rank)] - send_off[size_t(rank)];
@@ -1034,7 +1049,7 @@ void dropest_shard::partition_and_exchange() {
 			                        p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p, pack);
 			HIP_CHECK(hipGetLastError());
 		}
-		if (!(sampled && packed)) return true;
+		if (!(any_sampled && packed)) return true;
 		// did every read of every shard fit?  (one word from the device, one small collective)
 		uint64_t bad = 0;
 		if (n) { u32 b32 = 0; c.fetch(&b32, d_stats + 5, 4); bad = b32; }

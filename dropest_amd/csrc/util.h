@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cstdint>
 #include <cstdio>
@@ -115,9 +116,13 @@ struct DevDebug {
 			return x;
 		}
 	}
-	static DevDebug &slot() { static DevDebug d = read_env(); return d; }
-	static const DevDebug &get() { return slot(); }
-	static void refresh() { slot() = read_env(); }   // dropest_debug_refresh: tests switch the variables inside one process
+	// An immutable snapshot behind an atomic pointer: refresh() publishes a NEW one (the old ones stay allocated -- a few dozen bytes per
+	// refresh, tests only), so a shard thread that reads the switches while another thread refreshes them sees one consistent set.
+	static std::atomic<const DevDebug *> &slot() { static std::atomic<const DevDebug *> d{new DevDebug(read_env())}; return d; }
+	static const DevDebug &get() { return *slot().load(std::memory_order_acquire); }
+	// has the registry ever been on in this process?  Blocks registered then must leave `live` when they are freed, whatever the switches say now
+	static std::atomic<bool> &ever_on() { static std::atomic<bool> b{false}; return b; }
+	static void refresh() { slot().store(new DevDebug(read_env()), std::memory_order_release); }   // dropest_debug_refresh: tests switch the variables inside one process
 };
 struct DevRegistry {
 	struct Entry { size_t bytes; uint64_t ordinal; bool persistent; int device; };
@@ -144,6 +149,7 @@ struct DevRegistry {
 			if (e != hipSuccess) throw DeviceError(std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e) + " (" + file + ":" + std::to_string(line) + ")");
 			return p;
 		}
+		DevDebug::ever_on().store(true, std::memory_order_relaxed);
 		void *p = nullptr;
 		bool recycled = false;
 		uint64_t ordinal;
@@ -180,7 +186,9 @@ struct DevRegistry {
 	}
 	void release(void *p) {
 		const DevDebug &dbg = DevDebug::get();
-		if (!dbg.any) { (void)hipFree(p); return; }
+		// (a block registered while the switches were on and freed with them off must still leave `live`: poison_all would otherwise
+		// write into freed -- or reused -- memory once the registry is switched on again)
+		if (!dbg.any && !DevDebug::ever_on().load(std::memory_order_relaxed)) { (void)hipFree(p); return; }
 		size_t bytes = 0;
 		int device = 0;
 		{

@@ -54,9 +54,8 @@ def test_a_rank_that_never_arrives_fails_the_collective_on_the_others():
         p.join(timeout=30)
     assert all(rc != 0 for _, rc, _ in got), got
     assert all("did not arrive" in msg or "did not create" in msg or "failed" in msg for _, _, msg in got), got
-    for n in os.listdir("/dev/shm"):           # (rank 0 unlinks only after everybody attached: the object of a failed attach is removed here)
-        if n.startswith("dropest_mb_%x" % token):
-            os.unlink("/dev/shm/" + n)
+    # rank 0 normally unlinks once everybody is attached; after a failed attach its constructor removes the object itself
+    assert not any(n.startswith("dropest_mb_%x" % token) for n in os.listdir("/dev/shm"))
 
 
 def test_a_rank_that_dies_between_collectives_fails_the_others():

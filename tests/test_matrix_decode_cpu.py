@@ -90,3 +90,17 @@ def test_scalar_walk_equals_the_vector_walk(monkeypatch):
                 {"DROPEST_DECODE_NT": "0"}, {"DROPEST_DECODE_NT": "1"}, {"DROPEST_DECODE_THREADS": "1"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_workers_that_nap_after_claiming_a_slice_never_make_a_slice_count_twice(monkeypatch):
+    """a worker that claimed a slice, lost its CPU, and then stored 'somebody walks it' over the rescuer's 'done'
+    made the slice count twice -- the job finished one slice early.  Small slices + a nap between the claim and the walk: every slice
+    is rescued by the caller while its worker sleeps; the library checks that every slice was counted exactly once."""
+    monkeypatch.setenv("DROPEST_DECODE_SLICE", "256")
+    monkeypatch.setenv("DROPEST_DECODE_TEST_DELAY_US", "300")
+    rng = np.random.default_rng(21)
+    for _ in range(6):
+        colptr, rows, vals = random_matrix(rng, 3000, 30000, 30)
+        st, ro, vo = widen(colptr, *encode(colptr, rows, vals, rng))
+        assert st == 0, capi.lib().dropest_last_error()
+        assert np.array_equal(ro, rows) and np.array_equal(vo, vals)
