@@ -546,12 +546,17 @@ def main():
                 os.close(keep)
                 rccl_came_up = True
             plain_bytes = (line["config"].get("matrix_forms") or {}).get("bytes_ms_per_step")
+            slots = "dgCMatrix slots" in sh["config"]["matrix_form"]      # (the default since round 5: the sharded step ends where the plain one does)
+            same = line["ms_per_step"] if slots else plain_bytes
             line["secondary"]["c2_sharded_runner"] = dict({k: sh[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "step_ms", "exchange")},
                                                           x_plain=round(sh["ms_per_step"] / line["ms_per_step"], 3),
-                                                          x_plain_same_end_point=None if not plain_bytes else round(sh["ms_per_step"] / plain_bytes, 3),
-                                                          end_point="the sharded step ends with the byte form in the node-shared host buffer (every shard writes its columns over its own "
-                                                                    "PCIe link); the plain step of the headline ends with the 32-bit slots -- x_plain_same_end_point divides by the plain step "
-                                                                    "that also ends at the byte form (config.matrix_forms.bytes_ms_per_step, 3 steps)",
+                                                          x_plain_same_end_point=None if not same else round(sh["ms_per_step"] / same, 3),
+                                                          end_point_short="u32 slots" if slots else "bytes",
+                                                          end_point=("the sharded step ends with the 32-bit dgCMatrix slots in the node-shared host buffer, like the plain step of the headline: every "
+                                                                     "shard's columns cross its own PCIe link as bytes and are widened into the shared slots by its host threads under the copy -- "
+                                                                     "x_plain_same_end_point = x_plain") if slots else
+                                                                    ("the sharded step ends with the byte form in the node-shared host buffer; x_plain_same_end_point divides by the plain step "
+                                                                     "that also ends at the byte form (config.matrix_forms.bytes_ms_per_step, 3 steps)"),
                                                           parallelism=sh["config"]["parallelism"], matrix_form=sh["config"]["matrix_form"],
                                                           phases_ms_per_step={k: v for k, v in sh["host_stage_wall_ms_per_step"].items() if k.startswith("shard:")})
         except Exception as e:

@@ -196,6 +196,7 @@ def lib():
         "dropest_reserve_reads": (C.c_int, [vp, C.c_uint64]),
         "dropest_shard_group_step": (C.c_int, [vp, C.c_int32]),
         "dropest_shard_matrix": (C.c_int, [vp, C.c_int, u64p, u64p, P(vp), P(vp), P(vp), P(vp)]),
+        "dropest_shard_matrix_form": (C.c_int, [vp, C.c_int, P(C.c_int32)]),
         "dropest_shard_matrix_narrow": (C.c_int, [vp, C.c_int, u64p, u64p, P(vp), P(vp), P(vp), P(vp), u64p, P(vp), P(vp)]),
         "dropest_shard_matrix_bytes": (C.c_int, [vp, C.c_int, P(MatrixBytes), P(vp)]),
         "dropest_shard_merged_barcodes": (C.c_int, [vp, u64p, vp, vp]),
@@ -233,7 +234,7 @@ EXPORTED_SYMBOLS = [
     "dropest_dev_copy_to_host", "dropest_dev_copy_from_host", "dropest_dev_count", "dropest_dev_sync",
     "dropest_rand_sequence", "dropest_table_sizes",
     "dropest_shard_unique_id", "dropest_shard_create", "dropest_shard_group_create", "dropest_shard_destroy", "dropest_shard_ctx",
-    "dropest_shard_set_reads_device", "dropest_shard_push_reads", "dropest_reserve_reads", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix",
+    "dropest_shard_set_reads_device", "dropest_shard_push_reads", "dropest_reserve_reads", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix", "dropest_shard_matrix_form",
     "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option", "dropest_plan_columns",
     "dropest_key_width", "dropest_ctx_split", "dropest_shard_matrix_narrow", "dropest_shard_matrix_bytes", "dropest_add_umi_to_cell", "dropest_umi_first_seen", "dropest_resident_reads", "dropest_prefetch_raw_matrix_narrow", "dropest_narrow_matrix_possible", "dropest_count_matrix_csc_narrow",
     "dropest_prefetch_raw_matrix_bytes", "dropest_count_matrix_csc_bytes", "dropest_matrix_bytes_widen", "dropest_set_raw_matrix_prefetch", "dropest_set_matrix_wire", "dropest_debug_refresh", "dropest_push_reads_gather", "dropest_shard_set_umi_qualities", "dropest_shard_set_umi_qualities_var",

@@ -457,6 +457,27 @@ struct dropest_ctx {
 	bool filtered_valid = false;
 	u32 filtered_threshold = 0;
 	int filtered_max_cells = -1;
+	// host mirror of barcode -> cell id for dropest_cell_id_by_cb (FilteringBamProcessor.cpp:14-40 and user code ask per read): level 1 =
+	// the real-candidate cells (from `real`, no device access at all), level 2 = every barcode of the pass (cell_cb fetched once, on the first
+	// question about a barcode that is not a real cell's).  Valid for one pass: free_results() drops it.
+	struct CbMirror {
+		std::vector<u64> key; std::vector<u32> id; u64 mask = 0; int level = 0;
+		void clear() { key.clear(); id.clear(); mask = 0; level = 0; }
+		void build(size_t n, const std::function<void(size_t, u64 &, u32 &)> &item) {
+			size_t cap = 16; while (cap < n * 2 + 2) cap <<= 1;
+			key.assign(cap, 0ull); id.assign(cap, 0u); mask = cap - 1;
+			for (size_t i = 0; i < n; ++i) {
+				u64 k; u32 v; item(i, k, v);
+				u64 h = dropest::mix64(k) & mask;
+				while (key[h] != 0ull && key[h] != k) h = (h + 1) & mask;   // (packed codes carry a sentinel bit: never 0)
+				key[h] = k; id[h] = v;
+			}
+		}
+		long find(u64 k) const {
+			if (key.empty()) return -1;
+			for (u64 h = dropest::mix64(k) & mask;; h = (h + 1) & mask) { if (key[h] == k) return long(id[h]); if (key[h] == 0ull) return -1; }
+		}
+	} cb_mirror;
 	long real_find(u32 cell_id) const {                  // index in `real` (binary search, ids ascending) or -1
 		size_t lo = 0, hi = real.size();
 		while (lo < hi) { size_t mid = (lo + hi) / 2; if (real[mid].id < cell_id) lo = mid + 1; else hi = mid; }

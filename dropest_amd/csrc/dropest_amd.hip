@@ -224,6 +224,7 @@ void dropest_ctx::free_results() {
 	reseed_rng();    // a second pass over the same reads reproduces the first
 	shard.reset();
 	n_cells = n_mol = n_cg = n_chr_rows = 0;
+	cb_mirror.clear();
 	real.clear(); filtered.clear(); filtered_valid = false; merge_pairs.clear(); reassign.clear(); umi_overrides.clear(); n_real_now = 0;
 	merge_rank.clear(); reagg_prio = nullptr; extra_excluded.clear(); explicit_sources.clear(); mol_sorted_rows = 0xFFFFFFFFu;
 	layout = dropest::KeyLayout{}; umi_clean_bits = 0; umi_sentinel_stripped = false; chr_from_gene = false;   // nothing of the previous pass's key plan survives
@@ -2240,16 +2241,23 @@ dropest_status dropest_cell_id_by_cb(dropest_ctx *ctx, uint64_t barcode, int64_t
 	return guarded([&] {
 		need_init(ctx);
 		*id = -1;
-		if (ctx->n_cells == 0) return;
-		// host-side probe of the device table (a handful of 8-byte reads)
-		uint64_t h = mix64(barcode) & ctx->table.mask;
-		for (u32 probe = 0; probe < CB_MAX_PROBE; ++probe) {
-			CbSlot sl;
-			HIP_CHECK(hipMemcpy(&sl, ctx->table.slots + h, sizeof(sl), hipMemcpyDeviceToHost));
-			if (sl.key == barcode) { *id = sl.cell_id; return; }
-			if (sl.key == 0) return;
-			h = (h + 1) & ctx->table.mask;
+		if (ctx->n_cells == 0 || barcode == 0) return;
+		// No device round trip per question (round 4 probed the device table with one synchronous 16-byte hipMemcpy per slot): the real
+		// cells' barcodes are on the host already; the first question about any other barcode fetches the pass's barcode list once.
+		dropest_ctx::CbMirror &m = ctx->cb_mirror;
+		if (m.level == 0) {
+			m.build(ctx->real.size(), [&](size_t i, u64 &k, u32 &v) { k = ctx->real[i].row.barcode; v = ctx->real[i].id; });
+			m.level = 1;
 		}
+		long got = m.find(barcode);
+		if (got < 0 && m.level == 1) {
+			std::vector<u64> all(ctx->n_cells);
+			ctx->fetch(all.data(), ctx->cell_cb.p, size_t(ctx->n_cells) * 8);
+			m.build(all.size(), [&](size_t i, u64 &k, u32 &v) { k = all[i]; v = u32(i); });
+			m.level = 2;
+			got = m.find(barcode);
+		}
+		*id = got;
 	});
 }
 

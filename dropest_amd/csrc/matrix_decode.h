@@ -36,7 +36,9 @@ inline void cpu_relax() { host_cpu_relax(); }
 
 struct ByteMatrixView {
 	const uint8_t *rd = nullptr, *vb = nullptr;   // row deltas, values
-	const uint32_t *colptr = nullptr;
+	const uint32_t *colptr = nullptr;             // column c = entries [colptr[c], colend ? colend[c] : colptr[c + 1])
+	const uint32_t *colend = nullptr;             // set: the columns are a SELECTION of a larger matrix's (one shard's columns of the global
+	                                              // matrix of a sharded run, csrc/shard_run.h), each with its own begin and end
 	uint64_t ncols = 0, nnz = 0;
 };
 
@@ -44,10 +46,10 @@ struct ByteMatrixView {
 // read back from ro, a listed value is left alone.
 inline void widen_columns_scalar(const ByteMatrixView &m, size_t c0, size_t c1, uint32_t *__restrict ro, uint32_t *__restrict vo) {
 	const uint8_t *__restrict rd = m.rd, *__restrict vb = m.vb;
-	const uint32_t *__restrict cp = m.colptr;
+	const uint32_t *__restrict cp = m.colptr, *__restrict ce = m.colend;
 	for (size_t c = c0; c < c1; ++c) {
 		uint32_t prev1 = 0;   // previous row + 1
-		const uint32_t k1 = cp[c + 1];
+		const uint32_t k1 = ce ? ce[c] : cp[c + 1];
 		for (uint32_t k = cp[c]; k < k1; ++k) {
 			const uint32_t d = rd[k], v = vb[k];
 			const uint32_t row = d == 255u ? ro[k] : prev1 + d - 1u;
@@ -71,7 +73,7 @@ __attribute__((target("avx2"))) inline void widen_columns_avx2(const ByteMatrixV
 	for (size_t c = c0; c < c1; ++c) {
 		uint32_t prev1 = 0;
 		uint32_t k = cp[c];
-		const uint32_t k1 = cp[c + 1];
+		const uint32_t k1 = m.colend ? m.colend[c] : cp[c + 1];
 		auto scalar_to = [&](uint32_t end) {
 			for (; k < end; ++k) {
 				const uint32_t d = rd[k], v = vb[k];
@@ -129,7 +131,7 @@ __attribute__((target("avx512f,avx512bw,avx512vl"))) inline void widen_columns_a
 	for (size_t c = c0; c < c1; ++c) {
 		uint32_t prev1 = 0;
 		uint32_t k = cp[c];
-		const uint32_t k1 = cp[c + 1];
+		const uint32_t k1 = m.colend ? m.colend[c] : cp[c + 1];
 		auto scalar_to = [&](uint32_t end) {
 			for (; k < end; ++k) {
 				const uint32_t d = rd[k], v = vb[k];
@@ -218,6 +220,7 @@ struct DecodeJob {
 	// flags == nullptr: everything is on the host already.
 	const volatile uint32_t *flags = nullptr;
 	uint32_t epoch = 0;
+	const uint32_t *cut = nullptr;                  // [ncols + 1] running entry counts the slices are cut by (default: m.colptr; a selection of columns brings its own)
 	std::vector<uint32_t> chunk_end;                // chunk j = columns [chunk_end[j - 1], chunk_end[j])
 	// ---- set by prepare() ----
 	std::vector<uint32_t> slice_end, slice_chunk;   // slice s = columns [slice_end[s - 1], slice_end[s]) of chunk slice_chunk[s]
@@ -236,7 +239,7 @@ struct DecodeJob {
 		size_t c0 = 0;
 		for (size_t j = 0; j < chunk_end.size(); ++j) {
 			const size_t before = slice_end.size();
-			cut_columns(m.colptr, c0, chunk_end[j], slice_entries, slice_end);
+			cut_columns(cut ? cut : m.colptr, c0, chunk_end[j], slice_entries, slice_end);
 			slice_chunk.resize(slice_end.size(), uint32_t(j));
 			(void)before;
 			c0 = chunk_end[j];

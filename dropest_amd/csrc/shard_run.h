@@ -605,7 +605,13 @@ __global__ __launch_bounds__(256) void place_columns_bytes_kernel(const unsigned
                                                                   const uint32_t *__restrict__ src_vals, uint8_t *__restrict__ dst_delta,
                                                                   uint8_t *__restrict__ dst_val, uint32_t *__restrict__ counters /* [2] */,
                                                                   uint32_t *__restrict__ rl_pos, uint32_t *__restrict__ rl_row,
-                                                                  uint32_t *__restrict__ vl_pos, uint32_t *__restrict__ vl_val, uint32_t cap) {
+                                                                  uint32_t *__restrict__ vl_pos, uint32_t *__restrict__ vl_val, uint32_t cap,
+                                                                  uint32_t *__restrict__ slot_rows = nullptr, uint32_t *__restrict__ slot_vals = nullptr,
+                                                                  uint32_t *flag = nullptr, uint32_t epoch = 0) {
+	// flag / epoch (matrix_decode.h): the arrival flag of the chunk of columns placed BEFORE this launch on the stream -- this kernel runs, so
+	// that chunk is complete and visible to the host threads that widen it into the 32-bit slots.  slot_rows / slot_vals: the slots
+	// themselves (node-shared host memory); a listed entry is written there directly, so the widening needs no list at all.
+	if (flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	__shared__ uint32_t st_pos[2][PCB_STAGE], st_x[2][PCB_STAGE];
 	__shared__ uint32_t st_n[2], st_base[2];
 	const unsigned long long s = desc[3ull * blockIdx.x], d = desc[3ull * blockIdx.x + 1], len = desc[3ull * blockIdx.x + 2];
@@ -626,8 +632,8 @@ __global__ __launch_bounds__(256) void place_columns_bytes_kernel(const unsigned
 				inside |= 1u << b;
 				dd |= (delta >= 255u ? 255u : delta) << (8 * b);
 				vv |= (v >= 255u ? 255u : v) << (8 * b);
-				if (delta >= 255u) { const uint32_t at = atomicAdd(&st_n[0], 1u); st_pos[0][at] = uint32_t(g); st_x[0][at] = row; staged = 1; }
-				if (v >= 255u) { const uint32_t at = atomicAdd(&st_n[1], 1u); st_pos[1][at] = uint32_t(g); st_x[1][at] = v; staged = 1; }
+				if (delta >= 255u) { const uint32_t at = atomicAdd(&st_n[0], 1u); st_pos[0][at] = uint32_t(g); st_x[0][at] = row; staged = 1; if (slot_rows) slot_rows[g] = row; }
+				if (v >= 255u) { const uint32_t at = atomicAdd(&st_n[1], 1u); st_pos[1][at] = uint32_t(g); st_x[1][at] = v; staged = 1; if (slot_vals) slot_vals[g] = v; }
 			}
 			if (inside == 0xFu) {
 				reinterpret_cast<uint32_t *>(dst_delta)[w] = dd;
@@ -671,7 +677,8 @@ __global__ __launch_bounds__(256) void ordinals_from_answers_kernel(QueryTable t
 __global__ __launch_bounds__(256) void plan_raw_columns_kernel(RawPlanTable t, const unsigned long long *__restrict__ all, const uint32_t *__restrict__ col_cell,
                                                                const unsigned long long *__restrict__ cell_barcode, uint32_t n,
                                                                unsigned long long *__restrict__ desc, unsigned long long *__restrict__ colptr64,
-                                                               uint32_t *__restrict__ colptr32, unsigned long long *__restrict__ barcodes) {
+                                                               uint32_t *__restrict__ colptr32, unsigned long long *__restrict__ barcodes,
+                                                               uint32_t *__restrict__ h_begin = nullptr, uint32_t *__restrict__ h_end = nullptr) {
 	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= n) return;
 	const unsigned long long *mine = all + t.off[t.rank], *my_pre = mine + t.n[t.rank];
@@ -686,6 +693,7 @@ __global__ __launch_bounds__(256) void plan_raw_columns_kernel(RawPlanTable t, c
 	}
 	desc[3ull * i] = my_pre[i]; desc[3ull * i + 1] = at; desc[3ull * i + 2] = my_pre[i + 1] - my_pre[i];
 	colptr64[col] = at; colptr32[col] = uint32_t(at); barcodes[col] = cell_barcode[col_cell[i]];
+	if (h_begin) { h_begin[i] = uint32_t(at); h_end[i] = uint32_t(at + my_pre[i + 1] - my_pre[i]); }   // (pinned: what the host threads that widen this shard's columns walk by)
 }
 __global__ void copy_words_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t n) { if (threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x]; }
 // local read position -> global stream ordinal: position p came from source rank s = the block [recv_off[s], recv_off[s+1])
@@ -808,7 +816,23 @@ struct dropest_shard {
 		bool bytes = false, lists_ready = false;
 		const uint8_t *delta8 = nullptr, *vals8 = nullptr; const char *segments = nullptr; size_t seg_bytes = 0; u32 list_cap = 0;
 		std::vector<u32> colptr32, rl_pos, rl_row, vl_pos, vl_val;
+		// the 32-bit dgCMatrix slots i / x of the GLOBAL matrix in the shared buffer (option "slots_matrix", on): every shard's host threads
+		// widen ITS columns from the byte form as the chunks of columns land (matrix_decode.h) -- the step ends where the plain context's does
+		// (ResultsPrinter::create_matrix, Estimation/ResultsPrinter.cpp:433-442)
+		bool slots = false;                                       // this step's shared buffer has the slots region
+		u32 *slot_rows = nullptr, *slot_vals = nullptr;           // host views
+		std::shared_ptr<dropest::DecodeJob> job, late_job;
+		std::vector<u32> dec_begin, dec_end, dec_cut;             // this shard's columns: global begin / end of each, running local entry count
+		dropest::PinnedBuf<u32> h_begin, h_end;                   // ... written by the device when the columns are planned there (cm_raw)
+		dropest::PinnedBuf<u32> h_flags;
+		u32 epoch = 0;
+		void settle() {
+			if (job) { (void)job->wait(); job->quiesce(); job.reset(); }
+			if (late_job) { late_job->quiesce(); late_job.reset(); }
+		}
 	} mat[2];
+	bool slots_matrix = true;                                     // option "slots_matrix": the step ends with the 32-bit slots (needs byte_matrix)
+	void finish_slots(Mat &M);
 	bool narrow_matrix = true;                                    // option "narrow_matrix": 16-bit matrices when every gene id fits
 	bool byte_matrix = true;                                      // option "byte_matrix": the byte form (any gene id); wins over narrow_matrix
 	uint64_t byte_list_cap = 0;                                   // option "byte_list_cap": entries a shard may list per kind (0: 2^20)
@@ -821,9 +845,11 @@ struct dropest_shard {
 	struct RawPlan { std::vector<u32> col_cell, col_start, query; std::vector<u64> pre; std::vector<uint64_t> counts, q_out, q_in; uint64_t ncols = 0, nnz = 0; } raw_plan;
 	bool plan_raw();
 	void assemble_raw_device();
-	struct SharedLayout { char *host; void *dev; size_t base, off_val, off_seg, seg_bytes; dropest::u32 list_cap; bool bytes, narrow; };
+	struct SharedLayout { char *host; void *dev; size_t base, off_val, off_seg, seg_bytes, off_slots, slots_stride; dropest::u32 list_cap; bool bytes, narrow, slots; };
 	SharedLayout open_shared(Mat &M, int slot, size_t head_bytes);
-	void place_columns(Mat &M, int slot, bool filtered_m, const SharedLayout &L, const unsigned long long *d_descr, dropest::u32 nc, uint64_t local_nnz, hipStream_t st = nullptr);
+	// local_start[nc]: every column's offset among this shard's entries (what the placing launches and the widening are cut by)
+	void place_columns(Mat &M, int slot, bool filtered_m, const SharedLayout &L, const unsigned long long *d_descr, dropest::u32 nc, uint64_t local_nnz, hipStream_t st = nullptr,
+	                   const dropest::u32 *local_start = nullptr);
 	// cm_raw's columns leave on a stream of their own, under the host collectives and the assembly of cm (the plain context's prefetch,
 	// for shards): the placing kernel is the longest piece of the end of a pass and needs nothing of what follows it
 	hipStream_t place_stream = nullptr;
@@ -1542,6 +1568,7 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 	dropest_ctx &c = *ctx;
 	const int slot = filtered_m ? 0 : 1;
 	Mat &M = mat[slot];
+	M.settle();   // (a straggler of the previous widening reads dec_begin / dec_end)
 	std::vector<u32> sel;
 	for (u32 i = 0; i < G.size(); ++i) if (!filtered_m || G[i].req_genes >= c.min_after) sel.push_back(i);
 	std::vector<u32> order;
@@ -1567,6 +1594,8 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 		desc.push_back(local_nnz); desc.push_back(M.colptr[j]); desc.push_back(len);
 		local_nnz += len;
 	}
+	M.dec_begin.clear(); M.dec_end.clear();
+	for (size_t k = 0; k < col_cell.size(); ++k) { M.dec_begin.push_back(u32(desc[3 * k + 1])); M.dec_end.push_back(u32(desc[3 * k + 1] + desc[3 * k + 2])); }
 	M.nnz = M.colptr[ncols];
 	if (M.nnz > 0xFFFFFFF0ull || local_nnz > 0xFFFFFFF0ull) throw UnsupportedError("count matrix with more than 2^32 non-zeros");
 	M.colptr_p = M.colptr.data(); M.barcode_p = M.col_barcode.data();
@@ -1581,7 +1610,7 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 		std::memcpy(h_desc.p, desc.data(), desc.size() * 8);
 		HIP_CHECK(hipMemcpyAsync(d_desc.p, h_desc.p, desc.size() * 8, hipMemcpyHostToDevice, c.stream));
 	}
-	place_columns(M, slot, filtered_m, L, d_desc.p, nc, local_nnz);
+	place_columns(M, slot, filtered_m, L, d_desc.p, nc, local_nnz, nullptr, col_start.data());
 }
 
 // The node-shared host buffer of one matrix (collective: every shard takes the same decisions -- the gene ids are the agreed ones).
@@ -1597,12 +1626,20 @@ dropest_shard::SharedLayout dropest_shard::open_shared(Mat &M, int slot, size_t 
 	L.base = (head_bytes + 15) & ~size_t(15);
 	L.list_cap = u32(std::min<uint64_t>(byte_list_cap ? byte_list_cap : (1u << 20), (M.nnz + 15) & ~15ull));
 	L.off_val = (size_t(M.nnz) + 15) & ~size_t(15); L.off_seg = 2 * L.off_val; L.seg_bytes = 16 + 16 * size_t(L.list_cap);
-	const size_t payload = L.bytes ? L.off_seg + L.seg_bytes * size_t(world) : std::max<size_t>(size_t(M.nnz), 1) * (L.narrow ? 4 : 8);
+	// the slots behind the segments: rows | values, each padded to whole 64-byte lines (the widening stores whole lines)
+	L.slots = L.bytes && slots_matrix;
+	L.off_slots = (L.base + L.off_seg + L.seg_bytes * size_t(world) + 63) & ~size_t(63);   // (from the buffer's start: that is page-aligned)
+	L.slots_stride = ((size_t(M.nnz) + 15) & ~size_t(15)) * 4;
+	const size_t payload = L.bytes ? (L.slots ? L.off_slots - L.base + 2 * L.slots_stride : L.off_seg + L.seg_bytes * size_t(world))
+	                               : std::max<size_t>(size_t(M.nnz), 1) * (L.narrow ? 4 : 8);
+	M.settle();   // (a straggler of the previous step's widening may still be leaving: the buffer is about to be rewritten or replaced)
 	L.host = static_cast<char *>(tr->shared_host(slot, L.base + payload, &L.dev));
 	char *host = L.host + L.base;
 	M.narrow = L.narrow; M.widened = false; M.ovf_pos.clear(); M.ovf_val.clear();
 	M.bytes = L.bytes; M.lists_ready = false;
 	M.rows = M.vals = nullptr; M.rows16 = M.vals16 = nullptr; M.delta8 = M.vals8 = nullptr;
+	M.slots = L.slots; M.slot_rows = M.slot_vals = nullptr;
+	if (L.slots) { M.slot_rows = reinterpret_cast<u32 *>(L.host + L.off_slots); M.slot_vals = reinterpret_cast<u32 *>(L.host + L.off_slots + L.slots_stride); }
 	if (L.bytes) {
 		M.delta8 = reinterpret_cast<const uint8_t *>(host); M.vals8 = reinterpret_cast<const uint8_t *>(host) + L.off_val;
 		M.segments = host + L.off_seg; M.seg_bytes = L.seg_bytes; M.list_cap = L.list_cap;
@@ -1613,7 +1650,8 @@ dropest_shard::SharedLayout dropest_shard::open_shared(Mat &M, int slot, size_t 
 
 // this shard's columns (emitted into c.mat[slot] on the device; d_descr: local offset, global offset, length of each) -> their global
 // places in the shared buffer, in the form open_shared chose
-void dropest_shard::place_columns(Mat &M, int slot, bool filtered_m, const SharedLayout &L, const unsigned long long *d_descr, dropest::u32 nc, uint64_t local_nnz, hipStream_t st) {
+void dropest_shard::place_columns(Mat &M, int slot, bool filtered_m, const SharedLayout &L, const unsigned long long *d_descr, dropest::u32 nc, uint64_t local_nnz, hipStream_t st,
+                                  const dropest::u32 *local_start) {
 	using namespace dropest;
 	dropest_ctx &c = *ctx;
 	if (!st) st = c.stream;
@@ -1628,6 +1666,52 @@ void dropest_shard::place_columns(Mat &M, int slot, bool filtered_m, const Share
 		if (work) {
 			u32 *lists = seg_words + 4;
 			const size_t cap = L.list_cap;
+			if (L.slots && local_start) {
+				// The columns leave in chunks (whole columns, ~1/12 of this shard's entries each); the launch of chunk j + 1 starts by raising
+				// chunk j's arrival flag in pinned memory, and the pool's host threads widen a chunk's columns into the shared 32-bit slots as
+				// soon as its flag is up -- the walk of matrix_decode.h over this shard's SELECTION of the global matrix's columns.
+				using dropest::DecodeJob;
+				char *d_slots = static_cast<char *>(L.dev) + L.off_slots;
+				u32 *d_srows = reinterpret_cast<u32 *>(d_slots), *d_svals = reinterpret_cast<u32 *>(d_slots + L.slots_stride);
+				auto job = std::make_shared<DecodeJob>();
+				job->device = c.cfg.device;
+				M.dec_cut.assign(local_start, local_start + nc); M.dec_cut.push_back(u32(local_nnz));
+				job->cut = M.dec_cut.data();
+				static const uint64_t n_chunks = [] { const char *e = getenv("DROPEST_WIRE_CHUNKS"); return uint64_t(e ? std::max(1, atoi(e)) : 12); }();
+				dropest::cut_columns(M.dec_cut.data(), 0, size_t(nc), std::max<uint64_t>(local_nnz / n_chunks + 1, uint64_t(1) << 19), job->chunk_end);
+				const size_t K = job->chunk_end.size();
+				M.h_flags.ensure(K + 2);
+				for (size_t j = 0; j < K + 2; ++j) M.h_flags.p[j] = 0;
+				M.epoch = M.epoch + 1 ? M.epoch + 1 : 1;
+				M.h_flags.p[0] = M.epoch;   // no lists to wait for: listed entries reach the slots directly
+				job->flags = M.h_flags.p; job->epoch = M.epoch;
+				auto launch = [&] {
+					u32 c0 = 0;
+					for (size_t j = 0; j < K; ++j) {
+						const u32 c1 = job->chunk_end[j];
+						hipLaunchKernelGGL(place_columns_bytes_kernel, dim3(c1 - c0), dim3(256), 0, st, d_descr + 3ull * c0, R.d_row.p, R.d_val.p,
+						                   reinterpret_cast<uint8_t *>(d_payload), reinterpret_cast<uint8_t *>(d_payload) + L.off_val, cnt,
+						                   lists, lists + cap, lists + 2 * cap, lists + 3 * cap, L.list_cap, d_srows, d_svals,
+						                   j ? M.h_flags.p + j : static_cast<u32 *>(nullptr), M.epoch);
+						c0 = c1;
+					}
+					hipLaunchKernelGGL(dropest::matrix_flag_kernel, dim3(1), dim3(1), 0, st, M.h_flags.p + K, M.epoch);
+				};
+				if (st == c.stream) c.timed(filtered_m ? "place_columns:cm" : "place_columns:cm_raw", double(local_nnz) * 10, launch);
+				else launch();
+				HIP_CHECK(hipGetLastError());
+				job->m.rd = M.delta8; job->m.vb = M.vals8; job->m.ncols = nc; job->m.nnz = M.nnz;
+				// (cm: begin / end come from the host's plan; cm_raw planned on the device: from the pinned arrays its planning kernel wrote,
+				// complete before the first flag is raised -- stream order)
+				job->m.colptr = M.dec_begin.empty() ? M.h_begin.p : M.dec_begin.data();
+				job->m.colend = M.dec_end.empty() ? M.h_end.p : M.dec_end.data();
+				job->ro = M.slot_rows; job->vo = M.slot_vals;
+				static const uint64_t slice_entries = [] { const char *e = getenv("DROPEST_DECODE_SLICE"); return e && atoll(e) >= 1024 ? uint64_t(atoll(e)) : uint64_t(1) << 16; }();
+				job->prepare(slice_entries);
+				M.job = job;
+				dropest::DecodePool::get().prefer_node_of(M.slot_rows);
+				dropest::DecodePool::get().submit(job);
+			} else {
 			auto launch = [&] {
 				hipLaunchKernelGGL(place_columns_bytes_kernel, dim3(nc), dim3(256), 0, st, d_descr, R.d_row.p, R.d_val.p,
 				                   reinterpret_cast<uint8_t *>(d_payload), reinterpret_cast<uint8_t *>(d_payload) + L.off_val, cnt,
@@ -1635,6 +1719,7 @@ void dropest_shard::place_columns(Mat &M, int slot, bool filtered_m, const Share
 			};
 			if (st == c.stream) c.timed(filtered_m ? "place_columns:cm" : "place_columns:cm_raw", double(local_nnz) * 10, launch);
 			else launch();   // (the context's launch timer brackets its own stream)
+			}
 		}
 		hipLaunchKernelGGL(copy_words_kernel, dim3(1), dim3(64), 0, st, cnt, seg_words, 4u);   // the counts, behind the lists on the stream
 		HIP_CHECK(hipGetLastError());
@@ -1729,6 +1814,7 @@ void dropest_shard::assemble_raw_device() {
 	Phase ph(this, "matrix:cm_raw");
 	RawPlan &P = raw_plan;
 	Mat &M = mat[1];
+	M.settle();
 	const size_t w = 3 + size_t(world);
 	const u32 nl = u32(P.col_cell.size());
 	const uint64_t ncols = P.ncols;
@@ -1789,12 +1875,15 @@ void dropest_shard::assemble_raw_device() {
 	d_plan_all.ensure(total);
 	tr->gather_dev(d_plan_mine.p, d_plan_all.p, off.data(), bytes.data(), c.stream);
 	d_desc_raw.ensure(std::max<size_t>(3 * size_t(nl), 1));
+	M.dec_begin.clear(); M.dec_end.clear();
+	if (L.slots) { M.h_begin.ensure(std::max<u32>(nl, 1)); M.h_end.ensure(std::max<u32>(nl, 1)); }
 	if (nl) {
 		char *d_head = static_cast<char *>(L.dev);
 		hipLaunchKernelGGL(plan_raw_columns_kernel, dim3((nl + 255) / 256), dim3(256), 0, c.stream, pt, reinterpret_cast<const unsigned long long *>(d_plan_all.p),
 		                   d_col_cell.p, reinterpret_cast<const unsigned long long *>(c.cell_cb.p), nl, reinterpret_cast<unsigned long long *>(d_desc_raw.p),
 		                   reinterpret_cast<unsigned long long *>(d_head), reinterpret_cast<uint32_t *>(d_head + off_c32),
-		                   reinterpret_cast<unsigned long long *>(d_head + off_bc));
+		                   reinterpret_cast<unsigned long long *>(d_head + off_bc), L.slots ? M.h_begin.p : static_cast<u32 *>(nullptr),
+		                   L.slots ? M.h_end.p : static_cast<u32 *>(nullptr));
 		HIP_CHECK(hipGetLastError());
 	}
 	const uint64_t local_nnz = P.pre.back();
@@ -1807,7 +1896,7 @@ void dropest_shard::assemble_raw_device() {
 		HIP_CHECK(hipStreamWaitEvent(place_stream, ev_place, 0));
 		st = place_stream;
 	}
-	place_columns(M, 1, false, L, reinterpret_cast<const unsigned long long *>(d_desc_raw.p), nl, local_nnz, st);
+	place_columns(M, 1, false, L, reinterpret_cast<const unsigned long long *>(d_desc_raw.p), nl, local_nnz, st, P.col_start.data());
 }
 
 void dropest_shard::step() {
@@ -1905,7 +1994,11 @@ void dropest_shard::step() {
 	build_global_table();
 	assemble_matrix(true);
 	if (!raw_device_now) assemble_matrix(false);
-	auto wait_all = [&] { Phase ph(this, "matrix:wait"); HIP_CHECK(stream_wait(c.stream)); if (place_stream) HIP_CHECK(stream_wait(place_stream)); tr->barrier(); };
+	auto wait_all = [&] {
+		// this shard's columns widened (its thread takes part: what is unclaimed, then what a straggler holds), its streams drained, then everybody's
+		{ Phase ph(this, "matrix:decode_wait"); finish_slots(mat[1]); finish_slots(mat[0]); }
+		Phase ph(this, "matrix:wait"); HIP_CHECK(stream_wait(c.stream)); if (place_stream) HIP_CHECK(stream_wait(place_stream)); tr->barrier();
+	};
 	wait_all();
 	if (byte_matrix) {
 		// A shard that had more to list than its segment holds (very sparse columns: a small cell lists nearly every row) shows in the
@@ -1924,6 +2017,16 @@ void dropest_shard::step() {
 		Phase ph(this, "matrix:lists"); collect_lists(mat[0]); collect_lists(mat[1]);
 	}
 	c.collect_timings();
+}
+
+void dropest_shard::finish_slots(Mat &M) {
+	using dropest::DecodeJob;
+	if (!M.job) return;
+	M.job->work(true);
+	const int st = M.job->wait();
+	M.late_job = std::move(M.job);   // complete; a straggler may still be inside (settle() before the buffers are touched again)
+	M.job.reset();
+	if (st != DecodeJob::DONE) throw DeviceError("count matrix: widening this shard's columns of the byte form failed");
 }
 
 // the byte form's lists: every shard's segment of the shared buffer (written through its PCIe link, complete after the barrier)
@@ -2245,7 +2348,8 @@ dropest_status dropest_shard_matrix(dropest_shard *s, int filtered, uint64_t *nc
 		dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
 		*ncols = M.ncols; *nnz = M.nnz;
 		if (colptr) *colptr = reinterpret_cast<const uint64_t *>(M.colptr_p ? M.colptr_p : M.colptr.data());
-		if (M.bytes && (rowidx || values) && !M.widened) {    // the pass produced the byte form: decoded here, once, on host threads
+		if (M.bytes && M.slots && !M.widened) { M.rows = M.slot_rows; M.vals = M.slot_vals; }   // the step ended with the slots: every shard widened its columns
+		else if (M.bytes && (rowidx || values) && !M.widened) {    // the pass produced the byte form: decoded here, once, on host threads
 			s->collect_lists(M);
 			M.wide_rows.resize(M.nnz); M.wide_vals.resize(M.nnz);
 			dropest_matrix_bytes mb{M.ncols, M.nnz, M.colptr32_p, M.delta8, M.vals8, M.rl_pos.size(), M.rl_pos.data(), M.rl_row.data(),
@@ -2262,6 +2366,14 @@ dropest_status dropest_shard_matrix(dropest_shard *s, int filtered, uint64_t *nc
 		if (rowidx) *rowidx = M.rows;
 		if (values) *values = M.vals;
 		if (col_barcodes) *col_barcodes = reinterpret_cast<const uint64_t *>(M.barcode_p ? M.barcode_p : M.col_barcode.data());
+	});
+}
+
+dropest_status dropest_shard_matrix_form(dropest_shard *s, int filtered, int32_t *form) {
+	return guarded([&] {
+		if (!s || !form) throw InvalidError("null argument");
+		const dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
+		*form = M.bytes ? (M.slots ? 3 : 2) : (M.narrow ? 1 : 0);
 	});
 }
 
@@ -2371,6 +2483,7 @@ dropest_status dropest_shard_set_option(dropest_shard *s, const char *key, int64
 		else if (k == "reset_phase_stats") s->phases.clear();
 		else if (k == "narrow_matrix") s->narrow_matrix = value != 0;
 		else if (k == "byte_matrix") s->byte_matrix = value != 0;
+		else if (k == "slots_matrix") s->slots_matrix = value != 0;
 		else if (k == "raw_on_device") s->raw_on_device = value != 0;
 		else if (k == "byte_list_cap") s->byte_list_cap = value > 0 ? uint64_t((value + 15) & ~15ll) : 0;
 		else if (k == "packed_exchange") s->allow_packed = value != 0;

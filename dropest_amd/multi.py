@@ -95,6 +95,12 @@ class Shard:
         return (view(p, ncols.value + 1, C.c_uint64, np.uint64), view(r, nnz.value, C.c_uint32, np.uint32),
                 view(v, nnz.value, C.c_uint32, np.uint32), view(b, ncols.value, C.c_uint64, np.uint64))
 
+    def matrix_form(self, filtered):
+        """0 = 32-bit arrays, 1 = 16-bit, 2 = byte form only, 3 = byte form + the 32-bit slots widened inside the step."""
+        f = C.c_int32()
+        self._chk(self.L.dropest_shard_matrix_form(self.h, int(filtered), C.byref(f)))
+        return f.value
+
     def matrix_narrow(self, filtered):
         """(colptr u64, rowidx u16, values u16, column barcodes u64, overflow_pos u64, overflow_val u32) of the GLOBAL matrix in the
         narrow form the step wrote (dropest_shard_matrix_narrow); raises DropestError when the step produced the 32-bit form."""
@@ -261,13 +267,16 @@ class ShardedRun:
         self.shard.step()
         if self.rank != 0:
             return None, None, None
-        try:      # the form the step wrote: bytes (the default), 16-bit, or 32-bit -- no widening on the host here
-            cm, raw = self.shard.matrix_bytes(True), self.shard.matrix_bytes(False)
-        except capi.DropestError:
-            try:
-                cm, raw = self.shard.matrix_narrow(True), self.shard.matrix_narrow(False)
-            except capi.DropestError:
-                cm, raw = self.shard.matrix(True), self.shard.matrix(False)
+        # the form the step wrote: the 32-bit slots (the default: widened from the byte form inside the step), the byte form alone, 16-bit,
+        # or 32-bit arrays -- no widening on the host here
+        def take(filtered):
+            form = self.shard.matrix_form(filtered)
+            if form == 2:
+                return self.shard.matrix_bytes(filtered)
+            if form == 1:
+                return self.shard.matrix_narrow(filtered)
+            return self.shard.matrix(filtered)
+        cm, raw = take(True), take(False)
         return cm, raw, (cm.col_barcodes if isinstance(cm, ShardBytes) else cm[3])
 
     def set_profiling(self, on, only=None):

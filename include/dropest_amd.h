@@ -527,8 +527,16 @@ dropest_status dropest_shard_set_umi_qualities_var(dropest_shard *shard, const u
                                                    uint64_t n_reads);
 dropest_status dropest_shard_step(dropest_shard *shard);
 dropest_status dropest_shard_group_step(dropest_shard *const *shards, int32_t n);   /* one host thread per shard */
+/* The step ENDS with rowidx / values filled (shard options "byte_matrix" and "slots_matrix", both on by default): the 32-bit dgCMatrix
+ * slots i / x of ResultsPrinter::create_matrix (Estimation/ResultsPrinter.cpp:433-442) in the node-shared host buffer -- every shard's
+ * columns cross ITS PCIe link as bytes and are widened into the shared slots by that shard's host threads while the next chunk of
+ * columns is on the link (csrc/matrix_decode.h), as dropest_count_matrix_csc does for one context.  With "slots_matrix" off the step ends
+ * at the byte form and this call widens on first use. */
 dropest_status dropest_shard_matrix(dropest_shard *shard, int filtered, uint64_t *ncols, uint64_t *nnz, const uint64_t **colptr,
                                     const uint32_t **rowidx, const uint32_t **values, const uint64_t **col_barcodes);
+/* What the last step left in the shared buffer: 0 = 32-bit arrays, 1 = the 16-bit form, 2 = the byte form only, 3 = the byte form AND
+ * the 32-bit slots widened from it inside the step (the default). */
+dropest_status dropest_shard_matrix_form(dropest_shard *shard, int filtered, int32_t *form);
 /* The same matrix in the narrow form (see dropest_count_matrix_csc_narrow): what the step writes when every gene id fits 16 bits
  * the shard option "narrow_matrix" is on (the default) and "byte_matrix" is OFF -- each shard then puts half the bytes on its PCIe link; with it
  * dropest_shard_matrix widens on the host on first use.  overflow_pos = GLOBAL entry indices, ascending. */
