@@ -655,7 +655,7 @@ struct dropest_ctx {
 		std::function<void(u32 *, size_t)> globalize_umi_first;
 	};
 	std::shared_ptr<ShardHooks> hooks;
-	void emit_columns_device(bool filtered_m, bool reads_output, const std::vector<u32> &col_cell, const std::vector<u32> &col_start, uint64_t nnz);
+	void emit_columns_device(bool filtered_m, bool reads_output, const std::vector<u32> &col_cell, const std::vector<u32> &col_start, uint64_t nnz, bool wait = true);
 	struct GatheredGroups { std::vector<u32> size, off, begin, hr, hm, hfirst; std::vector<u64> hk; };   // begin: first molecule row of the group
 	void umi_gather_groups(const std::vector<u32> &groups, GatheredGroups &G, const u32 *d_first_table);
 	void umi_patch_groups(const std::vector<u32> &p_idx, const std::vector<u32> &p_all, const std::vector<u32> &p_req,

@@ -1809,7 +1809,7 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, 
 
 // Sharded runs: the columns of a caller-given list of cells, emitted compactly into the device staging of matrix slot
 // (filtered: cm values and zero-skipping; else cm_raw) -- the caller places them in the global matrix.
-void dropest_ctx::emit_columns_device(bool filtered_m, bool reads_output, const std::vector<u32> &col_cell, const std::vector<u32> &col_start, uint64_t nnz) {
+void dropest_ctx::emit_columns_device(bool filtered_m, bool reads_output, const std::vector<u32> &col_cell, const std::vector<u32> &col_start, uint64_t nnz, bool wait) {
 	invalidate_prefetch();
 	MatrixResult &M = mat[filtered_m ? 0 : 1];
 	const u32 ncols = u32(col_cell.size());
@@ -1826,7 +1826,7 @@ void dropest_ctx::emit_columns_device(bool filtered_m, bool reads_output, const 
 	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * 20, [&] {
 		hipLaunchKernelGGL(emit_matrix_kernel<0>, dim3(ncols), dim3(256), 0, stream, a);
 	});
-	HIP_CHECK(stream_wait(stream));   // the host vectors must outlive their copies
+	if (wait) HIP_CHECK(stream_wait(stream));   // the host vectors must outlive their copies (wait = false: the caller keeps them until the stream has drained)
 }
 
 // ResultsPrinter::get_count_matrix_filtered(container, query_marks) (ResultsPrinter.cpp:333-361) for a query other than

@@ -466,7 +466,8 @@ struct RcclTransport : Transport {
 			}
 		}
 		api.check(api.GroupEnd(), "ncclGroupEnd");
-		HIP_CHECK(stream_wait(st));
+		// (no wait here: whatever reads the received blocks is queued behind them on this stream -- cb_sample, cb_insert --, and the send
+		// buffers are not rewritten before the next pass's partition, on this stream too)
 	}
 	void gather_host(const void *mine, size_t bytes, void *all) override {
 		if (mailbox && mailbox->fits(bytes)) { mailbox->gather(mine, bytes, all); return; }
@@ -509,8 +510,7 @@ struct RcclTransport : Transport {
 			if (bytes[rank]) api.check(api.Send(d_mine, bytes[rank], ncclUint8, p, comm, st), "ncclSend");
 			if (bytes[p]) api.check(api.Recv(static_cast<char *>(d_all) + off[p], bytes[p], ncclUint8, p, comm, st), "ncclRecv");
 		}
-		api.check(api.GroupEnd(), "ncclGroupEnd");
-		HIP_CHECK(stream_wait(st));
+		api.check(api.GroupEnd(), "ncclGroupEnd");   // (stream-ordered like exchange(): the kernels that read d_all follow on `st`)
 	}
 	void barrier() override { unsigned char x = 0; std::vector<unsigned char> all(static_cast<size_t>(world)); gather_host(&x, 1, all.data()); }
 	void *shared_host(int slot, size_t bytes, void **d_ptr) override {
@@ -823,6 +823,7 @@ struct dropest_shard {
 		u32 *slot_rows = nullptr, *slot_vals = nullptr;           // host views
 		std::shared_ptr<dropest::DecodeJob> job, late_job;
 		std::vector<u32> dec_begin, dec_end, dec_cut;             // this shard's columns: global begin / end of each, running local entry count
+		std::vector<u32> col_cell, col_start;                     // ... their cells and local offsets (cm; cm_raw's are in raw_plan)
 		dropest::PinnedBuf<u32> h_begin, h_end;                   // ... written by the device when the columns are planned there (cm_raw)
 		dropest::PinnedBuf<u32> h_flags;
 		u32 epoch = 0;
@@ -1545,15 +1546,27 @@ void dropest_shard::build_global_table() {
 	Phase ph(this, "cells_allgather");
 	std::vector<GRow> mine;
 	std::vector<u32> pos;
-	for (const HostCell &h : c.real) {
-		if (h.merged || h.excluded || h.row.n_genes < c.min_before) continue;
-		if (raw_device_now && h.row.requested_genes < c.min_after) continue;   // cm_raw is planned on the device: the table serves cm only
+	auto take = [&](const HostCell &h) {
 		GRow r{};
 		r.barcode = h.row.barcode; r.n_genes = h.row.n_genes; r.req_genes = h.row.requested_genes; r.req_umis = h.row.requested_umis;
 		r.local_id = h.id; r.total_umis = h.row.total_umis; r.total_reads = h.row.total_reads; r.rank = u32(rank);
 		mine.push_back(r); pos.push_back(h.row.first_read);
+	};
+	if (raw_device_now && c.cfg.max_cells <= 0) {
+		// cm_raw is planned on the device: the table serves cm only, and its rows are the context's own filtered cells (collected on a few
+		// threads by sort_filtered; without -C nothing is cut from them locally) -- not another walk over every real cell
+		c.filtered_cells();
+		std::vector<u32> ridx(c.filtered_ridx);
+		std::sort(ridx.begin(), ridx.end());   // cell-id order, as the walk below gives it
+		for (u32 ri : ridx) take(c.real[ri]);
+	} else
+	for (const HostCell &h : c.real) {
+		if (h.merged || h.excluded || h.row.n_genes < c.min_before) continue;
+		if (raw_device_now && h.row.requested_genes < c.min_after) continue;   // cm_raw is planned on the device: the table serves cm only
+		take(h);
 	}
-	{ Phase p2(this, "cells:ordinals");
+	// first_global orders cm_raw's columns when the HOST plans them; cm is ordered by compare_cells: no device round trip for it
+	if (!raw_device_now) { Phase p2(this, "cells:ordinals");
 	const std::vector<u64> ord = global_ordinals(pos);
 	for (size_t i = 0; i < mine.size(); ++i) mine[i].first_global = ord[i]; }
 	std::vector<size_t> cnt;
@@ -1581,7 +1594,8 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 	Phase ph(this, filtered_m ? "matrix:cm" : "matrix:cm_raw");
 	const size_t ncols = order.size();
 	M.ncols = ncols; M.colptr.assign(ncols + 1, 0); M.col_barcode.resize(ncols);
-	std::vector<u32> col_cell, col_start;
+	std::vector<u32> &col_cell = M.col_cell, &col_start = M.col_start;   // (members: their copies to the device are not waited for here)
+	col_cell.clear(); col_start.clear();
 	std::vector<u64> desc;
 	uint64_t local_nnz = 0;
 	for (size_t j = 0; j < ncols; ++j) {
@@ -1605,7 +1619,7 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 	const SharedLayout L = open_shared(M, slot, 0);
 	const u32 nc = u32(col_cell.size());
 	if (nc && local_nnz) {
-		c.emit_columns_device(filtered_m, false, col_cell, col_start, local_nnz);
+		c.emit_columns_device(filtered_m, false, col_cell, col_start, local_nnz, false);
 		d_desc.ensure(desc.size()); h_desc.ensure(desc.size());
 		std::memcpy(h_desc.p, desc.data(), desc.size() * 8);
 		HIP_CHECK(hipMemcpyAsync(d_desc.p, h_desc.p, desc.size() * 8, hipMemcpyHostToDevice, c.stream));
@@ -1887,7 +1901,7 @@ void dropest_shard::assemble_raw_device() {
 		HIP_CHECK(hipGetLastError());
 	}
 	const uint64_t local_nnz = P.pre.back();
-	if (nl && local_nnz) c.emit_columns_device(false, false, P.col_cell, P.col_start, local_nnz);
+	if (nl && local_nnz) c.emit_columns_device(false, false, P.col_cell, P.col_start, local_nnz, false);
 	// the placing kernel on its own stream (byte form: nothing on the host waits for it before the end of the step)
 	hipStream_t st = c.stream;
 	if (L.bytes && !getenv("DROPEST_SHARD_NO_PLACE_STREAM")) {
@@ -2014,7 +2028,8 @@ void dropest_shard::step() {
 			if (wide_now[1] && !raw_device_now) assemble_matrix(false);
 			wait_all();
 		}
-		Phase ph(this, "matrix:lists"); collect_lists(mat[0]); collect_lists(mat[1]);
+		// (a matrix whose slots were widened inside the step needs its lists only if somebody asks for the byte form: collected then)
+		Phase ph(this, "matrix:lists"); for (int k = 0; k < 2; ++k) if (!mat[k].slots) collect_lists(mat[k]);
 	}
 	c.collect_timings();
 }

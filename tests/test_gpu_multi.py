@@ -435,7 +435,14 @@ def test_one_shard_over_rccl_and_forced_exchange():
     c.push_reads_device(*dev.ptrs, dev.n, adopt=True)
     c.set_initialized(); c.merge_and_filter()
     from dropest_amd.multi import ShardBytes
-    assert isinstance(cm, ShardBytes) and cm.nnz > 1000 and raw.n_row_listed > 0   # the step wrote the byte form (the default)
+    # the default: the step ends with the 32-bit slots, widened from the byte form by the shard's host threads under the copy
+    assert len(cm) == 4 and run.shard.matrix_form(True) == 3 and run.shard.matrix_form(False) == 3
+    slots = {"cm": [x.copy() for x in cm], "raw": [x.copy() for x in raw], "merged": run.merge_pairs}
+    check(slots, c)
+    assert run.shard.matrix_bytes(False).n_row_listed > 0    # (the byte form stands beside the slots)
+    run.shard.set_option("slots_matrix", 0)                  # the step that ends at the byte form
+    cm, raw, cols = run.step()
+    assert isinstance(cm, ShardBytes) and cm.nnz > 1000 and raw.n_row_listed > 0
     got = {"cm": widen_shard_matrix(cm), "raw": widen_shard_matrix(raw), "merged": run.merge_pairs}
     check(got, c)
     wide = run.shard.matrix(True)                            # ... and the 32-bit accessor widens it on the host
@@ -451,7 +458,7 @@ def test_one_shard_over_rccl_and_forced_exchange():
     run.shard.set_option("byte_matrix", 1)
     ph = run.shard.phase_stats()
     assert ph["exchange_record_bytes"]["bytes"] == 12        # barcode + UMI in 64 bits, gene + mark + chromosome in 32
-    assert ph["partition"]["steps"] == 4 and ph["all_to_all"]["steps"] == 4
+    assert ph["partition"]["steps"] == 5 and ph["all_to_all"]["steps"] == 5
     dev.free()
 
 

@@ -103,6 +103,14 @@ KINDS = {
 }
 
 
+def seeded_oracle(kw, arrays, side):
+    """The directional UMI merge never seeds rand() (its random fills of N-UMIs continue the PROCESS's sequence): the oracle -- which
+    draws from the C library -- starts from srand(1) like a fresh reference process; the library restates that sequence per pass."""
+    import ctypes
+    ctypes.CDLL("libc.so.6").srand(1)
+    return parity.oracle_run(Oracle, oracle_kw(kw), *arrays, side)
+
+
 def make_case(name):
     stream_kw, kw, n_rate = KINDS[name]
     cb, umi, gene, aux = parity.canonical_stream(*SynthStream(**stream_kw).generate_host())
@@ -118,7 +126,7 @@ def make_case(name):
 def test_shards_match_the_oracle(name, world):
     """Every merge kind (and the UMI merges) through `world` shards against the oracle's container over the whole stream."""
     arrays, kw, side = make_case(name)
-    o = parity.oracle_run(Oracle, oracle_kw(kw), *arrays, side)
+    o = seeded_oracle(kw, arrays, side)
     got = run_shards(arrays, kw, even_bounds(len(arrays[0]), world), side=side)
     want = check_vs_oracle(got, o, side)
     assert len(got["cm"][3]) >= 8
@@ -140,7 +148,7 @@ def test_eight_shards_with_ordinal_ranges_beyond_2_to_32(name):
     bounds = [0] + [int(c) for c in cuts] + [n]
     firsts = [i * 1_000_000_000 for i in range(8)]
     assert firsts[5] > 2 ** 32
-    o = parity.oracle_run(Oracle, oracle_kw(kw), *arrays, side)
+    o = seeded_oracle(kw, arrays, side)
     got = run_shards(arrays, kw, bounds, first_ordinals=firsts, side=side, steps=2)
     check_vs_oracle(got, o, side)
     plain = run_shards(arrays, kw, bounds, side=side)          # the same shards with ordinals below 2^32: the same matrices
@@ -154,7 +162,7 @@ def test_shards_that_disagree_on_exact_widths():
     arrays, kw, side = make_case("real:10x")
     arrays = [a.copy() for a in arrays]
     arrays[3][512 * 3 + 17] = (int(arrays[3][512 * 3 + 17]) & 0xFFFF0000) | 0x1FFF       # a chromosome id the sample does not see: the partition is repeated
-    o = parity.oracle_run(Oracle, oracle_kw(kw), *arrays, side)
+    o = seeded_oracle(kw, arrays, side)
     for opts in ([{"exact_widths": 1}, {}], [{}, {"exact_widths": 1}, {}]):
         got = run_shards(arrays, kw, even_bounds(len(arrays[0]), len(opts)), side=side, options=opts, steps=2)
         check_vs_oracle(got, o, side)
