@@ -695,7 +695,14 @@ struct dropest_ctx {
 	// 32-bit slots over the wire as bytes: true when this matrix takes that way (large enough, not switched off)
 	bool wire_wanted(uint64_t nnz, int form, bool to_host) const;
 	bool matrix_wire = true;        // dropest_set_matrix_wire
-	void wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_t st);   // after the byte-form emit on `st`: lists, chunked copies, the job
+	// (sharded runs) where a shard's columns go: the 32-bit slots of the GLOBAL matrix (node-shared host memory) and each local column's
+	// entry range there; the bytes themselves travel as the byte form of the shard's LOCAL matrix, contiguous, like one context's
+	struct WireTarget { u32 *rows = nullptr, *vals = nullptr; const u32 *begin = nullptr, *end = nullptr; uint64_t global_nnz = 0; };
+	void wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_t st, const WireTarget *target = nullptr);   // after the byte-form emit on `st`: lists, chunked copies, the job
+	// emit (this stream) + lists + chunked copies (copy_st, behind an event) + the widening job of the columns of `col_cell` into the target's slots
+	void ship_columns_to_slots(bool filtered_m, bool reads_output, const std::vector<u32> &col_cell, const std::vector<u32> &col_start, uint64_t nnz,
+	                           const WireTarget &target, hipStream_t copy_st);
+	hipEvent_t ev_ship = nullptr;
 	bool wire_finish(MatrixResult &M);                                          // waits for the job; false: the lists overflowed (emit the slots directly)
 	// columns of a count matrix from the host rows: cell id of every column, start of every column, number of entries
 	void matrix_columns(bool filtered_m, std::vector<u32> &col_cell, std::vector<u32> &colptr, uint64_t &nnz);

@@ -110,6 +110,7 @@ dropest_ctx::~dropest_ctx() {
 	if (stream2) { (void)stream_wait(stream2); (void)hipStreamDestroy(stream2); }
 	if (ev_fork) (void)hipEventDestroy(ev_fork);
 	if (ev_raw) (void)hipEventDestroy(ev_raw);
+	if (ev_ship) (void)hipEventDestroy(ev_ship);
 	if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -1598,15 +1599,20 @@ bool dropest_ctx::wire_wanted(uint64_t nnz, int form, bool to_host) const {
 	return form == 0 && to_host && !off && matrix_wire && nnz >= (1u << 18);
 }
 
-void dropest_ctx::wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_t st) {
+void dropest_ctx::wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_t st, const WireTarget *target) {
 	using namespace dropest;
-	M.h_row.ensure(nnz); M.h_val.ensure(nnz);
+	if (!target) { M.h_row.ensure(nnz); M.h_val.ensure(nnz); }
 	hipLaunchKernelGGL(matrix_lists_out_kernel, dim3(64), dim3(256), 0, st, M.d_rovf.p, M.rcap, M.h_rovf.p, M.d_ovf.p, M.vcap, M.h_ovf.p);
 	HIP_CHECK(hipGetLastError());
 	auto job = std::make_shared<DecodeJob>();
 	HIP_CHECK(hipGetDevice(&job->device));
 	job->m.rd = M.h_drow8.p; job->m.vb = M.h_val8.p; job->m.colptr = M.colptr.data(); job->m.ncols = M.ncols; job->m.nnz = nnz;
 	job->ro = M.h_row.p; job->vo = M.h_val.p;
+	if (target) {   // a shard's columns: bytes by the local colptr, slots at each column's global place
+		job->m.colptr = target->begin; job->m.colend = target->end; job->m.bytebeg = M.colptr.data(); job->m.nnz = target->global_nnz;
+		job->cut = M.colptr.data();
+		job->ro = target->rows; job->vo = target->vals;
+	}
 	job->r_count = M.h_rovf.p; job->r_pos = M.h_rovf.p + 1; job->r_val = M.h_rovf.p + 1 + M.rcap; job->rcap = M.rcap;
 	job->v_count = M.h_ovf.p; job->v_pos = M.h_ovf.p + 1; job->v_val = M.h_ovf.p + 1 + M.vcap; job->vcap = M.vcap;
 	static const uint64_t n_chunks = [] { const char *e = getenv("DROPEST_WIRE_CHUNKS"); return uint64_t(e ? std::max(1, atoi(e)) : 12); }();
@@ -1637,8 +1643,47 @@ void dropest_ctx::wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_
 	job->prepare(slice_entries);
 	M.job = job; M.wire = true;
 	M.job_t0 = std::chrono::steady_clock::now();
-	DecodePool::get().prefer_node_of(M.h_row.p);
+	DecodePool::get().prefer_node_of(target ? target->rows : M.h_row.p);
 	DecodePool::get().submit(job);
+}
+
+// Sharded runs: the columns of a caller-given list of cells (local offsets col_start, nnz entries in all) leave the device as the byte form
+// of a LOCAL matrix -- the emit of one context, the same chunked copies at the link's streaming rate -- and the pool's host threads widen
+// them into the caller's slots at each column's GLOBAL place (the target).  The caller ends with wire_finish(mat[...]); false = the lists
+// overflowed (very sparse columns): it then places the 32-bit form itself.
+void dropest_ctx::ship_columns_to_slots(bool filtered_m, bool reads_output, const std::vector<u32> &col_cell, const std::vector<u32> &col_start, uint64_t nnz,
+                                        const WireTarget &target, hipStream_t copy_st) {
+	using namespace dropest;
+	invalidate_prefetch();
+	MatrixResult &M = mat[filtered_m ? 0 : 1];
+	M.settle();
+	const u32 ncols = u32(col_cell.size());
+	M.colptr.assign(col_start.begin(), col_start.end()); M.colptr.push_back(u32(nnz));
+	M.nnz = nnz; M.ncols = ncols; M.narrow = 0; M.n_ovf = M.n_rovf = 0; M.wire = false;
+	if (!ncols || !nnz) return;
+	m_col_cell.ensure(ncols); m_col_start.ensure(ncols);
+	DevBuf<u32> &d_cell = filtered_m ? m_col_cell : m2_col_cell, &d_start = filtered_m ? m_col_start : m2_col_start;
+	d_cell.ensure(ncols); d_start.ensure(ncols);
+	MatrixArgs a{};
+	matrix_outputs(M, nnz, 2, true, a);
+	HIP_CHECK(hipMemcpyAsync(d_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemcpyAsync(d_start.p, col_start.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemsetAsync(M.d_ovf.p, 0, 4, stream));
+	HIP_CHECK(hipMemsetAsync(M.d_rovf.p, 0, 4, stream));
+	a.col_cell = d_cell.p; a.col_start = d_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
+	a.value = filtered_m ? (reads_output ? cg_reads_req.p : cg_n_req.p) : (reads_output ? cg_reads_all.p : cg_n_all.p);
+	a.gene_mask = layout.gene_none; a.skip_zero = filtered_m ? 1 : 0;
+	timed(filtered_m ? "emit_matrix:cm" : "emit_matrix:cm_raw", double(nnz) * 14, [&] {
+		std::vector<u32> rows(ncols);
+		for (u32 j = 0; j < ncols; ++j) rows[j] = M.colptr[j + 1] - M.colptr[j];
+		launch_emit_bytes(a, rows, filtered_m ? m_col_list : m2_col_list, filtered_m ? m_col_list_host : m2_col_list_host, stream);
+	});
+	if (copy_st && copy_st != stream) {
+		if (!ev_ship) HIP_CHECK(hipEventCreateWithFlags(&ev_ship, hipEventDisableTiming));
+		HIP_CHECK(hipEventRecord(ev_ship, stream));
+		HIP_CHECK(hipStreamWaitEvent(copy_st, ev_ship, 0));
+	} else copy_st = stream;
+	wire_copy_and_decode(M, nnz, copy_st, &target);
 }
 
 bool dropest_ctx::wire_finish(MatrixResult &M) {

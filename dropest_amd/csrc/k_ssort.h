@@ -443,6 +443,10 @@ struct SsLocalArgs {
 	uint32_t *order_flag;                // set to 1 when a bucket is found out of order after its sort (checked on EVERY pass)
 	unsigned long long *t_key;           // sparse rows: molecule key, reads, agg (bit 0 not-annotated, exon << 1, intron << 16)
 	uint32_t *t_reads, *t_agg, *n_loc;
+	// (cell, gene) heads INSIDE the bucket: records p > 0 whose key above the UMI field differs from their predecessor's (cg_shift = ms + UMI bits).
+	// ss_compact_cg turns them into the (cell, gene) table while it moves the molecule rows (zeroed before the launches: every wave adds its share)
+	uint32_t *cg_loc;
+	int cg_shift;
 };
 
 // LDS of ss_local (dynamic, 16-byte aligned): sk[cap] keys -- later aliased by agg[cap] + headpos[cap] (u32 each) --,
@@ -572,7 +576,7 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint3
 	// record, OR-reduced into a device flag the host reads together with the molecule count.  The one-atomic ranking above leans on
 	// the LDS applying same-address lanes of one instruction in lane order (undocumented); should that ever fail, molecules would
 	// silently split into several runs.  With this check it cannot be silent: the host falls back to the LSD sort.
-	uint32_t run = 0, pre[ITEMS], head_bits = 0;
+	uint32_t run = 0, pre[ITEMS], head_bits = 0, cg_heads = 0;
 	bool out_of_order = false;
 #pragma unroll
 	for (int i = 0; i < ITEMS; ++i) {
@@ -585,8 +589,10 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint3
 		pre[i] = run + __builtin_amdgcn_mbcnt_hi(uint32_t(bal >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bal), 0u));
 		run += uint32_t(__popcll(bal));
 		if (head) head_bits |= 1u << i;
+		if (a.cg_loc) cg_heads += uint32_t(__popcll(__ballot(valid && p && (prev >> a.cg_shift) != (key[i] >> a.cg_shift))));
 	}
 	if (lane == 0) wtot[w] = run;
+	if (a.cg_loc && lane == 0 && cg_heads) atomicAdd(&a.cg_loc[bucket], cg_heads);
 	if (__ballot(out_of_order) && lane == 0) atomicOr(a.order_flag, 1u);
 	lds_barrier();   // every sk[p - 1] is read: the key area may now hold the aggregates
 	uint32_t woff = 0, n_loc = 0;
@@ -710,6 +716,116 @@ __global__ __launch_bounds__(256) void ss_compact_kernel(SsCompactArgs a) {
 		a.mol_mark[dst + j] = (v & 1u) | (exon ? 2u : 0u) | (intron ? 4u : 0u);
 		a.mol_exon[dst + j] = exon;
 		a.mol_intron[dst + j] = intron;
+	}
+}
+
+// ---- compaction fused with molecules -> (cell, gene) ---------------------------------------------------------------------
+// ss_compact reads every sparse molecule row once to move it; the (cell, gene) table was then made by seg_count + seg_reduce<MoleculesTo
+// CellGeneX>, which read the dense table again (8 + 24 bytes per molecule).  The rows a wave moves are in key order, so it folds them into
+// (cell, gene) rows on the way: Gene::number_of_umis / number_of_requested_umis / reads (Gene.cpp:60-93) per row, exactly what the
+// policy MoleculesToCellGeneX (k_segreduce.h) computes.  Where a row goes needs the number of (cell, gene) heads in the buckets before:
+// ss_local counted the heads INSIDE each bucket (cg_loc), ss_cg_counts adds whether a bucket's first molecule opens a new pair (its
+// predecessor is the last molecule of the nearest non-empty bucket before it), the scan gives cg_prefix.
+__global__ __launch_bounds__(256) void ss_cg_counts_kernel(const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ n_loc, const unsigned long long *__restrict__ t_key,
+                                                           int umi_bits, uint32_t n_buckets, const uint32_t *__restrict__ cg_loc, uint32_t *__restrict__ cg_cnt) {
+	const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+	if (b >= n_buckets) return;
+	uint32_t c = 0;
+	if (n_loc[b]) {
+		uint32_t head0 = 1;
+		for (uint32_t q = b; q-- > 0;)
+			if (n_loc[q]) { head0 = (t_key[size_t(bucket_base[q]) + n_loc[q] - 1] >> umi_bits) != (t_key[bucket_base[b]] >> umi_bits); break; }
+		c = cg_loc[b] + head0;
+	}
+	cg_cnt[b] = c;
+}
+struct SsCompactCgArgs {
+	const uint32_t *bucket_base, *n_loc, *prefix, *cg_loc, *cg_cnt, *cg_prefix;
+	uint32_t n_buckets;
+	const unsigned long long *t_key;
+	const uint32_t *t_reads, *t_agg;
+	unsigned long long *mol_key;
+	uint32_t *mol_reads, *mol_mark, *mol_exon, *mol_intron;
+	unsigned long long *cg_key;
+	uint32_t *cg_mol_begin;
+	uint32_t *out[6];        // n_all, n_req, reads_all, reads_req, exon reads, intron reads (total + 1 rows each)
+	int umi_bits;
+	uint32_t query_mask, n_cg;
+};
+// The rows the fused kernel adds into with atomics -- the last (cell, gene) run of every bucket (the next bucket may continue it) -- and the
+// sentinel row behind the table are cleared first; every other row is written with plain stores.
+__global__ __launch_bounds__(256) void ss_cg_zero_borders_kernel(SsCompactCgArgs a) {
+	const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+	if (b == 0) {
+#pragma unroll
+		for (int c = 0; c < 6; ++c) a.out[c][a.n_cg] = 0;
+	}
+	if (b >= a.n_buckets || !a.cg_cnt[b]) return;
+	const uint32_t row = a.cg_prefix[b] + a.cg_cnt[b] - 1;
+#pragma unroll
+	for (int c = 0; c < 6; ++c) a.out[c][row] = 0;
+}
+// one wave per bucket
+__global__ __launch_bounds__(256) void ss_compact_cg_kernel(SsCompactCgArgs a) {
+	const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (b >= a.n_buckets) return;
+	const uint32_t n = a.n_loc[b];
+	if (!n) return;
+	const uint32_t src = a.bucket_base[b], dst = a.prefix[b], cgp = a.cg_prefix[b];
+	const uint32_t head0 = a.cg_cnt[b] - a.cg_loc[b];
+	const unsigned long long le = lane == 63u ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= this one
+	// the (cell, gene) run that is open at the end of the previous 64 rows: its sums so far (wave-uniform), run_base = heads seen before this chunk
+	// (run id r: 0 = the run the previous bucket left open, else the r-th head of this bucket; its row = cgp + r - 1)
+	uint32_t carry[6] = {0, 0, 0, 0, 0, 0}, run_base = 0;
+	unsigned long long prev_cg = 0;
+	auto emit = [&](uint32_t r, bool atomic, const uint32_t (&v)[6]) {
+		const uint32_t row = cgp + r - 1u;
+#pragma unroll
+		for (int c = 0; c < 6; ++c) { if (atomic) { if (v[c]) atomicAdd(&a.out[c][row], v[c]); } else a.out[c][row] = v[c]; }
+	};
+	for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+		const uint32_t j = j0 + lane;
+		const bool valid = j < n;
+		unsigned long long key = 0; uint32_t reads = 0, agg = 0;
+		if (valid) { key = a.t_key[size_t(src) + j]; reads = a.t_reads[size_t(src) + j]; agg = a.t_agg[size_t(src) + j]; }
+		const uint32_t exon = (agg >> 1) & 0x7FFFu, intron = (agg >> 16) & 0x7FFFu, mark = (agg & 1u) | (exon ? 2u : 0u) | (intron ? 4u : 0u);
+		if (valid) {
+			a.mol_key[size_t(dst) + j] = key; a.mol_reads[size_t(dst) + j] = reads; a.mol_mark[size_t(dst) + j] = mark;
+			a.mol_exon[size_t(dst) + j] = exon; a.mol_intron[size_t(dst) + j] = intron;
+		}
+		const unsigned long long cg = key >> a.umi_bits;
+		unsigned long long before = (unsigned long long)__shfl_up((long long)cg, 1, 64);
+		if (lane == 0) before = prev_cg;
+		const bool head = valid && (j == 0 ? head0 != 0 : cg != before);
+		const unsigned long long hm = __ballot(head), vm = __ballot(valid);
+		const unsigned long long mine = hm & le;
+		const uint32_t r = run_base + uint32_t(__popcll(mine));
+		const uint32_t start = mine ? 63u - uint32_t(__builtin_clzll(mine)) : 0u;   // first lane of this lane's run inside the chunk
+		const uint32_t req = (a.query_mask >> (mark & 7u)) & 1u;
+		// segmented inclusive sums over the lanes of one run: n_all | n_req << 16 (at most 64 each per chunk), reads, requested reads, exon, intron
+		uint32_t t[5] = {valid ? 1u | (req << 16) : 0u, valid ? reads : 0u, (valid && req) ? reads : 0u, valid ? exon : 0u, valid ? intron : 0u};
+#pragma unroll
+		for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
+			const bool take = lane >= dlt && lane - dlt >= start;
+#pragma unroll
+			for (int c = 0; c < 5; ++c) { const uint32_t o = uint32_t(__shfl_up(int(t[c]), dlt, 64)); if (take) t[c] += o; }
+		}
+		uint32_t tot[6] = {t[0] & 0xFFFFu, t[0] >> 16, t[1], t[2], t[3], t[4]};   // (the two counts shared a word inside the chunk only: a run of any length)
+		if (!mine) {   // the run came into the chunk open: what the earlier chunks saw of it
+#pragma unroll
+			for (int c = 0; c < 6; ++c) tot[c] += carry[c];
+		}
+		// the run that was open at the end of the previous chunk ended there if this chunk starts with a head: lane 0 writes it out
+		if (j0 && lane == 0 && head) emit(run_base, run_base == 0, carry);
+		if (head) { a.cg_key[cgp + r - 1u] = cg; a.cg_mol_begin[cgp + r - 1u] = dst + j; }
+		const bool next_valid = lane < 63u && ((vm >> (lane + 1u)) & 1ull), next_head = lane < 63u && ((hm >> (lane + 1u)) & 1ull);
+		const bool last_row = valid && j == n - 1u;
+		if (valid && (last_row || (next_valid && next_head))) emit(r, last_row || r == 0, tot);   // a run's last row inside the chunk (the bucket's last run: atomics)
+		// what stays open behind lane 63 (only when the bucket goes on)
+#pragma unroll
+		for (int c = 0; c < 6; ++c) carry[c] = uint32_t(__shfl(int(tot[c]), 63, 64));
+		run_base += uint32_t(__popcll(hm));
+		prev_cg = (unsigned long long)__shfl((long long)cg, 63, 64);
 	}
 }
 

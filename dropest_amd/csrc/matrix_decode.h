@@ -39,15 +39,18 @@ struct ByteMatrixView {
 	const uint32_t *colptr = nullptr;             // column c = entries [colptr[c], colend ? colend[c] : colptr[c + 1])
 	const uint32_t *colend = nullptr;             // set: the columns are a SELECTION of a larger matrix's (one shard's columns of the global
 	                                              // matrix of a sharded run, csrc/shard_run.h), each with its own begin and end
+	const uint32_t *bytebeg = nullptr;            // set (with colend): the bytes of column c stand at [bytebeg[c], ...) of rd / vb -- a shard's LOCAL byte
+	                                              // arrays, contiguous in its own column order -- while colptr / colend name the column's place in ro / vo
 	uint64_t ncols = 0, nnz = 0;
 };
 
 // Columns [c0, c1) of the byte form into (ro, vo).  Listed entries (a 255) were written to their places beforehand: a listed row is
 // read back from ro, a listed value is left alone.
 inline void widen_columns_scalar(const ByteMatrixView &m, size_t c0, size_t c1, uint32_t *__restrict ro, uint32_t *__restrict vo) {
-	const uint8_t *__restrict rd = m.rd, *__restrict vb = m.vb;
 	const uint32_t *__restrict cp = m.colptr, *__restrict ce = m.colend;
 	for (size_t c = c0; c < c1; ++c) {
+		const ptrdiff_t sh = m.bytebeg ? ptrdiff_t(m.bytebeg[c]) - ptrdiff_t(cp[c]) : 0;
+		const uint8_t *__restrict rd = m.rd + sh, *__restrict vb = m.vb + sh;
 		uint32_t prev1 = 0;   // previous row + 1
 		const uint32_t k1 = ce ? ce[c] : cp[c + 1];
 		for (uint32_t k = cp[c]; k < k1; ++k) {
@@ -66,11 +69,12 @@ inline void widen_columns_scalar(const ByteMatrixView &m, size_t c0, size_t c1, 
 // 16 instead of 8 bytes of memory traffic per entry) -- possible when ro and vo are equally aligned modulo 32 bytes.
 __attribute__((target("avx2"))) inline void widen_columns_avx2(const ByteMatrixView &m, size_t c0, size_t c1, uint32_t *__restrict ro,
                                                                uint32_t *__restrict vo, bool nt) {
-	const uint8_t *__restrict rd = m.rd, *__restrict vb = m.vb;
 	const uint32_t *__restrict cp = m.colptr;
 	if (nt && ((reinterpret_cast<uintptr_t>(ro) ^ reinterpret_cast<uintptr_t>(vo)) & 31u)) nt = false;
 	const __m128i ff = _mm_set1_epi8(char(0xFF));
 	for (size_t c = c0; c < c1; ++c) {
+		const ptrdiff_t sh = m.bytebeg ? ptrdiff_t(m.bytebeg[c]) - ptrdiff_t(cp[c]) : 0;
+		const uint8_t *__restrict rd = m.rd + sh, *__restrict vb = m.vb + sh;
 		uint32_t prev1 = 0;
 		uint32_t k = cp[c];
 		const uint32_t k1 = m.colend ? m.colend[c] : cp[c + 1];
@@ -123,12 +127,13 @@ __attribute__((target("avx2"))) inline void widen_columns_avx2(const ByteMatrixV
 // were written by different steps: slower than plain stores on those hosts).
 __attribute__((target("avx512f,avx512bw,avx512vl"))) inline void widen_columns_avx512(const ByteMatrixView &m, size_t c0, size_t c1, uint32_t *__restrict ro,
                                                                                       uint32_t *__restrict vo, bool nt) {
-	const uint8_t *__restrict rd = m.rd, *__restrict vb = m.vb;
 	const uint32_t *__restrict cp = m.colptr;
 	if (nt && ((reinterpret_cast<uintptr_t>(ro) ^ reinterpret_cast<uintptr_t>(vo)) & 63u)) nt = false;
 	const __m128i ff = _mm_set1_epi8(char(0xFF));
 	const __m512i zero = _mm512_setzero_si512();
 	for (size_t c = c0; c < c1; ++c) {
+		const ptrdiff_t sh = m.bytebeg ? ptrdiff_t(m.bytebeg[c]) - ptrdiff_t(cp[c]) : 0;
+		const uint8_t *__restrict rd = m.rd + sh, *__restrict vb = m.vb + sh;
 		uint32_t prev1 = 0;
 		uint32_t k = cp[c];
 		const uint32_t k1 = m.colend ? m.colend[c] : cp[c + 1];
@@ -267,6 +272,17 @@ struct DecodeJob {
 		const uint32_t n = rows ? n_r : n_v, b = (rows ? i : i - n_r_ranges) * LIST_RANGE, e = std::min(n, b + LIST_RANGE);
 		// (the bytes themselves may still be on their way: whether a listed entry stands on a 255 is checked only by
 		// dropest_matrix_bytes_widen, where everything is there; here a wrong position shows as a position beyond the matrix)
+		if (m.bytebeg) {   // a selection of columns with its own byte arrays: the lists name LOCAL entries -- to the column's global place
+			const uint32_t local_nnz = m.ncols ? cut[m.ncols] : 0u;
+			for (uint32_t k = b; k < e; ++k) {
+				const uint32_t pos = lpos[k];
+				if (pos >= local_nnz) { finish(rows ? BAD_ROW : BAD_VALUE); bad = true; return; }
+				size_t lo = 0, hi = size_t(m.ncols);            // last column whose local begin is <= pos
+				while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (m.bytebeg[mid] <= pos) lo = mid; else hi = mid; }
+				out[m.colptr[lo] + (pos - m.bytebeg[lo])] = lval[k];
+			}
+			return;
+		}
 		for (uint32_t k = b; k < e; ++k) {
 			const uint32_t pos = lpos[k];
 			if (pos >= m.nnz || (check_marks && mark[pos] != 255u)) { finish(rows ? BAD_ROW : BAD_VALUE); bad = true; return; }

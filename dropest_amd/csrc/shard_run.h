@@ -596,11 +596,13 @@ __global__ __launch_bounds__(256) void place_columns_narrow_kernel(const unsigne
 	}
 }
 // The BYTE form (dropest_matrix_bytes, include/dropest_amd.h): u8 row delta + u8 value at the entry's GLOBAL place, two bytes per entry
-// on the PCIe link.  A workgroup takes one column and walks it in aligned 4-entry words (one u32 store per array and lane; the
-// ragged ends of a column as bytes -- the neighbouring column may be another shard's).  Entries that do not fit a byte (255 =
-// listed) go to this shard's segment of the shared buffer with their global position: staged in LDS, one atomic per workgroup
-// and round on the shard's counters; the readers concatenate the segments (the lists carry no order).
-constexpr uint32_t PCB_STAGE = 1024;   // 256 lanes x 4 entries: a round cannot stage more
+// on the PCIe link.  A workgroup takes one column.  A lane takes SIXTEEN consecutive entries of an aligned group: a group that lies inside
+// the column leaves as one 16-byte store per array (a wave writes 1 KB of each array in one piece: the link takes whole lines -- with
+// 4-byte stores per lane the placing kernels of a C2 pass reached ~30 GB/s of the link's ~52), the ragged groups at a column's ends byte by
+// byte (the neighbouring column may be another shard's).  Entries that do not fit a byte (255 = listed) go to this shard's segment of the
+// shared buffer with their global position: a wave counts what its lanes list, takes its places with ONE atomic per kind on the shard's
+// counters, and the lanes write their entries there (no LDS, no workgroup barrier); the readers concatenate the segments (the lists
+// carry no order).
 __global__ __launch_bounds__(256) void place_columns_bytes_kernel(const unsigned long long *__restrict__ desc, const uint32_t *__restrict__ src_rows,
                                                                   const uint32_t *__restrict__ src_vals, uint8_t *__restrict__ dst_delta,
                                                                   uint8_t *__restrict__ dst_val, uint32_t *__restrict__ counters /* [2] */,
@@ -612,46 +614,55 @@ __global__ __launch_bounds__(256) void place_columns_bytes_kernel(const unsigned
 	// that chunk is complete and visible to the host threads that widen it into the 32-bit slots.  slot_rows / slot_vals: the slots
 	// themselves (node-shared host memory); a listed entry is written there directly, so the widening needs no list at all.
 	if (flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-	__shared__ uint32_t st_pos[2][PCB_STAGE], st_x[2][PCB_STAGE];
-	__shared__ uint32_t st_n[2], st_base[2];
 	const unsigned long long s = desc[3ull * blockIdx.x], d = desc[3ull * blockIdx.x + 1], len = desc[3ull * blockIdx.x + 2];
-	if (threadIdx.x < 2) st_n[threadIdx.x] = 0;
-	__syncthreads();
-	const unsigned long long w0 = d >> 2, w1 = (d + len + 3) >> 2;
-	for (unsigned long long wb = w0; wb < w1; wb += 256) {
-		const unsigned long long w = wb + threadIdx.x;
-		int staged = 0;
-		if (w < w1) {
-			uint32_t dd = 0, vv = 0, inside = 0;
-			for (uint32_t b = 0; b < 4; ++b) {
-				const unsigned long long g = 4 * w + b;
+	const uint32_t lane = threadIdx.x & 63u;
+	const unsigned long long g0 = d >> 4, g1 = (d + len + 15) >> 4;
+	for (unsigned long long gb = g0; gb < g1; gb += blockDim.x) {   // (256 threads for cm's long columns, one wave for cm_raw's mostly short ones)
+		const unsigned long long gq = gb + threadIdx.x, first = 16 * gq;
+		uint32_t dd[4] = {0, 0, 0, 0}, vv[4] = {0, 0, 0, 0}, inside = 0, n_listed[2] = {0, 0};
+		if (gq < g1) {
+			uint32_t prev = (first > d && first <= d + len) ? src_rows[s + (first - d) - 1] : 0xFFFFFFFFu;
+#pragma unroll
+			for (uint32_t b = 0; b < 16; ++b) {
+				const unsigned long long g = first + b;
 				if (g < d || g >= d + len) continue;
 				const unsigned long long t = g - d;
-				const uint32_t row = src_rows[s + t], prev = t ? src_rows[s + t - 1] : 0xFFFFFFFFu, v = src_vals[s + t];
+				const uint32_t row = src_rows[s + t], v = src_vals[s + t];
 				const uint32_t delta = row - prev;
+				prev = row;
 				inside |= 1u << b;
-				dd |= (delta >= 255u ? 255u : delta) << (8 * b);
-				vv |= (v >= 255u ? 255u : v) << (8 * b);
-				if (delta >= 255u) { const uint32_t at = atomicAdd(&st_n[0], 1u); st_pos[0][at] = uint32_t(g); st_x[0][at] = row; staged = 1; if (slot_rows) slot_rows[g] = row; }
-				if (v >= 255u) { const uint32_t at = atomicAdd(&st_n[1], 1u); st_pos[1][at] = uint32_t(g); st_x[1][at] = v; staged = 1; if (slot_vals) slot_vals[g] = v; }
+				dd[b >> 2] |= (delta >= 255u ? 255u : delta) << (8 * (b & 3u));
+				vv[b >> 2] |= (v >= 255u ? 255u : v) << (8 * (b & 3u));
+				if (delta >= 255u) { ++n_listed[0]; if (slot_rows) slot_rows[g] = row; }
+				if (v >= 255u) { ++n_listed[1]; if (slot_vals) slot_vals[g] = v; }
 			}
-			if (inside == 0xFu) {
-				reinterpret_cast<uint32_t *>(dst_delta)[w] = dd;
-				reinterpret_cast<uint32_t *>(dst_val)[w] = vv;
-			} else
-				for (uint32_t b = 0; b < 4; ++b) if (inside >> b & 1u) { dst_delta[4 * w + b] = uint8_t(dd >> (8 * b)); dst_val[4 * w + b] = uint8_t(vv >> (8 * b)); }
+			if (inside == 0xFFFFu) {
+				reinterpret_cast<uint4 *>(dst_delta)[gq] = make_uint4(dd[0], dd[1], dd[2], dd[3]);
+				reinterpret_cast<uint4 *>(dst_val)[gq] = make_uint4(vv[0], vv[1], vv[2], vv[3]);
+			} else {
+#pragma unroll
+				for (uint32_t b = 0; b < 16; ++b) if (inside >> b & 1u) { dst_delta[first + b] = uint8_t(dd[b >> 2] >> (8 * (b & 3u))); dst_val[first + b] = uint8_t(vv[b >> 2] >> (8 * (b & 3u))); }
+			}
 		}
-		if (__syncthreads_or(staged)) {
-			if (threadIdx.x < 2) st_base[threadIdx.x] = st_n[threadIdx.x] ? atomicAdd(&counters[threadIdx.x], st_n[threadIdx.x]) : 0u;
-			__syncthreads();
-			for (uint32_t k = 0; k < 2; ++k) {
+#pragma unroll
+		for (uint32_t k = 0; k < 2; ++k) {
+			if (!__ballot(n_listed[k] != 0)) continue;
+			const uint32_t incl = wave_incl_scan_u32(n_listed[k]);
+			const uint32_t total = uint32_t(__shfl(int(incl), 63, 64));
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd(&counters[k], total);
+			base = uint32_t(__shfl(int(base), 0, 64));
+			uint32_t at = base + incl - n_listed[k];
+			if (n_listed[k]) {
 				uint32_t *pos = k ? vl_pos : rl_pos, *x = k ? vl_val : rl_row;
-				const uint32_t n = st_n[k], base = st_base[k];
-				for (uint32_t i = threadIdx.x; i < n; i += 256) if (base + i < cap) { pos[base + i] = st_pos[k][i]; x[base + i] = st_x[k][i]; }
+				const uint32_t *src = k ? src_vals : src_rows;
+#pragma unroll
+				for (uint32_t b = 0; b < 16; ++b)
+					if ((inside >> b & 1u) && (((k ? vv[b >> 2] : dd[b >> 2]) >> (8 * (b & 3u))) & 0xFFu) == 255u) {
+						if (at < cap) { pos[at] = uint32_t(first + b); x[at] = src[s + (first + b - d)]; }
+						++at;
+					}
 			}
-			__syncthreads();
-			if (threadIdx.x < 2) st_n[threadIdx.x] = 0;
-			__syncthreads();
 		}
 	}
 }
@@ -819,21 +830,20 @@ struct dropest_shard {
 		// the 32-bit dgCMatrix slots i / x of the GLOBAL matrix in the shared buffer (option "slots_matrix", on): every shard's host threads
 		// widen ITS columns from the byte form as the chunks of columns land (matrix_decode.h) -- the step ends where the plain context's does
 		// (ResultsPrinter::create_matrix, Estimation/ResultsPrinter.cpp:433-442)
-		bool slots = false;                                       // this step's shared buffer has the slots region
+		bool slots = false;                                       // this step's shared buffer holds the slots (and no byte form)
 		u32 *slot_rows = nullptr, *slot_vals = nullptr;           // host views
-		std::shared_ptr<dropest::DecodeJob> job, late_job;
-		std::vector<u32> dec_begin, dec_end, dec_cut;             // this shard's columns: global begin / end of each, running local entry count
+		u32 *d_slot_rows = nullptr, *d_slot_vals = nullptr;       // this shard's device views of them (the 32-bit fall-back places there)
+		bool shipped = false;                                     // this shard has columns on their way (the context's widening job)
+		std::vector<u32> dec_begin, dec_end;                      // this shard's columns: global begin / end of each (cm: planned on the host)
 		std::vector<u32> col_cell, col_start;                     // ... their cells and local offsets (cm; cm_raw's are in raw_plan)
 		dropest::PinnedBuf<u32> h_begin, h_end;                   // ... written by the device when the columns are planned there (cm_raw)
-		dropest::PinnedBuf<u32> h_flags;
-		u32 epoch = 0;
-		void settle() {
-			if (job) { (void)job->wait(); job->quiesce(); job.reset(); }
-			if (late_job) { late_job->quiesce(); late_job.reset(); }
-		}
+		const unsigned long long *d_descr = nullptr; u32 nc = 0; uint64_t local_nnz = 0;   // what the fall-back needs again
+		// the byte form of a slots step, made on demand (dropest_shard_matrix_bytes)
+		std::vector<uint8_t> enc_delta, enc_vals; bool encoded = false;
 	} mat[2];
 	bool slots_matrix = true;                                     // option "slots_matrix": the step ends with the 32-bit slots (needs byte_matrix)
-	void finish_slots(Mat &M);
+	void finish_slots(int slot);
+	void encode_bytes(Mat &M);
 	bool narrow_matrix = true;                                    // option "narrow_matrix": 16-bit matrices when every gene id fits
 	bool byte_matrix = true;                                      // option "byte_matrix": the byte form (any gene id); wins over narrow_matrix
 	uint64_t byte_list_cap = 0;                                   // option "byte_list_cap": entries a shard may list per kind (0: 2^20)
@@ -1581,7 +1591,7 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 	dropest_ctx &c = *ctx;
 	const int slot = filtered_m ? 0 : 1;
 	Mat &M = mat[slot];
-	M.settle();   // (a straggler of the previous widening reads dec_begin / dec_end)
+	ctx->mat[slot].settle();   // (a straggler of the previous widening reads dec_begin / dec_end)
 	std::vector<u32> sel;
 	for (u32 i = 0; i < G.size(); ++i) if (!filtered_m || G[i].req_genes >= c.min_after) sel.push_back(i);
 	std::vector<u32> order;
@@ -1619,7 +1629,7 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 	const SharedLayout L = open_shared(M, slot, 0);
 	const u32 nc = u32(col_cell.size());
 	if (nc && local_nnz) {
-		c.emit_columns_device(filtered_m, false, col_cell, col_start, local_nnz, false);
+		if (!L.slots) c.emit_columns_device(filtered_m, false, col_cell, col_start, local_nnz, false);   // (a slots step emits the byte form of the local matrix: place_columns)
 		d_desc.ensure(desc.size()); h_desc.ensure(desc.size());
 		std::memcpy(h_desc.p, desc.data(), desc.size() * 8);
 		HIP_CHECK(hipMemcpyAsync(d_desc.p, h_desc.p, desc.size() * 8, hipMemcpyHostToDevice, c.stream));
@@ -1640,20 +1650,27 @@ dropest_shard::SharedLayout dropest_shard::open_shared(Mat &M, int slot, size_t 
 	L.base = (head_bytes + 15) & ~size_t(15);
 	L.list_cap = u32(std::min<uint64_t>(byte_list_cap ? byte_list_cap : (1u << 20), (M.nnz + 15) & ~15ull));
 	L.off_val = (size_t(M.nnz) + 15) & ~size_t(15); L.off_seg = 2 * L.off_val; L.seg_bytes = 16 + 16 * size_t(L.list_cap);
-	// the slots behind the segments: rows | values, each padded to whole 64-byte lines (the widening stores whole lines)
+	// slots step: the buffer holds the 32-bit slots only -- rows | values, each padded to whole 64-byte lines (the widening stores whole
+	// lines); every shard's bytes cross its link as the byte form of its LOCAL matrix and never stand in the shared buffer
 	L.slots = L.bytes && slots_matrix;
-	L.off_slots = (L.base + L.off_seg + L.seg_bytes * size_t(world) + 63) & ~size_t(63);   // (from the buffer's start: that is page-aligned)
+	if (L.slots) L.bytes = false;
+	L.off_slots = (L.base + 63) & ~size_t(63);   // (from the buffer's start: that is page-aligned)
 	L.slots_stride = ((size_t(M.nnz) + 15) & ~size_t(15)) * 4;
-	const size_t payload = L.bytes ? (L.slots ? L.off_slots - L.base + 2 * L.slots_stride : L.off_seg + L.seg_bytes * size_t(world))
-	                               : std::max<size_t>(size_t(M.nnz), 1) * (L.narrow ? 4 : 8);
-	M.settle();   // (a straggler of the previous step's widening may still be leaving: the buffer is about to be rewritten or replaced)
+	const size_t payload = L.slots ? L.off_slots - L.base + 2 * L.slots_stride
+	                               : (L.bytes ? L.off_seg + L.seg_bytes * size_t(world) : std::max<size_t>(size_t(M.nnz), 1) * (L.narrow ? 4 : 8));
+	ctx->mat[slot].settle();   // (a straggler of the previous step's widening may still be leaving: the buffer is about to be rewritten or replaced)
 	L.host = static_cast<char *>(tr->shared_host(slot, L.base + payload, &L.dev));
 	char *host = L.host + L.base;
 	M.narrow = L.narrow; M.widened = false; M.ovf_pos.clear(); M.ovf_val.clear();
 	M.bytes = L.bytes; M.lists_ready = false;
 	M.rows = M.vals = nullptr; M.rows16 = M.vals16 = nullptr; M.delta8 = M.vals8 = nullptr;
-	M.slots = L.slots; M.slot_rows = M.slot_vals = nullptr;
-	if (L.slots) { M.slot_rows = reinterpret_cast<u32 *>(L.host + L.off_slots); M.slot_vals = reinterpret_cast<u32 *>(L.host + L.off_slots + L.slots_stride); }
+	M.slots = L.slots; M.slot_rows = M.slot_vals = nullptr; M.shipped = false; M.encoded = false;
+	if (L.slots) {
+		M.slot_rows = reinterpret_cast<u32 *>(L.host + L.off_slots); M.slot_vals = reinterpret_cast<u32 *>(L.host + L.off_slots + L.slots_stride);
+		M.d_slot_rows = reinterpret_cast<u32 *>(static_cast<char *>(L.dev) + L.off_slots); M.d_slot_vals = reinterpret_cast<u32 *>(static_cast<char *>(L.dev) + L.off_slots + L.slots_stride);
+		M.rows = M.slot_rows; M.vals = M.slot_vals;
+		return L;
+	}
 	if (L.bytes) {
 		M.delta8 = reinterpret_cast<const uint8_t *>(host); M.vals8 = reinterpret_cast<const uint8_t *>(host) + L.off_val;
 		M.segments = host + L.off_seg; M.seg_bytes = L.seg_bytes; M.list_cap = L.list_cap;
@@ -1672,6 +1689,22 @@ void dropest_shard::place_columns(Mat &M, int slot, bool filtered_m, const Share
 	char *d_payload = static_cast<char *>(L.dev) + L.base;
 	const dropest_ctx::MatrixResult &R = c.mat[slot];
 	const bool work = nc && local_nnz;
+	if (L.slots) {
+		// The columns leave as the byte form of this shard's LOCAL matrix (the emit and the chunked copies of one context: whole lines at the
+		// link's streaming rate, whatever the columns' lengths -- placing bytes at their GLOBAL places straight from a kernel met ragged column
+		// ends with byte stores over PCIe: 22 GB/s on cm_raw's short columns), and the pool's host threads widen every chunk of columns into the
+		// shared 32-bit slots at the columns' global places as soon as its arrival flag is up (matrix_decode.h).
+		M.d_descr = d_descr; M.nc = nc; M.local_nnz = local_nnz;
+		if (!work) return;
+		dropest_ctx::WireTarget T;
+		T.rows = M.slot_rows; T.vals = M.slot_vals; T.global_nnz = M.nnz;
+		T.begin = M.dec_begin.empty() ? M.h_begin.p : M.dec_begin.data();
+		T.end = M.dec_end.empty() ? M.h_end.p : M.dec_end.data();
+		const std::vector<u32> &cells = filtered_m ? M.col_cell : raw_plan.col_cell, &starts = filtered_m ? M.col_start : raw_plan.col_start;
+		c.ship_columns_to_slots(filtered_m, false, cells, starts, local_nnz, T, st);
+		M.shipped = true;
+		return;
+	}
 	if (L.bytes) {
 		u32 *seg_words = reinterpret_cast<u32 *>(d_payload + L.off_seg + L.seg_bytes * size_t(rank));
 		d_list_count.ensure(8);
@@ -1680,54 +1713,9 @@ void dropest_shard::place_columns(Mat &M, int slot, bool filtered_m, const Share
 		if (work) {
 			u32 *lists = seg_words + 4;
 			const size_t cap = L.list_cap;
-			if (L.slots && local_start) {
-				// The columns leave in chunks (whole columns, ~1/12 of this shard's entries each); the launch of chunk j + 1 starts by raising
-				// chunk j's arrival flag in pinned memory, and the pool's host threads widen a chunk's columns into the shared 32-bit slots as
-				// soon as its flag is up -- the walk of matrix_decode.h over this shard's SELECTION of the global matrix's columns.
-				using dropest::DecodeJob;
-				char *d_slots = static_cast<char *>(L.dev) + L.off_slots;
-				u32 *d_srows = reinterpret_cast<u32 *>(d_slots), *d_svals = reinterpret_cast<u32 *>(d_slots + L.slots_stride);
-				auto job = std::make_shared<DecodeJob>();
-				job->device = c.cfg.device;
-				M.dec_cut.assign(local_start, local_start + nc); M.dec_cut.push_back(u32(local_nnz));
-				job->cut = M.dec_cut.data();
-				static const uint64_t n_chunks = [] { const char *e = getenv("DROPEST_WIRE_CHUNKS"); return uint64_t(e ? std::max(1, atoi(e)) : 12); }();
-				dropest::cut_columns(M.dec_cut.data(), 0, size_t(nc), std::max<uint64_t>(local_nnz / n_chunks + 1, uint64_t(1) << 19), job->chunk_end);
-				const size_t K = job->chunk_end.size();
-				M.h_flags.ensure(K + 2);
-				for (size_t j = 0; j < K + 2; ++j) M.h_flags.p[j] = 0;
-				M.epoch = M.epoch + 1 ? M.epoch + 1 : 1;
-				M.h_flags.p[0] = M.epoch;   // no lists to wait for: listed entries reach the slots directly
-				job->flags = M.h_flags.p; job->epoch = M.epoch;
-				auto launch = [&] {
-					u32 c0 = 0;
-					for (size_t j = 0; j < K; ++j) {
-						const u32 c1 = job->chunk_end[j];
-						hipLaunchKernelGGL(place_columns_bytes_kernel, dim3(c1 - c0), dim3(256), 0, st, d_descr + 3ull * c0, R.d_row.p, R.d_val.p,
-						                   reinterpret_cast<uint8_t *>(d_payload), reinterpret_cast<uint8_t *>(d_payload) + L.off_val, cnt,
-						                   lists, lists + cap, lists + 2 * cap, lists + 3 * cap, L.list_cap, d_srows, d_svals,
-						                   j ? M.h_flags.p + j : static_cast<u32 *>(nullptr), M.epoch);
-						c0 = c1;
-					}
-					hipLaunchKernelGGL(dropest::matrix_flag_kernel, dim3(1), dim3(1), 0, st, M.h_flags.p + K, M.epoch);
-				};
-				if (st == c.stream) c.timed(filtered_m ? "place_columns:cm" : "place_columns:cm_raw", double(local_nnz) * 10, launch);
-				else launch();
-				HIP_CHECK(hipGetLastError());
-				job->m.rd = M.delta8; job->m.vb = M.vals8; job->m.ncols = nc; job->m.nnz = M.nnz;
-				// (cm: begin / end come from the host's plan; cm_raw planned on the device: from the pinned arrays its planning kernel wrote,
-				// complete before the first flag is raised -- stream order)
-				job->m.colptr = M.dec_begin.empty() ? M.h_begin.p : M.dec_begin.data();
-				job->m.colend = M.dec_end.empty() ? M.h_end.p : M.dec_end.data();
-				job->ro = M.slot_rows; job->vo = M.slot_vals;
-				static const uint64_t slice_entries = [] { const char *e = getenv("DROPEST_DECODE_SLICE"); return e && atoll(e) >= 1024 ? uint64_t(atoll(e)) : uint64_t(1) << 16; }();
-				job->prepare(slice_entries);
-				M.job = job;
-				dropest::DecodePool::get().prefer_node_of(M.slot_rows);
-				dropest::DecodePool::get().submit(job);
-			} else {
+			{
 			auto launch = [&] {
-				hipLaunchKernelGGL(place_columns_bytes_kernel, dim3(nc), dim3(256), 0, st, d_descr, R.d_row.p, R.d_val.p,
+				hipLaunchKernelGGL(place_columns_bytes_kernel, dim3(nc), dim3(filtered_m ? 256 : 64), 0, st, d_descr, R.d_row.p, R.d_val.p,
 				                   reinterpret_cast<uint8_t *>(d_payload), reinterpret_cast<uint8_t *>(d_payload) + L.off_val, cnt,
 				                   lists, lists + cap, lists + 2 * cap, lists + 3 * cap, L.list_cap);
 			};
@@ -1828,7 +1816,7 @@ void dropest_shard::assemble_raw_device() {
 	Phase ph(this, "matrix:cm_raw");
 	RawPlan &P = raw_plan;
 	Mat &M = mat[1];
-	M.settle();
+	ctx->mat[1].settle();
 	const size_t w = 3 + size_t(world);
 	const u32 nl = u32(P.col_cell.size());
 	const uint64_t ncols = P.ncols;
@@ -1901,10 +1889,10 @@ void dropest_shard::assemble_raw_device() {
 		HIP_CHECK(hipGetLastError());
 	}
 	const uint64_t local_nnz = P.pre.back();
-	if (nl && local_nnz) c.emit_columns_device(false, false, P.col_cell, P.col_start, local_nnz, false);
+	if (nl && local_nnz && !L.slots) c.emit_columns_device(false, false, P.col_cell, P.col_start, local_nnz, false);
 	// the placing kernel on its own stream (byte form: nothing on the host waits for it before the end of the step)
 	hipStream_t st = c.stream;
-	if (L.bytes && !getenv("DROPEST_SHARD_NO_PLACE_STREAM")) {
+	if ((L.bytes || L.slots) && !getenv("DROPEST_SHARD_NO_PLACE_STREAM")) {
 		if (!place_stream) { HIP_CHECK(hipStreamCreateWithFlags(&place_stream, hipStreamNonBlocking)); HIP_CHECK(hipEventCreateWithFlags(&ev_place, hipEventDisableTiming)); }
 		HIP_CHECK(hipEventRecord(ev_place, c.stream));
 		HIP_CHECK(hipStreamWaitEvent(place_stream, ev_place, 0));
@@ -2010,7 +1998,7 @@ void dropest_shard::step() {
 	if (!raw_device_now) assemble_matrix(false);
 	auto wait_all = [&] {
 		// this shard's columns widened (its thread takes part: what is unclaimed, then what a straggler holds), its streams drained, then everybody's
-		{ Phase ph(this, "matrix:decode_wait"); finish_slots(mat[1]); finish_slots(mat[0]); }
+		{ Phase ph(this, "matrix:decode_wait"); finish_slots(1); finish_slots(0); }
 		Phase ph(this, "matrix:wait"); HIP_CHECK(stream_wait(c.stream)); if (place_stream) HIP_CHECK(stream_wait(place_stream)); tr->barrier();
 	};
 	wait_all();
@@ -2029,19 +2017,48 @@ void dropest_shard::step() {
 			wait_all();
 		}
 		// (a matrix whose slots were widened inside the step needs its lists only if somebody asks for the byte form: collected then)
-		Phase ph(this, "matrix:lists"); for (int k = 0; k < 2; ++k) if (!mat[k].slots) collect_lists(mat[k]);
+		Phase ph(this, "matrix:lists"); for (int k = 0; k < 2; ++k) collect_lists(mat[k]);   // (a slots step has no byte form in the buffer: nothing to collect)
 	}
 	c.collect_timings();
 }
 
-void dropest_shard::finish_slots(Mat &M) {
-	using dropest::DecodeJob;
-	if (!M.job) return;
-	M.job->work(true);
-	const int st = M.job->wait();
-	M.late_job = std::move(M.job);   // complete; a straggler may still be inside (settle() before the buffers are touched again)
-	M.job.reset();
-	if (st != DecodeJob::DONE) throw DeviceError("count matrix: widening this shard's columns of the byte form failed");
+void dropest_shard::finish_slots(int slot) {
+	using namespace dropest;
+	Mat &M = mat[slot];
+	if (!M.slots || !M.shipped) return;
+	M.shipped = false;
+	dropest_ctx &c = *ctx;
+	if (c.wire_finish(c.mat[slot])) return;
+	// The lists of this shard's byte form overflowed (very sparse columns: a small cell lists nearly every row).  The slots ARE the 32-bit
+	// form: this shard emits its columns as 32-bit arrays and places them there directly -- its own decision, no collective (ADVICE r3:
+	// the step cannot fail for the shape of the data).
+	phases["matrix:overflow"].launches++;
+	const bool filtered_m = slot == 0;
+	c.emit_columns_device(filtered_m, false, filtered_m ? M.col_cell : raw_plan.col_cell, filtered_m ? M.col_start : raw_plan.col_start, M.local_nnz, false);
+	const dropest_ctx::MatrixResult &R = c.mat[slot];
+	hipLaunchKernelGGL(place_columns_kernel, dim3(M.nc), dim3(256), 0, c.stream, M.d_descr, R.d_row.p, R.d_val.p, M.d_slot_rows, M.d_slot_vals);
+	HIP_CHECK(hipGetLastError());
+	HIP_CHECK(stream_wait(c.stream));
+}
+
+// The byte form of a matrix whose step ended with the slots (dropest_shard_matrix_bytes asks for it): encoded from the slots, once.
+void dropest_shard::encode_bytes(Mat &M) {
+	using namespace dropest;
+	if (M.encoded) return;
+	M.enc_delta.assign(size_t(M.nnz), 0); M.enc_vals.assign(size_t(M.nnz), 0);
+	M.rl_pos.clear(); M.rl_row.clear(); M.vl_pos.clear(); M.vl_val.clear();
+	const u32 *cp = M.colptr32_p;
+	for (uint64_t c = 0; c < M.ncols; ++c) {
+		uint32_t prev1 = 0;
+		for (uint32_t k = cp[c]; k < cp[c + 1]; ++k) {
+			const uint32_t row = M.slot_rows[k], v = M.slot_vals[k], d = row + 1u - prev1;
+			prev1 = row + 1u;
+			M.enc_delta[k] = uint8_t(d >= 255u ? 255u : d); M.enc_vals[k] = uint8_t(v >= 255u ? 255u : v);
+			if (d >= 255u) { M.rl_pos.push_back(k); M.rl_row.push_back(row); }
+			if (v >= 255u) { M.vl_pos.push_back(k); M.vl_val.push_back(v); }
+		}
+	}
+	M.delta8 = M.enc_delta.data(); M.vals8 = M.enc_vals.data(); M.lists_ready = true; M.encoded = true;
 }
 
 // the byte form's lists: every shard's segment of the shared buffer (written through its PCIe link, complete after the barrier)
@@ -2363,8 +2380,7 @@ dropest_status dropest_shard_matrix(dropest_shard *s, int filtered, uint64_t *nc
 		dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
 		*ncols = M.ncols; *nnz = M.nnz;
 		if (colptr) *colptr = reinterpret_cast<const uint64_t *>(M.colptr_p ? M.colptr_p : M.colptr.data());
-		if (M.bytes && M.slots && !M.widened) { M.rows = M.slot_rows; M.vals = M.slot_vals; }   // the step ended with the slots: every shard widened its columns
-		else if (M.bytes && (rowidx || values) && !M.widened) {    // the pass produced the byte form: decoded here, once, on host threads
+		if (M.bytes && (rowidx || values) && !M.widened) {    // the pass produced the byte form: decoded here, once, on host threads
 			s->collect_lists(M);
 			M.wide_rows.resize(M.nnz); M.wide_vals.resize(M.nnz);
 			dropest_matrix_bytes mb{M.ncols, M.nnz, M.colptr32_p, M.delta8, M.vals8, M.rl_pos.size(), M.rl_pos.data(), M.rl_row.data(),
@@ -2388,7 +2404,7 @@ dropest_status dropest_shard_matrix_form(dropest_shard *s, int filtered, int32_t
 	return guarded([&] {
 		if (!s || !form) throw InvalidError("null argument");
 		const dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
-		*form = M.bytes ? (M.slots ? 3 : 2) : (M.narrow ? 1 : 0);
+		*form = M.slots ? 3 : (M.bytes ? 2 : (M.narrow ? 1 : 0));
 	});
 }
 
@@ -2412,10 +2428,10 @@ dropest_status dropest_shard_matrix_bytes(dropest_shard *s, int filtered, dropes
 	return guarded([&] {
 		if (!s || !out) throw InvalidError("null argument");
 		dropest_shard::Mat &M = s->mat[filtered ? 0 : 1];
-		if (!M.bytes && M.nnz) throw UnsupportedError("the last step did not produce the byte-form matrices (the shard option byte_matrix is off)");
-		s->collect_lists(M);
+		if (!M.bytes && !M.slots && M.nnz) throw UnsupportedError("the last step did not produce the byte-form matrices (the shard option byte_matrix is off)");
+		if (M.slots) s->encode_bytes(M); else s->collect_lists(M);
 		static const uint32_t zero = 0;
-		*out = dropest_matrix_bytes{M.ncols, M.nnz, M.bytes ? M.colptr32_p : &zero, M.delta8, M.vals8, M.rl_pos.size(), M.rl_pos.data(), M.rl_row.data(),
+		*out = dropest_matrix_bytes{M.ncols, M.nnz, (M.bytes || M.slots) ? M.colptr32_p : &zero, M.delta8, M.vals8, M.rl_pos.size(), M.rl_pos.data(), M.rl_row.data(),
 		                            M.vl_pos.size(), M.vl_pos.data(), M.vl_val.data()};
 		if (col_barcodes) *col_barcodes = reinterpret_cast<const uint64_t *>(M.barcode_p ? M.barcode_p : M.col_barcode.data());
 	});

@@ -194,3 +194,16 @@ def test_cell_id_by_cb_answers_from_the_host_mirror():
             assert c.cell_id_by_cb(int(rows["barcode"][k])) == int(k) == o.cell_id_by_cb(capi.unpack_code(int(rows["barcode"][k])))
         assert c.cell_id_by_cb(int(capi.pack_seq("TTTTTTTTTTTTTTTT"))) == -1
         c.reset_results(); c.set_initialized(); c.merge_and_filter()
+
+
+def test_a_shard_whose_byte_lists_overflow_places_its_columns_as_32_bit_slots(monkeypatch):
+    """A row list too short for a shard's sparse columns (DROPEST_MATRIX_ROW_LIST_CAP: a dozen entries): that shard's widening reports the
+    overflow and the shard places the 32-bit form of its columns into the shared slots itself -- same matrices, no collective decision."""
+    arrays, kw, side = make_case("none")
+    bounds = even_bounds(len(arrays[0]), 3)
+    want = run_shards(arrays, kw, bounds)
+    monkeypatch.setenv("DROPEST_MATRIX_ROW_LIST_CAP", "12")
+    got = run_shards(arrays, kw, bounds, steps=2)
+    assert got["form"] == (3, 3) and got["phases"]["matrix:overflow"]["steps"] >= 2
+    for k in ("cm", "raw"):
+        assert all(np.array_equal(a, b) for a, b in zip(got[k], want[k]))
