@@ -549,6 +549,8 @@ struct dropest_ctx {
 	// splitter sort (k_ssort.h): sample, splitters, partition scratch, look-back words
 	dropest::DevBuf<u64> ss_sample_a, ss_sample_b, ss_fine, ss_coarse;
 	dropest::DevBuf<u32> ss_base1, ss_cnt2, ss_bucket_base, ss_bucket_cnt, ss_tmp, ss_n_loc, ss_prefix, ss_chunk, ss_big_list;
+	dropest::DevBuf<u32> ss_cg_loc, ss_cg_cnt, ss_cg_prefix;   // (cell, gene) heads per fine bucket: the compaction makes the (cell, gene) table on its way
+	bool cg_from_sort = false;                                 // this pass's (cell, gene) table came out of the splitter sort's compaction
 	dropest::DevBuf<u32> ss_cursors;   // partitions by reservation: the regions' cursors (k_ssort.h)
 	bool ss_no_reserve = false;        // a region overflowed in this pass: the counting partitions from here on
 	bool splitter_sort_reduce();   // false: not applicable / fell back, the caller runs the LSD sort + seg_reduce
@@ -697,7 +699,10 @@ struct dropest_ctx {
 	bool matrix_wire = true;        // dropest_set_matrix_wire
 	// (sharded runs) where a shard's columns go: the 32-bit slots of the GLOBAL matrix (node-shared host memory) and each local column's
 	// entry range there; the bytes themselves travel as the byte form of the shard's LOCAL matrix, contiguous, like one context's
-	struct WireTarget { u32 *rows = nullptr, *vals = nullptr; const u32 *begin = nullptr, *end = nullptr; uint64_t global_nnz = 0; };
+	struct WireTarget {
+		u32 *rows = nullptr, *vals = nullptr; const u32 *begin = nullptr, *end = nullptr; uint64_t global_nnz = 0;
+		const unsigned long long *d_descr = nullptr;   // device: (local start, global start, length) of every local column
+	};
 	void wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_t st, const WireTarget *target = nullptr);   // after the byte-form emit on `st`: lists, chunked copies, the job
 	// emit (this stream) + lists + chunked copies (copy_st, behind an event) + the widening job of the columns of `col_cell` into the target's slots
 	void ship_columns_to_slots(bool filtered_m, bool reads_output, const std::vector<u32> &col_cell, const std::vector<u32> &col_start, uint64_t nnz,

@@ -787,6 +787,15 @@ bool dropest_ctx::splitter_sort_reduce() {
 	a.atomic_below = u32(ms + layout.umi_bits);   // the UMI field: random digits
 	if (const char *e = getenv("DROPEST_SS_ATOMIC_BELOW")) a.atomic_below = u32(atoi(e));
 	a.cap = SMALL_MAX; a.skip_above = SMALL_MAX;
+	// the (cell, gene) table out of the compaction (k_ssort.h: ss_compact_cg) instead of seg_count + seg_reduce over the dense molecule table
+	static const bool fused_cg_off = getenv("DROPEST_SS_NO_FUSED_CG") != nullptr;
+	const bool fuse_cg = !fused_cg_off;
+	cg_from_sort = false;
+	if (fuse_cg) {
+		ss_cg_loc.ensure(F2); ss_cg_cnt.ensure(F2); ss_cg_prefix.ensure(F2);
+		HIP_CHECK(hipMemsetAsync(ss_cg_loc.p, 0, size_t(F2) * 4, stream));
+		a.cg_loc = ss_cg_loc.p; a.cg_shift = ms + layout.umi_bits;
+	}
 	auto launch_small = [&] {
 		static const int wave_mode = [] { const char *e = getenv("DROPEST_SS_LOCAL_WAVE"); return e ? atoi(e) : 0; }();
 		if ((wave_mode == 64 || wave_mode == 128) && atomic_rank) {
@@ -908,9 +917,14 @@ bool dropest_ctx::splitter_sort_reduce() {
 	timed("ss_scan", double(F2) * 12, [&] {
 		hipLaunchKernelGGL(ss_chunk_sums_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_n_loc.p, F2, ss_chunk.p);
 		hipLaunchKernelGGL(ss_prefix_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_n_loc.p, F2, ss_chunk.p, n_chunks, ss_prefix.p, scalars.p + 1);
+		if (fuse_cg) {   // heads per bucket (those inside it + whether its first molecule opens a pair), their prefix, their total
+			hipLaunchKernelGGL(ss_cg_counts_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, ss_bucket_base.p, ss_n_loc.p, keys_alt, layout.umi_bits, F2, ss_cg_loc.p, ss_cg_cnt.p);
+			hipLaunchKernelGGL(ss_chunk_sums_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_cg_cnt.p, F2, ss_chunk.p);
+			hipLaunchKernelGGL(ss_prefix_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_cg_cnt.p, F2, ss_chunk.p, n_chunks, ss_cg_prefix.p, scalars.p + 4);
+		}
 	});
-	u32 total_flag[2] = {0, 0};
-	fetch(total_flag, scalars.p + 1, 8);
+	u32 total_flag[4] = {0, 0, 0, 0};   // molecules, order flag, (overflow flag), (cell, gene) pairs
+	fetch(total_flag, scalars.p + 1, 16);
 	if (total_flag[1]) {
 		// A bucket came out of its LDS sort unsorted (the in-kernel check of ss_local, every pass): never silently.  The partitions
 		// consumed the keys, so they are built again and the LSD sort takes the pass; the one-atomic ranking is off for this device.
@@ -929,6 +943,24 @@ bool dropest_ctx::splitter_sort_reduce() {
 	c.bucket_base = ss_bucket_base.p; c.n_loc = ss_n_loc.p; c.prefix = ss_prefix.p; c.n_buckets = F2;
 	c.t_key = keys_alt; c.t_reads = ss_tmp.p; c.t_agg = ss_tmp.p + span;
 	c.mol_key = mol_key.p; c.mol_reads = mol_reads.p; c.mol_mark = mol_mark.p; c.mol_exon = mol_exon.p; c.mol_intron = mol_intron.p;
+	if (fuse_cg) {
+		n_cg = total_flag[3];
+		cg_key.ensure(size_t(n_cg) + 1); cg_mol_begin.ensure(size_t(n_cg) + 1);
+		for (DevBuf<u32> *b : {&cg_n_all, &cg_n_req, &cg_reads_all, &cg_reads_req, &cg_exon, &cg_intron}) b->ensure(size_t(n_cg) + 1);
+		SsCompactCgArgs g{};
+		g.bucket_base = ss_bucket_base.p; g.n_loc = ss_n_loc.p; g.prefix = ss_prefix.p; g.cg_loc = ss_cg_loc.p; g.cg_cnt = ss_cg_cnt.p; g.cg_prefix = ss_cg_prefix.p;
+		g.n_buckets = F2; g.t_key = keys_alt; g.t_reads = ss_tmp.p; g.t_agg = ss_tmp.p + span;
+		g.mol_key = mol_key.p; g.mol_reads = mol_reads.p; g.mol_mark = mol_mark.p; g.mol_exon = mol_exon.p; g.mol_intron = mol_intron.p;
+		g.cg_key = cg_key.p; g.cg_mol_begin = cg_mol_begin.p;
+		g.out[0] = cg_n_all.p; g.out[1] = cg_n_req.p; g.out[2] = cg_reads_all.p; g.out[3] = cg_reads_req.p; g.out[4] = cg_exon.p; g.out[5] = cg_intron.p;
+		g.umi_bits = layout.umi_bits; g.query_mask = query_mask; g.n_cg = n_cg;
+		timed("ss_compact:cell_gene", double(n_mol) * (16 + 24) + double(n_cg) * 36, [&] {
+			hipLaunchKernelGGL(ss_cg_zero_borders_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, g);
+			hipLaunchKernelGGL(ss_compact_cg_kernel, dim3(div_up(F2, 4)), dim3(256), 0, stream, g);
+		});
+		HIP_CHECK(hipMemcpyAsync(cg_mol_begin.p + n_cg, &n_mol, 4, hipMemcpyHostToDevice, stream));   // row i owns molecules [cg_mol_begin[i], cg_mol_begin[i + 1])
+		cg_from_sort = true;
+	} else
 	timed("ss_compact", double(n_mol) * (16 + 24), [&] {
 		hipLaunchKernelGGL(ss_compact_kernel, dim3(div_up(F2, 4)), dim3(256), 0, stream, c);
 	});
@@ -1007,7 +1039,7 @@ void dropest_ctx::reduce_all() {
 	const u64 varying = (counters.key_or ^ counters.key_and) & order_mask;
 	if (splitter_sort_reduce()) {
 		n_chr_rows = 0;
-		reduce_molecules_to_cell_gene();
+		if (!cg_from_sort) reduce_molecules_to_cell_gene();
 		reduce_cell_gene_to_cells();
 		HIP_CHECK(stream_wait(stream));
 		return;
@@ -1602,7 +1634,8 @@ bool dropest_ctx::wire_wanted(uint64_t nnz, int form, bool to_host) const {
 void dropest_ctx::wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_t st, const WireTarget *target) {
 	using namespace dropest;
 	if (!target) { M.h_row.ensure(nnz); M.h_val.ensure(nnz); }
-	hipLaunchKernelGGL(matrix_lists_out_kernel, dim3(64), dim3(256), 0, st, M.d_rovf.p, M.rcap, M.h_rovf.p, M.d_ovf.p, M.vcap, M.h_ovf.p);
+	if (target) hipLaunchKernelGGL(matrix_lists_out_global_kernel, dim3(64), dim3(256), 0, st, M.d_rovf.p, M.rcap, M.h_rovf.p, M.d_ovf.p, M.vcap, M.h_ovf.p, target->d_descr, u32(M.ncols));
+	else hipLaunchKernelGGL(matrix_lists_out_kernel, dim3(64), dim3(256), 0, st, M.d_rovf.p, M.rcap, M.h_rovf.p, M.d_ovf.p, M.vcap, M.h_ovf.p);
 	HIP_CHECK(hipGetLastError());
 	auto job = std::make_shared<DecodeJob>();
 	HIP_CHECK(hipGetDevice(&job->device));
@@ -1654,7 +1687,7 @@ void dropest_ctx::wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_
 void dropest_ctx::ship_columns_to_slots(bool filtered_m, bool reads_output, const std::vector<u32> &col_cell, const std::vector<u32> &col_start, uint64_t nnz,
                                         const WireTarget &target, hipStream_t copy_st) {
 	using namespace dropest;
-	invalidate_prefetch();
+	if (!filtered_m) invalidate_prefetch();   // (cm's columns use their own slot: cm_raw's may still be on their way, and stay so)
 	MatrixResult &M = mat[filtered_m ? 0 : 1];
 	M.settle();
 	const u32 ncols = u32(col_cell.size());

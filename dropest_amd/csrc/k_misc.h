@@ -442,6 +442,24 @@ __global__ __launch_bounds__(256) void matrix_lists_out_kernel(const uint32_t *_
 	if (nv <= vcap) for (uint32_t i = t; i < nv; i += stride) { h_v[1 + i] = d_v[1 + i]; h_v[1 + size_t(vcap) + i] = d_v[1 + size_t(vcap) + i]; }
 }
 
+// The same for a shard's columns (sharded runs): the lists name entries of the shard's LOCAL matrix; on their way out every position becomes
+// the entry's place in the GLOBAL matrix (desc[3c .. 3c + 2] = local start, global start, length of local column c, local starts
+// ascending: a binary search per listed entry -- on the host it cost 18 cache misses for each of cm_raw's 4e5 listed rows).
+__global__ __launch_bounds__(256) void matrix_lists_out_global_kernel(const uint32_t *__restrict__ d_r, uint32_t rcap, uint32_t *__restrict__ h_r,
+                                                                      const uint32_t *__restrict__ d_v, uint32_t vcap, uint32_t *__restrict__ h_v,
+                                                                      const unsigned long long *__restrict__ desc, uint32_t ncols) {
+	const uint32_t t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+	const uint32_t nr = d_r[0], nv = d_v[0];
+	if (t == 0) { h_r[0] = nr; h_v[0] = nv; }
+	auto to_global = [&](uint32_t pos) {
+		uint32_t lo = 0, hi = ncols;            // last column whose local start is <= pos
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (desc[3ull * mid] <= pos) lo = mid; else hi = mid; }
+		return uint32_t(desc[3ull * lo + 1] + (pos - desc[3ull * lo]));
+	};
+	if (nr <= rcap) for (uint32_t i = t; i < nr; i += stride) { h_r[1 + i] = to_global(d_r[1 + i]); h_r[1 + size_t(rcap) + i] = d_r[1 + size_t(rcap) + i]; }
+	if (nv <= vcap) for (uint32_t i = t; i < nv; i += stride) { h_v[1 + i] = to_global(d_v[1 + i]); h_v[1 + size_t(vcap) + i] = d_v[1 + size_t(vcap) + i]; }
+}
+
 // One chunk of a byte-form matrix (entries [k0, k1) of both byte arrays) from device memory to pinned host memory, by a kernel: a
 // device-to-host hipMemcpyAsync costs ~20 us of copy-engine set-up whatever its size, and the chunked copy (matrix_decode.h) makes two
 // dozen of them per matrix -- 0.5 ms on a 10 ms pass.  Source and destination are equally aligned (same index into arrays that both

@@ -34,6 +34,17 @@ namespace dropest {
 
 inline void cpu_relax() { host_cpu_relax(); }
 
+// NUMA node that holds the page of p, or -1.  (The page is read first: a page of a shared mapping this process has not touched yet -- the
+// node-shared result buffer of a sharded run -- is not in its page table, and move_pages answers -EFAULT for it.)
+inline int numa_node_of(const void *p) {
+	if (!p) return -1;
+	(void)*static_cast<const volatile unsigned char *>(p);
+	void *page = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(p) & ~uintptr_t(4095));
+	int status = -1;
+	if (syscall(SYS_move_pages, 0, 1ul, &page, nullptr, &status, 0) != 0 || status < 0) return -1;
+	return status;
+}
+
 struct ByteMatrixView {
 	const uint8_t *rd = nullptr, *vb = nullptr;   // row deltas, values
 	const uint32_t *colptr = nullptr;             // column c = entries [colptr[c], colend ? colend[c] : colptr[c + 1])
@@ -272,17 +283,7 @@ struct DecodeJob {
 		const uint32_t n = rows ? n_r : n_v, b = (rows ? i : i - n_r_ranges) * LIST_RANGE, e = std::min(n, b + LIST_RANGE);
 		// (the bytes themselves may still be on their way: whether a listed entry stands on a 255 is checked only by
 		// dropest_matrix_bytes_widen, where everything is there; here a wrong position shows as a position beyond the matrix)
-		if (m.bytebeg) {   // a selection of columns with its own byte arrays: the lists name LOCAL entries -- to the column's global place
-			const uint32_t local_nnz = m.ncols ? cut[m.ncols] : 0u;
-			for (uint32_t k = b; k < e; ++k) {
-				const uint32_t pos = lpos[k];
-				if (pos >= local_nnz) { finish(rows ? BAD_ROW : BAD_VALUE); bad = true; return; }
-				size_t lo = 0, hi = size_t(m.ncols);            // last column whose local begin is <= pos
-				while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (m.bytebeg[mid] <= pos) lo = mid; else hi = mid; }
-				out[m.colptr[lo] + (pos - m.bytebeg[lo])] = lval[k];
-			}
-			return;
-		}
+		// (a shard's selection of columns: the lists arrive with GLOBAL positions -- translated on the device, k_misc.h: matrix_lists_out_global)
 		for (uint32_t k = b; k < e; ++k) {
 			const uint32_t pos = lpos[k];
 			if (pos >= m.nnz || (check_marks && mark[pos] != 255u)) { finish(rows ? BAD_ROW : BAD_VALUE); bad = true; return; }
@@ -443,10 +444,8 @@ public:
 	void prefer_node_of(const void *p) {
 		static const bool off = [] { const char *e = getenv("DROPEST_DECODE_NUMA"); return e && atoi(e) == 0; }();
 		if (off || !p) return;
-		void *page = reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(p) & ~uintptr_t(4095));
-		int status = -1;
-		if (syscall(SYS_move_pages, 0, 1ul, &page, nullptr, &status, 0) != 0 || status < 0) return;
-		wanted_node.store(status, std::memory_order_relaxed);
+		const int node = numa_node_of(p);
+		if (node >= 0) wanted_node.store(node, std::memory_order_relaxed);
 	}
 private:
 	DecodePool() {

@@ -534,7 +534,15 @@ struct RcclTransport : Transport {
 			int fd = -1;
 			if (rank == 0) {
 				fd = shm_open(path, O_CREAT | O_EXCL | O_RDWR, 0600);
-				if (fd < 0 || posix_fallocate(fd, 0, off_t(cap)) != 0) ok = 0;   // reserve the pages now: a full tmpfs fails here, not with SIGBUS later
+				// The pages are reserved now (a full tmpfs fails here, not with SIGBUS later) -- on the NUMA node of this rank's GPU, where ROCm
+				// puts pinned host memory and where the threads that widen the matrices into this buffer run (matrix_decode.h): left to the
+				// default policy they land on whatever node this thread happens to run on, and every slot is then written across the sockets.
+				h_in.ensure(4096);
+				const int node = dropest::numa_node_of(h_in.p);
+				unsigned long mask[16] = {0};
+				const bool bound = node >= 0 && node < 1024 && (mask[node / 64] |= 1ul << (node % 64), syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1024ul) == 0);
+				if (fd < 0 || posix_fallocate(fd, 0, off_t(cap)) != 0) ok = 0;
+				if (bound) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
 			}
 			std::vector<uint64_t> oks(static_cast<size_t>(world));
 			gather_host(&ok, 8, oks.data());
@@ -865,7 +873,9 @@ struct dropest_shard {
 	// for shards): the placing kernel is the longest piece of the end of a pass and needs nothing of what follows it
 	hipStream_t place_stream = nullptr;
 	hipEvent_t ev_place = nullptr;
-	~dropest_shard() { if (place_stream) { (void)dropest::stream_wait(place_stream); (void)hipStreamDestroy(place_stream); } if (ev_place) (void)hipEventDestroy(ev_place); }
+	~dropest_shard() {
+		if (ctx) for (auto &R : ctx->mat) R.settle();   // (the widening threads write into the transport's shared buffer: they leave before it is unmapped)
+		if (place_stream) { (void)dropest::stream_wait(place_stream); (void)hipStreamDestroy(place_stream); } if (ev_place) (void)hipEventDestroy(ev_place); }
 	dropest::DevBuf<u64> d_desc_raw, d_ord_out64;
 	dropest::DevBuf<u32> d_ord_pos, d_ord_out;
 	dropest::DevBuf<u64> d_plan_mine, d_plan_all;
@@ -1626,7 +1636,8 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 	M.colptr32.resize(ncols + 1);
 	for (size_t j = 0; j <= ncols; ++j) M.colptr32[j] = u32(M.colptr[j]);
 	M.colptr32_p = M.colptr32.data();
-	const SharedLayout L = open_shared(M, slot, 0);
+	SharedLayout L;
+	{ Phase p2(this, filtered_m ? "cm:open_shared" : "raw:open_shared"); L = open_shared(M, slot, 0); }
 	const u32 nc = u32(col_cell.size());
 	if (nc && local_nnz) {
 		if (!L.slots) c.emit_columns_device(filtered_m, false, col_cell, col_start, local_nnz, false);   // (a slots step emits the byte form of the local matrix: place_columns)
@@ -1634,6 +1645,7 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 		std::memcpy(h_desc.p, desc.data(), desc.size() * 8);
 		HIP_CHECK(hipMemcpyAsync(d_desc.p, h_desc.p, desc.size() * 8, hipMemcpyHostToDevice, c.stream));
 	}
+	Phase p3(this, filtered_m ? "cm:place" : "raw:place");
 	place_columns(M, slot, filtered_m, L, d_desc.p, nc, local_nnz, nullptr, col_start.data());
 }
 
@@ -1697,7 +1709,7 @@ void dropest_shard::place_columns(Mat &M, int slot, bool filtered_m, const Share
 		M.d_descr = d_descr; M.nc = nc; M.local_nnz = local_nnz;
 		if (!work) return;
 		dropest_ctx::WireTarget T;
-		T.rows = M.slot_rows; T.vals = M.slot_vals; T.global_nnz = M.nnz;
+		T.rows = M.slot_rows; T.vals = M.slot_vals; T.global_nnz = M.nnz; T.d_descr = d_descr;
 		T.begin = M.dec_begin.empty() ? M.h_begin.p : M.dec_begin.data();
 		T.end = M.dec_end.empty() ? M.h_end.p : M.dec_end.data();
 		const std::vector<u32> &cells = filtered_m ? M.col_cell : raw_plan.col_cell, &starts = filtered_m ? M.col_start : raw_plan.col_start;

@@ -199,11 +199,14 @@ def test_cell_id_by_cb_answers_from_the_host_mirror():
 def test_a_shard_whose_byte_lists_overflow_places_its_columns_as_32_bit_slots(monkeypatch):
     """A row list too short for a shard's sparse columns (DROPEST_MATRIX_ROW_LIST_CAP: a dozen entries): that shard's widening reports the
     overflow and the shard places the 32-bit form of its columns into the shared slots itself -- same matrices, no collective decision."""
-    arrays, kw, side = make_case("none")
+    arrays = parity.canonical_stream(*SynthStream(n_reads=200_000, n_cells=50, n_genes=30000).generate_host())   # 30 000 genes: small cells list most rows
+    kw, side = dict(min_genes_before_merge=10, min_genes_after_merge=30), ()
     bounds = even_bounds(len(arrays[0]), 3)
+    o = seeded_oracle(kw, arrays, side)
     want = run_shards(arrays, kw, bounds)
+    check_vs_oracle(want, o, side)                      # (many listed rows: the lists' local positions are translated to global places)
+    assert int((np.diff(want["raw"][1].astype(np.int64)) >= 255).sum()) > 300
     monkeypatch.setenv("DROPEST_MATRIX_ROW_LIST_CAP", "12")
     got = run_shards(arrays, kw, bounds, steps=2)
     assert got["form"] == (3, 3) and got["phases"]["matrix:overflow"]["steps"] >= 2
-    for k in ("cm", "raw"):
-        assert all(np.array_equal(a, b) for a, b in zip(got[k], want[k]))
+    check_vs_oracle(got, o, side)
