@@ -954,6 +954,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 		g.cg_key = cg_key.p; g.cg_mol_begin = cg_mol_begin.p;
 		g.out[0] = cg_n_all.p; g.out[1] = cg_n_req.p; g.out[2] = cg_reads_all.p; g.out[3] = cg_reads_req.p; g.out[4] = cg_exon.p; g.out[5] = cg_intron.p;
 		g.umi_bits = layout.umi_bits; g.query_mask = query_mask; g.n_cg = n_cg;
+		if (const char *e = getenv("DROPEST_CG_DBG")) g.dbg = u32(atoi(e));
 		timed("ss_compact:cell_gene", double(n_mol) * (16 + 24) + double(n_cg) * 36, [&] {
 			hipLaunchKernelGGL(ss_cg_zero_borders_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, g);
 			hipLaunchKernelGGL(ss_compact_cg_kernel, dim3(div_up(F2, 4)), dim3(256), 0, stream, g);

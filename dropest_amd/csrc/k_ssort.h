@@ -751,6 +751,7 @@ struct SsCompactCgArgs {
 	uint32_t *out[6];        // n_all, n_req, reads_all, reads_req, exon reads, intron reads (total + 1 rows each)
 	int umi_bits;
 	uint32_t query_mask, n_cg;
+	uint32_t dbg;            // timing probes (DROPEST_CG_DBG; results unusable): 1 no segmented sums, 2 no (cell, gene) output, 4 no molecule rows
 };
 // The rows the fused kernel adds into with atomics -- the last (cell, gene) run of every bucket (the next bucket may continue it) -- and the
 // sentinel row behind the table are cleared first; every other row is written with plain stores.
@@ -765,23 +766,36 @@ __global__ __launch_bounds__(256) void ss_cg_zero_borders_kernel(SsCompactCgArgs
 #pragma unroll
 	for (int c = 0; c < 6; ++c) a.out[c][row] = 0;
 }
-// one wave per bucket
+// One wave per bucket.  The (cell, gene) rows a wave completes go through a ring in LDS (128 rows per wave) and leave 64 rows at a time,
+// one row per lane: whole lines on all eight output arrays.  (Written straight from the lanes where the runs end -- about every second
+// lane -- the same rows cost 0.93 ms per 1e8 reads instead of ~0.3: half-filled store instructions, partial lines.)
 __global__ __launch_bounds__(256) void ss_compact_cg_kernel(SsCompactCgArgs a) {
-	const uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	constexpr uint32_t RING = 128;
+	__shared__ unsigned long long s_key[4][RING];
+	__shared__ uint32_t s_begin[4][RING], s_v[4][6][RING];
+	const uint32_t w = threadIdx.x >> 6, b = blockIdx.x * 4 + w, lane = threadIdx.x & 63u;
 	if (b >= a.n_buckets) return;
 	const uint32_t n = a.n_loc[b];
 	if (!n) return;
-	const uint32_t src = a.bucket_base[b], dst = a.prefix[b], cgp = a.cg_prefix[b];
-	const uint32_t head0 = a.cg_cnt[b] - a.cg_loc[b];
+	const uint32_t src = a.bucket_base[b], dst = a.prefix[b], cgp = a.cg_prefix[b], runs_total = a.cg_cnt[b];
+	const uint32_t head0 = runs_total - a.cg_loc[b];
 	const unsigned long long le = lane == 63u ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= this one
 	// the (cell, gene) run that is open at the end of the previous 64 rows: its sums so far (wave-uniform), run_base = heads seen before this chunk
 	// (run id r: 0 = the run the previous bucket left open, else the r-th head of this bucket; its row = cgp + r - 1)
-	uint32_t carry[6] = {0, 0, 0, 0, 0, 0}, run_base = 0;
+	uint32_t carry[6] = {0, 0, 0, 0, 0, 0}, run_base = 0, flushed = 0;   // flushed: rows of this bucket already written out (rows 0 .. flushed - 1)
 	unsigned long long prev_cg = 0;
-	auto emit = [&](uint32_t r, bool atomic, const uint32_t (&v)[6]) {
-		const uint32_t row = cgp + r - 1u;
+	// the sums of a run that has ended: the run the previous bucket left open (r = 0) and this bucket's last run (which the next bucket may
+	// continue) are added into their rows with atomics; every other run goes to the ring
+	auto emit = [&](uint32_t r, bool border, const uint32_t (&v)[6]) {
+		if (a.dbg & 2u) return;
+		if (border) {
+			const uint32_t row = cgp + r - 1u;
 #pragma unroll
-		for (int c = 0; c < 6; ++c) { if (atomic) { if (v[c]) atomicAdd(&a.out[c][row], v[c]); } else a.out[c][row] = v[c]; }
+			for (int c = 0; c < 6; ++c) if (v[c]) atomicAdd(&a.out[c][row], v[c]);
+		} else {
+#pragma unroll
+			for (int c = 0; c < 6; ++c) s_v[w][c][(r - 1u) & (RING - 1u)] = v[c];
+		}
 	};
 	for (uint32_t j0 = 0; j0 < n; j0 += 64) {
 		const uint32_t j = j0 + lane;
@@ -789,7 +803,7 @@ __global__ __launch_bounds__(256) void ss_compact_cg_kernel(SsCompactCgArgs a) {
 		unsigned long long key = 0; uint32_t reads = 0, agg = 0;
 		if (valid) { key = a.t_key[size_t(src) + j]; reads = a.t_reads[size_t(src) + j]; agg = a.t_agg[size_t(src) + j]; }
 		const uint32_t exon = (agg >> 1) & 0x7FFFu, intron = (agg >> 16) & 0x7FFFu, mark = (agg & 1u) | (exon ? 2u : 0u) | (intron ? 4u : 0u);
-		if (valid) {
+		if (valid && !(a.dbg & 4u)) {
 			a.mol_key[size_t(dst) + j] = key; a.mol_reads[size_t(dst) + j] = reads; a.mol_mark[size_t(dst) + j] = mark;
 			a.mol_exon[size_t(dst) + j] = exon; a.mol_intron[size_t(dst) + j] = intron;
 		}
@@ -804,6 +818,7 @@ __global__ __launch_bounds__(256) void ss_compact_cg_kernel(SsCompactCgArgs a) {
 		const uint32_t req = (a.query_mask >> (mark & 7u)) & 1u;
 		// segmented inclusive sums over the lanes of one run: n_all | n_req << 16 (at most 64 each per chunk), reads, requested reads, exon, intron
 		uint32_t t[5] = {valid ? 1u | (req << 16) : 0u, valid ? reads : 0u, (valid && req) ? reads : 0u, valid ? exon : 0u, valid ? intron : 0u};
+		if (!(a.dbg & 1u))
 #pragma unroll
 		for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
 			const bool take = lane >= dlt && lane - dlt >= start;
@@ -815,17 +830,43 @@ __global__ __launch_bounds__(256) void ss_compact_cg_kernel(SsCompactCgArgs a) {
 #pragma unroll
 			for (int c = 0; c < 6; ++c) tot[c] += carry[c];
 		}
-		// the run that was open at the end of the previous chunk ended there if this chunk starts with a head: lane 0 writes it out
+		// the run that was open at the end of the previous chunk ended there if this chunk starts with a head: lane 0 hands it on
 		if (j0 && lane == 0 && head) emit(run_base, run_base == 0, carry);
-		if (head) { a.cg_key[cgp + r - 1u] = cg; a.cg_mol_begin[cgp + r - 1u] = dst + j; }
+		if (head && !(a.dbg & 2u)) {
+			if (r == runs_total) { a.cg_key[cgp + r - 1u] = cg; a.cg_mol_begin[cgp + r - 1u] = dst + j; }   // the bucket's last run never passes the ring
+			else { s_key[w][(r - 1u) & (RING - 1u)] = cg; s_begin[w][(r - 1u) & (RING - 1u)] = dst + j; }
+		}
 		const bool next_valid = lane < 63u && ((vm >> (lane + 1u)) & 1ull), next_head = lane < 63u && ((hm >> (lane + 1u)) & 1ull);
 		const bool last_row = valid && j == n - 1u;
-		if (valid && (last_row || (next_valid && next_head))) emit(r, last_row || r == 0, tot);   // a run's last row inside the chunk (the bucket's last run: atomics)
+		if (valid && (last_row || (next_valid && next_head))) emit(r, last_row || r == 0, tot);   // a run's last row inside the chunk
 		// what stays open behind lane 63 (only when the bucket goes on)
 #pragma unroll
 		for (int c = 0; c < 6; ++c) carry[c] = uint32_t(__shfl(int(tot[c]), 63, 64));
 		run_base += uint32_t(__popcll(hm));
 		prev_cg = (unsigned long long)__shfl((long long)cg, 63, 64);
+		// rows complete: the runs before the open one, and never the bucket's last run (run ids 1 .. done are rows 0 .. done - 1)
+		const bool final = j0 + 64 >= n;
+		uint32_t done = run_base ? run_base - 1u : 0u;
+		if (final && runs_total && done > runs_total - 1u) done = runs_total - 1u;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		while (!(a.dbg & 2u) && (done - flushed >= 64u || (final && done > flushed))) {
+			const uint32_t cnt = done - flushed < 64u ? done - flushed : 64u;
+			if (lane < cnt) {
+				const uint32_t row = flushed + lane, sl = row & (RING - 1u);
+				const unsigned long long k = s_key[w][sl];
+				const uint32_t mb = s_begin[w][sl];
+				uint32_t v[6];
+#pragma unroll
+				for (int c = 0; c < 6; ++c) v[c] = s_v[w][c][sl];
+				a.cg_key[cgp + row] = k; a.cg_mol_begin[cgp + row] = mb;
+#pragma unroll
+				for (int c = 0; c < 6; ++c) a.out[c][cgp + row] = v[c];
+			}
+			flushed += cnt;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
 	}
 }
 

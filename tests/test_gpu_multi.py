@@ -508,10 +508,12 @@ def test_matrix_forms_of_a_group_agree():
     # a shard that would have to list more than its segment holds: that matrix's columns are placed again in the 16-bit form, by every
     # shard alike (the step must not fail for the shape of the data).  A cap of 16 overflows both matrices, one of 2048 only
     # cm_raw (small real cells list nearly every row); cm_raw planned on the device and on the host.
+    # (the step that ENDS at the byte form in the shared buffer: slots_matrix off -- the default slots step has no shared lists, a shard whose
+    # own lists overflow places its columns as 32-bit slots by itself: test_gpu_multi_oracle.py)
     for raw_dev in (1, 0):
         for cap, wide in ((16, (True, True)), (2048, (False, True))):
             for sh in g.shards:
-                sh.set_option("raw_on_device", raw_dev); sh.set_option("byte_list_cap", cap)
+                sh.set_option("slots_matrix", 0); sh.set_option("raw_on_device", raw_dev); sh.set_option("byte_list_cap", cap)
             g.step()
             assert "matrix:overflow" in g.shards[0].phase_stats()
             for f, want, w in zip((True, False), forms["bytes"], wide):
@@ -524,7 +526,7 @@ def test_matrix_forms_of_a_group_agree():
     for sh in g.shards:
         sh.set_option("byte_list_cap", 0)
     g.step()                                          # and back: the byte form again
-    assert g.shards[0].matrix_bytes(False).n_row_listed > 100
+    assert g.shards[0].matrix_bytes(False).n_row_listed > 100 and g.shards[0].matrix_form(False) == 2
     for f, want in zip((True, False), forms["bytes"]):
         assert all(np.array_equal(x, y) for x, y in zip(g.shards[0].matrix(f), want))
     g.close()
