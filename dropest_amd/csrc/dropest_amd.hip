@@ -269,7 +269,7 @@ void dropest_ctx::build_cb_table() {
 		}
 		const uint64_t est = std::min<uint64_t>(n_reads, uint64_t(distinct) * stride);
 		cap = 1024; while (cap < est + est / 2) cap <<= 1;   // load <= 0.67 even when the estimate is exact
-		n_hot = 0;
+		n_hot = 0; hot_coverage = 0;
 		if (want_hot && cap < (1ull << 31)) {
 			int level = -1;
 			for (int l = 0; l < CB_HOT_LEVELS; ++l) if (head[4 + l] <= CB_HOT_MAX) { level = l; break; }
@@ -280,6 +280,11 @@ void dropest_ctx::build_cb_table() {
 					hipLaunchKernelGGL(cb_hot_collect_kernel, dim3(1024), dim3(256), 0, stream, ts, cb_hot_threshold(level), hot_key.p, scalars.p + 1);
 				});
 				n_hot = head[4 + level];
+				// how many of the sampled reads the list covers, from below: a barcode counted at threshold l and not at l + 1 has at least
+				// cb_hot_threshold(l) sample hits (the thresholds grow by 1.33-1.5x: the bound is within that of the truth)
+				double covered = 0;
+				for (int l = level; l < CB_HOT_LEVELS; ++l) covered += double(head[4 + l] - (l + 1 < CB_HOT_LEVELS ? head[4 + l + 1] : 0u)) * cb_hot_threshold(l);
+				hot_coverage = covered / double(std::max<u32>(1u, n_s));
 			}
 		}
 		if (profiling) stats["count:hot_barcodes"].launches = n_hot;
