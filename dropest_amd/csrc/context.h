@@ -412,6 +412,8 @@ struct dropest_ctx {
 	dropest::DevBuf<dropest::CellRowPod> real_rows_dev;
 	dropest::DevBuf<u32> sizes_dev;
 	bool real_list_current = false;          // real_list holds the ids of `real`, in order
+	bool real_pristine = false;              // no cell of `real` has changed since fetch_real_cells (flags, sizes, sums): real_rows_dev mirrors it
+	dropest::DevBuf<u64> scalars64;
 	// count matrices in CSC form: [0] filtered (cm), [1] raw (cm_raw); device staging + pinned host result
 	struct MatrixResult {
 		dropest::DevBuf<u32> d_row, d_val;

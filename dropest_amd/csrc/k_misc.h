@@ -787,6 +787,39 @@ __global__ __launch_bounds__(256) void gather_u64_kernel(const unsigned long lon
 // A small result written STRAIGHT into pinned host memory by the compute queue (the pointer is the host buffer's device view):
 // for read-backs that must not queue behind a large device-to-host copy on the DMA engine (the permutation of sort_filtered
 // while cm_raw's prefetch holds the copy engine: 15 ms of waiting for 10 MB at C3 size).
+// Ordering the real-candidate cells entirely on the device (dropest_ctx::sort_filtered, pristine list): the three sort columns straight from
+// the rows fetch_real_cells gathered -- barcode code, TOTAL_UMIS as Cell::umis_number casts it, (requested genes << 32 | requested UMIs) --
+// with the OR / AND of every column (constant digits are skipped by the sorts) and the smallest / largest barcode code length.
+// stats: [0..5] OR, AND of the three columns, [6] min bit length, [7] max bit length of the barcode codes (OR-ed with the escape bit's presence in [0])
+__global__ __launch_bounds__(256) void sortf_columns_kernel(const CellRowPod *__restrict__ rows, uint32_t n, unsigned long long *__restrict__ code,
+                                                            unsigned long long *__restrict__ umis, unsigned long long *__restrict__ sizes,
+                                                            unsigned long long *__restrict__ stats) {
+	unsigned long long o[3] = {0, 0, 0}, a[3] = {~0ull, ~0ull, ~0ull}, lmin = 64, lmax = 0;
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+		const CellRowPod r = rows[i];
+		const unsigned long long c = r.barcode, u = (unsigned long long)(size_t)(r.total_umis), z = ((unsigned long long)r.requested_genes << 32) | r.requested_umis;
+		code[i] = c; umis[i] = u; sizes[i] = z;
+		o[0] |= c; a[0] &= c; o[1] |= u; a[1] &= u; o[2] |= z; a[2] &= z;
+		const unsigned long long bl = c ? 64 - __builtin_clzll(c) : 0;
+		lmin = bl < lmin ? bl : lmin; lmax = bl > lmax ? bl : lmax;
+	}
+#pragma unroll
+	for (int k = 0; k < 3; ++k) { o[k] = wave_reduce_or_u64(o[k]); a[k] = wave_reduce_and_u64(a[k]); }
+	lmin = wave_reduce_min_u64(lmin); lmax = wave_reduce_max_u64(lmax);
+	if (lane_id() == 0) {
+#pragma unroll
+		for (int k = 0; k < 3; ++k) { atomicOr(&stats[2 * k], o[k]); atomicAnd(&stats[2 * k + 1], a[k]); }
+		atomicMin(&stats[6], lmin); atomicMax(&stats[7], lmax);
+	}
+}
+// the ordered list to pinned host memory: out[0..m) = cell id, out[m..2m) = index in the real list, out[2m..3m) = TOTAL_UMIS of the cell at place i
+__global__ __launch_bounds__(256) void sortf_out_kernel(const uint32_t *__restrict__ perm, const CellRowPod *__restrict__ rows, const uint32_t *__restrict__ ids, uint32_t m,
+                                                        uint32_t *__restrict__ host_out) {
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+		const uint32_t at = perm[i];
+		host_out[i] = ids[at]; host_out[size_t(m) + i] = at; host_out[2 * size_t(m) + i] = uint32_t(rows[at].total_umis);
+	}
+}
 __global__ __launch_bounds__(256) void store_u32_to_host_kernel(const uint32_t *__restrict__ src, uint32_t n, uint32_t *__restrict__ host_dst) {
 	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) host_dst[i] = src[i];
 }

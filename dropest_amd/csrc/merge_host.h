@@ -722,6 +722,7 @@ void dropest_ctx::run_cb_merge_real() {
 	// the (source, target) pairs in ascending source id: counted and filled over the same contiguous ranges
 	constexpr unsigned W = dropest::HostPool::MAX;
 	size_t n_of[W + 1] = {0};
+	real_pristine = false;
 	const unsigned workers = parallel_ranges(nR, [&](size_t b, size_t e, unsigned w) {
 		size_t c = 0;
 		for (size_t i = b; i < e; ++i) {
@@ -913,6 +914,7 @@ void dropest_ctx::refresh_real_rows() {
 	h_stage.ensure(size_t(count) * 12);
 	HIP_CHECK(hipMemcpyAsync(h_stage.p, sizes_dev.p, size_t(count) * 12, hipMemcpyDeviceToHost, stream));
 	HIP_CHECK(stream_wait(stream));
+	real_pristine = false;
 	const u32 *sz = reinterpret_cast<const u32 *>(h_stage.p);
 	parallel_ranges(count, [&](size_t b, size_t e, unsigned) {
 		for (size_t i = b; i < e; ++i) {

@@ -321,6 +321,7 @@ void dropest_ctx::shard_merge_finish(uint64_t n_local, const uint32_t *local_id,
 	if (!initialized) throw InvalidError("You must initialize container");
 	if (merged) throw InvalidError("merge_and_filter was already run");
 	HostStage hs(this, "shard_merge:finish");
+	real_pristine = false;
 	for (uint64_t i = 0; i < n_local; ++i) {
 		HostCell &h = real[real_at(local_id[i])];
 		h.excluded = excluded[i] != 0; h.merged = merged_away[i] != 0;

@@ -9,6 +9,7 @@ void dropest_ctx::mutate_exclude_cell(u32 cell) {
 	invalidate_prefetch();   // a cm_raw prefetch in flight reads the tables this call rewrites
 	const long ri = real_find(cell);
 	if (ri < 0) { extra_excluded.insert(cell); return; }   // not a real-candidate cell: only the flag is observable
+	real_pristine = false;
 	real[size_t(ri)].excluded = true;
 	request_filtered(filtered_threshold, filtered_max_cells);
 }
@@ -23,6 +24,7 @@ void dropest_ctx::mutate_merge_cells(u32 src, u32 tgt) {
 	HostCell &s = real[size_t(rs)], &t = real[size_t(rt)];
 	if (s.merged) throw InvalidError("merge_cells: the source cell was merged before");
 	// Stats::merge adds every counter (Stats.cpp:29-43); the per-chromosome counters follow the molecules on the device
+	real_pristine = false;
 	t.row.total_reads += s.row.total_reads; t.row.total_umis += s.row.total_umis;
 	s.merged = true;
 	merge_pairs.emplace_back(src, tgt);
@@ -110,6 +112,7 @@ void dropest_ctx::mutate_merge_umis(u32 cell, u32 gene, uint64_t n, const uint64
 	u64 or_and[2];
 	fetch(or_and, d_or_and, 16);
 	reaggregate_from_keys(or_and[0] ^ or_and[1]);
+	real_pristine = false;
 	real[size_t(ri)].row.total_umis -= removed;
 	request_filtered(filtered_threshold, filtered_max_cells);
 }
@@ -193,6 +196,7 @@ void dropest_ctx::mutate_add_umi_to_cell(u32 cell, u32 gene, uint64_t umi_code, 
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(stream_wait(stream));
 	}
+	real_pristine = false;
 	if (is_new) { const long ri = real_find(cell); if (ri >= 0) real[size_t(ri)].row.total_umis += 1; }   // TOTAL_UMIS_PER_CB (:360-363)
 	request_filtered(filtered_threshold, filtered_max_cells);
 }

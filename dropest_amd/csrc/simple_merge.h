@@ -486,6 +486,7 @@ void dropest_ctx::run_cb_merge_simple() {
 		merge_rank.assign(n_cells, 0);
 		for (u32 i = 0; i < nR; ++i) merge_rank[real[i].id] = rank[i];
 	}
+	real_pristine = false;
 	for (u32 i = 0; i < nR; ++i) {
 		real[i].row.total_reads = reads[i]; real[i].row.total_umis = umis[i];
 		if (cur[i] != i) { real[i].merged = true; merge_pairs.emplace_back(real[i].id, real[cur[i]].id); }

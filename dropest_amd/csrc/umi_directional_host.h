@@ -177,6 +177,7 @@ void dropest_ctx::run_umi_merge_directional() {
 		u64 or_and[2];
 		fetch(or_and, d_or_and, 16);
 		reaggregate_from_keys(or_and[0] ^ or_and[1]);   // the (cell, gene) rows keep their indices: groups never vanish
+		real_pristine = false;
 		for (u32 i = 0; i < nr; ++i) if (rem[i]) real[i].row.total_umis -= int(rem[i]);
 	}
 	if (!n_host && !hooks) return;   // (a shard without such groups still takes part in the exchange of the offsets)

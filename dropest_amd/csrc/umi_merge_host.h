@@ -167,6 +167,7 @@ void dropest_ctx::umi_patch_groups(const std::vector<u32> &p_idx, const std::vec
 	reduce_cell_gene_to_cells();
 	HIP_CHECK(stream_wait(stream));
 	refresh_real_rows();
+	real_pristine = false;
 	for (auto &kv : umis_removed) real[real_at(kv.first)].row.total_umis -= kv.second;
 }
 

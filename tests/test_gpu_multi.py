@@ -789,14 +789,16 @@ def test_umi_qualities_follow_a_barcode_merge_across_shards(world, poisson):
     g.close()
 
 
-def test_c4_at_its_per_gpu_size_single_context_and_four_shards():
-    """BASELINE configs[3] ("C4": inDrop v3, split 8 + 8 bp barcode, 8 bp UMI, -m + the inDrop v3 whitelist) at the size ONE of its four GPUs
-    holds: 1.25e8 reads, 5 000 cells.  Far beyond the oracle, so (a) size-independent properties of the single context -- every read counted
-    once, targets final whitelist cells, CSC structure -- and (b) the same stream cut into four contiguous ranges on four in-process shards
-    (all on this GPU: partition by owner, all-to-all, sharded whitelist merge, device-planned cm_raw) must assemble the same two matrices,
-    column barcodes and merged barcodes, entry for entry."""
-    n, world = 125_000_000, 4
-    s = SynthStream(n_reads=n, n_cells=5000, n_genes=30000, cb_len=16, whitelist="indrop_v3", umi_len=8, stream_id=4)
+@pytest.mark.parametrize("n,cells", [(125_000_000, 5000), (500_000_000, 20000)], ids=["per_gpu_share", "whole_workload"])
+def test_c4_single_context_and_four_shards(n, cells):
+    """BASELINE configs[3] ("C4": inDrop v3, split 8 + 8 bp barcode, 8 bp UMI, -m + the inDrop v3 whitelist; configs/indrop_v3.xml:22-29) at
+    the size ONE of its four GPUs holds (1.25e8 reads, 5 000 cells) and as the WHOLE workload (5e8 reads, 20 000 cells: 12 GB of reads, which
+    one MI355X holds).  Far beyond the oracle, so (a) size-independent properties of the single context -- every read counted once, targets
+    final whitelist cells, CSC structure -- and (b) the same stream cut into four contiguous ranges on four in-process shards (all on this
+    GPU: partition by owner, all-to-all, sharded whitelist merge, device-planned cm_raw, every shard's columns widened into the shared
+    slots) must assemble the same two matrices, column barcodes and merged barcodes, entry for entry."""
+    world = 4
+    s = SynthStream(n_reads=n, n_cells=cells, n_genes=30000, cb_len=16, whitelist="indrop_v3", umi_len=8, stream_id=4)
     cfg = {"min_before": 20, "min_after": 100, "merge": {"barcodes_kind": capi.BARCODES_CONST, "barcodes_file": os.path.join(DATA, "indrop_v3")}}
     kw = cfg_kwargs(cfg)
     dev = s.generate_device(0)
