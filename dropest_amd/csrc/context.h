@@ -551,6 +551,10 @@ struct dropest_ctx {
 	// splitter sort (k_ssort.h): sample, splitters, partition scratch, look-back words
 	dropest::DevBuf<u64> ss_sample_a, ss_sample_b, ss_fine, ss_coarse;
 	dropest::DevBuf<u32> ss_base1, ss_cnt2, ss_bucket_base, ss_bucket_cnt, ss_tmp, ss_n_loc, ss_prefix, ss_chunk, ss_big_list;
+	// (sharded runs) the reads arrive in chunks -- chunk k = piece k of every source's block, ranges of the SAME read arrays; ev fires when it
+	// has landed --: the barcode table is built chunk by chunk while the later ones travel (build_cb_table; csrc/shard_run.h sets them per step)
+	struct RecvChunk { hipEvent_t ev; dropest::CbRanges rg; };
+	std::vector<RecvChunk> recv_chunks;
 	double hot_coverage = 0;            // share of the sampled reads whose barcode is on the hot list (a lower bound)
 	dropest::DevBuf<u32> ss_cg_loc, ss_cg_cnt, ss_cg_prefix;   // (cell, gene) heads per fine bucket: the compaction makes the (cell, gene) table on its way
 	bool cg_from_sort = false;                                 // this pass's (cell, gene) table came out of the splitter sort's compaction

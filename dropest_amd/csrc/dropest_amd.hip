@@ -239,12 +239,26 @@ static constexpr u32 GENE_CHR_CAP = 1u << 20;   // genes beyond this id fall bac
 void dropest_ctx::build_cb_table() {
 	const u32 n = u32(n_reads);
 	uint64_t cap = forced_table_capacity ? forced_table_capacity : cfg.cb_table_capacity;
+	// A sharded run whose reads arrive in chunks (recv_chunks: piece k of every source's block, ranges of the same arrays): whatever SAMPLES
+	// the reads looks at chunk 0, the insert pass takes the chunks one after the other as their events fire -- the later ones are still
+	// on the links meanwhile.  (A rebuilt table, forced_table_capacity, finds everything arrived: the first attempt waited for every chunk.)
+	const bool chunked = !recv_chunks.empty() && !forced_table_capacity;
+	const u32 n_chunks_in = chunked ? u32(recv_chunks.size()) : 1u;
+	if (chunked) HIP_CHECK(hipStreamWaitEvent(stream, recv_chunks[0].ev, 0));
+	uint64_t n_first = n;   // reads a sampling kernel may look at now
+	if (chunked) n_first = recv_chunks[0].rg.total();
+	// f(first read, reads) over the ranges a sampling kernel may read
+	auto over_sample_ranges = [&](auto &&f) {
+		if (!chunked) { f(u32(0), n); return; }
+		const CbRanges &rg = recv_chunks[0].rg;
+		for (u32 q = 0; q < rg.n; ++q) if (rg.cnt[q]) f(rg.off[q], rg.cnt[q]);
+	};
 	uint64_t sample_min = uint64_t(1) << 22;
 	if (const char *e = getenv("DROPEST_CB_SAMPLE_MIN")) sample_min = uint64_t(std::max(1ll, atoll(e)));   // tests: the sampled sizing and the hot list on small streams
 	if (cap == 0 && n_reads >= sample_min && !getenv("DROPEST_CB_NO_SAMPLE")) {
 		// size the table from the distinct barcodes of every 64th read: a new barcode shows up at most 64 times as often in
 		// the whole stream (too small an estimate is caught below: the table is rebuilt larger when its load passes 0.7)
-		const u32 stride = 64, n_s = div_up(n, stride);
+		const u32 stride = 64, n_s = u32(div_up(u32(std::min<uint64_t>(n_first, n)), stride)) + (chunked ? 64u : 0u);   // (chunked: every range rounds up)
 		uint64_t cap_s = 1024; while (cap_s < uint64_t(n_s) * 2) cap_s <<= 1;
 		t_slots.ensure(cap_s); scalars.ensure(4 + CB_HOT_LEVELS + 4);
 		CbTable ts{t_slots.p, cap_s - 1};
@@ -252,7 +266,9 @@ void dropest_ctx::build_cb_table() {
 		HIP_CHECK(hipMemsetAsync(scalars.p, 0, 4, stream));
 		timed("cb_sample", double(n_s) * 8, [&] {
 			static const u32 count_every = [] { const char *e = getenv("DROPEST_CB_SAMPLE_COUNT_EVERY"); return e && atoi(e) >= 1 ? u32(atoi(e)) : 4u; }();
-			hipLaunchKernelGGL(cb_sample_distinct_kernel, dim3(std::min<u32>(div_up(n_s, 256), 2048u)), dim3(256), 0, stream, d_cb, n, stride, ts, scalars.p, rpack, count_every);
+			over_sample_ranges([&](u32 off, u32 cnt) {
+				hipLaunchKernelGGL(cb_sample_distinct_kernel, dim3(std::min<u32>(div_up(div_up(cnt, stride), 256), 2048u)), dim3(256), 0, stream, d_cb + off, cnt, stride, ts, scalars.p, rpack, count_every);
+			});
 		});
 		// ... and how many of the sampled barcodes reach 4, 16, ... sample hits: the hot list is the largest such set of at
 		// most CB_HOT_MAX barcodes (C2: the 5 000 real cells carry 92 % of the reads)
@@ -267,7 +283,8 @@ void dropest_ctx::build_cb_table() {
 			for (int l = 0; l < CB_HOT_LEVELS; ++l) fprintf(stderr, " %u:%u", cb_hot_threshold(l), head[4 + l]);
 			fprintf(stderr, "\n");
 		}
-		const uint64_t est = std::min<uint64_t>(n_reads, uint64_t(distinct) * stride);
+		// (sampled from the first chunk only: scaled to the whole stream)
+		const uint64_t est = std::min<uint64_t>(n_reads, uint64_t(double(distinct) * stride * (double(n) / double(std::max<uint64_t>(1, n_first)))));
 		cap = 1024; while (cap < est + est / 2) cap <<= 1;   // load <= 0.67 even when the estimate is exact
 		n_hot = 0; hot_coverage = 0;
 		if (want_hot && cap < (1ull << 31)) {
@@ -306,7 +323,9 @@ void dropest_ctx::build_cb_table() {
 		if (n >= (1u << 20) || lazy_stats) {   // the popular genes' entries are set before the big pass starts (k_cbhash.h)
 			const u32 stride = 2048, n_s = div_up(n, stride);
 			timed("gene_chr_seed", double(n_s) * 8, [&] {
-				hipLaunchKernelGGL(gene_chr_seed_kernel, dim3(std::min<u32>(div_up(n_s, 256), 64u)), dim3(256), 0, stream, d_gene, d_aux, n, stride, gene_chr.p, GENE_CHR_CAP, d_ingest.p, rpack);
+				over_sample_ranges([&](u32 off, u32 cnt) {
+					hipLaunchKernelGGL(gene_chr_seed_kernel, dim3(std::min<u32>(div_up(div_up(cnt, stride), 256), 64u)), dim3(256), 0, stream, d_gene + off, d_aux + off, cnt, stride, gene_chr.p, GENE_CHR_CAP, d_ingest.p, rpack);
+				});
 			});
 		}
 		const bool vec = ((uintptr_t(d_cb) | uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;   // adopted arrays may sit anywhere
@@ -314,7 +333,10 @@ void dropest_ctx::build_cb_table() {
 		const u32 blocks = std::min<u32>(div_up(n, 256 * 4), vec ? grid_v : grid_s);
 		if (lazy_stats)   // the plan's statistics: every 256th read (the exact ones come with build_keys)
 			timed("ingest_sample_stats", double(div_up(n, 256u)) * 16, [&] {
-				hipLaunchKernelGGL(ingest_sample_stats_kernel, dim3(std::min<u32>(div_up(div_up(n, 256u), 256), 1024u)), dim3(256), 0, stream, d_umi, d_gene, d_aux, n, 256u, d_ingest.p, rpack);
+				const u32 every = std::max<u32>(1u, 256u / n_chunks_in);   // (from the first chunk only: as many reads as every 256th of all)
+				over_sample_ranges([&](u32 off, u32 cnt) {
+					hipLaunchKernelGGL(ingest_sample_stats_kernel, dim3(std::min<u32>(div_up(div_up(cnt, every), 256), 1024u)), dim3(256), 0, stream, d_umi + off, d_gene + off, d_aux + off, cnt, every, d_ingest.p, rpack);
+				});
 			});
 		if (n_hot && attempt == 0 && cap < (1ull << 31)) {
 			// the hot list needs 128 KB of dynamic LDS in one workgroup: a device (or partition mode) that does not grant it takes the
@@ -338,7 +360,10 @@ void dropest_ctx::build_cb_table() {
 			timed("cb_insert", double(n) * (lazy_stats ? 8 + 4 : 8 + 8 + 4 + 4 + 4), [&] {
 				auto go = [&](auto kernel) {
 					HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-					hipLaunchKernelGGL(kernel, dim3(hb), dim3(1024), lds, stream, d_cb, d_umi, d_gene, d_aux, n, table, hot, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p, rpack);
+					for (u32 k = 0; k < n_chunks_in; ++k) {   // (one launch, or one per chunk of a chunked exchange as its reads land)
+						if (chunked && k) HIP_CHECK(hipStreamWaitEvent(stream, recv_chunks[k].ev, 0));
+						hipLaunchKernelGGL(kernel, dim3(hb), dim3(1024), lds, stream, d_cb, d_umi, d_gene, d_aux, chunked ? recv_chunks[k].rg : CbRanges::whole(n), table, hot, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p, rpack);
+					}
 				};
 				if (lazy_stats) { if (vec) go(cb_insert_hot_kernel<true, false>); else go(cb_insert_hot_kernel<false, false>); }
 				else if (vec) go(cb_insert_hot_kernel<true>); else go(cb_insert_hot_kernel<false>);
@@ -350,7 +375,7 @@ void dropest_ctx::build_cb_table() {
 				keys_a.ensure(n);
 				auto again = [&](const char *name, auto kernel) {
 					HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
-					timed(name, double(n) * 12, [&] { hipLaunchKernelGGL(kernel, dim3(hb), dim3(1024), lds, stream, d_cb, d_umi, d_gene, d_aux, n, table, hot, reinterpret_cast<u32 *>(keys_a.p), gene_chr.p, GENE_CHR_CAP, d_ingest.p); });
+					timed(name, double(n) * 12, [&] { hipLaunchKernelGGL(kernel, dim3(hb), dim3(1024), lds, stream, d_cb, d_umi, d_gene, d_aux, CbRanges::whole(n), table, hot, reinterpret_cast<u32 *>(keys_a.p), gene_chr.p, GENE_CHR_CAP, d_ingest.p); });
 				};
 				again("cbi:again", cb_insert_hot_kernel<true, false, 0>);
 				again("cbi:no_probe", cb_insert_hot_kernel<true, false, 1>);
@@ -363,7 +388,13 @@ void dropest_ctx::build_cb_table() {
 		} else {
 		n_hot = 0;   // (a rebuilt table: the slots of the first attempt are gone)
 		timed("cb_insert", double(n) * (lazy_stats ? 8 + 4 : 8 + 8 + 4 + 4 + 4), [&] {
-			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, n, table, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p, rpack); };
+			auto go = [&](auto kernel) {
+				const bool by_chunk = chunked && attempt == 0;
+				for (u32 k = 0; k < (by_chunk ? n_chunks_in : 1u); ++k) {
+					if (by_chunk && k) HIP_CHECK(hipStreamWaitEvent(stream, recv_chunks[k].ev, 0));
+					hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, stream, d_cb, d_umi, d_gene, d_aux, by_chunk ? recv_chunks[k].rg : CbRanges::whole(n), table, slot.p, gene_chr.p, GENE_CHR_CAP, d_ingest.p, rpack);
+				}
+			};
 			if (lazy_stats) { if (vec) go(cb_insert_kernel<256, true, false>); else go(cb_insert_kernel<256, false, false>); }
 			else if (vec) go(cb_insert_kernel<256, true>); else go(cb_insert_kernel<256, false>);
 		});

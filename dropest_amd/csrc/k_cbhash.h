@@ -194,22 +194,68 @@ __global__ __launch_bounds__(256) void ingest_sample_stats_kernel(const unsigned
 	}
 }
 
+// The ranges of the read arrays one launch covers.  One range = the whole stream (a plain context).  A sharded run that receives its reads in
+// chunks (csrc/shard_run.h: the all-to-all overlapped with the table build) hands the kernels chunk c of every source's block: ranges of
+// the SAME arrays, so a read's index stays its first-seen ordinal.
+struct CbRanges {
+	uint32_t n = 0;
+	uint32_t off[64], cnt[64];
+	static CbRanges whole(uint32_t n_reads) { CbRanges r; r.n = 1; r.off[0] = 0; r.cnt[0] = n_reads; return r; }
+	__host__ __device__ uint64_t total() const { uint64_t t = 0; for (uint32_t q = 0; q < n; ++q) t += cnt[q]; return t; }
+};
+// per-thread accumulators of the insert kernels (statistics + flags), committed once per launch
+struct CbInsertAcc {
+	unsigned long long umin = ~0ull, umax = 0ull, uesc = 0ull, cbesc = 0ull;
+	uint32_t gmax = 0, cmax = 0;
+	bool ok = true, chr_conflict = false;
+	__device__ inline void commit(IngestStats *stats) {
+		umin = wave_reduce_min_u64(umin); umax = wave_reduce_max_u64(umax); uesc = wave_reduce_max_u64(uesc);
+		cbesc = wave_reduce_add_u64(cbesc);
+		const unsigned long long g64 = wave_reduce_max_u64(gmax), c64 = wave_reduce_max_u64(cmax);
+		const unsigned long long conf = wave_reduce_max_u64(chr_conflict ? 1ull : 0ull), bad = wave_reduce_max_u64(ok ? 0ull : 1ull);
+		if (lane_id() == 0) {
+			if (umin != ~0ull) atomicMin(&stats->umi_clean_min, umin);
+			if (umax != 0ull) atomicMax(&stats->umi_clean_max, umax);
+			if (uesc) atomicMax(&stats->umi_escape_max_plus1, uesc);
+			if (cbesc) atomicAdd(&stats->cb_escape_count, cbesc);
+			if (g64) atomicMax(&stats->gene_max_plus1, uint32_t(g64));
+			if (bad) atomicMax(&stats->overflow, 1u);
+			if (c64) atomicMax(&stats->chr_max_plus1, uint32_t(c64));
+			if (conf) atomicMax(&stats->gene_chr_conflict, 1u);
+		}
+	}
+	// the part of a read's (umi, gene, aux) that sizes the sort key and decides whether the chromosome is a function of the gene
+	__device__ inline void add_read(unsigned long long u, uint32_t g, uint32_t a, uint32_t *__restrict__ gene_chr, uint32_t gene_chr_cap) {
+		if (u & ESCAPE_BIT) { const unsigned long long id1 = (u & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
+		else { umin = u < umin ? u : umin; umax = u > umax ? u : umax; }
+		if (g != NO_GENE && g + 1 > gmax) gmax = g + 1;
+		// Is the chromosome a function of the gene?  (Only reads that are counted per chromosome matter: gene-less reads and reads with an
+		// exon / intron mark, CellsDataContainer.cpp:73-78, :312-321.)
+		const uint32_t chr = a & 0xFFFFu, mark = (a >> 16) & 0xFFu;
+		if (g == NO_GENE) { if (chr + 1 > cmax) cmax = chr + 1; }
+		else if (mark & 6u) {
+			if (chr + 1 > cmax) cmax = chr + 1;
+			if (g >= gene_chr_cap) chr_conflict = true;
+			else {
+				uint32_t cur2 = gene_chr[g];            // L1/L2-hot table; the CAS runs once per gene
+				if (cur2 == GENE_CHR_UNSET) cur2 = atomicCAS(&gene_chr[g], GENE_CHR_UNSET, chr), cur2 = cur2 == GENE_CHR_UNSET ? chr : cur2;
+				if (cur2 != chr) chr_conflict = true;
+			}
+		}
+	}
+};
+
 // One pass over (cb, umi, gene): table insert + first ordinal + ingest statistics.  Each thread takes FOUR CONSECUTIVE
 // reads per iteration: with 16-byte-aligned arrays (VEC) every streaming access is a 16-byte load / store per lane (two
 // barcodes, two UMIs, four gene ids, four aux words, four slot indices) -- with one read per lane the 4- and 8-byte
 // accesses left the kernel at 1.4 TB/s whatever else it did (the table probes cost nothing: measured with the probe
 // switched off) -- and the four table probes are independent 16-byte loads in flight together.
-template <int THREADS, bool VEC, bool STATS = true>
-__global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long long *__restrict__ cb,
-                                                            const unsigned long long *__restrict__ umi,
-                                                            const uint32_t *__restrict__ gene,
-                                                            const uint32_t *__restrict__ aux, uint32_t n, CbTable t,
-                                                            uint32_t *__restrict__ slot_out, uint32_t *__restrict__ gene_chr,
-                                                            uint32_t gene_chr_cap, IngestStats *stats, ReadPack pk = ReadPack{}) {
+// One range of reads: the arrays point at the range's first read, whose first-seen ordinal is ord_base.
+template <int THREADS, bool VEC, bool STATS>
+__device__ inline void cb_insert_range(const unsigned long long *__restrict__ cb, const unsigned long long *__restrict__ umi,
+                                       const uint32_t *__restrict__ gene, const uint32_t *__restrict__ aux, uint32_t n, uint32_t ord_base, const CbTable &t,
+                                       uint32_t *__restrict__ slot_out, uint32_t *__restrict__ gene_chr, uint32_t gene_chr_cap, const ReadPack &pk, CbInsertAcc &acc) {
 	constexpr int ILP = 4;
-	unsigned long long umin = ~0ull, umax = 0ull, uesc = 0ull, cbesc = 0ull;
-	uint32_t gmax = 0, cmax = 0;
-	bool ok = true, chr_conflict = false;
 	const uint64_t stride = uint64_t(gridDim.x) * THREADS * ILP;
 	for (uint64_t r0 = (uint64_t(blockIdx.x) * THREADS + threadIdx.x) * ILP; r0 < n; r0 += stride) {
 		unsigned long long k[ILP], u[ILP];
@@ -266,37 +312,17 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 				else pending |= 1u << j;
 			}
 		}
-		if (pending) cb_resolve_together<ILP>(t, k, h, seen, pending, sl, ok);
+		if (pending) cb_resolve_together<ILP>(t, k, h, seen, pending, sl, acc.ok);
 #pragma unroll
 		for (int j = 0; j < ILP; ++j) {
 			const uint64_t r = r0 + j;
 			if (r >= n) continue;
-			const uint32_t s = sl[j];
+			const uint32_t s = sl[j], ord = ord_base + uint32_t(r);
 			// stale (too large) hints only cost an extra atomic; ordinals only ever decrease
 			const uint32_t first_hint = ((hinted >> j) & 1u) ? ~v[j].z : 0xFFFFFFFFu;
-			if (uint32_t(r) < first_hint) atomicMax(&t.slots[s].nfirst, ~uint32_t(r));
-			if (STATS) {
-				if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
-				else { umin = u[j] < umin ? u[j] : umin; umax = u[j] > umax ? u[j] : umax; }
-			}
-			if (k[j] & ESCAPE_BIT) ++cbesc;
-			if (STATS) {
-				if (g[j] != NO_GENE && g[j] + 1 > gmax) gmax = g[j] + 1;
-				// Is the chromosome a function of the gene?  (Only reads that are counted per chromosome matter:
-				// gene-less reads and reads with an exon / intron mark, CellsDataContainer.cpp:73-78, :312-321.)
-				const uint32_t chr = a[j] & 0xFFFFu, mark = (a[j] >> 16) & 0xFFu;
-				if (g[j] == NO_GENE) { if (chr + 1 > cmax) cmax = chr + 1; }
-				else if (mark & 6u) {
-					if (chr + 1 > cmax) cmax = chr + 1;
-					if (g[j] >= gene_chr_cap) chr_conflict = true;
-					else {
-						uint32_t cur2 = gene_chr[g[j]];            // L1/L2-hot table; the CAS runs once per gene
-						if (cur2 == GENE_CHR_UNSET) cur2 = atomicCAS(&gene_chr[g[j]], GENE_CHR_UNSET, chr), cur2 = cur2 == GENE_CHR_UNSET ? chr : cur2;
-						if (cur2 != chr) chr_conflict = true;
-					}
-				}
-		
-			}
+			if (ord < first_hint) atomicMax(&t.slots[s].nfirst, ~ord);
+			if (k[j] & ESCAPE_BIT) ++acc.cbesc;
+			if (STATS) acc.add_read(u[j], g[j], a[j], gene_chr, gene_chr_cap);
 		}
 		if (VEC && full) stream_store_u32x4(slot_out + r0, sl[0], sl[1], sl[2], sl[3]);
 		else {
@@ -304,22 +330,24 @@ __global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long 
 			for (int j = 0; j < ILP; ++j) if (r0 + j < n) slot_out[r0 + j] = sl[j];
 		}
 	}
-	umin = wave_reduce_min_u64(umin); umax = wave_reduce_max_u64(umax); uesc = wave_reduce_max_u64(uesc);
-	cbesc = wave_reduce_add_u64(cbesc);
-	unsigned long long g64 = wave_reduce_max_u64(gmax);
-	unsigned long long c64 = wave_reduce_max_u64(cmax);
-	unsigned long long conf = wave_reduce_max_u64(chr_conflict ? 1ull : 0ull);
-	unsigned long long bad = wave_reduce_max_u64(ok ? 0ull : 1ull);
-	if (lane_id() == 0) {
-		if (umin != ~0ull) atomicMin(&stats->umi_clean_min, umin);
-		if (umax != 0ull) atomicMax(&stats->umi_clean_max, umax);
-		if (uesc) atomicMax(&stats->umi_escape_max_plus1, uesc);
-		if (cbesc) atomicAdd(&stats->cb_escape_count, cbesc);
-		if (g64) atomicMax(&stats->gene_max_plus1, uint32_t(g64));
-		if (bad) atomicMax(&stats->overflow, 1u);
-		if (c64) atomicMax(&stats->chr_max_plus1, uint32_t(c64));
-		if (conf) atomicMax(&stats->gene_chr_conflict, 1u);
+}
+template <int THREADS, bool VEC, bool STATS = true>
+__global__ __launch_bounds__(THREADS) void cb_insert_kernel(const unsigned long long *__restrict__ cb,
+                                                            const unsigned long long *__restrict__ umi,
+                                                            const uint32_t *__restrict__ gene,
+                                                            const uint32_t *__restrict__ aux, CbRanges rg, CbTable t,
+                                                            uint32_t *__restrict__ slot_out, uint32_t *__restrict__ gene_chr,
+                                                            uint32_t gene_chr_cap, IngestStats *stats, ReadPack pk = ReadPack{}) {
+	CbInsertAcc acc;
+	for (uint32_t q = 0; q < rg.n; ++q) {
+		// (a range need not start on a 16-byte boundary of the arrays: its first reads up to one take the scalar accesses)
+		uint32_t o = rg.off[q], cnt = rg.cnt[q];
+		const uint32_t head = VEC ? (cnt < ((4u - (o & 3u)) & 3u) ? cnt : ((4u - (o & 3u)) & 3u)) : cnt;
+		if (head) cb_insert_range<THREADS, false, STATS>(cb + o, umi + o, gene + o, aux + o, head, o, t, slot_out + o, gene_chr, gene_chr_cap, pk, acc);
+		o += head; cnt -= head;
+		if (VEC && cnt) cb_insert_range<THREADS, true, STATS>(cb + o, umi + o, gene + o, aux + o, cnt, o, t, slot_out + o, gene_chr, gene_chr_cap, pk, acc);
 	}
+	acc.commit(stats);
 }
 
 // The gene -> chromosome table seeded from every `stride`-th read (same protocol as cb_insert's own check).  A gene's entry
@@ -432,34 +460,15 @@ __global__ __launch_bounds__(256) void cb_hot_preinsert_kernel(const unsigned lo
 struct CbHot { const unsigned long long *key; const uint32_t *slot; uint32_t n; };
 // EXP (timing probes, results not usable; launched only by builds with -DDROPEST_CBI_PROBE, see dropest_ctx::build_cb_table):
 // 1 no table probe, 2 no LDS look-up, 4 no atomics
-template <bool VEC, bool STATS = true, int EXP = 0>
-__global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long long *__restrict__ cb,
-                                                             const unsigned long long *__restrict__ umi,
-                                                             const uint32_t *__restrict__ gene,
-                                                             const uint32_t *__restrict__ aux, uint32_t n, CbTable t, CbHot hot,
-                                                             uint32_t *__restrict__ slot_out, uint32_t *__restrict__ gene_chr,
-                                                             uint32_t gene_chr_cap, IngestStats *stats, ReadPack pk = ReadPack{}) {
+struct CbHotLds { unsigned long long *lk; uint32_t *li, *lf; };   // [CB_HOT_LDS] key (0 = empty), hot index, smallest ordinal seen by this workgroup
+// one range of reads (see cb_insert_range): the LDS table is built once per launch, the ranges share it
+template <bool VEC, bool STATS, int EXP>
+__device__ inline void cb_insert_hot_range(const unsigned long long *__restrict__ cb, const unsigned long long *__restrict__ umi,
+                                           const uint32_t *__restrict__ gene, const uint32_t *__restrict__ aux, uint32_t n, uint32_t ord_base, const CbTable &t,
+                                           const CbHot &hot, const CbHotLds &L, uint32_t *__restrict__ slot_out, uint32_t *__restrict__ gene_chr,
+                                           uint32_t gene_chr_cap, const ReadPack &pk, CbInsertAcc &acc) {
 	constexpr int ILP = 4, THREADS = 1024;
-	extern __shared__ __attribute__((aligned(16))) unsigned char cb_smem[];
-	unsigned long long *lk = reinterpret_cast<unsigned long long *>(cb_smem);          // [CB_HOT_LDS] key, 0 = empty
-	uint32_t *li = reinterpret_cast<uint32_t *>(lk + CB_HOT_LDS);                        // [CB_HOT_LDS] hot index
-	uint32_t *lf = li + CB_HOT_LDS;                                                      // [CB_HOT_LDS] smallest ordinal seen here
-	for (uint32_t j = threadIdx.x; j < CB_HOT_LDS; j += THREADS) { lk[j] = 0ull; lf[j] = 0xFFFFFFFFu; }
-	__syncthreads();
-	for (uint32_t j = threadIdx.x; j < hot.n; j += THREADS) {
-		const unsigned long long k = hot.key[j];
-		uint32_t i = uint32_t(mix64(k) >> 40) & (CB_HOT_LDS - 1);
-		for (;;) {
-			const unsigned long long prev = atomicCAS(&lk[i], 0ull, k);
-			if (prev == 0ull) { li[i] = j; break; }
-			i = (i + 1) & (CB_HOT_LDS - 1);   // (hot keys are distinct: no equal key to find)
-		}
-	}
-	__syncthreads();
-
-	unsigned long long umin = ~0ull, umax = 0ull, uesc = 0ull, cbesc = 0ull;
-	uint32_t gmax = 0, cmax = 0;
-	bool ok = true, chr_conflict = false;
+	unsigned long long *lk = L.lk; uint32_t *li = L.li, *lf = L.lf;
 	const uint64_t stride = uint64_t(gridDim.x) * THREADS * ILP;
 	// the barcodes of the NEXT tile are in flight while this one is worked on (4 waves per SIMD do not hide the load by themselves)
 	auto load_cb = [&](uint64_t r0, unsigned long long (&kk)[ILP]) {
@@ -537,42 +546,25 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 				else pending |= 1u << j;
 			}
 		}
-		if (pending) cb_resolve_together<ILP>(t, k, h, seen, pending, sl, ok);
+		if (pending) cb_resolve_together<ILP>(t, k, h, seen, pending, sl, acc.ok);
 #pragma unroll
 		for (int j = 0; j < ILP; ++j) {
 			const uint64_t r = r0 + j;
 			if (r >= n) continue;
+			const uint32_t ord = ord_base + uint32_t(r);
 			if (hit[j] != 0xFFFFFFFFu) {
 				const uint32_t e = hit[j], hi = li[e];
 				sl[j] = CB_HOT_FLAG | hi;
-				if (!(EXP & 4) && uint32_t(r) < lf[e]) {
-					const uint32_t old = atomicMin(&lf[e], uint32_t(r));
-					if (uint32_t(r) < old) atomicMax(&t.slots[hot.slot[hi]].nfirst, ~uint32_t(r));
+				if (!(EXP & 4) && ord < lf[e]) {
+					const uint32_t old = atomicMin(&lf[e], ord);
+					if (ord < old) atomicMax(&t.slots[hot.slot[hi]].nfirst, ~ord);
 				}
 			} else {
 				const uint32_t first_hint = ((hinted >> j) & 1u) ? ~v[j].z : 0xFFFFFFFFu;
-				if (!(EXP & 5) && uint32_t(r) < first_hint) atomicMax(&t.slots[sl[j]].nfirst, ~uint32_t(r));
+				if (!(EXP & 5) && ord < first_hint) atomicMax(&t.slots[sl[j]].nfirst, ~ord);
 			}
-			if (STATS) {
-				if (u[j] & ESCAPE_BIT) { unsigned long long id1 = (u[j] & ~ESCAPE_BIT) + 1; uesc = id1 > uesc ? id1 : uesc; }
-				else { umin = u[j] < umin ? u[j] : umin; umax = u[j] > umax ? u[j] : umax; }
-			}
-			if (k[j] & ESCAPE_BIT) ++cbesc;
-			if (STATS) {
-				if (g[j] != NO_GENE && g[j] + 1 > gmax) gmax = g[j] + 1;
-				const uint32_t chr = a[j] & 0xFFFFu, mark = (a[j] >> 16) & 0xFFu;
-				if (g[j] == NO_GENE) { if (chr + 1 > cmax) cmax = chr + 1; }
-				else if (mark & 6u) {
-					if (chr + 1 > cmax) cmax = chr + 1;
-					if (g[j] >= gene_chr_cap) chr_conflict = true;
-					else {
-						uint32_t cur2 = gene_chr[g[j]];
-						if (cur2 == GENE_CHR_UNSET) cur2 = atomicCAS(&gene_chr[g[j]], GENE_CHR_UNSET, chr), cur2 = cur2 == GENE_CHR_UNSET ? chr : cur2;
-						if (cur2 != chr) chr_conflict = true;
-					}
-				}
-		
-			}
+			if (k[j] & ESCAPE_BIT) ++acc.cbesc;
+			if (STATS) acc.add_read(u[j], g[j], a[j], gene_chr, gene_chr_cap);
 		}
 		if (VEC && full) stream_store_u32x4(slot_out + r0, sl[0], sl[1], sl[2], sl[3]);
 		else {
@@ -580,22 +572,41 @@ __global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long
 			for (int j = 0; j < ILP; ++j) if (r0 + j < n) slot_out[r0 + j] = sl[j];
 		}
 	}
-	umin = wave_reduce_min_u64(umin); umax = wave_reduce_max_u64(umax); uesc = wave_reduce_max_u64(uesc);
-	cbesc = wave_reduce_add_u64(cbesc);
-	unsigned long long g64 = wave_reduce_max_u64(gmax);
-	unsigned long long c64 = wave_reduce_max_u64(cmax);
-	unsigned long long conf = wave_reduce_max_u64(chr_conflict ? 1ull : 0ull);
-	unsigned long long bad = wave_reduce_max_u64(ok ? 0ull : 1ull);
-	if (lane_id() == 0) {
-		if (umin != ~0ull) atomicMin(&stats->umi_clean_min, umin);
-		if (umax != 0ull) atomicMax(&stats->umi_clean_max, umax);
-		if (uesc) atomicMax(&stats->umi_escape_max_plus1, uesc);
-		if (cbesc) atomicAdd(&stats->cb_escape_count, cbesc);
-		if (g64) atomicMax(&stats->gene_max_plus1, uint32_t(g64));
-		if (bad) atomicMax(&stats->overflow, 1u);
-		if (c64) atomicMax(&stats->chr_max_plus1, uint32_t(c64));
-		if (conf) atomicMax(&stats->gene_chr_conflict, 1u);
+}
+template <bool VEC, bool STATS = true, int EXP = 0>
+__global__ __launch_bounds__(1024) void cb_insert_hot_kernel(const unsigned long long *__restrict__ cb,
+                                                             const unsigned long long *__restrict__ umi,
+                                                             const uint32_t *__restrict__ gene,
+                                                             const uint32_t *__restrict__ aux, CbRanges rg, CbTable t, CbHot hot,
+                                                             uint32_t *__restrict__ slot_out, uint32_t *__restrict__ gene_chr,
+                                                             uint32_t gene_chr_cap, IngestStats *stats, ReadPack pk = ReadPack{}) {
+	constexpr int THREADS = 1024;
+	extern __shared__ __attribute__((aligned(16))) unsigned char cb_smem[];
+	CbHotLds L;
+	L.lk = reinterpret_cast<unsigned long long *>(cb_smem);
+	L.li = reinterpret_cast<uint32_t *>(L.lk + CB_HOT_LDS);
+	L.lf = L.li + CB_HOT_LDS;
+	for (uint32_t j = threadIdx.x; j < CB_HOT_LDS; j += THREADS) { L.lk[j] = 0ull; L.lf[j] = 0xFFFFFFFFu; }
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < hot.n; j += THREADS) {
+		const unsigned long long k = hot.key[j];
+		uint32_t i = uint32_t(mix64(k) >> 40) & (CB_HOT_LDS - 1);
+		for (;;) {
+			const unsigned long long prev = atomicCAS(&L.lk[i], 0ull, k);
+			if (prev == 0ull) { L.li[i] = j; break; }
+			i = (i + 1) & (CB_HOT_LDS - 1);   // (hot keys are distinct: no equal key to find)
+		}
 	}
+	__syncthreads();
+	CbInsertAcc acc;
+	for (uint32_t q = 0; q < rg.n; ++q) {
+		uint32_t o = rg.off[q], cnt = rg.cnt[q];
+		const uint32_t head = VEC ? (cnt < ((4u - (o & 3u)) & 3u) ? cnt : ((4u - (o & 3u)) & 3u)) : cnt;
+		if (head) cb_insert_hot_range<false, STATS, EXP>(cb + o, umi + o, gene + o, aux + o, head, o, t, hot, L, slot_out + o, gene_chr, gene_chr_cap, pk, acc);
+		o += head; cnt -= head;
+		if (VEC && cnt) cb_insert_hot_range<true, STATS, EXP>(cb + o, umi + o, gene + o, aux + o, cnt, o, t, hot, L, slot_out + o, gene_chr, gene_chr_cap, pk, acc);
+	}
+	acc.commit(stats);
 }
 
 // ---- cell ids from the table alone ---------------------------------------------------------------------------

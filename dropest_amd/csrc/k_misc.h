@@ -631,6 +631,18 @@ __global__ __launch_bounds__(OP_T) void owner_hist_stats_kernel(const unsigned l
 	if (threadIdx.x < 256) hist[threadIdx.x * gridDim.x + blockIdx.x] = h[threadIdx.x];
 }
 
+// reads of every owner inside every chunk of blocks (bounds[0 .. chunks]: first block of each chunk): out[p * chunks + k], from the scanned
+// per-block histogram (hist[p * nblocks + b] = reads of owner p before block b) and the owners' totals
+__global__ __launch_bounds__(256) void owner_chunk_counts_kernel(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ row_total, uint32_t nblocks,
+                                                                 uint32_t n_parts, uint32_t chunks, const uint32_t *__restrict__ bounds, uint32_t *__restrict__ out) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_parts * chunks) return;
+	const uint32_t p = i / chunks, k = i % chunks;
+	const uint32_t lo = bounds[k], hi = bounds[k + 1];
+	const uint32_t before_lo = lo < nblocks ? hist[size_t(p) * nblocks + lo] : row_total[p], before_hi = hi < nblocks ? hist[size_t(p) * nblocks + hi] : row_total[p];
+	out[i] = before_hi - before_lo;
+}
+
 // A read packed for the exchange: w0 = barcode code | UMI code << cb_bits (64 bits), w1 = gene | mark << gene_bits | chromosome
 // << (gene_bits + 3) (32 bits; "no gene" = all ones of the gene field) -- 12 bytes where the five arrays are 28.
 struct ExchangePack { int cb_bits, gene_bits; };
@@ -673,12 +685,15 @@ __global__ __launch_bounds__(OP_T) void owner_scatter_kernel(const unsigned long
                                                              const uint32_t *__restrict__ hist, const uint32_t *__restrict__ owner_base,
                                                              unsigned long long *__restrict__ o_cb, unsigned long long *__restrict__ o_umi,
                                                              uint32_t *__restrict__ o_gene, uint32_t *__restrict__ o_aux, uint32_t *__restrict__ o_idx,
-                                                             ExchangePack pack, OwnerSelf self = OwnerSelf{}) {
+                                                             ExchangePack pack, OwnerSelf self = OwnerSelf{}, uint32_t block0 = 0, uint32_t blocks_total = 0) {
+	// block0 / blocks_total: the launch covers blocks [block0, block0 + gridDim.x) of a partition of blocks_total blocks (0: all of them) --
+	// a sharded run sends the blocks of an owner in chunks as soon as they are written (csrc/shard_run.h)
 	constexpr uint32_t WAVES = OP_T / 64;
 	__shared__ uint32_t wcnt[WAVES][256], goff[256], tcnt[256];
 	const uint32_t tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-	if (tid < 256) goff[tid] = owner_base[tid] + hist[tid * gridDim.x + blockIdx.x];
-	const uint32_t n_tiles = (n + OP_TILE - 1) / OP_TILE, first_tile = blockIdx.x * tiles_per_block;
+	const uint32_t blk = block0 + blockIdx.x, nblk = blocks_total ? blocks_total : gridDim.x;
+	if (tid < 256) goff[tid] = owner_base[tid] + hist[tid * nblk + blk];
+	const uint32_t n_tiles = (n + OP_TILE - 1) / OP_TILE, first_tile = blk * tiles_per_block;
 	const uint32_t lane_off = w * (64 * OP_I) + lane;
 	const OwnerMod owner_of(n_parts);
 	for (uint32_t tt = 0; tt < tiles_per_block; ++tt) {

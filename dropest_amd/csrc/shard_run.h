@@ -90,6 +90,11 @@ struct Transport {
 	// in_place: bit a set = the block of array a that stays on this shard is NOT copied (the caller reads it in d_send[a])
 	virtual void exchange(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_cnt,
 	                      const uint64_t *recv_cnt, hipStream_t st, uint32_t in_place = 0) = 0;
+	// One chunk of such an all-to-all(v): the piece for peer p starts at element send_off[p] of d_send[a] (send_cnt[p] elements) and lands at
+	// element recv_off[p] of d_recv[a] (recv_cnt[p] elements).  Enqueued on `st` and NOT waited for where the transport can (RCCL): the
+	// caller orders its consumers with an event on `st` -- the next chunk is partitioned, the previous one hashed, while this one travels.
+	virtual void exchange_at(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_off, const uint64_t *send_cnt,
+	                         const uint64_t *recv_off, const uint64_t *recv_cnt, hipStream_t st, uint32_t in_place = 0) = 0;
 	virtual void gather_host(const void *mine, size_t bytes, void *all) = 0;   // all: world x bytes, rank order
 	// every shard's device block to every shard: block of rank p = bytes[p] at d_all + off[p]
 	virtual void gather_dev(const void *d_mine, void *d_all, const size_t *off, const size_t *bytes, hipStream_t st) = 0;
@@ -176,6 +181,24 @@ struct LocalTransport : Transport {
 					HIP_CHECK(hipMemcpyAsync(static_cast<char *>(d_recv[a]) + roff * elem[a], static_cast<const char *>(src->d_send[a]) + soff * elem[a],
 					                         size_t(recv_cnt[p]) * elem[a], hipMemcpyDefault, st));
 			roff += recv_cnt[p];
+		}
+		HIP_CHECK(stream_wait(st));
+		hub->barrier();   // the senders' buffers may be reused
+	}
+	struct PubAt { const void *const *d_send; const size_t *elem; const uint64_t *send_off, *send_cnt; };
+	void exchange_at(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_off, const uint64_t *send_cnt,
+	                 const uint64_t *recv_off, const uint64_t *recv_cnt, hipStream_t st, uint32_t in_place = 0) override {
+		HIP_CHECK(stream_wait(st));   // the pieces the peers copy were written before this point of `st`
+		PubAt pub{d_send, elem, send_off, send_cnt};
+		hub->p0[size_t(rank)] = &pub;
+		hub->barrier();
+		for (int p = 0; p < world; ++p) {
+			const PubAt *src = static_cast<const PubAt *>(hub->p0[size_t(p)]);
+			if (src->send_cnt[rank] != recv_cnt[p]) throw DeviceError("chunked exchange: a peer's piece differs from the agreed size");
+			for (int a = 0; a < n_arrays; ++a)
+				if (recv_cnt[p] && !(p == rank && (in_place >> a & 1u)))
+					HIP_CHECK(hipMemcpyAsync(static_cast<char *>(d_recv[a]) + recv_off[p] * elem[a], static_cast<const char *>(src->d_send[a]) + src->send_off[rank] * elem[a],
+					                         size_t(recv_cnt[p]) * elem[a], hipMemcpyDefault, st));
 		}
 		HIP_CHECK(stream_wait(st));
 		hub->barrier();   // the senders' buffers may be reused
@@ -468,6 +491,58 @@ struct RcclTransport : Transport {
 		api.check(api.GroupEnd(), "ncclGroupEnd");
 		// (no wait here: whatever reads the received blocks is queued behind them on this stream -- cb_sample, cb_insert --, and the send
 		// buffers are not rewritten before the next pass's partition, on this stream too)
+	}
+	void exchange_at(int n_arrays, const void *const *d_send, void *const *d_recv, const size_t *elem, const uint64_t *send_off, const uint64_t *send_cnt,
+	                 const uint64_t *recv_off, const uint64_t *recv_cnt, hipStream_t st, uint32_t in_place = 0) override {
+		for (int a = 0; a < n_arrays; ++a)   // the piece a shard keeps never leaves the device
+			if (send_cnt[rank] && !(in_place >> a & 1u))
+				HIP_CHECK(hipMemcpyAsync(static_cast<char *>(d_recv[a]) + recv_off[rank] * elem[a], static_cast<const char *>(d_send[a]) + send_off[rank] * elem[a],
+				                         size_t(send_cnt[rank]) * elem[a], hipMemcpyDeviceToDevice, st));
+		if (shm_plane) {   // processes that share GPUs: the pieces cross through the staging segments, with the host in between
+			uint64_t total = 0;
+			for (int p = 0; p < world; ++p) total += p == rank ? 0 : send_cnt[p];
+			size_t need = size_t(world) * 16;
+			for (int a = 0; a < n_arrays; ++a) need += ((size_t(total) * elem[a] + 63) & ~size_t(63));
+			stage_prepare(need);
+			char *mine = static_cast<char *>(my_stage.host);
+			// header: for every peer, where its piece starts in each array's staged run (in elements) and its length
+			uint64_t *hdr = reinterpret_cast<uint64_t *>(mine);
+			uint64_t run = 0;
+			for (int p = 0; p < world; ++p) { hdr[2 * p] = run; hdr[2 * p + 1] = p == rank ? 0 : send_cnt[p]; run += hdr[2 * p + 1]; }
+			HIP_CHECK(stream_wait(st));
+			size_t at = size_t(world) * 16;
+			for (int a = 0; a < n_arrays; ++a) {
+				for (int p = 0; p < world; ++p)
+					if (p != rank && send_cnt[p])
+						HIP_CHECK(hipMemcpy(mine + at + size_t(hdr[2 * p]) * elem[a], static_cast<const char *>(d_send[a]) + send_off[p] * elem[a], size_t(send_cnt[p]) * elem[a], hipMemcpyDeviceToHost));
+				at += (size_t(total) * elem[a] + 63) & ~size_t(63);
+			}
+			barrier();
+			for (int p = 0; p < world; ++p) {
+				if (p == rank || !recv_cnt[p]) continue;
+				const char *peer = static_cast<const char *>(peer_stage[size_t(p)].host);
+				const uint64_t *ph = reinterpret_cast<const uint64_t *>(peer);
+				if (ph[2 * rank + 1] != recv_cnt[p]) throw DeviceError("shm data plane: a peer's piece differs from the agreed size");
+				uint64_t ptotal = 0;
+				for (int q = 0; q < world; ++q) ptotal += ph[2 * q + 1];
+				size_t pat = size_t(world) * 16;
+				for (int a = 0; a < n_arrays; ++a) {
+					HIP_CHECK(hipMemcpy(static_cast<char *>(d_recv[a]) + recv_off[p] * elem[a], peer + pat + size_t(ph[2 * rank]) * elem[a], size_t(recv_cnt[p]) * elem[a], hipMemcpyHostToDevice));
+					pat += (size_t(ptotal) * elem[a] + 63) & ~size_t(63);
+				}
+			}
+			barrier();   // nobody overwrites its segment while a peer still reads it
+			return;
+		}
+		const RcclApi &api = RcclApi::get();
+		api.check(api.GroupStart(), "ncclGroupStart");
+		for (int a = 0; a < n_arrays; ++a)
+			for (int p = 0; p < world; ++p) {
+				if (p == rank) continue;
+				if (send_cnt[p]) api.check(api.Send(static_cast<const char *>(d_send[a]) + send_off[p] * elem[a], size_t(send_cnt[p]) * elem[a], ncclUint8, p, comm, st), "ncclSend");
+				if (recv_cnt[p]) api.check(api.Recv(static_cast<char *>(d_recv[a]) + recv_off[p] * elem[a], size_t(recv_cnt[p]) * elem[a], ncclUint8, p, comm, st), "ncclRecv");
+			}
+		api.check(api.GroupEnd(), "ncclGroupEnd");
 	}
 	void gather_host(const void *mine, size_t bytes, void *all) override {
 		if (mailbox && mailbox->fits(bytes)) { mailbox->gather(mine, bytes, all); return; }
@@ -809,6 +884,15 @@ struct dropest_shard {
 	dropest::DevBuf<u32> p_w1, x_w1;
 	bool packed = false, idx_exchanged = false, allow_packed = true, unpacked = false;
 	bool exact_widths = false;   // option "exact_widths" / after a sampled pass missed a wide field: the histogram pass reads all four columns
+	// The all-to-all in chunks under the partition and the table build (option "exchange_chunks": 0 = 4 chunks from 2^22 resident reads on, 1 =
+	// one piece, k = k chunks): the blocks of every owner are written chunk by chunk; chunk k leaves on the exchange stream as soon as it is
+	// written, while chunk k + 1 is partitioned, and the barcode table takes chunk k of every source's block (dropest_ctx::recv_chunks)
+	// while chunk k + 1 travels.  For packed records without the index column and without quality strings (C2 / C5).
+	int exchange_chunks = 0;
+	bool chunked_now = false;
+	hipStream_t xchg_stream = nullptr;
+	std::vector<hipEvent_t> ev_scat, ev_recv;
+	dropest::DevBuf<u32> d_chunk_bounds, d_chunk_cnt;
 	dropest::ExchangePack exch_pack{};
 	void unpack_exchanged();
 	int rec_bytes = 28;
@@ -874,6 +958,9 @@ struct dropest_shard {
 	hipStream_t place_stream = nullptr;
 	hipEvent_t ev_place = nullptr;
 	~dropest_shard() {
+		if (xchg_stream) { (void)dropest::stream_wait(xchg_stream); (void)hipStreamDestroy(xchg_stream); }
+		for (hipEvent_t e : ev_scat) (void)hipEventDestroy(e);
+		for (hipEvent_t e : ev_recv) (void)hipEventDestroy(e);
 		if (ctx) for (auto &R : ctx->mat) R.settle();   // (the widening threads write into the transport's shared buffer: they leave before it is unmapped)
 		if (place_stream) { (void)dropest::stream_wait(place_stream); (void)hipStreamDestroy(place_stream); } if (ev_place) (void)hipEventDestroy(ev_place); }
 	dropest::DevBuf<u64> d_desc_raw, d_ord_out64;
@@ -1019,6 +1106,11 @@ void dropest_shard::partition_and_exchange() {
 	// The field widths of the packed record come from a SAMPLE of the reads (every 64th row of the histogram pass: that pass then reads
 	// the barcodes only, 8 bytes per read instead of 24); the scatter, which reads every field anyway, reports a read that does not fit.
 	// Then -- on every shard alike -- the partition is repeated with exact widths, and this shard object stays with those.
+	const int C_plan = exchange_chunks == 1 ? 1 : (exchange_chunks ? exchange_chunks : 4);   // (the same option on every shard, like the others)
+	std::vector<u32> chunk_bounds(size_t(C_plan) + 1, 0), my_chunk_cnt(size_t(world) * size_t(C_plan), 0);
+	std::vector<uint64_t> chunk_cnt_all;   // [source][destination][chunk]
+	chunked_now = false;
+	c.recv_chunks.clear();
 	auto partition = [&](bool sampled) -> bool {
 		Phase ph(this, "partition");
 		uint64_t need = 0;
@@ -1040,6 +1132,15 @@ void dropest_shard::partition_and_exchange() {
 			hipLaunchKernelGGL(rs_scan_totals_kernel<256>, dim3(1), dim3(256), 0, c.stream, row_total, digit_base);
 			HIP_CHECK(hipGetLastError());
 			HIP_CHECK(hipMemcpyAsync(totals.data(), row_total, RS_RADIX * 4, hipMemcpyDeviceToHost, c.stream));
+			if (C_plan > 1) {   // reads of every owner inside every chunk of blocks (the all-to-all may leave chunk by chunk)
+				for (int k = 0; k <= C_plan; ++k) chunk_bounds[size_t(k)] = u32(uint64_t(nblocks) * uint64_t(k) / uint64_t(C_plan));
+				d_chunk_bounds.ensure(size_t(C_plan) + 1); d_chunk_cnt.ensure(size_t(world) * size_t(C_plan));
+				HIP_CHECK(hipMemcpyAsync(d_chunk_bounds.p, chunk_bounds.data(), (size_t(C_plan) + 1) * 4, hipMemcpyHostToDevice, c.stream));
+				hipLaunchKernelGGL(owner_chunk_counts_kernel, dim3(div_up(u32(world) * u32(C_plan), 256u)), dim3(256), 0, c.stream, hist, row_total, nblocks, u32(world), u32(C_plan),
+				                   d_chunk_bounds.p, d_chunk_cnt.p);
+				HIP_CHECK(hipGetLastError());
+				HIP_CHECK(hipMemcpyAsync(my_chunk_cnt.data(), d_chunk_cnt.p, size_t(world) * size_t(C_plan) * 4, hipMemcpyDeviceToHost, c.stream));
+			}
 			c.fetch(stats, d_stats, 40);
 		}
 		for (int p = 0; p < world; ++p) send_cnt[size_t(p)] = totals[size_t(p)];
@@ -1047,12 +1148,15 @@ void dropest_shard::partition_and_exchange() {
 		// (the sixth word: did this shard measure its widths on a sample?  A shard that took the exact path -- its exact_widths option, an
 		// earlier pass that did not fit -- must still lay the record out like the others and join their 'did everything fit' collective:
 		// the layout below follows what ANY shard did, never this shard's own option alone -- ADVICE r4)
-		const size_t W = size_t(world) + 6;
+		const size_t WC = C_plan > 1 ? size_t(world) * size_t(C_plan) : 0, W = size_t(world) + 6 + WC;
 		std::vector<uint64_t> mine(W), every(W * size_t(world));
 		for (int p = 0; p < world; ++p) mine[size_t(p)] = send_cnt[size_t(p)];
 		for (int k = 0; k < 5; ++k) mine[size_t(world) + size_t(k)] = stats[k];
 		mine[size_t(world) + 5] = sampled ? 1u : 0u;
+		for (size_t i = 0; i < WC; ++i) mine[size_t(world) + 6 + i] = my_chunk_cnt[i];
 		tr->gather_host(mine.data(), mine.size() * 8, every.data());
+		chunk_cnt_all.assign(WC * size_t(world), 0);
+		for (int p = 0; p < world; ++p) for (size_t i = 0; i < WC; ++i) chunk_cnt_all[size_t(p) * WC + i] = every[size_t(p) * W + size_t(world) + 6 + i];
 		uint64_t g[5] = {0, 0, 0, 0, 0};
 		bool any_sampled = false;
 		for (int p = 0; p < world; ++p) {
@@ -1065,6 +1169,11 @@ void dropest_shard::partition_and_exchange() {
 		const int gene_bits = std::max(1, bit_length(g[2])), chr_bits = std::max(1, bit_length(g[3]));
 		packed = allow_packed && !g[4] && cb_bits + umi_bits <= 64 && gene_bits + 3 + chr_bits <= 32;   // (a code with N has bit 63 set: never packed)
 		idx_exchanged = want_idx || !packed;
+		{
+			uint64_t everybody = 0;
+			for (uint64_t x : all_cnt) everybody += x;
+			chunked_now = C_plan > 1 && packed && !idx_exchanged && !r_have_qual && (exchange_chunks > 1 || everybody >= (uint64_t(1) << 22) * uint64_t(world));
+		}
 		pack.cb_bits = cb_bits;
 		// sampled widths: the gene field takes every bit the chromosome does not need (a wider field costs nothing), the chromosome one bit of slack
 		pack.gene_bits = any_sampled && packed ? std::max(gene_bits, 32 - 3 - std::min(chr_bits + 1, 32 - 3 - gene_bits)) : gene_bits;
@@ -1090,11 +1199,58 @@ void dropest_shard::partition_and_exchange() {
 			self.owner = u32(rank);
 			self.w0 = x_w0.p + recv_off[size_t(rank)] - send_off[size_t(rank)];     // (index = position in the partition's output)
 			self.w1 = x_w1.p + recv_off[size_t(rank)] - send_off[size_t(rank)];
-			if (packed) hipLaunchKernelGGL(owner_scatter_kernel<true>, dim3(nblocks), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), owner_bits, tpb, hist, digit_base,
+			if (packed && chunked_now) {
+				// (launched chunk by chunk below, each chunk's pieces leaving as soon as they are written)
+			} else if (packed) hipLaunchKernelGGL(owner_scatter_kernel<true>, dim3(nblocks), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), owner_bits, tpb, hist, digit_base,
 			                               p_w0.p, static_cast<u64 *>(nullptr), p_w1.p, static_cast<u32 *>(nullptr), p_idx.p, pack, self);
 			else hipLaunchKernelGGL(owner_scatter_kernel<false>, dim3(nblocks), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), owner_bits, tpb, hist, digit_base,
 			                        p_cb.p, p_umi.p, p_gene.p, p_aux.p, p_idx.p, pack);
 			HIP_CHECK(hipGetLastError());
+		}
+		if (chunked_now) {
+			// chunk k: partition its blocks, then send its pieces (exchange stream) while chunk k + 1 is partitioned; ev_recv[k] = chunk k of every
+			// source's block has landed
+			if (!xchg_stream) HIP_CHECK(hipStreamCreateWithFlags(&xchg_stream, hipStreamNonBlocking));
+			while (ev_scat.size() < size_t(C_plan)) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_scat.push_back(e); }
+			while (ev_recv.size() < size_t(C_plan)) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev_recv.push_back(e); }
+			const size_t WC = size_t(world) * size_t(C_plan);
+			const int owner_bits = std::max(1, bit_length(uint64_t(world - 1)));
+			OwnerSelf self{};
+			if (any_sampled) self.bad = reinterpret_cast<u32 *>(d_stats + 5);   // (cleared above)
+			self.owner = u32(rank);
+			self.w0 = x_w0.p + recv_off[size_t(rank)] - send_off[size_t(rank)];
+			self.w1 = x_w1.p + recv_off[size_t(rank)] - send_off[size_t(rank)];
+			std::vector<uint64_t> s_off(static_cast<size_t>(world)), s_cnt(static_cast<size_t>(world)), r_off(static_cast<size_t>(world)), r_cnt(static_cast<size_t>(world));
+			std::vector<uint64_t> s_run(send_off.begin(), send_off.begin() + world), r_run(recv_off.begin(), recv_off.begin() + world);
+			c.recv_chunks.clear();
+			for (int k = 0; k < C_plan; ++k) {
+				const u32 b0 = chunk_bounds[size_t(k)], b1 = chunk_bounds[size_t(k) + 1];
+				if (n && b1 > b0) {
+					hipLaunchKernelGGL(owner_scatter_kernel<true>, dim3(b1 - b0), dim3(OP_T), 0, c.stream, r_cb, r_umi, r_gene, r_aux, n, u32(world), owner_bits, tpb, hist, digit_base,
+					                   p_w0.p, static_cast<u64 *>(nullptr), p_w1.p, static_cast<u32 *>(nullptr), p_idx.p, pack, self, b0, nblocks);
+					HIP_CHECK(hipGetLastError());
+				}
+				HIP_CHECK(hipEventRecord(ev_scat[size_t(k)], c.stream));
+				HIP_CHECK(hipStreamWaitEvent(xchg_stream, ev_scat[size_t(k)], 0));
+				dropest_ctx::RecvChunk rc{};
+				rc.ev = ev_recv[size_t(k)];
+				rc.rg.n = u32(world);
+				for (int p = 0; p < world; ++p) {
+					s_off[size_t(p)] = s_run[size_t(p)]; s_cnt[size_t(p)] = chunk_cnt_all[size_t(rank) * WC + size_t(p) * size_t(C_plan) + size_t(k)];
+					r_off[size_t(p)] = r_run[size_t(p)]; r_cnt[size_t(p)] = chunk_cnt_all[size_t(p) * WC + size_t(rank) * size_t(C_plan) + size_t(k)];
+					s_run[size_t(p)] += s_cnt[size_t(p)]; r_run[size_t(p)] += r_cnt[size_t(p)];
+					rc.rg.off[p] = u32(r_off[size_t(p)]); rc.rg.cnt[p] = u32(r_cnt[size_t(p)]);
+				}
+				const void *snd[2] = {p_w0.p, p_w1.p};
+				void *rcv[2] = {x_w0.p, x_w1.p};
+				const size_t elem[2] = {8, 4};
+				tr->exchange_at(2, snd, rcv, elem, s_off.data(), s_cnt.data(), r_off.data(), r_cnt.data(), xchg_stream, 3u);   // the kept pieces: already in place
+				HIP_CHECK(hipEventRecord(ev_recv[size_t(k)], xchg_stream));
+				c.recv_chunks.push_back(rc);
+			}
+			for (int p = 0; p < world; ++p)
+				if (s_run[size_t(p)] != send_off[size_t(p)] + send_cnt[size_t(p)] || r_run[size_t(p)] != recv_off[size_t(p)] + recv_cnt[size_t(p)])
+					throw InvalidError("internal: the chunks of the exchange do not add up to its blocks");
 		}
 		if (!(any_sampled && packed)) return true;
 		// did every read of every shard fit?  (one word from the device, one small collective)
@@ -1102,7 +1258,7 @@ void dropest_shard::partition_and_exchange() {
 		if (n) { u32 b32 = 0; c.fetch(&b32, d_stats + 5, 4); bad = b32; }
 		std::vector<uint64_t> bad_of(static_cast<size_t>(world));
 		tr->gather_host(&bad, 8, bad_of.data());
-		for (uint64_t x : bad_of) if (x) return false;
+		for (uint64_t x : bad_of) if (x) { if (chunked_now) { HIP_CHECK(stream_wait(xchg_stream)); c.recv_chunks.clear(); } return false; }
 		return true;
 	};
 	if (!partition(!exact_widths)) { exact_widths = true; phases["partition:exact_again"].launches++; partition(false); }
@@ -1114,7 +1270,9 @@ void dropest_shard::partition_and_exchange() {
 			for (DevBuf<u32> *b : {&x_gene, &x_aux}) b->ensure(std::max<size_t>(n_recv, 1));
 		}
 		if (idx_exchanged) x_idx.ensure(std::max<size_t>(n_recv, 1));
-		if (packed) {
+		if (packed && chunked_now) {
+			phases["all_to_all:chunks"].launches += u32(C_plan);   // (it left chunk by chunk, inside the partition)
+		} else if (packed) {
 			const void *snd[3] = {p_w0.p, p_w1.p, p_idx.p};
 			void *rcv[3] = {x_w0.p, x_w1.p, x_idx.p};
 			const size_t elem[3] = {8, 4, 4};
@@ -2531,6 +2689,7 @@ dropest_status dropest_shard_set_option(dropest_shard *s, const char *key, int64
 		else if (k == "byte_list_cap") s->byte_list_cap = value > 0 ? uint64_t((value + 15) & ~15ll) : 0;
 		else if (k == "packed_exchange") s->allow_packed = value != 0;
 		else if (k == "exact_widths") s->exact_widths = value != 0;
+		else if (k == "exchange_chunks") s->exchange_chunks = int(std::max<int64_t>(0, std::min<int64_t>(value, 16)));
 		else throw InvalidError("unknown shard option: " + k);
 	});
 }

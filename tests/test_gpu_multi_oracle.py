@@ -210,3 +210,18 @@ def test_a_shard_whose_byte_lists_overflow_places_its_columns_as_32_bit_slots(mo
     got = run_shards(arrays, kw, bounds, steps=2)
     assert got["form"] == (3, 3) and got["phases"]["matrix:overflow"]["steps"] >= 2
     check_vs_oracle(got, o, side)
+
+
+@pytest.mark.parametrize("world,chunks", [(1, 4), (2, 2), (3, 5), (8, 3)])
+@pytest.mark.parametrize("name", ["none", "none+N", "real:10x", "real:indrop+N"])
+def test_chunked_exchange_matches_the_oracle(name, world, chunks, monkeypatch):
+    """The all-to-all leaves chunk by chunk under the partition, and the barcode table is built chunk by chunk as the pieces land (shard
+    option exchange_chunks; on by itself from 2^22 reads per shard): ranges of the same read arrays, so every read keeps its first-seen
+    ordinal -- the hot list and the sampled table sizing (forced on these small streams) see the first chunk only."""
+    monkeypatch.setenv("DROPEST_CB_SAMPLE_MIN", "1000")
+    arrays, kw, side = make_case(name)
+    o = seeded_oracle(kw, arrays, side)
+    opts = [{"exchange_chunks": chunks, "force_exchange": 1}] * world
+    got = run_shards(arrays, kw, even_bounds(len(arrays[0]), world), side=side, options=opts, steps=2)
+    check_vs_oracle(got, o, side)
+    assert got["phases"]["all_to_all:chunks"]["steps"] == 2 * chunks

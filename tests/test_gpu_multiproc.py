@@ -139,6 +139,19 @@ def test_processes_byte_lists_overflow_falls_back():
     s = SynthStream(n_reads=300_000, n_cells=50, n_genes=9000, umi_len=8)
     arrays = parity.canonical_stream(*s.generate_host())
     kw = cfg_kwargs({"min_before": 1, "min_after": 5})
-    got = run_processes(2, arrays, kw, steps=2, opts=(("byte_list_cap", 16),))
+    got = run_processes(2, arrays, kw, steps=2, opts=(("slots_matrix", 0), ("byte_list_cap", 16)))
     check(got, arrays, kw)
+
+
+@pytest.mark.parametrize("world,chunks", [(2, 4), (3, 3)])
+def test_processes_chunked_exchange(world, chunks):
+    """The all-to-all in chunks under the partition and the barcode table (shard option exchange_chunks; the default from 2^22 reads per
+    shard on): piece k of every process's blocks crosses the shm data plane while piece k + 1 is partitioned, the table takes piece k of
+    every source.  Whitelist merge behind it; two passes.  Same matrices and merged barcodes as one context."""
+    s = SynthStream(n_reads=300_000, n_cells=40, n_genes=2000, umi_len=12, permille_neighbour=150)
+    arrays = parity.canonical_stream(*s.generate_host())
+    kw = cfg_kwargs({"min_before": 3, "min_after": 20, "merge": {"barcodes_kind": capi.BARCODES_CONST, "barcodes_file": os.path.join(DATA, "10x_aug_2016_split")}})
+    got = run_processes(world, arrays, kw, steps=2, opts=(("exchange_chunks", chunks),))
+    want = check(got, arrays, kw)
+    assert len(want) > 20
 
