@@ -224,4 +224,5 @@ def test_chunked_exchange_matches_the_oracle(name, world, chunks, monkeypatch):
     opts = [{"exchange_chunks": chunks, "force_exchange": 1}] * world
     got = run_shards(arrays, kw, even_bounds(len(arrays[0]), world), side=side, options=opts, steps=2)
     check_vs_oracle(got, o, side)
-    assert got["phases"]["all_to_all:chunks"]["steps"] == 2 * chunks
+    if "+N" not in name:    # (a UMI with N is an escaped code with bit 63 set: those streams travel as five arrays, in one piece)
+        assert got["phases"]["all_to_all:chunks"]["steps"] == 2 * chunks
