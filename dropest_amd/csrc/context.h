@@ -540,7 +540,13 @@ struct dropest_ctx {
 	void build_cb_table();
 	void assign_cell_ids();
 	void plan_key_layout();
-	void build_keys(bool with_stats = false);
+	// allow_fused: the keys may be built and partitioned into the coarse regions of the splitter sort in one pass (k_keyscatter.h); the
+	// fall-backs that need the plain key array (counting partitions, the LSD sort) say no
+	void build_keys(bool with_stats = false, bool allow_fused = true);
+	bool build_keys_fused(bool with_stats);   // false: not applicable for this pass (layout, size, LDS)
+	void ss_splitters_from_sample(u32 n_sample, u32 os, u32 Ff, u32 F2, u64 varying_of_sample);   // ss_sample_a holds the sample -> ss_fine / ss_coarse
+	bool keys_in_l1 = false;                  // keys_b / vals_b hold the keys in their coarse regions, ss_cursors their fills
+	dropest::DevBuf<u32> ks_flag;
 	u32 main_sort_passes = 0, main_sort_kind = 0;   // kind: 0 LSD radix sort, 1 splitter sort
 	// exclusive scan of n counters (tile counts) + their total: one workgroup for short arrays, chunk sums + prefix for long ones (2e5 tile
 	// counts at C3 size took one workgroup 0.28 ms, five times a pass)

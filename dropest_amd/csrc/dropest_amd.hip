@@ -10,6 +10,7 @@
 // This file contains no CPU implementation of the path: without a GPU every entry point fails loudly.
 
 #include "context.h"
+#include "k_keyscatter.h"
 
 #include <atomic>
 #include <sys/syscall.h>
@@ -536,7 +537,96 @@ static SsPlan ss_plan(uint64_t n_reads, bool chr_from_gene, int val_bytes) {
 	return P;
 }
 
-void dropest_ctx::build_keys(bool with_stats) {
+void dropest_ctx::ss_splitters_from_sample(u32 n_sample, u32 os, u32 Ff, u32 F2, u64 varying_of_sample) {
+	u64 *k = ss_sample_a.p, *k_alt = ss_sample_b.p;
+	u32 *v = nullptr, *v_alt = nullptr;
+	radix_sort(k, v, k_alt, v_alt, n_sample, varying_of_sample, 0, "ss_sample:");
+	hipLaunchKernelGGL(ss_pick_splitters_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, k, os, Ff, F2, ss_fine.p, ss_coarse.p);
+	HIP_CHECK(hipGetLastError());
+}
+
+// The keys built and partitioned into the coarse regions in ONE pass (k_keyscatter.h): the sample of the splitter sort comes from the reads
+// before the key pass, so the coarse splitters exist when the keys are made.
+bool dropest_ctx::build_keys_fused(bool with_stats) {
+	static const bool off = getenv("DROPEST_NO_FUSED_KEYS") != nullptr;
+	if (off || ss_no_reserve || !chr_from_gene || layout.val_bytes > 1) return false;
+	const SsPlan plan = ss_plan(n_reads, chr_from_gene, layout.val_bytes);
+	if (!plan.applicable || !plan.reserve) return false;
+	const u32 n = u32(n_reads);
+	const bool vec = ((uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;
+	if (!vec) return false;
+	const int fb1 = plan.fb1, fb2 = plan.fb2, ms = layout.mark_shift, VB = layout.val_bytes;
+	const u32 F1 = 1u << fb1, Ff = 1u << fb2, F2 = F1 * Ff;
+	if (F1 > KS_MAXF) return false;
+	uint64_t os_max = plan.os;
+	if (const char *e = getenv("DROPEST_SSORT_OS")) os_max = uint64_t(std::max(1, atoi(e)));
+	const u32 os = u32(std::max<uint64_t>(1, std::min<uint64_t>(os_max, uint64_t(n) / (uint64_t(F2) * 2))));
+	const u32 n_sample = F2 * os;
+	const u32 lds_genes = with_stats && !getenv("DROPEST_NO_LDS_GENE_TABLE") ? std::min<u32>((ingest.gene_max_plus1 + 3u) & ~3u, BK_LDS_GENES_MAX) : 0u;
+	const size_t lds = ks_dynamic_lds(lds_genes);
+	const size_t span = size_t(plan.span);
+	const size_t val_words = (span * size_t(VB) + 3) / 4 + 1;
+	keys_a.ensure(span); keys_b.ensure(span); vals_a.ensure(val_words); vals_b.ensure(val_words);
+	const CbHot hot{hot_key.p, hot_slot.p, n_hot};
+	// sample of the reads -> sorted -> fine / coarse splitters
+	ss_sample_a.ensure(n_sample); ss_sample_b.ensure(n_sample); ss_fine.ensure(F2); ss_coarse.ensure(F1);
+	timed("ss_sample", double(n_sample) * (20.0 / 16 * 8 + 8), [&] {
+		if (rpack.on()) hipLaunchKernelGGL(ss_sample_reads_kernel<true>, dim3(div_up(n_sample, 256)), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, hot, rpack, n_sample, ss_sample_a.p);
+		else hipLaunchKernelGGL(ss_sample_reads_kernel<false>, dim3(div_up(n_sample, 256)), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, hot, rpack, n_sample, ss_sample_a.p);
+	});
+	const int key_bits = layout.cell_bits + layout.gene_bits + layout.umi_bits;
+	ss_splitters_from_sample(n_sample, os, Ff, F2, key_bits >= 64 ? ~0ull : ((1ull << key_bits) - 1ull));   // (every bit of the key fields may vary: the sample's own OR / AND would cost a round trip)
+	// regions, cursors, flags
+	const u32 cap1 = u32(plan.cap1), CS1 = 32;
+	ss_cursors.ensure(size_t(F1) * CS1 + F2); ks_flag.ensure(1);
+	HIP_CHECK(hipMemsetAsync(ss_cursors.p, 0, (size_t(F1) * CS1 + F2) * 4, stream));
+	HIP_CHECK(hipMemsetAsync(ks_flag.p, 0, 4, stream));
+	d_counters.ensure(1);
+	GlobalCounters init{};
+	init.key_and = ~0ull;
+	HIP_CHECK(hipMemcpyAsync(d_counters.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
+	if (with_stats) {
+		IngestStats zero{};
+		zero.umi_clean_min = ~0ull;
+		zero.gene_chr_conflict = ingest.gene_chr_conflict;
+		HIP_CHECK(hipMemcpyAsync(d_ingest.p, &zero, sizeof(zero), hipMemcpyHostToDevice, stream));
+	}
+	int cus = 0, dev = 0;
+	HIP_CHECK(hipGetDevice(&dev));
+	HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+	const SsReserve r1{ss_cursors.p, CS1, cap1, 0u, ks_flag.p, 0u};
+	bool launched = true;
+	timed("build_keys+L1", double(n) * (8 + 4 + 4 + 4 + 4 + 8 + VB), [&] {
+		auto go = [&](auto kernel) {
+			if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) { (void)hipGetLastError(); launched = false; return; }
+			const u32 blocks = std::max<u32>(1u, std::min<u32>(div_up(n, u32(KS_TILE)), u32(std::max(1, cus))));
+			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(KS_T), lds, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, d_counters.p, hot, gene_chr.p, GENE_CHR_CAP, d_ingest.p,
+			                   lds_genes, rpack, keys_b.p, reinterpret_cast<uint8_t *>(vals_b.p), ms, fb1, ss_coarse.p, r1);
+		};
+		auto pick = [&](auto vb) {
+			constexpr int V = decltype(vb)::value;
+			const int mode = with_stats ? (lds_genes ? 2 : 1) : 0;
+			if (rpack.on()) { if (mode == 2) go(build_keys_scatter_kernel<V, 2, true>); else if (mode == 1) go(build_keys_scatter_kernel<V, 1, true>); else go(build_keys_scatter_kernel<V, 0, true>); }
+			else { if (mode == 2) go(build_keys_scatter_kernel<V, 2, false>); else if (mode == 1) go(build_keys_scatter_kernel<V, 1, false>); else go(build_keys_scatter_kernel<V, 0, false>); }
+		};
+		if (VB == 0) pick(std::integral_constant<int, 0>{}); else pick(std::integral_constant<int, 1>{});
+	});
+	if (!launched) return false;   // (a device that does not grant the LDS: the two kernels)
+	fetch(&counters, d_counters.p, sizeof(counters));
+	if (with_stats) {
+		IngestStats exact{};
+		fetch(&exact, d_ingest.p, sizeof(exact));
+		exact.cb_escape_count = ingest.cb_escape_count;
+		exact.overflow = 0;
+		ingest = exact;
+	}
+	keys_in_l1 = true;
+	return true;
+}
+
+void dropest_ctx::build_keys(bool with_stats, bool allow_fused) {
+	keys_in_l1 = false;
+	if (allow_fused && build_keys_fused(with_stats)) return;
 	const u32 n = u32(n_reads);
 	// value buffers hold val_bytes per record (0, 1 or 4): nothing at all for the keys-only layout
 	// (the splitter sort's partitions by reservation write into bucket regions with gaps: up to 1.75 n records of address space)
@@ -787,17 +877,15 @@ bool dropest_ctx::splitter_sort_reduce() {
 	u64 *keys = keys_a.p, *keys_alt = keys_b.p;
 	uint8_t *vals = reinterpret_cast<uint8_t *>(vals_a.p), *vals_alt = reinterpret_cast<uint8_t *>(vals_b.p);
 
-	// sample -> sorted -> splitters
-	ss_sample_a.ensure(n_sample); ss_sample_b.ensure(n_sample); ss_fine.ensure(F2); ss_coarse.ensure(F1);
-	timed("ss_sample", double(n_sample) * 16, [&] {
-		hipLaunchKernelGGL(ss_sample_kernel, dim3(div_up(n_sample, 256)), dim3(256), 0, stream, keys, n, ms, n_sample, ss_sample_a.p);
-	});
-	{
-		u64 *k = ss_sample_a.p, *k_alt = ss_sample_b.p;
-		u32 *v = nullptr, *v_alt = nullptr;
-		radix_sort(k, v, k_alt, v_alt, n_sample, varying >> ms, 0, "ss_sample:");
-		hipLaunchKernelGGL(ss_pick_splitters_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, k, os, Ff, F2, ss_fine.p, ss_coarse.p);
-		HIP_CHECK(hipGetLastError());
+	// sample -> sorted -> splitters (build_keys_fused took the sample from the reads and has the keys in their coarse regions already)
+	const bool in_l1 = keys_in_l1 && reserve;
+	if (keys_in_l1 && !reserve) throw InvalidError("internal: keys partitioned by the key pass, but the sort does not place by reservation");
+	if (!in_l1) {
+		ss_sample_a.ensure(n_sample); ss_sample_b.ensure(n_sample); ss_fine.ensure(F2); ss_coarse.ensure(F1);
+		timed("ss_sample", double(n_sample) * 16, [&] {
+			hipLaunchKernelGGL(ss_sample_kernel, dim3(div_up(n_sample, 256)), dim3(256), 0, stream, keys, n, ms, n_sample, ss_sample_a.p);
+		});
+		ss_splitters_from_sample(n_sample, os, Ff, F2, varying >> ms);
 	}
 
 	const u32 n_tiles = div_up(n, SS_TILE);
@@ -853,12 +941,13 @@ bool dropest_ctx::splitter_sort_reduce() {
 		// both partitions by reservation (k_ssort.h): a tile takes its places in the buckets' regions with one atomic per bucket; no histograms
 		const u32 cap1 = u32(plan.cap1), cap2 = u32(plan.cap2), CS1 = 32;
 		ss_cursors.ensure(size_t(F1) * CS1 + F2);
-		HIP_CHECK(hipMemsetAsync(ss_cursors.p, 0, (size_t(F1) * CS1 + F2) * 4, stream));
+		if (!in_l1) HIP_CHECK(hipMemsetAsync(ss_cursors.p, 0, (size_t(F1) * CS1 + F2) * 4, stream));
+		else HIP_CHECK(hipMemcpyAsync(scalars.p + 3, ks_flag.p, 4, hipMemcpyDeviceToDevice, stream));   // (a coarse region the key pass overflowed)
 		u32 *cur1 = ss_cursors.p, *cur2 = ss_cursors.p + size_t(F1) * CS1;
 		const u32 probe = [] { const char *e = getenv("DROPEST_SS_PROBE"); return e ? u32(atoi(e)) : 0u; }();
 		const bool no256 = getenv("DROPEST_SS_NO_F256") != nullptr;
 		const SsReserve r1{cur1, CS1, cap1, 0u, scalars.p + 3, probe}, r2{cur2, 1u, cap2, 0u, scalars.p + 3, probe};
-		timed(VB ? "ss_scatter:L1:key+1B" : "ss_scatter:L1:keys", double(n) * 2 * (8 + VB), [&] {
+		if (!in_l1) timed(VB ? "ss_scatter:L1:key+1B" : "ss_scatter:L1:keys", double(n) * 2 * (8 + VB), [&] {
 			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb1, ss_coarse.p, tpb, r1); };
 			if (wide) { if (VB) go(ss_scatter_res_l1_kernel<1, 1024>); else go(ss_scatter_res_l1_kernel<0, 1024>); }
 			else if (fb1 <= 8 && !no256) { if (VB) go(ss_scatter_res_l1_kernel<1, 256>); else go(ss_scatter_res_l1_kernel<0, 256>); }   // 45 KB of LDS: three workgroups per CU
@@ -885,7 +974,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 			build_keys(false);
 			return splitter_sort_reduce();
 		}
-		if (max_cnt > SS_LOCAL_MAX) { build_keys(false); return false; }   // (cannot happen while a region holds fewer records than the LDS sort takes)
+		if (max_cnt > SS_LOCAL_MAX) { build_keys(false, false); return false; }   // (cannot happen while a region holds fewer records than the LDS sort takes)
 	} else {
 	// L1: all records into the F1 coarse buckets
 	rs_hist.ensure(size_t(F1) * nblocks); rs_row_total.ensure(1024); ss_base1.ensure(F1 + 1);
@@ -966,7 +1055,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 		// consumed the keys, so they are built again and the LSD sort takes the pass; the one-atomic ranking is off for this device.
 		if (atomic_rank) lds_atomics_mark_unordered(cfg.device);
 		stats["count:ss_order_violation"].launches += 1;
-		build_keys(false);
+		build_keys(false, false);   // (the LSD sort wants the plain key array)
 		return false;
 	}
 	const u32 total = total_flag[0];
