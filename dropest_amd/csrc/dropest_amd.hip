@@ -548,8 +548,14 @@ void dropest_ctx::ss_splitters_from_sample(u32 n_sample, u32 os, u32 Ff, u32 F2,
 // The keys built and partitioned into the coarse regions in ONE pass (k_keyscatter.h): the sample of the splitter sort comes from the reads
 // before the key pass, so the coarse splitters exist when the keys are made.
 bool dropest_ctx::build_keys_fused(bool with_stats) {
-	static const bool off = getenv("DROPEST_NO_FUSED_KEYS") != nullptr;
+	const bool off = getenv("DROPEST_NO_FUSED_KEYS") != nullptr;   // (read at every pass: tests run both ways in one process)
 	if (off || ss_no_reserve || !chr_from_gene || layout.val_bytes > 1) return false;
+	// One workgroup per CU hides less latency than the two kernels' many: the fused pass wins where most reads find their cell id in LDS (C2:
+	// 0.86 + 0.55 -> 1.17 ms) and merely ties where most gather it from the table (C3 at 1e9 reads, 1 365 of 50 000 cells listed: 11.7 +
+	// 12.9 -> 25.0 ms).  Taken when the hot list covers a good part of the sampled reads.
+	const char *e_cov = getenv("DROPEST_FUSED_KEYS_MIN_COVERAGE");
+	const double min_cov = e_cov ? atof(e_cov) : 0.4;
+	if (hot_coverage < min_cov) return false;
 	const SsPlan plan = ss_plan(n_reads, chr_from_gene, layout.val_bytes);
 	if (!plan.applicable || !plan.reserve) return false;
 	const u32 n = u32(n_reads);

@@ -17,9 +17,26 @@ import test_gpu_stress as ts
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture
-def splitter(monkeypatch):
+@pytest.fixture(params=["fused_keys", "two_kernels"])
+def splitter(monkeypatch, request):
+    """The splitter sort forced on any size, both ways its first partition can run: fused into the key pass (k_keyscatter.h: the sample
+    comes from the reads; by default only when the hot list covers most reads) and as build_keys + ss_scatter_res_l1."""
     monkeypatch.setenv("DROPEST_SORT", "splitter")
+    if request.param == "fused_keys":
+        monkeypatch.setenv("DROPEST_FUSED_KEYS_MIN_COVERAGE", "0")
+    else:
+        monkeypatch.setenv("DROPEST_NO_FUSED_KEYS", "1")
+    return request.param
+
+
+def test_the_key_pass_partitions_when_asked(splitter):
+    s = SynthStream(n_reads=300_000, n_cells=60, n_genes=3000)
+    cb, umi, gene, aux = parity.canonical_stream(*s.generate_host())
+    c = parity.gpu_run(dict(min_genes_before_merge=10, min_genes_after_merge=30), cb, umi, gene, aux, profile=True)
+    k = c.kernel_stats()
+    assert ("build_keys+L1" in k) == (splitter == "fused_keys") and ("ss_scatter:L1:keys" in k) == (splitter == "two_kernels")
+    o = parity.oracle_run(Oracle, dict(min_genes_before=10, min_genes_after=30), cb, umi, gene, aux)
+    parity.compare(o, c)
 
 
 def test_c2_shapes_use_the_splitter_path(splitter):
