@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 # kernels of the splitter sort (dropest_amd/csrc/k_ssort.h), the scatter pass of the LSD sort (k_radix.h) and the barcode
 # table build.  Algorithmic bytes per launch are the ones DESIGN.md §2 states per kernel (e.g. a scatter pass =
 # 2 x (8 B key + value bytes) per record).
-DOMINANT = "ss_scatter|ss_local|ss_hist|rs_scatter|cb_insert|build_keys"
+DOMINANT = "ss_scatter|ss_local|ss_hist|ss_compact|rs_scatter|cb_insert|build_keys"
 
 
 def parse():
@@ -139,7 +139,7 @@ def cpu_baseline(stream, n_sample, cfg, name="C2"):
 
 
 # kernel-stat name (dropest_kernel_stats) -> start of the kernel's name in a rocprofv3 trace
-ROCPROF_NAME = {"cb_insert": "cb_insert_", "build_keys": "build_keys_kernel", "ss_local:keys": "ss_local_kernel<0",
+ROCPROF_NAME = {"cb_insert": "cb_insert_", "build_keys": "build_keys_kernel", "build_keys+L1": "build_keys_scatter_kernel", "ss_compact:cell_gene": "ss_compact_cg_kernel", "ss_local:keys": "ss_local_kernel<0",
                 "ss_local:key+1B": "ss_local_kernel<1", "ss_scatter:L1:keys": ("ss_scatter_res_l1_kernel<0", "ss_scatter_l1_kernel<0"),
                 "ss_scatter:L2:keys": ("ss_scatter_res_l2_kernel<0", "ss_scatter_l2_kernel<0"),
                 "ss_scatter:L1:key+1B": ("ss_scatter_res_l1_kernel<1", "ss_scatter_l1_kernel<1"), "ss_scatter:L2:key+1B": ("ss_scatter_res_l2_kernel<1", "ss_scatter_l2_kernel<1"),

@@ -824,7 +824,11 @@ void dropest_ctx::radix_sort(u64 *&keys, u32 *&vals, u64 *&keys_alt, u32 *&vals_
 static std::mutex g_lds_order_mu;
 static std::map<int, bool> g_lds_order_known;
 // a pass found a bucket out of order behind the one-atomic ranking: this device ranks with ballots from now on
-static void lds_atomics_mark_unordered(int device) { std::lock_guard<std::mutex> lk(g_lds_order_mu); g_lds_order_known[device] = false; }
+static void lds_atomics_mark_unordered(int device) {
+	std::lock_guard<std::mutex> lk(g_lds_order_mu);
+	g_lds_order_known[device] = false;
+	fprintf(stderr, "[dropest_amd] device %d: a bucket came out of its LDS sort unsorted behind the one-atomic ranking; the finishing sort ranks with ballots from now on (slower, same results)\n", device);
+}
 static bool lds_atomics_lane_ordered(int device, hipStream_t stream) {
 	std::mutex &mu = g_lds_order_mu;
 	std::map<int, bool> &known = g_lds_order_known;
@@ -851,6 +855,8 @@ static bool lds_atomics_lane_ordered(int device, hipStream_t stream) {
 		u32 seen[64] = {0};
 		for (u32 l = 0; l < 64; ++l) { const u32 d = h[size_t(r) * 64 + l]; if (got[size_t(r) * 64 + l] != seen[d]) ordered = false; ++seen[d]; }
 	}
+	// (said once per device: results never depend on it -- every pass verifies its buckets --, the speed of ss_local does)
+	if (!ordered) fprintf(stderr, "[dropest_amd] device %d: LDS atomics of one instruction are not applied in lane order here; the finishing sort of the splitter sort ranks with ballots (slower, same results)\n", device);
 	return known[device] = ordered;
 }
 

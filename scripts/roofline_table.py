@@ -38,8 +38,9 @@ if len(sys.argv) > 1 and os.path.exists(sys.argv[1]):
     for row in csv.DictReader(l for l in open(sys.argv[1]) if not l.startswith("#")):
         pmc[row["kernel"]] = float(row["hbm_bytes_per_launch"])
 # kernel-stat name -> substring of the rocprof kernel name
-alias = {"ss_local:keys": "ss_local_kernel<0>", "ss_local:big": "ss_local_big_kernel<0>", "ss_scatter:L1:keys": "ss_scatter_l1_kernel<0", "ss_scatter:L2:keys": "ss_scatter_l2_kernel<0",
-         "ss_hist:L1": "ss_hist_l1_kernel", "ss_hist:L2": "ss_hist_l2_kernel", "ss_compact": "ss_compact_kernel", "ss_sample": "ss_sample_kernel", "cb_sample": "cb_sample_distinct_kernel",
+alias = {"ss_local:keys": "ss_local_kernel<0", "ss_local:big": "ss_local_big_kernel<", "ss_scatter:L1:keys": "ss_scatter_res_l1_kernel<0", "ss_scatter:L2:keys": "ss_scatter_res_l2_kernel<0",
+         "build_keys+L1": "build_keys_scatter_kernel", "ss_compact:cell_gene": "ss_compact_cg_kernel", "emit_matrix:cm": "emit_matrix_kernel<2>", "emit_matrix:cm_raw": "emit_matrix_bytes_short_kernel",
+         "ss_hist:L1": "ss_hist_l1_kernel", "ss_hist:L2": "ss_hist_l2_kernel", "ss_compact": "ss_compact_kernel", "ss_sample": "ss_sample_", "cb_sample": "cb_sample_distinct_kernel",
          "rs_scatter:keys": "rs_scatter_kernel_t<512, 8, false, 0, 8>", "rs_hist": "rs_hist_kernel", "cb_insert": "cb_insert_",
          "build_keys": "build_keys_kernel", "seg_reduce:molecules": "seg_reduce_kernel<ReadsToMoleculesX<0>",
          "seg_reduce:cell_gene": "seg_reduce_kernel<MoleculesToCellGeneX>", "seg_reduce:cells": "seg_reduce_kernel<CellGeneToCells>",
