@@ -1094,7 +1094,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 		if (const char *e = getenv("DROPEST_CG_DBG")) g.dbg = u32(atoi(e));
 		timed("ss_compact:cell_gene", double(n_mol) * (16 + 24) + double(n_cg) * 36, [&] {
 			hipLaunchKernelGGL(ss_cg_zero_borders_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, g);
-			hipLaunchKernelGGL(ss_compact_cg_kernel, dim3(div_up(F2, 4)), dim3(256), 0, stream, g);
+			hipLaunchKernelGGL(ss_compact_cg_kernel<false>, dim3(div_up(F2, 4)), dim3(256), 0, stream, g);
 		});
 		HIP_CHECK(hipMemcpyAsync(cg_mol_begin.p + n_cg, &n_mol, 4, hipMemcpyHostToDevice, stream));   // row i owns molecules [cg_mol_begin[i], cg_mol_begin[i + 1])
 		cg_from_sort = true;

@@ -853,11 +853,54 @@ ResultsPrinter::SparseMatrix ResultsPrinter::get_count_matrix(const CellsDataCon
 	// the dgCMatrix slots i / x (ResultsPrinter.cpp:433-442).  The library sends a large matrix over PCIe as bytes (2 per entry instead of 8)
 	// and widens it into these slots on its host threads while the copy is still running; a matrix whose sparse columns do not suit the byte
 	// form comes as 32-bit arrays directly -- either way this call cannot fail for the shape of the data.
+	// walk_byte_form: the named matrix is built straight from the bytes that crossed PCIe (this thread decodes each column as it names it);
+	// no u32 arrays in between and no decode threads of the library involved.  A matrix the byte form refuses comes as 32-bit arrays.
+	if (walk_byte_form) {
+		dropest_matrix_bytes B{};
+		const dropest_status st = dropest_count_matrix_csc_bytes(c.handle(), filtered ? 1 : 0, reads_output ? 1 : 0, &B);
+		if (st == DROPEST_OK) return named_matrix(c, filtered, reference_row_order, ColumnSource(B));
+		if (st != DROPEST_ERR_UNSUPPORTED) throw std::runtime_error(dropest_last_error());
+	}
 	uint64_t ncols = 0, nnz = 0;
 	const uint32_t *colptr = nullptr, *rowidx = nullptr, *values = nullptr;
 	if (dropest_count_matrix_csc(c.handle(), filtered ? 1 : 0, reads_output ? 1 : 0, &ncols, &nnz, &colptr, &rowidx, &values) != DROPEST_OK)
 		throw std::runtime_error(dropest_last_error());
 	return named_matrix(c, filtered, reference_row_order, ncols, nnz, colptr, rowidx, values);
+}
+
+// the entries of one column, from either form of the matrix
+ResultsPrinter::ColumnSource::ColumnSource(const dropest_matrix_bytes &B) : ncols(B.ncols), nnz(B.nnz), colptr(B.colptr), bytes(&B) {
+	// the device appends to the lists as it goes: ordered by position here, once
+	row_listed.reserve(B.n_row_listed); value_listed.reserve(B.n_value_listed);
+	for (uint64_t k = 0; k < B.n_row_listed; ++k) row_listed.emplace_back(B.row_listed_pos[k], B.row_listed_row[k]);
+	for (uint64_t k = 0; k < B.n_value_listed; ++k) value_listed.emplace_back(B.value_listed_pos[k], B.value_listed_value[k]);
+	std::sort(row_listed.begin(), row_listed.end());
+	std::sort(value_listed.begin(), value_listed.end());
+}
+
+void ResultsPrinter::ColumnSource::column(uint64_t col, std::vector<std::pair<uint32_t, uint32_t>> &out) const {
+	out.clear();
+	const uint32_t b = colptr[col], e = colptr[col + 1];
+	if (!bytes) {
+		for (uint32_t k = b; k < e; ++k) out.emplace_back(rowidx[k], values[k]);
+		return;
+	}
+	auto rl = std::lower_bound(row_listed.begin(), row_listed.end(), std::make_pair(b, 0u));
+	auto vl = std::lower_bound(value_listed.begin(), value_listed.end(), std::make_pair(b, 0u));
+	uint32_t row = 0xFFFFFFFFu;   // deltas count from row -1 (dropest_amd.h: dropest_matrix_bytes)
+	for (uint32_t k = b; k < e; ++k) {
+		const uint8_t d = bytes->row_delta[k], v = bytes->value[k];
+		if (d == 255) {
+			if (rl == row_listed.end() || rl->first != k) throw std::runtime_error("byte-form matrix: a listed row is missing from the list");
+			row = (rl++)->second;
+		} else row += d;
+		uint32_t val = v;
+		if (v == 255) {
+			if (vl == value_listed.end() || vl->first != k) throw std::runtime_error("byte-form matrix: a listed value is missing from the list");
+			val = (vl++)->second;
+		}
+		out.emplace_back(row, val);
+	}
 }
 
 static std::string levels_code(const UMI::Mark::query_t &query) {   // inverse of UMI::Mark::get_by_code (UMI.cpp:112-154)
@@ -898,6 +941,14 @@ ResultsPrinter::SparseMatrix ResultsPrinter::sharded_matrix(const CellsDataConta
 ResultsPrinter::SparseMatrix ResultsPrinter::named_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order, uint64_t ncols,
                                                           uint64_t nnz, const uint32_t *colptr, const uint32_t *rowidx, const uint32_t *values,
                                                           const std::vector<std::string> *col_names) const {
+	return named_matrix(c, filtered, reference_row_order, ColumnSource(ncols, nnz, colptr, rowidx, values), col_names);
+}
+
+ResultsPrinter::SparseMatrix ResultsPrinter::named_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order, const ColumnSource &src,
+                                                          const std::vector<std::string> *col_names) const {
+	const uint64_t ncols = src.ncols, nnz = src.nnz;
+	const uint32_t *colptr = src.colptr;
+	std::vector<std::pair<uint32_t, uint32_t>> entries;   // (gene, value) of the column at hand
 	SparseMatrix M;
 	// column names: filtered cells in their order / real cells in cell-id order
 	if (col_names) M.col_names = *col_names;
@@ -909,7 +960,7 @@ ResultsPrinter::SparseMatrix ResultsPrinter::named_matrix(const CellsDataContain
 		for (auto const &r : rows) if (r.is_real) M.col_names.push_back(c.decode(r.barcode));
 	}
 	M.colptr.assign(colptr, colptr + ncols + 1);
-	M.values.assign(values, values + nnz);
+	M.values.resize(nnz);
 	M.rowidx.resize(nnz);
 	const auto &genes = c.gene_indexer().values();
 	std::vector<uint32_t> row_of_gene(genes.size(), 0xFFFFFFFFu);
@@ -920,24 +971,30 @@ ResultsPrinter::SparseMatrix ResultsPrinter::named_matrix(const CellsDataContain
 	if (!reference_row_order) {
 		// rows = genes that occur, in gene-index order
 		std::vector<char> seen(genes.size(), 0);
-		for (uint64_t k = 0; k < nnz; ++k) seen[rowidx[k]] = 1;
+		for (uint64_t col = 0; col < ncols; ++col) {   // (gene ids land in the slots first, their rows replace them below)
+			src.column(col, entries);
+			uint32_t k = colptr[col];
+			for (auto const &e : entries) { seen[e.first] = 1; M.rowidx[k] = e.first; M.values[k] = e.second; ++k; }
+		}
 		for (uint32_t g = 0; g < genes.size(); ++g) if (seen[g]) row_id(g);
-		for (uint64_t k = 0; k < nnz; ++k) M.rowidx[k] = row_of_gene[rowidx[k]];
+		for (uint64_t k = 0; k < nnz; ++k) M.rowidx[k] = row_of_gene[M.rowidx[k]];
 		return M;
 	}
 	// the reference numbers rows on first encounter while walking, per cell, an unordered_map<string,size_t> that was
 	// filled in gene-index order (filtered: Cell.cpp:54-68) -- replayed here with the same container type; the raw
 	// matrix walks the std::map directly (gene-index order, ResultsPrinter.cpp:376-387).  Inside a column the entries
 	// are then sorted by row id (Eigen::setFromTriplets builds a CSC with ascending inner indices).
+	std::vector<std::pair<uint32_t, uint32_t>> of_col;
 	for (uint64_t col = 0; col < ncols; ++col) {
-		std::vector<std::pair<uint32_t, uint32_t>> entries;   // (row, value)
+		src.column(col, of_col);
+		entries.clear();   // (row, value)
 		if (filtered) {
 			std::unordered_map<std::string, size_t> per_gene;
 			std::unordered_map<std::string, uint32_t> gene_of;
-			for (uint32_t k = colptr[col]; k < colptr[col + 1]; ++k) { per_gene.emplace(genes[rowidx[k]], values[k]); gene_of.emplace(genes[rowidx[k]], rowidx[k]); }
+			for (auto const &e : of_col) { per_gene.emplace(genes[e.first], e.second); gene_of.emplace(genes[e.first], e.first); }
 			for (auto const &kv : per_gene) entries.emplace_back(row_id(gene_of.at(kv.first)), uint32_t(kv.second));
 		} else {
-			for (uint32_t k = colptr[col]; k < colptr[col + 1]; ++k) entries.emplace_back(row_id(rowidx[k]), values[k]);
+			for (auto const &e : of_col) entries.emplace_back(row_id(e.first), e.second);
 		}
 		std::sort(entries.begin(), entries.end());
 		for (uint32_t k = colptr[col], j = 0; k < colptr[col + 1]; ++k, ++j) { M.rowidx[k] = entries[j].first; M.values[k] = entries[j].second; }
@@ -967,7 +1024,11 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 	using namespace Rds;
 	// both matrices are part of the list: cm_raw's emit + copy to the host start now, on the device's second stream, and
 	// run under the cell rows and cm (a sharded container has assembled both already)
-	if (!c.sharded() && dropest_prefetch_raw_matrix(c.handle(), reads_output ? 1 : 0) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+	if (!c.sharded()) {
+		dropest_status st = walk_byte_form ? dropest_prefetch_raw_matrix_bytes(c.handle(), reads_output ? 1 : 0) : DROPEST_ERR_UNSUPPORTED;
+		if (st == DROPEST_ERR_UNSUPPORTED) st = dropest_prefetch_raw_matrix(c.handle(), reads_output ? 1 : 0);
+		if (st != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+	}
 	const std::vector<Cell> real = c.real_cells();                      // cell-id order (sharded: of ONE container over the stream)
 	const std::vector<size_t> filtered_at = c.filtered_positions(real);
 	std::vector<std::string> real_names;

@@ -479,6 +479,9 @@ public:
 	};
 	ResultsPrinter(bool write_matrix_, bool reads_output_, bool /*validation_stats*/ = false, bool umi_correction_info_ = false)
 		: write_matrix(write_matrix_), reads_output(reads_output_), umi_correction_info(umi_correction_info_) {}
+	// get_count_matrix / save_mtx / save_results name the matrix straight from the byte form that crossed PCIe (two bytes per entry, decoded
+	// column by column on the calling thread) instead of from the 32-bit slots; false takes the slots (dropest_count_matrix_csc)
+	bool walk_byte_form = true;
 	// reference_row_order = true reproduces the row order of the reference's dgCMatrix (rows numbered on first
 	// encounter while iterating an unordered_map per cell, Cell.cpp:54-68 + ResultsPrinter.cpp:345-355); false keeps
 	// rows in gene-index order.
@@ -489,8 +492,20 @@ public:
 	// <base>.matrices.rds: list(exon, intron, spanning) of dgCMatrix (-V, ResultsPrinter.cpp:455-474)
 	void save_intron_exon_matrices(const CellsDataContainer &container, const std::string &filename) const;
 private:
+	// where a column's (gene id, count) entries come from: the 32-bit arrays, or the byte form walked directly (dropest_matrix_bytes)
+	struct ColumnSource {
+		uint64_t ncols = 0, nnz = 0;
+		const uint32_t *colptr = nullptr, *rowidx = nullptr, *values = nullptr;
+		const dropest_matrix_bytes *bytes = nullptr;
+		std::vector<std::pair<uint32_t, uint32_t>> row_listed, value_listed;   // (entry position, exact row / value), ascending
+		ColumnSource(uint64_t ncols_, uint64_t nnz_, const uint32_t *cp, const uint32_t *ri, const uint32_t *v) : ncols(ncols_), nnz(nnz_), colptr(cp), rowidx(ri), values(v) {}
+		explicit ColumnSource(const dropest_matrix_bytes &B);
+		void column(uint64_t col, std::vector<std::pair<uint32_t, uint32_t>> &out) const;
+	};
 	SparseMatrix named_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order, uint64_t ncols, uint64_t nnz,
 	                          const uint32_t *colptr, const uint32_t *rowidx, const uint32_t *values,
+	                          const std::vector<std::string> *col_names = nullptr) const;
+	SparseMatrix named_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order, const ColumnSource &src,
 	                          const std::vector<std::string> *col_names = nullptr) const;
 	SparseMatrix sharded_matrix(const CellsDataContainer &c, bool filtered, bool reference_row_order) const;
 public:

@@ -752,7 +752,38 @@ struct SsCompactCgArgs {
 	int umi_bits;
 	uint32_t query_mask, n_cg;
 	uint32_t dbg;            // timing probes (DROPEST_CG_DBG; results unusable): 1 no segmented sums, 2 no (cell, gene) output, 4 no molecule rows
+	// the re-keyed form (ss_compact_cg_kernel<true>, after a merge): the rows are the sorted (new key, old row) pairs of the molecule table, equal
+	// keys fold into one molecule (reads add, marks OR: Gene::merge / UMI::merge, Gene.cpp:26-58, UMI.cpp:15-19) on the way.  A "bucket" is then a
+	// tile of tile_rows pairs whose ends are moved forward to the next change of key (rk_tile_begin), n_loc is unused, prefix / cg_cnt / cg_prefix
+	// come from rk_counts_kernel + the scans.
+	const unsigned long long *rk_key;
+	const uint32_t *rk_idx, *old_reads, *old_mark, *old_exon, *old_intron;   // (old_exon / old_intron may be null: no exon / intron counts kept)
+	uint32_t n_rows, tile_rows;
 };
+// first row of tile t of the re-keyed pairs: t * tile_rows moved forward until a new key starts there (no molecule straddles two tiles)
+__device__ __forceinline__ uint32_t rk_tile_begin(const unsigned long long *__restrict__ key, uint32_t n, uint32_t tile_rows, uint32_t t) {
+	const unsigned long long x64 = (unsigned long long)t * tile_rows;
+	if (x64 >= n) return n;
+	uint32_t x = uint32_t(x64);
+	while (x && x < n && key[x] == key[x - 1]) ++x;
+	return x;
+}
+// per tile: the molecules (key heads) and the (cell, gene) heads in it; one wave per tile
+__global__ __launch_bounds__(256) void rk_counts_kernel(const unsigned long long *__restrict__ key, uint32_t n, uint32_t tile_rows, int umi_bits, uint32_t n_tiles,
+                                                        uint32_t *__restrict__ mol_cnt, uint32_t *__restrict__ cg_cnt) {
+	const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (t >= n_tiles) return;
+	const uint32_t s = rk_tile_begin(key, n, tile_rows, t), e = rk_tile_begin(key, n, tile_rows, t + 1);
+	uint32_t m = 0, c = 0;
+	for (uint32_t r = s + lane; r < e; r += 64) {
+		const unsigned long long k = __builtin_nontemporal_load(key + r), pk = r ? key[r - 1] : ~k;
+		m += k != pk;
+		c += r == 0 || (k >> umi_bits) != (pk >> umi_bits);
+	}
+#pragma unroll
+	for (int d = 32; d; d >>= 1) { m += uint32_t(__shfl_down(int(m), d, 64)); c += uint32_t(__shfl_down(int(c), d, 64)); }
+	if (lane == 0) { mol_cnt[t] = m; cg_cnt[t] = c; }
+}
 // The rows the fused kernel adds into with atomics -- the last (cell, gene) run of every bucket (the next bucket may continue it) -- and the
 // sentinel row behind the table are cleared first; every other row is written with plain stores.
 __global__ __launch_bounds__(256) void ss_cg_zero_borders_kernel(SsCompactCgArgs a) {
@@ -762,28 +793,39 @@ __global__ __launch_bounds__(256) void ss_cg_zero_borders_kernel(SsCompactCgArgs
 		for (int c = 0; c < 6; ++c) a.out[c][a.n_cg] = 0;
 	}
 	if (b >= a.n_buckets || !a.cg_cnt[b]) return;
-	const uint32_t row = a.cg_prefix[b] + a.cg_cnt[b] - 1;
+	const uint32_t row = a.cg_prefix[b] + a.cg_cnt[b] - 1;   // (buckets or tiles alike)
 #pragma unroll
 	for (int c = 0; c < 6; ++c) a.out[c][row] = 0;
 }
 // One wave per bucket.  The (cell, gene) rows a wave completes go through a ring in LDS (128 rows per wave) and leave 64 rows at a time,
 // one row per lane: whole lines on all eight output arrays.  (Written straight from the lanes where the runs end -- about every second
 // lane -- the same rows cost 0.93 ms per 1e8 reads instead of ~0.3: half-filled store instructions, partial lines.)
+template <bool RK>
 __global__ __launch_bounds__(256) void ss_compact_cg_kernel(SsCompactCgArgs a) {
 	constexpr uint32_t RING = 128;
 	__shared__ unsigned long long s_key[4][RING];
 	__shared__ uint32_t s_begin[4][RING], s_v[4][6][RING];
 	const uint32_t w = threadIdx.x >> 6, b = blockIdx.x * 4 + w, lane = threadIdx.x & 63u;
 	if (b >= a.n_buckets) return;
-	const uint32_t n = a.n_loc[b];
-	if (!n) return;
-	const uint32_t src = a.bucket_base[b], dst = a.prefix[b], cgp = a.cg_prefix[b], runs_total = a.cg_cnt[b];
-	const uint32_t head0 = runs_total - a.cg_loc[b];
+	uint32_t n, src, head0;
+	const uint32_t dst = a.prefix[b], cgp = a.cg_prefix[b], runs_total = a.cg_cnt[b];
+	if constexpr (RK) {
+		src = rk_tile_begin(a.rk_key, a.n_rows, a.tile_rows, b);
+		n = rk_tile_begin(a.rk_key, a.n_rows, a.tile_rows, b + 1) - src;
+		if (!n) return;
+		head0 = src == 0 || (a.rk_key[src - 1] >> a.umi_bits) != (a.rk_key[src] >> a.umi_bits);
+	} else {
+		n = a.n_loc[b];
+		if (!n) return;
+		src = a.bucket_base[b];
+		head0 = runs_total - a.cg_loc[b];
+	}
 	const unsigned long long le = lane == 63u ? ~0ull : ((2ull << lane) - 1ull);   // lanes <= this one
 	// the (cell, gene) run that is open at the end of the previous 64 rows: its sums so far (wave-uniform), run_base = heads seen before this chunk
 	// (run id r: 0 = the run the previous bucket left open, else the r-th head of this bucket; its row = cgp + r - 1)
 	uint32_t carry[6] = {0, 0, 0, 0, 0, 0}, run_base = 0, flushed = 0;   // flushed: rows of this bucket already written out (rows 0 .. flushed - 1)
-	unsigned long long prev_cg = 0;
+	uint32_t m_base = 0;   // (re-keyed form) molecules of this tile before the chunk
+	unsigned long long prev_key = 0;
 	// the sums of a run that has ended: the run the previous bucket left open (r = 0) and this bucket's last run (which the next bucket may
 	// continue) are added into their rows with atomics; every other run goes to the ring
 	auto emit = [&](uint32_t r, bool border, const uint32_t (&v)[6]) {
@@ -800,16 +842,38 @@ __global__ __launch_bounds__(256) void ss_compact_cg_kernel(SsCompactCgArgs a) {
 	for (uint32_t j0 = 0; j0 < n; j0 += 64) {
 		const uint32_t j = j0 + lane;
 		const bool valid = j < n;
-		unsigned long long key = 0; uint32_t reads = 0, agg = 0;
-		if (valid) { key = a.t_key[size_t(src) + j]; reads = a.t_reads[size_t(src) + j]; agg = a.t_agg[size_t(src) + j]; }
-		const uint32_t exon = (agg >> 1) & 0x7FFFu, intron = (agg >> 16) & 0x7FFFu, mark = (agg & 1u) | (exon ? 2u : 0u) | (intron ? 4u : 0u);
-		if (valid && !(a.dbg & 4u)) {
-			a.mol_key[size_t(dst) + j] = key; a.mol_reads[size_t(dst) + j] = reads; a.mol_mark[size_t(dst) + j] = mark;
-			a.mol_exon[size_t(dst) + j] = exon; a.mol_intron[size_t(dst) + j] = intron;
+		unsigned long long key = 0; uint32_t reads = 0, exon = 0, intron = 0, mark = 0;
+		if constexpr (RK) { if (valid) key = a.rk_key[size_t(src) + j]; }
+		else if (valid) key = a.t_key[size_t(src) + j];
+		unsigned long long before_key = (unsigned long long)__shfl_up((long long)key, 1, 64);
+		if (lane == 0) before_key = prev_key;
+		bool counts = valid;    // the row is a molecule of the output (re-keyed form: the first row of a run of equal keys, which takes the others in)
+		uint32_t mi = j;        // its place in the bucket's / tile's part of the molecule table
+		if constexpr (RK) {
+			counts = valid && (j == 0 || key != before_key);
+			const unsigned long long mm = __ballot(counts);
+			mi = m_base + uint32_t(__popcll(mm & le)) - 1u;
+			m_base += uint32_t(__popcll(mm));
+			if (counts) {
+				uint32_t o = a.rk_idx[size_t(src) + j];
+				reads = a.old_reads[o]; mark = a.old_mark[o];
+				if (a.old_exon) { exon = a.old_exon[o]; intron = a.old_intron[o]; }
+				for (uint32_t q = j + 1; q < n && a.rk_key[size_t(src) + q] == key; ++q) {
+					o = a.rk_idx[size_t(src) + q];
+					reads += a.old_reads[o]; mark |= a.old_mark[o];
+					if (a.old_exon) { exon += a.old_exon[o]; intron += a.old_intron[o]; }
+				}
+			}
+		} else {
+			uint32_t agg = 0;
+			if (valid) { reads = a.t_reads[size_t(src) + j]; agg = a.t_agg[size_t(src) + j]; }
+			exon = (agg >> 1) & 0x7FFFu; intron = (agg >> 16) & 0x7FFFu; mark = (agg & 1u) | (exon ? 2u : 0u) | (intron ? 4u : 0u);
 		}
-		const unsigned long long cg = key >> a.umi_bits;
-		unsigned long long before = (unsigned long long)__shfl_up((long long)cg, 1, 64);
-		if (lane == 0) before = prev_cg;
+		if (counts && !(a.dbg & 4u)) {
+			a.mol_key[size_t(dst) + mi] = key; a.mol_reads[size_t(dst) + mi] = reads; a.mol_mark[size_t(dst) + mi] = mark;
+			if (!RK || a.mol_exon) { a.mol_exon[size_t(dst) + mi] = exon; a.mol_intron[size_t(dst) + mi] = intron; }
+		}
+		const unsigned long long cg = key >> a.umi_bits, before = before_key >> a.umi_bits;
 		const bool head = valid && (j == 0 ? head0 != 0 : cg != before);
 		const unsigned long long hm = __ballot(head), vm = __ballot(valid);
 		const unsigned long long mine = hm & le;
@@ -817,7 +881,7 @@ __global__ __launch_bounds__(256) void ss_compact_cg_kernel(SsCompactCgArgs a) {
 		const uint32_t start = mine ? 63u - uint32_t(__builtin_clzll(mine)) : 0u;   // first lane of this lane's run inside the chunk
 		const uint32_t req = (a.query_mask >> (mark & 7u)) & 1u;
 		// segmented inclusive sums over the lanes of one run: n_all | n_req << 16 (at most 64 each per chunk), reads, requested reads, exon, intron
-		uint32_t t[5] = {valid ? 1u | (req << 16) : 0u, valid ? reads : 0u, (valid && req) ? reads : 0u, valid ? exon : 0u, valid ? intron : 0u};
+		uint32_t t[5] = {counts ? 1u | (req << 16) : 0u, counts ? reads : 0u, (counts && req) ? reads : 0u, counts ? exon : 0u, counts ? intron : 0u};
 		if (!(a.dbg & 1u))
 #pragma unroll
 		for (uint32_t dlt = 1; dlt < 64; dlt <<= 1) {
@@ -833,8 +897,8 @@ __global__ __launch_bounds__(256) void ss_compact_cg_kernel(SsCompactCgArgs a) {
 		// the run that was open at the end of the previous chunk ended there if this chunk starts with a head: lane 0 hands it on
 		if (j0 && lane == 0 && head) emit(run_base, run_base == 0, carry);
 		if (head && !(a.dbg & 2u)) {
-			if (r == runs_total) { a.cg_key[cgp + r - 1u] = cg; a.cg_mol_begin[cgp + r - 1u] = dst + j; }   // the bucket's last run never passes the ring
-			else { s_key[w][(r - 1u) & (RING - 1u)] = cg; s_begin[w][(r - 1u) & (RING - 1u)] = dst + j; }
+			if (r == runs_total) { a.cg_key[cgp + r - 1u] = cg; a.cg_mol_begin[cgp + r - 1u] = dst + mi; }   // the bucket's last run never passes the ring
+			else { s_key[w][(r - 1u) & (RING - 1u)] = cg; s_begin[w][(r - 1u) & (RING - 1u)] = dst + mi; }
 		}
 		const bool next_valid = lane < 63u && ((vm >> (lane + 1u)) & 1ull), next_head = lane < 63u && ((hm >> (lane + 1u)) & 1ull);
 		const bool last_row = valid && j == n - 1u;
@@ -843,7 +907,7 @@ __global__ __launch_bounds__(256) void ss_compact_cg_kernel(SsCompactCgArgs a) {
 #pragma unroll
 		for (int c = 0; c < 6; ++c) carry[c] = uint32_t(__shfl(int(tot[c]), 63, 64));
 		run_base += uint32_t(__popcll(hm));
-		prev_cg = (unsigned long long)__shfl((long long)cg, 63, 64);
+		prev_key = (unsigned long long)__shfl((long long)key, 63, 64);
 		// rows complete: the runs before the open one, and never the bucket's last run (run ids 1 .. done are rows 0 .. done - 1)
 		const bool final = j0 + 64 >= n;
 		uint32_t done = run_base ? run_base - 1u : 0u;

@@ -857,7 +857,48 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask, bool sorted_already) {
 	u32 *vals = vals_a.p, *vals_alt = vals_b.p;
 	if (!sorted_already && !resort_changed_rows(varying_mask)) radix_sort(keys, vals, keys_alt, vals_alt, n_mol, varying_mask);
 	u32 new_n = 0;
-	if (chr_from_gene) {
+	// fold + (cell, gene) rows in one pass over the sorted pairs (k_ssort.h: ss_compact_cg_kernel<true>) instead of seg_count + seg_reduce twice
+	const bool fused_fold = getenv("DROPEST_NO_FUSED_FOLD") == nullptr && n_mol != 0;
+	if (fused_fold) {
+		constexpr u32 T = 4096;
+		const u32 tiles = div_up(n_mol, T), n_chunks = div_up(tiles, 1024u);
+		ss_n_loc.ensure(tiles); ss_prefix.ensure(tiles); ss_cg_cnt.ensure(tiles); ss_cg_prefix.ensure(tiles); ss_chunk.ensure(1024); scalars.ensure(16);
+		timed("fold_counts", double(n_mol) * 8, [&] {
+			hipLaunchKernelGGL(rk_counts_kernel, dim3(div_up(tiles, 4u)), dim3(256), 0, stream, keys, n_mol, T, layout.umi_bits, tiles, ss_n_loc.p, ss_cg_cnt.p);
+			hipLaunchKernelGGL(ss_chunk_sums_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_n_loc.p, tiles, ss_chunk.p);
+			hipLaunchKernelGGL(ss_prefix_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_n_loc.p, tiles, ss_chunk.p, n_chunks, ss_prefix.p, scalars.p + 1);
+			hipLaunchKernelGGL(ss_chunk_sums_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_cg_cnt.p, tiles, ss_chunk.p);
+			hipLaunchKernelGGL(ss_prefix_kernel<1024>, dim3(n_chunks), dim3(1024), 0, stream, ss_cg_cnt.p, tiles, ss_chunk.p, n_chunks, ss_cg_prefix.p, scalars.p + 2);
+		});
+		u32 totals[2] = {0, 0};
+		fetch(totals, scalars.p + 1, 8);
+		new_n = totals[0];
+		const u32 new_cg = totals[1];
+		const size_t cap = std::max<size_t>(size_t(new_n) + 1, mol_key.n);   // (the twins keep the capacity of the tables they are swapped with, see below)
+		mol_key2.ensure(cap); mol_reads2.ensure(cap); mol_mark2.ensure(cap);
+		if (chr_from_gene) { mol_exon2.ensure(cap); mol_intron2.ensure(cap); }
+		cg_key.ensure(size_t(new_cg) + 1); cg_mol_begin.ensure(size_t(new_cg) + 1);
+		for (DevBuf<u32> *b : {&cg_n_all, &cg_n_req, &cg_reads_all, &cg_reads_req, &cg_exon, &cg_intron}) b->ensure(size_t(new_cg) + 1);
+		SsCompactCgArgs g{};
+		g.prefix = ss_prefix.p; g.cg_cnt = ss_cg_cnt.p; g.cg_prefix = ss_cg_prefix.p; g.n_buckets = tiles;
+		g.rk_key = keys; g.rk_idx = vals; g.n_rows = n_mol; g.tile_rows = T;
+		g.old_reads = mol_reads.p; g.old_mark = mol_mark.p;
+		if (chr_from_gene) { g.old_exon = mol_exon.p; g.old_intron = mol_intron.p; g.mol_exon = mol_exon2.p; g.mol_intron = mol_intron2.p; }
+		g.mol_key = mol_key2.p; g.mol_reads = mol_reads2.p; g.mol_mark = mol_mark2.p;
+		g.cg_key = cg_key.p; g.cg_mol_begin = cg_mol_begin.p;
+		g.out[0] = cg_n_all.p; g.out[1] = cg_n_req.p; g.out[2] = cg_reads_all.p; g.out[3] = cg_reads_req.p; g.out[4] = cg_exon.p; g.out[5] = cg_intron.p;
+		g.umi_bits = layout.umi_bits; g.query_mask = query_mask; g.n_cg = new_cg;
+		timed("fold:cell_gene", double(n_mol) * (12 + (chr_from_gene ? 16 : 8)) + double(new_n) * (chr_from_gene ? 24 : 16) + double(new_cg) * 36, [&] {
+			hipLaunchKernelGGL(ss_cg_zero_borders_kernel, dim3(div_up(tiles, 256u)), dim3(256), 0, stream, g);
+			hipLaunchKernelGGL(ss_compact_cg_kernel<true>, dim3(div_up(tiles, 4u)), dim3(256), 0, stream, g);
+		});
+		HIP_CHECK(hipMemcpyAsync(cg_mol_begin.p + new_cg, &new_n, 4, hipMemcpyHostToDevice, stream));   // row i owns molecules [cg_mol_begin[i], cg_mol_begin[i + 1])
+		for (DevBuf<u32> *b : {&mol_reads2, &mol_mark2}) HIP_CHECK(hipMemsetAsync(b->p + new_n, 0, 4, stream));   // sentinel row
+		if (chr_from_gene) for (DevBuf<u32> *b : {&mol_exon2, &mol_intron2}) HIP_CHECK(hipMemsetAsync(b->p + new_n, 0, 4, stream));
+		HIP_CHECK(stream_wait(stream));   // (new_n is a stack word)
+		if (chr_from_gene) { std::swap(mol_exon, mol_exon2); std::swap(mol_intron, mol_intron2); }
+		n_cg = new_cg;
+	} else if (chr_from_gene) {
 		RekeyedToMoleculesX p{};
 		p.keys = keys; p.idx = vals; p.old_reads = mol_reads.p; p.old_mark = mol_mark.p; p.old_exon = mol_exon.p; p.old_intron = mol_intron.p;
 		new_n = run_segmented_reduce(*this, "molecules_rekeyed", p, n_mol, 12 + 16, [&](u32 total) {
@@ -884,7 +925,7 @@ void dropest_ctx::reaggregate_from_keys(u64 varying_mask, bool sorted_already) {
 	requality_after_fold(keys, vals, n_mol, mol_key2.p, new_n);
 	std::swap(mol_key, mol_key2); std::swap(mol_reads, mol_reads2); std::swap(mol_mark, mol_mark2);
 	n_mol = new_n;
-	reduce_molecules_to_cell_gene();
+	if (!fused_fold) reduce_molecules_to_cell_gene();
 	reduce_cell_gene_to_cells();
 	HIP_CHECK(stream_wait(stream));
 	refresh_real_rows();

@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ / TCC counters of selected kernels over one set_initialized at C2 size (separate --pmc passes, kernel-trace only).
 # usage on the GPU box: bash scripts/pmc_kernels.sh "cb_insert|build_keys|ss_local"
+# PMC_CMD="python bench.py --config c3 --reads 1e9 --steps 1 --warmup 0 --cpu-sample 0 --no-secondary" takes the counters over another command (C3 size)
 set -u
 PAT=${1:-cb_insert}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -13,7 +14,8 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM" \
            "TCC_HIT_sum TCC_MISS_sum TCC_ATOMIC_sum TCC_EA0_RDREQ_sum" "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_EA0_WRREQ_sum" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  VARIANTS=0 timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/p$i -o r -- python $R/scripts/ss_probe.py > $OUT/p$i.log 2>&1
+  rm -rf $OUT/p$i
+  (cd $R && VARIANTS=0 timeout 600 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/p$i -o r -- ${PMC_CMD:-python $R/scripts/ss_probe.py} > $OUT/p$i.log 2>&1)
 done
 cd $R
 python - "$PAT" <<'PY'

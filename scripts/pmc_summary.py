@@ -85,7 +85,7 @@ def main():
     copies = sum(r[1] * r[5] for k, r in by.items() if k.startswith("__amd_rocclr"))
     # bench.py --steps 1 --warmup 0 runs the pass twice (the timed step + the kernel-table step): kernels launched once per
     # pass tell how many passes the trace holds
-    passes = max([v["launches"] for k, v in per_kernel.items() if k.startswith(("cb_insert_kernel", "build_keys_kernel"))] + [1])
+    passes = max([v["launches"] for k, v in per_kernel.items() if k.startswith(("cb_insert_kernel", "cb_insert_hot_kernel", "build_keys_kernel", "build_keys_scatter_kernel"))] + [1])
     total = sum(v["launches"] * v["hbm_bytes_per_launch"] for v in per_kernel.values()) / passes
     copies /= passes
     for v in per_kernel.values():

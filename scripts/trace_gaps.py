@@ -1,6 +1,8 @@
 """Idle time of the device inside one pass: from a rocprofv3 --kernel-trace CSV (kernel start / end timestamps) of a bench run, the gaps
-between consecutive kernels of the last pass, largest first, with the kernels on either side.  usage: trace_gaps.py <dir with *kernel_trace.csv>"""
-import csv, glob, sys
+between consecutive kernels of one pass (TRACE_PASS counts passes from the end: -1 = the last one, the default; bench.py --steps 2 --warmup 1
+runs warm-up, two timed steps, two table steps with HIP events around every launch: -3 is the second timed step), largest first, with the
+kernels on either side.  usage: trace_gaps.py <dir with *kernel_trace.csv> [how many of the pass's last kernels to list on a time line]"""
+import csv, glob, os, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -8,8 +10,10 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
 rows.sort()
 # the last pass: from the last cb_sample_distinct launch on
 starts = [i for i, r in enumerate(rows) if "cb_sample_distinct" in r[2]]
-lo = starts[-1]
-hi = len(rows)
+which = int(os.environ.get("TRACE_PASS", "-1"))
+lo = starts[which]
+hi = starts[which + 1] if which < -1 else len(rows)
+print("pass %d of %d in the trace" % (len(starts) + which + 1, len(starts)))
 seg = rows[lo:hi]
 busy = sum(e - s for s, e, _ in seg)
 span = max(e for _, e, _ in seg) - seg[0][0]

@@ -499,6 +499,40 @@ static void testWideKeyContainer() {
 	}
 }
 
+static void testByteFormWalk() {   // ResultsPrinter.cpp:433-442: the named matrix from the byte form directly == from the 32-bit slots
+	auto read_info = [](const std::string &cb, const std::string &umi, const std::string &gene) {
+		return ReadInfo(Tools::ReadParameters(cb, umi), gene, "chr1", Mark(Mark::HAS_EXONS));
+	};
+	auto strat = std::make_shared<Merge::RealBarcodesMergeStrategy>(Merge::RealBarcodesMergeStrategy::INDROP, g_data + "/test_est", 0, 0, 7, 0);
+	auto umis = std::make_shared<Merge::UMIs::MergeUMIsStrategySimple>(1);
+	CellsDataContainer c(strat, umis, Mark::get_by_code(Mark::DEFAULT_CODE));
+	const char *bases = "ACGT";
+	auto umi_of = [&](unsigned k) { std::string u(6, 'A'); for (int i = 0; i < 6; ++i) { u[i] = bases[k & 3]; k >>= 2; } return u; };
+	// gene ids in first-seen order: cell 1 names 1 000 genes in turn (row deltas of 1), cell 2 takes every 300th (deltas beyond a byte: listed
+	// rows) and stacks 300 UMIs / 700 reads on some of them (counts beyond a byte: listed values)
+	for (int g = 0; g < 1000; ++g) c.add_record(read_info("AAATTAGGTCCA", umi_of(unsigned(g)), "G" + std::to_string(g)));
+	for (int g = 0; g < 1000; g += 300) {
+		for (unsigned u = 0; u < (g == 300 ? 300u : 3u); ++u) c.add_record(read_info("AAATTAGGTCCC", umi_of(u * 7u + 1u), "G" + std::to_string(g)));
+		if (g == 600) for (int r = 0; r < 700; ++r) c.add_record(read_info("AAATTAGGTCCC", umi_of(5u), "G600"));
+	}
+	c.add_record(read_info("AAATTAGGTCCC", umi_of(9u), "G254")); c.add_record(read_info("AAATTAGGTCCC", umi_of(9u), "G555"));
+	c.set_initialized(); c.merge_and_filter();
+	for (bool reads_output : {false, true}) {
+		ResultsPrinter bytes(true, reads_output), slots(true, reads_output);
+		slots.walk_byte_form = false;
+		for (bool filtered : {true, false})
+			for (bool ref_order : {true, false}) {
+				const auto a = bytes.get_count_matrix(c, filtered, ref_order), b = slots.get_count_matrix(c, filtered, ref_order);
+				CHECK(a.col_names == b.col_names); CHECK(a.row_names == b.row_names);
+				CHECK(a.colptr == b.colptr); CHECK(a.rowidx == b.rowidx); CHECK(a.values == b.values);
+				CHECK_EQ(a.col_names.size(), size_t(2)); CHECK_EQ(a.values.size(), size_t(1000 + 6));
+				uint32_t top = 0;
+				for (uint32_t v : a.values) top = std::max(top, v);
+				CHECK_EQ(top, reads_output ? 703u : 300u);
+			}
+	}
+}
+
 int main(int argc, char **argv) {
 	g_data = argc > 1 ? argv[1] : "dropest_amd/data/barcodes";
 	const std::string tmp = argc > 2 ? argv[2] : "/tmp";
@@ -519,6 +553,7 @@ int main(int argc, char **argv) {
 		testMergeAndExcludeCells();
 		testShardedContainer();
 		testWideKeyContainer();
+		testByteFormWalk();
 	} catch (const std::exception &e) {
 		std::printf("UNEXPECTED EXCEPTION: %s\n", e.what());
 		return 2;
