@@ -128,6 +128,18 @@ void dropest_ctx::timed(const char *name, double bytes, F &&launch) {
 		}
 		return false;
 	};
+	// DROPEST_SYNC_TRACE=1 (hunting a device fault): every launch is named on stderr before it goes and waited for behind it -- the last
+	// name without its "done" is the kernel that faulted
+	static const bool sync_trace = getenv("DROPEST_SYNC_TRACE") != nullptr;
+	if (sync_trace) {
+		fprintf(stderr, "[launch %p] %s\n", static_cast<void *>(this), name);
+		launch();
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipStreamSynchronize(stream));
+		if (stream2) HIP_CHECK(hipStreamSynchronize(stream2));
+		fprintf(stderr, "[done   %p] %s\n", static_cast<void *>(this), name);
+		return;
+	}
 	if (!profiling || !selected()) {
 		launch(); HIP_CHECK(hipGetLastError()); return;
 	}

@@ -980,8 +980,11 @@ struct dropest_shard {
 		for (auto const &pr : c.merge_pairs) merged_barcodes.emplace_back(bc[size_t(pr.first)], bc[size_t(pr.second)]);
 		std::sort(merged_barcodes.begin(), merged_barcodes.end());
 	}
-	dropest::DevBuf<u64> d_desc;
-	dropest::PinnedBuf<u64> h_desc, h_plan;
+	// column descriptors of assemble_matrix, one set per matrix: cm_raw's (when the host plans it) are still on their way to the device --
+	// and read by its placing kernel, and kept for finish_slots -- while cm's are written (nothing waits in between since the emit does not)
+	dropest::DevBuf<u64> d_desc_m[2];
+	dropest::PinnedBuf<u64> h_desc_m[2], h_plan;
+	bool desc_in_flight[2] = {false, false};
 	dropest::DevBuf<u32> d_tmp32;
 	std::map<std::string, dropest::KernelStat> phases;
 
@@ -1760,6 +1763,8 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 	const int slot = filtered_m ? 0 : 1;
 	Mat &M = mat[slot];
 	ctx->mat[slot].settle();   // (a straggler of the previous widening reads dec_begin / dec_end)
+	dropest::DevBuf<u64> &d_desc = d_desc_m[slot];
+	dropest::PinnedBuf<u64> &h_desc = h_desc_m[slot];
 	std::vector<u32> sel;
 	for (u32 i = 0; i < G.size(); ++i) if (!filtered_m || G[i].req_genes >= c.min_after) sel.push_back(i);
 	std::vector<u32> order;
@@ -1799,9 +1804,13 @@ void dropest_shard::assemble_matrix(bool filtered_m) {
 	const u32 nc = u32(col_cell.size());
 	if (nc && local_nnz) {
 		if (!L.slots) c.emit_columns_device(filtered_m, false, col_cell, col_start, local_nnz, false);   // (a slots step emits the byte form of the local matrix: place_columns)
+		// (the same matrix assembled again inside one step -- the overflow fall-back -- or in the next step: the previous copy has left the
+		// staging buffer by then in every run seen, but nothing said so: wait, it costs nothing on a drained stream)
+		if (desc_in_flight[slot]) HIP_CHECK(stream_wait(c.stream));
 		d_desc.ensure(desc.size()); h_desc.ensure(desc.size());
 		std::memcpy(h_desc.p, desc.data(), desc.size() * 8);
 		HIP_CHECK(hipMemcpyAsync(d_desc.p, h_desc.p, desc.size() * 8, hipMemcpyHostToDevice, c.stream));
+		desc_in_flight[slot] = true;
 	}
 	Phase p3(this, filtered_m ? "cm:place" : "raw:place");
 	place_columns(M, slot, filtered_m, L, d_desc.p, nc, local_nnz, nullptr, col_start.data());
@@ -1826,7 +1835,7 @@ dropest_shard::SharedLayout dropest_shard::open_shared(Mat &M, int slot, size_t 
 	if (L.slots) L.bytes = false;
 	L.off_slots = (L.base + 63) & ~size_t(63);   // (from the buffer's start: that is page-aligned)
 	L.slots_stride = ((size_t(M.nnz) + 15) & ~size_t(15)) * 4;
-	const size_t payload = L.slots ? L.off_slots - L.base + 2 * L.slots_stride
+	const size_t payload = L.slots ? L.off_slots - L.base + std::max<size_t>(2 * L.slots_stride, 64)   // (an empty matrix still gets a buffer: the transports map what they are asked for)
 	                               : (L.bytes ? L.off_seg + L.seg_bytes * size_t(world) : std::max<size_t>(size_t(M.nnz), 1) * (L.narrow ? 4 : 8));
 	ctx->mat[slot].settle();   // (a straggler of the previous step's widening may still be leaving: the buffer is about to be rewritten or replaced)
 	L.host = static_cast<char *>(tr->shared_host(slot, L.base + payload, &L.dev));
@@ -2002,7 +2011,7 @@ void dropest_shard::assemble_raw_device() {
 	}
 	// this shard's (first-read ordinal [nl] | nnz prefix [nl + 1])
 	d_plan_mine.ensure(2 * size_t(nl) + 1); d_q.ensure(std::max<u32>(nl, 1)); d_col_cell.ensure(std::max<u32>(nl, 1));
-	h_plan.ensure(size_t(nl) + 1 + size_t(nl));   // staging of its own (cm's descriptors may still be on their way from h_desc): prefix (u64) | queries, cells (u32)
+	h_plan.ensure(size_t(nl) + 1 + size_t(nl));   // staging of its own (cm's descriptors may still be on their way from their staging buffer): prefix (u64) | queries, cells (u32)
 	std::memcpy(h_plan.p, P.pre.data(), (size_t(nl) + 1) * 8);
 	u32 *h32 = reinterpret_cast<u32 *>(h_plan.p + nl + 1);
 	if (nl) { std::memcpy(h32, P.query.data(), size_t(nl) * 4); std::memcpy(h32 + nl, P.col_cell.data(), size_t(nl) * 4); }

@@ -8,7 +8,7 @@ mkdir -p $OUT
 export PYTHONPATH=$R TMPDIR=/tmp
 CMD="python $R/bench.py --config c3 --reads 1e9 --steps 2 --warmup 1 --cpu-sample 0 --no-secondary"
 (cd $R && timeout 900 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o r -- $CMD > $OUT/bench_under_trace.json 2> $OUT/kt.err)
-TRACE_PASS=-3 python $R/scripts/trace_gaps.py $OUT/kt 40 > $OUT/gaps.txt 2>&1
+TRACE_PASS=2 python $R/scripts/trace_gaps.py $OUT/kt 40 > $OUT/gaps.txt 2>&1
 rm -rf $OUT/kt
 PMC_CMD="python $R/bench.py --config c3 --reads 1e9 --steps 1 --warmup 0 --cpu-sample 0 --no-secondary" bash $R/scripts/pmc_kernels.sh "cb_insert|build_keys|ss_scatter_res|ss_local_kernel|ss_compact_cg" > $OUT/sq_counters.txt 2>&1
 rm -rf $R/gpurun_out/pmc

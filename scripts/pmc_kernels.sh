@@ -29,6 +29,12 @@ for f in glob.glob("gpurun_out/pmc/p*/**/*counter_collection.csv", recursive=Tru
             agg[re.sub(r"\(.*", "", k)[:60]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in agg.items():
     print(k)
+    m = {c: sum(v) / len(v) for c, v in d.items()}
+    if all(c in m for c in ("SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_LDS_BANK_CONFLICT", "GRBM_GUI_ACTIVE")):
+        wc = m["SQ_WAVE_CYCLES"]
+        print("   wait_any %.0f%%  wait_inst %.0f%%  active %.0f%%  lds_conflict %.2f%%  waves %d  tcc_hit %.0f%%  EA reads %.3g (x 64 B = %.1f GB)  EA writes %.3g" % (
+            100 * m["SQ_WAIT_ANY"] / wc, 100 * m["SQ_WAIT_INST_ANY"] / wc, 100 * m["SQ_ACTIVE_INST_ANY"] / wc, 100 * m["SQ_LDS_BANK_CONFLICT"] / (256 * m["GRBM_GUI_ACTIVE"]),
+            m.get("SQ_WAVES", 0), 100 * m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), m.get("TCC_EA0_RDREQ_sum", 0), m.get("TCC_EA0_RDREQ_sum", 0) * 64 / 1e9, m.get("TCC_EA0_WRREQ_sum", 0)))
     for c, v in sorted(d.items()):
         print("   %-24s %.4g (x%d launches, mean)" % (c, sum(v) / len(v), len(v)))
 PY

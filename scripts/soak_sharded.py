@@ -79,9 +79,14 @@ for it in range(iters):
     cuts = np.sort(rng.integers(0, n + 1, world - 1)) if rng.random() < 0.5 else np.array([n * i // world for i in range(1, world)])
     bounds = [0] + [int(x) for x in cuts] + [n]
     opts = {"byte_matrix": int(rng.random() < 0.7), "narrow_matrix": int(rng.random() < 0.6), "raw_on_device": int(rng.random() < 0.8),
-            "packed_exchange": int(rng.random() < 0.8), "byte_list_cap": int(rng.choice([0, 0, 0, 16, 4096]))}
+            "packed_exchange": int(rng.random() < 0.8), "byte_list_cap": int(rng.choice([0, 0, 0, 16, 4096])),
+            "slots_matrix": int(rng.random() < 0.7), "exchange_chunks": int(rng.choice([1, 1, 2, 4, 7]))}   # (round 5: the slots end point, the all-to-all in chunks)
     tag = "it %d: n %d world %d merge %d N-UMIs %d qual %d bounds %s opts %s %s" % (it, n, world, merge, len(side), ql, bounds, opts, kw)
     t0 = time.time()
+    if it < int(os.environ.get("SOAK_START", "0")):   # (every random draw of the case is behind us: the cases after it stay what they were)
+        continue
+    if os.environ.get("SOAK_VERBOSE"):
+        print("run  %s" % tag, flush=True)
     try:
         g = ShardGroup([0] * world, **ckw)
         for i, s in enumerate(g.shards):

@@ -1,6 +1,6 @@
 """Idle time of the device inside one pass: from a rocprofv3 --kernel-trace CSV (kernel start / end timestamps) of a bench run, the gaps
-between consecutive kernels of one pass (TRACE_PASS counts passes from the end: -1 = the last one, the default; bench.py --steps 2 --warmup 1
-runs warm-up, two timed steps, two table steps with HIP events around every launch: -3 is the second timed step), largest first, with the
+between consecutive kernels of one pass (TRACE_PASS: 0-based from the start, negative from the end, default the last one; bench.py --steps 2 --warmup 1
+runs the warm-up, two timed steps, then table steps with HIP events around every launch and the other matrix forms: 2 is the second timed step), largest first, with the
 kernels on either side.  usage: trace_gaps.py <dir with *kernel_trace.csv> [how many of the pass's last kernels to list on a time line]"""
 import csv, glob, os, sys
 rows = []
@@ -12,8 +12,9 @@ rows.sort()
 starts = [i for i, r in enumerate(rows) if "cb_sample_distinct" in r[2]]
 which = int(os.environ.get("TRACE_PASS", "-1"))
 lo = starts[which]
-hi = starts[which + 1] if which < -1 else len(rows)
-print("pass %d of %d in the trace" % (len(starts) + which + 1, len(starts)))
+which = which % len(starts)
+hi = starts[which + 1] if which + 1 < len(starts) else len(rows)
+print("pass %d of %d in the trace (TRACE_PASS: 0-based from the start, negative from the end)" % (which + 1, len(starts)))
 seg = rows[lo:hi]
 busy = sum(e - s for s, e, _ in seg)
 span = max(e for _, e, _ in seg) - seg[0][0]

@@ -178,6 +178,33 @@ def test_slots_off_ends_at_the_byte_form_and_widens_to_the_same_matrix():
         assert all(np.array_equal(a, b) for a, b in zip(on[k], off[k]))
 
 
+def test_an_empty_filtered_matrix_in_a_slots_step():
+    """No cell passes min_genes_after_merge: cm has no column and no entry, cm_raw is as ever (the shared slots buffer of an empty matrix
+    used to be asked for with zero bytes: found by scripts/soak_sharded.py)."""
+    arrays, kw, side = make_case("none")
+    kw = dict(kw, min_genes_after_merge=100_000)
+    o = seeded_oracle(kw, arrays, side)
+    got = run_shards(arrays, kw, even_bounds(len(arrays[0]), 3), steps=2)
+    check_vs_oracle(got, o, side)
+    assert len(got["cm"][1]) == 0 and len(got["cm"][3]) == 0 and len(got["raw"][1]) > 1000
+
+
+@pytest.mark.parametrize("slots", [0, 1])
+def test_host_planned_cm_raw_beside_cm_with_eight_shards(slots):
+    """cm_raw planned on the HOST (raw_on_device 0) goes through the same assembling code as cm, right before it: its column descriptors were
+    staged in the buffer cm's were then written into while the copy to the device was still pending (nothing waits between the two since the
+    emit stopped waiting) -- wrong entries or a device fault in two runs of five (scripts/soak_sharded.py found it).  Each matrix has its own
+    buffers now; repeated here with lists that overflow (the matrix is then assembled twice inside one step)."""
+    arrays, kw, side = make_case("real:10x")
+    o = seeded_oracle(kw, arrays, side)
+    n = len(arrays[0])
+    cuts = [0, n // 9, n // 7, n // 5, n // 3, n // 2, 2 * n // 3, 7 * n // 8, n]
+    for cap in (0, 16):
+        opts = [{"raw_on_device": 0, "slots_matrix": slots, "byte_list_cap": cap, "narrow_matrix": 0}] * 8
+        for _ in range(3):
+            check_vs_oracle(run_shards(arrays, kw, cuts, options=opts, steps=2), o, side)
+
+
 def test_cell_id_by_cb_answers_from_the_host_mirror():
     """dropest_cell_id_by_cb (CellsDataContainer::cell_id_by_cb): real cells from the host's rows, any other barcode from one fetch of the
     pass's barcode list -- against the oracle, before and after a second pass."""
