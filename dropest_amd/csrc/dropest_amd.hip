@@ -936,7 +936,7 @@ bool dropest_ctx::splitter_sort_reduce() {
 	if (const char *e = getenv("DROPEST_SS_ATOMIC_BELOW")) a.atomic_below = u32(atoi(e));
 	a.cap = SMALL_MAX; a.skip_above = SMALL_MAX;
 	// the (cell, gene) table out of the compaction (k_ssort.h: ss_compact_cg) instead of seg_count + seg_reduce over the dense molecule table
-	static const bool fused_cg_off = getenv("DROPEST_SS_NO_FUSED_CG") != nullptr;
+	const bool fused_cg_off = getenv("DROPEST_SS_NO_FUSED_CG") != nullptr;   // (read at every pass: the soak scripts run both ways in one process)
 	const bool fuse_cg = !fused_cg_off;
 	cg_from_sort = false;
 	if (fuse_cg) {

@@ -9,7 +9,10 @@ import numpy as np
 from dropest_amd import capi
 from dropest_amd.synth import SynthStream, inject_n
 
-OLD = {"DROPEST_EXACT_INGEST_STATS": "1", "DROPEST_CB_NO_HOT": "1", "DROPEST_SORT": "lsd", "DROPEST_SS_BALLOT_RANK": "1"}
+OLD = {"DROPEST_EXACT_INGEST_STATS": "1", "DROPEST_CB_NO_HOT": "1", "DROPEST_SORT": "lsd", "DROPEST_SS_BALLOT_RANK": "1",
+       # round 5: no fused key pass / (cell, gene) rows out of the compaction (both moot under the LSD sort), the merge folds with seg_reduce twice,
+       # the filtered cells are ordered on the host
+       "DROPEST_NO_FUSED_KEYS": "1", "DROPEST_SS_NO_FUSED_CG": "1", "DROPEST_NO_FUSED_FOLD": "1", "DROPEST_SORTF_HOST": "1"}
 DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropest_amd", "data", "barcodes")
 
 
