@@ -904,6 +904,11 @@ bool dropest_ctx::splitter_sort_reduce() {
 	// sample -> sorted -> splitters (build_keys_fused took the sample from the reads and has the keys in their coarse regions already)
 	const bool in_l1 = keys_in_l1 && reserve;
 	if (keys_in_l1 && !reserve) throw InvalidError("internal: keys partitioned by the key pass, but the sort does not place by reservation");
+	// key + mark byte layout with the key filling the word (C3): the first level hands on ONE word per record -- the key counted from its
+	// coarse bucket's lower splitter, the mark in the three bits that frees (k_ssort.h: REBASE) -- and everything behind it runs on keys only
+	const bool rebase = VB == 1 && ms == 0 && reserve && !in_l1 && !getenv("DROPEST_SS_NO_REBASE");
+	const int VB2 = rebase ? 0 : VB, ms2 = rebase ? 3 : ms;          // layout behind the first level
+	const u64 rebase_mask = rebase ? ~((1ull << layout.umi_bits) - 1ull) : 0ull;
 	if (!in_l1) {
 		ss_sample_a.ensure(n_sample); ss_sample_b.ensure(n_sample); ss_fine.ensure(F2); ss_coarse.ensure(F1);
 		timed("ss_sample", double(n_sample) * 16, [&] {
@@ -928,11 +933,12 @@ bool dropest_ctx::splitter_sort_reduce() {
 	const bool atomic_rank = lds_atomics_lane_ordered(cfg.device, stream);
 	ss_tmp.ensure(span * 2 + 2); ss_n_loc.ensure(F2); ss_prefix.ensure(F2); ss_chunk.ensure(1024);
 	SsLocalArgs a{};
-	a.keys = keys; a.vals = vals; a.bucket_base = ss_bucket_base.p; a.bucket_cnt = ss_bucket_cnt.p; a.n_buckets = F2; a.ms = ms;
+	a.keys = keys; a.vals = vals; a.bucket_base = ss_bucket_base.p; a.bucket_cnt = ss_bucket_cnt.p; a.n_buckets = F2; a.ms = ms2;
+	if (rebase) { a.rebase_coarse = ss_coarse.p; a.rebase_mask = rebase_mask; a.rebase_div = Ff; }
 	a.t_key = keys_alt; a.t_reads = ss_tmp.p; a.t_agg = ss_tmp.p + span; a.n_loc = ss_n_loc.p;
 	if (const char *e = getenv("DROPEST_SS_DEBUG")) a.debug = u32(atoi(e));
 	a.order_flag = scalars.p + 2;
-	a.atomic_below = u32(ms + layout.umi_bits);   // the UMI field: random digits
+	a.atomic_below = u32(ms2 + layout.umi_bits);   // the UMI field: random digits
 	if (const char *e = getenv("DROPEST_SS_ATOMIC_BELOW")) a.atomic_below = u32(atoi(e));
 	a.cap = SMALL_MAX; a.skip_above = SMALL_MAX;
 	// the (cell, gene) table out of the compaction (k_ssort.h: ss_compact_cg) instead of seg_count + seg_reduce over the dense molecule table
@@ -942,22 +948,22 @@ bool dropest_ctx::splitter_sort_reduce() {
 	if (fuse_cg) {
 		ss_cg_loc.ensure(F2); ss_cg_cnt.ensure(F2); ss_cg_prefix.ensure(F2);
 		HIP_CHECK(hipMemsetAsync(ss_cg_loc.p, 0, size_t(F2) * 4, stream));
-		a.cg_loc = ss_cg_loc.p; a.cg_shift = ms + layout.umi_bits;
+		a.cg_loc = ss_cg_loc.p; a.cg_shift = ms2 + layout.umi_bits;
 	}
 	auto launch_small = [&] {
 		static const int wave_mode = [] { const char *e = getenv("DROPEST_SS_LOCAL_WAVE"); return e ? atoi(e) : 0; }();
 		if ((wave_mode == 64 || wave_mode == 128) && atomic_rank) {
 			const size_t lds1 = ss_local_lds_bytes(a.cap, wave_mode);
-			timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB), [&] {
-				if (wave_mode == 64) { if (VB) hipLaunchKernelGGL((ss_local_wave_kernel<64, 1, true>), dim3(F2), dim3(64), lds1, stream, a); else hipLaunchKernelGGL((ss_local_wave_kernel<64, 0, true>), dim3(F2), dim3(64), lds1, stream, a); }
-				else { if (VB) hipLaunchKernelGGL((ss_local_wave_kernel<128, 1, true>), dim3(F2), dim3(128), lds1, stream, a); else hipLaunchKernelGGL((ss_local_wave_kernel<128, 0, true>), dim3(F2), dim3(128), lds1, stream, a); }
+			timed(VB2 ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB2), [&] {
+				if (wave_mode == 64) { if (VB2) hipLaunchKernelGGL((ss_local_wave_kernel<64, 1, true>), dim3(F2), dim3(64), lds1, stream, a); else hipLaunchKernelGGL((ss_local_wave_kernel<64, 0, true>), dim3(F2), dim3(64), lds1, stream, a); }
+				else { if (VB2) hipLaunchKernelGGL((ss_local_wave_kernel<128, 1, true>), dim3(F2), dim3(128), lds1, stream, a); else hipLaunchKernelGGL((ss_local_wave_kernel<128, 0, true>), dim3(F2), dim3(128), lds1, stream, a); }
 			});
 			return;
 		}
 		const size_t lds = ss_local_lds_bytes(a.cap, 256);
-		timed(VB ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB), [&] {   // + 16 B per molecule row, added below once n_mol is known
-			if (atomic_rank) { if (VB) hipLaunchKernelGGL((ss_local_kernel<1, true>), dim3(F2), dim3(256), lds, stream, a); else hipLaunchKernelGGL((ss_local_kernel<0, true>), dim3(F2), dim3(256), lds, stream, a); }
-			else if (VB) hipLaunchKernelGGL(ss_local_kernel<1>, dim3(F2), dim3(256), lds, stream, a);
+		timed(VB2 ? "ss_local:key+1B" : "ss_local:keys", double(n) * (8 + VB2), [&] {   // + 16 B per molecule row, added below once n_mol is known
+			if (atomic_rank) { if (VB2) hipLaunchKernelGGL((ss_local_kernel<1, true>), dim3(F2), dim3(256), lds, stream, a); else hipLaunchKernelGGL((ss_local_kernel<0, true>), dim3(F2), dim3(256), lds, stream, a); }
+			else if (VB2) hipLaunchKernelGGL(ss_local_kernel<1>, dim3(F2), dim3(256), lds, stream, a);
 			else hipLaunchKernelGGL(ss_local_kernel<0>, dim3(F2), dim3(256), lds, stream, a);
 		});
 	};
@@ -970,18 +976,21 @@ bool dropest_ctx::splitter_sort_reduce() {
 		u32 *cur1 = ss_cursors.p, *cur2 = ss_cursors.p + size_t(F1) * CS1;
 		const u32 probe = [] { const char *e = getenv("DROPEST_SS_PROBE"); return e ? u32(atoi(e)) : 0u; }();
 		const bool no256 = getenv("DROPEST_SS_NO_F256") != nullptr;
-		const SsReserve r1{cur1, CS1, cap1, 0u, scalars.p + 3, probe}, r2{cur2, 1u, cap2, 0u, scalars.p + 3, probe};
-		if (!in_l1) timed(VB ? "ss_scatter:L1:key+1B" : "ss_scatter:L1:keys", double(n) * 2 * (8 + VB), [&] {
-			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb1, ss_coarse.p, tpb, r1); };
-			if (wide) { if (VB) go(ss_scatter_res_l1_kernel<1, 1024>); else go(ss_scatter_res_l1_kernel<0, 1024>); }
+		const u32 rebase_bits = [] { const char *e = getenv("DROPEST_SS_REBASE_BITS"); return e ? u32(std::min(61, std::max(1, atoi(e)))) : 61u; }();
+		const SsReserve r1{cur1, CS1, cap1, 0u, scalars.p + 3, probe, rebase_bits}, r2{cur2, 1u, cap2, 0u, scalars.p + 3, probe, 61u};
+		if (!in_l1) timed(VB ? "ss_scatter:L1:key+1B" : "ss_scatter:L1:keys", double(n) * (8 + VB + 8 + VB2), [&] {
+			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(SS_T), 0, stream, keys, vals, keys_alt, vals_alt, n, ms, fb1, ss_coarse.p, tpb, r1, rebase_mask); };
+			if (rebase) { if (wide) go(ss_scatter_res_l1_kernel<1, 1024, true>); else if (fb1 <= 8 && !no256) go(ss_scatter_res_l1_kernel<1, 256, true>); else go(ss_scatter_res_l1_kernel<1, 512, true>); }
+			else if (wide) { if (VB) go(ss_scatter_res_l1_kernel<1, 1024>); else go(ss_scatter_res_l1_kernel<0, 1024>); }
 			else if (fb1 <= 8 && !no256) { if (VB) go(ss_scatter_res_l1_kernel<1, 256>); else go(ss_scatter_res_l1_kernel<0, 256>); }   // 45 KB of LDS: three workgroups per CU
 			else { if (VB) go(ss_scatter_res_l1_kernel<1, 512>); else go(ss_scatter_res_l1_kernel<0, 512>); }
 		});
-		timed(VB ? "ss_scatter:L2:key+1B" : "ss_scatter:L2:keys", double(n) * 2 * (8 + VB), [&] {
-			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms, fb2, ss_fine.p, cur1, CS1, cap1, parts, r2); };
-			if (wide) { if (VB) go(ss_scatter_res_l2_kernel<1, 1024>); else go(ss_scatter_res_l2_kernel<0, 1024>); }
-			else if (fb2 <= 8 && !no256) { if (VB) go(ss_scatter_res_l2_kernel<1, 256>); else go(ss_scatter_res_l2_kernel<0, 256>); }
-			else { if (VB) go(ss_scatter_res_l2_kernel<1, 512>); else go(ss_scatter_res_l2_kernel<0, 512>); }
+		timed(VB2 ? "ss_scatter:L2:key+1B" : "ss_scatter:L2:keys", double(n) * 2 * (8 + VB2), [&] {
+			auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(F1 * parts), dim3(SS_T), 0, stream, keys_alt, vals_alt, keys, vals, ms2, fb2, ss_fine.p, cur1, CS1, cap1, parts, r2,
+			                                                 rebase ? ss_coarse.p : static_cast<const u64 *>(nullptr), rebase_mask); };
+			if (wide) { if (VB2) go(ss_scatter_res_l2_kernel<1, 1024>); else go(ss_scatter_res_l2_kernel<0, 1024>); }
+			else if (fb2 <= 8 && !no256) { if (VB2) go(ss_scatter_res_l2_kernel<1, 256>); else go(ss_scatter_res_l2_kernel<0, 256>); }
+			else { if (VB2) go(ss_scatter_res_l2_kernel<1, 512>); else go(ss_scatter_res_l2_kernel<0, 512>); }
 		});
 		timed("ss_scan", double(F2) * 12, [&] {
 			hipLaunchKernelGGL(ss_res_buckets_kernel, dim3(div_up(F2, 256)), dim3(256), 0, stream, cur2, F2, cap2, ss_bucket_base.p, ss_bucket_cnt.p, scalars.p);
@@ -1053,11 +1062,11 @@ bool dropest_ctx::splitter_sort_reduce() {
 		};
 		timed("ss_local:big", 0, [&] {
 			if (atomic_rank) {
-				if (!medium.empty()) { if (VB) launch(ss_local_big_kernel<256, 1, true>, 256, 4096, ss_big_list.p, medium.size()); else launch(ss_local_big_kernel<256, 0, true>, 256, 4096, ss_big_list.p, medium.size()); }
-				if (!big.empty()) { if (VB) launch(ss_local_big_kernel<512, 1, true>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); else launch(ss_local_big_kernel<512, 0, true>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); }
+				if (!medium.empty()) { if (VB2) launch(ss_local_big_kernel<256, 1, true>, 256, 4096, ss_big_list.p, medium.size()); else launch(ss_local_big_kernel<256, 0, true>, 256, 4096, ss_big_list.p, medium.size()); }
+				if (!big.empty()) { if (VB2) launch(ss_local_big_kernel<512, 1, true>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); else launch(ss_local_big_kernel<512, 0, true>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); }
 			} else {
-				if (!medium.empty()) { if (VB) launch(ss_local_big_kernel<256, 1>, 256, 4096, ss_big_list.p, medium.size()); else launch(ss_local_big_kernel<256, 0>, 256, 4096, ss_big_list.p, medium.size()); }
-				if (!big.empty()) { if (VB) launch(ss_local_big_kernel<512, 1>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); else launch(ss_local_big_kernel<512, 0>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); }
+				if (!medium.empty()) { if (VB2) launch(ss_local_big_kernel<256, 1>, 256, 4096, ss_big_list.p, medium.size()); else launch(ss_local_big_kernel<256, 0>, 256, 4096, ss_big_list.p, medium.size()); }
+				if (!big.empty()) { if (VB2) launch(ss_local_big_kernel<512, 1>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); else launch(ss_local_big_kernel<512, 0>, 512, SS_LOCAL_MAX, ss_big_list.p + medium.size(), big.size()); }
 			}
 		});
 		HIP_CHECK(stream_wait(stream));   // the host lists must outlive their copies

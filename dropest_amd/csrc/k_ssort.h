@@ -277,12 +277,22 @@ struct SsReserve {
 	uint32_t first;         // index of this block's first bucket among all regions of the level
 	uint32_t *overflow;
 	uint32_t dbg;           // timing probes (DROPEST_SS_PROBE; results unusable): 1 no splitter search, 2 no LDS regrouping
+	uint32_t rebase_bits;   // REBASE: bits a rebased key may take (61; tests: fewer, so that the fall-back runs)
 };
-template <int VB, int MAXF>
+// REBASE (first level of the key + mark byte layout, a key that fills all 64 bits: C3): a record leaves as ONE word,
+//   ((key - lo(bucket)) << 3) | mark,   lo(d) = the bucket's lower splitter with the UMI field cleared (0 for bucket 0),
+// so the second level and ss_local run on keys only (9 -> 8 bytes per record, no scattered byte stores): inside a coarse bucket the order
+// of the differences is the order of the keys, and differences above the UMI field are equal exactly when the fields are (lo has no UMI
+// bits).  ss_local adds lo back when it writes a molecule's key.  A difference that does not fit 61 bits (a coarse bucket spanning an
+// eighth of the key space: never with quantile splitters over used cell ids) raises the overflow flag: the pass is then redone with the
+// counting partitions, which keep the byte column.
+template <int VB, int MAXF, bool REBASE = false>
 __device__ inline void ss_scatter_res_range(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
                                             unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, uint32_t begin, uint32_t end,
                                             int ms, int fb, const unsigned long long *sp, const SsReserve rs, uint32_t *cnt, uint32_t *tstart,
-                                            uint32_t *gdelta, uint32_t *scratch, unsigned long long *sk, uint16_t *sd, uint8_t *sv) {
+                                            uint32_t *gdelta, uint32_t *scratch, unsigned long long *sk, uint16_t *sd, uint8_t *sv,
+                                            unsigned long long rebase_mask = 0) {
+	static_assert(!REBASE || VB == 1, "rebased keys carry the mark byte in their low bits");
 	constexpr int PER = (MAXF + SS_T - 1) / SS_T;   // table entries per thread (MAXF = 256: the upper half of the threads has none)
 	const uint32_t F = 1u << fb, tid = threadIdx.x;
 	// The records of the NEXT tile are requested as soon as this tile's have moved from registers to LDS: they are on their way while this
@@ -363,8 +373,14 @@ __device__ inline void ss_scatter_res_range(const unsigned long long *__restrict
 		for (uint32_t q = tid; q < in_tile; q += SS_T) {
 			const uint32_t d = sd[q], g = gdelta[d] + q;
 			if (g < (rs.first + d + 1u) * rs.cap) {
-				okeys[g] = sk[q];
-				if (VB) ovals[g] = sv[q];
+				if constexpr (REBASE) {
+					const unsigned long long diff = sk[q] - (d ? (sp[d - 1u] & rebase_mask) : 0ull);
+					if (diff >> rs.rebase_bits) atomicOr(rs.overflow, 1u);
+					okeys[g] = (diff << 3) | (unsigned long long)(sv[q] & 7u);
+				} else {
+					okeys[g] = sk[q];
+					if (VB) ovals[g] = sv[q];
+				}
 			}
 		}
 		if ((rs.dbg & 2u) && t0 + SS_TILE < end) load_tile(t0 + SS_TILE);
@@ -380,11 +396,11 @@ __device__ inline void ss_scatter_res_range(const unsigned long long *__restrict
 	__shared__ uint8_t sv[VB ? SS_TILE : 1];
 
 // first level: block blk owns tiles [blk * tpb, (blk + 1) * tpb); bucket j's region = [j * cap, (j + 1) * cap) of okeys
-template <int VB, int MAXF>
+template <int VB, int MAXF, bool REBASE = false>
 __global__ __launch_bounds__(SS_T) void ss_scatter_res_l1_kernel(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
                                                                  unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, uint32_t n,
                                                                  int ms, int fb, const unsigned long long *__restrict__ coarse,
-                                                                 uint32_t tiles_per_block, SsReserve rs) {
+                                                                 uint32_t tiles_per_block, SsReserve rs, unsigned long long rebase_mask) {
 	SS_SCATTER_RES_LDS(VB, MAXF)
 	const uint32_t F = 1u << fb;
 	for (uint32_t j = threadIdx.x; j < F; j += SS_T) sp[j] = j + 1 < F ? coarse[j] : ~0ull;
@@ -392,17 +408,23 @@ __global__ __launch_bounds__(SS_T) void ss_scatter_res_l1_kernel(const unsigned 
 	const uint64_t b64 = uint64_t(blockIdx.x) * tiles_per_block * SS_TILE;
 	uint64_t e64 = b64 + uint64_t(tiles_per_block) * SS_TILE;
 	if (e64 > n) e64 = n;
-	if (b64 < n) ss_scatter_res_range<VB, MAXF>(keys, vals, okeys, ovals, uint32_t(b64), uint32_t(e64), ms, fb, sp, rs, cnt, tstart, gdelta, scratch, sk, sd, sv);
+	if (b64 < n) ss_scatter_res_range<VB, MAXF, REBASE>(keys, vals, okeys, ovals, uint32_t(b64), uint32_t(e64), ms, fb, sp, rs, cnt, tstart, gdelta, scratch, sk, sd, sv, rebase_mask);
 }
 // second level: block (s, p) takes part p of coarse region s (cur1 = the first level's cursors = the regions' fills)
 template <int VB, int MAXF>
 __global__ __launch_bounds__(SS_T) void ss_scatter_res_l2_kernel(const unsigned long long *__restrict__ keys, const uint8_t *__restrict__ vals,
                                                                  unsigned long long *__restrict__ okeys, uint8_t *__restrict__ ovals, int ms, int fb,
                                                                  const unsigned long long *__restrict__ fine, const uint32_t *__restrict__ cur1,
-                                                                 uint32_t cstride1, uint32_t cap1, uint32_t parts, SsReserve rs) {
+                                                                 uint32_t cstride1, uint32_t cap1, uint32_t parts, SsReserve rs,
+                                                                 const unsigned long long *__restrict__ rebase_coarse, unsigned long long rebase_mask) {
 	SS_SCATTER_RES_LDS(VB, MAXF)
 	const uint32_t F = 1u << fb, s = blockIdx.x / parts, p = blockIdx.x % parts;
-	for (uint32_t j = threadIdx.x; j < F; j += SS_T) sp[j] = j + 1 < F ? fine[size_t(s) * F + j] : ~0ull;
+	// (rebased keys, see ss_scatter_res_range: the region's fine splitters move down by its lo as well)
+	const unsigned long long lo = (rebase_coarse && s) ? (rebase_coarse[s - 1] & rebase_mask) : 0ull;
+	for (uint32_t j = threadIdx.x; j < F; j += SS_T) {
+		const unsigned long long f = j + 1 < F ? fine[size_t(s) * F + j] : ~0ull;
+		sp[j] = j + 1 < F ? (f > lo ? f - lo : 0ull) : ~0ull;
+	}
 	__syncthreads();
 	const uint32_t fill = cur1[size_t(s) * cstride1], sb = s * cap1, se = sb + (fill < cap1 ? fill : cap1);
 	const uint32_t tiles = (se - sb + SS_TILE - 1) / SS_TILE, tpp = (tiles + parts - 1) / parts;
@@ -447,6 +469,10 @@ struct SsLocalArgs {
 	// ss_compact_cg turns them into the (cell, gene) table while it moves the molecule rows (zeroed before the launches: every wave adds its share)
 	uint32_t *cg_loc;
 	int cg_shift;
+	// rebased keys (ss_scatter_res_range<..., REBASE>): fine bucket b belongs to coarse bucket b / rebase_div, whose lo comes back onto the molecule keys
+	const unsigned long long *rebase_coarse;
+	unsigned long long rebase_mask;
+	uint32_t rebase_div;
 };
 
 // LDS of ss_local (dynamic, 16-byte aligned): sk[cap] keys -- later aliased by agg[cap] + headpos[cap] (u32 each) --,
@@ -470,6 +496,8 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint3
 	unsigned long long *red = reinterpret_cast<unsigned long long *>(misc + 4 + ((WAVES + 1) & 1u));   // [2 * WAVES], 8-byte aligned
 	uint8_t *sv = reinterpret_cast<uint8_t *>(red + 2 * WAVES);
 	const int ms = a.ms;
+	const uint32_t coarse_b = a.rebase_coarse ? bucket / a.rebase_div : 0u;
+	const unsigned long long kbase = coarse_b ? (a.rebase_coarse[coarse_b - 1u] & a.rebase_mask) : 0ull;
 
 	const uint32_t lane_off = w * (64 * ITEMS) + lane;   // position of item 0; item i sits at lane_off + 64 i: order = (wave, item, lane)
 	unsigned long long key[ITEMS];
@@ -609,7 +637,7 @@ __device__ inline void ss_local_run(const SsLocalArgs &a, uint32_t bucket, uint3
 		const uint32_t is_head = (head_bits >> i) & 1u;
 		const uint32_t m = woff + pre[i] + is_head - 1u;
 		const uint32_t mark = VB ? uint32_t(val[i]) & 7u : uint32_t(key[i]) & 7u;
-		if (is_head) { headpos[m] = p; a.t_key[base + m] = key[i] >> ms; }
+		if (is_head) { headpos[m] = p; a.t_key[base + m] = (key[i] >> ms) + kbase; }
 		const uint32_t add = (((mark >> 1) & 1u) << 1) | (((mark >> 2) & 1u) << 16);
 		if (add) atomicAdd(&agg[m], add);
 		if (mark & 1u) atomicOr(&agg[m], 1u);

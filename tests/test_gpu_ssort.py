@@ -66,6 +66,35 @@ def test_key_plus_mark_byte_layout(splitter, monkeypatch):
     assert c.sort_layout()["sort"] == "splitter" and c.sort_layout()["value_bytes"] == 1
 
 
+def test_rebased_keys_behind_the_first_partition(monkeypatch):
+    """Key + mark byte layout: the first partition hands on one word per record -- the key counted from its coarse bucket's lower splitter,
+    the mark in the three bits that frees -- so the second partition and the finishing sort run on keys only.  On, off
+    (DROPEST_SS_NO_REBASE) and with a difference that does not fit (DROPEST_SS_REBASE_BITS: the counting partitions redo the pass): the
+    oracle's results every time."""
+    monkeypatch.setenv("DROPEST_SORT", "splitter")
+    monkeypatch.setenv("DROPEST_NO_FUSED_KEYS", "1")
+    monkeypatch.setenv("DROPEST_FORCE_BYTE_VALUES", "1")
+    cb, umi, gene, aux = parity.canonical_stream(*SynthStream(n_reads=400_000, n_cells=80, n_genes=4000, umi_len=12).generate_host())
+    o = parity.oracle_run(Oracle, dict(min_genes_before=10, min_genes_after=30), cb, umi, gene, aux)
+    for mode in ("rebase", "off", "does_not_fit"):
+        if mode == "off":
+            monkeypatch.setenv("DROPEST_SS_NO_REBASE", "1")
+        if mode == "does_not_fit":
+            monkeypatch.delenv("DROPEST_SS_NO_REBASE")
+            monkeypatch.setenv("DROPEST_SS_REBASE_BITS", "12")
+        c = parity.gpu_run(dict(min_genes_before_merge=10, min_genes_after_merge=30), cb, umi, gene, aux, profile=True)
+        names = set(c.kernel_stats())
+        assert c.sort_layout()["sort"] == "splitter" and c.sort_layout()["value_bytes"] == 1
+        assert "ss_scatter:L1:key+1B" in names
+        if mode == "rebase":
+            assert "ss_scatter:L2:keys" in names and "ss_local:keys" in names and "count:ss_reserve_overflow" not in names, names
+        if mode == "off":
+            assert "ss_scatter:L2:key+1B" in names and "ss_local:key+1B" in names, names
+        if mode == "does_not_fit":
+            assert "count:ss_reserve_overflow" in names and "ss_hist:L1" in names, names
+        parity.compare(o, c)
+
+
 def test_general_layout_keeps_the_lsd_sort(splitter, monkeypatch):
     monkeypatch.setenv("DROPEST_FORCE_GENERAL_LAYOUT", "1")
     o, c = tp._both(dict(n_cells=40, n_genes=3000), 100_000, 20, 100)
