@@ -154,6 +154,7 @@ def lib():
         "dropest_matrix_bytes_widen": (C.c_int, [vp, vp, vp]),
         "dropest_set_raw_matrix_prefetch": (C.c_int, [vp, C.c_int, C.c_int]),
         "dropest_set_matrix_wire": (C.c_int, [vp, C.c_int]),
+        "dropest_set_umi_dictionary": (C.c_int, [vp, C.c_int]),
         "dropest_debug_refresh": (C.c_int, []),
         "dropest_push_reads_gather": (C.c_int, [vp, C.c_uint64, vp, vp, vp, vp, vp]),
         "dropest_shard_set_umi_qualities": (C.c_int, [vp, vp, C.c_uint32, C.c_uint64]),
@@ -237,7 +238,7 @@ EXPORTED_SYMBOLS = [
     "dropest_shard_set_reads_device", "dropest_shard_push_reads", "dropest_reserve_reads", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix", "dropest_shard_matrix_form",
     "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option", "dropest_plan_columns",
     "dropest_key_width", "dropest_ctx_split", "dropest_shard_matrix_narrow", "dropest_shard_matrix_bytes", "dropest_add_umi_to_cell", "dropest_umi_first_seen", "dropest_resident_reads", "dropest_prefetch_raw_matrix_narrow", "dropest_narrow_matrix_possible", "dropest_count_matrix_csc_narrow",
-    "dropest_prefetch_raw_matrix_bytes", "dropest_count_matrix_csc_bytes", "dropest_matrix_bytes_widen", "dropest_set_raw_matrix_prefetch", "dropest_set_matrix_wire", "dropest_debug_refresh", "dropest_push_reads_gather", "dropest_shard_set_umi_qualities", "dropest_shard_set_umi_qualities_var",
+    "dropest_prefetch_raw_matrix_bytes", "dropest_count_matrix_csc_bytes", "dropest_matrix_bytes_widen", "dropest_set_raw_matrix_prefetch", "dropest_set_matrix_wire", "dropest_set_umi_dictionary", "dropest_debug_refresh", "dropest_push_reads_gather", "dropest_shard_set_umi_qualities", "dropest_shard_set_umi_qualities_var",
     "dropest_debug_poison_scratch", "dropest_debug_trim_pool", "dropest_debug_alloc_ordinal", "dropest_debug_alloc_site",
 ]
 
@@ -468,6 +469,11 @@ class Context:
     def set_matrix_wire(self, on=True):
         """dropest_set_matrix_wire: large 32-bit matrices cross PCIe as bytes and are widened by host threads under the copy (default on)."""
         self._chk(self.L.dropest_set_matrix_wire(self.h, int(bool(on))))
+
+    def set_umi_dictionary(self, mode=0):
+        """dropest_set_umi_dictionary: 0 = UMI ranks in the key only when gene + UMI fields reach 64 bits, 1 = also before a key
+        wider than 64 bits is refused, 2 = always."""
+        self._chk(self.L.dropest_set_umi_dictionary(self.h, int(mode)))
 
     def set_raw_matrix_prefetch(self, form=2, reads_output=False):
         """Announce the form cm_raw will be asked for (0 / 1 / 2; -1: off): the container starts its prefetch by itself."""

@@ -364,6 +364,18 @@ struct dropest_ctx {
 	int umi_clean_bits = 0;          // bits of a clean UMI code inside the key
 	u32 wanted_bits[3] = {0, 0, 0};  // cell / gene / UMI field widths of the last layout plan (also when it did not fit 64 bits)
 	bool umi_sentinel_stripped = false;
+	// UMI dictionary (k_umidict.h): when gene + UMI fields alone reach 64 bits the UMI field of the key is the UMI's rank among
+	// the distinct clean UMIs of the gene-bearing reads; the key kernels then read `umi_ranked` in place of the UMI column.
+	// umi_dict_mode: 0 = only then, 1 = also before a key wider than 64 bits is refused (dropest_ctx_split not needed), 2 = always (tests).
+	int umi_dict_mode = 0;
+	bool umi_dict_on = false;                // this pass's keys carry ranks
+	u32 umi_dict_n = 0;
+	dropest::DevBuf<u64> umi_dict, umi_ranked;
+	std::vector<u64> umi_dict_host;          // ascending codes: unmap_umi / map_umi
+	const u64 *umi_key_column() const { return umi_dict_on ? umi_ranked.p : d_umi; }
+	void build_umi_dict();
+	bool map_umi(u64 api_code, u64 &field) const;   // inverse of unmap_umi; false: the code has no place in this pass's key layout
+	bool map_umi_or_add(u64 api_code, u64 &field);  // the same for the public mutators: a new clean UMI joins the dictionary
 	dropest::IngestStats ingest{};
 	dropest::GlobalCounters counters{};
 

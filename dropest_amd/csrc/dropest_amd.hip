@@ -11,6 +11,7 @@
 
 #include "context.h"
 #include "k_keyscatter.h"
+#include "k_umidict.h"
 
 #include <atomic>
 #include <sys/syscall.h>
@@ -242,6 +243,7 @@ void dropest_ctx::free_results() {
 	real.clear(); filtered.clear(); filtered_valid = false; merge_pairs.clear(); reassign.clear(); umi_overrides.clear(); n_real_now = 0;
 	merge_rank.clear(); reagg_prio = nullptr; extra_excluded.clear(); explicit_sources.clear(); mol_sorted_rows = 0xFFFFFFFFu;
 	layout = dropest::KeyLayout{}; umi_clean_bits = 0; umi_sentinel_stripped = false; chr_from_gene = false;   // nothing of the previous pass's key plan survives
+	umi_dict_on = false; umi_dict_n = 0; umi_dict_host.clear();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -470,22 +472,37 @@ void dropest_ctx::plan_key_layout() {
 			L.umi_strip_mask = ~0ull;
 		}
 	}
-	umi_clean_bits = clean_bits;
-	L.umi_escape_base = 1ull << clean_bits;
-	L.umi_bits = clean_bits;
-	if (ingest.umi_escape_max_plus1) L.umi_bits = bit_length(L.umi_escape_base + ingest.umi_escape_max_plus1 - 1);
 	// gene field: ids 0..gene_max, plus the "no gene" code = all ones
 	L.gene_bits = bit_length(uint64_t(ingest.gene_max_plus1));
 	if ((1ull << L.gene_bits) - 1 < ingest.gene_max_plus1) L.gene_bits++;
 	if (L.gene_bits == 0) L.gene_bits = 1;
 	L.gene_none = (1ull << L.gene_bits) - 1ull;
 	L.cell_bits = std::max(1, bit_length(uint64_t(n_cells ? n_cells - 1 : 0)));
+	// The UMI's own code as the field, unless the key cannot hold it: then its rank in a dictionary of the stream's UMIs
+	// (k_umidict.h; StringIndexer.cpp:10-18 has no width limit).  Once a pass has the dictionary it keeps it.
+	if (!umi_dict_on && n_reads && !hooks && !rpack.on()) {
+		int plain_bits = clean_bits;
+		if (ingest.umi_escape_max_plus1) plain_bits = bit_length((1ull << clean_bits) + ingest.umi_escape_max_plus1 - 1);
+		const int mode = getenv("DROPEST_UMI_DICT") ? atoi(getenv("DROPEST_UMI_DICT")) : umi_dict_mode;
+		if (mode >= 2 || L.gene_bits + plain_bits >= 64 || (mode == 1 && plain_bits + L.gene_bits + L.cell_bits > 64)) build_umi_dict();
+	}
+	if (umi_dict_on) {
+		umi_sentinel_stripped = false;
+		clean_bits = std::max(1, bit_length(uint64_t(umi_dict_n) + 255u));   // (room for UMIs the public mutators bring in: add_umi / merge_umis)
+		L.umi_strip_mask = ~0ull;   // ranks pass as they are
+	}
+	umi_clean_bits = clean_bits;
+	L.umi_escape_base = 1ull << clean_bits;
+	L.umi_bits = clean_bits;
+	if (ingest.umi_escape_max_plus1) L.umi_bits = bit_length(L.umi_escape_base + ingest.umi_escape_max_plus1 - 1);
 	wanted_bits[0] = u32(L.cell_bits); wanted_bits[1] = u32(L.gene_bits); wanted_bits[2] = u32(L.umi_bits);
+	if (L.gene_bits + L.umi_bits >= 64)
+		throw UnsupportedError("gene + UMI fields of the sort key need " + std::to_string(L.gene_bits + L.umi_bits) + " bits and leave no room for the cells; "
+		                       "one context then keys the UMIs by their rank in a dictionary (dropest_set_umi_dictionary), the shards of a split or sharded run cannot");
 	if (L.umi_bits + L.gene_bits + L.cell_bits > 64)
 		throw UnsupportedError("sort key needs " + std::to_string(L.umi_bits + L.gene_bits + L.cell_bits) +
 		                       " bits (cell " + std::to_string(L.cell_bits) + " + gene " + std::to_string(L.gene_bits) +
 		                       " + UMI " + std::to_string(L.umi_bits) + "); one context sorts 64-bit keys -- the cell field shrinks when the stream is split by barcode: dropest_ctx_split");
-	if (L.gene_bits + L.umi_bits >= 64) throw UnsupportedError("gene + UMI field too wide");
 	// sort-record layout (k_misc.h): derive the chromosome from the gene when that is a function and the chromosome
 	// of a gene-less read fits the UMI field; then the mark rides in the key if 3 bits are free, else as one byte
 	chr_from_gene = !ingest.gene_chr_conflict && (L.umi_bits >= 16 || (u64(ingest.chr_max_plus1) <= (1ull << L.umi_bits)));
@@ -500,10 +517,82 @@ void dropest_ctx::plan_key_layout() {
 	layout = L;
 }
 
+// The distinct clean UMIs of the gene-bearing reads, ascending, and every read's rank among them (k_umidict.h).
+void dropest_ctx::build_umi_dict() {
+	HostStage hs(this, "umi_dict");
+	need_columns();
+	const u32 n = u32(n_reads);
+	keys_a.ensure(n); keys_b.ensure(n); vals_a.ensure(1); vals_b.ensure(1);
+	u64 *k = keys_a.p, *k_alt = keys_b.p;
+	u32 *v = vals_a.p, *v_alt = vals_b.p;
+	timed("umi_dict:fill", double(n) * 20, [&] {
+		hipLaunchKernelGGL(umi_dict_fill_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n, k);
+	});
+	radix_sort(k, v, k_alt, v_alt, n, ~0ull, 0, "umi_dict:");
+	const u32 nb = div_up(n, u32(UD_T * UD_PER));
+	DevBuf<u32> cnt, base;
+	cnt.alloc(nb); base.alloc(nb);
+	scalars.ensure(16);
+	timed("umi_dict:unique", double(n) * 16, [&] {
+		hipLaunchKernelGGL(umi_dict_count_kernel, dim3(nb), dim3(UD_T), 0, stream, k, n, cnt.p);
+		scan_counts(cnt.p, base.p, nb, scalars.p);
+	});
+	u32 total = 0;
+	fetch(&total, scalars.p, 4);
+	umi_dict_n = total;
+	umi_dict.ensure(std::max<u32>(total, 1u));
+	umi_ranked.ensure(n);
+	timed("umi_dict:rank", double(n) * 20, [&] {
+		if (total) hipLaunchKernelGGL(umi_dict_write_kernel, dim3(nb), dim3(UD_T), 0, stream, k, n, base.p, umi_dict.p);
+		hipLaunchKernelGGL(umi_dict_rank_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n, umi_dict.p, total, umi_ranked.p);
+	});
+	HIP_CHECK(hipGetLastError());
+	umi_dict_host.resize(total);
+	if (total) fetch(umi_dict_host.data(), umi_dict.p, size_t(total) * 8);
+	else HIP_CHECK(stream_wait(stream));
+	umi_dict_on = true;
+	if (profiling) stats["count:umi_dictionary"].launches += 1;
+}
+
 dropest_ctx::u64 dropest_ctx::unmap_umi(u64 ucode) const {
 	if (ucode >= layout.umi_escape_base && ingest.umi_escape_max_plus1) return ESCAPE_BIT | (ucode - layout.umi_escape_base);
+	if (umi_dict_on) {
+		if (ucode >= umi_dict_host.size()) throw InvalidError("internal: UMI rank beyond the dictionary");
+		return umi_dict_host[size_t(ucode)];
+	}
 	if (umi_sentinel_stripped) return (1ull << umi_clean_bits) | ucode;
 	return ucode;
+}
+
+bool dropest_ctx::map_umi(u64 api_code, u64 &field) const {
+	const u64 umask = layout.umi_bits ? ((1ull << layout.umi_bits) - 1ull) : 0ull;
+	if (api_code & ESCAPE_BIT) {
+		const u64 id = api_code & ~ESCAPE_BIT;
+		if (id >= ingest.umi_escape_max_plus1) return false;
+		field = layout.umi_escape_base + id;
+		return true;
+	}
+	if (umi_dict_on) {   // the first umi_dict_n entries ascend (the device built them); what the mutators appended follows in their order
+		const auto sorted_end = umi_dict_host.begin() + umi_dict_n;
+		auto it = std::lower_bound(umi_dict_host.begin(), sorted_end, api_code);
+		if (it == sorted_end || *it != api_code) it = std::find(sorted_end, umi_dict_host.end(), api_code);
+		if (it == umi_dict_host.end()) return false;   // (a UMI no gene-bearing read of this pass carries)
+		field = u64(it - umi_dict_host.begin());
+		return true;
+	}
+	if (umi_sentinel_stripped && bit_length(api_code) - 1 != umi_clean_bits) return false;
+	field = api_code & layout.umi_strip_mask;
+	return !(field > umask || (ingest.umi_escape_max_plus1 && field >= layout.umi_escape_base));
+}
+
+// A clean UMI a public mutator names that no read carried (CellsDataContainer::add_umi_to_cell / Cell::merge_umis take any string;
+// StringIndexer::add hands it the next index): the dictionary takes it at its end while the UMI field has room.
+bool dropest_ctx::map_umi_or_add(u64 api_code, u64 &field) {
+	if (map_umi(api_code, field)) return true;
+	if (!umi_dict_on || (api_code & ESCAPE_BIT) || u64(umi_dict_host.size()) >= layout.umi_escape_base) return false;
+	field = u64(umi_dict_host.size());
+	umi_dict_host.push_back(api_code);
+	return true;
 }
 
 static int sort_mode_override() {   // read at every pass: tests switch it inside one process
@@ -571,7 +660,7 @@ bool dropest_ctx::build_keys_fused(bool with_stats) {
 	const SsPlan plan = ss_plan(n_reads, chr_from_gene, layout.val_bytes);
 	if (!plan.applicable || !plan.reserve) return false;
 	const u32 n = u32(n_reads);
-	const bool vec = ((uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;
+	const bool vec = ((uintptr_t(umi_key_column()) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;
 	if (!vec) return false;
 	const int fb1 = plan.fb1, fb2 = plan.fb2, ms = layout.mark_shift, VB = layout.val_bytes;
 	const u32 F1 = 1u << fb1, Ff = 1u << fb2, F2 = F1 * Ff;
@@ -589,8 +678,8 @@ bool dropest_ctx::build_keys_fused(bool with_stats) {
 	// sample of the reads -> sorted -> fine / coarse splitters
 	ss_sample_a.ensure(n_sample); ss_sample_b.ensure(n_sample); ss_fine.ensure(F2); ss_coarse.ensure(F1);
 	timed("ss_sample", double(n_sample) * (20.0 / 16 * 8 + 8), [&] {
-		if (rpack.on()) hipLaunchKernelGGL(ss_sample_reads_kernel<true>, dim3(div_up(n_sample, 256)), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, hot, rpack, n_sample, ss_sample_a.p);
-		else hipLaunchKernelGGL(ss_sample_reads_kernel<false>, dim3(div_up(n_sample, 256)), dim3(256), 0, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, hot, rpack, n_sample, ss_sample_a.p);
+		if (rpack.on()) hipLaunchKernelGGL(ss_sample_reads_kernel<true>, dim3(div_up(n_sample, 256)), dim3(256), 0, stream, umi_key_column(), d_gene, d_aux, slot.p, n, table, layout, hot, rpack, n_sample, ss_sample_a.p);
+		else hipLaunchKernelGGL(ss_sample_reads_kernel<false>, dim3(div_up(n_sample, 256)), dim3(256), 0, stream, umi_key_column(), d_gene, d_aux, slot.p, n, table, layout, hot, rpack, n_sample, ss_sample_a.p);
 	});
 	const int key_bits = layout.cell_bits + layout.gene_bits + layout.umi_bits;
 	ss_splitters_from_sample(n_sample, os, Ff, F2, key_bits >= 64 ? ~0ull : ((1ull << key_bits) - 1ull));   // (every bit of the key fields may vary: the sample's own OR / AND would cost a round trip)
@@ -618,7 +707,7 @@ bool dropest_ctx::build_keys_fused(bool with_stats) {
 		auto go = [&](auto kernel) {
 			if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) { (void)hipGetLastError(); launched = false; return; }
 			const u32 blocks = std::max<u32>(1u, std::min<u32>(div_up(n, u32(KS_TILE)), u32(std::max(1, cus))));
-			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(KS_T), lds, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, d_counters.p, hot, gene_chr.p, GENE_CHR_CAP, d_ingest.p,
+			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(KS_T), lds, stream, umi_key_column(), d_gene, d_aux, slot.p, n, table, layout, d_counters.p, hot, gene_chr.p, GENE_CHR_CAP, d_ingest.p,
 			                   lds_genes, rpack, keys_b.p, reinterpret_cast<uint8_t *>(vals_b.p), ms, fb1, ss_coarse.p, r1);
 		};
 		auto pick = [&](auto vb) {
@@ -661,7 +750,7 @@ void dropest_ctx::build_keys(bool with_stats, bool allow_fused) {
 		zero.gene_chr_conflict = ingest.gene_chr_conflict;
 		HIP_CHECK(hipMemcpyAsync(d_ingest.p, &zero, sizeof(zero), hipMemcpyHostToDevice, stream));
 	}
-	const bool vec = ((uintptr_t(d_umi) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;
+	const bool vec = ((uintptr_t(umi_key_column()) | uintptr_t(d_gene) | uintptr_t(d_aux)) & 15u) == 0;
 	timed("build_keys", double(n) * (8 + 4 + 4 + 4 + 4 + 8 + layout.val_bytes), [&] {
 		void *v = vals_a.p;
 		const CbHot hot{hot_key.p, hot_slot.p, n_hot};   // n_hot: slot[] holds CB_HOT_FLAG | hot index for the reads of the hot barcodes
@@ -676,7 +765,7 @@ void dropest_ctx::build_keys(bool with_stats, bool allow_fused) {
 			int per_cu = 0;
 			HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds));
 			const u32 blocks = std::max<u32>(1u, std::min<u32>(div_up(n, 256 * 4), u32(std::max(1, cus) * std::max(1, std::min(per_cu, 4)))));
-			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, stream, d_umi, d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p, hot,
+			hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, stream, umi_key_column(), d_gene, d_aux, slot.p, n, table, layout, keys_a.p, v, d_counters.p, hot,
 			                   gene_chr.p, GENE_CHR_CAP, d_ingest.p, lds, rpack);
 		};
 		if (rpack.on() && !vec) throw InvalidError("internal: packed exchange records that are not 16-byte aligned");
@@ -2793,6 +2882,15 @@ dropest_status dropest_set_matrix_wire(dropest_ctx *ctx, int enabled) {
 		if (!ctx) throw InvalidError("null context");
 		ctx->invalidate_prefetch();
 		ctx->matrix_wire = enabled != 0;
+	});
+}
+
+dropest_status dropest_set_umi_dictionary(dropest_ctx *ctx, int mode) {
+	return guarded([&] {
+		if (!ctx) throw InvalidError("null context");
+		if (mode < 0 || mode > 2) throw InvalidError("UMI dictionary mode out of range");
+		if (ctx->initialized) throw InvalidError("Container is already initialized");
+		ctx->umi_dict_mode = mode;
 	});
 }
 

@@ -87,10 +87,9 @@ void dropest_ctx::mutate_merge_umis(u32 cell, u32 gene, uint64_t n, const uint64
 		if (known != device_code.end()) field = known->second;
 		else {
 			if (kv.first & ESCAPE_BIT) throw UnsupportedError("merge_umis to a new UMI that contains N");
-			if (umi_sentinel_stripped && bit_length(kv.first) - 1 != umi_clean_bits) throw UnsupportedError("merge_umis to a UMI of another length");
-			field = kv.first & layout.umi_strip_mask;
-			if (field > umask || (ingest.umi_escape_max_plus1 && field >= layout.umi_escape_base))
-				throw UnsupportedError("merge_umis to a UMI outside the key layout");
+			if (!umi_dict_on && umi_sentinel_stripped && bit_length(kv.first) - 1 != umi_clean_bits) throw UnsupportedError("merge_umis to a UMI of another length");
+			if (!map_umi_or_add(kv.first, field))
+				throw UnsupportedError(umi_dict_on ? "merge_umis to a UMI outside the container's UMI dictionary" : "merge_umis to a UMI outside the key layout");
 		}
 		for (u32 r : kv.second) patch.emplace_back(r, (want << layout.umi_bits) | field);
 	}
@@ -135,16 +134,12 @@ void dropest_ctx::mutate_add_umi_to_cell(u32 cell, u32 gene, uint64_t umi_code, 
 	if (!chr_from_gene) throw UnsupportedError("add_umi_to_cell needs the chromosome-from-gene record layout (a gene on two chromosomes was seen)");
 	if (gene >= layout.gene_none) throw UnsupportedError("add_umi_to_cell: the gene index does not fit the key layout of this container");
 	if (mark > 7u) throw InvalidError("add_umi_to_cell: mark out of range");
-	const u64 umask = layout.umi_bits ? ((1ull << layout.umi_bits) - 1ull) : 0ull;
 	u64 field;
-	if (umi_code & ESCAPE_BIT) {
-		const u64 id = umi_code & ~ESCAPE_BIT;
-		if (id >= ingest.umi_escape_max_plus1) throw UnsupportedError("add_umi_to_cell: a UMI with N that no read of the container carries");
-		field = layout.umi_escape_base + id;
-	} else {
+	if (!map_umi_or_add(umi_code, field)) {
+		if (umi_code & ESCAPE_BIT) throw UnsupportedError("add_umi_to_cell: a UMI with N that no read of the container carries");
+		if (umi_dict_on) throw UnsupportedError("add_umi_to_cell: a UMI outside the container's UMI dictionary (no gene-bearing read carries it)");
 		if (umi_sentinel_stripped && bit_length(umi_code) - 1 != umi_clean_bits) throw UnsupportedError("add_umi_to_cell: a UMI of another length than the container's");
-		field = umi_code & layout.umi_strip_mask;
-		if (field > umask || (ingest.umi_escape_max_plus1 && field >= layout.umi_escape_base)) throw UnsupportedError("add_umi_to_cell: the UMI does not fit the key layout");
+		throw UnsupportedError("add_umi_to_cell: the UMI does not fit the key layout");
 	}
 	const u64 cg = (u64(cell) << layout.gene_bits) | gene;
 	if (umi_overrides.count(cg)) throw UnsupportedError("add_umi_to_cell on a group that the UMI merge strategy rewrote");

@@ -182,12 +182,12 @@ void dropest_ctx::accumulate_umi_qualities() {
 		read_row.alloc(n); first_read.alloc(n_mol);
 		HIP_CHECK(hipMemsetAsync(first_read.p, 0xFF, size_t(n_mol) * 4, stream));
 		timed("quality_first_read", double(n) * 24, [&] {
-			hipLaunchKernelGGL(quality_first_read_kernel, dim3(grid), dim3(256), 0, stream, d_umi, d_gene, slot.p, n, table, layout, mol_key.p, n_mol, hot_slot.p,
+			hipLaunchKernelGGL(quality_first_read_kernel, dim3(grid), dim3(256), 0, stream, umi_key_column(), d_gene, slot.p, n, table, layout, mol_key.p, n_mol, hot_slot.p,
 			                   read_row.p, first_read.p, scalars.p);
 		});
 	}
 	timed("quality_sums", double(n) * (20 + 5 * qual_len), [&] {
-		hipLaunchKernelGGL(quality_sums_kernel, dim3(grid), dim3(256), 0, stream, d_umi, d_gene, slot.p, n, table,
+		hipLaunchKernelGGL(quality_sums_kernel, dim3(grid), dim3(256), 0, stream, umi_key_column(), d_gene, slot.p, n, table,
 		                   layout, umi_qual.p, qual_len, qstride, mol_key.p, n_mol, mol_qsum.p, scalars.p, hot_slot.p, lens, read_row.p, first_read.p, scalars.p + 1);
 	});
 	hipLaunchKernelGGL(quality_row_lengths_kernel, dim3(div_up(n_mol, 256)), dim3(256), 0, stream, mol_qsum.p, n_mol, qstride, qual_len, lens, first_read.p);

@@ -337,7 +337,7 @@ void dropest_ctx::simple_replay_local(const std::vector<u32> &bases, SimpleRepla
 	const u32 n = u32(n_reads);
 	need_columns();   // (a sharded run's reads may still be packed records)
 	if (n) timed("umi_first_table", double(n) * 12, [&] {
-		hipLaunchKernelGGL(umi_first_table_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n, layout, umi_first.p);
+		hipLaunchKernelGGL(umi_first_table_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, umi_key_column(), d_gene, n, layout, umi_first.p);
 	});
 	if (globalize) {
 		if (!hooks || !hooks->globalize_umi_first) throw InvalidError("internal: a sharded replay without the shard hooks");

@@ -80,7 +80,7 @@ void dropest_ctx::run_umi_merge_directional() {
 	const u32 n = u32(n_reads);
 	timed("umi_first_table", double(n) * 12, [&] {
 		need_columns();   // (a sharded run's reads may still be packed records)
-		hipLaunchKernelGGL(umi_first_table_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n,
+		hipLaunchKernelGGL(umi_first_table_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, umi_key_column(), d_gene, n,
 		                   layout, umi_first.p);
 	});
 	if (hooks) hooks->globalize_umi_first(umi_first.p, table);   // sharded run: UMI index order of the whole stream
@@ -96,7 +96,7 @@ void dropest_ctx::run_umi_merge_directional() {
 	DirArgs a{};
 	a.cg_key = cg_key.p; a.cg_mol_begin = cg_mol_begin.p; a.n_cg = n_cg; a.mol_key = mol_key.p; a.mol_reads = mol_reads.p;
 	a.real_flag = remap.p; a.gene_bits = layout.gene_bits; a.umi_bits = layout.umi_bits;
-	a.umi_len = umi_sentinel_stripped ? umi_clean_bits / 2 : 0;
+	a.umi_len = umi_sentinel_stripped && !umi_dict_on ? umi_clean_bits / 2 : 0;   // (ranks of a UMI dictionary say nothing about bases: the host decides those groups)
 	a.gene_none = layout.gene_none; a.escape_base = ingest.umi_escape_max_plus1 ? layout.umi_escape_base : ~0ull;
 	a.umi_first = umi_first.p; a.mult = cfg.umi_merge_multiplier; a.max_ed = u32(cfg.max_umi_merge_edit_distance);
 	a.new_key = keys_a.p; a.cell_removed = d_removed.p; a.host_list = d_list.p; a.host_count = scalars.p; a.n_changed = scalars.p + 1;

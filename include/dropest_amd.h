@@ -245,6 +245,16 @@ dropest_status dropest_count_matrix_csc(dropest_ctx *ctx, int filtered, int read
  * arrays over the link.  Same results either way; DROPEST_MATRIX_DIRECT=1 in the environment switches it off for the process. */
 dropest_status dropest_set_matrix_wire(dropest_ctx *ctx, int enabled);
 
+/* Molecule keys of two words (Estimation/StringIndexer.cpp:10-18 hands out size_t indices: gene and UMI have no width limit there).
+ * One context sorts cell | gene | UMI in ONE 64-bit word with the UMI's own 2-bit code as its field.  When the gene and UMI fields
+ * alone reach 64 bits (a 24-base UMI beside 2^16 genes) the pass builds a dictionary of the stream's UMIs on the device
+ * (csrc/k_umidict.h: the distinct clean UMIs of the gene-bearing reads, ascending) and the key carries a UMI's RANK in it -- never
+ * more than 32 bits; ranks ascend with the codes, so every observable order stays what the plain layout gives.
+ * mode 0 (default): only then.  1: also before a key wider than 64 bits would be refused with "sort key needs ..." (one context
+ * then does what dropest_ctx_split does with several).  2: always (tests).  DROPEST_UMI_DICT in the environment overrides the mode.
+ * Not in sharded / split runs (ranks are local to a context): there gene + UMI >= 64 bits stays DROPEST_ERR_UNSUPPORTED. */
+dropest_status dropest_set_umi_dictionary(dropest_ctx *ctx, int mode);
+
 /* ResultsPrinter::save_results (ResultsPrinter.cpp:23-79) always builds both matrices.  This call starts cm_raw on a
  * second stream -- emit kernel and the device-to-host copy -- and returns at once; what the caller does next (the
  * ordering of the filtered cells, cm) runs under that copy.  A following dropest_count_matrix_csc(filtered = 0, same

@@ -139,7 +139,9 @@ def test_wide_key_merge_all_with_umi_qualities():
     g.close()
 
 
-def test_gene_and_umi_alone_too_wide_stays_refused():
+def test_gene_and_umi_alone_too_wide_take_the_umi_dictionary():
+    """Gene + UMI fields that alone fill the key: one context keys the UMIs by their rank in a dictionary (round 5, tests/test_gpu_umi_dict.py);
+    the shards of a split run cannot (ranks are local to a context) and say so."""
     P = capi.pack_seq
     n = 5
     cb = np.array([P("ACGT" * 7 + "AC" + "ACGT"[i % 4]) for i in range(n)], np.uint64)
@@ -147,12 +149,16 @@ def test_gene_and_umi_alone_too_wide_stays_refused():
     gene = np.array([1_000_000] * n, np.uint32)                # 20 bits
     c = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
     c.push_reads(cb, umi, gene, np.full(n, 2 << 16, np.uint32))
-    with pytest.raises(capi.DropestError):
-        c.set_initialized()
-    g = ShardGroup.split(c, 2)
+    c.set_initialized(); c.merge_and_filter()
+    assert c.key_width()[2] <= 9 and c.total_cells_number() == 4
+    mc, mg, mu, mr, mm = c.molecules()
+    assert sorted(mr.tolist()) == [1, 1, 1, 2] and set(capi.unpack_code(x) for x in mu) == {"TTGCA" * 6} and set(mg.tolist()) == {1_000_000}
+    c2 = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
+    c2.push_reads(cb, umi, gene, np.full(n, 2 << 16, np.uint32))
+    g = ShardGroup.split(c2, 2)
     with pytest.raises(capi.DropestError) as e:
         g.step()
-    assert e.value.status == 4
+    assert e.value.status == 4 and "gene + UMI" in str(e.value)
     g.close()
 
 
