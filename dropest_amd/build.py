@@ -7,9 +7,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libdropest_amd.so")
-SOURCES = ["dropest_amd.hip", "synth_api.hip", "annotation_api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function", "-pthread"]
+SOURCES = ["dropest_amd.hip", "synth_api.hip", "annotation_api.hip", "bgzf_api.hip"]
+# headers a small translation unit depends on (the others: everything under csrc/ and include/)
+DEPS = {"bgzf_api.hip": ["k_inflate.h", "k_bamparse.h", "util.h", "../../include/dropest_bgzf.h"],
+        "synth_api.hip": ["synth.h", "util.h", "k_cbhash.h", "../../include/dropest_synth.h"],
+        "annotation_api.hip": ["util.h", "../../include/dropest_annotation.h"]}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-pthread"]
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
 
 def _hipcc():
@@ -19,21 +23,43 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _deps_of(src):
+    if src in DEPS:
+        return [os.path.join(CSRC, src)] + [os.path.join(CSRC, d) for d in DEPS[src] if os.path.exists(os.path.join(CSRC, d))]
+    inc = os.path.join(HERE, "..", "include")
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".hip") or f == src] + [os.path.join(inc, f) for f in os.listdir(inc)]
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     deps += [os.path.join(HERE, "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "include"))]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.isfile(d) and os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source of the package into one shared library.  Returns its path."""
+    """Compile every HIP source of the package (one object per source, rebuilt when the source or a header it uses changed, or all of
+    them with force) and link them into one shared library.  Returns its path."""
     if not force and not _stale():
         return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc()] + FLAGS + os.environ.get("DROPEST_EXTRA_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    extra = os.environ.get("DROPEST_EXTRA_HIPCC_FLAGS", "").split()
+    objs, procs = [], []
+    for s in SOURCES:
+        obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and not extra and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps_of(s)):
+            continue
+        cmd = [_hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, s), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait():
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

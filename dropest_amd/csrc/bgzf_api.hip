@@ -1,0 +1,394 @@
+// bgzf_api.hip -- include/dropest_bgzf.h: BGZF block scan on the host, DEFLATE on the device (k_inflate.h).
+#include "../../include/dropest_bgzf.h"
+#include "k_inflate.h"
+#include "k_bamparse.h"
+#include "util.h"
+
+#include <chrono>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace dropest;
+
+namespace {
+thread_local std::string g_bgzf_error;
+inline uint32_t le16(const uint8_t *p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8); }
+inline uint32_t le32(const uint8_t *p) { return le16(p) | (le16(p + 2) << 16); }
+template <class F> int bgzf_guarded(F &&f) {
+	try { f(); return 0; }
+	catch (const std::exception &e) { g_bgzf_error = e.what(); return 1; }
+}
+}  // namespace
+
+extern "C" const char *dropest_bgzf_last_error(void) { return g_bgzf_error.c_str(); }
+
+extern "C" int dropest_bgzf_scan(const uint8_t *data, uint64_t len, uint64_t cap, uint64_t *in_off, uint32_t *in_len, uint64_t *out_off,
+                                 uint32_t *out_len, uint32_t *crc32, uint64_t *n_blocks, uint64_t *bytes_used, uint64_t *out_total) {
+	return bgzf_guarded([&] {
+		if (!data || !in_off || !in_len || !out_off || !out_len || !n_blocks) throw InvalidError("null argument");
+		uint64_t at = 0, n = 0, total = 0;
+		while (n < cap && at + 18 <= len) {
+			const uint8_t *h = data + at;
+			// gzip member with FEXTRA (SAMv1 4.1): 1f 8b 08 04, XLEN at 10, subfields of (SI1, SI2, SLEN, data); 'B' 'C' 2 holds BSIZE
+			if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) throw InvalidError("not a BGZF block header at offset " + std::to_string(at));
+			const uint32_t xlen = le16(h + 10);
+			if (at + 12 + xlen > len) break;
+			uint32_t bsize = 0;
+			for (uint32_t x = 0; x + 4 <= xlen;) {
+				const uint8_t *sf = h + 12 + x;
+				const uint32_t slen = le16(sf + 2);
+				if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = le16(sf + 4) + 1;
+				x += 4 + slen;
+			}
+			if (!bsize || bsize < 12 + xlen + 8) throw InvalidError("BGZF block without a BC subfield at offset " + std::to_string(at));
+			if (at + bsize > len) break;
+			in_off[n] = at + 12 + xlen; in_len[n] = bsize - 12 - xlen - 8;
+			out_off[n] = total; out_len[n] = le32(h + bsize - 4);
+			if (out_len[n] > 65536u) throw InvalidError("BGZF block with ISIZE beyond 64 KB at offset " + std::to_string(at));
+			if (crc32) crc32[n] = le32(h + bsize - 8);
+			total += out_len[n];
+			at += bsize; ++n;
+		}
+		*n_blocks = n;
+		if (bytes_used) *bytes_used = at;
+		if (out_total) *out_total = total;
+	});
+}
+
+extern "C" int dropest_bgzf_inflate_device(int device, void *stream, const uint8_t *d_in, uint64_t in_total, const uint64_t *d_in_off,
+                                           const uint32_t *d_in_len, const uint64_t *d_out_off, const uint32_t *d_out_len, uint32_t n_blocks,
+                                           uint8_t *d_out, uint32_t *d_status) {
+	return bgzf_guarded([&] {
+		if (!n_blocks) return;
+		if (!d_in || !d_in_off || !d_in_len || !d_out_off || !d_out_len || !d_out || !d_status) throw InvalidError("null argument");
+		if (uintptr_t(d_in) & 7u) throw InvalidError("the compressed bytes must be 8-byte aligned");
+		HIP_CHECK(hipSetDevice(device));
+		hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(INF_WAVES * 64), 0, hipStream_t(stream), d_in, in_total,
+		                   d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_out, d_status);
+		HIP_CHECK(hipGetLastError());
+	});
+}
+
+extern "C" int dropest_bgzf_inflate_buffer(int device, const uint8_t *data, uint64_t len, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
+                                           uint32_t *status, uint64_t status_cap, uint64_t *n_blocks, double *kernel_ms, int repeats) {
+	return bgzf_guarded([&] {
+		if (!data || !out_len || !n_blocks) throw InvalidError("null argument");
+		int n_dev = 0;
+		if (hipGetDeviceCount(&n_dev) != hipSuccess || device >= n_dev) throw DeviceError("no such GPU: BGZF blocks are inflated on the device only here");
+		HIP_CHECK(hipSetDevice(device));
+		const uint64_t cap = len / 26 + 1;
+		std::vector<uint64_t> in_off(cap), out_off(cap);
+		std::vector<uint32_t> in_len(cap), o_len(cap);
+		uint64_t n = 0, used = 0, total = 0;
+		if (dropest_bgzf_scan(data, len, cap, in_off.data(), in_len.data(), out_off.data(), o_len.data(), nullptr, &n, &used, &total)) throw InvalidError(g_bgzf_error);
+		*n_blocks = n; *out_len = total;
+		if (total > out_cap) throw InvalidError("output buffer too small: " + std::to_string(total) + " bytes needed");
+		if (!n) return;
+		if (n > 0xFFFFFFFFull) throw UnsupportedError("more than 2^32 blocks in one call");
+		DevBuf<uint8_t> d_in, d_out;
+		DevBuf<uint64_t> d_in_off, d_out_off;
+		DevBuf<uint32_t> d_in_len, d_out_len, d_status;
+		d_in.alloc(used + 8); d_out.alloc(total + 8); d_in_off.alloc(n); d_out_off.alloc(n); d_in_len.alloc(n); d_out_len.alloc(n); d_status.alloc(n);
+		HIP_CHECK(hipMemcpy(d_in.p, data, used, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy(d_in_off.p, in_off.data(), n * 8, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy(d_out_off.p, out_off.data(), n * 8, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy(d_in_len.p, in_len.data(), n * 4, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy(d_out_len.p, o_len.data(), n * 4, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemset(d_status.p, 0xFF, n * 4));
+		HIP_CHECK(hipMemset(d_out.p, 0, total + 8));
+		hipEvent_t e0, e1;
+		HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+		double ms_sum = 0;
+		const int reps = repeats > 0 ? repeats : 1;
+		for (int r = 0; r < reps; ++r) {
+			HIP_CHECK(hipEventRecord(e0, nullptr));
+			if (dropest_bgzf_inflate_device(device, nullptr, d_in.p, used, d_in_off.p, d_in_len.p, d_out_off.p, d_out_len.p, uint32_t(n), d_out.p, d_status.p))
+				throw DeviceError(g_bgzf_error);
+			HIP_CHECK(hipEventRecord(e1, nullptr));
+			HIP_CHECK(hipEventSynchronize(e1));
+			float ms = 0;
+			HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+			ms_sum += ms;
+		}
+		(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+		if (kernel_ms) *kernel_ms = ms_sum / reps;
+		if (out) HIP_CHECK(hipMemcpy(out, d_out.p, total, hipMemcpyDeviceToHost));
+		if (status) HIP_CHECK(hipMemcpy(status, d_status.p, std::min<uint64_t>(n, status_cap) * 4, hipMemcpyDeviceToHost));
+	});
+}
+
+// ---- BAM records of a window, on the device ------------------------------------------------------------------------------------
+struct dropest_bam_decoder {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	BamParseCfg cfg{};
+	DevBuf<uint8_t> d_in, d_out, d_tail, d_gather;
+	DevBuf<uint64_t> d_in_off, d_out_off, seg_start, seg_exit, rec_off, d_goff;
+	DevBuf<uint32_t> d_in_len, d_out_len, d_status, seg_count, seg_base, d_bad, d_list, d_gidx, d_gsize;
+	DevBuf<unsigned long long> o_cb, o_umi, dn_cb, dn_umi, p_cb, p_umi, g_keys;
+	DevBuf<uint32_t> o_gene, o_aux, dn_gene, dn_aux, tile_ok, tile_need, d_totals, nd_rec, nd_pos, nd_size, p_pos, p_gene, p_aux, g_vals;
+	DevBuf<int32_t> d_chr;
+	DevBuf<uint16_t> o_uql;
+	DevBuf<uint8_t> o_status, o_need;
+	DevBuf<BamWindowCounts> d_wc;
+	PinnedBuf<uint64_t> h_seg_start, h_seg_exit;
+	PinnedBuf<uint32_t> h_count, h_block_status, h_need_rec, h_need_pos, h_need_size, h_gsize;
+	std::vector<uint64_t> in_off, out_off;
+	std::vector<uint32_t> in_len, out_len, base;
+	uint32_t g_mask = 0;
+	uint64_t tail_len = 0, last_n_rec = 0, last_n_ok = 0;
+};
+
+extern "C" int dropest_bam_decoder_create(int device, const dropest_bam_parse_cfg *cfg, dropest_bam_decoder **out) {
+	return bgzf_guarded([&] {
+		if (!cfg || !out) throw InvalidError("null argument");
+		int n_dev = 0;
+		if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) throw DeviceError("no such GPU: the BAM decoder has no CPU implementation");
+		HIP_CHECK(hipSetDevice(device));
+		static_assert(sizeof(dropest_bam_parse_cfg) == sizeof(BamParseCfg), "the C struct and the kernels' struct are one layout");
+		if (cfg->intronic_len > 24 || cfg->intergenic_len > 24) throw InvalidError("read-type values longer than 24 characters");
+		if (cfg->n_refs < 0) throw InvalidError("negative number of references");
+		auto *d = new dropest_bam_decoder();
+		d->device = device;
+		std::memcpy(&d->cfg, cfg, sizeof(BamParseCfg));
+		try {
+			HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+			// empty dictionaries: every gene and chromosome is new
+			d->g_mask = 1023; d->g_keys.alloc(1024); d->g_vals.alloc(1024); d->d_chr.alloc(size_t(std::max(1, cfg->n_refs)));
+			HIP_CHECK(hipMemset(d->g_vals.p, 0, 1024 * 4));
+			HIP_CHECK(hipMemset(d->d_chr.p, 0xFF, size_t(std::max(1, cfg->n_refs)) * 4));
+		} catch (...) { delete d; throw; }
+		*out = d;
+	});
+}
+
+extern "C" void dropest_bam_decoder_destroy(dropest_bam_decoder *d) {
+	if (!d) return;
+	(void)hipSetDevice(d->device);
+	if (d->stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
+	delete d;
+}
+
+extern "C" int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, const uint64_t *gene_hash, const uint32_t *gene_id, uint32_t n_genes,
+                                                    const int32_t *chr_of_ref, uint32_t n_refs) {
+	return bgzf_guarded([&] {
+		if (!d || (n_genes && (!gene_hash || !gene_id)) || (n_refs && !chr_of_ref)) throw InvalidError("null argument");
+		if (n_refs != uint32_t(d->cfg.n_refs)) throw InvalidError("the chromosome table does not have one entry per reference");
+		HIP_CHECK(hipSetDevice(d->device));
+		uint32_t cap = 1024;
+		while (cap < n_genes * 2u + 16u) cap <<= 1;
+		std::vector<unsigned long long> keys(cap, 0);
+		std::vector<uint32_t> vals(cap, 0);
+		for (uint32_t k = 0; k < n_genes; ++k) {
+			uint32_t sl = bam_dict_slot(gene_hash[k], cap - 1);
+			while (vals[sl] && keys[sl] != gene_hash[k]) sl = (sl + 1) & (cap - 1);
+			if (!vals[sl]) { keys[sl] = gene_hash[k]; vals[sl] = gene_id[k] + 1; }      // (the first name with a hash keeps it, as the host's map does)
+		}
+		HIP_CHECK(hipStreamSynchronize(d->stream));
+		d->g_keys.ensure(cap); d->g_vals.ensure(cap);
+		HIP_CHECK(hipMemcpy(d->g_keys.p, keys.data(), size_t(cap) * 8, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy(d->g_vals.p, vals.data(), size_t(cap) * 4, hipMemcpyHostToDevice));
+		if (n_refs) HIP_CHECK(hipMemcpy(d->d_chr.p, chr_of_ref, size_t(n_refs) * 4, hipMemcpyHostToDevice));
+		d->g_mask = cap - 1;
+	});
+}
+
+extern "C" int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
+                                          dropest_bgzf_host_inflate inflate_fallback, void *user, dropest_bam_window *out) {
+	return bgzf_guarded([&] {
+		if (!d || !out || (len && !comp)) throw InvalidError("null argument");
+		using clk = std::chrono::steady_clock;
+		auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+		HIP_CHECK(hipSetDevice(d->device));
+		hipStream_t st = d->stream;
+		*out = dropest_bam_window{};
+		d->last_n_rec = 0; d->last_n_ok = 0;
+		// 1. the blocks
+		const uint64_t cap = len / 26 + 1;
+		d->in_off.resize(cap); d->out_off.resize(cap); d->in_len.resize(cap); d->out_len.resize(cap);
+		uint64_t n = 0, used = 0, total = 0;
+		if (len && dropest_bgzf_scan(comp, len, cap, d->in_off.data(), d->in_len.data(), d->out_off.data(), d->out_len.data(), nullptr, &n, &used, &total)) throw InvalidError(g_bgzf_error);
+		if (used != len) throw InvalidError("a window must hold whole BGZF blocks");
+		if (n > 0xFFFFFFFFull) throw UnsupportedError("more than 2^32 blocks in one window");
+		const uint64_t tail = d->tail_len, data_len = tail + total;
+		if (tail && first_skip) throw InvalidError("first_skip belongs to the first window");
+		if (data_len >= (uint64_t(1) << 40)) throw UnsupportedError("window too large");
+		auto t0 = clk::now();
+		d->d_out.ensure(data_len + data_len / 4 + 64);
+		if (tail) HIP_CHECK(hipMemcpyAsync(d->d_out.p, d->d_tail.p, tail, hipMemcpyDeviceToDevice, st));
+		if (n) {
+			d->d_in.ensure(len + len / 4 + 8); d->d_in_off.ensure(n + n / 4); d->d_out_off.ensure(n + n / 4); d->d_in_len.ensure(n + n / 4); d->d_out_len.ensure(n + n / 4);
+			d->d_status.ensure(n + n / 4); d->h_block_status.ensure(n);
+			HIP_CHECK(hipMemcpyAsync(d->d_in.p, comp, len, hipMemcpyHostToDevice, st));
+			HIP_CHECK(hipMemcpyAsync(d->d_in_off.p, d->in_off.data(), n * 8, hipMemcpyHostToDevice, st));
+			HIP_CHECK(hipMemcpyAsync(d->d_out_off.p, d->out_off.data(), n * 8, hipMemcpyHostToDevice, st));
+			HIP_CHECK(hipMemcpyAsync(d->d_in_len.p, d->in_len.data(), n * 4, hipMemcpyHostToDevice, st));
+			HIP_CHECK(hipMemcpyAsync(d->d_out_len.p, d->out_len.data(), n * 4, hipMemcpyHostToDevice, st));
+			HIP_CHECK(hipStreamSynchronize(st));
+			out->ms_copy = ms_since(t0);
+			t0 = clk::now();
+			if (dropest_bgzf_inflate_device(d->device, st, d->d_in.p, len, d->d_in_off.p, d->d_in_len.p, d->d_out_off.p, d->d_out_len.p, uint32_t(n), d->d_out.p + tail, d->d_status.p))
+				throw DeviceError(g_bgzf_error);
+			HIP_CHECK(hipMemcpyAsync(d->h_block_status.p, d->d_status.p, n * 4, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipStreamSynchronize(st));
+			std::vector<uint8_t> tmp;
+			for (uint64_t k = 0; k < n; ++k) {
+				if (!d->h_block_status.p[k]) continue;
+				++out->refused_blocks;
+				if (!inflate_fallback) throw InvalidError("the device refused BGZF block " + std::to_string(k) + " of the window (status " + std::to_string(d->h_block_status.p[k]) + ") and no host inflate was given");
+				tmp.resize(d->out_len[k] + 1);
+				if (inflate_fallback(comp + d->in_off[k], d->in_len[k], tmp.data(), d->out_len[k], user)) throw InvalidError("damaged BGZF block (neither the device nor the host inflates it)");
+				HIP_CHECK(hipMemcpy(d->d_out.p + tail + d->out_off[k], tmp.data(), d->out_len[k], hipMemcpyHostToDevice));
+			}
+			out->ms_inflate = ms_since(t0);
+		}
+		out->n_blocks = uint32_t(n); out->window_bytes = data_len;
+		// 2. the chain of records: guesses per segment, walks, the host's check
+		t0 = clk::now();
+		const uint32_t n_segs = uint32_t((data_len + BAM_SEG - 1) / BAM_SEG);
+		uint64_t expect = tail ? 0 : first_skip;
+		uint64_t n_rec = 0;
+		if (n_segs) {
+			const size_t sc = size_t(n_segs) + n_segs / 4;
+			d->seg_start.ensure(sc); d->seg_exit.ensure(sc); d->seg_count.ensure(sc); d->seg_base.ensure(sc); d->d_bad.ensure(1); d->d_list.ensure(1);
+			d->h_seg_start.ensure(n_segs); d->h_seg_exit.ensure(n_segs); d->h_count.ensure(n_segs);
+			HIP_CHECK(hipMemsetAsync(d->d_bad.p, 0, 4, st));
+			HIP_CHECK(hipMemcpyAsync(d->seg_start.p, &expect, 8, hipMemcpyHostToDevice, st));
+			if (n_segs > 1) hipLaunchKernelGGL(bam_seg_guess_kernel, dim3((n_segs - 1 + 3) / 4), dim3(256), 0, st, d->d_out.p, data_len, d->cfg.n_refs, n_segs, d->seg_start.p);
+			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, d->d_out.p, data_len, (const uint32_t *)nullptr, n_segs, d->seg_start.p,
+			                   d->seg_count.p, d->seg_exit.p, (const uint32_t *)nullptr, (uint64_t *)nullptr, d->d_bad.p);
+			HIP_CHECK(hipGetLastError());
+			HIP_CHECK(hipMemcpyAsync(d->h_seg_start.p, d->seg_start.p, size_t(n_segs) * 8, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(d->h_seg_exit.p, d->seg_exit.p, size_t(n_segs) * 8, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(d->h_count.p, d->seg_count.p, size_t(n_segs) * 4, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipStreamSynchronize(st));
+			d->base.resize(n_segs);
+			for (uint32_t k = 0; k < n_segs; ++k) {
+				const uint64_t seg_end = uint64_t(k + 1) * BAM_SEG;
+				const uint64_t want = expect < seg_end ? expect : BAM_NONE;      // no record starts in this segment: the chain is already past it
+				if (d->h_seg_start.p[k] != want) {                                 // the guess was not on the chain: walk again from the true place
+					if (k) ++out->guesses_repaired;
+					d->h_seg_start.p[k] = want;
+					HIP_CHECK(hipMemcpyAsync(d->seg_start.p + k, &d->h_seg_start.p[k], 8, hipMemcpyHostToDevice, st));
+					HIP_CHECK(hipMemcpyAsync(d->d_list.p, &k, 4, hipMemcpyHostToDevice, st));
+					hipLaunchKernelGGL(bam_seg_walk_kernel, dim3(1), dim3(256), 0, st, d->d_out.p, data_len, d->d_list.p, 1u, d->seg_start.p, d->seg_count.p, d->seg_exit.p,
+					                   (const uint32_t *)nullptr, (uint64_t *)nullptr, d->d_bad.p);
+					HIP_CHECK(hipMemcpyAsync(d->h_seg_exit.p + k, d->seg_exit.p + k, 8, hipMemcpyDeviceToHost, st));
+					HIP_CHECK(hipMemcpyAsync(d->h_count.p + k, d->seg_count.p + k, 4, hipMemcpyDeviceToHost, st));
+					HIP_CHECK(hipStreamSynchronize(st));
+				}
+				d->base[k] = uint32_t(n_rec);
+				n_rec += d->h_count.p[k];
+				if (want != BAM_NONE) expect = d->h_seg_exit.p[k];
+			}
+			uint32_t bad = 0;
+			HIP_CHECK(hipMemcpy(&bad, d->d_bad.p, 4, hipMemcpyDeviceToHost));
+			if (bad) throw InvalidError("Corrupt BAM record");
+			if (n_rec > 0xFFFFFFF0ull) throw UnsupportedError("more than 2^32 records in one window");
+		}
+		const uint64_t tail_start = n_segs ? expect : (tail ? 0 : first_skip);
+		if (tail_start > data_len) throw InvalidError("Corrupt BAM record");
+		if (final && tail_start != data_len) throw InvalidError("Truncated BAM file");
+		out->ms_boundaries = ms_since(t0);
+		// 3. record offsets, the fields, the accepted records made dense
+		t0 = clk::now();
+		BamWindowCounts wc{};
+		uint32_t totals[2] = {0, 0};
+		if (n_rec) {
+			const size_t rc = size_t(n_rec) + size_t(n_rec) / 4;
+			d->rec_off.ensure(rc);
+			HIP_CHECK(hipMemcpyAsync(d->seg_base.p, d->base.data(), size_t(n_segs) * 4, hipMemcpyHostToDevice, st));
+			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, d->d_out.p, data_len, (const uint32_t *)nullptr, n_segs, d->seg_start.p,
+			                   d->seg_count.p, d->seg_exit.p, d->seg_base.p, d->rec_off.p, d->d_bad.p);
+			d->o_cb.ensure(rc); d->o_umi.ensure(rc); d->o_gene.ensure(rc); d->o_aux.ensure(rc); d->o_uql.ensure(rc); d->o_status.ensure(rc); d->o_need.ensure(rc);
+			d->dn_cb.ensure(rc); d->dn_umi.ensure(rc); d->dn_gene.ensure(rc); d->dn_aux.ensure(rc); d->nd_rec.ensure(rc); d->nd_pos.ensure(rc); d->nd_size.ensure(rc);
+			const uint32_t tiles = uint32_t((n_rec + BAM_FIN_TILE - 1) / BAM_FIN_TILE);
+			d->tile_ok.ensure(tiles + tiles / 4 + 1); d->tile_need.ensure(tiles + tiles / 4 + 1); d->d_totals.ensure(2); d->d_wc.ensure(1);
+			HIP_CHECK(hipMemsetAsync(d->d_wc.p, 0, sizeof(BamWindowCounts), st));
+			const BamRecordOut ro{d->o_cb.p, d->o_umi.p, d->o_gene.p, d->o_aux.p, d->o_uql.p, d->o_status.p, d->o_need.p};
+			const BamDict dict{d->g_keys.p, d->g_vals.p, d->g_mask, d->d_chr.p};
+			const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, d->nd_rec.p, d->nd_pos.p, d->nd_size.p};
+			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + 255) / 256)), dim3(256), 0, st, d->d_out.p, d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro);
+			hipLaunchKernelGGL(bam_fin_count_kernel, dim3(tiles), dim3(256), 0, st, d->o_status.p, d->o_need.p, d->o_uql.p, uint32_t(n_rec), d->tile_ok.p, d->tile_need.p, d->d_wc.p);
+			hipLaunchKernelGGL(bam_fin_scan_kernel, dim3(1), dim3(1024), 0, st, d->tile_ok.p, d->tile_need.p, tiles, d->d_totals.p);
+			hipLaunchKernelGGL(bam_fin_scatter_kernel, dim3(tiles), dim3(256), 0, st, d->d_out.p, d->rec_off.p, ro, uint32_t(n_rec), d->tile_ok.p, d->tile_need.p, dn);
+			HIP_CHECK(hipGetLastError());
+			HIP_CHECK(hipMemcpyAsync(&wc, d->d_wc.p, sizeof(wc), hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(totals, d->d_totals.p, 8, hipMemcpyDeviceToHost, st));
+		}
+		// 4. the cut-off record opens the next window
+		const uint64_t new_tail = data_len - tail_start;
+		if (new_tail) {
+			d->d_tail.ensure(new_tail + 64);
+			HIP_CHECK(hipMemcpyAsync(d->d_tail.p, d->d_out.p + tail_start, new_tail, hipMemcpyDeviceToDevice, st));
+		}
+		HIP_CHECK(hipStreamSynchronize(st));
+		const uint32_t n_need = totals[1];
+		if (n_need) {
+			d->h_need_rec.ensure(n_need); d->h_need_pos.ensure(n_need); d->h_need_size.ensure(n_need);
+			HIP_CHECK(hipMemcpyAsync(d->h_need_rec.p, d->nd_rec.p, size_t(n_need) * 4, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(d->h_need_pos.p, d->nd_pos.p, size_t(n_need) * 4, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(d->h_need_size.p, d->nd_size.p, size_t(n_need) * 4, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipStreamSynchronize(st));
+		}
+		out->ms_parse = ms_since(t0);
+		d->tail_len = new_tail; d->last_n_rec = n_rec; d->last_n_ok = totals[0];
+		out->n_records = n_rec; out->tail_bytes = new_tail;
+		for (int k = 0; k < 5; ++k) out->counts[k] = wc.status[k];
+		out->n_accepted = totals[0];
+		if (out->n_accepted != out->counts[0]) throw DeviceError("internal: the dense columns and the counters disagree");
+		out->d_cb = reinterpret_cast<const uint64_t *>(d->dn_cb.p); out->d_umi = reinterpret_cast<const uint64_t *>(d->dn_umi.p); out->d_gene = d->dn_gene.p; out->d_aux = d->dn_aux.p;
+		out->n_need = n_need; out->need_rec = d->h_need_rec.p; out->need_pos = d->h_need_pos.p; out->need_size = d->h_need_size.p;
+		out->quality_seen = wc.quality; out->any_gene = wc.any_gene;
+	});
+}
+
+__global__ __launch_bounds__(256) void bam_record_sizes_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ rec_off, const uint32_t *__restrict__ idx, uint32_t n,
+                                                               uint32_t *__restrict__ size) {
+	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+	if (k < n) size[k] = 4u + b_le32(data + rec_off[idx[k]]);
+}
+
+extern "C" int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const uint32_t *idx, uint32_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *dst_off) {
+	return bgzf_guarded([&] {
+		if (!d || (n && (!idx || !dst || !dst_off))) throw InvalidError("null argument");
+		if (!n) return;
+		HIP_CHECK(hipSetDevice(d->device));
+		for (uint32_t k = 0; k < n; ++k) if (idx[k] >= d->last_n_rec) throw RangeError("record index outside the window");
+		d->d_gidx.ensure(n); d->d_goff.ensure(n); d->d_gsize.ensure(n); d->h_gsize.ensure(n);
+		HIP_CHECK(hipMemcpyAsync(d->d_gidx.p, idx, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
+		hipLaunchKernelGGL(bam_record_sizes_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, d->d_out.p, d->rec_off.p, d->d_gidx.p, n, d->d_gsize.p);
+		HIP_CHECK(hipMemcpyAsync(d->h_gsize.p, d->d_gsize.p, size_t(n) * 4, hipMemcpyDeviceToHost, d->stream));
+		HIP_CHECK(hipStreamSynchronize(d->stream));
+		uint64_t total = 0;
+		for (uint32_t k = 0; k < n; ++k) { dst_off[k] = total; total += d->h_gsize.p[k]; }
+		if (total > dst_cap) throw InvalidError("destination too small: " + std::to_string(total) + " bytes needed");
+		d->d_gather.ensure(total + total / 4 + 64);
+		HIP_CHECK(hipMemcpyAsync(d->d_goff.p, dst_off, size_t(n) * 8, hipMemcpyHostToDevice, d->stream));
+		hipLaunchKernelGGL(bam_gather_records_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, d->d_out.p, d->rec_off.p, d->d_gidx.p, d->d_goff.p, n, d->d_gather.p);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipMemcpyAsync(dst, d->d_gather.p, total, hipMemcpyDeviceToHost, d->stream));
+		HIP_CHECK(hipStreamSynchronize(d->stream));
+	});
+}
+
+extern "C" int dropest_bam_decoder_patch(dropest_bam_decoder *d, const uint32_t *pos, const uint64_t *cb, const uint64_t *umi, const uint32_t *gene,
+                                         const uint32_t *aux, uint32_t n) {
+	return bgzf_guarded([&] {
+		if (!d || (n && (!pos || !cb || !umi || !gene || !aux))) throw InvalidError("null argument");
+		if (!n) return;
+		HIP_CHECK(hipSetDevice(d->device));
+		for (uint32_t k = 0; k < n; ++k) if (pos[k] >= d->last_n_ok) throw RangeError("row outside the dense columns");
+		d->p_pos.ensure(n); d->p_cb.ensure(n); d->p_umi.ensure(n); d->p_gene.ensure(n); d->p_aux.ensure(n);
+		HIP_CHECK(hipMemcpyAsync(d->p_pos.p, pos, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
+		HIP_CHECK(hipMemcpyAsync(d->p_cb.p, cb, size_t(n) * 8, hipMemcpyHostToDevice, d->stream));
+		HIP_CHECK(hipMemcpyAsync(d->p_umi.p, umi, size_t(n) * 8, hipMemcpyHostToDevice, d->stream));
+		HIP_CHECK(hipMemcpyAsync(d->p_gene.p, gene, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
+		HIP_CHECK(hipMemcpyAsync(d->p_aux.p, aux, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
+		const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, nullptr, nullptr, nullptr};
+		hipLaunchKernelGGL(bam_patch_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, d->p_pos.p, d->p_cb.p, d->p_umi.p, d->p_gene.p, d->p_aux.p, n, dn);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipStreamSynchronize(d->stream));
+	});
+}

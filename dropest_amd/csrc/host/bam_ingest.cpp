@@ -1,6 +1,7 @@
 // bam_ingest.cpp -- see bam_ingest.h.
 #include "bam_ingest.h"
 #include "fast_inflate.h"
+#include "../../../include/dropest_bgzf.h"
 #include <atomic>
 
 #include <zlib.h>
@@ -677,9 +678,8 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 	};
 	const unsigned nthreads = _threads ? _threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 	for (auto const &bam_name : bam_files) {
-		BamReader reader(bam_name, _threads);
-		const auto &refs = reader.reference_names();
-		container.set_reference_names(refs);
+		std::unique_ptr<BamReader> reader_p;       // the host reader: opened only when it is the one that reads (its loader thread inflates ahead from the start)
+		std::vector<std::string> refs;
 		const uint8_t *data = nullptr;
 		std::vector<uint32_t> offsets;
 		std::vector<Parsed> parsed;
@@ -846,6 +846,178 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			}
 			return true;
 		};
+		// ---- device path (include/dropest_bgzf.h; DROPEST_BAM_DEVICE=1 or BamController::set_device_decode) ------------------------
+		// The blocks are inflated on the GPU (csrc/k_inflate.h: a wave per block), the chain of records is found and every record's tags
+		// are walked there (csrc/k_bamparse.h: a lane per record); 39 bytes per record come back instead of the ~300 of the record.  The
+		// dictionaries stay here: the workers turn gene hashes and reference ids into indices, and the records that bring something NEW
+		// (a gene name, a chromosome, a string with N) are fetched as bytes and go through parse_one + the intern_* members in file order,
+		// exactly like the Needs of fast_window.  Windows grow from 1 MB of compressed bytes (the first ones meet most gene names).
+		// A block's CRC-32 is not checked on this path.  Falls back to the host reader (returns false before anything was added) when
+		// the configuration needs what the kernels do not do: -g annotation, -r parameter files, gene = chromosome name, sharded containers.
+		auto device_file = [&]() -> bool {
+			if (_params_from_files || !_genes.is_empty() || _gene_in_chromosome_name || !container.bulk_ingest_possible()) return false;
+			if (_tags.intronic_read_value.size() > 24 || _tags.intergenic_read_value.size() > 24) return false;
+			struct Map { const uint8_t *p = nullptr; size_t n = 0; int fd = -1; ~Map() { if (p) munmap(const_cast<uint8_t *>(p), n); if (fd >= 0) close(fd); } } map;
+			map.fd = open(bam_name.c_str(), O_RDONLY);
+			if (map.fd < 0) return false;
+			struct stat sb;
+			if (fstat(map.fd, &sb) || sb.st_size <= 0) return false;
+			map.n = size_t(sb.st_size);
+			void *mp = mmap(nullptr, map.n, PROT_READ, MAP_PRIVATE, map.fd, 0);
+			if (mp == MAP_FAILED) return false;
+			map.p = static_cast<const uint8_t *>(mp);
+			// where the records begin: magic, l_text, text, n_ref, (l_name, name, l_ref) x n_ref -- blocks inflated here until that much is seen
+			size_t at = 0, c0 = 0; uint32_t u0 = 0;
+			{
+				std::vector<uint8_t> hdr;
+				std::vector<std::pair<size_t, size_t>> starts;   // (file offset of the block, inflated bytes before it)
+				auto have = [&](size_t nbytes) {
+					while (hdr.size() < nbytes) {
+						RawBlock b;
+						const size_t before = at;
+						if (!read_block(map.p, map.n, at, b, bam_name)) throw std::runtime_error("Truncated BAM header: " + bam_name);
+						starts.emplace_back(before, hdr.size());
+						hdr.resize(hdr.size() + b.isize);
+						inflate_block(b, hdr.data() + hdr.size() - b.isize);
+					}
+				};
+				have(12);
+				if (std::memcmp(hdr.data(), "BAM\1", 4) != 0) throw std::runtime_error("Can't open BAM file: " + bam_name);
+				size_t h = 8 + size_t(le32(hdr.data() + 4));
+				have(h + 4);
+				const uint32_t n_ref = le32(hdr.data() + h);
+				h += 4;
+				refs.clear();
+				for (uint32_t r = 0; r < n_ref; ++r) {
+					have(h + 4);
+					const size_t ln = le32(hdr.data() + h);
+					have(h + 4 + ln + 4);
+					refs.emplace_back(reinterpret_cast<const char *>(hdr.data() + h + 4), ln ? ln - 1 : 0);
+					h += 4 + ln + 4;
+				}
+				container.set_reference_names(refs);
+				c0 = at; u0 = 0;                                 // the header ends with a block: the records open the next one
+				for (size_t k = starts.size(); k-- > 0;)
+					if (starts[k].second <= h && h < (k + 1 < starts.size() ? starts[k + 1].second : hdr.size())) { c0 = starts[k].first; u0 = uint32_t(h - starts[k].second); break; }
+			}
+			dropest_bam_parse_cfg cfg{};
+			for (int k = 0; k < 6; ++k) cfg.tag[k] = wanted_tags[k];
+			cfg.filled_bam = _filled_bam ? 1 : 0; cfg.min_phred = _min_barcode_phred; cfg.has_read_type = _tags.read_type.empty() ? 0 : 1;
+			cfg.n_refs = int32_t(refs.size());
+			cfg.intronic_len = uint32_t(_tags.intronic_read_value.size()); cfg.intergenic_len = uint32_t(_tags.intergenic_read_value.size());
+			std::memcpy(cfg.intronic, _tags.intronic_read_value.data(), cfg.intronic_len);
+			std::memcpy(cfg.intergenic, _tags.intergenic_read_value.data(), cfg.intergenic_len);
+			dropest_bam_decoder *dec = nullptr;
+			if (dropest_bam_decoder_create(container.device(), &cfg, &dec)) return false;              // (no GPU for this: the host reader does it)
+			struct Free { dropest_bam_decoder *d; ~Free() { dropest_bam_decoder_destroy(d); } } free_dec{dec};
+			auto host_inflate = [](const uint8_t *in, uint32_t in_len, uint8_t *out_bytes, uint32_t out_len, void *) -> int {
+				RawBlock b; b.cdata = in; b.clen = in_len; b.isize = out_len; b.crc = le32(in + in_len);
+				try { inflate_block(b, out_bytes); } catch (...) { return 1; }
+				return 0;
+			};
+			std::vector<uint32_t> idx_all, p_pos, p_gene, p_aux; std::vector<uint64_t> need_off, p_cb, p_umi; std::vector<uint8_t> need_bytes;
+			std::vector<uint64_t> dict_hash; std::vector<uint32_t> dict_id; std::vector<int32_t> dict_chr;
+			double dev_ms[4] = {0, 0, 0, 0}, host_ms[3] = {0, 0, 0};
+			const auto t_file = clk::now();
+			size_t window_bytes = size_t(1) << 20, n_windows = 0, repaired = 0, refused = 0, n_needs = 0;
+			const size_t window_max = size_t(getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? std::max(1, atoi(getenv("DROPEST_BAM_DEVICE_WINDOW_MB"))) : 16) << 20;
+			at = c0;
+			bool first = true, dict_dirty = true;
+			while (at < map.n) {
+				const size_t begin = at;
+				while (at < map.n && at - begin < window_bytes) { RawBlock b; if (!read_block(map.p, map.n, at, b, bam_name)) break; }
+				const bool final = at >= map.n;
+				auto t_phase = clk::now();
+				if (dict_dirty) {      // the dictionaries as they stand (other files, earlier windows, add_record calls) go to the device
+					container.dictionary_snapshot(dict_hash, dict_id, dict_chr);
+					if (dropest_bam_decoder_set_dictionaries(dec, dict_hash.data(), dict_id.data(), uint32_t(dict_hash.size()), dict_chr.data(), uint32_t(dict_chr.size())))
+						throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					dict_dirty = false;
+				}
+				host_ms[0] += since(t_phase);
+				dropest_bam_window w{};
+				if (dropest_bam_decoder_window(dec, map.p + begin, at - begin, first ? u0 : 0u, final ? 1 : 0, host_inflate, nullptr, &w))
+					throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+				if (first) container.expect_reads(size_t(double(w.n_records) * double(map.n - c0) / double(std::max<size_t>(at - begin, 1)) * double(bam_files.size()) * 1.05));
+				first = false;
+				++n_windows; repaired += w.guesses_repaired; refused += w.refused_blocks;
+				dev_ms[0] += w.ms_copy; dev_ms[1] += w.ms_inflate; dev_ms[2] += w.ms_boundaries; dev_ms[3] += w.ms_parse;
+				window_bytes = std::min(window_bytes * 4, window_max);
+				const size_t n = size_t(w.n_records);
+				if (!n) continue;
+				t_phase = clk::now();
+				if (w.quality_seen) {
+					// UMI quality strings: every record of this window goes through the record-by-record path (the container keeps the strings)
+					idx_all.resize(n); need_off.resize(n);
+					for (size_t i = 0; i < n; ++i) idx_all[i] = uint32_t(i);
+					need_bytes.resize(size_t(w.window_bytes) + 16);
+					if (dropest_bam_decoder_fetch_records(dec, idx_all.data(), uint32_t(n), need_bytes.data(), need_bytes.size(), need_off.data()))
+						throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					Parsed tmp;
+					for (size_t i = 0; i < n; ++i) {
+						parse_one(need_bytes.data() + need_off[i], tmp);
+						switch (tmp.status) {
+							case SKIP: break;
+							case CANT_PARSE_NO_COUNT: ++_counters.cant_parse; break;
+							case CANT_PARSE: ++_counters.total_reads; ++_counters.cant_parse; break;
+							case LOW_QUALITY: ++_counters.total_reads; ++_counters.low_quality; break;
+							default: ++_counters.total_reads; container.add_record(tmp.r); ++_counters.saved;
+						}
+					}
+					dict_dirty = true;
+					host_ms[1] += since(t_phase);
+					continue;
+				}
+				// what the dictionaries have not seen, in file order (per record: barcode, UMI, gene, chromosome -- the order of add_record)
+				if (w.n_need) {
+					const size_t m = w.n_need;
+					n_needs += m;
+					size_t bytes = 0;
+					for (size_t k = 0; k < m; ++k) bytes += w.need_size[k];
+					need_bytes.resize(bytes + 16); need_off.resize(m);
+					p_pos.resize(m); p_cb.resize(m); p_umi.resize(m); p_gene.resize(m); p_aux.resize(m);
+					if (dropest_bam_decoder_fetch_records(dec, w.need_rec, uint32_t(m), need_bytes.data(), need_bytes.size(), need_off.data()))
+						throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					Parsed tmp;
+					for (size_t k = 0; k < m; ++k) {
+						parse_one(need_bytes.data() + need_off[k], tmp);
+						if (tmp.status != OK) throw std::runtime_error("internal: the device and the host read a BAM record differently: " + bam_name);
+						const CellsDataContainer::ParsedRead &r = tmp.r;
+						const bool has_gene = !r.gene.empty();
+						p_pos[k] = w.need_pos[k];
+						p_cb[k] = r.cb_code ? r.cb_code : container.intern_barcode(std::string(r.cb));
+						if (has_gene) {
+							p_umi[k] = r.umi_code ? r.umi_code : container.intern_umi(std::string(r.umi));
+							p_gene[k] = container.intern_gene(r.gene, r.gene_hash);
+						} else { p_umi[k] = 1; p_gene[k] = DROPEST_NO_GENE; }
+						uint32_t aux = uint32_t(r.mark) << 16;
+						if (!has_gene || (r.mark & (UMI::Mark::HAS_EXONS | UMI::Mark::HAS_INTRONS))) { container.intern_chromosome_of_ref(r.ref_id); aux |= uint32_t(container.chromosome_of_ref(r.ref_id)); }
+						p_aux[k] = aux;
+					}
+					if (dropest_bam_decoder_patch(dec, p_pos.data(), p_cb.data(), p_umi.data(), p_gene.data(), p_aux.data(), uint32_t(m)))
+						throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					dict_dirty = true;
+				}
+				host_ms[1] += since(t_phase); t_phase = clk::now();
+				container.add_records_packed_device(w.d_cb, w.d_umi, w.d_gene, w.d_aux, size_t(w.n_accepted), w.any_gene != 0);
+				host_ms[2] += since(t_phase);
+				_counters.cant_parse += size_t(w.counts[DROPEST_BAM_CANT_PARSE_NO_COUNT] + w.counts[DROPEST_BAM_CANT_PARSE]);
+				_counters.low_quality += size_t(w.counts[DROPEST_BAM_LOW_QUALITY]);
+				_counters.saved += size_t(w.counts[DROPEST_BAM_OK]);
+				_counters.total_reads += size_t(w.counts[DROPEST_BAM_OK] + w.counts[DROPEST_BAM_CANT_PARSE] + w.counts[DROPEST_BAM_LOW_QUALITY]);
+			}
+			if (getenv("DROPEST_BAM_TRACE"))
+				std::fprintf(stderr, "[bam] device path: %zu windows, %.1f ms behind the header; copy in %.1f ms, inflate %.1f ms (%zu blocks left to the host), record chain %.1f ms (%zu guesses "
+				             "repaired), fields + dense columns %.1f ms; host: dictionaries to the device %.1f ms, %zu records with something new %.1f ms, container %.1f ms\n",
+				             n_windows, since(t_file), dev_ms[0], dev_ms[1], refused, dev_ms[2], repaired, dev_ms[3], host_ms[0], n_needs, host_ms[1], host_ms[2]);
+			return true;
+		};
+		static const bool env_device = getenv("DROPEST_BAM_DEVICE") != nullptr && atoi(getenv("DROPEST_BAM_DEVICE")) != 0;
+		if ((_device_decode || env_device) && device_file()) continue;
+		reader_p.reset(new BamReader(bam_name, _threads));
+		BamReader &reader = *reader_p;
+		refs = reader.reference_names();
+		container.set_reference_names(refs);
 		static const bool force_slow = getenv("DROPEST_BAM_RECORD_BY_RECORD") != nullptr;   // tests: the two paths agree
 		bool first_window = true;
 		for (;;) {

@@ -87,6 +87,7 @@ private:
 	bool _filled_bam, _gene_in_chromosome_name;
 	int _min_barcode_phred;
 	unsigned _threads;
+	bool _device_decode = false;
 	Counters _counters;
 	Tools::GeneAnnotation::RefGenesContainer _genes;   // -g: empty unless a GTF / BED file was given
 public:
@@ -95,6 +96,10 @@ public:
 	              bool gene_in_chromosome_name, int min_barcode_phred, unsigned threads = 0);
 	// BamController::parse_bam_files with a BamProcessor: every accepted read reaches container.add_record in file order
 	void parse_bam_files(const std::vector<std::string> &bam_files, CellsDataContainer &container);
+	// BGZF inflate, record chain and tag walk on the container's GPU (include/dropest_bgzf.h) where the configuration allows it: tags or read
+	// names as the source of barcode / UMI / gene; not with -g, -r, gene = chromosome name, or a sharded container (the host reader then runs).
+	// A block's CRC-32 is not checked on that path.  DROPEST_BAM_DEVICE=1 in the environment does the same.
+	void set_device_decode(bool on) { _device_decode = on; }
 	const Counters &counters() const { return _counters; }
 };
 

@@ -322,6 +322,20 @@ void CellsDataContainer::add_records_packed(const uint64_t *cb, const uint64_t *
 	}
 }
 
+void CellsDataContainer::add_records_packed_device(const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene, const uint32_t *d_aux, size_t n, bool any_gene) {
+	if (_is_initialized) throw std::runtime_error("Container is already initialized");
+	if (!bulk_ingest_possible()) throw std::runtime_error("add_records_packed: the container is sharded or carries UMI qualities (use add_record)");
+	_preview_valid = false; ++_generation;
+	if (!n) return;
+	flush();                                   // whatever add_record collected comes first
+	if (_umi_quality_length == size_t(-1) && any_gene) { _umi_quality_length = 0; _qual_pending = 0; }   // the first gene-bearing read fixes the quality length: none
+	if (_umi_quality_length == size_t(-1)) _qual_pending += n;
+	_qual_reads += n;
+	if (!_qual_lens.empty()) _qual_lens.insert(_qual_lens.end(), n, uint8_t(0));
+	send_side_strings(_ctx);
+	check(dropest_push_reads_device(_ctx, d_cb, d_umi, d_gene, d_aux, n, 0));
+}
+
 void CellsDataContainer::set_reference_names(const std::vector<std::string> &names) {
 	_ref_names = names;
 	_ref_chr.assign(names.size(), -1);

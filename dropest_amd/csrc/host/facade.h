@@ -400,6 +400,18 @@ public:
 	// index of a gene that is ALREADY in the dictionary, -1 otherwise; safe to call from several threads as long as no
 	// add_record runs at the same time
 	int64_t lookup_gene(uint64_t gene_hash, std::string_view name) const;
+	// by the hash alone (the device BAM path has no string in hand: csrc/k_bamparse.h): the index of the FIRST name with this FNV-1a
+	// value, -1 = unseen.  Two names of one data set with the same 64-bit hash would share an index on that path (2^-64 per pair).
+	int64_t lookup_gene_hash(uint64_t gene_hash) const { auto it = _gene_by_hash.find(gene_hash); return it == _gene_by_hash.end() ? -1 : int64_t(it->second); }
+	int device() const { return _device; }
+	// the gene dictionary as (hash, index) pairs and the chromosome index of every reference (-1 = none yet): what the device BAM path looks records up in
+	void dictionary_snapshot(std::vector<uint64_t> &gene_hash, std::vector<uint32_t> &gene_id, std::vector<int32_t> &chr_of_ref) const {
+		gene_hash.clear(); gene_id.clear();
+		for (auto const &kv : _gene_by_hash) { gene_hash.push_back(kv.first); gene_id.push_back(kv.second); }
+		chr_of_ref.assign(_ref_chr.begin(), _ref_chr.end());
+	}
+	// add_records_packed for columns that already live in the container's GPU memory (include/dropest_bgzf.h); any_gene: some read carries a gene
+	void add_records_packed_device(const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene, const uint32_t *d_aux, size_t n, bool any_gene);
 	// ---- bulk ingest (the BAM reader's fast path) ----------------------------------------------------------------------
 	// add_record read by read costs a handful of vector appends and dictionary look-ups per read on ONE thread; a caller that
 	// parses records on many threads resolves the dictionaries itself -- the few reads per window that bring something new

@@ -1,0 +1,277 @@
+// k_inflate.h -- raw DEFLATE (RFC 1951) of BGZF blocks on the device: one 64-lane wave per block.
+//
+// What it replaces: BamTools' BgzfStream::InflateBlock (zlib inflate per block) under BamReader::GetNextAlignment, the loop
+// Estimation/BamProcessing/BamController.cpp:85 spends its time in.  A BGZF block (SAMv1 §4.1) is an independent
+// DEFLATE stream of <= 64 KB, so blocks are the parallel axis: thousands of them are in flight, one per wave.  Inside a block the
+// symbol stream is serial -- every code's position depends on the one before -- so the wave decodes with wave-uniform values
+// (all lanes compute the same thing, LDS look-ups are broadcasts) and uses its 64 lanes where the format allows:
+//   * the input is staged through a 1 KB ring in LDS, 512 bytes per coalesced load;
+//   * Huffman tables are built with ballots (rank of a symbol among the symbols of its code length), 64 symbols per step;
+//   * literals are collected in LDS and stored 64 at a time; a match is copied by all lanes, 64 bytes per step.
+// Tables per wave: a 10-bit root table for literal / length codes and an 8-bit one for distances (u16 entries: symbol << 4 | length);
+// longer codes (rare symbols) are decoded canonically from the per-length counts, bit by bit (the method of zlib's puff.c).
+// Written from RFC 1951.  The CRC-32 of a block is NOT checked here (the host reader checks it; dropest_bgzf.h says so); ISIZE is.
+// Integer work; no MFMA.  4.7 KB of LDS per wave: 8 workgroups of 4 waves per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dropest {
+
+constexpr int INF_WAVES = 4;
+constexpr int INF_LROOT = 10, INF_DROOT = 8;
+// status of a block: 0 = ok; anything else: the block was not (completely) written and the caller inflates it elsewhere
+enum : uint32_t { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_LENGTHS = 3, INF_OVERSUBSCRIBED = 4, INF_BAD_CODE = 5,
+                  INF_BAD_DISTANCE = 6, INF_OUTPUT_OVERRUN = 7, INF_INPUT_OVERRUN = 8, INF_SIZE_MISMATCH = 9 };
+
+struct InfWaveLds {
+	uint16_t lroot[1 << INF_LROOT];
+	uint16_t droot[1 << INF_DROOT];
+	uint16_t lsym[288];      // symbols in canonical order (by code length, then by symbol)
+	uint16_t dsym[32];
+	uint16_t lcount[16], dcount[16];
+	uint8_t lens[320];       // HLIT + HDIST code lengths
+	uint64_t in[128];        // input ring: the 1 024 bytes around the read position, indexed by (absolute offset / 8) mod 128
+	uint8_t lit[64];         // literals waiting for their store
+};
+
+__constant__ const uint16_t INF_LEN_BASE[32] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 0, 0, 0};
+__constant__ const uint8_t INF_LEN_EXTRA[32] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0, 0, 0, 0};
+__constant__ const uint16_t INF_DIST_BASE[32] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577, 0, 0};
+__constant__ const uint8_t INF_DIST_EXTRA[32] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 0, 0};
+__constant__ const uint8_t INF_CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct InfState {
+	const uint64_t *gin;     // the compressed bytes as aligned words
+	uint64_t in_words;       // words that may be read (the whole buffer)
+	uint64_t ipos;           // absolute byte offset of the next byte to enter `bits`
+	uint64_t loaded_hi;      // bytes below this absolute offset (a multiple of 512) are in the ring (the last 1 024 of them)
+	uint64_t bits;
+	int cnt;
+};
+
+// Everything the decoder keeps is the same in all 64 lanes; a value read from LDS is a vector register until it is named uniform:
+// then the bit buffer, the positions and the table entries live in scalar registers and the scalar unit does their arithmetic.
+__device__ inline uint32_t inf_uni(uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+__device__ inline uint64_t inf_uni64(uint64_t v) { return uint64_t(inf_uni(uint32_t(v))) | (uint64_t(inf_uni(uint32_t(v >> 32))) << 32); }
+
+__device__ inline void inf_ring_fill(InfState &s, InfWaveLds &L, uint32_t lane) {
+	while (s.ipos + 16 > s.loaded_hi) {
+		const uint64_t w = (s.loaded_hi >> 3) + lane;
+		L.in[w & 127u] = w < s.in_words ? s.gin[w] : 0ull;
+		s.loaded_hi += 512;
+	}
+}
+__device__ inline void inf_refill(InfState &s, InfWaveLds &L, uint32_t lane) {   // at least 56 valid bits afterwards
+	inf_ring_fill(s, L, lane);
+	const uint32_t idx = uint32_t(s.ipos >> 3) & 127u, sh = uint32_t(s.ipos & 7u) * 8u;
+	const uint64_t lo = inf_uni64(L.in[idx]), hi = inf_uni64(L.in[(idx + 1u) & 127u]);
+	const uint64_t w = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+	s.bits |= w << s.cnt;
+	const int adv = (63 - s.cnt) >> 3;
+	s.ipos += uint64_t(adv);
+	s.cnt += adv * 8;
+}
+__device__ inline uint32_t inf_take(InfState &s, InfWaveLds &L, uint32_t lane, int n) {   // n <= 16
+	if (s.cnt < n) inf_refill(s, L, lane);
+	const uint32_t v = uint32_t(s.bits) & ((1u << n) - 1u);
+	s.bits >>= n; s.cnt -= n;
+	return v;
+}
+
+// Canonical Huffman code of lens[0 .. n): root table (codes up to root_bits, indexed by the next input bits, LSB first), the symbols in
+// canonical order and the number of codes of every length.  All 64 lanes; n <= 320.  false: over-subscribed code.
+__device__ inline bool inf_build(const uint8_t *lens, int n, int root_bits, uint16_t *root, uint16_t *sym, uint16_t *count, uint32_t lane) {
+	uint32_t mylen[5];
+#pragma unroll
+	for (int c = 0; c < 5; ++c) { const int s = c * 64 + int(lane); mylen[c] = s < n ? lens[s] : 0u; }
+	for (uint32_t i = lane; i < (1u << root_bits); i += 64) root[i] = 0;
+	uint32_t cnt[16];
+	cnt[0] = 0;
+#pragma unroll
+	for (int l = 1; l <= 15; ++l) {
+		uint32_t c = 0;
+#pragma unroll
+		for (int k = 0; k < 5; ++k) c += uint32_t(__popcll(__ballot(mylen[k] == uint32_t(l))));
+		cnt[l] = c;
+	}
+	int left = 1;
+#pragma unroll
+	for (int l = 1; l <= 15; ++l) { left = (left << 1) - int(cnt[l]); if (left < 0) return false; }
+	if (lane < 16) count[lane] = 0;
+	uint32_t code = 0, off = 0;
+	const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+	for (int l = 1; l <= 15; ++l) {
+		code = (code + (l > 1 ? cnt[l - 1] : 0u)) << 1;   // first code of length l
+		if (lane == 0) count[l] = uint16_t(cnt[l]);
+		uint32_t seen = 0;
+#pragma unroll
+		for (int k = 0; k < 5; ++k) {
+			const bool mine = mylen[k] == uint32_t(l);
+			const uint64_t m = __ballot(mine);
+			if (mine) {
+				const uint32_t rank = seen + uint32_t(__popcll(m & lt));
+				const uint32_t s = uint32_t(k) * 64u + lane;
+				sym[off + rank] = uint16_t(s);
+				if (l <= root_bits) {
+					const uint32_t c = code + rank;                       // l bits, most significant first
+					const uint32_t r = __brev(c) >> (32 - l);             // as it arrives in the stream
+					const uint16_t e = uint16_t((s << 4) | uint32_t(l));
+					for (uint32_t j = r; j < (1u << root_bits); j += 1u << l) root[j] = e;
+				}
+			}
+			seen += uint32_t(__popcll(m));
+		}
+		off += cnt[l];
+	}
+	return true;
+}
+
+// One symbol: root table, or bit by bit for the codes the table does not hold.  Returns the symbol, 0xFFFF = no such code.
+__device__ inline uint32_t inf_decode(InfState &s, InfWaveLds &L, uint32_t lane, const uint16_t *root, int root_bits, const uint16_t *sym, const uint16_t *count) {
+	if (s.cnt < 15) inf_refill(s, L, lane);
+	const uint32_t e = inf_uni(root[uint32_t(s.bits) & ((1u << root_bits) - 1u)]);
+	if (e) { s.bits >>= (e & 15u); s.cnt -= int(e & 15u); return e >> 4; }
+	uint32_t code = 0, first = 0, index = 0;
+	uint64_t b = s.bits;
+	for (int len = 1; len <= 15; ++len) {
+		code |= uint32_t(b & 1u); b >>= 1;
+		const uint32_t c = inf_uni(count[len]);
+		if (code < first + c) { s.bits >>= len; s.cnt -= len; return inf_uni(sym[index + (code - first)]); }
+		index += c; first += c; first <<= 1; code <<= 1;
+	}
+	return 0xFFFFu;
+}
+
+// One BGZF block per wave.  in_off / in_len: the DEFLATE payload inside d_in (behind the 18-byte header); out_off / out_len: where its
+// ISIZE bytes go in d_out.  d_in must be 8-byte aligned and in_total_len is the number of bytes that may be read.
+// Waves per SIMD the register allocation aims at: measured on a 3.3 GB synthetic 10x BAM (scripts/experiments/inflate_variants/run.sh):
+// 4 (no spills) 77.5 GB/s, 5: 91.6, 6: 104.2, 8 (55 VGPRs spilled): 83.7.  The fence before a match copy costs nothing at any of them.
+#ifndef INF_WAVES_PER_EU
+#define INF_WAVES_PER_EU 6
+#endif
+__global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(INF_WAVES_PER_EU, INF_WAVES_PER_EU))) void bgzf_inflate_kernel(const uint8_t *__restrict__ d_in, uint64_t in_total_len,
+                                                                       const uint64_t *__restrict__ in_off, const uint32_t *__restrict__ in_len,
+                                                                       const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ out_len,
+                                                                       uint32_t n_blocks, uint8_t *d_out, uint32_t *__restrict__ status) {
+	__shared__ InfWaveLds lds[INF_WAVES];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t blk = blockIdx.x * INF_WAVES + wave;
+	if (blk >= n_blocks) return;
+	InfWaveLds &L = lds[wave];
+	InfState s;
+	s.gin = reinterpret_cast<const uint64_t *>(d_in);
+	s.in_words = (in_total_len + 7) >> 3;
+	const uint64_t in_begin = in_off[blk], in_end = in_begin + in_len[blk];
+	s.ipos = in_begin; s.loaded_hi = in_begin & ~uint64_t(511); s.bits = 0; s.cnt = 0;
+	uint8_t *const out = d_out + out_off[blk];
+	const uint32_t out_cap = out_len[blk];
+	uint32_t pos = 0, nlit = 0, err = INF_OK;
+
+	auto flush = [&]() {
+		if (nlit) { if (lane < nlit) out[pos + lane] = L.lit[lane]; pos += nlit; nlit = 0; }
+	};
+
+	for (bool last = false; !last && !err;) {
+		last = inf_take(s, L, lane, 1) != 0;
+		const uint32_t type = inf_take(s, L, lane, 2);
+		if (type == 0) {   // stored: to the byte boundary, LEN, NLEN, bytes
+			flush();
+			const int drop = s.cnt & 7;
+			s.bits >>= drop; s.cnt -= drop;
+			const uint32_t len = inf_take(s, L, lane, 16), nlen = inf_take(s, L, lane, 16);
+			if ((len ^ nlen) != 0xFFFFu) { err = INF_BAD_STORED; break; }
+			const uint64_t from = s.ipos - uint64_t(s.cnt >> 3);          // first byte not consumed yet
+			if (from + len > in_end) { err = INF_INPUT_OVERRUN; break; }
+			if (pos + len > out_cap) { err = INF_OUTPUT_OVERRUN; break; }
+			for (uint32_t i = lane; i < len; i += 64) out[pos + i] = d_in[from + i];
+			pos += len;
+			s.ipos = from + len; s.bits = 0; s.cnt = 0; s.loaded_hi = s.ipos & ~uint64_t(511);
+			continue;
+		}
+		if (type == 3) { err = INF_BAD_BLOCK_TYPE; break; }
+		int hlit, hdist;
+		if (type == 1) {   // fixed code (RFC 1951 3.2.6)
+			hlit = 288; hdist = 30;
+			for (uint32_t i = lane; i < 288u; i += 64) L.lens[i] = i < 144u ? 8 : (i < 256u ? 9 : (i < 280u ? 7 : 8));
+			if (lane < 30u) L.lens[288u + lane] = 5;
+		} else {           // dynamic code (3.2.7)
+			hlit = int(inf_take(s, L, lane, 5)) + 257; hdist = int(inf_take(s, L, lane, 5)) + 1;
+			const int hclen = int(inf_take(s, L, lane, 4)) + 4;
+			if (hlit > 286 || hdist > 30) { err = INF_BAD_LENGTHS; break; }
+			if (lane < 19u) L.lens[lane] = 0;
+			for (int i = 0; i < hclen; ++i) {
+				const uint32_t v = inf_take(s, L, lane, 3);
+				if (lane == 0) L.lens[INF_CL_ORDER[i]] = uint8_t(v);
+			}
+			// the code-length code borrows the distance tables (7-bit root)
+			if (!inf_build(L.lens, 19, 7, L.droot, L.dsym, L.dcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
+			int have = 0;
+			uint32_t prev = 0;
+			const int total = hlit + hdist;
+			while (have < total && !err) {
+				const uint32_t sy = inf_decode(s, L, lane, L.droot, 7, L.dsym, L.dcount);
+				uint32_t rep = 1, val = sy;
+				if (sy < 16u) { prev = sy; }
+				else if (sy == 16u) { if (!have) { err = INF_BAD_LENGTHS; break; } rep = 3 + inf_take(s, L, lane, 2); val = prev; }
+				else if (sy == 17u) { rep = 3 + inf_take(s, L, lane, 3); val = 0; prev = 0; }
+				else if (sy == 18u) { rep = 11 + inf_take(s, L, lane, 7); val = 0; prev = 0; }
+				else { err = INF_BAD_CODE; break; }
+				if (have + int(rep) > total) { err = INF_BAD_LENGTHS; break; }
+				// (the lengths land behind the 19 code-length lengths: lens[] is read again by inf_build below, from offset 0 -- so they are
+				// written to their final places only after the code-length table is no longer needed: it lives in droot / dsym, not in lens)
+				for (uint32_t i = lane; i < rep; i += 64) L.lens[uint32_t(have) + i] = uint8_t(val);
+				have += int(rep);
+			}
+			if (err) break;
+			if (inf_uni(L.lens[256]) == 0) { err = INF_BAD_LENGTHS; break; }   // no end-of-block code
+		}
+		if (!inf_build(L.lens, hlit, INF_LROOT, L.lroot, L.lsym, L.lcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
+		if (!inf_build(L.lens + hlit, hdist, INF_DROOT, L.droot, L.dsym, L.dcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
+
+		for (;;) {
+			const uint32_t sy = inf_decode(s, L, lane, L.lroot, INF_LROOT, L.lsym, L.lcount);
+			if (sy < 256u) {
+				if (lane == 0) L.lit[nlit] = uint8_t(sy);
+				if (++nlit == 64u) { if (pos + 64u > out_cap) { err = INF_OUTPUT_OVERRUN; break; } flush(); }
+				continue;
+			}
+			if (sy == 256u) break;
+			if (sy > 285u) { err = INF_BAD_CODE; break; }
+			if (pos + nlit > out_cap) { err = INF_OUTPUT_OVERRUN; break; }
+			flush();
+			const uint32_t li = sy - 257u;
+			uint32_t len = INF_LEN_BASE[li];
+			const int le = INF_LEN_EXTRA[li];
+			if (le) len += inf_take(s, L, lane, le);
+			const uint32_t ds = inf_decode(s, L, lane, L.droot, INF_DROOT, L.dsym, L.dcount);
+			if (ds > 29u) { err = INF_BAD_CODE; break; }
+			uint32_t dist = INF_DIST_BASE[ds];
+			const int de = INF_DIST_EXTRA[ds];
+			if (de) dist += inf_take(s, L, lane, de);
+			if (dist > pos) { err = INF_BAD_DISTANCE; break; }
+			if (pos + len > out_cap) { err = INF_OUTPUT_OVERRUN; break; }
+			// the source window [pos - dist, pos) is complete: a copy longer than dist repeats it
+#ifndef INF_NO_FENCE
+			__threadfence_block();   // this wave's earlier stores, before other lanes read them
+#endif
+			const uint8_t *src = out + (pos - dist);
+			if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) out[pos + i] = src[i]; }
+			else { for (uint32_t i = lane; i < len; i += 64) out[pos + i] = src[i % dist]; }
+			pos += len;
+		}
+	}
+	if (!err) {
+		if (pos + nlit > out_cap) err = INF_OUTPUT_OVERRUN;
+		else {
+			flush();
+			if (pos != out_cap) err = INF_SIZE_MISMATCH;
+			else if (s.ipos - uint64_t(s.cnt >> 3) > in_end) err = INF_INPUT_OVERRUN;
+		}
+	}
+	if (lane == 0) status[blk] = err;
+}
+
+}  // namespace dropest

@@ -1,0 +1,97 @@
+/* dropest_bgzf.h -- BGZF blocks inflated on the device (the BAM reader that feeds the path).
+ *
+ * What it replaces: BamTools' BgzfStream (zlib inflate, one block at a time) under BamReader::GetNextAlignment, the loop of
+ * Estimation/BamProcessing/BamController.cpp:85.  A BGZF block (SAMv1 §4.1) is an independent DEFLATE stream of at most 64 KB:
+ * dropest_bgzf_scan walks the block headers on the host (18 + 8 bytes per block), dropest_bgzf_inflate_device decodes every block
+ * with one 64-lane wave (csrc/k_inflate.h).  Plain C, no torch types.
+ *
+ * NOT checked on the device: a block's CRC-32 (dropest_bgzf_scan returns it; the host reader, csrc/host/bam_ingest.cpp, checks it).
+ * Checked: every Huffman code, distance and length, the input and output bounds, ISIZE.  A block the device refuses (status != 0)
+ * is left for the caller to inflate elsewhere; nothing outside its own output range is written. */
+#ifndef DROPEST_BGZF_H
+#define DROPEST_BGZF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Walks the BGZF blocks of data[0 .. len): for block k the DEFLATE payload is data[in_off[k] .. + in_len[k]), its ISIZE bytes belong at
+ * out_off[k] (running sum) and number out_len[k]; crc32[k] is the stored CRC-32 (may be NULL).  Stops at `cap` blocks, at a block that
+ * is not complete inside the buffer, or at the end; *bytes_used = offset of the first byte not consumed.  0 = ok, 1 = not a BGZF header. */
+int dropest_bgzf_scan(const uint8_t *data, uint64_t len, uint64_t cap, uint64_t *in_off, uint32_t *in_len, uint64_t *out_off,
+                      uint32_t *out_len, uint32_t *crc32, uint64_t *n_blocks, uint64_t *bytes_used, uint64_t *out_total);
+
+/* Every pointer is DEVICE memory of `device`; d_in 8-byte aligned, in_total = bytes of d_in that may be read.  Asynchronous on `stream`
+ * (a hipStream_t, NULL = the default stream).  d_status[k] = 0 when block k came out whole. */
+int dropest_bgzf_inflate_device(int device, void *stream, const uint8_t *d_in, uint64_t in_total, const uint64_t *d_in_off,
+                                const uint32_t *d_in_len, const uint64_t *d_out_off, const uint32_t *d_out_len, uint32_t n_blocks,
+                                uint8_t *d_out, uint32_t *d_status);
+
+/* Host buffer in, host buffer out (tests, scripts/bench_bgzf_inflate.py): scan + upload + kernel (`repeats` times; *kernel_ms = mean
+ * of the runs by HIP events) + download.  status[0 .. min(n_blocks, status_cap)) per block.  Returns 0, or 1 with
+ * dropest_bgzf_last_error() set (no GPU, out_cap too small, not BGZF). */
+int dropest_bgzf_inflate_buffer(int device, const uint8_t *data, uint64_t len, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
+                                uint32_t *status, uint64_t status_cap, uint64_t *n_blocks, double *kernel_ms, int repeats);
+
+/* ---- BAM records of a window of BGZF blocks, on the device (csrc/k_bamparse.h) -------------------------------------------------------
+ * What BamController::process_alignment (BamController.cpp:132-172) decides without a dictionary: the reader's status of a record, the
+ * 2-bit codes of its barcode and UMI, its UMI::Mark, and -- against a copy of the caller's dictionaries -- its gene and chromosome index:
+ * the accepted records leave as the four dense columns of dropest_push_reads IN DEVICE MEMORY (dropest_push_reads_device takes them as
+ * they are).  The dictionaries themselves (gene names, chromosomes, strings with N) stay with the caller, who asks for the bytes of the
+ * few records that bring something new, resolves them in file order and patches their rows. */
+typedef struct dropest_bam_decoder dropest_bam_decoder;
+
+typedef struct dropest_bam_parse_cfg {
+	uint16_t tag[6];          /* cell barcode, UMI, barcode quality, UMI quality, gene, read type (BamTags.cpp:7-24): letters lo | hi << 8, 0 = none */
+	int32_t filled_bam;       /* -f: 1 = barcode / UMI from tags (FilledBamParamsParser), 0 = from the read name "id!CB#UMI" */
+	int32_t min_phred;        /* min_barcode_phred as a character code (33 + score); the filter is on when > 33 */
+	int32_t has_read_type;
+	int32_t n_refs;
+	uint32_t intronic_len, intergenic_len;
+	uint8_t intronic[24], intergenic[24];
+} dropest_bam_parse_cfg;
+
+enum { DROPEST_BAM_OK = 0, DROPEST_BAM_SKIP = 1, DROPEST_BAM_CANT_PARSE_NO_COUNT = 2, DROPEST_BAM_CANT_PARSE = 3, DROPEST_BAM_LOW_QUALITY = 4 };
+
+typedef struct dropest_bam_window {        /* host pointers: pinned memory of the decoder; d_*: DEVICE memory; all valid until its next window */
+	uint64_t n_records;                    /* complete records that START in this window (the cut-off last one opens the next window) */
+	uint64_t counts[5];                    /* records per DROPEST_BAM_* status */
+	uint64_t n_accepted;                   /* = counts[DROPEST_BAM_OK]: rows of the dense columns below, in file order */
+	const uint64_t *d_cb, *d_umi;          /* the columns of dropest_push_reads (dropest_amd.h), as BamController's bulk path fills them: */
+	const uint32_t *d_gene, *d_aux;        /*   gene = index from the dictionary given to the decoder, aux = chromosome index | mark << 16 */
+	uint32_t n_need;                       /* accepted records the caller must see as bytes (a gene or chromosome the dictionaries lack, an N): */
+	const uint32_t *need_rec, *need_pos, *need_size;   /* record of the window, its row in the dense columns, its bytes (block_size field included) */
+	uint32_t quality_seen, any_gene;       /* an accepted record carries a UMI quality tag / a gene name */
+	uint64_t window_bytes, tail_bytes;     /* inflated bytes looked at; bytes of the cut-off last record carried over */
+	uint32_t n_blocks, refused_blocks;     /* blocks the device left to `inflate_fallback` */
+	uint32_t guesses_repaired, pad;        /* segments whose guessed first record was not on the chain (walked again from the true place) */
+	double ms_inflate, ms_boundaries, ms_parse, ms_copy;
+} dropest_bam_window;
+
+/* raw DEFLATE of one block on the host (zlib or the like) for the blocks the device refuses; 0 = ok */
+typedef int (*dropest_bgzf_host_inflate)(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, void *user);
+
+int dropest_bam_decoder_create(int device, const dropest_bam_parse_cfg *cfg, dropest_bam_decoder **out);
+void dropest_bam_decoder_destroy(dropest_bam_decoder *d);
+/* comp[0 .. len): whole BGZF blocks, following the previous window's.  first_skip: bytes of the first block to pass over (the BAM header;
+ * first window only).  final != 0: the file ends here (a cut-off record is then an error). */
+int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
+                               dropest_bgzf_host_inflate inflate_fallback, void *user, dropest_bam_window *out);
+/* The dictionaries the records are looked up in (copied): gene_hash[k] (FNV-1a of the name) -> gene_id[k]; chr_of_ref[r] = chromosome
+ * index of reference r, -1 = none yet.  Call again whenever they have grown. */
+int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, const uint64_t *gene_hash, const uint32_t *gene_id, uint32_t n_genes,
+                                         const int32_t *chr_of_ref, uint32_t n_refs);
+/* the bytes of records idx[0 .. n) of the LAST window (block_size field first), one after the other: dst_off[k] = where record idx[k] starts in dst */
+int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const uint32_t *idx, uint32_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *dst_off);
+/* rows pos[0 .. n) of the LAST window's dense columns take these values (what the caller resolved for the `need` records) */
+int dropest_bam_decoder_patch(dropest_bam_decoder *d, const uint32_t *pos, const uint64_t *cb, const uint64_t *umi, const uint32_t *gene,
+                              const uint32_t *aux, uint32_t n);
+
+const char *dropest_bgzf_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

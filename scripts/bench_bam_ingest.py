@@ -38,8 +38,10 @@ print("wrote %s: %d reads, %.1f MB, %.1f s" % (bam, n, os.path.getsize(bam) / 1e
 # is measured over seconds, and inflate / parse / push pipeline as they do on a real multi-gigabyte BAM)
 thread_counts = [int(x) for x in os.environ.get("THREADS", "1,4,16,64").split(",")]
 for threads in thread_counts:
-    for env, label in (({}, "bulk"), ({"DROPEST_BAM_RECORD_BY_RECORD": "1"}, "record-by-record")):
-        if label != "bulk" and threads not in (16,):
+    for env, label in (({}, "bulk"), ({"DROPEST_BAM_RECORD_BY_RECORD": "1"}, "record-by-record"), ({"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_TRACE": "1"}, "device")):
+        if label == "record-by-record" and threads not in (16,):
+            continue
+        if label == "device" and threads not in (4, 16):
             continue
         res = subprocess.run([os.path.join(ROOT, "tests", "cpp", "bam_to_counts"), os.path.join(tmp, "out"), "filled", "20", "100", "-",
                               str(threads), bam], capture_output=True, text=True, env=dict(os.environ, **env))

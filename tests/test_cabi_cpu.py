@@ -28,6 +28,8 @@ def test_library_exports_every_declared_symbol():
     assert sorted(names) == sorted(capi.EXPORTED_SYMBOLS)
     for n in _declared("dropest_annotation.h"):          # the device gene annotation (bound by tests/test_gpu_annotation.py)
         assert hasattr(L, n), "missing export: " + n
+    for n in _declared("dropest_bgzf.h"):                # BGZF blocks inflated on the device (bound by tests/test_gpu_bgzf.py)
+        assert hasattr(L, n), "missing export: " + n
 
 
 def test_cfg_defaults_match_reference_defaults():

@@ -95,7 +95,10 @@ def test_filled_bam_tags(tmp_path):
     assert len(chr_frames["Intron"].value) > 0 and len(chr_frames["Intergenic"].value) > 0
     # the record-by-record path (add_record per read on the caller's thread) and the bulk path (workers write packed records, the
     # caller resolves only what is new to the dictionaries) give the same container; several worker counts
-    for env, threads in (({"DROPEST_BAM_RECORD_BY_RECORD": "1"}, 3), ({}, 1), ({}, 7)):
+    # ... and the device path (DROPEST_BAM_DEVICE: blocks inflated, records found and tags walked on the GPU, csrc/k_inflate.h + k_bamparse.h),
+    # with one window per megabyte and with windows of whole files
+    for env, threads in (({"DROPEST_BAM_RECORD_BY_RECORD": "1"}, 3), ({}, 1), ({}, 7), ({"DROPEST_BAM_DEVICE": "1"}, 3),
+                         ({"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_DEVICE_WINDOW_MB": "1"}, 6)):
         got2, cells2, stats2, _ = _run(tmp_path / ("again%d%d" % (threads, len(env))), "filled", [b1, b2], 5, 10, threads=threads, env=env)
         assert cells2 == cells and got2 == got
         assert {k: stats2[k] for k in ("total_reads", "cant_parse", "low_quality", "saved")} == {k: stats[k] for k in ("total_reads", "cant_parse", "low_quality", "saved")}
@@ -124,6 +127,9 @@ def test_record_boundaries_found_by_the_loader(tmp_path, block):
     assert cells2 == cells and got2 == got and stats2["saved"] == stats["saved"]
     got3, cells3, _, _ = _run(tmp_path / "zlib", "filled", [bam], 3, 5, threads=2, env={"DROPEST_BAM_ZLIB": "1"})
     assert cells3 == cells and got3 == got
+    # the device finds the chain of records by guessing per 16 KB segment and checking the guesses (k_bamparse.h): same container
+    got4, cells4, stats4, _ = _run(tmp_path / "device", "filled", [bam], 3, 5, threads=4, env={"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_TRACE": "1"})
+    assert cells4 == cells and got4 == got and stats4["saved"] == stats["saved"]
 
 
 def test_read_name_encoding_and_whitelist_merge(tmp_path):
@@ -357,3 +363,49 @@ def test_read_parameter_files(tmp_path):
     # the qualities of the rows reached the molecules
     rp = d["reads_per_umi_per_cell"]
     assert len(rp["reads_per_umi"].value[0].value[0].value[1].value) == 8
+
+
+def test_device_path_read_names_long_records_and_strings_with_n(tmp_path):
+    """The device path on what its guesses find hard: read-name mode ("id!CB#UMI"), records longer than a 16 KB segment (no record starts in
+    some segments), names that look like nothing in particular, barcodes / UMIs with N (packed by the host), a gene met first in the LAST
+    window, UMI quality tags in one file (that window takes the record-by-record path).  Same .rds as the host reader, same counters."""
+    reads = _reads(30_000)
+    refs = [("chr%d" % i, 1_000_000) for i in range(25)]
+    rng = np.random.default_rng(9)
+    recs = []
+    for i, (cb, umi, g, chr_, mark) in enumerate(reads):
+        if i % 997 == 0:
+            umi = umi[:3] + "N" + umi[4:]
+        if i % 1499 == 0:
+            cb = "N" + cb[1:]
+        g2 = "LATE_GENE" if i > 29_900 and g else g
+        tags = ([("GX", "Z", g2)] if g2 else []) + [("NH", "i", 1)]
+        seq = "ACGT" * (6000 if i % 4001 == 7 else 1 + i % 13)                     # a few records of 36 KB
+        recs.append(bw.record(int(chr_[3:]), i, "x%d!%s#%s" % (i, cb, umi), seq=seq, tags=tags))
+    bam = str(tmp_path / "names.bam")
+    bw.write_bam(bam, refs, recs, block=30_000)
+    host = _run(tmp_path / "host", "name", [bam], 3, 5, threads=4)
+    dev = _run(tmp_path / "dev", "name", [bam], 3, 5, threads=4, env={"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_DEVICE_WINDOW_MB": "1"})
+    assert dev[1] == host[1] and dev[0] == host[0] and len(host[0]) > 500
+    assert {k: dev[2][k] for k in ("total_reads", "cant_parse", "low_quality", "saved")} == {k: host[2][k] for k in ("total_reads", "cant_parse", "low_quality", "saved")}
+    assert any(g == "LATE_GENE" for g, _ in host[0])
+    # UMI quality tags: the windows that carry them go record by record; the per-molecule quality sums land in the .rds
+    recs_q = []
+    for i, (cb, umi, g, chr_, mark) in enumerate(reads[:8000]):
+        tags = [("CB", "Z", cb), ("UB", "Z", umi), ("UQ", "Z", "".join(chr(33 + int(x)) for x in rng.integers(2, 40, len(umi))))] + ([("GX", "Z", g)] if g else [])
+        recs_q.append(bw.record(int(chr_[3:]), i, "q%d" % i, tags=tags))
+    bam_q = str(tmp_path / "qual.bam")
+    bw.write_bam(bam_q, refs, recs_q, block=20_000)
+    host_q = _run(tmp_path / "host_q", "filled", [bam_q], 2, 3, threads=3, env={"DROPEST_RPUPC": "1"})
+    dev_q = _run(tmp_path / "dev_q", "filled", [bam_q], 2, 3, threads=3, env={"DROPEST_BAM_DEVICE": "1", "DROPEST_RPUPC": "1"})
+    assert dev_q[1] == host_q[1] and dev_q[0] == host_q[0] and dev_q[2]["saved"] == host_q[2]["saved"] == 8000
+    def molecules(d):
+        rp = d["reads_per_umi_per_cell"]
+        cells_l, genes_l = rp["cells"].value, rp["genes"].value
+        seen = {}
+        for ci, gi, per_gene in zip(rp["cell_indexes"].value, rp["gene_indexes"].value, rp["reads_per_umi"].value):
+            for name, entry in zip(per_gene.names, per_gene.value):
+                seen[(cells_l[int(ci)], genes_l[int(gi)], name)] = (int(entry.value[0].value[0]), [float(x) for x in entry.value[1].value])
+        return seen
+    a, b = molecules(host_q[3]), molecules(dev_q[3])
+    assert len(a) > 1000 and a == b
