@@ -133,6 +133,7 @@ struct dropest_bam_decoder {
 	DevBuf<uint8_t> o_status, o_need;
 	DevBuf<BamWindowCounts> d_wc;
 	PinnedBuf<uint64_t> h_seg_start, h_seg_exit;
+	PinnedBuf<uint8_t> h_stage[2];
 	PinnedBuf<uint32_t> h_count, h_block_status, h_need_rec, h_need_pos, h_need_size, h_gsize;
 	std::vector<uint64_t> in_off, out_off;
 	std::vector<uint32_t> in_len, out_len, base;
@@ -160,6 +161,15 @@ extern "C" int dropest_bam_decoder_create(int device, const dropest_bam_parse_cf
 			HIP_CHECK(hipMemset(d->d_chr.p, 0xFF, size_t(std::max(1, cfg->n_refs)) * 4));
 		} catch (...) { delete d; throw; }
 		*out = d;
+	});
+}
+
+extern "C" int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, uint64_t bytes, uint8_t **out) {
+	return bgzf_guarded([&] {
+		if (!d || !out || which < 0 || which > 1) throw InvalidError("bad argument");
+		HIP_CHECK(hipSetDevice(d->device));
+		d->h_stage[which].ensure(bytes);
+		*out = d->h_stage[which].p;
 	});
 }
 

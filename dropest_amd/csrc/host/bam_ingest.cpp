@@ -920,13 +920,57 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			double dev_ms[4] = {0, 0, 0, 0}, host_ms[3] = {0, 0, 0};
 			const auto t_file = clk::now();
 			size_t window_bytes = size_t(1) << 20, n_windows = 0, repaired = 0, refused = 0, n_needs = 0;
-			const size_t window_max = size_t(getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? std::max(1, atoi(getenv("DROPEST_BAM_DEVICE_WINDOW_MB"))) : 16) << 20;
-			at = c0;
+			const size_t window_max = size_t(getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? std::max(1, atoi(getenv("DROPEST_BAM_DEVICE_WINDOW_MB"))) : 32) << 20;
+			// The compressed bytes reach the device through two pinned buffers of the decoder: a helper thread reads the next window from the file
+			// (pread: page cache -> pinned memory, whole blocks only) while the device and this thread work on the one before.
+			struct Staged { uint8_t *p = nullptr; size_t used = 0; bool final = false; std::string error; };
+			const size_t stage_cap = window_max + (size_t(1) << 17);
+			uint8_t *stage_p[2] = {nullptr, nullptr};
+			for (int k = 0; k < 2; ++k)
+				if (dropest_bam_decoder_staging(dec, k, stage_cap, &stage_p[k])) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+			const double ms_setup = since(t_file);
+			double ms_wait_read = 0, ms_window_calls = 0;
+			size_t file_at = c0;
+			auto read_window = [&](int which, size_t want) {
+				Staged st; st.p = stage_p[which];
+				const size_t ask = std::min(std::min(want + (size_t(1) << 16) + 64, stage_cap), map.n - file_at);
+				size_t got = 0;
+				while (got < ask) {
+					const ssize_t r = pread(map.fd, st.p + got, ask - got, off_t(file_at + got));
+					if (r < 0) { st.error = "Can't read BAM file"; return st; }
+					if (r == 0) break;
+					got += size_t(r);
+				}
+				size_t o = 0;                                    // whole blocks: up to `want` bytes of them (at least one)
+				while (o + 18 <= got && (o < want || o == 0)) {
+					const uint8_t *h = st.p + o;
+					if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { st.error = "Not a BGZF/BAM file"; return st; }
+					const size_t xlen = le16(h + 10);
+					if (o + 12 + xlen > got) break;
+					size_t bsize = 0;
+					for (size_t x = 0; x + 4 <= xlen;) { const uint8_t *sf = h + 12 + x; const size_t sl = le16(sf + 2); if (sf[0] == 'B' && sf[1] == 'C' && sl == 2 && x + 6 <= xlen) bsize = size_t(le16(sf + 4)) + 1; x += 4 + sl; }
+					if (!bsize) { st.error = "BGZF block without BC subfield"; return st; }
+					if (o + bsize > got) break;
+					o += bsize;
+				}
+				if (!o && got) { st.error = "Truncated BGZF block"; return st; }
+				st.used = o; file_at += o; st.final = file_at >= map.n;
+				return st;
+			};
 			bool first = true, dict_dirty = true;
-			while (at < map.n) {
-				const size_t begin = at;
-				while (at < map.n && at - begin < window_bytes) { RawBlock b; if (!read_block(map.p, map.n, at, b, bam_name)) break; }
-				const bool final = at >= map.n;
+			int which = 0;
+			std::future<Staged> next = std::async(std::launch::async, read_window, which, window_bytes);
+			for (;;) {
+				auto t_wait = clk::now();
+				Staged stg = next.get();
+				ms_wait_read += since(t_wait);
+				if (!stg.error.empty()) throw std::runtime_error(stg.error + ": " + bam_name);
+				const bool final = stg.final;
+				const size_t used = stg.used;
+				window_bytes = std::min(window_bytes * 4, window_max);
+				which ^= 1;
+				if (!final) next = std::async(std::launch::async, read_window, which, window_bytes);
+				struct Drain { std::future<Staged> &f; bool armed; ~Drain() { if (armed && f.valid()) f.wait(); } } drain{next, !final};   // (an exception below must not leave the reader running on freed buffers)
 				auto t_phase = clk::now();
 				if (dict_dirty) {      // the dictionaries as they stand (other files, earlier windows, add_record calls) go to the device
 					container.dictionary_snapshot(dict_hash, dict_id, dict_chr);
@@ -936,15 +980,16 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				}
 				host_ms[0] += since(t_phase);
 				dropest_bam_window w{};
-				if (dropest_bam_decoder_window(dec, map.p + begin, at - begin, first ? u0 : 0u, final ? 1 : 0, host_inflate, nullptr, &w))
+				auto t_call = clk::now();
+				if (dropest_bam_decoder_window(dec, stg.p, used, first ? u0 : 0u, final ? 1 : 0, host_inflate, nullptr, &w))
 					throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
-				if (first) container.expect_reads(size_t(double(w.n_records) * double(map.n - c0) / double(std::max<size_t>(at - begin, 1)) * double(bam_files.size()) * 1.05));
+				ms_window_calls += since(t_call);
+				if (first) container.expect_reads(size_t(double(w.n_records) * double(map.n - c0) / double(std::max<size_t>(used, 1)) * double(bam_files.size()) * 1.05));
 				first = false;
 				++n_windows; repaired += w.guesses_repaired; refused += w.refused_blocks;
 				dev_ms[0] += w.ms_copy; dev_ms[1] += w.ms_inflate; dev_ms[2] += w.ms_boundaries; dev_ms[3] += w.ms_parse;
-				window_bytes = std::min(window_bytes * 4, window_max);
 				const size_t n = size_t(w.n_records);
-				if (!n) continue;
+				if (!n) { if (final) break; continue; }
 				t_phase = clk::now();
 				if (w.quality_seen) {
 					// UMI quality strings: every record of this window goes through the record-by-record path (the container keeps the strings)
@@ -966,6 +1011,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					}
 					dict_dirty = true;
 					host_ms[1] += since(t_phase);
+					if (final) break;
 					continue;
 				}
 				// what the dictionaries have not seen, in file order (per record: barcode, UMI, gene, chromosome -- the order of add_record)
@@ -1005,11 +1051,13 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				_counters.low_quality += size_t(w.counts[DROPEST_BAM_LOW_QUALITY]);
 				_counters.saved += size_t(w.counts[DROPEST_BAM_OK]);
 				_counters.total_reads += size_t(w.counts[DROPEST_BAM_OK] + w.counts[DROPEST_BAM_CANT_PARSE] + w.counts[DROPEST_BAM_LOW_QUALITY]);
+				if (final) break;
 			}
 			if (getenv("DROPEST_BAM_TRACE"))
 				std::fprintf(stderr, "[bam] device path: %zu windows, %.1f ms behind the header; copy in %.1f ms, inflate %.1f ms (%zu blocks left to the host), record chain %.1f ms (%zu guesses "
 				             "repaired), fields + dense columns %.1f ms; host: dictionaries to the device %.1f ms, %zu records with something new %.1f ms, container %.1f ms\n",
-				             n_windows, since(t_file), dev_ms[0], dev_ms[1], refused, dev_ms[2], repaired, dev_ms[3], host_ms[0], n_needs, host_ms[1], host_ms[2]);
+				             n_windows, since(t_file), dev_ms[0], dev_ms[1], refused, dev_ms[2], repaired, dev_ms[3], host_ms[0], n_needs, host_ms[1], host_ms[2]),
+				std::fprintf(stderr, "[bam] device path: pinned staging buffers %.1f ms, waiting for the file reader %.1f ms, inside the window calls %.1f ms\n", ms_setup, ms_wait_read, ms_window_calls);
 			return true;
 		};
 		static const bool env_device = getenv("DROPEST_BAM_DEVICE") != nullptr && atoi(getenv("DROPEST_BAM_DEVICE")) != 0;
