@@ -119,24 +119,40 @@ extern "C" int dropest_bgzf_inflate_buffer(int device, const uint8_t *data, uint
 }
 
 // ---- BAM records of a window, on the device ------------------------------------------------------------------------------------
+// What the first half of a window produces (copy in, inflate, the chain of records) and the second half (fields, dense columns) consumes.  Two of
+// them: the caller may run the first half of window k + 1 on another thread while the second half of window k and its own work go on.
+struct BamFront {
+	hipStream_t stream = nullptr;
+	DevBuf<uint8_t> d_in, d_out;
+	DevBuf<uint64_t> d_in_off, d_out_off, seg_start, seg_exit;
+	DevBuf<uint32_t> d_in_len, d_out_len, d_status, seg_count, seg_base, d_bad, d_list;
+	PinnedBuf<uint64_t> h_seg_start, h_seg_exit;
+	PinnedBuf<uint32_t> h_count, h_block_status;
+	std::vector<uint64_t> in_off, out_off;
+	std::vector<uint32_t> in_len, out_len, base;
+	uint64_t data_len = 0, tail_start = 0, n_rec = 0;
+	uint32_t n_segs = 0, n_blocks = 0, refused = 0, repaired = 0;
+	double ms_copy = 0, ms_inflate = 0, ms_boundaries = 0;
+	bool begun = false;
+};
+
 struct dropest_bam_decoder {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	BamParseCfg cfg{};
-	DevBuf<uint8_t> d_in, d_out, d_tail, d_gather;
-	DevBuf<uint64_t> d_in_off, d_out_off, seg_start, seg_exit, rec_off, d_goff;
-	DevBuf<uint32_t> d_in_len, d_out_len, d_status, seg_count, seg_base, d_bad, d_list, d_gidx, d_gsize;
+	BamFront front[2];
+	int next_front = 0, last_front = 0;
+	DevBuf<uint8_t> d_tail, d_gather;
+	DevBuf<uint64_t> rec_off, d_goff;
+	DevBuf<uint32_t> d_gidx, d_gsize;
 	DevBuf<unsigned long long> o_cb, o_umi, dn_cb, dn_umi, p_cb, p_umi, g_keys;
 	DevBuf<uint32_t> o_gene, o_aux, dn_gene, dn_aux, tile_ok, tile_need, d_totals, nd_rec, nd_pos, nd_size, p_pos, p_gene, p_aux, g_vals;
 	DevBuf<int32_t> d_chr;
 	DevBuf<uint16_t> o_uql;
 	DevBuf<uint8_t> o_status, o_need;
 	DevBuf<BamWindowCounts> d_wc;
-	PinnedBuf<uint64_t> h_seg_start, h_seg_exit;
 	PinnedBuf<uint8_t> h_stage[2];
-	PinnedBuf<uint32_t> h_count, h_block_status, h_need_rec, h_need_pos, h_need_size, h_gsize;
-	std::vector<uint64_t> in_off, out_off;
-	std::vector<uint32_t> in_len, out_len, base;
+	PinnedBuf<uint32_t> h_need_rec, h_need_pos, h_need_size, h_gsize;
 	uint32_t g_mask = 0;
 	uint64_t tail_len = 0, last_n_rec = 0, last_n_ok = 0;
 };
@@ -155,6 +171,7 @@ extern "C" int dropest_bam_decoder_create(int device, const dropest_bam_parse_cf
 		std::memcpy(&d->cfg, cfg, sizeof(BamParseCfg));
 		try {
 			HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+			for (BamFront &f : d->front) HIP_CHECK(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
 			// empty dictionaries: every gene and chromosome is new
 			d->g_mask = 1023; d->g_keys.alloc(1024); d->g_vals.alloc(1024); d->d_chr.alloc(size_t(std::max(1, cfg->n_refs)));
 			HIP_CHECK(hipMemset(d->g_vals.p, 0, 1024 * 4));
@@ -177,6 +194,7 @@ extern "C" void dropest_bam_decoder_destroy(dropest_bam_decoder *d) {
 	if (!d) return;
 	(void)hipSetDevice(d->device);
 	if (d->stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
+	for (BamFront &f : d->front) if (f.stream) { (void)hipStreamSynchronize(f.stream); (void)hipStreamDestroy(f.stream); }
 	delete d;
 }
 
@@ -204,16 +222,19 @@ extern "C" int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, cons
 	});
 }
 
-extern "C" int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
-                                          dropest_bgzf_host_inflate inflate_fallback, void *user, dropest_bam_window *out) {
+extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
+                                                dropest_bgzf_host_inflate inflate_fallback, void *user, int *slot) {
 	return bgzf_guarded([&] {
-		if (!d || !out || (len && !comp)) throw InvalidError("null argument");
+		if (!dec || !slot || (len && !comp)) throw InvalidError("null argument");
+		BamFront *const d = &dec->front[dec->next_front];
+		*slot = dec->next_front;
+		dec->next_front ^= 1;
+		d->begun = false;
+		struct { uint32_t refused_blocks = 0, guesses_repaired = 0, n_blocks = 0; uint64_t window_bytes = 0; double ms_copy = 0, ms_inflate = 0, ms_boundaries = 0; } o_, *out = &o_;
 		using clk = std::chrono::steady_clock;
 		auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
-		HIP_CHECK(hipSetDevice(d->device));
+		HIP_CHECK(hipSetDevice(dec->device));
 		hipStream_t st = d->stream;
-		*out = dropest_bam_window{};
-		d->last_n_rec = 0; d->last_n_ok = 0;
 		// 1. the blocks
 		const uint64_t cap = len / 26 + 1;
 		d->in_off.resize(cap); d->out_off.resize(cap); d->in_len.resize(cap); d->out_len.resize(cap);
@@ -221,12 +242,12 @@ extern "C" int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t 
 		if (len && dropest_bgzf_scan(comp, len, cap, d->in_off.data(), d->in_len.data(), d->out_off.data(), d->out_len.data(), nullptr, &n, &used, &total)) throw InvalidError(g_bgzf_error);
 		if (used != len) throw InvalidError("a window must hold whole BGZF blocks");
 		if (n > 0xFFFFFFFFull) throw UnsupportedError("more than 2^32 blocks in one window");
-		const uint64_t tail = d->tail_len, data_len = tail + total;
+		const uint64_t tail = dec->tail_len, data_len = tail + total;
 		if (tail && first_skip) throw InvalidError("first_skip belongs to the first window");
 		if (data_len >= (uint64_t(1) << 40)) throw UnsupportedError("window too large");
 		auto t0 = clk::now();
 		d->d_out.ensure(data_len + data_len / 4 + 64);
-		if (tail) HIP_CHECK(hipMemcpyAsync(d->d_out.p, d->d_tail.p, tail, hipMemcpyDeviceToDevice, st));
+		if (tail) HIP_CHECK(hipMemcpyAsync(d->d_out.p, dec->d_tail.p, tail, hipMemcpyDeviceToDevice, st));
 		if (n) {
 			d->d_in.ensure(len + len / 4 + 8); d->d_in_off.ensure(n + n / 4); d->d_out_off.ensure(n + n / 4); d->d_in_len.ensure(n + n / 4); d->d_out_len.ensure(n + n / 4);
 			d->d_status.ensure(n + n / 4); d->h_block_status.ensure(n);
@@ -238,7 +259,7 @@ extern "C" int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t 
 			HIP_CHECK(hipStreamSynchronize(st));
 			out->ms_copy = ms_since(t0);
 			t0 = clk::now();
-			if (dropest_bgzf_inflate_device(d->device, st, d->d_in.p, len, d->d_in_off.p, d->d_in_len.p, d->d_out_off.p, d->d_out_len.p, uint32_t(n), d->d_out.p + tail, d->d_status.p))
+			if (dropest_bgzf_inflate_device(dec->device, st, d->d_in.p, len, d->d_in_off.p, d->d_in_len.p, d->d_out_off.p, d->d_out_len.p, uint32_t(n), d->d_out.p + tail, d->d_status.p))
 				throw DeviceError(g_bgzf_error);
 			HIP_CHECK(hipMemcpyAsync(d->h_block_status.p, d->d_status.p, n * 4, hipMemcpyDeviceToHost, st));
 			HIP_CHECK(hipStreamSynchronize(st));
@@ -265,7 +286,7 @@ extern "C" int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t 
 			d->h_seg_start.ensure(n_segs); d->h_seg_exit.ensure(n_segs); d->h_count.ensure(n_segs);
 			HIP_CHECK(hipMemsetAsync(d->d_bad.p, 0, 4, st));
 			HIP_CHECK(hipMemcpyAsync(d->seg_start.p, &expect, 8, hipMemcpyHostToDevice, st));
-			if (n_segs > 1) hipLaunchKernelGGL(bam_seg_guess_kernel, dim3((n_segs - 1 + 3) / 4), dim3(256), 0, st, d->d_out.p, data_len, d->cfg.n_refs, n_segs, d->seg_start.p);
+			if (n_segs > 1) hipLaunchKernelGGL(bam_seg_guess_kernel, dim3((n_segs - 1 + 3) / 4), dim3(256), 0, st, d->d_out.p, data_len, dec->cfg.n_refs, n_segs, d->seg_start.p);
 			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, d->d_out.p, data_len, (const uint32_t *)nullptr, n_segs, d->seg_start.p,
 			                   d->seg_count.p, d->seg_exit.p, (const uint32_t *)nullptr, (uint64_t *)nullptr, d->d_bad.p);
 			HIP_CHECK(hipGetLastError());
@@ -301,16 +322,47 @@ extern "C" int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t 
 		if (tail_start > data_len) throw InvalidError("Corrupt BAM record");
 		if (final && tail_start != data_len) throw InvalidError("Truncated BAM file");
 		out->ms_boundaries = ms_since(t0);
-		// 3. record offsets, the fields, the accepted records made dense
-		t0 = clk::now();
+		// the cut-off record opens the next window
+		const uint64_t new_tail = data_len - tail_start;
+		if (new_tail) {
+			dec->d_tail.ensure(new_tail + new_tail / 4 + 64);
+			HIP_CHECK(hipMemcpyAsync(dec->d_tail.p, d->d_out.p + tail_start, new_tail, hipMemcpyDeviceToDevice, st));
+			HIP_CHECK(hipStreamSynchronize(st));
+		}
+		dec->tail_len = new_tail;
+		d->data_len = data_len; d->tail_start = tail_start; d->n_rec = n_rec; d->n_segs = n_segs; d->n_blocks = uint32_t(n);
+		d->refused = out->refused_blocks; d->repaired = out->guesses_repaired;
+		d->ms_copy = out->ms_copy; d->ms_inflate = out->ms_inflate; d->ms_boundaries = out->ms_boundaries;
+		d->begun = true;
+	});
+}
+
+extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slot, dropest_bam_window *out) {
+	return bgzf_guarded([&] {
+		if (!d || !out || slot < 0 || slot > 1) throw InvalidError("bad argument");
+		BamFront &F = d->front[slot];
+		if (!F.begun) throw InvalidError("this window was not begun (or its first half failed)");
+		F.begun = false;
+		using clk = std::chrono::steady_clock;
+		auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+		HIP_CHECK(hipSetDevice(d->device));
+		hipStream_t st = d->stream;
+		*out = dropest_bam_window{};
+		d->last_n_rec = 0; d->last_n_ok = 0; d->last_front = slot;
+		const uint64_t n_rec = F.n_rec, data_len = F.data_len;
+		const uint32_t n_segs = F.n_segs;
+		out->n_blocks = F.n_blocks; out->window_bytes = data_len; out->refused_blocks = F.refused; out->guesses_repaired = F.repaired;
+		out->ms_copy = F.ms_copy; out->ms_inflate = F.ms_inflate; out->ms_boundaries = F.ms_boundaries;
+		auto t0 = clk::now();
+		// record offsets, the fields, the accepted records made dense
 		BamWindowCounts wc{};
 		uint32_t totals[2] = {0, 0};
 		if (n_rec) {
 			const size_t rc = size_t(n_rec) + size_t(n_rec) / 4;
 			d->rec_off.ensure(rc);
-			HIP_CHECK(hipMemcpyAsync(d->seg_base.p, d->base.data(), size_t(n_segs) * 4, hipMemcpyHostToDevice, st));
-			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, d->d_out.p, data_len, (const uint32_t *)nullptr, n_segs, d->seg_start.p,
-			                   d->seg_count.p, d->seg_exit.p, d->seg_base.p, d->rec_off.p, d->d_bad.p);
+			HIP_CHECK(hipMemcpyAsync(F.seg_base.p, F.base.data(), size_t(n_segs) * 4, hipMemcpyHostToDevice, st));
+			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, F.d_out.p, data_len, (const uint32_t *)nullptr, n_segs, F.seg_start.p,
+			                   F.seg_count.p, F.seg_exit.p, F.seg_base.p, d->rec_off.p, F.d_bad.p);
 			d->o_cb.ensure(rc); d->o_umi.ensure(rc); d->o_gene.ensure(rc); d->o_aux.ensure(rc); d->o_uql.ensure(rc); d->o_status.ensure(rc); d->o_need.ensure(rc);
 			d->dn_cb.ensure(rc); d->dn_umi.ensure(rc); d->dn_gene.ensure(rc); d->dn_aux.ensure(rc); d->nd_rec.ensure(rc); d->nd_pos.ensure(rc); d->nd_size.ensure(rc);
 			const uint32_t tiles = uint32_t((n_rec + BAM_FIN_TILE - 1) / BAM_FIN_TILE);
@@ -319,19 +371,13 @@ extern "C" int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t 
 			const BamRecordOut ro{d->o_cb.p, d->o_umi.p, d->o_gene.p, d->o_aux.p, d->o_uql.p, d->o_status.p, d->o_need.p};
 			const BamDict dict{d->g_keys.p, d->g_vals.p, d->g_mask, d->d_chr.p};
 			const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, d->nd_rec.p, d->nd_pos.p, d->nd_size.p};
-			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + 255) / 256)), dim3(256), 0, st, d->d_out.p, d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro);
+			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + 255) / 256)), dim3(256), 0, st, F.d_out.p, d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro);
 			hipLaunchKernelGGL(bam_fin_count_kernel, dim3(tiles), dim3(256), 0, st, d->o_status.p, d->o_need.p, d->o_uql.p, uint32_t(n_rec), d->tile_ok.p, d->tile_need.p, d->d_wc.p);
 			hipLaunchKernelGGL(bam_fin_scan_kernel, dim3(1), dim3(1024), 0, st, d->tile_ok.p, d->tile_need.p, tiles, d->d_totals.p);
-			hipLaunchKernelGGL(bam_fin_scatter_kernel, dim3(tiles), dim3(256), 0, st, d->d_out.p, d->rec_off.p, ro, uint32_t(n_rec), d->tile_ok.p, d->tile_need.p, dn);
+			hipLaunchKernelGGL(bam_fin_scatter_kernel, dim3(tiles), dim3(256), 0, st, F.d_out.p, d->rec_off.p, ro, uint32_t(n_rec), d->tile_ok.p, d->tile_need.p, dn);
 			HIP_CHECK(hipGetLastError());
 			HIP_CHECK(hipMemcpyAsync(&wc, d->d_wc.p, sizeof(wc), hipMemcpyDeviceToHost, st));
 			HIP_CHECK(hipMemcpyAsync(totals, d->d_totals.p, 8, hipMemcpyDeviceToHost, st));
-		}
-		// 4. the cut-off record opens the next window
-		const uint64_t new_tail = data_len - tail_start;
-		if (new_tail) {
-			d->d_tail.ensure(new_tail + 64);
-			HIP_CHECK(hipMemcpyAsync(d->d_tail.p, d->d_out.p + tail_start, new_tail, hipMemcpyDeviceToDevice, st));
 		}
 		HIP_CHECK(hipStreamSynchronize(st));
 		const uint32_t n_need = totals[1];
@@ -343,8 +389,8 @@ extern "C" int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t 
 			HIP_CHECK(hipStreamSynchronize(st));
 		}
 		out->ms_parse = ms_since(t0);
-		d->tail_len = new_tail; d->last_n_rec = n_rec; d->last_n_ok = totals[0];
-		out->n_records = n_rec; out->tail_bytes = new_tail;
+		d->last_n_rec = n_rec; d->last_n_ok = totals[0];
+		out->n_records = n_rec; out->tail_bytes = data_len - F.tail_start;
 		for (int k = 0; k < 5; ++k) out->counts[k] = wc.status[k];
 		out->n_accepted = totals[0];
 		if (out->n_accepted != out->counts[0]) throw DeviceError("internal: the dense columns and the counters disagree");
@@ -352,6 +398,13 @@ extern "C" int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t 
 		out->n_need = n_need; out->need_rec = d->h_need_rec.p; out->need_pos = d->h_need_pos.p; out->need_size = d->h_need_size.p;
 		out->quality_seen = wc.quality; out->any_gene = wc.any_gene;
 	});
+}
+
+extern "C" int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
+                                          dropest_bgzf_host_inflate inflate_fallback, void *user, dropest_bam_window *out) {
+	int slot = 0;
+	if (dropest_bam_decoder_window_begin(d, comp, len, first_skip, final, inflate_fallback, user, &slot)) return 1;
+	return dropest_bam_decoder_window_finish(d, slot, out);
 }
 
 __global__ __launch_bounds__(256) void bam_record_sizes_kernel(const uint8_t *__restrict__ data, const uint64_t *__restrict__ rec_off, const uint32_t *__restrict__ idx, uint32_t n,
@@ -368,7 +421,7 @@ extern "C" int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const u
 		for (uint32_t k = 0; k < n; ++k) if (idx[k] >= d->last_n_rec) throw RangeError("record index outside the window");
 		d->d_gidx.ensure(n); d->d_goff.ensure(n); d->d_gsize.ensure(n); d->h_gsize.ensure(n);
 		HIP_CHECK(hipMemcpyAsync(d->d_gidx.p, idx, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
-		hipLaunchKernelGGL(bam_record_sizes_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, d->d_out.p, d->rec_off.p, d->d_gidx.p, n, d->d_gsize.p);
+		hipLaunchKernelGGL(bam_record_sizes_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, d->front[d->last_front].d_out.p, d->rec_off.p, d->d_gidx.p, n, d->d_gsize.p);
 		HIP_CHECK(hipMemcpyAsync(d->h_gsize.p, d->d_gsize.p, size_t(n) * 4, hipMemcpyDeviceToHost, d->stream));
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		uint64_t total = 0;
@@ -376,7 +429,7 @@ extern "C" int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const u
 		if (total > dst_cap) throw InvalidError("destination too small: " + std::to_string(total) + " bytes needed");
 		d->d_gather.ensure(total + total / 4 + 64);
 		HIP_CHECK(hipMemcpyAsync(d->d_goff.p, dst_off, size_t(n) * 8, hipMemcpyHostToDevice, d->stream));
-		hipLaunchKernelGGL(bam_gather_records_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, d->d_out.p, d->rec_off.p, d->d_gidx.p, d->d_goff.p, n, d->d_gather.p);
+		hipLaunchKernelGGL(bam_gather_records_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, d->front[d->last_front].d_out.p, d->rec_off.p, d->d_gidx.p, d->d_goff.p, n, d->d_gather.p);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipMemcpyAsync(dst, d->d_gather.p, total, hipMemcpyDeviceToHost, d->stream));
 		HIP_CHECK(hipStreamSynchronize(d->stream));

@@ -82,6 +82,12 @@ void dropest_bam_decoder_destroy(dropest_bam_decoder *d);
  * first window only).  final != 0: the file ends here (a cut-off record is then an error). */
 int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
                                dropest_bgzf_host_inflate inflate_fallback, void *user, dropest_bam_window *out);
+/* The same in two halves, for a caller that overlaps windows: _begin (copy in, inflate, the chain of records; needs no dictionary) of window
+ * k + 1 may run on ANOTHER THREAD while _finish (fields against the dictionaries, dense columns) of window k and the caller's own work go on.
+ * Windows are begun in file order, one at a time; a window is finished before the one after the next is begun (two sets of buffers). */
+int dropest_bam_decoder_window_begin(dropest_bam_decoder *d, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
+                                     dropest_bgzf_host_inflate inflate_fallback, void *user, int *slot);
+int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slot, dropest_bam_window *out);
 /* The dictionaries the records are looked up in (copied): gene_hash[k] (FNV-1a of the name) -> gene_id[k]; chr_of_ref[r] = chromosome
  * index of reference r, -1 = none yet.  Call again whenever they have grown. */
 int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, const uint64_t *gene_hash, const uint32_t *gene_id, uint32_t n_genes,

@@ -53,4 +53,6 @@ for threads in thread_counts:
         st = json.loads(res.stdout.strip().splitlines()[-1])
         st.update(threads=threads, path=label, reads=n * copies, ingest_mreads_per_s=round(n * copies / st["ingest_ms"] / 1e3, 3), bam_mb=round(os.path.getsize(bam) / 1e6, 1))
         print(json.dumps(st), flush=True)
+if os.environ.get("KEEP_BAM"):
+    import shutil; shutil.copy(bam, os.environ["KEEP_BAM"])
 import shutil; shutil.rmtree(tmp, ignore_errors=True)

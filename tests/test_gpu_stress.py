@@ -155,16 +155,18 @@ def test_variable_lengths_and_ns():
 
 
 def test_key_wider_than_64_bits_is_refused_loudly():
+    """cell + gene + UMI = 6 + 20 + 40 bits: one context refuses it and names dropest_ctx_split (gene + UMI fields that ALONE reach 64 bits take
+    the UMI dictionary instead: tests/test_gpu_umi_dict.py)."""
     P = capi.pack_seq
-    n = 5
-    cb = np.array([P("ACGT" * 7 + "AC" + "ACGT"[i % 4]) for i in range(n)], np.uint64)          # 31 bases
-    umi = np.array([P("TTGCA" * 6)] * n, np.uint64)                                              # 30 bases -> 60 bits
+    n = 40
+    cb = np.array([P("ACGT" * 7 + "".join("ACGT"[(i >> (2 * j)) & 3] for j in range(3))) for i in range(n)], np.uint64)      # 31 bases, all distinct
+    umi = np.array([P("TTGCA" * 4)] * n, np.uint64)                                              # 20 bases -> 40 bits
     gene = np.array([1_000_000] * n, np.uint32)                                                  # 20 bits
     c = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
     c.push_reads(cb, umi, gene, np.full(n, 2 << 16, np.uint32))
     with pytest.raises(capi.DropestError) as e:
         c.set_initialized()
-    assert e.value.status == 4 and "bits" in str(e.value)
+    assert e.value.status == 4 and "bits" in str(e.value) and "dropest_ctx_split" in str(e.value)
 
 
 @pytest.mark.parametrize("poisson", [False, True])
