@@ -58,20 +58,22 @@ extern "C" int dropest_bgzf_scan(const uint8_t *data, uint64_t len, uint64_t cap
 
 extern "C" int dropest_bgzf_inflate_device(int device, void *stream, const uint8_t *d_in, uint64_t in_total, const uint64_t *d_in_off,
                                            const uint32_t *d_in_len, const uint64_t *d_out_off, const uint32_t *d_out_len, uint32_t n_blocks,
-                                           uint8_t *d_out, uint32_t *d_status) {
+                                           uint8_t *d_out, uint32_t *d_status, const uint32_t *d_crc32) {
 	return bgzf_guarded([&] {
 		if (!n_blocks) return;
 		if (!d_in || !d_in_off || !d_in_len || !d_out_off || !d_out_len || !d_out || !d_status) throw InvalidError("null argument");
 		if (uintptr_t(d_in) & 7u) throw InvalidError("the compressed bytes must be 8-byte aligned");
 		HIP_CHECK(hipSetDevice(device));
 		hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(INF_WAVES * 64), 0, hipStream_t(stream), d_in, in_total,
-		                   d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_out, d_status);
+		                   d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_out, d_status, d_crc32);
 		HIP_CHECK(hipGetLastError());
 	});
 }
 
 extern "C" int dropest_bgzf_inflate_buffer(int device, const uint8_t *data, uint64_t len, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
                                            uint32_t *status, uint64_t status_cap, uint64_t *n_blocks, double *kernel_ms, int repeats) {
+	const bool check_crc = repeats >= 0;     // (repeats < 0: |repeats| runs without the CRC-32 check -- what the check costs)
+	if (repeats < 0) repeats = -repeats;
 	return bgzf_guarded([&] {
 		if (!data || !out_len || !n_blocks) throw InvalidError("null argument");
 		int n_dev = 0;
@@ -79,17 +81,18 @@ extern "C" int dropest_bgzf_inflate_buffer(int device, const uint8_t *data, uint
 		HIP_CHECK(hipSetDevice(device));
 		const uint64_t cap = len / 26 + 1;
 		std::vector<uint64_t> in_off(cap), out_off(cap);
-		std::vector<uint32_t> in_len(cap), o_len(cap);
+		std::vector<uint32_t> in_len(cap), o_len(cap), crc(cap);
 		uint64_t n = 0, used = 0, total = 0;
-		if (dropest_bgzf_scan(data, len, cap, in_off.data(), in_len.data(), out_off.data(), o_len.data(), nullptr, &n, &used, &total)) throw InvalidError(g_bgzf_error);
+		if (dropest_bgzf_scan(data, len, cap, in_off.data(), in_len.data(), out_off.data(), o_len.data(), crc.data(), &n, &used, &total)) throw InvalidError(g_bgzf_error);
 		*n_blocks = n; *out_len = total;
 		if (total > out_cap) throw InvalidError("output buffer too small: " + std::to_string(total) + " bytes needed");
 		if (!n) return;
 		if (n > 0xFFFFFFFFull) throw UnsupportedError("more than 2^32 blocks in one call");
 		DevBuf<uint8_t> d_in, d_out;
 		DevBuf<uint64_t> d_in_off, d_out_off;
-		DevBuf<uint32_t> d_in_len, d_out_len, d_status;
-		d_in.alloc(used + 8); d_out.alloc(total + 8); d_in_off.alloc(n); d_out_off.alloc(n); d_in_len.alloc(n); d_out_len.alloc(n); d_status.alloc(n);
+		DevBuf<uint32_t> d_in_len, d_out_len, d_status, d_crc;
+		d_in.alloc(used + 8); d_out.alloc(total + 8); d_in_off.alloc(n); d_out_off.alloc(n); d_in_len.alloc(n); d_out_len.alloc(n); d_status.alloc(n); d_crc.alloc(n);
+		HIP_CHECK(hipMemcpy(d_crc.p, crc.data(), n * 4, hipMemcpyHostToDevice));
 		HIP_CHECK(hipMemcpy(d_in.p, data, used, hipMemcpyHostToDevice));
 		HIP_CHECK(hipMemcpy(d_in_off.p, in_off.data(), n * 8, hipMemcpyHostToDevice));
 		HIP_CHECK(hipMemcpy(d_out_off.p, out_off.data(), n * 8, hipMemcpyHostToDevice));
@@ -103,7 +106,7 @@ extern "C" int dropest_bgzf_inflate_buffer(int device, const uint8_t *data, uint
 		const int reps = repeats > 0 ? repeats : 1;
 		for (int r = 0; r < reps; ++r) {
 			HIP_CHECK(hipEventRecord(e0, nullptr));
-			if (dropest_bgzf_inflate_device(device, nullptr, d_in.p, used, d_in_off.p, d_in_len.p, d_out_off.p, d_out_len.p, uint32_t(n), d_out.p, d_status.p))
+			if (dropest_bgzf_inflate_device(device, nullptr, d_in.p, used, d_in_off.p, d_in_len.p, d_out_off.p, d_out_len.p, uint32_t(n), d_out.p, d_status.p, check_crc ? d_crc.p : nullptr))
 				throw DeviceError(g_bgzf_error);
 			HIP_CHECK(hipEventRecord(e1, nullptr));
 			HIP_CHECK(hipEventSynchronize(e1));
@@ -125,11 +128,11 @@ struct BamFront {
 	hipStream_t stream = nullptr;
 	DevBuf<uint8_t> d_in, d_out;
 	DevBuf<uint64_t> d_in_off, d_out_off, seg_start, seg_exit;
-	DevBuf<uint32_t> d_in_len, d_out_len, d_status, seg_count, seg_base, d_bad, d_list;
+	DevBuf<uint32_t> d_in_len, d_out_len, d_status, d_crc, seg_count, seg_base, d_bad, d_list;
 	PinnedBuf<uint64_t> h_seg_start, h_seg_exit;
 	PinnedBuf<uint32_t> h_count, h_block_status;
 	std::vector<uint64_t> in_off, out_off;
-	std::vector<uint32_t> in_len, out_len, base;
+	std::vector<uint32_t> in_len, out_len, crc, base;
 	uint64_t data_len = 0, tail_start = 0, n_rec = 0;
 	uint32_t n_segs = 0, n_blocks = 0, refused = 0, repaired = 0;
 	double ms_copy = 0, ms_inflate = 0, ms_boundaries = 0;
@@ -187,6 +190,19 @@ extern "C" int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, ui
 		HIP_CHECK(hipSetDevice(d->device));
 		d->h_stage[which].ensure(bytes);
 		*out = d->h_stage[which].p;
+		// the size of the caller's windows is known now: room for them up front (a BAM inflates ~4-12 x, a record is >= ~120 bytes), so that the
+		// first windows do not grow every buffer step by step (each growth is a free + an allocation that wait for the device)
+		BamFront &F = d->front[which];
+		const uint64_t out_bytes = bytes * 14, n_rec = out_bytes / 120, n_blk = bytes / 2048 + 1024, n_seg = out_bytes / BAM_SEG + 16;
+		F.d_in.ensure(bytes + 8); F.d_out.ensure(out_bytes);
+		F.d_in_off.ensure(n_blk); F.d_out_off.ensure(n_blk); F.d_in_len.ensure(n_blk); F.d_out_len.ensure(n_blk); F.d_status.ensure(n_blk); F.d_crc.ensure(n_blk); F.h_block_status.ensure(n_blk);
+		F.seg_start.ensure(n_seg); F.seg_exit.ensure(n_seg); F.seg_count.ensure(n_seg); F.seg_base.ensure(n_seg);
+		F.h_seg_start.ensure(n_seg); F.h_seg_exit.ensure(n_seg); F.h_count.ensure(n_seg);
+		if (which == 0) {
+			d->rec_off.ensure(n_rec); d->o_cb.ensure(n_rec); d->o_umi.ensure(n_rec); d->o_gene.ensure(n_rec); d->o_aux.ensure(n_rec); d->o_uql.ensure(n_rec);
+			d->o_status.ensure(n_rec); d->o_need.ensure(n_rec); d->dn_cb.ensure(n_rec); d->dn_umi.ensure(n_rec); d->dn_gene.ensure(n_rec); d->dn_aux.ensure(n_rec);
+			d->nd_rec.ensure(n_rec); d->nd_pos.ensure(n_rec); d->nd_size.ensure(n_rec);
+		}
 	});
 }
 
@@ -237,9 +253,9 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 		hipStream_t st = d->stream;
 		// 1. the blocks
 		const uint64_t cap = len / 26 + 1;
-		d->in_off.resize(cap); d->out_off.resize(cap); d->in_len.resize(cap); d->out_len.resize(cap);
+		d->in_off.resize(cap); d->out_off.resize(cap); d->in_len.resize(cap); d->out_len.resize(cap); d->crc.resize(cap);
 		uint64_t n = 0, used = 0, total = 0;
-		if (len && dropest_bgzf_scan(comp, len, cap, d->in_off.data(), d->in_len.data(), d->out_off.data(), d->out_len.data(), nullptr, &n, &used, &total)) throw InvalidError(g_bgzf_error);
+		if (len && dropest_bgzf_scan(comp, len, cap, d->in_off.data(), d->in_len.data(), d->out_off.data(), d->out_len.data(), d->crc.data(), &n, &used, &total)) throw InvalidError(g_bgzf_error);
 		if (used != len) throw InvalidError("a window must hold whole BGZF blocks");
 		if (n > 0xFFFFFFFFull) throw UnsupportedError("more than 2^32 blocks in one window");
 		const uint64_t tail = dec->tail_len, data_len = tail + total;
@@ -250,7 +266,8 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 		if (tail) HIP_CHECK(hipMemcpyAsync(d->d_out.p, dec->d_tail.p, tail, hipMemcpyDeviceToDevice, st));
 		if (n) {
 			d->d_in.ensure(len + len / 4 + 8); d->d_in_off.ensure(n + n / 4); d->d_out_off.ensure(n + n / 4); d->d_in_len.ensure(n + n / 4); d->d_out_len.ensure(n + n / 4);
-			d->d_status.ensure(n + n / 4); d->h_block_status.ensure(n);
+			d->d_status.ensure(n + n / 4); d->d_crc.ensure(n + n / 4); d->h_block_status.ensure(n);
+			HIP_CHECK(hipMemcpyAsync(d->d_crc.p, d->crc.data(), n * 4, hipMemcpyHostToDevice, st));
 			HIP_CHECK(hipMemcpyAsync(d->d_in.p, comp, len, hipMemcpyHostToDevice, st));
 			HIP_CHECK(hipMemcpyAsync(d->d_in_off.p, d->in_off.data(), n * 8, hipMemcpyHostToDevice, st));
 			HIP_CHECK(hipMemcpyAsync(d->d_out_off.p, d->out_off.data(), n * 8, hipMemcpyHostToDevice, st));
@@ -259,7 +276,7 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 			HIP_CHECK(hipStreamSynchronize(st));
 			out->ms_copy = ms_since(t0);
 			t0 = clk::now();
-			if (dropest_bgzf_inflate_device(dec->device, st, d->d_in.p, len, d->d_in_off.p, d->d_in_len.p, d->d_out_off.p, d->d_out_len.p, uint32_t(n), d->d_out.p + tail, d->d_status.p))
+			if (dropest_bgzf_inflate_device(dec->device, st, d->d_in.p, len, d->d_in_off.p, d->d_in_len.p, d->d_out_off.p, d->d_out_len.p, uint32_t(n), d->d_out.p + tail, d->d_status.p, d->d_crc.p))
 				throw DeviceError(g_bgzf_error);
 			HIP_CHECK(hipMemcpyAsync(d->h_block_status.p, d->d_status.p, n * 4, hipMemcpyDeviceToHost, st));
 			HIP_CHECK(hipStreamSynchronize(st));

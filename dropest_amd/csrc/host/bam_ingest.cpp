@@ -852,7 +852,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 		// dictionaries stay here: the workers turn gene hashes and reference ids into indices, and the records that bring something NEW
 		// (a gene name, a chromosome, a string with N) are fetched as bytes and go through parse_one + the intern_* members in file order,
 		// exactly like the Needs of fast_window.  Windows grow from 1 MB of compressed bytes (the first ones meet most gene names).
-		// A block's CRC-32 is not checked on this path.  Falls back to the host reader (returns false before anything was added) when
+		// Every block's CRC-32 is checked on the device (the wave that inflated it reads it back).  Falls back to the host reader (returns false before anything was added) when
 		// the configuration needs what the kernels do not do: -g annotation, -r parameter files, gene = chromosome name, sharded containers.
 		auto device_file = [&]() -> bool {
 			if (_params_from_files || !_genes.is_empty() || _gene_in_chromosome_name || !container.bulk_ingest_possible()) return false;

@@ -98,7 +98,7 @@ public:
 	void parse_bam_files(const std::vector<std::string> &bam_files, CellsDataContainer &container);
 	// BGZF inflate, record chain and tag walk on the container's GPU (include/dropest_bgzf.h) where the configuration allows it: tags or read
 	// names as the source of barcode / UMI / gene; not with -g, -r, gene = chromosome name, or a sharded container (the host reader then runs).
-	// A block's CRC-32 is not checked on that path.  DROPEST_BAM_DEVICE=1 in the environment does the same.
+	// CRC-32 and ISIZE of every block are checked there too.  DROPEST_BAM_DEVICE=1 in the environment does the same.
 	void set_device_decode(bool on) { _device_decode = on; }
 	const Counters &counters() const { return _counters; }
 };

@@ -10,7 +10,7 @@
 //   * literals are collected in LDS and stored 64 at a time; a match is copied by all lanes, 64 bytes per step.
 // Tables per wave: a 10-bit root table for literal / length codes and an 8-bit one for distances (u16 entries: symbol << 4 | length);
 // longer codes (rare symbols) are decoded canonically from the per-length counts, bit by bit (the method of zlib's puff.c).
-// Written from RFC 1951.  The CRC-32 of a block is NOT checked here (the host reader checks it; dropest_bgzf.h says so); ISIZE is.
+// Written from RFC 1951.  ISIZE and, when the caller hands over the stored values, the CRC-32 of every block are checked (inf_crc32_block).
 // Integer work; no MFMA.  4.7 KB of LDS per wave: 8 workgroups of 4 waves per CU.
 #pragma once
 
@@ -23,7 +23,7 @@ constexpr int INF_WAVES = 4;
 constexpr int INF_LROOT = 10, INF_DROOT = 8;
 // status of a block: 0 = ok; anything else: the block was not (completely) written and the caller inflates it elsewhere
 enum : uint32_t { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_LENGTHS = 3, INF_OVERSUBSCRIBED = 4, INF_BAD_CODE = 5,
-                  INF_BAD_DISTANCE = 6, INF_OUTPUT_OVERRUN = 7, INF_INPUT_OVERRUN = 8, INF_SIZE_MISMATCH = 9 };
+                  INF_BAD_DISTANCE = 6, INF_OUTPUT_OVERRUN = 7, INF_INPUT_OVERRUN = 8, INF_SIZE_MISMATCH = 9, INF_CRC_MISMATCH = 10 };
 
 struct InfWaveLds {
 	uint16_t lroot[1 << INF_LROOT];
@@ -145,6 +145,72 @@ __device__ inline uint32_t inf_decode(InfState &s, InfWaveLds &L, uint32_t lane,
 	return 0xFFFFu;
 }
 
+// ---- CRC-32 of the inflated block (the gzip trailer's, RFC 1952 8.) ----------------------------------------------------------------
+// Every lane takes 1 KB of the block, four bytes per step through four 256-entry tables (LDS, one set per workgroup); the 64 partial values are joined
+// in GF(2): crc(A || B) = crc(A) * x^(8 |B|) mod P  xor  crc(B), with x^(2^k) mod P squared up in LDS once per wave (the scheme of zlib's
+// crc32_combine).
+constexpr uint32_t INF_CRC_POLY = 0xEDB88320u;   // reflected
+// x^(2^k) mod P, k = 0 .. 31 (x^1 squared up; checked against zlib.crc32 of concatenations when the constants were made)
+__constant__ const uint32_t INF_X2N[32] = {0x40000000u, 0x20000000u, 0x08000000u, 0x00800000u, 0x00008000u, 0xedb88320u, 0xb1e6b092u, 0xa06a2517u,
+                                           0xed627daeu, 0x88d14467u, 0xd7bbfe6au, 0xec447f11u, 0x8e7ea170u, 0x6427800eu, 0x4d47bae0u, 0x09fe548fu,
+                                           0x83852d0fu, 0x30362f1au, 0x7b5a9cc3u, 0x31fec169u, 0x9fec022au, 0x6c8dedc4u, 0x15d6874du, 0x5fde7a4eu,
+                                           0xbad90e37u, 0x2e4e5eefu, 0x4eaba214u, 0xa8a472c0u, 0x429a969eu, 0x148d302au, 0xc40ba6d0u, 0xc4e22c3cu};
+__device__ inline uint32_t inf_multmodp(uint32_t a, uint32_t b) {   // a(x) * b(x) mod P, reflected representation (bit 31 = x^0)
+	uint32_t m = 1u << 31, p = 0;
+	for (;;) {
+		if (a & m) { p ^= b; if ((a & (m - 1u)) == 0u) break; }
+		m >>= 1;
+		b = (b & 1u) ? (b >> 1) ^ INF_CRC_POLY : b >> 1;
+	}
+	return p;
+}
+__device__ inline uint32_t inf_x8n(const uint32_t *x2n, uint32_t n_bytes) {   // x^(8 n) mod P
+	uint32_t p = 1u << 31, k = 3;
+	for (uint32_t n = n_bytes; n; n >>= 1, ++k) if (n & 1u) p = inf_multmodp(x2n[k & 31u], p);
+	return p;
+}
+// crc_tab: [4][256] of the workgroup; x2n: [32] of the wave.  All 64 lanes; returns the CRC-32 of out[0 .. len) in every lane.
+// A lane takes ONE 128-byte line per round (a kilobyte per lane re-fetched every line 32 times: + 19 % on the kernel), the 64 values of a
+// round of 8 KB are joined pairwise over six levels of shuffles -- the operator of a piece of 128 * 2^d bytes IS x2n[10 + d] -- and the rounds
+// one after the other.
+__device__ inline uint32_t inf_crc32_block(const uint8_t *out, uint32_t len, const uint32_t *crc_tab, uint32_t *x2n, uint32_t lane) {
+	if (lane < 32u) x2n[lane] = INF_X2N[lane];
+	uint32_t total = 0;
+	for (uint32_t base = 0; base < len; base += 8192u) {
+		const uint32_t begin = base + lane * 128u;
+		const uint32_t mine = begin < len ? (len - begin < 128u ? len - begin : 128u) : 0u;
+		uint32_t c = 0xFFFFFFFFu;
+		const uint8_t *p = out + begin;
+		uint32_t i = 0;
+		for (; i < mine && (uintptr_t(p + i) & 3u); ++i) c = crc_tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);      // to a word boundary
+		auto step4 = [&](uint32_t w) {                                                                   // four bytes per step (slicing by 4)
+			c ^= w;
+			c = crc_tab[768u + (c & 0xFFu)] ^ crc_tab[512u + ((c >> 8) & 0xFFu)] ^ crc_tab[256u + ((c >> 16) & 0xFFu)] ^ crc_tab[c >> 24];
+		};
+		for (; i + 32u <= mine; i += 32u) {              // eight words in flight before the chain through the tables waits for any of them
+			const uint32_t *q = reinterpret_cast<const uint32_t *>(p + i);
+			const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4], w5 = q[5], w6 = q[6], w7 = q[7];
+			step4(w0); step4(w1); step4(w2); step4(w3); step4(w4); step4(w5); step4(w6); step4(w7);
+		}
+		for (; i + 4u <= mine; i += 4u) step4(*reinterpret_cast<const uint32_t *>(p + i));
+		for (; i < mine; ++i) c = crc_tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+		c = ~c;                                          // (an empty piece: 0)
+		uint32_t clen = mine;
+#pragma unroll
+		for (int d = 0; d < 6; ++d) {
+			const uint32_t oc = uint32_t(__shfl_xor(int(c), 1 << d)), ol = uint32_t(__shfl_xor(int(clen), 1 << d));
+			if (!(lane & ((2u << d) - 1u))) {            // the left piece (lanes 0, 2^(d+1), ...) takes the right one in
+				const uint32_t op = ol == (128u << d) ? x2n[10 + d] : inf_x8n(x2n, ol);
+				c = inf_multmodp(op, c) ^ oc;
+				clen += ol;
+			}
+		}
+		const uint32_t rc = uint32_t(__shfl(int(c), 0)), rl = uint32_t(__shfl(int(clen), 0));
+		total = base ? (inf_multmodp(rl == 8192u ? x2n[16] : inf_x8n(x2n, rl), total) ^ rc) : rc;
+	}
+	return total;
+}
+
 // One BGZF block per wave.  in_off / in_len: the DEFLATE payload inside d_in (behind the 18-byte header); out_off / out_len: where its
 // ISIZE bytes go in d_out.  d_in must be 8-byte aligned and in_total_len is the number of bytes that may be read.
 // Waves per SIMD the register allocation aims at: measured on a 3.3 GB synthetic 10x BAM (scripts/experiments/inflate_variants/run.sh):
@@ -155,8 +221,19 @@ __device__ inline uint32_t inf_decode(InfState &s, InfWaveLds &L, uint32_t lane,
 __global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(INF_WAVES_PER_EU, INF_WAVES_PER_EU))) void bgzf_inflate_kernel(const uint8_t *__restrict__ d_in, uint64_t in_total_len,
                                                                        const uint64_t *__restrict__ in_off, const uint32_t *__restrict__ in_len,
                                                                        const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ out_len,
-                                                                       uint32_t n_blocks, uint8_t *d_out, uint32_t *__restrict__ status) {
+                                                                       uint32_t n_blocks, uint8_t *d_out, uint32_t *__restrict__ status,
+                                                                       const uint32_t *__restrict__ crc32 /* the blocks' stored CRC-32, or null: not checked */) {
 	__shared__ InfWaveLds lds[INF_WAVES];
+	__shared__ uint32_t crc_tab[4 * 256];               // slicing by 4: table k advances a byte that has k more bytes behind it in the word
+	__shared__ uint32_t crc_x2n[INF_WAVES][32];
+	if (crc32) {
+		uint32_t c = threadIdx.x;                       // 256 threads: one entry of every table each
+		for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ INF_CRC_POLY : c >> 1;
+		crc_tab[threadIdx.x] = c;
+		__syncthreads();
+		for (int t = 1; t < 4; ++t) { c = (c >> 8) ^ crc_tab[c & 0xFFu]; crc_tab[t * 256 + threadIdx.x] = c; }
+		__syncthreads();
+	}
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	const uint32_t blk = blockIdx.x * INF_WAVES + wave;
 	if (blk >= n_blocks) return;
@@ -270,6 +347,10 @@ __global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 			if (pos != out_cap) err = INF_SIZE_MISMATCH;
 			else if (s.ipos - uint64_t(s.cnt >> 3) > in_end) err = INF_INPUT_OVERRUN;
 		}
+	}
+	if (!err && crc32) {
+		__threadfence_block();   // the block's last stores, before every lane reads its kilobyte back
+		if (inf_crc32_block(out, out_cap, crc_tab, crc_x2n[wave], lane) != crc32[blk]) err = INF_CRC_MISMATCH;
 	}
 	if (lane == 0) status[blk] = err;
 }

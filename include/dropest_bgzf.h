@@ -5,9 +5,9 @@
  * dropest_bgzf_scan walks the block headers on the host (18 + 8 bytes per block), dropest_bgzf_inflate_device decodes every block
  * with one 64-lane wave (csrc/k_inflate.h).  Plain C, no torch types.
  *
- * NOT checked on the device: a block's CRC-32 (dropest_bgzf_scan returns it; the host reader, csrc/host/bam_ingest.cpp, checks it).
- * Checked: every Huffman code, distance and length, the input and output bounds, ISIZE.  A block the device refuses (status != 0)
- * is left for the caller to inflate elsewhere; nothing outside its own output range is written. */
+ * Checked on the device: every Huffman code, distance and length, the input and output bounds, ISIZE, and the block's CRC-32 (the wave
+ * that inflated a block reads it back: 64 partial CRCs joined in GF(2)).  A block the device refuses (status != 0: damaged, or a CRC that
+ * does not match) is left for the caller to inflate elsewhere; nothing outside its own output range is written. */
 #ifndef DROPEST_BGZF_H
 #define DROPEST_BGZF_H
 
@@ -27,10 +27,10 @@ int dropest_bgzf_scan(const uint8_t *data, uint64_t len, uint64_t cap, uint64_t 
  * (a hipStream_t, NULL = the default stream).  d_status[k] = 0 when block k came out whole. */
 int dropest_bgzf_inflate_device(int device, void *stream, const uint8_t *d_in, uint64_t in_total, const uint64_t *d_in_off,
                                 const uint32_t *d_in_len, const uint64_t *d_out_off, const uint32_t *d_out_len, uint32_t n_blocks,
-                                uint8_t *d_out, uint32_t *d_status);
+                                uint8_t *d_out, uint32_t *d_status, const uint32_t *d_crc32 /* stored CRC-32 per block, or NULL: not checked */);
 
 /* Host buffer in, host buffer out (tests, scripts/bench_bgzf_inflate.py): scan + upload + kernel (`repeats` times; *kernel_ms = mean
- * of the runs by HIP events) + download.  status[0 .. min(n_blocks, status_cap)) per block.  Returns 0, or 1 with
+ * of the runs by HIP events; repeats < 0: |repeats| runs WITHOUT the CRC-32 check) + download.  status[0 .. min(n_blocks, status_cap)) per block.  Returns 0, or 1 with
  * dropest_bgzf_last_error() set (no GPU, out_cap too small, not BGZF). */
 int dropest_bgzf_inflate_buffer(int device, const uint8_t *data, uint64_t len, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
                                 uint32_t *status, uint64_t status_cap, uint64_t *n_blocks, double *kernel_ms, int repeats);

@@ -1,4 +1,4 @@
-"""BGZF blocks inflated on the device (include/dropest_bgzf.h, csrc/k_inflate.h: one wave per block) against zlib: every block type
+"""BGZF blocks inflated (and their CRC-32 checked) on the device (include/dropest_bgzf.h, csrc/k_inflate.h: one wave per block) against zlib: every block type
 (stored, fixed code, dynamic code), every level, data that is random, repetitive (matches longer than their distance), BAM-like and empty;
 several DEFLATE blocks inside one BGZF block; damaged streams are refused block by block and nothing else is touched."""
 import ctypes as C
@@ -111,7 +111,10 @@ def test_damaged_blocks_are_refused_one_by_one():
     blocks[4] = bytearray(blocks[4][:18]) + bytearray(b"\x07") + blocks[4][19:]     # block type 3
     out, status, _ = inflate(b"".join(bytes(b) for b in blocks))
     assert status[0] == 0 and status[2] == 0 and status[5] == 0
-    assert status[3] != 0 and status[4] != 0                  # (a flipped payload byte may still decode: the CRC is the host reader's check)
+    assert status[1] != 0 and status[3] != 0 and status[4] != 0      # (a flipped payload byte that still decodes is caught by the block's CRC-32)
+    blocks[1] = bytearray(bgzf_block(good[1])); blocks[1][-8] ^= 1   # a good payload under a wrong stored CRC
+    _, status2, _ = inflate(b"".join(bytes(b) for b in blocks[:3]))
+    assert list(status2) == [0, 10, 0]
     off = np.cumsum([0] + [30_000, 30_000, 30_000, 29_999, 30_000, 30_000])
     for k in (0, 2, 5):
         assert out[off[k]:off[k + 1]] == good[k]
