@@ -449,6 +449,67 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
     return line
 
 
+def measure_bam_ingest(n_reads=250_000, copies=32, threads=16):
+    """BAM file -> CellsDataContainer (tests/cpp/bam_to_counts: BamController + the facade), host reader against the device path, on one
+    synthetic 10x-style BAM (CB / UB / GX tags, 98 bases; the records written `copies` times into one file); and the inflate kernel alone."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bam_writer as bw
+    from dropest_amd import capi
+    from dropest_amd.build import build_facade
+    from dropest_amd.synth import SynthStream
+    build_facade()
+    tool = os.path.join(ROOT, "tests", "cpp", "bam_to_counts")
+    s = SynthStream(n_reads=n_reads, n_cells=500, n_genes=5000, umi_len=10)
+    cb, umi, gene, aux = s.generate_host()
+    cbs = {int(c): capi.unpack_code(c) for c in np.unique(cb)}
+    recs = []
+    for i in range(n_reads):
+        tags = [("CB", "Z", cbs[int(cb[i])]), ("UB", "Z", capi.unpack_code(umi[i]))]
+        if gene[i] != capi.NO_GENE:
+            tags.append(("GX", "Z", "ENSG%011d" % gene[i]))
+        recs.append(bw.record(int(aux[i]) & 0xFFFF, i, "A00000:1:HXXXX:1:1101:%d:%d" % (i, i), seq="ACGT" * 24 + "AC", tags=tags))
+    tmp = tempfile.mkdtemp()
+    try:
+        bam = os.path.join(tmp, "synth.bam")
+        bw.write_bam(bam, [("chr%d" % i, 10_000_000) for i in range(25)], recs, repeat=copies)
+        out = {"reads": n_reads * copies, "bam_MB": round(os.path.getsize(bam) / 1e6, 1), "host_threads": threads,
+               "what": "ingest_ms of tests/cpp/bam_to_counts: BAM file (page cache) -> every accepted read in the container's device arrays"}
+        for label, env in (("host_reader", {}), ("device", {"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_TRACE": "1"})):
+            best = None
+            for _ in range(2):
+                res = subprocess.run([tool, os.path.join(tmp, "out"), "filled", "20", "100", "-", str(threads), bam], capture_output=True, text=True,
+                                     env=dict(os.environ, **env), timeout=600)
+                if res.returncode:
+                    raise RuntimeError(res.stderr[-300:])
+                st = json.loads(res.stdout.strip().splitlines()[-1])
+                if best is None or st["ingest_ms"] < best["ingest_ms"]:
+                    best = st
+                    trace = [ln for ln in res.stderr.splitlines() if "device path" in ln]
+            assert best["saved"] == n_reads * copies
+            out[label + "_ingest_ms"] = best["ingest_ms"]
+            out[label + "_Mreads_per_s"] = round(n_reads * copies / best["ingest_ms"] / 1e3, 1)
+            if label == "device" and trace:
+                out["device_trace"] = trace[0][6:]
+        L = capi.lib()
+        L.dropest_bgzf_inflate_buffer.restype = C.c_int
+        L.dropest_bgzf_inflate_buffer.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint64,
+                                                  C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.c_int]
+        blob = np.fromfile(bam, np.uint8)
+        n_out, n_blocks, ms = C.c_uint64(), C.c_uint64(), C.c_double()
+        status = np.zeros(len(blob) // 26 + 1, np.uint32)
+        if L.dropest_bgzf_inflate_buffer(0, blob.ctypes.data, len(blob), None, 1 << 62, C.byref(n_out), status.ctypes.data, len(status), C.byref(n_blocks), C.byref(ms), 3) == 0:
+            out.update(inflate_kernel_ms=round(ms.value, 3), inflated_GB=round(n_out.value / 1e9, 3), inflate_GB_per_s=round(n_out.value / 1e6 / ms.value, 1),
+                       blocks=int(n_blocks.value), blocks_refused=int((status[:n_blocks.value] != 0).sum()), crc32_checked_on_device=True)
+        out["x_host_reader"] = round(out["host_reader_ingest_ms"] / out["device_ingest_ms"], 2)
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def finish_line(line):
     """The numbers that matter stand twice in the line: as scalars inside `config` (what a reader of the parsed record keeps) and as the
     LAST key, `summary` (what a reader of the line's tail keeps); the kernel / stage tables stand in between."""
@@ -473,6 +534,11 @@ def finish_line(line):
                        c2_sharded_x_plain_same_end_point=sh.get("x_plain_same_end_point"), c2_sharded_end_point=sh.get("end_point_short"))
     elif "error" in sh:
         summary["c2_sharded_error"] = sh["error"][:200]
+    bi = sec.get("bam_ingest") or {}
+    if "device_Mreads_per_s" in bi:
+        summary.update(bam_device_Mreads_per_s=bi["device_Mreads_per_s"], bam_host_reader_Mreads_per_s=bi["host_reader_Mreads_per_s"], bam_inflate_GB_per_s=bi.get("inflate_GB_per_s"))
+    elif "error" in bi:
+        summary["bam_ingest_error"] = bi["error"][:200]
     for k, v in summary.items():           # scalars only: they survive in the parsed record's `config`
         if k not in ("value", "unit", "ms_per_step", "n_gpus") and v is not None:
             line["config"][k] = v
@@ -561,6 +627,13 @@ def main():
                                                           phases_ms_per_step={k: v for k, v in sh["host_stage_wall_ms_per_step"].items() if k.startswith("shard:")})
         except Exception as e:
             line["secondary"]["c2_sharded_runner"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    # What feeds the pass from a file: a synthetic 10x BAM through BamController into the container, by the host reader and by
+    # the device path (BGZF inflate + record walk + tag parse on the GPU, include/dropest_bgzf.h), and the inflate kernel alone.
+    if (line is not None and world == 1 and not force_sharded and args.config == "c2" and int(args.reads) == 100_000_000 and not args.no_secondary):
+        try:
+            line["secondary"]["bam_ingest"] = measure_bam_ingest()
+        except Exception as e:
+            line["secondary"]["bam_ingest"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         if saved_stdout is not None:
             sys.stdout.flush()
