@@ -251,9 +251,18 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 		auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
 		HIP_CHECK(hipSetDevice(dec->device));
 		hipStream_t st = d->stream;
-		// 1. the blocks
-		const uint64_t cap = len / 26 + 1;
-		d->in_off.resize(cap); d->out_off.resize(cap); d->in_len.resize(cap); d->out_len.resize(cap); d->crc.resize(cap);
+		// 1. the blocks (counted first: arrays for the smallest possible block, 26 bytes, would be 36 MB of page faults per 32 MB window)
+		uint64_t cap = 1;
+		for (uint64_t at = 0; at + 18 <= len; ++cap) {
+			const uint8_t *h = comp + at;
+			if (h[0] != 0x1f || h[1] != 0x8b) break;                      // (dropest_bgzf_scan below says what is wrong)
+			const uint32_t xlen = le16(h + 10);
+			uint32_t bsize = 0;
+			for (uint32_t x = 0; x + 4 <= xlen && at + 12 + x + 6 <= len;) { const uint8_t *sf = h + 12 + x; const uint32_t sl = le16(sf + 2); if (sf[0] == 'B' && sf[1] == 'C' && sl == 2) bsize = le16(sf + 4) + 1; x += 4 + sl; }
+			if (!bsize) break;
+			at += bsize;
+		}
+		if (d->in_off.size() < cap) { const uint64_t c2 = cap + cap / 2; d->in_off.resize(c2); d->out_off.resize(c2); d->in_len.resize(c2); d->out_len.resize(c2); d->crc.resize(c2); }
 		uint64_t n = 0, used = 0, total = 0;
 		if (len && dropest_bgzf_scan(comp, len, cap, d->in_off.data(), d->in_len.data(), d->out_off.data(), d->out_len.data(), d->crc.data(), &n, &used, &total)) throw InvalidError(g_bgzf_error);
 		if (used != len) throw InvalidError("a window must hold whole BGZF blocks");
