@@ -163,4 +163,20 @@ int dropest_annotation_query(dropest_annotation *a, uint64_t n, const int32_t *c
 	} catch (const std::exception &e) { g_ann_error = e.what(); return 1; }
 }
 
+// the same for arrays that are in this GPU's memory already (the device BAM path, bgzf_api.hip): asynchronous on `stream`
+int dropest_annotation_query_device(dropest_annotation *a, void *stream, uint64_t n, const int32_t *d_chr, const uint32_t *d_position,
+                                    const uint32_t *d_end_position, uint32_t *d_gene, int32_t *d_mark) {
+	try {
+		if (!a || (n && (!d_chr || !d_position || !d_end_position || !d_gene || !d_mark))) throw InvalidError("null argument");
+		if (!n) return 0;
+		HIP_CHECK(hipSetDevice(a->device));
+		hipLaunchKernelGGL(annotate_reads_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, hipStream_t(stream), a->f, n, d_chr, d_position, d_end_position, d_gene, d_mark);
+		HIP_CHECK(hipGetLastError());
+		return 0;
+	} catch (const std::exception &e) { g_ann_error = e.what(); return 1; }
+}
+
+uint32_t dropest_annotation_genes(const dropest_annotation *a) { return a ? a->f.n_genes : 0u; }
+int dropest_annotation_device(const dropest_annotation *a) { return a ? a->device : -1; }
+
 }  // extern "C"

@@ -1,5 +1,6 @@
 // bgzf_api.hip -- include/dropest_bgzf.h: BGZF block scan on the host, DEFLATE on the device (k_inflate.h).
 #include "../../include/dropest_bgzf.h"
+#include "../../include/dropest_annotation.h"
 #include "k_inflate.h"
 #include "k_bamparse.h"
 #include "util.h"
@@ -150,7 +151,10 @@ struct dropest_bam_decoder {
 	DevBuf<uint32_t> d_gidx, d_gsize;
 	DevBuf<unsigned long long> o_cb, o_umi, dn_cb, dn_umi, p_cb, p_umi, g_keys;
 	DevBuf<uint32_t> o_gene, o_aux, dn_gene, dn_aux, tile_ok, tile_need, d_totals, nd_rec, nd_pos, nd_size, p_pos, p_gene, p_aux, g_vals;
-	DevBuf<int32_t> d_chr;
+	DevBuf<int32_t> d_chr, d_ann_chr, d_ann_id, a_chr, a_mark;
+	DevBuf<uint32_t> a_pos, a_end, a_gene;
+	dropest_annotation *annotation = nullptr;   // -g: not owned
+	uint32_t n_ann_genes = 0;
 	DevBuf<uint16_t> o_uql;
 	DevBuf<uint8_t> o_status, o_need;
 	DevBuf<BamWindowCounts> d_wc;
@@ -212,6 +216,31 @@ extern "C" void dropest_bam_decoder_destroy(dropest_bam_decoder *d) {
 	if (d->stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
 	for (BamFront &f : d->front) if (f.stream) { (void)hipStreamSynchronize(f.stream); (void)hipStreamDestroy(f.stream); }
 	delete d;
+}
+
+extern "C" int dropest_bam_decoder_set_annotation(dropest_bam_decoder *d, dropest_annotation *a, const int32_t *ann_chr_of_ref, uint32_t n_refs) {
+	return bgzf_guarded([&] {
+		if (!d || !a || (n_refs && !ann_chr_of_ref)) throw InvalidError("null argument");
+		if (n_refs != uint32_t(d->cfg.n_refs)) throw InvalidError("one annotation chromosome per reference is expected");
+		if (dropest_annotation_device(a) != d->device) throw InvalidError("the annotation lives on another GPU");
+		HIP_CHECK(hipSetDevice(d->device));
+		d->annotation = a;
+		d->n_ann_genes = dropest_annotation_genes(a);
+		d->d_ann_chr.alloc(std::max<uint32_t>(n_refs, 1u));
+		if (n_refs) HIP_CHECK(hipMemcpy(d->d_ann_chr.p, ann_chr_of_ref, size_t(n_refs) * 4, hipMemcpyHostToDevice));
+		d->d_ann_id.alloc(std::max<uint32_t>(d->n_ann_genes, 1u));
+		HIP_CHECK(hipMemset(d->d_ann_id.p, 0xFF, size_t(std::max<uint32_t>(d->n_ann_genes, 1u)) * 4));   // no gene of the annotation is in the dictionary yet
+	});
+}
+
+extern "C" int dropest_bam_decoder_set_annotation_genes(dropest_bam_decoder *d, const int32_t *id_of_ann_gene, uint32_t n) {
+	return bgzf_guarded([&] {
+		if (!d || !d->annotation || (n && !id_of_ann_gene)) throw InvalidError("no annotation was given to this decoder");
+		if (n != d->n_ann_genes) throw InvalidError("one entry per gene of the annotation is expected");
+		HIP_CHECK(hipSetDevice(d->device));
+		HIP_CHECK(hipStreamSynchronize(d->stream));
+		if (n) HIP_CHECK(hipMemcpy(d->d_ann_id.p, id_of_ann_gene, size_t(n) * 4, hipMemcpyHostToDevice));
+	});
 }
 
 extern "C" int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, const uint64_t *gene_hash, const uint32_t *gene_id, uint32_t n_genes,
@@ -394,10 +423,16 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			const uint32_t tiles = uint32_t((n_rec + BAM_FIN_TILE - 1) / BAM_FIN_TILE);
 			d->tile_ok.ensure(tiles + tiles / 4 + 1); d->tile_need.ensure(tiles + tiles / 4 + 1); d->d_totals.ensure(2); d->d_wc.ensure(1);
 			HIP_CHECK(hipMemsetAsync(d->d_wc.p, 0, sizeof(BamWindowCounts), st));
-			const BamRecordOut ro{d->o_cb.p, d->o_umi.p, d->o_gene.p, d->o_aux.p, d->o_uql.p, d->o_status.p, d->o_need.p};
-			const BamDict dict{d->g_keys.p, d->g_vals.p, d->g_mask, d->d_chr.p};
+			if (d->annotation) { d->a_chr.ensure(rc); d->a_pos.ensure(rc); d->a_end.ensure(rc); d->a_gene.ensure(rc); d->a_mark.ensure(rc); }
+			const BamRecordOut ro{d->o_cb.p, d->o_umi.p, d->o_gene.p, d->o_aux.p, d->o_uql.p, d->o_status.p, d->o_need.p, d->a_chr.p, d->a_pos.p, d->a_end.p};
+			const BamDict dict{d->g_keys.p, d->g_vals.p, d->g_mask, d->d_chr.p, d->annotation ? d->d_ann_chr.p : nullptr, d->annotation ? d->d_ann_id.p : nullptr};
 			const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, d->nd_rec.p, d->nd_pos.p, d->nd_size.p};
+			if (d->annotation) HIP_CHECK(hipMemsetAsync(d->a_chr.p, 0xFF, size_t(n_rec) * 4, st));   // (records that are not accepted: "no such chromosome", ignored)
 			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + 255) / 256)), dim3(256), 0, st, F.d_out.p, d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro);
+			if (d->annotation) {
+				if (dropest_annotation_query_device(d->annotation, st, n_rec, d->a_chr.p, d->a_pos.p, d->a_end.p, d->a_gene.p, d->a_mark.p)) throw DeviceError(dropest_annotation_last_error());
+				hipLaunchKernelGGL(bam_resolve_annotated_kernel, dim3(uint32_t((n_rec + 255) / 256)), dim3(256), 0, st, uint32_t(n_rec), dict, ro, d->a_gene.p, d->a_mark.p);
+			}
 			hipLaunchKernelGGL(bam_fin_count_kernel, dim3(tiles), dim3(256), 0, st, d->o_status.p, d->o_need.p, d->o_uql.p, uint32_t(n_rec), d->tile_ok.p, d->tile_need.p, d->d_wc.p);
 			hipLaunchKernelGGL(bam_fin_scan_kernel, dim3(1), dim3(1024), 0, st, d->tile_ok.p, d->tile_need.p, tiles, d->d_totals.p);
 			hipLaunchKernelGGL(bam_fin_scatter_kernel, dim3(tiles), dim3(256), 0, st, F.d_out.p, d->rec_off.p, ro, uint32_t(n_rec), d->tile_ok.p, d->tile_need.p, dn);

@@ -2,6 +2,7 @@
 #include "bam_ingest.h"
 #include "fast_inflate.h"
 #include "../../../include/dropest_bgzf.h"
+#include "../../../include/dropest_annotation.h"
 #include <atomic>
 
 #include <zlib.h>
@@ -853,9 +854,9 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 		// (a gene name, a chromosome, a string with N) are fetched as bytes and go through parse_one + the intern_* members in file order,
 		// exactly like the Needs of fast_window.  Windows grow from 1 MB of compressed bytes (the first ones meet most gene names).
 		// Every block's CRC-32 is checked on the device (the wave that inflated it reads it back).  Falls back to the host reader (returns false before anything was added) when
-		// the configuration needs what the kernels do not do: -g annotation, -r parameter files, gene = chromosome name, sharded containers.
+		// the configuration needs what the kernels do not do: -r parameter files, gene = chromosome name, sharded containers.
 		auto device_file = [&]() -> bool {
-			if (_params_from_files || !_genes.is_empty() || _gene_in_chromosome_name || !container.bulk_ingest_possible()) return false;
+			if (_params_from_files || _gene_in_chromosome_name || !container.bulk_ingest_possible()) return false;
 			if (_tags.intronic_read_value.size() > 24 || _tags.intergenic_read_value.size() > 24) return false;
 			struct Map { const uint8_t *p = nullptr; size_t n = 0; int fd = -1; ~Map() { if (p) munmap(const_cast<uint8_t *>(p), n); if (fd >= 0) close(fd); } } map;
 			map.fd = open(bam_name.c_str(), O_RDONLY);
@@ -910,6 +911,29 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			dropest_bam_decoder *dec = nullptr;
 			if (dropest_bam_decoder_create(container.device(), &cfg, &dec)) return false;              // (no GPU for this: the host reader does it)
 			struct Free { dropest_bam_decoder *d; ~Free() { dropest_bam_decoder_destroy(d); } } free_dec{dec};
+			// -g: the annotation's flat tables on the device (annotation_api.hip); the decoder asks it about the two ends of every alignment
+			struct FreeAnn { dropest_annotation *a = nullptr; ~FreeAnn() { if (a) dropest_annotation_destroy(a); } } ann;
+			Tools::GeneAnnotation::RefGenesContainer::Flat flat;
+			std::vector<uint64_t> ann_gene_hash;
+			std::vector<int32_t> id_of_ann_gene;
+			if (!_genes.is_empty()) {
+				try { flat = _genes.flatten(); } catch (const std::exception &) { return false; }   // (positions beyond 32 bits: the host reader does it)
+				dropest_flat_annotation fa{};
+				fa.n_chr = uint32_t(flat.chr_names.size()); fa.n_seg = uint32_t(flat.seg_start.size()); fa.n_tr = uint32_t(flat.tr_gene.size()); fa.n_genes = uint32_t(flat.gene_names.size());
+				fa.use_introns_from_gtf = flat.use_introns_from_gtf ? 1 : 0;
+				fa.chr_seg_begin = flat.chr_seg_begin.data(); fa.seg_start = flat.seg_start.data(); fa.seg_end = flat.seg_end.data(); fa.seg_tr_begin = flat.seg_tr_begin.data();
+				fa.seg_tr = flat.seg_tr.data(); fa.tr_gene = flat.tr_gene.data(); fa.tr_exon_begin = flat.tr_exon_begin.data(); fa.tr_intron_begin = flat.tr_intron_begin.data();
+				fa.exon_start = flat.exon_start.data(); fa.exon_end = flat.exon_end.data(); fa.intron_start = flat.intron_start.data(); fa.intron_end = flat.intron_end.data();
+				if (dropest_annotation_create(container.device(), &fa, &ann.a)) return false;
+				std::unordered_map<std::string, int32_t> chr_index;
+				for (size_t k = 0; k < flat.chr_names.size(); ++k) chr_index.emplace(flat.chr_names[k], int32_t(k));
+				std::vector<int32_t> ann_chr_of_ref(refs.size(), -1);
+				for (size_t r = 0; r < refs.size(); ++r) { auto it = chr_index.find(refs[r]); if (it != chr_index.end()) ann_chr_of_ref[r] = it->second; }
+				if (dropest_bam_decoder_set_annotation(dec, ann.a, ann_chr_of_ref.data(), uint32_t(refs.size()))) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+				ann_gene_hash.resize(flat.gene_names.size());
+				for (size_t g = 0; g < flat.gene_names.size(); ++g) ann_gene_hash[g] = CellsDataContainer::hash_name(flat.gene_names[g]);
+				id_of_ann_gene.assign(flat.gene_names.size(), -1);
+			}
 			auto host_inflate = [](const uint8_t *in, uint32_t in_len, uint8_t *out_bytes, uint32_t out_len, void *) -> int {
 				RawBlock b; b.cdata = in; b.clen = in_len; b.isize = out_len; b.crc = le32(in + in_len);
 				try { inflate_block(b, out_bytes); } catch (...) { return 1; }
@@ -976,6 +1000,12 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					container.dictionary_snapshot(dict_hash, dict_id, dict_chr);
 					if (dropest_bam_decoder_set_dictionaries(dec, dict_hash.data(), dict_id.data(), uint32_t(dict_hash.size()), dict_chr.data(), uint32_t(dict_chr.size())))
 						throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					if (ann.a) {   // the annotation's genes that the dictionary holds by now
+						for (size_t g = 0; g < flat.gene_names.size(); ++g)
+							if (id_of_ann_gene[g] < 0) id_of_ann_gene[g] = int32_t(container.lookup_gene(ann_gene_hash[g], flat.gene_names[g]));
+						if (dropest_bam_decoder_set_annotation_genes(dec, id_of_ann_gene.data(), uint32_t(id_of_ann_gene.size())))
+							throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					}
 					dict_dirty = false;
 				}
 				host_ms[0] += since(t_phase);
@@ -1045,7 +1075,9 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					dict_dirty = true;
 				}
 				host_ms[1] += since(t_phase); t_phase = clk::now();
-				container.add_records_packed_device(w.d_cb, w.d_umi, w.d_gene, w.d_aux, size_t(w.n_accepted), w.any_gene != 0);
+				bool any_gene = w.any_gene != 0;
+				for (size_t k = 0; k < size_t(w.n_need) && !any_gene; ++k) any_gene = p_gene[k] != DROPEST_NO_GENE;
+				container.add_records_packed_device(w.d_cb, w.d_umi, w.d_gene, w.d_aux, size_t(w.n_accepted), any_gene);
 				host_ms[2] += since(t_phase);
 				_counters.cant_parse += size_t(w.counts[DROPEST_BAM_CANT_PARSE_NO_COUNT] + w.counts[DROPEST_BAM_CANT_PARSE]);
 				_counters.low_quality += size_t(w.counts[DROPEST_BAM_LOW_QUALITY]);

@@ -97,7 +97,8 @@ public:
 	// BamController::parse_bam_files with a BamProcessor: every accepted read reaches container.add_record in file order
 	void parse_bam_files(const std::vector<std::string> &bam_files, CellsDataContainer &container);
 	// BGZF inflate, record chain and tag walk on the container's GPU (include/dropest_bgzf.h) where the configuration allows it: tags or read
-	// names as the source of barcode / UMI / gene; not with -g, -r, gene = chromosome name, or a sharded container (the host reader then runs).
+	// names as the source of barcode / UMI, the gene tag or a -g annotation (annotation_api.hip) as the source of the gene; not with -r, gene =
+	// chromosome name, or a sharded container (the host reader then runs).
 	// CRC-32 and ISIZE of every block are checked there too.  DROPEST_BAM_DEVICE=1 in the environment does the same.
 	void set_device_decode(bool on) { _device_decode = on; }
 	const Counters &counters() const { return _counters; }

@@ -119,6 +119,9 @@ struct BamRecordOut {
 	uint32_t *gene, *aux;
 	uint16_t *umiq_len;
 	uint8_t *status, *need;
+	// -g (genes from a GTF / BED annotation, ReadParamsParser::get_gene_from_reference :92-151): the record's chromosome in the annotation's
+	// numbering and the two ends of its alignment go to annotate_reads (annotation_api.hip); bam_resolve_annotated finishes the columns
+	int32_t *a_chr; uint32_t *a_pos, *a_end;
 };
 
 // The host's dictionaries as the kernels read them: gene-name hash (FNV-1a, host/facade.cpp hash_name) -> gene index in an open-addressing
@@ -128,6 +131,8 @@ struct BamDict {
 	const uint32_t *gvals;
 	uint32_t gmask;
 	const int32_t *chr_of_ref;
+	const int32_t *ann_chr_of_ref;    // -g: reference id -> chromosome of the annotation (-1: it has none of that name); null without -g
+	const int32_t *id_of_ann_gene;    // -g: gene of the annotation -> index in the host's gene dictionary, -1 = not in it yet
 };
 __host__ __device__ inline uint32_t bam_dict_slot(unsigned long long h, uint32_t mask) { return uint32_t((h ^ (h >> 29)) * 0x9E3779B97F4A7C15ull >> 40) & mask; }
 
@@ -232,6 +237,21 @@ __global__ __launch_bounds__(256) void bam_parse_kernel(const uint8_t *__restric
 		if (!cb_n || !umi_n) { out.status[i] = BAM_CANT_PARSE; return; }
 	}
 	if (!pass) { out.status[i] = BAM_LOW_QUALITY; return; }
+	if (dict.ann_chr_of_ref) {                                                // -g: the gene comes from the alignment's place (bam_resolve_annotated)
+		int64_t ref_len = 0;                                                  // BamAlignment::GetEndPosition: reference bases of M, D, N, =, X
+		const uint8_t *cig = p + 32 + l_read_name;
+		for (uint32_t k = 0; k < n_cigar; ++k) {
+			const uint32_t op = b_le32(cig + 4ull * k), kind = op & 0xFu;
+			if (kind == 0 || kind == 2 || kind == 3 || kind == 7 || kind == 8) ref_len += op >> 4;
+		}
+		const int32_t position = int32_t(b_le32(p + 4));
+		out.a_chr[i] = dict.ann_chr_of_ref[ref_id];
+		out.a_pos[i] = uint32_t(position); out.a_end[i] = uint32_t(int32_t(int64_t(position) + ref_len));
+		out.cb[i] = bam_pack_bases(cb, cb_n); out.umi[i] = bam_pack_bases(umi, umi_n);
+		out.aux[i] = uint32_t(ref_id);
+		out.status[i] = BAM_OK;
+		return;
+	}
 	uint32_t mark;                                                            // get_gene + parse_read_type (ReadParamsParser.cpp:36-90)
 	unsigned long long gh = 0;
 	if (!found[T_GENE]) mark = 1;                                             // HAS_NOT_ANNOTATED
@@ -272,6 +292,34 @@ __global__ __launch_bounds__(256) void bam_parse_kernel(const uint8_t *__restric
 	out.cb[i] = cbc; out.umi[i] = uc; out.gene[i] = gid; out.aux[i] = aux_w;
 	out.need[i] = need ? (has_gene ? 3 : 1) : (has_gene ? 2 : 0);             // bit 0: the host must see the record; bit 1: it carries a gene
 	out.status[i] = BAM_OK;
+}
+
+// -g: what annotate_reads (annotation_api.hip) said about the accepted records -> the columns (host/bam_ingest.cpp parse_one, the -g branch)
+__global__ __launch_bounds__(256) void bam_resolve_annotated_kernel(uint32_t n_rec, BamDict dict, BamRecordOut out, const uint32_t *__restrict__ ann_gene,
+                                                                    const int32_t *__restrict__ ann_mark) {
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n_rec || out.status[i] != BAM_OK) return;
+	const int32_t m = ann_mark[i];
+	if (m == -1) { out.status[i] = BAM_CANT_PARSE; return; }                  // RefGenesContainer::ChrNotFoundException (BamController.cpp:153-161)
+	const int32_t ref_id = int32_t(out.aux[i]);
+	bool need = m == -2;                                                      // more results at an end point than the kernel holds: the host decides
+	const uint32_t g = ann_gene[i];
+	const bool has_gene = !need && g != 0xFFFFFFFFu;
+	const uint32_t mark = need ? 0u : uint32_t(m) & 7u;
+	need |= !out.cb[i];
+	uint32_t gid = 0xFFFFFFFFu;
+	if (has_gene) {
+		need |= !out.umi[i];
+		const int32_t id = dict.id_of_ann_gene[g];
+		if (id < 0) need = true; else gid = uint32_t(id);
+	} else out.umi[i] = 1;
+	uint32_t aux_w = mark << 16;
+	if (!has_gene || (mark & 6u)) {
+		const int32_t chr = dict.chr_of_ref[ref_id];
+		if (chr < 0) need = true; else aux_w |= uint32_t(chr);
+	}
+	out.gene[i] = gid; out.aux[i] = aux_w;
+	out.need[i] = need ? (has_gene ? 3 : 1) : (has_gene ? 2 : 0);
 }
 
 // ---- the accepted records, dense ------------------------------------------------------------------------------------------------

@@ -38,6 +38,12 @@ const char *dropest_annotation_last_error(void);
 int dropest_annotation_query(dropest_annotation *a, uint64_t n, const int32_t *chr, const uint32_t *position,
                              const uint32_t *end_position, uint32_t *gene, int32_t *mark);
 
+/* The same for DEVICE arrays of the annotation's GPU, asynchronous on `stream` (a hipStream_t; the device BAM path, dropest_bgzf.h). */
+int dropest_annotation_query_device(dropest_annotation *a, void *stream, uint64_t n, const int32_t *d_chr, const uint32_t *d_position,
+                                    const uint32_t *d_end_position, uint32_t *d_gene, int32_t *d_mark);
+uint32_t dropest_annotation_genes(const dropest_annotation *a);
+int dropest_annotation_device(const dropest_annotation *a);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,14 @@ int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slot, dropest_
  * index of reference r, -1 = none yet.  Call again whenever they have grown. */
 int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, const uint64_t *gene_hash, const uint32_t *gene_id, uint32_t n_genes,
                                          const int32_t *chr_of_ref, uint32_t n_refs);
+/* -g: genes from a GTF / BED annotation instead of the gene tag (ReadParamsParser::get_gene_from_reference, ReadParamsParser.cpp:92-151): the
+ * decoder asks `a` (dropest_annotation.h, same GPU; stays the caller's) about the two ends of every accepted alignment.  ann_chr_of_ref[r] =
+ * the annotation's chromosome for reference r, -1 = it has none of that name (such a record cannot be parsed, BamController.cpp:153-161).
+ * _annotation_genes: id_of_ann_gene[g] = index of the annotation's gene g in the caller's gene dictionary, -1 = not in it yet (a record
+ * that names it comes back through need_*); call again whenever the dictionary has grown. */
+struct dropest_annotation;
+int dropest_bam_decoder_set_annotation(dropest_bam_decoder *d, struct dropest_annotation *a, const int32_t *ann_chr_of_ref, uint32_t n_refs);
+int dropest_bam_decoder_set_annotation_genes(dropest_bam_decoder *d, const int32_t *id_of_ann_gene, uint32_t n);
 /* the bytes of records idx[0 .. n) of the LAST window (block_size field first), one after the other: dst_off[k] = where record idx[k] starts in dst */
 int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const uint32_t *idx, uint32_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *dst_off);
 /* rows pos[0 .. n) of the LAST window's dense columns take these values (what the caller resolved for the `need` records) */

@@ -2,7 +2,8 @@
 (DROPEST_BAM_DEVICE=1: csrc/k_inflate.h + k_bamparse.h) -- same counters, same cells, same count matrix.  What is drawn per file: BGZF block
 size (3 bytes .. 64 KB: records and their length fields cut anywhere), zlib level, tags in random order with numeric and array tags in
 between, missing barcode / UMI / gene tags, unmapped / secondary records, unknown reference ids, N in barcodes and UMIs, read-name mode,
-records of up to 70 KB, names of 1 .. 200 characters, the window size of the device path.
+records of up to 70 KB, names of 1 .. 200 characters, the window size of the device path; every third file takes its genes from a
+random GTF (-g) with spliced alignments.
 Run on a GPU box: PYTHONPATH=. python scripts/soak_bam_device.py   (SOAK_CASES, SOAK_SEED)"""
 import json
 import os
@@ -75,17 +76,35 @@ for case in range(int(os.environ.get("SOAK_CASES", "16"))):
         name = ("r%d" % i) + "q" * int(rng.integers(0, 3) ** 5 % 190)
         if mode == "name":
             name = "%s!%s#%s" % (name, cb, umi) if rng.random() > p_odd / 4 else name
-        recs.append(bw.record(ref, int(rng.integers(0, 1 << 28)), name, flag=flag, seq=seq, tags=tags))
+        recs.append(bw.record(ref, int(rng.integers(0, 60_000 if case % 3 == 1 else 1 << 28)), name, flag=flag, seq=seq, tags=tags,
+                              cigar=None if rng.random() < 0.6 else [(len(seq) // 2, "M"), (int(rng.integers(1, 2000)), "N"), (len(seq) - len(seq) // 2, "M")]))
     tmp = tempfile.mkdtemp()
     bam = os.path.join(tmp, "t.bam")
+    genv = {}
+    if case % 3 == 1:      # -g: genes from a random GTF over the first references (the others: "chromosome not found" = cannot be parsed)
+        import gzip
+        lines = []
+        for k in range(max(1, n_ref - 2)):
+            pos = int(rng.integers(0, 3000))
+            for g in range(int(rng.integers(5, 80))):
+                for x in range(int(rng.integers(1, 5))):
+                    ln = int(rng.integers(40, 500))
+                    lines.append('chr%d\tsrc\texon\t%d\t%d\t.\t+\t.\tgene_id "G%d_%d"; transcript_id "T%d_%d_%d";' % (k, pos + 1, pos + ln, k, g, k, g, x % 2))
+                    pos += ln + int(rng.integers(20, 700))
+                pos += int(rng.integers(0, 3000)) - 400 * int(rng.random() < 0.3)      # some genes overlap the next one
+                pos = max(pos, 0)
+        gtf = os.path.join(tmp, "a.gtf.gz")
+        with gzip.open(gtf, "wt") as f:
+            f.write("\n".join(lines) + "\n")
+        genv = {"DROPEST_GTF": gtf}
     block = int(rng.choice([3, 17, 250, 4000, 30_000, 0xFF00]))
     if block < 100 and n > 15_000:
         block = 4000
     bw.write_bam(bam, [("chr%d" % k, 1 << 28) for k in range(n_ref)], recs, block=block)
-    host = run(os.path.join(tmp, "host"), mode, bam, {})
-    dev = run(os.path.join(tmp, "dev"), mode, bam, {"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_DEVICE_WINDOW_MB": str(int(rng.choice([1, 1, 4, 32])))})
+    host = run(os.path.join(tmp, "host"), mode, bam, dict(genv))
+    dev = run(os.path.join(tmp, "dev"), mode, bam, dict(genv, DROPEST_BAM_DEVICE="1", DROPEST_BAM_DEVICE_WINDOW_MB=str(int(rng.choice([1, 1, 4, 32])))))
     same = host == dev
-    print(case, mode, "reads", n, "block", block, "p_n", p_n, "p_odd", p_odd, "long", long_every, "->", host.get("stats", host.get("error")),
+    print(case, mode + (" -g" if genv else ""), "reads", n, "block", block, "p_n", p_n, "p_odd", p_odd, "long", long_every, "->", host.get("stats", host.get("error")),
           "SAME" if same else "DIFFERENT %s" % (dev.get("stats", dev.get("error")),), "%.1fs" % (time.time() - t0), flush=True)
     if not same:
         sys.exit(1)

@@ -46,9 +46,14 @@ def _run(tmp_path, mode, bams, min_before, min_after, wl="-", threads=3, env=Non
     build_facade()
     os.makedirs(str(tmp_path), exist_ok=True)
     out = str(tmp_path / "res")
+    env = dict(env or {})
+    if env.get("DROPEST_BAM_DEVICE"):
+        env["DROPEST_BAM_TRACE"] = "1"
     res = subprocess.run([TOOL, out, mode, str(min_before), str(min_after), wl, str(threads)] + bams, capture_output=True, text=True, timeout=300,
-                         env=dict(os.environ, **(env or {})))
+                         env=dict(os.environ, **env))
     assert res.returncode == 0, res.stdout + res.stderr
+    if env.get("DROPEST_BAM_DEVICE"):      # the device path really ran (it hands a file it cannot do to the host reader without a word otherwise)
+        assert res.stderr.count("[bam] device path:") >= 2 * len(bams), res.stderr
     stats = json.loads(res.stdout.strip().splitlines()[-1])
     d = rr.read_rds(out + ".rds")
     cm, genes, cells = rr.dgcmatrix_to_dense(d["cm"])
@@ -263,11 +268,15 @@ def test_genes_from_a_gtf_annotation(tmp_path):
     os.environ["DROPEST_GTF"] = gtf
     try:
         got, cells, stats, d = _run(tmp_path, "filled", [bam], 2, 3)
+        # the same with the BAM inflated, walked and annotated on the device (k_bamparse.h -> annotation_api.hip -> bam_resolve_annotated)
+        got_d, cells_d, stats_d, _ = _run(tmp_path / "device", "filled", [bam], 2, 3, env={"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_DEVICE_WINDOW_MB": "1", "DROPEST_BAM_TRACE": "1"})
     finally:
         del os.environ["DROPEST_GTF"]
     want, cols = _oracle(kept, 2, 3)
     assert cells == cols and got == want and len(want) > 100
     assert stats["cant_parse"] == n_unknown > 0 and stats["saved"] == len(kept)
+    assert cells_d == cells and got_d == got
+    assert {k: stats_d[k] for k in ("total_reads", "cant_parse", "low_quality", "saved")} == {k: stats[k] for k in ("total_reads", "cant_parse", "low_quality", "saved")}
     assert sum(1 for k in kept if k[4] & 1) > 100 and sum(1 for k in kept if k[2] is None) > 1000    # half-annotated and intergenic reads
 
 
