@@ -449,7 +449,7 @@ def measure(args, config, reads_per_gpu, cells, steps, warmup, world, rank, loca
     return line
 
 
-def measure_bam_ingest(n_reads=250_000, copies=32, threads=16):
+def measure_bam_ingest(n_reads=250_000, copies=64, threads=16):
     """BAM file -> CellsDataContainer (tests/cpp/bam_to_counts: BamController + the facade), host reader against the device path, on one
     synthetic 10x-style BAM (CB / UB / GX tags, 98 bases; the records written `copies` times into one file); and the inflate kernel alone."""
     import ctypes as C
