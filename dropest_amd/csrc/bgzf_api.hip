@@ -188,6 +188,25 @@ extern "C" int dropest_bam_decoder_create(int device, const dropest_bam_parse_cf
 	});
 }
 
+// A decoder taken up again for another file (its buffers, streams and pinned memory stay): the parse configuration of that file, empty
+// dictionaries, no annotation, no record carried over.
+extern "C" int dropest_bam_decoder_reset(dropest_bam_decoder *d, const dropest_bam_parse_cfg *cfg) {
+	return bgzf_guarded([&] {
+		if (!d || !cfg) throw InvalidError("null argument");
+		if (cfg->intronic_len > 24 || cfg->intergenic_len > 24) throw InvalidError("read-type values longer than 24 characters");
+		if (cfg->n_refs < 0) throw InvalidError("negative number of references");
+		HIP_CHECK(hipSetDevice(d->device));
+		HIP_CHECK(hipStreamSynchronize(d->stream));
+		for (BamFront &f : d->front) { HIP_CHECK(hipStreamSynchronize(f.stream)); f.begun = false; }
+		std::memcpy(&d->cfg, cfg, sizeof(BamParseCfg));
+		d->tail_len = 0; d->last_n_rec = 0; d->last_n_ok = 0; d->next_front = 0; d->last_front = 0;
+		d->annotation = nullptr; d->n_ann_genes = 0;
+		HIP_CHECK(hipMemset(d->g_vals.p, 0, size_t(d->g_mask + 1) * 4));
+		d->d_chr.ensure(size_t(std::max(1, cfg->n_refs)));
+		HIP_CHECK(hipMemset(d->d_chr.p, 0xFF, size_t(std::max(1, cfg->n_refs)) * 4));
+	});
+}
+
 extern "C" int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, uint64_t bytes, uint8_t **out) {
 	return bgzf_guarded([&] {
 		if (!d || !out || which < 0 || which > 1) throw InvalidError("bad argument");

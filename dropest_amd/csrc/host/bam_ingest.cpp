@@ -616,6 +616,17 @@ bool BamRecord::get_string_tag(const std::string &tag, std::string &value, char 
 	return true;
 }
 
+namespace {
+std::mutex &decoder_cache_mutex() { static std::mutex m; return m; }
+std::unordered_map<int, dropest_bam_decoder *> &decoder_cache() { static auto *c = new std::unordered_map<int, dropest_bam_decoder *>(); return *c; }   // (never destroyed: the HIP runtime may be gone by then)
+}  // namespace
+
+void BamController::release_device_decoders() {
+	std::lock_guard<std::mutex> lk(decoder_cache_mutex());
+	for (auto &kv : decoder_cache()) dropest_bam_decoder_destroy(kv.second);
+	decoder_cache().clear();
+}
+
 BamController::BamController(const BamTags &tags, bool filled_bam, const std::string &read_param_filenames, const std::string &gtf_path,
                              bool gene_in_chromosome_name, int min_barcode_phred, unsigned threads)
 	: _tags(tags), _filled_bam(filled_bam), _gene_in_chromosome_name(gene_in_chromosome_name), _min_barcode_phred(min_barcode_phred),
@@ -857,6 +868,8 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 		// the configuration needs what the kernels do not do: -r parameter files, gene = chromosome name, sharded containers.
 		auto device_file = [&]() -> bool {
 			if (_params_from_files || _gene_in_chromosome_name || !container.bulk_ingest_possible()) return false;
+			const auto t_enter = clk::now();
+			double ms_header = 0, ms_create = 0;
 			if (_tags.intronic_read_value.size() > 24 || _tags.intergenic_read_value.size() > 24) return false;
 			struct Map { const uint8_t *p = nullptr; size_t n = 0; int fd = -1; ~Map() { if (p) munmap(const_cast<uint8_t *>(p), n); if (fd >= 0) close(fd); } } map;
 			map.fd = open(bam_name.c_str(), O_RDONLY);
@@ -901,6 +914,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				for (size_t k = starts.size(); k-- > 0;)
 					if (starts[k].second <= h && h < (k + 1 < starts.size() ? starts[k + 1].second : hdr.size())) { c0 = starts[k].first; u0 = uint32_t(h - starts[k].second); break; }
 			}
+			ms_header = since(t_enter);
 			dropest_bam_parse_cfg cfg{};
 			for (int k = 0; k < 6; ++k) cfg.tag[k] = wanted_tags[k];
 			cfg.filled_bam = _filled_bam ? 1 : 0; cfg.min_phred = _min_barcode_phred; cfg.has_read_type = _tags.read_type.empty() ? 0 : 1;
@@ -908,9 +922,27 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			cfg.intronic_len = uint32_t(_tags.intronic_read_value.size()); cfg.intergenic_len = uint32_t(_tags.intergenic_read_value.size());
 			std::memcpy(cfg.intronic, _tags.intronic_read_value.data(), cfg.intronic_len);
 			std::memcpy(cfg.intergenic, _tags.intergenic_read_value.data(), cfg.intergenic_len);
+			// One decoder per device is kept between files and until the process ends (BamController::release_device_decoders frees them):
+			// streams, ~1.5 GB of device buffers and 64 MB of pinned memory cost ~30 ms to set up and ~40 ms to give back.
 			dropest_bam_decoder *dec = nullptr;
-			if (dropest_bam_decoder_create(container.device(), &cfg, &dec)) return false;              // (no GPU for this: the host reader does it)
-			struct Free { dropest_bam_decoder *d; ~Free() { dropest_bam_decoder_destroy(d); } } free_dec{dec};
+			{
+				std::lock_guard<std::mutex> lk(decoder_cache_mutex());
+				auto it = decoder_cache().find(container.device());
+				if (it != decoder_cache().end()) { dec = it->second; decoder_cache().erase(it); }
+			}
+			if (dec && dropest_bam_decoder_reset(dec, &cfg)) { dropest_bam_decoder_destroy(dec); dec = nullptr; }
+			if (!dec && dropest_bam_decoder_create(container.device(), &cfg, &dec)) return false;       // (no GPU for this: the host reader does it)
+			ms_create = since(t_enter) - ms_header;
+			struct Keep {    // back into the cache when the file went through, destroyed when it did not (whatever state an exception left)
+				dropest_bam_decoder *d; int device; bool ok = false;
+				~Keep() {
+					if (!ok) { dropest_bam_decoder_destroy(d); return; }
+					std::lock_guard<std::mutex> lk(decoder_cache_mutex());
+					auto &slot = decoder_cache()[device];
+					if (slot) dropest_bam_decoder_destroy(slot);
+					slot = d;
+				}
+			} keep_dec{dec, container.device()};
 			// -g: the annotation's flat tables on the device (annotation_api.hip); the decoder asks it about the two ends of every alignment
 			struct FreeAnn { dropest_annotation *a = nullptr; ~FreeAnn() { if (a) dropest_annotation_destroy(a); } } ann;
 			Tools::GeneAnnotation::RefGenesContainer::Flat flat;
@@ -1089,7 +1121,9 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				std::fprintf(stderr, "[bam] device path: %zu windows, %.1f ms behind the header; copy in %.1f ms, inflate %.1f ms (%zu blocks left to the host), record chain %.1f ms (%zu guesses "
 				             "repaired), fields + dense columns %.1f ms; host: dictionaries to the device %.1f ms, %zu records with something new %.1f ms, container %.1f ms\n",
 				             n_windows, since(t_file), dev_ms[0], dev_ms[1], refused, dev_ms[2], repaired, dev_ms[3], host_ms[0], n_needs, host_ms[1], host_ms[2]),
+				std::fprintf(stderr, "[bam] device path: file mapped and header read %.1f ms, decoder created %.1f ms, annotation + the rest before the windows %.1f ms\n", ms_header, ms_create, std::chrono::duration<double, std::milli>(t_file - t_enter).count() - ms_header - ms_create),
 				std::fprintf(stderr, "[bam] device path: pinned staging buffers %.1f ms, waiting for the file reader %.1f ms, inside the window calls %.1f ms\n", ms_setup, ms_wait_read, ms_window_calls);
+			keep_dec.ok = true;
 			return true;
 		};
 		static const bool env_device = getenv("DROPEST_BAM_DEVICE") != nullptr && atoi(getenv("DROPEST_BAM_DEVICE")) != 0;

@@ -74,6 +74,9 @@ typedef struct dropest_bam_window {        /* host pointers: pinned memory of th
 typedef int (*dropest_bgzf_host_inflate)(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, void *user);
 
 int dropest_bam_decoder_create(int device, const dropest_bam_parse_cfg *cfg, dropest_bam_decoder **out);
+/* The decoder for another file: its device buffers, streams and pinned memory stay (creating and freeing them is ~60 ms per file), the
+ * dictionaries are emptied, the annotation and the record carried over are dropped. */
+int dropest_bam_decoder_reset(dropest_bam_decoder *d, const dropest_bam_parse_cfg *cfg);
 /* Two pinned host buffers of the decoder for the caller's compressed bytes (which = 0 / 1, at least `bytes` long): a window handed over from
  * one of them crosses PCIe at the link's rate; any other host memory works too (pageable memory is staged by the runtime at a third of it). */
 int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, uint64_t bytes, uint8_t **out);
