@@ -123,6 +123,14 @@ extern "C" int dropest_bgzf_inflate_buffer(int device, const uint8_t *data, uint
 }
 
 // ---- BAM records of a window, on the device ------------------------------------------------------------------------------------
+// tests: wrong guesses on purpose (every third segment one byte late, every seventh none at all) -- the host's check must find the true chain anyway
+__global__ __launch_bounds__(256) void bam_spoil_guesses_kernel(uint64_t *__restrict__ seg_start, uint32_t n_segs) {
+	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+	if (k == 0 || k >= n_segs) return;
+	if (k % 7u == 3u) seg_start[k] = BAM_NONE;
+	else if (k % 3u == 1u && seg_start[k] != BAM_NONE) seg_start[k] += 1;
+}
+
 // What the first half of a window produces (copy in, inflate, the chain of records) and the second half (fields, dense columns) consumes.  Two of
 // them: the caller may run the first half of window k + 1 on another thread while the second half of window k and its own work go on.
 struct BamFront {
@@ -356,13 +364,16 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 		uint64_t n_rec = 0;
 		if (n_segs) {
 			const size_t sc = size_t(n_segs) + n_segs / 4;
-			d->seg_start.ensure(sc); d->seg_exit.ensure(sc); d->seg_count.ensure(sc); d->seg_base.ensure(sc); d->d_bad.ensure(1); d->d_list.ensure(1);
+			d->seg_start.ensure(sc); d->seg_exit.ensure(sc); d->seg_count.ensure(sc); d->seg_base.ensure(sc); d->d_bad.ensure(2); d->d_list.ensure(1);
 			d->h_seg_start.ensure(n_segs); d->h_seg_exit.ensure(n_segs); d->h_count.ensure(n_segs);
-			HIP_CHECK(hipMemsetAsync(d->d_bad.p, 0, 4, st));
+			HIP_CHECK(hipMemsetAsync(d->d_bad.p, 0, 8, st));
 			HIP_CHECK(hipMemcpyAsync(d->seg_start.p, &expect, 8, hipMemcpyHostToDevice, st));
 			if (n_segs > 1) hipLaunchKernelGGL(bam_seg_guess_kernel, dim3((n_segs - 1 + 3) / 4), dim3(256), 0, st, d->d_out.p, data_len, dec->cfg.n_refs, n_segs, d->seg_start.p);
+			if (getenv("DROPEST_BAM_TEST_SPOIL_GUESSES")) hipLaunchKernelGGL(bam_spoil_guesses_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, d->seg_start.p, n_segs);
 			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, d->d_out.p, data_len, (const uint32_t *)nullptr, n_segs, d->seg_start.p,
-			                   d->seg_count.p, d->seg_exit.p, (const uint32_t *)nullptr, (uint64_t *)nullptr, d->d_bad.p);
+			                   d->seg_count.p, d->seg_exit.p, (const uint32_t *)nullptr, (uint64_t *)nullptr, d->d_bad.p + 1);
+			// (a walk from a guess that is not on the chain reads anything as a length: what these walks flag is not looked at -- the walk that
+			// writes the record offsets, from the checked starts, is the one whose flag counts: dropest_bam_decoder_window_finish)
 			HIP_CHECK(hipGetLastError());
 			HIP_CHECK(hipMemcpyAsync(d->h_seg_start.p, d->seg_start.p, size_t(n_segs) * 8, hipMemcpyDeviceToHost, st));
 			HIP_CHECK(hipMemcpyAsync(d->h_seg_exit.p, d->seg_exit.p, size_t(n_segs) * 8, hipMemcpyDeviceToHost, st));
@@ -378,7 +389,7 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 					HIP_CHECK(hipMemcpyAsync(d->seg_start.p + k, &d->h_seg_start.p[k], 8, hipMemcpyHostToDevice, st));
 					HIP_CHECK(hipMemcpyAsync(d->d_list.p, &k, 4, hipMemcpyHostToDevice, st));
 					hipLaunchKernelGGL(bam_seg_walk_kernel, dim3(1), dim3(256), 0, st, d->d_out.p, data_len, d->d_list.p, 1u, d->seg_start.p, d->seg_count.p, d->seg_exit.p,
-					                   (const uint32_t *)nullptr, (uint64_t *)nullptr, d->d_bad.p);
+					                   (const uint32_t *)nullptr, (uint64_t *)nullptr, d->d_bad.p + 1);
 					HIP_CHECK(hipMemcpyAsync(d->h_seg_exit.p + k, d->seg_exit.p + k, 8, hipMemcpyDeviceToHost, st));
 					HIP_CHECK(hipMemcpyAsync(d->h_count.p + k, d->seg_count.p + k, 4, hipMemcpyDeviceToHost, st));
 					HIP_CHECK(hipStreamSynchronize(st));
@@ -387,9 +398,6 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 				n_rec += d->h_count.p[k];
 				if (want != BAM_NONE) expect = d->h_seg_exit.p[k];
 			}
-			uint32_t bad = 0;
-			HIP_CHECK(hipMemcpy(&bad, d->d_bad.p, 4, hipMemcpyDeviceToHost));
-			if (bad) throw InvalidError("Corrupt BAM record");
 			if (n_rec > 0xFFFFFFF0ull) throw UnsupportedError("more than 2^32 records in one window");
 		}
 		const uint64_t tail_start = n_segs ? expect : (tail ? 0 : first_skip);
@@ -430,7 +438,7 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 		auto t0 = clk::now();
 		// record offsets, the fields, the accepted records made dense
 		BamWindowCounts wc{};
-		uint32_t totals[2] = {0, 0};
+		uint32_t totals[2] = {0, 0}, bad_record = 0;
 		if (n_rec) {
 			const size_t rc = size_t(n_rec) + size_t(n_rec) / 4;
 			d->rec_off.ensure(rc);
@@ -458,8 +466,10 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			HIP_CHECK(hipGetLastError());
 			HIP_CHECK(hipMemcpyAsync(&wc, d->d_wc.p, sizeof(wc), hipMemcpyDeviceToHost, st));
 			HIP_CHECK(hipMemcpyAsync(totals, d->d_totals.p, 8, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(&bad_record, F.d_bad.p, 4, hipMemcpyDeviceToHost, st));
 		}
 		HIP_CHECK(hipStreamSynchronize(st));
+		if (bad_record) throw InvalidError("Corrupt BAM record");      // (a block_size below the 32 bytes of a record's fixed part, met by the walk from the checked starts)
 		const uint32_t n_need = totals[1];
 		if (n_need) {
 			d->h_need_rec.ensure(n_need); d->h_need_pos.ensure(n_need); d->h_need_size.ensure(n_need);

@@ -2,6 +2,7 @@
 ResultsPrinter, compared with the CPU oracle fed with the same reads through add_record (strings)."""
 import json
 import os
+import struct
 import subprocess
 
 import numpy as np
@@ -54,7 +55,10 @@ def _run(tmp_path, mode, bams, min_before, min_after, wl="-", threads=3, env=Non
     assert res.returncode == 0, res.stdout + res.stderr
     if env.get("DROPEST_BAM_DEVICE"):      # the device path really ran (it hands a file it cannot do to the host reader without a word otherwise)
         assert res.stderr.count("[bam] device path:") >= 2 * len(bams), res.stderr
+    import re
+    rep = re.findall(r"\((\d+) guesses repaired\)", res.stderr)
     stats = json.loads(res.stdout.strip().splitlines()[-1])
+    stats["_guesses_repaired"] = sum(int(x) for x in rep)
     d = rr.read_rds(out + ".rds")
     cm, genes, cells = rr.dgcmatrix_to_dense(d["cm"])
     got = {(genes[r], cells[c]): int(cm[r, c]) for r, c in zip(*np.nonzero(cm))}
@@ -135,6 +139,12 @@ def test_record_boundaries_found_by_the_loader(tmp_path, block):
     # the device finds the chain of records by guessing per 16 KB segment and checking the guesses (k_bamparse.h): same container
     got4, cells4, stats4, _ = _run(tmp_path / "device", "filled", [bam], 3, 5, threads=4, env={"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_TRACE": "1"})
     assert cells4 == cells and got4 == got and stats4["saved"] == stats["saved"]
+    # ... whatever the guesses were: every third one spoiled by a byte, every seventh withheld (a test switch of the library) -- the host's check
+    # walks those segments again from the true place
+    got5, cells5, stats5, _ = _run(tmp_path / "spoiled", "filled", [bam], 3, 5, threads=4, env={"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_TEST_SPOIL_GUESSES": "1"})
+    assert cells5 == cells and got5 == got and stats5["saved"] == stats["saved"]
+    if block > 100:
+        assert stats5["_guesses_repaired"] > 0
 
 
 def test_read_name_encoding_and_whitelist_merge(tmp_path):
@@ -224,6 +234,33 @@ def test_bad_files(tmp_path):
     for bam in (p, str(tmp_path / "missing.bam")):
         res = subprocess.run([TOOL, str(tmp_path / "o"), "filled", "1", "1", "-", "1", bam], capture_output=True, text=True)
         assert res.returncode == 1 and "BAM" in res.stderr
+        res = subprocess.run([TOOL, str(tmp_path / "o"), "filled", "1", "1", "-", "1", bam], capture_output=True, text=True, env=dict(os.environ, DROPEST_BAM_DEVICE="1"))
+        assert res.returncode == 1 and "BAM" in res.stderr
+    # damage inside a file: a record whose length field says 7 bytes, a block with a flipped payload byte, a file cut in the middle of a block and in
+    # the middle of a record -- the host reader and the device path both refuse them (no result is written)
+    reads = _reads(6000)
+    refs = [("chr%d" % i, 1_000_000) for i in range(25)]
+    recs = [bw.record(int(c[3:]), i, "r%d" % i, tags=[("CB", "Z", cb), ("UB", "Z", umi)] + ([("GX", "Z", g)] if g else [])) for i, (cb, umi, g, c, m) in enumerate(reads)]
+    good = str(tmp_path / "good.bam")
+    bw.write_bam(good, refs, recs, block=20_000)
+    blob = open(good, "rb").read()
+    short = list(recs); short[3000] = struct.pack("<I", 7) + short[3000][4:]
+    bad_len = str(tmp_path / "bad_len.bam")
+    bw.write_bam(bad_len, refs, short, block=20_000)
+    flipped = bytearray(blob); flipped[len(blob) // 2] ^= 0x40
+    cut_block = blob[: len(blob) // 2]
+    whole_blocks = 0
+    at = 0
+    while at + 18 <= len(blob) * 2 // 3:
+        at += struct.unpack("<H", blob[at + 16:at + 18])[0] + 1
+    cut_record = blob[:at]                                       # whole blocks, but the stream ends inside a record (and without the EOF block)
+    for name, data in (("flipped", bytes(flipped)), ("cut_block", cut_block), ("cut_record", cut_record)):
+        open(str(tmp_path / (name + ".bam")), "wb").write(data)
+    for name in ("bad_len", "flipped", "cut_block", "cut_record"):
+        for env in ({}, {"DROPEST_BAM_DEVICE": "1"}):
+            res = subprocess.run([TOOL, str(tmp_path / "o2"), "filled", "1", "1", "-", "2", str(tmp_path / (name + ".bam"))], capture_output=True, text=True,
+                                 env=dict(os.environ, **env))
+            assert res.returncode == 1 and ("BAM" in res.stderr or "BGZF" in res.stderr), (name, env, res.stderr)
 
 
 def test_genes_from_a_gtf_annotation(tmp_path):
