@@ -252,6 +252,7 @@ __global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 	};
 
 	for (bool last = false; !last && !err;) {
+		if (s.ipos - uint64_t(s.cnt >> 3) > in_end + 8) { err = INF_INPUT_OVERRUN; break; }   // (a damaged stream of empty blocks must not read on through its neighbours)
 		last = inf_take(s, L, lane, 1) != 0;
 		const uint32_t type = inf_take(s, L, lane, 2);
 		if (type == 0) {   // stored: to the byte boundary, LEN, NLEN, bytes
