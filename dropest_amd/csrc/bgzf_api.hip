@@ -215,6 +215,14 @@ extern "C" int dropest_bam_decoder_reset(dropest_bam_decoder *d, const dropest_b
 	});
 }
 
+// BGZF blocks the device inflates at once (a wave each, INF_WAVES_PER_EU per SIMD): a window of that many blocks takes as long as one of fewer
+extern "C" uint32_t dropest_bam_decoder_wave_slots(const dropest_bam_decoder *d) {
+	if (!d) return 0;
+	hipDeviceProp_t prop{};
+	if (hipGetDeviceProperties(&prop, d->device) != hipSuccess) return 0;
+	return uint32_t(prop.multiProcessorCount) * 4u * uint32_t(INF_WAVES_PER_EU);
+}
+
 extern "C" int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, uint64_t bytes, uint8_t **out) {
 	return bgzf_guarded([&] {
 		if (!d || !out || which < 0 || which > 1) throw InvalidError("bad argument");

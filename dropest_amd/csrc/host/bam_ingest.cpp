@@ -976,7 +976,10 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			double dev_ms[4] = {0, 0, 0, 0}, host_ms[3] = {0, 0, 0};
 			const auto t_file = clk::now();
 			size_t window_bytes = size_t(1) << 20, n_windows = 0, repaired = 0, refused = 0, n_needs = 0;
-			const size_t window_max = size_t(getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? std::max(1, atoi(getenv("DROPEST_BAM_DEVICE_WINDOW_MB"))) : 32) << 20;
+			// windows: a machine's worth of blocks (one wave per block) in a file of a few hundred MB, two in a long one (measured on 0.4 and 1.6 GB:
+			// NOTES_r05 §11) -- the pinned staging buffers of larger windows cost more to allocate than their fuller kernels give back
+			const bool long_file = map.n > (size_t(1) << 30);
+			const size_t window_max = size_t(getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? std::max(1, atoi(getenv("DROPEST_BAM_DEVICE_WINDOW_MB"))) : (long_file ? 80 : 48)) << 20;
 			// The compressed bytes reach the device through two pinned buffers of the decoder: a helper thread reads the next window from the file
 			// (pread: page cache -> pinned memory, whole blocks only) while the device and this thread work on the one before.
 			struct Staged { uint8_t *p = nullptr; size_t used = 0; bool final = false; std::string error; };
@@ -987,6 +990,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			const double ms_setup = since(t_file);
 			double ms_wait_read = 0, ms_window_calls = 0;
 			size_t file_at = c0;
+			const size_t block_cap = getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? size_t(-1) : std::max<size_t>(1024, dropest_bam_decoder_wave_slots(dec)) * (long_file ? 2 : 1);   // (one wave per block: a full machine's worth per window)
 			auto read_window = [&](int which, size_t want) {
 				Staged st; st.p = stage_p[which];
 				const size_t ask = std::min(std::min(want + (size_t(1) << 16) + 64, stage_cap), map.n - file_at);
@@ -997,8 +1001,8 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					if (r == 0) break;
 					got += size_t(r);
 				}
-				size_t o = 0;                                    // whole blocks: up to `want` bytes of them (at least one)
-				while (o + 18 <= got && (o < want || o == 0)) {
+				size_t o = 0, n_blocks = 0;                      // whole blocks: up to `want` bytes of them (at least one), and no more than the device inflates at once
+				while (o + 18 <= got && (o < want || o == 0) && n_blocks < block_cap) {
 					const uint8_t *h = st.p + o;
 					if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { st.error = "Not a BGZF/BAM file"; return st; }
 					const size_t xlen = le16(h + 10);
@@ -1007,7 +1011,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					for (size_t x = 0; x + 4 <= xlen;) { const uint8_t *sf = h + 12 + x; const size_t sl = le16(sf + 2); if (sf[0] == 'B' && sf[1] == 'C' && sl == 2 && x + 6 <= xlen) bsize = size_t(le16(sf + 4)) + 1; x += 4 + sl; }
 					if (!bsize) { st.error = "BGZF block without BC subfield"; return st; }
 					if (o + bsize > got) break;
-					o += bsize;
+					o += bsize; ++n_blocks;
 				}
 				if (!o && got) { st.error = "Truncated BGZF block"; return st; }
 				st.used = o; file_at += o; st.final = file_at >= map.n;

@@ -77,6 +77,8 @@ int dropest_bam_decoder_create(int device, const dropest_bam_parse_cfg *cfg, dro
 /* The decoder for another file: its device buffers, streams and pinned memory stay (creating and freeing them is ~60 ms per file), the
  * dictionaries are emptied, the annotation and the record carried over are dropped. */
 int dropest_bam_decoder_reset(dropest_bam_decoder *d, const dropest_bam_parse_cfg *cfg);
+/* Blocks the device inflates at the same time (one wave each): a window of that many blocks takes about as long as a window of fewer. */
+uint32_t dropest_bam_decoder_wave_slots(const dropest_bam_decoder *d);
 /* Two pinned host buffers of the decoder for the caller's compressed bytes (which = 0 / 1, at least `bytes` long): a window handed over from
  * one of them crosses PCIe at the link's rate; any other host memory works too (pageable memory is staged by the runtime at a third of it). */
 int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, uint64_t bytes, uint8_t **out);
