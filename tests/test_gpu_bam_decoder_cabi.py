@@ -1,0 +1,153 @@
+"""The device BAM decoder through its C-ABI alone (include/dropest_bgzf.h: dropest_bam_decoder_*), without the facade: one window over a written
+BAM -- the reader's status of every record (BamController.cpp:87-107, FilledBamParamsParser.cpp:12-40), the dense columns of the accepted ones,
+the `need` list (everything while the dictionaries are empty; only strings with N once they are given), the bytes fetch_records returns, patch."""
+import ctypes as C
+import gzip
+import struct
+
+import numpy as np
+import pytest
+
+from dropest_amd import capi
+
+import bam_writer as bw
+
+pytestmark = pytest.mark.gpu
+P = C.POINTER
+
+
+class Cfg(C.Structure):
+    _fields_ = [("tag", C.c_uint16 * 6), ("filled_bam", C.c_int32), ("min_phred", C.c_int32), ("has_read_type", C.c_int32), ("n_refs", C.c_int32),
+                ("intronic_len", C.c_uint32), ("intergenic_len", C.c_uint32), ("intronic", C.c_uint8 * 24), ("intergenic", C.c_uint8 * 24)]
+
+
+class Window(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("counts", C.c_uint64 * 5), ("n_accepted", C.c_uint64), ("d_cb", C.c_void_p), ("d_umi", C.c_void_p), ("d_gene", C.c_void_p),
+                ("d_aux", C.c_void_p), ("n_need", C.c_uint32), ("need_rec", P(C.c_uint32)), ("need_pos", P(C.c_uint32)), ("need_size", P(C.c_uint32)),
+                ("quality_seen", C.c_uint32), ("any_gene", C.c_uint32), ("window_bytes", C.c_uint64), ("tail_bytes", C.c_uint64), ("n_blocks", C.c_uint32),
+                ("refused_blocks", C.c_uint32), ("guesses_repaired", C.c_uint32), ("pad", C.c_uint32), ("ms", C.c_double * 4)]
+
+
+def fnv1a(s):
+    h = 1469598103934665603
+    for c in s.encode():
+        h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def tag16(t):
+    return ord(t[0]) | (ord(t[1]) << 8)
+
+
+def device_array(ptr, n, dtype):
+    hip = C.CDLL("libamdhip64.so")
+    out = np.zeros(n, dtype)
+    if n:
+        assert hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) == 0
+    return out
+
+
+def test_one_window_through_the_c_abi(tmp_path):
+    L = capi.lib()
+    L.dropest_bgzf_last_error.restype = C.c_char_p
+    rng = np.random.default_rng(12)
+    refs = [("chr%d" % i, 1 << 20) for i in range(4)]
+    genes = ["GENE%d" % i for i in range(40)]
+    recs, want = [], []          # want: (status, cb, umi, gene or None, mark, ref) per record, by the rules of the host reader
+    for i in range(5000):
+        cb = "".join(rng.choice(list("ACGT"), 12)); umi = "".join(rng.choice(list("ACGT"), 8))
+        if i % 211 == 0:
+            umi = umi[:2] + "N" + umi[3:]
+        g = None if i % 9 == 0 else genes[int(rng.integers(0, len(genes)))]
+        rt = [None, "N", "I", "E"][i % 4] if g else None
+        tags = [("CB", "Z", cb), ("UB", "Z", umi)] + ([("GX", "Z", g)] if g else []) + ([("RE", "A", rt)] if rt else []) + [("NH", "i", 1)]
+        flag, ref, status = 0, int(rng.integers(0, 4)), 0
+        if i % 97 == 1:
+            flag, status = 4, 1
+        elif i % 97 == 2:
+            flag, status = 0x100, 1
+        elif i % 97 == 3:
+            ref, status = -1, 2
+        elif i % 97 == 4:
+            tags, status = [t for t in tags if t[0] != "UB"], 3
+        mark = 1 if g is None else (4 if rt == "N" else 1 if rt == "I" else 2)
+        recs.append(bw.record(ref, i, "r%d" % i, flag=flag, tags=tags))
+        want.append((status, cb, umi, g, mark, ref))
+    path = str(tmp_path / "c.bam")
+    bw.write_bam(path, refs, recs, block=12_345)
+    blob = open(path, "rb").read()
+    raw = gzip.decompress(blob)
+    l_text = struct.unpack_from("<I", raw, 4)[0]
+    h = 12 + l_text
+    for _ in refs:
+        h += 8 + struct.unpack_from("<I", raw, h)[0]
+    assert raw[h:h + len(recs[0])] == recs[0]
+    at, cum, c0, u0 = 0, 0, None, None        # the block that holds byte h of the inflated stream
+    while at < len(blob):
+        bsize = struct.unpack_from("<H", blob, at + 16)[0] + 1
+        isize = struct.unpack_from("<I", blob, at + bsize - 4)[0]
+        if cum <= h < cum + isize:
+            c0, u0 = at, h - cum
+            break
+        cum += isize; at += bsize
+    cfg = Cfg()
+    for k, t in enumerate(("CB", "UB", "CQ", "UQ", "GX", "RE")):
+        cfg.tag[k] = tag16(t)
+    cfg.filled_bam, cfg.min_phred, cfg.has_read_type, cfg.n_refs = 1, 0, 1, len(refs)
+    cfg.intronic_len, cfg.intergenic_len = 1, 1
+    cfg.intronic[0], cfg.intergenic[0] = ord("N"), ord("I")
+    dec = C.c_void_p()
+    assert L.dropest_bam_decoder_create(0, C.byref(cfg), C.byref(dec)) == 0, L.dropest_bgzf_last_error()
+    comp = np.frombuffer(blob[c0:], np.uint8)
+    INFLATE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p)
+    L.dropest_bam_decoder_window.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, P(Window)]
+    ok_idx = [i for i, w in enumerate(want) if w[0] == 0]
+
+    def window():
+        w = Window()
+        assert L.dropest_bam_decoder_window(dec, comp.ctypes.data, len(comp), u0, 1, None, None, C.byref(w)) == 0, L.dropest_bgzf_last_error()
+        return w
+    # 1. empty dictionaries: every accepted record brings something new
+    w = window()
+    assert w.n_records == len(recs) and w.tail_bytes == 0 and w.refused_blocks == 0
+    assert list(w.counts) == [sum(1 for x in want if x[0] == s) for s in range(5)]
+    assert w.n_accepted == len(ok_idx) == w.n_need and w.any_gene == 1 and w.quality_seen == 0
+    need_rec = np.ctypeslib.as_array(w.need_rec, (w.n_need,)).copy(); need_pos = np.ctypeslib.as_array(w.need_pos, (w.n_need,)).copy()
+    need_size = np.ctypeslib.as_array(w.need_size, (w.n_need,)).copy()
+    assert need_rec.tolist() == ok_idx and need_pos.tolist() == list(range(len(ok_idx))) and need_size.tolist() == [len(recs[i]) for i in ok_idx]
+    buf = np.zeros(int(need_size.sum()) + 16, np.uint8); off = np.zeros(len(ok_idx), np.uint64)
+    L.dropest_bam_decoder_fetch_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+    assert L.dropest_bam_decoder_fetch_records(dec, need_rec.ctypes.data, len(need_rec), buf.ctypes.data, len(buf), off.ctypes.data) == 0
+    assert buf[: int(need_size.sum())].tobytes() == b"".join(recs[i] for i in ok_idx)
+    cbc = device_array(w.d_cb, w.n_accepted, np.uint64)
+    assert cbc.tolist() == [capi.pack_seq(want[i][1]) for i in ok_idx]
+    # 2. the dictionaries given: only the UMIs with N are left to the caller; gene and chromosome indices come from the tables
+    gene_id = {g: 100 + k for k, g in enumerate(genes)}
+    hashes = np.array([fnv1a(g) for g in genes], np.uint64); ids = np.array([gene_id[g] for g in genes], np.uint32)
+    chr_of_ref = np.array([7, 5, 3, 1], np.int32)
+    L.dropest_bam_decoder_set_dictionaries.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    assert L.dropest_bam_decoder_set_dictionaries(dec, hashes.ctypes.data, ids.ctypes.data, len(genes), chr_of_ref.ctypes.data, len(refs)) == 0
+    L.dropest_bam_decoder_reset.argtypes = [C.c_void_p, C.c_void_p]
+    w = window()
+    with_n = [k for k, i in enumerate(ok_idx) if "N" in want[i][2] and want[i][3]]
+    assert np.ctypeslib.as_array(w.need_pos, (w.n_need,)).tolist() == with_n and len(with_n) > 5
+    umi = device_array(w.d_umi, w.n_accepted, np.uint64); gene = device_array(w.d_gene, w.n_accepted, np.uint32); aux = device_array(w.d_aux, w.n_accepted, np.uint32)
+    for k, i in enumerate(ok_idx):
+        st, cb, u, g, mark, ref = want[i]
+        assert gene[k] == (gene_id[g] if g else 0xFFFFFFFF)
+        assert umi[k] == ((capi.pack_seq(u) or 0) if g else 1)
+        touches = g is None or (mark & 6)
+        assert aux[k] == (mark << 16) | (int(chr_of_ref[ref]) if touches else 0), (k, i, aux[k], mark, ref)
+    # 3. patch: the caller's values for the rows it resolved
+    pos = np.array(with_n, np.uint32)
+    pc, pu = np.full(len(pos), 11, np.uint64), np.full(len(pos), 22, np.uint64); pg, pa = np.full(len(pos), 33, np.uint32), np.full(len(pos), 44, np.uint32)
+    L.dropest_bam_decoder_patch.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_uint32]
+    assert L.dropest_bam_decoder_patch(dec, pos.ctypes.data, pc.ctypes.data, pu.ctypes.data, pg.ctypes.data, pa.ctypes.data, len(pos)) == 0
+    umi2 = device_array(w.d_umi, w.n_accepted, np.uint64); aux2 = device_array(w.d_aux, w.n_accepted, np.uint32)
+    assert (umi2[pos] == 22).all() and (aux2[pos] == 44).all() and (np.delete(umi2, pos) == np.delete(umi, pos)).all()
+    # a reset decoder starts over: empty dictionaries again
+    assert L.dropest_bam_decoder_reset(dec, C.byref(cfg)) == 0
+    w = window()
+    assert w.n_need == len(ok_idx)
+    L.dropest_bam_decoder_destroy.argtypes = [C.c_void_p]
+    L.dropest_bam_decoder_destroy(dec)
