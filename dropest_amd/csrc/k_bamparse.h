@@ -35,8 +35,9 @@ struct BamParseCfg {
 	uint8_t intronic[24], intergenic[24];
 };
 
-__device__ inline uint32_t b_le16(const uint8_t *p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8); }
-__device__ inline uint32_t b_le32(const uint8_t *p) { return b_le16(p) | (b_le16(p + 2) << 16); }
+// (global memory takes a word at any address on this target: one load instead of four byte loads and their shifts; little-endian like BAM)
+__device__ inline uint32_t b_le16(const uint8_t *p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+__device__ inline uint32_t b_le32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
 // Does a record that makes sense start at offset o?  (block_size, refID, pos, l_read_name, n_cigar_op, l_seq, next_refID, next_pos, the
 // NUL that ends the name.)  bs = its block_size.
