@@ -463,7 +463,7 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			const BamDict dict{d->g_keys.p, d->g_vals.p, d->g_mask, d->d_chr.p, d->annotation ? d->d_ann_chr.p : nullptr, d->annotation ? d->d_ann_id.p : nullptr};
 			const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, d->nd_rec.p, d->nd_pos.p, d->nd_size.p};
 			if (d->annotation) HIP_CHECK(hipMemsetAsync(d->a_chr.p, 0xFF, size_t(n_rec) * 4, st));   // (records that are not accepted: "no such chromosome", ignored)
-			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + 255) / 256)), dim3(256), 0, st, F.d_out.p, d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro);
+			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + BAM_PARSE_T - 1) / BAM_PARSE_T)), dim3(BAM_PARSE_T), 0, st, F.d_out.p, d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro);
 			if (d->annotation) {
 				if (dropest_annotation_query_device(d->annotation, st, n_rec, d->a_chr.p, d->a_pos.p, d->a_end.p, d->a_gene.p, d->a_mark.p)) throw DeviceError(dropest_annotation_last_error());
 				hipLaunchKernelGGL(bam_resolve_annotated_kernel, dim3(uint32_t((n_rec + 255) / 256)), dim3(256), 0, st, uint32_t(n_rec), dict, ro, d->a_gene.p, d->a_mark.p);

@@ -156,11 +156,34 @@ __device__ inline bool bam_equal(const uint8_t *a, uint32_t n, const uint8_t *b,
 }
 
 // One lane per record (host/bam_ingest.cpp: parse_one, the branches that need no dictionary).
-__global__ __launch_bounds__(256) void bam_parse_kernel(const uint8_t *__restrict__ d, const uint64_t *__restrict__ rec_off, uint32_t n_rec, BamParseCfg cfg,
-                                                        BamDict dict, BamRecordOut out) {
-	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-	if (i >= n_rec) return;
-	const uint8_t *at = d + rec_off[i];
+// The 64 records of a wave follow one another in the stream (~17 KB of a 10x BAM): the wave copies them into LDS with coalesced 16-byte loads
+// and every lane walks ITS record there -- the walk is ~150 loads of single bytes per record, and from memory each of them is 64 transactions
+// per wave (the records lie 270 bytes apart), which is what bounded the kernel.  Records that do not fit the wave's 20 KB are walked in memory.
+constexpr uint32_t BAM_PARSE_T = 128, BAM_PARSE_STAGE = 20480;
+__global__ __launch_bounds__(BAM_PARSE_T) void bam_parse_kernel(const uint8_t *__restrict__ d, const uint64_t *__restrict__ rec_off, uint32_t n_rec, BamParseCfg cfg,
+                                                                BamDict dict, BamRecordOut out) {
+	__shared__ __attribute__((aligned(16))) uint8_t stage[BAM_PARSE_T / 64][BAM_PARSE_STAGE];
+	const uint32_t i = blockIdx.x * BAM_PARSE_T + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const bool valid = i < n_rec;
+	const uint64_t my_off = valid ? rec_off[i] : 0ull;
+	const uint64_t my_end = valid ? my_off + 4ull + b_le32(d + my_off) : 0ull;
+	const uint64_t m = __ballot(valid);
+	if (!m) return;
+	const int last = 63 - __clzll((long long)m);
+	const uint64_t r_begin = (uint64_t(uint32_t(__shfl(int(uint32_t(my_off)), 0))) | (uint64_t(uint32_t(__shfl(int(uint32_t(my_off >> 32)), 0))) << 32));
+	const uint64_t r_end = (uint64_t(uint32_t(__shfl(int(uint32_t(my_end)), last))) | (uint64_t(uint32_t(__shfl(int(uint32_t(my_end >> 32)), last))) << 32));
+	const uint8_t *at = d + my_off;
+	if (r_end > r_begin && r_end - r_begin <= BAM_PARSE_STAGE) {
+		const uint32_t bytes = uint32_t(r_end - r_begin);
+		for (uint32_t o = lane * 16u; o < bytes; o += 64u * 16u) {          // (the last slice may read up to 15 bytes past the records: the window's buffer has that room)
+			uint4 v;
+			__builtin_memcpy(&v, d + r_begin + o, 16);
+			*reinterpret_cast<uint4 *>(&stage[wave][o]) = v;
+		}
+		at = &stage[wave][uint32_t(my_off - r_begin)];
+	}
+	if (!valid) return;
 	const uint32_t block_size = b_le32(at);
 	const uint8_t *p = at + 4;
 	const int32_t ref_id = int32_t(b_le32(p));
