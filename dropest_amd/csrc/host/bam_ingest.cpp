@@ -790,14 +790,22 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 		// then takes one call per worker, in worker order = file order -- no second pass that closes the gaps (it was 170 ms of a 930 ms ingest)
 		std::vector<uint64_t> o_cb, o_umi;
 		std::vector<uint32_t> o_gene, o_aux;
-		struct Tally { size_t total = 0, cant = 0, low = 0, ok = 0; bool quality = false; char pad[64]; };
+		// UMI quality strings (UQ tags): while every gene-bearing read brings one of the same length, the window still goes in bulk -- every worker
+		// keeps where the strings of its records are and, once the length is known for the whole window, copies them into one row per read
+		// (CellsDataContainer::add_records_packed with rows); reads of different lengths, or a length other than the container's so far, leave the
+		// window to the record-by-record path (UMI::add_read's length check, UMI.cpp:26-28, is per molecule there)
+		constexpr uint32_t NO_QL = 0xFFFFFFFFu;
+		struct Tally { size_t total = 0, cant = 0, low = 0, ok = 0; uint32_t ql = NO_QL; bool mixed = false; char pad[64]; };
 		std::vector<Tally> tally(NT);
 		std::vector<CellsDataContainer::PackedRun> runs;
+		std::vector<const char *> o_qp;
+		std::vector<uint8_t> o_qual;
+		std::vector<const uint8_t *> q_rows;
 		double fw_ms[3] = {0, 0, 0};   // DROPEST_BAM_TRACE: parse + pack on the workers, new dictionary entries on this thread, container
 		auto fast_window = [&](size_t n) -> bool {
 			auto t_phase = clk::now();
 			auto phase = [&](int k) { fw_ms[k] += since(t_phase); t_phase = clk::now(); };
-			if (o_cb.size() < n) { o_cb.resize(n); o_umi.resize(n); o_gene.resize(n); o_aux.resize(n); }   // (never shrunk: no refill per window)
+			if (o_cb.size() < n) { o_cb.resize(n); o_umi.resize(n); o_gene.resize(n); o_aux.resize(n); o_qp.resize(n); }   // (never shrunk: no refill per window)
 			workers.run([&](unsigned t) {
 				Parsed tmp;
 				std::vector<Need> &mine = needs[t];
@@ -815,8 +823,9 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					}
 					++tl.total; ++tl.ok;
 					const CellsDataContainer::ParsedRead &r = tmp.r;
-					if (r.umi_quality_length) tl.quality = true;
 					const bool has_gene = !r.gene.empty();
+					o_qp[at] = has_gene ? r.umi_quality.data() : nullptr;
+					if (has_gene) { if (tl.ql == NO_QL) tl.ql = r.umi_quality_length; else if (tl.ql != r.umi_quality_length) tl.mixed = true; }
 					uint8_t what = 0;
 					o_cb[at] = r.cb_code; if (!r.cb_code) what |= NEED_CB;
 					if (has_gene) {
@@ -836,7 +845,14 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				tally[t] = tl;
 			});
 			phase(0);
-			for (unsigned t = 0; t < NT; ++t) if (tally[t].quality) return false;   // UMI quality strings: the record-by-record path keeps them
+			uint32_t ql = NO_QL;
+			for (unsigned t = 0; t < NT; ++t) {
+				if (tally[t].mixed) return false;
+				if (tally[t].ql == NO_QL) continue;
+				if (ql == NO_QL) ql = tally[t].ql; else if (ql != tally[t].ql) return false;
+			}
+			const bool with_quality = ql != NO_QL && ql > 0;
+			if (with_quality ? !container.bulk_ingest_possible_with_quality(ql) : !container.bulk_ingest_possible()) return false;
 			// in file order: what the dictionaries have not seen (per record: barcode, then UMI, gene, chromosome -- the order of add_record)
 			for (unsigned t = 0; t < NT; ++t)
 				for (const Need &nd : needs[t]) {
@@ -851,7 +867,19 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				const size_t b0 = n * t / NT;
 				if (tally[t].ok) runs.push_back(CellsDataContainer::PackedRun{o_cb.data() + b0, o_umi.data() + b0, o_gene.data() + b0, o_aux.data() + b0, tally[t].ok});
 			}
-			container.add_records_packed(runs);
+			if (with_quality) {    // one row of ql bytes per accepted read, beside the columns (zeros for reads without a gene)
+				if (o_qual.size() < n * size_t(ql)) o_qual.resize(n * size_t(ql));
+				workers.run([&](unsigned t) {
+					const size_t b0 = n * t / NT;
+					for (size_t k = 0; k < tally[t].ok; ++k) {
+						uint8_t *row = o_qual.data() + (b0 + k) * size_t(ql);
+						if (o_qp[b0 + k]) std::memcpy(row, o_qp[b0 + k], ql); else std::memset(row, 0, ql);
+					}
+				});
+				q_rows.clear();
+				for (unsigned t = 0; t < NT; ++t) if (tally[t].ok) q_rows.push_back(o_qual.data() + (n * t / NT) * size_t(ql));
+				container.add_records_packed(runs, q_rows, ql);
+			} else container.add_records_packed(runs);
 			phase(2);
 			for (unsigned t = 0; t < NT; ++t) {
 				_counters.total_reads += tally[t].total; _counters.cant_parse += tally[t].cant; _counters.low_quality += tally[t].low; _counters.saved += tally[t].ok;
@@ -867,7 +895,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 		// Every block's CRC-32 is checked on the device (the wave that inflated it reads it back).  Falls back to the host reader (returns false before anything was added) when
 		// the configuration needs what the kernels do not do: -r parameter files, gene = chromosome name, sharded containers.
 		auto device_file = [&]() -> bool {
-			if (_params_from_files || _gene_in_chromosome_name || !container.bulk_ingest_possible()) return false;
+			if (_params_from_files || _gene_in_chromosome_name || !container.bulk_ingest_possible_at_all()) return false;
 			const auto t_enter = clk::now();
 			double ms_header = 0, ms_create = 0;
 			if (_tags.intronic_read_value.size() > 24 || _tags.intergenic_read_value.size() > 24) return false;
@@ -1057,13 +1085,24 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				const size_t n = size_t(w.n_records);
 				if (!n) { if (final) break; continue; }
 				t_phase = clk::now();
-				if (w.quality_seen) {
-					// UMI quality strings: every record of this window goes through the record-by-record path (the container keeps the strings)
+				if (w.quality_seen || !container.bulk_ingest_possible()) {
+					// UMI quality strings (the container keeps them on the host): the records of this window come back as bytes and take the host
+					// reader's bulk path over them (fast_window: one quality row per read while the strings have one length), or, where that
+					// refuses, go record by record
 					idx_all.resize(n); need_off.resize(n);
 					for (size_t i = 0; i < n; ++i) idx_all[i] = uint32_t(i);
 					need_bytes.resize(size_t(w.window_bytes) + 16);
 					if (dropest_bam_decoder_fetch_records(dec, idx_all.data(), uint32_t(n), need_bytes.data(), need_bytes.size(), need_off.data()))
 						throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					data = need_bytes.data();
+					offsets.resize(n);
+					for (size_t i = 0; i < n; ++i) offsets[i] = uint32_t(need_off[i]);
+					if (w.window_bytes < (uint64_t(1) << 32) && !getenv("DROPEST_BAM_RECORD_BY_RECORD") && container.bulk_ingest_possible_at_all() && fast_window(n)) {
+						dict_dirty = true;
+						host_ms[1] += since(t_phase);
+						if (final) break;
+						continue;
+					}
 					Parsed tmp;
 					for (size_t i = 0; i < n; ++i) {
 						parse_one(need_bytes.data() + need_off[i], tmp);
@@ -1148,7 +1187,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				container.expect_reads(size_t(double(offsets.size()) * reader.file_over_first_batch() * double(bam_files.size()) * 1.05));
 			}
 			first_window = false;
-			if (!_params_from_files && !force_slow && NT <= 256 && container.bulk_ingest_possible()) {
+			if (!_params_from_files && !force_slow && NT <= 256 && container.bulk_ingest_possible_at_all()) {
 				auto t_fast = clk::now();
 				const bool done = fast_window(offsets.size());
 				_counters.parse_ms += since(t_fast);

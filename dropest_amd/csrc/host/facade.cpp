@@ -304,6 +304,33 @@ void CellsDataContainer::add_records_packed(const std::vector<PackedRun> &runs) 
 	check(dropest_push_reads_gather(_ctx, runs.size(), pc.data(), pu.data(), pg.data(), pa.data(), cnt.data()));
 }
 
+void CellsDataContainer::add_records_packed(const std::vector<PackedRun> &runs, const std::vector<const uint8_t *> &quality, size_t ql) {
+	if (_is_initialized) throw std::runtime_error("Container is already initialized");
+	if (!bulk_ingest_possible_with_quality(ql) || quality.size() != runs.size())
+		throw std::runtime_error("add_records_packed: UMI quality strings of this length cannot be taken in bulk here (use add_record)");
+	size_t n = 0;
+	for (const PackedRun &r : runs) n += r.n;
+	if (!n) return;
+	_preview_valid = false; ++_generation;
+	flush();                                   // whatever add_record collected comes first
+	if (_umi_quality_length == size_t(-1)) {   // the first gene-bearing read fixes the length (append_quality): the gene-less reads before it get their rows now
+		bool any_gene = false;
+		for (const PackedRun &r : runs) { for (size_t i = 0; i < r.n && !any_gene; ++i) any_gene = r.gene[i] != DROPEST_NO_GENE; if (any_gene) break; }
+		if (any_gene) {
+			_umi_quality_length = ql;
+			_qual.insert(_qual.end(), _qual_pending * ql, uint8_t(0));
+			_qual_pending = 0;
+		}
+	}
+	if (_umi_quality_length == size_t(-1)) _qual_pending += n;
+	else for (size_t k = 0; k < runs.size(); ++k) _qual.insert(_qual.end(), quality[k], quality[k] + runs[k].n * ql);
+	_qual_reads += n;
+	send_side_strings(_ctx);
+	std::vector<const uint64_t *> pc, pu; std::vector<const uint32_t *> pg, pa; std::vector<uint64_t> cnt;
+	for (const PackedRun &r : runs) { pc.push_back(r.cb); pu.push_back(r.umi); pg.push_back(r.gene); pa.push_back(r.aux); cnt.push_back(r.n); }
+	check(dropest_push_reads_gather(_ctx, runs.size(), pc.data(), pu.data(), pg.data(), pa.data(), cnt.data()));
+}
+
 void CellsDataContainer::add_records_packed(const uint64_t *cb, const uint64_t *umi, const uint32_t *gene, const uint32_t *aux, size_t n) {
 	if (_is_initialized) throw std::runtime_error("Container is already initialized");
 	if (!bulk_ingest_possible()) throw std::runtime_error("add_records_packed: the container is sharded or carries UMI qualities (use add_record)");

@@ -429,6 +429,14 @@ public:
 	// ... several such runs that follow one another in the stream, handed over in one piece (dropest_push_reads_gather)
 	struct PackedRun { const uint64_t *cb, *umi; const uint32_t *gene, *aux; size_t n; };
 	void add_records_packed(const std::vector<PackedRun> &runs);
+	// The same for reads with UMI quality strings of ONE length: quality[k] = counts-of-run-k rows of `ql` bytes (the row of a read without a gene is
+	// not looked at).  Allowed while every gene-bearing read so far had that length (bulk_ingest_possible_with_quality): what UMI::add_read's length
+	// check (UMI.cpp:26-28) needs beyond that goes through add_record.
+	bool bulk_ingest_possible_with_quality(size_t ql) const {
+		return !sharded() && !_is_initialized && !_mol_qlen_tracking && _qual_lens.empty() && ql > 0 && ql <= 255 && (_umi_quality_length == size_t(-1) || _umi_quality_length == ql);
+	}
+	void add_records_packed(const std::vector<PackedRun> &runs, const std::vector<const uint8_t *> &quality, size_t ql);
+	bool bulk_ingest_possible_at_all() const { return !sharded() && !_is_initialized && !_mol_qlen_tracking && _qual_lens.empty(); }   // (with or without quality rows: the window decides)
 	static bool pack_code(std::string_view s, uint64_t &code);
 	static uint64_t hash_name(std::string_view s);
 	void set_initialized();

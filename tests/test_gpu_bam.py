@@ -455,3 +455,48 @@ def test_device_path_read_names_long_records_and_strings_with_n(tmp_path):
         return seen
     a, b = molecules(host_q[3]), molecules(dev_q[3])
     assert len(a) > 1000 and a == b
+
+
+def test_quality_strings_in_bulk_and_where_bulk_must_not_be_taken(tmp_path):
+    """UQ tags of one length go through the bulk paths (one quality row per read beside the packed columns: host reader and device path); a file
+    whose later reads have no UQ tag, or one of another length, leaves those windows to the record-by-record path -- three readers, one answer:
+    the container of DROPEST_BAM_RECORD_BY_RECORD=1, matrices and the per-molecule quality means of reads_per_umi_per_cell."""
+    rng = np.random.default_rng(17)
+    reads = _reads(24_000, seed_cells=16)
+    refs = [("chr%d" % i, 1_000_000) for i in range(25)]
+    recs = []
+    for i, (cb, umi, g, chr_, mark) in enumerate(reads):
+        third = i * 3 // len(reads)
+        cb = ("AAAA", "CCCC", "GGGG")[third] + cb[4:]      # every third has cells of its own: its molecules are new ones (no length to clash with)
+        tags = [("CB", "Z", cb), ("UB", "Z", umi)] + ([("GX", "Z", g)] if g else [])
+        if third == 0:
+            tags.append(("UQ", "Z", "".join(chr(33 + int(x)) for x in rng.integers(2, 40, len(umi)))))
+        elif third == 2:
+            tags.append(("UQ", "Z", "".join(chr(33 + int(x)) for x in rng.integers(2, 40, len(umi) - 2))))     # shorter strings
+        recs.append(bw.record(int(chr_[3:]), i, "q%d" % i, tags=tags))
+    bam = str(tmp_path / "mixed.bam")
+    bw.write_bam(bam, refs, recs, block=25_000)
+
+    def molecules(d):
+        rp = d["reads_per_umi_per_cell"]
+        cells_l, genes_l = rp["cells"].value, rp["genes"].value
+        seen = {}
+        for ci, gi, per_gene in zip(rp["cell_indexes"].value, rp["gene_indexes"].value, rp["reads_per_umi"].value):
+            for name, entry in zip(per_gene.names, per_gene.value):
+                seen[(cells_l[int(ci)], genes_l[int(gi)], name)] = (int(entry.value[0].value[0]), [float(x) for x in entry.value[1].value])
+        return seen
+    runs = {}
+    for name, env in (("one_by_one", {"DROPEST_BAM_RECORD_BY_RECORD": "1"}), ("bulk", {}), ("device", {"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_DEVICE_WINDOW_MB": "1"})):
+        got, cells, stats, d = _run(tmp_path / name, "filled", [bam], 2, 3, threads=4, env=dict(env, DROPEST_RPUPC="1"))
+        runs[name] = (got, cells, {k: stats[k] for k in ("total_reads", "cant_parse", "low_quality", "saved")}, molecules(d))
+    assert runs["bulk"] == runs["one_by_one"] and runs["device"] == runs["one_by_one"]
+    m = runs["bulk"][3]
+    assert len(m) > 3000 and sum(1 for v in m.values() if len(v[1]) == 8) > 500 and sum(1 for v in m.values() if len(v[1]) == 6) > 500 and sum(1 for v in m.values() if not v[1]) > 500
+    # ... and a read without a quality string that meets a molecule created with one is UMI::add_read's exception (UMI.cpp:26-28) from all three
+    clash = list(recs[:8000]) + [bw.record(int(c[3:]), 8000 + i, "x%d" % i, tags=[("CB", "Z", "AAAA" + cb[4:]), ("UB", "Z", umi)] + ([("GX", "Z", g)] if g else []))
+                                for i, (cb, umi, g, c, m) in enumerate(reads[:8000])]
+    bam2 = str(tmp_path / "clash.bam")
+    bw.write_bam(bam2, refs, clash, block=25_000)
+    for env in ({"DROPEST_BAM_RECORD_BY_RECORD": "1"}, {}, {"DROPEST_BAM_DEVICE": "1"}):
+        res = subprocess.run([TOOL, str(tmp_path / "clash_out"), "filled", "2", "3", "-", "4", bam2], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert res.returncode == 1 and "Wrong quality length: 0, expected: 8" in res.stderr, (env, res.stderr)
