@@ -157,7 +157,9 @@ struct dropest_bam_decoder {
 	DevBuf<uint8_t> d_tail, d_gather;
 	DevBuf<uint64_t> rec_off, d_goff;
 	DevBuf<uint32_t> d_gidx, d_gsize;
-	DevBuf<unsigned long long> o_cb, o_umi, dn_cb, dn_umi, p_cb, p_umi, g_keys;
+	DevBuf<unsigned long long> o_cb, o_umi, dn_cb, dn_umi, p_cb, p_umi, g_keys, o_qoff, dn_qoff;
+	DevBuf<uint8_t> dn_qual;
+	PinnedBuf<uint8_t> h_qual;
 	DevBuf<uint32_t> o_gene, o_aux, dn_gene, dn_aux, tile_ok, tile_need, d_totals, nd_rec, nd_pos, nd_size, p_pos, p_gene, p_aux, g_vals;
 	DevBuf<int32_t> d_chr, d_ann_chr, d_ann_id, a_chr, a_mark;
 	DevBuf<uint32_t> a_pos, a_end, a_gene;
@@ -453,15 +455,16 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			HIP_CHECK(hipMemcpyAsync(F.seg_base.p, F.base.data(), size_t(n_segs) * 4, hipMemcpyHostToDevice, st));
 			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, F.d_out.p, data_len, (const uint32_t *)nullptr, n_segs, F.seg_start.p,
 			                   F.seg_count.p, F.seg_exit.p, F.seg_base.p, d->rec_off.p, F.d_bad.p);
+			d->o_qoff.ensure(rc); d->dn_qoff.ensure(rc);
 			d->o_cb.ensure(rc); d->o_umi.ensure(rc); d->o_gene.ensure(rc); d->o_aux.ensure(rc); d->o_uql.ensure(rc); d->o_status.ensure(rc); d->o_need.ensure(rc);
 			d->dn_cb.ensure(rc); d->dn_umi.ensure(rc); d->dn_gene.ensure(rc); d->dn_aux.ensure(rc); d->nd_rec.ensure(rc); d->nd_pos.ensure(rc); d->nd_size.ensure(rc);
 			const uint32_t tiles = uint32_t((n_rec + BAM_FIN_TILE - 1) / BAM_FIN_TILE);
 			d->tile_ok.ensure(tiles + tiles / 4 + 1); d->tile_need.ensure(tiles + tiles / 4 + 1); d->d_totals.ensure(2); d->d_wc.ensure(1);
 			HIP_CHECK(hipMemsetAsync(d->d_wc.p, 0, sizeof(BamWindowCounts), st));
 			if (d->annotation) { d->a_chr.ensure(rc); d->a_pos.ensure(rc); d->a_end.ensure(rc); d->a_gene.ensure(rc); d->a_mark.ensure(rc); }
-			const BamRecordOut ro{d->o_cb.p, d->o_umi.p, d->o_gene.p, d->o_aux.p, d->o_uql.p, d->o_status.p, d->o_need.p, d->a_chr.p, d->a_pos.p, d->a_end.p};
+			const BamRecordOut ro{d->o_cb.p, d->o_umi.p, d->o_gene.p, d->o_aux.p, d->o_uql.p, d->o_qoff.p, d->o_status.p, d->o_need.p, d->a_chr.p, d->a_pos.p, d->a_end.p};
 			const BamDict dict{d->g_keys.p, d->g_vals.p, d->g_mask, d->d_chr.p, d->annotation ? d->d_ann_chr.p : nullptr, d->annotation ? d->d_ann_id.p : nullptr};
-			const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, d->nd_rec.p, d->nd_pos.p, d->nd_size.p};
+			const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, d->nd_rec.p, d->nd_pos.p, d->nd_size.p, d->dn_qoff.p};
 			if (d->annotation) HIP_CHECK(hipMemsetAsync(d->a_chr.p, 0xFF, size_t(n_rec) * 4, st));   // (records that are not accepted: "no such chromosome", ignored)
 			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + BAM_PARSE_T - 1) / BAM_PARSE_T)), dim3(BAM_PARSE_T), 0, st, F.d_out.p, d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro);
 			if (d->annotation) {
@@ -495,6 +498,7 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 		out->d_cb = reinterpret_cast<const uint64_t *>(d->dn_cb.p); out->d_umi = reinterpret_cast<const uint64_t *>(d->dn_umi.p); out->d_gene = d->dn_gene.p; out->d_aux = d->dn_aux.p;
 		out->n_need = n_need; out->need_rec = d->h_need_rec.p; out->need_pos = d->h_need_pos.p; out->need_size = d->h_need_size.p;
 		out->quality_seen = wc.quality; out->any_gene = wc.any_gene;
+		out->quality_len_max = wc.any_gene ? wc.ql_max : 0u; out->quality_len_min = wc.any_gene ? 0xFFFFFFFFu - wc.ql_min_inv : 0u;
 	});
 }
 
@@ -534,6 +538,22 @@ extern "C" int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const u
 	});
 }
 
+extern "C" int dropest_bam_decoder_quality_rows(dropest_bam_decoder *d, uint32_t ql, const uint8_t **rows) {
+	return bgzf_guarded([&] {
+		if (!d || !rows || !ql || ql > 255) throw InvalidError("bad argument");
+		*rows = nullptr;
+		const uint64_t n = d->last_n_ok;
+		if (!n) return;
+		HIP_CHECK(hipSetDevice(d->device));
+		d->dn_qual.ensure(n * ql + n * ql / 4); d->h_qual.ensure(n * ql);
+		hipLaunchKernelGGL(bam_quality_rows_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, d->stream, d->front[d->last_front].d_out.p, d->dn_qoff.p, uint32_t(n), ql, d->dn_qual.p);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(hipMemcpyAsync(d->h_qual.p, d->dn_qual.p, n * ql, hipMemcpyDeviceToHost, d->stream));
+		HIP_CHECK(hipStreamSynchronize(d->stream));
+		*rows = d->h_qual.p;
+	});
+}
+
 extern "C" int dropest_bam_decoder_patch(dropest_bam_decoder *d, const uint32_t *pos, const uint64_t *cb, const uint64_t *umi, const uint32_t *gene,
                                          const uint32_t *aux, uint32_t n) {
 	return bgzf_guarded([&] {
@@ -547,7 +567,7 @@ extern "C" int dropest_bam_decoder_patch(dropest_bam_decoder *d, const uint32_t 
 		HIP_CHECK(hipMemcpyAsync(d->p_umi.p, umi, size_t(n) * 8, hipMemcpyHostToDevice, d->stream));
 		HIP_CHECK(hipMemcpyAsync(d->p_gene.p, gene, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
 		HIP_CHECK(hipMemcpyAsync(d->p_aux.p, aux, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
-		const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, nullptr, nullptr, nullptr};
+		const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, nullptr, nullptr, nullptr, nullptr};
 		hipLaunchKernelGGL(bam_patch_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, d->p_pos.p, d->p_cb.p, d->p_umi.p, d->p_gene.p, d->p_aux.p, n, dn);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipStreamSynchronize(d->stream));

@@ -1085,7 +1085,12 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				const size_t n = size_t(w.n_records);
 				if (!n) { if (final) break; continue; }
 				t_phase = clk::now();
-				if (w.quality_seen || !container.bulk_ingest_possible()) {
+				// UMI quality strings: one length over the gene-bearing reads of the window (and the container's so far) -> the device hands over one row
+				// per accepted read beside the columns; anything else -> the window's records come back as bytes (below)
+				const bool has_q = w.any_gene && w.quality_len_max > 0;
+				const uint32_t q_len = w.quality_len_max;
+				const bool q_bulk = has_q && w.quality_len_min == w.quality_len_max && container.bulk_ingest_possible_with_quality(q_len);
+				if (has_q ? !q_bulk : !container.bulk_ingest_possible()) {
 					// UMI quality strings (the container keeps them on the host): the records of this window come back as bytes and take the host
 					// reader's bulk path over them (fast_window: one quality row per read while the strings have one length), or, where that
 					// refuses, go record by record
@@ -1152,7 +1157,12 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				host_ms[1] += since(t_phase); t_phase = clk::now();
 				bool any_gene = w.any_gene != 0;
 				for (size_t k = 0; k < size_t(w.n_need) && !any_gene; ++k) any_gene = p_gene[k] != DROPEST_NO_GENE;
-				container.add_records_packed_device(w.d_cb, w.d_umi, w.d_gene, w.d_aux, size_t(w.n_accepted), any_gene);
+				if (q_bulk) {
+					const uint8_t *rows = nullptr;
+					if (dropest_bam_decoder_quality_rows(dec, q_len, &rows)) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					container.add_records_packed_device(w.d_cb, w.d_umi, w.d_gene, w.d_aux, size_t(w.n_accepted), any_gene, rows, q_len);
+				} else
+					container.add_records_packed_device(w.d_cb, w.d_umi, w.d_gene, w.d_aux, size_t(w.n_accepted), any_gene);
 				host_ms[2] += since(t_phase);
 				_counters.cant_parse += size_t(w.counts[DROPEST_BAM_CANT_PARSE_NO_COUNT] + w.counts[DROPEST_BAM_CANT_PARSE]);
 				_counters.low_quality += size_t(w.counts[DROPEST_BAM_LOW_QUALITY]);

@@ -363,6 +363,25 @@ void CellsDataContainer::add_records_packed_device(const uint64_t *d_cb, const u
 	check(dropest_push_reads_device(_ctx, d_cb, d_umi, d_gene, d_aux, n, 0));
 }
 
+void CellsDataContainer::add_records_packed_device(const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene, const uint32_t *d_aux, size_t n, bool any_gene,
+                                                   const uint8_t *quality_rows, size_t ql) {
+	if (_is_initialized) throw std::runtime_error("Container is already initialized");
+	if (!bulk_ingest_possible_with_quality(ql) || !quality_rows) throw std::runtime_error("add_records_packed: UMI quality strings of this length cannot be taken in bulk here (use add_record)");
+	_preview_valid = false; ++_generation;
+	if (!n) return;
+	flush();
+	if (_umi_quality_length == size_t(-1) && any_gene) {   // the first gene-bearing read fixes the length: the gene-less reads before it get their rows now
+		_umi_quality_length = ql;
+		_qual.insert(_qual.end(), _qual_pending * ql, uint8_t(0));
+		_qual_pending = 0;
+	}
+	if (_umi_quality_length == size_t(-1)) _qual_pending += n;
+	else _qual.insert(_qual.end(), quality_rows, quality_rows + n * ql);
+	_qual_reads += n;
+	send_side_strings(_ctx);
+	check(dropest_push_reads_device(_ctx, d_cb, d_umi, d_gene, d_aux, n, 0));
+}
+
 void CellsDataContainer::set_reference_names(const std::vector<std::string> &names) {
 	_ref_names = names;
 	_ref_chr.assign(names.size(), -1);

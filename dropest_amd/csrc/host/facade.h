@@ -412,6 +412,8 @@ public:
 	}
 	// add_records_packed for columns that already live in the container's GPU memory (include/dropest_bgzf.h); any_gene: some read carries a gene
 	void add_records_packed_device(const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene, const uint32_t *d_aux, size_t n, bool any_gene);
+	// ... with one row of ql quality bytes per read in HOST memory (bulk_ingest_possible_with_quality(ql); every gene-bearing read's string is ql long)
+	void add_records_packed_device(const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene, const uint32_t *d_aux, size_t n, bool any_gene, const uint8_t *quality_rows, size_t ql);
 	// ---- bulk ingest (the BAM reader's fast path) ----------------------------------------------------------------------
 	// add_record read by read costs a handful of vector appends and dictionary look-ups per read on ONE thread; a caller that
 	// parses records on many threads resolves the dictionaries itself -- the few reads per window that bring something new

@@ -119,6 +119,7 @@ struct BamRecordOut {
 	unsigned long long *cb, *umi;
 	uint32_t *gene, *aux;
 	uint16_t *umiq_len;
+	unsigned long long *qoff;     // where the record's UMI quality string stands in the window (~0: it has none)
 	uint8_t *status, *need;
 	// -g (genes from a GTF / BED annotation, ReadParamsParser::get_gene_from_reference :92-151): the record's chromosome in the annotation's
 	// numbering and the two ends of its alignment go to annotate_reads (annotation_api.hip); bam_resolve_annotated finishes the columns
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(BAM_PARSE_T) void bam_parse_kernel(const uint8_t *_
 	const uint8_t *p = at + 4;
 	const int32_t ref_id = int32_t(b_le32(p));
 	const uint32_t l_read_name = p[8], n_cigar = b_le16(p + 12), flag = b_le16(p + 14), l_seq = b_le32(p + 16);
-	out.umiq_len[i] = 0; out.need[i] = 0;
+	out.umiq_len[i] = 0; out.need[i] = 0; out.qoff[i] = ~0ull;
 	const uint64_t aux = 32ull + l_read_name + 4ull * n_cigar + (uint64_t(l_seq) + 1) / 2 + l_seq;
 	if (aux > block_size) { out.status[i] = BAM_CANT_PARSE; return; }       // (the host reader throws "Corrupt BAM record"; the caller checks `bad`)
 	if ((flag & 0x4u) || (flag & 0x100u)) { out.status[i] = BAM_SKIP; return; }                    // BamController.cpp:87-88
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(BAM_PARSE_T) void bam_parse_kernel(const uint8_t *_
 			if (found[T_UMIQ]) for (uint32_t j = 0; j < vlen[T_UMIQ]; ++j) pass &= int32_t(int8_t(val[T_UMIQ][j])) >= int32_t(int8_t(cfg.min_phred));
 		}
 		out.umiq_len[i] = uint16_t(found[T_UMIQ] ? (vlen[T_UMIQ] > 0xFFFFu ? 0xFFFFu : vlen[T_UMIQ]) : 0u);
+		if (found[T_UMIQ]) out.qoff[i] = my_off + uint64_t(val[T_UMIQ] - at);
 	} else {                                                                  // ReadParamsParser.cpp:20-33: "id!CB#UMI"
 		const uint8_t *name = p + 32;
 		const uint32_t nl = l_read_name ? l_read_name - 1 : 0;
@@ -348,34 +350,39 @@ __global__ __launch_bounds__(256) void bam_resolve_annotated_kernel(uint32_t n_r
 
 // ---- the accepted records, dense ------------------------------------------------------------------------------------------------
 constexpr uint32_t BAM_FIN_PER = 16, BAM_FIN_TILE = 256 * BAM_FIN_PER;
-struct BamWindowCounts { uint32_t status[5]; uint32_t quality, any_gene, pad; };
+// ql_max / ql_min_inv: over the accepted gene-bearing reads, the longest UMI quality string and 0xFFFFFFFF - the shortest (both grow from 0)
+struct BamWindowCounts { uint32_t status[5]; uint32_t quality, any_gene, ql_max, ql_min_inv, pad; };
 
 // accepted records and accepted records the host must see, per tile of 4 096 records; the window's counters
 __global__ __launch_bounds__(256) void bam_fin_count_kernel(const uint8_t *__restrict__ status, const uint8_t *__restrict__ need, const uint16_t *__restrict__ uql,
                                                             uint32_t n, uint32_t *__restrict__ tile_ok, uint32_t *__restrict__ tile_need, BamWindowCounts *__restrict__ wc) {
-	__shared__ uint32_t acc[8];
-	if (threadIdx.x < 8) acc[threadIdx.x] = 0;
+	__shared__ uint32_t acc[10];
+	if (threadIdx.x < 10) acc[threadIdx.x] = 0;
 	__syncthreads();
-	uint32_t c[5] = {0, 0, 0, 0, 0}, nn = 0, q = 0, g = 0;
+	uint32_t c[5] = {0, 0, 0, 0, 0}, nn = 0, q = 0, g = 0, qmax = 0, qmin_inv = 0;
 	const uint32_t first = blockIdx.x * BAM_FIN_TILE + threadIdx.x * BAM_FIN_PER;
 	for (uint32_t j = 0; j < BAM_FIN_PER; ++j) {
 		const uint32_t i = first + j;
 		if (i >= n) break;
 		const uint32_t st = status[i];
 		c[st < 5u ? st : 3u]++;
-		if (st == BAM_OK) { nn += need[i] & 1u; g |= (need[i] >> 1) & 1u; q |= uql[i] ? 1u : 0u; }
+		if (st == BAM_OK) {
+			nn += need[i] & 1u; g |= (need[i] >> 1) & 1u; q |= uql[i] ? 1u : 0u;
+			if (need[i] & 2u) { const uint32_t l = uql[i]; qmax = l > qmax ? l : qmax; qmin_inv = (0xFFFFFFFFu - l) > qmin_inv ? (0xFFFFFFFFu - l) : qmin_inv; }
+		}
 	}
 #pragma unroll
 	for (int k = 0; k < 5; ++k) if (c[k]) atomicAdd(&acc[k], c[k]);
 	if (nn) atomicAdd(&acc[5], nn);
 	if (q) atomicOr(&acc[6], 1u);
 	if (g) atomicOr(&acc[7], 1u);
+	if (g) { atomicMax(&acc[8], qmax); atomicMax(&acc[9], qmin_inv); }
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		tile_ok[blockIdx.x] = acc[0]; tile_need[blockIdx.x] = acc[5];
 		for (int k = 0; k < 5; ++k) if (acc[k]) atomicAdd(&wc->status[k], acc[k]);
 		if (acc[6]) atomicOr(&wc->quality, 1u);
-		if (acc[7]) atomicOr(&wc->any_gene, 1u);
+		if (acc[7]) { atomicOr(&wc->any_gene, 1u); atomicMax(&wc->ql_max, acc[8]); atomicMax(&wc->ql_min_inv, acc[9]); }
 	}
 }
 
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(1024) void bam_fin_scan_kernel(uint32_t *__restrict
 	if (threadIdx.x == 0) { totals[0] = carry[0]; totals[1] = carry[1]; }
 }
 
-struct BamDense { unsigned long long *cb, *umi; uint32_t *gene, *aux; uint32_t *need_rec, *need_pos, *need_size; };
+struct BamDense { unsigned long long *cb, *umi; uint32_t *gene, *aux; uint32_t *need_rec, *need_pos, *need_size; unsigned long long *qoff; };
 
 // the accepted records to their dense places (file order), and the list of those the host must see: (record, dense place, bytes)
 __global__ __launch_bounds__(256) void bam_fin_scatter_kernel(const uint8_t *__restrict__ d, const uint64_t *__restrict__ rec_off, BamRecordOut in, uint32_t n,
@@ -431,9 +438,22 @@ __global__ __launch_bounds__(256) void bam_fin_scatter_kernel(const uint8_t *__r
 		if (i >= n) break;
 		if (in.status[i] != BAM_OK) continue;
 		out.cb[at] = in.cb[i]; out.umi[at] = in.umi[i]; out.gene[at] = in.gene[i]; out.aux[at] = in.aux[i];
+		out.qoff[at] = (in.need[i] & 2u) ? in.qoff[i] : ~0ull;       // (the quality string of a read without a gene is not looked at)
 		if (in.need[i] & 1u) { out.need_rec[nat] = i; out.need_pos[nat] = at; out.need_size[nat] = 4u + b_le32(d + rec_off[i]); ++nat; }
 		++at;
 	}
+}
+
+// one row of ql bytes per accepted read: its UMI quality string (zeros for a read without a gene or without a string); the caller has seen that
+// every gene-bearing read's string is ql long
+__global__ __launch_bounds__(256) void bam_quality_rows_kernel(const uint8_t *__restrict__ d, const unsigned long long *__restrict__ qoff, uint32_t n, uint32_t ql,
+                                                               uint8_t *__restrict__ rows) {
+	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= n) return;
+	const unsigned long long o = qoff[k];
+	uint8_t *row = rows + size_t(k) * ql;
+	if (o == ~0ull) { for (uint32_t j = 0; j < ql; ++j) row[j] = 0; }
+	else { const uint8_t *q = d + o; for (uint32_t j = 0; j < ql; ++j) row[j] = q[j]; }
 }
 
 // what the host resolved (new dictionary entries, strings with N) back into the dense columns

@@ -68,6 +68,7 @@ typedef struct dropest_bam_window {        /* host pointers: pinned memory of th
 	uint32_t n_blocks, refused_blocks;     /* blocks the device left to `inflate_fallback` */
 	uint32_t guesses_repaired, pad;        /* segments whose guessed first record was not on the chain (walked again from the true place) */
 	double ms_inflate, ms_boundaries, ms_parse, ms_copy;
+	uint32_t quality_len_min, quality_len_max;   /* shortest / longest UMI quality string over the accepted GENE-BEARING reads (0 = none) */
 } dropest_bam_window;
 
 /* raw DEFLATE of one block on the host (zlib or the like) for the blocks the device refuses; 0 = ok */
@@ -107,6 +108,9 @@ int dropest_bam_decoder_set_annotation(dropest_bam_decoder *d, struct dropest_an
 int dropest_bam_decoder_set_annotation_genes(dropest_bam_decoder *d, const int32_t *id_of_ann_gene, uint32_t n);
 /* the bytes of records idx[0 .. n) of the LAST window (block_size field first), one after the other: dst_off[k] = where record idx[k] starts in dst */
 int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const uint32_t *idx, uint32_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *dst_off);
+/* One row of ql bytes per accepted read of the LAST window, in the order of the dense columns, in pinned HOST memory: the read's UMI quality string
+ * (zeros for a read without a gene).  For a window whose quality_len_min == quality_len_max == ql. */
+int dropest_bam_decoder_quality_rows(dropest_bam_decoder *d, uint32_t ql, const uint8_t **rows);
 /* rows pos[0 .. n) of the LAST window's dense columns take these values (what the caller resolved for the `need` records) */
 int dropest_bam_decoder_patch(dropest_bam_decoder *d, const uint32_t *pos, const uint64_t *cb, const uint64_t *umi, const uint32_t *gene,
                               const uint32_t *aux, uint32_t n);

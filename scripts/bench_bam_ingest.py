@@ -26,6 +26,8 @@ cb_of = dict(zip(np.unique(cb).tolist(), cbs))
 recs = []
 for i in range(n):
     tags = [("CB", "Z", cb_of[int(cb[i])]), ("UB", "Z", capi.unpack_code(umi[i]))]
+    if os.environ.get("QUAL"):      # UQ tags as a 10x BAM carries them: the readers keep one quality row per read
+        tags.append(("UQ", "Z", "FFFFFFFFFF"))
     if gene[i] != capi.NO_GENE:
         tags.append(("GX", "Z", "ENSG%011d" % gene[i]))
     recs.append(bw.record(int(aux[i]) & 0xFFFF, i, "A00000:1:HXXXX:1:1101:%d:%d" % (i, i), seq="ACGT" * 24 + "AC", tags=tags))

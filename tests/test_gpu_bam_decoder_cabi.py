@@ -25,7 +25,7 @@ class Window(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("counts", C.c_uint64 * 5), ("n_accepted", C.c_uint64), ("d_cb", C.c_void_p), ("d_umi", C.c_void_p), ("d_gene", C.c_void_p),
                 ("d_aux", C.c_void_p), ("n_need", C.c_uint32), ("need_rec", P(C.c_uint32)), ("need_pos", P(C.c_uint32)), ("need_size", P(C.c_uint32)),
                 ("quality_seen", C.c_uint32), ("any_gene", C.c_uint32), ("window_bytes", C.c_uint64), ("tail_bytes", C.c_uint64), ("n_blocks", C.c_uint32),
-                ("refused_blocks", C.c_uint32), ("guesses_repaired", C.c_uint32), ("pad", C.c_uint32), ("ms", C.c_double * 4)]
+                ("refused_blocks", C.c_uint32), ("guesses_repaired", C.c_uint32), ("pad", C.c_uint32), ("ms", C.c_double * 4), ("quality_len_min", C.c_uint32), ("quality_len_max", C.c_uint32)]
 
 
 def fnv1a(s):
