@@ -60,7 +60,8 @@ def test_one_window_through_the_c_abi(tmp_path):
             umi = umi[:2] + "N" + umi[3:]
         g = None if i % 9 == 0 else genes[int(rng.integers(0, len(genes)))]
         rt = [None, "N", "I", "E"][i % 4] if g else None
-        tags = [("CB", "Z", cb), ("UB", "Z", umi)] + ([("GX", "Z", g)] if g else []) + ([("RE", "A", rt)] if rt else []) + [("NH", "i", 1)]
+        uq = "".join(chr(33 + int(x)) for x in rng.integers(2, 40, 8))
+        tags = [("CB", "Z", cb), ("UB", "Z", umi), ("UQ", "Z", uq)] + ([("GX", "Z", g)] if g else []) + ([("RE", "A", rt)] if rt else []) + [("NH", "i", 1)]
         flag, ref, status = 0, int(rng.integers(0, 4)), 0
         if i % 97 == 1:
             flag, status = 4, 1
@@ -72,7 +73,7 @@ def test_one_window_through_the_c_abi(tmp_path):
             tags, status = [t for t in tags if t[0] != "UB"], 3
         mark = 1 if g is None else (4 if rt == "N" else 1 if rt == "I" else 2)
         recs.append(bw.record(ref, i, "r%d" % i, flag=flag, tags=tags))
-        want.append((status, cb, umi, g, mark, ref))
+        want.append((status, cb, umi, g, mark, ref, uq))
     path = str(tmp_path / "c.bam")
     bw.write_bam(path, refs, recs, block=12_345)
     blob = open(path, "rb").read()
@@ -111,7 +112,7 @@ def test_one_window_through_the_c_abi(tmp_path):
     w = window()
     assert w.n_records == len(recs) and w.tail_bytes == 0 and w.refused_blocks == 0
     assert list(w.counts) == [sum(1 for x in want if x[0] == s) for s in range(5)]
-    assert w.n_accepted == len(ok_idx) == w.n_need and w.any_gene == 1 and w.quality_seen == 0
+    assert w.n_accepted == len(ok_idx) == w.n_need and w.any_gene == 1 and w.quality_seen == 1 and w.quality_len_min == w.quality_len_max == 8
     need_rec = np.ctypeslib.as_array(w.need_rec, (w.n_need,)).copy(); need_pos = np.ctypeslib.as_array(w.need_pos, (w.n_need,)).copy()
     need_size = np.ctypeslib.as_array(w.need_size, (w.n_need,)).copy()
     assert need_rec.tolist() == ok_idx and need_pos.tolist() == list(range(len(ok_idx))) and need_size.tolist() == [len(recs[i]) for i in ok_idx]
@@ -133,11 +134,18 @@ def test_one_window_through_the_c_abi(tmp_path):
     assert np.ctypeslib.as_array(w.need_pos, (w.n_need,)).tolist() == with_n and len(with_n) > 5
     umi = device_array(w.d_umi, w.n_accepted, np.uint64); gene = device_array(w.d_gene, w.n_accepted, np.uint32); aux = device_array(w.d_aux, w.n_accepted, np.uint32)
     for k, i in enumerate(ok_idx):
-        st, cb, u, g, mark, ref = want[i]
+        st, cb, u, g, mark, ref, _ = want[i]
         assert gene[k] == (gene_id[g] if g else 0xFFFFFFFF)
         assert umi[k] == ((capi.pack_seq(u) or 0) if g else 1)
         touches = g is None or (mark & 6)
         assert aux[k] == (mark << 16) | (int(chr_of_ref[ref]) if touches else 0), (k, i, aux[k], mark, ref)
+    # the UMI quality strings of the accepted reads, one row each (zeros where the read has no gene)
+    rows_p = C.c_void_p()
+    L.dropest_bam_decoder_quality_rows.argtypes = [C.c_void_p, C.c_uint32, P(C.c_void_p)]
+    assert L.dropest_bam_decoder_quality_rows(dec, 8, C.byref(rows_p)) == 0
+    rows = np.ctypeslib.as_array(C.cast(rows_p, P(C.c_uint8)), (int(w.n_accepted), 8))
+    for k, i in enumerate(ok_idx):
+        assert rows[k].tobytes() == (want[i][6].encode() if want[i][3] else b"\0" * 8), (k, i)
     # 3. patch: the caller's values for the rows it resolved
     pos = np.array(with_n, np.uint32)
     pc, pu = np.full(len(pos), 11, np.uint64), np.full(len(pos), 22, np.uint64); pg, pa = np.full(len(pos), 33, np.uint32), np.full(len(pos), 44, np.uint32)
