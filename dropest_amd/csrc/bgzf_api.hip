@@ -538,6 +538,20 @@ extern "C" int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const u
 	});
 }
 
+extern "C" int dropest_bam_decoder_columns_to_host(dropest_bam_decoder *d, uint64_t *cb, uint64_t *umi, uint32_t *gene, uint32_t *aux) {
+	return bgzf_guarded([&] {
+		if (!d) throw InvalidError("null argument");
+		const uint64_t n = d->last_n_ok;
+		if (!n) return;
+		HIP_CHECK(hipSetDevice(d->device));
+		if (cb) HIP_CHECK(hipMemcpyAsync(cb, d->dn_cb.p, n * 8, hipMemcpyDeviceToHost, d->stream));
+		if (umi) HIP_CHECK(hipMemcpyAsync(umi, d->dn_umi.p, n * 8, hipMemcpyDeviceToHost, d->stream));
+		if (gene) HIP_CHECK(hipMemcpyAsync(gene, d->dn_gene.p, n * 4, hipMemcpyDeviceToHost, d->stream));
+		if (aux) HIP_CHECK(hipMemcpyAsync(aux, d->dn_aux.p, n * 4, hipMemcpyDeviceToHost, d->stream));
+		HIP_CHECK(hipStreamSynchronize(d->stream));
+	});
+}
+
 extern "C" int dropest_bam_decoder_quality_rows(dropest_bam_decoder *d, uint32_t ql, const uint8_t **rows) {
 	return bgzf_guarded([&] {
 		if (!d || !rows || !ql || ql > 255) throw InvalidError("bad argument");

@@ -108,6 +108,9 @@ int dropest_bam_decoder_set_annotation(dropest_bam_decoder *d, struct dropest_an
 int dropest_bam_decoder_set_annotation_genes(dropest_bam_decoder *d, const int32_t *id_of_ann_gene, uint32_t n);
 /* the bytes of records idx[0 .. n) of the LAST window (block_size field first), one after the other: dst_off[k] = where record idx[k] starts in dst */
 int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const uint32_t *idx, uint32_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *dst_off);
+/* The dense columns of the LAST window copied to host arrays of n_accepted entries each (any of them may be NULL): for a caller that keeps its
+ * reads on the host after all. */
+int dropest_bam_decoder_columns_to_host(dropest_bam_decoder *d, uint64_t *cb, uint64_t *umi, uint32_t *gene, uint32_t *aux);
 /* One row of ql bytes per accepted read of the LAST window, in the order of the dense columns, in pinned HOST memory: the read's UMI quality string
  * (zeros for a read without a gene).  For a window whose quality_len_min == quality_len_max == ql. */
 int dropest_bam_decoder_quality_rows(dropest_bam_decoder *d, uint32_t ql, const uint8_t **rows);

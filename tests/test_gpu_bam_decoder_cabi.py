@@ -39,12 +39,12 @@ def tag16(t):
     return ord(t[0]) | (ord(t[1]) << 8)
 
 
-def device_array(ptr, n, dtype):
-    hip = C.CDLL("libamdhip64.so")
-    out = np.zeros(n, dtype)
-    if n:
-        assert hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(out.nbytes), 2) == 0
-    return out
+def columns(L, dec, n):
+    cb, umi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+    gene, aux = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    L.dropest_bam_decoder_columns_to_host.argtypes = [C.c_void_p] * 5
+    assert L.dropest_bam_decoder_columns_to_host(dec, cb.ctypes.data, umi.ctypes.data, gene.ctypes.data, aux.ctypes.data) == 0, L.dropest_bgzf_last_error()
+    return cb, umi, gene, aux
 
 
 def test_one_window_through_the_c_abi(tmp_path):
@@ -120,7 +120,7 @@ def test_one_window_through_the_c_abi(tmp_path):
     L.dropest_bam_decoder_fetch_records.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
     assert L.dropest_bam_decoder_fetch_records(dec, need_rec.ctypes.data, len(need_rec), buf.ctypes.data, len(buf), off.ctypes.data) == 0
     assert buf[: int(need_size.sum())].tobytes() == b"".join(recs[i] for i in ok_idx)
-    cbc = device_array(w.d_cb, w.n_accepted, np.uint64)
+    cbc = columns(L, dec, int(w.n_accepted))[0]
     assert cbc.tolist() == [capi.pack_seq(want[i][1]) for i in ok_idx]
     # 2. the dictionaries given: only the UMIs with N are left to the caller; gene and chromosome indices come from the tables
     gene_id = {g: 100 + k for k, g in enumerate(genes)}
@@ -132,7 +132,7 @@ def test_one_window_through_the_c_abi(tmp_path):
     w = window()
     with_n = [k for k, i in enumerate(ok_idx) if "N" in want[i][2] and want[i][3]]
     assert np.ctypeslib.as_array(w.need_pos, (w.n_need,)).tolist() == with_n and len(with_n) > 5
-    umi = device_array(w.d_umi, w.n_accepted, np.uint64); gene = device_array(w.d_gene, w.n_accepted, np.uint32); aux = device_array(w.d_aux, w.n_accepted, np.uint32)
+    _, umi, gene, aux = columns(L, dec, int(w.n_accepted))
     for k, i in enumerate(ok_idx):
         st, cb, u, g, mark, ref, _ = want[i]
         assert gene[k] == (gene_id[g] if g else 0xFFFFFFFF)
@@ -151,7 +151,7 @@ def test_one_window_through_the_c_abi(tmp_path):
     pc, pu = np.full(len(pos), 11, np.uint64), np.full(len(pos), 22, np.uint64); pg, pa = np.full(len(pos), 33, np.uint32), np.full(len(pos), 44, np.uint32)
     L.dropest_bam_decoder_patch.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_uint32]
     assert L.dropest_bam_decoder_patch(dec, pos.ctypes.data, pc.ctypes.data, pu.ctypes.data, pg.ctypes.data, pa.ctypes.data, len(pos)) == 0
-    umi2 = device_array(w.d_umi, w.n_accepted, np.uint64); aux2 = device_array(w.d_aux, w.n_accepted, np.uint32)
+    _, umi2, _, aux2 = columns(L, dec, int(w.n_accepted))
     assert (umi2[pos] == 22).all() and (aux2[pos] == 44).all() and (np.delete(umi2, pos) == np.delete(umi, pos)).all()
     # a reset decoder starts over: empty dictionaries again
     assert L.dropest_bam_decoder_reset(dec, C.byref(cfg)) == 0
