@@ -1046,6 +1046,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				return st;
 			};
 			bool first = true, dict_dirty = true;
+			size_t est_reads = 0;
 			int which = 0;
 			std::future<Staged> next = std::async(std::launch::async, read_window, which, window_bytes);
 			for (;;) {
@@ -1078,7 +1079,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				if (dropest_bam_decoder_window(dec, stg.p, used, first ? u0 : 0u, final ? 1 : 0, host_inflate, nullptr, &w))
 					throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
 				ms_window_calls += since(t_call);
-				if (first) container.expect_reads(size_t(double(w.n_records) * double(map.n - c0) / double(std::max<size_t>(used, 1)) * double(bam_files.size()) * 1.05));
+				if (first) { est_reads = size_t(double(w.n_records) * double(map.n - c0) / double(std::max<size_t>(used, 1)) * double(bam_files.size()) * 1.05); container.expect_reads(est_reads); }
 				first = false;
 				++n_windows; repaired += w.guesses_repaired; refused += w.refused_blocks;
 				dev_ms[0] += w.ms_copy; dev_ms[1] += w.ms_inflate; dev_ms[2] += w.ms_boundaries; dev_ms[3] += w.ms_parse;
@@ -1158,6 +1159,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				bool any_gene = w.any_gene != 0;
 				for (size_t k = 0; k < size_t(w.n_need) && !any_gene; ++k) any_gene = p_gene[k] != DROPEST_NO_GENE;
 				if (q_bulk) {
+					container.reserve_quality_rows(est_reads, q_len);
 					const uint8_t *rows = nullptr;
 					if (dropest_bam_decoder_quality_rows(dec, q_len, &rows)) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
 					container.add_records_packed_device(w.d_cb, w.d_umi, w.d_gene, w.d_aux, size_t(w.n_accepted), any_gene, rows, q_len);

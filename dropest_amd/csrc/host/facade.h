@@ -438,6 +438,7 @@ public:
 		return !sharded() && !_is_initialized && !_mol_qlen_tracking && _qual_lens.empty() && ql > 0 && ql <= 255 && (_umi_quality_length == size_t(-1) || _umi_quality_length == ql);
 	}
 	void add_records_packed(const std::vector<PackedRun> &runs, const std::vector<const uint8_t *> &quality, size_t ql);
+	void reserve_quality_rows(size_t reads, size_t ql) { if (reads && ql && _qual.capacity() < reads * ql) _qual.reserve(reads * ql); }   // (a reader that knows how long the stream will be)
 	bool bulk_ingest_possible_at_all() const { return !sharded() && !_is_initialized && !_mol_qlen_tracking && _qual_lens.empty(); }   // (with or without quality rows: the window decides)
 	static bool pack_code(std::string_view s, uint64_t &code);
 	static uint64_t hash_name(std::string_view s);
