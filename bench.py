@@ -466,12 +466,13 @@ def measure_bam_ingest(n_reads=250_000, copies=64, threads=16):
     s = SynthStream(n_reads=n_reads, n_cells=500, n_genes=5000, umi_len=10)
     cb, umi, gene, aux = s.generate_host()
     cbs = {int(c): capi.unpack_code(c) for c in np.unique(cb)}
-    recs = []
+    recs, recs_uq = [], []
     for i in range(n_reads):
         tags = [("CB", "Z", cbs[int(cb[i])]), ("UB", "Z", capi.unpack_code(umi[i]))]
         if gene[i] != capi.NO_GENE:
             tags.append(("GX", "Z", "ENSG%011d" % gene[i]))
         recs.append(bw.record(int(aux[i]) & 0xFFFF, i, "A00000:1:HXXXX:1:1101:%d:%d" % (i, i), seq="ACGT" * 24 + "AC", tags=tags))
+        recs_uq.append(bw.record(int(aux[i]) & 0xFFFF, i, "A00000:1:HXXXX:1:1101:%d:%d" % (i, i), seq="ACGT" * 24 + "AC", tags=tags + [("UQ", "Z", "FFFFFFFFFF")]))
     tmp = tempfile.mkdtemp()
     try:
         bam = os.path.join(tmp, "synth.bam")
@@ -505,6 +506,19 @@ def measure_bam_ingest(n_reads=250_000, copies=64, threads=16):
             out.update(inflate_kernel_ms=round(ms.value, 3), inflated_GB=round(n_out.value / 1e9, 3), inflate_GB_per_s=round(n_out.value / 1e6 / ms.value, 1),
                        blocks=int(n_blocks.value), blocks_refused=int((status[:n_blocks.value] != 0).sum()), crc32_checked_on_device=True)
         out["x_host_reader"] = round(out["host_reader_ingest_ms"] / out["device_ingest_ms"], 2)
+        # the same records with a UMI quality tag (UQ: what a 10x BAM carries): both readers keep one quality row per read
+        bam_uq = os.path.join(tmp, "synth_uq.bam")
+        bw.write_bam(bam_uq, [("chr%d" % i, 10_000_000) for i in range(25)], recs_uq, repeat=copies)
+        uq = {}
+        for label, env in (("host_reader", {}), ("device", {"DROPEST_BAM_DEVICE": "1"})):
+            res = subprocess.run([tool, os.path.join(tmp, "out"), "filled", "20", "100", "-", str(threads), bam_uq], capture_output=True, text=True,
+                                 env=dict(os.environ, **env), timeout=600)
+            if res.returncode:
+                raise RuntimeError(res.stderr[-300:])
+            st = json.loads(res.stdout.strip().splitlines()[-1])
+            assert st["saved"] == n_reads * copies
+            uq[label + "_ingest_ms"] = st["ingest_ms"]; uq[label + "_Mreads_per_s"] = round(n_reads * copies / st["ingest_ms"] / 1e3, 1)
+        out["with_uq_tags"] = uq
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -537,6 +551,8 @@ def finish_line(line):
     bi = sec.get("bam_ingest") or {}
     if "device_Mreads_per_s" in bi:
         summary.update(bam_device_Mreads_per_s=bi["device_Mreads_per_s"], bam_host_reader_Mreads_per_s=bi["host_reader_Mreads_per_s"], bam_inflate_GB_per_s=bi.get("inflate_GB_per_s"))
+        if "with_uq_tags" in bi:
+            summary.update(bam_uq_device_Mreads_per_s=bi["with_uq_tags"].get("device_Mreads_per_s"), bam_uq_host_reader_Mreads_per_s=bi["with_uq_tags"].get("host_reader_Mreads_per_s"))
     elif "error" in bi:
         summary["bam_ingest_error"] = bi["error"][:200]
     for k, v in summary.items():           # scalars only: they survive in the parsed record's `config`
