@@ -951,7 +951,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			std::memcpy(cfg.intronic, _tags.intronic_read_value.data(), cfg.intronic_len);
 			std::memcpy(cfg.intergenic, _tags.intergenic_read_value.data(), cfg.intergenic_len);
 			// One decoder per device is kept between files and until the process ends (BamController::release_device_decoders frees them):
-			// streams, ~1.5 GB of device buffers and 64 MB of pinned memory cost ~30 ms to set up and ~40 ms to give back.
+			// streams, 1.5–3 GB of device buffers and 64 MB of pinned memory cost ~30 ms to set up and ~40 ms to give back.
 			dropest_bam_decoder *dec = nullptr;
 			{
 				std::lock_guard<std::mutex> lk(decoder_cache_mutex());

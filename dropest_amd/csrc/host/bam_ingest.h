@@ -101,7 +101,7 @@ public:
 	// chromosome name, or a sharded container (the host reader then runs).
 	// CRC-32 and ISIZE of every block are checked there too.  DROPEST_BAM_DEVICE=1 in the environment does the same.
 	void set_device_decode(bool on) { _device_decode = on; }
-	// the device path keeps one decoder per GPU (streams, ~1.5 GB of device buffers, 64 MB of pinned memory) between files and until the process ends
+	// the device path keeps one decoder per GPU (streams, 1.5–3 GB of device buffers, 64 MB of pinned memory) between files and until the process ends
 	static void release_device_decoders();
 	const Counters &counters() const { return _counters; }
 };
