@@ -799,6 +799,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 		std::vector<Tally> tally(NT);
 		std::vector<CellsDataContainer::PackedRun> runs;
 		std::vector<const char *> o_qp;
+		size_t est_reads_host = 0;
 		std::vector<uint8_t> o_qual;
 		std::vector<const uint8_t *> q_rows;
 		double fw_ms[3] = {0, 0, 0};   // DROPEST_BAM_TRACE: parse + pack on the workers, new dictionary entries on this thread, container
@@ -868,6 +869,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				if (tally[t].ok) runs.push_back(CellsDataContainer::PackedRun{o_cb.data() + b0, o_umi.data() + b0, o_gene.data() + b0, o_aux.data() + b0, tally[t].ok});
 			}
 			if (with_quality) {    // one row of ql bytes per accepted read, beside the columns (zeros for reads without a gene)
+				container.reserve_quality_rows(est_reads_host, ql);
 				if (o_qual.size() < n * size_t(ql)) o_qual.resize(n * size_t(ql));
 				workers.run([&](unsigned t) {
 					const size_t b0 = n * t / NT;
@@ -1196,7 +1198,8 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			if (first_window && &bam_name == &bam_files.front()) {
 				// a container over several GPUs deals contiguous ranges of the stream to its shards: tell it how long the stream
 				// will roughly be (records of the first window x file bytes / bytes the window covered, x the number of files)
-				container.expect_reads(size_t(double(offsets.size()) * reader.file_over_first_batch() * double(bam_files.size()) * 1.05));
+				est_reads_host = size_t(double(offsets.size()) * reader.file_over_first_batch() * double(bam_files.size()) * 1.05);
+				container.expect_reads(est_reads_host);
 			}
 			first_window = false;
 			if (!_params_from_files && !force_slow && NT <= 256 && container.bulk_ingest_possible_at_all()) {
