@@ -142,6 +142,18 @@ struct ReadStore {
 		cur ^= 1;
 		n += total;
 	}
+	// Device arrays copied to the tail of the store (dropest_push_reads_device without adoption): the reads stay ONE block, so a
+	// view of the container before it is initialised (dropest_resident_reads) and the freeze have nothing to concatenate.
+	void push_device(const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene, const uint32_t *d_aux, size_t count) {
+		if (!count) return;
+		reserve(n + count);
+		HIP_CHECK(hipMemcpyAsync(cb.p + n, d_cb, count * 8, hipMemcpyDeviceToDevice, copy));
+		HIP_CHECK(hipMemcpyAsync(umi.p + n, d_umi, count * 8, hipMemcpyDeviceToDevice, copy));
+		HIP_CHECK(hipMemcpyAsync(gene.p + n, d_gene, count * 4, hipMemcpyDeviceToDevice, copy));
+		HIP_CHECK(hipMemcpyAsync(aux.p + n, d_aux, count * 4, hipMemcpyDeviceToDevice, copy));
+		HIP_CHECK(stream_wait(copy));   // the caller's buffers are free again
+		n += count;
+	}
 	void wait() { if (copy) HIP_CHECK(stream_wait(copy)); }
 	void clear() { wait(); n = 0; }
 };

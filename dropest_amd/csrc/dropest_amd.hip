@@ -2403,6 +2403,15 @@ dropest_status dropest_push_reads_device(dropest_ctx *ctx, const uint64_t *d_cb,
 		push_common(ctx, n);
 		if (n == 0) return;
 		if (!d_cb || !d_umi || !d_gene || !d_aux) throw InvalidError("null read array");
+		// a copied chunk joins the growing store while that is the tail of the stream (every chunk so far was a copy): the reads
+		// stay one block, which the facade's preview of an uninitialised container needs (dropest_resident_reads)
+		if (!adopt && (ctx->store_chunk < 0 || size_t(ctx->store_chunk) + 1 == ctx->chunks.size())) {
+			if (ctx->store_chunk < 0) { ctx->store_chunk = long(ctx->chunks.size()); ctx->chunks.emplace_back(); }
+			ctx->store.push_device(d_cb, d_umi, d_gene, d_aux, n);
+			ctx->chunks[size_t(ctx->store_chunk)].n = ctx->store.n;
+			ctx->n_reads += n;
+			return;
+		}
 		ReadChunk c;
 		c.n = n;
 		if (adopt) {

@@ -26,13 +26,22 @@ B = list("ACGT")
 
 
 def run(out, mode, bam, env):
-    res = subprocess.run([TOOL, out, mode, "2", "3", "-", str(int(rng.integers(1, 9))), bam], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    res = subprocess.run([TOOL, out, mode, "2", "3", "-", str(int(rng.integers(1, 9))), bam], capture_output=True, text=True, timeout=600, env=dict(os.environ, DROPEST_RPUPC="1", **env))
     if res.returncode:
         return {"error": res.stderr.strip().splitlines()[-1] if res.stderr.strip() else "rc %d" % res.returncode}
     st = json.loads(res.stdout.strip().splitlines()[-1])
     d = rr.read_rds(out + ".rds")
     cm, genes, cells = rr.dgcmatrix_to_dense(d["cm"])
-    return {"stats": {k: st[k] for k in ("total_reads", "cant_parse", "low_quality", "saved", "cells", "real_cells")}, "cells": cells,
+    mol = {}
+    try:
+        rp = d["reads_per_umi_per_cell"]
+        cells_l, genes_l = rp["cells"].value, rp["genes"].value
+        for ci, gi, per_gene in zip(rp["cell_indexes"].value, rp["gene_indexes"].value, rp["reads_per_umi"].value):
+            for name, entry in zip(per_gene.names, per_gene.value):
+                mol[(cells_l[int(ci)], genes_l[int(gi)], name)] = (int(entry.value[0].value[0]), tuple(float(x) for x in entry.value[1].value))
+    except Exception as e:      # (no such entry: compare what there is)
+        mol = {"unreadable": str(e)}
+    return {"stats": {k: st[k] for k in ("total_reads", "cant_parse", "low_quality", "saved", "cells", "real_cells")}, "cells": cells, "molecules": mol,
             "cm": {(genes[r], cells[c]): int(cm[r, c]) for r, c in zip(*np.nonzero(cm))}}
 
 
@@ -44,9 +53,13 @@ for case in range(int(os.environ.get("SOAK_CASES", "16"))):
     cbs = ["".join(rng.choice(B, int(rng.integers(8, 17)))) for _ in range(n_cb)]
     umis = ["".join(rng.choice(B, 8)) for _ in range(n_umi)]
     p_n, p_odd, long_every = float(rng.choice([0, 0.002, 0.02])), float(rng.choice([0.0, 0.03, 0.15])), int(rng.choice([0, 0, 997, 211]))
+    # UMI quality tags: none / on every read / on the second half of the file (other cells: new molecules) / on nearly every read with a rare other length
+    uq_mode = int(rng.integers(0, 4)) if mode == "filled" else 0
     recs = []
     for i in range(n):
         cb, umi = cbs[int(rng.integers(0, n_cb))], umis[int(rng.integers(0, n_umi))]
+        if uq_mode == 2:
+            cb = ("A" if i > n // 2 else "C") + cb[1:]
         if rng.random() < p_n:
             j = int(rng.integers(0, len(umi))); umi = umi[:j] + "N" + umi[j + 1:]
         if rng.random() < p_n / 2:
@@ -55,6 +68,8 @@ for case in range(int(os.environ.get("SOAK_CASES", "16"))):
         tags = []
         if mode == "filled":
             tags += [("CB", "Z", cb), ("UB", "Z", umi)]
+            if uq_mode == 1 or (uq_mode == 2 and i > n // 2) or (uq_mode == 3 and rng.random() < 0.999):
+                tags.append(("UQ", "Z", "".join(chr(33 + int(x)) for x in rng.integers(2, 41, 8 if uq_mode != 3 or rng.random() < 0.9995 else 6))))
         if gene is not None:
             tags.append(("GX", "Z", gene))
             if rng.random() < 0.5:
@@ -102,9 +117,14 @@ for case in range(int(os.environ.get("SOAK_CASES", "16"))):
         block = 4000
     bw.write_bam(bam, [("chr%d" % k, 1 << 28) for k in range(n_ref)], recs, block=block)
     host = run(os.path.join(tmp, "host"), mode, bam, dict(genv))
+    if uq_mode and n < 40_000:      # the bulk path with quality rows against add_record per read
+        one = run(os.path.join(tmp, "one"), mode, bam, dict(genv, DROPEST_BAM_RECORD_BY_RECORD="1"))
+        if one != host:
+            print(case, "record-by-record and bulk DIFFER", one.get("stats", one.get("error")), host.get("stats", host.get("error")), flush=True)
+            sys.exit(1)
     dev = run(os.path.join(tmp, "dev"), mode, bam, dict(genv, DROPEST_BAM_DEVICE="1", DROPEST_BAM_DEVICE_WINDOW_MB=str(int(rng.choice([1, 1, 4, 32])))))
     same = host == dev
-    print(case, mode + (" -g" if genv else ""), "reads", n, "block", block, "p_n", p_n, "p_odd", p_odd, "long", long_every, "->", host.get("stats", host.get("error")),
+    print(case, mode + (" -g" if genv else ""), "reads", n, "block", block, "p_n", p_n, "p_odd", p_odd, "long", long_every, "uq", uq_mode, "->", host.get("stats", host.get("error")),
           "SAME" if same else "DIFFERENT %s" % (dev.get("stats", dev.get("error")),), "%.1fs" % (time.time() - t0), flush=True)
     if not same:
         sys.exit(1)

@@ -492,6 +492,16 @@ def test_quality_strings_in_bulk_and_where_bulk_must_not_be_taken(tmp_path):
     assert runs["bulk"] == runs["one_by_one"] and runs["device"] == runs["one_by_one"]
     m = runs["bulk"][3]
     assert len(m) > 3000 and sum(1 for v in m.values() if len(v[1]) == 8) > 500 and sum(1 for v in m.values() if len(v[1]) == 6) > 500 and sum(1 for v in m.values() if not v[1]) > 500
+    # the same reads in BGZF blocks of 40 bytes: the device path takes the file in several windows, and the window where tagged and untagged
+    # reads meet goes record by record AFTER windows that went to the container as device columns -- the look at the molecules made so far
+    # (quality length of an existing molecule) then reads columns that were pushed from the device
+    bam3 = str(tmp_path / "small_blocks.bam")
+    bw.write_bam(bam3, refs, recs[:16_000], block=40)
+    small = {}
+    for name, env in (("one_by_one", {"DROPEST_BAM_RECORD_BY_RECORD": "1"}), ("device", {"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_DEVICE_WINDOW_MB": "1"})):
+        got, cells, stats, d = _run(tmp_path / ("small_" + name), "filled", [bam3], 2, 3, threads=4, env=dict(env, DROPEST_RPUPC="1"))
+        small[name] = (got, cells, {k: stats[k] for k in ("total_reads", "cant_parse", "low_quality", "saved")}, molecules(d))
+    assert small["device"] == small["one_by_one"] and small["device"][2]["total_reads"] == 16_000
     # ... and a read without a quality string that meets a molecule created with one is UMI::add_read's exception (UMI.cpp:26-28) from all three
     clash = list(recs[:8000]) + [bw.record(int(c[3:]), 8000 + i, "x%d" % i, tags=[("CB", "Z", "AAAA" + cb[4:]), ("UB", "Z", umi)] + ([("GX", "Z", g)] if g else []))
                                 for i, (cb, umi, g, c, m) in enumerate(reads[:8000])]
