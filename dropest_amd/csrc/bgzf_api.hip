@@ -172,7 +172,35 @@ struct dropest_bam_decoder {
 	PinnedBuf<uint32_t> h_need_rec, h_need_pos, h_need_size, h_gsize;
 	uint32_t g_mask = 0;
 	uint64_t tail_len = 0, last_n_rec = 0, last_n_ok = 0;
+	// the compressed bytes of a staging buffer on their way to the device ahead of the window call (dropest_bam_decoder_upload)
+	hipStream_t up_stream = nullptr;
+	hipEvent_t up_done[2] = {nullptr, nullptr};
+	DevBuf<uint8_t> up_in[2];
+	uint64_t up_len[2] = {0, 0};
+	bool up_ready[2] = {false, false};
+	// ... and their block table, made by the same caller (a walk from header to header is one cache miss per block: ~2 ms per 64 MB window)
+	struct UpBlocks { std::vector<uint64_t> in_off, out_off; std::vector<uint32_t> in_len, out_len, crc; uint64_t n = 0, used = 0, total = 0; bool ok = false; } up_blocks[2];
 };
+
+// comp[0 .. len) walked from block header to block header: the arrays the inflate kernel and the host fall-back take.  false: not whole, sound blocks
+// (the caller says what is wrong with dropest_bgzf_scan's message)
+static bool bgzf_block_table(const uint8_t *comp, uint64_t len, std::vector<uint64_t> &in_off, std::vector<uint64_t> &out_off, std::vector<uint32_t> &in_len,
+                             std::vector<uint32_t> &out_len, std::vector<uint32_t> &crc, uint64_t *n, uint64_t *used, uint64_t *total) {
+	// counted first: arrays for the smallest possible block, 26 bytes, would be 36 MB of page faults per 32 MB window
+	uint64_t cap = 1;
+	for (uint64_t at = 0; at + 18 <= len; ++cap) {
+		const uint8_t *h = comp + at;
+		if (h[0] != 0x1f || h[1] != 0x8b) break;                      // (dropest_bgzf_scan below says what is wrong)
+		const uint32_t xlen = le16(h + 10);
+		uint32_t bsize = 0;
+		for (uint32_t x = 0; x + 4 <= xlen && at + 12 + x + 6 <= len;) { const uint8_t *sf = h + 12 + x; const uint32_t sl = le16(sf + 2); if (sf[0] == 'B' && sf[1] == 'C' && sl == 2) bsize = le16(sf + 4) + 1; x += 4 + sl; }
+		if (!bsize) break;
+		at += bsize;
+	}
+	if (in_off.size() < cap) { const uint64_t c2 = cap + cap / 2; in_off.resize(c2); out_off.resize(c2); in_len.resize(c2); out_len.resize(c2); crc.resize(c2); }
+	*n = *used = *total = 0;
+	return !len || dropest_bgzf_scan(comp, len, cap, in_off.data(), in_len.data(), out_off.data(), out_len.data(), crc.data(), n, used, total) == 0;
+}
 
 extern "C" int dropest_bam_decoder_create(int device, const dropest_bam_parse_cfg *cfg, dropest_bam_decoder **out) {
 	return bgzf_guarded([&] {
@@ -189,6 +217,8 @@ extern "C" int dropest_bam_decoder_create(int device, const dropest_bam_parse_cf
 		try {
 			HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
 			for (BamFront &f : d->front) HIP_CHECK(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
+			HIP_CHECK(hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking));
+			for (hipEvent_t &e : d->up_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 			// empty dictionaries: every gene and chromosome is new
 			d->g_mask = 1023; d->g_keys.alloc(1024); d->g_vals.alloc(1024); d->d_chr.alloc(size_t(std::max(1, cfg->n_refs)));
 			HIP_CHECK(hipMemset(d->g_vals.p, 0, 1024 * 4));
@@ -208,6 +238,8 @@ extern "C" int dropest_bam_decoder_reset(dropest_bam_decoder *d, const dropest_b
 		HIP_CHECK(hipSetDevice(d->device));
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		for (BamFront &f : d->front) { HIP_CHECK(hipStreamSynchronize(f.stream)); f.begun = false; }
+		HIP_CHECK(hipStreamSynchronize(d->up_stream));
+		d->up_ready[0] = d->up_ready[1] = false;
 		std::memcpy(&d->cfg, cfg, sizeof(BamParseCfg));
 		d->tail_len = 0; d->last_n_rec = 0; d->last_n_ok = 0; d->next_front = 0; d->last_front = 0;
 		d->annotation = nullptr; d->n_ann_genes = 0;
@@ -236,6 +268,7 @@ extern "C" int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, ui
 		BamFront &F = d->front[which];
 		const uint64_t out_bytes = bytes * 14, n_rec = out_bytes / 120, n_blk = bytes / 2048 + 1024, n_seg = out_bytes / BAM_SEG + 16;
 		F.d_in.ensure(bytes + 8); F.d_out.ensure(out_bytes);
+		d->up_in[which].ensure(bytes + 8);
 		F.d_in_off.ensure(n_blk); F.d_out_off.ensure(n_blk); F.d_in_len.ensure(n_blk); F.d_out_len.ensure(n_blk); F.d_status.ensure(n_blk); F.d_crc.ensure(n_blk); F.h_block_status.ensure(n_blk);
 		F.seg_start.ensure(n_seg); F.seg_exit.ensure(n_seg); F.seg_count.ensure(n_seg); F.seg_base.ensure(n_seg);
 		F.h_seg_start.ensure(n_seg); F.h_seg_exit.ensure(n_seg); F.h_count.ensure(n_seg);
@@ -247,9 +280,30 @@ extern "C" int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, ui
 	});
 }
 
+// The first `len` bytes of staging buffer `which` start their way to the device now, on a stream of their own: the window call that is then given
+// exactly that buffer and length waits for this copy instead of making one -- with a reader thread that calls this when its read is done, the
+// copy of window k + 1 runs under the kernels of window k.  Allocates nothing; the one call of the decoder that may run beside a window call
+// (from another thread).  A length the buffers were not sized for is not an error: the window call copies as before.
+extern "C" int dropest_bam_decoder_upload(dropest_bam_decoder *d, int which, uint64_t len) {
+	if (!d || which < 0 || which > 1) return 1;
+	d->up_ready[which] = false;
+	if (!len || !d->h_stage[which].p || len > d->h_stage[which].n || len + 8 > d->up_in[which].n) return 0;
+	if (hipSetDevice(d->device) != hipSuccess) return 1;
+	if (hipMemcpyAsync(d->up_in[which].p, d->h_stage[which].p, len, hipMemcpyHostToDevice, d->up_stream) != hipSuccess) return 1;
+	if (hipEventRecord(d->up_done[which], d->up_stream) != hipSuccess) return 1;
+	auto &b = d->up_blocks[which];      // while the copy runs: the block table of these bytes (a failure here is the window call's to report)
+	b.ok = false;
+	try { b.ok = bgzf_block_table(d->h_stage[which].p, len, b.in_off, b.out_off, b.in_len, b.out_len, b.crc, &b.n, &b.used, &b.total); } catch (...) { b.ok = false; }
+	d->up_len[which] = len;
+	d->up_ready[which] = true;
+	return 0;
+}
+
 extern "C" void dropest_bam_decoder_destroy(dropest_bam_decoder *d) {
 	if (!d) return;
 	(void)hipSetDevice(d->device);
+	if (d->up_stream) { (void)hipStreamSynchronize(d->up_stream); (void)hipStreamDestroy(d->up_stream); }
+	for (hipEvent_t e : d->up_done) if (e) (void)hipEventDestroy(e);
 	if (d->stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
 	for (BamFront &f : d->front) if (f.stream) { (void)hipStreamSynchronize(f.stream); (void)hipStreamDestroy(f.stream); }
 	delete d;
@@ -304,6 +358,12 @@ extern "C" int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, cons
 	});
 }
 
+__global__ __launch_bounds__(256) void bam_chain_to_host_kernel(const uint64_t *__restrict__ seg_start, const uint64_t *__restrict__ seg_exit, const uint32_t *__restrict__ seg_count, uint32_t n,
+                                                                uint64_t *h_start, uint64_t *h_exit, uint32_t *h_count) {
+	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+	if (k < n) { h_start[k] = seg_start[k]; h_exit[k] = seg_exit[k]; h_count[k] = seg_count[k]; }
+}
+
 extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
                                                 dropest_bgzf_host_inflate inflate_fallback, void *user, int *slot) {
 	return bgzf_guarded([&] {
@@ -317,20 +377,16 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 		auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
 		HIP_CHECK(hipSetDevice(dec->device));
 		hipStream_t st = d->stream;
-		// 1. the blocks (counted first: arrays for the smallest possible block, 26 bytes, would be 36 MB of page faults per 32 MB window)
-		uint64_t cap = 1;
-		for (uint64_t at = 0; at + 18 <= len; ++cap) {
-			const uint8_t *h = comp + at;
-			if (h[0] != 0x1f || h[1] != 0x8b) break;                      // (dropest_bgzf_scan below says what is wrong)
-			const uint32_t xlen = le16(h + 10);
-			uint32_t bsize = 0;
-			for (uint32_t x = 0; x + 4 <= xlen && at + 12 + x + 6 <= len;) { const uint8_t *sf = h + 12 + x; const uint32_t sl = le16(sf + 2); if (sf[0] == 'B' && sf[1] == 'C' && sl == 2) bsize = le16(sf + 4) + 1; x += 4 + sl; }
-			if (!bsize) break;
-			at += bsize;
-		}
-		if (d->in_off.size() < cap) { const uint64_t c2 = cap + cap / 2; d->in_off.resize(c2); d->out_off.resize(c2); d->in_len.resize(c2); d->out_len.resize(c2); d->crc.resize(c2); }
+		// 1. the blocks
+		int up = -1;      // the bytes went ahead (dropest_bam_decoder_upload)
+		for (int w = 0; w < 2; ++w)
+			if (dec->up_ready[w] && comp == dec->h_stage[w].p && len == dec->up_len[w]) { up = w; dec->up_ready[w] = false; }
 		uint64_t n = 0, used = 0, total = 0;
-		if (len && dropest_bgzf_scan(comp, len, cap, d->in_off.data(), d->in_len.data(), d->out_off.data(), d->out_len.data(), d->crc.data(), &n, &used, &total)) throw InvalidError(g_bgzf_error);
+		if (up >= 0 && dec->up_blocks[up].ok) {
+			auto &b = dec->up_blocks[up];
+			d->in_off.swap(b.in_off); d->out_off.swap(b.out_off); d->in_len.swap(b.in_len); d->out_len.swap(b.out_len); d->crc.swap(b.crc);
+			n = b.n; used = b.used; total = b.total; b.ok = false;
+		} else if (!bgzf_block_table(comp, len, d->in_off, d->out_off, d->in_len, d->out_len, d->crc, &n, &used, &total)) throw InvalidError(g_bgzf_error);
 		if (used != len) throw InvalidError("a window must hold whole BGZF blocks");
 		if (n > 0xFFFFFFFFull) throw UnsupportedError("more than 2^32 blocks in one window");
 		const uint64_t tail = dec->tail_len, data_len = tail + total;
@@ -340,10 +396,13 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 		d->d_out.ensure(data_len + data_len / 4 + 64);
 		if (tail) HIP_CHECK(hipMemcpyAsync(d->d_out.p, dec->d_tail.p, tail, hipMemcpyDeviceToDevice, st));
 		if (n) {
-			d->d_in.ensure(len + len / 4 + 8); d->d_in_off.ensure(n + n / 4); d->d_out_off.ensure(n + n / 4); d->d_in_len.ensure(n + n / 4); d->d_out_len.ensure(n + n / 4);
+			const uint8_t *uploaded = nullptr;
+			if (up >= 0) { uploaded = dec->up_in[up].p; HIP_CHECK(hipStreamWaitEvent(st, dec->up_done[up], 0)); }
+			else d->d_in.ensure(len + len / 4 + 8);
+			d->d_in_off.ensure(n + n / 4); d->d_out_off.ensure(n + n / 4); d->d_in_len.ensure(n + n / 4); d->d_out_len.ensure(n + n / 4);
 			d->d_status.ensure(n + n / 4); d->d_crc.ensure(n + n / 4); d->h_block_status.ensure(n);
 			HIP_CHECK(hipMemcpyAsync(d->d_crc.p, d->crc.data(), n * 4, hipMemcpyHostToDevice, st));
-			HIP_CHECK(hipMemcpyAsync(d->d_in.p, comp, len, hipMemcpyHostToDevice, st));
+			if (!uploaded) HIP_CHECK(hipMemcpyAsync(d->d_in.p, comp, len, hipMemcpyHostToDevice, st));
 			HIP_CHECK(hipMemcpyAsync(d->d_in_off.p, d->in_off.data(), n * 8, hipMemcpyHostToDevice, st));
 			HIP_CHECK(hipMemcpyAsync(d->d_out_off.p, d->out_off.data(), n * 8, hipMemcpyHostToDevice, st));
 			HIP_CHECK(hipMemcpyAsync(d->d_in_len.p, d->in_len.data(), n * 4, hipMemcpyHostToDevice, st));
@@ -351,7 +410,7 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 			HIP_CHECK(hipStreamSynchronize(st));
 			out->ms_copy = ms_since(t0);
 			t0 = clk::now();
-			if (dropest_bgzf_inflate_device(dec->device, st, d->d_in.p, len, d->d_in_off.p, d->d_in_len.p, d->d_out_off.p, d->d_out_len.p, uint32_t(n), d->d_out.p + tail, d->d_status.p, d->d_crc.p))
+			if (dropest_bgzf_inflate_device(dec->device, st, uploaded ? uploaded : d->d_in.p, len, d->d_in_off.p, d->d_in_len.p, d->d_out_off.p, d->d_out_len.p, uint32_t(n), d->d_out.p + tail, d->d_status.p, d->d_crc.p))
 				throw DeviceError(g_bgzf_error);
 			HIP_CHECK(hipMemcpyAsync(d->h_block_status.p, d->d_status.p, n * 4, hipMemcpyDeviceToHost, st));
 			HIP_CHECK(hipStreamSynchronize(st));
@@ -384,10 +443,10 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 			                   d->seg_count.p, d->seg_exit.p, (const uint32_t *)nullptr, (uint64_t *)nullptr, d->d_bad.p + 1);
 			// (a walk from a guess that is not on the chain reads anything as a length: what these walks flag is not looked at -- the walk that
 			// writes the record offsets, from the checked starts, is the one whose flag counts: dropest_bam_decoder_window_finish)
+			// (the three arrays go to the pinned host buffers by a kernel's stores, not by copies: a copy queues behind the next window's 80 MB on
+			// their way in -- dropest_bam_decoder_upload -- and the chain took 0.75 instead of 0.25 ms per window)
+			hipLaunchKernelGGL(bam_chain_to_host_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, d->seg_start.p, d->seg_exit.p, d->seg_count.p, n_segs, d->h_seg_start.p, d->h_seg_exit.p, d->h_count.p);
 			HIP_CHECK(hipGetLastError());
-			HIP_CHECK(hipMemcpyAsync(d->h_seg_start.p, d->seg_start.p, size_t(n_segs) * 8, hipMemcpyDeviceToHost, st));
-			HIP_CHECK(hipMemcpyAsync(d->h_seg_exit.p, d->seg_exit.p, size_t(n_segs) * 8, hipMemcpyDeviceToHost, st));
-			HIP_CHECK(hipMemcpyAsync(d->h_count.p, d->seg_count.p, size_t(n_segs) * 4, hipMemcpyDeviceToHost, st));
 			HIP_CHECK(hipStreamSynchronize(st));
 			d->base.resize(n_segs);
 			for (uint32_t k = 0; k < n_segs; ++k) {

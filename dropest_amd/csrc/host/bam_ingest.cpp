@@ -1015,22 +1015,41 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			struct Staged { uint8_t *p = nullptr; size_t used = 0; bool final = false; std::string error; };
 			const size_t stage_cap = window_max + (size_t(1) << 17);
 			uint8_t *stage_p[2] = {nullptr, nullptr};
-			for (int k = 0; k < 2; ++k)
+			for (int k = 0; k < 2; ++k)      // (pinning 2 x 80 MB and reserving a window's device buffers: 35-50 ms; side by side on two threads they take as long)
 				if (dropest_bam_decoder_staging(dec, k, stage_cap, &stage_p[k])) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
 			const double ms_setup = since(t_file);
 			double ms_wait_read = 0, ms_window_calls = 0;
 			size_t file_at = c0;
 			const size_t block_cap = getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? size_t(-1) : std::max<size_t>(1024, dropest_bam_decoder_wave_slots(dec)) * (long_file ? 2 : 1);   // (one wave per block: a full machine's worth per window)
+			const bool upload_ahead = !getenv("DROPEST_BAM_NO_UPLOAD_AHEAD");
 			auto read_window = [&](int which, size_t want) {
 				Staged st; st.p = stage_p[which];
 				const size_t ask = std::min(std::min(want + (size_t(1) << 16) + 64, stage_cap), map.n - file_at);
+				// (the copy out of the page cache runs at ~4-5 GB/s per thread: a long window is read in four pieces side by side, so that the reader
+				// stays ahead of the device -- which takes ~11 ms per 64 MB window)
+				auto read_piece = [&](size_t from, size_t len) -> long {
+					size_t g = 0;
+					while (g < len) {
+						const ssize_t r = pread(map.fd, st.p + from + g, len - g, off_t(file_at + from + g));
+						if (r < 0) return -1;
+						if (r == 0) break;
+						g += size_t(r);
+					}
+					return long(g);
+				};
 				size_t got = 0;
-				while (got < ask) {
-					const ssize_t r = pread(map.fd, st.p + got, ask - got, off_t(file_at + got));
-					if (r < 0) { st.error = "Can't read BAM file"; return st; }
-					if (r == 0) break;
-					got += size_t(r);
+				const size_t n_pieces = ask > (size_t(8) << 20) ? 4 : 1, piece = (ask / n_pieces + 4095) & ~size_t(4095);
+				std::vector<std::future<long>> rest;
+				for (size_t k = 1; k < n_pieces; ++k) if (k * piece < ask) rest.push_back(std::async(std::launch::async, read_piece, k * piece, std::min(piece, ask - k * piece)));
+				const long g0 = read_piece(0, std::min(piece, ask));
+				bool whole = g0 == long(std::min(piece, ask)), failed = g0 < 0;
+				if (g0 > 0) got = size_t(g0);
+				for (size_t k = 0; k < rest.size(); ++k) {
+					const long g = rest[k].get();
+					if (g < 0) failed = true;
+					else if (whole) { got += size_t(g); whole = size_t(g) == std::min(piece, ask - (k + 1) * piece); }
 				}
+				if (failed) { st.error = "Can't read BAM file"; return st; }
 				size_t o = 0, n_blocks = 0;                      // whole blocks: up to `want` bytes of them (at least one), and no more than the device inflates at once
 				while (o + 18 <= got && (o < want || o == 0) && n_blocks < block_cap) {
 					const uint8_t *h = st.p + o;
@@ -1045,6 +1064,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				}
 				if (!o && got) { st.error = "Truncated BGZF block"; return st; }
 				st.used = o; file_at += o; st.final = file_at >= map.n;
+				if (upload_ahead) (void)dropest_bam_decoder_upload(dec, which, o);   // on its way while the window before it is in the kernels (if this fails, the window call copies)
 				return st;
 			};
 			bool first = true, dict_dirty = true;

@@ -83,6 +83,11 @@ uint32_t dropest_bam_decoder_wave_slots(const dropest_bam_decoder *d);
 /* Two pinned host buffers of the decoder for the caller's compressed bytes (which = 0 / 1, at least `bytes` long): a window handed over from
  * one of them crosses PCIe at the link's rate; any other host memory works too (pageable memory is staged by the runtime at a third of it). */
 int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, uint64_t bytes, uint8_t **out);
+/* The first `len` bytes of staging buffer `which` start for the device now, on a stream of their own; the window call that is given exactly that
+ * buffer and length then waits for this copy instead of making one.  For a reader thread that calls it when its read is done: the copy of
+ * window k + 1 runs under the kernels of window k.  The one decoder call that may run beside a window call; allocates nothing; a length the
+ * buffers were not sized for is left to the window call (0 is returned all the same). */
+int dropest_bam_decoder_upload(dropest_bam_decoder *d, int which, uint64_t len);
 void dropest_bam_decoder_destroy(dropest_bam_decoder *d);
 /* comp[0 .. len): whole BGZF blocks, following the previous window's.  first_skip: bytes of the first block to pass over (the BAM header;
  * first window only).  final != 0: the file ends here (a cut-off record is then an error). */
