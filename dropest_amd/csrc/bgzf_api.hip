@@ -154,6 +154,7 @@ struct dropest_bam_decoder {
 	BamParseCfg cfg{};
 	BamFront front[2];
 	int next_front = 0, last_front = 0;
+	bool halves_in_sequence = false;   // dropest_bam_decoder_window is running: its first half uses `stream`
 	DevBuf<uint8_t> d_tail, d_gather;
 	DevBuf<uint64_t> rec_off, d_goff;
 	DevBuf<uint32_t> d_gidx, d_gsize;
@@ -173,7 +174,7 @@ struct dropest_bam_decoder {
 	uint32_t g_mask = 0;
 	uint64_t tail_len = 0, last_n_rec = 0, last_n_ok = 0;
 	// the compressed bytes of a staging buffer on their way to the device ahead of the window call (dropest_bam_decoder_upload)
-	hipStream_t up_stream = nullptr;
+	hipStream_t up_stream = nullptr;   // the device's null stream: it exists already (a stream of its own is 6-8 ms to create), and the decoder's other streams do not wait for it (non-blocking)
 	hipEvent_t up_done[2] = {nullptr, nullptr};
 	DevBuf<uint8_t> up_in[2];
 	uint64_t up_len[2] = {0, 0};
@@ -215,14 +216,22 @@ extern "C" int dropest_bam_decoder_create(int device, const dropest_bam_parse_cf
 		d->device = device;
 		std::memcpy(&d->cfg, cfg, sizeof(BamParseCfg));
 		try {
+			using clk = std::chrono::steady_clock;
+			const bool trace = getenv("DROPEST_BAM_TRACE") != nullptr;
+			auto t0 = clk::now();
+			auto lap = [&](const char *what) { if (trace) { std::fprintf(stderr, "[bam] decoder: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(clk::now() - t0).count()); t0 = clk::now(); } };
 			HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-			for (BamFront &f : d->front) HIP_CHECK(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking));
-			HIP_CHECK(hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking));
+			lap("first stream");
+			// (a stream is 6-8 ms to create: the first halves' own streams are made when a caller first asks for them --
+			// dropest_bam_decoder_window_begin called directly -- and dropest_bam_decoder_upload sends on the null stream)
 			for (hipEvent_t &e : d->up_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			lap("events");
 			// empty dictionaries: every gene and chromosome is new
 			d->g_mask = 1023; d->g_keys.alloc(1024); d->g_vals.alloc(1024); d->d_chr.alloc(size_t(std::max(1, cfg->n_refs)));
+			lap("dictionary buffers");
 			HIP_CHECK(hipMemset(d->g_vals.p, 0, 1024 * 4));
 			HIP_CHECK(hipMemset(d->d_chr.p, 0xFF, size_t(std::max(1, cfg->n_refs)) * 4));
+			lap("two memsets");
 		} catch (...) { delete d; throw; }
 		*out = d;
 	});
@@ -237,7 +246,7 @@ extern "C" int dropest_bam_decoder_reset(dropest_bam_decoder *d, const dropest_b
 		if (cfg->n_refs < 0) throw InvalidError("negative number of references");
 		HIP_CHECK(hipSetDevice(d->device));
 		HIP_CHECK(hipStreamSynchronize(d->stream));
-		for (BamFront &f : d->front) { HIP_CHECK(hipStreamSynchronize(f.stream)); f.begun = false; }
+		for (BamFront &f : d->front) { if (f.stream) HIP_CHECK(hipStreamSynchronize(f.stream)); f.begun = false; }
 		HIP_CHECK(hipStreamSynchronize(d->up_stream));
 		d->up_ready[0] = d->up_ready[1] = false;
 		std::memcpy(&d->cfg, cfg, sizeof(BamParseCfg));
@@ -261,7 +270,12 @@ extern "C" int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, ui
 	return bgzf_guarded([&] {
 		if (!d || !out || which < 0 || which > 1) throw InvalidError("bad argument");
 		HIP_CHECK(hipSetDevice(d->device));
+		using clk = std::chrono::steady_clock;
+		const bool trace = getenv("DROPEST_BAM_TRACE") != nullptr;
+		auto t0 = clk::now();
+		auto lap = [&](const char *what) { if (trace) { std::fprintf(stderr, "[bam] staging %d: %s %.1f ms\n", which, what, std::chrono::duration<double, std::milli>(clk::now() - t0).count()); t0 = clk::now(); } };
 		d->h_stage[which].ensure(bytes);
+		lap("pinned buffer");
 		*out = d->h_stage[which].p;
 		// the size of the caller's windows is known now: room for them up front (a BAM inflates ~4-12 x, a record is >= ~120 bytes), so that the
 		// first windows do not grow every buffer step by step (each growth is a free + an allocation that wait for the device)
@@ -277,6 +291,7 @@ extern "C" int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, ui
 			d->o_status.ensure(n_rec); d->o_need.ensure(n_rec); d->dn_cb.ensure(n_rec); d->dn_umi.ensure(n_rec); d->dn_gene.ensure(n_rec); d->dn_aux.ensure(n_rec);
 			d->nd_rec.ensure(n_rec); d->nd_pos.ensure(n_rec); d->nd_size.ensure(n_rec);
 		}
+		lap("device buffers");
 	});
 }
 
@@ -302,7 +317,7 @@ extern "C" int dropest_bam_decoder_upload(dropest_bam_decoder *d, int which, uin
 extern "C" void dropest_bam_decoder_destroy(dropest_bam_decoder *d) {
 	if (!d) return;
 	(void)hipSetDevice(d->device);
-	if (d->up_stream) { (void)hipStreamSynchronize(d->up_stream); (void)hipStreamDestroy(d->up_stream); }
+	(void)hipStreamSynchronize(d->up_stream);
 	for (hipEvent_t e : d->up_done) if (e) (void)hipEventDestroy(e);
 	if (d->stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
 	for (BamFront &f : d->front) if (f.stream) { (void)hipStreamSynchronize(f.stream); (void)hipStreamDestroy(f.stream); }
@@ -376,7 +391,10 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 		using clk = std::chrono::steady_clock;
 		auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
 		HIP_CHECK(hipSetDevice(dec->device));
-		hipStream_t st = d->stream;
+		// the first half of a window on a stream of its own, for a caller that runs it beside the second half of the window before; the two
+		// halves one after the other (dropest_bam_decoder_window) share the decoder's stream
+		if (!dec->halves_in_sequence && !d->stream) HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+		hipStream_t st = dec->halves_in_sequence ? dec->stream : d->stream;
 		// 1. the blocks
 		int up = -1;      // the bytes went ahead (dropest_bam_decoder_upload)
 		for (int w = 0; w < 2; ++w)
@@ -564,7 +582,10 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 extern "C" int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
                                           dropest_bgzf_host_inflate inflate_fallback, void *user, dropest_bam_window *out) {
 	int slot = 0;
-	if (dropest_bam_decoder_window_begin(d, comp, len, first_skip, final, inflate_fallback, user, &slot)) return 1;
+	if (d) d->halves_in_sequence = true;
+	const int rc = dropest_bam_decoder_window_begin(d, comp, len, first_skip, final, inflate_fallback, user, &slot);
+	if (d) d->halves_in_sequence = false;
+	if (rc) return 1;
 	return dropest_bam_decoder_window_finish(d, slot, out);
 }
 

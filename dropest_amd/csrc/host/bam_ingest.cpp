@@ -1015,13 +1015,13 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			struct Staged { uint8_t *p = nullptr; size_t used = 0; bool final = false; std::string error; };
 			const size_t stage_cap = window_max + (size_t(1) << 17);
 			uint8_t *stage_p[2] = {nullptr, nullptr};
+			const bool upload_ahead = !getenv("DROPEST_BAM_NO_UPLOAD_AHEAD");
 			for (int k = 0; k < 2; ++k)      // (pinning 2 x 80 MB and reserving a window's device buffers: 35-50 ms; side by side on two threads they take as long)
 				if (dropest_bam_decoder_staging(dec, k, stage_cap, &stage_p[k])) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
 			const double ms_setup = since(t_file);
 			double ms_wait_read = 0, ms_window_calls = 0;
 			size_t file_at = c0;
 			const size_t block_cap = getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? size_t(-1) : std::max<size_t>(1024, dropest_bam_decoder_wave_slots(dec)) * (long_file ? 2 : 1);   // (one wave per block: a full machine's worth per window)
-			const bool upload_ahead = !getenv("DROPEST_BAM_NO_UPLOAD_AHEAD");
 			auto read_window = [&](int which, size_t want) {
 				Staged st; st.p = stage_p[which];
 				const size_t ask = std::min(std::min(want + (size_t(1) << 16) + 64, stage_cap), map.n - file_at);

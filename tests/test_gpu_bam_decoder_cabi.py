@@ -157,5 +157,38 @@ def test_one_window_through_the_c_abi(tmp_path):
     assert L.dropest_bam_decoder_reset(dec, C.byref(cfg)) == 0
     w = window()
     assert w.n_need == len(ok_idx)
+    # the same bytes from the decoder's pinned staging buffer, sent ahead of the window call (dropest_bam_decoder_upload: what a reader thread does
+    # while the window before is in the kernels): the same window; a second call with that buffer (nothing sent ahead) copies by itself
+    L.dropest_bam_decoder_staging.argtypes = [C.c_void_p, C.c_int, C.c_uint64, P(C.c_void_p)]
+    L.dropest_bam_decoder_upload.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+    stage = C.c_void_p()
+    assert L.dropest_bam_decoder_staging(dec, 1, len(comp) + 4096, C.byref(stage)) == 0, L.dropest_bgzf_last_error()
+    C.memmove(stage, comp.ctypes.data, len(comp))
+    for ahead in (True, False, True):
+        assert L.dropest_bam_decoder_reset(dec, C.byref(cfg)) == 0
+        if ahead:
+            assert L.dropest_bam_decoder_upload(dec, 1, len(comp)) == 0
+        w2 = Window()
+        assert L.dropest_bam_decoder_window(dec, stage, len(comp), u0, 1, None, None, C.byref(w2)) == 0, L.dropest_bgzf_last_error()
+        assert (w2.n_records, w2.n_accepted, w2.n_need, list(w2.counts)) == (w.n_records, w.n_accepted, w.n_need, list(w.counts))
+        assert columns(L, dec, int(w2.n_accepted))[0].tolist() == cbc.tolist()
+    # bytes sent ahead that are not whole blocks: the window call says so (not the upload)
+    assert L.dropest_bam_decoder_reset(dec, C.byref(cfg)) == 0
+    assert L.dropest_bam_decoder_upload(dec, 1, len(comp) - 5) == 0
+    w2 = Window()
+    assert L.dropest_bam_decoder_window(dec, stage, len(comp) - 5, u0, 1, None, None, C.byref(w2)) != 0
+    assert L.dropest_bam_decoder_upload(dec, 1, 1 << 40) == 0 and L.dropest_bam_decoder_upload(dec, 2, 10) != 0      # too long: left to the window call; no such buffer
+    # the window call in its two halves (first: copy, inflate, chain, on a stream of its own; second: fields and dense columns)
+    L.dropest_bam_decoder_window_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, P(C.c_int)]
+    L.dropest_bam_decoder_window_finish.argtypes = [C.c_void_p, C.c_int, P(Window)]
+    for rep in range(2):
+        assert L.dropest_bam_decoder_reset(dec, C.byref(cfg)) == 0
+        slot, w3 = C.c_int(-1), Window()
+        assert L.dropest_bam_decoder_window_begin(dec, comp.ctypes.data, len(comp), u0, 1, None, None, C.byref(slot)) == 0, L.dropest_bgzf_last_error()
+        assert slot.value in (0, 1)
+        assert L.dropest_bam_decoder_window_finish(dec, slot.value, C.byref(w3)) == 0, L.dropest_bgzf_last_error()
+        assert (w3.n_records, w3.n_accepted, w3.n_need, list(w3.counts)) == (w.n_records, w.n_accepted, w.n_need, list(w.counts))
+        assert columns(L, dec, int(w3.n_accepted))[0].tolist() == cbc.tolist()
+        assert L.dropest_bam_decoder_window_finish(dec, slot.value, C.byref(w3)) != 0 and b"not begun" in L.dropest_bgzf_last_error()
     L.dropest_bam_decoder_destroy.argtypes = [C.c_void_p]
     L.dropest_bam_decoder_destroy(dec)
