@@ -7,11 +7,11 @@
 // (all lanes compute the same thing, LDS look-ups are broadcasts) and uses its 64 lanes where the format allows:
 //   * the input is staged through a 1 KB ring in LDS, 512 bytes per coalesced load;
 //   * Huffman tables are built with ballots (rank of a symbol among the symbols of its code length), 64 symbols per step;
-//   * literals are collected in LDS and stored 64 at a time; a match is copied by all lanes, 64 bytes per step.
+//   * literals wait in a register of the lane they will be stored by and leave 64 at a time; a match is copied by all lanes, 64 bytes per step.
 // Tables per wave: a 10-bit root table for literal / length codes and an 8-bit one for distances (u16 entries: symbol << 4 | length);
 // longer codes (rare symbols) are decoded canonically from the per-length counts, bit by bit (the method of zlib's puff.c).
 // Written from RFC 1951.  ISIZE and, when the caller hands over the stored values, the CRC-32 of every block are checked (inf_crc32_block).
-// Integer work; no MFMA.  4.7 KB of LDS per wave: 8 workgroups of 4 waves per CU.
+// Integer work; no MFMA.  4.6 KB of LDS per wave + 4.9 KB per workgroup (CRC-32 tables, base tables): 6 workgroups of 4 waves per CU.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -33,7 +33,6 @@ struct InfWaveLds {
 	uint16_t lcount[16], dcount[16];
 	uint8_t lens[320];       // HLIT + HDIST code lengths
 	uint64_t in[128];        // input ring: the 1 024 bytes around the read position, indexed by (absolute offset / 8) mod 128
-	uint8_t lit[64];         // literals waiting for their store
 };
 
 __constant__ const uint16_t INF_LEN_BASE[32] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 0, 0, 0};
@@ -252,9 +251,10 @@ __global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 	uint8_t *const out = d_out + out_off[blk];
 	const uint32_t out_cap = out_len[blk];
 	uint32_t pos = 0, nlit = 0, err = INF_OK;
+	uint32_t mylit = 0;      // literal number `lane` of those waiting for their store (a register per lane: no LDS round for a literal)
 
 	auto flush = [&]() {
-		if (nlit) { if (lane < nlit) out[pos + lane] = L.lit[lane]; pos += nlit; nlit = 0; }
+		if (nlit) { if (lane < nlit) out[pos + lane] = uint8_t(mylit); pos += nlit; nlit = 0; }
 	};
 
 	for (bool last = false; !last && !err;) {
@@ -316,9 +316,10 @@ __global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 		if (!inf_build(L.lens + hlit, hdist, INF_DROOT, L.droot, L.dsym, L.dcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
 
 		for (;;) {
-			const uint32_t sy = inf_decode(s, L, lane, L.lroot, INF_LROOT, L.lsym, L.lcount);
+			// (named uniform: the three comparisons below are then the scalar unit's, without a round through the execution mask)
+			const uint32_t sy = inf_uni(inf_decode(s, L, lane, L.lroot, INF_LROOT, L.lsym, L.lcount));
 			if (sy < 256u) {
-				if (lane == 0) L.lit[nlit] = uint8_t(sy);
+				mylit = lane == nlit ? sy : mylit;
 				if (++nlit == 64u) { if (pos + 64u > out_cap) { err = INF_OUTPUT_OVERRUN; break; } flush(); }
 				continue;
 			}
