@@ -519,6 +519,37 @@ def measure_bam_ingest(n_reads=250_000, copies=64, threads=16):
             assert st["saved"] == n_reads * copies
             uq[label + "_ingest_ms"] = st["ingest_ms"]; uq[label + "_Mreads_per_s"] = round(n_reads * copies / st["ingest_ms"] / 1e3, 1)
         out["with_uq_tags"] = uq
+        # ... and with bases drawn at random and binned qualities (75 % 'F', the rest ':' ',' '#'): such a file deflates ~3.2 x, as real 10x BAMs do,
+        # not 10.8 x like the one above (one sequence, no qualities) -- most DEFLATE symbols are literals then, and the inflate kernel is bound by its
+        # instructions per symbol (profiles/NOTES_r05.md, section 13)
+        rng = np.random.default_rng(5)
+        nib = rng.choice(np.array([1, 2, 4, 8], np.uint8), (n_reads, 98))
+        packed_seq = ((nib[:, 0::2] << 4) | nib[:, 1::2]).astype(np.uint8)
+        quals = rng.choice(np.array([37, 25, 11, 2], np.uint8), (n_reads, 98), p=[0.75, 0.12, 0.08, 0.05])
+        recs_real = []
+        for i, r in enumerate(recs):
+            r = bytearray(r)
+            o = 36 + r[12] + 4              # block_size + the fixed fields + the name (l_read_name, with its NUL) + one CIGAR operation
+            r[o:o + 49] = packed_seq[i].tobytes(); r[o + 49:o + 147] = quals[i].tobytes()
+            recs_real.append(bytes(r))
+        bam_real = os.path.join(tmp, "synth_real.bam")
+        real_copies = max(1, copies // 2)
+        bw.write_bam(bam_real, [("chr%d" % i, 10_000_000) for i in range(25)], recs_real, repeat=real_copies)
+        real = {"reads": n_reads * real_copies, "bam_MB": round(os.path.getsize(bam_real) / 1e6, 1)}
+        for label, env in (("host_reader", {}), ("device", {"DROPEST_BAM_DEVICE": "1"})):
+            res = subprocess.run([tool, os.path.join(tmp, "out"), "filled", "20", "100", "-", str(threads), bam_real], capture_output=True, text=True,
+                                 env=dict(os.environ, **env), timeout=600)
+            if res.returncode:
+                raise RuntimeError(res.stderr[-300:])
+            st = json.loads(res.stdout.strip().splitlines()[-1])
+            assert st["saved"] == n_reads * real_copies
+            real[label + "_ingest_ms"] = st["ingest_ms"]; real[label + "_Mreads_per_s"] = round(n_reads * real_copies / st["ingest_ms"] / 1e3, 1)
+        blob = np.fromfile(bam_real, np.uint8)
+        status = np.zeros(len(blob) // 26 + 1, np.uint32)
+        if L.dropest_bgzf_inflate_buffer(0, blob.ctypes.data, len(blob), None, 1 << 62, C.byref(n_out), status.ctypes.data, len(status), C.byref(n_blocks), C.byref(ms), 3) == 0:
+            real.update(inflate_kernel_ms=round(ms.value, 3), inflate_GB_per_s=round(n_out.value / 1e6 / ms.value, 1), deflate_ratio=round(n_out.value / len(blob), 2),
+                        blocks_refused=int((status[:n_blocks.value] != 0).sum()))
+        out["file_that_deflates_3x"] = real
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -553,6 +584,9 @@ def finish_line(line):
         summary.update(bam_device_Mreads_per_s=bi["device_Mreads_per_s"], bam_host_reader_Mreads_per_s=bi["host_reader_Mreads_per_s"], bam_inflate_GB_per_s=bi.get("inflate_GB_per_s"))
         if "with_uq_tags" in bi:
             summary.update(bam_uq_device_Mreads_per_s=bi["with_uq_tags"].get("device_Mreads_per_s"), bam_uq_host_reader_Mreads_per_s=bi["with_uq_tags"].get("host_reader_Mreads_per_s"))
+        if "file_that_deflates_3x" in bi:
+            r3 = bi["file_that_deflates_3x"]
+            summary.update(bam_3x_device_Mreads_per_s=r3.get("device_Mreads_per_s"), bam_3x_host_reader_Mreads_per_s=r3.get("host_reader_Mreads_per_s"), bam_3x_inflate_GB_per_s=r3.get("inflate_GB_per_s"))
     elif "error" in bi:
         summary["bam_ingest_error"] = bi["error"][:200]
     for k, v in summary.items():           # scalars only: they survive in the parsed record's `config`

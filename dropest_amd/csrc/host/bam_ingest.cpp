@@ -1009,7 +1009,25 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			// windows: a machine's worth of blocks (one wave per block) in a file of a few hundred MB, two in a long one (measured on 0.4 and 1.6 GB:
 			// NOTES_r05 §11) -- the pinned staging buffers of larger windows cost more to allocate than their fuller kernels give back
 			const bool long_file = map.n > (size_t(1) << 30);
-			const size_t window_max = size_t(getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? std::max(1, atoi(getenv("DROPEST_BAM_DEVICE_WINDOW_MB"))) : (long_file ? 80 : 48)) << 20;
+			size_t window_max = size_t(getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? std::max(1, atoi(getenv("DROPEST_BAM_DEVICE_WINDOW_MB"))) : (long_file ? 80 : 48)) << 20;
+			if (!getenv("DROPEST_BAM_DEVICE_WINDOW_MB")) {
+				// ... of blocks, not of bytes: a file that deflates 3 x (real bases and qualities) has blocks of ~20 KB where the 10 x synthetic ones have 6 KB,
+				// and a window of 48 MB of them would fill a third of the wave slots -- each window takes the time of ONE block however many it holds.
+				// The blocks behind the header say how large they are; up to 128 / 256 MB of staging (9.5 ms of pinning per 48 MB: NOTES_r05 section 13).
+				size_t at = c0, n_seen = 0, bytes_seen = 0;
+				while (n_seen < 64 && at + 18 <= map.n && map.p[at] == 31 && map.p[at + 1] == 139) {
+					const size_t xlen = le16(map.p + at + 10);
+					size_t bsize = 0;
+					for (size_t x = 0; x + 4 <= xlen && at + 12 + x + 6 <= map.n;) { const uint8_t *sf = map.p + at + 12 + x; const size_t sl = le16(sf + 2); if (sf[0] == 'B' && sf[1] == 'C' && sl == 2) bsize = size_t(le16(sf + 4)) + 1; x += 4 + sl; }
+					if (!bsize) break;
+					at += bsize; bytes_seen += bsize; ++n_seen;
+				}
+				if (n_seen >= 8) {
+					const size_t want = std::max<size_t>(1024, dropest_bam_decoder_wave_slots(dec)) * (long_file ? 2 : 1) * (bytes_seen / n_seen + 1);
+					window_max = std::min(std::max(window_max, want), size_t(long_file ? 256 : 128) << 20);
+					window_max = std::min(window_max, std::max<size_t>(map.n - c0, size_t(1) << 20));      // (no more than the file)
+				}
+			}
 			// The compressed bytes reach the device through two pinned buffers of the decoder: a helper thread reads the next window from the file
 			// (pread: page cache -> pinned memory, whole blocks only) while the device and this thread work on the one before.
 			struct Staged { uint8_t *p = nullptr; size_t used = 0; bool final = false; std::string error; };
@@ -1078,7 +1096,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				if (!stg.error.empty()) throw std::runtime_error(stg.error + ": " + bam_name);
 				const bool final = stg.final;
 				const size_t used = stg.used;
-				window_bytes = std::min(window_bytes * 4, window_max);
+				window_bytes = std::min(window_bytes * 4, window_max);       // (1, 4, 16, 64 MB ...: a ramp of x 16 measured the same, 188-201 ms on the 3 x file)
 				which ^= 1;
 				if (!final) next = std::async(std::launch::async, read_window, which, window_bytes);
 				struct Drain { std::future<Staged> &f; bool armed; ~Drain() { if (armed && f.valid()) f.wait(); } } drain{next, !final};   // (an exception below must not leave the reader running on freed buffers)

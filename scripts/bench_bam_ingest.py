@@ -31,6 +31,16 @@ for i in range(n):
     if gene[i] != capi.NO_GENE:
         tags.append(("GX", "Z", "ENSG%011d" % gene[i]))
     recs.append(bw.record(int(aux[i]) & 0xFFFF, i, "A00000:1:HXXXX:1:1101:%d:%d" % (i, i), seq="ACGT" * 24 + "AC", tags=tags))
+if os.environ.get("REAL"):      # bases drawn at random and binned qualities: the file deflates ~3.2 x, as real 10x BAMs do (not 10.8 x)
+    rng = np.random.default_rng(5)
+    nib = rng.choice(np.array([1, 2, 4, 8], np.uint8), (n, 98))
+    packed_seq = ((nib[:, 0::2] << 4) | nib[:, 1::2]).astype(np.uint8)
+    quals = rng.choice(np.array([37, 25, 11, 2], np.uint8), (n, 98), p=[0.75, 0.12, 0.08, 0.05])
+    for i in range(n):
+        r = bytearray(recs[i])
+        o = 36 + r[12] + 4
+        r[o:o + 49] = packed_seq[i].tobytes(); r[o + 49:o + 147] = quals[i].tobytes()
+        recs[i] = bytes(r)
 tmp = tempfile.mkdtemp()
 bam = os.path.join(tmp, "synth.bam")
 copies = int(os.environ.get("COPIES", "16"))
