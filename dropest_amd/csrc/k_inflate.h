@@ -5,13 +5,14 @@
 // DEFLATE stream of <= 64 KB, so blocks are the parallel axis: thousands of them are in flight, one per wave.  Inside a block the
 // symbol stream is serial -- every code's position depends on the one before -- so the wave decodes with wave-uniform values
 // (all lanes compute the same thing, LDS look-ups are broadcasts) and uses its 64 lanes where the format allows:
-//   * the input is staged through a 1 KB ring in LDS, 512 bytes per coalesced load;
+//   * the input is staged through a 512-byte ring in LDS, 256 bytes per coalesced load;
 //   * Huffman tables are built with ballots (rank of a symbol among the symbols of its code length), 64 symbols per step;
 //   * literals wait in a register of the lane they will be stored by and leave 64 at a time; a match is copied by all lanes, 64 bytes per step.
 // Tables per wave: a 10-bit root table for literal / length codes and an 8-bit one for distances (u16 entries: symbol << 4 | length);
 // longer codes (rare symbols) are decoded canonically from the per-length counts, bit by bit (the method of zlib's puff.c).
 // Written from RFC 1951.  ISIZE and, when the caller hands over the stored values, the CRC-32 of every block are checked (inf_crc32_block).
-// Integer work; no MFMA.  4.6 KB of LDS per wave + 4.9 KB per workgroup (CRC-32 tables, base tables): 6 workgroups of 4 waves per CU.
+// Integer work; no MFMA.  4.0 KB of LDS per wave + 5.4 KB per workgroup (CRC-32 tables, base tables): 4 workgroups of 8 waves per CU = 8 waves
+// per SIMD, which the symbol loop (a function of its own: 32 vector registers) can use; the rest of the kernel spills at that budget, off the hot path.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -19,7 +20,7 @@
 
 namespace dropest {
 
-constexpr int INF_WAVES = 4;
+constexpr int INF_WAVES = 8;
 constexpr int INF_LROOT = 10, INF_DROOT = 8;
 // status of a block: 0 = ok; anything else: the block was not (completely) written and the caller inflates it elsewhere
 enum : uint32_t { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_LENGTHS = 3, INF_OVERSUBSCRIBED = 4, INF_BAD_CODE = 5,
@@ -32,7 +33,7 @@ struct InfWaveLds {
 	uint16_t dsym[32];
 	uint16_t lcount[16], dcount[16];
 	uint8_t lens[320];       // HLIT + HDIST code lengths
-	uint64_t in[128];        // input ring: the 1 024 bytes around the read position, indexed by (absolute offset / 8) mod 128
+	uint64_t in[64];         // input ring: the 512 bytes around the read position, indexed by (absolute offset / 8) mod 64
 };
 
 __constant__ const uint16_t INF_LEN_BASE[32] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258, 0, 0, 0};
@@ -58,14 +59,14 @@ __device__ inline uint64_t inf_uni64(uint64_t v) { return uint64_t(inf_uni(uint3
 __device__ inline void inf_ring_fill(InfState &s, InfWaveLds &L, uint32_t lane) {
 	while (s.ipos + 16 > s.loaded_hi) {
 		const uint64_t w = (s.loaded_hi >> 3) + lane;
-		L.in[w & 127u] = w < s.in_words ? s.gin[w] : 0ull;
-		s.loaded_hi += 512;
+		if (lane < 32u) L.in[w & 63u] = w < s.in_words ? s.gin[w] : 0ull;
+		s.loaded_hi += 256;
 	}
 }
 __device__ inline void inf_refill(InfState &s, InfWaveLds &L, uint32_t lane) {   // at least 56 valid bits afterwards
 	inf_ring_fill(s, L, lane);
-	const uint32_t idx = uint32_t(s.ipos >> 3) & 127u, sh = uint32_t(s.ipos & 7u) * 8u;
-	const uint64_t lo = inf_uni64(L.in[idx]), hi = inf_uni64(L.in[(idx + 1u) & 127u]);
+	const uint32_t idx = uint32_t(s.ipos >> 3) & 63u, sh = uint32_t(s.ipos & 7u) * 8u;
+	const uint64_t lo = inf_uni64(L.in[idx]), hi = inf_uni64(L.in[(idx + 1u) & 63u]);
 	const uint64_t w = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
 	s.bits |= w << s.cnt;
 	const int adv = (63 - s.cnt) >> 3;
@@ -210,12 +211,80 @@ __device__ inline uint32_t inf_crc32_block(const uint8_t *out, uint32_t len, con
 	return total;
 }
 
+// The symbols of one DEFLATE block, as a function of its own (a real call): what it keeps -- bit buffer, counts, positions -- is named uniform on
+// entry and nothing lane-dependent decides a branch inside, so the state lives in scalar registers and the scalar unit does the bit-buffer
+// arithmetic (the look-up's address and the literal's select are what is left for the vector unit).  Inlined into the kernel the same code keeps
+// this state in vector registers (the compiler calls the table build's result divergent, and the block loop that hangs on it with it), and named
+// uniform there it spills: the kernel as a whole wants more than a wave's 100 scalar registers (NOTES_r05 §13).
+struct InfLoopIO {
+	uint64_t ipos, loaded_hi, bits;
+	int cnt;
+	uint32_t pos, nlit, mylit, err;
+};
+using InfLdsPtr = __attribute__((address_space(3))) InfWaveLds *;
+using InfLdsU32 = __attribute__((address_space(3))) uint32_t *;
+__device__ __attribute__((noinline)) InfLoopIO inf_symbol_loop(InfLoopIO io, const uint64_t *gin, uint64_t in_words, uint32_t lds_wave, uint32_t lds_len_tab, uint32_t lds_dist_tab,
+                                                               uint8_t *out_, uint32_t out_cap_) {
+	const uint32_t lane = threadIdx.x & 63u;
+	InfWaveLds &L = *(InfWaveLds *)(InfLdsPtr)(uintptr_t)inf_uni(lds_wave);
+	const uint32_t *len_tab = (const uint32_t *)(InfLdsU32)(uintptr_t)inf_uni(lds_len_tab), *dist_tab = (const uint32_t *)(InfLdsU32)(uintptr_t)inf_uni(lds_dist_tab);
+	using GlobalU8 = __attribute__((address_space(1))) uint8_t *;      // (device memory said aloud: global_, not flat_ loads and stores)
+	const GlobalU8 out = (GlobalU8)(uintptr_t)inf_uni64(reinterpret_cast<uint64_t>(out_));
+	const uint32_t out_cap = inf_uni(out_cap_);
+	InfState s;
+	s.gin = reinterpret_cast<const uint64_t *>(inf_uni64(reinterpret_cast<uint64_t>(gin))); s.in_words = inf_uni64(in_words);
+	s.ipos = inf_uni64(io.ipos); s.loaded_hi = inf_uni64(io.loaded_hi); s.bits = inf_uni64(io.bits); s.cnt = int(inf_uni(uint32_t(io.cnt)));
+	uint32_t pos = inf_uni(io.pos), nlit = inf_uni(io.nlit), err = INF_OK;
+	uint32_t mylit = io.mylit;      // literal number `lane` of those waiting for their store (a register per lane: no LDS round for a literal)
+	auto flush = [&]() {
+		if (nlit) { if (lane < nlit) out[pos + lane] = uint8_t(mylit); pos += nlit; nlit = 0; }
+	};
+	for (;;) {
+		const uint32_t sy = inf_uni(inf_decode(s, L, lane, L.lroot, INF_LROOT, L.lsym, L.lcount));
+		if (sy < 256u) {
+			mylit = lane == nlit ? sy : mylit;
+			if (++nlit == 64u) { if (pos + 64u > out_cap) { err = INF_OUTPUT_OVERRUN; break; } flush(); }
+			continue;
+		}
+		if (sy == 256u) break;
+		if (sy > 285u) { err = INF_BAD_CODE; break; }
+		if (pos + nlit > out_cap) { err = INF_OUTPUT_OVERRUN; break; }
+		flush();
+		const uint32_t li = sy - 257u;
+		const uint32_t lt = inf_uni(len_tab[li]);
+		uint32_t len = lt & 0xFFFFu;
+		const int le = int(lt >> 16);
+		if (le) len += inf_take(s, L, lane, le);
+		const uint32_t ds = inf_uni(inf_decode(s, L, lane, L.droot, INF_DROOT, L.dsym, L.dcount));
+		if (ds > 29u) { err = INF_BAD_CODE; break; }
+		const uint32_t dt = inf_uni(dist_tab[ds]);
+		uint32_t dist = dt & 0xFFFFu;
+		const int de = int(dt >> 16);
+		if (de) dist += inf_take(s, L, lane, de);
+		if (dist > pos) { err = INF_BAD_DISTANCE; break; }
+		if (pos + len > out_cap) { err = INF_OUTPUT_OVERRUN; break; }
+		// the source window [pos - dist, pos) is complete: a copy longer than dist repeats it
+#ifndef INF_NO_FENCE
+		__threadfence_block();   // this wave's earlier stores, before other lanes read them
+#endif
+		const GlobalU8 src = out + (pos - dist);
+		if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) out[pos + i] = src[i]; }
+		else { for (uint32_t i = lane; i < len; i += 64) out[pos + i] = src[i % dist]; }
+		pos += len;
+	}
+	InfLoopIO r;
+	r.ipos = s.ipos; r.loaded_hi = s.loaded_hi; r.bits = s.bits; r.cnt = s.cnt; r.pos = pos; r.nlit = nlit; r.mylit = mylit; r.err = err;
+	return r;
+}
+
 // One BGZF block per wave.  in_off / in_len: the DEFLATE payload inside d_in (behind the 18-byte header); out_off / out_len: where its
 // ISIZE bytes go in d_out.  d_in must be 8-byte aligned and in_total_len is the number of bytes that may be read.
-// Waves per SIMD the register allocation aims at: measured on a 3.3 GB synthetic 10x BAM (scripts/experiments/inflate_variants/run.sh):
-// 4 (no spills) 77.5 GB/s, 5: 91.6, 6: 104.2, 8 (55 VGPRs spilled): 83.7.  The fence before a match copy costs nothing at any of them.
+// Waves per SIMD the register allocation aims at (scripts/experiments/inflate_variants/run.sh; 3.3 GB synthetic 10x BAM / the same with random
+// bases and binned qualities): with the symbol loop inlined 4 / 5 / 6 waves gave 84.5 / 99.9 / 112.2 and 31.6 / 37.6 / 40.0 GB/s, and 8 real waves
+// 85.3 / 30.0 (the loop's state spilled); with the loop as a function of its own 6 waves 103.2 / 37.8 and 8 waves 131.3 / 44.7 (kept).  The fence
+// before a match copy costs nothing at any of them.
 #ifndef INF_WAVES_PER_EU
-#define INF_WAVES_PER_EU 6
+#define INF_WAVES_PER_EU 8
 #endif
 __global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(INF_WAVES_PER_EU, INF_WAVES_PER_EU))) void bgzf_inflate_kernel(const uint8_t *__restrict__ d_in, uint64_t in_total_len,
                                                                        const uint64_t *__restrict__ in_off, const uint32_t *__restrict__ in_len,
@@ -226,12 +295,11 @@ __global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 	__shared__ uint32_t crc_tab[4 * 256];               // slicing by 4: table k advances a byte that has k more bytes behind it in the word
 	__shared__ uint32_t crc_x2n[INF_WAVES][32];
 	if (crc32) {
-		uint32_t c = threadIdx.x;                       // 256 threads: one entry of every table each
+		uint32_t c = threadIdx.x & 255u;                // the first 256 threads: one entry of every table each
 		for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ INF_CRC_POLY : c >> 1;
-		crc_tab[threadIdx.x] = c;
+		if (threadIdx.x < 256) crc_tab[threadIdx.x] = c;
 		__syncthreads();
-		for (int t = 1; t < 4; ++t) { c = (c >> 8) ^ crc_tab[c & 0xFFu]; crc_tab[t * 256 + threadIdx.x] = c; }
-		__syncthreads();
+		for (int t = 1; t < 4; ++t) { c = (c >> 8) ^ crc_tab[c & 0xFFu]; if (threadIdx.x < 256) crc_tab[t * 256 + threadIdx.x] = c; __syncthreads(); }
 	}
 	// base | extra bits << 16 of the length / distance symbols, in LDS: as __constant__ arrays indexed by a decoded symbol they were two
 	// dependent loads through the vector memory path per match (94.1 -> 110.6 GB/s on the 10x BAM with them here)
@@ -247,7 +315,7 @@ __global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 	s.gin = reinterpret_cast<const uint64_t *>(d_in);
 	s.in_words = (in_total_len + 7) >> 3;
 	const uint64_t in_begin = in_off[blk], in_end = in_begin + in_len[blk];
-	s.ipos = in_begin; s.loaded_hi = in_begin & ~uint64_t(511); s.bits = 0; s.cnt = 0;
+	s.ipos = in_begin; s.loaded_hi = in_begin & ~uint64_t(255); s.bits = 0; s.cnt = 0;
 	uint8_t *const out = d_out + out_off[blk];
 	const uint32_t out_cap = out_len[blk];
 	uint32_t pos = 0, nlit = 0, err = INF_OK;
@@ -272,7 +340,7 @@ __global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 			if (pos + len > out_cap) { err = INF_OUTPUT_OVERRUN; break; }
 			for (uint32_t i = lane; i < len; i += 64) out[pos + i] = d_in[from + i];
 			pos += len;
-			s.ipos = from + len; s.bits = 0; s.cnt = 0; s.loaded_hi = s.ipos & ~uint64_t(511);
+			s.ipos = from + len; s.bits = 0; s.cnt = 0; s.loaded_hi = s.ipos & ~uint64_t(255);
 			continue;
 		}
 		if (type == 3) { err = INF_BAD_BLOCK_TYPE; break; }
@@ -315,39 +383,11 @@ __global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 		if (!inf_build(L.lens, hlit, INF_LROOT, L.lroot, L.lsym, L.lcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
 		if (!inf_build(L.lens + hlit, hdist, INF_DROOT, L.droot, L.dsym, L.dcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
 
-		for (;;) {
-			// (named uniform: the three comparisons below are then the scalar unit's, without a round through the execution mask)
-			const uint32_t sy = inf_uni(inf_decode(s, L, lane, L.lroot, INF_LROOT, L.lsym, L.lcount));
-			if (sy < 256u) {
-				mylit = lane == nlit ? sy : mylit;
-				if (++nlit == 64u) { if (pos + 64u > out_cap) { err = INF_OUTPUT_OVERRUN; break; } flush(); }
-				continue;
-			}
-			if (sy == 256u) break;
-			if (sy > 285u) { err = INF_BAD_CODE; break; }
-			if (pos + nlit > out_cap) { err = INF_OUTPUT_OVERRUN; break; }
-			flush();
-			const uint32_t li = sy - 257u;
-			const uint32_t lt = inf_uni(len_tab[li]);
-			uint32_t len = lt & 0xFFFFu;
-			const int le = int(lt >> 16);
-			if (le) len += inf_take(s, L, lane, le);
-			const uint32_t ds = inf_decode(s, L, lane, L.droot, INF_DROOT, L.dsym, L.dcount);
-			if (ds > 29u) { err = INF_BAD_CODE; break; }
-			const uint32_t dt = inf_uni(dist_tab[ds]);
-			uint32_t dist = dt & 0xFFFFu;
-			const int de = int(dt >> 16);
-			if (de) dist += inf_take(s, L, lane, de);
-			if (dist > pos) { err = INF_BAD_DISTANCE; break; }
-			if (pos + len > out_cap) { err = INF_OUTPUT_OVERRUN; break; }
-			// the source window [pos - dist, pos) is complete: a copy longer than dist repeats it
-#ifndef INF_NO_FENCE
-			__threadfence_block();   // this wave's earlier stores, before other lanes read them
-#endif
-			const uint8_t *src = out + (pos - dist);
-			if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) out[pos + i] = src[i]; }
-			else { for (uint32_t i = lane; i < len; i += 64) out[pos + i] = src[i % dist]; }
-			pos += len;
+		{
+			InfLoopIO io;
+			io.ipos = s.ipos; io.loaded_hi = s.loaded_hi; io.bits = s.bits; io.cnt = s.cnt; io.pos = pos; io.nlit = nlit; io.mylit = mylit; io.err = 0;
+			io = inf_symbol_loop(io, s.gin, s.in_words, uint32_t(uintptr_t((InfLdsPtr)&L)), uint32_t(uintptr_t((InfLdsU32)len_tab)), uint32_t(uintptr_t((InfLdsU32)dist_tab)), out, out_cap);
+			s.ipos = io.ipos; s.loaded_hi = io.loaded_hi; s.bits = io.bits; s.cnt = io.cnt; pos = io.pos; nlit = io.nlit; mylit = io.mylit; err = io.err;
 		}
 	}
 	if (!err) {
