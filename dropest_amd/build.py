@@ -8,10 +8,6 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libdropest_amd.so")
 SOURCES = ["dropest_amd.hip", "synth_api.hip", "annotation_api.hip", "bgzf_api.hip"]
-# headers a small translation unit depends on (the others: everything under csrc/ and include/)
-DEPS = {"bgzf_api.hip": ["k_inflate.h", "k_bamparse.h", "util.h", "../../include/dropest_bgzf.h"],
-        "synth_api.hip": ["synth.h", "util.h", "k_cbhash.h", "../../include/dropest_synth.h"],
-        "annotation_api.hip": ["util.h", "../../include/dropest_annotation.h"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-pthread"]
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 
@@ -24,8 +20,14 @@ def _hipcc():
 
 
 def _deps_of(src):
-    if src in DEPS:
-        return [os.path.join(CSRC, src)] + [os.path.join(CSRC, d) for d in DEPS[src] if os.path.exists(os.path.join(CSRC, d))]
+    """What the object of `src` was built from: the compiler's own list (hipcc -MMD writes obj/<name>.d beside the object; ADVICE r5: a hand-kept
+    list went stale).  Without one: every file under csrc/ and include/."""
+    dep = os.path.join(OBJ_DIR, src.replace(".hip", ".d"))
+    if os.path.exists(dep):
+        words = open(dep).read().replace("\\\n", " ").split()
+        files = [w for w in words[1:] if not w.endswith(":") and not w.startswith("/opt/")]
+        if files and all(os.path.exists(f) for f in files):
+            return files
     inc = os.path.join(HERE, "..", "include")
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".hip") or f == src] + [os.path.join(inc, f) for f in os.listdir(inc)]
 
@@ -52,7 +54,7 @@ def build(force=False, verbose=False):
         objs.append(obj)
         if not force and not extra and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps_of(s)):
             continue
-        cmd = [_hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, s), "-o", obj]
+        cmd = [_hipcc()] + FLAGS + extra + ["-MMD", "-MF", obj[:-2] + ".d", "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

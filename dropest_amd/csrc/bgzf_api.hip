@@ -5,6 +5,7 @@
 #include "k_bamparse.h"
 #include "util.h"
 
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <string>
@@ -178,7 +179,7 @@ struct dropest_bam_decoder {
 	hipEvent_t up_done[2] = {nullptr, nullptr};
 	DevBuf<uint8_t> up_in[2];
 	uint64_t up_len[2] = {0, 0};
-	bool up_ready[2] = {false, false};
+	std::atomic<bool> up_ready[2] = {{false}, {false}};   // written by the reader thread (dropest_bam_decoder_upload), read by the window call: release / acquire around up_len / up_blocks
 	// ... and their block table, made by the same caller (a walk from header to header is one cache miss per block: ~2 ms per 64 MB window)
 	struct UpBlocks { std::vector<uint64_t> in_off, out_off; std::vector<uint32_t> in_len, out_len, crc; uint64_t n = 0, used = 0, total = 0; bool ok = false; } up_blocks[2];
 };
@@ -248,7 +249,7 @@ extern "C" int dropest_bam_decoder_reset(dropest_bam_decoder *d, const dropest_b
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		for (BamFront &f : d->front) { if (f.stream) HIP_CHECK(hipStreamSynchronize(f.stream)); f.begun = false; }
 		HIP_CHECK(hipStreamSynchronize(d->up_stream));
-		d->up_ready[0] = d->up_ready[1] = false;
+		d->up_ready[0].store(false, std::memory_order_relaxed); d->up_ready[1].store(false, std::memory_order_relaxed);
 		std::memcpy(&d->cfg, cfg, sizeof(BamParseCfg));
 		d->tail_len = 0; d->last_n_rec = 0; d->last_n_ok = 0; d->next_front = 0; d->last_front = 0;
 		d->annotation = nullptr; d->n_ann_genes = 0;
@@ -301,7 +302,7 @@ extern "C" int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, ui
 // (from another thread).  A length the buffers were not sized for is not an error: the window call copies as before.
 extern "C" int dropest_bam_decoder_upload(dropest_bam_decoder *d, int which, uint64_t len) {
 	if (!d || which < 0 || which > 1) return 1;
-	d->up_ready[which] = false;
+	d->up_ready[which].store(false, std::memory_order_relaxed);
 	if (!len || !d->h_stage[which].p || len > d->h_stage[which].n || len + 8 > d->up_in[which].n) return 0;
 	if (hipSetDevice(d->device) != hipSuccess) return 1;
 	if (hipMemcpyAsync(d->up_in[which].p, d->h_stage[which].p, len, hipMemcpyHostToDevice, d->up_stream) != hipSuccess) return 1;
@@ -310,7 +311,7 @@ extern "C" int dropest_bam_decoder_upload(dropest_bam_decoder *d, int which, uin
 	b.ok = false;
 	try { b.ok = bgzf_block_table(d->h_stage[which].p, len, b.in_off, b.out_off, b.in_len, b.out_len, b.crc, &b.n, &b.used, &b.total); } catch (...) { b.ok = false; }
 	d->up_len[which] = len;
-	d->up_ready[which] = true;
+	d->up_ready[which].store(true, std::memory_order_release);
 	return 0;
 }
 
@@ -398,7 +399,8 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 		// 1. the blocks
 		int up = -1;      // the bytes went ahead (dropest_bam_decoder_upload)
 		for (int w = 0; w < 2; ++w)
-			if (dec->up_ready[w] && comp == dec->h_stage[w].p && len == dec->up_len[w]) { up = w; dec->up_ready[w] = false; }
+			// (the buffer first: only the slot these bytes stand in is looked at -- the reader thread may be filling the other one right now)
+			if (comp == dec->h_stage[w].p && dec->up_ready[w].load(std::memory_order_acquire) && len == dec->up_len[w]) { up = w; dec->up_ready[w].store(false, std::memory_order_relaxed); }
 		uint64_t n = 0, used = 0, total = 0;
 		if (up >= 0 && dec->up_blocks[up].ok) {
 			auto &b = dec->up_blocks[up];
@@ -543,7 +545,7 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			const BamDict dict{d->g_keys.p, d->g_vals.p, d->g_mask, d->d_chr.p, d->annotation ? d->d_ann_chr.p : nullptr, d->annotation ? d->d_ann_id.p : nullptr};
 			const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, d->nd_rec.p, d->nd_pos.p, d->nd_size.p, d->dn_qoff.p};
 			if (d->annotation) HIP_CHECK(hipMemsetAsync(d->a_chr.p, 0xFF, size_t(n_rec) * 4, st));   // (records that are not accepted: "no such chromosome", ignored)
-			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + BAM_PARSE_T - 1) / BAM_PARSE_T)), dim3(BAM_PARSE_T), 0, st, F.d_out.p, d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro);
+			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + BAM_PARSE_T - 1) / BAM_PARSE_T)), dim3(BAM_PARSE_T), 0, st, F.d_out.p, d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro, F.d_bad.p);
 			if (d->annotation) {
 				if (dropest_annotation_query_device(d->annotation, st, n_rec, d->a_chr.p, d->a_pos.p, d->a_end.p, d->a_gene.p, d->a_mark.p)) throw DeviceError(dropest_annotation_last_error());
 				hipLaunchKernelGGL(bam_resolve_annotated_kernel, dim3(uint32_t((n_rec + 255) / 256)), dim3(256), 0, st, uint32_t(n_rec), dict, ro, d->a_gene.p, d->a_mark.p);
@@ -557,7 +559,7 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			HIP_CHECK(hipMemcpyAsync(&bad_record, F.d_bad.p, 4, hipMemcpyDeviceToHost, st));
 		}
 		HIP_CHECK(hipStreamSynchronize(st));
-		if (bad_record) throw InvalidError("Corrupt BAM record");      // (a block_size below the 32 bytes of a record's fixed part, met by the walk from the checked starts)
+		if (bad_record) throw InvalidError("Corrupt BAM record");      // (a block_size below the 32 bytes of a record's fixed part or beyond 2^26, met by the walk from the checked starts; fixed part + name + cigar + bases longer than the record, met by the parse)
 		const uint32_t n_need = totals[1];
 		if (n_need) {
 			d->h_need_rec.ensure(n_need); d->h_need_pos.ensure(n_need); d->h_need_size.ensure(n_need);

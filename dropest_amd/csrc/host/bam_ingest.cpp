@@ -621,7 +621,31 @@ std::mutex &decoder_cache_mutex() { static std::mutex m; return m; }
 std::unordered_map<int, dropest_bam_decoder *> &decoder_cache() { static auto *c = new std::unordered_map<int, dropest_bam_decoder *>(); return *c; }   // (never destroyed: the HIP runtime may be gone by then)
 }  // namespace
 
+namespace {
+// The decoders of the files just read go back on a helper thread (several GB of device buffers and up to 512 MB of pinned staging: ~40 ms of
+// hipFree / hipHostFree that the container's passes need not wait for).  Joined before the next file list, by release_device_decoders(), and
+// at exit before the HIP runtime goes down (std::atexit handlers run in reverse order of registration, and the runtime registered first).
+std::thread *&release_thread() { static std::thread *t = nullptr; return t; }
+void join_release_thread() {
+	std::thread *t = nullptr;
+	{ std::lock_guard<std::mutex> lk(decoder_cache_mutex()); t = release_thread(); release_thread() = nullptr; }
+	if (t) { if (t->joinable()) t->join(); delete t; }
+}
+void release_decoders_in_background() {
+	join_release_thread();
+	std::lock_guard<std::mutex> lk(decoder_cache_mutex());
+	if (decoder_cache().empty()) return;
+	std::vector<dropest_bam_decoder *> gone;
+	for (auto &kv : decoder_cache()) gone.push_back(kv.second);
+	decoder_cache().clear();
+	static const bool at_exit = (std::atexit(join_release_thread), true);
+	(void)at_exit;
+	release_thread() = new std::thread([gone] { for (dropest_bam_decoder *d : gone) dropest_bam_decoder_destroy(d); });
+}
+}  // namespace
+
 void BamController::release_device_decoders() {
+	join_release_thread();
 	std::lock_guard<std::mutex> lk(decoder_cache_mutex());
 	for (auto &kv : decoder_cache()) dropest_bam_decoder_destroy(kv.second);
 	decoder_cache().clear();
@@ -689,6 +713,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 		std::string p_cb, p_umi, p_quality;     // -r: the served parameters (owned: the map entry is erased)
 	};
 	const unsigned nthreads = _threads ? _threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+	join_release_thread();
 	for (auto const &bam_name : bam_files) {
 		std::unique_ptr<BamReader> reader_p;       // the host reader: opened only when it is the one that reads (its loader thread inflates ahead from the start)
 		std::vector<std::string> refs;
@@ -952,8 +977,10 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			cfg.intronic_len = uint32_t(_tags.intronic_read_value.size()); cfg.intergenic_len = uint32_t(_tags.intergenic_read_value.size());
 			std::memcpy(cfg.intronic, _tags.intronic_read_value.data(), cfg.intronic_len);
 			std::memcpy(cfg.intergenic, _tags.intergenic_read_value.data(), cfg.intergenic_len);
-			// One decoder per device is kept between files and until the process ends (BamController::release_device_decoders frees them):
-			// streams, 1.5–3 GB of device buffers and 64 MB of pinned memory cost ~30 ms to set up and ~40 ms to give back.
+			// One decoder per device is kept between the files of one parse_bam_files call (streams, device buffers of ~15 x the staging size --
+			// 2 to 7 GB for windows of 128 to 256 MB -- and 2 x 32 to 2 x 256 MB of pinned staging: ~30 ms to set up, ~40 ms to give back); after the
+			// last file they are given back on a helper thread (release_decoders_in_background) unless DROPEST_BAM_KEEP_DECODERS=1 keeps them
+			// for the next call of a long-lived process.
 			dropest_bam_decoder *dec = nullptr;
 			{
 				std::lock_guard<std::mutex> lk(decoder_cache_mutex());
@@ -1295,6 +1322,8 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 		}
 		if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] bulk windows: parse + pack on the workers %.1f ms, new dictionary entries %.1f ms, container %.1f ms\n", fw_ms[0], fw_ms[1], fw_ms[2]);
 	}
+	// the device decoders' memory goes back before the container sorts (the cache was never released)
+	if (!getenv("DROPEST_BAM_KEEP_DECODERS")) release_decoders_in_background();
 }
 
 }  // namespace BamProcessing

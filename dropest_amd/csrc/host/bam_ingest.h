@@ -101,7 +101,9 @@ public:
 	// chromosome name, or a sharded container (the host reader then runs).
 	// CRC-32 and ISIZE of every block are checked there too.  DROPEST_BAM_DEVICE=1 in the environment does the same.
 	void set_device_decode(bool on) { _device_decode = on; }
-	// the device path keeps one decoder per GPU (streams, 1.5–3 GB of device buffers, 64 MB of pinned memory) between files and until the process ends
+	// the device path keeps one decoder per GPU (streams, 2-7 GB of device buffers, up to 512 MB of pinned staging) between the files of one
+	// parse_bam_files call; they are given back on a helper thread when the call ends (DROPEST_BAM_KEEP_DECODERS=1: kept for the next call).
+	// This waits for that thread and frees whatever is still cached.
 	static void release_device_decoders();
 	const Counters &counters() const { return _counters; }
 };

@@ -1069,8 +1069,29 @@ void ResultsPrinter::save_mtx(const CellsDataContainer &c, const std::string &ba
 	// Matrix::writeMM of a dgCMatrix: coordinate / real / general, 1-based, column-major
 	mtx << "%%MatrixMarket matrix coordinate real general\n";
 	mtx << M.row_names.size() << ' ' << M.col_names.size() << ' ' << M.values.size() << '\n';
-	for (size_t col = 0; col + 1 < M.colptr.size(); ++col)
-		for (uint32_t k = M.colptr[col]; k < M.colptr[col + 1]; ++k) mtx << (M.rowidx[k] + 1) << ' ' << (col + 1) << ' ' << M.values[k] << '\n';
+	// the entry lines are formatted by host threads, ~2^18 entries per piece (whole columns), and written in order
+	const size_t ncols = M.colptr.empty() ? 0 : M.colptr.size() - 1;
+	std::vector<size_t> cut{0};
+	for (size_t col = 0; col < ncols; ++col)
+		if (M.colptr[col + 1] - M.colptr[cut.back()] >= (1u << 18) || col + 1 == ncols) cut.push_back(col + 1);
+	std::vector<std::string> text(cut.size() - 1);
+	Rds::parallel_pieces(text.size(), 0, [&](size_t piece) {
+		std::string &t = text[piece];
+		t.reserve(size_t(M.colptr[cut[piece + 1]] - M.colptr[cut[piece]]) * 16);
+		char buf[48];
+		for (size_t col = cut[piece]; col < cut[piece + 1]; ++col)
+			for (uint32_t k = M.colptr[col]; k < M.colptr[col + 1]; ++k) {
+				char *e = buf + sizeof(buf), *p = e;
+				*--p = '\n';
+				for (uint32_t v = M.values[k];; v /= 10) { *--p = char('0' + v % 10); if (v < 10) break; }
+				*--p = ' ';
+				for (size_t v = col + 1;; v /= 10) { *--p = char('0' + v % 10); if (v < 10) break; }
+				*--p = ' ';
+				for (uint32_t v = M.rowidx[k] + 1;; v /= 10) { *--p = char('0' + v % 10); if (v < 10) break; }
+				t.append(p, size_t(e - p));
+			}
+	});
+	for (auto const &t : text) mtx.write(t.data(), std::streamsize(t.size()));
 	std::ofstream cells(base + ".cells.tsv"), genes(base + ".genes.tsv");
 	for (auto const &s : M.col_names) cells << s << '\n';
 	for (auto const &s : M.row_names) genes << s << '\n';
@@ -1095,8 +1116,8 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 	for (const Cell &cell : real) real_names.push_back(cell.barcode());
 
 	auto matrix = [&](bool filtered) {
-		const SparseMatrix M = get_count_matrix(c, filtered, true);
-		return dgCMatrix(M.colptr, M.rowidx, M.values, M.row_names, M.col_names);
+		SparseMatrix M = get_count_matrix(c, filtered, true);
+		return dgCMatrix(std::move(M.colptr), std::move(M.rowidx), std::move(M.values), M.row_names, M.col_names);   // (the slots are taken over: the writer's threads swap them from where they are)
 	};
 	// reads_per_chr_per_cells: as.data.frame of the cells x chromosomes IntegerMatrix (:144-172, :117-126)
 	auto chr_frame = [&](Stats::CellChrStatType stat) {
@@ -1201,8 +1222,8 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 void ResultsPrinter::save_intron_exon_matrices(const CellsDataContainer &c, const std::string &filename) const {   // ResultsPrinter.cpp:455-474
 	using namespace Rds;
 	auto m = [&](const char *code) {
-		const SparseMatrix M = get_count_matrix_filtered(c, UMI::Mark::get_by_code(code), true);
-		return dgCMatrix(M.colptr, M.rowidx, M.values, M.row_names, M.col_names);
+		SparseMatrix M = get_count_matrix_filtered(c, UMI::Mark::get_by_code(code), true);
+		return dgCMatrix(std::move(M.colptr), std::move(M.rowidx), std::move(M.values), M.row_names, M.col_names);
 	};
 	std::string base = filename;
 	const size_t dot = filename.find_last_of('.');

@@ -8,9 +8,15 @@
 // (REFSXP).  Only the node types the results need are implemented: NULL, symbols, pairlists (attributes only),
 // character / integer / double / logical vectors, generic vectors (lists) and S4 objects (dgCMatrix).
 // Host-only code (no HIP); integers are big-endian, doubles IEEE-754 big-endian.
+//
+// Round 6: the file is written as CONCATENATED GZIP MEMBERS (RFC 1952 2.2; R's gzfile / gzcon and zlib's gzread read them as one stream):
+// a serial walk over the value cuts the serialisation into pieces of ~2 MB -- small items as literal bytes, the long vectors (the dgCMatrix
+// slots i / x, saturation_info's reads / cbs / umis) as ranges of the vectors themselves -- and a pool of host threads byte-swaps and
+// deflates the pieces side by side.  One gzopen stream on one thread was the slowest stage of BAM -> .rds.
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <utility>
@@ -23,6 +29,8 @@ using ValuePtr = std::shared_ptr<Value>;
 
 struct Value {
 	enum Kind { Null, Integer, Real, String, List, S4 } kind = Null;
+	std::vector<uint32_t> u32s;                                    // Integer / Real from 32-bit unsigned slots (no widened copy: the writer converts as it swaps)
+	bool from_u32 = false;
 	std::vector<int32_t> ints;
 	std::vector<double> reals;
 	std::vector<std::string> strings;
@@ -42,10 +50,17 @@ ValuePtr with_names(ValuePtr v, std::vector<std::string> names);
 ValuePtr data_frame(const std::vector<std::string> &col_names, const std::vector<std::string> &row_names,
                     std::vector<std::vector<int32_t>> columns);
 // Matrix::dgCMatrix (CSC): p = column pointers, i = row indices (ascending inside a column), x = values
-ValuePtr dgCMatrix(const std::vector<uint32_t> &colptr, const std::vector<uint32_t> &rowidx, const std::vector<uint32_t> &values,
+// (the three slot vectors are taken over, not copied: pass std::move(...) where the caller is done with them)
+ValuePtr dgCMatrix(std::vector<uint32_t> colptr, std::vector<uint32_t> rowidx, std::vector<uint32_t> values,
                    const std::vector<std::string> &row_names, const std::vector<std::string> &col_names);
+ValuePtr integers_from_u32(std::vector<uint32_t> v);      // values must be below 2^31
+ValuePtr reals_from_u32(std::vector<uint32_t> v);
 
 // saveRDS(value, path): gzip-compressed XDR serialisation.  Throws std::runtime_error on I/O errors.
-void save(const ValuePtr &value, const std::string &path);
+// threads: host threads that swap + deflate the pieces (0: up to 16 of the machine's; 1: everything on the calling thread).
+void save(const ValuePtr &value, const std::string &path, unsigned threads = 0);
+
+// fn(piece) for piece = 0 .. n - 1 on up to `threads` host threads (0: up to 16 of the machine's); the first exception is rethrown
+void parallel_pieces(size_t n, unsigned threads, const std::function<void(size_t)> &fn);
 
 }  // namespace Rds

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void bam_seg_guess_kernel(const uint8_t *__res
 
 // A lane per listed segment walks the records that START in it, from seg_start: count[k] of them (their offsets to rec_off + base[k]
 // when rec_off is given), seg_exit[k] = where the chain stands afterwards (the first start at or beyond the segment's end, or the start
-// of the record the data cuts off).  bad[0] is raised by a record shorter than its fixed part.
+// of the record the data cuts off).  bad[0] is raised by a record shorter than its fixed part or longer than 2^26 bytes.
 __global__ __launch_bounds__(256) void bam_seg_walk_kernel(const uint8_t *__restrict__ d, uint64_t len, const uint32_t *__restrict__ list, uint32_t n_list,
                                                            const uint64_t *__restrict__ seg_start, uint32_t *__restrict__ count, uint64_t *__restrict__ seg_exit,
                                                            const uint32_t *__restrict__ base, uint64_t *__restrict__ rec_off, uint32_t *__restrict__ bad) {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void bam_seg_walk_kernel(const uint8_t *__rest
 	if (o == BAM_NONE) { count[k] = 0; seg_exit[k] = BAM_NONE; return; }
 	while (o < end && o + 4 <= len) {
 		const uint32_t bs = b_le32(d + o);
-		if (bs < 32u) { atomicOr(bad, 1u); break; }
+		if (bs < 32u || bs > (1u << 26)) { atomicOr(bad, 1u); break; }   // (beyond any record, as bam_plausible has it: garbage must not become a tail carried from window to window)
 		if (o + 4ull + bs > len) break;                // cut off by the end of the window: the tail of the next one
 		if (rec_off) rec_off[base[k] + c] = o;
 		++c;
@@ -162,7 +162,7 @@ __device__ inline bool bam_equal(const uint8_t *a, uint32_t n, const uint8_t *b,
 // per wave (the records lie 270 bytes apart), which is what bounded the kernel.  Records that do not fit the wave's 20 KB are walked in memory.
 constexpr uint32_t BAM_PARSE_T = 128, BAM_PARSE_STAGE = 20480;
 __global__ __launch_bounds__(BAM_PARSE_T) void bam_parse_kernel(const uint8_t *__restrict__ d, const uint64_t *__restrict__ rec_off, uint32_t n_rec, BamParseCfg cfg,
-                                                                BamDict dict, BamRecordOut out) {
+                                                                BamDict dict, BamRecordOut out, uint32_t *__restrict__ bad) {
 	__shared__ __attribute__((aligned(16))) uint8_t stage[BAM_PARSE_T / 64][BAM_PARSE_STAGE];
 	const uint32_t i = blockIdx.x * BAM_PARSE_T + threadIdx.x;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(BAM_PARSE_T) void bam_parse_kernel(const uint8_t *_
 	const uint32_t l_read_name = p[8], n_cigar = b_le16(p + 12), flag = b_le16(p + 14), l_seq = b_le32(p + 16);
 	out.umiq_len[i] = 0; out.need[i] = 0; out.qoff[i] = ~0ull;
 	const uint64_t aux = 32ull + l_read_name + 4ull * n_cigar + (uint64_t(l_seq) + 1) / 2 + l_seq;
-	if (aux > block_size) { out.status[i] = BAM_CANT_PARSE; return; }       // (the host reader throws "Corrupt BAM record"; the caller checks `bad`)
+	if (aux > block_size) { out.status[i] = BAM_CANT_PARSE; atomicOr(bad, 1u); return; }   // the host reader throws "Corrupt BAM record" (host/bam_ingest.cpp parse_one): so does the window, from this flag
 	if ((flag & 0x4u) || (flag & 0x100u)) { out.status[i] = BAM_SKIP; return; }                    // BamController.cpp:87-88
 	if (ref_id < 0 || ref_id >= cfg.n_refs) { out.status[i] = BAM_CANT_PARSE_NO_COUNT; return; }  // :90-104
 	// the tags asked for, in one walk (BamRecord::get_string_tags)

@@ -330,6 +330,9 @@ __global__ __launch_bounds__(INF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(
 		last = inf_take(s, L, lane, 1) != 0;
 		const uint32_t type = inf_take(s, L, lane, 2);
 		if (type == 0) {   // stored: to the byte boundary, LEN, NLEN, bytes
+			// (the literals an earlier DEFLATE block left waiting go out first -- inside this block's own output range only: a stream
+			// longer than its ISIZE must not write into its neighbour's bytes)
+			if (pos + nlit > out_cap) { err = INF_OUTPUT_OVERRUN; break; }
 			flush();
 			const int drop = s.cnt & 7;
 			s.bits >>= drop; s.cnt -= drop;

@@ -1,6 +1,8 @@
 // Writes one .rds with every node type the results use (tests/test_rds.py parses it back).  Host-only.
 #include <cstdio>
 #include <limits>
+#include <string>
+#include <vector>
 #include "../../dropest_amd/csrc/host/rds_writer.h"
 
 int main(int argc, char **argv) {
@@ -19,6 +21,28 @@ int main(int argc, char **argv) {
 		{"empty", named_list({})},
 	});
 	save(d, argv[1]);
+	if (argc > 2) {
+		// long vectors of every kind (referenced, cut into ~2 MB pieces, swapped and deflated side by side: concatenated gzip members), written
+		// twice -- by one thread and by many: the two files must hold the same serialisation
+		const size_t n = 700001;
+		std::vector<uint32_t> colptr(1001), rows(n), vals(n);
+		for (size_t c = 0; c <= 1000; ++c) colptr[c] = uint32_t(c * n / 1000);
+		for (size_t c = 0; c < 1000; ++c) for (uint32_t k = colptr[c]; k < colptr[c + 1]; ++k) { rows[k] = k - colptr[c]; vals[k] = uint32_t((k * 2654435761u) >> 12) + 1u; }
+		std::vector<std::string> genes(701), cells(1000), many(300001);
+		for (size_t g = 0; g < genes.size(); ++g) genes[g] = "G" + std::to_string(g);
+		for (size_t c = 0; c < cells.size(); ++c) cells[c] = "C" + std::to_string(c);
+		for (size_t k = 0; k < many.size(); ++k) many[k] = std::string(k % 37, char('A' + k % 4)) + std::to_string(k);
+		std::vector<int32_t> ints(1000003);
+		std::vector<double> dbl(500009);
+		for (size_t k = 0; k < ints.size(); ++k) ints[k] = int32_t(k * 7919u) - 1000000;
+		for (size_t k = 0; k < dbl.size(); ++k) dbl[k] = double(k) * 0.37 - 11.0;
+		auto big = [&] {
+			return named_list({{"cm", dgCMatrix(colptr, rows, vals, genes, cells)}, {"ints", integers(ints)}, {"reals", reals(dbl)}, {"strs", strings(many)},
+			                   {"tail", integers({1, 2, 3})}});
+		};
+		save(big(), std::string(argv[2]) + ".one.rds", 1);
+		save(big(), std::string(argv[2]) + ".many.rds", 8);
+	}
 	std::printf("ok\n");
 	return 0;
 }

@@ -122,6 +122,33 @@ def test_damaged_blocks_are_refused_one_by_one():
         inflate(b"not a bgzf file at all, not even close........")
 
 
+def test_literals_waiting_before_a_stored_block_stay_inside_the_blocks_own_range():
+    """A non-final literal-only DEFLATE block leaves up to 63 literals waiting for their store; the stored block behind it flushes them.  With an
+    ISIZE smaller than the stream (a damaged or crafted block) that flush must be refused like every other store beyond the block's own output
+    range (it ran before the capacity test and wrote into the neighbour's bytes)."""
+    rng = np.random.default_rng(17)
+    good = [rng.choice(np.frombuffer(b"ACGTN", np.uint8), 20_000).tobytes() for _ in range(2)]
+    lits = rng.integers(0, 256, 40, dtype=np.uint8).tobytes()
+    tail = rng.integers(0, 256, 300, dtype=np.uint8).tobytes()
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_HUFFMAN_ONLY)
+    cdata = comp.compress(lits) + comp.flush(zlib.Z_FULL_FLUSH)          # a literal-only block, then an empty STORED block (00 00 ff ff)
+    comp0 = zlib.compressobj(0, zlib.DEFLATED, -15)
+    cdata += comp0.compress(tail) + comp0.flush()                        # ... and a stored block with bytes, final
+    assert zlib.decompress(cdata, -15) == lits + tail
+
+    def block(isize, crc):
+        return (b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(cdata) + 25)
+                + cdata + struct.pack("<II", crc, isize))
+    whole = block(len(lits) + len(tail), zlib.crc32(lits + tail) & 0xFFFFFFFF)
+    out, status, _ = inflate(bgzf_block(good[0]) + whole + bgzf_block(good[1]))
+    assert list(status) == [0, 0, 0] and out == good[0] + lits + tail + good[1]
+    for isize in (10, 39, 41):                                           # shorter than the waiting literals / than literals + stored bytes
+        for _ in range(5):                                               # (which wave stores first is not decided: a few tries)
+            out, status, _ = inflate(bgzf_block(good[0]) + block(isize, 0) + bgzf_block(good[1]))
+            assert status[0] == 0 and status[2] == 0 and status[1] != 0
+            assert out[:20_000] == good[0] and out[20_000 + isize:] == good[1]
+
+
 def test_fuzzed_payloads_end_with_a_verdict_and_touch_nothing_else():
     """600 blocks with one to three random bytes of their DEFLATE payload changed, between untouched blocks: every block gets a status, an
     untouched block comes out whole, a block that reports 0 after all (the change hit bits that do not matter, or a stored block's bytes

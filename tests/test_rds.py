@@ -23,11 +23,44 @@ def test_reader_on_files_written_by_r():
     assert np.all(np.diff(df["umigs_count"].value) > 0)
 
 
+def _check_long_vectors(base):
+    """The file of long vectors (tests/cpp/test_rds_writer.cpp) written by one thread and by eight: several gzip members each, the same
+    serialisation, every value in place."""
+    one, many = open(base + ".one.rds", "rb").read(), open(base + ".many.rds", "rb").read()
+    assert one == many                                            # the pieces do not depend on who deflates them
+    import zlib
+    members, rest = 0, many
+    while rest:                                                   # concatenated gzip members (RFC 1952 2.2), as gzfile() reads them
+        z = zlib.decompressobj(31)
+        z.decompress(rest)
+        assert z.eof
+        rest = z.unused_data
+        members += 1
+    assert members > 5
+    d = rr.read_rds(base + ".many.rds")
+    assert d.names == ["cm", "ints", "reals", "strs", "tail"]
+    n = 700001
+    colptr = np.arange(1001, dtype=np.uint64) * n // 1000
+    k = np.arange(n, dtype=np.uint64)
+    m = d["cm"]
+    assert m["p"].value.tolist() == colptr.tolist() and m["i"].kind == "integer" and m["x"].kind == "double"
+    assert np.array_equal(m["i"].value, (k - np.repeat(colptr[:-1], np.diff(colptr).astype(np.int64))).astype(np.int64))
+    assert np.array_equal(m["x"].value, ((((k * 2654435761) & 0xFFFFFFFF) >> 12) + 1).astype(np.float64))
+    assert m["Dim"].value.tolist() == [701, 1000] and m["Dimnames"].value[1].value[999] == "C999"
+    ki = np.arange(1000003, dtype=np.uint64)
+    assert np.array_equal(d["ints"].value, (((ki * 7919) & 0xFFFFFFFF).astype(np.uint32).astype(np.int32).astype(np.int64) - 1000000).astype(np.int32))
+    assert np.array_equal(d["reals"].value, np.arange(500009, dtype=np.float64) * 0.37 - 11.0)
+    strs = d["strs"].value
+    assert len(strs) == 300001 and all(strs[j] == "ABCD"[j % 4] * (j % 37) + str(j) for j in (0, 1, 36, 37, 4095, 4096, 150000, 300000))
+    assert d["tail"].value.tolist() == [1, 2, 3]
+
+
 def test_writer_round_trip(tmp_path):
     exe, out = str(tmp_path / "w"), str(tmp_path / "t.rds")
     src = [os.path.join(ROOT, "tests", "cpp", "test_rds_writer.cpp"), os.path.join(ROOT, "dropest_amd", "csrc", "host", "rds_writer.cpp")]
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall"] + src + ["-o", exe, "-lz"])
-    assert subprocess.run([exe, out], capture_output=True, text=True).stdout.strip() == "ok"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall"] + src + ["-o", exe, "-lz", "-pthread"])
+    assert subprocess.run([exe, out, str(tmp_path / "big")], capture_output=True, text=True).stdout.strip() == "ok"
+    _check_long_vectors(str(tmp_path / "big"))
     raw = open(out, "rb").read()
     assert raw[:2] == b"\x1f\x8b"                                  # gzip container, like saveRDS
     data = rr.decompress(raw)
