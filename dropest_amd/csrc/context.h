@@ -385,7 +385,10 @@ struct dropest_ctx {
 	dropest::DevBuf<u64> umi_dict, umi_ranked;
 	std::vector<u64> umi_dict_host;          // ascending codes: unmap_umi / map_umi
 	const u64 *umi_key_column() const { return umi_dict_on ? umi_ranked.p : d_umi; }
-	void build_umi_dict();
+	void build_umi_dict(const std::function<void(dropest::DevBuf<u64> &, u32 &)> *across = nullptr);
+	bool umi_dict_wanted(int gene_bits, int cell_bits) const;
+	// the sorted distinct values of d[0, n) (device, any order, may repeat) in place: n becomes their number (k_umidict.h kernels; uses keys_a / keys_b)
+	void sort_unique_u64(dropest::DevBuf<u64> &d, u32 &n);
 	bool map_umi(u64 api_code, u64 &field) const;   // inverse of unmap_umi; false: the code has no place in this pass's key layout
 	bool map_umi_or_add(u64 api_code, u64 &field);  // the same for the public mutators: a new clean UMI joins the dictionary
 	dropest::IngestStats ingest{};

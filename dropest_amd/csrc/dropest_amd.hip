@@ -480,12 +480,9 @@ void dropest_ctx::plan_key_layout() {
 	L.cell_bits = std::max(1, bit_length(uint64_t(n_cells ? n_cells - 1 : 0)));
 	// The UMI's own code as the field, unless the key cannot hold it: then its rank in a dictionary of the stream's UMIs
 	// (k_umidict.h; StringIndexer.cpp:10-18 has no width limit).  Once a pass has the dictionary it keeps it.
-	if (!umi_dict_on && n_reads && !hooks && !rpack.on()) {
-		int plain_bits = clean_bits;
-		if (ingest.umi_escape_max_plus1) plain_bits = bit_length((1ull << clean_bits) + ingest.umi_escape_max_plus1 - 1);
-		const int mode = getenv("DROPEST_UMI_DICT") ? atoi(getenv("DROPEST_UMI_DICT")) : umi_dict_mode;
-		if (mode >= 2 || L.gene_bits + plain_bits >= 64 || (mode == 1 && plain_bits + L.gene_bits + L.cell_bits > 64)) build_umi_dict();
-	}
+	// (A sharded / split run builds ONE dictionary over all shards before the keys are planned -- csrc/shard_run.h: global_umi_dictionary, round 6 --
+	// and arrives here with it.)
+	if (!umi_dict_on && n_reads && !hooks && !rpack.on() && umi_dict_wanted(L.gene_bits, L.cell_bits)) build_umi_dict();
 	if (umi_dict_on) {
 		umi_sentinel_stripped = false;
 		clean_bits = std::max(1, bit_length(uint64_t(umi_dict_n) + 255u));   // (room for UMIs the public mutators bring in: add_umi / merge_umis)
@@ -498,7 +495,7 @@ void dropest_ctx::plan_key_layout() {
 	wanted_bits[0] = u32(L.cell_bits); wanted_bits[1] = u32(L.gene_bits); wanted_bits[2] = u32(L.umi_bits);
 	if (L.gene_bits + L.umi_bits >= 64)
 		throw UnsupportedError("gene + UMI fields of the sort key need " + std::to_string(L.gene_bits + L.umi_bits) + " bits and leave no room for the cells; "
-		                       "one context then keys the UMIs by their rank in a dictionary (dropest_set_umi_dictionary), the shards of a split or sharded run cannot");
+		                       "the pass should have keyed the UMIs by their rank in a dictionary (k_umidict.h; sharded runs: shard_run.h global_umi_dictionary)");
 	if (L.umi_bits + L.gene_bits + L.cell_bits > 64)
 		throw UnsupportedError("sort key needs " + std::to_string(L.umi_bits + L.gene_bits + L.cell_bits) +
 		                       " bits (cell " + std::to_string(L.cell_bits) + " + gene " + std::to_string(L.gene_bits) +
@@ -517,34 +514,55 @@ void dropest_ctx::plan_key_layout() {
 	layout = L;
 }
 
+// Does this pass key its UMIs by their rank in a dictionary?  From the ingest statistics alone (a sharded run asks after its shards have
+// agreed on them, so all of them answer alike); cell_bits only matters for mode 1.
+bool dropest_ctx::umi_dict_wanted(int gene_bits, int cell_bits) const {
+	int clean_bits = 0;
+	if (ingest.umi_clean_max != 0) {
+		const int bl_min = bit_length(ingest.umi_clean_min), bl_max = bit_length(ingest.umi_clean_max);
+		clean_bits = bl_min == bl_max ? bl_max - 1 : bl_max;
+	}
+	int plain_bits = clean_bits;
+	if (ingest.umi_escape_max_plus1) plain_bits = bit_length((1ull << clean_bits) + ingest.umi_escape_max_plus1 - 1);
+	const int mode = getenv("DROPEST_UMI_DICT") ? atoi(getenv("DROPEST_UMI_DICT")) : umi_dict_mode;
+	return mode >= 2 || gene_bits + plain_bits >= 64 || (mode == 1 && plain_bits + gene_bits + cell_bits > 64);
+}
+
 // The distinct clean UMIs of the gene-bearing reads, ascending, and every read's rank among them (k_umidict.h).
-void dropest_ctx::build_umi_dict() {
+// across: a sharded run's exchange -- given this shard's dictionary (device, ascending) it leaves the dictionary of ALL shards in its place
+// (csrc/shard_run.h); the ranks are then the same on every shard and still ascend with the codes.
+void dropest_ctx::build_umi_dict(const std::function<void(dropest::DevBuf<u64> &, u32 &)> *across) {
 	HostStage hs(this, "umi_dict");
 	need_columns();
 	const u32 n = u32(n_reads);
-	keys_a.ensure(n); keys_b.ensure(n); vals_a.ensure(1); vals_b.ensure(1);
-	u64 *k = keys_a.p, *k_alt = keys_b.p;
-	u32 *v = vals_a.p, *v_alt = vals_b.p;
-	timed("umi_dict:fill", double(n) * 20, [&] {
-		hipLaunchKernelGGL(umi_dict_fill_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n, k);
-	});
-	radix_sort(k, v, k_alt, v_alt, n, ~0ull, 0, "umi_dict:");
-	const u32 nb = div_up(n, u32(UD_T * UD_PER));
-	DevBuf<u32> cnt, base;
-	cnt.alloc(nb); base.alloc(nb);
-	scalars.ensure(16);
-	timed("umi_dict:unique", double(n) * 16, [&] {
-		hipLaunchKernelGGL(umi_dict_count_kernel, dim3(nb), dim3(UD_T), 0, stream, k, n, cnt.p);
-		scan_counts(cnt.p, base.p, nb, scalars.p);
-	});
 	u32 total = 0;
-	fetch(&total, scalars.p, 4);
-	umi_dict_n = total;
-	umi_dict.ensure(std::max<u32>(total, 1u));
-	umi_ranked.ensure(n);
-	timed("umi_dict:rank", double(n) * 20, [&] {
+	umi_dict.ensure(1);
+	if (n) {   // (a shard without reads still takes part in the exchange below)
+		keys_a.ensure(n); keys_b.ensure(n); vals_a.ensure(1); vals_b.ensure(1);
+		u64 *k = keys_a.p, *k_alt = keys_b.p;
+		u32 *v = vals_a.p, *v_alt = vals_b.p;
+		timed("umi_dict:fill", double(n) * 20, [&] {
+			hipLaunchKernelGGL(umi_dict_fill_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n, k);
+		});
+		radix_sort(k, v, k_alt, v_alt, n, ~0ull, 0, "umi_dict:");
+		const u32 nb = div_up(n, u32(UD_T * UD_PER));
+		DevBuf<u32> cnt, base;
+		cnt.alloc(nb); base.alloc(nb);
+		scalars.ensure(16);
+		timed("umi_dict:unique", double(n) * 16, [&] {
+			hipLaunchKernelGGL(umi_dict_count_kernel, dim3(nb), dim3(UD_T), 0, stream, k, n, cnt.p);
+			scan_counts(cnt.p, base.p, nb, scalars.p);
+		});
+		fetch(&total, scalars.p, 4);
+		umi_dict.ensure(std::max<u32>(total, 1u));
 		if (total) hipLaunchKernelGGL(umi_dict_write_kernel, dim3(nb), dim3(UD_T), 0, stream, k, n, base.p, umi_dict.p);
-		hipLaunchKernelGGL(umi_dict_rank_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n, umi_dict.p, total, umi_ranked.p);
+		HIP_CHECK(hipGetLastError());
+	}
+	if (across) { HIP_CHECK(stream_wait(stream)); (*across)(umi_dict, total); }
+	umi_dict_n = total;
+	umi_ranked.ensure(std::max<u32>(n, 1u));
+	timed("umi_dict:rank", double(n) * 20, [&] {
+		if (n) hipLaunchKernelGGL(umi_dict_rank_kernel, dim3(std::min<u32>(div_up(n, 256), 8192u)), dim3(256), 0, stream, d_umi, d_gene, n, umi_dict.p, total, umi_ranked.p);
 	});
 	HIP_CHECK(hipGetLastError());
 	umi_dict_host.resize(total);
@@ -552,6 +570,28 @@ void dropest_ctx::build_umi_dict() {
 	else HIP_CHECK(stream_wait(stream));
 	umi_dict_on = true;
 	if (profiling) stats["count:umi_dictionary"].launches += 1;
+}
+
+void dropest_ctx::sort_unique_u64(dropest::DevBuf<u64> &d, u32 &n) {
+	if (n == 0) return;
+	keys_a.ensure(n); keys_b.ensure(n); vals_a.ensure(1); vals_b.ensure(1);
+	HIP_CHECK(hipMemcpyAsync(keys_a.p, d.p, size_t(n) * 8, hipMemcpyDeviceToDevice, stream));
+	u64 *k = keys_a.p, *k_alt = keys_b.p;
+	u32 *v = vals_a.p, *v_alt = vals_b.p;
+	radix_sort(k, v, k_alt, v_alt, n, ~0ull, 0, "umi_dict:all:");
+	const u32 nb = div_up(n, u32(UD_T * UD_PER));
+	DevBuf<u32> cnt, base;
+	cnt.alloc(nb); base.alloc(nb);
+	scalars.ensure(16);
+	hipLaunchKernelGGL(umi_dict_count_kernel, dim3(nb), dim3(UD_T), 0, stream, k, n, cnt.p);
+	scan_counts(cnt.p, base.p, nb, scalars.p);
+	u32 total = 0;
+	fetch(&total, scalars.p, 4);
+	d.ensure(std::max<u32>(total, 1u));
+	if (total) hipLaunchKernelGGL(umi_dict_write_kernel, dim3(nb), dim3(UD_T), 0, stream, k, n, base.p, d.p);
+	HIP_CHECK(hipGetLastError());
+	HIP_CHECK(stream_wait(stream));
+	n = total;
 }
 
 dropest_ctx::u64 dropest_ctx::unmap_umi(u64 ucode) const {

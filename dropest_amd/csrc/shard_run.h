@@ -1002,6 +1002,7 @@ struct dropest_shard {
 	void step();
 	void partition_and_exchange();
 	void agree_on_key_fields();
+	void global_umi_dictionary();
 	// barcode merges across shards
 	struct MergeWorld {   // the cells that take part: every shard's rows in rank order, identical on every shard
 		struct LRow { u64 barcode; u32 n_genes, req_genes, req_umis, local_id; int32_t total_umis, total_reads; u32 first_read; };
@@ -1385,6 +1386,48 @@ void dropest_shard::agree_on_key_fields() {
 	if (g[3] > GENE_CHR_CAP) g[5] = 1;
 	c.ingest.umi_clean_min = g[0]; c.ingest.umi_clean_max = g[1]; c.ingest.umi_escape_max_plus1 = g[2];
 	c.ingest.gene_max_plus1 = u32(g[3]); c.ingest.chr_max_plus1 = u32(g[4]); c.ingest.gene_chr_conflict = u32(g[5]);
+}
+
+// The UMI dictionary of a sharded run (round 6; StringIndexer::add has no width limit, Estimation/StringIndexer.cpp:10-18, Gene.cpp:17-24): when the
+// gene and UMI fields alone reach 64 bits the key carries the UMI's rank among the distinct clean UMIs of the WHOLE stream.  Every shard
+// makes the sorted distinct UMIs of its own reads (k_umidict.h), all of them gather every shard's list (Transport::gather_dev: RCCL all-gather
+// across GPUs, peer copies inside a process, the shm plane across processes on one GPU), and each sorts the union and keeps the distinct
+// values: one dictionary, the same on every shard, ranks ascending with the codes -- so every order that hangs on the UMI field is the plain
+// layout's, and the molecule rows that cross between shards in a barcode merge carry ranks every shard reads alike.  (An all-to-all by
+// mix64(UMI) mod n with per-owner ranks would move 1 / n of the bytes but give ranks that do NOT ascend with the codes.)  The decision comes
+// from the agreed ingest statistics, so every shard takes it alike.
+void dropest_shard::global_umi_dictionary() {
+	using namespace dropest;
+	dropest_ctx &c = *ctx;
+	int gene_bits = bit_length(uint64_t(c.ingest.gene_max_plus1));
+	if ((1ull << gene_bits) - 1 < c.ingest.gene_max_plus1) gene_bits++;
+	if (gene_bits == 0) gene_bits = 1;
+	uint64_t cells_mine = c.n_cells;
+	std::vector<uint64_t> cells_all(static_cast<size_t>(world));
+	tr->gather_host(&cells_mine, 8, cells_all.data());
+	uint64_t cells_max = 0;
+	for (uint64_t x : cells_all) cells_max = std::max(cells_max, x);
+	const int cell_bits = std::max(1, bit_length(cells_max ? cells_max - 1 : 0));
+	if (!c.umi_dict_wanted(gene_bits, cell_bits)) return;
+	Phase ph(this, "umi_dictionary");
+	const std::function<void(DevBuf<u64> &, u32 &)> across = [&](DevBuf<u64> &dict, u32 &n) {
+		uint64_t mine = n;
+		std::vector<uint64_t> counts(static_cast<size_t>(world));
+		tr->gather_host(&mine, 8, counts.data());
+		std::vector<size_t> off(static_cast<size_t>(world)), bytes(static_cast<size_t>(world));
+		uint64_t total = 0;
+		for (int p = 0; p < world; ++p) { off[size_t(p)] = size_t(total) * 8; bytes[size_t(p)] = size_t(counts[size_t(p)]) * 8; total += counts[size_t(p)]; }
+		if (total >= 0xFFFFFFF0ull) throw UnsupportedError("the shards' UMI dictionaries hold more than 2^32 entries together");
+		DevBuf<u64> all;
+		all.alloc(std::max<uint64_t>(total, 1));
+		tr->gather_dev(dict.p, all.p, off.data(), bytes.data(), c.stream);
+		u32 m = u32(total);
+		c.sort_unique_u64(all, m);
+		dict = std::move(all);
+		n = m;
+		phases["umi_dictionary"].bytes += double(total) * 8;
+	};
+	c.build_umi_dict(&across);
 }
 
 // Order of table rows `sel` (indices into G): by_first = ascending global first ordinal (cell-id order of ONE container);
@@ -2157,7 +2200,7 @@ void dropest_shard::step() {
 		}
 	}
 	// (one shard has nobody to agree with: its pass runs in one piece and may plan the key layout from a sample like any context)
-	if (world > 1) { Phase ph(this, "ingest"); c.run_ingest(); agree_on_key_fields(); }
+	if (world > 1) { Phase ph(this, "ingest"); c.run_ingest(); agree_on_key_fields(); global_umi_dictionary(); }
 	install_umi_hooks();
 	{ Phase ph(this, "pipeline"); c.run_set_initialized(); }
 	merged_barcodes.clear();

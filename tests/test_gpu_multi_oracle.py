@@ -253,3 +253,54 @@ def test_chunked_exchange_matches_the_oracle(name, world, chunks, monkeypatch):
     check_vs_oracle(got, o, side)
     if "+N" not in name:    # (a UMI with N is an escaped code with bit 63 set: those streams travel as five arrays, in one piece)
         assert got["phases"]["all_to_all:chunks"]["steps"] == 2 * chunks
+
+
+# ---- the UMI dictionary across shards (round 6; Estimation/StringIndexer.cpp:10-18 has no width limit) ----
+def _dictionary_phase(got):
+    return got["phases"].get("umi_dictionary", {"steps": 0})["steps"]
+
+
+@pytest.mark.parametrize("world,n_rate", [(3, 0.0), (3, 5e-3), (2, 0.0), (8, 2e-3)])
+def test_gene_and_umi_of_64_bits_over_shards(world, n_rate):
+    """30-base UMIs (61 bits with the sentinel) beside a few thousand genes: gene + UMI alone pass 64 bits.  One context keys the UMIs by their
+    rank in a dictionary since round 5; the shards of a sharded run used to refuse.  Now every shard's distinct UMIs are gathered, the union is
+    sorted once per shard, and the ranks -- ascending with the codes, the same everywhere -- key the molecules: against the oracle, with N-UMIs
+    (random fills against the one global rand() sequence) and two passes on the same shards."""
+    s = SynthStream(n_reads=120_000, n_cells=30, n_genes=2500, umi_len=30)
+    arrays = parity.canonical_stream(*s.generate_host())
+    side = ()
+    if n_rate:
+        umi, side = inject_n(arrays[1], arrays[2], n_rate, 7, 30)
+        arrays = (arrays[0], umi, arrays[2], arrays[3])
+    kw = dict(min_genes_before_merge=5, min_genes_after_merge=15)
+    o = seeded_oracle(kw, arrays, side)
+    got = run_shards(arrays, kw, even_bounds(len(arrays[0]), world), side=side, steps=2)
+    assert _dictionary_phase(got) >= 2
+    check_vs_oracle(got, o, side)
+    assert len(got["cm"][3]) >= 8
+
+
+def test_wide_umis_whitelist_merge_across_shards():
+    """... and with -m: molecule rows cross between the shards carrying ranks of the one dictionary."""
+    s = SynthStream(n_reads=200_000, n_cells=40, n_genes=2000, umi_len=30, permille_neighbour=150)
+    arrays = parity.canonical_stream(*s.generate_host())
+    umi, side = inject_n(arrays[1], arrays[2], 2e-3, 5, 30)
+    arrays = (arrays[0], umi, arrays[2], arrays[3])
+    kw = dict(merge_kind=capi.MERGE_REAL_BARCODES, min_genes_before_merge=3, min_genes_after_merge=20, **WL_10X)
+    o = seeded_oracle(kw, arrays, side)
+    got = run_shards(arrays, kw, even_bounds(len(arrays[0]), 3), side=side)
+    assert _dictionary_phase(got) >= 1
+    want = check_vs_oracle(got, o, side)
+    assert len(want) > 10
+
+
+@pytest.mark.parametrize("name", sorted(KINDS))
+def test_every_merge_kind_over_shards_with_the_dictionary_forced(name, monkeypatch):
+    """The suite's own sharded cases once more with DROPEST_UMI_DICT=2: every consumer of the key's UMI field across shards (N-UMI groups, -u,
+    the UMI-gene index of the whitelist-free merges, the Poisson estimators' UMI histograms, imported molecule rows) must cope with ranks."""
+    monkeypatch.setenv("DROPEST_UMI_DICT", "2")
+    arrays, kw, side = make_case(name)
+    o = seeded_oracle(kw, arrays, side)
+    got = run_shards(arrays, kw, even_bounds(len(arrays[0]), 3), side=side)
+    assert _dictionary_phase(got) >= 1
+    check_vs_oracle(got, o, side)

@@ -115,17 +115,24 @@ def test_wide_fields_directional_umi_merge():
     assert int(c.molecules()[0].shape[0]) < distinct * 0.98
 
 
-def test_wide_fields_in_a_split_run_stay_refused():
-    """Ranks are local to a context: the shards of a split / sharded run keep the UMI's own code and say so."""
+def test_wide_fields_in_a_split_run_share_one_dictionary():
+    """Round 6: the shards of a split / sharded run gather ONE dictionary (shard_run.h: global_umi_dictionary): ranks mean the same on every
+    shard.  The split of a context against one context over the same reads (which other tests pin on the oracle)."""
     cb, umi, gene, aux, side = wide_stream(7400, n=4000)
-    c = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
+    kw = dict(min_genes_before_merge=0, min_genes_after_merge=0)
+    one = parity.gpu_run(kw, cb, umi, gene, aux, side)
+    c = capi.Context(**kw)
     if side:
         c.set_side_strings(side)
     c.push_reads(cb, umi, gene, aux)
     g = ShardGroup.split(c, 2)
-    with pytest.raises(capi.DropestError) as e:
-        g.step()
-    assert e.value.status == 4 and "gene + UMI" in str(e.value)
+    g.step()
+    s0 = g.shards[0]
+    assert s0.phase_stats().get("umi_dictionary", {"steps": 0})["steps"] == 1
+    for filt in (True, False):
+        p, i, x, b = s0.matrix(filt)
+        p1, i1, x1 = one.count_matrix_csc(filtered=filt)
+        assert np.array_equal(p.astype(np.uint64), p1.astype(np.uint64)) and np.array_equal(i, i1) and np.array_equal(x, x1)
     g.close()
 
 

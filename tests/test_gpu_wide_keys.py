@@ -141,7 +141,7 @@ def test_wide_key_merge_all_with_umi_qualities():
 
 def test_gene_and_umi_alone_too_wide_take_the_umi_dictionary():
     """Gene + UMI fields that alone fill the key: one context keys the UMIs by their rank in a dictionary (round 5, tests/test_gpu_umi_dict.py);
-    the shards of a split run cannot (ranks are local to a context) and say so."""
+    the shards of a split run gather ONE dictionary over all of them (round 6, shard_run.h: global_umi_dictionary) -- they used to refuse."""
     P = capi.pack_seq
     n = 5
     cb = np.array([P("ACGT" * 7 + "AC" + "ACGT"[i % 4]) for i in range(n)], np.uint64)
@@ -156,9 +156,11 @@ def test_gene_and_umi_alone_too_wide_take_the_umi_dictionary():
     c2 = capi.Context(min_genes_before_merge=0, min_genes_after_merge=0)
     c2.push_reads(cb, umi, gene, np.full(n, 2 << 16, np.uint32))
     g = ShardGroup.split(c2, 2)
-    with pytest.raises(capi.DropestError) as e:
-        g.step()
-    assert e.value.status == 4 and "gene + UMI" in str(e.value)
+    g.step()
+    s0 = g.shards[0]
+    assert s0.phase_stats().get("umi_dictionary", {"steps": 0})["steps"] == 1
+    p, i, x, b = s0.matrix(False)
+    assert len(p) - 1 == 4 and sorted(x.tolist()) == [1, 1, 1, 1]          # four cells, one molecule each (the barcode seen twice: two reads, one molecule)
     g.close()
 
 
