@@ -147,6 +147,13 @@ struct BamFront {
 	uint32_t n_segs = 0, n_blocks = 0, refused = 0, repaired = 0;
 	double ms_copy = 0, ms_inflate = 0, ms_boundaries = 0;
 	bool begun = false;
+	// the window's data stand at d_out + base_off: [the record the window before cut off | the inflated blocks].  The blocks are inflated to
+	// d_out + reserve BEFORE the window before has said how long its cut-off record is (dropest_bam_decoder_window_inflate: the inflate of window
+	// k + 1 runs beside the chain / parse / host work of window k); the record is put in front of them afterwards (.._window_chain).
+	uint64_t base_off = 0, reserve = 0, total = 0, comp_len = 0;
+	const uint8_t *comp = nullptr;
+	bool inflating = false;
+	uint8_t *data() { return d_out.p + base_off; }
 };
 
 struct dropest_bam_decoder {
@@ -247,7 +254,7 @@ extern "C" int dropest_bam_decoder_reset(dropest_bam_decoder *d, const dropest_b
 		if (cfg->n_refs < 0) throw InvalidError("negative number of references");
 		HIP_CHECK(hipSetDevice(d->device));
 		HIP_CHECK(hipStreamSynchronize(d->stream));
-		for (BamFront &f : d->front) { if (f.stream) HIP_CHECK(hipStreamSynchronize(f.stream)); f.begun = false; }
+		for (BamFront &f : d->front) { if (f.stream) HIP_CHECK(hipStreamSynchronize(f.stream)); f.begun = false; f.inflating = false; }
 		HIP_CHECK(hipStreamSynchronize(d->up_stream));
 		d->up_ready[0].store(false, std::memory_order_relaxed); d->up_ready[1].store(false, std::memory_order_relaxed);
 		std::memcpy(&d->cfg, cfg, sizeof(BamParseCfg));
@@ -380,23 +387,31 @@ __global__ __launch_bounds__(256) void bam_chain_to_host_kernel(const uint64_t *
 	if (k < n) { h_start[k] = seg_start[k]; h_exit[k] = seg_exit[k]; h_count[k] = seg_count[k]; }
 }
 
-extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
-                                                dropest_bgzf_host_inflate inflate_fallback, void *user, int *slot) {
+// First half of a window, part A: the block table, the tables and (unless dropest_bam_decoder_upload sent them ahead) the compressed bytes to the
+// device, the inflate kernel enqueued -- and back, without waiting for any of it.  The blocks land at a fixed distance from the start of the
+// front's buffer, so this may be called for window k + 1 while window k is still in its chain / fields / host work: the device then always has
+// the next window's blocks to fill the wave slots that window k's finished blocks leave (a window's inflate takes as long as its slowest
+// block, ~7-11 ms on a file that deflates 3 x, however few blocks are left running).  comp must stay as it is until .._window_chain returns.
+constexpr uint64_t BAM_TAIL_RESERVE = uint64_t(1) << 20;
+extern "C" int dropest_bam_decoder_window_inflate(dropest_bam_decoder *dec, const uint8_t *comp, uint64_t len, int *slot) {
 	return bgzf_guarded([&] {
 		if (!dec || !slot || (len && !comp)) throw InvalidError("null argument");
 		BamFront *const d = &dec->front[dec->next_front];
+		if (d->inflating) throw InvalidError("this front still holds a window whose blocks are being inflated (call .._window_chain first)");
+		d->begun = false;
 		*slot = dec->next_front;
 		dec->next_front ^= 1;
-		d->begun = false;
-		struct { uint32_t refused_blocks = 0, guesses_repaired = 0, n_blocks = 0; uint64_t window_bytes = 0; double ms_copy = 0, ms_inflate = 0, ms_boundaries = 0; } o_, *out = &o_;
 		using clk = std::chrono::steady_clock;
 		auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
 		HIP_CHECK(hipSetDevice(dec->device));
 		// the first half of a window on a stream of its own, for a caller that runs it beside the second half of the window before; the two
 		// halves one after the other (dropest_bam_decoder_window) share the decoder's stream
+		// (Beside window k's chain / fields kernels the inflate of window k + 1 holds every wave slot of the device for 7-11 ms: whatever else is
+		// launched meanwhile waits for slots.  Measured on the 3.2 x file: the chain 1.3 -> 52 ms, the dictionaries' copies 1.2 -> 31 ms; with a CU
+		// mask on this stream that leaves 32 CUs alone the chain is back at 2 ms but the fields kernels run on those 32 CUs, 28 -> 49 ms, and a
+		// masked stream is a blocking one: every null-stream copy waits for the inflate.  NOTES_r06 section 3.)
 		if (!dec->halves_in_sequence && !d->stream) HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
 		hipStream_t st = dec->halves_in_sequence ? dec->stream : d->stream;
-		// 1. the blocks
 		int up = -1;      // the bytes went ahead (dropest_bam_decoder_upload)
 		for (int w = 0; w < 2; ++w)
 			// (the buffer first: only the slot these bytes stand in is looked at -- the reader thread may be filling the other one right now)
@@ -409,12 +424,12 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 		} else if (!bgzf_block_table(comp, len, d->in_off, d->out_off, d->in_len, d->out_len, d->crc, &n, &used, &total)) throw InvalidError(g_bgzf_error);
 		if (used != len) throw InvalidError("a window must hold whole BGZF blocks");
 		if (n > 0xFFFFFFFFull) throw UnsupportedError("more than 2^32 blocks in one window");
-		const uint64_t tail = dec->tail_len, data_len = tail + total;
-		if (tail && first_skip) throw InvalidError("first_skip belongs to the first window");
-		if (data_len >= (uint64_t(1) << 40)) throw UnsupportedError("window too large");
+		if (total >= (uint64_t(1) << 40)) throw UnsupportedError("window too large");
+		static const uint64_t reserve_min = [] { const char *e = getenv("DROPEST_BAM_TEST_TAIL_RESERVE"); return e ? uint64_t(std::max(0ll, atoll(e))) : BAM_TAIL_RESERVE; }();
+		d->reserve = (std::max(reserve_min, dec->tail_len) + 255u) & ~uint64_t(255);   // (the last cut-off record seen is a hint; a longer one moves the data: .._window_chain)
 		auto t0 = clk::now();
-		d->d_out.ensure(data_len + data_len / 4 + 64);
-		if (tail) HIP_CHECK(hipMemcpyAsync(d->d_out.p, dec->d_tail.p, tail, hipMemcpyDeviceToDevice, st));
+		d->d_out.ensure(d->reserve + total + total / 4 + 64);
+		d->ms_copy = d->ms_inflate = d->ms_boundaries = 0;
 		if (n) {
 			const uint8_t *uploaded = nullptr;
 			if (up >= 0) { uploaded = dec->up_in[up].p; HIP_CHECK(hipStreamWaitEvent(st, dec->up_done[up], 0)); }
@@ -427,13 +442,40 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 			HIP_CHECK(hipMemcpyAsync(d->d_out_off.p, d->out_off.data(), n * 8, hipMemcpyHostToDevice, st));
 			HIP_CHECK(hipMemcpyAsync(d->d_in_len.p, d->in_len.data(), n * 4, hipMemcpyHostToDevice, st));
 			HIP_CHECK(hipMemcpyAsync(d->d_out_len.p, d->out_len.data(), n * 4, hipMemcpyHostToDevice, st));
-			HIP_CHECK(hipStreamSynchronize(st));
-			out->ms_copy = ms_since(t0);
-			t0 = clk::now();
-			if (dropest_bgzf_inflate_device(dec->device, st, uploaded ? uploaded : d->d_in.p, len, d->d_in_off.p, d->d_in_len.p, d->d_out_off.p, d->d_out_len.p, uint32_t(n), d->d_out.p + tail, d->d_status.p, d->d_crc.p))
+			d->ms_copy = ms_since(t0);
+			if (dropest_bgzf_inflate_device(dec->device, st, uploaded ? uploaded : d->d_in.p, len, d->d_in_off.p, d->d_in_len.p, d->d_out_off.p, d->d_out_len.p, uint32_t(n), d->d_out.p + d->reserve, d->d_status.p, d->d_crc.p))
 				throw DeviceError(g_bgzf_error);
 			HIP_CHECK(hipMemcpyAsync(d->h_block_status.p, d->d_status.p, n * 4, hipMemcpyDeviceToHost, st));
-			HIP_CHECK(hipStreamSynchronize(st));
+		}
+		d->n_blocks = uint32_t(n); d->total = total; d->comp = comp; d->comp_len = len;
+		d->inflating = true;
+	});
+}
+
+// First half of a window, part B: waits for the inflate of `slot`, has refused blocks inflated on the host, puts the record the window before cut
+// off in front of the data, and finds the chain of records (guesses per segment, walks, the host's check).  Windows take this call in file order.
+extern "C" int dropest_bam_decoder_window_chain(dropest_bam_decoder *dec, int slot, uint32_t first_skip, int final, dropest_bgzf_host_inflate inflate_fallback, void *user) {
+	return bgzf_guarded([&] {
+		if (!dec || slot < 0 || slot > 1) throw InvalidError("bad argument");
+		BamFront *const d = &dec->front[slot];
+		if (!d->inflating) throw InvalidError("this window's inflate was not started (or failed)");
+		d->inflating = false;
+		struct { uint32_t refused_blocks = 0, guesses_repaired = 0; double ms_boundaries = 0; } o_, *out = &o_;
+		using clk = std::chrono::steady_clock;
+		auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+		HIP_CHECK(hipSetDevice(dec->device));
+		// (the blocks were inflated on the front's stream, which may leave CUs alone -- see _inflate; everything from here on runs on the
+		// decoder's own stream, which may use them all: it must not queue behind the next window's inflate)
+		hipStream_t st_inflate = dec->halves_in_sequence ? dec->stream : d->stream;
+		hipStream_t st = dec->stream;
+		const uint64_t n = d->n_blocks, total = d->total;
+		const uint8_t *comp = d->comp;
+		const uint64_t tail = dec->tail_len, data_len = tail + total;
+		if (tail && first_skip) throw InvalidError("first_skip belongs to the first window");
+		if (data_len >= (uint64_t(1) << 40)) throw UnsupportedError("window too large");
+		auto t0 = clk::now();
+		HIP_CHECK(hipStreamSynchronize(st_inflate));      // the blocks are inflated (and their verdicts on the host)
+		if (n) {
 			std::vector<uint8_t> tmp;
 			for (uint64_t k = 0; k < n; ++k) {
 				if (!d->h_block_status.p[k]) continue;
@@ -441,11 +483,22 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 				if (!inflate_fallback) throw InvalidError("the device refused BGZF block " + std::to_string(k) + " of the window (status " + std::to_string(d->h_block_status.p[k]) + ") and no host inflate was given");
 				tmp.resize(d->out_len[k] + 1);
 				if (inflate_fallback(comp + d->in_off[k], d->in_len[k], tmp.data(), d->out_len[k], user)) throw InvalidError("damaged BGZF block (neither the device nor the host inflates it)");
-				HIP_CHECK(hipMemcpy(d->d_out.p + tail + d->out_off[k], tmp.data(), d->out_len[k], hipMemcpyHostToDevice));
+				HIP_CHECK(hipMemcpy(d->d_out.p + d->reserve + d->out_off[k], tmp.data(), d->out_len[k], hipMemcpyHostToDevice));
 			}
-			out->ms_inflate = ms_since(t0);
 		}
-		out->n_blocks = uint32_t(n); out->window_bytes = data_len;
+		d->ms_inflate = ms_since(t0);
+		// the cut-off record of the window before, in front of the blocks
+		if (tail > d->reserve) {      // longer than the room left for it: the window moves behind it in a buffer of its own (a record beyond 1 MB: rare)
+			DevBuf<uint8_t> moved;
+			moved.alloc(data_len + data_len / 4 + 64);
+			if (total) HIP_CHECK(hipMemcpyAsync(moved.p + tail, d->d_out.p + d->reserve, total, hipMemcpyDeviceToDevice, st));
+			HIP_CHECK(hipStreamSynchronize(st));
+			d->d_out = std::move(moved);
+			d->reserve = tail;
+		}
+		d->base_off = d->reserve - tail;
+		uint8_t *const data = d->data();
+		if (tail) HIP_CHECK(hipMemcpyAsync(data, dec->d_tail.p, tail, hipMemcpyDeviceToDevice, st));
 		// 2. the chain of records: guesses per segment, walks, the host's check
 		t0 = clk::now();
 		const uint32_t n_segs = uint32_t((data_len + BAM_SEG - 1) / BAM_SEG);
@@ -457,9 +510,9 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 			d->h_seg_start.ensure(n_segs); d->h_seg_exit.ensure(n_segs); d->h_count.ensure(n_segs);
 			HIP_CHECK(hipMemsetAsync(d->d_bad.p, 0, 8, st));
 			HIP_CHECK(hipMemcpyAsync(d->seg_start.p, &expect, 8, hipMemcpyHostToDevice, st));
-			if (n_segs > 1) hipLaunchKernelGGL(bam_seg_guess_kernel, dim3((n_segs - 1 + 3) / 4), dim3(256), 0, st, d->d_out.p, data_len, dec->cfg.n_refs, n_segs, d->seg_start.p);
+			if (n_segs > 1) hipLaunchKernelGGL(bam_seg_guess_kernel, dim3((n_segs - 1 + 3) / 4), dim3(256), 0, st, data, data_len, dec->cfg.n_refs, n_segs, d->seg_start.p);
 			if (getenv("DROPEST_BAM_TEST_SPOIL_GUESSES")) hipLaunchKernelGGL(bam_spoil_guesses_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, d->seg_start.p, n_segs);
-			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, d->d_out.p, data_len, (const uint32_t *)nullptr, n_segs, d->seg_start.p,
+			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, data, data_len, (const uint32_t *)nullptr, n_segs, d->seg_start.p,
 			                   d->seg_count.p, d->seg_exit.p, (const uint32_t *)nullptr, (uint64_t *)nullptr, d->d_bad.p + 1);
 			// (a walk from a guess that is not on the chain reads anything as a length: what these walks flag is not looked at -- the walk that
 			// writes the record offsets, from the checked starts, is the one whose flag counts: dropest_bam_decoder_window_finish)
@@ -477,7 +530,7 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 					d->h_seg_start.p[k] = want;
 					HIP_CHECK(hipMemcpyAsync(d->seg_start.p + k, &d->h_seg_start.p[k], 8, hipMemcpyHostToDevice, st));
 					HIP_CHECK(hipMemcpyAsync(d->d_list.p, &k, 4, hipMemcpyHostToDevice, st));
-					hipLaunchKernelGGL(bam_seg_walk_kernel, dim3(1), dim3(256), 0, st, d->d_out.p, data_len, d->d_list.p, 1u, d->seg_start.p, d->seg_count.p, d->seg_exit.p,
+					hipLaunchKernelGGL(bam_seg_walk_kernel, dim3(1), dim3(256), 0, st, data, data_len, d->d_list.p, 1u, d->seg_start.p, d->seg_count.p, d->seg_exit.p,
 					                   (const uint32_t *)nullptr, (uint64_t *)nullptr, d->d_bad.p + 1);
 					HIP_CHECK(hipMemcpyAsync(d->h_seg_exit.p + k, d->seg_exit.p + k, 8, hipMemcpyDeviceToHost, st));
 					HIP_CHECK(hipMemcpyAsync(d->h_count.p + k, d->seg_count.p + k, 4, hipMemcpyDeviceToHost, st));
@@ -497,15 +550,24 @@ extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const 
 		const uint64_t new_tail = data_len - tail_start;
 		if (new_tail) {
 			dec->d_tail.ensure(new_tail + new_tail / 4 + 64);
-			HIP_CHECK(hipMemcpyAsync(dec->d_tail.p, d->d_out.p + tail_start, new_tail, hipMemcpyDeviceToDevice, st));
+			HIP_CHECK(hipMemcpyAsync(dec->d_tail.p, data + tail_start, new_tail, hipMemcpyDeviceToDevice, st));
 			HIP_CHECK(hipStreamSynchronize(st));
 		}
 		dec->tail_len = new_tail;
-		d->data_len = data_len; d->tail_start = tail_start; d->n_rec = n_rec; d->n_segs = n_segs; d->n_blocks = uint32_t(n);
+		d->data_len = data_len; d->tail_start = tail_start; d->n_rec = n_rec; d->n_segs = n_segs;
 		d->refused = out->refused_blocks; d->repaired = out->guesses_repaired;
-		d->ms_copy = out->ms_copy; d->ms_inflate = out->ms_inflate; d->ms_boundaries = out->ms_boundaries;
+		d->ms_boundaries = out->ms_boundaries;
 		d->begun = true;
 	});
+}
+
+// The two parts one after the other (the first half of a window as rounds before 6 had it)
+extern "C" int dropest_bam_decoder_window_begin(dropest_bam_decoder *dec, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
+                                                dropest_bgzf_host_inflate inflate_fallback, void *user, int *slot) {
+	if (dropest_bam_decoder_window_inflate(dec, comp, len, slot)) return 1;
+	const int rc = dropest_bam_decoder_window_chain(dec, *slot, first_skip, final, inflate_fallback, user);
+	if (rc && dec) dec->front[*slot].inflating = false;
+	return rc;
 }
 
 extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slot, dropest_bam_window *out) {
@@ -532,7 +594,7 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			const size_t rc = size_t(n_rec) + size_t(n_rec) / 4;
 			d->rec_off.ensure(rc);
 			HIP_CHECK(hipMemcpyAsync(F.seg_base.p, F.base.data(), size_t(n_segs) * 4, hipMemcpyHostToDevice, st));
-			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, F.d_out.p, data_len, (const uint32_t *)nullptr, n_segs, F.seg_start.p,
+			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, F.data(), data_len, (const uint32_t *)nullptr, n_segs, F.seg_start.p,
 			                   F.seg_count.p, F.seg_exit.p, F.seg_base.p, d->rec_off.p, F.d_bad.p);
 			d->o_qoff.ensure(rc); d->dn_qoff.ensure(rc);
 			d->o_cb.ensure(rc); d->o_umi.ensure(rc); d->o_gene.ensure(rc); d->o_aux.ensure(rc); d->o_uql.ensure(rc); d->o_status.ensure(rc); d->o_need.ensure(rc);
@@ -545,14 +607,14 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			const BamDict dict{d->g_keys.p, d->g_vals.p, d->g_mask, d->d_chr.p, d->annotation ? d->d_ann_chr.p : nullptr, d->annotation ? d->d_ann_id.p : nullptr};
 			const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, d->nd_rec.p, d->nd_pos.p, d->nd_size.p, d->dn_qoff.p};
 			if (d->annotation) HIP_CHECK(hipMemsetAsync(d->a_chr.p, 0xFF, size_t(n_rec) * 4, st));   // (records that are not accepted: "no such chromosome", ignored)
-			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + BAM_PARSE_T - 1) / BAM_PARSE_T)), dim3(BAM_PARSE_T), 0, st, F.d_out.p, d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro, F.d_bad.p);
+			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + BAM_PARSE_T - 1) / BAM_PARSE_T)), dim3(BAM_PARSE_T), 0, st, F.data(), d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro, F.d_bad.p);
 			if (d->annotation) {
 				if (dropest_annotation_query_device(d->annotation, st, n_rec, d->a_chr.p, d->a_pos.p, d->a_end.p, d->a_gene.p, d->a_mark.p)) throw DeviceError(dropest_annotation_last_error());
 				hipLaunchKernelGGL(bam_resolve_annotated_kernel, dim3(uint32_t((n_rec + 255) / 256)), dim3(256), 0, st, uint32_t(n_rec), dict, ro, d->a_gene.p, d->a_mark.p);
 			}
 			hipLaunchKernelGGL(bam_fin_count_kernel, dim3(tiles), dim3(256), 0, st, d->o_status.p, d->o_need.p, d->o_uql.p, uint32_t(n_rec), d->tile_ok.p, d->tile_need.p, d->d_wc.p);
 			hipLaunchKernelGGL(bam_fin_scan_kernel, dim3(1), dim3(1024), 0, st, d->tile_ok.p, d->tile_need.p, tiles, d->d_totals.p);
-			hipLaunchKernelGGL(bam_fin_scatter_kernel, dim3(tiles), dim3(256), 0, st, F.d_out.p, d->rec_off.p, ro, uint32_t(n_rec), d->tile_ok.p, d->tile_need.p, dn);
+			hipLaunchKernelGGL(bam_fin_scatter_kernel, dim3(tiles), dim3(256), 0, st, F.data(), d->rec_off.p, ro, uint32_t(n_rec), d->tile_ok.p, d->tile_need.p, dn);
 			HIP_CHECK(hipGetLastError());
 			HIP_CHECK(hipMemcpyAsync(&wc, d->d_wc.p, sizeof(wc), hipMemcpyDeviceToHost, st));
 			HIP_CHECK(hipMemcpyAsync(totals, d->d_totals.p, 8, hipMemcpyDeviceToHost, st));
@@ -605,7 +667,7 @@ extern "C" int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const u
 		for (uint32_t k = 0; k < n; ++k) if (idx[k] >= d->last_n_rec) throw RangeError("record index outside the window");
 		d->d_gidx.ensure(n); d->d_goff.ensure(n); d->d_gsize.ensure(n); d->h_gsize.ensure(n);
 		HIP_CHECK(hipMemcpyAsync(d->d_gidx.p, idx, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
-		hipLaunchKernelGGL(bam_record_sizes_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, d->front[d->last_front].d_out.p, d->rec_off.p, d->d_gidx.p, n, d->d_gsize.p);
+		hipLaunchKernelGGL(bam_record_sizes_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, d->front[d->last_front].data(), d->rec_off.p, d->d_gidx.p, n, d->d_gsize.p);
 		HIP_CHECK(hipMemcpyAsync(d->h_gsize.p, d->d_gsize.p, size_t(n) * 4, hipMemcpyDeviceToHost, d->stream));
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		uint64_t total = 0;
@@ -613,7 +675,7 @@ extern "C" int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const u
 		if (total > dst_cap) throw InvalidError("destination too small: " + std::to_string(total) + " bytes needed");
 		d->d_gather.ensure(total + total / 4 + 64);
 		HIP_CHECK(hipMemcpyAsync(d->d_goff.p, dst_off, size_t(n) * 8, hipMemcpyHostToDevice, d->stream));
-		hipLaunchKernelGGL(bam_gather_records_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, d->front[d->last_front].d_out.p, d->rec_off.p, d->d_gidx.p, d->d_goff.p, n, d->d_gather.p);
+		hipLaunchKernelGGL(bam_gather_records_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, d->front[d->last_front].data(), d->rec_off.p, d->d_gidx.p, d->d_goff.p, n, d->d_gather.p);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipMemcpyAsync(dst, d->d_gather.p, total, hipMemcpyDeviceToHost, d->stream));
 		HIP_CHECK(hipStreamSynchronize(d->stream));
@@ -642,7 +704,7 @@ extern "C" int dropest_bam_decoder_quality_rows(dropest_bam_decoder *d, uint32_t
 		if (!n) return;
 		HIP_CHECK(hipSetDevice(d->device));
 		d->dn_qual.ensure(n * ql + n * ql / 4); d->h_qual.ensure(n * ql);
-		hipLaunchKernelGGL(bam_quality_rows_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, d->stream, d->front[d->last_front].d_out.p, d->dn_qoff.p, uint32_t(n), ql, d->dn_qual.p);
+		hipLaunchKernelGGL(bam_quality_rows_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, d->stream, d->front[d->last_front].data(), d->dn_qoff.p, uint32_t(n), ql, d->dn_qual.p);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipMemcpyAsync(d->h_qual.p, d->dn_qual.p, n * ql, hipMemcpyDeviceToHost, d->stream));
 		HIP_CHECK(hipStreamSynchronize(d->stream));

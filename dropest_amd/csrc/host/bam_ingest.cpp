@@ -1116,17 +1116,43 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			size_t est_reads = 0;
 			int which = 0;
 			std::future<Staged> next = std::async(std::launch::async, read_window, which, window_bytes);
+			// Round 6, DROPEST_BAM_PIPELINE=1 (off by default): the inflate of window k + 1 is given to the device BEFORE this thread waits for window k
+			// (dropest_bam_decoder_window_inflate / _chain).  A window's inflate lasts as long as its slowest block (7-11 ms on a file that deflates
+			// 3 x) and one window after the other leaves wave slots empty -- 86 ms of inflate in situ for a kernel that needs 42
+			// (profiles/r06a_bam_3x_file_device_trace.txt) -- but the next window's blocks then hold every slot while this window's small kernels
+			// and copies want some: inside the window calls 109-121 -> 81-95 ms, the dictionaries' copies 1 -> 31 ms, two more streams to create
+			// (8 ms each): ingest 195 -> 233 ms on the same box.  Kept as an order the library supports and the suite runs; not the default.
+			const bool pipeline = upload_ahead && getenv("DROPEST_BAM_PIPELINE") && !getenv("DROPEST_BAM_NO_PIPELINE");
+			Staged stg_ahead; int slot_cur = 0, slot_ahead = 0; bool have_ahead = false;
 			for (;;) {
 				auto t_wait = clk::now();
-				Staged stg = next.get();
-				ms_wait_read += since(t_wait);
-				if (!stg.error.empty()) throw std::runtime_error(stg.error + ": " + bam_name);
+				Staged stg;
+				if (have_ahead) { stg = std::move(stg_ahead); slot_cur = slot_ahead; have_ahead = false; }
+				else {
+					stg = next.get();
+					ms_wait_read += since(t_wait);
+					if (!stg.error.empty()) throw std::runtime_error(stg.error + ": " + bam_name);
+					window_bytes = std::min(window_bytes * 4, window_max);       // (1, 4, 16, 64 MB ...: a ramp of x 16 measured the same, 188-201 ms on the 3 x file)
+					which ^= 1;
+					if (!stg.final) next = std::async(std::launch::async, read_window, which, window_bytes);
+					if (pipeline && dropest_bam_decoder_window_inflate(dec, stg.p, stg.used, &slot_cur)) {
+						if (next.valid()) next.wait();
+						throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					}
+				}
 				const bool final = stg.final;
 				const size_t used = stg.used;
-				window_bytes = std::min(window_bytes * 4, window_max);       // (1, 4, 16, 64 MB ...: a ramp of x 16 measured the same, 188-201 ms on the 3 x file)
-				which ^= 1;
-				if (!final) next = std::async(std::launch::async, read_window, which, window_bytes);
-				struct Drain { std::future<Staged> &f; bool armed; ~Drain() { if (armed && f.valid()) f.wait(); } } drain{next, !final};   // (an exception below must not leave the reader running on freed buffers)
+				struct Drain { std::future<Staged> &f; ~Drain() { if (f.valid()) f.wait(); } } drain{next};   // (an exception below must not leave the reader running on freed buffers)
+				if (pipeline && !final) {      // the window after this one: read by now (its buffer is the other one), its blocks to the device
+					t_wait = clk::now();
+					stg_ahead = next.get();
+					ms_wait_read += since(t_wait);
+					if (!stg_ahead.error.empty()) throw std::runtime_error(stg_ahead.error + ": " + bam_name);
+					auto t_a = clk::now();
+					if (dropest_bam_decoder_window_inflate(dec, stg_ahead.p, stg_ahead.used, &slot_ahead)) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					ms_window_calls += since(t_a);
+					have_ahead = true;
+				}
 				auto t_phase = clk::now();
 				if (dict_dirty) {      // the dictionaries as they stand (other files, earlier windows, add_record calls) go to the device
 					container.dictionary_snapshot(dict_hash, dict_id, dict_chr);
@@ -1143,8 +1169,20 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				host_ms[0] += since(t_phase);
 				dropest_bam_window w{};
 				auto t_call = clk::now();
-				if (dropest_bam_decoder_window(dec, stg.p, used, first ? u0 : 0u, final ? 1 : 0, host_inflate, nullptr, &w))
-					throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+				if (!pipeline) {
+					if (dropest_bam_decoder_window(dec, stg.p, used, first ? u0 : 0u, final ? 1 : 0, host_inflate, nullptr, &w))
+						throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+				} else {
+					if (dropest_bam_decoder_window_chain(dec, slot_cur, first ? u0 : 0u, final ? 1 : 0, host_inflate, nullptr))
+						throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					// this window's compressed bytes are done with: the reader may fill their buffer with the window after the next
+					if (have_ahead && !stg_ahead.final) {
+						window_bytes = std::min(window_bytes * 4, window_max);
+						which ^= 1;
+						next = std::async(std::launch::async, read_window, which, window_bytes);
+					}
+					if (dropest_bam_decoder_window_finish(dec, slot_cur, &w)) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+				}
 				ms_window_calls += since(t_call);
 				if (first) { est_reads = size_t(double(w.n_records) * double(map.n - c0) / double(std::max<size_t>(used, 1)) * double(bam_files.size()) * 1.05); container.expect_reads(est_reads); }
 				first = false;

@@ -3,6 +3,8 @@
 #include "rds_writer.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 
@@ -834,6 +836,11 @@ void CellsDataContainer::get_stat_by_real_cells(Stats::CellChrStatType stat, nam
 	std::vector<int> column(present.size(), -1);
 	for (size_t c = 0; c < present.size(); ++c) if (present[c]) { column[c] = int(chromosome_names.size()); chromosome_names.push_back(_chr_indexer.get_value(c)); }
 	const size_t width = chromosome_names.size();
+	// the cells' barcodes from ONE fetch of the rows (round 6: cell(index) twice per row here was two device round trips each -- 3 000 of
+	// them, 59 of the 127 ms of save_results on a 500-cell sample)
+	const size_t n_cells = total_cells_number();
+	std::vector<dropest_cell_row> all_rows(n_cells);
+	if (n_cells) check(dropest_cell_rows(_ctx, 0, n_cells, all_rows.data()));
 	size_t i = 0;
 	while (i < n) {
 		const uint32_t cur = cell[i];
@@ -842,8 +849,8 @@ void CellsDataContainer::get_stat_by_real_cells(Stats::CellChrStatType stat, nam
 		for (; i < n && cell[i] == cur; ++i)
 			if (kind[i] == uint32_t(stat)) { row[size_t(column[chr[i]])] = cnt[i]; any = true; }
 		if (!any) continue;   // Stats::get returns false for a cell without entries of this kind (Stats.cpp:50-63)
-		this->cell(cur);      // (validates the id)
-		cell_barcodes.push_back(decode(this->cell(cur)._row.barcode));
+		if (cur >= n_cells) throw std::out_of_range("cell index out of range");
+		cell_barcodes.push_back(decode(all_rows[cur].barcode));
 		counts.insert(counts.end(), row.begin(), row.end());
 	}
 }
@@ -1012,12 +1019,12 @@ ResultsPrinter::SparseMatrix ResultsPrinter::named_matrix(const CellsDataContain
 	SparseMatrix M;
 	// column names: filtered cells in their order / real cells in cell-id order
 	if (col_names) M.col_names = *col_names;
-	else if (filtered) { for (size_t id : c.filtered_cells()) M.col_names.push_back(c.cell(id).barcode()); }
-	else {
+	else {      // (one fetch of the rows for either list: cell(id) per filtered cell was a device round trip each)
 		const size_t n = c.total_cells_number();
 		std::vector<dropest_cell_row> rows(n);
 		if (n && dropest_cell_rows(c.handle(), 0, n, rows.data()) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
-		for (auto const &r : rows) if (r.is_real) M.col_names.push_back(c.decode(r.barcode));
+		if (filtered) { for (size_t id : c.filtered_cells()) M.col_names.push_back(c.decode(rows.at(id).barcode)); }
+		else for (auto const &r : rows) if (r.is_real) M.col_names.push_back(c.decode(r.barcode));
 	}
 	M.colptr.assign(colptr, colptr + ncols + 1);
 	M.values.resize(nnz);
@@ -1044,21 +1051,39 @@ ResultsPrinter::SparseMatrix ResultsPrinter::named_matrix(const CellsDataContain
 	// filled in gene-index order (filtered: Cell.cpp:54-68) -- replayed here with the same container type; the raw
 	// matrix walks the std::map directly (gene-index order, ResultsPrinter.cpp:376-387).  Inside a column the entries
 	// are then sorted by row id (Eigen::setFromTriplets builds a CSC with ascending inner indices).
-	std::vector<std::pair<uint32_t, uint32_t>> of_col;
-	for (uint64_t col = 0; col < ncols; ++col) {
-		src.column(col, of_col);
-		entries.clear();   // (row, value)
-		if (filtered) {
-			std::unordered_map<std::string, size_t> per_gene;
-			std::unordered_map<std::string, uint32_t> gene_of;
-			for (auto const &e : of_col) { per_gene.emplace(genes[e.first], e.second); gene_of.emplace(genes[e.first], e.first); }
-			for (auto const &kv : per_gene) entries.emplace_back(row_id(gene_of.at(kv.first)), uint32_t(kv.second));
-		} else {
-			for (auto const &e : of_col) entries.emplace_back(row_id(e.first), e.second);
+	// Three steps (round 6: the one loop over the columns -- two string-keyed hash maps per filtered column -- was most of what save_results
+	// still took): (1) every column's entries in the order the reference meets them, columns side by side on host threads (the iteration order
+	// of a column's own unordered_map hangs on nothing outside it); (2) rows numbered on first encounter, one walk in column order; (3) rows in
+	// place of the genes and every column sorted by row, side by side again.  M.rowidx holds gene ids between (1) and (3).
+	const size_t n_pieces = std::max<size_t>(1, std::min<size_t>(size_t(ncols), 256));
+	auto piece_cols = [&](size_t piece, uint64_t &c0, uint64_t &c1) { c0 = ncols * piece / n_pieces; c1 = ncols * (piece + 1) / n_pieces; };
+	Rds::parallel_pieces(n_pieces, 0, [&](size_t piece) {
+		uint64_t c0, c1; piece_cols(piece, c0, c1);
+		std::vector<std::pair<uint32_t, uint32_t>> of_col;
+		for (uint64_t col = c0; col < c1; ++col) {
+			src.column(col, of_col);
+			uint32_t k = colptr[col];
+			if (filtered) {
+				std::unordered_map<std::string, size_t> per_gene;
+				std::unordered_map<std::string, uint32_t> gene_of;
+				for (auto const &e : of_col) { per_gene.emplace(genes[e.first], e.second); gene_of.emplace(genes[e.first], e.first); }
+				for (auto const &kv : per_gene) { M.rowidx[k] = gene_of.at(kv.first); M.values[k] = uint32_t(kv.second); ++k; }
+			} else {
+				for (auto const &e : of_col) { M.rowidx[k] = e.first; M.values[k] = e.second; ++k; }
+			}
 		}
-		std::sort(entries.begin(), entries.end());
-		for (uint32_t k = colptr[col], j = 0; k < colptr[col + 1]; ++k, ++j) { M.rowidx[k] = entries[j].first; M.values[k] = entries[j].second; }
-	}
+	});
+	for (uint64_t k = 0; k < nnz; ++k) row_id(M.rowidx[k]);
+	Rds::parallel_pieces(n_pieces, 0, [&](size_t piece) {
+		uint64_t c0, c1; piece_cols(piece, c0, c1);
+		std::vector<std::pair<uint32_t, uint32_t>> ent;
+		for (uint64_t col = c0; col < c1; ++col) {
+			ent.clear();
+			for (uint32_t k = colptr[col]; k < colptr[col + 1]; ++k) ent.emplace_back(row_of_gene[M.rowidx[k]], M.values[k]);
+			std::sort(ent.begin(), ent.end());
+			for (uint32_t k = colptr[col], j = 0; k < colptr[col + 1]; ++k, ++j) { M.rowidx[k] = ent[j].first; M.values[k] = ent[j].second; }
+		}
+	});
 	return M;
 }
 
@@ -1103,6 +1128,15 @@ void ResultsPrinter::save_mtx(const CellsDataContainer &c, const std::string &ba
 // reads_per_umi_per_cell) is not pinned by anything and is deterministic here: cell-id order, then gene index, then UMI.
 Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 	using namespace Rds;
+	// DROPEST_RDS_TRACE=1: where save_results spends its time (stderr)
+	const bool rds_trace = getenv("DROPEST_RDS_TRACE") != nullptr;
+	auto rds_t0 = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!rds_trace) return;
+		const auto now = std::chrono::steady_clock::now();
+		std::fprintf(stderr, "[rds] %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - rds_t0).count());
+		rds_t0 = now;
+	};
 	// both matrices are part of the list: cm_raw's emit + copy to the host start now, on the device's second stream, and
 	// run under the cell rows and cm (a sharded container has assembled both already)
 	if (!c.sharded()) {
@@ -1114,6 +1148,7 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 	const std::vector<size_t> filtered_at = c.filtered_positions(real);
 	std::vector<std::string> real_names;
 	for (const Cell &cell : real) real_names.push_back(cell.barcode());
+	lap("real cells and their names");
 
 	auto matrix = [&](bool filtered) {
 		SparseMatrix M = get_count_matrix(c, filtered, true);
@@ -1138,7 +1173,60 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 	std::unordered_map<size_t, std::vector<Cell::MoleculeRow>> filtered_mols;   // by position in `real`
 	std::vector<char> is_filtered(real.size(), 0);
 	for (size_t k : filtered_at) is_filtered[k] = 1;
-	for (size_t k = 0; k < real.size(); ++k) {
+	// One fetch of the whole molecule table (ascending cell id, gene id, UMI code: the order the per-cell walks below see) instead of three
+	// device round trips per real cell, and the barcodes / UMIs of saturation_info as packed codes that the writer's threads turn into
+	// strings (round 6: with 500 real cells and 4e6 molecules the walks and their strings were 200 of the 245 ms of save_results).
+	// Not with umi_correction_info (per-molecule quality sums), a sharded container, or strings with N in play (escaped codes).
+	ValuePtr sat_cbs_packed, sat_umis_packed;
+	bool bulk = !c.sharded() && !umi_correction_info;
+	if (bulk) {
+		uint64_t n_mol = 0;
+		if (dropest_molecules(c.handle(), &n_mol, nullptr, nullptr, nullptr, nullptr, nullptr) != DROPEST_OK) throw std::runtime_error(dropest_last_error());
+		std::vector<uint32_t> m_cell(n_mol), m_gene(n_mol), m_reads(n_mol);
+		std::vector<uint64_t> m_umi(n_mol);
+		std::vector<uint8_t> m_mark(n_mol);
+		if (n_mol && dropest_molecules(c.handle(), &n_mol, m_cell.data(), m_gene.data(), m_umi.data(), m_reads.data(), m_mark.data()) != DROPEST_OK)
+			throw std::runtime_error(dropest_last_error());
+		uint8_t wanted[8] = {0, 0, 0, 0, 0, 0, 0, 0};                         // mark bits -> does it match the container's levels
+		for (int b = 0; b < 8; ++b) {
+			UMI::Mark m;
+			if (b & 1) m.add(UMI::Mark::HAS_NOT_ANNOTATED);
+			if (b & 2) m.add(UMI::Mark::HAS_EXONS);
+			if (b & 4) m.add(UMI::Mark::HAS_INTRONS);
+			wanted[b] = m.match(c.gene_match_level()) ? 1 : 0;
+		}
+		// every real cell's rows [lo, hi) of the table, its sums, and its place in the three saturation vectors
+		std::vector<size_t> lo(real.size()), hi(real.size()), sat_at(real.size() + 1, 0);
+		Rds::parallel_pieces(real.size(), 0, [&](size_t k) {
+			const uint32_t id = uint32_t(real[k].id());
+			lo[k] = size_t(std::lower_bound(m_cell.begin(), m_cell.end(), id) - m_cell.begin());
+			hi[k] = size_t(std::upper_bound(m_cell.begin() + long(lo[k]), m_cell.end(), id) - m_cell.begin());
+			double reads = 0; size_t rr = 0, ns = 0;
+			for (size_t i = lo[k]; i < hi[k]; ++i) { reads += double(m_reads[i]); if (wanted[m_mark[i] & 7]) { rr += m_reads[i]; ++ns; } }
+			mean_rpu[k] = reads / double(hi[k] - lo[k]);
+			req_reads[k] = int32_t(rr);
+			sat_at[k + 1] = ns;
+		});
+		for (size_t k = 0; k < real.size(); ++k) { sat_at[k + 1] += sat_at[k]; req_umis[k] = int32_t(real[k].requested_umis_num()); }
+		std::vector<uint64_t> cb_codes(sat_at.back()), umi_codes(sat_at.back());
+		sat_reads.resize(sat_at.back());
+		std::atomic<bool> escaped{false};
+		Rds::parallel_pieces(real.size(), 0, [&](size_t k) {
+			size_t at = sat_at[k];
+			const uint64_t cbc = real[k].barcode_code();
+			if (cbc >> 63) escaped.store(true, std::memory_order_relaxed);
+			for (size_t i = lo[k]; i < hi[k]; ++i)
+				if (wanted[m_mark[i] & 7]) { sat_reads[at] = int32_t(m_reads[i]); cb_codes[at] = cbc; umi_codes[at] = m_umi[i]; if (m_umi[i] >> 63) escaped.store(true, std::memory_order_relaxed); ++at; }
+		});
+		if (escaped.load()) {      // strings with N: as strings (the side table lives in the container)
+			sat_cbs.resize(cb_codes.size()); sat_umis.resize(umi_codes.size());
+			Rds::parallel_pieces((cb_codes.size() + 65535) / 65536, 0, [&](size_t piece) {
+				for (size_t i = piece * 65536; i < std::min(cb_codes.size(), (piece + 1) * 65536); ++i) { sat_cbs[i] = c.decode(cb_codes[i]); sat_umis[i] = c.decode(umi_codes[i]); }
+			});
+		} else { sat_cbs_packed = strings_from_packed(std::move(cb_codes)); sat_umis_packed = strings_from_packed(std::move(umi_codes)); }
+	}
+	lap("molecule table and saturation vectors (bulk)");
+	for (size_t k = 0; !bulk && k < real.size(); ++k) {
 		const Cell &cell = real[k];
 		auto mols = cell.molecules();
 		double reads = 0;
@@ -1170,15 +1258,20 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 	std::vector<int32_t> aligned_reads(real.size()), aligned_umis(real.size());
 	for (size_t k = 0; k < real.size(); ++k) { aligned_reads[k] = real[k].stat(Stats::TOTAL_READS_PER_CB); aligned_umis[k] = real[k].stat(Stats::TOTAL_UMIS_PER_CB); }
 
+	lap("merge targets, per-cell vectors");
+	ValuePtr v_cm = matrix(true);
+	lap("cm named");
+	ValuePtr v_raw = matrix(false);
+	lap("cm_raw named");
 	std::vector<std::pair<std::string, ValuePtr>> d = {
-		{"cm", matrix(true)},
-		{"cm_raw", matrix(false)},
+		{"cm", v_cm},
+		{"cm_raw", v_raw},
 		{"reads_per_chr_per_cells", named_list({{"Exon", chr_frame(Stats::EXON_READS_PER_CHR_PER_CELL)},
 		                                        {"Intron", chr_frame(Stats::INTRON_READS_PER_CHR_PER_CELL)},
 		                                        {"Intergenic", chr_frame(Stats::INTERGENIC_READS_PER_CHR_PER_CELL)}})},
 		{"mean_reads_per_umi", with_names(reals(std::move(mean_rpu)), real_names)},
-		{"saturation_info", named_list({{"reads", integers(std::move(sat_reads))}, {"cbs", strings(std::move(sat_cbs))},
-		                                {"umis", strings(std::move(sat_umis))}})},
+		{"saturation_info", named_list({{"reads", integers(std::move(sat_reads))}, {"cbs", sat_cbs_packed ? sat_cbs_packed : strings(std::move(sat_cbs))},
+		                                {"umis", sat_umis_packed ? sat_umis_packed : strings(std::move(sat_umis))}})},
 		{"merge_targets", named_list(std::move(merged))},
 		{"aligned_reads_per_cell", with_names(integers(std::move(aligned_reads)), real_names)},
 		{"aligned_umis_per_cell", with_names(integers(std::move(aligned_umis)), real_names)},
@@ -1216,6 +1309,7 @@ Rds::ValuePtr ResultsPrinter::results_list(const CellsDataContainer &c) const {
 		                                                     {"gene_indexes", integers(std::move(gene_indexes))},
 		                                                     {"reads_per_umi", list(std::move(per_gene))}}));
 	}
+	lap("chromosome frames and the list");
 	return named_list(std::move(d));
 }
 
@@ -1235,7 +1329,10 @@ void ResultsPrinter::save_results(const CellsDataContainer &c, const std::string
 	std::string base = filename;
 	const size_t dot = filename.find_last_of('.');
 	if (dot != std::string::npos && filename.substr(dot + 1) == "rds") base = filename.substr(0, dot);
-	Rds::save(results_list(c), base + ".rds");                          // save_rds (:442-452)
+	const Rds::ValuePtr v = results_list(c);
+	const auto t_save = std::chrono::steady_clock::now();
+	Rds::save(v, base + ".rds");                                        // save_rds (:442-452)
+	if (getenv("DROPEST_RDS_TRACE")) std::fprintf(stderr, "[rds] serialise + deflate + write %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_save).count());
 	if (write_matrix) save_mtx(c, base);
 }
 

@@ -255,6 +255,7 @@ public:
 		}
 	};
 	uint64_t barcode_code() const { return _row.barcode; }   // (a cell's barcode never changes)
+	size_t id() const { return _id; }                        // index in the container (first-seen rank of the barcode)
 	bool is_merged() const { sync(); return _row.is_merged; }
 	bool is_excluded() const { sync(); return _row.is_excluded; }
 	bool is_real() const { sync(); return _row.is_real; }

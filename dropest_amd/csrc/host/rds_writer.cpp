@@ -50,6 +50,7 @@ constexpr size_t LONG_VECTOR = 4096;                 // vectors from here on are
 inline void put32(unsigned char *b, uint32_t u) { b[0] = static_cast<unsigned char>(u >> 24); b[1] = static_cast<unsigned char>(u >> 16); b[2] = static_cast<unsigned char>(u >> 8); b[3] = static_cast<unsigned char>(u); }
 inline void put64(unsigned char *b, uint64_t u) { put32(b, uint32_t(u >> 32)); put32(b + 4, uint32_t(u)); }
 inline size_t charsxp_size(const std::string &s) { return 8 + s.size(); }
+inline size_t packed_length(uint64_t code) { return code ? size_t(63 - __builtin_clzll(code)) / 2 : 0; }   // bases of a packed code (sentinel bit above them)
 inline void charsxp_to(std::vector<unsigned char> &out, const std::string &s) {
 	bool ascii = true;
 	for (unsigned char c : s) ascii &= c < 128;
@@ -63,7 +64,7 @@ inline void charsxp_to(std::vector<unsigned char> &out, const std::string &s) {
 
 // One stretch of the serialisation: literal bytes [a, b) of the arena, or elements [a, b) of a vector the value owns.
 struct Part {
-	enum Kind { Literal, I32, U32AsI32, F64, U32AsF64, Strings } kind;
+	enum Kind { Literal, I32, U32AsI32, F64, U32AsF64, Strings, Packed } kind;
 	const void *src;
 	size_t a, b;
 };
@@ -140,6 +141,13 @@ public:
 				else { length(v.reals.size()); for (double x : v.reals) f64(x); }
 				break;
 			case Value::String:
+				if (v.from_packed) {
+					i32(STRSXP | extra); length(v.packed.size());
+					size_t bytes = 0;      // (sized from every 64th code)
+					for (size_t k = 0; k < v.packed.size(); k += 64) bytes += 8 + packed_length(v.packed[k]);
+					range(Part::Packed, v.packed.data(), v.packed.size(), std::max<size_t>(8, bytes / std::max<size_t>(1, (v.packed.size() + 63) / 64)));
+					break;
+				}
 				i32(STRSXP | extra); length(v.strings.size());
 				if (v.strings.size() >= LONG_VECTOR) {
 					// (sized from the vector's own mean: the pieces need not be equal, only bounded)
@@ -189,6 +197,18 @@ public:
 					for (size_t i = 0; i < n; ++i) { const double x = double(s[i]); uint64_t u; std::memcpy(&u, &x, 8); u = __builtin_bswap64(u); std::memcpy(d + 8 * i, &u, 8); }
 					break;
 				}
+				case Part::Packed: {
+					const uint64_t *c = static_cast<const uint64_t *>(p.src);
+					for (size_t i = p.a; i < p.b; ++i) {
+						if (c[i] >> 63) throw std::runtime_error("rds: an escaped code in a packed string vector");
+						const size_t len = packed_length(c[i]), w = out.size();
+						out.resize(w + 8 + len);
+						put32(&out[w], uint32_t(CHARSXP | (GP_ASCII << 12)));
+						put32(&out[w + 4], uint32_t(len));
+						for (size_t b = 0; b < len; ++b) out[w + 8 + b] = static_cast<unsigned char>("ACGT"[(c[i] >> (2 * (len - 1 - b))) & 3]);
+					}
+					break;
+				}
 				case Part::Strings: {
 					const std::string *s = static_cast<const std::string *>(p.src);
 					for (size_t i = p.a; i < p.b; ++i) charsxp_to(out, s[i]);
@@ -222,6 +242,7 @@ ValuePtr integers(std::vector<int32_t> v) { auto p = make(Value::Integer); p->in
 ValuePtr reals(std::vector<double> v) { auto p = make(Value::Real); p->reals = std::move(v); return p; }
 ValuePtr integers_from_u32(std::vector<uint32_t> v) { auto p = make(Value::Integer); p->u32s = std::move(v); p->from_u32 = true; return p; }
 ValuePtr reals_from_u32(std::vector<uint32_t> v) { auto p = make(Value::Real); p->u32s = std::move(v); p->from_u32 = true; return p; }
+ValuePtr strings_from_packed(std::vector<uint64_t> codes) { auto p = make(Value::String); p->packed = std::move(codes); p->from_packed = true; return p; }
 ValuePtr strings(std::vector<std::string> v) { auto p = make(Value::String); p->strings = std::move(v); return p; }
 ValuePtr list(std::vector<ValuePtr> items) { auto p = make(Value::List); p->items = std::move(items); return p; }
 

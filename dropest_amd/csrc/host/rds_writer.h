@@ -31,6 +31,8 @@ struct Value {
 	enum Kind { Null, Integer, Real, String, List, S4 } kind = Null;
 	std::vector<uint32_t> u32s;                                    // Integer / Real from 32-bit unsigned slots (no widened copy: the writer converts as it swaps)
 	bool from_u32 = false;
+	std::vector<uint64_t> packed;                                  // String from 2-bit packed base codes (include/dropest_amd.h: sentinel bit + 2 bits per base): decoded by the writer's threads
+	bool from_packed = false;
 	std::vector<int32_t> ints;
 	std::vector<double> reals;
 	std::vector<std::string> strings;
@@ -53,6 +55,9 @@ ValuePtr data_frame(const std::vector<std::string> &col_names, const std::vector
 // (the three slot vectors are taken over, not copied: pass std::move(...) where the caller is done with them)
 ValuePtr dgCMatrix(std::vector<uint32_t> colptr, std::vector<uint32_t> rowidx, std::vector<uint32_t> values,
                    const std::vector<std::string> &row_names, const std::vector<std::string> &col_names);
+// a character vector of base strings given as packed codes (no escapes: bit 63 clear; 0 = the empty string) -- millions of barcodes / UMIs
+// (saturation_info) become strings only inside the writer's pieces
+ValuePtr strings_from_packed(std::vector<uint64_t> codes);
 ValuePtr integers_from_u32(std::vector<uint32_t> v);      // values must be below 2^31
 ValuePtr reals_from_u32(std::vector<uint32_t> v);
 

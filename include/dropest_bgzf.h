@@ -99,6 +99,13 @@ int dropest_bam_decoder_window(dropest_bam_decoder *d, const uint8_t *comp, uint
 int dropest_bam_decoder_window_begin(dropest_bam_decoder *d, const uint8_t *comp, uint64_t len, uint32_t first_skip, int final,
                                      dropest_bgzf_host_inflate inflate_fallback, void *user, int *slot);
 int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slot, dropest_bam_window *out);
+/* _begin in two parts, for ONE thread that keeps the device busy (round 6; what BamController::parse_bam_files does on the device path,
+ * BamProcessing/BamController.cpp:70-116): _inflate enqueues the copies and the inflate kernel of a window and returns at once -- it needs
+ * nothing from the window before, so window k + 1 is given to the device BEFORE the caller waits for window k; _chain then waits for the
+ * inflate of `slot`, puts the record the window before cut off in front of the data and finds the chain of records (windows take _chain in
+ * file order).  The order per window k:  _inflate(k + 1); _chain(k); _finish(k).  comp must stay untouched until _chain has returned. */
+int dropest_bam_decoder_window_inflate(dropest_bam_decoder *d, const uint8_t *comp, uint64_t len, int *slot);
+int dropest_bam_decoder_window_chain(dropest_bam_decoder *d, int slot, uint32_t first_skip, int final, dropest_bgzf_host_inflate inflate_fallback, void *user);
 /* The dictionaries the records are looked up in (copied): gene_hash[k] (FNV-1a of the name) -> gene_id[k]; chr_of_ref[r] = chromosome
  * index of reference r, -1 = none yet.  Call again whenever they have grown. */
 int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, const uint64_t *gene_hash, const uint32_t *gene_id, uint32_t n_genes,

@@ -37,8 +37,10 @@ int main(int argc, char **argv) {
 		for (size_t k = 0; k < ints.size(); ++k) ints[k] = int32_t(k * 7919u) - 1000000;
 		for (size_t k = 0; k < dbl.size(); ++k) dbl[k] = double(k) * 0.37 - 11.0;
 		auto big = [&] {
+			std::vector<uint64_t> codes(200003);      // packed base strings (sentinel bit + 2 bits per base), lengths 0..31
+			for (size_t k = 0; k < codes.size(); ++k) { const int len = int(k % 32); uint64_t c = len ? 1 : 0; for (int b = 0; b < len; ++b) c = (c << 2) | ((k >> (b % 17)) & 3); codes[k] = c; }
 			return named_list({{"cm", dgCMatrix(colptr, rows, vals, genes, cells)}, {"ints", integers(ints)}, {"reals", reals(dbl)}, {"strs", strings(many)},
-			                   {"tail", integers({1, 2, 3})}});
+			                   {"packed", strings_from_packed(codes)}, {"tail", integers({1, 2, 3})}});
 		};
 		save(big(), std::string(argv[2]) + ".one.rds", 1);
 		save(big(), std::string(argv[2]) + ".many.rds", 8);

@@ -38,7 +38,11 @@ def _check_long_vectors(base):
         members += 1
     assert members > 5
     d = rr.read_rds(base + ".many.rds")
-    assert d.names == ["cm", "ints", "reals", "strs", "tail"]
+    assert d.names == ["cm", "ints", "reals", "strs", "packed", "tail"]
+    pk = d["packed"].value
+    assert len(pk) == 200003
+    for j in (0, 1, 31, 32, 33, 4097, 100000, 200002):
+        assert pk[j] == "".join("ACGT"[(j >> (b % 17)) & 3] for b in range(j % 32)), j
     n = 700001
     colptr = np.arange(1001, dtype=np.uint64) * n // 1000
     k = np.arange(n, dtype=np.uint64)
