@@ -180,6 +180,10 @@ struct dropest_bam_decoder {
 	PinnedBuf<uint8_t> h_stage[2];
 	PinnedBuf<uint32_t> h_need_rec, h_need_pos, h_need_size, h_gsize;
 	uint32_t g_mask = 0;
+	DevBuf<uint32_t> g_name_off;      // the dictionary's gene names by index (dropest_bam_decoder_set_gene_names), 0 names: hashes alone
+	DevBuf<uint8_t> g_name_pool;
+	uint32_t n_gene_names = 0;
+	unsigned long long hash_mask = ~0ull;
 	uint64_t tail_len = 0, last_n_rec = 0, last_n_ok = 0;
 	// the compressed bytes of a staging buffer on their way to the device ahead of the window call (dropest_bam_decoder_upload)
 	hipStream_t up_stream = nullptr;   // the device's null stream: it exists already (a stream of its own is 6-8 ms to create), and the decoder's other streams do not wait for it (non-blocking)
@@ -223,6 +227,7 @@ extern "C" int dropest_bam_decoder_create(int device, const dropest_bam_parse_cf
 		auto *d = new dropest_bam_decoder();
 		d->device = device;
 		std::memcpy(&d->cfg, cfg, sizeof(BamParseCfg));
+		if (const char *e = getenv("DROPEST_BAM_TEST_GENE_HASH_BITS")) { const int b = atoi(e); if (b > 0 && b < 64) d->hash_mask = (1ull << b) - 1ull; }   // (tests: names that collide)
 		try {
 			using clk = std::chrono::steady_clock;
 			const bool trace = getenv("DROPEST_BAM_TRACE") != nullptr;
@@ -259,7 +264,7 @@ extern "C" int dropest_bam_decoder_reset(dropest_bam_decoder *d, const dropest_b
 		d->up_ready[0].store(false, std::memory_order_relaxed); d->up_ready[1].store(false, std::memory_order_relaxed);
 		std::memcpy(&d->cfg, cfg, sizeof(BamParseCfg));
 		d->tail_len = 0; d->last_n_rec = 0; d->last_n_ok = 0; d->next_front = 0; d->last_front = 0;
-		d->annotation = nullptr; d->n_ann_genes = 0;
+		d->annotation = nullptr; d->n_ann_genes = 0; d->n_gene_names = 0;
 		HIP_CHECK(hipMemset(d->g_vals.p, 0, size_t(d->g_mask + 1) * 4));
 		d->d_chr.ensure(size_t(std::max(1, cfg->n_refs)));
 		HIP_CHECK(hipMemset(d->d_chr.p, 0xFF, size_t(std::max(1, cfg->n_refs)) * 4));
@@ -354,6 +359,23 @@ extern "C" int dropest_bam_decoder_set_annotation_genes(dropest_bam_decoder *d, 
 		HIP_CHECK(hipSetDevice(d->device));
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		if (n) HIP_CHECK(hipMemcpy(d->d_ann_id.p, id_of_ann_gene, size_t(n) * 4, hipMemcpyHostToDevice));
+	});
+}
+
+// The names of the genes in the dictionary, by index: name k = pool[off[k] .. off[k + 1]).  With them a record's gene is accepted on the device
+// only if its bytes ARE the name the hash points at; a name that merely shares the FNV-1a value of another goes to the host (which interns it
+// by its bytes, CellsDataContainer::intern_gene).  Call after dropest_bam_decoder_set_dictionaries, with every gene the dictionary holds.
+extern "C" int dropest_bam_decoder_set_gene_names(dropest_bam_decoder *d, const uint32_t *off, const uint8_t *pool, uint32_t n_names) {
+	return bgzf_guarded([&] {
+		if (!d || (n_names && (!off || !pool))) throw InvalidError("null argument");
+		HIP_CHECK(hipSetDevice(d->device));
+		HIP_CHECK(hipStreamSynchronize(d->stream));
+		d->n_gene_names = 0;
+		if (!n_names) return;
+		d->g_name_off.ensure(size_t(n_names) + 1 + n_names / 4); d->g_name_pool.ensure(size_t(off[n_names]) + off[n_names] / 4 + 16);
+		HIP_CHECK(hipMemcpy(d->g_name_off.p, off, (size_t(n_names) + 1) * 4, hipMemcpyHostToDevice));
+		if (off[n_names]) HIP_CHECK(hipMemcpy(d->g_name_pool.p, pool, off[n_names], hipMemcpyHostToDevice));
+		d->n_gene_names = n_names;
 	});
 }
 
@@ -604,7 +626,8 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			HIP_CHECK(hipMemsetAsync(d->d_wc.p, 0, sizeof(BamWindowCounts), st));
 			if (d->annotation) { d->a_chr.ensure(rc); d->a_pos.ensure(rc); d->a_end.ensure(rc); d->a_gene.ensure(rc); d->a_mark.ensure(rc); }
 			const BamRecordOut ro{d->o_cb.p, d->o_umi.p, d->o_gene.p, d->o_aux.p, d->o_uql.p, d->o_qoff.p, d->o_status.p, d->o_need.p, d->a_chr.p, d->a_pos.p, d->a_end.p};
-			const BamDict dict{d->g_keys.p, d->g_vals.p, d->g_mask, d->d_chr.p, d->annotation ? d->d_ann_chr.p : nullptr, d->annotation ? d->d_ann_id.p : nullptr};
+			const BamDict dict{d->g_keys.p, d->g_vals.p, d->g_mask, d->d_chr.p, d->annotation ? d->d_ann_chr.p : nullptr, d->annotation ? d->d_ann_id.p : nullptr,
+			                   d->n_gene_names ? d->g_name_off.p : nullptr, d->g_name_pool.p, d->n_gene_names, d->hash_mask};
 			const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, d->nd_rec.p, d->nd_pos.p, d->nd_size.p, d->dn_qoff.p};
 			if (d->annotation) HIP_CHECK(hipMemsetAsync(d->a_chr.p, 0xFF, size_t(n_rec) * 4, st));   // (records that are not accepted: "no such chromosome", ignored)
 			hipLaunchKernelGGL(bam_parse_kernel, dim3(uint32_t((n_rec + BAM_PARSE_T - 1) / BAM_PARSE_T)), dim3(BAM_PARSE_T), 0, st, F.data(), d->rec_off.p, uint32_t(n_rec), d->cfg, dict, ro, F.d_bad.p);

@@ -1030,6 +1030,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			};
 			std::vector<uint32_t> idx_all, p_pos, p_gene, p_aux; std::vector<uint64_t> need_off, p_cb, p_umi; std::vector<uint8_t> need_bytes;
 			std::vector<uint64_t> dict_hash; std::vector<uint32_t> dict_id; std::vector<int32_t> dict_chr;
+			std::vector<uint32_t> name_off; std::vector<uint8_t> name_pool;
 			double dev_ms[4] = {0, 0, 0, 0}, host_ms[3] = {0, 0, 0};
 			const auto t_file = clk::now();
 			size_t window_bytes = size_t(1) << 20, n_windows = 0, repaired = 0, refused = 0, n_needs = 0;
@@ -1158,6 +1159,17 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					container.dictionary_snapshot(dict_hash, dict_id, dict_chr);
 					if (dropest_bam_decoder_set_dictionaries(dec, dict_hash.data(), dict_id.data(), uint32_t(dict_hash.size()), dict_chr.data(), uint32_t(dict_chr.size())))
 						throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					{   // ... and the genes' names: a hash the device finds is confirmed byte by byte (two names with one FNV-1a value must not share an index)
+						const auto &names = container.gene_indexer().values();
+						name_off.resize(names.size() + 1);
+						size_t bytes = 0;
+						for (size_t g = 0; g < names.size(); ++g) { name_off[g] = uint32_t(bytes); bytes += names[g].size(); }
+						name_off[names.size()] = uint32_t(bytes);
+						name_pool.resize(bytes + 1);
+						for (size_t g = 0; g < names.size(); ++g) std::memcpy(name_pool.data() + name_off[g], names[g].data(), names[g].size());
+						if (bytes > 0xFFFFFFF0ull || dropest_bam_decoder_set_gene_names(dec, name_off.data(), name_pool.data(), uint32_t(names.size())))
+							throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+					}
 					if (ann.a) {   // the annotation's genes that the dictionary holds by now
 						for (size_t g = 0; g < flat.gene_names.size(); ++g)
 							if (id_of_ann_gene[g] < 0) id_of_ann_gene[g] = int32_t(container.lookup_gene(ann_gene_hash[g], flat.gene_names[g]));

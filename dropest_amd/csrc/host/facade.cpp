@@ -262,7 +262,8 @@ bool CellsDataContainer::pack_code(std::string_view s, uint64_t &code) { return 
 uint64_t CellsDataContainer::hash_name(std::string_view s) {   // FNV-1a
 	uint64_t h = 1469598103934665603ull;
 	for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
-	return h;
+	static const uint64_t mask = [] { const char *e = getenv("DROPEST_BAM_TEST_GENE_HASH_BITS"); const int b = e ? atoi(e) : 0; return b > 0 && b < 64 ? (1ull << b) - 1ull : ~0ull; }();   // (tests: names that collide)
+	return h & mask;
 }
 
 int64_t CellsDataContainer::lookup_gene(uint64_t gene_hash, std::string_view name) const {

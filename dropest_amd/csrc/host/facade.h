@@ -401,8 +401,8 @@ public:
 	// index of a gene that is ALREADY in the dictionary, -1 otherwise; safe to call from several threads as long as no
 	// add_record runs at the same time
 	int64_t lookup_gene(uint64_t gene_hash, std::string_view name) const;
-	// by the hash alone (the device BAM path has no string in hand: csrc/k_bamparse.h): the index of the FIRST name with this FNV-1a
-	// value, -1 = unseen.  Two names of one data set with the same 64-bit hash would share an index on that path (2^-64 per pair).
+	// by the hash alone: the index of the FIRST name with this FNV-1a value, -1 = unseen.  (The device BAM path confirms a hit against the
+	// name's bytes since round 6 -- dropest_bam_decoder_set_gene_names -- so two names with one hash do not share an index there either.)
 	int64_t lookup_gene_hash(uint64_t gene_hash) const { auto it = _gene_by_hash.find(gene_hash); return it == _gene_by_hash.end() ? -1 : int64_t(it->second); }
 	int device() const { return _device; }
 	// the gene dictionary as (hash, index) pairs and the chromosome index of every reference (-1 = none yet): what the device BAM path looks records up in

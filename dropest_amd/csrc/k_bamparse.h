@@ -135,6 +135,12 @@ struct BamDict {
 	const int32_t *chr_of_ref;
 	const int32_t *ann_chr_of_ref;    // -g: reference id -> chromosome of the annotation (-1: it has none of that name); null without -g
 	const int32_t *id_of_ann_gene;    // -g: gene of the annotation -> index in the host's gene dictionary, -1 = not in it yet
+	// the names of the dictionary's genes by index (dropest_bam_decoder_set_gene_names; null: none given): a hash that is found is confirmed
+	// byte by byte, so two names with one FNV-1a value cannot share an index -- the second one goes to the host like any unseen name
+	const uint32_t *name_off;         // [n_names + 1]
+	const uint8_t *name_pool;
+	uint32_t n_names;
+	unsigned long long hash_mask;     // all ones (tests: a few bits, so that names do collide)
 };
 __host__ __device__ inline uint32_t bam_dict_slot(unsigned long long h, uint32_t mask) { return uint32_t((h ^ (h >> 29)) * 0x9E3779B97F4A7C15ull >> 40) & mask; }
 
@@ -285,6 +291,7 @@ __global__ __launch_bounds__(BAM_PARSE_T) void bam_parse_kernel(const uint8_t *_
 		if (vlen[T_GENE]) {
 			gh = 1469598103934665603ull;                                      // FNV-1a, as CellsDataContainer::hash_name
 			for (uint32_t j = 0; j < vlen[T_GENE]; ++j) { gh ^= val[T_GENE][j]; gh *= 1099511628211ull; }
+			gh &= dict.hash_mask;
 		}
 		if (!cfg.has_read_type || !found[T_TYPE]) mark = 2;                   // HAS_EXONS
 		else if (bam_equal(val[T_TYPE], vlen[T_TYPE], cfg.intronic, cfg.intronic_len)) mark = 4;
@@ -308,6 +315,15 @@ __global__ __launch_bounds__(BAM_PARSE_T) void bam_parse_kernel(const uint8_t *_
 			if (!v) { need = true; break; }
 			if (dict.gkeys[sl] == gh) { gid = v - 1; break; }
 			sl = (sl + 1) & dict.gmask;
+		}
+		if (!need && dict.name_off) {      // the name behind the hash, byte by byte ("exact only with probability" otherwise)
+			bool same = gid < dict.n_names;
+			if (same) {
+				const uint32_t o = dict.name_off[gid], nlen = dict.name_off[gid + 1] - o;
+				same = nlen == vlen[T_GENE];
+				for (uint32_t j = 0; same && j < nlen; ++j) same = dict.name_pool[o + j] == val[T_GENE][j];
+			}
+			if (!same) { need = true; gid = 0; }
 		}
 	}
 	uint32_t aux_w = mark << 16;

@@ -110,6 +110,11 @@ int dropest_bam_decoder_window_chain(dropest_bam_decoder *d, int slot, uint32_t 
  * index of reference r, -1 = none yet.  Call again whenever they have grown. */
 int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, const uint64_t *gene_hash, const uint32_t *gene_id, uint32_t n_genes,
                                          const int32_t *chr_of_ref, uint32_t n_refs);
+/* The names of the dictionary's genes by index (name k = pool[off[k] .. off[k + 1]), n_names + 1 offsets): a gene found by its hash is then
+ * confirmed byte by byte on the device, and a name that only shares the FNV-1a value of another comes back to the host like an unseen one
+ * (CellsDataContainer::intern_gene compares the bytes: Estimation/StringIndexer.cpp:10-18 keys by the string itself).  Optional: without it
+ * the hash alone decides.  Call after _set_dictionaries, whenever the dictionary has grown. */
+int dropest_bam_decoder_set_gene_names(dropest_bam_decoder *d, const uint32_t *off, const uint8_t *pool, uint32_t n_names);
 /* -g: genes from a GTF / BED annotation instead of the gene tag (ReadParamsParser::get_gene_from_reference, ReadParamsParser.cpp:92-151): the
  * decoder asks `a` (dropest_annotation.h, same GPU; stays the caller's) about the two ends of every accepted alignment.  ann_chr_of_ref[r] =
  * the annotation's chromosome for reference r, -1 = it has none of that name (such a record cannot be parsed, BamController.cpp:153-161).

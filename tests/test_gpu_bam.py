@@ -147,6 +147,24 @@ def test_record_boundaries_found_by_the_loader(tmp_path, block):
         assert stats5["_guesses_repaired"] > 0
 
 
+def test_gene_names_that_share_a_hash_do_not_share_an_index(tmp_path):
+    """The device finds a record's gene by the FNV-1a value of its name in a copy of the host's dictionary (k_bamparse.h) and, since round 6,
+    confirms the hit against the name's bytes (dropest_bam_decoder_set_gene_names).  With the hash cut to 3 bits (a test switch of both sides)
+    nearly every name collides with another: the container must be the host reader's all the same -- and without the names on the device it is not."""
+    reads = _reads(20_000)
+    refs = [("chr%d" % i, 1_000_000) for i in range(25)]
+    recs = [bw.record(int(chr_[3:]), i, "r%d" % i, tags=[("CB", "Z", cb), ("UB", "Z", umi)] + ([("GX", "Z", g)] if g else [])) for i, (cb, umi, g, chr_, mark) in enumerate(reads)]
+    bam = str(tmp_path / "genes.bam")
+    bw.write_bam(bam, refs, recs, block=20_000)
+    host = _run(tmp_path / "host", "filled", [bam], 3, 5, threads=4)
+    assert len({g for g, _ in host[0]}) > 50
+    for bits in ("3", "1"):
+        dev = _run(tmp_path / ("dev" + bits), "filled", [bam], 3, 5, threads=4, env={"DROPEST_BAM_DEVICE": "1", "DROPEST_BAM_DEVICE_WINDOW_MB": "1", "DROPEST_BAM_TEST_GENE_HASH_BITS": bits})
+        assert dev[1] == host[1] and dev[0] == host[0] and dev[2]["saved"] == host[2]["saved"]
+        host_weak = _run(tmp_path / ("hostweak" + bits), "filled", [bam], 3, 5, threads=4, env={"DROPEST_BAM_TEST_GENE_HASH_BITS": bits})
+        assert host_weak[1] == host[1] and host_weak[0] == host[0]
+
+
 def test_read_name_encoding_and_whitelist_merge(tmp_path):
     """Without -f the barcodes come from the read name "id!CB#UMI" (ReadParamsParser.cpp:20-33); with -m + whitelist."""
     s = SynthStream(n_reads=40_000, n_cells=20, n_genes=300, umi_len=8, permille_neighbour=150)
