@@ -6,6 +6,7 @@
 //          (reassign, :64-82), Stats::merge bookkeeping (Stats.cpp:29-43)
 //   then the molecule table is re-keyed and re-reduced on the device (= the unions done by Gene::merge).
 #pragma once
+#include <unordered_set>
 #include <thread>
 
 namespace {
@@ -751,6 +752,14 @@ void dropest_ctx::run_cb_merge_real() {
 void dropest_ctx::reaggregate_after_merge() {
 	invalidate_prefetch();   // a cm_raw prefetch in flight reads the tables this call rewrites
 	HostStage hs(this, "cb_merge:reaggregate");
+	if (getenv("DROPEST_MP_TRACE")) {   // the cells that RECEIVE rows and the share of the molecule table they hold (NOTES_r06 section 4)
+		std::unordered_set<u32> targets;
+		for (auto const &pr : merge_pairs) targets.insert(u32(pr.second));
+		uint64_t mol_targets = 0;
+		for (auto const &r : real) if (targets.count(r.id)) mol_targets += uint64_t(std::max(0, r.row.total_umis));
+		fprintf(stderr, "[mp] %zu merged cells into %zu targets; the targets hold %llu of %u molecule rows (%.1f %%)\n", merge_pairs.size(), targets.size(),
+		        (unsigned long long)mol_targets, n_mol, 100.0 * double(mol_targets) / std::max<u32>(1u, n_mol));
+	}
 	remap.ensure(n_cells);
 	{
 		std::vector<u32> &src = ms.src, &tgt = ms.tgt32;
@@ -829,6 +838,14 @@ bool dropest_ctx::resort_changed_rows(u64 varying_mask, const u32 *d_remap, int 
 		std::memcpy(or_and, head + 4, 16);
 		varying_mask = or_and[0] ^ or_and[1];
 		if (varying_out) *varying_out = varying_mask;
+	}
+	if (getenv("DROPEST_MP_TRACE")) {   // how the changed rows spread over the tiles of 4 096 (what "re-aggregate only what a merge changed" could skip: NOTES_r06 section 4)
+		std::vector<u32> per_tile(tiles);
+		fetch(per_tile.data(), tile_counts.p, size_t(tiles) * 4);
+		size_t touched = 0;
+		for (u32 c : per_tile) touched += c != 0;
+		fprintf(stderr, "[mp] %u molecule rows in %u tiles of %u: %u rows change their key (%.1f %%), in %zu tiles (%.1f %% of the tiles)\n", n_mol, tiles, u32(MP_TILE), nb,
+		        100.0 * nb / std::max<u32>(1u, n_mol), touched, 100.0 * double(touched) / std::max<u32>(1u, tiles));
 	}
 	if (nb == 0 || nb > n_mol / 4) return false;
 	const u32 na = n_mol - nb;
