@@ -152,6 +152,7 @@ def lib():
         "dropest_prefetch_raw_matrix_bytes": (C.c_int, [vp, C.c_int]),
         "dropest_count_matrix_csc_bytes": (C.c_int, [vp, C.c_int, C.c_int, vp]),
         "dropest_matrix_bytes_widen": (C.c_int, [vp, vp, vp]),
+        "dropest_matrix_rider_widen": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp, vp]),
         "dropest_set_raw_matrix_prefetch": (C.c_int, [vp, C.c_int, C.c_int]),
         "dropest_set_matrix_wire": (C.c_int, [vp, C.c_int]),
         "dropest_set_umi_dictionary": (C.c_int, [vp, C.c_int]),
@@ -238,7 +239,7 @@ EXPORTED_SYMBOLS = [
     "dropest_shard_set_reads_device", "dropest_shard_push_reads", "dropest_reserve_reads", "dropest_shard_step", "dropest_shard_group_step", "dropest_shard_matrix", "dropest_shard_matrix_form",
     "dropest_shard_merged_barcodes", "dropest_shard_phase_stats", "dropest_shard_set_option", "dropest_plan_columns",
     "dropest_key_width", "dropest_ctx_split", "dropest_shard_matrix_narrow", "dropest_shard_matrix_bytes", "dropest_add_umi_to_cell", "dropest_umi_first_seen", "dropest_resident_reads", "dropest_prefetch_raw_matrix_narrow", "dropest_narrow_matrix_possible", "dropest_count_matrix_csc_narrow",
-    "dropest_prefetch_raw_matrix_bytes", "dropest_count_matrix_csc_bytes", "dropest_matrix_bytes_widen", "dropest_set_raw_matrix_prefetch", "dropest_set_matrix_wire", "dropest_set_umi_dictionary", "dropest_debug_refresh", "dropest_push_reads_gather", "dropest_shard_set_umi_qualities", "dropest_shard_set_umi_qualities_var",
+    "dropest_prefetch_raw_matrix_bytes", "dropest_count_matrix_csc_bytes", "dropest_matrix_bytes_widen", "dropest_matrix_rider_widen", "dropest_set_raw_matrix_prefetch", "dropest_set_matrix_wire", "dropest_set_umi_dictionary", "dropest_debug_refresh", "dropest_push_reads_gather", "dropest_shard_set_umi_qualities", "dropest_shard_set_umi_qualities_var",
     "dropest_debug_poison_scratch", "dropest_debug_trim_pool", "dropest_debug_alloc_ordinal", "dropest_debug_alloc_site",
 ]
 

@@ -462,7 +462,13 @@ struct dropest_ctx {
 		bool wire = false;
 		std::shared_ptr<dropest::DecodeJob> job, late_job;   // late_job: finished, but a decoding thread may not have left it yet
 		std::chrono::steady_clock::time_point job_t0;
+		// cm as a rider on cm_raw (round 6; k_misc.h: emit_values_on_rows_kernel): this slot's job reads ANOTHER slot's bytes and row slots.  The
+		// base names its rider in `dependent` and settles it first; rider_out / rider_cnt: per column of the base, where it lands in this matrix.
+		MatrixResult *dependent = nullptr;
+		std::vector<u32> rider_out, rider_cnt, wire_chunk_end;
+		dropest::DevBuf<u32> d_rider_out;
 		void settle() {   // nobody reads or writes this slot's host buffers any more
+			if (dependent) { MatrixResult *d = dependent; dependent = nullptr; d->settle(); }
 			if (job) { (void)job->wait(); job->quiesce(); job.reset(); }
 			if (late_job) { late_job->quiesce(); late_job.reset(); }
 		}
@@ -754,7 +760,8 @@ struct dropest_ctx {
 	// cm_raw produced and copied to the host on a second stream while the caller goes on (dropest_prefetch_raw_matrix)
 	struct RawPrefetch { bool valid = false, reads_output = false, in_flight = false; int narrow = 0; std::vector<u32> col_cell; } raw_pf;
 	hipStream_t stream2 = nullptr;
-	hipEvent_t ev_fork = nullptr, ev_raw = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_raw = nullptr, ev_raw_cols = nullptr;   // ev_raw_cols: cm_raw's column arrays are on the device (a rider's emit reads them)
+	bool emit_rider(bool reads_output, const std::vector<u32> &col_cell, uint64_t nnz);
 	dropest::DevBuf<u32> m2_col_cell, m2_col_start, m2_col_list, m_col_list;
 	std::vector<u32> m2_col_list_host, m_col_list_host;   // (host sides of asynchronous uploads: kept with the context)
 	void launch_emit_bytes(dropest::MatrixArgs a, const std::vector<u32> &rows_per_column, dropest::DevBuf<u32> &list, std::vector<u32> &host_list, hipStream_t st);

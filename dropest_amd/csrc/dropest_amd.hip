@@ -1981,6 +1981,7 @@ void dropest_ctx::wire_copy_and_decode(MatrixResult &M, uint64_t nnz, hipStream_
 	job->v_count = M.h_ovf.p; job->v_pos = M.h_ovf.p + 1; job->v_val = M.h_ovf.p + 1 + M.vcap; job->vcap = M.vcap;
 	static const uint64_t n_chunks = [] { const char *e = getenv("DROPEST_WIRE_CHUNKS"); return uint64_t(e ? std::max(1, atoi(e)) : 12); }();
 	cut_columns(M.colptr.data(), 0, size_t(M.ncols), std::max<uint64_t>(nnz / n_chunks + 1, uint64_t(1) << 19), job->chunk_end);
+	M.wire_chunk_end = job->chunk_end;   // (a rider on this matrix moves its bytes in the same chunks: emit_rider)
 	// Arrival flags (matrix_decode.h): [0] the lists, [1 + j] chunk j; the value of this emit is a number no earlier emit of the slot used.
 	const size_t K = job->chunk_end.size();
 	M.h_flags.ensure(K + 2);
@@ -2056,7 +2057,7 @@ bool dropest_ctx::wire_finish(MatrixResult &M) {
 	HostStage hs(this, "matrix:decode_wait");
 	const auto w0 = std::chrono::steady_clock::now();
 	M.job->work(true);   // the caller takes part: what is unclaimed, then what a straggler holds
-	const int st = M.job->wait();
+	const int st = M.job->finish_rider();   // (= wait(); a rider's listed values are put in place here)
 	if (M.job->trace) {
 		const auto now = std::chrono::steady_clock::now();
 		{   // where the buffers live (NUMA node of a few pages each) and where this thread runs
@@ -2139,6 +2140,8 @@ void dropest_ctx::prefetch_raw_matrix(bool reads_output, int narrow, const drope
 	HIP_CHECK(hipStreamWaitEvent(stream2, ev_fork, 0));
 	HIP_CHECK(hipMemcpyAsync(m2_col_cell.p, raw_pf.col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream2));
 	HIP_CHECK(hipMemcpyAsync(m2_col_start.p, M.colptr.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream2));
+	if (!ev_raw_cols) HIP_CHECK(hipEventCreateWithFlags(&ev_raw_cols, hipEventDisableTiming));
+	HIP_CHECK(hipEventRecord(ev_raw_cols, stream2));
 	if (dev_form) HIP_CHECK(hipMemsetAsync(M.d_ovf.p, 0, 4, stream2));
 	if (dev_form == 2) HIP_CHECK(hipMemsetAsync(M.d_rovf.p, 0, 4, stream2));
 	a.col_cell = m2_col_cell.p; a.col_start = m2_col_start.p; a.cell_cg_begin = cell_cg_begin.p; a.cell_cg_count = cell_cg_count.p; a.cg_key = cg_key.p;
@@ -2186,6 +2189,15 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, 
 	m_col_cell.ensure(ncols); m_col_start.ensure(ncols);
 	MatrixArgs a{};
 	const bool wire = !direct && wire_wanted(nnz, narrow, to_host);
+	if (wire && filtered_m && emit_rider(reads_output, col_cell, nnz)) {   // cm's values ride on cm_raw's rows: half of cm's bytes stay off the link
+		tail_mark("rider enqueued");
+		HIP_CHECK(stream_wait(stream));
+		const bool ok = wire_finish(M);
+		tail_mark("matrix done");
+		collect_timings();
+		if (!ok) emit_matrix(filtered_m, reads_output, to_host, narrow, true);
+		return;
+	}
 	const int dev_form = wire ? 2 : narrow;
 	matrix_outputs(M, nnz, dev_form, to_host, a);
 	HIP_CHECK(hipMemcpyAsync(m_col_cell.p, col_cell.data(), size_t(ncols) * 4, hipMemcpyHostToDevice, stream));
@@ -2214,6 +2226,85 @@ void dropest_ctx::emit_matrix(bool filtered_m, bool reads_output, bool to_host, 
 	tail_mark("matrix done");
 	collect_timings();
 	if (!ok) emit_matrix(filtered_m, reads_output, to_host, narrow, true);
+}
+
+// cm as a rider on cm_raw (k_misc.h: emit_values_on_rows_kernel, matrix_decode.h: widen_derived).  Taken when cm_raw of the
+// same value kind is on its way (or there) in the byte form: one byte per entry of cm_raw -- its value in cm, 0 = not in cm -- crosses the link
+// in cm_raw's chunks, and the host threads build cm's slots from cm_raw's row deltas.  mat[0].colptr / nnz are cm's own (the caller set them).
+// false: not possible here (the caller emits cm's own byte form).
+bool dropest_ctx::emit_rider(bool reads_output, const std::vector<u32> &col_cell, uint64_t nnz) {
+	using namespace dropest;
+	static const bool off = getenv("DROPEST_NO_RIDER") != nullptr;
+	MatrixResult &M = mat[0], &R = mat[1];
+	// Measured (NOTES_r06 section 5): at C3 (1.9e8 entries per matrix) the step is 6 ms shorter with the rider (132.7 -> 126.7 ms); at C2 (1.9e7
+	// entries) the 0.35 ms of link time it saves are within the noise of its own dependencies (cm's columns wait for cm_raw's lists and
+	// chunks): 9.53 against 9.32 ms over five pairs of runs.  Taken from 2^26 entries of cm_raw on; DROPEST_RIDER_MIN_NNZ moves the gate (tests: 0).
+	const char *e_min = getenv("DROPEST_RIDER_MIN_NNZ");
+	const uint64_t min_nnz = e_min ? uint64_t(std::max(0ll, atoll(e_min))) : (uint64_t(1) << 26);
+	if (R.nnz < min_nnz) return false;
+	if (off || !raw_pf.valid || !R.wire || R.narrow != 0 || raw_pf.reads_output != reads_output || !R.nnz || R.wire_chunk_end.empty() || !ev_raw_cols) return false;
+	if (R.job == nullptr && R.late_job == nullptr) return false;   // (cm_raw's bytes have been let go)
+	if (R.job && !R.job->running() && R.job->status.load() != DecodeJob::DONE) return false;   // cm_raw takes a wider form
+	const u32 rcols = u32(R.ncols), ncols = u32(col_cell.size());
+	if (raw_pf.col_cell.size() != rcols) return false;
+	M.rider_out.assign(rcols, 0xFFFFFFFFu); M.rider_cnt.assign(rcols, 0u);
+	for (u32 j = 0; j < ncols; ++j) {   // (cm_raw's columns ascend by cell id)
+		auto it = std::lower_bound(raw_pf.col_cell.begin(), raw_pf.col_cell.end(), col_cell[j]);
+		if (it == raw_pf.col_cell.end() || *it != col_cell[j]) return false;       // a filtered cell that is no column of cm_raw: not this way
+		const size_t r = size_t(it - raw_pf.col_cell.begin());
+		M.rider_out[r] = M.colptr[j]; M.rider_cnt[r] = M.colptr[j + 1] - M.colptr[j];
+	}
+	MatrixArgs a{};
+	matrix_outputs(M, R.nnz, 2, true, a);          // (value bytes and lists sized for cm_raw's entries; settles the slot's previous job)
+	M.h_row.ensure(nnz); M.h_val.ensure(nnz);
+	M.d_rider_out.ensure(rcols);
+	HIP_CHECK(hipMemcpyAsync(M.d_rider_out.p, M.rider_out.data(), size_t(rcols) * 4, hipMemcpyHostToDevice, stream));
+	HIP_CHECK(hipMemsetAsync(M.d_ovf.p, 0, 4, stream));
+	HIP_CHECK(hipMemsetAsync(M.d_rovf.p, 0, 4, stream));
+	HIP_CHECK(hipStreamWaitEvent(stream, ev_raw_cols, 0));   // cm_raw's column arrays (m2_col_cell / m2_col_start) are on the device
+	timed("emit_matrix:cm", double(R.nnz) * 13, [&] {
+		hipLaunchKernelGGL(emit_values_on_rows_kernel, dim3(std::min<u32>(div_up(rcols, 4u), 8192u)), dim3(256), 0, stream, m2_col_cell.p, m2_col_start.p, rcols, cell_cg_begin.p,
+		                   cell_cg_count.p, cg_key.p, layout.gene_none, reads_output ? cg_reads_req.p : cg_n_req.p, M.d_rider_out.p, M.d_val8.p, a.ovf_count, a.ovf_pos, a.ovf_val, a.ovf_cap);
+	});
+	hipLaunchKernelGGL(matrix_lists_out_kernel, dim3(64), dim3(256), 0, stream, M.d_rovf.p, M.rcap, M.h_rovf.p, M.d_ovf.p, M.vcap, M.h_ovf.p);
+	HIP_CHECK(hipGetLastError());
+	auto job = std::make_shared<DecodeJob>();
+	HIP_CHECK(hipGetDevice(&job->device));
+	job->m.rd = R.h_drow8.p; job->m.vb = M.h_val8.p; job->m.colptr = R.colptr.data(); job->m.ncols = rcols; job->m.nnz = nnz;
+	job->ro = M.h_row.p; job->vo = M.h_val.p;
+	job->r_count = M.h_rovf.p; job->r_pos = M.h_rovf.p + 1; job->r_val = M.h_rovf.p + 1 + M.rcap; job->rcap = M.rcap;   // (always empty: a rider has no rows of its own)
+	job->v_count = M.h_ovf.p; job->v_pos = M.h_ovf.p + 1; job->v_val = M.h_ovf.p + 1 + M.vcap; job->vcap = M.vcap;
+	job->derived = true;
+	job->dv.base_ro = R.h_row.p; job->dv.out_begin = M.rider_out.data(); job->dv.out_count = M.rider_cnt.data();
+	if (R.job && R.job->running()) { job->base_job = R.job; job->flags2 = R.h_flags.p; job->epoch2 = R.wire_epoch; }
+	job->chunk_end = R.wire_chunk_end;
+	const size_t K = job->chunk_end.size();
+	M.h_flags.ensure(K + 2);
+	for (size_t j = 0; j < K + 2; ++j) M.h_flags.p[j] = 0;
+	M.wire_epoch = M.wire_epoch + 1 ? M.wire_epoch + 1 : 1;
+	job->flags = M.h_flags.p; job->epoch = M.wire_epoch;
+	u32 c0 = 0;
+	for (size_t j = 0; j < K; ++j) {
+		const u32 c1 = job->chunk_end[j];
+		const size_t k0 = R.colptr[c0], k1 = R.colptr[c1];
+		hipLaunchKernelGGL(matrix_chunk_to_host_kernel, dim3(u32(std::max<size_t>(1, std::min<size_t>(128, (k1 - k0 + 4095) / 4096)))), dim3(256), 0, stream, M.d_val8.p,
+		                   static_cast<const uint8_t *>(nullptr), M.h_val8.p, static_cast<uint8_t *>(nullptr), k0, k1, M.h_flags.p + j, M.wire_epoch);
+		c0 = c1;
+	}
+	hipLaunchKernelGGL(matrix_flag_kernel, dim3(1), dim3(1), 0, stream, M.h_flags.p + K, M.wire_epoch);
+	HIP_CHECK(hipGetLastError());
+	static const bool trace = getenv("DROPEST_WIRE_TRACE") != nullptr;
+	job->trace = trace;
+	static const uint64_t slice_entries = [] { const char *e = getenv("DROPEST_DECODE_SLICE"); return e && atoll(e) >= 1024 ? uint64_t(atoll(e)) : uint64_t(1) << 16; }();
+	job->prepare(slice_entries);
+	M.narrow = 0; M.n_ovf = M.n_rovf = 0;
+	M.job = job; M.wire = true;
+	M.job_t0 = std::chrono::steady_clock::now();
+	R.dependent = &M;
+	DecodePool::get().prefer_node_of(M.h_row.p);
+	DecodePool::get().submit(job);
+	if (profiling) stats["count:cm_rides_on_cm_raw"].launches += 1;
+	return true;
 }
 
 // Sharded runs: the columns of a caller-given list of cells, emitted compactly into the device staging of matrix slot
@@ -2994,6 +3085,36 @@ dropest_status dropest_matrix_bytes_widen(const dropest_matrix_bytes *m, uint32_
 		if (st == dropest::DecodeJob::BAD_ROW) throw InvalidError("byte matrix: a listed row does not stand on a 255");
 		if (st == dropest::DecodeJob::BAD_VALUE) throw InvalidError("byte matrix: a listed value does not stand on a 255");
 		if (st != dropest::DecodeJob::DONE) throw InvalidError("byte matrix: the decode failed");
+	});
+}
+
+dropest_status dropest_matrix_rider_widen(const dropest_matrix_bytes *base, const uint32_t *base_rows, const uint8_t *value, const uint32_t *out_begin,
+                                          const uint32_t *out_count, uint64_t rider_nnz, uint64_t n_listed, const uint32_t *listed_pos,
+                                          const uint32_t *listed_value, uint32_t *rowidx, uint32_t *values) {
+	return guarded([&] {
+		if (!base || (base->nnz && (!base_rows || !value)) || (base->ncols && (!out_begin || !out_count)) || (rider_nnz && (!rowidx || !values)) ||
+		    (n_listed && (!listed_pos || !listed_value))) throw InvalidError("null argument");
+		if (n_listed > 0xFFFFFFFFull || rider_nnz > 0xFFFFFFF0ull) throw InvalidError("rider matrix: too many entries");
+		if (!base->nnz || !rider_nnz) return;
+		auto job = std::make_shared<dropest::DecodeJob>();
+		(void)hipGetDevice(&job->device);
+		(void)hipGetLastError();   // (no device: the walk needs none)
+		job->m.rd = base->row_delta; job->m.vb = value; job->m.colptr = base->colptr; job->m.ncols = base->ncols; job->m.nnz = rider_nnz;
+		job->ro = rowidx; job->vo = values;
+		const uint32_t nv = uint32_t(n_listed);
+		job->v_count = &nv; job->v_pos = listed_pos; job->v_val = listed_value; job->vcap = nv;
+		job->derived = true;
+		job->dv.base_ro = base_rows; job->dv.out_begin = out_begin; job->dv.out_count = out_count;
+		const char *e_slice = getenv("DROPEST_DECODE_SLICE"), *e_delay = getenv("DROPEST_DECODE_TEST_DELAY_US");
+		if (e_delay) job->test_delay_us = uint32_t(std::max(0, atoi(e_delay)));
+		job->prepare(e_slice && atoll(e_slice) >= 64 ? uint64_t(atoll(e_slice)) : uint64_t(1) << 16);
+		dropest::DecodePool::get().submit(job);
+		job->work(true);
+		const int st = job->finish_rider();
+		job->quiesce();
+		if (st == dropest::DecodeJob::BAD_ROW) throw InvalidError("rider matrix: a column keeps another number of entries than announced");
+		if (st == dropest::DecodeJob::BAD_VALUE) throw InvalidError("rider matrix: a listed value lies outside the matrix");
+		if (st != dropest::DecodeJob::DONE) throw InvalidError("rider matrix: the decode failed");
 	});
 }
 

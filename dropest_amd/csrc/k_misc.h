@@ -471,16 +471,48 @@ __global__ __launch_bounds__(256) void matrix_chunk_to_host_kernel(const uint8_t
 	if (flag && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	const size_t a0 = (k0 + 15) & ~size_t(15), a1 = k1 & ~size_t(15);
 	const size_t t = size_t(blockIdx.x) * 256 + threadIdx.x, stride = size_t(gridDim.x) * 256;
+	const bool two = d_b != nullptr;   // (one array: the value bytes of a matrix that rides on another one's rows, emit_values_on_rows_kernel)
 	if (a0 >= a1) {   // shorter than a line: bytes
-		for (size_t k = k0 + t; k < k1; k += stride) { h_a[k] = d_a[k]; h_b[k] = d_b[k]; }
+		for (size_t k = k0 + t; k < k1; k += stride) { h_a[k] = d_a[k]; if (two) h_b[k] = d_b[k]; }
 		return;
 	}
-	for (size_t k = k0 + t; k < a0; k += stride) { h_a[k] = d_a[k]; h_b[k] = d_b[k]; }
-	for (size_t k = a1 + t; k < k1; k += stride) { h_a[k] = d_a[k]; h_b[k] = d_b[k]; }
+	for (size_t k = k0 + t; k < a0; k += stride) { h_a[k] = d_a[k]; if (two) h_b[k] = d_b[k]; }
+	for (size_t k = a1 + t; k < k1; k += stride) { h_a[k] = d_a[k]; if (two) h_b[k] = d_b[k]; }
 	const uint4 *sa = reinterpret_cast<const uint4 *>(d_a + a0), *sb = reinterpret_cast<const uint4 *>(d_b + a0);
 	uint4 *da = reinterpret_cast<uint4 *>(h_a + a0), *db = reinterpret_cast<uint4 *>(h_b + a0);
 	const size_t n16 = (a1 - a0) >> 4;
-	for (size_t i = t; i < n16; i += stride) { da[i] = sa[i]; db[i] = sb[i]; }
+	if (two) for (size_t i = t; i < n16; i += stride) { da[i] = sa[i]; db[i] = sb[i]; }
+	else for (size_t i = t; i < n16; i += stride) da[i] = sa[i];
+}
+
+// cm as a rider on cm_raw (round 6): cm's columns are a subset of cm_raw's (filtered cells are real cells) and a column's
+// entries are cm_raw's entries of that cell with values that are equal or smaller (requested UMIs against all UMIs of the same (cell, gene)
+// row: Cell.cpp:54-68, ResultsPrinter.cpp:334-396), 0 = the entry is not in cm.  So cm needs no row bytes of its own: ONE byte per entry of
+// cm_raw -- the value in cm, aligned with cm_raw's entries -- crosses the link, and the host reads the rows from cm_raw's delta bytes
+// (csrc/matrix_decode.h: widen_derived) and leaves the zeros out.  col_out[c]: where column c of cm_raw starts in cm's slots, 0xFFFFFFFF = the
+// cell is not a column of cm (its bytes are zeros).  A value beyond 254 is listed with its place in cm's SLOTS (the wave counts the entries it keeps).
+// One wave per column of cm_raw; rows of a cell ascend by gene, the gene-less row (all ones) comes last and is no entry.
+__global__ __launch_bounds__(256) void emit_values_on_rows_kernel(const uint32_t *__restrict__ col_cell, const uint32_t *__restrict__ col_start, uint32_t ncols,
+                                                                  const uint32_t *__restrict__ cell_cg_begin, const uint32_t *__restrict__ cell_cg_count,
+                                                                  const unsigned long long *__restrict__ cg_key, unsigned long long gene_mask,
+                                                                  const uint32_t *__restrict__ value, const uint32_t *__restrict__ col_out,
+                                                                  uint8_t *__restrict__ t_val8, uint32_t *ovf_count, uint32_t *ovf_pos, uint32_t *ovf_val, uint32_t ovf_cap) {
+	const uint32_t lane = threadIdx.x & 63u;
+	for (uint32_t col = blockIdx.x * 4u + (threadIdx.x >> 6); col < ncols; col += gridDim.x * 4u) {
+		const uint32_t cell = col_cell[col];
+		const uint32_t b = cell_cg_begin[cell], e = b + cell_cg_count[cell];
+		const uint32_t first = col_start[col], oc = col_out[col];
+		uint32_t kept = 0;
+		for (uint32_t base = b; base < e; base += 64) {
+			const uint32_t i = base + lane;
+			const bool entry = i < e && (cg_key[i] & gene_mask) != gene_mask;
+			const uint32_t v = entry && oc != 0xFFFFFFFFu ? value[i] : 0u;
+			if (entry) t_val8[first + (i - b)] = v >= 255u ? uint8_t(255u) : uint8_t(v);
+			const unsigned long long keep = __ballot(v != 0u);
+			matrix_list_append(v >= 255u, oc + kept + uint32_t(__popcll(keep & ((1ull << lane) - 1ull))), v, ovf_count, ovf_pos, ovf_val, ovf_cap);
+			kept += uint32_t(__popcll(keep));
+		}
+	}
 }
 
 __global__ void matrix_flag_kernel(uint32_t *flag, uint32_t epoch) { __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }

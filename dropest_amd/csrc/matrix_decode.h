@@ -207,6 +207,113 @@ inline void widen_columns(const ByteMatrixView &m, size_t c0, size_t c1, uint32_
 	}
 }
 
+// ---- a matrix that rides on another one's rows (round 6: cm on cm_raw; k_misc.h: emit_values_on_rows_kernel) -------------------------------
+// The BASE matrix's byte form gives the rows (m.rd, m.colptr: entries [colptr[c], colptr[c + 1]) of base column c); vb holds, aligned with the
+// base's entries, the value each entry has in THIS matrix (0: not an entry here, 255: listed -- already written to its slot).  Column c's
+// kept entries go to [out_begin[c], out_begin[c] + out_count[c]) of (ro, vo); out_begin[c] == 0xFFFFFFFF: the column is not in this matrix.
+// A listed row of the base (delta 255) is read from the base's slots base_ro (the base's job has put it there: DecodeJob waits for that).
+// Listed values (255) are written to their slots AFTER the walk (a rider's job scatters its list last).
+// Returns false when a column does not keep the number of entries it was announced with.
+struct DerivedView {
+	const uint32_t *base_ro = nullptr, *out_begin = nullptr, *out_count = nullptr;
+};
+inline bool widen_derived_scalar(const ByteMatrixView &m, const DerivedView &dv, size_t c0, size_t c1, uint32_t *__restrict ro, uint32_t *__restrict vo) {
+	const uint32_t *__restrict cp = m.colptr;
+	for (size_t c = c0; c < c1; ++c) {
+		uint32_t out = dv.out_begin[c];
+		if (out == 0xFFFFFFFFu) continue;
+		const uint32_t end = out + dv.out_count[c];
+		uint32_t prev1 = 0;
+		for (uint32_t k = cp[c]; k < cp[c + 1]; ++k) {
+			const uint32_t d = m.rd[k], v = m.vb[k];
+			const uint32_t row = d == 255u ? dv.base_ro[k] : prev1 + d - 1u;
+			prev1 = row + 1u;
+			if (!v) continue;
+			if (out >= end) return false;
+			ro[out] = row;
+			vo[out] = v;      // (255: the listed value comes after the walk)
+			++out;
+		}
+		if (out != end) return false;
+	}
+	return true;
+}
+// sixteen base entries per step: rows by the prefix sums of the plain walk, the entries with a value compressed to the front of a small
+// pending buffer, and whole 64-byte lines of it streamed to the slots (non-temporal: a line that is written whole needs no read for ownership --
+// with plain stores the rider's walk moved twice the bytes of the plain one and was the tail of the step).  Listed values are written to their
+// slots AFTER the walk (DecodeJob: a rider scatters its list last), so a line may be stored over a slot that waits for one.
+__attribute__((target("avx512f,avx512bw,avx512vl"))) inline bool widen_derived_avx512(const ByteMatrixView &m, const DerivedView &dv, size_t c0, size_t c1,
+                                                                                      uint32_t *__restrict ro, uint32_t *__restrict vo) {
+	const uint32_t *__restrict cp = m.colptr;
+	const __m128i ff = _mm_set1_epi8(char(0xFF));
+	const __m512i zero = _mm512_setzero_si512();
+	const bool nt = decode_use_nt() && !((reinterpret_cast<uintptr_t>(ro) ^ reinterpret_cast<uintptr_t>(vo)) & 63u);
+	alignas(64) uint32_t pr[48], pv[48];      // pending kept entries of the column at hand (fewer than 16 between steps)
+	for (size_t c = c0; c < c1; ++c) {
+		uint32_t out = dv.out_begin[c];
+		if (out == 0xFFFFFFFFu) continue;
+		const uint32_t end = out + dv.out_count[c];
+		uint32_t prev1 = 0, k = cp[c], pend = 0;      // `out` counts the entries stored; out + pend the entries kept
+		const uint32_t k1 = cp[c + 1];
+		bool ok = true;
+		auto flush_all = [&]() { for (uint32_t i = 0; i < pend; ++i) { ro[out + i] = pr[i]; vo[out + i] = pv[i]; } out += pend; pend = 0; };
+		auto scalar_to = [&](uint32_t stop) {
+			flush_all();
+			for (; k < stop; ++k) {
+				const uint32_t d = m.rd[k], v = m.vb[k];
+				const uint32_t row = d == 255u ? dv.base_ro[k] : prev1 + d - 1u;
+				prev1 = row + 1u;
+				if (!v) continue;
+				if (out >= end) { ok = false; k = stop; return; }
+				ro[out] = row;
+				vo[out] = v;      // (255: the listed value comes after the walk)
+				++out;
+			}
+		};
+		if (k1 - k >= 64u) {
+			while (ok && k < k1 && ((reinterpret_cast<uintptr_t>(ro + out) & 63u) != 0)) scalar_to(k + 1u);      // to a line boundary of the slots
+			while (ok && k + 16u <= k1) {
+				const __m128i d8 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(m.rd + k));
+				const __m128i v8 = _mm_loadu_si128(reinterpret_cast<const __m128i *>(m.vb + k));
+				if (_mm_movemask_epi8(_mm_cmpeq_epi8(d8, ff))) {      // a listed row of the base: these sixteen one by one (then to a line boundary again)
+					scalar_to(k + 16u);
+					while (ok && k < k1 && ((reinterpret_cast<uintptr_t>(ro + out) & 63u) != 0)) scalar_to(k + 1u);
+					continue;
+				}
+				__m512i sum = _mm512_cvtepu8_epi32(d8);
+				sum = _mm512_add_epi32(sum, _mm512_alignr_epi32(sum, zero, 15));
+				sum = _mm512_add_epi32(sum, _mm512_alignr_epi32(sum, zero, 14));
+				sum = _mm512_add_epi32(sum, _mm512_alignr_epi32(sum, zero, 12));
+				sum = _mm512_add_epi32(sum, _mm512_alignr_epi32(sum, zero, 8));
+				const __m512i rows = _mm512_add_epi32(sum, _mm512_set1_epi32(int(prev1 - 1u)));
+				const __m512i x = _mm512_cvtepu8_epi32(v8);
+				const __mmask16 keep = _mm512_test_epi32_mask(x, x);
+				const uint32_t cnt = uint32_t(__builtin_popcount(unsigned(keep)));
+				if (out + pend + cnt > end) { ok = false; break; }
+				_mm512_storeu_si512(pr + pend, _mm512_maskz_compress_epi32(keep, rows));
+				_mm512_storeu_si512(pv + pend, _mm512_maskz_compress_epi32(keep, x));
+				pend += cnt;
+				if (pend >= 16u) {
+					const __m512i lr = _mm512_load_si512(pr), lv = _mm512_load_si512(pv);
+					if (nt) { _mm512_stream_si512(reinterpret_cast<__m512i *>(ro + out), lr); _mm512_stream_si512(reinterpret_cast<__m512i *>(vo + out), lv); }
+					else { _mm512_storeu_si512(ro + out, lr); _mm512_storeu_si512(vo + out, lv); }
+					out += 16u; pend -= 16u;
+					_mm512_store_si512(pr, _mm512_loadu_si512(pr + 16)); _mm512_store_si512(pv, _mm512_loadu_si512(pv + 16));
+				}
+				prev1 += uint32_t(_mm_extract_epi32(_mm512_extracti32x4_epi32(sum, 3), 3));
+				k += 16u;
+			}
+		}
+		if (ok) scalar_to(k1);
+		if (!ok || out != end) return false;
+	}
+	if (nt) _mm_sfence();
+	return true;
+}
+inline bool widen_derived(const ByteMatrixView &m, const DerivedView &dv, size_t c0, size_t c1, uint32_t *ro, uint32_t *vo) {
+	return decode_isa() == 2 ? widen_derived_avx512(m, dv, c0, c1, ro, vo) : widen_derived_scalar(m, dv, c0, c1, ro, vo);
+}
+
 // Cuts the columns [c0, c1) into runs of about `target` entries (whole columns: a long column is a run by itself).
 inline void cut_columns(const uint32_t *colptr, size_t c0, size_t c1, uint64_t target, std::vector<uint32_t> &ends) {
 	size_t c = c0;
@@ -237,6 +344,14 @@ struct DecodeJob {
 	const volatile uint32_t *flags = nullptr;
 	uint32_t epoch = 0;
 	const uint32_t *cut = nullptr;                  // [ncols + 1] running entry counts the slices are cut by (default: m.colptr; a selection of columns brings its own)
+	// A matrix that rides on another one's rows (DerivedView above): m describes the BASE's byte form with this matrix's value bytes as vb, the
+	// chunks are the base's, a chunk is ready when BOTH matrices' bytes of it have landed (flags2 / epoch2: the base's flags; null: all there),
+	// and the columns wait until the base's job has put its listed rows into its slots (base_job; null or finished: they are there).
+	bool derived = false;
+	DerivedView dv;
+	std::shared_ptr<DecodeJob> base_job;
+	const volatile uint32_t *flags2 = nullptr;
+	uint32_t epoch2 = 0;
 	std::vector<uint32_t> chunk_end;                // chunk j = columns [chunk_end[j - 1], chunk_end[j])
 	// ---- set by prepare() ----
 	std::vector<uint32_t> slice_end, slice_chunk;   // slice s = columns [slice_end[s - 1], slice_end[s]) of chunk slice_chunk[s]
@@ -312,6 +427,7 @@ struct DecodeJob {
 				n_r = nr; n_v = nv;   // (several threads may write the same numbers)
 				n_r_ranges = (nr + LIST_RANGE - 1) / LIST_RANGE;
 				n_list_ranges = n_r_ranges + (nv + LIST_RANGE - 1) / LIST_RANGE;
+				if (derived) n_r_ranges = n_list_ranges = 0;   // (a rider's listed values go to their slots after the walk, by the owner: finish_rider)
 				lists_state.store(2u, std::memory_order_release);
 				break;
 			}
@@ -334,6 +450,18 @@ struct DecodeJob {
 				break;
 			}
 			cpu_relax();
+		}
+		// (a rider: the base's listed rows must stand in the base's slots before a column reads them)
+		if (derived && base_job) {
+			for (uint32_t it = 0;; ++it) {
+				if (!running()) return;
+				const int bst = base_job->status.load(std::memory_order_acquire);
+				if (bst == DONE) break;
+				if (bst != RUNNING) { finish(bst == OVERFLOW ? OVERFLOW : FAILED); return; }      // the base takes a wider form: so does the rider
+				if (base_job->lists_state.load(std::memory_order_acquire) == 2u && base_job->list_done.load(std::memory_order_acquire) >= base_job->n_list_ranges) break;
+				if (it > PATIENCE) { base_job->work(false); it = 0; continue; }   // nobody is on the base's lists: this thread is
+				idle(it);
+			}
 		}
 		// 3. the columns, slice by slice as their chunks land
 		const uint32_t n_slices = uint32_t(slice_end.size());
@@ -364,7 +492,8 @@ struct DecodeJob {
 	}
 	void walk_slice(uint32_t s, uint32_t n_slices) {
 		const auto t0 = trace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-		widen_columns(m, s ? slice_end[s - 1] : 0u, slice_end[s], ro, vo);
+		if (!derived) widen_columns(m, s ? slice_end[s - 1] : 0u, slice_end[s], ro, vo);
+		else if (!widen_derived(m, dv, s ? slice_end[s - 1] : 0u, slice_end[s], ro, vo)) { finish(BAD_ROW); return; }
 		if (trace) {
 			const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 			uint64_t cur = slowest_slice_ns.load(std::memory_order_relaxed);
@@ -386,11 +515,24 @@ struct DecodeJob {
 		for (uint32_t it = 0;; ++it) {
 			if (chunk_ready[j].load(std::memory_order_acquire)) return true;
 			if (!running()) return false;
-			if (flags[1 + j] == epoch) { std::atomic_thread_fence(std::memory_order_acquire); chunk_ready[j].store(1, std::memory_order_release); return true; }
+			if (flags[1 + j] == epoch && (!flags2 || flags2[1 + j] == epoch2)) { std::atomic_thread_fence(std::memory_order_acquire); chunk_ready[j].store(1, std::memory_order_release); return true; }
 			if (it == 4096u) t0 = std::chrono::steady_clock::now();
 			else if (it > 4096u && (it & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > FLAG_TIMEOUT_S) { finish(FAILED); return false; }
 			idle(it);
 		}
+	}
+	// A rider's walk stores whole lines over slots that wait for a listed value, so the list is applied LAST -- by the job's owner, once the job
+	// is DONE and every thread has left it (a straggler that walks a slice a second time would write its 255s over the values again).
+	// Returns the job's status (BAD_VALUE: a listed entry outside the matrix).
+	int finish_rider() {
+		const int st = wait();
+		if (!derived || st != DONE) return st;
+		quiesce();
+		for (uint32_t k = 0; k < n_v; ++k) {
+			if (v_pos[k] >= m.nnz) return BAD_VALUE;
+			vo[v_pos[k]] = v_val[k];
+		}
+		return DONE;
 	}
 	bool check_marks = false;
 	uint32_t test_delay_us = 0;                      // DROPEST_DECODE_TEST_DELAY_US (tests only): every worker naps between claiming a slice and walking it

@@ -295,6 +295,16 @@ typedef struct dropest_matrix_bytes {
 dropest_status dropest_count_matrix_csc_bytes(dropest_ctx *ctx, int filtered, int reads_output, dropest_matrix_bytes *out);
 dropest_status dropest_prefetch_raw_matrix_bytes(dropest_ctx *ctx, int reads_output);
 dropest_status dropest_matrix_bytes_widen(const dropest_matrix_bytes *m, uint32_t *rowidx, uint32_t *values);
+/* A matrix that RIDES on another one's rows (round 6: what dropest_count_matrix_csc(filtered = 1) does inside the library when cm_raw is on
+ * its way in the byte form).  cm's columns are a subset of cm_raw's and a column's entries are cm_raw's entries of that cell with equal or
+ * smaller values (get_count_matrix_filtered / _raw, ResultsPrinter.cpp:334-396; Cell::requested_umis_per_gene, Cell.cpp:54-68), so cm crosses
+ * PCIe as ONE byte per entry of cm_raw: value[k] = the value entry k of `base` has in the rider (0: not an entry of it; 255: listed -- in
+ * (listed_pos, listed_value), pos = the entry's place in the RIDER's slots).  base_rows = the base's widened row slots (dropest_matrix_bytes_widen
+ * of `base`); column c of the base lands at [out_begin[c], out_begin[c] + out_count[c]) of (rowidx, values), out_begin[c] = 0xFFFFFFFF: not a
+ * column of the rider.  DROPEST_ERR_INVALID when a column keeps another number of entries than announced.  Plain host code. */
+dropest_status dropest_matrix_rider_widen(const dropest_matrix_bytes *base, const uint32_t *base_rows, const uint8_t *value, const uint32_t *out_begin,
+                                          const uint32_t *out_count, uint64_t rider_nnz, uint64_t n_listed, const uint32_t *listed_pos,
+                                          const uint32_t *listed_value, uint32_t *rowidx, uint32_t *values);
 /* Announces that cm_raw will be asked for in `form` (0: 32-bit, 1: 16-bit, 2: bytes; -1 takes the announcement back) with UMI counts
  * (reads_output = 0) or read counts: the container then starts the prefetch by itself as early as the matrix is final -- at the end of
  * set_initialized when merge_and_filter cannot change it (no CB merge, the Simple UMI merge, no UMI with N: merge_and_filter then only

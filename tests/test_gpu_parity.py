@@ -215,6 +215,17 @@ def _wire_equals_direct(c):
             assert np.array_equal(a, d) and np.array_equal(b, d), (filt, listed)
         c.set_matrix_wire(True)
         del wire, byt, direct
+    # round 6: with cm_raw's prefetch under way cm crosses the link as one byte per entry of cm_raw and takes its rows from cm_raw's deltas
+    # (from 2^26 entries on: the 1e9-read workloads) -- the same slots as the direct copy
+    c.set_matrix_wire(True)
+    c.prefetch_raw_matrix(form=0)
+    cm = [x.copy() for x in c.count_matrix_csc(filtered=True)]
+    raw = [x.copy() for x in c.count_matrix_csc(filtered=False)]
+    c.set_matrix_wire(False)
+    for got, filt in ((cm, True), (raw, False)):
+        for a, d in zip(got, c.count_matrix_csc(filtered=filt)):
+            assert np.array_equal(a, d), filt
+    c.set_matrix_wire(True)
 
 
 def test_merge_properties_at_scale():

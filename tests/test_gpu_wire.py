@@ -12,6 +12,12 @@ import parity
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _rider_on_small_matrices(monkeypatch):
+    """cm rides on cm_raw's rows from 2^26 entries on (round 6): these tests take that path on their small matrices as well."""
+    monkeypatch.setenv("DROPEST_RIDER_MIN_NNZ", "0")
+
+
 def matrices(c, wire, reads_output=False):
     c.set_matrix_wire(wire)
     return {f: [x.copy() for x in c.count_matrix_csc(filtered=f, reads_output=reads_output)] for f in (True, False)}
@@ -86,4 +92,40 @@ def test_a_forced_small_row_list_falls_back_on_a_dense_matrix(monkeypatch):
     c.set_matrix_wire(True)
     c.reset_results(); c.set_initialized(); c.merge_and_filter()
     assert same(matrices(c, True), direct)
+    c.close()
+
+
+@pytest.mark.parametrize("kind", ["plain", "reads", "max_cells", "merge"])
+def test_cm_rides_on_cm_raw(kind, monkeypatch):
+    """Round 6: with cm_raw on its way in the byte form, cm crosses PCIe as one byte per entry of cm_raw (its value in cm, 0 = not in cm) and the
+    host threads take the rows from cm_raw's deltas (k_misc.h: emit_values_on_rows_kernel, matrix_decode.h: widen_derived).  The slots must be the
+    direct copy's: UMI counts, read counts (values beyond 254 are listed), a -C cut (most real cells are no column of cm), after a whitelist merge."""
+    import os
+    monkeypatch.setenv("DROPEST_RIDER_MIN_NNZ", "0")      # (the library takes the rider from 2^26 entries on: here on a small matrix)
+    reads_output = kind == "reads"
+    kw = dict(min_genes_before_merge=20, min_genes_after_merge=100)
+    if kind == "max_cells":
+        kw["max_cells"] = 150
+    if kind == "merge":
+        data = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropest_amd", "data", "barcodes")
+        kw.update(merge_kind=capi.MERGE_REAL_BARCODES, barcodes_kind=capi.BARCODES_CONST, barcodes_file=os.path.join(data, "10x_aug_2016_split"))
+        s = SynthStream(n_reads=4_000_000, n_cells=400, n_genes=20000, umi_len=12, permille_neighbour=100)
+    else:
+        s = SynthStream(n_reads=4_000_000, n_cells=400, n_genes=20000, reads_per_molecule=40 if reads_output else 4)
+    c = capi.Context(**kw)
+    c.push_reads(*parity.canonical_stream(*s.generate_host()))
+    c.set_profiling(True)
+    for _ in range(2):      # (twice: kept buffers, a rider's job settled before cm_raw's slot is used again)
+        c.set_raw_matrix_prefetch(0, reads_output)
+        c.set_matrix_wire(True)
+        c.reset_results(); c.set_initialized(); c.merge_and_filter()
+        c.prefetch_raw_matrix(reads_output=reads_output, form=0)
+        cm = [x.copy() for x in c.count_matrix_csc(filtered=True, reads_output=reads_output)]
+        raw = [x.copy() for x in c.count_matrix_csc(filtered=False, reads_output=reads_output)]
+        assert c.kernel_stats().get("count:cm_rides_on_cm_raw", {"launches": 0})["launches"] >= 1
+        direct = matrices(c, False, reads_output)
+        assert all(np.array_equal(x, y) for x, y in zip(cm, direct[True])) and all(np.array_equal(x, y) for x, y in zip(raw, direct[False]))
+        assert len(cm[1]) > 50_000 and (not reads_output or int(cm[2].max()) > 254)
+        if kind == "max_cells":
+            assert len(cm[0]) - 1 == 150 and len(raw[0]) - 1 > 300
     c.close()

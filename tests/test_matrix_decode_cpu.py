@@ -104,3 +104,77 @@ def test_workers_that_nap_after_claiming_a_slice_never_make_a_slice_count_twice(
         st, ro, vo = widen(colptr, *encode(colptr, rows, vals, rng))
         assert st == 0, capi.lib().dropest_last_error()
         assert np.array_equal(ro, rows) and np.array_equal(vo, vals)
+
+
+# ---- a matrix that rides on another one's rows (round 6: cm on cm_raw; dropest_matrix_rider_widen) ----
+def make_rider(rng, colptr, rows, vals, p_col=0.7, p_keep=0.95, big_rate=0.002):
+    """A subset of the base's columns in another order, a column's entries a subset of the base's with values <= the base's (a few beyond 254)."""
+    ncols = len(colptr) - 1
+    chosen = np.flatnonzero(rng.random(ncols) < p_col)
+    rng.shuffle(chosen)
+    value = np.zeros(len(rows), np.uint8)
+    out_begin = np.full(ncols, 0xFFFFFFFF, np.uint32); out_count = np.zeros(ncols, np.uint32)
+    want_rows, want_vals, lpos, lval = [], [], [], []
+    at = 0
+    for c in chosen:
+        b, e = int(colptr[c]), int(colptr[c + 1])
+        keep = rng.random(e - b) < p_keep
+        v = np.minimum(vals[b:e], np.maximum(1, rng.integers(1, 400, e - b))).astype(np.uint32)
+        big = rng.random(e - b) < big_rate
+        v[big] = rng.integers(255, 1 << 20, int(big.sum()))
+        v[~keep] = 0
+        value[b:e] = np.where(v >= 255, 255, v)
+        kept = np.flatnonzero(v)
+        out_begin[c] = at; out_count[c] = len(kept)
+        for j in np.flatnonzero(v[kept] >= 255):
+            lpos.append(at + j); lval.append(v[kept][j])
+        want_rows.append(rows[b:e][kept]); want_vals.append(v[kept])
+        at += len(kept)
+    perm = rng.permutation(len(lpos))
+    return (value, out_begin, out_count, at, np.array(lpos, np.uint32)[perm], np.array(lval, np.uint32)[perm],
+            np.concatenate(want_rows + [np.zeros(0, np.uint32)]).astype(np.uint32), np.concatenate(want_vals + [np.zeros(0, np.uint32)]).astype(np.uint32))
+
+
+def rider_widen(colptr, d8, rows, value, out_begin, out_count, nnz_out, lpos, lval):
+    L = capi.lib()
+    L.dropest_matrix_rider_widen.restype = C.c_int
+    L.dropest_matrix_rider_widen.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    m = capi.MatrixBytes()
+    keep = [np.ascontiguousarray(a) for a in (colptr, d8, rows, value, out_begin, out_count, lpos, lval)]
+    m.ncols, m.nnz = len(colptr) - 1, len(d8)
+    m.colptr, m.row_delta = keep[0].ctypes.data, keep[1].ctypes.data
+    ro = np.full(nnz_out + 16, 0xDEADBEEF, np.uint32); vo = np.full(nnz_out + 16, 0xDEADBEEF, np.uint32)
+    st = L.dropest_matrix_rider_widen(C.byref(m), keep[2].ctypes.data, keep[3].ctypes.data, keep[4].ctypes.data, keep[5].ctypes.data, nnz_out, len(lpos),
+                                      keep[6].ctypes.data, keep[7].ctypes.data, ro.ctypes.data, vo.ctypes.data)
+    return st, ro, vo
+
+
+@pytest.mark.parametrize("seed,ncols,dense", [(31, 3000, 40), (32, 300, 300), (33, 40000, 0), (34, 2, 2)])
+def test_rider_takes_its_rows_from_the_base(seed, ncols, dense):
+    rng = np.random.default_rng(seed)
+    colptr, rows, vals = random_matrix(rng, ncols, 30000, dense)
+    d8 = encode(colptr, rows, vals, rng)[0]
+    value, ob, oc, nnz_out, lpos, lval, want_r, want_v = make_rider(rng, colptr, rows, vals)
+    st, ro, vo = rider_widen(colptr, d8, rows, value, ob, oc, nnz_out, lpos, lval)
+    assert st == 0, capi.lib().dropest_last_error()
+    assert np.array_equal(ro[:nnz_out], want_r) and np.array_equal(vo[:nnz_out], want_v)
+    assert (ro[nnz_out:] == 0xDEADBEEF).all() and (vo[nnz_out:] == 0xDEADBEEF).all()      # nothing written behind the matrix
+    if nnz_out:      # a column announced with one entry too few is refused
+        c = int(np.flatnonzero(oc)[0])
+        oc2 = oc.copy(); oc2[c] -= 1
+        st, _, _ = rider_widen(colptr, d8, rows, value, ob, oc2, nnz_out, lpos, lval)
+        assert st != 0 and b"announced" in capi.lib().dropest_last_error()
+
+
+def test_rider_scalar_walk_equals_the_vector_walk():
+    import subprocess, sys, os
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_matrix_decode_cpu as t\n"
+            "rng = np.random.default_rng(41); colptr, rows, vals = t.random_matrix(rng, 4000, 30000, 60)\n"
+            "d8 = t.encode(colptr, rows, vals, rng)[0]\n"
+            "value, ob, oc, n, lp, lv, wr, wv = t.make_rider(rng, colptr, rows, vals)\n"
+            "st, ro, vo = t.rider_widen(colptr, d8, rows, value, ob, oc, n, lp, lv)\n"
+            "assert st == 0 and np.array_equal(ro[:n], wr) and np.array_equal(vo[:n], wv)\n") % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__))
+    for env in ({"DROPEST_DECODE": "scalar"}, {}, {"DROPEST_DECODE_THREADS": "1"}, {"DROPEST_DECODE_SLICE": "256", "DROPEST_DECODE_TEST_DELAY_US": "200"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
