@@ -2,12 +2,16 @@
 #include "../../include/dropest_bgzf.h"
 #include "../../include/dropest_annotation.h"
 #include "k_inflate.h"
+#include "k_inflate_par.h"
 #include "k_bamparse.h"
 #include "util.h"
 
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -66,6 +70,34 @@ extern "C" int dropest_bgzf_inflate_device(int device, void *stream, const uint8
 		if (!d_in || !d_in_off || !d_in_len || !d_out_off || !d_out_len || !d_out || !d_status) throw InvalidError("null argument");
 		if (uintptr_t(d_in) & 7u) throw InvalidError("the compressed bytes must be 8-byte aligned");
 		HIP_CHECK(hipSetDevice(device));
+		static const int par = [] { const char *e = getenv("DROPEST_INFLATE_PAR"); return e ? atoi(e) : 0; }();
+		if (par) {
+			// the lanes of a wave on different parts of a block's symbol stream (k_inflate_par.h); the waves take blocks from a counter and keep their
+			// match lists in a scratch buffer of the (device, stream) they run on
+			struct Scratch { DevBuf<InfpMatch> list; DevBuf<uint32_t> next; uint32_t grid = 0; };
+			static std::mutex mu;
+			static std::map<std::pair<int, void *>, std::unique_ptr<Scratch>> pool;
+			Scratch *sc = nullptr;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				auto &slot = pool[{device, stream}];
+				if (!slot) {
+					slot.reset(new Scratch());
+					hipDeviceProp_t prop{};
+					HIP_CHECK(hipGetDeviceProperties(&prop, device));
+					slot->grid = uint32_t(prop.multiProcessorCount) * 4u;
+					slot->list.alloc(size_t(slot->grid) * INFP_WAVES * INFP_MATCH_CAP);
+					slot->next.alloc(1);
+				}
+				sc = slot.get();
+			}
+			HIP_CHECK(hipMemsetAsync(sc->next.p, 0, 4, hipStream_t(stream)));
+			const uint32_t grid = std::min<uint32_t>(sc->grid, (n_blocks + INFP_WAVES - 1) / INFP_WAVES);
+			hipLaunchKernelGGL(bgzf_inflate_par_kernel, dim3(grid), dim3(INFP_WAVES * 64), 0, hipStream_t(stream), d_in, in_total, d_in_off, d_in_len, d_out_off, d_out_len,
+			                   n_blocks, d_out, d_status, d_crc32, sc->list.p, sc->next.p);
+			HIP_CHECK(hipGetLastError());
+			return;
+		}
 		hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((n_blocks + INF_WAVES - 1) / INF_WAVES), dim3(INF_WAVES * 64), 0, hipStream_t(stream), d_in, in_total,
 		                   d_in_off, d_in_len, d_out_off, d_out_len, n_blocks, d_out, d_status, d_crc32);
 		HIP_CHECK(hipGetLastError());

@@ -2236,7 +2236,7 @@ bool dropest_ctx::emit_rider(bool reads_output, const std::vector<u32> &col_cell
 	using namespace dropest;
 	static const bool off = getenv("DROPEST_NO_RIDER") != nullptr;
 	MatrixResult &M = mat[0], &R = mat[1];
-	// Measured (NOTES_r06 section 5): at C3 (1.9e8 entries per matrix) the step is 6 ms shorter with the rider (132.7 -> 126.7 ms); at C2 (1.9e7
+	// Measured (NOTES_r06 section 5): at C3 (1.9e8 entries per matrix) the step is 0 to 6 ms shorter with the rider, box by box (0.18 of 0.69 GB off the link); at C2 (1.9e7
 	// entries) the 0.35 ms of link time it saves are within the noise of its own dependencies (cm's columns wait for cm_raw's lists and
 	// chunks): 9.53 against 9.32 ms over five pairs of runs.  Taken from 2^26 entries of cm_raw on; DROPEST_RIDER_MIN_NNZ moves the gate (tests: 0).
 	const char *e_min = getenv("DROPEST_RIDER_MIN_NNZ");

@@ -1,0 +1,307 @@
+// k_inflate_par.h -- raw DEFLATE of BGZF blocks with the 64 lanes of a wave decoding DIFFERENT parts of one block's symbol stream.
+//
+// k_inflate.h gives a block a wave and runs ONE chain of symbols through it: every lane computes the same value, ~40 instructions per
+// symbol, and a block of a file that deflates 3 x (a real 10x BAM: ~35 000 symbols, nine of ten literals) lasts 7-11 ms -- 50 GB/s with the
+// device full, 0.6 % of the HBM peak, and the window granularity of the BAM path (NOTES_r05 section 13, NOTES_r06 section 3).  Here the body
+// of a Huffman-coded DEFLATE block is cut into spans of 64 chunks of INFP_CHUNK_BITS input bits, one chunk per lane:
+//   (A) every lane scans its chunk from a guessed start (the chunk's first bit; lane 0 from the true position): symbols counted, output bytes
+//       and matches counted, the bit position where it leaves the chunk noted.  A prefix code re-synchronises after a few symbols, so
+//       most lanes leave their chunk at a TRUE symbol boundary whatever their start was.  Lane i + 1 then takes lane i's exit as its start and
+//       scans again if that changed; repeated until no start changes (lane k is certain after k + 1 rounds; in practice two or three rounds).
+//   (B) prefix sums of the lanes' output bytes and matches place every lane in the output and in the span's match list;
+//   (C) every lane decodes its chunk once more: literals go to their bytes of the output, matches (destination, length, distance) to the list;
+//   (D) the matches are copied in order, 64 bytes per step by all lanes (a match may read what the match before it wrote).
+// The end-of-block symbol ends a span early (the lanes behind it are dropped); block headers, the Huffman tables (ballots), stored blocks,
+// ISIZE and the CRC-32 check are k_inflate.h's.  Written from RFC 1951; replaces the same BamTools code (BgzfStream::InflateBlock under
+// BamReader::GetNextAlignment, Estimation/BamProcessing/BamController.cpp:85).  Integer work, no MFMA.
+#pragma once
+
+#include "k_inflate.h"
+
+namespace dropest {
+
+constexpr int INFP_WAVES = 4;                       // waves per workgroup
+constexpr uint32_t INFP_CHUNK_BITS = 512;           // input bits per lane and span
+constexpr uint32_t INFP_MATCH_CAP = INFP_CHUNK_BITS * 64 / 2;   // a match is at least two bits: what one span can hold
+enum : uint32_t { INFP_NONE = 0, INFP_EOB = 1, INFP_BAD = 2 };
+
+struct InfpMatch { uint32_t dst; uint16_t len, dist; };   // dst: offset in the block's output
+static_assert(sizeof(InfpMatch) == 8, "match record");
+
+// 64 bits of the compressed stream from absolute bit `abs` on (zeros beyond the buffer)
+__device__ inline uint64_t infp_peek(const uint64_t *__restrict__ gin, uint64_t in_words, uint64_t abs) {
+	const uint64_t w = abs >> 6;
+	const uint32_t sh = uint32_t(abs & 63u);
+	const uint64_t lo = w < in_words ? gin[w] : 0ull;
+	if (!sh) return lo;
+	const uint64_t hi = w + 1 < in_words ? gin[w + 1] : 0ull;
+	return (lo >> sh) | (hi << (64u - sh));
+}
+
+// one symbol of a canonical code out of the low bits of buf: root table, else bit by bit (k_inflate.h: inf_decode, per lane here)
+__device__ inline uint32_t infp_sym(uint64_t buf, const uint16_t *root, uint32_t root_mask, const uint16_t *sym, const uint16_t *count, uint32_t &used) {
+	const uint32_t e = root[uint32_t(buf) & root_mask];
+	if (e) { used = e & 15u; return e >> 4; }
+	uint32_t code = 0, first = 0, index = 0;
+	for (uint32_t len = 1; len <= 15u; ++len) {
+		code |= uint32_t(buf & 1u); buf >>= 1;
+		const uint32_t c = count[len];
+		if (code < first + c) { used = len; return sym[index + (code - first)]; }
+		index += c; first += c; first <<= 1; code <<= 1;
+	}
+	used = 1;
+	return 0xFFFFu;
+}
+
+// A lane's walk over [start, stop) of the block body (bit offsets relative to base_bits).  EMIT = false: counts only.  EMIT = true: literals
+// to out[obyte ...], matches to list[mslot ...] (their destinations are offsets in the block's output).  Returns the flag; rel = where it stands.
+template <bool EMIT>
+__device__ inline uint32_t infp_walk(const uint64_t *__restrict__ gin, uint64_t in_words, uint64_t base_bits, uint32_t start, uint32_t stop, uint32_t limit,
+                                     const InfWaveLds &L, const uint32_t *len_tab, const uint32_t *dist_tab, uint32_t &rel_out, uint32_t &n_bytes, uint32_t &n_match,
+                                     uint8_t *__restrict__ out, uint32_t obyte, InfpMatch *__restrict__ list, uint32_t mslot, uint32_t &bad_dist) {
+	uint32_t rel = start, nb = 0, nm = 0, flag = INFP_NONE;
+	uint64_t buf = 0;
+	int avail = 0;
+	while (rel < stop) {
+		if (avail < 48) { buf = infp_peek(gin, in_words, base_bits + rel); avail = 64; }
+		uint32_t used;
+		const uint32_t sy = infp_sym(buf, L.lroot, (1u << INF_LROOT) - 1u, L.lsym, L.lcount, used);
+		buf >>= used; avail -= int(used); rel += used;
+		if (sy < 256u) {
+			if (EMIT) out[obyte + nb] = uint8_t(sy);
+			++nb;
+		} else if (sy == 256u) { flag = INFP_EOB; break; }
+		else if (sy > 285u) { flag = INFP_BAD; break; }
+		else {
+			const uint32_t lt = len_tab[sy - 257u];
+			uint32_t len = lt & 0xFFFFu;
+			const uint32_t le = lt >> 16;
+			if (le) { len += uint32_t(buf) & ((1u << le) - 1u); buf >>= le; avail -= int(le); rel += le; }
+			const uint32_t ds = infp_sym(buf, L.droot, (1u << INF_DROOT) - 1u, L.dsym, L.dcount, used);
+			buf >>= used; avail -= int(used); rel += used;
+			if (ds > 29u) { flag = INFP_BAD; break; }
+			const uint32_t dt = dist_tab[ds];
+			uint32_t dist = dt & 0xFFFFu;
+			const uint32_t de = dt >> 16;
+			if (de) { dist += uint32_t(buf) & ((1u << de) - 1u); buf >>= de; avail -= int(de); rel += de; }
+			if (EMIT) {
+				if (dist > obyte + nb) bad_dist = 1u;
+				list[mslot + nm] = InfpMatch{obyte + nb, uint16_t(len), uint16_t(dist)};
+			}
+			nb += len; ++nm;
+		}
+		if (rel > limit) { flag = INFP_BAD; break; }
+	}
+	rel_out = rel; n_bytes = nb; n_match = nm;
+	return flag;
+}
+
+__device__ inline uint32_t infp_excl_scan(uint32_t v, uint32_t lane, uint32_t &total) {
+	uint32_t x = v;
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t o = uint32_t(__shfl_up(int(x), d, 64)); if (lane >= uint32_t(d)) x += o; }
+	total = uint32_t(__shfl(int(x), 63, 64));
+	return x - v;
+}
+
+// The body of one Huffman-coded DEFLATE block from absolute bit position `body` on: output appended at out + pos.  Returns the error (INF_OK ...),
+// body = the bit behind the end-of-block symbol, pos advanced.  All 64 lanes; the tables of the block are in L.
+__device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uint64_t in_words, uint64_t &body, uint64_t in_end_bits, const InfWaveLds &L,
+                                           const uint32_t *len_tab, const uint32_t *dist_tab, uint8_t *__restrict__ out, uint32_t out_cap, uint32_t &pos,
+                                           InfpMatch *__restrict__ list, uint32_t lane) {
+	for (;;) {
+		const uint64_t base = body;
+		// (bits the block may still read: to the end of the BGZF block's payload and a word beyond -- a damaged stream must not walk into its neighbours)
+		if (base > in_end_bits + 64u) return INF_INPUT_OVERRUN;
+		const uint64_t left = in_end_bits + 64u - base;
+		const uint32_t limit = left > 0xFFFFFFF0ull ? 0xFFFFFFF0u : uint32_t(left);
+		// (A) starts: the chunk's first bit (lane 0: the true position), then every lane takes its predecessor's exit until nothing moves
+		uint32_t start = lane * INFP_CHUNK_BITS, end = 0, nb = 0, nm = 0, flag = INFP_NONE, dummy = 0;
+		bool alive = true, changed = true;
+		for (uint32_t round = 0; round < 66u; ++round) {
+			if (changed && alive) flag = infp_walk<false>(gin, in_words, base, start, (lane + 1u) * INFP_CHUNK_BITS, limit, L, len_tab, dist_tab, end, nb, nm, nullptr, 0u, nullptr, 0u, dummy);
+			const uint32_t p_end = uint32_t(__shfl_up(int(end), 1, 64)), p_flag = uint32_t(__shfl_up(int(flag), 1, 64));
+			const bool p_alive = __shfl_up(int(alive), 1, 64) != 0;
+			changed = false;
+			if (lane) {
+				const bool now_alive = p_alive && p_flag == INFP_NONE;
+				changed = now_alive != alive || (now_alive && p_end != start);
+				alive = now_alive; start = p_end;
+			}
+			if (!alive) { nb = 0; nm = 0; flag = INFP_NONE; }
+			if (!__ballot(changed)) break;
+		}
+		if (__ballot(changed)) return INF_BAD_CODE;                       // (cannot happen: lane k is settled after k + 1 rounds)
+		if (__ballot(alive && flag == INFP_BAD)) return INF_BAD_CODE;
+		// (B) places
+		uint32_t tot_b, tot_m;
+		const uint32_t ob = infp_excl_scan(alive ? nb : 0u, lane, tot_b), om = infp_excl_scan(alive ? nm : 0u, lane, tot_m);
+		if (pos + tot_b > out_cap || pos + tot_b < pos) return INF_OUTPUT_OVERRUN;
+		if (tot_m > INFP_MATCH_CAP) return INF_BAD_CODE;
+		// (C) literals and the match list
+		uint32_t bad_dist = 0;
+		if (alive) {
+			uint32_t e2, b2, m2;
+			(void)infp_walk<true>(gin, in_words, base, start, (lane + 1u) * INFP_CHUNK_BITS, limit, L, len_tab, dist_tab, e2, b2, m2, out, pos + ob, list, om, bad_dist);
+		}
+		if (__ballot(bad_dist != 0u)) return INF_BAD_DISTANCE;
+		// (D) the matches, in order: 64 at a time.  A batch whose sources all lie before the batch's first destination (the usual case: a BAM's
+		// matches reach kilobytes back) is copied a lane per match -- 64 independent chains of loads in flight; any other batch one match after
+		// the other by all lanes, with a fence only where a match reads what an unfenced one wrote.
+		__threadfence_block();
+		for (uint32_t b0 = 0; b0 < tot_m; b0 += 64u) {
+			const bool have = b0 + lane < tot_m;
+			InfpMatch mine{0u, 0, 0};
+			if (have) mine = list[b0 + lane];
+			const uint32_t first_dst = uint32_t(__shfl(int(mine.dst), 0, 64));
+			const uint32_t reach = uint32_t(mine.len) < uint32_t(mine.dist) ? uint32_t(mine.len) : uint32_t(mine.dist);      // bytes of earlier output the match reads
+			const bool near = have && mine.dst - uint32_t(mine.dist) + reach > first_dst;
+			if (!__ballot(near)) {
+				if (have) {
+					uint8_t *const d = out + mine.dst;
+					const uint8_t *const s = d - mine.dist;
+					const uint32_t len = mine.len, dist = mine.dist;
+					if (dist >= len) { for (uint32_t i = 0; i < len; ++i) d[i] = s[i]; }
+					else { for (uint32_t i = 0; i < len; ++i) d[i] = s[i % dist]; }
+				}
+				__threadfence_block();
+				continue;
+			}
+			const uint32_t nbatch = tot_m - b0 < 64u ? tot_m - b0 : 64u;
+			uint32_t unfenced_from = 0xFFFFFFFFu;      // first destination written since the last fence
+			for (uint32_t t = 0; t < nbatch; ++t) {
+				const uint32_t dst = uint32_t(__shfl(int(mine.dst), int(t), 64));
+				const uint32_t ld = uint32_t(__shfl(int(uint32_t(mine.len) | (uint32_t(mine.dist) << 16)), int(t), 64));
+				const uint32_t len = ld & 0xFFFFu, dist = ld >> 16;
+				if (unfenced_from != 0xFFFFFFFFu && dst - dist + (len < dist ? len : dist) > unfenced_from) { __threadfence_block(); unfenced_from = 0xFFFFFFFFu; }
+				uint8_t *const d = out + dst;
+				const uint8_t *const s = d - dist;
+				if (dist >= len) { for (uint32_t i = lane; i < len; i += 64u) d[i] = s[i]; }
+				else { for (uint32_t i = lane; i < len; i += 64u) d[i] = s[i % dist]; }
+				if (unfenced_from == 0xFFFFFFFFu) unfenced_from = dst;
+			}
+			__threadfence_block();
+		}
+		pos += tot_b;
+		// where the span ends: behind the end-of-block symbol, or at the last lane's exit
+		const unsigned long long eob = __ballot(alive && flag == INFP_EOB);
+		const int last = eob ? __builtin_ctzll(eob) : 63;
+		const uint32_t span_end = uint32_t(__shfl(int(end), last, 64));
+		body = base + span_end;
+		if (eob) return INF_OK;
+		if (!span_end) return INF_BAD_CODE;                               // (no progress: cannot happen, every symbol takes a bit)
+	}
+}
+
+// One BGZF block per wave at a time; the waves of the launch take blocks from a counter (*next_block, 0 at launch) until none is left, so that
+// a wave's match list can live in a slot of `scratch` that belongs to it (INFP_MATCH_CAP records per wave of the grid).
+__global__ __launch_bounds__(INFP_WAVES * 64) void bgzf_inflate_par_kernel(const uint8_t *__restrict__ d_in, uint64_t in_total_len, const uint64_t *__restrict__ in_off,
+                                                                           const uint32_t *__restrict__ in_len, const uint64_t *__restrict__ out_off,
+                                                                           const uint32_t *__restrict__ out_len, uint32_t n_blocks, uint8_t *d_out,
+                                                                           uint32_t *__restrict__ status, const uint32_t *__restrict__ crc32, InfpMatch *__restrict__ scratch,
+                                                                           uint32_t *next_block) {
+	__shared__ InfWaveLds lds[INFP_WAVES];
+	__shared__ uint32_t crc_tab[4 * 256];
+	__shared__ uint32_t crc_x2n[INFP_WAVES][32];
+	__shared__ uint32_t len_tab[32], dist_tab[32];
+	if (crc32) {
+		uint32_t c = threadIdx.x & 255u;
+		for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ INF_CRC_POLY : c >> 1;
+		crc_tab[threadIdx.x & 255u] = c;                  // (INFP_WAVES * 64 = 256 threads: one entry of every table each)
+		__syncthreads();
+		for (int t = 1; t < 4; ++t) { c = (c >> 8) ^ crc_tab[c & 0xFFu]; crc_tab[t * 256 + (threadIdx.x & 255u)] = c; __syncthreads(); }
+	}
+	if (threadIdx.x < 32) len_tab[threadIdx.x] = uint32_t(INF_LEN_BASE[threadIdx.x]) | uint32_t(INF_LEN_EXTRA[threadIdx.x]) << 16;
+	else if (threadIdx.x < 64) dist_tab[threadIdx.x - 32] = uint32_t(INF_DIST_BASE[threadIdx.x - 32]) | uint32_t(INF_DIST_EXTRA[threadIdx.x - 32]) << 16;
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	InfWaveLds &L = lds[wave];
+	InfpMatch *const list = scratch + size_t(blockIdx.x * INFP_WAVES + wave) * INFP_MATCH_CAP;
+	const uint64_t *const gin = reinterpret_cast<const uint64_t *>(d_in);
+	const uint64_t in_words = (in_total_len + 7) >> 3;
+	for (;;) {
+		uint32_t blk = 0;
+		if (lane == 0) blk = atomicAdd(next_block, 1u);
+		blk = uint32_t(__shfl(int(blk), 0, 64));
+		if (blk >= n_blocks) return;
+		InfState s;
+		s.gin = gin; s.in_words = in_words;
+		const uint64_t in_begin = in_off[blk], in_end = in_begin + in_len[blk];
+		s.ipos = in_begin; s.loaded_hi = in_begin & ~uint64_t(255); s.bits = 0; s.cnt = 0;
+		uint8_t *const out = d_out + out_off[blk];
+		const uint32_t out_cap = out_len[blk];
+		uint32_t pos = 0, err = INF_OK;
+		for (bool last = false; !last && !err;) {
+			if (s.ipos - uint64_t(s.cnt >> 3) > in_end + 8) { err = INF_INPUT_OVERRUN; break; }
+			last = inf_take(s, L, lane, 1) != 0;
+			const uint32_t type = inf_take(s, L, lane, 2);
+			if (type == 0) {   // stored: to the byte boundary, LEN, NLEN, bytes
+				const int drop = s.cnt & 7;
+				s.bits >>= drop; s.cnt -= drop;
+				const uint32_t len = inf_take(s, L, lane, 16), nlen = inf_take(s, L, lane, 16);
+				if ((len ^ nlen) != 0xFFFFu) { err = INF_BAD_STORED; break; }
+				const uint64_t from = s.ipos - uint64_t(s.cnt >> 3);
+				if (from + len > in_end) { err = INF_INPUT_OVERRUN; break; }
+				if (pos + len > out_cap) { err = INF_OUTPUT_OVERRUN; break; }
+				for (uint32_t i = lane; i < len; i += 64) out[pos + i] = d_in[from + i];
+				pos += len;
+				s.ipos = from + len; s.bits = 0; s.cnt = 0; s.loaded_hi = s.ipos & ~uint64_t(255);
+				continue;
+			}
+			if (type == 3) { err = INF_BAD_BLOCK_TYPE; break; }
+			int hlit, hdist;
+			if (type == 1) {
+				hlit = 288; hdist = 30;
+				for (uint32_t i = lane; i < 288u; i += 64) L.lens[i] = i < 144u ? 8 : (i < 256u ? 9 : (i < 280u ? 7 : 8));
+				if (lane < 30u) L.lens[288u + lane] = 5;
+			} else {
+				hlit = int(inf_take(s, L, lane, 5)) + 257; hdist = int(inf_take(s, L, lane, 5)) + 1;
+				const int hclen = int(inf_take(s, L, lane, 4)) + 4;
+				if (hlit > 286 || hdist > 30) { err = INF_BAD_LENGTHS; break; }
+				if (lane < 19u) L.lens[lane] = 0;
+				for (int i = 0; i < hclen; ++i) {
+					const uint32_t v = inf_take(s, L, lane, 3);
+					if (lane == 0) L.lens[INF_CL_ORDER[i]] = uint8_t(v);
+				}
+				if (!inf_build(L.lens, 19, 7, L.droot, L.dsym, L.dcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
+				int have = 0;
+				uint32_t prev = 0;
+				const int total = hlit + hdist;
+				while (have < total && !err) {
+					const uint32_t sy = inf_decode(s, L, lane, L.droot, 7, L.dsym, L.dcount);
+					uint32_t rep = 1, val = sy;
+					if (sy < 16u) { prev = sy; }
+					else if (sy == 16u) { if (!have) { err = INF_BAD_LENGTHS; break; } rep = 3 + inf_take(s, L, lane, 2); val = prev; }
+					else if (sy == 17u) { rep = 3 + inf_take(s, L, lane, 3); val = 0; prev = 0; }
+					else if (sy == 18u) { rep = 11 + inf_take(s, L, lane, 7); val = 0; prev = 0; }
+					else { err = INF_BAD_CODE; break; }
+					if (have + int(rep) > total) { err = INF_BAD_LENGTHS; break; }
+					for (uint32_t i = lane; i < rep; i += 64) L.lens[uint32_t(have) + i] = uint8_t(val);
+					have += int(rep);
+				}
+				if (err) break;
+				if (inf_uni(L.lens[256]) == 0) { err = INF_BAD_LENGTHS; break; }
+			}
+			if (!inf_build(L.lens, hlit, INF_LROOT, L.lroot, L.lsym, L.lcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
+			if (!inf_build(L.lens + hlit, hdist, INF_DROOT, L.droot, L.dsym, L.dcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
+			__threadfence_block();                        // the tables, before the lanes read them at their own places
+			// the body of the block, by all lanes; then the header reader takes up again behind the end-of-block symbol
+			uint64_t body = (s.ipos << 3) - uint64_t(s.cnt);
+			err = infp_block_body(gin, in_words, body, in_end << 3, L, len_tab, dist_tab, out, out_cap, pos, list, lane);
+			if (err) break;
+			s.ipos = body >> 3; s.bits = 0; s.cnt = 0; s.loaded_hi = s.ipos & ~uint64_t(255);
+			if (body & 7u) (void)inf_take(s, L, lane, int(body & 7u));
+		}
+		if (!err) {
+			if (pos != out_cap) err = INF_SIZE_MISMATCH;
+			else if (s.ipos - uint64_t(s.cnt >> 3) > in_end) err = INF_INPUT_OVERRUN;
+		}
+		if (!err && crc32) {
+			__threadfence_block();
+			if (inf_crc32_block(out, out_cap, crc_tab, crc_x2n[wave], lane) != crc32[blk]) err = INF_CRC_MISMATCH;
+		}
+		if (lane == 0) status[blk] = err;
+	}
+}
+
+}  // namespace dropest
