@@ -94,7 +94,7 @@ extern "C" int dropest_bgzf_inflate_device(int device, void *stream, const uint8
 			HIP_CHECK(hipMemsetAsync(sc->next.p, 0, 4, hipStream_t(stream)));
 			const uint32_t grid = std::min<uint32_t>(sc->grid, (n_blocks + INFP_WAVES - 1) / INFP_WAVES);
 			hipLaunchKernelGGL(bgzf_inflate_par_kernel, dim3(grid), dim3(INFP_WAVES * 64), 0, hipStream_t(stream), d_in, in_total, d_in_off, d_in_len, d_out_off, d_out_len,
-			                   n_blocks, d_out, d_status, d_crc32, sc->list.p, sc->next.p);
+			                   n_blocks, d_out, d_status, d_crc32, sc->list.p, sc->next.p, uint32_t(getenv("DROPEST_INFLATE_PAR_DBG") ? atoi(getenv("DROPEST_INFLATE_PAR_DBG")) : 0));
 			HIP_CHECK(hipGetLastError());
 			return;
 		}
