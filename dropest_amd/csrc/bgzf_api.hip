@@ -70,7 +70,10 @@ extern "C" int dropest_bgzf_inflate_device(int device, void *stream, const uint8
 		if (!d_in || !d_in_off || !d_in_len || !d_out_off || !d_out_len || !d_out || !d_status) throw InvalidError("null argument");
 		if (uintptr_t(d_in) & 7u) throw InvalidError("the compressed bytes must be 8-byte aligned");
 		HIP_CHECK(hipSetDevice(device));
-		static const int par = [] { const char *e = getenv("DROPEST_INFLATE_PAR"); return e ? atoi(e) : 0; }();
+		// DROPEST_INFLATE_PAR=0: one chain of symbols per block (k_inflate.h: 131 GB/s on a file that deflates 10.8 x, 52 on one that deflates 3.2 x like
+		// a real 10x BAM); default: the lanes of a wave on different chunks of the block's symbols (k_inflate_par.h: 123 / 94 GB/s, and a block lasts
+		// 0.7 ms instead of 7-11, which is what a window of the BAM path waits for)
+		static const int par = [] { const char *e = getenv("DROPEST_INFLATE_PAR"); return e ? atoi(e) : 1; }();
 		if (par) {
 			// the lanes of a wave on different parts of a block's symbol stream (k_inflate_par.h); the waves take blocks from a counter and keep their
 			// match lists in a scratch buffer of the (device, stream) they run on

@@ -21,8 +21,18 @@
 namespace dropest {
 
 constexpr int INFP_WAVES = 4;                       // waves per workgroup
-constexpr uint32_t INFP_CHUNK_BITS = 512;           // input bits per lane and span
+#ifndef INFP_CHUNK
+#define INFP_CHUNK 512
+#endif
+constexpr uint32_t INFP_CHUNK_BITS = INFP_CHUNK;     // input bits per lane and span
 constexpr uint32_t INFP_MATCH_CAP = INFP_CHUNK_BITS * 64 / 2;   // a match is at least two bits: what one span can hold
+#ifndef INFP_OVERLAP_BITS
+#define INFP_OVERLAP_BITS 0
+#endif
+// A lane's first, guessed walk may start this many bits BEFORE its chunk (by the chunk's first bit it has usually fallen in step with the true
+// symbols, and then needs no second walk).  Measured with 96: 93.8 -> 89.5 GB/s on the 3.2 x file -- the longer first walks cost more than the
+// second walks they save.  0: off.
+constexpr uint32_t INFP_OVERLAP = INFP_OVERLAP_BITS;
 constexpr uint32_t INFP_SPAN_WORDS = INFP_CHUNK_BITS + 8;       // 64-bit words of input a span may look at: its 64 chunks, the word its first bit stands in, and a symbol's reach behind its last bit
 enum : uint32_t { INFP_NONE = 0, INFP_EOB = 1, INFP_BAD = 2 };
 
@@ -56,14 +66,16 @@ __device__ inline uint32_t infp_sym(uint64_t buf, const uint16_t *root, uint32_t
 // A lane's walk over [start, stop) of the block body (bit offsets relative to base_bits).  EMIT = false: counts only.  EMIT = true: literals
 // to out[obyte ...], matches to list[mslot ...] (their destinations are offsets in the block's output).  Returns the flag; rel = where it stands.
 template <bool EMIT>
-__device__ inline uint32_t infp_walk(const uint64_t *span, uint32_t span_bit0, uint32_t start, uint32_t stop, uint32_t limit,
+__device__ inline uint32_t infp_walk(const uint64_t *span, uint32_t span_bit0, uint32_t start, uint32_t count_from, uint32_t &entry, uint32_t stop, uint32_t limit,
                                      const InfWaveLds &L, const uint32_t *len_tab, const uint32_t *dist_tab, uint32_t &rel_out, uint32_t &n_bytes, uint32_t &n_match,
                                      uint8_t *__restrict__ out, uint32_t obyte, InfpMatch *__restrict__ list, uint32_t mslot, uint32_t &bad_dist) {
 	uint32_t rel = start, nb = 0, nm = 0, flag = INFP_NONE;
 	uint64_t buf = 0;
 	int avail = 0;
+	entry = 0xFFFFFFFFu;      // the first symbol boundary at or behind count_from: what is counted starts there
 	for (uint32_t steps = 0; rel < stop; ++steps) {
-		if (steps > INFP_CHUNK_BITS + 64u) { flag = INFP_BAD; break; }      // (every symbol takes a bit: never reached)
+		if (steps > INFP_CHUNK_BITS + INFP_OVERLAP + 64u) { flag = INFP_BAD; break; }      // (every symbol takes a bit: never reached)
+		if (entry == 0xFFFFFFFFu && rel >= count_from) { entry = rel; nb = 0; nm = 0; }
 		if (avail < 48) { buf = infp_peek(span, span_bit0 + rel); avail = 64; }
 		uint32_t used;
 		const uint32_t sy = infp_sym(buf, L.lroot, (1u << INF_LROOT) - 1u, L.lsym, L.lcount, used);
@@ -123,10 +135,16 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 		for (uint32_t i = lane; i < INFP_SPAN_WORDS; i += 64u) span[i] = word0 + i < in_words ? gin[word0 + i] : 0ull;
 		__threadfence_block();
 		// (A) starts: the chunk's first bit (lane 0: the true position), then every lane takes its predecessor's exit until nothing moves
-		uint32_t start = lane * INFP_CHUNK_BITS, end = 0, nb = 0, nm = 0, flag = INFP_NONE, dummy = 0;
+		// (round 0: from INFP_OVERLAP bits before the chunk, counting from the first boundary inside it -- when that boundary is where the lane
+		// before leaves ITS chunk, which it mostly is, the lane needs no second walk)
+		uint32_t start = lane * INFP_CHUNK_BITS, end = 0, nb = 0, nm = 0, flag = INFP_NONE, dummy = 0, entry = 0;
 		bool alive = true, changed = true;
 		for (uint32_t round = 0; round < 66u; ++round) {
-			if (changed && alive) flag = infp_walk<false>(span, bit0, start, (lane + 1u) * INFP_CHUNK_BITS, limit, L, len_tab, dist_tab, end, nb, nm, nullptr, 0u, nullptr, 0u, dummy);
+			if (changed && alive) {
+				const uint32_t from = round == 0u && lane ? start - INFP_OVERLAP : start;
+				flag = infp_walk<false>(span, bit0, from, start, entry, (lane + 1u) * INFP_CHUNK_BITS, limit, L, len_tab, dist_tab, end, nb, nm, nullptr, 0u, nullptr, 0u, dummy);
+				if (round == 0u && lane) start = entry;      // (0xFFFFFFFF: the guess ran out before the chunk began -- the lane before will say where to start)
+			}
 			const uint32_t p_end = uint32_t(__shfl_up(int(end), 1, 64)), p_flag = uint32_t(__shfl_up(int(flag), 1, 64));
 			const bool p_alive = __shfl_up(int(alive), 1, 64) != 0;
 			changed = false;
@@ -151,7 +169,7 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 		uint32_t bad_dist = 0;
 		if (alive && dbg != 12) {      // (dbg 11 / 12: timing probes -- no match copies / no second walk either; the output is wrong then)
 			uint32_t e2, b2, m2;
-			(void)infp_walk<true>(span, bit0, start, (lane + 1u) * INFP_CHUNK_BITS, limit, L, len_tab, dist_tab, e2, b2, m2, out, pos + ob, list, om, bad_dist);
+			(void)infp_walk<true>(span, bit0, start, start, dummy, (lane + 1u) * INFP_CHUNK_BITS, limit, L, len_tab, dist_tab, e2, b2, m2, out, pos + ob, list, om, bad_dist);
 		}
 		if (__ballot(bad_dist != 0u)) return INF_BAD_DISTANCE;
 		if (dbg == 5) return 205u;
