@@ -8,6 +8,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <future>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -95,7 +96,9 @@ extern "C" int dropest_bgzf_inflate_device(int device, void *stream, const uint8
 				sc = slot.get();
 			}
 			HIP_CHECK(hipMemsetAsync(sc->next.p, 0, 4, hipStream_t(stream)));
-			const uint32_t grid = std::min<uint32_t>(sc->grid, (n_blocks + INFP_WAVES - 1) / INFP_WAVES);
+			// (DROPEST_INFLATE_PAR_WGS_PER_CU=1..3: fewer workgroups than the CUs hold, so that kernels of other streams find wave slots and LDS beside this one)
+			static const uint32_t wgs_per_cu = [] { const char *e = getenv("DROPEST_INFLATE_PAR_WGS_PER_CU"); const int v = e ? atoi(e) : 4; return uint32_t(v < 1 ? 1 : v > 4 ? 4 : v); }();
+			const uint32_t grid = std::min<uint32_t>(sc->grid / 4u * wgs_per_cu, (n_blocks + INFP_WAVES - 1) / INFP_WAVES);
 			hipLaunchKernelGGL(bgzf_inflate_par_kernel, dim3(grid), dim3(INFP_WAVES * 64), 0, hipStream_t(stream), d_in, in_total, d_in_off, d_in_len, d_out_off, d_out_len,
 			                   n_blocks, d_out, d_status, d_crc32, sc->list.p, sc->next.p, uint32_t(getenv("DROPEST_INFLATE_PAR_DBG") ? atoi(getenv("DROPEST_INFLATE_PAR_DBG")) : 0));
 			HIP_CHECK(hipGetLastError());
@@ -106,6 +109,15 @@ extern "C" int dropest_bgzf_inflate_device(int device, void *stream, const uint8
 		HIP_CHECK(hipGetLastError());
 	});
 }
+
+#ifdef INFP_PROFILE
+// (variant builds of scripts/experiments/inflate_variants only: the kernel's own account of its phases, read and cleared)
+extern "C" int dropest_bgzf_inflate_profile(unsigned long long *out16) {
+	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(dropest::infp_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+	unsigned long long zero[16] = {};
+	return hipMemcpyToSymbol(HIP_SYMBOL(dropest::infp_prof), zero, sizeof(zero)) != hipSuccess;
+}
+#endif
 
 extern "C" int dropest_bgzf_inflate_buffer(int device, const uint8_t *data, uint64_t len, uint8_t *out, uint64_t out_cap, uint64_t *out_len,
                                            uint32_t *status, uint64_t status_cap, uint64_t *n_blocks, double *kernel_ms, int repeats) {
@@ -221,7 +233,25 @@ struct dropest_bam_decoder {
 	unsigned long long hash_mask = ~0ull;
 	uint64_t tail_len = 0, last_n_rec = 0, last_n_ok = 0;
 	// the compressed bytes of a staging buffer on their way to the device ahead of the window call (dropest_bam_decoder_upload)
-	hipStream_t up_stream = nullptr;   // the device's null stream: it exists already (a stream of its own is 6-8 ms to create), and the decoder's other streams do not wait for it (non-blocking)
+	// Two streams: `stream` for the kernels and the small copies, `up_stream` for the compressed bytes on their way in under the kernels of the
+	// window before.  A stream is 8-20 ms to create (and its first dispatch as much again), and every other HIP call of the process waits
+	// meanwhile -- measured three ways in round 6 (created up front: 16 ms; on a helper thread beside the pinned allocation: the allocation runs,
+	// hipMalloc and the reader's first copies wait, nothing gained; NOTES_r06 section 7).  So the decoder creates none unless it has to:
+	// `stream` is LENT by the caller for a file (dropest_bam_decoder_use_stream: the container's own, which exists and has run kernels; a
+	// decoder that is lent none makes one when first needed), and the uploads take the device's null stream, which the non-blocking streams
+	// do not wait for.
+	hipStream_t up_stream = nullptr;
+	bool up_begun[2] = {false, false};
+	hipStream_t own_stream = nullptr;      // `stream` is this one, or the caller's
+	bool tables_fresh = true;              // the empty dictionaries' memsets have not been queued yet (they wait for `stream`)
+	std::mutex ready_mutex;
+	// pinned pieces (dropest_bam_decoder_pieces): the compressed bytes of a window go to the device piece by piece, so that the pinned memory
+	// (0.15-0.4 ms per MB to allocate) does not grow with the window
+	PinnedBuf<uint8_t> piece_mem;      // one allocation (each has a fixed cost of a few ms), cut into the pieces
+	uint32_t n_pieces = 0;
+	uint64_t piece_bytes = 0;
+	std::vector<hipEvent_t> piece_done;
+	std::atomic<const uint8_t *> up_host[2] = {{nullptr}, {nullptr}};   // the host bytes that up_in[w] holds (or will, once up_done[w] has passed)
 	hipEvent_t up_done[2] = {nullptr, nullptr};
 	DevBuf<uint8_t> up_in[2];
 	uint64_t up_len[2] = {0, 0};
@@ -229,6 +259,20 @@ struct dropest_bam_decoder {
 	// ... and their block table, made by the same caller (a walk from header to header is one cache miss per block: ~2 ms per 64 MB window)
 	struct UpBlocks { std::vector<uint64_t> in_off, out_off; std::vector<uint32_t> in_len, out_len, crc; uint64_t n = 0, used = 0, total = 0; bool ok = false; } up_blocks[2];
 };
+
+// The decoder's streams exist from here on (the helper thread of dropest_bam_decoder_create is joined by the first call that needs them)
+static void bam_ready(dropest_bam_decoder *d) {
+	std::lock_guard<std::mutex> lk(d->ready_mutex);
+	if (!d->stream) {
+		if (!d->own_stream) HIP_CHECK(hipStreamCreateWithFlags(&d->own_stream, hipStreamNonBlocking));
+		d->stream = d->own_stream;
+	}
+	if (d->tables_fresh) {
+		HIP_CHECK(hipMemsetAsync(d->g_vals.p, 0, size_t(d->g_mask + 1) * 4, d->stream));
+		HIP_CHECK(hipMemsetAsync(d->d_chr.p, 0xFF, d->d_chr.n * 4, d->stream));
+		d->tables_fresh = false;
+	}
+}
 
 // comp[0 .. len) walked from block header to block header: the arrays the inflate kernel and the host fall-back take.  false: not whole, sound blocks
 // (the caller says what is wrong with dropest_bgzf_scan's message)
@@ -268,18 +312,11 @@ extern "C" int dropest_bam_decoder_create(int device, const dropest_bam_parse_cf
 			const bool trace = getenv("DROPEST_BAM_TRACE") != nullptr;
 			auto t0 = clk::now();
 			auto lap = [&](const char *what) { if (trace) { std::fprintf(stderr, "[bam] decoder: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(clk::now() - t0).count()); t0 = clk::now(); } };
-			HIP_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-			lap("first stream");
-			// (a stream is 6-8 ms to create: the first halves' own streams are made when a caller first asks for them --
-			// dropest_bam_decoder_window_begin called directly -- and dropest_bam_decoder_upload sends on the null stream)
-			for (hipEvent_t &e : d->up_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-			lap("events");
 			// empty dictionaries: every gene and chromosome is new
 			d->g_mask = 1023; d->g_keys.alloc(1024); d->g_vals.alloc(1024); d->d_chr.alloc(size_t(std::max(1, cfg->n_refs)));
 			lap("dictionary buffers");
-			HIP_CHECK(hipMemset(d->g_vals.p, 0, 1024 * 4));
-			HIP_CHECK(hipMemset(d->d_chr.p, 0xFF, size_t(std::max(1, cfg->n_refs)) * 4));
-			lap("two memsets");
+			for (hipEvent_t &e : d->up_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			lap("events");
 		} catch (...) { delete d; throw; }
 		*out = d;
 	});
@@ -293,16 +330,19 @@ extern "C" int dropest_bam_decoder_reset(dropest_bam_decoder *d, const dropest_b
 		if (cfg->intronic_len > 24 || cfg->intergenic_len > 24) throw InvalidError("read-type values longer than 24 characters");
 		if (cfg->n_refs < 0) throw InvalidError("negative number of references");
 		HIP_CHECK(hipSetDevice(d->device));
+		bam_ready(d);
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		for (BamFront &f : d->front) { if (f.stream) HIP_CHECK(hipStreamSynchronize(f.stream)); f.begun = false; f.inflating = false; }
 		HIP_CHECK(hipStreamSynchronize(d->up_stream));
 		d->up_ready[0].store(false, std::memory_order_relaxed); d->up_ready[1].store(false, std::memory_order_relaxed);
+		d->up_host[0].store(nullptr, std::memory_order_relaxed); d->up_host[1].store(nullptr, std::memory_order_relaxed);
 		std::memcpy(&d->cfg, cfg, sizeof(BamParseCfg));
 		d->tail_len = 0; d->last_n_rec = 0; d->last_n_ok = 0; d->next_front = 0; d->last_front = 0;
 		d->annotation = nullptr; d->n_ann_genes = 0; d->n_gene_names = 0;
-		HIP_CHECK(hipMemset(d->g_vals.p, 0, size_t(d->g_mask + 1) * 4));
 		d->d_chr.ensure(size_t(std::max(1, cfg->n_refs)));
-		HIP_CHECK(hipMemset(d->d_chr.p, 0xFF, size_t(std::max(1, cfg->n_refs)) * 4));
+		HIP_CHECK(hipMemsetAsync(d->g_vals.p, 0, size_t(d->g_mask + 1) * 4, d->stream));
+		HIP_CHECK(hipMemsetAsync(d->d_chr.p, 0xFF, d->d_chr.n * 4, d->stream));
+		HIP_CHECK(hipStreamSynchronize(d->stream));
 	});
 }
 
@@ -312,6 +352,24 @@ extern "C" uint32_t dropest_bam_decoder_wave_slots(const dropest_bam_decoder *d)
 	hipDeviceProp_t prop{};
 	if (hipGetDeviceProperties(&prop, d->device) != hipSuccess) return 0;
 	return uint32_t(prop.multiProcessorCount) * 4u * uint32_t(INF_WAVES_PER_EU);
+}
+
+// Room on the device for windows of `bytes` compressed bytes in front `which`, up front (a BAM inflates ~4-12 x, a record is >= ~120 bytes), so that
+// the first windows do not grow every buffer step by step (each growth is a free + an allocation that wait for the device)
+static void bam_reserve(dropest_bam_decoder *d, int which, uint64_t bytes, uint64_t out_hint = 0) {
+	BamFront &F = d->front[which];
+	// (14 x when the caller does not know better: 2 x 1.8 GB for windows of 128 MB, 1-2 ms on most boxes and 130 ms on some)
+	const uint64_t out_bytes = out_hint ? out_hint + out_hint / 8 + (uint64_t(1) << 20) : bytes * 14, n_rec = out_bytes / 120, n_blk = bytes / 2048 + 1024, n_seg = out_bytes / BAM_SEG + 16;
+	F.d_in.ensure(bytes + 8); F.d_out.ensure(out_bytes);
+	d->up_in[which].ensure(bytes + 8);
+	F.d_in_off.ensure(n_blk); F.d_out_off.ensure(n_blk); F.d_in_len.ensure(n_blk); F.d_out_len.ensure(n_blk); F.d_status.ensure(n_blk); F.d_crc.ensure(n_blk); F.h_block_status.ensure(n_blk);
+	F.seg_start.ensure(n_seg); F.seg_exit.ensure(n_seg); F.seg_count.ensure(n_seg); F.seg_base.ensure(n_seg);
+	F.h_seg_start.ensure(n_seg); F.h_seg_exit.ensure(n_seg); F.h_count.ensure(n_seg);
+	if (which == 0) {
+		d->rec_off.ensure(n_rec); d->o_cb.ensure(n_rec); d->o_umi.ensure(n_rec); d->o_gene.ensure(n_rec); d->o_aux.ensure(n_rec); d->o_uql.ensure(n_rec);
+		d->o_status.ensure(n_rec); d->o_need.ensure(n_rec); d->dn_cb.ensure(n_rec); d->dn_umi.ensure(n_rec); d->dn_gene.ensure(n_rec); d->dn_aux.ensure(n_rec);
+		d->nd_rec.ensure(n_rec); d->nd_pos.ensure(n_rec); d->nd_size.ensure(n_rec);
+	}
 }
 
 extern "C" int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, uint64_t bytes, uint8_t **out) {
@@ -325,22 +383,98 @@ extern "C" int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, ui
 		d->h_stage[which].ensure(bytes);
 		lap("pinned buffer");
 		*out = d->h_stage[which].p;
-		// the size of the caller's windows is known now: room for them up front (a BAM inflates ~4-12 x, a record is >= ~120 bytes), so that the
-		// first windows do not grow every buffer step by step (each growth is a free + an allocation that wait for the device)
-		BamFront &F = d->front[which];
-		const uint64_t out_bytes = bytes * 14, n_rec = out_bytes / 120, n_blk = bytes / 2048 + 1024, n_seg = out_bytes / BAM_SEG + 16;
-		F.d_in.ensure(bytes + 8); F.d_out.ensure(out_bytes);
-		d->up_in[which].ensure(bytes + 8);
-		F.d_in_off.ensure(n_blk); F.d_out_off.ensure(n_blk); F.d_in_len.ensure(n_blk); F.d_out_len.ensure(n_blk); F.d_status.ensure(n_blk); F.d_crc.ensure(n_blk); F.h_block_status.ensure(n_blk);
-		F.seg_start.ensure(n_seg); F.seg_exit.ensure(n_seg); F.seg_count.ensure(n_seg); F.seg_base.ensure(n_seg);
-		F.h_seg_start.ensure(n_seg); F.h_seg_exit.ensure(n_seg); F.h_count.ensure(n_seg);
-		if (which == 0) {
-			d->rec_off.ensure(n_rec); d->o_cb.ensure(n_rec); d->o_umi.ensure(n_rec); d->o_gene.ensure(n_rec); d->o_aux.ensure(n_rec); d->o_uql.ensure(n_rec);
-			d->o_status.ensure(n_rec); d->o_need.ensure(n_rec); d->dn_cb.ensure(n_rec); d->dn_umi.ensure(n_rec); d->dn_gene.ensure(n_rec); d->dn_aux.ensure(n_rec);
-			d->nd_rec.ensure(n_rec); d->nd_pos.ensure(n_rec); d->nd_size.ensure(n_rec);
-		}
+		bam_reserve(d, which, bytes);
 		lap("device buffers");
 	});
+}
+
+// The same without the pinned buffer: for a caller that sends the compressed bytes in pieces (below)
+extern "C" int dropest_bam_decoder_reserve(dropest_bam_decoder *d, int which, uint64_t bytes, uint64_t inflated_bytes) {
+	return bgzf_guarded([&] {
+		if (!d || which < 0 || which > 1) throw InvalidError("bad argument");
+		HIP_CHECK(hipSetDevice(d->device));
+		bam_reserve(d, which, bytes, inflated_bytes);
+	});
+}
+
+// n pinned pieces of `bytes` each (kept by the decoder; a second call with other sizes replaces them): out[k] = piece k
+extern "C" int dropest_bam_decoder_pieces(dropest_bam_decoder *d, uint32_t n, uint64_t bytes, uint8_t **out) {
+	return bgzf_guarded([&] {
+		if (!d || !out || !n || n > 64 || !bytes) throw InvalidError("bad argument");
+		HIP_CHECK(hipSetDevice(d->device));
+		if (d->n_pieces) HIP_CHECK(hipStreamSynchronize(d->up_stream));      // (copies out of the pieces there are)
+		if (d->n_pieces != n) {
+			for (hipEvent_t e : d->piece_done) if (e) (void)hipEventDestroy(e);
+			d->piece_done.clear();
+			d->n_pieces = 0;
+			d->piece_done.assign(n, nullptr);
+			for (hipEvent_t &e : d->piece_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		}
+		const uint64_t each = (bytes + 4095u) & ~uint64_t(4095);
+		d->piece_mem.ensure(each * n);
+		d->n_pieces = n; d->piece_bytes = each;
+		for (uint32_t k = 0; k < n; ++k) out[k] = d->piece_mem.p + each * k;
+	});
+}
+
+// Piece `piece` is free again: the copy that read it last has finished (at once when there was none)
+extern "C" int dropest_bam_decoder_piece_wait(dropest_bam_decoder *d, uint32_t piece) {
+	if (!d || piece >= d->n_pieces) return 1;
+	if (hipSetDevice(d->device) != hipSuccess) return 1;
+	return hipEventSynchronize(d->piece_done[piece]) == hipSuccess ? 0 : 1;
+}
+
+// A window's pieces are about to be sent to up-buffer `which` (one thread; the .._upload_piece calls that follow may come from several)
+extern "C" int dropest_bam_decoder_upload_begin(dropest_bam_decoder *d, int which) {
+	if (!d || which < 0 || which > 1 || !d->n_pieces) return 1;
+	d->up_ready[which].store(false, std::memory_order_relaxed);
+	d->up_begun[which] = true;
+	return 0;
+}
+
+// The first `len` bytes of piece `piece` to up-buffer `which` at byte `dst_off`, on the upload stream; does not wait.  May be called from several
+// threads (different pieces).  .._upload_done(which, host bytes, total length) then says what the buffer holds.
+extern "C" int dropest_bam_decoder_upload_piece(dropest_bam_decoder *d, int which, uint32_t piece, uint64_t dst_off, uint64_t len) {
+	if (!d || which < 0 || which > 1 || piece >= d->n_pieces || len > d->piece_bytes || dst_off + len + 8 > d->up_in[which].n) return 1;
+	if (!len) return 0;
+	if (hipSetDevice(d->device) != hipSuccess) return 1;
+	if (!d->up_begun[which]) return 1;      // (.._upload_begin was not called)
+	if (hipMemcpyAsync(d->up_in[which].p + dst_off, d->piece_mem.p + d->piece_bytes * piece, len, hipMemcpyHostToDevice, d->up_stream) != hipSuccess) return 1;
+	return hipEventRecord(d->piece_done[piece], d->up_stream) == hipSuccess ? 0 : 1;
+}
+
+// Every piece of a window has been given to .._upload_piece: up-buffer `which` holds (will hold, when those copies are through) host[0 .. len).
+// The block table is made from `host` (which must stay readable until the window call that is given `host` and `len` has returned -- the host
+// fall-back for a refused block reads it).
+extern "C" int dropest_bam_decoder_upload_done(dropest_bam_decoder *d, int which, const uint8_t *host, uint64_t len, const dropest_bgzf_blocks *blocks) {
+	if (!d || which < 0 || which > 1) return 1;
+	d->up_ready[which].store(false, std::memory_order_relaxed);
+	if (!len || !host || len + 8 > d->up_in[which].n) return 0;
+	if (hipSetDevice(d->device) != hipSuccess) return 1;
+	if (!d->up_begun[which] || hipEventRecord(d->up_done[which], d->up_stream) != hipSuccess) return 1;
+	d->up_begun[which] = false;
+	auto &b = d->up_blocks[which];
+	b.ok = false;
+	try {
+		if (blocks && blocks->n && blocks->in_off && blocks->in_len && blocks->out_len && blocks->crc32) {
+			// the caller's table (made while it read the file: `host` is then not touched at all unless a block is refused), checked for what the kernel relies on
+			const uint64_t n = blocks->n;
+			if (b.in_off.size() < n) { const uint64_t c2 = n + n / 2; b.in_off.resize(c2); b.out_off.resize(c2); b.in_len.resize(c2); b.out_len.resize(c2); b.crc.resize(c2); }
+			uint64_t total = 0, at = 0;
+			bool sound = true;
+			for (uint64_t k = 0; k < n && sound; ++k) {
+				sound = blocks->in_off[k] >= at + 18 && blocks->in_off[k] + blocks->in_len[k] + 8 <= len && blocks->out_len[k] <= 65536u;
+				b.in_off[k] = blocks->in_off[k]; b.in_len[k] = blocks->in_len[k]; b.out_off[k] = total; b.out_len[k] = blocks->out_len[k]; b.crc[k] = blocks->crc32[k];
+				total += blocks->out_len[k]; at = blocks->in_off[k] + blocks->in_len[k] + 8;
+			}
+			if (sound && at == len) { b.n = n; b.used = len; b.total = total; b.ok = true; }
+		}
+		if (!b.ok) b.ok = bgzf_block_table(host, len, b.in_off, b.out_off, b.in_len, b.out_len, b.crc, &b.n, &b.used, &b.total);
+	} catch (...) { b.ok = false; }
+	d->up_len[which] = len;
+	d->up_host[which].store(host, std::memory_order_relaxed);
+	d->up_ready[which].store(true, std::memory_order_release);
+	return 0;
 }
 
 // The first `len` bytes of staging buffer `which` start their way to the device now, on a stream of their own: the window call that is then given
@@ -358,8 +492,22 @@ extern "C" int dropest_bam_decoder_upload(dropest_bam_decoder *d, int which, uin
 	b.ok = false;
 	try { b.ok = bgzf_block_table(d->h_stage[which].p, len, b.in_off, b.out_off, b.in_len, b.out_len, b.crc, &b.n, &b.used, &b.total); } catch (...) { b.ok = false; }
 	d->up_len[which] = len;
+	d->up_host[which].store(d->h_stage[which].p, std::memory_order_relaxed);
 	d->up_ready[which].store(true, std::memory_order_release);
 	return 0;
+}
+
+// The decoder's kernels and small copies run on `stream` (a hipStream_t of the decoder's device) from now on -- the caller's own, which exists and
+// has run kernels, instead of one the decoder would have to create (~16 ms with its first dispatch).  NULL: back to a stream of the decoder's own
+// (made when first needed); call that before the lent stream goes away.  Not while a window is in flight.
+extern "C" int dropest_bam_decoder_use_stream(dropest_bam_decoder *d, void *stream) {
+	return bgzf_guarded([&] {
+		if (!d) throw InvalidError("null argument");
+		HIP_CHECK(hipSetDevice(d->device));
+		std::lock_guard<std::mutex> lk(d->ready_mutex);
+		if (d->stream) HIP_CHECK(hipStreamSynchronize(d->stream));
+		d->stream = stream ? hipStream_t(stream) : d->own_stream;      // (null: bam_ready makes the decoder's own)
+	});
 }
 
 extern "C" void dropest_bam_decoder_destroy(dropest_bam_decoder *d) {
@@ -367,7 +515,8 @@ extern "C" void dropest_bam_decoder_destroy(dropest_bam_decoder *d) {
 	(void)hipSetDevice(d->device);
 	(void)hipStreamSynchronize(d->up_stream);
 	for (hipEvent_t e : d->up_done) if (e) (void)hipEventDestroy(e);
-	if (d->stream) { (void)hipStreamSynchronize(d->stream); (void)hipStreamDestroy(d->stream); }
+	for (hipEvent_t e : d->piece_done) if (e) (void)hipEventDestroy(e);
+	if (d->own_stream) { (void)hipStreamSynchronize(d->own_stream); (void)hipStreamDestroy(d->own_stream); }
 	for (BamFront &f : d->front) if (f.stream) { (void)hipStreamSynchronize(f.stream); (void)hipStreamDestroy(f.stream); }
 	delete d;
 }
@@ -378,12 +527,14 @@ extern "C" int dropest_bam_decoder_set_annotation(dropest_bam_decoder *d, dropes
 		if (n_refs != uint32_t(d->cfg.n_refs)) throw InvalidError("one annotation chromosome per reference is expected");
 		if (dropest_annotation_device(a) != d->device) throw InvalidError("the annotation lives on another GPU");
 		HIP_CHECK(hipSetDevice(d->device));
+		bam_ready(d);
 		d->annotation = a;
 		d->n_ann_genes = dropest_annotation_genes(a);
 		d->d_ann_chr.alloc(std::max<uint32_t>(n_refs, 1u));
-		if (n_refs) HIP_CHECK(hipMemcpy(d->d_ann_chr.p, ann_chr_of_ref, size_t(n_refs) * 4, hipMemcpyHostToDevice));
+		if (n_refs) HIP_CHECK(hipMemcpyAsync(d->d_ann_chr.p, ann_chr_of_ref, size_t(n_refs) * 4, hipMemcpyHostToDevice, d->stream));
 		d->d_ann_id.alloc(std::max<uint32_t>(d->n_ann_genes, 1u));
-		HIP_CHECK(hipMemset(d->d_ann_id.p, 0xFF, size_t(std::max<uint32_t>(d->n_ann_genes, 1u)) * 4));   // no gene of the annotation is in the dictionary yet
+		HIP_CHECK(hipMemsetAsync(d->d_ann_id.p, 0xFF, size_t(std::max<uint32_t>(d->n_ann_genes, 1u)) * 4, d->stream));   // no gene of the annotation is in the dictionary yet
+		HIP_CHECK(hipStreamSynchronize(d->stream));
 	});
 }
 
@@ -392,8 +543,9 @@ extern "C" int dropest_bam_decoder_set_annotation_genes(dropest_bam_decoder *d, 
 		if (!d || !d->annotation || (n && !id_of_ann_gene)) throw InvalidError("no annotation was given to this decoder");
 		if (n != d->n_ann_genes) throw InvalidError("one entry per gene of the annotation is expected");
 		HIP_CHECK(hipSetDevice(d->device));
+		bam_ready(d);
 		HIP_CHECK(hipStreamSynchronize(d->stream));
-		if (n) HIP_CHECK(hipMemcpy(d->d_ann_id.p, id_of_ann_gene, size_t(n) * 4, hipMemcpyHostToDevice));
+		if (n) { HIP_CHECK(hipMemcpyAsync(d->d_ann_id.p, id_of_ann_gene, size_t(n) * 4, hipMemcpyHostToDevice, d->stream)); HIP_CHECK(hipStreamSynchronize(d->stream)); }
 	});
 }
 
@@ -404,12 +556,14 @@ extern "C" int dropest_bam_decoder_set_gene_names(dropest_bam_decoder *d, const 
 	return bgzf_guarded([&] {
 		if (!d || (n_names && (!off || !pool))) throw InvalidError("null argument");
 		HIP_CHECK(hipSetDevice(d->device));
+		bam_ready(d);
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		d->n_gene_names = 0;
 		if (!n_names) return;
 		d->g_name_off.ensure(size_t(n_names) + 1 + n_names / 4); d->g_name_pool.ensure(size_t(off[n_names]) + off[n_names] / 4 + 16);
-		HIP_CHECK(hipMemcpy(d->g_name_off.p, off, (size_t(n_names) + 1) * 4, hipMemcpyHostToDevice));
-		if (off[n_names]) HIP_CHECK(hipMemcpy(d->g_name_pool.p, pool, off[n_names], hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpyAsync(d->g_name_off.p, off, (size_t(n_names) + 1) * 4, hipMemcpyHostToDevice, d->stream));
+		if (off[n_names]) HIP_CHECK(hipMemcpyAsync(d->g_name_pool.p, pool, off[n_names], hipMemcpyHostToDevice, d->stream));
+		HIP_CHECK(hipStreamSynchronize(d->stream));
 		d->n_gene_names = n_names;
 	});
 }
@@ -420,6 +574,7 @@ extern "C" int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, cons
 		if (!d || (n_genes && (!gene_hash || !gene_id)) || (n_refs && !chr_of_ref)) throw InvalidError("null argument");
 		if (n_refs != uint32_t(d->cfg.n_refs)) throw InvalidError("the chromosome table does not have one entry per reference");
 		HIP_CHECK(hipSetDevice(d->device));
+		bam_ready(d);
 		uint32_t cap = 1024;
 		while (cap < n_genes * 2u + 16u) cap <<= 1;
 		std::vector<unsigned long long> keys(cap, 0);
@@ -431,9 +586,10 @@ extern "C" int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, cons
 		}
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		d->g_keys.ensure(cap); d->g_vals.ensure(cap);
-		HIP_CHECK(hipMemcpy(d->g_keys.p, keys.data(), size_t(cap) * 8, hipMemcpyHostToDevice));
-		HIP_CHECK(hipMemcpy(d->g_vals.p, vals.data(), size_t(cap) * 4, hipMemcpyHostToDevice));
-		if (n_refs) HIP_CHECK(hipMemcpy(d->d_chr.p, chr_of_ref, size_t(n_refs) * 4, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpyAsync(d->g_keys.p, keys.data(), size_t(cap) * 8, hipMemcpyHostToDevice, d->stream));
+		HIP_CHECK(hipMemcpyAsync(d->g_vals.p, vals.data(), size_t(cap) * 4, hipMemcpyHostToDevice, d->stream));
+		if (n_refs) HIP_CHECK(hipMemcpyAsync(d->d_chr.p, chr_of_ref, size_t(n_refs) * 4, hipMemcpyHostToDevice, d->stream));
+		HIP_CHECK(hipStreamSynchronize(d->stream));
 		d->g_mask = cap - 1;
 	});
 }
@@ -461,6 +617,7 @@ extern "C" int dropest_bam_decoder_window_inflate(dropest_bam_decoder *dec, cons
 		using clk = std::chrono::steady_clock;
 		auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
 		HIP_CHECK(hipSetDevice(dec->device));
+		bam_ready(dec);
 		// the first half of a window on a stream of its own, for a caller that runs it beside the second half of the window before; the two
 		// halves one after the other (dropest_bam_decoder_window) share the decoder's stream
 		// (Beside window k's chain / fields kernels the inflate of window k + 1 holds every wave slot of the device for 7-11 ms: whatever else is
@@ -472,7 +629,7 @@ extern "C" int dropest_bam_decoder_window_inflate(dropest_bam_decoder *dec, cons
 		int up = -1;      // the bytes went ahead (dropest_bam_decoder_upload)
 		for (int w = 0; w < 2; ++w)
 			// (the buffer first: only the slot these bytes stand in is looked at -- the reader thread may be filling the other one right now)
-			if (comp == dec->h_stage[w].p && dec->up_ready[w].load(std::memory_order_acquire) && len == dec->up_len[w]) { up = w; dec->up_ready[w].store(false, std::memory_order_relaxed); }
+			if (comp && comp == dec->up_host[w].load(std::memory_order_relaxed) && dec->up_ready[w].load(std::memory_order_acquire) && len == dec->up_len[w]) { up = w; dec->up_ready[w].store(false, std::memory_order_relaxed); }
 		uint64_t n = 0, used = 0, total = 0;
 		if (up >= 0 && dec->up_blocks[up].ok) {
 			auto &b = dec->up_blocks[up];
@@ -521,6 +678,7 @@ extern "C" int dropest_bam_decoder_window_chain(dropest_bam_decoder *dec, int sl
 		using clk = std::chrono::steady_clock;
 		auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
 		HIP_CHECK(hipSetDevice(dec->device));
+		bam_ready(dec);
 		// (the blocks were inflated on the front's stream, which may leave CUs alone -- see _inflate; everything from here on runs on the
 		// decoder's own stream, which may use them all: it must not queue behind the next window's inflate)
 		hipStream_t st_inflate = dec->halves_in_sequence ? dec->stream : d->stream;
@@ -540,7 +698,8 @@ extern "C" int dropest_bam_decoder_window_chain(dropest_bam_decoder *dec, int sl
 				if (!inflate_fallback) throw InvalidError("the device refused BGZF block " + std::to_string(k) + " of the window (status " + std::to_string(d->h_block_status.p[k]) + ") and no host inflate was given");
 				tmp.resize(d->out_len[k] + 1);
 				if (inflate_fallback(comp + d->in_off[k], d->in_len[k], tmp.data(), d->out_len[k], user)) throw InvalidError("damaged BGZF block (neither the device nor the host inflates it)");
-				HIP_CHECK(hipMemcpy(d->d_out.p + d->reserve + d->out_off[k], tmp.data(), d->out_len[k], hipMemcpyHostToDevice));
+				HIP_CHECK(hipMemcpyAsync(d->d_out.p + d->reserve + d->out_off[k], tmp.data(), d->out_len[k], hipMemcpyHostToDevice, st));
+				HIP_CHECK(hipStreamSynchronize(st));
 			}
 		}
 		d->ms_inflate = ms_since(t0);
@@ -636,6 +795,7 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 		using clk = std::chrono::steady_clock;
 		auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
 		HIP_CHECK(hipSetDevice(d->device));
+		bam_ready(d);
 		hipStream_t st = d->stream;
 		*out = dropest_bam_window{};
 		d->last_n_rec = 0; d->last_n_ok = 0; d->last_front = slot;
@@ -722,6 +882,7 @@ extern "C" int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const u
 		if (!d || (n && (!idx || !dst || !dst_off))) throw InvalidError("null argument");
 		if (!n) return;
 		HIP_CHECK(hipSetDevice(d->device));
+		bam_ready(d);
 		for (uint32_t k = 0; k < n; ++k) if (idx[k] >= d->last_n_rec) throw RangeError("record index outside the window");
 		d->d_gidx.ensure(n); d->d_goff.ensure(n); d->d_gsize.ensure(n); d->h_gsize.ensure(n);
 		HIP_CHECK(hipMemcpyAsync(d->d_gidx.p, idx, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
@@ -746,6 +907,7 @@ extern "C" int dropest_bam_decoder_columns_to_host(dropest_bam_decoder *d, uint6
 		const uint64_t n = d->last_n_ok;
 		if (!n) return;
 		HIP_CHECK(hipSetDevice(d->device));
+		bam_ready(d);
 		if (cb) HIP_CHECK(hipMemcpyAsync(cb, d->dn_cb.p, n * 8, hipMemcpyDeviceToHost, d->stream));
 		if (umi) HIP_CHECK(hipMemcpyAsync(umi, d->dn_umi.p, n * 8, hipMemcpyDeviceToHost, d->stream));
 		if (gene) HIP_CHECK(hipMemcpyAsync(gene, d->dn_gene.p, n * 4, hipMemcpyDeviceToHost, d->stream));
@@ -761,6 +923,7 @@ extern "C" int dropest_bam_decoder_quality_rows(dropest_bam_decoder *d, uint32_t
 		const uint64_t n = d->last_n_ok;
 		if (!n) return;
 		HIP_CHECK(hipSetDevice(d->device));
+		bam_ready(d);
 		d->dn_qual.ensure(n * ql + n * ql / 4); d->h_qual.ensure(n * ql);
 		hipLaunchKernelGGL(bam_quality_rows_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, d->stream, d->front[d->last_front].data(), d->dn_qoff.p, uint32_t(n), ql, d->dn_qual.p);
 		HIP_CHECK(hipGetLastError());
@@ -776,6 +939,7 @@ extern "C" int dropest_bam_decoder_patch(dropest_bam_decoder *d, const uint32_t 
 		if (!d || (n && (!pos || !cb || !umi || !gene || !aux))) throw InvalidError("null argument");
 		if (!n) return;
 		HIP_CHECK(hipSetDevice(d->device));
+		bam_ready(d);
 		for (uint32_t k = 0; k < n; ++k) if (pos[k] >= d->last_n_ok) throw RangeError("row outside the dense columns");
 		d->p_pos.ensure(n); d->p_cb.ensure(n); d->p_umi.ensure(n); d->p_gene.ensure(n); d->p_aux.ensure(n);
 		HIP_CHECK(hipMemcpyAsync(d->p_pos.p, pos, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));

@@ -926,7 +926,15 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			const auto t_enter = clk::now();
 			double ms_header = 0, ms_create = 0;
 			if (_tags.intronic_read_value.size() > 24 || _tags.intergenic_read_value.size() > 24) return false;
-			struct Map { const uint8_t *p = nullptr; size_t n = 0; int fd = -1; ~Map() { if (p) munmap(const_cast<uint8_t *>(p), n); if (fd >= 0) close(fd); } } map;
+			struct Map {
+				const uint8_t *p = nullptr; size_t n = 0; int fd = -1;
+				~Map() {
+					const auto t = std::chrono::steady_clock::now();
+					if (p) munmap(const_cast<uint8_t *>(p), n);
+					if (fd >= 0) close(fd);
+					if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] device path: file unmapped %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count());
+				}
+			} map;
 			map.fd = open(bam_name.c_str(), O_RDONLY);
 			if (map.fd < 0) return false;
 			struct stat sb;
@@ -935,6 +943,9 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			void *mp = mmap(nullptr, map.n, PROT_READ, MAP_PRIVATE, map.fd, 0);
 			if (mp == MAP_FAILED) return false;
 			map.p = static_cast<const uint8_t *>(mp);
+			// (the mapping is read at every block's header only, a cache line per ~20 KB: without this every fault maps its 16 neighbours too, and
+			// half a million page-table entries of a 683 MB file took 38 ms to unmap)
+			(void)madvise(mp, map.n, MADV_RANDOM);
 			// where the records begin: magic, l_text, text, n_ref, (l_name, name, l_ref) x n_ref -- blocks inflated here until that much is seen
 			size_t at = 0, c0 = 0; uint32_t u0 = 0;
 			{
@@ -989,10 +1000,13 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			}
 			if (dec && dropest_bam_decoder_reset(dec, &cfg)) { dropest_bam_decoder_destroy(dec); dec = nullptr; }
 			if (!dec && dropest_bam_decoder_create(container.device(), &cfg, &dec)) return false;       // (no GPU for this: the host reader does it)
+			// its kernels on the container's stream for this file: that one exists and has run kernels; one of the decoder's own is ~16 ms to make
+			if (container.handle() && dropest_bam_decoder_use_stream(dec, dropest_stream(container.handle()))) { dropest_bam_decoder_destroy(dec); return false; }
 			ms_create = since(t_enter) - ms_header;
 			struct Keep {    // back into the cache when the file went through, destroyed when it did not (whatever state an exception left)
 				dropest_bam_decoder *d; int device; bool ok = false;
 				~Keep() {
+					(void)dropest_bam_decoder_use_stream(d, nullptr);      // (the container's stream is the container's)
 					if (!ok) { dropest_bam_decoder_destroy(d); return; }
 					std::lock_guard<std::mutex> lk(decoder_cache_mutex());
 					auto &slot = decoder_cache()[device];
@@ -1038,6 +1052,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			// NOTES_r05 §11) -- the pinned staging buffers of larger windows cost more to allocate than their fuller kernels give back
 			const bool long_file = map.n > (size_t(1) << 30);
 			size_t window_max = size_t(getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? std::max(1, atoi(getenv("DROPEST_BAM_DEVICE_WINDOW_MB"))) : (long_file ? 80 : 48)) << 20;
+			size_t inflated_seen = 0, compressed_seen = 0;      // over the first 64 blocks behind the header: how far this file inflates
 			if (!getenv("DROPEST_BAM_DEVICE_WINDOW_MB")) {
 				// ... of blocks, not of bytes: a file that deflates 3 x (real bases and qualities) has blocks of ~20 KB where the 10 x synthetic ones have 6 KB,
 				// and a window of 48 MB of them would fill a third of the wave slots -- each window takes the time of ONE block however many it holds.
@@ -1047,36 +1062,150 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					const size_t xlen = le16(map.p + at + 10);
 					size_t bsize = 0;
 					for (size_t x = 0; x + 4 <= xlen && at + 12 + x + 6 <= map.n;) { const uint8_t *sf = map.p + at + 12 + x; const size_t sl = le16(sf + 2); if (sf[0] == 'B' && sf[1] == 'C' && sl == 2) bsize = size_t(le16(sf + 4)) + 1; x += 4 + sl; }
-					if (!bsize) break;
+					if (!bsize || at + bsize > map.n) break;
+					inflated_seen += le32(map.p + at + bsize - 4);
 					at += bsize; bytes_seen += bsize; ++n_seen;
 				}
+				compressed_seen = bytes_seen;
 				if (n_seen >= 8) {
 					const size_t want = std::max<size_t>(1024, dropest_bam_decoder_wave_slots(dec)) * (long_file ? 2 : 1) * (bytes_seen / n_seen + 1);
 					window_max = std::min(std::max(window_max, want), size_t(long_file ? 256 : 128) << 20);
 					window_max = std::min(window_max, std::max<size_t>(map.n - c0, size_t(1) << 20));      // (no more than the file)
 				}
 			}
-			// The compressed bytes reach the device through two pinned buffers of the decoder: a helper thread reads the next window from the file
-			// (pread: page cache -> pinned memory, whole blocks only) while the device and this thread work on the one before.
-			struct Staged { uint8_t *p = nullptr; size_t used = 0; bool final = false; std::string error; };
+			// The compressed bytes reach the device in pieces: a helper thread (and three more for a long window) reads the next window from the file into
+			// pinned pieces of 4 MB (pread: page cache -> pinned memory) and sends each on its way (dropest_bam_decoder_upload_piece) while the device
+			// and this thread work on the window before.  The window itself is the mapped file's bytes: the block table is made from them, the host
+			// fall-back for a refused block reads them.  (Rounds 4-6a read whole windows into two pinned buffers of the window's size: 2 x 128 MB were
+			// 35-65 ms to allocate, a fifth to a third of a 16 M read file's time -- DROPEST_BAM_WHOLE_WINDOW_STAGING=1 takes that road.)
+			struct Staged { const uint8_t *p = nullptr; size_t used = 0; bool final = false; std::string error; };
 			const size_t stage_cap = window_max + (size_t(1) << 17);
-			uint8_t *stage_p[2] = {nullptr, nullptr};
 			const bool upload_ahead = !getenv("DROPEST_BAM_NO_UPLOAD_AHEAD");
-			for (int k = 0; k < 2; ++k)      // (pinning 2 x 80 MB and reserving a window's device buffers: 35-50 ms; side by side on two threads they take as long)
-				if (dropest_bam_decoder_staging(dec, k, stage_cap, &stage_p[k])) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+			const bool in_pieces = upload_ahead && !getenv("DROPEST_BAM_WHOLE_WINDOW_STAGING");
+			uint8_t *stage_p[2] = {nullptr, nullptr};
+			constexpr size_t PIECE = size_t(4) << 20;
+			constexpr uint32_t READERS = 4, N_PIECES = 2 * READERS;      // (the copy out of the page cache runs at ~4-5 GB/s per thread; a piece being sent, one being filled, per reader)
+			uint8_t *piece_p[N_PIECES] = {};
+			if (in_pieces) {
+				for (int k = 0; k < 2; ++k)      // (first: the upload stream is made beside the pinned allocation, and a device allocation would wait for it)
+					if (dropest_bam_decoder_reserve(dec, k, stage_cap, compressed_seen ? uint64_t(double(stage_cap) * double(inflated_seen) / double(compressed_seen) * 1.25) : 0)) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+				if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] device path: the device buffers of two windows of %zu MB %.1f ms\n", stage_cap >> 20, since(t_file));
+				if (dropest_bam_decoder_pieces(dec, N_PIECES, PIECE, piece_p)) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
+				if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] device path: ... and %u pinned pieces of %zu MB %.1f ms\n", N_PIECES, PIECE >> 20, since(t_file));
+			} else
+				for (int k = 0; k < 2; ++k)      // (pinning 2 x 80 MB and reserving a window's device buffers: 35-50 ms; side by side on two threads they take as long)
+					if (dropest_bam_decoder_staging(dec, k, stage_cap, &stage_p[k])) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
 			const double ms_setup = since(t_file);
 			double ms_wait_read = 0, ms_window_calls = 0;
 			size_t file_at = c0;
 			const size_t block_cap = getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? size_t(-1) : std::max<size_t>(1024, dropest_bam_decoder_wave_slots(dec)) * (long_file ? 2 : 1);   // (one wave per block: a full machine's worth per window)
+			// whole blocks of p[0 .. got): up to `want` bytes of them (at least one), and no more than the device inflates at once
+			auto whole_blocks = [&](const uint8_t *p, size_t got, size_t want, Staged &st) -> size_t {
+				size_t o = 0, n_blocks = 0;
+				while (o + 18 <= got && (o < want || o == 0) && n_blocks < block_cap) {
+					const uint8_t *h = p + o;
+					if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { st.error = "Not a BGZF/BAM file"; return 0; }
+					const size_t xlen = le16(h + 10);
+					if (o + 12 + xlen > got) break;
+					size_t bsize = 0;
+					for (size_t x = 0; x + 4 <= xlen;) { const uint8_t *sf = h + 12 + x; const size_t sl = le16(sf + 2); if (sf[0] == 'B' && sf[1] == 'C' && sl == 2 && x + 6 <= xlen) bsize = size_t(le16(sf + 4)) + 1; x += 4 + sl; }
+					if (!bsize) { st.error = "BGZF block without BC subfield"; return 0; }
+					if (o + bsize > got) break;
+					o += bsize; ++n_blocks;
+				}
+				if (!o && got) st.error = "Truncated BGZF block";
+				return o;
+			};
+			// The same from the file itself, one pread per block (the eight bytes that end a block and the header of the next), with the block table the
+			// inflate kernel takes as a by-product -- the mapped file is then not touched at all (walking it there mapped half a million pages of a
+			// 683 MB file, 38 ms to unmap when the file was done)
+			struct Blocks {
+				std::vector<uint64_t> in_off; std::vector<uint32_t> in_len, out_len, crc;
+				void clear() { in_off.clear(); in_len.clear(); out_len.clear(); crc.clear(); }
+			} blocks_of[2];
+			auto whole_blocks_of_file = [&](size_t avail, size_t want, Blocks &B, Staged &st) -> size_t {
+				B.clear();
+				uint8_t hb[8 + 64];
+				std::vector<uint8_t> big;
+				auto get = [&](uint8_t *to, size_t off, size_t n) -> bool {
+					size_t g = 0;
+					while (g < n) { const ssize_t r = pread(map.fd, to + g, n - g, off_t(file_at + off + g)); if (r <= 0) return false; g += size_t(r); }
+					return true;
+				};
+				size_t o = 0, n_blocks = 0, h_len = std::min<size_t>(avail, 64);
+				if (!get(hb + 8, 0, h_len)) { st.error = "Can't read BAM file"; return 0; }
+				while (o + 18 <= avail && (o < want || o == 0) && n_blocks < block_cap) {
+					const uint8_t *h = hb + 8;
+					if (h_len < 18) break;
+					if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { st.error = "Not a BGZF/BAM file"; return 0; }
+					const size_t xlen = le16(h + 10);
+					if (o + 12 + xlen > avail) break;
+					if (12 + xlen > h_len) {      // (an extra field beyond the 52 bytes read ahead: never from htslib)
+						big.resize(12 + xlen);
+						if (!get(big.data(), o, 12 + xlen)) { st.error = "Can't read BAM file"; return 0; }
+						h = big.data();
+					}
+					size_t bsize = 0;
+					for (size_t x = 0; x + 4 <= xlen;) { const uint8_t *sf = h + 12 + x; const size_t sl = le16(sf + 2); if (sf[0] == 'B' && sf[1] == 'C' && sl == 2 && x + 6 <= xlen) bsize = size_t(le16(sf + 4)) + 1; x += 4 + sl; }
+					if (!bsize || bsize < 12 + xlen + 8) { st.error = "BGZF block without BC subfield"; return 0; }
+					if (o + bsize > avail) break;
+					const size_t t_off = o + bsize - 8, t_len = std::min<size_t>(avail - t_off, sizeof(hb));
+					if (!get(hb, t_off, t_len)) { st.error = "Can't read BAM file"; return 0; }
+					const uint32_t isize = le32(hb + 4);
+					if (isize > 65536u) { st.error = "BGZF block with ISIZE beyond 64 KB"; return 0; }
+					B.in_off.push_back(o + 12 + xlen); B.in_len.push_back(uint32_t(bsize - 12 - xlen - 8)); B.out_len.push_back(isize); B.crc.push_back(le32(hb));
+					o += bsize; ++n_blocks;
+					h_len = t_len - 8;
+				}
+				if (!o && avail) st.error = "Truncated BGZF block";
+				return o;
+			};
 			auto read_window = [&](int which, size_t want) {
-				Staged st; st.p = stage_p[which];
+				Staged st;
 				const size_t ask = std::min(std::min(want + (size_t(1) << 16) + 64, stage_cap), map.n - file_at);
+				if (in_pieces) {
+					// the window's bytes to the device piece by piece (helper threads: everything up to `want` needs no block boundary), its extent and
+					// block table from the file meanwhile (this thread), the last blocks' bytes beyond `want` at the end
+					st.p = map.p + file_at;
+					Blocks &B = blocks_of[which];
+					std::atomic<bool> failed{dropest_bam_decoder_upload_begin(dec, which) != 0};
+					const size_t covered = std::min(want, ask);
+					const size_t n_pieces = (covered + PIECE - 1) / PIECE;
+					const uint32_t n_readers = uint32_t(std::min<size_t>(READERS, n_pieces));
+					auto send = [&](uint32_t slot, size_t from, size_t len) {
+						if (dropest_bam_decoder_piece_wait(dec, slot)) { failed = true; return; }
+						size_t g = 0;
+						while (g < len) {
+							const ssize_t got = pread(map.fd, piece_p[slot] + g, len - g, off_t(file_at + from + g));
+							if (got <= 0) { failed = true; return; }
+							g += size_t(got);
+						}
+						if (dropest_bam_decoder_upload_piece(dec, which, slot, from, len)) failed = true;
+					};
+					auto reader = [&](uint32_t r) {
+						for (size_t k = r, turn = 0; k < n_pieces && !failed.load(std::memory_order_relaxed); k += n_readers, ++turn)
+							send(2u * r + uint32_t(turn & 1u), k * PIECE, std::min(PIECE, covered - k * PIECE));
+					};
+					std::vector<std::future<void>> helpers;
+					for (uint32_t r = 0; r < n_readers; ++r) helpers.push_back(std::async(std::launch::async, reader, r));
+					const size_t o = whole_blocks_of_file(ask, want, B, st);
+					for (auto &f : helpers) f.get();
+					if (!st.error.empty()) return st;
+					for (size_t from = covered; from < o && !failed.load(); from += PIECE) send(0, from, std::min(PIECE, o - from));      // (at most 64 KB)
+					st.used = o; file_at += o; st.final = file_at >= map.n;
+					// (a piece that could not be read or sent: nothing is declared, and the window call copies the mapped bytes itself)
+					const dropest_bgzf_blocks table{uint64_t(B.in_off.size()), B.in_off.data(), B.in_len.data(), B.out_len.data(), B.crc.data()};
+					if (!failed.load()) (void)dropest_bam_decoder_upload_done(dec, which, st.p, o, &table);
+					return st;
+				}
+				uint8_t *const buf = stage_p[which];
+				st.p = buf;
 				// (the copy out of the page cache runs at ~4-5 GB/s per thread: a long window is read in four pieces side by side, so that the reader
 				// stays ahead of the device -- which takes ~11 ms per 64 MB window)
 				auto read_piece = [&](size_t from, size_t len) -> long {
 					size_t g = 0;
 					while (g < len) {
-						const ssize_t r = pread(map.fd, st.p + from + g, len - g, off_t(file_at + from + g));
+						const ssize_t r = pread(map.fd, buf + from + g, len - g, off_t(file_at + from + g));
 						if (r < 0) return -1;
 						if (r == 0) break;
 						g += size_t(r);
@@ -1096,19 +1225,8 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					else if (whole) { got += size_t(g); whole = size_t(g) == std::min(piece, ask - (k + 1) * piece); }
 				}
 				if (failed) { st.error = "Can't read BAM file"; return st; }
-				size_t o = 0, n_blocks = 0;                      // whole blocks: up to `want` bytes of them (at least one), and no more than the device inflates at once
-				while (o + 18 <= got && (o < want || o == 0) && n_blocks < block_cap) {
-					const uint8_t *h = st.p + o;
-					if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { st.error = "Not a BGZF/BAM file"; return st; }
-					const size_t xlen = le16(h + 10);
-					if (o + 12 + xlen > got) break;
-					size_t bsize = 0;
-					for (size_t x = 0; x + 4 <= xlen;) { const uint8_t *sf = h + 12 + x; const size_t sl = le16(sf + 2); if (sf[0] == 'B' && sf[1] == 'C' && sl == 2 && x + 6 <= xlen) bsize = size_t(le16(sf + 4)) + 1; x += 4 + sl; }
-					if (!bsize) { st.error = "BGZF block without BC subfield"; return st; }
-					if (o + bsize > got) break;
-					o += bsize; ++n_blocks;
-				}
-				if (!o && got) { st.error = "Truncated BGZF block"; return st; }
+				const size_t o = whole_blocks(buf, got, want, st);
+				if (!st.error.empty()) return st;
 				st.used = o; file_at += o; st.final = file_at >= map.n;
 				if (upload_ahead) (void)dropest_bam_decoder_upload(dec, which, o);   // on its way while the window before it is in the kernels (if this fails, the window call copies)
 				return st;
@@ -1296,6 +1414,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				std::fprintf(stderr, "[bam] device path: file mapped and header read %.1f ms, decoder created %.1f ms, annotation + the rest before the windows %.1f ms\n", ms_header, ms_create, std::chrono::duration<double, std::milli>(t_file - t_enter).count() - ms_header - ms_create),
 				std::fprintf(stderr, "[bam] device path: pinned staging buffers %.1f ms, waiting for the file reader %.1f ms, inside the window calls %.1f ms\n", ms_setup, ms_wait_read, ms_window_calls);
 			keep_dec.ok = true;
+			if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] device path: %.1f ms from the file's name to its last window\n", since(t_enter));
 			return true;
 		};
 		static const bool env_device = getenv("DROPEST_BAM_DEVICE") != nullptr && atoi(getenv("DROPEST_BAM_DEVICE")) != 0;

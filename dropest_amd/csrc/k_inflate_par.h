@@ -36,6 +36,21 @@ constexpr uint32_t INFP_OVERLAP = INFP_OVERLAP_BITS;
 constexpr uint32_t INFP_SPAN_WORDS = INFP_CHUNK_BITS + 8;       // 64-bit words of input a span may look at: its 64 chunks, the word its first bit stands in, and a symbol's reach behind its last bit
 enum : uint32_t { INFP_NONE = 0, INFP_EOB = 1, INFP_BAD = 2 };
 
+// -DINFP_PROFILE (scripts/experiments/inflate_variants): where a block's time goes, summed over the launch in 10 ns ticks (wall_clock64) by lane 0 of
+// every wave -- 0 header + tables, 1 span input to LDS, 2 (A), 3 (B), 4 (C), 5 (D), 6 CRC-32; counts: 7 rounds of (A), 8 spans, 11 BGZF blocks, 12 matches; inside (D):
+// 9 window moved and filled, 10 the rounds, 13 the batch to memory, 14 rounds, 15 batches.  (-DINFP_PROFILE_LOOP instead of the (D) slots: 13 iterations of the symbol
+// loop per wave, 14 / 15 of them with a literal-length / distance code beyond the root table in some lane -- an atomic per iteration, the times mean nothing then.)  dropest_bgzf_inflate_profile() reads and clears them.
+#ifdef INFP_PROFILE
+__device__ unsigned long long infp_prof[16];
+#define INFP_TICK(t) const uint64_t t = wall_clock64()
+#define INFP_ACC(slot, t) do { if (lane == 0) atomicAdd(&infp_prof[slot], (unsigned long long)(wall_clock64() - (t))); } while (0)
+#define INFP_CNT(slot, v) do { if (lane == 0) atomicAdd(&infp_prof[slot], (unsigned long long)(v)); } while (0)
+#else
+#define INFP_TICK(t) do { } while (0)
+#define INFP_ACC(slot, t) do { } while (0)
+#define INFP_CNT(slot, v) do { } while (0)
+#endif
+
 struct InfpMatch { uint32_t dst; uint16_t len, dist; };   // dst: offset in the block's output
 static_assert(sizeof(InfpMatch) == 8, "match record");
 
@@ -52,6 +67,9 @@ __device__ inline uint64_t infp_peek(const uint64_t *span, uint32_t bit) {
 __device__ inline uint32_t infp_sym(uint64_t buf, const uint16_t *root, uint32_t root_mask, const uint16_t *sym, const uint16_t *count, uint32_t &used) {
 	const uint32_t e = root[uint32_t(buf) & root_mask];
 	if (e) { used = e & 15u; return e >> 4; }
+#ifdef INFP_PROFILE_LOOP
+	if (__lane_id() == uint32_t(__builtin_ctzll(__ballot(1)))) atomicAdd(&infp_prof[root_mask > 300u ? 14 : 15], 1ull);
+#endif
 	uint32_t code = 0, first = 0, index = 0;
 	for (uint32_t len = 1; len <= 15u; ++len) {
 		code |= uint32_t(buf & 1u); buf >>= 1;
@@ -62,6 +80,14 @@ __device__ inline uint32_t infp_sym(uint64_t buf, const uint16_t *root, uint32_t
 	used = 1;
 	return 0xFFFFu;
 }
+
+// Between two rounds of (D): this wave's stores before this wave's loads.  The vector memory operations of ONE wave are performed in order (a wavefront-scope
+// fence is a matter for the compiler only); -DINFP_ROUND_FENCE_WG: the workgroup-scope fence of the first version, which also waits for the stores' acknowledgements.
+#ifdef INFP_ROUND_FENCE_WG
+#define INFP_ROUND_FENCE() __threadfence_block()
+#else
+#define INFP_ROUND_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#endif
 
 // A lane's walk over [start, stop) of the block body (bit offsets relative to base_bits).  EMIT = false: counts only.  EMIT = true: literals
 // to out[obyte ...], matches to list[mslot ...] (their destinations are offsets in the block's output).  Returns the flag; rel = where it stands.
@@ -76,6 +102,9 @@ __device__ inline uint32_t infp_walk(const uint64_t *span, uint32_t span_bit0, u
 	for (uint32_t steps = 0; rel < stop; ++steps) {
 		if (steps > INFP_CHUNK_BITS + INFP_OVERLAP + 64u) { flag = INFP_BAD; break; }      // (every symbol takes a bit: never reached)
 		if (entry == 0xFFFFFFFFu && rel >= count_from) { entry = rel; nb = 0; nm = 0; }
+#ifdef INFP_PROFILE_LOOP
+		if (__lane_id() == uint32_t(__builtin_ctzll(__ballot(1)))) atomicAdd(&infp_prof[13], 1ull);
+#endif
 		if (avail < 48) { buf = infp_peek(span, span_bit0 + rel); avail = 64; }
 		uint32_t used;
 		const uint32_t sy = infp_sym(buf, L.lroot, (1u << INF_LROOT) - 1u, L.lsym, L.lcount, used);
@@ -109,6 +138,13 @@ __device__ inline uint32_t infp_walk(const uint64_t *span, uint32_t span_bit0, u
 	return flag;
 }
 
+// the low n (< 8) bytes of v to p (LDS, any alignment): four, two, one -- never a byte beyond, the next match's place belongs to another lane
+__device__ inline void infp_put_tail(uint8_t *p, uint64_t v, uint32_t n) {
+	if (n & 4u) { const uint32_t x = uint32_t(v); __builtin_memcpy(p, &x, 4); p += 4; v >>= 32; }
+	if (n & 2u) { const uint16_t x = uint16_t(v); __builtin_memcpy(p, &x, 2); p += 2; v >>= 16; }
+	if (n & 1u) *p = uint8_t(v);
+}
+
 __device__ inline uint32_t infp_excl_scan(uint32_t v, uint32_t lane, uint32_t &total) {
 	uint32_t x = v;
 #pragma unroll
@@ -132,14 +168,18 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 		// the span's input into LDS: the words from the one `base` stands in on (zeros beyond the buffer)
 		const uint64_t word0 = base >> 6;
 		const uint32_t bit0 = uint32_t(base & 63u);
+		INFP_TICK(t_in);
 		for (uint32_t i = lane; i < INFP_SPAN_WORDS; i += 64u) span[i] = word0 + i < in_words ? gin[word0 + i] : 0ull;
 		__threadfence_block();
+		INFP_ACC(1, t_in); INFP_CNT(8, 1);
+		INFP_TICK(t_a);
 		// (A) starts: the chunk's first bit (lane 0: the true position), then every lane takes its predecessor's exit until nothing moves
 		// (round 0: from INFP_OVERLAP bits before the chunk, counting from the first boundary inside it -- when that boundary is where the lane
 		// before leaves ITS chunk, which it mostly is, the lane needs no second walk)
 		uint32_t start = lane * INFP_CHUNK_BITS, end = 0, nb = 0, nm = 0, flag = INFP_NONE, dummy = 0, entry = 0;
 		bool alive = true, changed = true;
 		for (uint32_t round = 0; round < 66u; ++round) {
+			INFP_CNT(7, 1);
 			if (changed && alive) {
 				const uint32_t from = round == 0u && lane ? start - INFP_OVERLAP : start;
 				flag = infp_walk<false>(span, bit0, from, start, entry, (lane + 1u) * INFP_CHUNK_BITS, limit, L, len_tab, dist_tab, end, nb, nm, nullptr, 0u, nullptr, 0u, dummy);
@@ -156,58 +196,140 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 			if (!alive) { nb = 0; nm = 0; flag = INFP_NONE; }
 			if (!__ballot(changed)) break;
 		}
+		INFP_ACC(2, t_a);
 		if (dbg == 3) return 203u;
 		if (__ballot(changed)) return INF_BAD_CODE;                       // (cannot happen: lane k is settled after k + 1 rounds)
 		if (__ballot(alive && flag == INFP_BAD)) return INF_BAD_CODE;
 		// (B) places
 		uint32_t tot_b, tot_m;
+		INFP_TICK(t_b);
 		const uint32_t ob = infp_excl_scan(alive ? nb : 0u, lane, tot_b), om = infp_excl_scan(alive ? nm : 0u, lane, tot_m);
 		if (pos + tot_b > out_cap || pos + tot_b < pos) return INF_OUTPUT_OVERRUN;
 		if (tot_m > INFP_MATCH_CAP) return INF_BAD_CODE;
+		INFP_ACC(3, t_b); INFP_CNT(12, tot_m);
 		if (dbg == 4) return 204u;
 		// (C) literals and the match list
 		uint32_t bad_dist = 0;
+		INFP_TICK(t_c);
 		if (alive && dbg != 12) {      // (dbg 11 / 12: timing probes -- no match copies / no second walk either; the output is wrong then)
 			uint32_t e2, b2, m2;
 			(void)infp_walk<true>(span, bit0, start, start, dummy, (lane + 1u) * INFP_CHUNK_BITS, limit, L, len_tab, dist_tab, e2, b2, m2, out, pos + ob, list, om, bad_dist);
 		}
 		if (__ballot(bad_dist != 0u)) return INF_BAD_DISTANCE;
+		INFP_ACC(4, t_c);
 		if (dbg == 5) return 205u;
+		INFP_TICK(t_d);
 		// (D) the matches: 64 at a time, a lane per match.  Everything before the destination of the first match that is still waiting is final
 		// (literals are written, earlier matches are copied), so every waiting match whose source ends there or earlier can be copied NOW, side by
-		// side -- a BAM's matches reach a record back (~270 bytes, eight matches or so), which is eight matches per round instead of one.  A run
-		// (distance below length) reads only the bytes in front of its own destination, again and again: a lane's own loop.
+		// side -- a BAM's matches reach a record back (~270 bytes, eight matches or so), which is eight matches per round instead of one.
+		// The rounds of a block are as many as its chains of matches are deep (a record copies from the record before: ~240 rounds per block), and
+		// a round through memory lasts as long as a load that follows a store (0.7-2 us: 600 us of a block's 2 ms with the device empty, 1 450 of
+		// 3 100 with it full).  So the rounds run in LDS: the span's input is done with after (C), and its 4 KB hold a WINDOW of the output --
+		// bytes [wb, wb + WIN) of the block, the batch's destinations and what lies before them.  A batch loads the part of its range the window
+		// does not hold yet (literals of (C); the matches' own places hold anything), the rounds read and write the window (sources in front of it,
+		// final long ago, come from memory), and the batch's range goes to memory in whole words at the end.  Long matches: fewer than 64 to a batch.
 		__threadfence_block();
-		for (uint32_t b0 = 0; b0 < (dbg == 11 || dbg == 12 ? 0u : tot_m); b0 += 64u) {
-			const bool have = b0 + lane < tot_m;
-			InfpMatch mine{0u, 0, 0};
-			if (have) mine = list[b0 + lane];
+		uint8_t *const ring = reinterpret_cast<uint8_t *>(span);
+		constexpr uint32_t WIN = INFP_CHUNK_BITS * 8u, KEEP = WIN / 4u;      // bytes of window; history a slide keeps at least
+		static_assert(WIN >= 1024u && WIN <= INFP_SPAN_WORDS * 8u, "a match of 258 bytes and its word edges fit the window many times");
+		uint32_t wb = 0, ring_hi = 0;
+		bool ring_on = false;
+		InfpMatch cur{0u, 0, 0};
+		if (lane < tot_m) cur = list[lane];
+		uint32_t n_rounds = 0, n_batches = 0;
+		for (uint32_t b0 = 0, n_take = 0; b0 < (dbg == 11 || dbg == 12 ? 0u : tot_m); b0 += n_take) {
+			bool have = b0 + lane < tot_m;
+			const InfpMatch mine = cur;
+			InfpMatch nxt{0u, 0, 0};                  // the 64 matches after these: on their way while the rounds run
+			if (b0 + 64u + lane < tot_m) nxt = list[b0 + 64u + lane];
 			const uint32_t len = mine.len, dist = mine.dist;
 			const uint32_t src_end = mine.dst - dist + (len < dist ? len : dist);      // the bytes of earlier output the match reads end here
+			// the batch: the matches of these 64 whose destinations end inside one window's length from the first one's (long matches: fewer than 64)
+			const uint32_t lo = uint32_t(__shfl(int(mine.dst), 0, 64)), lo8 = lo & ~7u;
+			have = have && mine.dst + len - lo8 <= WIN - 8u;
+			n_take = uint32_t(__builtin_popcountll(__ballot(have)));       // (destinations ascend: a prefix; at least the first)
+			if (!n_take) return INF_BAD_CODE;
+			const uint32_t hi = uint32_t(__shfl(int(mine.dst + len), int(n_take - 1u), 64)), hi8 = (hi + 7u) & ~7u;
+			++n_batches;
+			INFP_TICK(t_d1);
+			if (!ring_on) { wb = lo8; ring_hi = lo8; ring_on = true; }
+			if (hi8 - wb > WIN) {      // the window moves up: its last bytes (KEEP of them at least, more if there is room) slide to its start
+				uint32_t nwb = lo8 > KEEP ? lo8 - KEEP : 0u;
+				if (nwb < hi8 - WIN) nwb = hi8 - WIN;
+				if (nwb < wb) nwb = wb;
+				if (ring_hi > nwb) {
+					const uint32_t shift = (nwb - wb) >> 3, n_words = (ring_hi - nwb) >> 3;
+					for (uint32_t i = lane; i < ((n_words + 63u) & ~63u); i += 64u) {      // (a pass reads ahead of what it writes, and all of it before it writes)
+						uint64_t v = 0;
+						if (i < n_words) v = span[i + shift];
+						INFP_ROUND_FENCE();
+						if (i < n_words) span[i] = v;
+					}
+				} else ring_hi = nwb;
+				wb = nwb;
+			}
+			for (uint32_t p = ring_hi + lane * 8u; p < hi8; p += 512u) {      // (the block's own bytes only: the last word byte by byte)
+				uint64_t v = 0;
+				if (p + 8u <= out_cap) __builtin_memcpy(&v, out + p, 8);
+				else for (uint32_t k = 0; p + k < out_cap; ++k) v |= uint64_t(out[p + k]) << (8u * k);
+				span[(p - wb) >> 3] = v;
+			}
+			ring_hi = hi8;
+			INFP_ROUND_FENCE();
+			INFP_ACC(9, t_d1);
+			INFP_TICK(t_d2);
 			bool waiting = have;
 			for (unsigned long long w = __ballot(waiting); w; w = __ballot(waiting)) {
+				++n_rounds;
 				const int first = __builtin_ctzll(w);
 				const uint32_t final_to = uint32_t(__shfl(int(mine.dst), first, 64));
 				if (waiting && (int(lane) == first || src_end <= final_to)) {
-					uint8_t *const d = out + mine.dst;
-					const uint8_t *const s = d - dist;
-					if (dist >= len) {
-						uint32_t i = 0;
-						for (; i + 32u <= len; i += 32u) {      // (the loads first: four independent requests in flight)
-							uint64_t a, b, c, e;
-							__builtin_memcpy(&a, s + i, 8); __builtin_memcpy(&b, s + i + 8, 8); __builtin_memcpy(&c, s + i + 16, 8); __builtin_memcpy(&e, s + i + 24, 8);
-							__builtin_memcpy(d + i, &a, 8); __builtin_memcpy(d + i + 8, &b, 8); __builtin_memcpy(d + i + 16, &c, 8); __builtin_memcpy(d + i + 24, &e, 8);
+					const uint32_t q0 = mine.dst - dist;
+					uint8_t *const d = ring + (mine.dst - wb);
+					if (q0 >= wb) {                           // in the window: words (a read of eight bytes may reach beyond the source, never beyond the window)
+						const uint8_t *const s = ring + (q0 - wb);
+						if (dist >= 8u) {
+							uint32_t i = 0;
+							for (; i + 8u <= len; i += 8u) { uint64_t a; __builtin_memcpy(&a, s + i, 8); __builtin_memcpy(d + i, &a, 8); }      // (never reaches what this match has not written yet)
+							if (i < len) { uint64_t a; __builtin_memcpy(&a, s + i, 8); infp_put_tail(d + i, a, len - i); }
+						} else {                                  // a run: its period filled up to a word, laid down at every multiple of the period that a word holds
+							uint64_t a; __builtin_memcpy(&a, s, 8);
+							a &= (1ull << (8u * dist)) - 1ull;
+							a |= a << (8u * dist);
+							if (dist < 4u) a |= a << (16u * dist);
+							if (dist < 2u) a |= a << 32;
+							const uint32_t stride = (8u / dist) * dist;
+							uint32_t i = 0;
+							for (; i + 8u <= len; i += stride) __builtin_memcpy(d + i, &a, 8);
+							if (i < len) infp_put_tail(d + i, a, len - i);
 						}
+					} else if (src_end <= wb && dist >= len) {   // in front of the window: from memory
+						const uint8_t *const s = out + q0;
+						uint32_t i = 0;
 						for (; i + 8u <= len; i += 8u) { uint64_t a; __builtin_memcpy(&a, s + i, 8); __builtin_memcpy(d + i, &a, 8); }
 						for (; i < len; ++i) d[i] = s[i];
-					} else {
-						for (uint32_t i = 0; i < len; ++i) d[i] = s[i % dist];
+					} else {                                  // across the window's start
+						for (uint32_t i = 0, j = 0; i < len; ++i) { const uint32_t q = q0 + j; d[i] = q >= wb ? ring[q - wb] : out[q]; if (++j == dist) j = 0; }
 					}
 					waiting = false;
 				}
-				__threadfence_block();
+				INFP_ROUND_FENCE();
 			}
+			INFP_ACC(10, t_d2);
+			INFP_TICK(t_d3);
+			// the batch's range to memory, whole words (what lies behind `hi` in the last word is what memory held: literals, or the place of a
+			// match of the next batch, which writes it again); never beyond the block's own bytes
+			for (uint32_t p = lo8 + lane * 8u; p < hi8; p += 512u) {
+				const uint64_t v = span[(p - wb) >> 3];
+				if (p + 8u <= out_cap) __builtin_memcpy(out + p, &v, 8);
+				else for (uint32_t k = 0; p + k < out_cap; ++k) out[p + k] = uint8_t(v >> (8u * k));
+			}
+			INFP_ROUND_FENCE();
+			INFP_ACC(13, t_d3);
+			if (n_take == 64u) cur = nxt;
+			else { cur = InfpMatch{0u, 0, 0}; if (b0 + n_take + lane < tot_m) cur = list[b0 + n_take + lane]; }
 		}
+		INFP_ACC(5, t_d); INFP_CNT(14, n_rounds); INFP_CNT(15, n_batches); (void)n_rounds; (void)n_batches;
 		if (dbg == 6) return 206u;
 		pos += tot_b;
 		// where the span ends: behind the end-of-block symbol, or at the last lane's exit
@@ -264,7 +386,9 @@ __global__ __launch_bounds__(INFP_WAVES * 64) __attribute__((amdgpu_waves_per_eu
 		const uint32_t out_cap = out_len[blk];
 		uint32_t pos = 0, err = INF_OK;
 		uint32_t n_deflate_blocks = 0;
+		INFP_CNT(11, 1);
 		for (bool last = false; !last && !err;) {
+			INFP_TICK(t_h);
 			if (s.ipos - uint64_t(s.cnt >> 3) > in_end + 8) { err = INF_INPUT_OVERRUN; break; }
 			if (++n_deflate_blocks > 70000u) { err = INF_BAD_BLOCK_TYPE; break; }
 			last = inf_take(s, L, lane, 1) != 0;
@@ -319,6 +443,7 @@ __global__ __launch_bounds__(INFP_WAVES * 64) __attribute__((amdgpu_waves_per_eu
 			if (!inf_build(L.lens, hlit, INF_LROOT, L.lroot, L.lsym, L.lcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
 			if (!inf_build(L.lens + hlit, hdist, INF_DROOT, L.droot, L.dsym, L.dcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
 			__threadfence_block();                        // the tables, before the lanes read them at their own places
+			INFP_ACC(0, t_h);
 			if (dbg == 2) { err = 202u; break; }
 			// the body of the block, by all lanes; then the header reader takes up again behind the end-of-block symbol
 			uint64_t body = (s.ipos << 3) - uint64_t(s.cnt);
@@ -334,7 +459,9 @@ __global__ __launch_bounds__(INFP_WAVES * 64) __attribute__((amdgpu_waves_per_eu
 		if (dbg == 7 && !err) err = 207u;
 		if (!err && crc32) {
 			__threadfence_block();
+			INFP_TICK(t_crc);
 			if (inf_crc32_block(out, out_cap, crc_tab, crc_x2n[wave], lane) != crc32[blk]) err = INF_CRC_MISMATCH;
+			INFP_ACC(6, t_crc);
 		}
 		if (lane == 0) status[blk] = err;
 	}

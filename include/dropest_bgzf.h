@@ -88,6 +88,25 @@ int dropest_bam_decoder_staging(dropest_bam_decoder *d, int which, uint64_t byte
  * window k + 1 runs under the kernels of window k.  The one decoder call that may run beside a window call; allocates nothing; a length the
  * buffers were not sized for is left to the window call (0 is returned all the same). */
 int dropest_bam_decoder_upload(dropest_bam_decoder *d, int which, uint64_t len);
+/* The same road in pieces, so that the pinned memory (0.15-0.4 ms per MB to allocate: 35-65 ms for two windows of 128 MB) does not grow with the
+ * window: .._reserve sizes the device side of up-buffer / front `which` for windows of `bytes` compressed bytes; .._pieces makes n pinned pieces
+ * of `bytes` each (out[k] = piece k); a reader fills a piece (.._piece_wait(piece) first: the copy that read it last is through), sends its
+ * first `len` bytes to byte `dst_off` of up-buffer `which` (.._upload_piece: asynchronous, callable from several threads on different pieces),
+ * and when a window's pieces are all on their way says what the buffer holds: .._upload_done(which, host, len, blocks) -- `host` are the same bytes in
+ * host memory of any kind (the mapped file), from which the block table is made and which the window call is then given
+ * (dropest_bam_decoder_window(d, host, len, ...)); they stay readable until that call has returned. */
+int dropest_bam_decoder_reserve(dropest_bam_decoder *d, int which, uint64_t bytes, uint64_t inflated_bytes /* what such a window inflates to, if the caller knows (0: 14 x bytes) */);
+int dropest_bam_decoder_pieces(dropest_bam_decoder *d, uint32_t n, uint64_t bytes, uint8_t **out);
+int dropest_bam_decoder_piece_wait(dropest_bam_decoder *d, uint32_t piece);
+int dropest_bam_decoder_upload_begin(dropest_bam_decoder *d, int which);   /* before a window's first piece: picks the stream its pieces travel on */
+int dropest_bam_decoder_upload_piece(dropest_bam_decoder *d, int which, uint32_t piece, uint64_t dst_off, uint64_t len);
+/* blocks != NULL: the window's block table as the caller found it while reading the file (block k: payload at in_off[k], in_len[k] bytes long, ISIZE
+ * out_len[k], CRC-32 crc32[k]); `host` is then read only if the device refuses a block. */
+typedef struct { uint64_t n; const uint64_t *in_off; const uint32_t *in_len, *out_len, *crc32; } dropest_bgzf_blocks;
+int dropest_bam_decoder_upload_done(dropest_bam_decoder *d, int which, const uint8_t *host, uint64_t len, const dropest_bgzf_blocks *blocks);
+/* The decoder's kernels run on `stream` (a hipStream_t of its device that the caller lends: one that exists and has run kernels saves the ~16 ms
+ * a new stream and its first dispatch cost) until NULL gives it back -- before that stream is destroyed.  Not while a window is in flight. */
+int dropest_bam_decoder_use_stream(dropest_bam_decoder *d, void *stream);
 void dropest_bam_decoder_destroy(dropest_bam_decoder *d);
 /* comp[0 .. len): whole BGZF blocks, following the previous window's.  first_skip: bytes of the first block to pass over (the BAM header;
  * first window only).  final != 0: the file ends here (a cut-off record is then an error). */

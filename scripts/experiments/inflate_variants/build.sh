@@ -6,7 +6,7 @@
 set -e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 D=scripts/experiments/inflate_variants
-for v in "par_c256:-DINFP_CHUNK=256" "par_c1024:-DINFP_CHUNK=1024" "par_w3:-DINFP_WAVES_PER_EU=3" "w4:-DINF_WAVES_PER_EU=4" "w5:-DINF_WAVES_PER_EU=5" "w6:-DINF_WAVES_PER_EU=6" "w8:-DINF_WAVES_PER_EU=8" "w8_nofence:-DINF_WAVES_PER_EU=8 -DINF_NO_FENCE"; do
+for v in "par_prof:-DINFP_PROFILE" "par_c256:-DINFP_CHUNK=256" "par_c1024:-DINFP_CHUNK=1024" "par_w3:-DINFP_WAVES_PER_EU=3" "w4:-DINF_WAVES_PER_EU=4" "w5:-DINF_WAVES_PER_EU=5" "w6:-DINF_WAVES_PER_EU=6" "w8:-DINF_WAVES_PER_EU=8" "w8_nofence:-DINF_WAVES_PER_EU=8 -DINF_NO_FENCE"; do
   name=${v%%:*}; flags=${v#*:}
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -pthread -shared $flags dropest_amd/csrc/bgzf_api.hip dropest_amd/csrc/annotation_api.hip -o $D/libbgzf_$name.so
   echo "built $D/libbgzf_$name.so ($flags)"
