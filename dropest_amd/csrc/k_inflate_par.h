@@ -54,31 +54,57 @@ __device__ unsigned long long infp_prof[16];
 struct InfpMatch { uint32_t dst; uint16_t len, dist; };   // dst: offset in the block's output
 static_assert(sizeof(InfpMatch) == 8, "match record");
 
-// 64 bits of the span's input from bit `bit` of the staged words on (a lane's refill: two LDS words -- from memory it was a dependent global load
-// every three symbols, ~1 000 of them in a row per block: the whole of a block's 0.7 ms)
-__device__ inline uint64_t infp_peek(const uint64_t *span, uint32_t bit) {
-	const uint32_t w = bit >> 6, sh = bit & 63u;
-	const uint64_t lo = span[w];
-	if (!sh) return lo;
-	return (lo >> sh) | (span[w + 1] << (64u - sh));
+// Codes longer than the root table's index.  A canonical code read most-significant-bit first and padded to 15 bits lies below
+// limit[l] = (first code of length l + number of codes of length l) << (15 - l) exactly when it is at most l bits long, and limit[] does not
+// fall as l grows: the length is the smallest l with r < limit[l], the symbol sym[base[l] + (r >> (15 - l))] with base[l] = (codes shorter
+// than l) - (first code of length l).  One entry per length, limit in the low half and base in the high half; made from count[] (inf_build) by
+// the first 16 lanes.  (k_inflate.h walks the lengths bit by bit from 1, a load per step: with 64 lanes on different symbols some lane was on
+// that path in a third of the iterations -- measured -- and every lane waited for its 11 to 15 steps.)
+struct InfpLong { uint32_t lit[16], dst[16]; };
+
+__device__ inline void infp_long_table(const uint16_t *count, uint32_t *lc, uint32_t lane) {
+	if (lane < 16u) {
+		uint32_t first = 0, shorter = 0;
+		for (uint32_t l = 1; l <= lane; ++l) { const uint32_t below = l > 1u ? uint32_t(count[l - 1u]) : 0u; first = (first + below) << 1; shorter += below; }
+		const uint32_t limit = lane ? (first + uint32_t(count[lane])) << (15u - lane) : 0u;      // (<= 0x8000: the code is not over-subscribed)
+		lc[lane] = limit | ((shorter - first) & 0xFFFFu) << 16;
+	}
 }
 
-// one symbol of a canonical code out of the low bits of buf: root table, else bit by bit (k_inflate.h: inf_decode, per lane here)
-__device__ inline uint32_t infp_sym(uint64_t buf, const uint16_t *root, uint32_t root_mask, const uint16_t *sym, const uint16_t *count, uint32_t &used) {
-	const uint32_t e = root[uint32_t(buf) & root_mask];
+// one symbol of a canonical code out of the low bits of buf: the root table, else the lengths beyond it (above)
+__device__ inline uint32_t infp_sym(uint64_t buf, const uint16_t *root, uint32_t root_bits, const uint32_t *lc, const uint16_t *sym, uint32_t &used) {
+	const uint32_t e = root[uint32_t(buf) & ((1u << root_bits) - 1u)];
 	if (e) { used = e & 15u; return e >> 4; }
 #ifdef INFP_PROFILE_LOOP
-	if (__lane_id() == uint32_t(__builtin_ctzll(__ballot(1)))) atomicAdd(&infp_prof[root_mask > 300u ? 14 : 15], 1ull);
+	if (__lane_id() == uint32_t(__builtin_ctzll(__ballot(1)))) atomicAdd(&infp_prof[root_bits > 8u ? 14 : 15], 1ull);
 #endif
-	uint32_t code = 0, first = 0, index = 0;
-	for (uint32_t len = 1; len <= 15u; ++len) {
-		code |= uint32_t(buf & 1u); buf >>= 1;
-		const uint32_t c = count[len];
-		if (code < first + c) { used = len; return sym[index + (code - first)]; }
-		index += c; first += c; first <<= 1; code <<= 1;
-	}
-	used = 1;
-	return 0xFFFFu;
+	const uint32_t r = __brev(uint32_t(buf)) >> 17;
+	uint32_t len = 16u, ent = 0;
+	for (uint32_t l = 15u; l > root_bits; --l) { const uint32_t c = lc[l]; if (r < (c & 0xFFFFu)) { len = l; ent = c; } }      // (independent loads; the smallest such l stays)
+	if (len > 15u) { used = 1; return 0xFFFFu; }
+	used = len;
+	return sym[((ent >> 16) + (r >> (15u - len))) & 0xFFFFu];
+}
+
+// DEFLATE's length and distance codes without their tables: base and extra bits by arithmetic (a table lookup is an LDS round trip on the path
+// every lane of the wave waits for)
+__device__ inline uint32_t infp_len_base(uint32_t k, uint32_t &extra) {      // k = symbol - 257, 0 .. 28
+	if (k < 8u) { extra = 0; return 3u + k; }
+	if (k == 28u) { extra = 0; return 258u; }
+	extra = (k >> 2) - 1u;
+	return 3u + ((4u + (k & 3u)) << extra);
+}
+__device__ inline uint32_t infp_dist_base(uint32_t d, uint32_t &extra) {     // d = 0 .. 29
+	if (d < 4u) { extra = 0; return 1u + d; }
+	extra = (d >> 1) - 1u;
+	return 1u + ((2u + (d & 1u)) << extra);
+}
+
+// the low n (< 8) bytes of v to global memory at p, any alignment
+__device__ inline void infp_put_tail_global(uint8_t *p, uint64_t v, uint32_t n) {
+	if (n & 4u) { const uint32_t x = uint32_t(v); __builtin_memcpy(p, &x, 4); p += 4; v >>= 32; }
+	if (n & 2u) { const uint16_t x = uint16_t(v); __builtin_memcpy(p, &x, 2); p += 2; v >>= 16; }
+	if (n & 1u) *p = uint8_t(v);
 }
 
 // Between two rounds of (D): this wave's stores before this wave's loads.  The vector memory operations of ONE wave are performed in order (a wavefront-scope
@@ -90,14 +116,18 @@ __device__ inline uint32_t infp_sym(uint64_t buf, const uint16_t *root, uint32_t
 #endif
 
 // A lane's walk over [start, stop) of the block body (bit offsets relative to base_bits).  EMIT = false: counts only.  EMIT = true: literals
-// to out[obyte ...], matches to list[mslot ...] (their destinations are offsets in the block's output).  Returns the flag; rel = where it stands.
+// to out[obyte ...] (gathered eight to a store), matches to list[mslot ...] (their destinations are offsets in the block's output).  Returns the
+// flag; rel = where it stands.  The input: three words of the span in registers, the next one loaded when the position crosses a word -- long
+// before it is looked at -- so that a symbol costs one LDS round trip (its root entry), a match two.
 template <bool EMIT>
 __device__ inline uint32_t infp_walk(const uint64_t *span, uint32_t span_bit0, uint32_t start, uint32_t count_from, uint32_t &entry, uint32_t stop, uint32_t limit,
-                                     const InfWaveLds &L, const uint32_t *len_tab, const uint32_t *dist_tab, uint32_t &rel_out, uint32_t &n_bytes, uint32_t &n_match,
+                                     const InfWaveLds &L, const InfpLong &X, uint32_t &rel_out, uint32_t &n_bytes, uint32_t &n_match,
                                      uint8_t *__restrict__ out, uint32_t obyte, InfpMatch *__restrict__ list, uint32_t mslot, uint32_t &bad_dist) {
 	uint32_t rel = start, nb = 0, nm = 0, flag = INFP_NONE;
-	uint64_t buf = 0;
-	int avail = 0;
+	uint32_t W = (span_bit0 + rel) >> 6;
+	uint64_t w0 = span[W], w1 = span[W + 1u], w2 = span[W + 2u];
+	uint64_t acc = 0;      // EMIT: the literals not yet stored, the oldest in the low byte
+	uint32_t na = 0;
 	entry = 0xFFFFFFFFu;      // the first symbol boundary at or behind count_from: what is counted starts there
 	for (uint32_t steps = 0; rel < stop; ++steps) {
 		if (steps > INFP_CHUNK_BITS + INFP_OVERLAP + 64u) { flag = INFP_BAD; break; }      // (every symbol takes a bit: never reached)
@@ -105,28 +135,32 @@ __device__ inline uint32_t infp_walk(const uint64_t *span, uint32_t span_bit0, u
 #ifdef INFP_PROFILE_LOOP
 		if (__lane_id() == uint32_t(__builtin_ctzll(__ballot(1)))) atomicAdd(&infp_prof[13], 1ull);
 #endif
-		if (avail < 48) { buf = infp_peek(span, span_bit0 + rel); avail = 64; }
+		const uint32_t p = span_bit0 + rel;
+		if ((p >> 6) != W) { w0 = w1; w1 = w2; ++W; w2 = span[W + 2u]; }      // (a symbol is at most 48 bits: one word at a time)
+		const uint32_t sh = p & 63u;
+		uint64_t buf = sh ? (w0 >> sh) | (w1 << (64u - sh)) : w0;
 		uint32_t used;
-		const uint32_t sy = infp_sym(buf, L.lroot, (1u << INF_LROOT) - 1u, L.lsym, L.lcount, used);
-		buf >>= used; avail -= int(used); rel += used;
+		const uint32_t sy = infp_sym(buf, L.lroot, INF_LROOT, X.lit, L.lsym, used);
+		buf >>= used; rel += used;
 		if (sy < 256u) {
-			if (EMIT) out[obyte + nb] = uint8_t(sy);
+			if (EMIT) {
+				acc |= uint64_t(sy) << (8u * na);
+				if (++na == 8u) { __builtin_memcpy(out + obyte + nb - 7u, &acc, 8); acc = 0; na = 0; }
+			}
 			++nb;
 		} else if (sy == 256u) { flag = INFP_EOB; break; }
 		else if (sy > 285u) { flag = INFP_BAD; break; }
 		else {
-			const uint32_t lt = len_tab[sy - 257u];
-			uint32_t len = lt & 0xFFFFu;
-			const uint32_t le = lt >> 16;
-			if (le) { len += uint32_t(buf) & ((1u << le) - 1u); buf >>= le; avail -= int(le); rel += le; }
-			const uint32_t ds = infp_sym(buf, L.droot, (1u << INF_DROOT) - 1u, L.dsym, L.dcount, used);
-			buf >>= used; avail -= int(used); rel += used;
+			uint32_t le, de;
+			uint32_t len = infp_len_base(sy - 257u, le);
+			len += uint32_t(buf) & ((1u << le) - 1u); buf >>= le; rel += le;
+			const uint32_t ds = infp_sym(buf, L.droot, INF_DROOT, X.dst, L.dsym, used);
+			buf >>= used; rel += used;
 			if (ds > 29u) { flag = INFP_BAD; break; }
-			const uint32_t dt = dist_tab[ds];
-			uint32_t dist = dt & 0xFFFFu;
-			const uint32_t de = dt >> 16;
-			if (de) { dist += uint32_t(buf) & ((1u << de) - 1u); buf >>= de; avail -= int(de); rel += de; }
+			uint32_t dist = infp_dist_base(ds, de);
+			dist += uint32_t(buf) & ((1u << de) - 1u); rel += de;
 			if (EMIT) {
+				if (na) { infp_put_tail_global(out + obyte + nb - na, acc, na); acc = 0; na = 0; }
 				if (dist > obyte + nb) bad_dist = 1u;
 				list[mslot + nm] = InfpMatch{obyte + nb, uint16_t(len), uint16_t(dist)};
 			}
@@ -134,6 +168,7 @@ __device__ inline uint32_t infp_walk(const uint64_t *span, uint32_t span_bit0, u
 		}
 		if (rel > limit) { flag = INFP_BAD; break; }
 	}
+	if (EMIT && na) infp_put_tail_global(out + obyte + nb - na, acc, na);
 	rel_out = rel; n_bytes = nb; n_match = nm;
 	return flag;
 }
@@ -156,7 +191,7 @@ __device__ inline uint32_t infp_excl_scan(uint32_t v, uint32_t lane, uint32_t &t
 // The body of one Huffman-coded DEFLATE block from absolute bit position `body` on: output appended at out + pos.  Returns the error (INF_OK ...),
 // body = the bit behind the end-of-block symbol, pos advanced.  All 64 lanes; the tables of the block are in L.
 __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uint64_t in_words, uint64_t &body, uint64_t in_end_bits, const InfWaveLds &L,
-                                           const uint32_t *len_tab, const uint32_t *dist_tab, uint8_t *__restrict__ out, uint32_t out_cap, uint32_t &pos,
+                                           const InfpLong &X, uint8_t *__restrict__ out, uint32_t out_cap, uint32_t &pos,
                                            InfpMatch *__restrict__ list, uint64_t *span, uint32_t lane, uint32_t dbg = 0) {
 	for (uint32_t spans = 0;; ++spans) {
 		if (spans > 4096u) return INF_BAD_CODE;                           // (64 KB of output are at most a few hundred spans)
@@ -182,7 +217,7 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 			INFP_CNT(7, 1);
 			if (changed && alive) {
 				const uint32_t from = round == 0u && lane ? start - INFP_OVERLAP : start;
-				flag = infp_walk<false>(span, bit0, from, start, entry, (lane + 1u) * INFP_CHUNK_BITS, limit, L, len_tab, dist_tab, end, nb, nm, nullptr, 0u, nullptr, 0u, dummy);
+				flag = infp_walk<false>(span, bit0, from, start, entry, (lane + 1u) * INFP_CHUNK_BITS, limit, L, X, end, nb, nm, nullptr, 0u, nullptr, 0u, dummy);
 				if (round == 0u && lane) start = entry;      // (0xFFFFFFFF: the guess ran out before the chunk began -- the lane before will say where to start)
 			}
 			const uint32_t p_end = uint32_t(__shfl_up(int(end), 1, 64)), p_flag = uint32_t(__shfl_up(int(flag), 1, 64));
@@ -213,7 +248,7 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 		INFP_TICK(t_c);
 		if (alive && dbg != 12) {      // (dbg 11 / 12: timing probes -- no match copies / no second walk either; the output is wrong then)
 			uint32_t e2, b2, m2;
-			(void)infp_walk<true>(span, bit0, start, start, dummy, (lane + 1u) * INFP_CHUNK_BITS, limit, L, len_tab, dist_tab, e2, b2, m2, out, pos + ob, list, om, bad_dist);
+			(void)infp_walk<true>(span, bit0, start, start, dummy, (lane + 1u) * INFP_CHUNK_BITS, limit, L, X, e2, b2, m2, out, pos + ob, list, om, bad_dist);
 		}
 		if (__ballot(bad_dist != 0u)) return INF_BAD_DISTANCE;
 		INFP_ACC(4, t_c);
@@ -355,7 +390,7 @@ __global__ __launch_bounds__(INFP_WAVES * 64) __attribute__((amdgpu_waves_per_eu
 	__shared__ InfWaveLds lds[INFP_WAVES];
 	__shared__ uint32_t crc_tab[4 * 256];
 	__shared__ uint32_t crc_x2n[INFP_WAVES][32];
-	__shared__ uint32_t len_tab[32], dist_tab[32];
+	__shared__ InfpLong longs[INFP_WAVES];
 	__shared__ uint64_t span_in[INFP_WAVES][INFP_SPAN_WORDS];
 	if (crc32) {
 		uint32_t c = threadIdx.x & 255u;
@@ -364,8 +399,6 @@ __global__ __launch_bounds__(INFP_WAVES * 64) __attribute__((amdgpu_waves_per_eu
 		__syncthreads();
 		for (int t = 1; t < 4; ++t) { c = (c >> 8) ^ crc_tab[c & 0xFFu]; crc_tab[t * 256 + (threadIdx.x & 255u)] = c; __syncthreads(); }
 	}
-	if (threadIdx.x < 32) len_tab[threadIdx.x] = uint32_t(INF_LEN_BASE[threadIdx.x]) | uint32_t(INF_LEN_EXTRA[threadIdx.x]) << 16;
-	else if (threadIdx.x < 64) dist_tab[threadIdx.x - 32] = uint32_t(INF_DIST_BASE[threadIdx.x - 32]) | uint32_t(INF_DIST_EXTRA[threadIdx.x - 32]) << 16;
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	InfWaveLds &L = lds[wave];
@@ -442,12 +475,15 @@ __global__ __launch_bounds__(INFP_WAVES * 64) __attribute__((amdgpu_waves_per_eu
 			}
 			if (!inf_build(L.lens, hlit, INF_LROOT, L.lroot, L.lsym, L.lcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
 			if (!inf_build(L.lens + hlit, hdist, INF_DROOT, L.droot, L.dsym, L.dcount, lane)) { err = INF_OVERSUBSCRIBED; break; }
+			__threadfence_block();
+			infp_long_table(L.lcount, longs[wave].lit, lane);
+			infp_long_table(L.dcount, longs[wave].dst, lane);
 			__threadfence_block();                        // the tables, before the lanes read them at their own places
 			INFP_ACC(0, t_h);
 			if (dbg == 2) { err = 202u; break; }
 			// the body of the block, by all lanes; then the header reader takes up again behind the end-of-block symbol
 			uint64_t body = (s.ipos << 3) - uint64_t(s.cnt);
-			err = infp_block_body(gin, in_words, body, in_end << 3, L, len_tab, dist_tab, out, out_cap, pos, list, span_in[wave], lane, dbg);
+			err = infp_block_body(gin, in_words, body, in_end << 3, L, longs[wave], out, out_cap, pos, list, span_in[wave], lane, dbg);
 			if (err) break;
 			s.ipos = body >> 3; s.bits = 0; s.cnt = 0; s.loaded_hi = s.ipos & ~uint64_t(255);
 			if (body & 7u) (void)inf_take(s, L, lane, int(body & 7u));
