@@ -43,10 +43,14 @@ enum : uint32_t { INFP_NONE = 0, INFP_EOB = 1, INFP_BAD = 2 };
 #ifdef INFP_PROFILE
 __device__ unsigned long long infp_prof[16];
 #define INFP_TICK(t) const uint64_t t = wall_clock64()
+#define INFP_SUM(acc, t) acc += wall_clock64() - (t)
+#define INFP_DECL(acc) uint64_t acc = 0
 #define INFP_ACC(slot, t) do { if (lane == 0) atomicAdd(&infp_prof[slot], (unsigned long long)(wall_clock64() - (t))); } while (0)
 #define INFP_CNT(slot, v) do { if (lane == 0) atomicAdd(&infp_prof[slot], (unsigned long long)(v)); } while (0)
 #else
 #define INFP_TICK(t) do { } while (0)
+#define INFP_SUM(acc, t) do { } while (0)
+#define INFP_DECL(acc) do { } while (0)
 #define INFP_ACC(slot, t) do { } while (0)
 #define INFP_CNT(slot, v) do { } while (0)
 #endif
@@ -122,7 +126,7 @@ __device__ inline void infp_put_tail_global(uint8_t *p, uint64_t v, uint32_t n) 
 template <bool EMIT>
 __device__ inline uint32_t infp_walk(const uint64_t *span, uint32_t span_bit0, uint32_t start, uint32_t count_from, uint32_t &entry, uint32_t stop, uint32_t limit,
                                      const InfWaveLds &L, const InfpLong &X, uint32_t &rel_out, uint32_t &n_bytes, uint32_t &n_match,
-                                     uint8_t *__restrict__ out, uint32_t obyte, InfpMatch *__restrict__ list, uint32_t mslot, uint32_t &bad_dist) {
+                                     uint8_t *__restrict__ out, uint32_t obyte, InfpMatch *__restrict__ list, uint32_t mslot, uint32_t &bad_dist, uint32_t own_bytes = 0) {
 	uint32_t rel = start, nb = 0, nm = 0, flag = INFP_NONE;
 	uint32_t W = (span_bit0 + rel) >> 6;
 	uint64_t w0 = span[W], w1 = span[W + 1u], w2 = span[W + 2u];
@@ -160,7 +164,13 @@ __device__ inline uint32_t infp_walk(const uint64_t *span, uint32_t span_bit0, u
 			uint32_t dist = infp_dist_base(ds, de);
 			dist += uint32_t(buf) & ((1u << de) - 1u); rel += de;
 			if (EMIT) {
-				if (na) { infp_put_tail_global(out + obyte + nb - na, acc, na); acc = 0; na = 0; }
+				// the literals in front of the match: a whole word when the eight bytes all lie in this lane's own part of the output (what it writes
+				// beyond the literals is the match's place, filled in (D), and bytes this lane writes itself later), else exactly
+				if (na) {
+					if (nb - na + 8u <= own_bytes) __builtin_memcpy(out + obyte + nb - na, &acc, 8);
+					else infp_put_tail_global(out + obyte + nb - na, acc, na);
+					acc = 0; na = 0;
+				}
 				if (dist > obyte + nb) bad_dist = 1u;
 				list[mslot + nm] = InfpMatch{obyte + nb, uint16_t(len), uint16_t(dist)};
 			}
@@ -248,7 +258,7 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 		INFP_TICK(t_c);
 		if (alive && dbg != 12) {      // (dbg 11 / 12: timing probes -- no match copies / no second walk either; the output is wrong then)
 			uint32_t e2, b2, m2;
-			(void)infp_walk<true>(span, bit0, start, start, dummy, (lane + 1u) * INFP_CHUNK_BITS, limit, L, X, e2, b2, m2, out, pos + ob, list, om, bad_dist);
+			(void)infp_walk<true>(span, bit0, start, start, dummy, (lane + 1u) * INFP_CHUNK_BITS, limit, L, X, e2, b2, m2, out, pos + ob, list, om, bad_dist, nb);
 		}
 		if (__ballot(bad_dist != 0u)) return INF_BAD_DISTANCE;
 		INFP_ACC(4, t_c);
@@ -269,9 +279,11 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 		static_assert(WIN >= 1024u && WIN <= INFP_SPAN_WORDS * 8u, "a match of 258 bytes and its word edges fit the window many times");
 		uint32_t wb = 0, ring_hi = 0;
 		bool ring_on = false;
+
 		InfpMatch cur{0u, 0, 0};
 		if (lane < tot_m) cur = list[lane];
 		uint32_t n_rounds = 0, n_batches = 0;
+		INFP_DECL(ticks_window); INFP_DECL(ticks_rounds); INFP_DECL(ticks_flush);
 		for (uint32_t b0 = 0, n_take = 0; b0 < (dbg == 11 || dbg == 12 ? 0u : tot_m); b0 += n_take) {
 			bool have = b0 + lane < tot_m;
 			const InfpMatch mine = cur;
@@ -303,6 +315,8 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 				} else ring_hi = nwb;
 				wb = nwb;
 			}
+			// (asking for the next kilobyte of these words a batch ahead, to land when the next batch begins, changed nothing: 111.9 -> 111.5 GB/s --
+			// the kernel waits for its vector ALUs, 74 % busy, not for these loads)
 			for (uint32_t p = ring_hi + lane * 8u; p < hi8; p += 512u) {      // (the block's own bytes only: the last word byte by byte)
 				uint64_t v = 0;
 				if (p + 8u <= out_cap) __builtin_memcpy(&v, out + p, 8);
@@ -311,33 +325,46 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 			}
 			ring_hi = hi8;
 			INFP_ROUND_FENCE();
-			INFP_ACC(9, t_d1);
+			INFP_SUM(ticks_window, t_d1);
 			INFP_TICK(t_d2);
+			// which matches of the batch must be copied before this one: those whose destination holds a byte of this one's source [q0, src_end).
+			// Destinations ascend and do not overlap, so they are the lanes a .. b - 1 with a = destinations that end at or before q0, b = destinations
+			// that begin before src_end (all of them lanes below this one): two binary searches over the lanes.  (Until round 6e a match waited for
+			// EVERY match before it that was still waiting -- the first one's destination was the frontier -- and a run behind a literal, whose source
+			// is that literal, took a round of its own: 5.8 rounds per batch instead of the 2-3 that the records' chains are deep.)
+			const uint32_t q0 = mine.dst - dist;
+			unsigned long long before = 0;
+			{
+				const uint32_t my_dst = have ? mine.dst : 0xFFFFFFFFu, my_end = have ? mine.dst + len : 0xFFFFFFFFu;
+				uint32_t a = 0, b = 0;
+#pragma unroll
+				for (uint32_t step = 32u; step; step >>= 1) {
+					const uint32_t ea = uint32_t(__shfl(int(my_end), int(a + step - 1u), 64)), db = uint32_t(__shfl(int(my_dst), int(b + step - 1u), 64));
+					if (ea <= q0) a += step;
+					if (db < src_end) b += step;
+				}
+				if (b > a) before = ((1ull << (b - a)) - 1ull) << a;
+			}
 			bool waiting = have;
 			for (unsigned long long w = __ballot(waiting); w; w = __ballot(waiting)) {
 				++n_rounds;
-				const int first = __builtin_ctzll(w);
-				const uint32_t final_to = uint32_t(__shfl(int(mine.dst), first, 64));
-				if (waiting && (int(lane) == first || src_end <= final_to)) {
-					const uint32_t q0 = mine.dst - dist;
+				if (waiting && !(w & before)) {
 					uint8_t *const d = ring + (mine.dst - wb);
 					if (q0 >= wb) {                           // in the window: words (a read of eight bytes may reach beyond the source, never beyond the window)
 						const uint8_t *const s = ring + (q0 - wb);
+						uint64_t a; __builtin_memcpy(&a, s, 8);
+						uint32_t i = 0;
 						if (dist >= 8u) {
-							uint32_t i = 0;
-							for (; i + 8u <= len; i += 8u) { uint64_t a; __builtin_memcpy(&a, s + i, 8); __builtin_memcpy(d + i, &a, 8); }      // (never reaches what this match has not written yet)
-							if (i < len) { uint64_t a; __builtin_memcpy(&a, s + i, 8); infp_put_tail(d + i, a, len - i); }
+							for (; i + 8u <= len; i += 8u) { __builtin_memcpy(d + i, &a, 8); __builtin_memcpy(&a, s + i + 8u, 8); }      // (never reaches what this match has not written yet)
 						} else {                                  // a run: its period filled up to a word, laid down at every multiple of the period that a word holds
-							uint64_t a; __builtin_memcpy(&a, s, 8);
 							a &= (1ull << (8u * dist)) - 1ull;
 							a |= a << (8u * dist);
 							if (dist < 4u) a |= a << (16u * dist);
 							if (dist < 2u) a |= a << 32;
-							const uint32_t stride = (8u / dist) * dist;
-							uint32_t i = 0;
+							const uint32_t stride = (0x7658688u >> (4u * (dist - 1u))) & 15u;      // (8 / dist) * dist for dist = 1 .. 7
 							for (; i + 8u <= len; i += stride) __builtin_memcpy(d + i, &a, 8);
-							if (i < len) infp_put_tail(d + i, a, len - i);
 						}
+						if (i < len) infp_put_tail(d + i, a, len - i);
 					} else if (src_end <= wb && dist >= len) {   // in front of the window: from memory
 						const uint8_t *const s = out + q0;
 						uint32_t i = 0;
@@ -350,7 +377,7 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 				}
 				INFP_ROUND_FENCE();
 			}
-			INFP_ACC(10, t_d2);
+			INFP_SUM(ticks_rounds, t_d2);
 			INFP_TICK(t_d3);
 			// the batch's range to memory, whole words (what lies behind `hi` in the last word is what memory held: literals, or the place of a
 			// match of the next batch, which writes it again); never beyond the block's own bytes
@@ -360,11 +387,12 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 				else for (uint32_t k = 0; p + k < out_cap; ++k) out[p + k] = uint8_t(v >> (8u * k));
 			}
 			INFP_ROUND_FENCE();
-			INFP_ACC(13, t_d3);
+			INFP_SUM(ticks_flush, t_d3);
 			if (n_take == 64u) cur = nxt;
 			else { cur = InfpMatch{0u, 0, 0}; if (b0 + n_take + lane < tot_m) cur = list[b0 + n_take + lane]; }
 		}
 		INFP_ACC(5, t_d); INFP_CNT(14, n_rounds); INFP_CNT(15, n_batches); (void)n_rounds; (void)n_batches;
+		INFP_CNT(9, ticks_window); INFP_CNT(10, ticks_rounds); INFP_CNT(13, ticks_flush);
 		if (dbg == 6) return 206u;
 		pos += tot_b;
 		// where the span ends: behind the end-of-block symbol, or at the last lane's exit
