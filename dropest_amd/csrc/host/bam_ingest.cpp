@@ -1084,8 +1084,9 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			const bool in_pieces = upload_ahead && !getenv("DROPEST_BAM_WHOLE_WINDOW_STAGING");
 			uint8_t *stage_p[2] = {nullptr, nullptr};
 			constexpr size_t PIECE = size_t(4) << 20;
-			constexpr uint32_t READERS = 4, N_PIECES = 2 * READERS;      // (the copy out of the page cache runs at ~4-5 GB/s per thread; a piece being sent, one being filled, per reader)
-			uint8_t *piece_p[N_PIECES] = {};
+			// (the copy out of the page cache runs at ~4-5 GB/s per thread; a piece being sent, one being filled, per reader)
+			const uint32_t READERS = uint32_t(std::min(8, std::max(1, getenv("DROPEST_BAM_READERS") ? atoi(getenv("DROPEST_BAM_READERS")) : 4))), N_PIECES = 2 * READERS;
+			uint8_t *piece_p[16] = {};
 			if (in_pieces) {
 				for (int k = 0; k < 2; ++k)      // (first: the upload stream is made beside the pinned allocation, and a device allocation would wait for it)
 					if (dropest_bam_decoder_reserve(dec, k, stage_cap, compressed_seen ? uint64_t(double(stage_cap) * double(inflated_seen) / double(compressed_seen) * 1.25) : 0)) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
