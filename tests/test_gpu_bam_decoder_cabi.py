@@ -190,5 +190,69 @@ def test_one_window_through_the_c_abi(tmp_path):
         assert (w3.n_records, w3.n_accepted, w3.n_need, list(w3.counts)) == (w.n_records, w.n_accepted, w.n_need, list(w.counts))
         assert columns(L, dec, int(w3.n_accepted))[0].tolist() == cbc.tolist()
         assert L.dropest_bam_decoder_window_finish(dec, slot.value, C.byref(w3)) != 0 and b"not begun" in L.dropest_bgzf_last_error()
+    # the compressed bytes in pinned PIECES (what BamController's readers do: the pinned memory does not grow with the window): pieces of 4 KB so that
+    # this small file takes several, sent in a scrambled order from two slots; the block table the caller's, the decoder's own, and a wrong one
+    # (refused: the decoder makes its own from the host bytes); a window whose pieces were never declared is copied by the window call itself
+    class Blocks(C.Structure):
+        _fields_ = [("n", C.c_uint64), ("in_off", C.c_void_p), ("in_len", C.c_void_p), ("out_len", C.c_void_p), ("crc32", C.c_void_p)]
+    L.dropest_bam_decoder_reserve.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64]
+    L.dropest_bam_decoder_pieces.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, P(C.c_void_p)]
+    L.dropest_bam_decoder_piece_wait.argtypes = [C.c_void_p, C.c_uint32]
+    L.dropest_bam_decoder_upload_begin.argtypes = [C.c_void_p, C.c_int]
+    L.dropest_bam_decoder_upload_piece.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64]
+    L.dropest_bam_decoder_upload_done.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, P(Blocks)]
+    PIECE = 4096
+    ptrs = (C.c_void_p * 3)()
+    assert L.dropest_bam_decoder_reserve(dec, 0, len(comp) + 4096, 0) == 0 and L.dropest_bam_decoder_reserve(dec, 0, len(comp) + 4096, 40 * len(comp)) == 0
+    assert L.dropest_bam_decoder_pieces(dec, 3, PIECE, ptrs) == 0, L.dropest_bgzf_last_error()
+    assert L.dropest_bam_decoder_upload_piece(dec, 0, 0, 0, 16) != 0                       # no .._upload_begin yet
+    # the table: header (12 + XLEN bytes), payload, CRC-32, ISIZE per block
+    in_off, in_len, out_len, crcs, at = [], [], [], [], 0
+    raw = comp.tobytes()
+    while at < len(raw):
+        xlen = int.from_bytes(raw[at + 10:at + 12], "little"); bsize = int.from_bytes(raw[at + 16:at + 18], "little") + 1
+        in_off.append(at + 12 + xlen); in_len.append(bsize - 12 - xlen - 8)
+        crcs.append(int.from_bytes(raw[at + bsize - 8:at + bsize - 4], "little")); out_len.append(int.from_bytes(raw[at + bsize - 4:at + bsize], "little"))
+        at += bsize
+    a_off, a_len, a_out, a_crc = np.array(in_off, np.uint64), np.array(in_len, np.uint32), np.array(out_len, np.uint32), np.array(crcs, np.uint32)
+    for table in ("callers", "none", "wrong", "undeclared"):
+        assert L.dropest_bam_decoder_reset(dec, C.byref(cfg)) == 0
+        assert L.dropest_bam_decoder_upload_begin(dec, 0) == 0
+        order = list(range(0, len(comp), PIECE))
+        order = order[1::2] + order[0::2]
+        for k, from_ in enumerate(order):
+            slot = k % 3
+            assert L.dropest_bam_decoder_piece_wait(dec, slot) == 0
+            n = min(PIECE, len(comp) - from_)
+            C.memmove(ptrs[slot], comp.ctypes.data + from_, n)
+            assert L.dropest_bam_decoder_upload_piece(dec, 0, slot, from_, n) == 0
+        assert L.dropest_bam_decoder_upload_piece(dec, 0, 0, 1 << 40, PIECE) != 0 and L.dropest_bam_decoder_upload_piece(dec, 0, 7, 0, 16) != 0      # beyond what .._reserve made room for; no such piece
+        if table == "callers":
+            b = Blocks(len(a_off), a_off.ctypes.data, a_len.ctypes.data, a_out.ctypes.data, a_crc.ctypes.data)
+            assert L.dropest_bam_decoder_upload_done(dec, 0, comp.ctypes.data, len(comp), C.byref(b)) == 0
+        elif table == "wrong":
+            bad = a_len.copy(); bad[0] += 3
+            b = Blocks(len(a_off), a_off.ctypes.data, bad.ctypes.data, a_out.ctypes.data, a_crc.ctypes.data)
+            assert L.dropest_bam_decoder_upload_done(dec, 0, comp.ctypes.data, len(comp), C.byref(b)) == 0
+        elif table == "none":
+            assert L.dropest_bam_decoder_upload_done(dec, 0, comp.ctypes.data, len(comp), None) == 0
+        w4 = Window()
+        assert L.dropest_bam_decoder_window(dec, comp.ctypes.data, len(comp), u0, 1, None, None, C.byref(w4)) == 0, L.dropest_bgzf_last_error()
+        assert (w4.n_records, w4.n_accepted, w4.n_need, list(w4.counts), w4.refused_blocks) == (w.n_records, w.n_accepted, w.n_need, list(w.counts), 0), table
+        assert columns(L, dec, int(w4.n_accepted))[0].tolist() == cbc.tolist(), table
+    # the kernels on a stream the caller lends (torch's current one), and back on the decoder's own
+    hip = C.CDLL("libamdhip64.so")
+    L.dropest_bam_decoder_use_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lent = C.c_void_p()
+    assert hip.hipStreamCreateWithFlags(C.byref(lent), 1) == 0            # (hipStreamNonBlocking)
+    for stream in (lent, None, lent):
+        assert L.dropest_bam_decoder_use_stream(dec, stream) == 0, L.dropest_bgzf_last_error()
+        assert L.dropest_bam_decoder_reset(dec, C.byref(cfg)) == 0
+        w5 = window()
+        assert (w5.n_records, w5.n_accepted, w5.n_need, list(w5.counts)) == (w.n_records, w.n_accepted, w.n_need, list(w.counts))
+        assert columns(L, dec, int(w5.n_accepted))[0].tolist() == cbc.tolist()
+    assert L.dropest_bam_decoder_use_stream(dec, None) == 0
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    assert hip.hipStreamDestroy(lent) == 0
     L.dropest_bam_decoder_destroy.argtypes = [C.c_void_p]
     L.dropest_bam_decoder_destroy(dec)
