@@ -187,9 +187,9 @@ struct BamFront {
 	DevBuf<uint64_t> d_in_off, d_out_off, seg_start, seg_exit;
 	DevBuf<uint32_t> d_in_len, d_out_len, d_status, d_crc, seg_count, seg_base, d_bad, d_list;
 	PinnedBuf<uint64_t> h_seg_start, h_seg_exit;
-	PinnedBuf<uint32_t> h_count, h_block_status;
+	PinnedBuf<uint32_t> h_count, h_block_status, h_base;
 	std::vector<uint64_t> in_off, out_off;
-	std::vector<uint32_t> in_len, out_len, crc, base;
+	std::vector<uint32_t> in_len, out_len, crc;
 	uint64_t data_len = 0, tail_start = 0, n_rec = 0;
 	uint32_t n_segs = 0, n_blocks = 0, refused = 0, repaired = 0;
 	double ms_copy = 0, ms_inflate = 0, ms_boundaries = 0;
@@ -225,7 +225,7 @@ struct dropest_bam_decoder {
 	DevBuf<uint8_t> o_status, o_need;
 	DevBuf<BamWindowCounts> d_wc;
 	PinnedBuf<uint8_t> h_stage[2];
-	PinnedBuf<uint32_t> h_need_rec, h_need_pos, h_need_size, h_gsize;
+	PinnedBuf<uint32_t> h_need_rec, h_need_pos, h_need_size, h_gsize, h_result;      // h_result: a window's counters, totals and flag (13 words)
 	uint32_t g_mask = 0;
 	DevBuf<uint32_t> g_name_off;      // the dictionary's gene names by index (dropest_bam_decoder_set_gene_names), 0 names: hashes alone
 	DevBuf<uint8_t> g_name_pool;
@@ -364,11 +364,15 @@ static void bam_reserve(dropest_bam_decoder *d, int which, uint64_t bytes, uint6
 	d->up_in[which].ensure(bytes + 8);
 	F.d_in_off.ensure(n_blk); F.d_out_off.ensure(n_blk); F.d_in_len.ensure(n_blk); F.d_out_len.ensure(n_blk); F.d_status.ensure(n_blk); F.d_crc.ensure(n_blk); F.h_block_status.ensure(n_blk);
 	F.seg_start.ensure(n_seg); F.seg_exit.ensure(n_seg); F.seg_count.ensure(n_seg); F.seg_base.ensure(n_seg);
-	F.h_seg_start.ensure(n_seg); F.h_seg_exit.ensure(n_seg); F.h_count.ensure(n_seg);
+	F.h_seg_start.ensure(n_seg); F.h_seg_exit.ensure(n_seg); F.h_count.ensure(n_seg); F.h_base.ensure(n_seg);
 	if (which == 0) {
 		d->rec_off.ensure(n_rec); d->o_cb.ensure(n_rec); d->o_umi.ensure(n_rec); d->o_gene.ensure(n_rec); d->o_aux.ensure(n_rec); d->o_uql.ensure(n_rec);
 		d->o_status.ensure(n_rec); d->o_need.ensure(n_rec); d->dn_cb.ensure(n_rec); d->dn_umi.ensure(n_rec); d->dn_gene.ensure(n_rec); d->dn_aux.ensure(n_rec);
 		d->nd_rec.ensure(n_rec); d->nd_pos.ensure(n_rec); d->nd_size.ensure(n_rec);
+		d->o_qoff.ensure(n_rec); d->dn_qoff.ensure(n_rec);
+		const uint64_t tiles = n_rec / BAM_FIN_TILE + 2;
+		d->tile_ok.ensure(tiles); d->tile_need.ensure(tiles); d->d_totals.ensure(2); d->d_wc.ensure(1);
+		if (d->annotation) { d->a_chr.ensure(n_rec); d->a_pos.ensure(n_rec); d->a_end.ensure(n_rec); d->a_gene.ensure(n_rec); d->a_mark.ensure(n_rec); }
 	}
 }
 
@@ -737,7 +741,7 @@ extern "C" int dropest_bam_decoder_window_chain(dropest_bam_decoder *dec, int sl
 			hipLaunchKernelGGL(bam_chain_to_host_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, d->seg_start.p, d->seg_exit.p, d->seg_count.p, n_segs, d->h_seg_start.p, d->h_seg_exit.p, d->h_count.p);
 			HIP_CHECK(hipGetLastError());
 			HIP_CHECK(hipStreamSynchronize(st));
-			d->base.resize(n_segs);
+			d->h_base.ensure(n_segs + n_segs / 4);
 			for (uint32_t k = 0; k < n_segs; ++k) {
 				const uint64_t seg_end = uint64_t(k + 1) * BAM_SEG;
 				const uint64_t want = expect < seg_end ? expect : BAM_NONE;      // no record starts in this segment: the chain is already past it
@@ -752,7 +756,7 @@ extern "C" int dropest_bam_decoder_window_chain(dropest_bam_decoder *dec, int sl
 					HIP_CHECK(hipMemcpyAsync(d->h_count.p + k, d->seg_count.p + k, 4, hipMemcpyDeviceToHost, st));
 					HIP_CHECK(hipStreamSynchronize(st));
 				}
-				d->base[k] = uint32_t(n_rec);
+				d->h_base.p[k] = uint32_t(n_rec);
 				n_rec += d->h_count.p[k];
 				if (want != BAM_NONE) expect = d->h_seg_exit.p[k];
 			}
@@ -807,10 +811,12 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 		// record offsets, the fields, the accepted records made dense
 		BamWindowCounts wc{};
 		uint32_t totals[2] = {0, 0}, bad_record = 0;
+		static_assert(sizeof(BamWindowCounts) == 40, "ten words");
+		d->h_result.ensure(16);
 		if (n_rec) {
 			const size_t rc = size_t(n_rec) + size_t(n_rec) / 4;
 			d->rec_off.ensure(rc);
-			HIP_CHECK(hipMemcpyAsync(F.seg_base.p, F.base.data(), size_t(n_segs) * 4, hipMemcpyHostToDevice, st));
+			HIP_CHECK(hipMemcpyAsync(F.seg_base.p, F.h_base.p, size_t(n_segs) * 4, hipMemcpyHostToDevice, st));      // (pinned: the copy is queued, not staged)
 			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, F.data(), data_len, (const uint32_t *)nullptr, n_segs, F.seg_start.p,
 			                   F.seg_count.p, F.seg_exit.p, F.seg_base.p, d->rec_off.p, F.d_bad.p);
 			d->o_qoff.ensure(rc); d->dn_qoff.ensure(rc);
@@ -834,11 +840,13 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			hipLaunchKernelGGL(bam_fin_scan_kernel, dim3(1), dim3(1024), 0, st, d->tile_ok.p, d->tile_need.p, tiles, d->d_totals.p);
 			hipLaunchKernelGGL(bam_fin_scatter_kernel, dim3(tiles), dim3(256), 0, st, F.data(), d->rec_off.p, ro, uint32_t(n_rec), d->tile_ok.p, d->tile_need.p, dn);
 			HIP_CHECK(hipGetLastError());
-			HIP_CHECK(hipMemcpyAsync(&wc, d->d_wc.p, sizeof(wc), hipMemcpyDeviceToHost, st));
-			HIP_CHECK(hipMemcpyAsync(totals, d->d_totals.p, 8, hipMemcpyDeviceToHost, st));
-			HIP_CHECK(hipMemcpyAsync(&bad_record, F.d_bad.p, 4, hipMemcpyDeviceToHost, st));
+			// (into pinned words: a copy to pageable memory is staged and waits for the stream each time -- three of them per window)
+			HIP_CHECK(hipMemcpyAsync(d->h_result.p, d->d_wc.p, sizeof(wc), hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(d->h_result.p + 10, d->d_totals.p, 8, hipMemcpyDeviceToHost, st));
+			HIP_CHECK(hipMemcpyAsync(d->h_result.p + 12, F.d_bad.p, 4, hipMemcpyDeviceToHost, st));
 		}
 		HIP_CHECK(hipStreamSynchronize(st));
+		if (n_rec) { std::memcpy(&wc, d->h_result.p, sizeof(wc)); totals[0] = d->h_result.p[10]; totals[1] = d->h_result.p[11]; bad_record = d->h_result.p[12]; }
 		if (bad_record) throw InvalidError("Corrupt BAM record");      // (a block_size below the 32 bytes of a record's fixed part or beyond 2^26, met by the walk from the checked starts; fixed part + name + cigar + bases longer than the record, met by the parse)
 		const uint32_t n_need = totals[1];
 		if (n_need) {
