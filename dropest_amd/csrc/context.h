@@ -61,8 +61,10 @@ struct ReadStore {
 	void reserve(size_t want) {
 		if (want <= capacity() && cb.p) return;
 		size_t cap = std::max<size_t>(want, std::max<size_t>(capacity() * 2, size_t(1) << 20));
-		if (!copy) HIP_CHECK(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
-		HIP_CHECK(stream_wait(copy));
+		// (the copy stream is made when something has to travel on it: a stream is 8-16 ms to create with its first use, and a store that is
+		// reserved empty and then filled from device arrays -- the BAM decoder's windows -- never needs one)
+		if (n && !copy) HIP_CHECK(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+		if (copy) HIP_CHECK(stream_wait(copy));
 		DevBuf<u64> ncb, numi; DevBuf<u32> ngene, naux;
 		ncb.alloc(cap); numi.alloc(cap); ngene.alloc(cap); naux.alloc(cap);
 		ncb.mark_persistent(); numi.mark_persistent(); ngene.mark_persistent(); naux.mark_persistent();
@@ -83,6 +85,7 @@ struct ReadStore {
 	void push(const uint64_t *h_cb, const uint64_t *h_umi, const uint32_t *h_gene, const uint32_t *h_aux, size_t count) {
 		if (!count) return;
 		reserve(n + count);
+		if (!copy) HIP_CHECK(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
 		if (is_pinned(h_cb) && is_pinned(h_umi) && is_pinned(h_gene) && is_pinned(h_aux)) {
 			HIP_CHECK(hipMemcpyAsync(cb.p + n, h_cb, count * 8, hipMemcpyHostToDevice, copy));
 			HIP_CHECK(hipMemcpyAsync(umi.p + n, h_umi, count * 8, hipMemcpyHostToDevice, copy));
@@ -121,6 +124,7 @@ struct ReadStore {
 		if (!total) return;
 		if (total > (size_t(4) << 20)) { for (size_t k = 0; k < n_seg; ++k) push(h_cb[k], h_umi[k], h_gene[k], h_aux[k], size_t(counts[k])); return; }
 		reserve(n + total);
+		if (!copy) HIP_CHECK(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
 		PinnedBuf<unsigned char> &st = stage[cur];
 		if (!done[cur]) HIP_CHECK(hipEventCreateWithFlags(&done[cur], hipEventDisableTiming));
 		else HIP_CHECK(event_wait(done[cur]));
@@ -144,14 +148,15 @@ struct ReadStore {
 	}
 	// Device arrays copied to the tail of the store (dropest_push_reads_device without adoption): the reads stay ONE block, so a
 	// view of the container before it is initialised (dropest_resident_reads) and the freeze have nothing to concatenate.
-	void push_device(const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene, const uint32_t *d_aux, size_t count) {
+	// (device to device, on the context's own stream `on`: whatever wrote the caller's arrays on that stream is in front of the copies)
+	void push_device(const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene, const uint32_t *d_aux, size_t count, hipStream_t on) {
 		if (!count) return;
 		reserve(n + count);
-		HIP_CHECK(hipMemcpyAsync(cb.p + n, d_cb, count * 8, hipMemcpyDeviceToDevice, copy));
-		HIP_CHECK(hipMemcpyAsync(umi.p + n, d_umi, count * 8, hipMemcpyDeviceToDevice, copy));
-		HIP_CHECK(hipMemcpyAsync(gene.p + n, d_gene, count * 4, hipMemcpyDeviceToDevice, copy));
-		HIP_CHECK(hipMemcpyAsync(aux.p + n, d_aux, count * 4, hipMemcpyDeviceToDevice, copy));
-		HIP_CHECK(stream_wait(copy));   // the caller's buffers are free again
+		HIP_CHECK(hipMemcpyAsync(cb.p + n, d_cb, count * 8, hipMemcpyDeviceToDevice, on));
+		HIP_CHECK(hipMemcpyAsync(umi.p + n, d_umi, count * 8, hipMemcpyDeviceToDevice, on));
+		HIP_CHECK(hipMemcpyAsync(gene.p + n, d_gene, count * 4, hipMemcpyDeviceToDevice, on));
+		HIP_CHECK(hipMemcpyAsync(aux.p + n, d_aux, count * 4, hipMemcpyDeviceToDevice, on));
+		HIP_CHECK(stream_wait(on));   // the caller's buffers are free again
 		n += count;
 	}
 	void wait() { if (copy) HIP_CHECK(stream_wait(copy)); }

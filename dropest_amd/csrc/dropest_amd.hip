@@ -100,6 +100,18 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 	if (c.device < 0 || c.device >= ndev) throw InvalidError("device ordinal out of range");
 	HIP_CHECK(hipSetDevice(c.device));
 	HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+	// The stream's hardware queue -- and the null stream's, which synchronous copies and the BAM decoder's uploads use -- are made by their first
+	// dispatch (~8 ms each, during which every other HIP call of the process waits): here, with the other start-up costs, not inside the first
+	// window of a BAM file or the first pass.
+	{
+		void *scratch = nullptr;
+		HIP_CHECK(hipMalloc(&scratch, 256));
+		(void)hipMemsetAsync(scratch, 0, 256, stream);
+		(void)hipMemsetAsync(scratch, 0, 256, nullptr);
+		(void)hipStreamSynchronize(stream);
+		(void)hipStreamSynchronize(nullptr);
+		(void)hipFree(scratch);
+	}
 	// MergeUMIsStrategySimple's constructor seeds rand() with 42 (MergeUMIsStrategySimple.cpp:15-19); MergeUMIsStrategyDirectional
 	// does not seed, i.e. a fresh reference process draws from srand(1).  The container keeps its own restated generator.
 	reseed_rng();
@@ -2538,7 +2550,7 @@ dropest_status dropest_push_reads_device(dropest_ctx *ctx, const uint64_t *d_cb,
 		// stay one block, which the facade's preview of an uninitialised container needs (dropest_resident_reads)
 		if (!adopt && (ctx->store_chunk < 0 || size_t(ctx->store_chunk) + 1 == ctx->chunks.size())) {
 			if (ctx->store_chunk < 0) { ctx->store_chunk = long(ctx->chunks.size()); ctx->chunks.emplace_back(); }
-			ctx->store.push_device(d_cb, d_umi, d_gene, d_aux, n);
+			ctx->store.push_device(d_cb, d_umi, d_gene, d_aux, n, ctx->stream);
 			ctx->chunks[size_t(ctx->store_chunk)].n = ctx->store.n;
 			ctx->n_reads += n;
 			return;
