@@ -294,6 +294,13 @@ static bool bgzf_block_table(const uint8_t *comp, uint64_t len, std::vector<uint
 	return !len || dropest_bgzf_scan(comp, len, cap, in_off.data(), in_len.data(), out_off.data(), out_len.data(), crc.data(), n, used, total) == 0;
 }
 
+// This translation unit's kernels are loaded onto the device by the first launch of one of them (~10 ms): a context does it when it is created
+// (dropest_amd.hip), with the other start-up costs, so that it does not fall into the first window of the first BAM file.
+extern "C" void dropest_bgzf_warm_up(void *stream) {
+	hipLaunchKernelGGL(bam_spoil_guesses_kernel, dim3(1), dim3(256), 0, hipStream_t(stream), (uint64_t *)nullptr, 0u);      // (no segment: nothing is touched)
+	(void)hipGetLastError();
+}
+
 extern "C" int dropest_bam_decoder_create(int device, const dropest_bam_parse_cfg *cfg, dropest_bam_decoder **out) {
 	return bgzf_guarded([&] {
 		if (!cfg || !out) throw InvalidError("null argument");
@@ -509,6 +516,15 @@ extern "C" int dropest_bam_decoder_use_stream(dropest_bam_decoder *d, void *stre
 		if (!d) throw InvalidError("null argument");
 		HIP_CHECK(hipSetDevice(d->device));
 		std::lock_guard<std::mutex> lk(d->ready_mutex);
+		if (getenv("DROPEST_BAM_TRACE_SYNC")) {      // (development: which stream still has work when a file is done)
+			using clk = std::chrono::steady_clock;
+			auto t0 = clk::now();
+			(void)hipStreamSynchronize(d->up_stream);
+			std::fprintf(stderr, "[bam] use_stream: the upload stream waited for %.1f ms\n", std::chrono::duration<double, std::milli>(clk::now() - t0).count());
+			t0 = clk::now();
+			if (d->stream) (void)hipStreamSynchronize(d->stream);
+			std::fprintf(stderr, "[bam] use_stream: the kernels' stream waited for %.1f ms\n", std::chrono::duration<double, std::milli>(clk::now() - t0).count());
+		}
 		if (d->stream) HIP_CHECK(hipStreamSynchronize(d->stream));
 		d->stream = stream ? hipStream_t(stream) : d->own_stream;      // (null: bam_ready makes the decoder's own)
 	});

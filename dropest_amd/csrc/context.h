@@ -44,6 +44,13 @@ struct ReadChunk {
 
 struct KernelStat { u32 launches = 0; double ms = 0, bytes = 0; };
 
+// the four columns of `count` reads appended to the store's arrays in one launch (four device-to-device hipMemcpyAsync calls cost the host
+// ~0.3 ms each: 11-15 ms over the nine windows of a BAM file)
+__global__ __launch_bounds__(256) void store_append_kernel(const u64 *__restrict__ s_cb, const u64 *__restrict__ s_umi, const u32 *__restrict__ s_gene, const u32 *__restrict__ s_aux,
+                                                           u64 *__restrict__ d_cb, u64 *__restrict__ d_umi, u32 *__restrict__ d_gene, u32 *__restrict__ d_aux, size_t count) {
+	for (size_t i = size_t(blockIdx.x) * 256u + threadIdx.x; i < count; i += size_t(gridDim.x) * 256u) { d_cb[i] = s_cb[i]; d_umi[i] = s_umi[i]; d_gene[i] = s_gene[i]; d_aux[i] = s_aux[i]; }
+}
+
 // Pushed reads (CellsDataContainer::add_record, batched): ONE set of device arrays that grows geometrically -- no
 // allocation per batch, nothing to concatenate later -- fed over PCIe on its own stream.  Host arrays that are already
 // pinned are copied from in place; pageable ones go through two pinned staging buffers, the host memcpy of batch k + 1
@@ -152,11 +159,11 @@ struct ReadStore {
 	void push_device(const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene, const uint32_t *d_aux, size_t count, hipStream_t on) {
 		if (!count) return;
 		reserve(n + count);
-		HIP_CHECK(hipMemcpyAsync(cb.p + n, d_cb, count * 8, hipMemcpyDeviceToDevice, on));
-		HIP_CHECK(hipMemcpyAsync(umi.p + n, d_umi, count * 8, hipMemcpyDeviceToDevice, on));
-		HIP_CHECK(hipMemcpyAsync(gene.p + n, d_gene, count * 4, hipMemcpyDeviceToDevice, on));
-		HIP_CHECK(hipMemcpyAsync(aux.p + n, d_aux, count * 4, hipMemcpyDeviceToDevice, on));
-		HIP_CHECK(stream_wait(on));   // the caller's buffers are free again
+		hipLaunchKernelGGL(store_append_kernel, dim3(unsigned(std::min<size_t>((count + 255) / 256, 4096))), dim3(256), 0, on, reinterpret_cast<const u64 *>(d_cb),
+		                   reinterpret_cast<const u64 *>(d_umi), d_gene, d_aux, cb.p + n, umi.p + n, gene.p + n, aux.p + n, count);
+		HIP_CHECK(hipGetLastError());
+		HIP_CHECK(stream_wait(on));   // the caller's buffers are free again (not waiting -- the BAM decoder's later work is queued on `on` too -- left the
+		                              // last launch of a file unsubmitted for 23-28 ms: measured, dropped)
 		n += count;
 	}
 	void wait() { if (copy) HIP_CHECK(stream_wait(copy)); }

@@ -10,6 +10,7 @@
 // This file contains no CPU implementation of the path: without a GPU every entry point fails loudly.
 
 #include "context.h"
+extern "C" void dropest_bgzf_warm_up(void *stream);
 #include "k_keyscatter.h"
 #include "k_umidict.h"
 
@@ -108,6 +109,11 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 		HIP_CHECK(hipMalloc(&scratch, 256));
 		(void)hipMemsetAsync(scratch, 0, 256, stream);
 		(void)hipMemsetAsync(scratch, 0, 256, nullptr);
+		// (... and this library's kernels are loaded onto the device by the first launch of one of them: ~10 ms)
+		hipLaunchKernelGGL(store_append_kernel, dim3(1), dim3(256), 0, stream, (const u64 *)nullptr, (const u64 *)nullptr, (const u32 *)nullptr, (const u32 *)nullptr,
+		                   (u64 *)nullptr, (u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, size_t(0));
+		(void)hipGetLastError();
+		dropest_bgzf_warm_up(stream);      // (bgzf_api.hip's, for a BAM read on the device)
 		(void)hipStreamSynchronize(stream);
 		(void)hipStreamSynchronize(nullptr);
 		(void)hipFree(scratch);

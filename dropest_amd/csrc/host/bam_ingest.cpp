@@ -713,6 +713,8 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 		std::string p_cb, p_umi, p_quality;     // -r: the served parameters (owned: the map entry is erased)
 	};
 	const unsigned nthreads = _threads ? _threads : std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+	const auto t_parse = std::chrono::steady_clock::now();
+	struct SayAll { std::chrono::steady_clock::time_point t; ~SayAll() { if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] parse_bam_files: %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count()); } } say_all{t_parse};
 	join_release_thread();
 	for (auto const &bam_name : bam_files) {
 		std::unique_ptr<BamReader> reader_p;       // the host reader: opened only when it is the one that reads (its loader thread inflates ahead from the start)
@@ -1006,7 +1008,9 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			struct Keep {    // back into the cache when the file went through, destroyed when it did not (whatever state an exception left)
 				dropest_bam_decoder *d; int device; bool ok = false;
 				~Keep() {
+					const auto t_k = std::chrono::steady_clock::now();
 					(void)dropest_bam_decoder_use_stream(d, nullptr);      // (the container's stream is the container's)
+					if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] device path: the lent stream given back (and waited for) %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_k).count());
 					if (!ok) { dropest_bam_decoder_destroy(d); return; }
 					std::lock_guard<std::mutex> lk(decoder_cache_mutex());
 					auto &slot = decoder_cache()[device];
@@ -1047,7 +1051,10 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			std::vector<uint32_t> name_off; std::vector<uint8_t> name_pool;
 			double dev_ms[4] = {0, 0, 0, 0}, host_ms[3] = {0, 0, 0};
 			const auto t_file = clk::now();
-			size_t window_bytes = size_t(1) << 20, n_windows = 0, repaired = 0, refused = 0, n_needs = 0;
+			// (DROPEST_BAM_RAMP="first MB,factor": the first window and how fast the windows grow to window_max)
+			size_t ramp_first = 1, ramp_factor = 4;
+			if (const char *e = getenv("DROPEST_BAM_RAMP")) { int a = 0, b = 0; if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 2) { ramp_first = size_t(a); ramp_factor = size_t(b); } }
+			size_t window_bytes = ramp_first << 20, n_windows = 0, repaired = 0, refused = 0, n_needs = 0;
 			// windows: a machine's worth of blocks (one wave per block) in a file of a few hundred MB, two in a long one (measured on 0.4 and 1.6 GB:
 			// NOTES_r05 §11) -- the pinned staging buffers of larger windows cost more to allocate than their fuller kernels give back
 			const bool long_file = map.n > (size_t(1) << 30);
@@ -1252,7 +1259,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					stg = next.get();
 					ms_wait_read += since(t_wait);
 					if (!stg.error.empty()) throw std::runtime_error(stg.error + ": " + bam_name);
-					window_bytes = std::min(window_bytes * 4, window_max);       // (1, 4, 16, 64 MB ...: a ramp of x 16 measured the same, 188-201 ms on the 3 x file)
+					window_bytes = std::min(window_bytes * ramp_factor, window_max);       // (1, 4, 16, 64 MB ...: a ramp of x 16 measured the same, 188-201 ms on the 3 x file)
 					which ^= 1;
 					if (!stg.final) next = std::async(std::launch::async, read_window, which, window_bytes);
 					if (pipeline && dropest_bam_decoder_window_inflate(dec, stg.p, stg.used, &slot_cur)) {
@@ -1308,7 +1315,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 						throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
 					// this window's compressed bytes are done with: the reader may fill their buffer with the window after the next
 					if (have_ahead && !stg_ahead.final) {
-						window_bytes = std::min(window_bytes * 4, window_max);
+						window_bytes = std::min(window_bytes * ramp_factor, window_max);
 						which ^= 1;
 						next = std::async(std::launch::async, read_window, which, window_bytes);
 					}
@@ -1419,7 +1426,12 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			return true;
 		};
 		static const bool env_device = getenv("DROPEST_BAM_DEVICE") != nullptr && atoi(getenv("DROPEST_BAM_DEVICE")) != 0;
-		if ((_device_decode || env_device) && device_file()) continue;
+		if (_device_decode || env_device) {
+			const auto t_df = std::chrono::steady_clock::now();
+			const bool done = device_file();
+			if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] device path: %.1f ms in all for this file (taken: %d)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_df).count(), int(done));
+			if (done) continue;
+		}
 		reader_p.reset(new BamReader(bam_name, _threads));
 		BamReader &reader = *reader_p;
 		refs = reader.reference_names();

@@ -361,9 +361,17 @@ void CellsDataContainer::add_records_packed_device(const uint64_t *d_cb, const u
 	if (_umi_quality_length == size_t(-1) && any_gene) { _umi_quality_length = 0; _qual_pending = 0; }   // the first gene-bearing read fixes the quality length: none
 	if (_umi_quality_length == size_t(-1)) _qual_pending += n;
 	_qual_reads += n;
+	static const bool trace = getenv("DROPEST_BAM_TRACE") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
 	if (!_qual_lens.empty()) _qual_lens.insert(_qual_lens.end(), n, uint8_t(0));
+	const auto t1 = std::chrono::steady_clock::now();
 	send_side_strings(_ctx);
+	const auto t2 = std::chrono::steady_clock::now();
 	check(dropest_push_reads_device(_ctx, d_cb, d_umi, d_gene, d_aux, n, 0));
+	if (trace) {
+		auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+		std::fprintf(stderr, "[bam] container: %zu reads: quality lengths %.2f ms, side strings %.2f ms (%zu), push %.2f ms\n", n, ms(t0, t1), ms(t1, t2), _side.size(), ms(t2, std::chrono::steady_clock::now()));
+	}
 }
 
 void CellsDataContainer::add_records_packed_device(const uint64_t *d_cb, const uint64_t *d_umi, const uint32_t *d_gene, const uint32_t *d_aux, size_t n, bool any_gene,

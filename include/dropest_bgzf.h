@@ -74,6 +74,8 @@ typedef struct dropest_bam_window {        /* host pointers: pinned memory of th
 /* raw DEFLATE of one block on the host (zlib or the like) for the blocks the device refuses; 0 = ok */
 typedef int (*dropest_bgzf_host_inflate)(const uint8_t *in, uint32_t in_len, uint8_t *out, uint32_t out_len, void *user);
 
+/* Loads this path's kernels onto the current device (their first launch otherwise does, ~10 ms); dropest_ctx_create calls it. */
+void dropest_bgzf_warm_up(void *stream);
 int dropest_bam_decoder_create(int device, const dropest_bam_parse_cfg *cfg, dropest_bam_decoder **out);
 /* The decoder for another file: its device buffers, streams and pinned memory stay (creating and freeing them is ~60 ms per file), the
  * dictionaries are emptied, the annotation and the record carried over are dropped. */
