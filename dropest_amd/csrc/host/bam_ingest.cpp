@@ -1090,7 +1090,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			const bool upload_ahead = !getenv("DROPEST_BAM_NO_UPLOAD_AHEAD");
 			const bool in_pieces = upload_ahead && !getenv("DROPEST_BAM_WHOLE_WINDOW_STAGING");
 			uint8_t *stage_p[2] = {nullptr, nullptr};
-			constexpr size_t PIECE = size_t(4) << 20;
+			const size_t PIECE = size_t(std::min(16, std::max(1, getenv("DROPEST_BAM_PIECE_MB") ? atoi(getenv("DROPEST_BAM_PIECE_MB")) : 4))) << 20;
 			// (the copy out of the page cache runs at ~4-5 GB/s per thread; a piece being sent, one being filled, per reader)
 			const uint32_t READERS = uint32_t(std::min(8, std::max(1, getenv("DROPEST_BAM_READERS") ? atoi(getenv("DROPEST_BAM_READERS")) : 4))), N_PIECES = 2 * READERS;
 			uint8_t *piece_p[16] = {};
