@@ -1080,8 +1080,8 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					window_max = std::min(window_max, std::max<size_t>(map.n - c0, size_t(1) << 20));      // (no more than the file)
 				}
 			}
-			// The compressed bytes reach the device in pieces: a helper thread (and three more for a long window) reads the next window from the file into
-			// pinned pieces of 4 MB (pread: page cache -> pinned memory) and sends each on its way (dropest_bam_decoder_upload_piece) while the device
+			// The compressed bytes reach the device in pieces: helper threads (up to eight for a long window) read the next window from the file into
+			// pinned pieces of 2 MB (pread: page cache -> pinned memory) and sends each on its way (dropest_bam_decoder_upload_piece) while the device
 			// and this thread work on the window before.  The window itself is the mapped file's bytes: the block table is made from them, the host
 			// fall-back for a refused block reads them.  (Rounds 4-6a read whole windows into two pinned buffers of the window's size: 2 x 128 MB were
 			// 35-65 ms to allocate, a fifth to a third of a 16 M read file's time -- DROPEST_BAM_WHOLE_WINDOW_STAGING=1 takes that road.)
@@ -1090,9 +1090,9 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			const bool upload_ahead = !getenv("DROPEST_BAM_NO_UPLOAD_AHEAD");
 			const bool in_pieces = upload_ahead && !getenv("DROPEST_BAM_WHOLE_WINDOW_STAGING");
 			uint8_t *stage_p[2] = {nullptr, nullptr};
-			const size_t PIECE = size_t(std::min(16, std::max(1, getenv("DROPEST_BAM_PIECE_MB") ? atoi(getenv("DROPEST_BAM_PIECE_MB")) : 4))) << 20;
+			const size_t PIECE = size_t(std::min(16, std::max(1, getenv("DROPEST_BAM_PIECE_MB") ? atoi(getenv("DROPEST_BAM_PIECE_MB")) : 2))) << 20;
 			// (the copy out of the page cache runs at ~4-5 GB/s per thread; a piece being sent, one being filled, per reader)
-			const uint32_t READERS = uint32_t(std::min(8, std::max(1, getenv("DROPEST_BAM_READERS") ? atoi(getenv("DROPEST_BAM_READERS")) : 4))), N_PIECES = 2 * READERS;
+			const uint32_t READERS = uint32_t(std::min(8, std::max(1, getenv("DROPEST_BAM_READERS") ? atoi(getenv("DROPEST_BAM_READERS")) : 8))), N_PIECES = 2 * READERS;
 			uint8_t *piece_p[16] = {};
 			if (in_pieces) {
 				for (int k = 0; k < 2; ++k)      // (first: the upload stream is made beside the pinned allocation, and a device allocation would wait for it)
@@ -1322,7 +1322,12 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					if (dropest_bam_decoder_window_finish(dec, slot_cur, &w)) throw std::runtime_error(std::string(dropest_bgzf_last_error()) + ": " + bam_name);
 				}
 				ms_window_calls += since(t_call);
-				if (first) { est_reads = size_t(double(w.n_records) * double(map.n - c0) / double(std::max<size_t>(used, 1)) * double(bam_files.size()) * 1.05); container.expect_reads(est_reads); }
+				if (first) {
+					est_reads = size_t(double(w.n_records) * double(map.n - c0) / double(std::max<size_t>(used, 1)) * double(bam_files.size()) * 1.05);
+					const auto t_e = clk::now();
+					container.expect_reads(est_reads);
+					if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] device path: the container told to expect %zu reads %.1f ms\n", est_reads, since(t_e));
+				}
 				first = false;
 				++n_windows; repaired += w.guesses_repaired; refused += w.refused_blocks;
 				dev_ms[0] += w.ms_copy; dev_ms[1] += w.ms_inflate; dev_ms[2] += w.ms_boundaries; dev_ms[3] += w.ms_parse;
