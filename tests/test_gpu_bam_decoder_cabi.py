@@ -240,11 +240,11 @@ def test_one_window_through_the_c_abi(tmp_path):
         assert L.dropest_bam_decoder_window(dec, comp.ctypes.data, len(comp), u0, 1, None, None, C.byref(w4)) == 0, L.dropest_bgzf_last_error()
         assert (w4.n_records, w4.n_accepted, w4.n_need, list(w4.counts), w4.refused_blocks) == (w.n_records, w.n_accepted, w.n_need, list(w.counts), 0), table
         assert columns(L, dec, int(w4.n_accepted))[0].tolist() == cbc.tolist(), table
-    # the kernels on a stream the caller lends (torch's current one), and back on the decoder's own
-    hip = C.CDLL("libamdhip64.so")
+    # the kernels on a stream the caller lends, and back on the decoder's own
     L.dropest_bam_decoder_use_stream.argtypes = [C.c_void_p, C.c_void_p]
-    lent = C.c_void_p()
-    assert hip.hipStreamCreateWithFlags(C.byref(lent), 1) == 0            # (hipStreamNonBlocking)
+    ctx = capi.Context(device=0)                                        # (what BamController lends: the container's context's stream)
+    lent = C.c_void_p(capi.lib().dropest_stream(ctx.h))
+    assert lent.value
     for stream in (lent, None, lent):
         assert L.dropest_bam_decoder_use_stream(dec, stream) == 0, L.dropest_bgzf_last_error()
         assert L.dropest_bam_decoder_reset(dec, C.byref(cfg)) == 0
@@ -252,7 +252,6 @@ def test_one_window_through_the_c_abi(tmp_path):
         assert (w5.n_records, w5.n_accepted, w5.n_need, list(w5.counts)) == (w.n_records, w.n_accepted, w.n_need, list(w.counts))
         assert columns(L, dec, int(w5.n_accepted))[0].tolist() == cbc.tolist()
     assert L.dropest_bam_decoder_use_stream(dec, None) == 0
-    hip.hipStreamDestroy.argtypes = [C.c_void_p]
-    assert hip.hipStreamDestroy(lent) == 0
+    ctx.close()
     L.dropest_bam_decoder_destroy.argtypes = [C.c_void_p]
     L.dropest_bam_decoder_destroy(dec)
