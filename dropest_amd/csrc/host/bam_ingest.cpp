@@ -1131,8 +1131,9 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				std::vector<uint64_t> in_off; std::vector<uint32_t> in_len, out_len, crc;
 				void clear() { in_off.clear(); in_len.clear(); out_len.clear(); crc.clear(); }
 			} blocks_of[2];
-			auto whole_blocks_of_file = [&](size_t avail, size_t want, Blocks &B, Staged &st) -> size_t {
-				B.clear();
+			// blocks from offset `from` of the window (a block's first byte) until one begins at or behind `until` (and at least one), none beyond `avail`,
+			// at most max_blocks; their table appended to B (offsets relative to the window); returns where it stopped
+			auto walk_blocks = [&](size_t from, size_t until, size_t avail, size_t max_blocks, Blocks &B, std::string &error) -> size_t {
 				uint8_t hb[8 + 64];
 				std::vector<uint8_t> big;
 				auto get = [&](uint8_t *to, size_t off, size_t n) -> bool {
@@ -1140,31 +1141,101 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					while (g < n) { const ssize_t r = pread(map.fd, to + g, n - g, off_t(file_at + off + g)); if (r <= 0) return false; g += size_t(r); }
 					return true;
 				};
-				size_t o = 0, n_blocks = 0, h_len = std::min<size_t>(avail, 64);
-				if (!get(hb + 8, 0, h_len)) { st.error = "Can't read BAM file"; return 0; }
-				while (o + 18 <= avail && (o < want || o == 0) && n_blocks < block_cap) {
+				size_t o = from, n_blocks = 0, h_len = std::min<size_t>(avail - from, 64);
+				if (!get(hb + 8, from, h_len)) { error = "Can't read BAM file"; return from; }
+				while (o + 18 <= avail && (o < until || o == from) && n_blocks < max_blocks) {
 					const uint8_t *h = hb + 8;
 					if (h_len < 18) break;
-					if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { st.error = "Not a BGZF/BAM file"; return 0; }
+					if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { error = "Not a BGZF/BAM file"; return from; }
 					const size_t xlen = le16(h + 10);
 					if (o + 12 + xlen > avail) break;
 					if (12 + xlen > h_len) {      // (an extra field beyond the 52 bytes read ahead: never from htslib)
 						big.resize(12 + xlen);
-						if (!get(big.data(), o, 12 + xlen)) { st.error = "Can't read BAM file"; return 0; }
+						if (!get(big.data(), o, 12 + xlen)) { error = "Can't read BAM file"; return from; }
 						h = big.data();
 					}
 					size_t bsize = 0;
 					for (size_t x = 0; x + 4 <= xlen;) { const uint8_t *sf = h + 12 + x; const size_t sl = le16(sf + 2); if (sf[0] == 'B' && sf[1] == 'C' && sl == 2 && x + 6 <= xlen) bsize = size_t(le16(sf + 4)) + 1; x += 4 + sl; }
-					if (!bsize || bsize < 12 + xlen + 8) { st.error = "BGZF block without BC subfield"; return 0; }
+					if (!bsize || bsize < 12 + xlen + 8) { error = "BGZF block without BC subfield"; return from; }
 					if (o + bsize > avail) break;
 					const size_t t_off = o + bsize - 8, t_len = std::min<size_t>(avail - t_off, sizeof(hb));
-					if (!get(hb, t_off, t_len)) { st.error = "Can't read BAM file"; return 0; }
+					if (!get(hb, t_off, t_len)) { error = "Can't read BAM file"; return from; }
 					const uint32_t isize = le32(hb + 4);
-					if (isize > 65536u) { st.error = "BGZF block with ISIZE beyond 64 KB"; return 0; }
+					if (isize > 65536u) { error = "BGZF block with ISIZE beyond 64 KB"; return from; }
 					B.in_off.push_back(o + 12 + xlen); B.in_len.push_back(uint32_t(bsize - 12 - xlen - 8)); B.out_len.push_back(isize); B.crc.push_back(le32(hb));
 					o += bsize; ++n_blocks;
 					h_len = t_len - 8;
 				}
+				return o;
+			};
+			// The first block that begins at or behind `from`, found by its first sixteen bytes as htslib and bgzip write them (gzip magic, FEXTRA, XLEN 6,
+			// the BC subfield of two bytes) and by the block behind it beginning the same way; size_t(-1): none in the next 64 KB + (not such a file)
+			auto find_block = [&](size_t from, size_t avail) -> size_t {
+				static const uint8_t magic[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0};
+				if (from + 64 >= avail) return size_t(-1);
+				std::vector<uint8_t> buf(std::min<size_t>(avail - from, (size_t(1) << 16) + 32));
+				size_t g = 0;
+				while (g < buf.size()) { const ssize_t r = pread(map.fd, buf.data() + g, buf.size() - g, off_t(file_at + from + g)); if (r <= 0) return size_t(-1); g += size_t(r); }
+				for (size_t i = 0; i + 18 <= buf.size(); ++i) {
+					if (buf[i] != 31 || std::memcmp(buf.data() + i, magic, 16)) continue;
+					const size_t bsize = size_t(le16(buf.data() + i + 16)) + 1, next = from + i + bsize;
+					if (bsize < 26 || next + 16 > avail) continue;
+					uint8_t nb[16];
+					size_t h = 0;
+					while (h < 16) { const ssize_t r = pread(map.fd, nb + h, 16 - h, off_t(file_at + next + h)); if (r <= 0) return size_t(-1); h += size_t(r); }
+					if (!std::memcmp(nb, magic, 16)) return from + i;
+				}
+				return size_t(-1);
+			};
+			// The whole blocks of a window and their table.  A walk from header to header is one pread per block (~0.7 us): 270 000 blocks of a
+			// 1.6 GB file of 6 KB blocks are 0.2 s on one thread -- more than the device needs for the file -- so a long window is cut into four
+			// stretches, each begun at a block found by its magic bytes; the stretches must meet (a stretch ends where the next one began), else
+			// one walk from the start decides.
+			std::atomic<size_t> stretched_windows{0};
+			auto whole_blocks_of_file = [&](size_t avail, size_t want, Blocks &B, Staged &st) -> size_t {
+				B.clear();
+				constexpr size_t STRETCHES = 4;
+				// (no further than the blocks the device takes at once are expected to reach: beyond that the stretches' blocks would be thrown away)
+				const size_t avg_block = compressed_seen >= 64 ? std::max<size_t>(compressed_seen / 64, 64) : size_t(1) << 14;
+				const size_t reach = block_cap == size_t(-1) ? want : std::min<size_t>(want, size_t(double(block_cap) * double(avg_block) * 0.9));
+				const size_t span = std::min(reach, avail);
+				static const bool one_walker = getenv("DROPEST_BAM_ONE_WALKER") != nullptr;
+				// (tests: DROPEST_BAM_TEST_STRETCH="bytes,blocks" lowers the two thresholds so that small files take the four stretches)
+				static const std::pair<size_t, size_t> least = [] {
+					size_t a = size_t(8) << 20, b = 8192;
+					if (const char *e = getenv("DROPEST_BAM_TEST_STRETCH")) { long x = 0, y = 0; if (std::sscanf(e, "%ld,%ld", &x, &y) == 2 && x > 0 && y > 0) { a = size_t(x); b = size_t(y); } }
+					return std::make_pair(a, b);
+				}();
+				if (span >= least.first && span / avg_block >= least.second && !one_walker) {      // (measured: files of 6 KB blocks 213-250 -> 196-200 ms for 64 M reads; windows of fewer, larger blocks the same or a little slower)
+					Blocks part[STRETCHES];
+					size_t begin[STRETCHES], end[STRETCHES];
+					std::string err[STRETCHES];
+					std::vector<std::future<void>> th;
+					bool found = true;
+					begin[0] = 0;
+					for (size_t k = 1; k < STRETCHES && found; ++k) { begin[k] = find_block(span / STRETCHES * k, avail); found = begin[k] != size_t(-1); }
+					if (found) {
+						auto stretch = [&](size_t k) { end[k] = walk_blocks(begin[k], k + 1 < STRETCHES ? span / STRETCHES * (k + 1) : reach, avail, size_t(-1), part[k], err[k]); };
+						for (size_t k = 1; k < STRETCHES; ++k) th.push_back(std::async(std::launch::async, stretch, k));
+						stretch(0);
+						for (auto &f : th) f.get();
+						bool meet = true;
+						for (size_t k = 0; k < STRETCHES; ++k) meet = meet && err[k].empty() && (k + 1 == STRETCHES || end[k] == begin[k + 1]);
+						size_t total = 0;
+						for (size_t k = 0; k < STRETCHES; ++k) total += part[k].in_off.size();
+						if (meet && total && total <= block_cap) {
+							for (size_t k = 0; k < STRETCHES; ++k) {
+								B.in_off.insert(B.in_off.end(), part[k].in_off.begin(), part[k].in_off.end()); B.in_len.insert(B.in_len.end(), part[k].in_len.begin(), part[k].in_len.end());
+								B.out_len.insert(B.out_len.end(), part[k].out_len.begin(), part[k].out_len.end()); B.crc.insert(B.crc.end(), part[k].crc.begin(), part[k].crc.end());
+							}
+							++stretched_windows;
+							return end[STRETCHES - 1];
+						}
+					}
+					B.clear();
+				}
+				const size_t o = walk_blocks(0, want, avail, block_cap, B, st.error);
+				if (!st.error.empty()) return 0;
 				if (!o && avail) st.error = "Truncated BGZF block";
 				return o;
 			};
@@ -1427,7 +1498,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				std::fprintf(stderr, "[bam] device path: file mapped and header read %.1f ms, decoder created %.1f ms, annotation + the rest before the windows %.1f ms\n", ms_header, ms_create, std::chrono::duration<double, std::milli>(t_file - t_enter).count() - ms_header - ms_create),
 				std::fprintf(stderr, "[bam] device path: pinned staging buffers %.1f ms, waiting for the file reader %.1f ms, inside the window calls %.1f ms\n", ms_setup, ms_wait_read, ms_window_calls);
 			keep_dec.ok = true;
-			if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] device path: %.1f ms from the file's name to its last window\n", since(t_enter));
+			if (getenv("DROPEST_BAM_TRACE")) std::fprintf(stderr, "[bam] device path: %.1f ms from the file's name to its last window (block tables from four stretches: %zu windows)\n", since(t_enter), stretched_windows.load());
 			return true;
 		};
 		static const bool env_device = getenv("DROPEST_BAM_DEVICE") != nullptr && atoi(getenv("DROPEST_BAM_DEVICE")) != 0;

@@ -460,7 +460,9 @@ def test_device_path_read_names_long_records_and_strings_with_n(tmp_path):
     # through two pinned buffers as in rounds 4-5; DROPEST_BAM_NO_UPLOAD_AHEAD: copied by the window call; one reader thread instead of four)
     for env in ({"DROPEST_BAM_TEST_TAIL_RESERVE": "64"}, {"DROPEST_BAM_PIPELINE": "1"}, {"DROPEST_BAM_PIPELINE": "1", "DROPEST_BAM_TEST_TAIL_RESERVE": "64"},
                 {"DROPEST_BAM_PIPELINE": "1", "DROPEST_BAM_TEST_TAIL_RESERVE": "0", "DROPEST_BAM_TEST_SPOIL_GUESSES": "1"},
-                {"DROPEST_BAM_WHOLE_WINDOW_STAGING": "1"}, {"DROPEST_BAM_NO_UPLOAD_AHEAD": "1"}, {"DROPEST_BAM_READERS": "1"}, {"DROPEST_INFLATE_PAR": "0"}):
+                {"DROPEST_BAM_WHOLE_WINDOW_STAGING": "1"}, {"DROPEST_BAM_NO_UPLOAD_AHEAD": "1"}, {"DROPEST_BAM_READERS": "1"}, {"DROPEST_INFLATE_PAR": "0"},
+                # the block table of a window from four stretches, each begun at a block found by its magic bytes (files of many small blocks)
+                {"DROPEST_BAM_TEST_STRETCH": "100000,8"}, {"DROPEST_BAM_TEST_STRETCH": "100000,8", "DROPEST_BAM_PIECE_MB": "1", "DROPEST_BAM_READERS": "3"}):
         again = _run(tmp_path / ("dev_" + "_".join(sorted(env))), "name", [bam], 3, 5, threads=4, env=dict(env, DROPEST_BAM_DEVICE="1", DROPEST_BAM_DEVICE_WINDOW_MB="1"))
         assert again[1] == host[1] and again[0] == host[0] and again[2]["saved"] == host[2]["saved"]
     # UMI quality tags: the windows that carry them go record by record; the per-molecule quality sums land in the .rds
