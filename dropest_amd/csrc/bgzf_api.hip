@@ -112,9 +112,9 @@ extern "C" int dropest_bgzf_inflate_device(int device, void *stream, const uint8
 
 #ifdef INFP_PROFILE
 // (variant builds of scripts/experiments/inflate_variants only: the kernel's own account of its phases, read and cleared)
-extern "C" int dropest_bgzf_inflate_profile(unsigned long long *out16) {
-	if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(dropest::infp_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
-	unsigned long long zero[16] = {};
+extern "C" int dropest_bgzf_inflate_profile(unsigned long long *out24) {
+	if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(dropest::infp_prof), 24 * sizeof(unsigned long long)) != hipSuccess) return 1;
+	unsigned long long zero[24] = {};
 	return hipMemcpyToSymbol(HIP_SYMBOL(dropest::infp_prof), zero, sizeof(zero)) != hipSuccess;
 }
 #endif

@@ -35,13 +35,12 @@ constexpr uint32_t INFP_MATCH_CAP = INFP_CHUNK_BITS * 64 / 2;   // a match is at
 constexpr uint32_t INFP_OVERLAP = INFP_OVERLAP_BITS;
 constexpr uint32_t INFP_SPAN_WORDS = INFP_CHUNK_BITS + 8;       // 64-bit words of input a span may look at: its 64 chunks, the word its first bit stands in, and a symbol's reach behind its last bit
 enum : uint32_t { INFP_NONE = 0, INFP_EOB = 1, INFP_BAD = 2 };
-
 // -DINFP_PROFILE (scripts/experiments/inflate_variants): where a block's time goes, summed over the launch in 10 ns ticks (wall_clock64) by lane 0 of
 // every wave -- 0 header + tables, 1 span input to LDS, 2 (A), 3 (B), 4 (C), 5 (D), 6 CRC-32; counts: 7 rounds of (A), 8 spans, 11 BGZF blocks, 12 matches; inside (D):
-// 9 window moved and filled, 10 the rounds, 13 the batch to memory, 14 rounds, 15 batches.  (-DINFP_PROFILE_LOOP instead of the (D) slots: 13 iterations of the symbol
+// 9 window moved and filled, 10 the rounds, 13 the batch to memory, 14 rounds, 15 batches; 17 rounds of (A) in which some lane walked.  (-DINFP_PROFILE_LOOP instead of the (D) slots: 13 iterations of the symbol
 // loop per wave, 14 / 15 of them with a literal-length / distance code beyond the root table in some lane -- an atomic per iteration, the times mean nothing then.)  dropest_bgzf_inflate_profile() reads and clears them.
 #ifdef INFP_PROFILE
-__device__ unsigned long long infp_prof[16];
+__device__ unsigned long long infp_prof[24];
 #define INFP_TICK(t) const uint64_t t = wall_clock64()
 #define INFP_SUM(acc, t) acc += wall_clock64() - (t)
 #define INFP_DECL(acc) uint64_t acc = 0
@@ -223,8 +222,10 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 		// before leaves ITS chunk, which it mostly is, the lane needs no second walk)
 		uint32_t start = lane * INFP_CHUNK_BITS, end = 0, nb = 0, nm = 0, flag = INFP_NONE, dummy = 0, entry = 0;
 		bool alive = true, changed = true;
+		uint32_t walk_rounds = 0;
 		for (uint32_t round = 0; round < 66u; ++round) {
 			INFP_CNT(7, 1);
+			if (__ballot(changed && alive)) ++walk_rounds;      // (rounds in which the lanes behind an end-of-block symbol drop out one after the other cost nothing)
 			if (changed && alive) {
 				const uint32_t from = round == 0u && lane ? start - INFP_OVERLAP : start;
 				flag = infp_walk<false>(span, bit0, from, start, entry, (lane + 1u) * INFP_CHUNK_BITS, limit, L, X, end, nb, nm, nullptr, 0u, nullptr, 0u, dummy);
@@ -239,9 +240,26 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 				alive = now_alive; start = p_end;
 			}
 			if (!alive) { nb = 0; nm = 0; flag = INFP_NONE; }
-			if (!__ballot(changed)) break;
+			const unsigned long long moved = __ballot(changed);
+			if (!moved) break;
+			// The lanes below the first one that moved are final (a lane's start hangs on the lanes before it only).  An end-of-block symbol in one of
+			// them ends the span THERE: the lanes behind it walk garbage, and kept the wave walking -- one more of them dropped out per round -- for up to
+			// 64 rounds in the last span of every block.
+			{
+				const unsigned long long final_eob = __ballot(alive && flag == INFP_EOB) & ((1ull << __builtin_ctzll(moved)) - 1ull);
+				if (final_eob) {
+					if (int(lane) > __builtin_ctzll(final_eob)) { alive = false; nb = 0; nm = 0; flag = INFP_NONE; }
+					changed = false;
+					break;
+				}
+			}
+			// (Codes of nearly one length never fall in step -- six symbols of 2-3 bits, Huffman-only streams: lane k is then certain only after k + 1
+			// rounds, 64 full walks per span, 17-28 ms a block against the 7-11 of one chain of symbols.  Handing such a block's rest to k_inflate.h's
+			// serial loop after 12 / 24 / 40 walking rounds was built and measured: 9 % of the blocks of a BAM with random bases have a span that takes
+			// 40 rounds and more -- and finish it sooner than the serial loop finishes the rest of the block: 115 -> 70 GB/s.  Dropped; DROPEST_INFLATE_PAR=0
+			// is the switch for files of that kind.)
 		}
-		INFP_ACC(2, t_a);
+		INFP_ACC(2, t_a); INFP_CNT(17, walk_rounds);
 		if (dbg == 3) return 203u;
 		if (__ballot(changed)) return INF_BAD_CODE;                       // (cannot happen: lane k is settled after k + 1 rounds)
 		if (__ballot(alive && flag == INFP_BAD)) return INF_BAD_CODE;

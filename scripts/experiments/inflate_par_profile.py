@@ -34,7 +34,7 @@ body = bytes(body)
 blocks = [bw._bgzf_block(body[o:o + 0xFF00]) for o in range(0, len(body), 0xFF00)][:-1]
 print("blocks made:", len(blocks), "mean compressed bytes", sum(map(len, blocks)) // len(blocks), flush=True)
 L = C.CDLL(os.environ["DROPEST_BGZF_LIB"])
-prof = (C.c_ulonglong * 16)()
+prof = (C.c_ulonglong * 24)()
 have_prof = hasattr(L, "dropest_bgzf_inflate_profile")
 names = ["header", "span_in", "A", "B", "C", "D", "crc"]
 for nb in (1, 1024, 4096, 16384):
@@ -47,6 +47,7 @@ for nb in (1, 1024, 4096, 16384):
         p = [int(x) for x in prof]
         k = max(1, p[11])
         line += " | per block us: " + " ".join("%s %.0f" % (names[j], p[j] / k / 100.0) for j in range(7))
-        line += " | D: window %.0f rounds %.0f flush %.0f us; spans/block %.1f, A rounds/span %.1f, D batches/block %.0f, D rounds/block %.0f, matches/block %.0f" % (
-            p[9] / k / 100.0, p[10] / k / 100.0, p[13] / k / 100.0, p[8] / k, p[7] / max(1, p[8]), p[15] / k, p[14] / k, p[12] / k)
+        line += " | D: window %.0f rounds %.0f flush %.0f us; spans/block %.1f, A rounds/span %.1f, D batches/block %.0f, D rounds/block %.0f, matches/block %.0f, serial fall-backs/block %.2f" % (
+            p[9] / k / 100.0, p[10] / k / 100.0, p[13] / k / 100.0, p[8] / k, p[7] / max(1, p[8]), p[15] / k, p[14] / k, p[12] / k, p[16] / k)
+        line += ", walking rounds of (A)/span %.1f" % (p[17] / max(1, p[8]))
     print(line, flush=True)
