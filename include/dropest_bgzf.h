@@ -3,7 +3,8 @@
  * What it replaces: BamTools' BgzfStream (zlib inflate, one block at a time) under BamReader::GetNextAlignment, the loop of
  * Estimation/BamProcessing/BamController.cpp:85.  A BGZF block (SAMv1 §4.1) is an independent DEFLATE stream of at most 64 KB:
  * dropest_bgzf_scan walks the block headers on the host (18 + 8 bytes per block), dropest_bgzf_inflate_device decodes every block
- * with one 64-lane wave (csrc/k_inflate.h).  Plain C, no torch types.
+ * with one 64-lane wave whose lanes take different chunks of the block's symbol stream (csrc/k_inflate_par.h; csrc/k_inflate.h, one chain of
+ * symbols per block, behind DROPEST_INFLATE_PAR=0 -- both written from RFC 1951).  Plain C, no torch types.
  *
  * Checked on the device: every Huffman code, distance and length, the input and output bounds, ISIZE, and the block's CRC-32 (the wave
  * that inflated a block reads it back: 64 partial CRCs joined in GF(2)).  A block the device refuses (status != 0: damaged, or a CRC that
