@@ -1059,6 +1059,8 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			// NOTES_r05 §11) -- the pinned staging buffers of larger windows cost more to allocate than their fuller kernels give back
 			const bool long_file = map.n > (size_t(1) << 30);
 			size_t window_max = size_t(getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? std::max(1, atoi(getenv("DROPEST_BAM_DEVICE_WINDOW_MB"))) : (long_file ? 80 : 48)) << 20;
+			// (DROPEST_BAM_WINDOW_BLOCKS: blocks per window instead of the device's wave slots, twice that in a long file)
+			const size_t window_blocks = getenv("DROPEST_BAM_WINDOW_BLOCKS") ? size_t(std::max(64, atoi(getenv("DROPEST_BAM_WINDOW_BLOCKS")))) : std::max<size_t>(1024, dropest_bam_decoder_wave_slots(dec)) * (long_file ? 2 : 1);
 			size_t inflated_seen = 0, compressed_seen = 0;      // over the first 64 blocks behind the header: how far this file inflates
 			if (!getenv("DROPEST_BAM_DEVICE_WINDOW_MB")) {
 				// ... of blocks, not of bytes: a file that deflates 3 x (real bases and qualities) has blocks of ~20 KB where the 10 x synthetic ones have 6 KB,
@@ -1075,8 +1077,8 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				}
 				compressed_seen = bytes_seen;
 				if (n_seen >= 8) {
-					const size_t want = std::max<size_t>(1024, dropest_bam_decoder_wave_slots(dec)) * (long_file ? 2 : 1) * (bytes_seen / n_seen + 1);
-					window_max = std::min(std::max(window_max, want), size_t(long_file ? 256 : 128) << 20);
+					const size_t want = window_blocks * (bytes_seen / n_seen + 1);
+					window_max = std::min(std::max(window_max, want), size_t(getenv("DROPEST_BAM_WINDOW_BLOCKS") ? 512 : long_file ? 256 : 128) << 20);
 					window_max = std::min(window_max, std::max<size_t>(map.n - c0, size_t(1) << 20));      // (no more than the file)
 				}
 			}
@@ -1106,7 +1108,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			const double ms_setup = since(t_file);
 			double ms_wait_read = 0, ms_window_calls = 0;
 			size_t file_at = c0;
-			const size_t block_cap = getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? size_t(-1) : std::max<size_t>(1024, dropest_bam_decoder_wave_slots(dec)) * (long_file ? 2 : 1);   // (one wave per block: a full machine's worth per window)
+			const size_t block_cap = getenv("DROPEST_BAM_DEVICE_WINDOW_MB") ? size_t(-1) : window_blocks;   // (one wave per block: a full machine's worth per window)
 			// whole blocks of p[0 .. got): up to `want` bytes of them (at least one), and no more than the device inflates at once
 			auto whole_blocks = [&](const uint8_t *p, size_t got, size_t want, Staged &st) -> size_t {
 				size_t o = 0, n_blocks = 0;

@@ -259,7 +259,7 @@ __device__ inline uint32_t infp_block_body(const uint64_t *__restrict__ gin, uin
 			// 40 rounds and more -- and finish it sooner than the serial loop finishes the rest of the block: 115 -> 70 GB/s.  Dropped; DROPEST_INFLATE_PAR=0
 			// is the switch for files of that kind.)
 		}
-		INFP_ACC(2, t_a); INFP_CNT(17, walk_rounds);
+		INFP_ACC(2, t_a); INFP_CNT(17, walk_rounds); (void)walk_rounds;
 		if (dbg == 3) return 203u;
 		if (__ballot(changed)) return INF_BAD_CODE;                       // (cannot happen: lane k is settled after k + 1 rounds)
 		if (__ballot(alive && flag == INFP_BAD)) return INF_BAD_CODE;
