@@ -422,7 +422,9 @@ extern "C" int dropest_bam_decoder_pieces(dropest_bam_decoder *d, uint32_t n, ui
 			for (hipEvent_t &e : d->piece_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 		}
 		const uint64_t each = (bytes + 4095u) & ~uint64_t(4095);
-		d->piece_mem.ensure(each * n);
+		// (DROPEST_BAM_PINNED_COHERENT=1: the default kind of pinned memory, fine-grained, instead of memory the CPU caches)
+		static const bool coherent = getenv("DROPEST_BAM_PINNED_COHERENT") != nullptr;
+		d->piece_mem.ensure_exact(each * n, coherent ? hipHostMallocDefault : hipHostMallocNonCoherent);
 		d->n_pieces = n; d->piece_bytes = each;
 		for (uint32_t k = 0; k < n; ++k) out[k] = d->piece_mem.p + each * k;
 	});

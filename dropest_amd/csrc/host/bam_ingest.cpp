@@ -1249,19 +1249,27 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					// block table from the file meanwhile (this thread), the last blocks' bytes beyond `want` at the end
 					st.p = map.p + file_at;
 					Blocks &B = blocks_of[which];
+					const auto t_rw = clk::now();
+					struct SayRw { decltype(t_rw) t; size_t &used; ~SayRw() { if (getenv("DROPEST_BAM_TRACE_READER")) std::fprintf(stderr, "[bam] reader: a window of %.1f MB read and sent in %.2f ms\n", double(used) / 1048576.0, std::chrono::duration<double, std::milli>(clk::now() - t).count()); } } say_rw{t_rw, st.used};
 					std::atomic<bool> failed{dropest_bam_decoder_upload_begin(dec, which) != 0};
 					const size_t covered = std::min(want, ask);
 					const size_t n_pieces = (covered + PIECE - 1) / PIECE;
 					const uint32_t n_readers = uint32_t(std::min<size_t>(READERS, n_pieces));
+					const bool trace_rw = getenv("DROPEST_BAM_TRACE_READER") != nullptr && file_at == c0;
+					auto lap_rw = [&](const char *what) { if (trace_rw) std::fprintf(stderr, "[bam] reader, first window: %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(clk::now() - t_rw).count()); };
+					lap_rw("upload_begin done");
 					auto send = [&](uint32_t slot, size_t from, size_t len) {
 						if (dropest_bam_decoder_piece_wait(dec, slot)) { failed = true; return; }
+						lap_rw("piece_wait done");
 						size_t g = 0;
 						while (g < len) {
 							const ssize_t got = pread(map.fd, piece_p[slot] + g, len - g, off_t(file_at + from + g));
 							if (got <= 0) { failed = true; return; }
 							g += size_t(got);
 						}
+						lap_rw("pread done");
 						if (dropest_bam_decoder_upload_piece(dec, which, slot, from, len)) failed = true;
+						lap_rw("upload_piece done");
 					};
 					auto reader = [&](uint32_t r) {
 						for (size_t k = r, turn = 0; k < n_pieces && !failed.load(std::memory_order_relaxed); k += n_readers, ++turn)
@@ -1270,13 +1278,16 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					std::vector<std::future<void>> helpers;
 					for (uint32_t r = 0; r < n_readers; ++r) helpers.push_back(std::async(std::launch::async, reader, r));
 					const size_t o = whole_blocks_of_file(ask, want, B, st);
+					lap_rw("block walk done");
 					for (auto &f : helpers) f.get();
+					lap_rw("helpers joined");
 					if (!st.error.empty()) return st;
 					for (size_t from = covered; from < o && !failed.load(); from += PIECE) send(0, from, std::min(PIECE, o - from));      // (at most 64 KB)
 					st.used = o; file_at += o; st.final = file_at >= map.n;
 					// (a piece that could not be read or sent: nothing is declared, and the window call copies the mapped bytes itself)
 					const dropest_bgzf_blocks table{uint64_t(B.in_off.size()), B.in_off.data(), B.in_len.data(), B.out_len.data(), B.crc.data()};
 					if (!failed.load()) (void)dropest_bam_decoder_upload_done(dec, which, st.p, o, &table);
+					lap_rw("upload_done done");
 					return st;
 				}
 				uint8_t *const buf = stage_p[which];

@@ -264,6 +264,15 @@ struct PinnedBuf {
 		{ auto &r = PinnedRegistry::get(); std::lock_guard<std::mutex> lk(r.mu); r.live.erase(p); }
 		(void)hipHostFree(p); p = nullptr; n = 0;
 	}
+	// exactly `count` elements, with hipHostMalloc flags of the caller's choice (hipHostMallocNonCoherent: memory the CPU caches -- staging that host
+	// threads fill and the device's DMA engines read)
+	void ensure_exact(size_t count, unsigned flags) {
+		if (count <= n) return;
+		release();
+		HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&p), count * sizeof(T), flags));
+		n = count;
+		{ auto &r = PinnedRegistry::get(); std::lock_guard<std::mutex> lk(r.mu); r.live[p] = count * sizeof(T); }
+	}
 	void ensure(size_t count) {
 		if (count <= n) return;
 		release();
