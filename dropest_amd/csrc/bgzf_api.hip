@@ -188,6 +188,7 @@ struct BamFront {
 	DevBuf<uint32_t> d_in_len, d_out_len, d_status, d_crc, seg_count, seg_base, d_bad, d_list;
 	PinnedBuf<uint64_t> h_seg_start, h_seg_exit;
 	PinnedBuf<uint32_t> h_count, h_block_status, h_base;
+	PinnedBuf<uint64_t> h_tab;      // the window's block table on its way to the device: in_off | out_off | in_len, out_len, crc (28 bytes a block)
 	std::vector<uint64_t> in_off, out_off;
 	std::vector<uint32_t> in_len, out_len, crc;
 	uint64_t data_len = 0, tail_start = 0, n_rec = 0;
@@ -209,6 +210,7 @@ struct dropest_bam_decoder {
 	BamParseCfg cfg{};
 	BamFront front[2];
 	int next_front = 0, last_front = 0;
+	bool traced_first = false;
 	bool halves_in_sequence = false;   // dropest_bam_decoder_window is running: its first half uses `stream`
 	DevBuf<uint8_t> d_tail, d_gather;
 	DevBuf<uint64_t> rec_off, d_goff;
@@ -371,7 +373,7 @@ static void bam_reserve(dropest_bam_decoder *d, int which, uint64_t bytes, uint6
 	d->up_in[which].ensure(bytes + 8);
 	F.d_in_off.ensure(n_blk); F.d_out_off.ensure(n_blk); F.d_in_len.ensure(n_blk); F.d_out_len.ensure(n_blk); F.d_status.ensure(n_blk); F.d_crc.ensure(n_blk); F.h_block_status.ensure(n_blk);
 	F.seg_start.ensure(n_seg); F.seg_exit.ensure(n_seg); F.seg_count.ensure(n_seg); F.seg_base.ensure(n_seg);
-	F.h_seg_start.ensure(n_seg); F.h_seg_exit.ensure(n_seg); F.h_count.ensure(n_seg); F.h_base.ensure(n_seg);
+	F.h_seg_start.ensure(n_seg); F.h_seg_exit.ensure(n_seg); F.h_count.ensure(n_seg); F.h_base.ensure(n_seg); F.h_tab.ensure(n_blk * 4 + 8);
 	if (which == 0) {
 		d->rec_off.ensure(n_rec); d->o_cb.ensure(n_rec); d->o_umi.ensure(n_rec); d->o_gene.ensure(n_rec); d->o_aux.ensure(n_rec); d->o_uql.ensure(n_rec);
 		d->o_status.ensure(n_rec); d->o_need.ensure(n_rec); d->dn_cb.ensure(n_rec); d->dn_umi.ensure(n_rec); d->dn_gene.ensure(n_rec); d->dn_aux.ensure(n_rec);
@@ -622,6 +624,34 @@ __global__ __launch_bounds__(256) void bam_chain_to_host_kernel(const uint64_t *
 	if (k < n) { h_start[k] = seg_start[k]; h_exit[k] = seg_exit[k]; h_count[k] = seg_count[k]; }
 }
 
+// a window's block table from pinned host memory to the device's arrays, in one launch (five hipMemcpyAsync calls out of pageable vectors are staged by
+// the runtime; one of them took 8 ms whenever its staging had to grow)
+__global__ __launch_bounds__(256) void bam_tables_from_host_kernel(const uint64_t *h_in_off, const uint64_t *h_out_off, const uint32_t *h_in_len, const uint32_t *h_out_len, const uint32_t *h_crc,
+                                                                   uint64_t *__restrict__ in_off, uint64_t *__restrict__ out_off, uint32_t *__restrict__ in_len, uint32_t *__restrict__ out_len,
+                                                                   uint32_t *__restrict__ crc, uint32_t n) {
+	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+	if (k < n) { in_off[k] = h_in_off[k]; out_off[k] = h_out_off[k]; in_len[k] = h_in_len[k]; out_len[k] = h_out_len[k]; crc[k] = h_crc[k]; }
+}
+
+// words of a pinned host array to the device by a kernel's loads (a hipMemcpyAsync of ~50 KB took 4-7 ms the first time a window was large enough to need one)
+__global__ __launch_bounds__(256) void bam_words_from_host_kernel(const uint32_t *h, uint32_t *__restrict__ d, uint32_t n) {
+	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+	if (k < n) d[k] = h[k];
+}
+
+// ... and words of a device array to a pinned host array by a kernel's stores (the blocks' verdicts)
+__global__ __launch_bounds__(256) void bam_words_to_host_kernel(const uint32_t *__restrict__ d, uint32_t *h, uint32_t n) {
+	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+	if (k < n) h[k] = d[k];
+}
+
+// the records the host must see, to its pinned arrays by a kernel's stores (three copies of ~50 KB took 7.5 ms the first time a process made them)
+__global__ __launch_bounds__(256) void bam_need_to_host_kernel(const uint32_t *__restrict__ rec, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ size, uint32_t n,
+                                                               uint32_t *h_rec, uint32_t *h_pos, uint32_t *h_size) {
+	const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+	if (k < n) { h_rec[k] = rec[k]; h_pos[k] = pos[k]; h_size[k] = size[k]; }
+}
+
 // First half of a window, part A: the block table, the tables and (unless dropest_bam_decoder_upload sent them ahead) the compressed bytes to the
 // device, the inflate kernel enqueued -- and back, without waiting for any of it.  The blocks land at a fixed distance from the start of the
 // front's buffer, so this may be called for window k + 1 while window k is still in its chain / fields / host work: the device then always has
@@ -672,16 +702,22 @@ extern "C" int dropest_bam_decoder_window_inflate(dropest_bam_decoder *dec, cons
 			else d->d_in.ensure(len + len / 4 + 8);
 			d->d_in_off.ensure(n + n / 4); d->d_out_off.ensure(n + n / 4); d->d_in_len.ensure(n + n / 4); d->d_out_len.ensure(n + n / 4);
 			d->d_status.ensure(n + n / 4); d->d_crc.ensure(n + n / 4); d->h_block_status.ensure(n);
-			HIP_CHECK(hipMemcpyAsync(d->d_crc.p, d->crc.data(), n * 4, hipMemcpyHostToDevice, st));
 			if (!uploaded) HIP_CHECK(hipMemcpyAsync(d->d_in.p, comp, len, hipMemcpyHostToDevice, st));
-			HIP_CHECK(hipMemcpyAsync(d->d_in_off.p, d->in_off.data(), n * 8, hipMemcpyHostToDevice, st));
-			HIP_CHECK(hipMemcpyAsync(d->d_out_off.p, d->out_off.data(), n * 8, hipMemcpyHostToDevice, st));
-			HIP_CHECK(hipMemcpyAsync(d->d_in_len.p, d->in_len.data(), n * 4, hipMemcpyHostToDevice, st));
-			HIP_CHECK(hipMemcpyAsync(d->d_out_len.p, d->out_len.data(), n * 4, hipMemcpyHostToDevice, st));
+			{
+				d->h_tab.ensure(size_t(n) * 4 + 8);      // (words of 8 bytes: 2 n for the offsets, 1.5 n for the three 32-bit arrays)
+				uint64_t *const t_in = d->h_tab.p, *const t_out = t_in + n;
+				uint32_t *const t_ilen = reinterpret_cast<uint32_t *>(t_out + n), *const t_olen = t_ilen + n, *const t_crc = t_olen + n;
+				std::memcpy(t_in, d->in_off.data(), n * 8); std::memcpy(t_out, d->out_off.data(), n * 8);
+				std::memcpy(t_ilen, d->in_len.data(), n * 4); std::memcpy(t_olen, d->out_len.data(), n * 4); std::memcpy(t_crc, d->crc.data(), n * 4);
+				hipLaunchKernelGGL(bam_tables_from_host_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, st, t_in, t_out, t_ilen, t_olen, t_crc, d->d_in_off.p, d->d_out_off.p, d->d_in_len.p,
+				                   d->d_out_len.p, d->d_crc.p, uint32_t(n));
+				HIP_CHECK(hipGetLastError());
+			}
 			d->ms_copy = ms_since(t0);
 			if (dropest_bgzf_inflate_device(dec->device, st, uploaded ? uploaded : d->d_in.p, len, d->d_in_off.p, d->d_in_len.p, d->d_out_off.p, d->d_out_len.p, uint32_t(n), d->d_out.p + d->reserve, d->d_status.p, d->d_crc.p))
 				throw DeviceError(g_bgzf_error);
-			HIP_CHECK(hipMemcpyAsync(d->h_block_status.p, d->d_status.p, n * 4, hipMemcpyDeviceToHost, st));
+			hipLaunchKernelGGL(bam_words_to_host_kernel, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, st, d->d_status.p, d->h_block_status.p, uint32_t(n));
+			HIP_CHECK(hipGetLastError());
 		}
 		d->n_blocks = uint32_t(n); d->total = total; d->comp = comp; d->comp_len = len;
 		d->inflating = true;
@@ -826,17 +862,23 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 		out->n_blocks = F.n_blocks; out->window_bytes = data_len; out->refused_blocks = F.refused; out->guesses_repaired = F.repaired;
 		out->ms_copy = F.ms_copy; out->ms_inflate = F.ms_inflate; out->ms_boundaries = F.ms_boundaries;
 		auto t0 = clk::now();
+		static const int trace_laps = getenv("DROPEST_BAM_TRACE_READER") ? atoi(getenv("DROPEST_BAM_TRACE_READER")) : 0;
+		auto lap = [&](const char *what) { if (trace_laps >= 2 || (trace_laps && !d->traced_first)) std::fprintf(stderr, "[bam] a window's fields (%llu records): %s at %.2f ms\n", (unsigned long long)F.n_rec, what, ms_since(t0)); };
 		// record offsets, the fields, the accepted records made dense
 		BamWindowCounts wc{};
 		uint32_t totals[2] = {0, 0}, bad_record = 0;
 		static_assert(sizeof(BamWindowCounts) == 40, "ten words");
 		d->h_result.ensure(16);
+		lap("result words pinned");
 		if (n_rec) {
 			const size_t rc = size_t(n_rec) + size_t(n_rec) / 4;
 			d->rec_off.ensure(rc);
-			HIP_CHECK(hipMemcpyAsync(F.seg_base.p, F.h_base.p, size_t(n_segs) * 4, hipMemcpyHostToDevice, st));      // (pinned: the copy is queued, not staged)
+			lap("rec_off ensured");
+			hipLaunchKernelGGL(bam_words_from_host_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, F.h_base.p, F.seg_base.p, n_segs);
+			lap("segment bases copy queued");
 			hipLaunchKernelGGL(bam_seg_walk_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, F.data(), data_len, (const uint32_t *)nullptr, n_segs, F.seg_start.p,
 			                   F.seg_count.p, F.seg_exit.p, F.seg_base.p, d->rec_off.p, F.d_bad.p);
+			lap("record offsets walked (queued)");
 			d->o_qoff.ensure(rc); d->dn_qoff.ensure(rc);
 			d->o_cb.ensure(rc); d->o_umi.ensure(rc); d->o_gene.ensure(rc); d->o_aux.ensure(rc); d->o_uql.ensure(rc); d->o_status.ensure(rc); d->o_need.ensure(rc);
 			d->dn_cb.ensure(rc); d->dn_umi.ensure(rc); d->dn_gene.ensure(rc); d->dn_aux.ensure(rc); d->nd_rec.ensure(rc); d->nd_pos.ensure(rc); d->nd_size.ensure(rc);
@@ -844,6 +886,7 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			d->tile_ok.ensure(tiles + tiles / 4 + 1); d->tile_need.ensure(tiles + tiles / 4 + 1); d->d_totals.ensure(2); d->d_wc.ensure(1);
 			HIP_CHECK(hipMemsetAsync(d->d_wc.p, 0, sizeof(BamWindowCounts), st));
 			if (d->annotation) { d->a_chr.ensure(rc); d->a_pos.ensure(rc); d->a_end.ensure(rc); d->a_gene.ensure(rc); d->a_mark.ensure(rc); }
+			lap("buffers ensured");
 			const BamRecordOut ro{d->o_cb.p, d->o_umi.p, d->o_gene.p, d->o_aux.p, d->o_uql.p, d->o_qoff.p, d->o_status.p, d->o_need.p, d->a_chr.p, d->a_pos.p, d->a_end.p};
 			const BamDict dict{d->g_keys.p, d->g_vals.p, d->g_mask, d->d_chr.p, d->annotation ? d->d_ann_chr.p : nullptr, d->annotation ? d->d_ann_id.p : nullptr,
 			                   d->n_gene_names ? d->g_name_off.p : nullptr, d->g_name_pool.p, d->n_gene_names, d->hash_mask};
@@ -863,17 +906,21 @@ extern "C" int dropest_bam_decoder_window_finish(dropest_bam_decoder *d, int slo
 			HIP_CHECK(hipMemcpyAsync(d->h_result.p + 10, d->d_totals.p, 8, hipMemcpyDeviceToHost, st));
 			HIP_CHECK(hipMemcpyAsync(d->h_result.p + 12, F.d_bad.p, 4, hipMemcpyDeviceToHost, st));
 		}
+		lap("kernels and copies queued");
 		HIP_CHECK(hipStreamSynchronize(st));
+		lap("kernels done");
 		if (n_rec) { std::memcpy(&wc, d->h_result.p, sizeof(wc)); totals[0] = d->h_result.p[10]; totals[1] = d->h_result.p[11]; bad_record = d->h_result.p[12]; }
 		if (bad_record) throw InvalidError("Corrupt BAM record");      // (a block_size below the 32 bytes of a record's fixed part or beyond 2^26, met by the walk from the checked starts; fixed part + name + cigar + bases longer than the record, met by the parse)
 		const uint32_t n_need = totals[1];
 		if (n_need) {
 			d->h_need_rec.ensure(n_need); d->h_need_pos.ensure(n_need); d->h_need_size.ensure(n_need);
-			HIP_CHECK(hipMemcpyAsync(d->h_need_rec.p, d->nd_rec.p, size_t(n_need) * 4, hipMemcpyDeviceToHost, st));
-			HIP_CHECK(hipMemcpyAsync(d->h_need_pos.p, d->nd_pos.p, size_t(n_need) * 4, hipMemcpyDeviceToHost, st));
-			HIP_CHECK(hipMemcpyAsync(d->h_need_size.p, d->nd_size.p, size_t(n_need) * 4, hipMemcpyDeviceToHost, st));
+			lap("need arrays pinned");
+			hipLaunchKernelGGL(bam_need_to_host_kernel, dim3((n_need + 255) / 256), dim3(256), 0, st, d->nd_rec.p, d->nd_pos.p, d->nd_size.p, n_need, d->h_need_rec.p, d->h_need_pos.p, d->h_need_size.p);
+			HIP_CHECK(hipGetLastError());
 			HIP_CHECK(hipStreamSynchronize(st));
 		}
+		lap("need arrays copied");
+		d->traced_first = true;
 		out->ms_parse = ms_since(t0);
 		d->last_n_rec = n_rec; d->last_n_ok = totals[0];
 		out->n_records = n_rec; out->tail_bytes = data_len - F.tail_start;

@@ -118,6 +118,13 @@ void dropest_ctx::init_from_cfg(const dropest_cfg &c) {
 				(void)hipMemcpyAsync(big, pin, mb, hipMemcpyHostToDevice, nullptr);
 				(void)hipMemcpyAsync(pin, big, mb, hipMemcpyDeviceToHost, nullptr);
 				(void)hipStreamSynchronize(nullptr);
+				// (and on the context's stream, at the sizes between the runtime's small and large copies too: the first copy of ~50 KB either way took
+				// 7.5-9 ms in whichever BAM window made it)
+				for (size_t bytes : {size_t(8) << 10, size_t(48) << 10, size_t(256) << 10, mb}) {
+					(void)hipMemcpyAsync(big, pin, bytes, hipMemcpyHostToDevice, stream);
+					(void)hipMemcpyAsync(pin, big, bytes, hipMemcpyDeviceToHost, stream);
+				}
+				(void)hipStreamSynchronize(stream);
 			}
 			if (big) (void)hipFree(big);
 			if (pin) (void)hipHostFree(pin);

@@ -1415,6 +1415,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 				first = false;
 				++n_windows; repaired += w.guesses_repaired; refused += w.refused_blocks;
 				dev_ms[0] += w.ms_copy; dev_ms[1] += w.ms_inflate; dev_ms[2] += w.ms_boundaries; dev_ms[3] += w.ms_parse;
+				if (getenv("DROPEST_BAM_TRACE_READER")) std::fprintf(stderr, "[bam] window %zu: %.1f MB, %u blocks, %llu records: copy in %.2f, inflate %.2f, chain %.2f, fields %.2f ms; the call %.2f ms\n", n_windows, double(used) / 1048576.0, w.n_blocks, (unsigned long long)w.n_records, w.ms_copy, w.ms_inflate, w.ms_boundaries, w.ms_parse, since(t_call));
 				const size_t n = size_t(w.n_records);
 				if (!n) { if (final) break; continue; }
 				t_phase = clk::now();
