@@ -1052,7 +1052,10 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 			double dev_ms[4] = {0, 0, 0, 0}, host_ms[3] = {0, 0, 0};
 			const auto t_file = clk::now();
 			// (DROPEST_BAM_RAMP="first MB,factor": the first window and how fast the windows grow to window_max)
-			size_t ramp_first = 1, ramp_factor = 4;
+			// (1 MB first: the file's genes and chromosomes are mostly met there, and every one of them is a record the host parses -- a first window of
+			// 4 / 8 / 16 MB: 65 -> 76 / 79 / 87 ms on the 3.2 x file; then x 8: 1, 8, 64 MB ... measured against x 4 and x 16 with the round's final decoder:
+			// 3.2 x file 65-70 -> 59-67 ms, 10.8 x file 85-87 -> 73-75)
+			size_t ramp_first = 1, ramp_factor = 8;
 			if (const char *e = getenv("DROPEST_BAM_RAMP")) { int a = 0, b = 0; if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 2) { ramp_first = size_t(a); ramp_factor = size_t(b); } }
 			size_t window_bytes = ramp_first << 20, n_windows = 0, repaired = 0, refused = 0, n_needs = 0;
 			// windows: a machine's worth of blocks (one wave per block) in a file of a few hundred MB, two in a long one (measured on 0.4 and 1.6 GB:
@@ -1343,7 +1346,7 @@ void BamController::parse_bam_files(const std::vector<std::string> &bam_files, C
 					stg = next.get();
 					ms_wait_read += since(t_wait);
 					if (!stg.error.empty()) throw std::runtime_error(stg.error + ": " + bam_name);
-					window_bytes = std::min(window_bytes * ramp_factor, window_max);       // (1, 4, 16, 64 MB ...: a ramp of x 16 measured the same, 188-201 ms on the 3 x file)
+					window_bytes = std::min(window_bytes * ramp_factor, window_max);
 					which ^= 1;
 					if (!stg.final) next = std::async(std::launch::async, read_window, which, window_bytes);
 					if (pipeline && dropest_bam_decoder_window_inflate(dec, stg.p, stg.used, &slot_cur)) {
