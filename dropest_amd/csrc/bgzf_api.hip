@@ -227,7 +227,9 @@ struct dropest_bam_decoder {
 	DevBuf<uint8_t> o_status, o_need;
 	DevBuf<BamWindowCounts> d_wc;
 	PinnedBuf<uint8_t> h_stage[2];
-	PinnedBuf<uint32_t> h_need_rec, h_need_pos, h_need_size, h_gsize, h_result;      // h_result: a window's counters, totals and flag (13 words)
+	PinnedBuf<uint32_t> h_need_rec, h_need_pos, h_need_size, h_gsize, h_gidx, h_result;
+	PinnedBuf<uint64_t> h_goff, h_patch;
+	PinnedBuf<uint8_t> h_gather, h_dict;      // h_result: a window's counters, totals and flag (13 words)
 	uint32_t g_mask = 0;
 	DevBuf<uint32_t> g_name_off;      // the dictionary's gene names by index (dropest_bam_decoder_set_gene_names), 0 names: hashes alone
 	DevBuf<uint8_t> g_name_pool;
@@ -322,7 +324,10 @@ extern "C" int dropest_bam_decoder_create(int device, const dropest_bam_parse_cf
 			auto t0 = clk::now();
 			auto lap = [&](const char *what) { if (trace) { std::fprintf(stderr, "[bam] decoder: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(clk::now() - t0).count()); t0 = clk::now(); } };
 			// empty dictionaries: every gene and chromosome is new
-			d->g_mask = 1023; d->g_keys.alloc(1024); d->g_vals.alloc(1024); d->d_chr.alloc(size_t(std::max(1, cfg->n_refs)));
+			// (room for 32 000 genes and their names from the start: growing these tables between two windows is a hipFree, a hipMalloc and a pinned
+			// reallocation -- ~10 ms of "dictionaries to the device" in the window that first knows a few thousand genes)
+			d->g_mask = 1023; d->g_keys.alloc(size_t(1) << 16); d->g_vals.alloc(size_t(1) << 16); d->d_chr.alloc(size_t(std::max(1, cfg->n_refs)));
+			d->g_name_off.ensure(size_t(1) << 15); d->g_name_pool.ensure(size_t(1) << 20); d->h_dict.ensure(size_t(2) << 20);
 			lap("dictionary buffers");
 			for (hipEvent_t &e : d->up_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 			lap("events");
@@ -545,6 +550,24 @@ extern "C" void dropest_bam_decoder_destroy(dropest_bam_decoder *d) {
 	delete d;
 }
 
+// Host bytes to a device array without a staged copy: into the decoder's pinned staging (at `*at`, which moves on), then a kernel's loads.  The
+// dictionaries' tables are 17 KB to a few hundred KB -- sizes at which hipMemcpyAsync out of pageable memory took 8-12 ms now and then (measured:
+// "dictionaries to the device" 0.7 or 12 ms per file).  The caller waits for the stream before the staging is used again.
+__global__ __launch_bounds__(256) void bam_bytes_from_host_kernel(const uint8_t *h, uint8_t *__restrict__ d, uint64_t n) {
+	const uint64_t k = (uint64_t(blockIdx.x) * 256 + threadIdx.x) * 16;
+	if (k + 16 <= n) { uint4 v; __builtin_memcpy(&v, h + k, 16); __builtin_memcpy(d + k, &v, 16); }
+	else for (uint64_t i = k; i < n; ++i) d[i] = h[i];
+}
+static void bam_to_device(dropest_bam_decoder *d, void *dst, const void *src, size_t bytes, size_t &at) {
+	if (!bytes) return;
+	const size_t from = (at + 15) & ~size_t(15);
+	if (from + bytes > d->h_dict.n) throw InvalidError("internal: the dictionaries' staging is too small");
+	std::memcpy(d->h_dict.p + from, src, bytes);
+	hipLaunchKernelGGL(bam_bytes_from_host_kernel, dim3(uint32_t((bytes + 4095) / 4096)), dim3(256), 0, d->stream, d->h_dict.p + from, static_cast<uint8_t *>(dst), uint64_t(bytes));
+	HIP_CHECK(hipGetLastError());
+	at = from + bytes;
+}
+
 extern "C" int dropest_bam_decoder_set_annotation(dropest_bam_decoder *d, dropest_annotation *a, const int32_t *ann_chr_of_ref, uint32_t n_refs) {
 	return bgzf_guarded([&] {
 		if (!d || !a || (n_refs && !ann_chr_of_ref)) throw InvalidError("null argument");
@@ -555,7 +578,9 @@ extern "C" int dropest_bam_decoder_set_annotation(dropest_bam_decoder *d, dropes
 		d->annotation = a;
 		d->n_ann_genes = dropest_annotation_genes(a);
 		d->d_ann_chr.alloc(std::max<uint32_t>(n_refs, 1u));
-		if (n_refs) HIP_CHECK(hipMemcpyAsync(d->d_ann_chr.p, ann_chr_of_ref, size_t(n_refs) * 4, hipMemcpyHostToDevice, d->stream));
+		size_t at = 0;
+		d->h_dict.ensure(size_t(n_refs) * 4 + 64);
+		if (n_refs) bam_to_device(d, d->d_ann_chr.p, ann_chr_of_ref, size_t(n_refs) * 4, at);
 		d->d_ann_id.alloc(std::max<uint32_t>(d->n_ann_genes, 1u));
 		HIP_CHECK(hipMemsetAsync(d->d_ann_id.p, 0xFF, size_t(std::max<uint32_t>(d->n_ann_genes, 1u)) * 4, d->stream));   // no gene of the annotation is in the dictionary yet
 		HIP_CHECK(hipStreamSynchronize(d->stream));
@@ -569,7 +594,7 @@ extern "C" int dropest_bam_decoder_set_annotation_genes(dropest_bam_decoder *d, 
 		HIP_CHECK(hipSetDevice(d->device));
 		bam_ready(d);
 		HIP_CHECK(hipStreamSynchronize(d->stream));
-		if (n) { HIP_CHECK(hipMemcpyAsync(d->d_ann_id.p, id_of_ann_gene, size_t(n) * 4, hipMemcpyHostToDevice, d->stream)); HIP_CHECK(hipStreamSynchronize(d->stream)); }
+		if (n) { size_t at = 0; d->h_dict.ensure(size_t(n) * 4 + 64); bam_to_device(d, d->d_ann_id.p, id_of_ann_gene, size_t(n) * 4, at); HIP_CHECK(hipStreamSynchronize(d->stream)); }
 	});
 }
 
@@ -585,8 +610,10 @@ extern "C" int dropest_bam_decoder_set_gene_names(dropest_bam_decoder *d, const 
 		d->n_gene_names = 0;
 		if (!n_names) return;
 		d->g_name_off.ensure(size_t(n_names) + 1 + n_names / 4); d->g_name_pool.ensure(size_t(off[n_names]) + off[n_names] / 4 + 16);
-		HIP_CHECK(hipMemcpyAsync(d->g_name_off.p, off, (size_t(n_names) + 1) * 4, hipMemcpyHostToDevice, d->stream));
-		if (off[n_names]) HIP_CHECK(hipMemcpyAsync(d->g_name_pool.p, pool, off[n_names], hipMemcpyHostToDevice, d->stream));
+		size_t at = 0;
+		d->h_dict.ensure((size_t(n_names) + 1) * 4 + size_t(off[n_names]) + 128);
+		bam_to_device(d, d->g_name_off.p, off, (size_t(n_names) + 1) * 4, at);
+		if (off[n_names]) bam_to_device(d, d->g_name_pool.p, pool, off[n_names], at);
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		d->n_gene_names = n_names;
 	});
@@ -610,9 +637,11 @@ extern "C" int dropest_bam_decoder_set_dictionaries(dropest_bam_decoder *d, cons
 		}
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		d->g_keys.ensure(cap); d->g_vals.ensure(cap);
-		HIP_CHECK(hipMemcpyAsync(d->g_keys.p, keys.data(), size_t(cap) * 8, hipMemcpyHostToDevice, d->stream));
-		HIP_CHECK(hipMemcpyAsync(d->g_vals.p, vals.data(), size_t(cap) * 4, hipMemcpyHostToDevice, d->stream));
-		if (n_refs) HIP_CHECK(hipMemcpyAsync(d->d_chr.p, chr_of_ref, size_t(n_refs) * 4, hipMemcpyHostToDevice, d->stream));
+		size_t at = 0;
+		d->h_dict.ensure(size_t(cap) * 12 + size_t(n_refs) * 4 + 128);
+		bam_to_device(d, d->g_keys.p, keys.data(), size_t(cap) * 8, at);
+		bam_to_device(d, d->g_vals.p, vals.data(), size_t(cap) * 4, at);
+		if (n_refs) bam_to_device(d, d->d_chr.p, chr_of_ref, size_t(n_refs) * 4, at);
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		d->g_mask = cap - 1;
 	});
@@ -950,6 +979,9 @@ __global__ __launch_bounds__(256) void bam_record_sizes_kernel(const uint8_t *__
 	if (k < n) size[k] = 4u + b_le32(data + rec_off[idx[k]]);
 }
 
+// (The indices, sizes, offsets and the gathered bytes go through pinned memory that the kernels read and write themselves: the five copies this call
+// used to make were 17 KB to 1 MB each -- sizes at which a hipMemcpyAsync out of or into pageable memory is staged, and took 8 ms whenever the
+// staging grew: 3.3 -> 12.4 ms per file once the second window was 8 MB.)
 extern "C" int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const uint32_t *idx, uint32_t n, uint8_t *dst, uint64_t dst_cap, uint64_t *dst_off) {
 	return bgzf_guarded([&] {
 		if (!d || (n && (!idx || !dst || !dst_off))) throw InvalidError("null argument");
@@ -957,20 +989,19 @@ extern "C" int dropest_bam_decoder_fetch_records(dropest_bam_decoder *d, const u
 		HIP_CHECK(hipSetDevice(d->device));
 		bam_ready(d);
 		for (uint32_t k = 0; k < n; ++k) if (idx[k] >= d->last_n_rec) throw RangeError("record index outside the window");
-		d->d_gidx.ensure(n); d->d_goff.ensure(n); d->d_gsize.ensure(n); d->h_gsize.ensure(n);
-		HIP_CHECK(hipMemcpyAsync(d->d_gidx.p, idx, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
-		hipLaunchKernelGGL(bam_record_sizes_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, d->front[d->last_front].data(), d->rec_off.p, d->d_gidx.p, n, d->d_gsize.p);
-		HIP_CHECK(hipMemcpyAsync(d->h_gsize.p, d->d_gsize.p, size_t(n) * 4, hipMemcpyDeviceToHost, d->stream));
+		d->h_gidx.ensure(n); d->h_goff.ensure(n); d->h_gsize.ensure(n);
+		std::memcpy(d->h_gidx.p, idx, size_t(n) * 4);
+		hipLaunchKernelGGL(bam_record_sizes_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, d->front[d->last_front].data(), d->rec_off.p, d->h_gidx.p, n, d->h_gsize.p);
+		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 		uint64_t total = 0;
-		for (uint32_t k = 0; k < n; ++k) { dst_off[k] = total; total += d->h_gsize.p[k]; }
+		for (uint32_t k = 0; k < n; ++k) { dst_off[k] = total; d->h_goff.p[k] = total; total += d->h_gsize.p[k]; }
 		if (total > dst_cap) throw InvalidError("destination too small: " + std::to_string(total) + " bytes needed");
-		d->d_gather.ensure(total + total / 4 + 64);
-		HIP_CHECK(hipMemcpyAsync(d->d_goff.p, dst_off, size_t(n) * 8, hipMemcpyHostToDevice, d->stream));
-		hipLaunchKernelGGL(bam_gather_records_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, d->front[d->last_front].data(), d->rec_off.p, d->d_gidx.p, d->d_goff.p, n, d->d_gather.p);
+		d->h_gather.ensure(total + total / 4 + 64);
+		hipLaunchKernelGGL(bam_gather_records_kernel, dim3((n + 3) / 4), dim3(256), 0, d->stream, d->front[d->last_front].data(), d->rec_off.p, d->h_gidx.p, d->h_goff.p, n, d->h_gather.p);
 		HIP_CHECK(hipGetLastError());
-		HIP_CHECK(hipMemcpyAsync(dst, d->d_gather.p, total, hipMemcpyDeviceToHost, d->stream));
 		HIP_CHECK(hipStreamSynchronize(d->stream));
+		std::memcpy(dst, d->h_gather.p, total);
 	});
 }
 
@@ -1014,14 +1045,14 @@ extern "C" int dropest_bam_decoder_patch(dropest_bam_decoder *d, const uint32_t 
 		HIP_CHECK(hipSetDevice(d->device));
 		bam_ready(d);
 		for (uint32_t k = 0; k < n; ++k) if (pos[k] >= d->last_n_ok) throw RangeError("row outside the dense columns");
-		d->p_pos.ensure(n); d->p_cb.ensure(n); d->p_umi.ensure(n); d->p_gene.ensure(n); d->p_aux.ensure(n);
-		HIP_CHECK(hipMemcpyAsync(d->p_pos.p, pos, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
-		HIP_CHECK(hipMemcpyAsync(d->p_cb.p, cb, size_t(n) * 8, hipMemcpyHostToDevice, d->stream));
-		HIP_CHECK(hipMemcpyAsync(d->p_umi.p, umi, size_t(n) * 8, hipMemcpyHostToDevice, d->stream));
-		HIP_CHECK(hipMemcpyAsync(d->p_gene.p, gene, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
-		HIP_CHECK(hipMemcpyAsync(d->p_aux.p, aux, size_t(n) * 4, hipMemcpyHostToDevice, d->stream));
+		// (the caller's five arrays into one pinned buffer that the kernel reads itself: no staged copies)
+		d->h_patch.ensure(size_t(n) * 4 + 8);      // words of 8 bytes: cb | umi | pos, gene, aux
+		unsigned long long *const q_cb = reinterpret_cast<unsigned long long *>(d->h_patch.p), *const q_umi = q_cb + n;
+		uint32_t *const q_pos = reinterpret_cast<uint32_t *>(q_umi + n), *const q_gene = q_pos + n, *const q_aux = q_gene + n;
+		std::memcpy(q_cb, cb, size_t(n) * 8); std::memcpy(q_umi, umi, size_t(n) * 8);
+		std::memcpy(q_pos, pos, size_t(n) * 4); std::memcpy(q_gene, gene, size_t(n) * 4); std::memcpy(q_aux, aux, size_t(n) * 4);
 		const BamDense dn{d->dn_cb.p, d->dn_umi.p, d->dn_gene.p, d->dn_aux.p, nullptr, nullptr, nullptr, nullptr};
-		hipLaunchKernelGGL(bam_patch_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, d->p_pos.p, d->p_cb.p, d->p_umi.p, d->p_gene.p, d->p_aux.p, n, dn);
+		hipLaunchKernelGGL(bam_patch_kernel, dim3((n + 255) / 256), dim3(256), 0, d->stream, q_pos, q_cb, q_umi, q_gene, q_aux, n, dn);
 		HIP_CHECK(hipGetLastError());
 		HIP_CHECK(hipStreamSynchronize(d->stream));
 	});
