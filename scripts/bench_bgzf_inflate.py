@@ -1,4 +1,4 @@
-"""Developer tool: rate of the device BGZF inflate (csrc/k_inflate.h) on a synthetic 10x-style BAM: GB/s of inflated bytes and the
+"""Developer tool: rate of the device BGZF inflate (csrc/k_inflate_par.h; DROPEST_INFLATE_PAR=0: csrc/k_inflate.h) on a synthetic 10x-style BAM: GB/s of inflated bytes and the
 Mreads/s that corresponds to, beside zlib on one host thread.  usage: python scripts/bench_bgzf_inflate.py [reads] [copies]"""
 import json
 import os
